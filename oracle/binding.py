@@ -1,0 +1,399 @@
+"""ctypes binding of the CPU oracle (oracle/libafvo.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg.  The product package never imports this module.  PARITY UNPINNED (see oracle/afvo.h).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+MAX_LEVELS = 16
+BORDER = 23
+
+
+class Keypoint(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("size", C.c_float), ("angle", C.c_float),
+                ("response", C.c_float), ("octave", C.c_int32), ("class_id", C.c_int32)]
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+CAND_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("level", "<i4"), ("fast_score", "<i4"),
+                       ("ha", "<i4"), ("hb", "<i4"), ("hc", "<i4"), ("response", "<f4")])
+
+
+class Params(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("nlevels", C.c_int32), ("scale_factor", C.c_float),
+                ("fast_threshold", C.c_int32)]
+
+
+class Trace(C.Structure):
+    _fields_ = [("nlevels", C.c_int), ("lw", C.c_int * MAX_LEVELS), ("lh", C.c_int * MAX_LEVELS),
+                ("lscale", C.c_float * MAX_LEVELS), ("level", C.POINTER(C.c_uint8) * MAX_LEVELS),
+                ("blurred", C.POINTER(C.c_uint8) * MAX_LEVELS), ("cand", C.c_void_p), ("ncand", C.c_int),
+                ("keep1", C.POINTER(C.c_uint8)), ("keep2", C.POINTER(C.c_uint8)), ("t_counts", C.c_int * MAX_LEVELS)]
+
+
+class BowJob(C.Structure):
+    _fields_ = [("desc1", C.c_void_p), ("n1", C.c_int32), ("desc2", C.c_void_p), ("n2", C.c_int32),
+                ("desc_bytes", C.c_int32),
+                ("node_id1", C.c_void_p), ("seg_ptr1", C.c_void_p), ("seg_idx1", C.c_void_p), ("nnodes1", C.c_int32),
+                ("node_id2", C.c_void_p), ("seg_ptr2", C.c_void_p), ("seg_idx2", C.c_void_p), ("nnodes2", C.c_int32),
+                ("valid1", C.c_void_p), ("valid2", C.c_void_p), ("angle1", C.c_void_p), ("angle2", C.c_void_p),
+                ("th_low", C.c_float), ("nnratio", C.c_float), ("check_orientation", C.c_int32)]
+
+
+class TriJob(C.Structure):
+    _fields_ = [("bow", BowJob), ("x1", C.c_void_p), ("y1", C.c_void_p), ("x2", C.c_void_p), ("y2", C.c_void_p),
+                ("sigma2_2", C.c_void_p), ("F12", C.c_float * 9), ("ex", C.c_float), ("ey", C.c_float)]
+
+
+class L2Job(C.Structure):
+    _fields_ = [("desc1", C.c_void_p), ("n1", C.c_int32), ("desc2", C.c_void_p), ("n2", C.c_int32), ("dim", C.c_int32),
+                ("valid1", C.c_void_p), ("valid2", C.c_void_p), ("th_low", C.c_float), ("nnratio", C.c_float)]
+
+
+def build(native=False):
+    """(Re)build the oracle with gcc; returns the path of the library."""
+    target = "native" if native else "all"
+    subprocess.run(["make", "-C", _HERE, target], check=True, stdout=subprocess.DEVNULL)
+    return os.path.join(_HERE, "libafvo_native.so" if native else "libafvo.so")
+
+
+_lib = None
+
+
+def lib(path=None):
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.path.join(_HERE, "libafvo.so")
+    if not os.path.exists(p):
+        build()
+    L = C.CDLL(p)
+    L.afvo_fast_atan2.restype = C.c_float
+    L.afvo_fast_atan2.argtypes = [C.c_float, C.c_float]
+    L.afvo_harris_response.restype = C.c_float
+    L.afvo_harris_response.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.afvo_ic_angle.restype = C.c_float
+    L.afvo_keypoint_size.restype = C.c_float
+    L.afvo_keypoint_size.argtypes = [C.c_int, C.c_float]
+    L.afvo_l2sqr.restype = C.c_float
+    L.afvo_brief_pattern.restype = C.POINTER(C.c_int8)
+    L.afvo_rotation_bin.argtypes = [C.c_float, C.c_float]
+    L.afvo_level_geometry.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.afvo_quotas_extractor.argtypes = [C.c_int, C.c_int, C.c_float, C.c_void_p]
+    L.afvo_quotas_cvorb.argtypes = [C.c_int, C.c_int, C.c_float, C.c_void_p]
+    L.afvo_sincos_deg.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
+    L.afvo_size_sigma.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.afvo_brief_descriptor.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
+    if path is None:
+        _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _u8(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    assert img.ndim == 2
+    return img
+
+
+# ---- tables ----
+def level_geometry(w, h, nlevels=8, scale_factor=1.2):
+    lw = np.zeros(nlevels, np.int32); lh = np.zeros(nlevels, np.int32); ls = np.zeros(nlevels, np.float32)
+    lib().afvo_level_geometry(w, h, nlevels, scale_factor, _p(lw), _p(lh), _p(ls))
+    return lw, lh, ls
+
+
+def quotas_extractor(nfeatures, nlevels=8, scale_factor=1.2):
+    q = np.zeros(nlevels, np.int32)
+    lib().afvo_quotas_extractor(nfeatures, nlevels, scale_factor, _p(q))
+    return q
+
+
+def quotas_cvorb(nfeatures, nlevels=8, scale_factor=1.2):
+    q = np.zeros(nlevels, np.int32)
+    lib().afvo_quotas_cvorb(nfeatures, nlevels, scale_factor, _p(q))
+    return q
+
+
+def umax():
+    u = np.zeros(17, np.int32)
+    lib().afvo_umax(_p(u))
+    return u[:16]
+
+
+def gauss7_taps():
+    t = np.zeros(7, np.int32)
+    lib().afvo_gauss7_taps(_p(t))
+    return t
+
+
+def brief_pattern():
+    return np.ctypeslib.as_array(lib().afvo_brief_pattern(), shape=(1024,)).copy()
+
+
+def fast_atan2(y, x):
+    return float(lib().afvo_fast_atan2(float(y), float(x)))
+
+
+def sincos_deg(angle):
+    c = C.c_float(); s = C.c_float()
+    lib().afvo_sincos_deg(float(angle), C.byref(c), C.byref(s))
+    return c.value, s.value
+
+
+def size_sigma(kps, scale_factor=1.2):
+    kps = np.ascontiguousarray(kps, dtype=KP_DTYPE)
+    n = len(kps)
+    size = np.zeros(n, np.float32); s2 = np.zeros(n, np.float32); inf = np.zeros(n, np.float32)
+    lib().afvo_size_sigma(_p(kps), n, scale_factor, _p(size), _p(s2), _p(inf))
+    return size, s2, inf
+
+
+# ---- image stages ----
+def resize_linear_exact(src, dw, dh):
+    src = _u8(src)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().afvo_resize_linear_exact(_p(src), src.shape[1], src.shape[0], src.shape[1], _p(dst), dw, dh, dw)
+    return dst
+
+
+def make_border101(src, border=BORDER):
+    src = _u8(src)
+    h, w = src.shape
+    dst = np.zeros((h + 2 * border, w + 2 * border), np.uint8)
+    lib().afvo_make_border101(_p(src), w, h, w, _p(dst), border)
+    return dst
+
+
+def fast9_16(img, threshold=20):
+    img = _u8(img)
+    h, w = img.shape
+    cap = ((w + 1) // 2) * ((h + 1) // 2) + 16
+    xs = np.zeros(cap, np.int32); ys = np.zeros(cap, np.int32); sc = np.zeros(cap, np.int32)
+    n = lib().afvo_fast9_16(_p(img), w, h, w, threshold, _p(xs), _p(ys), _p(sc), cap)
+    return xs[:n].copy(), ys[:n].copy(), sc[:n].copy()
+
+
+def fast_score_map(img, threshold=20):
+    img = _u8(img)
+    h, w = img.shape
+    out = np.zeros((h, w), np.uint8)
+    lib().afvo_fast_score_map(_p(img), w, h, w, threshold, _p(out))
+    return out
+
+
+def harris(img, x, y):
+    b = make_border101(img)
+    a_ = C.c_int(); b_ = C.c_int(); c_ = C.c_int()
+    lib().afvo_harris_sums(_p(b), b.shape[1], int(x), int(y), C.byref(a_), C.byref(b_), C.byref(c_))
+    return a_.value, b_.value, c_.value, float(lib().afvo_harris_response(a_.value, b_.value, c_.value))
+
+
+def harris_response(a, b, c):
+    return float(lib().afvo_harris_response(int(a), int(b), int(c)))
+
+
+def ic_angle(img, x, y):
+    b = make_border101(img)
+    lib().afvo_ic_angle.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    return float(lib().afvo_ic_angle(_p(b), b.shape[1], int(x), int(y)))
+
+
+def gaussian_blur7(img):
+    img = _u8(img)
+    h, w = img.shape
+    b = make_border101(img)
+    out = np.zeros((h, w), np.uint8)
+    lib().afvo_gaussian_blur7(_p(b), w, h, b.shape[1], _p(out), w)
+    return out
+
+
+def brief_descriptor(img_unblurred, img_blurred, cx, cy, angle_deg):
+    """rBRIEF at (cx,cy): interior = blurred level, apron = reflect-101 of the UNBLURRED level."""
+    bb = make_border101(img_unblurred)
+    h, w = img_unblurred.shape
+    bb[BORDER:BORDER + h, BORDER:BORDER + w] = img_blurred
+    d = np.zeros(32, np.uint8)
+    lib().afvo_brief_descriptor(_p(bb), bb.shape[1], int(cx), int(cy), float(angle_deg), _p(d))
+    return d
+
+
+# ---- selection ----
+def retain_best_mask(resp, k):
+    resp = np.ascontiguousarray(resp, np.float32)
+    keep = np.zeros(len(resp), np.uint8)
+    lib().afvo_retain_best_mask(_p(resp), len(resp), int(k), _p(keep))
+    return keep.astype(bool)
+
+
+def quadtree(px, py, resp, N, w, h, tiebreak=None):
+    px = np.ascontiguousarray(px, np.float32); py = np.ascontiguousarray(py, np.float32)
+    resp = np.ascontiguousarray(resp, np.float32)
+    tb = None if tiebreak is None else np.ascontiguousarray(tiebreak, np.int64)
+    cap = N + 16
+    out = np.zeros(cap, np.int32)
+    n = lib().afvo_quadtree(_p(px), _p(py), _p(resp), _p(tb), len(px), 0, int(w), 0, int(h), int(N), _p(out), cap)
+    assert n <= cap
+    return out[:n].copy()
+
+
+# ---- full extraction ----
+def default_params(nfeatures=1000, nlevels=8, scale_factor=1.2, fast_threshold=20):
+    return Params(nfeatures, nlevels, scale_factor, fast_threshold)
+
+
+def orb_extract(gray, params=None, variant=0, cap=None):
+    gray = _u8(gray)
+    h, w = gray.shape
+    params = params or default_params()
+    cap = cap or (params.nfeatures + 3 * params.nlevels + 64)
+    kps = np.zeros(cap, KP_DTYPE)
+    desc = np.zeros((cap, 32), np.uint8)
+    n = C.c_int(0)
+    rc = lib().afvo_orb_extract(C.byref(params), _p(gray), w, h, w, int(variant), _p(kps), _p(desc), cap, C.byref(n))
+    if rc != 0:
+        raise RuntimeError("afvo_orb_extract rc=%d" % rc)
+    return kps[:n.value].copy(), desc[:n.value].copy()
+
+
+def orb_extract_trace(gray, params=None, cap=None):
+    """Returns (kps, desc, trace dict with levels / blurred / candidates / keep masks / per-level counts)."""
+    gray = _u8(gray)
+    h, w = gray.shape
+    params = params or default_params()
+    cap = cap or (params.nfeatures + 3 * params.nlevels + 64)
+    kps = np.zeros(cap, KP_DTYPE)
+    desc = np.zeros((cap, 32), np.uint8)
+    n = C.c_int(0)
+    tr = Trace()
+    rc = lib().afvo_orb_extract_trace(C.byref(params), _p(gray), w, h, w, C.byref(tr), _p(kps), _p(desc), cap, C.byref(n))
+    if rc != 0:
+        raise RuntimeError("afvo_orb_extract_trace rc=%d" % rc)
+    out = {"lw": list(tr.lw[:tr.nlevels]), "lh": list(tr.lh[:tr.nlevels]), "lscale": list(tr.lscale[:tr.nlevels]),
+           "level": [], "blurred": [], "t_counts": list(tr.t_counts[:tr.nlevels])}
+    for l in range(tr.nlevels):
+        shape = (tr.lh[l], tr.lw[l])
+        out["level"].append(np.ctypeslib.as_array(tr.level[l], shape=shape).copy())
+        out["blurred"].append(np.ctypeslib.as_array(tr.blurred[l], shape=shape).copy())
+    nc = tr.ncand
+    buf = (C.c_char * (nc * CAND_DTYPE.itemsize)).from_address(tr.cand) if nc else b""
+    out["cand"] = np.frombuffer(buf, dtype=CAND_DTYPE, count=nc).copy()
+    out["keep1"] = np.ctypeslib.as_array(tr.keep1, shape=(max(nc, 1),))[:nc].astype(bool)
+    out["keep2"] = np.ctypeslib.as_array(tr.keep2, shape=(max(nc, 1),))[:nc].astype(bool)
+    lib().afvo_trace_free(C.byref(tr))
+    return kps[:n.value].copy(), desc[:n.value].copy(), out
+
+
+# ---- matching ----
+def hamming256(a, b):
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return int(lib().afvo_hamming256(_p(a), _p(b)))
+
+
+def hamming_bytes(a, b):
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return int(lib().afvo_hamming_bytes(_p(a), _p(b), len(a)))
+
+
+def l2sqr(a, b):
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    return float(lib().afvo_l2sqr(_p(a), _p(b), len(a)))
+
+
+def _csr(nodes):
+    """nodes: None (brute force) or list of (node_id, [feature indices]) sorted by node_id."""
+    if nodes is None:
+        return None, None, None, 0
+    ids = np.array([n for n, _ in nodes], np.int32)
+    ptr = np.zeros(len(nodes) + 1, np.int32)
+    for i, (_, idx) in enumerate(nodes):
+        ptr[i + 1] = ptr[i] + len(idx)
+    flat = np.concatenate([np.asarray(idx, np.int32) for _, idx in nodes]) if nodes else np.zeros(0, np.int32)
+    return ids, ptr, np.ascontiguousarray(flat, np.int32), len(nodes)
+
+
+def _bow_job(desc1, desc2, nodes1, nodes2, valid1, valid2, angle1, angle2, th_low, nnratio, check_ori, keep):
+    desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    j = BowJob()
+    j.desc1 = _p(desc1); j.n1 = desc1.shape[0]; j.desc2 = _p(desc2); j.n2 = desc2.shape[0]
+    j.desc_bytes = desc1.shape[1] if desc1.ndim == 2 and desc1.shape[0] else (desc2.shape[1] if desc2.ndim == 2 else 32)
+    i1, p1, f1, n1 = _csr(nodes1); i2, p2, f2, n2 = _csr(nodes2)
+    j.node_id1 = _p(i1); j.seg_ptr1 = _p(p1); j.seg_idx1 = _p(f1); j.nnodes1 = n1
+    j.node_id2 = _p(i2); j.seg_ptr2 = _p(p2); j.seg_idx2 = _p(f2); j.nnodes2 = n2
+    v1 = None if valid1 is None else np.ascontiguousarray(valid1, np.uint8)
+    v2 = None if valid2 is None else np.ascontiguousarray(valid2, np.uint8)
+    a1 = None if angle1 is None else np.ascontiguousarray(angle1, np.float32)
+    a2 = None if angle2 is None else np.ascontiguousarray(angle2, np.float32)
+    j.valid1 = _p(v1); j.valid2 = _p(v2); j.angle1 = _p(a1); j.angle2 = _p(a2)
+    j.th_low = th_low; j.nnratio = nnratio; j.check_orientation = int(bool(check_ori))
+    keep.extend([desc1, desc2, i1, p1, f1, i2, p2, f2, v1, v2, a1, a2])
+    return j
+
+
+def search_by_bow_kf_kf(desc1, desc2, nodes1=None, nodes2=None, valid1=None, valid2=None, angle1=None, angle2=None,
+                        th_low=75.0, nnratio=0.6, check_orientation=False):
+    keep = []
+    j = _bow_job(desc1, desc2, nodes1, nodes2, valid1, valid2, angle1, angle2, th_low, nnratio, check_orientation, keep)
+    out = np.zeros(max(j.n1, 1), np.int32)
+    nm = lib().afvo_search_by_bow_kf_kf(C.byref(j), _p(out))
+    return out[:j.n1].copy(), nm
+
+
+def search_by_bow_kf_frame(desc_kf, desc_f, nodes_kf=None, nodes_f=None, valid_kf=None, angle_kf=None, angle_f=None,
+                           th_low=75.0, nnratio=0.7, check_orientation=False):
+    keep = []
+    j = _bow_job(desc_kf, desc_f, nodes_kf, nodes_f, valid_kf, None, angle_kf, angle_f, th_low, nnratio, check_orientation, keep)
+    out = np.zeros(max(j.n2, 1), np.int32)
+    nm = lib().afvo_search_by_bow_kf_frame(C.byref(j), _p(out))
+    return out[:j.n2].copy(), nm
+
+
+def search_for_triangulation(desc1, desc2, pts1, pts2, sigma2_2, F12, epipole, nodes1=None, nodes2=None,
+                             has_mp1=None, has_mp2=None, th_low=75.0):
+    keep = []
+    t = TriJob()
+    t.bow = _bow_job(desc1, desc2, nodes1, nodes2, has_mp1, has_mp2, None, None, th_low, 0.6, False, keep)
+    pts1 = np.asarray(pts1, np.float32); pts2 = np.asarray(pts2, np.float32)
+    x1 = np.ascontiguousarray(pts1[:, 0]); y1 = np.ascontiguousarray(pts1[:, 1])
+    x2 = np.ascontiguousarray(pts2[:, 0]); y2 = np.ascontiguousarray(pts2[:, 1])
+    s2 = np.ascontiguousarray(sigma2_2, np.float32)
+    t.x1 = _p(x1); t.y1 = _p(y1); t.x2 = _p(x2); t.y2 = _p(y2); t.sigma2_2 = _p(s2)
+    F = np.asarray(F12, np.float32).reshape(9)
+    for i in range(9):
+        t.F12[i] = float(F[i])
+    t.ex, t.ey = float(epipole[0]), float(epipole[1])
+    out = np.zeros(max(t.bow.n1, 1), np.int32)
+    nm = lib().afvo_search_for_triangulation(C.byref(t), _p(out))
+    return out[:t.bow.n1].copy(), nm
+
+
+def match_l2_bruteforce(desc1, desc2, th_low=0.5, nnratio=0.6, valid1=None, valid2=None):
+    desc1 = np.ascontiguousarray(desc1, np.float32); desc2 = np.ascontiguousarray(desc2, np.float32)
+    j = L2Job()
+    j.desc1 = _p(desc1); j.n1 = desc1.shape[0]; j.desc2 = _p(desc2); j.n2 = desc2.shape[0]; j.dim = desc1.shape[1]
+    v1 = None if valid1 is None else np.ascontiguousarray(valid1, np.uint8)
+    v2 = None if valid2 is None else np.ascontiguousarray(valid2, np.uint8)
+    j.valid1 = _p(v1); j.valid2 = _p(v2); j.th_low = th_low; j.nnratio = nnratio
+    out = np.zeros(max(j.n1, 1), np.int32)
+    nm = lib().afvo_match_l2_bruteforce(C.byref(j), _p(out))
+    return out[:j.n1].copy(), nm
+
+
+def rotation_bin(a1, a2):
+    return int(lib().afvo_rotation_bin(float(a1), float(a2)))
+
+
+def three_maxima(sizes):
+    sizes = np.ascontiguousarray(sizes, np.int32)
+    i1 = C.c_int(); i2 = C.c_int(); i3 = C.c_int()
+    lib().afvo_three_maxima(_p(sizes), len(sizes), C.byref(i1), C.byref(i2), C.byref(i3))
+    return i1.value, i2.value, i3.value
