@@ -1,0 +1,16 @@
+"""anyfeature-vslam_amd — MI355X-native ORB32 extraction + descriptor matching behind AnyFeature-VSLAM's
+FeatureExtractor / FeatureMatcher interface.  (The directory name carries a hyphen: import it with
+importlib.import_module("anyfeature-vslam_amd").)
+
+Layout:
+  csrc/          hand-written HIP kernels for gfx950 + the C-ABI runtime (libafv_hip.so, include/afv_hip.h)
+  adapter/       C++ host adapter mirroring the reference's classes on top of the C-ABI
+  _lib.py        ctypes binding
+  extractor.py   FeatureExtractorSettings / FeatureExtractor_orb32 mirror (reference: Feature_orb32.{h,cpp})
+  matcher.py     FeatureMatcher mirror (reference: FeatureMatcher.{h,cc})
+  synth.py       bit-reproducible synthetic inputs
+"""
+from . import _lib, synth  # noqa: F401
+from .extractor import (CovarianceMethod, FeatureExtractorSettings, FeatureExtractor_orb32, Context,  # noqa: F401
+                        KP_DTYPE)
+from .matcher import FeatureMatcher, FeatureView, DescriptorDistance_orb32  # noqa: F401

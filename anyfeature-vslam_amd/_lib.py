@@ -1,0 +1,105 @@
+"""ctypes binding of libafv_hip.so (the C-ABI declared in include/afv_hip.h).
+
+Plumbing only: no arithmetic happens here.  The library is the hand-written HIP path; if it is missing the import
+fails loudly — there is no CPU fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libafv_hip.so")
+
+MAX_LEVELS = 8
+DESC_BYTES = 32
+OK, EINVAL, ENODEV, ENOMEM, EHIP, ECAPACITY, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+MATCH_KF_KF, MATCH_KF_FRAME = 0, 1
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("nlevels", C.c_int32), ("scale_factor", C.c_float),
+                ("fast_threshold", C.c_int32), ("max_width", C.c_int32), ("max_height", C.c_int32),
+                ("max_batch", C.c_int32)]
+
+
+class Geometry(C.Structure):
+    _fields_ = [("nlevels", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("lw", C.c_int32 * MAX_LEVELS), ("lh", C.c_int32 * MAX_LEVELS), ("lscale", C.c_float * MAX_LEVELS),
+                ("quota", C.c_int32 * MAX_LEVELS), ("cv_quota", C.c_int32 * MAX_LEVELS),
+                ("cand_cap", C.c_int32 * MAX_LEVELS)]
+
+
+class MatchJob(C.Structure):
+    _fields_ = [("desc1", C.c_void_p), ("n1", C.c_int32), ("desc2", C.c_void_p), ("n2", C.c_int32),
+                ("desc_bytes", C.c_int32),
+                ("node_id1", C.c_void_p), ("seg_ptr1", C.c_void_p), ("seg_idx1", C.c_void_p), ("nnodes1", C.c_int32),
+                ("node_id2", C.c_void_p), ("seg_ptr2", C.c_void_p), ("seg_idx2", C.c_void_p), ("nnodes2", C.c_int32),
+                ("valid1", C.c_void_p), ("valid2", C.c_void_p), ("angle1", C.c_void_p), ("angle2", C.c_void_p),
+                ("th_low", C.c_float), ("nnratio", C.c_float), ("check_orientation", C.c_int32), ("mode", C.c_int32)]
+
+
+class TriJob(C.Structure):
+    _fields_ = [("bow", MatchJob), ("x1", C.c_void_p), ("y1", C.c_void_p), ("x2", C.c_void_p), ("y2", C.c_void_p),
+                ("sigma2_2", C.c_void_p), ("F12", C.c_float * 9), ("ex", C.c_float), ("ey", C.c_float)]
+
+
+# every symbol include/afv_hip.h declares: (name, restype, argtypes)
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+SYMBOLS = {
+    "afv_default_orb_params": (None, [C.POINTER(OrbParams)]),
+    "afv_create": (_i, [_i, C.POINTER(OrbParams), C.POINTER(_vp)]),
+    "afv_destroy": (None, [_vp]),
+    "afv_strerror": (C.c_char_p, [_i]),
+    "afv_last_error": (C.c_char_p, [_vp]),
+    "afv_max_keypoints_per_frame": (_i, [_vp]),
+    "afv_stream": (_vp, [_vp]),
+    "afv_orb_extract": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, C.POINTER(_i)]),
+    "afv_orb_extract_batch": (_i, [_vp, C.POINTER(_vp), _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "afv_orb_extract_batch_device": (_i, [_vp, _vp, _i, _i, _i, _i, _sz, _vp, _vp, _i, _vp, _vp, _vp]),
+    "afv_orb_size_sigma": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "afv_match_bow": (_i, [_vp, C.POINTER(MatchJob), _i, _vp, _vp]),
+    "afv_match_triangulation": (_i, [_vp, C.POINTER(TriJob), _i, _vp, _vp]),
+    "afv_match_bruteforce_pairs_device": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _f, _f, _i, _vp, _vp, _vp]),
+    "afv_match_l2": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _f, _f, _vp, _vp]),
+    "afv_hamming256": (_i, [_vp, _vp]),
+    "afv_get_geometry": (_i, [_vp, C.POINTER(Geometry)]),
+    "afv_debug_get_level": (_i, [_vp, _i, _i, _vp]),
+    "afv_debug_get_candidates": (_i, [_vp, _i, _i, _vp, _vp, _i, C.POINTER(_i)]),
+    "afv_debug_get_selected": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, C.POINTER(_i)]),
+    "afv_debug_blur_level": (_i, [_vp, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libafv_hip.so and bind every declared symbol.  Raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: build the HIP extension first (python __graft_entry__.py or "
+                          "anyfeature-vslam_amd/build.py); there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class AfvError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        msg = load().afv_strerror(code).decode()
+        super().__init__("afv error %d (%s)%s" % (code, msg, (": " + detail) if detail else ""))
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)

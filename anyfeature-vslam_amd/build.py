@@ -1,0 +1,53 @@
+"""Build libafv_hip.so (gfx950) in-tree with hipcc.  Used by __graft_entry__.build() and `python build.py`.
+
+hipcc cross-compiles without a GPU.  Flags that matter for parity:
+  -ffp-contract=off   one rounding per float operator (Harris response, fastAtan2, rBRIEF rotation, epipolar tests)
+  (no -ffast-math)    IEEE division / sqrt (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt stays on)
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libafv_hip.so")
+SOURCES = ["k_pyramid.hip", "k_fast.hip", "k_select.hip", "k_describe.hip", "k_match.hip", "afv_api.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-Wall", "-Wno-unused-function"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, "afv_device.h"), os.path.join(CSRC, "brief_pattern.inc"),
+               os.path.join(HERE, "..", "include", "afv_hip.h"), os.path.abspath(__file__)]
+    objs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + headers):
+            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+    if force or _stale(OUT, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

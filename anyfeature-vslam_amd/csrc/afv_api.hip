@@ -1,0 +1,817 @@
+// afv_api.hip — host runtime behind the C-ABI of include/afv_hip.h.
+// Owns the HIP stream, the per-geometry tables (level sizes, resize coefficients, quotas) and the device scratch
+// of one context; stages host-pointer calls; enqueues the kernel pipeline
+//   resize x (nlevels-1) -> FAST+NMS+Harris -> retainBest x2 + quadtree -> IC + blur + rBRIEF.
+// No CPU fallback exists: without a HIP device afv_create fails with AFV_ENODEV.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "afv_device.h"
+
+// ---- kernel launchers (k_*.hip) ----
+extern "C" void afv_launch_resize(const uint8_t *src, int sw, int sh, int spitch, size_t sframe, uint8_t *dst, int dw, int dh,
+                                  int dpitch, size_t dframe, const short2 *xt, const short2 *yt, int nframes, hipStream_t stream);
+extern "C" void afv_launch_fast_harris(const Geo *geo, int total_tiles, const FrameSrc *src0, const uint8_t *pyr,
+                                       uint32_t *cand_packed, float *cand_resp, int *cand_count, int nframes, hipStream_t stream);
+extern "C" size_t afv_select_lds_bytes(int M);
+extern "C" void afv_launch_select(const Geo *geo_dev, int nlevels, const uint32_t *cand_packed, const float *cand_resp,
+                                  const int *cand_count, uint32_t *kept_xy, float *kept_resp, uint16_t *kept_node, SelPoint *sel,
+                                  int *sel_count, int M, int nframes, hipStream_t stream);
+extern "C" void afv_launch_describe(const Geo *geo_dev, int nlevels, int max_sel_cap, const FrameSrc *src0, const uint8_t *pyr,
+                                    const SelPoint *sel, const int *sel_count, afv_keypoint *kps, uint8_t *desc,
+                                    int cap_per_frame, int *n_out, int *status, int nframes, hipStream_t stream);
+extern "C" void afv_launch_blur_level(const uint8_t *img, int w, int h, int pitch, uint8_t *out, hipStream_t stream);
+
+struct Seg { int s1, n1, s2, n2; };
+struct DevMatchJob {
+    const uint32_t *d1; const uint32_t *d2; int n1, n2, words;
+    const Seg *segs; int nseg; const int *idx1; const int *idx2;
+    const uint8_t *valid1; const uint8_t *valid2; const float *ang1; const float *ang2; int ang_stride;
+    float th, ratio; int check_ori, mode; int *out; int *nmatches;
+};
+struct DevTriJob {
+    DevMatchJob m;
+    const float *x1, *y1, *x2, *y2, *sigma2_2;
+    float F[9];
+    float ex, ey;
+};
+extern "C" void afv_launch_match_bow(const DevMatchJob *jobs, int njobs, hipStream_t stream);
+extern "C" void afv_launch_match_pairs(const uint8_t *desc, const afv_keypoint *kps, const int *nset, int cap, const int *pa,
+                                       const int *pb, int npairs, float th, float ratio, int check_ori, int *match,
+                                       int *nmatches, hipStream_t stream);
+extern "C" void afv_launch_match_tri(const DevTriJob *jobs, int njobs, hipStream_t stream);
+extern "C" void afv_launch_match_l2(const float *d1, int n1, const float *d2, int n2, int dim, const uint8_t *v1,
+                                    const uint8_t *v2, float th, float ratio, int *out, int *nmatches, hipStream_t stream);
+
+#define AFV_MAX_SIDE 8192
+
+struct afv_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    afv_orb_params p{};
+    Geo geo{};          // current geometry (host copy)
+    Geo cap_geo{};      // geometry of (max_width, max_height): sizes every allocation
+    Geo *d_geo = nullptr;
+    bool geo_valid = false;
+    short2 *d_tab = nullptr;  // resize tables, all levels
+    size_t tab_off_x[AFV_MAX_LEVELS]{}, tab_off_y[AFV_MAX_LEVELS]{};
+    size_t tab_elems = 0;
+    uint8_t *d_pyr = nullptr;
+    uint32_t *d_cand_packed = nullptr, *d_kept_xy = nullptr;
+    float *d_cand_resp = nullptr, *d_kept_resp = nullptr;
+    uint16_t *d_kept_node = nullptr;
+    int *d_cand_count = nullptr, *d_sel_count = nullptr;
+    SelPoint *d_sel = nullptr;
+    int select_M = 64;
+    // staging of the host-pointer entry points
+    uint8_t *d_frames = nullptr;
+    size_t frames_pitch = 0, frames_stride = 0;
+    afv_keypoint *d_kps = nullptr;
+    uint8_t *d_desc = nullptr;
+    int *d_n = nullptr, *d_status = nullptr;
+    int stage_cap = 0;
+    std::vector<afv_keypoint> h_kps;
+    std::vector<uint8_t> h_desc;
+    std::vector<int> h_n;
+    // matcher staging (grow only)
+    uint8_t *d_match = nullptr;
+    size_t match_bytes = 0;
+    // last extraction (debug getters)
+    FrameSrc last_src{};
+    int last_nframes = 0;
+    std::string last_error;
+};
+
+static const char *k_errors[] = {"ok", "invalid argument", "no usable HIP device", "out of memory", "HIP runtime error",
+                                 "output capacity too small", "unsupported"};
+
+#define HIPCHK(ctx, call)                                                                            \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            (ctx)->last_error = std::string(#call) + ": " + hipGetErrorString(e_);                  \
+            return e_ == hipErrorOutOfMemory ? AFV_ENOMEM : AFV_EHIP;                                \
+        }                                                                                            \
+    } while (0)
+
+static inline int cv_round(float v) { return (int)lrintf(v); }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" void afv_default_orb_params(afv_orb_params *p) {
+    if (!p) return;
+    p->nfeatures = 1000;
+    p->nlevels = 8;
+    p->scale_factor = 1.2f;
+    p->fast_threshold = 20;
+    p->max_width = 640;
+    p->max_height = 480;
+    p->max_batch = 1;
+}
+
+extern "C" const char *afv_strerror(int code) {
+    const int i = -code;
+    if (i < 0 || i > 6) return "unknown error";
+    return k_errors[i];
+}
+extern "C" const char *afv_last_error(const afv_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+extern "C" void *afv_stream(afv_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+// ---- geometry (host).  Mirrors cv::ORB's level sizes / quotas and FeatureExtractor.cpp:97-108 ----
+static int build_geometry(const afv_orb_params &p, int w, int h, int max_batch, Geo &g) {
+    std::memset(&g, 0, sizeof(g));
+    if (p.nlevels < 1 || p.nlevels > AFV_MAX_LEVELS || w < 1 || h < 1 || w > 4095 || h > 4095) return AFV_EINVAL;
+    g.nlevels = p.nlevels;
+    g.width = w;
+    g.height = h;
+    g.fast_threshold = std::min(std::max(p.fast_threshold, 0), 255);
+    {
+        const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+        g.harris_scale4 = scale * scale * scale * scale;
+    }
+    g.n_ini = (int)roundf((float)w / (float)h);  // ORBextractor.cc:243
+    if (g.n_ini < 1 || g.n_ini > 16) return AFV_EUNSUPPORTED;
+    g.h_x = (float)w / (float)g.n_ini;
+    // quadtree quotas (FeatureExtractor.cpp:97-108)
+    int quota[AFV_MAX_LEVELS], cvq[AFV_MAX_LEVELS];
+    {
+        const float factor = 1.0f / p.scale_factor;
+        float desired = (float)p.nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)p.nlevels));
+        int sum = 0;
+        for (int l = 0; l < p.nlevels - 1; ++l) {
+            quota[l] = cv_round(desired);
+            sum += quota[l];
+            desired *= factor;
+        }
+        quota[p.nlevels - 1] = std::max(p.nfeatures - sum, 0);
+    }
+    {   // cv::ORB computeKeyPoints with nfeatures*10 (Feature_orb32.cpp:22), scaleFactor held as double
+        const int nf = p.nfeatures * 10;
+        const float factor = (float)(1.0 / (double)p.scale_factor);
+        float desired = nf * (1 - factor) / (1 - (float)std::pow((double)factor, (double)p.nlevels));
+        int sum = 0;
+        for (int l = 0; l < p.nlevels - 1; ++l) {
+            cvq[l] = cv_round(desired);
+            sum += cvq[l];
+            desired *= factor;
+        }
+        cvq[p.nlevels - 1] = std::max(nf - sum, 0);
+    }
+    size_t pyr_off = 0, cand_off = 0;
+    int tile_base = 0, sel_base = 0;
+    for (int l = 0; l < p.nlevels; ++l) {
+        LevelGeo &L = g.lv[l];
+        L.scale = (float)std::pow((double)p.scale_factor, (double)l);
+        L.inv_scale = 1.0f / L.scale;
+        L.w = cv_round((float)w * L.inv_scale);
+        L.h = cv_round((float)h * L.inv_scale);
+        if (L.w < 32 || L.h < 32) return AFV_EUNSUPPORTED;  // single-reflection apron needs >= 32 px levels
+        L.pitch = (int)align_up((size_t)L.w, 64);
+        L.tiles_x = (L.w + FT_W - 1) / FT_W;
+        L.tiles_y = (L.h + FT_H - 1) / FT_H;
+        L.tile_base = tile_base;
+        tile_base += L.tiles_x * L.tiles_y;
+        L.quota = quota[l];
+        L.cv_quota = cvq[l];
+        L.cand_cap = ((L.w + 1) / 2) * ((L.h + 1) / 2);
+        L.sel_cap = L.quota + 3;
+        L.sel_base = sel_base;
+        sel_base += L.sel_cap;
+        L.pyr_frame_stride = align_up((size_t)L.h * L.pitch + 64, 256);
+        L.pyr_off = pyr_off;
+        if (l > 0) pyr_off += L.pyr_frame_stride * (size_t)max_batch;
+        L.cand_frame_stride = (size_t)L.cand_cap;
+        L.cand_off = cand_off;
+        cand_off += L.cand_frame_stride * (size_t)max_batch;
+    }
+    g.total_tiles = tile_base;
+    g.sel_per_frame = sel_base;
+    return AFV_OK;
+}
+
+static size_t geo_pyr_bytes(const Geo &g, int max_batch) {
+    const LevelGeo &L = g.lv[g.nlevels - 1];
+    return g.nlevels > 1 ? L.pyr_off + L.pyr_frame_stride * (size_t)max_batch : 256;
+}
+static size_t geo_cand_elems(const Geo &g, int max_batch) {
+    const LevelGeo &L = g.lv[g.nlevels - 1];
+    return L.cand_off + L.cand_frame_stride * (size_t)max_batch;
+}
+
+// OpenCV resize_bitExact / interpolation_linear<uchar>::getCoeffs: per destination index {offset, weight of right tap}
+static void resize_table(int src, int dst, short2 *t) {
+    const double inv_scale = (double)dst / (double)src;
+    const double scale = 1.0 / inv_scale;
+    for (int d = 0; d < dst; ++d) {
+        const double f = scale * ((double)d + 0.5) - 0.5;
+        const int i = (int)std::floor(f);
+        short2 e;
+        if (i >= 0 && src > 1) {
+            if (i < src - 1) {
+                e.x = (short)i;
+                e.y = (short)lrint((f - (double)i) * 256.0);
+            } else {
+                e.x = (short)(src - 1);
+                e.y = 0;
+            }
+        } else {
+            e.x = 0;
+            e.y = 0;
+        }
+        t[d] = e;
+    }
+}
+
+static int set_geometry(afv_ctx *c, int w, int h) {
+    if (c->geo_valid && c->geo.width == w && c->geo.height == h) return AFV_OK;
+    if (w > c->p.max_width || h > c->p.max_height) return AFV_EINVAL;
+    Geo g;
+    const int rc = build_geometry(c->p, w, h, c->p.max_batch, g);
+    if (rc) return rc;
+    // allocation layout always follows the capacity geometry so buffers never move
+    for (int l = 0; l < g.nlevels; ++l) {
+        if (g.lv[l].cand_cap > c->cap_geo.lv[l].cand_cap || g.lv[l].pyr_frame_stride > c->cap_geo.lv[l].pyr_frame_stride)
+            return AFV_EINVAL;
+        g.lv[l].pyr_off = c->cap_geo.lv[l].pyr_off;
+        g.lv[l].pyr_frame_stride = c->cap_geo.lv[l].pyr_frame_stride;
+        g.lv[l].cand_off = c->cap_geo.lv[l].cand_off;
+        g.lv[l].cand_frame_stride = c->cap_geo.lv[l].cand_frame_stride;
+    }
+    std::vector<short2> tab(c->tab_elems);
+    size_t off = 0;
+    for (int l = 1; l < g.nlevels; ++l) {
+        c->tab_off_x[l] = off;
+        resize_table(g.lv[l - 1].w, g.lv[l].w, tab.data() + off);
+        off += (size_t)g.lv[l].w;
+        c->tab_off_y[l] = off;
+        resize_table(g.lv[l - 1].h, g.lv[l].h, tab.data() + off);
+        off += (size_t)g.lv[l].h;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(c->d_tab, tab.data(), off * sizeof(short2), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_geo, &g, sizeof(Geo), hipMemcpyHostToDevice));
+    c->geo = g;
+    c->geo_valid = true;
+    return AFV_OK;
+}
+
+extern "C" int afv_max_keypoints_per_frame(const afv_ctx *c) {
+    if (!c) return AFV_EINVAL;
+    int s = 0;
+    for (int l = 0; l < c->cap_geo.nlevels; ++l) s += c->cap_geo.lv[l].quota + 2;
+    return s;
+}
+
+extern "C" void afv_destroy(afv_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void *ptrs[] = {c->d_geo, c->d_tab, c->d_pyr, c->d_cand_packed, c->d_kept_xy, c->d_cand_resp, c->d_kept_resp,
+                    c->d_kept_node, c->d_cand_count, c->d_sel_count, c->d_sel, c->d_frames, c->d_kps, c->d_desc,
+                    c->d_n, c->d_status, c->d_match};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int afv_create(int device, const afv_orb_params *params, afv_ctx **out) {
+    if (!params || !out) return AFV_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return AFV_ENODEV;
+    if (device < 0 || device >= ndev) return AFV_ENODEV;
+    if (params->nfeatures < 1 || params->nfeatures > 4000 || params->max_batch < 1 || params->max_batch > 65535 ||
+        params->scale_factor <= 1.0f)
+        return AFV_EINVAL;
+    afv_ctx *c = new (std::nothrow) afv_ctx();
+    if (!c) return AFV_ENOMEM;
+    c->device = device;
+    c->p = *params;
+    int rc = build_geometry(c->p, params->max_width, params->max_height, params->max_batch, c->cap_geo);
+    if (rc) {
+        delete c;
+        return rc;
+    }
+    const Geo &g = c->cap_geo;
+    const int B = params->max_batch;
+#define CREATE_CHK(call)                                                         \
+    do {                                                                         \
+        hipError_t e_ = (call);                                                  \
+        if (e_ != hipSuccess) {                                                  \
+            fprintf(stderr, "afv_create: %s: %s\n", #call, hipGetErrorString(e_)); \
+            afv_destroy(c);                                                      \
+            return e_ == hipErrorOutOfMemory ? AFV_ENOMEM : AFV_EHIP;            \
+        }                                                                        \
+    } while (0)
+    CREATE_CHK(hipSetDevice(device));
+    CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CREATE_CHK(hipMalloc(&c->d_geo, sizeof(Geo)));
+    c->tab_elems = 0;
+    for (int l = 1; l < g.nlevels; ++l) c->tab_elems += (size_t)g.lv[l].w + (size_t)g.lv[l].h;
+    CREATE_CHK(hipMalloc(&c->d_tab, std::max<size_t>(c->tab_elems, 1) * sizeof(short2)));
+    CREATE_CHK(hipMalloc(&c->d_pyr, geo_pyr_bytes(g, B)));
+    const size_t ce = geo_cand_elems(g, B);
+    CREATE_CHK(hipMalloc(&c->d_cand_packed, ce * 4));
+    CREATE_CHK(hipMalloc(&c->d_cand_resp, ce * 4));
+    CREATE_CHK(hipMalloc(&c->d_kept_xy, ce * 4));
+    CREATE_CHK(hipMalloc(&c->d_kept_resp, ce * 4));
+    CREATE_CHK(hipMalloc(&c->d_kept_node, ce * 2));
+    CREATE_CHK(hipMalloc(&c->d_cand_count, (size_t)B * AFV_MAX_LEVELS * sizeof(int)));
+    CREATE_CHK(hipMalloc(&c->d_sel_count, (size_t)B * AFV_MAX_LEVELS * sizeof(int)));
+    CREATE_CHK(hipMalloc(&c->d_sel, (size_t)B * g.sel_per_frame * sizeof(SelPoint)));
+    CREATE_CHK(hipMemset(c->d_sel_count, 0, (size_t)B * AFV_MAX_LEVELS * sizeof(int)));
+    // staging for host-pointer calls
+    c->frames_pitch = align_up((size_t)params->max_width, 64);
+    c->frames_stride = align_up(c->frames_pitch * (size_t)params->max_height + 64, 256);
+    CREATE_CHK(hipMalloc(&c->d_frames, c->frames_stride * (size_t)B));
+    c->stage_cap = afv_max_keypoints_per_frame(c);
+    CREATE_CHK(hipMalloc(&c->d_kps, (size_t)B * c->stage_cap * sizeof(afv_keypoint)));
+    CREATE_CHK(hipMalloc(&c->d_desc, (size_t)B * c->stage_cap * AFV_DESC_BYTES));
+    CREATE_CHK(hipMalloc(&c->d_n, (size_t)B * sizeof(int)));
+    CREATE_CHK(hipMalloc(&c->d_status, sizeof(int)));
+    c->h_kps.resize((size_t)B * c->stage_cap);
+    c->h_desc.resize((size_t)B * c->stage_cap * AFV_DESC_BYTES);
+    c->h_n.resize(B);
+    // quadtree node capacity: alive nodes <= max(quota + 3, 4 * n_ini)
+    int M = 64;
+    for (int l = 0; l < g.nlevels; ++l) M = std::max(M, g.lv[l].quota + 8);
+    M = std::max(M, 4 * 16 + 8);
+    M = (int)align_up((size_t)M, 64);
+    c->select_M = M;
+    if (afv_select_lds_bytes(M) > 160 * 1024) {
+        afv_destroy(c);
+        return AFV_EUNSUPPORTED;
+    }
+#undef CREATE_CHK
+    *out = c;
+    return AFV_OK;
+}
+
+extern "C" int afv_get_geometry(const afv_ctx *c, afv_geometry *g) {
+    if (!c || !g) return AFV_EINVAL;
+    const Geo &s = c->geo_valid ? c->geo : c->cap_geo;
+    std::memset(g, 0, sizeof(*g));
+    g->nlevels = s.nlevels;
+    g->width = s.width;
+    g->height = s.height;
+    for (int l = 0; l < s.nlevels; ++l) {
+        g->lw[l] = s.lv[l].w;
+        g->lh[l] = s.lv[l].h;
+        g->lscale[l] = s.lv[l].scale;
+        g->quota[l] = s.lv[l].quota;
+        g->cv_quota[l] = s.lv[l].cv_quota;
+        g->cand_cap[l] = s.lv[l].cand_cap;
+    }
+    return AFV_OK;
+}
+
+// ---- the pipeline ----
+static int enqueue_extract(afv_ctx *c, const FrameSrc &src, int nframes, afv_keypoint *d_kps, uint8_t *d_desc, int cap,
+                           int *d_n, int *d_status, hipStream_t s) {
+    const Geo &g = c->geo;
+    HIPCHK(c, hipMemsetAsync(c->d_cand_count, 0, (size_t)nframes * AFV_MAX_LEVELS * sizeof(int), s));
+    if (d_status) HIPCHK(c, hipMemsetAsync(d_status, 0, sizeof(int), s));
+    for (int l = 1; l < g.nlevels; ++l) {
+        const LevelGeo &S = g.lv[l - 1], &D = g.lv[l];
+        const uint8_t *sp = (l == 1) ? src.base : c->d_pyr + S.pyr_off;
+        const int spitch = (l == 1) ? src.stride : S.pitch;
+        const size_t sframe = (l == 1) ? src.frame_stride : S.pyr_frame_stride;
+        afv_launch_resize(sp, S.w, S.h, spitch, sframe, c->d_pyr + D.pyr_off, D.w, D.h, D.pitch, D.pyr_frame_stride,
+                          c->d_tab + c->tab_off_x[l], c->d_tab + c->tab_off_y[l], nframes, s);
+    }
+    afv_launch_fast_harris(c->d_geo, g.total_tiles, &src, c->d_pyr, c->d_cand_packed, c->d_cand_resp, c->d_cand_count, nframes, s);
+    afv_launch_select(c->d_geo, g.nlevels, c->d_cand_packed, c->d_cand_resp, c->d_cand_count, c->d_kept_xy, c->d_kept_resp,
+                      c->d_kept_node, c->d_sel, c->d_sel_count, c->select_M, nframes, s);
+    int max_sel = 0;
+    for (int l = 0; l < g.nlevels; ++l) max_sel = std::max(max_sel, g.lv[l].sel_cap);
+    afv_launch_describe(c->d_geo, g.nlevels, max_sel, &src, c->d_pyr, c->d_sel, c->d_sel_count, d_kps, d_desc, cap, d_n,
+                        d_status, nframes, s);
+    HIPCHK(c, hipGetLastError());
+    c->last_src = src;
+    c->last_nframes = nframes;
+    return AFV_OK;
+}
+
+extern "C" int afv_orb_extract_batch_device(afv_ctx *c, const uint8_t *d_frames, int nframes, int width, int height,
+                                            int stride_bytes, size_t frame_stride_bytes, afv_keypoint *d_kps,
+                                            uint8_t *d_desc32, int cap_per_frame, int32_t *d_n_out, int32_t *d_status_out,
+                                            void *stream) {
+    if (!c || !d_frames || !d_kps || !d_desc32 || !d_n_out) return AFV_EINVAL;
+    if (nframes < 1 || nframes > c->p.max_batch || cap_per_frame < 1 || stride_bytes < width) return AFV_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(d_frames) & 3) || (stride_bytes & 3) || (frame_stride_bytes & 3)) return AFV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = set_geometry(c, width, height);
+    if (rc) return rc;
+    FrameSrc src{d_frames, stride_bytes, frame_stride_bytes};
+    return enqueue_extract(c, src, nframes, d_kps, d_desc32, cap_per_frame, d_n_out, d_status_out,
+                           stream ? (hipStream_t)stream : c->stream);
+}
+
+extern "C" int afv_orb_extract_batch(afv_ctx *c, const uint8_t *const *frames, int nframes, int width, int height,
+                                     int stride_bytes, afv_keypoint *kps, uint8_t *desc32, int cap_per_frame, int *n_out) {
+    if (!c || !frames || !kps || !desc32 || !n_out) return AFV_EINVAL;
+    if (nframes < 1 || nframes > c->p.max_batch || cap_per_frame < 1 || stride_bytes < width) return AFV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = set_geometry(c, width, height);
+    if (rc) return rc;
+    for (int f = 0; f < nframes; ++f) {
+        if (!frames[f]) return AFV_EINVAL;
+        HIPCHK(c, hipMemcpy2DAsync(c->d_frames + (size_t)f * c->frames_stride, c->frames_pitch, frames[f], (size_t)stride_bytes,
+                                   (size_t)width, (size_t)height, hipMemcpyHostToDevice, c->stream));
+    }
+    FrameSrc src{c->d_frames, (int)c->frames_pitch, c->frames_stride};
+    rc = enqueue_extract(c, src, nframes, c->d_kps, c->d_desc, c->stage_cap, c->d_n, c->d_status, c->stream);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->h_n.data(), c->d_n, (size_t)nframes * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_kps.data(), c->d_kps, (size_t)nframes * c->stage_cap * sizeof(afv_keypoint),
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_desc.data(), c->d_desc, (size_t)nframes * c->stage_cap * AFV_DESC_BYTES,
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int result = AFV_OK;
+    for (int f = 0; f < nframes; ++f) {
+        int n = c->h_n[f];
+        if (n > cap_per_frame) {
+            n = cap_per_frame;
+            result = AFV_ECAPACITY;
+        }
+        n_out[f] = n;
+        std::memcpy(kps + (size_t)f * cap_per_frame, c->h_kps.data() + (size_t)f * c->stage_cap, (size_t)n * sizeof(afv_keypoint));
+        std::memcpy(desc32 + (size_t)f * cap_per_frame * AFV_DESC_BYTES, c->h_desc.data() + (size_t)f * c->stage_cap * AFV_DESC_BYTES,
+                    (size_t)n * AFV_DESC_BYTES);
+    }
+    return result;
+}
+
+extern "C" int afv_orb_extract(afv_ctx *c, const uint8_t *gray, int width, int height, int stride_bytes, afv_keypoint *kps,
+                               uint8_t *desc32, int cap, int *n_out) {
+    const uint8_t *frames[1] = {gray};
+    return afv_orb_extract_batch(c, frames, 1, width, height, stride_bytes, kps, desc32, cap, n_out);
+}
+
+// E12 (FeatureExtractor.cpp:132-172, settings FeatureExtractor.cpp:52-55)
+extern "C" int afv_orb_size_sigma(const afv_ctx *c, const afv_keypoint *kps, int n, float *size, float *sigma2, float *inf) {
+    if (!c || (n > 0 && (!kps || !size || !sigma2 || !inf)) || n < 0) return AFV_EINVAL;
+    const float scale_factor_orb = 1.2f;
+    const float max_size0 = powf(scale_factor_orb, float(8 - 1.0));
+    const float max_size = max_size0, min_size = 1.0f;
+    for (int i = 0; i < n; ++i) {
+        const float s = powf(c->p.scale_factor, float(kps[i].octave));  // GetKeypointSize Feature_orb32.cpp:59-61
+        float norm = max_size;
+        if (max_size > min_size) norm = 1.0f + (s - min_size) * (max_size0 - 1.0f) / (max_size - min_size);
+        size[i] = norm;
+        const float s2 = norm * norm;
+        sigma2[i] = s2;
+        inf[i] = 1.0f / s2;
+    }
+    return AFV_OK;
+}
+
+extern "C" int afv_hamming256(const uint8_t *a, const uint8_t *b) {
+    int d = 0;
+    for (int i = 0; i < 8; ++i) {
+        uint32_t x, y;
+        std::memcpy(&x, a + 4 * i, 4);
+        std::memcpy(&y, b + 4 * i, 4);
+        d += __builtin_popcount(x ^ y);
+    }
+    return d;
+}
+
+// ---- debug getters ----
+static const uint8_t *level_ptr(const afv_ctx *c, int frame, int level, int *pitch) {
+    const LevelGeo &L = c->geo.lv[level];
+    if (level == 0) {
+        *pitch = c->last_src.stride;
+        return c->last_src.base + (size_t)frame * c->last_src.frame_stride;
+    }
+    *pitch = L.pitch;
+    return c->d_pyr + L.pyr_off + (size_t)frame * L.pyr_frame_stride;
+}
+
+extern "C" int afv_debug_get_level(afv_ctx *c, int frame, int level, uint8_t *out) {
+    if (!c || !out || !c->geo_valid || frame < 0 || frame >= c->last_nframes || level < 0 || level >= c->geo.nlevels) return AFV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    int pitch;
+    const uint8_t *p = level_ptr(c, frame, level, &pitch);
+    const LevelGeo &L = c->geo.lv[level];
+    HIPCHK(c, hipMemcpy2D(out, (size_t)L.w, p, (size_t)pitch, (size_t)L.w, (size_t)L.h, hipMemcpyDeviceToHost));
+    return AFV_OK;
+}
+
+extern "C" int afv_debug_get_candidates(afv_ctx *c, int frame, int level, uint32_t *packed, float *response, int cap, int *n_out) {
+    if (!c || !packed || !response || !n_out || !c->geo_valid || frame < 0 || frame >= c->last_nframes || level < 0 ||
+        level >= c->geo.nlevels)
+        return AFV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    int n = 0;
+    HIPCHK(c, hipMemcpy(&n, c->d_cand_count + frame * AFV_MAX_LEVELS + level, sizeof(int), hipMemcpyDeviceToHost));
+    const LevelGeo &L = c->geo.lv[level];
+    n = std::min(n, L.cand_cap);
+    *n_out = n;
+    const int m = std::min(n, cap);
+    const size_t base = L.cand_off + (size_t)frame * L.cand_frame_stride;
+    if (m > 0) {
+        HIPCHK(c, hipMemcpy(packed, c->d_cand_packed + base, (size_t)m * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(response, c->d_cand_resp + base, (size_t)m * 4, hipMemcpyDeviceToHost));
+    }
+    return n > cap ? AFV_ECAPACITY : AFV_OK;
+}
+
+extern "C" int afv_debug_get_selected(afv_ctx *c, int frame, int level, int32_t *x, int32_t *y, float *response, int cap, int *n_out) {
+    if (!c || !x || !y || !response || !n_out || !c->geo_valid || frame < 0 || frame >= c->last_nframes || level < 0 ||
+        level >= c->geo.nlevels)
+        return AFV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    int n = 0;
+    HIPCHK(c, hipMemcpy(&n, c->d_sel_count + frame * AFV_MAX_LEVELS + level, sizeof(int), hipMemcpyDeviceToHost));
+    *n_out = n;
+    const int m = std::min(n, cap);
+    std::vector<SelPoint> tmp(std::max(m, 1));
+    if (m > 0)
+        HIPCHK(c, hipMemcpy(tmp.data(), c->d_sel + (size_t)frame * c->geo.sel_per_frame + c->geo.lv[level].sel_base,
+                            (size_t)m * sizeof(SelPoint), hipMemcpyDeviceToHost));
+    for (int i = 0; i < m; ++i) {
+        x[i] = tmp[i].x;
+        y[i] = tmp[i].y;
+        response[i] = tmp[i].response;
+    }
+    return n > cap ? AFV_ECAPACITY : AFV_OK;
+}
+
+extern "C" int afv_debug_blur_level(afv_ctx *c, int frame, int level, uint8_t *out) {
+    if (!c || !out || !c->geo_valid || frame < 0 || frame >= c->last_nframes || level < 0 || level >= c->geo.nlevels) return AFV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    int pitch;
+    const uint8_t *p = level_ptr(c, frame, level, &pitch);
+    const LevelGeo &L = c->geo.lv[level];
+    uint8_t *d_out = nullptr;
+    HIPCHK(c, hipMalloc(&d_out, (size_t)L.w * L.h));
+    afv_launch_blur_level(p, L.w, L.h, pitch, d_out, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, (size_t)L.w * L.h, hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    HIPCHK(c, e);
+    return AFV_OK;
+}
+
+// ---- matcher staging ----
+struct Blob {  // host image of the device staging buffer
+    std::vector<uint8_t> h;
+    size_t put(const void *src, size_t bytes, size_t align = 16) {
+        const size_t off = align_up(h.size(), align);
+        h.resize(off + bytes);
+        if (src && bytes) std::memcpy(h.data() + off, src, bytes);
+        return off;
+    }
+    size_t reserve(size_t bytes, size_t align = 16) {
+        const size_t off = align_up(h.size(), align);
+        h.resize(off + bytes);
+        return off;
+    }
+};
+
+static int ensure_match_buffer(afv_ctx *c, size_t bytes) {
+    if (bytes <= c->match_bytes) return AFV_OK;
+    if (c->d_match) (void)hipFree(c->d_match);
+    c->d_match = nullptr;
+    c->match_bytes = 0;
+    const size_t want = align_up(bytes + bytes / 2, 1 << 20);
+    HIPCHK(c, hipMalloc(&c->d_match, want));
+    c->match_bytes = want;
+    return AFV_OK;
+}
+
+// descriptors -> rows of `words` dwords (zero padded)
+static size_t put_desc(Blob &b, const uint8_t *d, int n, int desc_bytes, int words) {
+    const size_t off = b.reserve((size_t)std::max(n, 1) * words * 4);
+    for (int i = 0; i < n; ++i) {
+        uint8_t *row = b.h.data() + off + (size_t)i * words * 4;
+        std::memset(row, 0, (size_t)words * 4);
+        std::memcpy(row, d + (size_t)i * desc_bytes, (size_t)desc_bytes);
+    }
+    return off;
+}
+
+// merge-join of the two FeatureVectors (FeatureMatcher.cc:205-276): list of (range1, range2) for shared node ids
+static void shared_segments(const afv_match_job &j, std::vector<Seg> &segs) {
+    segs.clear();
+    if (j.nnodes1 == 0 || j.nnodes2 == 0) {
+        segs.push_back(Seg{0, j.n1, 0, j.n2});
+        return;
+    }
+    int a = 0, b = 0;
+    while (a < j.nnodes1 && b < j.nnodes2) {
+        if (j.node_id1[a] == j.node_id2[b]) {
+            segs.push_back(Seg{j.seg_ptr1[a], j.seg_ptr1[a + 1] - j.seg_ptr1[a], j.seg_ptr2[b], j.seg_ptr2[b + 1] - j.seg_ptr2[b]});
+            ++a;
+            ++b;
+        } else if (j.node_id1[a] < j.node_id2[b]) {
+            ++a;
+        } else {
+            ++b;
+        }
+    }
+}
+
+struct JobOffsets {
+    size_t d1, d2, segs, idx1, idx2, v1, v2, a1, a2, out, nm;
+    int nseg, words, nout;
+    bool has_idx, has_v1, has_v2, has_ang;
+};
+
+static int validate_job(const afv_match_job &j, bool need_angles) {
+    if (j.n1 < 0 || j.n2 < 0 || j.n1 > AFV_MAX_SIDE || j.n2 > AFV_MAX_SIDE) return AFV_EINVAL;
+    if ((j.n1 > 0 && !j.desc1) || (j.n2 > 0 && !j.desc2)) return AFV_EINVAL;
+    if (j.desc_bytes < 1 || j.desc_bytes > 64) return AFV_EINVAL;
+    if (j.nnodes1 < 0 || j.nnodes2 < 0) return AFV_EINVAL;
+    if (j.nnodes1 > 0 && (!j.node_id1 || !j.seg_ptr1 || !j.seg_idx1)) return AFV_EINVAL;
+    if (j.nnodes2 > 0 && (!j.node_id2 || !j.seg_ptr2 || !j.seg_idx2)) return AFV_EINVAL;
+    if (need_angles && j.check_orientation && (!j.angle1 || !j.angle2)) return AFV_EINVAL;
+    return AFV_OK;
+}
+
+static void stage_job(Blob &b, const afv_match_job &j, bool tri, JobOffsets &o) {
+    o.words = j.desc_bytes <= 32 ? 8 : 16;
+    o.d1 = put_desc(b, j.desc1, j.n1, j.desc_bytes, o.words);
+    o.d2 = put_desc(b, j.desc2, j.n2, j.desc_bytes, o.words);
+    std::vector<Seg> segs;
+    shared_segments(j, segs);
+    o.nseg = (int)segs.size();
+    o.segs = b.put(segs.data(), segs.size() * sizeof(Seg));
+    o.has_idx = j.nnodes1 > 0 && j.nnodes2 > 0;
+    if (o.has_idx) {
+        o.idx1 = b.put(j.seg_idx1, (size_t)j.seg_ptr1[j.nnodes1] * 4);
+        o.idx2 = b.put(j.seg_idx2, (size_t)j.seg_ptr2[j.nnodes2] * 4);
+    }
+    o.has_v1 = j.valid1 != nullptr;
+    o.has_v2 = j.valid2 != nullptr && (tri || j.mode != AFV_MATCH_KF_FRAME);
+    if (o.has_v1) o.v1 = b.put(j.valid1, (size_t)j.n1);
+    if (o.has_v2) o.v2 = b.put(j.valid2, (size_t)j.n2);
+    o.has_ang = !tri && j.check_orientation;
+    if (o.has_ang) {
+        o.a1 = b.put(j.angle1, (size_t)j.n1 * 4);
+        o.a2 = b.put(j.angle2, (size_t)j.n2 * 4);
+    }
+    o.nout = (!tri && j.mode == AFV_MATCH_KF_FRAME) ? j.n2 : j.n1;
+}
+
+static void fill_dev_job(DevMatchJob &d, const afv_match_job &j, const JobOffsets &o, uint8_t *base, bool tri) {
+    d.d1 = reinterpret_cast<const uint32_t *>(base + o.d1);
+    d.d2 = reinterpret_cast<const uint32_t *>(base + o.d2);
+    d.n1 = j.n1;
+    d.n2 = j.n2;
+    d.words = o.words;
+    d.segs = reinterpret_cast<const Seg *>(base + o.segs);
+    d.nseg = o.nseg;
+    d.idx1 = o.has_idx ? reinterpret_cast<const int *>(base + o.idx1) : nullptr;
+    d.idx2 = o.has_idx ? reinterpret_cast<const int *>(base + o.idx2) : nullptr;
+    d.valid1 = o.has_v1 ? base + o.v1 : nullptr;
+    d.valid2 = o.has_v2 ? base + o.v2 : nullptr;
+    d.ang1 = o.has_ang ? reinterpret_cast<const float *>(base + o.a1) : nullptr;
+    d.ang2 = o.has_ang ? reinterpret_cast<const float *>(base + o.a2) : nullptr;
+    d.ang_stride = 1;
+    d.th = j.th_low;
+    d.ratio = j.nnratio;
+    d.check_ori = tri ? 0 : (j.check_orientation != 0);
+    d.mode = tri ? AFV_MATCH_KF_KF : j.mode;
+    d.out = reinterpret_cast<int *>(base + o.out);
+    d.nmatches = reinterpret_cast<int *>(base + o.nm);
+}
+
+extern "C" int afv_match_bow(afv_ctx *c, const afv_match_job *jobs, int njobs, int32_t *out, int32_t *nmatches) {
+    if (!c || !jobs || njobs < 1 || !out || !nmatches) return AFV_EINVAL;
+    for (int i = 0; i < njobs; ++i) {
+        const int rc = validate_job(jobs[i], true);
+        if (rc) return rc;
+        if (jobs[i].mode != AFV_MATCH_KF_KF && jobs[i].mode != AFV_MATCH_KF_FRAME) return AFV_EINVAL;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    Blob b;
+    std::vector<JobOffsets> offs(njobs);
+    for (int i = 0; i < njobs; ++i) stage_job(b, jobs[i], false, offs[i]);
+    const size_t in_bytes = b.h.size();
+    size_t total_out = 0;
+    for (int i = 0; i < njobs; ++i) total_out += (size_t)offs[i].nout;
+    const size_t out_off = b.reserve(std::max<size_t>(total_out, 1) * 4);
+    const size_t nm_off = b.reserve((size_t)njobs * 4);
+    const size_t jobs_off = b.reserve((size_t)njobs * sizeof(DevMatchJob));
+    int rc = ensure_match_buffer(c, b.h.size());
+    if (rc) return rc;
+    size_t acc = 0;
+    for (int i = 0; i < njobs; ++i) {
+        offs[i].out = out_off + acc * 4;
+        offs[i].nm = nm_off + (size_t)i * 4;
+        acc += (size_t)offs[i].nout;
+        fill_dev_job(reinterpret_cast<DevMatchJob *>(b.h.data() + jobs_off)[i], jobs[i], offs[i], c->d_match, false);
+    }
+    (void)in_bytes;
+    HIPCHK(c, hipMemcpyAsync(c->d_match, b.h.data(), b.h.size(), hipMemcpyHostToDevice, c->stream));
+    afv_launch_match_bow(reinterpret_cast<const DevMatchJob *>(c->d_match + jobs_off), njobs, c->stream);
+    HIPCHK(c, hipGetLastError());
+    if (total_out) HIPCHK(c, hipMemcpyAsync(out, c->d_match + out_off, total_out * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(nmatches, c->d_match + nm_off, (size_t)njobs * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AFV_OK;
+}
+
+extern "C" int afv_match_triangulation(afv_ctx *c, const afv_tri_job *jobs, int njobs, int32_t *match12, int32_t *nmatches) {
+    if (!c || !jobs || njobs < 1 || !match12 || !nmatches) return AFV_EINVAL;
+    for (int i = 0; i < njobs; ++i) {
+        const int rc = validate_job(jobs[i].bow, false);
+        if (rc) return rc;
+        const afv_tri_job &t = jobs[i];
+        if ((t.bow.n1 > 0 && (!t.x1 || !t.y1)) || (t.bow.n2 > 0 && (!t.x2 || !t.y2 || !t.sigma2_2))) return AFV_EINVAL;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    Blob b;
+    std::vector<JobOffsets> offs(njobs);
+    std::vector<size_t> geo_off(njobs * 5);
+    for (int i = 0; i < njobs; ++i) {
+        stage_job(b, jobs[i].bow, true, offs[i]);
+        const afv_tri_job &t = jobs[i];
+        geo_off[5 * i + 0] = b.put(t.x1, (size_t)t.bow.n1 * 4);
+        geo_off[5 * i + 1] = b.put(t.y1, (size_t)t.bow.n1 * 4);
+        geo_off[5 * i + 2] = b.put(t.x2, (size_t)t.bow.n2 * 4);
+        geo_off[5 * i + 3] = b.put(t.y2, (size_t)t.bow.n2 * 4);
+        geo_off[5 * i + 4] = b.put(t.sigma2_2, (size_t)t.bow.n2 * 4);
+    }
+    size_t total_out = 0;
+    for (int i = 0; i < njobs; ++i) total_out += (size_t)jobs[i].bow.n1;
+    const size_t out_off = b.reserve(std::max<size_t>(total_out, 1) * 4);
+    const size_t nm_off = b.reserve((size_t)njobs * 4);
+    const size_t jobs_off = b.reserve((size_t)njobs * sizeof(DevTriJob));
+    int rc = ensure_match_buffer(c, b.h.size());
+    if (rc) return rc;
+    size_t acc = 0;
+    for (int i = 0; i < njobs; ++i) {
+        offs[i].out = out_off + acc * 4;
+        offs[i].nm = nm_off + (size_t)i * 4;
+        acc += (size_t)jobs[i].bow.n1;
+        DevTriJob &d = reinterpret_cast<DevTriJob *>(b.h.data() + jobs_off)[i];
+        fill_dev_job(d.m, jobs[i].bow, offs[i], c->d_match, true);
+        d.x1 = reinterpret_cast<const float *>(c->d_match + geo_off[5 * i + 0]);
+        d.y1 = reinterpret_cast<const float *>(c->d_match + geo_off[5 * i + 1]);
+        d.x2 = reinterpret_cast<const float *>(c->d_match + geo_off[5 * i + 2]);
+        d.y2 = reinterpret_cast<const float *>(c->d_match + geo_off[5 * i + 3]);
+        d.sigma2_2 = reinterpret_cast<const float *>(c->d_match + geo_off[5 * i + 4]);
+        std::memcpy(d.F, jobs[i].F12, sizeof(d.F));
+        d.ex = jobs[i].ex;
+        d.ey = jobs[i].ey;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_match, b.h.data(), b.h.size(), hipMemcpyHostToDevice, c->stream));
+    afv_launch_match_tri(reinterpret_cast<const DevTriJob *>(c->d_match + jobs_off), njobs, c->stream);
+    HIPCHK(c, hipGetLastError());
+    if (total_out) HIPCHK(c, hipMemcpyAsync(match12, c->d_match + out_off, total_out * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(nmatches, c->d_match + nm_off, (size_t)njobs * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AFV_OK;
+}
+
+extern "C" int afv_match_bruteforce_pairs_device(afv_ctx *c, const uint8_t *d_desc, const afv_keypoint *d_kps,
+                                                 const int32_t *d_n, int nsets, int cap, const int32_t *d_pair_a,
+                                                 const int32_t *d_pair_b, int npairs, float th_low, float nnratio,
+                                                 int check_orientation, int32_t *d_match, int32_t *d_nmatches, void *stream) {
+    if (!c || !d_desc || !d_n || !d_pair_a || !d_pair_b || !d_match || !d_nmatches) return AFV_EINVAL;
+    if (nsets < 1 || npairs < 1 || cap < 1 || cap > AFV_MAX_SIDE) return AFV_EINVAL;
+    if (check_orientation && !d_kps) return AFV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    afv_launch_match_pairs(d_desc, d_kps, d_n, cap, d_pair_a, d_pair_b, npairs, th_low, nnratio, check_orientation, d_match,
+                           d_nmatches, stream ? (hipStream_t)stream : c->stream);
+    HIPCHK(c, hipGetLastError());
+    return AFV_OK;
+}
+
+extern "C" int afv_match_l2(afv_ctx *c, const float *desc1, int n1, const float *desc2, int n2, int dim, const uint8_t *valid1,
+                            const uint8_t *valid2, float th_low, float nnratio, int32_t *match12, int32_t *nmatches) {
+    if (!c || !match12 || !nmatches || n1 < 0 || n2 < 0 || n1 > AFV_MAX_SIDE || n2 > AFV_MAX_SIDE || dim < 1 || dim > 1024)
+        return AFV_EINVAL;
+    if ((n1 > 0 && !desc1) || (n2 > 0 && !desc2)) return AFV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    Blob b;
+    const size_t o1 = b.put(desc1, (size_t)n1 * dim * 4), o2 = b.put(desc2, (size_t)n2 * dim * 4);
+    const size_t ov1 = valid1 ? b.put(valid1, (size_t)n1) : 0, ov2 = valid2 ? b.put(valid2, (size_t)n2) : 0;
+    const size_t oo = b.reserve((size_t)std::max(n1, 1) * 4), on = b.reserve(4);
+    const int rc = ensure_match_buffer(c, b.h.size());
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_match, b.h.data(), b.h.size(), hipMemcpyHostToDevice, c->stream));
+    afv_launch_match_l2(reinterpret_cast<const float *>(c->d_match + o1), n1, reinterpret_cast<const float *>(c->d_match + o2), n2,
+                        dim, valid1 ? c->d_match + ov1 : nullptr, valid2 ? c->d_match + ov2 : nullptr, th_low, nnratio,
+                        reinterpret_cast<int *>(c->d_match + oo), reinterpret_cast<int *>(c->d_match + on), c->stream);
+    HIPCHK(c, hipGetLastError());
+    if (n1) HIPCHK(c, hipMemcpyAsync(match12, c->d_match + oo, (size_t)n1 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(nmatches, c->d_match + on, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AFV_OK;
+}

@@ -1,0 +1,65 @@
+// afv_device.h — structures shared by the host runtime and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/afv_hip.h"
+
+#define AFV_WAVE 64
+
+// FAST / Harris tile: 64 x 32 output pixels per 256-thread workgroup, 4 px halo
+#define FT_W 64
+#define FT_H 32
+#define FT_HALO 4
+#define FT_LW (FT_W + 2 * FT_HALO)  // 72
+#define FT_LH (FT_H + 2 * FT_HALO)  // 40
+#define FT_MAXC 1024                 // candidates per tile after NMS: <= (64/2)*(32/2) = 512 (strict 3x3 maxima)
+
+// quadtree limits
+#define QT_MAX_NODES 1536  // alive nodes <= N+3 ; supports per-level quotas up to ~1500 (nfeatures <= ~6900)
+
+struct LevelGeo {
+    int w, h, pitch;        // level size, row pitch in bytes
+    int tiles_x, tiles_y;   // FAST tiling
+    int tile_base;          // first flat tile index of this level
+    int quota;              // mnFeaturesPerLevel (FeatureExtractor.cpp:97-108)
+    int cv_quota;           // cv::ORB nfeaturesPerLevel for nfeatures*10
+    int cand_cap;           // candidate slots per frame at this level
+    int sel_cap;            // quota + 3
+    int sel_base;           // first selected slot of this level inside a frame's `sel` row
+    float scale;            // (float)pow(1.2f, l)
+    float inv_scale;        // 1.f / scale
+    size_t pyr_off;         // byte offset of frame 0 of this level in the pyramid buffer (level 0: unused)
+    size_t pyr_frame_stride;
+    size_t cand_off;        // element offset of frame 0 of this level in the candidate arrays
+    size_t cand_frame_stride;
+};
+
+struct Geo {
+    int nlevels, width, height;
+    int total_tiles;
+    int sel_per_frame;      // sum of sel_cap
+    int n_ini;              // DistributeOctTree: round(w/h)
+    float h_x;              // (float)w / n_ini
+    int fast_threshold;
+    float harris_scale4;    // (1/(4*7*255))^4
+    LevelGeo lv[AFV_MAX_LEVELS];
+};
+
+// level-0 image comes straight from the caller's buffer
+struct FrameSrc {
+    const uint8_t *base;
+    int stride;
+    size_t frame_stride;
+};
+
+struct SelPoint {  // quadtree survivor, level coordinates
+    uint16_t x, y;
+    float response;
+};
+
+static inline __host__ __device__ int afv_reflect101(int p, int n) {
+    // BORDER_REFLECT_101 for |overshoot| < n (apron 23 px / patch halo <= 21 px, levels >= 32 px)
+    if (p < 0) p = -p;
+    if (p >= n) p = 2 * n - 2 - p;
+    return p;
+}

@@ -1,0 +1,296 @@
+// k_describe.hip — E6 + E9 + E10 + E11 fused: IC angle, 7x7 Gaussian blur and rotated BRIEF, one wavefront
+// per selected keypoint; plus the standalone level blur used by afv_debug_blur_level.
+//
+// Replaces ICAngles (cv::ORB::detect, Feature_orb32.cpp:34 == IC_Angle ORBextractor.cc:143-170), the
+// GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) of every pyramid level and computeOrbDescriptors inside each
+// cv::ORB::compute call (Feature_orb32.cpp:48; same arithmetic as computeOrbDescriptor FeatureExtractor.h:178-217),
+// and mergeKeypointLevels (FeatureExtractor.cpp:296-308).
+//
+// The reference blurs whole levels (36 level-blurs per frame because compute() is called once per level).  Only the
+// 37x37 neighbourhood of a keypoint is ever sampled, so each wavefront stages the 43x43 UNBLURRED patch around its
+// keypoint in LDS (reflect-101 at the image edge = cv::ORB's apron), computes the intensity-centroid moments from it,
+// blurs it separably in LDS with the integer taps [18,34,49,55,49,34,18] (row pass exact int, column pass
+// round-half-even(S/65536)) and evaluates the 256 rotated tests from LDS.  A test that falls outside the level ROI
+// reads the unblurred apron pixel, as in OpenCV where only the ROI is blurred in place.  No blurred image ever
+// touches HBM.
+#include "afv_device.h"
+
+__device__ __constant__ const signed char k_brief_pattern[1024] = {
+#include "brief_pattern.inc"
+};
+// umax[v], v = 0..15: last column of row v of the radius-15 disc (orb.cpp / ORBextractor.cc:124-139)
+__device__ __constant__ const signed char k_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+#define PR 21        // patch radius: 18 (BRIEF reach) + 3 (blur)
+#define PS 43        // patch side
+#define PP 48        // LDS pitch of the patch rows (dword staged)
+#define BS 37        // blurred side
+#define BP 40        // LDS pitch of the blurred rows
+#define KP_PER_BLOCK 4
+
+// cv::fastAtan2 (OpenCV mathfuncs_core atan_f32), degrees
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    const float rad2deg = (float)(180.0 / 3.1415926535897932384626433832795);
+    const float p1 = 0.9997878412794807f * rad2deg, p3 = -0.3258083974640975f * rad2deg;
+    const float p5 = 0.1555786518463281f * rad2deg, p7 = -0.04432655554792128f * rad2deg;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + 2.2204460492503131e-16f);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + 2.2204460492503131e-16f);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// cos/sin of angle_deg*(pi/180) (float product, as FeatureExtractor.h:181): explicit double algorithm (Cody-Waite by
+// pi/2 + Taylor), rounded once to float — bit-identical to the oracle's restatement, independent of any libm.
+__device__ __forceinline__ void sincos_deg(float angle_deg, float &c_out, float &s_out) {
+    const float factor_pi = (float)(3.1415926535897932384626433832795 / 180.f);
+    const double t = (double)(angle_deg * factor_pi);
+    const double kd = floor(t * 0.63661977236758138 + 0.5);
+    const int k = (int)kd;
+    const double r = (t - kd * 1.5707963267341256e+00) - kd * 6.0771005065061922e-11;
+    const double z = r * r;
+    const double sp = 1.0 + z * (-1.6666666666666666e-01 + z * (8.3333333333333332e-03 + z * (-1.9841269841269841e-04 +
+                      z * (2.7557319223985893e-06 + z * (-2.5052108385441720e-08 + z * (1.6059043836821613e-10 +
+                      z * (-7.6471637318198164e-13)))))));
+    const double s = r * sp;
+    const double c = 1.0 + z * (-0.5 + z * (4.1666666666666664e-02 + z * (-1.3888888888888889e-03 + z * (2.4801587301587302e-05 +
+                     z * (-2.7557319223985888e-07 + z * (2.0876756987868100e-09 + z * (-1.1470745597729725e-11 +
+                     z * (4.7794773323873853e-14))))))));
+    double co, si;
+    switch (k & 3) {
+    case 0: co = c; si = s; break;
+    case 1: co = -s; si = c; break;
+    case 2: co = -c; si = -s; break;
+    default: co = s; si = -c; break;
+    }
+    c_out = (float)co;
+    s_out = (float)si;
+}
+
+// LDS hand-off between lanes of ONE wavefront: DS operations of a wave execute in order, so only the compiler has
+// to be kept from moving the reads above the writes.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__device__ __forceinline__ uint8_t blur_round(int S) {
+    int q = S >> 16;
+    const int r = S & 0xffff;
+    q += (r > 32768) || (r == 32768 && (q & 1));
+    return (uint8_t)min(q, 255);
+}
+
+__global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__restrict__ geo_p, FrameSrc src0,
+                                                                const uint8_t *__restrict__ pyr,
+                                                                const SelPoint *__restrict__ sel,
+                                                                const int *__restrict__ sel_count,
+                                                                afv_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
+                                                                int cap_per_frame, int *__restrict__ n_out,
+                                                                int *__restrict__ status) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_patch[KP_PER_BLOCK][PS * PP];
+    __shared__ __attribute__((aligned(16))) uint16_t s_h[KP_PER_BLOCK][PS * BP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_blur[KP_PER_BLOCK][BS * BP];
+
+    const Geo &geo = *geo_p;
+    const int l = blockIdx.y, f = blockIdx.z;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * KP_PER_BLOCK + wv;
+    const int *sc = sel_count + f * AFV_MAX_LEVELS;
+    const LevelGeo &L = geo.lv[l];
+
+    // frame-level bookkeeping by one wave: total count, capacity status
+    int level_base = 0, total = 0;
+    for (int i = 0; i < geo.nlevels; ++i) {
+        const int c = sc[i];
+        if (i < l) level_base += c;
+        total += c;
+    }
+    if (blockIdx.x == 0 && l == 0 && threadIdx.x == 0) {
+        n_out[f] = min(total, cap_per_frame);
+        if (status && total > cap_per_frame) atomicMin(status, AFV_ECAPACITY);
+    }
+    if (idx >= sc[l]) return;  // wave-uniform
+    const int out_idx = level_base + idx;
+    if (out_idx >= cap_per_frame) return;
+
+    const SelPoint sp = sel[(size_t)f * geo.sel_per_frame + L.sel_base + idx];
+    const int cx = sp.x, cy = sp.y;
+    const int lw = L.w, lh = L.h;
+    const uint8_t *img;
+    int pitch;
+    if (l == 0) {
+        img = src0.base + (size_t)f * src0.frame_stride;
+        pitch = src0.stride;
+    } else {
+        img = pyr + L.pyr_off + (size_t)f * L.pyr_frame_stride;
+        pitch = L.pitch;
+    }
+    uint8_t *P = s_patch[wv];
+    uint16_t *H = s_h[wv];
+    uint8_t *B = s_blur[wv];
+
+    // ---- 1. stage the 43x43 unblurred patch; P[r][a + c] = level(cx-21+c, cy-21+r) with reflect-101 ----
+    const int px0 = cx - PR, py0 = cy - PR;
+    int a;  // column offset of patch column 0 inside the LDS row
+    if (px0 >= 0 && py0 >= 0 && px0 + PP <= lw && py0 + PS <= lh) {
+        // interior: 12 aligned dwords per row, 5 rows per wave instruction
+        a = px0 & 3;
+        const int ax0 = px0 - a;
+        const int rr = lane / 12, rq = lane - rr * 12;
+        if (lane < 60) {
+            for (int r = rr; r < PS; r += 5) {
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(img + (size_t)(py0 + r) * pitch + ax0 + rq * 4);
+                *reinterpret_cast<uint32_t *>(&P[r * PP + rq * 4]) = v;
+            }
+        }
+    } else {
+        a = 0;
+        for (int i = lane; i < PS * PS; i += 64) {
+            const int r = i / PS, c = i - r * PS;
+            const int y = afv_reflect101(py0 + r, lh), x = afv_reflect101(px0 + c, lw);
+            P[r * PP + c] = img[(size_t)y * pitch + x];
+        }
+    }
+    wave_sync();  // each wave owns its LDS slices: no workgroup barrier anywhere in this kernel
+
+    // ---- 2. intensity centroid over the radius-15 disc: lane = (row, half) ----
+    const uint8_t *C = &P[PR * PP + PR + a];  // patch centre
+    int m10 = 0, m01 = 0;
+    {
+        const int v = (lane >> 1) - 15;  // -15..16
+        if (v <= 15) {
+            const int av = v < 0 ? -v : v;
+            const int d = k_umax[av];
+            // half 0: u in [-d, -1], half 1: u in [0, d]
+            const int u0 = (lane & 1) ? 0 : -d, u1 = (lane & 1) ? d : -1;
+            const uint8_t *row = C + v * PP;
+            int su = 0, s1 = 0;
+            for (int u = u0; u <= u1; ++u) {
+                const int val = row[u];
+                su += u * val;
+                s1 += val;
+            }
+            m10 = su;
+            m01 = v * s1;
+        }
+    }
+    m10 = wave_sum(m10);
+    m01 = wave_sum(m01);
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    // ---- 3. separable blur of the patch: H = row pass (43 rows x 37 cols), B = column pass (37 x 37) ----
+    for (int i = lane; i < PS * BS; i += 64) {
+        const int r = i / BS, c = i - r * BS;
+        const uint8_t *p = &P[r * PP + c + a];
+        const int acc = 18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3];
+        H[r * BP + c] = (uint16_t)acc;
+    }
+    wave_sync();
+    for (int i = lane; i < BS * BS; i += 64) {
+        const int r = i / BS, c = i - r * BS;
+        const uint16_t *h = &H[r * BP + c];
+        const int S = 18 * ((int)h[0] + h[6 * BP]) + 34 * ((int)h[BP] + h[5 * BP]) + 49 * ((int)h[2 * BP] + h[4 * BP]) + 55 * (int)h[3 * BP];
+        B[r * BP + c] = blur_round(S);
+    }
+    wave_sync();
+
+    // ---- 4. rotated BRIEF: lane handles tests lane, lane+64, lane+128, lane+192 ----
+    float ca, sb;
+    sincos_deg(angle, ca, sb);
+    // BRIEF centre = cvRound(pt * (1/scale)) with pt = level coordinate * scale (orb.cpp computeOrbDescriptors)
+    const float ptx = (float)cx * L.scale, pty = (float)cy * L.scale;
+    const int bx = (int)rintf(ptx * L.inv_scale), by = (int)rintf(pty * L.inv_scale);
+    const int ox = bx - cx, oy = by - cy;  // 0 in practice; kept literal
+    uint32_t words[8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int t = g * 64 + lane;
+        const signed char *pt = &k_brief_pattern[t * 4];
+        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+        const int ix0 = (int)rintf(x0 * ca - y0 * sb) + ox, iy0 = (int)rintf(x0 * sb + y0 * ca) + oy;
+        const int ix1 = (int)rintf(x1 * ca - y1 * sb) + ox, iy1 = (int)rintf(x1 * sb + y1 * ca) + oy;
+        // inside the ROI -> blurred, outside -> unblurred apron
+        const int gx0 = cx + ix0, gy0 = cy + iy0, gx1 = cx + ix1, gy1 = cy + iy1;
+        const int t0 = (gx0 >= 0 && gx0 < lw && gy0 >= 0 && gy0 < lh) ? B[(iy0 + 18) * BP + ix0 + 18] : C[iy0 * PP + ix0];
+        const int t1 = (gx1 >= 0 && gx1 < lw && gy1 >= 0 && gy1 < lh) ? B[(iy1 + 18) * BP + ix1 + 18] : C[iy1 * PP + ix1];
+        const unsigned long long m = __ballot(t0 < t1);
+        words[2 * g] = (uint32_t)m;
+        words[2 * g + 1] = (uint32_t)(m >> 32);
+    }
+    // ---- 5. outputs (E11 merge: ascending level, list order inside a level) ----
+    const size_t o = (size_t)f * cap_per_frame + out_idx;
+    if (lane < 8) {
+        uint32_t w = words[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i)
+            if (lane == i) w = words[i];
+        reinterpret_cast<uint32_t *>(desc + o * 32)[lane] = w;
+    }
+    if (lane == 0) {
+        afv_keypoint k;
+        k.x = ptx;
+        k.y = pty;
+        k.size = 31 * L.scale;
+        k.angle = angle;
+        k.response = sp.response;
+        k.octave = l;
+        k.class_id = -1;
+        kps[o] = k;
+    }
+}
+
+extern "C" void afv_launch_describe(const Geo *geo_dev, int nlevels, int max_sel_cap, const FrameSrc *src0, const uint8_t *pyr,
+                                    const SelPoint *sel, const int *sel_count, afv_keypoint *kps, uint8_t *desc,
+                                    int cap_per_frame, int *n_out, int *status, int nframes, hipStream_t stream) {
+    dim3 grid((max_sel_cap + KP_PER_BLOCK - 1) / KP_PER_BLOCK, nlevels, nframes);
+    hipLaunchKernelGGL(k_describe, grid, dim3(64 * KP_PER_BLOCK), 0, stream, geo_dev, *src0, pyr, sel, sel_count, kps, desc,
+                       cap_per_frame, n_out, status);
+}
+
+// ---------------- standalone E9: blur one level of one frame (debug / parity of the blur arithmetic) ----------------
+__global__ __launch_bounds__(256) void k_blur_level(const uint8_t *__restrict__ img, int w, int h, int pitch,
+                                                    uint8_t *__restrict__ out) {
+    __shared__ uint8_t t[(16 + 6) * 72];
+    __shared__ uint16_t hh[(16 + 6) * 64];
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 16;
+    for (int i = threadIdx.x; i < 22 * 70; i += 256) {
+        const int r = i / 70, c = i - r * 70;
+        const int y = min(max(afv_reflect101(y0 + r - 3, h), 0), h - 1), x = min(max(afv_reflect101(x0 + c - 3, w), 0), w - 1);
+        t[r * 72 + c] = img[(size_t)y * pitch + x];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 22 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        const uint8_t *p = &t[r * 72 + c];
+        hh[r * 64 + c] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 16 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        const uint16_t *q = &hh[r * 64 + c];
+        const int S = 18 * ((int)q[0] + q[6 * 64]) + 34 * ((int)q[64] + q[5 * 64]) + 49 * ((int)q[2 * 64] + q[4 * 64]) + 55 * (int)q[3 * 64];
+        if (x0 + c < w && y0 + r < h) out[(size_t)(y0 + r) * w + x0 + c] = blur_round(S);
+    }
+}
+
+extern "C" void afv_launch_blur_level(const uint8_t *img, int w, int h, int pitch, uint8_t *out, hipStream_t stream) {
+    dim3 grid((w + 63) / 64, (h + 15) / 16);
+    hipLaunchKernelGGL(k_blur_level, grid, dim3(256), 0, stream, img, w, h, pitch, out);
+}

@@ -1,0 +1,367 @@
+// k_match.hip — M1..M6, M8: Hamming / L2 descriptor matchers.
+//
+// Replaces FeatureMatcher::SearchByBoW(KF,KF) (FeatureMatcher.cc:561-660), SearchByBoW(KF,Frame) (:186-283),
+// SearchForTriangulation (:662-790) with CheckDistEpipolarLine (:165-182), the rotation-histogram filter
+// (:1579-1668) and DescriptorDistance_orb32 / _sift128 (Feature_orb32.cpp:67-84, Feature_sift128.cpp:132-134).
+//
+// SearchByBoW is greedy: row idx1 may only take a column that no earlier row has taken (vbMatched2 / the
+// vpMapPointMatches test).  One 256-thread workgroup owns a job and walks the rows in the reference's order; for
+// each row the 256 lanes scan the node's columns in parallel (xor + v_bcnt per 32-bit word — the popcount
+// north_star asks for; distance of a 256-bit pair = 8 xor + 8 bcnt-accumulate), keep a packed (distance, position)
+// minimum and the second-best distance per lane, and merge them with wavefront shuffles + one LDS hop.  Lane 0 then
+// applies the float predicates exactly as written in the reference (strict/non-strict threshold, nnratio product).
+// SearchForTriangulation has no cross-row dependency: every wavefront takes its own rows.
+#include "afv_device.h"
+
+#define MT 256
+#define NO_KEY 0x7fffffff
+#define MAX_SIDE 8192  // features per side a job may hold (LDS bitset + bin table)
+
+struct Seg {
+    int s1, n1, s2, n2;  // ranges into idx1/idx2 (or identity when the idx pointer is null)
+};
+
+struct DevMatchJob {
+    const uint32_t *d1;
+    const uint32_t *d2;
+    int n1, n2, words;  // words per descriptor (8 for ORB32)
+    const Seg *segs;
+    int nseg;
+    const int *idx1;
+    const int *idx2;
+    const uint8_t *valid1;
+    const uint8_t *valid2;
+    const float *ang1;
+    const float *ang2;
+    int ang_stride;  // in floats (1 for plain arrays, 7 for afv_keypoint::angle)
+    float th, ratio;
+    int check_ori, mode;
+    int *out;
+    int *nmatches;
+};
+
+__device__ __forceinline__ int rotation_bin(float a1, float a2) {
+    // FeatureMatcher.cc:1587-1599, rotFactor = 1/30 (:1579-1585)
+    const float rot_factor = 1.0f / 30.0f;
+    float rot = a1 - a2;
+    if (rot < 0.0f) rot += 360.0f;
+    int bin = (int)roundf(rot * rot_factor);
+    if (bin == 30) bin = 0;
+    return bin;
+}
+
+// merge two (best key, second distance) summaries.  key = dist << 16 | position
+__device__ __forceinline__ void merge_best(int &k, int &s, int k2, int s2) {
+    if (k2 < k) {
+        s = min(s2, k >> 16);
+        k = k2;
+    } else {
+        s = min(s, k2 >> 16);
+    }
+}
+
+template <int W>
+__device__ __forceinline__ int hamming_words(const uint32_t *a_regs, const uint32_t *b) {
+    int d = 0;
+#pragma unroll
+    for (int i = 0; i < W; ++i) d += __popc(a_regs[i] ^ b[i]);
+    return d;
+}
+
+// core of M2 / M3 for one job, executed by a whole workgroup.  s_* are LDS scratch.
+template <int W>
+__device__ void match_bow_job(const DevMatchJob &J, uint32_t *s_matched, uint8_t *s_bin, int *s_red, int *s_hist) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool kf_frame = J.mode == AFV_MATCH_KF_FRAME;
+    const int nout = kf_frame ? J.n2 : J.n1;
+    for (int i = tid; i < nout; i += MT) J.out[i] = -1;
+    for (int i = tid; i < (J.n2 + 31) / 32; i += MT) s_matched[i] = 0;
+    if (tid < 32) s_hist[tid] = 0;
+    if (tid == 0) s_red[16] = 0;
+    __syncthreads();
+
+    for (int sg = 0; sg < J.nseg; ++sg) {
+        const Seg S = J.segs[sg];
+        for (int a = 0; a < S.n1; ++a) {
+            const int idx1 = J.idx1 ? J.idx1[S.s1 + a] : S.s1 + a;
+            if (J.valid1 && !J.valid1[idx1]) continue;  // uniform
+            uint32_t q[W];
+#pragma unroll
+            for (int i = 0; i < W; ++i) q[i] = J.d1[(size_t)idx1 * W + i];
+            int k = NO_KEY, s = NO_KEY >> 16;
+            for (int b = tid; b < S.n2; b += MT) {
+                const int idx2 = J.idx2 ? J.idx2[S.s2 + b] : S.s2 + b;
+                if ((s_matched[idx2 >> 5] >> (idx2 & 31)) & 1u) continue;
+                if (!kf_frame && J.valid2 && !J.valid2[idx2]) continue;
+                const int d = hamming_words<W>(q, J.d2 + (size_t)idx2 * W);
+                merge_best(k, s, (d << 16) | b, NO_KEY >> 16);
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                const int k2 = __shfl_xor(k, m, 64), s2 = __shfl_xor(s, m, 64);
+                merge_best(k, s, k2, s2);
+            }
+            if (lane == 0) {
+                s_red[wv * 2] = k;
+                s_red[wv * 2 + 1] = s;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int K = s_red[0], Sx = s_red[1];
+                for (int w = 1; w < MT / 64; ++w) merge_best(K, Sx, s_red[2 * w], s_red[2 * w + 1]);
+                if (K != NO_KEY) {
+                    const float best1 = (float)(K >> 16);
+                    const float best2 = (Sx == (NO_KEY >> 16)) ? 3.402823466e+38f : (float)Sx;
+                    const bool under = kf_frame ? (best1 <= J.th) : (best1 < J.th);  // FeatureMatcher.cc:250 / :630
+                    if (under && best1 < J.ratio * best2) {                            // :252 / :632
+                        const int b = K & 0xffff;
+                        const int idx2 = J.idx2 ? J.idx2[S.s2 + b] : S.s2 + b;
+                        const int key = kf_frame ? idx2 : idx1;
+                        J.out[key] = kf_frame ? idx1 : idx2;
+                        s_matched[idx2 >> 5] |= 1u << (idx2 & 31);
+                        s_red[16]++;
+                        if (J.check_ori) {
+                            const int bin = rotation_bin(J.ang1[(size_t)idx1 * J.ang_stride], J.ang2[(size_t)idx2 * J.ang_stride]);
+                            s_bin[key] = (uint8_t)bin;
+                            s_hist[bin]++;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // M6: keep only the three dominant rotation bins (computeThreeMaxima :1631-1668)
+    if (J.check_ori) {
+        if (tid == 0) {
+            int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+            for (int i = 0; i < 30; ++i) {
+                const int sz = s_hist[i];
+                if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; i3 = i2; i2 = i1; i1 = i; }
+                else if (sz > max2) { max3 = max2; max2 = sz; i3 = i2; i2 = i; }
+                else if (sz > max3) { max3 = sz; i3 = i; }
+            }
+            if ((float)max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+            else if ((float)max3 < 0.1f * (float)max1) { i3 = -1; }
+            s_red[8] = i1; s_red[9] = i2; s_red[10] = i3;
+        }
+        __syncthreads();
+        const int i1 = s_red[8], i2 = s_red[9], i3 = s_red[10];
+        int dropped = 0;
+        for (int i = tid; i < nout; i += MT) {
+            if (J.out[i] >= 0) {
+                const int b = s_bin[i];
+                if (b != i1 && b != i2 && b != i3) {
+                    J.out[i] = -1;
+                    ++dropped;
+                }
+            }
+        }
+        if (dropped) atomicSub(&s_red[16], dropped);
+        __syncthreads();
+    }
+    if (tid == 0) *J.nmatches = s_red[16];
+}
+
+__global__ __launch_bounds__(MT) void k_match_bow(const DevMatchJob *__restrict__ jobs) {
+    __shared__ uint32_t s_matched[MAX_SIDE / 32];
+    __shared__ uint8_t s_bin[MAX_SIDE];
+    __shared__ int s_red[32];
+    __shared__ int s_hist[32];
+    const DevMatchJob J = jobs[blockIdx.x];
+    if (J.words == 8) match_bow_job<8>(J, s_matched, s_bin, s_red, s_hist);
+    else match_bow_job<16>(J, s_matched, s_bin, s_red, s_hist);
+}
+
+// device-resident brute-force pairs over a descriptor table [nsets][cap][32]
+__global__ __launch_bounds__(MT) void k_match_pairs(const uint8_t *__restrict__ desc, const afv_keypoint *__restrict__ kps,
+                                                    const int *__restrict__ nset, int cap, const int *__restrict__ pair_a,
+                                                    const int *__restrict__ pair_b, float th, float ratio, int check_ori,
+                                                    int *__restrict__ match, int *__restrict__ nmatches) {
+    __shared__ uint32_t s_matched[MAX_SIDE / 32];
+    __shared__ uint8_t s_bin[MAX_SIDE];
+    __shared__ int s_red[32];
+    __shared__ int s_hist[32];
+    __shared__ Seg s_seg;
+    const int p = blockIdx.x;
+    const int a = pair_a[p], b = pair_b[p];
+    DevMatchJob J;
+    J.d1 = reinterpret_cast<const uint32_t *>(desc + (size_t)a * cap * 32);
+    J.d2 = reinterpret_cast<const uint32_t *>(desc + (size_t)b * cap * 32);
+    J.n1 = min(nset[a], cap);
+    J.n2 = min(nset[b], cap);
+    J.words = 8;
+    if (threadIdx.x == 0) s_seg = Seg{0, J.n1, 0, J.n2};
+    J.segs = &s_seg;
+    J.nseg = 1;
+    J.idx1 = J.idx2 = nullptr;
+    J.valid1 = J.valid2 = nullptr;
+    J.ang1 = kps ? &kps[(size_t)a * cap].angle : nullptr;
+    J.ang2 = kps ? &kps[(size_t)b * cap].angle : nullptr;
+    J.ang_stride = sizeof(afv_keypoint) / sizeof(float);
+    J.th = th;
+    J.ratio = ratio;
+    J.check_ori = check_ori && kps;
+    J.mode = AFV_MATCH_KF_KF;
+    J.out = match + (size_t)p * cap;
+    J.nmatches = nmatches + p;
+    for (int i = J.n1 + threadIdx.x; i < cap; i += MT) J.out[i] = -1;
+    __syncthreads();
+    match_bow_job<8>(J, s_matched, s_bin, s_red, s_hist);
+}
+
+// ---------------- M4: SearchForTriangulation ----------------
+struct DevTriJob {
+    DevMatchJob m;  // valid1/valid2 = "has a map point" => skip
+    const float *x1, *y1, *x2, *y2, *sigma2_2;
+    float F[9];
+    float ex, ey;
+};
+
+template <int W>
+__device__ void tri_job(const DevTriJob &T, int *s_count) {
+    const DevMatchJob &J = T.m;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < J.n1; i += MT) J.out[i] = -1;
+    if (tid == 0) *s_count = 0;
+    __syncthreads();
+    int found = 0;
+    for (int sg = 0; sg < J.nseg; ++sg) {
+        const Seg S = J.segs[sg];
+        for (int a = wv; a < S.n1; a += MT / 64) {
+            const int idx1 = J.idx1 ? J.idx1[S.s1 + a] : S.s1 + a;
+            if (J.valid1 && J.valid1[idx1]) continue;  // already has a MapPoint (:699-703)
+            uint32_t q[W];
+#pragma unroll
+            for (int i = 0; i < W; ++i) q[i] = J.d1[(size_t)idx1 * W + i];
+            const float kx = T.x1[idx1], ky = T.y1[idx1];
+            // epipolar line in image 2: l = x1' F12 (:168-170)
+            const float la = kx * T.F[0] + ky * T.F[3] + T.F[6];
+            const float lb = kx * T.F[1] + ky * T.F[4] + T.F[7];
+            const float lc = kx * T.F[2] + ky * T.F[5] + T.F[8];
+            const float den = la * la + lb * lb;
+            int k = NO_KEY;  // dist << 16 | (0xffff - position): equal distances -> LAST position wins (:736)
+            for (int b = lane; b < S.n2; b += 64) {
+                const int idx2 = J.idx2 ? J.idx2[S.s2 + b] : S.s2 + b;
+                if (J.valid2 && J.valid2[idx2]) continue;
+                const int d = hamming_words<W>(q, J.d2 + (size_t)idx2 * W);
+                if ((float)d > J.th) continue;
+                const float x2 = T.x2[idx2], y2 = T.y2[idx2], sg2 = T.sigma2_2[idx2];
+                const float dex = T.ex - x2, dey = T.ey - y2;
+                if (dex * dex + dey * dey < 100.0f * sqrtf(sg2)) continue;  // too close to the epipole (:741-748)
+                const float num = la * x2 + lb * y2 + lc;
+                if (den == 0) continue;
+                const float dsqr = num * num / den;
+                if (!(dsqr < 3.84f * sg2)) continue;  // CheckDistEpipolarLine (:172-181)
+                k = min(k, (d << 16) | (0xffff - b));
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) k = min(k, __shfl_xor(k, m, 64));
+            if (lane == 0 && k != NO_KEY) {
+                const int b = 0xffff - (k & 0xffff);
+                J.out[idx1] = J.idx2 ? J.idx2[S.s2 + b] : S.s2 + b;
+                ++found;
+            }
+        }
+    }
+    if (lane == 0 && found) atomicAdd(s_count, found);
+    __syncthreads();
+    if (tid == 0) *J.nmatches = *s_count;
+}
+
+__global__ __launch_bounds__(MT) void k_match_tri(const DevTriJob *__restrict__ jobs) {
+    __shared__ int s_count;
+    const DevTriJob T = jobs[blockIdx.x];
+    if (T.m.words == 8) tri_job<8>(T, &s_count);
+    else tri_job<16>(T, &s_count);
+}
+
+// ---------------- M8: float descriptors, L2^2 (cv::norm NORM_L2SQR semantics) ----------------
+__device__ __forceinline__ float l2sqr(const float *a, const float *b, int n) {
+    // normL2Sqr<float,double>: float differences, double squares, 4-way partial sums
+    double s = 0;
+    int i = 0;
+    for (; i <= n - 4; i += 4) {
+        const double v0 = (double)(a[i] - b[i]), v1 = (double)(a[i + 1] - b[i + 1]), v2 = (double)(a[i + 2] - b[i + 2]),
+                     v3 = (double)(a[i + 3] - b[i + 3]);
+        s += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
+    }
+    for (; i < n; ++i) {
+        const double v = (double)(a[i] - b[i]);
+        s += v * v;
+    }
+    return (float)s;
+}
+
+__device__ __forceinline__ void merge_best_f(float &d, int &p, float &s, float d2, int p2, float s2) {
+    if (d2 < d || (d2 == d && p2 < p)) {
+        s = fminf(s2, d);
+        d = d2;
+        p = p2;
+    } else {
+        s = fminf(s, d2);
+    }
+}
+
+__global__ __launch_bounds__(MT) void k_match_l2(const float *__restrict__ d1, int n1, const float *__restrict__ d2, int n2,
+                                                 int dim, const uint8_t *__restrict__ valid1,
+                                                 const uint8_t *__restrict__ valid2, float th, float ratio,
+                                                 int *__restrict__ out, int *__restrict__ nmatches) {
+    __shared__ uint32_t s_matched[MAX_SIDE / 32];
+    __shared__ float s_d[4], s_s[4];
+    __shared__ int s_p[4], s_n;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float FMAX = 3.402823466e+38f;
+    for (int i = tid; i < (n2 + 31) / 32; i += MT) s_matched[i] = 0;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    for (int i = 0; i < n1; ++i) {
+        if (tid == 0) out[i] = -1;
+        if (valid1 && !valid1[i]) continue;
+        float bd = FMAX, bs = FMAX;
+        int bp = 0x7fffffff;
+        for (int k = tid; k < n2; k += MT) {
+            if ((s_matched[k >> 5] >> (k & 31)) & 1u) continue;
+            if (valid2 && !valid2[k]) continue;
+            const float d = l2sqr(d1 + (size_t)i * dim, d2 + (size_t)k * dim, dim);
+            merge_best_f(bd, bp, bs, d, k, FMAX);
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const float d2_ = __shfl_xor(bd, m, 64), s2_ = __shfl_xor(bs, m, 64);
+            const int p2_ = __shfl_xor(bp, m, 64);
+            merge_best_f(bd, bp, bs, d2_, p2_, s2_);
+        }
+        if (lane == 0) { s_d[wv] = bd; s_p[wv] = bp; s_s[wv] = bs; }
+        __syncthreads();
+        if (tid == 0) {
+            float D = s_d[0], Sx = s_s[0];
+            int P = s_p[0];
+            for (int w = 1; w < 4; ++w) merge_best_f(D, P, Sx, s_d[w], s_p[w], s_s[w]);
+            if (P != 0x7fffffff && D < th && D < ratio * Sx) {
+                out[i] = P;
+                s_matched[P >> 5] |= 1u << (P & 31);
+                s_n++;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *nmatches = s_n;
+}
+
+extern "C" void afv_launch_match_bow(const DevMatchJob *jobs, int njobs, hipStream_t stream) {
+    hipLaunchKernelGGL(k_match_bow, dim3(njobs), dim3(MT), 0, stream, jobs);
+}
+extern "C" void afv_launch_match_pairs(const uint8_t *desc, const afv_keypoint *kps, const int *nset, int cap, const int *pa,
+                                       const int *pb, int npairs, float th, float ratio, int check_ori, int *match,
+                                       int *nmatches, hipStream_t stream) {
+    hipLaunchKernelGGL(k_match_pairs, dim3(npairs), dim3(MT), 0, stream, desc, kps, nset, cap, pa, pb, th, ratio, check_ori,
+                       match, nmatches);
+}
+extern "C" void afv_launch_match_tri(const DevTriJob *jobs, int njobs, hipStream_t stream) {
+    hipLaunchKernelGGL(k_match_tri, dim3(njobs), dim3(MT), 0, stream, jobs);
+}
+extern "C" void afv_launch_match_l2(const float *d1, int n1, const float *d2, int n2, int dim, const uint8_t *v1,
+                                    const uint8_t *v2, float th, float ratio, int *out, int *nmatches, hipStream_t stream) {
+    hipLaunchKernelGGL(k_match_l2, dim3(1), dim3(MT), 0, stream, d1, n1, d2, n2, dim, v1, v2, th, ratio, out, nmatches);
+}

@@ -1,0 +1,448 @@
+// k_select.hip — E4 + E7: retainBest x2 and DistributeOctTree, one workgroup per (frame, level).
+//
+// Replaces KeyPointsFilter::retainBest(2*quota) on the FAST score and retainBest(quota) on the Harris response
+// (inside cv::ORB::detect, Feature_orb32.cpp:34) and FeatureExtractor::DistributeOctTree
+// (ORBextractor.cc:239-458, called through filterKeypoints_notScaled FeatureExtractor.cpp:276-284).
+//
+// Everything here is a SET operation plus a deterministic sequential algorithm, re-expressed so that 256 lanes can
+// run it in lock step:
+//   * retainBest = "keep everything >= the k-th largest key": k-th largest by histogram (8-bit FAST score) and by a
+//     3-pass 11/11/10-bit radix select on the order-preserving integer image of the float response.
+//   * DistributeOctTree is a level-synchronous quadtree build.  std::list order is fully determined by creation
+//     order (children are always push_front'ed, nodes never move), so the list is kept as a dense array in list
+//     order and every round recomputes it with prefix sums:
+//       phase A (ORBextractor.cc:292-367): every node with >1 point splits; new list = children of the split nodes
+//         in reverse processing order (n4,n3,n2,n1 each), then the untouched nodes in their old order;
+//       phase B (:370-431): nodes created in the previous round are processed largest-first (ties: later-created
+//         first == smaller list index) until the node count reaches N; the stop point is found with a prefix sum
+//         over the rank-ordered size deltas.
+//     Termination tests (:366-369, :427-430) are evaluated on the same quantities as the reference.
+//   * the survivor of each node is the max-response point, ties -> smallest raster index (== "first max wins" on
+//     raster-ordered input, :446-453), found with one 64-bit LDS atomic max per point.
+#include "afv_device.h"
+
+#define ST 256  // threads per workgroup
+
+struct Rect16 {
+    short x0, y0, x1, y1;
+};
+
+__device__ __forceinline__ uint32_t float_key(float r) {
+    const uint32_t u = __float_as_uint(r);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(uint32_t k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// ---- block-wide helpers (256 threads = 4 waves) ----
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// exclusive prefix sum of arr[0..n) in place; returns the total.  n <= ST * 16.  `tmp` = 8 ints of LDS.
+__device__ int block_excl_scan(int *arr, int n, int *tmp) {
+    const int per = (n + ST - 1) / ST;
+    const int b = threadIdx.x * per, e = min(b + per, n);
+    int local = 0;
+    for (int i = b; i < e; ++i) local += arr[i];
+    const int incl = wave_incl_scan(local);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) tmp[w] = incl;
+    __syncthreads();
+    int base = incl - local;
+    for (int k = 0; k < w; ++k) base += tmp[k];
+    const int total = tmp[0] + tmp[1] + tmp[2] + tmp[3];
+    for (int i = b; i < e; ++i) {
+        const int v = arr[i];
+        arr[i] = base;
+        base += v;
+    }
+    __syncthreads();
+    return total;
+}
+
+// k-th largest over a histogram hist[0..nbins): returns the bin b such that sum(hist[b+1..]) < k <= sum(hist[b..]),
+// and *above = sum(hist[b+1..]).  hist is destroyed.  Requires sum(hist) >= k >= 1.
+__device__ int block_kth_from_top(int *hist, int nbins, int k, int *above, int *tmp) {
+    // suffix sums via a prefix scan of the reversed index space
+    const int per = (nbins + ST - 1) / ST;
+    const int b = threadIdx.x * per, e = min(b + per, nbins);
+    int local = 0;
+    for (int i = b; i < e; ++i) local += hist[nbins - 1 - i];
+    const int incl = wave_incl_scan(local);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) tmp[w] = incl;
+    if (threadIdx.x == 0) tmp[4] = -1;
+    __syncthreads();
+    int base = incl - local;
+    for (int q = 0; q < w; ++q) base += tmp[q];
+    // this thread's chunk (in reversed order) covers cumulative counts (base, base+local]
+    if (base < k && k <= base + local) {
+        int cum = base;
+        for (int i = b; i < e; ++i) {
+            const int h = hist[nbins - 1 - i];
+            if (cum < k && k <= cum + h) {
+                tmp[4] = nbins - 1 - i;
+                tmp[5] = cum;
+            }
+            cum += h;
+        }
+    }
+    __syncthreads();
+    const int bin = tmp[4];
+    *above = tmp[5];
+    __syncthreads();
+    return bin;
+}
+
+__device__ __forceinline__ int point_quadrant(uint32_t xy, float scale, const Rect16 r) {
+    // ExtractorNode::DivideNode (ORBextractor.cc:181-224): halfX = ceil((UR.x-UL.x)/2), float compares
+    const float px = (float)(xy & 4095u) * scale, py = (float)(xy >> 12) * scale;
+    const int hx = (r.x1 - r.x0 + 1) >> 1, hy = (r.y1 - r.y0 + 1) >> 1;
+    const float mx = (float)(r.x0 + hx), my = (float)(r.y0 + hy);
+    // n1: x<mx,y<my   n2: x>=mx,y<my   n3: x<mx,y>=my   n4: x>=mx,y>=my
+    return (px < mx ? 0 : 1) + (py < my ? 0 : 2);
+}
+
+__device__ __forceinline__ Rect16 child_rect(const Rect16 r, int q) {
+    const int hx = (r.x1 - r.x0 + 1) >> 1, hy = (r.y1 - r.y0 + 1) >> 1;
+    Rect16 c;
+    c.x0 = (q & 1) ? (short)(r.x0 + hx) : r.x0;
+    c.x1 = (q & 1) ? r.x1 : (short)(r.x0 + hx);
+    c.y0 = (q & 2) ? (short)(r.y0 + hy) : r.y0;
+    c.y1 = (q & 2) ? r.y1 : (short)(r.y0 + hy);
+    return c;
+}
+
+// dynamic LDS layout, M = max nodes (multiple of 64):
+//   int   hist[2048]            (also scratch for scans)
+//   Rect16 rect[2][M]; int cnt[2][M]; int child[M*4]; uint16 remap[M*4]; int aux[M]; int aux2[M];
+//   unsigned long long best[M]; int tmp[16]
+__global__ __launch_bounds__(ST) void k_select_quadtree(const Geo *__restrict__ geo_p, const uint32_t *__restrict__ cand_packed,
+                                                       const float *__restrict__ cand_resp,
+                                                       const int *__restrict__ cand_count, uint32_t *__restrict__ kept_xy,
+                                                       float *__restrict__ kept_resp, uint16_t *__restrict__ kept_node,
+                                                       SelPoint *__restrict__ sel, int *__restrict__ sel_count, int M) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *hist = reinterpret_cast<int *>(smem);
+    unsigned long long *best = reinterpret_cast<unsigned long long *>(hist + 2048);
+    Rect16 *rect0 = reinterpret_cast<Rect16 *>(best + M);
+    Rect16 *rect1 = rect0 + M;
+    int *cnt0 = reinterpret_cast<int *>(rect1 + M);
+    int *cnt1 = cnt0 + M;
+    int *child = cnt1 + M;
+    int *aux = child + 4 * M;
+    int *aux2 = aux + M;
+    int *tmp = aux2 + M;
+    uint16_t *remap = reinterpret_cast<uint16_t *>(tmp + 16);
+
+    const Geo &geo = *geo_p;
+    const int l = blockIdx.x, f = blockIdx.y;
+    const LevelGeo &L = geo.lv[l];
+    const size_t base = L.cand_off + (size_t)f * L.cand_frame_stride;
+    const uint32_t *cp = cand_packed + base;
+    const float *cr = cand_resp + base;
+    uint32_t *kxy = kept_xy + base;
+    float *kr = kept_resp + base;
+    uint16_t *kn = kept_node + base;
+    const int n = min(cand_count[f * AFV_MAX_LEVELS + l], L.cand_cap);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const float scale = L.scale;
+    const int N = L.quota;
+
+    // ---------------- E4a: threshold on the FAST score ----------------
+    int T1 = 0;
+    if (n > 2 * L.cv_quota) {  // uniform branch
+        for (int i = tid; i < 256; i += ST) hist[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += ST) atomicAdd(&hist[cp[i] >> 24], 1);
+        __syncthreads();
+        int above;
+        T1 = block_kth_from_top(hist, 256, 2 * L.cv_quota, &above, tmp);
+    }
+    // ---------------- E4b: threshold on the Harris response among the survivors ----------------
+    if (tid == 0) tmp[8] = 0;
+    __syncthreads();
+    {
+        int c = 0;
+        for (int i = tid; i < n; i += ST) c += ((int)(cp[i] >> 24) >= T1);
+        c = wave_incl_scan(c);
+        if (lane == 63) atomicAdd(&tmp[8], c);
+    }
+    __syncthreads();
+    const int n1 = tmp[8];
+    __syncthreads();
+    uint32_t T2 = 0;
+    if (n1 > L.cv_quota) {  // uniform
+        int k = L.cv_quota;
+        uint32_t prefix = 0, mask = 0;
+        const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+        for (int p = 0; p < 3; ++p) {
+            const int nb = 1 << bits[p];
+            for (int i = tid; i < nb; i += ST) hist[i] = 0;
+            __syncthreads();
+            for (int i = tid; i < n; i += ST) {
+                if ((int)(cp[i] >> 24) < T1) continue;
+                const uint32_t key = float_key(cr[i]);
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shifts[p]) & (nb - 1)], 1);
+            }
+            __syncthreads();
+            int above;
+            const int bin = block_kth_from_top(hist, nb, k, &above, tmp);
+            k -= above;
+            prefix |= (uint32_t)bin << shifts[p];
+            mask |= (uint32_t)(nb - 1) << shifts[p];
+        }
+        T2 = prefix;
+    }
+
+    // ---------------- compaction of the survivors + root assignment ----------------
+    const int n_ini = geo.n_ini;
+    if (tid < 16) aux[tid] = 0;  // points per root
+    if (tid == 0) tmp[8] = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += ST) {
+        const int i = i0 + tid;
+        bool keep = false;
+        uint32_t e = 0;
+        float r = 0.f;
+        if (i < n) {
+            e = cp[i];
+            r = cr[i];
+            keep = ((int)(e >> 24) >= T1) && (float_key(r) >= T2);
+        }
+        const unsigned long long m = __ballot(keep);
+        int wbase = 0;
+        if (lane == 0 && m) wbase = atomicAdd(&tmp[8], __popcll(m));
+        wbase = __shfl(wbase, 0, 64);
+        if (keep) {
+            const int slot = wbase + __popcll(m & ((1ull << lane) - 1ull));
+            const uint32_t xy = e & 0x00ffffffu;
+            kxy[slot] = xy;
+            kr[slot] = r;
+            int root = 0;
+            if (n_ini > 1) {
+                root = (int)(((float)(xy & 4095u) * scale) / geo.h_x);  // vpIniNodes[kp.pt.x/hX]
+                root = min(root, n_ini - 1);
+                atomicAdd(&aux[root], 1);
+            }
+            kn[slot] = (uint16_t)root;
+        }
+    }
+    __syncthreads();
+    const int m2 = tmp[8];
+    __threadfence_block();
+
+    // initial list (ORBextractor.cc:243-283): non-empty roots in order
+    if (tid == 0) {
+        int sz = 0;
+        for (int i = 0; i < n_ini; ++i) {
+            const int c = (n_ini > 1) ? aux[i] : m2;
+            if (c > 0) {
+                Rect16 r;
+                r.x0 = (short)(int)(geo.h_x * (float)i);
+                r.x1 = (short)(int)(geo.h_x * (float)(i + 1));
+                r.y0 = 0;
+                r.y1 = (short)geo.height;
+                rect0[sz] = r;
+                cnt0[sz] = c;
+                aux2[i] = sz;
+                ++sz;
+            } else {
+                aux2[i] = 0;
+            }
+        }
+        tmp[9] = sz;
+    }
+    __syncthreads();
+    if (n_ini > 1) {
+        for (int p = tid; p < m2; p += ST) kn[p] = (uint16_t)aux2[kn[p]];
+    }
+    int size = tmp[9];
+    __syncthreads();
+
+    Rect16 *rc = rect0, *rn = rect1;
+    int *cc = cnt0, *cn = cnt1;
+    bool finish = (m2 == 0);
+    bool phase_b = false;
+
+    while (!finish) {
+        const int prev_size = size;
+        // 1. child occupancy of every node that may split this round
+        for (int i = tid; i < size * 4; i += ST) child[i] = 0;
+        __syncthreads();
+        for (int p = tid; p < m2; p += ST) {
+            const int nd = kn[p];
+            if (cc[nd] > 1) atomicAdd(&child[nd * 4 + point_quadrant(kxy[p], scale, rc[nd])], 1);
+        }
+        __syncthreads();
+        // 2. processing order.  aux[key] = number of non-empty children of the node processed key-th (0 if that
+        //    node does not split); aux2[i] = key of node i or -1.
+        int nproc;  // number of processing slots
+        if (!phase_b) {
+            for (int i = tid; i < size; i += ST) {
+                int ne = 0;
+                if (cc[i] > 1) ne = (child[4 * i] > 0) + (child[4 * i + 1] > 0) + (child[4 * i + 2] > 0) + (child[4 * i + 3] > 0);
+                aux[i] = ne;
+                aux2[i] = (cc[i] > 1) ? i : -1;
+            }
+            nproc = size;
+            __syncthreads();
+        } else {
+            // rank among expandable nodes by (count desc, list index asc) == sort ascending by (size, pointer) walked
+            // from the back (ORBextractor.cc:381-382) with pointer ties resolved by creation order
+            if (tid == 0) tmp[10] = 0;
+            for (int i = tid; i < size; i += ST) aux[i] = 0;
+            __syncthreads();
+            int ecount = 0;
+            for (int i = tid; i < size; i += ST) {
+                int key = -1;
+                const int ci = cc[i];
+                if (ci > 1) {
+                    int r = 0;
+                    for (int j = 0; j < size; ++j) {
+                        const int cj = cc[j];
+                        r += (cj > 1) && (cj > ci || (cj == ci && j < i));
+                    }
+                    key = r;
+                    ++ecount;
+                }
+                aux2[i] = key;
+            }
+            ecount = wave_incl_scan(ecount);
+            if (lane == 63) atomicAdd(&tmp[10], ecount);
+            __syncthreads();
+            const int E = tmp[10];
+            // deltas in rank order -> inclusive prefix -> first rank at which size + prefix >= N
+            for (int i = tid; i < size; i += ST) {
+                const int key = aux2[i];
+                if (key >= 0) {
+                    const int ne = (child[4 * i] > 0) + (child[4 * i + 1] > 0) + (child[4 * i + 2] > 0) + (child[4 * i + 3] > 0);
+                    aux[key] = ne - 1;
+                }
+            }
+            __syncthreads();
+            block_excl_scan(aux, E, tmp);  // aux[r] = sum of deltas of ranks < r  (deltas >= 0: monotone)
+            if (tid == 0) tmp[11] = E - 1;
+            __syncthreads();
+            // stop rank r*: smallest r whose split lifts the node count to >= N (ORBextractor.cc:424-425); the
+            // count after rank r is prev_size + aux[r+1]; if no rank reaches N every node is processed
+            for (int r = tid; r + 1 < E; r += ST)
+                if (prev_size + aux[r + 1] >= N) atomicMin(&tmp[11], r);
+            __syncthreads();
+            const int rstar = tmp[11];
+            // rebuild aux as "non-empty children by processing slot", dropping ranks > r*
+            __syncthreads();
+            for (int i = tid; i < E; i += ST) aux[i] = 0;
+            __syncthreads();
+            for (int i = tid; i < size; i += ST) {
+                int key = aux2[i];
+                if (key > rstar) key = -1;
+                aux2[i] = key;
+                if (key >= 0)
+                    aux[key] = (child[4 * i] > 0) + (child[4 * i + 1] > 0) + (child[4 * i + 2] > 0) + (child[4 * i + 3] > 0);
+            }
+            nproc = rstar + 1;
+            __syncthreads();
+        }
+        // 3. suffix sums over the processing order: children of later-processed nodes come first in the new list
+        const int total_children = block_excl_scan(aux, nproc, tmp);  // aux[key] = children of keys < key
+        // child (node i, quadrant q) -> position (total - aux[key] - ne(i)) + #non-empty children with quadrant > q
+        // untouched node i -> total_children + rank among untouched nodes
+        for (int i = tid; i < size; i += ST) hist[i] = (aux2[i] < 0) ? 1 : 0;
+        __syncthreads();
+        const int untouched = block_excl_scan(hist, size, tmp);
+        const int new_size = total_children + untouched;
+        int n_expand_local = 0;
+        for (int i = tid; i < size; i += ST) {
+            const int key = aux2[i];
+            if (key < 0) {
+                const int pos = total_children + hist[i];
+                rn[pos] = rc[i];
+                cn[pos] = cc[i];
+                remap[4 * i] = (uint16_t)pos;
+            } else {
+                const int c0 = child[4 * i], c1 = child[4 * i + 1], c2 = child[4 * i + 2], c3 = child[4 * i + 3];
+                const int ne = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
+                int pos = total_children - aux[key] - ne;  // first slot of this node's children (n4 first)
+                const Rect16 r = rc[i];
+                const int cs[4] = {c0, c1, c2, c3};
+#pragma unroll
+                for (int q = 3; q >= 0; --q) {
+                    if (cs[q] > 0) {
+                        rn[pos] = child_rect(r, q);
+                        cn[pos] = cs[q];
+                        remap[4 * i + q] = (uint16_t)pos;
+                        n_expand_local += (cs[q] > 1);
+                        ++pos;
+                    }
+                }
+            }
+        }
+        n_expand_local = wave_incl_scan(n_expand_local);
+        if (tid == 0) tmp[12] = 0;
+        __syncthreads();
+        if (lane == 63) atomicAdd(&tmp[12], n_expand_local);
+        // 4. relabel the points
+        for (int p = tid; p < m2; p += ST) {
+            const int nd = kn[p];
+            const int q = (aux2[nd] >= 0) ? point_quadrant(kxy[p], scale, rc[nd]) : 0;
+            kn[p] = remap[4 * nd + q];
+        }
+        __syncthreads();
+        const int n_expand = tmp[12];
+        size = new_size;
+        {
+            Rect16 *t = rc; rc = rn; rn = t;
+            int *u = cc; cc = cn; cn = u;
+        }
+        // 5. termination (ORBextractor.cc:366-370, :427-430)
+        if (size >= N || size == prev_size) finish = true;
+        else if (!phase_b && size + n_expand * 3 > N) phase_b = true;
+        __syncthreads();
+    }
+
+    // ---------------- survivor of each node ----------------
+    for (int i = tid; i < size; i += ST) best[i] = 0ull;
+    __syncthreads();
+    const int lw = L.w;
+    for (int p = tid; p < m2; p += ST) {
+        const uint32_t xy = kxy[p];
+        const uint32_t raster = (xy >> 12) * (uint32_t)lw + (xy & 4095u);
+        const unsigned long long key = ((unsigned long long)float_key(kr[p]) << 32) | (unsigned long long)(0xffffffffu - raster);
+        atomicMax(&best[kn[p]], key);
+    }
+    __syncthreads();
+    SelPoint *out = sel + (size_t)f * geo.sel_per_frame + L.sel_base;
+    const int nout = min(size, L.sel_cap);
+    for (int i = tid; i < nout; i += ST) {
+        const unsigned long long key = best[i];
+        const uint32_t raster = 0xffffffffu - (uint32_t)(key & 0xffffffffu);
+        SelPoint s;
+        s.y = (uint16_t)(raster / (uint32_t)lw);
+        s.x = (uint16_t)(raster - (uint32_t)s.y * (uint32_t)lw);
+        s.response = key_float((uint32_t)(key >> 32));
+        out[i] = s;
+    }
+    if (tid == 0) sel_count[f * AFV_MAX_LEVELS + l] = nout;
+}
+
+extern "C" size_t afv_select_lds_bytes(int M) {
+    return (size_t)2048 * 4 + (size_t)M * 8 /*best*/ + (size_t)M * 8 * 2 /*rect*/ + (size_t)M * 4 * 2 /*cnt*/ +
+           (size_t)M * 16 /*child*/ + (size_t)M * 4 * 2 /*aux*/ + 64 /*tmp*/ + (size_t)M * 8 /*remap*/;
+}
+
+extern "C" void afv_launch_select(const Geo *geo_dev, int nlevels, const uint32_t *cand_packed, const float *cand_resp,
+                                  const int *cand_count, uint32_t *kept_xy, float *kept_resp, uint16_t *kept_node,
+                                  SelPoint *sel, int *sel_count, int M, int nframes, hipStream_t stream) {
+    dim3 grid(nlevels, nframes);
+    hipLaunchKernelGGL(k_select_quadtree, grid, dim3(ST), afv_select_lds_bytes(M), stream, geo_dev, cand_packed, cand_resp,
+                       cand_count, kept_xy, kept_resp, kept_node, sel, sel_count, M);
+}

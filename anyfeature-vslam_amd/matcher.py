@@ -1,0 +1,184 @@
+"""Host-side mirror of the reference's FeatureMatcher (include/FeatureMatcher.h:36-118, src/FeatureMatcher.cc).
+
+The reference walks KeyFrame / Frame / MapPoint objects; a drop-in flattens them (under their mutexes) into the
+arrays below — that is what `FeatureView` holds — and calls the C-ABI.  Method names, thresholds and return values
+follow the reference: SearchByBoW(KF,KF) -> (vpMatches12, nmatches), SearchByBoW(KF,F) -> (vpMapPointMatches, n),
+SearchForTriangulation -> (vMatchedPairs, n).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import MatchJob, TriJob, ptr
+
+
+def DescriptorDistance_orb32(a, b):
+    """Feature_orb32.cpp:67-84 (host utility; the kernels use xor + v_bcnt on the GPU)."""
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return float(_lib.load().afv_hamming256(ptr(a), ptr(b)))
+
+
+class FeatureView:
+    """Flattened view of one KeyFrame / Frame for matching.
+
+    descriptors  N x desc_bytes uint8           (KeyFrame::mDescriptors, const after construction KeyFrame.h:190)
+    featvec      None (brute force) or list of (node_id, [feature indices]) ascending by node id
+                 (DBoW2::FeatureVector, KeyFrame.h:194)
+    valid        N uint8: map point exists and !isBad()  (for SearchForTriangulation: "has a map point")
+    angles       N float32 degrees (mvKeysUn[i].angle)
+    pts          N x 2 float32 (mvKeysUn[i].pt), sigma2 N float32 (GetKeyPt1DSigma2) — triangulation only
+    """
+
+    def __init__(self, descriptors, featvec=None, valid=None, angles=None, pts=None, sigma2=None):
+        self.descriptors = np.ascontiguousarray(descriptors, np.uint8)
+        if self.descriptors.ndim != 2:
+            self.descriptors = self.descriptors.reshape(0, 32)
+        self.N = self.descriptors.shape[0]
+        self.featvec = featvec
+        self.valid = None if valid is None else np.ascontiguousarray(valid, np.uint8)
+        self.angles = None if angles is None else np.ascontiguousarray(angles, np.float32)
+        self.pts = None if pts is None else np.ascontiguousarray(pts, np.float32)
+        self.sigma2 = None if sigma2 is None else np.ascontiguousarray(sigma2, np.float32)
+        self._csr = None
+
+    def csr(self):
+        if self._csr is None:
+            if self.featvec is None:
+                self._csr = (None, None, None, 0)
+            else:
+                ids = np.array([n for n, _ in self.featvec], np.int32)
+                ptrs = np.zeros(len(self.featvec) + 1, np.int32)
+                for i, (_, idx) in enumerate(self.featvec):
+                    ptrs[i + 1] = ptrs[i] + len(idx)
+                flat = (np.concatenate([np.asarray(idx, np.int32) for _, idx in self.featvec])
+                        if self.featvec else np.zeros(0, np.int32))
+                self._csr = (ids, ptrs, np.ascontiguousarray(flat, np.int32), len(self.featvec))
+        return self._csr
+
+
+class FeatureMatcher:
+    """FeatureMatcher(nnratio=0.6, checkOri=true) (FeatureMatcher.h:41)."""
+    TH_LOW = 0.0   # FeatureMatcher.cc:56-59 (all four are set from matchingTh, :1533-1545)
+    TH_HIGH = 0.0
+    descDistTh_high_reloc = 0.0
+    descDistTh_low_reloc = 0.0
+    HISTO_LENGTH = 30
+
+    def __init__(self, nnratio=0.6, checkOri=True, ctx=None):
+        from .extractor import Context
+        self.mfNNratio = float(nnratio)
+        self.mbCheckOrientation = bool(checkOri)
+        self.ctx = ctx or Context()
+        self.lib = self.ctx.lib
+
+    @classmethod
+    def setDescriptorDistanceThresholds(cls, settings):
+        """settings: matchingTh float, dict with 'FeatureMatcher.matchingTh', or YAML path (FeatureMatcher.cc:1533-1545)."""
+        if isinstance(settings, str):
+            import yaml
+            with open(settings) as fh:
+                text = fh.read()
+            if text.startswith("%YAML"):
+                text = text.split("\n", 1)[1]
+            settings = yaml.safe_load(text)
+        th = float(settings["FeatureMatcher.matchingTh"]) if isinstance(settings, dict) else float(settings)
+        cls.TH_LOW = th
+        cls.TH_HIGH = th
+        cls.descDistTh_low_reloc = th
+        cls.descDistTh_high_reloc = th
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        return DescriptorDistance_orb32(a, b)
+
+    def _job(self, v1, v2, mode, keep):
+        j = MatchJob()
+        j.desc1 = ptr(v1.descriptors); j.n1 = v1.N
+        j.desc2 = ptr(v2.descriptors); j.n2 = v2.N
+        j.desc_bytes = v1.descriptors.shape[1] if v1.N else (v2.descriptors.shape[1] if v2.N else 32)
+        i1, p1, f1, n1 = v1.csr(); i2, p2, f2, n2 = v2.csr()
+        j.node_id1 = ptr(i1); j.seg_ptr1 = ptr(p1); j.seg_idx1 = ptr(f1); j.nnodes1 = n1
+        j.node_id2 = ptr(i2); j.seg_ptr2 = ptr(p2); j.seg_idx2 = ptr(f2); j.nnodes2 = n2
+        j.valid1 = ptr(v1.valid); j.valid2 = ptr(v2.valid)
+        j.angle1 = ptr(v1.angles); j.angle2 = ptr(v2.angles)
+        j.th_low = self.TH_LOW; j.nnratio = self.mfNNratio
+        j.check_orientation = int(self.mbCheckOrientation); j.mode = mode
+        keep.extend([i1, p1, f1, i2, p2, f2])
+        return j
+
+    def _run_bow(self, pairs, mode):
+        keep = []
+        jobs = (MatchJob * len(pairs))(*[self._job(a, b, mode, keep) for a, b in pairs])
+        nouts = [(b.N if mode == _lib.MATCH_KF_FRAME else a.N) for a, b in pairs]
+        out = np.full(max(sum(nouts), 1), -1, np.int32)
+        nm = np.zeros(len(pairs), np.int32)
+        self.ctx.check(self.lib.afv_match_bow(self.ctx.handle, jobs, len(pairs), ptr(out), ptr(nm)), "afv_match_bow")
+        res, o = [], 0
+        for k, n in enumerate(nouts):
+            res.append((out[o:o + n].copy(), int(nm[k])))
+            o += n
+        return res
+
+    def SearchByBoW(self, pKF, other, frame=False):
+        """SearchByBoW(KF1,KF2) (FeatureMatcher.cc:561-660) -> (vpMatches12[N1] = idx in KF2 | -1, nMatches);
+        with frame=True: SearchByBoW(KF,Frame) (:186-283) -> (vpMapPointMatches[F.N] = idx in KF | -1, nMatches)."""
+        mode = _lib.MATCH_KF_FRAME if frame else _lib.MATCH_KF_KF
+        return self._run_bow([(pKF, other)], mode)[0]
+
+    def SearchByBoW_batch(self, pairs, frame=False):
+        mode = _lib.MATCH_KF_FRAME if frame else _lib.MATCH_KF_KF
+        return self._run_bow(list(pairs), mode)
+
+    def SearchForTriangulation(self, pKF1, pKF2, F12, epipole):
+        """FeatureMatcher.cc:662-790 (mono) -> (vMatchedPairs [(idx1, idx2)...] ascending idx1, nMatches).
+        pKF*.valid = has-map-point masks; epipole = projection of camera 1's centre in image 2 (:669-675)."""
+        keep = []
+        t = TriJob()
+        t.bow = self._job(pKF1, pKF2, _lib.MATCH_KF_KF, keep)
+        x1 = np.ascontiguousarray(pKF1.pts[:, 0]); y1 = np.ascontiguousarray(pKF1.pts[:, 1])
+        x2 = np.ascontiguousarray(pKF2.pts[:, 0]); y2 = np.ascontiguousarray(pKF2.pts[:, 1])
+        t.x1 = ptr(x1); t.y1 = ptr(y1); t.x2 = ptr(x2); t.y2 = ptr(y2); t.sigma2_2 = ptr(pKF2.sigma2)
+        F = np.asarray(F12, np.float32).reshape(9)
+        for i in range(9):
+            t.F12[i] = float(F[i])
+        t.ex, t.ey = float(epipole[0]), float(epipole[1])
+        out = np.full(max(pKF1.N, 1), -1, np.int32)
+        nm = np.zeros(1, np.int32)
+        jobs = (TriJob * 1)(t)
+        self.ctx.check(self.lib.afv_match_triangulation(self.ctx.handle, jobs, 1, ptr(out), ptr(nm)), "afv_match_triangulation")
+        out = out[:pKF1.N]
+        pairs = [(int(i), int(out[i])) for i in np.nonzero(out >= 0)[0]]
+        return pairs, int(nm[0])
+
+    def match_l2(self, desc1, desc2, th_low, nnratio=None, valid1=None, valid2=None):
+        """float descriptors (SIFT128 ...): brute force with SearchByBoW(KF,KF) control flow, distance =
+        cv::norm(a,b,NORM_L2SQR) (Feature_sift128.cpp:132-134)."""
+        desc1 = np.ascontiguousarray(desc1, np.float32); desc2 = np.ascontiguousarray(desc2, np.float32)
+        v1 = None if valid1 is None else np.ascontiguousarray(valid1, np.uint8)
+        v2 = None if valid2 is None else np.ascontiguousarray(valid2, np.uint8)
+        out = np.full(max(len(desc1), 1), -1, np.int32)
+        nm = np.zeros(1, np.int32)
+        rc = self.lib.afv_match_l2(self.ctx.handle, ptr(desc1), len(desc1), ptr(desc2), len(desc2), desc1.shape[1], ptr(v1), ptr(v2),
+                                   float(th_low), float(self.mfNNratio if nnratio is None else nnratio), ptr(out), ptr(nm))
+        self.ctx.check(rc, "afv_match_l2")
+        return out[:len(desc1)].copy(), int(nm[0])
+
+    def match_pairs_device(self, desc, kps, n, pair_a, pair_b, th_low=None, check_orientation=None, match=None, nmatches=None,
+                           stream=None):
+        """device-resident brute-force SearchByBoW(KF,KF) over a descriptor table (torch CUDA tensors)."""
+        import torch
+        nsets, cap = desc.shape[0], desc.shape[1]
+        npairs = pair_a.numel()
+        if match is None:
+            match = torch.empty((npairs, cap), dtype=torch.int32, device=desc.device)
+        if nmatches is None:
+            nmatches = torch.empty((npairs,), dtype=torch.int32, device=desc.device)
+        s = stream if stream is not None else torch.cuda.current_stream(desc.device).cuda_stream
+        co = self.mbCheckOrientation if check_orientation is None else check_orientation
+        rc = self.lib.afv_match_bruteforce_pairs_device(
+            self.ctx.handle, desc.data_ptr(), kps.data_ptr() if kps is not None else None, n.data_ptr(), nsets, cap,
+            pair_a.data_ptr(), pair_b.data_ptr(), npairs, float(self.TH_LOW if th_low is None else th_low), self.mfNNratio,
+            int(bool(co)), match.data_ptr(), nmatches.data_ptr(), s)
+        self.ctx.check(rc, "afv_match_bruteforce_pairs_device")
+        return match, nmatches

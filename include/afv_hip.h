@@ -1,0 +1,167 @@
+/*
+ * afv_hip.h — C-ABI of libafv_hip.so: MI355X (gfx950) ORB32 extraction + descriptor matching.
+ *
+ * Drop-in boundary for AnyFeature-VSLAM's front end.  Every entry point is plain C:
+ * pointers, sizes, POD structs; returns 0 on success or a negative AFV_E* code; never throws, never
+ * terminates the process.  One afv_ctx owns one HIP stream and its scratch buffers: use one context per
+ * calling thread (Tracking / LocalMapping / LoopClosing each call matchers concurrently in the reference,
+ * FeatureMatcher.cc §3.2) — a context is NOT re-entrant, different contexts are independent.
+ *
+ * Reference interfaces replaced (file:line under the reference tree):
+ *   afv_orb_extract*            FeatureExtractor::operator() 6/3-arg (src/FeatureExtractor.cpp:111-129) ->
+ *                               FeatureExtractor_orb32::detectAndCompute (src/Feature_orb32.cpp:11-18):
+ *                               detectKeypoints(:26-40, cv::ORB::detect) + filterKeypoints(:63-65 ->
+ *                               DistributeOctTree src/ORBextractor.cc:239-458) + computeDescriptors(:42-53,
+ *                               cv::ORB::compute per level) + mergeKeypointLevels (FeatureExtractor.cpp:296-308)
+ *   afv_orb_size_sigma          computeSize / computeSigma (src/FeatureExtractor.cpp:132-172)
+ *   afv_match_bow*              FeatureMatcher::SearchByBoW(KF,KF) (src/FeatureMatcher.cc:561-660) and
+ *                               SearchByBoW(KF,Frame) (:186-283), incl. the rotation histogram (:1579-1668);
+ *                               with no node segments = the brute-force form (north_star "Hamming brute force")
+ *   afv_match_triangulation*    FeatureMatcher::SearchForTriangulation (:662-790) + CheckDistEpipolarLine (:165-182)
+ *   afv_match_l2                DescriptorDistance_sift128 (src/Feature_sift128.cpp:132-134) inside the
+ *                               SearchByBoW(KF,KF) control flow (config #3)
+ *   afv_hamming256              DescriptorDistance_orb32 (src/Feature_orb32.cpp:67-84)
+ */
+#ifndef AFV_HIP_H
+#define AFV_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AFV_MAX_LEVELS 8
+#define AFV_DESC_BYTES 32
+
+enum {
+    AFV_OK = 0,
+    AFV_EINVAL = -1,     /* bad argument (null pointer, size out of range for the context) */
+    AFV_ENODEV = -2,     /* no usable HIP device / device ordinal out of range */
+    AFV_ENOMEM = -3,     /* device or host allocation failed */
+    AFV_EHIP = -4,       /* a HIP runtime call or kernel failed; see afv_last_error() */
+    AFV_ECAPACITY = -5,  /* caller-provided output capacity too small; outputs truncated */
+    AFV_EUNSUPPORTED = -6
+};
+
+typedef struct afv_ctx afv_ctx;
+
+/* bit-compatible with cv::KeyPoint {Point2f pt; float size, angle, response; int octave, class_id;} */
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} afv_keypoint;
+
+typedef struct {
+    int32_t nfeatures;      /* quadtree budget, Tracking.cc:1515-1520 (1000 @ 640x480); 1..4000 */
+    int32_t nlevels;        /* FeatureExtractor.numOctaves (settings/orb32_settings.yaml:6); 1..8 */
+    float scale_factor;     /* FeatureExtractor.scaleFactor (:7) */
+    int32_t fast_threshold; /* int(FeatureExtractor.detectionTh) (:8, Feature_orb32.cpp:30) */
+    int32_t max_width;      /* largest frame the context must accept (<= 4096) */
+    int32_t max_height;
+    int32_t max_batch;      /* frames per afv_orb_extract_batch* call */
+} afv_orb_params;
+
+void afv_default_orb_params(afv_orb_params *p); /* ORB32 defaults: 1000, 8, 1.2f, 20, 640x480, batch 1 */
+
+int afv_create(int device_ordinal, const afv_orb_params *params, afv_ctx **out);
+void afv_destroy(afv_ctx *ctx);
+const char *afv_strerror(int code);
+const char *afv_last_error(const afv_ctx *ctx); /* text of the last failing HIP call, "" if none */
+int afv_max_keypoints_per_frame(const afv_ctx *ctx); /* sum over levels of (quota_l + 2): safe `cap` */
+void *afv_stream(afv_ctx *ctx); /* the context's hipStream_t (for callers that enqueue their own copies) */
+
+/* ---- extraction: host-buffer plugin path (one frame; synchronous) ---- */
+int afv_orb_extract(afv_ctx *ctx, const uint8_t *gray, int width, int height, int stride_bytes,
+                    afv_keypoint *kps, uint8_t *desc32, int cap, int *n_out);
+
+/* ---- extraction: host-buffer batch (vocabulary builder shape, createVocabulary.cpp:161-174) ---- */
+int afv_orb_extract_batch(afv_ctx *ctx, const uint8_t *const *frames, int nframes, int width, int height,
+                          int stride_bytes, afv_keypoint *kps, uint8_t *desc32, int cap_per_frame, int *n_out);
+
+/* ---- extraction: device-resident batch (benchmark / pipelines).  All pointers are DEVICE pointers;
+ * frames are [nframes][height][stride_bytes] with frame_stride_bytes between frames (4-byte aligned base and
+ * strides); outputs kps[nframes][cap_per_frame], desc32[nframes][cap_per_frame][32], n_out[nframes].
+ * Enqueued on `stream` (hipStream_t, NULL = the context's stream); asynchronous — the caller synchronises.
+ * status_out (device int32, may be NULL) receives 0 or AFV_ECAPACITY. ---- */
+int afv_orb_extract_batch_device(afv_ctx *ctx, const uint8_t *d_frames, int nframes, int width, int height,
+                                 int stride_bytes, size_t frame_stride_bytes, afv_keypoint *d_kps,
+                                 uint8_t *d_desc32, int cap_per_frame, int32_t *d_n_out, int32_t *d_status_out,
+                                 void *stream);
+
+/* E12: size_i = normalised powf(scale, octave); sigma2_i = size^2; inf_i = 1/size^2 (host arithmetic) */
+int afv_orb_size_sigma(const afv_ctx *ctx, const afv_keypoint *kps, int n, float *size, float *sigma2, float *inf);
+
+/* ---- matching ---- */
+enum { AFV_MATCH_KF_KF = 0, AFV_MATCH_KF_FRAME = 1 };
+
+typedef struct {
+    const uint8_t *desc1; int32_t n1;   /* side 1 (KF1 / KF), n1 x desc_bytes, row-major */
+    const uint8_t *desc2; int32_t n2;   /* side 2 (KF2 / Frame) */
+    int32_t desc_bytes;                 /* 32 for ORB; any multiple of 4 up to 64 (AKAZE61 rows padded to 64 with zeros) */
+    /* DBoW2::FeatureVector of each side as CSR over ascending node ids; nnodes == 0 on either side => brute
+       force: a single node holding 0..n-1 on both sides */
+    const int32_t *node_id1; const int32_t *seg_ptr1; const int32_t *seg_idx1; int32_t nnodes1;
+    const int32_t *node_id2; const int32_t *seg_ptr2; const int32_t *seg_idx2; int32_t nnodes2;
+    const uint8_t *valid1; const uint8_t *valid2; /* map point exists && !isBad(); NULL => all valid.
+                                                     KF_FRAME ignores valid2 (FeatureMatcher.cc:216-232) */
+    const float *angle1; const float *angle2;     /* keypoint angles in degrees; required iff check_orientation */
+    float th_low;                       /* FeatureMatcher::TH_LOW (matchingTh, 75 for ORB) */
+    float nnratio;                      /* mfNNratio */
+    int32_t check_orientation;          /* mbCheckOrientation */
+    int32_t mode;                       /* AFV_MATCH_KF_KF: out[n1] = idx2|-1, accept best < th_low;
+                                           AFV_MATCH_KF_FRAME: out[n2] = idx1|-1, accept best <= th_low */
+} afv_match_job;
+
+/* host pointers; jobs are staged, matched on the GPU and copied back.  out = concatenation over jobs of
+   int32[n1] (KF_KF) or int32[n2] (KF_FRAME); nmatches[njobs]. */
+int afv_match_bow(afv_ctx *ctx, const afv_match_job *jobs, int njobs, int32_t *out, int32_t *nmatches);
+
+typedef struct {
+    afv_match_job bow;               /* valid1/valid2 mean "already HAS a map point" => skipped; mode/nnratio/
+                                        check_orientation ignored */
+    const float *x1, *y1, *x2, *y2; /* mvKeysUn */
+    const float *sigma2_2;           /* KeyFrame::GetKeyPt1DSigma2 of side 2 */
+    float F12[9];                    /* row-major fundamental matrix */
+    float ex, ey;                    /* epipole of camera 1 in image 2 */
+} afv_tri_job;
+int afv_match_triangulation(afv_ctx *ctx, const afv_tri_job *jobs, int njobs, int32_t *match12, int32_t *nmatches);
+
+/* device-resident brute-force batch: pair p matches descriptor set a[p] (side 1) against set b[p] (side 2) of a
+   table d_desc[nsets][cap][32] with per-set counts d_n[nsets] and angles d_kps (afv_keypoint, may be NULL when
+   !check_orientation).  d_match[npairs][cap] (idx2 | -1), d_nmatches[npairs].  SearchByBoW(KF,KF) semantics. */
+int afv_match_bruteforce_pairs_device(afv_ctx *ctx, const uint8_t *d_desc, const afv_keypoint *d_kps,
+                                      const int32_t *d_n, int nsets, int cap, const int32_t *d_pair_a,
+                                      const int32_t *d_pair_b, int npairs, float th_low, float nnratio,
+                                      int check_orientation, int32_t *d_match, int32_t *d_nmatches, void *stream);
+
+/* float descriptors, L2^2 distance (config #3): brute force with SearchByBoW(KF,KF) control flow */
+int afv_match_l2(afv_ctx *ctx, const float *desc1, int n1, const float *desc2, int n2, int dim,
+                 const uint8_t *valid1, const uint8_t *valid2, float th_low, float nnratio, int32_t *match12,
+                 int32_t *nmatches);
+
+/* DescriptorDistance_orb32 on the host (utility for adapters / tests) */
+int afv_hamming256(const uint8_t *a, const uint8_t *b);
+
+/* ---- stage-level introspection of the LAST afv_orb_extract* call (parity tests / profiling) ---- */
+typedef struct {
+    int32_t nlevels, width, height;
+    int32_t lw[AFV_MAX_LEVELS], lh[AFV_MAX_LEVELS];
+    float lscale[AFV_MAX_LEVELS];
+    int32_t quota[AFV_MAX_LEVELS];    /* mnFeaturesPerLevel */
+    int32_t cv_quota[AFV_MAX_LEVELS]; /* cv::ORB nfeaturesPerLevel for nfeatures*10 */
+    int32_t cand_cap[AFV_MAX_LEVELS];
+} afv_geometry;
+int afv_get_geometry(const afv_ctx *ctx, afv_geometry *g);
+/* copy pyramid level `level` of frame `frame` to host (tightly packed lw x lh) */
+int afv_debug_get_level(afv_ctx *ctx, int frame, int level, uint8_t *out);
+/* FAST+NMS candidates of (frame, level), unordered: packed[i] = x | y<<12 | score<<24, response[i] = Harris */
+int afv_debug_get_candidates(afv_ctx *ctx, int frame, int level, uint32_t *packed, float *response, int cap, int *n_out);
+/* keypoints chosen by the quadtree for (frame, level) in list order: x,y level coordinates */
+int afv_debug_get_selected(afv_ctx *ctx, int frame, int level, int32_t *x, int32_t *y, float *response, int cap, int *n_out);
+/* standalone 7x7 Gaussian blur of a level (E9) — same arithmetic as the fused describe kernel */
+int afv_debug_blur_level(afv_ctx *ctx, int frame, int level, uint8_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,197 @@
+"""-m gpu: HIP matchers vs the CPU oracle through the C-ABI.  Bar: match-set identical (every output index equal)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _sets(afv, seed, n1=700, n2=800):
+    s = afv.synth
+    d1 = s.random_descriptors(seed, n1)
+    d2 = s.perturbed_descriptors(np.resize(d1, (n2, 32)).copy(), seed + 100)
+    a1 = (s.lcg_states(seed + 1, n1) % 36000).astype(np.float32) / 100.0
+    a2 = (s.lcg_states(seed + 2, n2) % 36000).astype(np.float32) / 100.0
+    return d1, d2, a1, a2
+
+
+def _featvec(afv, seed, n, nnodes):
+    """random DBoW2-like FeatureVector: node -> ascending feature indices"""
+    node_of = afv.synth.lcg_states(seed, n) % nnodes
+    fv = []
+    for k in range(nnodes):
+        idx = np.nonzero(node_of == k)[0]
+        if len(idx):
+            fv.append((int(k * 3 + 1), idx.tolist()))
+    return fv
+
+
+@pytest.fixture(scope="module")
+def matcher(afv, gpu_ctx):
+    afv.FeatureMatcher.setDescriptorDistanceThresholds({"FeatureMatcher.matchingTh": 75.0})
+    return afv.FeatureMatcher(0.6, True, ctx=gpu_ctx)
+
+
+@pytest.mark.parametrize("check_ori", [False, True])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_bruteforce_kf_kf(afv, oracle, matcher, seed, check_ori):
+    d1, d2, a1, a2 = _sets(afv, seed)
+    matcher.mbCheckOrientation = check_ori
+    got, n = matcher.SearchByBoW(afv.FeatureView(d1, angles=a1), afv.FeatureView(d2, angles=a2))
+    want, wn = oracle.search_by_bow_kf_kf(d1, d2, angle1=a1, angle2=a2, th_low=75.0, nnratio=0.6, check_orientation=check_ori)
+    assert n == wn and np.array_equal(got, want)
+    assert wn > 50  # the generator must produce real matches
+
+
+@pytest.mark.parametrize("frame", [False, True])
+def test_bow_guided_with_validity(afv, oracle, matcher, frame):
+    d1, d2, a1, a2 = _sets(afv, 11, 900, 1000)
+    fv1, fv2 = _featvec(afv, 5, 900, 60), _featvec(afv, 6, 1000, 60)
+    v1 = (afv.synth.lcg_bytes(7, 900) > 40).astype(np.uint8)
+    v2 = (afv.synth.lcg_bytes(8, 1000) > 40).astype(np.uint8)
+    matcher.mbCheckOrientation = True
+    matcher.mfNNratio = 0.75
+    k1 = afv.FeatureView(d1, fv1, v1, a1)
+    k2 = afv.FeatureView(d2, fv2, v2, a2)
+    got, n = matcher.SearchByBoW(k1, k2, frame=frame)
+    if frame:
+        want, wn = oracle.search_by_bow_kf_frame(d1, d2, fv1, fv2, v1, a1, a2, 75.0, 0.75, True)
+    else:
+        want, wn = oracle.search_by_bow_kf_kf(d1, d2, fv1, fv2, v1, v2, a1, a2, 75.0, 0.75, True)
+    matcher.mfNNratio = 0.6
+    assert n == wn and np.array_equal(got, want)
+
+
+def test_threshold_and_ratio_equalities(afv, oracle, matcher):
+    """dist == TH_LOW: accepted by SearchByBoW(KF,F) (<=, :250), rejected by SearchByBoW(KF,KF) (<, :630); ties between
+    equal best distances -> first column wins; ratio equality is rejected (strict <)"""
+    base = np.zeros((4, 32), np.uint8)
+    d1 = base[:1].copy()
+    d2 = np.zeros((3, 32), np.uint8)
+    d2[0, :9] = 0xFF; d2[0, 9] = 0x07       # 75 bits
+    d2[1, :9] = 0xFF; d2[1, 9] = 0x07; d2[1, 31] = 0      # also 75 (tie)
+    d2[2, :] = 0xFF                          # 256
+    matcher.mbCheckOrientation = False
+    matcher.mfNNratio = 2.0
+    for frame in (False, True):
+        got, n = matcher.SearchByBoW(afv.FeatureView(d1), afv.FeatureView(d2), frame=frame)
+        if frame:
+            want, wn = oracle.search_by_bow_kf_frame(d1, d2, th_low=75.0, nnratio=2.0)
+        else:
+            want, wn = oracle.search_by_bow_kf_kf(d1, d2, th_low=75.0, nnratio=2.0)
+        assert n == wn and np.array_equal(got, want), frame
+    # ratio equality: best 30, second 50, ratio 0.6 -> 30 < 0.6*50 is false
+    d2 = np.zeros((2, 32), np.uint8)
+    d2[0, :3] = 0xFF; d2[0, 3] = 0x3F        # 30
+    d2[1, :6] = 0xFF; d2[1, 6] = 0x03        # 50
+    matcher.mfNNratio = 0.6
+    got, n = matcher.SearchByBoW(afv.FeatureView(d1), afv.FeatureView(d2))
+    want, wn = oracle.search_by_bow_kf_kf(d1, d2, th_low=75.0, nnratio=0.6)
+    assert n == wn == 0 and np.array_equal(got, want)
+
+
+def test_empty_and_ragged(afv, oracle, matcher):
+    matcher.mbCheckOrientation = False
+    d = afv.synth.random_descriptors(3, 10)
+    empty = np.zeros((0, 32), np.uint8)
+    for a, b in [(empty, d), (d, empty), (empty, empty), (d[:1], d[:1])]:
+        got, n = matcher.SearchByBoW(afv.FeatureView(a), afv.FeatureView(b))
+        want, wn = oracle.search_by_bow_kf_kf(a, b, th_low=75.0, nnratio=0.6)
+        assert n == wn and np.array_equal(got, want)
+    # disjoint node ids: nothing to compare
+    fv1 = [(1, [0, 1, 2])]; fv2 = [(2, [0, 1, 2])]
+    got, n = matcher.SearchByBoW(afv.FeatureView(d, fv1), afv.FeatureView(d, fv2))
+    assert n == 0 and np.all(got == -1)
+
+
+def test_batch_of_jobs(afv, oracle, matcher):
+    matcher.mbCheckOrientation = True
+    pairs, want = [], []
+    for s in range(6):
+        d1, d2, a1, a2 = _sets(afv, 50 + s, 300 + 37 * s, 280 + 53 * s)
+        pairs.append((afv.FeatureView(d1, angles=a1), afv.FeatureView(d2, angles=a2)))
+        want.append(oracle.search_by_bow_kf_kf(d1, d2, angle1=a1, angle2=a2, th_low=75.0, nnratio=0.6, check_orientation=True))
+    got = matcher.SearchByBoW_batch(pairs)
+    for g, w in zip(got, want):
+        assert g[1] == w[1] and np.array_equal(g[0], w[0])
+
+
+def test_triangulation(afv, oracle, matcher):
+    s = afv.synth
+    n1, n2 = 800, 900
+    d1, d2, _, _ = _sets(afv, 21, n1, n2)
+    fv1, fv2 = _featvec(afv, 31, n1, 40), _featvec(afv, 32, n2, 40)
+    p1 = np.stack([(s.lcg_states(41, n1) % 64000) / 100.0, (s.lcg_states(42, n1) % 48000) / 100.0], 1).astype(np.float32)
+    p2 = np.stack([(s.lcg_states(43, n2) % 64000) / 100.0, (s.lcg_states(44, n2) % 48000) / 100.0], 1).astype(np.float32)
+    oct2 = s.lcg_states(45, n2) % 8
+    sigma2 = (np.float32(1.2) ** oct2.astype(np.float32)) ** 2
+    has1 = (s.lcg_bytes(46, n1) > 128).astype(np.uint8)
+    has2 = (s.lcg_bytes(47, n2) > 128).astype(np.uint8)
+    # a gentle fundamental matrix: horizontal epipolar lines y2 ~ y1 with a wide gate via large sigma
+    F = np.array([[0, 0, 0], [0, 0, -1e-3], [0, 1e-3, 0]], np.float32)
+    ep = (1e6, 240.0)
+    sigma2 = sigma2.astype(np.float32) * 400.0
+    for th in (75.0, 120.0):
+        afv.FeatureMatcher.TH_LOW = th
+        k1 = afv.FeatureView(d1, fv1, has1, pts=p1)
+        k2 = afv.FeatureView(d2, fv2, has2, pts=p2, sigma2=sigma2)
+        pairs, n = matcher.SearchForTriangulation(k1, k2, F, ep)
+        want, wn = oracle.search_for_triangulation(d1, d2, p1, p2, sigma2, F, ep, fv1, fv2, has1, has2, th)
+        got = np.full(n1, -1, np.int32)
+        for a, b in pairs:
+            got[a] = b
+        assert n == wn and np.array_equal(got, want)
+    afv.FeatureMatcher.TH_LOW = 75.0
+    assert wn > 10
+
+
+def test_l2_float_descriptors(afv, oracle, matcher):
+    """config #3: SIFT-like unit-norm non-negative 128-float descriptors, TH = 0.5"""
+    s = afv.synth
+    n = 500
+    a = (s.lcg_bytes(61, n * 128).reshape(n, 128).astype(np.float32)) ** 2
+    a /= np.linalg.norm(a, axis=1, keepdims=True)
+    noise = (s.lcg_bytes(62, n * 128).reshape(n, 128).astype(np.float32) - 128) / 2000.0
+    b = np.abs(a + noise).astype(np.float32)
+    b /= np.linalg.norm(b, axis=1, keepdims=True)
+    b = b[::-1].copy()
+    got, gn = matcher.match_l2(a, b, 0.5, 0.8)
+    want, wn = oracle.match_l2_bruteforce(a, b, 0.5, 0.8)
+    assert gn == wn and np.array_equal(got, want) and wn > 100
+
+
+def test_akaze61_byte_hamming(afv, oracle, matcher):
+    """61-byte descriptors (Feature_akaze61.cpp:75-77): rows are zero padded to 64 bytes on the device"""
+    s = afv.synth
+    d1 = s.random_descriptors(71, 300, 61)
+    d2 = s.perturbed_descriptors(d1.copy(), 72)
+    matcher.mbCheckOrientation = False
+    afv.FeatureMatcher.TH_LOW = 128.0
+    got, n = matcher.SearchByBoW(afv.FeatureView(d1), afv.FeatureView(d2))
+    want, wn = oracle.search_by_bow_kf_kf(d1, d2, th_low=128.0, nnratio=0.6)
+    afv.FeatureMatcher.TH_LOW = 75.0
+    assert n == wn and np.array_equal(got, want) and wn > 50
+
+
+def test_device_pairs_match_extracted_frames(afv, oracle, matcher, gpu_ctx):
+    """bench shape: extract a batch on the device, match frame t against t-1 without leaving HBM"""
+    import torch
+    frames = np.stack([afv.synth.corners_frame(80 + i) for i in range(4)])
+    # make consecutive frames overlap: frame i+1 = frame i shifted by 3 px
+    for i in range(1, 4):
+        frames[i] = np.roll(frames[0], 3 * i, axis=1)
+    t = torch.from_numpy(frames).cuda()
+    kps, desc, n, status = gpu_ctx.extract_batch_device(t)
+    pa = torch.arange(1, 4, dtype=torch.int32, device="cuda")
+    pb = torch.arange(0, 3, dtype=torch.int32, device="cuda")
+    matcher.mbCheckOrientation = True
+    match, nm = matcher.match_pairs_device(desc, kps, n, pa, pb, th_low=75.0)
+    torch.cuda.synchronize()
+    kps = kps.cpu().numpy(); desc = desc.cpu().numpy(); n = n.cpu().numpy(); match = match.cpu().numpy(); nm = nm.cpu().numpy()
+    for p in range(3):
+        a, b = p + 1, p
+        ka = kps[a, :n[a]].reshape(-1).view(afv.KP_DTYPE); kb = kps[b, :n[b]].reshape(-1).view(afv.KP_DTYPE)
+        want, wn = oracle.search_by_bow_kf_kf(desc[a, :n[a]], desc[b, :n[b]], angle1=ka["angle"], angle2=kb["angle"], th_low=75.0,
+                                              nnratio=0.6, check_orientation=True)
+        assert nm[p] == wn and np.array_equal(match[p, :n[a]], want), p
+        assert np.all(match[p, n[a]:] == -1)
+    assert nm.sum() > 100
