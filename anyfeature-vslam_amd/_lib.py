@@ -15,6 +15,7 @@ MAX_LEVELS = 8
 DESC_BYTES = 32
 OK, EINVAL, ENODEV, ENOMEM, EHIP, ECAPACITY, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 MATCH_KF_KF, MATCH_KF_FRAME = 0, 1
+STAGES = ("pyramid", "fast_harris", "select_quadtree", "describe", "match")
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
                      ("octave", "<i4"), ("class_id", "<i4")])
@@ -67,6 +68,8 @@ SYMBOLS = {
     "afv_match_bruteforce_pairs_device": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _f, _f, _i, _vp, _vp, _vp]),
     "afv_match_l2": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _f, _f, _vp, _vp]),
     "afv_hamming256": (_i, [_vp, _vp]),
+    "afv_profile_enable": (_i, [_vp, _i]),
+    "afv_profile_read": (_i, [_vp, _vp, _vp]),
     "afv_get_geometry": (_i, [_vp, C.POINTER(Geometry)]),
     "afv_debug_get_level": (_i, [_vp, _i, _i, _vp]),
     "afv_debug_get_candidates": (_i, [_vp, _i, _i, _vp, _vp, _i, C.POINTER(_i)]),

@@ -87,6 +87,36 @@ struct afv_ctx {
     FrameSrc last_src{};
     int last_nframes = 0;
     std::string last_error;
+    // live stage timing
+    bool prof = false;
+    std::vector<hipEvent_t> prof_ev[AFV_NUM_STAGES];  // pairs (begin, end)
+    size_t prof_used[AFV_NUM_STAGES]{};
+    int prof_launches[AFV_NUM_STAGES]{};
+    float prof_ms[AFV_NUM_STAGES]{};
+};
+
+struct StageTimer {  // RAII: record begin/end events around one stage on the launch stream
+    afv_ctx *c;
+    int stage;
+    hipStream_t s;
+    hipEvent_t e1 = nullptr;
+    StageTimer(afv_ctx *c_, int stage_, hipStream_t s_) : c(c_), stage(stage_), s(s_) {
+        if (!c->prof) return;
+        auto &v = c->prof_ev[stage];
+        size_t &u = c->prof_used[stage];
+        if (u + 2 > v.size()) {
+            hipEvent_t a = nullptr, b = nullptr;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            v.push_back(a);
+            v.push_back(b);
+        }
+        (void)hipEventRecord(v[u], s);
+        e1 = v[u + 1];
+        u += 2;
+    }
+    ~StageTimer() {
+        if (e1) (void)hipEventRecord(e1, s);
+    }
 };
 
 static const char *k_errors[] = {"ok", "invalid argument", "no usable HIP device", "out of memory", "HIP runtime error",
@@ -277,6 +307,8 @@ extern "C" void afv_destroy(afv_ctx *c) {
                     c->d_n, c->d_status, c->d_match};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    for (auto &v : c->prof_ev)
+        for (hipEvent_t e : v) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -354,6 +386,44 @@ extern "C" int afv_create(int device, const afv_orb_params *params, afv_ctx **ou
     return AFV_OK;
 }
 
+static void profile_drain(afv_ctx *c) {
+    for (int st = 0; st < AFV_NUM_STAGES; ++st) {
+        for (size_t i = 0; i + 1 < c->prof_used[st]; i += 2) {
+            float ms = 0.f;
+            if (hipEventSynchronize(c->prof_ev[st][i + 1]) == hipSuccess &&
+                hipEventElapsedTime(&ms, c->prof_ev[st][i], c->prof_ev[st][i + 1]) == hipSuccess) {
+                c->prof_ms[st] += ms;
+                c->prof_launches[st] += 1;
+            }
+        }
+        c->prof_used[st] = 0;
+    }
+}
+
+extern "C" int afv_profile_enable(afv_ctx *c, int enable) {
+    if (!c) return AFV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    profile_drain(c);
+    c->prof = enable != 0;
+    if (enable)
+        for (int st = 0; st < AFV_NUM_STAGES; ++st) {
+            c->prof_ms[st] = 0.f;
+            c->prof_launches[st] = 0;
+        }
+    return AFV_OK;
+}
+
+extern "C" int afv_profile_read(afv_ctx *c, int32_t *launches, float *total_ms) {
+    if (!c || !launches || !total_ms) return AFV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    profile_drain(c);
+    for (int st = 0; st < AFV_NUM_STAGES; ++st) {
+        launches[st] = c->prof_launches[st];
+        total_ms[st] = c->prof_ms[st];
+    }
+    return AFV_OK;
+}
+
 extern "C" int afv_get_geometry(const afv_ctx *c, afv_geometry *g) {
     if (!c || !g) return AFV_EINVAL;
     const Geo &s = c->geo_valid ? c->geo : c->cap_geo;
@@ -378,6 +448,8 @@ static int enqueue_extract(afv_ctx *c, const FrameSrc &src, int nframes, afv_key
     const Geo &g = c->geo;
     HIPCHK(c, hipMemsetAsync(c->d_cand_count, 0, (size_t)nframes * AFV_MAX_LEVELS * sizeof(int), s));
     if (d_status) HIPCHK(c, hipMemsetAsync(d_status, 0, sizeof(int), s));
+    {
+    StageTimer t_(c, AFV_STAGE_PYRAMID, s);
     for (int l = 1; l < g.nlevels; ++l) {
         const LevelGeo &S = g.lv[l - 1], &D = g.lv[l];
         const uint8_t *sp = (l == 1) ? src.base : c->d_pyr + S.pyr_off;
@@ -386,13 +458,23 @@ static int enqueue_extract(afv_ctx *c, const FrameSrc &src, int nframes, afv_key
         afv_launch_resize(sp, S.w, S.h, spitch, sframe, c->d_pyr + D.pyr_off, D.w, D.h, D.pitch, D.pyr_frame_stride,
                           c->d_tab + c->tab_off_x[l], c->d_tab + c->tab_off_y[l], nframes, s);
     }
-    afv_launch_fast_harris(c->d_geo, g.total_tiles, &src, c->d_pyr, c->d_cand_packed, c->d_cand_resp, c->d_cand_count, nframes, s);
-    afv_launch_select(c->d_geo, g.nlevels, c->d_cand_packed, c->d_cand_resp, c->d_cand_count, c->d_kept_xy, c->d_kept_resp,
-                      c->d_kept_node, c->d_sel, c->d_sel_count, c->select_M, nframes, s);
+    }
+    {
+        StageTimer t_(c, AFV_STAGE_FAST_HARRIS, s);
+        afv_launch_fast_harris(c->d_geo, g.total_tiles, &src, c->d_pyr, c->d_cand_packed, c->d_cand_resp, c->d_cand_count, nframes, s);
+    }
+    {
+        StageTimer t_(c, AFV_STAGE_SELECT, s);
+        afv_launch_select(c->d_geo, g.nlevels, c->d_cand_packed, c->d_cand_resp, c->d_cand_count, c->d_kept_xy, c->d_kept_resp,
+                          c->d_kept_node, c->d_sel, c->d_sel_count, c->select_M, nframes, s);
+    }
     int max_sel = 0;
     for (int l = 0; l < g.nlevels; ++l) max_sel = std::max(max_sel, g.lv[l].sel_cap);
-    afv_launch_describe(c->d_geo, g.nlevels, max_sel, &src, c->d_pyr, c->d_sel, c->d_sel_count, d_kps, d_desc, cap, d_n,
-                        d_status, nframes, s);
+    {
+        StageTimer t_(c, AFV_STAGE_DESCRIBE, s);
+        afv_launch_describe(c->d_geo, g.nlevels, max_sel, &src, c->d_pyr, c->d_sel, c->d_sel_count, d_kps, d_desc, cap, d_n,
+                            d_status, nframes, s);
+    }
     HIPCHK(c, hipGetLastError());
     c->last_src = src;
     c->last_nframes = nframes;
@@ -787,8 +869,12 @@ extern "C" int afv_match_bruteforce_pairs_device(afv_ctx *c, const uint8_t *d_de
     if (nsets < 1 || npairs < 1 || cap < 1 || cap > AFV_MAX_SIDE) return AFV_EINVAL;
     if (check_orientation && !d_kps) return AFV_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
-    afv_launch_match_pairs(d_desc, d_kps, d_n, cap, d_pair_a, d_pair_b, npairs, th_low, nnratio, check_orientation, d_match,
-                           d_nmatches, stream ? (hipStream_t)stream : c->stream);
+    {
+        hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+        StageTimer t_(c, AFV_STAGE_MATCH, s);
+        afv_launch_match_pairs(d_desc, d_kps, d_n, cap, d_pair_a, d_pair_b, npairs, th_low, nnratio, check_orientation, d_match,
+                               d_nmatches, s);
+    }
     HIPCHK(c, hipGetLastError());
     return AFV_OK;
 }

@@ -155,6 +155,15 @@ class Context:
         self.check(self.lib.afv_orb_size_sigma(self.handle, ptr(kps), n, ptr(size), ptr(s2), ptr(inf)))
         return size, s2, inf
 
+    # ---- live stage timing (hipEvents on the launch stream) ----
+    def profile_enable(self, enable=True):
+        self.check(self.lib.afv_profile_enable(self.handle, int(bool(enable))))
+
+    def profile_read(self):
+        launches = np.zeros(len(_lib.STAGES), np.int32); ms = np.zeros(len(_lib.STAGES), np.float32)
+        self.check(self.lib.afv_profile_read(self.handle, ptr(launches), ptr(ms)))
+        return {name: {"launches": int(launches[i]), "total_ms": float(ms[i])} for i, name in enumerate(_lib.STAGES)}
+
     # ---- stage introspection (parity tests) ----
     def debug_level(self, frame, level):
         g = self.geometry()

@@ -142,6 +142,15 @@ int afv_match_l2(afv_ctx *ctx, const float *desc1, int n1, const float *desc2, i
 /* DescriptorDistance_orb32 on the host (utility for adapters / tests) */
 int afv_hamming256(const uint8_t *a, const uint8_t *b);
 
+/* ---- live stage timing: when enabled, every afv_orb_extract_batch_device / afv_match_bruteforce_pairs_device call
+ * brackets each kernel stage with hipEvents recorded on the stream the kernels are launched on.
+ * afv_profile_read waits for the recorded events and returns, per stage, the number of launches and the summed
+ * duration in milliseconds since the last afv_profile_enable(ctx, 1).  Stages: ---- */
+enum { AFV_STAGE_PYRAMID = 0, AFV_STAGE_FAST_HARRIS = 1, AFV_STAGE_SELECT = 2, AFV_STAGE_DESCRIBE = 3, AFV_STAGE_MATCH = 4,
+       AFV_NUM_STAGES = 5 };
+int afv_profile_enable(afv_ctx *ctx, int enable);
+int afv_profile_read(afv_ctx *ctx, int32_t *launches /*[AFV_NUM_STAGES]*/, float *total_ms /*[AFV_NUM_STAGES]*/);
+
 /* ---- stage-level introspection of the LAST afv_orb_extract* call (parity tests / profiling) ---- */
 typedef struct {
     int32_t nlevels, width, height;

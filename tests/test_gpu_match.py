@@ -79,14 +79,20 @@ def test_threshold_and_ratio_equalities(afv, oracle, matcher):
         else:
             want, wn = oracle.search_by_bow_kf_kf(d1, d2, th_low=75.0, nnratio=2.0)
         assert n == wn and np.array_equal(got, want), frame
-    # ratio equality: best 30, second 50, ratio 0.6 -> 30 < 0.6*50 is false
+    # ratio equality: best 25, second 50, ratio 0.5 (exact in binary) -> 25 < 0.5*50 is false (strict, :632)
     d2 = np.zeros((2, 32), np.uint8)
-    d2[0, :3] = 0xFF; d2[0, 3] = 0x3F        # 30
+    d2[0, :3] = 0xFF; d2[0, 3] = 0x01        # 25
     d2[1, :6] = 0xFF; d2[1, 6] = 0x03        # 50
+    matcher.mfNNratio = 0.5
+    got, n = matcher.SearchByBoW(afv.FeatureView(d1), afv.FeatureView(d2))
+    want, wn = oracle.search_by_bow_kf_kf(d1, d2, th_low=75.0, nnratio=0.5)
+    assert n == wn == 0 and np.array_equal(got, want)
+    # ... and 0.6f*50 = 30.000002 > 30: a 30/50 pair IS accepted with the default ratio (float semantics, not decimal)
+    d2[0] = 0; d2[0, :3] = 0xFF; d2[0, 3] = 0x3F   # 30
     matcher.mfNNratio = 0.6
     got, n = matcher.SearchByBoW(afv.FeatureView(d1), afv.FeatureView(d2))
     want, wn = oracle.search_by_bow_kf_kf(d1, d2, th_low=75.0, nnratio=0.6)
-    assert n == wn == 0 and np.array_equal(got, want)
+    assert n == wn == 1 and np.array_equal(got, want)
 
 
 def test_empty_and_ragged(afv, oracle, matcher):
