@@ -85,6 +85,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # Load order matters: PyTorch ships its own libamdhip64; if libafv_hip.so pulled in /opt/rocm's copy first, a
+    # later `import torch` would bring a SECOND HIP runtime into the process and one of the two fails to see the
+    # GPU.  Importing torch first makes libafv_hip.so bind to the runtime that is already loaded.
+    try:
+        import torch  # noqa: F401  (plumbing only: device memory, streams, torch.distributed)
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing: build the HIP extension first (python __graft_entry__.py or "
                           "anyfeature-vslam_amd/build.py); there is no CPU fallback" % LIB_PATH)
