@@ -189,3 +189,68 @@ def test_plugin_interface(afv, oracle):
     assert ext.settings.ON_automaticTuning is False
     k0, d0 = ext.detectAndCompute(np.zeros((0, 0), np.uint8))
     assert len(k0) == 0
+
+
+# ---------------- committed golden fixtures (tests/golden/, independent of the oracle binary on this box) ----------------
+import os
+import zlib
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name", ["toy", "corners1", "corners2", "noise3"])
+def test_hip_reproduces_golden_fixtures(gpu_ctx, afv, name):
+    gold = np.load(os.path.join(GOLD, "orb32_expected.npz"))
+    if name == "toy":
+        img = np.load(os.path.join(GOLD, "toy_gray.npz"))["gray"]  # real 640x480 TUM frame of the reference's toy sequence
+    elif name == "noise3":
+        img = afv.synth.noise_frame(3)
+    else:
+        img = afv.synth.corners_frame(int(name[-1]))
+    kps, desc = gpu_ctx.extract(img)
+    assert kps.tobytes() == gold[name + "_kps"].tobytes()
+    assert np.array_equal(desc, gold[name + "_desc"])
+    for l in range(8):
+        assert zlib.crc32(gpu_ctx.debug_level(0, l).tobytes()) == int(gold[name + "_level_crc"][l]), l
+        x, y, s, r = gpu_ctx.debug_candidates(0, l)
+        assert len(x) == int(gold[name + "_ncand"][l])
+        a = np.stack([y, x, s], 1).astype(np.int32)
+        a = a[np.lexsort((a[:, 1], a[:, 0]))]
+        assert zlib.crc32(a.tobytes()) == int(gold[name + "_cand_crc"][l]), l
+        assert len(gpu_ctx.debug_selected(0, l)[0]) == int(gold[name + "_tcounts"][l])
+    for l in (0, 4, 7):
+        assert zlib.crc32(gpu_ctx.debug_blur_level(0, l).tobytes()) == int(gold[name + "_blur_crc"][l]), l
+
+
+def test_hip_matcher_reproduces_golden(gpu_ctx, afv):
+    gold = np.load(os.path.join(GOLD, "orb32_expected.npz"))
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+    m = afv.FeatureMatcher(0.6, True, ctx=gpu_ctx)
+    got, n = m.SearchByBoW(afv.FeatureView(gold["shift4_desc"], angles=gold["shift4_kps"]["angle"]),
+                           afv.FeatureView(gold["corners1_desc"], angles=gold["corners1_kps"]["angle"]))
+    assert n == int(gold["shift4_nmatches"][0]) and np.array_equal(got, gold["shift4_match12"])
+
+
+def test_batch_properties_at_full_size(gpu_ctx, afv):
+    """size-independent properties on a device batch: per-level counts within [quota, quota+2], ascending octaves,
+    idempotence (same frames -> same bytes), independence from batch position"""
+    import torch
+    ctx = afv.Context(max_batch=32)
+    frames = np.stack([afv.synth.corners_frame(200 + (i % 8)) for i in range(32)])
+    t = torch.from_numpy(frames).cuda()
+    k1, d1, n1, st = ctx.extract_batch_device(t)
+    torch.cuda.synchronize()
+    k1, d1, n1 = k1.cpu().numpy().copy(), d1.cpu().numpy().copy(), n1.cpu().numpy().copy()
+    k2, d2, n2, st = ctx.extract_batch_device(t)
+    torch.cuda.synchronize()
+    assert np.array_equal(n1, n2.cpu().numpy()) and int(st.item()) == 0
+    quota = ctx.geometry()["quota"]
+    for i in range(32):
+        n = int(n1[i])
+        ki = k1[i, :n].reshape(-1).view(afv.KP_DTYPE)
+        assert ki.tobytes() == k2.cpu().numpy()[i, :n].tobytes() and np.array_equal(d1[i, :n], d2.cpu().numpy()[i, :n])
+        assert ki.tobytes() == k1[i % 8, :n].tobytes() and np.array_equal(d1[i, :n], d1[i % 8, :n])  # position independent
+        assert np.all(np.diff(ki["octave"]) >= 0)
+        counts = np.bincount(ki["octave"], minlength=8)
+        assert all(quota[l] <= counts[l] <= quota[l] + 2 for l in range(8))
+    ctx.close()

@@ -1,0 +1,422 @@
+"""CPU: pin the oracle.  The reference has no tests or golden vectors and cannot be built here, so the
+oracle is "parity unpinned" for the OpenCV stages; what CAN be pinned is pinned here:
+  * known-answer values derivable from the reference's text (quotas, level sizes, umax, thresholds, BRIEF table);
+  * algebraic identities of each restated stage (what the formulas must satisfy whatever the data);
+  * the committed golden fixtures (tests/golden/, produced by tests/golden/make_golden.py).
+"""
+import math
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLD, "orb32_expected.npz"))
+
+
+# ---------------- known answers from the reference text ----------------
+def test_quotas_known_answers(oracle):
+    # FeatureExtractor.cpp:97-108 with nfeatures 1000 / 2000 (Tracking.h:239,332); SURVEY.md §4
+    assert oracle.quotas_extractor(1000).tolist() == [217, 181, 151, 126, 105, 87, 73, 60]
+    assert oracle.quotas_extractor(2000).tolist() == [434, 362, 302, 251, 209, 175, 145, 122]
+    # cv::ORB with nfeatures*10 (Feature_orb32.cpp:22)
+    assert oracle.quotas_cvorb(10000).tolist() == [2172, 1810, 1508, 1257, 1047, 873, 727, 606]
+    assert oracle.quotas_extractor(1000).sum() == 1000 and oracle.quotas_cvorb(10000).sum() == 10000
+
+
+def test_level_geometry_known_answers(oracle):
+    lw, lh, ls = oracle.level_geometry(640, 480)
+    assert lw.tolist() == [640, 533, 444, 370, 309, 257, 214, 179]
+    assert lh.tolist() == [480, 400, 333, 278, 231, 193, 161, 134]
+    assert int((lw.astype(np.int64) * lh).sum()) == 950532  # algorithmic pixel count
+    lw, lh, _ = oracle.level_geometry(1280, 720)
+    assert int((lw.astype(np.int64) * lh).sum()) == 2853088
+    assert ls[0] == 1.0 and np.float32(ls[1]) == np.float32(1.2)
+
+
+def test_umax_and_gauss_taps(oracle):
+    assert oracle.umax().tolist() == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    # disc of 749 pixels
+    u = oracle.umax()
+    assert (2 * u[0] + 1) + 2 * int(sum(2 * u[v] + 1 for v in range(1, 16))) == 749
+    taps = oracle.gauss7_taps()
+    assert taps.tolist() == [18, 34, 49, 55, 49, 34, 18] and taps.sum() == 257
+    # margins: none of the 256*g values is near a rounding boundary
+    g = np.exp(-0.5 * (np.arange(7) - 3.0) ** 2 / 4.0)
+    g = g / g.sum() * 256
+    assert np.all(np.abs(g - np.round(g)) < 0.46)
+
+
+def test_brief_pattern_table(oracle):
+    pat = oracle.brief_pattern()
+    assert pat.shape == (1024,) and pat.min() == -13 and pat.max() == 12
+    assert zlib.crc32(pat.astype(np.int8).tobytes()) == 0xD1A39030  # tools/gen_brief_pattern.py
+    assert pat[:8].tolist() == [8, -3, 9, 5, 4, 2, 7, -12]          # FeatureExtractor.h:221-222
+    assert pat[-4:].tolist() == [-1, -6, 0, -11]                     # FeatureExtractor.h:476
+    # every rotated tap stays inside the 37x37 patch the HIP kernel stages
+    r = np.hypot(pat[0::2].astype(float), pat[1::2].astype(float))
+    assert r.max() < 18.5
+
+
+def test_hamming_swar_equals_popcount(oracle, afv):
+    d = afv.synth.random_descriptors(9, 64)
+    for i in range(0, 64, 2):
+        want = int(np.unpackbits(d[i] ^ d[i + 1]).sum())
+        assert oracle.hamming256(d[i], d[i + 1]) == want == oracle.hamming_bytes(d[i], d[i + 1])
+    z = np.zeros(32, np.uint8); o = np.full(32, 255, np.uint8)
+    assert oracle.hamming256(z, z) == 0 and oracle.hamming256(z, o) == 256
+
+
+def test_rotation_histogram_quirks(oracle):
+    # FeatureMatcher.cc:1587-1599: factor 1/30 with a 30-bin histogram => only bins 0..12 are ever hit
+    assert oracle.rotation_bin(10.0, 5.0) == 0
+    assert oracle.rotation_bin(5.0, 10.0) == 12      # -5 + 360 = 355 -> round(11.83) = 12
+    assert oracle.rotation_bin(45.0, 0.0) == 2       # round(1.5) = 2: half away from zero
+    assert oracle.rotation_bin(15.0, 0.0) == 1       # round(0.5) = 1
+    assert max(oracle.rotation_bin(a, 0.0) for a in np.arange(0, 360, 0.5)) == 12
+    # computeThreeMaxima (:1631-1668): strict >, 10 % rule
+    h = [0] * 30
+    h[3], h[7], h[9] = 100, 50, 9
+    assert oracle.three_maxima(h) == (3, 7, -1)
+    h[9] = 10
+    assert oracle.three_maxima(h) == (3, 7, 9)
+    h[7] = 9
+    assert oracle.three_maxima(h) == (3, 9, -1)      # 10 is not < 0.1f*100: second kept, third (9) dropped
+    h[9] = 9
+    assert oracle.three_maxima(h) == (3, -1, -1)
+    assert oracle.three_maxima([5, 5, 5] + [0] * 27) == (0, 1, 2)  # ties: earlier bin wins
+    assert oracle.three_maxima([0] * 30) == (-1, -1, -1)
+
+
+def test_thresholds_from_reference_yaml_values(afv):
+    # settings/orb32_settings.yaml:6-11
+    afv.FeatureMatcher.setDescriptorDistanceThresholds({"FeatureMatcher.matchingTh": 75.0})
+    m = afv.FeatureMatcher
+    assert m.TH_LOW == m.TH_HIGH == m.descDistTh_low_reloc == m.descDistTh_high_reloc == 75.0 and m.HISTO_LENGTH == 30
+
+
+# ---------------- stage identities ----------------
+def test_fast_atan2_matches_atan2_within_spec(oracle):
+    rng = np.random.default_rng(1)
+    for _ in range(2000):
+        y, x = rng.integers(-200000, 200000, 2)
+        if x == 0 and y == 0:
+            continue
+        want = math.degrees(math.atan2(y, x)) % 360.0
+        got = oracle.fast_atan2(y, x)
+        d = abs(got - want)
+        assert min(d, 360 - d) < 0.3 and 0.0 <= got <= 360.0  # OpenCV documents ~0.3 degree accuracy
+    assert oracle.fast_atan2(0, 0) == 0.0 and oracle.fast_atan2(0, 5) == 0.0
+    assert abs(oracle.fast_atan2(5, 0) - 90.0) < 1e-3 and abs(oracle.fast_atan2(0, -5) - 180.0) < 1e-3
+
+
+def test_sincos_is_correctly_rounded(oracle):
+    """the explicit double algorithm must agree with libm's double cos/sin rounded to float"""
+    bad = 0
+    angles = np.concatenate([np.linspace(0, 360, 7201, dtype=np.float32), np.float32([33.3, 179.99, 359.9, 0.0, 90.0, 270.0])])
+    for a in angles:
+        c, s = oracle.sincos_deg(a)
+        t = np.float64(np.float32(a) * np.float32(math.pi / np.float32(180.0)))
+        bad += (np.float32(math.cos(t)) != np.float32(c)) + (np.float32(math.sin(t)) != np.float32(s))
+    assert bad == 0
+    assert oracle.sincos_deg(0.0) == (1.0, 0.0)
+
+
+def test_resize_identities(oracle, afv):
+    img = afv.synth.noise_frame(5, 64, 48)
+    assert np.array_equal(oracle.resize_linear_exact(img, 64, 48), img)               # identity
+    c = np.full((48, 64), 173, np.uint8)
+    assert np.all(oracle.resize_linear_exact(c, 53, 40) == 173)                        # weights sum to 256
+    r = oracle.resize_linear_exact(img, 53, 40)
+    assert r.shape == (40, 53)
+    # exact 2:1 decimation = 2x2 box average with round-half-up ((sum*64*64... +2^15)>>16 == (sum+2)>>2)
+    half = oracle.resize_linear_exact(img, 32, 24).astype(int)
+    s = img.astype(int)
+    box = (s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2
+    assert np.array_equal(half, box)
+    # upscale path exercises the clamped borders
+    up = oracle.resize_linear_exact(img[:8, :8], 19, 13)
+    assert up[0, 0] == img[0, 0] and up[-1, -1] == img[7, 7]
+
+
+def test_fast_on_constructed_corner(oracle):
+    img = np.full((32, 32), 100, np.uint8)
+    ring = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0),
+            (-3, 1), (-2, 2), (-1, 3)]
+    cx = cy = 15
+    for k in range(9):  # exactly 9 contiguous brighter pixels, margin 50
+        dx, dy = ring[k]
+        img[cy + dy, cx + dx] = 150
+    x, y, s = oracle.fast9_16(img, 20)
+    assert (cx, cy) in set(zip(x.tolist(), y.tolist()))
+    assert s[list(zip(x.tolist(), y.tolist())).index((cx, cy))] == 49  # largest t with ring > v+t is 49
+    img[cy + ring[4][1], cx + ring[4][0]] = 100  # break the arc: 4 + 4 contiguous only
+    x, y, s = oracle.fast9_16(img, 20)
+    assert (cx, cy) not in set(zip(x.tolist(), y.tolist()))
+    # threshold is strict: margin exactly 20 is not a corner
+    img2 = np.full((32, 32), 100, np.uint8)
+    for k in range(9):
+        dx, dy = ring[k]
+        img2[cy + dy, cx + dx] = 120
+    assert len(oracle.fast9_16(img2, 20)[0]) == 0
+    img2[img2 == 120] = 121
+    x, y, s = oracle.fast9_16(img2, 20)
+    assert (cx, cy) in set(zip(x.tolist(), y.tolist())) and s.max() == 20
+
+
+def test_fast_nms_and_margins(oracle, afv):
+    img = afv.synth.noise_frame(2, 96, 64)
+    x, y, s = oracle.fast9_16(img, 20)
+    assert len(x) > 50
+    assert x.min() >= 3 and y.min() >= 3 and x.max() <= 96 - 4 and y.max() <= 64 - 4
+    sm = oracle.fast_score_map(img, 20).astype(int)
+    for xi, yi, si in zip(x, y, s):
+        nb = sm[yi - 1:yi + 2, xi - 1:xi + 2].copy()
+        assert nb[1, 1] == si
+        nb[1, 1] = -1
+        assert si > nb.max()
+    # raster order (row-major)
+    key = y.astype(np.int64) * 96 + x
+    assert np.all(np.diff(key) > 0)
+
+
+def test_harris_hand_computed(oracle):
+    # vertical step edge: Ix = 4*step on the two columns next to the edge, Iy = 0
+    img = np.zeros((40, 40), np.uint8)
+    img[:, 20:] = 10
+    a, b, c, r = oracle.harris(img, 20, 20)
+    # block columns 17..23; Ix != 0 only at x = 19 and 20: (10-0)*2 + 10 + 10 = 40 -> 2 cols * 7 rows * 1600
+    assert (a, b, c) == (2 * 7 * 1600, 0, 0)
+    assert r == oracle.harris_response(a, b, c) and r < 0  # pure edge: det = 0, -k*trace^2
+    f = np.float32
+    scale = f(1) / f(4 * 7 * 255.0)
+    want = (f(a) * f(b) - f(c) * f(c) - f(0.04) * (f(a) + f(b)) * (f(a) + f(b))) * (scale * scale * scale * scale)
+    assert f(r) == want
+
+
+def test_ic_angle_symmetries(oracle):
+    yy, xx = np.mgrid[0:64, 0:64]
+    right = np.clip(xx * 4, 0, 255).astype(np.uint8)   # brighter to the right -> 0 degrees
+    down = np.clip(yy * 4, 0, 255).astype(np.uint8)    # brighter downwards  -> 90 degrees (image y axis)
+    assert abs(oracle.ic_angle(right, 32, 32)) < 1e-3 or abs(oracle.ic_angle(right, 32, 32) - 360) < 1e-3
+    assert abs(oracle.ic_angle(down, 32, 32) - 90.0) < 1e-3
+    assert abs(oracle.ic_angle(right[:, ::-1].copy(), 31, 32) - 180.0) < 1e-3
+    assert oracle.ic_angle(np.full((64, 64), 9, np.uint8), 32, 32) == 0.0
+
+
+def test_blur_identities(oracle, afv):
+    c = np.full((40, 50), 64, np.uint8)
+    # 257*257*64/65536 = 64.50098 -> 65: the taps sum to 257, not 256 (as in OpenCV's 8U path)
+    assert np.all(oracle.gaussian_blur7(c) == 65)
+    assert np.all(oracle.gaussian_blur7(np.zeros((40, 50), np.uint8)) == 0)
+    assert np.all(oracle.gaussian_blur7(np.full((40, 50), 255, np.uint8)) == 255)  # saturates
+    img = afv.synth.noise_frame(4, 50, 40)
+    b = oracle.gaussian_blur7(img)
+    # direct 2-D evaluation with reflect-101 and round-half-even
+    taps = np.array([18, 34, 49, 55, 49, 34, 18], np.int64)
+    p = np.pad(img.astype(np.int64), 3, mode="reflect")
+    S = np.zeros((40, 50), np.int64)
+    for i in range(7):
+        for j in range(7):
+            S += taps[i] * taps[j] * p[i:i + 40, j:j + 50]
+    q, r = S >> 16, S & 0xFFFF
+    q = q + ((r > 32768) | ((r == 32768) & (q & 1 == 1)))
+    assert np.array_equal(b, np.minimum(q, 255).astype(np.uint8))
+    # symmetric under flips
+    assert np.array_equal(oracle.gaussian_blur7(img[::-1, ::-1].copy()), b[::-1, ::-1])
+
+
+def test_brief_rotation_consistency(oracle, afv):
+    """rotating the image by 90 degrees and the angle by 90 gives the same descriptor (pattern taps land on the same
+    pixels because cos/sin are exact at multiples of 90)"""
+    img = afv.synth.noise_frame(8, 96, 96)
+    bl = oracle.gaussian_blur7(img)
+    d0 = oracle.brief_descriptor(img, bl, 48, 48, 0.0)
+    img90 = np.rot90(img, k=-1).copy()   # clockwise: (x, y) -> (95 - y, x)
+    bl90 = np.rot90(bl, k=-1).copy()
+    d90 = oracle.brief_descriptor(img90, bl90, 95 - 48, 48, 90.0)
+    assert np.array_equal(d0, d90)
+    # bit i of byte b is test 8*b+i: first test compares taps (8,-3) and (9,5)
+    t0 = int(bl[48 - 3, 48 + 8]) < int(bl[48 + 5, 48 + 9])
+    assert (d0[0] & 1) == int(t0)
+
+
+def test_retain_best_semantics(oracle):
+    r = np.float32([5, 1, 5, 3, 9, 3, 3, 0])
+    assert oracle.retain_best_mask(r, 8).all() and oracle.retain_best_mask(r, 100).all()
+    assert oracle.retain_best_mask(r, 1).tolist() == [0, 0, 0, 0, 1, 0, 0, 0]
+    assert oracle.retain_best_mask(r, 2).tolist() == [1, 0, 1, 0, 1, 0, 0, 0]   # ties at the boundary are all kept
+    assert oracle.retain_best_mask(r, 4).sum() == 6
+    assert oracle.retain_best_mask(r, 0).sum() == 0
+
+
+def test_quadtree_properties(oracle, afv):
+    s = afv.synth
+    for (n, N) in [(0, 217), (1, 217), (2, 217), (217, 217), (3000, 217), (3000, 60), (20000, 434), (500, 1000)]:
+        st = s.lcg_states(n + N, 3 * max(n, 1))
+        px = (st[:n] % 6400).astype(np.float32) / 10.0
+        py = (st[n:2 * n] % 4800).astype(np.float32) / 10.0
+        resp = (st[2 * n:3 * n] % 1000).astype(np.float32)
+        tb = np.arange(n, dtype=np.int64)
+        sel = oracle.quadtree(px, py, resp, N, 640, 480, tb)
+        assert len(set(sel.tolist())) == len(sel)
+        if n == 0:
+            assert len(sel) == 0
+            continue
+        distinct = len(set(zip(px.tolist(), py.tolist())))
+        if distinct >= N + 3:
+            assert N <= len(sel) <= N + 2, (n, N, len(sel))     # ORBextractor.cc:427: each split is net <= +3
+        else:
+            assert len(sel) <= distinct
+        # order independence: shuffling the input (with raster tie-break ids) selects the same points in the same order
+        perm = np.argsort(s.lcg_states(7, n), kind="stable")
+        sel2 = oracle.quadtree(px[perm], py[perm], resp[perm], N, 640, 480, tb[perm])
+        assert np.array_equal(perm[sel2], sel)
+
+
+def test_quadtree_picks_max_response_per_cell(oracle):
+    # four points in four different quadrants + a weaker twin next to each: N = 4 keeps the strong ones
+    px = np.float32([100, 101, 500, 501, 100, 101, 500, 501])
+    py = np.float32([100, 101, 100, 101, 400, 401, 400, 401])
+    resp = np.float32([1, 2, 4, 3, 5, 6, 8, 7])
+    sel = oracle.quadtree(px, py, resp, 4, 640, 480)
+    assert sorted(sel.tolist()) == [1, 2, 5, 6]
+    # list order: children are pushed front n1..n4 => n4 (bottom right) first
+    assert sel.tolist() == [6, 5, 2, 1]
+
+
+def test_extract_variants_agree(oracle, afv):
+    img = afv.synth.corners_frame(5, 320, 240)
+    k0, d0 = oracle.orb_extract(img, variant=0)
+    k1, d1 = oracle.orb_extract(img, variant=1)
+    assert k0.tobytes() == k1.tobytes() and np.array_equal(d0, d1) and len(k0) > 300
+
+
+def test_extract_structure(oracle, afv):
+    img = afv.synth.corners_frame(1)
+    kps, desc, tr = oracle.orb_extract_trace(img)
+    q = oracle.quotas_extractor(1000)
+    assert all(q[l] <= tr["t_counts"][l] <= q[l] + 2 for l in range(8))
+    assert np.all(np.diff(kps["octave"]) >= 0)                       # mergeKeypointLevels: ascending level
+    assert np.all(kps["class_id"] == -1) and np.all((kps["angle"] >= 0) & (kps["angle"] <= 360))
+    ls = np.float32(tr["lscale"])
+    assert np.array_equal(kps["size"], np.float32(31) * ls[kps["octave"]])
+    # edgeThreshold = 0: keypoints may sit 3 px from the level border (Feature_orb32.cpp:23)
+    xl = np.rint(kps["x"] / ls[kps["octave"]]).astype(int)
+    assert xl.min() >= 3
+    # keep2 subset of keep1; retainBest thresholds respected
+    assert not np.any(tr["keep2"] & ~tr["keep1"])
+    assert len(oracle.orb_extract(afv.synth.constant_frame(50))[0]) == 0
+
+
+def test_size_sigma(oracle):
+    k = np.zeros(8, oracle.KP_DTYPE)
+    k["octave"] = np.arange(8)
+    size, s2, inf = oracle.size_sigma(k)
+    assert size[0] == 1.0 and abs(size[7] - 1.2 ** 7) < 1e-5
+    assert np.allclose(s2, size * size) and np.allclose(inf * s2, 1.0)
+
+
+# ---------------- matcher restatement: hand-checkable cases ----------------
+def _d(bits):
+    d = np.zeros(32, np.uint8)
+    for b in range(bits):
+        d[b // 8] |= 1 << (b % 8)
+    return d
+
+
+def test_m2_greedy_order_dependence(oracle):
+    """SearchByBoW(KF,KF) is greedy: an earlier row takes the column, a later row must settle for its next best"""
+    d1 = np.stack([_d(0), _d(2)])
+    d2 = np.stack([_d(1), _d(40)])
+    m, n = oracle.search_by_bow_kf_kf(d1, d2, th_low=75.0, nnratio=0.6)
+    # row 0: dists (1, 40) -> takes col 0; row 1: col 0 gone -> only col 1 (38), second = FLT_MAX -> accepted
+    assert m.tolist() == [0, 1] and n == 2
+    m, n = oracle.search_by_bow_kf_kf(d1[::-1].copy(), d2, th_low=75.0, nnratio=0.6)
+    # reversed rows: row 0 (= _d(2)): dists (1, 38) -> col 0; row 1 (= _d(0)): only col 1 (40) -> accepted
+    assert m.tolist() == [0, 1] and n == 2
+    m, n = oracle.search_by_bow_kf_kf(d1, d2, th_low=30.0, nnratio=0.6)
+    assert m.tolist() == [0, -1] and n == 1
+
+
+def test_m3_indexing_and_inclusive_threshold(oracle):
+    dkf = np.stack([_d(0), _d(100)])
+    df = np.stack([_d(75), _d(101), _d(200)])
+    out, n = oracle.search_by_bow_kf_frame(dkf, df, th_low=75.0, nnratio=0.9)
+    # KF0: dists (75,101,200): best 75 <= 75 and 75 < 0.9*101 -> F0 := KF0.  KF1: F0 taken; dists to F1,F2 = (1,100) -> F1 := KF1
+    assert out.tolist() == [0, 1, -1] and n == 2
+    out, n = oracle.search_by_bow_kf_kf(dkf, df, th_low=75.0, nnratio=0.9)
+    assert out.tolist() == [-1, 1] and n == 1   # strict < in the KF-KF flavour
+
+
+def test_m2_validity_and_nodes(oracle):
+    d1 = np.stack([_d(0), _d(0), _d(0)])
+    d2 = np.stack([_d(1), _d(2), _d(3)])
+    # node 5 holds {0,1} x {1,2}; node 9 holds {2} x {0}
+    fv1 = [(5, [0, 1]), (9, [2])]
+    fv2 = [(5, [1, 2]), (7, []), (9, [0])]
+    m, n = oracle.search_by_bow_kf_kf(d1, d2, fv1, fv2, th_low=75.0, nnratio=1.0)
+    # row0 in node5: dists (2,3) -> col1 (2 < 1.0*3).  row1: only col2 left, second FLT_MAX -> col2.  row2 node9 -> col0
+    assert m.tolist() == [1, 2, 0] and n == 3
+    m, n = oracle.search_by_bow_kf_kf(d1, d2, fv1, fv2, valid1=[1, 0, 1], valid2=[1, 1, 1], th_low=75.0, nnratio=1.0)
+    assert m.tolist() == [1, -1, 0]
+    m, n = oracle.search_by_bow_kf_kf(d1, d2, fv1, fv2, valid1=[1, 1, 1], valid2=[0, 0, 1], th_low=75.0, nnratio=1.0)
+    assert m.tolist() == [2, -1, -1] and n == 1
+
+
+def test_m4_last_minimum_wins_and_epipolar_gate(oracle):
+    d1 = np.stack([_d(0)])
+    d2 = np.stack([_d(10), _d(10), _d(50)])
+    p1 = np.float32([[100, 100]])
+    p2 = np.float32([[50, 100], [60, 100], [70, 300]])
+    F = np.float32([[0, 0, 0], [0, 0, -1], [0, 1, 0]])     # line in image 2: y2 = y1
+    s2 = np.float32([1, 1, 1])
+    m, n = oracle.search_for_triangulation(d1, d2, p1, p2, s2, F, (1e6, 0.0), th_low=75.0)
+    assert m.tolist() == [1] and n == 1                     # equal distances: the LATER column wins (<=, :736)
+    p2[1, 1] = 103.0                                        # 9 px^2 off the line > 3.84 * sigma^2
+    m, n = oracle.search_for_triangulation(d1, d2, p1, p2, s2, F, (1e6, 0.0), th_low=75.0)
+    assert m.tolist() == [0]
+    m, n = oracle.search_for_triangulation(d1, d2, p1, p2, s2, F, (50.0, 100.0), th_low=75.0)
+    assert m.tolist() == [-1] and n == 0                    # col 0 sits on the epipole (:741-748), col 1 off the line
+    m, n = oracle.search_for_triangulation(d1, d2, p1, p2, s2, F, (1e6, 0.0), has_mp1=[1], th_low=75.0)
+    assert m.tolist() == [-1]
+
+
+def test_l2sqr(oracle):
+    a = np.float32([1, 2, 3, 4, 5]); b = np.float32([0, 0, 0, 0, 0])
+    assert oracle.l2sqr(a, b) == 55.0
+    rng = np.random.default_rng(3)
+    x = rng.random(128, dtype=np.float32); y = rng.random(128, dtype=np.float32)
+    assert abs(oracle.l2sqr(x, y) - float(((x.astype(np.float64) - y) ** 2).sum())) < 1e-4
+
+
+# ---------------- committed golden fixtures ----------------
+@pytest.mark.parametrize("name", ["toy", "corners1", "corners2", "noise3"])
+def test_oracle_reproduces_golden(oracle, afv, gold, name):
+    if name == "toy":
+        img = np.load(os.path.join(GOLD, "toy_gray.npz"))["gray"]
+    elif name == "noise3":
+        img = afv.synth.noise_frame(3)
+    else:
+        img = afv.synth.corners_frame(int(name[-1]))
+    kps, desc, tr = oracle.orb_extract_trace(img)
+    assert kps.tobytes() == gold[name + "_kps"].tobytes()
+    assert np.array_equal(desc, gold[name + "_desc"])
+    assert [zlib.crc32(l.tobytes()) for l in tr["level"]] == gold[name + "_level_crc"].tolist()
+    assert [zlib.crc32(l.tobytes()) for l in tr["blurred"]] == gold[name + "_blur_crc"].tolist()
+    assert tr["t_counts"] == gold[name + "_tcounts"].tolist()
+
+
+def test_golden_matcher_vector(oracle, afv, gold):
+    m, n = oracle.search_by_bow_kf_kf(gold["shift4_desc"], gold["corners1_desc"], angle1=gold["shift4_kps"]["angle"],
+                                      angle2=gold["corners1_kps"]["angle"], th_low=75.0, nnratio=0.6, check_orientation=True)
+    assert n == int(gold["shift4_nmatches"][0]) and np.array_equal(m, gold["shift4_match12"])
+    # a 4 px shift must mostly match keypoints 4 px apart
+    ok = m >= 0
+    dx = gold["shift4_kps"]["x"][ok] - gold["corners1_kps"]["x"][m[ok]]
+    assert np.mean(np.abs(dx - 4.0 * 1.0) < 8.0) > 0.9 and n > 300
