@@ -46,6 +46,9 @@ extern "C" void afv_launch_match_bow(const DevMatchJob *jobs, int njobs, hipStre
 extern "C" void afv_launch_match_pairs(const uint8_t *desc, const afv_keypoint *kps, const int *nset, int cap, const int *pa,
                                        const int *pb, int npairs, float th, float ratio, int check_ori, int *match,
                                        int *nmatches, hipStream_t stream);
+extern "C" void afv_launch_match_pairs2(const uint8_t *desc, const afv_keypoint *kps, const int *nset, int cap, const int *pa,
+                                        const int *pb, int npairs, float th, float ratio, int check_ori, int *match,
+                                        int *nmatches, void *topk_scratch, hipStream_t stream);
 extern "C" void afv_launch_match_tri(const DevTriJob *jobs, int njobs, hipStream_t stream);
 extern "C" void afv_launch_match_l2(const float *d1, int n1, const float *d2, int n2, int dim, const uint8_t *v1,
                                     const uint8_t *v2, float th, float ratio, int *out, int *nmatches, hipStream_t stream);
@@ -83,6 +86,8 @@ struct afv_ctx {
     // matcher staging (grow only)
     uint8_t *d_match = nullptr;
     size_t match_bytes = 0;
+    void *d_topk = nullptr;  // [npairs][cap] int4: top-4 (distance, column) keys per row
+    size_t topk_bytes = 0;
     // last extraction (debug getters)
     FrameSrc last_src{};
     int last_nframes = 0;
@@ -304,7 +309,7 @@ extern "C" void afv_destroy(afv_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_geo, c->d_tab, c->d_pyr, c->d_cand_packed, c->d_kept_xy, c->d_cand_resp, c->d_kept_resp,
                     c->d_kept_node, c->d_cand_count, c->d_sel_count, c->d_sel, c->d_frames, c->d_kps, c->d_desc,
-                    c->d_n, c->d_status, c->d_match};
+                    c->d_n, c->d_status, c->d_match, c->d_topk};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &v : c->prof_ev)
@@ -871,9 +876,18 @@ extern "C" int afv_match_bruteforce_pairs_device(afv_ctx *c, const uint8_t *d_de
     HIPCHK(c, hipSetDevice(c->device));
     {
         hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+        const size_t need = (size_t)npairs * cap * 16;
+        if (need > c->topk_bytes) {  // grow-only scratch (first call / larger batch): implies a device sync
+            HIPCHK(c, hipDeviceSynchronize());
+            if (c->d_topk) (void)hipFree(c->d_topk);
+            c->d_topk = nullptr;
+            c->topk_bytes = 0;
+            HIPCHK(c, hipMalloc(&c->d_topk, need));
+            c->topk_bytes = need;
+        }
         StageTimer t_(c, AFV_STAGE_MATCH, s);
-        afv_launch_match_pairs(d_desc, d_kps, d_n, cap, d_pair_a, d_pair_b, npairs, th_low, nnratio, check_orientation, d_match,
-                               d_nmatches, s);
+        afv_launch_match_pairs2(d_desc, d_kps, d_n, cap, d_pair_a, d_pair_b, npairs, th_low, nnratio, check_orientation, d_match,
+                                d_nmatches, c->d_topk, s);
     }
     HIPCHK(c, hipGetLastError());
     return AFV_OK;
