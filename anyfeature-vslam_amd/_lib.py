@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libafv_hip.so")
+LIB_PATH = os.environ.get("AFV_LIB_PATH") or os.path.join(_HERE, "libafv_hip.so")  # override: kernel experiments only
 
 MAX_LEVELS = 8
 DESC_BYTES = 32

@@ -23,11 +23,13 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, extra_flags=(), out=None, objdir=None):
+    """extra_flags/out/objdir: kernel experiments (tools/experiments.py) build variant libraries next to the real one"""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    objdir = os.path.join(HERE, "build")
+    objdir = objdir or os.path.join(HERE, "build")
+    out = out or OUT
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, "afv_device.h"), os.path.join(CSRC, "brief_pattern.inc"),
                os.path.join(HERE, "..", "include", "afv_hip.h"), os.path.abspath(__file__)]
@@ -37,16 +39,16 @@ def build(force=False, verbose=False):
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)
-    if force or _stale(OUT, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    if force or _stale(out, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

@@ -5,62 +5,126 @@
 // HarrisResponses(blockSize 7, k 0.04) (OpenCV orb.cpp).  One 256-thread workgroup owns a 64x32 tile:
 //   1. the tile plus a 4 px halo is staged in LDS with coalesced dword loads (reflect-101 at the image edge —
 //      FAST never reads it, Harris does, exactly like cv::ORB's 23 px apron);
-//   2. every pixel of the 66x34 inner ring gets its corner score = largest threshold for which it is still a
-//      9-arc corner (sliding-window min/max over the 16 ring differences, packed 2 x i16 per VGPR);
-//   3. strict 3x3 maxima are compacted into an LDS list (<= 512 per tile);
-//   4. the list is processed densely: integer Harris sums a,b,c over the 7x7 block from LDS, one float
+//   2a. every pixel of the 66x34 ring-extended tile takes OpenCV's necessary pre-test (each of the 4 even antipodal
+//      ring pairs must hold a darker / a brighter pixel), evaluated on packed (v-r, r-v) i16 pairs; survivors are
+//      compacted into an LDS list so that
+//   2b. the exact corner score = largest threshold for which the pixel is still a 9-arc corner runs on dense
+//      wavefronts: 16 ring differences packed as (v-r, r-v), van-Herk prefix/suffix minima over the two ring halves
+//      (59 packed min/max for both polarities), corner iff score > threshold;
+//   3. strict 3x3 maxima are compacted into a second LDS list (<= 512 per tile);
+//   4. that list is processed densely: integer Harris sums a,b,c over the 7x7 block from LDS, one float
 //      expression for the response;
 //   5. one global atomic per tile reserves output slots in the (frame, level) candidate array.
+// Thread (tx, ty) = (tid & 63, tid >> 6) walks rows ty, ty+4, ...: no integer division, row validity is wave-uniform.
 // Candidates leave the kernel unordered; everything downstream is order-independent (ties are broken by the
 // raster index), see DESIGN.md "canonical order".
 #include "afv_device.h"
 
+#ifndef AFV_EXP
+#define AFV_EXP 0
+#endif
+
 typedef short short2v __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ short2v pk(int lo, int hi) {
-    short2v r;
-    r.x = (short)lo;
-    r.y = (short)hi;
-    return r;
-}
 __device__ __forceinline__ short2v pkmin(short2v a, short2v b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ short2v pkmax(short2v a, short2v b) { return __builtin_elementwise_max(a, b); }
 
+// packed ring difference (v - r, r - v) = (r, r) * (-1, +1) + (v, -v): one v_pk_mad_i16 per ring pixel
+__device__ __forceinline__ short2v ring_diff(const uint8_t *c, int off, short2v vn) {
+    const short r = (short)c[off];
+    short2v R;
+    R.x = r;
+    R.y = r;
+    short2v K;
+    K.x = -1;
+    K.y = 1;
+    return R * K + vn;
+}
+
+#define RING_OFF(dx, dy) ((dy) * FT_LW + (dx))
+
+// OpenCV pre-test on the even antipodal pairs (0,8) (2,10) (4,12) (6,14): lo halves carry "darker", hi "brighter"
+__device__ __forceinline__ bool fast_pretest(const uint8_t *c, int threshold) {
+    const short v = (short)c[0];
+    short2v vn;
+    vn.x = v;
+    vn.y = (short)-v;
+    const short2v m0 = pkmax(ring_diff(c, RING_OFF(0, 3), vn), ring_diff(c, RING_OFF(0, -3), vn));
+    const short2v m2 = pkmax(ring_diff(c, RING_OFF(2, 2), vn), ring_diff(c, RING_OFF(-2, -2), vn));
+    const short2v m4 = pkmax(ring_diff(c, RING_OFF(3, 0), vn), ring_diff(c, RING_OFF(-3, 0), vn));
+    const short2v m6 = pkmax(ring_diff(c, RING_OFF(2, -2), vn), ring_diff(c, RING_OFF(-2, 2), vn));
+    const short2v m = pkmin(pkmin(m0, m2), pkmin(m4, m6));
+    return max((int)m.x, (int)m.y) > threshold;
+}
 
 // score = max over the 16 arcs of 9 contiguous ring pixels of min(v - ring) [dark arc] and of min(ring - v)
 // [bright arc]; corner iff score > threshold; cornerScore<16> returns score - 1.
 __device__ __forceinline__ int fast_score(const uint8_t *c, int threshold) {
-    const int v = c[0];
+    const short v = (short)c[0];
+    short2v vn;
+    vn.x = v;
+    vn.y = (short)-v;
     short2v d[16];
+    d[0] = ring_diff(c, RING_OFF(0, 3), vn);
+    d[1] = ring_diff(c, RING_OFF(1, 3), vn);
+    d[2] = ring_diff(c, RING_OFF(2, 2), vn);
+    d[3] = ring_diff(c, RING_OFF(3, 1), vn);
+    d[4] = ring_diff(c, RING_OFF(3, 0), vn);
+    d[5] = ring_diff(c, RING_OFF(3, -1), vn);
+    d[6] = ring_diff(c, RING_OFF(2, -2), vn);
+    d[7] = ring_diff(c, RING_OFF(1, -3), vn);
+    d[8] = ring_diff(c, RING_OFF(0, -3), vn);
+    d[9] = ring_diff(c, RING_OFF(-1, -3), vn);
+    d[10] = ring_diff(c, RING_OFF(-2, -2), vn);
+    d[11] = ring_diff(c, RING_OFF(-3, -1), vn);
+    d[12] = ring_diff(c, RING_OFF(-3, 0), vn);
+    d[13] = ring_diff(c, RING_OFF(-3, 1), vn);
+    d[14] = ring_diff(c, RING_OFF(-2, 2), vn);
+    d[15] = ring_diff(c, RING_OFF(-1, 3), vn);
+    // van Herk: window k (9 long, circular) = suffix of its ring half starting at k + prefix of the other half
+    short2v suf0[8], pre0[8], suf1[8], pre1[8];
+    suf0[7] = d[7];
+    suf1[7] = d[15];
+    pre0[0] = d[0];
+    pre1[0] = d[8];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        // compile-time ring offsets (the loop is fully unrolled)
-        constexpr int dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
-        constexpr int dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
-        const int diff = v - (int)c[dy[k] * FT_LW + dx[k]];
-        d[k] = pk(diff, -diff);
+    for (int k = 6; k >= 0; --k) {
+        suf0[k] = pkmin(d[k], suf0[k + 1]);
+        suf1[k] = pkmin(d[8 + k], suf1[k + 1]);
     }
-    short2v m2[16], m4[16], m8[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) m2[k] = pkmin(d[k], d[(k + 1) & 15]);
+    for (int k = 1; k < 8; ++k) {
+        pre0[k] = pkmin(d[k], pre0[k - 1]);
+        pre1[k] = pkmin(d[8 + k], pre1[k - 1]);
+    }
+    short2v best = pkmin(suf0[0], pre1[0]);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) m4[k] = pkmin(m2[k], m2[(k + 2) & 15]);
+    for (int k = 1; k < 8; ++k) best = pkmax(best, pkmin(suf0[k], pre1[k]));
 #pragma unroll
-    for (int k = 0; k < 16; ++k) m8[k] = pkmin(m4[k], m4[(k + 4) & 15]);
-    short2v best = pkmin(m8[0], d[8]);
-#pragma unroll
-    for (int k = 1; k < 16; ++k) best = pkmax(best, pkmin(m8[k], d[(k + 8) & 15]));
+    for (int k = 0; k < 8; ++k) best = pkmax(best, pkmin(suf1[k], pre0[k]));
     const int s = max((int)best.x, (int)best.y);
     return s > threshold ? s - 1 : 0;
+}
+
+// wave-aggregated append of `val` to an LDS list (one LDS atomic per wavefront)
+__device__ __forceinline__ void wave_push(bool pred, unsigned short *list, int *count, unsigned short val, int lane) {
+    const unsigned long long m = __ballot(pred);
+    if (m) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(count, __popcll(m));
+        base = __shfl(base, 0, 64);
+        if (pred) list[base + __popcll(m & ((1ull << lane) - 1ull))] = val;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_fast_harris(const Geo *__restrict__ geo_p, FrameSrc src0, const uint8_t *__restrict__ pyr,
                                                      uint32_t *__restrict__ cand_packed, float *__restrict__ cand_resp,
                                                      int *__restrict__ cand_count) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[FT_LH * FT_LW];
-    __shared__ uint8_t sc[(FT_H + 2) * 68];
+    __shared__ __attribute__((aligned(16))) uint8_t sc[FT_LH * FT_LW];  // same geometry as `tile`
+    __shared__ unsigned short pre[(FT_W + 2) * (FT_H + 2)];
     __shared__ uint32_t list[512];
-    __shared__ int list_n, out_base;
+    __shared__ int list_n, out_base, pre_n;
 
     const Geo &geo = *geo_p;
     const int f = blockIdx.y;
@@ -70,9 +134,10 @@ __global__ __launch_bounds__(256) void k_fast_harris(const Geo *__restrict__ geo
         if (i < geo.nlevels && (int)blockIdx.x >= geo.lv[i].tile_base) l = i;
     const LevelGeo &L = geo.lv[l];
     const int t = blockIdx.x - L.tile_base;
-    const int ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
-    const int gx0 = tx * FT_W - FT_HALO, gy0 = ty * FT_H - FT_HALO;
+    const int tyi = t / L.tiles_x, txi = t - tyi * L.tiles_x;
+    const int gx0 = txi * FT_W - FT_HALO, gy0 = tyi * FT_H - FT_HALO;
     const int lw = L.w, lh = L.h;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, lane = tx;
 
     const uint8_t *img;
     int pitch;
@@ -83,9 +148,12 @@ __global__ __launch_bounds__(256) void k_fast_harris(const Geo *__restrict__ geo
         img = pyr + L.pyr_off + (size_t)f * L.pyr_frame_stride;
         pitch = L.pitch;
     }
-    if (threadIdx.x == 0) list_n = 0;
+    if (threadIdx.x == 0) {
+        list_n = 0;
+        pre_n = 0;
+    }
 
-    // 1. stage 72x40 bytes: 18 dwords per row
+    // 1. stage 72x40 bytes: 18 dwords per row; clear the score plane
     for (int i = threadIdx.x; i < FT_LH * (FT_LW / 4); i += 256) {
         const int ry = i / (FT_LW / 4), rq = i - ry * (FT_LW / 4);
         int gy = gy0 + ry;
@@ -104,55 +172,108 @@ __global__ __launch_bounds__(256) void k_fast_harris(const Geo *__restrict__ geo
             }
         }
         *reinterpret_cast<uint32_t *>(&tile[ry * FT_LW + rq * 4]) = v;
+        *reinterpret_cast<uint32_t *>(&sc[ry * FT_LW + rq * 4]) = 0u;
     }
     __syncthreads();
 
-    // 2. scores on the 66x34 ring-extended tile
+#if AFV_EXP == 1
+    if (tile[threadIdx.x] == 300) cand_count[0] = 1;
+    return;
+#endif
+    // 2a. pre-test on LDS rows 3..36 x columns 3..68 (= tile pixels -1..64 x -1..32); survivors -> `pre`
     const int thr = geo.fast_threshold;
-    for (int i = threadIdx.x; i < (FT_W + 2) * (FT_H + 2); i += 256) {
-        const int sy = i / (FT_W + 2), sx = i - sy * (FT_W + 2);  // position (sx-1, sy-1) relative to the tile
-        const int gx = gx0 + FT_HALO - 1 + sx, gy = gy0 + FT_HALO - 1 + sy;
-        int s = 0;
-        if (gx >= 3 && gx < lw - 3 && gy >= 3 && gy < lh - 3) s = fast_score(&tile[(sy + 3) * FT_LW + (sx + 3)], thr);
-        sc[sy * 68 + sx] = (uint8_t)s;
+    {
+        const int col = 3 + tx, gx = gx0 + col;
+        const bool col_ok = gx >= 3 && gx < lw - 3;
+        for (int r = ty; r < FT_H + 2; r += 4) {  // wave-uniform row
+            const int gy = gy0 + 3 + r;
+            if (gy < 3 || gy >= lh - 3) continue;
+            const int p = (r + 3) * FT_LW + col;
+            wave_push(col_ok && fast_pretest(&tile[p], thr), pre, &pre_n, (unsigned short)p, lane);
+        }
+        if (threadIdx.x < 128) {  // the two extra columns 67, 68: 34 rows x 2 = 68 positions on waves 0 and 1
+            const int r = threadIdx.x >> 1, c2 = 67 + (threadIdx.x & 1);
+            const int gy = gy0 + 3 + r, gx2 = gx0 + c2;
+            const bool ok = r < FT_H + 2 && gy >= 3 && gy < lh - 3 && gx2 >= 3 && gx2 < lw - 3;
+            const int p = (r + 3) * FT_LW + c2;
+            wave_push(ok && fast_pretest(&tile[ok ? p : 4 * FT_LW + 4], thr), pre, &pre_n, (unsigned short)p, lane);
+        }
+    }
+    __syncthreads();
+#if AFV_EXP == 2
+    if (pre_n == 70000) cand_count[0] = 1;
+    return;
+#endif
+    // 2b. exact corner score for the survivors (dense)
+    const int npre = pre_n;
+    for (int i = threadIdx.x; i < npre; i += 256) {
+        const int p = pre[i];
+        sc[p] = (uint8_t)fast_score(&tile[p], thr);
     }
     __syncthreads();
 
-    // 3. strict 3x3 maxima -> LDS list
-    for (int i = threadIdx.x; i < FT_W * FT_H; i += 256) {
-        const int py = i >> 6, px = i & 63;
-        const uint8_t *p = &sc[(py + 1) * 68 + (px + 1)];
+#if AFV_EXP == 3
+    if (sc[threadIdx.x * 11] == 255) cand_count[0] = 1;
+    return;
+#endif
+    // 3. strict 3x3 maxima over the 64x32 interior -> LDS list
+    for (int r = ty; r < FT_H; r += 4) {
+        const uint8_t *p = &sc[(r + FT_HALO) * FT_LW + (tx + FT_HALO)];
         const int s = p[0];
-        if (s != 0 && s > p[-1] && s > p[1] && s > p[-69] && s > p[-68] && s > p[-67] && s > p[67] && s > p[68] &&
-            s > p[69]) {
-            const int slot = atomicAdd(&list_n, 1);
-            list[slot] = (uint32_t)px | ((uint32_t)py << 8) | ((uint32_t)s << 16);
+        const bool keep = s != 0 && s > p[-1] && s > p[1] && s > p[-FT_LW - 1] && s > p[-FT_LW] && s > p[-FT_LW + 1] &&
+                          s > p[FT_LW - 1] && s > p[FT_LW] && s > p[FT_LW + 1];
+        const unsigned long long m = __ballot(keep);
+        if (m) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&list_n, __popcll(m));
+            base = __shfl(base, 0, 64);
+            if (keep) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)tx | ((uint32_t)r << 8) | ((uint32_t)s << 16);
         }
     }
     __syncthreads();
     const int n = list_n;
     if (n == 0) return;
+#if AFV_EXP == 4
+    if (n == 70000) cand_count[0] = 1;
+    return;
+#endif
     if (threadIdx.x == 0) out_base = atomicAdd(&cand_count[f * AFV_MAX_LEVELS + l], n);
     __syncthreads();
 
-    // 4. Harris response for the compacted candidates
+    // 4. Harris response for the compacted candidates: 8 lanes per candidate, lane `sub` owns block row sub-3 (3 source
+    //    rows of 9 pixels -> 7 gradient pairs), partial integer sums are combined with 3 xor-shuffles.  All four
+    //    wavefronts share the work, so no wave is left with a long serial tail.
     const size_t obase = L.cand_off + (size_t)f * L.cand_frame_stride + (size_t)out_base;
-    for (int ci = threadIdx.x; ci < n; ci += 256) {
-        const uint32_t e = list[ci];
+    const int sub = threadIdx.x & 7;
+    for (int c0 = 0; c0 < n; c0 += 32) {
+        const int ci = c0 + (threadIdx.x >> 3);
+        const bool act = ci < n;
+        const uint32_t e = list[act ? ci : 0];
         const int px = e & 255, py = (e >> 8) & 255, s = e >> 16;
-        const uint8_t *c = &tile[(py + FT_HALO) * FT_LW + (px + FT_HALO)];
         int a = 0, b = 0, cc = 0;
-        // rows r-1, r, r+1 of 9 pixels slide down over the 7 block rows
-        int r0[9], r1[9], r2[9];
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            r0[j] = c[-4 * FT_LW + (j - 4)];
-            r1[j] = c[-3 * FT_LW + (j - 4)];
-        }
-#pragma unroll
-        for (int i = -3; i <= 3; ++i) {
-#pragma unroll
-            for (int j = 0; j < 9; ++j) r2[j] = c[(i + 1) * FT_LW + (j - 4)];
+        if (act && sub < 7 && AFV_EXP != 6) {
+            const uint8_t *c = &tile[(py + FT_HALO + (sub - 3)) * FT_LW + (px + FT_HALO)];
+            // 3 source rows x 9 pixels [x-4, x+4]: three aligned dwords per row, funnel-shifted so that byte k of the
+            // row sits at a lane-independent position (bytes are then picked with static SDWA selects)
+            int r0[9], r1[9], r2[9];
+            const int xa = (px + FT_HALO - 4) & ~3, sh = ((px + FT_HALO - 4) & 3) * 8;
+            const uint8_t *rowp = &tile[(py + FT_HALO + (sub - 3) - 1) * FT_LW + xa];
+#define LOAD_ROW(R, PTR)                                                                      \
+    {                                                                                         \
+        const uint32_t w0 = *reinterpret_cast<const uint32_t *>(PTR);                          \
+        const uint32_t w1 = *reinterpret_cast<const uint32_t *>((PTR) + 4);                    \
+        const uint32_t w2 = *reinterpret_cast<const uint32_t *>((PTR) + 8);                    \
+        const uint32_t a0 = __builtin_amdgcn_alignbit(w1, w0, sh), a1 = __builtin_amdgcn_alignbit(w2, w1, sh); \
+        const uint32_t a2 = w2 >> sh;                                                          \
+        R[0] = a0 & 255; R[1] = (a0 >> 8) & 255; R[2] = (a0 >> 16) & 255; R[3] = a0 >> 24;     \
+        R[4] = a1 & 255; R[5] = (a1 >> 8) & 255; R[6] = (a1 >> 16) & 255; R[7] = a1 >> 24;     \
+        R[8] = a2 & 255;                                                                       \
+    }
+            LOAD_ROW(r0, rowp)
+            LOAD_ROW(r1, rowp + FT_LW)
+            LOAD_ROW(r2, rowp + 2 * FT_LW)
+#undef LOAD_ROW
+            (void)c;
 #pragma unroll
             for (int j = 1; j <= 7; ++j) {
                 const int Ix = (r1[j + 1] - r1[j - 1]) * 2 + (r0[j + 1] - r0[j - 1]) + (r2[j + 1] - r2[j - 1]);
@@ -161,18 +282,21 @@ __global__ __launch_bounds__(256) void k_fast_harris(const Geo *__restrict__ geo
                 b += Iy * Iy;
                 cc += Ix * Iy;
             }
-#pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                r0[j] = r1[j];
-                r1[j] = r2[j];
-            }
         }
-        const float fa = (float)a, fb = (float)b, fc = (float)cc;
-        const float sum = fa + fb;
-        const float resp = ((fa * fb - fc * fc) - (0.04f * sum) * sum) * geo.harris_scale4;
-        const int gx = gx0 + FT_HALO + px, gy = gy0 + FT_HALO + py;
-        cand_packed[obase + ci] = (uint32_t)gx | ((uint32_t)gy << 12) | ((uint32_t)s << 24);
-        cand_resp[obase + ci] = resp;
+#pragma unroll
+        for (int m = 1; m <= 4; m <<= 1) {
+            a += __shfl_xor(a, m, 64);
+            b += __shfl_xor(b, m, 64);
+            cc += __shfl_xor(cc, m, 64);
+        }
+        if (act && sub == 0 && (AFV_EXP != 5 || a == 123456789)) {
+            const float fa = (float)a, fb = (float)b, fc = (float)cc;
+            const float sum = fa + fb;
+            const float resp = ((fa * fb - fc * fc) - (0.04f * sum) * sum) * geo.harris_scale4;
+            const int gx = gx0 + FT_HALO + px, gy = gy0 + FT_HALO + py;
+            cand_packed[obase + ci] = (uint32_t)gx | ((uint32_t)gy << 12) | ((uint32_t)s << 24);
+            cand_resp[obase + ci] = resp;
+        }
     }
 }
 

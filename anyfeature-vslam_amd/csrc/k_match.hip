@@ -255,7 +255,7 @@ __global__ __launch_bounds__(MT) void k_match_topk(const uint8_t *__restrict__ d
     if (row < n1) topk[(size_t)p * cap + row] = make_int4(k[0], k[1], k[2], k[3]);
 }
 
-__global__ __launch_bounds__(64) void k_match_resolve(const uint8_t *__restrict__ desc, const afv_keypoint *__restrict__ kps,
+__global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict__ desc, const afv_keypoint *__restrict__ kps,
                                                       const int *__restrict__ nset, int cap, const int *__restrict__ pair_a,
                                                       const int *__restrict__ pair_b, const int4 *__restrict__ topk, float th,
                                                       float ratio, int check_ori, int *__restrict__ match,
@@ -263,113 +263,132 @@ __global__ __launch_bounds__(64) void k_match_resolve(const uint8_t *__restrict_
     __shared__ uint32_t s_matched[MAX_SIDE / 32];
     __shared__ uint8_t s_bin[MAX_SIDE];
     __shared__ unsigned short s_live[MAX_SIDE];
+    __shared__ __attribute__((aligned(16))) int4 s_keys[2048];  // top-4 keys of the live rows (first 2048 of them)
     __shared__ int s_hist[32];
-    const int p = blockIdx.x, lane = threadIdx.x;
+    __shared__ int s_wave[8];
+    __shared__ int s_nm, s_drop[3];
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int a = pair_a[p], b = pair_b[p];
     const int n1 = min(nset[a], cap), n2 = min(nset[b], cap);
     const int4 *tk = topk + (size_t)p * cap;
     int *out = match + (size_t)p * cap;
-    for (int i = lane; i < cap; i += 64) out[i] = -1;
-    for (int i = lane; i < (n2 + 31) / 32; i += 64) s_matched[i] = 0;
-    if (lane < 32) s_hist[lane] = 0;
-    // rows whose best distance fails TH_LOW can never match: compact the others, keeping the row order
+    for (int i = tid; i < cap; i += MT) out[i] = -1;
+    for (int i = tid; i < (n2 + 31) / 32; i += MT) s_matched[i] = 0;
+    if (tid < 32) s_hist[tid] = 0;
+    // rows whose best distance fails TH_LOW can never match: compact the others IN ROW ORDER, keys staged in LDS
     int nlive = 0;
-    for (int i0 = 0; i0 < n1; i0 += 64) {
-        const int i = i0 + lane;
-        const bool live = i < n1 && (float)(tk[i].x >> 16) < th && tk[i].x != NO_KEY;
+    for (int i0 = 0; i0 < n1; i0 += MT) {
+        const int i = i0 + tid;
+        int4 t4 = make_int4(NO_KEY, NO_KEY, NO_KEY, NO_KEY);
+        if (i < n1) t4 = tk[i];
+        const bool live = t4.x != NO_KEY && (float)(t4.x >> 16) < th;
         const unsigned long long m = __ballot(live);
-        if (live) s_live[nlive + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)i;
-        nlive += __popcll(m);
+        if (lane == 0) s_wave[wv] = __popcll(m);
+        __syncthreads();
+        int off = nlive;
+        for (int w = 0; w < wv; ++w) off += s_wave[w];
+        if (live) {
+            const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
+            s_live[slot] = (unsigned short)i;
+            if (slot < 2048) s_keys[slot] = t4;
+        }
+        nlive += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    int nm = 0;
-    const uint32_t *d1 = reinterpret_cast<const uint32_t *>(desc + (size_t)a * cap * 32);
-    const uint32_t *d2 = reinterpret_cast<const uint32_t *>(desc + (size_t)b * cap * 32);
-    for (int li = 0; li < nlive; ++li) {
-        const int i = s_live[li];
-        const int4 t4 = tk[i];  // uniform address
-        const int keys[TOPK] = {t4.x, t4.y, t4.z, t4.w};
-        int best = NO_KEY, second = -1;  // second: -1 = not found yet
-        bool exhausted = true;
+    if (wv == 0) {
+        // ordered walk (one wavefront; every lane evaluates the same uniform data, lane 0 commits)
+        int nm = 0;
+        const uint32_t *d1 = reinterpret_cast<const uint32_t *>(desc + (size_t)a * cap * 32);
+        const uint32_t *d2 = reinterpret_cast<const uint32_t *>(desc + (size_t)b * cap * 32);
+        for (int li = 0; li < nlive; ++li) {
+            const int i = s_live[li];
+            const int4 t4 = li < 2048 ? s_keys[li] : tk[i];
+            const int keys[TOPK] = {t4.x, t4.y, t4.z, t4.w};
+            int best = NO_KEY, second = -1;  // second: -1 = not found yet
+            bool exhausted = true;
 #pragma unroll
-        for (int q = 0; q < TOPK; ++q) {
-            const int key = keys[q];
-            if (key == NO_KEY) { exhausted = false; break; }  // fewer than K columns exist: the list is complete
-            const int col = key & 0xffff;
-            if ((s_matched[col >> 5] >> (col & 31)) & 1u) continue;
-            if (best == NO_KEY) best = key;
-            else { second = key >> 16; exhausted = false; break; }
-        }
-        // the best unmatched column already fails TH_LOW: no match whatever the second-best is
-        if (best != NO_KEY && !((float)(best >> 16) < th)) continue;
-        int bdist, bcol, sdist;  // sdist = NO_KEY>>16 means FLT_MAX
-        if (exhausted && n2 > TOPK) {
-            // exact rescan of the unmatched columns by the whole wave (rare)
-            uint32_t q[8];
-#pragma unroll
-            for (int w = 0; w < 8; ++w) q[w] = d1[(size_t)i * 8 + w];
-            int k = NO_KEY, s = NO_KEY >> 16;
-            for (int c = lane; c < n2; c += 64) {
-                if ((s_matched[c >> 5] >> (c & 31)) & 1u) continue;
-                const int d = hamming_words<8>(q, d2 + (size_t)c * 8);
-                merge_best(k, s, (d << 16) | c, NO_KEY >> 16);
+            for (int q = 0; q < TOPK; ++q) {
+                const int key = keys[q];
+                if (key == NO_KEY) { exhausted = false; break; }  // fewer than K columns exist: the list is complete
+                const int col = key & 0xffff;
+                if ((s_matched[col >> 5] >> (col & 31)) & 1u) continue;
+                if (best == NO_KEY) best = key;
+                else { second = key >> 16; exhausted = false; break; }
             }
+            // the best unmatched column already fails TH_LOW: no match whatever the second-best is
+            if (best != NO_KEY && !((float)(best >> 16) < th)) continue;
+            int bdist, bcol, sdist;  // sdist = NO_KEY>>16 means FLT_MAX
+            if (exhausted && n2 > TOPK) {
+                // exact rescan of the unmatched columns by the whole wave (rare)
+                uint32_t q[8];
 #pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) {
-                const int k2 = __shfl_xor(k, m, 64), s2 = __shfl_xor(s, m, 64);
-                merge_best(k, s, k2, s2);
-            }
-            if (k == NO_KEY) continue;
-            bdist = k >> 16; bcol = k & 0xffff; sdist = s;
-        } else {
-            if (best == NO_KEY) continue;
-            bdist = best >> 16; bcol = best & 0xffff; sdist = second < 0 ? (NO_KEY >> 16) : second;
-        }
-        const float best1 = (float)bdist;
-        const float best2 = (sdist == (NO_KEY >> 16)) ? 3.402823466e+38f : (float)sdist;
-        if (best1 < th && best1 < ratio * best2) {  // FeatureMatcher.cc:630,632
-            if (lane == 0) {
-                out[i] = bcol;
-                s_matched[bcol >> 5] |= 1u << (bcol & 31);
-                if (check_ori) {
-                    const int bin = rotation_bin(kps[(size_t)a * cap + i].angle, kps[(size_t)b * cap + bcol].angle);
-                    s_bin[i] = (uint8_t)bin;
-                    s_hist[bin]++;
+                for (int w = 0; w < 8; ++w) q[w] = d1[(size_t)i * 8 + w];
+                int k = NO_KEY, s = NO_KEY >> 16;
+                for (int c = lane; c < n2; c += 64) {
+                    if ((s_matched[c >> 5] >> (c & 31)) & 1u) continue;
+                    const int d = hamming_words<8>(q, d2 + (size_t)c * 8);
+                    merge_best(k, s, (d << 16) | c, NO_KEY >> 16);
                 }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) {
+                    const int k2 = __shfl_xor(k, m, 64), s2 = __shfl_xor(s, m, 64);
+                    merge_best(k, s, k2, s2);
+                }
+                if (k == NO_KEY) continue;
+                bdist = k >> 16; bcol = k & 0xffff; sdist = s;
+            } else {
+                if (best == NO_KEY) continue;
+                bdist = best >> 16; bcol = best & 0xffff; sdist = second < 0 ? (NO_KEY >> 16) : second;
             }
-            ++nm;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const float best1 = (float)bdist;
+            const float best2 = (sdist == (NO_KEY >> 16)) ? 3.402823466e+38f : (float)sdist;
+            if (best1 < th && best1 < ratio * best2) {  // FeatureMatcher.cc:630,632
+                if (lane == 0) {
+                    out[i] = bcol;
+                    s_matched[bcol >> 5] |= 1u << (bcol & 31);
+                    if (check_ori) {
+                        const int bin = rotation_bin(kps[(size_t)a * cap + i].angle, kps[(size_t)b * cap + bcol].angle);
+                        s_bin[i] = (uint8_t)bin;
+                        s_hist[bin]++;
+                    }
+                }
+                ++nm;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+        }
+        if (lane == 0) {
+            s_nm = nm;
+            int i1 = -1, i2 = -1, i3 = -1;
+            if (check_ori) {  // computeThreeMaxima (FeatureMatcher.cc:1631-1668)
+                int max1 = 0, max2 = 0, max3 = 0;
+                for (int i = 0; i < 30; ++i) {
+                    const int sz = s_hist[i];
+                    if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; i3 = i2; i2 = i1; i1 = i; }
+                    else if (sz > max2) { max3 = max2; max2 = sz; i3 = i2; i2 = i; }
+                    else if (sz > max3) { max3 = sz; i3 = i; }
+                }
+                if ((float)max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+                else if ((float)max3 < 0.1f * (float)max1) { i3 = -1; }
+            }
+            s_drop[0] = i1; s_drop[1] = i2; s_drop[2] = i3;
         }
     }
+    __syncthreads();
     if (check_ori) {
-        int i1 = -1, i2 = -1, i3 = -1;
-        {
-            int max1 = 0, max2 = 0, max3 = 0;
-            for (int i = 0; i < 30; ++i) {
-                const int sz = s_hist[i];
-                if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; i3 = i2; i2 = i1; i1 = i; }
-                else if (sz > max2) { max3 = max2; max2 = sz; i3 = i2; i2 = i; }
-                else if (sz > max3) { max3 = sz; i3 = i; }
-            }
-            if ((float)max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
-            else if ((float)max3 < 0.1f * (float)max1) { i3 = -1; }
-        }
+        const int i1 = s_drop[0], i2 = s_drop[1], i3 = s_drop[2];
         int dropped = 0;
-        for (int i = lane; i < n1; i += 64) {
+        for (int i = tid; i < n1; i += MT) {
             if (out[i] >= 0) {
                 const int bb = s_bin[i];
                 if (bb != i1 && bb != i2 && bb != i3) { out[i] = -1; ++dropped; }
             }
         }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) dropped += __shfl_xor(dropped, m, 64);
-        nm -= dropped;
+        if (dropped) atomicSub(&s_nm, dropped);
+        __syncthreads();
     }
-    if (lane == 0) nmatches[p] = nm;
+    if (tid == 0) nmatches[p] = s_nm;
 }
 
 // ---------------- M4: SearchForTriangulation ----------------
@@ -525,7 +544,7 @@ extern "C" void afv_launch_match_pairs2(const uint8_t *desc, const afv_keypoint 
                                         int *nmatches, void *topk_scratch, hipStream_t stream) {
     int4 *topk = reinterpret_cast<int4 *>(topk_scratch);
     hipLaunchKernelGGL(k_match_topk, dim3((cap + MT - 1) / MT, npairs), dim3(MT), 0, stream, desc, nset, cap, pa, pb, topk);
-    hipLaunchKernelGGL(k_match_resolve, dim3(npairs), dim3(64), 0, stream, desc, kps, nset, cap, pa, pb, topk, th, ratio,
+    hipLaunchKernelGGL(k_match_resolve, dim3(npairs), dim3(MT), 0, stream, desc, kps, nset, cap, pa, pb, topk, th, ratio,
                        check_ori, match, nmatches);
 }
 extern "C" void afv_launch_match_tri(const DevTriJob *jobs, int njobs, hipStream_t stream) {
