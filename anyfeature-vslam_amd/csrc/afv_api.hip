@@ -871,7 +871,7 @@ extern "C" int afv_match_bruteforce_pairs_device(afv_ctx *c, const uint8_t *d_de
                                                  const int32_t *d_pair_b, int npairs, float th_low, float nnratio,
                                                  int check_orientation, int32_t *d_match, int32_t *d_nmatches, void *stream) {
     if (!c || !d_desc || !d_n || !d_pair_a || !d_pair_b || !d_match || !d_nmatches) return AFV_EINVAL;
-    if (nsets < 1 || npairs < 1 || cap < 1 || cap > AFV_MAX_SIDE) return AFV_EINVAL;
+    if (nsets < 1 || npairs < 1 || cap < 1 || cap > 4096) return AFV_EINVAL;  // PAIR_MAX_SIDE in k_match.hip
     if (check_orientation && !d_kps) return AFV_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
     {

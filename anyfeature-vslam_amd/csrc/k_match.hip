@@ -255,14 +255,23 @@ __global__ __launch_bounds__(MT) void k_match_topk(const uint8_t *__restrict__ d
     if (row < n1) topk[(size_t)p * cap + row] = make_int4(k[0], k[1], k[2], k[3]);
 }
 
+#define PAIR_MAX_SIDE 4096  // rows / columns per set in the pairs path (LDS tables below)
+#define WAVE_LDS_SYNC()                                        \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
+    } while (0)
+
 __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict__ desc, const afv_keypoint *__restrict__ kps,
                                                       const int *__restrict__ nset, int cap, const int *__restrict__ pair_a,
                                                       const int *__restrict__ pair_b, const int4 *__restrict__ topk, float th,
                                                       float ratio, int check_ori, int *__restrict__ match,
                                                       int *__restrict__ nmatches) {
-    __shared__ uint32_t s_matched[MAX_SIDE / 32];
-    __shared__ uint8_t s_bin[MAX_SIDE];
-    __shared__ unsigned short s_live[MAX_SIDE];
+    __shared__ uint32_t s_matched[PAIR_MAX_SIDE / 32];
+    __shared__ uint8_t s_bin[PAIR_MAX_SIDE];
+    __shared__ unsigned short s_live[PAIR_MAX_SIDE];
+    __shared__ int s_claim[PAIR_MAX_SIDE];
     __shared__ __attribute__((aligned(16))) int4 s_keys[2048];  // top-4 keys of the live rows (first 2048 of them)
     __shared__ int s_hist[32];
     __shared__ int s_wave[8];
@@ -274,6 +283,7 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
     int *out = match + (size_t)p * cap;
     for (int i = tid; i < cap; i += MT) out[i] = -1;
     for (int i = tid; i < (n2 + 31) / 32; i += MT) s_matched[i] = 0;
+    for (int i = tid; i < n2; i += MT) s_claim[i] = 0x7fffffff;
     if (tid < 32) s_hist[tid] = 0;
     // rows whose best distance fails TH_LOW can never match: compact the others IN ROW ORDER, keys staged in LDS
     int nlive = 0;
@@ -296,66 +306,123 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
         __syncthreads();
     }
     if (wv == 0) {
-        // ordered walk (one wavefront; every lane evaluates the same uniform data, lane 0 commits)
+        // Ordered walk, 64 live rows per round.  Every lane evaluates ITS row against the current matched set; an
+        // accepting lane claims its column (LDS atomic min of the lane index).  A lane is "dirty" when an EARLIER lane of
+        // the round claimed a column it relied on (its best or second-best unmatched column); a row whose 4 keys are
+        // used up needs the exact rescan.  The clean prefix before the first dirty / rescan lane is committed, the
+        // rest is replayed against the updated set.  Lane 0 is never dirty, so every round retires at least one row
+        // and the outcome is exactly that of the sequential loop (FeatureMatcher.cc:587-641).
         int nm = 0;
         const uint32_t *d1 = reinterpret_cast<const uint32_t *>(desc + (size_t)a * cap * 32);
         const uint32_t *d2 = reinterpret_cast<const uint32_t *>(desc + (size_t)b * cap * 32);
-        for (int li = 0; li < nlive; ++li) {
-            const int i = s_live[li];
-            const int4 t4 = li < 2048 ? s_keys[li] : tk[i];
+        int pos = 0;
+        while (pos < nlive) {
+            const int li = pos + lane;
+            const bool act = li < nlive;
+            const int row = act ? s_live[li] : 0;
+            int4 t4 = make_int4(NO_KEY, NO_KEY, NO_KEY, NO_KEY);
+            if (act) t4 = li < 2048 ? s_keys[li] : tk[row];
             const int keys[TOPK] = {t4.x, t4.y, t4.z, t4.w};
-            int best = NO_KEY, second = -1;  // second: -1 = not found yet
-            bool exhausted = true;
+            int best = NO_KEY, second = -1, e0 = -1, e1 = -1;
+            bool open = act;  // still walking the key list
+            bool exhausted = act;
 #pragma unroll
             for (int q = 0; q < TOPK; ++q) {
                 const int key = keys[q];
-                if (key == NO_KEY) { exhausted = false; break; }  // fewer than K columns exist: the list is complete
-                const int col = key & 0xffff;
-                if ((s_matched[col >> 5] >> (col & 31)) & 1u) continue;
-                if (best == NO_KEY) best = key;
-                else { second = key >> 16; exhausted = false; break; }
+                if (open) {
+                    if (key == NO_KEY) {  // fewer than K columns exist: the list is complete
+                        open = false;
+                        exhausted = false;
+                    } else {
+                        const int col = key & 0xffff;
+                        if (!((s_matched[col >> 5] >> (col & 31)) & 1u)) {
+                            if (best == NO_KEY) {
+                                best = key;
+                                e0 = col;
+                            } else {
+                                second = key >> 16;
+                                e1 = col;
+                                open = false;
+                                exhausted = false;
+                            }
+                        }
+                    }
+                }
             }
-            // the best unmatched column already fails TH_LOW: no match whatever the second-best is
-            if (best != NO_KEY && !((float)(best >> 16) < th)) continue;
-            int bdist, bcol, sdist;  // sdist = NO_KEY>>16 means FLT_MAX
-            if (exhausted && n2 > TOPK) {
-                // exact rescan of the unmatched columns by the whole wave (rare)
+            int type = 0;  // 0 = no match, 1 = accept column e0, 2 = exact rescan needed
+            if (act) {
+                if (best != NO_KEY && !((float)(best >> 16) < th)) {
+                    e0 = -1;  // the best unmatched column already fails TH_LOW: final whatever happens to the set
+                    e1 = -1;
+                } else if (exhausted && n2 > TOPK) {
+                    type = 2;
+                } else if (best != NO_KEY) {
+                    const float best1 = (float)(best >> 16);
+                    const float best2 = second < 0 ? 3.402823466e+38f : (float)second;
+                    type = (best1 < th && best1 < ratio * best2) ? 1 : 0;  // FeatureMatcher.cc:630,632
+                }
+            }
+            if (type == 1) atomicMin(&s_claim[e0], lane);
+            WAVE_LDS_SYNC();
+            bool stopper = type == 2;
+            if (act && type != 2) {
+                if (e0 >= 0 && s_claim[e0] < lane) stopper = true;
+                if (e1 >= 0 && s_claim[e1] < lane) stopper = true;
+            }
+            const unsigned long long sm = __ballot(stopper);
+            const int stop = sm ? (int)__builtin_ctzll(sm) : 64;
+            // commit the clean prefix
+            const bool commit = type == 1 && lane < stop;
+            if (commit) {
+                out[row] = e0;
+                atomicOr(&s_matched[e0 >> 5], 1u << (e0 & 31));
+                if (check_ori) {
+                    const int bin = rotation_bin(kps[(size_t)a * cap + row].angle, kps[(size_t)b * cap + e0].angle);
+                    s_bin[row] = (uint8_t)bin;
+                    atomicAdd(&s_hist[bin], 1);
+                }
+            }
+            nm += __popcll(__ballot(commit));
+            if (type == 1) s_claim[e0] = 0x7fffffff;  // release every claim of this round
+            WAVE_LDS_SYNC();
+            if (stop == 0) {
+                // the first row of the round needs the exact rescan of the unmatched columns (rare): whole wave
+                const int i = s_live[pos];
                 uint32_t q[8];
 #pragma unroll
                 for (int w = 0; w < 8; ++w) q[w] = d1[(size_t)i * 8 + w];
-                int k = NO_KEY, s = NO_KEY >> 16;
+                int k = NO_KEY, s2nd = NO_KEY >> 16;
                 for (int c = lane; c < n2; c += 64) {
                     if ((s_matched[c >> 5] >> (c & 31)) & 1u) continue;
                     const int d = hamming_words<8>(q, d2 + (size_t)c * 8);
-                    merge_best(k, s, (d << 16) | c, NO_KEY >> 16);
+                    merge_best(k, s2nd, (d << 16) | c, NO_KEY >> 16);
                 }
 #pragma unroll
                 for (int m = 32; m >= 1; m >>= 1) {
-                    const int k2 = __shfl_xor(k, m, 64), s2 = __shfl_xor(s, m, 64);
-                    merge_best(k, s, k2, s2);
+                    const int k2 = __shfl_xor(k, m, 64), s2 = __shfl_xor(s2nd, m, 64);
+                    merge_best(k, s2nd, k2, s2);
                 }
-                if (k == NO_KEY) continue;
-                bdist = k >> 16; bcol = k & 0xffff; sdist = s;
-            } else {
-                if (best == NO_KEY) continue;
-                bdist = best >> 16; bcol = best & 0xffff; sdist = second < 0 ? (NO_KEY >> 16) : second;
-            }
-            const float best1 = (float)bdist;
-            const float best2 = (sdist == (NO_KEY >> 16)) ? 3.402823466e+38f : (float)sdist;
-            if (best1 < th && best1 < ratio * best2) {  // FeatureMatcher.cc:630,632
-                if (lane == 0) {
-                    out[i] = bcol;
-                    s_matched[bcol >> 5] |= 1u << (bcol & 31);
-                    if (check_ori) {
-                        const int bin = rotation_bin(kps[(size_t)a * cap + i].angle, kps[(size_t)b * cap + bcol].angle);
-                        s_bin[i] = (uint8_t)bin;
-                        s_hist[bin]++;
+                if (k != NO_KEY) {
+                    const float best1 = (float)(k >> 16);
+                    const float best2 = (s2nd == (NO_KEY >> 16)) ? 3.402823466e+38f : (float)s2nd;
+                    if (best1 < th && best1 < ratio * best2) {
+                        const int bcol = k & 0xffff;
+                        if (lane == 0) {
+                            out[i] = bcol;
+                            s_matched[bcol >> 5] |= 1u << (bcol & 31);
+                            if (check_ori) {
+                                const int bin = rotation_bin(kps[(size_t)a * cap + i].angle, kps[(size_t)b * cap + bcol].angle);
+                                s_bin[i] = (uint8_t)bin;
+                                s_hist[bin]++;
+                            }
+                        }
+                        ++nm;
                     }
                 }
-                ++nm;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                WAVE_LDS_SYNC();
+                pos += 1;
+            } else {
+                pos += stop;
             }
         }
         if (lane == 0) {

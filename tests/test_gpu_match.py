@@ -201,3 +201,49 @@ def test_device_pairs_match_extracted_frames(afv, oracle, matcher, gpu_ctx):
         assert nm[p] == wn and np.array_equal(match[p, :n[a]], want), p
         assert np.all(match[p, n[a]:] == -1)
     assert nm.sum() > 100
+
+
+@pytest.mark.parametrize("nproto,flips", [(40, 2), (8, 1), (200, 6)])
+def test_device_pairs_heavy_contention(afv, oracle, matcher, gpu_ctx, nproto, flips):
+    """many rows compete for the same few columns: exercises the claim / replay logic of the ordered resolve and the
+    exact-rescan path taken when a row's four best columns are all gone"""
+    import torch
+    s = afv.synth
+    cap = 640
+    proto = s.random_descriptors(300 + nproto, nproto)
+
+    def cluster(seed, n):
+        idx = s.lcg_states(seed, n) % nproto
+        d = proto[idx].copy()
+        pos = s.lcg_states(seed + 1, n * flips).reshape(n, flips) % 256
+        for k in range(flips):
+            d[np.arange(n), pos[:, k] // 8] ^= (1 << (pos[:, k] % 8)).astype(np.uint8)
+        return d
+
+    sets = [cluster(11, 600), cluster(12, 500), cluster(13, 640), cluster(14, 3)]
+    table = np.zeros((4, cap, 32), np.uint8)
+    counts = np.zeros(4, np.int32)
+    kps = np.zeros((4, cap), afv.KP_DTYPE)
+    for i, d in enumerate(sets):
+        table[i, :len(d)] = d
+        counts[i] = len(d)
+        kps[i, :len(d)]["angle"] = (s.lcg_states(20 + i, len(d)) % 36000).astype(np.float32) / 100.0
+    pa = np.array([0, 1, 2, 0, 3, 2], np.int32)
+    pb = np.array([1, 0, 0, 2, 2, 3], np.int32)
+    t_desc = torch.from_numpy(table).cuda()
+    t_kps = torch.from_numpy(kps.view(np.float32).reshape(4, cap, 7)).cuda()
+    t_n = torch.from_numpy(counts).cuda()
+    for ori in (False, True):
+        for ratio in (0.6, 0.95):
+            matcher.mfNNratio = ratio
+            match, nm = matcher.match_pairs_device(t_desc, t_kps, t_n, torch.from_numpy(pa).cuda(), torch.from_numpy(pb).cuda(),
+                                                   th_low=75.0, check_orientation=ori)
+            torch.cuda.synchronize()
+            match = match.cpu().numpy(); nm = nm.cpu().numpy()
+            for p in range(len(pa)):
+                a, b = pa[p], pb[p]
+                want, wn = oracle.search_by_bow_kf_kf(table[a, :counts[a]], table[b, :counts[b]], angle1=kps[a, :counts[a]]["angle"],
+                                                      angle2=kps[b, :counts[b]]["angle"], th_low=75.0, nnratio=ratio,
+                                                      check_orientation=ori)
+                assert nm[p] == wn and np.array_equal(match[p, :counts[a]], want), (p, ori, ratio)
+    matcher.mfNNratio = 0.6
