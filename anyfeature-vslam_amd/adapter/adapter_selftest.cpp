@@ -1,0 +1,71 @@
+// adapter_selftest.cpp — compile check (always) and run check (GPU box) of the C++ host adapter.
+//   adapter_selftest <frame.raw> <w> <h> <out_prefix>   extracts with FeatureExtractor_orb32_hip and matches the frame
+//   against itself shifted by 4 px; writes <out_prefix>.kps / .desc / .match for the python test to compare with the
+//   oracle.  Exit code 0 on success, 3 when no HIP device is present (afv_create -> AFV_ENODEV).
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+#include "afv_adapter.hpp"
+
+static bool dump(const std::string &path, const void *p, size_t n) {
+    std::ofstream f(path, std::ios::binary);
+    f.write(reinterpret_cast<const char *>(p), (std::streamsize)n);
+    return (bool)f;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 5) {
+        std::fprintf(stderr, "usage: %s frame.raw w h out_prefix\n", argv[0]);
+        return 2;
+    }
+    const int w = std::atoi(argv[2]), h = std::atoi(argv[3]);
+    const std::string out = argv[4];
+    afv::Image img, img2;
+    img.grayImg.create(h, w);
+    {
+        std::ifstream f(argv[1], std::ios::binary);
+        f.read(reinterpret_cast<char *>(img.grayImg.ptr()), (std::streamsize)w * h);
+        if (!f) return 2;
+    }
+    img2.grayImg.create(h, w);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) img2.grayImg.ptr(y)[x] = img.grayImg.ptr(y)[(x + w - 4) % w];  // np.roll(img, 4, axis=1)
+
+    {   // probe for a device first: the adapter itself terminates on failure, like the reference's plugins
+        afv_orb_params p;
+        afv_default_orb_params(&p);
+        afv_ctx *probe = nullptr;
+        const int rc = afv_create(0, &p, &probe);
+        if (rc == AFV_ENODEV) {
+            std::fprintf(stderr, "no HIP device\n");
+            return 3;
+        }
+        afv_destroy(probe);
+    }
+    auto settings = std::make_shared<afv::FeatureExtractorSettings>();
+    afv::FeatureExtractor_orb32_hip extractor(1000, settings, 0, w, h);
+    std::vector<afv::KeyPoint> k1, k2;
+    afv::Mat8 d1, d2;
+    std::vector<afv::Mat2f> s2, inf;
+    std::vector<float> size;
+    extractor(img, k1, d1, s2, inf, size);  // 6-arg operator()
+    extractor(img2, k2, d2);                // 3-arg operator()
+    if (settings->ON_automaticTuning || k1.empty() || (int)size.size() != (int)k1.size()) return 4;
+
+    afv::FeatureMatcherHip::setDescriptorDistanceThresholds(75.0f);
+    afv::FeatureMatcherHip matcher(extractor.context(), 0.6f, true);
+    std::vector<float> a1(k1.size()), a2(k2.size());
+    for (size_t i = 0; i < k1.size(); ++i) a1[i] = k1[i].angle;
+    for (size_t i = 0; i < k2.size(); ++i) a2[i] = k2[i].angle;
+    afv::FeatureView v1, v2;
+    v1.descriptors = d1.ptr(); v1.N = (int)k1.size(); v1.angles = a1.data();
+    v2.descriptors = d2.ptr(); v2.N = (int)k2.size(); v2.angles = a2.data();
+    std::vector<int> m21;
+    const int nm = matcher.SearchByBoW(v2, v1, m21);
+    std::printf("%zu %zu %d\n", k1.size(), k2.size(), nm);
+    bool ok = dump(out + ".kps1", k1.data(), k1.size() * sizeof(afv::KeyPoint)) && dump(out + ".desc1", d1.ptr(), d1.data.size()) &&
+              dump(out + ".kps2", k2.data(), k2.size() * sizeof(afv::KeyPoint)) && dump(out + ".desc2", d2.ptr(), d2.data.size()) &&
+              dump(out + ".match21", m21.data(), m21.size() * sizeof(int)) && dump(out + ".size1", size.data(), size.size() * 4);
+    return ok ? 0 : 5;
+}

@@ -1,0 +1,263 @@
+// afv_adapter.hpp — header-only C++17 host adapter over the C-ABI (include/afv_hip.h).
+//
+// It mirrors the reference's plugin classes so that a host which HAS OpenCV can drop the GPU path in by compiling
+// this header with -DAFV_WITH_OPENCV (then afv::KeyPoint = cv::KeyPoint, afv::Mat8 = cv::Mat) — see INTEGRATION.md for
+// the subclass that plugs into Tracking.cc:1523-1552.  Without OpenCV (this repository's build container) the same
+// code works on two layout-compatible PODs, which is what adapter_selftest.cpp compiles and runs.
+//
+// Reference interfaces mirrored (file:line in the reference tree):
+//   FeatureExtractorSettings        include/FeatureExtractor.h:23-66, src/FeatureExtractor.cpp:21-56
+//   FeatureExtractor::operator()    include/FeatureExtractor.h:76-93, src/FeatureExtractor.cpp:111-129
+//   FeatureExtractor_orb32          include/Feature_orb32.h:12-33, src/Feature_orb32.cpp:11-65
+//   FeatureMatcher::SearchByBoW x2  include/FeatureMatcher.h:59-60, src/FeatureMatcher.cc:186-283, 561-660
+//   FeatureMatcher::SearchForTriangulation  include/FeatureMatcher.h:66-67, src/FeatureMatcher.cc:662-790
+// Error behaviour follows the reference: no exceptions cross the boundary; an empty image leaves the outputs
+// untouched (ORBextractor.cc:570-571); an unrecoverable device error terminates (cf. Feature_sift128.cpp:61).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <exception>
+#include <map>
+#include <memory>
+#include <utility>
+#include <vector>
+
+#include "afv_hip.h"
+
+#ifdef AFV_WITH_OPENCV
+#include <opencv2/core.hpp>
+#endif
+
+namespace afv {
+
+#ifdef AFV_WITH_OPENCV
+using KeyPoint = cv::KeyPoint;
+static_assert(sizeof(cv::KeyPoint) == sizeof(afv_keypoint), "cv::KeyPoint layout changed");
+#else
+struct KeyPoint {  // same member order and size as cv::KeyPoint
+    struct { float x, y; } pt;
+    float size, angle, response;
+    int octave, class_id;
+};
+struct Mat8 {  // minimal stand-in for a continuous CV_8UC1 cv::Mat
+    int rows = 0, cols = 0;
+    std::vector<uint8_t> data;
+    void create(int r, int c) { rows = r; cols = c; data.assign((size_t)r * c, 0); }
+    uint8_t *ptr(int r = 0) { return data.data() + (size_t)r * cols; }
+    const uint8_t *ptr(int r = 0) const { return data.data() + (size_t)r * cols; }
+    bool empty() const { return rows == 0 || cols == 0; }
+    size_t step() const { return (size_t)cols; }
+};
+struct Image {  // include/Image.h:13-29: the extractor reads grayImg only
+    Mat8 grayImg;
+};
+#endif
+static_assert(sizeof(KeyPoint) == sizeof(afv_keypoint), "KeyPoint must be bit-compatible with afv_keypoint");
+
+struct Mat2f { float m[2][2]; };  // Eigen::Matrix<float,2,2> (Types.h:139), row/column symmetric here
+
+struct FeatureExtractorSettings {  // FeatureExtractor.h:23-66
+    static inline int numOctaves0 = 8;
+    static inline float scaleFactor0 = 1.2f;
+    static inline float th0 = 20.0f;
+    float scaleFactor = scaleFactor0;
+    int nOctaves = numOctaves0;
+    float detectTh = th0;
+    bool ON_automaticTuning = true;
+    static float GetDetectorNominalScaleFactor() { return scaleFactor0; }
+    static int GetDetectorNominalNumOctaves() { return numOctaves0; }
+    static float GetDetectorNominalThreshold() { return th0; }
+};
+
+[[noreturn]] inline void fatal(const char *what, int rc, afv_ctx *ctx) {
+    std::fprintf(stderr, "afv: %s failed: %s (%s)\n", what, afv_strerror(rc), ctx ? afv_last_error(ctx) : "");
+    std::terminate();
+}
+
+// drop-in for FeatureExtractor_orb32: same call operators, GPU behind them
+class FeatureExtractor_orb32_hip {
+  public:
+    std::shared_ptr<FeatureExtractorSettings> settings;
+
+    FeatureExtractor_orb32_hip(const int &nfeatures_, std::shared_ptr<FeatureExtractorSettings> &settings_, int device = 0,
+                               int max_width = 640, int max_height = 480)
+        : settings(settings_), nfeatures(nfeatures_) {
+        afv_orb_params p;
+        afv_default_orb_params(&p);
+        p.nfeatures = nfeatures_;
+        p.nlevels = settings->nOctaves;
+        p.scale_factor = settings->scaleFactor;
+        p.fast_threshold = int(settings->detectTh);  // Feature_orb32.cpp:30 setFastThreshold(int(detectTh))
+        p.max_width = max_width;
+        p.max_height = max_height;
+        const int rc = afv_create(device, &p, &ctx);
+        if (rc != AFV_OK) fatal("afv_create", rc, nullptr);
+        cap = afv_max_keypoints_per_frame(ctx);
+        mvScaleFactor.resize(settings->nOctaves);  // FeatureExtractor.cpp:77-85
+        mvScaleFactor[0] = 1.0f;
+        for (int i = 1; i < settings->nOctaves; i++) mvScaleFactor[i] = mvScaleFactor[i - 1] * settings->scaleFactor;
+    }
+    ~FeatureExtractor_orb32_hip() { afv_destroy(ctx); }
+    FeatureExtractor_orb32_hip(const FeatureExtractor_orb32_hip &) = delete;
+    FeatureExtractor_orb32_hip &operator=(const FeatureExtractor_orb32_hip &) = delete;
+
+    // 6-argument operator() (FeatureExtractor.cpp:111-121)
+    template <class ImageT, class MatT>
+    void operator()(const ImageT &img, std::vector<KeyPoint> &keypoints, MatT &descriptors, std::vector<Mat2f> &keyPtsSigma2,
+                    std::vector<Mat2f> &keyPtsInf, std::vector<float> &keyPtsSize) {
+        (*this)(img, keypoints, descriptors);
+        const int n = (int)keypoints.size();
+        keyPtsSize.assign(n, 0.f);
+        std::vector<float> s2(n), inf(n);
+        const int rc = afv_orb_size_sigma(ctx, reinterpret_cast<const afv_keypoint *>(keypoints.data()), n, keyPtsSize.data(),
+                                          s2.data(), inf.data());
+        if (rc != AFV_OK) fatal("afv_orb_size_sigma", rc, ctx);
+        keyPtsSigma2.clear();
+        keyPtsInf.clear();
+        for (int i = 0; i < n; ++i) {  // computeSigma(SIZE): sigma^2 * I, 1/sigma^2 * I (FeatureExtractor.cpp:159-170)
+            keyPtsSigma2.push_back(Mat2f{{{s2[i], 0.f}, {0.f, s2[i]}}});
+            keyPtsInf.push_back(Mat2f{{{inf[i], 0.f}, {0.f, inf[i]}}});
+        }
+    }
+
+    // 3-argument operator() (FeatureExtractor.cpp:123-129)
+    template <class ImageT, class MatT>
+    void operator()(const ImageT &img, std::vector<KeyPoint> &keypoints, MatT &descriptors) {
+        if (settings->ON_automaticTuning) {  // automaticTuning (FeatureExtractor.cpp:195-274): detectTh = th0, once
+            settings->detectTh = FeatureExtractorSettings::GetDetectorNominalThreshold();
+            settings->ON_automaticTuning = false;
+        }
+        detectAndCompute(img, keypoints, descriptors);
+    }
+
+    // Feature_orb32.cpp:11-18: detect -> quadtree -> describe -> merge, all on the GPU
+    template <class ImageT, class MatT>
+    void detectAndCompute(const ImageT &img, std::vector<KeyPoint> &keypoints, MatT &descriptors) {
+        const auto &g = img.grayImg;
+        if (g.empty()) return;  // outputs untouched (ORBextractor.cc:570-571)
+        std::vector<KeyPoint> kps((size_t)cap);
+        std::vector<uint8_t> desc((size_t)cap * AFV_DESC_BYTES);
+        int n = 0;
+        const int rc = afv_orb_extract(ctx, g.ptr(0), g.cols, g.rows, (int)row_step(g), reinterpret_cast<afv_keypoint *>(kps.data()),
+                                       desc.data(), cap, &n);
+        if (rc != AFV_OK) fatal("afv_orb_extract", rc, ctx);
+        kps.resize((size_t)n);
+        keypoints.swap(kps);  // mergeKeypointLevels clears and refills (FeatureExtractor.cpp:300-307)
+        fill_descriptors(descriptors, desc.data(), n);
+    }
+
+    int GetLevels() { return settings->nOctaves; }
+    float GetScaleFactor() { return settings->scaleFactor; }
+    std::vector<float> GetScaleFactors() { return mvScaleFactor; }
+    int GetKeypointOctave(const KeyPoint &kp) const { return kp.octave; }                                  // Feature_orb32.cpp:55-57
+    float GetKeypointSize(const KeyPoint &kp) const { return powf(settings->scaleFactor, float(kp.octave)); }  // :59-61
+    afv_ctx *context() { return ctx; }
+
+  private:
+    template <class M> static size_t row_step(const M &m) {
+#ifdef AFV_WITH_OPENCV
+        return (size_t)m.step;
+#else
+        return m.step();
+#endif
+    }
+    template <class M> static void fill_descriptors(M &m, const uint8_t *src, int n) {
+#ifdef AFV_WITH_OPENCV
+        m.create(n, AFV_DESC_BYTES, CV_8U);
+#else
+        m.create(n, AFV_DESC_BYTES);
+#endif
+        for (int i = 0; i < n; ++i) std::copy(src + (size_t)i * AFV_DESC_BYTES, src + (size_t)(i + 1) * AFV_DESC_BYTES, m.ptr(i));
+    }
+    int nfeatures;
+    afv_ctx *ctx = nullptr;
+    int cap = 0;
+    std::vector<float> mvScaleFactor;
+};
+
+// ---- matcher side: flat view of what FeatureMatcher reads from KeyFrame / Frame ----
+using FeatureVector = std::map<unsigned, std::vector<unsigned>>;  // DBoW2::FeatureVector (node id -> feature indices)
+
+struct FeatureView {
+    const uint8_t *descriptors = nullptr;  // N x 32, continuous (KeyFrame::mDescriptors)
+    int N = 0;
+    const FeatureVector *featVec = nullptr;  // nullptr => brute force
+    const uint8_t *valid = nullptr;          // map point exists && !isBad() (triangulation: has a map point)
+    const float *angles = nullptr;           // mvKeysUn[i].angle
+    const float *x = nullptr, *y = nullptr;  // mvKeysUn[i].pt       (triangulation)
+    const float *sigma2 = nullptr;           // GetKeyPt1DSigma2(i)  (triangulation)
+};
+
+class FeatureMatcherHip {
+  public:
+    static inline float TH_LOW = 0.0f, TH_HIGH = 0.0f;  // FeatureMatcher.cc:56-59
+    static void setDescriptorDistanceThresholds(float matchingTh) { TH_LOW = TH_HIGH = matchingTh; }  // :1533-1545
+
+    FeatureMatcherHip(afv_ctx *ctx_, float nnratio = 0.6f, bool checkOri = true) : ctx(ctx_), mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+
+    // SearchByBoW(KF1, KF2, vpMatches12) (FeatureMatcher.cc:561-660): matches12[i] = index in KF2 or -1
+    int SearchByBoW(const FeatureView &kf1, const FeatureView &kf2, std::vector<int> &matches12) {
+        return run(kf1, kf2, AFV_MATCH_KF_KF, matches12);
+    }
+    // SearchByBoW(KF, Frame, vpMapPointMatches) (:186-283): matchesF[idxF] = index in KF or -1
+    int SearchByBoW_Frame(const FeatureView &kf, const FeatureView &frame, std::vector<int> &matchesF) {
+        return run(kf, frame, AFV_MATCH_KF_FRAME, matchesF);
+    }
+    // SearchForTriangulation (:662-790, mono): vMatchedPairs ascending idx1
+    int SearchForTriangulation(const FeatureView &kf1, const FeatureView &kf2, const float F12[9], float ex, float ey,
+                               std::vector<std::pair<size_t, size_t>> &vMatchedPairs) {
+        Csr c1(kf1), c2(kf2);
+        afv_tri_job t{};
+        fill(t.bow, kf1, kf2, c1, c2, AFV_MATCH_KF_KF);
+        t.x1 = kf1.x; t.y1 = kf1.y; t.x2 = kf2.x; t.y2 = kf2.y; t.sigma2_2 = kf2.sigma2;
+        for (int i = 0; i < 9; ++i) t.F12[i] = F12[i];
+        t.ex = ex; t.ey = ey;
+        std::vector<int32_t> m((size_t)std::max(kf1.N, 1), -1);
+        int32_t n = 0;
+        const int rc = afv_match_triangulation(ctx, &t, 1, m.data(), &n);
+        if (rc != AFV_OK) fatal("afv_match_triangulation", rc, ctx);
+        vMatchedPairs.clear();
+        for (int i = 0; i < kf1.N; ++i)
+            if (m[i] >= 0) vMatchedPairs.emplace_back((size_t)i, (size_t)m[i]);
+        return n;
+    }
+
+  private:
+    struct Csr {
+        std::vector<int32_t> id, ptr, idx;
+        explicit Csr(const FeatureView &v) {
+            if (!v.featVec) return;
+            ptr.push_back(0);
+            for (const auto &kv : *v.featVec) {
+                id.push_back((int32_t)kv.first);
+                for (unsigned f : kv.second) idx.push_back((int32_t)f);
+                ptr.push_back((int32_t)idx.size());
+            }
+        }
+    };
+    void fill(afv_match_job &j, const FeatureView &a, const FeatureView &b, const Csr &ca, const Csr &cb, int mode) const {
+        j.desc1 = a.descriptors; j.n1 = a.N; j.desc2 = b.descriptors; j.n2 = b.N; j.desc_bytes = AFV_DESC_BYTES;
+        j.node_id1 = ca.id.data(); j.seg_ptr1 = ca.ptr.data(); j.seg_idx1 = ca.idx.data(); j.nnodes1 = (int32_t)ca.id.size();
+        j.node_id2 = cb.id.data(); j.seg_ptr2 = cb.ptr.data(); j.seg_idx2 = cb.idx.data(); j.nnodes2 = (int32_t)cb.id.size();
+        j.valid1 = a.valid; j.valid2 = b.valid; j.angle1 = a.angles; j.angle2 = b.angles;
+        j.th_low = TH_LOW; j.nnratio = mfNNratio; j.check_orientation = mbCheckOrientation && a.angles && b.angles; j.mode = mode;
+    }
+    int run(const FeatureView &a, const FeatureView &b, int mode, std::vector<int> &out) {
+        Csr ca(a), cb(b);
+        afv_match_job j{};
+        fill(j, a, b, ca, cb, mode);
+        const int nout = mode == AFV_MATCH_KF_FRAME ? b.N : a.N;
+        out.assign((size_t)std::max(nout, 1), -1);
+        int32_t n = 0;
+        const int rc = afv_match_bow(ctx, &j, 1, out.data(), &n);
+        if (rc != AFV_OK) fatal("afv_match_bow", rc, ctx);
+        out.resize((size_t)nout);
+        return n;
+    }
+    afv_ctx *ctx;
+    float mfNNratio;
+    bool mbCheckOrientation;
+};
+
+}  // namespace afv

@@ -18,6 +18,7 @@
 // ---- kernel launchers (k_*.hip) ----
 extern "C" void afv_launch_resize(const uint8_t *src, int sw, int sh, int spitch, size_t sframe, uint8_t *dst, int dw, int dh,
                                   int dpitch, size_t dframe, const short2 *xt, const short2 *yt, int nframes, hipStream_t stream);
+extern "C" int afv_resize_window_ok(int sw, int sh, int dw, int dh);
 extern "C" void afv_launch_fast_harris(const Geo *geo, int total_tiles, const FrameSrc *src0, const uint8_t *pyr,
                                        uint32_t *cand_packed, float *cand_resp, int *cand_count, int nframes, hipStream_t stream);
 extern "C" size_t afv_select_lds_bytes(int M);
@@ -207,6 +208,7 @@ static int build_geometry(const afv_orb_params &p, int w, int h, int max_batch, 
         L.w = cv_round((float)w * L.inv_scale);
         L.h = cv_round((float)h * L.inv_scale);
         if (L.w < 32 || L.h < 32) return AFV_EUNSUPPORTED;  // single-reflection apron needs >= 32 px levels
+        if (l > 0 && !afv_resize_window_ok(g.lv[l - 1].w, g.lv[l - 1].h, L.w, L.h)) return AFV_EUNSUPPORTED;  // scale factor > ~1.37
         L.pitch = (int)align_up((size_t)L.w, 64);
         L.tiles_x = (L.w + FT_W - 1) / FT_W;
         L.tiles_y = (L.h + FT_H - 1) / FT_H;

@@ -7,12 +7,12 @@
 // and mergeKeypointLevels (FeatureExtractor.cpp:296-308).
 //
 // The reference blurs whole levels (36 level-blurs per frame because compute() is called once per level).  Only the
-// 37x37 neighbourhood of a keypoint is ever sampled, so each wavefront stages the 43x43 UNBLURRED patch around its
-// keypoint in LDS (reflect-101 at the image edge = cv::ORB's apron), computes the intensity-centroid moments from it,
-// blurs it separably in LDS with the integer taps [18,34,49,55,49,34,18] (row pass exact int, column pass
-// round-half-even(S/65536)) and evaluates the 256 rotated tests from LDS.  A test that falls outside the level ROI
-// reads the unblurred apron pixel, as in OpenCV where only the ROI is blurred in place.  No blurred image ever
-// touches HBM.
+// 512 rotated test locations inside the 37x37 neighbourhood of a keypoint are ever sampled, so each wavefront stages
+// the 43x43 UNBLURRED patch around its keypoint in LDS (reflect-101 at the image edge = cv::ORB's apron), computes
+// the intensity-centroid moments from it and evaluates the blur ONLY at the sampled locations: 7 row sums with the
+// integer taps [18,34,49,55,49,34,18] (two v_dot4_u32_u8 per row on funnel-shifted dwords, exact), the column sum and
+// round-half-even(S/65536).  A test that falls outside the level ROI reads the unblurred apron pixel, as in OpenCV
+// where only the ROI is blurred in place.  No blurred image ever touches HBM.
 #include "afv_device.h"
 
 __device__ __constant__ const signed char k_brief_pattern[1024] = {
@@ -23,9 +23,7 @@ __device__ __constant__ const signed char k_umax[16] = {15, 15, 15, 15, 14, 14, 
 
 #define PR 21        // patch radius: 18 (BRIEF reach) + 3 (blur)
 #define PS 43        // patch side
-#define PP 48        // LDS pitch of the patch rows (dword staged)
-#define BS 37        // blurred side
-#define BP 40        // LDS pitch of the blurred rows
+#define PP 52        // LDS pitch of the patch rows: 13 dwords (odd => conflict-free row strides)
 #define KP_PER_BLOCK 4
 
 // cv::fastAtan2 (OpenCV mathfuncs_core atan_f32), degrees
@@ -97,6 +95,26 @@ __device__ __forceinline__ uint8_t blur_round(int S) {
     return (uint8_t)min(q, 255);
 }
 
+// 7-tap blur of the staged patch at patch position (row y, column x) [x, y relative to the patch origin, taps centred]:
+// exact integer arithmetic of the separable 8U filter: row sums with taps [18,34,49,55,49,34,18] (two v_dot4 per row
+// on funnel-shifted dwords), column sum, then round-half-even(S / 65536).
+__device__ __forceinline__ int blur_at(const uint8_t *P, int x, int y) {
+    const uint32_t T_LO = 18u | (34u << 8) | (49u << 16) | (55u << 24);  // taps for bytes x-3 .. x
+    const uint32_t T_HI = 49u | (34u << 8) | (18u << 16);                // taps for bytes x+1 .. x+3
+    const int xb = x - 3;
+    const int sh = (xb & 3) * 8;
+    const uint32_t *row = reinterpret_cast<const uint32_t *>(P + (y - 3) * PP + (xb & ~3));
+    uint32_t h[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const uint32_t d0 = row[k * (PP / 4)], d1 = row[k * (PP / 4) + 1], d2 = row[k * (PP / 4) + 2];
+        const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+        h[k] = __builtin_amdgcn_udot4(hi, T_HI, __builtin_amdgcn_udot4(lo, T_LO, 0u, false), false);
+    }
+    const int S = 18 * (int)(h[0] + h[6]) + 34 * (int)(h[1] + h[5]) + 49 * (int)(h[2] + h[4]) + 55 * (int)h[3];
+    return blur_round(S);
+}
+
 __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__restrict__ geo_p, FrameSrc src0,
                                                                 const uint8_t *__restrict__ pyr,
                                                                 const SelPoint *__restrict__ sel,
@@ -104,9 +122,9 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
                                                                 afv_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
                                                                 int cap_per_frame, int *__restrict__ n_out,
                                                                 int *__restrict__ status) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_patch[KP_PER_BLOCK][PS * PP];
-    __shared__ __attribute__((aligned(16))) uint16_t s_h[KP_PER_BLOCK][PS * BP];
-    __shared__ __attribute__((aligned(16))) uint8_t s_blur[KP_PER_BLOCK][BS * BP];
+    // patch rows are PP = 52 bytes apart (13 dwords: odd -> rows spread over all LDS banks); 2 guard rows/dwords so that
+    // the 3-dword row reads of blur_at never leave the slice
+    __shared__ __attribute__((aligned(16))) uint8_t s_patch[KP_PER_BLOCK][(PS + 1) * PP];
 
     const Geo &geo = *geo_p;
     const int l = blockIdx.y, f = blockIdx.z;
@@ -115,7 +133,7 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
     const int *sc = sel_count + f * AFV_MAX_LEVELS;
     const LevelGeo &L = geo.lv[l];
 
-    // frame-level bookkeeping by one wave: total count, capacity status
+    // frame-level bookkeeping: total count, capacity status
     int level_base = 0, total = 0;
     for (int i = 0; i < geo.nlevels; ++i) {
         const int c = sc[i];
@@ -143,13 +161,11 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
         pitch = L.pitch;
     }
     uint8_t *P = s_patch[wv];
-    uint16_t *H = s_h[wv];
-    uint8_t *B = s_blur[wv];
 
     // ---- 1. stage the 43x43 unblurred patch; P[r][a + c] = level(cx-21+c, cy-21+r) with reflect-101 ----
     const int px0 = cx - PR, py0 = cy - PR;
     int a;  // column offset of patch column 0 inside the LDS row
-    if (px0 >= 0 && py0 >= 0 && px0 + PP <= lw && py0 + PS <= lh) {
+    if (px0 >= 0 && py0 >= 0 && px0 + 48 <= lw && py0 + PS <= lh) {
         // interior: 12 aligned dwords per row, 5 rows per wave instruction
         a = px0 & 3;
         const int ax0 = px0 - a;
@@ -161,14 +177,17 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
             }
         }
     } else {
+        // border: lane = patch column (reflected once), rows reflected per iteration (wave-uniform)
         a = 0;
-        for (int i = lane; i < PS * PS; i += 64) {
-            const int r = i / PS, c = i - r * PS;
-            const int y = afv_reflect101(py0 + r, lh), x = afv_reflect101(px0 + c, lw);
-            P[r * PP + c] = img[(size_t)y * pitch + x];
+        if (lane < PS) {
+            const int x = afv_reflect101(px0 + lane, lw);
+            for (int r = 0; r < PS; ++r) {
+                const int y = afv_reflect101(py0 + r, lh);
+                P[r * PP + lane] = img[(size_t)y * pitch + x];
+            }
         }
     }
-    wave_sync();  // each wave owns its LDS slices: no workgroup barrier anywhere in this kernel
+    wave_sync();  // each wave owns its LDS slice: no workgroup barrier anywhere in this kernel
 
     // ---- 2. intensity centroid over the radius-15 disc: lane = (row, half) ----
     const uint8_t *C = &P[PR * PP + PR + a];  // patch centre
@@ -195,23 +214,8 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
     m01 = wave_sum(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-    // ---- 3. separable blur of the patch: H = row pass (43 rows x 37 cols), B = column pass (37 x 37) ----
-    for (int i = lane; i < PS * BS; i += 64) {
-        const int r = i / BS, c = i - r * BS;
-        const uint8_t *p = &P[r * PP + c + a];
-        const int acc = 18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3];
-        H[r * BP + c] = (uint16_t)acc;
-    }
-    wave_sync();
-    for (int i = lane; i < BS * BS; i += 64) {
-        const int r = i / BS, c = i - r * BS;
-        const uint16_t *h = &H[r * BP + c];
-        const int S = 18 * ((int)h[0] + h[6 * BP]) + 34 * ((int)h[BP] + h[5 * BP]) + 49 * ((int)h[2 * BP] + h[4 * BP]) + 55 * (int)h[3 * BP];
-        B[r * BP + c] = blur_round(S);
-    }
-    wave_sync();
-
-    // ---- 4. rotated BRIEF: lane handles tests lane, lane+64, lane+128, lane+192 ----
+    // ---- 3+4. rotated BRIEF on the blurred patch: lane handles tests lane, lane+64, lane+128, lane+192; the blur is
+    // evaluated only where a test samples it (512 of the 1369 patch positions) ----
     float ca, sb;
     sincos_deg(angle, ca, sb);
     // BRIEF centre = cvRound(pt * (1/scale)) with pt = level coordinate * scale (orb.cpp computeOrbDescriptors)
@@ -228,8 +232,8 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
         const int ix1 = (int)rintf(x1 * ca - y1 * sb) + ox, iy1 = (int)rintf(x1 * sb + y1 * ca) + oy;
         // inside the ROI -> blurred, outside -> unblurred apron
         const int gx0 = cx + ix0, gy0 = cy + iy0, gx1 = cx + ix1, gy1 = cy + iy1;
-        const int t0 = (gx0 >= 0 && gx0 < lw && gy0 >= 0 && gy0 < lh) ? B[(iy0 + 18) * BP + ix0 + 18] : C[iy0 * PP + ix0];
-        const int t1 = (gx1 >= 0 && gx1 < lw && gy1 >= 0 && gy1 < lh) ? B[(iy1 + 18) * BP + ix1 + 18] : C[iy1 * PP + ix1];
+        const int t0 = (gx0 >= 0 && gx0 < lw && gy0 >= 0 && gy0 < lh) ? blur_at(P, PR + a + ix0, PR + iy0) : C[iy0 * PP + ix0];
+        const int t1 = (gx1 >= 0 && gx1 < lw && gy1 >= 0 && gy1 < lh) ? blur_at(P, PR + a + ix1, PR + iy1) : C[iy1 * PP + ix1];
         const unsigned long long m = __ballot(t0 < t1);
         words[2 * g] = (uint32_t)m;
         words[2 * g + 1] = (uint32_t)(m >> 32);
