@@ -57,6 +57,16 @@ struct SelPoint {  // quadtree survivor, level coordinates
     float response;
 };
 
+// XCD-aware block -> work-item mapping (cdna_hip_programming.md T1): hardware places linear block b on XCD b % 8, each
+// XCD has its own L2.  Work items that share cache lines (neighbouring tiles of one frame) must therefore be given
+// to blocks that are congruent mod 8: XCD k takes the contiguous range [k*ceil(n/8), ...) of the work list.
+// Pure performance device: any placement computes the same result.
+static inline __device__ int afv_xcd_remap(int b, int n) {
+    const int per = (n + 7) >> 3;
+    const int v = (b & 7) * per + (b >> 3);
+    return v;  // may be >= n for the last XCDs when n % 8 != 0: caller skips
+}
+
 static inline __host__ __device__ int afv_reflect101(int p, int n) {
     // BORDER_REFLECT_101 for |overshoot| < n (apron 23 px / patch halo <= 21 px, levels >= 32 px)
     if (p < 0) p = -p;

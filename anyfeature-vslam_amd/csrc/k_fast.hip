@@ -119,7 +119,7 @@ __device__ __forceinline__ void wave_push(bool pred, unsigned short *list, int *
 
 __global__ __launch_bounds__(256) void k_fast_harris(const Geo *__restrict__ geo_p, FrameSrc src0, const uint8_t *__restrict__ pyr,
                                                      uint32_t *__restrict__ cand_packed, float *__restrict__ cand_resp,
-                                                     int *__restrict__ cand_count) {
+                                                     int *__restrict__ cand_count, int total_blocks) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[FT_LH * FT_LW];
     __shared__ __attribute__((aligned(16))) uint8_t sc[FT_LH * FT_LW];  // same geometry as `tile`
     __shared__ unsigned short pre[(FT_W + 2) * (FT_H + 2)];
@@ -127,13 +127,17 @@ __global__ __launch_bounds__(256) void k_fast_harris(const Geo *__restrict__ geo
     __shared__ int list_n, out_base, pre_n;
 
     const Geo &geo = *geo_p;
-    const int f = blockIdx.y;
+    // XCD-aware placement: every XCD works on whole frames, so the halo / cache-line sharing between neighbouring
+    // tiles stays inside one L2
+    const int work = afv_xcd_remap(blockIdx.x, total_blocks);
+    if (work >= total_blocks) return;
+    const int f = work / geo.total_tiles, tile_id = work - f * geo.total_tiles;
     int l = 0;
 #pragma unroll
     for (int i = 1; i < AFV_MAX_LEVELS; ++i)
-        if (i < geo.nlevels && (int)blockIdx.x >= geo.lv[i].tile_base) l = i;
+        if (i < geo.nlevels && tile_id >= geo.lv[i].tile_base) l = i;
     const LevelGeo &L = geo.lv[l];
-    const int t = blockIdx.x - L.tile_base;
+    const int t = tile_id - L.tile_base;
     const int tyi = t / L.tiles_x, txi = t - tyi * L.tiles_x;
     const int gx0 = txi * FT_W - FT_HALO, gy0 = tyi * FT_H - FT_HALO;
     const int lw = L.w, lh = L.h;
@@ -303,6 +307,7 @@ __global__ __launch_bounds__(256) void k_fast_harris(const Geo *__restrict__ geo
 // `geo` is the DEVICE copy of the geometry
 extern "C" void afv_launch_fast_harris(const Geo *geo, int total_tiles, const FrameSrc *src0, const uint8_t *pyr, uint32_t *cand_packed,
                                        float *cand_resp, int *cand_count, int nframes, hipStream_t stream) {
-    dim3 grid(total_tiles, nframes);
-    hipLaunchKernelGGL(k_fast_harris, grid, dim3(256), 0, stream, geo, *src0, pyr, cand_packed, cand_resp, cand_count);
+    const int total = total_tiles * nframes;
+    dim3 grid((total + 7) / 8 * 8);
+    hipLaunchKernelGGL(k_fast_harris, grid, dim3(256), 0, stream, geo, *src0, pyr, cand_packed, cand_resp, cand_count, total);
 }

@@ -23,12 +23,16 @@ struct ResizeTab {
 
 __global__ __launch_bounds__(256) void k_resize_level(const uint8_t *__restrict__ src, int sw, int sh, int spitch,
                                                       size_t sframe, uint8_t *__restrict__ dst, int dw, int dh,
-                                                      int dpitch, size_t dframe, ResizeTab tab) {
+                                                      int dpitch, size_t dframe, ResizeTab tab, int total_blocks) {
     __shared__ __attribute__((aligned(16))) uint8_t win[RS_H * RS_W];
     __shared__ short2 s_xt[RT_W];
     __shared__ short2 s_yt[RT_H];
-    const int f = blockIdx.z;
-    const int x0 = blockIdx.x * RT_W, y0 = blockIdx.y * RT_H;
+    // XCD-aware placement: whole frames per XCD (neighbouring tiles share source cache lines)
+    const int tiles_x = (dw + RT_W - 1) / RT_W, tiles_y = (dh + RT_H - 1) / RT_H;
+    const int work = afv_xcd_remap(blockIdx.x, total_blocks);
+    if (work >= total_blocks) return;
+    const int f = work / (tiles_x * tiles_y), tt = work - f * (tiles_x * tiles_y);
+    const int x0 = (tt % tiles_x) * RT_W, y0 = (tt / tiles_x) * RT_H;
     const int nx = min(RT_W, dw - x0), ny = min(RT_H, dh - y0);
     const uint8_t *s = src + (size_t)f * sframe;
     // source window: rows [sy0, sy1], dword-aligned columns [sx0, ...).  Offsets are monotone in the tables.
@@ -97,8 +101,9 @@ extern "C" int afv_resize_window_ok(int sw, int sh, int dw, int dh) {
 extern "C" void afv_launch_resize(const uint8_t *src, int sw, int sh, int spitch, size_t sframe, uint8_t *dst, int dw,
                                   int dh, int dpitch, size_t dframe, const short2 *xt, const short2 *yt, int nframes,
                                   hipStream_t stream) {
-    dim3 grid((dw + RT_W - 1) / RT_W, (dh + RT_H - 1) / RT_H, nframes);
+    const int total = ((dw + RT_W - 1) / RT_W) * ((dh + RT_H - 1) / RT_H) * nframes;
+    dim3 grid((total + 7) / 8 * 8);
     ResizeTab tab{xt, yt};
     hipLaunchKernelGGL(k_resize_level, grid, dim3(256), 0, stream, src, sw, sh, spitch, sframe, dst, dw, dh, dpitch,
-                       dframe, tab);
+                       dframe, tab, total);
 }

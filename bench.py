@@ -44,6 +44,21 @@ def level_pixels(w, h, nlevels=8, scale=1.2):
     return tot
 
 
+def pmc_traffic(kernel, batch):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r*/traffic_pmc.json: FETCH_SIZE
+    and WRITE_SIZE collected in separate passes and corrected as MI355X_MICROARCH.md prescribes); None if no pass was
+    taken at this batch size.  PMC counters cannot be read from inside a normal run."""
+    import glob
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic_pmc.json")), reverse=True):
+        try:
+            d = json.load(open(p))
+            if d.get("batch") == batch and kernel in d["kernels"]:
+                return d["kernels"][kernel]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+    return None
+
+
 def cpu_baseline(afv, nframes, seed0):
     """oracle, one thread: extraction (reference-faithful variant) + brute-force match of consecutive frames"""
     import oracle
@@ -169,7 +184,7 @@ def main():
                 ms = fh["total_ms"] / fh["launches"]
                 achieved = px * B / (ms * 1e-3) / 1e9
                 out["roofline"] = {"bound": "hbm", "kernel": "k_fast_harris", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                                   "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_fast_harris", B),
                                    "algorithmic_bytes_per_launch": px * B, "avg_launch_ms": ms,
                                    "note": "integer VALU-bound kernel (FAST ring tests): HBM fraction is low by construction, see DESIGN.md"}
             out["stage_ms_per_step"] = {kk: (v["total_ms"] / args.steps) for kk, v in stages.items()}
