@@ -13,6 +13,10 @@
 // SearchForTriangulation has no cross-row dependency: every wavefront takes its own rows.
 #include "afv_device.h"
 
+#ifndef AFV_EXP
+#define AFV_EXP 0
+#endif
+
 #define MT 256
 #define NO_KEY 0x7fffffff
 #define MAX_SIDE 8192  // features per side a job may hold (LDS bitset + bin table)
@@ -256,6 +260,7 @@ __global__ __launch_bounds__(MT) void k_match_topk(const uint8_t *__restrict__ d
 }
 
 #define PAIR_MAX_SIDE 4096  // rows / columns per set in the pairs path (LDS tables below)
+#define PAIR_LDS_DESC 1280  // side-2 sets up to this size are copied to LDS (40 KB) so that rescans never leave the CU
 #define WAVE_LDS_SYNC()                                        \
     do {                                                       \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
@@ -273,12 +278,18 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
     __shared__ unsigned short s_live[PAIR_MAX_SIDE];
     __shared__ int s_claim[PAIR_MAX_SIDE];
     __shared__ __attribute__((aligned(16))) int4 s_keys[2048];  // top-4 keys of the live rows (first 2048 of them)
+    __shared__ __attribute__((aligned(16))) uint32_t s_d2[PAIR_LDS_DESC * 8];  // side-2 descriptors for the exact rescan
     __shared__ int s_hist[32];
     __shared__ int s_wave[8];
     __shared__ int s_nm, s_drop[3];
     const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int a = pair_a[p], b = pair_b[p];
     const int n1 = min(nset[a], cap), n2 = min(nset[b], cap);
+    const bool d2_in_lds = n2 <= PAIR_LDS_DESC;
+    if (d2_in_lds) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(desc + (size_t)b * cap * 32);
+        for (int i = tid; i < n2 * 2; i += MT) reinterpret_cast<uint4 *>(s_d2)[i] = src[i];
+    }
     const int4 *tk = topk + (size_t)p * cap;
     int *out = match + (size_t)p * cap;
     for (int i = tid; i < cap; i += MT) out[i] = -1;
@@ -314,7 +325,7 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
         // and the outcome is exactly that of the sequential loop (FeatureMatcher.cc:587-641).
         int nm = 0;
         const uint32_t *d1 = reinterpret_cast<const uint32_t *>(desc + (size_t)a * cap * 32);
-        const uint32_t *d2 = reinterpret_cast<const uint32_t *>(desc + (size_t)b * cap * 32);
+        const uint32_t *d2 = d2_in_lds ? s_d2 : reinterpret_cast<const uint32_t *>(desc + (size_t)b * cap * 32);
         int pos = 0;
         while (pos < nlive) {
             const int li = pos + lane;
@@ -355,7 +366,10 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
                     e0 = -1;  // the best unmatched column already fails TH_LOW: final whatever happens to the set
                     e1 = -1;
                 } else if (exhausted && n2 > TOPK) {
-                    type = 2;
+                    // best found but the second-best unmatched column lies beyond the 4 keys: it is at least as far as
+                    // the last key, so the ratio test is already decided when it passes against that lower bound
+                    if (best != NO_KEY && (float)(best >> 16) < ratio * (float)(keys[TOPK - 1] >> 16)) type = 1;
+                    else type = 2;
                 } else if (best != NO_KEY) {
                     const float best1 = (float)(best >> 16);
                     const float best2 = second < 0 ? 3.402823466e+38f : (float)second;
@@ -376,11 +390,6 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
             if (commit) {
                 out[row] = e0;
                 atomicOr(&s_matched[e0 >> 5], 1u << (e0 & 31));
-                if (check_ori) {
-                    const int bin = rotation_bin(kps[(size_t)a * cap + row].angle, kps[(size_t)b * cap + e0].angle);
-                    s_bin[row] = (uint8_t)bin;
-                    atomicAdd(&s_hist[bin], 1);
-                }
             }
             nm += __popcll(__ballot(commit));
             if (type == 1) s_claim[e0] = 0x7fffffff;  // release every claim of this round
@@ -410,11 +419,6 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
                         if (lane == 0) {
                             out[i] = bcol;
                             s_matched[bcol >> 5] |= 1u << (bcol & 31);
-                            if (check_ori) {
-                                const int bin = rotation_bin(kps[(size_t)a * cap + i].angle, kps[(size_t)b * cap + bcol].angle);
-                                s_bin[i] = (uint8_t)bin;
-                                s_hist[bin]++;
-                            }
                         }
                         ++nm;
                     }
@@ -425,25 +429,34 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
                 pos += stop;
             }
         }
-        if (lane == 0) {
-            s_nm = nm;
-            int i1 = -1, i2 = -1, i3 = -1;
-            if (check_ori) {  // computeThreeMaxima (FeatureMatcher.cc:1631-1668)
-                int max1 = 0, max2 = 0, max3 = 0;
-                for (int i = 0; i < 30; ++i) {
-                    const int sz = s_hist[i];
-                    if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; i3 = i2; i2 = i1; i1 = i; }
-                    else if (sz > max2) { max3 = max2; max2 = sz; i3 = i2; i2 = i; }
-                    else if (sz > max3) { max3 = sz; i3 = i; }
-                }
-                if ((float)max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
-                else if ((float)max3 < 0.1f * (float)max1) { i3 = -1; }
-            }
-            s_drop[0] = i1; s_drop[1] = i2; s_drop[2] = i3;
-        }
+        if (lane == 0) s_nm = nm;
     }
     __syncthreads();
     if (check_ori) {
+        // rotation histogram of the accepted matches (FeatureMatcher.cc:1587-1599): it never influences the walk, so
+        // it is built afterwards by the whole workgroup
+        for (int i = tid; i < n1; i += MT) {
+            const int c = out[i];
+            if (c >= 0) {
+                const int bin = rotation_bin(kps[(size_t)a * cap + i].angle, kps[(size_t)b * cap + c].angle);
+                s_bin[i] = (uint8_t)bin;
+                atomicAdd(&s_hist[bin], 1);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {  // computeThreeMaxima (FeatureMatcher.cc:1631-1668)
+            int i1 = -1, i2 = -1, i3 = -1, max1 = 0, max2 = 0, max3 = 0;
+            for (int i = 0; i < 30; ++i) {
+                const int sz = s_hist[i];
+                if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; i3 = i2; i2 = i1; i1 = i; }
+                else if (sz > max2) { max3 = max2; max2 = sz; i3 = i2; i2 = i; }
+                else if (sz > max3) { max3 = sz; i3 = i; }
+            }
+            if ((float)max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+            else if ((float)max3 < 0.1f * (float)max1) { i3 = -1; }
+            s_drop[0] = i1; s_drop[1] = i2; s_drop[2] = i3;
+        }
+        __syncthreads();
         const int i1 = s_drop[0], i2 = s_drop[1], i3 = s_drop[2];
         int dropped = 0;
         for (int i = tid; i < n1; i += MT) {

@@ -34,14 +34,19 @@ import torch
 afv = importlib.import_module("anyfeature-vslam_amd")
 B = %d
 ctx = afv.Context(max_batch=B)
-frames = torch.from_numpy(afv.synth.corners_batch(1, 32)).cuda().repeat(B // 32, 1, 1).contiguous()
-for _ in range(2): ctx.extract_batch_device(frames)
+frames = torch.from_numpy(afv.synth.corners_batch(1, B)).cuda()
+afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+m = afv.FeatureMatcher(0.6, True, ctx=ctx)
+pa = torch.arange(B, dtype=torch.int32, device="cuda"); pb = (pa + B - 1) %% B
+for _ in range(2):
+    out = ctx.extract_batch_device(frames); m.match_pairs_device(out[1], out[0], out[2], pa, pb, th_low=75.0)
 torch.cuda.synchronize()
 ctx.profile_enable(True)
-for _ in range(%d): out = ctx.extract_batch_device(frames)
+for _ in range(%d):
+    out = ctx.extract_batch_device(frames); mm = m.match_pairs_device(out[1], out[0], out[2], pa, pb, th_low=75.0)
 torch.cuda.synchronize()
 st = ctx.profile_read()
-print(json.dumps({k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in st.items()}), int(out[2].sum().item()))
+print(json.dumps({k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in st.items()}), int(out[2].sum().item()), "nm_sum", int(mm[1].sum().item()), "nm_max", int(mm[1].max().item()))
 ''' % (ROOT, batch, steps)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     print("exp %d:" % n, (r.stdout.strip().splitlines() or [r.stderr[-400:]])[-1])
