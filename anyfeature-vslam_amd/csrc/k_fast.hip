@@ -20,9 +20,6 @@
 // raster index), see DESIGN.md "canonical order".
 #include "afv_device.h"
 
-#ifndef AFV_EXP
-#define AFV_EXP 0
-#endif
 
 typedef short short2v __attribute__((ext_vector_type(2)));
 
@@ -180,34 +177,49 @@ __global__ __launch_bounds__(256) void k_fast_harris(const Geo *__restrict__ geo
     }
     __syncthreads();
 
-#if AFV_EXP == 1
-    if (tile[threadIdx.x] == 300) cand_count[0] = 1;
-    return;
-#endif
-    // 2a. pre-test on LDS rows 3..36 x columns 3..68 (= tile pixels -1..64 x -1..32); survivors -> `pre`
+    // 2a. pre-test on LDS rows 3..36 x columns 3..68 (= tile pixels -1..64 x -1..32).  Each lane owns one column and
+    //     walks rows ty, ty+4, ...; its pass bits are collected in a register and compacted once per wavefront.
     const int thr = geo.fast_threshold;
     {
         const int col = 3 + tx, gx = gx0 + col;
         const bool col_ok = gx >= 3 && gx < lw - 3;
-        for (int r = ty; r < FT_H + 2; r += 4) {  // wave-uniform row
+        uint32_t bits = 0;
+#pragma unroll
+        for (int k = 0; k < (FT_H + 2 + 3) / 4; ++k) {
+            const int r = ty + 4 * k;  // wave-uniform row
             const int gy = gy0 + 3 + r;
-            if (gy < 3 || gy >= lh - 3) continue;
-            const int p = (r + 3) * FT_LW + col;
-            wave_push(col_ok && fast_pretest(&tile[p], thr), pre, &pre_n, (unsigned short)p, lane);
+            if (r < FT_H + 2 && gy >= 3 && gy < lh - 3) {
+                if (col_ok && fast_pretest(&tile[(r + 3) * FT_LW + col], thr)) bits |= 1u << k;
+            }
         }
-        if (threadIdx.x < 128) {  // the two extra columns 67, 68: 34 rows x 2 = 68 positions on waves 0 and 1
+        // the two extra columns 67, 68: 34 rows x 2 = 68 positions, handled by waves 0 and 1 (bit 15)
+        int p_extra = 0;
+        if (threadIdx.x < 128) {
             const int r = threadIdx.x >> 1, c2 = 67 + (threadIdx.x & 1);
             const int gy = gy0 + 3 + r, gx2 = gx0 + c2;
             const bool ok = r < FT_H + 2 && gy >= 3 && gy < lh - 3 && gx2 >= 3 && gx2 < lw - 3;
-            const int p = (r + 3) * FT_LW + c2;
-            wave_push(ok && fast_pretest(&tile[ok ? p : 4 * FT_LW + 4], thr), pre, &pre_n, (unsigned short)p, lane);
+            p_extra = (r + 3) * FT_LW + c2;
+            if (ok && fast_pretest(&tile[p_extra], thr)) bits |= 1u << 15;
+        }
+        // wave-level exclusive prefix of popcounts -> one LDS atomic per wavefront
+        const int cnt = __popc(bits);
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t2 = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t2;
+        }
+        int base = 0;
+        if (lane == 63) base = atomicAdd(&pre_n, incl);
+        base = __shfl(base, 63, 64) + incl - cnt;
+        uint32_t b = bits;
+        while (b) {
+            const int k = __builtin_ctz(b);
+            b &= b - 1;
+            pre[base++] = (unsigned short)(k == 15 ? p_extra : (ty + 4 * k + 3) * FT_LW + col);
         }
     }
     __syncthreads();
-#if AFV_EXP == 2
-    if (pre_n == 70000) cand_count[0] = 1;
-    return;
-#endif
     // 2b. exact corner score for the survivors (dense)
     const int npre = pre_n;
     for (int i = threadIdx.x; i < npre; i += 256) {
@@ -216,31 +228,32 @@ __global__ __launch_bounds__(256) void k_fast_harris(const Geo *__restrict__ geo
     }
     __syncthreads();
 
-#if AFV_EXP == 3
-    if (sc[threadIdx.x * 11] == 255) cand_count[0] = 1;
-    return;
-#endif
-    // 3. strict 3x3 maxima over the 64x32 interior -> LDS list
-    for (int r = ty; r < FT_H; r += 4) {
-        const uint8_t *p = &sc[(r + FT_HALO) * FT_LW + (tx + FT_HALO)];
-        const int s = p[0];
-        const bool keep = s != 0 && s > p[-1] && s > p[1] && s > p[-FT_LW - 1] && s > p[-FT_LW] && s > p[-FT_LW + 1] &&
-                          s > p[FT_LW - 1] && s > p[FT_LW] && s > p[FT_LW + 1];
+    // 3. strict 3x3 maxima -> LDS list.  Only scored positions can be corners, so the NMS walks the survivor list of
+    //    step 2 (interior positions only) instead of all 2048 pixels.
+    for (int i0 = 0; i0 < npre; i0 += 256) {
+        const int i = i0 + threadIdx.x;
+        bool keep = false;
+        int px = 0, py = 0, s0 = 0;
+        if (i < npre) {
+            const int p = pre[i];
+            py = p / FT_LW - FT_HALO;
+            px = p - (py + FT_HALO) * FT_LW - FT_HALO;
+            const uint8_t *q = &sc[p];
+            s0 = q[0];
+            keep = s0 != 0 && px >= 0 && px < FT_W && py >= 0 && py < FT_H && s0 > q[-1] && s0 > q[1] && s0 > q[-FT_LW - 1] &&
+                   s0 > q[-FT_LW] && s0 > q[-FT_LW + 1] && s0 > q[FT_LW - 1] && s0 > q[FT_LW] && s0 > q[FT_LW + 1];
+        }
         const unsigned long long m = __ballot(keep);
         if (m) {
             int base = 0;
             if (lane == 0) base = atomicAdd(&list_n, __popcll(m));
             base = __shfl(base, 0, 64);
-            if (keep) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)tx | ((uint32_t)r << 8) | ((uint32_t)s << 16);
+            if (keep) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)px | ((uint32_t)py << 8) | ((uint32_t)s0 << 16);
         }
     }
     __syncthreads();
     const int n = list_n;
     if (n == 0) return;
-#if AFV_EXP == 4
-    if (n == 70000) cand_count[0] = 1;
-    return;
-#endif
     if (threadIdx.x == 0) out_base = atomicAdd(&cand_count[f * AFV_MAX_LEVELS + l], n);
     __syncthreads();
 
@@ -255,7 +268,7 @@ __global__ __launch_bounds__(256) void k_fast_harris(const Geo *__restrict__ geo
         const uint32_t e = list[act ? ci : 0];
         const int px = e & 255, py = (e >> 8) & 255, s = e >> 16;
         int a = 0, b = 0, cc = 0;
-        if (act && sub < 7 && AFV_EXP != 6) {
+        if (act && sub < 7) {
             const uint8_t *c = &tile[(py + FT_HALO + (sub - 3)) * FT_LW + (px + FT_HALO)];
             // 3 source rows x 9 pixels [x-4, x+4]: three aligned dwords per row, funnel-shifted so that byte k of the
             // row sits at a lane-independent position (bytes are then picked with static SDWA selects)
@@ -293,7 +306,7 @@ __global__ __launch_bounds__(256) void k_fast_harris(const Geo *__restrict__ geo
             b += __shfl_xor(b, m, 64);
             cc += __shfl_xor(cc, m, 64);
         }
-        if (act && sub == 0 && (AFV_EXP != 5 || a == 123456789)) {
+        if (act && sub == 0) {
             const float fa = (float)a, fb = (float)b, fc = (float)cc;
             const float sum = fa + fb;
             const float resp = ((fa * fb - fc * fc) - (0.04f * sum) * sum) * geo.harris_scale4;
