@@ -69,7 +69,8 @@ SYMBOLS = {
     "afv_match_l2": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _f, _f, _vp, _vp]),
     "afv_hamming256": (_i, [_vp, _vp]),
     "afv_profile_enable": (_i, [_vp, _i]),
-    "afv_profile_read": (_i, [_vp, _vp, _vp]),
+    "afv_profile_read": (_i, [_vp, _vp, _vp, _vp]),
+    "afv_set_split_threshold": (_i, [_vp, _i]),
     "afv_get_geometry": (_i, [_vp, C.POINTER(Geometry)]),
     "afv_debug_get_level": (_i, [_vp, _i, _i, _vp]),
     "afv_debug_get_candidates": (_i, [_vp, _i, _i, _vp, _vp, _i, C.POINTER(_i)]),

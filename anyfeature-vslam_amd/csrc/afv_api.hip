@@ -17,17 +17,17 @@
 
 // ---- kernel launchers (k_*.hip) ----
 extern "C" void afv_launch_resize(const uint8_t *src, int sw, int sh, int spitch, size_t sframe, uint8_t *dst, int dw, int dh,
-                                  int dpitch, size_t dframe, const short2 *xt, const short2 *yt, int nframes, hipStream_t stream);
+                                  int dpitch, size_t dframe, const short2 *xt, const short2 *yt, int frame_base, int nframes, hipStream_t stream);
 extern "C" int afv_resize_window_ok(int sw, int sh, int dw, int dh);
 extern "C" void afv_launch_fast_harris(const Geo *geo, int total_tiles, const FrameSrc *src0, const uint8_t *pyr,
-                                       uint32_t *cand_packed, float *cand_resp, int *cand_count, int nframes, hipStream_t stream);
+                                       uint32_t *cand_packed, float *cand_resp, int *cand_count, int frame_base, int nframes, hipStream_t stream);
 extern "C" size_t afv_select_lds_bytes(int M);
 extern "C" void afv_launch_select(const Geo *geo_dev, int nlevels, const uint32_t *cand_packed, const float *cand_resp,
                                   const int *cand_count, uint32_t *kept_xy, float *kept_resp, uint16_t *kept_node, SelPoint *sel,
-                                  int *sel_count, int M, int nframes, hipStream_t stream);
+                                  int *sel_count, int M, int frame_base, int nframes, hipStream_t stream);
 extern "C" void afv_launch_describe(const Geo *geo_dev, int nlevels, int max_sel_cap, const FrameSrc *src0, const uint8_t *pyr,
                                     const SelPoint *sel, const int *sel_count, afv_keypoint *kps, uint8_t *desc,
-                                    int cap_per_frame, int *n_out, int *status, int nframes, hipStream_t stream);
+                                    int cap_per_frame, int *n_out, int *status, int frame_base, int nframes, hipStream_t stream);
 extern "C" void afv_launch_blur_level(const uint8_t *img, int w, int h, int pitch, uint8_t *out, hipStream_t stream);
 
 struct Seg { int s1, n1, s2, n2; };
@@ -49,7 +49,7 @@ extern "C" void afv_launch_match_pairs(const uint8_t *desc, const afv_keypoint *
                                        int *nmatches, hipStream_t stream);
 extern "C" void afv_launch_match_pairs2(const uint8_t *desc, const afv_keypoint *kps, const int *nset, int cap, const int *pa,
                                         const int *pb, int npairs, float th, float ratio, int check_ori, int *match,
-                                        int *nmatches, void *topk_scratch, hipStream_t stream);
+                                        int *nmatches, void *topk_scratch, int pair_base, hipStream_t stream);
 extern "C" void afv_launch_match_tri(const DevTriJob *jobs, int njobs, hipStream_t stream);
 extern "C" void afv_launch_match_l2(const float *d1, int n1, const float *d2, int n2, int dim, const uint8_t *v1,
                                     const uint8_t *v2, float th, float ratio, int *out, int *nmatches, hipStream_t stream);
@@ -59,6 +59,9 @@ extern "C" void afv_launch_match_l2(const float *d1, int n1, const float *d2, in
 struct afv_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // second lane for split batches (latency-bound kernels overlap VALU-bound ones)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int split_min_frames = 64;     // batches of at least this many frames / pairs are split over the two streams
     afv_orb_params p{};
     Geo geo{};          // current geometry (host copy)
     Geo cap_geo{};      // geometry of (max_width, max_height): sizes every allocation
@@ -99,6 +102,7 @@ struct afv_ctx {
     size_t prof_used[AFV_NUM_STAGES]{};
     int prof_launches[AFV_NUM_STAGES]{};
     float prof_ms[AFV_NUM_STAGES]{};
+    long long prof_units[AFV_NUM_STAGES]{};  // frames (pairs for the match stage) covered by the timed launches
 };
 
 struct StageTimer {  // RAII: record begin/end events around one stage on the launch stream
@@ -106,8 +110,9 @@ struct StageTimer {  // RAII: record begin/end events around one stage on the la
     int stage;
     hipStream_t s;
     hipEvent_t e1 = nullptr;
-    StageTimer(afv_ctx *c_, int stage_, hipStream_t s_) : c(c_), stage(stage_), s(s_) {
+    StageTimer(afv_ctx *c_, int stage_, hipStream_t s_, int units = 0) : c(c_), stage(stage_), s(s_) {
         if (!c->prof) return;
+        c->prof_units[stage] += units;
         auto &v = c->prof_ev[stage];
         size_t &u = c->prof_used[stage];
         if (u + 2 > v.size()) {
@@ -309,6 +314,7 @@ extern "C" void afv_destroy(afv_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     void *ptrs[] = {c->d_geo, c->d_tab, c->d_pyr, c->d_cand_packed, c->d_kept_xy, c->d_cand_resp, c->d_kept_resp,
                     c->d_kept_node, c->d_cand_count, c->d_sel_count, c->d_sel, c->d_frames, c->d_kps, c->d_desc,
                     c->d_n, c->d_status, c->d_match, c->d_topk};
@@ -316,6 +322,9 @@ extern "C" void afv_destroy(afv_ctx *c) {
         if (p) (void)hipFree(p);
     for (auto &v : c->prof_ev)
         for (hipEvent_t e : v) (void)hipEventDestroy(e);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -351,6 +360,9 @@ extern "C" int afv_create(int device, const afv_orb_params *params, afv_ctx **ou
     } while (0)
     CREATE_CHK(hipSetDevice(device));
     CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CREATE_CHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    CREATE_CHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    CREATE_CHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     CREATE_CHK(hipMalloc(&c->d_geo, sizeof(Geo)));
     c->tab_elems = 0;
     for (int l = 1; l < g.nlevels; ++l) c->tab_elems += (size_t)g.lv[l].w + (size_t)g.lv[l].h;
@@ -407,6 +419,12 @@ static void profile_drain(afv_ctx *c) {
     }
 }
 
+extern "C" int afv_set_split_threshold(afv_ctx *c, int min_frames) {
+    if (!c || min_frames < 2) return AFV_EINVAL;
+    c->split_min_frames = min_frames;
+    return AFV_OK;
+}
+
 extern "C" int afv_profile_enable(afv_ctx *c, int enable) {
     if (!c) return AFV_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
@@ -416,17 +434,19 @@ extern "C" int afv_profile_enable(afv_ctx *c, int enable) {
         for (int st = 0; st < AFV_NUM_STAGES; ++st) {
             c->prof_ms[st] = 0.f;
             c->prof_launches[st] = 0;
+            c->prof_units[st] = 0;
         }
     return AFV_OK;
 }
 
-extern "C" int afv_profile_read(afv_ctx *c, int32_t *launches, float *total_ms) {
+extern "C" int afv_profile_read(afv_ctx *c, int32_t *launches, float *total_ms, int64_t *units) {
     if (!c || !launches || !total_ms) return AFV_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
     profile_drain(c);
     for (int st = 0; st < AFV_NUM_STAGES; ++st) {
         launches[st] = c->prof_launches[st];
         total_ms[st] = c->prof_ms[st];
+        if (units) units[st] = c->prof_units[st];
     }
     return AFV_OK;
 }
@@ -450,37 +470,55 @@ extern "C" int afv_get_geometry(const afv_ctx *c, afv_geometry *g) {
 }
 
 // ---- the pipeline ----
-static int enqueue_extract(afv_ctx *c, const FrameSrc &src, int nframes, afv_keypoint *d_kps, uint8_t *d_desc, int cap,
-                           int *d_n, int *d_status, hipStream_t s) {
+// kernels of one contiguous frame range [f0, f0 + nf) on stream s
+static void enqueue_range(afv_ctx *c, const FrameSrc &src, int f0, int nf, afv_keypoint *d_kps, uint8_t *d_desc, int cap, int *d_n,
+                          int *d_status, hipStream_t s) {
     const Geo &g = c->geo;
-    HIPCHK(c, hipMemsetAsync(c->d_cand_count, 0, (size_t)nframes * AFV_MAX_LEVELS * sizeof(int), s));
-    if (d_status) HIPCHK(c, hipMemsetAsync(d_status, 0, sizeof(int), s));
+    (void)hipMemsetAsync(c->d_cand_count + (size_t)f0 * AFV_MAX_LEVELS, 0, (size_t)nf * AFV_MAX_LEVELS * sizeof(int), s);
     {
-    StageTimer t_(c, AFV_STAGE_PYRAMID, s);
-    for (int l = 1; l < g.nlevels; ++l) {
-        const LevelGeo &S = g.lv[l - 1], &D = g.lv[l];
-        const uint8_t *sp = (l == 1) ? src.base : c->d_pyr + S.pyr_off;
-        const int spitch = (l == 1) ? src.stride : S.pitch;
-        const size_t sframe = (l == 1) ? src.frame_stride : S.pyr_frame_stride;
-        afv_launch_resize(sp, S.w, S.h, spitch, sframe, c->d_pyr + D.pyr_off, D.w, D.h, D.pitch, D.pyr_frame_stride,
-                          c->d_tab + c->tab_off_x[l], c->d_tab + c->tab_off_y[l], nframes, s);
-    }
-    }
-    {
-        StageTimer t_(c, AFV_STAGE_FAST_HARRIS, s);
-        afv_launch_fast_harris(c->d_geo, g.total_tiles, &src, c->d_pyr, c->d_cand_packed, c->d_cand_resp, c->d_cand_count, nframes, s);
+        StageTimer t_(c, AFV_STAGE_PYRAMID, s, nf);
+        for (int l = 1; l < g.nlevels; ++l) {
+            const LevelGeo &S = g.lv[l - 1], &D = g.lv[l];
+            const uint8_t *sp = (l == 1) ? src.base : c->d_pyr + S.pyr_off;
+            const int spitch = (l == 1) ? src.stride : S.pitch;
+            const size_t sframe = (l == 1) ? src.frame_stride : S.pyr_frame_stride;
+            afv_launch_resize(sp, S.w, S.h, spitch, sframe, c->d_pyr + D.pyr_off, D.w, D.h, D.pitch, D.pyr_frame_stride,
+                              c->d_tab + c->tab_off_x[l], c->d_tab + c->tab_off_y[l], f0, nf, s);
+        }
     }
     {
-        StageTimer t_(c, AFV_STAGE_SELECT, s);
+        StageTimer t_(c, AFV_STAGE_FAST_HARRIS, s, nf);
+        afv_launch_fast_harris(c->d_geo, g.total_tiles, &src, c->d_pyr, c->d_cand_packed, c->d_cand_resp, c->d_cand_count, f0, nf, s);
+    }
+    {
+        StageTimer t_(c, AFV_STAGE_SELECT, s, nf);
         afv_launch_select(c->d_geo, g.nlevels, c->d_cand_packed, c->d_cand_resp, c->d_cand_count, c->d_kept_xy, c->d_kept_resp,
-                          c->d_kept_node, c->d_sel, c->d_sel_count, c->select_M, nframes, s);
+                          c->d_kept_node, c->d_sel, c->d_sel_count, c->select_M, f0, nf, s);
     }
     int max_sel = 0;
     for (int l = 0; l < g.nlevels; ++l) max_sel = std::max(max_sel, g.lv[l].sel_cap);
     {
-        StageTimer t_(c, AFV_STAGE_DESCRIBE, s);
+        StageTimer t_(c, AFV_STAGE_DESCRIBE, s, nf);
         afv_launch_describe(c->d_geo, g.nlevels, max_sel, &src, c->d_pyr, c->d_sel, c->d_sel_count, d_kps, d_desc, cap, d_n,
-                            d_status, nframes, s);
+                            d_status, f0, nf, s);
+    }
+}
+
+// ---- the pipeline ----
+static int enqueue_extract(afv_ctx *c, const FrameSrc &src, int nframes, afv_keypoint *d_kps, uint8_t *d_desc, int cap,
+                           int *d_n, int *d_status, hipStream_t s) {
+    if (d_status) HIPCHK(c, hipMemsetAsync(d_status, 0, sizeof(int), s));
+    if (nframes >= c->split_min_frames) {
+        // two halves on two streams: the select / describe tail of one half overlaps the FAST kernel of the other
+        const int h = nframes / 2;
+        HIPCHK(c, hipEventRecord(c->ev_fork, s));
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        enqueue_range(c, src, 0, h, d_kps, d_desc, cap, d_n, d_status, s);
+        enqueue_range(c, src, h, nframes - h, d_kps, d_desc, cap, d_n, d_status, c->stream2);
+        HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0));
+    } else {
+        enqueue_range(c, src, 0, nframes, d_kps, d_desc, cap, d_n, d_status, s);
     }
     HIPCHK(c, hipGetLastError());
     c->last_src = src;
@@ -887,9 +925,27 @@ extern "C" int afv_match_bruteforce_pairs_device(afv_ctx *c, const uint8_t *d_de
             HIPCHK(c, hipMalloc(&c->d_topk, need));
             c->topk_bytes = need;
         }
-        StageTimer t_(c, AFV_STAGE_MATCH, s);
-        afv_launch_match_pairs2(d_desc, d_kps, d_n, cap, d_pair_a, d_pair_b, npairs, th_low, nnratio, check_orientation, d_match,
-                                d_nmatches, c->d_topk, s);
+        if (npairs >= c->split_min_frames) {
+            const int h = npairs / 2;
+            HIPCHK(c, hipEventRecord(c->ev_fork, s));
+            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+            {
+                StageTimer t_(c, AFV_STAGE_MATCH, s, h);
+                afv_launch_match_pairs2(d_desc, d_kps, d_n, cap, d_pair_a, d_pair_b, h, th_low, nnratio, check_orientation, d_match,
+                                        d_nmatches, c->d_topk, 0, s);
+            }
+            {
+                StageTimer t_(c, AFV_STAGE_MATCH, c->stream2, npairs - h);
+                afv_launch_match_pairs2(d_desc, d_kps, d_n, cap, d_pair_a, d_pair_b, npairs - h, th_low, nnratio, check_orientation,
+                                        d_match, d_nmatches, c->d_topk, h, c->stream2);
+            }
+            HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
+            HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0));
+        } else {
+            StageTimer t_(c, AFV_STAGE_MATCH, s, npairs);
+            afv_launch_match_pairs2(d_desc, d_kps, d_n, cap, d_pair_a, d_pair_b, npairs, th_low, nnratio, check_orientation, d_match,
+                                    d_nmatches, c->d_topk, 0, s);
+        }
     }
     HIPCHK(c, hipGetLastError());
     return AFV_OK;

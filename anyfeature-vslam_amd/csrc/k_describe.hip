@@ -121,13 +121,13 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
                                                                 const int *__restrict__ sel_count,
                                                                 afv_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
                                                                 int cap_per_frame, int *__restrict__ n_out,
-                                                                int *__restrict__ status) {
+                                                                int *__restrict__ status, int frame_base) {
     // patch rows are PP = 52 bytes apart (13 dwords: odd -> rows spread over all LDS banks); 2 guard rows/dwords so that
     // the 3-dword row reads of blur_at never leave the slice
     __shared__ __attribute__((aligned(16))) uint8_t s_patch[KP_PER_BLOCK][(PS + 1) * PP];
 
     const Geo &geo = *geo_p;
-    const int l = blockIdx.y, f = blockIdx.z;
+    const int l = blockIdx.y, f = frame_base + blockIdx.z;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int idx = blockIdx.x * KP_PER_BLOCK + wv;
     const int *sc = sel_count + f * AFV_MAX_LEVELS;
@@ -262,10 +262,10 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
 
 extern "C" void afv_launch_describe(const Geo *geo_dev, int nlevels, int max_sel_cap, const FrameSrc *src0, const uint8_t *pyr,
                                     const SelPoint *sel, const int *sel_count, afv_keypoint *kps, uint8_t *desc,
-                                    int cap_per_frame, int *n_out, int *status, int nframes, hipStream_t stream) {
+                                    int cap_per_frame, int *n_out, int *status, int frame_base, int nframes, hipStream_t stream) {
     dim3 grid((max_sel_cap + KP_PER_BLOCK - 1) / KP_PER_BLOCK, nlevels, nframes);
     hipLaunchKernelGGL(k_describe, grid, dim3(64 * KP_PER_BLOCK), 0, stream, geo_dev, *src0, pyr, sel, sel_count, kps, desc,
-                       cap_per_frame, n_out, status);
+                       cap_per_frame, n_out, status, frame_base);
 }
 
 // ---------------- standalone E9: blur one level of one frame (debug / parity of the blur arithmetic) ----------------

@@ -116,7 +116,7 @@ __device__ __forceinline__ void wave_push(bool pred, unsigned short *list, int *
 
 __global__ __launch_bounds__(256) void k_fast_harris(const Geo *__restrict__ geo_p, FrameSrc src0, const uint8_t *__restrict__ pyr,
                                                      uint32_t *__restrict__ cand_packed, float *__restrict__ cand_resp,
-                                                     int *__restrict__ cand_count, int total_blocks) {
+                                                     int *__restrict__ cand_count, int total_blocks, int frame_base) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[FT_LH * FT_LW];
     __shared__ __attribute__((aligned(16))) uint8_t sc[FT_LH * FT_LW];  // same geometry as `tile`
     __shared__ unsigned short pre[(FT_W + 2) * (FT_H + 2)];
@@ -128,7 +128,8 @@ __global__ __launch_bounds__(256) void k_fast_harris(const Geo *__restrict__ geo
     // tiles stays inside one L2
     const int work = afv_xcd_remap(blockIdx.x, total_blocks);
     if (work >= total_blocks) return;
-    const int f = work / geo.total_tiles, tile_id = work - f * geo.total_tiles;
+    const int f0 = work / geo.total_tiles, tile_id = work - f0 * geo.total_tiles;
+    const int f = frame_base + f0;
     int l = 0;
 #pragma unroll
     for (int i = 1; i < AFV_MAX_LEVELS; ++i)
@@ -319,8 +320,8 @@ __global__ __launch_bounds__(256) void k_fast_harris(const Geo *__restrict__ geo
 
 // `geo` is the DEVICE copy of the geometry
 extern "C" void afv_launch_fast_harris(const Geo *geo, int total_tiles, const FrameSrc *src0, const uint8_t *pyr, uint32_t *cand_packed,
-                                       float *cand_resp, int *cand_count, int nframes, hipStream_t stream) {
+                                       float *cand_resp, int *cand_count, int frame_base, int nframes, hipStream_t stream) {
     const int total = total_tiles * nframes;
     dim3 grid((total + 7) / 8 * 8);
-    hipLaunchKernelGGL(k_fast_harris, grid, dim3(256), 0, stream, geo, *src0, pyr, cand_packed, cand_resp, cand_count, total);
+    hipLaunchKernelGGL(k_fast_harris, grid, dim3(256), 0, stream, geo, *src0, pyr, cand_packed, cand_resp, cand_count, total, frame_base);
 }

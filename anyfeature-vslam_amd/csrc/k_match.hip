@@ -228,9 +228,9 @@ __global__ __launch_bounds__(MT) void k_match_pairs(const uint8_t *__restrict__ 
 
 __global__ __launch_bounds__(MT) void k_match_topk(const uint8_t *__restrict__ desc, const int *__restrict__ nset, int cap,
                                                    const int *__restrict__ pair_a, const int *__restrict__ pair_b,
-                                                   int4 *__restrict__ topk) {
+                                                   int4 *__restrict__ topk, int pair_base) {
     __shared__ __attribute__((aligned(16))) uint32_t s_cols[COL_TILE * 8];
-    const int p = blockIdx.y;
+    const int p = pair_base + blockIdx.y;
     const int a = pair_a[p], b = pair_b[p];
     const int n1 = min(nset[a], cap), n2 = min(nset[b], cap);
     const int row = blockIdx.x * MT + threadIdx.x;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
                                                       const int *__restrict__ nset, int cap, const int *__restrict__ pair_a,
                                                       const int *__restrict__ pair_b, const int4 *__restrict__ topk, float th,
                                                       float ratio, int check_ori, int *__restrict__ match,
-                                                      int *__restrict__ nmatches) {
+                                                      int *__restrict__ nmatches, int pair_base) {
     __shared__ uint32_t s_matched[PAIR_MAX_SIDE / 32];
     __shared__ uint8_t s_bin[PAIR_MAX_SIDE];
     __shared__ unsigned short s_live[PAIR_MAX_SIDE];
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
     __shared__ int s_hist[32];
     __shared__ int s_wave[8];
     __shared__ int s_nm, s_drop[3];
-    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int p = pair_base + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int a = pair_a[p], b = pair_b[p];
     const int n1 = min(nset[a], cap), n2 = min(nset[b], cap);
     const bool d2_in_lds = n2 <= PAIR_LDS_DESC;
@@ -621,11 +621,11 @@ extern "C" void afv_launch_match_pairs(const uint8_t *desc, const afv_keypoint *
 }
 extern "C" void afv_launch_match_pairs2(const uint8_t *desc, const afv_keypoint *kps, const int *nset, int cap, const int *pa,
                                         const int *pb, int npairs, float th, float ratio, int check_ori, int *match,
-                                        int *nmatches, void *topk_scratch, hipStream_t stream) {
+                                        int *nmatches, void *topk_scratch, int pair_base, hipStream_t stream) {
     int4 *topk = reinterpret_cast<int4 *>(topk_scratch);
-    hipLaunchKernelGGL(k_match_topk, dim3((cap + MT - 1) / MT, npairs), dim3(MT), 0, stream, desc, nset, cap, pa, pb, topk);
+    hipLaunchKernelGGL(k_match_topk, dim3((cap + MT - 1) / MT, npairs), dim3(MT), 0, stream, desc, nset, cap, pa, pb, topk, pair_base);
     hipLaunchKernelGGL(k_match_resolve, dim3(npairs), dim3(MT), 0, stream, desc, kps, nset, cap, pa, pb, topk, th, ratio,
-                       check_ori, match, nmatches);
+                       check_ori, match, nmatches, pair_base);
 }
 extern "C" void afv_launch_match_tri(const DevTriJob *jobs, int njobs, hipStream_t stream) {
     hipLaunchKernelGGL(k_match_tri, dim3(njobs), dim3(MT), 0, stream, jobs);

@@ -23,7 +23,7 @@ struct ResizeTab {
 
 __global__ __launch_bounds__(256) void k_resize_level(const uint8_t *__restrict__ src, int sw, int sh, int spitch,
                                                       size_t sframe, uint8_t *__restrict__ dst, int dw, int dh,
-                                                      int dpitch, size_t dframe, ResizeTab tab, int total_blocks) {
+                                                      int dpitch, size_t dframe, ResizeTab tab, int total_blocks, int frame_base) {
     __shared__ __attribute__((aligned(16))) uint8_t win[RS_H * RS_W];
     __shared__ short2 s_xt[RT_W];
     __shared__ short2 s_yt[RT_H];
@@ -31,7 +31,8 @@ __global__ __launch_bounds__(256) void k_resize_level(const uint8_t *__restrict_
     const int tiles_x = (dw + RT_W - 1) / RT_W, tiles_y = (dh + RT_H - 1) / RT_H;
     const int work = afv_xcd_remap(blockIdx.x, total_blocks);
     if (work >= total_blocks) return;
-    const int f = work / (tiles_x * tiles_y), tt = work - f * (tiles_x * tiles_y);
+    const int fl = work / (tiles_x * tiles_y), tt = work - fl * (tiles_x * tiles_y);
+    const int f = frame_base + fl;
     const int x0 = (tt % tiles_x) * RT_W, y0 = (tt / tiles_x) * RT_H;
     const int nx = min(RT_W, dw - x0), ny = min(RT_H, dh - y0);
     const uint8_t *s = src + (size_t)f * sframe;
@@ -99,11 +100,11 @@ extern "C" int afv_resize_window_ok(int sw, int sh, int dw, int dh) {
 }
 
 extern "C" void afv_launch_resize(const uint8_t *src, int sw, int sh, int spitch, size_t sframe, uint8_t *dst, int dw,
-                                  int dh, int dpitch, size_t dframe, const short2 *xt, const short2 *yt, int nframes,
-                                  hipStream_t stream) {
+                                  int dh, int dpitch, size_t dframe, const short2 *xt, const short2 *yt, int frame_base,
+                                  int nframes, hipStream_t stream) {
     const int total = ((dw + RT_W - 1) / RT_W) * ((dh + RT_H - 1) / RT_H) * nframes;
     dim3 grid((total + 7) / 8 * 8);
     ResizeTab tab{xt, yt};
     hipLaunchKernelGGL(k_resize_level, grid, dim3(256), 0, stream, src, sw, sh, spitch, sframe, dst, dw, dh, dpitch,
-                       dframe, tab, total);
+                       dframe, tab, total, frame_base);
 }

@@ -161,8 +161,13 @@ class Context:
 
     def profile_read(self):
         launches = np.zeros(len(_lib.STAGES), np.int32); ms = np.zeros(len(_lib.STAGES), np.float32)
-        self.check(self.lib.afv_profile_read(self.handle, ptr(launches), ptr(ms)))
-        return {name: {"launches": int(launches[i]), "total_ms": float(ms[i])} for i, name in enumerate(_lib.STAGES)}
+        units = np.zeros(len(_lib.STAGES), np.int64)
+        self.check(self.lib.afv_profile_read(self.handle, ptr(launches), ptr(ms), ptr(units)))
+        return {name: {"launches": int(launches[i]), "total_ms": float(ms[i]), "units": int(units[i])}
+                for i, name in enumerate(_lib.STAGES)}
+
+    def set_split_threshold(self, min_frames):
+        self.check(self.lib.afv_set_split_threshold(self.handle, int(min_frames)))
 
     # ---- stage introspection (parity tests) ----
     def debug_level(self, frame, level):

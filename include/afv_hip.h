@@ -149,7 +149,11 @@ int afv_hamming256(const uint8_t *a, const uint8_t *b);
 enum { AFV_STAGE_PYRAMID = 0, AFV_STAGE_FAST_HARRIS = 1, AFV_STAGE_SELECT = 2, AFV_STAGE_DESCRIBE = 3, AFV_STAGE_MATCH = 4,
        AFV_NUM_STAGES = 5 };
 int afv_profile_enable(afv_ctx *ctx, int enable);
-int afv_profile_read(afv_ctx *ctx, int32_t *launches /*[AFV_NUM_STAGES]*/, float *total_ms /*[AFV_NUM_STAGES]*/);
+int afv_profile_read(afv_ctx *ctx, int32_t *launches /*[AFV_NUM_STAGES]*/, float *total_ms /*[AFV_NUM_STAGES]*/,
+                     int64_t *units /*[AFV_NUM_STAGES], frames (pairs for MATCH) covered by those launches; may be NULL*/);
+/* batches of at least `min_frames` frames (pairs) are split over the context's two streams so that latency-bound kernels of
+ * one half overlap the VALU-bound ones of the other (default 64; 0x7fffffff disables the split) */
+int afv_set_split_threshold(afv_ctx *ctx, int min_frames);
 
 /* ---- stage-level introspection of the LAST afv_orb_extract* call (parity tests / profiling) ---- */
 typedef struct {

@@ -254,3 +254,42 @@ def test_batch_properties_at_full_size(gpu_ctx, afv):
         counts = np.bincount(ki["octave"], minlength=8)
         assert all(quota[l] <= counts[l] <= quota[l] + 2 for l in range(8))
     ctx.close()
+
+
+def test_split_batch_two_streams(afv, oracle):
+    """batches >= 64 frames are split over the context's two streams (odd sizes included): every frame must still be
+    bit-identical to the single-frame path, and the frame-pair matcher split must equal the oracle"""
+    import torch
+    nf = 67
+    ctx = afv.Context(max_batch=nf)
+    uniq = [afv.synth.corners_frame(300 + i) for i in range(5)]
+    frames = np.stack([uniq[i % 5] for i in range(nf)])
+    ref = [oracle.orb_extract(u) for u in uniq]
+    t = torch.from_numpy(frames).cuda()
+    kps, desc, n, st = ctx.extract_batch_device(t)
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+    m = afv.FeatureMatcher(0.6, True, ctx=ctx)
+    pa = torch.arange(nf, dtype=torch.int32, device="cuda")
+    pb = (pa + nf - 1) % nf
+    match, nm = m.match_pairs_device(desc, kps, n, pa, pb, th_low=75.0)
+    torch.cuda.synchronize()
+    assert int(st.item()) == 0
+    kps = kps.cpu().numpy(); desc = desc.cpu().numpy(); n = n.cpu().numpy(); match = match.cpu().numpy(); nm = nm.cpu().numpy()
+    for i in range(nf):
+        rk, rd = ref[i % 5]
+        assert n[i] == len(rk)
+        assert kps[i, :n[i]].reshape(-1).view(afv.KP_DTYPE).tobytes() == rk.tobytes() and np.array_equal(desc[i, :n[i]], rd), i
+    want = {}
+    for i in range(nf):
+        a, b = i % 5, ((i + nf - 1) % nf) % 5
+        if (a, b) not in want:
+            want[(a, b)] = oracle.search_by_bow_kf_kf(ref[a][1], ref[b][1], angle1=ref[a][0]["angle"], angle2=ref[b][0]["angle"],
+                                                      th_low=75.0, nnratio=0.6, check_orientation=True)
+        w, wn = want[(a, b)]
+        assert nm[i] == wn and np.array_equal(match[i, :n[i]], w), i
+    # the split can be switched off and gives the same bytes
+    ctx.set_split_threshold(1 << 30)
+    k2, d2, n2, _ = ctx.extract_batch_device(t)
+    torch.cuda.synchronize()
+    assert np.array_equal(n2.cpu().numpy(), n) and np.array_equal(d2.cpu().numpy()[:, :900], desc[:, :900])
+    ctx.close()
