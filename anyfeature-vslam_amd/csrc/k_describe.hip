@@ -121,15 +121,21 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
                                                                 const int *__restrict__ sel_count,
                                                                 afv_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
                                                                 int cap_per_frame, int *__restrict__ n_out,
-                                                                int *__restrict__ status, int frame_base) {
+                                                                int *__restrict__ status, int frame_base, int nblk_x, int total_blocks) {
     // patch rows are PP = 52 bytes apart (13 dwords: odd -> rows spread over all LDS banks); 2 guard rows/dwords so that
     // the 3-dword row reads of blur_at never leave the slice
     __shared__ __attribute__((aligned(16))) uint8_t s_patch[KP_PER_BLOCK][(PS + 1) * PP];
 
     const Geo &geo = *geo_p;
-    const int l = blockIdx.y, f = frame_base + blockIdx.z;
+    // XCD-aware placement: all keypoints of a frame are described on one XCD (their patches share L2 lines)
+    const int work = afv_xcd_remap(blockIdx.x, total_blocks);
+    if (work >= total_blocks) return;
+    const int per_frame = nblk_x * geo.nlevels;
+    const int fl = work / per_frame, rem = work - fl * per_frame;
+    const int l = rem / nblk_x, kblk = rem - l * nblk_x;
+    const int f = frame_base + fl;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int idx = blockIdx.x * KP_PER_BLOCK + wv;
+    const int idx = kblk * KP_PER_BLOCK + wv;
     const int *sc = sel_count + f * AFV_MAX_LEVELS;
     const LevelGeo &L = geo.lv[l];
 
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
         if (i < l) level_base += c;
         total += c;
     }
-    if (blockIdx.x == 0 && l == 0 && threadIdx.x == 0) {
+    if (kblk == 0 && l == 0 && threadIdx.x == 0) {
         n_out[f] = min(total, cap_per_frame);
         if (status && total > cap_per_frame) atomicMin(status, AFV_ECAPACITY);
     }
@@ -263,9 +269,11 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
 extern "C" void afv_launch_describe(const Geo *geo_dev, int nlevels, int max_sel_cap, const FrameSrc *src0, const uint8_t *pyr,
                                     const SelPoint *sel, const int *sel_count, afv_keypoint *kps, uint8_t *desc,
                                     int cap_per_frame, int *n_out, int *status, int frame_base, int nframes, hipStream_t stream) {
-    dim3 grid((max_sel_cap + KP_PER_BLOCK - 1) / KP_PER_BLOCK, nlevels, nframes);
+    const int nblk_x = (max_sel_cap + KP_PER_BLOCK - 1) / KP_PER_BLOCK;
+    const int total = nblk_x * nlevels * nframes;
+    dim3 grid((total + 7) / 8 * 8);
     hipLaunchKernelGGL(k_describe, grid, dim3(64 * KP_PER_BLOCK), 0, stream, geo_dev, *src0, pyr, sel, sel_count, kps, desc,
-                       cap_per_frame, n_out, status, frame_base);
+                       cap_per_frame, n_out, status, frame_base, nblk_x, total);
 }
 
 // ---------------- standalone E9: blur one level of one frame (debug / parity of the blur arithmetic) ----------------

@@ -129,7 +129,8 @@ __global__ __launch_bounds__(ST) void k_select_quadtree(const Geo *__restrict__ 
                                                        const float *__restrict__ cand_resp,
                                                        const int *__restrict__ cand_count, uint32_t *__restrict__ kept_xy,
                                                        float *__restrict__ kept_resp, uint16_t *__restrict__ kept_node,
-                                                       SelPoint *__restrict__ sel, int *__restrict__ sel_count, int M, int frame_base) {
+                                                       SelPoint *__restrict__ sel, int *__restrict__ sel_count, int M, int frame_base,
+                                                       int total_blocks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *hist = reinterpret_cast<int *>(smem);
     unsigned long long *best = reinterpret_cast<unsigned long long *>(hist + 2048);
@@ -144,7 +145,10 @@ __global__ __launch_bounds__(ST) void k_select_quadtree(const Geo *__restrict__ 
     uint16_t *remap = reinterpret_cast<uint16_t *>(tmp + 16);
 
     const Geo &geo = *geo_p;
-    const int l = blockIdx.x, f = frame_base + blockIdx.y;
+    // XCD-aware placement: the 8 level-workgroups of a frame run on one XCD (they read what that frame's FAST tiles wrote)
+    const int work = afv_xcd_remap(blockIdx.x, total_blocks);
+    if (work >= total_blocks) return;
+    const int l = work % geo.nlevels, f = frame_base + work / geo.nlevels;
     const LevelGeo &L = geo.lv[l];
     const size_t base = L.cand_off + (size_t)f * L.cand_frame_stride;
     const uint32_t *cp = cand_packed + base;
@@ -442,7 +446,8 @@ extern "C" size_t afv_select_lds_bytes(int M) {
 extern "C" void afv_launch_select(const Geo *geo_dev, int nlevels, const uint32_t *cand_packed, const float *cand_resp,
                                   const int *cand_count, uint32_t *kept_xy, float *kept_resp, uint16_t *kept_node,
                                   SelPoint *sel, int *sel_count, int M, int frame_base, int nframes, hipStream_t stream) {
-    dim3 grid(nlevels, nframes);
+    const int total = nlevels * nframes;
+    dim3 grid((total + 7) / 8 * 8);
     hipLaunchKernelGGL(k_select_quadtree, grid, dim3(ST), afv_select_lds_bytes(M), stream, geo_dev, cand_packed, cand_resp,
-                       cand_count, kept_xy, kept_resp, kept_node, sel, sel_count, M, frame_base);
+                       cand_count, kept_xy, kept_resp, kept_node, sel, sel_count, M, frame_base, total);
 }

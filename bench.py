@@ -45,7 +45,7 @@ def level_pixels(w, h, nlevels=8, scale=1.2):
 
 
 def pmc_traffic(kernel, batch):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r*/traffic_pmc.json: FETCH_SIZE
+    """HBM bytes per FRAME of `kernel` from the committed rocprofv3 PMC passes (profiles/r*/traffic_pmc.json: FETCH_SIZE
     and WRITE_SIZE collected in separate passes and corrected as MI355X_MICROARCH.md prescribes); None if no pass was
     taken at this batch size.  PMC counters cannot be read from inside a normal run."""
     import glob
@@ -53,7 +53,7 @@ def pmc_traffic(kernel, batch):
         try:
             d = json.load(open(p))
             if d.get("batch") == batch and kernel in d["kernels"]:
-                return d["kernels"][kernel]["hbm_bytes_per_launch"]
+                return d["kernels"][kernel]["hbm_bytes_per_frame"]
         except Exception:
             pass
     return None
@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
-    ap.add_argument("--cpu-frames", type=int, default=24, help="frames in the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=256, help="frames in the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage hipEvents")
     args = ap.parse_args()
 
@@ -187,7 +187,7 @@ def main():
                 traffic = pmc_traffic("k_fast_harris", B)
                 out["roofline"] = {"bound": "hbm", "kernel": "k_fast_harris", "achieved": achieved, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                   "traffic": None if traffic is None else traffic * frames_per_launch / B,
+                                   "traffic": None if traffic is None else traffic * frames_per_launch,
                                    "algorithmic_bytes_per_launch": px * frames_per_launch, "avg_launch_ms": ms,
                                    "frames_per_launch": frames_per_launch,
                                    "note": "integer-VALU-bound kernel (FAST ring tests + Harris): the HBM fraction is low by "
