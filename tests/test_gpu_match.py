@@ -247,3 +247,38 @@ def test_device_pairs_heavy_contention(afv, oracle, matcher, gpu_ctx, nproto, fl
                                                       check_orientation=ori)
                 assert nm[p] == wn and np.array_equal(match[p, :counts[a]], want), (p, ori, ratio)
     matcher.mfNNratio = 0.6
+
+
+def test_config4_pair_jobs_from_descriptor_table(afv, oracle, matcher, gpu_ctx):
+    """config #4 shape on one GPU: K keyframes x N x 32 B table (keyframe k+1 = perturbed keyframe k), LCG-drawn (i, j)
+    pair jobs through dist.match_jobs_sharded with the DEVICE matcher (world size 1: broadcast is a no-op)"""
+    import importlib
+    import torch
+    dist_mod = importlib.import_module("anyfeature-vslam_amd.dist")
+    s = afv.synth
+    K, cap, njobs = 40, 512, 300
+    table = np.zeros((K, cap, 32), np.uint8)
+    counts = np.zeros(K, np.int32)
+    d = s.random_descriptors(5, cap)
+    for k in range(K):
+        nk = cap - (k * 7) % 60
+        table[k, :nk] = d[:nk]
+        counts[k] = nk
+        d = s.perturbed_descriptors(d, 500 + k)
+    a, b = dist_mod.lcg_pairs(9, njobs, K)
+    t_table = torch.from_numpy(table).cuda(); t_counts = torch.from_numpy(counts).cuda()
+    matcher.mbCheckOrientation = False
+    matcher.mfNNratio = 0.6
+
+    def device_match(tab, cnt, pa, pb):
+        _, nm = matcher.match_pairs_device(tab, None, cnt, pa.contiguous(), pb.contiguous(), th_low=75.0, check_orientation=False)
+        return nm
+
+    got = dist_mod.match_jobs_sharded(t_table, t_counts, torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), device_match)
+    torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    for j in range(0, njobs, 7):
+        _, wn = oracle.search_by_bow_kf_kf(table[a[j], :counts[a[j]]], table[b[j], :counts[b[j]]], th_low=75.0, nnratio=0.6)
+        assert got[j] == wn, j
+    assert got.sum() > 50  # only keyframes a few perturbation steps apart still match
+    matcher.mbCheckOrientation = True
