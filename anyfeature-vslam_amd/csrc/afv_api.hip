@@ -44,6 +44,8 @@ struct DevTriJob {
     float ex, ey;
 };
 extern "C" void afv_launch_match_bow(const DevMatchJob *jobs, int njobs, hipStream_t stream);
+extern "C" void afv_launch_match_bow_seg(const DevMatchJob *jobs, int njobs, const void *tasks, int ntasks, int *hist, uint8_t *bins,
+                                         const int *bin_off, int any_ori, hipStream_t stream);
 extern "C" void afv_launch_match_pairs(const uint8_t *desc, const afv_keypoint *kps, const int *nset, int cap, const int *pa,
                                        const int *pb, int npairs, float th, float ratio, int check_ori, int *match,
                                        int *nmatches, hipStream_t stream);
@@ -825,15 +827,105 @@ extern "C" int afv_match_bow(afv_ctx *c, const afv_match_job *jobs, int njobs, i
         if (jobs[i].mode != AFV_MATCH_KF_KF && jobs[i].mode != AFV_MATCH_KF_FRAME) return AFV_EINVAL;
     }
     HIPCHK(c, hipSetDevice(c->device));
+    {
+        // plain brute-force KF-KF jobs over 32-byte descriptors take the two-phase path of the device pipeline
+        // (parallel top-4 + ordered resolve): stage them as a descriptor table of 2 sets per job
+        bool eligible = true;
+        int cap = 1;
+        for (int i = 0; i < njobs; ++i) {
+            const afv_match_job &j = jobs[i];
+            eligible = eligible && (j.nnodes1 == 0 || j.nnodes2 == 0) && j.mode == AFV_MATCH_KF_KF && j.desc_bytes == 32 &&
+                       !j.valid1 && !j.valid2 && j.n1 <= 4096 && j.n2 <= 4096;
+            cap = std::max(cap, std::max(j.n1, j.n2));
+        }
+        if (eligible) {
+            Blob b;
+            const int nsets = 2 * njobs;
+            const size_t desc_off = b.reserve((size_t)nsets * cap * 32);
+            const size_t n_off = b.reserve((size_t)nsets * 4);
+            const size_t pa_off = b.reserve((size_t)njobs * 4), pb_off = b.reserve((size_t)njobs * 4);
+            bool any_ori = false;
+            for (int i = 0; i < njobs; ++i) any_ori = any_ori || jobs[i].check_orientation;
+            const size_t kps_off = any_ori ? b.reserve((size_t)nsets * cap * sizeof(afv_keypoint)) : 0;
+            for (int i = 0; i < njobs; ++i) {
+                const afv_match_job &j = jobs[i];
+                if (j.n1) std::memcpy(b.h.data() + desc_off + (size_t)(2 * i) * cap * 32, j.desc1, (size_t)j.n1 * 32);
+                if (j.n2) std::memcpy(b.h.data() + desc_off + (size_t)(2 * i + 1) * cap * 32, j.desc2, (size_t)j.n2 * 32);
+                int32_t *n = reinterpret_cast<int32_t *>(b.h.data() + n_off);
+                n[2 * i] = j.n1;
+                n[2 * i + 1] = j.n2;
+                reinterpret_cast<int32_t *>(b.h.data() + pa_off)[i] = 2 * i;
+                reinterpret_cast<int32_t *>(b.h.data() + pb_off)[i] = 2 * i + 1;
+                if (any_ori && j.check_orientation) {
+                    afv_keypoint *k1 = reinterpret_cast<afv_keypoint *>(b.h.data() + kps_off) + (size_t)(2 * i) * cap;
+                    afv_keypoint *k2 = k1 + cap;
+                    for (int q = 0; q < j.n1; ++q) k1[q].angle = j.angle1[q];
+                    for (int q = 0; q < j.n2; ++q) k2[q].angle = j.angle2[q];
+                }
+            }
+            const size_t match_off = b.reserve((size_t)njobs * cap * 4), nm_off = b.reserve((size_t)njobs * 4);
+            const size_t topk_off = b.reserve((size_t)njobs * cap * 16);
+            int rc = ensure_match_buffer(c, b.h.size());
+            if (rc) return rc;
+            HIPCHK(c, hipMemcpyAsync(c->d_match, b.h.data(), match_off, hipMemcpyHostToDevice, c->stream));  // inputs only
+            // jobs may differ in mbCheckOrientation / thresholds: launch runs of identical settings
+            int i0 = 0;
+            while (i0 < njobs) {
+                int i1 = i0 + 1;
+                while (i1 < njobs && jobs[i1].th_low == jobs[i0].th_low && jobs[i1].nnratio == jobs[i0].nnratio &&
+                       (jobs[i1].check_orientation != 0) == (jobs[i0].check_orientation != 0))
+                    ++i1;
+                afv_launch_match_pairs2(c->d_match + desc_off, any_ori ? reinterpret_cast<const afv_keypoint *>(c->d_match + kps_off) : nullptr,
+                                        reinterpret_cast<const int *>(c->d_match + n_off), cap,
+                                        reinterpret_cast<const int *>(c->d_match + pa_off), reinterpret_cast<const int *>(c->d_match + pb_off),
+                                        i1 - i0, jobs[i0].th_low, jobs[i0].nnratio, jobs[i0].check_orientation != 0,
+                                        reinterpret_cast<int *>(c->d_match + match_off), reinterpret_cast<int *>(c->d_match + nm_off),
+                                        c->d_match + topk_off, i0, c->stream);
+                i0 = i1;
+            }
+            HIPCHK(c, hipGetLastError());
+            std::vector<int32_t> m((size_t)njobs * cap);
+            HIPCHK(c, hipMemcpyAsync(m.data(), c->d_match + match_off, m.size() * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(nmatches, c->d_match + nm_off, (size_t)njobs * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            size_t acc = 0;
+            for (int i = 0; i < njobs; ++i) {
+                std::memcpy(out + acc, m.data() + (size_t)i * cap, (size_t)jobs[i].n1 * 4);
+                acc += (size_t)jobs[i].n1;
+            }
+            return AFV_OK;
+        }
+    }
     Blob b;
     std::vector<JobOffsets> offs(njobs);
     for (int i = 0; i < njobs; ++i) stage_job(b, jobs[i], false, offs[i]);
-    const size_t in_bytes = b.h.size();
     size_t total_out = 0;
     for (int i = 0; i < njobs; ++i) total_out += (size_t)offs[i].nout;
+    // BoW-guided jobs (more than one shared node) run one wavefront per node; a single-segment job (brute force) keeps
+    // the ordered workgroup-per-job kernel
+    bool per_node = false;
+    for (int i = 0; i < njobs; ++i) per_node = per_node || offs[i].nseg > 1;
     const size_t out_off = b.reserve(std::max<size_t>(total_out, 1) * 4);
     const size_t nm_off = b.reserve((size_t)njobs * 4);
     const size_t jobs_off = b.reserve((size_t)njobs * sizeof(DevMatchJob));
+    struct SegTaskH { int job, seg; };
+    std::vector<SegTaskH> tasks;
+    std::vector<int> bin_off(njobs, 0);
+    size_t tasks_off = 0, hist_off = 0, bins_off = 0, binoff_off = 0;
+    bool any_ori = false;
+    if (per_node) {
+        size_t acc = 0;
+        for (int i = 0; i < njobs; ++i) {
+            for (int sgi = 0; sgi < offs[i].nseg; ++sgi) tasks.push_back(SegTaskH{i, sgi});
+            bin_off[i] = (int)acc;
+            acc += (size_t)offs[i].nout;
+            any_ori = any_ori || jobs[i].check_orientation;
+        }
+        tasks_off = b.put(tasks.data(), tasks.size() * sizeof(SegTaskH));
+        hist_off = b.reserve((size_t)njobs * 32 * 4);
+        bins_off = b.reserve(std::max<size_t>(acc, 1));
+        binoff_off = b.put(bin_off.data(), (size_t)njobs * 4);
+    }
     int rc = ensure_match_buffer(c, b.h.size());
     if (rc) return rc;
     size_t acc = 0;
@@ -843,9 +935,17 @@ extern "C" int afv_match_bow(afv_ctx *c, const afv_match_job *jobs, int njobs, i
         acc += (size_t)offs[i].nout;
         fill_dev_job(reinterpret_cast<DevMatchJob *>(b.h.data() + jobs_off)[i], jobs[i], offs[i], c->d_match, false);
     }
-    (void)in_bytes;
+    if (per_node) {  // the per-node kernel accumulates: outputs start at -1, counters at 0 (the blob is zero-filled)
+        int32_t *o = reinterpret_cast<int32_t *>(b.h.data() + out_off);
+        for (size_t i = 0; i < total_out; ++i) o[i] = -1;
+    }
     HIPCHK(c, hipMemcpyAsync(c->d_match, b.h.data(), b.h.size(), hipMemcpyHostToDevice, c->stream));
-    afv_launch_match_bow(reinterpret_cast<const DevMatchJob *>(c->d_match + jobs_off), njobs, c->stream);
+    if (per_node)
+        afv_launch_match_bow_seg(reinterpret_cast<const DevMatchJob *>(c->d_match + jobs_off), njobs, c->d_match + tasks_off,
+                                 (int)tasks.size(), reinterpret_cast<int *>(c->d_match + hist_off), c->d_match + bins_off,
+                                 reinterpret_cast<const int *>(c->d_match + binoff_off), any_ori ? 1 : 0, c->stream);
+    else
+        afv_launch_match_bow(reinterpret_cast<const DevMatchJob *>(c->d_match + jobs_off), njobs, c->stream);
     HIPCHK(c, hipGetLastError());
     if (total_out) HIPCHK(c, hipMemcpyAsync(out, c->d_match + out_off, total_out * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(nmatches, c->d_match + nm_off, (size_t)njobs * 4, hipMemcpyDeviceToHost, c->stream));

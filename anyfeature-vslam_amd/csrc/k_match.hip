@@ -21,6 +21,15 @@
 #define NO_KEY 0x7fffffff
 #define MAX_SIDE 8192  // features per side a job may hold (LDS bitset + bin table)
 
+// LDS hand-off between lanes of ONE wavefront: DS operations of a wave execute in order, only the compiler has to be
+// kept from moving reads above writes
+#define WAVE_LDS_SYNC()                                        \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
+    } while (0)
+
 struct Seg {
     int s1, n1, s2, n2;  // ranges into idx1/idx2 (or identity when the idx pointer is null)
 };
@@ -177,6 +186,119 @@ __global__ __launch_bounds__(MT) void k_match_bow(const DevMatchJob *__restrict_
     else match_bow_job<16>(J, s_matched, s_bin, s_red, s_hist);
 }
 
+// ---------------- BoW-guided jobs: one WAVEFRONT per (job, shared node) ----------------
+// vbMatched2 / vpMapPointMatches only couple rows inside ONE vocabulary node (a feature belongs to exactly one node),
+// so the nodes of a job are independent: each wavefront walks the rows of its node in the reference's order, the 64
+// lanes scan the node's columns, and the "taken" flags live in a per-wave LDS bitset indexed by the column's position
+// inside the node.  Orientation bins go to a per-job histogram (global atomics); k_match_bow_finish applies M6.
+struct SegTask {
+    int job, seg;
+};
+
+template <int W>
+__device__ void bow_segment(const DevMatchJob &J, const Seg S, uint32_t *s_taken, int *hist, uint8_t *bins) {
+    const int lane = threadIdx.x & 63;
+    const bool kf_frame = J.mode == AFV_MATCH_KF_FRAME;
+    for (int i = lane; i < (S.n2 + 31) / 32; i += 64) s_taken[i] = 0;
+    WAVE_LDS_SYNC();
+    int nm = 0;
+    for (int a = 0; a < S.n1; ++a) {
+        const int idx1 = J.idx1 ? J.idx1[S.s1 + a] : S.s1 + a;
+        if (J.valid1 && !J.valid1[idx1]) continue;  // uniform
+        uint32_t q[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i) q[i] = J.d1[(size_t)idx1 * W + i];
+        int k = NO_KEY, s = NO_KEY >> 16;
+        for (int b = lane; b < S.n2; b += 64) {
+            if ((s_taken[b >> 5] >> (b & 31)) & 1u) continue;
+            const int idx2 = J.idx2 ? J.idx2[S.s2 + b] : S.s2 + b;
+            if (!kf_frame && J.valid2 && !J.valid2[idx2]) continue;
+            const int d = hamming_words<W>(q, J.d2 + (size_t)idx2 * W);
+            merge_best(k, s, (d << 16) | b, NO_KEY >> 16);
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const int k2 = __shfl_xor(k, m, 64), s2 = __shfl_xor(s, m, 64);
+            merge_best(k, s, k2, s2);
+        }
+        if (k == NO_KEY) continue;
+        const float best1 = (float)(k >> 16);
+        const float best2 = (s == (NO_KEY >> 16)) ? 3.402823466e+38f : (float)s;
+        const bool under = kf_frame ? (best1 <= J.th) : (best1 < J.th);  // FeatureMatcher.cc:250 / :630
+        if (under && best1 < J.ratio * best2) {                            // :252 / :632
+            const int b = k & 0xffff;
+            if (lane == 0) {
+                const int idx2 = J.idx2 ? J.idx2[S.s2 + b] : S.s2 + b;
+                const int key = kf_frame ? idx2 : idx1;
+                J.out[key] = kf_frame ? idx1 : idx2;
+                s_taken[b >> 5] |= 1u << (b & 31);
+                if (J.check_ori) {
+                    const int bin = rotation_bin(J.ang1[(size_t)idx1 * J.ang_stride], J.ang2[(size_t)idx2 * J.ang_stride]);
+                    bins[key] = (uint8_t)bin;
+                    atomicAdd(&hist[bin], 1);
+                }
+            }
+            ++nm;
+            WAVE_LDS_SYNC();
+        }
+    }
+    if (lane == 0 && nm) atomicAdd(J.nmatches, nm);
+}
+
+// hist: [njobs][32] ints, bins: per job a byte per output slot (offsets in bin_off)
+__global__ __launch_bounds__(MT) void k_match_bow_seg(const DevMatchJob *__restrict__ jobs, const SegTask *__restrict__ tasks,
+                                                      int ntasks, int *__restrict__ hist, uint8_t *__restrict__ bins,
+                                                      const int *__restrict__ bin_off) {
+    __shared__ uint32_t s_taken[MT / 64][MAX_SIDE / 32];
+    const int wv = threadIdx.x >> 6;
+    const int t = blockIdx.x * (MT / 64) + wv;
+    if (t >= ntasks) return;  // wave-uniform; no workgroup barrier below
+    const SegTask T = tasks[t];
+    const DevMatchJob J = jobs[T.job];
+    const Seg S = J.segs[T.seg];
+    if (J.words == 8) bow_segment<8>(J, S, s_taken[wv], hist + T.job * 32, bins + bin_off[T.job]);
+    else bow_segment<16>(J, S, s_taken[wv], hist + T.job * 32, bins + bin_off[T.job]);
+}
+
+// M6 for the per-node kernel: keep only the three dominant rotation bins (computeThreeMaxima :1631-1668)
+__global__ __launch_bounds__(MT) void k_match_bow_finish(const DevMatchJob *__restrict__ jobs, const int *__restrict__ hist,
+                                                         const uint8_t *__restrict__ bins, const int *__restrict__ bin_off) {
+    __shared__ int s_i[3], s_drop;
+    const DevMatchJob J = jobs[blockIdx.x];
+    if (!J.check_ori) return;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        const int *h = hist + blockIdx.x * 32;
+        int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+        for (int i = 0; i < 30; ++i) {
+            const int sz = h[i];
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; i3 = i2; i2 = i1; i1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; i3 = i2; i2 = i; }
+            else if (sz > max3) { max3 = sz; i3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { i3 = -1; }
+        s_i[0] = i1; s_i[1] = i2; s_i[2] = i3;
+        s_drop = 0;
+    }
+    __syncthreads();
+    const int nout = J.mode == AFV_MATCH_KF_FRAME ? J.n2 : J.n1;
+    const uint8_t *bj = bins + bin_off[blockIdx.x];
+    int dropped = 0;
+    for (int i = tid; i < nout; i += MT) {
+        if (J.out[i] >= 0) {
+            const int b = bj[i];
+            if (b != s_i[0] && b != s_i[1] && b != s_i[2]) {
+                J.out[i] = -1;
+                ++dropped;
+            }
+        }
+    }
+    if (dropped) atomicAdd(&s_drop, dropped);
+    __syncthreads();
+    if (tid == 0 && s_drop) *J.nmatches -= s_drop;
+}
+
 // device-resident brute-force pairs over a descriptor table [nsets][cap][32]
 __global__ __launch_bounds__(MT) void k_match_pairs(const uint8_t *__restrict__ desc, const afv_keypoint *__restrict__ kps,
                                                     const int *__restrict__ nset, int cap, const int *__restrict__ pair_a,
@@ -261,12 +383,6 @@ __global__ __launch_bounds__(MT) void k_match_topk(const uint8_t *__restrict__ d
 
 #define PAIR_MAX_SIDE 4096  // rows / columns per set in the pairs path (LDS tables below)
 #define PAIR_LDS_DESC 1280  // side-2 sets up to this size are copied to LDS (40 KB) so that rescans never leave the CU
-#define WAVE_LDS_SYNC()                                        \
-    do {                                                       \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
-        __builtin_amdgcn_wave_barrier();                       \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
-    } while (0)
 
 __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict__ desc, const afv_keypoint *__restrict__ kps,
                                                       const int *__restrict__ nset, int cap, const int *__restrict__ pair_a,
@@ -612,6 +728,12 @@ __global__ __launch_bounds__(MT) void k_match_l2(const float *__restrict__ d1, i
 
 extern "C" void afv_launch_match_bow(const DevMatchJob *jobs, int njobs, hipStream_t stream) {
     hipLaunchKernelGGL(k_match_bow, dim3(njobs), dim3(MT), 0, stream, jobs);
+}
+extern "C" void afv_launch_match_bow_seg(const DevMatchJob *jobs, int njobs, const void *tasks, int ntasks, int *hist, uint8_t *bins,
+                                         const int *bin_off, int any_ori, hipStream_t stream) {
+    hipLaunchKernelGGL(k_match_bow_seg, dim3((ntasks + MT / 64 - 1) / (MT / 64)), dim3(MT), 0, stream, jobs,
+                       reinterpret_cast<const SegTask *>(tasks), ntasks, hist, bins, bin_off);
+    if (any_ori) hipLaunchKernelGGL(k_match_bow_finish, dim3(njobs), dim3(MT), 0, stream, jobs, hist, bins, bin_off);
 }
 extern "C" void afv_launch_match_pairs(const uint8_t *desc, const afv_keypoint *kps, const int *nset, int cap, const int *pa,
                                        const int *pb, int npairs, float th, float ratio, int check_ori, int *match,
