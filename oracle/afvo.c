@@ -255,6 +255,23 @@ static const int k_ring_dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 
  * else the largest threshold for which the pixel is still a 9-arc corner (as uchar). */
 static int fast_corner_score(const u8 *p, int stride, int threshold) {
     int v = p[0];
+    {   /* FAST_t's cheap rejection (fast.cpp): every antipodal ring pair must hold a darker (1) / brighter (2) pixel.
+           Pure speed-up of the CPU baseline: a 9-arc always satisfies it, so results are unchanged. */
+        const int lo = v - threshold, hi = v + threshold;
+#define CLS(k) ((p[k_ring_dy[k] * stride + k_ring_dx[k]] < lo ? 1 : 0) | (p[k_ring_dy[k] * stride + k_ring_dx[k]] > hi ? 2 : 0))
+        int c = CLS(0) | CLS(8);
+        if (!c) return 0;
+        c &= CLS(2) | CLS(10);
+        c &= CLS(4) | CLS(12);
+        c &= CLS(6) | CLS(14);
+        if (!c) return 0;
+        c &= CLS(1) | CLS(9);
+        c &= CLS(3) | CLS(11);
+        c &= CLS(5) | CLS(13);
+        c &= CLS(7) | CLS(15);
+        if (!c) return 0;
+#undef CLS
+    }
     int d[25];
     for (int k = 0; k < 16; ++k) d[k] = v - p[k_ring_dy[k] * stride + k_ring_dx[k]];
     for (int k = 16; k < 25; ++k) d[k] = d[k - 16];
