@@ -59,6 +59,16 @@ def pmc_traffic(kernel, batch):
     return None
 
 
+def valu_pmc():
+    import glob
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "valu_pmc.json")), reverse=True):
+        try:
+            return json.load(open(p))
+        except Exception:
+            pass
+    return None
+
+
 def cpu_baseline(afv, nframes, seed0):
     """oracle, one thread: extraction (reference-faithful variant) + brute-force match of consecutive frames"""
     import oracle
@@ -193,6 +203,14 @@ def main():
                                    "note": "integer-VALU-bound kernel (FAST ring tests + Harris): the HBM fraction is low by "
                                            "construction; two half-batch launches run concurrently on two streams, so a launch "
                                            "shares the chip with the other half's kernels (DESIGN.md section 4)"}
+            vp = valu_pmc()
+            if vp:
+                ach = vp["valu_winst_per_frame_total"] * out["frames_per_s"]
+                out["valu_issue"] = {"achieved": ach, "peak": vp["valu_peak_winst_per_s"], "unit": "wave-instr/s",
+                                     "frac": ach / vp["valu_peak_winst_per_s"],
+                                     "note": "whole pipeline: SQ_INSTS_VALU per frame (committed PMC pass, profiles/r*/valu_pmc.json) x measured "
+                                             "frames/s vs the measured integer-VALU issue peak (tools/calib_valu.hip) - the bound that actually "
+                                             "limits this integer/byte path"}
             out["stage_ms_per_step"] = {kk: (v["total_ms"] / args.steps) for kk, v in stages.items()}  # overlapping streams: sums exceed ms_per_step
         if args.cpu_frames > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(afv, args.cpu_frames, seed0)
