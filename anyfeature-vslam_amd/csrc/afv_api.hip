@@ -46,9 +46,6 @@ struct DevTriJob {
 extern "C" void afv_launch_match_bow(const DevMatchJob *jobs, int njobs, hipStream_t stream);
 extern "C" void afv_launch_match_bow_seg(const DevMatchJob *jobs, int njobs, const void *tasks, int ntasks, int *hist, uint8_t *bins,
                                          const int *bin_off, int any_ori, hipStream_t stream);
-extern "C" void afv_launch_match_pairs(const uint8_t *desc, const afv_keypoint *kps, const int *nset, int cap, const int *pa,
-                                       const int *pb, int npairs, float th, float ratio, int check_ori, int *match,
-                                       int *nmatches, hipStream_t stream);
 extern "C" void afv_launch_match_pairs2(const uint8_t *desc, const afv_keypoint *kps, const int *nset, int cap, const int *pa,
                                         const int *pb, int npairs, float th, float ratio, int check_ori, int *match,
                                         int *nmatches, void *topk_scratch, int pair_base, hipStream_t stream);

@@ -5,17 +5,16 @@
 // (:1579-1668) and DescriptorDistance_orb32 / _sift128 (Feature_orb32.cpp:67-84, Feature_sift128.cpp:132-134).
 //
 // SearchByBoW is greedy: row idx1 may only take a column that no earlier row has taken (vbMatched2 / the
-// vpMapPointMatches test).  One 256-thread workgroup owns a job and walks the rows in the reference's order; for
-// each row the 256 lanes scan the node's columns in parallel (xor + v_bcnt per 32-bit word — the popcount
-// north_star asks for; distance of a 256-bit pair = 8 xor + 8 bcnt-accumulate), keep a packed (distance, position)
-// minimum and the second-best distance per lane, and merge them with wavefront shuffles + one LDS hop.  Lane 0 then
-// applies the float predicates exactly as written in the reference (strict/non-strict threshold, nnratio product).
-// SearchForTriangulation has no cross-row dependency: every wavefront takes its own rows.
+// vpMapPointMatches test).  Distance of a 256-bit pair = 8 xor + 8 v_bcnt-accumulate (the popcount north_star asks for).
+// Three kernels share that arithmetic and the reference's float predicates (strict / non-strict threshold, nnratio
+// product, rotation histogram):
+//   * k_match_topk + k_match_resolve — brute force over whole descriptor sets (pipeline path and plain host jobs):
+//     parallel top-4 per row, then the ordered greedy walk in speculative 64-row rounds;
+//   * k_match_bow_seg (+ k_match_bow_finish) — BoW-guided jobs, one wavefront per shared vocabulary node;
+//   * k_match_bow — generic ordered workgroup-per-job kernel (jobs with validity masks / KF-Frame mode and one node).
+// SearchForTriangulation (k_match_tri) has no cross-row dependency: every wavefront takes its own rows.
 #include "afv_device.h"
 
-#ifndef AFV_EXP
-#define AFV_EXP 0
-#endif
 
 #define MT 256
 #define NO_KEY 0x7fffffff
@@ -298,44 +297,6 @@ __global__ __launch_bounds__(MT) void k_match_bow_finish(const DevMatchJob *__re
     __syncthreads();
     if (tid == 0 && s_drop) *J.nmatches -= s_drop;
 }
-
-// device-resident brute-force pairs over a descriptor table [nsets][cap][32]
-__global__ __launch_bounds__(MT) void k_match_pairs(const uint8_t *__restrict__ desc, const afv_keypoint *__restrict__ kps,
-                                                    const int *__restrict__ nset, int cap, const int *__restrict__ pair_a,
-                                                    const int *__restrict__ pair_b, float th, float ratio, int check_ori,
-                                                    int *__restrict__ match, int *__restrict__ nmatches) {
-    __shared__ uint32_t s_matched[MAX_SIDE / 32];
-    __shared__ uint8_t s_bin[MAX_SIDE];
-    __shared__ int s_red[32];
-    __shared__ int s_hist[32];
-    __shared__ Seg s_seg;
-    const int p = blockIdx.x;
-    const int a = pair_a[p], b = pair_b[p];
-    DevMatchJob J;
-    J.d1 = reinterpret_cast<const uint32_t *>(desc + (size_t)a * cap * 32);
-    J.d2 = reinterpret_cast<const uint32_t *>(desc + (size_t)b * cap * 32);
-    J.n1 = min(nset[a], cap);
-    J.n2 = min(nset[b], cap);
-    J.words = 8;
-    if (threadIdx.x == 0) s_seg = Seg{0, J.n1, 0, J.n2};
-    J.segs = &s_seg;
-    J.nseg = 1;
-    J.idx1 = J.idx2 = nullptr;
-    J.valid1 = J.valid2 = nullptr;
-    J.ang1 = kps ? &kps[(size_t)a * cap].angle : nullptr;
-    J.ang2 = kps ? &kps[(size_t)b * cap].angle : nullptr;
-    J.ang_stride = sizeof(afv_keypoint) / sizeof(float);
-    J.th = th;
-    J.ratio = ratio;
-    J.check_ori = check_ori && kps;
-    J.mode = AFV_MATCH_KF_KF;
-    J.out = match + (size_t)p * cap;
-    J.nmatches = nmatches + p;
-    for (int i = J.n1 + threadIdx.x; i < cap; i += MT) J.out[i] = -1;
-    __syncthreads();
-    match_bow_job<8>(J, s_matched, s_bin, s_red, s_hist);
-}
-
 
 // ---------------- brute-force pairs, two-phase form (bench / pipeline path) ----------------
 // SearchByBoW's greedy rule only ever removes columns.  So the K best columns of a row, ordered by
@@ -734,12 +695,6 @@ extern "C" void afv_launch_match_bow_seg(const DevMatchJob *jobs, int njobs, con
     hipLaunchKernelGGL(k_match_bow_seg, dim3((ntasks + MT / 64 - 1) / (MT / 64)), dim3(MT), 0, stream, jobs,
                        reinterpret_cast<const SegTask *>(tasks), ntasks, hist, bins, bin_off);
     if (any_ori) hipLaunchKernelGGL(k_match_bow_finish, dim3(njobs), dim3(MT), 0, stream, jobs, hist, bins, bin_off);
-}
-extern "C" void afv_launch_match_pairs(const uint8_t *desc, const afv_keypoint *kps, const int *nset, int cap, const int *pa,
-                                       const int *pb, int npairs, float th, float ratio, int check_ori, int *match,
-                                       int *nmatches, hipStream_t stream) {
-    hipLaunchKernelGGL(k_match_pairs, dim3(npairs), dim3(MT), 0, stream, desc, kps, nset, cap, pa, pb, th, ratio, check_ori,
-                       match, nmatches);
 }
 extern "C" void afv_launch_match_pairs2(const uint8_t *desc, const afv_keypoint *kps, const int *nset, int cap, const int *pa,
                                         const int *pb, int npairs, float th, float ratio, int check_ori, int *match,

@@ -34,6 +34,7 @@ import torch
 afv = importlib.import_module("anyfeature-vslam_amd")
 B = %d
 ctx = afv.Context(max_batch=B)
+ctx.set_split_threshold(1 << 30)  # one stream: clean per-kernel times
 frames = torch.from_numpy(afv.synth.corners_batch(1, B)).cuda()
 afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
 m = afv.FeatureMatcher(0.6, True, ctx=ctx)
