@@ -22,6 +22,8 @@
 #include "afv_device.h"
 
 #define ST 256  // threads per workgroup
+#define CPT 40        // candidates a thread keeps in registers: the fast path covers n <= ST * CPT = 10240
+#define KEPT_LDS 3072 // retainBest survivors kept in LDS for the quadtree rounds (else global scratch)
 
 struct Rect16 {
     short x0, y0, x1, y1;
@@ -124,7 +126,7 @@ __device__ __forceinline__ Rect16 child_rect(const Rect16 r, int q) {
 // dynamic LDS layout, M = max nodes (multiple of 64):
 //   int   hist[2048]            (also scratch for scans)
 //   Rect16 rect[2][M]; int cnt[2][M]; int child[M*4]; uint16 remap[M*4]; int aux[M]; int aux2[M];
-//   unsigned long long best[M]; int tmp[16]
+//   unsigned long long best[M]; int tmp[16]; then kept_xy u32[KEPT_LDS], kept_resp f32[KEPT_LDS], kept_node u16[KEPT_LDS]
 __global__ __launch_bounds__(ST) void k_select_quadtree(const Geo *__restrict__ geo_p, const uint32_t *__restrict__ cand_packed,
                                                        const float *__restrict__ cand_resp,
                                                        const int *__restrict__ cand_count, uint32_t *__restrict__ kept_xy,
@@ -153,20 +155,61 @@ __global__ __launch_bounds__(ST) void k_select_quadtree(const Geo *__restrict__ 
     const size_t base = L.cand_off + (size_t)f * L.cand_frame_stride;
     const uint32_t *cp = cand_packed + base;
     const float *cr = cand_resp + base;
-    uint32_t *kxy = kept_xy + base;
+    uint32_t *kxy = kept_xy + base;  // re-pointed to LDS below when the survivors fit
     float *kr = kept_resp + base;
     uint16_t *kn = kept_node + base;
+    uint32_t *lds_kxy = reinterpret_cast<uint32_t *>(remap + 4 * M);
+    float *lds_kr = reinterpret_cast<float *>(lds_kxy + KEPT_LDS);
+    uint16_t *lds_kn = reinterpret_cast<uint16_t *>(lds_kr + KEPT_LDS);
     const int n = min(cand_count[f * AFV_MAX_LEVELS + l], L.cand_cap);
     const int tid = threadIdx.x, lane = tid & 63;
     const float scale = L.scale;
     const int N = L.quota;
+
+    // Fast path: every thread keeps its share of the candidate list (items tid, tid+256, ...) in registers, so the
+    // histogram / radix / count / compaction passes below never go back to memory.  Lists longer than ST*CPT (only
+    // noise-like images at level 0) stream from global memory instead.
+    const bool reg = n <= ST * CPT;
+    uint32_t cpk[CPT];
+    float crs[CPT];
+    if (reg) {
+#pragma unroll
+        for (int k_ = 0; k_ < CPT; ++k_) {
+            const int i = k_ * ST + tid;
+            cpk[k_] = 0;
+            crs[k_] = 0.f;
+            if (k_ * ST < n && i < n) {
+                cpk[k_] = cp[i];
+                crs[k_] = cr[i];
+            }
+        }
+    }
+#define FOR_CAND(BODY)                                          \
+    if (reg) {                                                  \
+        _Pragma("unroll") for (int k_ = 0; k_ < CPT; ++k_) {    \
+            if (k_ * ST >= n) break;                            \
+            if (k_ * ST + tid < n) {                            \
+                const uint32_t e = cpk[k_];                     \
+                const float r = crs[k_];                        \
+                (void)r;                                        \
+                BODY                                            \
+            }                                                   \
+        }                                                       \
+    } else {                                                    \
+        for (int i_ = tid; i_ < n; i_ += ST) {                  \
+            const uint32_t e = cp[i_];                          \
+            const float r = cr[i_];                             \
+            (void)r;                                            \
+            BODY                                                \
+        }                                                       \
+    }
 
     // ---------------- E4a: threshold on the FAST score ----------------
     int T1 = 0;
     if (n > 2 * L.cv_quota) {  // uniform branch
         for (int i = tid; i < 256; i += ST) hist[i] = 0;
         __syncthreads();
-        for (int i = tid; i < n; i += ST) atomicAdd(&hist[cp[i] >> 24], 1);
+        FOR_CAND(atomicAdd(&hist[e >> 24], 1);)
         __syncthreads();
         int above;
         T1 = block_kth_from_top(hist, 256, 2 * L.cv_quota, &above, tmp);
@@ -176,7 +219,7 @@ __global__ __launch_bounds__(ST) void k_select_quadtree(const Geo *__restrict__ 
     __syncthreads();
     {
         int c = 0;
-        for (int i = tid; i < n; i += ST) c += ((int)(cp[i] >> 24) >= T1);
+        FOR_CAND(c += ((int)(e >> 24) >= T1);)
         c = wave_incl_scan(c);
         if (lane == 63) atomicAdd(&tmp[8], c);
     }
@@ -190,38 +233,46 @@ __global__ __launch_bounds__(ST) void k_select_quadtree(const Geo *__restrict__ 
         const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
         for (int p = 0; p < 3; ++p) {
             const int nb = 1 << bits[p];
+            const int sh = shifts[p];
             for (int i = tid; i < nb; i += ST) hist[i] = 0;
             __syncthreads();
-            for (int i = tid; i < n; i += ST) {
-                if ((int)(cp[i] >> 24) < T1) continue;
-                const uint32_t key = float_key(cr[i]);
-                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shifts[p]) & (nb - 1)], 1);
-            }
+            FOR_CAND(if ((int)(e >> 24) >= T1) {
+                const uint32_t key = float_key(r);
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> sh) & (nb - 1)], 1);
+            })
             __syncthreads();
             int above;
             const int bin = block_kth_from_top(hist, nb, k, &above, tmp);
             k -= above;
-            prefix |= (uint32_t)bin << shifts[p];
-            mask |= (uint32_t)(nb - 1) << shifts[p];
+            prefix |= (uint32_t)bin << sh;
+            mask |= (uint32_t)(nb - 1) << sh;
         }
         T2 = prefix;
     }
+    // number of survivors decides where they live during the quadtree rounds
+    if (tid == 0) tmp[9] = 0;
+    __syncthreads();
+    {
+        int c = 0;
+        FOR_CAND(c += ((int)(e >> 24) >= T1) && (float_key(r) >= T2);)
+        c = wave_incl_scan(c);
+        if (lane == 63) atomicAdd(&tmp[9], c);
+    }
+    __syncthreads();
+    if (tmp[9] <= KEPT_LDS) {
+        kxy = lds_kxy;
+        kr = lds_kr;
+        kn = lds_kn;
+    }
+    __syncthreads();
 
     // ---------------- compaction of the survivors + root assignment ----------------
     const int n_ini = geo.n_ini;
     if (tid < 16) aux[tid] = 0;  // points per root
     if (tid == 0) tmp[8] = 0;
     __syncthreads();
-    for (int i0 = 0; i0 < n; i0 += ST) {
-        const int i = i0 + tid;
-        bool keep = false;
-        uint32_t e = 0;
-        float r = 0.f;
-        if (i < n) {
-            e = cp[i];
-            r = cr[i];
-            keep = ((int)(e >> 24) >= T1) && (float_key(r) >= T2);
-        }
+    // wave-aggregated, order-free compaction of one candidate per lane
+    auto emit = [&](bool keep, uint32_t e, float r) {
         const unsigned long long m = __ballot(keep);
         int wbase = 0;
         if (lane == 0 && m) wbase = atomicAdd(&tmp[8], __popcll(m));
@@ -238,6 +289,25 @@ __global__ __launch_bounds__(ST) void k_select_quadtree(const Geo *__restrict__ 
                 atomicAdd(&aux[root], 1);
             }
             kn[slot] = (uint16_t)root;
+        }
+    };
+    if (reg) {
+#pragma unroll
+        for (int k_ = 0; k_ < CPT; ++k_) {
+            if (k_ * ST >= n) break;
+            const bool in = k_ * ST + tid < n;
+            emit(in && ((int)(cpk[k_] >> 24) >= T1) && (float_key(crs[k_]) >= T2), cpk[k_], crs[k_]);
+        }
+    } else {
+        for (int i0 = 0; i0 < n; i0 += ST) {
+            const int i = i0 + tid;
+            uint32_t e = 0;
+            float r = 0.f;
+            if (i < n) {
+                e = cp[i];
+                r = cr[i];
+            }
+            emit(i < n && ((int)(e >> 24) >= T1) && (float_key(r) >= T2), e, r);
         }
     }
     __syncthreads();
@@ -440,7 +510,8 @@ __global__ __launch_bounds__(ST) void k_select_quadtree(const Geo *__restrict__ 
 
 extern "C" size_t afv_select_lds_bytes(int M) {
     return (size_t)2048 * 4 + (size_t)M * 8 /*best*/ + (size_t)M * 8 * 2 /*rect*/ + (size_t)M * 4 * 2 /*cnt*/ +
-           (size_t)M * 16 /*child*/ + (size_t)M * 4 * 2 /*aux*/ + 64 /*tmp*/ + (size_t)M * 8 /*remap*/;
+           (size_t)M * 16 /*child*/ + (size_t)M * 4 * 2 /*aux*/ + 64 /*tmp*/ + (size_t)M * 8 /*remap*/ +
+           (size_t)KEPT_LDS * 10 /*kept xy, response, node*/;
 }
 
 extern "C" void afv_launch_select(const Geo *geo_dev, int nlevels, const uint32_t *cand_packed, const float *cand_resp,
