@@ -13,4 +13,5 @@ Layout:
 from . import _lib, synth  # noqa: F401
 from .extractor import (CovarianceMethod, FeatureExtractorSettings, FeatureExtractor_orb32, Context,  # noqa: F401
                         KP_DTYPE)
-from .matcher import FeatureMatcher, FeatureView, DescriptorDistance_orb32  # noqa: F401
+from .matcher import (FeatureMatcher, FeatureView, FrameGridView, ProjectionQueries,  # noqa: F401
+                      DescriptorDistance_orb32)

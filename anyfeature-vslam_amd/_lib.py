@@ -15,6 +15,7 @@ MAX_LEVELS = 8
 DESC_BYTES = 32
 OK, EINVAL, ENODEV, ENOMEM, EHIP, ECAPACITY, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 MATCH_KF_KF, MATCH_KF_FRAME = 0, 1
+PROJ_LOCALMAP, PROJ_LASTFRAME = 0, 1
 STAGES = ("pyramid", "fast_harris", "select_quadtree", "describe", "match")
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
@@ -49,6 +50,17 @@ class TriJob(C.Structure):
                 ("sigma2_2", C.c_void_p), ("F12", C.c_float * 9), ("ex", C.c_float), ("ey", C.c_float)]
 
 
+class ProjJob(C.Structure):
+    _fields_ = [("desc", C.c_void_p), ("n", C.c_int32), ("desc_bytes", C.c_int32),
+                ("x", C.c_void_p), ("y", C.c_void_p), ("size", C.c_void_p), ("angle", C.c_void_p), ("occupied", C.c_void_p),
+                ("min_x", C.c_float), ("min_y", C.c_float), ("grid_inv_w", C.c_float), ("grid_inv_h", C.c_float),
+                ("grid_cols", C.c_int32), ("grid_rows", C.c_int32), ("nq", C.c_int32),
+                ("qdesc", C.c_void_p), ("qvalid", C.c_void_p), ("qu", C.c_void_p), ("qv", C.c_void_p), ("qr", C.c_void_p),
+                ("qmin_size", C.c_void_p), ("qmax_size", C.c_void_p), ("qangle", C.c_void_p), ("qoccupies", C.c_void_p),
+                ("th_high", C.c_float), ("nnratio", C.c_float), ("size_tol", C.c_float), ("inv_size_tol", C.c_float),
+                ("check_orientation", C.c_int32), ("mode", C.c_int32)]
+
+
 # every symbol include/afv_hip.h declares: (name, restype, argtypes)
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SYMBOLS = {
@@ -67,6 +79,7 @@ SYMBOLS = {
     "afv_match_triangulation": (_i, [_vp, C.POINTER(TriJob), _i, _vp, _vp]),
     "afv_match_bruteforce_pairs_device": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _f, _f, _i, _vp, _vp, _vp]),
     "afv_match_l2": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _f, _f, _vp, _vp]),
+    "afv_match_projection": (_i, [_vp, C.POINTER(ProjJob), _i, _vp, _vp]),
     "afv_hamming256": (_i, [_vp, _vp]),
     "afv_profile_enable": (_i, [_vp, _i]),
     "afv_profile_read": (_i, [_vp, _vp, _vp, _vp]),

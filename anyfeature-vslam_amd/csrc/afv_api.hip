@@ -53,6 +53,18 @@ extern "C" void afv_launch_match_tri(const DevTriJob *jobs, int njobs, hipStream
 extern "C" void afv_launch_match_l2(const float *d1, int n1, const float *d2, int n2, int dim, const uint8_t *v1,
                                     const uint8_t *v2, float th, float ratio, int *out, int *nmatches, hipStream_t stream);
 
+struct DevProjJob {
+    const uint32_t *fdesc; int n, words;
+    const float *x, *y, *size, *angle; const uint8_t *occupied;
+    float min_x, min_y, inv_w, inv_h; int cols, rows;
+    const int *cell_ptr, *cell_idx;
+    int nq; const uint32_t *qdesc; const uint8_t *qvalid;
+    const float *qu, *qv, *qr, *qmin, *qmax, *qangle; const uint8_t *qocc;
+    float th, ratio, tol, inv_tol; int check_ori, mode;
+    unsigned long long *keys; int *ncand; int *orilist; int *assign; int *nmatches;
+};
+extern "C" void afv_launch_match_projection(const DevProjJob *jobs, int njobs, hipStream_t stream);
+
 #define AFV_MAX_SIDE 8192
 
 struct afv_ctx {
@@ -1067,6 +1079,101 @@ extern "C" int afv_match_l2(afv_ctx *c, const float *desc1, int n1, const float 
     HIPCHK(c, hipGetLastError());
     if (n1) HIPCHK(c, hipMemcpyAsync(match12, c->d_match + oo, (size_t)n1 * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(nmatches, c->d_match + on, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AFV_OK;
+}
+
+// ---- projection-guided matching ----
+extern "C" int afv_match_projection(afv_ctx *c, const afv_proj_job *jobs, int njobs, int32_t *assign, int32_t *nmatches) {
+    if (!c || !jobs || njobs < 1 || !assign || !nmatches) return AFV_EINVAL;
+    for (int i = 0; i < njobs; ++i) {
+        const afv_proj_job &j = jobs[i];
+        if (j.n < 0 || j.n > AFV_MAX_SIDE || j.nq < 0 || j.nq > 65535 || j.desc_bytes < 1 || j.desc_bytes > 64) return AFV_EINVAL;
+        if (j.grid_cols < 1 || j.grid_rows < 1 || (long)j.grid_cols * j.grid_rows > 65536) return AFV_EINVAL;
+        if (j.n > 0 && (!j.desc || !j.x || !j.y || !j.size)) return AFV_EINVAL;
+        if (j.nq > 0 && (!j.qdesc || !j.qu || !j.qv || !j.qr || !j.qmin_size || !j.qmax_size)) return AFV_EINVAL;
+        if (j.mode != AFV_PROJ_LOCALMAP && j.mode != AFV_PROJ_LASTFRAME) return AFV_EINVAL;
+        if (j.mode == AFV_PROJ_LASTFRAME && j.check_orientation && ((j.n > 0 && !j.angle) || (j.nq > 0 && !j.qangle))) return AFV_EINVAL;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    Blob b;
+    struct Off { size_t fd, x, y, size, angle, occ, cptr, cidx, qd, qvalid, qu, qv, qr, qmin, qmax, qang, qocc, keys, ncand, ori, assign, nm; int words; };
+    std::vector<Off> offs(njobs);
+    size_t total_out = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const afv_proj_job &j = jobs[i];
+        Off &o = offs[i];
+        o.words = j.desc_bytes <= 32 ? 8 : 16;
+        o.fd = put_desc(b, j.desc, j.n, j.desc_bytes, o.words);
+        o.x = b.put(j.x, (size_t)j.n * 4); o.y = b.put(j.y, (size_t)j.n * 4); o.size = b.put(j.size, (size_t)j.n * 4);
+        o.angle = j.angle ? b.put(j.angle, (size_t)j.n * 4) : 0;
+        o.occ = j.occupied ? b.put(j.occupied, (size_t)j.n) : 0;
+        // Frame::AssignFeaturesToGrid / PosInGrid (Frame.cc:225-240, 383-394): cell = ix * rows + iy, ascending index
+        const int nc = j.grid_cols * j.grid_rows;
+        std::vector<int> cptr((size_t)nc + 1, 0), cidx((size_t)std::max(j.n, 1)), cell((size_t)std::max(j.n, 1));
+        for (int f = 0; f < j.n; ++f) {
+            const int px = (int)roundf((j.x[f] - j.min_x) * j.grid_inv_w), py = (int)roundf((j.y[f] - j.min_y) * j.grid_inv_h);
+            cell[f] = (px < 0 || px >= j.grid_cols || py < 0 || py >= j.grid_rows) ? -1 : px * j.grid_rows + py;
+            if (cell[f] >= 0) cptr[cell[f] + 1]++;
+        }
+        for (int q = 0; q < nc; ++q) cptr[q + 1] += cptr[q];
+        std::vector<int> fill(cptr.begin(), cptr.end() - 1);
+        for (int f = 0; f < j.n; ++f)
+            if (cell[f] >= 0) cidx[fill[cell[f]]++] = f;
+        o.cptr = b.put(cptr.data(), cptr.size() * 4);
+        o.cidx = b.put(cidx.data(), cidx.size() * 4);
+        o.qd = put_desc(b, j.qdesc, j.nq, j.desc_bytes, o.words);
+        o.qvalid = j.qvalid ? b.put(j.qvalid, (size_t)j.nq) : 0;
+        o.qu = b.put(j.qu, (size_t)j.nq * 4); o.qv = b.put(j.qv, (size_t)j.nq * 4); o.qr = b.put(j.qr, (size_t)j.nq * 4);
+        o.qmin = b.put(j.qmin_size, (size_t)j.nq * 4); o.qmax = b.put(j.qmax_size, (size_t)j.nq * 4);
+        o.qang = j.qangle ? b.put(j.qangle, (size_t)j.nq * 4) : 0;
+        o.qocc = j.qoccupies ? b.put(j.qoccupies, (size_t)j.nq) : 0;
+        total_out += (size_t)j.n;
+    }
+    const size_t in_bytes = b.h.size();
+    for (int i = 0; i < njobs; ++i) {  // device-only scratch
+        const afv_proj_job &j = jobs[i];
+        offs[i].keys = b.reserve((size_t)std::max(j.nq, 1) * 4 * 8);
+        offs[i].ncand = b.reserve((size_t)std::max(j.nq, 1) * 4);
+        offs[i].ori = b.reserve((size_t)std::max(j.nq, 1) * 8);
+    }
+    const size_t out_off = b.reserve(std::max<size_t>(total_out, 1) * 4);
+    const size_t nm_off = b.reserve((size_t)njobs * 4);
+    const size_t jobs_off = b.reserve((size_t)njobs * sizeof(DevProjJob));
+    int rc = ensure_match_buffer(c, b.h.size());
+    if (rc) return rc;
+    uint8_t *B = c->d_match;
+    size_t acc = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const afv_proj_job &j = jobs[i];
+        const Off &o = offs[i];
+        DevProjJob &d = reinterpret_cast<DevProjJob *>(b.h.data() + jobs_off)[i];
+        d.fdesc = reinterpret_cast<const uint32_t *>(B + o.fd); d.n = j.n; d.words = o.words;
+        d.x = reinterpret_cast<const float *>(B + o.x); d.y = reinterpret_cast<const float *>(B + o.y);
+        d.size = reinterpret_cast<const float *>(B + o.size);
+        d.angle = j.angle ? reinterpret_cast<const float *>(B + o.angle) : nullptr;
+        d.occupied = j.occupied ? B + o.occ : nullptr;
+        d.min_x = j.min_x; d.min_y = j.min_y; d.inv_w = j.grid_inv_w; d.inv_h = j.grid_inv_h; d.cols = j.grid_cols; d.rows = j.grid_rows;
+        d.cell_ptr = reinterpret_cast<const int *>(B + o.cptr); d.cell_idx = reinterpret_cast<const int *>(B + o.cidx);
+        d.nq = j.nq; d.qdesc = reinterpret_cast<const uint32_t *>(B + o.qd); d.qvalid = j.qvalid ? B + o.qvalid : nullptr;
+        d.qu = reinterpret_cast<const float *>(B + o.qu); d.qv = reinterpret_cast<const float *>(B + o.qv);
+        d.qr = reinterpret_cast<const float *>(B + o.qr); d.qmin = reinterpret_cast<const float *>(B + o.qmin);
+        d.qmax = reinterpret_cast<const float *>(B + o.qmax);
+        d.qangle = j.qangle ? reinterpret_cast<const float *>(B + o.qang) : nullptr;
+        d.qocc = j.qoccupies ? B + o.qocc : nullptr;
+        d.th = j.th_high; d.ratio = j.nnratio; d.tol = j.size_tol; d.inv_tol = j.inv_size_tol;
+        d.check_ori = j.check_orientation != 0; d.mode = j.mode;
+        d.keys = reinterpret_cast<unsigned long long *>(B + o.keys); d.ncand = reinterpret_cast<int *>(B + o.ncand);
+        d.orilist = reinterpret_cast<int *>(B + o.ori);
+        d.assign = reinterpret_cast<int *>(B + out_off + acc * 4); d.nmatches = reinterpret_cast<int *>(B + nm_off + (size_t)i * 4);
+        acc += (size_t)j.n;
+    }
+    HIPCHK(c, hipMemcpyAsync(B, b.h.data(), in_bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(B + jobs_off, b.h.data() + jobs_off, (size_t)njobs * sizeof(DevProjJob), hipMemcpyHostToDevice, c->stream));
+    afv_launch_match_projection(reinterpret_cast<const DevProjJob *>(B + jobs_off), njobs, c->stream);
+    HIPCHK(c, hipGetLastError());
+    if (total_out) HIPCHK(c, hipMemcpyAsync(assign, B + out_off, total_out * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(nmatches, B + nm_off, (size_t)njobs * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return AFV_OK;
 }

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import MatchJob, TriJob, ptr
+from ._lib import MatchJob, ProjJob, TriJob, ptr
 
 
 def DescriptorDistance_orb32(a, b):
@@ -55,6 +55,42 @@ class FeatureView:
                         if self.featvec else np.zeros(0, np.int32))
                 self._csr = (ids, ptrs, np.ascontiguousarray(flat, np.int32), len(self.featvec))
         return self._csr
+
+
+class FrameGridView:
+    """What the projection-guided matchers read from a Frame: mvKeysUn (pts, angles), keyPtsSize, mDescriptors, the
+    occupancy of F.pts (point present with NumberOfObservations() > 0) and the feature grid parameters
+    (Frame.cc:100-101: mnMinX, mnMinY, mfGridElementWidthInv/HeightInv; Frame.h:40-41: 64 x 48 cells)."""
+
+    def __init__(self, descriptors, pts, sizes, angles=None, occupied=None, min_x=0.0, min_y=0.0, max_x=640.0, max_y=480.0,
+                 grid_cols=64, grid_rows=48, size_tolerance=1.2):
+        self.descriptors = np.ascontiguousarray(descriptors, np.uint8)
+        self.N = self.descriptors.shape[0]
+        pts = np.asarray(pts, np.float32).reshape(-1, 2)
+        self.x = np.ascontiguousarray(pts[:, 0]); self.y = np.ascontiguousarray(pts[:, 1])
+        self.sizes = np.ascontiguousarray(sizes, np.float32)
+        self.angles = None if angles is None else np.ascontiguousarray(angles, np.float32)
+        self.occupied = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+        self.min_x, self.min_y = np.float32(min_x), np.float32(min_y)
+        self.grid_inv_w = np.float32(grid_cols) / (np.float32(max_x) - np.float32(min_x))
+        self.grid_inv_h = np.float32(grid_rows) / (np.float32(max_y) - np.float32(min_y))
+        self.grid_cols, self.grid_rows = grid_cols, grid_rows
+        self.sizeTolerance = np.float32(size_tolerance)               # Frame.cc:73 extractor->GetScaleFactor()
+        self.invSizeTolerance = np.float32(1.0) / self.sizeTolerance   # Frame.cc:74
+
+
+class ProjectionQueries:
+    """Projected map points / last-frame keypoints in the reference's iteration order: descriptor, projected (u, v),
+    window radius r, admissible keyPtsSize band, validity, angle (last-frame mode), occupies (observations > 0)."""
+
+    def __init__(self, descriptors, u, v, r, min_size, max_size, valid=None, angles=None, occupies=None):
+        self.descriptors = np.ascontiguousarray(descriptors, np.uint8)
+        self.n = self.descriptors.shape[0]
+        f = lambda a: np.ascontiguousarray(a, np.float32)
+        self.u, self.v, self.r, self.min_size, self.max_size = f(u), f(v), f(r), f(min_size), f(max_size)
+        self.valid = None if valid is None else np.ascontiguousarray(valid, np.uint8)
+        self.angles = None if angles is None else f(angles)
+        self.occupies = None if occupies is None else np.ascontiguousarray(occupies, np.uint8)
 
 
 class FeatureMatcher:
@@ -150,6 +186,28 @@ class FeatureMatcher:
         out = out[:pKF1.N]
         pairs = [(int(i), int(out[i])) for i in np.nonzero(out >= 0)[0]]
         return pairs, int(nm[0])
+
+    def SearchByProjection(self, F, queries, last_frame=False):
+        """matching core of SearchByProjection(F, vpMapPoints, radiusTh) (FeatureMatcher.cc:73-154) or, with
+        last_frame=True, of SearchByProjection(CurrentFrame, LastFrame, ...) (:1291-1402, mono).  Returns
+        (assign[F.N] = query index now stored in F.pts[i] | -1, nmatches)."""
+        j = ProjJob()
+        j.desc = ptr(F.descriptors); j.n = F.N; j.desc_bytes = F.descriptors.shape[1] if F.N else 32
+        j.x = ptr(F.x); j.y = ptr(F.y); j.size = ptr(F.sizes); j.angle = ptr(F.angles); j.occupied = ptr(F.occupied)
+        j.min_x = float(F.min_x); j.min_y = float(F.min_y); j.grid_inv_w = float(F.grid_inv_w); j.grid_inv_h = float(F.grid_inv_h)
+        j.grid_cols = F.grid_cols; j.grid_rows = F.grid_rows
+        j.nq = queries.n; j.qdesc = ptr(queries.descriptors); j.qvalid = ptr(queries.valid)
+        j.qu = ptr(queries.u); j.qv = ptr(queries.v); j.qr = ptr(queries.r)
+        j.qmin_size = ptr(queries.min_size); j.qmax_size = ptr(queries.max_size)
+        j.qangle = ptr(queries.angles); j.qoccupies = ptr(queries.occupies)
+        j.th_high = self.TH_HIGH; j.nnratio = self.mfNNratio
+        j.size_tol = float(F.sizeTolerance); j.inv_size_tol = float(F.invSizeTolerance)
+        j.check_orientation = int(self.mbCheckOrientation); j.mode = _lib.PROJ_LASTFRAME if last_frame else _lib.PROJ_LOCALMAP
+        out = np.full(max(F.N, 1), -1, np.int32)
+        nm = np.zeros(1, np.int32)
+        jobs = (ProjJob * 1)(j)
+        self.ctx.check(self.lib.afv_match_projection(self.ctx.handle, jobs, 1, ptr(out), ptr(nm)), "afv_match_projection")
+        return out[:F.N].copy(), int(nm[0])
 
     def match_l2(self, desc1, desc2, th_low, nnratio=None, valid1=None, valid2=None):
         """float descriptors (SIFT128 ...): brute force with SearchByBoW(KF,KF) control flow, distance =

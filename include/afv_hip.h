@@ -139,6 +139,32 @@ int afv_match_l2(afv_ctx *ctx, const float *desc1, int n1, const float *desc2, i
                  const uint8_t *valid1, const uint8_t *valid2, float th_low, float nnratio, int32_t *match12,
                  int32_t *nmatches);
 
+/* ---- projection-guided matching core (grid window + Hamming) ----
+ * Matching loops of FeatureMatcher::SearchByProjection(F, localMapPoints) (src/FeatureMatcher.cc:73-154, mode
+ * AFV_PROJ_LOCALMAP) and SearchByProjection(CurrentFrame, LastFrame) (:1291-1402, AFV_PROJ_LASTFRAME, mono) incl.
+ * Frame::GetFeaturesInArea (src/Frame.cc:333-382) over the grid of AssignFeaturesToGrid (Frame.cc:225-240).  The caller
+ * evaluates the projection as the reference does and passes, per query in the reference's iteration order:
+ * (u, v) = projected position, r = window radius (:91 / :1343), [min_size, max_size] = admissible keyPtsSize band. */
+enum { AFV_PROJ_LOCALMAP = 0, AFV_PROJ_LASTFRAME = 1 };
+typedef struct {
+    const uint8_t *desc; int32_t n; int32_t desc_bytes; /* frame features F.mDescriptors (n <= 8192) */
+    const float *x; const float *y;                     /* F.mvKeysUn[i].pt */
+    const float *size;                                  /* F.keyPtsSize[i] */
+    const float *angle;                                 /* F.mvKeysUn[i].angle (LASTFRAME + check_orientation) */
+    const uint8_t *occupied;                            /* F.pts[i] && F.pts[i]->NumberOfObservations() > 0; NULL = none */
+    float min_x, min_y, grid_inv_w, grid_inv_h;         /* mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv */
+    int32_t grid_cols, grid_rows;                       /* FRAME_GRID_COLS 64, FRAME_GRID_ROWS 48 (Frame.h:40-41) */
+    int32_t nq;                                         /* queries: map points / last-frame keypoints */
+    const uint8_t *qdesc; const uint8_t *qvalid;        /* pMP->GetDescriptor(); pMP && in view && !isBad (NULL = all) */
+    const float *qu; const float *qv; const float *qr; const float *qmin_size; const float *qmax_size;
+    const float *qangle;                                /* LastFrame.mvKeysUn[i].angle (LASTFRAME + check_orientation) */
+    const uint8_t *qoccupies;                           /* pMP->NumberOfObservations() > 0 (NULL = yes) */
+    float th_high, nnratio, size_tol, inv_size_tol;     /* TH_HIGH, mfNNratio, F.sizeTolerance, F.invSizeTolerance */
+    int32_t check_orientation, mode;
+} afv_proj_job;
+/* assign = concatenation over jobs of int32[n]: index of the query assigned to feature i (F.pts[i] = pMP) or -1 */
+int afv_match_projection(afv_ctx *ctx, const afv_proj_job *jobs, int njobs, int32_t *assign, int32_t *nmatches);
+
 /* DescriptorDistance_orb32 on the host (utility for adapters / tests) */
 int afv_hamming256(const uint8_t *a, const uint8_t *b);
 

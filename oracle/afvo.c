@@ -1138,3 +1138,103 @@ int afvo_match_l2_bruteforce(const afvo_l2_job *j, int32_t *match12) {
     free(matched2);
     return nm;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * projection-guided matching core
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { int *cell_ptr; int *cell_idx; } proj_grid;
+
+/* Frame::AssignFeaturesToGrid + PosInGrid (Frame.cc:225-240, 383-394): cell (ix, iy) lists, feature order ascending */
+static void build_grid(const afvo_proj_job *j, proj_grid *g) {
+    const int nc = j->grid_cols * j->grid_rows;
+    g->cell_ptr = (int *)calloc((size_t)nc + 1, sizeof(int));
+    g->cell_idx = (int *)malloc(sizeof(int) * (size_t)(j->n > 0 ? j->n : 1));
+    int *cell = (int *)malloc(sizeof(int) * (size_t)(j->n > 0 ? j->n : 1));
+    for (int i = 0; i < j->n; ++i) {
+        const int px = (int)roundf((j->x[i] - j->min_x) * j->grid_inv_w);
+        const int py = (int)roundf((j->y[i] - j->min_y) * j->grid_inv_h);
+        cell[i] = (px < 0 || px >= j->grid_cols || py < 0 || py >= j->grid_rows) ? -1 : px * j->grid_rows + py;
+        if (cell[i] >= 0) g->cell_ptr[cell[i] + 1]++;
+    }
+    for (int c = 0; c < nc; ++c) g->cell_ptr[c + 1] += g->cell_ptr[c];
+    int *fill = (int *)malloc(sizeof(int) * (size_t)nc);
+    memcpy(fill, g->cell_ptr, sizeof(int) * (size_t)nc);
+    for (int i = 0; i < j->n; ++i)
+        if (cell[i] >= 0) g->cell_idx[fill[cell[i]]++] = i;
+    free(fill);
+    free(cell);
+}
+
+int afvo_match_projection(const afvo_proj_job *j, int32_t *assign) {
+    proj_grid g;
+    build_grid(j, &g);
+    u8 *occ = (u8 *)calloc((size_t)j->n + 1, 1);
+    if (j->occupied) memcpy(occ, j->occupied, (size_t)j->n);
+    for (int i = 0; i < j->n; ++i) assign[i] = -1;
+    int nmatches = 0;
+    int *okey = (int *)malloc(sizeof(int) * (size_t)(2 * j->nq + 2)), *obin = okey + j->nq + 1, on = 0;
+    for (int q = 0; q < j->nq; ++q) {
+        if (j->qvalid && !j->qvalid[q]) continue;
+        const float x = j->qu[q], y = j->qv[q], r = j->qr[q], min_size = j->qmin_size[q], max_size = j->qmax_size[q];
+        /* Frame::GetFeaturesInArea (Frame.cc:333-382) */
+        const int min_cx = imax(0, (int)floorf((x - j->min_x - r) * j->grid_inv_w));
+        if (min_cx >= j->grid_cols) continue;
+        const int max_cx = imin(j->grid_cols - 1, (int)ceilf((x - j->min_x + r) * j->grid_inv_w));
+        if (max_cx < 0) continue;
+        const int min_cy = imax(0, (int)floorf((y - j->min_y - r) * j->grid_inv_h));
+        if (min_cy >= j->grid_rows) continue;
+        const int max_cy = imin(j->grid_rows - 1, (int)ceilf((y - j->min_y + r) * j->grid_inv_h));
+        if (max_cy < 0) continue;
+        float best = FLT_MAX, best2 = FLT_MAX, best_size = -1.0f, best_size2 = -1.0f;
+        int best_idx = -1;
+        for (int ix = min_cx; ix <= max_cx; ++ix)
+            for (int iy = min_cy; iy <= max_cy; ++iy) {
+                const int c = ix * j->grid_rows + iy;
+                for (int k = g.cell_ptr[c]; k < g.cell_ptr[c + 1]; ++k) {
+                    const int idx = g.cell_idx[k];
+                    if (j->size[idx] < min_size) continue;
+                    if (j->size[idx] > max_size) continue;
+                    const float dx = j->x[idx] - x, dy = j->y[idx] - y;
+                    if (!(fabsf(dx) < r && fabsf(dy) < r)) continue;
+                    /* matching loop (FeatureMatcher.cc:108-139 / :1362-1386) */
+                    if (occ[idx]) continue;
+                    const u8 *a = j->qdesc + (size_t)q * j->desc_bytes, *b = j->desc + (size_t)idx * j->desc_bytes;
+                    const float d = (float)(j->desc_bytes == 32 ? afvo_hamming256(a, b) : afvo_hamming_bytes(a, b, j->desc_bytes));
+                    if (d < best) {
+                        best2 = best; best = d; best_idx = idx;
+                        best_size2 = best_size; best_size = j->size[idx];
+                    } else if (j->mode == 0 && d < best2) {
+                        best2 = d; best_size2 = j->size[idx];
+                    }
+                }
+            }
+        if (best <= j->th_high) {
+            if (j->mode == 0) { /* ratio test only if best and second lie in the same scale band (FeatureMatcher.cc:142-148) */
+                if ((best_size / best_size2 < j->size_tol) && (best_size / best_size2 > j->inv_size_tol) && (best_size2 > 0.0f)) {
+                    if (best > j->nnratio * best2) continue;
+                }
+            }
+            assign[best_idx] = q;
+            if (!j->qoccupies || j->qoccupies[q]) occ[best_idx] = 1;
+            nmatches++;
+            if (j->mode == 1 && j->check_orientation) { /* :1392-1393 */
+                okey[on] = best_idx;
+                obin[on] = afvo_rotation_bin(j->qangle[q], j->angle[best_idx]);
+                on++;
+            }
+        }
+    }
+    if (j->mode == 1 && j->check_orientation) { /* filterMatchesWithOrientation (Pt version, :1601-1613) */
+        int hs[30], i1, i2, i3;
+        memset(hs, 0, sizeof(hs));
+        for (int i = 0; i < on; ++i) hs[obin[i]]++;
+        afvo_three_maxima(hs, 30, &i1, &i2, &i3);
+        for (int i = 0; i < on; ++i) {
+            if (obin[i] == i1 || obin[i] == i2 || obin[i] == i3) continue;
+            assign[okey[i]] = -1;
+            nmatches--;
+        }
+    }
+    free(okey); free(occ); free(g.cell_ptr); free(g.cell_idx);
+    return nmatches;
+}

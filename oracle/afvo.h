@@ -146,6 +146,27 @@ typedef struct {
 } afvo_l2_job;
 int afvo_match_l2_bruteforce(const afvo_l2_job *j, int32_t *match12);
 
+/* ---- projection-guided matching core (grid window + Hamming) ----
+ * Flat restatement of the matching loops of SearchByProjection(F, localMapPoints) (FeatureMatcher.cc:73-154, mode 0) and
+ * SearchByProjection(CurrentFrame, LastFrame) (:1291-1402, mode 1, mono) over Frame::GetFeaturesInArea (Frame.cc:333-382)
+ * and the 64x48 grid of Frame::AssignFeaturesToGrid / PosInGrid (Frame.cc:225-240, :383-394).  The projection itself
+ * (pose * point, radius from viewing angle / keypoint size) is evaluated by the caller exactly as the reference does and
+ * arrives as (u, v, r, min_size, max_size) per query. */
+typedef struct {
+    const uint8_t *desc; int32_t n; int32_t desc_bytes;   /* frame features */
+    const float *x, *y, *size, *angle;                    /* mvKeysUn pt / keyPtsSize / mvKeysUn angle */
+    const uint8_t *occupied;                              /* F.pts[i] && NumberOfObservations() > 0; NULL = none */
+    float min_x, min_y, grid_inv_w, grid_inv_h;           /* mnMinX, mnMinY, mfGridElementWidthInv/HeightInv */
+    int32_t grid_cols, grid_rows;                         /* 64, 48 */
+    int32_t nq;                                           /* queries in the reference's iteration order */
+    const uint8_t *qdesc; const uint8_t *qvalid;
+    const float *qu, *qv, *qr, *qmin_size, *qmax_size, *qangle;
+    const uint8_t *qoccupies;                             /* assigned point has observations (> 0); NULL = yes */
+    float th_high, nnratio, size_tol, inv_size_tol;
+    int32_t check_orientation, mode;                      /* mode 0 = local map, 1 = last frame */
+} afvo_proj_job;
+int afvo_match_projection(const afvo_proj_job *j, int32_t *assign /* [n]: query index or -1 */);
+
 /* M6 pieces, exposed for KATs */
 int afvo_rotation_bin(float a1, float a2); /* FeatureMatcher.cc:1587-1599 */
 void afvo_three_maxima(const int *hist_sizes, int L, int *i1, int *i2, int *i3); /* :1631-1668 */

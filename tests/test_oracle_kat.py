@@ -420,3 +420,29 @@ def test_golden_matcher_vector(oracle, afv, gold):
     ok = m >= 0
     dx = gold["shift4_kps"]["x"][ok] - gold["corners1_kps"]["x"][m[ok]]
     assert np.mean(np.abs(dx - 4.0 * 1.0) < 8.0) > 0.9 and n > 300
+
+
+# ---------------- projection-guided matching core ----------------
+def test_projection_hand_checked(oracle, afv):
+    """three features in one grid neighbourhood, two map points competing for the closest one"""
+    desc = np.stack([_d(0), _d(8), _d(60)])
+    pts = np.float32([[100, 100], [104, 100], [300, 300]])
+    F = afv.FrameGridView(desc, pts, np.float32([1.0, 1.0, 1.0]))
+    q = np.stack([_d(1), _d(2)])
+    Q = afv.ProjectionQueries(q, [101, 101], [100, 100], [10, 10], [0.8, 0.8], [1.3, 1.3])
+    # q0: dists (1, 7) -> same size band: 1 <= 0.8*7 -> takes feature 0.  q1: feature 0 occupied -> only feature 1 (6) -> takes it
+    a, n = oracle.match_projection(F, Q, th_high=75.0, nnratio=0.8)
+    assert a.tolist() == [0, 1, -1] and n == 2
+    # ratio test rejects when best and second are close AND in the same scale band ...
+    a, n = oracle.match_projection(F, Q, th_high=75.0, nnratio=0.1)
+    assert a.tolist() == [-1, -1, -1] and n == 0  # q0: 1 > 0.1*7 rejected; q1 sees (2, 6): 2 > 0.1*6 rejected as well
+    F2 = afv.FrameGridView(desc, pts, np.float32([1.0, 1.25, 1.0]))
+    a2, n2 = oracle.match_projection(F2, Q, th_high=75.0, nnratio=0.1)
+    assert a2.tolist()[0] == 0  # second best lies in another scale band -> no ratio test (FeatureMatcher.cc:144)
+    # window and size band filters
+    Q3 = afv.ProjectionQueries(q, [101, 101], [100, 100], [2.5, 10], [0.8, 1.1], [1.3, 1.3])
+    a3, n3 = oracle.match_projection(F, Q3, th_high=75.0, nnratio=0.8)
+    assert a3.tolist() == [0, -1, -1]  # q0 sees only feature 0 (|dx| < 2.5); q1's size band excludes every feature
+    # last-frame flavour: best only, inclusive threshold
+    a4, n4 = oracle.match_projection(F, Q, th_high=1.0, nnratio=0.8, last_frame=True)
+    assert a4.tolist() == [0, -1, -1] and n4 == 1
