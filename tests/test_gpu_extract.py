@@ -293,3 +293,27 @@ def test_split_batch_two_streams(afv, oracle):
     torch.cuda.synchronize()
     assert np.array_equal(n2.cpu().numpy(), n) and np.array_equal(d2.cpu().numpy()[:, :900], desc[:, :900])
     ctx.close()
+
+
+def test_large_frame_and_budget(afv, oracle):
+    """1920x1080 frame, 3000 features (quota level 0 = 651 nodes), radix / quadtree capacities at scale"""
+    img = afv.synth.corners_frame(77, 1920, 1080)
+    ctx = afv.Context(nfeatures=3000, max_width=1920, max_height=1080, max_batch=1)
+    kps, desc = ctx.extract(img)
+    okps, odesc = oracle.orb_extract(img, oracle.default_params(3000, 8, 1.2, 20), cap=3200)
+    assert len(kps) == len(okps) > 2900
+    assert kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
+    ctx.close()
+
+
+def test_noise_frame_worst_case_candidates(afv, oracle):
+    """pure noise: FAST fires on a third of the pixels -> candidate lists far beyond the register / LDS fast paths of
+    the select kernel (global fallback), retainBest with massive score ties"""
+    img = afv.synth.noise_frame(9, 800, 600)
+    ctx = afv.Context(max_width=800, max_height=600)
+    kps, desc = ctx.extract(img)
+    okps, odesc = oracle.orb_extract(img)
+    assert kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
+    n0 = len(ctx.debug_candidates(0, 0)[0])
+    assert n0 > 10240  # beyond ST * CPT
+    ctx.close()
