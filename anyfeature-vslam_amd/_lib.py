@@ -53,7 +53,7 @@ class TriJob(C.Structure):
 class ProjJob(C.Structure):
     _fields_ = [("desc", C.c_void_p), ("n", C.c_int32), ("desc_bytes", C.c_int32),
                 ("x", C.c_void_p), ("y", C.c_void_p), ("size", C.c_void_p), ("angle", C.c_void_p), ("occupied", C.c_void_p),
-                ("min_x", C.c_float), ("min_y", C.c_float), ("grid_inv_w", C.c_float), ("grid_inv_h", C.c_float),
+                ("inf", C.c_void_p), ("min_x", C.c_float), ("min_y", C.c_float), ("grid_inv_w", C.c_float), ("grid_inv_h", C.c_float),
                 ("grid_cols", C.c_int32), ("grid_rows", C.c_int32), ("nq", C.c_int32),
                 ("qdesc", C.c_void_p), ("qvalid", C.c_void_p), ("qu", C.c_void_p), ("qv", C.c_void_p), ("qr", C.c_void_p),
                 ("qmin_size", C.c_void_p), ("qmax_size", C.c_void_p), ("qangle", C.c_void_p), ("qoccupies", C.c_void_p),
@@ -80,6 +80,7 @@ SYMBOLS = {
     "afv_match_bruteforce_pairs_device": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _f, _f, _i, _vp, _vp, _vp]),
     "afv_match_l2": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _f, _f, _vp, _vp]),
     "afv_match_projection": (_i, [_vp, C.POINTER(ProjJob), _i, _vp, _vp]),
+    "afv_match_fuse": (_i, [_vp, C.POINTER(ProjJob), _i, _vp, _vp]),
     "afv_hamming256": (_i, [_vp, _vp]),
     "afv_profile_enable": (_i, [_vp, _i]),
     "afv_profile_read": (_i, [_vp, _vp, _vp, _vp]),

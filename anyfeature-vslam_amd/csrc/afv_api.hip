@@ -55,7 +55,7 @@ extern "C" void afv_launch_match_l2(const float *d1, int n1, const float *d2, in
 
 struct DevProjJob {
     const uint32_t *fdesc; int n, words;
-    const float *x, *y, *size, *angle; const uint8_t *occupied;
+    const float *x, *y, *size, *angle; const uint8_t *occupied; const float *inf;
     float min_x, min_y, inv_w, inv_h; int cols, rows;
     const int *cell_ptr, *cell_idx;
     int nq; const uint32_t *qdesc; const uint8_t *qvalid;
@@ -64,6 +64,7 @@ struct DevProjJob {
     unsigned long long *keys; int *ncand; int *orilist; int *assign; int *nmatches;
 };
 extern "C" void afv_launch_match_projection(const DevProjJob *jobs, int njobs, hipStream_t stream);
+extern "C" void afv_launch_match_fuse(const DevProjJob *jobs, int njobs, hipStream_t stream);
 
 #define AFV_MAX_SIDE 8192
 
@@ -1084,7 +1085,7 @@ extern "C" int afv_match_l2(afv_ctx *c, const float *desc1, int n1, const float 
 }
 
 // ---- projection-guided matching ----
-extern "C" int afv_match_projection(afv_ctx *c, const afv_proj_job *jobs, int njobs, int32_t *assign, int32_t *nmatches) {
+static int match_projection_impl(afv_ctx *c, const afv_proj_job *jobs, int njobs, int32_t *assign, int32_t *nmatches, bool fuse) {
     if (!c || !jobs || njobs < 1 || !assign || !nmatches) return AFV_EINVAL;
     for (int i = 0; i < njobs; ++i) {
         const afv_proj_job &j = jobs[i];
@@ -1092,12 +1093,13 @@ extern "C" int afv_match_projection(afv_ctx *c, const afv_proj_job *jobs, int nj
         if (j.grid_cols < 1 || j.grid_rows < 1 || (long)j.grid_cols * j.grid_rows > 65536) return AFV_EINVAL;
         if (j.n > 0 && (!j.desc || !j.x || !j.y || !j.size)) return AFV_EINVAL;
         if (j.nq > 0 && (!j.qdesc || !j.qu || !j.qv || !j.qr || !j.qmin_size || !j.qmax_size)) return AFV_EINVAL;
-        if (j.mode != AFV_PROJ_LOCALMAP && j.mode != AFV_PROJ_LASTFRAME) return AFV_EINVAL;
-        if (j.mode == AFV_PROJ_LASTFRAME && j.check_orientation && ((j.n > 0 && !j.angle) || (j.nq > 0 && !j.qangle))) return AFV_EINVAL;
+        if (fuse && j.n > 0 && !j.inf) return AFV_EINVAL;
+        if (!fuse && j.mode != AFV_PROJ_LOCALMAP && j.mode != AFV_PROJ_LASTFRAME) return AFV_EINVAL;
+        if (!fuse && j.mode == AFV_PROJ_LASTFRAME && j.check_orientation && ((j.n > 0 && !j.angle) || (j.nq > 0 && !j.qangle))) return AFV_EINVAL;
     }
     HIPCHK(c, hipSetDevice(c->device));
     Blob b;
-    struct Off { size_t fd, x, y, size, angle, occ, cptr, cidx, qd, qvalid, qu, qv, qr, qmin, qmax, qang, qocc, keys, ncand, ori, assign, nm; int words; };
+    struct Off { size_t fd, x, y, size, angle, occ, inf, cptr, cidx, qd, qvalid, qu, qv, qr, qmin, qmax, qang, qocc, keys, ncand, ori, assign, nm; int words; };
     std::vector<Off> offs(njobs);
     size_t total_out = 0;
     for (int i = 0; i < njobs; ++i) {
@@ -1108,6 +1110,7 @@ extern "C" int afv_match_projection(afv_ctx *c, const afv_proj_job *jobs, int nj
         o.x = b.put(j.x, (size_t)j.n * 4); o.y = b.put(j.y, (size_t)j.n * 4); o.size = b.put(j.size, (size_t)j.n * 4);
         o.angle = j.angle ? b.put(j.angle, (size_t)j.n * 4) : 0;
         o.occ = j.occupied ? b.put(j.occupied, (size_t)j.n) : 0;
+        o.inf = (fuse && j.inf) ? b.put(j.inf, (size_t)j.n * 4) : 0;
         // Frame::AssignFeaturesToGrid / PosInGrid (Frame.cc:225-240, 383-394): cell = ix * rows + iy, ascending index
         const int nc = j.grid_cols * j.grid_rows;
         std::vector<int> cptr((size_t)nc + 1, 0), cidx((size_t)std::max(j.n, 1)), cell((size_t)std::max(j.n, 1));
@@ -1128,7 +1131,7 @@ extern "C" int afv_match_projection(afv_ctx *c, const afv_proj_job *jobs, int nj
         o.qmin = b.put(j.qmin_size, (size_t)j.nq * 4); o.qmax = b.put(j.qmax_size, (size_t)j.nq * 4);
         o.qang = j.qangle ? b.put(j.qangle, (size_t)j.nq * 4) : 0;
         o.qocc = j.qoccupies ? b.put(j.qoccupies, (size_t)j.nq) : 0;
-        total_out += (size_t)j.n;
+        total_out += (size_t)(fuse ? j.nq : j.n);
     }
     const size_t in_bytes = b.h.size();
     for (int i = 0; i < njobs; ++i) {  // device-only scratch
@@ -1153,6 +1156,7 @@ extern "C" int afv_match_projection(afv_ctx *c, const afv_proj_job *jobs, int nj
         d.size = reinterpret_cast<const float *>(B + o.size);
         d.angle = j.angle ? reinterpret_cast<const float *>(B + o.angle) : nullptr;
         d.occupied = j.occupied ? B + o.occ : nullptr;
+        d.inf = (fuse && j.inf) ? reinterpret_cast<const float *>(B + o.inf) : nullptr;
         d.min_x = j.min_x; d.min_y = j.min_y; d.inv_w = j.grid_inv_w; d.inv_h = j.grid_inv_h; d.cols = j.grid_cols; d.rows = j.grid_rows;
         d.cell_ptr = reinterpret_cast<const int *>(B + o.cptr); d.cell_idx = reinterpret_cast<const int *>(B + o.cidx);
         d.nq = j.nq; d.qdesc = reinterpret_cast<const uint32_t *>(B + o.qd); d.qvalid = j.qvalid ? B + o.qvalid : nullptr;
@@ -1166,14 +1170,22 @@ extern "C" int afv_match_projection(afv_ctx *c, const afv_proj_job *jobs, int nj
         d.keys = reinterpret_cast<unsigned long long *>(B + o.keys); d.ncand = reinterpret_cast<int *>(B + o.ncand);
         d.orilist = reinterpret_cast<int *>(B + o.ori);
         d.assign = reinterpret_cast<int *>(B + out_off + acc * 4); d.nmatches = reinterpret_cast<int *>(B + nm_off + (size_t)i * 4);
-        acc += (size_t)j.n;
+        acc += (size_t)(fuse ? j.nq : j.n);
     }
     HIPCHK(c, hipMemcpyAsync(B, b.h.data(), in_bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(B + jobs_off, b.h.data() + jobs_off, (size_t)njobs * sizeof(DevProjJob), hipMemcpyHostToDevice, c->stream));
-    afv_launch_match_projection(reinterpret_cast<const DevProjJob *>(B + jobs_off), njobs, c->stream);
+    if (fuse) afv_launch_match_fuse(reinterpret_cast<const DevProjJob *>(B + jobs_off), njobs, c->stream);
+    else afv_launch_match_projection(reinterpret_cast<const DevProjJob *>(B + jobs_off), njobs, c->stream);
     HIPCHK(c, hipGetLastError());
     if (total_out) HIPCHK(c, hipMemcpyAsync(assign, B + out_off, total_out * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(nmatches, B + nm_off, (size_t)njobs * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return AFV_OK;
+}
+
+extern "C" int afv_match_projection(afv_ctx *c, const afv_proj_job *jobs, int njobs, int32_t *assign, int32_t *nmatches) {
+    return match_projection_impl(c, jobs, njobs, assign, nmatches, false);
+}
+extern "C" int afv_match_fuse(afv_ctx *c, const afv_proj_job *jobs, int njobs, int32_t *best, int32_t *nfound) {
+    return match_projection_impl(c, jobs, njobs, best, nfound, true);
 }

@@ -30,6 +30,7 @@ struct DevProjJob {
     int n, words;
     const float *x, *y, *size, *angle;
     const uint8_t *occupied;
+    const float *inf;
     float min_x, min_y, inv_w, inv_h;
     int cols, rows;
     const int *cell_ptr, *cell_idx;  // grid CSR, cell = ix * rows + iy, ascending feature index inside a cell
@@ -319,6 +320,52 @@ __global__ __launch_bounds__(PT) void k_match_projection(const DevProjJob *__res
     const DevProjJob J = jobs[blockIdx.x];
     if (J.words == 8) proj_job<8>(J);
     else proj_job<16>(J);
+}
+
+// Fuse: independent map points, one thread each; first minimal distance in visiting order wins (strict <, :905)
+template <int W>
+__device__ void fuse_job(const DevProjJob &J) {
+    __shared__ int s_found;
+    if (threadIdx.x == 0) s_found = 0;
+    __syncthreads();
+    int found = 0;
+    for (int q = threadIdx.x; q < J.nq; q += PT) {
+        int best_idx = -1, best = 0x7fffffff;
+        if (!J.qvalid || J.qvalid[q]) {
+            uint32_t qd[W];
+#pragma unroll
+            for (int i = 0; i < W; ++i) qd[i] = J.qdesc[(size_t)q * W + i];
+            const float u = J.qu[q], v = J.qv[q];
+            PROJ_FOR_WINDOW(J, q, {
+                (void)rank;
+                const float ex = u - J.x[idx];
+                const float ey = v - J.y[idx];
+                const float e2 = ex * ex + ey * ey;
+                if ((double)(e2 * J.inf[idx]) > 5.99) continue;  // FeatureMatcher.cc:897-898
+                const int d = proj_hamming<W>(qd, J.fdesc + (size_t)idx * W);
+                if (d < best) {
+                    best = d;
+                    best_idx = idx;
+                }
+            })
+            if (!(best_idx >= 0 && (float)best <= J.th)) best_idx = -1;
+        }
+        J.assign[q] = best_idx;
+        found += best_idx >= 0;
+    }
+    if (found) atomicAdd(&s_found, found);
+    __syncthreads();
+    if (threadIdx.x == 0) *J.nmatches = s_found;
+}
+
+__global__ __launch_bounds__(PT) void k_match_fuse(const DevProjJob *__restrict__ jobs) {
+    const DevProjJob J = jobs[blockIdx.x];
+    if (J.words == 8) fuse_job<8>(J);
+    else fuse_job<16>(J);
+}
+
+extern "C" void afv_launch_match_fuse(const DevProjJob *jobs, int njobs, hipStream_t stream) {
+    hipLaunchKernelGGL(k_match_fuse, dim3(njobs), dim3(PT), 0, stream, jobs);
 }
 
 extern "C" void afv_launch_match_projection(const DevProjJob *jobs, int njobs, hipStream_t stream) {

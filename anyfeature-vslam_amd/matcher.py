@@ -63,7 +63,7 @@ class FrameGridView:
     (Frame.cc:100-101: mnMinX, mnMinY, mfGridElementWidthInv/HeightInv; Frame.h:40-41: 64 x 48 cells)."""
 
     def __init__(self, descriptors, pts, sizes, angles=None, occupied=None, min_x=0.0, min_y=0.0, max_x=640.0, max_y=480.0,
-                 grid_cols=64, grid_rows=48, size_tolerance=1.2):
+                 grid_cols=64, grid_rows=48, size_tolerance=1.2, inf=None):
         self.descriptors = np.ascontiguousarray(descriptors, np.uint8)
         self.N = self.descriptors.shape[0]
         pts = np.asarray(pts, np.float32).reshape(-1, 2)
@@ -71,6 +71,7 @@ class FrameGridView:
         self.sizes = np.ascontiguousarray(sizes, np.float32)
         self.angles = None if angles is None else np.ascontiguousarray(angles, np.float32)
         self.occupied = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+        self.inf = None if inf is None else np.ascontiguousarray(inf, np.float32)  # GetKeyPt1DInf (Fuse)
         self.min_x, self.min_y = np.float32(min_x), np.float32(min_y)
         self.grid_inv_w = np.float32(grid_cols) / (np.float32(max_x) - np.float32(min_x))
         self.grid_inv_h = np.float32(grid_rows) / (np.float32(max_y) - np.float32(min_y))
@@ -186,6 +187,32 @@ class FeatureMatcher:
         out = out[:pKF1.N]
         pairs = [(int(i), int(out[i])) for i in np.nonzero(out >= 0)[0]]
         return pairs, int(nm[0])
+
+    def _proj_job(self, F, queries):
+        j = ProjJob()
+        j.desc = ptr(F.descriptors); j.n = F.N; j.desc_bytes = F.descriptors.shape[1] if F.N else 32
+        j.x = ptr(F.x); j.y = ptr(F.y); j.size = ptr(F.sizes); j.angle = ptr(F.angles); j.occupied = ptr(F.occupied)
+        j.inf = ptr(F.inf)
+        j.min_x = float(F.min_x); j.min_y = float(F.min_y); j.grid_inv_w = float(F.grid_inv_w); j.grid_inv_h = float(F.grid_inv_h)
+        j.grid_cols = F.grid_cols; j.grid_rows = F.grid_rows
+        j.nq = queries.n; j.qdesc = ptr(queries.descriptors); j.qvalid = ptr(queries.valid)
+        j.qu = ptr(queries.u); j.qv = ptr(queries.v); j.qr = ptr(queries.r)
+        j.qmin_size = ptr(queries.min_size); j.qmax_size = ptr(queries.max_size)
+        j.qangle = ptr(queries.angles); j.qoccupies = ptr(queries.occupies)
+        j.nnratio = self.mfNNratio
+        j.size_tol = float(F.sizeTolerance); j.inv_size_tol = float(F.invSizeTolerance)
+        return j
+
+    def Fuse(self, pKF, queries):
+        """matching core of Fuse(pKF, vpMapPoints, th) (FeatureMatcher.cc:794-940, mono): returns (bestIdx per map point
+        | -1, nFused candidates); the Replace / AddObservation surgery (:918-936) stays with the caller."""
+        j = self._proj_job(pKF, queries)
+        j.th_high = self.TH_LOW
+        out = np.full(max(queries.n, 1), -1, np.int32)
+        nm = np.zeros(1, np.int32)
+        jobs = (ProjJob * 1)(j)
+        self.ctx.check(self.lib.afv_match_fuse(self.ctx.handle, jobs, 1, ptr(out), ptr(nm)), "afv_match_fuse")
+        return out[:queries.n].copy(), int(nm[0])
 
     def SearchByProjection(self, F, queries, last_frame=False):
         """matching core of SearchByProjection(F, vpMapPoints, radiusTh) (FeatureMatcher.cc:73-154) or, with

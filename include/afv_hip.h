@@ -152,6 +152,7 @@ typedef struct {
     const float *size;                                  /* F.keyPtsSize[i] */
     const float *angle;                                 /* F.mvKeysUn[i].angle (LASTFRAME + check_orientation) */
     const uint8_t *occupied;                            /* F.pts[i] && F.pts[i]->NumberOfObservations() > 0; NULL = none */
+    const float *inf;                                   /* KeyFrame::GetKeyPt1DInf(i): afv_match_fuse only */
     float min_x, min_y, grid_inv_w, grid_inv_h;         /* mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv */
     int32_t grid_cols, grid_rows;                       /* FRAME_GRID_COLS 64, FRAME_GRID_ROWS 48 (Frame.h:40-41) */
     int32_t nq;                                         /* queries: map points / last-frame keypoints */
@@ -164,6 +165,12 @@ typedef struct {
 } afv_proj_job;
 /* assign = concatenation over jobs of int32[n]: index of the query assigned to feature i (F.pts[i] = pMP) or -1 */
 int afv_match_projection(afv_ctx *ctx, const afv_proj_job *jobs, int njobs, int32_t *assign, int32_t *nmatches);
+/* matching core of FeatureMatcher::Fuse(pKF, vpMapPoints, th) (src/FeatureMatcher.cc:794-940, mono) over
+ * KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:613-652): per map point the most similar keypoint of the window that lies in
+ * the size band [qmin_size, qmax_size] (= predictedSize / sizeTolerance .. * sizeTolerance, :871-873) and passes the
+ * reprojection gate e2 * inf <= 5.99 (:897); th_high carries TH_LOW (:915).  Map points are independent here; the map surgery
+ * (:918-936) stays with the caller.  best = concatenation over jobs of int32[nq] (feature index or -1); nfound[njobs]. */
+int afv_match_fuse(afv_ctx *ctx, const afv_proj_job *jobs, int njobs, int32_t *best, int32_t *nfound);
 
 /* DescriptorDistance_orb32 on the host (utility for adapters / tests) */
 int afv_hamming256(const uint8_t *a, const uint8_t *b);

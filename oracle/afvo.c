@@ -1238,3 +1238,48 @@ int afvo_match_projection(const afvo_proj_job *j, int32_t *assign) {
     free(okey); free(occ); free(g.cell_ptr); free(g.cell_idx);
     return nmatches;
 }
+
+int afvo_match_fuse(const afvo_proj_job *j, int32_t *best_out) {
+    proj_grid g;
+    build_grid(j, &g);
+    int nfound = 0;
+    for (int q = 0; q < j->nq; ++q) {
+        best_out[q] = -1;
+        if (j->qvalid && !j->qvalid[q]) continue;
+        const float u = j->qu[q], v = j->qv[q], r = j->qr[q], min_size = j->qmin_size[q], max_size = j->qmax_size[q];
+        /* KeyFrame::GetFeaturesInArea (KeyFrame.cc:613-652) */
+        const int min_cx = imax(0, (int)floorf((u - j->min_x - r) * j->grid_inv_w));
+        if (min_cx >= j->grid_cols) continue;
+        const int max_cx = imin(j->grid_cols - 1, (int)ceilf((u - j->min_x + r) * j->grid_inv_w));
+        if (max_cx < 0) continue;
+        const int min_cy = imax(0, (int)floorf((v - j->min_y - r) * j->grid_inv_h));
+        if (min_cy >= j->grid_rows) continue;
+        const int max_cy = imin(j->grid_rows - 1, (int)ceilf((v - j->min_y + r) * j->grid_inv_h));
+        if (max_cy < 0) continue;
+        float best = FLT_MAX;
+        int best_idx = -1;
+        for (int ix = min_cx; ix <= max_cx; ++ix)
+            for (int iy = min_cy; iy <= max_cy; ++iy) {
+                const int c = ix * j->grid_rows + iy;
+                for (int k = g.cell_ptr[c]; k < g.cell_ptr[c + 1]; ++k) {
+                    const int idx = g.cell_idx[k];
+                    const float dx = j->x[idx] - u, dy = j->y[idx] - v;
+                    if (!(fabsf(dx) < r && fabsf(dy) < r)) continue;
+                    const float sz = j->size[idx];
+                    if ((sz < min_size) || (sz > max_size)) continue;             /* :871-873 */
+                    const float ex = u - j->x[idx], ey = v - j->y[idx];
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * j->inf[idx] > 5.99) continue;                        /* :897-898 (float product vs double) */
+                    const u8 *a = j->qdesc + (size_t)q * j->desc_bytes, *b = j->desc + (size_t)idx * j->desc_bytes;
+                    const float d = (float)(j->desc_bytes == 32 ? afvo_hamming256(a, b) : afvo_hamming_bytes(a, b, j->desc_bytes));
+                    if (d < best) { best = d; best_idx = idx; }
+                }
+            }
+        if (best <= j->th_high) { /* caller passes TH_LOW here (:915) */
+            best_out[q] = best_idx;
+            nfound++;
+        }
+    }
+    free(g.cell_ptr); free(g.cell_idx);
+    return nfound;
+}

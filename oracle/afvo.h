@@ -156,6 +156,7 @@ typedef struct {
     const uint8_t *desc; int32_t n; int32_t desc_bytes;   /* frame features */
     const float *x, *y, *size, *angle;                    /* mvKeysUn pt / keyPtsSize / mvKeysUn angle */
     const uint8_t *occupied;                              /* F.pts[i] && NumberOfObservations() > 0; NULL = none */
+    const float *inf;                                     /* KeyFrame::GetKeyPt1DInf(i) (Fuse only) */
     float min_x, min_y, grid_inv_w, grid_inv_h;           /* mnMinX, mnMinY, mfGridElementWidthInv/HeightInv */
     int32_t grid_cols, grid_rows;                         /* 64, 48 */
     int32_t nq;                                           /* queries in the reference's iteration order */
@@ -166,6 +167,10 @@ typedef struct {
     int32_t check_orientation, mode;                      /* mode 0 = local map, 1 = last frame */
 } afvo_proj_job;
 int afvo_match_projection(const afvo_proj_job *j, int32_t *assign /* [n]: query index or -1 */);
+/* matching core of FeatureMatcher::Fuse(pKF, vpMapPoints, th) (FeatureMatcher.cc:794-940, mono): per map point the most
+ * similar keypoint in the window that lies in the predicted size band and passes the 5.99 reprojection gate; best[q] = feature
+ * index or -1 (bestDist > TH_LOW).  Independent per point: the map surgery (:918-936) stays with the caller.  returns #found */
+int afvo_match_fuse(const afvo_proj_job *j, int32_t *best /* [nq] */);
 
 /* M6 pieces, exposed for KATs */
 int afvo_rotation_bin(float a1, float a2); /* FeatureMatcher.cc:1587-1599 */

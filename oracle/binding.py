@@ -54,7 +54,7 @@ class TriJob(C.Structure):
 class ProjJob(C.Structure):
     _fields_ = [("desc", C.c_void_p), ("n", C.c_int32), ("desc_bytes", C.c_int32),
                 ("x", C.c_void_p), ("y", C.c_void_p), ("size", C.c_void_p), ("angle", C.c_void_p), ("occupied", C.c_void_p),
-                ("min_x", C.c_float), ("min_y", C.c_float), ("grid_inv_w", C.c_float), ("grid_inv_h", C.c_float),
+                ("inf", C.c_void_p), ("min_x", C.c_float), ("min_y", C.c_float), ("grid_inv_w", C.c_float), ("grid_inv_h", C.c_float),
                 ("grid_cols", C.c_int32), ("grid_rows", C.c_int32), ("nq", C.c_int32),
                 ("qdesc", C.c_void_p), ("qvalid", C.c_void_p), ("qu", C.c_void_p), ("qv", C.c_void_p), ("qr", C.c_void_p),
                 ("qmin_size", C.c_void_p), ("qmax_size", C.c_void_p), ("qangle", C.c_void_p), ("qoccupies", C.c_void_p),
@@ -410,11 +410,12 @@ def three_maxima(sizes):
     return i1.value, i2.value, i3.value
 
 
-def match_projection(F, Q, th_high=75.0, nnratio=0.8, check_orientation=False, last_frame=False):
+def match_projection(F, Q, th_high=75.0, nnratio=0.8, check_orientation=False, last_frame=False, fuse=False):
     """F / Q: objects with the attributes of anyfeature-vslam_amd's FrameGridView / ProjectionQueries"""
     j = ProjJob()
     j.desc = _p(F.descriptors); j.n = F.N; j.desc_bytes = F.descriptors.shape[1] if F.N else 32
     j.x = _p(F.x); j.y = _p(F.y); j.size = _p(F.sizes); j.angle = _p(F.angles); j.occupied = _p(F.occupied)
+    j.inf = _p(getattr(F, 'inf', None))
     j.min_x = float(F.min_x); j.min_y = float(F.min_y); j.grid_inv_w = float(F.grid_inv_w); j.grid_inv_h = float(F.grid_inv_h)
     j.grid_cols = F.grid_cols; j.grid_rows = F.grid_rows
     j.nq = Q.n; j.qdesc = _p(Q.descriptors); j.qvalid = _p(Q.valid)
@@ -422,6 +423,10 @@ def match_projection(F, Q, th_high=75.0, nnratio=0.8, check_orientation=False, l
     j.qangle = _p(Q.angles); j.qoccupies = _p(Q.occupies)
     j.th_high = th_high; j.nnratio = nnratio; j.size_tol = float(F.sizeTolerance); j.inv_size_tol = float(F.invSizeTolerance)
     j.check_orientation = int(bool(check_orientation)); j.mode = 1 if last_frame else 0
+    if fuse:
+        out = np.zeros(max(Q.n, 1), np.int32)
+        nm = lib().afvo_match_fuse(C.byref(j), _p(out))
+        return out[:Q.n].copy(), nm
     out = np.zeros(max(F.N, 1), np.int32)
     nm = lib().afvo_match_projection(C.byref(j), _p(out))
     return out[:F.N].copy(), nm

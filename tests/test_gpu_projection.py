@@ -94,3 +94,16 @@ def test_projection_dense_cluster_forces_rescans(afv, oracle, gpu_ctx):
         want, wn = oracle.match_projection(F, Q, th_high=75.0, nnratio=ratio, last_frame=mode)
         assert nn == wn and np.array_equal(got, want), (mode, ratio)
     assert wn == n  # every feature ends up taken
+
+
+@pytest.mark.parametrize("seed,shift,rs", [(11, 4, 15.0), (12, 1, 50.0)])
+def test_fuse_core(afv, oracle, gpu_ctx, seed, shift, rs):
+    """Fuse(pKF, vpMapPoints): independent map points, size band + 5.99 reprojection gate, first minimum wins"""
+    F, Q = _scene(afv, gpu_ctx, seed, shift, rs)
+    F.inf = np.ascontiguousarray(np.float32(0.2) / (F.sizes * F.sizes))   # GetKeyPt1DInf ~ 1/sigma^2 (loosened)
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+    m = afv.FeatureMatcher(0.6, True, ctx=gpu_ctx)
+    got, n = m.Fuse(F, Q)
+    want, wn = oracle.match_projection(F, Q, th_high=75.0, fuse=True)
+    assert n == wn and np.array_equal(got, want)
+    assert 50 < wn < Q.n  # the gate and the threshold both bite
