@@ -66,6 +66,19 @@ struct DevProjJob {
 extern "C" void afv_launch_match_projection(const DevProjJob *jobs, int njobs, hipStream_t stream);
 extern "C" void afv_launch_match_fuse(const DevProjJob *jobs, int njobs, hipStream_t stream);
 
+struct DevVocab {
+    int k, L, nnodes, words;
+    const int *child_ptr, *child_idx;
+    const uint32_t *desc;
+};
+extern "C" void afv_launch_bow_transform(const DevVocab *v, const uint32_t *desc, int n, int levelsup, int *leaf_node,
+                                         int *node_at_level, hipStream_t stream);
+struct afv_vocab {
+    DevVocab dev{};
+    int desc_bytes = 32;
+    void *d_child_ptr = nullptr, *d_child_idx = nullptr, *d_desc = nullptr;
+};
+
 #define AFV_MAX_SIDE 8192
 
 struct afv_ctx {
@@ -1188,4 +1201,72 @@ extern "C" int afv_match_projection(afv_ctx *c, const afv_proj_job *jobs, int nj
 }
 extern "C" int afv_match_fuse(afv_ctx *c, const afv_proj_job *jobs, int njobs, int32_t *best, int32_t *nfound) {
     return match_projection_impl(c, jobs, njobs, best, nfound, true);
+}
+
+// ---- BoW quantisation ----
+extern "C" int afv_vocab_create(afv_ctx *c, int k, int L, int nnodes, const int32_t *child_ptr, const int32_t *child_idx,
+                                const uint8_t *desc, int desc_bytes, afv_vocab **out) {
+    if (!c || !out || !child_ptr || !child_idx || !desc || k < 1 || L < 1 || nnodes < 1 || desc_bytes < 1 || desc_bytes > 64)
+        return AFV_EINVAL;
+    *out = nullptr;
+    const int nchild = child_ptr[nnodes];
+    if (child_ptr[0] != 0 || nchild < 0 || nchild > nnodes) return AFV_EINVAL;
+    for (int i = 0; i < nnodes; ++i)
+        if (child_ptr[i + 1] < child_ptr[i]) return AFV_EINVAL;
+    for (int i = 0; i < nchild; ++i)
+        if (child_idx[i] <= 0 || child_idx[i] >= nnodes) return AFV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    afv_vocab *v = new (std::nothrow) afv_vocab();
+    if (!v) return AFV_ENOMEM;
+    v->desc_bytes = desc_bytes;
+    const int words = desc_bytes <= 32 ? 8 : 16;
+    std::vector<uint8_t> padded((size_t)nnodes * words * 4, 0);
+    for (int i = 0; i < nnodes; ++i) std::memcpy(padded.data() + (size_t)i * words * 4, desc + (size_t)i * desc_bytes, (size_t)desc_bytes);
+    hipError_t e = hipMalloc(&v->d_child_ptr, (size_t)(nnodes + 1) * 4);
+    if (e == hipSuccess) e = hipMalloc(&v->d_child_idx, (size_t)std::max(nchild, 1) * 4);
+    if (e == hipSuccess) e = hipMalloc(&v->d_desc, padded.size());
+    if (e == hipSuccess) e = hipMemcpy(v->d_child_ptr, child_ptr, (size_t)(nnodes + 1) * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nchild) e = hipMemcpy(v->d_child_idx, child_idx, (size_t)nchild * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(v->d_desc, padded.data(), padded.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        c->last_error = std::string("afv_vocab_create: ") + hipGetErrorString(e);
+        afv_vocab_destroy(c, v);
+        return e == hipErrorOutOfMemory ? AFV_ENOMEM : AFV_EHIP;
+    }
+    v->dev = DevVocab{k, L, nnodes, words, (const int *)v->d_child_ptr, (const int *)v->d_child_idx, (const uint32_t *)v->d_desc};
+    *out = v;
+    return AFV_OK;
+}
+
+extern "C" void afv_vocab_destroy(afv_ctx *c, afv_vocab *v) {
+    if (!v) return;
+    if (c) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+    }
+    if (v->d_child_ptr) (void)hipFree(v->d_child_ptr);
+    if (v->d_child_idx) (void)hipFree(v->d_child_idx);
+    if (v->d_desc) (void)hipFree(v->d_desc);
+    delete v;
+}
+
+extern "C" int afv_bow_transform(afv_ctx *c, const afv_vocab *v, const uint8_t *desc, int n, int levelsup, int32_t *leaf_node,
+                                 int32_t *node_at_level) {
+    if (!c || !v || n < 0 || (n > 0 && (!desc || !leaf_node || !node_at_level))) return AFV_EINVAL;
+    if (n == 0) return AFV_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    Blob b;
+    const size_t d_off = put_desc(b, desc, n, v->desc_bytes, v->dev.words);
+    const size_t in_bytes = b.h.size();
+    const size_t leaf_off = b.reserve((size_t)n * 4), nid_off = b.reserve((size_t)n * 4);
+    const int rc = ensure_match_buffer(c, b.h.size());
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_match, b.h.data(), in_bytes, hipMemcpyHostToDevice, c->stream));
+    afv_launch_bow_transform(&v->dev, reinterpret_cast<const uint32_t *>(c->d_match + d_off), n, levelsup,
+                             reinterpret_cast<int *>(c->d_match + leaf_off), reinterpret_cast<int *>(c->d_match + nid_off), c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(leaf_node, c->d_match + leaf_off, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(node_at_level, c->d_match + nid_off, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AFV_OK;
 }

@@ -172,6 +172,20 @@ int afv_match_projection(afv_ctx *ctx, const afv_proj_job *jobs, int njobs, int3
  * (:918-936) stays with the caller.  best = concatenation over jobs of int32[nq] (feature index or -1); nfound[njobs]. */
 int afv_match_fuse(afv_ctx *ctx, const afv_proj_job *jobs, int njobs, int32_t *best, int32_t *nfound);
 
+/* ---- BoW quantisation ----
+ * DBoW2 TemplatedVocabulary::transform(features, BowVector, FeatureVector, levelsup) as called by Vocabulary::transform
+ * (src/Vocabulary.cpp:156-206, levelsup = 4; Frame::ComputeBoW src/Frame.cc:397-401, KeyFrame::ComputeBoW
+ * src/KeyFrame.cc:65-73).  The tree is uploaded once; per descriptor the kernel descends it (k-way Hamming argmin per level,
+ * first minimum wins) and returns the leaf node and the node met at depth L - levelsup, from which the host builds the
+ * FeatureVector (node -> ascending feature indices) that afv_match_bow consumes and the BowVector (word weights). */
+typedef struct afv_vocab afv_vocab;
+/* children of node i = child_idx[child_ptr[i] .. child_ptr[i+1]) in DBoW2 order; node 0 = root; desc = nnodes x desc_bytes */
+int afv_vocab_create(afv_ctx *ctx, int k, int L, int nnodes, const int32_t *child_ptr, const int32_t *child_idx,
+                     const uint8_t *desc, int desc_bytes, afv_vocab **out);
+void afv_vocab_destroy(afv_ctx *ctx, afv_vocab *v);
+int afv_bow_transform(afv_ctx *ctx, const afv_vocab *v, const uint8_t *desc, int n, int levelsup, int32_t *leaf_node,
+                      int32_t *node_at_level);
+
 /* DescriptorDistance_orb32 on the host (utility for adapters / tests) */
 int afv_hamming256(const uint8_t *a, const uint8_t *b);
 

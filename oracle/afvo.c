@@ -1283,3 +1283,31 @@ int afvo_match_fuse(const afvo_proj_job *j, int32_t *best_out) {
     free(g.cell_ptr); free(g.cell_idx);
     return nfound;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * BoW quantisation (DBoW2 transform, upstream semantics; parity unpinned)
+ * ---------------------------------------------------------------------------------------------- */
+void afvo_bow_transform(const afvo_vocab *v, const uint8_t *desc, int n, int levelsup, int32_t *leaf_node, int32_t *node_at_level) {
+    const int nid_level = v->L - levelsup;
+    for (int i = 0; i < n; ++i) {
+        const u8 *f = desc + (size_t)i * v->desc_bytes;
+        int final_id = 0, level = 0, nid = 0;
+        while (v->child_ptr[final_id + 1] > v->child_ptr[final_id]) { /* !isLeaf() */
+            ++level;
+            const int b = v->child_ptr[final_id], e = v->child_ptr[final_id + 1];
+            int best = v->child_idx[b];
+            int best_d = v->desc_bytes == 32 ? afvo_hamming256(f, v->desc + (size_t)best * 32)
+                                             : afvo_hamming_bytes(f, v->desc + (size_t)best * v->desc_bytes, v->desc_bytes);
+            for (int c = b + 1; c < e; ++c) {
+                const int id = v->child_idx[c];
+                const int d = v->desc_bytes == 32 ? afvo_hamming256(f, v->desc + (size_t)id * 32)
+                                                  : afvo_hamming_bytes(f, v->desc + (size_t)id * v->desc_bytes, v->desc_bytes);
+                if (d < best_d) { best_d = d; best = id; }
+            }
+            final_id = best;
+            if (level == nid_level) nid = final_id;
+        }
+        leaf_node[i] = final_id;
+        node_at_level[i] = nid_level <= 0 ? 0 : nid;
+    }
+}

@@ -172,6 +172,19 @@ int afvo_match_projection(const afvo_proj_job *j, int32_t *assign /* [n]: query 
  * index or -1 (bestDist > TH_LOW).  Independent per point: the map surgery (:918-936) stays with the caller.  returns #found */
 int afvo_match_fuse(const afvo_proj_job *j, int32_t *best /* [nq] */);
 
+/* ---- BoW quantisation (DBoW2 TemplatedVocabulary::transform(features, v, fv, levelsup), called from
+ * Vocabulary.cpp:156-206 with levelsup = 4).  DBoW2 is an empty submodule: restated from upstream DBoW2 (parity unpinned).
+ * Tree in CSR form: children of node i are child_idx[child_ptr[i] .. child_ptr[i+1]) in DBoW2's order, node 0 = root,
+ * a node without children is a word.  Per feature: greedy descent, first minimal Hamming distance wins (strict <);
+ * word[i] = node id of the reached leaf, node_at_level[i] = node id met at depth L - levelsup (0 if that depth is <= 0 or
+ * the leaf is reached earlier). */
+typedef struct {
+    int32_t k, L, nnodes;
+    const int32_t *child_ptr, *child_idx;
+    const uint8_t *desc; int32_t desc_bytes;
+} afvo_vocab;
+void afvo_bow_transform(const afvo_vocab *v, const uint8_t *desc, int n, int levelsup, int32_t *leaf_node, int32_t *node_at_level);
+
 /* M6 pieces, exposed for KATs */
 int afvo_rotation_bin(float a1, float a2); /* FeatureMatcher.cc:1587-1599 */
 void afvo_three_maxima(const int *hist_sizes, int L, int *i1, int *i2, int *i3); /* :1631-1668 */

@@ -430,3 +430,21 @@ def match_projection(F, Q, th_high=75.0, nnratio=0.8, check_orientation=False, l
     out = np.zeros(max(F.N, 1), np.int32)
     nm = lib().afvo_match_projection(C.byref(j), _p(out))
     return out[:F.N].copy(), nm
+
+
+class Vocab(C.Structure):
+    _fields_ = [("k", C.c_int32), ("L", C.c_int32), ("nnodes", C.c_int32), ("child_ptr", C.c_void_p), ("child_idx", C.c_void_p),
+                ("desc", C.c_void_p), ("desc_bytes", C.c_int32)]
+
+
+def bow_transform(vocab, desc, levelsup=4):
+    """vocab: object with k, L, child_ptr, child_idx, node_desc (anyfeature-vslam_amd Vocabulary); returns (leaf node ids,
+    node ids at depth L - levelsup)"""
+    desc = np.ascontiguousarray(desc, np.uint8)
+    v = Vocab()
+    v.k, v.L, v.nnodes = vocab.k, vocab.L, len(vocab.child_ptr) - 1
+    v.child_ptr = _p(vocab.child_ptr); v.child_idx = _p(vocab.child_idx); v.desc = _p(vocab.node_desc)
+    v.desc_bytes = vocab.node_desc.shape[1]
+    leaf = np.zeros(max(len(desc), 1), np.int32); nid = np.zeros(max(len(desc), 1), np.int32)
+    lib().afvo_bow_transform(C.byref(v), _p(desc), len(desc), int(levelsup), _p(leaf), _p(nid))
+    return leaf[:len(desc)].copy(), nid[:len(desc)].copy()

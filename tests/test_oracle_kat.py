@@ -446,3 +446,27 @@ def test_projection_hand_checked(oracle, afv):
     # last-frame flavour: best only, inclusive threshold
     a4, n4 = oracle.match_projection(F, Q, th_high=1.0, nnratio=0.8, last_frame=True)
     assert a4.tolist() == [0, -1, -1] and n4 == 1
+
+
+def test_bow_transform_hand_tree(afv, oracle):
+    """k=2, L=2 tree with hand-picked node descriptors: descent by Hamming argmin, first minimum wins, node_at_level at
+    depth L - levelsup (DBoW2 transform semantics restated; parity unpinned)."""
+    parent = [0, 0, 0, 1, 1, 2, 2]
+    desc = np.zeros((7, 32), np.uint8)
+    desc[1] = 0x00; desc[2] = 0xFF
+    desc[3] = 0x00; desc[4] = 0x0F; desc[5] = 0xFF; desc[6] = 0xF0
+    leaf = [False, False, False, True, True, True, True]
+    voc = afv.Vocabulary(2, 2, parent, desc, np.ones(7), leaf)
+    assert voc.child_ptr.tolist() == [0, 2, 4, 6, 6, 6, 6, 6] and voc.child_idx.tolist() == [1, 2, 3, 4, 5, 6]
+    assert voc.word_id.tolist() == [-1, -1, -1, 0, 1, 2, 3]
+    q = np.zeros((4, 32), np.uint8)
+    q[0] = 0x01        # near node 1, then node 3
+    q[1] = 0x0F        # equidistant from 1 and 2 (128 each) -> first child (1); then node 4 exactly
+    q[2] = 0xFE        # near 2, then 5
+    q[3] = 0xF0        # tie 1/2 -> 1; children 3 (d=128) / 4 (d=256) -> 3
+    lf, nid = oracle.bow_transform(voc, q, levelsup=1)
+    assert lf.tolist() == [3, 4, 5, 3] and nid.tolist() == [1, 1, 2, 1]
+    lf, nid = oracle.bow_transform(voc, q, levelsup=4)
+    assert lf.tolist() == [3, 4, 5, 3] and nid.tolist() == [0, 0, 0, 0]
+    lf, nid = oracle.bow_transform(voc, q, levelsup=0)
+    assert nid.tolist() == lf.tolist()
