@@ -81,6 +81,8 @@ SYMBOLS = {
     "afv_match_l2": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _f, _f, _vp, _vp]),
     "afv_match_projection": (_i, [_vp, C.POINTER(ProjJob), _i, _vp, _vp]),
     "afv_match_fuse": (_i, [_vp, C.POINTER(ProjJob), _i, _vp, _vp]),
+    "afv_match_sim3": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "afv_match_initialization": (_i, [_vp, _vp, _i, _vp, _vp]),
     "afv_vocab_create": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, C.POINTER(_vp)]),
     "afv_vocab_destroy": (None, [_vp, _vp]),
     "afv_bow_transform": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),

@@ -65,6 +65,7 @@ struct DevProjJob {
 };
 extern "C" void afv_launch_match_projection(const DevProjJob *jobs, int njobs, hipStream_t stream);
 extern "C" void afv_launch_match_fuse(const DevProjJob *jobs, int njobs, hipStream_t stream);
+extern "C" void afv_launch_match_init(const DevProjJob *jobs, int njobs, hipStream_t stream);
 
 struct DevVocab {
     int k, L, nnodes, words;
@@ -1098,7 +1099,9 @@ extern "C" int afv_match_l2(afv_ctx *c, const float *desc1, int n1, const float 
 }
 
 // ---- projection-guided matching ----
-static int match_projection_impl(afv_ctx *c, const afv_proj_job *jobs, int njobs, int32_t *assign, int32_t *nmatches, bool fuse) {
+enum { KIND_PROJ = 0, KIND_FUSE = 1, KIND_INIT = 2 };
+static int match_projection_impl(afv_ctx *c, const afv_proj_job *jobs, int njobs, int32_t *assign, int32_t *nmatches, int kind) {
+    const bool fuse = kind == KIND_FUSE, per_query = kind != KIND_PROJ;
     if (!c || !jobs || njobs < 1 || !assign || !nmatches) return AFV_EINVAL;
     for (int i = 0; i < njobs; ++i) {
         const afv_proj_job &j = jobs[i];
@@ -1106,9 +1109,9 @@ static int match_projection_impl(afv_ctx *c, const afv_proj_job *jobs, int njobs
         if (j.grid_cols < 1 || j.grid_rows < 1 || (long)j.grid_cols * j.grid_rows > 65536) return AFV_EINVAL;
         if (j.n > 0 && (!j.desc || !j.x || !j.y || !j.size)) return AFV_EINVAL;
         if (j.nq > 0 && (!j.qdesc || !j.qu || !j.qv || !j.qr || !j.qmin_size || !j.qmax_size)) return AFV_EINVAL;
-        if (fuse && j.n > 0 && !j.inf) return AFV_EINVAL;
-        if (!fuse && j.mode != AFV_PROJ_LOCALMAP && j.mode != AFV_PROJ_LASTFRAME) return AFV_EINVAL;
-        if (!fuse && j.mode == AFV_PROJ_LASTFRAME && j.check_orientation && ((j.n > 0 && !j.angle) || (j.nq > 0 && !j.qangle))) return AFV_EINVAL;
+        if (kind == KIND_INIT && j.check_orientation && ((j.n > 0 && !j.angle) || (j.nq > 0 && !j.qangle))) return AFV_EINVAL;
+        if (kind == KIND_PROJ && j.mode != AFV_PROJ_LOCALMAP && j.mode != AFV_PROJ_LASTFRAME) return AFV_EINVAL;
+        if (kind == KIND_PROJ && j.mode == AFV_PROJ_LASTFRAME && j.check_orientation && ((j.n > 0 && !j.angle) || (j.nq > 0 && !j.qangle))) return AFV_EINVAL;
     }
     HIPCHK(c, hipSetDevice(c->device));
     Blob b;
@@ -1144,7 +1147,7 @@ static int match_projection_impl(afv_ctx *c, const afv_proj_job *jobs, int njobs
         o.qmin = b.put(j.qmin_size, (size_t)j.nq * 4); o.qmax = b.put(j.qmax_size, (size_t)j.nq * 4);
         o.qang = j.qangle ? b.put(j.qangle, (size_t)j.nq * 4) : 0;
         o.qocc = j.qoccupies ? b.put(j.qoccupies, (size_t)j.nq) : 0;
-        total_out += (size_t)(fuse ? j.nq : j.n);
+        total_out += (size_t)(per_query ? j.nq : j.n);
     }
     const size_t in_bytes = b.h.size();
     for (int i = 0; i < njobs; ++i) {  // device-only scratch
@@ -1183,11 +1186,12 @@ static int match_projection_impl(afv_ctx *c, const afv_proj_job *jobs, int njobs
         d.keys = reinterpret_cast<unsigned long long *>(B + o.keys); d.ncand = reinterpret_cast<int *>(B + o.ncand);
         d.orilist = reinterpret_cast<int *>(B + o.ori);
         d.assign = reinterpret_cast<int *>(B + out_off + acc * 4); d.nmatches = reinterpret_cast<int *>(B + nm_off + (size_t)i * 4);
-        acc += (size_t)(fuse ? j.nq : j.n);
+        acc += (size_t)(per_query ? j.nq : j.n);
     }
     HIPCHK(c, hipMemcpyAsync(B, b.h.data(), in_bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(B + jobs_off, b.h.data() + jobs_off, (size_t)njobs * sizeof(DevProjJob), hipMemcpyHostToDevice, c->stream));
     if (fuse) afv_launch_match_fuse(reinterpret_cast<const DevProjJob *>(B + jobs_off), njobs, c->stream);
+    else if (kind == KIND_INIT) afv_launch_match_init(reinterpret_cast<const DevProjJob *>(B + jobs_off), njobs, c->stream);
     else afv_launch_match_projection(reinterpret_cast<const DevProjJob *>(B + jobs_off), njobs, c->stream);
     HIPCHK(c, hipGetLastError());
     if (total_out) HIPCHK(c, hipMemcpyAsync(assign, B + out_off, total_out * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1197,10 +1201,34 @@ static int match_projection_impl(afv_ctx *c, const afv_proj_job *jobs, int njobs
 }
 
 extern "C" int afv_match_projection(afv_ctx *c, const afv_proj_job *jobs, int njobs, int32_t *assign, int32_t *nmatches) {
-    return match_projection_impl(c, jobs, njobs, assign, nmatches, false);
+    return match_projection_impl(c, jobs, njobs, assign, nmatches, KIND_PROJ);
 }
 extern "C" int afv_match_fuse(afv_ctx *c, const afv_proj_job *jobs, int njobs, int32_t *best, int32_t *nfound) {
-    return match_projection_impl(c, jobs, njobs, best, nfound, true);
+    return match_projection_impl(c, jobs, njobs, best, nfound, KIND_FUSE);
+}
+extern "C" int afv_match_initialization(afv_ctx *c, const afv_proj_job *jobs, int njobs, int32_t *match12, int32_t *nmatches) {
+    return match_projection_impl(c, jobs, njobs, match12, nmatches, KIND_INIT);
+}
+extern "C" int afv_match_sim3(afv_ctx *c, const afv_proj_job *j12, const afv_proj_job *j21, int32_t *match12, int32_t *nfound) {
+    if (!c || !j12 || !j21 || !match12 || !nfound) return AFV_EINVAL;
+    if (j12->nq != j21->n || j21->nq != j12->n) return AFV_EINVAL;
+    afv_proj_job jobs[2] = {*j12, *j21};
+    jobs[0].inf = nullptr;  // no reprojection gate in SearchBySim3
+    jobs[1].inf = nullptr;
+    std::vector<int32_t> best((size_t)j12->nq + (size_t)j21->nq + 1);
+    int32_t nf[2];
+    const int rc = match_projection_impl(c, jobs, 2, best.data(), nf, KIND_FUSE);
+    if (rc) return rc;
+    const int32_t *m1 = best.data(), *m2 = best.data() + j12->nq;
+    int found = 0;
+    for (int i1 = 0; i1 < j12->nq; ++i1) {  // FeatureMatcher.cc:1268-1284
+        const int idx2 = m1[i1];
+        const bool agree = idx2 >= 0 && m2[idx2] == i1;
+        match12[i1] = agree ? idx2 : -1;
+        found += agree;
+    }
+    *nfound = found;
+    return AFV_OK;
 }
 
 // ---- BoW quantisation ----

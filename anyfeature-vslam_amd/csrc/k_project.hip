@@ -341,7 +341,7 @@ __device__ void fuse_job(const DevProjJob &J) {
                 const float ex = u - J.x[idx];
                 const float ey = v - J.y[idx];
                 const float e2 = ex * ex + ey * ey;
-                if ((double)(e2 * J.inf[idx]) > 5.99) continue;  // FeatureMatcher.cc:897-898
+                if (J.inf && (double)(e2 * J.inf[idx]) > 5.99) continue;  // FeatureMatcher.cc:897-898 (absent in Fuse(Sim3) / SearchBySim3)
                 const int d = proj_hamming<W>(qd, J.fdesc + (size_t)idx * W);
                 if (d < best) {
                     best = d;
@@ -362,6 +362,131 @@ __global__ __launch_bounds__(PT) void k_match_fuse(const DevProjJob *__restrict_
     const DevProjJob J = jobs[blockIdx.x];
     if (J.words == 8) fuse_job<8>(J);
     else fuse_job<16>(J);
+}
+
+// SearchForInitialization (FeatureMatcher.cc:399-557, active part :480-556): queries = level-0 features of F1 searched in a
+// fixed window around vbPrevMatched in F2.  Inherently ordered: a candidate is skipped when an earlier query already
+// matched it at a distance <= the current one (:513), and a later query steals the feature (:531-535).  One wave per
+// job walks the queries in order; the 64 lanes split the window's cells (cell-major = the reference's visiting order),
+// so a query costs ceil(cells / 64) rounds plus two 64-bit wave minima.
+#define INIT_NO_KEY 0xffffffffffffffffull
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long t = __shfl_xor(v, o, 64);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
+template <int W>
+__device__ void init_job(const DevProjJob &J) {
+    __shared__ int s_m21[P_MAX_FEATS];
+    __shared__ unsigned short s_mdist[P_MAX_FEATS];
+    __shared__ int s_hist[32];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < J.n; i += 64) {
+        s_m21[i] = -1;
+        s_mdist[i] = 0xffff;
+    }
+    for (int q = lane; q < J.nq; q += 64) J.assign[q] = -1;
+    if (lane < 32) s_hist[lane] = 0;
+    WAVE_LDS_SYNC();
+    int nm = 0, nori = 0;
+    for (int q = 0; q < J.nq; ++q) {
+        if (J.qvalid && !J.qvalid[q]) continue;  // level1 > 0 (:489-491)
+        const float x = J.qu[q], y = J.qv[q], r = J.qr[q], mn = J.qmin[q], mx = J.qmax[q];
+        const Window w = proj_window(J, x, y, r);
+        if (!w.ok) continue;
+        uint32_t qd[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i) qd[i] = J.qdesc[(size_t)q * W + i];
+        const int ny = w.cy1 - w.cy0 + 1, ncells = (w.cx1 - w.cx0 + 1) * ny;
+        unsigned long long k0 = INIT_NO_KEY, k1 = INIT_NO_KEY;
+        for (int c = lane; c < ncells; c += 64) {
+            const int cell = (w.cx0 + c / ny) * J.rows + (w.cy0 + c % ny);
+            const int kb = J.cell_ptr[cell], ke = J.cell_ptr[cell + 1];
+            for (int k = kb; k < ke; ++k) {
+                const int idx = J.cell_idx[k];
+                const float sz = J.size[idx];
+                if (sz < mn || sz > mx) continue;
+                if (!(fabsf(J.x[idx] - x) < r && fabsf(J.y[idx] - y) < r)) continue;
+                const int d = proj_hamming<W>(qd, J.fdesc + (size_t)idx * W);
+                if ((int)s_mdist[idx] <= d) continue;  // vMatchedDistance[i2] <= descDist (:513)
+                // key: distance, then visiting order (cell rank, position in cell), then the feature itself
+                const unsigned long long key = ((unsigned long long)d << 48) | ((unsigned long long)c << 32) |
+                                               ((unsigned long long)((k - kb) & 0xffff) << 16) | (unsigned)idx;
+                if (key < k0) {
+                    k1 = k0;
+                    k0 = key;
+                } else if (key < k1) {
+                    k1 = key;
+                }
+            }
+        }
+        const unsigned long long g0 = wave_min_u64(k0);
+        if (g0 == INIT_NO_KEY) continue;
+        const unsigned long long g1 = wave_min_u64(k0 == g0 ? k1 : k0);
+        const float best = (float)(int)(g0 >> 48);
+        const float best2 = g1 == INIT_NO_KEY ? 3.402823466e+38f : (float)(int)(g1 >> 48);
+        const int bidx = (int)(g0 & 0xffff);
+        if (best <= J.th && best < best2 * J.ratio) {  // :529-531
+            if (lane == 0) {
+                const int prev = s_m21[bidx];
+                if (prev >= 0) J.assign[prev] = -1;
+                J.assign[q] = bidx;
+                s_m21[bidx] = q;
+                s_mdist[bidx] = (unsigned short)(int)best;
+                if (J.check_ori) {
+                    const int bin = proj_rotation_bin(J.qangle[q], J.angle[bidx]);  // F1 keypoint first (:543)
+                    J.orilist[2 * nori] = q;
+                    J.orilist[2 * nori + 1] = bin;
+                    s_hist[bin]++;
+                }
+            }
+            nm += 1;
+            nori += 1;
+            // a stolen feature takes one match away again (:533-537); every lane tracks the count uniformly
+            WAVE_LDS_SYNC();
+        }
+    }
+    // the steal count: matches still standing = queries whose assign survived; recount exactly
+    __threadfence_block();
+    WAVE_LDS_SYNC();
+    if (J.check_ori) {
+        // filterMatchesWithOrientation (int flavour, :1615-1629): histogram over every accepted match, stolen ones included
+        int i1 = -1, i2 = -1, i3 = -1, max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < 30; ++i) {
+            const int sz = s_hist[i];
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; i3 = i2; i2 = i1; i1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; i3 = i2; i2 = i; }
+            else if (sz > max3) { max3 = sz; i3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { i3 = -1; }
+        for (int i = lane; i < nori; i += 64) {
+            const int b = J.orilist[2 * i + 1];
+            if (b != i1 && b != i2 && b != i3) J.assign[J.orilist[2 * i]] = -1;
+        }
+        __threadfence_block();
+        WAVE_LDS_SYNC();
+    }
+    int cnt = 0;
+    for (int q = lane; q < J.nq; q += 64) cnt += J.assign[q] >= 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (lane == 0) *J.nmatches = cnt;
+    (void)nm;
+}
+
+__global__ __launch_bounds__(64) void k_match_init(const DevProjJob *__restrict__ jobs) {
+    const DevProjJob J = jobs[blockIdx.x];
+    if (J.words == 8) init_job<8>(J);
+    else init_job<16>(J);
+}
+
+extern "C" void afv_launch_match_init(const DevProjJob *jobs, int njobs, hipStream_t stream) {
+    hipLaunchKernelGGL(k_match_init, dim3(njobs), dim3(64), 0, stream, jobs);
 }
 
 extern "C" void afv_launch_match_fuse(const DevProjJob *jobs, int njobs, hipStream_t stream) {

@@ -214,27 +214,75 @@ class FeatureMatcher:
         self.ctx.check(self.lib.afv_match_fuse(self.ctx.handle, jobs, 1, ptr(out), ptr(nm)), "afv_match_fuse")
         return out[:queries.n].copy(), int(nm[0])
 
-    def SearchByProjection(self, F, queries, last_frame=False):
-        """matching core of SearchByProjection(F, vpMapPoints, radiusTh) (FeatureMatcher.cc:73-154) or, with
-        last_frame=True, of SearchByProjection(CurrentFrame, LastFrame, ...) (:1291-1402, mono).  Returns
-        (assign[F.N] = query index now stored in F.pts[i] | -1, nmatches)."""
-        j = ProjJob()
-        j.desc = ptr(F.descriptors); j.n = F.N; j.desc_bytes = F.descriptors.shape[1] if F.N else 32
-        j.x = ptr(F.x); j.y = ptr(F.y); j.size = ptr(F.sizes); j.angle = ptr(F.angles); j.occupied = ptr(F.occupied)
-        j.min_x = float(F.min_x); j.min_y = float(F.min_y); j.grid_inv_w = float(F.grid_inv_w); j.grid_inv_h = float(F.grid_inv_h)
-        j.grid_cols = F.grid_cols; j.grid_rows = F.grid_rows
-        j.nq = queries.n; j.qdesc = ptr(queries.descriptors); j.qvalid = ptr(queries.valid)
-        j.qu = ptr(queries.u); j.qv = ptr(queries.v); j.qr = ptr(queries.r)
-        j.qmin_size = ptr(queries.min_size); j.qmax_size = ptr(queries.max_size)
-        j.qangle = ptr(queries.angles); j.qoccupies = ptr(queries.occupies)
-        j.th_high = self.TH_HIGH; j.nnratio = self.mfNNratio
-        j.size_tol = float(F.sizeTolerance); j.inv_size_tol = float(F.invSizeTolerance)
-        j.check_orientation = int(self.mbCheckOrientation); j.mode = _lib.PROJ_LASTFRAME if last_frame else _lib.PROJ_LOCALMAP
+    def _run_projection(self, F, queries, th, mode, check_orientation):
+        j = self._proj_job(F, queries)
+        j.th_high = float(th)
+        j.check_orientation = int(bool(check_orientation)); j.mode = mode
         out = np.full(max(F.N, 1), -1, np.int32)
         nm = np.zeros(1, np.int32)
         jobs = (ProjJob * 1)(j)
         self.ctx.check(self.lib.afv_match_projection(self.ctx.handle, jobs, 1, ptr(out), ptr(nm)), "afv_match_projection")
         return out[:F.N].copy(), int(nm[0])
+
+    def SearchByProjection(self, F, queries, last_frame=False):
+        """matching core of SearchByProjection(F, vpMapPoints, radiusTh) (FeatureMatcher.cc:73-154) or, with
+        last_frame=True, of SearchByProjection(CurrentFrame, LastFrame, ...) (:1291-1402, mono).  Returns
+        (assign[F.N] = query index now stored in F.pts[i] | -1, nmatches)."""
+        return self._run_projection(F, queries, self.TH_HIGH, _lib.PROJ_LASTFRAME if last_frame else _lib.PROJ_LOCALMAP,
+                                    self.mbCheckOrientation)
+
+    def SearchByProjection_reloc(self, CurrentFrame, queries, useHighMatchingThreshold=False):
+        """matching core of SearchByProjection(CurrentFrame, pKF, sAlreadyFound, radiusTh, useHigh) (FeatureMatcher.cc:1404-1506):
+        queries = pKF's map points in keyframe feature order (valid = good, not in sAlreadyFound, projects inside the image
+        and the distance band; angles = pKF->mvKeysUn[i].angle); CurrentFrame.occupied = pts[i] != NULL."""
+        th = self.descDistTh_high_reloc if useHighMatchingThreshold else self.descDistTh_low_reloc
+        return self._run_projection(CurrentFrame, queries, th, _lib.PROJ_LASTFRAME, self.mbCheckOrientation)
+
+    def SearchByProjection_sim3(self, pKF, queries):
+        """matching core of SearchByProjection(pKF, Scw, vpPoints, vpMatched, radiusTh) (FeatureMatcher.cc:287-397):
+        pKF.occupied = vpMatched[i] != NULL; size band = predictedSize / , * sizeTolerance (:365-367); no orientation check;
+        accept bestDist <= TH_LOW (:380).  assign[i] = index into vpPoints now stored in vpMatched[i]."""
+        return self._run_projection(pKF, queries, self.TH_LOW, _lib.PROJ_LASTFRAME, False)
+
+    def Fuse_sim3(self, pKF, queries):
+        """matching core of Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (FeatureMatcher.cc:942-1064): as Fuse without the
+        reprojection gate."""
+        j = self._proj_job(pKF, queries)
+        j.inf = None
+        j.th_high = self.TH_LOW
+        out = np.full(max(queries.n, 1), -1, np.int32)
+        nm = np.zeros(1, np.int32)
+        jobs = (ProjJob * 1)(j)
+        self.ctx.check(self.lib.afv_match_fuse(self.ctx.handle, jobs, 1, ptr(out), ptr(nm)), "afv_match_fuse")
+        return out[:queries.n].copy(), int(nm[0])
+
+    def SearchBySim3(self, pKF1, queries1, pKF2, queries2):
+        """SearchBySim3 (FeatureMatcher.cc:1066-1287): queries1 = KF1's map points (one per KF1 feature) projected into KF2,
+        queries2 the reverse.  Returns (match12[N1] = KF2 feature index | -1, nFound)."""
+        j12 = self._proj_job(pKF2, queries1); j21 = self._proj_job(pKF1, queries2)
+        j12.th_high = j21.th_high = self.TH_HIGH
+        out = np.full(max(queries1.n, 1), -1, np.int32)
+        nm = np.zeros(1, np.int32)
+        self.ctx.check(self.lib.afv_match_sim3(self.ctx.handle, C.byref(j12), C.byref(j21), ptr(out), ptr(nm)), "afv_match_sim3")
+        return out[:queries1.n].copy(), int(nm[0])
+
+    def SearchForInitialization(self, F1_queries, F2, vbPrevMatched=None):
+        """SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (FeatureMatcher.cc:399-557).
+        F1_queries: ProjectionQueries over F1's features (valid = octave 0, u/v = vbPrevMatched, r = windowSize,
+        min_size = 0, max_size = F1.maxKeyPtSize, angles).  Returns (vnMatches12, nMatches) and, when vbPrevMatched (N1 x 2)
+        is given, refreshes it in place like :551-553."""
+        j = self._proj_job(F2, F1_queries)
+        j.th_high = self.TH_LOW
+        j.check_orientation = int(self.mbCheckOrientation)
+        out = np.full(max(F1_queries.n, 1), -1, np.int32)
+        nm = np.zeros(1, np.int32)
+        jobs = (ProjJob * 1)(j)
+        self.ctx.check(self.lib.afv_match_initialization(self.ctx.handle, jobs, 1, ptr(out), ptr(nm)), "afv_match_initialization")
+        out = out[:F1_queries.n].copy()
+        if vbPrevMatched is not None:
+            m = out >= 0
+            vbPrevMatched[m, 0] = F2.x[out[m]]; vbPrevMatched[m, 1] = F2.y[out[m]]
+        return out, int(nm[0])
 
     def match_l2(self, desc1, desc2, th_low, nnratio=None, valid1=None, valid2=None):
         """float descriptors (SIFT128 ...): brute force with SearchByBoW(KF,KF) control flow, distance =

@@ -171,6 +171,28 @@ int afv_match_projection(afv_ctx *ctx, const afv_proj_job *jobs, int njobs, int3
  * reprojection gate e2 * inf <= 5.99 (:897); th_high carries TH_LOW (:915).  Map points are independent here; the map surgery
  * (:918-936) stays with the caller.  best = concatenation over jobs of int32[nq] (feature index or -1); nfound[njobs]. */
 int afv_match_fuse(afv_ctx *ctx, const afv_proj_job *jobs, int njobs, int32_t *best, int32_t *nfound);
+/* inf == NULL in a job drops the reprojection gate: that is the matching core of Fuse(pKF, Scw, vpPoints, th, vpReplacePoint)
+ * (src/FeatureMatcher.cc:942-1064).  The remaining SearchByProjection flavours need no extra entry point:
+ *   - SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (:287-397): afv_match_projection, mode AFV_PROJ_LASTFRAME,
+ *     check_orientation 0, occupied = vpMatched[i] != NULL, qmin/qmax = predictedSize / , * sizeTolerance, th_high = TH_LOW;
+ *   - SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, useHigh) (:1404-1506, relocalisation): the same mode with
+ *     check_orientation = mbCheckOrientation, qangle = pKF->mvKeysUn[i].angle, occupied = CurrentFrame.pts[i] != NULL,
+ *     th_high = descDistTh_{low,high}_reloc. */
+
+/* SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (src/FeatureMatcher.cc:1066-1287): j12 = map points of KF1
+ * (query q = KF1 feature index; q_valid = has a good, not already matched map point that projects into KF2) searched among
+ * KF2's features, j21 the reverse; both are gate-less best-only searches with th_high = TH_HIGH (:1171, :1254); the
+ * agreement check (:1268-1284) runs here too.  Requires j12->nq == j21->n and j21->nq == j12->n.
+ * match12[j12->nq] = KF2 feature index or -1. */
+int afv_match_sim3(afv_ctx *ctx, const afv_proj_job *j12, const afv_proj_job *j21, int32_t *match12, int32_t *nfound);
+
+/* SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (src/FeatureMatcher.cc:399-557; active code
+ * :480-556): queries = F1's features (q_valid = octave 0, q_u/q_v = vbPrevMatched, q_radius = windowSize,
+ * q_size_min = 0, q_size_max = F1.maxKeyPtSize, q_angle = F1 keypoint angle), features = F2 with its grid, th_high = TH_LOW,
+ * nnratio, check_orientation.  Ordered: a feature already matched at a distance <= the current one is skipped (:513) and a
+ * later query steals it otherwise (:531-535).  match12 = concatenation over jobs of int32[nq]; the caller refreshes
+ * vbPrevMatched (:551-553). */
+int afv_match_initialization(afv_ctx *ctx, const afv_proj_job *jobs, int njobs, int32_t *match12, int32_t *nmatches);
 
 /* ---- BoW quantisation ----
  * DBoW2 TemplatedVocabulary::transform(features, BowVector, FeatureVector, levelsup) as called by Vocabulary::transform

@@ -1269,7 +1269,7 @@ int afvo_match_fuse(const afvo_proj_job *j, int32_t *best_out) {
                     if ((sz < min_size) || (sz > max_size)) continue;             /* :871-873 */
                     const float ex = u - j->x[idx], ey = v - j->y[idx];
                     const float e2 = ex * ex + ey * ey;
-                    if (e2 * j->inf[idx] > 5.99) continue;                        /* :897-898 (float product vs double) */
+                    if (j->inf && e2 * j->inf[idx] > 5.99) continue;              /* :897-898 (float product vs double); no gate in Fuse(Sim3) / SearchBySim3 */
                     const u8 *a = j->qdesc + (size_t)q * j->desc_bytes, *b = j->desc + (size_t)idx * j->desc_bytes;
                     const float d = (float)(j->desc_bytes == 32 ? afvo_hamming256(a, b) : afvo_hamming_bytes(a, b, j->desc_bytes));
                     if (d < best) { best = d; best_idx = idx; }
@@ -1282,6 +1282,90 @@ int afvo_match_fuse(const afvo_proj_job *j, int32_t *best_out) {
     }
     free(g.cell_ptr); free(g.cell_idx);
     return nfound;
+}
+
+/* SearchBySim3 (FeatureMatcher.cc:1066-1287): both directed searches are the gate-less fuse core with TH_HIGH, then the
+ * agreement check (:1268-1284).  j12: queries = KF1 features (their map points) searched in KF2; j21 the other way. */
+int afvo_match_sim3(const afvo_proj_job *j12, const afvo_proj_job *j21, int32_t *match12) {
+    int32_t *m1 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(j12->nq + 1)), *m2 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(j21->nq + 1));
+    afvo_match_fuse(j12, m1);
+    afvo_match_fuse(j21, m2);
+    int nfound = 0;
+    for (int i1 = 0; i1 < j12->nq; ++i1) {
+        match12[i1] = -1;
+        const int idx2 = m1[i1];
+        if (idx2 >= 0 && idx2 < j21->nq && m2[idx2] == i1) { match12[i1] = idx2; nfound++; }
+    }
+    free(m1); free(m2);
+    return nfound;
+}
+
+/* SearchForInitialization (FeatureMatcher.cc:399-557, active code :480-556).  queries = F1 features (qvalid = octave 0,
+ * qu/qv = vbPrevMatched, qr = windowSize, size band [0, F1.maxKeyPtSize]); features = F2 with its grid; th_high carries
+ * TH_LOW.  match12[q] = F2 index or -1. */
+int afvo_match_initialization(const afvo_proj_job *j, int32_t *match12) {
+    proj_grid g;
+    build_grid(j, &g);
+    float *mdist = (float *)malloc(sizeof(float) * (size_t)(j->n + 1));
+    int *m21 = (int *)malloc(sizeof(int) * (size_t)(j->n + 1));
+    for (int i = 0; i < j->n; ++i) { mdist[i] = FLT_MAX; m21[i] = -1; }
+    for (int q = 0; q < j->nq; ++q) match12[q] = -1;
+    int nmatches = 0;
+    int hist[30]; memset(hist, 0, sizeof hist);
+    int *oq = (int *)malloc(sizeof(int) * (size_t)(2 * j->nq + 2)), *obin = oq + j->nq + 1, on = 0;
+    for (int q = 0; q < j->nq; ++q) {
+        if (j->qvalid && !j->qvalid[q]) continue;                                  /* :489-491 */
+        const float x = j->qu[q], y = j->qv[q], r = j->qr[q], min_size = j->qmin_size[q], max_size = j->qmax_size[q];
+        const int min_cx = imax(0, (int)floorf((x - j->min_x - r) * j->grid_inv_w));
+        if (min_cx >= j->grid_cols) continue;
+        const int max_cx = imin(j->grid_cols - 1, (int)ceilf((x - j->min_x + r) * j->grid_inv_w));
+        if (max_cx < 0) continue;
+        const int min_cy = imax(0, (int)floorf((y - j->min_y - r) * j->grid_inv_h));
+        if (min_cy >= j->grid_rows) continue;
+        const int max_cy = imin(j->grid_rows - 1, (int)ceilf((y - j->min_y + r) * j->grid_inv_h));
+        if (max_cy < 0) continue;
+        float best = FLT_MAX, best2 = FLT_MAX;
+        int best_idx = -1;
+        for (int ix = min_cx; ix <= max_cx; ++ix)
+            for (int iy = min_cy; iy <= max_cy; ++iy) {
+                const int c = ix * j->grid_rows + iy;
+                for (int k = g.cell_ptr[c]; k < g.cell_ptr[c + 1]; ++k) {
+                    const int idx = g.cell_idx[k];
+                    if (j->size[idx] < min_size) continue;
+                    if (j->size[idx] > max_size) continue;
+                    const float dx = j->x[idx] - x, dy = j->y[idx] - y;
+                    if (!(fabsf(dx) < r && fabsf(dy) < r)) continue;
+                    const u8 *a = j->qdesc + (size_t)q * j->desc_bytes, *b = j->desc + (size_t)idx * j->desc_bytes;
+                    const float d = (float)(j->desc_bytes == 32 ? afvo_hamming256(a, b) : afvo_hamming_bytes(a, b, j->desc_bytes));
+                    if (mdist[idx] <= d) continue;                                 /* :513-514 */
+                    if (d < best) { best2 = best; best = d; best_idx = idx; }
+                    else if (d < best2) best2 = d;
+                }
+            }
+        if (best <= j->th_high) {                                                  /* :527 */
+            if ((float)best < (float)best2 * j->nnratio) {                         /* :529 */
+                if (m21[best_idx] >= 0) { match12[m21[best_idx]] = -1; nmatches--; }
+                match12[q] = best_idx;
+                m21[best_idx] = q;
+                mdist[best_idx] = best;
+                nmatches++;
+                if (j->check_orientation) {
+                    const int bin = afvo_rotation_bin(j->qangle[q], j->angle[best_idx]);
+                    oq[on] = q; obin[on] = bin; on++; hist[bin]++;
+                }
+            }
+        }
+    }
+    if (j->check_orientation) {                                                    /* :1615-1629, int flavour */
+        int i1, i2, i3;
+        afvo_three_maxima(hist, 30, &i1, &i2, &i3);
+        for (int e = 0; e < on; ++e) {
+            if (obin[e] == i1 || obin[e] == i2 || obin[e] == i3) continue;
+            if (match12[oq[e]] >= 0) { nmatches--; match12[oq[e]] = -1; }
+        }
+    }
+    free(oq); free(mdist); free(m21); free(g.cell_ptr); free(g.cell_idx);
+    return nmatches;
 }
 
 /* ------------------------------------------------------------------------------------------------

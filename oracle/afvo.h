@@ -170,7 +170,11 @@ int afvo_match_projection(const afvo_proj_job *j, int32_t *assign /* [n]: query 
 /* matching core of FeatureMatcher::Fuse(pKF, vpMapPoints, th) (FeatureMatcher.cc:794-940, mono): per map point the most
  * similar keypoint in the window that lies in the predicted size band and passes the 5.99 reprojection gate; best[q] = feature
  * index or -1 (bestDist > TH_LOW).  Independent per point: the map surgery (:918-936) stays with the caller.  returns #found */
-int afvo_match_fuse(const afvo_proj_job *j, int32_t *best /* [nq] */);
+int afvo_match_fuse(const afvo_proj_job *j, int32_t *best /* [nq] */);   /* inf == NULL: no gate = Fuse(Sim3) core (:942-1064) */
+/* SearchBySim3 (FeatureMatcher.cc:1066-1287): two gate-less directed searches + agreement; match12[j12->nq] */
+int afvo_match_sim3(const afvo_proj_job *j12, const afvo_proj_job *j21, int32_t *match12);
+/* SearchForInitialization (FeatureMatcher.cc:480-556): ordered, with distance-gated skipping and stealing; match12[nq] */
+int afvo_match_initialization(const afvo_proj_job *j, int32_t *match12);
 
 /* ---- BoW quantisation (DBoW2 TemplatedVocabulary::transform(features, v, fv, levelsup), called from
  * Vocabulary.cpp:156-206 with levelsup = 4).  DBoW2 is an empty submodule: restated from upstream DBoW2 (parity unpinned).

@@ -410,8 +410,7 @@ def three_maxima(sizes):
     return i1.value, i2.value, i3.value
 
 
-def match_projection(F, Q, th_high=75.0, nnratio=0.8, check_orientation=False, last_frame=False, fuse=False):
-    """F / Q: objects with the attributes of anyfeature-vslam_amd's FrameGridView / ProjectionQueries"""
+def _proj_job(F, Q, th_high, nnratio, check_orientation, last_frame):
     j = ProjJob()
     j.desc = _p(F.descriptors); j.n = F.N; j.desc_bytes = F.descriptors.shape[1] if F.N else 32
     j.x = _p(F.x); j.y = _p(F.y); j.size = _p(F.sizes); j.angle = _p(F.angles); j.occupied = _p(F.occupied)
@@ -423,6 +422,12 @@ def match_projection(F, Q, th_high=75.0, nnratio=0.8, check_orientation=False, l
     j.qangle = _p(Q.angles); j.qoccupies = _p(Q.occupies)
     j.th_high = th_high; j.nnratio = nnratio; j.size_tol = float(F.sizeTolerance); j.inv_size_tol = float(F.invSizeTolerance)
     j.check_orientation = int(bool(check_orientation)); j.mode = 1 if last_frame else 0
+    return j
+
+
+def match_projection(F, Q, th_high=75.0, nnratio=0.8, check_orientation=False, last_frame=False, fuse=False):
+    """F / Q: objects with the attributes of anyfeature-vslam_amd's FrameGridView / ProjectionQueries"""
+    j = _proj_job(F, Q, th_high, nnratio, check_orientation, last_frame)
     if fuse:
         out = np.zeros(max(Q.n, 1), np.int32)
         nm = lib().afvo_match_fuse(C.byref(j), _p(out))
@@ -448,3 +453,17 @@ def bow_transform(vocab, desc, levelsup=4):
     leaf = np.zeros(max(len(desc), 1), np.int32); nid = np.zeros(max(len(desc), 1), np.int32)
     lib().afvo_bow_transform(C.byref(v), _p(desc), len(desc), int(levelsup), _p(leaf), _p(nid))
     return leaf[:len(desc)].copy(), nid[:len(desc)].copy()
+
+
+def match_initialization(F2, Q1, th_low=75.0, nnratio=0.9, check_orientation=True):
+    j = _proj_job(F2, Q1, th_low, nnratio, check_orientation, False)
+    out = np.zeros(max(Q1.n, 1), np.int32)
+    nm = lib().afvo_match_initialization(C.byref(j), _p(out))
+    return out[:Q1.n].copy(), nm
+
+
+def match_sim3(F2, Q1, F1, Q2, th_high=75.0):
+    j12 = _proj_job(F2, Q1, th_high, 1.0, False, False); j21 = _proj_job(F1, Q2, th_high, 1.0, False, False)
+    out = np.zeros(max(Q1.n, 1), np.int32)
+    nm = lib().afvo_match_sim3(C.byref(j12), C.byref(j21), _p(out))
+    return out[:Q1.n].copy(), nm

@@ -107,3 +107,100 @@ def test_fuse_core(afv, oracle, gpu_ctx, seed, shift, rs):
     want, wn = oracle.match_projection(F, Q, th_high=75.0, fuse=True)
     assert n == wn and np.array_equal(got, want)
     assert 50 < wn < Q.n  # the gate and the threshold both bite
+
+
+# ---- the remaining rank-1 searches: relocalisation / Sim3 projection, Fuse(Sim3), SearchBySim3, SearchForInitialization ----
+@pytest.mark.parametrize("use_high", [False, True])
+def test_relocalisation_and_sim3_projection(afv, oracle, gpu_ctx, use_high):
+    F, Q = _scene(afv, gpu_ctx, 21, 5, 30.0)
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(60.0)
+    m = afv.FeatureMatcher(0.9, True, ctx=gpu_ctx)
+    afv.FeatureMatcher.descDistTh_high_reloc = 90.0
+    th = 90.0 if use_high else 60.0
+    got, n = m.SearchByProjection_reloc(F, Q, useHighMatchingThreshold=use_high)
+    want, wn = oracle.match_projection(F, Q, th_high=th, nnratio=0.9, check_orientation=True, last_frame=True)
+    assert n == wn and np.array_equal(got, want) and wn > 100
+    got, n = m.SearchByProjection_sim3(F, Q)
+    want, wn = oracle.match_projection(F, Q, th_high=60.0, nnratio=0.9, check_orientation=False, last_frame=True)
+    assert n == wn and np.array_equal(got, want) and wn > 100
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+
+
+def test_fuse_sim3_core(afv, oracle, gpu_ctx):
+    F, Q = _scene(afv, gpu_ctx, 22, 4, 25.0)
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+    m = afv.FeatureMatcher(0.8, True, ctx=gpu_ctx)
+    got, n = m.Fuse_sim3(F, Q)
+    F.inf = None
+    want, wn = oracle.match_projection(F, Q, th_high=75.0, fuse=True)
+    assert n == wn and np.array_equal(got, want) and wn > 300
+
+
+def test_search_by_sim3(afv, oracle, gpu_ctx):
+    s = afv.synth
+    img = s.corners_frame(23)
+    k1, d1 = gpu_ctx.extract(img)
+    k2, d2 = gpu_ctx.extract(np.roll(img, 6, axis=1))
+    z1, _, _ = gpu_ctx.size_sigma(k1); z2, _, _ = gpu_ctx.size_sigma(k2)
+    F1 = afv.FrameGridView(d1, np.stack([k1["x"], k1["y"]], 1), z1)
+    F2 = afv.FrameGridView(d2, np.stack([k2["x"], k2["y"]], 1), z2)
+    jit = lambda seed, n: (s.lcg_states(seed, n) % 7).astype(np.float32) - 3
+    v1 = (s.lcg_bytes(31, len(k1)) > 40).astype(np.uint8); v2 = (s.lcg_bytes(32, len(k2)) > 40).astype(np.uint8)
+    Q1 = afv.ProjectionQueries(d1, k1["x"] + 6 + jit(33, len(k1)), k1["y"] + jit(34, len(k1)), 12.0 * z1, z1 / np.float32(1.2),
+                               z1 * np.float32(1.2), valid=v1)
+    Q2 = afv.ProjectionQueries(d2, k2["x"] - 6 + jit(35, len(k2)), k2["y"] + jit(36, len(k2)), 12.0 * z2, z2 / np.float32(1.2),
+                               z2 * np.float32(1.2), valid=v2)
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+    m = afv.FeatureMatcher(0.8, True, ctx=gpu_ctx)
+    got, n = m.SearchBySim3(F1, Q1, F2, Q2)
+    want, wn = oracle.match_sim3(F2, Q1, F1, Q2, th_high=75.0)
+    assert n == wn and np.array_equal(got, want) and wn > 200
+    assert np.all(got[v1 == 0] == -1)
+
+
+@pytest.mark.parametrize("ori", [False, True])
+@pytest.mark.parametrize("seed,shift,window", [(24, 6, 100.0), (25, 30, 40.0), (26, 0, 12.0)])
+def test_search_for_initialization(afv, oracle, gpu_ctx, seed, shift, window, ori):
+    s = afv.synth
+    ctx2k = afv.Context(nfeatures=2000)
+    img = s.corners_frame(seed)
+    k1, d1 = ctx2k.extract(img)
+    k2, d2 = ctx2k.extract(np.roll(img, shift, axis=1))
+    z1, _, _ = ctx2k.size_sigma(k1); z2, _, _ = ctx2k.size_sigma(k2)
+    F2 = afv.FrameGridView(d2, np.stack([k2["x"], k2["y"]], 1), z2, angles=k2["angle"])
+    prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)          # vbPrevMatched starts as F1's own keypoints
+    n1 = len(k1)
+    Q1 = afv.ProjectionQueries(d1, prev[:, 0].copy(), prev[:, 1].copy(), np.full(n1, window, np.float32), np.zeros(n1, np.float32),
+                               np.full(n1, z1.max(), np.float32), valid=(k1["octave"] == 0).astype(np.uint8), angles=k1["angle"])
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+    m = afv.FeatureMatcher(0.9, ori, ctx=gpu_ctx)
+    got, n = m.SearchForInitialization(Q1, F2, vbPrevMatched=prev)
+    want, wn = oracle.match_initialization(F2, Q1, th_low=75.0, nnratio=0.9, check_orientation=ori)
+    assert n == wn and np.array_equal(got, want)
+    assert np.all(got[k1["octave"] != 0] == -1)
+    if shift <= window:
+        assert wn > 50
+    mt = got >= 0
+    assert np.array_equal(prev[mt, 0], F2.x[got[mt]]) and np.array_equal(prev[mt, 1], F2.y[got[mt]])
+    # matches are one-to-one (stealing keeps vnMatches21 consistent)
+    assert len(np.unique(got[mt])) == mt.sum()
+    ctx2k.close()
+
+
+def test_initialization_stealing_hand_case(afv, oracle, gpu_ctx):
+    """three F1 features aim at the same F2 feature with decreasing distance: each later one steals it (:531-535); a fourth at
+    a larger distance is skipped by the vMatchedDistance gate (:513) and falls back to its own second candidate."""
+    d2 = np.zeros((2, 32), np.uint8); d2[1] = 0xFF
+    F2 = afv.FrameGridView(d2, [[100.0, 100.0], [104.0, 100.0]], [1.0, 1.0], angles=[0.0, 0.0])
+    d1 = np.zeros((4, 32), np.uint8)
+    d1[0, :3] = 0xFF      # 24 bits from feature 0
+    d1[1, :2] = 0xFF      # 16
+    d1[2, :1] = 0xFF      # 8
+    d1[3, :26] = 0xFF     # 208 from feature 0, 48 from feature 1 (gate hides feature 0 -> best = feature 1 alone)
+    Q1 = afv.ProjectionQueries(d1, [100.0] * 4, [100.0] * 4, [20.0] * 4, [0.0] * 4, [10.0] * 4, valid=[1] * 4, angles=[0.0] * 4)
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+    m = afv.FeatureMatcher(0.9, False, ctx=gpu_ctx)
+    got, n = m.SearchForInitialization(Q1, F2)
+    want, wn = oracle.match_initialization(F2, Q1, th_low=75.0, nnratio=0.9, check_orientation=False)
+    assert want.tolist() == [-1, -1, 0, 1] and wn == 2
+    assert got.tolist() == want.tolist() and n == wn
