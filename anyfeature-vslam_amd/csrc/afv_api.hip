@@ -65,6 +65,10 @@ struct DevProjJob {
 };
 extern "C" void afv_launch_match_projection(const DevProjJob *jobs, int njobs, hipStream_t stream);
 extern "C" void afv_launch_match_fuse(const DevProjJob *jobs, int njobs, hipStream_t stream);
+extern "C" size_t afv_match_l2_scratch_bytes(int n1, int n2, int *ntiles_out, int *cols_per_tile_out);
+extern "C" int afv_launch_match_l2_tiled(const float *d1, int n1, const float *d2, int n2, int dim, const uint8_t *v1, const uint8_t *v2,
+                                         float th, float ratio, int *out, int *nmatches, void *scratch, int ntiles, int cols_per_tile,
+                                         hipStream_t stream);
 extern "C" void afv_launch_match_init(const DevProjJob *jobs, int njobs, hipStream_t stream);
 
 struct DevVocab {
@@ -1084,13 +1088,18 @@ extern "C" int afv_match_l2(afv_ctx *c, const float *desc1, int n1, const float 
     Blob b;
     const size_t o1 = b.put(desc1, (size_t)n1 * dim * 4), o2 = b.put(desc2, (size_t)n2 * dim * 4);
     const size_t ov1 = valid1 ? b.put(valid1, (size_t)n1) : 0, ov2 = valid2 ? b.put(valid2, (size_t)n2) : 0;
+    const size_t in_bytes = b.h.size();
     const size_t oo = b.reserve((size_t)std::max(n1, 1) * 4), on = b.reserve(4);
+    int ntiles = 1, cols_per_tile = 32;
+    const size_t ok = b.reserve(afv_match_l2_scratch_bytes(n1, n2, &ntiles, &cols_per_tile));
     const int rc = ensure_match_buffer(c, b.h.size());
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->d_match, b.h.data(), b.h.size(), hipMemcpyHostToDevice, c->stream));
-    afv_launch_match_l2(reinterpret_cast<const float *>(c->d_match + o1), n1, reinterpret_cast<const float *>(c->d_match + o2), n2,
-                        dim, valid1 ? c->d_match + ov1 : nullptr, valid2 ? c->d_match + ov2 : nullptr, th_low, nnratio,
-                        reinterpret_cast<int *>(c->d_match + oo), reinterpret_cast<int *>(c->d_match + on), c->stream);
+    HIPCHK(c, hipMemcpyAsync(c->d_match, b.h.data(), in_bytes, hipMemcpyHostToDevice, c->stream));
+    const float *p1 = reinterpret_cast<const float *>(c->d_match + o1), *p2 = reinterpret_cast<const float *>(c->d_match + o2);
+    const uint8_t *pv1 = valid1 ? c->d_match + ov1 : nullptr, *pv2 = valid2 ? c->d_match + ov2 : nullptr;
+    int *pout = reinterpret_cast<int *>(c->d_match + oo), *pn = reinterpret_cast<int *>(c->d_match + on);
+    if (!afv_launch_match_l2_tiled(p1, n1, p2, n2, dim, pv1, pv2, th_low, nnratio, pout, pn, c->d_match + ok, ntiles, cols_per_tile, c->stream))
+        afv_launch_match_l2(p1, n1, p2, n2, dim, pv1, pv2, th_low, nnratio, pout, pn, c->stream);
     HIPCHK(c, hipGetLastError());
     if (n1) HIPCHK(c, hipMemcpyAsync(match12, c->d_match + oo, (size_t)n1 * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(nmatches, c->d_match + on, 4, hipMemcpyDeviceToHost, c->stream));

@@ -165,6 +165,47 @@ def test_l2_float_descriptors(afv, oracle, matcher):
     assert gn == wn and np.array_equal(got, want) and wn > 100
 
 
+def _sift_like(s, seed, n, dim, noise_div):
+    a = (s.lcg_bytes(seed, n * dim).reshape(n, dim).astype(np.float32)) ** 2
+    a /= np.linalg.norm(a, axis=1, keepdims=True)
+    noise = (s.lcg_bytes(seed + 1, n * dim).reshape(n, dim).astype(np.float32) - 128) / noise_div
+    b = np.abs(a + noise).astype(np.float32)
+    b /= np.linalg.norm(b, axis=1, keepdims=True)
+    perm = np.argsort(s.lcg_states(seed + 2, n), kind="stable")
+    return a, b[perm].copy()
+
+
+@pytest.mark.parametrize("n1,n2,dim,ratio,noise", [(1000, 1000, 128, 0.8, 2000.0), (1000, 1000, 128, 0.95, 600.0), (333, 1500, 64, 0.9, 1500.0),
+                                                   (70, 20, 128, 0.9, 2000.0), (257, 300, 100, 0.8, 2000.0), (5, 3, 128, 1.5, 2000.0)])
+def test_l2_tiled_matcher(afv, oracle, matcher, n1, n2, dim, ratio, noise):
+    """config #3 at full size (1000 x 1000 x 128) and ragged shapes; dim 100 takes the generic kernel.  Validity masks on both
+    sides; the noisy / high-ratio case forces conflicts and exact rescans in the ordered phase."""
+    s = afv.synth
+    n = max(n1, n2)
+    a, b = _sift_like(s, 200 + n1 + dim, n, dim, noise)
+    a, b = a[:n1].copy(), b[:n2].copy()
+    v1 = (s.lcg_bytes(5, n1) > 25).astype(np.uint8); v2 = (s.lcg_bytes(6, n2) > 25).astype(np.uint8)
+    got, gn = matcher.match_l2(a, b, 0.5, ratio, valid1=v1, valid2=v2)
+    want, wn = oracle.match_l2_bruteforce(a, b, 0.5, ratio, v1, v2)
+    assert gn == wn and np.array_equal(got, want)
+    if n1 >= 257:
+        assert wn > 10
+    got, gn = matcher.match_l2(a, b, 0.5, ratio)
+    want, wn = oracle.match_l2_bruteforce(a, b, 0.5, ratio)
+    assert gn == wn and np.array_equal(got, want)
+
+
+def test_l2_duplicate_columns_ties(afv, oracle, matcher):
+    """identical train descriptors: equal distances must resolve to the lowest column, and the duplicates make the ratio test
+    fail (best == second) until all but one copy are taken"""
+    s = afv.synth
+    a, b = _sift_like(s, 400, 128, 128, 3000.0)
+    b[1::2] = b[0::2]
+    got, gn = matcher.match_l2(a, b, 0.5, 1.01)
+    want, wn = oracle.match_l2_bruteforce(a, b, 0.5, 1.01)
+    assert gn == wn and np.array_equal(got, want) and wn > 20
+
+
 def test_akaze61_byte_hamming(afv, oracle, matcher):
     """61-byte descriptors (Feature_akaze61.cpp:75-77): rows are zero padded to 64 bytes on the device"""
     s = afv.synth
