@@ -127,19 +127,28 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="frames per GPU per step")
     ap.add_argument("--cpu-frames", type=int, default=256, help="frames in the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage hipEvents")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
+                                                      "multi-rank control flow on a 1-GPU box)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
     args = ap.parse_args()
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    if args.single_device:
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")   # where the two scalar reductions live
 
     afv = importlib.import_module("anyfeature-vslam_amd")
     B = args.batch
@@ -190,8 +199,8 @@ def main():
 
     kp_step = int(n_out.sum().item())
     nm_step = int(nmatch.sum().item())
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    k = torch.tensor([kp_step], dtype=torch.int64, device=dev)
+    t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    k = torch.tensor([kp_step], dtype=torch.int64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(k, op=dist.ReduceOp.SUM)
