@@ -63,13 +63,13 @@ struct DevProjJob {
     float th, ratio, tol, inv_tol; int check_ori, mode;
     unsigned long long *keys; int *ncand; int *orilist; int *assign; int *nmatches;
 };
-extern "C" void afv_launch_match_projection(const DevProjJob *jobs, int njobs, hipStream_t stream);
-extern "C" void afv_launch_match_fuse(const DevProjJob *jobs, int njobs, hipStream_t stream);
+extern "C" void afv_launch_match_projection(const DevProjJob *jobs, int njobs, int max_nq, hipStream_t stream);
+extern "C" void afv_launch_match_fuse(const DevProjJob *jobs, int njobs, int max_nq, hipStream_t stream);
 extern "C" size_t afv_match_l2_scratch_bytes(int n1, int n2, int *ntiles_out, int *cols_per_tile_out);
 extern "C" int afv_launch_match_l2_tiled(const float *d1, int n1, const float *d2, int n2, int dim, const uint8_t *v1, const uint8_t *v2,
                                          float th, float ratio, int *out, int *nmatches, void *scratch, int ntiles, int cols_per_tile,
                                          hipStream_t stream);
-extern "C" void afv_launch_match_init(const DevProjJob *jobs, int njobs, hipStream_t stream);
+extern "C" void afv_launch_match_init(const DevProjJob *jobs, int njobs, int max_nq, hipStream_t stream);
 
 struct DevVocab {
     int k, L, nnodes, words;
@@ -120,6 +120,9 @@ struct afv_ctx {
     // matcher staging (grow only)
     uint8_t *d_match = nullptr;
     size_t match_bytes = 0;
+    uint8_t *h_stage = nullptr;  // pinned host image of d_match (matcher staging both ways), grow-only
+    size_t stage_bytes = 0;
+    bool stage_pinned = false;
     void *d_topk = nullptr;  // [npairs][cap] int4: top-4 (distance, column) keys per row
     size_t topk_bytes = 0;
     // last extraction (debug getters)
@@ -350,6 +353,10 @@ extern "C" void afv_destroy(afv_ctx *c) {
                     c->d_n, c->d_status, c->d_match, c->d_topk};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (c->h_stage) {
+        if (c->stage_pinned) (void)hipHostFree(c->h_stage);
+        else std::free(c->h_stage);
+    }
     for (auto &v : c->prof_ev)
         for (hipEvent_t e : v) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -723,19 +730,83 @@ extern "C" int afv_debug_blur_level(afv_ctx *c, int frame, int level, uint8_t *o
     return AFV_OK;
 }
 
+// the C-ABI never throws: host allocation failures inside the matcher entry points become AFV_ENOMEM
+template <class F>
+static int guarded(afv_ctx *c, F &&f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        if (c) c->last_error = "out of host memory";
+        return AFV_ENOMEM;
+    } catch (...) {
+        if (c) c->last_error = "unexpected exception";
+        return AFV_EHIP;
+    }
+}
+
 // ---- matcher staging ----
-struct Blob {  // host image of the device staging buffer
-    std::vector<uint8_t> h;
+// Host image of the device staging buffer.  It lives in the context's pinned arena, so the one H2D copy of a call and the
+// D2H copies of its results are true async DMA transfers (no pageable bounce inside the runtime); results land at the same
+// offsets in the arena and are handed to the caller's arrays after the stream sync.
+struct HostImage {
+    afv_ctx *c;
+    size_t n = 0;
+    uint8_t *data() { return c->h_stage; }
+    size_t size() const { return n; }
+    void resize(size_t m, bool zero) {
+        if (m > c->stage_bytes) {
+            const size_t want = align_up(m + m / 2, 1 << 20);
+            uint8_t *np = nullptr;
+            bool pinned = hipHostMalloc(reinterpret_cast<void **>(&np), want, hipHostMallocDefault) == hipSuccess && np;
+            if (!pinned) {
+                (void)hipGetLastError();
+                np = static_cast<uint8_t *>(std::malloc(want));
+                if (!np) throw std::bad_alloc();
+            }
+            if (n) std::memcpy(np, c->h_stage, n);
+            if (c->h_stage) {
+                if (c->stage_pinned) (void)hipHostFree(c->h_stage);
+                else std::free(c->h_stage);
+            }
+            c->h_stage = np;
+            c->stage_bytes = want;
+            c->stage_pinned = pinned;
+        }
+        if (zero && m > n) std::memset(c->h_stage + n, 0, m - n);
+        n = m;
+    }
+};
+
+struct Blob {
+    HostImage h;
+    struct Pending { void *dst; size_t off, bytes; };
+    std::vector<Pending> pending;
+    explicit Blob(afv_ctx *c) : h{c} {}
     size_t put(const void *src, size_t bytes, size_t align = 16) {
         const size_t off = align_up(h.size(), align);
-        h.resize(off + bytes);
+        h.resize(off + bytes, src == nullptr);
         if (src && bytes) std::memcpy(h.data() + off, src, bytes);
         return off;
     }
-    size_t reserve(size_t bytes, size_t align = 16) {
+    size_t reserve(size_t bytes, size_t align = 16) {  // zero-filled (counters, histograms, padded rows rely on it)
         const size_t off = align_up(h.size(), align);
-        h.resize(off + bytes);
+        h.resize(off + bytes, true);
         return off;
+    }
+    size_t reserve_scratch(size_t bytes, size_t align = 16) {  // device-only scratch: never copied, never filled
+        const size_t off = align_up(h.size(), align);
+        h.resize(off + bytes, false);
+        return off;
+    }
+    // queue a device -> caller copy of [off, off + bytes): DMA into the arena now, memcpy to dst in finish()
+    hipError_t fetch(void *dst, size_t off, size_t bytes, hipStream_t s) {
+        if (!bytes) return hipSuccess;
+        pending.push_back(Pending{dst, off, bytes});
+        return hipMemcpyAsync(h.data() + off, h.c->d_match + off, bytes, hipMemcpyDeviceToHost, s);
+    }
+    void finish() {
+        for (const Pending &p : pending) std::memcpy(p.dst, h.data() + p.off, p.bytes);
+        pending.clear();
     }
 };
 
@@ -847,7 +918,7 @@ static void fill_dev_job(DevMatchJob &d, const afv_match_job &j, const JobOffset
     d.nmatches = reinterpret_cast<int *>(base + o.nm);
 }
 
-extern "C" int afv_match_bow(afv_ctx *c, const afv_match_job *jobs, int njobs, int32_t *out, int32_t *nmatches) {
+static int afv_match_bow_impl(afv_ctx *c, const afv_match_job *jobs, int njobs, int32_t *out, int32_t *nmatches) {
     if (!c || !jobs || njobs < 1 || !out || !nmatches) return AFV_EINVAL;
     for (int i = 0; i < njobs; ++i) {
         const int rc = validate_job(jobs[i], true);
@@ -867,7 +938,7 @@ extern "C" int afv_match_bow(afv_ctx *c, const afv_match_job *jobs, int njobs, i
             cap = std::max(cap, std::max(j.n1, j.n2));
         }
         if (eligible) {
-            Blob b;
+            Blob b(c);
             const int nsets = 2 * njobs;
             const size_t desc_off = b.reserve((size_t)nsets * cap * 32);
             const size_t n_off = b.reserve((size_t)nsets * 4);
@@ -892,7 +963,7 @@ extern "C" int afv_match_bow(afv_ctx *c, const afv_match_job *jobs, int njobs, i
                 }
             }
             const size_t match_off = b.reserve((size_t)njobs * cap * 4), nm_off = b.reserve((size_t)njobs * 4);
-            const size_t topk_off = b.reserve((size_t)njobs * cap * 16);
+            const size_t topk_off = b.reserve_scratch((size_t)njobs * cap * 16);
             int rc = ensure_match_buffer(c, b.h.size());
             if (rc) return rc;
             HIPCHK(c, hipMemcpyAsync(c->d_match, b.h.data(), match_off, hipMemcpyHostToDevice, c->stream));  // inputs only
@@ -912,19 +983,18 @@ extern "C" int afv_match_bow(afv_ctx *c, const afv_match_job *jobs, int njobs, i
                 i0 = i1;
             }
             HIPCHK(c, hipGetLastError());
-            std::vector<int32_t> m((size_t)njobs * cap);
-            HIPCHK(c, hipMemcpyAsync(m.data(), c->d_match + match_off, m.size() * 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(nmatches, c->d_match + nm_off, (size_t)njobs * 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
             size_t acc = 0;
             for (int i = 0; i < njobs; ++i) {
-                std::memcpy(out + acc, m.data() + (size_t)i * cap, (size_t)jobs[i].n1 * 4);
+                HIPCHK(c, b.fetch(out + acc, match_off + (size_t)i * cap * 4, (size_t)jobs[i].n1 * 4, c->stream));
                 acc += (size_t)jobs[i].n1;
             }
+            HIPCHK(c, b.fetch(nmatches, nm_off, (size_t)njobs * 4, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            b.finish();
             return AFV_OK;
         }
     }
-    Blob b;
+    Blob b(c);
     std::vector<JobOffsets> offs(njobs);
     for (int i = 0; i < njobs; ++i) stage_job(b, jobs[i], false, offs[i]);
     size_t total_out = 0;
@@ -975,13 +1045,17 @@ extern "C" int afv_match_bow(afv_ctx *c, const afv_match_job *jobs, int njobs, i
     else
         afv_launch_match_bow(reinterpret_cast<const DevMatchJob *>(c->d_match + jobs_off), njobs, c->stream);
     HIPCHK(c, hipGetLastError());
-    if (total_out) HIPCHK(c, hipMemcpyAsync(out, c->d_match + out_off, total_out * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(nmatches, c->d_match + nm_off, (size_t)njobs * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, b.fetch(out, out_off, total_out * 4, c->stream));
+    HIPCHK(c, b.fetch(nmatches, nm_off, (size_t)njobs * 4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    b.finish();
     return AFV_OK;
 }
+extern "C" int afv_match_bow(afv_ctx *c, const afv_match_job *jobs, int njobs, int32_t *out, int32_t *nmatches) {
+    return guarded(c, [&] { return afv_match_bow_impl(c, jobs, njobs, out, nmatches); });
+}
 
-extern "C" int afv_match_triangulation(afv_ctx *c, const afv_tri_job *jobs, int njobs, int32_t *match12, int32_t *nmatches) {
+static int afv_match_triangulation_impl(afv_ctx *c, const afv_tri_job *jobs, int njobs, int32_t *match12, int32_t *nmatches) {
     if (!c || !jobs || njobs < 1 || !match12 || !nmatches) return AFV_EINVAL;
     for (int i = 0; i < njobs; ++i) {
         const int rc = validate_job(jobs[i].bow, false);
@@ -990,7 +1064,7 @@ extern "C" int afv_match_triangulation(afv_ctx *c, const afv_tri_job *jobs, int 
         if ((t.bow.n1 > 0 && (!t.x1 || !t.y1)) || (t.bow.n2 > 0 && (!t.x2 || !t.y2 || !t.sigma2_2))) return AFV_EINVAL;
     }
     HIPCHK(c, hipSetDevice(c->device));
-    Blob b;
+    Blob b(c);
     std::vector<JobOffsets> offs(njobs);
     std::vector<size_t> geo_off(njobs * 5);
     for (int i = 0; i < njobs; ++i) {
@@ -1028,10 +1102,14 @@ extern "C" int afv_match_triangulation(afv_ctx *c, const afv_tri_job *jobs, int 
     HIPCHK(c, hipMemcpyAsync(c->d_match, b.h.data(), b.h.size(), hipMemcpyHostToDevice, c->stream));
     afv_launch_match_tri(reinterpret_cast<const DevTriJob *>(c->d_match + jobs_off), njobs, c->stream);
     HIPCHK(c, hipGetLastError());
-    if (total_out) HIPCHK(c, hipMemcpyAsync(match12, c->d_match + out_off, total_out * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(nmatches, c->d_match + nm_off, (size_t)njobs * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, b.fetch(match12, out_off, total_out * 4, c->stream));
+    HIPCHK(c, b.fetch(nmatches, nm_off, (size_t)njobs * 4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    b.finish();
     return AFV_OK;
+}
+extern "C" int afv_match_triangulation(afv_ctx *c, const afv_tri_job *jobs, int njobs, int32_t *match12, int32_t *nmatches) {
+    return guarded(c, [&] { return afv_match_triangulation_impl(c, jobs, njobs, match12, nmatches); });
 }
 
 extern "C" int afv_match_bruteforce_pairs_device(afv_ctx *c, const uint8_t *d_desc, const afv_keypoint *d_kps,
@@ -1079,19 +1157,19 @@ extern "C" int afv_match_bruteforce_pairs_device(afv_ctx *c, const uint8_t *d_de
     return AFV_OK;
 }
 
-extern "C" int afv_match_l2(afv_ctx *c, const float *desc1, int n1, const float *desc2, int n2, int dim, const uint8_t *valid1,
+static int afv_match_l2_impl(afv_ctx *c, const float *desc1, int n1, const float *desc2, int n2, int dim, const uint8_t *valid1,
                             const uint8_t *valid2, float th_low, float nnratio, int32_t *match12, int32_t *nmatches) {
     if (!c || !match12 || !nmatches || n1 < 0 || n2 < 0 || n1 > AFV_MAX_SIDE || n2 > AFV_MAX_SIDE || dim < 1 || dim > 1024)
         return AFV_EINVAL;
     if ((n1 > 0 && !desc1) || (n2 > 0 && !desc2)) return AFV_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
-    Blob b;
+    Blob b(c);
     const size_t o1 = b.put(desc1, (size_t)n1 * dim * 4), o2 = b.put(desc2, (size_t)n2 * dim * 4);
     const size_t ov1 = valid1 ? b.put(valid1, (size_t)n1) : 0, ov2 = valid2 ? b.put(valid2, (size_t)n2) : 0;
     const size_t in_bytes = b.h.size();
     const size_t oo = b.reserve((size_t)std::max(n1, 1) * 4), on = b.reserve(4);
     int ntiles = 1, cols_per_tile = 32;
-    const size_t ok = b.reserve(afv_match_l2_scratch_bytes(n1, n2, &ntiles, &cols_per_tile));
+    const size_t ok = b.reserve_scratch(afv_match_l2_scratch_bytes(n1, n2, &ntiles, &cols_per_tile));
     const int rc = ensure_match_buffer(c, b.h.size());
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->d_match, b.h.data(), in_bytes, hipMemcpyHostToDevice, c->stream));
@@ -1101,10 +1179,15 @@ extern "C" int afv_match_l2(afv_ctx *c, const float *desc1, int n1, const float 
     if (!afv_launch_match_l2_tiled(p1, n1, p2, n2, dim, pv1, pv2, th_low, nnratio, pout, pn, c->d_match + ok, ntiles, cols_per_tile, c->stream))
         afv_launch_match_l2(p1, n1, p2, n2, dim, pv1, pv2, th_low, nnratio, pout, pn, c->stream);
     HIPCHK(c, hipGetLastError());
-    if (n1) HIPCHK(c, hipMemcpyAsync(match12, c->d_match + oo, (size_t)n1 * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(nmatches, c->d_match + on, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, b.fetch(match12, oo, (size_t)n1 * 4, c->stream));
+    HIPCHK(c, b.fetch(nmatches, on, 4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    b.finish();
     return AFV_OK;
+}
+extern "C" int afv_match_l2(afv_ctx *c, const float *desc1, int n1, const float *desc2, int n2, int dim, const uint8_t *valid1,
+                            const uint8_t *valid2, float th_low, float nnratio, int32_t *match12, int32_t *nmatches) {
+    return guarded(c, [&] { return afv_match_l2_impl(c, desc1, n1, desc2, n2, dim, valid1, valid2, th_low, nnratio, match12, nmatches); });
 }
 
 // ---- projection-guided matching ----
@@ -1123,7 +1206,7 @@ static int match_projection_impl(afv_ctx *c, const afv_proj_job *jobs, int njobs
         if (kind == KIND_PROJ && j.mode == AFV_PROJ_LASTFRAME && j.check_orientation && ((j.n > 0 && !j.angle) || (j.nq > 0 && !j.qangle))) return AFV_EINVAL;
     }
     HIPCHK(c, hipSetDevice(c->device));
-    Blob b;
+    Blob b(c);
     struct Off { size_t fd, x, y, size, angle, occ, inf, cptr, cidx, qd, qvalid, qu, qv, qr, qmin, qmax, qang, qocc, keys, ncand, ori, assign, nm; int words; };
     std::vector<Off> offs(njobs);
     size_t total_out = 0;
@@ -1161,9 +1244,9 @@ static int match_projection_impl(afv_ctx *c, const afv_proj_job *jobs, int njobs
     const size_t in_bytes = b.h.size();
     for (int i = 0; i < njobs; ++i) {  // device-only scratch
         const afv_proj_job &j = jobs[i];
-        offs[i].keys = b.reserve((size_t)std::max(j.nq, 1) * 4 * 8);
-        offs[i].ncand = b.reserve((size_t)std::max(j.nq, 1) * 4);
-        offs[i].ori = b.reserve((size_t)std::max(j.nq, 1) * 8);
+        offs[i].keys = b.reserve_scratch((size_t)std::max(j.nq, 1) * 64);  // 64-byte record / 8 keys per query
+        offs[i].ncand = b.reserve_scratch((size_t)std::max(j.nq, 1) * 4);
+        offs[i].ori = b.reserve_scratch((size_t)std::max(j.nq, 1) * 8);
     }
     const size_t out_off = b.reserve(std::max<size_t>(total_out, 1) * 4);
     const size_t nm_off = b.reserve((size_t)njobs * 4);
@@ -1199,26 +1282,38 @@ static int match_projection_impl(afv_ctx *c, const afv_proj_job *jobs, int njobs
     }
     HIPCHK(c, hipMemcpyAsync(B, b.h.data(), in_bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(B + jobs_off, b.h.data() + jobs_off, (size_t)njobs * sizeof(DevProjJob), hipMemcpyHostToDevice, c->stream));
-    if (fuse) afv_launch_match_fuse(reinterpret_cast<const DevProjJob *>(B + jobs_off), njobs, c->stream);
-    else if (kind == KIND_INIT) afv_launch_match_init(reinterpret_cast<const DevProjJob *>(B + jobs_off), njobs, c->stream);
-    else afv_launch_match_projection(reinterpret_cast<const DevProjJob *>(B + jobs_off), njobs, c->stream);
+    int max_nq = 0;
+    for (int i = 0; i < njobs; ++i) max_nq = std::max(max_nq, jobs[i].nq);
+    if (fuse) afv_launch_match_fuse(reinterpret_cast<const DevProjJob *>(B + jobs_off), njobs, max_nq, c->stream);
+    else if (kind == KIND_INIT) afv_launch_match_init(reinterpret_cast<const DevProjJob *>(B + jobs_off), njobs, max_nq, c->stream);
+    else afv_launch_match_projection(reinterpret_cast<const DevProjJob *>(B + jobs_off), njobs, max_nq, c->stream);
     HIPCHK(c, hipGetLastError());
-    if (total_out) HIPCHK(c, hipMemcpyAsync(assign, B + out_off, total_out * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(nmatches, B + nm_off, (size_t)njobs * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, b.fetch(assign, out_off, total_out * 4, c->stream));
+    if (!fuse) HIPCHK(c, b.fetch(nmatches, nm_off, (size_t)njobs * 4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    b.finish();
+    if (fuse) {  // independent queries: the count is just the number of hits
+        size_t at = 0;
+        for (int i = 0; i < njobs; ++i) {
+            int found = 0;
+            for (int q = 0; q < jobs[i].nq; ++q) found += assign[at + q] >= 0;
+            nmatches[i] = found;
+            at += (size_t)jobs[i].nq;
+        }
+    }
     return AFV_OK;
 }
 
 extern "C" int afv_match_projection(afv_ctx *c, const afv_proj_job *jobs, int njobs, int32_t *assign, int32_t *nmatches) {
-    return match_projection_impl(c, jobs, njobs, assign, nmatches, KIND_PROJ);
+    return guarded(c, [&] { return match_projection_impl(c, jobs, njobs, assign, nmatches, KIND_PROJ); });
 }
 extern "C" int afv_match_fuse(afv_ctx *c, const afv_proj_job *jobs, int njobs, int32_t *best, int32_t *nfound) {
-    return match_projection_impl(c, jobs, njobs, best, nfound, KIND_FUSE);
+    return guarded(c, [&] { return match_projection_impl(c, jobs, njobs, best, nfound, KIND_FUSE); });
 }
 extern "C" int afv_match_initialization(afv_ctx *c, const afv_proj_job *jobs, int njobs, int32_t *match12, int32_t *nmatches) {
-    return match_projection_impl(c, jobs, njobs, match12, nmatches, KIND_INIT);
+    return guarded(c, [&] { return match_projection_impl(c, jobs, njobs, match12, nmatches, KIND_INIT); });
 }
-extern "C" int afv_match_sim3(afv_ctx *c, const afv_proj_job *j12, const afv_proj_job *j21, int32_t *match12, int32_t *nfound) {
+static int afv_match_sim3_impl(afv_ctx *c, const afv_proj_job *j12, const afv_proj_job *j21, int32_t *match12, int32_t *nfound) {
     if (!c || !j12 || !j21 || !match12 || !nfound) return AFV_EINVAL;
     if (j12->nq != j21->n || j21->nq != j12->n) return AFV_EINVAL;
     afv_proj_job jobs[2] = {*j12, *j21};
@@ -1238,6 +1333,9 @@ extern "C" int afv_match_sim3(afv_ctx *c, const afv_proj_job *j12, const afv_pro
     }
     *nfound = found;
     return AFV_OK;
+}
+extern "C" int afv_match_sim3(afv_ctx *c, const afv_proj_job *j12, const afv_proj_job *j21, int32_t *match12, int32_t *nfound) {
+    return guarded(c, [&] { return afv_match_sim3_impl(c, j12, j21, match12, nfound); });
 }
 
 // ---- BoW quantisation ----
@@ -1287,12 +1385,12 @@ extern "C" void afv_vocab_destroy(afv_ctx *c, afv_vocab *v) {
     delete v;
 }
 
-extern "C" int afv_bow_transform(afv_ctx *c, const afv_vocab *v, const uint8_t *desc, int n, int levelsup, int32_t *leaf_node,
+static int afv_bow_transform_impl(afv_ctx *c, const afv_vocab *v, const uint8_t *desc, int n, int levelsup, int32_t *leaf_node,
                                  int32_t *node_at_level) {
     if (!c || !v || n < 0 || (n > 0 && (!desc || !leaf_node || !node_at_level))) return AFV_EINVAL;
     if (n == 0) return AFV_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    Blob b;
+    Blob b(c);
     const size_t d_off = put_desc(b, desc, n, v->desc_bytes, v->dev.words);
     const size_t in_bytes = b.h.size();
     const size_t leaf_off = b.reserve((size_t)n * 4), nid_off = b.reserve((size_t)n * 4);
@@ -1302,8 +1400,13 @@ extern "C" int afv_bow_transform(afv_ctx *c, const afv_vocab *v, const uint8_t *
     afv_launch_bow_transform(&v->dev, reinterpret_cast<const uint32_t *>(c->d_match + d_off), n, levelsup,
                              reinterpret_cast<int *>(c->d_match + leaf_off), reinterpret_cast<int *>(c->d_match + nid_off), c->stream);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(leaf_node, c->d_match + leaf_off, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(node_at_level, c->d_match + nid_off, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, b.fetch(leaf_node, leaf_off, (size_t)n * 4, c->stream));
+    HIPCHK(c, b.fetch(node_at_level, nid_off, (size_t)n * 4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    b.finish();
     return AFV_OK;
+}
+extern "C" int afv_bow_transform(afv_ctx *c, const afv_vocab *v, const uint8_t *desc, int n, int levelsup, int32_t *leaf_node,
+                                 int32_t *node_at_level) {
+    return guarded(c, [&] { return afv_bow_transform_impl(c, v, desc, n, levelsup, leaf_node, node_at_level); });
 }

@@ -29,3 +29,38 @@ for _ in range(2): m.SearchByBoW_batch(pairs)
 t = time.perf_counter()
 for _ in range(10): m.SearchByBoW_batch(pairs)
 print("SearchByBoW_batch 20 BoW jobs: %.3f ms" % ((time.perf_counter() - t) / 10 * 1e3))
+# SearchForTriangulation: 100-node feature vectors, nothing has a map point yet, a plausible F12
+has0 = np.zeros(len(d), np.uint8); has02 = np.zeros(len(d2), np.uint8)
+p1 = np.stack([k["x"], k["y"]], 1); p2 = np.stack([k2["x"], k2["y"]], 1)
+sz2, sg2, _ = ctx.size_sigma(k2)
+t1 = afv.FeatureView(d, fv(len(d), 100, 3), has0, pts=p1)
+t2 = afv.FeatureView(d2, fv(len(d2), 100, 4), has02, pts=p2, sigma2=sz2 * sz2)
+F12 = np.array([[0, 0, 0], [0, 0, -1e-3], [0, 1e-3, 0]], np.float32)   # pure x translation: epipolar lines are rows
+for _ in range(3): m.SearchForTriangulation(t1, t2, F12, (1e6, 240.0))
+t = time.perf_counter()
+for _ in range(N): r = m.SearchForTriangulation(t1, t2, F12, (1e6, 240.0))
+print("SearchForTriangulation 100 nodes: %.3f ms  (%d pairs)" % ((time.perf_counter() - t) / N * 1e3, r[1]))
+# projection searches
+sz1, _, _ = ctx.size_sigma(k)
+F = afv.FrameGridView(d, p1, sz1, angles=k["angle"])
+Q = afv.ProjectionQueries(d2, k2["x"] - 4, k2["y"], 15.0 * sz2, sz2 / np.float32(1.2), sz2 * np.float32(1.2), angles=k2["angle"])
+for name, kw in (("local map", {}), ("last frame", {"last_frame": True})):
+    for _ in range(3): m.SearchByProjection(F, Q, **kw)
+    t = time.perf_counter()
+    for _ in range(N): r = m.SearchByProjection(F, Q, **kw)
+    print("SearchByProjection %-12s %.3f ms  (%d matches)" % (name, (time.perf_counter() - t) / N * 1e3, r[1]))
+for _ in range(3): m.Fuse_sim3(F, Q)
+t = time.perf_counter()
+for _ in range(N): r = m.Fuse_sim3(F, Q)
+print("Fuse core: %.3f ms  (%d found)" % ((time.perf_counter() - t) / N * 1e3, r[1]))
+Q1 = afv.ProjectionQueries(d2, k2["x"], k2["y"], np.full(len(k2), 100.0, np.float32), np.zeros(len(k2), np.float32),
+                           np.full(len(k2), 10.0, np.float32), valid=(k2["octave"] == 0).astype(np.uint8), angles=k2["angle"])
+for _ in range(3): m.SearchForInitialization(Q1, F)
+t = time.perf_counter()
+for _ in range(N): r = m.SearchForInitialization(Q1, F)
+print("SearchForInitialization (window 100): %.3f ms  (%d matches)" % ((time.perf_counter() - t) / N * 1e3, r[1]))
+voc = afv.Vocabulary.random(3, k=10, L=4, ctx=ctx)
+for _ in range(3): voc.transform_nodes(d, 2)
+t = time.perf_counter()
+for _ in range(N): voc.transform_nodes(d, 2)
+print("Vocabulary descent (k=10, L=4, %d descriptors): %.3f ms" % (len(d), (time.perf_counter() - t) / N * 1e3))
