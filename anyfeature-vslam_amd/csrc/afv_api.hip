@@ -42,6 +42,7 @@ struct DevTriJob {
     const float *x1, *y1, *x2, *y2, *sigma2_2;
     float F[9];
     float ex, ey;
+    const int *row_seg;
 };
 extern "C" void afv_launch_match_bow(const DevMatchJob *jobs, int njobs, hipStream_t stream);
 extern "C" void afv_launch_match_bow_seg(const DevMatchJob *jobs, int njobs, const void *tasks, int ntasks, int *hist, uint8_t *bins,
@@ -49,7 +50,7 @@ extern "C" void afv_launch_match_bow_seg(const DevMatchJob *jobs, int njobs, con
 extern "C" void afv_launch_match_pairs2(const uint8_t *desc, const afv_keypoint *kps, const int *nset, int cap, const int *pa,
                                         const int *pb, int npairs, float th, float ratio, int check_ori, int *match,
                                         int *nmatches, void *topk_scratch, int pair_base, hipStream_t stream);
-extern "C" void afv_launch_match_tri(const DevTriJob *jobs, int njobs, hipStream_t stream);
+extern "C" void afv_launch_match_tri(const DevTriJob *jobs, int njobs, int max_n1, hipStream_t stream);
 extern "C" void afv_launch_match_l2(const float *d1, int n1, const float *d2, int n2, int dim, const uint8_t *v1,
                                     const uint8_t *v2, float th, float ratio, int *out, int *nmatches, hipStream_t stream);
 
@@ -1066,7 +1067,7 @@ static int afv_match_triangulation_impl(afv_ctx *c, const afv_tri_job *jobs, int
     HIPCHK(c, hipSetDevice(c->device));
     Blob b(c);
     std::vector<JobOffsets> offs(njobs);
-    std::vector<size_t> geo_off(njobs * 5);
+    std::vector<size_t> geo_off(njobs * 5), rowseg_off(njobs);
     for (int i = 0; i < njobs; ++i) {
         stage_job(b, jobs[i].bow, true, offs[i]);
         const afv_tri_job &t = jobs[i];
@@ -1075,6 +1076,17 @@ static int afv_match_triangulation_impl(afv_ctx *c, const afv_tri_job *jobs, int
         geo_off[5 * i + 2] = b.put(t.x2, (size_t)t.bow.n2 * 4);
         geo_off[5 * i + 3] = b.put(t.y2, (size_t)t.bow.n2 * 4);
         geo_off[5 * i + 4] = b.put(t.sigma2_2, (size_t)t.bow.n2 * 4);
+        // feature -> shared node (a feature sits in exactly one node of its FeatureVector)
+        std::vector<Seg> segs;
+        shared_segments(t.bow, segs);
+        std::vector<int> row_seg((size_t)std::max(t.bow.n1, 1), -1);
+        const bool has_idx = t.bow.nnodes1 > 0 && t.bow.nnodes2 > 0;
+        for (size_t sgi = 0; sgi < segs.size(); ++sgi)
+            for (int r = 0; r < segs[sgi].n1; ++r) {
+                const int f = has_idx ? t.bow.seg_idx1[segs[sgi].s1 + r] : segs[sgi].s1 + r;
+                if (f >= 0 && f < t.bow.n1) row_seg[f] = (int)sgi;
+            }
+        rowseg_off[i] = b.put(row_seg.data(), row_seg.size() * 4);
     }
     size_t total_out = 0;
     for (int i = 0; i < njobs; ++i) total_out += (size_t)jobs[i].bow.n1;
@@ -1098,9 +1110,12 @@ static int afv_match_triangulation_impl(afv_ctx *c, const afv_tri_job *jobs, int
         std::memcpy(d.F, jobs[i].F12, sizeof(d.F));
         d.ex = jobs[i].ex;
         d.ey = jobs[i].ey;
+        d.row_seg = reinterpret_cast<const int *>(c->d_match + rowseg_off[i]);
     }
     HIPCHK(c, hipMemcpyAsync(c->d_match, b.h.data(), b.h.size(), hipMemcpyHostToDevice, c->stream));
-    afv_launch_match_tri(reinterpret_cast<const DevTriJob *>(c->d_match + jobs_off), njobs, c->stream);
+    int max_n1 = 0;
+    for (int i = 0; i < njobs; ++i) max_n1 = std::max(max_n1, jobs[i].bow.n1);
+    afv_launch_match_tri(reinterpret_cast<const DevTriJob *>(c->d_match + jobs_off), njobs, max_n1, c->stream);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, b.fetch(match12, out_off, total_out * 4, c->stream));
     HIPCHK(c, b.fetch(nmatches, nm_off, (size_t)njobs * 4, c->stream));

@@ -554,64 +554,57 @@ struct DevTriJob {
     const float *x1, *y1, *x2, *y2, *sigma2_2;
     float F[9];
     float ex, ey;
+    const int *row_seg;  // [n1] index of the shared node holding the feature, -1 = none
 };
 
+// One thread per KF1 feature (row_seg = the shared node it belongs to, -1 if none): rows are independent here (vbMatched2 is
+// never set, FeatureMatcher.cc:681,724), so the whole job runs in one pass; the threads of a wave mostly sit in the same node
+// and read the same KF2 candidates (uniform loads).  Equal distances: the LAST candidate in the node's order wins (:736).
 template <int W>
-__device__ void tri_job(const DevTriJob &T, int *s_count) {
+__device__ int tri_row(const DevTriJob &T, int idx1) {
     const DevMatchJob &J = T.m;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int i = tid; i < J.n1; i += MT) J.out[i] = -1;
-    if (tid == 0) *s_count = 0;
-    __syncthreads();
-    int found = 0;
-    for (int sg = 0; sg < J.nseg; ++sg) {
-        const Seg S = J.segs[sg];
-        for (int a = wv; a < S.n1; a += MT / 64) {
-            const int idx1 = J.idx1 ? J.idx1[S.s1 + a] : S.s1 + a;
-            if (J.valid1 && J.valid1[idx1]) continue;  // already has a MapPoint (:699-703)
-            uint32_t q[W];
+    const int sg = T.row_seg[idx1];
+    if (sg < 0) return -1;
+    if (J.valid1 && J.valid1[idx1]) return -1;  // already has a MapPoint (:699-703)
+    const Seg S = J.segs[sg];
+    uint32_t q[W];
 #pragma unroll
-            for (int i = 0; i < W; ++i) q[i] = J.d1[(size_t)idx1 * W + i];
-            const float kx = T.x1[idx1], ky = T.y1[idx1];
-            // epipolar line in image 2: l = x1' F12 (:168-170)
-            const float la = kx * T.F[0] + ky * T.F[3] + T.F[6];
-            const float lb = kx * T.F[1] + ky * T.F[4] + T.F[7];
-            const float lc = kx * T.F[2] + ky * T.F[5] + T.F[8];
-            const float den = la * la + lb * lb;
-            int k = NO_KEY;  // dist << 16 | (0xffff - position): equal distances -> LAST position wins (:736)
-            for (int b = lane; b < S.n2; b += 64) {
-                const int idx2 = J.idx2 ? J.idx2[S.s2 + b] : S.s2 + b;
-                if (J.valid2 && J.valid2[idx2]) continue;
-                const int d = hamming_words<W>(q, J.d2 + (size_t)idx2 * W);
-                if ((float)d > J.th) continue;
-                const float x2 = T.x2[idx2], y2 = T.y2[idx2], sg2 = T.sigma2_2[idx2];
-                const float dex = T.ex - x2, dey = T.ey - y2;
-                if (dex * dex + dey * dey < 100.0f * sqrtf(sg2)) continue;  // too close to the epipole (:741-748)
-                const float num = la * x2 + lb * y2 + lc;
-                if (den == 0) continue;
-                const float dsqr = num * num / den;
-                if (!(dsqr < 3.84f * sg2)) continue;  // CheckDistEpipolarLine (:172-181)
-                k = min(k, (d << 16) | (0xffff - b));
-            }
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) k = min(k, __shfl_xor(k, m, 64));
-            if (lane == 0 && k != NO_KEY) {
-                const int b = 0xffff - (k & 0xffff);
-                J.out[idx1] = J.idx2 ? J.idx2[S.s2 + b] : S.s2 + b;
-                ++found;
-            }
-        }
+    for (int i = 0; i < W; ++i) q[i] = J.d1[(size_t)idx1 * W + i];
+    const float kx = T.x1[idx1], ky = T.y1[idx1];
+    // epipolar line in image 2: l = x1' F12 (:168-170)
+    const float la = kx * T.F[0] + ky * T.F[3] + T.F[6];
+    const float lb = kx * T.F[1] + ky * T.F[4] + T.F[7];
+    const float lc = kx * T.F[2] + ky * T.F[5] + T.F[8];
+    const float den = la * la + lb * lb;
+    if (den == 0) return -1;
+    int best = 0x7fffffff, best_idx = -1;
+    for (int b = 0; b < S.n2; ++b) {
+        const int idx2 = J.idx2 ? J.idx2[S.s2 + b] : S.s2 + b;
+        if (J.valid2 && J.valid2[idx2]) continue;
+        const int d = hamming_words<W>(q, J.d2 + (size_t)idx2 * W);
+        if ((float)d > J.th || d > best) continue;
+        const float x2 = T.x2[idx2], y2 = T.y2[idx2], sg2 = T.sigma2_2[idx2];
+        const float dex = T.ex - x2, dey = T.ey - y2;
+        if (dex * dex + dey * dey < 100.0f * sqrtf(sg2)) continue;  // too close to the epipole (:741-748)
+        const float num = la * x2 + lb * y2 + lc;
+        const float dsqr = num * num / den;
+        if (!(dsqr < 3.84f * sg2)) continue;  // CheckDistEpipolarLine (:172-181)
+        best = d;
+        best_idx = idx2;
     }
-    if (lane == 0 && found) atomicAdd(s_count, found);
-    __syncthreads();
-    if (tid == 0) *J.nmatches = *s_count;
+    return best_idx;
 }
 
 __global__ __launch_bounds__(MT) void k_match_tri(const DevTriJob *__restrict__ jobs) {
-    __shared__ int s_count;
-    const DevTriJob T = jobs[blockIdx.x];
-    if (T.m.words == 8) tri_job<8>(T, &s_count);
-    else tri_job<16>(T, &s_count);
+    const DevTriJob &T = jobs[blockIdx.y];
+    const int i = blockIdx.x * MT + threadIdx.x;
+    int r = -1;
+    if (i < T.m.n1) {
+        r = T.m.words == 8 ? tri_row<8>(T, i) : tri_row<16>(T, i);
+        T.m.out[i] = r;
+    }
+    const int cnt = __popcll(__ballot(r >= 0));
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(T.m.nmatches, cnt);  // the counter arrives zeroed with the staging blob
 }
 
 // ---------------- M8: float descriptors, L2^2 (cv::norm NORM_L2SQR semantics) ----------------
@@ -704,8 +697,8 @@ extern "C" void afv_launch_match_pairs2(const uint8_t *desc, const afv_keypoint 
     hipLaunchKernelGGL(k_match_resolve, dim3(npairs), dim3(MT), 0, stream, desc, kps, nset, cap, pa, pb, topk, th, ratio,
                        check_ori, match, nmatches, pair_base);
 }
-extern "C" void afv_launch_match_tri(const DevTriJob *jobs, int njobs, hipStream_t stream) {
-    hipLaunchKernelGGL(k_match_tri, dim3(njobs), dim3(MT), 0, stream, jobs);
+extern "C" void afv_launch_match_tri(const DevTriJob *jobs, int njobs, int max_n1, hipStream_t stream) {
+    if (max_n1 > 0) hipLaunchKernelGGL(k_match_tri, dim3((max_n1 + MT - 1) / MT, njobs), dim3(MT), 0, stream, jobs);
 }
 extern "C" void afv_launch_match_l2(const float *d1, int n1, const float *d2, int n2, int dim, const uint8_t *v1,
                                     const uint8_t *v2, float th, float ratio, int *out, int *nmatches, hipStream_t stream) {
