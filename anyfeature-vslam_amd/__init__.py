@@ -14,5 +14,7 @@ from . import _lib, synth  # noqa: F401
 from .extractor import (CovarianceMethod, FeatureExtractorSettings, FeatureExtractor_orb32, Context,  # noqa: F401
                         KP_DTYPE)
 from .vocabulary import Vocabulary  # noqa: F401
+from . import akaze  # noqa: F401
+from .akaze import AkazeContext  # noqa: F401
 from .matcher import (FeatureMatcher, FeatureView, FrameGridView, ProjectionQueries,  # noqa: F401
                       DescriptorDistance_orb32)

@@ -87,6 +87,19 @@ SYMBOLS = {
     "afv_vocab_destroy": (None, [_vp, _vp]),
     "afv_bow_transform": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "afv_hamming256": (_i, [_vp, _vp]),
+    # include/afv_akaze.h
+    "afv_akaze_default_params": (None, [_vp]),
+    "afv_akaze_create": (_i, [_i, _vp, C.POINTER(_vp)]),
+    "afv_akaze_destroy": (None, [_vp]),
+    "afv_akaze_last_error": (C.c_char_p, [_vp]),
+    "afv_akaze_plan_for": (_i, [_vp, _i, _i, _vp]),
+    "afv_akaze_scale_space": (_i, [_vp, _vp, _i, _i, _i, _i, C.c_size_t]),
+    "afv_akaze_scale_space_device": (_i, [_vp, _vp, _i, _i, _i, _i, C.c_size_t]),
+    "afv_akaze_synchronize": (_i, [_vp]),
+    "afv_akaze_get_plane": (_i, [_vp, _i, _i, _i, _vp]),
+    "afv_akaze_get_kcontrast": (_i, [_vp, _i, _vp]),
+    "afv_akaze_profile_enable": (_i, [_vp, _i]),
+    "afv_akaze_profile_read": (_i, [_vp, _vp, _vp, _vp]),
     "afv_profile_enable": (_i, [_vp, _i]),
     "afv_profile_read": (_i, [_vp, _vp, _vp, _vp]),
     "afv_set_split_threshold": (_i, [_vp, _i]),
@@ -129,6 +142,10 @@ class AfvError(RuntimeError):
         self.code = code
         msg = load().afv_strerror(code).decode()
         super().__init__("afv error %d (%s)%s" % (code, msg, (": " + detail) if detail else ""))
+
+
+def strerror(code):
+    return load().afv_strerror(int(code)).decode()
 
 
 def ptr(a):

@@ -1,0 +1,370 @@
+// akaze_api.hip — host runtime of the AKAZE61 path (include/afv_akaze.h): evolution plan, HBM layout, stage enqueue.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/afv_akaze.h"
+#include "../../include/afv_hip.h"
+
+extern "C" int afv_akz_launch_gauss(const void *src, int is_u8, int src_stride, size_t src_frame_stride, int w, int h, int nframes,
+                                    const float *taps, int ksize, float *dst, hipStream_t st);
+extern "C" void afv_akz_launch_kcontrast(const float *gsm, int w, int h, int nframes, float *modg, unsigned int *hmax_bits, int *hist,
+                                         int nbins, float perc, float *kcontrast, hipStream_t st);
+extern "C" void afv_akz_launch_halfsample(const float *src, int w, int h, float *dst, int dw, int dh, int nframes, hipStream_t st);
+extern "C" void afv_akz_launch_flow(const float *lsm, int w, int h, int nframes, const float *kcontrast, int octave, float *flow,
+                                    hipStream_t st);
+extern "C" void afv_akz_launch_nld_step(const float *Lt, const float *flow, int w, int h, int nframes, float tau, float *out, hipStream_t st);
+extern "C" int afv_akz_launch_hessian(const float *lsm, int w, int h, int nframes, int s, float *dx, float *dy, float *Lx, float *Ly,
+                                      float *Ldet, hipStream_t st);
+
+struct afv_akaze {
+    int device = 0;
+    afv_akaze_params prm{};
+    afv_akaze_plan plan{};  // for the current frame size
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    // HBM: per level 5 planes x max_batch frames (level 0: Lsmooth aliases Lt); scratch at level-0 size
+    float *lt[AFV_AKZ_MAX_LEVELS] = {}, *lsm[AFV_AKZ_MAX_LEVELS] = {}, *lx[AFV_AKZ_MAX_LEVELS] = {}, *ly[AFV_AKZ_MAX_LEVELS] = {},
+          *ldet[AFV_AKZ_MAX_LEVELS] = {};
+    float *flow = nullptr, *pong = nullptr, *half = nullptr, *dx = nullptr, *dy = nullptr;
+    float *d_taps = nullptr;  // gauss_soffset[32] | gauss_one[8]
+    unsigned int *d_hmax = nullptr;
+    int *d_hist = nullptr;
+    float *d_kcontrast = nullptr;
+    uint8_t *d_gray = nullptr;
+    size_t gray_bytes = 0;
+    int cur_w = 0, cur_h = 0, cur_frames = 0;
+    bool profiling = false;
+    hipEvent_t ev[3] = {};
+    float ms_ss = 0, ms_hess = 0;
+    int launches = 0;
+    std::vector<void *> allocs;
+};
+
+#define AKZ_HIPCHK(a, expr)                                                               \
+    do {                                                                                  \
+        const hipError_t e_ = (expr);                                                     \
+        if (e_ != hipSuccess) {                                                           \
+            (a)->last_error = std::string(#expr) + ": " + hipGetErrorString(e_);          \
+            return e_ == hipErrorOutOfMemory ? AFV_ENOMEM : AFV_EHIP;                     \
+        }                                                                                 \
+    } while (0)
+
+static inline int f_round(float x) { return (int)(x + 0.5f); }
+
+// ---- FED time steps (libAKAZE fed.cpp) ----
+static bool fed_is_prime(int n) {
+    if (n <= 1) return false;
+    if (n == 2 || n == 3 || n == 5 || n == 7) return true;
+    if (n % 2 == 0 || n % 3 == 0 || n % 5 == 0 || n % 7 == 0) return false;
+    const int upper = (int)(std::sqrt((double)n + 1.0));
+    for (int d = 11; d <= upper; d += 2)
+        if (n % d == 0) return false;
+    return true;
+}
+static int fed_tau(float T, float tau_max, float *tau) {
+    const int n = (int)(ceilf(sqrtf(3.0f * T / tau_max + 0.25f) - 0.5f - 1.0e-8f) + 0.5f);
+    if (n > AFV_AKZ_MAX_FED) return -1;
+    if (n <= 0) return 0;
+    const float scale = 3.0f * T / (tau_max * (float)(n * (n + 1)));
+    float tauh[AFV_AKZ_MAX_FED];
+    const float c = 1.0f / (4.0f * (float)n + 2.0f), d = scale * tau_max / 2.0f;
+    for (int k = 0; k < n; ++k) {
+        const float hcos = cosf(3.14159265358979323846f * (2.0f * (float)k + 1.0f) * c);
+        tauh[k] = d / (hcos * hcos);
+    }
+    const int kappa = n / 2;
+    int prime = n + 1;
+    while (!fed_is_prime(prime)) prime++;
+    for (int k = 0, l = 0; l < n; ++k, ++l) {
+        int index;
+        while ((index = ((k + 1) * kappa) % prime - 1) >= n) k++;
+        tau[l] = tauh[index];
+    }
+    return n;
+}
+static int gauss_ksize(float sigma) {
+    int ks = (int)ceilf(2.0f * (1.0f + (sigma - 0.8f) / 0.3f));
+    if ((ks % 2) == 0) ks += 1;
+    return ks;
+}
+static void gauss_taps(float sigma, int n, float *k) {  // cv::getGaussianKernel(n, sigma, CV_32F), sigma > 0
+    const double s = (double)sigma, scale2x = -0.5 / (s * s);
+    double t[64], sum = 0;
+    for (int i = 0; i < n; ++i) {
+        const double x = i - (n - 1) * 0.5;
+        t[i] = std::exp(scale2x * x * x);
+        sum += t[i];
+    }
+    for (int i = 0; i < n; ++i) k[i] = (float)(t[i] / sum);
+}
+
+extern "C" void afv_akaze_default_params(afv_akaze_params *p) {
+    if (!p) return;
+    p->omax = 2; p->nsublevels = 4; p->soffset = 1.6f; p->derivative_factor = 1.5f;
+    p->dthreshold = 0.0005f; p->min_dthreshold = 0.00001f; p->kcontrast_percentile = 0.7f; p->kcontrast_nbins = 300;
+    p->max_width = 1280; p->max_height = 720; p->max_batch = 1;
+}
+
+extern "C" int afv_akaze_plan_for(const afv_akaze_params *o, int w, int h, afv_akaze_plan *p) {
+    if (!o || !p || w < 16 || h < 16 || o->omax < 1 || o->nsublevels < 1) return AFV_EINVAL;
+    std::memset(p, 0, sizeof *p);
+    p->w = w; p->h = h;
+    int n = 0;
+    for (int i = 0; i < o->omax; ++i) {
+        const float rfactor = 1.0f / powf(2.0f, (float)i);
+        const int lh = (int)((float)h * rfactor), lw = (int)((float)w * rfactor);
+        if ((lw < 80 || lh < 40) && i != 0) break;
+        for (int j = 0; j < o->nsublevels; ++j) {
+            if (n >= AFV_AKZ_MAX_LEVELS) return AFV_EINVAL;
+            afv_akaze_level &L = p->lv[n++];
+            L.w = lw; L.h = lh; L.octave = i; L.sublevel = j;
+            L.esigma = o->soffset * powf(2.0f, (float)j / (float)o->nsublevels + (float)i);
+            L.etime = 0.5f * (L.esigma * L.esigma);
+            L.sigma_size = f_round(L.esigma * o->derivative_factor / powf(2.0f, (float)i));
+            if (L.sigma_size < 2 || L.sigma_size > 8) return AFV_EUNSUPPORTED;  // sparse-tap Scharr path (k_akz_deriv1)
+        }
+    }
+    p->nlevels = n;
+    for (int i = 1; i < n; ++i) {
+        const int ns = fed_tau(p->lv[i].etime - p->lv[i - 1].etime, 0.25f, p->lv[i].tau);
+        if (ns < 0) return AFV_EUNSUPPORTED;
+        p->lv[i].nsteps = ns;
+        if (p->lv[i].octave > p->lv[i - 1].octave && ((p->lv[i - 1].w & 1) || (p->lv[i - 1].h & 1))) return AFV_EUNSUPPORTED;  // exact 2x INTER_AREA only
+    }
+    p->ksize_soffset = gauss_ksize(o->soffset);
+    p->ksize_one = gauss_ksize(1.0f);
+    if (p->ksize_soffset > 13 || p->ksize_one > 7) return AFV_EUNSUPPORTED;
+    gauss_taps(o->soffset, p->ksize_soffset, p->gauss_soffset);
+    gauss_taps(1.0f, p->ksize_one, p->gauss_one);
+    return AFV_OK;
+}
+
+extern "C" const char *afv_akaze_last_error(const afv_akaze *a) { return a ? a->last_error.c_str() : "null context"; }
+
+extern "C" void afv_akaze_destroy(afv_akaze *a) {
+    if (!a) return;
+    (void)hipSetDevice(a->device);
+    if (a->stream) (void)hipStreamSynchronize(a->stream);
+    for (void *p : a->allocs)
+        if (p) (void)hipFree(p);
+    if (a->d_gray) (void)hipFree(a->d_gray);
+    for (hipEvent_t e : a->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (a->stream) (void)hipStreamDestroy(a->stream);
+    delete a;
+}
+
+template <class T>
+static int akz_alloc(afv_akaze *a, T **p, size_t count) {
+    void *v = nullptr;
+    AKZ_HIPCHK(a, hipMalloc(&v, std::max<size_t>(count, 1) * sizeof(T)));
+    a->allocs.push_back(v);
+    *p = static_cast<T *>(v);
+    return AFV_OK;
+}
+
+extern "C" int afv_akaze_create(int device, const afv_akaze_params *prm, afv_akaze **out) {
+    if (!prm || !out) return AFV_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return AFV_ENODEV;  // no CPU fallback: fail loudly
+    if (device < 0 || device >= ndev) return AFV_ENODEV;
+    if (prm->max_batch < 1 || prm->max_width < 80 || prm->max_height < 40) return AFV_EINVAL;
+    afv_akaze_plan plan;
+    int rc = afv_akaze_plan_for(prm, prm->max_width, prm->max_height, &plan);
+    if (rc) return rc;
+    afv_akaze *a = new (std::nothrow) afv_akaze();
+    if (!a) return AFV_ENOMEM;
+    a->device = device;
+    a->prm = *prm;
+    a->plan = plan;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete a;
+        return AFV_EHIP;
+    }
+    const size_t B = (size_t)prm->max_batch;
+    for (int i = 0; i < plan.nlevels && rc == AFV_OK; ++i) {
+        const size_t n = (size_t)plan.lv[i].w * plan.lv[i].h * B;
+        rc = akz_alloc(a, &a->lt[i], n);
+        if (rc == AFV_OK) {
+            if (i == 0) a->lsm[0] = a->lt[0];  // evolution_[0].Lt.copyTo(evolution_[0].Lsmooth)
+            else rc = akz_alloc(a, &a->lsm[i], n);
+        }
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->lx[i], n);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ly[i], n);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ldet[i], n);
+    }
+    const size_t n0 = (size_t)prm->max_width * prm->max_height * B;
+    if (rc == AFV_OK) rc = akz_alloc(a, &a->flow, n0);
+    if (rc == AFV_OK) rc = akz_alloc(a, &a->pong, n0);
+    if (rc == AFV_OK) rc = akz_alloc(a, &a->half, n0 / 4 + B);
+    if (rc == AFV_OK) rc = akz_alloc(a, &a->dx, n0);
+    if (rc == AFV_OK) rc = akz_alloc(a, &a->dy, n0);
+    if (rc == AFV_OK) rc = akz_alloc(a, &a->d_taps, 40);
+    if (rc == AFV_OK) rc = akz_alloc(a, &a->d_hmax, B);
+    if (rc == AFV_OK) rc = akz_alloc(a, &a->d_hist, B * (size_t)(prm->kcontrast_nbins + 1));
+    if (rc == AFV_OK) rc = akz_alloc(a, &a->d_kcontrast, B);
+    for (hipEvent_t &e : a->ev)
+        if (rc == AFV_OK && hipEventCreate(&e) != hipSuccess) rc = AFV_EHIP;
+    if (rc != AFV_OK) {
+        afv_akaze_destroy(a);
+        return rc;
+    }
+    *out = a;
+    return AFV_OK;
+}
+
+static int akz_enqueue(afv_akaze *a, const uint8_t *d_gray, int nframes, int w, int h, int stride, size_t frame_stride) {
+    if (w != a->cur_w || h != a->cur_h) {
+        afv_akaze_plan plan;
+        const int rc = afv_akaze_plan_for(&a->prm, w, h, &plan);
+        if (rc) return rc;
+        a->plan = plan;
+        a->cur_w = w;
+        a->cur_h = h;
+        float taps[40] = {};
+        std::memcpy(taps, plan.gauss_soffset, sizeof(float) * 32);
+        std::memcpy(taps + 32, plan.gauss_one, sizeof(float) * 8);
+        AKZ_HIPCHK(a, hipMemcpyAsync(a->d_taps, taps, sizeof taps, hipMemcpyHostToDevice, a->stream));
+        AKZ_HIPCHK(a, hipStreamSynchronize(a->stream));  // `taps` is a stack buffer
+    }
+    a->cur_frames = nframes;
+    const afv_akaze_plan &P = a->plan;
+    hipStream_t st = a->stream;
+    const int nb = a->prm.kcontrast_nbins;
+    if (a->profiling) AKZ_HIPCHK(a, hipEventRecord(a->ev[0], st));
+    // level 0: Lt = GaussianBlur(convert(gray), soffset); contrast factor from the sigma = 1 smoothed image
+    if (afv_akz_launch_gauss(d_gray, 1, stride, frame_stride, w, h, nframes, a->d_taps, P.ksize_soffset, a->lt[0], st)) return AFV_EUNSUPPORTED;
+    if (afv_akz_launch_gauss(d_gray, 1, stride, frame_stride, w, h, nframes, a->d_taps + 32, P.ksize_one, a->pong, st)) return AFV_EUNSUPPORTED;
+    AKZ_HIPCHK(a, hipMemsetAsync(a->d_hmax, 0, (size_t)nframes * sizeof(unsigned int), st));
+    AKZ_HIPCHK(a, hipMemsetAsync(a->d_hist, 0, (size_t)nframes * (nb + 1) * sizeof(int), st));
+    afv_akz_launch_kcontrast(a->pong, w, h, nframes, a->flow, a->d_hmax, a->d_hist, nb, a->prm.kcontrast_percentile, a->d_kcontrast, st);
+    for (int i = 1; i < P.nlevels; ++i) {
+        const afv_akaze_level &L = P.lv[i], &Q = P.lv[i - 1];
+        const float *src = a->lt[i - 1];
+        if (L.octave > Q.octave) {
+            afv_akz_launch_halfsample(a->lt[i - 1], Q.w, Q.h, a->half, L.w, L.h, nframes, st);
+            src = a->half;
+        }
+        if (afv_akz_launch_gauss(src, 0, L.w, (size_t)L.w * L.h, L.w, L.h, nframes, a->d_taps + 32, P.ksize_one, a->lsm[i], st))
+            return AFV_EUNSUPPORTED;
+        afv_akz_launch_flow(a->lsm[i], L.w, L.h, nframes, a->d_kcontrast, L.octave, a->flow, st);
+        // FED cycle, ping-pong so that the last step lands in Lt of this level
+        const float *cur = src;
+        for (int j = 0; j < L.nsteps; ++j) {
+            float *dst = ((L.nsteps - 1 - j) % 2 == 0) ? a->lt[i] : a->pong;
+            afv_akz_launch_nld_step(cur, a->flow, L.w, L.h, nframes, L.tau[j], dst, st);
+            cur = dst;
+        }
+        if (L.nsteps == 0) AKZ_HIPCHK(a, hipMemcpyAsync(a->lt[i], src, (size_t)L.w * L.h * nframes * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    if (a->profiling) AKZ_HIPCHK(a, hipEventRecord(a->ev[1], st));
+    for (int i = 0; i < P.nlevels; ++i) {
+        const afv_akaze_level &L = P.lv[i];
+        if (afv_akz_launch_hessian(a->lsm[i], L.w, L.h, nframes, L.sigma_size, a->dx, a->dy, a->lx[i], a->ly[i], a->ldet[i], st))
+            return AFV_EUNSUPPORTED;
+    }
+    if (a->profiling) {
+        AKZ_HIPCHK(a, hipEventRecord(a->ev[2], st));
+        AKZ_HIPCHK(a, hipEventSynchronize(a->ev[2]));
+        float m0 = 0, m1 = 0;
+        AKZ_HIPCHK(a, hipEventElapsedTime(&m0, a->ev[0], a->ev[1]));
+        AKZ_HIPCHK(a, hipEventElapsedTime(&m1, a->ev[1], a->ev[2]));
+        a->ms_ss += m0;
+        a->ms_hess += m1;
+        a->launches += 1;
+    }
+    AKZ_HIPCHK(a, hipGetLastError());
+    return AFV_OK;
+}
+
+static int akz_check(afv_akaze *a, const uint8_t *gray, int nframes, int w, int h, int stride, size_t frame_stride) {
+    if (!a || !gray || nframes < 1 || nframes > a->prm.max_batch || w < 80 || h < 40 || w > a->prm.max_width || h > a->prm.max_height ||
+        stride < w || frame_stride < (size_t)stride * (h - 1) + w || (size_t)w * h > (size_t)a->prm.max_width * a->prm.max_height)
+        return AFV_EINVAL;
+    return AFV_OK;
+}
+
+extern "C" int afv_akaze_scale_space_device(afv_akaze *a, const uint8_t *d_gray, int nframes, int w, int h, int stride, size_t frame_stride) {
+    const int rc = akz_check(a, d_gray, nframes, w, h, stride, frame_stride);
+    if (rc) return rc;
+    AKZ_HIPCHK(a, hipSetDevice(a->device));
+    return akz_enqueue(a, d_gray, nframes, w, h, stride, frame_stride);
+}
+
+extern "C" int afv_akaze_scale_space(afv_akaze *a, const uint8_t *gray, int nframes, int w, int h, int stride, size_t frame_stride) {
+    int rc = akz_check(a, gray, nframes, w, h, stride, frame_stride);
+    if (rc) return rc;
+    AKZ_HIPCHK(a, hipSetDevice(a->device));
+    const size_t need = (size_t)nframes * w * h;
+    if (need > a->gray_bytes) {
+        AKZ_HIPCHK(a, hipStreamSynchronize(a->stream));
+        if (a->d_gray) (void)hipFree(a->d_gray);
+        a->d_gray = nullptr;
+        a->gray_bytes = 0;
+        AKZ_HIPCHK(a, hipMalloc(reinterpret_cast<void **>(&a->d_gray), need));
+        a->gray_bytes = need;
+    }
+    for (int f = 0; f < nframes; ++f)
+        AKZ_HIPCHK(a, hipMemcpy2DAsync(a->d_gray + (size_t)f * w * h, (size_t)w, gray + (size_t)f * frame_stride, (size_t)stride, (size_t)w,
+                                       (size_t)h, hipMemcpyHostToDevice, a->stream));
+    rc = akz_enqueue(a, a->d_gray, nframes, w, h, w, (size_t)w * h);
+    if (rc) return rc;
+    AKZ_HIPCHK(a, hipStreamSynchronize(a->stream));
+    return AFV_OK;
+}
+
+extern "C" int afv_akaze_synchronize(afv_akaze *a) {
+    if (!a) return AFV_EINVAL;
+    AKZ_HIPCHK(a, hipSetDevice(a->device));
+    AKZ_HIPCHK(a, hipStreamSynchronize(a->stream));
+    return AFV_OK;
+}
+
+extern "C" int afv_akaze_get_plane(afv_akaze *a, int frame, int level, int which, float *out) {
+    if (!a || !out || frame < 0 || frame >= a->cur_frames || level < 0 || level >= a->plan.nlevels || a->cur_w == 0) return AFV_EINVAL;
+    const afv_akaze_level &L = a->plan.lv[level];
+    const float *base = nullptr;
+    switch (which) {
+        case AFV_AKZ_LT: base = a->lt[level]; break;
+        case AFV_AKZ_LSMOOTH: base = a->lsm[level]; break;
+        case AFV_AKZ_LX: base = a->lx[level]; break;
+        case AFV_AKZ_LY: base = a->ly[level]; break;
+        case AFV_AKZ_LDET: base = a->ldet[level]; break;
+        default: return AFV_EINVAL;
+    }
+    AKZ_HIPCHK(a, hipSetDevice(a->device));
+    AKZ_HIPCHK(a, hipStreamSynchronize(a->stream));
+    AKZ_HIPCHK(a, hipMemcpy(out, base + (size_t)frame * L.w * L.h, (size_t)L.w * L.h * sizeof(float), hipMemcpyDeviceToHost));
+    return AFV_OK;
+}
+
+extern "C" int afv_akaze_get_kcontrast(afv_akaze *a, int frame, float *out) {
+    if (!a || !out || frame < 0 || frame >= a->cur_frames) return AFV_EINVAL;
+    AKZ_HIPCHK(a, hipSetDevice(a->device));
+    AKZ_HIPCHK(a, hipStreamSynchronize(a->stream));
+    AKZ_HIPCHK(a, hipMemcpy(out, a->d_kcontrast + frame, sizeof(float), hipMemcpyDeviceToHost));
+    return AFV_OK;
+}
+
+extern "C" int afv_akaze_profile_enable(afv_akaze *a, int on) {
+    if (!a) return AFV_EINVAL;
+    a->profiling = on != 0;
+    a->ms_ss = a->ms_hess = 0;
+    a->launches = 0;
+    return AFV_OK;
+}
+
+extern "C" int afv_akaze_profile_read(afv_akaze *a, float *ms_scale_space, float *ms_hessian, int *launches) {
+    if (!a) return AFV_EINVAL;
+    if (ms_scale_space) *ms_scale_space = a->ms_ss;
+    if (ms_hessian) *ms_hessian = a->ms_hess;
+    if (launches) *launches = a->launches;
+    return AFV_OK;
+}

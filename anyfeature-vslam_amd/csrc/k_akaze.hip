@@ -1,0 +1,345 @@
+// k_akaze.hip — SURVEY §8f rank 4 (config #5): AKAZE nonlinear scale space + determinant-of-Hessian response.
+//
+// Replaces libAKAZE's Create_Nonlinear_Scale_Space and Compute_Determinant_Hessian_Response as driven by
+// FeatureExtractor_akaze61::initializeExtractor / detectKeypoints (Feature_akaze61.cpp:26-47).  The library is an absent
+// fork (fontan::akaze); the arithmetic follows upstream libAKAZE 1.5 with the explicit operation order written down in
+// oracle/akaze.c (parity unpinned against the fork, bit-exact against that restatement).
+//
+// All of it is float stencil work on planes of w x h x 4 B — the HBM-bound part of this path.  Every kernel owns a
+// 64 x 32 output tile per 256-thread workgroup, stages its inputs (+ halo, with the border rule of the OpenCV call it
+// replaces baked into the staging coordinates) in LDS with coalesced row reads, and writes each output once.
+// Batch layout: plane[frame][y][x], frame stride = w * h of the level.
+#include "afv_device.h"
+
+#define AT_W 64
+#define AT_H 32
+#define AKZ_T 256
+
+__device__ __forceinline__ int akz_clamp(int v, int n) { return min(max(v, 0), n - 1); }
+__device__ __forceinline__ int akz_reflect(int p, int n) {  // BORDER_REFLECT_101, any distance
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
+    return p;
+}
+
+// stage a (AT_W + 2R) x (AT_H + 2R) float tile around (x0, y0); REFLECT: reflect-101 coordinates, else clamped (replicate)
+template <int R, bool REFLECT>
+__device__ __forceinline__ void akz_stage(const float *__restrict__ src, int w, int h, int x0, int y0, float *lds) {
+    constexpr int LW = AT_W + 2 * R, LH = AT_H + 2 * R;
+    for (int i = threadIdx.x; i < LW * LH; i += AKZ_T) {
+        const int ly = i / LW, lx = i - ly * LW;
+        const int gx = REFLECT ? akz_reflect(x0 - R + lx, w) : akz_clamp(x0 - R + lx, w);
+        const int gy = REFLECT ? akz_reflect(y0 - R + ly, h) : akz_clamp(y0 - R + ly, h);
+        lds[i] = src[(size_t)gy * w + gx];
+    }
+}
+
+// ---- convertTo(CV_32F, 1/255) + GaussianBlur(ksize, sigma, BORDER_REPLICATE) ----
+// U8: source is the gray image (converted on the fly); else a float plane.  Symmetric separable filter, rows then columns,
+// s = k[r] * c + sum_j k[r + j] * (S[+j] + S[-j]).
+template <int R, bool U8>
+__global__ __launch_bounds__(AKZ_T) void k_akz_gauss(const void *__restrict__ src_v, int src_stride, size_t src_frame_stride, int w, int h,
+                                                     const float *__restrict__ taps, float *__restrict__ dst) {
+    constexpr int LW = AT_W + 2 * R, LH = AT_H + 2 * R;
+    __shared__ float s_in[LW * LH];
+    __shared__ float s_row[AT_W * LH];
+    __shared__ float s_k[2 * R + 1];
+    const int f = blockIdx.z, x0 = blockIdx.x * AT_W, y0 = blockIdx.y * AT_H;
+    if (threadIdx.x < 2 * R + 1) s_k[threadIdx.x] = taps[threadIdx.x];
+    if (U8) {
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(src_v) + (size_t)f * src_frame_stride;
+        const float a = (float)(1.0 / 255.0);
+        for (int i = threadIdx.x; i < LW * LH; i += AKZ_T) {
+            const int ly = i / LW, lx = i - ly * LW;
+            const int gx = akz_clamp(x0 - R + lx, w), gy = akz_clamp(y0 - R + ly, h);
+            s_in[i] = (float)src[(size_t)gy * src_stride + gx] * a;
+        }
+    } else {
+        akz_stage<R, false>(reinterpret_cast<const float *>(src_v) + (size_t)f * src_frame_stride, w, h, x0, y0, s_in);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < AT_W * LH; i += AKZ_T) {
+        const int ly = i / AT_W, lx = i - ly * AT_W;
+        const float *c = &s_in[ly * LW + lx + R];
+        float s = s_k[R] * c[0];
+#pragma unroll
+        for (int j = 1; j <= R; ++j) s += s_k[R + j] * (c[j] + c[-j]);
+        s_row[i] = s;
+    }
+    __syncthreads();
+    float *out = dst + (size_t)f * w * h;
+    for (int i = threadIdx.x; i < AT_W * AT_H; i += AKZ_T) {
+        const int ly = i / AT_W, lx = i - ly * AT_W;
+        const int gx = x0 + lx, gy = y0 + ly;
+        if (gx < w && gy < h) {
+            const float *c = &s_row[(ly + R) * AT_W + lx];
+            float s = s_k[R] * c[0];
+#pragma unroll
+            for (int j = 1; j <= R; ++j) s += s_k[R + j] * (c[j * AT_W] + c[-j * AT_W]);
+            out[(size_t)gy * w + gx] = s;
+        }
+    }
+}
+
+// cv::Scharr 3x3 on an LDS tile with pitch LW, centre pointer c
+__device__ __forceinline__ float akz_scharr_x(const float *c, int LW) {
+    const float t0 = c[-LW + 1] - c[-LW - 1], t1 = c[1] - c[-1], t2 = c[LW + 1] - c[LW - 1];
+    return 10.0f * t1 + 3.0f * (t0 + t2);
+}
+__device__ __forceinline__ float akz_scharr_y(const float *c, int LW) {
+    const float u0 = 10.0f * c[-LW] + 3.0f * (c[-LW - 1] + c[-LW + 1]);
+    const float u2 = 10.0f * c[LW] + 3.0f * (c[LW - 1] + c[LW + 1]);
+    return u2 - u0;
+}
+
+// ---- compute_k_percentile, pass 1: gradient magnitude of the sigma = 1 smoothed image over the interior; frame maximum ----
+__global__ __launch_bounds__(AKZ_T) void k_akz_modg(const float *__restrict__ gsm, int w, int h, float *__restrict__ modg,
+                                                    unsigned int *__restrict__ hmax_bits) {
+    constexpr int LW = AT_W + 2, LH = AT_H + 2;
+    __shared__ float s_in[LW * LH];
+    __shared__ unsigned int s_max;
+    const int f = blockIdx.z, x0 = blockIdx.x * AT_W, y0 = blockIdx.y * AT_H;
+    if (threadIdx.x == 0) s_max = 0;
+    akz_stage<1, true>(gsm + (size_t)f * w * h, w, h, x0, y0, s_in);
+    __syncthreads();
+    float *out = modg + (size_t)f * w * h;
+    unsigned int mx = 0;
+    for (int i = threadIdx.x; i < AT_W * AT_H; i += AKZ_T) {
+        const int ly = i / AT_W, lx = i - ly * AT_W;
+        const int gx = x0 + lx, gy = y0 + ly;
+        if (gx < w && gy < h) {
+            float m = 0.0f;
+            if (gx >= 1 && gx < w - 1 && gy >= 1 && gy < h - 1) {  // the histogram skips the 1 px border
+                const float *c = &s_in[(ly + 1) * LW + lx + 1];
+                const float lxv = akz_scharr_x(c, LW), lyv = akz_scharr_y(c, LW);
+                m = sqrtf(lxv * lxv + lyv * lyv);
+            }
+            out[(size_t)gy * w + gx] = m;
+            mx = max(mx, __float_as_uint(m));  // m >= 0: the bit pattern orders like the value
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned int)__shfl_xor((int)mx, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(&s_max, mx);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_max) atomicMax(&hmax_bits[f], s_max);
+}
+
+// pass 2: histogram of the non-zero magnitudes (bins depend on the frame maximum)
+__global__ __launch_bounds__(AKZ_T) void k_akz_hist(const float *__restrict__ modg, int w, int h, const unsigned int *__restrict__ hmax_bits,
+                                                    int nbins, int *__restrict__ hist /* [frame][nbins + 1]: bins, then npoints */) {
+    extern __shared__ int s_hist[];
+    const int f = blockIdx.y;
+    for (int i = threadIdx.x; i <= nbins; i += AKZ_T) s_hist[i] = 0;
+    __syncthreads();
+    const float hmax = __uint_as_float(hmax_bits[f]);
+    const float *src = modg + (size_t)f * w * h;
+    const int n = w * h;
+    for (int i = blockIdx.x * AKZ_T + threadIdx.x; i < n; i += gridDim.x * AKZ_T) {
+        const float m = src[i];
+        if (m != 0.0f) {
+            int nbin = (int)floorf((float)nbins * (m / hmax));
+            if (nbin == nbins) nbin--;
+            atomicAdd(&s_hist[nbin], 1);
+            atomicAdd(&s_hist[nbins], 1);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= nbins; i += AKZ_T)
+        if (s_hist[i]) atomicAdd(&hist[(size_t)f * (nbins + 1) + i], s_hist[i]);
+}
+
+// percentile walk (one thread per frame; 300 bins)
+__global__ void k_akz_kperc(const int *__restrict__ hist, const unsigned int *__restrict__ hmax_bits, int nbins, float perc, int nframes,
+                            float *__restrict__ kcontrast) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nframes) return;
+    const int *hh = hist + (size_t)f * (nbins + 1);
+    const float hmax = __uint_as_float(hmax_bits[f]);
+    const int nthreshold = (int)((float)hh[nbins] * perc);
+    int k = 0, nelements = 0;
+    for (k = 0; nelements < nthreshold && k < nbins; ++k) nelements += hh[k];
+    kcontrast[f] = (nelements < nthreshold || hmax == 0.0f) ? 0.03f : hmax * ((float)k / (float)nbins);
+}
+
+// ---- halfsample_image (INTER_AREA, exact factor 2) ----
+__global__ __launch_bounds__(AKZ_T) void k_akz_halfsample(const float *__restrict__ src, int w, int h, float *__restrict__ dst, int dw, int dh) {
+    const int f = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    const float *r0 = src + (size_t)f * w * h + (size_t)(2 * y) * w + 2 * x, *r1 = r0 + w;
+    const float2 a = *reinterpret_cast<const float2 *>(r0), b = *reinterpret_cast<const float2 *>(r1);
+    dst[(size_t)f * dw * dh + (size_t)y * dw + x] = ((a.x + a.y) + (b.x + b.y)) * 0.25f;
+}
+
+// ---- image_derivatives_scharr x 2 + pm_g2 ----
+__global__ __launch_bounds__(AKZ_T) void k_akz_flow(const float *__restrict__ lsm, int w, int h, const float *__restrict__ kcontrast,
+                                                    int octave, float *__restrict__ flow) {
+    constexpr int LW = AT_W + 2, LH = AT_H + 2;
+    __shared__ float s_in[LW * LH];
+    const int f = blockIdx.z, x0 = blockIdx.x * AT_W, y0 = blockIdx.y * AT_H;
+    akz_stage<1, true>(lsm + (size_t)f * w * h, w, h, x0, y0, s_in);
+    __syncthreads();
+    float k = kcontrast[f];
+    for (int i = 0; i < octave; ++i) k = k * 0.75f;  // `options_.kcontrast *= 0.75` once per octave change
+    const float k2inv = 1.0f / (k * k);
+    float *out = flow + (size_t)f * w * h;
+    for (int i = threadIdx.x; i < AT_W * AT_H; i += AKZ_T) {
+        const int ly = i / AT_W, lx = i - ly * AT_W;
+        const int gx = x0 + lx, gy = y0 + ly;
+        if (gx < w && gy < h) {
+            const float *c = &s_in[(ly + 1) * LW + lx + 1];
+            const float lxv = akz_scharr_x(c, LW), lyv = akz_scharr_y(c, LW);
+            out[(size_t)gy * w + gx] = 1.0f / (1.0f + (lxv * lxv + lyv * lyv) * k2inv);
+        }
+    }
+}
+
+// ---- nld_step_scalar: one explicit diffusion step, zero flux across the image border ----
+__global__ __launch_bounds__(AKZ_T) void k_akz_nld_step(const float *__restrict__ Lt, const float *__restrict__ flow, int w, int h, float tau,
+                                                        float *__restrict__ out) {
+    constexpr int LW = AT_W + 2, LH = AT_H + 2;
+    __shared__ float s_l[LW * LH], s_c[LW * LH];
+    const int f = blockIdx.z, x0 = blockIdx.x * AT_W, y0 = blockIdx.y * AT_H;
+    akz_stage<1, false>(Lt + (size_t)f * w * h, w, h, x0, y0, s_l);
+    akz_stage<1, false>(flow + (size_t)f * w * h, w, h, x0, y0, s_c);
+    __syncthreads();
+    const double hs = 0.5 * (double)tau;
+    float *o = out + (size_t)f * w * h;
+    for (int i = threadIdx.x; i < AT_W * AT_H; i += AKZ_T) {
+        const int ly = i / AT_W, lx = i - ly * AT_W;
+        const int gx = x0 + lx, gy = y0 + ly;
+        if (gx < w && gy < h) {
+            const int p = (ly + 1) * LW + lx + 1;
+            const float L = s_l[p], c = s_c[p];
+            const float xpos = gx + 1 < w ? (c + s_c[p + 1]) * (s_l[p + 1] - L) : 0.0f;
+            const float xneg = gx > 0 ? (s_c[p - 1] + c) * (L - s_l[p - 1]) : 0.0f;
+            const float ypos = gy + 1 < h ? (c + s_c[p + LW]) * (s_l[p + LW] - L) : 0.0f;
+            const float yneg = gy > 0 ? (s_c[p - LW] + c) * (L - s_l[p - LW]) : 0.0f;
+            const float sum = ((xpos - xneg) + ypos) - yneg;
+            o[(size_t)gy * w + gx] = L + (float)(hs * (double)sum);
+        }
+    }
+}
+
+// ---- Compute_Multiscale_Derivatives, first derivatives (unscaled): sparse 3-tap Scharr at distance s ----
+#define AKZ_MAX_S 8
+__global__ __launch_bounds__(AKZ_T) void k_akz_deriv1(const float *__restrict__ lsm, int w, int h, int s, float *__restrict__ dx,
+                                                      float *__restrict__ dy) {
+    extern __shared__ float s_in[];  // (AT_W + 2s) x (AT_H + 2s)
+    const int LW = AT_W + 2 * s, LH = AT_H + 2 * s;
+    const int f = blockIdx.z, x0 = blockIdx.x * AT_W, y0 = blockIdx.y * AT_H;
+    const float *src = lsm + (size_t)f * w * h;
+    for (int i = threadIdx.x; i < LW * LH; i += AKZ_T) {
+        const int ly = i / LW, lx = i - ly * LW;
+        s_in[i] = src[(size_t)akz_reflect(y0 - s + ly, h) * w + akz_reflect(x0 - s + lx, w)];
+    }
+    __syncthreads();
+    const float wgt = 10.0f / 3.0f, norm = 1.0f / (2.0f * (float)s * (wgt + 2.0f)), mid = wgt * norm;
+    for (int i = threadIdx.x; i < AT_W * AT_H; i += AKZ_T) {
+        const int ly = i / AT_W, lx = i - ly * AT_W;
+        const int gx = x0 + lx, gy = y0 + ly;
+        if (gx < w && gy < h) {
+            const float *c = &s_in[(ly + s) * LW + lx + s];
+            // Lx: row derivative, column smoothing
+            const float t0 = c[-s * LW + s] - c[-s * LW - s], t1 = c[s] - c[-s], t2 = c[s * LW + s] - c[s * LW - s];
+            const float vx = mid * t1 + norm * (t0 + t2);
+            // Ly: row smoothing, column derivative
+            const float u0 = mid * c[-s * LW] + norm * (c[-s * LW - s] + c[-s * LW + s]);
+            const float u2 = mid * c[s * LW] + norm * (c[s * LW - s] + c[s * LW + s]);
+            const size_t o = (size_t)f * w * h + (size_t)gy * w + gx;
+            dx[o] = vx;
+            dy[o] = u2 - u0;
+        }
+    }
+}
+
+// second derivatives from the unscaled first ones, the sigma_size normalisation and the determinant
+__global__ __launch_bounds__(AKZ_T) void k_akz_hessian(const float *__restrict__ dx, const float *__restrict__ dy, int w, int h, int s,
+                                                       float *__restrict__ Lx, float *__restrict__ Ly, float *__restrict__ Ldet) {
+    extern __shared__ float s_mem[];  // two (AT_W + 2s) x (AT_H + 2s) planes
+    const int LW = AT_W + 2 * s, LH = AT_H + 2 * s;
+    float *s_x = s_mem, *s_y = s_mem + LW * LH;
+    const int f = blockIdx.z, x0 = blockIdx.x * AT_W, y0 = blockIdx.y * AT_H;
+    const float *px = dx + (size_t)f * w * h, *py = dy + (size_t)f * w * h;
+    for (int i = threadIdx.x; i < LW * LH; i += AKZ_T) {
+        const int ly = i / LW, lx = i - ly * LW;
+        const size_t g = (size_t)akz_reflect(y0 - s + ly, h) * w + akz_reflect(x0 - s + lx, w);
+        s_x[i] = px[g];
+        s_y[i] = py[g];
+    }
+    __syncthreads();
+    const float wgt = 10.0f / 3.0f, norm = 1.0f / (2.0f * (float)s * (wgt + 2.0f)), mid = wgt * norm;
+    const float fs = (float)s, fs2 = (float)(s * s);
+    for (int i = threadIdx.x; i < AT_W * AT_H; i += AKZ_T) {
+        const int ly = i / AT_W, lx = i - ly * AT_W;
+        const int gx = x0 + lx, gy = y0 + ly;
+        if (gx < w && gy < h) {
+            const int p = (ly + s) * LW + lx + s;
+            const float *cx = &s_x[p], *cy = &s_y[p];
+            // Lxx = d/dx of Lx: row derivative, column smoothing
+            const float t0 = cx[-s * LW + s] - cx[-s * LW - s], t1 = cx[s] - cx[-s], t2 = cx[s * LW + s] - cx[s * LW - s];
+            const float lxx = (mid * t1 + norm * (t0 + t2)) * fs2;
+            // Lyy = d/dy of Ly: row smoothing, column derivative
+            const float u0 = mid * cy[-s * LW] + norm * (cy[-s * LW - s] + cy[-s * LW + s]);
+            const float u2 = mid * cy[s * LW] + norm * (cy[s * LW - s] + cy[s * LW + s]);
+            const float lyy = (u2 - u0) * fs2;
+            // Lxy = d/dy of Lx
+            const float v0 = mid * cx[-s * LW] + norm * (cx[-s * LW - s] + cx[-s * LW + s]);
+            const float v2 = mid * cx[s * LW] + norm * (cx[s * LW - s] + cx[s * LW + s]);
+            const float lxy = (v2 - v0) * fs2;
+            const size_t o = (size_t)f * w * h + (size_t)gy * w + gx;
+            Lx[o] = cx[0] * fs;
+            Ly[o] = cy[0] * fs;
+            Ldet[o] = lxx * lyy - lxy * lxy;
+        }
+    }
+}
+
+// ---------------- launchers ----------------
+static inline dim3 akz_grid(int w, int h, int nframes) { return dim3((w + AT_W - 1) / AT_W, (h + AT_H - 1) / AT_H, nframes); }
+
+extern "C" int afv_akz_launch_gauss(const void *src, int is_u8, int src_stride, size_t src_frame_stride, int w, int h, int nframes,
+                                    const float *taps, int ksize, float *dst, hipStream_t st) {
+    const dim3 g = akz_grid(w, h, nframes);
+    const int r = ksize / 2;
+#define AKZ_GAUSS_CASE(R)                                                                                                   \
+    case R:                                                                                                                 \
+        if (is_u8) hipLaunchKernelGGL((k_akz_gauss<R, true>), g, dim3(AKZ_T), 0, st, src, src_stride, src_frame_stride, w, h, taps, dst); \
+        else hipLaunchKernelGGL((k_akz_gauss<R, false>), g, dim3(AKZ_T), 0, st, src, src_stride, src_frame_stride, w, h, taps, dst);      \
+        return 0;
+    switch (r) {
+        AKZ_GAUSS_CASE(1) AKZ_GAUSS_CASE(2) AKZ_GAUSS_CASE(3) AKZ_GAUSS_CASE(4) AKZ_GAUSS_CASE(5) AKZ_GAUSS_CASE(6)
+        default: return -1;
+    }
+#undef AKZ_GAUSS_CASE
+}
+
+extern "C" void afv_akz_launch_kcontrast(const float *gsm, int w, int h, int nframes, float *modg, unsigned int *hmax_bits, int *hist,
+                                         int nbins, float perc, float *kcontrast, hipStream_t st) {
+    hipLaunchKernelGGL(k_akz_modg, akz_grid(w, h, nframes), dim3(AKZ_T), 0, st, gsm, w, h, modg, hmax_bits);
+    hipLaunchKernelGGL(k_akz_hist, dim3(64, nframes), dim3(AKZ_T), (size_t)(nbins + 1) * sizeof(int), st, modg, w, h, hmax_bits, nbins, hist);
+    hipLaunchKernelGGL(k_akz_kperc, dim3((nframes + 63) / 64), dim3(64), 0, st, hist, hmax_bits, nbins, perc, nframes, kcontrast);
+}
+
+extern "C" void afv_akz_launch_halfsample(const float *src, int w, int h, float *dst, int dw, int dh, int nframes, hipStream_t st) {
+    hipLaunchKernelGGL(k_akz_halfsample, dim3((dw + 63) / 64, (dh + 3) / 4, nframes), dim3(AKZ_T), 0, st, src, w, h, dst, dw, dh);
+}
+
+extern "C" void afv_akz_launch_flow(const float *lsm, int w, int h, int nframes, const float *kcontrast, int octave, float *flow,
+                                    hipStream_t st) {
+    hipLaunchKernelGGL(k_akz_flow, akz_grid(w, h, nframes), dim3(AKZ_T), 0, st, lsm, w, h, kcontrast, octave, flow);
+}
+
+extern "C" void afv_akz_launch_nld_step(const float *Lt, const float *flow, int w, int h, int nframes, float tau, float *out, hipStream_t st) {
+    hipLaunchKernelGGL(k_akz_nld_step, akz_grid(w, h, nframes), dim3(AKZ_T), 0, st, Lt, flow, w, h, tau, out);
+}
+
+extern "C" int afv_akz_launch_hessian(const float *lsm, int w, int h, int nframes, int s, float *dx, float *dy, float *Lx, float *Ly,
+                                      float *Ldet, hipStream_t st) {
+    if (s < 1 || s > AKZ_MAX_S) return -1;
+    const size_t plane = (size_t)(AT_W + 2 * s) * (AT_H + 2 * s) * sizeof(float);
+    hipLaunchKernelGGL(k_akz_deriv1, akz_grid(w, h, nframes), dim3(AKZ_T), plane, st, lsm, w, h, s, dx, dy);
+    hipLaunchKernelGGL(k_akz_hessian, akz_grid(w, h, nframes), dim3(AKZ_T), 2 * plane, st, dx, dy, w, h, s, Lx, Ly, Ldet);
+    return 0;
+}

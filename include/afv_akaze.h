@@ -1,0 +1,70 @@
+/* afv_akaze.h — C-ABI of the AKAZE61 path, same library as afv_hip.h (libafv_hip.so).
+ *
+ * Replaces what FeatureExtractor_akaze61 (reference src/Feature_akaze61.cpp:9-61) obtains from the un-vendored libAKAZE fork
+ * `fontan::akaze` (environment.yml:33): libAKAZE::AKAZE(options), Create_Nonlinear_Scale_Space, Feature_Detection,
+ * Compute_Descriptors.  PARITY UNPINNED against that fork; the arithmetic is upstream libAKAZE 1.5 as restated in
+ * oracle/akaze.c, and the HIP kernels are bit-exact against that restatement. */
+#ifndef AFV_AKAZE_H
+#define AFV_AKAZE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AFV_AKZ_MAX_LEVELS 16
+#define AFV_AKZ_MAX_FED 32
+
+typedef struct afv_akaze afv_akaze;
+
+/* AKAZEOptions as FeatureExtractor_akaze61's constructor fills them (Feature_akaze61.cpp:9-15) + capacities */
+typedef struct {
+    int32_t omax, nsublevels;       /* numOctaves / 4, numOctaves / 2 -> 2, 4 */
+    float soffset, derivative_factor;
+    float dthreshold, min_dthreshold; /* settings detectionTh = 0.0005 (settings/akaze61_settings.yaml:8) */
+    float kcontrast_percentile;
+    int32_t kcontrast_nbins;
+    int32_t max_width, max_height, max_batch;
+} afv_akaze_params;
+
+typedef struct {
+    int32_t w, h, octave, sublevel, sigma_size;
+    float esigma, etime;
+    int32_t nsteps;
+    float tau[AFV_AKZ_MAX_FED];
+} afv_akaze_level;
+
+typedef struct {
+    int32_t nlevels, w, h;
+    afv_akaze_level lv[AFV_AKZ_MAX_LEVELS];
+    float gauss_soffset[32]; int32_t ksize_soffset;
+    float gauss_one[8];      int32_t ksize_one;
+} afv_akaze_plan;
+
+enum { AFV_AKZ_LT = 0, AFV_AKZ_LSMOOTH = 1, AFV_AKZ_LX = 2, AFV_AKZ_LY = 3, AFV_AKZ_LDET = 4 };
+
+void afv_akaze_default_params(afv_akaze_params *p);                 /* the reference's akaze61 configuration, 1280 x 720, batch 1 */
+int afv_akaze_create(int device, const afv_akaze_params *p, afv_akaze **out);
+void afv_akaze_destroy(afv_akaze *a);
+const char *afv_akaze_last_error(const afv_akaze *a);
+/* AKAZE::Allocate_Memory_Evolution + FED time steps for a w x h image (host side, no GPU work) */
+int afv_akaze_plan_for(const afv_akaze_params *p, int w, int h, afv_akaze_plan *out);
+
+/* Create_Nonlinear_Scale_Space + Compute_Determinant_Hessian_Response for a batch of gray frames (host pointers:
+ * frame f starts at gray + f * frame_stride).  Results stay on the device for detection / description. */
+int afv_akaze_scale_space(afv_akaze *a, const uint8_t *gray, int nframes, int w, int h, int stride, size_t frame_stride);
+/* same with frames already in HBM; nothing is synchronised */
+int afv_akaze_scale_space_device(afv_akaze *a, const uint8_t *d_gray, int nframes, int w, int h, int stride, size_t frame_stride);
+int afv_akaze_synchronize(afv_akaze *a);
+
+/* test / inspection access (synchronises) */
+int afv_akaze_get_plane(afv_akaze *a, int frame, int level, int which, float *out);
+int afv_akaze_get_kcontrast(afv_akaze *a, int frame, float *out);
+/* per-stage timing like afv_profile_*: stage 0 scale space, 1 hessian */
+int afv_akaze_profile_enable(afv_akaze *a, int on);
+int afv_akaze_profile_read(afv_akaze *a, float *ms_scale_space, float *ms_hessian, int *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

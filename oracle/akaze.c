@@ -1,0 +1,283 @@
+/* oracle/akaze.c — see akaze.h.  PARITY UNPINNED (libAKAZE fork absent; restated from upstream libAKAZE 1.5).
+ * TEST INFRASTRUCTURE ONLY: nothing under anyfeature-vslam_amd/ may link or call this. */
+#include "akaze.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline int iclamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline int reflect101(int p, int n) {
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
+    return p;
+}
+static inline int f_round(float x) { return (int)(x + 0.5f); } /* libAKAZE fRound */
+
+void akz_default_options(akz_options *o) {
+    o->omax = 2; o->nsublevels = 4; o->soffset = 1.6f; o->derivative_factor = 1.5f; o->dthreshold = 0.0005f;
+    o->min_dthreshold = 0.00001f; o->kcontrast_percentile = 0.7f; o->kcontrast_nbins = 300;
+}
+
+/* ---- FED (libAKAZE fed.cpp) ---- */
+static int fed_is_prime(int n) {
+    if (n <= 1) return 0;
+    if (n == 2 || n == 3 || n == 5 || n == 7) return 1;
+    if (n % 2 == 0 || n % 3 == 0 || n % 5 == 0 || n % 7 == 0) return 0;
+    const int upper = (int)(sqrt((double)n + 1.0));
+    for (int d = 11; d <= upper; d += 2)
+        if (n % d == 0) return 0;
+    return 1;
+}
+static int fed_tau_internal(int n, float scale, float tau_max, float *tau) {
+    if (n <= 0) return 0;
+    float tauh[AKZ_MAX_FED];
+    const float c = 1.0f / (4.0f * (float)n + 2.0f);
+    const float d = scale * tau_max / 2.0f;
+    for (int k = 0; k < n; ++k) {
+        const float h = cosf(3.14159265358979323846f * (2.0f * (float)k + 1.0f) * c);
+        tauh[k] = d / (h * h);
+    }
+    /* reordering: kappa-cycle with the next prime >= n + 1 */
+    const int kappa = n / 2;
+    int prime = n + 1;
+    while (!fed_is_prime(prime)) prime++;
+    for (int k = 0, l = 0; l < n; ++k, ++l) {
+        int index;
+        while ((index = ((k + 1) * kappa) % prime - 1) >= n) k++;
+        tau[l] = tauh[index];
+    }
+    return n;
+}
+static int fed_tau_by_process_time(float T, int M, float tau_max, float *tau) {
+    const int n = (int)(ceilf(sqrtf(3.0f * T / ((float)M * tau_max) + 0.25f) - 0.5f - 1.0e-8f) + 0.5f);
+    if (n > AKZ_MAX_FED) return -1;
+    const float scale = 3.0f * T / (tau_max * (float)(n * (n + 1)));
+    return fed_tau_internal(n, scale, tau_max, tau);
+}
+
+/* cv::getGaussianKernel(n, sigma, CV_32F) for sigma > 0 */
+static void gauss_taps(float sigma, int n, float *k) {
+    const double s = (double)sigma, scale2x = -0.5 / (s * s);
+    double t[64], sum = 0;
+    for (int i = 0; i < n; ++i) {
+        const double x = i - (n - 1) * 0.5;
+        t[i] = exp(scale2x * x * x);
+        sum += t[i];
+    }
+    for (int i = 0; i < n; ++i) k[i] = (float)(t[i] / sum);
+}
+static int gauss_ksize(float sigma) { /* libAKAZE gaussian_2D_convolution with ksize 0 */
+    int ks = (int)ceilf(2.0f * (1.0f + (sigma - 0.8f) / 0.3f));
+    if ((ks % 2) == 0) ks += 1;
+    return ks;
+}
+
+int akz_make_plan(const akz_options *o, int w, int h, akz_plan *p) {
+    memset(p, 0, sizeof *p);
+    p->w = w; p->h = h;
+    int n = 0;
+    for (int i = 0; i < o->omax; ++i) {
+        const float rfactor = 1.0f / powf(2.0f, (float)i);
+        const int lh = (int)((float)h * rfactor), lw = (int)((float)w * rfactor);
+        if ((lw < 80 || lh < 40) && i != 0) break; /* smallest octave libAKAZE keeps */
+        for (int j = 0; j < o->nsublevels; ++j) {
+            if (n >= AKZ_MAX_LEVELS) return -1;
+            akz_level_info *L = &p->lv[n++];
+            L->w = lw; L->h = lh; L->octave = i; L->sublevel = j;
+            L->esigma = o->soffset * powf(2.0f, (float)j / (float)o->nsublevels + (float)i);
+            L->etime = 0.5f * (L->esigma * L->esigma);
+            L->sigma_size = f_round(L->esigma * o->derivative_factor / powf(2.0f, (float)i));
+        }
+    }
+    p->nlevels = n;
+    for (int i = 1; i < n; ++i) {
+        const float ttime = p->lv[i].etime - p->lv[i - 1].etime;
+        const int ns = fed_tau_by_process_time(ttime, 1, 0.25f, p->lv[i].tau);
+        if (ns < 0) return -1;
+        p->lv[i].nsteps = ns;
+    }
+    p->ksize_soffset = gauss_ksize(o->soffset);
+    p->ksize_one = gauss_ksize(1.0f);
+    if (p->ksize_soffset > 31 || p->ksize_one > 7) return -1;
+    gauss_taps(o->soffset, p->ksize_soffset, p->gauss_soffset);
+    gauss_taps(1.0f, p->ksize_one, p->gauss_one);
+    return 0;
+}
+
+/* img.grayImg.convertTo(img_32, CV_32F, 1.0/255.0, 0) (Feature_akaze61.cpp:28) */
+void akz_convert(const uint8_t *gray, int stride, int w, int h, float *dst) {
+    const float a = (float)(1.0 / 255.0);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) dst[(size_t)y * w + x] = (float)gray[(size_t)y * stride + x] * a;
+}
+
+/* cv::GaussianBlur(src, dst, ksize, sigma, sigma, BORDER_REPLICATE) as a symmetric separable float filter: rows then columns,
+ * s = k[r] * c + sum_{j=1..r} k[r+j] * (S[+j] + S[-j]) in that order */
+void akz_gauss(const float *src, int w, int h, const float *k, int ksize, float *dst) {
+    const int r = ksize / 2;
+    float *tmp = (float *)malloc(sizeof(float) * (size_t)w * h);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const float *row = src + (size_t)y * w;
+            float s = k[r] * row[x];
+            for (int j = 1; j <= r; ++j) s += k[r + j] * (row[iclamp(x + j, 0, w - 1)] + row[iclamp(x - j, 0, w - 1)]);
+            tmp[(size_t)y * w + x] = s;
+        }
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            float s = k[r] * tmp[(size_t)y * w + x];
+            for (int j = 1; j <= r; ++j)
+                s += k[r + j] * (tmp[(size_t)iclamp(y + j, 0, h - 1) * w + x] + tmp[(size_t)iclamp(y - j, 0, h - 1) * w + x]);
+            dst[(size_t)y * w + x] = s;
+        }
+    free(tmp);
+}
+
+/* cv::Scharr(src, dst, CV_32F, 1, 0) / (0, 1), BORDER_REFLECT_101: derivative [-1 0 1], smoothing [3 10 3] */
+static inline float scharr_x(const float *s, int w, int h, int x, int y) {
+    const int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w), ym = reflect101(y - 1, h), yp = reflect101(y + 1, h);
+    const float t0 = s[(size_t)ym * w + xp] - s[(size_t)ym * w + xm];
+    const float t1 = s[(size_t)y * w + xp] - s[(size_t)y * w + xm];
+    const float t2 = s[(size_t)yp * w + xp] - s[(size_t)yp * w + xm];
+    return 10.0f * t1 + 3.0f * (t0 + t2);
+}
+static inline float scharr_y(const float *s, int w, int h, int x, int y) {
+    const int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w), ym = reflect101(y - 1, h), yp = reflect101(y + 1, h);
+    const float u0 = 10.0f * s[(size_t)ym * w + x] + 3.0f * (s[(size_t)ym * w + xm] + s[(size_t)ym * w + xp]);
+    const float u2 = 10.0f * s[(size_t)yp * w + x] + 3.0f * (s[(size_t)yp * w + xm] + s[(size_t)yp * w + xp]);
+    return u2 - u0;
+}
+
+/* compute_k_percentile(img, perc, gscale = 1, nbins, 0, 0) */
+float akz_kcontrast(const float *img, int w, int h, const akz_plan *p, const akz_options *o) {
+    const int nbins = o->kcontrast_nbins;
+    float *g = (float *)malloc(sizeof(float) * (size_t)w * h);
+    akz_gauss(img, w, h, p->gauss_one, p->ksize_one, g);
+    float hmax = 0.0f;
+    for (int y = 1; y < h - 1; ++y)
+        for (int x = 1; x < w - 1; ++x) {
+            const float lx = scharr_x(g, w, h, x, y), ly = scharr_y(g, w, h, x, y);
+            const float m = sqrtf(lx * lx + ly * ly);
+            if (m > hmax) hmax = m;
+        }
+    int *hist = (int *)calloc((size_t)nbins, sizeof(int));
+    int npoints = 0;
+    for (int y = 1; y < h - 1; ++y)
+        for (int x = 1; x < w - 1; ++x) {
+            const float lx = scharr_x(g, w, h, x, y), ly = scharr_y(g, w, h, x, y);
+            const float m = sqrtf(lx * lx + ly * ly);
+            if (m != 0.0f) {
+                int nbin = (int)floorf((float)nbins * (m / hmax));
+                if (nbin == nbins) nbin--;
+                hist[nbin]++;
+                npoints++;
+            }
+        }
+    const int nthreshold = (int)((float)npoints * o->kcontrast_percentile);
+    int k = 0, nelements = 0;
+    for (k = 0; nelements < nthreshold && k < nbins; ++k) nelements += hist[k];
+    /* hmax == 0 (constant image): upstream would return 0 and turn the conductivity into NaN; keep its own fallback value */
+    float kperc = (nelements < nthreshold || hmax == 0.0f) ? 0.03f : hmax * ((float)k / (float)nbins);
+    free(hist); free(g);
+    return kperc;
+}
+
+/* halfsample_image: cv::resize(..., INTER_AREA) by exactly 2 = mean of the 2x2 block, ((a + b) + (c + d)) * 0.25f */
+void akz_halfsample(const float *src, int w, int h, float *dst, int dw, int dh) {
+    (void)h;
+    for (int y = 0; y < dh; ++y)
+        for (int x = 0; x < dw; ++x) {
+            const float *r0 = src + (size_t)(2 * y) * w + 2 * x, *r1 = r0 + w;
+            dst[(size_t)y * dw + x] = ((r0[0] + r0[1]) + (r1[0] + r1[1])) * 0.25f;
+        }
+}
+
+/* image_derivatives_scharr x2 + pm_g2: g = 1 / (1 + (Lx^2 + Ly^2) * (1 / k^2)) */
+void akz_flow_g2(const float *Ls, int w, int h, float k, float *flow) {
+    const float k2inv = 1.0f / (k * k);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const float lx = scharr_x(Ls, w, h, x, y), ly = scharr_y(Ls, w, h, x, y);
+            flow[(size_t)y * w + x] = 1.0f / (1.0f + (lx * lx + ly * ly) * k2inv);
+        }
+}
+
+/* nld_step_scalar: out = Lt + 0.5 * tau * div(c grad Lt); one-sided differences on the image border (zero flux) */
+void akz_nld_step(const float *L, const float *c, int w, int h, float tau, float *out) {
+    const double hs = 0.5 * (double)tau; /* upstream writes 0.5*stepsize*(...): the product is formed in double */
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const size_t i = (size_t)y * w + x;
+            const float xpos = x + 1 < w ? (c[i] + c[i + 1]) * (L[i + 1] - L[i]) : 0.0f;
+            const float xneg = x > 0 ? (c[i - 1] + c[i]) * (L[i] - L[i - 1]) : 0.0f;
+            const float ypos = y + 1 < h ? (c[i] + c[i + w]) * (L[i + w] - L[i]) : 0.0f;
+            const float yneg = y > 0 ? (c[i - w] + c[i]) * (L[i] - L[i - w]) : 0.0f;
+            const float sum = ((xpos - xneg) + ypos) - yneg; /* upstream: xpos-xneg + ypos-yneg, left to right */
+            out[i] = L[i] + (float)(hs * (double)sum);
+        }
+}
+
+/* compute_scharr_derivatives(src, dst, xorder, yorder, scale) for scale >= 2: 3 sparse taps at distance `scale`,
+ * derivative (-1, 0, 1), smoothing (norm, w * norm, norm), w = 10/3, norm = 1 / (2 * scale * (w + 2)); BORDER_REFLECT_101.
+ * sepFilter2D runs the row (x) kernel first, then the column kernel. */
+static void scharr_scaled(const float *src, int w, int h, int xorder, int scale, float *dst, float *tmp) {
+    const float wgt = 10.0f / 3.0f, norm = 1.0f / (2.0f * (float)scale * (wgt + 2.0f)), mid = wgt * norm;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const float a = src[(size_t)y * w + reflect101(x - scale, w)], b = src[(size_t)y * w + reflect101(x + scale, w)];
+            tmp[(size_t)y * w + x] = xorder ? (b - a) : (mid * src[(size_t)y * w + x] + norm * (a + b));
+        }
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const float a = tmp[(size_t)reflect101(y - scale, h) * w + x], b = tmp[(size_t)reflect101(y + scale, h) * w + x];
+            dst[(size_t)y * w + x] = xorder ? (mid * tmp[(size_t)y * w + x] + norm * (a + b)) : (b - a);
+        }
+}
+
+void akz_hessian(const float *Ls, int w, int h, int s, float *Lx, float *Ly, float *Ldet) {
+    const size_t n = (size_t)w * h;
+    float *tmp = (float *)malloc(sizeof(float) * n), *Lxx = (float *)malloc(sizeof(float) * n), *Lyy = (float *)malloc(sizeof(float) * n),
+          *Lxy = (float *)malloc(sizeof(float) * n);
+    scharr_scaled(Ls, w, h, 1, s, Lx, tmp);
+    scharr_scaled(Ls, w, h, 0, s, Ly, tmp);
+    scharr_scaled(Lx, w, h, 1, s, Lxx, tmp);
+    scharr_scaled(Ly, w, h, 0, s, Lyy, tmp);
+    scharr_scaled(Lx, w, h, 0, s, Lxy, tmp);
+    const float fs = (float)s, fs2 = (float)(s * s);
+    for (size_t i = 0; i < n; ++i) {
+        const float lxx = Lxx[i] * fs2, lyy = Lyy[i] * fs2, lxy = Lxy[i] * fs2;
+        Lx[i] = Lx[i] * fs;
+        Ly[i] = Ly[i] * fs;
+        Ldet[i] = lxx * lyy - lxy * lxy;
+    }
+    free(tmp); free(Lxx); free(Lyy); free(Lxy);
+}
+
+void akz_scale_space(const akz_plan *p, const akz_options *o, const uint8_t *gray, int stride, akz_planes *lv, float *k0) {
+    const int w = p->w, h = p->h;
+    float *img = (float *)malloc(sizeof(float) * (size_t)w * h);
+    akz_convert(gray, stride, w, h, img);
+    akz_gauss(img, w, h, p->gauss_soffset, p->ksize_soffset, lv[0].Lt);
+    memcpy(lv[0].Lsmooth, lv[0].Lt, sizeof(float) * (size_t)w * h);
+    float kc = akz_kcontrast(img, w, h, p, o);
+    if (k0) *k0 = kc;
+    free(img);
+    float *flow = (float *)malloc(sizeof(float) * (size_t)w * h), *pong = (float *)malloc(sizeof(float) * (size_t)w * h);
+    for (int i = 1; i < p->nlevels; ++i) {
+        const akz_level_info *L = &p->lv[i], *P = &p->lv[i - 1];
+        const size_t n = (size_t)L->w * L->h;
+        if (L->octave > P->octave) {
+            akz_halfsample(lv[i - 1].Lt, P->w, P->h, lv[i].Lt, L->w, L->h);
+            kc = kc * 0.75f;
+        } else {
+            memcpy(lv[i].Lt, lv[i - 1].Lt, sizeof(float) * n);
+        }
+        akz_gauss(lv[i].Lt, L->w, L->h, p->gauss_one, p->ksize_one, lv[i].Lsmooth);
+        akz_flow_g2(lv[i].Lsmooth, L->w, L->h, kc, flow);
+        for (int j = 0; j < L->nsteps; ++j) {
+            akz_nld_step(lv[i].Lt, flow, L->w, L->h, L->tau[j], pong);
+            memcpy(lv[i].Lt, pong, sizeof(float) * n);
+        }
+    }
+    free(flow); free(pong);
+}

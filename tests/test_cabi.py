@@ -1,4 +1,4 @@
-"""CPU: the C-ABI library loads, exports every symbol include/afv_hip.h declares, and fails loudly without a GPU."""
+"""CPU: the C-ABI library loads, exports every symbol include/afv_hip.h and include/afv_akaze.h declare, and fails loudly without a GPU."""
 import ctypes as C
 import os
 import re
@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared_functions():
-    text = open(os.path.join(ROOT, "include", "afv_hip.h")).read()
+    text = open(os.path.join(ROOT, "include", "afv_hip.h")).read() + open(os.path.join(ROOT, "include", "afv_akaze.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = re.findall(r"\b(afv_[a-z0-9_]+)\s*\(", text)
     return sorted(set(names))

@@ -1,0 +1,90 @@
+"""-m gpu: SURVEY 8f rank 4 — AKAZE61 (config #5).  HIP kernels vs the CPU restatement in oracle/akaze.c, stage by stage and
+end to end; bit-exact float parity (same expressions, one rounding per operator on both sides).  The libAKAZE fork the
+reference links is absent: parity against it is unpinned (oracle/akaze.h)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def akz():
+    from oracle import akaze_binding
+    return akaze_binding
+
+
+def _oracle_plan(akz, plan):
+    """feed the oracle the product's own evolution plan (sizes, FED steps, Gaussian taps): the stage comparisons below then do
+    not depend on host libm details; the plans themselves are compared in test_plan_matches_oracle"""
+    p = akz.Plan()
+    C.memmove(C.byref(p), C.byref(plan), C.sizeof(p))
+    return p
+
+
+def _frames(afv, w, h, seeds):
+    return np.stack([afv.synth.corners_batch(s, 1, w, h)[0] for s in seeds])
+
+
+def test_plan_matches_oracle(afv, akz):
+    prm = afv.akaze.default_params()
+    for (w, h) in ((1280, 720), (640, 480), (752, 480)):
+        plan = afv.akaze.plan_for(prm, w, h)
+        ref = akz.make_plan(w, h)
+        assert C.sizeof(plan) == C.sizeof(ref)
+        assert plan.nlevels == ref.nlevels == 8
+        for i in range(plan.nlevels):
+            a, b = plan.lv[i], ref.lv[i]
+            assert (a.w, a.h, a.octave, a.sublevel, a.sigma_size, a.nsteps) == (b.w, b.h, b.octave, b.sublevel, b.sigma_size, b.nsteps)
+            assert a.esigma == b.esigma and a.etime == b.etime
+            assert list(a.tau)[:a.nsteps] == list(b.tau)[:b.nsteps]
+        assert list(plan.gauss_soffset) == list(ref.gauss_soffset) and list(plan.gauss_one) == list(ref.gauss_one)
+    # FED cycle lengths of the reference configuration and their defining property: the steps add up to the evolution time
+    p = afv.akaze.plan_for(prm, 1280, 720)
+    assert [p.lv[i].nsteps for i in range(8)] == [0, 3, 3, 4, 4, 5, 6, 7]
+    for i in range(1, 8):
+        assert abs(sum(list(p.lv[i].tau)[:p.lv[i].nsteps]) - (p.lv[i].etime - p.lv[i - 1].etime)) < 1e-5
+
+
+@pytest.mark.parametrize("w,h", [(640, 480), (200, 120)])
+def test_scale_space_stages_bit_exact(afv, akz, w, h):
+    ctx = afv.AkazeContext(afv.akaze.default_params(max_width=w, max_height=h, max_batch=2))
+    frames = _frames(afv, w, h, (3, 4))
+    plan = ctx.scale_space(frames)
+    op = _oracle_plan(akz, plan)
+    for f in range(2):
+        levels, k0 = akz.scale_space(frames[f], op)
+        assert ctx.kcontrast(f) == np.float32(k0)
+        for i in range(plan.nlevels):
+            assert np.array_equal(ctx.plane(f, i, afv.akaze.LSMOOTH), levels[i]["Lsmooth"]), (f, i, "Lsmooth")
+            assert np.array_equal(ctx.plane(f, i, afv.akaze.LT), levels[i]["Lt"]), (f, i, "Lt")
+            lx, ly, ldet = akz.hessian(levels[i]["Lsmooth"], plan.lv[i].sigma_size)
+            assert np.array_equal(ctx.plane(f, i, afv.akaze.LX), lx), (f, i, "Lx")
+            assert np.array_equal(ctx.plane(f, i, afv.akaze.LY), ly), (f, i, "Ly")
+            assert np.array_equal(ctx.plane(f, i, afv.akaze.LDET), ldet), (f, i, "Ldet")
+    ctx.close()
+
+
+def test_scale_space_properties_at_config5_size(afv, akz):
+    """1280 x 720 (config #5): diffusion keeps the mean (zero-flux border) and obeys the maximum principle; a constant image
+    stays constant with zero response"""
+    ctx = afv.AkazeContext(afv.akaze.default_params(max_batch=2))
+    frames = _frames(afv, 1280, 720, (5,))
+    frames = np.concatenate([frames, np.full((1, 720, 1280), 77, np.uint8)])
+    plan = ctx.scale_space(frames)
+    lt0 = ctx.plane(0, 0, afv.akaze.LT)
+    for i in range(1, 4):
+        lt = ctx.plane(0, i, afv.akaze.LT)
+        assert abs(float(lt.mean(dtype=np.float64)) - float(lt0.mean(dtype=np.float64))) < 1e-5
+        assert lt.min() >= lt0.min() - 1e-6 and lt.max() <= lt0.max() + 1e-6
+        assert float(lt.var(dtype=np.float64)) < float(lt0.var(dtype=np.float64))
+    for i in range(plan.nlevels):
+        c = ctx.plane(1, i, afv.akaze.LT)
+        assert np.all(np.abs(c - np.float32(77) * np.float32(1.0 / 255.0)) < 1e-6)
+        assert np.all(np.abs(ctx.plane(1, i, afv.akaze.LDET)) < 1e-12)
+    # one level of the big frame against the oracle (the CPU restatement needs ~0.4 s for it)
+    op = _oracle_plan(akz, plan)
+    levels, _ = akz.scale_space(frames[0], op)
+    assert np.array_equal(ctx.plane(0, 7, afv.akaze.LT), levels[7]["Lt"])
+    ctx.close()
