@@ -98,6 +98,9 @@ SYMBOLS = {
     "afv_akaze_synchronize": (_i, [_vp]),
     "afv_akaze_get_plane": (_i, [_vp, _i, _i, _i, _vp]),
     "afv_akaze_get_kcontrast": (_i, [_vp, _i, _vp]),
+    "afv_akaze_detect": (_i, [_vp]),
+    "afv_akaze_get_keypoints": (_i, [_vp, _i, _vp, _i, _vp]),
+    "afv_akaze_get_candidates": (_i, [_vp, _i, _i, _vp, _i, _vp]),
     "afv_akaze_profile_enable": (_i, [_vp, _i]),
     "afv_akaze_profile_read": (_i, [_vp, _vp, _vp, _vp]),
     "afv_profile_enable": (_i, [_vp, _i]),

@@ -99,6 +99,25 @@ class AkazeContext:
         self.check(self.lib.afv_akaze_get_kcontrast(self.handle, frame, C.byref(v)), "afv_akaze_get_kcontrast")
         return float(v.value)
 
+    def detect(self):
+        """Feature_Detection on the current scale space (asynchronous)"""
+        self.check(self.lib.afv_akaze_detect(self.handle), "afv_akaze_detect")
+
+    def candidates(self, frame, level):
+        n = C.c_int()
+        self.check(self.lib.afv_akaze_get_candidates(self.handle, frame, level, None, 0, C.byref(n)), "afv_akaze_get_candidates")
+        out = np.zeros(max(n.value, 1), np.int32)
+        self.check(self.lib.afv_akaze_get_candidates(self.handle, frame, level, ptr(out), len(out), C.byref(n)), "afv_akaze_get_candidates")
+        return out[:n.value].copy()
+
+    def keypoints(self, frame=0):
+        from .extractor import KP_DTYPE
+        n = C.c_int()
+        self.check(self.lib.afv_akaze_get_keypoints(self.handle, frame, None, 0, C.byref(n)), "afv_akaze_get_keypoints")
+        out = np.zeros(max(n.value, 1), KP_DTYPE)
+        self.check(self.lib.afv_akaze_get_keypoints(self.handle, frame, ptr(out), len(out), C.byref(n)), "afv_akaze_get_keypoints")
+        return out[:n.value].copy()
+
     def profile_enable(self, on=True):
         self.check(self.lib.afv_akaze_profile_enable(self.handle, int(on)), "afv_akaze_profile_enable")
 

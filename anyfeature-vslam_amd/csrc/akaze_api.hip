@@ -22,6 +22,35 @@ extern "C" void afv_akz_launch_nld_step(const float *Lt, const float *flow, int 
 extern "C" int afv_akz_launch_hessian(const float *lsm, int w, int h, int nframes, int s, float *dx, float *dy, float *Lx, float *Ly,
                                       float *Ldet, hipStream_t st);
 
+// mirrors of the kernel-side structs in k_akaze_detect.hip
+struct AkdLevel {
+    int w, h, octave, sigma_size;
+    float psize, ratio;
+    const float *ldet;
+    int cand_off, cand_cap, row_off;
+};
+struct AkdParams {
+    int nlevels, W, H;
+    float dthreshold, min_dthreshold;
+    AkdLevel lv[16];
+    int cand_stride, rows_stride, gw, gh, entry_cap, kp_cap;
+};
+struct AkdState {
+    float *ex, *ey, *eresp;
+    int *elevel;
+    unsigned short *cells;
+    int *cell_cnt;
+    unsigned char *keep;
+};
+extern "C" void afv_akz_launch_candidates(const AkdParams *P, int nframes, int *row_count, int *row_start, int *cand, int *cand_count,
+                                          int *status, hipStream_t st);
+extern "C" void afv_akz_launch_suppress(const AkdParams *P, const AkdState *S, int nframes, const int *cand, const int *cand_count,
+                                        afv_keypoint *kps, int *kp_count, int *status, hipStream_t st);
+#define AKD_CELL 10.0f
+#define AKD_CELLCAP 32
+#define AKD_MAX_CELLS 12288
+#define AKD_ENTRY_CAP 65535
+
 struct afv_akaze {
     int device = 0;
     afv_akaze_params prm{};
@@ -39,6 +68,13 @@ struct afv_akaze {
     uint8_t *d_gray = nullptr;
     size_t gray_bytes = 0;
     int cur_w = 0, cur_h = 0, cur_frames = 0;
+    // detection
+    AkdParams dp{};
+    AkdState ds{};
+    int *d_row_count = nullptr, *d_row_start = nullptr, *d_cand = nullptr, *d_cand_count = nullptr, *d_kp_count = nullptr, *d_status = nullptr;
+    afv_keypoint *d_kps = nullptr;
+    size_t cand_stride_max = 0, rows_stride_max = 0;
+    bool have_scale_space = false, have_keypoints = false;
     bool profiling = false;
     hipEvent_t ev[3] = {};
     float ms_ss = 0, ms_hess = 0;
@@ -210,6 +246,29 @@ extern "C" int afv_akaze_create(int device, const afv_akaze_params *prm, afv_aka
     if (rc == AFV_OK) rc = akz_alloc(a, &a->d_hmax, B);
     if (rc == AFV_OK) rc = akz_alloc(a, &a->d_hist, B * (size_t)(prm->kcontrast_nbins + 1));
     if (rc == AFV_OK) rc = akz_alloc(a, &a->d_kcontrast, B);
+    {   // detection buffers sized for the largest frame
+        size_t cands = 0, rows = 0;
+        for (int i = 0; i < plan.nlevels; ++i) {
+            cands += (size_t)plan.lv[i].w * plan.lv[i].h / 8 + 64;
+            rows += (size_t)plan.lv[i].h;
+        }
+        a->cand_stride_max = cands;
+        a->rows_stride_max = rows;
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->d_row_count, rows * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->d_row_start, rows * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->d_cand, cands * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->d_cand_count, 16 * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->d_kp_count, B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->d_status, 1);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->d_kps, (size_t)AKD_ENTRY_CAP * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.ex, (size_t)AKD_ENTRY_CAP * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.ey, (size_t)AKD_ENTRY_CAP * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.eresp, (size_t)AKD_ENTRY_CAP * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.elevel, (size_t)AKD_ENTRY_CAP * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.keep, (size_t)AKD_ENTRY_CAP * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.cells, (size_t)2 * AKD_MAX_CELLS * AKD_CELLCAP * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.cell_cnt, (size_t)2 * AKD_MAX_CELLS * B);
+    }
     for (hipEvent_t &e : a->ev)
         if (rc == AFV_OK && hipEventCreate(&e) != hipSuccess) rc = AFV_EHIP;
     if (rc != AFV_OK) {
@@ -235,6 +294,8 @@ static int akz_enqueue(afv_akaze *a, const uint8_t *d_gray, int nframes, int w, 
         AKZ_HIPCHK(a, hipStreamSynchronize(a->stream));  // `taps` is a stack buffer
     }
     a->cur_frames = nframes;
+    a->have_scale_space = true;
+    a->have_keypoints = false;
     const afv_akaze_plan &P = a->plan;
     hipStream_t st = a->stream;
     const int nb = a->prm.kcontrast_nbins;
@@ -366,5 +427,89 @@ extern "C" int afv_akaze_profile_read(afv_akaze *a, float *ms_scale_space, float
     if (ms_scale_space) *ms_scale_space = a->ms_ss;
     if (ms_hessian) *ms_hessian = a->ms_hess;
     if (launches) *launches = a->launches;
+    return AFV_OK;
+}
+
+// ---- Feature_Detection ----
+static int akz_detect_enqueue(afv_akaze *a) {
+    if (!a->have_scale_space) return AFV_EINVAL;
+    const afv_akaze_plan &P = a->plan;
+    AkdParams &D = a->dp;
+    D = AkdParams{};
+    D.nlevels = P.nlevels; D.W = P.w; D.H = P.h;
+    D.dthreshold = a->prm.dthreshold; D.min_dthreshold = a->prm.min_dthreshold;
+    int coff = 0, roff = 0;
+    float max_size = 0;
+    for (int i = 0; i < P.nlevels; ++i) {
+        AkdLevel &L = D.lv[i];
+        L.w = P.lv[i].w; L.h = P.lv[i].h; L.octave = P.lv[i].octave;
+        L.psize = P.lv[i].esigma * a->prm.derivative_factor;
+        L.ratio = powf(2.0f, (float)P.lv[i].octave);
+        L.sigma_size = (int)(L.psize / L.ratio + 0.5f);
+        L.ldet = a->ldet[i];
+        L.cand_off = coff; L.cand_cap = L.w * L.h / 8 + 64; L.row_off = roff;
+        coff += L.cand_cap; roff += L.h;
+        max_size = std::max(max_size, L.psize);
+    }
+    D.cand_stride = coff; D.rows_stride = roff;
+    if ((size_t)coff > a->cand_stride_max || (size_t)roff > a->rows_stride_max) return AFV_EINVAL;
+    if (max_size > AKD_CELL) return AFV_EUNSUPPORTED;  // the 3 x 3 cell neighbourhood must cover a keypoint radius
+    D.gw = (int)((float)P.w / AKD_CELL) + 1; D.gh = (int)((float)P.h / AKD_CELL) + 1;
+    if (D.gw * D.gh > AKD_MAX_CELLS) return AFV_EUNSUPPORTED;
+    D.entry_cap = AKD_ENTRY_CAP; D.kp_cap = AKD_ENTRY_CAP;
+    hipStream_t st = a->stream;
+    AKZ_HIPCHK(a, hipMemsetAsync(a->d_status, 0, sizeof(int), st));
+    afv_akz_launch_candidates(&D, a->cur_frames, a->d_row_count, a->d_row_start, a->d_cand, a->d_cand_count, a->d_status, st);
+    afv_akz_launch_suppress(&D, &a->ds, a->cur_frames, a->d_cand, a->d_cand_count, a->d_kps, a->d_kp_count, a->d_status, st);
+    AKZ_HIPCHK(a, hipGetLastError());
+    a->have_keypoints = true;
+    return AFV_OK;
+}
+
+extern "C" int afv_akaze_detect(afv_akaze *a) {
+    if (!a) return AFV_EINVAL;
+    AKZ_HIPCHK(a, hipSetDevice(a->device));
+    return akz_detect_enqueue(a);
+}
+
+static int akz_status(afv_akaze *a) {
+    int st = 0;
+    AKZ_HIPCHK(a, hipStreamSynchronize(a->stream));
+    AKZ_HIPCHK(a, hipMemcpy(&st, a->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    if (st) {
+        a->last_error = st == 1 ? "candidate capacity exceeded" : st == 2 ? "grid cell capacity exceeded" : st == 3 ? "keypoint list capacity exceeded"
+                                                                                                                      : "output capacity exceeded";
+        return AFV_ECAPACITY;
+    }
+    return AFV_OK;
+}
+
+extern "C" int afv_akaze_get_candidates(afv_akaze *a, int frame, int level, int32_t *out_idx, int cap, int *n_out) {
+    if (!a || !n_out || frame < 0 || frame >= a->cur_frames || level < 0 || level >= a->plan.nlevels || !a->have_keypoints) return AFV_EINVAL;
+    AKZ_HIPCHK(a, hipSetDevice(a->device));
+    const int rc = akz_status(a);
+    if (rc) return rc;
+    int n = 0;
+    AKZ_HIPCHK(a, hipMemcpy(&n, a->d_cand_count + frame * 16 + level, sizeof(int), hipMemcpyDeviceToHost));
+    *n_out = n;
+    if (out_idx && n > 0) {
+        if (n > cap) return AFV_ECAPACITY;
+        AKZ_HIPCHK(a, hipMemcpy(out_idx, a->d_cand + (size_t)frame * a->dp.cand_stride + a->dp.lv[level].cand_off, (size_t)n * 4, hipMemcpyDeviceToHost));
+    }
+    return AFV_OK;
+}
+
+extern "C" int afv_akaze_get_keypoints(afv_akaze *a, int frame, afv_keypoint *out, int cap, int *n_out) {
+    if (!a || !n_out || frame < 0 || frame >= a->cur_frames || !a->have_keypoints) return AFV_EINVAL;
+    AKZ_HIPCHK(a, hipSetDevice(a->device));
+    const int rc = akz_status(a);
+    if (rc) return rc;
+    int n = 0;
+    AKZ_HIPCHK(a, hipMemcpy(&n, a->d_kp_count + frame, sizeof(int), hipMemcpyDeviceToHost));
+    *n_out = n;
+    if (out && n > 0) {
+        if (n > cap) return AFV_ECAPACITY;
+        AKZ_HIPCHK(a, hipMemcpy(out, a->d_kps + (size_t)frame * AKD_ENTRY_CAP, (size_t)n * sizeof(afv_keypoint), hipMemcpyDeviceToHost));
+    }
     return AFV_OK;
 }

@@ -8,6 +8,8 @@
 #define AFV_AKAZE_H
 #include <stddef.h>
 #include <stdint.h>
+
+#include "afv_hip.h" /* afv_keypoint, error codes */
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -56,6 +58,16 @@ int afv_akaze_scale_space(afv_akaze *a, const uint8_t *gray, int nframes, int w,
 /* same with frames already in HBM; nothing is synchronised */
 int afv_akaze_scale_space_device(afv_akaze *a, const uint8_t *d_gray, int nframes, int w, int h, int stride, size_t frame_stride);
 int afv_akaze_synchronize(afv_akaze *a);
+
+/* Feature_Detection on the scale space built by the last afv_akaze_scale_space* call: Find_Scale_Space_Extrema (ordered
+ * duplicate suppression, upper-level filter) + Do_Subpixel_Refinement; keypoints stay on the device (asynchronous). */
+int afv_akaze_detect(afv_akaze *a);
+/* keypoints of one frame in libAKAZE's output order: pt in level-0 pixels, size = 2 * esigma * derivative_factor, angle 0,
+ * response = |Ldet|, octave, class_id = evolution level (what FeatureExtractor_akaze61::GetKeypointOctave reads).
+ * out == NULL returns only the count. */
+int afv_akaze_get_keypoints(afv_akaze *a, int frame, afv_keypoint *out, int cap, int *n_out);
+/* raster-ordered local-maximum candidates of one level (index = y * w + x), for stage-by-stage tests */
+int afv_akaze_get_candidates(afv_akaze *a, int frame, int level, int32_t *out_idx, int cap, int *n_out);
 
 /* test / inspection access (synchronises) */
 int afv_akaze_get_plane(afv_akaze *a, int frame, int level, int which, float *out);

@@ -281,3 +281,181 @@ void akz_scale_space(const akz_plan *p, const akz_options *o, const uint8_t *gra
     }
     free(flow); free(pong);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Feature_Detection (libAKAZE AKAZE::Find_Scale_Space_Extrema / Do_Subpixel_Refinement)
+ * ---------------------------------------------------------------------------------------------- */
+static int is_out_of_bounds(float px, float py, int sigma_size, int w, int h) {
+    const float smax = 10.0f * sqrtf(2.0f); /* MLDB sampling reach */
+    const int left_x = f_round(px - smax * (float)sigma_size) - 1, right_x = f_round(px + smax * (float)sigma_size) + 1;
+    const int up_y = f_round(py - smax * (float)sigma_size) - 1, down_y = f_round(py + smax * (float)sigma_size) + 1;
+    return left_x < 0 || right_x >= w || up_y < 0 || down_y >= h;
+}
+
+int akz_level_candidates(const akz_plan *p, const akz_options *o, int level, const float *Ldet, int32_t *out_idx, int cap) {
+    const akz_level_info *L = &p->lv[level];
+    const int w = L->w, h = L->h;
+    const float psize = L->esigma * o->derivative_factor, ratio = powf(2.0f, (float)L->octave);
+    const int sigma_size = f_round(psize / ratio);
+    int n = 0;
+    for (int iy = 1; iy < h - 1; ++iy) {
+        const float *m = Ldet + (size_t)(iy - 1) * w, *c = m + w, *q = c + w;
+        for (int jx = 1; jx < w - 1; ++jx) {
+            const float v = c[jx];
+            if (v > o->dthreshold && v >= o->min_dthreshold && v > c[jx - 1] && v > c[jx + 1] && v > m[jx - 1] && v > m[jx] && v > m[jx + 1] &&
+                v > q[jx - 1] && v > q[jx] && v > q[jx + 1]) {
+                /* a point that fails the border test never changes kpts_aux, so it can be dropped before the ordered pass */
+                if (is_out_of_bounds((float)jx, (float)iy, sigma_size, w, h)) continue;
+                if (n < cap) out_idx[n] = iy * w + jx;
+                n++;
+            }
+        }
+    }
+    return n;
+}
+
+typedef struct { int *slot; int n, cap; } akz_cell;
+typedef struct { akz_cell *cells; int gw, gh; float cell; } akz_grid;
+static void grid_init(akz_grid *g, int w, int h, float cell) {
+    g->cell = cell; g->gw = (int)((float)w / cell) + 2; g->gh = (int)((float)h / cell) + 2;
+    g->cells = (akz_cell *)calloc((size_t)g->gw * g->gh, sizeof(akz_cell));
+}
+static void grid_free(akz_grid *g) {
+    for (int i = 0; i < g->gw * g->gh; ++i) free(g->cells[i].slot);
+    free(g->cells);
+}
+static akz_cell *grid_cell(akz_grid *g, float x, float y) {
+    int cx = (int)(x / g->cell), cy = (int)(y / g->cell);
+    cx = iclamp(cx, 0, g->gw - 1); cy = iclamp(cy, 0, g->gh - 1);
+    return &g->cells[cy * g->gw + cx];
+}
+static void grid_add(akz_grid *g, float x, float y, int slot) {
+    akz_cell *c = grid_cell(g, x, y);
+    if (c->n == c->cap) { c->cap = c->cap ? 2 * c->cap : 8; c->slot = (int *)realloc(c->slot, sizeof(int) * (size_t)c->cap); }
+    c->slot[c->n++] = slot;
+}
+static void grid_remove(akz_grid *g, float x, float y, int slot) {
+    akz_cell *c = grid_cell(g, x, y);
+    for (int i = 0; i < c->n; ++i)
+        if (c->slot[i] == slot) { c->slot[i] = c->slot[--c->n]; return; }
+}
+
+int akz_find_extrema(const akz_plan *p, const akz_options *o, const akz_planes *lv, akz_keypoint *out, int cap) {
+    const int W = p->w, H = p->h;
+    int aux_cap = 1 << 14, naux = 0;
+    akz_keypoint *aux = (akz_keypoint *)malloc(sizeof(akz_keypoint) * (size_t)aux_cap);
+    /* the linear "first entry in kpts_aux order that is close enough" scan of upstream, served from a uniform grid over
+     * level-0 coordinates: the first match is the smallest slot among the matches */
+    float max_size = 0;
+    for (int i = 0; i < p->nlevels; ++i) max_size = fmaxf(max_size, p->lv[i].esigma * o->derivative_factor);
+    akz_grid g;
+    grid_init(&g, W, H, max_size + 1.0f);
+    int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (size_t)W * H / 4 + 64);
+    for (int i = 0; i < p->nlevels; ++i) {
+        const akz_level_info *L = &p->lv[i];
+        const int nc = akz_level_candidates(p, o, i, lv[i].Ldet, cand, W * H / 4);
+        const float psize = L->esigma * o->derivative_factor, ratio = powf(2.0f, (float)L->octave);
+        for (int k = 0; k < nc; ++k) {
+            const int iy = cand[k] / L->w, jx = cand[k] - iy * L->w;
+            akz_keypoint pt;
+            pt.response = fabsf(lv[i].Ldet[cand[k]]);
+            pt.size = psize; pt.octave = L->octave; pt.class_id = i; pt.angle = 0;
+            pt.x = (float)jx; pt.y = (float)iy;
+            const float sx = pt.x * ratio, sy = pt.y * ratio;
+            int first = -1;
+            const int cx = (int)(sx / g.cell), cy = (int)(sy / g.cell);
+            for (int gy = cy - 1; gy <= cy + 1; ++gy)
+                for (int gx = cx - 1; gx <= cx + 1; ++gx) {
+                    if (gx < 0 || gy < 0 || gx >= g.gw || gy >= g.gh) continue;
+                    const akz_cell *c = &g.cells[gy * g.gw + gx];
+                    for (int e = 0; e < c->n; ++e) {
+                        const akz_keypoint *a = &aux[c->slot[e]];
+                        if ((pt.class_id - 1) == a->class_id || pt.class_id == a->class_id) {
+                            const float dist = (sx - a->x) * (sx - a->x) + (sy - a->y) * (sy - a->y);
+                            if (dist <= pt.size * pt.size && (first < 0 || c->slot[e] < first)) first = c->slot[e];
+                        }
+                    }
+                }
+            int is_extremum = 1, is_repeated = 0;
+            if (first >= 0) {
+                if (pt.response > aux[first].response) is_repeated = 1;
+                else is_extremum = 0;
+            }
+            if (!is_extremum) continue;
+            pt.x = sx; pt.y = sy; /* point.pt.x *= ratio */
+            if (!is_repeated) {
+                if (naux == aux_cap) { aux_cap *= 2; aux = (akz_keypoint *)realloc(aux, sizeof(akz_keypoint) * (size_t)aux_cap); }
+                aux[naux] = pt;
+                grid_add(&g, pt.x, pt.y, naux);
+                naux++;
+            } else {
+                grid_remove(&g, aux[first].x, aux[first].y, first);
+                aux[first] = pt;
+                grid_add(&g, pt.x, pt.y, first);
+            }
+        }
+    }
+    free(cand);
+    /* "Now filter points with the upper scale level" */
+    int n = 0;
+    for (int i = 0; i < naux; ++i) {
+        const akz_keypoint *a = &aux[i];
+        int is_repeated = 0;
+        const int cx = (int)(a->x / g.cell), cy = (int)(a->y / g.cell);
+        for (int gy = cy - 1; gy <= cy + 1 && !is_repeated; ++gy)
+            for (int gx = cx - 1; gx <= cx + 1 && !is_repeated; ++gx) {
+                if (gx < 0 || gy < 0 || gx >= g.gw || gy >= g.gh) continue;
+                const akz_cell *c = &g.cells[gy * g.gw + gx];
+                for (int e = 0; e < c->n; ++e) {
+                    const int j = c->slot[e];
+                    if (j <= i) continue;
+                    const akz_keypoint *b = &aux[j];
+                    if ((a->class_id + 1) == b->class_id) {
+                        const float dist = (a->x - b->x) * (a->x - b->x) + (a->y - b->y) * (a->y - b->y);
+                        if (dist <= a->size * a->size && a->response < b->response) { is_repeated = 1; break; }
+                    }
+                }
+            }
+        if (!is_repeated) {
+            if (n < cap) out[n] = *a;
+            n++;
+        }
+    }
+    grid_free(&g);
+    free(aux);
+    return n;
+}
+
+int akz_subpixel(const akz_plan *p, const akz_planes *lv, akz_keypoint *kpts, int n) {
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        akz_keypoint k = kpts[i];
+        const akz_level_info *L = &p->lv[k.class_id];
+        const float ratio = powf(2.0f, (float)k.octave);
+        const int x = f_round(k.x / ratio), y = f_round(k.y / ratio), w = L->w;
+        const float *D = lv[k.class_id].Ldet;
+#define LD(yy, xx) D[(size_t)(yy) * w + (xx)]
+        /* derivatives: upstream mixes double literals into float expressions; the roundings are kept */
+        const float Dx = (float)(0.5 * (double)(LD(y, x + 1) - LD(y, x - 1)));
+        const float Dy = (float)(0.5 * (double)(LD(y + 1, x) - LD(y - 1, x)));
+        const float Dxx = (float)((double)(LD(y, x + 1) + LD(y, x - 1)) - 2.0 * (double)LD(y, x));
+        const float Dyy = (float)((double)(LD(y + 1, x) + LD(y - 1, x)) - 2.0 * (double)LD(y, x));
+        const float Dxy = (float)(0.25 * (double)(LD(y + 1, x + 1) + LD(y - 1, x - 1)) - 0.25 * (double)(LD(y - 1, x + 1) + LD(y + 1, x - 1)));
+#undef LD
+        /* cv::solve(A, b, dst, DECOMP_LU) for a 2x2 float system: Cramer's rule in double */
+        const double det = (double)Dxx * (double)Dyy - (double)Dxy * (double)Dxy;
+        if (det == 0.0) continue; /* dst stays at its previous content upstream; a singular system has no refinement: dropped */
+        const double b0 = -(double)Dx, b1 = -(double)Dy, inv = 1.0 / det;
+        const float d0 = (float)((b0 * (double)Dyy - b1 * (double)Dxy) * inv);
+        const float d1 = (float)((b1 * (double)Dxx - b0 * (double)Dxy) * inv);
+        if (fabsf(d0) <= 1.0f && fabsf(d1) <= 1.0f) {
+            const int power = (int)powf(2.0f, (float)L->octave);
+            k.x = ((float)x + d0) * (float)power;
+            k.y = ((float)y + d1) * (float)power;
+            k.angle = 0.0f;
+            k.size = k.size * 2.0f;
+            kpts[m++] = k;
+        }
+    }
+    return m;
+}

@@ -64,6 +64,17 @@ void akz_nld_step(const float *Lt, const float *flow, int w, int h, float tau, f
 /* Compute_Multiscale_Derivatives + Compute_Determinant_Hessian_Response for one level */
 void akz_hessian(const float *Lsmooth, int w, int h, int sigma_size, float *Lx, float *Ly, float *Ldet);
 
+/* ---- Feature_Detection ---- */
+typedef struct { float x, y, size, angle, response; int32_t octave, class_id; } akz_keypoint; /* = cv::KeyPoint */
+/* local-maximum candidates of one level in raster order (Find_Scale_Space_Extrema's inner test incl. the descriptor-border test);
+ * out_xy[i] = y * w + x; returns the count (<= cap) */
+int akz_level_candidates(const akz_plan *p, const akz_options *o, int level, const float *Ldet, int32_t *out_idx, int cap);
+/* Find_Scale_Space_Extrema: ordered duplicate suppression across the same / lower level, then the upper-level filter.
+ * Keypoints come out in kpts_aux slot order with pt in level-0 pixels, size = esigma * derivative_factor, class_id = level. */
+int akz_find_extrema(const akz_plan *p, const akz_options *o, const akz_planes *lv, akz_keypoint *out, int cap);
+/* Do_Subpixel_Refinement: 2x2 solve on Ldet; drops points that move more than one pixel; size *= 2; returns the new count */
+int akz_subpixel(const akz_plan *p, const akz_planes *lv, akz_keypoint *kpts, int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -129,3 +129,51 @@ def scale_space(gray, plan=None, opts=None):
     k0 = C.c_float()
     lib().akz_scale_space(C.byref(plan), C.byref(opts), _p(gray), w, arr, C.byref(k0))
     return keep, float(k0.value)
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+
+
+def _planes_array(plan, levels, keys=("Lt", "Lsmooth", "Lx", "Ly", "Ldet")):
+    arr = (Planes * plan.nlevels)()
+    for i in range(plan.nlevels):
+        for k in keys:
+            if k in levels[i]:
+                setattr(arr[i], k, _p(levels[i][k]))
+    return arr
+
+
+def full_evolution(gray, plan=None, opts=None):
+    """scale space + multiscale derivatives: list of dict(Lt, Lsmooth, Lx, Ly, Ldet)"""
+    opts = opts or default_options()
+    gray = np.ascontiguousarray(gray, np.uint8)
+    plan = plan or make_plan(gray.shape[1], gray.shape[0], opts)
+    levels, k0 = scale_space(gray, plan, opts)
+    for i in range(plan.nlevels):
+        lx, ly, ldet = hessian(levels[i]["Lsmooth"], plan.lv[i].sigma_size)
+        levels[i].update(Lx=lx, Ly=ly, Ldet=ldet)
+    return levels, k0
+
+
+def level_candidates(plan, level, ldet, opts=None):
+    opts = opts or default_options()
+    ldet = np.ascontiguousarray(ldet, np.float32)
+    cap = ldet.size // 4 + 64
+    out = np.zeros(cap, np.int32)
+    n = lib().akz_level_candidates(C.byref(plan), C.byref(opts), int(level), _p(ldet), _p(out), cap)
+    return out[:n].copy()
+
+
+def find_extrema(plan, levels, opts=None, cap=200000):
+    opts = opts or default_options()
+    arr = _planes_array(plan, levels)
+    out = np.zeros(cap, KP_DTYPE)
+    n = lib().akz_find_extrema(C.byref(plan), C.byref(opts), arr, _p(out), cap)
+    return out[:n].copy()
+
+
+def subpixel(plan, levels, kpts):
+    arr = _planes_array(plan, levels)
+    kpts = np.ascontiguousarray(kpts, KP_DTYPE).copy()
+    n = lib().akz_subpixel(C.byref(plan), arr, _p(kpts), len(kpts))
+    return kpts[:n].copy()

@@ -88,3 +88,24 @@ def test_scale_space_properties_at_config5_size(afv, akz):
     levels, _ = akz.scale_space(frames[0], op)
     assert np.array_equal(ctx.plane(0, 7, afv.akaze.LT), levels[7]["Lt"])
     ctx.close()
+
+
+@pytest.mark.parametrize("w,h,seeds", [(640, 480, (3, 9)), (320, 200, (4,))])
+def test_detection_matches_oracle(afv, akz, w, h, seeds):
+    """candidates in raster order per level, then Find_Scale_Space_Extrema's ordered suppression / upper-level filter and the
+    sub-pixel refinement: same keypoints, same order, same floats"""
+    ctx = afv.AkazeContext(afv.akaze.default_params(max_width=w, max_height=h, max_batch=len(seeds)))
+    frames = _frames(afv, w, h, seeds)
+    plan = ctx.scale_space(frames)
+    ctx.detect()
+    op = _oracle_plan(akz, plan)
+    for f in range(len(seeds)):
+        levels, _ = akz.full_evolution(frames[f], op)
+        for i in range(plan.nlevels):
+            assert np.array_equal(ctx.candidates(f, i), akz.level_candidates(op, i, levels[i]["Ldet"])), (f, i)
+        want = akz.subpixel(op, levels, akz.find_extrema(op, levels))
+        got = ctx.keypoints(f)
+        assert len(got) == len(want) and len(want) > 500
+        for name in ("x", "y", "size", "angle", "response", "octave", "class_id"):
+            assert np.array_equal(got[name], want[name]), (f, name)
+    ctx.close()
