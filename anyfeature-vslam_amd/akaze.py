@@ -14,7 +14,8 @@ LT, LSMOOTH, LX, LY, LDET = 0, 1, 2, 3, 4
 class AkazeParams(C.Structure):
     _fields_ = [("omax", C.c_int32), ("nsublevels", C.c_int32), ("soffset", C.c_float), ("derivative_factor", C.c_float),
                 ("dthreshold", C.c_float), ("min_dthreshold", C.c_float), ("kcontrast_percentile", C.c_float),
-                ("kcontrast_nbins", C.c_int32), ("max_width", C.c_int32), ("max_height", C.c_int32), ("max_batch", C.c_int32)]
+                ("kcontrast_nbins", C.c_int32), ("max_width", C.c_int32), ("max_height", C.c_int32), ("max_batch", C.c_int32),
+                ("nfeatures", C.c_int32), ("scale_factor", C.c_float)]
 
 
 class AkazeLevel(C.Structure):
@@ -27,7 +28,7 @@ class AkazePlan(C.Structure):
                 ("gauss_soffset", C.c_float * 32), ("ksize_soffset", C.c_int32), ("gauss_one", C.c_float * 8), ("ksize_one", C.c_int32)]
 
 
-def default_params(num_octaves=8, detection_th=0.0005, max_width=1280, max_height=720, max_batch=1):
+def default_params(num_octaves=8, detection_th=0.0005, max_width=1280, max_height=720, max_batch=1, nfeatures=1000, scale_factor=1.1892):
     """AKAZEOptions as FeatureExtractor_akaze61's constructor sets them (Feature_akaze61.cpp:9-15) from
     settings/akaze61_settings.yaml (numOctaves 8, detectionTh 0.0005)"""
     p = AkazeParams()
@@ -36,6 +37,7 @@ def default_params(num_octaves=8, detection_th=0.0005, max_width=1280, max_heigh
     p.nsublevels = num_octaves // 2
     p.dthreshold = detection_th
     p.max_width, p.max_height, p.max_batch = max_width, max_height, max_batch
+    p.nfeatures, p.scale_factor = nfeatures, scale_factor
     return p
 
 
@@ -117,6 +119,43 @@ class AkazeContext:
         out = np.zeros(max(n.value, 1), KP_DTYPE)
         self.check(self.lib.afv_akaze_get_keypoints(self.handle, frame, ptr(out), len(out), C.byref(n)), "afv_akaze_get_keypoints")
         return out[:n.value].copy()
+
+    def describe(self):
+        self.check(self.lib.afv_akaze_describe(self.handle), "afv_akaze_describe")
+
+    def features(self, frame=0):
+        from .extractor import KP_DTYPE
+        n = C.c_int()
+        self.check(self.lib.afv_akaze_get_features(self.handle, frame, None, None, 0, C.byref(n)), "afv_akaze_get_features")
+        kps = np.zeros(max(n.value, 1), KP_DTYPE); desc = np.zeros((max(n.value, 1), 61), np.uint8)
+        self.check(self.lib.afv_akaze_get_features(self.handle, frame, ptr(kps), ptr(desc), len(kps), C.byref(n)), "afv_akaze_get_features")
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def quotas(self):
+        q = np.zeros(16, np.int32)
+        self.check(self.lib.afv_akaze_get_quotas(self.handle, ptr(q)), "afv_akaze_get_quotas")
+        return q
+
+    def extract(self, frames):
+        """FeatureExtractor_akaze61::detectAndCompute for (H, W) or (B, H, W) uint8 frames -> list of (keypoints, N x 61 descriptors)"""
+        from .extractor import KP_DTYPE
+        frames = np.ascontiguousarray(frames, np.uint8)
+        single = frames.ndim == 2
+        if single:
+            frames = frames[None]
+        b, h, w = frames.shape
+        cap = self.params.nfeatures + 3 * 16
+        kps = np.zeros((b, cap), KP_DTYPE); desc = np.zeros((b, cap, 61), np.uint8); n = np.zeros(b, np.int32)
+        self.check(self.lib.afv_akaze_extract(self.handle, ptr(frames), b, w, h, w, w * h, ptr(kps), ptr(desc), cap, ptr(n)), "afv_akaze_extract")
+        self.plan = plan_for(self.params, w, h)
+        out = [(kps[f, :n[f]].copy(), desc[f, :n[f]].copy()) for f in range(b)]
+        return out[0] if single else out
+
+    def extract_device(self, frames_t):
+        b, h, w = frames_t.shape
+        self.check(self.lib.afv_akaze_extract_device(self.handle, C.c_void_p(frames_t.data_ptr()), b, w, h, w, w * h), "afv_akaze_extract_device")
+        if self.plan is None or (self.plan.w, self.plan.h) != (w, h):
+            self.plan = plan_for(self.params, w, h)
 
     def profile_enable(self, on=True):
         self.check(self.lib.afv_akaze_profile_enable(self.handle, int(on)), "afv_akaze_profile_enable")

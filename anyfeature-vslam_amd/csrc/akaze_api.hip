@@ -46,6 +46,26 @@ extern "C" void afv_akz_launch_candidates(const AkdParams *P, int nframes, int *
                                           int *status, hipStream_t st);
 extern "C" void afv_akz_launch_suppress(const AkdParams *P, const AkdState *S, int nframes, const int *cand, const int *cand_count,
                                         afv_keypoint *kps, int *kp_count, int *status, hipStream_t st);
+struct AksParams {
+    int nlevels, W, H, n_ini;
+    float h_x;
+    int quota[16];
+    int kp_cap, sel_cap, out_cap, M;
+};
+struct AkdLevelPlanes {
+    const float *lt, *lx, *ly;
+    int w, h, octave;
+};
+struct AkdDescParams {
+    int nlevels, kp_cap, sel_cap, out_cap, desc_pitch;
+    AkdLevelPlanes lv[16];
+};
+extern "C" size_t afv_akz_select_lds_bytes(int M);
+extern "C" void afv_akz_launch_select(const AksParams *P, int nframes, const afv_keypoint *kps, const int *kp_count, int *lvl_idx,
+                                      uint16_t *lvl_node, int *sel, int *sel_count, hipStream_t st);
+extern "C" void afv_akz_launch_describe(const AkdDescParams *P, int nframes, int max_out, const afv_keypoint *kps, const int *sel,
+                                        const int *sel_count, afv_keypoint *out_kps, uint8_t *out_desc, int *out_count, int *status,
+                                        hipStream_t st);
 #define AKD_CELL 10.0f
 #define AKD_CELLCAP 32
 #define AKD_MAX_CELLS 12288
@@ -74,7 +94,14 @@ struct afv_akaze {
     int *d_row_count = nullptr, *d_row_start = nullptr, *d_cand = nullptr, *d_cand_count = nullptr, *d_kp_count = nullptr, *d_status = nullptr;
     afv_keypoint *d_kps = nullptr;
     size_t cand_stride_max = 0, rows_stride_max = 0;
-    bool have_scale_space = false, have_keypoints = false;
+    bool have_scale_space = false, have_keypoints = false, have_descriptors = false;
+    // plugin tail: quadtree filter + descriptors
+    int *d_lvl_idx = nullptr, *d_sel = nullptr, *d_sel_count = nullptr, *d_out_count = nullptr;
+    uint16_t *d_lvl_node = nullptr;
+    afv_keypoint *d_out_kps = nullptr;
+    uint8_t *d_out_desc = nullptr;
+    int sel_cap = 0, out_cap = 0, qt_M = 0;
+    int quota[16] = {};
     bool profiling = false;
     hipEvent_t ev[3] = {};
     float ms_ss = 0, ms_hess = 0;
@@ -145,6 +172,7 @@ extern "C" void afv_akaze_default_params(afv_akaze_params *p) {
     p->omax = 2; p->nsublevels = 4; p->soffset = 1.6f; p->derivative_factor = 1.5f;
     p->dthreshold = 0.0005f; p->min_dthreshold = 0.00001f; p->kcontrast_percentile = 0.7f; p->kcontrast_nbins = 300;
     p->max_width = 1280; p->max_height = 720; p->max_batch = 1;
+    p->nfeatures = 1000; p->scale_factor = 1.1892f;  // Tracking.cc:1515-1520, settings/akaze61_settings.yaml:7
 }
 
 extern "C" int afv_akaze_plan_for(const afv_akaze_params *o, int w, int h, afv_akaze_plan *p) {
@@ -211,7 +239,9 @@ extern "C" int afv_akaze_create(int device, const afv_akaze_params *prm, afv_aka
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return AFV_ENODEV;  // no CPU fallback: fail loudly
     if (device < 0 || device >= ndev) return AFV_ENODEV;
-    if (prm->max_batch < 1 || prm->max_width < 80 || prm->max_height < 40) return AFV_EINVAL;
+    if (prm->max_batch < 1 || prm->max_width < 80 || prm->max_height < 40 || prm->nfeatures < 1 || prm->nfeatures > 8000 ||
+        !(prm->scale_factor > 1.0f))
+        return AFV_EINVAL;
     afv_akaze_plan plan;
     int rc = afv_akaze_plan_for(prm, prm->max_width, prm->max_height, &plan);
     if (rc) return rc;
@@ -268,6 +298,30 @@ extern "C" int afv_akaze_create(int device, const afv_akaze_params *prm, afv_aka
         if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.keep, (size_t)AKD_ENTRY_CAP * B);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.cells, (size_t)2 * AKD_MAX_CELLS * AKD_CELLCAP * B);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.cell_cnt, (size_t)2 * AKD_MAX_CELLS * B);
+    }
+    {   // quadtree quotas (FeatureExtractor.cpp:97-108) for nfeatures / scaleFactor / nlevels of the akaze61 settings
+        const int nl = plan.nlevels;
+        const float factor = 1.0f / prm->scale_factor;
+        float desired = (float)prm->nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nl));
+        int sum = 0, qmax = 0;
+        for (int l = 0; l < nl - 1; ++l) {
+            a->quota[l] = (int)lrintf(desired);  // cvRound
+            sum += a->quota[l];
+            desired *= factor;
+        }
+        a->quota[nl - 1] = std::max(prm->nfeatures - sum, 0);
+        for (int l = 0; l < nl; ++l) qmax = std::max(qmax, a->quota[l]);
+        a->sel_cap = qmax + 3;
+        a->out_cap = prm->nfeatures + 3 * nl;
+        a->qt_M = (std::max(qmax + 8, 4 * 16 + 8) + 63) / 64 * 64;
+        if (afv_akz_select_lds_bytes(a->qt_M) > 150 * 1024) rc = AFV_EUNSUPPORTED;
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->d_lvl_idx, (size_t)nl * AKD_ENTRY_CAP * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->d_lvl_node, (size_t)nl * AKD_ENTRY_CAP * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->d_sel, (size_t)nl * a->sel_cap * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->d_sel_count, 16 * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->d_out_count, B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->d_out_kps, (size_t)a->out_cap * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->d_out_desc, (size_t)a->out_cap * 64 * B);
     }
     for (hipEvent_t &e : a->ev)
         if (rc == AFV_OK && hipEventCreate(&e) != hipSuccess) rc = AFV_EHIP;
@@ -463,6 +517,7 @@ static int akz_detect_enqueue(afv_akaze *a) {
     afv_akz_launch_suppress(&D, &a->ds, a->cur_frames, a->d_cand, a->d_cand_count, a->d_kps, a->d_kp_count, a->d_status, st);
     AKZ_HIPCHK(a, hipGetLastError());
     a->have_keypoints = true;
+    a->have_descriptors = false;
     return AFV_OK;
 }
 
@@ -511,5 +566,84 @@ extern "C" int afv_akaze_get_keypoints(afv_akaze *a, int frame, afv_keypoint *ou
         if (n > cap) return AFV_ECAPACITY;
         AKZ_HIPCHK(a, hipMemcpy(out, a->d_kps + (size_t)frame * AKD_ENTRY_CAP, (size_t)n * sizeof(afv_keypoint), hipMemcpyDeviceToHost));
     }
+    return AFV_OK;
+}
+
+// ---- plugin tail: filterKeypoints (quadtree per level) + computeDescriptors + mergeKeypointLevels ----
+static int akz_describe_enqueue(afv_akaze *a) {
+    if (!a->have_keypoints) return AFV_EINVAL;
+    const afv_akaze_plan &P = a->plan;
+    AksParams S{};
+    S.nlevels = P.nlevels; S.W = P.w; S.H = P.h;
+    S.n_ini = (int)roundf((float)P.w / (float)P.h);  // ORBextractor.cc:243
+    if (S.n_ini < 1 || S.n_ini > 16) return AFV_EUNSUPPORTED;
+    S.h_x = (float)P.w / (float)S.n_ini;
+    for (int l = 0; l < P.nlevels; ++l) S.quota[l] = a->quota[l];
+    S.kp_cap = AKD_ENTRY_CAP; S.sel_cap = a->sel_cap; S.out_cap = a->out_cap; S.M = a->qt_M;
+    AkdDescParams D{};
+    D.nlevels = P.nlevels; D.kp_cap = AKD_ENTRY_CAP; D.sel_cap = a->sel_cap; D.out_cap = a->out_cap; D.desc_pitch = 64;
+    for (int l = 0; l < P.nlevels; ++l) D.lv[l] = AkdLevelPlanes{a->lt[l], a->lx[l], a->ly[l], P.lv[l].w, P.lv[l].h, P.lv[l].octave};
+    hipStream_t st = a->stream;
+    afv_akz_launch_select(&S, a->cur_frames, a->d_kps, a->d_kp_count, a->d_lvl_idx, a->d_lvl_node, a->d_sel, a->d_sel_count, st);
+    afv_akz_launch_describe(&D, a->cur_frames, a->out_cap, a->d_kps, a->d_sel, a->d_sel_count, a->d_out_kps, a->d_out_desc, a->d_out_count,
+                            a->d_status, st);
+    AKZ_HIPCHK(a, hipGetLastError());
+    a->have_descriptors = true;
+    return AFV_OK;
+}
+
+extern "C" int afv_akaze_describe(afv_akaze *a) {
+    if (!a) return AFV_EINVAL;
+    AKZ_HIPCHK(a, hipSetDevice(a->device));
+    return akz_describe_enqueue(a);
+}
+
+extern "C" int afv_akaze_get_features(afv_akaze *a, int frame, afv_keypoint *kps, uint8_t *desc61, int cap, int *n_out) {
+    if (!a || !n_out || frame < 0 || frame >= a->cur_frames || !a->have_descriptors) return AFV_EINVAL;
+    AKZ_HIPCHK(a, hipSetDevice(a->device));
+    const int rc = akz_status(a);
+    if (rc) return rc;
+    int n = 0;
+    AKZ_HIPCHK(a, hipMemcpy(&n, a->d_out_count + frame, sizeof(int), hipMemcpyDeviceToHost));
+    *n_out = n;
+    if (n > 0 && (kps || desc61)) {
+        if (n > cap) return AFV_ECAPACITY;
+        if (kps) AKZ_HIPCHK(a, hipMemcpy(kps, a->d_out_kps + (size_t)frame * a->out_cap, (size_t)n * sizeof(afv_keypoint), hipMemcpyDeviceToHost));
+        if (desc61)
+            AKZ_HIPCHK(a, hipMemcpy2D(desc61, 61, a->d_out_desc + (size_t)frame * a->out_cap * 64, 64, 61, (size_t)n, hipMemcpyDeviceToHost));
+    }
+    return AFV_OK;
+}
+
+// FeatureExtractor_akaze61::detectAndCompute for a batch of host frames (Feature_akaze61.cpp:17-24 after initializeExtractor)
+extern "C" int afv_akaze_extract(afv_akaze *a, const uint8_t *gray, int nframes, int w, int h, int stride, size_t frame_stride,
+                                 afv_keypoint *kps, uint8_t *desc61, int cap_per_frame, int32_t *n_out) {
+    if (!a || !n_out || !kps || !desc61 || cap_per_frame < 1) return AFV_EINVAL;
+    int rc = afv_akaze_scale_space(a, gray, nframes, w, h, stride, frame_stride);
+    if (rc) return rc;
+    rc = akz_detect_enqueue(a);
+    if (rc) return rc;
+    rc = akz_describe_enqueue(a);
+    if (rc) return rc;
+    for (int f = 0; f < nframes; ++f) {
+        int n = 0;
+        rc = afv_akaze_get_features(a, f, kps + (size_t)f * cap_per_frame, desc61 + (size_t)f * cap_per_frame * 61, cap_per_frame, &n);
+        n_out[f] = n;
+        if (rc) return rc;
+    }
+    return AFV_OK;
+}
+
+extern "C" int afv_akaze_extract_device(afv_akaze *a, const uint8_t *d_gray, int nframes, int w, int h, int stride, size_t frame_stride) {
+    int rc = afv_akaze_scale_space_device(a, d_gray, nframes, w, h, stride, frame_stride);
+    if (rc) return rc;
+    rc = akz_detect_enqueue(a);
+    if (rc) return rc;
+    return akz_describe_enqueue(a);
+}
+
+extern "C" int afv_akaze_get_quotas(const afv_akaze *a, int32_t *quota16) {
+    if (!a || !quota16) return AFV_EINVAL;
+    for (int l = 0; l < 16; ++l) quota16[l] = a->quota[l];
     return AFV_OK;
 }

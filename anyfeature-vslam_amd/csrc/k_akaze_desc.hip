@@ -1,0 +1,302 @@
+// k_akaze_desc.hip — AKAZE61 plugin tail: per-level quadtree filter + Compute_Descriptors.
+//
+//  k_akz_select   = FeatureExtractor_akaze61::detectKeypoints' bucketing by class_id (Feature_akaze61.cpp:43-46) +
+//                   filterKeypoints -> FeatureExtractor::filterKeypoints_notScaled -> DistributeOctTree
+//                   (Feature_akaze61.cpp:63-65, FeatureExtractor.cpp:276-284, ORBextractor.cc:239-458): one workgroup per
+//                   (frame, level), quadtree core shared with the ORB path (afv_quadtree.h).
+//  k_akz_describe = libAKAZE Compute_Main_Orientation + Get_MLDB_Full_Descriptor (486 bits, 3 channels), one wavefront per
+//                   surviving keypoint, in the order mergeKeypointLevels produces (levels ascending, list order inside).
+// Float sums are order sensitive, so every accumulation below runs in upstream's loop order inside one lane: the 42
+// orientation windows and the 29 MLDB grid cells are spread over lanes, their inner sums stay sequential.
+#include "afv_device.h"
+#include "../../include/afv_hip.h"
+#include "afv_quadtree.h"
+#include "akaze_tables.inc"
+
+#define AKS_MAX_LEVELS 16
+
+struct AksParams {
+    int nlevels, W, H, n_ini;
+    float h_x;
+    int quota[AKS_MAX_LEVELS];
+    int kp_cap;    // detected keypoints per frame (input stride)
+    int sel_cap;   // selected per (frame, level)
+    int out_cap;   // final keypoints per frame
+    int M;         // quadtree node capacity
+};
+
+struct AksPts {
+    const afv_keypoint *k;
+    const int *idx;
+    __device__ __forceinline__ float x(int p) const { return k[idx[p]].x; }
+    __device__ __forceinline__ float y(int p) const { return k[idx[p]].y; }
+};
+
+__global__ __launch_bounds__(QT_T) void k_akz_select(AksParams P, const afv_keypoint *__restrict__ kps, const int *__restrict__ kp_count,
+                                                     int *__restrict__ lvl_idx, uint16_t *__restrict__ lvl_node, int *__restrict__ sel,
+                                                     int *__restrict__ sel_count) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int level = blockIdx.x, f = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const QtScratch S = qt_carve(smem, P.M);
+    unsigned long long *best = reinterpret_cast<unsigned long long *>(smem + qt_lds_bytes(P.M));
+    __shared__ int s_wsum[4], s_base;
+    const afv_keypoint *k = kps + (size_t)f * P.kp_cap;
+    int *idx = lvl_idx + ((size_t)f * P.nlevels + level) * P.kp_cap;
+    uint16_t *kn = lvl_node + ((size_t)f * P.nlevels + level) * P.kp_cap;
+    const int n = kp_count[f];
+    // ordered gather of this level's keypoints (keypoints_level[class_id].push_back in detection order)
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += QT_T) {
+        const int i = i0 + tid;
+        const bool mine = i < n && k[i].class_id == level;
+        const unsigned long long m = __ballot(mine);
+        if (lane == 0) s_wsum[tid >> 6] = __popcll(m);
+        __syncthreads();
+        int base = s_base;
+        for (int w = 0; w < (tid >> 6); ++w) base += s_wsum[w];
+        if (mine) idx[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
+        if (tid == 0) s_base += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        __syncthreads();
+    }
+    const int m2 = s_base;
+    __threadfence_block();
+    __syncthreads();
+    AksPts pts{k, idx};
+    const int size = qt_build(pts, m2, P.quota[level], P.n_ini, P.h_x, P.H, kn, S);
+    // survivor of each node: max response, first in input order on ties (ORBextractor.cc:446-453)
+    for (int i = tid; i < size; i += QT_T) best[i] = 0ull;
+    __syncthreads();
+    for (int p = tid; p < m2; p += QT_T) {
+        const unsigned long long key = ((unsigned long long)qt_float_key(k[idx[p]].response) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)p);
+        atomicMax(&best[kn[p]], key);
+    }
+    __syncthreads();
+    const int nout = min(size, P.sel_cap);
+    int *out = sel + ((size_t)f * P.nlevels + level) * P.sel_cap;
+    for (int i = tid; i < nout; i += QT_T) out[i] = idx[0xffffffffu - (uint32_t)(best[i] & 0xffffffffu)];
+    if (tid == 0) sel_count[f * AKS_MAX_LEVELS + level] = nout;
+}
+
+// ---------------- Compute_Descriptors ----------------
+struct AkdLevelPlanes {
+    const float *lt, *lx, *ly;  // [frame][h][w]
+    int w, h, octave;
+};
+struct AkdDescParams {
+    int nlevels, kp_cap, sel_cap, out_cap, desc_pitch;
+    AkdLevelPlanes lv[AKS_MAX_LEVELS];
+};
+
+#define AKZ_PI_D 3.14159265358979323846
+
+__device__ __forceinline__ int akd_fround(float x) { return (int)(x + 0.5f); }
+__device__ __forceinline__ int akd_iclamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// atan(z), z >= 0, same explicit algorithm as oracle/akaze.c atan_pos_f64
+__device__ __forceinline__ double akd_atan_pos(double z) {
+    const double pio2 = 1.5707963267948966, pio4 = 0.78539816339744831;
+    double base, t;
+    if (z > 2.414213562373095) { base = pio2; t = -1.0 / z; }
+    else if (z > 0.4142135623730950) { base = pio4; t = (z - 1.0) / (z + 1.0); }
+    else { base = 0.0; t = z; }
+    const double w = t * t;
+    double s = 1.0 / 23.0;
+    s = 1.0 / 21.0 - w * s;
+    s = 1.0 / 19.0 - w * s;
+    s = 1.0 / 17.0 - w * s;
+    s = 1.0 / 15.0 - w * s;
+    s = 1.0 / 13.0 - w * s;
+    s = 1.0 / 11.0 - w * s;
+    s = 1.0 / 9.0 - w * s;
+    s = 1.0 / 7.0 - w * s;
+    s = 1.0 / 5.0 - w * s;
+    s = 1.0 / 3.0 - w * s;
+    s = 1.0 - w * s;
+    return base + t * s;
+}
+__device__ __forceinline__ float akd_atanf(float z) { return (float)akd_atan_pos((double)z); }
+__device__ __forceinline__ float akd_get_angle(float x, float y) {
+    if (x >= 0 && y >= 0) return akd_atanf(y / x);
+    if (x < 0 && y >= 0) return (float)(AKZ_PI_D - (double)akd_atanf(-y / x));
+    if (x < 0 && y < 0) return (float)(AKZ_PI_D + (double)akd_atanf(y / x));
+    if (x >= 0 && y < 0) return (float)(2.0 * AKZ_PI_D - (double)akd_atanf(-y / x));
+    return 0.0f;
+}
+__device__ __forceinline__ void akd_sincos(double t, double *c_out, double *s_out) {  // as k_describe.hip / oracle
+    const double two_over_pi = 0.63661977236758138;
+    const double pio2_hi = 1.5707963267341256e+00, pio2_lo = 6.0771005065061922e-11;
+    const double kd = floor(t * two_over_pi + 0.5);
+    const int k = (int)kd;
+    const double r = (t - kd * pio2_hi) - kd * pio2_lo;
+    const double z = r * r;
+    const double sp = 1.0 + z * (-1.6666666666666666e-01 + z * (8.3333333333333332e-03 + z * (-1.9841269841269841e-04 +
+                      z * (2.7557319223985893e-06 + z * (-2.5052108385441720e-08 + z * (1.6059043836821613e-10 +
+                      z * (-7.6471637318198164e-13)))))));
+    const double s = r * sp;
+    const double c = 1.0 + z * (-0.5 + z * (4.1666666666666664e-02 + z * (-1.3888888888888889e-03 + z * (2.4801587301587302e-05 +
+                     z * (-2.7557319223985888e-07 + z * (2.0876756987868100e-09 + z * (-1.1470745597729725e-11 +
+                     z * (4.7794773323873853e-14))))))));
+    switch (k & 3) {
+        case 0: *c_out = c; *s_out = s; break;
+        case 1: *c_out = -s; *s_out = c; break;
+        case 2: *c_out = -c; *s_out = -s; break;
+        default: *c_out = s; *s_out = -c; break;
+    }
+}
+
+__constant__ float k_gauss25[7][7] = {
+    {0.02546481f, 0.02350698f, 0.01849125f, 0.01239505f, 0.00708017f, 0.00344629f, 0.00142946f},
+    {0.02350698f, 0.02169968f, 0.01706957f, 0.01144208f, 0.00653582f, 0.00318132f, 0.00131956f},
+    {0.01849125f, 0.01706957f, 0.01342740f, 0.00900066f, 0.00514126f, 0.00250252f, 0.00103800f},
+    {0.01239505f, 0.01144208f, 0.00900066f, 0.00603332f, 0.00344629f, 0.00167749f, 0.00069579f},
+    {0.00708017f, 0.00653582f, 0.00514126f, 0.00344629f, 0.00196855f, 0.00095820f, 0.00039744f},
+    {0.00344629f, 0.00318132f, 0.00250252f, 0.00167749f, 0.00095820f, 0.00046640f, 0.00019346f},
+    {0.00142946f, 0.00131956f, 0.00103800f, 0.00069579f, 0.00039744f, 0.00019346f, 0.00008024f}};
+
+#define AKD_LDS_SYNC()                                         \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
+    } while (0)
+
+__global__ __launch_bounds__(256) void k_akz_describe(AkdDescParams P, const afv_keypoint *__restrict__ kps, const int *__restrict__ sel,
+                                                      const int *__restrict__ sel_count, afv_keypoint *__restrict__ out_kps,
+                                                      uint8_t *__restrict__ out_desc, int *__restrict__ out_count, int *__restrict__ status) {
+    __shared__ float s_rx[4][112], s_ry[4][112], s_ang[4][112], s_val[4][96];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, f = blockIdx.y;
+    const int slot = blockIdx.x * 4 + wv;
+    // slot -> (level, position): levels ascending (mergeKeypointLevels, FeatureExtractor.cpp:296-308)
+    int level = -1, pos = slot, total = 0;
+    for (int l = 0; l < P.nlevels; ++l) {
+        const int c = sel_count[f * AKS_MAX_LEVELS + l];
+        if (level < 0 && pos < c) level = l;
+        if (level < 0) pos -= c;
+        total += c;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out_count[f] = min(total, P.out_cap);
+        if (total > P.out_cap) atomicExch(status, 4);
+    }
+    if (level < 0 || slot >= P.out_cap) return;
+    afv_keypoint kp = kps[(size_t)f * P.kp_cap + sel[((size_t)f * P.nlevels + level) * P.sel_cap + pos]];
+    const AkdLevelPlanes L = P.lv[level];
+    const size_t fo = (size_t)f * L.w * L.h;
+    const float *Lt = L.lt + fo, *Lx = L.lx + fo, *Ly = L.ly + fo;
+    const float ratio = (float)(1 << L.octave);
+    const float xf = kp.x / ratio, yf = kp.y / ratio;
+    float *rx = s_rx[wv], *ry = s_ry[wv], *an = s_ang[wv], *val = s_val[wv];
+    // ---- Compute_Main_Orientation ----
+    {
+        const int s = akd_fround((float)(0.5 * (double)kp.size / (double)ratio));
+        for (int idx = lane; idx < 109; idx += 64) {
+            const int i = k_ori_ij[idx][0], j = k_ori_ij[idx][1];
+            const int iy = akd_iclamp(akd_fround(yf + (float)(j * s)), 0, L.h - 1), ix = akd_iclamp(akd_fround(xf + (float)(i * s)), 0, L.w - 1);
+            const float gw = k_gauss25[i < 0 ? -i : i][j < 0 ? -j : j];
+            const float vx = gw * Lx[(size_t)iy * L.w + ix], vy = gw * Ly[(size_t)iy * L.w + ix];
+            rx[idx] = vx;
+            ry[idx] = vy;
+            an[idx] = akd_get_angle(vx, vy);
+        }
+        AKD_LDS_SYNC();
+        // 42 sliding windows (ang1 = 0, 0.15, ... accumulated in float like upstream's loop variable), one per lane
+        float ang1 = 0.0f;
+        for (int t = 0; t < lane; ++t) ang1 += 0.15f;
+        const bool live = (double)ang1 < 2.0 * AKZ_PI_D;
+        float sumX = 0.f, sumY = 0.f;
+        if (live) {
+            const float ang2 =
+                (float)((double)ang1 + AKZ_PI_D / 3.0 > 2.0 * AKZ_PI_D ? (double)ang1 - 5.0 * AKZ_PI_D / 3.0 : (double)ang1 + AKZ_PI_D / 3.0);
+            for (int k = 0; k < 109; ++k) {
+                const float ang = an[k];
+                if (ang1 < ang2 && ang1 < ang && ang < ang2) {
+                    sumX += rx[k];
+                    sumY += ry[k];
+                } else if (ang2 < ang1 && ((ang > 0 && ang < ang2) || (ang > ang1 && (double)ang < 2.0 * AKZ_PI_D))) {
+                    sumX += rx[k];
+                    sumY += ry[k];
+                }
+            }
+        }
+        const float mag = live ? sumX * sumX + sumY * sumY : 0.0f;
+        // first window with the largest magnitude wins (upstream updates on strict >); magnitude 0 never wins
+        unsigned long long key = ((unsigned long long)__float_as_uint(mag) << 32) | (unsigned)(63 - lane);
+        if (!(mag > 0.0f)) key = 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long t = __shfl_xor(key, o, 64);
+            key = t > key ? t : key;
+        }
+        if (key != 0) {
+            const int win = 63 - (int)(key & 0xffffffffu);
+            const float wx = __shfl(sumX, win, 64), wy = __shfl(sumY, win, 64);
+            kp.angle = akd_get_angle(wx, wy);
+        }
+    }
+    // ---- Get_MLDB_Full_Descriptor ----
+    {
+        const float scale = (float)akd_fround(0.5f * kp.size / ratio);
+        double cd, sd;
+        akd_sincos((double)kp.angle, &cd, &sd);
+        const float co = (float)cd, si = (float)sd;
+        if (lane < 29) {
+            const int i0 = k_mldb_cell[lane][1], j0 = k_mldb_cell[lane][2], step = k_mldb_cell[lane][3];
+            float di = 0.f, dx = 0.f, dy = 0.f;
+            for (int k = i0; k < i0 + step; ++k)
+                for (int l = j0; l < j0 + step; ++l) {
+                    const float sample_y = yf + ((float)l * co * scale + (float)k * si * scale);
+                    const float sample_x = xf + (-(float)l * si * scale + (float)k * co * scale);
+                    const int y1 = akd_iclamp(akd_fround(sample_y), 0, L.h - 1), x1 = akd_iclamp(akd_fround(sample_x), 0, L.w - 1);
+                    const size_t o = (size_t)y1 * L.w + x1;
+                    const float ri = Lt[o], vx = Lx[o], vy = Ly[o];
+                    di += ri;
+                    const float rry = vx * co + vy * si, rrx = -vx * si + vy * co;
+                    dx += rrx;
+                    dy += rry;
+                }
+            const float ns = (float)(step * step);
+            val[3 * lane] = di / ns;
+            val[3 * lane + 1] = dx / ns;
+            val[3 * lane + 2] = dy / ns;
+        }
+        AKD_LDS_SYNC();
+        unsigned long long m[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int b = t * 64 + lane;
+            bool bit = false;
+            if (b < 486) {
+                int va = __float_as_int(val[k_mldb_bits[b][0]]), vb = __float_as_int(val[k_mldb_bits[b][1]]);
+                va ^= (va < 0 ? 0x7fffffff : 0);  // CV_TOGGLE_FLT
+                vb ^= (vb < 0 ? 0x7fffffff : 0);
+                bit = va > vb;
+            }
+            m[t] = __ballot(bit);
+        }
+        if (lane < 61) {
+            unsigned long long word = m[0];
+#pragma unroll
+            for (int t = 1; t < 8; ++t)
+                if ((lane >> 3) == t) word = m[t];
+            out_desc[((size_t)f * P.out_cap + slot) * P.desc_pitch + lane] = (uint8_t)(word >> (8 * (lane & 7)));
+        }
+    }
+    if (lane == 0) out_kps[(size_t)f * P.out_cap + slot] = kp;
+}
+
+extern "C" size_t afv_akz_select_lds_bytes(int M) { return qt_lds_bytes(M) + (size_t)M * 8; }
+
+extern "C" void afv_akz_launch_select(const AksParams *P, int nframes, const afv_keypoint *kps, const int *kp_count, int *lvl_idx,
+                                      uint16_t *lvl_node, int *sel, int *sel_count, hipStream_t st) {
+    hipLaunchKernelGGL(k_akz_select, dim3(P->nlevels, nframes), dim3(QT_T), afv_akz_select_lds_bytes(P->M), st, *P, kps, kp_count, lvl_idx,
+                       lvl_node, sel, sel_count);
+}
+
+extern "C" void afv_akz_launch_describe(const AkdDescParams *P, int nframes, int max_out, const afv_keypoint *kps, const int *sel,
+                                        const int *sel_count, afv_keypoint *out_kps, uint8_t *out_desc, int *out_count, int *status,
+                                        hipStream_t st) {
+    hipLaunchKernelGGL(k_akz_describe, dim3((max_out + 3) / 4, nframes), dim3(256), 0, st, *P, kps, sel, sel_count, out_kps, out_desc, out_count,
+                       status);
+}

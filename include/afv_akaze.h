@@ -27,6 +27,8 @@ typedef struct {
     float kcontrast_percentile;
     int32_t kcontrast_nbins;
     int32_t max_width, max_height, max_batch;
+    int32_t nfeatures;              /* quadtree budget (Tracking.cc:1515-1520: 1000) */
+    float scale_factor;             /* settings scaleFactor used for the per-level quotas: 1.1892 (akaze61_settings.yaml:7) */
 } afv_akaze_params;
 
 typedef struct {
@@ -68,6 +70,20 @@ int afv_akaze_detect(afv_akaze *a);
 int afv_akaze_get_keypoints(afv_akaze *a, int frame, afv_keypoint *out, int cap, int *n_out);
 /* raster-ordered local-maximum candidates of one level (index = y * w + x), for stage-by-stage tests */
 int afv_akaze_get_candidates(afv_akaze *a, int frame, int level, int32_t *out_idx, int cap, int *n_out);
+
+/* plugin tail on the detected keypoints: bucket by class_id, DistributeOctTree per level with the quotas of
+ * FeatureExtractor.cpp:97-108 (filterKeypoints_notScaled, FeatureExtractor.cpp:276-284), Compute_Main_Orientation +
+ * MLDB-486 descriptors, levels merged in ascending order (mergeKeypointLevels, FeatureExtractor.cpp:296-308).  Asynchronous. */
+int afv_akaze_describe(afv_akaze *a);
+/* final keypoints (angle in radians as libAKAZE leaves it) and N x 61 descriptors of one frame; NULL pointers skip a part */
+int afv_akaze_get_features(afv_akaze *a, int frame, afv_keypoint *kps, uint8_t *desc61, int cap, int *n_out);
+/* FeatureExtractor_akaze61::detectAndCompute for a batch: scale space + detect + describe + copy out.
+ * kps / desc61: nframes x cap_per_frame (x 61 bytes); n_out[nframes]. */
+int afv_akaze_extract(afv_akaze *a, const uint8_t *gray, int nframes, int w, int h, int stride, size_t frame_stride, afv_keypoint *kps,
+                      uint8_t *desc61, int cap_per_frame, int32_t *n_out);
+/* same, frames in HBM, everything stays on the device (read back with afv_akaze_get_features); asynchronous */
+int afv_akaze_extract_device(afv_akaze *a, const uint8_t *d_gray, int nframes, int w, int h, int stride, size_t frame_stride);
+int afv_akaze_get_quotas(const afv_akaze *a, int32_t *quota16);
 
 /* test / inspection access (synchronises) */
 int afv_akaze_get_plane(afv_akaze *a, int frame, int level, int which, float *out);

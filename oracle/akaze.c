@@ -459,3 +459,173 @@ int akz_subpixel(const akz_plan *p, const akz_planes *lv, akz_keypoint *kpts, in
     }
     return m;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Compute_Descriptors
+ * ---------------------------------------------------------------------------------------------- */
+#define AKZ_PI 3.14159265358979323846 /* CV_PI */
+
+/* atan(z), z >= 0 (or +inf / NaN), in double: argument reduction at tan(pi/8), tan(3pi/8), Taylor to t^23 */
+static double atan_pos_f64(double z) {
+    const double pio2 = 1.5707963267948966, pio4 = 0.78539816339744831;
+    double base, t;
+    if (z > 2.414213562373095) { base = pio2; t = -1.0 / z; }
+    else if (z > 0.4142135623730950) { base = pio4; t = (z - 1.0) / (z + 1.0); }
+    else { base = 0.0; t = z; }
+    const double w = t * t;
+    double s = 1.0 / 23.0;
+    s = 1.0 / 21.0 - w * s;
+    s = 1.0 / 19.0 - w * s;
+    s = 1.0 / 17.0 - w * s;
+    s = 1.0 / 15.0 - w * s;
+    s = 1.0 / 13.0 - w * s;
+    s = 1.0 / 11.0 - w * s;
+    s = 1.0 / 9.0 - w * s;
+    s = 1.0 / 7.0 - w * s;
+    s = 1.0 / 5.0 - w * s;
+    s = 1.0 / 3.0 - w * s;
+    s = 1.0 - w * s;
+    return base + t * s;
+}
+static float atanf_det(float z) { return (float)atan_pos_f64((double)z); }
+
+/* libAKAZE get_angle: quadrant-wise atanf, result in [0, 2 pi) */
+float akz_get_angle(float x, float y) {
+    if (x >= 0 && y >= 0) return atanf_det(y / x);
+    if (x < 0 && y >= 0) return (float)(AKZ_PI - (double)atanf_det(-y / x));
+    if (x < 0 && y < 0) return (float)(AKZ_PI + (double)atanf_det(y / x));
+    if (x >= 0 && y < 0) return (float)(2.0 * AKZ_PI - (double)atanf_det(-y / x));
+    return 0.0f;
+}
+
+/* same Cody-Waite + Taylor cos/sin as oracle/afvo.c (shared with the kernels) */
+static void sincos_f64(double t, double *c_out, double *s_out) {
+    const double two_over_pi = 0.63661977236758138;
+    const double pio2_hi = 1.5707963267341256e+00, pio2_lo = 6.0771005065061922e-11;
+    double kd = floor(t * two_over_pi + 0.5);
+    int k = (int)kd;
+    double r = (t - kd * pio2_hi) - kd * pio2_lo;
+    double z = r * r;
+    double sp = 1.0 + z * (-1.6666666666666666e-01 + z * (8.3333333333333332e-03 + z * (-1.9841269841269841e-04 +
+                z * (2.7557319223985893e-06 + z * (-2.5052108385441720e-08 + z * (1.6059043836821613e-10 +
+                z * (-7.6471637318198164e-13)))))));
+    double s = r * sp;
+    double c = 1.0 + z * (-0.5 + z * (4.1666666666666664e-02 + z * (-1.3888888888888889e-03 + z * (2.4801587301587302e-05 +
+               z * (-2.7557319223985888e-07 + z * (2.0876756987868100e-09 + z * (-1.1470745597729725e-11 +
+               z * (4.7794773323873853e-14))))))));
+    switch (k & 3) {
+    case 0: *c_out = c; *s_out = s; break;
+    case 1: *c_out = -s; *s_out = c; break;
+    case 2: *c_out = -c; *s_out = -s; break;
+    default: *c_out = s; *s_out = -c; break;
+    }
+}
+
+/* SURF's 7 x 7 Gaussian (sigma 2.5) weight table used by Compute_Main_Orientation */
+static const float k_gauss25[7][7] = {
+    {0.02546481f, 0.02350698f, 0.01849125f, 0.01239505f, 0.00708017f, 0.00344629f, 0.00142946f},
+    {0.02350698f, 0.02169968f, 0.01706957f, 0.01144208f, 0.00653582f, 0.00318132f, 0.00131956f},
+    {0.01849125f, 0.01706957f, 0.01342740f, 0.00900066f, 0.00514126f, 0.00250252f, 0.00103800f},
+    {0.01239505f, 0.01144208f, 0.00900066f, 0.00603332f, 0.00344629f, 0.00167749f, 0.00069579f},
+    {0.00708017f, 0.00653582f, 0.00514126f, 0.00344629f, 0.00196855f, 0.00095820f, 0.00039744f},
+    {0.00344629f, 0.00318132f, 0.00250252f, 0.00167749f, 0.00095820f, 0.00046640f, 0.00019346f},
+    {0.00142946f, 0.00131956f, 0.00103800f, 0.00069579f, 0.00039744f, 0.00019346f, 0.00008024f}};
+
+void akz_main_orientation(const akz_plan *p, const akz_planes *lv, akz_keypoint *kp) {
+    static const int id[13] = {6, 5, 4, 3, 2, 1, 0, 1, 2, 3, 4, 5, 6};
+    const int level = kp->class_id;
+    const akz_level_info *L = &p->lv[level];
+    const float ratio = (float)(1 << L->octave);
+    const int s = f_round((float)(0.5 * (double)kp->size / (double)ratio));
+    const float xf = kp->x / ratio, yf = kp->y / ratio;
+    float resX[109], resY[109], Ang[109];
+    int idx = 0;
+    for (int i = -6; i <= 6; ++i)
+        for (int j = -6; j <= 6; ++j)
+            if (i * i + j * j < 36) {
+                const int iy = iclamp(f_round(yf + (float)(j * s)), 0, L->h - 1), ix = iclamp(f_round(xf + (float)(i * s)), 0, L->w - 1);
+                const float gw = k_gauss25[id[i + 6]][id[j + 6]];
+                resX[idx] = gw * lv[level].Lx[(size_t)iy * L->w + ix];
+                resY[idx] = gw * lv[level].Ly[(size_t)iy * L->w + ix];
+                Ang[idx] = akz_get_angle(resX[idx], resY[idx]);
+                ++idx;
+            }
+    float max = 0.0f, angle = kp->angle;
+    for (float ang1 = 0; (double)ang1 < 2.0 * AKZ_PI; ang1 += 0.15f) {
+        const float ang2 = (float)((double)ang1 + AKZ_PI / 3.0 > 2.0 * AKZ_PI ? (double)ang1 - 5.0 * AKZ_PI / 3.0 : (double)ang1 + AKZ_PI / 3.0);
+        float sumX = 0.f, sumY = 0.f;
+        for (int k = 0; k < 109; ++k) {
+            const float ang = Ang[k];
+            if (ang1 < ang2 && ang1 < ang && ang < ang2) { sumX += resX[k]; sumY += resY[k]; }
+            else if (ang2 < ang1 && ((ang > 0 && ang < ang2) || (ang > ang1 && (double)ang < 2.0 * AKZ_PI))) { sumX += resX[k]; sumY += resY[k]; }
+        }
+        if (sumX * sumX + sumY * sumY > max) {
+            max = sumX * sumX + sumY * sumY;
+            angle = akz_get_angle(sumX, sumY);
+        }
+    }
+    kp->angle = angle;
+}
+
+static inline int32_t toggle_flt(int32_t x) { return x ^ (x < 0 ? 0x7fffffff : 0); } /* CV_TOGGLE_FLT */
+
+void akz_mldb(const akz_plan *p, const akz_planes *lv, const akz_keypoint *kp, uint8_t *desc) {
+    const int level = kp->class_id;
+    const akz_level_info *L = &p->lv[level];
+    const int w = L->w, h = L->h;
+    const float ratio = (float)(1 << kp->octave);
+    const float scale = (float)f_round(0.5f * kp->size / ratio);
+    const float xf = kp->x / ratio, yf = kp->y / ratio;
+    double cd, sd;
+    sincos_f64((double)kp->angle, &cd, &sd);
+    const float co = (float)cd, si = (float)sd;
+    const int pattern_size = 10;
+    static const int sample_step[3] = {10, 7, 5}; /* ceil(10 * {1, 2/3, 1/2}) */
+    memset(desc, 0, 61);
+    int dpos = 0;
+    for (int lvl = 0; lvl < 3; ++lvl) {
+        const int step = sample_step[lvl], val_count = (lvl + 2) * (lvl + 2);
+        float values[16 * 3];
+        int valpos = 0;
+        for (int i = -pattern_size; i < pattern_size; i += step)
+            for (int j = -pattern_size; j < pattern_size; j += step) {
+                float di = 0, dx = 0, dy = 0;
+                int nsamples = 0;
+                for (int k = i; k < i + step; ++k)
+                    for (int l = j; l < j + step; ++l) {
+                        const float sample_y = yf + ((float)l * co * scale + (float)k * si * scale);
+                        const float sample_x = xf + (-(float)l * si * scale + (float)k * co * scale);
+                        const int y1 = iclamp(f_round(sample_y), 0, h - 1), x1 = iclamp(f_round(sample_x), 0, w - 1);
+                        const size_t o = (size_t)y1 * w + x1;
+                        const float ri = lv[level].Lt[o], rx = lv[level].Lx[o], ry = lv[level].Ly[o];
+                        di += ri;
+                        const float rry = rx * co + ry * si, rrx = -rx * si + ry * co;
+                        dx += rrx;
+                        dy += rry;
+                        nsamples++;
+                    }
+                di /= (float)nsamples; dx /= (float)nsamples; dy /= (float)nsamples;
+                values[valpos] = di; values[valpos + 1] = dx; values[valpos + 2] = dy;
+                valpos += 3;
+            }
+        /* MLDB_Binary_Comparisons: per channel, all ordered pairs (i < j): bit = value_i > value_j (integer compare of toggled floats) */
+        int32_t iv[16 * 3];
+        memcpy(iv, values, sizeof(float) * (size_t)val_count * 3);
+        for (int i = 0; i < val_count * 3; ++i) iv[i] = toggle_flt(iv[i]);
+        for (int pos = 0; pos < 3; ++pos)
+            for (int i = 0; i < val_count; ++i) {
+                const int32_t ival = iv[3 * i + pos];
+                for (int j = i + 1; j < val_count; ++j) {
+                    if (ival > iv[3 * j + pos]) desc[dpos >> 3] |= (uint8_t)(1 << (dpos & 7));
+                    dpos++;
+                }
+            }
+    }
+}
+
+void akz_compute_descriptors(const akz_plan *p, const akz_planes *lv, akz_keypoint *kpts, int n, uint8_t *desc) {
+    for (int i = 0; i < n; ++i) {
+        akz_main_orientation(p, lv, &kpts[i]);
+        akz_mldb(p, lv, &kpts[i], desc + (size_t)i * 61);
+    }
+}

@@ -75,6 +75,15 @@ int akz_find_extrema(const akz_plan *p, const akz_options *o, const akz_planes *
 /* Do_Subpixel_Refinement: 2x2 solve on Ldet; drops points that move more than one pixel; size *= 2; returns the new count */
 int akz_subpixel(const akz_plan *p, const akz_planes *lv, akz_keypoint *kpts, int n);
 
+/* ---- Compute_Descriptors: Compute_Main_Orientation + Get_MLDB_Full_Descriptor (486 bits = 61 bytes, 3 channels) ----
+ * atanf / cos / sin are replaced by explicit double-precision algorithms shared with the HIP kernels (libm and the device
+ * library do not agree in the last bit); sample coordinates are clamped to the level (upstream reads a few pixels outside
+ * the image for diagonal orientations near the border rule's limit). */
+float akz_get_angle(float x, float y);
+void akz_main_orientation(const akz_plan *p, const akz_planes *lv, akz_keypoint *k);
+void akz_mldb(const akz_plan *p, const akz_planes *lv, const akz_keypoint *k, uint8_t *desc61);
+void akz_compute_descriptors(const akz_plan *p, const akz_planes *lv, akz_keypoint *kpts, int n, uint8_t *desc /* n x 61 */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -177,3 +177,16 @@ def subpixel(plan, levels, kpts):
     kpts = np.ascontiguousarray(kpts, KP_DTYPE).copy()
     n = lib().akz_subpixel(C.byref(plan), arr, _p(kpts), len(kpts))
     return kpts[:n].copy()
+
+
+def compute_descriptors(plan, levels, kpts):
+    arr = _planes_array(plan, levels)
+    kpts = np.ascontiguousarray(kpts, KP_DTYPE).copy()
+    desc = np.zeros((max(len(kpts), 1), 61), np.uint8)
+    lib().akz_compute_descriptors(C.byref(plan), arr, _p(kpts), len(kpts), _p(desc))
+    return kpts, desc[:len(kpts)].copy()
+
+
+def get_angle(x, y):
+    lib().akz_get_angle.restype = C.c_float
+    return float(lib().akz_get_angle(C.c_float(x), C.c_float(y)))

@@ -109,3 +109,60 @@ def test_detection_matches_oracle(afv, akz, w, h, seeds):
         for name in ("x", "y", "size", "angle", "response", "octave", "class_id"):
             assert np.array_equal(got[name], want[name]), (f, name)
     ctx.close()
+
+
+def _oracle_detect_and_compute(afv, akz, oracle, op, frame, quotas, w, h):
+    """FeatureExtractor_akaze61::detectAndCompute restated with the oracle pieces: Feature_Detection, bucket by class_id,
+    DistributeOctTree per level (oracle/afvo.c), Compute_Descriptors on the levels in ascending order"""
+    levels, _ = akz.full_evolution(frame, op)
+    kp = akz.subpixel(op, levels, akz.find_extrema(op, levels))
+    chosen = []
+    for lvl in range(op.nlevels):
+        idx = np.nonzero(kp["class_id"] == lvl)[0]
+        if len(idx) == 0:
+            continue
+        sel = oracle.quadtree(kp["x"][idx], kp["y"][idx], kp["response"][idx], int(quotas[lvl]), w, h, tiebreak=np.arange(len(idx)))
+        chosen.append(idx[sel])
+    chosen = np.concatenate(chosen) if chosen else np.zeros(0, np.int64)
+    return akz.compute_descriptors(op, levels, kp[chosen])
+
+
+@pytest.mark.parametrize("w,h,seeds,nfeatures", [(640, 480, (3, 9), 1000), (320, 200, (4,), 300), (640, 360, (6,), 1000)])
+def test_detect_and_compute_matches_oracle(afv, akz, oracle, w, h, seeds, nfeatures):
+    prm = afv.akaze.default_params(max_width=w, max_height=h, max_batch=len(seeds), nfeatures=nfeatures)
+    ctx = afv.AkazeContext(prm)
+    frames = _frames(afv, w, h, seeds)
+    res = ctx.extract(frames)
+    plan = ctx.plan
+    op = _oracle_plan(akz, plan)
+    quotas = ctx.quotas()
+    assert quotas[:8].tolist() == oracle.quotas_extractor(nfeatures, 8, 1.1892).tolist()
+    for f in range(len(seeds)):
+        wk, wd = _oracle_detect_and_compute(afv, akz, oracle, op, frames[f], quotas, w, h)
+        gk, gd = res[f]
+        assert len(gk) == len(wk) and len(wk) > 0.5 * nfeatures
+        for name in ("x", "y", "size", "angle", "response", "octave", "class_id"):
+            assert np.array_equal(gk[name], wk[name]), (f, name)
+        assert np.array_equal(gd, wd)
+        assert np.all(np.diff(gk["class_id"]) >= 0)          # levels ascending
+        assert gd.shape[1] == 61 and np.all(gd[:, 60] < 64)  # 486 bits: the top two bits of the last byte stay clear
+    ctx.close()
+
+
+def test_akaze_descriptors_feed_the_hamming_matcher(afv, oracle, gpu_ctx):
+    """config #5 end to end: AKAZE61 features of two shifted frames through the 61-byte Hamming matcher (matchingTh 128,
+    settings/akaze61_settings.yaml:11)"""
+    ctx = afv.AkazeContext(afv.akaze.default_params(max_width=640, max_height=480, max_batch=2))
+    img = afv.synth.corners_frame(11)
+    (k1, d1), (k2, d2) = ctx.extract(np.stack([img, np.roll(img, 5, axis=1)]))
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(128.0)
+    m = afv.FeatureMatcher(0.8, False, ctx=gpu_ctx)
+    got, n = m.SearchByBoW(afv.FeatureView(d1), afv.FeatureView(d2))
+    want, wn = oracle.search_by_bow_kf_kf(d1, d2, None, None, None, None, None, None, 128.0, 0.8, False)
+    assert n == wn and np.array_equal(got, want) and wn > 200
+    # most matches are the 5 px shift
+    ok = got >= 0
+    dx = k2["x"][got[ok]] - k1["x"][ok]
+    assert np.mean(np.abs(dx - 5.0) < 1.5) > 0.8
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+    ctx.close()
