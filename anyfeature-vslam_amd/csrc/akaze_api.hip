@@ -38,7 +38,7 @@ struct AkdParams {
 struct AkdState {
     float *ex, *ey, *eresp;
     int *elevel;
-    unsigned short *cells;
+    uint4 *cells;
     int *cell_cnt;
     unsigned char *keep;
 };
@@ -67,7 +67,7 @@ extern "C" void afv_akz_launch_describe(const AkdDescParams *P, int nframes, int
                                         const int *sel_count, afv_keypoint *out_kps, uint8_t *out_desc, int *out_count, int *status,
                                         hipStream_t st);
 #define AKD_CELL 10.0f
-#define AKD_CELLCAP 32
+#define AKD_CELLCAP 48
 #define AKD_MAX_CELLS 12288
 #define AKD_ENTRY_CAP 65535
 
@@ -297,7 +297,7 @@ extern "C" int afv_akaze_create(int device, const afv_akaze_params *prm, afv_aka
         if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.elevel, (size_t)AKD_ENTRY_CAP * B);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.keep, (size_t)AKD_ENTRY_CAP * B);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.cells, (size_t)2 * AKD_MAX_CELLS * AKD_CELLCAP * B);
-        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.cell_cnt, (size_t)2 * AKD_MAX_CELLS * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.cell_cnt, (size_t)AKD_MAX_CELLS * B);
     }
     {   // quadtree quotas (FeatureExtractor.cpp:97-108) for nfeatures / scaleFactor / nlevels of the akaze61 settings
         const int nl = plan.nlevels;

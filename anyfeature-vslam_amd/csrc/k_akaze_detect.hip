@@ -7,18 +7,19 @@
 //     count pass, a per-(frame, level) scan over rows and a write pass leave every level's candidates in RASTER order
 //     without a sort (upstream's loop order is part of the result).
 //  2. k_akz_suppress: upstream inserts the candidates one by one into kpts_aux, comparing each against the FIRST earlier
-//     entry of the same / previous level within its radius (replace it or drop the newcomer).  One wavefront per frame
-//     replays that loop in speculative rounds of 64 consecutive candidates: every lane looks its first match up in two
-//     uniform grids (previous level, current level), lanes that change the list mark the grid cells they touch, and the
-//     round commits up to the first lane that sees a mark of an earlier lane in its 3x3 cell neighbourhood.  A candidate
-//     only interacts inside its radius (<= one cell), so everything committed in a round is independent.
+//     entry of the same / previous level within its radius (replace it or drop the newcomer).  One workgroup per frame
+//     replays that loop in speculative rounds of 64 consecutive candidates: the (candidate, grid cell) pairs of a round
+//     are scanned by all threads in two uniform grids (previous level, current level; entries inline in the cell lists,
+//     list lengths in LDS); then every candidate checks exactly whether an earlier candidate of the round changes what
+//     its search saw (a new / moved entry inside its radius, or a replaced entry that lay inside it) and the round
+//     commits, in parallel, up to the first such candidate.
 //  3. the upper-level filter, the 2x2 sub-pixel solve and the ordered compaction run at the end of the same kernel.
 #include "afv_device.h"
 #include "../../include/afv_hip.h"
 
 #define AKD_CELL 10.0f       // grid cell edge in level-0 pixels; must be >= the largest keypoint radius (esigma * derivative_factor)
-#define AKD_CELLCAP 32       // entries of one level per cell (strict 3x3 maxima are >= 2 px apart: <= 25 in a 10 px cell)
-#define AKD_MAX_CELLS 12288  // LDS mark table (48 KB): 1280 x 960 at 10 px cells
+#define AKD_CELLCAP 48       // list elements per cell and level: <= 25 live entries in a 10 px cell (3x3 strict maxima) + dead ones
+#define AKD_MAX_CELLS 12288  // 2 x u16 list lengths in LDS (48 KB): 1280 x 960 at 10 px cells
 
 struct AkdLevel {
     int w, h, octave, sigma_size;
@@ -113,51 +114,56 @@ __global__ __launch_bounds__(256) void k_akz_cand_scan(AkdParams P, const int *_
     }
 }
 
-// ---------------- ordered suppression + upper-level filter + sub-pixel refinement: one wavefront per frame ----------------
+// ---------------- ordered suppression + upper-level filter + sub-pixel refinement: one workgroup per frame ----------------
+// Cell lists hold the entries inline (x, y, response bits, slot), so a neighbourhood scan is one global load per entry; the
+// cell counts of both grids live in LDS.  A replaced entry is not unlinked: its old list element is marked dead and a fresh
+// element goes into the list of its new cell, so every list only grows and all commits of a round run in parallel.
 struct AkdState {
     float *ex, *ey, *eresp;   // [frame][entry_cap]
     int *elevel;              // [frame][entry_cap]
-    unsigned short *cells;    // [frame][2][ncells][AKD_CELLCAP] slots
-    int *cell_cnt;            // [frame][2][ncells]
+    uint4 *cells;             // [frame][2][ncells][AKD_CELLCAP] {x, y, response, slot}
+    int *cell_cnt;            // [frame][ncells] scratch counts of the upper-level filter
     unsigned char *keep;      // [frame][entry_cap]
 };
 
+#define AKD_T 512
+#define AKD_PAIRS 18  // 2 grids x 3 x 3 cells per candidate
+#define AKD_ITERS ((64 * AKD_PAIRS + AKD_T - 1) / AKD_T)
+#define AKD_DEAD 0xffffffffu
+#define AKD_NONE 0xffffffffffffffffull
 #define AKD_WAVE_SYNC()                                        \
     do {                                                       \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
         __builtin_amdgcn_wave_barrier();                       \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
     } while (0)
-// global-memory visibility inside the one wavefront that owns a frame's state
-#define AKD_MEM_SYNC()                 \
-    do {                               \
-        __threadfence();               \
-        __builtin_amdgcn_wave_barrier(); \
-    } while (0)
 
-__global__ __launch_bounds__(64) void k_akz_suppress(AkdParams P, AkdState S, const int *__restrict__ cand, const int *__restrict__ cand_count,
-                                                     afv_keypoint *__restrict__ kps, int *__restrict__ kp_count, int *__restrict__ status) {
-    __shared__ unsigned int s_mark[AKD_MAX_CELLS];
-    const int f = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S, const int *__restrict__ cand, const int *__restrict__ cand_count,
+                                                        afv_keypoint *__restrict__ kps, int *__restrict__ kp_count, int *__restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) char akd_smem[];
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int ncells = P.gw * P.gh;
+    unsigned short *s_cnt = reinterpret_cast<unsigned short *>(akd_smem);  // [2][ncells] list lengths, both grids
+    unsigned int *s_cnt32 = reinterpret_cast<unsigned int *>(akd_smem);    // the same counters as packed pairs (LDS atomics)
+    __shared__ unsigned long long s_best[64];  // per candidate of the round: slot << 32 | response bits (min = first match)
+    __shared__ float s_sx[64], s_sy[64], s_ox[64], s_oy[64];
+    __shared__ int s_cx[64], s_cy[64], s_loc[64], s_stop, s_nout, s_wsum[AKD_T / 64];
     float *ex = S.ex + (size_t)f * P.entry_cap, *ey = S.ey + (size_t)f * P.entry_cap, *er = S.eresp + (size_t)f * P.entry_cap;
     int *el = S.elevel + (size_t)f * P.entry_cap;
-    unsigned short *cells = S.cells + (size_t)f * 2 * ncells * AKD_CELLCAP;
-    int *ccnt = S.cell_cnt + (size_t)f * 2 * ncells;
+    uint4 *cells = S.cells + (size_t)f * 2 * ncells * AKD_CELLCAP;
+    int *ccnt = S.cell_cnt + (size_t)f * ncells;
     unsigned char *keep = S.keep + (size_t)f * P.entry_cap;
-    for (int i = lane; i < ncells; i += 64) s_mark[i] = 0xffu;
-    for (int i = lane; i < 2 * ncells; i += 64) ccnt[i] = 0;
-    AKD_MEM_SYNC();
-    AKD_WAVE_SYNC();
+    for (int i = tid; i < 2 * ncells; i += AKD_T) s_cnt[i] = 0;
+    __syncthreads();
     int nE = 0;
-    int cur = 0;  // grid index of the current level
+    int cur = 0;
     const float inv_cell = 1.0f / AKD_CELL;
     for (int c = 0; c < P.nlevels; ++c) {
         const AkdLevel L = P.lv[c];
         if (c > 0) {  // the previous level's grid becomes "prev"; the other one is recycled
             cur ^= 1;
-            for (int i = lane; i < ncells; i += 64) ccnt[cur * ncells + i] = 0;
-            AKD_MEM_SYNC();
+            for (int i = tid; i < ncells; i += AKD_T) s_cnt[cur * ncells + i] = 0;
+            __syncthreads();
         }
         const int prv = cur ^ 1;
         const float *ld = L.ldet + (size_t)f * L.w * L.h;
@@ -165,126 +171,180 @@ __global__ __launch_bounds__(64) void k_akz_suppress(AkdParams P, AkdState S, co
         const int n = cand_count[f * 16 + c];
         const float size2 = L.psize * L.psize;
         int pos = 0;
+#ifdef AFV_AKZ_STATS
+        int st_rounds = 0;
+#endif
         while (pos < n) {
-            const int q = pos + lane;
-            const bool act = q < n;
+#ifdef AFV_AKZ_STATS
+            ++st_rounds;
+#endif
+            const int nround = min(64, n - pos);
+            // ---- 1. the round's candidates (wave 0) ----
             float sx = 0, sy = 0, resp = 0;
-            int first = -1, cx = 0, cy = 0;
-            if (act) {
-                const int idx = cd[q];
-                const int iy = idx / L.w, jx = idx - iy * L.w;
-                resp = fabsf(ld[idx]);
-                sx = (float)jx * L.ratio;
-                sy = (float)iy * L.ratio;
-                cx = min((int)(sx * inv_cell), P.gw - 1);
-                cy = min((int)(sy * inv_cell), P.gh - 1);
-                // first entry (smallest slot) of level c-1 / c within the radius
-                unsigned int best = 0xffffffffu;
-                for (int g = 0; g < 2; ++g) {
-                    if (g == 0 && c == 0) continue;
-                    const int gi = g == 0 ? prv : cur;
-                    for (int yy = max(cy - 1, 0); yy <= min(cy + 1, P.gh - 1); ++yy)
-                        for (int xx = max(cx - 1, 0); xx <= min(cx + 1, P.gw - 1); ++xx) {
-                            const int cell = yy * P.gw + xx;
-                            const int cn = ccnt[gi * ncells + cell];
-                            const unsigned short *sl = cells + ((size_t)gi * ncells + cell) * AKD_CELLCAP;
-                            for (int e = 0; e < cn; ++e) {
-                                const unsigned int slot = sl[e];
-                                const float dx = sx - ex[slot], dy = sy - ey[slot];
-                                const float dist = dx * dx + dy * dy;
-                                if (dist <= size2) best = min(best, slot);
-                            }
+            int cx = 0, cy = 0;
+            const bool act = tid < nround;
+            if (tid < 64) {
+                if (act) {
+                    const int idx = cd[pos + tid];
+                    const int iy = idx / L.w, jx = idx - iy * L.w;
+                    resp = fabsf(ld[idx]);
+                    sx = (float)jx * L.ratio;
+                    sy = (float)iy * L.ratio;
+                    cx = min((int)(sx * inv_cell), P.gw - 1);
+                    cy = min((int)(sy * inv_cell), P.gh - 1);
+                }
+                s_sx[tid] = sx; s_sy[tid] = sy; s_cx[tid] = cx; s_cy[tid] = cy;
+                s_best[tid] = AKD_NONE;
+            }
+            __syncthreads();
+            // ---- 2. neighbourhood scan: the (candidate, cell) pairs of the round spread over the whole workgroup ----
+            unsigned long long lbest[AKD_ITERS];
+            int lloc[AKD_ITERS];
+#pragma unroll
+            for (int it = 0; it < AKD_ITERS; ++it) {
+                lbest[it] = AKD_NONE;
+                lloc[it] = 0;
+                const int t = tid + it * AKD_T;
+                if (t >= nround * AKD_PAIRS) continue;
+                const int q = t / AKD_PAIRS, k = t - q * AKD_PAIRS;
+                const int g = k / 9, kk = k - g * 9;
+                if (g == 0 && c == 0) continue;
+                const int xx = s_cx[q] + (kk % 3) - 1, yy = s_cy[q] + (kk / 3) - 1;
+                if (xx < 0 || yy < 0 || xx >= P.gw || yy >= P.gh) continue;
+                const int gi = g == 0 ? prv : cur;
+                const int cell = yy * P.gw + xx;
+                const int cn = min((int)s_cnt[gi * ncells + cell], AKD_CELLCAP);
+                if (cn == 0) continue;
+                const size_t lb = ((size_t)gi * ncells + cell) * AKD_CELLCAP;
+                const float qx = s_sx[q], qy = s_sy[q];
+                unsigned long long best = AKD_NONE;
+                int beste = 0;
+                for (int e = 0; e < cn; ++e) {
+                    const uint4 v = cells[lb + e];
+                    if (v.w == AKD_DEAD) continue;  // replaced earlier: the entry lives on in another list
+                    const float dx = qx - __uint_as_float(v.x), dy = qy - __uint_as_float(v.y);
+                    if (dx * dx + dy * dy <= size2) {
+                        const unsigned long long key = ((unsigned long long)v.w << 32) | v.z;
+                        if (key < best) {
+                            best = key;
+                            beste = e;
                         }
-                }
-                first = best == 0xffffffffu ? -1 : (int)best;
-            }
-            // 0 drop, 1 append, 2 replace `first`
-            int type = 0;
-            int ocell = -1;
-            if (act) {
-                if (first < 0) type = 1;
-                else if (resp > er[first]) {
-                    type = 2;
-                    ocell = min((int)(ey[first] * inv_cell), P.gh - 1) * P.gw + min((int)(ex[first] * inv_cell), P.gw - 1);
-                }
-            }
-            const int mycell = cy * P.gw + cx;
-            if (type != 0) {  // lanes that change the list mark the cells they touch with their lane number
-                atomicMin(&s_mark[mycell], (unsigned)lane);
-                if (type == 2) atomicMin(&s_mark[ocell], (unsigned)lane);
-            }
-            AKD_WAVE_SYNC();
-            bool conflict = false;
-            if (act) {
-                for (int yy = max(cy - 1, 0); yy <= min(cy + 1, P.gh - 1); ++yy)
-                    for (int xx = max(cx - 1, 0); xx <= min(cx + 1, P.gw - 1); ++xx)
-                        if (s_mark[yy * P.gw + xx] < (unsigned)lane) conflict = true;
-            }
-            const unsigned long long cm = __ballot(conflict);
-            const int stop = cm ? (int)__builtin_ctzll(cm) : 64;
-            const bool commit = act && lane < stop;
-            const unsigned long long am = __ballot(commit && type == 1);
-            AKD_WAVE_SYNC();
-            // clear the marks (every marking lane resets its own cells)
-            if (type != 0) {
-                s_mark[mycell] = 0xffu;
-                if (type == 2) s_mark[ocell] = 0xffu;
-            }
-            if (commit && type != 0) {
-                int slot;
-                if (type == 1) {
-                    slot = nE + __popcll(am & ((1ull << lane) - 1ull));
-                } else {
-                    slot = first;
-                    // take the slot out of its old cell list (grid of the old entry's level)
-                    const int gi = el[first] == c ? cur : prv;
-                    unsigned short *sl = cells + ((size_t)gi * ncells + ocell) * AKD_CELLCAP;
-                    const int cn = ccnt[gi * ncells + ocell];
-                    for (int e = 0; e < cn; ++e)
-                        if (sl[e] == (unsigned short)first) {
-                            sl[e] = sl[cn - 1];
-                            break;
-                        }
-                    ccnt[gi * ncells + ocell] = cn - 1;
-                }
-                if (slot < P.entry_cap) {
-                    ex[slot] = sx;
-                    ey[slot] = sy;
-                    er[slot] = resp;
-                    el[slot] = c;
-                    const int cn = ccnt[cur * ncells + mycell];
-                    if (cn < AKD_CELLCAP) {
-                        cells[((size_t)cur * ncells + mycell) * AKD_CELLCAP + cn] = (unsigned short)slot;
-                        ccnt[cur * ncells + mycell] = cn + 1;
-                    } else {
-                        atomicExch(status, 2);
                     }
-                } else {
-                    atomicExch(status, 3);
+                }
+                if (best != AKD_NONE) {
+                    atomicMin(&s_best[q], best);
+                    lbest[it] = best;
+                    lloc[it] = (int)lb + beste;
                 }
             }
-            nE = min(nE + __popcll(am), P.entry_cap);
-            AKD_MEM_SYNC();
-            AKD_WAVE_SYNC();
-            pos += stop;
+            __syncthreads();
+            // the thread that found a candidate's first match publishes where that list element sits (slots are unique)
+#pragma unroll
+            for (int it = 0; it < AKD_ITERS; ++it) {
+                if (lbest[it] != AKD_NONE) {
+                    const int q = (tid + it * AKD_T) / AKD_PAIRS;
+                    if (s_best[q] == lbest[it]) s_loc[q] = lloc[it];
+                }
+            }
+            __syncthreads();
+            // ---- 3. decisions, exact conflict test against the earlier lanes of the round, commit (wave 0) ----
+            if (tid < 64) {
+                const unsigned long long b = s_best[tid];
+                const int first = (act && b != AKD_NONE) ? (int)(b >> 32) : -1;
+                int type = 0;  // 0 drop, 1 append, 2 replace `first`
+                float oex = 0, oey = 0;
+                if (act) {
+                    if (first < 0) type = 1;
+                    else if (resp > __uint_as_float((unsigned int)(b & 0xffffffffu))) {
+                        type = 2;
+                        const uint4 v = cells[s_loc[tid]];
+                        oex = __uint_as_float(v.x);
+                        oey = __uint_as_float(v.y);
+                    }
+                }
+                // a lane's decision stands unless an earlier lane of the round changes what its search sees: a new / moved
+                // entry inside its radius, or a replaced entry that used to lie inside its radius
+                s_ox[tid] = oex;
+                s_oy[tid] = oey;
+                const unsigned long long modm = __ballot(type != 0), repm = __ballot(type == 2);
+                AKD_WAVE_SYNC();
+                bool conflict = false;
+                if (act) {
+                    unsigned long long mm = modm & ((1ull << lane) - 1ull);
+                    while (mm) {
+                        const int j = (int)__builtin_ctzll(mm);
+                        mm &= mm - 1;
+                        const float dx = sx - s_sx[j], dy = sy - s_sy[j];
+                        if (dx * dx + dy * dy <= size2) conflict = true;
+                        if ((repm >> j) & 1ull) {
+                            const float ux = sx - s_ox[j], uy = sy - s_oy[j];
+                            if (ux * ux + uy * uy <= size2) conflict = true;
+                        }
+                    }
+                }
+                const unsigned long long cm = __ballot(conflict);
+                const int stop = cm ? (int)__builtin_ctzll(cm) : nround;
+                const bool commit = act && lane < stop && type != 0;
+                const unsigned long long am = __ballot(commit && type == 1);
+                if (commit) {
+                    int slot;
+                    if (type == 1) {
+                        slot = nE + __popcll(am & ((1ull << lane) - 1ull));
+                    } else {
+                        slot = first;
+                        cells[s_loc[tid]].w = AKD_DEAD;
+                    }
+                    if (slot < P.entry_cap) {
+                        ex[slot] = sx;
+                        ey[slot] = sy;
+                        er[slot] = resp;
+                        el[slot] = c;
+                        // list slot from an LDS atomic on the packed 16-bit counters (several commits may share a cell)
+                        const int ci = cur * ncells + cy * P.gw + cx;
+                        const unsigned int old = atomicAdd(&s_cnt32[ci >> 1], (ci & 1) ? 0x10000u : 1u);
+                        const int cn = (int)((old >> ((ci & 1) * 16)) & 0xffffu);
+                        if (cn < AKD_CELLCAP) {
+                            cells[(size_t)ci * AKD_CELLCAP + cn] = make_uint4(__float_as_uint(sx), __float_as_uint(sy), __float_as_uint(resp), (unsigned)slot);
+                        } else {
+                            atomicExch(status, 2);
+                        }
+                    } else {
+                        atomicExch(status, 3);
+                    }
+                }
+                if (lane == 0) {
+                    s_stop = stop;
+                    s_nout = min(nE + __popcll(am), P.entry_cap);
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+            pos += s_stop;
+            nE = s_nout;
+            __syncthreads();
         }
+#ifdef AFV_AKZ_STATS
+        if (tid == 0 && f == 0) printf("akz_suppress: level %d candidates %d rounds %d entries %d\n", c, n, st_rounds, nE);
+#endif
     }
     // ---- "Now filter points with the upper scale level": entry i of level c is repeated if a LATER entry of level c+1 lies
-    //      within size_i and has a larger response.  Per level pair: grid of the level c+1 entries, then one lane per entry.
-    for (int i = lane; i < nE; i += 64) keep[i] = 1;
+    //      within size_i and has a larger response.  Per level pair: grid of the level c+1 entries, then one thread per entry.
+    for (int i = tid; i < nE; i += AKD_T) keep[i] = 1;
     for (int c = 0; c + 1 < P.nlevels; ++c) {
-        for (int i = lane; i < ncells; i += 64) ccnt[i] = 0;
-        AKD_MEM_SYNC();
-        for (int i = lane; i < nE; i += 64)
+        for (int i = tid; i < ncells; i += AKD_T) ccnt[i] = 0;
+        __threadfence_block();
+        __syncthreads();
+        for (int i = tid; i < nE; i += AKD_T)
             if (el[i] == c + 1) {
                 const int cell = min((int)(ey[i] * inv_cell), P.gh - 1) * P.gw + min((int)(ex[i] * inv_cell), P.gw - 1);
                 const int k = atomicAdd(&ccnt[cell], 1);
-                if (k < AKD_CELLCAP) cells[(size_t)cell * AKD_CELLCAP + k] = (unsigned short)i;
+                if (k < AKD_CELLCAP) cells[(size_t)cell * AKD_CELLCAP + k] = make_uint4(__float_as_uint(ex[i]), __float_as_uint(ey[i]), __float_as_uint(er[i]), (unsigned)i);
                 else atomicExch(status, 2);
             }
-        AKD_MEM_SYNC();
+        __threadfence_block();
+        __syncthreads();
         const float sz = P.lv[c].psize, sz2 = sz * sz;
-        for (int i = lane; i < nE; i += 64)
+        for (int i = tid; i < nE; i += AKD_T)
             if (el[i] == c) {
                 const float x = ex[i], y = ey[i], r = er[i];
                 const int cx = min((int)(x * inv_cell), P.gw - 1), cy = min((int)(y * inv_cell), P.gh - 1);
@@ -294,10 +354,10 @@ __global__ __launch_bounds__(64) void k_akz_suppress(AkdParams P, AkdState S, co
                         const int cell = yy * P.gw + xx;
                         const int cn = min(ccnt[cell], AKD_CELLCAP);
                         for (int e = 0; e < cn; ++e) {
-                            const int j = cells[(size_t)cell * AKD_CELLCAP + e];
-                            if (j <= i) continue;
-                            const float dx = x - ex[j], dy = y - ey[j];
-                            if (dx * dx + dy * dy <= sz2 && r < er[j]) {
+                            const uint4 v = cells[(size_t)cell * AKD_CELLCAP + e];
+                            if ((int)v.w <= i) continue;
+                            const float dx = x - __uint_as_float(v.x), dy = y - __uint_as_float(v.y);
+                            if (dx * dx + dy * dy <= sz2 && r < __uint_as_float(v.z)) {
                                 rep = true;
                                 break;
                             }
@@ -305,12 +365,13 @@ __global__ __launch_bounds__(64) void k_akz_suppress(AkdParams P, AkdState S, co
                     }
                 if (rep) keep[i] = 0;
             }
-        AKD_MEM_SYNC();
+        __threadfence_block();
+        __syncthreads();
     }
     // ---- Do_Subpixel_Refinement + ordered compaction ----
     int nout = 0;
-    for (int i0 = 0; i0 < nE; i0 += 64) {
-        const int i = i0 + lane;
+    for (int i0 = 0; i0 < nE; i0 += AKD_T) {
+        const int i = i0 + tid;
         bool ok = i < nE && keep[i] != 0;
         float kx = 0, ky = 0, ksize = 0, kresp = 0;
         int koct = 0, klev = 0;
@@ -347,8 +408,15 @@ __global__ __launch_bounds__(64) void k_akz_suppress(AkdParams P, AkdState S, co
             }
         }
         const unsigned long long m = __ballot(ok);
+        if (lane == 0) s_wsum[tid >> 6] = __popcll(m);
+        __syncthreads();
+        int base = nout, tot = 0;
+        for (int w = 0; w < AKD_T / 64; ++w) {
+            if (w < (tid >> 6)) base += s_wsum[w];
+            tot += s_wsum[w];
+        }
         if (ok) {
-            const int o = nout + __popcll(m & ((1ull << lane) - 1ull));
+            const int o = base + __popcll(m & ((1ull << lane) - 1ull));
             if (o < P.kp_cap) {
                 afv_keypoint k;
                 k.x = kx; k.y = ky; k.size = ksize; k.angle = 0.0f; k.response = kresp; k.octave = koct; k.class_id = klev;
@@ -357,9 +425,10 @@ __global__ __launch_bounds__(64) void k_akz_suppress(AkdParams P, AkdState S, co
                 atomicExch(status, 4);
             }
         }
-        nout += __popcll(m);
+        nout += tot;
+        __syncthreads();
     }
-    if (lane == 0) kp_count[f] = min(nout, P.kp_cap);
+    if (tid == 0) kp_count[f] = min(nout, P.kp_cap);
 }
 
 extern "C" void afv_akz_launch_candidates(const AkdParams *P, int nframes, int *row_count, int *row_start, int *cand, int *cand_count,
@@ -373,5 +442,6 @@ extern "C" void afv_akz_launch_candidates(const AkdParams *P, int nframes, int *
 
 extern "C" void afv_akz_launch_suppress(const AkdParams *P, const AkdState *S, int nframes, const int *cand, const int *cand_count,
                                         afv_keypoint *kps, int *kp_count, int *status, hipStream_t st) {
-    hipLaunchKernelGGL(k_akz_suppress, dim3(nframes), dim3(64), 0, st, *P, *S, cand, cand_count, kps, kp_count, status);
+    const size_t lds = ((size_t)P->gw * P->gh * 2 * sizeof(unsigned short) + 15) & ~(size_t)15;  // two count grids (u16)
+    hipLaunchKernelGGL(k_akz_suppress, dim3(nframes), dim3(AKD_T), lds, st, *P, *S, cand, cand_count, kps, kp_count, status);
 }

@@ -1,6 +1,8 @@
-"""AKAZE61 scale space + Hessian throughput (config #5: 1280 x 720), device-resident frames.
-usage: python tools/bench_akaze.py [batch] [steps]"""
+"""AKAZE61 (config #5: 1280 x 720) throughput: scale space + detection + quadtree + MLDB descriptors, device-resident frames;
+CPU oracle timed beside it on a bounded sample.
+usage: python tools/bench_akaze.py [batch] [steps] [cpu_frames]"""
 import importlib
+import json
 import sys
 import time
 
@@ -11,36 +13,59 @@ sys.path.insert(0, ".")
 afv = importlib.import_module("anyfeature-vslam_amd")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+cpu_frames = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 W, H = 1280, 720
 ctx = afv.AkazeContext(afv.akaze.default_params(max_batch=B))
-frames = torch.from_numpy(afv.synth.corners_batch(1, B, W, H)).cuda()
+frames_h = afv.synth.corners_batch(1, B, W, H)
+frames = torch.from_numpy(frames_h).cuda()
 for _ in range(2):
-    ctx.scale_space_device(frames)
+    ctx.extract_device(frames)
 ctx.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    ctx.extract_device(frames)
+ctx.synchronize()
+dt = (time.perf_counter() - t0) / steps
+nk = sum(len(ctx.features(f)[0]) for f in range(B))
+det = sum(len(ctx.keypoints(f)) for f in range(B))
 t0 = time.perf_counter()
 for _ in range(steps):
     ctx.scale_space_device(frames)
 ctx.synchronize()
-dt = (time.perf_counter() - t0) / steps
+dt_ss = (time.perf_counter() - t0) / steps
 plan = ctx.plan
 px0 = W * H
-# algorithmic HBM bytes per frame (each plane moved once per kernel that must touch it)
-by = px0 + 4 * px0            # level 0: read u8, write Lt
-by += px0 + 4 * px0 + 4 * px0 + 4 * px0   # k-percentile: read u8, write smoothed, read it, write |grad|, read |grad|
-by += 4 * px0
+by = px0 + 4 * px0 + px0 + 4 * px0 + 4 * px0 + 4 * px0 + 4 * px0   # level 0 + contrast percentile passes
 for i in range(1, plan.nlevels):
     L, Q = plan.lv[i], plan.lv[i - 1]
     n = L.w * L.h
     if L.octave > Q.octave:
-        by += 4 * Q.w * Q.h + 4 * n       # halfsample
-    by += 8 * n                            # gauss: Lt -> Lsmooth
-    by += 8 * n                            # flow
-    by += L.nsteps * 12 * n                # FED steps: read Lt, flow; write Lt
+        by += 4 * Q.w * Q.h + 4 * n
+    by += 8 * n + 8 * n + L.nsteps * 12 * n      # gauss, flow, FED steps
 for i in range(plan.nlevels):
-    n = plan.lv[i].w * plan.lv[i].h
-    by += 12 * n + 20 * n                  # deriv1: read 1 write 2; hessian: read 2 write 3
-print("batch %d: %.3f ms per step, %.1f frames/s, algorithmic %.1f MB/frame -> %.0f GB/s (%.1f %% of 8 TB/s)" %
-      (B, dt * 1e3, B / dt, by / 1e6, by * B / dt / 1e9, by * B / dt / 8e12 * 100))
-ctx.profile_enable(True)
-ctx.scale_space_device(frames)
-print(ctx.profile_read())
+    by += 32 * plan.lv[i].w * plan.lv[i].h        # deriv1 (1 -> 2 planes) + hessian (2 -> 3 planes)
+out = {"workload": "AKAZE61 1280x720 synthetic corners frames, omax 2 x 4 sublevels, dthreshold 0.0005, 1000-feature quadtree, MLDB-486",
+       "batch": B, "ms_per_step": dt * 1e3, "frames_per_s": B / dt, "keypoints_per_s": nk / dt, "detected_per_frame": det / B,
+       "described_per_frame": nk / B, "scale_space_ms_per_step": dt_ss * 1e3,
+       "scale_space_algorithmic_MB_per_frame": by / 1e6, "scale_space_GBps": by * B / dt_ss / 1e9, "scale_space_frac_of_8TBps": by * B / dt_ss / 8e12}
+if cpu_frames:
+    from oracle import akaze_binding as ak
+    from oracle import binding as ob
+    op = ak.make_plan(W, H)
+    q = ctx.quotas()
+    t0 = time.perf_counter()
+    tot = 0
+    for f in range(cpu_frames):
+        levels, _ = ak.full_evolution(frames_h[f], op)
+        kp = ak.subpixel(op, levels, ak.find_extrema(op, levels))
+        chosen = []
+        for lvl in range(op.nlevels):
+            idx = np.nonzero(kp["class_id"] == lvl)[0]
+            if len(idx):
+                chosen.append(idx[ob.quadtree(kp["x"][idx], kp["y"][idx], kp["response"][idx], int(q[lvl]), W, H, tiebreak=np.arange(len(idx)))])
+        kk, dd = ak.compute_descriptors(op, levels, kp[np.concatenate(chosen)])
+        tot += len(kk)
+    ct = time.perf_counter() - t0
+    out["cpu_baseline"] = {"value": tot / ct, "unit": "keypoints/s", "cores": 1, "kind": "port", "ms_per_frame": ct / cpu_frames * 1e3,
+                           "sample": "%d frames 1280x720 through oracle/akaze.c + oracle quadtree, single thread" % cpu_frames}
+print(json.dumps(out))
