@@ -164,3 +164,41 @@ class AkazeContext:
         a, b, n = C.c_float(), C.c_float(), C.c_int()
         self.check(self.lib.afv_akaze_profile_read(self.handle, C.byref(a), C.byref(b), C.byref(n)), "afv_akaze_profile_read")
         return {"scale_space_ms": a.value, "hessian_ms": b.value, "launches": n.value}
+
+
+class FeatureExtractor_akaze61:
+    """Mirror of ANYFEATURE_VSLAM::FeatureExtractor_akaze61 (include/Feature_akaze61.h, src/Feature_akaze61.cpp): same
+    constructor arguments and method names; detectAndCompute runs initializeExtractor (scale space), detectKeypoints,
+    filterKeypoints and computeDescriptors on the GPU in one call."""
+
+    def __init__(self, nfeatures, settings=None, device=0, max_width=1280, max_height=720, max_batch=1):
+        from .extractor import FeatureExtractorSettings
+        self.settings = settings or FeatureExtractorSettings()
+        self.nfeatures = int(nfeatures)
+        s = self.settings
+        # Feature_akaze61.cpp:11-14: omax = nominal octaves / 4, nsublevels = nominal octaves / 2, dthreshold = detectTh
+        self.params = default_params(num_octaves=s.GetDetectorNominalNumOctaves(), detection_th=float(s.detectTh), max_width=max_width,
+                                     max_height=max_height, max_batch=max_batch, nfeatures=self.nfeatures,
+                                     scale_factor=float(s.GetDetectorNominalScaleFactor()))
+        self.ctx = AkazeContext(self.params, device)
+
+    def detectAndCompute(self, gray):
+        """-> (keypoints [KP_DTYPE: pt in level-0 pixels, size, angle (radians), response, octave, class_id = level], N x 61 u8)"""
+        return self.ctx.extract(gray)
+
+    def __call__(self, gray):
+        return self.detectAndCompute(gray)
+
+    @staticmethod
+    def GetKeypointOctave(keypoint):
+        return int(keypoint["class_id"])              # Feature_akaze61.cpp:55-57
+
+    def GetKeypointSize(self, keypoint):
+        # Feature_akaze61.cpp:59-61: powf(GetDetectorNominalScaleFactor(), octave)
+        return float(np.float32(self.settings.GetDetectorNominalScaleFactor()) ** np.float32(self.GetKeypointOctave(keypoint)))
+
+    def GetLevels(self):
+        return self.settings.nOctaves
+
+    def close(self):
+        self.ctx.close()

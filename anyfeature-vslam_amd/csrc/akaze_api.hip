@@ -401,7 +401,7 @@ static int akz_enqueue(afv_akaze *a, const uint8_t *d_gray, int nframes, int w, 
 
 static int akz_check(afv_akaze *a, const uint8_t *gray, int nframes, int w, int h, int stride, size_t frame_stride) {
     if (!a || !gray || nframes < 1 || nframes > a->prm.max_batch || w < 80 || h < 40 || w > a->prm.max_width || h > a->prm.max_height ||
-        stride < w || frame_stride < (size_t)stride * (h - 1) + w || (size_t)w * h > (size_t)a->prm.max_width * a->prm.max_height)
+        stride < w || (nframes > 1 && frame_stride < (size_t)stride * (h - 1) + w) || (size_t)w * h > (size_t)a->prm.max_width * a->prm.max_height)
         return AFV_EINVAL;
     return AFV_OK;
 }

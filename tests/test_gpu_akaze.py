@@ -166,3 +166,23 @@ def test_akaze_descriptors_feed_the_hamming_matcher(afv, oracle, gpu_ctx):
     assert np.mean(np.abs(dx - 5.0) < 1.5) > 0.8
     afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
     ctx.close()
+
+
+def test_hip_reproduces_golden_fixture(afv):
+    """independent of the oracle binary: the committed expected outputs (tests/golden/make_golden_akaze.py)"""
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(gold, "akaze61_expected.npz"))
+    toy = np.load(os.path.join(gold, "toy_gray.npz"))["gray"]
+    settings = afv.FeatureExtractorSettings({"FeatureExtractor.numOctaves": 8, "FeatureExtractor.scaleFactor": 1.1892,
+                                             "FeatureExtractor.detectionTh": 0.0005})
+    ext = afv.akaze.FeatureExtractor_akaze61(1000, settings, max_width=640, max_height=480)
+    for name, img in (("toy", toy), ("corners5", afv.synth.corners_frame(5))):
+        kps, desc = ext.detectAndCompute(img)
+        assert np.array_equal(kps, g[name + "_kps"]) and np.array_equal(desc, g[name + "_desc"]), name
+        assert ext.ctx.kcontrast(0) == g[name + "_k0"]
+        assert len(ext.ctx.keypoints(0)) == int(g[name + "_ndetected"])
+    k = kps[0]
+    assert ext.GetKeypointOctave(k) == k["class_id"] and abs(ext.GetKeypointSize(k) - 1.1892 ** k["class_id"]) < 1e-5
+    ext.close()
+    afv.FeatureExtractorSettings({"FeatureExtractor.numOctaves": 8, "FeatureExtractor.scaleFactor": 1.2, "FeatureExtractor.detectionTh": 20.0})
