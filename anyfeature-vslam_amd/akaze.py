@@ -157,6 +157,9 @@ class AkazeContext:
         if self.plan is None or (self.plan.w, self.plan.h) != (w, h):
             self.plan = plan_for(self.params, w, h)
 
+    def set_step_by_step(self, on=True):
+        self.check(self.lib.afv_akaze_set_step_by_step(self.handle, int(on)), "afv_akaze_set_step_by_step")
+
     def profile_enable(self, on=True):
         self.check(self.lib.afv_akaze_profile_enable(self.handle, int(on)), "afv_akaze_profile_enable")
 

@@ -19,6 +19,8 @@ extern "C" void afv_akz_launch_halfsample(const float *src, int w, int h, float 
 extern "C" void afv_akz_launch_flow(const float *lsm, int w, int h, int nframes, const float *kcontrast, int octave, float *flow,
                                     hipStream_t st);
 extern "C" void afv_akz_launch_nld_step(const float *Lt, const float *flow, int w, int h, int nframes, float tau, float *out, hipStream_t st);
+extern "C" int afv_akz_launch_fed_fused(const float *Lt_in, const float *lsm, int w, int h, int nframes, const float *kcontrast, int octave,
+                                        int nsteps, const float *tau, float *Lt_out, hipStream_t st);
 extern "C" int afv_akz_launch_hessian(const float *lsm, int w, int h, int nframes, int s, float *dx, float *dy, float *Lx, float *Ly,
                                       float *Ldet, hipStream_t st);
 
@@ -102,6 +104,7 @@ struct afv_akaze {
     uint8_t *d_out_desc = nullptr;
     int sel_cap = 0, out_cap = 0, qt_M = 0;
     int quota[16] = {};
+    bool step_by_step = false;  // test hook: one kernel per FED step instead of the fused level kernel
     bool profiling = false;
     hipEvent_t ev[3] = {};
     float ms_ss = 0, ms_hess = 0;
@@ -369,6 +372,9 @@ static int akz_enqueue(afv_akaze *a, const uint8_t *d_gray, int nframes, int w, 
         }
         if (afv_akz_launch_gauss(src, 0, L.w, (size_t)L.w * L.h, L.w, L.h, nframes, a->d_taps + 32, P.ksize_one, a->lsm[i], st))
             return AFV_EUNSUPPORTED;
+        if (!a->step_by_step &&
+            afv_akz_launch_fed_fused(src, a->lsm[i], L.w, L.h, nframes, a->d_kcontrast, L.octave, L.nsteps, L.tau, a->lt[i], st))
+            continue;  // conductivity + the whole FED cycle of this level in one kernel
         afv_akz_launch_flow(a->lsm[i], L.w, L.h, nframes, a->d_kcontrast, L.octave, a->flow, st);
         // FED cycle, ping-pong so that the last step lands in Lt of this level
         const float *cur = src;
@@ -645,5 +651,12 @@ extern "C" int afv_akaze_extract_device(afv_akaze *a, const uint8_t *d_gray, int
 extern "C" int afv_akaze_get_quotas(const afv_akaze *a, int32_t *quota16) {
     if (!a || !quota16) return AFV_EINVAL;
     for (int l = 0; l < 16; ++l) quota16[l] = a->quota[l];
+    return AFV_OK;
+}
+
+// test hook: 1 = run pm_g2 and every FED step as its own kernel (the reference structure), 0 = fused level kernel (default)
+extern "C" int afv_akaze_set_step_by_step(afv_akaze *a, int on) {
+    if (!a) return AFV_EINVAL;
+    a->step_by_step = on != 0;
     return AFV_OK;
 }

@@ -222,6 +222,84 @@ __global__ __launch_bounds__(AKZ_T) void k_akz_nld_step(const float *__restrict_
     }
 }
 
+// ---- fused level update: pm_g2 conductivity from Lsmooth + the whole FED cycle (N <= 8 steps) in LDS ----
+// One tile = (64 - 2N) x 48 outputs with a halo of N pixels (one wavefront per LDS row): Lt (halo N) and Lsmooth (halo N + 1,
+// reflect-101 for the Scharr stencil)
+// are read once, the conductivity never leaves LDS, step j updates the region that still has valid neighbours (halo N - 1 - j),
+// and Lt of the new level is written once.  Every pixel sees exactly the per-step arithmetic of k_akz_flow / k_akz_nld_step
+// (zero flux across the image border; out-of-image halo cells are never read), so the result is bit-identical to the
+// step-by-step path — only the traffic changes: 12 B/px per level instead of 8 + 12 B/px per step.
+#define AKZ_FED_MAX 8
+struct AkzTau {
+    float t[AKZ_FED_MAX];
+};
+
+#define AKZ_FT 512
+#define AKZ_FH 48  // output rows per fused tile; the tile is (64 - 2N) x 48 outputs so that output + halo is exactly one wave wide
+__global__ __launch_bounds__(AKZ_FT) void k_akz_fed_fused(const float *__restrict__ Lt_in, const float *__restrict__ lsm, int w, int h,
+                                                          const float *__restrict__ kcontrast, int octave, int nsteps, AkzTau tau,
+                                                          float *__restrict__ Lt_out) {
+    extern __shared__ float s_fed[];
+    const int N = nsteps;
+    const int OW = 64 - 2 * N;                          // output columns of this tile
+    constexpr int LW = 64;                              // Lt / flow planes: output + halo = one wavefront per row
+    const int LH = AKZ_FH + 2 * N;
+    constexpr int SW = LW + 2;                          // Lsmooth plane (one more ring)
+    const int SH = LH + 2;
+    float *s_a = s_fed, *s_b = s_a + LW * LH, *s_c = s_b + LW * LH, *s_s = s_c + LW * LH;
+    const int f = blockIdx.z, x0 = blockIdx.x * OW, y0 = blockIdx.y * AKZ_FH;
+    const float *pin = Lt_in + (size_t)f * w * h, *ps = lsm + (size_t)f * w * h;
+    // thread (tx, ty) owns column tx and rows ty, ty + 8, ... of every LDS plane: no divisions, full wavefronts
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int ly = ty; ly < SH; ly += AKZ_FT / 64) {
+        const float *rs = ps + (size_t)akz_reflect(y0 - N - 1 + ly, h) * w;
+        for (int lx = tx; lx < SW; lx += 64) s_s[ly * SW + lx] = rs[akz_reflect(x0 - N - 1 + lx, w)];
+    }
+    const int gx = x0 - N + tx;                          // this thread's image column
+    {
+        const int cxl = akz_clamp(gx, w);
+        for (int ly = ty; ly < LH; ly += AKZ_FT / 64) s_a[ly * LW + tx] = pin[(size_t)akz_clamp(y0 - N + ly, h) * w + cxl];
+    }
+    __syncthreads();
+    float k = kcontrast[f];
+    for (int i = 0; i < octave; ++i) k = k * 0.75f;
+    const float k2inv = 1.0f / (k * k);
+    for (int ly = ty; ly < LH; ly += AKZ_FT / 64) {
+        const float *c = &s_s[(ly + 1) * SW + tx + 1];
+        const float lxv = akz_scharr_x(c, SW), lyv = akz_scharr_y(c, SW);
+        s_c[ly * LW + tx] = 1.0f / (1.0f + (lxv * lxv + lyv * lyv) * k2inv);
+    }
+    __syncthreads();
+    float *cur = s_a, *nxt = s_b;
+    const bool col_in = gx >= 0 && gx < w;
+    const bool has_r = gx + 1 < w, has_l = gx > 0;
+    for (int j = 0; j < N; ++j) {
+        const int lo = j + 1;                           // first LDS row / column that still has valid neighbours
+        const double hs = 0.5 * (double)tau.t[j];
+        const bool col_ok = col_in && tx >= lo && tx < LW - lo;
+        for (int ly = lo + ty; ly < LH - lo; ly += AKZ_FT / 64) {
+            const int gy = y0 - N + ly;
+            if (!col_ok || gy < 0 || gy >= h) continue;
+            const int p = ly * LW + tx;
+            const float L = cur[p], c = s_c[p];
+            const float xpos = has_r ? (c + s_c[p + 1]) * (cur[p + 1] - L) : 0.0f;
+            const float xneg = has_l ? (s_c[p - 1] + c) * (L - cur[p - 1]) : 0.0f;
+            const float ypos = gy + 1 < h ? (c + s_c[p + LW]) * (cur[p + LW] - L) : 0.0f;
+            const float yneg = gy > 0 ? (s_c[p - LW] + c) * (L - cur[p - LW]) : 0.0f;
+            const float sum = ((xpos - xneg) + ypos) - yneg;
+            nxt[p] = L + (float)(hs * (double)sum);
+        }
+        __syncthreads();
+        float *t = cur; cur = nxt; nxt = t;
+    }
+    float *o = Lt_out + (size_t)f * w * h;
+    if (tx >= N && tx < N + OW && col_in)
+        for (int ly = ty; ly < AKZ_FH; ly += AKZ_FT / 64) {
+            const int gy = y0 + ly;
+            if (gy < h) o[(size_t)gy * w + gx] = cur[(ly + N) * LW + tx];
+        }
+}
+
 // ---- Compute_Multiscale_Derivatives, first derivatives (unscaled): sparse 3-tap Scharr at distance s ----
 #define AKZ_MAX_S 8
 __global__ __launch_bounds__(AKZ_T) void k_akz_deriv1(const float *__restrict__ lsm, int w, int h, int s, float *__restrict__ dx,
@@ -333,6 +411,19 @@ extern "C" void afv_akz_launch_flow(const float *lsm, int w, int h, int nframes,
 
 extern "C" void afv_akz_launch_nld_step(const float *Lt, const float *flow, int w, int h, int nframes, float tau, float *out, hipStream_t st) {
     hipLaunchKernelGGL(k_akz_nld_step, akz_grid(w, h, nframes), dim3(AKZ_T), 0, st, Lt, flow, w, h, tau, out);
+}
+
+// returns 0 when the cycle does not fit the fused kernel (the caller then steps through k_akz_flow + k_akz_nld_step)
+extern "C" int afv_akz_launch_fed_fused(const float *Lt_in, const float *lsm, int w, int h, int nframes, const float *kcontrast, int octave,
+                                        int nsteps, const float *tau, float *Lt_out, hipStream_t st) {
+    if (nsteps < 1 || nsteps > AKZ_FED_MAX) return 0;
+    AkzTau t{};
+    for (int i = 0; i < nsteps; ++i) t.t[i] = tau[i];
+    const int LH = AKZ_FH + 2 * nsteps, OW = 64 - 2 * nsteps;
+    const size_t lds = ((size_t)3 * 64 * LH + (size_t)66 * (LH + 2)) * sizeof(float);
+    const dim3 grid((w + OW - 1) / OW, (h + AKZ_FH - 1) / AKZ_FH, nframes);
+    hipLaunchKernelGGL(k_akz_fed_fused, grid, dim3(AKZ_FT), lds, st, Lt_in, lsm, w, h, kcontrast, octave, nsteps, t, Lt_out);
+    return 1;
 }
 
 extern "C" int afv_akz_launch_hessian(const float *lsm, int w, int h, int nframes, int s, float *dx, float *dy, float *Lx, float *Ly,

@@ -88,6 +88,9 @@ int afv_akaze_get_quotas(const afv_akaze *a, int32_t *quota16);
 /* test / inspection access (synchronises) */
 int afv_akaze_get_plane(afv_akaze *a, int frame, int level, int which, float *out);
 int afv_akaze_get_kcontrast(afv_akaze *a, int frame, float *out);
+/* 1 = conductivity and every FED step as separate kernels (upstream's structure), 0 = one fused kernel per level (default);
+ * both produce identical planes (tests/test_gpu_akaze.py) */
+int afv_akaze_set_step_by_step(afv_akaze *a, int on);
 /* per-stage timing like afv_profile_*: stage 0 scale space, 1 hessian */
 int afv_akaze_profile_enable(afv_akaze *a, int on);
 int afv_akaze_profile_read(afv_akaze *a, float *ms_scale_space, float *ms_hessian, int *launches);

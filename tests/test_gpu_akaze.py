@@ -66,6 +66,20 @@ def test_scale_space_stages_bit_exact(afv, akz, w, h):
     ctx.close()
 
 
+def test_fused_and_step_by_step_scale_space_agree(afv):
+    """the fused level kernel (conductivity + whole FED cycle in LDS) against one kernel per step, at a size whose tiles are
+    ragged on both axes"""
+    ctx = afv.AkazeContext(afv.akaze.default_params(max_width=700, max_height=404, max_batch=1))
+    frame = _frames(afv, 700, 404, (8,))
+    plan = ctx.scale_space(frame)
+    fused = [ctx.plane(0, i, afv.akaze.LT) for i in range(plan.nlevels)]
+    ctx.set_step_by_step(True)
+    ctx.scale_space(frame)
+    for i in range(plan.nlevels):
+        assert np.array_equal(ctx.plane(0, i, afv.akaze.LT), fused[i]), i
+    ctx.close()
+
+
 def test_scale_space_properties_at_config5_size(afv, akz):
     """1280 x 720 (config #5): diffusion keeps the mean (zero-flux border) and obeys the maximum principle; a constant image
     stays constant with zero response"""
