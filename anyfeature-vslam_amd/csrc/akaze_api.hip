@@ -44,9 +44,10 @@ struct AkdState {
     int *cell_cnt;
     unsigned char *keep;
 };
-extern "C" void afv_akz_launch_candidates(const AkdParams *P, int nframes, int *row_count, int *row_start, int *cand, int *cand_count,
-                                          int *status, hipStream_t st);
-extern "C" void afv_akz_launch_suppress(const AkdParams *P, const AkdState *S, int nframes, const int *cand, const int *cand_count,
+extern "C" void afv_akz_launch_candidates(const AkdParams *P, int nframes, int *row_count, int *row_start, int *cand, float *cand_resp,
+                                          int *cand_count, int *status, hipStream_t st);
+extern "C" void afv_akz_launch_suppress(const AkdParams *P, const AkdState *S, int nframes, const int *cand, const float *cand_resp,
+                                        const int *cand_count,
                                         afv_keypoint *kps, int *kp_count, int *status, hipStream_t st);
 struct AksParams {
     int nlevels, W, H, n_ini;
@@ -93,6 +94,7 @@ struct afv_akaze {
     // detection
     AkdParams dp{};
     AkdState ds{};
+    float *d_cand_resp = nullptr;
     int *d_row_count = nullptr, *d_row_start = nullptr, *d_cand = nullptr, *d_cand_count = nullptr, *d_kp_count = nullptr, *d_status = nullptr;
     afv_keypoint *d_kps = nullptr;
     size_t cand_stride_max = 0, rows_stride_max = 0;
@@ -290,6 +292,7 @@ extern "C" int afv_akaze_create(int device, const afv_akaze_params *prm, afv_aka
         if (rc == AFV_OK) rc = akz_alloc(a, &a->d_row_count, rows * B);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->d_row_start, rows * B);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->d_cand, cands * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->d_cand_resp, cands * B);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->d_cand_count, 16 * B);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->d_kp_count, B);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->d_status, 1);
@@ -519,8 +522,8 @@ static int akz_detect_enqueue(afv_akaze *a) {
     D.entry_cap = AKD_ENTRY_CAP; D.kp_cap = AKD_ENTRY_CAP;
     hipStream_t st = a->stream;
     AKZ_HIPCHK(a, hipMemsetAsync(a->d_status, 0, sizeof(int), st));
-    afv_akz_launch_candidates(&D, a->cur_frames, a->d_row_count, a->d_row_start, a->d_cand, a->d_cand_count, a->d_status, st);
-    afv_akz_launch_suppress(&D, &a->ds, a->cur_frames, a->d_cand, a->d_cand_count, a->d_kps, a->d_kp_count, a->d_status, st);
+    afv_akz_launch_candidates(&D, a->cur_frames, a->d_row_count, a->d_row_start, a->d_cand, a->d_cand_resp, a->d_cand_count, a->d_status, st);
+    afv_akz_launch_suppress(&D, &a->ds, a->cur_frames, a->d_cand, a->d_cand_resp, a->d_cand_count, a->d_kps, a->d_kp_count, a->d_status, st);
     AKZ_HIPCHK(a, hipGetLastError());
     a->have_keypoints = true;
     a->have_descriptors = false;

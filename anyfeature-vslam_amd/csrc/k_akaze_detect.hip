@@ -59,7 +59,7 @@ __device__ __forceinline__ bool akd_is_candidate(const AkdParams &P, const AkdLe
 // pass A (write == 0): candidates per row; pass C (write == 1): write them at row offset + rank.  One wavefront per row.
 template <int WRITE>
 __global__ __launch_bounds__(256) void k_akz_cand_rows(AkdParams P, int level, int *__restrict__ row_count, const int *__restrict__ row_start,
-                                                       int *__restrict__ cand, int *__restrict__ status) {
+                                                       int *__restrict__ cand, float *__restrict__ cand_resp, int *__restrict__ status) {
     const AkdLevel L = P.lv[level];
     const int f = blockIdx.y, lane = threadIdx.x & 63;
     const int iy = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -75,7 +75,10 @@ __global__ __launch_bounds__(256) void k_akz_cand_rows(AkdParams P, int level, i
             const unsigned long long m = __ballot(ok);
             if (WRITE && ok) {
                 const int k = base + total + __popcll(m & ((1ull << lane) - 1ull));
-                if (k < L.cand_cap) cand[(size_t)f * P.cand_stride + L.cand_off + k] = iy * L.w + jx;
+                if (k < L.cand_cap) {
+                    cand[(size_t)f * P.cand_stride + L.cand_off + k] = iy * L.w + jx;
+                    cand_resp[(size_t)f * P.cand_stride + L.cand_off + k] = fabsf(ld[(size_t)iy * L.w + jx]);
+                }
                 else atomicExch(status, 1);
             }
             total += __popcll(m);
@@ -126,7 +129,7 @@ struct AkdState {
     unsigned char *keep;      // [frame][entry_cap]
 };
 
-#define AKD_T 512
+#define AKD_T 1024
 #define AKD_PAIRS 18  // 2 grids x 3 x 3 cells per candidate
 #define AKD_ITERS ((64 * AKD_PAIRS + AKD_T - 1) / AKD_T)
 #define AKD_DEAD 0xffffffffu
@@ -138,7 +141,8 @@ struct AkdState {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
     } while (0)
 
-__global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S, const int *__restrict__ cand, const int *__restrict__ cand_count,
+__global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S, const int *__restrict__ cand, const float *__restrict__ cand_resp,
+                                                        const int *__restrict__ cand_count,
                                                         afv_keypoint *__restrict__ kps, int *__restrict__ kp_count, int *__restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) char akd_smem[];
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -146,8 +150,9 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
     unsigned short *s_cnt = reinterpret_cast<unsigned short *>(akd_smem);  // [2][ncells] list lengths, both grids
     unsigned int *s_cnt32 = reinterpret_cast<unsigned int *>(akd_smem);    // the same counters as packed pairs (LDS atomics)
     __shared__ unsigned long long s_best[64];  // per candidate of the round: slot << 32 | response bits (min = first match)
-    __shared__ float s_sx[64], s_sy[64], s_ox[64], s_oy[64];
+    __shared__ float s_sx[64], s_sy[64];
     __shared__ int s_cx[64], s_cy[64], s_loc[64], s_stop, s_nout, s_wsum[AKD_T / 64];
+    __shared__ float s_mx[64], s_my[64];  // position of a candidate's first match
     float *ex = S.ex + (size_t)f * P.entry_cap, *ey = S.ey + (size_t)f * P.entry_cap, *er = S.eresp + (size_t)f * P.entry_cap;
     int *el = S.elevel + (size_t)f * P.entry_cap;
     uint4 *cells = S.cells + (size_t)f * 2 * ncells * AKD_CELLCAP;
@@ -158,6 +163,9 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
     int nE = 0;
     int cur = 0;
     const float inv_cell = 1.0f / AKD_CELL;
+#ifdef AFV_AKZ_STATS
+    const long long st_t0 = wall_clock64();
+#endif
     for (int c = 0; c < P.nlevels; ++c) {
         const AkdLevel L = P.lv[c];
         if (c > 0) {  // the previous level's grid becomes "prev"; the other one is recycled
@@ -166,11 +174,13 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
             __syncthreads();
         }
         const int prv = cur ^ 1;
-        const float *ld = L.ldet + (size_t)f * L.w * L.h;
         const int *cd = cand + (size_t)f * P.cand_stride + L.cand_off;
+        const float *cr = cand_resp + (size_t)f * P.cand_stride + L.cand_off;
         const int n = cand_count[f * 16 + c];
         const float size2 = L.psize * L.psize;
         int pos = 0;
+        int pf_pos = -1, pf_idx = 0;
+        float pf_resp = 0.f;
 #ifdef AFV_AKZ_STATS
         int st_rounds = 0;
 #endif
@@ -179,15 +189,21 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
             ++st_rounds;
 #endif
             const int nround = min(64, n - pos);
-            // ---- 1. the round's candidates (wave 0) ----
+            // ---- 1. the round's candidates (wave 0); the next 64 are prefetched while this round is scanned ----
             float sx = 0, sy = 0, resp = 0;
             int cx = 0, cy = 0;
             const bool act = tid < nround;
             if (tid < 64) {
                 if (act) {
-                    const int idx = cd[pos + tid];
+                    int idx;
+                    if (pf_pos == pos) {
+                        idx = pf_idx;
+                        resp = pf_resp;
+                    } else {
+                        idx = cd[pos + tid];
+                        resp = cr[pos + tid];
+                    }
                     const int iy = idx / L.w, jx = idx - iy * L.w;
-                    resp = fabsf(ld[idx]);
                     sx = (float)jx * L.ratio;
                     sy = (float)iy * L.ratio;
                     cx = min((int)(sx * inv_cell), P.gw - 1);
@@ -195,15 +211,23 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
                 }
                 s_sx[tid] = sx; s_sy[tid] = sy; s_cx[tid] = cx; s_cy[tid] = cy;
                 s_best[tid] = AKD_NONE;
+                pf_pos = pos + 64;  // valid if this round commits all 64 (the common case)
+                if (pf_pos + tid < n) {
+                    pf_idx = cd[pf_pos + tid];
+                    pf_resp = cr[pf_pos + tid];
+                }
             }
             __syncthreads();
             // ---- 2. neighbourhood scan: the (candidate, cell) pairs of the round spread over the whole workgroup ----
             unsigned long long lbest[AKD_ITERS];
             int lloc[AKD_ITERS];
+            float lmx[AKD_ITERS], lmy[AKD_ITERS];
 #pragma unroll
             for (int it = 0; it < AKD_ITERS; ++it) {
                 lbest[it] = AKD_NONE;
                 lloc[it] = 0;
+                lmx[it] = 0.f;
+                lmy[it] = 0.f;
                 const int t = tid + it * AKD_T;
                 if (t >= nround * AKD_PAIRS) continue;
                 const int q = t / AKD_PAIRS, k = t - q * AKD_PAIRS;
@@ -219,6 +243,7 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
                 const float qx = s_sx[q], qy = s_sy[q];
                 unsigned long long best = AKD_NONE;
                 int beste = 0;
+                float bx = 0.f, by = 0.f;
                 for (int e = 0; e < cn; ++e) {
                     const uint4 v = cells[lb + e];
                     if (v.w == AKD_DEAD) continue;  // replaced earlier: the entry lives on in another list
@@ -228,6 +253,8 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
                         if (key < best) {
                             best = key;
                             beste = e;
+                            bx = __uint_as_float(v.x);
+                            by = __uint_as_float(v.y);
                         }
                     }
                 }
@@ -235,6 +262,8 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
                     atomicMin(&s_best[q], best);
                     lbest[it] = best;
                     lloc[it] = (int)lb + beste;
+                    lmx[it] = bx;
+                    lmy[it] = by;
                 }
             }
             __syncthreads();
@@ -243,7 +272,11 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
             for (int it = 0; it < AKD_ITERS; ++it) {
                 if (lbest[it] != AKD_NONE) {
                     const int q = (tid + it * AKD_T) / AKD_PAIRS;
-                    if (s_best[q] == lbest[it]) s_loc[q] = lloc[it];
+                    if (s_best[q] == lbest[it]) {
+                        s_loc[q] = lloc[it];
+                        s_mx[q] = lmx[it];
+                        s_my[q] = lmy[it];
+                    }
                 }
             }
             __syncthreads();
@@ -257,30 +290,28 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
                     if (first < 0) type = 1;
                     else if (resp > __uint_as_float((unsigned int)(b & 0xffffffffu))) {
                         type = 2;
-                        const uint4 v = cells[s_loc[tid]];
-                        oex = __uint_as_float(v.x);
-                        oey = __uint_as_float(v.y);
+                        oex = s_mx[tid];
+                        oey = s_my[tid];
                     }
                 }
                 // a lane's decision stands unless an earlier lane of the round changes what its search sees: a new / moved
                 // entry inside its radius, or a replaced entry that used to lie inside its radius
-                s_ox[tid] = oex;
-                s_oy[tid] = oey;
+                // (uniform loop over the round's lanes; lane j's data is broadcast with v_readlane)
                 const unsigned long long modm = __ballot(type != 0), repm = __ballot(type == 2);
-                AKD_WAVE_SYNC();
                 bool conflict = false;
-                if (act) {
-                    unsigned long long mm = modm & ((1ull << lane) - 1ull);
-                    while (mm) {
-                        const int j = (int)__builtin_ctzll(mm);
-                        mm &= mm - 1;
-                        const float dx = sx - s_sx[j], dy = sy - s_sy[j];
-                        if (dx * dx + dy * dy <= size2) conflict = true;
-                        if ((repm >> j) & 1ull) {
-                            const float ux = sx - s_ox[j], uy = sy - s_oy[j];
-                            if (ux * ux + uy * uy <= size2) conflict = true;
-                        }
+                for (int j = 0; j + 1 < nround; ++j) {
+                    if (!((modm >> j) & 1ull)) continue;  // wave-uniform
+                    const float xj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sx), j));
+                    const float yj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sy), j));
+                    const float dx = sx - xj, dy = sy - yj;
+                    bool hit = dx * dx + dy * dy <= size2;
+                    if ((repm >> j) & 1ull) {
+                        const float oxj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, oex), j));
+                        const float oyj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, oey), j));
+                        const float ux = sx - oxj, uy = sy - oyj;
+                        hit = hit || (ux * ux + uy * uy <= size2);
                     }
+                    if (hit && act && lane > j) conflict = true;
                 }
                 const unsigned long long cm = __ballot(conflict);
                 const int stop = cm ? (int)__builtin_ctzll(cm) : nround;
@@ -327,6 +358,9 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
         if (tid == 0 && f == 0) printf("akz_suppress: level %d candidates %d rounds %d entries %d\n", c, n, st_rounds, nE);
 #endif
     }
+#ifdef AFV_AKZ_STATS
+    const long long st_t1 = wall_clock64();
+#endif
     // ---- "Now filter points with the upper scale level": entry i of level c is repeated if a LATER entry of level c+1 lies
     //      within size_i and has a larger response.  Per level pair: grid of the level c+1 entries, then one thread per entry.
     for (int i = tid; i < nE; i += AKD_T) keep[i] = 1;
@@ -368,6 +402,9 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
         __threadfence_block();
         __syncthreads();
     }
+#ifdef AFV_AKZ_STATS
+    const long long st_t2 = wall_clock64();
+#endif
     // ---- Do_Subpixel_Refinement + ordered compaction ----
     int nout = 0;
     for (int i0 = 0; i0 < nE; i0 += AKD_T) {
@@ -428,20 +465,26 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
         nout += tot;
         __syncthreads();
     }
+#ifdef AFV_AKZ_STATS
+    if (tid == 0 && f == 0) printf("akz_suppress phases (us at 100 MHz): rounds %lld upper %lld subpixel %lld\n", (st_t1 - st_t0) / 100, (st_t2 - st_t1) / 100, (wall_clock64() - st_t2) / 100);
+#endif
     if (tid == 0) kp_count[f] = min(nout, P.kp_cap);
 }
 
-extern "C" void afv_akz_launch_candidates(const AkdParams *P, int nframes, int *row_count, int *row_start, int *cand, int *cand_count,
-                                          int *status, hipStream_t st) {
+extern "C" void afv_akz_launch_candidates(const AkdParams *P, int nframes, int *row_count, int *row_start, int *cand, float *cand_resp,
+                                          int *cand_count, int *status, hipStream_t st) {
     for (int l = 0; l < P->nlevels; ++l)
-        hipLaunchKernelGGL(k_akz_cand_rows<0>, dim3((P->lv[l].h + 3) / 4, nframes), dim3(256), 0, st, *P, l, row_count, row_start, cand, status);
+        hipLaunchKernelGGL(k_akz_cand_rows<0>, dim3((P->lv[l].h + 3) / 4, nframes), dim3(256), 0, st, *P, l, row_count, row_start, cand, cand_resp,
+                           status);
     hipLaunchKernelGGL(k_akz_cand_scan, dim3(P->nlevels, nframes), dim3(256), 0, st, *P, row_count, row_start, cand_count);
     for (int l = 0; l < P->nlevels; ++l)
-        hipLaunchKernelGGL(k_akz_cand_rows<1>, dim3((P->lv[l].h + 3) / 4, nframes), dim3(256), 0, st, *P, l, row_count, row_start, cand, status);
+        hipLaunchKernelGGL(k_akz_cand_rows<1>, dim3((P->lv[l].h + 3) / 4, nframes), dim3(256), 0, st, *P, l, row_count, row_start, cand, cand_resp,
+                           status);
 }
 
-extern "C" void afv_akz_launch_suppress(const AkdParams *P, const AkdState *S, int nframes, const int *cand, const int *cand_count,
+extern "C" void afv_akz_launch_suppress(const AkdParams *P, const AkdState *S, int nframes, const int *cand, const float *cand_resp,
+                                        const int *cand_count,
                                         afv_keypoint *kps, int *kp_count, int *status, hipStream_t st) {
     const size_t lds = ((size_t)P->gw * P->gh * 2 * sizeof(unsigned short) + 15) & ~(size_t)15;  // two count grids (u16)
-    hipLaunchKernelGGL(k_akz_suppress, dim3(nframes), dim3(AKD_T), lds, st, *P, *S, cand, cand_count, kps, kp_count, status);
+    hipLaunchKernelGGL(k_akz_suppress, dim3(nframes), dim3(AKD_T), lds, st, *P, *S, cand, cand_resp, cand_count, kps, kp_count, status);
 }
