@@ -66,6 +66,28 @@ def test_invalid_arguments_do_not_crash(afv):
     assert lib.afv_profile_enable(None, 1) == afv._lib.EINVAL
 
 
+def test_akaze_abi_without_gpu(afv):
+    """the AKAZE entry points: plan (host only) works anywhere; creation fails loudly without a device; NULLs are EINVAL"""
+    import torch
+    lib = afv._lib.load()
+    prm = afv.akaze.default_params()
+    assert (prm.omax, prm.nsublevels, prm.kcontrast_nbins, prm.nfeatures) == (2, 4, 300, 1000)
+    assert abs(prm.dthreshold - 0.0005) < 1e-9 and abs(prm.scale_factor - 1.1892) < 1e-6
+    plan = afv.akaze.plan_for(prm, 1280, 720)
+    assert plan.nlevels == 8 and [plan.lv[i].nsteps for i in range(8)] == [0, 3, 3, 4, 4, 5, 6, 7]
+    with pytest.raises(ValueError):
+        afv.akaze.plan_for(prm, 8, 8)
+    h = C.c_void_p()
+    assert lib.afv_akaze_create(0, None, C.byref(h)) == afv._lib.EINVAL
+    lib.afv_akaze_destroy(None)
+    assert lib.afv_akaze_detect(None) == afv._lib.EINVAL
+    assert lib.afv_akaze_extract(None, None, 0, 0, 0, 0, 0, None, None, 0, None) == afv._lib.EINVAL
+    assert lib.afv_akaze_get_features(None, 0, None, None, 0, None) == afv._lib.EINVAL
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            afv.AkazeContext()
+
+
 def test_host_hamming_utility(afv, oracle):
     d = afv.synth.random_descriptors(4, 16)
     for i in range(0, 16, 2):

@@ -323,3 +323,44 @@ def test_config4_pair_jobs_from_descriptor_table(afv, oracle, matcher, gpu_ctx):
         assert got[j] == wn, j
     assert got.sum() > 50  # only keyframes a few perturbation steps apart still match
     matcher.mbCheckOrientation = True
+
+
+def test_three_threads_three_contexts(afv, oracle):
+    """the matchers are called from three threads of the reference (tracking, local mapping, loop closing); the
+    C-ABI is used with one context per calling thread.  Three threads extract + match concurrently (ctypes releases the GIL
+    inside the calls); every thread must reproduce the serial results."""
+    import threading
+    s = afv.synth
+    imgs = [s.corners_frame(40 + i) for i in range(3)]
+    serial_ctx = afv.Context()
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+    want = []
+    for im in imgs:
+        k1, d1 = serial_ctx.extract(im)
+        k2, d2 = serial_ctx.extract(np.roll(im, 3, axis=1))
+        m = afv.FeatureMatcher(0.7, True, ctx=serial_ctx)
+        want.append((d1.copy(), m.SearchByBoW(afv.FeatureView(d1, angles=k1["angle"]), afv.FeatureView(d2, angles=k2["angle"]))))
+    got = [None] * 3
+    errs = []
+
+    def work(i):
+        try:
+            ctx = afv.Context()
+            m = afv.FeatureMatcher(0.7, True, ctx=ctx)
+            for _ in range(5):
+                k1, d1 = ctx.extract(imgs[i])
+                k2, d2 = ctx.extract(np.roll(imgs[i], 3, axis=1))
+                r = m.SearchByBoW(afv.FeatureView(d1, angles=k1["angle"]), afv.FeatureView(d2, angles=k2["angle"]))
+            got[i] = (d1.copy(), r)
+            ctx.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for i in range(3):
+        assert np.array_equal(got[i][0], want[i][0])
+        assert got[i][1][1] == want[i][1][1] and np.array_equal(got[i][1][0], want[i][1][0])
+    serial_ctx.close()
