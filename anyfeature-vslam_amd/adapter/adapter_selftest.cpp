@@ -67,5 +67,48 @@ int main(int argc, char **argv) {
     bool ok = dump(out + ".kps1", k1.data(), k1.size() * sizeof(afv::KeyPoint)) && dump(out + ".desc1", d1.ptr(), d1.data.size()) &&
               dump(out + ".kps2", k2.data(), k2.size() * sizeof(afv::KeyPoint)) && dump(out + ".desc2", d2.ptr(), d2.data.size()) &&
               dump(out + ".match21", m21.data(), m21.size() * sizeof(int)) && dump(out + ".size1", size.data(), size.size() * 4);
+    if (!ok) return 5;
+
+    // ---- Vocabulary::transform + SearchByBoW over the feature vectors (KeyFrame::ComputeBoW -> SearchByBoW(KF, KF)) ----
+    {
+        // deterministic 2-level tree, k = 6: node descriptors from an LCG, weights 1 (0 for every 7th leaf)
+        const int k = 6, L = 2, n = 1 + k + k * k;
+        std::vector<int> parent((size_t)n, 0);
+        std::vector<uint8_t> leaf((size_t)n, 0), nd((size_t)n * 32, 0);
+        std::vector<double> wgt((size_t)n, 1.0);
+        for (int i = 1 + k; i < n; ++i) { parent[i] = 1 + (i - 1 - k) / k; leaf[i] = 1; if (i % 7 == 0) wgt[i] = 0.0; }
+        uint32_t x = 12345u;
+        for (size_t i = 32; i < nd.size(); ++i) { x = x * 1664525u + 1013904223u; nd[i] = (uint8_t)((x >> 8) & 255u); }
+        wgt[0] = 0.0;
+        afv::VocabularyHip voc(extractor.context(), k, L, parent, leaf, nd, wgt);
+        afv::BowVector bow1, bow2;
+        afv::FeatureVector fv1, fv2;
+        voc.transform(d1.ptr(), (int)k1.size(), bow1, fv1, 1);
+        voc.transform(d2.ptr(), (int)k2.size(), bow2, fv2, 1);
+        afv::FeatureView b1 = v1, b2 = v2;
+        b1.featVec = &fv1; b2.featVec = &fv2;
+        std::vector<int> m12;
+        const int nb = matcher.SearchByBoW(b1, b2, m12);
+        std::printf("bow %zu %zu %d\n", fv1.size(), fv2.size(), nb);
+        std::vector<int> flat;  // (node, feature) pairs of fv1
+        for (const auto &kv : fv1) for (unsigned f : kv.second) { flat.push_back((int)kv.first); flat.push_back((int)f); }
+        ok = dump(out + ".bowmatch12", m12.data(), m12.size() * sizeof(int)) && dump(out + ".fv1", flat.data(), flat.size() * sizeof(int)) &&
+             dump(out + ".vocdesc", nd.data(), nd.size());
+        if (!ok) return 5;
+    }
+    // ---- AKAZE61 plugin ----
+    {
+        auto s2 = std::make_shared<afv::FeatureExtractorSettings>();
+        afv::FeatureExtractorSettings::numOctaves0 = 8;
+        afv::FeatureExtractorSettings::scaleFactor0 = 1.1892f;
+        s2->detectTh = 0.0005f;
+        afv::FeatureExtractor_akaze61_hip akz(1000, s2, 0, w, h);
+        std::vector<afv::KeyPoint> ka;
+        afv::Mat8 da;
+        akz.detectAndCompute(img, ka, da);
+        std::printf("akaze %zu %d\n", ka.size(), da.cols);
+        if (ka.empty() || da.cols != 61 || akz.GetKeypointOctave(ka[0]) != ka[0].class_id) return 6;
+        ok = dump(out + ".akz_kps", ka.data(), ka.size() * sizeof(afv::KeyPoint)) && dump(out + ".akz_desc", da.ptr(), da.data.size());
+    }
     return ok ? 0 : 5;
 }

@@ -23,6 +23,9 @@
 #include <utility>
 #include <vector>
 
+#include <cstring>
+
+#include "afv_akaze.h"
 #include "afv_hip.h"
 
 #ifdef AFV_WITH_OPENCV
@@ -258,6 +261,115 @@ class FeatureMatcherHip {
     afv_ctx *ctx;
     float mfNNratio;
     bool mbCheckOrientation;
+};
+
+
+// ---- AKAZE61 plugin (reference include/Feature_akaze61.h, src/Feature_akaze61.cpp) ----
+class FeatureExtractor_akaze61_hip {
+  public:
+    FeatureExtractor_akaze61_hip(const int &nfeatures_, std::shared_ptr<FeatureExtractorSettings> &settings_, int device = 0,
+                                 int max_width = 1280, int max_height = 720)
+        : settings(settings_), nfeatures(nfeatures_) {
+        afv_akaze_params p;
+        afv_akaze_default_params(&p);
+        p.omax = FeatureExtractorSettings::numOctaves0 / 4;        // Feature_akaze61.cpp:12
+        p.nsublevels = FeatureExtractorSettings::numOctaves0 / 2;  // :13
+        p.dthreshold = settings->detectTh;                         // :14
+        p.nfeatures = nfeatures;
+        p.scale_factor = FeatureExtractorSettings::scaleFactor0;
+        p.max_width = max_width; p.max_height = max_height; p.max_batch = 1;
+        const int rc = afv_akaze_create(device, &p, &akz);
+        if (rc != AFV_OK) fatal("afv_akaze_create", rc, nullptr);
+        cap = nfeatures + 64;
+        kbuf.resize((size_t)cap);
+        dbuf.resize((size_t)cap * 61);
+    }
+    ~FeatureExtractor_akaze61_hip() { afv_akaze_destroy(akz); }
+    FeatureExtractor_akaze61_hip(const FeatureExtractor_akaze61_hip &) = delete;
+    FeatureExtractor_akaze61_hip &operator=(const FeatureExtractor_akaze61_hip &) = delete;
+
+    // detectAndCompute (Feature_akaze61.cpp:17-24): initializeExtractor + detectKeypoints + filterKeypoints + computeDescriptors +
+    // mergeKeypointLevels in one call; descriptors = N x 61 CV_8U
+    template <class ImageT, class MatT>
+    void detectAndCompute(const ImageT &img, std::vector<KeyPoint> &keypoints, MatT &descriptors) {
+        const auto &g = img.grayImg;
+        if (g.empty()) return;
+        int32_t n = 0;
+        const int rc = afv_akaze_extract(akz, g.ptr(), 1, g.cols, g.rows, (int)row_step(g), 0, kbuf.data(), dbuf.data(), cap, &n);
+        if (rc != AFV_OK) {
+            std::fprintf(stderr, "afv: afv_akaze_extract failed: %s (%s)\n", afv_strerror(rc), afv_akaze_last_error(akz));
+            std::terminate();
+        }
+        keypoints.resize((size_t)n);
+        static_assert(sizeof(KeyPoint) == sizeof(afv_keypoint), "KeyPoint layout");
+        if (n) std::memcpy(static_cast<void *>(keypoints.data()), kbuf.data(), (size_t)n * sizeof(afv_keypoint));
+        descriptors.create(n, 61);
+        for (int i = 0; i < n; ++i) std::memcpy(descriptors.ptr(i), dbuf.data() + (size_t)i * 61, 61);
+    }
+    int GetKeypointOctave(const KeyPoint &kp) const { return kp.class_id; }  // Feature_akaze61.cpp:55-57
+    float GetKeypointSize(const KeyPoint &kp) const { return powf(FeatureExtractorSettings::scaleFactor0, float(GetKeypointOctave(kp))); }  // :59-61
+    std::shared_ptr<FeatureExtractorSettings> settings;
+
+  private:
+    template <class M> static size_t row_step(const M &m) { return (size_t)m.cols; }
+    int nfeatures, cap = 0;
+    afv_akaze *akz = nullptr;
+    std::vector<afv_keypoint> kbuf;
+    std::vector<uint8_t> dbuf;
+};
+
+// ---- Vocabulary::transform on the GPU (reference include/Vocabulary.h, src/Vocabulary.cpp:156-206) ----
+using BowVector = std::map<unsigned, double>;  // DBoW2::BowVector (word id -> weight)
+
+class VocabularyHip {
+  public:
+    // nodes in DBoW2 id order (node 0 = root): parent id, leaf flag, 32-byte descriptor, weight — what loadFromTextFile reads
+    VocabularyHip(afv_ctx *ctx_, int k_, int L_, const std::vector<int> &parent, const std::vector<uint8_t> &is_leaf,
+                  const std::vector<uint8_t> &node_desc, const std::vector<double> &weight_)
+        : ctx(ctx_), k(k_), L(L_), weight(weight_) {
+        const int n = (int)parent.size();
+        std::vector<int32_t> child_ptr((size_t)n + 1, 0), child_idx((size_t)std::max(n - 1, 1));
+        for (int i = 1; i < n; ++i) child_ptr[(size_t)parent[i] + 1]++;
+        for (int i = 0; i < n; ++i) child_ptr[i + 1] += child_ptr[i];
+        std::vector<int32_t> fill(child_ptr.begin(), child_ptr.end() - 1);
+        for (int i = 1; i < n; ++i) child_idx[(size_t)fill[parent[i]]++] = i;  // children keep their id order
+        word_id.assign((size_t)n, -1);
+        int words = 0;
+        for (int i = 0; i < n; ++i)
+            if (is_leaf[i]) word_id[i] = words++;
+        const int rc = afv_vocab_create(ctx, k, L, n, child_ptr.data(), child_idx.data(), node_desc.data(), 32, &voc);
+        if (rc != AFV_OK) fatal("afv_vocab_create", rc, ctx);
+    }
+    ~VocabularyHip() { afv_vocab_destroy(ctx, voc); }
+    VocabularyHip(const VocabularyHip &) = delete;
+    VocabularyHip &operator=(const VocabularyHip &) = delete;
+
+    // transform(mDescriptors, mBowVec, mFeatVec) with levelsup = 4 (Vocabulary.cpp:156-206)
+    void transform(const uint8_t *descriptors, int n, BowVector &bow, FeatureVector &fv, int levelsup = 4) {
+        bow.clear();
+        fv.clear();
+        std::vector<int32_t> leaf((size_t)std::max(n, 1)), nid((size_t)std::max(n, 1));
+        const int rc = afv_bow_transform(ctx, voc, descriptors, n, levelsup, leaf.data(), nid.data());
+        if (rc != AFV_OK) fatal("afv_bow_transform", rc, ctx);
+        for (int i = 0; i < n; ++i) {
+            const double w = weight[(size_t)leaf[i]];
+            if (w > 0) {
+                bow[(unsigned)word_id[(size_t)leaf[i]]] += w;  // BowVector::addWeight
+                fv[(unsigned)nid[i]].push_back((unsigned)i);    // FeatureVector::addFeature
+            }
+        }
+        double s = 0;
+        for (const auto &kv : bow) s += std::fabs(kv.second);
+        if (s > 0)
+            for (auto &kv : bow) kv.second /= s;  // BowVector::normalize(L1)
+    }
+
+  private:
+    afv_ctx *ctx;
+    int k, L;
+    std::vector<double> weight;
+    std::vector<int32_t> word_id;
+    afv_vocab *voc = nullptr;
 };
 
 }  // namespace afv

@@ -20,7 +20,8 @@ def test_cpp_adapter_end_to_end(afv, oracle, tmp_path):
     out = str(tmp_path / "o")
     r = subprocess.run([BIN, str(raw), "640", "480", out], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    n1, n2, nm = [int(v) for v in r.stdout.split()]
+    lines = r.stdout.strip().splitlines()
+    n1, n2, nm = [int(v) for v in lines[0].split()]
     k1 = np.fromfile(out + ".kps1", dtype=afv.KP_DTYPE); d1 = np.fromfile(out + ".desc1", dtype=np.uint8).reshape(-1, 32)
     k2 = np.fromfile(out + ".kps2", dtype=afv.KP_DTYPE); d2 = np.fromfile(out + ".desc2", dtype=np.uint8).reshape(-1, 32)
     m21 = np.fromfile(out + ".match21", dtype=np.int32)
@@ -34,3 +35,38 @@ def test_cpp_adapter_end_to_end(afv, oracle, tmp_path):
                                           check_orientation=True)
     assert nm == wn and np.array_equal(m21, want) and wn > 300
     assert np.array_equal(size1, oracle.size_sigma(ok1)[0])
+
+    # Vocabulary::transform + SearchByBoW over the feature vectors (the selftest's LCG tree, k = 6, L = 2, levelsup 1)
+    from oracle import akaze_binding as akz
+    k, L = 6, 2
+    n = 1 + k + k * k
+    parent = [0] * (1 + k) + [1 + (i - 1 - k) // k for i in range(1 + k, n)]
+    leaf = [False] * (1 + k) + [True] * (k * k)
+    weight = np.ones(n); weight[[i for i in range(1 + k, n) if i % 7 == 0]] = 0.0; weight[0] = 0.0
+    nd = np.fromfile(out + ".vocdesc", dtype=np.uint8).reshape(n, 32)
+    voc = afv.Vocabulary(k, L, parent, nd, weight, leaf)
+    fvs = []
+    for d in (od1, od2):
+        lf, nid = oracle.bow_transform(voc, d, 1)
+        fv = {}
+        for i in np.nonzero(voc.weight[lf] > 0)[0].tolist():
+            fv.setdefault(int(nid[i]), []).append(i)
+        fvs.append(sorted(fv.items()))
+    flat = np.fromfile(out + ".fv1", dtype=np.int32).reshape(-1, 2)
+    assert flat.tolist() == [[nd_, f] for nd_, idx in fvs[0] for f in idx]
+    nb = int(lines[1].split()[3])
+    wantb, wnb = oracle.search_by_bow_kf_kf(od1, od2, fvs[0], fvs[1], None, None, ok1["angle"], ok2["angle"], 75.0, 0.6, True)
+    assert nb == wnb and np.array_equal(np.fromfile(out + ".bowmatch12", dtype=np.int32), wantb)
+    # AKAZE61 plugin through the C++ adapter vs the oracle pipeline
+    ka = np.fromfile(out + ".akz_kps", dtype=afv.KP_DTYPE); da = np.fromfile(out + ".akz_desc", dtype=np.uint8).reshape(-1, 61)
+    plan = akz.make_plan(640, 480)
+    levels, _ = akz.full_evolution(img, plan)
+    kp = akz.subpixel(plan, levels, akz.find_extrema(plan, levels))
+    q = oracle.quotas_extractor(1000, 8, 1.1892)
+    chosen = []
+    for lvl in range(8):
+        idx = np.nonzero(kp["class_id"] == lvl)[0]
+        if len(idx):
+            chosen.append(idx[oracle.quadtree(kp["x"][idx], kp["y"][idx], kp["response"][idx], int(q[lvl]), 640, 480, tiebreak=np.arange(len(idx)))])
+    wk, wd = akz.compute_descriptors(plan, levels, kp[np.concatenate(chosen)])
+    assert ka.tobytes() == wk.tobytes() and np.array_equal(da, wd)
