@@ -3,13 +3,23 @@ import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 afv = importlib.import_module("anyfeature-vslam_amd")
+
+
+def med(fn, n=50, warm=3):
+    """median wall time of one call in ms (the HIP runtime has occasional multi-ms housekeeping stalls: a mean would report those)"""
+    for _ in range(warm):
+        r = fn()
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter(); r = fn(); ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)) * 1e3, r
+
 ctx = afv.Context()
 s = afv.synth
 img = s.corners_frame(1)
-for _ in range(3): ctx.extract(img)
-t = time.perf_counter(); N = 50
-for _ in range(N): k, d = ctx.extract(img)
-print("afv_orb_extract (1 frame, host buffers): %.3f ms" % ((time.perf_counter() - t) / N * 1e3))
+N = 50
+ms, (k, d) = med(lambda: ctx.extract(img))
+print("afv_orb_extract (1 frame, host buffers): %.3f ms" % ms)
 k2, d2 = ctx.extract(np.roll(img, 4, axis=1))
 afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
 m = afv.FeatureMatcher(0.6, True, ctx=ctx)
@@ -20,15 +30,11 @@ v1 = afv.FeatureView(d, angles=k["angle"]); v2 = afv.FeatureView(d2, angles=k2["
 b1 = afv.FeatureView(d, fv(len(d), 100, 3), angles=k["angle"], valid=np.ones(len(d), np.uint8))
 b2 = afv.FeatureView(d2, fv(len(d2), 100, 4), angles=k2["angle"], valid=np.ones(len(d2), np.uint8))
 for name, a, b in (("brute force 1000x1000", v1, v2), ("BoW 100 nodes", b1, b2)):
-    for _ in range(3): m.SearchByBoW(a, b)
-    t = time.perf_counter()
-    for _ in range(N): r = m.SearchByBoW(a, b)
-    print("SearchByBoW %-24s %.3f ms  (%d matches)" % (name, (time.perf_counter() - t) / N * 1e3, r[1]))
+    ms, r = med(lambda: m.SearchByBoW(a, b))
+    print("SearchByBoW %-24s %.3f ms  (%d matches)" % (name, ms, r[1]))
 pairs = [(b1, b2)] * 20
-for _ in range(2): m.SearchByBoW_batch(pairs)
-t = time.perf_counter()
-for _ in range(10): m.SearchByBoW_batch(pairs)
-print("SearchByBoW_batch 20 BoW jobs: %.3f ms" % ((time.perf_counter() - t) / 10 * 1e3))
+ms, _ = med(lambda: m.SearchByBoW_batch(pairs), n=20)
+print("SearchByBoW_batch 20 BoW jobs: %.3f ms" % ms)
 # SearchForTriangulation: 100-node feature vectors, nothing has a map point yet, a plausible F12
 has0 = np.zeros(len(d), np.uint8); has02 = np.zeros(len(d2), np.uint8)
 p1 = np.stack([k["x"], k["y"]], 1); p2 = np.stack([k2["x"], k2["y"]], 1)
@@ -36,31 +42,26 @@ sz2, sg2, _ = ctx.size_sigma(k2)
 t1 = afv.FeatureView(d, fv(len(d), 100, 3), has0, pts=p1)
 t2 = afv.FeatureView(d2, fv(len(d2), 100, 4), has02, pts=p2, sigma2=sz2 * sz2)
 F12 = np.array([[0, 0, 0], [0, 0, -1e-3], [0, 1e-3, 0]], np.float32)   # pure x translation: epipolar lines are rows
-for _ in range(3): m.SearchForTriangulation(t1, t2, F12, (1e6, 240.0))
-t = time.perf_counter()
-for _ in range(N): r = m.SearchForTriangulation(t1, t2, F12, (1e6, 240.0))
-print("SearchForTriangulation 100 nodes: %.3f ms  (%d pairs)" % ((time.perf_counter() - t) / N * 1e3, r[1]))
+ms, r = med(lambda: m.SearchForTriangulation(t1, t2, F12, (1e6, 240.0)))
+print("SearchForTriangulation 100 nodes: %.3f ms  (%d pairs)" % (ms, r[1]))
 # projection searches
 sz1, _, _ = ctx.size_sigma(k)
 F = afv.FrameGridView(d, p1, sz1, angles=k["angle"])
 Q = afv.ProjectionQueries(d2, k2["x"] - 4, k2["y"], 15.0 * sz2, sz2 / np.float32(1.2), sz2 * np.float32(1.2), angles=k2["angle"])
 for name, kw in (("local map", {}), ("last frame", {"last_frame": True})):
-    for _ in range(3): m.SearchByProjection(F, Q, **kw)
-    t = time.perf_counter()
-    for _ in range(N): r = m.SearchByProjection(F, Q, **kw)
-    print("SearchByProjection %-12s %.3f ms  (%d matches)" % (name, (time.perf_counter() - t) / N * 1e3, r[1]))
-for _ in range(3): m.Fuse_sim3(F, Q)
-t = time.perf_counter()
-for _ in range(N): r = m.Fuse_sim3(F, Q)
-print("Fuse core: %.3f ms  (%d found)" % ((time.perf_counter() - t) / N * 1e3, r[1]))
+    ms, r = med(lambda: m.SearchByProjection(F, Q, **kw))
+    print("SearchByProjection %-12s %.3f ms  (%d matches)" % (name, ms, r[1]))
+ms, r = med(lambda: m.Fuse_sim3(F, Q))
+print("Fuse core: %.3f ms  (%d found)" % (ms, r[1]))
 Q1 = afv.ProjectionQueries(d2, k2["x"], k2["y"], np.full(len(k2), 100.0, np.float32), np.zeros(len(k2), np.float32),
                            np.full(len(k2), 10.0, np.float32), valid=(k2["octave"] == 0).astype(np.uint8), angles=k2["angle"])
-for _ in range(3): m.SearchForInitialization(Q1, F)
-t = time.perf_counter()
-for _ in range(N): r = m.SearchForInitialization(Q1, F)
-print("SearchForInitialization (window 100): %.3f ms  (%d matches)" % ((time.perf_counter() - t) / N * 1e3, r[1]))
+ms, r = med(lambda: m.SearchForInitialization(Q1, F))
+print("SearchForInitialization (window 100): %.3f ms  (%d matches)" % (ms, r[1]))
 voc = afv.Vocabulary.random(3, k=10, L=4, ctx=ctx)
-for _ in range(3): voc.transform_nodes(d, 2)
-t = time.perf_counter()
-for _ in range(N): voc.transform_nodes(d, 2)
-print("Vocabulary descent (k=10, L=4, %d descriptors): %.3f ms" % (len(d), (time.perf_counter() - t) / N * 1e3))
+ms, _ = med(lambda: voc.transform_nodes(d, 2))
+print("Vocabulary descent (k=10, L=4, %d descriptors): %.3f ms" % (len(d), ms))
+# AKAZE61 single frame (1280 x 720, host buffers)
+actx = afv.AkazeContext(afv.akaze.default_params())
+big = s.corners_batch(1, 1, 1280, 720)[0]
+ms, r = med(lambda: actx.extract(big), n=10)
+print("afv_akaze_extract (1 frame 1280x720, host buffers): %.3f ms  (%d keypoints)" % (ms, len(r[0])))
