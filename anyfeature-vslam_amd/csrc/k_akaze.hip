@@ -15,6 +15,16 @@
 #define AT_H 32
 #define AKZ_T 256
 
+// XCD-aware tile order: the launch is 1-D, block b runs on XCD b % 8 (afv_device.h) and takes work item
+// (b % 8) * ceil(n / 8) + b / 8 of the (frame, tile row, tile column) list, so that tiles sharing halo rows stay in one L2.
+#define AKZ_TILE(TW, TH)                                                                        \
+    const int tiles_x_ = (w + (TW) - 1) / (TW), tiles_y_ = (h + (TH) - 1) / (TH);               \
+    const int total_ = tiles_x_ * tiles_y_ * nframes;                                           \
+    const int work_ = afv_xcd_remap(blockIdx.x, total_);                                        \
+    if (work_ >= total_) return;                                                                \
+    const int f = work_ / (tiles_x_ * tiles_y_), t_ = work_ - f * (tiles_x_ * tiles_y_);        \
+    const int y0 = (t_ / tiles_x_) * (TH), x0 = (t_ - (t_ / tiles_x_) * tiles_x_) * (TW);
+
 __device__ __forceinline__ int akz_clamp(int v, int n) { return min(max(v, 0), n - 1); }
 __device__ __forceinline__ int akz_reflect(int p, int n) {  // BORDER_REFLECT_101, any distance
     if (n == 1) return 0;
@@ -39,12 +49,12 @@ __device__ __forceinline__ void akz_stage(const float *__restrict__ src, int w, 
 // s = k[r] * c + sum_j k[r + j] * (S[+j] + S[-j]).
 template <int R, bool U8>
 __global__ __launch_bounds__(AKZ_T) void k_akz_gauss(const void *__restrict__ src_v, int src_stride, size_t src_frame_stride, int w, int h,
-                                                     const float *__restrict__ taps, float *__restrict__ dst) {
+                                                     int nframes, const float *__restrict__ taps, float *__restrict__ dst) {
     constexpr int LW = AT_W + 2 * R, LH = AT_H + 2 * R;
     __shared__ float s_in[LW * LH];
     __shared__ float s_row[AT_W * LH];
     __shared__ float s_k[2 * R + 1];
-    const int f = blockIdx.z, x0 = blockIdx.x * AT_W, y0 = blockIdx.y * AT_H;
+    AKZ_TILE(AT_W, AT_H)
     if (threadIdx.x < 2 * R + 1) s_k[threadIdx.x] = taps[threadIdx.x];
     if (U8) {
         const uint8_t *src = reinterpret_cast<const uint8_t *>(src_v) + (size_t)f * src_frame_stride;
@@ -93,12 +103,12 @@ __device__ __forceinline__ float akz_scharr_y(const float *c, int LW) {
 }
 
 // ---- compute_k_percentile, pass 1: gradient magnitude of the sigma = 1 smoothed image over the interior; frame maximum ----
-__global__ __launch_bounds__(AKZ_T) void k_akz_modg(const float *__restrict__ gsm, int w, int h, float *__restrict__ modg,
+__global__ __launch_bounds__(AKZ_T) void k_akz_modg(const float *__restrict__ gsm, int w, int h, int nframes, float *__restrict__ modg,
                                                     unsigned int *__restrict__ hmax_bits) {
     constexpr int LW = AT_W + 2, LH = AT_H + 2;
     __shared__ float s_in[LW * LH];
     __shared__ unsigned int s_max;
-    const int f = blockIdx.z, x0 = blockIdx.x * AT_W, y0 = blockIdx.y * AT_H;
+    AKZ_TILE(AT_W, AT_H)
     if (threadIdx.x == 0) s_max = 0;
     akz_stage<1, true>(gsm + (size_t)f * w * h, w, h, x0, y0, s_in);
     __syncthreads();
@@ -173,11 +183,11 @@ __global__ __launch_bounds__(AKZ_T) void k_akz_halfsample(const float *__restric
 }
 
 // ---- image_derivatives_scharr x 2 + pm_g2 ----
-__global__ __launch_bounds__(AKZ_T) void k_akz_flow(const float *__restrict__ lsm, int w, int h, const float *__restrict__ kcontrast,
+__global__ __launch_bounds__(AKZ_T) void k_akz_flow(const float *__restrict__ lsm, int w, int h, int nframes, const float *__restrict__ kcontrast,
                                                     int octave, float *__restrict__ flow) {
     constexpr int LW = AT_W + 2, LH = AT_H + 2;
     __shared__ float s_in[LW * LH];
-    const int f = blockIdx.z, x0 = blockIdx.x * AT_W, y0 = blockIdx.y * AT_H;
+    AKZ_TILE(AT_W, AT_H)
     akz_stage<1, true>(lsm + (size_t)f * w * h, w, h, x0, y0, s_in);
     __syncthreads();
     float k = kcontrast[f];
@@ -196,11 +206,11 @@ __global__ __launch_bounds__(AKZ_T) void k_akz_flow(const float *__restrict__ ls
 }
 
 // ---- nld_step_scalar: one explicit diffusion step, zero flux across the image border ----
-__global__ __launch_bounds__(AKZ_T) void k_akz_nld_step(const float *__restrict__ Lt, const float *__restrict__ flow, int w, int h, float tau,
+__global__ __launch_bounds__(AKZ_T) void k_akz_nld_step(const float *__restrict__ Lt, const float *__restrict__ flow, int w, int h, int nframes, float tau,
                                                         float *__restrict__ out) {
     constexpr int LW = AT_W + 2, LH = AT_H + 2;
     __shared__ float s_l[LW * LH], s_c[LW * LH];
-    const int f = blockIdx.z, x0 = blockIdx.x * AT_W, y0 = blockIdx.y * AT_H;
+    AKZ_TILE(AT_W, AT_H)
     akz_stage<1, false>(Lt + (size_t)f * w * h, w, h, x0, y0, s_l);
     akz_stage<1, false>(flow + (size_t)f * w * h, w, h, x0, y0, s_c);
     __syncthreads();
@@ -236,7 +246,7 @@ struct AkzTau {
 
 #define AKZ_FT 512
 #define AKZ_FH 48  // output rows per fused tile; the tile is (64 - 2N) x 48 outputs so that output + halo is exactly one wave wide
-__global__ __launch_bounds__(AKZ_FT) void k_akz_fed_fused(const float *__restrict__ Lt_in, const float *__restrict__ lsm, int w, int h,
+__global__ __launch_bounds__(AKZ_FT) void k_akz_fed_fused(const float *__restrict__ Lt_in, const float *__restrict__ lsm, int w, int h, int nframes,
                                                           const float *__restrict__ kcontrast, int octave, int nsteps, AkzTau tau,
                                                           float *__restrict__ Lt_out) {
     extern __shared__ float s_fed[];
@@ -247,7 +257,7 @@ __global__ __launch_bounds__(AKZ_FT) void k_akz_fed_fused(const float *__restric
     constexpr int SW = LW + 2;                          // Lsmooth plane (one more ring)
     const int SH = LH + 2;
     float *s_a = s_fed, *s_b = s_a + LW * LH, *s_c = s_b + LW * LH, *s_s = s_c + LW * LH;
-    const int f = blockIdx.z, x0 = blockIdx.x * OW, y0 = blockIdx.y * AKZ_FH;
+    AKZ_TILE(OW, AKZ_FH)
     const float *pin = Lt_in + (size_t)f * w * h, *ps = lsm + (size_t)f * w * h;
     // thread (tx, ty) owns column tx and rows ty, ty + 8, ... of every LDS plane: no divisions, full wavefronts
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -302,11 +312,11 @@ __global__ __launch_bounds__(AKZ_FT) void k_akz_fed_fused(const float *__restric
 
 // ---- Compute_Multiscale_Derivatives, first derivatives (unscaled): sparse 3-tap Scharr at distance s ----
 #define AKZ_MAX_S 8
-__global__ __launch_bounds__(AKZ_T) void k_akz_deriv1(const float *__restrict__ lsm, int w, int h, int s, float *__restrict__ dx,
+__global__ __launch_bounds__(AKZ_T) void k_akz_deriv1(const float *__restrict__ lsm, int w, int h, int nframes, int s, float *__restrict__ dx,
                                                       float *__restrict__ dy) {
     extern __shared__ float s_in[];  // (AT_W + 2s) x (AT_H + 2s)
     const int LW = AT_W + 2 * s, LH = AT_H + 2 * s;
-    const int f = blockIdx.z, x0 = blockIdx.x * AT_W, y0 = blockIdx.y * AT_H;
+    AKZ_TILE(AT_W, AT_H)
     const float *src = lsm + (size_t)f * w * h;
     for (int i = threadIdx.x; i < LW * LH; i += AKZ_T) {
         const int ly = i / LW, lx = i - ly * LW;
@@ -333,12 +343,12 @@ __global__ __launch_bounds__(AKZ_T) void k_akz_deriv1(const float *__restrict__ 
 }
 
 // second derivatives from the unscaled first ones, the sigma_size normalisation and the determinant
-__global__ __launch_bounds__(AKZ_T) void k_akz_hessian(const float *__restrict__ dx, const float *__restrict__ dy, int w, int h, int s,
+__global__ __launch_bounds__(AKZ_T) void k_akz_hessian(const float *__restrict__ dx, const float *__restrict__ dy, int w, int h, int nframes, int s,
                                                        float *__restrict__ Lx, float *__restrict__ Ly, float *__restrict__ Ldet) {
     extern __shared__ float s_mem[];  // two (AT_W + 2s) x (AT_H + 2s) planes
     const int LW = AT_W + 2 * s, LH = AT_H + 2 * s;
     float *s_x = s_mem, *s_y = s_mem + LW * LH;
-    const int f = blockIdx.z, x0 = blockIdx.x * AT_W, y0 = blockIdx.y * AT_H;
+    AKZ_TILE(AT_W, AT_H)
     const float *px = dx + (size_t)f * w * h, *py = dy + (size_t)f * w * h;
     for (int i = threadIdx.x; i < LW * LH; i += AKZ_T) {
         const int ly = i / LW, lx = i - ly * LW;
@@ -375,7 +385,11 @@ __global__ __launch_bounds__(AKZ_T) void k_akz_hessian(const float *__restrict__
 }
 
 // ---------------- launchers ----------------
-static inline dim3 akz_grid(int w, int h, int nframes) { return dim3((w + AT_W - 1) / AT_W, (h + AT_H - 1) / AT_H, nframes); }
+static inline dim3 akz_grid1(int w, int h, int nframes, int tw, int th) {  // 1-D, padded to a multiple of 8 (XCD remap)
+    const int total = ((w + tw - 1) / tw) * ((h + th - 1) / th) * nframes;
+    return dim3((total + 7) / 8 * 8);
+}
+static inline dim3 akz_grid(int w, int h, int nframes) { return akz_grid1(w, h, nframes, AT_W, AT_H); }
 
 extern "C" int afv_akz_launch_gauss(const void *src, int is_u8, int src_stride, size_t src_frame_stride, int w, int h, int nframes,
                                     const float *taps, int ksize, float *dst, hipStream_t st) {
@@ -383,8 +397,8 @@ extern "C" int afv_akz_launch_gauss(const void *src, int is_u8, int src_stride, 
     const int r = ksize / 2;
 #define AKZ_GAUSS_CASE(R)                                                                                                   \
     case R:                                                                                                                 \
-        if (is_u8) hipLaunchKernelGGL((k_akz_gauss<R, true>), g, dim3(AKZ_T), 0, st, src, src_stride, src_frame_stride, w, h, taps, dst); \
-        else hipLaunchKernelGGL((k_akz_gauss<R, false>), g, dim3(AKZ_T), 0, st, src, src_stride, src_frame_stride, w, h, taps, dst);      \
+        if (is_u8) hipLaunchKernelGGL((k_akz_gauss<R, true>), g, dim3(AKZ_T), 0, st, src, src_stride, src_frame_stride, w, h, nframes, taps, dst); \
+        else hipLaunchKernelGGL((k_akz_gauss<R, false>), g, dim3(AKZ_T), 0, st, src, src_stride, src_frame_stride, w, h, nframes, taps, dst);      \
         return 0;
     switch (r) {
         AKZ_GAUSS_CASE(1) AKZ_GAUSS_CASE(2) AKZ_GAUSS_CASE(3) AKZ_GAUSS_CASE(4) AKZ_GAUSS_CASE(5) AKZ_GAUSS_CASE(6)
@@ -395,7 +409,7 @@ extern "C" int afv_akz_launch_gauss(const void *src, int is_u8, int src_stride, 
 
 extern "C" void afv_akz_launch_kcontrast(const float *gsm, int w, int h, int nframes, float *modg, unsigned int *hmax_bits, int *hist,
                                          int nbins, float perc, float *kcontrast, hipStream_t st) {
-    hipLaunchKernelGGL(k_akz_modg, akz_grid(w, h, nframes), dim3(AKZ_T), 0, st, gsm, w, h, modg, hmax_bits);
+    hipLaunchKernelGGL(k_akz_modg, akz_grid(w, h, nframes), dim3(AKZ_T), 0, st, gsm, w, h, nframes, modg, hmax_bits);
     hipLaunchKernelGGL(k_akz_hist, dim3(64, nframes), dim3(AKZ_T), (size_t)(nbins + 1) * sizeof(int), st, modg, w, h, hmax_bits, nbins, hist);
     hipLaunchKernelGGL(k_akz_kperc, dim3((nframes + 63) / 64), dim3(64), 0, st, hist, hmax_bits, nbins, perc, nframes, kcontrast);
 }
@@ -406,11 +420,11 @@ extern "C" void afv_akz_launch_halfsample(const float *src, int w, int h, float 
 
 extern "C" void afv_akz_launch_flow(const float *lsm, int w, int h, int nframes, const float *kcontrast, int octave, float *flow,
                                     hipStream_t st) {
-    hipLaunchKernelGGL(k_akz_flow, akz_grid(w, h, nframes), dim3(AKZ_T), 0, st, lsm, w, h, kcontrast, octave, flow);
+    hipLaunchKernelGGL(k_akz_flow, akz_grid(w, h, nframes), dim3(AKZ_T), 0, st, lsm, w, h, nframes, kcontrast, octave, flow);
 }
 
 extern "C" void afv_akz_launch_nld_step(const float *Lt, const float *flow, int w, int h, int nframes, float tau, float *out, hipStream_t st) {
-    hipLaunchKernelGGL(k_akz_nld_step, akz_grid(w, h, nframes), dim3(AKZ_T), 0, st, Lt, flow, w, h, tau, out);
+    hipLaunchKernelGGL(k_akz_nld_step, akz_grid(w, h, nframes), dim3(AKZ_T), 0, st, Lt, flow, w, h, nframes, tau, out);
 }
 
 // returns 0 when the cycle does not fit the fused kernel (the caller then steps through k_akz_flow + k_akz_nld_step)
@@ -421,8 +435,8 @@ extern "C" int afv_akz_launch_fed_fused(const float *Lt_in, const float *lsm, in
     for (int i = 0; i < nsteps; ++i) t.t[i] = tau[i];
     const int LH = AKZ_FH + 2 * nsteps, OW = 64 - 2 * nsteps;
     const size_t lds = ((size_t)3 * 64 * LH + (size_t)66 * (LH + 2)) * sizeof(float);
-    const dim3 grid((w + OW - 1) / OW, (h + AKZ_FH - 1) / AKZ_FH, nframes);
-    hipLaunchKernelGGL(k_akz_fed_fused, grid, dim3(AKZ_FT), lds, st, Lt_in, lsm, w, h, kcontrast, octave, nsteps, t, Lt_out);
+    hipLaunchKernelGGL(k_akz_fed_fused, akz_grid1(w, h, nframes, OW, AKZ_FH), dim3(AKZ_FT), lds, st, Lt_in, lsm, w, h, nframes, kcontrast, octave,
+                       nsteps, t, Lt_out);
     return 1;
 }
 
@@ -430,7 +444,7 @@ extern "C" int afv_akz_launch_hessian(const float *lsm, int w, int h, int nframe
                                       float *Ldet, hipStream_t st) {
     if (s < 1 || s > AKZ_MAX_S) return -1;
     const size_t plane = (size_t)(AT_W + 2 * s) * (AT_H + 2 * s) * sizeof(float);
-    hipLaunchKernelGGL(k_akz_deriv1, akz_grid(w, h, nframes), dim3(AKZ_T), plane, st, lsm, w, h, s, dx, dy);
-    hipLaunchKernelGGL(k_akz_hessian, akz_grid(w, h, nframes), dim3(AKZ_T), 2 * plane, st, dx, dy, w, h, s, Lx, Ly, Ldet);
+    hipLaunchKernelGGL(k_akz_deriv1, akz_grid(w, h, nframes), dim3(AKZ_T), plane, st, lsm, w, h, nframes, s, dx, dy);
+    hipLaunchKernelGGL(k_akz_hessian, akz_grid(w, h, nframes), dim3(AKZ_T), 2 * plane, st, dx, dy, w, h, nframes, s, Lx, Ly, Ldet);
     return 0;
 }
