@@ -44,7 +44,7 @@ struct AkdState {
     int *cell_cnt;
     unsigned char *keep;
 };
-extern "C" void afv_akz_launch_candidates(const AkdParams *P, int nframes, int *row_count, int *row_start, int *cand, float *cand_resp,
+extern "C" void afv_akz_launch_candidates(const AkdParams *P, int nframes, unsigned long long *mask, int *row_start, int *cand, float *cand_resp,
                                           int *cand_count, int *status, hipStream_t st);
 extern "C" void afv_akz_launch_suppress(const AkdParams *P, const AkdState *S, int nframes, const int *cand, const float *cand_resp,
                                         const int *cand_count,
@@ -95,6 +95,7 @@ struct afv_akaze {
     AkdParams dp{};
     AkdState ds{};
     float *d_cand_resp = nullptr;
+    unsigned long long *d_mask = nullptr;  // [frame][rows][32] candidate bitmap words
     int *d_row_count = nullptr, *d_row_start = nullptr, *d_cand = nullptr, *d_cand_count = nullptr, *d_kp_count = nullptr, *d_status = nullptr;
     afv_keypoint *d_kps = nullptr;
     size_t cand_stride_max = 0, rows_stride_max = 0;
@@ -289,7 +290,7 @@ extern "C" int afv_akaze_create(int device, const afv_akaze_params *prm, afv_aka
         }
         a->cand_stride_max = cands;
         a->rows_stride_max = rows;
-        if (rc == AFV_OK) rc = akz_alloc(a, &a->d_row_count, rows * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->d_mask, rows * 32 * B);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->d_row_start, rows * B);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->d_cand, cands * B);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->d_cand_resp, cands * B);
@@ -516,13 +517,13 @@ static int akz_detect_enqueue(afv_akaze *a) {
     }
     D.cand_stride = coff; D.rows_stride = roff;
     if ((size_t)coff > a->cand_stride_max || (size_t)roff > a->rows_stride_max) return AFV_EINVAL;
-    if (max_size > AKD_CELL) return AFV_EUNSUPPORTED;  // the 3 x 3 cell neighbourhood must cover a keypoint radius
+    if (max_size > AKD_CELL || P.w > 2048) return AFV_EUNSUPPORTED;  // the 3 x 3 cell neighbourhood must cover a keypoint radius
     D.gw = (int)((float)P.w / AKD_CELL) + 1; D.gh = (int)((float)P.h / AKD_CELL) + 1;
     if (D.gw * D.gh > AKD_MAX_CELLS) return AFV_EUNSUPPORTED;
     D.entry_cap = AKD_ENTRY_CAP; D.kp_cap = AKD_ENTRY_CAP;
     hipStream_t st = a->stream;
     AKZ_HIPCHK(a, hipMemsetAsync(a->d_status, 0, sizeof(int), st));
-    afv_akz_launch_candidates(&D, a->cur_frames, a->d_row_count, a->d_row_start, a->d_cand, a->d_cand_resp, a->d_cand_count, a->d_status, st);
+    afv_akz_launch_candidates(&D, a->cur_frames, a->d_mask, a->d_row_start, a->d_cand, a->d_cand_resp, a->d_cand_count, a->d_status, st);
     afv_akz_launch_suppress(&D, &a->ds, a->cur_frames, a->d_cand, a->d_cand_resp, a->d_cand_count, a->d_kps, a->d_kp_count, a->d_status, st);
     AKZ_HIPCHK(a, hipGetLastError());
     a->have_keypoints = true;

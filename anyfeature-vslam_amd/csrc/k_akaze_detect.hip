@@ -3,9 +3,10 @@
 // Do_Subpixel_Refinement (the calls behind FeatureExtractor_akaze61::detectKeypoints, Feature_akaze61.cpp:38-47); the
 // operation order is the one written down in oracle/akaze.c.
 //
-//  1. candidates: one wavefront per image row tests the 3x3 strict maximum + thresholds + descriptor-border rule; a row
-//     count pass, a per-(frame, level) scan over rows and a write pass leave every level's candidates in RASTER order
-//     without a sort (upstream's loop order is part of the result).
+//  1. candidates: a tiled pass turns every level's Ldet plane into a bitmap of (3x3 strict maximum + thresholds +
+//     descriptor-border rule); one workgroup per (level, frame) then counts the rows from the bitmap, scans them and
+//     expands the bits, which leaves the candidates in RASTER order without a sort (upstream's loop order is part of
+//     the result).
 //  2. k_akz_suppress: upstream inserts the candidates one by one into kpts_aux, comparing each against the FIRST earlier
 //     entry of the same / previous level within its radius (replace it or drop the newcomer).  One workgroup per frame
 //     replays that loop in speculative rounds of 64 consecutive candidates: the (candidate, grid cell) pairs of a round
@@ -56,64 +57,124 @@ __device__ __forceinline__ bool akd_is_candidate(const AkdParams &P, const AkdLe
     return !(left_x < 0 || right_x >= L.w || up_y < 0 || down_y >= L.h);
 }
 
-// pass A (write == 0): candidates per row; pass C (write == 1): write them at row offset + rank.  One wavefront per row.
-template <int WRITE>
-__global__ __launch_bounds__(256) void k_akz_cand_rows(AkdParams P, int level, int *__restrict__ row_count, const int *__restrict__ row_start,
-                                                       int *__restrict__ cand, float *__restrict__ cand_resp, int *__restrict__ status) {
+// pass A: candidate bitmap of one level.  64 x 32 tile + 1 px ring in LDS (the Ldet plane is streamed once); bit x of word
+// mask[frame][row][x / 64] = pixel (x, row) is a candidate.
+#define AKD_MAXCHUNKS 32  // 64-column chunks per row: levels up to 2048 pixels wide
+__global__ __launch_bounds__(256) void k_akz_cand_mask(AkdParams P, int level, int nframes, unsigned long long *__restrict__ mask) {
+    constexpr int LW = 66, LH = 34;
+    __shared__ float s_d[LW * LH];
     const AkdLevel L = P.lv[level];
-    const int f = blockIdx.y, lane = threadIdx.x & 63;
-    const int iy = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (iy >= L.h) return;
+    const int tiles_x = (L.w + 63) / 64, tiles_y = (L.h + 31) / 32, total = tiles_x * tiles_y * nframes;
+    const int work = afv_xcd_remap(blockIdx.x, total);
+    if (work >= total) return;
+    const int f = work / (tiles_x * tiles_y), t = work - f * (tiles_x * tiles_y);
+    const int ty0 = (t / tiles_x) * 32, tx0 = (t - (t / tiles_x) * tiles_x) * 64;
     const float *ld = L.ldet + (size_t)f * L.w * L.h;
-    int total = 0;
-    int base = 0;
-    if (WRITE) base = row_start[(size_t)f * P.rows_stride + L.row_off + iy];
-    if (iy >= 1 && iy < L.h - 1) {
-        for (int x0 = 0; x0 < L.w; x0 += 64) {
-            const int jx = x0 + lane;
-            const bool ok = jx >= 1 && jx < L.w - 1 && akd_is_candidate(P, L, ld, jx, iy);
-            const unsigned long long m = __ballot(ok);
-            if (WRITE && ok) {
-                const int k = base + total + __popcll(m & ((1ull << lane) - 1ull));
-                if (k < L.cand_cap) {
-                    cand[(size_t)f * P.cand_stride + L.cand_off + k] = iy * L.w + jx;
-                    cand_resp[(size_t)f * P.cand_stride + L.cand_off + k] = fabsf(ld[(size_t)iy * L.w + jx]);
-                }
-                else atomicExch(status, 1);
-            }
-            total += __popcll(m);
-        }
+    for (int i = threadIdx.x; i < LW * LH; i += 256) {
+        const int ly = i / LW, lx = i - ly * LW;
+        const int gx = min(max(tx0 - 1 + lx, 0), L.w - 1), gy = min(max(ty0 - 1 + ly, 0), L.h - 1);
+        s_d[i] = ld[(size_t)gy * L.w + gx];
     }
-    if (!WRITE && lane == 0) row_count[(size_t)f * P.rows_stride + L.row_off + iy] = total;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const float smax = 10.0f * sqrtf(2.0f), r = smax * (float)L.sigma_size;
+    const int jx = tx0 + lane;
+    // descriptor-border rule ("is_out"), column part: such a point never changes kpts_aux, so it is dropped before the ordered pass
+    const float px = (float)jx;
+    const bool col_ok = jx >= 1 && jx < L.w - 1 && !(akd_fround(px - r) - 1 < 0 || akd_fround(px + r) + 1 >= L.w);
+    for (int ly = wv; ly < 32; ly += 4) {
+        const int iy = ty0 + ly;
+        if (iy >= L.h) break;
+        bool ok = false;
+        if (col_ok && iy >= 1 && iy < L.h - 1) {
+            const float *c = &s_d[(ly + 1) * LW + lane + 1];
+            const float v = c[0];
+            ok = v > P.dthreshold && v >= P.min_dthreshold && v > c[-1] && v > c[1] && v > c[-LW - 1] && v > c[-LW] && v > c[-LW + 1] &&
+                 v > c[LW - 1] && v > c[LW] && v > c[LW + 1];
+            if (ok) {
+                const float py = (float)iy;
+                ok = !(akd_fround(py - r) - 1 < 0 || akd_fround(py + r) + 1 >= L.h);
+            }
+        }
+        const unsigned long long m = __ballot(ok);
+        if (lane == 0) mask[((size_t)f * P.rows_stride + L.row_off + iy) * AKD_MAXCHUNKS + (tx0 >> 6)] = m;
+    }
 }
 
-// pass B: exclusive scan of the row counts of one (frame, level); also the level's candidate count
-__global__ __launch_bounds__(256) void k_akz_cand_scan(AkdParams P, const int *__restrict__ row_count, int *__restrict__ row_start,
-                                                       int *__restrict__ cand_count) {
-    __shared__ int s_part[256];
-    const int level = blockIdx.x, f = blockIdx.y;
+// pass B: one workgroup per (level, frame): row counts from the bitmap, exclusive scan over the rows, then every wavefront
+// expands its rows in raster order (index + |response|)
+#define AKE_T 1024
+__global__ __launch_bounds__(AKE_T) void k_akz_cand_emit(AkdParams P, const unsigned long long *__restrict__ mask, int *__restrict__ row_start,
+                                                       int *__restrict__ cand, float *__restrict__ cand_resp, int *__restrict__ cand_count,
+                                                       int *__restrict__ status) {
+    __shared__ int s_part[AKE_T];
+    const int level = blockIdx.x, f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const AkdLevel L = P.lv[level];
-    const int *rc = row_count + (size_t)f * P.rows_stride + L.row_off;
+    const int nchunks = (L.w + 63) >> 6;
+    const unsigned long long *mk = mask + ((size_t)f * P.rows_stride + L.row_off) * AKD_MAXCHUNKS;
     int *rs = row_start + (size_t)f * P.rows_stride + L.row_off;
-    const int per = (L.h + 255) / 256, b = threadIdx.x * per, e = min(L.h, b + per);
-    int s = 0;
-    for (int i = b; i < e; ++i) s += rc[i];
-    s_part[threadIdx.x] = s;
+    const int per = (L.h + AKE_T - 1) / AKE_T, b = min(tid * per, L.h), e = min(L.h, b + per);
+    int sum = 0;
+    for (int r = b; r < e; ++r) {
+        int c = 0;
+        for (int k = 0; k < nchunks; ++k) c += __popcll(mk[(size_t)r * AKD_MAXCHUNKS + k]);
+        rs[r] = c;  // row count for now
+        sum += c;
+    }
+    s_part[tid] = sum;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         int acc = 0;
-        for (int i = 0; i < 256; ++i) {
+        for (int i = 0; i < AKE_T; ++i) {
             const int t = s_part[i];
             s_part[i] = acc;
             acc += t;
         }
         cand_count[f * 16 + level] = min(acc, L.cand_cap);
+        if (acc > L.cand_cap) atomicExch(status, 1);
     }
     __syncthreads();
-    int acc = s_part[threadIdx.x];
-    for (int i = b; i < e; ++i) {
-        rs[i] = acc;
-        acc += rc[i];
+    {
+        int acc = s_part[tid];
+        for (int r = b; r < e; ++r) {
+            const int c = rs[r];
+            rs[r] = acc;
+            acc += c;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    const float *ld = L.ldet + (size_t)f * L.w * L.h;
+    int *co = cand + (size_t)f * P.cand_stride + L.cand_off;
+    float *cr = cand_resp + (size_t)f * P.cand_stride + L.cand_off;
+    for (int r = wv; r < L.h; r += AKE_T / 64) {
+        // lane k holds chunk k's word; exclusive scan of the popcounts gives every chunk its offset inside the row
+        const unsigned long long m = lane < nchunks ? mk[(size_t)r * AKD_MAXCHUNKS + lane] : 0ull;
+        const int cnt = __popcll(m);
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        const int row_total = __shfl(incl, 63, 64);
+        if (row_total == 0) continue;
+        const int base = rs[r];
+        unsigned long long live = __ballot(cnt != 0);
+        while (live) {
+            const int k = (int)__builtin_ctzll(live);
+            live &= live - 1;
+            const unsigned long long mkk = __shfl(m, k, 64);
+            const int off = base + __shfl(incl - cnt, k, 64);
+            if ((mkk >> lane) & 1ull) {
+                const int kk = off + __popcll(mkk & ((1ull << lane) - 1ull));
+                if (kk < L.cand_cap) {
+                    const int idx = r * L.w + (k << 6) + lane;
+                    co[kk] = idx;
+                    cr[kk] = fabsf(ld[idx]);
+                }
+            }
+        }
     }
 }
 
@@ -471,15 +532,13 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
     if (tid == 0) kp_count[f] = min(nout, P.kp_cap);
 }
 
-extern "C" void afv_akz_launch_candidates(const AkdParams *P, int nframes, int *row_count, int *row_start, int *cand, float *cand_resp,
+extern "C" void afv_akz_launch_candidates(const AkdParams *P, int nframes, unsigned long long *mask, int *row_start, int *cand, float *cand_resp,
                                           int *cand_count, int *status, hipStream_t st) {
-    for (int l = 0; l < P->nlevels; ++l)
-        hipLaunchKernelGGL(k_akz_cand_rows<0>, dim3((P->lv[l].h + 3) / 4, nframes), dim3(256), 0, st, *P, l, row_count, row_start, cand, cand_resp,
-                           status);
-    hipLaunchKernelGGL(k_akz_cand_scan, dim3(P->nlevels, nframes), dim3(256), 0, st, *P, row_count, row_start, cand_count);
-    for (int l = 0; l < P->nlevels; ++l)
-        hipLaunchKernelGGL(k_akz_cand_rows<1>, dim3((P->lv[l].h + 3) / 4, nframes), dim3(256), 0, st, *P, l, row_count, row_start, cand, cand_resp,
-                           status);
+    for (int l = 0; l < P->nlevels; ++l) {
+        const int total = ((P->lv[l].w + 63) / 64) * ((P->lv[l].h + 31) / 32) * nframes;
+        hipLaunchKernelGGL(k_akz_cand_mask, dim3((total + 7) / 8 * 8), dim3(256), 0, st, *P, l, nframes, mask);
+    }
+    hipLaunchKernelGGL(k_akz_cand_emit, dim3(P->nlevels, nframes), dim3(AKE_T), 0, st, *P, mask, row_start, cand, cand_resp, cand_count, status);
 }
 
 extern "C" void afv_akz_launch_suppress(const AkdParams *P, const AkdState *S, int nframes, const int *cand, const float *cand_resp,
