@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -93,6 +94,7 @@ struct afv_ctx {
     hipStream_t stream2 = nullptr;  // second lane for split batches (latency-bound kernels overlap VALU-bound ones)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int split_min_frames = 64;     // batches of at least this many frames / pairs are split over the two streams
+    int split_chunks = 4;          // ... into this many chunks (alternating streams); AFV_SPLIT_CHUNKS overrides (experiments)
     afv_orb_params p{};
     Geo geo{};          // current geometry (host copy)
     Geo cap_geo{};      // geometry of (max_width, max_height): sizes every allocation
@@ -399,6 +401,7 @@ extern "C" int afv_create(int device, const afv_orb_params *params, afv_ctx **ou
     CREATE_CHK(hipSetDevice(device));
     CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CREATE_CHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    if (const char *e = std::getenv("AFV_SPLIT_CHUNKS")) c->split_chunks = std::max(2, std::atoi(e));
     CREATE_CHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     CREATE_CHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     CREATE_CHK(hipMalloc(&c->d_geo, sizeof(Geo)));
@@ -548,11 +551,13 @@ static int enqueue_extract(afv_ctx *c, const FrameSrc &src, int nframes, afv_key
     if (d_status) HIPCHK(c, hipMemsetAsync(d_status, 0, sizeof(int), s));
     if (nframes >= c->split_min_frames) {
         // two halves on two streams: the select / describe tail of one half overlaps the FAST kernel of the other
-        const int h = nframes / 2;
         HIPCHK(c, hipEventRecord(c->ev_fork, s));
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-        enqueue_range(c, src, 0, h, d_kps, d_desc, cap, d_n, d_status, s);
-        enqueue_range(c, src, h, nframes - h, d_kps, d_desc, cap, d_n, d_status, c->stream2);
+        const int K = std::max(2, c->split_chunks);
+        for (int k = 0; k < K; ++k) {  // chunk k on stream k % 2
+            const int b = (int)((long)nframes * k / K), e = (int)((long)nframes * (k + 1) / K);
+            if (e > b) enqueue_range(c, src, b, e - b, d_kps, d_desc, cap, d_n, d_status, (k & 1) ? c->stream2 : s);
+        }
         HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0));
     } else {
