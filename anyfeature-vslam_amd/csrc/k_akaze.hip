@@ -245,69 +245,100 @@ struct AkzTau {
 };
 
 #define AKZ_FT 512
-#define AKZ_FH 48  // output rows per fused tile; the tile is (64 - 2N) x 48 outputs so that output + halo is exactly one wave wide
+#define AKZ_FH 48   // output rows per fused tile; the tile is (64 - 2N) x 48 outputs so that output + halo is exactly one wave wide
+#define AKZ_FR 8    // rows per wavefront: 8 waves x 8 rows >= 48 + 2N
+// Register-resident formulation: lane = tile column, every wavefront owns a band of 8 tile rows and keeps Lt and the four
+// neighbour-conductivity sums of its band in registers for the whole cycle.  Horizontal neighbours come from DPP wave shifts,
+// vertical ones from the registers of the same lane; only the two boundary rows of a band go through LDS per step.
+__device__ __forceinline__ float akz_from_left(float v) {   // lane i <- lane i - 1 (DPP wave_shr:1)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float akz_from_right(float v) {  // lane i <- lane i + 1 (DPP wave_shl:1)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
 __global__ __launch_bounds__(AKZ_FT) void k_akz_fed_fused(const float *__restrict__ Lt_in, const float *__restrict__ lsm, int w, int h, int nframes,
                                                           const float *__restrict__ kcontrast, int octave, int nsteps, AkzTau tau,
                                                           float *__restrict__ Lt_out) {
     extern __shared__ float s_fed[];
     const int N = nsteps;
     const int OW = 64 - 2 * N;                          // output columns of this tile
-    constexpr int LW = 64;                              // Lt / flow planes: output + halo = one wavefront per row
-    const int LH = AKZ_FH + 2 * N;
-    constexpr int SW = LW + 2;                          // Lsmooth plane (one more ring)
+    const int LH = AKZ_FH + 2 * N;                      // tile rows incl. halo (<= 64)
+    constexpr int SW = 66;                              // Lsmooth plane: tile + one more ring
     const int SH = LH + 2;
-    float *s_a = s_fed, *s_b = s_a + LW * LH, *s_c = s_b + LW * LH, *s_s = s_c + LW * LH;
+    float *s_s = s_fed;                                 // [SH][SW]
+    float *s_x = s_fed + SW * 66;                       // boundary-row exchange: [2 parities][2 (top, bottom)][8 waves][64]
     AKZ_TILE(OW, AKZ_FH)
     const float *pin = Lt_in + (size_t)f * w * h, *ps = lsm + (size_t)f * w * h;
-    // thread (tx, ty) owns column tx and rows ty, ty + 8, ... of every LDS plane: no divisions, full wavefronts
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int ly = ty; ly < SH; ly += AKZ_FT / 64) {
+    const int tx = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int ly = wv; ly < SH; ly += AKZ_FT / 64) {
         const float *rs = ps + (size_t)akz_reflect(y0 - N - 1 + ly, h) * w;
         for (int lx = tx; lx < SW; lx += 64) s_s[ly * SW + lx] = rs[akz_reflect(x0 - N - 1 + lx, w)];
-    }
-    const int gx = x0 - N + tx;                          // this thread's image column
-    {
-        const int cxl = akz_clamp(gx, w);
-        for (int ly = ty; ly < LH; ly += AKZ_FT / 64) s_a[ly * LW + tx] = pin[(size_t)akz_clamp(y0 - N + ly, h) * w + cxl];
     }
     __syncthreads();
     float k = kcontrast[f];
     for (int i = 0; i < octave; ++i) k = k * 0.75f;
     const float k2inv = 1.0f / (k * k);
-    for (int ly = ty; ly < LH; ly += AKZ_FT / 64) {
-        const float *c = &s_s[(ly + 1) * SW + tx + 1];
-        const float lxv = akz_scharr_x(c, SW), lyv = akz_scharr_y(c, SW);
-        s_c[ly * LW + tx] = 1.0f / (1.0f + (lxv * lxv + lyv * lyv) * k2inv);
+    const int gx = x0 - N + tx;
+    const bool col_in = gx >= 0 && gx < w, has_r = gx + 1 < w, has_l = gx > 0;
+    const int r0 = wv * AKZ_FR;
+    // conductivity of the band rows and of the rows just above / below it (rows outside the tile are never used by a valid pixel)
+    float c[AKZ_FR + 2];
+#pragma unroll
+    for (int j = 0; j < AKZ_FR + 2; ++j) {
+        const int r = min(max(r0 - 1 + j, 0), LH - 1);
+        const float *q = &s_s[(r + 1) * SW + tx + 1];
+        const float lxv = akz_scharr_x(q, SW), lyv = akz_scharr_y(q, SW);
+        c[j] = 1.0f / (1.0f + (lxv * lxv + lyv * lyv) * k2inv);
     }
-    __syncthreads();
-    float *cur = s_a, *nxt = s_b;
-    const bool col_in = gx >= 0 && gx < w;
-    const bool has_r = gx + 1 < w, has_l = gx > 0;
-    for (int j = 0; j < N; ++j) {
-        const int lo = j + 1;                           // first LDS row / column that still has valid neighbours
-        const double hs = 0.5 * (double)tau.t[j];
-        const bool col_ok = col_in && tx >= lo && tx < LW - lo;
-        for (int ly = lo + ty; ly < LH - lo; ly += AKZ_FT / 64) {
-            const int gy = y0 - N + ly;
-            if (!col_ok || gy < 0 || gy >= h) continue;
-            const int p = ly * LW + tx;
-            const float L = cur[p], c = s_c[p];
-            const float xpos = has_r ? (c + s_c[p + 1]) * (cur[p + 1] - L) : 0.0f;
-            const float xneg = has_l ? (s_c[p - 1] + c) * (L - cur[p - 1]) : 0.0f;
-            const float ypos = gy + 1 < h ? (c + s_c[p + LW]) * (cur[p + LW] - L) : 0.0f;
-            const float yneg = gy > 0 ? (s_c[p - LW] + c) * (L - cur[p - LW]) : 0.0f;
-            const float sum = ((xpos - xneg) + ypos) - yneg;
-            nxt[p] = L + (float)(hs * (double)sum);
-        }
+    float cR[AKZ_FR], cL[AKZ_FR], cD[AKZ_FR], cU[AKZ_FR], L[AKZ_FR];
+    bool upd[AKZ_FR], has_d[AKZ_FR], has_u[AKZ_FR];
+#pragma unroll
+    for (int j = 0; j < AKZ_FR; ++j) {
+        const float cc = c[j + 1];
+        cR[j] = cc + akz_from_right(cc);
+        cL[j] = akz_from_left(cc) + cc;
+        cD[j] = cc + c[j + 2];
+        cU[j] = c[j] + cc;
+        const int r = r0 + j, gy = y0 - N + r;
+        upd[j] = col_in && r < LH && gy >= 0 && gy < h;
+        has_d[j] = gy + 1 < h;
+        has_u[j] = gy > 0;
+        L[j] = pin[(size_t)akz_clamp(gy, h) * w + akz_clamp(gx, w)];
+    }
+    for (int st = 0; st < N; ++st) {
+        // boundary rows of every band through LDS (double-buffered by step parity: one barrier per step)
+        float *xb = s_x + (st & 1) * (2 * 8 * 64);
+        xb[wv * 64 + tx] = L[0];
+        xb[8 * 64 + wv * 64 + tx] = L[AKZ_FR - 1];
         __syncthreads();
-        float *t = cur; cur = nxt; nxt = t;
+        const float up_halo = wv > 0 ? xb[8 * 64 + (wv - 1) * 64 + tx] : 0.0f;
+        const float dn_halo = wv < 7 ? xb[(wv + 1) * 64 + tx] : 0.0f;
+        const double hs = 0.5 * (double)tau.t[st];
+        float nl[AKZ_FR];
+#pragma unroll
+        for (int j = 0; j < AKZ_FR; ++j) {
+            const float Lc = L[j];
+            const float Lr = akz_from_right(Lc), Ll = akz_from_left(Lc);
+            const float Lu = j > 0 ? L[j - 1] : up_halo, Ld = j < AKZ_FR - 1 ? L[j + 1] : dn_halo;
+            const float xpos = has_r ? cR[j] * (Lr - Lc) : 0.0f;
+            const float xneg = has_l ? cL[j] * (Lc - Ll) : 0.0f;
+            const float ypos = has_d[j] ? cD[j] * (Ld - Lc) : 0.0f;
+            const float yneg = has_u[j] ? cU[j] * (Lc - Lu) : 0.0f;
+            const float sum = ((xpos - xneg) + ypos) - yneg;
+            nl[j] = upd[j] ? Lc + (float)(hs * (double)sum) : Lc;
+        }
+#pragma unroll
+        for (int j = 0; j < AKZ_FR; ++j) L[j] = nl[j];
     }
     float *o = Lt_out + (size_t)f * w * h;
-    if (tx >= N && tx < N + OW && col_in)
-        for (int ly = ty; ly < AKZ_FH; ly += AKZ_FT / 64) {
-            const int gy = y0 + ly;
-            if (gy < h) o[(size_t)gy * w + gx] = cur[(ly + N) * LW + tx];
+    if (tx >= N && tx < N + OW && col_in) {
+#pragma unroll
+        for (int j = 0; j < AKZ_FR; ++j) {
+            const int r = r0 + j, gy = y0 - N + r;
+            if (r >= N && r < N + AKZ_FH && gy < h) o[(size_t)gy * w + gx] = L[j];
         }
+    }
 }
 
 // ---- Compute_Multiscale_Derivatives, first derivatives (unscaled): sparse 3-tap Scharr at distance s ----
@@ -433,8 +464,8 @@ extern "C" int afv_akz_launch_fed_fused(const float *Lt_in, const float *lsm, in
     if (nsteps < 1 || nsteps > AKZ_FED_MAX) return 0;
     AkzTau t{};
     for (int i = 0; i < nsteps; ++i) t.t[i] = tau[i];
-    const int LH = AKZ_FH + 2 * nsteps, OW = 64 - 2 * nsteps;
-    const size_t lds = ((size_t)3 * 64 * LH + (size_t)66 * (LH + 2)) * sizeof(float);
+    const int OW = 64 - 2 * nsteps;
+    const size_t lds = ((size_t)66 * 66 + 2 * 2 * 8 * 64) * sizeof(float);
     hipLaunchKernelGGL(k_akz_fed_fused, akz_grid1(w, h, nframes, OW, AKZ_FH), dim3(AKZ_FT), lds, st, Lt_in, lsm, w, h, nframes, kcontrast, octave,
                        nsteps, t, Lt_out);
     return 1;
