@@ -284,12 +284,29 @@ __global__ __launch_bounds__(AKZ_FT) void k_akz_fed_fused(const float *__restric
     const int r0 = wv * AKZ_FR;
     // conductivity of the band rows and of the rows just above / below it (rows outside the tile are never used by a valid pixel)
     float c[AKZ_FR + 2];
+    {
+        // Scharr on a sliding 3-row window: one LDS read per source row (the centre column); the left / right columns are the
+        // neighbouring lanes' centres (DPP), except for the two edge lanes which read the extra ring column
+        float vc[AKZ_FR + 4], vl[AKZ_FR + 4], vr[AKZ_FR + 4];
 #pragma unroll
-    for (int j = 0; j < AKZ_FR + 2; ++j) {
-        const int r = min(max(r0 - 1 + j, 0), LH - 1);
-        const float *q = &s_s[(r + 1) * SW + tx + 1];
-        const float lxv = akz_scharr_x(q, SW), lyv = akz_scharr_y(q, SW);
-        c[j] = 1.0f / (1.0f + (lxv * lxv + lyv * lyv) * k2inv);
+        for (int j = 0; j < AKZ_FR + 4; ++j) {
+            const int sr = min(max(r0 - 1 + j, 0), SH - 1);  // s_s row of tile row r0 - 2 + j
+            const float *q = &s_s[sr * SW + tx + 1];
+            vc[j] = q[0];
+            const float dl = akz_from_left(vc[j]), dr = akz_from_right(vc[j]);
+            vl[j] = tx == 0 ? q[-1] : dl;
+            vr[j] = tx == 63 ? q[1] : dr;
+        }
+#pragma unroll
+        for (int j = 0; j < AKZ_FR + 2; ++j) {
+            // tile row r0 - 1 + j: source rows j (above), j + 1 (centre), j + 2 (below); rows clamped into the tile are never used by a valid pixel
+            const float t0 = vr[j] - vl[j], t1 = vr[j + 1] - vl[j + 1], t2 = vr[j + 2] - vl[j + 2];
+            const float lxv = 10.0f * t1 + 3.0f * (t0 + t2);
+            const float u0 = 10.0f * vc[j] + 3.0f * (vl[j] + vr[j]);
+            const float u2 = 10.0f * vc[j + 2] + 3.0f * (vl[j + 2] + vr[j + 2]);
+            const float lyv = u2 - u0;
+            c[j] = 1.0f / (1.0f + (lxv * lxv + lyv * lyv) * k2inv);
+        }
     }
     float cR[AKZ_FR], cL[AKZ_FR], cD[AKZ_FR], cU[AKZ_FR], L[AKZ_FR];
     bool upd[AKZ_FR], has_d[AKZ_FR], has_u[AKZ_FR];
@@ -314,7 +331,10 @@ __global__ __launch_bounds__(AKZ_FT) void k_akz_fed_fused(const float *__restric
         __syncthreads();
         const float up_halo = wv > 0 ? xb[8 * 64 + (wv - 1) * 64 + tx] : 0.0f;
         const float dn_halo = wv < 7 ? xb[(wv + 1) * 64 + tx] : 0.0f;
-        const double hs = 0.5 * (double)tau.t[st];
+        // upstream forms 0.5 * stepsize * sum in double; 0.5 * tau is exact in float and a float x float product rounded once
+        // from double equals the IEEE float product, so the float multiply below is bit-identical (tests compare with the
+        // double formulation of the step-by-step kernel and of the oracle)
+        const float hs = 0.5f * tau.t[st];
         float nl[AKZ_FR];
 #pragma unroll
         for (int j = 0; j < AKZ_FR; ++j) {
@@ -326,7 +346,7 @@ __global__ __launch_bounds__(AKZ_FT) void k_akz_fed_fused(const float *__restric
             const float ypos = has_d[j] ? cD[j] * (Ld - Lc) : 0.0f;
             const float yneg = has_u[j] ? cU[j] * (Lc - Lu) : 0.0f;
             const float sum = ((xpos - xneg) + ypos) - yneg;
-            nl[j] = upd[j] ? Lc + (float)(hs * (double)sum) : Lc;
+            nl[j] = upd[j] ? Lc + hs * sum : Lc;
         }
 #pragma unroll
         for (int j = 0; j < AKZ_FR; ++j) L[j] = nl[j];
