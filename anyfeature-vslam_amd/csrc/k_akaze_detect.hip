@@ -214,6 +214,7 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
     __shared__ float s_sx[64], s_sy[64];
     __shared__ int s_cx[64], s_cy[64], s_loc[64], s_stop, s_nout, s_wsum[AKD_T / 64];
     __shared__ float s_mx[64], s_my[64];  // position of a candidate's first match
+    __shared__ int s_type[64], s_conf[64];
     float *ex = S.ex + (size_t)f * P.entry_cap, *ey = S.ey + (size_t)f * P.entry_cap, *er = S.eresp + (size_t)f * P.entry_cap;
     int *el = S.elevel + (size_t)f * P.entry_cap;
     uint4 *cells = S.cells + (size_t)f * 2 * ncells * AKD_CELLCAP;
@@ -226,6 +227,7 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
     const float inv_cell = 1.0f / AKD_CELL;
 #ifdef AFV_AKZ_STATS
     const long long st_t0 = wall_clock64();
+    long long st_p[4] = {0, 0, 0, 0};
 #endif
     for (int c = 0; c < P.nlevels; ++c) {
         const AkdLevel L = P.lv[c];
@@ -250,6 +252,9 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
             ++st_rounds;
 #endif
             const int nround = min(64, n - pos);
+#ifdef AFV_AKZ_STATS
+            const long long ph0 = wall_clock64();
+#endif
             // ---- 1. the round's candidates (wave 0); the next 64 are prefetched while this round is scanned ----
             float sx = 0, sy = 0, resp = 0;
             int cx = 0, cy = 0;
@@ -279,6 +284,9 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
                 }
             }
             __syncthreads();
+#ifdef AFV_AKZ_STATS
+            const long long ph1 = wall_clock64();
+#endif
             // ---- 2. neighbourhood scan: the (candidate, cell) pairs of the round spread over the whole workgroup ----
             unsigned long long lbest[AKD_ITERS];
             int lloc[AKD_ITERS];
@@ -328,6 +336,9 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
                 }
             }
             __syncthreads();
+#ifdef AFV_AKZ_STATS
+            const long long ph2 = wall_clock64();
+#endif
             // the thread that found a candidate's first match publishes where that list element sits (slots are unique)
 #pragma unroll
             for (int it = 0; it < AKD_ITERS; ++it) {
@@ -341,12 +352,16 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
                 }
             }
             __syncthreads();
+#ifdef AFV_AKZ_STATS
+            const long long ph3 = wall_clock64();
+#endif
             // ---- 3. decisions, exact conflict test against the earlier lanes of the round, commit (wave 0) ----
+            // 3a. decisions (wave 0)
+            int first = -1, type = 0;  // type: 0 drop, 1 append, 2 replace `first`
+            float oex = 0, oey = 0;
             if (tid < 64) {
                 const unsigned long long b = s_best[tid];
-                const int first = (act && b != AKD_NONE) ? (int)(b >> 32) : -1;
-                int type = 0;  // 0 drop, 1 append, 2 replace `first`
-                float oex = 0, oey = 0;
+                first = (act && b != AKD_NONE) ? (int)(b >> 32) : -1;
                 if (act) {
                     if (first < 0) type = 1;
                     else if (resp > __uint_as_float((unsigned int)(b & 0xffffffffu))) {
@@ -355,25 +370,37 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
                         oey = s_my[tid];
                     }
                 }
-                // a lane's decision stands unless an earlier lane of the round changes what its search sees: a new / moved
-                // entry inside its radius, or a replaced entry that used to lie inside its radius
-                // (uniform loop over the round's lanes; lane j's data is broadcast with v_readlane)
-                const unsigned long long modm = __ballot(type != 0), repm = __ballot(type == 2);
-                bool conflict = false;
-                for (int j = 0; j + 1 < nround; ++j) {
-                    if (!((modm >> j) & 1ull)) continue;  // wave-uniform
-                    const float xj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sx), j));
-                    const float yj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sy), j));
-                    const float dx = sx - xj, dy = sy - yj;
-                    bool hit = dx * dx + dy * dy <= size2;
-                    if ((repm >> j) & 1ull) {
-                        const float oxj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, oex), j));
-                        const float oyj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, oey), j));
-                        const float ux = sx - oxj, uy = sy - oyj;
-                        hit = hit || (ux * ux + uy * uy <= size2);
+                s_type[tid] = type;
+                s_mx[tid] = oex;
+                s_my[tid] = oey;
+                s_conf[tid] = 0;
+            }
+            __syncthreads();
+            // 3b. a candidate's decision stands unless an earlier candidate of the round changes what its search sees: a new /
+            //     moved entry inside its radius, or a replaced entry that used to lie inside its radius.  The 64 x 63 / 2 ordered
+            //     pairs are spread over the workgroup (thread = candidate i x 16 strided earlier candidates j).
+            {
+                const int i = tid >> 4;
+                if (i < nround) {
+                    const float xi = s_sx[i], yi = s_sy[i];
+                    bool hit = false;
+                    for (int j = tid & 15; j < i; j += 16) {
+                        const int tj = s_type[j];
+                        if (tj == 0) continue;
+                        const float dx = xi - s_sx[j], dy = yi - s_sy[j];
+                        hit = hit || (dx * dx + dy * dy <= size2);
+                        if (tj == 2) {
+                            const float ux = xi - s_mx[j], uy = yi - s_my[j];
+                            hit = hit || (ux * ux + uy * uy <= size2);
+                        }
                     }
-                    if (hit && act && lane > j) conflict = true;
+                    if (hit) s_conf[i] = 1;
                 }
+            }
+            __syncthreads();
+            // 3c. commit up to the first conflicting candidate (wave 0)
+            if (tid < 64) {
+                const bool conflict = act && s_conf[tid] != 0;
                 const unsigned long long cm = __ballot(conflict);
                 const int stop = cm ? (int)__builtin_ctzll(cm) : nround;
                 const bool commit = act && lane < stop && type != 0;
@@ -413,7 +440,9 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
             __syncthreads();
             pos += s_stop;
             nE = s_nout;
-            __syncthreads();
+#ifdef AFV_AKZ_STATS
+            { const long long ph4 = wall_clock64(); st_p[0] += ph1 - ph0; st_p[1] += ph2 - ph1; st_p[2] += ph3 - ph2; st_p[3] += ph4 - ph3; }
+#endif
         }
 #ifdef AFV_AKZ_STATS
         if (tid == 0 && f == 0) printf("akz_suppress: level %d candidates %d rounds %d entries %d\n", c, n, st_rounds, nE);
@@ -527,7 +556,7 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
         __syncthreads();
     }
 #ifdef AFV_AKZ_STATS
-    if (tid == 0 && f == 0) printf("akz_suppress phases (us at 100 MHz): rounds %lld upper %lld subpixel %lld\n", (st_t1 - st_t0) / 100, (st_t2 - st_t1) / 100, (wall_clock64() - st_t2) / 100);
+    if (tid == 0 && f == 0) printf("akz_suppress phases (us at 100 MHz): rounds %lld upper %lld subpixel %lld | per-round parts: load %lld scan %lld publish %lld decide+commit %lld\n", (st_t1 - st_t0) / 100, (st_t2 - st_t1) / 100, (wall_clock64() - st_t2) / 100, st_p[0] / 100, st_p[1] / 100, st_p[2] / 100, st_p[3] / 100);
 #endif
     if (tid == 0) kp_count[f] = min(nout, P.kp_cap);
 }
