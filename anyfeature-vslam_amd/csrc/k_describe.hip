@@ -9,9 +9,9 @@
 // The reference blurs whole levels (36 level-blurs per frame because compute() is called once per level).  Only the
 // 512 rotated test locations inside the 37x37 neighbourhood of a keypoint are ever sampled, so each wavefront stages
 // the 43x43 UNBLURRED patch around its keypoint in LDS (reflect-101 at the image edge = cv::ORB's apron), computes
-// the intensity-centroid moments from it and evaluates the blur ONLY at the sampled locations: 7 row sums with the
-// integer taps [18,34,49,55,49,34,18] (two v_dot4_u32_u8 per row on funnel-shifted dwords, exact), the column sum and
-// round-half-even(S/65536).  A test that falls outside the level ROI reads the unblurred apron pixel, as in OpenCV
+// the intensity-centroid moments from it, runs the ROW pass of the blur over the patch once (integer taps
+// [18,34,49,55,49,34,18], two v_dot4_u32_u8 per output on funnel-shifted dwords, exact in 16 bits) and evaluates the COLUMN
+// pass + round-half-even(S/65536) only at the sampled locations.  A test that falls outside the level ROI reads the unblurred apron pixel, as in OpenCV
 // where only the ROI is blurred in place.  No blurred image ever touches HBM.
 #include "afv_device.h"
 
@@ -95,23 +95,36 @@ __device__ __forceinline__ uint8_t blur_round(int S) {
     return (uint8_t)min(q, 255);
 }
 
-// 7-tap blur of the staged patch at patch position (row y, column x) [x, y relative to the patch origin, taps centred]:
-// exact integer arithmetic of the separable 8U filter: row sums with taps [18,34,49,55,49,34,18] (two v_dot4 per row
-// on funnel-shifted dwords), column sum, then round-half-even(S / 65536).
-__device__ __forceinline__ int blur_at(const uint8_t *P, int x, int y) {
-    const uint32_t T_LO = 18u | (34u << 8) | (49u << 16) | (55u << 24);  // taps for bytes x-3 .. x
-    const uint32_t T_HI = 49u | (34u << 8) | (18u << 16);                // taps for bytes x+1 .. x+3
-    const int xb = x - 3;
-    const int sh = (xb & 3) * 8;
-    const uint32_t *row = reinterpret_cast<const uint32_t *>(P + (y - 3) * PP + (xb & ~3));
-    uint32_t h[7];
+// Row pass of the separable 8U filter over the whole staged patch, once per keypoint: H[r][xh] = sum_k taps[k] * P[r][xh + k]
+// for xh = 0..39 (<= 257 * 255 = 65535: exact in 16 bits).  One lane per group of 4 adjacent outputs: 3 aligned dwords in, two
+// v_dot4_u32_u8 per output on funnel-shifted dwords, 4 x u16 out.
+#define HP 44  // u16 pitch of the row-filtered plane (88 bytes: 8-byte aligned rows)
+__device__ __forceinline__ void blur_rows(const uint8_t *P, uint16_t *H, int lane) {
+    const uint32_t T_LO = 18u | (34u << 8) | (49u << 16) | (55u << 24);  // taps for bytes xh .. xh+3
+    const uint32_t T_HI = 49u | (34u << 8) | (18u << 16);                // taps for bytes xh+4 .. xh+6
+    for (int i = lane; i < PS * 10; i += 64) {
+        const int r = i / 10, g = i - r * 10;
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(P + r * PP + g * 4);
+        const uint32_t d0 = row[0], d1 = row[1], d2 = row[2];
+        uint32_t o[4];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        const uint32_t d0 = row[k * (PP / 4)], d1 = row[k * (PP / 4) + 1], d2 = row[k * (PP / 4) + 2];
-        const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
-        h[k] = __builtin_amdgcn_udot4(hi, T_HI, __builtin_amdgcn_udot4(lo, T_LO, 0u, false), false);
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t lo = k ? __builtin_amdgcn_alignbit(d1, d0, 8 * k) : d0, hi = k ? __builtin_amdgcn_alignbit(d2, d1, 8 * k) : d1;
+            o[k] = __builtin_amdgcn_udot4(hi, T_HI, __builtin_amdgcn_udot4(lo, T_LO, 0u, false), false);
+        }
+        uint2 w;
+        w.x = o[0] | (o[1] << 16);
+        w.y = o[2] | (o[3] << 16);
+        *reinterpret_cast<uint2 *>(&H[r * HP + g * 4]) = w;
     }
-    const int S = 18 * (int)(h[0] + h[6]) + 34 * (int)(h[1] + h[5]) + 49 * (int)(h[2] + h[4]) + 55 * (int)h[3];
+}
+
+// column pass + rounding at patch position (row y, column x), taps centred: exact integer arithmetic of the separable filter,
+// then round-half-even(S / 65536)
+__device__ __forceinline__ int blur_at(const uint16_t *H, int x, int y) {
+    const uint16_t *c = H + (y - 3) * HP + (x - 3);
+    const int S = 18 * ((int)c[0] + (int)c[6 * HP]) + 34 * ((int)c[HP] + (int)c[5 * HP]) + 49 * ((int)c[2 * HP] + (int)c[4 * HP]) +
+                  55 * (int)c[3 * HP];
     return blur_round(S);
 }
 
@@ -125,6 +138,7 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
     // patch rows are PP = 52 bytes apart (13 dwords: odd -> rows spread over all LDS banks); 2 guard rows/dwords so that
     // the 3-dword row reads of blur_at never leave the slice
     __shared__ __attribute__((aligned(16))) uint8_t s_patch[KP_PER_BLOCK][(PS + 1) * PP];
+    __shared__ __attribute__((aligned(16))) uint16_t s_rows[KP_PER_BLOCK][PS * HP];  // row-filtered patch
 
     const Geo &geo = *geo_p;
     // XCD-aware placement: all keypoints of a frame are described on one XCD (their patches share L2 lines)
@@ -167,6 +181,7 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
         pitch = L.pitch;
     }
     uint8_t *P = s_patch[wv];
+    uint16_t *H = s_rows[wv];
 
     // ---- 1. stage the 43x43 unblurred patch; P[r][a + c] = level(cx-21+c, cy-21+r) with reflect-101 ----
     const int px0 = cx - PR, py0 = cy - PR;
@@ -194,6 +209,7 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
         }
     }
     wave_sync();  // each wave owns its LDS slice: no workgroup barrier anywhere in this kernel
+    blur_rows(P, H, lane);  // consumed after the IC stage below (wave_sync before the BRIEF tests)
 
     // ---- 2. intensity centroid over the radius-15 disc: lane = (row, half) ----
     const uint8_t *C = &P[PR * PP + PR + a];  // patch centre
@@ -224,6 +240,7 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
     // evaluated only where a test samples it (512 of the 1369 patch positions) ----
     float ca, sb;
     sincos_deg(angle, ca, sb);
+    wave_sync();  // row-filtered plane complete
     // BRIEF centre = cvRound(pt * (1/scale)) with pt = level coordinate * scale (orb.cpp computeOrbDescriptors)
     const float ptx = (float)cx * L.scale, pty = (float)cy * L.scale;
     const int bx = (int)rintf(ptx * L.inv_scale), by = (int)rintf(pty * L.inv_scale);
@@ -238,8 +255,8 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
         const int ix1 = (int)rintf(x1 * ca - y1 * sb) + ox, iy1 = (int)rintf(x1 * sb + y1 * ca) + oy;
         // inside the ROI -> blurred, outside -> unblurred apron
         const int gx0 = cx + ix0, gy0 = cy + iy0, gx1 = cx + ix1, gy1 = cy + iy1;
-        const int t0 = (gx0 >= 0 && gx0 < lw && gy0 >= 0 && gy0 < lh) ? blur_at(P, PR + a + ix0, PR + iy0) : C[iy0 * PP + ix0];
-        const int t1 = (gx1 >= 0 && gx1 < lw && gy1 >= 0 && gy1 < lh) ? blur_at(P, PR + a + ix1, PR + iy1) : C[iy1 * PP + ix1];
+        const int t0 = (gx0 >= 0 && gx0 < lw && gy0 >= 0 && gy0 < lh) ? blur_at(H, PR + a + ix0, PR + iy0) : C[iy0 * PP + ix0];
+        const int t1 = (gx1 >= 0 && gx1 < lw && gy1 >= 0 && gy1 < lh) ? blur_at(H, PR + a + ix1, PR + iy1) : C[iy1 * PP + ix1];
         const unsigned long long m = __ballot(t0 < t1);
         words[2 * g] = (uint32_t)m;
         words[2 * g + 1] = (uint32_t)(m >> 32);
