@@ -219,17 +219,33 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
         if (v <= 15) {
             const int av = v < 0 ? -v : v;
             const int d = k_umax[av];
-            // half 0: u in [-d, -1], half 1: u in [0, d]
-            const int u0 = (lane & 1) ? 0 : -d, u1 = (lane & 1) ? d : -1;
-            const uint8_t *row = C + v * PP;
-            int su = 0, s1 = 0;
-            for (int u = u0; u <= u1; ++u) {
-                const int val = row[u];
-                su += u * val;
-                s1 += val;
+            // half 0: u in [-d, -1] = bytes j = 16-d .. 15 of the 16 bytes starting at u = -16; half 1: u in [0, d] = bytes
+            // j = 0 .. d of the 16 bytes starting at u = 0.  Five aligned dwords, funnel-shifted to the start byte, bytes outside
+            // the disc masked to zero, then sum(val) and sum(j * val) by v_dot4_u32_u8.
+            const int half = lane & 1;
+            const int A = (PR + v) * PP + PR + a + (half ? 0 : -16);
+            const uint32_t *wp = reinterpret_cast<const uint32_t *>(P + (A & ~3));
+            const int sh = (A & 3) * 8;
+            const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3], w4 = wp[4];
+            uint32_t b[4] = {__builtin_amdgcn_alignbit(w1, w0, sh), __builtin_amdgcn_alignbit(w2, w1, sh), __builtin_amdgcn_alignbit(w3, w2, sh),
+                             __builtin_amdgcn_alignbit(w4, w3, sh)};
+            uint32_t s1 = 0, sj = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t m;
+                if (half) {
+                    const int nb = min(max(d + 1 - 4 * q, 0), 4);                  // valid leading bytes
+                    m = nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
+                } else {
+                    const int nz = min(max(16 - d - 4 * q, 0), 4);                 // invalid leading bytes
+                    m = nz >= 4 ? 0u : (0xffffffffu << (8 * nz));
+                }
+                const uint32_t x = b[q] & m;
+                s1 = __builtin_amdgcn_udot4(x, 0x01010101u, s1, false);
+                sj = __builtin_amdgcn_udot4(x, 0x03020100u + 0x04040404u * (uint32_t)q, sj, false);
             }
-            m10 = su;
-            m01 = v * s1;
+            m10 = half ? (int)sj : (int)sj - 16 * (int)s1;
+            m01 = v * (int)s1;
         }
     }
     m10 = wave_sum(m10);
