@@ -186,7 +186,8 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
     // ---- 1. stage the 43x43 unblurred patch; P[r][a + c] = level(cx-21+c, cy-21+r) with reflect-101 ----
     const int px0 = cx - PR, py0 = cy - PR;
     int a;  // column offset of patch column 0 inside the LDS row
-    if (px0 >= 0 && py0 >= 0 && px0 + 48 <= lw && py0 + PS <= lh) {
+    const bool interior = px0 >= 0 && py0 >= 0 && px0 + 48 <= lw && py0 + PS <= lh;  // wave-uniform
+    if (interior) {
         // interior: 12 aligned dwords per row, 5 rows per wave instruction
         a = px0 & 3;
         const int ax0 = px0 - a;
@@ -269,10 +270,16 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
         const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
         const int ix0 = (int)rintf(x0 * ca - y0 * sb) + ox, iy0 = (int)rintf(x0 * sb + y0 * ca) + oy;
         const int ix1 = (int)rintf(x1 * ca - y1 * sb) + ox, iy1 = (int)rintf(x1 * sb + y1 * ca) + oy;
-        // inside the ROI -> blurred, outside -> unblurred apron
-        const int gx0 = cx + ix0, gy0 = cy + iy0, gx1 = cx + ix1, gy1 = cy + iy1;
-        const int t0 = (gx0 >= 0 && gx0 < lw && gy0 >= 0 && gy0 < lh) ? blur_at(H, PR + a + ix0, PR + iy0) : C[iy0 * PP + ix0];
-        const int t1 = (gx1 >= 0 && gx1 < lw && gy1 >= 0 && gy1 < lh) ? blur_at(H, PR + a + ix1, PR + iy1) : C[iy1 * PP + ix1];
+        // inside the ROI -> blurred, outside -> unblurred apron (a patch that lies inside the level has no outside samples)
+        int t0, t1;
+        if (interior) {
+            t0 = blur_at(H, PR + a + ix0, PR + iy0);
+            t1 = blur_at(H, PR + a + ix1, PR + iy1);
+        } else {
+            const int gx0 = cx + ix0, gy0 = cy + iy0, gx1 = cx + ix1, gy1 = cy + iy1;
+            t0 = (gx0 >= 0 && gx0 < lw && gy0 >= 0 && gy0 < lh) ? blur_at(H, PR + a + ix0, PR + iy0) : C[iy0 * PP + ix0];
+            t1 = (gx1 >= 0 && gx1 < lw && gy1 >= 0 && gy1 < lh) ? blur_at(H, PR + a + ix1, PR + iy1) : C[iy1 * PP + ix1];
+        }
         const unsigned long long m = __ballot(t0 < t1);
         words[2 * g] = (uint32_t)m;
         words[2 * g + 1] = (uint32_t)(m >> 32);
