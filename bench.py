@@ -233,8 +233,8 @@ def main():
                                    "algorithmic_bytes_per_launch": px * frames_per_launch, "avg_launch_ms": ms,
                                    "frames_per_launch": frames_per_launch,
                                    "note": "integer-VALU-bound kernel (FAST ring tests + Harris): the HBM fraction is low by "
-                                           "construction; two half-batch launches run concurrently on two streams, so a launch "
-                                           "shares the chip with the other half's kernels (DESIGN.md section 4)"}
+                                           "construction; the runtime runs a step as four quarter-batch launches per kernel over two "
+                                           "streams, so a launch shares the chip with the other stream's kernels (DESIGN.md section 4)"}
             vp = valu_pmc()
             if vp:
                 ach = vp["valu_winst_per_frame_total"] * out["frames_per_s"]
