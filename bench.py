@@ -119,6 +119,88 @@ def cpu_baseline(afv, nframes, seed0):
             "ms_per_frame": 1e3 * ta / half, "dedup_ms_per_frame": 1e3 * tb / max(len(frames[half:] or frames[:half]), 1)}
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# --workload akaze61 (BASELINE.json configs[4]: AKAZE61, 1280x720, 1 GPU) — a secondary line, not the contract metric
+# ---------------------------------------------------------------------------------------------------------------------
+def akaze_cpu_baseline(afv, frames, quotas):
+    """oracle/akaze.c + the oracle quadtree, one thread (kind "port"; the libAKAZE fork cannot be built here)"""
+    from oracle import akaze_binding as ak
+    from oracle import binding as ob
+    h, w = frames[0].shape
+    op = ak.make_plan(w, h)
+    t0 = time.perf_counter()
+    tot = 0
+    for fr in frames:
+        levels, _ = ak.full_evolution(fr, op)
+        kp = ak.subpixel(op, levels, ak.find_extrema(op, levels))
+        chosen = []
+        for lvl in range(op.nlevels):
+            idx = np.nonzero(kp["class_id"] == lvl)[0]
+            if len(idx):
+                chosen.append(idx[ob.quadtree(kp["x"][idx], kp["y"][idx], kp["response"][idx], int(quotas[lvl]), w, h, tiebreak=np.arange(len(idx)))])
+        kk, _ = ak.compute_descriptors(op, levels, kp[np.concatenate(chosen)])
+        tot += len(kk)
+    ct = time.perf_counter() - t0
+    return {"value": tot / ct, "unit": "keypoints/s", "cores": 1, "kind": "port", "ms_per_frame": ct / len(frames) * 1e3,
+            "sample": "%d frames %dx%d through oracle/akaze.c + oracle quadtree, single thread" % (len(frames), w, h)}
+
+
+def akaze_main(args):
+    import torch
+    afv = importlib.import_module("anyfeature-vslam_amd")
+    B, steps = args.batch, args.steps
+    Wa, Ha = 1280, 720
+    ctx = afv.AkazeContext(afv.akaze.default_params(max_batch=B))
+    frames_h = afv.synth.corners_batch(1, B, Wa, Ha)
+    frames = torch.from_numpy(frames_h).cuda()
+    for _ in range(max(args.warmup, 1)):
+        ctx.extract_device(frames)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.extract_device(frames)
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    nk = sum(len(ctx.features(f)[0]) for f in range(B))
+    det = sum(len(ctx.keypoints(f)) for f in range(B))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.scale_space_device(frames)
+    ctx.synchronize()
+    dt_ss = (time.perf_counter() - t0) / steps
+    plan = ctx.plan
+    px0 = Wa * Ha
+    # Algorithmic HBM bytes per frame of scale space + Hessian, each datum moved once: level 0 reads the u8 frame twice (Gaussian
+    # and contrast percentile) and writes Lt; every further level reads the previous Lt, writes Lsmooth and Lt; the Hessian reads
+    # Lsmooth and writes Lx, Ly, Ldet.  The kernel structure moves more ("kernel_structure": gauss, level kernel, 2 derivative kernels).
+    strict = 2 * px0 + 4 * px0
+    kern = px0 + 4 * px0 + px0 + 4 * px0 + 4 * px0 + 4 * px0 + 4 * px0
+    for i in range(1, plan.nlevels):
+        L, Q = plan.lv[i], plan.lv[i - 1]
+        n = L.w * L.h
+        strict += (4 * Q.w * Q.h if L.octave > Q.octave else 4 * n) + 8 * n
+        if L.octave > Q.octave:
+            kern += 4 * Q.w * Q.h + 4 * n
+        kern += 8 * n + 12 * n
+    for i in range(plan.nlevels):
+        n = plan.lv[i].w * plan.lv[i].h
+        strict += 16 * n
+        kern += 32 * n
+    out = {"metric": "keypoints extracted+described /sec (AKAZE61, 1280x720)", "value": nk / dt, "unit": "keypoints/s", "n_gpus": 1, "steps": steps,
+           "warmup": max(args.warmup, 1), "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic",
+           "config": {"workload": "AKAZE61 1280x720 synthetic corners frames, omax 2 x 4 sublevels, dthreshold 0.0005, 1000-feature quadtree, MLDB-486",
+                      "frames_per_gpu_per_step": B, "detected_per_frame": det / B, "described_per_frame": nk / B},
+           "frames_per_s": B / dt, "scale_space_ms_per_step": dt_ss * 1e3,
+           "roofline": {"bound": "hbm", "kernel": "scale space + Hessian (k_akz_*)", "achieved": strict * B / dt_ss / 1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": strict * B / dt_ss / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "algorithmic_bytes_per_frame": strict, "kernel_structure_bytes_per_frame": kern,
+                        "kernel_structure_GBps": kern * B / dt_ss / 1e9}}
+    if args.cpu_frames > 0:
+        out["cpu_baseline"] = akaze_cpu_baseline(afv, frames_h[:min(args.cpu_frames, B, 4)], ctx.quotas())
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,7 +212,11 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
                                                       "multi-rank control flow on a 1-GPU box)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
+    ap.add_argument("--workload", default="orb32", choices=["orb32", "akaze61"],
+                    help="orb32 = the BASELINE.json metric (default); akaze61 = configs[4], 1280x720, single GPU (use --batch 64)")
     args = ap.parse_args()
+    if args.workload == "akaze61":
+        return akaze_main(args)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))

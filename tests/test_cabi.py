@@ -88,6 +88,14 @@ def test_akaze_abi_without_gpu(afv):
             afv.AkazeContext()
 
 
+def test_tools_do_not_import_the_oracle():
+    """tools/ are not test infrastructure either"""
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith(".py"):
+            text = open(os.path.join(ROOT, "tools", f)).read()
+            assert "from oracle" not in text and "import oracle" not in text, f
+
+
 def test_host_hamming_utility(afv, oracle):
     d = afv.synth.random_descriptors(4, 16)
     for i in range(0, 16, 2):
@@ -101,4 +109,5 @@ def test_product_does_not_import_the_oracle():
         for f in files:
             if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
-                assert "import oracle" not in text and "from oracle" not in text and "afvo" not in text, os.path.join(dirpath, f)
+                assert "import oracle" not in text and "from oracle" not in text and "afvo" not in text and "libakz" not in text and \
+                    "akaze_binding" not in text, os.path.join(dirpath, f)
