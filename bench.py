@@ -321,6 +321,11 @@ def main():
                                    "note": "integer-VALU-bound kernel (FAST ring tests + Harris): the HBM fraction is low by "
                                            "construction; the runtime runs a step as four quarter-batch launches per kernel over two "
                                            "streams, so a launch shares the chip with the other stream's kernels (DESIGN.md section 4)"}
+            # whole-pipeline algorithmic bytes (resize 1 569 878 + FAST read 950 532 + blur 1 901 064 + outputs
+            # 60 000 = 4 481 534 B per 640x480 frame; the blur never touches HBM here, the figure is the reference's data flow)
+            out["roofline_pipeline"] = {"bound": "hbm", "achieved": out["frames_per_s"] * 4481534 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": out["frames_per_s"] * 4481534 / 1e9 / HBM_PEAK_GBS,
+                                        "algorithmic_bytes_per_frame": 4481534}
             vp = valu_pmc()
             if vp:
                 ach = vp["valu_winst_per_frame_total"] * out["frames_per_s"]
