@@ -192,7 +192,8 @@ struct AkdState {
 
 #define AKD_T 1024
 #define AKD_PAIRS 18  // 2 grids x 3 x 3 cells per candidate
-#define AKD_ITERS ((64 * AKD_PAIRS + AKD_T - 1) / AKD_T)
+#define AKD_R 128      // candidates per speculative round (two wavefronts decide / commit)
+#define AKD_ITERS ((AKD_R * AKD_PAIRS + AKD_T - 1) / AKD_T)
 #define AKD_DEAD 0xffffffffu
 #define AKD_NONE 0xffffffffffffffffull
 #define AKD_WAVE_SYNC()                                        \
@@ -210,11 +211,12 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
     const int ncells = P.gw * P.gh;
     unsigned short *s_cnt = reinterpret_cast<unsigned short *>(akd_smem);  // [2][ncells] list lengths, both grids
     unsigned int *s_cnt32 = reinterpret_cast<unsigned int *>(akd_smem);    // the same counters as packed pairs (LDS atomics)
-    __shared__ unsigned long long s_best[64];  // per candidate of the round: slot << 32 | response bits (min = first match)
-    __shared__ float s_sx[64], s_sy[64];
-    __shared__ int s_cx[64], s_cy[64], s_loc[64], s_stop, s_nout, s_wsum[AKD_T / 64];
-    __shared__ float s_mx[64], s_my[64];  // position of a candidate's first match
-    __shared__ int s_type[64], s_conf[64];
+    __shared__ unsigned long long s_best[AKD_R];  // per candidate of the round: slot << 32 | response bits (min = first match)
+    __shared__ float s_sx[AKD_R], s_sy[AKD_R];
+    __shared__ int s_cx[AKD_R], s_cy[AKD_R], s_loc[AKD_R], s_wsum[AKD_T / 64];
+    __shared__ float s_mx[AKD_R], s_my[AKD_R];  // position of a candidate's first match
+    __shared__ int s_type[AKD_R], s_conf[AKD_R];
+    __shared__ int s_first[AKD_R / 64], s_apps[AKD_R / 64], s_napp[AKD_R / 64];  // per deciding wavefront: first conflict, appends, committed appends
     float *ex = S.ex + (size_t)f * P.entry_cap, *ey = S.ey + (size_t)f * P.entry_cap, *er = S.eresp + (size_t)f * P.entry_cap;
     int *el = S.elevel + (size_t)f * P.entry_cap;
     uint4 *cells = S.cells + (size_t)f * 2 * ncells * AKD_CELLCAP;
@@ -251,15 +253,15 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
 #ifdef AFV_AKZ_STATS
             ++st_rounds;
 #endif
-            const int nround = min(64, n - pos);
+            const int nround = min(AKD_R, n - pos);
 #ifdef AFV_AKZ_STATS
             const long long ph0 = wall_clock64();
 #endif
-            // ---- 1. the round's candidates (wave 0); the next 64 are prefetched while this round is scanned ----
+            // ---- 1. the round's candidates (first AKD_R threads); the next round's are prefetched while this one is scanned ----
             float sx = 0, sy = 0, resp = 0;
             int cx = 0, cy = 0;
             const bool act = tid < nround;
-            if (tid < 64) {
+            if (tid < AKD_R) {
                 if (act) {
                     int idx;
                     if (pf_pos == pos) {
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
                 }
                 s_sx[tid] = sx; s_sy[tid] = sy; s_cx[tid] = cx; s_cy[tid] = cy;
                 s_best[tid] = AKD_NONE;
-                pf_pos = pos + 64;  // valid if this round commits all 64 (the common case)
+                pf_pos = pos + AKD_R;  // valid if this round commits all of its candidates (the common case)
                 if (pf_pos + tid < n) {
                     pf_idx = cd[pf_pos + tid];
                     pf_resp = cr[pf_pos + tid];
@@ -356,10 +358,10 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
             const long long ph3 = wall_clock64();
 #endif
             // ---- 3. decisions, exact conflict test against the earlier lanes of the round, commit (wave 0) ----
-            // 3a. decisions (wave 0)
+            // 3a. decisions (first AKD_R threads)
             int first = -1, type = 0;  // type: 0 drop, 1 append, 2 replace `first`
             float oex = 0, oey = 0;
-            if (tid < 64) {
+            if (tid < AKD_R) {
                 const unsigned long long b = s_best[tid];
                 first = (act && b != AKD_NONE) ? (int)(b >> 32) : -1;
                 if (act) {
@@ -374,17 +376,20 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
                 s_mx[tid] = oex;
                 s_my[tid] = oey;
                 s_conf[tid] = 0;
+                const unsigned long long apm = __ballot(type == 1);
+                if (lane == 0) s_apps[tid >> 6] = __popcll(apm);
             }
             __syncthreads();
             // 3b. a candidate's decision stands unless an earlier candidate of the round changes what its search sees: a new /
-            //     moved entry inside its radius, or a replaced entry that used to lie inside its radius.  The 64 x 63 / 2 ordered
-            //     pairs are spread over the workgroup (thread = candidate i x 16 strided earlier candidates j).
+            //     moved entry inside its radius, or a replaced entry that used to lie inside its radius.  The ordered pairs (j < i)
+            //     are spread over the workgroup (AKD_T / AKD_R threads per candidate i, strided over the earlier candidates j).
             {
-                const int i = tid >> 4;
+                constexpr int PER = AKD_T / AKD_R;  // threads per candidate
+                const int i = tid / PER;
                 if (i < nround) {
                     const float xi = s_sx[i], yi = s_sy[i];
                     bool hit = false;
-                    for (int j = tid & 15; j < i; j += 16) {
+                    for (int j = tid % PER; j < i; j += PER) {
                         const int tj = s_type[j];
                         if (tj == 0) continue;
                         const float dx = xi - s_sx[j], dy = yi - s_sy[j];
@@ -398,17 +403,26 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
                 }
             }
             __syncthreads();
-            // 3c. commit up to the first conflicting candidate (wave 0)
-            if (tid < 64) {
+            // 3c. commit up to the first conflicting candidate (first AKD_R threads = AKD_R / 64 wavefronts)
+            if (tid < AKD_R) {
                 const bool conflict = act && s_conf[tid] != 0;
                 const unsigned long long cm = __ballot(conflict);
-                const int stop = cm ? (int)__builtin_ctzll(cm) : nround;
-                const bool commit = act && lane < stop && type != 0;
+                if (lane == 0) s_first[tid >> 6] = cm ? (tid & ~63) + (int)__builtin_ctzll(cm) : AKD_R;
+            }
+            __syncthreads();
+            int stop = nround;
+#pragma unroll
+            for (int w = 0; w < AKD_R / 64; ++w) stop = min(stop, s_first[w]);
+            if (tid < AKD_R) {
+                const bool commit = act && tid < stop && type != 0;
                 const unsigned long long am = __ballot(commit && type == 1);
                 if (commit) {
                     int slot;
                     if (type == 1) {
-                        slot = nE + __popcll(am & ((1ull << lane) - 1ull));
+                        // appends of the earlier deciding wavefronts all commit when this wavefront commits anything
+                        int before = 0;
+                        for (int w = 0; w < (tid >> 6); ++w) before += s_apps[w];
+                        slot = nE + before + __popcll(am & ((1ull << lane) - 1ull));
                     } else {
                         slot = first;
                         cells[s_loc[tid]].w = AKD_DEAD;
@@ -431,15 +445,14 @@ __global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S,
                         atomicExch(status, 3);
                     }
                 }
-                if (lane == 0) {
-                    s_stop = stop;
-                    s_nout = min(nE + __popcll(am), P.entry_cap);
-                }
+                if (lane == 0) s_napp[tid >> 6] = __popcll(am);
             }
             __threadfence_block();
             __syncthreads();
-            pos += s_stop;
-            nE = s_nout;
+            pos += stop;
+#pragma unroll
+            for (int w = 0; w < AKD_R / 64; ++w) nE += s_napp[w];
+            nE = min(nE, P.entry_cap);
 #ifdef AFV_AKZ_STATS
             { const long long ph4 = wall_clock64(); st_p[0] += ph1 - ph0; st_p[1] += ph2 - ph1; st_p[2] += ph3 - ph2; st_p[3] += ph4 - ph3; }
 #endif
