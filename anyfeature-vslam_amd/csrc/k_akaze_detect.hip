@@ -9,7 +9,7 @@
 //     the result).
 //  2. k_akz_suppress: upstream inserts the candidates one by one into kpts_aux, comparing each against the FIRST earlier
 //     entry of the same / previous level within its radius (replace it or drop the newcomer).  One workgroup per frame
-//     replays that loop in speculative rounds of 64 consecutive candidates: the (candidate, grid cell) pairs of a round
+//     replays that loop in speculative rounds of AKD_R (128) consecutive candidates: the (candidate, grid cell) pairs of a round
 //     are scanned by all threads in two uniform grids (previous level, current level; entries inline in the cell lists,
 //     list lengths in LDS); then every candidate checks exactly whether an earlier candidate of the round changes what
 //     its search saw (a new / moved entry inside its radius, or a replaced entry that lay inside it) and the round
