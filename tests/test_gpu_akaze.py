@@ -200,3 +200,31 @@ def test_hip_reproduces_golden_fixture(afv):
     assert ext.GetKeypointOctave(k) == k["class_id"] and abs(ext.GetKeypointSize(k) - 1.1892 ** k["class_id"]) < 1e-5
     ext.close()
     afv.FeatureExtractorSettings({"FeatureExtractor.numOctaves": 8, "FeatureExtractor.scaleFactor": 1.2, "FeatureExtractor.detectionTh": 20.0})
+
+
+@pytest.mark.parametrize("num_octaves,th,w,h,nfeatures", [(4, 0.001, 640, 480, 500), (8, 0.0002, 1280, 720, 1000)])
+def test_other_settings_and_full_size(afv, akz, oracle, num_octaves, th, w, h, nfeatures):
+    """other FeatureExtractor settings (numOctaves 4 -> omax 1 x 2 sublevels; a lower threshold) and one full config #5 frame
+    (1280 x 720, two quadtree roots) through the whole plugin path"""
+    prm = afv.akaze.default_params(num_octaves=num_octaves, detection_th=th, max_width=w, max_height=h, nfeatures=nfeatures)
+    ctx = afv.AkazeContext(prm)
+    frame = _frames(afv, w, h, (12,))[0]
+    gk, gd = ctx.extract(frame)
+    plan = ctx.plan
+    assert plan.nlevels == (num_octaves // 4) * (num_octaves // 2)
+    op = _oracle_plan(akz, plan)
+    opts = akz.default_options()
+    opts.omax, opts.nsublevels, opts.dthreshold = prm.omax, prm.nsublevels, prm.dthreshold
+    levels, _ = akz.full_evolution(frame, op, opts)
+    kp = akz.subpixel(op, levels, akz.find_extrema(op, levels, opts))
+    quotas = ctx.quotas()
+    assert quotas[:plan.nlevels].tolist() == oracle.quotas_extractor(nfeatures, plan.nlevels, 1.1892).tolist()
+    chosen = []
+    for lvl in range(op.nlevels):
+        idx = np.nonzero(kp["class_id"] == lvl)[0]
+        if len(idx):
+            chosen.append(idx[oracle.quadtree(kp["x"][idx], kp["y"][idx], kp["response"][idx], int(quotas[lvl]), w, h, tiebreak=np.arange(len(idx)))])
+    wk, wd = akz.compute_descriptors(op, levels, kp[np.concatenate(chosen)])
+    assert len(gk) == len(wk) and len(wk) > 0.4 * nfeatures
+    assert gk.tobytes() == wk.tobytes() and np.array_equal(gd, wd)
+    ctx.close()
