@@ -16,7 +16,7 @@ DESC_BYTES = 32
 OK, EINVAL, ENODEV, ENOMEM, EHIP, ECAPACITY, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 MATCH_KF_KF, MATCH_KF_FRAME = 0, 1
 PROJ_LOCALMAP, PROJ_LASTFRAME = 0, 1
-STAGES = ("pyramid", "fast_harris", "select_quadtree", "describe", "match")
+STAGES = ("pyramid", "fast_harris", "select_quadtree", "describe", "match_topk", "match_resolve")
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
                      ("octave", "<i4"), ("class_id", "<i4")])
@@ -50,6 +50,11 @@ class TriJob(C.Structure):
                 ("sigma2_2", C.c_void_p), ("F12", C.c_float * 9), ("ex", C.c_float), ("ey", C.c_float)]
 
 
+class TableTriJob(C.Structure):
+    _fields_ = [("F12", C.c_float * 9), ("ex", C.c_float), ("ey", C.c_float), ("has_mp1", C.c_void_p), ("has_mp2", C.c_void_p),
+                ("th_low", C.c_float)]
+
+
 class ProjJob(C.Structure):
     _fields_ = [("desc", C.c_void_p), ("n", C.c_int32), ("desc_bytes", C.c_int32),
                 ("x", C.c_void_p), ("y", C.c_void_p), ("size", C.c_void_p), ("angle", C.c_void_p), ("occupied", C.c_void_p),
@@ -78,6 +83,26 @@ SYMBOLS = {
     "afv_match_bow": (_i, [_vp, C.POINTER(MatchJob), _i, _vp, _vp]),
     "afv_match_triangulation": (_i, [_vp, C.POINTER(TriJob), _i, _vp, _vp]),
     "afv_match_bruteforce_pairs_device": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _f, _f, _i, _vp, _vp, _vp]),
+    "afv_table_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "afv_table_destroy": (None, [_vp]),
+    "afv_table_set": (_i, [_vp, _i, _vp, _vp, _i]),
+    "afv_table_set_featvec": (_i, [_vp, _i, _vp, _vp, _vp, _i]),
+    "afv_table_set_geometry": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "afv_table_device_ptrs": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "afv_table_sync_counts": (_i, [_vp]),
+    "afv_table_match_pairs": (_i, [_vp, _vp, _vp, _i, _f, _f, _i, _vp, _vp]),
+    "afv_table_match_pairs_device": (_i, [_vp, _vp, _vp, _i, _f, _f, _i, _vp, _vp, _vp]),
+    "afv_table_match_bow": (_i, [_vp, _vp, _vp, _i, _f, _f, _i, _vp, _vp]),
+    "afv_table_match_triangulation": (_i, [_vp, _vp, _vp, C.POINTER(TableTriJob), _i, _vp, _vp]),
+    "afv_table_broadcast": (_i, [_vp, _vp, _i, C.POINTER(_f)]),
+    "afv_comm_unique_id": (_i, [_vp]),
+    "afv_comm_create": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
+    "afv_comm_destroy": (None, [_vp]),
+    "afv_comm_rank": (_i, [_vp]),
+    "afv_comm_size": (_i, [_vp]),
+    "afv_comm_broadcast": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "afv_comm_allgather": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "afv_shard_range": (None, [C.c_long, _i, _i, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "afv_match_l2": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _f, _f, _vp, _vp]),
     "afv_match_projection": (_i, [_vp, C.POINTER(ProjJob), _i, _vp, _vp]),
     "afv_match_fuse": (_i, [_vp, C.POINTER(ProjJob), _i, _vp, _vp]),
@@ -112,6 +137,7 @@ SYMBOLS = {
     "afv_profile_enable": (_i, [_vp, _i]),
     "afv_profile_read": (_i, [_vp, _vp, _vp, _vp]),
     "afv_set_split_threshold": (_i, [_vp, _i]),
+    "afv_set_split_chunks": (_i, [_vp, _i]),
     "afv_get_geometry": (_i, [_vp, C.POINTER(Geometry)]),
     "afv_debug_get_level": (_i, [_vp, _i, _i, _vp]),
     "afv_debug_get_candidates": (_i, [_vp, _i, _i, _vp, _vp, _i, C.POINTER(_i)]),
@@ -159,3 +185,17 @@ def strerror(code):
 
 def ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+HIP_STREAM_LEGACY = 1  # hipStreamLegacy: the C-ABI reserves NULL for "the context's own stream"
+
+
+def torch_stream_handle(device=None, stream=None):
+    """hipStream_t to hand to the *_device entry points so that the work is ordered with torch's CURRENT stream.
+    torch reports its default stream as handle 0, which the C-ABI reads as "use the context's private stream"
+    (unordered with torch): map it to hipStreamLegacy instead."""
+    if stream is not None:
+        return stream
+    import torch
+    s = torch.cuda.current_stream(device).cuda_stream
+    return s if s else HIP_STREAM_LEGACY

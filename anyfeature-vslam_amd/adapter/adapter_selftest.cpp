@@ -96,6 +96,63 @@ int main(int argc, char **argv) {
              dump(out + ".vocdesc", nd.data(), nd.size());
         if (!ok) return 5;
     }
+    // ---- projection-guided searches through the FeatureMatcherHip wrappers (the python test rebuilds the same views from the
+    // dumped keypoints and compares every output with the oracle) ----
+    {
+        std::vector<afv::KeyPoint> k2b;
+        afv::Mat8 d2b;
+        std::vector<afv::Mat2f> s2b, infb;
+        std::vector<float> size2;
+        extractor(img2, k2b, d2b, s2b, infb, size2);
+        if (k2b.size() != k2.size()) return 7;
+        const size_t n1 = k1.size(), n2 = k2.size();
+        std::vector<float> x1(n1), y1(n1), inf1(n1), x2(n2), y2(n2), inf2(n2);
+        for (size_t i = 0; i < n1; ++i) { x1[i] = k1[i].pt.x; y1[i] = k1[i].pt.y; inf1[i] = inf[i].m[0][0]; }
+        for (size_t i = 0; i < n2; ++i) { x2[i] = k2[i].pt.x; y2[i] = k2[i].pt.y; inf2[i] = infb[i].m[0][0]; }
+        using M = afv::FeatureMatcherHip;
+        auto grid = [&](const afv::Mat8 &d, size_t n, const float *x, const float *y, const float *sz, const float *ang, const float *inf_) {
+            M::FrameGridView F;
+            F.descriptors = d.ptr(); F.N = (int)n; F.x = x; F.y = y; F.size = sz; F.angle = ang; F.inf = inf_;
+            F.mfGridElementWidthInv = 64.0f / ((float)w - 0.0f);
+            F.mfGridElementHeightInv = 48.0f / ((float)h - 0.0f);
+            return F;
+        };
+        const M::FrameGridView F1 = grid(d1, n1, x1.data(), y1.data(), size.data(), a1.data(), inf1.data());
+        const M::FrameGridView F2 = grid(d2, n2, x2.data(), y2.data(), size2.data(), a2.data(), inf2.data());
+        // queries: the other frame's keypoints "projected" with the known 4 px shift; window 15 * size; size band /1.2 .. *1.2
+        std::vector<float> u2(n2), r2(n2), lo2(n2), hi2(n2), u1(n1), r1(n1), lo1(n1), hi1(n1), zero1(n1, 0.f), big1(n1, 3.6f), win1(n1, 100.f);
+        std::vector<uint8_t> oct0(n1);
+        for (size_t i = 0; i < n2; ++i) { u2[i] = x2[i] - 4.0f; r2[i] = 15.0f * size2[i]; lo2[i] = size2[i] / 1.2f; hi2[i] = size2[i] * 1.2f; }
+        for (size_t i = 0; i < n1; ++i) { u1[i] = x1[i] + 4.0f; r1[i] = 15.0f * size[i]; lo1[i] = size[i] / 1.2f; hi1[i] = size[i] * 1.2f; oct0[i] = k1[i].octave == 0; }
+        M::ProjectionQueries Q2;  // frame-2 keypoints searched in frame 1
+        Q2.descriptors = d2.ptr(); Q2.n = (int)n2; Q2.u = u2.data(); Q2.v = y2.data(); Q2.r = r2.data(); Q2.min_size = lo2.data();
+        Q2.max_size = hi2.data(); Q2.angle = a2.data();
+        M::ProjectionQueries Q1;  // frame-1 keypoints searched in frame 2
+        Q1.descriptors = d1.ptr(); Q1.n = (int)n1; Q1.u = u1.data(); Q1.v = y1.data(); Q1.r = r1.data(); Q1.min_size = lo1.data();
+        Q1.max_size = hi1.data(); Q1.angle = a1.data();
+        M::ProjectionQueries QI;  // SearchForInitialization: F1's level-0 features, vbPrevMatched = own position, window 100
+        QI.descriptors = d1.ptr(); QI.n = (int)n1; QI.u = x1.data(); QI.v = y1.data(); QI.r = win1.data(); QI.min_size = zero1.data();
+        QI.max_size = big1.data(); QI.valid = oct0.data(); QI.angle = a1.data();
+        afv::FeatureMatcherHip pm(extractor.context(), 0.8f, true);
+        std::vector<int> o_local, o_last, o_reloc, o_sim3p, o_fuse, o_fuse3, o_sim3, o_init;
+        const int c0 = pm.SearchByProjection(F1, Q2, o_local);
+        const int c1 = pm.SearchByProjection_LastFrame(F1, Q2, o_last);
+        const int c2 = pm.SearchByProjection_Reloc(F1, Q2, 60.0f, o_reloc);
+        const int c3 = pm.SearchByProjection_Sim3(F1, Q2, o_sim3p);
+        const int c4 = pm.Fuse(F1, Q2, o_fuse);
+        M::FrameGridView F1n = F1;
+        F1n.inf = nullptr;
+        const int c5 = pm.Fuse(F1n, Q2, o_fuse3);
+        const int c6 = pm.SearchBySim3(F1, Q1, F2, Q2, o_sim3);
+        afv::FeatureMatcherHip im(extractor.context(), 0.9f, true);
+        const int c7 = im.SearchForInitialization(F2, QI, o_init);
+        std::printf("proj %d %d %d %d %d %d %d %d\n", c0, c1, c2, c3, c4, c5, c6, c7);
+        auto dumpv = [&](const char *name, const std::vector<int> &v) { return dump(out + name, v.data(), v.size() * sizeof(int)); };
+        ok = dumpv(".p_local", o_local) && dumpv(".p_last", o_last) && dumpv(".p_reloc", o_reloc) && dumpv(".p_sim3p", o_sim3p) &&
+             dumpv(".p_fuse", o_fuse) && dumpv(".p_fuse3", o_fuse3) && dumpv(".p_sim3", o_sim3) && dumpv(".p_init", o_init) &&
+             dump(out + ".size2", size2.data(), size2.size() * 4) && dump(out + ".inf1", inf1.data(), inf1.size() * 4);
+        if (!ok) return 5;
+    }
     // ---- AKAZE61 plugin ----
     {
         auto s2 = std::make_shared<afv::FeatureExtractorSettings>();

@@ -11,6 +11,11 @@
 //   FeatureExtractor_orb32          include/Feature_orb32.h:12-33, src/Feature_orb32.cpp:11-65
 //   FeatureMatcher::SearchByBoW x2  include/FeatureMatcher.h:59-60, src/FeatureMatcher.cc:186-283, 561-660
 //   FeatureMatcher::SearchForTriangulation  include/FeatureMatcher.h:66-67, src/FeatureMatcher.cc:662-790
+//   FeatureMatcher::SearchByProjection x4 / Fuse x2 / SearchBySim3 / SearchForInitialization (matching cores)
+//                                   include/FeatureMatcher.h:47-82, src/FeatureMatcher.cc:73-154, 287-397, 399-557, 794-1064,
+//                                   1066-1287, 1291-1506 — the projection geometry stays with the caller, as in the reference
+// MONO ONLY: the reference binary is vslamlab_anyfeature_mono; the stereo branches (FeatureMatcher.cc:118-123, 706-733) and
+// mvImagePyramid (FeatureExtractor.h:142, read only by Frame::ComputeStereoMatches, Frame.cc:475,568) are not provided.
 // Error behaviour follows the reference: no exceptions cross the boundary; an empty image leaves the outputs
 // untouched (ORBextractor.cc:570-571); an unrecoverable device error terminates (cf. Feature_sift128.cpp:61).
 #pragma once
@@ -226,7 +231,101 @@ class FeatureMatcherHip {
         return n;
     }
 
+    // ---- projection-guided searches.  The caller evaluates the projections exactly as the reference does
+    // and hands over, per query in the reference's iteration order, (u, v, r, size band); see include/afv_hip.h ----
+    struct FrameGridView {  // what the matchers read from a Frame / KeyFrame (Frame.cc:100-101, Frame.h:40-41)
+        const uint8_t *descriptors = nullptr; int N = 0;
+        const float *x = nullptr, *y = nullptr;  // mvKeysUn[i].pt
+        const float *size = nullptr;             // keyPtsSize[i]
+        const float *angle = nullptr;            // mvKeysUn[i].angle
+        const uint8_t *occupied = nullptr;       // pts[i] (&& observations > 0 where the reference asks) ; nullptr = none
+        const float *inf = nullptr;              // GetKeyPt1DInf(i) (Fuse only)
+        float mnMinX = 0.f, mnMinY = 0.f, mfGridElementWidthInv = 0.f, mfGridElementHeightInv = 0.f;
+        int grid_cols = 64, grid_rows = 48;      // FRAME_GRID_COLS / ROWS
+        float sizeTolerance = 1.2f, invSizeTolerance = 1.0f / 1.2f;  // Frame.cc:73-74
+    };
+    struct ProjectionQueries {
+        const uint8_t *descriptors = nullptr; int n = 0;  // pMP->GetDescriptor() / LastFrame.mDescriptors
+        const float *u = nullptr, *v = nullptr, *r = nullptr, *min_size = nullptr, *max_size = nullptr;
+        const uint8_t *valid = nullptr;      // nullptr = all
+        const float *angle = nullptr;        // last-frame style searches with orientation check
+        const uint8_t *occupies = nullptr;   // pMP->NumberOfObservations() > 0 (nullptr = yes)
+    };
+    // SearchByProjection(F, vpMapPoints, radiusTh) (FeatureMatcher.cc:73-154): assign[i] = query stored in F.pts[i] or -1
+    int SearchByProjection(const FrameGridView &F, const ProjectionQueries &q, std::vector<int> &assign) {
+        return projection(F, q, TH_HIGH, AFV_PROJ_LOCALMAP, false, assign);
+    }
+    // SearchByProjection(CurrentFrame, LastFrame, radiusTh) (:1291-1402, mono)
+    int SearchByProjection_LastFrame(const FrameGridView &F, const ProjectionQueries &q, std::vector<int> &assign) {
+        return projection(F, q, TH_HIGH, AFV_PROJ_LASTFRAME, mbCheckOrientation, assign);
+    }
+    // SearchByProjection(CurrentFrame, pKF, sAlreadyFound, radiusTh, useHighMatchingThreshold) (:1404-1506, relocalisation)
+    int SearchByProjection_Reloc(const FrameGridView &F, const ProjectionQueries &q, float th, std::vector<int> &assign) {
+        return projection(F, q, th, AFV_PROJ_LASTFRAME, mbCheckOrientation, assign);
+    }
+    // SearchByProjection(pKF, Scw, vpPoints, vpMatched, radiusTh) (:287-397, loop closing)
+    int SearchByProjection_Sim3(const FrameGridView &KF, const ProjectionQueries &q, std::vector<int> &assign) {
+        return projection(KF, q, TH_LOW, AFV_PROJ_LASTFRAME, false, assign);
+    }
+    // Fuse(pKF, vpMapPoints, radiusTh) (:794-940): best[q] = keypoint index or -1; with KF.inf == nullptr it is
+    // Fuse(pKF, Scw, vpPoints, radiusTh, vpReplacePoint) (:942-1064)
+    int Fuse(const FrameGridView &KF, const ProjectionQueries &q, std::vector<int> &best) {
+        afv_proj_job j = proj_job(KF, q);
+        j.th_high = TH_LOW;
+        best.assign((size_t)std::max(q.n, 1), -1);
+        int32_t n = 0;
+        const int rc = afv_match_fuse(ctx, &j, 1, best.data(), &n);
+        if (rc != AFV_OK) fatal("afv_match_fuse", rc, ctx);
+        best.resize((size_t)q.n);
+        return n;
+    }
+    // SearchBySim3(pKF1, pKF2, vpMatches12, ...) (:1066-1287): q1 = KF1's map points projected into KF2, q2 the reverse
+    int SearchBySim3(const FrameGridView &KF1, const ProjectionQueries &q1, const FrameGridView &KF2, const ProjectionQueries &q2,
+                     std::vector<int> &matches12) {
+        afv_proj_job j12 = proj_job(KF2, q1), j21 = proj_job(KF1, q2);
+        j12.th_high = j21.th_high = TH_HIGH;
+        matches12.assign((size_t)std::max(q1.n, 1), -1);
+        int32_t n = 0;
+        const int rc = afv_match_sim3(ctx, &j12, &j21, matches12.data(), &n);
+        if (rc != AFV_OK) fatal("afv_match_sim3", rc, ctx);
+        matches12.resize((size_t)q1.n);
+        return n;
+    }
+    // SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (:399-557): q = F1's features
+    int SearchForInitialization(const FrameGridView &F2, const ProjectionQueries &q, std::vector<int> &vnMatches12) {
+        afv_proj_job j = proj_job(F2, q);
+        j.th_high = TH_LOW;
+        j.check_orientation = mbCheckOrientation;
+        vnMatches12.assign((size_t)std::max(q.n, 1), -1);
+        int32_t n = 0;
+        const int rc = afv_match_initialization(ctx, &j, 1, vnMatches12.data(), &n);
+        if (rc != AFV_OK) fatal("afv_match_initialization", rc, ctx);
+        vnMatches12.resize((size_t)q.n);
+        return n;
+    }
+
   private:
+    afv_proj_job proj_job(const FrameGridView &F, const ProjectionQueries &q) const {
+        afv_proj_job j{};
+        j.desc = F.descriptors; j.n = F.N; j.desc_bytes = AFV_DESC_BYTES;
+        j.x = F.x; j.y = F.y; j.size = F.size; j.angle = F.angle; j.occupied = F.occupied; j.inf = F.inf;
+        j.min_x = F.mnMinX; j.min_y = F.mnMinY; j.grid_inv_w = F.mfGridElementWidthInv; j.grid_inv_h = F.mfGridElementHeightInv;
+        j.grid_cols = F.grid_cols; j.grid_rows = F.grid_rows;
+        j.nq = q.n; j.qdesc = q.descriptors; j.qvalid = q.valid; j.qu = q.u; j.qv = q.v; j.qr = q.r;
+        j.qmin_size = q.min_size; j.qmax_size = q.max_size; j.qangle = q.angle; j.qoccupies = q.occupies;
+        j.nnratio = mfNNratio; j.size_tol = F.sizeTolerance; j.inv_size_tol = F.invSizeTolerance;
+        return j;
+    }
+    int projection(const FrameGridView &F, const ProjectionQueries &q, float th, int mode, bool ori, std::vector<int> &assign) {
+        afv_proj_job j = proj_job(F, q);
+        j.th_high = th; j.mode = mode; j.check_orientation = ori;
+        assign.assign((size_t)std::max(F.N, 1), -1);
+        int32_t n = 0;
+        const int rc = afv_match_projection(ctx, &j, 1, assign.data(), &n);
+        if (rc != AFV_OK) fatal("afv_match_projection", rc, ctx);
+        assign.resize((size_t)F.N);
+        return n;
+    }
     struct Csr {
         std::vector<int32_t> id, ptr, idx;
         explicit Csr(const FeatureView &v) {
@@ -296,14 +395,23 @@ class FeatureExtractor_akaze61_hip {
         if (g.empty()) return;
         int32_t n = 0;
         const int rc = afv_akaze_extract(akz, g.ptr(), 1, g.cols, g.rows, (int)row_step(g), 0, kbuf.data(), dbuf.data(), cap, &n);
-        if (rc != AFV_OK) {
+        if (rc == AFV_ECAPACITY) {
+            // a device-side capacity was exceeded on a very busy frame: the outputs are a truncated but valid result
+            // (the reference has no such limit; losing the surplus beats terminating the SLAM process)
+            std::fprintf(stderr, "afv: afv_akaze_extract: %s (%s) - keeping %d keypoints\n", afv_strerror(rc), afv_akaze_last_error(akz), (int)n);
+            if (n < 0 || n > cap) n = 0;
+        } else if (rc != AFV_OK) {
             std::fprintf(stderr, "afv: afv_akaze_extract failed: %s (%s)\n", afv_strerror(rc), afv_akaze_last_error(akz));
             std::terminate();
         }
         keypoints.resize((size_t)n);
         static_assert(sizeof(KeyPoint) == sizeof(afv_keypoint), "KeyPoint layout");
         if (n) std::memcpy(static_cast<void *>(keypoints.data()), kbuf.data(), (size_t)n * sizeof(afv_keypoint));
+#ifdef AFV_WITH_OPENCV
+        descriptors.create(n, 61, CV_8U);
+#else
         descriptors.create(n, 61);
+#endif
         for (int i = 0; i < n; ++i) std::memcpy(descriptors.ptr(i), dbuf.data() + (size_t)i * 61, 61);
     }
     int GetKeypointOctave(const KeyPoint &kp) const { return kp.class_id; }  // Feature_akaze61.cpp:55-57
@@ -311,7 +419,13 @@ class FeatureExtractor_akaze61_hip {
     std::shared_ptr<FeatureExtractorSettings> settings;
 
   private:
-    template <class M> static size_t row_step(const M &m) { return (size_t)m.cols; }
+    template <class M> static size_t row_step(const M &m) {  // ROI / non-continuous images: the true row stride
+#ifdef AFV_WITH_OPENCV
+        return (size_t)m.step;
+#else
+        return m.step();
+#endif
+    }
     int nfeatures, cap = 0;
     afv_akaze *akz = nullptr;
     std::vector<afv_keypoint> kbuf;

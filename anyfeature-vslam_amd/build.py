@@ -11,7 +11,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libafv_hip.so")
-SOURCES = ["k_pyramid.hip", "k_fast.hip", "k_select.hip", "k_describe.hip", "k_match.hip", "k_project.hip", "k_bow.hip", "k_match_l2.hip", "afv_api.hip", "k_akaze.hip", "k_akaze_detect.hip", "k_akaze_desc.hip", "akaze_api.hip"]
+SOURCES = ["k_pyramid.hip", "k_fast.hip", "k_select.hip", "k_describe.hip", "k_match.hip", "k_project.hip", "k_bow.hip", "k_match_l2.hip",
+           "afv_api.hip", "afv_comm.hip", "k_akaze.hip", "k_akaze_detect.hip", "k_akaze_desc.hip", "akaze_api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]
 
@@ -31,8 +32,10 @@ def build(force=False, verbose=False, extra_flags=(), out=None, objdir=None):
     objdir = objdir or os.path.join(HERE, "build")
     out = out or OUT
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "afv_device.h"), os.path.join(CSRC, "brief_pattern.inc"),
-               os.path.join(HERE, "..", "include", "afv_hip.h"), os.path.abspath(__file__)]
+    import glob
+    # every header / table any translation unit may include: a stale object silently breaks the bit-exact parity tests
+    headers = (glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) +
+               glob.glob(os.path.join(HERE, "..", "include", "*.h")) + [os.path.abspath(__file__)])
     objs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
@@ -44,7 +47,7 @@ def build(force=False, verbose=False, extra_flags=(), out=None, objdir=None):
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)
     if force or _stale(out, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

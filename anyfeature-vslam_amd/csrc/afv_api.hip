@@ -3,183 +3,11 @@
 // of one context; stages host-pointer calls; enqueues the kernel pipeline
 //   resize x (nlevels-1) -> FAST+NMS+Harris -> retainBest x2 + quadtree -> IC + blur + rBRIEF.
 // No CPU fallback exists: without a HIP device afv_create fails with AFV_ENODEV.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <new>
-#include <string>
-#include <vector>
-
-#include "afv_device.h"
-
-// ---- kernel launchers (k_*.hip) ----
-extern "C" void afv_launch_resize(const uint8_t *src, int sw, int sh, int spitch, size_t sframe, uint8_t *dst, int dw, int dh,
-                                  int dpitch, size_t dframe, const short2 *xt, const short2 *yt, int frame_base, int nframes, hipStream_t stream);
-extern "C" int afv_resize_window_ok(int sw, int sh, int dw, int dh);
-extern "C" void afv_launch_fast_harris(const Geo *geo, int total_tiles, const FrameSrc *src0, const uint8_t *pyr,
-                                       uint32_t *cand_packed, float *cand_resp, int *cand_count, int frame_base, int nframes, hipStream_t stream);
-extern "C" size_t afv_select_lds_bytes(int M);
-extern "C" void afv_launch_select(const Geo *geo_dev, int nlevels, const uint32_t *cand_packed, const float *cand_resp,
-                                  const int *cand_count, uint32_t *kept_xy, float *kept_resp, uint16_t *kept_node, SelPoint *sel,
-                                  int *sel_count, int M, int frame_base, int nframes, hipStream_t stream);
-extern "C" void afv_launch_describe(const Geo *geo_dev, int nlevels, int max_sel_cap, const FrameSrc *src0, const uint8_t *pyr,
-                                    const SelPoint *sel, const int *sel_count, afv_keypoint *kps, uint8_t *desc,
-                                    int cap_per_frame, int *n_out, int *status, int frame_base, int nframes, hipStream_t stream);
-extern "C" void afv_launch_blur_level(const uint8_t *img, int w, int h, int pitch, uint8_t *out, hipStream_t stream);
-
-struct Seg { int s1, n1, s2, n2; };
-struct DevMatchJob {
-    const uint32_t *d1; const uint32_t *d2; int n1, n2, words;
-    const Seg *segs; int nseg; const int *idx1; const int *idx2;
-    const uint8_t *valid1; const uint8_t *valid2; const float *ang1; const float *ang2; int ang_stride;
-    float th, ratio; int check_ori, mode; int *out; int *nmatches;
-};
-struct DevTriJob {
-    DevMatchJob m;
-    const float *x1, *y1, *x2, *y2, *sigma2_2;
-    float F[9];
-    float ex, ey;
-    const int *row_seg;
-};
-extern "C" void afv_launch_match_bow(const DevMatchJob *jobs, int njobs, hipStream_t stream);
-extern "C" void afv_launch_match_bow_seg(const DevMatchJob *jobs, int njobs, const void *tasks, int ntasks, int *hist, uint8_t *bins,
-                                         const int *bin_off, int any_ori, hipStream_t stream);
-extern "C" void afv_launch_match_pairs2(const uint8_t *desc, const afv_keypoint *kps, const int *nset, int cap, const int *pa,
-                                        const int *pb, int npairs, float th, float ratio, int check_ori, int *match,
-                                        int *nmatches, void *topk_scratch, int pair_base, hipStream_t stream);
-extern "C" void afv_launch_match_tri(const DevTriJob *jobs, int njobs, int max_n1, hipStream_t stream);
-extern "C" void afv_launch_match_l2(const float *d1, int n1, const float *d2, int n2, int dim, const uint8_t *v1,
-                                    const uint8_t *v2, float th, float ratio, int *out, int *nmatches, hipStream_t stream);
-
-struct DevProjJob {
-    const uint32_t *fdesc; int n, words;
-    const float *x, *y, *size, *angle; const uint8_t *occupied; const float *inf;
-    float min_x, min_y, inv_w, inv_h; int cols, rows;
-    const int *cell_ptr, *cell_idx;
-    int nq; const uint32_t *qdesc; const uint8_t *qvalid;
-    const float *qu, *qv, *qr, *qmin, *qmax, *qangle; const uint8_t *qocc;
-    float th, ratio, tol, inv_tol; int check_ori, mode;
-    unsigned long long *keys; int *ncand; int *orilist; int *assign; int *nmatches;
-};
-extern "C" void afv_launch_match_projection(const DevProjJob *jobs, int njobs, int max_nq, hipStream_t stream);
-extern "C" void afv_launch_match_fuse(const DevProjJob *jobs, int njobs, int max_nq, hipStream_t stream);
-extern "C" size_t afv_match_l2_scratch_bytes(int n1, int n2, int *ntiles_out, int *cols_per_tile_out);
-extern "C" int afv_launch_match_l2_tiled(const float *d1, int n1, const float *d2, int n2, int dim, const uint8_t *v1, const uint8_t *v2,
-                                         float th, float ratio, int *out, int *nmatches, void *scratch, int ntiles, int cols_per_tile,
-                                         hipStream_t stream);
-extern "C" void afv_launch_match_init(const DevProjJob *jobs, int njobs, int max_nq, hipStream_t stream);
-
-struct DevVocab {
-    int k, L, nnodes, words;
-    const int *child_ptr, *child_idx;
-    const uint32_t *desc;
-};
-extern "C" void afv_launch_bow_transform(const DevVocab *v, const uint32_t *desc, int n, int levelsup, int *leaf_node,
-                                         int *node_at_level, hipStream_t stream);
-struct afv_vocab {
-    DevVocab dev{};
-    int desc_bytes = 32;
-    void *d_child_ptr = nullptr, *d_child_idx = nullptr, *d_desc = nullptr;
-};
-
-#define AFV_MAX_SIDE 8192
-
-struct afv_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;  // second lane for split batches (latency-bound kernels overlap VALU-bound ones)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int split_min_frames = 64;     // batches of at least this many frames / pairs are split over the two streams
-    int split_chunks = 4;          // ... into this many chunks (alternating streams); AFV_SPLIT_CHUNKS overrides (experiments)
-    afv_orb_params p{};
-    Geo geo{};          // current geometry (host copy)
-    Geo cap_geo{};      // geometry of (max_width, max_height): sizes every allocation
-    Geo *d_geo = nullptr;
-    bool geo_valid = false;
-    short2 *d_tab = nullptr;  // resize tables, all levels
-    size_t tab_off_x[AFV_MAX_LEVELS]{}, tab_off_y[AFV_MAX_LEVELS]{};
-    size_t tab_elems = 0;
-    uint8_t *d_pyr = nullptr;
-    uint32_t *d_cand_packed = nullptr, *d_kept_xy = nullptr;
-    float *d_cand_resp = nullptr, *d_kept_resp = nullptr;
-    uint16_t *d_kept_node = nullptr;
-    int *d_cand_count = nullptr, *d_sel_count = nullptr;
-    SelPoint *d_sel = nullptr;
-    int select_M = 64;
-    // staging of the host-pointer entry points
-    uint8_t *d_frames = nullptr;
-    size_t frames_pitch = 0, frames_stride = 0;
-    afv_keypoint *d_kps = nullptr;
-    uint8_t *d_desc = nullptr;
-    int *d_n = nullptr, *d_status = nullptr;
-    int stage_cap = 0;
-    std::vector<afv_keypoint> h_kps;
-    std::vector<uint8_t> h_desc;
-    std::vector<int> h_n;
-    // matcher staging (grow only)
-    uint8_t *d_match = nullptr;
-    size_t match_bytes = 0;
-    uint8_t *h_stage = nullptr;  // pinned host image of d_match (matcher staging both ways), grow-only
-    size_t stage_bytes = 0;
-    bool stage_pinned = false;
-    void *d_topk = nullptr;  // [npairs][cap] int4: top-4 (distance, column) keys per row
-    size_t topk_bytes = 0;
-    // last extraction (debug getters)
-    FrameSrc last_src{};
-    int last_nframes = 0;
-    std::string last_error;
-    // live stage timing
-    bool prof = false;
-    std::vector<hipEvent_t> prof_ev[AFV_NUM_STAGES];  // pairs (begin, end)
-    size_t prof_used[AFV_NUM_STAGES]{};
-    int prof_launches[AFV_NUM_STAGES]{};
-    float prof_ms[AFV_NUM_STAGES]{};
-    long long prof_units[AFV_NUM_STAGES]{};  // frames (pairs for the match stage) covered by the timed launches
-};
-
-struct StageTimer {  // RAII: record begin/end events around one stage on the launch stream
-    afv_ctx *c;
-    int stage;
-    hipStream_t s;
-    hipEvent_t e1 = nullptr;
-    StageTimer(afv_ctx *c_, int stage_, hipStream_t s_, int units = 0) : c(c_), stage(stage_), s(s_) {
-        if (!c->prof) return;
-        c->prof_units[stage] += units;
-        auto &v = c->prof_ev[stage];
-        size_t &u = c->prof_used[stage];
-        if (u + 2 > v.size()) {
-            hipEvent_t a = nullptr, b = nullptr;
-            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
-            v.push_back(a);
-            v.push_back(b);
-        }
-        (void)hipEventRecord(v[u], s);
-        e1 = v[u + 1];
-        u += 2;
-    }
-    ~StageTimer() {
-        if (e1) (void)hipEventRecord(e1, s);
-    }
-};
+#include "afv_runtime.h"
 
 static const char *k_errors[] = {"ok", "invalid argument", "no usable HIP device", "out of memory", "HIP runtime error",
                                  "output capacity too small", "unsupported"};
 
-#define HIPCHK(ctx, call)                                                                            \
-    do {                                                                                             \
-        hipError_t e_ = (call);                                                                      \
-        if (e_ != hipSuccess) {                                                                      \
-            (ctx)->last_error = std::string(#call) + ": " + hipGetErrorString(e_);                  \
-            return e_ == hipErrorOutOfMemory ? AFV_ENOMEM : AFV_EHIP;                                \
-        }                                                                                            \
-    } while (0)
-
-static inline int cv_round(float v) { return (int)lrintf(v); }
-static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 extern "C" void afv_default_orb_params(afv_orb_params *p) {
     if (!p) return;
@@ -258,7 +86,9 @@ static int build_geometry(const afv_orb_params &p, int w, int h, int max_batch, 
         L.quota = quota[l];
         L.cv_quota = cvq[l];
         L.cand_cap = ((L.w + 1) / 2) * ((L.h + 1) / 2);
-        L.sel_cap = L.quota + 3;
+        // DistributeOctTree returns quota .. quota+2 nodes when saturated, but the first split round is unconditional
+        // (ORBextractor.cc:283-366) and leaves up to 4 * n_ini nodes even when the quota is smaller
+        L.sel_cap = std::max(L.quota + 3, 4 * g.n_ini);
         L.sel_base = sel_base;
         sel_base += L.sel_cap;
         L.pyr_frame_stride = align_up((size_t)L.h * L.pitch + 64, 256);
@@ -313,6 +143,7 @@ static int set_geometry(afv_ctx *c, int w, int h) {
     const int rc = build_geometry(c->p, w, h, c->p.max_batch, g);
     if (rc) return rc;
     // allocation layout always follows the capacity geometry so buffers never move
+    if (g.sel_per_frame > c->cap_geo.sel_per_frame) return AFV_EINVAL;  // wider aspect ratio than the capacity geometry
     for (int l = 0; l < g.nlevels; ++l) {
         if (g.lv[l].cand_cap > c->cap_geo.lv[l].cand_cap || g.lv[l].pyr_frame_stride > c->cap_geo.lv[l].pyr_frame_stride)
             return AFV_EINVAL;
@@ -342,7 +173,7 @@ static int set_geometry(afv_ctx *c, int w, int h) {
 extern "C" int afv_max_keypoints_per_frame(const afv_ctx *c) {
     if (!c) return AFV_EINVAL;
     int s = 0;
-    for (int l = 0; l < c->cap_geo.nlevels; ++l) s += c->cap_geo.lv[l].quota + 2;
+    for (int l = 0; l < c->cap_geo.nlevels; ++l) s += std::max(c->cap_geo.lv[l].quota + 2, 4 * c->cap_geo.n_ini);
     return s;
 }
 
@@ -351,6 +182,7 @@ extern "C" void afv_destroy(afv_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    afv_table_release_all(c);
     void *ptrs[] = {c->d_geo, c->d_tab, c->d_pyr, c->d_cand_packed, c->d_kept_xy, c->d_cand_resp, c->d_kept_resp,
                     c->d_kept_node, c->d_cand_count, c->d_sel_count, c->d_sel, c->d_frames, c->d_kps, c->d_desc,
                     c->d_n, c->d_status, c->d_match, c->d_topk};
@@ -401,7 +233,6 @@ extern "C" int afv_create(int device, const afv_orb_params *params, afv_ctx **ou
     CREATE_CHK(hipSetDevice(device));
     CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CREATE_CHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-    if (const char *e = std::getenv("AFV_SPLIT_CHUNKS")) c->split_chunks = std::max(2, std::atoi(e));
     CREATE_CHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     CREATE_CHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     CREATE_CHK(hipMalloc(&c->d_geo, sizeof(Geo)));
@@ -463,6 +294,11 @@ static void profile_drain(afv_ctx *c) {
 extern "C" int afv_set_split_threshold(afv_ctx *c, int min_frames) {
     if (!c || min_frames < 2) return AFV_EINVAL;
     c->split_min_frames = min_frames;
+    return AFV_OK;
+}
+extern "C" int afv_set_split_chunks(afv_ctx *c, int chunks) {
+    if (!c || chunks < 2 || chunks > 64) return AFV_EINVAL;
+    c->split_chunks = chunks;
     return AFV_OK;
 }
 
@@ -736,110 +572,9 @@ extern "C" int afv_debug_blur_level(afv_ctx *c, int frame, int level, uint8_t *o
     return AFV_OK;
 }
 
-// the C-ABI never throws: host allocation failures inside the matcher entry points become AFV_ENOMEM
-template <class F>
-static int guarded(afv_ctx *c, F &&f) {
-    try {
-        return f();
-    } catch (const std::bad_alloc &) {
-        if (c) c->last_error = "out of host memory";
-        return AFV_ENOMEM;
-    } catch (...) {
-        if (c) c->last_error = "unexpected exception";
-        return AFV_EHIP;
-    }
-}
-
-// ---- matcher staging ----
-// Host image of the device staging buffer.  It lives in the context's pinned arena, so the one H2D copy of a call and the
-// D2H copies of its results are true async DMA transfers (no pageable bounce inside the runtime); results land at the same
-// offsets in the arena and are handed to the caller's arrays after the stream sync.
-struct HostImage {
-    afv_ctx *c;
-    size_t n = 0;
-    uint8_t *data() { return c->h_stage; }
-    size_t size() const { return n; }
-    void resize(size_t m, bool zero) {
-        if (m > c->stage_bytes) {
-            const size_t want = align_up(m + m / 2, 1 << 20);
-            uint8_t *np = nullptr;
-            bool pinned = hipHostMalloc(reinterpret_cast<void **>(&np), want, hipHostMallocDefault) == hipSuccess && np;
-            if (!pinned) {
-                (void)hipGetLastError();
-                np = static_cast<uint8_t *>(std::malloc(want));
-                if (!np) throw std::bad_alloc();
-            }
-            if (n) std::memcpy(np, c->h_stage, n);
-            if (c->h_stage) {
-                if (c->stage_pinned) (void)hipHostFree(c->h_stage);
-                else std::free(c->h_stage);
-            }
-            c->h_stage = np;
-            c->stage_bytes = want;
-            c->stage_pinned = pinned;
-        }
-        if (zero && m > n) std::memset(c->h_stage + n, 0, m - n);
-        n = m;
-    }
-};
-
-struct Blob {
-    HostImage h;
-    struct Pending { void *dst; size_t off, bytes; };
-    std::vector<Pending> pending;
-    explicit Blob(afv_ctx *c) : h{c} {}
-    size_t put(const void *src, size_t bytes, size_t align = 16) {
-        const size_t off = align_up(h.size(), align);
-        h.resize(off + bytes, src == nullptr);
-        if (src && bytes) std::memcpy(h.data() + off, src, bytes);
-        return off;
-    }
-    size_t reserve(size_t bytes, size_t align = 16) {  // zero-filled (counters, histograms, padded rows rely on it)
-        const size_t off = align_up(h.size(), align);
-        h.resize(off + bytes, true);
-        return off;
-    }
-    size_t reserve_scratch(size_t bytes, size_t align = 16) {  // device-only scratch: never copied, never filled
-        const size_t off = align_up(h.size(), align);
-        h.resize(off + bytes, false);
-        return off;
-    }
-    // queue a device -> caller copy of [off, off + bytes): DMA into the arena now, memcpy to dst in finish()
-    hipError_t fetch(void *dst, size_t off, size_t bytes, hipStream_t s) {
-        if (!bytes) return hipSuccess;
-        pending.push_back(Pending{dst, off, bytes});
-        return hipMemcpyAsync(h.data() + off, h.c->d_match + off, bytes, hipMemcpyDeviceToHost, s);
-    }
-    void finish() {
-        for (const Pending &p : pending) std::memcpy(p.dst, h.data() + p.off, p.bytes);
-        pending.clear();
-    }
-};
-
-static int ensure_match_buffer(afv_ctx *c, size_t bytes) {
-    if (bytes <= c->match_bytes) return AFV_OK;
-    if (c->d_match) (void)hipFree(c->d_match);
-    c->d_match = nullptr;
-    c->match_bytes = 0;
-    const size_t want = align_up(bytes + bytes / 2, 1 << 20);
-    HIPCHK(c, hipMalloc(&c->d_match, want));
-    c->match_bytes = want;
-    return AFV_OK;
-}
-
-// descriptors -> rows of `words` dwords (zero padded)
-static size_t put_desc(Blob &b, const uint8_t *d, int n, int desc_bytes, int words) {
-    const size_t off = b.reserve((size_t)std::max(n, 1) * words * 4);
-    for (int i = 0; i < n; ++i) {
-        uint8_t *row = b.h.data() + off + (size_t)i * words * 4;
-        std::memset(row, 0, (size_t)words * 4);
-        std::memcpy(row, d + (size_t)i * desc_bytes, (size_t)desc_bytes);
-    }
-    return off;
-}
 
 // merge-join of the two FeatureVectors (FeatureMatcher.cc:205-276): list of (range1, range2) for shared node ids
-static void shared_segments(const afv_match_job &j, std::vector<Seg> &segs) {
+void afv_shared_segments(const afv_match_job &j, std::vector<Seg> &segs) {
     segs.clear();
     if (j.nnodes1 == 0 || j.nnodes2 == 0) {
         segs.push_back(Seg{0, j.n1, 0, j.n2});
@@ -873,6 +608,21 @@ static int validate_job(const afv_match_job &j, bool need_angles) {
     if (j.nnodes1 > 0 && (!j.node_id1 || !j.seg_ptr1 || !j.seg_idx1)) return AFV_EINVAL;
     if (j.nnodes2 > 0 && (!j.node_id2 || !j.seg_ptr2 || !j.seg_idx2)) return AFV_EINVAL;
     if (need_angles && j.check_orientation && (!j.angle1 || !j.angle2)) return AFV_EINVAL;
+    // the CSR FeatureVectors size host copies and index descriptors on the device: check them here, O(n)
+    const int32_t *ptrs[2] = {j.seg_ptr1, j.seg_ptr2}, *idxs[2] = {j.seg_idx1, j.seg_idx2}, *ids[2] = {j.node_id1, j.node_id2};
+    const int nn[2] = {j.nnodes1, j.nnodes2}, nf[2] = {j.n1, j.n2};
+    for (int s = 0; s < 2; ++s) {
+        if (nn[s] == 0) continue;
+        if (ptrs[s][0] != 0) return AFV_EINVAL;
+        for (int i = 0; i < nn[s]; ++i) {
+            if (ptrs[s][i + 1] < ptrs[s][i]) return AFV_EINVAL;
+            if (i > 0 && ids[s][i] <= ids[s][i - 1]) return AFV_EINVAL;  // std::map order: strictly ascending node ids
+        }
+        const int total = ptrs[s][nn[s]];
+        if (total > nf[s]) return AFV_EINVAL;  // a feature sits in exactly one node
+        for (int i = 0; i < total; ++i)
+            if (idxs[s][i] < 0 || idxs[s][i] >= nf[s]) return AFV_EINVAL;
+    }
     return AFV_OK;
 }
 
@@ -881,7 +631,7 @@ static void stage_job(Blob &b, const afv_match_job &j, bool tri, JobOffsets &o) 
     o.d1 = put_desc(b, j.desc1, j.n1, j.desc_bytes, o.words);
     o.d2 = put_desc(b, j.desc2, j.n2, j.desc_bytes, o.words);
     std::vector<Seg> segs;
-    shared_segments(j, segs);
+    afv_shared_segments(j, segs);
     o.nseg = (int)segs.size();
     o.segs = b.put(segs.data(), segs.size() * sizeof(Seg));
     o.has_idx = j.nnodes1 > 0 && j.nnodes2 > 0;
@@ -951,7 +701,7 @@ static int afv_match_bow_impl(afv_ctx *c, const afv_match_job *jobs, int njobs, 
             const size_t pa_off = b.reserve((size_t)njobs * 4), pb_off = b.reserve((size_t)njobs * 4);
             bool any_ori = false;
             for (int i = 0; i < njobs; ++i) any_ori = any_ori || jobs[i].check_orientation;
-            const size_t kps_off = any_ori ? b.reserve((size_t)nsets * cap * sizeof(afv_keypoint)) : 0;
+            const size_t ang_off = any_ori ? b.reserve((size_t)nsets * cap * sizeof(float)) : 0;
             for (int i = 0; i < njobs; ++i) {
                 const afv_match_job &j = jobs[i];
                 if (j.n1) std::memcpy(b.h.data() + desc_off + (size_t)(2 * i) * cap * 32, j.desc1, (size_t)j.n1 * 32);
@@ -962,10 +712,9 @@ static int afv_match_bow_impl(afv_ctx *c, const afv_match_job *jobs, int njobs, 
                 reinterpret_cast<int32_t *>(b.h.data() + pa_off)[i] = 2 * i;
                 reinterpret_cast<int32_t *>(b.h.data() + pb_off)[i] = 2 * i + 1;
                 if (any_ori && j.check_orientation) {
-                    afv_keypoint *k1 = reinterpret_cast<afv_keypoint *>(b.h.data() + kps_off) + (size_t)(2 * i) * cap;
-                    afv_keypoint *k2 = k1 + cap;
-                    for (int q = 0; q < j.n1; ++q) k1[q].angle = j.angle1[q];
-                    for (int q = 0; q < j.n2; ++q) k2[q].angle = j.angle2[q];
+                    float *a1 = reinterpret_cast<float *>(b.h.data() + ang_off) + (size_t)(2 * i) * cap;
+                    std::memcpy(a1, j.angle1, (size_t)j.n1 * sizeof(float));
+                    std::memcpy(a1 + cap, j.angle2, (size_t)j.n2 * sizeof(float));
                 }
             }
             const size_t match_off = b.reserve((size_t)njobs * cap * 4), nm_off = b.reserve((size_t)njobs * 4);
@@ -980,12 +729,13 @@ static int afv_match_bow_impl(afv_ctx *c, const afv_match_job *jobs, int njobs, 
                 while (i1 < njobs && jobs[i1].th_low == jobs[i0].th_low && jobs[i1].nnratio == jobs[i0].nnratio &&
                        (jobs[i1].check_orientation != 0) == (jobs[i0].check_orientation != 0))
                     ++i1;
-                afv_launch_match_pairs2(c->d_match + desc_off, any_ori ? reinterpret_cast<const afv_keypoint *>(c->d_match + kps_off) : nullptr,
-                                        reinterpret_cast<const int *>(c->d_match + n_off), cap,
-                                        reinterpret_cast<const int *>(c->d_match + pa_off), reinterpret_cast<const int *>(c->d_match + pb_off),
-                                        i1 - i0, jobs[i0].th_low, jobs[i0].nnratio, jobs[i0].check_orientation != 0,
-                                        reinterpret_cast<int *>(c->d_match + match_off), reinterpret_cast<int *>(c->d_match + nm_off),
-                                        c->d_match + topk_off, i0, c->stream);
+                const float *angp = any_ori ? reinterpret_cast<const float *>(c->d_match + ang_off) : nullptr;
+                const int *np_ = reinterpret_cast<const int *>(c->d_match + n_off);
+                const int *pa_ = reinterpret_cast<const int *>(c->d_match + pa_off), *pb_ = reinterpret_cast<const int *>(c->d_match + pb_off);
+                afv_launch_match_topk(c->d_match + desc_off, np_, cap, pa_, pb_, i1 - i0, c->d_match + topk_off, i0, c->stream);
+                afv_launch_match_resolve(c->d_match + desc_off, angp, 1, np_, cap, pa_, pb_, i1 - i0, jobs[i0].th_low, jobs[i0].nnratio,
+                                         jobs[i0].check_orientation != 0, reinterpret_cast<int *>(c->d_match + match_off),
+                                         reinterpret_cast<int *>(c->d_match + nm_off), c->d_match + topk_off, i0, c->stream);
                 i0 = i1;
             }
             HIPCHK(c, hipGetLastError());
@@ -1083,7 +833,7 @@ static int afv_match_triangulation_impl(afv_ctx *c, const afv_tri_job *jobs, int
         geo_off[5 * i + 4] = b.put(t.sigma2_2, (size_t)t.bow.n2 * 4);
         // feature -> shared node (a feature sits in exactly one node of its FeatureVector)
         std::vector<Seg> segs;
-        shared_segments(t.bow, segs);
+        afv_shared_segments(t.bow, segs);
         std::vector<int> row_seg((size_t)std::max(t.bow.n1, 1), -1);
         const bool has_idx = t.bow.nnodes1 > 0 && t.bow.nnodes2 > 0;
         for (size_t sgi = 0; sgi < segs.size(); ++sgi)
@@ -1132,6 +882,52 @@ extern "C" int afv_match_triangulation(afv_ctx *c, const afv_tri_job *jobs, int 
     return guarded(c, [&] { return afv_match_triangulation_impl(c, jobs, njobs, match12, nmatches); });
 }
 
+// core of the device-resident brute-force batch; angles as a strided float array (see afv_launch_match_resolve)
+int afv_match_pairs_core(afv_ctx *c, const uint8_t *d_desc, const float *d_ang, int ang_stride, const int32_t *d_n, int cap,
+                         const int32_t *d_pair_a, const int32_t *d_pair_b, int npairs, float th_low, float nnratio,
+                         int check_orientation, int32_t *d_match, int32_t *d_nmatches, hipStream_t s) {
+    const size_t need = (size_t)npairs * cap * 16;
+    if (need > c->topk_bytes) {  // grow-only scratch (first call / larger batch): implies a device sync
+        HIPCHK(c, hipDeviceSynchronize());
+        if (c->d_topk) (void)hipFree(c->d_topk);
+        c->d_topk = nullptr;
+        c->topk_bytes = 0;
+        HIPCHK(c, hipMalloc(&c->d_topk, need));
+        c->topk_bytes = need;
+    }
+    if (npairs >= c->split_min_frames) {
+        // grid.y carries the pair index (<= 65535 per launch) and the two streams overlap the latency-bound ordered
+        // resolve of one chunk with the VALU-bound top-k of the other
+        HIPCHK(c, hipEventRecord(c->ev_fork, s));
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        const int K = std::max(2, (npairs + 32767) / 32768 * 2);
+        for (int k = 0; k < K; ++k) {
+            const int b0 = (int)((long)npairs * k / K), e0 = (int)((long)npairs * (k + 1) / K);
+            if (e0 <= b0) continue;
+            hipStream_t ks = (k & 1) ? c->stream2 : s;
+            {
+                StageTimer t_(c, AFV_STAGE_MATCH, ks, e0 - b0);
+                afv_launch_match_topk(d_desc, d_n, cap, d_pair_a, d_pair_b, e0 - b0, c->d_topk, b0, ks);
+            }
+            StageTimer t_(c, AFV_STAGE_MATCH_RESOLVE, ks, e0 - b0);
+            afv_launch_match_resolve(d_desc, d_ang, ang_stride, d_n, cap, d_pair_a, d_pair_b, e0 - b0, th_low, nnratio, check_orientation,
+                                     d_match, d_nmatches, c->d_topk, b0, ks);
+        }
+        HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0));
+    } else {
+        {
+            StageTimer t_(c, AFV_STAGE_MATCH, s, npairs);
+            afv_launch_match_topk(d_desc, d_n, cap, d_pair_a, d_pair_b, npairs, c->d_topk, 0, s);
+        }
+        StageTimer t_(c, AFV_STAGE_MATCH_RESOLVE, s, npairs);
+        afv_launch_match_resolve(d_desc, d_ang, ang_stride, d_n, cap, d_pair_a, d_pair_b, npairs, th_low, nnratio, check_orientation, d_match,
+                                 d_nmatches, c->d_topk, 0, s);
+    }
+    HIPCHK(c, hipGetLastError());
+    return AFV_OK;
+}
+
 extern "C" int afv_match_bruteforce_pairs_device(afv_ctx *c, const uint8_t *d_desc, const afv_keypoint *d_kps,
                                                  const int32_t *d_n, int nsets, int cap, const int32_t *d_pair_a,
                                                  const int32_t *d_pair_b, int npairs, float th_low, float nnratio,
@@ -1140,41 +936,9 @@ extern "C" int afv_match_bruteforce_pairs_device(afv_ctx *c, const uint8_t *d_de
     if (nsets < 1 || npairs < 1 || cap < 1 || cap > 4096) return AFV_EINVAL;  // PAIR_MAX_SIDE in k_match.hip
     if (check_orientation && !d_kps) return AFV_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
-    {
-        hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-        const size_t need = (size_t)npairs * cap * 16;
-        if (need > c->topk_bytes) {  // grow-only scratch (first call / larger batch): implies a device sync
-            HIPCHK(c, hipDeviceSynchronize());
-            if (c->d_topk) (void)hipFree(c->d_topk);
-            c->d_topk = nullptr;
-            c->topk_bytes = 0;
-            HIPCHK(c, hipMalloc(&c->d_topk, need));
-            c->topk_bytes = need;
-        }
-        if (npairs >= c->split_min_frames) {
-            const int h = npairs / 2;
-            HIPCHK(c, hipEventRecord(c->ev_fork, s));
-            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-            {
-                StageTimer t_(c, AFV_STAGE_MATCH, s, h);
-                afv_launch_match_pairs2(d_desc, d_kps, d_n, cap, d_pair_a, d_pair_b, h, th_low, nnratio, check_orientation, d_match,
-                                        d_nmatches, c->d_topk, 0, s);
-            }
-            {
-                StageTimer t_(c, AFV_STAGE_MATCH, c->stream2, npairs - h);
-                afv_launch_match_pairs2(d_desc, d_kps, d_n, cap, d_pair_a, d_pair_b, npairs - h, th_low, nnratio, check_orientation,
-                                        d_match, d_nmatches, c->d_topk, h, c->stream2);
-            }
-            HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
-            HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0));
-        } else {
-            StageTimer t_(c, AFV_STAGE_MATCH, s, npairs);
-            afv_launch_match_pairs2(d_desc, d_kps, d_n, cap, d_pair_a, d_pair_b, npairs, th_low, nnratio, check_orientation, d_match,
-                                    d_nmatches, c->d_topk, 0, s);
-        }
-    }
-    HIPCHK(c, hipGetLastError());
-    return AFV_OK;
+    return afv_match_pairs_core(c, d_desc, d_kps ? &d_kps->angle : nullptr, (int)(sizeof(afv_keypoint) / sizeof(float)), d_n, cap,
+                                d_pair_a, d_pair_b, npairs, th_low, nnratio, check_orientation, d_match, d_nmatches,
+                                stream ? (hipStream_t)stream : c->stream);
 }
 
 static int afv_match_l2_impl(afv_ctx *c, const float *desc1, int n1, const float *desc2, int n2, int dim, const uint8_t *valid1,
@@ -1368,8 +1132,23 @@ extern "C" int afv_vocab_create(afv_ctx *c, int k, int L, int nnodes, const int3
     if (child_ptr[0] != 0 || nchild < 0 || nchild > nnodes) return AFV_EINVAL;
     for (int i = 0; i < nnodes; ++i)
         if (child_ptr[i + 1] < child_ptr[i]) return AFV_EINVAL;
-    for (int i = 0; i < nchild; ++i)
-        if (child_idx[i] <= 0 || child_idx[i] >= nnodes) return AFV_EINVAL;
+    {   // a tree: every non-root node is the child of exactly one node (no duplicates => no cycles reachable from the
+        // root, so the descent of k_bow_transform terminates)
+        std::vector<uint8_t> seen((size_t)nnodes, 0);
+        for (int i = 0; i < nchild; ++i) {
+            if (child_idx[i] <= 0 || child_idx[i] >= nnodes || seen[child_idx[i]]) return AFV_EINVAL;
+            seen[child_idx[i]] = 1;
+        }
+        // ... and no node is its own ancestor: walk the levels from the root, at most L of them may have children
+        std::vector<int> frontier{0}, next;
+        for (int depth = 0; !frontier.empty(); ++depth) {
+            next.clear();
+            for (int nd : frontier)
+                for (int q = child_ptr[nd]; q < child_ptr[nd + 1]; ++q) next.push_back(child_idx[q]);
+            if (!next.empty() && depth >= L) return AFV_EINVAL;
+            frontier.swap(next);
+        }
+    }
     HIPCHK(c, hipSetDevice(c->device));
     afv_vocab *v = new (std::nothrow) afv_vocab();
     if (!v) return AFV_ENOMEM;

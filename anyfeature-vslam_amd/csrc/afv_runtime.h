@@ -1,0 +1,288 @@
+// afv_runtime.h — host-side internals shared by the translation units behind the C-ABI (afv_api.hip, afv_comm.hip):
+// the context, the pinned staging arena (Blob) and the kernel launcher prototypes.  Not part of the public interface.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "afv_device.h"
+
+// ---- kernel launchers (k_*.hip) ----
+extern "C" void afv_launch_resize(const uint8_t *src, int sw, int sh, int spitch, size_t sframe, uint8_t *dst, int dw, int dh,
+                                  int dpitch, size_t dframe, const short2 *xt, const short2 *yt, int frame_base, int nframes, hipStream_t stream);
+extern "C" int afv_resize_window_ok(int sw, int sh, int dw, int dh);
+extern "C" void afv_launch_fast_harris(const Geo *geo, int total_tiles, const FrameSrc *src0, const uint8_t *pyr,
+                                       uint32_t *cand_packed, float *cand_resp, int *cand_count, int frame_base, int nframes, hipStream_t stream);
+extern "C" size_t afv_select_lds_bytes(int M);
+extern "C" void afv_launch_select(const Geo *geo_dev, int nlevels, const uint32_t *cand_packed, const float *cand_resp,
+                                  const int *cand_count, uint32_t *kept_xy, float *kept_resp, uint16_t *kept_node, SelPoint *sel,
+                                  int *sel_count, int M, int frame_base, int nframes, hipStream_t stream);
+extern "C" void afv_launch_describe(const Geo *geo_dev, int nlevels, int max_sel_cap, const FrameSrc *src0, const uint8_t *pyr,
+                                    const SelPoint *sel, const int *sel_count, afv_keypoint *kps, uint8_t *desc,
+                                    int cap_per_frame, int *n_out, int *status, int frame_base, int nframes, hipStream_t stream);
+extern "C" void afv_launch_blur_level(const uint8_t *img, int w, int h, int pitch, uint8_t *out, hipStream_t stream);
+
+struct Seg { int s1, n1, s2, n2; };
+struct DevMatchJob {
+    const uint32_t *d1; const uint32_t *d2; int n1, n2, words;
+    const Seg *segs; int nseg; const int *idx1; const int *idx2;
+    const uint8_t *valid1; const uint8_t *valid2; const float *ang1; const float *ang2; int ang_stride;
+    float th, ratio; int check_ori, mode; int *out; int *nmatches;
+};
+struct DevTriJob {
+    DevMatchJob m;
+    const float *x1, *y1, *x2, *y2, *sigma2_2;
+    float F[9];
+    float ex, ey;
+    const int *row_seg;
+};
+extern "C" void afv_launch_match_bow(const DevMatchJob *jobs, int njobs, hipStream_t stream);
+extern "C" void afv_launch_match_bow_seg(const DevMatchJob *jobs, int njobs, const void *tasks, int ntasks, int *hist, uint8_t *bins,
+                                         const int *bin_off, int any_ori, hipStream_t stream);
+extern "C" void afv_launch_match_topk(const uint8_t *desc, const int *nset, int cap, const int *pa, const int *pb, int npairs,
+                                      void *topk_scratch, int pair_base, hipStream_t stream);
+extern "C" void afv_launch_match_resolve(const uint8_t *desc, const float *ang, int ang_stride, const int *nset, int cap, const int *pa,
+                                         const int *pb, int npairs, float th, float ratio, int check_ori, int *match, int *nmatches,
+                                         const void *topk_scratch, int pair_base, hipStream_t stream);
+extern "C" void afv_launch_match_tri(const DevTriJob *jobs, int njobs, int max_n1, hipStream_t stream);
+extern "C" void afv_launch_match_l2(const float *d1, int n1, const float *d2, int n2, int dim, const uint8_t *v1,
+                                    const uint8_t *v2, float th, float ratio, int *out, int *nmatches, hipStream_t stream);
+
+struct DevProjJob {
+    const uint32_t *fdesc; int n, words;
+    const float *x, *y, *size, *angle; const uint8_t *occupied; const float *inf;
+    float min_x, min_y, inv_w, inv_h; int cols, rows;
+    const int *cell_ptr, *cell_idx;
+    int nq; const uint32_t *qdesc; const uint8_t *qvalid;
+    const float *qu, *qv, *qr, *qmin, *qmax, *qangle; const uint8_t *qocc;
+    float th, ratio, tol, inv_tol; int check_ori, mode;
+    unsigned long long *keys; int *ncand; int *orilist; int *assign; int *nmatches;
+};
+extern "C" void afv_launch_match_projection(const DevProjJob *jobs, int njobs, int max_nq, hipStream_t stream);
+extern "C" void afv_launch_match_fuse(const DevProjJob *jobs, int njobs, int max_nq, hipStream_t stream);
+extern "C" size_t afv_match_l2_scratch_bytes(int n1, int n2, int *ntiles_out, int *cols_per_tile_out);
+extern "C" int afv_launch_match_l2_tiled(const float *d1, int n1, const float *d2, int n2, int dim, const uint8_t *v1, const uint8_t *v2,
+                                         float th, float ratio, int *out, int *nmatches, void *scratch, int ntiles, int cols_per_tile,
+                                         hipStream_t stream);
+extern "C" void afv_launch_match_init(const DevProjJob *jobs, int njobs, int max_nq, hipStream_t stream);
+
+struct DevVocab {
+    int k, L, nnodes, words;
+    const int *child_ptr, *child_idx;
+    const uint32_t *desc;
+};
+extern "C" void afv_launch_bow_transform(const DevVocab *v, const uint32_t *desc, int n, int levelsup, int *leaf_node,
+                                         int *node_at_level, hipStream_t stream);
+struct afv_vocab {
+    DevVocab dev{};
+    int desc_bytes = 32;
+    void *d_child_ptr = nullptr, *d_child_idx = nullptr, *d_desc = nullptr;
+};
+
+#define AFV_MAX_SIDE 8192
+
+struct afv_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // second lane for split batches (latency-bound kernels overlap VALU-bound ones)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int split_min_frames = 64;     // batches of at least this many frames / pairs are split over the two streams
+    int split_chunks = 4;          // ... into this many chunks (alternating streams); afv_set_split_chunks
+    afv_orb_params p{};
+    Geo geo{};          // current geometry (host copy)
+    Geo cap_geo{};      // geometry of (max_width, max_height): sizes every allocation
+    Geo *d_geo = nullptr;
+    bool geo_valid = false;
+    short2 *d_tab = nullptr;  // resize tables, all levels
+    size_t tab_off_x[AFV_MAX_LEVELS]{}, tab_off_y[AFV_MAX_LEVELS]{};
+    size_t tab_elems = 0;
+    uint8_t *d_pyr = nullptr;
+    uint32_t *d_cand_packed = nullptr, *d_kept_xy = nullptr;
+    float *d_cand_resp = nullptr, *d_kept_resp = nullptr;
+    uint16_t *d_kept_node = nullptr;
+    int *d_cand_count = nullptr, *d_sel_count = nullptr;
+    SelPoint *d_sel = nullptr;
+    int select_M = 64;
+    // staging of the host-pointer entry points
+    uint8_t *d_frames = nullptr;
+    size_t frames_pitch = 0, frames_stride = 0;
+    afv_keypoint *d_kps = nullptr;
+    uint8_t *d_desc = nullptr;
+    int *d_n = nullptr, *d_status = nullptr;
+    int stage_cap = 0;
+    std::vector<afv_keypoint> h_kps;
+    std::vector<uint8_t> h_desc;
+    std::vector<int> h_n;
+    // matcher staging (grow only)
+    uint8_t *d_match = nullptr;
+    size_t match_bytes = 0;
+    uint8_t *h_stage = nullptr;  // pinned host image of d_match (matcher staging both ways), grow-only
+    size_t stage_bytes = 0;
+    bool stage_pinned = false;
+    void *d_topk = nullptr;  // [npairs][cap] int4: top-4 (distance, column) keys per row
+    size_t topk_bytes = 0;
+    // last extraction (debug getters)
+    FrameSrc last_src{};
+    int last_nframes = 0;
+    std::string last_error;
+    // live stage timing
+    bool prof = false;
+    std::vector<hipEvent_t> prof_ev[AFV_NUM_STAGES];  // pairs (begin, end)
+    size_t prof_used[AFV_NUM_STAGES]{};
+    int prof_launches[AFV_NUM_STAGES]{};
+    float prof_ms[AFV_NUM_STAGES]{};
+    long long prof_units[AFV_NUM_STAGES]{};  // frames (pairs for the match stage) covered by the timed launches
+};
+
+struct StageTimer {  // RAII: record begin/end events around one stage on the launch stream
+    afv_ctx *c;
+    int stage;
+    hipStream_t s;
+    hipEvent_t e1 = nullptr;
+    StageTimer(afv_ctx *c_, int stage_, hipStream_t s_, int units = 0) : c(c_), stage(stage_), s(s_) {
+        if (!c->prof) return;
+        c->prof_units[stage] += units;
+        auto &v = c->prof_ev[stage];
+        size_t &u = c->prof_used[stage];
+        if (u + 2 > v.size()) {
+            hipEvent_t a = nullptr, b = nullptr;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            v.push_back(a);
+            v.push_back(b);
+        }
+        (void)hipEventRecord(v[u], s);
+        e1 = v[u + 1];
+        u += 2;
+    }
+    ~StageTimer() {
+        if (e1) (void)hipEventRecord(e1, s);
+    }
+};
+
+
+#define HIPCHK(ctx, call)                                                                            \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            (ctx)->last_error = std::string(#call) + ": " + hipGetErrorString(e_);                  \
+            return e_ == hipErrorOutOfMemory ? AFV_ENOMEM : AFV_EHIP;                                \
+        }                                                                                            \
+    } while (0)
+
+static inline int cv_round(float v) { return (int)lrintf(v); }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+// the C-ABI never throws: host allocation failures inside the matcher entry points become AFV_ENOMEM
+template <class F>
+static inline int guarded(afv_ctx *c, F &&f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        if (c) c->last_error = "out of host memory";
+        return AFV_ENOMEM;
+    } catch (...) {
+        if (c) c->last_error = "unexpected exception";
+        return AFV_EHIP;
+    }
+}
+
+// ---- matcher staging ----
+// Host image of the device staging buffer.  It lives in the context's pinned arena, so the one H2D copy of a call and the
+// D2H copies of its results are true async DMA transfers (no pageable bounce inside the runtime); results land at the same
+// offsets in the arena and are handed to the caller's arrays after the stream sync.
+struct HostImage {
+    afv_ctx *c;
+    size_t n = 0;
+    uint8_t *data() { return c->h_stage; }
+    size_t size() const { return n; }
+    void resize(size_t m, bool zero) {
+        if (m > c->stage_bytes) {
+            const size_t want = align_up(m + m / 2, 1 << 20);
+            uint8_t *np = nullptr;
+            bool pinned = hipHostMalloc(reinterpret_cast<void **>(&np), want, hipHostMallocDefault) == hipSuccess && np;
+            if (!pinned) {
+                (void)hipGetLastError();
+                np = static_cast<uint8_t *>(std::malloc(want));
+                if (!np) throw std::bad_alloc();
+            }
+            if (n) std::memcpy(np, c->h_stage, n);
+            if (c->h_stage) {
+                if (c->stage_pinned) (void)hipHostFree(c->h_stage);
+                else std::free(c->h_stage);
+            }
+            c->h_stage = np;
+            c->stage_bytes = want;
+            c->stage_pinned = pinned;
+        }
+        if (zero && m > n) std::memset(c->h_stage + n, 0, m - n);
+        n = m;
+    }
+};
+
+struct Blob {
+    HostImage h;
+    struct Pending { void *dst; size_t off, bytes; };
+    std::vector<Pending> pending;
+    explicit Blob(afv_ctx *c) : h{c} {}
+    size_t put(const void *src, size_t bytes, size_t align = 16) {
+        const size_t off = align_up(h.size(), align);
+        h.resize(off + bytes, src == nullptr);
+        if (src && bytes) std::memcpy(h.data() + off, src, bytes);
+        return off;
+    }
+    size_t reserve(size_t bytes, size_t align = 16) {  // zero-filled (counters, histograms, padded rows rely on it)
+        const size_t off = align_up(h.size(), align);
+        h.resize(off + bytes, true);
+        return off;
+    }
+    size_t reserve_scratch(size_t bytes, size_t align = 16) {  // device-only scratch: never copied, never filled
+        const size_t off = align_up(h.size(), align);
+        h.resize(off + bytes, false);
+        return off;
+    }
+    // queue a device -> caller copy of [off, off + bytes): DMA into the arena now, memcpy to dst in finish()
+    hipError_t fetch(void *dst, size_t off, size_t bytes, hipStream_t s) {
+        if (!bytes) return hipSuccess;
+        pending.push_back(Pending{dst, off, bytes});
+        return hipMemcpyAsync(h.data() + off, h.c->d_match + off, bytes, hipMemcpyDeviceToHost, s);
+    }
+    void finish() {
+        for (const Pending &p : pending) std::memcpy(p.dst, h.data() + p.off, p.bytes);
+        pending.clear();
+    }
+};
+
+static inline int ensure_match_buffer(afv_ctx *c, size_t bytes) {
+    if (bytes <= c->match_bytes) return AFV_OK;
+    if (c->d_match) (void)hipFree(c->d_match);
+    c->d_match = nullptr;
+    c->match_bytes = 0;
+    const size_t want = align_up(bytes + bytes / 2, 1 << 20);
+    HIPCHK(c, hipMalloc(&c->d_match, want));
+    c->match_bytes = want;
+    return AFV_OK;
+}
+
+// descriptors -> rows of `words` dwords (zero padded)
+static inline size_t put_desc(Blob &b, const uint8_t *d, int n, int desc_bytes, int words) {
+    const size_t off = b.reserve((size_t)std::max(n, 1) * words * 4);
+    for (int i = 0; i < n; ++i) {
+        uint8_t *row = b.h.data() + off + (size_t)i * words * 4;
+        std::memset(row, 0, (size_t)words * 4);
+        std::memcpy(row, d + (size_t)i * desc_bytes, (size_t)desc_bytes);
+    }
+    return off;
+}
+
+// ---- shared between afv_api.hip and afv_comm.hip ----
+int afv_match_pairs_core(afv_ctx *c, const uint8_t *d_desc, const float *d_ang, int ang_stride, const int32_t *d_n, int cap,
+                         const int32_t *d_pair_a, const int32_t *d_pair_b, int npairs, float th_low, float nnratio,
+                         int check_orientation, int32_t *d_match, int32_t *d_nmatches, hipStream_t s);
+void afv_shared_segments(const afv_match_job &j, std::vector<Seg> &segs);
+void afv_table_release_all(afv_ctx *c);  // afv_destroy: tables / communicators still alive die with their context

@@ -345,7 +345,7 @@ __global__ __launch_bounds__(MT) void k_match_topk(const uint8_t *__restrict__ d
 #define PAIR_MAX_SIDE 4096  // rows / columns per set in the pairs path (LDS tables below)
 #define PAIR_LDS_DESC 1280  // side-2 sets up to this size are copied to LDS (40 KB) so that rescans never leave the CU
 
-__global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict__ desc, const afv_keypoint *__restrict__ kps,
+__global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict__ desc, const float *__restrict__ ang, int ang_stride,
                                                       const int *__restrict__ nset, int cap, const int *__restrict__ pair_a,
                                                       const int *__restrict__ pair_b, const int4 *__restrict__ topk, float th,
                                                       float ratio, int check_ori, int *__restrict__ match,
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
         for (int i = tid; i < n1; i += MT) {
             const int c = out[i];
             if (c >= 0) {
-                const int bin = rotation_bin(kps[(size_t)a * cap + i].angle, kps[(size_t)b * cap + c].angle);
+                const int bin = rotation_bin(ang[((size_t)a * cap + i) * ang_stride], ang[((size_t)b * cap + c) * ang_stride]);
                 s_bin[i] = (uint8_t)bin;
                 atomicAdd(&s_hist[bin], 1);
             }
@@ -689,12 +689,19 @@ extern "C" void afv_launch_match_bow_seg(const DevMatchJob *jobs, int njobs, con
                        reinterpret_cast<const SegTask *>(tasks), ntasks, hist, bins, bin_off);
     if (any_ori) hipLaunchKernelGGL(k_match_bow_finish, dim3(njobs), dim3(MT), 0, stream, jobs, hist, bins, bin_off);
 }
-extern "C" void afv_launch_match_pairs2(const uint8_t *desc, const afv_keypoint *kps, const int *nset, int cap, const int *pa,
-                                        const int *pb, int npairs, float th, float ratio, int check_ori, int *match,
-                                        int *nmatches, void *topk_scratch, int pair_base, hipStream_t stream) {
+// phase 1 (VALU-bound: the 8 xor + 8 v_bcnt per descriptor pair) and phase 2 (latency-bound ordered resolve) are launched
+// separately so that the runtime can time them apart.
+extern "C" void afv_launch_match_topk(const uint8_t *desc, const int *nset, int cap, const int *pa, const int *pb, int npairs,
+                                      void *topk_scratch, int pair_base, hipStream_t stream) {
     int4 *topk = reinterpret_cast<int4 *>(topk_scratch);
     hipLaunchKernelGGL(k_match_topk, dim3((cap + MT - 1) / MT, npairs), dim3(MT), 0, stream, desc, nset, cap, pa, pb, topk, pair_base);
-    hipLaunchKernelGGL(k_match_resolve, dim3(npairs), dim3(MT), 0, stream, desc, kps, nset, cap, pa, pb, topk, th, ratio,
+}
+// ang: keypoint angles in degrees, element (set, i) at ang[(set * cap + i) * ang_stride] (stride 7 = afv_keypoint::angle)
+extern "C" void afv_launch_match_resolve(const uint8_t *desc, const float *ang, int ang_stride, const int *nset, int cap, const int *pa,
+                                         const int *pb, int npairs, float th, float ratio, int check_ori, int *match, int *nmatches,
+                                         const void *topk_scratch, int pair_base, hipStream_t stream) {
+    const int4 *topk = reinterpret_cast<const int4 *>(topk_scratch);
+    hipLaunchKernelGGL(k_match_resolve, dim3(npairs), dim3(MT), 0, stream, desc, ang, ang_stride, nset, cap, pa, pb, topk, th, ratio,
                        check_ori, match, nmatches, pair_base);
 }
 extern "C" void afv_launch_match_tri(const DevTriJob *jobs, int njobs, int max_n1, hipStream_t stream) {

@@ -141,7 +141,7 @@ class Context:
             n_out = torch.empty((B,), dtype=torch.int32, device=dev)
         if status is None:
             status = torch.empty((1,), dtype=torch.int32, device=dev)
-        s = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        s = _lib.torch_stream_handle(dev, stream)
         rc = self.lib.afv_orb_extract_batch_device(self.handle, frames.data_ptr(), B, W, H, frames.stride(1),
                                                    frames.stride(0), kps.data_ptr(), desc.data_ptr(), cap,
                                                    n_out.data_ptr(), status.data_ptr(), s)
@@ -168,6 +168,14 @@ class Context:
 
     def set_split_threshold(self, min_frames):
         self.check(self.lib.afv_set_split_threshold(self.handle, int(min_frames)))
+
+    def set_split_chunks(self, chunks):
+        self.check(self.lib.afv_set_split_chunks(self.handle, int(chunks)))
+
+    @property
+    def stream(self):
+        """the context's own hipStream_t (what a NULL `stream` argument selects)"""
+        return self.lib.afv_stream(self.handle)
 
     # ---- stage introspection (parity tests) ----
     def debug_level(self, frame, level):

@@ -307,7 +307,7 @@ class FeatureMatcher:
             match = torch.empty((npairs, cap), dtype=torch.int32, device=desc.device)
         if nmatches is None:
             nmatches = torch.empty((npairs,), dtype=torch.int32, device=desc.device)
-        s = stream if stream is not None else torch.cuda.current_stream(desc.device).cuda_stream
+        s = _lib.torch_stream_handle(desc.device, stream)
         co = self.mbCheckOrientation if check_orientation is None else check_orientation
         rc = self.lib.afv_match_bruteforce_pairs_device(
             self.ctx.handle, desc.data_ptr(), kps.data_ptr() if kps is not None else None, n.data_ptr(), nsets, cap,

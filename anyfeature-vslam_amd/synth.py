@@ -70,7 +70,7 @@ def random_descriptors(seed, n, nbytes=32):
     return lcg_bytes(seed, n * nbytes).reshape(n, nbytes)
 
 
-def perturbed_descriptors(desc, seed, flip_prob_256=26, replace_frac_256=77):
+def perturbed_descriptors(desc, seed, flip_prob_256=26, replace_frac_256=77, return_mask=False):
     """keyframe k+1 from keyframe k: each bit flipped w.p. flip_prob_256/256 (~0.1), and rows replaced
     w.p. replace_frac_256/256 (~0.3) (config #4 generator)."""
     n, nb = desc.shape
@@ -83,4 +83,28 @@ def perturbed_descriptors(desc, seed, flip_prob_256=26, replace_frac_256=77):
     repl = st[n * nb * 8:n * nb * 8 + n] < replace_frac_256
     fresh = st[n * nb * 8 + n:].reshape(n, nb)
     out[repl] = fresh[repl]
-    return out
+    return (out, repl) if return_mask else out
+
+
+def keyframe_table(nkeyframes, cap=1000, seed=7):
+    """config #4 table: K keyframes x cap x 32-byte descriptors, keyframe k+1 = keyframe k with each bit
+    flipped w.p. ~0.1 and ~30 % of the rows replaced.  Angles (degrees) follow the keyframes: a common rotation of
+    -10..10 degrees per step plus -1..1 degree of per-feature jitter; replaced rows get a fresh angle.
+    Returns (table uint8 [K, cap, 32], angles float32 [K, cap], counts int32 [K])."""
+    table = np.zeros((nkeyframes, cap, 32), np.uint8)
+    angles = np.zeros((nkeyframes, cap), np.float32)
+    d = random_descriptors(seed, cap)
+    a = (lcg_states(seed + 1, cap) >> np.uint32(8)) % np.uint32(36000)
+    a = a.astype(np.int64)                                    # centi-degrees: exact integer bookkeeping
+    for k in range(nkeyframes):
+        table[k] = d
+        angles[k] = (a.astype(np.float32) / np.float32(100.0))
+        nd, replaced = perturbed_descriptors(d, 100003 + 17 * k + seed, return_mask=True)
+        st = lcg_states(200003 + 31 * k + seed, 2 * cap + 1)
+        rot = int((st[0] >> np.uint32(8)) % np.uint32(2001)) - 1000
+        jit = ((st[1:cap + 1] >> np.uint32(8)) % np.uint32(201)).astype(np.int64) - 100
+        fresh = ((st[cap + 1:] >> np.uint32(8)) % np.uint32(36000)).astype(np.int64)
+        a = (a + rot + jit) % 36000
+        a = np.where(replaced, fresh, a)
+        d = nd
+    return table, angles, np.full(nkeyframes, cap, np.int32)

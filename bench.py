@@ -201,6 +201,237 @@ def akaze_main(args):
     print(json.dumps(out))
 
 
+
+# ---------------------------------------------------------------------------------------------------------------------
+# --workload pairs10k (BASELINE.json configs[3]: 10 000 keyframe-pair Hamming match jobs over a K = 1000 keyframe table,
+# sharded over the GPUs of one node, ONE RCCL broadcast of the table) — the path's only exchange step
+# ---------------------------------------------------------------------------------------------------------------------
+PAIR_ALG_BYTES = 2 * 32000 + 4000     # two 1000 x 32 B descriptor sets read + 1000 x 4 B matches written per job
+
+
+def pairs_cpu_baseline(table, angles, counts, pa, pb, budget_s=12.0):
+    """oracle SearchByBoW(KF,KF) brute force (FeatureMatcher.cc:561-660), one pinned thread, on the first jobs of the list"""
+    import oracle
+    try:
+        oracle.lib(oracle.build(native=True))
+    except Exception:
+        oracle.lib()
+    try:
+        os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})
+    except Exception:
+        pass
+
+    def one(i):
+        a, b = int(pa[i]), int(pb[i])
+        return oracle.search_by_bow_kf_kf(table[a, :counts[a]], table[b, :counts[b]], angle1=angles[a, :counts[a]], angle2=angles[b, :counts[b]],
+                                          th_low=75.0, nnratio=0.75, check_orientation=True)[1]
+    one(0)
+    reps = []
+    per_rep = None
+    for _ in range(5):                      # BASELINE.md section 3: warm-up + >= 5 repetitions, median
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            one(n % len(pa))
+            n += 1
+            if per_rep is not None and n >= per_rep:
+                break
+            if per_rep is None and time.perf_counter() - t0 > budget_s / 5:
+                per_rep = n
+                break
+        reps.append(n / (time.perf_counter() - t0))
+    reps.sort()
+    return {"value": reps[len(reps) // 2], "unit": "jobs/s", "cores": 1, "kind": "port", "min": reps[0], "max": reps[-1],
+            "sample": "median of 5 repetitions of the first %d jobs (1000 x 1000 brute-force SearchByBoW(KF,KF) with orientation check) through "
+                      "oracle/afvo.c, 1 pinned thread, %d logical cores on the host" % (per_rep, os.cpu_count() or 0)}
+
+
+def pairs_main(args):
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    if args.single_device:
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")
+    afv = importlib.import_module("anyfeature-vslam_amd")
+    tbl_mod = importlib.import_module("anyfeature-vslam_amd.table")
+    dmod = importlib.import_module("anyfeature-vslam_amd.dist")
+    K, cap, njobs = args.keyframes, 1000, args.jobs
+    TH, RATIO = 75.0, 0.75                                  # LoopClosing.cc:255: FeatureMatcher matcher(0.75, true); TH_LOW = matchingTh
+    ctx = afv.Context(max_batch=1, device=local)
+    table = tbl_mod.DescriptorTable(ctx, K, cap)
+    host = None
+    if rank == 0:                                           # the table exists on ONE rank before the exchange step
+        host = afv.synth.keyframe_table(K, cap)
+        table.upload(*host)
+    d_desc, d_ang, d_n = table.device_views()
+    torch.cuda.synchronize(dev)
+
+    # ---- the exchange step: RCCL broadcast through the C-ABI communicator (afv_comm_*), timed on its own ----
+    def exchange_id(ident):
+        if world == 1:
+            return ident
+        t = torch.zeros(128, dtype=torch.uint8, device=red_dev)
+        if rank == 0:
+            t.copy_(torch.frombuffer(bytearray(ident), dtype=torch.uint8))
+        dist.broadcast(t, src=0)
+        return bytes(t.cpu().numpy().tobytes())
+
+    bc = {"bytes": int(K * cap * 32 + K * cap * 4 + K * 4), "via": None}
+    comm = None
+    if args.backend == "nccl":
+        try:
+            comm = tbl_mod.Communicator(ctx, rank, world, exchange_id)
+            bc["via"] = "afv_table_broadcast (ncclBroadcast through the C-ABI communicator)"
+        except Exception as e:  # RCCL not initialisable on this box: say so, use torch.distributed for N > 1
+            bc["comm_error"] = str(e)[:200]
+    times = []
+    for _ in range(max(args.bcast_reps, 1)):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        if comm is not None:
+            dev_ms = table.broadcast(comm, root=0)
+        else:
+            dmod.broadcast_descriptor_table(d_desc, d_n, src=0)
+            if world > 1:
+                dist.broadcast(d_ang, src=0)
+            dev_ms = None
+            bc["via"] = "torch.distributed.broadcast (%s)" % args.backend
+        torch.cuda.synchronize(dev)
+        times.append((time.perf_counter() - t0) * 1e3)
+    table.sync_counts()
+    bc["wall_ms_first"] = times[0]
+    bc["wall_ms_min"] = min(times)
+    bc["device_ms_last"] = dev_ms
+    bc["GBps_at_min"] = bc["bytes"] / (min(times) * 1e-3) / 1e9
+    bc["note"] = "world size 1: the collective degenerates to a local no-op" if world == 1 else "rank 0 -> all ranks over xGMI"
+
+    # ---- jobs: the same LCG list on every rank, block-partitioned ----
+    def jobs_for(kind):
+        a, b = dmod.lcg_pairs(12345, njobs, K)
+        if kind == "covisible":                             # loop candidates close in the keyframe chain: real match load
+            b = ((a.astype(np.int64) + 1 + (b.astype(np.int64) % 3)) % K).astype(np.int32)
+        return a, b
+
+    def run(kind, steps, warmup, profile):
+        a, b = jobs_for(kind)
+        lo, hi = tbl_mod.shard_range(njobs, rank, world)
+        pa = torch.from_numpy(a[lo:hi].copy()).to(dev)
+        pb = torch.from_numpy(b[lo:hi].copy()).to(dev)
+        match = torch.empty((hi - lo, cap), dtype=torch.int32, device=dev)
+        nm = torch.empty((hi - lo,), dtype=torch.int32, device=dev)
+        side = torch.cuda.Stream(dev)
+
+        def step():
+            with torch.cuda.stream(side):
+                table.match_pairs_device(pa, pb, TH, RATIO, True, match=match, nmatches=nm)
+
+        def barrier():
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+        for _ in range(warmup):
+            step()
+        barrier()
+        if profile:
+            ctx.profile_enable(True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        stages = ctx.profile_read() if profile else None
+        if profile:
+            ctx.profile_enable(False)
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # per-job counts of ALL jobs on every rank (the optional gather of SURVEY.md 8e), outside the timed region
+        t1 = time.perf_counter()
+        if world > 1:
+            allnm = dmod.gather_job_results(nm if args.backend == "nccl" else nm.cpu(), njobs).cpu().numpy()
+        else:
+            allnm = nm.cpu().numpy()
+        gather_ms = (time.perf_counter() - t1) * 1e3
+        return float(t.item()), stages, allnm, gather_ms, (a, b), match
+
+    dt, stages, allnm, gather_ms, (ja, jb), match = run("uniform", args.steps, args.warmup, not args.no_profile)
+    dt_c, _, allnm_c, _, _, _ = run("covisible", max(args.steps // 2, 1), 1, False)
+
+    if rank == 0:
+        jobs_s = njobs * args.steps / dt
+        out = {"metric": "keyframe-pair Hamming match jobs /sec (ORB32, 1000x1000 brute-force SearchByBoW(KF,KF))", "value": jobs_s, "unit": "jobs/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "config": {"workload": "BASELINE.json configs[3]: %d (a, b) keyframe-pair jobs drawn by LCG over a table of K = %d keyframes x %d x 32 B "
+                                      "(keyframe k+1 = keyframe k with 10 %% bit flips and 30 %% rows replaced); brute-force SearchByBoW(KF,KF), TH_LOW 75, "
+                                      "nnratio 0.75, orientation check; table built on rank 0 and replicated with one broadcast; jobs block-partitioned"
+                                      % (njobs, K, cap), "jobs_per_step": njobs, "jobs_per_gpu_per_step": tbl_mod.shard_range(njobs, 0, world)[1],
+                          "parallelism": "jobs sharded x%d, table replicated" % world,
+                          "matches_per_job": float(allnm.mean()), "jobs_with_matches": int((allnm > 0).sum())},
+               "descriptor_pairs_per_s": jobs_s * cap * cap,
+               "broadcast": bc, "gather_ms": gather_ms,
+               "covisible": {"jobs_per_s": njobs * max(args.steps // 2, 1) / dt_c, "matches_per_job": float(allnm_c.mean()),
+                             "note": "same table and job count, but b = a + 1..3 (loop candidates that really overlap): loads k_match_resolve"}}
+        if stages and stages["match_topk"]["launches"]:
+            tk, rs = stages["match_topk"], stages["match_resolve"]
+            ms = tk["total_ms"] / tk["launches"]
+            jobs_per_launch = tk["units"] / tk["launches"]
+            ach = PAIR_ALG_BYTES * jobs_per_launch / (ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "k_match_topk", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                               "traffic": None, "algorithmic_bytes_per_launch": PAIR_ALG_BYTES * jobs_per_launch, "avg_launch_ms": ms,
+                               "jobs_per_launch": jobs_per_launch,
+                               "note": "68 000 B per job against 8e6 xor+popcount32: this kernel is integer-VALU-bound by four orders of magnitude; see valu_issue"}
+            calib = valu_calibration()
+            pairs_s = jobs_per_launch * cap * cap / (ms * 1e-3)
+            # 8 v_xor_b32 + 8 v_bcnt_u32_b32 per descriptor pair and lane; a wave instruction covers 64 lanes
+            winst = pairs_s * 16 / 64
+            out["valu_issue"] = {"kernel": "k_match_topk", "achieved": winst, "unit": "wave-instr/s (xor + popcount only)",
+                                 "peak": calib["peak"], "frac": winst / calib["peak"], "peak_source": calib["source"],
+                                 "descriptor_pairs_per_s_in_kernel": pairs_s,
+                                 "note": "the remaining issue slots of the kernel go to the branch-free top-4 insertion (8 VALU per pair)"}
+            out["stage_ms_per_step"] = {"match_topk": tk["total_ms"] / args.steps, "match_resolve": rs["total_ms"] / args.steps}
+        if args.cpu_frames > 0 and world == 1 and host is not None:
+            out["cpu_baseline"] = pairs_cpu_baseline(host[0], host[1], host[2], ja, jb)
+        elif args.cpu_frames > 0:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if comm is not None:
+        comm.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def valu_calibration():
+    """integer-VALU issue peak in wave-instructions/s: the newest committed tools/calib_valu run (profiles/r*/calib_valu.json), else
+    the nominal 1024 SIMDs x 2.4 GHz / 4 cycles"""
+    import glob
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "calib_valu.json")), reverse=True):
+        try:
+            d = json.load(open(p))
+            return {"peak": float(d["valu_peak_winst_per_s"]), "source": os.path.relpath(p, ROOT)}
+        except Exception:
+            pass
+    return {"peak": 1024 * 2.4e9 / 4, "source": "nominal: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,11 +443,17 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
                                                       "multi-rank control flow on a 1-GPU box)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
-    ap.add_argument("--workload", default="orb32", choices=["orb32", "akaze61"],
-                    help="orb32 = the BASELINE.json metric (default); akaze61 = configs[4], 1280x720, single GPU (use --batch 64)")
+    ap.add_argument("--workload", default="orb32", choices=["orb32", "akaze61", "pairs10k"],
+                    help="orb32 = the BASELINE.json metric (default); akaze61 = configs[4], 1280x720, single GPU (use --batch 64); "
+                         "pairs10k = configs[3], 10 000 keyframe-pair match jobs over a K = 1000 table, RCCL broadcast timed separately")
+    ap.add_argument("--keyframes", type=int, default=1000, help="pairs10k: keyframes in the table")
+    ap.add_argument("--jobs", type=int, default=10000, help="pairs10k: pair jobs per step (whole job, all GPUs)")
+    ap.add_argument("--bcast-reps", type=int, default=3, help="pairs10k: repetitions of the table broadcast")
     args = ap.parse_args()
     if args.workload == "akaze61":
         return akaze_main(args)
+    if args.workload == "pairs10k":
+        return pairs_main(args)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))

@@ -67,7 +67,7 @@ int afv_create(int device_ordinal, const afv_orb_params *params, afv_ctx **out);
 void afv_destroy(afv_ctx *ctx);
 const char *afv_strerror(int code);
 const char *afv_last_error(const afv_ctx *ctx); /* text of the last failing HIP call, "" if none */
-int afv_max_keypoints_per_frame(const afv_ctx *ctx); /* sum over levels of (quota_l + 2): safe `cap` */
+int afv_max_keypoints_per_frame(const afv_ctx *ctx); /* sum over levels of max(quota_l + 2, 4 * nIni): safe `cap` */
 void *afv_stream(afv_ctx *ctx); /* the context's hipStream_t (for callers that enqueue their own copies) */
 
 /* ---- extraction: host-buffer plugin path (one frame; synchronous) ---- */
@@ -81,7 +81,9 @@ int afv_orb_extract_batch(afv_ctx *ctx, const uint8_t *const *frames, int nframe
 /* ---- extraction: device-resident batch (benchmark / pipelines).  All pointers are DEVICE pointers;
  * frames are [nframes][height][stride_bytes] with frame_stride_bytes between frames (4-byte aligned base and
  * strides); outputs kps[nframes][cap_per_frame], desc32[nframes][cap_per_frame][32], n_out[nframes].
- * Enqueued on `stream` (hipStream_t, NULL = the context's stream); asynchronous — the caller synchronises.
+ * Enqueued on `stream` (hipStream_t); asynchronous — the caller synchronises.  STREAM RULE (all *_device entry points):
+ * NULL selects the context's own non-blocking stream (afv_stream), which is NOT ordered with any stream of the caller —
+ * synchronise it explicitly.  To run on HIP's legacy default stream pass hipStreamLegacy ((hipStream_t)1), not NULL.
  * status_out (device int32, may be NULL) receives 0 or AFV_ECAPACITY. ---- */
 int afv_orb_extract_batch_device(afv_ctx *ctx, const uint8_t *d_frames, int nframes, int width, int height,
                                  int stride_bytes, size_t frame_stride_bytes, afv_keypoint *d_kps,
@@ -133,6 +135,82 @@ int afv_match_bruteforce_pairs_device(afv_ctx *ctx, const uint8_t *d_desc, const
                                       const int32_t *d_n, int nsets, int cap, const int32_t *d_pair_a,
                                       const int32_t *d_pair_b, int npairs, float th_low, float nnratio,
                                       int check_orientation, int32_t *d_match, int32_t *d_nmatches, void *stream);
+
+/* ---- keyframe descriptor table resident in HBM + multi-GPU replication (BASELINE.json configs[3]) ----
+ * The reference matches a query keyframe against every loop / relocalisation candidate, one SearchByBoW call per
+ * candidate (LoopClosing::ComputeSim3 src/LoopClosing.cc:255-281 over the candidates of KeyFrameDatabase::
+ * DetectLoopCandidates src/KeyFrameDatabase.cc:76-197; Tracking::Relocalization src/Tracking.cc:1162-1182).  Here the
+ * keyframes' descriptors (KeyFrame::mDescriptors, const after construction, include/KeyFrame.h:190), keypoint angles
+ * (mvKeysUn[i].angle) and optionally their DBoW2::FeatureVector (mFeatVec, KeyFrame.h:194) live in ONE device table
+ * of `nsets` slots x `cap` features; batches of (slot a, slot b) pair jobs are matched without any descriptor leaving
+ * HBM.  With several GPUs (one process per GPU) the table is built on one rank and replicated with ONE RCCL broadcast
+ * per array over xGMI (afv_table_broadcast); every rank then matches its own share of the jobs against its replica.
+ * A table belongs to the context it was created on and is destroyed before it. */
+typedef struct afv_table afv_table;
+int afv_table_create(afv_ctx *ctx, int nsets, int cap /* <= 4096 */, afv_table **out);
+void afv_table_destroy(afv_table *t);
+/* upload keyframe `set`: n x 32-byte descriptors, angles[n] in degrees (NULL = zeros).  Host pointers; synchronous. */
+int afv_table_set(afv_table *t, int set, const uint8_t *desc32, const float *angles, int n);
+/* the keyframe's FeatureVector as CSR over ascending node ids (as in afv_match_job); needed by afv_table_match_bow only.
+ * The node ids / segment sizes stay on the host too (the merge-join of two FeatureVectors, FeatureMatcher.cc:205-276,
+ * is host work: <= a few hundred ints per pair), the feature indices go to the device. */
+int afv_table_set_featvec(afv_table *t, int set, const int32_t *node_id, const int32_t *seg_ptr, const int32_t *seg_idx,
+                          int nnodes);
+/* device views for zero-copy callers: d_desc[nsets][cap][32], d_angle[nsets][cap] (float), d_n[nsets] (int32) */
+int afv_table_device_ptrs(afv_table *t, uint8_t **d_desc, float **d_angle, int32_t **d_n);
+/* brute-force SearchByBoW(KF,KF) (FeatureMatcher.cc:561-660 with one node holding everything) of npairs (a, b) slot
+ * pairs.  pair arrays are HOST int32; outputs are HOST arrays: match12[npairs][cap] (may be NULL: counts only) and
+ * nmatches[npairs].  The descriptors never leave the device; only the pair list goes in and the results come out. */
+int afv_table_match_pairs(afv_table *t, const int32_t *pair_a, const int32_t *pair_b, int npairs, float th_low, float nnratio,
+                          int check_orientation, int32_t *match12, int32_t *nmatches);
+/* same, fully device-resident and asynchronous on `stream` (see afv_orb_extract_batch_device for the stream rule):
+ * d_pair_a / d_pair_b / d_match12[npairs][cap] / d_nmatches[npairs] are DEVICE pointers */
+int afv_table_match_pairs_device(afv_table *t, const int32_t *d_pair_a, const int32_t *d_pair_b, int npairs, float th_low,
+                                 float nnratio, int check_orientation, int32_t *d_match12, int32_t *d_nmatches, void *stream);
+/* BoW-guided SearchByBoW(KF,KF) (FeatureMatcher.cc:561-660: merge-join of the two FeatureVectors, per shared node the
+ * ordered greedy scan) of npairs slot pairs whose FeatureVectors were stored with afv_table_set_featvec.  Host pair
+ * arrays in, host results out (match12 may be NULL); descriptors and feature indices stay in HBM. */
+int afv_table_match_bow(afv_table *t, const int32_t *pair_a, const int32_t *pair_b, int npairs, float th_low, float nnratio,
+                        int check_orientation, int32_t *match12, int32_t *nmatches);
+/* SearchForTriangulation (FeatureMatcher.cc:662-790, mono) of npairs slot pairs over the stored FeatureVectors and the
+ * per-keyframe geometry stored with afv_table_set_geometry (mvKeysUn[i].pt and KeyFrame::GetKeyPt1DSigma2(i)): what
+ * LocalMapping::CreateNewMapPoints does against <= 20 neighbours (src/LocalMapping.cc:238-297).  Per pair only the
+ * fundamental matrix, the epipole and the "already has a map point" masks travel. */
+int afv_table_set_geometry(afv_table *t, int set, const float *x, const float *y, const float *sigma2);
+typedef struct {
+    float F12[9];            /* row-major fundamental matrix (as afv_tri_job) */
+    float ex, ey;            /* epipole of camera a in image b */
+    const uint8_t *has_mp1;  /* [n_a] feature already has a map point => skipped (NULL = none has) */
+    const uint8_t *has_mp2;  /* [n_b] */
+    float th_low;            /* FeatureMatcher::TH_LOW */
+} afv_table_tri_job;
+int afv_table_match_triangulation(afv_table *t, const int32_t *pair_a, const int32_t *pair_b, const afv_table_tri_job *geo, int npairs,
+                                  int32_t *match12 /*[npairs][cap]: idx_b | -1*/, int32_t *nmatches);
+/* refresh the host copy of the per-slot counts after the caller wrote d_n on the device itself */
+int afv_table_sync_counts(afv_table *t);
+
+/* RCCL communicator (one process per GPU).  No RCCL symbol is linked: the library is looked up at run time
+ * (an RCCL already loaded into the process, e.g. by PyTorch, is reused; otherwise librccl.so.1 is opened). */
+typedef struct afv_comm afv_comm;
+#define AFV_COMM_ID_BYTES 128
+/* rank 0 creates the id and hands it to the other ranks through any host channel (file, socket, MPI, torch store) */
+int afv_comm_unique_id(uint8_t id[AFV_COMM_ID_BYTES]);
+int afv_comm_create(afv_ctx *ctx, const uint8_t id[AFV_COMM_ID_BYTES], int nranks, int rank, afv_comm **out);
+void afv_comm_destroy(afv_comm *comm);
+int afv_comm_rank(const afv_comm *comm);
+int afv_comm_size(const afv_comm *comm);
+/* in-place broadcast of `bytes` at device pointer `d_buf` from rank `root` (ncclBroadcast, uint8), asynchronous on
+ * `stream` (NULL = the context's stream) */
+int afv_comm_broadcast(afv_comm *comm, void *d_buf, size_t bytes, int root, void *stream);
+/* every rank contributes bytes_per_rank at d_send; d_recv receives nranks * bytes_per_rank in rank order */
+int afv_comm_allgather(afv_comm *comm, const void *d_send, void *d_recv, size_t bytes_per_rank, void *stream);
+/* replicate the whole table (descriptors, angles, counts; the FeatureVector indices if present on root) from `root`:
+ * one broadcast per array, then a stream synchronisation.  elapsed_ms (may be NULL) = device time of the broadcasts
+ * (hipEvents on the context's stream).  The FeatureVector host metadata of the root is NOT shipped: ranks that need
+ * afv_table_match_bow call afv_table_set_featvec themselves (it is host data they already hold). */
+int afv_table_broadcast(afv_comm *comm, afv_table *t, int root, float *elapsed_ms);
+/* block partition of n_units over the ranks: unit u belongs to the rank whose [lo, hi) holds it */
+void afv_shard_range(long n_units, int rank, int nranks, long *lo, long *hi);
 
 /* float descriptors, L2^2 distance (config #3): brute force with SearchByBoW(KF,KF) control flow */
 int afv_match_l2(afv_ctx *ctx, const float *desc1, int n1, const float *desc2, int n2, int dim,
@@ -211,18 +289,20 @@ int afv_bow_transform(afv_ctx *ctx, const afv_vocab *v, const uint8_t *desc, int
 /* DescriptorDistance_orb32 on the host (utility for adapters / tests) */
 int afv_hamming256(const uint8_t *a, const uint8_t *b);
 
-/* ---- live stage timing: when enabled, every afv_orb_extract_batch_device / afv_match_bruteforce_pairs_device call
+/* ---- live stage timing: when enabled, every afv_orb_extract_batch_device / afv_match_bruteforce_pairs_device / afv_table_match_pairs* call
  * brackets each kernel stage with hipEvents recorded on the stream the kernels are launched on.
  * afv_profile_read waits for the recorded events and returns, per stage, the number of launches and the summed
  * duration in milliseconds since the last afv_profile_enable(ctx, 1).  Stages: ---- */
-enum { AFV_STAGE_PYRAMID = 0, AFV_STAGE_FAST_HARRIS = 1, AFV_STAGE_SELECT = 2, AFV_STAGE_DESCRIBE = 3, AFV_STAGE_MATCH = 4,
-       AFV_NUM_STAGES = 5 };
+enum { AFV_STAGE_PYRAMID = 0, AFV_STAGE_FAST_HARRIS = 1, AFV_STAGE_SELECT = 2, AFV_STAGE_DESCRIBE = 3,
+       AFV_STAGE_MATCH = 4 /* k_match_topk: the xor + popcount phase */, AFV_STAGE_MATCH_RESOLVE = 5 /* ordered greedy resolve */,
+       AFV_NUM_STAGES = 6 };
 int afv_profile_enable(afv_ctx *ctx, int enable);
 int afv_profile_read(afv_ctx *ctx, int32_t *launches /*[AFV_NUM_STAGES]*/, float *total_ms /*[AFV_NUM_STAGES]*/,
                      int64_t *units /*[AFV_NUM_STAGES], frames (pairs for MATCH) covered by those launches; may be NULL*/);
 /* batches of at least `min_frames` frames (pairs) are split over the context's two streams so that latency-bound kernels of
  * one half overlap the VALU-bound ones of the other (default 64; 0x7fffffff disables the split) */
 int afv_set_split_threshold(afv_ctx *ctx, int min_frames);
+int afv_set_split_chunks(afv_ctx *ctx, int chunks); /* ... into this many chunks alternating over the two streams (default 4) */
 
 /* ---- stage-level introspection of the LAST afv_orb_extract* call (parity tests / profiling) ---- */
 typedef struct {

@@ -766,9 +766,12 @@ int afvo_orb_extract_trace(const afvo_params *p, const u8 *gray, int w, int h, i
             tb[j] = (int64_t)c[i].y * lw[l] + c[i].x;
             src[j++] = i;
         }
-        int32_t *sel = (int32_t *)malloc(sizeof(int32_t) * (size_t)(q[l] + 8));
+        /* saturated: q..q+2 nodes; but the first split round is unconditional (ORBextractor.cc:283-366), so a small quota
+           still yields up to 4 * nIni nodes */
+        const int sel_cap = imax(q[l], 4 * (int)roundf((float)w / (float)h)) + 8;
+        int32_t *sel = (int32_t *)malloc(sizeof(int32_t) * (size_t)sel_cap);
         int ns = 0;
-        if (m2 > 0) ns = afvo_quadtree(px, py, pr, tb, m2, 0, w, 0, h, q[l], sel, q[l] + 8);
+        if (m2 > 0) ns = afvo_quadtree(px, py, pr, tb, m2, 0, w, 0, h, q[l], sel, sel_cap);
         if (tr) tr->t_counts[l] = ns;
         /* E6 + E8..E10 for the selected keypoints of this level */
         u8 *bb = NULL;

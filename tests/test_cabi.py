@@ -111,3 +111,14 @@ def test_product_does_not_import_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "import oracle" not in text and "from oracle" not in text and "afvo" not in text and "libakz" not in text and \
                     "akaze_binding" not in text, os.path.join(dirpath, f)
+
+
+def test_adapter_compiles_in_its_opencv_configuration():
+    """afv_adapter.hpp has cv::Mat / cv::KeyPoint branches (-DAFV_WITH_OPENCV) that the POD selftest never compiles; OpenCV is
+    absent here, so they are syntax-checked against a mock of the few OpenCV names they use (tests/opencv_mock)."""
+    import subprocess
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-DAFV_WITH_OPENCV", "-I", os.path.join(ROOT, "tests", "opencv_mock"),
+           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "anyfeature-vslam_amd", "adapter"),
+           os.path.join(ROOT, "tests", "opencv_mock", "compile_check.cpp")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr

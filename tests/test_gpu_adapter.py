@@ -12,8 +12,7 @@ BIN = os.path.join(ROOT, "anyfeature-vslam_amd", "adapter", "adapter_selftest")
 
 
 def test_cpp_adapter_end_to_end(afv, oracle, tmp_path):
-    if not os.path.exists(BIN):
-        pytest.skip("adapter_selftest not built (run __graft_entry__.build())")
+    assert os.path.exists(BIN), "adapter_selftest is not built: __graft_entry__.build() compiles it (g++, no GPU needed)"
     img = afv.synth.corners_frame(1)
     raw = tmp_path / "frame.raw"
     raw.write_bytes(img.tobytes())
@@ -57,6 +56,36 @@ def test_cpp_adapter_end_to_end(afv, oracle, tmp_path):
     nb = int(lines[1].split()[3])
     wantb, wnb = oracle.search_by_bow_kf_kf(od1, od2, fvs[0], fvs[1], None, None, ok1["angle"], ok2["angle"], 75.0, 0.6, True)
     assert nb == wnb and np.array_equal(np.fromfile(out + ".bowmatch12", dtype=np.int32), wantb)
+    # ---- the projection-guided wrappers of FeatureMatcherHip (SearchByProjection x4, Fuse x2, SearchBySim3,
+    # SearchForInitialization) vs the oracle on the views the selftest built ----
+    size2 = np.fromfile(out + ".size2", dtype=np.float32)
+    inf1 = np.fromfile(out + ".inf1", dtype=np.float32)
+    assert np.array_equal(size2, oracle.size_sigma(ok2)[0]) and np.array_equal(inf1, oracle.size_sigma(ok1)[2])
+    f32 = np.float32
+    F1 = afv.FrameGridView(od1, np.stack([ok1["x"], ok1["y"]], 1), size1, angles=ok1["angle"], inf=inf1)
+    F2 = afv.FrameGridView(od2, np.stack([ok2["x"], ok2["y"]], 1), size2, angles=ok2["angle"], inf=oracle.size_sigma(ok2)[2])
+    Q2 = afv.ProjectionQueries(od2, ok2["x"] - f32(4.0), ok2["y"], f32(15.0) * size2, size2 / f32(1.2), size2 * f32(1.2), angles=ok2["angle"])
+    Q1 = afv.ProjectionQueries(od1, ok1["x"] + f32(4.0), ok1["y"], f32(15.0) * size1, size1 / f32(1.2), size1 * f32(1.2), angles=ok1["angle"])
+    n1 = len(ok1)
+    QI = afv.ProjectionQueries(od1, ok1["x"], ok1["y"], np.full(n1, 100.0, f32), np.zeros(n1, f32), np.full(n1, 3.6, f32),
+                               valid=(ok1["octave"] == 0).astype(np.uint8), angles=ok1["angle"])
+    counts = [int(v) for v in lines[2].split()[1:]]
+    rd = lambda name: np.fromfile(out + name, dtype=np.int32)
+    cases = [
+        (".p_local", oracle.match_projection(F1, Q2, th_high=75.0, nnratio=0.8)),
+        (".p_last", oracle.match_projection(F1, Q2, th_high=75.0, nnratio=0.8, check_orientation=True, last_frame=True)),
+        (".p_reloc", oracle.match_projection(F1, Q2, th_high=60.0, nnratio=0.8, check_orientation=True, last_frame=True)),
+        (".p_sim3p", oracle.match_projection(F1, Q2, th_high=75.0, nnratio=0.8, check_orientation=False, last_frame=True)),
+        (".p_fuse", oracle.match_projection(F1, Q2, th_high=75.0, fuse=True)),
+    ]
+    F1n = afv.FrameGridView(od1, np.stack([ok1["x"], ok1["y"]], 1), size1, angles=ok1["angle"])
+    cases.append((".p_fuse3", oracle.match_projection(F1n, Q2, th_high=75.0, fuse=True)))
+    cases.append((".p_sim3", oracle.match_sim3(F2, Q1, F1, Q2, th_high=75.0)))
+    cases.append((".p_init", oracle.match_initialization(F2, QI, th_low=75.0, nnratio=0.9, check_orientation=True)))
+    for (name, (want_v, want_n)), got_n in zip(cases, counts):
+        assert got_n == want_n, (name, got_n, want_n)
+        assert np.array_equal(rd(name), want_v), name
+    assert counts[0] > 300 and counts[6] > 200 and counts[7] > 50
     # AKAZE61 plugin through the C++ adapter vs the oracle pipeline
     ka = np.fromfile(out + ".akz_kps", dtype=afv.KP_DTYPE); da = np.fromfile(out + ".akz_desc", dtype=np.uint8).reshape(-1, 61)
     plan = akz.make_plan(640, 480)

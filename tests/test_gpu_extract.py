@@ -137,6 +137,52 @@ def test_other_budgets(afv, oracle):
         ctx.close()
 
 
+def test_tiny_budgets_keep_the_unconditional_first_split(afv, oracle):
+    """DistributeOctTree's first split round is unconditional (ORBextractor.cc:283-366): a level whose quota is 0..3 still
+    returns up to 4 * nIni keypoints, so a 5-feature extractor yields ~26 keypoints.  Capacities must follow."""
+    img = afv.synth.corners_frame(21)
+    for nf in (5, 12, 40):
+        ctx = afv.Context(nfeatures=nf)
+        kps, desc = ctx.extract(img)
+        okps, odesc = oracle.orb_extract(img, oracle.default_params(nf, 8, 1.2, 20))
+        assert len(okps) > nf
+        assert kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc), nf
+        assert ctx.cap >= len(kps)
+        ctx.close()
+    wide = afv.synth.corners_frame(3, 1280, 400)          # nIni = 3 roots
+    ctx = afv.Context(nfeatures=12, max_width=1280, max_height=400)
+    kps, desc = ctx.extract(wide)
+    okps, odesc = oracle.orb_extract(wide, oracle.default_params(12, 8, 1.2, 20))
+    assert len(okps) > 40 and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
+    ctx.close()
+
+
+def test_device_call_is_ordered_with_torchs_current_stream(afv, oracle):
+    """the *_device entry points run on torch's CURRENT stream (default stream included): producing the input and reading
+    the outputs on that stream needs no device-wide synchronisation"""
+    import torch
+    ctx = afv.Context(max_batch=16)
+    frames_h = afv.synth.corners_batch(70, 16)
+    want = [oracle.orb_extract(f) for f in frames_h[:3]]
+    for use_side in (False, True):
+        stream = torch.cuda.Stream() if use_side else torch.cuda.current_stream()
+        with torch.cuda.stream(stream):
+            for rep in range(3):
+                staging = torch.from_numpy(frames_h).cuda(non_blocking=True)
+                frames = (staging.to(torch.int16) + 0).to(torch.uint8)        # produced by kernels on this stream
+                kps, desc, n, status = ctx.extract_batch_device(frames)
+                n_h = n.cpu()                                                  # stream-ordered copy, no device sync
+                total = int(n.sum().item())
+                assert int(status.cpu().item()) == 0
+                assert total == int(n_h.sum()) and total > 16 * 900
+                for i in range(3):
+                    k = kps[i, :int(n_h[i])].cpu().numpy().view(afv.KP_DTYPE).reshape(-1)
+                    assert k.tobytes() == want[i][0].tobytes(), (use_side, rep, i)
+                    assert np.array_equal(desc[i, :int(n_h[i])].cpu().numpy(), want[i][1])
+                del kps, desc, n, status, frames                               # let the caching allocator reuse them
+    ctx.close()
+
+
 def test_strided_input_and_batch(gpu_ctx, oracle, afv):
     base = np.zeros((480, 704), np.uint8)
     frames = [afv.synth.corners_frame(30 + i) for i in range(5)]

@@ -1,0 +1,290 @@
+"""-m gpu: BASELINE.json configs[3] — keyframe descriptor table resident in HBM, pair-job batches, the C-ABI RCCL
+communicator.  Bar: every match vector / count equal to the CPU oracle's SearchByBoW / SearchForTriangulation."""
+import importlib
+import os
+import socket
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TH, RATIO = 75.0, 0.75
+
+
+@pytest.fixture(scope="module")
+def tbl(afv):
+    return importlib.import_module("anyfeature-vslam_amd.table")
+
+
+@pytest.fixture(scope="module")
+def dist_mod(afv):
+    return importlib.import_module("anyfeature-vslam_amd.dist")
+
+
+def _oracle_job(oracle, host, a, b, ori=True, ratio=RATIO):
+    t, ang, cnt = host
+    return oracle.search_by_bow_kf_kf(t[a, :cnt[a]], t[b, :cnt[b]], angle1=ang[a, :cnt[a]], angle2=ang[b, :cnt[b]], th_low=TH, nnratio=ratio,
+                                      check_orientation=ori)
+
+
+@pytest.mark.timeout(900)
+def test_config4_full_size_10k_jobs(afv, oracle, tbl, dist_mod):
+    """K = 1000 keyframes x 1000 x 32 B, 10 000 LCG pair jobs on one GPU: EVERY job count and 128 full match
+    vectors against the oracle; plus the covisible job list, whose jobs really match."""
+    import torch
+    K, cap, njobs = 1000, 1000, 10000
+    host = afv.synth.keyframe_table(K, cap)
+    ctx = afv.Context()
+    table = tbl.DescriptorTable(ctx, K, cap)
+    table.upload(*host)
+    a, b = dist_mod.lcg_pairs(12345, njobs, K)
+    bc = ((a.astype(np.int64) + 1 + (b.astype(np.int64) % 3)) % K).astype(np.int32)
+    for kind, pb in (("uniform", b), ("covisible", bc)):
+        d_a, d_b = torch.from_numpy(a).cuda(), torch.from_numpy(pb).cuda()
+        match, nm = table.match_pairs_device(d_a, d_b, TH, RATIO, True)
+        torch.cuda.synchronize()
+        nm = nm.cpu().numpy()
+        check = range(njobs) if kind == "uniform" else range(0, njobs, 20)   # the covisible oracle jobs walk ~500 matches each
+        with ThreadPoolExecutor(max(os.cpu_count() or 4, 4)) as ex:          # ctypes releases the GIL inside the oracle
+            want = list(ex.map(lambda j: _oracle_job(oracle, host, int(a[j]), int(pb[j])), check))
+        for j, (wm, wn) in zip(check, want):
+            assert nm[j] == wn, (kind, j, int(a[j]), int(pb[j]))
+        full = list(check)[::max(len(list(check)) // 128, 1)][:128]
+        got = match[torch.tensor(full, device="cuda")].cpu().numpy()
+        lut = dict(zip(check, want))
+        for r, j in enumerate(full):
+            assert np.array_equal(got[r], lut[j][0]), (kind, j)
+        if kind == "covisible":
+            assert nm.mean() > 100            # overlapping keyframes: hundreds of matches per job
+    # the host-array entry point returns the same thing
+    m2, nm2 = table.match_pairs(a[:64], bc[:64], TH, RATIO, True)
+    ref = table.match_pairs_device(torch.from_numpy(a[:64]).cuda(), torch.from_numpy(bc[:64]).cuda(), TH, RATIO, True)
+    torch.cuda.synchronize()
+    assert np.array_equal(m2, ref[0].cpu().numpy()) and np.array_equal(nm2, ref[1].cpu().numpy())
+    table.close()
+    ctx.close()
+
+
+def _small_table(afv, K=24, cap=384):
+    t, ang, cnt = afv.synth.keyframe_table(K, cap, seed=3)
+    cnt = cnt.copy()
+    for k in range(K):                       # ragged: different feature counts, one empty keyframe
+        cnt[k] = cap - (k * 13) % 90
+    cnt[5] = 0
+    return t, ang, cnt
+
+
+def _featvec(afv, seed, n, nnodes):
+    node_of = afv.synth.lcg_states(seed, max(n, 1))[:n] % nnodes
+    fv = []
+    for k in range(nnodes):
+        idx = np.nonzero(node_of == k)[0]
+        if len(idx):
+            fv.append((int(k * 3 + 1), idx.tolist()))
+    return fv
+
+
+def _csr(fv):
+    ids = np.array([k for k, _ in fv], np.int32)
+    ptr = np.zeros(len(fv) + 1, np.int32)
+    for i, (_, v) in enumerate(fv):
+        ptr[i + 1] = ptr[i] + len(v)
+    idx = np.array([x for _, v in fv for x in v], np.int32)
+    return ids, ptr, idx
+
+
+@pytest.mark.parametrize("ori", [False, True])
+def test_table_bow_guided_pairs(afv, oracle, tbl, ori):
+    """device-resident BoW-guided SearchByBoW(KF,KF) (FeatureMatcher.cc:561-660): merge-join on the host, descriptors and
+    feature indices in HBM"""
+    host = _small_table(afv)
+    t, ang, cnt = host
+    K = len(cnt)
+    ctx = afv.Context()
+    table = tbl.DescriptorTable(ctx, K, t.shape[1])
+    fvs = []
+    for k in range(K):
+        table.set(k, t[k, :cnt[k]], ang[k, :cnt[k]])
+        fv = _featvec(afv, 50 + k, int(cnt[k]), 40 if k % 3 else 7)
+        fvs.append(fv)
+        table.set_featvec(k, *_csr(fv))
+    pa = np.array([k for k in range(K) for _ in range(3)], np.int32)
+    pb = np.array([(k + 1 + j) % K for k in range(K) for j in range(3)], np.int32)
+    m, nm = table.match_bow(pa, pb, TH, RATIO, ori)
+    total = 0
+    for p in range(len(pa)):
+        a, b = int(pa[p]), int(pb[p])
+        want, wn = oracle.search_by_bow_kf_kf(t[a, :cnt[a]], t[b, :cnt[b]], fvs[a], fvs[b], None, None, ang[a, :cnt[a]], ang[b, :cnt[b]], TH, RATIO, ori)
+        assert nm[p] == wn, (p, a, b)
+        assert np.array_equal(m[p, :cnt[a]], want), (p, a, b)
+        assert np.all(m[p, cnt[a]:] == -1)
+        total += wn
+    assert total > 200
+    # counts-only call
+    _, nm2 = table.match_bow(pa, pb, TH, RATIO, ori, want_matches=False)
+    assert np.array_equal(nm, nm2)
+    table.close()
+    ctx.close()
+
+
+def test_table_triangulation_pairs(afv, oracle, tbl):
+    """device-resident SearchForTriangulation (FeatureMatcher.cc:662-790): per-keyframe geometry in the table, per pair only
+    F12 / epipole / map-point masks"""
+    s = afv.synth
+    host = _small_table(afv, K=12, cap=320)
+    t, ang, cnt = host
+    K, cap = len(cnt), t.shape[1]
+    ctx = afv.Context()
+    table = tbl.DescriptorTable(ctx, K, cap)
+    fvs, geo = [], []
+    for k in range(K):
+        n = int(cnt[k])
+        table.set(k, t[k, :n], ang[k, :n])
+        fv = _featvec(afv, 90 + k, n, 25)
+        fvs.append(fv)
+        table.set_featvec(k, *_csr(fv))
+        x = (s.lcg_states(300 + k, max(n, 1))[:n] % 64000).astype(np.float32) / 100.0
+        y = (s.lcg_states(400 + k, max(n, 1))[:n] % 48000).astype(np.float32) / 100.0
+        oct_ = s.lcg_states(500 + k, max(n, 1))[:n] % 8
+        sg = (np.float32(1.2) ** oct_.astype(np.float32)) ** 2
+        geo.append((x, y, sg.astype(np.float32)))
+        table.set_geometry(k, x, y, sg)
+    pa = np.arange(K, dtype=np.int32)
+    pb = ((pa + 1) % K).astype(np.int32)
+    F = np.zeros((K, 9), np.float32)
+    ep = np.zeros((K, 2), np.float32)
+    mp1, mp2 = [], []
+    for p in range(K):
+        f = (s.lcg_states(700 + p, 9) % 2001).astype(np.float32) / 1000.0 - 1.0
+        F[p] = f * np.array([1e-5, 1e-5, 1e-3, 1e-5, 1e-5, 1e-3, 1e-3, 1e-3, 1.0], np.float32)
+        ep[p] = (float(s.lcg_states(800 + p, 1)[0] % 640), float(s.lcg_states(801 + p, 1)[0] % 480))
+        mp1.append((s.lcg_bytes(900 + p, max(int(cnt[pa[p]]), 1))[:cnt[pa[p]]] > 200).astype(np.uint8) if p % 2 else None)
+        mp2.append((s.lcg_bytes(950 + p, max(int(cnt[pb[p]]), 1))[:cnt[pb[p]]] > 200).astype(np.uint8) if p % 3 else None)
+    m, nm = table.match_triangulation(pa, pb, F, ep, TH, mp1, mp2)
+    total = 0
+    for p in range(K):
+        a, b = int(pa[p]), int(pb[p])
+        na, nb = int(cnt[a]), int(cnt[b])
+        pts1 = np.stack([geo[a][0], geo[a][1]], 1) if na else np.zeros((0, 2), np.float32)
+        pts2 = np.stack([geo[b][0], geo[b][1]], 1) if nb else np.zeros((0, 2), np.float32)
+        want, wn = oracle.search_for_triangulation(t[a, :na], t[b, :nb], pts1, pts2, geo[b][2], F[p].reshape(3, 3), ep[p], fvs[a], fvs[b], mp1[p], mp2[p], TH)
+        got = m[p, :na]
+        if isinstance(want, np.ndarray) and want.ndim == 2:      # list of (idx1, idx2) pairs
+            vec = np.full(na, -1, np.int32)
+            for i1, i2 in want:
+                vec[i1] = i2
+            want = vec
+        assert nm[p] == wn, (p, nm[p], wn)
+        assert np.array_equal(got, np.asarray(want)[:na]), p
+        total += wn
+    assert total > 0
+    table.close()
+    ctx.close()
+
+
+def test_comm_world1_broadcast_and_allgather(afv, tbl):
+    """the C-ABI communicator on a single rank: RCCL is found at run time, a world-1 broadcast / all-gather are identities and
+    the table broadcast reports its device time.  (A 2-rank run needs 2 GPUs: see test_comm_two_ranks.)"""
+    import torch
+    ctx = afv.Context()
+    comm = tbl.Communicator(ctx, 0, 1, lambda ident: ident)
+    host = _small_table(afv, K=6, cap=128)
+    table = tbl.DescriptorTable(ctx, 6, 128)
+    table.upload(*host)
+    ms = table.broadcast(comm, root=0)
+    assert ms >= 0.0
+    d, a, n = table.device_views()
+    assert np.array_equal(d.cpu().numpy(), host[0]) and np.array_equal(n.cpu().numpy(), host[2])
+    x = torch.arange(1000, dtype=torch.int32, device="cuda")
+    y = torch.empty_like(x)
+    torch.cuda.synchronize()          # the collectives run on the context's own stream (stream = NULL)
+    comm.broadcast(x)
+    comm.allgather(x, y)
+    torch.cuda.synchronize()
+    assert afv._lib.load().afv_comm_rank(comm.handle) == 0 and afv._lib.load().afv_comm_size(comm.handle) == 1
+    assert torch.equal(x, y)
+    comm.close()
+    table.close()
+    ctx.close()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _two_rank_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # host channel for the id only; the data path is RCCL in the library
+    afv = importlib.import_module("anyfeature-vslam_amd")
+    tbl = importlib.import_module("anyfeature-vslam_amd.table")
+    dmod = importlib.import_module("anyfeature-vslam_amd.dist")
+
+    def exchange(ident):
+        box = [ident]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+    ctx = afv.Context(device=rank)
+    comm = tbl.Communicator(ctx, rank, world, exchange)
+    K, cap, njobs = 16, 256, 101
+    host = afv.synth.keyframe_table(K, cap, seed=9)
+    table = tbl.DescriptorTable(ctx, K, cap)
+    if rank == 0:
+        table.upload(*host)
+    table.broadcast(comm, root=0)
+    a, b = dmod.lcg_pairs(4, njobs, K)
+    b = ((a.astype(np.int64) + 1 + (b.astype(np.int64) % 3)) % K).astype(np.int32)
+    lo, hi = tbl.shard_range(njobs, rank, world)
+    _, nm = table.match_pairs(a[lo:hi], b[lo:hi], TH, RATIO, True, want_matches=False)
+    pad = tbl.shard_range(njobs, 0, world)[1]
+    send = torch.full((pad,), -1, dtype=torch.int32, device="cuda")
+    send[:hi - lo] = torch.from_numpy(nm).cuda()
+    recv = torch.empty((pad * world,), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    comm.allgather(send, recv)
+    torch.cuda.synchronize()          # device-wide: covers the context's stream the collective ran on
+    r = recv.cpu().numpy().reshape(world, pad)
+    allnm = np.concatenate([r[k, :tbl.shard_range(njobs, k, world)[1] - tbl.shard_range(njobs, k, world)[0]] for k in range(world)])
+    q.put((rank, allnm.tolist()))
+    dist.barrier()
+    comm.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_comm_two_ranks(afv, oracle):
+    """2-rank RCCL run of the config-#4 exchange through the C-ABI: broadcast of the table, sharded jobs, all-gather of the
+    counts.  Needs two GPUs (the round-end box has one: skipped there)."""
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    dmod = importlib.import_module("anyfeature-vslam_amd.dist")
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=500) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    K, cap, njobs = 16, 256, 101
+    host = afv.synth.keyframe_table(K, cap, seed=9)
+    a, b = dmod.lcg_pairs(4, njobs, K)
+    b = ((a.astype(np.int64) + 1 + (b.astype(np.int64) % 3)) % K).astype(np.int32)
+    want = [_oracle_job(oracle, host, int(a[j]), int(b[j]))[1] for j in range(njobs)]
+    assert res[0][1] == want and res[1][1] == want

@@ -57,3 +57,55 @@ def test_shard_range_partitions_exactly(afv):
             assert max(sizes) - min(sizes) <= 1 and sizes == dist.shard_sizes(n, world)
     a, b = dist.lcg_pairs(3, 1000, 50)
     assert a.min() >= 0 and a.max() < 50 and np.all(a != b)
+
+
+def test_library_shard_range_matches_python(afv):
+    """afv_shard_range (C-ABI, what a C++ host uses) and dist.shard_range (Python mirror) are the same block partition"""
+    import importlib
+    tbl = importlib.import_module("anyfeature-vslam_amd.table")
+    d = importlib.import_module("anyfeature-vslam_amd.dist")
+    for n in (0, 1, 7, 8, 9, 10000, 10007):
+        for world in (1, 2, 3, 4, 8):
+            covered = 0
+            for r in range(world):
+                lo, hi = tbl.shard_range(n, r, world)
+                assert (lo, hi) == d.shard_range(n, r, world)
+                assert lo == covered
+                covered = hi
+            assert covered == n
+
+
+def test_table_and_comm_reject_bad_arguments(afv):
+    import ctypes as C
+    lib = afv._lib.load()
+    h = C.c_void_p()
+    E = afv._lib.EINVAL
+    assert lib.afv_table_create(None, 4, 4, C.byref(h)) == E
+    lib.afv_table_destroy(None)
+    assert lib.afv_table_set(None, 0, None, None, 0) == E
+    assert lib.afv_table_set_featvec(None, 0, None, None, None, 0) == E
+    assert lib.afv_table_set_geometry(None, 0, None, None, None) == E
+    assert lib.afv_table_match_pairs(None, None, None, 0, 75.0, 0.75, 1, None, None) == E
+    assert lib.afv_table_match_pairs_device(None, None, None, 0, 75.0, 0.75, 1, None, None, None) == E
+    assert lib.afv_table_match_bow(None, None, None, 0, 75.0, 0.75, 1, None, None) == E
+    assert lib.afv_table_match_triangulation(None, None, None, None, 0, None, None) == E
+    assert lib.afv_table_broadcast(None, None, 0, None) == E
+    assert lib.afv_table_sync_counts(None) == E
+    assert lib.afv_comm_unique_id(None) == E
+    assert lib.afv_comm_create(None, None, 1, 0, C.byref(h)) == E
+    lib.afv_comm_destroy(None)
+    assert lib.afv_comm_rank(None) == E and lib.afv_comm_size(None) == E
+    assert lib.afv_comm_broadcast(None, None, 0, 0, None) == E
+    assert lib.afv_comm_allgather(None, None, None, 0, None) == E
+    assert lib.afv_set_split_chunks(None, 4) == E
+
+
+def test_keyframe_table_generator_is_reproducible(afv):
+    t1, a1, n1 = afv.synth.keyframe_table(6, 64, seed=3)
+    t2, a2, n2 = afv.synth.keyframe_table(6, 64, seed=3)
+    assert np.array_equal(t1, t2) and np.array_equal(a1, a2) and np.array_equal(n1, n2)
+    assert t1.shape == (6, 64, 32) and a1.dtype == np.float32 and (a1 >= 0).all() and (a1 < 360).all()
+    # neighbours share most rows up to ~10 % bit flips, distant keyframes do not
+    near = np.unpackbits(t1[0] ^ t1[1], axis=1).sum(axis=1)
+    far = np.unpackbits(t1[0] ^ t1[5], axis=1).sum(axis=1)
+    assert (near < 75).sum() > 30 and (far < 75).sum() < (near < 75).sum()
