@@ -187,15 +187,26 @@ def ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-HIP_STREAM_LEGACY = 1  # hipStreamLegacy: the C-ABI reserves NULL for "the context's own stream"
-
-
-def torch_stream_handle(device=None, stream=None):
-    """hipStream_t to hand to the *_device entry points so that the work is ordered with torch's CURRENT stream.
-    torch reports its default stream as handle 0, which the C-ABI reads as "use the context's private stream"
-    (unordered with torch): map it to hipStreamLegacy instead."""
+def launch_ordered(ctx, device, stream, fn, tensors=()):
+    """Call fn(hipStream_t) so that the work is ordered with torch's CURRENT stream.
+    An explicit `stream` or a non-default torch stream is handed to the library as is.  torch reports its default stream
+    as handle 0, which the C-ABI reads as "the context's own non-blocking stream" (not ordered with torch): in that case
+    the context's stream is bridged with events through torch.cuda.ExternalStream: wait for torch's stream before, make
+    torch's stream wait after."""
     if stream is not None:
-        return stream
+        return fn(stream)
     import torch
-    s = torch.cuda.current_stream(device).cuda_stream
-    return s if s else HIP_STREAM_LEGACY
+    cur = torch.cuda.current_stream(device)
+    if cur.cuda_stream:
+        return fn(cur.cuda_stream)
+    ext = getattr(ctx, "_ext_stream", None)
+    if ext is None:
+        ext = torch.cuda.ExternalStream(ctx.stream, device=device)
+        ctx._ext_stream = ext
+    ext.wait_stream(cur)
+    rc = fn(None)
+    cur.wait_stream(ext)
+    # no tensor.record_stream(ext): everything torch does with these tensors later (including freeing and reusing their
+    # memory) is enqueued on `cur` AFTER the wait above, and the allocator must never touch the context's stream — it is
+    # destroyed with the context while cached blocks live on
+    return rc

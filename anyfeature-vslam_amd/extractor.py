@@ -78,6 +78,7 @@ class Context:
 
     def close(self):
         if getattr(self, "handle", None):
+            self._ext_stream = None  # torch wrapper of the context's stream (_lib.launch_ordered): dies with it
             self.lib.afv_destroy(self.handle)
             self.handle = None
 
@@ -141,10 +142,9 @@ class Context:
             n_out = torch.empty((B,), dtype=torch.int32, device=dev)
         if status is None:
             status = torch.empty((1,), dtype=torch.int32, device=dev)
-        s = _lib.torch_stream_handle(dev, stream)
-        rc = self.lib.afv_orb_extract_batch_device(self.handle, frames.data_ptr(), B, W, H, frames.stride(1),
-                                                   frames.stride(0), kps.data_ptr(), desc.data_ptr(), cap,
-                                                   n_out.data_ptr(), status.data_ptr(), s)
+        rc = _lib.launch_ordered(self, dev, stream, lambda s: self.lib.afv_orb_extract_batch_device(
+            self.handle, frames.data_ptr(), B, W, H, frames.stride(1), frames.stride(0), kps.data_ptr(), desc.data_ptr(), cap,
+            n_out.data_ptr(), status.data_ptr(), s), (frames, kps, desc, n_out, status))
         self.check(rc, "afv_orb_extract_batch_device")
         return kps, desc, n_out, status
 

@@ -307,11 +307,10 @@ class FeatureMatcher:
             match = torch.empty((npairs, cap), dtype=torch.int32, device=desc.device)
         if nmatches is None:
             nmatches = torch.empty((npairs,), dtype=torch.int32, device=desc.device)
-        s = _lib.torch_stream_handle(desc.device, stream)
         co = self.mbCheckOrientation if check_orientation is None else check_orientation
-        rc = self.lib.afv_match_bruteforce_pairs_device(
+        rc = _lib.launch_ordered(self.ctx, desc.device, stream, lambda s: self.lib.afv_match_bruteforce_pairs_device(
             self.ctx.handle, desc.data_ptr(), kps.data_ptr() if kps is not None else None, n.data_ptr(), nsets, cap,
             pair_a.data_ptr(), pair_b.data_ptr(), npairs, float(self.TH_LOW if th_low is None else th_low), self.mfNNratio,
-            int(bool(co)), match.data_ptr(), nmatches.data_ptr(), s)
+            int(bool(co)), match.data_ptr(), nmatches.data_ptr(), s), (desc, kps, n, pair_a, pair_b, match, nmatches))
         self.ctx.check(rc, "afv_match_bruteforce_pairs_device")
         return match, nmatches

@@ -164,9 +164,10 @@ class DescriptorTable:
             match = torch.empty((n, self.cap), dtype=torch.int32, device=pair_a.device)
         if nmatches is None:
             nmatches = torch.empty((n,), dtype=torch.int32, device=pair_a.device)
-        s = _lib.torch_stream_handle(pair_a.device, stream)
-        self.ctx.check(self.lib.afv_table_match_pairs_device(self.handle, pair_a.data_ptr(), pair_b.data_ptr(), n, float(th_low), float(nnratio),
-                                                             int(bool(check_orientation)), match.data_ptr(), nmatches.data_ptr(), s),
+        rc = _lib.launch_ordered(self.ctx, pair_a.device, stream, lambda s: self.lib.afv_table_match_pairs_device(
+            self.handle, pair_a.data_ptr(), pair_b.data_ptr(), n, float(th_low), float(nnratio), int(bool(check_orientation)),
+            match.data_ptr(), nmatches.data_ptr(), s), (pair_a, pair_b, match, nmatches))
+        self.ctx.check(rc,
                        "afv_table_match_pairs_device")
         return match, nmatches
 

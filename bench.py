@@ -493,10 +493,13 @@ def main():
     pair_a = torch.arange(B, dtype=torch.int32, device=dev)
     pair_b = (pair_a + (B - 1)) % B  # t-1, frame 0 pairs with frame B-1
 
+    side = torch.cuda.Stream(dev)    # a real stream: the library enqueues on it (the default stream would be event-bridged)
+
     def step():
-        ctx.extract_batch_device(frames, kps, desc, n_out, status, cap)
-        matcher.match_pairs_device(desc, kps, n_out, pair_a, pair_b, th_low=75.0, check_orientation=True, match=match,
-                                   nmatches=nmatch)
+        with torch.cuda.stream(side):
+            ctx.extract_batch_device(frames, kps, desc, n_out, status, cap)
+            matcher.match_pairs_device(desc, kps, n_out, pair_a, pair_b, th_low=75.0, check_orientation=True, match=match,
+                                       nmatches=nmatch)
 
     def barrier():
         torch.cuda.synchronize(dev)

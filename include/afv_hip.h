@@ -83,7 +83,9 @@ int afv_orb_extract_batch(afv_ctx *ctx, const uint8_t *const *frames, int nframe
  * strides); outputs kps[nframes][cap_per_frame], desc32[nframes][cap_per_frame][32], n_out[nframes].
  * Enqueued on `stream` (hipStream_t); asynchronous — the caller synchronises.  STREAM RULE (all *_device entry points):
  * NULL selects the context's own non-blocking stream (afv_stream), which is NOT ordered with any stream of the caller —
- * synchronise it explicitly.  To run on HIP's legacy default stream pass hipStreamLegacy ((hipStream_t)1), not NULL.
+ * not even HIP's null stream: either pass one of your own (non-null) streams, or order afv_stream(ctx) with events
+ * (hipEventRecord + hipStreamWaitEvent both ways) or synchronise it.  The Python mirror does the event bridging when torch's
+ * current stream is the default stream (_lib.launch_ordered).
  * status_out (device int32, may be NULL) receives 0 or AFV_ECAPACITY. ---- */
 int afv_orb_extract_batch_device(afv_ctx *ctx, const uint8_t *d_frames, int nframes, int width, int height,
                                  int stride_bytes, size_t frame_stride_bytes, afv_keypoint *d_kps,

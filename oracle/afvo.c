@@ -1291,8 +1291,11 @@ int afvo_match_fuse(const afvo_proj_job *j, int32_t *best_out) {
  * agreement check (:1268-1284).  j12: queries = KF1 features (their map points) searched in KF2; j21 the other way. */
 int afvo_match_sim3(const afvo_proj_job *j12, const afvo_proj_job *j21, int32_t *match12) {
     int32_t *m1 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(j12->nq + 1)), *m2 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(j21->nq + 1));
-    afvo_match_fuse(j12, m1);
-    afvo_match_fuse(j21, m2);
+    afvo_proj_job a = *j12, b = *j21;
+    a.inf = NULL; /* gate-less: SearchBySim3 has no chi-square test on the reprojection (:1130-1180, :1210-1262) */
+    b.inf = NULL;
+    afvo_match_fuse(&a, m1);
+    afvo_match_fuse(&b, m2);
     int nfound = 0;
     for (int i1 = 0; i1 < j12->nq; ++i1) {
         match12[i1] = -1;
