@@ -5,79 +5,93 @@
 // HarrisResponses(blockSize 7, k 0.04) (OpenCV orb.cpp).  One 256-thread workgroup owns a 64x32 tile:
 //   1. the tile plus a 4 px halo is staged in LDS with coalesced dword loads (reflect-101 at the image edge —
 //      FAST never reads it, Harris does, exactly like cv::ORB's 23 px apron);
-//   2a. every pixel of the 66x34 ring-extended tile takes OpenCV's necessary pre-test (each of the 4 even antipodal
-//      ring pairs must hold a darker / a brighter pixel), evaluated on packed (v-r, r-v) i16 pairs; survivors are
-//      compacted into an LDS list so that
-//   2b. the exact corner score = largest threshold for which the pixel is still a 9-arc corner runs on dense
-//      wavefronts: 16 ring differences packed as (v-r, r-v), van-Herk prefix/suffix minima over the two ring halves
-//      (59 packed min/max for both polarities), corner iff score > threshold;
-//   3. strict 3x3 maxima are compacted into a second LDS list (<= 512 per tile);
-//   4. that list is processed densely: integer Harris sums a,b,c over the 7x7 block from LDS, one float
-//      expression for the response;
+//   2a. OpenCV's necessary pre-test (each of the 4 even antipodal ring pairs must hold a brighter / a darker pixel) on
+//      the 66x34 ring-extended tile, TWO horizontally adjacent pixels per lane as packed u16 pairs: per polarity
+//      min over the pairs of max(a, b) - v > t  /  v - max over the pairs of min(a, b) > t.  Survivors go to an LDS list,
+//      one entry per (pixel, polarity);
+//   2b. the exact corner score = largest threshold for which the pixel is still a 9-arc corner, two list entries per
+//      lane (the packed halves now carry two different pixels of one polarity each): 16 ring differences,
+//      van-Herk prefix/suffix minima over the two ring halves (59 packed min/max), corner iff score > threshold; scores go
+//      to an LDS score plane (a pixel is a corner in at most one polarity: two 9-arcs of a 16-ring overlap);
+//   3. strict 3x3 maxima, dense over the score plane (again two pixels per lane, packed max), compacted into an LDS list
+//      (<= 512 per tile);
+//   4. that list is processed densely, 8 lanes per candidate: integer Harris sums a,b,c over the 7x7 block with packed
+//      i16 Sobel rows and v_dot2_i32_i16 accumulation, one float expression for the response;
 //   5. one global atomic per tile reserves output slots in the (frame, level) candidate array.
-// Thread (tx, ty) = (tid & 63, tid >> 6) walks rows ty, ty+4, ...: no integer division, row validity is wave-uniform.
 // Candidates leave the kernel unordered; everything downstream is order-independent (ties are broken by the
 // raster index), see DESIGN.md "canonical order".
-#include "afv_device.h"
+#include <type_traits>
 
+#include "afv_device.h"
 
 typedef short short2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ short2v pkmin(short2v a, short2v b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ short2v pkmax(short2v a, short2v b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ uint32_t as_u32(short2v v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ short2v as_s2(uint32_t v) { return __builtin_bit_cast(short2v, v); }
+typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_shr1(uint32_t v) {  // v_pk_lshrrev_b16: both 16-bit halves >> 1
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(ushort2v, v) >> (unsigned short)1);
+}
 
-// packed ring difference (v - r, r - v) = (r, r) * (-1, +1) + (v, -v): one v_pk_mad_i16 per ring pixel
-__device__ __forceinline__ short2v ring_diff(const uint8_t *c, int off, short2v vn) {
-    const short r = (short)c[off];
-    short2v R;
-    R.x = r;
-    R.y = r;
-    short2v K;
-    K.x = -1;
-    K.y = 1;
-    return R * K + vn;
+// ---- cross-lane helpers on DPP (no LDS round trips) ----
+#define DPP_QUAD_XOR1 0xB1       // quad_perm:[1,0,3,2]
+#define DPP_QUAD_XOR2 0x4E       // quad_perm:[2,3,0,1]
+#define DPP_ROW_HALF_MIRROR 0x141
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+// inclusive prefix sum over the 64 lanes of a wavefront: 4 Hillis-Steele steps inside each row of 16 lanes, then the row
+// totals are carried over with row_bcast15 (rows 1, 3) and row_bcast31 (rows 2, 3)
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(1), 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(2), 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(4), 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(8), 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_BCAST15, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_BCAST31, 0xc, 0xf, false);
+    return v;
+}
+// sum over aligned groups of 8 lanes (every lane of the group receives the total)
+__device__ __forceinline__ int group8_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, DPP_QUAD_XOR1, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, DPP_QUAD_XOR2, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_HALF_MIRROR, 0xf, 0xf, true);
+    return v;
 }
 
 #define RING_OFF(dx, dy) ((dy) * FT_LW + (dx))
+#define PRE_ROWS (FT_H + 2)             // LDS rows 3 .. 36 (tile pixels -1 .. 32)
+#define PRE_PAIRS ((FT_W + 4) / 2)      // LDS columns 2 .. 69 as 34 pixel pairs at EVEN columns (aligned 16-bit LDS reads); columns
+                                        // 2 and 69 are outside the ring-extended tile and masked out
+#define PRE_GROUPS (256 / PRE_PAIRS)      // 7 row groups of 34 threads
+#define PRE_ITERS ((PRE_ROWS + PRE_GROUPS - 1) / PRE_GROUPS)  // rows rg, rg + 7, ... : 5 iterations
+#define PRE_MAX (2 * PRE_ROWS * 2 * PRE_PAIRS)  // one entry per (pixel, polarity)
 
-// OpenCV pre-test on the even antipodal pairs (0,8) (2,10) (4,12) (6,14): lo halves carry "darker", hi "brighter"
-__device__ __forceinline__ bool fast_pretest(const uint8_t *c, int threshold) {
-    const short v = (short)c[0];
-    short2v vn;
-    vn.x = v;
-    vn.y = (short)-v;
-    const short2v m0 = pkmax(ring_diff(c, RING_OFF(0, 3), vn), ring_diff(c, RING_OFF(0, -3), vn));
-    const short2v m2 = pkmax(ring_diff(c, RING_OFF(2, 2), vn), ring_diff(c, RING_OFF(-2, -2), vn));
-    const short2v m4 = pkmax(ring_diff(c, RING_OFF(3, 0), vn), ring_diff(c, RING_OFF(-3, 0), vn));
-    const short2v m6 = pkmax(ring_diff(c, RING_OFF(2, -2), vn), ring_diff(c, RING_OFF(-2, 2), vn));
-    const short2v m = pkmin(pkmin(m0, m2), pkmin(m4, m6));
-    return max((int)m.x, (int)m.y) > threshold;
+// two horizontally adjacent tile bytes as a packed u16 pair: one 16-bit LDS read (any alignment) + one byte permute
+__device__ __forceinline__ short2v ld_pair(const uint8_t *c, int off) {
+    unsigned short w;
+    __builtin_memcpy(&w, c + off, 2);
+    return as_s2(__builtin_amdgcn_perm(0u, (uint32_t)w, 0x0c010c00u));
+}
+// the same ring position of two different pixels
+__device__ __forceinline__ short2v ld_two(const uint8_t *c0, const uint8_t *c1, int off) {
+    short2v r;
+    r.x = (short)c0[off];
+    r.y = (short)c1[off];
+    return r;
 }
 
-// score = max over the 16 arcs of 9 contiguous ring pixels of min(v - ring) [dark arc] and of min(ring - v)
-// [bright arc]; corner iff score > threshold; cornerScore<16> returns score - 1.
-__device__ __forceinline__ int fast_score(const uint8_t *c, int threshold) {
-    const short v = (short)c[0];
-    short2v vn;
-    vn.x = v;
-    vn.y = (short)-v;
+// score = max over the 16 arcs of 9 contiguous ring pixels of min(d) where d = ring - v (bright list) or v - ring (dark
+// list); the two halves of every register belong to two different list entries of the same polarity.
+template <bool DARK>
+__device__ __forceinline__ short2v fast_score2(const uint8_t *c0, const uint8_t *c1, short2v V) {
     short2v d[16];
-    d[0] = ring_diff(c, RING_OFF(0, 3), vn);
-    d[1] = ring_diff(c, RING_OFF(1, 3), vn);
-    d[2] = ring_diff(c, RING_OFF(2, 2), vn);
-    d[3] = ring_diff(c, RING_OFF(3, 1), vn);
-    d[4] = ring_diff(c, RING_OFF(3, 0), vn);
-    d[5] = ring_diff(c, RING_OFF(3, -1), vn);
-    d[6] = ring_diff(c, RING_OFF(2, -2), vn);
-    d[7] = ring_diff(c, RING_OFF(1, -3), vn);
-    d[8] = ring_diff(c, RING_OFF(0, -3), vn);
-    d[9] = ring_diff(c, RING_OFF(-1, -3), vn);
-    d[10] = ring_diff(c, RING_OFF(-2, -2), vn);
-    d[11] = ring_diff(c, RING_OFF(-3, -1), vn);
-    d[12] = ring_diff(c, RING_OFF(-3, 0), vn);
-    d[13] = ring_diff(c, RING_OFF(-3, 1), vn);
-    d[14] = ring_diff(c, RING_OFF(-2, 2), vn);
-    d[15] = ring_diff(c, RING_OFF(-1, 3), vn);
+#define RD(k, dx, dy) d[k] = DARK ? (V - ld_two(c0, c1, RING_OFF(dx, dy))) : (ld_two(c0, c1, RING_OFF(dx, dy)) - V)
+    RD(0, 0, 3); RD(1, 1, 3); RD(2, 2, 2); RD(3, 3, 1); RD(4, 3, 0); RD(5, 3, -1); RD(6, 2, -2); RD(7, 1, -3);
+    RD(8, 0, -3); RD(9, -1, -3); RD(10, -2, -2); RD(11, -3, -1); RD(12, -3, 0); RD(13, -3, 1); RD(14, -2, 2); RD(15, -1, 3);
+#undef RD
     // van Herk: window k (9 long, circular) = suffix of its ring half starting at k + prefix of the other half
     short2v suf0[8], pre0[8], suf1[8], pre1[8];
     suf0[7] = d[7];
@@ -99,29 +113,17 @@ __device__ __forceinline__ int fast_score(const uint8_t *c, int threshold) {
     for (int k = 1; k < 8; ++k) best = pkmax(best, pkmin(suf0[k], pre1[k]));
 #pragma unroll
     for (int k = 0; k < 8; ++k) best = pkmax(best, pkmin(suf1[k], pre0[k]));
-    const int s = max((int)best.x, (int)best.y);
-    return s > threshold ? s - 1 : 0;
-}
-
-// wave-aggregated append of `val` to an LDS list (one LDS atomic per wavefront)
-__device__ __forceinline__ void wave_push(bool pred, unsigned short *list, int *count, unsigned short val, int lane) {
-    const unsigned long long m = __ballot(pred);
-    if (m) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(count, __popcll(m));
-        base = __shfl(base, 0, 64);
-        if (pred) list[base + __popcll(m & ((1ull << lane) - 1ull))] = val;
-    }
+    return best;
 }
 
 __global__ __launch_bounds__(256) void k_fast_harris(const Geo *__restrict__ geo_p, FrameSrc src0, const uint8_t *__restrict__ pyr,
                                                      uint32_t *__restrict__ cand_packed, float *__restrict__ cand_resp,
                                                      int *__restrict__ cand_count, int total_blocks, int frame_base) {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[FT_LH * FT_LW];
+    __shared__ __attribute__((aligned(16))) uint8_t tile[FT_LH * FT_LW + 16];  // + pad: the masked column-69 pair reads 2 bytes past row 39
     __shared__ __attribute__((aligned(16))) uint8_t sc[FT_LH * FT_LW];  // same geometry as `tile`
-    __shared__ unsigned short pre[(FT_W + 2) * (FT_H + 2)];
-    __shared__ uint32_t list[512];
-    __shared__ int list_n, out_base, pre_n;
+    __shared__ __attribute__((aligned(4))) unsigned short pre[PRE_MAX];  // bright entries from the front, dark entries from the back
+    __shared__ int list_n, out_base, pre_nb, pre_nd;
+    uint32_t *list = reinterpret_cast<uint32_t *>(pre);  // NMS survivors (<= 512): reuses `pre`, which is dead after step 2b
 
     const Geo &geo = *geo_p;
     // XCD-aware placement: every XCD works on whole frames, so the halo / cache-line sharing between neighbouring
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256) void k_fast_harris(const Geo *__restrict__ geo
     const int tyi = t / L.tiles_x, txi = t - tyi * L.tiles_x;
     const int gx0 = txi * FT_W - FT_HALO, gy0 = tyi * FT_H - FT_HALO;
     const int lw = L.w, lh = L.h;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, lane = tx;
+    const int tid = threadIdx.x, lane = tid & 63;
 
     const uint8_t *img;
     int pitch;
@@ -150,163 +152,272 @@ __global__ __launch_bounds__(256) void k_fast_harris(const Geo *__restrict__ geo
         img = pyr + L.pyr_off + (size_t)f * L.pyr_frame_stride;
         pitch = L.pitch;
     }
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         list_n = 0;
-        pre_n = 0;
+        pre_nb = 0;
+        pre_nd = 0;
     }
 
-    // 1. stage 72x40 bytes: 18 dwords per row; clear the score plane
-    for (int i = threadIdx.x; i < FT_LH * (FT_LW / 4); i += 256) {
-        const int ry = i / (FT_LW / 4), rq = i - ry * (FT_LW / 4);
-        int gy = gy0 + ry;
+    // 1. stage 72x40 bytes and clear the score plane.  Thread (rq, rs) = (tid % 18, tid / 18) owns the dword column rq of the rows
+    //    rs, rs + 14, rs + 28 (252 of the 256 threads): the column part of the address (and its reflect-101 handling at the left /
+    //    right image edge) is computed once, each row costs one reflect + one 32-bit load + two LDS writes.
+    {
+        const int rs = (int)(__umul24((unsigned)tid, 3641u) >> 16);  // tid / 18 (exact for tid < 256)
+        const int rq = tid - rs * (FT_LW / 4);
         const int gx = gx0 + rq * 4;
-        gy = min(max(afv_reflect101(gy, lh), 0), lh - 1);
-        uint32_t v;
-        const uint8_t *row = img + (size_t)gy * pitch;
-        if (gx >= 0 && gx + 3 < lw) {
-            v = *reinterpret_cast<const uint32_t *>(row + gx);
-        } else {
-            v = 0;
+        const bool interior = gx >= 0 && gx + 3 < lw;
+        int xs[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int x = min(max(afv_reflect101(gx + k, lw), 0), lw - 1);
-                v |= (uint32_t)row[x] << (8 * k);
+        for (int k = 0; k < 4; ++k) xs[k] = min(max(afv_reflect101(gx + k, lw), 0), lw - 1);
+        if (rs < 14) {
+#pragma unroll
+            for (int k3 = 0; k3 < 3; ++k3) {
+                const int ry = rs + 14 * k3;
+                if (ry < FT_LH) {
+                    const int gy = min(max(afv_reflect101(gy0 + ry, lh), 0), lh - 1);
+                    const uint8_t *row = img + (size_t)gy * pitch;
+                    uint32_t v;
+                    if (interior) v = *reinterpret_cast<const uint32_t *>(row + gx);
+                    else v = (uint32_t)row[xs[0]] | ((uint32_t)row[xs[1]] << 8) | ((uint32_t)row[xs[2]] << 16) | ((uint32_t)row[xs[3]] << 24);
+                    *reinterpret_cast<uint32_t *>(&tile[ry * FT_LW + rq * 4]) = v;
+                    *reinterpret_cast<uint32_t *>(&sc[ry * FT_LW + rq * 4]) = 0u;
+                }
             }
         }
-        *reinterpret_cast<uint32_t *>(&tile[ry * FT_LW + rq * 4]) = v;
-        *reinterpret_cast<uint32_t *>(&sc[ry * FT_LW + rq * 4]) = 0u;
     }
     __syncthreads();
 
-    // 2a. pre-test on LDS rows 3..36 x columns 3..68 (= tile pixels -1..64 x -1..32).  Each lane owns one column and
-    //     walks rows ty, ty+4, ...; its pass bits are collected in a register and compacted once per wavefront.
+#if defined(AFV_FAST_STOP) && AFV_FAST_STOP == 1
+    if (tile[tid] == 255 && sc[tid] == 77) cand_count[0] = 1;  // keep the staging alive
+    return;
+#endif
+    // 2a. pre-test on LDS rows 3..36 x columns 3..68 (= tile pixels -1..32 x -1..64).  Thread (pr, rg) = (tid % 34, tid / 34)
+    //     owns the pixel pair at columns 2 + 2 pr, 3 + 2 pr of the rows 5 rg .. 5 rg + 4 (238 of the 256 threads): the column
+    //     never changes, so every LDS read of the unrolled loop is base + immediate.  The pass bits are the CLEAR sign bits
+    //     of (min over pairs of max(a, b)) - v - (t + 1) [bright] and v - (max over pairs of min(a, b)) - (t + 1) [dark]; they
+    //     are shifted into `fb` / `fd`: after the loop bit 15 - (PRE_ITERS - 1 - it) (pixel 0) and bit 31 - (PRE_ITERS - 1 - it)
+    //     (pixel 1) hold the FAIL flag of iteration `it`.
     const int thr = geo.fast_threshold;
     {
-        const int col = 3 + tx, gx = gx0 + col;
-        const bool col_ok = gx >= 3 && gx < lw - 3;
-        uint32_t bits = 0;
+        const int rg = (int)(__umul24((unsigned)tid, 1928u) >> 16);  // tid / 34 (exact for tid < 256)
+        const int pr = tid - rg * PRE_PAIRS;
+        const int col = 2 + 2 * pr, gx = gx0 + col;
+        uint32_t fb = 0xffffffffu, fd = 0xffffffffu;  // idle threads (tid >= 238): everything failed
+        if (rg < PRE_GROUPS) {
+            fb = fd = 0u;
+            short2v T1;
+            T1.x = T1.y = (short)(thr + 1);
+            const uint8_t *c = &tile[(rg * PRE_ITERS + 3) * FT_LW + col];
+            // centre row: v and the ring pixels at dx = -3 / +3 sit at ODD distances, and an unaligned LDS read stalls the LDS pipe
+            // (SQ_LDS_UNALIGNED_STALL).  So the row is read as the three ALIGNED dwords that hold bytes col-4 .. col+5 and the
+            // three pairs are cut out with byte permutes whose selectors depend on col & 2 only (computed once per thread).
+            const int sh = (col - 4) & 3;  // 0 or 2
+            const uint32_t *cw = reinterpret_cast<const uint32_t *>(c - 4 - sh);
+            const uint32_t sel_b = 0x0c020c01u + (uint32_t)sh * 0x00010001u;  // (col-3, col-2) out of (w1:w0)
+            const uint32_t sel_v = 0x0c050c04u + (uint32_t)sh * 0x00010001u;  // (col,   col+1) out of (w1:w0)
+            const uint32_t sel_a = 0x0c040c03u + (uint32_t)sh * 0x00010001u;  // (col+3, col+4) out of (w2:w1)
 #pragma unroll
-        for (int k = 0; k < (FT_H + 2 + 3) / 4; ++k) {
-            const int r = ty + 4 * k;  // wave-uniform row
-            const int gy = gy0 + 3 + r;
-            if (r < FT_H + 2 && gy >= 3 && gy < lh - 3) {
-                if (col_ok && fast_pretest(&tile[(r + 3) * FT_LW + col], thr)) bits |= 1u << k;
+            for (int it = 0; it < PRE_ITERS; ++it) {
+                const int r = rg * PRE_ITERS + it;
+                const int gy = gy0 + 3 + r;
+                uint32_t xb = 0x80008000u, xd = 0x80008000u;
+                if (r < PRE_ROWS && gy >= 3 && gy < lh - 3) {
+                    const int o = it * FT_LW;
+                    const uint32_t w0 = cw[o / 4], w1 = cw[o / 4 + 1], w2 = cw[o / 4 + 2];
+                    const short2v V = as_s2(__builtin_amdgcn_perm(w1, w0, sel_v));
+                    const short2v a4 = as_s2(__builtin_amdgcn_perm(w2, w1, sel_a)), b4 = as_s2(__builtin_amdgcn_perm(w1, w0, sel_b));
+                    const short2v a0 = ld_pair(c, o + RING_OFF(0, 3)), b0 = ld_pair(c, o + RING_OFF(0, -3));
+                    const short2v a2 = ld_pair(c, o + RING_OFF(2, 2)), b2 = ld_pair(c, o + RING_OFF(-2, -2));
+                    const short2v a6 = ld_pair(c, o + RING_OFF(2, -2)), b6 = ld_pair(c, o + RING_OFF(-2, 2));
+                    const short2v hi = pkmin(pkmin(pkmax(a0, b0), pkmax(a2, b2)), pkmin(pkmax(a4, b4), pkmax(a6, b6)));
+                    const short2v lo = pkmax(pkmax(pkmin(a0, b0), pkmin(a2, b2)), pkmax(pkmin(a4, b4), pkmin(a6, b6)));
+                    xb = as_u32(hi - (V + T1));
+                    xd = as_u32((V - T1) - lo);
+                }
+                fb = pk_shr1(fb) | (xb & 0x80008000u);  // halves shift independently: pixel 1's bits never reach pixel 0's
+                fd = pk_shr1(fd) | (xd & 0x80008000u);
             }
         }
-        // the two extra columns 67, 68: 34 rows x 2 = 68 positions, handled by waves 0 and 1 (bit 15)
-        int p_extra = 0;
-        if (threadIdx.x < 128) {
-            const int r = threadIdx.x >> 1, c2 = 67 + (threadIdx.x & 1);
-            const int gy = gy0 + 3 + r, gx2 = gx0 + c2;
-            const bool ok = r < FT_H + 2 && gy >= 3 && gy < lh - 3 && gx2 >= 3 && gx2 < lw - 3;
-            p_extra = (r + 3) * FT_LW + c2;
-            if (ok && fast_pretest(&tile[p_extra], thr)) bits |= 1u << 15;
+        // pass = !fail, restricted to the iteration bits and to the columns inside the FAST border of the level
+        const uint32_t itm = (0xffffu << (16 - PRE_ITERS)) & 0xffffu;
+        const uint32_t colm = ((pr > 0 && gx >= 3 && gx < lw - 3) ? itm : 0u) |
+                              ((pr < PRE_PAIRS - 1 && gx + 1 >= 3 && gx + 1 < lw - 3) ? (itm << 16) : 0u);
+        const uint32_t bb = ~fb & colm, bd = ~fd & colm;
+        // Compaction: exclusive prefix of the per-lane survivor counts (both polarities packed in one register, one DPP scan), two
+        // LDS atomics per wavefront, then every lane writes its own <= 10 + 10 entries with predicated stores (no loops, no
+        // ballots).  A lane's entries are a 2 x 5 pixel block and neighbouring lanes hold neighbouring column pairs, so list
+        // neighbours stay image neighbours and the scattered ring reads of step 2b hit few LDS bank windows.
+        const int cnt = __popc(bb) | (__popc(bd) << 16);
+        const int incl = wave_incl_scan(cnt);
+        int base_b = 0, base_d = 0;
+        if (lane == 63) {
+            base_b = atomicAdd(&pre_nb, incl & 0xffff);
+            base_d = atomicAdd(&pre_nd, incl >> 16);
         }
-        // wave-level exclusive prefix of popcounts -> one LDS atomic per wavefront
-        const int cnt = __popc(bits);
-        int incl = cnt;
+        const int excl = incl - cnt;
+        unsigned short *wb = pre + __shfl(base_b, 63, 64) + (excl & 0xffff);
+        unsigned short *wd = pre + (PRE_MAX - 1) - (__shfl(base_d, 63, 64) + (excl >> 16));
+        const int p00 = (rg * PRE_ITERS + 3) * FT_LW + col;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t2 = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += t2;
-        }
-        int base = 0;
-        if (lane == 63) base = atomicAdd(&pre_n, incl);
-        base = __shfl(base, 63, 64) + incl - cnt;
-        uint32_t b = bits;
-        while (b) {
-            const int k = __builtin_ctz(b);
-            b &= b - 1;
-            pre[base++] = (unsigned short)(k == 15 ? p_extra : (ty + 4 * k + 3) * FT_LW + col);
+        for (int it = 0; it < PRE_ITERS; ++it) {
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                const int pos = 16 * px + 16 - PRE_ITERS + it;
+                const unsigned short val = (unsigned short)(p00 + it * FT_LW + px);
+                if ((bb >> pos) & 1u) *wb = val;
+                wb += (bb >> pos) & 1u;
+                if ((bd >> pos) & 1u) *wd = val;
+                wd -= (bd >> pos) & 1u;
+            }
         }
     }
     __syncthreads();
-    // 2b. exact corner score for the survivors (dense)
-    const int npre = pre_n;
-    for (int i = threadIdx.x; i < npre; i += 256) {
-        const int p = pre[i];
-        sc[p] = (uint8_t)fast_score(&tile[p], thr);
-    }
+#if defined(AFV_FAST_STOP) && AFV_FAST_STOP == 2
+    if (pre[tid] == 0xffff) cand_count[0] = pre_nb + pre_nd;
+    return;
+#endif
+    // 2b. exact corner score, two list entries of one polarity per lane
+    auto score_list = [&](auto dark_tag, int nlist) {
+        constexpr bool DARK = decltype(dark_tag)::value;
+        for (int i0 = 0; 2 * i0 < nlist; i0 += 256) {
+            const int i = i0 + tid;
+            if (2 * i < nlist) {
+                const bool two = 2 * i + 1 < nlist;
+                // bright: entries 2i, 2i+1 from the front; dark: entries PRE_MAX-1-2i, PRE_MAX-2-2i (one aligned dword either way)
+                const uint32_t e2 = *reinterpret_cast<const uint32_t *>(&pre[DARK ? PRE_MAX - 2 - 2 * i : 2 * i]);
+                const int p0 = (int)(DARK ? (e2 >> 16) : (e2 & 0xffffu));
+                const int p1 = two ? (int)(DARK ? (e2 & 0xffffu) : (e2 >> 16)) : p0;
+                const uint8_t *c0 = &tile[p0], *c1 = &tile[p1];
+                const short2v best = fast_score2<DARK>(c0, c1, ld_two(c0, c1, 0));
+                const int s0 = best.x, s1 = best.y;
+                // a pixel is a corner in at most one polarity (two 9-arcs of a 16-ring overlap): no write conflicts
+                if (s0 > thr) sc[p0] = (uint8_t)(s0 - 1);
+                if (s1 > thr) sc[p1] = (uint8_t)(s1 - 1);
+            }
+        }
+    };
+    score_list(std::false_type{}, pre_nb);
+    score_list(std::true_type{}, pre_nd);
     __syncthreads();
 
-    // 3. strict 3x3 maxima -> LDS list.  Only scored positions can be corners, so the NMS walks the survivor list of
-    //    step 2 (interior positions only) instead of all 2048 pixels.
-    for (int i0 = 0; i0 < npre; i0 += 256) {
-        const int i = i0 + threadIdx.x;
-        bool keep = false;
-        int px = 0, py = 0, s0 = 0;
-        if (i < npre) {
-            const int p = pre[i];
-            py = p / FT_LW - FT_HALO;
-            px = p - (py + FT_HALO) * FT_LW - FT_HALO;
-            const uint8_t *q = &sc[p];
-            s0 = q[0];
-            keep = s0 != 0 && px >= 0 && px < FT_W && py >= 0 && py < FT_H && s0 > q[-1] && s0 > q[1] && s0 > q[-FT_LW - 1] &&
-                   s0 > q[-FT_LW] && s0 > q[-FT_LW + 1] && s0 > q[FT_LW - 1] && s0 > q[FT_LW] && s0 > q[FT_LW + 1];
+#if defined(AFV_FAST_STOP) && AFV_FAST_STOP == 3
+    if (sc[tid] == 255) cand_count[0] = 1;
+    return;
+#endif
+    // 3. strict 3x3 maxima, dense over the score plane: thread (pair, rr) = (tid & 31, tid >> 5) owns the pixel pair at LDS columns
+    //    4 + 2 pair, 5 + 2 pair of rows 4 + rr, 12 + rr, 20 + rr, 28 + rr.  Per row of the 3x3 neighbourhood the three packed pairs
+    //    A = (s[c-1], s[c]), B = (s[c], s[c+1]), C = (s[c+1], s[c+2]) hold the neighbours of pixel 0 in the low and of pixel 1 in the
+    //    high halves; keep <=> own score > every neighbour (a zero score never is).  Keep flags -> one compaction per wavefront.
+    {
+        const int c = 4 + 2 * (tid & 31), rr = tid >> 5;
+        const uint8_t *q0 = &sc[(4 + rr) * FT_LW + c];
+        uint32_t kb = 0;
+#pragma unroll
+        for (int it = 0; it < FT_H / 8; ++it) {
+            const uint8_t *q = q0 + it * 8 * FT_LW;
+            unsigned short top, mid, bot;
+            __builtin_memcpy(&top, q - FT_LW, 2);
+            __builtin_memcpy(&mid, q, 2);
+            __builtin_memcpy(&bot, q + FT_LW, 2);
+            const uint32_t tl = q[-FT_LW - 1], tr = q[-FT_LW + 2], ml = q[-1], mr = q[2], bl = q[FT_LW - 1], br = q[FT_LW + 2];
+#define NMS_A(w, l) as_s2(__builtin_amdgcn_perm((uint32_t)(w), (l), 0x0c040c00u))  // (left, w.byte0)
+#define NMS_B(w) as_s2(__builtin_amdgcn_perm(0u, (uint32_t)(w), 0x0c010c00u))       // (w.byte0, w.byte1)
+#define NMS_C(w, r) as_s2(__builtin_amdgcn_perm((uint32_t)(w), (r), 0x0c000c05u))  // (w.byte1, right)
+            const short2v nt = pkmax(pkmax(NMS_A(top, tl), NMS_B(top)), NMS_C(top, tr));
+            const short2v nb = pkmax(pkmax(NMS_A(bot, bl), NMS_B(bot)), NMS_C(bot, br));
+            const short2v nm = pkmax(NMS_A(mid, ml), NMS_C(mid, mr));
+            const short2v self = NMS_B(mid);
+#undef NMS_A
+#undef NMS_B
+#undef NMS_C
+            const uint32_t x = as_u32(pkmax(pkmax(nt, nb), nm) - self);  // sign bit set <=> self > every neighbour
+            kb = pk_shr1(kb) | (x & 0x80008000u);
         }
-        const unsigned long long m = __ballot(keep);
-        if (m) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&list_n, __popcll(m));
-            base = __shfl(base, 0, 64);
-            if (keep) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)px | ((uint32_t)py << 8) | ((uint32_t)s0 << 16);
+        kb &= ((0xffffu << (16 - FT_H / 8)) & 0xffffu) * 0x00010001u;
+        const int cnt = __popc(kb);
+        const int incl = wave_incl_scan(cnt);
+        int base = 0;
+        if (lane == 63) base = atomicAdd(&list_n, incl);
+        base = __shfl(base, 63, 64) + incl - cnt;
+        // `list` aliases `pre`: every wavefront must be done with the score lists before anyone writes (barrier above)
+        while (kb) {
+            const int qb = __builtin_ctz(kb);
+            kb &= kb - 1;
+            const int px = c - FT_HALO + (qb >> 4), py = rr + 8 * ((qb & 15) - (16 - FT_H / 8));
+            list[base++] = (uint32_t)px | ((uint32_t)py << 8) | ((uint32_t)sc[(py + FT_HALO) * FT_LW + px + FT_HALO] << 16);
         }
     }
     __syncthreads();
+#if defined(AFV_FAST_STOP) && AFV_FAST_STOP == 4
+    if (list[tid] == 0xffffffffu) cand_count[0] = list_n;
+    return;
+#endif
     const int n = list_n;
     if (n == 0) return;
-    if (threadIdx.x == 0) out_base = atomicAdd(&cand_count[f * AFV_MAX_LEVELS + l], n);
+    if (tid == 0) out_base = atomicAdd(&cand_count[f * AFV_MAX_LEVELS + l], n);
     __syncthreads();
 
     // 4. Harris response for the compacted candidates: 8 lanes per candidate, lane `sub` owns block row sub-3 (3 source
-    //    rows of 9 pixels -> 7 gradient pairs), partial integer sums are combined with 3 xor-shuffles.  All four
-    //    wavefronts share the work, so no wave is left with a long serial tail.
+    //    rows of 9 pixels -> 7 gradient pairs).  Source rows are expanded to packed u16 pairs P_k = (x[2k], x[2k+1]);
+    //    with S = r0 + 2 r1 + r2 and D = r2 - r0 per column, the gradients of columns (2k+1, 2k+2) are
+    //      Ix = S_{k+1} - S_k,   Iy = D_k + D_{k+1} + 2 * (D_k.hi, D_{k+1}.lo),
+    //    and a, b, c accumulate with v_dot2_i32_i16.  Partial sums are combined with 3 DPP steps.
     const size_t obase = L.cand_off + (size_t)f * L.cand_frame_stride + (size_t)out_base;
-    const int sub = threadIdx.x & 7;
+    const int sub = tid & 7;
     for (int c0 = 0; c0 < n; c0 += 32) {
-        const int ci = c0 + (threadIdx.x >> 3);
+        const int ci = c0 + (tid >> 3);
         const bool act = ci < n;
         const uint32_t e = list[act ? ci : 0];
         const int px = e & 255, py = (e >> 8) & 255, s = e >> 16;
         int a = 0, b = 0, cc = 0;
         if (act && sub < 7) {
-            const uint8_t *c = &tile[(py + FT_HALO + (sub - 3)) * FT_LW + (px + FT_HALO)];
-            // 3 source rows x 9 pixels [x-4, x+4]: three aligned dwords per row, funnel-shifted so that byte k of the
-            // row sits at a lane-independent position (bytes are then picked with static SDWA selects)
-            int r0[9], r1[9], r2[9];
-            const int xa = (px + FT_HALO - 4) & ~3, sh = ((px + FT_HALO - 4) & 3) * 8;
+            // 9 row bytes [x-4, x+4] start at byte `sh` of three aligned dwords (w0, w1, w2); the pair (byte sh+2k, byte sh+2k+1)
+            // is picked by ONE v_perm_b32 with a lane-dependent selector: k = 0, 1 from (w1:w0), k = 2, 3 from (w2:w1) with the
+            // same two selectors, k = 4 (byte sh+8, low half only) from w2
+            const int xa = (px + FT_HALO - 4) & ~3, sh = (px + FT_HALO - 4) & 3;
+            const uint32_t selA = 0x0c010c00u + (uint32_t)sh * 0x00010001u, selB = selA + 0x00020002u, selC = 0x0c0c0c00u + (uint32_t)sh;
             const uint8_t *rowp = &tile[(py + FT_HALO + (sub - 3) - 1) * FT_LW + xa];
-#define LOAD_ROW(R, PTR)                                                                      \
-    {                                                                                         \
-        const uint32_t w0 = *reinterpret_cast<const uint32_t *>(PTR);                          \
-        const uint32_t w1 = *reinterpret_cast<const uint32_t *>((PTR) + 4);                    \
-        const uint32_t w2 = *reinterpret_cast<const uint32_t *>((PTR) + 8);                    \
-        const uint32_t a0 = __builtin_amdgcn_alignbit(w1, w0, sh), a1 = __builtin_amdgcn_alignbit(w2, w1, sh); \
-        const uint32_t a2 = w2 >> sh;                                                          \
-        R[0] = a0 & 255; R[1] = (a0 >> 8) & 255; R[2] = (a0 >> 16) & 255; R[3] = a0 >> 24;     \
-        R[4] = a1 & 255; R[5] = (a1 >> 8) & 255; R[6] = (a1 >> 16) & 255; R[7] = a1 >> 24;     \
-        R[8] = a2 & 255;                                                                       \
+            short2v R0[5], R1[5], R2[5];
+#define LOAD_ROW(R, PTR)                                                        \
+    {                                                                           \
+        const uint32_t w0 = *reinterpret_cast<const uint32_t *>(PTR);            \
+        const uint32_t w1 = *reinterpret_cast<const uint32_t *>((PTR) + 4);      \
+        const uint32_t w2 = *reinterpret_cast<const uint32_t *>((PTR) + 8);      \
+        R[0] = as_s2(__builtin_amdgcn_perm(w1, w0, selA));                       \
+        R[1] = as_s2(__builtin_amdgcn_perm(w1, w0, selB));                       \
+        R[2] = as_s2(__builtin_amdgcn_perm(w2, w1, selA));                       \
+        R[3] = as_s2(__builtin_amdgcn_perm(w2, w1, selB));                       \
+        R[4] = as_s2(__builtin_amdgcn_perm(0u, w2, selC));                       \
     }
-            LOAD_ROW(r0, rowp)
-            LOAD_ROW(r1, rowp + FT_LW)
-            LOAD_ROW(r2, rowp + 2 * FT_LW)
+            LOAD_ROW(R0, rowp)
+            LOAD_ROW(R1, rowp + FT_LW)
+            LOAD_ROW(R2, rowp + 2 * FT_LW)
 #undef LOAD_ROW
-            (void)c;
+            short2v Sp[5], Dp[5];
+            short2v two;
+            two.x = two.y = 2;
 #pragma unroll
-            for (int j = 1; j <= 7; ++j) {
-                const int Ix = (r1[j + 1] - r1[j - 1]) * 2 + (r0[j + 1] - r0[j - 1]) + (r2[j + 1] - r2[j - 1]);
-                const int Iy = (r2[j] - r0[j]) * 2 + (r2[j - 1] - r0[j - 1]) + (r2[j + 1] - r0[j + 1]);
-                a += Ix * Ix;
-                b += Iy * Iy;
-                cc += Ix * Iy;
+            for (int k = 0; k < 5; ++k) {
+                Sp[k] = R1[k] * two + R0[k] + R2[k];
+                Dp[k] = R2[k] - R0[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                short2v Ix = Sp[k + 1] - Sp[k];
+                const short2v O = as_s2(__builtin_amdgcn_alignbit(as_u32(Dp[k + 1]), as_u32(Dp[k]), 16));
+                short2v Iy = O * two + Dp[k] + Dp[k + 1];
+                if (k == 3) {  // column 8 is outside the block
+                    Ix = as_s2(as_u32(Ix) & 0xffffu);
+                    Iy = as_s2(as_u32(Iy) & 0xffffu);
+                }
+                a = __builtin_amdgcn_sdot2(Ix, Ix, a, false);
+                b = __builtin_amdgcn_sdot2(Iy, Iy, b, false);
+                cc = __builtin_amdgcn_sdot2(Ix, Iy, cc, false);
             }
         }
-#pragma unroll
-        for (int m = 1; m <= 4; m <<= 1) {
-            a += __shfl_xor(a, m, 64);
-            b += __shfl_xor(b, m, 64);
-            cc += __shfl_xor(cc, m, 64);
-        }
+        a = group8_sum(a);
+        b = group8_sum(b);
+        cc = group8_sum(cc);
         if (act && sub == 0) {
             const float fa = (float)a, fb = (float)b, fc = (float)cc;
             const float sum = fa + fb;

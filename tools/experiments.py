@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
-"""Kernel experiments: build variant libraries (-DAFV_EXP=<n>) into gpurun_out-independent scratch dirs and time the
-extraction stages of each on the GPU.  Usage:
-   python tools/experiments.py build 0 1 2 3      (here, CPU)   -> anyfeature-vslam_amd/build_exp/libafv_exp<n>.so
-   python tools/experiments.py run 0 1 2 3        (GPU box)     -> stage times per variant
-"""
-import importlib
+"""Kernel experiments: build variant libraries (extra -D flags) next to the real one under anyfeature-vslam_amd/build_exp/ and
+time / count them on the GPU box.  Variants may produce wrong results (e.g. AFV_FAST_STOP=n ends k_fast_harris after stage n to
+attribute its cost) — this is measurement tooling, never the product.  Usage:
+  python tools/experiments.py build NAME=FLAG[,FLAG...] ...      (here or on the box)
+  python tools/experiments.py run NAME ...                        (on the box: bench --no-profile under rocprofv3 PMC)
+build_exp/ is git-ignored; delete it after use (it travels to the GPU box)."""
+import csv
+import glob
 import importlib.util
 import json
 import os
@@ -16,47 +18,46 @@ PKG = os.path.join(ROOT, "anyfeature-vslam_amd")
 EXP = os.path.join(PKG, "build_exp")
 
 
-def build(n):
+def build(name, flags):
     spec = importlib.util.spec_from_file_location("afv_build", os.path.join(PKG, "build.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    os.makedirs(EXP, exist_ok=True)
-    return mod.build(force=True, extra_flags=["-DAFV_EXP=%d" % n], out=os.path.join(EXP, "libafv_exp%d.so" % n),
-                     objdir=os.path.join(EXP, "obj%d" % n))
+    d = os.path.join(EXP, name)
+    os.makedirs(d, exist_ok=True)
+    return mod.build(extra_flags=flags, out=os.path.join(EXP, "libafv_%s.so" % name), objdir=d)
 
 
-def run_one(n, batch=256, steps=5):
-    env = dict(os.environ, AFV_LIB_PATH=os.path.join(EXP, "libafv_exp%d.so" % n))
-    code = r'''
-import importlib, sys, json
-sys.path.insert(0, %r)
-import torch
-afv = importlib.import_module("anyfeature-vslam_amd")
-B = %d
-ctx = afv.Context(max_batch=B)
-ctx.set_split_threshold(1 << 30)  # one stream: clean per-kernel times
-frames = torch.from_numpy(afv.synth.corners_batch(1, B)).cuda()
-afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
-m = afv.FeatureMatcher(0.6, True, ctx=ctx)
-pa = torch.arange(B, dtype=torch.int32, device="cuda"); pb = (pa + B - 1) %% B
-for _ in range(2):
-    out = ctx.extract_batch_device(frames); m.match_pairs_device(out[1], out[0], out[2], pa, pb, th_low=75.0)
-torch.cuda.synchronize()
-ctx.profile_enable(True)
-for _ in range(%d):
-    out = ctx.extract_batch_device(frames); mm = m.match_pairs_device(out[1], out[0], out[2], pa, pb, th_low=75.0)
-torch.cuda.synchronize()
-st = ctx.profile_read()
-print(json.dumps({k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in st.items()}), int(out[2].sum().item()), "nm_sum", int(mm[1].sum().item()), "nm_max", int(mm[1].max().item()))
-''' % (ROOT, batch, steps)
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
-    print("exp %d:" % n, (r.stdout.strip().splitlines() or [r.stderr[-400:]])[-1])
+def run(name, batch=256):
+    lib = os.path.join(EXP, "libafv_%s.so" % name) if name != "base" else os.path.join(PKG, "libafv_hip.so")
+    out = os.path.join(ROOT, "gpurun_out", "exp", name)
+    os.makedirs(out, exist_ok=True)
+    env = dict(os.environ, AFV_LIB_PATH=lib, TMPDIR="/tmp")
+    counters = os.environ.get("AFV_EXP_PMC", "SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU").split()
+    cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + counters + ["-d", out, "-o", "pmc",
+           "--output-format", "csv", "--", sys.executable, os.path.join(ROOT, "bench.py"), "--batch", str(batch), "--steps", "2", "--warmup", "1",
+           "--cpu-frames", "0", "--no-profile"]
+    subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    res = {"name": name}
+    acc, cnt = {}, {}
+    for r in csv.DictReader(open(glob.glob(os.path.join(out, "**", "pmc_counter_collection.csv"), recursive=True)[0])):
+        if "k_fast_harris" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+            cnt[r["Counter_Name"]] = cnt.get(r["Counter_Name"], 0) + 1
+    frames_per_launch = batch / 4
+    for k in acc:
+        res[k + "_per_frame"] = acc[k] / cnt[k] / frames_per_launch
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in
+         csv.DictReader(open(glob.glob(os.path.join(out, "**", "pmc_kernel_trace.csv"), recursive=True)[0])) if "k_fast_harris" in r["Kernel_Name"]]
+    res["us_per_launch"] = sum(d) / len(d)
+    res["frames_per_launch"] = frames_per_launch
+    print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":
-    cmd, ids = sys.argv[1], [int(a) for a in sys.argv[2:]]
-    for n in ids:
-        if cmd == "build":
-            print(build(n))
-        else:
-            run_one(n)
+    if sys.argv[1] == "build":
+        for a in sys.argv[2:]:
+            name, flags = a.split("=", 1)
+            print(build(name, ["-D" + f for f in flags.split(",") if f]))
+    else:
+        for a in sys.argv[2:]:
+            run(a)
