@@ -15,7 +15,7 @@
 //      to an LDS score plane (a pixel is a corner in at most one polarity: two 9-arcs of a 16-ring overlap);
 //   3. strict 3x3 maxima, dense over the score plane (again two pixels per lane, packed max), compacted into an LDS list
 //      (<= 512 per tile);
-//   4. that list is processed densely, 8 lanes per candidate: integer Harris sums a,b,c over the 7x7 block with packed
+//   4. that list is processed densely, 4 lanes per candidate: integer Harris sums a,b,c over the 7x7 block with packed
 //      i16 Sobel rows and v_dot2_i32_i16 accumulation, one float expression for the response;
 //   5. one global atomic per tile reserves output slots in the (frame, level) candidate array.
 // Candidates leave the kernel unordered; everything downstream is order-independent (ties are broken by the
@@ -34,6 +34,7 @@ typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_shr1(uint32_t v) {  // v_pk_lshrrev_b16: both 16-bit halves >> 1
     return __builtin_bit_cast(uint32_t, __builtin_bit_cast(ushort2v, v) >> (unsigned short)1);
 }
+__device__ __forceinline__ short2v pk_sar15(short2v v) { return v >> (short)15; }  // v_pk_ashrrev_i16: 0xffff where negative
 
 // ---- cross-lane helpers on DPP (no LDS round trips) ----
 #define DPP_QUAD_XOR1 0xB1       // quad_perm:[1,0,3,2]
@@ -53,11 +54,10 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_BCAST31, 0xc, 0xf, false);
     return v;
 }
-// sum over aligned groups of 8 lanes (every lane of the group receives the total)
-__device__ __forceinline__ int group8_sum(int v) {
+// sum over aligned groups of 4 lanes (every lane of the group receives the total)
+__device__ __forceinline__ int group4_sum(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, DPP_QUAD_XOR1, 0xf, 0xf, true);
     v += __builtin_amdgcn_update_dpp(0, v, DPP_QUAD_XOR2, 0xf, 0xf, true);
-    v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_HALF_MIRROR, 0xf, 0xf, true);
     return v;
 }
 
@@ -119,7 +119,7 @@ __device__ __forceinline__ short2v fast_score2(const uint8_t *c0, const uint8_t 
 __global__ __launch_bounds__(256) void k_fast_harris(const Geo *__restrict__ geo_p, FrameSrc src0, const uint8_t *__restrict__ pyr,
                                                      uint32_t *__restrict__ cand_packed, float *__restrict__ cand_resp,
                                                      int *__restrict__ cand_count, int total_blocks, int frame_base) {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[FT_LH * FT_LW + 16];  // + pad: the masked column-69 pair reads 2 bytes past row 39
+    __shared__ __attribute__((aligned(16))) uint8_t tile[(FT_LH + 1) * FT_LW + 16];  // + pad: masked pre-test positions (row 34, column 69) read up to one row + 2 bytes past row 39
     __shared__ __attribute__((aligned(16))) uint8_t sc[FT_LH * FT_LW];  // same geometry as `tile`
     __shared__ __attribute__((aligned(4))) unsigned short pre[PRE_MAX];  // bright entries from the front, dark entries from the back
     __shared__ int list_n, out_base, pre_nb, pre_nd;
@@ -166,20 +166,34 @@ __global__ __launch_bounds__(256) void k_fast_harris(const Geo *__restrict__ geo
         const int rq = tid - rs * (FT_LW / 4);
         const int gx = gx0 + rq * 4;
         const bool interior = gx >= 0 && gx + 3 < lw;
-        int xs[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) xs[k] = min(max(afv_reflect101(gx + k, lw), 0), lw - 1);
         if (rs < 14) {
+            // the three row offsets first, then the three loads back to back (one global round trip), then the LDS writes;
+            // row 28 + rs only exists for rs < 12: its load is redirected to row 39 and its write dropped
+            uint32_t roff[3], v[3];
+#pragma unroll
+            for (int k3 = 0; k3 < 3; ++k3) {
+                const int ry = min(rs + 14 * k3, FT_LH - 1);
+                const int gy = min(max(afv_reflect101(gy0 + ry, lh), 0), lh - 1);
+                roff[k3] = (uint32_t)gy * (uint32_t)pitch;
+            }
+            if (interior) {
+#pragma unroll
+                for (int k3 = 0; k3 < 3; ++k3) v[k3] = *reinterpret_cast<const uint32_t *>(img + (roff[k3] + (uint32_t)gx));
+            } else {  // left / right image edge: four reflected byte gathers per row
+                uint32_t xs[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xs[k] = (uint32_t)min(max(afv_reflect101(gx + k, lw), 0), lw - 1);
+#pragma unroll
+                for (int k3 = 0; k3 < 3; ++k3) {
+                    const uint8_t *row = img + roff[k3];
+                    v[k3] = (uint32_t)row[xs[0]] | ((uint32_t)row[xs[1]] << 8) | ((uint32_t)row[xs[2]] << 16) | ((uint32_t)row[xs[3]] << 24);
+                }
+            }
 #pragma unroll
             for (int k3 = 0; k3 < 3; ++k3) {
                 const int ry = rs + 14 * k3;
                 if (ry < FT_LH) {
-                    const int gy = min(max(afv_reflect101(gy0 + ry, lh), 0), lh - 1);
-                    const uint8_t *row = img + (size_t)gy * pitch;
-                    uint32_t v;
-                    if (interior) v = *reinterpret_cast<const uint32_t *>(row + gx);
-                    else v = (uint32_t)row[xs[0]] | ((uint32_t)row[xs[1]] << 8) | ((uint32_t)row[xs[2]] << 16) | ((uint32_t)row[xs[3]] << 24);
-                    *reinterpret_cast<uint32_t *>(&tile[ry * FT_LW + rq * 4]) = v;
+                    *reinterpret_cast<uint32_t *>(&tile[ry * FT_LW + rq * 4]) = v[k3];
                     *reinterpret_cast<uint32_t *>(&sc[ry * FT_LW + rq * 4]) = 0u;
                 }
             }
@@ -193,20 +207,17 @@ __global__ __launch_bounds__(256) void k_fast_harris(const Geo *__restrict__ geo
 #endif
     // 2a. pre-test on LDS rows 3..36 x columns 3..68 (= tile pixels -1..32 x -1..64).  Thread (pr, rg) = (tid % 34, tid / 34)
     //     owns the pixel pair at columns 2 + 2 pr, 3 + 2 pr of the rows 5 rg .. 5 rg + 4 (238 of the 256 threads): the column
-    //     never changes, so every LDS read of the unrolled loop is base + immediate.  The pass bits are the CLEAR sign bits
-    //     of (min over pairs of max(a, b)) - v - (t + 1) [bright] and v - (max over pairs of min(a, b)) - (t + 1) [dark]; they
-    //     are shifted into `fb` / `fd`: after the loop bit 15 - (PRE_ITERS - 1 - it) (pixel 0) and bit 31 - (PRE_ITERS - 1 - it)
-    //     (pixel 1) hold the FAIL flag of iteration `it`.
+    //     never changes, so every LDS read of the unrolled loop is base + immediate.  The pass flags are the sign bits of
+    //     (v + t) - (min over pairs of max(a, b)) [bright] and (max over pairs of min(a, b)) - (v - t) [dark].
     const int thr = geo.fast_threshold;
     {
         const int rg = (int)(__umul24((unsigned)tid, 1928u) >> 16);  // tid / 34 (exact for tid < 256)
         const int pr = tid - rg * PRE_PAIRS;
         const int col = 2 + 2 * pr, gx = gx0 + col;
-        uint32_t fb = 0xffffffffu, fd = 0xffffffffu;  // idle threads (tid >= 238): everything failed
+        uint32_t pb = 0, pd = 0;  // PASS flags: bit (16 - PRE_ITERS + it) = pixel 0, bit (32 - PRE_ITERS + it) = pixel 1 of iteration it
         if (rg < PRE_GROUPS) {
-            fb = fd = 0u;
-            short2v T1;
-            T1.x = T1.y = (short)(thr + 1);
+            short2v T0;
+            T0.x = T0.y = (short)thr;
             const uint8_t *c = &tile[(rg * PRE_ITERS + 3) * FT_LW + col];
             // centre row: v and the ring pixels at dx = -3 / +3 sit at ODD distances, and an unaligned LDS read stalls the LDS pipe
             // (SQ_LDS_UNALIGNED_STALL).  So the row is read as the three ALIGNED dwords that hold bytes col-4 .. col+5 and the
@@ -216,33 +227,37 @@ __global__ __launch_bounds__(256) void k_fast_harris(const Geo *__restrict__ geo
             const uint32_t sel_b = 0x0c020c01u + (uint32_t)sh * 0x00010001u;  // (col-3, col-2) out of (w1:w0)
             const uint32_t sel_v = 0x0c050c04u + (uint32_t)sh * 0x00010001u;  // (col,   col+1) out of (w1:w0)
             const uint32_t sel_a = 0x0c040c03u + (uint32_t)sh * 0x00010001u;  // (col+3, col+4) out of (w2:w1)
+            // No row test inside the loop: rows outside the FAST border of the level (and row 34 of the last row group, which
+            // reads one row past the tile into the padding) are computed like the others and masked out afterwards.
 #pragma unroll
             for (int it = 0; it < PRE_ITERS; ++it) {
-                const int r = rg * PRE_ITERS + it;
-                const int gy = gy0 + 3 + r;
-                uint32_t xb = 0x80008000u, xd = 0x80008000u;
-                if (r < PRE_ROWS && gy >= 3 && gy < lh - 3) {
-                    const int o = it * FT_LW;
-                    const uint32_t w0 = cw[o / 4], w1 = cw[o / 4 + 1], w2 = cw[o / 4 + 2];
-                    const short2v V = as_s2(__builtin_amdgcn_perm(w1, w0, sel_v));
-                    const short2v a4 = as_s2(__builtin_amdgcn_perm(w2, w1, sel_a)), b4 = as_s2(__builtin_amdgcn_perm(w1, w0, sel_b));
-                    const short2v a0 = ld_pair(c, o + RING_OFF(0, 3)), b0 = ld_pair(c, o + RING_OFF(0, -3));
-                    const short2v a2 = ld_pair(c, o + RING_OFF(2, 2)), b2 = ld_pair(c, o + RING_OFF(-2, -2));
-                    const short2v a6 = ld_pair(c, o + RING_OFF(2, -2)), b6 = ld_pair(c, o + RING_OFF(-2, 2));
-                    const short2v hi = pkmin(pkmin(pkmax(a0, b0), pkmax(a2, b2)), pkmin(pkmax(a4, b4), pkmax(a6, b6)));
-                    const short2v lo = pkmax(pkmax(pkmin(a0, b0), pkmin(a2, b2)), pkmax(pkmin(a4, b4), pkmin(a6, b6)));
-                    xb = as_u32(hi - (V + T1));
-                    xd = as_u32((V - T1) - lo);
-                }
-                fb = pk_shr1(fb) | (xb & 0x80008000u);  // halves shift independently: pixel 1's bits never reach pixel 0's
-                fd = pk_shr1(fd) | (xd & 0x80008000u);
+                const int o = it * FT_LW;
+                const uint32_t w0 = cw[o / 4], w1 = cw[o / 4 + 1], w2 = cw[o / 4 + 2];
+                const short2v V = as_s2(__builtin_amdgcn_perm(w1, w0, sel_v));
+                const short2v a4 = as_s2(__builtin_amdgcn_perm(w2, w1, sel_a)), b4 = as_s2(__builtin_amdgcn_perm(w1, w0, sel_b));
+                const short2v a0 = ld_pair(c, o + RING_OFF(0, 3)), b0 = ld_pair(c, o + RING_OFF(0, -3));
+                const short2v a2 = ld_pair(c, o + RING_OFF(2, 2)), b2 = ld_pair(c, o + RING_OFF(-2, -2));
+                const short2v a6 = ld_pair(c, o + RING_OFF(2, -2)), b6 = ld_pair(c, o + RING_OFF(-2, 2));
+                const short2v hi = pkmin(pkmin(pkmax(a0, b0), pkmax(a2, b2)), pkmin(pkmax(a4, b4), pkmax(a6, b6)));
+                const short2v lo = pkmax(pkmax(pkmin(a0, b0), pkmin(a2, b2)), pkmax(pkmin(a4, b4), pkmin(a6, b6)));
+                // (V + t) - hi < 0  <=>  hi - V > t (bright);  lo - (V - t) < 0  <=>  V - lo > t (dark): the arithmetic shift spreads
+                // the sign over the half, the iteration's bit is kept
+                const uint32_t bit = 0x00010001u << (16 - PRE_ITERS + it);
+                pb |= as_u32(pk_sar15((V + T0) - hi)) & bit;
+                pd |= as_u32(pk_sar15(lo - (V - T0))) & bit;
             }
+            // rows: iteration `it` is row r = 5 rg + it, global row gy0 + 3 + r; valid <=> r < PRE_ROWS and 3 <= gy < lh - 3
+            const int gyr = gy0 + 3 + rg * PRE_ITERS;
+            const int it_lo = max(3 - gyr, 0), it_hi = min(min(lh - 3 - gyr, PRE_ROWS - rg * PRE_ITERS), PRE_ITERS);
+            const uint32_t rowm = it_hi > it_lo ? (((1u << it_hi) - (1u << it_lo)) << (16 - PRE_ITERS)) * 0x00010001u : 0u;
+            pb &= rowm;
+            pd &= rowm;
         }
-        // pass = !fail, restricted to the iteration bits and to the columns inside the FAST border of the level
+        // columns inside the FAST border of the level (and inside the ring-extended tile)
         const uint32_t itm = (0xffffu << (16 - PRE_ITERS)) & 0xffffu;
         const uint32_t colm = ((pr > 0 && gx >= 3 && gx < lw - 3) ? itm : 0u) |
                               ((pr < PRE_PAIRS - 1 && gx + 1 >= 3 && gx + 1 < lw - 3) ? (itm << 16) : 0u);
-        const uint32_t bb = ~fb & colm, bd = ~fd & colm;
+        const uint32_t bb = pb & colm, bd = pd & colm;
         // Compaction: exclusive prefix of the per-lane survivor counts (both polarities packed in one register, one DPP scan), two
         // LDS atomics per wavefront, then every lane writes its own <= 10 + 10 entries with predicated stores (no loops, no
         // ballots).  A lane's entries are a 2 x 5 pixel block and neighbouring lanes hold neighbouring column pairs, so list
@@ -357,27 +372,34 @@ __global__ __launch_bounds__(256) void k_fast_harris(const Geo *__restrict__ geo
     if (tid == 0) out_base = atomicAdd(&cand_count[f * AFV_MAX_LEVELS + l], n);
     __syncthreads();
 
-    // 4. Harris response for the compacted candidates: 8 lanes per candidate, lane `sub` owns block row sub-3 (3 source
-    //    rows of 9 pixels -> 7 gradient pairs).  Source rows are expanded to packed u16 pairs P_k = (x[2k], x[2k+1]);
-    //    with S = r0 + 2 r1 + r2 and D = r2 - r0 per column, the gradients of columns (2k+1, 2k+2) are
+    // 4. Harris response for the compacted candidates: 4 lanes per candidate, lane q owns the block rows 2q and 2q + 1 (q = 3: row 6
+    //    only), i.e. the four source rows 2q .. 2q + 3 of the 9 x 9 window, the middle two shared by its two block rows.  A typical
+    //    tile holds ~70 candidates, so one pass of the 256 threads (64 candidates) is usually all there is.  Source rows are
+    //    expanded to packed u16 pairs P_k = (x[2k], x[2k+1]); with S = r0 + 2 r1 + r2 and D = r2 - r0 per column, the gradients
+    //    of columns (2k+1, 2k+2) are
     //      Ix = S_{k+1} - S_k,   Iy = D_k + D_{k+1} + 2 * (D_k.hi, D_{k+1}.lo),
-    //    and a, b, c accumulate with v_dot2_i32_i16.  Partial sums are combined with 3 DPP steps.
+    //    and a, b, c accumulate with v_dot2_i32_i16.  Partial sums are combined with 2 DPP steps.
     const size_t obase = L.cand_off + (size_t)f * L.cand_frame_stride + (size_t)out_base;
-    const int sub = tid & 7;
-    for (int c0 = 0; c0 < n; c0 += 32) {
-        const int ci = c0 + (tid >> 3);
+    const int q = tid & 3;
+    short2v two;
+    two.x = two.y = 2;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int ci = c0 + (tid >> 2);
         const bool act = ci < n;
         const uint32_t e = list[act ? ci : 0];
         const int px = e & 255, py = (e >> 8) & 255, s = e >> 16;
         int a = 0, b = 0, cc = 0;
-        if (act && sub < 7) {
+        if (act) {
             // 9 row bytes [x-4, x+4] start at byte `sh` of three aligned dwords (w0, w1, w2); the pair (byte sh+2k, byte sh+2k+1)
             // is picked by ONE v_perm_b32 with a lane-dependent selector: k = 0, 1 from (w1:w0), k = 2, 3 from (w2:w1) with the
             // same two selectors, k = 4 (byte sh+8, low half only) from w2
             const int xa = (px + FT_HALO - 4) & ~3, sh = (px + FT_HALO - 4) & 3;
             const uint32_t selA = 0x0c010c00u + (uint32_t)sh * 0x00010001u, selB = selA + 0x00020002u, selC = 0x0c0c0c00u + (uint32_t)sh;
-            const uint8_t *rowp = &tile[(py + FT_HALO + (sub - 3) - 1) * FT_LW + xa];
-            short2v R0[5], R1[5], R2[5];
+            // source row 2q of the window = tile row (py + HALO - 4) + 2q; the last lane's fourth row (window row 9) does not
+            // exist: it re-reads row 8 and its block row is dropped below
+            const uint8_t *rowp = &tile[(py + FT_HALO - 4 + 2 * q) * FT_LW + xa];
+            const int last = (q == 3) ? 2 * FT_LW : 3 * FT_LW;
+            short2v R0[5], R1[5], R2[5], R3[5];
 #define LOAD_ROW(R, PTR)                                                        \
     {                                                                           \
         const uint32_t w0 = *reinterpret_cast<const uint32_t *>(PTR);            \
@@ -392,33 +414,42 @@ __global__ __launch_bounds__(256) void k_fast_harris(const Geo *__restrict__ geo
             LOAD_ROW(R0, rowp)
             LOAD_ROW(R1, rowp + FT_LW)
             LOAD_ROW(R2, rowp + 2 * FT_LW)
+            LOAD_ROW(R3, rowp + last)
 #undef LOAD_ROW
-            short2v Sp[5], Dp[5];
-            short2v two;
-            two.x = two.y = 2;
+            auto block_row = [&](const short2v *r0, const short2v *r1, const short2v *r2, int &sa, int &sb, int &sc_) {
+                short2v Sp[5], Dp[5];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                Sp[k] = R1[k] * two + R0[k] + R2[k];
-                Dp[k] = R2[k] - R0[k];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                short2v Ix = Sp[k + 1] - Sp[k];
-                const short2v O = as_s2(__builtin_amdgcn_alignbit(as_u32(Dp[k + 1]), as_u32(Dp[k]), 16));
-                short2v Iy = O * two + Dp[k] + Dp[k + 1];
-                if (k == 3) {  // column 8 is outside the block
-                    Ix = as_s2(as_u32(Ix) & 0xffffu);
-                    Iy = as_s2(as_u32(Iy) & 0xffffu);
+                for (int k = 0; k < 5; ++k) {
+                    Sp[k] = r1[k] * two + r0[k] + r2[k];
+                    Dp[k] = r2[k] - r0[k];
                 }
-                a = __builtin_amdgcn_sdot2(Ix, Ix, a, false);
-                b = __builtin_amdgcn_sdot2(Iy, Iy, b, false);
-                cc = __builtin_amdgcn_sdot2(Ix, Iy, cc, false);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    short2v Ix = Sp[k + 1] - Sp[k];
+                    const short2v O = as_s2(__builtin_amdgcn_alignbit(as_u32(Dp[k + 1]), as_u32(Dp[k]), 16));
+                    short2v Iy = O * two + Dp[k] + Dp[k + 1];
+                    if (k == 3) {  // column 8 is outside the block
+                        Ix = as_s2(as_u32(Ix) & 0xffffu);
+                        Iy = as_s2(as_u32(Iy) & 0xffffu);
+                    }
+                    sa = __builtin_amdgcn_sdot2(Ix, Ix, sa, false);
+                    sb = __builtin_amdgcn_sdot2(Iy, Iy, sb, false);
+                    sc_ = __builtin_amdgcn_sdot2(Ix, Iy, sc_, false);
+                }
+            };
+            block_row(R0, R1, R2, a, b, cc);
+            int a2 = 0, b2 = 0, c2 = 0;
+            block_row(R1, R2, R3, a2, b2, c2);
+            if (q < 3) {
+                a += a2;
+                b += b2;
+                cc += c2;
             }
         }
-        a = group8_sum(a);
-        b = group8_sum(b);
-        cc = group8_sum(cc);
-        if (act && sub == 0) {
+        a = group4_sum(a);
+        b = group4_sum(b);
+        cc = group4_sum(cc);
+        if (act && q == 0) {
             const float fa = (float)a, fb = (float)b, fc = (float)cc;
             const float sum = fa + fb;
             const float resp = ((fa * fb - fc * fc) - (0.04f * sum) * sum) * geo.harris_scale4;
