@@ -194,6 +194,8 @@ extern "C" void afv_destroy(afv_ctx *c) {
     }
     for (auto &v : c->prof_ev)
         for (hipEvent_t e : v) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->pipe_ev) (void)hipEventDestroy(e);
+    if (c->stream_copy) (void)hipStreamDestroy(c->stream_copy);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -252,16 +254,13 @@ extern "C" int afv_create(int device, const afv_orb_params *params, afv_ctx **ou
     CREATE_CHK(hipMemset(c->d_sel_count, 0, (size_t)B * AFV_MAX_LEVELS * sizeof(int)));
     // staging for host-pointer calls
     c->frames_pitch = align_up((size_t)params->max_width, 64);
-    c->frames_stride = align_up(c->frames_pitch * (size_t)params->max_height + 64, 256);
-    CREATE_CHK(hipMalloc(&c->d_frames, c->frames_stride * (size_t)B));
+    c->frames_stride = align_up(c->frames_pitch * (size_t)params->max_height, 256);
+    CREATE_CHK(hipMalloc(&c->d_frames, c->frames_stride * (size_t)B + 256));  // frames back to back, one guard at the very end
     c->stage_cap = afv_max_keypoints_per_frame(c);
     CREATE_CHK(hipMalloc(&c->d_kps, (size_t)B * c->stage_cap * sizeof(afv_keypoint)));
     CREATE_CHK(hipMalloc(&c->d_desc, (size_t)B * c->stage_cap * AFV_DESC_BYTES));
     CREATE_CHK(hipMalloc(&c->d_n, (size_t)B * sizeof(int)));
     CREATE_CHK(hipMalloc(&c->d_status, sizeof(int)));
-    c->h_kps.resize((size_t)B * c->stage_cap);
-    c->h_desc.resize((size_t)B * c->stage_cap * AFV_DESC_BYTES);
-    c->h_n.resize(B);
     // quadtree node capacity: alive nodes <= max(quota + 3, 4 * n_ini)
     int M = 64;
     for (int l = 0; l < g.nlevels; ++l) M = std::max(M, g.lv[l].quota + 8);
@@ -294,6 +293,12 @@ static void profile_drain(afv_ctx *c) {
 extern "C" int afv_set_split_threshold(afv_ctx *c, int min_frames) {
     if (!c || min_frames < 2) return AFV_EINVAL;
     c->split_min_frames = min_frames;
+    return AFV_OK;
+}
+extern "C" int afv_set_pipeline_chunk(afv_ctx *c, int frames, int chunks_ahead) {
+    if (!c || frames < 1 || chunks_ahead < 1 || chunks_ahead > 64) return AFV_EINVAL;
+    c->pipe_chunk = frames;
+    c->pipe_ahead = chunks_ahead;
     return AFV_OK;
 }
 extern "C" int afv_set_split_chunks(afv_ctx *c, int chunks) {
@@ -420,40 +425,172 @@ extern "C" int afv_orb_extract_batch_device(afv_ctx *c, const uint8_t *d_frames,
                            stream ? (hipStream_t)stream : c->stream);
 }
 
+// true when `p` is page-locked host memory the DMA engines can reach directly (hipHostMalloc / hipHostRegister / torch pin_memory)
+static bool is_pinned_host(const void *p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();  // plain malloc'ed memory: "invalid value", not an error for us
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
+static int ensure_events(afv_ctx *c, size_t n) {
+    while (c->pipe_ev.size() < n) {
+        hipEvent_t e = nullptr;
+        HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->pipe_ev.push_back(e);
+    }
+    return AFV_OK;
+}
+
+// Host-buffer batch (the vocabulary-builder shape, createVocabulary.cpp:161-174), software-pipelined over chunks of frames:
+//   copy lane     ... D2H(k-1), H2D(k+1), D2H(k), H2D(k+2) ...   (one stream: the two directions do not overlap each other)
+//   compute       pyramid .. describe of chunk k (alternating over the context's two streams)
+// Page-locked caller memory is DMA'd in place (frames in, keypoints / descriptors out); pageable memory goes through the
+// context's pinned arena with one CPU memcpy each way.  Results are identical to the serial path (same kernels, same chunks).
 extern "C" int afv_orb_extract_batch(afv_ctx *c, const uint8_t *const *frames, int nframes, int width, int height,
                                      int stride_bytes, afv_keypoint *kps, uint8_t *desc32, int cap_per_frame, int *n_out) {
     if (!c || !frames || !kps || !desc32 || !n_out) return AFV_EINVAL;
     if (nframes < 1 || nframes > c->p.max_batch || cap_per_frame < 1 || stride_bytes < width) return AFV_EINVAL;
+    for (int f = 0; f < nframes; ++f)
+        if (!frames[f]) return AFV_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
     int rc = set_geometry(c, width, height);
     if (rc) return rc;
-    for (int f = 0; f < nframes; ++f) {
-        if (!frames[f]) return AFV_EINVAL;
-        HIPCHK(c, hipMemcpy2DAsync(c->d_frames + (size_t)f * c->frames_stride, c->frames_pitch, frames[f], (size_t)stride_bytes,
-                                   (size_t)width, (size_t)height, hipMemcpyHostToDevice, c->stream));
-    }
-    FrameSrc src{c->d_frames, (int)c->frames_pitch, c->frames_stride};
-    rc = enqueue_extract(c, src, nframes, c->d_kps, c->d_desc, c->stage_cap, c->d_n, c->d_status, c->stream);
-    if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->h_n.data(), c->d_n, (size_t)nframes * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_kps.data(), c->d_kps, (size_t)nframes * c->stage_cap * sizeof(afv_keypoint),
-                             hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_desc.data(), c->d_desc, (size_t)nframes * c->stage_cap * AFV_DESC_BYTES,
-                             hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    int result = AFV_OK;
-    for (int f = 0; f < nframes; ++f) {
-        int n = c->h_n[f];
-        if (n > cap_per_frame) {
-            n = cap_per_frame;
-            result = AFV_ECAPACITY;
+    return guarded(c, [&]() -> int {
+        // device staging layout for THIS geometry: frames back to back when the row pitch allows it (one DMA per chunk)
+        const size_t pitch = align_up((size_t)width, 64);
+        const size_t fstride = align_up(pitch * (size_t)height, 256);
+        FrameSrc src{c->d_frames, (int)pitch, fstride};
+        const int CH = nframes >= 2 * c->pipe_chunk ? c->pipe_chunk : nframes;  // small batches: one chunk (plugin path: 1 frame)
+        const int nchunks = (nframes + CH - 1) / CH;
+        rc = ensure_events(c, (size_t)nchunks * 3);
+        if (rc) return rc;
+        const bool out_direct = is_pinned_host(kps) && is_pinned_host(desc32) && cap_per_frame >= 1;
+        const int ocap = std::min(cap_per_frame, c->stage_cap);
+        // pinned arena: [pageable frames of the chunks in flight][n][kps][desc] (only what is not DMA'd in place)
+        bool all_pinned_in = true;
+        for (int f = 0; f < nframes && all_pinned_in; f += CH) all_pinned_in = is_pinned_host(frames[f]);
+        HostImage arena{c};
+        const size_t frame_bytes = (size_t)width * height;
+        const size_t in_off = 0, in_bytes = all_pinned_in ? 0 : frame_bytes * (size_t)nframes;
+        const size_t n_off = align_up(in_off + in_bytes, 64), n_bytes = (size_t)nframes * sizeof(int);
+        const size_t k_off = align_up(n_off + n_bytes, 64), k_bytes = out_direct ? 0 : (size_t)nframes * c->stage_cap * sizeof(afv_keypoint);
+        const size_t d_off = align_up(k_off + k_bytes, 64), d_bytes = out_direct ? 0 : (size_t)nframes * c->stage_cap * AFV_DESC_BYTES;
+        arena.resize(d_off + d_bytes, false);
+        uint8_t *hb = arena.data();
+        // one chunk (the single-frame plugin path): everything on the context's stream, no cross-stream hand-offs
+        hipStream_t s_copy = c->stream, s_back = c->stream;
+        if (nchunks > 1) {
+            if (!c->stream_copy) HIPCHK(c, hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
+            s_copy = s_back = c->stream_copy;
         }
-        n_out[f] = n;
-        std::memcpy(kps + (size_t)f * cap_per_frame, c->h_kps.data() + (size_t)f * c->stage_cap, (size_t)n * sizeof(afv_keypoint));
-        std::memcpy(desc32 + (size_t)f * cap_per_frame * AFV_DESC_BYTES, c->h_desc.data() + (size_t)f * c->stage_cap * AFV_DESC_BYTES,
-                    (size_t)n * AFV_DESC_BYTES);
-    }
-    return result;
+        HIPCHK(c, hipMemsetAsync(c->d_status, 0, sizeof(int), c->stream));
+        if (nchunks > 1) {
+            HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+            HIPCHK(c, hipStreamWaitEvent(s_copy, c->ev_fork, 0));  // earlier work of this context that still reads d_frames
+        }
+        // H2D of chunk k (on the copy lane; the single-chunk case runs everything on the context's stream)
+        auto upload = [&](int k) -> int {
+            const int f0 = k * CH, nf = std::min(CH, nframes - f0);
+            bool contiguous = (size_t)stride_bytes == (size_t)width && pitch == (size_t)width && fstride == frame_bytes;
+            for (int f = f0 + 1; f < f0 + nf && contiguous; ++f) contiguous = frames[f] == frames[f - 1] + frame_bytes;
+            const bool pinned_in = all_pinned_in;
+            if (!pinned_in) {  // pageable source: gather the chunk into the pinned arena (tight rows), then DMA from there
+                for (int f = f0; f < f0 + nf; ++f)
+                    for (int y = 0; y < height; ++y)
+                        std::memcpy(hb + in_off + (size_t)f * frame_bytes + (size_t)y * width, frames[f] + (size_t)y * stride_bytes, (size_t)width);
+            }
+            if (pinned_in && contiguous) {
+                HIPCHK(c, hipMemcpyAsync(c->d_frames + (size_t)f0 * fstride, frames[f0], frame_bytes * (size_t)nf, hipMemcpyHostToDevice, s_copy));
+            } else if (!pinned_in && pitch == (size_t)width && fstride == frame_bytes) {
+                HIPCHK(c, hipMemcpyAsync(c->d_frames + (size_t)f0 * fstride, hb + in_off + (size_t)f0 * frame_bytes, frame_bytes * (size_t)nf,
+                                         hipMemcpyHostToDevice, s_copy));
+            } else {
+                for (int f = f0; f < f0 + nf; ++f) {
+                    const uint8_t *sp = pinned_in ? frames[f] : hb + in_off + (size_t)f * frame_bytes;
+                    const size_t spitch = pinned_in ? (size_t)stride_bytes : (size_t)width;
+                    HIPCHK(c, hipMemcpy2DAsync(c->d_frames + (size_t)f * fstride, pitch, sp, spitch, (size_t)width, (size_t)height,
+                                               hipMemcpyHostToDevice, s_copy));
+                }
+            }
+            if (nchunks > 1) HIPCHK(c, hipEventRecord(c->pipe_ev[3 * k], s_copy));
+            return AFV_OK;
+        };
+        // Both directions share ONE copy lane: concurrent H2D + D2H halves each direction on this platform (measured 56 GB/s one
+        // way, 24 + 24 GB/s both ways), so the lane carries H2D(k+AHEAD) behind D2H(k): uploads stay AHEAD chunks ahead of the compute.
+        const int AHEAD = std::max(c->pipe_ahead, 1);
+        for (int k = 0; k < std::min(AHEAD, nchunks); ++k) {
+            rc = upload(k);
+            if (rc) return rc;
+        }
+        for (int k = 0; k < nchunks; ++k) {
+            const int f0 = k * CH, nf = std::min(CH, nframes - f0);
+            hipEvent_t e_in = c->pipe_ev[3 * k], e_done = c->pipe_ev[3 * k + 1], e_out = c->pipe_ev[3 * k + 2];
+            // ---- compute ----
+            hipStream_t cs = (k & 1) ? c->stream2 : c->stream;
+            if (nchunks > 1) HIPCHK(c, hipStreamWaitEvent(cs, e_in, 0));
+            enqueue_range(c, src, f0, nf, c->d_kps, c->d_desc, c->stage_cap, c->d_n, c->d_status, cs);
+            // ---- D2H ----
+            if (nchunks > 1) {
+                HIPCHK(c, hipEventRecord(e_done, cs));
+                HIPCHK(c, hipStreamWaitEvent(s_back, e_done, 0));
+            }
+            HIPCHK(c, hipMemcpyAsync(hb + n_off + (size_t)f0 * sizeof(int), c->d_n + f0, (size_t)nf * sizeof(int), hipMemcpyDeviceToHost, s_back));
+            if (out_direct && cap_per_frame == c->stage_cap) {  // same row length on both sides: two plain DMA transfers
+                HIPCHK(c, hipMemcpyAsync(kps + (size_t)f0 * cap_per_frame, c->d_kps + (size_t)f0 * c->stage_cap,
+                                         (size_t)nf * c->stage_cap * sizeof(afv_keypoint), hipMemcpyDeviceToHost, s_back));
+                HIPCHK(c, hipMemcpyAsync(desc32 + (size_t)f0 * cap_per_frame * AFV_DESC_BYTES, c->d_desc + (size_t)f0 * c->stage_cap * AFV_DESC_BYTES,
+                                         (size_t)nf * c->stage_cap * AFV_DESC_BYTES, hipMemcpyDeviceToHost, s_back));
+            } else if (out_direct) {
+                HIPCHK(c, hipMemcpy2DAsync(kps + (size_t)f0 * cap_per_frame, (size_t)cap_per_frame * sizeof(afv_keypoint),
+                                           c->d_kps + (size_t)f0 * c->stage_cap, (size_t)c->stage_cap * sizeof(afv_keypoint),
+                                           (size_t)ocap * sizeof(afv_keypoint), (size_t)nf, hipMemcpyDeviceToHost, s_back));
+                HIPCHK(c, hipMemcpy2DAsync(desc32 + (size_t)f0 * cap_per_frame * AFV_DESC_BYTES, (size_t)cap_per_frame * AFV_DESC_BYTES,
+                                           c->d_desc + (size_t)f0 * c->stage_cap * AFV_DESC_BYTES, (size_t)c->stage_cap * AFV_DESC_BYTES,
+                                           (size_t)ocap * AFV_DESC_BYTES, (size_t)nf, hipMemcpyDeviceToHost, s_back));
+            } else {
+                HIPCHK(c, hipMemcpyAsync(hb + k_off + (size_t)f0 * c->stage_cap * sizeof(afv_keypoint), c->d_kps + (size_t)f0 * c->stage_cap,
+                                         (size_t)nf * c->stage_cap * sizeof(afv_keypoint), hipMemcpyDeviceToHost, s_back));
+                HIPCHK(c, hipMemcpyAsync(hb + d_off + (size_t)f0 * c->stage_cap * AFV_DESC_BYTES, c->d_desc + (size_t)f0 * c->stage_cap * AFV_DESC_BYTES,
+                                         (size_t)nf * c->stage_cap * AFV_DESC_BYTES, hipMemcpyDeviceToHost, s_back));
+            }
+            HIPCHK(c, hipEventRecord(e_out, s_back));
+            if (k + AHEAD < nchunks) {
+                rc = upload(k + AHEAD);
+                if (rc) return rc;
+            }
+        }
+        HIPCHK(c, hipGetLastError());
+        c->last_src = src;
+        c->last_nframes = nframes;
+        // ---- hand the chunks over as they complete ----
+        int result = AFV_OK;
+        for (int k = 0; k < nchunks; ++k) {
+            const int f0 = k * CH, nf = std::min(CH, nframes - f0);
+            HIPCHK(c, hipEventSynchronize(c->pipe_ev[3 * k + 2]));
+            const int *hn = reinterpret_cast<const int *>(hb + n_off);
+            for (int f = f0; f < f0 + nf; ++f) {
+                int n = hn[f];
+                if (n > cap_per_frame) {
+                    n = cap_per_frame;
+                    result = AFV_ECAPACITY;
+                }
+                n_out[f] = n;
+                if (!out_direct) {
+                    std::memcpy(kps + (size_t)f * cap_per_frame, hb + k_off + (size_t)f * c->stage_cap * sizeof(afv_keypoint), (size_t)n * sizeof(afv_keypoint));
+                    std::memcpy(desc32 + (size_t)f * cap_per_frame * AFV_DESC_BYTES, hb + d_off + (size_t)f * c->stage_cap * AFV_DESC_BYTES,
+                                (size_t)n * AFV_DESC_BYTES);
+                }
+            }
+        }
+        // the context's streams are idle again (the next call may overwrite d_frames)
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream2));
+        return result;
+    });
 }
 
 extern "C" int afv_orb_extract(afv_ctx *c, const uint8_t *gray, int width, int height, int stride_bytes, afv_keypoint *kps,

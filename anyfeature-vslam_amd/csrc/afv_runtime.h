@@ -93,6 +93,10 @@ struct afv_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // second lane for split batches (latency-bound kernels overlap VALU-bound ones)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t stream_copy = nullptr;                         // copy lane of the host-buffer batch pipeline (created on first use)
+    std::vector<hipEvent_t> pipe_ev;                           // 3 events per chunk in flight
+    int pipe_chunk = 64;                                       // frames per pipeline chunk
+    int pipe_ahead = 8;                                        // uploads run this many chunks ahead of the compute
     int split_min_frames = 64;     // batches of at least this many frames / pairs are split over the two streams
     int split_chunks = 4;          // ... into this many chunks (alternating streams); afv_set_split_chunks
     afv_orb_params p{};
@@ -117,9 +121,6 @@ struct afv_ctx {
     uint8_t *d_desc = nullptr;
     int *d_n = nullptr, *d_status = nullptr;
     int stage_cap = 0;
-    std::vector<afv_keypoint> h_kps;
-    std::vector<uint8_t> h_desc;
-    std::vector<int> h_n;
     // matcher staging (grow only)
     uint8_t *d_match = nullptr;
     size_t match_bytes = 0;

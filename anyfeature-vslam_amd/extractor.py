@@ -125,6 +125,22 @@ class Context:
         self.check(rc, "afv_orb_extract_batch")
         return [(kps[i, :n[i]].copy(), desc[i, :n[i]].copy()) for i in range(nf)]
 
+    def extract_batch_host(self, frames, kps, desc, n_out, cap=None):
+        """afv_orb_extract_batch on caller-owned HOST buffers without any Python-side copies: frames uint8 [B,H,W] (numpy array or
+        CPU torch tensor, rows contiguous), kps float32 [B,cap,7], desc uint8 [B,cap,32], n_out int32 [B].  Page-locked buffers
+        (torch pin_memory) are DMA'd in place by the library's chunk pipeline; pageable ones go through its pinned arena."""
+        def addr(a):
+            return a.data_ptr() if hasattr(a, "data_ptr") else a.ctypes.data
+        B, H, W = frames.shape
+        cap = cap or kps.shape[1]
+        row = frames.stride(1) if hasattr(frames, "stride") else frames.strides[1]
+        fst = (frames.stride(0) if hasattr(frames, "stride") else frames.strides[0])
+        base = addr(frames)
+        arr = (C.c_void_p * B)(*[base + f * fst for f in range(B)])
+        rc = self.lib.afv_orb_extract_batch(self.handle, arr, B, W, H, row, C.c_void_p(addr(kps)), C.c_void_p(addr(desc)), cap,
+                                            C.c_void_p(addr(n_out)))
+        self.check(rc, "afv_orb_extract_batch")
+
     def extract_batch_device(self, frames, kps=None, desc=None, n_out=None, status=None, cap=None, stream=None):
         """frames: CUDA uint8 tensor [B,H,W] (contiguous rows, 4-byte aligned strides).  Returns device tensors
         (kps float32 [B,cap,7] viewable as afv_keypoint, desc uint8 [B,cap,32], n int32 [B], status int32 [1]).
@@ -168,6 +184,9 @@ class Context:
 
     def set_split_threshold(self, min_frames):
         self.check(self.lib.afv_set_split_threshold(self.handle, int(min_frames)))
+
+    def set_pipeline_chunk(self, frames, chunks_ahead=8):
+        self.check(self.lib.afv_set_pipeline_chunk(self.handle, int(frames), int(chunks_ahead)))
 
     def set_split_chunks(self, chunks):
         self.check(self.lib.afv_set_split_chunks(self.handle, int(chunks)))

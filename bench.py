@@ -93,7 +93,9 @@ def cpu_baseline(afv, nframes, seed0):
                 break
     except Exception:
         pass
-    frames = [afv.synth.corners_frame(seed0 + i) for i in range(nframes)]
+    reps = 5                                                    # 1 warm-up + >= 5 repetitions, median
+    per_rep = max(nframes // (2 * reps), 2)
+    frames = [afv.synth.corners_frame(seed0 + i) for i in range(per_rep)]
     oracle.orb_extract(frames[0])  # warm-up
 
     def run(variant, fr):
@@ -109,14 +111,17 @@ def cpu_baseline(afv, nframes, seed0):
         dt = time.perf_counter() - t0
         return nk / dt, dt
 
-    half = max(nframes // 2, 1)
-    va, ta = run(1, frames[:half])
-    vb, tb = run(0, frames[half:] or frames[:half])
+    ra = sorted(run(1, frames) for _ in range(reps))
+    rb = sorted(run(0, frames) for _ in range(reps))
+    va, ta = ra[reps // 2]
+    vb, tb = rb[reps // 2]
     return {"value": va, "unit": "keypoints/s", "cores": 1, "kind": "port", "dedup_value": vb,
-            "sample": "variant A (reference call pattern): %d frames 640x480 corners in %.1f s; variant B (de-duplicated): %d frames "
-                      "in %.1f s; extraction + brute-force match vs previous frame; 1 thread pinned; host %s, %d logical cores"
-                      % (half, ta, len(frames[half:] or frames[:half]), tb, cpu, os.cpu_count() or 0),
-            "ms_per_frame": 1e3 * ta / half, "dedup_ms_per_frame": 1e3 * tb / max(len(frames[half:] or frames[:half]), 1)}
+            "min": ra[0][0], "max": ra[-1][0], "repetitions": reps,
+            "sample": "median of %d repetitions over the same %d frames 640x480 corners (%.1f s each): variant A = reference call pattern "
+                      "(1 detect pyramid + 8 compute passes); dedup_value = variant B (8 builds, 8 blurs, %.1f s per repetition); extraction + "
+                      "brute-force match vs previous frame; 1 thread pinned; host %s, %d logical cores"
+                      % (reps, per_rep, ta, tb, cpu, os.cpu_count() or 0),
+            "ms_per_frame": 1e3 * ta / per_rep, "dedup_ms_per_frame": 1e3 * tb / per_rep}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -432,6 +437,75 @@ def valu_calibration():
     return {"peak": 1024 * 2.4e9 / 4, "source": "nominal: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction"}
 
 
+
+def host_fed(afv, ctx, frames_h, steps, dev_extract_fps):
+    """the reference's real boundary (host images in, host keypoints / descriptors out: FeatureExtractor.cpp:111-129,
+    createVocabulary.cpp:161-174) through afv_orb_extract_batch's chunk pipeline, extraction only.  Page-locked and pageable
+    caller memory; PCIe bytes = frames in + keypoints / descriptors / counts out."""
+    import torch
+    B = frames_h.shape[0]
+    cap = ctx.cap
+    out = {}
+    for kind in ("pinned", "pageable"):
+        fr = torch.from_numpy(frames_h)
+        kps = torch.zeros((B, cap, 7), dtype=torch.float32)
+        desc = torch.zeros((B, cap, 32), dtype=torch.uint8)
+        n = torch.zeros((B,), dtype=torch.int32)
+        if kind == "pinned":
+            fr, kps, desc, n = fr.pin_memory(), kps.pin_memory(), desc.pin_memory(), n.pin_memory()
+        ctx.extract_batch_host(fr, kps, desc, n)      # warm-up (arena / events / streams)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.extract_batch_host(fr, kps, desc, n)
+        dt = (time.perf_counter() - t0) / steps
+        nbytes = B * frames_h.shape[1] * frames_h.shape[2] + B * (cap * 60 + 4)
+        out[kind] = {"frames_per_s": B / dt, "ms_per_batch": dt * 1e3, "pcie_GBps": nbytes / dt / 1e9, "frac_of_63GBps": nbytes / dt / 63e9,
+                     "keypoints": int(n.sum())}
+    out["device_resident_extract_frames_per_s"] = dev_extract_fps
+    out["pinned_vs_device_resident"] = out["pinned"]["frames_per_s"] / dev_extract_fps
+    out["note"] = "extraction only (the host API returns descriptors to the host; matching them is a second call); batch of %d frames in chunks of 64" % B
+    return out
+
+
+def batch_sweep(afv, device, sizes=(1, 64, 256, 1024)):
+    """SURVEY.md 8d batch sizes: the full step (extract + describe + match t vs t-1), device-resident, a few steps each"""
+    import torch
+    res = {}
+    for B in sizes:
+        ctx = afv.Context(max_batch=B, device=device)
+        m = afv.FeatureMatcher(0.6, True, ctx=ctx)
+        frames = torch.from_numpy(afv.synth.corners_batch(1, min(B, 64), W, H)).cuda(device)
+        if B > 64:
+            frames = frames.repeat((B + 63) // 64, 1, 1)[:B].contiguous()
+        cap = ctx.cap
+        kps = torch.empty((B, cap, 7), dtype=torch.float32, device=frames.device)
+        desc = torch.empty((B, cap, 32), dtype=torch.uint8, device=frames.device)
+        n = torch.empty((B,), dtype=torch.int32, device=frames.device)
+        st = torch.zeros((1,), dtype=torch.int32, device=frames.device)
+        match = torch.empty((B, cap), dtype=torch.int32, device=frames.device)
+        nm = torch.empty((B,), dtype=torch.int32, device=frames.device)
+        pa = torch.arange(B, dtype=torch.int32, device=frames.device)
+        pb = (pa + (B - 1)) % B
+        side = torch.cuda.Stream(frames.device)
+
+        def step():
+            with torch.cuda.stream(side):
+                ctx.extract_batch_device(frames, kps, desc, n, st, cap)
+                m.match_pairs_device(desc, kps, n, pa, pb, th_low=75.0, check_orientation=True, match=match, nmatches=nm)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        reps = 40 if B == 1 else (10 if B <= 256 else 4)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        res[str(B)] = {"ms_per_step": dt * 1e3, "keypoints_per_s": float(n.sum().item()) / dt}
+        ctx.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -440,6 +514,7 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="frames per GPU per step")
     ap.add_argument("--cpu-frames", type=int, default=256, help="frames in the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage hipEvents")
+    ap.add_argument("--no-extras", action="store_true", help="skip the host-fed pipeline figure and the batch-size sweep (N = 1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
                                                       "multi-rank control flow on a 1-GPU box)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
@@ -575,6 +650,17 @@ def main():
                                              "frames/s vs the measured integer-VALU issue peak (tools/calib_valu.hip) - the bound that actually "
                                              "limits this integer/byte path"}
             out["stage_ms_per_step"] = {kk: (v["total_ms"] / args.steps) for kk, v in stages.items()}  # overlapping streams: sums exceed ms_per_step
+        if world == 1 and not args.no_extras:
+            # extraction alone, device-resident (the yardstick of the host-fed pipeline)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(max(args.steps // 2, 2)):
+                with torch.cuda.stream(side):
+                    ctx.extract_batch_device(frames, kps, desc, n_out, status, cap)
+            barrier()
+            dev_fps = B * max(args.steps // 2, 2) / (time.perf_counter() - t1)
+            out["host_fed"] = host_fed(afv, ctx, frames.cpu().numpy(), max(args.steps // 4, 2), dev_fps)
+            out["batch_sweep"] = batch_sweep(afv, local)
         if args.cpu_frames > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(afv, args.cpu_frames, seed0)
         elif args.cpu_frames > 0:

@@ -74,7 +74,11 @@ void *afv_stream(afv_ctx *ctx); /* the context's hipStream_t (for callers that e
 int afv_orb_extract(afv_ctx *ctx, const uint8_t *gray, int width, int height, int stride_bytes,
                     afv_keypoint *kps, uint8_t *desc32, int cap, int *n_out);
 
-/* ---- extraction: host-buffer batch (vocabulary builder shape, createVocabulary.cpp:161-174) ---- */
+/* ---- extraction: host-buffer batch (vocabulary builder shape, createVocabulary.cpp:161-174).  frames[f] = row-major gray image
+ * with stride_bytes between rows; outputs kps[nframes][cap_per_frame], desc32[nframes][cap_per_frame][32], n_out[nframes].
+ * Batches of at least two pipeline chunks are software-pipelined (upload of the next chunks / compute / download of the
+ * finished chunk overlap).  Page-locked caller buffers (hipHostMalloc, hipHostRegister) are DMA'd in place — entries of a row beyond
+ * n_out[f] are then unspecified; pageable buffers are staged through the context's pinned arena. ---- */
 int afv_orb_extract_batch(afv_ctx *ctx, const uint8_t *const *frames, int nframes, int width, int height,
                           int stride_bytes, afv_keypoint *kps, uint8_t *desc32, int cap_per_frame, int *n_out);
 
@@ -305,6 +309,9 @@ int afv_profile_read(afv_ctx *ctx, int32_t *launches /*[AFV_NUM_STAGES]*/, float
  * one half overlap the VALU-bound ones of the other (default 64; 0x7fffffff disables the split) */
 int afv_set_split_threshold(afv_ctx *ctx, int min_frames);
 int afv_set_split_chunks(afv_ctx *ctx, int chunks); /* ... into this many chunks alternating over the two streams (default 4) */
+/* afv_orb_extract_batch pipelines H2D / compute / D2H over chunks of `frames` frames with the uploads `chunks_ahead` chunks ahead of
+ * the compute (defaults 64 and 8; batches below two chunks run as one) */
+int afv_set_pipeline_chunk(afv_ctx *ctx, int frames, int chunks_ahead);
 
 /* ---- stage-level introspection of the LAST afv_orb_extract* call (parity tests / profiling) ---- */
 typedef struct {

@@ -195,6 +195,38 @@ def test_strided_input_and_batch(gpu_ctx, oracle, afv):
     assert kps.tobytes() == res[0][0].tobytes() and np.array_equal(desc, res[0][1])
 
 
+@pytest.mark.parametrize("pinned", [False, True])
+def test_host_batch_pipeline_chunks(afv, oracle, pinned):
+    """afv_orb_extract_batch pipelines batches >= 128 frames in chunks of 64 (H2D of chunk k+1 / compute of k / D2H of k-1 on
+    separate streams); page-locked caller buffers are DMA'd in place, pageable ones go through the pinned arena.  Every frame
+    must equal the single-frame path / the oracle, for both kinds of memory and for a ragged last chunk."""
+    import torch
+    nf = 150                                  # 64 + 64 + 22
+    ctx = afv.Context(max_batch=nf)
+    uniq = [afv.synth.corners_frame(400 + i) for i in range(6)] + [afv.synth.constant_frame(90)]
+    ref = [oracle.orb_extract(u) for u in uniq]
+    frames = torch.from_numpy(np.stack([uniq[i % 7] for i in range(nf)]))
+    cap = ctx.cap
+    kps = torch.zeros((nf, cap, 7), dtype=torch.float32)
+    desc = torch.zeros((nf, cap, 32), dtype=torch.uint8)
+    n = torch.zeros((nf,), dtype=torch.int32)
+    if pinned:
+        frames, kps, desc, n = frames.pin_memory(), kps.pin_memory(), desc.pin_memory(), n.pin_memory()
+    for rep in range(2):                      # second call reuses the arena / events
+        ctx.extract_batch_host(frames, kps, desc, n)
+        kn, dn, nn = kps.numpy(), desc.numpy(), n.numpy()
+        for i in range(nf):
+            rk, rd = ref[i % 7]
+            assert nn[i] == len(rk), (pinned, rep, i)
+            assert kn[i, :nn[i]].reshape(-1).view(afv.KP_DTYPE).tobytes() == rk.tobytes() and np.array_equal(dn[i, :nn[i]], rd), (pinned, rep, i)
+    # the list-of-arrays wrapper (pageable numpy frames with a row stride) goes through the same entry point
+    base = np.zeros((480, 704), np.uint8)
+    base[:, :640] = uniq[2]
+    res = ctx.extract_batch([base[:, :640], uniq[3]])
+    assert res[1][0].tobytes() == ref[3][0].tobytes() and np.array_equal(res[0][1], ref[2][1])
+    ctx.close()
+
+
 def test_device_resident_batch_matches_host_path(gpu_ctx, afv):
     import torch
     frames = np.stack([afv.synth.corners_frame(40 + i) for i in range(6)])
