@@ -44,29 +44,43 @@ def level_pixels(w, h, nlevels=8, scale=1.2):
     return tot
 
 
-def pmc_traffic(kernel, batch):
-    """HBM bytes per FRAME of `kernel` from the committed rocprofv3 PMC passes (profiles/r*/traffic_pmc.json: FETCH_SIZE
-    and WRITE_SIZE collected in separate passes and corrected as MI355X_MICROARCH.md prescribes); None if no pass was
-    taken at this batch size.  PMC counters cannot be read from inside a normal run."""
+def _csrc_sha():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from csrc_sha import csrc_sha
+        return csrc_sha(ROOT)
+    except Exception:
+        return None
+
+
+def _newest_profile(name):
+    """newest committed profiles/r*/<name> (collected by tools/collect_profiles.sh) and whether it still matches the sources:
+    every such file carries the sha of csrc/ + include/ it was measured on"""
     import glob
-    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic_pmc.json")), reverse=True):
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)), reverse=True):
         try:
             d = json.load(open(p))
-            if kernel in d["kernels"]:  # per-frame figure: independent of the batch size
-                return d["kernels"][kernel]["hbm_bytes_per_frame"]
         except Exception:
-            pass
+            continue
+        sha = _csrc_sha()
+        d["_path"] = os.path.relpath(p, ROOT)
+        d["_stale"] = (d.get("csrc_sha") is None) or (sha is not None and d.get("csrc_sha") != sha)
+        return d
     return None
+
+
+def pmc_traffic(kernel, batch):
+    """HBM bytes per FRAME of `kernel` from the newest committed rocprofv3 PMC passes (profiles/r*/traffic_pmc.json: FETCH_SIZE
+    and WRITE_SIZE collected in separate passes and corrected as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read
+    from inside a normal run, so the figure is only valid for the source tree it was collected on: (None, path) when stale."""
+    d = _newest_profile("traffic_pmc.json")
+    if d is None or kernel not in d.get("kernels", {}):
+        return None, None, False
+    return d["kernels"][kernel]["hbm_bytes_per_frame"], d["_path"], d["_stale"]
 
 
 def valu_pmc():
-    import glob
-    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "valu_pmc.json")), reverse=True):
-        try:
-            return json.load(open(p))
-        except Exception:
-            pass
-    return None
+    return _newest_profile("valu_pmc.json")
 
 
 def cpu_baseline(afv, nframes, seed0):
@@ -627,15 +641,17 @@ def main():
                 ms = fh["total_ms"] / fh["launches"]                 # mean launch duration (hipEvents on the launch stream)
                 frames_per_launch = fh["units"] / fh["launches"]     # the runtime splits a batch over two streams
                 achieved = px * frames_per_launch / (ms * 1e-3) / 1e9
-                traffic = pmc_traffic("k_fast_harris", B)
+                traffic, tpath, tstale = pmc_traffic("k_fast_harris", B)
                 out["roofline"] = {"bound": "hbm", "kernel": "k_fast_harris", "achieved": achieved, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                   "traffic": None if traffic is None else traffic * frames_per_launch,
+                                   "traffic": None if (traffic is None or tstale) else traffic * frames_per_launch,
+                                   "traffic_source": tpath, "traffic_stale": bool(tstale),
                                    "algorithmic_bytes_per_launch": px * frames_per_launch, "avg_launch_ms": ms,
                                    "frames_per_launch": frames_per_launch,
                                    "note": "integer-VALU-bound kernel (FAST ring tests + Harris): the HBM fraction is low by "
                                            "construction; the runtime runs a step as four quarter-batch launches per kernel over two "
-                                           "streams, so a launch shares the chip with the other stream's kernels (DESIGN.md section 4)"}
+                                           "streams, so a launch shares the chip with the other stream's kernels (DESIGN.md section 4); "
+                                           "traffic = committed PMC pass, null when the sources changed since (traffic_stale)"}
             # whole-pipeline algorithmic bytes (resize 1 569 878 + FAST read 950 532 + blur 1 901 064 + outputs
             # 60 000 = 4 481 534 B per 640x480 frame; the blur never touches HBM here, the figure is the reference's data flow)
             out["roofline_pipeline"] = {"bound": "hbm", "achieved": out["frames_per_s"] * 4481534 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -643,12 +659,14 @@ def main():
                                         "algorithmic_bytes_per_frame": 4481534}
             vp = valu_pmc()
             if vp:
+                stale = bool(vp["_stale"])
                 ach = vp["valu_winst_per_frame_total"] * out["frames_per_s"]
-                out["valu_issue"] = {"achieved": ach, "peak": vp["valu_peak_winst_per_s"], "unit": "wave-instr/s",
-                                     "frac": ach / vp["valu_peak_winst_per_s"],
-                                     "note": "whole pipeline: SQ_INSTS_VALU per frame (committed PMC pass, profiles/r*/valu_pmc.json) x measured "
-                                             "frames/s vs the measured integer-VALU issue peak (tools/calib_valu.hip) - the bound that actually "
-                                             "limits this integer/byte path"}
+                out["valu_issue"] = {"achieved": None if stale else ach, "peak": vp["valu_peak_winst_per_s"], "unit": "wave-instr/s",
+                                     "frac": None if stale else ach / vp["valu_peak_winst_per_s"], "stale": stale, "source": vp["_path"],
+                                     "kernels_winst_per_frame": {k: v["valu_winst_per_frame"] for k, v in vp["kernels"].items()},
+                                     "note": "whole pipeline: SQ_INSTS_VALU per frame (committed PMC pass of tools/collect_profiles.sh, stamped with the "
+                                             "sha of the sources it ran on) x live frames/s vs the integer-VALU issue peak measured by tools/calib_valu.hip "
+                                             "on the same box; stale = the sources changed since the pass, the fraction is withheld"}
             out["stage_ms_per_step"] = {kk: (v["total_ms"] / args.steps) for kk, v in stages.items()}  # overlapping streams: sums exceed ms_per_step
         if world == 1 and not args.no_extras:
             # extraction alone, device-resident (the yardstick of the host-fed pipeline)

@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed) {
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                if (OP == 0) a[i] = a[i] + b;
+                if (OP == 0) a[i] = a[i] + a[(i + 3) & 7];  // not foldable into one multiply-add
                 if (OP == 1) { short2v x = __builtin_bit_cast(short2v, a[i]), y = __builtin_bit_cast(short2v, b); a[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(x, y)) + 1u; }
                 if (OP == 2) { short2v x = __builtin_bit_cast(short2v, a[i]), y = __builtin_bit_cast(short2v, b); a[i] = __builtin_bit_cast(uint32_t, x * y + y); }
                 if (OP == 3) a[i] = __builtin_amdgcn_udot4(a[i], b, a[i], false);

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""sha256 over the kernel / runtime sources a profile depends on (csrc/*.hip, *.h, *.inc and include/*.h, sorted by name).
+Every profiles/r*/{traffic,valu}_pmc.json carries the value it was collected on; bench.py marks a figure "stale" when the
+tree no longer matches."""
+import glob
+import hashlib
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def csrc_sha(root=ROOT):
+    h = hashlib.sha256()
+    files = []
+    for pat in ("anyfeature-vslam_amd/csrc/*.hip", "anyfeature-vslam_amd/csrc/*.h", "anyfeature-vslam_amd/csrc/*.inc", "include/*.h"):
+        files += glob.glob(os.path.join(root, pat))
+    for f in sorted(files):
+        h.update(os.path.relpath(f, root).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+if __name__ == "__main__":
+    print(csrc_sha())
