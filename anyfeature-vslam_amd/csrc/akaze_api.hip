@@ -21,7 +21,7 @@ extern "C" void afv_akz_launch_flow(const float *lsm, int w, int h, int nframes,
 extern "C" void afv_akz_launch_nld_step(const float *Lt, const float *flow, int w, int h, int nframes, float tau, float *out, hipStream_t st);
 extern "C" int afv_akz_launch_fed_fused(const float *Lt_in, const float *lsm, int w, int h, int nframes, const float *kcontrast, int octave,
                                         int nsteps, const float *tau, float *Lt_out, hipStream_t st);
-extern "C" int afv_akz_launch_hessian(const float *lsm, int w, int h, int nframes, int s, float *dx, float *dy, float *Lx, float *Ly,
+extern "C" int afv_akz_launch_hessian(const float *lsm, int w, int h, int nframes, int s, float *dx, float *dy,
                                       float *Ldet, hipStream_t st);
 
 // mirrors of the kernel-side structs in k_akaze_detect.hip
@@ -58,6 +58,7 @@ struct AksParams {
 struct AkdLevelPlanes {
     const float *lt, *lx, *ly;
     int w, h, octave;
+    float fs;
 };
 struct AkdDescParams {
     int nlevels, kp_cap, sel_cap, out_cap, desc_pitch;
@@ -83,7 +84,7 @@ struct afv_akaze {
     // HBM: per level 5 planes x max_batch frames (level 0: Lsmooth aliases Lt); scratch at level-0 size
     float *lt[AFV_AKZ_MAX_LEVELS] = {}, *lsm[AFV_AKZ_MAX_LEVELS] = {}, *lx[AFV_AKZ_MAX_LEVELS] = {}, *ly[AFV_AKZ_MAX_LEVELS] = {},
           *ldet[AFV_AKZ_MAX_LEVELS] = {};
-    float *flow = nullptr, *pong = nullptr, *half = nullptr, *dx = nullptr, *dy = nullptr;
+    float *flow = nullptr, *pong = nullptr, *half = nullptr;
     float *d_taps = nullptr;  // gauss_soffset[32] | gauss_one[8]
     unsigned int *d_hmax = nullptr;
     int *d_hist = nullptr;
@@ -276,8 +277,6 @@ extern "C" int afv_akaze_create(int device, const afv_akaze_params *prm, afv_aka
     if (rc == AFV_OK) rc = akz_alloc(a, &a->flow, n0);
     if (rc == AFV_OK) rc = akz_alloc(a, &a->pong, n0);
     if (rc == AFV_OK) rc = akz_alloc(a, &a->half, n0 / 4 + B);
-    if (rc == AFV_OK) rc = akz_alloc(a, &a->dx, n0);
-    if (rc == AFV_OK) rc = akz_alloc(a, &a->dy, n0);
     if (rc == AFV_OK) rc = akz_alloc(a, &a->d_taps, 40);
     if (rc == AFV_OK) rc = akz_alloc(a, &a->d_hmax, B);
     if (rc == AFV_OK) rc = akz_alloc(a, &a->d_hist, B * (size_t)(prm->kcontrast_nbins + 1));
@@ -392,7 +391,8 @@ static int akz_enqueue(afv_akaze *a, const uint8_t *d_gray, int nframes, int w, 
     if (a->profiling) AKZ_HIPCHK(a, hipEventRecord(a->ev[1], st));
     for (int i = 0; i < P.nlevels; ++i) {
         const afv_akaze_level &L = P.lv[i];
-        if (afv_akz_launch_hessian(a->lsm[i], L.w, L.h, nframes, L.sigma_size, a->dx, a->dy, a->lx[i], a->ly[i], a->ldet[i], st))
+        // lx / ly keep the UNSCALED first derivatives; readers apply sigma_size (k_akz_describe, afv_akaze_get_plane)
+        if (afv_akz_launch_hessian(a->lsm[i], L.w, L.h, nframes, L.sigma_size, a->lx[i], a->ly[i], a->ldet[i], st))
             return AFV_EUNSUPPORTED;
     }
     if (a->profiling) {
@@ -467,6 +467,10 @@ extern "C" int afv_akaze_get_plane(afv_akaze *a, int frame, int level, int which
     AKZ_HIPCHK(a, hipSetDevice(a->device));
     AKZ_HIPCHK(a, hipStreamSynchronize(a->stream));
     AKZ_HIPCHK(a, hipMemcpy(out, base + (size_t)frame * L.w * L.h, (size_t)L.w * L.h * sizeof(float), hipMemcpyDeviceToHost));
+    if (which == AFV_AKZ_LX || which == AFV_AKZ_LY) {  // the device planes are unscaled: Lx *= sigma_size as upstream does in place
+        const float fs = (float)L.sigma_size;
+        for (size_t i = 0, n = (size_t)L.w * L.h; i < n; ++i) out[i] = out[i] * fs;
+    }
     return AFV_OK;
 }
 
@@ -592,7 +596,7 @@ static int akz_describe_enqueue(afv_akaze *a) {
     S.kp_cap = AKD_ENTRY_CAP; S.sel_cap = a->sel_cap; S.out_cap = a->out_cap; S.M = a->qt_M;
     AkdDescParams D{};
     D.nlevels = P.nlevels; D.kp_cap = AKD_ENTRY_CAP; D.sel_cap = a->sel_cap; D.out_cap = a->out_cap; D.desc_pitch = 64;
-    for (int l = 0; l < P.nlevels; ++l) D.lv[l] = AkdLevelPlanes{a->lt[l], a->lx[l], a->ly[l], P.lv[l].w, P.lv[l].h, P.lv[l].octave};
+    for (int l = 0; l < P.nlevels; ++l) D.lv[l] = AkdLevelPlanes{a->lt[l], a->lx[l], a->ly[l], P.lv[l].w, P.lv[l].h, P.lv[l].octave, (float)P.lv[l].sigma_size};
     hipStream_t st = a->stream;
     afv_akz_launch_select(&S, a->cur_frames, a->d_kps, a->d_kp_count, a->d_lvl_idx, a->d_lvl_node, a->d_sel, a->d_sel_count, st);
     afv_akz_launch_describe(&D, a->cur_frames, a->out_cap, a->d_kps, a->d_sel, a->d_sel_count, a->d_out_kps, a->d_out_desc, a->d_out_count,

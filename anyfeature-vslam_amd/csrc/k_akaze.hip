@@ -393,9 +393,12 @@ __global__ __launch_bounds__(AKZ_T) void k_akz_deriv1(const float *__restrict__ 
     }
 }
 
-// second derivatives from the unscaled first ones, the sigma_size normalisation and the determinant
+// second derivatives from the unscaled first ones, the sigma_size normalisation and the determinant.  Upstream scales Lx / Ly by
+// sigma_size in place AFTER this (Compute_Multiscale_Derivatives); here the per-level planes keep the UNSCALED first derivatives
+// and every consumer multiplies by sigma_size as it reads (the same single float product) — the scaled copies were 8 B/px of
+// pure re-write traffic.
 __global__ __launch_bounds__(AKZ_T) void k_akz_hessian(const float *__restrict__ dx, const float *__restrict__ dy, int w, int h, int nframes, int s,
-                                                       float *__restrict__ Lx, float *__restrict__ Ly, float *__restrict__ Ldet) {
+                                                       float *__restrict__ Ldet) {
     extern __shared__ float s_mem[];  // two (AT_W + 2s) x (AT_H + 2s) planes
     const int LW = AT_W + 2 * s, LH = AT_H + 2 * s;
     float *s_x = s_mem, *s_y = s_mem + LW * LH;
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(AKZ_T) void k_akz_hessian(const float *__restrict__
     }
     __syncthreads();
     const float wgt = 10.0f / 3.0f, norm = 1.0f / (2.0f * (float)s * (wgt + 2.0f)), mid = wgt * norm;
-    const float fs = (float)s, fs2 = (float)(s * s);
+    const float fs2 = (float)(s * s);
     for (int i = threadIdx.x; i < AT_W * AT_H; i += AKZ_T) {
         const int ly = i / AT_W, lx = i - ly * AT_W;
         const int gx = x0 + lx, gy = y0 + ly;
@@ -428,8 +431,6 @@ __global__ __launch_bounds__(AKZ_T) void k_akz_hessian(const float *__restrict__
             const float v2 = mid * cx[s * LW] + norm * (cx[s * LW - s] + cx[s * LW + s]);
             const float lxy = (v2 - v0) * fs2;
             const size_t o = (size_t)f * w * h + (size_t)gy * w + gx;
-            Lx[o] = cx[0] * fs;
-            Ly[o] = cy[0] * fs;
             Ldet[o] = lxx * lyy - lxy * lxy;
         }
     }
@@ -491,11 +492,11 @@ extern "C" int afv_akz_launch_fed_fused(const float *Lt_in, const float *lsm, in
     return 1;
 }
 
-extern "C" int afv_akz_launch_hessian(const float *lsm, int w, int h, int nframes, int s, float *dx, float *dy, float *Lx, float *Ly,
-                                      float *Ldet, hipStream_t st) {
+// dx, dy: the level's first-derivative planes (unscaled; written here, kept for the descriptor stage)
+extern "C" int afv_akz_launch_hessian(const float *lsm, int w, int h, int nframes, int s, float *dx, float *dy, float *Ldet, hipStream_t st) {
     if (s < 1 || s > AKZ_MAX_S) return -1;
     const size_t plane = (size_t)(AT_W + 2 * s) * (AT_H + 2 * s) * sizeof(float);
     hipLaunchKernelGGL(k_akz_deriv1, akz_grid(w, h, nframes), dim3(AKZ_T), plane, st, lsm, w, h, nframes, s, dx, dy);
-    hipLaunchKernelGGL(k_akz_hessian, akz_grid(w, h, nframes), dim3(AKZ_T), 2 * plane, st, dx, dy, w, h, nframes, s, Lx, Ly, Ldet);
+    hipLaunchKernelGGL(k_akz_hessian, akz_grid(w, h, nframes), dim3(AKZ_T), 2 * plane, st, dx, dy, w, h, nframes, s, Ldet);
     return 0;
 }

@@ -81,8 +81,9 @@ __global__ __launch_bounds__(QT_T) void k_akz_select(AksParams P, const afv_keyp
 
 // ---------------- Compute_Descriptors ----------------
 struct AkdLevelPlanes {
-    const float *lt, *lx, *ly;  // [frame][h][w]
+    const float *lt, *lx, *ly;  // [frame][h][w]; lx / ly hold the UNSCALED first derivatives
     int w, h, octave;
+    float fs;                   // sigma_size: Lx = lx * fs, Ly = ly * fs (the in-place scaling of Compute_Multiscale_Derivatives)
 };
 struct AkdDescParams {
     int nlevels, kp_cap, sel_cap, out_cap, desc_pitch;
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256) void k_akz_describe(AkdDescParams P, const afv
             const int i = k_ori_ij[idx][0], j = k_ori_ij[idx][1];
             const int iy = akd_iclamp(akd_fround(yf + (float)(j * s)), 0, L.h - 1), ix = akd_iclamp(akd_fround(xf + (float)(i * s)), 0, L.w - 1);
             const float gw = k_gauss25[i < 0 ? -i : i][j < 0 ? -j : j];
-            const float vx = gw * Lx[(size_t)iy * L.w + ix], vy = gw * Ly[(size_t)iy * L.w + ix];
+            const float vx = gw * (Lx[(size_t)iy * L.w + ix] * L.fs), vy = gw * (Ly[(size_t)iy * L.w + ix] * L.fs);
             rx[idx] = vx;
             ry[idx] = vy;
             an[idx] = akd_get_angle(vx, vy);
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256) void k_akz_describe(AkdDescParams P, const afv
                     const float sample_x = xf + (-(float)l * si * scale + (float)k * co * scale);
                     const int y1 = akd_iclamp(akd_fround(sample_y), 0, L.h - 1), x1 = akd_iclamp(akd_fround(sample_x), 0, L.w - 1);
                     const size_t o = (size_t)y1 * L.w + x1;
-                    const float ri = Lt[o], vx = Lx[o], vy = Ly[o];
+                    const float ri = Lt[o], vx = Lx[o] * L.fs, vy = Ly[o] * L.fs;
                     di += ri;
                     const float rry = vx * co + vy * si, rrx = -vx * si + vy * co;
                     dx += rrx;

@@ -135,8 +135,7 @@ def test_hip_against_real_opencv(afv, oracle, path):
     cand_xy, cand_resp = [], []
     cvq = g["cv_quota"]
     for l in range(nl):
-        packed, resp = ctx.debug_candidates(0, l)
-        x, y, s = packed & 4095, (packed >> 12) & 4095, packed >> 24
+        x, y, s, resp = ctx.debug_candidates(0, l)
         want = {(int(a), int(b)): int(c) for a, b, c in d["fast_%d" % l]}
         got = {(int(a), int(b)): int(c) for a, b, c in zip(x, y, s)}
         nfast += want != got
