@@ -88,6 +88,7 @@ SYMBOLS = {
     "afv_table_set": (_i, [_vp, _i, _vp, _vp, _i]),
     "afv_table_set_featvec": (_i, [_vp, _i, _vp, _vp, _vp, _i]),
     "afv_table_set_geometry": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "afv_table_set_valid": (_i, [_vp, _i, _vp]),
     "afv_table_device_ptrs": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "afv_table_sync_counts": (_i, [_vp]),
     "afv_table_match_pairs": (_i, [_vp, _vp, _vp, _i, _f, _f, _i, _vp, _vp]),

@@ -33,6 +33,7 @@ struct afv_table {
     int32_t *d_n = nullptr;     // [nsets]
     int32_t *d_idx = nullptr;   // [nsets][cap] FeatureVector feature indices in node order (afv_table_set_featvec), lazily allocated
     float *d_geo = nullptr;     // [3][nsets][cap]: x, y, sigma2 (afv_table_set_geometry), lazily allocated
+    uint8_t *d_valid = nullptr; // [nsets][cap] "map point exists && !isBad()" (afv_table_set_valid), lazily allocated, default 1
     std::vector<int32_t> h_n;
     std::vector<HostFeatVec> fv;
     // grow-only device buffers of the pair entry points + their pinned host image
@@ -57,7 +58,7 @@ static std::vector<afv_comm *> g_comms;
 static void table_free(afv_table *t) {
     if (!t) return;
     if (t->c) (void)hipSetDevice(t->c->device);
-    void *ptrs[] = {t->d_desc, t->d_angle, t->d_n, t->d_idx, t->d_geo, t->d_pairs, t->d_out, t->d_nm};
+    void *ptrs[] = {t->d_desc, t->d_angle, t->d_n, t->d_idx, t->d_geo, t->d_valid, t->d_pairs, t->d_out, t->d_nm};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (t->h_pin) (void)hipHostFree(t->h_pin);
@@ -173,6 +174,24 @@ extern "C" int afv_table_set_geometry(afv_table *t, int set, const float *x, con
     const float *src[3] = {x, y, sigma2};
     for (int k = 0; k < 3; ++k)
         HIPCHK(c, hipMemcpy(t->d_geo + k * plane + (size_t)set * t->cap, src[k], (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    return AFV_OK;
+}
+
+extern "C" int afv_table_set_valid(afv_table *t, int set, const uint8_t *valid) {
+    if (!t || set < 0 || set >= t->nsets) return AFV_EINVAL;
+    afv_ctx *c = t->c;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!t->d_valid) {
+        if (!valid) return AFV_OK;  // nothing was ever restricted
+        HIPCHK(c, hipMalloc(&t->d_valid, (size_t)t->nsets * t->cap));
+        HIPCHK(c, hipMemset(t->d_valid, 1, (size_t)t->nsets * t->cap));
+    }
+    const int n = t->h_n[set];
+    if (valid) {
+        if (n) HIPCHK(c, hipMemcpy(t->d_valid + (size_t)set * t->cap, valid, (size_t)n, hipMemcpyHostToDevice));
+    } else {
+        HIPCHK(c, hipMemset(t->d_valid + (size_t)set * t->cap, 1, (size_t)t->cap));
+    }
     return AFV_OK;
 }
 
@@ -311,7 +330,8 @@ static int table_match_bow_impl(afv_table *t, const int32_t *pair_a, const int32
         d.nseg = seg_first[p + 1] - seg_first[p];
         d.idx1 = t->d_idx + (size_t)a * cap;
         d.idx2 = t->d_idx + (size_t)bb * cap;
-        d.valid1 = d.valid2 = nullptr;
+        d.valid1 = t->d_valid ? t->d_valid + (size_t)a * cap : nullptr;   // FeatureMatcher.cc:593-597 / :609-613
+        d.valid2 = t->d_valid ? t->d_valid + (size_t)bb * cap : nullptr;
         d.ang1 = t->d_angle + (size_t)a * cap;
         d.ang2 = t->d_angle + (size_t)bb * cap;
         d.ang_stride = 1;
@@ -565,7 +585,7 @@ extern "C" int afv_table_broadcast(afv_comm *m, afv_table *t, int root, float *e
     afv_ctx *c = t->c;
     HIPCHK(c, hipSetDevice(c->device));
     // does the root hold FeatureVector indices / geometry?  (ranks allocate them on demand so the buffers exist everywhere)
-    int32_t flags[2] = {t->d_idx != nullptr, t->d_geo != nullptr};
+    int32_t flags[3] = {t->d_idx != nullptr, t->d_geo != nullptr, t->d_valid != nullptr};
     int32_t *d_flags = nullptr;
     HIPCHK(c, hipMalloc(&d_flags, sizeof(flags)));
     hipError_t e = hipMemcpyAsync(d_flags, flags, sizeof(flags), hipMemcpyHostToDevice, c->stream);
@@ -578,12 +598,14 @@ extern "C" int afv_table_broadcast(afv_comm *m, afv_table *t, int root, float *e
     const size_t plane = (size_t)t->nsets * t->cap;
     if (flags[0] && !t->d_idx) HIPCHK(c, hipMalloc(&t->d_idx, plane * sizeof(int32_t)));
     if (flags[1] && !t->d_geo) HIPCHK(c, hipMalloc(&t->d_geo, 3 * plane * sizeof(float)));
+    if (flags[2] && !t->d_valid) HIPCHK(c, hipMalloc(&t->d_valid, plane));
     HIPCHK(c, hipEventRecord(t->ev0, c->stream));
     rc = afv_comm_broadcast(m, t->d_desc, plane * 32, root, c->stream);
     if (!rc) rc = afv_comm_broadcast(m, t->d_angle, plane * sizeof(float), root, c->stream);
     if (!rc) rc = afv_comm_broadcast(m, t->d_n, (size_t)t->nsets * sizeof(int32_t), root, c->stream);
     if (!rc && flags[0]) rc = afv_comm_broadcast(m, t->d_idx, plane * sizeof(int32_t), root, c->stream);
     if (!rc && flags[1]) rc = afv_comm_broadcast(m, t->d_geo, 3 * plane * sizeof(float), root, c->stream);
+    if (!rc && flags[2]) rc = afv_comm_broadcast(m, t->d_valid, plane, root, c->stream);
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(t->ev1, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -102,6 +102,11 @@ class DescriptorTable:
         x, y, s = (np.ascontiguousarray(v, np.float32) for v in (x, y, sigma2))
         self.ctx.check(self.lib.afv_table_set_geometry(self.handle, int(slot), ptr(x), ptr(y), ptr(s)), "afv_table_set_geometry")
 
+    def set_valid(self, slot, valid):
+        """valid[i] = feature i has a good map point (None = all valid); honoured by match_bow"""
+        v = None if valid is None else np.ascontiguousarray(valid, np.uint8)
+        self.ctx.check(self.lib.afv_table_set_valid(self.handle, int(slot), ptr(v)), "afv_table_set_valid")
+
     def device_views(self):
         """zero-copy torch views of the table: desc uint8 [nsets, cap, 32], angle float32 [nsets, cap], n int32 [nsets]"""
         import torch

@@ -162,6 +162,10 @@ int afv_table_set(afv_table *t, int set, const uint8_t *desc32, const float *ang
  * is host work: <= a few hundred ints per pair), the feature indices go to the device. */
 int afv_table_set_featvec(afv_table *t, int set, const int32_t *node_id, const int32_t *seg_ptr, const int32_t *seg_idx,
                           int nnodes);
+/* per-feature validity of keyframe `set` for afv_table_match_bow: valid[i] = map point exists && !isBad() (FeatureMatcher.cc:593-597,
+ * :609-613; it changes as the map evolves, so the host re-uploads the n bytes when it does).  NULL = every feature valid (the
+ * default).  The brute-force pair entry points take every feature as valid. */
+int afv_table_set_valid(afv_table *t, int set, const uint8_t *valid);
 /* device views for zero-copy callers: d_desc[nsets][cap][32], d_angle[nsets][cap] (float), d_n[nsets] (int32) */
 int afv_table_device_ptrs(afv_table *t, uint8_t **d_desc, float **d_angle, int32_t **d_n);
 /* brute-force SearchByBoW(KF,KF) (FeatureMatcher.cc:561-660 with one node holding everything) of npairs (a, b) slot

@@ -113,11 +113,16 @@ def test_table_bow_guided_pairs(afv, oracle, tbl, ori):
         table.set_featvec(k, *_csr(fv))
     pa = np.array([k for k in range(K) for _ in range(3)], np.int32)
     pb = np.array([(k + 1 + j) % K for k in range(K) for j in range(3)], np.int32)
+    # map-point validity masks on every third keyframe (FeatureMatcher.cc:593-597, :609-613): they change the greedy walk
+    valid = [None] * K
+    for k in range(0, K, 3):
+        valid[k] = (afv.synth.lcg_bytes(700 + k, max(int(cnt[k]), 1))[:cnt[k]] > 60).astype(np.uint8)
+        table.set_valid(k, valid[k])
     m, nm = table.match_bow(pa, pb, TH, RATIO, ori)
     total = 0
     for p in range(len(pa)):
         a, b = int(pa[p]), int(pb[p])
-        want, wn = oracle.search_by_bow_kf_kf(t[a, :cnt[a]], t[b, :cnt[b]], fvs[a], fvs[b], None, None, ang[a, :cnt[a]], ang[b, :cnt[b]], TH, RATIO, ori)
+        want, wn = oracle.search_by_bow_kf_kf(t[a, :cnt[a]], t[b, :cnt[b]], fvs[a], fvs[b], valid[a], valid[b], ang[a, :cnt[a]], ang[b, :cnt[b]], TH, RATIO, ori)
         assert nm[p] == wn, (p, a, b)
         assert np.array_equal(m[p, :cnt[a]], want), (p, a, b)
         assert np.all(m[p, cnt[a]:] == -1)

@@ -85,6 +85,7 @@ def test_table_and_comm_reject_bad_arguments(afv):
     assert lib.afv_table_set(None, 0, None, None, 0) == E
     assert lib.afv_table_set_featvec(None, 0, None, None, None, 0) == E
     assert lib.afv_table_set_geometry(None, 0, None, None, None) == E
+    assert lib.afv_table_set_valid(None, 0, None) == E
     assert lib.afv_table_match_pairs(None, None, None, 0, 75.0, 0.75, 1, None, None) == E
     assert lib.afv_table_match_pairs_device(None, None, None, 0, 75.0, 0.75, 1, None, None, None) == E
     assert lib.afv_table_match_bow(None, None, None, 0, 75.0, 0.75, 1, None, None) == E
