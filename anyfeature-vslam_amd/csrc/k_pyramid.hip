@@ -5,16 +5,22 @@
 // geometry on the host exactly as OpenCV's interpolation_linear<uchar>::getCoeffs does (IEEE double), so the
 // kernel is pure integer arithmetic: horizontal pass in 8.8, vertical pass (+2^15)>>16.
 //
-// HBM/latency-bound stage.  One 256-thread workgroup produces a 64x32 output tile: the source window it needs
-// (<= 80 x 42 pixels for the 1.2 pyramid) is staged in LDS with coalesced dword loads issued together with the
-// tile's slice of the coefficient tables — ONE global round trip per workgroup — then every thread blends
-// 4 x 2 output pixels from LDS and stores two dwords.
+// One 256-thread workgroup produces a 64x32 output tile: the source window it needs (<= 80 x 42 pixels for the 1.2 pyramid) is
+// staged in LDS with coalesced dword loads issued together with the tile's slice of the coefficient tables — ONE global round
+// trip per workgroup.  The blend is separable, exactly as OpenCV evaluates it:
+//   horizontal  h[r][c] = (256 - wx_c) * S[r][o_c] + wx_c * S[r][o_c + 1]      (8.8 fixed point, <= 65280: exact in u16)
+//   vertical    out = (h[ya][c] * (256 - wy) + h[ya + 1][c] * wy + 2^15) >> 16
+// so every source row is filtered ONCE (a 1.2x level reuses a filtered row for ~1.6 output rows): the horizontal pass works on
+// packed column pairs (v_pk_mul_lo_u16 + v_pk_mad_u16 per pair and row), the vertical pass is one v_dot2_u32_u16 per pixel on
+// the (upper, lower) pair with the 2^15 rounding term as its accumulator.
 #include "afv_device.h"
 
 #define RT_W 64
 #define RT_H 32
 #define RS_W 96   // LDS source window pitch (bytes); source span of 64 outputs at scale <= 1.4 plus alignment slack
 #define RS_H 48
+
+typedef unsigned short ushort2r __attribute__((ext_vector_type(2)));
 
 struct ResizeTab {
     const short2 *xt;  // [dw]  {src offset, weight of the right tap}
@@ -25,6 +31,7 @@ __global__ __launch_bounds__(256) void k_resize_level(const uint8_t *__restrict_
                                                       size_t sframe, uint8_t *__restrict__ dst, int dw, int dh,
                                                       int dpitch, size_t dframe, ResizeTab tab, int total_blocks, int frame_base) {
     __shared__ __attribute__((aligned(16))) uint8_t win[RS_H * RS_W];
+    __shared__ __attribute__((aligned(16))) uint32_t hrow[RS_H * (RT_W / 2)];  // horizontally filtered rows, column pairs (u16, u16)
     __shared__ short2 s_xt[RT_W];
     __shared__ short2 s_yt[RT_H];
     // XCD-aware placement: whole frames per XCD (neighbouring tiles share source cache lines)
@@ -54,9 +61,14 @@ __global__ __launch_bounds__(256) void k_resize_level(const uint8_t *__restrict_
         }
         *reinterpret_cast<uint32_t *>(&win[r * RS_W + q * 4]) = v;
     }
-    if (threadIdx.x < nx) {
-        short2 e = tab.xt[x0 + threadIdx.x];
-        e.x = (short)(e.x - sx0);
+    if (threadIdx.x < RT_W) {  // columns past the image edge: offset 0, weight 0 (their outputs are never stored)
+        short2 e;
+        e.x = 0;
+        e.y = 0;
+        if (threadIdx.x < nx) {
+            e = tab.xt[x0 + threadIdx.x];
+            e.x = (short)(e.x - sx0);
+        }
         s_xt[threadIdx.x] = e;
     } else if (threadIdx.x >= 64 && threadIdx.x < 64 + ny) {
         short2 e = tab.yt[y0 + threadIdx.x - 64];
@@ -64,32 +76,52 @@ __global__ __launch_bounds__(256) void k_resize_level(const uint8_t *__restrict_
         s_yt[threadIdx.x - 64] = e;
     }
     __syncthreads();
-    // thread -> 4 consecutive columns, rows ry and ry + 16
+    const int xr_max = sx_last - sx0, yr_max = sy1 - sy0;
+    // ---- horizontal pass: thread = column pair (cp) x row group (rg); rows rg, rg + 8, ... of the staged window ----
+    {
+        const int cp = threadIdx.x & 31, rg = threadIdx.x >> 5;
+        const short2 xa = s_xt[2 * cp], xb = s_xt[2 * cp + 1];
+        const int a0 = xa.x, a1 = min(xa.x + 1, xr_max), b0 = xb.x, b1 = min(xb.x + 1, xr_max);
+        ushort2r WR, WL;
+        WR.x = (unsigned short)xa.y;
+        WR.y = (unsigned short)xb.y;
+        WL.x = (unsigned short)(256 - xa.y);
+        WL.y = (unsigned short)(256 - xb.y);
+        for (int r = rg; r < nrows; r += 8) {
+            const uint8_t *row = &win[r * RS_W];
+            ushort2r L, R;
+            L.x = row[a0];
+            L.y = row[b0];
+            R.x = row[a1];
+            R.y = row[b1];
+            const ushort2r hv = WL * L + WR * R;  // <= 256 * 255: no overflow
+            hrow[r * (RT_W / 2) + cp] = __builtin_bit_cast(uint32_t, hv);
+        }
+    }
+    __syncthreads();
+    // ---- vertical pass: thread -> 4 consecutive columns, rows ry and ry + 16 ----
     const int cx = (threadIdx.x & 15) * 4, ry = threadIdx.x >> 4;
     if (cx >= nx) return;
-    const int xr_max = sx_last - sx0, yr_max = sy1 - sy0;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int y = ry + half * 16;
         if (y >= ny) break;
         const short2 yt = s_yt[y];
-        const uint8_t *r0 = &win[yt.x * RS_W];
-        const uint8_t *r1 = &win[min(yt.x + 1, yr_max) * RS_W];
-        const uint32_t cy = (uint32_t)yt.y;
-        uint32_t out = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (cx + k < nx) {
-                const short2 xt = s_xt[cx + k];
-                const int o0 = xt.x, o1 = min(xt.x + 1, xr_max);
-                const uint32_t wx = (uint32_t)xt.y;
-                const uint32_t h0 = (256u - wx) * r0[o0] + wx * r0[o1];
-                const uint32_t h1 = (256u - wx) * r1[o0] + wx * r1[o1];
-                out |= ((h0 * (256u - cy) + h1 * cy + 32768u) >> 16) << (8 * k);
-            }
-        }
-        // pitch is a multiple of 64: the dword store never leaves the row
-        *reinterpret_cast<uint32_t *>(dst + (size_t)f * dframe + (size_t)(y0 + y) * dpitch + x0 + cx) = out;
+        const uint32_t *h0 = &hrow[yt.x * (RT_W / 2) + (cx >> 1)];
+        const uint32_t *h1 = &hrow[min(yt.x + 1, yr_max) * (RT_W / 2) + (cx >> 1)];
+        ushort2r WY;
+        WY.x = (unsigned short)(256 - yt.y);
+        WY.y = (unsigned short)yt.y;
+        const uint2 u = *reinterpret_cast<const uint2 *>(h0), l = *reinterpret_cast<const uint2 *>(h1);  // 8-byte aligned: cx % 4 == 0
+        // (upper, lower) pairs of the four columns
+        const ushort2r p0 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(l.x, u.x, 0x05040100u));
+        const ushort2r p1 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(l.x, u.x, 0x07060302u));
+        const ushort2r p2 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(l.y, u.y, 0x05040100u));
+        const ushort2r p3 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(l.y, u.y, 0x07060302u));
+        const uint32_t o0 = __builtin_amdgcn_udot2(p0, WY, 32768u, false) >> 16, o1 = __builtin_amdgcn_udot2(p1, WY, 32768u, false) >> 16;
+        const uint32_t o2 = __builtin_amdgcn_udot2(p2, WY, 32768u, false) >> 16, o3 = __builtin_amdgcn_udot2(p3, WY, 32768u, false) >> 16;
+        // pitch is a multiple of 64: the dword store never leaves the row (columns past nx hold filtered padding, never read)
+        *reinterpret_cast<uint32_t *>(dst + (size_t)f * dframe + (size_t)(y0 + y) * dpitch + x0 + cx) = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
     }
 }
 

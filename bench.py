@@ -624,6 +624,10 @@ def main():
     B = args.batch
     ctx = afv.Context(nfeatures=1000, nlevels=8, scale_factor=1.2, fast_threshold=20, max_width=W, max_height=H, max_batch=B,
                       device=local)
+    if os.environ.get("AFV_EXP_CHUNKS"):      # tools/timeline.py experiments only
+        ctx.set_split_chunks(int(os.environ["AFV_EXP_CHUNKS"]))
+    if os.environ.get("AFV_EXP_NOSPLIT"):
+        ctx.set_split_threshold(0x7fffffff)
     afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
     matcher = afv.FeatureMatcher(0.6, True, ctx=ctx)
 
