@@ -22,8 +22,16 @@
 #include "afv_device.h"
 
 #define ST 256  // threads per workgroup
-#define CPT 40        // candidates a thread keeps in registers: the fast path covers n <= ST * CPT = 10240
-#define KEPT_LDS 3072 // retainBest survivors kept in LDS for the quadtree rounds (else global scratch)
+#define CPT 20        // candidates a thread keeps in registers: the fast path covers n <= ST * CPT = 5120
+#define KEPT_LDS 2304 // retainBest survivors (position + node label) kept in LDS for the quadtree rounds (else global scratch)
+// The kernel is a chain of short dependent phases (latency-, not throughput-bound): what a batch costs is set by how many
+// (frame, level) workgroups a CU holds at once, so the LDS footprint (~29 KB at M = 256 -> 5 workgroups per CU) and the
+// register budget (<= 96 VGPRs, 5 waves per SIMD) are the tuning parameters here.
+
+// quadtree region of the LDS layout (see the kernel); never smaller than the 2048-bin histogram that shares it
+__host__ __device__ constexpr size_t afv_select_tree_bytes(int M) {
+    return (size_t)M * 60 > 8192 ? (size_t)M * 60 : 8192;
+}
 
 struct Rect16 {
     short x0, y0, x1, y1;
@@ -124,10 +132,11 @@ __device__ __forceinline__ Rect16 child_rect(const Rect16 r, int q) {
 }
 
 // dynamic LDS layout, M = max nodes (multiple of 64):
-//   int   hist[2048]            (also scratch for scans)
-//   Rect16 rect[2][M]; int cnt[2][M]; int child[M*4]; uint16 remap[M*4]; int aux[M]; int aux2[M];
-//   unsigned long long best[M]; int tmp[16]; then kept_xy u32[KEPT_LDS], kept_resp f32[KEPT_LDS], kept_node u16[KEPT_LDS]
-__global__ __launch_bounds__(ST) void k_select_quadtree(const Geo *__restrict__ geo_p, const uint32_t *__restrict__ cand_packed,
+//   quadtree region (60 * M bytes): Rect16 rect[2][M]; int cnt[2][M]; int child[M*4] (the survivor keys best[M] reuse it after the
+//     last round); int aux[M], aux2[M], unt[M]; uint16 remap[M*4]
+//   the retainBest histograms hist[2048] live on top of that region (dead before the first node is created)
+//   int tmp[16]; kept_xy u32[KEPT_LDS]; kept_node u16[KEPT_LDS]        (the responses of the survivors stay in global scratch)
+__global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_select_quadtree(const Geo *__restrict__ geo_p, const uint32_t *__restrict__ cand_packed,
                                                        const float *__restrict__ cand_resp,
                                                        const int *__restrict__ cand_count, uint32_t *__restrict__ kept_xy,
                                                        float *__restrict__ kept_resp, uint16_t *__restrict__ kept_node,
@@ -135,16 +144,17 @@ __global__ __launch_bounds__(ST) void k_select_quadtree(const Geo *__restrict__ 
                                                        int total_blocks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *hist = reinterpret_cast<int *>(smem);
-    unsigned long long *best = reinterpret_cast<unsigned long long *>(hist + 2048);
-    Rect16 *rect0 = reinterpret_cast<Rect16 *>(best + M);
+    Rect16 *rect0 = reinterpret_cast<Rect16 *>(smem);
     Rect16 *rect1 = rect0 + M;
     int *cnt0 = reinterpret_cast<int *>(rect1 + M);
     int *cnt1 = cnt0 + M;
     int *child = cnt1 + M;
+    unsigned long long *best = reinterpret_cast<unsigned long long *>(child);  // 8-byte aligned: 24 * M bytes in
     int *aux = child + 4 * M;
     int *aux2 = aux + M;
-    int *tmp = aux2 + M;
-    uint16_t *remap = reinterpret_cast<uint16_t *>(tmp + 16);
+    int *unt = aux2 + M;
+    uint16_t *remap = reinterpret_cast<uint16_t *>(unt + M);
+    int *tmp = reinterpret_cast<int *>(smem + afv_select_tree_bytes(M));
 
     const Geo &geo = *geo_p;
     // XCD-aware placement: the 8 level-workgroups of a frame run on one XCD (they read what that frame's FAST tiles wrote)
@@ -158,9 +168,8 @@ __global__ __launch_bounds__(ST) void k_select_quadtree(const Geo *__restrict__ 
     uint32_t *kxy = kept_xy + base;  // re-pointed to LDS below when the survivors fit
     float *kr = kept_resp + base;
     uint16_t *kn = kept_node + base;
-    uint32_t *lds_kxy = reinterpret_cast<uint32_t *>(remap + 4 * M);
-    float *lds_kr = reinterpret_cast<float *>(lds_kxy + KEPT_LDS);
-    uint16_t *lds_kn = reinterpret_cast<uint16_t *>(lds_kr + KEPT_LDS);
+    uint32_t *lds_kxy = reinterpret_cast<uint32_t *>(tmp + 16);
+    uint16_t *lds_kn = reinterpret_cast<uint16_t *>(lds_kxy + KEPT_LDS);
     const int n = min(cand_count[f * AFV_MAX_LEVELS + l], L.cand_cap);
     const int tid = threadIdx.x, lane = tid & 63;
     const float scale = L.scale;
@@ -261,7 +270,6 @@ __global__ __launch_bounds__(ST) void k_select_quadtree(const Geo *__restrict__ 
     __syncthreads();
     if (tmp[9] <= KEPT_LDS) {
         kxy = lds_kxy;
-        kr = lds_kr;
         kn = lds_kn;
     }
     __syncthreads();
@@ -430,15 +438,15 @@ __global__ __launch_bounds__(ST) void k_select_quadtree(const Geo *__restrict__ 
         const int total_children = block_excl_scan(aux, nproc, tmp);  // aux[key] = children of keys < key
         // child (node i, quadrant q) -> position (total - aux[key] - ne(i)) + #non-empty children with quadrant > q
         // untouched node i -> total_children + rank among untouched nodes
-        for (int i = tid; i < size; i += ST) hist[i] = (aux2[i] < 0) ? 1 : 0;
+        for (int i = tid; i < size; i += ST) unt[i] = (aux2[i] < 0) ? 1 : 0;
         __syncthreads();
-        const int untouched = block_excl_scan(hist, size, tmp);
+        const int untouched = block_excl_scan(unt, size, tmp);
         const int new_size = total_children + untouched;
         int n_expand_local = 0;
         for (int i = tid; i < size; i += ST) {
             const int key = aux2[i];
             if (key < 0) {
-                const int pos = total_children + hist[i];
+                const int pos = total_children + unt[i];
                 rn[pos] = rc[i];
                 cn[pos] = cc[i];
                 remap[4 * i] = (uint16_t)pos;
@@ -509,9 +517,7 @@ __global__ __launch_bounds__(ST) void k_select_quadtree(const Geo *__restrict__ 
 }
 
 extern "C" size_t afv_select_lds_bytes(int M) {
-    return (size_t)2048 * 4 + (size_t)M * 8 /*best*/ + (size_t)M * 8 * 2 /*rect*/ + (size_t)M * 4 * 2 /*cnt*/ +
-           (size_t)M * 16 /*child*/ + (size_t)M * 4 * 2 /*aux*/ + 64 /*tmp*/ + (size_t)M * 8 /*remap*/ +
-           (size_t)KEPT_LDS * 10 /*kept xy, response, node*/;
+    return afv_select_tree_bytes(M) + 64 /*tmp*/ + (size_t)KEPT_LDS * 6 /*kept xy, node*/;
 }
 
 extern "C" void afv_launch_select(const Geo *geo_dev, int nlevels, const uint32_t *cand_packed, const float *cand_resp,
