@@ -183,7 +183,7 @@ extern "C" void afv_destroy(afv_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     afv_table_release_all(c);
-    void *ptrs[] = {c->d_geo, c->d_tab, c->d_pyr, c->d_cand_packed, c->d_kept_xy, c->d_cand_resp, c->d_kept_resp,
+    void *ptrs[] = {c->d_geo, c->d_tab, c->d_pyr, c->d_cand_packed, c->d_kept_xy, c->d_l1, c->d_l1_resp, c->d_l1_count, c->d_hq, c->d_hq_n, c->d_kept_resp,
                     c->d_kept_node, c->d_cand_count, c->d_sel_count, c->d_sel, c->d_frames, c->d_kps, c->d_desc,
                     c->d_n, c->d_status, c->d_match, c->d_topk};
     for (void *p : ptrs)
@@ -244,7 +244,12 @@ extern "C" int afv_create(int device, const afv_orb_params *params, afv_ctx **ou
     CREATE_CHK(hipMalloc(&c->d_pyr, geo_pyr_bytes(g, B)));
     const size_t ce = geo_cand_elems(g, B);
     CREATE_CHK(hipMalloc(&c->d_cand_packed, ce * 4));
-    CREATE_CHK(hipMalloc(&c->d_cand_resp, ce * 4));
+    CREATE_CHK(hipMalloc(&c->d_l1, ce * 4));
+    CREATE_CHK(hipMalloc(&c->d_l1_resp, ce * 4));
+    CREATE_CHK(hipMalloc(&c->d_l1_count, (size_t)B * AFV_MAX_LEVELS * sizeof(int)));
+    c->hq_per_frame = afv_harris_queue_per_frame(&g);
+    CREATE_CHK(hipMalloc(&c->d_hq, c->hq_per_frame * (size_t)B * sizeof(uint2)));
+    CREATE_CHK(hipMalloc(&c->d_hq_n, (size_t)B * sizeof(int)));
     CREATE_CHK(hipMalloc(&c->d_kept_xy, ce * 4));
     CREATE_CHK(hipMalloc(&c->d_kept_resp, ce * 4));
     CREATE_CHK(hipMalloc(&c->d_kept_node, ce * 2));
@@ -357,6 +362,7 @@ static void enqueue_range(afv_ctx *c, const FrameSrc &src, int f0, int nf, afv_k
                           int *d_status, hipStream_t s) {
     const Geo &g = c->geo;
     (void)hipMemsetAsync(c->d_cand_count + (size_t)f0 * AFV_MAX_LEVELS, 0, (size_t)nf * AFV_MAX_LEVELS * sizeof(int), s);
+    (void)hipMemsetAsync(c->d_hq_n + f0, 0, sizeof(int), s);
     {
         StageTimer t_(c, AFV_STAGE_PYRAMID, s, nf);
         for (int l = 1; l < g.nlevels; ++l) {
@@ -369,12 +375,17 @@ static void enqueue_range(afv_ctx *c, const FrameSrc &src, int f0, int nf, afv_k
         }
     }
     {
-        StageTimer t_(c, AFV_STAGE_FAST_HARRIS, s, nf);
-        afv_launch_fast_harris(c->d_geo, g.total_tiles, &src, c->d_pyr, c->d_cand_packed, c->d_cand_resp, c->d_cand_count, f0, nf, s);
+        StageTimer t_(c, AFV_STAGE_FAST_NMS, s, nf);
+        afv_launch_fast_nms(c->d_geo, g.total_tiles, &src, c->d_pyr, c->d_cand_packed, c->d_cand_count, f0, nf, s);
+    }
+    {
+        StageTimer t_(c, AFV_STAGE_HARRIS, s, nf);
+        afv_launch_retain_harris(c->d_geo, g.nlevels, &src, c->d_pyr, c->d_cand_packed, c->d_cand_count, c->d_l1, c->d_l1_count,
+                                 c->d_l1_resp, c->d_hq + (size_t)f0 * c->hq_per_frame, c->d_hq_n + f0, f0, nf, s);
     }
     {
         StageTimer t_(c, AFV_STAGE_SELECT, s, nf);
-        afv_launch_select(c->d_geo, g.nlevels, c->d_cand_packed, c->d_cand_resp, c->d_cand_count, c->d_kept_xy, c->d_kept_resp,
+        afv_launch_select(c->d_geo, g.nlevels, c->d_l1, c->d_l1_resp, c->d_l1_count, c->d_kept_xy, c->d_kept_resp,
                           c->d_kept_node, c->d_sel, c->d_sel_count, c->select_M, f0, nf, s);
     }
     int max_sel = 0;
@@ -665,7 +676,23 @@ extern "C" int afv_debug_get_candidates(afv_ctx *c, int frame, int level, uint32
     const size_t base = L.cand_off + (size_t)frame * L.cand_frame_stride;
     if (m > 0) {
         HIPCHK(c, hipMemcpy(packed, c->d_cand_packed + base, (size_t)m * 4, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(response, c->d_cand_resp + base, (size_t)m * 4, hipMemcpyDeviceToHost));
+        // the Harris response exists for the candidates that survived retainBest on the score (the level's l1 list); 0 for the rest
+        int n1 = 0;
+        HIPCHK(c, hipMemcpy(&n1, c->d_l1_count + frame * AFV_MAX_LEVELS + level, sizeof(int), hipMemcpyDeviceToHost));
+        n1 = std::min(std::max(n1, 0), L.cand_cap);
+        std::vector<uint32_t> l1(std::max(n1, 1));
+        std::vector<float> r1(std::max(n1, 1));
+        if (n1 > 0) {
+            HIPCHK(c, hipMemcpy(l1.data(), c->d_l1 + base, (size_t)n1 * 4, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(r1.data(), c->d_l1_resp + base, (size_t)n1 * 4, hipMemcpyDeviceToHost));
+        }
+        std::unordered_map<uint32_t, float> by_pos;
+        by_pos.reserve((size_t)n1 * 2);
+        for (int i = 0; i < n1; ++i) by_pos[l1[i] & 0x00ffffffu] = r1[i];
+        for (int i = 0; i < m; ++i) {
+            auto it = by_pos.find(packed[i] & 0x00ffffffu);
+            response[i] = it == by_pos.end() ? 0.f : it->second;
+        }
     }
     return n > cap ? AFV_ECAPACITY : AFV_OK;
 }

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "afv_device.h"
@@ -18,8 +19,12 @@
 extern "C" void afv_launch_resize(const uint8_t *src, int sw, int sh, int spitch, size_t sframe, uint8_t *dst, int dw, int dh,
                                   int dpitch, size_t dframe, const short2 *xt, const short2 *yt, int frame_base, int nframes, hipStream_t stream);
 extern "C" int afv_resize_window_ok(int sw, int sh, int dw, int dh);
-extern "C" void afv_launch_fast_harris(const Geo *geo, int total_tiles, const FrameSrc *src0, const uint8_t *pyr,
-                                       uint32_t *cand_packed, float *cand_resp, int *cand_count, int frame_base, int nframes, hipStream_t stream);
+extern "C" void afv_launch_fast_nms(const Geo *geo, int total_tiles, const FrameSrc *src0, const uint8_t *pyr, uint32_t *cand_packed,
+                                    int *cand_count, int frame_base, int nframes, hipStream_t stream);
+extern "C" size_t afv_harris_queue_per_frame(const Geo *g);
+extern "C" void afv_launch_retain_harris(const Geo *geo_dev, int nlevels, const FrameSrc *src0, const uint8_t *pyr,
+                                         const uint32_t *cand_packed, const int *cand_count, uint32_t *l1, int *l1_count,
+                                         float *l1_resp, uint2 *queue, int *queue_n, int frame_base, int nframes, hipStream_t stream);
 extern "C" size_t afv_select_lds_bytes(int M);
 extern "C" void afv_launch_select(const Geo *geo_dev, int nlevels, const uint32_t *cand_packed, const float *cand_resp,
                                   const int *cand_count, uint32_t *kept_xy, float *kept_resp, uint16_t *kept_node, SelPoint *sel,
@@ -109,7 +114,13 @@ struct afv_ctx {
     size_t tab_elems = 0;
     uint8_t *d_pyr = nullptr;
     uint32_t *d_cand_packed = nullptr, *d_kept_xy = nullptr;
-    float *d_cand_resp = nullptr, *d_kept_resp = nullptr;
+    uint32_t *d_l1 = nullptr;          // per (frame, level): the candidates that survive retainBest on the FAST score ...
+    float *d_l1_resp = nullptr;        // ... and their Harris responses
+    int *d_l1_count = nullptr;
+    uint2 *d_hq = nullptr;             // Harris work queue, `hq_per_frame` items per frame; a launch over the frames
+    int *d_hq_n = nullptr;             // [f0, f0 + nf) owns the slice starting at frame f0 and the counter d_hq_n[f0]
+    size_t hq_per_frame = 0;
+    float *d_kept_resp = nullptr;
     uint16_t *d_kept_node = nullptr;
     int *d_cand_count = nullptr, *d_sel_count = nullptr;
     SelPoint *d_sel = nullptr;

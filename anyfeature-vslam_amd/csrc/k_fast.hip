@@ -1,10 +1,10 @@
-// k_fast.hip — E3 + E5 fused: FAST-9/16 score, 3x3 non-max suppression and Harris response.
+// k_fast.hip — E3: FAST-9/16 score and 3x3 non-max suppression.
 //
-// Replaces, for every pyramid level of every frame of the batch, the per-level work of cv::ORB::detect
-// (Feature_orb32.cpp:34): FastFeatureDetector(20, true) (OpenCV fast.cpp FAST_t<16> + cornerScore<16>) and
-// HarrisResponses(blockSize 7, k 0.04) (OpenCV orb.cpp).  One 256-thread workgroup owns a 64x32 tile:
-//   1. the tile plus a 4 px halo is staged in LDS with coalesced dword loads (reflect-101 at the image edge —
-//      FAST never reads it, Harris does, exactly like cv::ORB's 23 px apron);
+// Replaces, for every pyramid level of every frame of the batch, the FastFeatureDetector(20, true) call inside cv::ORB::detect
+// (Feature_orb32.cpp:34; OpenCV fast.cpp FAST_t<16> + cornerScore<16>).  The Harris responses cv::ORB computes next are
+// k_harris.hip's job: they are only needed for the candidates that survive retainBest on the FAST score, which is known once
+// every tile of a level is done.  One 256-thread workgroup owns a 64x32 tile:
+//   1. the tile plus a 4 px halo (ring radius 3 + the NMS neighbour) is staged in LDS with coalesced dword loads;
 //   2a. OpenCV's necessary pre-test (each of the 4 even antipodal ring pairs must hold a brighter / a darker pixel) on
 //      the 66x34 ring-extended tile, TWO horizontally adjacent pixels per lane as packed u16 pairs: per polarity
 //      min over the pairs of max(a, b) - v > t  /  v - max over the pairs of min(a, b) > t.  Survivors go to an LDS list,
@@ -15,9 +15,7 @@
 //      to an LDS score plane (a pixel is a corner in at most one polarity: two 9-arcs of a 16-ring overlap);
 //   3. strict 3x3 maxima, dense over the score plane (again two pixels per lane, packed max), compacted into an LDS list
 //      (<= 512 per tile);
-//   4. that list is processed densely, 4 lanes per candidate: integer Harris sums a,b,c over the 7x7 block with packed
-//      i16 Sobel rows and v_dot2_i32_i16 accumulation, one float expression for the response;
-//   5. one global atomic per tile reserves output slots in the (frame, level) candidate array.
+//   4. one global atomic per tile reserves output slots in the (frame, level) candidate array.
 // Candidates leave the kernel unordered; everything downstream is order-independent (ties are broken by the
 // raster index), see DESIGN.md "canonical order".
 #include <type_traits>
@@ -54,13 +52,6 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_BCAST31, 0xc, 0xf, false);
     return v;
 }
-// sum over aligned groups of 4 lanes (every lane of the group receives the total)
-__device__ __forceinline__ int group4_sum(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, DPP_QUAD_XOR1, 0xf, 0xf, true);
-    v += __builtin_amdgcn_update_dpp(0, v, DPP_QUAD_XOR2, 0xf, 0xf, true);
-    return v;
-}
-
 #define RING_OFF(dx, dy) ((dy) * FT_LW + (dx))
 #define PRE_ROWS (FT_H + 2)             // LDS rows 3 .. 36 (tile pixels -1 .. 32)
 #define PRE_PAIRS ((FT_W + 4) / 2)      // LDS columns 2 .. 69 as 34 pixel pairs at EVEN columns (aligned 16-bit LDS reads); columns
@@ -116,9 +107,9 @@ __device__ __forceinline__ short2v fast_score2(const uint8_t *c0, const uint8_t 
     return best;
 }
 
-__global__ __launch_bounds__(256) void k_fast_harris(const Geo *__restrict__ geo_p, FrameSrc src0, const uint8_t *__restrict__ pyr,
-                                                     uint32_t *__restrict__ cand_packed, float *__restrict__ cand_resp,
-                                                     int *__restrict__ cand_count, int total_blocks, int frame_base) {
+__global__ __launch_bounds__(256) void k_fast_nms(const Geo *__restrict__ geo_p, FrameSrc src0, const uint8_t *__restrict__ pyr,
+                                                  uint32_t *__restrict__ cand_packed, int *__restrict__ cand_count, int total_blocks,
+                                                  int frame_base) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[(FT_LH + 1) * FT_LW + 16];  // + pad: masked pre-test positions (row 34, column 69) read up to one row + 2 bytes past row 39
     __shared__ __attribute__((aligned(16))) uint8_t sc[FT_LH * FT_LW];  // same geometry as `tile`
     __shared__ __attribute__((aligned(4))) unsigned short pre[PRE_MAX];  // bright entries from the front, dark entries from the back
@@ -372,98 +363,20 @@ __global__ __launch_bounds__(256) void k_fast_harris(const Geo *__restrict__ geo
     if (tid == 0) out_base = atomicAdd(&cand_count[f * AFV_MAX_LEVELS + l], n);
     __syncthreads();
 
-    // 4. Harris response for the compacted candidates: 4 lanes per candidate, lane q owns the block rows 2q and 2q + 1 (q = 3: row 6
-    //    only), i.e. the four source rows 2q .. 2q + 3 of the 9 x 9 window, the middle two shared by its two block rows.  A typical
-    //    tile holds ~70 candidates, so one pass of the 256 threads (64 candidates) is usually all there is.  Source rows are
-    //    expanded to packed u16 pairs P_k = (x[2k], x[2k+1]); with S = r0 + 2 r1 + r2 and D = r2 - r0 per column, the gradients
-    //    of columns (2k+1, 2k+2) are
-    //      Ix = S_{k+1} - S_k,   Iy = D_k + D_{k+1} + 2 * (D_k.hi, D_{k+1}.lo),
-    //    and a, b, c accumulate with v_dot2_i32_i16.  Partial sums are combined with 2 DPP steps.
+    // 4. one global atomic per tile reserved the output slots; the survivors leave as (x | y << 12 | score << 24) in level coordinates.
+    //    Their Harris responses are computed later (k_harris.hip) and only for the ones that survive retainBest on the score.
     const size_t obase = L.cand_off + (size_t)f * L.cand_frame_stride + (size_t)out_base;
-    const int q = tid & 3;
-    short2v two;
-    two.x = two.y = 2;
-    for (int c0 = 0; c0 < n; c0 += 64) {
-        const int ci = c0 + (tid >> 2);
-        const bool act = ci < n;
-        const uint32_t e = list[act ? ci : 0];
-        const int px = e & 255, py = (e >> 8) & 255, s = e >> 16;
-        int a = 0, b = 0, cc = 0;
-        if (act) {
-            // 9 row bytes [x-4, x+4] start at byte `sh` of three aligned dwords (w0, w1, w2); the pair (byte sh+2k, byte sh+2k+1)
-            // is picked by ONE v_perm_b32 with a lane-dependent selector: k = 0, 1 from (w1:w0), k = 2, 3 from (w2:w1) with the
-            // same two selectors, k = 4 (byte sh+8, low half only) from w2
-            const int xa = (px + FT_HALO - 4) & ~3, sh = (px + FT_HALO - 4) & 3;
-            const uint32_t selA = 0x0c010c00u + (uint32_t)sh * 0x00010001u, selB = selA + 0x00020002u, selC = 0x0c0c0c00u + (uint32_t)sh;
-            // source row 2q of the window = tile row (py + HALO - 4) + 2q; the last lane's fourth row (window row 9) does not
-            // exist: it re-reads row 8 and its block row is dropped below
-            const uint8_t *rowp = &tile[(py + FT_HALO - 4 + 2 * q) * FT_LW + xa];
-            const int last = (q == 3) ? 2 * FT_LW : 3 * FT_LW;
-            short2v R0[5], R1[5], R2[5], R3[5];
-#define LOAD_ROW(R, PTR)                                                        \
-    {                                                                           \
-        const uint32_t w0 = *reinterpret_cast<const uint32_t *>(PTR);            \
-        const uint32_t w1 = *reinterpret_cast<const uint32_t *>((PTR) + 4);      \
-        const uint32_t w2 = *reinterpret_cast<const uint32_t *>((PTR) + 8);      \
-        R[0] = as_s2(__builtin_amdgcn_perm(w1, w0, selA));                       \
-        R[1] = as_s2(__builtin_amdgcn_perm(w1, w0, selB));                       \
-        R[2] = as_s2(__builtin_amdgcn_perm(w2, w1, selA));                       \
-        R[3] = as_s2(__builtin_amdgcn_perm(w2, w1, selB));                       \
-        R[4] = as_s2(__builtin_amdgcn_perm(0u, w2, selC));                       \
-    }
-            LOAD_ROW(R0, rowp)
-            LOAD_ROW(R1, rowp + FT_LW)
-            LOAD_ROW(R2, rowp + 2 * FT_LW)
-            LOAD_ROW(R3, rowp + last)
-#undef LOAD_ROW
-            auto block_row = [&](const short2v *r0, const short2v *r1, const short2v *r2, int &sa, int &sb, int &sc_) {
-                short2v Sp[5], Dp[5];
-#pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    Sp[k] = r1[k] * two + r0[k] + r2[k];
-                    Dp[k] = r2[k] - r0[k];
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    short2v Ix = Sp[k + 1] - Sp[k];
-                    const short2v O = as_s2(__builtin_amdgcn_alignbit(as_u32(Dp[k + 1]), as_u32(Dp[k]), 16));
-                    short2v Iy = O * two + Dp[k] + Dp[k + 1];
-                    if (k == 3) {  // column 8 is outside the block
-                        Ix = as_s2(as_u32(Ix) & 0xffffu);
-                        Iy = as_s2(as_u32(Iy) & 0xffffu);
-                    }
-                    sa = __builtin_amdgcn_sdot2(Ix, Ix, sa, false);
-                    sb = __builtin_amdgcn_sdot2(Iy, Iy, sb, false);
-                    sc_ = __builtin_amdgcn_sdot2(Ix, Iy, sc_, false);
-                }
-            };
-            block_row(R0, R1, R2, a, b, cc);
-            int a2 = 0, b2 = 0, c2 = 0;
-            block_row(R1, R2, R3, a2, b2, c2);
-            if (q < 3) {
-                a += a2;
-                b += b2;
-                cc += c2;
-            }
-        }
-        a = group4_sum(a);
-        b = group4_sum(b);
-        cc = group4_sum(cc);
-        if (act && q == 0) {
-            const float fa = (float)a, fb = (float)b, fc = (float)cc;
-            const float sum = fa + fb;
-            const float resp = ((fa * fb - fc * fc) - (0.04f * sum) * sum) * geo.harris_scale4;
-            const int gx = gx0 + FT_HALO + px, gy = gy0 + FT_HALO + py;
-            cand_packed[obase + ci] = (uint32_t)gx | ((uint32_t)gy << 12) | ((uint32_t)s << 24);
-            cand_resp[obase + ci] = resp;
-        }
+    for (int ci = tid; ci < n; ci += 256) {
+        const uint32_t e = list[ci];
+        const int gx = gx0 + FT_HALO + (int)(e & 255u), gy = gy0 + FT_HALO + (int)((e >> 8) & 255u);
+        cand_packed[obase + ci] = (uint32_t)gx | ((uint32_t)gy << 12) | ((e >> 16) << 24);
     }
 }
 
 // `geo` is the DEVICE copy of the geometry
-extern "C" void afv_launch_fast_harris(const Geo *geo, int total_tiles, const FrameSrc *src0, const uint8_t *pyr, uint32_t *cand_packed,
-                                       float *cand_resp, int *cand_count, int frame_base, int nframes, hipStream_t stream) {
+extern "C" void afv_launch_fast_nms(const Geo *geo, int total_tiles, const FrameSrc *src0, const uint8_t *pyr, uint32_t *cand_packed,
+                                    int *cand_count, int frame_base, int nframes, hipStream_t stream) {
     const int total = total_tiles * nframes;
     dim3 grid((total + 7) / 8 * 8);
-    hipLaunchKernelGGL(k_fast_harris, grid, dim3(256), 0, stream, geo, *src0, pyr, cand_packed, cand_resp, cand_count, total, frame_base);
+    hipLaunchKernelGGL(k_fast_nms, grid, dim3(256), 0, stream, geo, *src0, pyr, cand_packed, cand_count, total, frame_base);
 }

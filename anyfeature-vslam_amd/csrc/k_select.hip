@@ -1,13 +1,13 @@
-// k_select.hip — E4 + E7: retainBest x2 and DistributeOctTree, one workgroup per (frame, level).
+// k_select.hip — E4b + E7: retainBest on the Harris response and DistributeOctTree, one workgroup per (frame, level).
 //
-// Replaces KeyPointsFilter::retainBest(2*quota) on the FAST score and retainBest(quota) on the Harris response
-// (inside cv::ORB::detect, Feature_orb32.cpp:34) and FeatureExtractor::DistributeOctTree
+// Replaces KeyPointsFilter::retainBest(quota) on the Harris response (inside cv::ORB::detect, Feature_orb32.cpp:34; the
+// retainBest(2*quota) on the FAST score before it is k_harris.hip's k_retain_score) and FeatureExtractor::DistributeOctTree
 // (ORBextractor.cc:239-458, called through filterKeypoints_notScaled FeatureExtractor.cpp:276-284).
 //
 // Everything here is a SET operation plus a deterministic sequential algorithm, re-expressed so that 256 lanes can
 // run it in lock step:
-//   * retainBest = "keep everything >= the k-th largest key": k-th largest by histogram (8-bit FAST score) and by a
-//     3-pass 11/11/10-bit radix select on the order-preserving integer image of the float response.
+//   * retainBest = "keep everything >= the k-th largest key": k-th largest by a 3-pass 11/11/10-bit radix select on the
+//     order-preserving integer image of the float response.
 //   * DistributeOctTree is a level-synchronous quadtree build.  std::list order is fully determined by creation
 //     order (children are always push_front'ed, nodes never move), so the list is kept as a dense array in list
 //     order and every round recomputes it with prefix sums:
@@ -198,43 +198,19 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         _Pragma("unroll") for (int k_ = 0; k_ < CPT; ++k_) {    \
             if (k_ * ST >= n) break;                            \
             if (k_ * ST + tid < n) {                            \
-                const uint32_t e = cpk[k_];                     \
                 const float r = crs[k_];                        \
-                (void)r;                                        \
                 BODY                                            \
             }                                                   \
         }                                                       \
     } else {                                                    \
         for (int i_ = tid; i_ < n; i_ += ST) {                  \
-            const uint32_t e = cp[i_];                          \
             const float r = cr[i_];                             \
-            (void)r;                                            \
             BODY                                                \
         }                                                       \
     }
 
-    // ---------------- E4a: threshold on the FAST score ----------------
-    int T1 = 0;
-    if (n > 2 * L.cv_quota) {  // uniform branch
-        for (int i = tid; i < 256; i += ST) hist[i] = 0;
-        __syncthreads();
-        FOR_CAND(atomicAdd(&hist[e >> 24], 1);)
-        __syncthreads();
-        int above;
-        T1 = block_kth_from_top(hist, 256, 2 * L.cv_quota, &above, tmp);
-    }
-    // ---------------- E4b: threshold on the Harris response among the survivors ----------------
-    if (tid == 0) tmp[8] = 0;
-    __syncthreads();
-    {
-        int c = 0;
-        FOR_CAND(c += ((int)(e >> 24) >= T1);)
-        c = wave_incl_scan(c);
-        if (lane == 63) atomicAdd(&tmp[8], c);
-    }
-    __syncthreads();
-    const int n1 = tmp[8];
-    __syncthreads();
+    // ---------------- E4b: threshold on the Harris response (retainBest on the score already happened: k_harris.hip) ----------------
+    const int n1 = n;
     uint32_t T2 = 0;
     if (n1 > L.cv_quota) {  // uniform
         int k = L.cv_quota;
@@ -245,7 +221,7 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             const int sh = shifts[p];
             for (int i = tid; i < nb; i += ST) hist[i] = 0;
             __syncthreads();
-            FOR_CAND(if ((int)(e >> 24) >= T1) {
+            FOR_CAND({
                 const uint32_t key = float_key(r);
                 if ((key & mask) == prefix) atomicAdd(&hist[(key >> sh) & (nb - 1)], 1);
             })
@@ -263,7 +239,7 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     __syncthreads();
     {
         int c = 0;
-        FOR_CAND(c += ((int)(e >> 24) >= T1) && (float_key(r) >= T2);)
+        FOR_CAND(c += (float_key(r) >= T2);)
         c = wave_incl_scan(c);
         if (lane == 63) atomicAdd(&tmp[9], c);
     }
@@ -304,7 +280,7 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         for (int k_ = 0; k_ < CPT; ++k_) {
             if (k_ * ST >= n) break;
             const bool in = k_ * ST + tid < n;
-            emit(in && ((int)(cpk[k_] >> 24) >= T1) && (float_key(crs[k_]) >= T2), cpk[k_], crs[k_]);
+            emit(in && (float_key(crs[k_]) >= T2), cpk[k_], crs[k_]);
         }
     } else {
         for (int i0 = 0; i0 < n; i0 += ST) {
@@ -315,7 +291,7 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                 e = cp[i];
                 r = cr[i];
             }
-            emit(i < n && ((int)(e >> 24) >= T1) && (float_key(r) >= T2), e, r);
+            emit(i < n && (float_key(r) >= T2), e, r);
         }
     }
     __syncthreads();

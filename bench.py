@@ -12,7 +12,7 @@ N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), frames shar
 collective (weak scaling: B frames per GPU per step); barrier + synchronize around the timed region, max over ranks.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (k_fast_harris): algorithmic bytes (every pyramid pixel read once = 950 532 B/frame at
+  roofline      dominant kernel (k_fast_nms): algorithmic bytes (every pyramid pixel read once = 950 532 B/frame at
                 640x480) x frames per launch / mean launch duration measured with hipEvents recorded on
                 the launch stream inside the timed region; peak = 8 TB/s HBM3E.
   cpu_baseline  the CPU oracle (oracle/, kind "port": the reference cannot be built here) timed single-threaded on
@@ -698,19 +698,19 @@ def main():
         }
         if stages:
             px = level_pixels(W, H)
-            fh = stages["fast_harris"]
+            fh = stages["fast_nms"]
             if fh["launches"]:
                 ms = fh["total_ms"] / fh["launches"]                 # mean launch duration (hipEvents on the launch stream)
                 frames_per_launch = fh["units"] / fh["launches"]     # the runtime splits a batch over two streams
                 achieved = px * frames_per_launch / (ms * 1e-3) / 1e9
-                traffic, tpath, tstale = pmc_traffic("k_fast_harris", B)
-                out["roofline"] = {"bound": "hbm", "kernel": "k_fast_harris", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                traffic, tpath, tstale = pmc_traffic("k_fast_nms", B)
+                out["roofline"] = {"bound": "hbm", "kernel": "k_fast_nms", "achieved": achieved, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                    "traffic": None if (traffic is None or tstale) else traffic * frames_per_launch,
                                    "traffic_source": tpath, "traffic_stale": bool(tstale),
                                    "algorithmic_bytes_per_launch": px * frames_per_launch, "avg_launch_ms": ms,
                                    "frames_per_launch": frames_per_launch,
-                                   "note": "integer-VALU-bound kernel (FAST ring tests + Harris): the HBM fraction is low by "
+                                   "note": "integer-VALU-bound kernel (FAST ring tests, exact scores, NMS): the HBM fraction is low by "
                                            "construction; the runtime runs a step as four quarter-batch launches per kernel over two "
                                            "streams, so a launch shares the chip with the other stream's kernels (DESIGN.md section 4); "
                                            "traffic = committed PMC pass, null when the sources changed since (traffic_stale)"}

@@ -303,9 +303,10 @@ int afv_hamming256(const uint8_t *a, const uint8_t *b);
  * brackets each kernel stage with hipEvents recorded on the stream the kernels are launched on.
  * afv_profile_read waits for the recorded events and returns, per stage, the number of launches and the summed
  * duration in milliseconds since the last afv_profile_enable(ctx, 1).  Stages: ---- */
-enum { AFV_STAGE_PYRAMID = 0, AFV_STAGE_FAST_HARRIS = 1, AFV_STAGE_SELECT = 2, AFV_STAGE_DESCRIBE = 3,
+enum { AFV_STAGE_PYRAMID = 0, AFV_STAGE_FAST_NMS = 1 /* k_fast_nms */, AFV_STAGE_SELECT = 2, AFV_STAGE_DESCRIBE = 3,
        AFV_STAGE_MATCH = 4 /* k_match_topk: the xor + popcount phase */, AFV_STAGE_MATCH_RESOLVE = 5 /* ordered greedy resolve */,
-       AFV_NUM_STAGES = 6 };
+       AFV_STAGE_HARRIS = 6 /* k_retain_score + k_harris: retainBest on the score, Harris response of the survivors */,
+       AFV_NUM_STAGES = 7 };
 int afv_profile_enable(afv_ctx *ctx, int enable);
 int afv_profile_read(afv_ctx *ctx, int32_t *launches /*[AFV_NUM_STAGES]*/, float *total_ms /*[AFV_NUM_STAGES]*/,
                      int64_t *units /*[AFV_NUM_STAGES], frames (pairs for MATCH) covered by those launches; may be NULL*/);

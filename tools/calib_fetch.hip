@@ -1,6 +1,6 @@
 // calib_fetch.hip — calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE against a known byte count for the access widths
 // this project uses (MI355X_MICROARCH.md §HBM: FETCH_SIZE is only calibrated for 16 B/lane streams).
-//   k_read4  : coalesced 4 B/lane reads  (the LDS tile staging of k_fast_harris / k_resize_level / k_describe)
+//   k_read4  : coalesced 4 B/lane reads  (the LDS tile staging of k_fast_nms / k_resize_level / k_describe)
 //   k_read16 : coalesced 16 B/lane reads (the guide's reference pattern: expected to report 1/2)
 //   k_write4 : coalesced 4 B/lane writes
 // Each kernel moves exactly BYTES bytes of a buffer larger than the 256 MiB Infinity Cache.

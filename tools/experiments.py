@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel experiments: build variant libraries (extra -D flags) next to the real one under anyfeature-vslam_amd/build_exp/ and
-time / count them on the GPU box.  Variants may produce wrong results (e.g. AFV_FAST_STOP=n ends k_fast_harris after stage n to
+time / count them on the GPU box.  Variants may produce wrong results (e.g. AFV_FAST_STOP=n ends k_fast_nms after stage n to
 attribute its cost) — this is measurement tooling, never the product.  Usage:
   python tools/experiments.py build NAME=FLAG[,FLAG...] ...      (here or on the box)
   python tools/experiments.py run NAME ...                        (on the box: bench --no-profile under rocprofv3 PMC)
@@ -37,17 +37,18 @@ def run(name, batch=256):
            "--output-format", "csv", "--", sys.executable, os.path.join(ROOT, "bench.py"), "--batch", str(batch), "--steps", "2", "--warmup", "1",
            "--cpu-frames", "0", "--no-profile", "--no-extras"]
     subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
-    res = {"name": name}
+    kern = os.environ.get("AFV_EXP_KERNEL", "k_fast_nms")
+    res = {"name": name, "kernel": kern}
     acc, cnt = {}, {}
     for r in csv.DictReader(open(glob.glob(os.path.join(out, "**", "pmc_counter_collection.csv"), recursive=True)[0])):
-        if "k_fast_harris" in r["Kernel_Name"]:
+        if kern in r["Kernel_Name"]:
             acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
             cnt[r["Counter_Name"]] = cnt.get(r["Counter_Name"], 0) + 1
     frames_per_launch = batch / 4
     for k in acc:
         res[k + "_per_frame"] = acc[k] / cnt[k] / frames_per_launch
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in
-         csv.DictReader(open(glob.glob(os.path.join(out, "**", "pmc_kernel_trace.csv"), recursive=True)[0])) if "k_fast_harris" in r["Kernel_Name"]]
+         csv.DictReader(open(glob.glob(os.path.join(out, "**", "pmc_kernel_trace.csv"), recursive=True)[0])) if kern in r["Kernel_Name"]]
     res["us_per_launch"] = sum(d) / len(d)
     res["frames_per_launch"] = frames_per_launch
     print(json.dumps(res), flush=True)
