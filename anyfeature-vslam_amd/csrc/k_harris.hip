@@ -226,7 +226,10 @@ __global__ __launch_bounds__(256) void k_harris(const Geo *__restrict__ geo_p, F
     const int lane = threadIdx.x & 63;
     // one queue item per wavefront and step; a contiguous range of the queue per wavefront (neighbouring items are neighbouring
     // candidates of one level image)
-    const int nwaves = (int)gridDim.x * 4, wv = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+    // XCD-aware: the workgroups of one XCD take one contiguous eighth of the queue, so the chunks of a level image (contiguous in
+    // the queue) are fetched through one L2 instead of eight (gridDim.x is a multiple of 8)
+    const int nwaves = (int)gridDim.x * 4;
+    const int wv = __builtin_amdgcn_readfirstlane(afv_xcd_remap((int)blockIdx.x, (int)gridDim.x) * 4 + (int)(threadIdx.x >> 6));
     const int per = (qn + nwaves - 1) / nwaves;
     const int w_end = min(qn, (wv + 1) * per);
     for (int w = wv * per; w < w_end; ++w) {
@@ -249,6 +252,6 @@ extern "C" void afv_launch_retain_harris(const Geo *geo_dev, int nlevels, const 
     const int total = nlevels * nframes;
     hipLaunchKernelGGL(k_retain_score, dim3((total + 7) / 8 * 8), dim3(256), 0, stream, geo_dev, cand_packed, cand_count, l1, l1_count,
                        queue, queue_n, frame_base, total);
-    const int grid = (int)std::min<long>(std::max<long>((long)nframes * 80, 256), 65536);  // 4 items per workgroup and step
+    const int grid = (int)std::min<long>(std::max<long>((long)nframes * 80, 256), 65536) & ~7;  // 4 items per workgroup and step
     hipLaunchKernelGGL(k_harris, dim3(grid), dim3(256), 0, stream, geo_dev, *src0, pyr, l1, l1_resp, queue, queue_n);
 }

@@ -60,6 +60,43 @@ def test_fast_nms_harris_candidates(gpu_ctx, oracle, frames, name):
             assert gmap[(int(c["y"]), int(c["x"]))] == int(np.float32(c["response"]).view(np.uint32)), (l, c)
 
 
+def _border_dots(w, h, seed=11):
+    """isolated bright pixels (each one a FAST corner) on a background whose contrast stays below the FAST threshold, placed on
+    the first / last positions FAST can report: their 9 x 9 Harris windows leave the image by one pixel on every side and in
+    every corner (BORDER_REFLECT_101), and the bottom-right ones end at the last byte of the frame"""
+    rng = np.random.default_rng(seed)
+    img = rng.integers(40, 60, size=(h, w), dtype=np.uint8)
+    xs = list(range(3, w - 12, 16)) + [w - 4]   # a 16 px lattice (isolated corners) that starts and ends on the FAST border
+    ys = list(range(3, h - 12, 16)) + [h - 4]
+    for y in ys:
+        for x in xs:
+            img[y, x] = 250
+    return img
+
+
+@pytest.mark.parametrize("w,h", [(640, 480), (642, 481), (203, 150)])
+def test_harris_windows_at_the_image_border(afv, oracle, w, h):
+    """k_harris reads the windows from the level image itself: the reflected row / column, the left-edge byte shift and the
+    last-bytes-of-the-image path are only reached by corners on the outermost FAST positions"""
+    img = _border_dots(w, h)
+    ctx = afv.Context(max_width=w, max_height=h, max_batch=1)
+    ctx.extract(img)
+    _, _, tr = oracle.orb_extract_trace(img)
+    n_checked = 0
+    for l in range(8):
+        got, oc, keep1 = _cand_sets(ctx, tr, l)
+        assert [g[:3] for g in got] == sorted(zip(oc["y"].tolist(), oc["x"].tolist(), oc["fast_score"].tolist())), l
+        gmap = {(g[0], g[1]): g[3] for g in got}
+        for c in oc[keep1]:
+            assert gmap[(int(c["y"]), int(c["x"]))] == int(np.float32(c["response"]).view(np.uint32)), (l, c)
+            n_checked += 1
+    c0 = tr["cand"][(tr["cand"]["level"] == 0) & tr["keep1"]]
+    on_edge = {(int(c["x"]), int(c["y"])) for c in c0}
+    assert {(3, 3), (w - 4, h - 4), (3, h - 4), (w - 4, 3)} <= on_edge, "the corner positions must be candidates for this test to bite"
+    assert n_checked >= 49
+    ctx.close()
+
+
 def test_harris_integer_sums(gpu_ctx, oracle, frames):
     """the response is a pure function of the integer sums (a,b,c): equal float bits <=> equal sums for the oracle's
     expression; check the expression itself against the oracle's on the sums of real candidates"""
