@@ -388,11 +388,9 @@ static void enqueue_range(afv_ctx *c, const FrameSrc &src, int f0, int nf, afv_k
         afv_launch_select(c->d_geo, g.nlevels, c->d_l1, c->d_l1_resp, c->d_l1_count, c->d_kept_xy, c->d_kept_resp,
                           c->d_kept_node, c->d_sel, c->d_sel_count, c->select_M, f0, nf, s);
     }
-    int max_sel = 0;
-    for (int l = 0; l < g.nlevels; ++l) max_sel = std::max(max_sel, g.lv[l].sel_cap);
     {
         StageTimer t_(c, AFV_STAGE_DESCRIBE, s, nf);
-        afv_launch_describe(c->d_geo, g.nlevels, max_sel, &src, c->d_pyr, c->d_sel, c->d_sel_count, d_kps, d_desc, cap, d_n,
+        afv_launch_describe(c->d_geo, afv_describe_blocks_per_frame(&g), &src, c->d_pyr, c->d_sel, c->d_sel_count, d_kps, d_desc, cap, d_n,
                             d_status, f0, nf, s);
     }
 }

@@ -29,7 +29,8 @@ extern "C" size_t afv_select_lds_bytes(int M);
 extern "C" void afv_launch_select(const Geo *geo_dev, int nlevels, const uint32_t *cand_packed, const float *cand_resp,
                                   const int *cand_count, uint32_t *kept_xy, float *kept_resp, uint16_t *kept_node, SelPoint *sel,
                                   int *sel_count, int M, int frame_base, int nframes, hipStream_t stream);
-extern "C" void afv_launch_describe(const Geo *geo_dev, int nlevels, int max_sel_cap, const FrameSrc *src0, const uint8_t *pyr,
+extern "C" int afv_describe_blocks_per_frame(const Geo *g);
+extern "C" void afv_launch_describe(const Geo *geo_dev, int blocks_per_frame, const FrameSrc *src0, const uint8_t *pyr,
                                     const SelPoint *sel, const int *sel_count, afv_keypoint *kps, uint8_t *desc,
                                     int cap_per_frame, int *n_out, int *status, int frame_base, int nframes, hipStream_t stream);
 extern "C" void afv_launch_blur_level(const uint8_t *img, int w, int h, int pitch, uint8_t *out, hipStream_t stream);

@@ -82,10 +82,15 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// sum over the 64 lanes (every lane receives it): DPP row reductions, then the last lane's total through a scalar register
 __device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112 /*row_shr:2*/, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114 /*row_shr:4*/, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118 /*row_shr:8*/, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142 /*row_bcast:15*/, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143 /*row_bcast:31*/, 0xc, 0xf, false);
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 __device__ __forceinline__ uint8_t blur_round(int S) {
@@ -121,11 +126,25 @@ __device__ __forceinline__ void blur_rows(const uint8_t *P, uint16_t *H, int lan
 
 // column pass + rounding at patch position (row y, column x), taps centred: exact integer arithmetic of the separable filter,
 // then round-half-even(S / 65536)
+typedef unsigned short ushort2d __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int blur_at(const uint16_t *H, int x, int y) {
     const uint16_t *c = H + (y - 3) * HP + (x - 3);
-    const int S = 18 * ((int)c[0] + (int)c[6 * HP]) + 34 * ((int)c[HP] + (int)c[5 * HP]) + 49 * ((int)c[2 * HP] + (int)c[4 * HP]) +
-                  55 * (int)c[3 * HP];
-    return blur_round(S);
+    // symmetric taps: rows k and 6 - k share a weight -> three v_dot2_u32_u16 on (row k, row 6 - k) pairs + the centre row
+    ushort2d p0, p1, p2, t0, t1, t2;
+    p0.x = c[0];
+    p0.y = c[6 * HP];
+    p1.x = c[HP];
+    p1.y = c[5 * HP];
+    p2.x = c[2 * HP];
+    p2.y = c[4 * HP];
+    t0.x = t0.y = 18;
+    t1.x = t1.y = 34;
+    t2.x = t2.y = 49;
+    uint32_t S = 55u * (uint32_t)c[3 * HP];
+    S = __builtin_amdgcn_udot2(p0, t0, S, false);
+    S = __builtin_amdgcn_udot2(p1, t1, S, false);
+    S = __builtin_amdgcn_udot2(p2, t2, S, false);
+    return blur_round((int)S);
 }
 
 __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__restrict__ geo_p, FrameSrc src0,
@@ -134,7 +153,7 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
                                                                 const int *__restrict__ sel_count,
                                                                 afv_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
                                                                 int cap_per_frame, int *__restrict__ n_out,
-                                                                int *__restrict__ status, int frame_base, int nblk_x, int total_blocks) {
+                                                                int *__restrict__ status, int frame_base, int per_frame, int total_blocks) {
     // patch rows are PP = 52 bytes apart (13 dwords: odd -> rows spread over all LDS banks); 2 guard rows/dwords so that
     // the 3-dword row reads of blur_at never leave the slice
     __shared__ __attribute__((aligned(16))) uint8_t s_patch[KP_PER_BLOCK][(PS + 1) * PP];
@@ -144,9 +163,14 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
     // XCD-aware placement: all keypoints of a frame are described on one XCD (their patches share L2 lines)
     const int work = afv_xcd_remap(blockIdx.x, total_blocks);
     if (work >= total_blocks) return;
-    const int per_frame = nblk_x * geo.nlevels;
-    const int fl = work / per_frame, rem = work - fl * per_frame;
-    const int l = rem / nblk_x, kblk = rem - l * nblk_x;
+    // a frame's blocks: level after level, ceil(sel_cap / KP_PER_BLOCK) blocks each (per_frame in total)
+    const int fl = work / per_frame;
+    int kblk = work - fl * per_frame, l = 0;
+    for (; l + 1 < geo.nlevels; ++l) {
+        const int nb = (geo.lv[l].sel_cap + KP_PER_BLOCK - 1) / KP_PER_BLOCK;
+        if (kblk < nb) break;
+        kblk -= nb;
+    }
     const int f = frame_base + fl;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int idx = kblk * KP_PER_BLOCK + wv;
@@ -193,10 +217,15 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
         const int ax0 = px0 - a;
         const int rr = lane / 12, rq = lane - rr * 12;
         if (lane < 60) {
-            for (int r = rr; r < PS; r += 5) {
-                const uint32_t v = *reinterpret_cast<const uint32_t *>(img + (size_t)(py0 + r) * pitch + ax0 + rq * 4);
-                *reinterpret_cast<uint32_t *>(&P[r * PP + rq * 4]) = v;
-            }
+            const uint8_t *gp = img + (size_t)(py0 + rr) * pitch + ax0 + rq * 4;
+            uint8_t *lp = &P[rr * PP + rq * 4];
+            uint32_t v[9];  // rows rr, rr + 5, ..., rr + 40 (PS = 43: the last one exists for rr < 3): loads first, then the LDS writes
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                if (k < 8 || rr < PS - 40) v[k] = *reinterpret_cast<const uint32_t *>(gp + (size_t)k * 5 * pitch);
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                if (k < 8 || rr < PS - 40) *reinterpret_cast<uint32_t *>(lp + k * 5 * PP) = v[k];
         }
     } else {
         // border: lane = patch column (reflected once), rows reflected per iteration (wave-uniform)
@@ -306,14 +335,19 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
     }
 }
 
-extern "C" void afv_launch_describe(const Geo *geo_dev, int nlevels, int max_sel_cap, const FrameSrc *src0, const uint8_t *pyr,
+extern "C" int afv_describe_blocks_per_frame(const Geo *g) {
+    int n = 0;
+    for (int l = 0; l < g->nlevels; ++l) n += (g->lv[l].sel_cap + KP_PER_BLOCK - 1) / KP_PER_BLOCK;
+    return n;
+}
+
+extern "C" void afv_launch_describe(const Geo *geo_dev, int blocks_per_frame, const FrameSrc *src0, const uint8_t *pyr,
                                     const SelPoint *sel, const int *sel_count, afv_keypoint *kps, uint8_t *desc,
                                     int cap_per_frame, int *n_out, int *status, int frame_base, int nframes, hipStream_t stream) {
-    const int nblk_x = (max_sel_cap + KP_PER_BLOCK - 1) / KP_PER_BLOCK;
-    const int total = nblk_x * nlevels * nframes;
+    const int total = blocks_per_frame * nframes;
     dim3 grid((total + 7) / 8 * 8);
     hipLaunchKernelGGL(k_describe, grid, dim3(64 * KP_PER_BLOCK), 0, stream, geo_dev, *src0, pyr, sel, sel_count, kps, desc,
-                       cap_per_frame, n_out, status, frame_base, nblk_x, total);
+                       cap_per_frame, n_out, status, frame_base, blocks_per_frame, total);
 }
 
 // ---------------- standalone E9: blur one level of one frame (debug / parity of the blur arithmetic) ----------------

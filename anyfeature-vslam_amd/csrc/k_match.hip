@@ -72,6 +72,12 @@ __device__ __forceinline__ void merge_best(int &k, int &s, int k2, int s2) {
     }
 }
 
+__device__ __forceinline__ int med3_i32(int a, int b, int c) {  // v_med3_i32 (no clang builtin for the integer form)
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 template <int W>
 __device__ __forceinline__ int hamming_words(const uint32_t *a_regs, const uint32_t *b) {
     int d = 0;
@@ -332,11 +338,11 @@ __global__ __launch_bounds__(MT) void k_match_topk(const uint8_t *__restrict__ d
             int d = __popc(q0.x ^ c_lo.x) + __popc(q0.y ^ c_lo.y) + __popc(q0.z ^ c_lo.z) + __popc(q0.w ^ c_lo.w);
             d += __popc(q1.x ^ c_hi.x) + __popc(q1.y ^ c_hi.y) + __popc(q1.z ^ c_hi.z) + __popc(q1.w ^ c_hi.w);
             const int key = (d << 16) | (c0 + j);
-            int t = min(k[3], key);
-            const int m3 = max(k[2], t); t = min(k[2], t);
-            const int m2 = max(k[1], t); t = min(k[1], t);
-            const int m1 = max(k[0], t);
-            k[0] = min(k[0], t); k[1] = m1; k[2] = m2; k[3] = m3;
+            // sorted insert into k[0] <= k[1] <= k[2] <= k[3], the largest of the five falls out: the new k[i] is the median of
+            // (k[i-1], k[i], key) — one v_min + three v_med3 per column
+            const int n3 = med3_i32(k[2], k[3], key), n2 = med3_i32(k[1], k[2], key);
+            const int n1 = med3_i32(k[0], k[1], key);
+            k[0] = min(k[0], key); k[1] = n1; k[2] = n2; k[3] = n3;
         }
     }
     if (row < n1) topk[(size_t)p * cap + row] = make_int4(k[0], k[1], k[2], k[3]);
