@@ -13,6 +13,8 @@
 //   * k_match_bow_seg (+ k_match_bow_finish) — BoW-guided jobs, one wavefront per shared vocabulary node;
 //   * k_match_bow — generic ordered workgroup-per-job kernel (jobs with validity masks / KF-Frame mode and one node).
 // SearchForTriangulation (k_match_tri) has no cross-row dependency: every wavefront takes its own rows.
+#include <algorithm>
+
 #include "afv_device.h"
 
 
@@ -348,31 +350,34 @@ __global__ __launch_bounds__(MT) void k_match_topk(const uint8_t *__restrict__ d
     if (row < n1) topk[(size_t)p * cap + row] = make_int4(k[0], k[1], k[2], k[3]);
 }
 
-#define PAIR_MAX_SIDE 4096  // rows / columns per set in the pairs path (LDS tables below)
-#define PAIR_LDS_DESC 1280  // side-2 sets up to this size are copied to LDS (40 KB) so that rescans never leave the CU
+#define PAIR_MAX_SIDE 4096  // rows / columns per set in the pairs path (16-bit row / column indices)
+#define PAIR_KEYS_LDS 2048  // top-4 keys of at most this many live rows are staged in LDS
+
+// LDS of one k_match_resolve workgroup, sized by the per-set capacity of the launch (23 KB at cap = 1024, so several pairs share a
+// CU: the ordered walk is one wavefront deep and latency-bound, what a batch costs is set by how many walks run at once)
+static inline size_t resolve_lds_bytes(int cap) {
+    const size_t c = ((size_t)cap + 63) & ~(size_t)63;
+    return std::min<size_t>(c, PAIR_KEYS_LDS) * 16 /*keys*/ + c * 4 /*claim*/ + c * 2 /*live*/ + c /*bin*/ + c / 8 /*matched*/;
+}
 
 __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict__ desc, const float *__restrict__ ang, int ang_stride,
                                                       const int *__restrict__ nset, int cap, const int *__restrict__ pair_a,
                                                       const int *__restrict__ pair_b, const int4 *__restrict__ topk, float th,
                                                       float ratio, int check_ori, int *__restrict__ match,
                                                       int *__restrict__ nmatches, int pair_base) {
-    __shared__ uint32_t s_matched[PAIR_MAX_SIDE / 32];
-    __shared__ uint8_t s_bin[PAIR_MAX_SIDE];
-    __shared__ unsigned short s_live[PAIR_MAX_SIDE];
-    __shared__ int s_claim[PAIR_MAX_SIDE];
-    __shared__ __attribute__((aligned(16))) int4 s_keys[2048];  // top-4 keys of the live rows (first 2048 of them)
-    __shared__ __attribute__((aligned(16))) uint32_t s_d2[PAIR_LDS_DESC * 8];  // side-2 descriptors for the exact rescan
+    extern __shared__ __attribute__((aligned(16))) char s_dyn[];
+    const int capr = (cap + 63) & ~63;
+    int4 *s_keys = reinterpret_cast<int4 *>(s_dyn);  // top-4 keys of the live rows (first PAIR_KEYS_LDS of them)
+    int *s_claim = reinterpret_cast<int *>(s_keys + min(capr, PAIR_KEYS_LDS));
+    unsigned short *s_live = reinterpret_cast<unsigned short *>(s_claim + capr);
+    uint8_t *s_bin = reinterpret_cast<uint8_t *>(s_live + capr);
+    uint32_t *s_matched = reinterpret_cast<uint32_t *>(s_bin + capr);
     __shared__ int s_hist[32];
     __shared__ int s_wave[8];
     __shared__ int s_nm, s_drop[3];
     const int p = pair_base + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int a = pair_a[p], b = pair_b[p];
     const int n1 = min(nset[a], cap), n2 = min(nset[b], cap);
-    const bool d2_in_lds = n2 <= PAIR_LDS_DESC;
-    if (d2_in_lds) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(desc + (size_t)b * cap * 32);
-        for (int i = tid; i < n2 * 2; i += MT) reinterpret_cast<uint4 *>(s_d2)[i] = src[i];
-    }
     const int4 *tk = topk + (size_t)p * cap;
     int *out = match + (size_t)p * cap;
     for (int i = tid; i < cap; i += MT) out[i] = -1;
@@ -394,7 +399,7 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
         if (live) {
             const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
             s_live[slot] = (unsigned short)i;
-            if (slot < 2048) s_keys[slot] = t4;
+            if (slot < PAIR_KEYS_LDS) s_keys[slot] = t4;
         }
         nlive += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
         __syncthreads();
@@ -408,14 +413,14 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
         // and the outcome is exactly that of the sequential loop (FeatureMatcher.cc:587-641).
         int nm = 0;
         const uint32_t *d1 = reinterpret_cast<const uint32_t *>(desc + (size_t)a * cap * 32);
-        const uint32_t *d2 = d2_in_lds ? s_d2 : reinterpret_cast<const uint32_t *>(desc + (size_t)b * cap * 32);
+        const uint32_t *d2 = reinterpret_cast<const uint32_t *>(desc + (size_t)b * cap * 32);  // the rescan (rare) reads through L2
         int pos = 0;
         while (pos < nlive) {
             const int li = pos + lane;
             const bool act = li < nlive;
             const int row = act ? s_live[li] : 0;
             int4 t4 = make_int4(NO_KEY, NO_KEY, NO_KEY, NO_KEY);
-            if (act) t4 = li < 2048 ? s_keys[li] : tk[row];
+            if (act) t4 = li < PAIR_KEYS_LDS ? s_keys[li] : tk[row];
             const int keys[TOPK] = {t4.x, t4.y, t4.z, t4.w};
             int best = NO_KEY, second = -1, e0 = -1, e1 = -1;
             bool open = act;  // still walking the key list
@@ -707,7 +712,7 @@ extern "C" void afv_launch_match_resolve(const uint8_t *desc, const float *ang, 
                                          const int *pb, int npairs, float th, float ratio, int check_ori, int *match, int *nmatches,
                                          const void *topk_scratch, int pair_base, hipStream_t stream) {
     const int4 *topk = reinterpret_cast<const int4 *>(topk_scratch);
-    hipLaunchKernelGGL(k_match_resolve, dim3(npairs), dim3(MT), 0, stream, desc, ang, ang_stride, nset, cap, pa, pb, topk, th, ratio,
+    hipLaunchKernelGGL(k_match_resolve, dim3(npairs), dim3(MT), resolve_lds_bytes(cap), stream, desc, ang, ang_stride, nset, cap, pa, pb, topk, th, ratio,
                        check_ori, match, nmatches, pair_base);
 }
 extern "C" void afv_launch_match_tri(const DevTriJob *jobs, int njobs, int max_n1, hipStream_t stream) {
