@@ -50,31 +50,34 @@ __global__ __launch_bounds__(RT_T) void k_resize_level(const uint8_t *__restrict
     const int sy0 = tab.yt[y0].x, sy1 = min(tab.yt[y0 + ny - 1].x + 1, sh - 1);
     const int sx0 = sx_first & ~3;
     const int ndw = (sx_last - sx0) / 4 + 1, nrows = sy1 - sy0 + 1;  // <= RS_W/4, <= RS_H (host checks the scale)
-    // all loads of the window first (one global round trip), then the LDS writes
-    constexpr int STG = (RS_H * RS_W / 4 + RT_T - 1) / RT_T;
+    // all loads of the window first (one global round trip), then the LDS writes.  Thread (q, rr) = (tid % 24, tid / 24) owns the
+    // dword column q of the rows rr, rr + 5, ... (120 of the 128 threads): no division by a run-time width, addresses by increments
+    constexpr int SQ = RS_W / 4, SG = RT_T / SQ, STG = (RS_H + SG - 1) / SG;  // 24 dword columns, 5 row groups, 10 rows per thread
+    const int srr = (int)(__umul24(threadIdx.x, 2731u) >> 16);  // tid / 24 (exact for tid < 128)
+    const int sq = (int)threadIdx.x - srr * SQ;
+    const bool s_on = srr < SG && sq < ndw;
+    const bool s_dword = sx0 + sq * 4 + 3 < spitch;  // else: the last bytes of a row whose pitch is not a multiple of 4
     uint32_t stg[STG];
+    {
+        const uint8_t *p = s + (size_t)(sy0 + srr) * spitch + sx0 + sq * 4;
 #pragma unroll
-    for (int k = 0; k < STG; ++k) {
-        const int i = threadIdx.x + k * RT_T;
-        stg[k] = 0;
-        if (i < nrows * ndw) {
-            const int r = i / ndw, q = i - r * ndw;
-            const uint8_t *p = s + (size_t)(sy0 + r) * spitch + sx0 + q * 4;
-            if (sx0 + q * 4 + 3 < spitch) {
-                stg[k] = *reinterpret_cast<const uint32_t *>(p);
-            } else {
-                for (int b = 0; b < 4; ++b)
-                    if (sx0 + q * 4 + b < sw) stg[k] |= (uint32_t)p[b] << (8 * b);
+        for (int k = 0; k < STG; ++k) {
+            stg[k] = 0;
+            if (s_on && srr + k * SG < nrows) {
+                if (s_dword) {
+                    stg[k] = *reinterpret_cast<const uint32_t *>(p);
+                } else {
+                    for (int b = 0; b < 4; ++b)
+                        if (sx0 + sq * 4 + b < sw) stg[k] |= (uint32_t)p[b] << (8 * b);
+                }
             }
+            p += (size_t)SG * spitch;
         }
     }
+    if (s_on) {
 #pragma unroll
-    for (int k = 0; k < STG; ++k) {
-        const int i = threadIdx.x + k * RT_T;
-        if (i < nrows * ndw) {
-            const int r = i / ndw, q = i - r * ndw;
-            *reinterpret_cast<uint32_t *>(&win[r * RS_W + q * 4]) = stg[k];
-        }
+        for (int k = 0; k < STG; ++k)
+            if (srr + k * SG < nrows) *reinterpret_cast<uint32_t *>(&win[(srr + k * SG) * RS_W + sq * 4]) = stg[k];
     }
     if (threadIdx.x < RT_W) {  // columns past the image edge: offset 0, weight 0 (their outputs are never stored)
         short2 e;
