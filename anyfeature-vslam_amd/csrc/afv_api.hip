@@ -307,7 +307,7 @@ extern "C" int afv_set_pipeline_chunk(afv_ctx *c, int frames, int chunks_ahead) 
     return AFV_OK;
 }
 extern "C" int afv_set_split_chunks(afv_ctx *c, int chunks) {
-    if (!c || chunks < 2 || chunks > 64) return AFV_EINVAL;
+    if (!c || (chunks != 0 && chunks < 2) || chunks > 64) return AFV_EINVAL;
     c->split_chunks = chunks;
     return AFV_OK;
 }
@@ -403,7 +403,9 @@ static int enqueue_extract(afv_ctx *c, const FrameSrc &src, int nframes, afv_key
         // two halves on two streams: the select / describe tail of one half overlaps the FAST kernel of the other
         HIPCHK(c, hipEventRecord(c->ev_fork, s));
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-        const int K = std::max(2, c->split_chunks);
+        // automatic: chunks of ~85 frames (measured optimum at 640x480: large enough to fill the chip, small enough that the
+        // latency-bound kernels of one chunk hide behind the VALU-bound ones of the next)
+        const int K = c->split_chunks ? c->split_chunks : std::min(64, std::max(2, (nframes + 42) / 85));
         for (int k = 0; k < K; ++k) {  // chunk k on stream k % 2
             const int b = (int)((long)nframes * k / K), e = (int)((long)nframes * (k + 1) / K);
             if (e > b) enqueue_range(c, src, b, e - b, d_kps, d_desc, cap, d_n, d_status, (k & 1) ? c->stream2 : s);

@@ -104,7 +104,7 @@ struct afv_ctx {
     int pipe_chunk = 64;                                       // frames per pipeline chunk
     int pipe_ahead = 8;                                        // uploads run this many chunks ahead of the compute
     int split_min_frames = 64;     // batches of at least this many frames / pairs are split over the two streams
-    int split_chunks = 4;          // ... into this many chunks (alternating streams); afv_set_split_chunks
+    int split_chunks = 0;          // ... into this many chunks (alternating streams); 0 = about 85 frames each; afv_set_split_chunks
     afv_orb_params p{};
     Geo geo{};          // current geometry (host copy)
     Geo cap_geo{};      // geometry of (max_width, max_height): sizes every allocation

@@ -313,7 +313,8 @@ int afv_profile_read(afv_ctx *ctx, int32_t *launches /*[AFV_NUM_STAGES]*/, float
 /* batches of at least `min_frames` frames (pairs) are split over the context's two streams so that latency-bound kernels of
  * one half overlap the VALU-bound ones of the other (default 64; 0x7fffffff disables the split) */
 int afv_set_split_threshold(afv_ctx *ctx, int min_frames);
-int afv_set_split_chunks(afv_ctx *ctx, int chunks); /* ... into this many chunks alternating over the two streams (default 4) */
+int afv_set_split_chunks(afv_ctx *ctx, int chunks); /* ... into this many chunks alternating over the two streams (2..64; 0 = automatic,
+                                                      * chunks of about 85 frames: the default) */
 /* afv_orb_extract_batch pipelines H2D / compute / D2H over chunks of `frames` frames with the uploads `chunks_ahead` chunks ahead of
  * the compute (defaults 64 and 8; batches below two chunks run as one) */
 int afv_set_pipeline_chunk(afv_ctx *ctx, int frames, int chunks_ahead);
