@@ -24,6 +24,7 @@ typedef unsigned int uint3v __attribute__((ext_vector_type(3)));
 __device__ __forceinline__ uint32_t as_u32(short2v v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ short2v as_s2(uint32_t v) { return __builtin_bit_cast(short2v, v); }
 
+#define RS_CPT 36    // candidates per thread k_retain_score keeps in registers (lists up to 9216 entries)
 #define HQ_CHUNK 64  // candidates per queue item {frame * AFV_MAX_LEVELS + level, first candidate | count << 24}: one pass of a 256-thread workgroup
 
 __device__ __forceinline__ int wave_incl_scan_shfl(int v) {
@@ -55,6 +56,17 @@ __global__ __launch_bounds__(256) void k_retain_score(const Geo *__restrict__ ge
     const int tid = threadIdx.x, lane = tid & 63;
     const int K = 2 * L.cv_quota;
     int n1 = n;
+    // the candidate list is read ONCE: every thread keeps its share (items tid, tid + 256, ...) in registers for the histogram and
+    // the compaction pass; lists longer than 256 * RS_CPT (noise-like images) stream from memory a second time instead
+    const bool reg = n <= 256 * RS_CPT;
+    uint32_t cpk[RS_CPT];
+    if (reg) {
+#pragma unroll
+        for (int k = 0; k < RS_CPT; ++k) {
+            cpk[k] = 0;
+            if (k * 256 < n && k * 256 + tid < n) cpk[k] = cp[k * 256 + tid];
+        }
+    }
     if (n > K) {  // uniform
         hist[tid] = 0;
         if (tid == 0) {
@@ -62,7 +74,13 @@ __global__ __launch_bounds__(256) void k_retain_score(const Geo *__restrict__ ge
             s_n1 = 0;
         }
         __syncthreads();
-        for (int i = tid; i < n; i += 256) atomicAdd(&hist[cp[i] >> 24], 1);
+        if (reg) {
+#pragma unroll
+            for (int k = 0; k < RS_CPT; ++k)
+                if (k * 256 < n && k * 256 + tid < n) atomicAdd(&hist[cpk[k] >> 24], 1);
+        } else {
+            for (int i = tid; i < n; i += 256) atomicAdd(&hist[cp[i] >> 24], 1);
+        }
         __syncthreads();
         // thread t owns bin 255 - t: the threshold is the bin at which the count from the top reaches K
         const int h = hist[255 - tid];
@@ -75,18 +93,32 @@ __global__ __launch_bounds__(256) void k_retain_score(const Geo *__restrict__ ge
         __syncthreads();
         const int T1 = s_T1;
         // order-free, wave-aggregated compaction (everything downstream is order-independent)
-        for (int i0 = 0; i0 < n; i0 += 256) {
-            const int i = i0 + tid;
-            const uint32_t e = i < n ? cp[i] : 0u;
-            const bool keep = i < n && (int)(e >> 24) >= T1;
+        auto emit = [&](bool in, uint32_t e) {
+            const bool keep = in && (int)(e >> 24) >= T1;
             const unsigned long long m = __ballot(keep);
             int wbase = 0;
             if (lane == 0 && m) wbase = atomicAdd(&s_n1, __popcll(m));
             wbase = __shfl(wbase, 0, 64);
             if (keep) out[wbase + __popcll(m & ((1ull << lane) - 1ull))] = e;
+        };
+        if (reg) {
+#pragma unroll
+            for (int k = 0; k < RS_CPT; ++k) {
+                if (k * 256 >= n) break;
+                emit(k * 256 + tid < n, cpk[k]);
+            }
+        } else {
+            for (int i0 = 0; i0 < n; i0 += 256) {
+                const int i = i0 + tid;
+                emit(i < n, i < n ? cp[i] : 0u);
+            }
         }
         __syncthreads();
         n1 = s_n1;
+    } else if (reg) {
+#pragma unroll
+        for (int k = 0; k < RS_CPT; ++k)
+            if (k * 256 < n && k * 256 + tid < n) out[k * 256 + tid] = cpk[k];
     } else {
         for (int i = tid; i < n; i += 256) out[i] = cp[i];
     }
