@@ -31,7 +31,7 @@ PYEOF
 echo "== calibration: FETCH_SIZE / WRITE_SIZE against known byte counts (tools/calib_fetch.hip)"
 hipcc --offload-arch=gfx950 -O3 "$ROOT/tools/calib_fetch.hip" -o /tmp/calib_fetch
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C -d "$OUT/calib_$C" -o c --output-format csv -- /tmp/calib_fetch > /dev/null 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $C -d "$OUT/calib_$C" -o c --output-format csv -- /tmp/calib_fetch > /dev/null 2>&1
 done
 $PY - "$OUT" <<'PYEOF'
 import csv, glob, json, sys
@@ -55,17 +55,17 @@ PYEOF
 
 echo "== default bench (the BENCH line) + kernel stats of the same command"
 cd "$ROOT" && $PY bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"; cd /tmp
-rocprofv3 --kernel-trace --stats -d "$OUT/stats_default" -o st --output-format csv -- $PY "$ROOT/bench.py" --cpu-frames 0 --no-extras > /dev/null 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d "$OUT/stats_default" -o st --output-format csv -- $PY "$ROOT/bench.py" --cpu-frames 0 --no-extras > /dev/null 2>&1
 cp "$OUT"/stats_default/*kernel_stats.csv "$OUT/kernel_stats_default.csv" 2>/dev/null || cp "$OUT"/stats_default/*/*kernel_stats.csv "$OUT/kernel_stats_default.csv"
 
 echo "== PMC passes on: bench.py $BENCHARGS"
 for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
-  rocprofv3 --kernel-trace --pmc $C -d "$OUT/pmc_$C" -o p --output-format csv -- $PY "$ROOT/bench.py" $BENCHARGS > /dev/null 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc $C -d "$OUT/pmc_$C" -o p --output-format csv -- $PY "$ROOT/bench.py" $BENCHARGS > /dev/null 2>&1
   F=$(find "$OUT/pmc_$C" -name "*counter_collection.csv" | head -1); cp "$F" "$OUT/pmc_${C}_counter_collection.csv"
 done
-rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS -d "$OUT/pmc_LDS" -o p --output-format csv -- $PY "$ROOT/bench.py" $BENCHARGS > /dev/null 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS -d "$OUT/pmc_LDS" -o p --output-format csv -- $PY "$ROOT/bench.py" $BENCHARGS > /dev/null 2>&1
 cp "$(find "$OUT/pmc_LDS" -name "*counter_collection.csv" | head -1)" "$OUT/pmc_lds_counter_collection.csv"
-rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d "$OUT/pmc_L2" -o p --output-format csv -- $PY "$ROOT/bench.py" $BENCHARGS > /dev/null 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d "$OUT/pmc_L2" -o p --output-format csv -- $PY "$ROOT/bench.py" $BENCHARGS > /dev/null 2>&1
 cp "$(find "$OUT/pmc_L2" -name "*counter_collection.csv" | head -1)" "$OUT/pmc_l2_counter_collection.csv" 2>/dev/null
 cd "$ROOT" && $PY tools/pmc_per_frame.py $B $((STEPS + WARM)) "$OUT" "$OUT/pmc_FETCH_SIZE_counter_collection.csv" "$OUT/pmc_WRITE_SIZE_counter_collection.csv" \
     "$OUT/pmc_SQ_INSTS_VALU_counter_collection.csv" "$OUT/calib_fetch.json" "$OUT/calib_valu.json" > "$OUT/pmc_per_frame.txt"
@@ -74,12 +74,12 @@ cd /tmp
 
 echo "== config #4: pairs10k bench + kernel stats"
 cd "$ROOT" && $PY bench.py --workload pairs10k > "$OUT/bench_pairs10k.json" 2> "$OUT/bench_pairs10k.err"; cd /tmp
-rocprofv3 --kernel-trace --stats -d "$OUT/stats_pairs" -o st --output-format csv -- $PY "$ROOT/bench.py" --workload pairs10k --steps 5 --cpu-frames 0 > /dev/null 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d "$OUT/stats_pairs" -o st --output-format csv -- $PY "$ROOT/bench.py" --workload pairs10k --steps 5 --cpu-frames 0 > /dev/null 2>&1
 cp "$(find "$OUT/stats_pairs" -name "*kernel_stats.csv" | head -1)" "$OUT/kernel_stats_pairs10k.csv"
 
 echo "== config #5: AKAZE61 bench + kernel stats"
 cd "$ROOT" && $PY bench.py --workload akaze61 --batch 64 --steps 5 > "$OUT/bench_akaze61.json" 2> "$OUT/bench_akaze61.err"; cd /tmp
-rocprofv3 --kernel-trace --stats -d "$OUT/stats_akaze" -o st --output-format csv -- $PY "$ROOT/bench.py" --workload akaze61 --batch 64 --steps 3 --cpu-frames 0 > /dev/null 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d "$OUT/stats_akaze" -o st --output-format csv -- $PY "$ROOT/bench.py" --workload akaze61 --batch 64 --steps 3 --cpu-frames 0 > /dev/null 2>&1
 cp "$(find "$OUT/stats_akaze" -name "*kernel_stats.csv" | head -1)" "$OUT/kernel_stats_akaze61.csv"
 
 rm -rf "$OUT"/calib_FETCH_SIZE "$OUT"/calib_WRITE_SIZE "$OUT"/stats_default "$OUT"/stats_pairs "$OUT"/stats_akaze "$OUT"/pmc_FETCH_SIZE "$OUT"/pmc_WRITE_SIZE "$OUT"/pmc_SQ_INSTS_VALU "$OUT"/pmc_LDS "$OUT"/pmc_L2

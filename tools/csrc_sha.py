@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""sha256 over the kernel / runtime sources a profile depends on (csrc/*.hip, *.h, *.inc and include/*.h, sorted by name).
+"""sha256 over the kernel / runtime sources the ORB32 / matcher profiles depend on (csrc/*.hip, *.h, *.inc and include/*.h, sorted
+by name; the AKAZE-only sources — *akaze* — are left out: they never run in the default or the pairs10k workload).
 Every profiles/r*/{traffic,valu}_pmc.json carries the value it was collected on; bench.py marks a figure "stale" when the
 tree no longer matches."""
 import glob
@@ -14,6 +15,7 @@ def csrc_sha(root=ROOT):
     files = []
     for pat in ("anyfeature-vslam_amd/csrc/*.hip", "anyfeature-vslam_amd/csrc/*.h", "anyfeature-vslam_amd/csrc/*.inc", "include/*.h"):
         files += glob.glob(os.path.join(root, pat))
+    files = [f for f in files if "akaze" not in os.path.basename(f)]
     for f in sorted(files):
         h.update(os.path.relpath(f, root).encode())
         h.update(open(f, "rb").read())
