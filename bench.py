@@ -723,12 +723,22 @@ def main():
             if vp:
                 stale = bool(vp["_stale"])
                 ach = vp["valu_winst_per_frame_total"] * out["frames_per_s"]
+                classes = {}
+                try:
+                    classes = json.load(open(os.path.join(ROOT, os.path.dirname(vp["_path"]), "calib_valu.json")))["classes_winst_per_s"]
+                except Exception:
+                    pass
+                pk = classes.get("v_pk_min_i16+add")
                 out["valu_issue"] = {"achieved": None if stale else ach, "peak": vp["valu_peak_winst_per_s"], "unit": "wave-instr/s",
                                      "frac": None if stale else ach / vp["valu_peak_winst_per_s"], "stale": stale, "source": vp["_path"],
+                                     "peak_by_op_class": classes,
+                                     "frac_vs_packed_i16_class": None if (stale or not pk) else ach / pk,
                                      "kernels_winst_per_frame": {k: v["valu_winst_per_frame"] for k, v in vp["kernels"].items()},
                                      "note": "whole pipeline: SQ_INSTS_VALU per frame (committed PMC pass of tools/collect_profiles.sh, stamped with the "
-                                             "sha of the sources it ran on) x live frames/s vs the integer-VALU issue peak measured by tools/calib_valu.hip "
-                                             "on the same box; stale = the sources changed since the pass, the fraction is withheld"}
+                                             "sha of the sources it ran on) x live frames/s vs the integer-VALU issue rates measured by tools/calib_valu.hip "
+                                             "on the same box: peak = the fastest op class (plain 32-bit adds); the packed-i16 / dot4 / popcount ops that "
+                                             "make up most of this pipeline issue at the packed class rate.  stale = the sources changed since the pass, "
+                                             "the fractions are withheld"}
             out["stage_ms_per_step"] = {kk: (v["total_ms"] / args.steps) for kk, v in stages.items()}  # overlapping streams: sums exceed ms_per_step
         if world == 1 and not args.no_extras:
             # extraction alone, device-resident (the yardstick of the host-fed pipeline)
