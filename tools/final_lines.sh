@@ -1,0 +1,18 @@
+#!/bin/bash
+# Regenerates the bench lines committed under profiles/<tag>/ AFTER the PMC passes of collect_profiles.sh were copied there (so that
+# roofline.traffic / valu_issue are live, not stale), plus the N = 2 rehearsal of the distributed path on one device and the
+# per-kernel busy / overlap breakdown.  Run on the GPU box: bash tools/final_lines.sh r02
+TAG=${1:-rXX}
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$ROOT/gpurun_out/final_$TAG
+mkdir -p "$OUT"
+cd "$ROOT"
+python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+AFV_EXP_NOSPLIT=1 python tools/timeline.py > "$OUT/timeline_single_stream.json" 2>/dev/null
+python tools/timeline.py > "$OUT/timeline_default.json" 2>/dev/null
+for W in orb32 pairs10k; do
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 2 \
+      --backend gloo --single-device --workload $W --cpu-frames 0 > "$OUT/rehearsal_gloo2_$W.json" 2> "$OUT/rehearsal_gloo2_$W.err"
+done
+python tools/probe_pcie.py > "$OUT/pcie_probe.txt" 2>&1
+ls -la "$OUT"
