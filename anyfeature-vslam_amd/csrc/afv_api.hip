@@ -316,7 +316,9 @@ extern "C" int afv_profile_enable(afv_ctx *c, int enable) {
     if (!c) return AFV_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
     profile_drain(c);
-    c->prof = enable != 0;
+    c->prof = false;
+    c->prof_every = enable > 0 ? enable : 0;
+    c->prof_tick_extract = c->prof_tick_match = 0;
     if (enable)
         for (int st = 0; st < AFV_NUM_STAGES; ++st) {
             c->prof_ms[st] = 0.f;
@@ -398,6 +400,7 @@ static void enqueue_range(afv_ctx *c, const FrameSrc &src, int f0, int nf, afv_k
 // ---- the pipeline ----
 static int enqueue_extract(afv_ctx *c, const FrameSrc &src, int nframes, afv_keypoint *d_kps, uint8_t *d_desc, int cap,
                            int *d_n, int *d_status, hipStream_t s) {
+    c->prof = c->prof_every && (c->prof_tick_extract++ % (unsigned)c->prof_every) == 0;
     if (d_status) HIPCHK(c, hipMemsetAsync(d_status, 0, sizeof(int), s));
     if (nframes >= c->split_min_frames) {
         // two halves on two streams: the select / describe tail of one half overlaps the FAST kernel of the other
@@ -469,6 +472,7 @@ extern "C" int afv_orb_extract_batch(afv_ctx *c, const uint8_t *const *frames, i
     HIPCHK(c, hipSetDevice(c->device));
     int rc = set_geometry(c, width, height);
     if (rc) return rc;
+    c->prof = c->prof_every && (c->prof_tick_extract++ % (unsigned)c->prof_every) == 0;
     return guarded(c, [&]() -> int {
         // device staging layout for THIS geometry: frames back to back when the row pitch allows it (one DMA per chunk)
         const size_t pitch = align_up((size_t)width, 64);
@@ -1050,6 +1054,7 @@ extern "C" int afv_match_triangulation(afv_ctx *c, const afv_tri_job *jobs, int 
 int afv_match_pairs_core(afv_ctx *c, const uint8_t *d_desc, const float *d_ang, int ang_stride, const int32_t *d_n, int cap,
                          const int32_t *d_pair_a, const int32_t *d_pair_b, int npairs, float th_low, float nnratio,
                          int check_orientation, int32_t *d_match, int32_t *d_nmatches, hipStream_t s) {
+    c->prof = c->prof_every && (c->prof_tick_match++ % (unsigned)c->prof_every) == 0;
     const size_t need = (size_t)npairs * cap * 16;
     if (need > c->topk_bytes) {  // grow-only scratch (first call / larger batch): implies a device sync
         HIPCHK(c, hipDeviceSynchronize());

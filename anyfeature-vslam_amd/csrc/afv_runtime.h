@@ -146,7 +146,9 @@ struct afv_ctx {
     int last_nframes = 0;
     std::string last_error;
     // live stage timing
-    bool prof = false;
+    bool prof = false;             // the CURRENT call is timed (set per entry-point call from prof_every and the call counters)
+    int prof_every = 0;            // 0 = profiling off; n = time the stages of every n-th extraction / pair-match call
+    unsigned prof_tick_extract = 0, prof_tick_match = 0;
     std::vector<hipEvent_t> prof_ev[AFV_NUM_STAGES];  // pairs (begin, end)
     size_t prof_used[AFV_NUM_STAGES]{};
     int prof_launches[AFV_NUM_STAGES]{};

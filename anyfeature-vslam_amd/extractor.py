@@ -172,8 +172,9 @@ class Context:
         return size, s2, inf
 
     # ---- live stage timing (hipEvents on the launch stream) ----
-    def profile_enable(self, enable=True):
-        self.check(self.lib.afv_profile_enable(self.handle, int(bool(enable))))
+    def profile_enable(self, enable=True, every=1):
+        """every = n: only every n-th extraction / pair-match call records its stage events"""
+        self.check(self.lib.afv_profile_enable(self.handle, int(every) if enable else 0))
 
     def profile_read(self):
         launches = np.zeros(len(_lib.STAGES), np.int32); ms = np.zeros(len(_lib.STAGES), np.float32)

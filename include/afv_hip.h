@@ -307,7 +307,9 @@ enum { AFV_STAGE_PYRAMID = 0, AFV_STAGE_FAST_NMS = 1 /* k_fast_nms */, AFV_STAGE
        AFV_STAGE_MATCH = 4 /* k_match_topk: the xor + popcount phase */, AFV_STAGE_MATCH_RESOLVE = 5 /* ordered greedy resolve */,
        AFV_STAGE_HARRIS = 6 /* k_retain_score + k_harris: retainBest on the score, Harris response of the survivors */,
        AFV_NUM_STAGES = 7 };
-int afv_profile_enable(afv_ctx *ctx, int enable);
+int afv_profile_enable(afv_ctx *ctx, int enable); /* 0 = off; n >= 1 = time the stages of every n-th extraction / pair-match call
+                                                     * (1 = every call; the event pairs cost ~3 % of a batch step, sampling keeps that
+                                                     * out of a timed run); resets the accumulated figures */
 int afv_profile_read(afv_ctx *ctx, int32_t *launches /*[AFV_NUM_STAGES]*/, float *total_ms /*[AFV_NUM_STAGES]*/,
                      int64_t *units /*[AFV_NUM_STAGES], frames (pairs for MATCH) covered by those launches; may be NULL*/);
 /* batches of at least `min_frames` frames (pairs) are split over the context's two streams so that latency-bound kernels of
