@@ -363,8 +363,11 @@ extern "C" int afv_get_geometry(const afv_ctx *c, afv_geometry *g) {
 static void enqueue_range(afv_ctx *c, const FrameSrc &src, int f0, int nf, afv_keypoint *d_kps, uint8_t *d_desc, int cap, int *d_n,
                           int *d_status, hipStream_t s) {
     const Geo &g = c->geo;
-    (void)hipMemsetAsync(c->d_cand_count + (size_t)f0 * AFV_MAX_LEVELS, 0, (size_t)nf * AFV_MAX_LEVELS * sizeof(int), s);
-    (void)hipMemsetAsync(c->d_hq_n + f0, 0, sizeof(int), s);
+    int *cnt0 = c->d_cand_count + (size_t)f0 * AFV_MAX_LEVELS;
+    if (g.nlevels < 2) {  // no pyramid launch to carry the clears
+        (void)hipMemsetAsync(cnt0, 0, (size_t)nf * AFV_MAX_LEVELS * sizeof(int), s);
+        (void)hipMemsetAsync(c->d_hq_n + f0, 0, sizeof(int), s);
+    }
     {
         StageTimer t_(c, AFV_STAGE_PYRAMID, s, nf);
         for (int l = 1; l < g.nlevels; ++l) {
@@ -373,7 +376,8 @@ static void enqueue_range(afv_ctx *c, const FrameSrc &src, int f0, int nf, afv_k
             const int spitch = (l == 1) ? src.stride : S.pitch;
             const size_t sframe = (l == 1) ? src.frame_stride : S.pyr_frame_stride;
             afv_launch_resize(sp, S.w, S.h, spitch, sframe, c->d_pyr + D.pyr_off, D.w, D.h, D.pitch, D.pyr_frame_stride,
-                              c->d_tab + c->tab_off_x[l], c->d_tab + c->tab_off_y[l], f0, nf, s);
+                              c->d_tab + c->tab_off_x[l], c->d_tab + c->tab_off_y[l], f0, nf, l == 1 ? cnt0 : nullptr, nf * AFV_MAX_LEVELS,
+                              l == 1 ? c->d_hq_n + f0 : nullptr, s);
         }
     }
     {

@@ -17,7 +17,8 @@
 
 // ---- kernel launchers (k_*.hip) ----
 extern "C" void afv_launch_resize(const uint8_t *src, int sw, int sh, int spitch, size_t sframe, uint8_t *dst, int dw, int dh,
-                                  int dpitch, size_t dframe, const short2 *xt, const short2 *yt, int frame_base, int nframes, hipStream_t stream);
+                                  int dpitch, size_t dframe, const short2 *xt, const short2 *yt, int frame_base, int nframes, int *zero_counts,
+                                  int n_zero, int *zero_one, hipStream_t stream);
 extern "C" int afv_resize_window_ok(int sw, int sh, int dw, int dh);
 extern "C" void afv_launch_fast_nms(const Geo *geo, int total_tiles, const FrameSrc *src0, const uint8_t *pyr, uint32_t *cand_packed,
                                     int *cand_count, int frame_base, int nframes, hipStream_t stream);

@@ -27,6 +27,11 @@ typedef unsigned short ushort2r __attribute__((ext_vector_type(2)));
 struct ResizeTab {
     const short2 *xt;  // [dw]  {src offset, weight of the right tap}
     const short2 *yt;  // [dh]
+    // the first launch of a frame range also clears that range's per-level candidate counters and its Harris queue counter (the FAST
+    // tiles that add to them run after the whole pyramid): two fill kernels per chunk less on the stream
+    int *zero_counts;
+    int n_zero;
+    int *zero_one;
 };
 
 __global__ __launch_bounds__(RT_T) void k_resize_level(const uint8_t *__restrict__ src, int sw, int sh, int spitch,
@@ -38,6 +43,10 @@ __global__ __launch_bounds__(RT_T) void k_resize_level(const uint8_t *__restrict
     __shared__ short2 s_yt[RT_H];
     // XCD-aware placement: whole frames per XCD (neighbouring tiles share source cache lines)
     const int tiles_x = (dw + RT_W - 1) / RT_W, tiles_y = (dh + RT_H - 1) / RT_H;
+    if (tab.zero_counts && blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < tab.n_zero; i += RT_T) tab.zero_counts[i] = 0;
+        if (threadIdx.x == 0 && tab.zero_one) *tab.zero_one = 0;
+    }
     const int work = afv_xcd_remap(blockIdx.x, total_blocks);
     if (work >= total_blocks) return;
     const int fl = work / (tiles_x * tiles_y), tt = work - fl * (tiles_x * tiles_y);
@@ -151,10 +160,10 @@ extern "C" int afv_resize_window_ok(int sw, int sh, int dw, int dh) {
 
 extern "C" void afv_launch_resize(const uint8_t *src, int sw, int sh, int spitch, size_t sframe, uint8_t *dst, int dw,
                                   int dh, int dpitch, size_t dframe, const short2 *xt, const short2 *yt, int frame_base,
-                                  int nframes, hipStream_t stream) {
+                                  int nframes, int *zero_counts, int n_zero, int *zero_one, hipStream_t stream) {
     const int total = ((dw + RT_W - 1) / RT_W) * ((dh + RT_H - 1) / RT_H) * nframes;
     dim3 grid((total + 7) / 8 * 8);
-    ResizeTab tab{xt, yt};
+    ResizeTab tab{xt, yt, zero_counts, n_zero, zero_one};
     hipLaunchKernelGGL(k_resize_level, grid, dim3(RT_T), 0, stream, src, sw, sh, spitch, sframe, dst, dw, dh, dpitch,
                        dframe, tab, total, frame_base);
 }
