@@ -19,12 +19,13 @@ d_fr = fr.cuda(); dk = torch.empty((B, cap, 7), dtype=torch.float32, device="cud
 side = torch.cuda.Stream()
 def dev():
     with torch.cuda.stream(side): ctx.extract_batch_device(d_fr, dk, dd, dn, st, cap)
-for sc in (4, 8):
+for sc in (0, 4, 8):
     ctx.set_split_chunks(sc)
-    print("device-resident extract, %d chunks: %.3f ms" % (sc, t(dev)), flush=True)
+    print("device-resident extract, %d chunks (0 = automatic): %.3f ms" % (sc, t(dev)), flush=True)
+ctx.set_split_chunks(0)
 print("H2D only: %.3f ms" % t(lambda: d_fr.copy_(fr, non_blocking=True)))
 print("D2H only: %.3f ms" % t(lambda: (kps.copy_(dk, non_blocking=True), desc.copy_(dd, non_blocking=True))))
-for ch in (32, 64):
-    for ahead in (2, 3, 4, 8):
+for ch in (16, 32, 48, 64, 96):
+    for ahead in (4, 8, 16):
         ctx.set_pipeline_chunk(ch, ahead)
         print("host-fed chunk %d ahead %d: %.3f ms" % (ch, ahead, t(lambda: ctx.extract_batch_host(fr, kps, desc, n))), flush=True)
