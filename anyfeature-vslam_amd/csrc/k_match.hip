@@ -415,7 +415,14 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
         const uint32_t *d1 = reinterpret_cast<const uint32_t *>(desc + (size_t)a * cap * 32);
         const uint32_t *d2 = reinterpret_cast<const uint32_t *>(desc + (size_t)b * cap * 32);  // the rescan (rare) reads through L2
         int pos = 0;
+#ifdef AFV_RESOLVE_STATS
+        int st_rounds = 0, st_rescans = 0, st_full = 0;
+        const long long st_t0 = wall_clock64();
+#endif
         while (pos < nlive) {
+#ifdef AFV_RESOLVE_STATS
+            ++st_rounds;
+#endif
             const int li = pos + lane;
             const bool act = li < nlive;
             const int row = act ? s_live[li] : 0;
@@ -469,7 +476,9 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
             bool stopper = type == 2;
             if (act && type != 2) {
                 if (e0 >= 0 && s_claim[e0] < lane) stopper = true;
-                if (e1 >= 0 && s_claim[e1] < lane) stopper = true;
+                // losing the SECOND-best column to an earlier row of the round cannot undo an acceptance: the next unmatched column
+                // is at least as far, so best1 < ratio * best2 only gets easier.  It can turn a ratio rejection into a match.
+                if (type != 1 && e1 >= 0 && s_claim[e1] < lane) stopper = true;
             }
             const unsigned long long sm = __ballot(stopper);
             const int stop = sm ? (int)__builtin_ctzll(sm) : 64;
@@ -482,6 +491,10 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
             nm += __popcll(__ballot(commit));
             if (type == 1) s_claim[e0] = 0x7fffffff;  // release every claim of this round
             WAVE_LDS_SYNC();
+#ifdef AFV_RESOLVE_STATS
+            if (stop == 0) ++st_rescans;
+            if (stop == 64) ++st_full;
+#endif
             if (stop == 0) {
                 // the first row of the round needs the exact rescan of the unmatched columns (rare): whole wave
                 const int i = s_live[pos];
@@ -518,6 +531,9 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
             }
         }
         if (lane == 0) s_nm = nm;
+#ifdef AFV_RESOLVE_STATS
+        if (lane == 0 && (p == 1 || p == 2)) printf("resolve pair %d: n1 %d nlive %d rounds %d (full %d) rescans %d matches %d walk %lld us\n", p, n1, nlive, st_rounds, st_full, st_rescans, nm, (wall_clock64() - st_t0) / 100);
+#endif
     }
     __syncthreads();
     if (check_ori) {
