@@ -427,7 +427,7 @@ def pairs_main(args):
             out["valu_issue"] = {"kernel": "k_match_topk", "achieved": winst, "unit": "wave-instr/s (xor + popcount only)",
                                  "peak": calib["peak"], "frac": winst / calib["peak"], "peak_source": calib["source"],
                                  "descriptor_pairs_per_s_in_kernel": pairs_s,
-                                 "note": "the remaining issue slots of the kernel go to the branch-free top-4 insertion (8 VALU per pair)"}
+                                 "note": "the remaining issue slots of the kernel go to the key and the branch-free top-4 insertion (1 + 4 VALU per pair: v_min + 3 v_med3)"}
             out["stage_ms_per_step"] = {"match_topk": tk["total_ms"] / args.steps, "match_resolve": rs["total_ms"] / args.steps}
         if args.cpu_frames > 0 and world == 1 and host is not None:
             out["cpu_baseline"] = pairs_cpu_baseline(host[0], host[1], host[2], ja, jb)
@@ -448,6 +448,9 @@ def valu_calibration():
     for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "calib_valu.json")), reverse=True):
         try:
             d = json.load(open(p))
+            cls = d.get("classes_winst_per_s", {})
+            if "xor+bcnt" in cls:   # the op class the counted instructions of k_match_topk belong to
+                return {"peak": float(cls["xor+bcnt"]), "source": os.path.relpath(p, ROOT) + " (xor+bcnt class)", "classes": cls}
             return {"peak": float(d["valu_peak_winst_per_s"]), "source": os.path.relpath(p, ROOT)}
         except Exception:
             pass
