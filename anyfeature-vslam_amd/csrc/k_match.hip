@@ -502,10 +502,24 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
 #pragma unroll
                 for (int w = 0; w < 8; ++w) q[w] = d1[(size_t)i * 8 + w];
                 int k = NO_KEY, s2nd = NO_KEY >> 16;
-                for (int c = lane; c < n2; c += 64) {
-                    if ((s_matched[c >> 5] >> (c & 31)) & 1u) continue;
-                    const int d = hamming_words<8>(q, d2 + (size_t)c * 8);
-                    merge_best(k, s2nd, (d << 16) | c, NO_KEY >> 16);
+                // four columns per lane and step: their eight 16-byte loads are in flight together (one L2 round trip per 256 columns)
+                for (int c0 = lane; c0 < n2; c0 += 256) {
+                    uint4 lo[4], hi[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int c = min(c0 + 64 * u, n2 - 1);
+                        const uint4 *pc = reinterpret_cast<const uint4 *>(d2 + (size_t)c * 8);
+                        lo[u] = pc[0];
+                        hi[u] = pc[1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int c = c0 + 64 * u;
+                        if (c >= n2 || ((s_matched[c >> 5] >> (c & 31)) & 1u)) continue;
+                        const int d = __popc(q[0] ^ lo[u].x) + __popc(q[1] ^ lo[u].y) + __popc(q[2] ^ lo[u].z) + __popc(q[3] ^ lo[u].w) +
+                                      __popc(q[4] ^ hi[u].x) + __popc(q[5] ^ hi[u].y) + __popc(q[6] ^ hi[u].z) + __popc(q[7] ^ hi[u].w);
+                        merge_best(k, s2nd, (d << 16) | c, NO_KEY >> 16);
+                    }
                 }
 #pragma unroll
                 for (int m = 32; m >= 1; m >>= 1) {
