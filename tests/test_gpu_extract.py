@@ -432,3 +432,27 @@ def test_noise_frame_worst_case_candidates(afv, oracle):
     n0 = len(ctx.debug_candidates(0, 0)[0])
     assert n0 > 10240  # beyond ST * CPT
     ctx.close()
+
+
+def test_stage_profile_sampling_and_chunk_settings(afv):
+    """afv_profile_enable(ctx, n) times every n-th batch call; afv_set_split_chunks takes 0 (automatic) or 2..64"""
+    import torch
+    ctx = afv.Context(max_batch=8)
+    t = torch.from_numpy(afv.synth.corners_batch(3, 8)).cuda()
+    ctx.profile_enable(True, every=2)
+    for _ in range(4):
+        ctx.extract_batch_device(t)
+    torch.cuda.synchronize()
+    st = ctx.profile_read()
+    assert st["fast_nms"]["launches"] == 2 and st["fast_nms"]["units"] == 16 and st["retain_harris"]["launches"] == 2
+    assert st["fast_nms"]["total_ms"] > 0 and st["pyramid"]["launches"] == 2
+    ctx.profile_enable(True)            # every call, figures reset
+    ctx.extract_batch_device(t)
+    torch.cuda.synchronize()
+    assert ctx.profile_read()["describe"]["launches"] == 1
+    ctx.profile_enable(False)
+    ctx.set_split_chunks(0)
+    ctx.set_split_chunks(6)
+    with pytest.raises(Exception):
+        ctx.set_split_chunks(1)
+    ctx.close()
