@@ -346,6 +346,35 @@ def test_hip_matcher_reproduces_golden(gpu_ctx, afv):
     assert n == int(gold["shift4_nmatches"][0]) and np.array_equal(got, gold["shift4_match12"])
 
 
+def test_hip_reproduces_toy_sequence(afv):
+    """BASELINE.json configs[0] end to end on the device: the five toy frames as one batch, every frame matched against its
+    predecessor through the device-resident pair matcher — compared with the committed fixtures, not with the oracle binary"""
+    import torch
+    gray = np.load(os.path.join(GOLD, "toy_seq_gray.npz"))["gray"]
+    want = np.load(os.path.join(GOLD, "toy_seq_expected.npz"))
+    ctx = afv.Context(max_batch=5)
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+    m = afv.FeatureMatcher(0.6, True, ctx=ctx)
+    t = torch.from_numpy(gray).cuda()
+    kps, desc, n, st = ctx.extract_batch_device(t)
+    pa = torch.arange(1, 5, dtype=torch.int32, device="cuda")
+    pb = pa - 1
+    match, nm = m.match_pairs_device(desc, kps, n, pa, pb, th_low=75.0, check_orientation=True)
+    torch.cuda.synchronize()
+    n = n.cpu().numpy()
+    kh = kps.cpu().numpy().view(np.uint8)
+    dh = desc.cpu().numpy()
+    for i in range(5):
+        w = want["kps_%d" % i]
+        assert n[i] == len(w)
+        assert kh[i, :n[i]].tobytes() == w.tobytes() and np.array_equal(dh[i, :n[i]], want["desc_%d" % i])
+    mh, nmh = match.cpu().numpy(), nm.cpu().numpy()
+    for j, i in enumerate(range(1, 5)):
+        assert nmh[j] == int(want["nmatch_%d" % i][0])
+        assert np.array_equal(mh[j, :n[i]], want["match_%d" % i])
+    ctx.close()
+
+
 def test_batch_properties_at_full_size(gpu_ctx, afv):
     """size-independent properties on a device batch: per-level counts within [quota, quota+2], ascending octaves,
     idempotence (same frames -> same bytes), independence from batch position"""

@@ -422,6 +422,22 @@ def test_golden_matcher_vector(oracle, afv, gold):
     assert np.mean(np.abs(dx - 4.0 * 1.0) < 8.0) > 0.9 and n > 300
 
 
+def test_oracle_reproduces_toy_sequence(oracle):
+    """BASELINE.json configs[0]: all five frames of the reference's toy sequence, and every frame matched against its predecessor"""
+    gray = np.load(os.path.join(GOLD, "toy_seq_gray.npz"))["gray"]
+    want = np.load(os.path.join(GOLD, "toy_seq_expected.npz"))
+    assert gray.shape == (5, 480, 640)
+    prev = None
+    for i in range(5):
+        kps, desc = oracle.orb_extract(gray[i])
+        assert kps.tobytes() == want["kps_%d" % i].tobytes() and np.array_equal(desc, want["desc_%d" % i])
+        if prev is not None:
+            m, n = oracle.search_by_bow_kf_kf(desc, prev[1], angle1=kps["angle"], angle2=prev[0]["angle"], th_low=75.0, nnratio=0.6,
+                                              check_orientation=True)
+            assert n == int(want["nmatch_%d" % i][0]) > 200 and np.array_equal(m, want["match_%d" % i])
+        prev = (kps, desc)
+
+
 # ---------------- SURVEY 8f rank 1: projection-guided matching core ----------------
 def test_projection_hand_checked(oracle, afv):
     """three features in one grid neighbourhood, two map points competing for the closest one"""
