@@ -58,8 +58,12 @@ def noise_frame(seed, w=640, h=480):
 
 def frames():
     out = {"corners1": corners_frame(1), "corners2": corners_frame(2), "noise3": noise_frame(3)}
-    toy = os.path.join(OUT, "toy_gray.npz")  # one frame of the reference's docs/toy_sequence, committed as data
-    if os.path.exists(toy):
+    seq = os.path.join(OUT, "toy_seq_gray.npz")  # the five frames of the reference's docs/toy_sequence, committed as data
+    toy = os.path.join(OUT, "toy_gray.npz")     # (its first frame)
+    if os.path.exists(seq):
+        for i, g in enumerate(np.load(seq)["gray"]):
+            out["toy%d" % i] = g
+    elif os.path.exists(toy):
         out["toy"] = np.load(toy)["gray"]
     return out
 
