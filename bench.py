@@ -720,7 +720,7 @@ def main():
                                    "algorithmic_bytes_per_launch": px * frames_per_launch, "avg_launch_ms": ms,
                                    "frames_per_launch": frames_per_launch,
                                    "note": "integer-VALU-bound kernel (FAST ring tests, exact scores, NMS): the HBM fraction is low by "
-                                           "construction; the runtime runs a step as four quarter-batch launches per kernel over two "
+                                           "construction; the runtime runs a step as chunks of about 85 frames alternating over two "
                                            "streams, so a launch shares the chip with the other stream's kernels (DESIGN.md section 4); "
                                            "traffic = committed PMC pass, null when the sources changed since (traffic_stale)"}
             # whole-pipeline algorithmic bytes (resize 1 569 878 + FAST read 950 532 + blur 1 901 064 + outputs
