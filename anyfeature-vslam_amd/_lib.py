@@ -139,6 +139,7 @@ SYMBOLS = {
     "afv_profile_read": (_i, [_vp, _vp, _vp, _vp]),
     "afv_set_split_threshold": (_i, [_vp, _i]),
     "afv_set_split_chunks": (_i, [_vp, _i]),
+    "afv_set_match_engine": (_i, [_vp, _i]),
     "afv_set_pipeline_chunk": (_i, [_vp, _i, _i]),
     "afv_get_geometry": (_i, [_vp, C.POINTER(Geometry)]),
     "afv_debug_get_level": (_i, [_vp, _i, _i, _vp]),

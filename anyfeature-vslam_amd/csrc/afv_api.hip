@@ -306,6 +306,12 @@ extern "C" int afv_set_pipeline_chunk(afv_ctx *c, int frames, int chunks_ahead) 
     c->pipe_ahead = chunks_ahead;
     return AFV_OK;
 }
+extern "C" int afv_set_match_engine(afv_ctx *c, int engine) {
+    if (!c || (engine != AFV_MATCH_ENGINE_POPCOUNT && engine != AFV_MATCH_ENGINE_MFMA)) return AFV_EINVAL;
+    c->match_engine = engine;
+    return AFV_OK;
+}
+
 extern "C" int afv_set_split_chunks(afv_ctx *c, int chunks) {
     if (!c || (chunks != 0 && chunks < 2) || chunks > 64) return AFV_EINVAL;
     c->split_chunks = chunks;
@@ -904,7 +910,7 @@ static int afv_match_bow_impl(afv_ctx *c, const afv_match_job *jobs, int njobs, 
                 const float *angp = any_ori ? reinterpret_cast<const float *>(c->d_match + ang_off) : nullptr;
                 const int *np_ = reinterpret_cast<const int *>(c->d_match + n_off);
                 const int *pa_ = reinterpret_cast<const int *>(c->d_match + pa_off), *pb_ = reinterpret_cast<const int *>(c->d_match + pb_off);
-                afv_launch_match_topk(c->d_match + desc_off, np_, cap, pa_, pb_, i1 - i0, c->d_match + topk_off, i0, c->stream);
+                afv_launch_match_topk(c->d_match + desc_off, np_, cap, pa_, pb_, i1 - i0, c->d_match + topk_off, i0, c->match_engine, c->stream);
                 afv_launch_match_resolve(c->d_match + desc_off, angp, 1, np_, cap, pa_, pb_, i1 - i0, jobs[i0].th_low, jobs[i0].nnratio,
                                          jobs[i0].check_orientation != 0, reinterpret_cast<int *>(c->d_match + match_off),
                                          reinterpret_cast<int *>(c->d_match + nm_off), c->d_match + topk_off, i0, c->stream);
@@ -1080,7 +1086,7 @@ int afv_match_pairs_core(afv_ctx *c, const uint8_t *d_desc, const float *d_ang, 
             hipStream_t ks = (k & 1) ? c->stream2 : s;
             {
                 StageTimer t_(c, AFV_STAGE_MATCH, ks, e0 - b0);
-                afv_launch_match_topk(d_desc, d_n, cap, d_pair_a, d_pair_b, e0 - b0, c->d_topk, b0, ks);
+                afv_launch_match_topk(d_desc, d_n, cap, d_pair_a, d_pair_b, e0 - b0, c->d_topk, b0, c->match_engine, ks);
             }
             StageTimer t_(c, AFV_STAGE_MATCH_RESOLVE, ks, e0 - b0);
             afv_launch_match_resolve(d_desc, d_ang, ang_stride, d_n, cap, d_pair_a, d_pair_b, e0 - b0, th_low, nnratio, check_orientation,
@@ -1091,7 +1097,7 @@ int afv_match_pairs_core(afv_ctx *c, const uint8_t *d_desc, const float *d_ang, 
     } else {
         {
             StageTimer t_(c, AFV_STAGE_MATCH, s, npairs);
-            afv_launch_match_topk(d_desc, d_n, cap, d_pair_a, d_pair_b, npairs, c->d_topk, 0, s);
+            afv_launch_match_topk(d_desc, d_n, cap, d_pair_a, d_pair_b, npairs, c->d_topk, 0, c->match_engine, s);
         }
         StageTimer t_(c, AFV_STAGE_MATCH_RESOLVE, s, npairs);
         afv_launch_match_resolve(d_desc, d_ang, ang_stride, d_n, cap, d_pair_a, d_pair_b, npairs, th_low, nnratio, check_orientation, d_match,

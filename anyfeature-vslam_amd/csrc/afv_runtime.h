@@ -54,7 +54,7 @@ extern "C" void afv_launch_match_bow(const DevMatchJob *jobs, int njobs, hipStre
 extern "C" void afv_launch_match_bow_seg(const DevMatchJob *jobs, int njobs, const void *tasks, int ntasks, int *hist, uint8_t *bins,
                                          const int *bin_off, int any_ori, hipStream_t stream);
 extern "C" void afv_launch_match_topk(const uint8_t *desc, const int *nset, int cap, const int *pa, const int *pb, int npairs,
-                                      void *topk_scratch, int pair_base, hipStream_t stream);
+                                      void *topk_scratch, int pair_base, int engine, hipStream_t stream);
 extern "C" void afv_launch_match_resolve(const uint8_t *desc, const float *ang, int ang_stride, const int *nset, int cap, const int *pa,
                                          const int *pb, int npairs, float th, float ratio, int check_ori, int *match, int *nmatches,
                                          const void *topk_scratch, int pair_base, hipStream_t stream);
@@ -105,6 +105,7 @@ struct afv_ctx {
     int pipe_chunk = 64;                                       // frames per pipeline chunk
     int pipe_ahead = 8;                                        // uploads run this many chunks ahead of the compute
     int split_min_frames = 64;     // batches of at least this many frames / pairs are split over the two streams
+    int match_engine = AFV_MATCH_ENGINE_MFMA;  // phase 1 of the brute-force pair matcher; afv_set_match_engine
     int split_chunks = 0;          // ... into this many chunks (alternating streams); 0 = about 85 frames each; afv_set_split_chunks
     afv_orb_params p{};
     Geo geo{};          // current geometry (host copy)

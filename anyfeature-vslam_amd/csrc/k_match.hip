@@ -732,8 +732,16 @@ extern "C" void afv_launch_match_bow_seg(const DevMatchJob *jobs, int njobs, con
 }
 // phase 1 (VALU-bound: the 8 xor + 8 v_bcnt per descriptor pair) and phase 2 (latency-bound ordered resolve) are launched
 // separately so that the runtime can time them apart.
+extern "C" void afv_launch_match_topk_mfma(const uint8_t *desc, const int *nset, int cap, const int *pa, const int *pb, int npairs,
+                                           void *topk_scratch, int pair_base, hipStream_t stream);
+// engine: AFV_MATCH_ENGINE_MFMA (default: the exact i8 contraction of k_match_mfma.hip; its keys hold the column in 13 bits) or
+// AFV_MATCH_ENGINE_POPCOUNT (k_match_topk below).  Both write the same top-4 keys.
 extern "C" void afv_launch_match_topk(const uint8_t *desc, const int *nset, int cap, const int *pa, const int *pb, int npairs,
-                                      void *topk_scratch, int pair_base, hipStream_t stream) {
+                                      void *topk_scratch, int pair_base, int engine, hipStream_t stream) {
+    if (engine == AFV_MATCH_ENGINE_MFMA && cap < 8192) {
+        afv_launch_match_topk_mfma(desc, nset, cap, pa, pb, npairs, topk_scratch, pair_base, stream);
+        return;
+    }
     int4 *topk = reinterpret_cast<int4 *>(topk_scratch);
     hipLaunchKernelGGL(k_match_topk, dim3((cap + MT - 1) / MT, npairs), dim3(MT), 0, stream, desc, nset, cap, pa, pb, topk, pair_base);
 }

@@ -1,0 +1,175 @@
+// k_match_mfma.hip — M1/M5 phase 1 on the matrix cores: the 256-bit Hamming distance as an EXACT integer contraction.
+//
+// Replaces the distance loop of the brute-force matchers (DescriptorDistance_orb32, Feature_orb32.cpp:67-84, called n1 x n2 times per
+// keyframe pair from FeatureMatcher.cc:587-641) for whole descriptor sets; same output as k_match_topk (k_match.hip): every row's four
+// smallest keys  distance << 16 | column.
+//
+// popcount(a ^ b) over 256 bits is a dot product in disguise: with the bits of the train descriptor as +-64 and the bits of the query
+// as -+64 (opposite signs), sum_k A_k B_k = 4096 * (#differing - #equal) = 8192 * d - 2^20.  i8 x i8 -> i32 is exact, so
+// v_mfma_i32_32x32x32_i8 (8 instructions cover the 256 bits of 32 train x 32 query descriptors) delivers 1024 distances per 8
+// instructions, and — because the accumulator is preloaded with the train descriptor's index m — directly the ORDERING KEY
+// 8192 * d - 2^20 + m  (m < 8192: distance first, then position, exactly the order of  d << 16 | m).  In the C/D register layout of
+// the 32x32 forms a lane owns ONE column (= one query) and 16 rows (= 16 train descriptors), so the top-4 insertion is the same
+// lane-private  v_min + 3 v_med3  per value as in k_match_topk, with no cross-lane traffic; the VALU work per descriptor pair drops
+// from 8 xor + 8 v_bcnt + 5 to 1 + 4 and runs beside the MFMA pipe.
+//
+// Workgroup = 4 wavefronts = 256 queries (64 per wavefront: two 32-column blocks, their B fragments live in registers for the whole
+// kernel).  Train descriptors are expanded 64 at a time into LDS (bit -> +-64 byte through a 256-entry byte -> 8-byte table that also
+// lives in LDS), double-buffered, one barrier per tile; every wavefront reads its A fragments with ds_read_b128 (row pitch 272 B:
+// 16 consecutive rows cover all 64 banks).
+#include "afv_device.h"
+
+#define MQ_T 256
+#define NO_KEY 0x7fffffff
+#define T_TILE 64
+#define A_PITCH 272
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// median of three, written as the min / max form the backend selects v_med3_i32 for.  NOT inline assembly: the hazard recogniser has to
+// see these instructions to place the wait states a VALU read of a fresh MFMA result needs.
+__device__ __forceinline__ int mq_med3(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }
+
+// sorted insert into k[0] <= k[1] <= k[2] <= k[3]; the largest of the five falls out
+__device__ __forceinline__ void mq_insert(int (&k)[4], int key) {
+    const int n3 = mq_med3(k[2], k[3], key), n2 = mq_med3(k[1], k[2], key), n1 = mq_med3(k[0], k[1], key);
+    k[0] = min(k[0], key);
+    k[1] = n1;
+    k[2] = n2;
+    k[3] = n3;
+}
+
+// expand 64 train descriptors (rows tile_row0 .. +63, clamped to n2 - 1) into one LDS buffer
+__device__ __forceinline__ void mq_stage(const uint32_t *__restrict__ train, int n2, int tile_row0, const uint2 *lut, uint8_t *buf, int tid) {
+    uint32_t w[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int idx = tid + MQ_T * k, row = idx >> 3, wd = idx & 7;
+        w[k] = train[(size_t)min(tile_row0 + row, n2 - 1) * 8 + wd];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int idx = tid + MQ_T * k, row = idx >> 3, wd = idx & 7;
+        const uint2 e0 = lut[w[k] & 255u], e1 = lut[(w[k] >> 8) & 255u], e2 = lut[(w[k] >> 16) & 255u], e3 = lut[w[k] >> 24];
+        uint4 *dst = reinterpret_cast<uint4 *>(buf + row * A_PITCH + wd * 32);
+        dst[0] = make_uint4(e0.x, e0.y, e1.x, e1.y);
+        dst[1] = make_uint4(e2.x, e2.y, e3.x, e3.y);
+    }
+}
+
+template <bool PARTIAL>
+__device__ __forceinline__ void mq_compute(const uint8_t *buf, const v4i (&bq)[2][8], int (&kk)[2][4], const int (&idx)[16], int tile_row0, int n2,
+                                           int lane) {
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+        v4i a[8];
+        const uint8_t *ap = buf + (sub * 32 + (lane & 31)) * A_PITCH + (lane >> 5) * 16;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) a[t] = *reinterpret_cast<const v4i *>(ap + t * 32);
+        const int off = tile_row0 + sub * 32;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            v16i acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = idx[r] + off;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[t], bq[qb][t], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int key = acc[r];
+                if (PARTIAL) key = (idx[r] + off < n2) ? key : NO_KEY;
+                mq_insert(kk[qb], key);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(MQ_T, 2) void k_match_topk_mfma(const uint8_t *__restrict__ desc, const int *__restrict__ nset, int cap,
+                                                             const int *__restrict__ pair_a, const int *__restrict__ pair_b,
+                                                             int4 *__restrict__ topk, int pair_base) {
+    __shared__ __attribute__((aligned(16))) uint2 s_lut[256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_a[2][T_TILE * A_PITCH];
+    const int p = pair_base + blockIdx.y;
+    const int sa = pair_a[p], sb = pair_b[p];
+    const int n1 = min(nset[sa], cap), n2 = min(nset[sb], cap);
+    if (blockIdx.x * MQ_T >= n1) return;  // uniform
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    {   // byte -> eight +-64 bytes: bit j of the byte -> byte j (0x40 if set, 0xC0 = -64 if clear)
+        const uint32_t lo = ((uint32_t)(tid & 15) * 0x00204081u) & 0x01010101u, hi = ((uint32_t)(tid >> 4) * 0x00204081u) & 0x01010101u;
+        s_lut[tid] = make_uint2(0xC0C0C0C0u - lo * 0x80u, 0xC0C0C0C0u - hi * 0x80u);
+    }
+    int kk[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kk[qb][i] = NO_KEY;
+    const int row0 = blockIdx.x * MQ_T + wv * 64;  // first query of this wavefront
+    if (n2 > 0) {
+        __syncthreads();  // table ready
+        // B fragments: lane (n = lane & 31, g = lane >> 5) holds, for instruction t, the k-slots 32 t + 16 g .. + 15 = descriptor bytes
+        // 4 t + 2 g, 4 t + 2 g + 1 of query row0 + 32 qb + n, signs flipped
+        v4i bq[2][8];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const int q = min(row0 + 32 * qb + (lane & 31), n1 - 1);
+            const uint4 *qp = reinterpret_cast<const uint4 *>(desc + ((size_t)sa * cap + q) * 32);
+            const uint4 q0 = qp[0], q1 = qp[1];
+            const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const uint32_t h = (lane >> 5) ? (w[t] >> 16) : (w[t] & 0xffffu);
+                const uint2 e0 = s_lut[h & 255u], e1 = s_lut[h >> 8];
+                v4i v;
+                v[0] = (int)(e0.x ^ 0x80808080u);
+                v[1] = (int)(e0.y ^ 0x80808080u);
+                v[2] = (int)(e1.x ^ 0x80808080u);
+                v[3] = (int)(e1.y ^ 0x80808080u);
+                bq[qb][t] = v;
+            }
+        }
+        // accumulator preload: train index of C/D register r inside a 32-row block (row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+        int idx[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) idx[r] = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const uint32_t *train = reinterpret_cast<const uint32_t *>(desc + (size_t)sb * cap * 32);
+        const int ntiles = (n2 + T_TILE - 1) / T_TILE;
+        const bool wave_has_rows = row0 < n1;
+        mq_stage(train, n2, 0, s_lut, s_a[0], tid);
+        __syncthreads();
+        for (int tile = 0; tile < ntiles; ++tile) {
+            if (tile + 1 < ntiles) mq_stage(train, n2, (tile + 1) * T_TILE, s_lut, s_a[(tile + 1) & 1], tid);
+            if (wave_has_rows) {
+                if ((tile + 1) * T_TILE <= n2) mq_compute<false>(s_a[tile & 1], bq, kk, idx, tile * T_TILE, n2, lane);
+                else mq_compute<true>(s_a[tile & 1], bq, kk, idx, tile * T_TILE, n2, lane);
+            }
+            __syncthreads();
+        }
+    }
+    // the two lane halves hold the top-4 over disjoint train rows of the same queries: merge, convert to d << 16 | m, write
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        int o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = __shfl_xor(kk[qb][i], 32, 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mq_insert(kk[qb], o[i]);
+        const int row = row0 + 32 * qb + (lane & 31);
+        if ((lane >> 5) == qb && row < n1) {
+            int s[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int D = kk[qb][i] + (1 << 20);
+                s[i] = kk[qb][i] == NO_KEY ? NO_KEY : (((D >> 13) << 16) | (D & 8191));
+            }
+            topk[(size_t)p * cap + row] = make_int4(s[0], s[1], s[2], s[3]);
+        }
+    }
+}
+
+extern "C" void afv_launch_match_topk_mfma(const uint8_t *desc, const int *nset, int cap, const int *pa, const int *pb, int npairs,
+                                           void *topk_scratch, int pair_base, hipStream_t stream) {
+    int4 *topk = reinterpret_cast<int4 *>(topk_scratch);
+    hipLaunchKernelGGL(k_match_topk_mfma, dim3((cap + MQ_T - 1) / MQ_T, npairs), dim3(MQ_T), 0, stream, desc, nset, cap, pa, pb, topk,
+                       pair_base);
+}

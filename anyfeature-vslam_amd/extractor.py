@@ -189,6 +189,10 @@ class Context:
     def set_pipeline_chunk(self, frames, chunks_ahead=8):
         self.check(self.lib.afv_set_pipeline_chunk(self.handle, int(frames), int(chunks_ahead)))
 
+    def set_match_engine(self, engine):
+        """0 = popcount on the vector ALU, 1 = exact i8 contraction on the matrix cores (default); identical results"""
+        self.check(self.lib.afv_set_match_engine(self.handle, int(engine)))
+
     def set_split_chunks(self, chunks):
         self.check(self.lib.afv_set_split_chunks(self.handle, int(chunks)))
 

@@ -293,6 +293,8 @@ def pairs_main(args):
     K, cap, njobs = args.keyframes, 1000, args.jobs
     TH, RATIO = 75.0, 0.75                                  # LoopClosing.cc:255: FeatureMatcher matcher(0.75, true); TH_LOW = matchingTh
     ctx = afv.Context(max_batch=1, device=local)
+    if args.match_engine is not None:
+        ctx.set_match_engine(args.match_engine)
     table = tbl_mod.DescriptorTable(ctx, K, cap)
     host = None
     if rank == 0:                                           # the table exists on ONE rank before the exchange step
@@ -599,6 +601,8 @@ def main():
     ap.add_argument("--workload", default="orb32", choices=["orb32", "akaze61", "pairs10k"],
                     help="orb32 = the BASELINE.json metric (default); akaze61 = configs[4], 1280x720, single GPU (use --batch 64); "
                          "pairs10k = configs[3], 10 000 keyframe-pair match jobs over a K = 1000 table, RCCL broadcast timed separately")
+    ap.add_argument("--match-engine", type=int, default=None, choices=[0, 1], help="phase 1 of the pair matcher: 1 = matrix cores (library "
+                    "default), 0 = popcount on the vector ALU (A/B measurement; identical results)")
     ap.add_argument("--keyframes", type=int, default=1000, help="pairs10k: keyframes in the table")
     ap.add_argument("--jobs", type=int, default=10000, help="pairs10k: pair jobs per step (whole job, all GPUs)")
     ap.add_argument("--bcast-reps", type=int, default=3, help="pairs10k: repetitions of the table broadcast")
@@ -630,6 +634,8 @@ def main():
     B = args.batch
     ctx = afv.Context(nfeatures=1000, nlevels=8, scale_factor=1.2, fast_threshold=20, max_width=W, max_height=H, max_batch=B,
                       device=local)
+    if args.match_engine is not None:
+        ctx.set_match_engine(args.match_engine)
     if os.environ.get("AFV_EXP_CHUNKS"):      # tools/timeline.py experiments only
         ctx.set_split_chunks(int(os.environ["AFV_EXP_CHUNKS"]))
     if os.environ.get("AFV_EXP_NOSPLIT"):

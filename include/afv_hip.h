@@ -317,6 +317,12 @@ int afv_profile_read(afv_ctx *ctx, int32_t *launches /*[AFV_NUM_STAGES]*/, float
 int afv_set_split_threshold(afv_ctx *ctx, int min_frames);
 int afv_set_split_chunks(afv_ctx *ctx, int chunks); /* ... into this many chunks alternating over the two streams (2..64; 0 = automatic,
                                                       * chunks of about 85 frames: the default) */
+/* Phase 1 of the brute-force pair matchers (afv_match_bruteforce_pairs_device, afv_table_match_pairs*, plain SearchByBoW jobs without
+ * a FeatureVector): every row's four nearest columns.  Both engines produce identical keys, hence identical match vectors.
+ *   AFV_MATCH_ENGINE_MFMA (default): Hamming distance as an exact i8 x i8 -> i32 contraction on the matrix cores
+ *   AFV_MATCH_ENGINE_POPCOUNT:       8 xor + 8 v_bcnt per descriptor pair on the vector ALU */
+enum { AFV_MATCH_ENGINE_POPCOUNT = 0, AFV_MATCH_ENGINE_MFMA = 1 };
+int afv_set_match_engine(afv_ctx *ctx, int engine);
 /* afv_orb_extract_batch pipelines H2D / compute / D2H over chunks of `frames` frames with the uploads `chunks_ahead` chunks ahead of
  * the compute (defaults 64 and 8; batches below two chunks run as one) */
 int afv_set_pipeline_chunk(afv_ctx *ctx, int frames, int chunks_ahead);

@@ -290,6 +290,48 @@ def test_device_pairs_heavy_contention(afv, oracle, matcher, gpu_ctx, nproto, fl
     matcher.mfNNratio = 0.6
 
 
+@pytest.mark.parametrize("engine", [0, 1])
+def test_match_engines_on_ragged_sizes(afv, oracle, matcher, gpu_ctx, engine):
+    """phase 1 on the vector ALU (popcount) and on the matrix cores (exact i8 contraction, 32 x 32 x 32 tiles, 64 train rows per LDS
+    stage, 256 queries per workgroup): set sizes on every tile boundary, fewer than four columns, near-duplicate rows (distance
+    ties are ordered by column).  Both engines must reproduce the oracle's match vector."""
+    import torch
+    s = afv.synth
+    sizes = [1, 2, 3, 4, 5, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 513, 1000]
+    cap = 1000
+    base = s.random_descriptors(77, cap)
+    table = np.zeros((len(sizes), cap, 32), np.uint8)
+    counts = np.array(sizes, np.int32)
+    kps = np.zeros((len(sizes), cap), afv.KP_DTYPE)
+    for i, n in enumerate(sizes):
+        d = s.perturbed_descriptors(base.copy(), 900 + i, flip_prob_256=10, replace_frac_256=40)
+        d[1::7] = d[0::7][:len(d[1::7])]          # exact duplicates: equal distances, the earlier column must win
+        table[i, :n] = d[:n]
+        kps[i, :n]["angle"] = (s.lcg_states(40 + i, n) % 36000).astype(np.float32) / 100.0
+    pa, pb = [], []
+    for i in range(len(sizes)):
+        for j in (0, 3, 5, 8, 11, 14, 17, 19, (i + 1) % len(sizes)):
+            pa.append(i); pb.append(j)
+    pa = np.array(pa, np.int32); pb = np.array(pb, np.int32)
+    gpu_ctx.set_match_engine(engine)
+    try:
+        match, nm = matcher.match_pairs_device(torch.from_numpy(table).cuda(), torch.from_numpy(kps.view(np.float32).reshape(len(sizes), cap, 7)).cuda(),
+                                               torch.from_numpy(counts).cuda(), torch.from_numpy(pa).cuda(), torch.from_numpy(pb).cuda(),
+                                               th_low=75.0, check_orientation=True)
+        torch.cuda.synchronize()
+    finally:
+        gpu_ctx.set_match_engine(1)
+    match = match.cpu().numpy(); nm = nm.cpu().numpy()
+    total = 0
+    for p in range(len(pa)):
+        a, b = pa[p], pb[p]
+        want, wn = oracle.search_by_bow_kf_kf(table[a, :counts[a]], table[b, :counts[b]], angle1=kps[a, :counts[a]]["angle"],
+                                              angle2=kps[b, :counts[b]]["angle"], th_low=75.0, nnratio=0.6, check_orientation=True)
+        assert nm[p] == wn and np.array_equal(match[p, :counts[a]], want), (p, a, b)
+        total += wn
+    assert total > 2000
+
+
 def test_config4_pair_jobs_from_descriptor_table(afv, oracle, matcher, gpu_ctx):
     """config #4 shape on one GPU: K keyframes x N x 32 B table (keyframe k+1 = perturbed keyframe k), LCG-drawn (i, j)
     pair jobs through dist.match_jobs_sharded with the DEVICE matcher (world size 1: broadcast is a no-op)"""
