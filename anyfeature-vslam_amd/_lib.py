@@ -16,7 +16,7 @@ DESC_BYTES = 32
 OK, EINVAL, ENODEV, ENOMEM, EHIP, ECAPACITY, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 MATCH_KF_KF, MATCH_KF_FRAME = 0, 1
 PROJ_LOCALMAP, PROJ_LASTFRAME = 0, 1
-STAGES = ("pyramid", "fast_nms", "select_quadtree", "describe", "match_topk", "match_resolve", "retain_harris", "blur")
+STAGES = ("pyramid", "fast_nms", "select_quadtree", "describe", "match_topk", "match_resolve", "retain_harris")
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
                      ("octave", "<i4"), ("class_id", "<i4")])
@@ -146,8 +146,6 @@ SYMBOLS = {
     "afv_debug_get_candidates": (_i, [_vp, _i, _i, _vp, _vp, _i, C.POINTER(_i)]),
     "afv_debug_get_selected": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, C.POINTER(_i)]),
     "afv_debug_blur_level": (_i, [_vp, _i, _i, _vp]),
-    "afv_debug_get_plane": (_i, [_vp, _i, _i, _i, _vp]),
-    "afv_num_stages": (_i, []),
 }
 
 _lib = None

@@ -68,8 +68,8 @@ static int build_geometry(const afv_orb_params &p, int w, int h, int max_batch, 
         }
         cvq[p.nlevels - 1] = std::max(nf - sum, 0);
     }
-    size_t pyr_off = 0, cand_off = 0, b_off = 0;
-    int tile_base = 0, sel_base = 0, ap_blk_base = 0, bl_wave_base = 0, desc_blk_base = 0;
+    size_t pyr_off = 0, cand_off = 0;
+    int tile_base = 0, sel_base = 0;
     for (int l = 0; l < p.nlevels; ++l) {
         LevelGeo &L = g.lv[l];
         L.scale = (float)std::pow((double)p.scale_factor, (double)l);
@@ -97,28 +97,8 @@ static int build_geometry(const afv_orb_params &p, int w, int h, int max_batch, 
         L.cand_frame_stride = (size_t)L.cand_cap;
         L.cand_off = cand_off;
         cand_off += L.cand_frame_stride * (size_t)max_batch;
-        // blur / raw planes with their apron (k_blur.hip)
-        const int bw = L.w + 2 * AFV_APRON, bh = L.h + 2 * AFV_APRON;
-        L.bpitch = (int)align_up((size_t)bw, 64);
-        L.ap_chunks = (L.bpitch / 4 + 63) / 64;
-        L.ap_strips = (bh + AFV_AP_ROWS - 1) / AFV_AP_ROWS;
-        L.ap_blk_base = ap_blk_base;
-        ap_blk_base += L.ap_chunks * L.ap_strips;
-        L.bl_nstrips = (L.h + 31) / 32;
-        L.bl_sr = (int)align_up((size_t)(L.h + L.bl_nstrips - 1) / L.bl_nstrips, 8);  // <= 7 rows of overshoot: inside the apron
-        L.bl_groups = (L.w + 3) / 4;
-        L.bl_wave_base = bl_wave_base;
-        bl_wave_base += (L.bl_nstrips * L.bl_groups + 63) / 64;
-        L.desc_blk_base = desc_blk_base;
-        desc_blk_base += (L.sel_cap + 3) / 4;
-        // + 24 rows: the strips of k_blur_strips run up to 31 rows past the level and read 7 rows ahead (values never stored)
-        L.b_frame_stride = align_up((size_t)(bh + 24) * L.bpitch + 64, 256);
-        L.b_off = b_off;
-        b_off += L.b_frame_stride * (size_t)max_batch;
     }
     g.total_tiles = tile_base;
-    g.ap_blocks = ap_blk_base;
-    g.bl_waves = bl_wave_base;
     g.sel_per_frame = sel_base;
     return AFV_OK;
 }
@@ -126,10 +106,6 @@ static int build_geometry(const afv_orb_params &p, int w, int h, int max_batch, 
 static size_t geo_pyr_bytes(const Geo &g, int max_batch) {
     const LevelGeo &L = g.lv[g.nlevels - 1];
     return g.nlevels > 1 ? L.pyr_off + L.pyr_frame_stride * (size_t)max_batch : 256;
-}
-static size_t geo_plane_bytes(const Geo &g, int max_batch) {
-    const LevelGeo &L = g.lv[g.nlevels - 1];
-    return L.b_off + L.b_frame_stride * (size_t)max_batch;
 }
 static size_t geo_cand_elems(const Geo &g, int max_batch) {
     const LevelGeo &L = g.lv[g.nlevels - 1];
@@ -169,11 +145,8 @@ static int set_geometry(afv_ctx *c, int w, int h) {
     // allocation layout always follows the capacity geometry so buffers never move
     if (g.sel_per_frame > c->cap_geo.sel_per_frame) return AFV_EINVAL;  // wider aspect ratio than the capacity geometry
     for (int l = 0; l < g.nlevels; ++l) {
-        if (g.lv[l].cand_cap > c->cap_geo.lv[l].cand_cap || g.lv[l].pyr_frame_stride > c->cap_geo.lv[l].pyr_frame_stride ||
-            g.lv[l].b_frame_stride > c->cap_geo.lv[l].b_frame_stride)
+        if (g.lv[l].cand_cap > c->cap_geo.lv[l].cand_cap || g.lv[l].pyr_frame_stride > c->cap_geo.lv[l].pyr_frame_stride)
             return AFV_EINVAL;
-        g.lv[l].b_off = c->cap_geo.lv[l].b_off;
-        g.lv[l].b_frame_stride = c->cap_geo.lv[l].b_frame_stride;
         g.lv[l].pyr_off = c->cap_geo.lv[l].pyr_off;
         g.lv[l].pyr_frame_stride = c->cap_geo.lv[l].pyr_frame_stride;
         g.lv[l].cand_off = c->cap_geo.lv[l].cand_off;
@@ -210,7 +183,7 @@ extern "C" void afv_destroy(afv_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     afv_table_release_all(c);
-    void *ptrs[] = {c->d_blur, c->d_raw, c->d_geo, c->d_tab, c->d_pyr, c->d_cand_packed, c->d_kept_xy, c->d_l1, c->d_l1_resp, c->d_l1_count, c->d_hq, c->d_hq_n, c->d_kept_resp,
+    void *ptrs[] = {c->d_geo, c->d_tab, c->d_pyr, c->d_cand_packed, c->d_kept_xy, c->d_l1, c->d_l1_resp, c->d_l1_count, c->d_hq, c->d_hq_n, c->d_kept_resp,
                     c->d_kept_node, c->d_cand_count, c->d_sel_count, c->d_sel, c->d_frames, c->d_kps, c->d_desc,
                     c->d_n, c->d_status, c->d_match, c->d_topk};
     for (void *p : ptrs)
@@ -269,8 +242,6 @@ extern "C" int afv_create(int device, const afv_orb_params *params, afv_ctx **ou
     for (int l = 1; l < g.nlevels; ++l) c->tab_elems += (size_t)g.lv[l].w + (size_t)g.lv[l].h;
     CREATE_CHK(hipMalloc(&c->d_tab, std::max<size_t>(c->tab_elems, 1) * sizeof(short2)));
     CREATE_CHK(hipMalloc(&c->d_pyr, geo_pyr_bytes(g, B)));
-    CREATE_CHK(hipMalloc(&c->d_blur, geo_plane_bytes(g, B)));
-    CREATE_CHK(hipMalloc(&c->d_raw, geo_plane_bytes(g, B)));
     const size_t ce = geo_cand_elems(g, B);
     CREATE_CHK(hipMalloc(&c->d_cand_packed, ce * 4));
     CREATE_CHK(hipMalloc(&c->d_l1, ce * 4));
@@ -363,8 +334,6 @@ extern "C" int afv_profile_enable(afv_ctx *c, int enable) {
     return AFV_OK;
 }
 
-extern "C" int afv_num_stages(void) { return AFV_NUM_STAGES; }
-
 extern "C" int afv_profile_read(afv_ctx *c, int32_t *launches, float *total_ms, int64_t *units) {
     if (!c || !launches || !total_ms) return AFV_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
@@ -432,12 +401,8 @@ static void enqueue_range(afv_ctx *c, const FrameSrc &src, int f0, int nf, afv_k
                           c->d_kept_node, c->d_sel, c->d_sel_count, c->select_M, f0, nf, s);
     }
     {
-        StageTimer t_(c, AFV_STAGE_BLUR, s, nf);
-        afv_launch_blur_planes(c->d_geo, g.ap_blocks, g.bl_waves, &src, c->d_pyr, c->d_blur, c->d_raw, f0, nf, s);
-    }
-    {
         StageTimer t_(c, AFV_STAGE_DESCRIBE, s, nf);
-        afv_launch_describe(c->d_geo, afv_describe_blocks_per_frame(&g), c->d_blur, c->d_raw, c->d_sel, c->d_sel_count, d_kps, d_desc, cap, d_n,
+        afv_launch_describe(c->d_geo, afv_describe_blocks_per_frame(&g), &src, c->d_pyr, c->d_sel, c->d_sel_count, d_kps, d_desc, cap, d_n,
                             d_status, f0, nf, s);
     }
 }
@@ -772,22 +737,16 @@ extern "C" int afv_debug_blur_level(afv_ctx *c, int frame, int level, uint8_t *o
     if (!c || !out || !c->geo_valid || frame < 0 || frame >= c->last_nframes || level < 0 || level >= c->geo.nlevels) return AFV_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipDeviceSynchronize());
-    // the ROI of the blur plane the last extraction wrote (what k_describe sampled)
+    int pitch;
+    const uint8_t *p = level_ptr(c, frame, level, &pitch);
     const LevelGeo &L = c->geo.lv[level];
-    const uint8_t *p = c->d_blur + L.b_off + (size_t)frame * L.b_frame_stride + (size_t)AFV_APRON * L.bpitch + AFV_APRON;
-    HIPCHK(c, hipMemcpy2D(out, (size_t)L.w, p, (size_t)L.bpitch, (size_t)L.w, (size_t)L.h, hipMemcpyDeviceToHost));
-    return AFV_OK;
-}
-
-extern "C" int afv_debug_get_plane(afv_ctx *c, int frame, int level, int which, uint8_t *out) {
-    if (!c || !out || !c->geo_valid || frame < 0 || frame >= c->last_nframes || level < 0 || level >= c->geo.nlevels || which < 0 || which > 1)
-        return AFV_EINVAL;
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipDeviceSynchronize());
-    const LevelGeo &L = c->geo.lv[level];
-    const uint8_t *p = (which ? c->d_raw : c->d_blur) + L.b_off + (size_t)frame * L.b_frame_stride;
-    const size_t bw = (size_t)L.w + 2 * AFV_APRON, bh = (size_t)L.h + 2 * AFV_APRON;
-    HIPCHK(c, hipMemcpy2D(out, bw, p, (size_t)L.bpitch, bw, bh, hipMemcpyDeviceToHost));
+    uint8_t *d_out = nullptr;
+    HIPCHK(c, hipMalloc(&d_out, (size_t)L.w * L.h));
+    afv_launch_blur_level(p, L.w, L.h, pitch, d_out, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, (size_t)L.w * L.h, hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    HIPCHK(c, e);
     return AFV_OK;
 }
 

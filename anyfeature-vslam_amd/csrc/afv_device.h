@@ -14,11 +14,6 @@
 #define FT_LH (FT_H + 2 * FT_HALO)  // 40
 #define FT_MAXC 1024                 // candidates per tile after NMS: <= (64/2)*(32/2) = 512 (strict 3x3 maxima)
 
-// apron of the blur / raw planes (k_blur.hip): 18 px BRIEF reach + 1, rounded to a dword multiple; also covers the radius-15 IC disc
-// read as aligned dwords
-#define AFV_APRON 20
-#define AFV_AP_ROWS 16  // plane rows per k_apron_copy block
-
 // quadtree limits
 #define QT_MAX_NODES 1536  // alive nodes <= N+3 ; supports per-level quotas up to ~1500 (nfeatures <= ~6900)
 
@@ -37,20 +32,11 @@ struct LevelGeo {
     size_t pyr_frame_stride;
     size_t cand_off;        // element offset of frame 0 of this level in the candidate arrays
     size_t cand_frame_stride;
-    int bpitch;             // row pitch of the blur / raw planes ((w + 2 AFV_APRON) rounded up to 64)
-    int ap_chunks, ap_strips, ap_blk_base;  // k_apron_copy: 64-dword column chunks x AFV_AP_ROWS-row strips of the plane
-    int bl_sr, bl_nstrips, bl_groups;       // k_blur_strips: rows per strip (multiple of 8), strips, 4-px column groups of the ROI
-    int bl_wave_base;                       // first wavefront of this level in a frame's k_blur_strips work list
-    int desc_blk_base;                      // first k_describe block of this level in a frame's block list
-    size_t b_off;           // byte offset of frame 0 of this level in the blur / raw buffers
-    size_t b_frame_stride;
 };
 
 struct Geo {
     int nlevels, width, height;
     int total_tiles;
-    int ap_blocks;          // k_apron_copy blocks per frame
-    int bl_waves;           // k_blur_strips wavefronts per frame
     int sel_per_frame;      // sum of sel_cap
     int n_ini;              // DistributeOctTree: round(w/h)
     float h_x;              // (float)w / n_ini

@@ -31,11 +31,10 @@ extern "C" void afv_launch_select(const Geo *geo_dev, int nlevels, const uint32_
                                   const int *cand_count, uint32_t *kept_xy, float *kept_resp, uint16_t *kept_node, SelPoint *sel,
                                   int *sel_count, int M, int frame_base, int nframes, hipStream_t stream);
 extern "C" int afv_describe_blocks_per_frame(const Geo *g);
-extern "C" void afv_launch_describe(const Geo *geo_dev, int blocks_per_frame, const uint8_t *blur, const uint8_t *raw, const SelPoint *sel,
-                                    const int *sel_count, afv_keypoint *kps, uint8_t *desc, int cap_per_frame, int *n_out, int *status,
-                                    int frame_base, int nframes, hipStream_t stream);
-extern "C" void afv_launch_blur_planes(const Geo *geo, int ap_blocks, int bl_waves, const FrameSrc *src0, const uint8_t *pyr, uint8_t *blur,
-                                       uint8_t *raw, int frame_base, int nframes, hipStream_t stream);
+extern "C" void afv_launch_describe(const Geo *geo_dev, int blocks_per_frame, const FrameSrc *src0, const uint8_t *pyr,
+                                    const SelPoint *sel, const int *sel_count, afv_keypoint *kps, uint8_t *desc,
+                                    int cap_per_frame, int *n_out, int *status, int frame_base, int nframes, hipStream_t stream);
+extern "C" void afv_launch_blur_level(const uint8_t *img, int w, int h, int pitch, uint8_t *out, hipStream_t stream);
 
 struct Seg { int s1, n1, s2, n2; };
 struct DevMatchJob {
@@ -117,7 +116,6 @@ struct afv_ctx {
     size_t tab_off_x[AFV_MAX_LEVELS]{}, tab_off_y[AFV_MAX_LEVELS]{};
     size_t tab_elems = 0;
     uint8_t *d_pyr = nullptr;
-    uint8_t *d_blur = nullptr, *d_raw = nullptr;  // apron planes of every (frame, level): blurred ROI / unblurred (k_blur.hip)
     uint32_t *d_cand_packed = nullptr, *d_kept_xy = nullptr;
     uint32_t *d_l1 = nullptr;          // per (frame, level): the candidates that survive retainBest on the FAST score ...
     float *d_l1_resp = nullptr;        // ... and their Harris responses

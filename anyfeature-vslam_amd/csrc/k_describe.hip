@@ -1,28 +1,29 @@
-// k_describe.hip — E6 + E10 + E11 fused: IC angle and rotated BRIEF, one wavefront per selected keypoint.
+// k_describe.hip — E6 + E9 + E10 + E11 fused: IC angle, 7x7 Gaussian blur and rotated BRIEF, one wavefront
+// per selected keypoint; plus the standalone level blur used by afv_debug_blur_level.
 //
-// Replaces ICAngles (cv::ORB::detect, Feature_orb32.cpp:34 == IC_Angle ORBextractor.cc:143-170), computeOrbDescriptors inside each
-// cv::ORB::compute call (Feature_orb32.cpp:48; same arithmetic as computeOrbDescriptor FeatureExtractor.h:178-217) and
-// mergeKeypointLevels (FeatureExtractor.cpp:296-308).
+// Replaces ICAngles (cv::ORB::detect, Feature_orb32.cpp:34 == IC_Angle ORBextractor.cc:143-170), the
+// GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) of every pyramid level and computeOrbDescriptors inside each
+// cv::ORB::compute call (Feature_orb32.cpp:48; same arithmetic as computeOrbDescriptor FeatureExtractor.h:178-217),
+// and mergeKeypointLevels (FeatureExtractor.cpp:296-308).
 //
-// Inputs are the two apron planes k_blur.hip writes per (frame, level): `blur` (ROI blurred 7x7, apron = unblurred reflect-101: the
-// memory image OpenCV samples) and `raw` (unblurred + apron).  With a 20 px apron no keypoint has a border case: every wavefront
-//   1. loads the 37 x 37 window of the blur plane around the BRIEF centre (7 aligned dword loads per lane, 6 rows per wave
-//      instruction) and the radius-15 disc of the raw plane (lane = (row, half): 5 aligned dwords straight from global memory, no
-//      LDS round trip), all loads issued together;
-//   2. intensity-centroid moments by v_dot4_u32_u8 on masked dwords + DPP wave sums, cv::fastAtan2, explicit f64 sincos;
-//   3. the 512 rotated tests: each lane gathers 8 bytes of the blurred window from LDS (4 tests), ballot-assembled descriptor.
+// The reference blurs whole levels (36 level-blurs per frame because compute() is called once per level).  Only the
+// 512 rotated test locations inside the 37x37 neighbourhood of a keypoint are ever sampled, so each wavefront stages
+// the 43x43 UNBLURRED patch around its keypoint in LDS (reflect-101 at the image edge = cv::ORB's apron), computes
+// the intensity-centroid moments from it, runs the ROW pass of the blur over the patch once (integer taps
+// [18,34,49,55,49,34,18], two v_dot4_u32_u8 per output on funnel-shifted dwords, exact in 16 bits) and evaluates the COLUMN
+// pass + round-half-even(S/65536) only at the sampled locations.  A test that falls outside the level ROI reads the unblurred apron pixel, as in OpenCV
+// where only the ROI is blurred in place.  No blurred image ever touches HBM.
 #include "afv_device.h"
 
-// the 256 test pairs (x0, y0, x1, y1) as floats (FeatureExtractor.h:219-477): one 16-byte load per test, no conversions
-__device__ __constant__ __attribute__((aligned(16))) const float k_brief_pattern[1024] = {
+__device__ __constant__ const signed char k_brief_pattern[1024] = {
 #include "brief_pattern.inc"
 };
 // umax[v], v = 0..15: last column of row v of the radius-15 disc (orb.cpp / ORBextractor.cc:124-139)
 __device__ __constant__ const signed char k_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
-#define WR 18        // window radius: BRIEF reach (13 * sqrt 2 rounded)
-#define WS 37        // window side
-#define WP 44        // LDS pitch of the window rows: 11 dwords (odd => row strides spread over the banks)
+#define PR 21        // patch radius: 18 (BRIEF reach) + 3 (blur)
+#define PS 43        // patch side
+#define PP 52        // LDS pitch of the patch rows: 13 dwords (odd => conflict-free row strides)
 #define KP_PER_BLOCK 4
 
 // cv::fastAtan2 (OpenCV mathfuncs_core atan_f32), degrees
@@ -92,137 +93,227 @@ __device__ __forceinline__ int wave_sum(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
-__global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__restrict__ geo_p, const uint8_t *__restrict__ blur,
-                                                                const uint8_t *__restrict__ raw, const SelPoint *__restrict__ sel,
-                                                                const int *__restrict__ sel_count, afv_keypoint *__restrict__ kps,
-                                                                uint8_t *__restrict__ desc, int cap_per_frame, int *__restrict__ n_out,
+__device__ __forceinline__ uint8_t blur_round(int S) {
+    int q = S >> 16;
+    const int r = S & 0xffff;
+    q += (r > 32768) || (r == 32768 && (q & 1));
+    return (uint8_t)min(q, 255);
+}
+
+// Row pass of the separable 8U filter over the whole staged patch, once per keypoint: H[r][xh] = sum_k taps[k] * P[r][xh + k]
+// for xh = 0..39 (<= 257 * 255 = 65535: exact in 16 bits).  One lane per group of 4 adjacent outputs: 3 aligned dwords in, two
+// v_dot4_u32_u8 per output on funnel-shifted dwords, 4 x u16 out.
+#define HP 44  // u16 pitch of the row-filtered plane (88 bytes: 8-byte aligned rows)
+__device__ __forceinline__ void blur_rows(const uint8_t *P, uint16_t *H, int lane) {
+    const uint32_t T_LO = 18u | (34u << 8) | (49u << 16) | (55u << 24);  // taps for bytes xh .. xh+3
+    const uint32_t T_HI = 49u | (34u << 8) | (18u << 16);                // taps for bytes xh+4 .. xh+6
+    for (int i = lane; i < PS * 10; i += 64) {
+        const int r = i / 10, g = i - r * 10;
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(P + r * PP + g * 4);
+        const uint32_t d0 = row[0], d1 = row[1], d2 = row[2];
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t lo = k ? __builtin_amdgcn_alignbit(d1, d0, 8 * k) : d0, hi = k ? __builtin_amdgcn_alignbit(d2, d1, 8 * k) : d1;
+            o[k] = __builtin_amdgcn_udot4(hi, T_HI, __builtin_amdgcn_udot4(lo, T_LO, 0u, false), false);
+        }
+        uint2 w;
+        w.x = o[0] | (o[1] << 16);
+        w.y = o[2] | (o[3] << 16);
+        *reinterpret_cast<uint2 *>(&H[r * HP + g * 4]) = w;
+    }
+}
+
+// column pass + rounding at patch position (row y, column x), taps centred: exact integer arithmetic of the separable filter,
+// then round-half-even(S / 65536)
+typedef unsigned short ushort2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int blur_at(const uint16_t *H, int x, int y) {
+    const uint16_t *c = H + (y - 3) * HP + (x - 3);
+    // symmetric taps: rows k and 6 - k share a weight -> three v_dot2_u32_u16 on (row k, row 6 - k) pairs + the centre row
+    ushort2d p0, p1, p2, t0, t1, t2;
+    p0.x = c[0];
+    p0.y = c[6 * HP];
+    p1.x = c[HP];
+    p1.y = c[5 * HP];
+    p2.x = c[2 * HP];
+    p2.y = c[4 * HP];
+    t0.x = t0.y = 18;
+    t1.x = t1.y = 34;
+    t2.x = t2.y = 49;
+    uint32_t S = 55u * (uint32_t)c[3 * HP];
+    S = __builtin_amdgcn_udot2(p0, t0, S, false);
+    S = __builtin_amdgcn_udot2(p1, t1, S, false);
+    S = __builtin_amdgcn_udot2(p2, t2, S, false);
+    return blur_round((int)S);
+}
+
+__global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__restrict__ geo_p, FrameSrc src0,
+                                                                const uint8_t *__restrict__ pyr,
+                                                                const SelPoint *__restrict__ sel,
+                                                                const int *__restrict__ sel_count,
+                                                                afv_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
+                                                                int cap_per_frame, int *__restrict__ n_out,
                                                                 int *__restrict__ status, int frame_base, int per_frame, int total_blocks) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_win[KP_PER_BLOCK][WS * WP + 4];
+    // patch rows are PP = 52 bytes apart (13 dwords: odd -> rows spread over all LDS banks); 2 guard rows/dwords so that
+    // the 3-dword row reads of blur_at never leave the slice
+    __shared__ __attribute__((aligned(16))) uint8_t s_patch[KP_PER_BLOCK][(PS + 1) * PP];
+    __shared__ __attribute__((aligned(16))) uint16_t s_rows[KP_PER_BLOCK][PS * HP];  // row-filtered patch
 
     const Geo &geo = *geo_p;
-    // XCD-aware placement: all keypoints of a frame are described on one XCD (their windows share L2 lines)
+    // XCD-aware placement: all keypoints of a frame are described on one XCD (their patches share L2 lines)
     const int work = afv_xcd_remap(blockIdx.x, total_blocks);
     if (work >= total_blocks) return;
     // a frame's blocks: level after level, ceil(sel_cap / KP_PER_BLOCK) blocks each (per_frame in total)
     const int fl = work / per_frame;
-    const int blk = work - fl * per_frame;
-    int l = 0;
-#pragma unroll
-    for (int i = 1; i < AFV_MAX_LEVELS; ++i)
-        if (i < geo.nlevels && blk >= geo.lv[i].desc_blk_base) l = i;
-    const LevelGeo &L = geo.lv[l];
-    const int kblk = blk - L.desc_blk_base;
+    int kblk = work - fl * per_frame, l = 0;
+    for (; l + 1 < geo.nlevels; ++l) {
+        const int nb = (geo.lv[l].sel_cap + KP_PER_BLOCK - 1) / KP_PER_BLOCK;
+        if (kblk < nb) break;
+        kblk -= nb;
+    }
     const int f = frame_base + fl;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int idx = kblk * KP_PER_BLOCK + wv;
+    const int *sc = sel_count + f * AFV_MAX_LEVELS;
+    const LevelGeo &L = geo.lv[l];
 
-    // frame-level bookkeeping: counts of the eight levels (two scalar loads), this level's first output slot, total
-    const int4 *scp = reinterpret_cast<const int4 *>(sel_count + f * AFV_MAX_LEVELS);
-    const int4 ca_ = scp[0], cb_ = scp[1];
-    const int cnt[AFV_MAX_LEVELS] = {ca_.x, ca_.y, ca_.z, ca_.w, cb_.x, cb_.y, cb_.z, cb_.w};
-    int level_base = 0, total = 0, mine = 0;
-#pragma unroll
-    for (int i = 0; i < AFV_MAX_LEVELS; ++i) {
-        const int c = i < geo.nlevels ? cnt[i] : 0;
-        level_base += i < l ? c : 0;
-        mine = i == l ? c : mine;
+    // frame-level bookkeeping: total count, capacity status
+    int level_base = 0, total = 0;
+    for (int i = 0; i < geo.nlevels; ++i) {
+        const int c = sc[i];
+        if (i < l) level_base += c;
         total += c;
     }
-    if (blk == 0 && threadIdx.x == 0) {
+    if (kblk == 0 && l == 0 && threadIdx.x == 0) {
         n_out[f] = min(total, cap_per_frame);
         if (status && total > cap_per_frame) atomicMin(status, AFV_ECAPACITY);
     }
-    if (idx >= mine) return;  // wave-uniform
+    if (idx >= sc[l]) return;  // wave-uniform
     const int out_idx = level_base + idx;
     if (out_idx >= cap_per_frame) return;
 
     const SelPoint sp = sel[(size_t)f * geo.sel_per_frame + L.sel_base + idx];
     const int cx = sp.x, cy = sp.y;
-    const int bpitch = L.bpitch;
-    const size_t plane = L.b_off + (size_t)f * L.b_frame_stride;
-    // BRIEF centre = cvRound(pt * (1/scale)) with pt = level coordinate * scale (orb.cpp computeOrbDescriptors); equals (cx, cy) in
-    // practice, kept literal
-    const float ptx = (float)cx * L.scale, pty = (float)cy * L.scale;
-    const int bx = (int)rintf(ptx * L.inv_scale), by = (int)rintf(pty * L.inv_scale);
-    uint8_t *P = s_win[wv];
-
-    // ---- 1. loads: the blurred window (plane coordinates: + AFV_APRON) and this lane's part of the IC disc ----
-    const int wx0 = bx + AFV_APRON - WR, wy0 = by + AFV_APRON - WR;
-    const int a = wx0 & 3;  // column of window column 0 inside the LDS row
-    // rows rr, rr + 6, ..., rr + 36 of 10 dwords: lanes 60..63 shadow lane 59 and row 36 is loaded by every row slot (same value to the
-    // same LDS address): no predication anywhere
-    uint32_t wv_[7];
-    const int ln = min(lane, 59);
-    const int rr = (int)(__umul24((unsigned)ln, 6554u) >> 16), rq = ln - rr * 10;  // ln / 10, ln % 10
-    {
-        const uint8_t *gp = blur + plane + (size_t)(wy0 + rr) * bpitch + (wx0 - a) + rq * 4;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) wv_[k] = *reinterpret_cast<const uint32_t *>(gp + (size_t)(k < 6 ? k * 6 : 36 - rr) * bpitch);
+    const int lw = L.w, lh = L.h;
+    const uint8_t *img;
+    int pitch;
+    if (l == 0) {
+        img = src0.base + (size_t)f * src0.frame_stride;
+        pitch = src0.stride;
+    } else {
+        img = pyr + L.pyr_off + (size_t)f * L.pyr_frame_stride;
+        pitch = L.pitch;
     }
-    // IC disc: lane = (row v = (lane >> 1) - 15, half): half 0 covers u in [-16, -1], half 1 covers u in [0, 15]; five aligned dwords
-    const int v = (lane >> 1) - 15, half = lane & 1;
-    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0;
-    int sh = 0;
-    if (v <= 15) {
-        const int A = (cx + AFV_APRON) + (half ? 0 : -16);
-        const uint32_t *wp = reinterpret_cast<const uint32_t *>(raw + plane + (size_t)(cy + AFV_APRON + v) * bpitch + (A & ~3));
-        sh = (A & 3) * 8;
-        w0 = wp[0]; w1 = wp[1]; w2 = wp[2]; w3 = wp[3]; w4 = wp[4];
-    }
-#pragma unroll
-    for (int k = 0; k < 7; ++k) *reinterpret_cast<uint32_t *>(&P[(k < 6 ? rr + 6 * k : 36) * WP + rq * 4]) = wv_[k];
+    uint8_t *P = s_patch[wv];
+    uint16_t *H = s_rows[wv];
 
-    // ---- 2. intensity centroid over the radius-15 disc ----
-    int m10 = 0, m01 = 0;
-    if (v <= 15) {
-        const int av = v < 0 ? -v : v;
-        const int d = k_umax[av];
-        // half 0: u in [-d, -1] = bytes j = 16-d .. 15 of the 16 bytes starting at u = -16; half 1: u in [0, d] = bytes j = 0 .. d of the 16
-        // bytes starting at u = 0.  Funnel-shifted to the start byte, bytes outside the disc masked to zero, then sum(val) and
-        // sum(j * val) by v_dot4_u32_u8.
-        uint32_t b[4] = {__builtin_amdgcn_alignbit(w1, w0, sh), __builtin_amdgcn_alignbit(w2, w1, sh), __builtin_amdgcn_alignbit(w3, w2, sh),
-                         __builtin_amdgcn_alignbit(w4, w3, sh)};
-        uint32_t s1 = 0, sj = 0;
+    // ---- 1. stage the 43x43 unblurred patch; P[r][a + c] = level(cx-21+c, cy-21+r) with reflect-101 ----
+    const int px0 = cx - PR, py0 = cy - PR;
+    int a;  // column offset of patch column 0 inside the LDS row
+    const bool interior = px0 >= 0 && py0 >= 0 && px0 + 48 <= lw && py0 + PS <= lh;  // wave-uniform
+    if (interior) {
+        // interior: 12 aligned dwords per row, 5 rows per wave instruction
+        a = px0 & 3;
+        const int ax0 = px0 - a;
+        const int rr = lane / 12, rq = lane - rr * 12;
+        if (lane < 60) {
+            const uint8_t *gp = img + (size_t)(py0 + rr) * pitch + ax0 + rq * 4;
+            uint8_t *lp = &P[rr * PP + rq * 4];
+            uint32_t v[9];  // rows rr, rr + 5, ..., rr + 40 (PS = 43: the last one exists for rr < 3): loads first, then the LDS writes
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            uint32_t m;
-            if (half) {
-                const int nb = min(max(d + 1 - 4 * q, 0), 4);                  // valid leading bytes
-                m = nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
-            } else {
-                const int nz = min(max(16 - d - 4 * q, 0), 4);                 // invalid leading bytes
-                m = nz >= 4 ? 0u : (0xffffffffu << (8 * nz));
-            }
-            const uint32_t x = b[q] & m;
-            s1 = __builtin_amdgcn_udot4(x, 0x01010101u, s1, false);
-            sj = __builtin_amdgcn_udot4(x, 0x03020100u + 0x04040404u * (uint32_t)q, sj, false);
+            for (int k = 0; k < 9; ++k)
+                if (k < 8 || rr < PS - 40) v[k] = *reinterpret_cast<const uint32_t *>(gp + (size_t)k * 5 * pitch);
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                if (k < 8 || rr < PS - 40) *reinterpret_cast<uint32_t *>(lp + k * 5 * PP) = v[k];
         }
-        m10 = half ? (int)sj : (int)sj - 16 * (int)s1;
-        m01 = v * (int)s1;
+    } else {
+        // border: lane = patch column (reflected once), rows reflected per iteration (wave-uniform)
+        a = 0;
+        if (lane < PS) {
+            const int x = afv_reflect101(px0 + lane, lw);
+            for (int r = 0; r < PS; ++r) {
+                const int y = afv_reflect101(py0 + r, lh);
+                P[r * PP + lane] = img[(size_t)y * pitch + x];
+            }
+        }
+    }
+    wave_sync();  // each wave owns its LDS slice: no workgroup barrier anywhere in this kernel
+    blur_rows(P, H, lane);  // consumed after the IC stage below (wave_sync before the BRIEF tests)
+
+    // ---- 2. intensity centroid over the radius-15 disc: lane = (row, half) ----
+    const uint8_t *C = &P[PR * PP + PR + a];  // patch centre
+    int m10 = 0, m01 = 0;
+    {
+        const int v = (lane >> 1) - 15;  // -15..16
+        if (v <= 15) {
+            const int av = v < 0 ? -v : v;
+            const int d = k_umax[av];
+            // half 0: u in [-d, -1] = bytes j = 16-d .. 15 of the 16 bytes starting at u = -16; half 1: u in [0, d] = bytes
+            // j = 0 .. d of the 16 bytes starting at u = 0.  Five aligned dwords, funnel-shifted to the start byte, bytes outside
+            // the disc masked to zero, then sum(val) and sum(j * val) by v_dot4_u32_u8.
+            const int half = lane & 1;
+            const int A = (PR + v) * PP + PR + a + (half ? 0 : -16);
+            const uint32_t *wp = reinterpret_cast<const uint32_t *>(P + (A & ~3));
+            const int sh = (A & 3) * 8;
+            const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3], w4 = wp[4];
+            uint32_t b[4] = {__builtin_amdgcn_alignbit(w1, w0, sh), __builtin_amdgcn_alignbit(w2, w1, sh), __builtin_amdgcn_alignbit(w3, w2, sh),
+                             __builtin_amdgcn_alignbit(w4, w3, sh)};
+            uint32_t s1 = 0, sj = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t m;
+                if (half) {
+                    const int nb = min(max(d + 1 - 4 * q, 0), 4);                  // valid leading bytes
+                    m = nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
+                } else {
+                    const int nz = min(max(16 - d - 4 * q, 0), 4);                 // invalid leading bytes
+                    m = nz >= 4 ? 0u : (0xffffffffu << (8 * nz));
+                }
+                const uint32_t x = b[q] & m;
+                s1 = __builtin_amdgcn_udot4(x, 0x01010101u, s1, false);
+                sj = __builtin_amdgcn_udot4(x, 0x03020100u + 0x04040404u * (uint32_t)q, sj, false);
+            }
+            m10 = half ? (int)sj : (int)sj - 16 * (int)s1;
+            m01 = v * (int)s1;
+        }
     }
     m10 = wave_sum(m10);
     m01 = wave_sum(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-    // ---- 3. rotated BRIEF on the blurred window: lane handles tests lane, lane+64, lane+128, lane+192 ----
+    // ---- 3+4. rotated BRIEF on the blurred patch: lane handles tests lane, lane+64, lane+128, lane+192; the blur is
+    // evaluated only where a test samples it (512 of the 1369 patch positions) ----
     float ca, sb;
     sincos_deg(angle, ca, sb);
-    wave_sync();  // window complete (each wave owns its LDS slice: no workgroup barrier anywhere in this kernel)
-    const uint8_t *C = &P[WR * WP + WR + a];  // window centre
+    wave_sync();  // row-filtered plane complete
+    // BRIEF centre = cvRound(pt * (1/scale)) with pt = level coordinate * scale (orb.cpp computeOrbDescriptors)
+    const float ptx = (float)cx * L.scale, pty = (float)cy * L.scale;
+    const int bx = (int)rintf(ptx * L.inv_scale), by = (int)rintf(pty * L.inv_scale);
+    const int ox = bx - cx, oy = by - cy;  // 0 in practice; kept literal
     uint32_t words[8];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int t = g * 64 + lane;
-        const float4 pt = reinterpret_cast<const float4 *>(k_brief_pattern)[t];
-        const float x0 = pt.x, y0 = pt.y, x1 = pt.z, y1 = pt.w;
-        const int ix0 = (int)rintf(x0 * ca - y0 * sb), iy0 = (int)rintf(x0 * sb + y0 * ca);
-        const int ix1 = (int)rintf(x1 * ca - y1 * sb), iy1 = (int)rintf(x1 * sb + y1 * ca);
-        const int t0 = C[iy0 * WP + ix0], t1 = C[iy1 * WP + ix1];
+        const signed char *pt = &k_brief_pattern[t * 4];
+        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+        const int ix0 = (int)rintf(x0 * ca - y0 * sb) + ox, iy0 = (int)rintf(x0 * sb + y0 * ca) + oy;
+        const int ix1 = (int)rintf(x1 * ca - y1 * sb) + ox, iy1 = (int)rintf(x1 * sb + y1 * ca) + oy;
+        // inside the ROI -> blurred, outside -> unblurred apron (a patch that lies inside the level has no outside samples)
+        int t0, t1;
+        if (interior) {
+            t0 = blur_at(H, PR + a + ix0, PR + iy0);
+            t1 = blur_at(H, PR + a + ix1, PR + iy1);
+        } else {
+            const int gx0 = cx + ix0, gy0 = cy + iy0, gx1 = cx + ix1, gy1 = cy + iy1;
+            t0 = (gx0 >= 0 && gx0 < lw && gy0 >= 0 && gy0 < lh) ? blur_at(H, PR + a + ix0, PR + iy0) : C[iy0 * PP + ix0];
+            t1 = (gx1 >= 0 && gx1 < lw && gy1 >= 0 && gy1 < lh) ? blur_at(H, PR + a + ix1, PR + iy1) : C[iy1 * PP + ix1];
+        }
         const unsigned long long m = __ballot(t0 < t1);
         words[2 * g] = (uint32_t)m;
         words[2 * g + 1] = (uint32_t)(m >> 32);
     }
-    // ---- 4. outputs (E11 merge: ascending level, list order inside a level) ----
+    // ---- 5. outputs (E11 merge: ascending level, list order inside a level) ----
     const size_t o = (size_t)f * cap_per_frame + out_idx;
     if (lane < 8) {
         uint32_t w = words[0];
@@ -250,11 +341,42 @@ extern "C" int afv_describe_blocks_per_frame(const Geo *g) {
     return n;
 }
 
-extern "C" void afv_launch_describe(const Geo *geo_dev, int blocks_per_frame, const uint8_t *blur, const uint8_t *raw, const SelPoint *sel,
-                                    const int *sel_count, afv_keypoint *kps, uint8_t *desc, int cap_per_frame, int *n_out, int *status,
-                                    int frame_base, int nframes, hipStream_t stream) {
+extern "C" void afv_launch_describe(const Geo *geo_dev, int blocks_per_frame, const FrameSrc *src0, const uint8_t *pyr,
+                                    const SelPoint *sel, const int *sel_count, afv_keypoint *kps, uint8_t *desc,
+                                    int cap_per_frame, int *n_out, int *status, int frame_base, int nframes, hipStream_t stream) {
     const int total = blocks_per_frame * nframes;
     dim3 grid((total + 7) / 8 * 8);
-    hipLaunchKernelGGL(k_describe, grid, dim3(64 * KP_PER_BLOCK), 0, stream, geo_dev, blur, raw, sel, sel_count, kps, desc, cap_per_frame,
-                       n_out, status, frame_base, blocks_per_frame, total);
+    hipLaunchKernelGGL(k_describe, grid, dim3(64 * KP_PER_BLOCK), 0, stream, geo_dev, *src0, pyr, sel, sel_count, kps, desc,
+                       cap_per_frame, n_out, status, frame_base, blocks_per_frame, total);
+}
+
+// ---------------- standalone E9: blur one level of one frame (debug / parity of the blur arithmetic) ----------------
+__global__ __launch_bounds__(256) void k_blur_level(const uint8_t *__restrict__ img, int w, int h, int pitch,
+                                                    uint8_t *__restrict__ out) {
+    __shared__ uint8_t t[(16 + 6) * 72];
+    __shared__ uint16_t hh[(16 + 6) * 64];
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 16;
+    for (int i = threadIdx.x; i < 22 * 70; i += 256) {
+        const int r = i / 70, c = i - r * 70;
+        const int y = min(max(afv_reflect101(y0 + r - 3, h), 0), h - 1), x = min(max(afv_reflect101(x0 + c - 3, w), 0), w - 1);
+        t[r * 72 + c] = img[(size_t)y * pitch + x];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 22 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        const uint8_t *p = &t[r * 72 + c];
+        hh[r * 64 + c] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 16 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        const uint16_t *q = &hh[r * 64 + c];
+        const int S = 18 * ((int)q[0] + q[6 * 64]) + 34 * ((int)q[64] + q[5 * 64]) + 49 * ((int)q[2 * 64] + q[4 * 64]) + 55 * (int)q[3 * 64];
+        if (x0 + c < w && y0 + r < h) out[(size_t)(y0 + r) * w + x0 + c] = blur_round(S);
+    }
+}
+
+extern "C" void afv_launch_blur_level(const uint8_t *img, int w, int h, int pitch, uint8_t *out, hipStream_t stream) {
+    dim3 grid((w + 63) / 64, (h + 15) / 16);
+    hipLaunchKernelGGL(k_blur_level, grid, dim3(256), 0, stream, img, w, h, pitch, out);
 }

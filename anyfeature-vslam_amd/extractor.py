@@ -214,13 +214,6 @@ class Context:
         self.check(self.lib.afv_debug_blur_level(self.handle, frame, level, ptr(out)))
         return out
 
-    def debug_plane(self, frame, level, which):
-        """apron plane of (frame, level): which = 0 blur plane (ROI blurred, apron unblurred reflect-101), 1 raw plane"""
-        g = self.geometry()
-        out = np.zeros((g["lh"][level] + 40, g["lw"][level] + 40), np.uint8)
-        self.check(self.lib.afv_debug_get_plane(self.handle, frame, level, int(which), ptr(out)))
-        return out
-
     def debug_candidates(self, frame, level):
         g = self.geometry()
         cap = g["cand_cap"][level]

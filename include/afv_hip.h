@@ -306,16 +306,12 @@ int afv_hamming256(const uint8_t *a, const uint8_t *b);
 enum { AFV_STAGE_PYRAMID = 0, AFV_STAGE_FAST_NMS = 1 /* k_fast_nms */, AFV_STAGE_SELECT = 2, AFV_STAGE_DESCRIBE = 3,
        AFV_STAGE_MATCH = 4 /* k_match_topk: the xor + popcount phase */, AFV_STAGE_MATCH_RESOLVE = 5 /* ordered greedy resolve */,
        AFV_STAGE_HARRIS = 6 /* k_retain_score + k_harris: retainBest on the score, Harris response of the survivors */,
-       AFV_STAGE_BLUR = 7 /* k_blur_apron: dense 7x7 blur of every level + apron planes */,
-       AFV_NUM_STAGES = 8 };
-/* The stage list grows between releases: size the arrays passed to afv_profile_read with afv_num_stages() (or AFV_NUM_STAGES of
- * the header the caller was compiled against, after checking that afv_num_stages() is not larger). */
-int afv_num_stages(void);
+       AFV_NUM_STAGES = 7 };
 int afv_profile_enable(afv_ctx *ctx, int enable); /* 0 = off; n >= 1 = time the stages of every n-th extraction / pair-match call
                                                      * (1 = every call; the event pairs cost ~3 % of a batch step, sampling keeps that
                                                      * out of a timed run); resets the accumulated figures */
-int afv_profile_read(afv_ctx *ctx, int32_t *launches /*[afv_num_stages()]*/, float *total_ms /*[afv_num_stages()]*/,
-                     int64_t *units /*[afv_num_stages()], frames (pairs for MATCH) covered by those launches; may be NULL*/);
+int afv_profile_read(afv_ctx *ctx, int32_t *launches /*[AFV_NUM_STAGES]*/, float *total_ms /*[AFV_NUM_STAGES]*/,
+                     int64_t *units /*[AFV_NUM_STAGES], frames (pairs for MATCH) covered by those launches; may be NULL*/);
 /* batches of at least `min_frames` frames (pairs) are split over the context's two streams so that latency-bound kernels of
  * one half overlap the VALU-bound ones of the other (default 64; 0x7fffffff disables the split) */
 int afv_set_split_threshold(afv_ctx *ctx, int min_frames);
@@ -347,11 +343,8 @@ int afv_debug_get_level(afv_ctx *ctx, int frame, int level, uint8_t *out);
 int afv_debug_get_candidates(afv_ctx *ctx, int frame, int level, uint32_t *packed, float *response, int cap, int *n_out);
 /* keypoints chosen by the quadtree for (frame, level) in list order: x,y level coordinates */
 int afv_debug_get_selected(afv_ctx *ctx, int frame, int level, int32_t *x, int32_t *y, float *response, int cap, int *n_out);
-/* the 7x7 Gaussian blur of a level (E9) as the last extraction wrote it: the ROI of the blur plane k_describe sampled (lw x lh) */
+/* standalone 7x7 Gaussian blur of a level (E9) — same arithmetic as the fused describe kernel */
 int afv_debug_blur_level(afv_ctx *ctx, int frame, int level, uint8_t *out);
-/* a whole apron plane of (frame, level), (lw + 40) x (lh + 40) tightly packed: which = 0 the blur plane (ROI blurred, apron = the
- * unblurred level reflected), which = 1 the raw plane (unblurred level + the same apron) */
-int afv_debug_get_plane(afv_ctx *ctx, int frame, int level, int which, uint8_t *out);
 
 #ifdef __cplusplus
 }

@@ -133,23 +133,6 @@ def test_blur_bit_exact(gpu_ctx, oracle, frames, name):
         assert np.array_equal(gpu_ctx.debug_blur_level(0, l), tr["blurred"][l]), l
 
 
-@pytest.mark.parametrize("name", ["corners1", "noise"])
-def test_apron_planes(gpu_ctx, oracle, frames, name):
-    """k_blur_apron writes what cv::ORB's pyramid buffer holds around every level: the raw plane is the level with a 20 px
-    BORDER_REFLECT_101 apron, the blur plane is the same memory with the ROI blurred in place (a rotated BRIEF test
-    that leaves the level samples the UNBLURRED apron)"""
-    img = frames[name]
-    gpu_ctx.extract(img)
-    _, _, tr = oracle.orb_extract_trace(img)
-    for l in range(8):
-        lvl = gpu_ctx.debug_level(0, l)
-        want_raw = np.pad(lvl, 20, mode="reflect")
-        assert np.array_equal(gpu_ctx.debug_plane(0, l, 1), want_raw), l
-        want_blur = want_raw.copy()
-        want_blur[20:-20, 20:-20] = tr["blurred"][l]
-        assert np.array_equal(gpu_ctx.debug_plane(0, l, 0), want_blur), l
-
-
 @pytest.mark.parametrize("name", ["corners1", "corners7", "noise", "ramp", "constant"])
 def test_extract_end_to_end_bit_exact(gpu_ctx, oracle, frames, name):
     img = frames[name]
