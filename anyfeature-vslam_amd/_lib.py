@@ -146,6 +146,7 @@ SYMBOLS = {
     "afv_debug_get_candidates": (_i, [_vp, _i, _i, _vp, _vp, _i, C.POINTER(_i)]),
     "afv_debug_get_selected": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, C.POINTER(_i)]),
     "afv_debug_blur_level": (_i, [_vp, _i, _i, _vp]),
+    "afv_num_stages": (_i, []),
 }
 
 _lib = None

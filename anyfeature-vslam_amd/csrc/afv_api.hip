@@ -69,7 +69,7 @@ static int build_geometry(const afv_orb_params &p, int w, int h, int max_batch, 
         cvq[p.nlevels - 1] = std::max(nf - sum, 0);
     }
     size_t pyr_off = 0, cand_off = 0;
-    int tile_base = 0, sel_base = 0;
+    int tile_base = 0, sel_base = 0, desc_blk_base = 0;
     for (int l = 0; l < p.nlevels; ++l) {
         LevelGeo &L = g.lv[l];
         L.scale = (float)std::pow((double)p.scale_factor, (double)l);
@@ -81,6 +81,7 @@ static int build_geometry(const afv_orb_params &p, int w, int h, int max_batch, 
         L.pitch = (int)align_up((size_t)L.w, 64);
         L.tiles_x = (L.w + FT_W - 1) / FT_W;
         L.tiles_y = (L.h + FT_H - 1) / FT_H;
+        L.dv_tiles_x = afv_div_magic((uint32_t)L.tiles_x);
         L.tile_base = tile_base;
         tile_base += L.tiles_x * L.tiles_y;
         L.quota = quota[l];
@@ -91,6 +92,8 @@ static int build_geometry(const afv_orb_params &p, int w, int h, int max_batch, 
         L.sel_cap = std::max(L.quota + 3, 4 * g.n_ini);
         L.sel_base = sel_base;
         sel_base += L.sel_cap;
+        L.desc_blk_base = desc_blk_base;
+        desc_blk_base += (L.sel_cap + 3) / 4;  // KP_PER_BLOCK keypoints per k_describe block
         L.pyr_frame_stride = align_up((size_t)L.h * L.pitch + 64, 256);
         L.pyr_off = pyr_off;
         if (l > 0) pyr_off += L.pyr_frame_stride * (size_t)max_batch;
@@ -99,7 +102,9 @@ static int build_geometry(const afv_orb_params &p, int w, int h, int max_batch, 
         cand_off += L.cand_frame_stride * (size_t)max_batch;
     }
     g.total_tiles = tile_base;
+    g.dv_total_tiles = afv_div_magic((uint32_t)tile_base);
     g.sel_per_frame = sel_base;
+    g.dv_desc_per_frame = afv_div_magic((uint32_t)afv_describe_blocks_per_frame(&g));
     return AFV_OK;
 }
 
@@ -334,6 +339,8 @@ extern "C" int afv_profile_enable(afv_ctx *c, int enable) {
     return AFV_OK;
 }
 
+extern "C" int afv_num_stages(void) { return AFV_NUM_STAGES; }
+
 extern "C" int afv_profile_read(afv_ctx *c, int32_t *launches, float *total_ms, int64_t *units) {
     if (!c || !launches || !total_ms) return AFV_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
@@ -369,6 +376,14 @@ extern "C" int afv_get_geometry(const afv_ctx *c, afv_geometry *g) {
 static void enqueue_range(afv_ctx *c, const FrameSrc &src, int f0, int nf, afv_keypoint *d_kps, uint8_t *d_desc, int cap, int *d_n,
                           int *d_status, hipStream_t s) {
     const Geo &g = c->geo;
+    {   // work lists are indexed with afv_udiv (exact below AFV_MAX_WORK items): longer ranges go out in pieces
+        const int per = std::max(std::max(g.total_tiles, afv_describe_blocks_per_frame(&g)), 1);
+        const int max_nf = std::max(1, (AFV_MAX_WORK - 8) / per);
+        if (nf > max_nf) {
+            for (int b = 0; b < nf; b += max_nf) enqueue_range(c, src, f0 + b, std::min(max_nf, nf - b), d_kps, d_desc, cap, d_n, d_status, s);
+            return;
+        }
+    }
     int *cnt0 = c->d_cand_count + (size_t)f0 * AFV_MAX_LEVELS;
     if (g.nlevels < 2) {  // no pyramid launch to carry the clears
         (void)hipMemsetAsync(cnt0, 0, (size_t)nf * AFV_MAX_LEVELS * sizeof(int), s);

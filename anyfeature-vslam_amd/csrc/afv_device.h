@@ -17,8 +17,26 @@
 // quadtree limits
 #define QT_MAX_NODES 1536  // alive nodes <= N+3 ; supports per-level quotas up to ~1500 (nfeatures <= ~6900)
 
+// Division of a work index by a launch-invariant divisor without the float-reciprocal sequence the compiler emits (about 20 vector
+// instructions per wavefront and division; on block-uniform values this form stays on the scalar unit): q = (n * m) >> k with
+// k = 26 + ceil(log2 d), m = ceil(2^k / d) < 2^27 — exact for n < 2^26 (launchers keep their work lists below that).
+struct DivMagic {
+    uint32_t m, k;
+};
+static inline DivMagic afv_div_magic(uint32_t d) {
+    uint32_t lg = 0;
+    while ((1u << lg) < d) ++lg;
+    DivMagic r;
+    r.k = 26 + lg;
+    r.m = (uint32_t)((((uint64_t)1 << r.k) + d - 1) / d);
+    return r;
+}
+static inline __host__ __device__ uint32_t afv_udiv(uint32_t n, DivMagic dm) { return (uint32_t)(((uint64_t)n * dm.m) >> dm.k); }
+#define AFV_MAX_WORK (1 << 26)
+
 struct LevelGeo {
     int w, h, pitch;        // level size, row pitch in bytes
+    DivMagic dv_tiles_x;    // / tiles_x
     int tiles_x, tiles_y;   // FAST tiling
     int tile_base;          // first flat tile index of this level
     int quota;              // mnFeaturesPerLevel (FeatureExtractor.cpp:97-108)
@@ -26,6 +44,7 @@ struct LevelGeo {
     int cand_cap;           // candidate slots per frame at this level
     int sel_cap;            // quota + 3
     int sel_base;           // first selected slot of this level inside a frame's `sel` row
+    int desc_blk_base;      // first k_describe block of this level in a frame's block list
     float scale;            // (float)pow(1.2f, l)
     float inv_scale;        // 1.f / scale
     size_t pyr_off;         // byte offset of frame 0 of this level in the pyramid buffer (level 0: unused)
@@ -37,6 +56,8 @@ struct LevelGeo {
 struct Geo {
     int nlevels, width, height;
     int total_tiles;
+    DivMagic dv_total_tiles;     // / total_tiles
+    DivMagic dv_desc_per_frame;  // / k_describe blocks per frame
     int sel_per_frame;      // sum of sel_cap
     int n_ini;              // DistributeOctTree: round(w/h)
     float h_x;              // (float)w / n_ini

@@ -15,7 +15,8 @@
 // where only the ROI is blurred in place.  No blurred image ever touches HBM.
 #include "afv_device.h"
 
-__device__ __constant__ const signed char k_brief_pattern[1024] = {
+// the 256 test pairs (x0, y0, x1, y1) as floats (FeatureExtractor.h:219-477): one 16-byte load per test, no conversions
+__device__ __constant__ __attribute__((aligned(16))) const float k_brief_pattern[1024] = {
 #include "brief_pattern.inc"
 };
 // umax[v], v = 0..15: last column of row v of the radius-15 disc (orb.cpp / ORBextractor.cc:124-139)
@@ -93,12 +94,10 @@ __device__ __forceinline__ int wave_sum(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
-__device__ __forceinline__ uint8_t blur_round(int S) {
-    int q = S >> 16;
-    const int r = S & 0xffff;
-    q += (r > 32768) || (r == 32768 && (q & 1));
-    return (uint8_t)min(q, 255);
-}
+// round-half-even(S / 65536) saturated to 255.  S < 2^24 whenever the result is not saturated, so u32 -> f32 is exact, the scaling by
+// 2^-16 is exact, and v_cvt_pk_u8_f32 rounds to nearest even and clamps: identical to the integer rule for every S the filter can
+// produce (all 16 842 496 values checked on the device: tools/probes/probe_cvt_pk_u8.hip)
+__device__ __forceinline__ uint32_t blur_round(uint32_t S) { return __builtin_amdgcn_cvt_pk_u8_f32((float)S * (1.0f / 65536.0f), 0, 0u); }
 
 // Row pass of the separable 8U filter over the whole staged patch, once per keypoint: H[r][xh] = sum_k taps[k] * P[r][xh + k]
 // for xh = 0..39 (<= 257 * 255 = 65535: exact in 16 bits).  One lane per group of 4 adjacent outputs: 3 aligned dwords in, two
@@ -144,7 +143,7 @@ __device__ __forceinline__ int blur_at(const uint16_t *H, int x, int y) {
     S = __builtin_amdgcn_udot2(p0, t0, S, false);
     S = __builtin_amdgcn_udot2(p1, t1, S, false);
     S = __builtin_amdgcn_udot2(p2, t2, S, false);
-    return blur_round((int)S);
+    return (int)blur_round(S);
 }
 
 __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__restrict__ geo_p, FrameSrc src0,
@@ -164,31 +163,35 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
     const int work = afv_xcd_remap(blockIdx.x, total_blocks);
     if (work >= total_blocks) return;
     // a frame's blocks: level after level, ceil(sel_cap / KP_PER_BLOCK) blocks each (per_frame in total)
-    const int fl = work / per_frame;
-    int kblk = work - fl * per_frame, l = 0;
-    for (; l + 1 < geo.nlevels; ++l) {
-        const int nb = (geo.lv[l].sel_cap + KP_PER_BLOCK - 1) / KP_PER_BLOCK;
-        if (kblk < nb) break;
-        kblk -= nb;
-    }
+    const int fl = (int)afv_udiv((uint32_t)work, geo.dv_desc_per_frame);
+    const int blk = work - fl * per_frame;
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < AFV_MAX_LEVELS; ++i)
+        if (i < geo.nlevels && blk >= geo.lv[i].desc_blk_base) l = i;
+    const LevelGeo &L = geo.lv[l];
+    const int kblk = blk - L.desc_blk_base;
     const int f = frame_base + fl;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int idx = kblk * KP_PER_BLOCK + wv;
-    const int *sc = sel_count + f * AFV_MAX_LEVELS;
-    const LevelGeo &L = geo.lv[l];
 
-    // frame-level bookkeeping: total count, capacity status
-    int level_base = 0, total = 0;
-    for (int i = 0; i < geo.nlevels; ++i) {
-        const int c = sc[i];
-        if (i < l) level_base += c;
+    // frame-level bookkeeping: counts of the eight levels (scalar loads), this level's first output slot, total
+    const int4 *scp = reinterpret_cast<const int4 *>(sel_count + f * AFV_MAX_LEVELS);
+    const int4 ca_ = scp[0], cb_ = scp[1];
+    const int cnt[AFV_MAX_LEVELS] = {ca_.x, ca_.y, ca_.z, ca_.w, cb_.x, cb_.y, cb_.z, cb_.w};
+    int level_base = 0, total = 0, mine = 0;
+#pragma unroll
+    for (int i = 0; i < AFV_MAX_LEVELS; ++i) {
+        const int c = i < geo.nlevels ? cnt[i] : 0;
+        level_base += i < l ? c : 0;
+        mine = i == l ? c : mine;
         total += c;
     }
-    if (kblk == 0 && l == 0 && threadIdx.x == 0) {
+    if (blk == 0 && threadIdx.x == 0) {
         n_out[f] = min(total, cap_per_frame);
         if (status && total > cap_per_frame) atomicMin(status, AFV_ECAPACITY);
     }
-    if (idx >= sc[l]) return;  // wave-uniform
+    if (idx >= mine) return;  // wave-uniform
     const int out_idx = level_base + idx;
     if (out_idx >= cap_per_frame) return;
 
@@ -295,8 +298,8 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int t = g * 64 + lane;
-        const signed char *pt = &k_brief_pattern[t * 4];
-        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+        const float4 pt = reinterpret_cast<const float4 *>(k_brief_pattern)[t];
+        const float x0 = pt.x, y0 = pt.y, x1 = pt.z, y1 = pt.w;
         const int ix0 = (int)rintf(x0 * ca - y0 * sb) + ox, iy0 = (int)rintf(x0 * sb + y0 * ca) + oy;
         const int ix1 = (int)rintf(x1 * ca - y1 * sb) + ox, iy1 = (int)rintf(x1 * sb + y1 * ca) + oy;
         // inside the ROI -> blurred, outside -> unblurred apron (a patch that lies inside the level has no outside samples)
@@ -372,7 +375,7 @@ __global__ __launch_bounds__(256) void k_blur_level(const uint8_t *__restrict__ 
         const int r = i >> 6, c = i & 63;
         const uint16_t *q = &hh[r * 64 + c];
         const int S = 18 * ((int)q[0] + q[6 * 64]) + 34 * ((int)q[64] + q[5 * 64]) + 49 * ((int)q[2 * 64] + q[4 * 64]) + 55 * (int)q[3 * 64];
-        if (x0 + c < w && y0 + r < h) out[(size_t)(y0 + r) * w + x0 + c] = blur_round(S);
+        if (x0 + c < w && y0 + r < h) out[(size_t)(y0 + r) * w + x0 + c] = (uint8_t)blur_round((uint32_t)S);
     }
 }
 

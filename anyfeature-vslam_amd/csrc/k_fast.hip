@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Geo *__restrict__ geo_p,
     // tiles stays inside one L2
     const int work = afv_xcd_remap(blockIdx.x, total_blocks);
     if (work >= total_blocks) return;
-    const int f0 = work / geo.total_tiles, tile_id = work - f0 * geo.total_tiles;
+    const int f0 = (int)afv_udiv((uint32_t)work, geo.dv_total_tiles), tile_id = work - f0 * geo.total_tiles;
     const int f = frame_base + f0;
     int l = 0;
 #pragma unroll
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Geo *__restrict__ geo_p,
         if (i < geo.nlevels && tile_id >= geo.lv[i].tile_base) l = i;
     const LevelGeo &L = geo.lv[l];
     const int t = tile_id - L.tile_base;
-    const int tyi = t / L.tiles_x, txi = t - tyi * L.tiles_x;
+    const int tyi = (int)afv_udiv((uint32_t)t, L.dv_tiles_x), txi = t - tyi * L.tiles_x;
     const int gx0 = txi * FT_W - FT_HALO, gy0 = tyi * FT_H - FT_HALO;
     const int lw = L.w, lh = L.h;
     const int tid = threadIdx.x, lane = tid & 63;

@@ -7,22 +7,23 @@
 // popcount(a ^ b) over 256 bits is a dot product in disguise: with the bits of the train descriptor as +-64 and the bits of the query
 // as -+64 (opposite signs), sum_k A_k B_k = 4096 * (#differing - #equal) = 8192 * d - 2^20.  i8 x i8 -> i32 is exact, so
 // v_mfma_i32_32x32x32_i8 (8 instructions cover the 256 bits of 32 train x 32 query descriptors) delivers 1024 distances per 8
-// instructions, and — because the accumulator is preloaded with the train descriptor's index m — directly the ORDERING KEY
-// 8192 * d - 2^20 + m  (m < 8192: distance first, then position, exactly the order of  d << 16 | m).  In the C/D register layout of
+// instructions, and — because a ninth instruction contracts two more k-slots, (m & 63, m >> 6) of the train row against (1, 64) —
+// directly the ORDERING KEY  8192 * d - 2^20 + m  (m < 8192 = the train descriptor's index: distance first, then position, exactly
+// the order of  d << 16 | m).  The accumulator chain starts from the inline constant 0: no vector instruction prepares it.  In the C/D register layout of
 // the 32x32 forms a lane owns ONE column (= one query) and 16 rows (= 16 train descriptors), so the top-4 insertion is the same
 // lane-private  v_min + 3 v_med3  per value as in k_match_topk, with no cross-lane traffic; the VALU work per descriptor pair drops
-// from 8 xor + 8 v_bcnt + 5 to 1 + 4 and runs beside the MFMA pipe.
+// from 8 xor + 8 v_bcnt + 5 to 4 and runs beside the MFMA pipe.
 //
 // Workgroup = 4 wavefronts = 256 queries (64 per wavefront: two 32-column blocks, their B fragments live in registers for the whole
 // kernel).  Train descriptors are expanded 64 at a time into LDS (bit -> +-64 byte through a 256-entry byte -> 8-byte table that also
-// lives in LDS), double-buffered, one barrier per tile; every wavefront reads its A fragments with ds_read_b128 (row pitch 272 B:
-// 16 consecutive rows cover all 64 banks).
+// lives in LDS), double-buffered, one barrier per tile; every wavefront reads its A fragments with ds_read_b128 (row pitch 304 B =
+// 256 expanded bytes + the 32 index slots + 16: 16 consecutive rows start in 16 different bank quads).
 #include "afv_device.h"
 
 #define MQ_T 256
 #define NO_KEY 0x7fffffff
 #define T_TILE 64
-#define A_PITCH 272
+#define A_PITCH 304
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -55,30 +56,36 @@ __device__ __forceinline__ void mq_stage(const uint32_t *__restrict__ train, int
         uint4 *dst = reinterpret_cast<uint4 *>(buf + row * A_PITCH + wd * 32);
         dst[0] = make_uint4(e0.x, e0.y, e1.x, e1.y);
         dst[1] = make_uint4(e2.x, e2.y, e3.x, e3.y);
+        if (wd == 0) {  // the index slots: k-slots 256, 257 = (m & 63, m >> 6), the other 30 zero
+            const uint32_t mi = (uint32_t)(tile_row0 + row);
+            uint4 *ix = reinterpret_cast<uint4 *>(buf + row * A_PITCH + 256);
+            ix[0] = make_uint4((mi & 63u) | ((mi >> 6) << 8), 0u, 0u, 0u);
+            ix[1] = make_uint4(0u, 0u, 0u, 0u);
+        }
     }
 }
 
 template <bool PARTIAL>
-__device__ __forceinline__ void mq_compute(const uint8_t *buf, const v4i (&bq)[2][8], int (&kk)[2][4], const int (&idx)[16], int tile_row0, int n2,
+__device__ __forceinline__ void mq_compute(const uint8_t *buf, const v4i (&bq)[2][8], const v4i &bidx, int (&kk)[2][4], int tile_row0, int n2,
                                            int lane) {
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
-        v4i a[8];
+        v4i a[9];
         const uint8_t *ap = buf + (sub * 32 + (lane & 31)) * A_PITCH + (lane >> 5) * 16;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) a[t] = *reinterpret_cast<const v4i *>(ap + t * 32);
-        const int off = tile_row0 + sub * 32;
+        for (int t = 0; t < 9; ++t) a[t] = *reinterpret_cast<const v4i *>(ap + t * 32);
+        const int off = tile_row0 + sub * 32 + 4 * (lane >> 5);
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-            v16i acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = idx[r] + off;
+            v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[8], bidx, acc, 0, 0, 0);  // + m
 #pragma unroll
             for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[t], bq[qb][t], acc, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int key = acc[r];
-                if (PARTIAL) key = (idx[r] + off < n2) ? key : NO_KEY;
+                // C/D register r holds train row (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the 32-row block
+                if (PARTIAL) key = ((r & 3) + 8 * (r >> 2) + off < n2) ? key : NO_KEY;
                 mq_insert(kk[qb], key);
             }
         }
@@ -128,10 +135,9 @@ __global__ __launch_bounds__(MQ_T, 2) void k_match_topk_mfma(const uint8_t *__re
                 bq[qb][t] = v;
             }
         }
-        // accumulator preload: train index of C/D register r inside a 32-row block (row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
-        int idx[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) idx[r] = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        // B fragment of the index instruction: k-slots 256, 257 (lanes 0..31 hold them) carry the weights (1, 64)
+        v4i bidx = {0, 0, 0, 0};
+        if (lane < 32) bidx[0] = 1 | (64 << 8);
         const uint32_t *train = reinterpret_cast<const uint32_t *>(desc + (size_t)sb * cap * 32);
         const int ntiles = (n2 + T_TILE - 1) / T_TILE;
         const bool wave_has_rows = row0 < n1;
@@ -140,8 +146,8 @@ __global__ __launch_bounds__(MQ_T, 2) void k_match_topk_mfma(const uint8_t *__re
         for (int tile = 0; tile < ntiles; ++tile) {
             if (tile + 1 < ntiles) mq_stage(train, n2, (tile + 1) * T_TILE, s_lut, s_a[(tile + 1) & 1], tid);
             if (wave_has_rows) {
-                if ((tile + 1) * T_TILE <= n2) mq_compute<false>(s_a[tile & 1], bq, kk, idx, tile * T_TILE, n2, lane);
-                else mq_compute<true>(s_a[tile & 1], bq, kk, idx, tile * T_TILE, n2, lane);
+                if ((tile + 1) * T_TILE <= n2) mq_compute<false>(s_a[tile & 1], bq, bidx, kk, tile * T_TILE, n2, lane);
+                else mq_compute<true>(s_a[tile & 1], bq, bidx, kk, tile * T_TILE, n2, lane);
             }
             __syncthreads();
         }

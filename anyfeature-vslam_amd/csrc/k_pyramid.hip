@@ -32,6 +32,7 @@ struct ResizeTab {
     int *zero_counts;
     int n_zero;
     int *zero_one;
+    DivMagic dv_tiles, dv_tiles_x;  // / (tiles per frame), / tiles_x
 };
 
 __global__ __launch_bounds__(RT_T) void k_resize_level(const uint8_t *__restrict__ src, int sw, int sh, int spitch,
@@ -49,9 +50,10 @@ __global__ __launch_bounds__(RT_T) void k_resize_level(const uint8_t *__restrict
     }
     const int work = afv_xcd_remap(blockIdx.x, total_blocks);
     if (work >= total_blocks) return;
-    const int fl = work / (tiles_x * tiles_y), tt = work - fl * (tiles_x * tiles_y);
+    const int fl = (int)afv_udiv((uint32_t)work, tab.dv_tiles), tt = work - fl * (tiles_x * tiles_y);
     const int f = frame_base + fl;
-    const int x0 = (tt % tiles_x) * RT_W, y0 = (tt / tiles_x) * RT_H;
+    const int tty = (int)afv_udiv((uint32_t)tt, tab.dv_tiles_x);
+    const int x0 = (tt - tty * tiles_x) * RT_W, y0 = tty * RT_H;
     const int nx = min(RT_W, dw - x0), ny = min(RT_H, dh - y0);
     const uint8_t *s = src + (size_t)f * sframe;
     // source window: rows [sy0, sy1], dword-aligned columns [sx0, ...).  Offsets are monotone in the tables.
@@ -161,9 +163,10 @@ extern "C" int afv_resize_window_ok(int sw, int sh, int dw, int dh) {
 extern "C" void afv_launch_resize(const uint8_t *src, int sw, int sh, int spitch, size_t sframe, uint8_t *dst, int dw,
                                   int dh, int dpitch, size_t dframe, const short2 *xt, const short2 *yt, int frame_base,
                                   int nframes, int *zero_counts, int n_zero, int *zero_one, hipStream_t stream) {
-    const int total = ((dw + RT_W - 1) / RT_W) * ((dh + RT_H - 1) / RT_H) * nframes;
+    const int tx = (dw + RT_W - 1) / RT_W, per_frame = tx * ((dh + RT_H - 1) / RT_H);
+    const int total = per_frame * nframes;
     dim3 grid((total + 7) / 8 * 8);
-    ResizeTab tab{xt, yt, zero_counts, n_zero, zero_one};
+    ResizeTab tab{xt, yt, zero_counts, n_zero, zero_one, afv_div_magic((uint32_t)per_frame), afv_div_magic((uint32_t)tx)};
     hipLaunchKernelGGL(k_resize_level, grid, dim3(RT_T), 0, stream, src, sw, sh, spitch, sframe, dst, dw, dh, dpitch,
                        dframe, tab, total, frame_base);
 }

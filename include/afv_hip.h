@@ -307,11 +307,14 @@ enum { AFV_STAGE_PYRAMID = 0, AFV_STAGE_FAST_NMS = 1 /* k_fast_nms */, AFV_STAGE
        AFV_STAGE_MATCH = 4 /* k_match_topk: the xor + popcount phase */, AFV_STAGE_MATCH_RESOLVE = 5 /* ordered greedy resolve */,
        AFV_STAGE_HARRIS = 6 /* k_retain_score + k_harris: retainBest on the score, Harris response of the survivors */,
        AFV_NUM_STAGES = 7 };
+/* The stage list grows between releases: size the arrays passed to afv_profile_read with afv_num_stages() (or with the AFV_NUM_STAGES
+ * of the header the caller was compiled against, after checking that afv_num_stages() is not larger). */
+int afv_num_stages(void);
 int afv_profile_enable(afv_ctx *ctx, int enable); /* 0 = off; n >= 1 = time the stages of every n-th extraction / pair-match call
                                                      * (1 = every call; the event pairs cost ~3 % of a batch step, sampling keeps that
                                                      * out of a timed run); resets the accumulated figures */
-int afv_profile_read(afv_ctx *ctx, int32_t *launches /*[AFV_NUM_STAGES]*/, float *total_ms /*[AFV_NUM_STAGES]*/,
-                     int64_t *units /*[AFV_NUM_STAGES], frames (pairs for MATCH) covered by those launches; may be NULL*/);
+int afv_profile_read(afv_ctx *ctx, int32_t *launches /*[afv_num_stages()]*/, float *total_ms /*[afv_num_stages()]*/,
+                     int64_t *units /*[afv_num_stages()], frames (pairs for MATCH) covered by those launches; may be NULL*/);
 /* batches of at least `min_frames` frames (pairs) are split over the context's two streams so that latency-bound kernels of
  * one half overlap the VALU-bound ones of the other (default 64; 0x7fffffff disables the split) */
 int afv_set_split_threshold(afv_ctx *ctx, int min_frames);
