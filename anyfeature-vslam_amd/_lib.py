@@ -9,7 +9,17 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("AFV_LIB_PATH") or os.path.join(_HERE, "libafv_hip.so")  # override: kernel experiments only
+LIB_PATH = os.path.join(_HERE, "libafv_hip.so")
+
+
+def use_library(path):
+    """measurement tooling only (bench.py --lib, tools/experiments.py): bind a variant build of the library instead of the in-tree
+    one.  Must be called before the first load(); nothing in the environment can redirect the loader."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("the library is already loaded")
+    LIB_PATH = os.path.abspath(path)
+
 
 MAX_LEVELS = 8
 DESC_BYTES = 32
@@ -96,6 +106,7 @@ SYMBOLS = {
     "afv_table_match_bow": (_i, [_vp, _vp, _vp, _i, _f, _f, _i, _vp, _vp]),
     "afv_table_match_triangulation": (_i, [_vp, _vp, _vp, C.POINTER(TableTriJob), _i, _vp, _vp]),
     "afv_table_broadcast": (_i, [_vp, _vp, _i, C.POINTER(_f)]),
+    "afv_table_clone": (_i, [_vp, _vp]),
     "afv_comm_unique_id": (_i, [_vp]),
     "afv_comm_create": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
     "afv_comm_destroy": (None, [_vp]),

@@ -499,6 +499,15 @@ extern "C" int afv_orb_extract_batch(afv_ctx *c, const uint8_t *const *frames, i
     if (rc) return rc;
     c->prof = c->prof_every && (c->prof_tick_extract++ % (unsigned)c->prof_every) == 0;
     return guarded(c, [&]() -> int {
+        // whatever path leaves this function, no DMA may still be in flight into the caller's buffers or the staging arena
+        struct Quiesce {
+            afv_ctx *c;
+            ~Quiesce() {
+                (void)hipStreamSynchronize(c->stream);
+                (void)hipStreamSynchronize(c->stream2);
+                if (c->stream_copy) (void)hipStreamSynchronize(c->stream_copy);
+            }
+        } quiesce{c};
         // device staging layout for THIS geometry: frames back to back when the row pitch allows it (one DMA per chunk)
         const size_t pitch = align_up((size_t)width, 64);
         const size_t fstride = align_up(pitch * (size_t)height, 256);
@@ -507,11 +516,17 @@ extern "C" int afv_orb_extract_batch(afv_ctx *c, const uint8_t *const *frames, i
         const int nchunks = (nframes + CH - 1) / CH;
         rc = ensure_events(c, (size_t)nchunks * 3);
         if (rc) return rc;
-        const bool out_direct = is_pinned_host(kps) && is_pinned_host(desc32) && cap_per_frame >= 1;
+        // in-place DMA needs the WHOLE output arrays page-locked: first and last byte are probed (one registration covers a buffer)
+        const bool out_direct = is_pinned_host(kps) && is_pinned_host(desc32) &&
+                                is_pinned_host(reinterpret_cast<const uint8_t *>(kps + (size_t)nframes * cap_per_frame) - 1) &&
+                                is_pinned_host(desc32 + (size_t)nframes * cap_per_frame * AFV_DESC_BYTES - 1);
         const int ocap = std::min(cap_per_frame, c->stage_cap);
         // pinned arena: [pageable frames of the chunks in flight][n][kps][desc] (only what is not DMA'd in place)
+        // all or nothing: frames are DMA'd in place only when the first and the last frame of EVERY chunk are page-locked (a probe per
+        // frame would cost as much as the extraction of a small batch); a mix of pinned and pageable frames inside a chunk is not supported
         bool all_pinned_in = true;
-        for (int f = 0; f < nframes && all_pinned_in; f += CH) all_pinned_in = is_pinned_host(frames[f]);
+        for (int f = 0; f < nframes && all_pinned_in; f += CH)
+            all_pinned_in = is_pinned_host(frames[f]) && is_pinned_host(frames[std::min(f + CH, nframes) - 1] + (size_t)(height - 1) * stride_bytes + width - 1);
         HostImage arena{c};
         const size_t frame_bytes = (size_t)width * height;
         const size_t in_off = 0, in_bytes = all_pinned_in ? 0 : frame_bytes * (size_t)nframes;

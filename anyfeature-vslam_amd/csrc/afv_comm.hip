@@ -12,7 +12,18 @@
 // time (dlopen / already-loaded copy), so libafv_hip.so carries no link dependency on it and single-GPU hosts never
 // touch it.
 #include <dlfcn.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// hosts without the RCCL development headers: the few declarations this file needs (the library is resolved with dlopen at run time)
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1 } ncclDataType_t;
+}
+#endif
 
 #include <mutex>
 
@@ -36,6 +47,7 @@ struct afv_table {
     uint8_t *d_valid = nullptr; // [nsets][cap] "map point exists && !isBad()" (afv_table_set_valid), lazily allocated, default 1
     std::vector<int32_t> h_n;
     std::vector<HostFeatVec> fv;
+    std::vector<uint8_t> has_fv, has_geo;  // per set: afv_table_set_featvec / afv_table_set_geometry called since the last afv_table_set
     // grow-only device buffers of the pair entry points + their pinned host image
     int32_t *d_pairs = nullptr;  // [2][pair_cap]
     int32_t *d_out = nullptr;    // [pair_cap][cap]
@@ -91,6 +103,8 @@ extern "C" int afv_table_create(afv_ctx *c, int nsets, int cap, afv_table **out)
     try {
         t->h_n.assign((size_t)nsets, 0);
         t->fv.resize((size_t)nsets);
+        t->has_fv.assign((size_t)nsets, 0);
+        t->has_geo.assign((size_t)nsets, 0);
         std::lock_guard<std::mutex> g(g_reg_mutex);
         g_tables.push_back(t);
     } catch (...) {
@@ -127,7 +141,12 @@ extern "C" int afv_table_set(afv_table *t, int set, const uint8_t *desc32, const
     else if (n)
         HIPCHK(c, hipMemsetAsync(t->d_angle + (size_t)set * t->cap, 0, (size_t)n * sizeof(float), c->stream));
     t->h_n[set] = n;
-    t->fv[set] = HostFeatVec();  // indices of an earlier FeatureVector may no longer be in range
+    // a recycled slot must not inherit anything of its previous occupant: FeatureVector (indices may be out of range), "map point
+    // exists" mask (unset = all valid), geometry (afv_table_match_triangulation refuses the slot until it is set again)
+    t->fv[set] = HostFeatVec();
+    t->has_fv[set] = 0;
+    t->has_geo[set] = 0;
+    if (t->d_valid) HIPCHK(c, hipMemsetAsync(t->d_valid + (size_t)set * t->cap, 1, (size_t)t->cap, c->stream));
     HIPCHK(c, hipMemcpyAsync(t->d_n + set, &t->h_n[set], sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return AFV_OK;
@@ -159,6 +178,7 @@ extern "C" int afv_table_set_featvec(afv_table *t, int set, const int32_t *node_
         f.seg_ptr.assign(seg_ptr, seg_ptr + (nnodes ? nnodes + 1 : 0));
         f.seg_idx.assign(seg_idx, seg_idx + total);
         if (total) HIPCHK(c, hipMemcpy(t->d_idx + (size_t)set * t->cap, seg_idx, (size_t)total * sizeof(int32_t), hipMemcpyHostToDevice));
+        t->has_fv[set] = 1;
         return AFV_OK;
     });
 }
@@ -170,6 +190,7 @@ extern "C" int afv_table_set_geometry(afv_table *t, int set, const float *x, con
     const size_t plane = (size_t)t->nsets * t->cap;
     if (!t->d_geo) HIPCHK(c, hipMalloc(&t->d_geo, 3 * plane * sizeof(float)));
     const int n = t->h_n[set];
+    t->has_geo[set] = 1;
     if (n == 0) return AFV_OK;
     const float *src[3] = {x, y, sigma2};
     for (int k = 0; k < 3; ++k)
@@ -207,9 +228,101 @@ extern "C" int afv_table_sync_counts(afv_table *t) {  // after a broadcast / ext
     if (!t) return AFV_EINVAL;
     afv_ctx *c = t->c;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpy(t->h_n.data(), t->d_n, (size_t)t->nsets * sizeof(int32_t), hipMemcpyDeviceToHost));
-    for (int &v : t->h_n) v = std::min(std::max(v, 0), t->cap);
+    std::vector<int32_t> fresh((size_t)t->nsets);
+    HIPCHK(c, hipMemcpy(fresh.data(), t->d_n, (size_t)t->nsets * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int s = 0; s < t->nsets; ++s) {
+        const int v = std::min(std::max(fresh[s], 0), t->cap);
+        if (v < t->h_n[s] && t->has_fv[s]) {
+            // the set shrank under a stored FeatureVector: indices >= v would address rows that no longer exist
+            bool stale = false;
+            for (int32_t i : t->fv[s].seg_idx) stale |= i >= v;
+            if (stale) {
+                t->fv[s] = HostFeatVec();
+                t->has_fv[s] = 0;
+            }
+        }
+        t->h_n[s] = v;
+    }
     return AFV_OK;
+}
+
+// ---- replica image: everything a replica needs besides the device planes (host-side FeatureVector structure + per-set flags).
+// Layout (int32): [nsets] then per set {has_fv, has_geo, nnodes, node_id[nnodes], seg_ptr[nnodes + 1] (absent when nnodes == 0)}.
+// The feature indices themselves travel with the d_idx plane. ----
+static void table_pack_meta(const afv_table *t, std::vector<int32_t> &blob) {
+    blob.clear();
+    blob.push_back(t->nsets);
+    for (int s = 0; s < t->nsets; ++s) {
+        const HostFeatVec &f = t->fv[s];
+        blob.push_back(t->has_fv[s]);
+        blob.push_back(t->has_geo[s]);
+        blob.push_back((int32_t)f.node_id.size());
+        blob.insert(blob.end(), f.node_id.begin(), f.node_id.end());
+        blob.insert(blob.end(), f.seg_ptr.begin(), f.seg_ptr.end());
+    }
+}
+
+// rebuilds fv[] / flags of `t` from a replica image; the d_idx plane and the counts (h_n) must already be in place
+static int table_unpack_meta(afv_table *t, const int32_t *blob, size_t len) {
+    afv_ctx *c = t->c;
+    if (len < 1 || blob[0] != t->nsets) return AFV_EINVAL;
+    size_t pos = 1;
+    std::vector<int32_t> idx_row((size_t)t->cap);
+    for (int s = 0; s < t->nsets; ++s) {
+        if (pos + 3 > len) return AFV_EINVAL;
+        const int has_fv = blob[pos], has_geo = blob[pos + 1], nnodes = blob[pos + 2];
+        pos += 3;
+        if (nnodes < 0 || pos + (size_t)nnodes + (nnodes ? (size_t)nnodes + 1 : 0) > len) return AFV_EINVAL;
+        HostFeatVec f;
+        f.node_id.assign(blob + pos, blob + pos + nnodes);
+        pos += (size_t)nnodes;
+        if (nnodes) {
+            f.seg_ptr.assign(blob + pos, blob + pos + nnodes + 1);
+            pos += (size_t)nnodes + 1;
+            const int total = f.seg_ptr[nnodes];
+            if (total < 0 || total > t->h_n[s] || !t->d_idx) return AFV_EINVAL;
+            if (total) {
+                HIPCHK(c, hipMemcpy(idx_row.data(), t->d_idx + (size_t)s * t->cap, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost));
+                for (int i = 0; i < total; ++i)
+                    if (idx_row[i] < 0 || idx_row[i] >= t->h_n[s]) return AFV_EINVAL;
+                f.seg_idx.assign(idx_row.begin(), idx_row.begin() + total);
+            }
+        }
+        t->fv[s] = std::move(f);
+        t->has_fv[s] = has_fv != 0;
+        t->has_geo[s] = has_geo != 0;
+    }
+    return pos == len ? AFV_OK : AFV_EINVAL;
+}
+
+extern "C" int afv_table_clone(const afv_table *src, afv_table *dst) {
+    if (!src || !dst || src == dst || src->nsets != dst->nsets || src->cap != dst->cap) return AFV_EINVAL;
+    afv_ctx *c = dst->c;
+    return guarded(c, [&]() -> int {
+        HIPCHK(c, hipSetDevice(src->c->device));
+        HIPCHK(c, hipStreamSynchronize(src->c->stream));
+        HIPCHK(c, hipSetDevice(c->device));
+        const size_t plane = (size_t)dst->nsets * dst->cap;
+        if (src->d_idx && !dst->d_idx) HIPCHK(c, hipMalloc(&dst->d_idx, plane * sizeof(int32_t)));
+        if (src->d_geo && !dst->d_geo) HIPCHK(c, hipMalloc(&dst->d_geo, 3 * plane * sizeof(float)));
+        if (src->d_valid && !dst->d_valid) HIPCHK(c, hipMalloc(&dst->d_valid, plane));
+        HIPCHK(c, hipMemcpy(dst->d_desc, src->d_desc, plane * 32, hipMemcpyDefault));
+        HIPCHK(c, hipMemcpy(dst->d_angle, src->d_angle, plane * sizeof(float), hipMemcpyDefault));
+        HIPCHK(c, hipMemcpy(dst->d_n, src->d_n, (size_t)dst->nsets * sizeof(int32_t), hipMemcpyDefault));
+        if (src->d_idx) HIPCHK(c, hipMemcpy(dst->d_idx, src->d_idx, plane * sizeof(int32_t), hipMemcpyDefault));
+        if (src->d_geo) HIPCHK(c, hipMemcpy(dst->d_geo, src->d_geo, 3 * plane * sizeof(float), hipMemcpyDefault));
+        if (src->d_valid) HIPCHK(c, hipMemcpy(dst->d_valid, src->d_valid, plane, hipMemcpyDefault));
+        else if (dst->d_valid) HIPCHK(c, hipMemset(dst->d_valid, 1, plane));
+        for (int s = 0; s < dst->nsets; ++s) {  // nothing of the destination's previous content survives
+            dst->fv[s] = HostFeatVec();
+            dst->has_fv[s] = dst->has_geo[s] = 0;
+        }
+        int rc = afv_table_sync_counts(dst);
+        if (rc) return rc;
+        std::vector<int32_t> blob;
+        table_pack_meta(src, blob);
+        return table_unpack_meta(dst, blob.data(), blob.size());  // the code path every receiver of afv_table_broadcast runs
+    });
 }
 
 static int table_reserve_pairs(afv_table *t, int npairs) {
@@ -292,6 +405,12 @@ static int table_match_bow_impl(afv_table *t, const int32_t *pair_a, const int32
                                 int check_orientation, int32_t *match12, int32_t *nmatches) {
     afv_ctx *c = t->c;
     if (!t->d_idx) return AFV_EINVAL;  // no FeatureVector was ever stored
+    for (int p = 0; p < npairs; ++p)
+        for (int s : {pair_a[p], pair_b[p]})
+            if (t->h_n[s] > 0 && !t->has_fv[s]) {  // "no shared node" must not be confused with "FeatureVector never stored"
+                c->last_error = "afv_table_match_bow: set " + std::to_string(s) + " holds features but no FeatureVector (afv_table_set_featvec)";
+                return AFV_EINVAL;
+            }
     HIPCHK(c, hipSetDevice(c->device));
     const int cap = t->cap;
     Blob b(c);
@@ -368,6 +487,12 @@ static int table_match_tri_impl(afv_table *t, const int32_t *pair_a, const int32
                                 int32_t *match12, int32_t *nmatches) {
     afv_ctx *c = t->c;
     if (!t->d_idx || !t->d_geo) return AFV_EINVAL;
+    for (int p = 0; p < npairs; ++p)
+        for (int s : {pair_a[p], pair_b[p]})
+            if (t->h_n[s] > 0 && (!t->has_fv[s] || !t->has_geo[s])) {
+                c->last_error = "afv_table_match_triangulation: set " + std::to_string(s) + " lacks its FeatureVector or geometry";
+                return AFV_EINVAL;
+            }
     HIPCHK(c, hipSetDevice(c->device));
     const int cap = t->cap;
     const size_t plane = (size_t)t->nsets * cap;
@@ -384,7 +509,11 @@ static int table_match_tri_impl(afv_table *t, const int32_t *pair_a, const int32
         const int n1 = t->h_n[pair_a[p]], n2 = t->h_n[pair_b[p]];
         row_seg.assign((size_t)std::max(n1, 1), -1);  // feature -> shared node (a feature sits in exactly one node)
         for (size_t s = before; s < segs.size(); ++s)
-            for (int r = 0; r < segs[s].n1; ++r) row_seg[A.seg_idx[segs[s].s1 + r]] = (int)(s - before);
+            for (int r = 0; r < segs[s].n1; ++r) {
+                const int fi = A.seg_idx[segs[s].s1 + r];
+                if (fi < 0 || fi >= n1) return AFV_EINVAL;  // cannot happen while afv_table_sync_counts drops stale FeatureVectors
+                row_seg[fi] = (int)(s - before);
+            }
         rowseg_off[p] = b.put(row_seg.data(), row_seg.size() * sizeof(int));
         if (geo[p].has_mp1 && n1) m1_off[p] = b.put(geo[p].has_mp1, (size_t)n1);
         if (geo[p].has_mp2 && n2) m2_off[p] = b.put(geo[p].has_mp2, (size_t)n2);
@@ -583,34 +712,59 @@ extern "C" int afv_comm_allgather(afv_comm *m, const void *d_send, void *d_recv,
 extern "C" int afv_table_broadcast(afv_comm *m, afv_table *t, int root, float *elapsed_ms) {
     if (!m || !t || m->c != t->c || root < 0 || root >= m->nranks) return AFV_EINVAL;
     afv_ctx *c = t->c;
-    HIPCHK(c, hipSetDevice(c->device));
-    // does the root hold FeatureVector indices / geometry?  (ranks allocate them on demand so the buffers exist everywhere)
-    int32_t flags[3] = {t->d_idx != nullptr, t->d_geo != nullptr, t->d_valid != nullptr};
-    int32_t *d_flags = nullptr;
-    HIPCHK(c, hipMalloc(&d_flags, sizeof(flags)));
-    hipError_t e = hipMemcpyAsync(d_flags, flags, sizeof(flags), hipMemcpyHostToDevice, c->stream);
-    int rc = e == hipSuccess ? afv_comm_broadcast(m, d_flags, sizeof(flags), root, c->stream) : AFV_EHIP;
-    if (rc == AFV_OK) e = hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream);
-    if (rc == AFV_OK && e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d_flags);
-    if (rc) return rc;
-    HIPCHK(c, e);
-    const size_t plane = (size_t)t->nsets * t->cap;
-    if (flags[0] && !t->d_idx) HIPCHK(c, hipMalloc(&t->d_idx, plane * sizeof(int32_t)));
-    if (flags[1] && !t->d_geo) HIPCHK(c, hipMalloc(&t->d_geo, 3 * plane * sizeof(float)));
-    if (flags[2] && !t->d_valid) HIPCHK(c, hipMalloc(&t->d_valid, plane));
-    HIPCHK(c, hipEventRecord(t->ev0, c->stream));
-    rc = afv_comm_broadcast(m, t->d_desc, plane * 32, root, c->stream);
-    if (!rc) rc = afv_comm_broadcast(m, t->d_angle, plane * sizeof(float), root, c->stream);
-    if (!rc) rc = afv_comm_broadcast(m, t->d_n, (size_t)t->nsets * sizeof(int32_t), root, c->stream);
-    if (!rc && flags[0]) rc = afv_comm_broadcast(m, t->d_idx, plane * sizeof(int32_t), root, c->stream);
-    if (!rc && flags[1]) rc = afv_comm_broadcast(m, t->d_geo, 3 * plane * sizeof(float), root, c->stream);
-    if (!rc && flags[2]) rc = afv_comm_broadcast(m, t->d_valid, plane, root, c->stream);
-    if (rc) return rc;
-    HIPCHK(c, hipEventRecord(t->ev1, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (elapsed_ms) HIPCHK(c, hipEventElapsedTime(elapsed_ms, t->ev0, t->ev1));
-    return afv_table_sync_counts(t);
+    return guarded(c, [&]() -> int {
+        HIPCHK(c, hipSetDevice(c->device));
+        // what the root holds: optional planes (ranks allocate them on demand so the buffers exist everywhere) and the length of its
+        // replica image (host-side FeatureVector structure + per-set flags)
+        std::vector<int32_t> blob;
+        if (m->rank == root) table_pack_meta(t, blob);
+        int32_t flags[4] = {t->d_idx != nullptr, t->d_geo != nullptr, t->d_valid != nullptr, (int32_t)blob.size()};
+        int32_t *d_flags = nullptr;
+        HIPCHK(c, hipMalloc(&d_flags, sizeof(flags)));
+        hipError_t e = hipMemcpyAsync(d_flags, flags, sizeof(flags), hipMemcpyHostToDevice, c->stream);
+        int rc = e == hipSuccess ? afv_comm_broadcast(m, d_flags, sizeof(flags), root, c->stream) : AFV_EHIP;
+        if (rc == AFV_OK) e = hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream);
+        if (rc == AFV_OK && e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        (void)hipFree(d_flags);
+        if (rc) return rc;
+        HIPCHK(c, e);
+        if (flags[3] < 1) return AFV_EINVAL;
+        const size_t plane = (size_t)t->nsets * t->cap;
+        if (flags[0] && !t->d_idx) HIPCHK(c, hipMalloc(&t->d_idx, plane * sizeof(int32_t)));
+        if (flags[1] && !t->d_geo) HIPCHK(c, hipMalloc(&t->d_geo, 3 * plane * sizeof(float)));
+        if (flags[2] && !t->d_valid) HIPCHK(c, hipMalloc(&t->d_valid, plane));
+        int32_t *d_meta = nullptr;
+        HIPCHK(c, hipMalloc(&d_meta, (size_t)flags[3] * sizeof(int32_t)));
+        struct Free { void *p; ~Free() { (void)hipFree(p); } } free_meta{d_meta};
+        if (m->rank == root) HIPCHK(c, hipMemcpyAsync(d_meta, blob.data(), blob.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipEventRecord(t->ev0, c->stream));
+        rc = afv_comm_broadcast(m, t->d_desc, plane * 32, root, c->stream);
+        if (!rc) rc = afv_comm_broadcast(m, t->d_angle, plane * sizeof(float), root, c->stream);
+        if (!rc) rc = afv_comm_broadcast(m, t->d_n, (size_t)t->nsets * sizeof(int32_t), root, c->stream);
+        if (!rc && flags[0]) rc = afv_comm_broadcast(m, t->d_idx, plane * sizeof(int32_t), root, c->stream);
+        if (!rc && flags[1]) rc = afv_comm_broadcast(m, t->d_geo, 3 * plane * sizeof(float), root, c->stream);
+        if (!rc && flags[2]) rc = afv_comm_broadcast(m, t->d_valid, plane, root, c->stream);
+        if (!rc) rc = afv_comm_broadcast(m, d_meta, (size_t)flags[3] * sizeof(int32_t), root, c->stream);
+        if (rc) {
+            (void)hipStreamSynchronize(c->stream);
+            return rc;
+        }
+        HIPCHK(c, hipEventRecord(t->ev1, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (elapsed_ms) HIPCHK(c, hipEventElapsedTime(elapsed_ms, t->ev0, t->ev1));
+        if (m->rank == root) return afv_table_sync_counts(t);
+        // receivers: nothing of the previous content survives; counts first, then the FeatureVectors against them
+        for (int s = 0; s < t->nsets; ++s) {
+            t->fv[s] = HostFeatVec();
+            t->has_fv[s] = t->has_geo[s] = 0;
+        }
+        if (!flags[2] && t->d_valid) HIPCHK(c, hipMemset(t->d_valid, 1, plane));
+        rc = afv_table_sync_counts(t);
+        if (rc) return rc;
+        blob.resize((size_t)flags[3]);
+        HIPCHK(c, hipMemcpy(blob.data(), d_meta, blob.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        return table_unpack_meta(t, blob.data(), blob.size());
+    });
 }
 
 extern "C" void afv_shard_range(long n_units, int rank, int nranks, long *lo, long *hi) {

@@ -145,10 +145,16 @@ class DescriptorTable:
 
     # ---- replication ----
     def broadcast(self, comm, root=0):
-        """one RCCL broadcast per array; returns the device time of the broadcasts in ms"""
+        """one RCCL broadcast per array + one for the replica image (FeatureVector structure, per-slot flags); returns the device time
+        of the broadcasts in ms"""
         ms = C.c_float(0.0)
         self.ctx.check(self.lib.afv_table_broadcast(comm.handle, self.handle, int(root), C.byref(ms)), "afv_table_broadcast")
         return float(ms.value)
+
+    def clone_into(self, other):
+        """replica without a communicator: everything this table holds, rebuilt in `other` the way a broadcast receiver does"""
+        other.ctx.check(self.lib.afv_table_clone(self.handle, other.handle), "afv_table_clone")
+        return other
 
     # ---- matching ----
     def match_pairs(self, pair_a, pair_b, th_low, nnratio, check_orientation=True, want_matches=True):

@@ -167,6 +167,27 @@ def akaze_cpu_baseline(afv, frames, quotas):
             "sample": "%d frames %dx%d through oracle/akaze.c + oracle quadtree, single thread" % (len(frames), w, h)}
 
 
+def akaze_algorithmic_bytes(plan, Wa, Ha):
+    """Algorithmic HBM bytes per frame of scale space + Hessian, each datum moved once: level 0 reads the u8 frame twice (Gaussian
+    and contrast percentile) and writes Lt; every further level reads the previous Lt, writes Lsmooth and Lt; the Hessian reads
+    Lsmooth and writes Lx, Ly, Ldet.  The kernel structure moves more (second value: gauss, level kernel, 2 derivative kernels)."""
+    px0 = Wa * Ha
+    strict = 2 * px0 + 4 * px0
+    kern = px0 + 4 * px0 + px0 + 4 * px0 + 4 * px0 + 4 * px0 + 4 * px0
+    for i in range(1, plan.nlevels):
+        L, Q = plan.lv[i], plan.lv[i - 1]
+        n = L.w * L.h
+        strict += (4 * Q.w * Q.h if L.octave > Q.octave else 4 * n) + 8 * n
+        if L.octave > Q.octave:
+            kern += 4 * Q.w * Q.h + 4 * n
+        kern += 8 * n + 12 * n
+    for i in range(plan.nlevels):
+        n = plan.lv[i].w * plan.lv[i].h
+        strict += 16 * n
+        kern += 24 * n
+    return strict, kern
+
+
 def akaze_main(args):
     import torch
     afv = importlib.import_module("anyfeature-vslam_amd")
@@ -190,24 +211,7 @@ def akaze_main(args):
         ctx.scale_space_device(frames)
     ctx.synchronize()
     dt_ss = (time.perf_counter() - t0) / steps
-    plan = ctx.plan
-    px0 = Wa * Ha
-    # Algorithmic HBM bytes per frame of scale space + Hessian, each datum moved once: level 0 reads the u8 frame twice (Gaussian
-    # and contrast percentile) and writes Lt; every further level reads the previous Lt, writes Lsmooth and Lt; the Hessian reads
-    # Lsmooth and writes Lx, Ly, Ldet.  The kernel structure moves more ("kernel_structure": gauss, level kernel, 2 derivative kernels).
-    strict = 2 * px0 + 4 * px0
-    kern = px0 + 4 * px0 + px0 + 4 * px0 + 4 * px0 + 4 * px0 + 4 * px0
-    for i in range(1, plan.nlevels):
-        L, Q = plan.lv[i], plan.lv[i - 1]
-        n = L.w * L.h
-        strict += (4 * Q.w * Q.h if L.octave > Q.octave else 4 * n) + 8 * n
-        if L.octave > Q.octave:
-            kern += 4 * Q.w * Q.h + 4 * n
-        kern += 8 * n + 12 * n
-    for i in range(plan.nlevels):
-        n = plan.lv[i].w * plan.lv[i].h
-        strict += 16 * n
-        kern += 24 * n
+    strict, kern = akaze_algorithmic_bytes(ctx.plan, Wa, Ha)
     out = {"metric": "keypoints extracted+described /sec (AKAZE61, 1280x720)", "value": nk / dt, "unit": "keypoints/s", "n_gpus": 1, "steps": steps,
            "warmup": max(args.warmup, 1), "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic",
@@ -492,8 +496,6 @@ def host_fed(afv, ctx, frames_h, steps, dev_extract_fps):
             t0 = time.perf_counter()
             ctx.extract_batch_host(fr, kps, desc, n)
             reps.append(time.perf_counter() - t0)
-        if os.environ.get("AFV_BENCH_DEBUG"):
-            print("host_fed", kind, ["%.2f" % (r * 1e3) for r in reps], file=sys.stderr)
         dt = sorted(reps)[len(reps) // 2]
         nbytes = B * frames_h.shape[1] * frames_h.shape[2] + B * (cap * 60 + 4)
         out[kind] = {"frames_per_s": B / dt, "ms_per_batch": dt * 1e3, "ms_per_batch_all": [round(r * 1e3, 3) for r in reps], "statistic": "median", "pcie_GBps": nbytes / dt / 1e9, "frac_of_63GBps": nbytes / dt / 63e9,
@@ -586,7 +588,127 @@ def batch_sweep(afv, device, sizes=(1, 64, 256, 1024)):
     return res
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# compact sub-runs that ride in the default --gpus 1 line (BASELINE.json configs[2], [3], [4] on the driver's record); the
+# headline `value` never includes them
+# ---------------------------------------------------------------------------------------------------------------------
+def extra_pairs10k(afv, device, steps=5):
+    """configs[3] on one GPU: K = 1000 keyframes x 1000 x 32 B, 10 000 LCG pair jobs, brute-force SearchByBoW(KF,KF) with orientation
+    check; phase 1 on the matrix cores (default) and, for the A/B, on the vector ALU"""
+    import torch
+    tbl_mod = importlib.import_module("anyfeature-vslam_amd.table")
+    dmod = importlib.import_module("anyfeature-vslam_amd.dist")
+    K, cap, njobs = 1000, 1000, 10000
+    ctx = afv.Context(max_batch=1, device=device)
+    table = tbl_mod.DescriptorTable(ctx, K, cap)
+    table.upload(*afv.synth.keyframe_table(K, cap))
+    a, b = dmod.lcg_pairs(12345, njobs, K)
+    dev = torch.device("cuda", device)
+    pa, pb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    match = torch.empty((njobs, cap), dtype=torch.int32, device=dev)
+    nm = torch.empty((njobs,), dtype=torch.int32, device=dev)
+    side = torch.cuda.Stream(dev)
+    out = {"jobs": njobs, "keyframes": K, "steps": steps}
+    for engine, name in ((1, "mfma"), (0, "popcount")):
+        ctx.set_match_engine(engine)
+
+        def step():
+            with torch.cuda.stream(side):
+                table.match_pairs_device(pa, pb, 75.0, 0.75, True, match=match, nmatches=nm)
+        step()
+        torch.cuda.synchronize(dev)
+        ctx.profile_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / steps
+        st = ctx.profile_read()
+        ctx.profile_enable(False)
+        out[name] = {"jobs_per_s": njobs / dt, "ms_per_step": dt * 1e3, "descriptor_pairs_per_s": njobs * cap * cap / dt,
+                     # stage sums of the two alternating streams (they overlap: the sums exceed ms_per_step)
+                     "stage_ms_per_step": {"match_topk": st["match_topk"]["total_ms"] / steps, "match_resolve": st["match_resolve"]["total_ms"] / steps}}
+    ctx.set_match_engine(1)
+    out["matches_per_job"] = float(nm.float().mean().item())
+    # whole-step rates (phase 2 included): 2 * 256 integer ops per descriptor pair on the i8 MFMA against the measured 32x32x32
+    # ceiling (MI355X_MICROARCH.md: 4404 TOPS); 8 xor + 8 v_bcnt per pair and lane against the measured issue rate of that op class
+    out["mfma"]["i8_mfma_frac_of_4404_TOPS"] = out["mfma"]["descriptor_pairs_per_s"] * 512 / 4404e12
+    cal = valu_calibration()
+    out["popcount"]["xor_bcnt_issue_frac"] = out["popcount"]["descriptor_pairs_per_s"] * 16 / 64 / cal["peak"]
+    out["note"] = "the table broadcast is timed by `--workload pairs10k` (world size 1 here: a no-op)"
+    table.close()
+    ctx.close()
+    return out
+
+
+def extra_l2_sift128(afv, device, reps=20):
+    """configs[2]: float descriptors, L2^2 brute force (cv::norm operation order), 1000 x 1000 x 128, host-buffer call"""
+    s = afv.synth
+    n, dim = 1000, 128
+    a = (s.lcg_bytes(1, n * dim).reshape(n, dim).astype(np.float32)) ** 2
+    a /= np.linalg.norm(a, axis=1, keepdims=True)
+    noise = (s.lcg_bytes(2, n * dim).reshape(n, dim).astype(np.float32) - 128) / 2000.0
+    b = np.abs(a + noise).astype(np.float32)
+    b /= np.linalg.norm(b, axis=1, keepdims=True)
+    b = b[np.argsort(s.lcg_states(3, n), kind="stable")].copy()
+    ctx = afv.Context(device=device)
+    m = afv.FeatureMatcher(0.8, False, ctx=ctx)
+    m.match_l2(a, b, 0.5, 0.8)
+    ts = []
+    gn = 0
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        _, gn = m.match_l2(a, b, 0.5, 0.8)
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    ctx.close()
+    return {"n1": n, "n2": n, "dim": dim, "us_per_job_host_to_host": ts[len(ts) // 2] * 1e6, "us_min": ts[0] * 1e6, "matches": int(gn),
+            "note": "afv_match_l2 through host buffers (upload 1 MB, three kernels, download); kernel-only times: profiles/"}
+
+
+def extra_akaze61(afv, device, B=64, steps=3):
+    """configs[4]: AKAZE61 at 1280 x 720, device-resident batch"""
+    import torch
+    Wa, Ha = 1280, 720
+    ctx = afv.AkazeContext(afv.akaze.default_params(max_batch=B))
+    frames = torch.from_numpy(afv.synth.corners_batch(1, B, Wa, Ha)).cuda(device)
+    ctx.extract_device(frames)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.extract_device(frames)
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    nk = sum(len(ctx.features(f)[0]) for f in range(B))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.scale_space_device(frames)
+    ctx.synchronize()
+    dt_ss = (time.perf_counter() - t0) / steps
+    strict = akaze_algorithmic_bytes(ctx.plan, Wa, Ha)[0]
+    out = {"frames_per_step": B, "steps": steps, "frames_per_s": B / dt, "ms_per_step": dt * 1e3, "keypoints_per_s": nk / dt,
+           "described_per_frame": nk / B, "scale_space_ms_per_step": dt_ss * 1e3, "scale_space_GBps": strict * B / dt_ss / 1e9,
+           "scale_space_frac_of_hbm_peak": strict * B / dt_ss / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_frame": strict}
+    del ctx
+    return out
+
+
+def _self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU"""
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
 def main():
+    # RCCL prints a version banner on STDOUT when NCCL_DEBUG=VERSION: the driver reads ONE JSON line from stdout
+    if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
+        os.environ["NCCL_DEBUG"] = "WARN"
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -603,10 +725,17 @@ def main():
                          "pairs10k = configs[3], 10 000 keyframe-pair match jobs over a K = 1000 table, RCCL broadcast timed separately")
     ap.add_argument("--match-engine", type=int, default=None, choices=[0, 1], help="phase 1 of the pair matcher: 1 = matrix cores (library "
                     "default), 0 = popcount on the vector ALU (A/B measurement; identical results)")
+    ap.add_argument("--lib", default=None, help="measurement tooling: bind this build of libafv_hip.so (tools/experiments.py variants)")
+    ap.add_argument("--split-chunks", type=int, default=0, help="orb32: chunks a batch is split into over the two streams (0 = automatic)")
+    ap.add_argument("--no-split", action="store_true", help="orb32: one stream, one chunk (per-kernel timelines)")
     ap.add_argument("--keyframes", type=int, default=1000, help="pairs10k: keyframes in the table")
     ap.add_argument("--jobs", type=int, default=10000, help="pairs10k: pair jobs per step (whole job, all GPUs)")
     ap.add_argument("--bcast-reps", type=int, default=3, help="pairs10k: repetitions of the table broadcast")
     args = ap.parse_args()
+    if args.lib:
+        importlib.import_module("anyfeature-vslam_amd._lib").use_library(args.lib)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and args.workload != "akaze61":
+        _self_launch(args)
     if args.workload == "akaze61":
         return akaze_main(args)
     if args.workload == "pairs10k":
@@ -636,9 +765,9 @@ def main():
                       device=local)
     if args.match_engine is not None:
         ctx.set_match_engine(args.match_engine)
-    if os.environ.get("AFV_EXP_CHUNKS"):      # tools/timeline.py experiments only
-        ctx.set_split_chunks(int(os.environ["AFV_EXP_CHUNKS"]))
-    if os.environ.get("AFV_EXP_NOSPLIT"):
+    if args.split_chunks:
+        ctx.set_split_chunks(args.split_chunks)
+    if args.no_split:
         ctx.set_split_threshold(0x7fffffff)
     afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
     matcher = afv.FeatureMatcher(0.6, True, ctx=ctx)
@@ -768,6 +897,11 @@ def main():
             out["host_fed"] = host_fed(afv, ctx, frames.cpu().numpy(), max(args.steps // 3, 5), dev_fps)
             out["batch_sweep"] = batch_sweep(afv, local)
             out["overlap_match"] = overlap_step(afv, local)
+            for key, fn in (("pairs10k", extra_pairs10k), ("l2_sift128", extra_l2_sift128), ("akaze61", extra_akaze61)):
+                try:
+                    out[key] = fn(afv, local)
+                except Exception as e:  # a secondary figure must never cost the headline line
+                    out[key] = {"error": repr(e)[:300]}
         if args.cpu_frames > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(afv, args.cpu_frames, seed0)
         elif args.cpu_frames > 0:

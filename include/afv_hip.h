@@ -77,8 +77,11 @@ int afv_orb_extract(afv_ctx *ctx, const uint8_t *gray, int width, int height, in
 /* ---- extraction: host-buffer batch (vocabulary builder shape, createVocabulary.cpp:161-174).  frames[f] = row-major gray image
  * with stride_bytes between rows; outputs kps[nframes][cap_per_frame], desc32[nframes][cap_per_frame][32], n_out[nframes].
  * Batches of at least two pipeline chunks are software-pipelined (upload of the next chunks / compute / download of the
- * finished chunk overlap).  Page-locked caller buffers (hipHostMalloc, hipHostRegister) are DMA'd in place — entries of a row beyond
- * n_out[f] are then unspecified; pageable buffers are staged through the context's pinned arena. ---- */
+ * finished chunk overlap).  Page-locked caller buffers (hipHostMalloc, hipHostRegister) are DMA'd in place: the whole rows
+ * kps[f][0..cap) / desc32[f][0..cap) are then overwritten and entries beyond n_out[f] are unspecified.  All or nothing: the frames
+ * count as page-locked only if the first and last frame of every chunk are (mixing pinned and pageable frames inside a chunk is not
+ * supported), the outputs only if both arrays are page-locked end to end.  Pageable buffers are staged through the context's pinned
+ * arena — correct, but about 3x slower over PCIe.  On any error no transfer is left in flight. ---- */
 int afv_orb_extract_batch(afv_ctx *ctx, const uint8_t *const *frames, int nframes, int width, int height,
                           int stride_bytes, afv_keypoint *kps, uint8_t *desc32, int cap_per_frame, int *n_out);
 
@@ -187,6 +190,9 @@ int afv_table_match_bow(afv_table *t, const int32_t *pair_a, const int32_t *pair
  * LocalMapping::CreateNewMapPoints does against <= 20 neighbours (src/LocalMapping.cc:238-297).  Per pair only the
  * fundamental matrix, the epipole and the "already has a map point" masks travel. */
 int afv_table_set_geometry(afv_table *t, int set, const float *x, const float *y, const float *sigma2);
+/* afv_table_set (a recycled slot) forgets the slot's FeatureVector, geometry and validity mask: afv_table_match_bow /
+ * afv_table_match_triangulation return AFV_EINVAL for a slot that holds features but lacks what the call needs, instead of
+ * answering "no matches". */
 typedef struct {
     float F12[9];            /* row-major fundamental matrix (as afv_tri_job) */
     float ex, ey;            /* epipole of camera a in image b */
@@ -214,11 +220,15 @@ int afv_comm_size(const afv_comm *comm);
 int afv_comm_broadcast(afv_comm *comm, void *d_buf, size_t bytes, int root, void *stream);
 /* every rank contributes bytes_per_rank at d_send; d_recv receives nranks * bytes_per_rank in rank order */
 int afv_comm_allgather(afv_comm *comm, const void *d_send, void *d_recv, size_t bytes_per_rank, void *stream);
-/* replicate the whole table (descriptors, angles, counts; the FeatureVector indices if present on root) from `root`:
- * one broadcast per array, then a stream synchronisation.  elapsed_ms (may be NULL) = device time of the broadcasts
- * (hipEvents on the context's stream).  The FeatureVector host metadata of the root is NOT shipped: ranks that need
- * afv_table_match_bow call afv_table_set_featvec themselves (it is host data they already hold). */
+/* replicate the WHOLE table from `root`: descriptors, angles, counts, and — when the root holds them — FeatureVectors (the
+ * feature-index plane plus the host-side node structure), geometry and validity planes: one broadcast per array and one for the
+ * "replica image" (node ids / CSR pointers / per-set flags), then a stream synchronisation.  After the call every rank answers
+ * afv_table_match_pairs, afv_table_match_bow and afv_table_match_triangulation exactly as the root does; whatever a receiver held
+ * before is replaced.  elapsed_ms (may be NULL) = device time of the broadcasts (hipEvents on the context's stream). */
 int afv_table_broadcast(afv_comm *comm, afv_table *t, int root, float *elapsed_ms);
+/* copy everything `src` holds into `dst` (same nsets / cap; may live on another context or device) through the same replica image
+ * and rebuild step the receivers of afv_table_broadcast run — a replica without a communicator (e.g. one table per calling thread) */
+int afv_table_clone(const afv_table *src, afv_table *dst);
 /* block partition of n_units over the ranks: unit u belongs to the rank whose [lo, hi) holds it */
 void afv_shard_range(long n_units, int rank, int nranks, long *lo, long *hi);
 

@@ -195,6 +195,109 @@ def test_table_triangulation_pairs(afv, oracle, tbl):
     ctx.close()
 
 
+def _replica_fixture(afv, tbl, ctx, K=10, cap=256):
+    """a table with everything a replica has to carry: ragged counts, FeatureVectors, geometry, validity masks"""
+    s = afv.synth
+    t, ang, cnt = _small_table(afv, K=K, cap=cap)
+    table = tbl.DescriptorTable(ctx, K, cap)
+    x0 = (s.lcg_states(301, cap) % 60000).astype(np.float32) / 100.0
+    y0 = (s.lcg_states(401, cap) % 47000).astype(np.float32) / 100.0
+    sg0 = ((np.float32(1.2) ** (s.lcg_states(501, cap) % 8).astype(np.float32)) ** 2).astype(np.float32)
+    fvs, geo, valid = [], [], [None] * K
+    for k in range(K):
+        n = int(cnt[k])
+        table.set(k, t[k, :n], ang[k, :n])
+        fv = _featvec(afv, 91, n, 25)
+        fvs.append(fv)
+        table.set_featvec(k, *_csr(fv))
+        g = (x0[:n] + np.float32(2 * k), y0[:n].copy(), sg0[:n].copy())
+        geo.append(g)
+        table.set_geometry(k, *g)
+        if k % 3 == 0:
+            valid[k] = (s.lcg_bytes(710 + k, max(n, 1))[:n] > 60).astype(np.uint8)
+            table.set_valid(k, valid[k])
+    return table, (t, ang, cnt), fvs, geo, valid
+
+
+def _replica_jobs(afv, K, cnt):
+    s = afv.synth
+    pa = np.array([k for k in range(K) for _ in range(2)], np.int32)
+    pb = np.array([(k + 1 + j) % K for k in range(K) for j in range(2)], np.int32)
+    F = np.tile(np.array([0, 0, 0, 0, 0, -1, 1e-4, 1, 0], np.float32), (len(pa), 1))
+    ep = np.tile(np.array([1.0e6, 240.0], np.float32), (len(pa), 1))
+    mp1 = [(s.lcg_bytes(905 + p, max(int(cnt[pa[p]]), 1))[:cnt[pa[p]]] > 200).astype(np.uint8) if p % 2 else None for p in range(len(pa))]
+    return pa, pb, F, ep, mp1
+
+
+def test_replica_answers_like_the_original(afv, oracle, tbl):
+    """afv_table_clone rebuilds a second table (on another context) through the replica image + rebuild step that every receiver
+    of afv_table_broadcast runs (LoopClosing.cc:255-281: the loop search on a non-root rank is BoW-guided too).  A table that was
+    populated ONLY that way must answer the BoW-guided and triangulation batches exactly like the original — and like the oracle."""
+    ctx_a, ctx_b = afv.Context(), afv.Context()
+    table, (t, ang, cnt), fvs, geo, valid = _replica_fixture(afv, tbl, ctx_a)
+    K, cap = len(cnt), t.shape[1]
+    replica = tbl.DescriptorTable(ctx_b, K, cap)
+    replica.set(0, t[1, :50], ang[1, :50])                     # previous content of the receiver must not survive
+    replica.set_featvec(0, *_csr(_featvec(afv, 5, 50, 7)))
+    table.clone_into(replica)
+    pa, pb, F, ep, mp1 = _replica_jobs(afv, K, cnt)
+    for ori in (False, True):
+        m0, n0 = table.match_bow(pa, pb, TH, RATIO, ori)
+        m1, n1 = replica.match_bow(pa, pb, TH, RATIO, ori)
+        assert np.array_equal(n0, n1) and np.array_equal(m0, m1)
+    assert n1.sum() > 50
+    for p in range(0, len(pa), 3):
+        a, b = int(pa[p]), int(pb[p])
+        want, wn = oracle.search_by_bow_kf_kf(t[a, :cnt[a]], t[b, :cnt[b]], fvs[a], fvs[b], valid[a], valid[b], ang[a, :cnt[a]], ang[b, :cnt[b]],
+                                              TH, RATIO, True)
+        assert n1[p] == wn and np.array_equal(m1[p, :cnt[a]], want), p
+    t0 = table.match_triangulation(pa, pb, F, ep, TH, mp1, None)
+    t1 = replica.match_triangulation(pa, pb, F, ep, TH, mp1, None)
+    assert np.array_equal(t0[1], t1[1]) and np.array_equal(t0[0], t1[0]) and t1[1].sum() > 100
+    bp = replica.match_pairs(pa, pb, TH, RATIO, True)
+    assert np.array_equal(bp[1], table.match_pairs(pa, pb, TH, RATIO, True)[1])
+    replica.close(); table.close(); ctx_b.close(); ctx_a.close()
+
+
+def test_recycled_slot_and_shrunk_counts(afv, tbl):
+    """afv_table_set on a used slot forgets the slot's FeatureVector / geometry / validity mask, and a count that shrinks under a stored
+    FeatureVector (afv_table_sync_counts after an external write of d_n) drops it: the guided batches then refuse the slot
+    (AFV_EINVAL) instead of answering "no matches" or indexing rows that no longer exist"""
+    import torch
+    ctx = afv.Context()
+    table, (t, ang, cnt), fvs, geo, valid = _replica_fixture(afv, tbl, ctx, K=6, cap=128)
+    pa, pb = np.array([0, 1], np.int32), np.array([1, 2], np.int32)
+    _, nm = table.match_bow(pa, pb, TH, RATIO, True)
+    table.set(1, t[3, :100], ang[3, :100])                       # slot 1 recycled for another keyframe
+    with pytest.raises(Exception):
+        table.match_bow(pa, pb, TH, RATIO, True)
+    table.set_featvec(1, *_csr(_featvec(afv, 91, 100, 25)))
+    table.match_bow(pa, pb, TH, RATIO, True)                     # FeatureVector back: served again
+    with pytest.raises(Exception):                               # ... but its geometry is still the old keyframe's
+        table.match_triangulation(pa, pb, np.tile(np.array([0, 0, 0, 0, 0, -1, 0, 1, 0], np.float32), (2, 1)),
+                                  np.tile(np.array([1e6, 240.0], np.float32), (2, 1)), TH)
+    # validity row of the recycled slot is "all valid" again: same answer as a fresh table holding the same data
+    fresh = tbl.DescriptorTable(ctx, 6, 128)
+    for k in range(6):
+        src = 3 if k == 1 else k
+        n = 100 if k == 1 else int(cnt[k])
+        fresh.set(k, t[src, :n], ang[src, :n])
+        fresh.set_featvec(k, *_csr(_featvec(afv, 91, n, 25)))
+        if k % 3 == 0:
+            fresh.set_valid(k, valid[k])
+    a1, b1 = np.array([1, 2], np.int32), np.array([2, 1], np.int32)
+    r0, r1 = table.match_bow(a1, b1, TH, RATIO, True), fresh.match_bow(a1, b1, TH, RATIO, True)
+    assert np.array_equal(r0[0], r1[0]) and np.array_equal(r0[1], r1[1])
+    # shrink slot 2 behind the library's back
+    d, a, n = table.device_views()
+    n[2] = 10
+    torch.cuda.synchronize()
+    table.sync_counts()
+    with pytest.raises(Exception):
+        table.match_bow(a1, b1, TH, RATIO, True)
+    fresh.close(); table.close(); ctx.close()
+
+
 def test_comm_world1_broadcast_and_allgather(afv, tbl):
     """the C-ABI communicator on a single rank: RCCL is found at run time, a world-1 broadcast / all-gather are identities and
     the table broadcast reports its device time.  (A 2-rank run needs 2 GPUs: see test_comm_two_ranks.)"""
@@ -258,6 +361,18 @@ def _two_rank_worker(rank, world, port, q):
     b = ((a.astype(np.int64) + 1 + (b.astype(np.int64) % 3)) % K).astype(np.int32)
     lo, hi = tbl.shard_range(njobs, rank, world)
     _, nm = table.match_pairs(a[lo:hi], b[lo:hi], TH, RATIO, True, want_matches=False)
+    # the BoW-guided loop search on every rank's replica: only rank 0 ever called set_featvec / set_geometry
+    rtab = tbl.DescriptorTable(ctx, 10, 256)
+    if rank == 0:
+        rtab.close()
+        rtab, _, _, _, _ = _replica_fixture(afv, tbl, ctx)
+    rtab.broadcast(comm, root=0)
+    t_, ang_, cnt_ = _small_table(afv, K=10, cap=256)
+    pa2, pb2, F2, ep2, mp12 = _replica_jobs(afv, 10, cnt_)
+    bow = rtab.match_bow(pa2, pb2, TH, RATIO, True)
+    tri = rtab.match_triangulation(pa2, pb2, F2, ep2, TH, mp12, None)
+    q.put(("guided", rank, bow[0].tobytes(), bow[1].tolist(), tri[0].tobytes(), tri[1].tolist()))
+    rtab.close()
     pad = tbl.shard_range(njobs, 0, world)[1]
     send = torch.full((pad,), -1, dtype=torch.int32, device="cuda")
     send[:hi - lo] = torch.from_numpy(nm).cuda()
@@ -288,7 +403,10 @@ def test_comm_two_ranks(afv, oracle):
     procs = [mpc.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=500) for _ in range(2))
+    msgs = [q.get(timeout=500) for _ in range(4)]
+    guided = sorted((m for m in msgs if m[0] == "guided"), key=lambda m: m[1])
+    assert guided[0][2:] == guided[1][2:] and sum(guided[1][3]) > 50 and sum(guided[1][5]) > 100   # the replica answers like the root
+    res = sorted(m for m in msgs if m[0] != "guided")
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

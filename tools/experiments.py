@@ -31,11 +31,11 @@ def run(name, batch=256):
     lib = os.path.join(EXP, "libafv_%s.so" % name) if name != "base" else os.path.join(PKG, "libafv_hip.so")
     out = os.path.join(ROOT, "gpurun_out", "exp", name)
     os.makedirs(out, exist_ok=True)
-    env = dict(os.environ, AFV_LIB_PATH=lib, TMPDIR="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
     counters = os.environ.get("AFV_EXP_PMC", "SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU").split()
     cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + counters + ["-d", out, "-o", "pmc",
            "--output-format", "csv", "--", sys.executable, os.path.join(ROOT, "bench.py"), "--batch", str(batch), "--steps", "2", "--warmup", "1",
-           "--cpu-frames", "0", "--no-profile", "--no-extras"]
+           "--cpu-frames", "0", "--no-profile", "--no-extras", "--lib", lib]
     subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
     kern = os.environ.get("AFV_EXP_KERNEL", "k_fast_nms")
     res = {"name": name, "kernel": kern}

@@ -10,7 +10,7 @@ cd "$ROOT"
 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 python bench.py --workload pairs10k 2> "$OUT/bench_pairs10k.err" | head -1 > "$OUT/bench_pairs10k.json"
 python bench.py --workload akaze61 --batch 64 --steps 5 2> "$OUT/bench_akaze61.err" | head -1 > "$OUT/bench_akaze61.json"
-AFV_EXP_NOSPLIT=1 python tools/timeline.py > "$OUT/timeline_single_stream.json" 2>/dev/null
+python tools/timeline.py --no-split > "$OUT/timeline_single_stream.json" 2>/dev/null
 python tools/timeline.py > "$OUT/timeline_default.json" 2>/dev/null
 for W in orb32 pairs10k; do
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 2 \
