@@ -31,6 +31,16 @@
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
     } while (0)
 
+// The same hand-off when nothing but LDS traffic of THIS wavefront has to be ordered: a workgroup-scope release also drains the
+// vector-memory counter, i.e. it waits for every global store / load the wavefront still has in flight (about 2 us per round of the
+// ordered resolve walk, measured) — wavefront scope keeps the compiler from reordering and costs nothing at run time.
+#define WAVE_LDS_ONLY_SYNC()                                   \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+
 struct Seg {
     int s1, n1, s2, n2;  // ranges into idx1/idx2 (or identity when the idx pointer is null)
 };
@@ -72,6 +82,27 @@ __device__ __forceinline__ void merge_best(int &k, int &s, int k2, int s2) {
     } else {
         s = min(s, k2 >> 16);
     }
+}
+
+// wave-wide merge_best over the 64 lanes on DPP (row shifts, then the row totals carried with row_bcast15 / row_bcast31: no LDS
+// crossbar); lanes without a source merge the identity.  Every lane receives the result.
+__device__ __forceinline__ void wave_merge_best(int &k, int &s) {
+    const int IDK = 0x7fffffff, IDS = 0x7fffffff >> 16;
+#define AFV_MB_STEP(ctrl, rmask)                                                               \
+    {                                                                                          \
+        const int k2 = __builtin_amdgcn_update_dpp(IDK, k, ctrl, rmask, 0xf, false);           \
+        const int s2 = __builtin_amdgcn_update_dpp(IDS, s, ctrl, rmask, 0xf, false);           \
+        merge_best(k, s, k2, s2);                                                              \
+    }
+    AFV_MB_STEP(0x111, 0xf)  // row_shr:1
+    AFV_MB_STEP(0x112, 0xf)  // row_shr:2
+    AFV_MB_STEP(0x114, 0xf)  // row_shr:4
+    AFV_MB_STEP(0x118, 0xf)  // row_shr:8
+    AFV_MB_STEP(0x142, 0xa)  // row_bcast:15 into rows 1, 3
+    AFV_MB_STEP(0x143, 0xc)  // row_bcast:31 into rows 2, 3
+#undef AFV_MB_STEP
+    k = __builtin_amdgcn_readlane(k, 63);
+    s = __builtin_amdgcn_readlane(s, 63);
 }
 
 __device__ __forceinline__ int med3_i32(int a, int b, int c) {  // v_med3_i32 (no clang builtin for the integer form)
@@ -355,9 +386,12 @@ __global__ __launch_bounds__(MT) void k_match_topk(const uint8_t *__restrict__ d
 
 // LDS of one k_match_resolve workgroup, sized by the per-set capacity of the launch (23 KB at cap = 1024, so several pairs share a
 // CU: the ordered walk is one wavefront deep and latency-bound, what a batch costs is set by how many walks run at once)
+#define PAIR_COLS_LDS 1024  // sets up to this capacity also keep the column descriptors in LDS (exact rescans of the walk): 56 KB in all,
+                            // below the 64 KB a launch may ask for without raising the function's dynamic-LDS limit
 static inline size_t resolve_lds_bytes(int cap) {
     const size_t c = ((size_t)cap + 63) & ~(size_t)63;
-    return std::min<size_t>(c, PAIR_KEYS_LDS) * 16 /*keys*/ + c * 4 /*claim*/ + c * 2 /*live*/ + c /*bin*/ + c / 8 /*matched*/;
+    return std::min<size_t>(c, PAIR_KEYS_LDS) * 16 /*keys*/ + c * 4 /*claim*/ + c * 2 /*live*/ + c /*bin*/ + c / 8 /*matched*/ +
+           (cap <= PAIR_COLS_LDS ? c * 32 + 16 : 0) /*columns, 16-byte aligned*/;
 }
 
 __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict__ desc, const float *__restrict__ ang, int ang_stride,
@@ -372,6 +406,9 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
     unsigned short *s_live = reinterpret_cast<unsigned short *>(s_claim + capr);
     uint8_t *s_bin = reinterpret_cast<uint8_t *>(s_live + capr);
     uint32_t *s_matched = reinterpret_cast<uint32_t *>(s_bin + capr);
+    const bool cols_in_lds = cap <= PAIR_COLS_LDS;
+    uint32_t *s_cols = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(s_matched + capr / 32) + 15) & ~(uintptr_t)15);
+    __shared__ int s_cols_ready;
     __shared__ int s_hist[32];
     __shared__ int s_wave[8];
     __shared__ int s_nm, s_drop[3];
@@ -384,6 +421,7 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
     for (int i = tid; i < (n2 + 31) / 32; i += MT) s_matched[i] = 0;
     for (int i = tid; i < n2; i += MT) s_claim[i] = 0x7fffffff;
     if (tid < 32) s_hist[tid] = 0;
+    if (tid == 0) s_cols_ready = 0;
     // rows whose best distance fails TH_LOW can never match: compact the others IN ROW ORDER, keys staged in LDS
     int nlive = 0;
     for (int i0 = 0; i0 < n1; i0 += MT) {
@@ -404,24 +442,39 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
         nlive += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
         __syncthreads();
     }
-    if (wv == 0) {
-        // Ordered walk, 64 live rows per round.  Every lane evaluates ITS row against the current matched set; an
-        // accepting lane claims its column (LDS atomic min of the lane index).  A lane is "dirty" when an EARLIER lane of
-        // the round claimed a column it relied on (its best or second-best unmatched column); a row whose 4 keys are
-        // used up needs the exact rescan.  The clean prefix before the first dirty / rescan lane is committed, the
-        // rest is replayed against the updated set.  Lane 0 is never dirty, so every round retires at least one row
-        // and the outcome is exactly that of the sequential loop (FeatureMatcher.cc:587-641).
+    const uint32_t *d1 = reinterpret_cast<const uint32_t *>(desc + (size_t)a * cap * 32);
+    const uint32_t *d2 = reinterpret_cast<const uint32_t *>(desc + (size_t)b * cap * 32);
+    if (wv != 0) {
+        // The ordered walk below is one wavefront deep.  While it runs, the other three wavefronts copy the column descriptors into
+        // LDS (when the launch reserved room for them) so that the exact rescans of the walk read LDS instead of L2; a flag in
+        // LDS, not a barrier, hands the copy over.
+        if (cols_in_lds && nlive > 0) {
+            uint4 *sc = reinterpret_cast<uint4 *>(s_cols);
+            const uint4 *gc = reinterpret_cast<const uint4 *>(d2);
+            for (int i = tid - 64; i < n2 * 2; i += MT - 64) sc[i] = gc[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) atomicAdd(&s_cols_ready, 1);
+        }
+    } else {
+        // Ordered walk, 64 live rows per round, solved as a FIXED POINT instead of "commit the clean prefix, replay the rest":
+        // every lane evaluates ITS row against the matched set plus the columns claimed by EARLIER lanes of the round (claim =
+        // LDS atomic min of the lane index), claims are rebuilt, and the evaluation repeats until no lane changes its claim.  Lane k
+        // depends only on lanes < k, so lane k is final after at most k + 1 passes (in practice the depth of the longest chain of
+        // rows competing for a column: 2..4 with the same corner detected on several pyramid levels) and the fixed point IS the
+        // outcome of the sequential loop (FeatureMatcher.cc:587-641).  A row whose four keys are used up needs the exact rescan of
+        // the unmatched columns: the round is cut there, the rows before it are committed, the rescan runs, the walk goes on.
         int nm = 0;
-        const uint32_t *d1 = reinterpret_cast<const uint32_t *>(desc + (size_t)a * cap * 32);
-        const uint32_t *d2 = reinterpret_cast<const uint32_t *>(desc + (size_t)b * cap * 32);  // the rescan (rare) reads through L2
         int pos = 0;
+        bool cols_ready = false;
 #ifdef AFV_RESOLVE_STATS
-        int st_rounds = 0, st_rescans = 0, st_full = 0;
+        int st_rounds = 0, st_rescans = 0, st_iters = 0;
+        long long st_pre = 0, st_pass = 0, st_commit = 0, st_resc = 0, st_mark = 0;
         const long long st_t0 = wall_clock64();
 #endif
         while (pos < nlive) {
 #ifdef AFV_RESOLVE_STATS
             ++st_rounds;
+            st_mark = wall_clock64();
 #endif
             const int li = pos + lane;
             const bool act = li < nlive;
@@ -429,88 +482,119 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
             int4 t4 = make_int4(NO_KEY, NO_KEY, NO_KEY, NO_KEY);
             if (act) t4 = li < PAIR_KEYS_LDS ? s_keys[li] : tk[row];
             const int keys[TOPK] = {t4.x, t4.y, t4.z, t4.w};
-            int best = NO_KEY, second = -1, e0 = -1, e1 = -1;
-            bool open = act;  // still walking the key list
-            bool exhausted = act;
+            // every lane fetches its row's descriptor now: if the round is cut at this lane, the rescan needs it, and the round trip
+            // hides behind the fixed-point passes
+            const uint4 *qp = reinterpret_cast<const uint4 *>(d1 + (size_t)row * 8);
+            const uint4 qlo = qp[0], qhi = qp[1];
+            // the matched set does not change inside a round: one look per key
+            bool gone[TOPK];
 #pragma unroll
             for (int q = 0; q < TOPK; ++q) {
-                const int key = keys[q];
-                if (open) {
-                    if (key == NO_KEY) {  // fewer than K columns exist: the list is complete
-                        open = false;
-                        exhausted = false;
-                    } else {
-                        const int col = key & 0xffff;
-                        if (!((s_matched[col >> 5] >> (col & 31)) & 1u)) {
-                            if (best == NO_KEY) {
-                                best = key;
-                                e0 = col;
-                            } else {
-                                second = key >> 16;
-                                e1 = col;
-                                open = false;
-                                exhausted = false;
+                const int col = keys[q] & 0xffff;
+                gone[q] = keys[q] != NO_KEY && ((s_matched[col >> 5] >> (col & 31)) & 1u);
+            }
+            int type = 0, e0 = -1, my_claim = -1;
+#ifdef AFV_RESOLVE_STATS
+            if (gone[0] && lane == 99) st_pre = 1;  // keep the loads above the timer
+            { const long long t = wall_clock64(); st_pre += t - st_mark; st_mark = t; }
+#endif
+            for (int pass = 0; pass < 66; ++pass) {
+#ifdef AFV_RESOLVE_STATS
+                ++st_iters;
+#endif
+                int best = NO_KEY, second = -1;
+                bool open = act, exhausted = act;
+                e0 = -1;
+#pragma unroll
+                for (int q = 0; q < TOPK; ++q) {
+                    const int key = keys[q];
+                    if (open) {
+                        if (key == NO_KEY) {  // fewer than K columns exist: the list is complete
+                            open = false;
+                            exhausted = false;
+                        } else {
+                            const int col = key & 0xffff;
+                            if (!gone[q] && !(s_claim[col] < lane)) {
+                                if (best == NO_KEY) {
+                                    best = key;
+                                    e0 = col;
+                                } else {
+                                    second = key >> 16;
+                                    open = false;
+                                    exhausted = false;
+                                }
                             }
                         }
                     }
                 }
-            }
-            int type = 0;  // 0 = no match, 1 = accept column e0, 2 = exact rescan needed
-            if (act) {
-                if (best != NO_KEY && !((float)(best >> 16) < th)) {
-                    e0 = -1;  // the best unmatched column already fails TH_LOW: final whatever happens to the set
-                    e1 = -1;
-                } else if (exhausted && n2 > TOPK) {
-                    // best found but the second-best unmatched column lies beyond the 4 keys: it is at least as far as
-                    // the last key, so the ratio test is already decided when it passes against that lower bound
-                    if (best != NO_KEY && (float)(best >> 16) < ratio * (float)(keys[TOPK - 1] >> 16)) type = 1;
-                    else type = 2;
-                } else if (best != NO_KEY) {
-                    const float best1 = (float)(best >> 16);
-                    const float best2 = second < 0 ? 3.402823466e+38f : (float)second;
-                    type = (best1 < th && best1 < ratio * best2) ? 1 : 0;  // FeatureMatcher.cc:630,632
+                type = 0;  // 0 = no match, 1 = accept column e0, 2 = exact rescan needed
+                if (act) {
+                    if (best != NO_KEY && !((float)(best >> 16) < th)) {
+                        // the best unmatched column already fails TH_LOW: final whatever happens to the set
+                    } else if (exhausted && n2 > TOPK) {
+                        // the (second-)best unmatched column lies beyond the 4 keys: it is at least as far as the last key, so
+                        // the ratio test is already decided when it passes against that lower bound, and a row without any key left
+                        // cannot match when even that bound fails TH_LOW.  (Carrying the fifth-nearest distance as a tighter bound was
+                        // measured: same 42 rescans per overlapping pair — the competing copies of a corner come in clusters of more
+                        // than five — and phase 1 13 % slower.)
+                        if (best != NO_KEY) type = ((float)(best >> 16) < ratio * (float)(keys[TOPK - 1] >> 16)) ? 1 : 2;
+                        else type = ((float)(keys[TOPK - 1] >> 16) < th) ? 2 : 0;
+                    } else if (best != NO_KEY) {
+                        const float best1 = (float)(best >> 16);
+                        const float best2 = second < 0 ? 3.402823466e+38f : (float)second;
+                        type = (best1 < th && best1 < ratio * best2) ? 1 : 0;  // FeatureMatcher.cc:630,632
+                    }
                 }
+                const int want = type == 1 ? e0 : -1;
+                if (!__ballot(want != my_claim)) break;  // fixed point
+                // rebuild the claims: release all, then claim all (two lanes may hold the same column: the lower one must survive)
+                if (my_claim >= 0) s_claim[my_claim] = 0x7fffffff;
+                WAVE_LDS_ONLY_SYNC();
+                if (want >= 0) atomicMin(&s_claim[want], lane);
+                my_claim = want;
+                WAVE_LDS_ONLY_SYNC();
             }
-            if (type == 1) atomicMin(&s_claim[e0], lane);
-            WAVE_LDS_SYNC();
-            bool stopper = type == 2;
-            if (act && type != 2) {
-                if (e0 >= 0 && s_claim[e0] < lane) stopper = true;
-                // losing the SECOND-best column to an earlier row of the round cannot undo an acceptance: the next unmatched column
-                // is at least as far, so best1 < ratio * best2 only gets easier.  It can turn a ratio rejection into a match.
-                if (type != 1 && e1 >= 0 && s_claim[e1] < lane) stopper = true;
-            }
-            const unsigned long long sm = __ballot(stopper);
+#ifdef AFV_RESOLVE_STATS
+            { const long long t = wall_clock64(); st_pass += t - st_mark; st_mark = t; }
+#endif
+            const unsigned long long sm = __ballot(type == 2);
             const int stop = sm ? (int)__builtin_ctzll(sm) : 64;
-            // commit the clean prefix
             const bool commit = type == 1 && lane < stop;
             if (commit) {
                 out[row] = e0;
                 atomicOr(&s_matched[e0 >> 5], 1u << (e0 & 31));
             }
             nm += __popcll(__ballot(commit));
-            if (type == 1) s_claim[e0] = 0x7fffffff;  // release every claim of this round
-            WAVE_LDS_SYNC();
+            if (my_claim >= 0) s_claim[my_claim] = 0x7fffffff;  // release every claim of this round
+            WAVE_LDS_ONLY_SYNC();
+            pos += stop;
 #ifdef AFV_RESOLVE_STATS
-            if (stop == 0) ++st_rescans;
-            if (stop == 64) ++st_full;
+            { const long long t = wall_clock64(); st_commit += t - st_mark; st_mark = t; }
 #endif
-            if (stop == 0) {
-                // the first row of the round needs the exact rescan of the unmatched columns (rare): whole wave
-                const int i = s_live[pos];
+            if (stop < 64 && pos < nlive) {
+                // row `pos` needs the exact rescan of the unmatched columns: whole wave, columns from LDS once the copy has landed
+#ifdef AFV_RESOLVE_STATS
+                ++st_rescans;
+#endif
+                if (cols_in_lds && !cols_ready) {
+                    while (__hip_atomic_load(&s_cols_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < MT / 64 - 1) __builtin_amdgcn_s_sleep(1);
+                    cols_ready = true;
+                }
+                const uint4 *cb = cols_in_lds ? reinterpret_cast<const uint4 *>(s_cols) : reinterpret_cast<const uint4 *>(d2);
+                const int i = __builtin_amdgcn_readlane(row, stop);
+                const uint32_t qv[8] = {qlo.x, qlo.y, qlo.z, qlo.w, qhi.x, qhi.y, qhi.z, qhi.w};
                 uint32_t q[8];
 #pragma unroll
-                for (int w = 0; w < 8; ++w) q[w] = d1[(size_t)i * 8 + w];
+                for (int w = 0; w < 8; ++w) q[w] = (uint32_t)__builtin_amdgcn_readlane((int)qv[w], stop);
                 int k = NO_KEY, s2nd = NO_KEY >> 16;
-                // four columns per lane and step: their eight 16-byte loads are in flight together (one L2 round trip per 256 columns)
+                // four columns per lane and step: their eight 16-byte loads are in flight together
                 for (int c0 = lane; c0 < n2; c0 += 256) {
                     uint4 lo[4], hi[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int c = min(c0 + 64 * u, n2 - 1);
-                        const uint4 *pc = reinterpret_cast<const uint4 *>(d2 + (size_t)c * 8);
-                        lo[u] = pc[0];
-                        hi[u] = pc[1];
+                        lo[u] = cb[2 * c];
+                        hi[u] = cb[2 * c + 1];
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -521,11 +605,7 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
                         merge_best(k, s2nd, (d << 16) | c, NO_KEY >> 16);
                     }
                 }
-#pragma unroll
-                for (int m = 32; m >= 1; m >>= 1) {
-                    const int k2 = __shfl_xor(k, m, 64), s2 = __shfl_xor(s2nd, m, 64);
-                    merge_best(k, s2nd, k2, s2);
-                }
+                wave_merge_best(k, s2nd);
                 if (k != NO_KEY) {
                     const float best1 = (float)(k >> 16);
                     const float best2 = (s2nd == (NO_KEY >> 16)) ? 3.402823466e+38f : (float)s2nd;
@@ -538,15 +618,16 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
                         ++nm;
                     }
                 }
-                WAVE_LDS_SYNC();
+                WAVE_LDS_ONLY_SYNC();
                 pos += 1;
-            } else {
-                pos += stop;
+#ifdef AFV_RESOLVE_STATS
+                { const long long t = wall_clock64(); st_resc += t - st_mark; st_mark = t; }
+#endif
             }
         }
         if (lane == 0) s_nm = nm;
 #ifdef AFV_RESOLVE_STATS
-        if (lane == 0 && (p == 1 || p == 2)) printf("resolve pair %d: n1 %d nlive %d rounds %d (full %d) rescans %d matches %d walk %lld us\n", p, n1, nlive, st_rounds, st_full, st_rescans, nm, (wall_clock64() - st_t0) / 100);
+        if (lane == 0 && (p == 1 || p == 2)) printf("resolve pair %d: n1 %d nlive %d rounds %d passes %d rescans %d matches %d walk %lld us (prologue %lld passes %lld commit %lld rescan %lld)\n", p, n1, nlive, st_rounds, st_iters, st_rescans, nm, (wall_clock64() - st_t0) / 100, st_pre / 100, st_pass / 100, st_commit / 100, st_resc / 100);
 #endif
     }
     __syncthreads();
