@@ -468,7 +468,7 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
         bool cols_ready = false;
 #ifdef AFV_RESOLVE_STATS
         int st_rounds = 0, st_rescans = 0, st_iters = 0;
-        long long st_pre = 0, st_pass = 0, st_commit = 0, st_resc = 0, st_mark = 0;
+        long long st_pre = 0, st_pass = 0, st_commit = 0, st_resc = 0, st_mark = 0, st_r1 = 0, st_r2 = 0, st_r3 = 0;
         const long long st_t0 = wall_clock64();
 #endif
         while (pos < nlive) {
@@ -580,6 +580,9 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
                     while (__hip_atomic_load(&s_cols_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < MT / 64 - 1) __builtin_amdgcn_s_sleep(1);
                     cols_ready = true;
                 }
+#ifdef AFV_RESOLVE_STATS
+                const long long tr0 = wall_clock64();
+#endif
                 const uint4 *cb = cols_in_lds ? reinterpret_cast<const uint4 *>(s_cols) : reinterpret_cast<const uint4 *>(d2);
                 const int i = __builtin_amdgcn_readlane(row, stop);
                 const uint32_t qv[8] = {qlo.x, qlo.y, qlo.z, qlo.w, qhi.x, qhi.y, qhi.z, qhi.w};
@@ -587,25 +590,40 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
 #pragma unroll
                 for (int w = 0; w < 8; ++w) q[w] = (uint32_t)__builtin_amdgcn_readlane((int)qv[w], stop);
                 int k = NO_KEY, s2nd = NO_KEY >> 16;
-                // four columns per lane and step: their eight 16-byte loads are in flight together
+                // four columns per lane and step, branch-free: the eight 16-byte loads and the four matched-bit words are in flight
+                // together, a taken or out-of-range column enters as the "no column" key.  k = best key, s2nd = second-best distance
+                // (invariant s2nd >= k >> 16): inserting a key is  s2nd = min(s2nd, max(k, key) >> 16), k = min(k, key).
                 for (int c0 = lane; c0 < n2; c0 += 256) {
                     uint4 lo[4], hi[4];
+                    uint32_t mw[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int c = min(c0 + 64 * u, n2 - 1);
                         lo[u] = cb[2 * c];
                         hi[u] = cb[2 * c + 1];
+                        mw[u] = s_matched[c >> 5];
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int c = c0 + 64 * u;
-                        if (c >= n2 || ((s_matched[c >> 5] >> (c & 31)) & 1u)) continue;
                         const int d = __popc(q[0] ^ lo[u].x) + __popc(q[1] ^ lo[u].y) + __popc(q[2] ^ lo[u].z) + __popc(q[3] ^ lo[u].w) +
                                       __popc(q[4] ^ hi[u].x) + __popc(q[5] ^ hi[u].y) + __popc(q[6] ^ hi[u].z) + __popc(q[7] ^ hi[u].w);
-                        merge_best(k, s2nd, (d << 16) | c, NO_KEY >> 16);
+                        const bool usable = c < n2 && !((mw[u] >> (c & 31)) & 1u);
+                        const int key = usable ? ((d << 16) | c) : NO_KEY;
+                        s2nd = min(s2nd, max(k, key) >> 16);
+                        k = min(k, key);
                     }
                 }
+#ifdef AFV_RESOLVE_STATS
+                if (k == 12345 && lane == 77) st_r1 = 1;
+                const long long tr1 = wall_clock64();
+#endif
                 wave_merge_best(k, s2nd);
+#ifdef AFV_RESOLVE_STATS
+                if (k == 12345 && lane == 77) st_r1 = 1;
+                const long long tr2 = wall_clock64();
+                st_r1 += tr0 - st_mark; st_r2 += tr1 - tr0; st_r3 += tr2 - tr1;
+#endif
                 if (k != NO_KEY) {
                     const float best1 = (float)(k >> 16);
                     const float best2 = (s2nd == (NO_KEY >> 16)) ? 3.402823466e+38f : (float)s2nd;
@@ -627,7 +645,7 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
         }
         if (lane == 0) s_nm = nm;
 #ifdef AFV_RESOLVE_STATS
-        if (lane == 0 && (p == 1 || p == 2)) printf("resolve pair %d: n1 %d nlive %d rounds %d passes %d rescans %d matches %d walk %lld us (prologue %lld passes %lld commit %lld rescan %lld)\n", p, n1, nlive, st_rounds, st_iters, st_rescans, nm, (wall_clock64() - st_t0) / 100, st_pre / 100, st_pass / 100, st_commit / 100, st_resc / 100);
+        if (lane == 0 && (p == 1 || p == 2)) printf("resolve pair %d: n1 %d nlive %d rounds %d passes %d rescans %d matches %d walk %lld us (prologue %lld passes %lld commit %lld rescan %lld = wait %lld scan %lld reduce %lld)\n", p, n1, nlive, st_rounds, st_iters, st_rescans, nm, (wall_clock64() - st_t0) / 100, st_pre / 100, st_pass / 100, st_commit / 100, st_resc / 100, st_r1 / 100, st_r2 / 100, st_r3 / 100);
 #endif
     }
     __syncthreads();

