@@ -16,5 +16,5 @@ for W in orb32 pairs10k; do
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 2 \
       --backend gloo --single-device --workload $W --cpu-frames 0 > "$OUT/rehearsal_gloo2_$W.json" 2> "$OUT/rehearsal_gloo2_$W.err"
 done
-python tools/probe_pcie.py > "$OUT/pcie_probe.txt" 2>&1
+python tools/probes/probe_pcie.py > "$OUT/pcie_probe.txt" 2>&1
 ls -la "$OUT"
