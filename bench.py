@@ -31,6 +31,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 METRIC = "keypoints extracted+matched /sec (ORB32, 640x480)"
+_REAL_STDOUT = None
+
+
+def emit(obj):
+    """the ONE JSON line of this run, on the process's original stdout"""
+    f = _REAL_STDOUT or sys.stdout
+    f.write(json.dumps(obj) + "\n")
+    f.flush()
+
 HBM_PEAK_GBS = 8000.0
 W, H = 640, 480
 
@@ -224,7 +233,7 @@ def akaze_main(args):
                         "kernel_structure_GBps": kern * B / dt_ss / 1e9}}
     if args.cpu_frames > 0:
         out["cpu_baseline"] = akaze_cpu_baseline(afv, frames_h[:min(args.cpu_frames, B, 4)], ctx.quotas())
-    print(json.dumps(out))
+    emit(out)
 
 
 
@@ -421,25 +430,39 @@ def pairs_main(args):
             tk, rs = stages["match_topk"], stages["match_resolve"]
             ms = tk["total_ms"] / tk["launches"]
             jobs_per_launch = tk["units"] / tk["launches"]
-            ach = PAIR_ALG_BYTES * jobs_per_launch / (ms * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "k_match_topk", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": None, "algorithmic_bytes_per_launch": PAIR_ALG_BYTES * jobs_per_launch, "avg_launch_ms": ms,
-                               "jobs_per_launch": jobs_per_launch,
-                               "note": "68 000 B per job against 8e6 xor+popcount32: this kernel is integer-VALU-bound by four orders of magnitude; see valu_issue"}
-            calib = valu_calibration()
             pairs_s = jobs_per_launch * cap * cap / (ms * 1e-3)
-            # 8 v_xor_b32 + 8 v_bcnt_u32_b32 per descriptor pair and lane; a wave instruction covers 64 lanes
-            winst = pairs_s * 16 / 64
-            out["valu_issue"] = {"kernel": "k_match_topk", "achieved": winst, "unit": "wave-instr/s (xor + popcount only)",
-                                 "peak": calib["peak"], "frac": winst / calib["peak"], "peak_source": calib["source"],
-                                 "descriptor_pairs_per_s_in_kernel": pairs_s,
-                                 "note": "the remaining issue slots of the kernel go to the key and the branch-free top-4 insertion (1 + 4 VALU per pair: v_min + 3 v_med3)"}
+            engine = 1 if args.match_engine is None else args.match_engine
+            if engine == 1:
+                # phase 1 on the matrix cores: 2 x 256 integer ops per descriptor pair (the +-64 contraction of k_match_mfma.hip; the ninth,
+                # index-injecting MFMA per 32 x 32 block is overhead and not counted).  Peak: the guide lists no spec figure for i8; its
+                # measured 32x32x32 ceiling is 4404 TOPS (MI355X_MICROARCH.md, MFMA table).  Launches of the two alternating streams overlap,
+                # so the per-launch figure is a lower bound of what the kernel does alone.
+                ach = pairs_s * 512 / 1e12
+                out["roofline"] = {"bound": "mfma", "kernel": "k_match_topk_mfma", "achieved": ach, "peak": 4404.0, "unit": "TOP/s", "frac": ach / 4404.0,
+                                   "traffic": None, "algorithmic_ops_per_launch": 512.0 * jobs_per_launch * cap * cap, "avg_launch_ms": ms,
+                                   "jobs_per_launch": jobs_per_launch, "hbm_algorithmic_GBps": PAIR_ALG_BYTES * jobs_per_launch / (ms * 1e-3) / 1e9,
+                                   "note": "exact i8 x i8 -> i32 Hamming contraction; the kernel is co-limited by the lane-private top-4 insertion "
+                                           "(1 v_min + 3 v_med3 per distance, about 5.3 cycles each; an MFMA hides only ~2/3 of its 32 cycles behind them: "
+                                           "tools/probes/probe_mfma_valu.hip), see DESIGN.md section 4"}
+            else:
+                ach = PAIR_ALG_BYTES * jobs_per_launch / (ms * 1e-3) / 1e9
+                out["roofline"] = {"bound": "hbm", "kernel": "k_match_topk", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                   "traffic": None, "algorithmic_bytes_per_launch": PAIR_ALG_BYTES * jobs_per_launch, "avg_launch_ms": ms,
+                                   "jobs_per_launch": jobs_per_launch,
+                                   "note": "68 000 B per job against 8e6 xor+popcount32: this kernel is integer-VALU-bound by four orders of magnitude; see valu_issue"}
+                calib = valu_calibration()
+                winst = pairs_s * 16 / 64   # 8 v_xor_b32 + 8 v_bcnt_u32_b32 per descriptor pair and lane; a wave instruction covers 64 lanes
+                out["valu_issue"] = {"kernel": "k_match_topk", "achieved": winst, "unit": "wave-instr/s (xor + popcount only)",
+                                     "peak": calib["peak"], "frac": winst / calib["peak"], "peak_source": calib["source"],
+                                     "descriptor_pairs_per_s_in_kernel": pairs_s,
+                                     "note": "the remaining issue slots of the kernel go to the key and the branch-free top-4 insertion (1 + 4 VALU per pair: v_min + 3 v_med3)"}
+            out["match_engine"] = "mfma_i8" if engine == 1 else "popcount"
             out["stage_ms_per_step"] = {"match_topk": tk["total_ms"] / args.steps, "match_resolve": rs["total_ms"] / args.steps}
         if args.cpu_frames > 0 and world == 1 and host is not None:
             out["cpu_baseline"] = pairs_cpu_baseline(host[0], host[1], host[2], ja, jb)
         elif args.cpu_frames > 0:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        emit(out)
     if comm is not None:
         comm.close()
     if world > 1:
@@ -706,9 +729,6 @@ def _self_launch(args):
 
 
 def main():
-    # RCCL prints a version banner on STDOUT when NCCL_DEBUG=VERSION: the driver reads ONE JSON line from stdout
-    if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
-        os.environ["NCCL_DEBUG"] = "WARN"
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -736,6 +756,12 @@ def main():
         importlib.import_module("anyfeature-vslam_amd._lib").use_library(args.lib)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and args.workload != "akaze61":
         _self_launch(args)
+    # RCCL writes its banner / warnings to the C-level stdout whenever it initialises; the driver reads ONE JSON line from stdout.
+    # So fd 1 is pointed at stderr for the whole run and the JSON line goes out through a private copy of the original stdout.
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if args.workload == "akaze61":
         return akaze_main(args)
     if args.workload == "pairs10k":
@@ -906,7 +932,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(afv, args.cpu_frames, seed0)
         elif args.cpu_frames > 0:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One command that regenerates the profile evidence bench.py and DESIGN.md quote.  Run it ON the GPU box:
-#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r02'
-# then copy gpurun_out/profiles_r02/* into profiles/r02/ and commit.  Counter passes are separate rocprofv3 runs with
+#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r03'
+# then copy gpurun_out/profiles_r03/* into profiles/r03/ and commit.  Counter passes are separate rocprofv3 runs with
 # --kernel-trace only (no other trace domain), as gpurun requires.
 set -u
 TAG=${1:-rXX}
@@ -77,10 +77,14 @@ cd "$ROOT" && $PY bench.py --workload pairs10k > "$OUT/bench_pairs10k.json" 2> "
 timeout 400 rocprofv3 --kernel-trace --stats -d "$OUT/stats_pairs" -o st --output-format csv -- $PY "$ROOT/bench.py" --workload pairs10k --steps 5 --cpu-frames 0 > /dev/null 2>&1
 cp "$(find "$OUT/stats_pairs" -name "*kernel_stats.csv" | head -1)" "$OUT/kernel_stats_pairs10k.csv"
 
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT -d "$OUT/pmc_pairs" -o p --output-format csv -- $PY "$ROOT/bench.py" --workload pairs10k --steps 3 --cpu-frames 0 --no-profile > /dev/null 2>&1
+cp "$(find "$OUT/pmc_pairs" -name "*counter_collection.csv" | head -1)" "$OUT/pmc_pairs10k_counter_collection.csv" 2>/dev/null
+$PY "$ROOT/tools/pmc_summary.py" "$OUT/pmc_pairs10k_counter_collection.csv" > "$OUT/pmc_pairs10k_summary.txt" 2>/dev/null
+
 echo "== config #5: AKAZE61 bench + kernel stats"
 cd "$ROOT" && $PY bench.py --workload akaze61 --batch 64 --steps 5 > "$OUT/bench_akaze61.json" 2> "$OUT/bench_akaze61.err"; cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats -d "$OUT/stats_akaze" -o st --output-format csv -- $PY "$ROOT/bench.py" --workload akaze61 --batch 64 --steps 3 --cpu-frames 0 > /dev/null 2>&1
 cp "$(find "$OUT/stats_akaze" -name "*kernel_stats.csv" | head -1)" "$OUT/kernel_stats_akaze61.csv"
 
-rm -rf "$OUT"/calib_FETCH_SIZE "$OUT"/calib_WRITE_SIZE "$OUT"/stats_default "$OUT"/stats_pairs "$OUT"/stats_akaze "$OUT"/pmc_FETCH_SIZE "$OUT"/pmc_WRITE_SIZE "$OUT"/pmc_SQ_INSTS_VALU "$OUT"/pmc_LDS "$OUT"/pmc_L2
+rm -rf "$OUT"/calib_FETCH_SIZE "$OUT"/calib_WRITE_SIZE "$OUT"/stats_default "$OUT"/stats_pairs "$OUT"/stats_akaze "$OUT"/pmc_FETCH_SIZE "$OUT"/pmc_WRITE_SIZE "$OUT"/pmc_SQ_INSTS_VALU "$OUT"/pmc_LDS "$OUT"/pmc_L2 "$OUT"/pmc_pairs
 ls -la "$OUT"

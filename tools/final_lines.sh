@@ -7,14 +7,21 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/final_$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
+# same GPU call as collect_profiles.sh: put its PMC / calibration files where bench.py looks for them (profiles/<tag>/)
+if [ -d "$ROOT/gpurun_out/profiles_$TAG" ]; then mkdir -p "$ROOT/profiles/$TAG" && cp "$ROOT"/gpurun_out/profiles_$TAG/*.json "$ROOT/profiles/$TAG/" 2>/dev/null; fi
 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
-python bench.py --workload pairs10k 2> "$OUT/bench_pairs10k.err" | head -1 > "$OUT/bench_pairs10k.json"
-python bench.py --workload akaze61 --batch 64 --steps 5 2> "$OUT/bench_akaze61.err" | head -1 > "$OUT/bench_akaze61.json"
+python bench.py --workload pairs10k 2> "$OUT/bench_pairs10k.err" | grep "^{" > "$OUT/bench_pairs10k.json"
+python bench.py --workload akaze61 --batch 64 --steps 5 2> "$OUT/bench_akaze61.err" | grep "^{" > "$OUT/bench_akaze61.json"
 python tools/timeline.py --no-split > "$OUT/timeline_single_stream.json" 2>/dev/null
 python tools/timeline.py > "$OUT/timeline_default.json" 2>/dev/null
 for W in orb32 pairs10k; do
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 2 \
       --backend gloo --single-device --workload $W --cpu-frames 0 > "$OUT/rehearsal_gloo2_$W.json" 2> "$OUT/rehearsal_gloo2_$W.err"
 done
+python tools/timeline.py --batch 1 --no-split > "$OUT/timeline_single_frame.json" 2>/dev/null
+python tools/bench_single_frame.py > "$OUT/single_frame.txt" 2>/dev/null
 python tools/probes/probe_pcie.py > "$OUT/pcie_probe.txt" 2>&1
+for P in probe_cvt_pk_u8 probe_mfma_valu; do
+  hipcc --offload-arch=gfx950 -O3 tools/probes/$P.hip -o /tmp/$P 2>/dev/null && /tmp/$P > "$OUT/$P.txt" 2>&1
+done
 ls -la "$OUT"
