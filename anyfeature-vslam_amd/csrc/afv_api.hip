@@ -926,7 +926,7 @@ static int afv_match_bow_impl(afv_ctx *c, const afv_match_job *jobs, int njobs, 
                 }
             }
             const size_t match_off = b.reserve((size_t)njobs * cap * 4), nm_off = b.reserve((size_t)njobs * 4);
-            const size_t topk_off = b.reserve_scratch((size_t)njobs * cap * 16);
+            const size_t topk_off = b.reserve_scratch((size_t)njobs * cap * 32);
             int rc = ensure_match_buffer(c, b.h.size());
             if (rc) return rc;
             HIPCHK(c, hipMemcpyAsync(c->d_match, b.h.data(), match_off, hipMemcpyHostToDevice, c->stream));  // inputs only
@@ -1095,7 +1095,7 @@ int afv_match_pairs_core(afv_ctx *c, const uint8_t *d_desc, const float *d_ang, 
                          const int32_t *d_pair_a, const int32_t *d_pair_b, int npairs, float th_low, float nnratio,
                          int check_orientation, int32_t *d_match, int32_t *d_nmatches, hipStream_t s) {
     c->prof = c->prof_every && (c->prof_tick_match++ % (unsigned)c->prof_every) == 0;
-    const size_t need = (size_t)npairs * cap * 16;
+    const size_t need = (size_t)npairs * cap * 32;  // one 2 x int4 key record per row
     if (need > c->topk_bytes) {  // grow-only scratch (first call / larger batch): implies a device sync
         HIPCHK(c, hipDeviceSynchronize());
         if (c->d_topk) (void)hipFree(c->d_topk);

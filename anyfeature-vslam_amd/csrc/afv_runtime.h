@@ -141,7 +141,7 @@ struct afv_ctx {
     uint8_t *h_stage = nullptr;  // pinned host image of d_match (matcher staging both ways), grow-only
     size_t stage_bytes = 0;
     bool stage_pinned = false;
-    void *d_topk = nullptr;  // [npairs][cap] int4: top-4 (distance, column) keys per row
+    void *d_topk = nullptr;  // [npairs][cap] 2 x int4: key record per row (seven (distance, column) keys + the exact-prefix length)
     size_t topk_bytes = 0;
     // last extraction (debug getters)
     FrameSrc last_src{};

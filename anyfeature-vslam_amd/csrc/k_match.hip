@@ -341,7 +341,7 @@ __global__ __launch_bounds__(MT) void k_match_bow_finish(const DevMatchJob *__re
 // SearchByBoW's greedy rule only ever removes columns.  So the K best columns of a row, ordered by
 // (distance, position), contain the row's best and second-best UNMATCHED column unless more than K-2 of them have been
 // taken by earlier rows.  Phase 1 (embarrassingly parallel, the 1e6 popcount distances per pair) computes each row's
-// top-4 keys with one LANE per row: the column descriptors are broadcast from LDS, no cross-lane traffic at all.
+// top-4 keys (a record of 2 x int4 per row, see k_match_resolve) with one LANE per row: the column descriptors are broadcast from LDS, no cross-lane traffic at all.
 // Phase 2 walks the rows in the reference's order on one wavefront per pair, consuming those 4 keys; a row whose best
 // distance already fails TH_LOW is skipped (it can never match), and a row that runs out of keys falls back to an exact
 // wave-wide rescan of the unmatched columns.  Results are identical to the sequential algorithm.
@@ -378,11 +378,15 @@ __global__ __launch_bounds__(MT) void k_match_topk(const uint8_t *__restrict__ d
             k[0] = min(k[0], key); k[1] = n1; k[2] = n2; k[3] = n3;
         }
     }
-    if (row < n1) topk[(size_t)p * cap + row] = make_int4(k[0], k[1], k[2], k[3]);
+    if (row < n1) {  // record = 7 key slots + the number of EXACT leading keys (this engine: four)
+        topk[((size_t)p * cap + row) * 2] = make_int4(k[0], k[1], k[2], k[3]);
+        topk[((size_t)p * cap + row) * 2 + 1] = make_int4(NO_KEY, NO_KEY, NO_KEY, TOPK);
+    }
 }
 
 #define PAIR_MAX_SIDE 4096  // rows / columns per set in the pairs path (16-bit row / column indices)
-#define PAIR_KEYS_LDS 2048  // top-4 keys of at most this many live rows are staged in LDS
+#define PAIR_KEYS_LDS 1024  // the key records of at most this many live rows are staged in LDS
+#define RKEYS 7             // key slots of a record (int4 x 2: seven keys + the exact-prefix length)
 
 // LDS of one k_match_resolve workgroup, sized by the per-set capacity of the launch (23 KB at cap = 1024, so several pairs share a
 // CU: the ordered walk is one wavefront deep and latency-bound, what a batch costs is set by how many walks run at once)
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(MT) void k_match_topk(const uint8_t *__restrict__ d
                             // below the 64 KB a launch may ask for without raising the function's dynamic-LDS limit
 static inline size_t resolve_lds_bytes(int cap) {
     const size_t c = ((size_t)cap + 63) & ~(size_t)63;
-    return std::min<size_t>(c, PAIR_KEYS_LDS) * 16 /*keys*/ + c * 4 /*claim*/ + c * 2 /*live*/ + c /*bin*/ + c / 8 /*matched*/ +
+    return std::min<size_t>(c, PAIR_KEYS_LDS) * 32 /*key records*/ + c * 4 /*claim*/ + c * 2 /*live*/ + c /*bin*/ + c / 8 /*matched*/ +
            (cap <= PAIR_COLS_LDS ? c * 32 + 16 : 0) /*columns, 16-byte aligned*/;
 }
 
@@ -401,21 +405,27 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
                                                       int *__restrict__ nmatches, int pair_base) {
     extern __shared__ __attribute__((aligned(16))) char s_dyn[];
     const int capr = (cap + 63) & ~63;
-    int4 *s_keys = reinterpret_cast<int4 *>(s_dyn);  // top-4 keys of the live rows (first PAIR_KEYS_LDS of them)
-    int *s_claim = reinterpret_cast<int *>(s_keys + min(capr, PAIR_KEYS_LDS));
+    int4 *s_keys = reinterpret_cast<int4 *>(s_dyn);  // key records (2 x int4) of the live rows (first PAIR_KEYS_LDS of them)
+    int *s_claim = reinterpret_cast<int *>(s_keys + 2 * min(capr, PAIR_KEYS_LDS));
     unsigned short *s_live = reinterpret_cast<unsigned short *>(s_claim + capr);
     uint8_t *s_bin = reinterpret_cast<uint8_t *>(s_live + capr);
     uint32_t *s_matched = reinterpret_cast<uint32_t *>(s_bin + capr);
     const bool cols_in_lds = cap <= PAIR_COLS_LDS;
     uint32_t *s_cols = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(s_matched + capr / 32) + 15) & ~(uintptr_t)15);
     __shared__ int s_cols_ready;
+#ifdef AFV_RESOLVE_STATS
+    __shared__ long long s_t[2];
+#endif
     __shared__ int s_hist[32];
     __shared__ int s_wave[8];
     __shared__ int s_nm, s_drop[3];
     const int p = pair_base + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#ifdef AFV_RESOLVE_STATS
+    const long long st_k0 = wall_clock64();
+#endif
     const int a = pair_a[p], b = pair_b[p];
     const int n1 = min(nset[a], cap), n2 = min(nset[b], cap);
-    const int4 *tk = topk + (size_t)p * cap;
+    const int4 *tk = topk + (size_t)p * cap * 2;
     int *out = match + (size_t)p * cap;
     for (int i = tid; i < cap; i += MT) out[i] = -1;
     for (int i = tid; i < (n2 + 31) / 32; i += MT) s_matched[i] = 0;
@@ -426,8 +436,11 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
     int nlive = 0;
     for (int i0 = 0; i0 < n1; i0 += MT) {
         const int i = i0 + tid;
-        int4 t4 = make_int4(NO_KEY, NO_KEY, NO_KEY, NO_KEY);
-        if (i < n1) t4 = tk[i];
+        int4 t4 = make_int4(NO_KEY, NO_KEY, NO_KEY, NO_KEY), t8 = make_int4(NO_KEY, NO_KEY, NO_KEY, TOPK);
+        if (i < n1) {
+            t4 = tk[2 * i];
+            t8 = tk[2 * i + 1];
+        }
         const bool live = t4.x != NO_KEY && (float)(t4.x >> 16) < th;
         const unsigned long long m = __ballot(live);
         if (lane == 0) s_wave[wv] = __popcll(m);
@@ -437,13 +450,19 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
         if (live) {
             const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
             s_live[slot] = (unsigned short)i;
-            if (slot < PAIR_KEYS_LDS) s_keys[slot] = t4;
+            if (slot < PAIR_KEYS_LDS) {
+                s_keys[2 * slot] = t4;
+                s_keys[2 * slot + 1] = t8;
+            }
         }
         nlive += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
         __syncthreads();
     }
     const uint32_t *d1 = reinterpret_cast<const uint32_t *>(desc + (size_t)a * cap * 32);
     const uint32_t *d2 = reinterpret_cast<const uint32_t *>(desc + (size_t)b * cap * 32);
+#ifdef AFV_RESOLVE_STATS
+    if (tid == 0) s_t[0] = wall_clock64();
+#endif
     if (wv != 0) {
         // The ordered walk below is one wavefront deep.  While it runs, the other three wavefronts copy the column descriptors into
         // LDS (when the launch reserved room for them) so that the exact rescans of the walk read LDS instead of L2; a flag in
@@ -479,19 +498,29 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
             const int li = pos + lane;
             const bool act = li < nlive;
             const int row = act ? s_live[li] : 0;
-            int4 t4 = make_int4(NO_KEY, NO_KEY, NO_KEY, NO_KEY);
-            if (act) t4 = li < PAIR_KEYS_LDS ? s_keys[li] : tk[row];
-            const int keys[TOPK] = {t4.x, t4.y, t4.z, t4.w};
+            int4 t4 = make_int4(NO_KEY, NO_KEY, NO_KEY, NO_KEY), t8 = make_int4(NO_KEY, NO_KEY, NO_KEY, TOPK);
+            if (act) {
+                t4 = li < PAIR_KEYS_LDS ? s_keys[2 * li] : tk[2 * row];
+                t8 = li < PAIR_KEYS_LDS ? s_keys[2 * li + 1] : tk[2 * row + 1];
+            }
+            // the first nk keys are the row's nk nearest columns EXACTLY (4 from the popcount engine; 4..7 from the matrix-core engine,
+            // whose two lane halves each keep a top-4 over half of the columns: the merged list is exact up to the first half's 4th key)
+            const int keys[RKEYS] = {t4.x, t4.y, t4.z, t4.w, t8.x, t8.y, t8.z};
+            const int nk = min(max(t8.w, 1), RKEYS);
+            int last_key = keys[0];
+#pragma unroll
+            for (int q = 1; q < RKEYS; ++q) last_key = q < nk ? keys[q] : last_key;
+            const float last_d = (float)(last_key >> 16);  // every column outside the list is at least this far
             // every lane fetches its row's descriptor now: if the round is cut at this lane, the rescan needs it, and the round trip
             // hides behind the fixed-point passes
             const uint4 *qp = reinterpret_cast<const uint4 *>(d1 + (size_t)row * 8);
             const uint4 qlo = qp[0], qhi = qp[1];
             // the matched set does not change inside a round: one look per key
-            bool gone[TOPK];
+            bool gone[RKEYS];
 #pragma unroll
-            for (int q = 0; q < TOPK; ++q) {
+            for (int q = 0; q < RKEYS; ++q) {
                 const int col = keys[q] & 0xffff;
-                gone[q] = keys[q] != NO_KEY && ((s_matched[col >> 5] >> (col & 31)) & 1u);
+                gone[q] = q < nk && keys[q] != NO_KEY && ((s_matched[col >> 5] >> (col & 31)) & 1u);
             }
             int type = 0, e0 = -1, my_claim = -1;
 #ifdef AFV_RESOLVE_STATS
@@ -506,10 +535,10 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
                 bool open = act, exhausted = act;
                 e0 = -1;
 #pragma unroll
-                for (int q = 0; q < TOPK; ++q) {
+                for (int q = 0; q < RKEYS; ++q) {
                     const int key = keys[q];
-                    if (open) {
-                        if (key == NO_KEY) {  // fewer than K columns exist: the list is complete
+                    if (open && q < nk) {
+                        if (key == NO_KEY) {  // fewer than nk columns exist: the list is complete
                             open = false;
                             exhausted = false;
                         } else {
@@ -531,14 +560,12 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
                 if (act) {
                     if (best != NO_KEY && !((float)(best >> 16) < th)) {
                         // the best unmatched column already fails TH_LOW: final whatever happens to the set
-                    } else if (exhausted && n2 > TOPK) {
-                        // the (second-)best unmatched column lies beyond the 4 keys: it is at least as far as the last key, so
+                    } else if (exhausted && n2 > nk) {
+                        // the (second-)best unmatched column lies beyond the exact keys: it is at least as far as the last of them, so
                         // the ratio test is already decided when it passes against that lower bound, and a row without any key left
-                        // cannot match when even that bound fails TH_LOW.  (Carrying the fifth-nearest distance as a tighter bound was
-                        // measured: same 42 rescans per overlapping pair — the competing copies of a corner come in clusters of more
-                        // than five — and phase 1 13 % slower.)
-                        if (best != NO_KEY) type = ((float)(best >> 16) < ratio * (float)(keys[TOPK - 1] >> 16)) ? 1 : 2;
-                        else type = ((float)(keys[TOPK - 1] >> 16) < th) ? 2 : 0;
+                        // cannot match when even that bound fails TH_LOW.
+                        if (best != NO_KEY) type = ((float)(best >> 16) < ratio * last_d) ? 1 : 2;
+                        else type = (last_d < th) ? 2 : 0;
                     } else if (best != NO_KEY) {
                         const float best1 = (float)(best >> 16);
                         const float best2 = second < 0 ? 3.402823466e+38f : (float)second;
@@ -645,7 +672,10 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
         }
         if (lane == 0) s_nm = nm;
 #ifdef AFV_RESOLVE_STATS
-        if (lane == 0 && (p == 1 || p == 2)) printf("resolve pair %d: n1 %d nlive %d rounds %d passes %d rescans %d matches %d walk %lld us (prologue %lld passes %lld commit %lld rescan %lld = wait %lld scan %lld reduce %lld)\n", p, n1, nlive, st_rounds, st_iters, st_rescans, nm, (wall_clock64() - st_t0) / 100, st_pre / 100, st_pass / 100, st_commit / 100, st_resc / 100, st_r1 / 100, st_r2 / 100, st_r3 / 100);
+        if (lane == 0) s_t[1] = wall_clock64();
+#endif
+#ifdef AFV_RESOLVE_STATS
+        if (AFV_RESOLVE_STATS == 1 && lane == 0 && (p == 1 || p == 2)) printf("resolve pair %d: n1 %d nlive %d rounds %d passes %d rescans %d matches %d walk %lld us (prologue %lld passes %lld commit %lld rescan %lld = wait %lld scan %lld reduce %lld)\n", p, n1, nlive, st_rounds, st_iters, st_rescans, nm, (wall_clock64() - st_t0) / 100, st_pre / 100, st_pass / 100, st_commit / 100, st_resc / 100, st_r1 / 100, st_r2 / 100, st_r3 / 100);
 #endif
     }
     __syncthreads();
@@ -686,6 +716,11 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
         __syncthreads();
     }
     if (tid == 0) nmatches[p] = s_nm;
+#ifdef AFV_RESOLVE_STATS
+    if (AFV_RESOLVE_STATS == 2 && tid == 0 && (p == 1 || p == 2))
+        printf("resolve pair %d: whole workgroup %lld us (set-up + compaction %lld, walk %lld, histogram %lld)\n", p, (wall_clock64() - st_k0) / 100,
+               (s_t[0] - st_k0) / 100, (s_t[1] - s_t[0]) / 100, (wall_clock64() - s_t[1]) / 100);
+#endif
 }
 
 // ---------------- M4: SearchForTriangulation ----------------
@@ -849,7 +884,17 @@ extern "C" void afv_launch_match_resolve(const uint8_t *desc, const float *ang, 
                                          const int *pb, int npairs, float th, float ratio, int check_ori, int *match, int *nmatches,
                                          const void *topk_scratch, int pair_base, hipStream_t stream) {
     const int4 *topk = reinterpret_cast<const int4 *>(topk_scratch);
-    hipLaunchKernelGGL(k_match_resolve, dim3(npairs), dim3(MT), resolve_lds_bytes(cap), stream, desc, ang, ang_stride, nset, cap, pa, pb, topk, th, ratio,
+    const size_t lds = resolve_lds_bytes(cap);  // 71 KB at cap <= 1024 (records + column descriptors): above the default 64 KB limit
+    if (lds > 64 * 1024) {  // once per device: the attribute belongs to the device's copy of the function
+        static bool done[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 0 && dev < 64 && !done[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_match_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            done[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL(k_match_resolve, dim3(npairs), dim3(MT), lds, stream, desc, ang, ang_stride, nset, cap, pa, pb, topk, th, ratio,
                        check_ori, match, nmatches, pair_base);
 }
 extern "C" void afv_launch_match_tri(const DevTriJob *jobs, int njobs, int max_n1, hipStream_t stream) {

@@ -2,7 +2,8 @@
 //
 // Replaces the distance loop of the brute-force matchers (DescriptorDistance_orb32, Feature_orb32.cpp:67-84, called n1 x n2 times per
 // keyframe pair from FeatureMatcher.cc:587-641) for whole descriptor sets; same output as k_match_topk (k_match.hip): every row's four
-// smallest keys  distance << 16 | column.
+// smallest keys  distance << 16 | column — and, for free, up to three more: the record phase 2 reads holds the first seven keys of the
+// merged top-4 lists of the two lane halves + how many of them are exact (4..7).
 //
 // popcount(a ^ b) over 256 bits is a dot product in disguise: with the bits of the train descriptor as +-64 and the bits of the query
 // as -+64 (opposite signs), sum_k A_k B_k = 4096 * (#differing - #equal) = 8192 * d - 2^20.  i8 x i8 -> i32 is exact, so
@@ -152,23 +153,38 @@ __global__ __launch_bounds__(MQ_T, 2) void k_match_topk_mfma(const uint8_t *__re
             __syncthreads();
         }
     }
-    // the two lane halves hold the top-4 over disjoint train rows of the same queries: merge, convert to d << 16 | m, write
+    // The two lane halves hold the top-4 over DISJOINT halves of the train rows of the same queries.  Their merged list is exact as far
+    // as the smaller of the two fourth keys t (every unseen column of a half is farther than that half's fourth key): the record is the
+    // first seven merged keys + nk = the number of them <= t (4..7; a half with fewer than four columns has no unseen ones).
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         int o[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = __shfl_xor(kk[qb][i], 32, 64);
+        const int t = min(kk[qb][3], o[3]);
+        int m[8] = {kk[qb][0], kk[qb][1], kk[qb][2], kk[qb][3], NO_KEY, NO_KEY, NO_KEY, NO_KEY};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) mq_insert(kk[qb], o[i]);
+        for (int i = 0; i < 4; ++i) {
+            const int key = o[i];
+#pragma unroll
+            for (int j = 7; j >= 1; --j) m[j] = mq_med3(m[j - 1], m[j], key);
+            m[0] = min(m[0], key);
+        }
+        int nk = 0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) nk += (m[j] != NO_KEY && m[j] <= t) ? 1 : 0;
+        if (t == NO_KEY) nk = 7;  // both halves complete: every valid key is exact, the NO_KEY slots end the list
         const int row = row0 + 32 * qb + (lane & 31);
         if ((lane >> 5) == qb && row < n1) {
-            int s[4];
+            int s[7];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int D = kk[qb][i] + (1 << 20);
-                s[i] = kk[qb][i] == NO_KEY ? NO_KEY : (((D >> 13) << 16) | (D & 8191));
+            for (int i = 0; i < 7; ++i) {
+                const int D = m[i] + (1 << 20);
+                s[i] = m[i] == NO_KEY ? NO_KEY : (((D >> 13) << 16) | (D & 8191));
             }
-            topk[(size_t)p * cap + row] = make_int4(s[0], s[1], s[2], s[3]);
+            int4 *rec = topk + ((size_t)p * cap + row) * 2;
+            rec[0] = make_int4(s[0], s[1], s[2], s[3]);
+            rec[1] = make_int4(s[4], s[5], s[6], max(nk, 1));
         }
     }
 }

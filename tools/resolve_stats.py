@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""k_match_resolve on overlapping frames: build the library with -DAFV_RESOLVE_STATS (python tools/experiments.py build rs=AFV_RESOLVE_STATS)
+"""k_match_resolve on overlapping frames: build the library with -DAFV_RESOLVE_STATS=1 (walk: rounds / passes / rescans / section times) or =2
+(whole workgroup: set-up, walk, histogram; no printf inside the walk) — python tools/experiments.py build rs=AFV_RESOLVE_STATS=1 —
 and run  python tools/resolve_stats.py anyfeature-vslam_amd/build_exp/libafv_rs.so  on the GPU box: the kernel prints rounds / passes /
 rescans / walk time of pairs 1 and 2 (pair 1: frame 1 = frame 0 shifted by 3 px, pair 2: unrelated frames)."""
 import importlib
