@@ -392,17 +392,17 @@ __global__ __launch_bounds__(MT) void k_match_topk(const uint8_t *__restrict__ d
 // CU: the ordered walk is one wavefront deep and latency-bound, what a batch costs is set by how many walks run at once)
 #define PAIR_COLS_LDS 1024  // sets up to this capacity also keep the column descriptors in LDS (exact rescans of the walk): 56 KB in all,
                             // below the 64 KB a launch may ask for without raising the function's dynamic-LDS limit
-static inline size_t resolve_lds_bytes(int cap) {
+static inline size_t resolve_lds_bytes(int cap, bool stage_cols) {
     const size_t c = ((size_t)cap + 63) & ~(size_t)63;
     return std::min<size_t>(c, PAIR_KEYS_LDS) * 32 /*key records*/ + c * 4 /*claim*/ + c * 2 /*live*/ + c /*bin*/ + c / 8 /*matched*/ +
-           (cap <= PAIR_COLS_LDS ? c * 32 + 16 : 0) /*columns, 16-byte aligned*/;
+           (stage_cols ? c * 32 + 16 : 0) /*columns, 16-byte aligned*/;
 }
 
-__global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict__ desc, const float *__restrict__ ang, int ang_stride,
+__global__ __launch_bounds__(MT, 2) void k_match_resolve(const uint8_t *__restrict__ desc, const float *__restrict__ ang, int ang_stride,
                                                       const int *__restrict__ nset, int cap, const int *__restrict__ pair_a,
                                                       const int *__restrict__ pair_b, const int4 *__restrict__ topk, float th,
                                                       float ratio, int check_ori, int *__restrict__ match,
-                                                      int *__restrict__ nmatches, int pair_base) {
+                                                      int *__restrict__ nmatches, int pair_base, int stage_cols) {
     extern __shared__ __attribute__((aligned(16))) char s_dyn[];
     const int capr = (cap + 63) & ~63;
     int4 *s_keys = reinterpret_cast<int4 *>(s_dyn);  // key records (2 x int4) of the live rows (first PAIR_KEYS_LDS of them)
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
     unsigned short *s_live = reinterpret_cast<unsigned short *>(s_claim + capr);
     uint8_t *s_bin = reinterpret_cast<uint8_t *>(s_live + capr);
     uint32_t *s_matched = reinterpret_cast<uint32_t *>(s_bin + capr);
-    const bool cols_in_lds = cap <= PAIR_COLS_LDS;
+    const bool cols_in_lds = stage_cols != 0;
     uint32_t *s_cols = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(s_matched + capr / 32) + 15) & ~(uintptr_t)15);
     __shared__ int s_cols_ready;
 #ifdef AFV_RESOLVE_STATS
@@ -470,7 +470,15 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
         if (cols_in_lds && nlive > 0) {
             uint4 *sc = reinterpret_cast<uint4 *>(s_cols);
             const uint4 *gc = reinterpret_cast<const uint4 *>(d2);
-            for (int i = tid - 64; i < n2 * 2; i += MT - 64) sc[i] = gc[i];
+            // all loads of a thread in flight together (<= 11 x 16 B at PAIR_COLS_LDS = 1024): two round trips instead of eleven
+            static_assert(PAIR_COLS_LDS * 2 <= 11 * (MT - 64), "column copy: eleven 16-byte loads per thread");
+            const int last = n2 * 2 - 1, i0 = tid - 64;
+#define AFV_COL(k) const uint4 v##k = gc[min(i0 + (k) * (MT - 64), last)];
+            AFV_COL(0) AFV_COL(1) AFV_COL(2) AFV_COL(3) AFV_COL(4) AFV_COL(5) AFV_COL(6) AFV_COL(7) AFV_COL(8) AFV_COL(9) AFV_COL(10)
+#undef AFV_COL
+#define AFV_COL(k) if (i0 + (k) * (MT - 64) <= last) sc[i0 + (k) * (MT - 64)] = v##k;
+            AFV_COL(0) AFV_COL(1) AFV_COL(2) AFV_COL(3) AFV_COL(4) AFV_COL(5) AFV_COL(6) AFV_COL(7) AFV_COL(8) AFV_COL(9) AFV_COL(10)
+#undef AFV_COL
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) atomicAdd(&s_cols_ready, 1);
         }
@@ -515,47 +523,42 @@ __global__ __launch_bounds__(MT) void k_match_resolve(const uint8_t *__restrict_
             // hides behind the fixed-point passes
             const uint4 *qp = reinterpret_cast<const uint4 *>(d1 + (size_t)row * 8);
             const uint4 qlo = qp[0], qhi = qp[1];
-            // the matched set does not change inside a round: one look per key
-            bool gone[RKEYS];
+            // the matched set does not change inside a round: one look per key.  v[q] = the key while it can still be chosen, else
+            // "none"; cq[q] = its column (0 for a slot that holds no key: a harmless claim lookup)
+            int v[RKEYS], cq[RKEYS];
+            bool complete = false;  // a NO_KEY inside the exact prefix: the row has fewer than nk columns, the list is all there is
 #pragma unroll
             for (int q = 0; q < RKEYS; ++q) {
-                const int col = keys[q] & 0xffff;
-                gone[q] = q < nk && keys[q] != NO_KEY && ((s_matched[col >> 5] >> (col & 31)) & 1u);
+                const bool has = q < nk && keys[q] != NO_KEY;
+                complete = complete || (q < nk && keys[q] == NO_KEY);
+                cq[q] = has ? (keys[q] & 0xffff) : 0;
+                const bool gone = has && ((s_matched[cq[q] >> 5] >> (cq[q] & 31)) & 1u);
+                v[q] = (has && !gone) ? keys[q] : NO_KEY;
             }
             int type = 0, e0 = -1, my_claim = -1;
 #ifdef AFV_RESOLVE_STATS
-            if (gone[0] && lane == 99) st_pre = 1;  // keep the loads above the timer
+            if (v[0] == 12345 && lane == 99) st_pre = 1;  // keep the loads above the timer
             { const long long t = wall_clock64(); st_pre += t - st_mark; st_mark = t; }
 #endif
             for (int pass = 0; pass < 66; ++pass) {
 #ifdef AFV_RESOLVE_STATS
                 ++st_iters;
 #endif
-                int best = NO_KEY, second = -1;
-                bool open = act, exhausted = act;
-                e0 = -1;
+                // branch-free: the keys are unique and sorted, so best / second-best available = the two smallest of the surviving slots
+                int cl[RKEYS], a[RKEYS];
 #pragma unroll
-                for (int q = 0; q < RKEYS; ++q) {
-                    const int key = keys[q];
-                    if (open && q < nk) {
-                        if (key == NO_KEY) {  // fewer than nk columns exist: the list is complete
-                            open = false;
-                            exhausted = false;
-                        } else {
-                            const int col = key & 0xffff;
-                            if (!gone[q] && !(s_claim[col] < lane)) {
-                                if (best == NO_KEY) {
-                                    best = key;
-                                    e0 = col;
-                                } else {
-                                    second = key >> 16;
-                                    open = false;
-                                    exhausted = false;
-                                }
-                            }
-                        }
-                    }
-                }
+                for (int q = 0; q < RKEYS; ++q) cl[q] = s_claim[cq[q]];  // seven LDS reads in flight together
+#pragma unroll
+                for (int q = 0; q < RKEYS; ++q) a[q] = (cl[q] < lane) ? NO_KEY : v[q];
+                const int best = act ? min(min(min(a[0], a[1]), min(a[2], a[3])), min(min(a[4], a[5]), a[6])) : NO_KEY;
+#pragma unroll
+                for (int q = 0; q < RKEYS; ++q) a[q] = a[q] > best ? a[q] : NO_KEY;
+                const int second_key = min(min(min(a[0], a[1]), min(a[2], a[3])), min(min(a[4], a[5]), a[6]));
+                const int second = second_key == NO_KEY ? -1 : (second_key >> 16);
+                // the walk through the list ends early at the second available key or at the end of a complete list; otherwise it ran
+                // out of exact keys
+                const bool exhausted = act && second < 0 && !complete;
+                e0 = best == NO_KEY ? -1 : (best & 0xffff);
                 type = 0;  // 0 = no match, 1 = accept column e0, 2 = exact rescan needed
                 if (act) {
                     if (best != NO_KEY && !((float)(best >> 16) < th)) {
@@ -884,7 +887,10 @@ extern "C" void afv_launch_match_resolve(const uint8_t *desc, const float *ang, 
                                          const int *pb, int npairs, float th, float ratio, int check_ori, int *match, int *nmatches,
                                          const void *topk_scratch, int pair_base, hipStream_t stream) {
     const int4 *topk = reinterpret_cast<const int4 *>(topk_scratch);
-    const size_t lds = resolve_lds_bytes(cap);  // 71 KB at cap <= 1024 (records + column descriptors): above the default 64 KB limit
+    // the column descriptors ride in LDS (for the exact rescans) when they fit and the launch is a batch; a handful of pairs (the
+    // single-frame plugin path) runs leaner: 39 KB instead of 71 KB, rescans through L2
+    const bool stage_cols = cap <= PAIR_COLS_LDS && npairs > 8;
+    const size_t lds = resolve_lds_bytes(cap, stage_cols);  // 71 KB with the columns: above the default 64 KB limit
     if (lds > 64 * 1024) {  // once per device: the attribute belongs to the device's copy of the function
         static bool done[64] = {};
         int dev = 0;
@@ -895,7 +901,7 @@ extern "C" void afv_launch_match_resolve(const uint8_t *desc, const float *ang, 
         }
     }
     hipLaunchKernelGGL(k_match_resolve, dim3(npairs), dim3(MT), lds, stream, desc, ang, ang_stride, nset, cap, pa, pb, topk, th, ratio,
-                       check_ori, match, nmatches, pair_base);
+                       check_ori, match, nmatches, pair_base, stage_cols ? 1 : 0);
 }
 extern "C" void afv_launch_match_tri(const DevTriJob *jobs, int njobs, int max_n1, hipStream_t stream) {
     if (max_n1 > 0) hipLaunchKernelGGL(k_match_tri, dim3((max_n1 + MT - 1) / MT, njobs), dim3(MT), 0, stream, jobs);

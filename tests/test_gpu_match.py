@@ -313,6 +313,8 @@ def test_match_engines_on_ragged_sizes(afv, oracle, matcher, gpu_ctx, engine):
         for j in (0, 3, 5, 8, 11, 14, 17, 19, (i + 1) % len(sizes)):
             pa.append(i); pb.append(j)
     pa = np.array(pa, np.int32); pb = np.array(pb, np.int32)
+    with pytest.raises(Exception):
+        gpu_ctx.set_match_engine(7)                   # unknown engine: AFV_EINVAL, the setting is untouched
     gpu_ctx.set_match_engine(engine)
     try:
         match, nm = matcher.match_pairs_device(torch.from_numpy(table).cuda(), torch.from_numpy(kps.view(np.float32).reshape(len(sizes), cap, 7)).cuda(),
