@@ -88,6 +88,21 @@ static inline __device__ int afv_xcd_remap(int b, int n) {
     return v;  // may be >= n for the last XCDs when n % 8 != 0: caller skips
 }
 
+// inclusive prefix sum over the 64 lanes of a wavefront on DPP (no LDS crossbar: a __shfl_up step is a ds_bpermute, ~100+ cycles of
+// latency each; the latency-bound kernels — quadtree, retainBest — run dozens of these scans back to back): 4 Hillis-Steele steps
+// inside each row of 16 lanes, then the row totals are carried over with row_bcast15 (rows 1, 3) and row_bcast31 (rows 2, 3)
+#ifdef __HIPCC__
+static inline __device__ int afv_wave_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112 /*row_shr:2*/, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114 /*row_shr:4*/, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118 /*row_shr:8*/, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142 /*row_bcast:15*/, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143 /*row_bcast:31*/, 0xc, 0xf, false);
+    return v;
+}
+#endif
+
 static inline __host__ __device__ int afv_reflect101(int p, int n) {
     // BORDER_REFLECT_101 for |overshoot| < n (apron 23 px / patch halo <= 21 px, levels >= 32 px)
     if (p < 0) p = -p;

@@ -21,15 +21,7 @@ __device__ __forceinline__ uint32_t qt_float_key(float r) {  // order-preserving
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
-__device__ __forceinline__ int qt_wave_incl_scan(int v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
-    return v;
-}
+__device__ __forceinline__ int qt_wave_incl_scan(int v) { return afv_wave_incl_scan(v); }
 
 // exclusive prefix sum of arr[0..n) in place; returns the total.  `tmp` = 8 ints of LDS.
 __device__ inline int qt_block_excl_scan(int *arr, int n, int *tmp) {

@@ -151,12 +151,7 @@ __global__ __launch_bounds__(AKE_T) void k_akz_cand_emit(AkdParams P, const unsi
         // lane k holds chunk k's word; exclusive scan of the popcounts gives every chunk its offset inside the row
         const unsigned long long m = lane < nchunks ? mk[(size_t)r * AKD_MAXCHUNKS + lane] : 0ull;
         const int cnt = __popcll(m);
-        int incl = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += t;
-        }
+        const int incl = afv_wave_incl_scan(cnt);
         const int row_total = __shfl(incl, 63, 64);
         if (row_total == 0) continue;
         const int base = rs[r];

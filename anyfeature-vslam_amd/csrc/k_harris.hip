@@ -27,15 +27,7 @@ __device__ __forceinline__ short2v as_s2(uint32_t v) { return __builtin_bit_cast
 #define RS_CPT 36    // candidates per thread k_retain_score keeps in registers (lists up to 9216 entries)
 #define HQ_CHUNK 64  // candidates per queue item {frame * AFV_MAX_LEVELS + level, first candidate | count << 24}: one pass of a 256-thread workgroup
 
-__device__ __forceinline__ int wave_incl_scan_shfl(int v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
-    return v;
-}
+__device__ __forceinline__ int wave_incl_scan_shfl(int v) { return afv_wave_incl_scan(v); }
 
 __global__ __launch_bounds__(256) void k_retain_score(const Geo *__restrict__ geo_p, const uint32_t *__restrict__ cand_packed,
                                                       const int *__restrict__ cand_count, uint32_t *__restrict__ l1,

@@ -46,15 +46,7 @@ __device__ __forceinline__ float key_float(uint32_t k) {
 }
 
 // ---- block-wide helpers (256 threads = 4 waves) ----
-__device__ __forceinline__ int wave_incl_scan(int v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
-    return v;
-}
+__device__ __forceinline__ int wave_incl_scan(int v) { return afv_wave_incl_scan(v); }
 
 // exclusive prefix sum of arr[0..n) in place; returns the total.  n <= ST * 16.  `tmp` = 8 ints of LDS.
 __device__ int block_excl_scan(int *arr, int n, int *tmp) {
