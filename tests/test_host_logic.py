@@ -110,3 +110,30 @@ def test_keyframe_table_generator_is_reproducible(afv):
     near = np.unpackbits(t1[0] ^ t1[1], axis=1).sum(axis=1)
     far = np.unpackbits(t1[0] ^ t1[5], axis=1).sum(axis=1)
     assert (near < 75).sum() > 30 and (far < 75).sum() < (near < 75).sum()
+
+
+def test_bench_self_launches_ranks_without_a_launcher(monkeypatch):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment re-executes itself under torch.distributed.run (one rank per
+    GPU, rendezvous on 127.0.0.1) instead of asserting — before anything touches the GPU or the process's stdout"""
+    import importlib
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_execv(exe, argv):
+        seen["exe"], seen["argv"] = exe, list(argv)
+        raise SystemExit(0)
+    monkeypatch.setattr(os, "execv", fake_execv)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--workload", "pairs10k"])
+    try:
+        bench.main()
+    except SystemExit:
+        pass
+    a = seen["argv"]
+    assert seen["exe"] == sys.executable and a[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in a and a[a.index("--nproc-per-node") + 1] == "4"
+    assert a[a.index("--master-addr") + 1] == "127.0.0.1" and a[-6:] == ["--gpus", "4", "--steps", "3", "--workload", "pairs10k"]
+    assert bench._REAL_STDOUT is None          # stdout untouched on the launching side
