@@ -716,6 +716,50 @@ def extra_akaze61(afv, device, B=64, steps=3):
     return out
 
 
+def extra_single_frame(afv, device, reps=200):
+    """The plugin shape (Frame.cc:186: ONE frame per call; Tracking.cc:78,84 keeps two extractor instances): latency of one
+    640 x 480 frame extracted + matched against its predecessor on one context, and the frame rate when 2 / 4 contexts (each with its own
+    streams and scratch) take the frames of a video round robin — every frame still is its own extract + match call, the calls of
+    different contexts overlap on the device"""
+    import torch
+    dev = torch.device("cuda", device)
+    frames_h = afv.synth.corners_batch(7001, 8, W, H)
+    out = {}
+    for nctx in (1, 2, 4):
+        ctxs = [afv.Context(max_batch=2, device=device) for _ in range(nctx)]
+        ms = [afv.FeatureMatcher(0.6, True, ctx=c) for c in ctxs]
+        cap = ctxs[0].cap
+        st = []
+        for c in ctxs:   # per context: a two-frame ring (previous + current) and its outputs
+            st.append(dict(fr=torch.from_numpy(frames_h[:2].copy()).to(dev), kps=torch.empty((2, cap, 7), dtype=torch.float32, device=dev),
+                           desc=torch.empty((2, cap, 32), dtype=torch.uint8, device=dev), n=torch.empty((2,), dtype=torch.int32, device=dev),
+                           s=torch.zeros((1,), dtype=torch.int32, device=dev), match=torch.empty((1, cap), dtype=torch.int32, device=dev),
+                           nm=torch.empty((1,), dtype=torch.int32, device=dev), pa=torch.tensor([1], dtype=torch.int32, device=dev),
+                           pb=torch.tensor([0], dtype=torch.int32, device=dev), stream=torch.cuda.Stream(dev)))
+        for c, b in zip(ctxs, st):  # the "previous" frame of every ring
+            with torch.cuda.stream(b["stream"]):
+                c.extract_batch_device(b["fr"][0:1], b["kps"][0:1], b["desc"][0:1], b["n"][0:1], b["s"], cap)
+
+        def one(i):
+            c, m, b = ctxs[i % nctx], ms[i % nctx], st[i % nctx]
+            with torch.cuda.stream(b["stream"]):
+                c.extract_batch_device(b["fr"][1:2], b["kps"][1:2], b["desc"][1:2], b["n"][1:2], b["s"], cap)
+                m.match_pairs_device(b["desc"], b["kps"], b["n"], b["pa"], b["pb"], th_low=75.0, check_orientation=True, match=b["match"], nmatches=b["nm"])
+        for i in range(4 * nctx):
+            one(i)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(reps):
+            one(i)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / reps
+        out["contexts_%d" % nctx] = {"frames_per_s": 1.0 / dt, "ms_per_frame": dt * 1e3}
+        for c in ctxs:
+            c.close()
+    out["note"] = "one extract + match call per frame; contexts_1 = back-to-back latency, contexts_2 / _4 = calls of different contexts overlap"
+    return out
+
+
 def _self_launch(args):
     """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU"""
     import socket
@@ -923,7 +967,7 @@ def main():
             out["host_fed"] = host_fed(afv, ctx, frames.cpu().numpy(), max(args.steps // 3, 5), dev_fps)
             out["batch_sweep"] = batch_sweep(afv, local)
             out["overlap_match"] = overlap_step(afv, local)
-            for key, fn in (("pairs10k", extra_pairs10k), ("l2_sift128", extra_l2_sift128), ("akaze61", extra_akaze61)):
+            for key, fn in (("single_frame", extra_single_frame), ("pairs10k", extra_pairs10k), ("l2_sift128", extra_l2_sift128), ("akaze61", extra_akaze61)):
                 try:
                     out[key] = fn(afv, local)
                 except Exception as e:  # a secondary figure must never cost the headline line
