@@ -334,6 +334,50 @@ def test_match_engines_on_ragged_sizes(afv, oracle, matcher, gpu_ctx, engine):
     assert total > 2000
 
 
+@pytest.mark.parametrize("engine", [0, 1])
+def test_device_pairs_above_the_lds_limits(afv, oracle, matcher, gpu_ctx, engine):
+    """sets larger than 1024 rows: the resolve walk keeps only the first 1024 key records in LDS (the rest are read from global
+    memory) and rescans through L2 instead of an LDS copy of the columns; clustered descriptors force rescans"""
+    import torch
+    s = afv.synth
+    cap = 1300
+    proto = s.random_descriptors(991, 60)
+
+    def cluster(seed, n):
+        idx = s.lcg_states(seed, n) % 60
+        d = proto[idx].copy()
+        pos = s.lcg_states(seed + 1, n * 2).reshape(n, 2) % 256
+        for k in range(2):
+            d[np.arange(n), pos[:, k] // 8] ^= (1 << (pos[:, k] % 8)).astype(np.uint8)
+        return d
+    sizes = [1100, 1300, 1250]
+    table = np.zeros((3, cap, 32), np.uint8)
+    kps = np.zeros((3, cap), afv.KP_DTYPE)
+    for i, n in enumerate(sizes):
+        table[i, :n] = cluster(31 + i, n)
+        kps[i, :n]["angle"] = (s.lcg_states(60 + i, n) % 36000).astype(np.float32) / 100.0
+    counts = np.array(sizes, np.int32)
+    pa = np.array([0, 1, 2, 2], np.int32)
+    pb = np.array([1, 2, 0, 1], np.int32)
+    gpu_ctx.set_match_engine(engine)
+    try:
+        matcher.mfNNratio = 0.9
+        match, nm = matcher.match_pairs_device(torch.from_numpy(table).cuda(), torch.from_numpy(kps.view(np.float32).reshape(3, cap, 7)).cuda(),
+                                               torch.from_numpy(counts).cuda(), torch.from_numpy(pa).cuda(), torch.from_numpy(pb).cuda(),
+                                               th_low=75.0, check_orientation=True)
+        torch.cuda.synchronize()
+    finally:
+        gpu_ctx.set_match_engine(1)
+        matcher.mfNNratio = 0.6
+    match = match.cpu().numpy(); nm = nm.cpu().numpy()
+    for p in range(len(pa)):
+        a, b = pa[p], pb[p]
+        want, wn = oracle.search_by_bow_kf_kf(table[a, :counts[a]], table[b, :counts[b]], angle1=kps[a, :counts[a]]["angle"],
+                                              angle2=kps[b, :counts[b]]["angle"], th_low=75.0, nnratio=0.9, check_orientation=True)
+        assert nm[p] == wn and np.array_equal(match[p, :counts[a]], want), (p, a, b)
+    assert nm.sum() > 100
+
+
 def test_config4_pair_jobs_from_descriptor_table(afv, oracle, matcher, gpu_ctx):
     """config #4 shape on one GPU: K keyframes x N x 32 B table (keyframe k+1 = perturbed keyframe k), LCG-drawn (i, j)
     pair jobs through dist.match_jobs_sharded with the DEVICE matcher (world size 1: broadcast is a no-op)"""
