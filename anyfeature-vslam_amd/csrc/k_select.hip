@@ -70,6 +70,36 @@ __device__ int block_excl_scan(int *arr, int n, int *tmp) {
     return total;
 }
 
+// two exclusive prefix sums in ONE pass: a[0..na) and u[0..nu) (na <= nu), both with totals < 65536 so that the pair rides one packed
+// wave scan.  Returns (total of a) | (total of u) << 16.  `tmp` = 4 ints of LDS.  One barrier inside, one at the end.
+__device__ int block_excl_scan2(int *a, int na, int *u, int nu, int *tmp) {
+    const int per = (nu + ST - 1) / ST;
+    const int b = threadIdx.x * per, e = min(b + per, nu), ea = min(e, na);
+    int local = 0;
+    for (int i = b; i < ea; ++i) local += a[i];
+    for (int i = b; i < e; ++i) local += u[i] << 16;
+    const int incl = wave_incl_scan(local);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) tmp[w] = incl;
+    __syncthreads();
+    int base = incl - local;
+    for (int k = 0; k < w; ++k) base += tmp[k];
+    const int total = tmp[0] + tmp[1] + tmp[2] + tmp[3];
+    int ba = base & 0xffff, bu = (int)((unsigned)base >> 16);
+    for (int i = b; i < ea; ++i) {
+        const int v = a[i];
+        a[i] = ba;
+        ba += v;
+    }
+    for (int i = b; i < e; ++i) {
+        const int v = u[i];
+        u[i] = bu;
+        bu += v;
+    }
+    __syncthreads();
+    return total;
+}
+
 // k-th largest over a histogram hist[0..nbins): returns the bin b such that sum(hist[b+1..]) < k <= sum(hist[b..]),
 // and *above = sum(hist[b+1..]).  hist is destroyed.  Requires sum(hist) >= k >= 1.
 __device__ int block_kth_from_top(int *hist, int nbins, int k, int *above, int *tmp) {
@@ -148,6 +178,12 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     uint16_t *remap = reinterpret_cast<uint16_t *>(unt + M);
     int *tmp = reinterpret_cast<int *>(smem + afv_select_tree_bytes(M));
 
+#ifdef AFV_SELECT_STATS
+    const long long st0 = wall_clock64();
+    long long st1 = 0, st2 = 0, st3 = 0;
+    int st_rounds = 0, st_b = 0;
+    long long st_r[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_occ = 0;
+#endif
     const Geo &geo = *geo_p;
     // XCD-aware placement: the 8 level-workgroups of a frame run on one XCD (they read what that frame's FAST tiles wrote)
     const int work = afv_xcd_remap(blockIdx.x, total_blocks);
@@ -226,6 +262,9 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         }
         T2 = prefix;
     }
+#ifdef AFV_SELECT_STATS
+    st1 = wall_clock64();
+#endif
     // number of survivors decides where they live during the quadtree rounds
     if (tid == 0) tmp[9] = 0;
     __syncthreads();
@@ -316,23 +355,77 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         for (int p = tid; p < m2; p += ST) kn[p] = (uint16_t)aux2[kn[p]];
     }
     int size = tmp[9];
+    // every round starts with child[0 .. 4*size) and its n_expand slot cleared (the previous round does it; this is round 0's)
+    for (int i = tid; i < size * 4; i += ST) child[i] = 0;
+    if (tid == 0) {
+        tmp[12] = tmp[13] = tmp[10] = 0;
+        tmp[11] = 0x7fffffff;
+    }
     __syncthreads();
 
+#ifdef AFV_SELECT_STATS
+    st2 = wall_clock64();
+#endif
     Rect16 *rc = rect0, *rn = rect1;
     int *cc = cnt0, *cn = cnt1;
     bool finish = (m2 == 0);
     bool phase_b = false;
+    // the usual case (survivors fit the LDS arrays): every thread keeps its <= PPT points (position, node label) in registers for
+    // all rounds; kn[] is written back once after the last round
+    constexpr int PPT = KEPT_LDS / ST;
+    const bool small = m2 > 0 && m2 <= KEPT_LDS;
+    int nd_[PPT];
+    uint32_t xy_[PPT];
+    if (small) {
+#pragma unroll
+        for (int k_ = 0; k_ < PPT; ++k_) {
+            const int p = min(tid + k_ * ST, m2 - 1);  // clamped: the tail threads carry a duplicate they never count
+            nd_[k_] = kn[p];
+            xy_[k_] = kxy[p];
+        }
+    }
+    int par = 0;  // n_expand slot of this round: tmp[12 + par]
 
+    // Barriers per round: occupancy | order | (scan: 2) | new list | relabel.  Everything a later phase reads is written at
+    // least one barrier earlier; the clears for the NEXT round ride the relabel phase, which touches neither array.
     while (!finish) {
+#ifdef AFV_SELECT_STATS
+        const long long r0 = wall_clock64();
+        ++st_rounds;
+        st_b += phase_b;
+#endif
         const int prev_size = size;
         // 1. child occupancy of every node that may split this round
-        for (int i = tid; i < size * 4; i += ST) child[i] = 0;
-        __syncthreads();
-        for (int p = tid; p < m2; p += ST) {
-            const int nd = kn[p];
-            if (cc[nd] > 1) atomicAdd(&child[nd * 4 + point_quadrant(kxy[p], scale, rc[nd])], 1);
+        // each point's quadrant is computed ONCE per round (here) and reused when the points are relabelled in step 4: a thread keeps
+        // the quadrants of its <= PPT points in a register while the survivors live in LDS (the usual case)
+        uint32_t quads = 0;  // 2 bits per point of this thread
+        if (small) {
+            // staged so that the PPT node lookups are in flight together (one LDS round trip per stage, not per point)
+            int c_[PPT];
+            Rect16 r_[PPT];
+#pragma unroll
+            for (int k_ = 0; k_ < PPT; ++k_) {
+                c_[k_] = cc[nd_[k_]];
+                r_[k_] = rc[nd_[k_]];
+            }
+#pragma unroll
+            for (int k_ = 0; k_ < PPT; ++k_) {
+                if (tid + k_ * ST < m2 && c_[k_] > 1) {
+                    const int q = point_quadrant(xy_[k_], scale, r_[k_]);
+                    quads |= (uint32_t)q << (2 * k_);
+                    atomicAdd(&child[nd_[k_] * 4 + q], 1);
+                }
+            }
+        } else {
+            for (int p = tid; p < m2; p += ST) {
+                const int nd = kn[p];
+                if (cc[nd] > 1) atomicAdd(&child[nd * 4 + point_quadrant(kxy[p], scale, rc[nd])], 1);
+            }
         }
         __syncthreads();
+#ifdef AFV_SELECT_STATS
+        st_occ += wall_clock64() - r0;
+#endif
         // 2. processing order.  aux[key] = number of non-empty children of the node processed key-th (0 if that
         //    node does not split); aux2[i] = key of node i or -1.
         int nproc;  // number of processing slots
@@ -342,27 +435,35 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                 if (cc[i] > 1) ne = (child[4 * i] > 0) + (child[4 * i + 1] > 0) + (child[4 * i + 2] > 0) + (child[4 * i + 3] > 0);
                 aux[i] = ne;
                 aux2[i] = (cc[i] > 1) ? i : -1;
+                unt[i] = (cc[i] > 1) ? 0 : 1;
             }
             nproc = size;
             __syncthreads();
         } else {
             // rank among expandable nodes by (count desc, list index asc) == sort ascending by (size, pointer) walked
-            // from the back (ORBextractor.cc:381-382) with pointer ties resolved by creation order
-            if (tid == 0) tmp[10] = 0;
-            for (int i = tid; i < size; i += ST) aux[i] = 0;
-            __syncthreads();
+            // from the back (ORBextractor.cc:381-382) with pointer ties resolved by creation order.  The ranks are a
+            // permutation of 0..E-1, so aux[0..E) is fully rewritten here: aux[rank] = nodes gained by that split.
+            // tmp[10] (E) and tmp[11] (stop rank) were reset in the previous round's relabel phase.
             int ecount = 0;
             for (int i = tid; i < size; i += ST) {
                 int key = -1;
                 const int ci = cc[i];
                 if (ci > 1) {
+                    // (count, -index) as one key: node j goes first iff kj > ki.  Four nodes per LDS read (cnt arrays are
+                    // 16-byte aligned, M is a multiple of 64); slots past `size` are masked.
+                    const int ki = (ci << 12) | (4095 - i);
                     int r = 0;
-                    for (int j = 0; j < size; ++j) {
-                        const int cj = cc[j];
-                        r += (cj > 1) && (cj > ci || (cj == ci && j < i));
+#pragma unroll 4
+                    for (int j = 0; j < size; j += 4) {
+                        const int4 c4 = *reinterpret_cast<const int4 *>(cc + j);
+                        const int k0 = (c4.x << 12) | (4095 - j), k1 = (c4.y << 12) | (4094 - j);
+                        const int k2 = (c4.z << 12) | (4093 - j), k3 = (c4.w << 12) | (4092 - j);
+                        r += (c4.x > 1 && k0 > ki) + (j + 1 < size && c4.y > 1 && k1 > ki) + (j + 2 < size && c4.z > 1 && k2 > ki) +
+                             (j + 3 < size && c4.w > 1 && k3 > ki);
                     }
                     key = r;
                     ++ecount;
+                    aux[key] = (child[4 * i] > 0) + (child[4 * i + 1] > 0) + (child[4 * i + 2] > 0) + (child[4 * i + 3] > 0) - 1;
                 }
                 aux2[i] = key;
             }
@@ -370,32 +471,19 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             if (lane == 63) atomicAdd(&tmp[10], ecount);
             __syncthreads();
             const int E = tmp[10];
-            // deltas in rank order -> inclusive prefix -> first rank at which size + prefix >= N
-            for (int i = tid; i < size; i += ST) {
-                const int key = aux2[i];
-                if (key >= 0) {
-                    const int ne = (child[4 * i] > 0) + (child[4 * i + 1] > 0) + (child[4 * i + 2] > 0) + (child[4 * i + 3] > 0);
-                    aux[key] = ne - 1;
-                }
-            }
-            __syncthreads();
             block_excl_scan(aux, E, tmp);  // aux[r] = sum of deltas of ranks < r  (deltas >= 0: monotone)
-            if (tid == 0) tmp[11] = E - 1;
-            __syncthreads();
             // stop rank r*: smallest r whose split lifts the node count to >= N (ORBextractor.cc:424-425); the
             // count after rank r is prev_size + aux[r+1]; if no rank reaches N every node is processed
             for (int r = tid; r + 1 < E; r += ST)
                 if (prev_size + aux[r + 1] >= N) atomicMin(&tmp[11], r);
             __syncthreads();
-            const int rstar = tmp[11];
-            // rebuild aux as "non-empty children by processing slot", dropping ranks > r*
-            __syncthreads();
-            for (int i = tid; i < E; i += ST) aux[i] = 0;
-            __syncthreads();
+            const int rstar = min(tmp[11], E - 1);
+            // rebuild aux as "non-empty children by processing slot" for the ranks <= r* (later slots are never read)
             for (int i = tid; i < size; i += ST) {
                 int key = aux2[i];
                 if (key > rstar) key = -1;
                 aux2[i] = key;
+                unt[i] = (key < 0) ? 1 : 0;
                 if (key >= 0)
                     aux[key] = (child[4 * i] > 0) + (child[4 * i + 1] > 0) + (child[4 * i + 2] > 0) + (child[4 * i + 3] > 0);
             }
@@ -403,12 +491,10 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             __syncthreads();
         }
         // 3. suffix sums over the processing order: children of later-processed nodes come first in the new list
-        const int total_children = block_excl_scan(aux, nproc, tmp);  // aux[key] = children of keys < key
         // child (node i, quadrant q) -> position (total - aux[key] - ne(i)) + #non-empty children with quadrant > q
-        // untouched node i -> total_children + rank among untouched nodes
-        for (int i = tid; i < size; i += ST) unt[i] = (aux2[i] < 0) ? 1 : 0;
-        __syncthreads();
-        const int untouched = block_excl_scan(unt, size, tmp);
+        // untouched node i (unt[i] = 1, set with aux2 above) -> total_children + rank among untouched nodes
+        const int totals = block_excl_scan2(aux, nproc, unt, size, tmp);  // aux[key] = children of keys < key
+        const int total_children = totals & 0xffff, untouched = (int)((unsigned)totals >> 16);
         const int new_size = total_children + untouched;
         int n_expand_local = 0;
         for (int i = tid; i < size; i += ST) {
@@ -437,17 +523,34 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             }
         }
         n_expand_local = wave_incl_scan(n_expand_local);
-        if (tid == 0) tmp[12] = 0;
+        if (lane == 63) atomicAdd(&tmp[12 + par], n_expand_local);
         __syncthreads();
-        if (lane == 63) atomicAdd(&tmp[12], n_expand_local);
-        // 4. relabel the points
-        for (int p = tid; p < m2; p += ST) {
-            const int nd = kn[p];
-            const int q = (aux2[nd] >= 0) ? point_quadrant(kxy[p], scale, rc[nd]) : 0;
-            kn[p] = remap[4 * nd + q];
+        // 4. relabel the points; clear the next round's occupancy counters and n_expand slot
+        for (int i = tid; i < new_size * 4; i += ST) child[i] = 0;
+        if (tid == 0) {
+            tmp[12 + (par ^ 1)] = 0;
+            tmp[10] = 0;
+            tmp[11] = 0x7fffffff;
+        }
+        if (small) {
+            int key_[PPT];
+#pragma unroll
+            for (int k_ = 0; k_ < PPT; ++k_) key_[k_] = aux2[nd_[k_]];
+#pragma unroll
+            for (int k_ = 0; k_ < PPT; ++k_) {
+                const int q = (key_[k_] >= 0) ? (int)((quads >> (2 * k_)) & 3u) : 0;  // aux2 >= 0 implies the node had > 1 point
+                nd_[k_] = remap[4 * nd_[k_] + q];
+            }
+        } else {
+            for (int p = tid; p < m2; p += ST) {
+                const int nd = kn[p];
+                const int q = (aux2[nd] >= 0) ? point_quadrant(kxy[p], scale, rc[nd]) : 0;
+                kn[p] = remap[4 * nd + q];
+            }
         }
         __syncthreads();
-        const int n_expand = tmp[12];
+        const int n_expand = tmp[12 + par];
+        par ^= 1;
         size = new_size;
         {
             Rect16 *t = rc; rc = rn; rn = t;
@@ -456,9 +559,19 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         // 5. termination (ORBextractor.cc:366-370, :427-430)
         if (size >= N || size == prev_size) finish = true;
         else if (!phase_b && size + n_expand * 3 > N) phase_b = true;
-        __syncthreads();
+#ifdef AFV_SELECT_STATS
+        if (st_rounds <= 8) st_r[st_rounds - 1] = wall_clock64() - r0;
+#endif
     }
 
+    if (small) {
+#pragma unroll
+        for (int k_ = 0; k_ < PPT; ++k_)
+            if (tid + k_ * ST < m2) kn[tid + k_ * ST] = (uint16_t)nd_[k_];
+    }
+#ifdef AFV_SELECT_STATS
+    st3 = wall_clock64();
+#endif
     // ---------------- survivor of each node ----------------
     for (int i = tid; i < size; i += ST) best[i] = 0ull;
     __syncthreads();
@@ -482,6 +595,12 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         out[i] = s;
     }
     if (tid == 0) sel_count[f * AFV_MAX_LEVELS + l] = nout;
+#ifdef AFV_SELECT_STATS
+    if (tid == 0 && f == 0)
+        printf("select level %d: n %d kept %d nodes %d rounds %d (phase B %d) | us: load + radix %lld, count + compaction + roots %lld, quadtree %lld, survivors %lld\n", l, n, m2, size,
+               st_rounds, st_b, (st1 - st0) / 100, (st2 - st1) / 100, (st3 - st2) / 100, (wall_clock64() - st3) / 100),
+        printf("   level %d rounds (x10 ns): %lld %lld %lld %lld %lld | occupancy total %lld\n", l, st_r[0], st_r[1], st_r[2], st_r[3], st_r[4], st_occ);
+#endif
 }
 
 extern "C" size_t afv_select_lds_bytes(int M) {
