@@ -30,24 +30,27 @@ struct AkdLevel {
     float psize, ratio;
     const float *ldet;
     int cand_off, cand_cap, row_off;
+    float ginv;
+    int gw, gh, gcap, gcell_off, gelem_off;
 };
 struct AkdParams {
     int nlevels, W, H;
     float dthreshold, min_dthreshold;
     AkdLevel lv[16];
-    int cand_stride, rows_stride, gw, gh, entry_cap, kp_cap;
+    int cand_stride, rows_stride, gcells, gelems, lds_bytes, entry_cap, kp_cap;
 };
 struct AkdState {
     float *ex, *ey, *eresp;
     int *elevel;
     uint4 *cells;
-    int *cell_cnt;
+    int *gcnt, *ticket, *used, *chunk_cnt;
     unsigned char *keep;
+    unsigned int epoch;
 };
 extern "C" void afv_akz_launch_candidates(const AkdParams *P, int nframes, unsigned long long *mask, int *row_start, int *cand, float *cand_resp,
                                           int *cand_count, int *status, hipStream_t st);
 extern "C" void afv_akz_launch_suppress(const AkdParams *P, const AkdState *S, int nframes, const int *cand, const float *cand_resp,
-                                        const int *cand_count,
+                                        const int *cand_count, const int *row_start,
                                         afv_keypoint *kps, int *kp_count, int *status, hipStream_t st);
 struct AksParams {
     int nlevels, W, H, n_ini;
@@ -70,10 +73,8 @@ extern "C" void afv_akz_launch_select(const AksParams *P, int nframes, const afv
 extern "C" void afv_akz_launch_describe(const AkdDescParams *P, int nframes, int max_out, const afv_keypoint *kps, const int *sel,
                                         const int *sel_count, afv_keypoint *out_kps, uint8_t *out_desc, int *out_count, int *status,
                                         hipStream_t st);
-#define AKD_CELL 10.0f
-#define AKD_CELLCAP 48
-#define AKD_MAX_CELLS 12288
-#define AKD_ENTRY_CAP 65535
+#define AKD_ENTRY_CAP 65535   // keypoints per frame after detection
+#define AKD_SLOT_CAP 131072   // slot space of the ordered suppression: one slot per candidate (all levels of a frame)
 
 struct afv_akaze {
     int device = 0;
@@ -99,7 +100,7 @@ struct afv_akaze {
     unsigned long long *d_mask = nullptr;  // [frame][rows][32] candidate bitmap words
     int *d_row_count = nullptr, *d_row_start = nullptr, *d_cand = nullptr, *d_cand_count = nullptr, *d_kp_count = nullptr, *d_status = nullptr;
     afv_keypoint *d_kps = nullptr;
-    size_t cand_stride_max = 0, rows_stride_max = 0;
+    size_t cand_stride_max = 0, rows_stride_max = 0, grid_cells_max = 0, grid_elems_max = 0, cells_bytes = 0;
     bool have_scale_space = false, have_keypoints = false, have_descriptors = false;
     // plugin tail: quadtree filter + descriptors
     int *d_lvl_idx = nullptr, *d_sel = nullptr, *d_sel_count = nullptr, *d_out_count = nullptr;
@@ -240,6 +241,35 @@ static int akz_alloc(afv_akaze *a, T **p, size_t count) {
     return AFV_OK;
 }
 
+// Grids of the ordered suppression (k_akaze_detect.hip, AkdLevel): level c's entries are searched with the radii of levels c-1
+// (upper-level filter), c and c+1, so its cell edge is twice the largest of those (a disc then overlaps at most 2 x 2 cells);
+// a list can never hold more elements than there are strict 3 x 3 maxima of level c inside one cell.
+static int akz_grid_geometry(const afv_akaze_plan &P, float derivative_factor, AkdLevel *lv, int *gcells, int *gelems, int *lds_bytes) {
+    int cells = 0, elems = 0, lds = 0, prev_cells = 0;
+    for (int i = 0; i < P.nlevels; ++i) {
+        const float r = P.lv[i].esigma * derivative_factor;
+        const float rn = i + 1 < P.nlevels ? P.lv[i + 1].esigma * derivative_factor : r;
+        const float edge = 2.0f * std::max(r, rn) * 1.0002f + 0.01f;
+        const float ratio = powf(2.0f, (float)P.lv[i].octave);
+        AkdLevel &L = lv[i];
+        L.ginv = 1.0f / edge;
+        L.gw = (int)((float)P.w * L.ginv) + 1;
+        L.gh = (int)((float)P.h * L.ginv) + 1;
+        const int side = (int)(edge / ratio) + 2;  // pixel positions of this level along one cell edge
+        L.gcap = ((side + 1) / 2) * ((side + 1) / 2);
+        if (L.gw >= 65536 || L.gh >= 16384 || L.gcap > 255) return AFV_EUNSUPPORTED;  // akd_box packing, u8 list lengths
+        L.gcell_off = cells;
+        L.gelem_off = elems;
+        const int nc = L.gw * L.gh;
+        lds = std::max(lds, ((nc + 15) & ~15) + ((prev_cells + 15) & ~15));
+        prev_cells = nc;
+        cells += nc;
+        elems += nc * L.gcap;
+    }
+    *gcells = cells; *gelems = elems; *lds_bytes = lds;
+    return AFV_OK;
+}
+
 extern "C" int afv_akaze_create(int device, const afv_akaze_params *prm, afv_akaze **out) {
     if (!prm || !out) return AFV_EINVAL;
     *out = nullptr;
@@ -297,13 +327,24 @@ extern "C" int afv_akaze_create(int device, const afv_akaze_params *prm, afv_aka
         if (rc == AFV_OK) rc = akz_alloc(a, &a->d_kp_count, B);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->d_status, 1);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->d_kps, (size_t)AKD_ENTRY_CAP * B);
-        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.ex, (size_t)AKD_ENTRY_CAP * B);
-        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.ey, (size_t)AKD_ENTRY_CAP * B);
-        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.eresp, (size_t)AKD_ENTRY_CAP * B);
-        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.elevel, (size_t)AKD_ENTRY_CAP * B);
-        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.keep, (size_t)AKD_ENTRY_CAP * B);
-        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.cells, (size_t)2 * AKD_MAX_CELLS * AKD_CELLCAP * B);
-        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.cell_cnt, (size_t)AKD_MAX_CELLS * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.ex, (size_t)AKD_SLOT_CAP * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.ey, (size_t)AKD_SLOT_CAP * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.eresp, (size_t)AKD_SLOT_CAP * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.elevel, (size_t)AKD_SLOT_CAP * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.keep, (size_t)AKD_SLOT_CAP * B);
+        // one cell grid per level (the levels of a frame are suppressed as a pipeline), sized for the largest frame
+        // one cell grid per level (the levels of a frame are suppressed as a pipeline), sized for the largest frame
+        AkdLevel glv[16];
+        int gcells = 0, gelems = 0, glds = 0;
+        if (rc == AFV_OK) rc = akz_grid_geometry(plan, prm->derivative_factor, glv, &gcells, &gelems, &glds);
+        a->grid_cells_max = (size_t)gcells;
+        a->grid_elems_max = (size_t)gelems;
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.cells, (size_t)gelems * B);
+        a->cells_bytes = (size_t)gelems * B * sizeof(uint4);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.gcnt, (size_t)gcells * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.ticket, (size_t)8 + 16 * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.used, (size_t)16 * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.chunk_cnt, (size_t)(AKD_SLOT_CAP / 1024) * B);
     }
     {   // quadtree quotas (FeatureExtractor.cpp:97-108) for nfeatures / scaleFactor / nlevels of the akaze61 settings
         const int nl = plan.nlevels;
@@ -507,7 +548,6 @@ static int akz_detect_enqueue(afv_akaze *a) {
     D.nlevels = P.nlevels; D.W = P.w; D.H = P.h;
     D.dthreshold = a->prm.dthreshold; D.min_dthreshold = a->prm.min_dthreshold;
     int coff = 0, roff = 0;
-    float max_size = 0;
     for (int i = 0; i < P.nlevels; ++i) {
         AkdLevel &L = D.lv[i];
         L.w = P.lv[i].w; L.h = P.lv[i].h; L.octave = P.lv[i].octave;
@@ -517,18 +557,26 @@ static int akz_detect_enqueue(afv_akaze *a) {
         L.ldet = a->ldet[i];
         L.cand_off = coff; L.cand_cap = L.w * L.h / 8 + 64; L.row_off = roff;
         coff += L.cand_cap; roff += L.h;
-        max_size = std::max(max_size, L.psize);
     }
     D.cand_stride = coff; D.rows_stride = roff;
     if ((size_t)coff > a->cand_stride_max || (size_t)roff > a->rows_stride_max) return AFV_EINVAL;
-    if (max_size > AKD_CELL || P.w > 2048) return AFV_EUNSUPPORTED;  // the 3 x 3 cell neighbourhood must cover a keypoint radius
-    D.gw = (int)((float)P.w / AKD_CELL) + 1; D.gh = (int)((float)P.h / AKD_CELL) + 1;
-    if (D.gw * D.gh > AKD_MAX_CELLS) return AFV_EUNSUPPORTED;
-    D.entry_cap = AKD_ENTRY_CAP; D.kp_cap = AKD_ENTRY_CAP;
+    if (P.w > 2048) return AFV_EUNSUPPORTED;
+    {
+        const int rc = akz_grid_geometry(P, a->prm.derivative_factor, D.lv, &D.gcells, &D.gelems, &D.lds_bytes);
+        if (rc) return rc;
+        if ((size_t)D.gcells > a->grid_cells_max || (size_t)D.gelems > a->grid_elems_max || D.lds_bytes > 60 * 1024) return AFV_EUNSUPPORTED;
+    }
+    D.entry_cap = AKD_SLOT_CAP; D.kp_cap = AKD_ENTRY_CAP;
     hipStream_t st = a->stream;
     AKZ_HIPCHK(a, hipMemsetAsync(a->d_status, 0, sizeof(int), st));
+    // list elements carry a 14-bit launch epoch (k_akaze_detect.hip); the grids are wiped whenever it starts over
+    if (a->ds.epoch == 0 || a->ds.epoch >= 0x3fffu) {
+        AKZ_HIPCHK(a, hipMemsetAsync(a->ds.cells, 0, a->cells_bytes, st));
+        a->ds.epoch = 0;
+    }
+    ++a->ds.epoch;
     afv_akz_launch_candidates(&D, a->cur_frames, a->d_mask, a->d_row_start, a->d_cand, a->d_cand_resp, a->d_cand_count, a->d_status, st);
-    afv_akz_launch_suppress(&D, &a->ds, a->cur_frames, a->d_cand, a->d_cand_resp, a->d_cand_count, a->d_kps, a->d_kp_count, a->d_status, st);
+    afv_akz_launch_suppress(&D, &a->ds, a->cur_frames, a->d_cand, a->d_cand_resp, a->d_cand_count, a->d_row_start, a->d_kps, a->d_kp_count, a->d_status, st);
     AKZ_HIPCHK(a, hipGetLastError());
     a->have_keypoints = true;
     a->have_descriptors = false;
@@ -547,7 +595,7 @@ static int akz_status(afv_akaze *a) {
     AKZ_HIPCHK(a, hipMemcpy(&st, a->d_status, sizeof(int), hipMemcpyDeviceToHost));
     if (st) {
         a->last_error = st == 1 ? "candidate capacity exceeded" : st == 2 ? "grid cell capacity exceeded" : st == 3 ? "keypoint list capacity exceeded"
-                                                                                                                      : "output capacity exceeded";
+                        : st == 5 ? "level pipeline stalled (suppression)" : "output capacity exceeded";
         return AFV_ECAPACITY;
     }
     return AFV_OK;

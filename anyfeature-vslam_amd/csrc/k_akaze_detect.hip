@@ -18,10 +18,6 @@
 #include "afv_device.h"
 #include "../../include/afv_hip.h"
 
-#define AKD_CELL 10.0f       // grid cell edge in level-0 pixels; must be >= the largest keypoint radius (esigma * derivative_factor)
-#define AKD_CELLCAP 48       // list elements per cell and level: <= 25 live entries in a 10 px cell (3x3 strict maxima) + dead ones
-#define AKD_MAX_CELLS 12288  // 2 x u16 list lengths in LDS (48 KB): 1280 x 960 at 10 px cells
-
 struct AkdLevel {
     int w, h, octave, sigma_size;
     float psize, ratio;      // esigma * derivative_factor, 2^octave
@@ -29,6 +25,12 @@ struct AkdLevel {
     int cand_off;            // offset of this level's candidate slice inside a frame's candidate array
     int cand_cap;
     int row_off;             // offset of this level's rows inside a frame's row-count array
+    // uniform grid over the entries of this level (level-0 pixel coordinates).  The cell edge is at least twice the largest
+    // radius the grid is ever searched with (this level's and the next one's), so a search disc overlaps at most 2 x 2 cells;
+    // gcap = the number of strict 3 x 3 maxima that fit into a cell = the longest a cell list can get.
+    float ginv;              // 1 / cell edge
+    int gw, gh, gcap;
+    int gcell_off, gelem_off;  // offsets of this level's cells / list elements inside a frame's arrays
 };
 
 struct AkdParams {
@@ -37,7 +39,8 @@ struct AkdParams {
     AkdLevel lv[16];
     int cand_stride;   // candidates per frame (all levels)
     int rows_stride;   // rows per frame (all levels)
-    int gw, gh;        // grid geometry
+    int gcells, gelems;  // cells / list elements per frame (all levels)
+    int lds_bytes;       // list lengths (u8) of a level's own grid + length hints of the grid below, largest level pair
     int entry_cap, kp_cap;
 };
 
@@ -173,400 +176,557 @@ __global__ __launch_bounds__(AKE_T) void k_akz_cand_emit(AkdParams P, const unsi
     }
 }
 
-// ---------------- ordered suppression + upper-level filter + sub-pixel refinement: one workgroup per frame ----------------
-// Cell lists hold the entries inline (x, y, response bits, slot), so a neighbourhood scan is one global load per entry; the
-// cell counts of both grids live in LDS.  A replaced entry is not unlinked: its old list element is marked dead and a fresh
-// element goes into the list of its new cell, so every list only grows and all commits of a round run in parallel.
+// ---------------- ordered suppression + upper-level filter: one workgroup per (frame, level), levels pipelined ----------------
+// Upstream runs the levels one after the other.  A level-c candidate q only looks at (and only changes) list entries of level
+// c-1 / c inside its radius r_c, and a level-(c-1) candidate p only looks at / changes entries inside r_(c-1) of p.  So q sees
+// the final state as soon as every level-(c-1) candidate on rows <= y_q + r_c + r_(c-1) is committed, and nothing q does can be
+// seen by the level-(c-1) candidates that are still to come (they sit further down).  The eight levels of a frame therefore
+// run as a software pipeline of eight workgroups.  What keeps the result identical to the serial loop:
+//   * slots: level c appends into its own slot range [sum of the candidate counts of the levels below, + its own count), so
+//     slot order == upstream's insertion order whatever the interleaving;
+//   * one cell grid per level: grid c holds the entries whose level is c.  Only workgroup c appends to it (list lengths in its
+//     LDS).  A list element is {x, y, response, tag}: tag = slot | launch epoch << 17 | dead << 31.  A reader that does not own
+//     the grid trusts an element only if its epoch matches (the host clears the grids when the 14-bit epoch wraps, so a
+//     matching epoch means "written by this launch"); the owner also publishes its list lengths, but only as a hint that keeps
+//     the reader away from empty cells (whose lines would come cold from HBM): a length that is ahead of the elements the
+//     reader can see, or left over from the previous launch, only makes it look at elements whose epoch does not match -
+//     by the argument above never one it needs.
+//   * hand-off (cdna_hip_programming.md §6 Guideline 16): the producer's waves drain their stores, barrier, then ONE lane
+//     issues an agent-scope release fence and stores the number of committed candidates (relaxed, agent scope); the consumer's
+//     communication lane polls that number relaxed, issues ONE agent-scope acquire fence, barrier, plain loads.  Correct for any
+//     placement of the workgroups; the ticket order below only makes it fast (one frame's levels share an XCD's L2).
+//   * no dispatch-order assumption: a workgroup draws a ticket from its XCD's counter (falling over to the other XCDs' counters
+//     if its own list is used up) and ticket t of list x is (frame (t / nlevels) * 8 + x, level t % nlevels).  Whoever holds
+//     ticket t is running, and only ever waits for tickets t-1 and t-2 of the same list, whose holders started earlier.
+// A replaced entry is not unlinked: its old list element is marked dead and a fresh element goes into the list of its new cell
+// (in the replacing candidate's level grid), so every list only grows and all commits of a round run in parallel.
 struct AkdState {
-    float *ex, *ey, *eresp;   // [frame][entry_cap]
+    float *ex, *ey, *eresp;   // [frame][entry_cap]  (slot-indexed)
     int *elevel;              // [frame][entry_cap]
-    uint4 *cells;             // [frame][2][ncells][AKD_CELLCAP] {x, y, response, slot}
-    int *cell_cnt;            // [frame][ncells] scratch counts of the upper-level filter
-    unsigned char *keep;      // [frame][entry_cap]
+    uint4 *cells;             // [frame][gelems] {x, y, response, tag}; level c's lists start at lv[c].gelem_off
+    int *gcnt;                // [frame][gcells] published list lengths (hints, see above)
+    int *ticket;              // [8] per-XCD ticket counters, then [frame][16] committed candidates per level (all zeroed before the launch)
+    int *used;                // [frame][16] slots used per level
+    int *chunk_cnt;           // [frame][AKD_CHUNKS] refined keypoints per 1024-slot chunk
+    unsigned char *keep;      // [frame][entry_cap]  (set to 1 before the launch; the upper-level filter clears)
+    unsigned int epoch;       // 1 .. AKD_EPOCH_MAX, changes with every launch
 };
 
 #define AKD_T 1024
-#define AKD_PAIRS 18  // 2 grids x 3 x 3 cells per candidate
-#define AKD_R 128      // candidates per speculative round (two wavefronts decide / commit)
-#define AKD_ITERS ((AKD_R * AKD_PAIRS + AKD_T - 1) / AKD_T)
-#define AKD_DEAD 0xffffffffu
+#define AKD_COMM (AKD_T - 64)    // the lane that talks to the neighbouring levels (first lane of the last wavefront)
+#define AKD_PAIRS 8   // 2 grids x the (at most) 2 x 2 cells a candidate's disc overlaps
+#define AKD_R 128      // candidates per speculative round (two wavefronts decide / commit); AKD_R * AKD_PAIRS == AKD_T: one pair per thread
+#define AKD_DEADBIT 0x80000000u
+#define AKD_SLOTMASK 0x1ffffu   // 17 bits: entry_cap <= 131072
+#define AKD_EPOCH_MAX 0x3fffu
 #define AKD_NONE 0xffffffffffffffffull
-#define AKD_WAVE_SYNC()                                        \
-    do {                                                       \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
-        __builtin_amdgcn_wave_barrier();                       \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
-    } while (0)
+#define AKD_SPIN_LIMIT (1 << 21)  // x ~0.5 us: about a second, not forever
 
-__global__ __launch_bounds__(AKD_T) void k_akz_suppress(AkdParams P, AkdState S, const int *__restrict__ cand, const float *__restrict__ cand_resp,
-                                                        const int *__restrict__ cand_count,
-                                                        afv_keypoint *__restrict__ kps, int *__restrict__ kp_count, int *__restrict__ status) {
+__device__ __forceinline__ unsigned akd_tag_epoch(unsigned w) { return (w >> 17) & AKD_EPOCH_MAX; }
+
+// one lane: wait (relaxed polls) until *p >= need; -1 after AKD_SPIN_LIMIT tries.  The caller issues the acquire fence.
+__device__ __forceinline__ int akd_poll(const int *p, int need) {
+    for (int it = 0; it < AKD_SPIN_LIMIT; ++it) {
+        const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v >= need) return v;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    return -1;
+}
+// one lane, after a barrier behind which every wave has drained its stores: publish `v`
+__device__ __forceinline__ void akd_publish(int *p, int v) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // restated where the compiler cannot drop it (ROCm 7.2)
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the (at most 2 x 2) cells of grid G a disc of radius rq around (x, y) overlaps: x0 | y0 << 16 | (x1 - x0) << 30 | (y1 - y0) << 31
+__device__ __forceinline__ unsigned akd_box(const AkdLevel &G, float x, float y, float rq) {
+    const int x0 = min((int)(fmaxf(x - rq, 0.f) * G.ginv), G.gw - 1), x1 = min((int)((x + rq) * G.ginv), G.gw - 1);
+    const int y0 = min((int)(fmaxf(y - rq, 0.f) * G.ginv), G.gh - 1), y1 = min((int)((y + rq) * G.ginv), G.gh - 1);
+    return (unsigned)x0 | ((unsigned)y0 << 16) | ((unsigned)(x1 > x0) << 30) | ((unsigned)(y1 > y0) << 31);
+}
+__device__ __forceinline__ int akd_box_y0(unsigned b) { return (int)((b >> 16) & 0x3fffu); }
+__device__ __forceinline__ int akd_box_y1(unsigned b) { return (int)((b >> 16) & 0x3fffu) + (int)(b >> 31); }
+
+// first match of (qx, qy) in one cell list: smallest slot among the live elements within the radius; key = slot << 32 | element index
+__device__ __forceinline__ void akd_consider(const uint4 v, unsigned idx, float qx, float qy, float size2, unsigned long long &best) {
+    if (v.w & AKD_DEADBIT) return;  // replaced earlier: the entry lives on in another list
+    const float dx = qx - __uint_as_float(v.x), dy = qy - __uint_as_float(v.y);
+    if (dx * dx + dy * dy <= size2) {
+        const unsigned long long key = ((unsigned long long)(v.w & AKD_SLOTMASK) << 32) | idx;
+        best = key < best ? key : best;
+    }
+}
+
+__global__ __launch_bounds__(AKD_T, 8) void k_akz_suppress(AkdParams P, AkdState S, int nframes, const int *__restrict__ cand,
+                                                        const float *__restrict__ cand_resp, const int *__restrict__ cand_count,
+                                                        const int *__restrict__ row_start, int *__restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) char akd_smem[];
-    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int ncells = P.gw * P.gh;
-    unsigned short *s_cnt = reinterpret_cast<unsigned short *>(akd_smem);  // [2][ncells] list lengths, both grids
-    unsigned int *s_cnt32 = reinterpret_cast<unsigned int *>(akd_smem);    // the same counters as packed pairs (LDS atomics)
-    __shared__ unsigned long long s_best[AKD_R];  // per candidate of the round: slot << 32 | response bits (min = first match)
+    __shared__ int s_item;
+    const int NL = P.nlevels;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) {
+        const int share = (int)gridDim.x / 8;  // items per XCD list
+        const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);  // HW_REG_XCC_ID[3:0]
+        int item = -1;
+        for (int k = 0; k < 8 && item < 0; ++k) {
+            const int x = (xcc + k) & 7;
+            if (__hip_atomic_load(S.ticket + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= share) continue;
+            const int t = atomicAdd(S.ticket + x, 1);
+            if (t < share) item = t * 8 + x;
+        }
+        s_item = item;
+    }
+    __syncthreads();
+    if (s_item < 0) return;
+    const int f = ((s_item >> 3) / NL) * 8 + (s_item & 7), c = (s_item >> 3) % NL;
+    if (f >= nframes) return;
+    const AkdLevel L = P.lv[c];
+    const AkdLevel Lp = P.lv[c > 0 ? c - 1 : 0];  // the level below
+    const int ncells = L.gw * L.gh, pcells = c > 0 ? Lp.gw * Lp.gh : 0;
+    unsigned char *s_cnt = reinterpret_cast<unsigned char *>(akd_smem);  // [ncells] list lengths of this level's grid ...
+    unsigned int *s_cnt32 = reinterpret_cast<unsigned int *>(akd_smem);  // ... four to a word for the LDS atomics
+    unsigned char *s_pcnt = s_cnt + ((ncells + 15) & ~15);               // [pcells] length hints of the grid below, refreshed row-wise
+    __shared__ unsigned long long s_best[AKD_R];  // per candidate of the round: slot << 32 | element index (min = first match)
     __shared__ float s_sx[AKD_R], s_sy[AKD_R];
-    __shared__ int s_cx[AKD_R], s_cy[AKD_R], s_loc[AKD_R], s_wsum[AKD_T / 64];
-    __shared__ float s_mx[AKD_R], s_my[AKD_R];  // position of a candidate's first match
-    __shared__ int s_type[AKD_R], s_conf[AKD_R];
-    __shared__ int s_first[AKD_R / 64], s_apps[AKD_R / 64], s_napp[AKD_R / 64];  // per deciding wavefront: first conflict, appends, committed appends
+    __shared__ unsigned s_boxo[AKD_R], s_boxp[AKD_R];  // cells the disc overlaps in this level's grid / the grid below (akd_box)
+    __shared__ float4 s_moved[AKD_R];  // what a candidate changes if it commits: {new entry x, y, replaced entry's old x, y}, 1e30 where nothing
+    __shared__ int s_apps[AKD_R / 64], s_napp[AKD_R / 64];  // per deciding wavefront: appends, committed appends
+    __shared__ int s_stop[2];                                // first candidate of the round that must be redone (by round parity)
+    __shared__ int s_reacq;                                  // the communication lane had to wait (and acquire) this round
     float *ex = S.ex + (size_t)f * P.entry_cap, *ey = S.ey + (size_t)f * P.entry_cap, *er = S.eresp + (size_t)f * P.entry_cap;
     int *el = S.elevel + (size_t)f * P.entry_cap;
-    uint4 *cells = S.cells + (size_t)f * 2 * ncells * AKD_CELLCAP;
-    int *ccnt = S.cell_cnt + (size_t)f * ncells;
+    uint4 *cells = S.cells + (size_t)f * P.gelems;
+    int *gcnt_own = S.gcnt + (size_t)f * P.gcells + L.gcell_off;
+    const int *gcnt_prev = S.gcnt + (size_t)f * P.gcells + Lp.gcell_off;
+    int *prog_own = S.ticket + 8 + f * 16 + c;
+    const int *prog_prev = prog_own - 1;
     unsigned char *keep = S.keep + (size_t)f * P.entry_cap;
-    for (int i = tid; i < 2 * ncells; i += AKD_T) s_cnt[i] = 0;
+    const unsigned epoch = S.epoch;
+    const int n = cand_count[f * 16 + c];
+    int slot_base = 0, n_prev = 0, n_prev2 = 0;
+    for (int k = 0; k < c; ++k) {
+        n_prev2 = n_prev;
+        n_prev = cand_count[f * 16 + k];
+        slot_base += n_prev;
+    }
+    for (int i = tid; i < (ncells + 3) / 4; i += AKD_T) s_cnt32[i] = 0;
+    for (int i = tid; i < pcells; i += AKD_T) s_pcnt[i] = 0;
+    for (int i = tid; i < ncells; i += AKD_T) gcnt_own[i] = 0;
+    if (tid < AKD_R / 64) s_napp[tid] = 0;
     __syncthreads();
-    int nE = 0;
-    int cur = 0;
-    const float inv_cell = 1.0f / AKD_CELL;
+    // rows of the level below that must be final before a candidate on (scaled) row y may look: y + r_c + r_(c-1), one row spare
+    const int *rs_prev = row_start + (size_t)f * P.rows_stride + Lp.row_off;
+    const int *cd = cand + (size_t)f * P.cand_stride + L.cand_off;
+    const float *cr = cand_resp + (size_t)f * P.cand_stride + L.cand_off;
+    const float reach = L.psize + Lp.psize + 2.0f * Lp.ratio;
+    const float size2 = L.psize * L.psize;
+    const float rq = L.psize * 1.0001f + 1e-3f;  // what "dx * dx + dy * dy <= size2" can reach in float arithmetic, with room
+    const bool has_reader = c + 1 < NL;  // the last level's progress is nobody's business
+    int nE = 0;       // appends of this level so far
+    int pos = 0, par = 0;
+    int seen = 0;      // (communication lane) progress of the level below as last acquired; -1: gave up
+    int published = 0; // (communication lane)
+    int pub_cell = -1;  // cell whose list this thread extended in the previous round: its length is published one barrier later
+    int pf_pos = -1, pf_idx = 0;
+    float pf_resp = 0.f;
 #ifdef AFV_AKZ_STATS
     const long long st_t0 = wall_clock64();
-    long long st_p[4] = {0, 0, 0, 0};
+    long long st_p[6] = {0, 0, 0, 0, 0, 0};
+    int st_rounds = 0;
 #endif
-    for (int c = 0; c < P.nlevels; ++c) {
-        const AkdLevel L = P.lv[c];
-        if (c > 0) {  // the previous level's grid becomes "prev"; the other one is recycled
-            cur ^= 1;
-            for (int i = tid; i < ncells; i += AKD_T) s_cnt[cur * ncells + i] = 0;
+    while (pos < n) {
+        const int nround = min(AKD_R, n - pos);
+#ifdef AFV_AKZ_STATS
+        ++st_rounds;
+        const long long ph0 = wall_clock64();
+#endif
+        // ---- 1. the round's candidates (first AKD_R threads); the next round's are prefetched while this one is scanned.
+        //         Meanwhile the communication lane makes sure the level below is far enough ahead of the round's last candidate.
+        //         There is no barrier between a round's commit and this point: the stores of the commit drain here. ----
+        float sx = 0, sy = 0, resp = 0;
+        int ci = 0;  // the candidate's own cell
+        const bool act = tid < nround;
+        if (tid < AKD_R) {
+            if (act) {
+                int idx;
+                if (pf_pos == pos) {
+                    idx = pf_idx;
+                    resp = pf_resp;
+                } else {
+                    idx = cd[pos + tid];
+                    resp = cr[pos + tid];
+                }
+                const int iy = idx / L.w, jx = idx - iy * L.w;
+                sx = (float)jx * L.ratio;
+                sy = (float)iy * L.ratio;
+                ci = min((int)(sy * L.ginv), L.gh - 1) * L.gw + min((int)(sx * L.ginv), L.gw - 1);
+                s_boxo[tid] = akd_box(L, sx, sy, rq);
+                s_boxp[tid] = akd_box(Lp, sx, sy, rq);
+            }
+            s_sx[tid] = sx; s_sy[tid] = sy;
+            s_best[tid] = AKD_NONE;
+            if (tid == 0) s_stop[par] = nround;
+            pf_pos = pos + AKD_R;  // valid if this round commits all of its candidates (the common case)
+            if (pf_pos + tid < n) {
+                pf_idx = cd[pf_pos + tid];
+                pf_resp = cr[pf_pos + tid];
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the previous round's stores have left
+        } else if (tid == AKD_COMM && c > 0) {
+            const int row = (int)(((float)(cd[pos + nround - 1] / L.w) * L.ratio + reach) / Lp.ratio) + 1;  // first row of the level below that may still be open
+            const int need = row >= Lp.h ? n_prev : min(rs_prev[row], n_prev);
+            s_reacq = (seen >= 0 && seen < need) ? 1 : 0;
+            if (seen >= 0 && seen < need) {
+                // waiting costs an acquire (this CU's L1 is dropped): ask for two rounds more than needed so that a level running
+                // in lock-step with the one below does not pay it every round.  Here and only here: no other wavefront has a
+                // grid load in flight between a round's commit and the barrier below.
+                seen = akd_poll(prog_prev, min(n_prev, need + 2 * AKD_R));
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (seen < 0) atomicExch(status, 5);  // the level below never got there: report and run on without waiting
+            }
+        }
+        // length hints of the cell rows (grid below) this round can touch: raster order, first .. last candidate.  Read before the
+        // barrier, i.e. possibly before the communication lane's acquire - then they are read again behind it.  Agent-scope
+        // loads (L2-served): these loads may be in flight while that acquire drops the L1, and nothing stale may settle there.
+        int h0 = 0, h1 = 0;
+        if (c > 0) {
+            const float yf = (float)(cd[pos] / L.w) * L.ratio, yl = (float)(cd[pos + nround - 1] / L.w) * L.ratio;
+            h0 = min((int)(fmaxf(yf - rq, 0.f) * Lp.ginv), Lp.gh - 1) * Lp.gw;
+            h1 = (min((int)((yl + rq) * Lp.ginv), Lp.gh - 1) + 1) * Lp.gw;
+            for (int i = h0 + tid; i < h1; i += AKD_T)
+                s_pcnt[i] = (unsigned char)min(__hip_atomic_load(gcnt_prev + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 255);
+        }
+        __syncthreads();
+#ifdef AFV_AKZ_STATS
+        const long long ph1 = wall_clock64();
+#endif
+#pragma unroll
+        for (int w = 0; w < AKD_R / 64; ++w) nE += s_napp[w];  // the previous round's appends
+        // every commit of the previous round is behind the barrier: the lengths of the lists it extended can go out (plain
+        // stores; drained before the barrier after the scan, published with the round's count)
+        if (tid < AKD_R && pub_cell >= 0) {
+            gcnt_own[pub_cell] = s_cnt[pub_cell];
+            pub_cell = -1;
+        }
+        if (c > 0 && s_reacq) {
+            for (int i = h0 + tid; i < h1; i += AKD_T)
+                s_pcnt[i] = (unsigned char)min(__hip_atomic_load(gcnt_prev + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 255);
             __syncthreads();
         }
-        const int prv = cur ^ 1;
-        const int *cd = cand + (size_t)f * P.cand_stride + L.cand_off;
-        const float *cr = cand_resp + (size_t)f * P.cand_stride + L.cand_off;
-        const int n = cand_count[f * 16 + c];
-        const float size2 = L.psize * L.psize;
-        int pos = 0;
-        int pf_pos = -1, pf_idx = 0;
-        float pf_resp = 0.f;
-#ifdef AFV_AKZ_STATS
-        int st_rounds = 0;
-#endif
-        while (pos < n) {
-#ifdef AFV_AKZ_STATS
-            ++st_rounds;
-#endif
-            const int nround = min(AKD_R, n - pos);
-#ifdef AFV_AKZ_STATS
-            const long long ph0 = wall_clock64();
-#endif
-            // ---- 1. the round's candidates (first AKD_R threads); the next round's are prefetched while this one is scanned ----
-            float sx = 0, sy = 0, resp = 0;
-            int cx = 0, cy = 0;
-            const bool act = tid < nround;
-            if (tid < AKD_R) {
-                if (act) {
-                    int idx;
-                    if (pf_pos == pos) {
-                        idx = pf_idx;
-                        resp = pf_resp;
-                    } else {
-                        idx = cd[pos + tid];
-                        resp = cr[pos + tid];
-                    }
-                    const int iy = idx / L.w, jx = idx - iy * L.w;
-                    sx = (float)jx * L.ratio;
-                    sy = (float)iy * L.ratio;
-                    cx = min((int)(sx * inv_cell), P.gw - 1);
-                    cy = min((int)(sy * inv_cell), P.gh - 1);
-                }
-                s_sx[tid] = sx; s_sy[tid] = sy; s_cx[tid] = cx; s_cy[tid] = cy;
-                s_best[tid] = AKD_NONE;
-                pf_pos = pos + AKD_R;  // valid if this round commits all of its candidates (the common case)
-                if (pf_pos + tid < n) {
-                    pf_idx = cd[pf_pos + tid];
-                    pf_resp = cr[pf_pos + tid];
-                }
-            }
-            __syncthreads();
-#ifdef AFV_AKZ_STATS
-            const long long ph1 = wall_clock64();
-#endif
-            // ---- 2. neighbourhood scan: the (candidate, cell) pairs of the round spread over the whole workgroup ----
-            unsigned long long lbest[AKD_ITERS];
-            int lloc[AKD_ITERS];
-            float lmx[AKD_ITERS], lmy[AKD_ITERS];
-#pragma unroll
-            for (int it = 0; it < AKD_ITERS; ++it) {
-                lbest[it] = AKD_NONE;
-                lloc[it] = 0;
-                lmx[it] = 0.f;
-                lmy[it] = 0.f;
-                const int t = tid + it * AKD_T;
-                if (t >= nround * AKD_PAIRS) continue;
-                const int q = t / AKD_PAIRS, k = t - q * AKD_PAIRS;
-                const int g = k / 9, kk = k - g * 9;
-                if (g == 0 && c == 0) continue;
-                const int xx = s_cx[q] + (kk % 3) - 1, yy = s_cy[q] + (kk / 3) - 1;
-                if (xx < 0 || yy < 0 || xx >= P.gw || yy >= P.gh) continue;
-                const int gi = g == 0 ? prv : cur;
-                const int cell = yy * P.gw + xx;
-                const int cn = min((int)s_cnt[gi * ncells + cell], AKD_CELLCAP);
-                if (cn == 0) continue;
-                const size_t lb = ((size_t)gi * ncells + cell) * AKD_CELLCAP;
-                const float qx = s_sx[q], qy = s_sy[q];
-                unsigned long long best = AKD_NONE;
-                int beste = 0;
-                float bx = 0.f, by = 0.f;
+        // ---- 2. neighbourhood scan: one (candidate, cell) pair per thread ----
+        do {
+            if (tid >= nround * AKD_PAIRS) break;
+            const int q = tid >> 3, k = tid & 7;
+            const bool below = k < 4;
+            if (below && c == 0) break;
+            const unsigned box = below ? s_boxp[q] : s_boxo[q];
+            if (((k & 1) && !((box >> 30) & 1u)) || ((k & 2) && !(box >> 31))) break;
+            const float qx = s_sx[q], qy = s_sy[q];
+            unsigned long long best = AKD_NONE;
+            // one 16-byte load per element: a wavefront's 64 lanes look at 64 different lists, and the lists are short
+            if (below) {  // hinted length, every element checked against the epoch
+                const int cell = (akd_box_y0(box) + ((k >> 1) & 1)) * Lp.gw + (int)(box & 0xffffu) + (k & 1);
+                const int cn = min((int)s_pcnt[cell], Lp.gcap);
+                const unsigned lb = (unsigned)Lp.gelem_off + (unsigned)cell * Lp.gcap;
                 for (int e = 0; e < cn; ++e) {
                     const uint4 v = cells[lb + e];
-                    if (v.w == AKD_DEAD) continue;  // replaced earlier: the entry lives on in another list
-                    const float dx = qx - __uint_as_float(v.x), dy = qy - __uint_as_float(v.y);
-                    if (dx * dx + dy * dy <= size2) {
-                        const unsigned long long key = ((unsigned long long)v.w << 32) | v.z;
-                        if (key < best) {
-                            best = key;
-                            beste = e;
-                            bx = __uint_as_float(v.x);
-                            by = __uint_as_float(v.y);
-                        }
-                    }
+                    if (akd_tag_epoch(v.w) != epoch) break;
+                    akd_consider(v, lb + e, qx, qy, size2, best);
                 }
-                if (best != AKD_NONE) {
-                    atomicMin(&s_best[q], best);
-                    lbest[it] = best;
-                    lloc[it] = (int)lb + beste;
-                    lmx[it] = bx;
-                    lmy[it] = by;
-                }
+            } else {
+                const int cell = (akd_box_y0(box) + ((k >> 1) & 1)) * L.gw + (int)(box & 0xffffu) + (k & 1);
+                const int cn = min((int)s_cnt[cell], L.gcap);
+                const unsigned lb = (unsigned)L.gelem_off + (unsigned)cell * L.gcap;
+                for (int e = 0; e < cn; ++e) akd_consider(cells[lb + e], lb + e, qx, qy, size2, best);
             }
-            __syncthreads();
+            if (best != AKD_NONE) atomicMin(&s_best[q], best);
+        } while (false);
+        if (tid < AKD_R) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the published lengths have left
+        __syncthreads();
+        // communication lane: everything before this round is committed and drained.  The L2 write-back is started here and
+        // runs behind the decision phases; the count is stored once it is through.
+        const bool publish = tid == AKD_COMM && has_reader && pos > published;
+        if (publish) asm volatile("buffer_wbl2 sc1" ::: "memory");
 #ifdef AFV_AKZ_STATS
-            const long long ph2 = wall_clock64();
+        const long long ph2 = wall_clock64();
 #endif
-            // the thread that found a candidate's first match publishes where that list element sits (slots are unique)
-#pragma unroll
-            for (int it = 0; it < AKD_ITERS; ++it) {
-                if (lbest[it] != AKD_NONE) {
-                    const int q = (tid + it * AKD_T) / AKD_PAIRS;
-                    if (s_best[q] == lbest[it]) {
-                        s_loc[q] = lloc[it];
-                        s_mx[q] = lmx[it];
-                        s_my[q] = lmy[it];
-                    }
-                }
-            }
-            __syncthreads();
-#ifdef AFV_AKZ_STATS
-            const long long ph3 = wall_clock64();
-#endif
-            // ---- 3. decisions, exact conflict test against the earlier lanes of the round, commit (wave 0) ----
-            // 3a. decisions (first AKD_R threads)
-            int first = -1, type = 0;  // type: 0 drop, 1 append, 2 replace `first`
+        // ---- 3. decisions, exact conflict test against the earlier candidates of the round, commit ----
+        // 3a. decisions (first AKD_R threads): the first match is re-read from its list (response, position, tag)
+        int first = -1, type = 0;  // type: 0 drop, 1 append, 2 replace `first`
+        unsigned mloc = 0, mtag = 0;
+        if (tid < AKD_R) {
+            const unsigned long long b = s_best[tid];
             float oex = 0, oey = 0;
-            if (tid < AKD_R) {
-                const unsigned long long b = s_best[tid];
-                first = (act && b != AKD_NONE) ? (int)(b >> 32) : -1;
-                if (act) {
-                    if (first < 0) type = 1;
-                    else if (resp > __uint_as_float((unsigned int)(b & 0xffffffffu))) {
+            if (act) {
+                if (b == AKD_NONE) {
+                    type = 1;
+                } else {
+                    first = (int)(b >> 32);
+                    mloc = (unsigned)(b & 0xffffffffu);
+                    const uint4 v = cells[mloc];
+                    mtag = v.w;
+                    if (resp > __uint_as_float(v.z)) {
                         type = 2;
-                        oex = s_mx[tid];
-                        oey = s_my[tid];
+                        oex = __uint_as_float(v.x);
+                        oey = __uint_as_float(v.y);
                     }
                 }
-                s_type[tid] = type;
-                s_mx[tid] = oex;
-                s_my[tid] = oey;
-                s_conf[tid] = 0;
-                const unsigned long long apm = __ballot(type == 1);
-                if (lane == 0) s_apps[tid >> 6] = __popcll(apm);
             }
-            __syncthreads();
-            // 3b. a candidate's decision stands unless an earlier candidate of the round changes what its search sees: a new /
-            //     moved entry inside its radius, or a replaced entry that used to lie inside its radius.  The ordered pairs (j < i)
-            //     are spread over the workgroup (AKD_T / AKD_R threads per candidate i, strided over the earlier candidates j).
-            {
-                constexpr int PER = AKD_T / AKD_R;  // threads per candidate
-                const int i = tid / PER;
-                if (i < nround) {
-                    const float xi = s_sx[i], yi = s_sy[i];
-                    bool hit = false;
-                    for (int j = tid % PER; j < i; j += PER) {
-                        const int tj = s_type[j];
-                        if (tj == 0) continue;
-                        const float dx = xi - s_sx[j], dy = yi - s_sy[j];
-                        hit = hit || (dx * dx + dy * dy <= size2);
-                        if (tj == 2) {
-                            const float ux = xi - s_mx[j], uy = yi - s_my[j];
-                            hit = hit || (ux * ux + uy * uy <= size2);
-                        }
-                    }
-                    if (hit) s_conf[i] = 1;
-                }
-            }
-            __syncthreads();
-            // 3c. commit up to the first conflicting candidate (first AKD_R threads = AKD_R / 64 wavefronts)
-            if (tid < AKD_R) {
-                const bool conflict = act && s_conf[tid] != 0;
-                const unsigned long long cm = __ballot(conflict);
-                if (lane == 0) s_first[tid >> 6] = cm ? (tid & ~63) + (int)__builtin_ctzll(cm) : AKD_R;
-            }
-            __syncthreads();
-            int stop = nround;
-#pragma unroll
-            for (int w = 0; w < AKD_R / 64; ++w) stop = min(stop, s_first[w]);
-            if (tid < AKD_R) {
-                const bool commit = act && tid < stop && type != 0;
-                const unsigned long long am = __ballot(commit && type == 1);
-                if (commit) {
-                    int slot;
-                    if (type == 1) {
-                        // appends of the earlier deciding wavefronts all commit when this wavefront commits anything
-                        int before = 0;
-                        for (int w = 0; w < (tid >> 6); ++w) before += s_apps[w];
-                        slot = nE + before + __popcll(am & ((1ull << lane) - 1ull));
-                    } else {
-                        slot = first;
-                        cells[s_loc[tid]].w = AKD_DEAD;
-                    }
-                    if (slot < P.entry_cap) {
-                        ex[slot] = sx;
-                        ey[slot] = sy;
-                        er[slot] = resp;
-                        el[slot] = c;
-                        // list slot from an LDS atomic on the packed 16-bit counters (several commits may share a cell)
-                        const int ci = cur * ncells + cy * P.gw + cx;
-                        const unsigned int old = atomicAdd(&s_cnt32[ci >> 1], (ci & 1) ? 0x10000u : 1u);
-                        const int cn = (int)((old >> ((ci & 1) * 16)) & 0xffffu);
-                        if (cn < AKD_CELLCAP) {
-                            cells[(size_t)ci * AKD_CELLCAP + cn] = make_uint4(__float_as_uint(sx), __float_as_uint(sy), __float_as_uint(resp), (unsigned)slot);
-                        } else {
-                            atomicExch(status, 2);
-                        }
-                    } else {
-                        atomicExch(status, 3);
-                    }
-                }
-                if (lane == 0) s_napp[tid >> 6] = __popcll(am);
-            }
-            __threadfence_block();
-            __syncthreads();
-            pos += stop;
-#pragma unroll
-            for (int w = 0; w < AKD_R / 64; ++w) nE += s_napp[w];
-            nE = min(nE, P.entry_cap);
+            s_moved[tid] = make_float4(type != 0 ? sx : 1e30f, sy, type == 2 ? oex : 1e30f, oey);
+            const unsigned long long apm = __ballot(type == 1);
+            if (lane == 0) s_apps[tid >> 6] = __popcll(apm);
+        }
+        __syncthreads();
 #ifdef AFV_AKZ_STATS
-            { const long long ph4 = wall_clock64(); st_p[0] += ph1 - ph0; st_p[1] += ph2 - ph1; st_p[2] += ph3 - ph2; st_p[3] += ph4 - ph3; }
+        const long long ph3 = wall_clock64();
 #endif
+        // 3b. a candidate's decision stands unless an earlier candidate of the round changes what its search sees: a new /
+        //     moved entry inside its radius, or a replaced entry that used to lie inside its radius.  The round commits up to
+        //     the first candidate that was hit.  Rows i and AKD_R - 1 - i of the (j < i) triangle have AKD_R - 1 pairs together:
+        //     16 threads per such row pair, every thread the same number of pairs, one LDS read per pair.
+        {
+            const int rp = tid >> 4, part = tid & 15;  // AKD_T / 16 = AKD_R / 2 row pairs
+            const int i1 = rp, i2 = AKD_R - 1 - rp;
+            const float x1 = s_sx[i1], y1 = s_sy[i1], x2 = s_sx[i2], y2 = s_sy[i2];
+            bool hit1 = false, hit2 = false;
+#pragma unroll
+            for (int it = 0; it < AKD_R / 16; ++it) {  // all LDS reads in flight together
+                const int m = part + 16 * it;
+                if (m >= AKD_R - 1) break;
+                const bool lo = m < i1;
+                const float4 o = s_moved[lo ? m : m - i1];
+                const float xi = lo ? x1 : x2, yi = lo ? y1 : y2;
+                const float dx = xi - o.x, dy = yi - o.y, ux = xi - o.z, uy = yi - o.w;
+                const bool hit = (dx * dx + dy * dy <= size2) || (ux * ux + uy * uy <= size2);
+                hit1 = hit1 || (hit && lo);
+                hit2 = hit2 || (hit && !lo);
+            }
+            if (hit1 && i1 < nround) atomicMin(&s_stop[par], i1);
+            if (hit2 && i2 < nround) atomicMin(&s_stop[par], i2);
         }
 #ifdef AFV_AKZ_STATS
-        if (tid == 0 && f == 0) printf("akz_suppress: level %d candidates %d rounds %d entries %d\n", c, n, st_rounds, nE);
+        const long long ph3a = wall_clock64();
+#endif
+        __syncthreads();
+#ifdef AFV_AKZ_STATS
+        const long long ph3b = wall_clock64();
+#endif
+        if (publish) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(prog_own, pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            published = pos;
+        }
+        const int stop = s_stop[par];
+        // 3c. commit (first AKD_R threads = AKD_R / 64 wavefronts).  No barrier follows: the next round's first phase touches
+        //     nothing this one still reads (s_stop alternates), and s_napp is read behind the next barrier.
+        if (tid < AKD_R) {
+            const bool commit = act && tid < stop && type != 0;
+            const unsigned long long am = __ballot(commit && type == 1);
+            if (commit) {
+                int slot;
+                if (type == 1) {
+                    // appends of the earlier deciding wavefronts all commit when this wavefront commits anything
+                    int before = 0;
+                    for (int w = 0; w < (tid >> 6); ++w) before += s_apps[w];
+                    slot = slot_base + nE + before + __popcll(am & ((1ull << lane) - 1ull));
+                } else {
+                    slot = first;
+                    cells[mloc].w = mtag | AKD_DEADBIT;
+                }
+                if (slot < P.entry_cap) {
+                    ex[slot] = sx;
+                    ey[slot] = sy;
+                    er[slot] = resp;
+                    el[slot] = c;
+                    // list slot from an LDS atomic on the packed 8-bit counters (several commits may share a cell)
+                    const unsigned int old = atomicAdd(&s_cnt32[ci >> 2], 1u << ((ci & 3) * 8));
+                    const int cn = (int)((old >> ((ci & 3) * 8)) & 0xffu);
+                    if (cn < L.gcap) {
+                        cells[(unsigned)L.gelem_off + (unsigned)ci * L.gcap + cn] =
+                            make_uint4(__float_as_uint(sx), __float_as_uint(sy), __float_as_uint(resp), (unsigned)slot | (epoch << 17));
+                        pub_cell = ci;
+                    } else {
+                        atomicExch(status, 2);
+                    }
+                } else {
+                    atomicExch(status, 3);
+                }
+            }
+            if (lane == 0) s_napp[tid >> 6] = __popcll(am);
+        }
+        pos += stop;
+        par ^= 1;
+#ifdef AFV_AKZ_STATS
+        { const long long ph4 = wall_clock64(); st_p[0] += ph1 - ph0; st_p[1] += ph2 - ph1; st_p[2] += ph3 - ph2; st_p[3] += ph4 - ph3; st_p[4] += ph3a - ph3; st_p[5] += ph3b - ph3a; }
 #endif
     }
+    // the last round's stores and list lengths, then "this level is final"; wait for the two levels below to be final as well
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < AKD_R / 64; ++w) nE += s_napp[w];
+    if (tid < AKD_R && pub_cell >= 0) gcnt_own[pub_cell] = s_cnt[pub_cell];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == AKD_COMM) {
+        S.used[f * 16 + c] = nE;
+        if (has_reader) akd_publish(prog_own, n);
+        if (c > 0 && seen >= 0) {  // a level with few candidates finishes before the one below it
+            int v = akd_poll(prog_prev, n_prev);
+            if (c > 1 && v >= 0) v = akd_poll(prog_prev - 1, n_prev2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (v < 0) atomicExch(status, 5);
+        }
+    }
+    __syncthreads();
 #ifdef AFV_AKZ_STATS
     const long long st_t1 = wall_clock64();
 #endif
-    // ---- "Now filter points with the upper scale level": entry i of level c is repeated if a LATER entry of level c+1 lies
-    //      within size_i and has a larger response.  Per level pair: grid of the level c+1 entries, then one thread per entry.
-    for (int i = tid; i < nE; i += AKD_T) keep[i] = 1;
-    for (int c = 0; c + 1 < P.nlevels; ++c) {
-        for (int i = tid; i < ncells; i += AKD_T) ccnt[i] = 0;
-        __threadfence_block();
-        __syncthreads();
-        for (int i = tid; i < nE; i += AKD_T)
-            if (el[i] == c + 1) {
-                const int cell = min((int)(ey[i] * inv_cell), P.gh - 1) * P.gw + min((int)(ex[i] * inv_cell), P.gw - 1);
-                const int k = atomicAdd(&ccnt[cell], 1);
-                if (k < AKD_CELLCAP) cells[(size_t)cell * AKD_CELLCAP + k] = make_uint4(__float_as_uint(ex[i]), __float_as_uint(ey[i]), __float_as_uint(er[i]), (unsigned)i);
-                else atomicExch(status, 2);
-            }
-        __threadfence_block();
-        __syncthreads();
-        const float sz = P.lv[c].psize, sz2 = sz * sz;
-        for (int i = tid; i < nE; i += AKD_T)
-            if (el[i] == c) {
-                const float x = ex[i], y = ey[i], r = er[i];
-                const int cx = min((int)(x * inv_cell), P.gw - 1), cy = min((int)(y * inv_cell), P.gh - 1);
+    // ---- "Now filter points with the upper scale level": entry i of level a is repeated if a LATER entry of level a+1 lies
+    //      within size_a and has a larger response.  Grid a holds exactly the level-a entries once level a+1 has run, grid a+1
+    //      the level-(a+1) entries once level a+2 has run: pair (c-2, c-1) is closed here, after this level's own rounds; the
+    //      last level also closes (c-1, c).
+    for (int a = c - 2; a <= (c == NL - 1 ? c - 1 : c - 2); ++a) {
+        if (a < 0) continue;
+        const AkdLevel A = P.lv[a], B = P.lv[a + 1];
+        const float sz2 = A.psize * A.psize, ra = A.psize * 1.0001f + 1e-3f;
+        const int *gA = S.gcnt + (size_t)f * P.gcells + A.gcell_off, *gB = S.gcnt + (size_t)f * P.gcells + B.gcell_off;
+        for (int cell = tid; cell < A.gw * A.gh; cell += AKD_T) {
+            const int cna = min(gA[cell], A.gcap);
+            for (int e0 = 0; e0 < cna; ++e0) {
+                const uint4 u = cells[(unsigned)A.gelem_off + (unsigned)cell * A.gcap + e0];
+                if (akd_tag_epoch(u.w) != epoch) break;
+                if (u.w & AKD_DEADBIT) continue;
+                const float x = __uint_as_float(u.x), y = __uint_as_float(u.y), r = __uint_as_float(u.z);
+                const unsigned i = u.w & AKD_SLOTMASK;
+                const unsigned box = akd_box(B, x, y, ra);
                 bool rep = false;
-                for (int yy = max(cy - 1, 0); yy <= min(cy + 1, P.gh - 1) && !rep; ++yy)
-                    for (int xx = max(cx - 1, 0); xx <= min(cx + 1, P.gw - 1) && !rep; ++xx) {
-                        const int cell = yy * P.gw + xx;
-                        const int cn = min(ccnt[cell], AKD_CELLCAP);
-                        for (int e = 0; e < cn; ++e) {
-                            const uint4 v = cells[(size_t)cell * AKD_CELLCAP + e];
-                            if ((int)v.w <= i) continue;
-                            const float dx = x - __uint_as_float(v.x), dy = y - __uint_as_float(v.y);
-                            if (dx * dx + dy * dy <= sz2 && r < __uint_as_float(v.z)) {
-                                rep = true;
-                                break;
-                            }
+                for (int k = 0; k < 4 && !rep; ++k) {
+                    if (((k & 1) && !((box >> 30) & 1u)) || ((k & 2) && !(box >> 31))) continue;
+                    const int c2 = (akd_box_y0(box) + (k >> 1)) * B.gw + (int)(box & 0xffffu) + (k & 1);
+                    const int cnb = min(gB[c2], B.gcap);
+                    const unsigned lb = (unsigned)B.gelem_off + (unsigned)c2 * B.gcap;
+                    for (int e = 0; e < cnb; ++e) {
+                        const uint4 v = cells[lb + e];
+                        if (akd_tag_epoch(v.w) != epoch) break;
+                        if ((v.w & AKD_DEADBIT) || (v.w & AKD_SLOTMASK) <= i) continue;
+                        const float dx = x - __uint_as_float(v.x), dy = y - __uint_as_float(v.y);
+                        if (dx * dx + dy * dy <= sz2 && r < __uint_as_float(v.z)) {
+                            rep = true;
+                            break;
                         }
                     }
+                }
                 if (rep) keep[i] = 0;
             }
-        __threadfence_block();
-        __syncthreads();
+        }
     }
 #ifdef AFV_AKZ_STATS
-    const long long st_t2 = wall_clock64();
+    if (tid == 0 && f == 0)
+        printf("akz_suppress level %d: candidates %d rounds %d appends %d | us: rounds %lld upper %lld | per-round parts: load+wait %lld scan %lld decide %lld conflicts+commit %lld (test %lld barrier %lld)\n", c, n,
+               st_rounds, nE, (st_t1 - st_t0) / 100, (wall_clock64() - st_t1) / 100, st_p[0] / 100, st_p[1] / 100, st_p[2] / 100, st_p[3] / 100, st_p[4] / 100, st_p[5] / 100);
 #endif
-    // ---- Do_Subpixel_Refinement + ordered compaction ----
-    int nout = 0;
-    for (int i0 = 0; i0 < nE; i0 += AKD_T) {
-        const int i = i0 + tid;
-        bool ok = i < nE && keep[i] != 0;
-        float kx = 0, ky = 0, ksize = 0, kresp = 0;
-        int koct = 0, klev = 0;
-        if (ok) {
-            klev = el[i];
-            const AkdLevel L = P.lv[klev];
-            koct = L.octave;
-            kresp = er[i];
-            const int x = akd_fround(ex[i] / L.ratio), y = akd_fround(ey[i] / L.ratio), w = L.w;
-            const float *D = L.ldet + (size_t)f * L.w * L.h;
+}
+
+// ---------------- Do_Subpixel_Refinement + ordered compaction over the slot space, two passes ----------------
+// pass A: one thread per slot: level range -> used? kept? -> the 2x2 solve; the refined position goes back into ex / ey, the
+//         verdict into keep, the number of survivors of every 1024-slot chunk into chunk_cnt
+// pass B: chunk offset = sum of the earlier chunks' counts; survivors written in slot order
+#define AKD_CHUNK 1024
+__global__ __launch_bounds__(AKD_CHUNK) void k_akz_refine_a(AkdParams P, AkdState S, const int *__restrict__ cand_count) {
+    __shared__ int s_wsum[AKD_CHUNK / 64];
+    const int f = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int slot = chunk * AKD_CHUNK + tid;
+    float *ex = S.ex + (size_t)f * P.entry_cap, *ey = S.ey + (size_t)f * P.entry_cap;
+    unsigned char *keep = S.keep + (size_t)f * P.entry_cap;
+    bool ok = false;
+    {
+        int base = 0;
+        for (int k = 0; k < P.nlevels; ++k) {  // slot ranges: level k appended into [base, base + candidates of k)
+            const int nk = cand_count[f * 16 + k];
+            if (slot >= base && slot - base < S.used[f * 16 + k]) ok = true;
+            base += nk;
+        }
+    }
+    ok = ok && slot < P.entry_cap && keep[slot] != 0;
+    if (ok) {
+        const AkdLevel L = P.lv[S.elevel[(size_t)f * P.entry_cap + slot]];
+        const int x = akd_fround(ex[slot] / L.ratio), y = akd_fround(ey[slot] / L.ratio), w = L.w;
+        const float *D = L.ldet + (size_t)f * L.w * L.h;
 #define LD(yy, xx) D[(size_t)(yy) * w + (xx)]
-            const float Dx = (float)(0.5 * (double)(LD(y, x + 1) - LD(y, x - 1)));
-            const float Dy = (float)(0.5 * (double)(LD(y + 1, x) - LD(y - 1, x)));
-            const float Dxx = (float)((double)(LD(y, x + 1) + LD(y, x - 1)) - 2.0 * (double)LD(y, x));
-            const float Dyy = (float)((double)(LD(y + 1, x) + LD(y - 1, x)) - 2.0 * (double)LD(y, x));
-            const float Dxy =
-                (float)(0.25 * (double)(LD(y + 1, x + 1) + LD(y - 1, x - 1)) - 0.25 * (double)(LD(y - 1, x + 1) + LD(y + 1, x - 1)));
+        const float Dx = (float)(0.5 * (double)(LD(y, x + 1) - LD(y, x - 1)));
+        const float Dy = (float)(0.5 * (double)(LD(y + 1, x) - LD(y - 1, x)));
+        const float Dxx = (float)((double)(LD(y, x + 1) + LD(y, x - 1)) - 2.0 * (double)LD(y, x));
+        const float Dyy = (float)((double)(LD(y + 1, x) + LD(y - 1, x)) - 2.0 * (double)LD(y, x));
+        const float Dxy = (float)(0.25 * (double)(LD(y + 1, x + 1) + LD(y - 1, x - 1)) - 0.25 * (double)(LD(y - 1, x + 1) + LD(y + 1, x - 1)));
 #undef LD
-            const double det = (double)Dxx * (double)Dyy - (double)Dxy * (double)Dxy;
-            if (det == 0.0) {
+        const double det = (double)Dxx * (double)Dyy - (double)Dxy * (double)Dxy;
+        if (det == 0.0) {
+            ok = false;
+        } else {
+            const double b0 = -(double)Dx, b1 = -(double)Dy, inv = 1.0 / det;
+            const float d0 = (float)((b0 * (double)Dyy - b1 * (double)Dxy) * inv);
+            const float d1 = (float)((b1 * (double)Dxx - b0 * (double)Dxy) * inv);
+            if (fabsf(d0) <= 1.0f && fabsf(d1) <= 1.0f) {
+                const float power = (float)(1 << L.octave);
+                ex[slot] = ((float)x + d0) * power;
+                ey[slot] = ((float)y + d1) * power;
+            } else {
                 ok = false;
-            } else {
-                const double b0 = -(double)Dx, b1 = -(double)Dy, inv = 1.0 / det;
-                const float d0 = (float)((b0 * (double)Dyy - b1 * (double)Dxy) * inv);
-                const float d1 = (float)((b1 * (double)Dxx - b0 * (double)Dxy) * inv);
-                if (fabsf(d0) <= 1.0f && fabsf(d1) <= 1.0f) {
-                    const float power = (float)(1 << L.octave);
-                    kx = ((float)x + d0) * power;
-                    ky = ((float)y + d1) * power;
-                    ksize = L.psize * 2.0f;
-                } else {
-                    ok = false;
-                }
             }
         }
-        const unsigned long long m = __ballot(ok);
-        if (lane == 0) s_wsum[tid >> 6] = __popcll(m);
-        __syncthreads();
-        int base = nout, tot = 0;
-        for (int w = 0; w < AKD_T / 64; ++w) {
-            if (w < (tid >> 6)) base += s_wsum[w];
-            tot += s_wsum[w];
-        }
-        if (ok) {
-            const int o = base + __popcll(m & ((1ull << lane) - 1ull));
-            if (o < P.kp_cap) {
-                afv_keypoint k;
-                k.x = kx; k.y = ky; k.size = ksize; k.angle = 0.0f; k.response = kresp; k.octave = koct; k.class_id = klev;
-                kps[(size_t)f * P.kp_cap + o] = k;
-            } else {
-                atomicExch(status, 4);
-            }
-        }
-        nout += tot;
-        __syncthreads();
     }
-#ifdef AFV_AKZ_STATS
-    if (tid == 0 && f == 0) printf("akz_suppress phases (us at 100 MHz): rounds %lld upper %lld subpixel %lld | per-round parts: load %lld scan %lld publish %lld decide+commit %lld\n", (st_t1 - st_t0) / 100, (st_t2 - st_t1) / 100, (wall_clock64() - st_t2) / 100, st_p[0] / 100, st_p[1] / 100, st_p[2] / 100, st_p[3] / 100);
-#endif
-    if (tid == 0) kp_count[f] = min(nout, P.kp_cap);
+    if (slot < P.entry_cap) keep[slot] = ok ? 1 : 0;
+    const unsigned long long m = __ballot(ok);
+    if (lane == 0) s_wsum[tid >> 6] = __popcll(m);
+    __syncthreads();
+    if (tid == 0) {
+        int tot = 0;
+        for (int w = 0; w < AKD_CHUNK / 64; ++w) tot += s_wsum[w];
+        S.chunk_cnt[(size_t)f * gridDim.x + chunk] = tot;
+    }
+}
+
+__global__ __launch_bounds__(AKD_CHUNK) void k_akz_refine_b(AkdParams P, AkdState S, afv_keypoint *__restrict__ kps, int *__restrict__ kp_count,
+                                                            int *__restrict__ status) {
+    __shared__ int s_wsum[AKD_CHUNK / 64], s_base, s_total;
+    const int f = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x, tid = threadIdx.x, lane = tid & 63;
+    const int slot = chunk * AKD_CHUNK + tid;
+    const int *cc = S.chunk_cnt + (size_t)f * nchunks;
+    if (tid < 64) {  // nchunks <= 256: four per lane
+        int before = 0, all = 0;
+        for (int j = lane; j < nchunks; j += 64) {
+            const int v = cc[j];
+            all += v;
+            if (j < chunk) before += v;
+        }
+        before = afv_wave_incl_scan(before);
+        all = afv_wave_incl_scan(all);
+        if (lane == 63) {
+            s_base = before;
+            s_total = all;
+        }
+    }
+    const bool ok = slot < P.entry_cap && S.keep[(size_t)f * P.entry_cap + slot] != 0;
+    const unsigned long long m = __ballot(ok);
+    if (lane == 0) s_wsum[tid >> 6] = __popcll(m);
+    __syncthreads();
+    if (chunk == 0 && tid == 0) {
+        kp_count[f] = min(s_total, P.kp_cap);
+        if (s_total > P.kp_cap) atomicExch(status, 4);
+    }
+    if (!ok) return;
+    int o = s_base + __popcll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < (tid >> 6); ++w) o += s_wsum[w];
+    if (o >= P.kp_cap) return;
+    const size_t si = (size_t)f * P.entry_cap + slot;
+    const int klev = S.elevel[si];
+    const AkdLevel L = P.lv[klev];
+    afv_keypoint k;
+    k.x = S.ex[si]; k.y = S.ey[si]; k.size = L.psize * 2.0f; k.angle = 0.0f; k.response = S.eresp[si]; k.octave = L.octave; k.class_id = klev;
+    kps[(size_t)f * P.kp_cap + o] = k;
 }
 
 extern "C" void afv_akz_launch_candidates(const AkdParams *P, int nframes, unsigned long long *mask, int *row_start, int *cand, float *cand_resp,
@@ -579,8 +739,14 @@ extern "C" void afv_akz_launch_candidates(const AkdParams *P, int nframes, unsig
 }
 
 extern "C" void afv_akz_launch_suppress(const AkdParams *P, const AkdState *S, int nframes, const int *cand, const float *cand_resp,
-                                        const int *cand_count,
+                                        const int *cand_count, const int *row_start,
                                         afv_keypoint *kps, int *kp_count, int *status, hipStream_t st) {
-    const size_t lds = ((size_t)P->gw * P->gh * 2 * sizeof(unsigned short) + 15) & ~(size_t)15;  // two count grids (u16)
-    hipLaunchKernelGGL(k_akz_suppress, dim3(nframes), dim3(AKD_T), lds, st, *P, *S, cand, cand_resp, cand_count, kps, kp_count, status);
+    const size_t lds = (size_t)P->lds_bytes;  // list lengths (u8): a level's own grid + hints of the one below
+    (void)hipMemsetAsync(S->ticket, 0, (size_t)(8 + nframes * 16) * sizeof(int), st);
+    (void)hipMemsetAsync(S->keep, 1, (size_t)nframes * P->entry_cap, st);
+    const int blocks = (nframes + 7) / 8 * 8 * P->nlevels;
+    hipLaunchKernelGGL(k_akz_suppress, dim3(blocks), dim3(AKD_T), lds, st, *P, *S, nframes, cand, cand_resp, cand_count, row_start, status);
+    const int nchunks = (P->entry_cap + AKD_CHUNK - 1) / AKD_CHUNK;
+    hipLaunchKernelGGL(k_akz_refine_a, dim3(nchunks, nframes), dim3(AKD_CHUNK), 0, st, *P, *S, cand_count);
+    hipLaunchKernelGGL(k_akz_refine_b, dim3(nchunks, nframes), dim3(AKD_CHUNK), 0, st, *P, *S, kps, kp_count, status);
 }

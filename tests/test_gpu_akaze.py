@@ -125,6 +125,40 @@ def test_detection_matches_oracle(afv, akz, w, h, seeds):
     ctx.close()
 
 
+def test_level_pipeline_under_load(afv, akz):
+    """the eight levels of a frame are suppressed by eight workgroups that hand list state to each other (k_akaze_detect.hip):
+    more workgroups than the chip holds at once, a chip that is busy with something else, repeated launches (the launch epoch in
+    the list elements moves on) -> the same keypoints every time, and they are the oracle's"""
+    import torch
+    w, h, B = 640, 480, 72
+    ctx = afv.AkazeContext(afv.akaze.default_params(max_width=w, max_height=h, max_batch=B))
+    frames = _frames(afv, w, h, tuple(range(100, 100 + B)))
+    plan = ctx.scale_space(frames)
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device="cuda", dtype=torch.float16)
+    runs = []
+    for rep in range(3):
+        if rep:
+            with torch.cuda.stream(side):
+                for _ in range(40):
+                    a @ a
+        ctx.detect()
+        runs.append([ctx.keypoints(f) for f in range(B)])
+        torch.cuda.synchronize()
+    for rep in (1, 2):
+        for f in range(B):
+            assert runs[rep][f].tobytes() == runs[0][f].tobytes(), (rep, f)
+    op = _oracle_plan(akz, plan)
+    for f in (0, 35, B - 1):
+        levels, _ = akz.full_evolution(frames[f], op)
+        want = akz.subpixel(op, levels, akz.find_extrema(op, levels))
+        got = runs[2][f]
+        assert len(got) == len(want) and len(want) > 500
+        for name in ("x", "y", "response", "class_id"):
+            assert np.array_equal(got[name], want[name]), (f, name)
+    ctx.close()
+
+
 def _oracle_detect_and_compute(afv, akz, oracle, op, frame, quotas, w, h):
     """FeatureExtractor_akaze61::detectAndCompute restated with the oracle pieces: Feature_Detection, bucket by class_id,
     DistributeOctTree per level (oracle/afvo.c), Compute_Descriptors on the levels in ascending order"""
