@@ -105,12 +105,13 @@ __global__ __launch_bounds__(256) void k_akz_cand_mask(AkdParams P, int level, i
 }
 
 // pass B: one workgroup per (level, frame): row counts from the bitmap, exclusive scan over the rows, then every wavefront
-// expands its rows in raster order (index + |response|)
+// expands its rows in raster order (lane = 64-column chunk, each lane walks the bits of its own word), and a last flat pass
+// fetches |response| for the emitted indices (independent loads; fetched inside the expansion they serialised it)
 #define AKE_T 1024
 __global__ __launch_bounds__(AKE_T) void k_akz_cand_emit(AkdParams P, const unsigned long long *__restrict__ mask, int *__restrict__ row_start,
                                                        int *__restrict__ cand, float *__restrict__ cand_resp, int *__restrict__ cand_count,
                                                        int *__restrict__ status) {
-    __shared__ int s_part[AKE_T];
+    __shared__ int s_w[AKE_T / 64];
     const int level = blockIdx.x, f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const AkdLevel L = P.lv[level];
     const int nchunks = (L.w + 63) >> 6;
@@ -124,26 +125,24 @@ __global__ __launch_bounds__(AKE_T) void k_akz_cand_emit(AkdParams P, const unsi
         rs[r] = c;  // row count for now
         sum += c;
     }
-    s_part[tid] = sum;
+    const int incl = afv_wave_incl_scan(sum);
+    if (lane == 63) s_w[wv] = incl;
     __syncthreads();
-    if (tid == 0) {
-        int acc = 0;
-        for (int i = 0; i < AKE_T; ++i) {
-            const int t = s_part[i];
-            s_part[i] = acc;
-            acc += t;
-        }
-        cand_count[f * 16 + level] = min(acc, L.cand_cap);
-        if (acc > L.cand_cap) atomicExch(status, 1);
+    int acc = incl - sum, total = 0;
+#pragma unroll
+    for (int w = 0; w < AKE_T / 64; ++w) {
+        const int t = s_w[w];
+        if (w < wv) acc += t;
+        total += t;
     }
-    __syncthreads();
-    {
-        int acc = s_part[tid];
-        for (int r = b; r < e; ++r) {
-            const int c = rs[r];
-            rs[r] = acc;
-            acc += c;
-        }
+    if (tid == 0) {
+        cand_count[f * 16 + level] = min(total, L.cand_cap);
+        if (total > L.cand_cap) atomicExch(status, 1);
+    }
+    for (int r = b; r < e; ++r) {
+        const int c = rs[r];
+        rs[r] = acc;
+        acc += c;
     }
     __threadfence_block();
     __syncthreads();
@@ -152,28 +151,23 @@ __global__ __launch_bounds__(AKE_T) void k_akz_cand_emit(AkdParams P, const unsi
     float *cr = cand_resp + (size_t)f * P.cand_stride + L.cand_off;
     for (int r = wv; r < L.h; r += AKE_T / 64) {
         // lane k holds chunk k's word; exclusive scan of the popcounts gives every chunk its offset inside the row
-        const unsigned long long m = lane < nchunks ? mk[(size_t)r * AKD_MAXCHUNKS + lane] : 0ull;
+        unsigned long long m = lane < nchunks ? mk[(size_t)r * AKD_MAXCHUNKS + lane] : 0ull;
         const int cnt = __popcll(m);
-        const int incl = afv_wave_incl_scan(cnt);
-        const int row_total = __shfl(incl, 63, 64);
-        if (row_total == 0) continue;
-        const int base = rs[r];
-        unsigned long long live = __ballot(cnt != 0);
-        while (live) {
-            const int k = (int)__builtin_ctzll(live);
-            live &= live - 1;
-            const unsigned long long mkk = __shfl(m, k, 64);
-            const int off = base + __shfl(incl - cnt, k, 64);
-            if ((mkk >> lane) & 1ull) {
-                const int kk = off + __popcll(mkk & ((1ull << lane) - 1ull));
-                if (kk < L.cand_cap) {
-                    const int idx = r * L.w + (k << 6) + lane;
-                    co[kk] = idx;
-                    cr[kk] = fabsf(ld[idx]);
-                }
-            }
+        const int in = afv_wave_incl_scan(cnt);
+        if (__shfl(in, 63, 64) == 0) continue;
+        int o = rs[r] + in - cnt;
+        const int idx0 = r * L.w + (lane << 6);
+        while (m) {
+            const int bit = (int)__builtin_ctzll(m);
+            m &= m - 1;
+            if (o < L.cand_cap) co[o] = idx0 + bit;
+            ++o;
         }
     }
+    __threadfence_block();
+    __syncthreads();
+    const int ntot = min(total, L.cand_cap);
+    for (int k = tid; k < ntot; k += AKE_T) cr[k] = fabsf(ld[co[k]]);
 }
 
 // ---------------- ordered suppression + upper-level filter: one workgroup per (frame, level), levels pipelined ----------------
@@ -215,7 +209,10 @@ struct AkdState {
 #define AKD_T 1024
 #define AKD_COMM (AKD_T - 64)    // the lane that talks to the neighbouring levels (first lane of the last wavefront)
 #define AKD_PAIRS 8   // 2 grids x the (at most) 2 x 2 cells a candidate's disc overlaps
-#define AKD_R 128      // candidates per speculative round (two wavefronts decide / commit); AKD_R * AKD_PAIRS == AKD_T: one pair per thread
+#ifndef AKD_R
+#define AKD_R 128      // candidates per speculative round (AKD_R / 64 wavefronts decide / commit); AKD_R * AKD_PAIRS / AKD_T pairs per thread
+#endif
+#define AKD_CPER (AKD_T / (AKD_R / 2))  // threads per row pair of the conflict test
 #define AKD_DEADBIT 0x80000000u
 #define AKD_SLOTMASK 0x1ffffu   // 17 bits: entry_cap <= 131072
 #define AKD_EPOCH_MAX 0x3fffu
@@ -416,13 +413,12 @@ __global__ __launch_bounds__(AKD_T, 8) void k_akz_suppress(AkdParams P, AkdState
             __syncthreads();
         }
         // ---- 2. neighbourhood scan: one (candidate, cell) pair per thread ----
-        do {
-            if (tid >= nround * AKD_PAIRS) break;
-            const int q = tid >> 3, k = tid & 7;
+        for (int t = tid; t < nround * AKD_PAIRS; t += AKD_T) {
+            const int q = t >> 3, k = t & 7;
             const bool below = k < 4;
-            if (below && c == 0) break;
+            if (below && c == 0) continue;
             const unsigned box = below ? s_boxp[q] : s_boxo[q];
-            if (((k & 1) && !((box >> 30) & 1u)) || ((k & 2) && !(box >> 31))) break;
+            if (((k & 1) && !((box >> 30) & 1u)) || ((k & 2) && !(box >> 31))) continue;
             const float qx = s_sx[q], qy = s_sy[q];
             unsigned long long best = AKD_NONE;
             // one 16-byte load per element: a wavefront's 64 lanes look at 64 different lists, and the lists are short
@@ -442,7 +438,7 @@ __global__ __launch_bounds__(AKD_T, 8) void k_akz_suppress(AkdParams P, AkdState
                 for (int e = 0; e < cn; ++e) akd_consider(cells[lb + e], lb + e, qx, qy, size2, best);
             }
             if (best != AKD_NONE) atomicMin(&s_best[q], best);
-        } while (false);
+        }
         if (tid < AKD_R) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the published lengths have left
         __syncthreads();
         // communication lane: everything before this round is committed and drained.  The L2 write-back is started here and
@@ -485,15 +481,15 @@ __global__ __launch_bounds__(AKD_T, 8) void k_akz_suppress(AkdParams P, AkdState
         // 3b. a candidate's decision stands unless an earlier candidate of the round changes what its search sees: a new /
         //     moved entry inside its radius, or a replaced entry that used to lie inside its radius.  The round commits up to
         //     the first candidate that was hit.  Rows i and AKD_R - 1 - i of the (j < i) triangle have AKD_R - 1 pairs together:
-        //     16 threads per such row pair, every thread the same number of pairs, one LDS read per pair.
+        //     AKD_CPER threads per such row pair, every thread the same number of pairs, one LDS read per pair.
         {
-            const int rp = tid >> 4, part = tid & 15;  // AKD_T / 16 = AKD_R / 2 row pairs
+            const int rp = tid / AKD_CPER, part = tid % AKD_CPER;  // AKD_R / 2 row pairs
             const int i1 = rp, i2 = AKD_R - 1 - rp;
             const float x1 = s_sx[i1], y1 = s_sy[i1], x2 = s_sx[i2], y2 = s_sy[i2];
             bool hit1 = false, hit2 = false;
-#pragma unroll
-            for (int it = 0; it < AKD_R / 16; ++it) {  // all LDS reads in flight together
-                const int m = part + 16 * it;
+#pragma unroll 8
+            for (int it = 0; it < (AKD_R + AKD_CPER - 2) / AKD_CPER; ++it) {  // several LDS reads in flight together
+                const int m = part + AKD_CPER * it;
                 if (m >= AKD_R - 1) break;
                 const bool lo = m < i1;
                 const float4 o = s_moved[lo ? m : m - i1];
