@@ -60,47 +60,85 @@ __device__ __forceinline__ bool akd_is_candidate(const AkdParams &P, const AkdLe
     return !(left_x < 0 || right_x >= L.w || up_y < 0 || down_y >= L.h);
 }
 
-// pass A: candidate bitmap of one level.  64 x 32 tile + 1 px ring in LDS (the Ldet plane is streamed once); bit x of word
+// pass A: candidate bitmap of all levels in one launch.  One wavefront per strip of 64 columns x AKM_ROWS rows: lane = column,
+// the rows slide through registers (row above / centre / below), the horizontal neighbours come from DPP wave shifts plus one
+// edge column either side, so the Ldet plane is streamed once with full-line loads and no LDS.  v > all eight neighbours  <=>
+// v > max(left, right) of its own row and v > the 3-wide row maxima above and below.  Bit x of word
 // mask[frame][row][x / 64] = pixel (x, row) is a candidate.
 #define AKD_MAXCHUNKS 32  // 64-column chunks per row: levels up to 2048 pixels wide
-__global__ __launch_bounds__(256) void k_akz_cand_mask(AkdParams P, int level, int nframes, unsigned long long *__restrict__ mask) {
-    constexpr int LW = 66, LH = 34;
-    __shared__ float s_d[LW * LH];
+#define AKM_ROWS 32
+struct AkmWork {
+    int strip_off[17];  // first strip of every level (strips of a level: chunks x row blocks x frames)
+};
+__device__ __forceinline__ float akm_from_left(float v) {   // lane i <- lane i - 1 (DPP wave_shr:1)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float akm_from_right(float v) {  // lane i <- lane i + 1 (DPP wave_shl:1)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+__global__ __launch_bounds__(256) void k_akz_cand_mask(AkdParams P, AkmWork W, int nframes, unsigned long long *__restrict__ mask) {
+    const int lane = threadIdx.x & 63;
+    const int strip = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    if (strip >= W.strip_off[P.nlevels]) return;
+    int level = 0;
+    while (strip >= W.strip_off[level + 1]) ++level;
     const AkdLevel L = P.lv[level];
-    const int tiles_x = (L.w + 63) / 64, tiles_y = (L.h + 31) / 32, total = tiles_x * tiles_y * nframes;
-    const int work = afv_xcd_remap(blockIdx.x, total);
-    if (work >= total) return;
-    const int f = work / (tiles_x * tiles_y), t = work - f * (tiles_x * tiles_y);
-    const int ty0 = (t / tiles_x) * 32, tx0 = (t - (t / tiles_x) * tiles_x) * 64;
+    const int nchunks = (L.w + 63) >> 6, nrb = (L.h + AKM_ROWS - 1) / AKM_ROWS;
+    int t = strip - W.strip_off[level];
+    const int f = t / (nchunks * nrb);
+    t -= f * nchunks * nrb;
+    const int rb = t / nchunks, ch = t - rb * nchunks;
+    const int tx0 = ch << 6, ty0 = rb * AKM_ROWS;
     const float *ld = L.ldet + (size_t)f * L.w * L.h;
-    for (int i = threadIdx.x; i < LW * LH; i += 256) {
-        const int ly = i / LW, lx = i - ly * LW;
-        const int gx = min(max(tx0 - 1 + lx, 0), L.w - 1), gy = min(max(ty0 - 1 + ly, 0), L.h - 1);
-        s_d[i] = ld[(size_t)gy * L.w + gx];
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int jx = tx0 + lane, xc = min(jx, L.w - 1), xl = max(tx0 - 1, 0), xr = min(tx0 + 64, L.w - 1);
     const float smax = 10.0f * sqrtf(2.0f), r = smax * (float)L.sigma_size;
-    const int jx = tx0 + lane;
     // descriptor-border rule ("is_out"), column part: such a point never changes kpts_aux, so it is dropped before the ordered pass
     const float px = (float)jx;
     const bool col_ok = jx >= 1 && jx < L.w - 1 && !(akd_fround(px - r) - 1 < 0 || akd_fround(px + r) + 1 >= L.w);
-    for (int ly = wv; ly < 32; ly += 4) {
-        const int iy = ty0 + ly;
-        if (iy >= L.h) break;
-        bool ok = false;
-        if (col_ok && iy >= 1 && iy < L.h - 1) {
-            const float *c = &s_d[(ly + 1) * LW + lane + 1];
-            const float v = c[0];
-            ok = v > P.dthreshold && v >= P.min_dthreshold && v > c[-1] && v > c[1] && v > c[-LW - 1] && v > c[-LW] && v > c[-LW + 1] &&
-                 v > c[LW - 1] && v > c[LW] && v > c[LW + 1];
+    unsigned long long *mk = mask + ((size_t)f * P.rows_stride + L.row_off) * AKD_MAXCHUNKS + ch;
+    // row y of the window: centre value, max(left, right), 3-wide maximum
+    auto reduce_row = [&](float c, float e, float &side, float &m3) {  // e: the edge column (lanes 0 and 63 only)
+        const float dl = akm_from_left(c), dr = akm_from_right(c);
+        const float l = lane == 0 ? e : dl, rr = lane == 63 ? e : dr;
+        side = fmaxf(l, rr);
+        m3 = fmaxf(side, c);
+    };
+    auto row_ptr = [&](int y) { return ld + (size_t)min(max(y, 0), L.h - 1) * L.w; };
+    const int xe = lane == 0 ? xl : xr;
+    float c_m, side_m, m3_u, m3_m;
+    {
+        const float *r0 = row_ptr(ty0 - 1), *r1 = row_ptr(ty0);
+        const float c0 = r0[xc], e0 = r0[xe], c1 = r1[xc], e1 = r1[xe];
+        float side_u;
+        reduce_row(c0, e0, side_u, m3_u);
+        reduce_row(c1, e1, side_m, m3_m);
+        c_m = c1;
+    }
+    const int rows = min(AKM_ROWS, L.h - ty0);
+    constexpr int G = 4;  // rows fetched together: a wavefront keeps G full lines in flight
+    for (int g0 = 0; g0 < rows; g0 += G) {
+        float cd[G], ed[G];
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            const float *rp = row_ptr(ty0 + g0 + k + 1);
+            cd[k] = rp[xc];
+            ed[k] = rp[xe];
+        }
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            const int iy = ty0 + g0 + k;
+            float side_d, m3_d;
+            reduce_row(cd[k], ed[k], side_d, m3_d);
+            const float v = c_m;
+            bool ok = col_ok && iy >= 1 && iy < L.h - 1 && v > P.dthreshold && v >= P.min_dthreshold && v > side_m && v > m3_u && v > m3_d;
             if (ok) {
                 const float py = (float)iy;
                 ok = !(akd_fround(py - r) - 1 < 0 || akd_fround(py + r) + 1 >= L.h);
             }
+            const unsigned long long m = __ballot(ok);
+            if (lane == 0 && g0 + k < rows) mk[(size_t)iy * AKD_MAXCHUNKS] = m;
+            m3_u = m3_m; c_m = cd[k]; side_m = side_d; m3_m = m3_d;
         }
-        const unsigned long long m = __ballot(ok);
-        if (lane == 0) mask[((size_t)f * P.rows_stride + L.row_off + iy) * AKD_MAXCHUNKS + (tx0 >> 6)] = m;
     }
 }
 
@@ -727,10 +765,14 @@ __global__ __launch_bounds__(AKD_CHUNK) void k_akz_refine_b(AkdParams P, AkdStat
 
 extern "C" void afv_akz_launch_candidates(const AkdParams *P, int nframes, unsigned long long *mask, int *row_start, int *cand, float *cand_resp,
                                           int *cand_count, int *status, hipStream_t st) {
+    AkmWork W;
+    int strips = 0;
     for (int l = 0; l < P->nlevels; ++l) {
-        const int total = ((P->lv[l].w + 63) / 64) * ((P->lv[l].h + 31) / 32) * nframes;
-        hipLaunchKernelGGL(k_akz_cand_mask, dim3((total + 7) / 8 * 8), dim3(256), 0, st, *P, l, nframes, mask);
+        W.strip_off[l] = strips;
+        strips += ((P->lv[l].w + 63) / 64) * ((P->lv[l].h + AKM_ROWS - 1) / AKM_ROWS) * nframes;
     }
+    for (int l = P->nlevels; l < 17; ++l) W.strip_off[l] = strips;
+    hipLaunchKernelGGL(k_akz_cand_mask, dim3((strips + 3) / 4), dim3(256), 0, st, *P, W, nframes, mask);
     hipLaunchKernelGGL(k_akz_cand_emit, dim3(P->nlevels, nframes), dim3(AKE_T), 0, st, *P, mask, row_start, cand, cand_resp, cand_count, status);
 }
 
