@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256) void k_akz_describe(AkdDescParams P, const afv
                                                       const int *__restrict__ sel_count, afv_keypoint *__restrict__ out_kps,
                                                       uint8_t *__restrict__ out_desc, int *__restrict__ out_count, int *__restrict__ status) {
     __shared__ float s_rx[4][112], s_ry[4][112], s_ang[4][112], s_val[4][96];
+    __shared__ float s_smp[4][441 * 3];  // MLDB samples of the 21 x 21 pattern positions: {Lt, rotated Lx, rotated Ly}
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, f = blockIdx.y;
     const int slot = blockIdx.x * 4 + wv;
     // slot -> (level, position): levels ascending (mergeKeypointLevels, FeatureExtractor.cpp:296-308)
@@ -192,14 +193,26 @@ __global__ __launch_bounds__(256) void k_akz_describe(AkdDescParams P, const afv
     // ---- Compute_Main_Orientation ----
     {
         const int s = akd_fround((float)(0.5 * (double)kp.size / (double)ratio));
-        for (int idx = lane; idx < 109; idx += 64) {
+        float ox[2], oy[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {  // both gathers of a lane in flight together
+            const int idx = min(lane + 64 * it, 108);
             const int i = k_ori_ij[idx][0], j = k_ori_ij[idx][1];
             const int iy = akd_iclamp(akd_fround(yf + (float)(j * s)), 0, L.h - 1), ix = akd_iclamp(akd_fround(xf + (float)(i * s)), 0, L.w - 1);
-            const float gw = k_gauss25[i < 0 ? -i : i][j < 0 ? -j : j];
-            const float vx = gw * (Lx[(size_t)iy * L.w + ix] * L.fs), vy = gw * (Ly[(size_t)iy * L.w + ix] * L.fs);
-            rx[idx] = vx;
-            ry[idx] = vy;
-            an[idx] = akd_get_angle(vx, vy);
+            ox[it] = Lx[(size_t)iy * L.w + ix];
+            oy[it] = Ly[(size_t)iy * L.w + ix];
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = lane + 64 * it;
+            if (idx < 109) {
+                const int i = k_ori_ij[idx][0], j = k_ori_ij[idx][1];
+                const float gw = k_gauss25[i < 0 ? -i : i][j < 0 ? -j : j];
+                const float vx = gw * (ox[it] * L.fs), vy = gw * (oy[it] * L.fs);
+                rx[idx] = vx;
+                ry[idx] = vy;
+                an[idx] = akd_get_angle(vx, vy);
+            }
         }
         AKD_LDS_SYNC();
         // 42 sliding windows (ang1 = 0, 0.15, ... accumulated in float like upstream's loop variable), one per lane
@@ -242,20 +255,45 @@ __global__ __launch_bounds__(256) void k_akz_describe(AkdDescParams P, const afv
         double cd, sd;
         akd_sincos((double)kp.angle, &cd, &sd);
         const float co = (float)cd, si = (float)sd;
+        // The 2 x 2, 3 x 3 and 4 x 4 grids all sum samples at the integer pattern positions (k, l) in [-10, 10]^2, and a sample
+        // depends on (k, l) only: the 441 positions are fetched once, all lanes in parallel (1241 dependent gathers per keypoint
+        // if every cell fetches its own), and every cell then adds ITS samples in upstream's (k, l) loop order from LDS.
+        float *smp = s_smp[wv];
+        {
+            float ri[7], gx[7], gy[7];  // all 21 gathers of a lane in flight together
+#pragma unroll
+            for (int it = 0; it < 7; ++it) {
+                const int p = min(lane + 64 * it, 440);
+                const int k = p / 21 - 10, l = p - (p / 21) * 21 - 10;
+                const float sample_y = yf + ((float)l * co * scale + (float)k * si * scale);
+                const float sample_x = xf + (-(float)l * si * scale + (float)k * co * scale);
+                const int y1 = akd_iclamp(akd_fround(sample_y), 0, L.h - 1), x1 = akd_iclamp(akd_fround(sample_x), 0, L.w - 1);
+                const size_t o = (size_t)y1 * L.w + x1;
+                ri[it] = Lt[o];
+                gx[it] = Lx[o];
+                gy[it] = Ly[o];
+            }
+#pragma unroll
+            for (int it = 0; it < 7; ++it) {
+                const int p = lane + 64 * it;
+                if (p < 441) {
+                    const float vx = gx[it] * L.fs, vy = gy[it] * L.fs;
+                    smp[3 * p] = ri[it];
+                    smp[3 * p + 1] = -vx * si + vy * co;  // rrx
+                    smp[3 * p + 2] = vx * co + vy * si;   // rry
+                }
+            }
+        }
+        AKD_LDS_SYNC();
         if (lane < 29) {
             const int i0 = k_mldb_cell[lane][1], j0 = k_mldb_cell[lane][2], step = k_mldb_cell[lane][3];
             float di = 0.f, dx = 0.f, dy = 0.f;
             for (int k = i0; k < i0 + step; ++k)
                 for (int l = j0; l < j0 + step; ++l) {
-                    const float sample_y = yf + ((float)l * co * scale + (float)k * si * scale);
-                    const float sample_x = xf + (-(float)l * si * scale + (float)k * co * scale);
-                    const int y1 = akd_iclamp(akd_fround(sample_y), 0, L.h - 1), x1 = akd_iclamp(akd_fround(sample_x), 0, L.w - 1);
-                    const size_t o = (size_t)y1 * L.w + x1;
-                    const float ri = Lt[o], vx = Lx[o] * L.fs, vy = Ly[o] * L.fs;
-                    di += ri;
-                    const float rry = vx * co + vy * si, rrx = -vx * si + vy * co;
-                    dx += rrx;
-                    dy += rry;
+                    const float *q = smp + 3 * ((k + 10) * 21 + (l + 10));
+                    di += q[0];
+                    dx += q[1];
+                    dy += q[2];
                 }
             const float ns = (float)(step * step);
             val[3 * lane] = di / ns;
