@@ -308,19 +308,21 @@ __global__ __launch_bounds__(AKZ_FT) void k_akz_fed_fused(const float *__restric
             c[j] = 1.0f / (1.0f + (lxv * lxv + lyv * lyv) * k2inv);
         }
     }
+    // The image border (no neighbour: that flux term is 0) and the pixels this tile does not update (outside the image or the
+    // tile: they keep their value) are folded into the conductivity sums once, instead of four selects + one per pixel and step:
+    // a zero conductivity makes the flux term +-0, and Lc + hs * (+-0) == Lc for every Lc except -0.0, which a smoothed
+    // non-negative image never holds.
     float cR[AKZ_FR], cL[AKZ_FR], cD[AKZ_FR], cU[AKZ_FR], L[AKZ_FR];
-    bool upd[AKZ_FR], has_d[AKZ_FR], has_u[AKZ_FR];
 #pragma unroll
     for (int j = 0; j < AKZ_FR; ++j) {
         const float cc = c[j + 1];
-        cR[j] = cc + akz_from_right(cc);
-        cL[j] = akz_from_left(cc) + cc;
-        cD[j] = cc + c[j + 2];
-        cU[j] = c[j] + cc;
         const int r = r0 + j, gy = y0 - N + r;
-        upd[j] = col_in && r < LH && gy >= 0 && gy < h;
-        has_d[j] = gy + 1 < h;
-        has_u[j] = gy > 0;
+        const bool upd = col_in && r < LH && gy >= 0 && gy < h;
+        const float cr = cc + akz_from_right(cc), cl = akz_from_left(cc) + cc;
+        cR[j] = upd && has_r ? cr : 0.0f;
+        cL[j] = upd && has_l ? cl : 0.0f;
+        cD[j] = upd && gy + 1 < h ? cc + c[j + 2] : 0.0f;
+        cU[j] = upd && gy > 0 ? c[j] + cc : 0.0f;
         L[j] = pin[(size_t)akz_clamp(gy, h) * w + akz_clamp(gx, w)];
     }
     for (int st = 0; st < N; ++st) {
@@ -341,12 +343,12 @@ __global__ __launch_bounds__(AKZ_FT) void k_akz_fed_fused(const float *__restric
             const float Lc = L[j];
             const float Lr = akz_from_right(Lc), Ll = akz_from_left(Lc);
             const float Lu = j > 0 ? L[j - 1] : up_halo, Ld = j < AKZ_FR - 1 ? L[j + 1] : dn_halo;
-            const float xpos = has_r ? cR[j] * (Lr - Lc) : 0.0f;
-            const float xneg = has_l ? cL[j] * (Lc - Ll) : 0.0f;
-            const float ypos = has_d[j] ? cD[j] * (Ld - Lc) : 0.0f;
-            const float yneg = has_u[j] ? cU[j] * (Lc - Lu) : 0.0f;
+            const float xpos = cR[j] * (Lr - Lc);
+            const float xneg = cL[j] * (Lc - Ll);
+            const float ypos = cD[j] * (Ld - Lc);
+            const float yneg = cU[j] * (Lc - Lu);
             const float sum = ((xpos - xneg) + ypos) - yneg;
-            nl[j] = upd[j] ? Lc + hs * sum : Lc;
+            nl[j] = Lc + hs * sum;
         }
 #pragma unroll
         for (int j = 0; j < AKZ_FR; ++j) L[j] = nl[j];

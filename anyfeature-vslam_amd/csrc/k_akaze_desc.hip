@@ -166,8 +166,9 @@ __constant__ float k_gauss25[7][7] = {
 __global__ __launch_bounds__(256) void k_akz_describe(AkdDescParams P, const afv_keypoint *__restrict__ kps, const int *__restrict__ sel,
                                                       const int *__restrict__ sel_count, afv_keypoint *__restrict__ out_kps,
                                                       uint8_t *__restrict__ out_desc, int *__restrict__ out_count, int *__restrict__ status) {
-    __shared__ float s_rx[4][112], s_ry[4][112], s_ang[4][112], s_val[4][96];
-    __shared__ float s_smp[4][441 * 3];  // MLDB samples of the 21 x 21 pattern positions: {Lt, rotated Lx, rotated Ly}
+    __shared__ float4 s_ori[4][112];  // orientation samples: {angle, weighted Lx, weighted Ly, angle < 2 pi (as 1 / 0)}
+    __shared__ float s_val[4][96];
+    __shared__ float4 s_smp[4][441];  // MLDB samples of the 21 x 21 pattern positions: {Lt, rotated Lx, rotated Ly, -}
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, f = blockIdx.y;
     const int slot = blockIdx.x * 4 + wv;
     // slot -> (level, position): levels ascending (mergeKeypointLevels, FeatureExtractor.cpp:296-308)
@@ -189,7 +190,8 @@ __global__ __launch_bounds__(256) void k_akz_describe(AkdDescParams P, const afv
     const float *Lt = L.lt + fo, *Lx = L.lx + fo, *Ly = L.ly + fo;
     const float ratio = (float)(1 << L.octave);
     const float xf = kp.x / ratio, yf = kp.y / ratio;
-    float *rx = s_rx[wv], *ry = s_ry[wv], *an = s_ang[wv], *val = s_val[wv];
+    float4 *ori = s_ori[wv];
+    float *val = s_val[wv];
     // ---- Compute_Main_Orientation ----
     {
         const int s = akd_fround((float)(0.5 * (double)kp.size / (double)ratio));
@@ -209,9 +211,8 @@ __global__ __launch_bounds__(256) void k_akz_describe(AkdDescParams P, const afv
                 const int i = k_ori_ij[idx][0], j = k_ori_ij[idx][1];
                 const float gw = k_gauss25[i < 0 ? -i : i][j < 0 ? -j : j];
                 const float vx = gw * (ox[it] * L.fs), vy = gw * (oy[it] * L.fs);
-                rx[idx] = vx;
-                ry[idx] = vy;
-                an[idx] = akd_get_angle(vx, vy);
+                const float ang = akd_get_angle(vx, vy);
+                ori[idx] = make_float4(ang, vx, vy, (double)ang < 2.0 * AKZ_PI_D ? 1.0f : 0.0f);
             }
         }
         AKD_LDS_SYNC();
@@ -223,15 +224,15 @@ __global__ __launch_bounds__(256) void k_akz_describe(AkdDescParams P, const afv
         if (live) {
             const float ang2 =
                 (float)((double)ang1 + AKZ_PI_D / 3.0 > 2.0 * AKZ_PI_D ? (double)ang1 - 5.0 * AKZ_PI_D / 3.0 : (double)ang1 + AKZ_PI_D / 3.0);
+            // upstream: if (ang1 < ang2 && ang1 < ang && ang < ang2) add; else if (ang2 < ang1 && ((ang > 0 && ang < ang2) ||
+            // (ang > ang1 && ang < 2 pi))) add - the window either wraps or it does not, which is a property of the lane
+            const bool nowrap = ang1 < ang2, wrap = ang2 < ang1;
             for (int k = 0; k < 109; ++k) {
-                const float ang = an[k];
-                if (ang1 < ang2 && ang1 < ang && ang < ang2) {
-                    sumX += rx[k];
-                    sumY += ry[k];
-                } else if (ang2 < ang1 && ((ang > 0 && ang < ang2) || (ang > ang1 && (double)ang < 2.0 * AKZ_PI_D))) {
-                    sumX += rx[k];
-                    sumY += ry[k];
-                }
+                const float4 o = ori[k];  // one broadcast read per sample
+                const bool a1 = ang1 < o.x, a2 = o.x < ang2;
+                const bool in = nowrap ? (a1 && a2) : (wrap && ((o.x > 0 && a2) || (a1 && o.w != 0.0f)));
+                sumX = in ? sumX + o.y : sumX;
+                sumY = in ? sumY + o.z : sumY;
             }
         }
         const float mag = live ? sumX * sumX + sumY * sumY : 0.0f;
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256) void k_akz_describe(AkdDescParams P, const afv
         // The 2 x 2, 3 x 3 and 4 x 4 grids all sum samples at the integer pattern positions (k, l) in [-10, 10]^2, and a sample
         // depends on (k, l) only: the 441 positions are fetched once, all lanes in parallel (1241 dependent gathers per keypoint
         // if every cell fetches its own), and every cell then adds ITS samples in upstream's (k, l) loop order from LDS.
-        float *smp = s_smp[wv];
+        float4 *smp = s_smp[wv];
         {
             float ri[7], gx[7], gy[7];  // all 21 gathers of a lane in flight together
 #pragma unroll
@@ -278,9 +279,7 @@ __global__ __launch_bounds__(256) void k_akz_describe(AkdDescParams P, const afv
                 const int p = lane + 64 * it;
                 if (p < 441) {
                     const float vx = gx[it] * L.fs, vy = gy[it] * L.fs;
-                    smp[3 * p] = ri[it];
-                    smp[3 * p + 1] = -vx * si + vy * co;  // rrx
-                    smp[3 * p + 2] = vx * co + vy * si;   // rry
+                    smp[p] = make_float4(ri[it], -vx * si + vy * co /* rrx */, vx * co + vy * si /* rry */, 0.0f);
                 }
             }
         }
@@ -288,13 +287,15 @@ __global__ __launch_bounds__(256) void k_akz_describe(AkdDescParams P, const afv
         if (lane < 29) {
             const int i0 = k_mldb_cell[lane][1], j0 = k_mldb_cell[lane][2], step = k_mldb_cell[lane][3];
             float di = 0.f, dx = 0.f, dy = 0.f;
-            for (int k = i0; k < i0 + step; ++k)
-                for (int l = j0; l < j0 + step; ++l) {
-                    const float *q = smp + 3 * ((k + 10) * 21 + (l + 10));
-                    di += q[0];
-                    dx += q[1];
-                    dy += q[2];
+            for (int k = i0; k < i0 + step; ++k) {
+                const float4 *q = smp + (k + 10) * 21 + (j0 + 10);
+                for (int l = 0; l < step; ++l) {
+                    const float4 v = q[l];
+                    di += v.x;
+                    dx += v.y;
+                    dy += v.z;
                 }
+            }
             const float ns = (float)(step * step);
             val[3 * lane] = di / ns;
             val[3 * lane + 1] = dx / ns;
