@@ -21,7 +21,7 @@ extern "C" void afv_akz_launch_flow(const float *lsm, int w, int h, int nframes,
 extern "C" void afv_akz_launch_nld_step(const float *Lt, const float *flow, int w, int h, int nframes, float tau, float *out, hipStream_t st);
 extern "C" int afv_akz_launch_fed_fused(const float *Lt_in, const float *lsm, int w, int h, int nframes, const float *kcontrast, int octave,
                                         int nsteps, const float *tau, float *Lt_out, hipStream_t st);
-extern "C" int afv_akz_launch_hessian(const float *lsm, int w, int h, int nframes, int s, float *dx, float *dy,
+extern "C" int afv_akz_launch_hessian(const float *lsm, int w, int h, int nframes, int s, int two_kernels, float *dx, float *dy,
                                       float *Ldet, hipStream_t st);
 
 // mirrors of the kernel-side structs in k_akaze_detect.hip
@@ -433,7 +433,7 @@ static int akz_enqueue(afv_akaze *a, const uint8_t *d_gray, int nframes, int w, 
     for (int i = 0; i < P.nlevels; ++i) {
         const afv_akaze_level &L = P.lv[i];
         // lx / ly keep the UNSCALED first derivatives; readers apply sigma_size (k_akz_describe, afv_akaze_get_plane)
-        if (afv_akz_launch_hessian(a->lsm[i], L.w, L.h, nframes, L.sigma_size, a->lx[i], a->ly[i], a->ldet[i], st))
+        if (afv_akz_launch_hessian(a->lsm[i], L.w, L.h, nframes, L.sigma_size, a->step_by_step ? 1 : 0, a->lx[i], a->ly[i], a->ldet[i], st))
             return AFV_EUNSUPPORTED;
     }
     if (a->profiling) {

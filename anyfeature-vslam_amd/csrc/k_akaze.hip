@@ -438,6 +438,97 @@ __global__ __launch_bounds__(AKZ_T) void k_akz_hessian(const float *__restrict__
     }
 }
 
+// ---- first derivatives + Hessian determinant in one pass (sigma_size 2 .. 4: every level of the akaze61 settings) ----
+// One wavefront per strip: lane = column, the rows slide through registers.  Every row of Lsmooth is loaded once (full lines), the
+// +-s column neighbours come from ds_bpermute, the +-s row neighbours from register rings of depth 2s + 1 (the row loop is unrolled
+// by the ring depth, so every ring index is a compile-time constant).  Four stages per loaded row v:
+//   1. D[v] = S[x+s] - S[x-s], U[v] = mid * S[x] + norm * (S[x-s] + S[x+s])
+//   2. row q = v - s:  Lx = mid * D[q] + norm * (D[q-s] + D[q+s]),  Ly = U[q+s] - U[q-s]            -> stored (unscaled)
+//   3. the same two filters over Lx / Ly of row q (DX, UX, UY)
+//   4. row p = q - s:  Lxx, Lyy, Lxy, Ldet                                                        -> stored
+// which are k_akz_deriv1's and k_akz_hessian's expressions term for term (the two-kernel form stays for other sigma sizes and as
+// the test reference).  Borders: those kernels read their inputs at BORDER_REFLECT_101 coordinates.  A lane on a column outside the
+// image holds S at the reflected column, so its neighbours deliver exactly the reflected taps; what it computes there is the
+// derivative "at a virtual position", and since the filters are odd / even under the reflection, Lx at a virtual COLUMN is exactly
+// -Lx at the reflected column and Ly at a virtual ROW exactly -Ly at the reflected row (a - b == -(b - a), sums commute): two sign
+// flips give stage 3 the values k_akz_hessian reads.  HBM bytes per pixel: 4 read (+ halo) + 12 written, against 12 + 12.
+#define AKZ_DH_ROWS 128
+template <int S>
+__global__ __launch_bounds__(256) void k_akz_dhess(const float *__restrict__ lsm, int w, int h, int nframes, float *__restrict__ dx,
+                                                   float *__restrict__ dy, float *__restrict__ Ldet) {
+    constexpr int P = 2 * S + 1;     // ring depth
+    constexpr int OW = 64 - 4 * S;   // output columns per strip
+    const int lane = threadIdx.x & 63;
+    const int nstr = (w + OW - 1) / OW, nband = (h + AKZ_DH_ROWS - 1) / AKZ_DH_ROWS;
+    int id = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    if (id >= nstr * nband * nframes) return;
+    const int f = id / (nstr * nband);
+    id -= f * nstr * nband;
+    const int band = id / nstr, x0 = (id - band * nstr) * OW, y0 = band * AKZ_DH_ROWS;
+    const int gx = x0 - 2 * S + lane;
+    const bool colv = gx < 0 || gx >= w;  // virtual column
+    const int cx = akz_reflect(gx, w);
+    const bool out_lane = lane >= 2 * S && lane < 64 - 2 * S && gx < w;
+    const int am = ((lane - S) & 63) * 4, ap = ((lane + S) & 63) * 4;
+    const float *src = lsm + (size_t)f * w * h;
+    const size_t fo = (size_t)f * w * h;
+    const float wgt = 10.0f / 3.0f, norm = 1.0f / (2.0f * (float)S * (wgt + 2.0f)), mid = wgt * norm;
+    const float fs2 = (float)(S * S);
+    const int rows = min(AKZ_DH_ROWS, h - y0);
+    const int T = rows + 4 * S;  // Lsmooth rows y0 - 2S .. y0 + rows - 1 + 2S
+    float D[P], U[P], DX[P], UX[P], UY[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) D[k] = U[k] = DX[k] = UX[k] = UY[k] = 0.0f;
+    auto shl = [&](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(am, __builtin_bit_cast(int, v))); };  // value of lane - S
+    auto shr = [&](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(ap, __builtin_bit_cast(int, v))); };  // value of lane + S
+    // the rows of the NEXT group of P are fetched while this group is worked on: P full lines in flight per wavefront
+    float cur[P], nxt[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) cur[k] = src[(size_t)akz_reflect(y0 - 2 * S + k, h) * w + cx];
+    for (int t0 = 0; t0 < T; t0 += P) {
+#pragma unroll
+        for (int k = 0; k < P; ++k) nxt[k] = src[(size_t)akz_reflect(y0 - 2 * S + t0 + P + k, h) * w + cx];
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const int t = t0 + k;
+            if (t >= T) break;
+            const int km = (k + P - S) % P, kmm = (k + P - 2 * S) % P;  // ring slots of the rows S and 2S back
+            const int v = y0 - 2 * S + t;
+            // stage 1
+            const float sc = cur[k];
+            const float sm = shl(sc), sp = shr(sc);
+            D[k] = sp - sm;
+            U[k] = mid * sc + norm * (sm + sp);
+            if (t < 2 * S) continue;
+            // stage 2: row q
+            const int q = v - S;
+            const float lx = mid * D[km] + norm * (D[kmm] + D[k]);
+            const float ly = U[k] - U[kmm];
+            if (q >= y0 && q < y0 + rows && out_lane) {
+                const size_t o = fo + (size_t)q * w + gx;
+                dx[o] = lx;
+                dy[o] = ly;
+            }
+            const float lxf = colv ? -lx : lx;
+            const float lyf = (q < 0 || q >= h) ? -ly : ly;
+            // stage 3
+            const float xm = shl(lxf), xp = shr(lxf), ym = shl(lyf), yp = shr(lyf);
+            DX[k] = xp - xm;
+            UX[k] = mid * lxf + norm * (xm + xp);
+            UY[k] = mid * lyf + norm * (ym + yp);
+            if (t < 4 * S) continue;
+            // stage 4: row p
+            const int pr = q - S;
+            const float lxx = (mid * DX[km] + norm * (DX[kmm] + DX[k])) * fs2;
+            const float lyy = (UY[k] - UY[kmm]) * fs2;
+            const float lxy = (UX[k] - UX[kmm]) * fs2;
+            if (out_lane) Ldet[fo + (size_t)pr * w + gx] = lxx * lyy - lxy * lxy;
+        }
+#pragma unroll
+        for (int k = 0; k < P; ++k) cur[k] = nxt[k];
+    }
+}
+
 // ---------------- launchers ----------------
 static inline dim3 akz_grid1(int w, int h, int nframes, int tw, int th) {  // 1-D, padded to a multiple of 8 (XCD remap)
     const int total = ((w + tw - 1) / tw) * ((h + th - 1) / th) * nframes;
@@ -495,8 +586,18 @@ extern "C" int afv_akz_launch_fed_fused(const float *Lt_in, const float *lsm, in
 }
 
 // dx, dy: the level's first-derivative planes (unscaled; written here, kept for the descriptor stage)
-extern "C" int afv_akz_launch_hessian(const float *lsm, int w, int h, int nframes, int s, float *dx, float *dy, float *Ldet, hipStream_t st) {
+extern "C" int afv_akz_launch_hessian(const float *lsm, int w, int h, int nframes, int s, int two_kernels, float *dx, float *dy, float *Ldet,
+                                      hipStream_t st) {
     if (s < 1 || s > AKZ_MAX_S) return -1;
+    if (s >= 2 && s <= 4 && !two_kernels) {
+        const int ow = 64 - 4 * s;
+        const int strips = ((w + ow - 1) / ow) * ((h + AKZ_DH_ROWS - 1) / AKZ_DH_ROWS) * nframes;
+        const dim3 g((strips + 3) / 4);
+        if (s == 2) hipLaunchKernelGGL(k_akz_dhess<2>, g, dim3(256), 0, st, lsm, w, h, nframes, dx, dy, Ldet);
+        else if (s == 3) hipLaunchKernelGGL(k_akz_dhess<3>, g, dim3(256), 0, st, lsm, w, h, nframes, dx, dy, Ldet);
+        else hipLaunchKernelGGL(k_akz_dhess<4>, g, dim3(256), 0, st, lsm, w, h, nframes, dx, dy, Ldet);
+        return 0;
+    }
     const size_t plane = (size_t)(AT_W + 2 * s) * (AT_H + 2 * s) * sizeof(float);
     hipLaunchKernelGGL(k_akz_deriv1, akz_grid(w, h, nframes), dim3(AKZ_T), plane, st, lsm, w, h, nframes, s, dx, dy);
     hipLaunchKernelGGL(k_akz_hessian, akz_grid(w, h, nframes), dim3(AKZ_T), 2 * plane, st, dx, dy, w, h, nframes, s, Ldet);

@@ -67,16 +67,18 @@ def test_scale_space_stages_bit_exact(afv, akz, w, h):
 
 
 def test_fused_and_step_by_step_scale_space_agree(afv):
-    """the fused level kernel (conductivity + whole FED cycle in LDS) against one kernel per step, at a size whose tiles are
-    ragged on both axes"""
+    """the fused level kernel (conductivity + whole FED cycle in LDS) against one kernel per step, and the one-pass derivative /
+    Hessian strip kernel against its two-kernel form, at a size whose tiles are ragged on both axes"""
     ctx = afv.AkazeContext(afv.akaze.default_params(max_width=700, max_height=404, max_batch=1))
     frame = _frames(afv, 700, 404, (8,))
     plan = ctx.scale_space(frame)
-    fused = [ctx.plane(0, i, afv.akaze.LT) for i in range(plan.nlevels)]
-    ctx.set_step_by_step(True)
+    planes = (afv.akaze.LT, afv.akaze.LX, afv.akaze.LY, afv.akaze.LDET)
+    fused = [[ctx.plane(0, i, which) for which in planes] for i in range(plan.nlevels)]
+    ctx.set_step_by_step(True)  # also: first derivatives and Hessian as two LDS-tiled kernels instead of the one-pass strip kernel
     ctx.scale_space(frame)
     for i in range(plan.nlevels):
-        assert np.array_equal(ctx.plane(0, i, afv.akaze.LT), fused[i]), i
+        for k, which in enumerate(planes):
+            assert np.array_equal(ctx.plane(0, i, which), fused[i][k]), (i, which)
     ctx.close()
 
 
