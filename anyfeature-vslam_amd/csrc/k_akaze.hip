@@ -257,8 +257,13 @@ __device__ __forceinline__ float akz_from_right(float v) {  // lane i <- lane i 
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
 
-__global__ __launch_bounds__(AKZ_FT) void k_akz_fed_fused(const float *__restrict__ Lt_in, const float *__restrict__ lsm, int w, int h, int nframes,
-                                                          const float *__restrict__ kcontrast, int octave, int nsteps, AkzTau tau,
+// GAUSS: the level's Lsmooth = GaussianBlur(Lt_in, 5 x 5, sigma 1, BORDER_REPLICATE) is computed here as well (k_akz_gauss<2, false>'s
+// expressions on a tile with two more rings, rows then columns) and written out for the derivative kernels, instead of being read
+// back from a kernel that ran just before: Lt_in is read once for both, Lsmooth is never read by this kernel.
+#define AKZ_FSRC 70  // source tile edge: 66 + 2 x 2
+template <bool GAUSS>
+__global__ __launch_bounds__(AKZ_FT) void k_akz_fed_fused(const float *__restrict__ Lt_in, float *__restrict__ lsm, const float *__restrict__ taps, int w,
+                                                          int h, int nframes, const float *__restrict__ kcontrast, int octave, int nsteps, AkzTau tau,
                                                           float *__restrict__ Lt_out) {
     extern __shared__ float s_fed[];
     const int N = nsteps;
@@ -266,22 +271,94 @@ __global__ __launch_bounds__(AKZ_FT) void k_akz_fed_fused(const float *__restric
     const int LH = AKZ_FH + 2 * N;                      // tile rows incl. halo (<= 64)
     constexpr int SW = 66;                              // Lsmooth plane: tile + one more ring
     const int SH = LH + 2;
-    float *s_s = s_fed;                                 // [SH][SW]
-    float *s_x = s_fed + SW * 66;                       // boundary-row exchange: [2 parities][2 (top, bottom)][8 waves][64]
+    float *s_s = s_fed;                                 // [SH][SW]  (GAUSS: on top of the source tile, which is dead by then)
+    float *s_x = s_fed + (GAUSS ? AKZ_FSRC * AKZ_FSRC : SW * 66);  // boundary-row exchange: [2 parities][2 (top, bottom)][8 waves][64]
     AKZ_TILE(OW, AKZ_FH)
-    const float *pin = Lt_in + (size_t)f * w * h, *ps = lsm + (size_t)f * w * h;
+    const float *pin = Lt_in + (size_t)f * w * h;
     const int tx = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int ly = wv; ly < SH; ly += AKZ_FT / 64) {
-        const float *rs = ps + (size_t)akz_reflect(y0 - N - 1 + ly, h) * w;
-        for (int lx = tx; lx < SW; lx += 64) s_s[ly * SW + lx] = rs[akz_reflect(x0 - N - 1 + lx, w)];
+    const int gx = x0 - N + tx;
+    const int r0 = wv * AKZ_FR;
+    float L[AKZ_FR];
+    if (GAUSS) {
+        float *s_src = s_fed;                                        // [SH + 4][AKZ_FSRC], replicate coordinates
+        float *s_row = s_fed + AKZ_FSRC * AKZ_FSRC + 2 * 2 * 8 * 64;  // [SH + 4][SW] after the row pass
+        const float k0 = taps[2], k1 = taps[3], k2 = taps[4];
+        for (int py = wv; py < SH + 4; py += AKZ_FT / 64) {
+            const float *rs = pin + (size_t)akz_clamp(y0 - N - 3 + py, h) * w;
+            for (int px = tx; px < AKZ_FSRC; px += 64) s_src[py * AKZ_FSRC + px] = rs[akz_clamp(x0 - N - 3 + px, w)];
+        }
+        __syncthreads();
+        // the band's own pixels of Lt (tile row r0 + j, tile column tx) sit in the source tile
+#pragma unroll
+        for (int j = 0; j < AKZ_FR; ++j) L[j] = s_src[min(r0 + j + 3, SH + 3) * AKZ_FSRC + tx + 3];
+        // both passes as runs of 9 outputs from a 13-value register window (a tap is read from LDS once, not five times)
+        constexpr int RUN = 9;  // 8 runs cover 66 columns / up to 66 rows
+        for (int i = threadIdx.x; i < (SH + 4) * 8; i += AKZ_FT) {  // row pass: item = (source row, run of columns)
+            const int g = i / (SH + 4), py = i - g * (SH + 4);
+            const int c0 = g * RUN, n = min(RUN, SW - c0);
+            const float *c = &s_src[py * AKZ_FSRC + c0];
+            float v[RUN + 4];
+#pragma unroll
+            for (int k = 0; k < RUN + 4; ++k) v[k] = c[min(k, n + 3)];
+#pragma unroll
+            for (int k = 0; k < RUN; ++k) {
+                float a = k0 * v[k + 2];
+                a += k1 * (v[k + 3] + v[k + 1]);
+                a += k2 * (v[k + 4] + v[k]);
+                if (k < n) s_row[py * SW + c0 + k] = a;
+            }
+        }
+        __syncthreads();
+        float *pl = lsm + (size_t)f * w * h;
+        for (int i = threadIdx.x; i < SW * 8; i += AKZ_FT) {  // column pass: item = (column, run of rows)
+            const int g = i / SW, lx = i - g * SW;
+            const int l0 = g * RUN, n = min(RUN, SH - l0);
+            if (n <= 0) continue;
+            const float *c = &s_row[l0 * SW + lx];
+            float v[RUN + 4];
+#pragma unroll
+            for (int k = 0; k < RUN + 4; ++k) v[k] = c[min(k, n + 3) * SW];
+            const int ix = x0 - N - 1 + lx;
+#pragma unroll
+            for (int k = 0; k < RUN; ++k) {
+                float a = k0 * v[k + 2];
+                a += k1 * (v[k + 3] + v[k + 1]);
+                a += k2 * (v[k + 4] + v[k]);
+                if (k < n) {
+                    const int ly = l0 + k, iy = y0 - N - 1 + ly;
+                    s_s[ly * SW + lx] = a;
+                    // this tile owns the outputs (x0 .. x0 + OW) x (y0 .. y0 + AKZ_FH): their Lsmooth goes out for the derivative kernels
+                    if (ly > N && ly <= N + AKZ_FH && lx > N && lx <= N + OW && iy < h && ix < w) pl[(size_t)iy * w + ix] = a;
+                }
+            }
+        }
+        __syncthreads();
+        // entries outside the image (border tiles only): the conductivity stencil reads Lsmooth at BORDER_REFLECT_101 coordinates;
+        // the mirror entry is inside the tile for everything a valid pixel can reach (N + 1 pixels beyond the border), further out
+        // it is clamped
+        if (x0 - N - 1 < 0 || y0 - N - 1 < 0 || x0 - N - 1 + SW > w || y0 - N - 1 + SH > h) {
+            for (int ly = wv; ly < SH; ly += AKZ_FT / 64)
+                for (int lx = tx; lx < SW; lx += 64) {
+                    const int iy = y0 - N - 1 + ly, ix = x0 - N - 1 + lx;
+                    if (iy < 0 || iy >= h || ix < 0 || ix >= w) {
+                        const int my = min(max(akz_reflect(iy, h) - (y0 - N - 1), 0), SH - 1), mx = min(max(akz_reflect(ix, w) - (x0 - N - 1), 0), SW - 1);
+                        s_s[ly * SW + lx] = s_s[my * SW + mx];
+                    }
+                }
+            __syncthreads();
+        }
+    } else {
+        const float *ps = lsm + (size_t)f * w * h;
+        for (int ly = wv; ly < SH; ly += AKZ_FT / 64) {
+            const float *rs = ps + (size_t)akz_reflect(y0 - N - 1 + ly, h) * w;
+            for (int lx = tx; lx < SW; lx += 64) s_s[ly * SW + lx] = rs[akz_reflect(x0 - N - 1 + lx, w)];
+        }
+        __syncthreads();
     }
-    __syncthreads();
     float k = kcontrast[f];
     for (int i = 0; i < octave; ++i) k = k * 0.75f;
     const float k2inv = 1.0f / (k * k);
-    const int gx = x0 - N + tx;
     const bool col_in = gx >= 0 && gx < w, has_r = gx + 1 < w, has_l = gx > 0;
-    const int r0 = wv * AKZ_FR;
     // conductivity of the band rows and of the rows just above / below it (rows outside the tile are never used by a valid pixel)
     float c[AKZ_FR + 2];
     {
@@ -312,7 +389,7 @@ __global__ __launch_bounds__(AKZ_FT) void k_akz_fed_fused(const float *__restric
     // tile: they keep their value) are folded into the conductivity sums once, instead of four selects + one per pixel and step:
     // a zero conductivity makes the flux term +-0, and Lc + hs * (+-0) == Lc for every Lc except -0.0, which a smoothed
     // non-negative image never holds.
-    float cR[AKZ_FR], cL[AKZ_FR], cD[AKZ_FR], cU[AKZ_FR], L[AKZ_FR];
+    float cR[AKZ_FR], cL[AKZ_FR], cD[AKZ_FR], cU[AKZ_FR];
 #pragma unroll
     for (int j = 0; j < AKZ_FR; ++j) {
         const float cc = c[j + 1];
@@ -323,7 +400,7 @@ __global__ __launch_bounds__(AKZ_FT) void k_akz_fed_fused(const float *__restric
         cL[j] = upd && has_l ? cl : 0.0f;
         cD[j] = upd && gy + 1 < h ? cc + c[j + 2] : 0.0f;
         cU[j] = upd && gy > 0 ? c[j] + cc : 0.0f;
-        L[j] = pin[(size_t)akz_clamp(gy, h) * w + akz_clamp(gx, w)];
+        if (!GAUSS) L[j] = pin[(size_t)akz_clamp(gy, h) * w + akz_clamp(gx, w)];
     }
     for (int st = 0; st < N; ++st) {
         // boundary rows of every band through LDS (double-buffered by step parity: one barrier per step)
@@ -573,15 +650,22 @@ extern "C" void afv_akz_launch_nld_step(const float *Lt, const float *flow, int 
 }
 
 // returns 0 when the cycle does not fit the fused kernel (the caller then steps through k_akz_flow + k_akz_nld_step)
-extern "C" int afv_akz_launch_fed_fused(const float *Lt_in, const float *lsm, int w, int h, int nframes, const float *kcontrast, int octave,
-                                        int nsteps, const float *tau, float *Lt_out, hipStream_t st) {
+// taps != nullptr: the 5 taps of the level's Gaussian; Lsmooth is then COMPUTED here (and written to lsm) instead of read
+extern "C" int afv_akz_launch_fed_fused(const float *Lt_in, float *lsm, const float *taps, int w, int h, int nframes, const float *kcontrast,
+                                        int octave, int nsteps, const float *tau, float *Lt_out, hipStream_t st) {
     if (nsteps < 1 || nsteps > AKZ_FED_MAX) return 0;
     AkzTau t{};
     for (int i = 0; i < nsteps; ++i) t.t[i] = tau[i];
     const int OW = 64 - 2 * nsteps;
-    const size_t lds = ((size_t)66 * 66 + 2 * 2 * 8 * 64) * sizeof(float);
-    hipLaunchKernelGGL(k_akz_fed_fused, akz_grid1(w, h, nframes, OW, AKZ_FH), dim3(AKZ_FT), lds, st, Lt_in, lsm, w, h, nframes, kcontrast, octave,
-                       nsteps, t, Lt_out);
+    if (taps) {
+        const size_t lds = ((size_t)AKZ_FSRC * AKZ_FSRC + 2 * 2 * 8 * 64 + (size_t)AKZ_FSRC * 66) * sizeof(float);
+        hipLaunchKernelGGL(k_akz_fed_fused<true>, akz_grid1(w, h, nframes, OW, AKZ_FH), dim3(AKZ_FT), lds, st, Lt_in, lsm, taps, w, h, nframes, kcontrast,
+                           octave, nsteps, t, Lt_out);
+    } else {
+        const size_t lds = ((size_t)66 * 66 + 2 * 2 * 8 * 64) * sizeof(float);
+        hipLaunchKernelGGL(k_akz_fed_fused<false>, akz_grid1(w, h, nframes, OW, AKZ_FH), dim3(AKZ_FT), lds, st, Lt_in, lsm, taps, w, h, nframes, kcontrast,
+                           octave, nsteps, t, Lt_out);
+    }
     return 1;
 }
 

@@ -86,5 +86,33 @@ cd "$ROOT" && $PY bench.py --workload akaze61 --batch 64 --steps 5 > "$OUT/bench
 timeout 400 rocprofv3 --kernel-trace --stats -d "$OUT/stats_akaze" -o st --output-format csv -- $PY "$ROOT/bench.py" --workload akaze61 --batch 64 --steps 3 --cpu-frames 0 > /dev/null 2>&1
 cp "$(find "$OUT/stats_akaze" -name "*kernel_stats.csv" | head -1)" "$OUT/kernel_stats_akaze61.csv"
 
-rm -rf "$OUT"/calib_FETCH_SIZE "$OUT"/calib_WRITE_SIZE "$OUT"/stats_default "$OUT"/stats_pairs "$OUT"/stats_akaze "$OUT"/pmc_FETCH_SIZE "$OUT"/pmc_WRITE_SIZE "$OUT"/pmc_SQ_INSTS_VALU "$OUT"/pmc_LDS "$OUT"/pmc_L2 "$OUT"/pmc_pairs
+echo "== AKAZE scale space + Hessian: fabric traffic per frame (FETCH_SIZE / WRITE_SIZE, separate passes, calibrated as above)"
+AKB=16
+for C in FETCH_SIZE WRITE_SIZE; do
+  cd "$ROOT" && timeout 400 rocprofv3 --kernel-trace --pmc $C -d "$OUT/pmc_akz_$C" -o p --output-format csv -- $PY tools/akaze_scale_space_only.py $AKB 2 > /dev/null 2>&1; cd /tmp
+done
+$PY - "$OUT" $AKB 2 <<'PYEOF'
+import csv, glob, json, sys
+out, B, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+cal = json.load(open(out + "/calib_fetch.json"))
+tot, per_kernel = {}, {}
+for C in ("FETCH_SIZE", "WRITE_SIZE"):
+    for p in glob.glob(out + "/pmc_akz_%s/**/*counter_collection.csv" % C, recursive=True):
+        for r in csv.DictReader(open(p)):
+            if r["Counter_Name"] == C and "k_akz_" in r["Kernel_Name"]:
+                k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                per_kernel.setdefault(k, {}).setdefault(C, 0.0)
+                per_kernel[k][C] += float(r["Counter_Value"])
+                tot[C] = tot.get(C, 0.0) + float(r["Counter_Value"])
+fr, wr = cal.get("fetch_ratio_4B") or 0.5, cal.get("write_ratio_4B") or 1.0
+def mb(d):
+    return (d.get("FETCH_SIZE", 0.0) * 1024 / fr + d.get("WRITE_SIZE", 0.0) * 1024 / wr) / (B * steps) / 1e6
+res = {"frames": B, "scale_space_calls": steps, "hbm_MB_per_frame": mb(tot), "algorithmic_MB_per_frame": 126.2592,
+       "per_kernel_MB_per_frame": {k: round(mb(v), 2) for k, v in sorted(per_kernel.items())}}
+res["ratio_to_algorithmic"] = res["hbm_MB_per_frame"] / res["algorithmic_MB_per_frame"]
+json.dump(res, open(out + "/akaze_traffic_pmc.json", "w"), indent=1)
+print(json.dumps(res))
+PYEOF
+
+rm -rf "$OUT"/pmc_akz_FETCH_SIZE "$OUT"/pmc_akz_WRITE_SIZE "$OUT"/calib_FETCH_SIZE "$OUT"/calib_WRITE_SIZE "$OUT"/stats_default "$OUT"/stats_pairs "$OUT"/stats_akaze "$OUT"/pmc_FETCH_SIZE "$OUT"/pmc_WRITE_SIZE "$OUT"/pmc_SQ_INSTS_VALU "$OUT"/pmc_LDS "$OUT"/pmc_L2 "$OUT"/pmc_pairs
 ls -la "$OUT"
