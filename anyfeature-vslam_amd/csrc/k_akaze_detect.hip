@@ -3,18 +3,19 @@
 // Do_Subpixel_Refinement (the calls behind FeatureExtractor_akaze61::detectKeypoints, Feature_akaze61.cpp:38-47); the
 // operation order is the one written down in oracle/akaze.c.
 //
-//  1. candidates: a tiled pass turns every level's Ldet plane into a bitmap of (3x3 strict maximum + thresholds +
+//  1. candidates: a streaming pass turns every level's Ldet plane into a bitmap of (3x3 strict maximum + thresholds +
 //     descriptor-border rule); one workgroup per (level, frame) then counts the rows from the bitmap, scans them and
 //     expands the bits, which leaves the candidates in RASTER order without a sort (upstream's loop order is part of
 //     the result).
 //  2. k_akz_suppress: upstream inserts the candidates one by one into kpts_aux, comparing each against the FIRST earlier
-//     entry of the same / previous level within its radius (replace it or drop the newcomer).  One workgroup per frame
-//     replays that loop in speculative rounds of AKD_R (128) consecutive candidates: the (candidate, grid cell) pairs of a round
-//     are scanned by all threads in two uniform grids (previous level, current level; entries inline in the cell lists,
-//     list lengths in LDS); then every candidate checks exactly whether an earlier candidate of the round changes what
-//     its search saw (a new / moved entry inside its radius, or a replaced entry that lay inside it) and the round
-//     commits, in parallel, up to the first such candidate.
-//  3. the upper-level filter, the 2x2 sub-pixel solve and the ordered compaction run at the end of the same kernel.
+//     entry of the same / previous level within its radius (replace it or drop the newcomer).  One workgroup per (frame,
+//     level) replays that loop in speculative rounds of AKD_R (128) consecutive candidates: the (candidate, grid cell) pairs
+//     of a round are scanned by all threads in two uniform grids (the level below, this level; entries inline in the cell
+//     lists); then every candidate checks exactly whether an earlier candidate of the round changes what its search saw (a
+//     new / moved entry inside its radius, or a replaced entry that lay inside it) and the round commits, in parallel, up to
+//     the first such candidate.  The levels of a frame run as a pipeline (see the kernel); the upper-level filter of a level
+//     pair runs in the workgroup that finishes it.
+//  3. k_akz_refine_a / _b: the 2x2 sub-pixel solve and the ordered compaction over the slot space.
 #include "afv_device.h"
 #include "../../include/afv_hip.h"
 
