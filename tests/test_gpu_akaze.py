@@ -124,6 +124,16 @@ def test_detection_matches_oracle(afv, akz, w, h, seeds):
         assert len(got) == len(want) and len(want) > 500
         for name in ("x", "y", "size", "angle", "response", "octave", "class_id"):
             assert np.array_equal(got[name], want[name]), (f, name)
+    # the step-by-step scale space (separate Gaussian, one kernel per FED step, two derivative kernels) must lead to the same detection
+    first = [[ctx.candidates(f, i) for i in range(plan.nlevels)] for f in range(len(seeds))]
+    kps = [ctx.keypoints(f) for f in range(len(seeds))]
+    ctx.set_step_by_step(True)
+    ctx.scale_space(frames)
+    ctx.detect()
+    for f in range(len(seeds)):
+        for i in range(plan.nlevels):
+            assert np.array_equal(ctx.candidates(f, i), first[f][i]), (f, i)
+        assert ctx.keypoints(f).tobytes() == kps[f].tobytes(), f
     ctx.close()
 
 
