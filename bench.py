@@ -943,15 +943,37 @@ def main():
                 except Exception:
                     pass
                 pk = classes.get("v_pk_min_i16+add")
+                # ONE blended peak: static op-class shares of every kernel (tools/isa_valu_classes.py, from the ISA) weighted with
+                # the kernels' dynamic instruction counts (PMC), every class at its measured issue rate
+                isa = _newest_profile("isa_valu_classes.json")
+                mix_peak = None
+                if isa and not isa["_stale"] and classes.get("v_add_u32"):
+                    plain = classes["v_add_u32"]
+                    rate = {"plain": plain, "pk_i16": pk or plain, "pk_mad": classes.get("v_pk_mad_u16", plain),
+                            "dot": classes.get("v_dot4_u32_u8", plain)}
+                    xb = classes.get("xor+bcnt")
+                    rate["bcnt"] = 1.0 / (2.0 / xb - 1.0 / plain) if xb else plain  # the calibration loop alternates xor and bcnt
+                    n_tot, t_tot = 0.0, 0.0
+                    for k, v in vp["kernels"].items():
+                        sh = isa["kernels"].get(k, {}).get("shares")
+                        if not sh:
+                            continue
+                        n = v["valu_winst_per_frame"]
+                        n_tot += n
+                        t_tot += n * sum(share / rate.get(c, plain) for c, share in sh.items())
+                    mix_peak = n_tot / t_tot if t_tot > 0 else None
                 out["valu_issue"] = {"achieved": None if stale else ach, "peak": vp["valu_peak_winst_per_s"], "unit": "wave-instr/s",
                                      "frac": None if stale else ach / vp["valu_peak_winst_per_s"], "stale": stale, "source": vp["_path"],
                                      "peak_by_op_class": classes,
                                      "frac_vs_packed_i16_class": None if (stale or not pk) else ach / pk,
+                                     "peak_isa_mix": mix_peak, "frac_vs_isa_mix": None if (stale or not mix_peak) else ach / mix_peak,
                                      "kernels_winst_per_frame": {k: v["valu_winst_per_frame"] for k, v in vp["kernels"].items()},
                                      "note": "whole pipeline: SQ_INSTS_VALU per frame (committed PMC pass of tools/collect_profiles.sh, stamped with the "
                                              "sha of the sources it ran on) x live frames/s vs the integer-VALU issue rates measured by tools/calib_valu.hip "
                                              "on the same box: peak = the fastest op class (plain 32-bit adds); the packed-i16 / dot4 / popcount ops that "
-                                             "make up most of this pipeline issue at the packed class rate.  stale = the sources changed since the pass, "
+                                             "make up most of this pipeline issue at the packed class rate; peak_isa_mix blends the class rates with every kernel's static "
+                                             "op-class shares (profiles/r*/isa_valu_classes.json) and dynamic counts - uncalibrated classes at the plain rate, so "
+                                             "frac_vs_isa_mix is a lower bound.  stale = the sources changed since the pass, "
                                              "the fractions are withheld"}
             out["stage_ms_per_step"] = {kk: (v["total_ms"] / prof_steps) for kk, v in stages.items()}  # overlapping streams: sums exceed ms_per_step
             out["stage_events_on_steps"] = "%d of %d timed steps (every %d-th)" % (prof_steps, args.steps, PROF_EVERY)

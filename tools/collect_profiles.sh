@@ -72,6 +72,9 @@ cd "$ROOT" && $PY tools/pmc_per_frame.py $B $((STEPS + WARM)) "$OUT" "$OUT/pmc_F
 $PY tools/pmc_summary.py "$OUT/pmc_lds_counter_collection.csv" "$OUT/pmc_l2_counter_collection.csv" > "$OUT/pmc_lds_l2_summary.txt" 2>/dev/null
 cd /tmp
 
+echo "== static VALU op-class shares of the kernels (from the ISA; feeds valu_issue.peak_isa_mix)"
+cd "$ROOT" && $PY tools/isa_valu_classes.py "$OUT/isa_valu_classes.json" > "$OUT/isa_valu_classes.txt" 2>&1; cd /tmp
+
 echo "== config #4: pairs10k bench + kernel stats"
 cd "$ROOT" && $PY bench.py --workload pairs10k > "$OUT/bench_pairs10k.json" 2> "$OUT/bench_pairs10k.err"; cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats -d "$OUT/stats_pairs" -o st --output-format csv -- $PY "$ROOT/bench.py" --workload pairs10k --steps 5 --cpu-frames 0 > /dev/null 2>&1
