@@ -432,8 +432,9 @@ static int enqueue_extract(afv_ctx *c, const FrameSrc &src, int nframes, afv_key
         HIPCHK(c, hipEventRecord(c->ev_fork, s));
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
         // automatic: chunks of ~85 frames (measured optimum at 640x480: large enough to fill the chip, small enough that the
-        // latency-bound kernels of one chunk hide behind the VALU-bound ones of the next)
-        const int K = c->split_chunks ? c->split_chunks : std::min(64, std::max(2, (nframes + 42) / 85));
+        // latency-bound kernels of one chunk hide behind the VALU-bound ones of the next), and an EVEN number of them: an odd
+        // last chunk runs with nothing beside it (256 frames: 2 chunks 1.55 ms, 3 chunks 1.61; 384: 4 chunks 2.25, 5 chunks 2.33)
+        const int K = c->split_chunks ? c->split_chunks : std::min(64, 2 * std::max(1, (int)((float)nframes / 170.0f + 0.45f)));
         for (int k = 0; k < K; ++k) {  // chunk k on stream k % 2
             const int b = (int)((long)nframes * k / K), e = (int)((long)nframes * (k + 1) / K);
             if (e > b) enqueue_range(c, src, b, e - b, d_kps, d_desc, cap, d_n, d_status, (k & 1) ? c->stream2 : s);
