@@ -171,6 +171,22 @@ def test_level_pipeline_under_load(afv, akz):
     ctx.close()
 
 
+def test_detection_survives_the_epoch_wrap(afv):
+    """list elements of the suppression grids carry a 14-bit launch epoch; when it wraps the grids are wiped (akaze_api.hip).  More
+    launches than that on one context: the keypoints never change"""
+    w, h = 160, 96
+    ctx = afv.AkazeContext(afv.akaze.default_params(max_width=w, max_height=h, max_batch=2))
+    ctx.scale_space(_frames(afv, w, h, (21, 22)))
+    ctx.detect()
+    first = [ctx.keypoints(f).tobytes() for f in range(2)]
+    assert len(first[0]) > 0
+    for i in range(0x3fff + 40):
+        ctx.detect()
+        if i % 4096 == 0 or i > 0x3fff - 8:
+            assert [ctx.keypoints(f).tobytes() for f in range(2)] == first, i
+    ctx.close()
+
+
 def _oracle_detect_and_compute(afv, akz, oracle, op, frame, quotas, w, h):
     """FeatureExtractor_akaze61::detectAndCompute restated with the oracle pieces: Feature_Detection, bucket by class_id,
     DistributeOctTree per level (oracle/afvo.c), Compute_Descriptors on the levels in ascending order"""
