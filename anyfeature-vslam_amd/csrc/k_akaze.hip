@@ -51,42 +51,78 @@ template <int R, bool U8>
 __global__ __launch_bounds__(AKZ_T) void k_akz_gauss(const void *__restrict__ src_v, int src_stride, size_t src_frame_stride, int w, int h,
                                                      int nframes, const float *__restrict__ taps, float *__restrict__ dst) {
     constexpr int LW = AT_W + 2 * R, LH = AT_H + 2 * R;
-    __shared__ float s_in[LW * LH];
+    constexpr int LP = LW | 1;  // odd LDS pitch: the row pass walks down rows lane by lane
+    constexpr int RUN = 8;      // outputs per register window: a tap is read from LDS once per run, not once per output
+    __shared__ float s_in[LP * LH];
     __shared__ float s_row[AT_W * LH];
-    __shared__ float s_k[2 * R + 1];
     AKZ_TILE(AT_W, AT_H)
-    if (threadIdx.x < 2 * R + 1) s_k[threadIdx.x] = taps[threadIdx.x];
+    float k[R + 1];  // k[j] = tap at distance j
+#pragma unroll
+    for (int j = 0; j <= R; ++j) k[j] = taps[R + j];
     if (U8) {
         const uint8_t *src = reinterpret_cast<const uint8_t *>(src_v) + (size_t)f * src_frame_stride;
         const float a = (float)(1.0 / 255.0);
+        if (LW % 4 == 0 && x0 - R >= 0 && x0 - R + LW <= w) {
+            // no column of the tile is clamped: four pixels per load (LW = 64 + 2R is a multiple of 4 for even R)
+            for (int i = threadIdx.x; i < (LW / 4) * LH; i += AKZ_T) {
+                const int ly = i / (LW / 4), q = i - ly * (LW / 4);
+                const int gy = akz_clamp(y0 - R + ly, h);
+                uint32_t v;
+                __builtin_memcpy(&v, src + (size_t)gy * src_stride + (x0 - R + 4 * q), 4);
+                float *d = &s_in[ly * LP + 4 * q];
+                d[0] = (float)(v & 0xffu) * a;
+                d[1] = (float)((v >> 8) & 0xffu) * a;
+                d[2] = (float)((v >> 16) & 0xffu) * a;
+                d[3] = (float)(v >> 24) * a;
+            }
+        } else {
+            for (int i = threadIdx.x; i < LW * LH; i += AKZ_T) {
+                const int ly = i / LW, lx = i - ly * LW;
+                const int gx = akz_clamp(x0 - R + lx, w), gy = akz_clamp(y0 - R + ly, h);
+                s_in[ly * LP + lx] = (float)src[(size_t)gy * src_stride + gx] * a;
+            }
+        }
+    } else {
+        const float *src = reinterpret_cast<const float *>(src_v) + (size_t)f * src_frame_stride;
         for (int i = threadIdx.x; i < LW * LH; i += AKZ_T) {
             const int ly = i / LW, lx = i - ly * LW;
             const int gx = akz_clamp(x0 - R + lx, w), gy = akz_clamp(y0 - R + ly, h);
-            s_in[i] = (float)src[(size_t)gy * src_stride + gx] * a;
+            s_in[ly * LP + lx] = src[(size_t)gy * w + gx];
         }
-    } else {
-        akz_stage<R, false>(reinterpret_cast<const float *>(src_v) + (size_t)f * src_frame_stride, w, h, x0, y0, s_in);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < AT_W * LH; i += AKZ_T) {
-        const int ly = i / AT_W, lx = i - ly * AT_W;
-        const float *c = &s_in[ly * LW + lx + R];
-        float s = s_k[R] * c[0];
+    // rows: item = (tile row, run of RUN columns)
+    for (int i = threadIdx.x; i < LH * (AT_W / RUN); i += AKZ_T) {
+        const int g = i / LH, ly = i - g * LH;
+        const float *c = &s_in[ly * LP + g * RUN];
+        float v[RUN + 2 * R];
 #pragma unroll
-        for (int j = 1; j <= R; ++j) s += s_k[R + j] * (c[j] + c[-j]);
-        s_row[i] = s;
+        for (int t = 0; t < RUN + 2 * R; ++t) v[t] = c[t];
+#pragma unroll
+        for (int t = 0; t < RUN; ++t) {
+            float a = k[0] * v[t + R];
+#pragma unroll
+            for (int j = 1; j <= R; ++j) a += k[j] * (v[t + R + j] + v[t + R - j]);
+            s_row[ly * AT_W + g * RUN + t] = a;
+        }
     }
     __syncthreads();
+    // columns: item = (tile column, run of RUN rows): AT_W x AT_H / RUN items == AKZ_T
     float *out = dst + (size_t)f * w * h;
-    for (int i = threadIdx.x; i < AT_W * AT_H; i += AKZ_T) {
-        const int ly = i / AT_W, lx = i - ly * AT_W;
-        const int gx = x0 + lx, gy = y0 + ly;
-        if (gx < w && gy < h) {
-            const float *c = &s_row[(ly + R) * AT_W + lx];
-            float s = s_k[R] * c[0];
+    for (int i = threadIdx.x; i < AT_W * (AT_H / RUN); i += AKZ_T) {
+        const int g = i / AT_W, lx = i - g * AT_W;
+        const float *c = &s_row[g * RUN * AT_W + lx];
+        float v[RUN + 2 * R];
 #pragma unroll
-            for (int j = 1; j <= R; ++j) s += s_k[R + j] * (c[j * AT_W] + c[-j * AT_W]);
-            out[(size_t)gy * w + gx] = s;
+        for (int t = 0; t < RUN + 2 * R; ++t) v[t] = c[t * AT_W];
+        const int gx = x0 + lx;
+#pragma unroll
+        for (int t = 0; t < RUN; ++t) {
+            float a = k[0] * v[t + R];
+#pragma unroll
+            for (int j = 1; j <= R; ++j) a += k[j] * (v[t + R + j] + v[t + R - j]);
+            const int gy = y0 + g * RUN + t;
+            if (gx < w && gy < h) out[(size_t)gy * w + gx] = a;
         }
     }
 }
