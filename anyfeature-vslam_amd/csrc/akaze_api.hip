@@ -13,8 +13,9 @@
 
 extern "C" int afv_akz_launch_gauss(const void *src, int is_u8, int src_stride, size_t src_frame_stride, int w, int h, int nframes,
                                     const float *taps, int ksize, float *dst, hipStream_t st);
-extern "C" void afv_akz_launch_kcontrast(const float *gsm, int w, int h, int nframes, float *modg, unsigned int *hmax_bits, int *hist,
-                                         int nbins, float perc, float *kcontrast, hipStream_t st);
+extern "C" void afv_akz_launch_kcontrast(const float *gsm, const uint8_t *gray, int src_stride, size_t src_frame_stride, const float *taps, int w,
+                                         int h, int nframes, float *modg, unsigned int *hmax_bits, int *hist, int nbins, float perc,
+                                         float *kcontrast, hipStream_t st);
 extern "C" void afv_akz_launch_halfsample(const float *src, int w, int h, float *dst, int dw, int dh, int nframes, hipStream_t st);
 extern "C" void afv_akz_launch_flow(const float *lsm, int w, int h, int nframes, const float *kcontrast, int octave, float *flow,
                                     hipStream_t st);
@@ -403,10 +404,14 @@ static int akz_enqueue(afv_akaze *a, const uint8_t *d_gray, int nframes, int w, 
     if (a->profiling) AKZ_HIPCHK(a, hipEventRecord(a->ev[0], st));
     // level 0: Lt = GaussianBlur(convert(gray), soffset); contrast factor from the sigma = 1 smoothed image
     if (afv_akz_launch_gauss(d_gray, 1, stride, frame_stride, w, h, nframes, a->d_taps, P.ksize_soffset, a->lt[0], st)) return AFV_EUNSUPPORTED;
-    if (afv_akz_launch_gauss(d_gray, 1, stride, frame_stride, w, h, nframes, a->d_taps + 32, P.ksize_one, a->pong, st)) return AFV_EUNSUPPORTED;
+    // the sigma = 1 image only feeds the gradient magnitude: with the usual 5-tap Gaussian it is formed inside that kernel
+    const bool fused_contrast = !a->step_by_step && P.ksize_one == 5;
+    if (!fused_contrast && afv_akz_launch_gauss(d_gray, 1, stride, frame_stride, w, h, nframes, a->d_taps + 32, P.ksize_one, a->pong, st))
+        return AFV_EUNSUPPORTED;
     AKZ_HIPCHK(a, hipMemsetAsync(a->d_hmax, 0, (size_t)nframes * sizeof(unsigned int), st));
     AKZ_HIPCHK(a, hipMemsetAsync(a->d_hist, 0, (size_t)nframes * (nb + 1) * sizeof(int), st));
-    afv_akz_launch_kcontrast(a->pong, w, h, nframes, a->flow, a->d_hmax, a->d_hist, nb, a->prm.kcontrast_percentile, a->d_kcontrast, st);
+    afv_akz_launch_kcontrast(fused_contrast ? nullptr : a->pong, d_gray, stride, (size_t)frame_stride, a->d_taps + 32, w, h, nframes, a->flow, a->d_hmax,
+                             a->d_hist, nb, a->prm.kcontrast_percentile, a->d_kcontrast, st);
     for (int i = 1; i < P.nlevels; ++i) {
         const afv_akaze_level &L = P.lv[i], &Q = P.lv[i - 1];
         const float *src = a->lt[i - 1];

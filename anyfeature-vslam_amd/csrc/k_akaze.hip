@@ -171,6 +171,99 @@ __global__ __launch_bounds__(AKZ_T) void k_akz_modg(const float *__restrict__ gs
     if (threadIdx.x == 0 && s_max) atomicMax(&hmax_bits[f], s_max);
 }
 
+// pass 1 without the detour through HBM: the sigma = 1 image (k_akz_gauss<2, true>'s expressions: convertTo(1/255) + 5 x 5 Gaussian,
+// BORDER_REPLICATE) of the tile and one ring around it stays in LDS, k_akz_modg's expressions run on it.  Only pixels whose whole
+// 3 x 3 neighbourhood is inside the image get a magnitude, so nothing of the ring that lies outside the image is ever used.
+__global__ __launch_bounds__(AKZ_T) void k_akz_contrast_modg(const uint8_t *__restrict__ gray, int src_stride, size_t src_frame_stride, int w, int h,
+                                                             int nframes, const float *__restrict__ taps, float *__restrict__ modg,
+                                                             unsigned int *__restrict__ hmax_bits) {
+    constexpr int R = 3;                          // Gaussian radius 2 + the Scharr ring
+    constexpr int LW = AT_W + 2 * R + 2, LH = AT_H + 2 * R, LP = LW | 1;  // 70 x 38 source pixels, staged as 72 columns from x0 - 4 (dwords)
+    constexpr int PW = AT_W + 2, PH = AT_H + 2;   // smoothed tile + ring: 66 x 34
+    constexpr int RUNX = 11, RUNY = 9;            // 6 x 11 = 66 columns, 4 x 9 >= 34 rows
+    __shared__ float s_in[LP * LH];
+    __shared__ float s_row[PW * LH];
+    __shared__ float s_p[PW * PH];
+    __shared__ unsigned int s_max;
+    AKZ_TILE(AT_W, AT_H)
+    if (threadIdx.x == 0) s_max = 0;
+    const float k0 = taps[2], k1 = taps[3], k2 = taps[4];
+    const uint8_t *src = gray + (size_t)f * src_frame_stride;
+    const float a = (float)(1.0 / 255.0);
+    if (x0 - R - 1 >= 0 && x0 - R - 1 + LW <= w) {  // no column clamped: four pixels per load
+        for (int i = threadIdx.x; i < (LW / 4) * LH; i += AKZ_T) {
+            const int ly = i / (LW / 4), q = i - ly * (LW / 4);
+            const int gy = akz_clamp(y0 - R + ly, h);
+            uint32_t v;
+            __builtin_memcpy(&v, src + (size_t)gy * src_stride + (x0 - R - 1 + 4 * q), 4);
+            float *d = &s_in[ly * LP + 4 * q];
+            d[0] = (float)(v & 0xffu) * a;
+            d[1] = (float)((v >> 8) & 0xffu) * a;
+            d[2] = (float)((v >> 16) & 0xffu) * a;
+            d[3] = (float)(v >> 24) * a;
+        }
+    } else {
+        for (int i = threadIdx.x; i < LW * LH; i += AKZ_T) {
+            const int ly = i / LW, lx = i - ly * LW;
+            const int gx = akz_clamp(x0 - R - 1 + lx, w), gy = akz_clamp(y0 - R + ly, h);
+            s_in[ly * LP + lx] = (float)src[(size_t)gy * src_stride + gx] * a;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < LH * (PW / RUNX); i += AKZ_T) {  // rows: item = (source row, run of 11 columns)
+        const int g = i / LH, ly = i - g * LH;
+        const float *c = &s_in[ly * LP + g * RUNX + 1];  // smoothed column j of the ring-extended tile sits on staged columns j + 1 .. j + 5
+        float v[RUNX + 4];
+#pragma unroll
+        for (int t = 0; t < RUNX + 4; ++t) v[t] = c[t];
+#pragma unroll
+        for (int t = 0; t < RUNX; ++t) {
+            float r = k0 * v[t + 2];
+            r += k1 * (v[t + 3] + v[t + 1]);
+            r += k2 * (v[t + 4] + v[t]);
+            s_row[ly * PW + g * RUNX + t] = r;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PW * 4; i += AKZ_T) {  // columns: item = (column, run of 9 rows)
+        const int g = i / PW, lx = i - g * PW;
+        const int l0 = g * RUNY, n = min(RUNY, PH - l0);
+        const float *c = &s_row[l0 * PW + lx];
+        float v[RUNY + 4];
+#pragma unroll
+        for (int t = 0; t < RUNY + 4; ++t) v[t] = c[min(t, n + 3) * PW];
+#pragma unroll
+        for (int t = 0; t < RUNY; ++t) {
+            float r = k0 * v[t + 2];
+            r += k1 * (v[t + 3] + v[t + 1]);
+            r += k2 * (v[t + 4] + v[t]);
+            if (t < n) s_p[(l0 + t) * PW + lx] = r;
+        }
+    }
+    __syncthreads();
+    float *out = modg + (size_t)f * w * h;
+    unsigned int mx = 0;
+    for (int i = threadIdx.x; i < AT_W * AT_H; i += AKZ_T) {
+        const int ly = i / AT_W, lx = i - ly * AT_W;
+        const int gx = x0 + lx, gy = y0 + ly;
+        if (gx < w && gy < h) {
+            float m = 0.0f;
+            if (gx >= 1 && gx < w - 1 && gy >= 1 && gy < h - 1) {  // the histogram skips the 1 px border
+                const float *c = &s_p[(ly + 1) * PW + lx + 1];
+                const float lxv = akz_scharr_x(c, PW), lyv = akz_scharr_y(c, PW);
+                m = sqrtf(lxv * lxv + lyv * lyv);
+            }
+            out[(size_t)gy * w + gx] = m;
+            mx = max(mx, __float_as_uint(m));  // m >= 0: the bit pattern orders like the value
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned int)__shfl_xor((int)mx, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(&s_max, mx);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_max) atomicMax(&hmax_bits[f], s_max);
+}
+
 // pass 2: histogram of the non-zero magnitudes (bins depend on the frame maximum)
 __global__ __launch_bounds__(AKZ_T) void k_akz_hist(const float *__restrict__ modg, int w, int h, const unsigned int *__restrict__ hmax_bits,
                                                     int nbins, int *__restrict__ hist /* [frame][nbins + 1]: bins, then npoints */) {
@@ -665,9 +758,14 @@ extern "C" int afv_akz_launch_gauss(const void *src, int is_u8, int src_stride, 
 #undef AKZ_GAUSS_CASE
 }
 
-extern "C" void afv_akz_launch_kcontrast(const float *gsm, int w, int h, int nframes, float *modg, unsigned int *hmax_bits, int *hist,
-                                         int nbins, float perc, float *kcontrast, hipStream_t st) {
-    hipLaunchKernelGGL(k_akz_modg, akz_grid(w, h, nframes), dim3(AKZ_T), 0, st, gsm, w, h, nframes, modg, hmax_bits);
+// gsm != nullptr: the sigma = 1 image was written by k_akz_gauss; else it is formed inside the magnitude kernel from the gray frame
+// (5-tap Gaussian `taps`)
+extern "C" void afv_akz_launch_kcontrast(const float *gsm, const uint8_t *gray, int src_stride, size_t src_frame_stride, const float *taps, int w,
+                                         int h, int nframes, float *modg, unsigned int *hmax_bits, int *hist, int nbins, float perc,
+                                         float *kcontrast, hipStream_t st) {
+    if (gsm) hipLaunchKernelGGL(k_akz_modg, akz_grid(w, h, nframes), dim3(AKZ_T), 0, st, gsm, w, h, nframes, modg, hmax_bits);
+    else hipLaunchKernelGGL(k_akz_contrast_modg, akz_grid(w, h, nframes), dim3(AKZ_T), 0, st, gray, src_stride, src_frame_stride, w, h, nframes, taps,
+                            modg, hmax_bits);
     hipLaunchKernelGGL(k_akz_hist, dim3(64, nframes), dim3(AKZ_T), (size_t)(nbins + 1) * sizeof(int), st, modg, w, h, hmax_bits, nbins, hist);
     hipLaunchKernelGGL(k_akz_kperc, dim3((nframes + 63) / 64), dim3(64), 0, st, hist, hmax_bits, nbins, perc, nframes, kcontrast);
 }
