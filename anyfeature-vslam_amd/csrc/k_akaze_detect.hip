@@ -229,8 +229,9 @@ __global__ __launch_bounds__(AKE_T) void k_akz_cand_emit(AkdParams P, const unsi
 //     communication lane polls that number relaxed, issues ONE agent-scope acquire fence, barrier, plain loads.  Correct for any
 //     placement of the workgroups; the ticket order below only makes it fast (one frame's levels share an XCD's L2).
 //   * no dispatch-order assumption: a workgroup draws a ticket from its XCD's counter (falling over to the other XCDs' counters
-//     if its own list is used up) and ticket t of list x is (frame (t / nlevels) * 8 + x, level t % nlevels).  Whoever holds
-//     ticket t is running, and only ever waits for tickets t-1 and t-2 of the same list, whose holders started earlier.
+//     if its own list is used up); a list holds the levels of the frames x, x + 8, ... in groups of G <= 8 frames, level-major
+//     inside a group (decoding below).  Whoever holds ticket t is running, and only ever waits for tickets t - G and t - 2G of
+//     the same list (the two levels below of the same frame), whose holders started earlier.
 // A replaced entry is not unlinked: its old list element is marked dead and a fresh element goes into the list of its new cell
 // (in the replacing candidate's level grid), so every list only grows and all commits of a round run in parallel.
 struct AkdState {
@@ -316,7 +317,13 @@ __global__ __launch_bounds__(AKD_T, 8) void k_akz_suppress(AkdParams P, AkdState
     }
     __syncthreads();
     if (s_item < 0) return;
-    const int f = ((s_item >> 3) / NL) * 8 + (s_item & 7), c = (s_item >> 3) % NL;
+    // ticket t of list x: the list's frames (x, x + 8, ...) in groups of G, level-major inside a group: (frame 0, level 0), (frame 1,
+    // level 0), ..., (frame G-1, level 0), (frame 0, level 1), ...  The level below is G tickets back.  (Workgroups that start one
+    // after the other tend to land on different CUs and the k-th and (k + #CUs)-th on the same one: level-major order puts a busy low
+    // level and a mostly waiting high level together - speed only.)
+    const int nfx = (nframes + 7) / 8, G = min(8, nfx);
+    const int t_ = s_item >> 3, r_ = t_ % (G * NL);
+    const int f = ((t_ / (G * NL)) * G + r_ % G) * 8 + (s_item & 7), c = r_ / G;
     if (f >= nframes) return;
     const AkdLevel L = P.lv[c];
     const AkdLevel Lp = P.lv[c > 0 ? c - 1 : 0];  // the level below
@@ -783,7 +790,8 @@ extern "C" void afv_akz_launch_suppress(const AkdParams *P, const AkdState *S, i
     const size_t lds = (size_t)P->lds_bytes;  // list lengths (u8): a level's own grid + hints of the one below
     (void)hipMemsetAsync(S->ticket, 0, (size_t)(8 + nframes * 16) * sizeof(int), st);
     (void)hipMemsetAsync(S->keep, 1, (size_t)nframes * P->entry_cap, st);
-    const int blocks = (nframes + 7) / 8 * 8 * P->nlevels;
+    const int nfx = (nframes + 7) / 8, G = nfx < 8 ? nfx : 8;  // frames per XCD list, group size (see the ticket decoding in the kernel)
+    const int blocks = (nfx + G - 1) / G * G * P->nlevels * 8;
     hipLaunchKernelGGL(k_akz_suppress, dim3(blocks), dim3(AKD_T), lds, st, *P, *S, nframes, cand, cand_resp, cand_count, row_start, status);
     const int nchunks = (P->entry_cap + AKD_CHUNK - 1) / AKD_CHUNK;
     hipLaunchKernelGGL(k_akz_refine_a, dim3(nchunks, nframes), dim3(AKD_CHUNK), 0, st, *P, *S, cand_count);
