@@ -62,7 +62,10 @@ int afv_akaze_scale_space_device(afv_akaze *a, const uint8_t *d_gray, int nframe
 int afv_akaze_synchronize(afv_akaze *a);
 
 /* Feature_Detection on the scale space built by the last afv_akaze_scale_space* call: Find_Scale_Space_Extrema (ordered
- * duplicate suppression, upper-level filter) + Do_Subpixel_Refinement; keypoints stay on the device (asynchronous). */
+ * duplicate suppression, upper-level filter) + Do_Subpixel_Refinement; keypoints stay on the device (asynchronous).
+ * Capacities per frame: w * h / 8 + 64 extrema candidates per level, 131 072 candidates over all levels (one list slot each),
+ * 65 535 keypoints; beyond that the getters return AFV_ECAPACITY (afv_akaze_last_error names the limit) - never a silently
+ * truncated result. */
 int afv_akaze_detect(afv_akaze *a);
 /* keypoints of one frame in libAKAZE's output order: pt in level-0 pixels, size = 2 * esigma * derivative_factor, angle 0,
  * response = |Ldet|, octave, class_id = evolution level (what FeatureExtractor_akaze61::GetKeypointOctave reads).
