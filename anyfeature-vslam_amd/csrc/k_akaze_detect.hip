@@ -305,7 +305,11 @@ __global__ __launch_bounds__(AKD_T, 8) void k_akz_suppress(AkdParams P, AkdState
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid == 0) {
         const int share = (int)gridDim.x / 8;  // items per XCD list
+#ifdef AFV_AKZ_MIX_XCD  // stress build (tools/experiments.py): every list is served by workgroups of ALL XCDs - the hand-off must not care
+        const int xcc = ((int)blockIdx.x >> 3) & 7;
+#else
         const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);  // HW_REG_XCC_ID[3:0]
+#endif
         int item = -1;
         for (int k = 0; k < 8 && item < 0; ++k) {
             const int x = (xcc + k) & 7;
