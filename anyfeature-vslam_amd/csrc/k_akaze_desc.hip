@@ -166,9 +166,9 @@ __constant__ float k_gauss25[7][7] = {
 __global__ __launch_bounds__(256) void k_akz_describe(AkdDescParams P, const afv_keypoint *__restrict__ kps, const int *__restrict__ sel,
                                                       const int *__restrict__ sel_count, afv_keypoint *__restrict__ out_kps,
                                                       uint8_t *__restrict__ out_desc, int *__restrict__ out_count, int *__restrict__ status) {
-    __shared__ float4 s_ori[4][112];  // orientation samples: {angle, weighted Lx, weighted Ly, angle < 2 pi (as 1 / 0)}
     __shared__ float s_val[4][96];
-    __shared__ float4 s_smp[4][441];  // MLDB samples of the 21 x 21 pattern positions: {Lt, rotated Lx, rotated Ly, -}
+    __shared__ float4 s_smp[4][441];  // MLDB samples of the 21 x 21 pattern positions: {Lt, rotated Lx, rotated Ly, -}; before that, the
+                                      // first 109 entries hold the orientation samples {angle, weighted Lx, weighted Ly, angle < 2 pi (as 1 / 0)}
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, f = blockIdx.y;
     const int slot = blockIdx.x * 4 + wv;
     // slot -> (level, position): levels ascending (mergeKeypointLevels, FeatureExtractor.cpp:296-308)
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k_akz_describe(AkdDescParams P, const afv
     const float *Lt = L.lt + fo, *Lx = L.lx + fo, *Ly = L.ly + fo;
     const float ratio = (float)(1 << L.octave);
     const float xf = kp.x / ratio, yf = kp.y / ratio;
-    float4 *ori = s_ori[wv];
+    float4 *ori = s_smp[wv];
     float *val = s_val[wv];
     // ---- Compute_Main_Orientation ----
     {
@@ -259,6 +259,7 @@ __global__ __launch_bounds__(256) void k_akz_describe(AkdDescParams P, const afv
         // The 2 x 2, 3 x 3 and 4 x 4 grids all sum samples at the integer pattern positions (k, l) in [-10, 10]^2, and a sample
         // depends on (k, l) only: the 441 positions are fetched once, all lanes in parallel (1241 dependent gathers per keypoint
         // if every cell fetches its own), and every cell then adds ITS samples in upstream's (k, l) loop order from LDS.
+        AKD_LDS_SYNC();  // every lane is through with the orientation samples that share this wavefront's block
         float4 *smp = s_smp[wv];
         {
             float ri[7], gx[7], gy[7];  // all 21 gathers of a lane in flight together
