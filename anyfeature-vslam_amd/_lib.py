@@ -116,6 +116,7 @@ SYMBOLS = {
     "afv_comm_allgather": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "afv_shard_range": (None, [C.c_long, _i, _i, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "afv_match_l2": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _f, _f, _vp, _vp]),
+    "afv_match_l2_pairs_device": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _f, _f, _vp, _vp, _vp]),
     "afv_match_projection": (_i, [_vp, C.POINTER(ProjJob), _i, _vp, _vp]),
     "afv_match_fuse": (_i, [_vp, C.POINTER(ProjJob), _i, _vp, _vp]),
     "afv_match_sim3": (_i, [_vp, _vp, _vp, _vp, _vp]),

@@ -1184,6 +1184,37 @@ extern "C" int afv_match_l2(afv_ctx *c, const float *desc1, int n1, const float 
     return guarded(c, [&] { return afv_match_l2_impl(c, desc1, n1, desc2, n2, dim, valid1, valid2, th_low, nnratio, match12, nmatches); });
 }
 
+// device-resident batch of the float-descriptor matcher (config #3 as a throughput path, like afv_match_bruteforce_pairs_device for
+// ORB32): the key scratch is the Hamming path's grow-only buffer (32 B per row there as well)
+extern "C" int afv_match_l2_pairs_device(afv_ctx *c, const float *d_desc, const int32_t *d_n, int cap, int dim, const int32_t *d_pair_a,
+                                         const int32_t *d_pair_b, int npairs, float th_low, float nnratio, int32_t *d_match,
+                                         int32_t *d_nmatches, void *stream) {
+    return guarded(c, [&]() -> int {
+        if (!c || !d_desc || !d_n || !d_pair_a || !d_pair_b || !d_match || !d_nmatches || npairs < 0 || cap < 1 || cap > AFV_MAX_SIDE)
+            return AFV_EINVAL;
+        if (dim != 64 && dim != 128) return AFV_EUNSUPPORTED;
+        if (npairs == 0) return AFV_OK;
+        HIPCHK(c, hipSetDevice(c->device));
+        hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+        const int chunk = std::min(npairs, 2048);  // pairs per launch: grid.y and the scratch stay bounded
+        const size_t need = (size_t)chunk * cap * 32;
+        if (need > c->topk_bytes) {  // grow-only scratch (first call / larger batch): implies a device sync
+            HIPCHK(c, hipDeviceSynchronize());
+            if (c->d_topk) (void)hipFree(c->d_topk);
+            c->d_topk = nullptr;
+            c->topk_bytes = 0;
+            HIPCHK(c, hipMalloc(&c->d_topk, need));
+            c->topk_bytes = need;
+        }
+        for (int b0 = 0; b0 < npairs; b0 += chunk)
+            if (!afv_launch_match_l2_pairs(d_desc, d_n, cap, dim, d_pair_a, d_pair_b, std::min(chunk, npairs - b0), b0, th_low, nnratio, d_match,
+                                           d_nmatches, c->d_topk, s))
+                return AFV_EUNSUPPORTED;
+        HIPCHK(c, hipGetLastError());
+        return AFV_OK;
+    });
+}
+
 // ---- projection-guided matching ----
 enum { KIND_PROJ = 0, KIND_FUSE = 1, KIND_INIT = 2 };
 static int match_projection_impl(afv_ctx *c, const afv_proj_job *jobs, int njobs, int32_t *assign, int32_t *nmatches, int kind) {

@@ -78,6 +78,8 @@ extern "C" size_t afv_match_l2_scratch_bytes(int n1, int n2, int *ntiles_out, in
 extern "C" int afv_launch_match_l2_tiled(const float *d1, int n1, const float *d2, int n2, int dim, const uint8_t *v1, const uint8_t *v2,
                                          float th, float ratio, int *out, int *nmatches, void *scratch, int ntiles, int cols_per_tile,
                                          hipStream_t stream);
+extern "C" int afv_launch_match_l2_pairs(const float *desc, const int *nset, int cap, int dim, const int *pa, const int *pb, int npairs,
+                                         int pair_base, float th, float ratio, int *out, int *nmatches, void *scratch, hipStream_t stream);
 extern "C" void afv_launch_match_init(const DevProjJob *jobs, int njobs, int max_nq, hipStream_t stream);
 
 struct DevVocab {

@@ -39,20 +39,21 @@ __device__ __forceinline__ void l2_insert(unsigned long long (&k)[L2K], unsigned
     }
 }
 
+// row tile bx (64 rows) x column tile by of one job
 template <int DIM>
-__global__ __launch_bounds__(L2T) void k_l2_topk(const float *__restrict__ d1, int n1, const float *__restrict__ d2, int n2,
-                                                 const uint8_t *__restrict__ valid2, int cols_per_tile, int ntiles,
-                                                 unsigned long long *__restrict__ keys) {
+__device__ __forceinline__ void l2_topk_body(const float *__restrict__ d1, int n1, const float *__restrict__ d2, int n2,
+                                             const uint8_t *__restrict__ valid2, int cols_per_tile, int ntiles,
+                                             unsigned long long *__restrict__ keys, int bx, int by) {
     __shared__ float4 s_col[L2_CHUNK * DIM / 4];
     __shared__ unsigned long long s_keys[L2T / 64][64][L2K];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int row = blockIdx.x * 64 + lane;
+    const int row = bx * 64 + lane;
     const int rowc = min(row, n1 - 1);
     float4 a[DIM / 4];
     const float4 *ap = reinterpret_cast<const float4 *>(d1 + (size_t)rowc * DIM);
 #pragma unroll
     for (int i = 0; i < DIM / 4; ++i) a[i] = ap[i];
-    const int c_begin = blockIdx.y * cols_per_tile, c_end = min(n2, c_begin + cols_per_tile);
+    const int c_begin = by * cols_per_tile, c_end = min(n2, c_begin + cols_per_tile);
     unsigned long long k[L2K] = {L2_NO_KEY, L2_NO_KEY, L2_NO_KEY, L2_NO_KEY};
     for (int cb = c_begin; cb < c_end; cb += L2_CHUNK) {
         const int nc = min(L2_CHUNK, c_end - cb);
@@ -83,8 +84,27 @@ __global__ __launch_bounds__(L2T) void k_l2_topk(const float *__restrict__ d1, i
 #pragma unroll
             for (int s = 0; s < L2K; ++s) l2_insert(k, s_keys[w][lane][s]);
 #pragma unroll
-        for (int s = 0; s < L2K; ++s) keys[((size_t)row * ntiles + blockIdx.y) * L2K + s] = k[s];
+        for (int s = 0; s < L2K; ++s) keys[((size_t)row * ntiles + by) * L2K + s] = k[s];
     }
+}
+template <int DIM>
+__global__ __launch_bounds__(L2T) void k_l2_topk(const float *__restrict__ d1, int n1, const float *__restrict__ d2, int n2,
+                                                 const uint8_t *__restrict__ valid2, int cols_per_tile, int ntiles,
+                                                 unsigned long long *__restrict__ keys) {
+    l2_topk_body<DIM>(d1, n1, d2, n2, valid2, cols_per_tile, ntiles, keys, blockIdx.x, blockIdx.y);
+}
+// batch form over a device-resident table desc[set][cap][DIM] with counts nset[set]: blockIdx.y = pair; one column tile per pair
+// (the pairs fill the chip), so the keys need no merge
+template <int DIM>
+__global__ __launch_bounds__(L2T) void k_l2_topk_pairs(const float *__restrict__ desc, const int *__restrict__ nset, int cap,
+                                                       const int *__restrict__ pa, const int *__restrict__ pb, int pair_base,
+                                                       unsigned long long *__restrict__ keys) {
+    const int p = pair_base + blockIdx.y, sa = pa[p], sb = pb[p];
+    const int n1 = min(nset[sa], cap), n2 = min(nset[sb], cap);
+    if ((int)blockIdx.x * 64 >= n1) return;  // uniform
+    const int cols = ((max(n2, 1) + L2_CHUNK - 1) / L2_CHUNK) * L2_CHUNK;
+    l2_topk_body<DIM>(desc + (size_t)sa * cap * DIM, n1, desc + (size_t)sb * cap * DIM, n2, nullptr, cols, 1,
+                      keys + (size_t)blockIdx.y * cap * L2K, blockIdx.x, 0);
 }
 
 // one wave per row: fold the column tiles' keys into the row's 4 best (written over the row's first slot)
@@ -129,11 +149,11 @@ __device__ __forceinline__ float l2_exact(const float *a, const float *b, int di
     return (float)s;
 }
 
-__global__ __launch_bounds__(L2T) void k_l2_resolve(const float *__restrict__ d1, int n1, const float *__restrict__ d2, int n2,
-                                                    int dim, const uint8_t *__restrict__ valid1,
-                                                    const uint8_t *__restrict__ valid2, float th, float ratio, int ntiles,
-                                                    unsigned long long *__restrict__ keys, int *__restrict__ out,
-                                                    int *__restrict__ nmatches) {
+__device__ __forceinline__ void l2_resolve_body(const float *__restrict__ d1, int n1, const float *__restrict__ d2, int n2,
+                                                int dim, const uint8_t *__restrict__ valid1,
+                                                const uint8_t *__restrict__ valid2, float th, float ratio, int ntiles,
+                                                const unsigned long long *__restrict__ keys, int *__restrict__ out,
+                                                int *__restrict__ nmatches) {
     __shared__ uint32_t s_matched[L2_MAX_SIDE / 32];
     __shared__ int s_claim[L2_MAX_SIDE];
     __shared__ int s_nvalid2;
@@ -261,6 +281,25 @@ __global__ __launch_bounds__(L2T) void k_l2_resolve(const float *__restrict__ d1
     }
     if (lane == 0) *nmatches = nm;
 }
+__global__ __launch_bounds__(L2T) void k_l2_resolve(const float *__restrict__ d1, int n1, const float *__restrict__ d2, int n2,
+                                                    int dim, const uint8_t *__restrict__ valid1,
+                                                    const uint8_t *__restrict__ valid2, float th, float ratio, int ntiles,
+                                                    unsigned long long *__restrict__ keys, int *__restrict__ out,
+                                                    int *__restrict__ nmatches) {
+    l2_resolve_body(d1, n1, d2, n2, dim, valid1, valid2, th, ratio, ntiles, keys, out, nmatches);
+}
+// one workgroup per pair; out[pair][cap] (rows >= n1 of a pair are set to -1 as well)
+__global__ __launch_bounds__(L2T) void k_l2_resolve_pairs(const float *__restrict__ desc, const int *__restrict__ nset, int cap, int dim,
+                                                          const int *__restrict__ pa, const int *__restrict__ pb, int pair_base, float th,
+                                                          float ratio, const unsigned long long *__restrict__ keys, int *__restrict__ out,
+                                                          int *__restrict__ nmatches) {
+    const int p = pair_base + blockIdx.x, sa = pa[p], sb = pb[p];
+    const int n1 = min(nset[sa], cap), n2 = min(nset[sb], cap);
+    int *o = out + (size_t)p * cap;
+    for (int row = n1 + (int)threadIdx.x; row < cap; row += L2T) o[row] = -1;
+    l2_resolve_body(desc + (size_t)sa * cap * dim, n1, desc + (size_t)sb * cap * dim, n2, dim, nullptr, nullptr, th, ratio, 1,
+                    keys + (size_t)blockIdx.x * cap * L2K, o, nmatches + p);
+}
 
 extern "C" size_t afv_match_l2_scratch_bytes(int n1, int n2, int *ntiles_out, int *cols_per_tile_out) {
     // enough (row tile, column tile) blocks to cover the chip: 256 CUs x 4 waves per block
@@ -290,5 +329,19 @@ extern "C" int afv_launch_match_l2_tiled(const float *d1, int n1, const float *d
     else hipLaunchKernelGGL(k_l2_topk<64>, grid, dim3(L2T), 0, stream, d1, n1, d2, n2, v2, cols_per_tile, ntiles, keys);
     hipLaunchKernelGGL(k_l2_merge, dim3((n1 + L2T / 64 - 1) / (L2T / 64)), dim3(L2T), 0, stream, n1, ntiles, keys);
     hipLaunchKernelGGL(k_l2_resolve, dim3(1), dim3(L2T), 0, stream, d1, n1, d2, n2, dim, v1, v2, th, ratio, ntiles, keys, out, nmatches);
+    return 1;
+}
+
+// batch over a device-resident table (dim 64 / 128, cap <= L2_MAX_SIDE): pairs [pair_base, pair_base + npairs); `scratch` holds
+// npairs * cap * L2K keys.  Returns 0 if the shape is not supported.
+extern "C" int afv_launch_match_l2_pairs(const float *desc, const int *nset, int cap, int dim, const int *pa, const int *pb, int npairs,
+                                         int pair_base, float th, float ratio, int *out, int *nmatches, void *scratch, hipStream_t stream) {
+    if ((dim != 64 && dim != 128) || cap < 1 || cap > L2_MAX_SIDE || npairs < 1) return 0;
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(scratch);
+    const dim3 grid((cap + 63) / 64, npairs);
+    if (dim == 128) hipLaunchKernelGGL(k_l2_topk_pairs<128>, grid, dim3(L2T), 0, stream, desc, nset, cap, pa, pb, pair_base, keys);
+    else hipLaunchKernelGGL(k_l2_topk_pairs<64>, grid, dim3(L2T), 0, stream, desc, nset, cap, pa, pb, pair_base, keys);
+    hipLaunchKernelGGL(k_l2_resolve_pairs, dim3(npairs), dim3(L2T), 0, stream, desc, nset, cap, dim, pa, pb, pair_base, th, ratio, keys, out,
+                       nmatches);
     return 1;
 }

@@ -297,6 +297,23 @@ class FeatureMatcher:
         self.ctx.check(rc, "afv_match_l2")
         return out[:len(desc1)].copy(), int(nm[0])
 
+    def match_l2_pairs_device(self, desc, n, pair_a, pair_b, th_low, nnratio=None, match=None, nmatches=None, stream=None):
+        """match_l2 over a device-resident table: desc (nsets, cap, dim) float32 CUDA tensor (dim 64 / 128), n (nsets,) int32, pair
+        lists int32; returns (match (npairs, cap) int32, nmatches (npairs,) int32) on the device (asynchronous)."""
+        import torch
+        cap, dim = desc.shape[1], desc.shape[2]
+        npairs = pair_a.numel()
+        if match is None:
+            match = torch.empty((npairs, cap), dtype=torch.int32, device=desc.device)
+        if nmatches is None:
+            nmatches = torch.empty((npairs,), dtype=torch.int32, device=desc.device)
+        rc = _lib.launch_ordered(self.ctx, desc.device, stream, lambda s: self.lib.afv_match_l2_pairs_device(
+            self.ctx.handle, desc.data_ptr(), n.data_ptr(), cap, dim, pair_a.data_ptr(), pair_b.data_ptr(), npairs, float(th_low),
+            float(self.mfNNratio if nnratio is None else nnratio), match.data_ptr(), nmatches.data_ptr(), s),
+            (desc, n, pair_a, pair_b, match, nmatches))
+        self.ctx.check(rc, "afv_match_l2_pairs_device")
+        return match, nmatches
+
     def match_pairs_device(self, desc, kps, n, pair_a, pair_b, th_low=None, check_orientation=None, match=None, nmatches=None,
                            stream=None):
         """device-resident brute-force SearchByBoW(KF,KF) over a descriptor table (torch CUDA tensors)."""

@@ -684,9 +684,40 @@ def extra_l2_sift128(afv, device, reps=20):
         _, gn = m.match_l2(a, b, 0.5, 0.8)
         ts.append(time.perf_counter() - t0)
     ts.sort()
+    out = {"n1": n, "n2": n, "dim": dim, "us_per_job_host_to_host": ts[len(ts) // 2] * 1e6, "us_min": ts[0] * 1e6, "matches": int(gn),
+           "note": "afv_match_l2 through host buffers (upload 1 MB, three kernels, download); kernel-only times: profiles/"}
+    # the throughput form: a device-resident table of K float descriptor sets, LCG pair jobs (the float counterpart of pairs10k)
+    import torch
+    dmod = importlib.import_module("anyfeature-vslam_amd.dist")
+    K, njobs = 64, 2048
+    dev = torch.device("cuda", device)
+    table = np.empty((K, n, dim), np.float32)
+    for k in range(K):  # set k = the base set, every row perturbed a little more than in set k - 1, rows rotated
+        nz = (s.lcg_bytes(100 + k, n * dim).reshape(n, dim).astype(np.float32) - 128) / 4000.0
+        t = np.abs(a + nz * (1 + k % 4)).astype(np.float32)
+        table[k] = np.roll(t / np.linalg.norm(t, axis=1, keepdims=True), 17 * k, axis=0)
+    tt = torch.from_numpy(table).to(dev)
+    cnt = torch.full((K,), n, dtype=torch.int32, device=dev)
+    ja, jb = dmod.lcg_pairs(777, njobs, K)
+    pa, pb = torch.from_numpy(ja).to(dev), torch.from_numpy(jb).to(dev)
+    match = torch.empty((njobs, n), dtype=torch.int32, device=dev)
+    nm = torch.empty((njobs,), dtype=torch.int32, device=dev)
+    side = torch.cuda.Stream(dev)
+    with torch.cuda.stream(side):
+        m.match_l2_pairs_device(tt, cnt, pa, pb, 0.5, 0.8, match=match, nmatches=nm)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        with torch.cuda.stream(side):
+            m.match_l2_pairs_device(tt, cnt, pa, pb, 0.5, 0.8, match=match, nmatches=nm)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / 3
+    out["pairs_device"] = {"keyframes": K, "jobs": njobs, "jobs_per_s": njobs / dt, "us_per_job": dt / njobs * 1e6,
+                           "descriptor_pairs_per_s": njobs * n * n / dt, "matches_per_job": float(nm.float().mean().item()),
+                           "note": "afv_match_l2_pairs_device: table resident in HBM, one launch pair per 2048 jobs; every distance is 128 float "
+                                   "differences squared and summed in double in cv::norm's order (no MFMA: the order is part of the result)"}
     ctx.close()
-    return {"n1": n, "n2": n, "dim": dim, "us_per_job_host_to_host": ts[len(ts) // 2] * 1e6, "us_min": ts[0] * 1e6, "matches": int(gn),
-            "note": "afv_match_l2 through host buffers (upload 1 MB, three kernels, download); kernel-only times: profiles/"}
+    return out
 
 
 def extra_akaze61(afv, device, B=64, steps=3):

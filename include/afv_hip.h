@@ -236,6 +236,12 @@ void afv_shard_range(long n_units, int rank, int nranks, long *lo, long *hi);
 int afv_match_l2(afv_ctx *ctx, const float *desc1, int n1, const float *desc2, int n2, int dim,
                  const uint8_t *valid1, const uint8_t *valid2, float th_low, float nnratio, int32_t *match12,
                  int32_t *nmatches);
+/* the same matcher over a device-resident table of float descriptors, many (set a, set b) pair jobs per call (the float counterpart of
+ * afv_match_bruteforce_pairs_device): d_desc[(set * cap + row) * dim], d_n[set] rows per set, dim 64 or 128; d_match[pair * cap + row] =
+ * index into set b or -1 (rows past the set's count: -1), d_nmatches[pair].  Asynchronous on `stream` (NULL: the context's stream). */
+int afv_match_l2_pairs_device(afv_ctx *ctx, const float *d_desc, const int32_t *d_n, int cap, int dim, const int32_t *d_pair_a,
+                              const int32_t *d_pair_b, int npairs, float th_low, float nnratio, int32_t *d_match, int32_t *d_nmatches,
+                              void *stream);
 
 /* ---- projection-guided matching core (grid window + Hamming) ----
  * Matching loops of FeatureMatcher::SearchByProjection(F, localMapPoints) (src/FeatureMatcher.cc:73-154, mode

@@ -195,6 +195,37 @@ def test_l2_tiled_matcher(afv, oracle, matcher, n1, n2, dim, ratio, noise):
     assert gn == wn and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("dim,noise,ratio", [(128, 2000.0, 0.8), (64, 700.0, 0.95)])
+def test_l2_pairs_over_a_device_table(afv, oracle, matcher, dim, noise, ratio):
+    """config #3 as a batch: a device-resident table of float descriptor sets (ragged counts, one empty set) and a list of pair jobs
+    through afv_match_l2_pairs_device; every job must equal the oracle's answer for that pair (the high-ratio case forces conflicts and
+    exact rescans)"""
+    import torch
+    s = afv.synth
+    K, cap = 6, 700
+    counts = [700, 513, 64, 0, 699, 1]
+    table = np.zeros((K, cap, dim), np.float32)
+    base, other = _sift_like(s, 900 + dim, cap, dim, noise)
+    for k in range(K):
+        src = base if k % 2 == 0 else other
+        table[k, :counts[k]] = np.roll(src, 37 * k, axis=0)[:counts[k]]
+    pa = np.array([0, 1, 2, 0, 4, 3, 5, 1, 4], np.int32)
+    pb = np.array([1, 0, 1, 4, 1, 0, 0, 3, 4], np.int32)
+    dev = torch.device("cuda", 0)
+    m, nm = matcher.match_l2_pairs_device(torch.from_numpy(table).to(dev), torch.tensor(counts, dtype=torch.int32, device=dev),
+                                          torch.from_numpy(pa).to(dev), torch.from_numpy(pb).to(dev), 0.5, ratio)
+    torch.cuda.synchronize()
+    m, nm = m.cpu().numpy(), nm.cpu().numpy()
+    total = 0
+    for j in range(len(pa)):
+        a, b = table[pa[j], :counts[pa[j]]], table[pb[j], :counts[pb[j]]]
+        want, wn = oracle.match_l2_bruteforce(a, b, 0.5, ratio) if len(a) and len(b) else (np.full(len(a), -1, np.int32), 0)
+        assert nm[j] == wn, j
+        assert np.array_equal(m[j, :len(a)], want) and (m[j, len(a):] == -1).all(), j
+        total += wn
+    assert total > 500
+
+
 def test_l2_duplicate_columns_ties(afv, oracle, matcher):
     """identical train descriptors: equal distances must resolve to the lowest column, and the duplicates make the ratio test
     fail (best == second) until all but one copy are taken"""
