@@ -77,7 +77,7 @@ static int build_geometry(const afv_orb_params &p, int w, int h, int max_batch, 
         L.w = cv_round((float)w * L.inv_scale);
         L.h = cv_round((float)h * L.inv_scale);
         if (L.w < 32 || L.h < 32) return AFV_EUNSUPPORTED;  // single-reflection apron needs >= 32 px levels
-        if (l > 0 && !afv_resize_window_ok(g.lv[l - 1].w, g.lv[l - 1].h, L.w, L.h)) return AFV_EUNSUPPORTED;  // scale factor > ~1.37
+        if (l > 0 && !afv_resize_window_ok(g.lv[l - 1].w, g.lv[l - 1].h, L.w, L.h)) return AFV_EUNSUPPORTED;  // level ratio > ~2.37
         L.pitch = (int)align_up((size_t)L.w, 64);
         L.tiles_x = (L.w + FT_W - 1) / FT_W;
         L.tiles_y = (L.h + FT_H - 1) / FT_H;
@@ -141,6 +141,149 @@ static void resize_table(int src, int dst, short2 *t) {
     }
 }
 
+// Region bookkeeping of k_pyramid_fused (k_pyramid.hip): per level and per tile index of the TOP level, the range a workgroup
+// computes (need) and the range it stores (own), x and y separately.  own: the top level is cut into tiles of tw x th; one level
+// down a tile owns what lies between the source offsets of its own and of its right / lower neighbour's first pixel (monotone
+// tables: a disjoint cover).  need: the owned range (x: widened to whole dwords) united with the source span of the level above.
+static int ceil_log2(int v) {
+    int lg = 0;
+    while ((1 << lg) < v) ++lg;
+    return lg;
+}
+static bool plan_pyr_fuse(const Geo &g, const short2 *tab, const size_t *tab_off_x, const size_t *tab_off_y, int TW, int TH,
+                          std::vector<short4> &reg, PyrFuseArgs &A, size_t &lds) {
+    const int NL = g.nlevels, L = NL - 1;
+    if (NL < 2 || TW < 4 || (TW & 3) || TH < 1) return false;
+    const int ntx = (g.lv[L].w + TW - 1) / TW, nty = (g.lv[L].h + TH - 1) / TH;
+    reg.assign((size_t)NL * (ntx + nty), short4{0, 0, 0, 0});
+    int maxlen[2][AFV_MAX_LEVELS] = {};
+    for (int ax = 0; ax < 2; ++ax) {
+        const bool is_x = ax == 0;
+        const int nt = is_x ? ntx : nty, T = is_x ? TW : TH;
+        auto dim = [&](int l) { return is_x ? g.lv[l].w : g.lv[l].h; };
+        auto offs = [&](int l) { return tab + (is_x ? tab_off_x[l] : tab_off_y[l]); };  // table of level l: offsets into level l - 1
+        short4 *out = reg.data() + (is_x ? 0 : (size_t)NL * ntx);
+        for (int t = 0; t < nt; ++t) {
+            int own_lo[AFV_MAX_LEVELS], own_hi[AFV_MAX_LEVELS], lo[AFV_MAX_LEVELS], hi[AFV_MAX_LEVELS];
+            own_lo[L] = t * T;
+            own_hi[L] = std::min((t + 1) * T, dim(L));
+            for (int l = L - 1; l >= 1; --l) {
+                own_lo[l] = t == 0 ? 0 : (own_lo[l + 1] < dim(l + 1) ? offs(l + 1)[own_lo[l + 1]].x : dim(l));
+                own_hi[l] = t == nt - 1 ? dim(l) : (own_hi[l + 1] < dim(l + 1) ? offs(l + 1)[own_hi[l + 1]].x : dim(l));
+            }
+            for (int l = L; l >= 1; --l) {
+                int a = own_lo[l], b = own_hi[l];
+                if (is_x) {
+                    a &= ~3;
+                    b = (b + 3) & ~3;
+                }
+                int lo_ = a, hi_ = b - 1;
+                if (l < L) {
+                    const int n0 = lo[l + 1], n1 = std::min(hi[l + 1], dim(l + 1) - 1);
+                    const int lo2 = offs(l + 1)[n0].x, hi2 = std::min(offs(l + 1)[n1].x + 1, dim(l) - 1);
+                    if (b > a) {
+                        lo_ = std::min(lo_, lo2);
+                        hi_ = std::max(hi_, hi2);
+                    } else {
+                        lo_ = lo2;
+                        hi_ = hi2;
+                    }
+                }
+                if (is_x) {
+                    lo_ &= ~3;
+                    hi_ = lo_ + ((hi_ - lo_ + 4) & ~3) - 1;
+                }
+                lo[l] = lo_;
+                hi[l] = hi_;
+                out[(size_t)l * nt + t] = short4{(short)lo_, (short)hi_, (short)own_lo[l], (short)own_hi[l]};
+                maxlen[ax][l] = std::max(maxlen[ax][l], hi_ - lo_ + 1);
+            }
+            {   // the level-0 window
+                const int n0 = lo[1], n1 = std::min(hi[1], dim(1) - 1);
+                int lo0 = offs(1)[n0].x;
+                const int hi0 = std::min(offs(1)[n1].x + 1, dim(0) - 1);
+                if (is_x) lo0 &= ~3;
+                out[t] = short4{(short)lo0, (short)hi0, 0, 0};
+                maxlen[ax][0] = std::max(maxlen[ax][0], hi0 - lo0 + 1);
+            }
+        }
+    }
+    std::memset(&A, 0, sizeof(A));
+    A.nlevels = NL;
+    A.ntx = ntx;
+    A.nty = nty;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off = align_up(off + bytes, 16);
+        return (int)o;
+    };
+    A.off_reg = take(2 * AFV_MAX_LEVELS * sizeof(short4));
+    size_t buf[2] = {0, 0}, hrow = 0;
+    for (int l = 0; l < NL; ++l) {
+        A.pitch[l] = (int)align_up((size_t)maxlen[0][l], 4);
+        A.lg_p[l] = l == 0 ? ceil_log2(A.pitch[l] / 4) + 1 : std::max(1, ceil_log2(A.pitch[l] / 2));
+        if (A.lg_p[l] > 10) return false;  // more column slots per row than the workgroup has threads
+        buf[l & 1] = std::max(buf[l & 1], (size_t)A.pitch[l] * maxlen[1][l]);
+        if (l > 0) {
+            A.tabx[l] = (int)tab_off_x[l];
+            A.taby[l] = (int)tab_off_y[l];
+            A.off_xt[l] = take((size_t)A.pitch[l] * sizeof(short2));
+            A.off_yt[l] = take((size_t)maxlen[1][l] * sizeof(short2));
+            hrow = std::max(hrow, (size_t)maxlen[1][l - 1] * ((size_t)4 << A.lg_p[l]));
+        }
+    }
+    A.off_buf[0] = take(buf[0]);
+    A.off_buf[1] = take(buf[1]);
+    A.off_hrow = take(hrow);
+    lds = off;
+    return true;
+}
+static bool build_pyr_fuse(afv_ctx *c, const Geo &g, const short2 *tab, std::vector<short4> &reg, PyrFuseArgs &A, size_t &lds) {
+    return plan_pyr_fuse(g, tab, c->tab_off_x, c->tab_off_y, c->pf_tw, c->pf_th, reg, A, lds) && afv_pyramid_fused_prepare(lds) != 0;
+}
+
+// host-only view of the plan and of the coefficient tables (no device needed): tests/test_host_logic.py replays the one-launch pyramid
+// on the CPU from exactly these numbers and compares it with the level-by-level resize
+extern "C" int afv_debug_pyramid_plan(const afv_orb_params *p, int width, int height, int tile_w, int tile_h, int16_t *regions, int regions_cap,
+                                      int32_t *info, int16_t *tables, int tables_cap) {
+    if (!p || !regions || !info) return AFV_EINVAL;
+    Geo g;
+    const int rc = build_geometry(*p, width, height, 1, g);
+    if (rc) return rc;
+    size_t tox[AFV_MAX_LEVELS] = {}, toy[AFV_MAX_LEVELS] = {}, n = 0;
+    for (int l = 1; l < g.nlevels; ++l) n += (size_t)g.lv[l].w + (size_t)g.lv[l].h;
+    std::vector<short2> tab(std::max<size_t>(n, 1));
+    size_t off = 0;
+    for (int l = 1; l < g.nlevels; ++l) {
+        tox[l] = off;
+        resize_table(g.lv[l - 1].w, g.lv[l].w, tab.data() + off);
+        off += (size_t)g.lv[l].w;
+        toy[l] = off;
+        resize_table(g.lv[l - 1].h, g.lv[l].h, tab.data() + off);
+        off += (size_t)g.lv[l].h;
+    }
+    std::vector<short4> reg;
+    PyrFuseArgs A;
+    size_t lds = 0;
+    if (!plan_pyr_fuse(g, tab.data(), tox, toy, tile_w, tile_h, reg, A, lds)) return AFV_EUNSUPPORTED;
+    if ((int)reg.size() * 4 > regions_cap || (tables && (int)n * 2 > tables_cap)) return AFV_ECAPACITY;
+    std::memcpy(regions, reg.data(), reg.size() * sizeof(short4));
+    if (tables) std::memcpy(tables, tab.data(), n * sizeof(short2));
+    int k = 0;
+    info[k++] = g.nlevels;
+    info[k++] = A.ntx;
+    info[k++] = A.nty;
+    info[k++] = (int)lds;
+    for (int l = 0; l < AFV_MAX_LEVELS; ++l) info[k++] = g.lv[l].w;
+    for (int l = 0; l < AFV_MAX_LEVELS; ++l) info[k++] = g.lv[l].h;
+    for (int l = 0; l < AFV_MAX_LEVELS; ++l) info[k++] = A.pitch[l];
+    for (int l = 0; l < AFV_MAX_LEVELS; ++l) info[k++] = A.lg_p[l];
+    for (int l = 0; l < AFV_MAX_LEVELS; ++l) info[k++] = A.tabx[l];
+    for (int l = 0; l < AFV_MAX_LEVELS; ++l) info[k++] = A.taby[l];
+    return AFV_OK;  // info: 4 + 6 * AFV_MAX_LEVELS ints
+}
+
 static int set_geometry(afv_ctx *c, int w, int h) {
     if (c->geo_valid && c->geo.width == w && c->geo.height == h) return AFV_OK;
     if (w > c->p.max_width || h > c->p.max_height) return AFV_EINVAL;
@@ -170,6 +313,23 @@ static int set_geometry(afv_ctx *c, int w, int h) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(c->d_tab, tab.data(), off * sizeof(short2), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_geo, &g, sizeof(Geo), hipMemcpyHostToDevice));
+    {   // the one-launch pyramid of the small-batch path
+        std::vector<short4> reg;
+        c->pf_ok = build_pyr_fuse(c, g, tab.data(), reg, c->pf, c->pf_lds);
+        if (c->pf_ok) {
+            if (reg.size() > c->pf_reg_cap) {
+                if (c->d_pf_reg) (void)hipFree(c->d_pf_reg);
+                c->d_pf_reg = nullptr;
+                c->pf_reg_cap = 0;
+                HIPCHK(c, hipMalloc(&c->d_pf_reg, reg.size() * sizeof(short4)));
+                c->pf_reg_cap = reg.size();
+            }
+            HIPCHK(c, hipMemcpy(c->d_pf_reg, reg.data(), reg.size() * sizeof(short4), hipMemcpyHostToDevice));
+            c->pf.tab = c->d_tab;
+            c->pf.rx = c->d_pf_reg;
+            c->pf.ry = c->d_pf_reg + (size_t)g.nlevels * c->pf.ntx;
+        }
+    }
     c->geo = g;
     c->geo_valid = true;
     return AFV_OK;
@@ -190,7 +350,7 @@ extern "C" void afv_destroy(afv_ctx *c) {
     afv_table_release_all(c);
     void *ptrs[] = {c->d_geo, c->d_tab, c->d_pyr, c->d_cand_packed, c->d_kept_xy, c->d_l1, c->d_l1_resp, c->d_l1_count, c->d_hq, c->d_hq_n, c->d_kept_resp,
                     c->d_kept_node, c->d_cand_count, c->d_sel_count, c->d_sel, c->d_frames, c->d_kps, c->d_desc,
-                    c->d_n, c->d_status, c->d_match, c->d_topk};
+                    c->d_n, c->d_status, c->d_match, c->d_topk, c->d_pf_reg};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_stage) {
@@ -317,6 +477,13 @@ extern "C" int afv_set_match_engine(afv_ctx *c, int engine) {
     return AFV_OK;
 }
 
+extern "C" int afv_set_small_batch_path(afv_ctx *c, int mode, int max_frames) {
+    if (!c || mode < 0 || mode > 2 || max_frames < 0) return AFV_EINVAL;
+    c->small_mode = mode;
+    if (max_frames > 0) c->small_max_frames = max_frames;
+    return AFV_OK;
+}
+
 extern "C" int afv_set_split_chunks(afv_ctx *c, int chunks) {
     if (!c || (chunks != 0 && chunks < 2) || chunks > 64) return AFV_EINVAL;
     c->split_chunks = chunks;
@@ -372,6 +539,13 @@ extern "C" int afv_get_geometry(const afv_ctx *c, afv_geometry *g) {
 }
 
 // ---- the pipeline ----
+// The small-batch ("latency") path: kernels shaped for one or a few frames (Tracking extracts ONE frame per call, Frame.cc:186) -
+// the whole pyramid in one launch, ... - same results bit for bit.  afv_set_small_batch_path: 0 = never, 1 = batches of at most
+// `small_max_frames` frames (default), 2 = always (parity tests).
+static bool small_batch_path(const afv_ctx *c, int nf) {
+    return c->small_mode == 2 || (c->small_mode == 1 && nf <= c->small_max_frames);
+}
+
 // kernels of one contiguous frame range [f0, f0 + nf) on stream s
 static void enqueue_range(afv_ctx *c, const FrameSrc &src, int f0, int nf, afv_keypoint *d_kps, uint8_t *d_desc, int cap, int *d_n,
                           int *d_status, hipStream_t s) {
@@ -389,7 +563,15 @@ static void enqueue_range(afv_ctx *c, const FrameSrc &src, int f0, int nf, afv_k
         (void)hipMemsetAsync(cnt0, 0, (size_t)nf * AFV_MAX_LEVELS * sizeof(int), s);
         (void)hipMemsetAsync(c->d_hq_n + f0, 0, sizeof(int), s);
     }
-    {
+    const bool small = small_batch_path(c, nf);
+    if (small && c->pf_ok) {
+        StageTimer t_(c, AFV_STAGE_PYRAMID, s, nf);
+        PyrFuseArgs A = c->pf;
+        A.zero_counts = cnt0;
+        A.n_zero = nf * AFV_MAX_LEVELS;
+        A.zero_one = c->d_hq_n + f0;
+        afv_launch_pyramid_fused(c->d_geo, &src, c->d_pyr, &A, c->pf_lds, f0, nf, s);
+    } else {
         StageTimer t_(c, AFV_STAGE_PYRAMID, s, nf);
         for (int l = 1; l < g.nlevels; ++l) {
             const LevelGeo &S = g.lv[l - 1], &D = g.lv[l];

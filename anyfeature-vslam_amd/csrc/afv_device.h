@@ -78,6 +78,21 @@ struct SelPoint {  // quadtree survivor, level coordinates
     float response;
 };
 
+// arguments of k_pyramid_fused (k_pyramid.hip: the whole pyramid of a frame in one launch); filled by afv_api.hip: build_pyr_fuse
+struct PyrFuseArgs {
+    const short2 *tab;          // resize tables of all levels (afv_ctx::d_tab)
+    const short4 *rx, *ry;      // [nlevels][ntx] / [nlevels][nty]: (need.lo, need.hi inclusive, own.lo, own.hi exclusive) per tile index; level 0: the source window
+    int tabx[AFV_MAX_LEVELS], taby[AFV_MAX_LEVELS];  // element offset of level l's x / y table in `tab`
+    int pitch[AFV_MAX_LEVELS];  // LDS row pitch of level l's region (bytes, multiple of 4; level 0 = the source window)
+    int lg_p[AFV_MAX_LEVELS];   // log2 of the column-PAIR slots per row of level l (power of two >= pitch / 2)
+    int off_xt[AFV_MAX_LEVELS], off_yt[AFV_MAX_LEVELS];  // LDS byte offsets of the staged tables
+    int off_buf[2], off_hrow, off_reg;  // LDS byte offsets: region buffers (level parity), filtered rows, region descriptors
+    int nlevels, ntx, nty;
+    int *zero_counts;           // as in ResizeTab: the candidate / queue counters of the frame range are cleared here
+    int n_zero;
+    int *zero_one;
+};
+
 // XCD-aware block -> work-item mapping (cdna_hip_programming.md T1): hardware places linear block b on XCD b % 8, each
 // XCD has its own L2.  Work items that share cache lines (neighbouring tiles of one frame) must therefore be given
 // to blocks that are congruent mod 8: XCD k takes the contiguous range [k*ceil(n/8), ...) of the work list.

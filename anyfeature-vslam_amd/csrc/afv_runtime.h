@@ -20,6 +20,9 @@ extern "C" void afv_launch_resize(const uint8_t *src, int sw, int sh, int spitch
                                   int dpitch, size_t dframe, const short2 *xt, const short2 *yt, int frame_base, int nframes, int *zero_counts,
                                   int n_zero, int *zero_one, hipStream_t stream);
 extern "C" int afv_resize_window_ok(int sw, int sh, int dw, int dh);
+extern "C" void afv_launch_pyramid_fused(const Geo *geo_dev, const FrameSrc *src0, uint8_t *pyr, const PyrFuseArgs *args, size_t lds_bytes,
+                                         int frame_base, int nframes, hipStream_t stream);
+extern "C" int afv_pyramid_fused_prepare(size_t lds_bytes);
 extern "C" void afv_launch_fast_nms(const Geo *geo, int total_tiles, const FrameSrc *src0, const uint8_t *pyr, uint32_t *cand_packed,
                                     int *cand_count, int frame_base, int nframes, hipStream_t stream);
 extern "C" size_t afv_harris_queue_per_frame(const Geo *g);
@@ -109,6 +112,15 @@ struct afv_ctx {
     int split_min_frames = 64;     // batches of at least this many frames / pairs are split over the two streams
     int match_engine = AFV_MATCH_ENGINE_MFMA;  // phase 1 of the brute-force pair matcher; afv_set_match_engine
     int split_chunks = 0;          // ... into this many chunks (alternating streams); 0 = about 85 frames each; afv_set_split_chunks
+    // small-batch ("latency") path: kernels shaped for one or a few frames; afv_set_small_batch_path
+    int small_mode = 1;            // 0 = never, 1 = batches of at most small_max_frames, 2 = always
+    int small_max_frames = 4;
+    int pf_tw = 32, pf_th = 16;    // top-level tile of the one-launch pyramid (k_pyramid_fused)
+    bool pf_ok = false;            // the current geometry has a one-launch pyramid (else: level-by-level launches)
+    PyrFuseArgs pf{};
+    size_t pf_lds = 0;
+    short4 *d_pf_reg = nullptr;    // region descriptors, [nlevels][ntx] then [nlevels][nty]
+    size_t pf_reg_cap = 0;
     afv_orb_params p{};
     Geo geo{};          // current geometry (host copy)
     Geo cap_geo{};      // geometry of (max_width, max_height): sizes every allocation

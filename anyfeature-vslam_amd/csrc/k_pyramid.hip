@@ -17,8 +17,9 @@
 
 #define RT_W 64
 #define RT_H 32
-#define RS_W 96   // LDS source window pitch (bytes); source span of 64 outputs at scale <= 1.4 plus alignment slack
-#define RS_H 48
+// LDS source window (bytes per row x rows) = source span of a 64 x 32 output tile plus alignment slack; two instantiations:
+// 96 x 48 for level ratios up to 1.37 (the ORB pyramid's 1.2, 2^(1/4)), 160 x 80 for ratios up to 2.37 (the reference's settings files
+// go up to FeatureExtractor.scaleFactor 2.0: settings/sift128_settings.yaml:7)
 #define RT_T 128  // threads per workgroup: the kernel waits on its global loads most of the time, so what counts is how many tiles a
                   // CU has in flight (LDS 10.9 KB, 2 waves per tile -> 14 tiles per CU instead of 8 with 256 threads)
 
@@ -35,6 +36,13 @@ struct ResizeTab {
     DivMagic dv_tiles, dv_tiles_x;  // / (tiles per frame), / tiles_x
 };
 
+constexpr bool rs_div_exact(int sq) {  // tid / sq == (tid * ceil(65536 / sq)) >> 16 for every tid of the workgroup
+    for (int t = 0; t < RT_T; ++t)
+        if ((int)(((unsigned)t * (unsigned)((65536 + sq - 1) / sq)) >> 16) != t / sq) return false;
+    return true;
+}
+
+template <int RS_W, int RS_H>
 __global__ __launch_bounds__(RT_T) void k_resize_level(const uint8_t *__restrict__ src, int sw, int sh, int spitch,
                                                       size_t sframe, uint8_t *__restrict__ dst, int dw, int dh,
                                                       int dpitch, size_t dframe, ResizeTab tab, int total_blocks, int frame_base) {
@@ -63,8 +71,9 @@ __global__ __launch_bounds__(RT_T) void k_resize_level(const uint8_t *__restrict
     const int ndw = (sx_last - sx0) / 4 + 1, nrows = sy1 - sy0 + 1;  // <= RS_W/4, <= RS_H (host checks the scale)
     // all loads of the window first (one global round trip), then the LDS writes.  Thread (q, rr) = (tid % 24, tid / 24) owns the
     // dword column q of the rows rr, rr + 5, ... (120 of the 128 threads): no division by a run-time width, addresses by increments
-    constexpr int SQ = RS_W / 4, SG = RT_T / SQ, STG = (RS_H + SG - 1) / SG;  // 24 dword columns, 5 row groups, 10 rows per thread
-    const int srr = (int)(__umul24(threadIdx.x, 2731u) >> 16);  // tid / 24 (exact for tid < 128)
+    constexpr int SQ = RS_W / 4, SG = RT_T / SQ, STG = (RS_H + SG - 1) / SG;  // 96 x 48: 24 dword columns, 5 row groups, 10 rows per thread
+    static_assert(rs_div_exact(SQ), "tid / SQ by multiplication");
+    const int srr = (int)(__umul24(threadIdx.x, (unsigned)((65536 + SQ - 1) / SQ)) >> 16);  // tid / SQ
     const int sq = (int)threadIdx.x - srr * SQ;
     const bool s_on = srr < SG && sq < ndw;
     const bool s_dword = sx0 + sq * 4 + 3 < spitch;  // else: the last bytes of a row whose pitch is not a multiple of 4
@@ -154,10 +163,12 @@ __global__ __launch_bounds__(RT_T) void k_resize_level(const uint8_t *__restrict
     }
 }
 
+// which instantiation holds the source span of a 64x32 output tile (plus alignment slack and the +1 tap): 1 = 96 x 48, 2 = 160 x 80, 0 = none
 extern "C" int afv_resize_window_ok(int sw, int sh, int dw, int dh) {
-    // the LDS window must hold the source span of a 64x32 output tile (plus alignment slack and the +1 tap)
     const double fx = (double)sw / dw, fy = (double)sh / dh;
-    return (RT_W * fx + 8 <= RS_W) && (RT_H * fy + 3 <= RS_H);
+    if ((RT_W * fx + 8 <= 96) && (RT_H * fy + 3 <= 48)) return 1;
+    if ((RT_W * fx + 8 <= 160) && (RT_H * fy + 3 <= 80)) return 2;
+    return 0;
 }
 
 extern "C" void afv_launch_resize(const uint8_t *src, int sw, int sh, int spitch, size_t sframe, uint8_t *dst, int dw,
@@ -167,6 +178,175 @@ extern "C" void afv_launch_resize(const uint8_t *src, int sw, int sh, int spitch
     const int total = per_frame * nframes;
     dim3 grid((total + 7) / 8 * 8);
     ResizeTab tab{xt, yt, zero_counts, n_zero, zero_one, afv_div_magic((uint32_t)per_frame), afv_div_magic((uint32_t)tx)};
-    hipLaunchKernelGGL(k_resize_level, grid, dim3(RT_T), 0, stream, src, sw, sh, spitch, sframe, dst, dw, dh, dpitch,
-                       dframe, tab, total, frame_base);
+    if (afv_resize_window_ok(sw, sh, dw, dh) == 1)
+        hipLaunchKernelGGL((k_resize_level<96, 48>), grid, dim3(RT_T), 0, stream, src, sw, sh, spitch, sframe, dst, dw, dh, dpitch, dframe, tab,
+                           total, frame_base);
+    else
+        hipLaunchKernelGGL((k_resize_level<160, 80>), grid, dim3(RT_T), 0, stream, src, sw, sh, spitch, sframe, dst, dw, dh, dpitch, dframe, tab,
+                           total, frame_base);
+}
+
+// ---------------- the whole pyramid in ONE launch (the per-frame plugin call: Frame.cc:186 extracts one frame at a time) ----------------
+// Seven dependent k_resize_level launches cost ~4.8 us each on one frame (34 us of a 110 us extraction) although the arithmetic is a
+// few hundred nanoseconds of the chip: what is paid is seven kernel ramps and seven cache write-back / invalidate boundaries.  Here
+// one workgroup owns one tile of the TOP level and computes, level by level, everything that tile depends on: its regions of levels
+// 1 .. L live in LDS (ping-pong), only level 0 is read from memory.  Neighbouring workgroups recompute the overlap of their regions
+// (a halo of ~2 px per level: 1.7x the pixels at a 32x16 top tile) instead of waiting for each other - no workgroup ever
+// reads what another one wrote, so there is no hand-off at all.  Every pixel is produced by the same two expressions as in
+// k_resize_level from the same source pixels, so the levels are bit-identical whichever workgroup writes them: level l is
+// partitioned into OWNED rectangles (own_l(t) = [off_(l+1)[own_(l+1)(t).lo], off_(l+1)[own_(l+1)(t + 1).lo)): monotone tables make
+// them a disjoint cover) and a workgroup stores exactly its rectangle, widened to whole dwords - two workgroups may store the same
+// dword, with the same bytes.  Region bookkeeping (per level and tile index: needed range, owned range) is host work, done once per
+// geometry (afv_api.hip: build_pyr_fuse).
+
+#define PF_T 1024
+
+__global__ __launch_bounds__(PF_T) void k_pyramid_fused(const Geo *__restrict__ geo_p, FrameSrc src0, uint8_t *__restrict__ pyr, PyrFuseArgs A,
+                                                        int frame_base, int total_blocks) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t pf_smem[];
+    const Geo &geo = *geo_p;
+    const int tid = threadIdx.x;
+    if (A.zero_counts && blockIdx.x == 0) {
+        for (int i = tid; i < A.n_zero; i += PF_T) A.zero_counts[i] = 0;
+        if (tid == 0 && A.zero_one) *A.zero_one = 0;
+    }
+    const int work = afv_xcd_remap(blockIdx.x, total_blocks);  // a frame's tiles share level-0 cache lines: keep them on one XCD
+    if (work >= total_blocks) return;
+    const int per_frame = A.ntx * A.nty;
+    const int fl = work / per_frame, t = work - fl * per_frame, ty = t / A.ntx, tx = t - ty * A.ntx;
+    const int f = frame_base + fl;
+    const int NL = A.nlevels;
+    short4 *s_rx = reinterpret_cast<short4 *>(pf_smem + A.off_reg), *s_ry = s_rx + AFV_MAX_LEVELS;
+    if (tid < NL) s_rx[tid] = A.rx[tid * A.ntx + tx];
+    else if (tid >= 64 && tid < 64 + NL) s_ry[tid - 64] = A.ry[(tid - 64) * A.nty + ty];
+    __syncthreads();
+    // stage every level's slice of the coefficient tables (offsets relative to the source region) and the level-0 window: all
+    // global loads of the kernel are issued here, behind one round trip for the region descriptors
+    for (int l = 1; l < NL; ++l) {
+        const short4 rx = s_rx[l], rxp = s_rx[l - 1], ry = s_ry[l], ryp = s_ry[l - 1];
+        const int lw = geo.lv[l].w;
+        short2 *xt = reinterpret_cast<short2 *>(pf_smem + A.off_xt[l]), *yt = reinterpret_cast<short2 *>(pf_smem + A.off_yt[l]);
+        const int nxe = rx.y - rx.x + 1, nye = ry.y - ry.x + 1;
+        for (int i = tid; i < nxe + nye; i += PF_T) {
+            short2 e;
+            e.x = 0;
+            e.y = 0;
+            if (i < nxe) {
+                if (rx.x + i < lw) {  // columns past the level's width (dword padding): offset 0, weight 0
+                    e = A.tab[A.tabx[l] + rx.x + i];
+                    e.x = (short)(e.x - rxp.x);
+                }
+                xt[i] = e;
+            } else {
+                e = A.tab[A.taby[l] + ry.x + (i - nxe)];
+                e.x = (short)(e.x - ryp.x);
+                yt[i - nxe] = e;
+            }
+        }
+    }
+    {
+        const short4 rx = s_rx[0], ry = s_ry[0];
+        const uint8_t *img = src0.base + (size_t)f * src0.frame_stride;
+        uint8_t *S = pf_smem + A.off_buf[0];
+        const int sp = A.pitch[0], lg = A.lg_p[0] - 1;  // dword slots per row = pair slots / 2
+        const int ndw = (rx.y - rx.x + 4) >> 2, nrows = ry.y - ry.x + 1, w0 = geo.width;
+        const int q = tid & ((1 << lg) - 1);
+        if (q < ndw) {
+            const int gx = rx.x + 4 * q;
+            const bool dw_ok = gx + 3 < src0.stride;
+#pragma unroll 4
+            for (int r = tid >> lg; r < nrows; r += PF_T >> lg) {
+                const uint8_t *p = img + (size_t)(ry.x + r) * src0.stride + gx;
+                uint32_t v = 0;
+                if (dw_ok) {
+                    v = *reinterpret_cast<const uint32_t *>(p);
+                } else {
+                    for (int b = 0; b < 4; ++b)
+                        if (gx + b < w0) v |= (uint32_t)p[b] << (8 * b);
+                }
+                *reinterpret_cast<uint32_t *>(S + r * sp + 4 * q) = v;
+            }
+        }
+    }
+    __syncthreads();
+    for (int l = 1; l < NL; ++l) {
+        const short4 rx = s_rx[l], ry = s_ry[l], rxp = s_rx[l - 1], ryp = s_ry[l - 1];
+        const uint8_t *S = pf_smem + A.off_buf[(l - 1) & 1];
+        uint8_t *D = pf_smem + A.off_buf[l & 1];
+        uint32_t *hrow = reinterpret_cast<uint32_t *>(pf_smem + A.off_hrow);
+        const short2 *xt = reinterpret_cast<const short2 *>(pf_smem + A.off_xt[l]), *yt = reinterpret_cast<const short2 *>(pf_smem + A.off_yt[l]);
+        const int sp = A.pitch[l - 1], dp = A.pitch[l], lgp = A.lg_p[l];
+        const int sw = rxp.y - rxp.x + 1, sh = ryp.y - ryp.x + 1;  // source region
+        const int dwp = rx.y - rx.x + 1, dh = ry.y - ry.x + 1;     // this level's region (width a multiple of 4)
+        // ---- horizontal pass over every source row: thread = column pair (fixed) x row group ----
+        {
+            const int cp = tid & ((1 << lgp) - 1);
+            if (2 * cp < dwp) {
+                const short2 xa = xt[2 * cp], xb = xt[2 * cp + 1];
+                const int a0 = xa.x, a1 = min(xa.x + 1, sw - 1), b0 = xb.x, b1 = min(xb.x + 1, sw - 1);
+                ushort2r WR, WL;
+                WR.x = (unsigned short)xa.y;
+                WR.y = (unsigned short)xb.y;
+                WL.x = (unsigned short)(256 - xa.y);
+                WL.y = (unsigned short)(256 - xb.y);
+#pragma unroll 2
+                for (int r = tid >> lgp; r < sh; r += PF_T >> lgp) {
+                    const uint8_t *row = S + r * sp;
+                    ushort2r Lv, Rv;
+                    Lv.x = row[a0];
+                    Lv.y = row[b0];
+                    Rv.x = row[a1];
+                    Rv.y = row[b1];
+                    const ushort2r hv = WL * Lv + WR * Rv;
+                    hrow[(r << lgp) + cp] = __builtin_bit_cast(uint32_t, hv);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- vertical pass: thread = 4 consecutive columns (fixed) x row group; the owned rectangle also goes to memory ----
+        {
+            const int lgq = lgp - 1, cq = tid & ((1 << lgq) - 1);
+            if (4 * cq < dwp) {
+                const LevelGeo &Lg = geo.lv[l];
+                uint8_t *dst = pyr + Lg.pyr_off + (size_t)f * Lg.pyr_frame_stride;
+                const int gx = rx.x + 4 * cq;
+                const bool own_x = gx >= (rx.z & ~3) && gx < rx.w;  // owned columns [own.lo & ~3, align4(own.hi)): whole dwords
+                for (int y = tid >> lgq; y < dh; y += PF_T >> lgq) {
+                    const short2 e = yt[y];
+                    const uint32_t *h0 = hrow + (e.x << lgp) + 2 * cq, *h1 = hrow + (min(e.x + 1, sh - 1) << lgp) + 2 * cq;
+                    ushort2r WY;
+                    WY.x = (unsigned short)(256 - e.y);
+                    WY.y = (unsigned short)e.y;
+                    const uint2 u = *reinterpret_cast<const uint2 *>(h0), lo = *reinterpret_cast<const uint2 *>(h1);
+                    const ushort2r p0 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(lo.x, u.x, 0x05040100u));
+                    const ushort2r p1 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(lo.x, u.x, 0x07060302u));
+                    const ushort2r p2 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(lo.y, u.y, 0x05040100u));
+                    const ushort2r p3 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(lo.y, u.y, 0x07060302u));
+                    const uint32_t o0 = __builtin_amdgcn_udot2(p0, WY, 32768u, false) >> 16, o1 = __builtin_amdgcn_udot2(p1, WY, 32768u, false) >> 16;
+                    const uint32_t o2 = __builtin_amdgcn_udot2(p2, WY, 32768u, false) >> 16, o3 = __builtin_amdgcn_udot2(p3, WY, 32768u, false) >> 16;
+                    const uint32_t o = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
+                    *reinterpret_cast<uint32_t *>(D + y * dp + 4 * cq) = o;
+                    const int gy = ry.x + y;
+                    if (own_x && gy >= ry.z && gy < ry.w) *reinterpret_cast<uint32_t *>(dst + (size_t)gy * Lg.pitch + gx) = o;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" void afv_launch_pyramid_fused(const Geo *geo_dev, const FrameSrc *src0, uint8_t *pyr, const PyrFuseArgs *args, size_t lds_bytes,
+                                         int frame_base, int nframes, hipStream_t stream) {
+    const int total = args->ntx * args->nty * nframes;
+    hipLaunchKernelGGL(k_pyramid_fused, dim3((total + 7) / 8 * 8), dim3(PF_T), lds_bytes, stream, geo_dev, *src0, pyr, *args, frame_base, total);
+}
+
+extern "C" int afv_pyramid_fused_prepare(size_t lds_bytes) {
+    if (lds_bytes > 160 * 1024) return 0;
+    if (lds_bytes > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_pyramid_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return 1;
 }

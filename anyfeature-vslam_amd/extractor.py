@@ -193,6 +193,10 @@ class Context:
         """0 = popcount on the vector ALU, 1 = exact i8 contraction on the matrix cores (default); identical results"""
         self.check(self.lib.afv_set_match_engine(self.handle, int(engine)))
 
+    def set_small_batch_path(self, mode, max_frames=0):
+        """0 = never, 1 = calls of at most max_frames frames / pairs (default), 2 = always; identical results either way"""
+        self.check(self.lib.afv_set_small_batch_path(self.handle, int(mode), int(max_frames)))
+
     def set_split_chunks(self, chunks):
         self.check(self.lib.afv_set_split_chunks(self.handle, int(chunks)))
 

@@ -336,6 +336,13 @@ int afv_profile_read(afv_ctx *ctx, int32_t *launches /*[afv_num_stages()]*/, flo
 int afv_set_split_threshold(afv_ctx *ctx, int min_frames);
 int afv_set_split_chunks(afv_ctx *ctx, int chunks); /* ... into this many chunks alternating over the two streams (2..64; 0 = automatic,
                                                       * chunks of about 85 frames: the default) */
+/* The small-batch ("latency") path.  Tracking extracts ONE frame per call (src/Frame.cc:186 -> src/FeatureExtractor.cpp:111-121) and
+ * matches it against ONE other frame: at that size the batch kernels are a chain of dependent launches, each a few microseconds of
+ * ramp and cache boundary around a fraction of a microsecond of work.  Calls of at most `max_frames` frames / pairs (default 4) run
+ * kernels shaped for that case instead - the whole pyramid in one launch, retainBest + Harris in one launch, a quadtree workgroup of
+ * 1024 threads, the brute-force distance phase split over column slices - with bit-identical results.
+ *   mode 0 = never, 1 = calls of at most max_frames frames (default), 2 = always (parity tests); max_frames 0 keeps the current value */
+int afv_set_small_batch_path(afv_ctx *ctx, int mode, int max_frames);
 /* Phase 1 of the brute-force pair matchers (afv_match_bruteforce_pairs_device, afv_table_match_pairs*, plain SearchByBoW jobs without
  * a FeatureVector): every row's four nearest columns.  Both engines produce identical keys, hence identical match vectors.
  *   AFV_MATCH_ENGINE_MFMA (default): Hamming distance as an exact i8 x i8 -> i32 contraction on the matrix cores
@@ -364,6 +371,13 @@ int afv_debug_get_candidates(afv_ctx *ctx, int frame, int level, uint32_t *packe
 int afv_debug_get_selected(afv_ctx *ctx, int frame, int level, int32_t *x, int32_t *y, float *response, int cap, int *n_out);
 /* standalone 7x7 Gaussian blur of a level (E9) — same arithmetic as the fused describe kernel */
 int afv_debug_blur_level(afv_ctx *ctx, int frame, int level, uint8_t *out);
+/* host-only (no device, no context): the work plan of the one-launch pyramid for a geometry - per level and per tile index of the top
+ * level the (need.lo, need.hi, own.lo, own.hi) ranges in x (first [nlevels][ntx] quadruples) and y ([nlevels][nty]), the resize
+ * coefficient tables (pairs (source offset, weight of the right tap) per level: x then y, levels 1..) and, in info[4 + 6 * 8]:
+ * nlevels, ntx, nty, LDS bytes, then per level w, h, LDS pitch, log2 pair slots, x-table offset, y-table offset (in pairs).
+ * tests/test_host_logic.py replays the kernel's data flow on the CPU from exactly these numbers. */
+int afv_debug_pyramid_plan(const afv_orb_params *params, int width, int height, int tile_w, int tile_h, int16_t *regions,
+                           int regions_cap, int32_t *info, int16_t *tables, int tables_cap);
 
 #ifdef __cplusplus
 }

@@ -137,3 +137,87 @@ def test_bench_self_launches_ranks_without_a_launcher(monkeypatch):
     assert "--nproc-per-node" in a and a[a.index("--nproc-per-node") + 1] == "4"
     assert a[a.index("--master-addr") + 1] == "127.0.0.1" and a[-6:] == ["--gpus", "4", "--steps", "3", "--workload", "pairs10k"]
     assert bench._REAL_STDOUT is None          # stdout untouched on the launching side
+
+
+# ---------------- the one-launch pyramid's work plan (host logic of k_pyramid_fused), replayed on the CPU ----------------
+def _pyramid_plan(afv, w, h, nlevels, sf, tw, th):
+    import ctypes as C
+    lib = afv._lib.load()
+    p = afv._lib.OrbParams(1000, nlevels, sf, 20, w, h, 1)
+    regions = np.zeros(8 * 4096 * 4, np.int16)
+    info = np.zeros(4 + 6 * 8, np.int32)
+    tables = np.zeros(2 * 8 * 2 * 4096, np.int16)
+    rc = lib.afv_debug_pyramid_plan(C.byref(p), w, h, tw, th, afv._lib.ptr(regions), regions.size, afv._lib.ptr(info), afv._lib.ptr(tables),
+                                    tables.size)
+    assert rc == 0, rc
+    nl, ntx, nty, lds = (int(v) for v in info[:4])
+    f = info[4:].reshape(6, 8)
+    rx = regions[:nl * ntx * 4].reshape(nl, ntx, 4).astype(int)
+    ry = regions[nl * ntx * 4:nl * (ntx + nty) * 4].reshape(nl, nty, 4).astype(int)
+    tab = tables.reshape(-1, 2).astype(int)
+    return dict(nl=nl, ntx=ntx, nty=nty, lds=lds, w=f[0], h=f[1], pitch=f[2], lg_p=f[3], tabx=f[4], taby=f[5], rx=rx, ry=ry, tab=tab)
+
+
+def _replay_fused_pyramid(P, img):
+    """the data flow of k_pyramid_fused: per top-level tile, regions of levels 1.. computed from the level-0 window through
+    region-relative tables; the owned rectangle (x widened to dwords) is stored.  Returns the levels and a write-count map."""
+    nl = P["nl"]
+    levels = [img] + [np.zeros((P["h"][l], (P["w"][l] + 3) // 4 * 4 + 4), np.int64) - 1 for l in range(1, nl)]
+    for ty in range(P["nty"]):
+        for tx in range(P["ntx"]):
+            rx0, ry0 = P["rx"][0, tx], P["ry"][0, ty]
+            S = np.zeros((ry0[1] - ry0[0] + 1, (rx0[1] - rx0[0] + 4) // 4 * 4), np.int64)
+            src = img[ry0[0]:ry0[1] + 1, rx0[0]:rx0[0] + S.shape[1]]
+            S[:, :src.shape[1]] = src
+            prev_x, prev_y = rx0, ry0
+            for l in range(1, nl):
+                rx, ry = P["rx"][l, tx], P["ry"][l, ty]
+                dwp, dh = rx[1] - rx[0] + 1, ry[1] - ry[0] + 1
+                assert dwp % 4 == 0 and rx[0] % 4 == 0 and dwp <= P["pitch"][l] and dwp // 2 <= (1 << P["lg_p"][l])
+                sw, sh = prev_x[1] - prev_x[0] + 1, S.shape[0]
+                X = rx[0] + np.arange(dwp)
+                inside = X < P["w"][l]
+                ex = P["tab"][P["tabx"][l] + np.minimum(X, P["w"][l] - 1)]
+                ox = np.where(inside, ex[:, 0] - prev_x[0], 0)
+                wx = np.where(inside, ex[:, 1], 0)
+                assert ox.min() >= 0 and ox.max() < sw, (l, tx)
+                ey = P["tab"][P["taby"][l] + ry[0] + np.arange(dh)]
+                oy, wy = ey[:, 0] - prev_y[0], ey[:, 1]
+                assert oy.min() >= 0 and oy.max() < sh, (l, ty)
+                # a tap with a non-zero weight must be a pixel the region really holds
+                assert np.all((ox + 1 < sw) | (wx == 0)) and np.all((oy + 1 < sh) | (wy == 0))
+                hrow = (256 - wx) * S[:, ox] + wx * S[:, np.minimum(ox + 1, sw - 1)]
+                D = (hrow[oy] * (256 - wy)[:, None] + hrow[np.minimum(oy + 1, sh - 1)] * wy[:, None] + 32768) >> 16
+                gx = rx[0] + np.arange(dwp)
+                own_x = (gx // 4 * 4 >= (rx[2] & ~3)) & (gx // 4 * 4 < rx[3])
+                gy = ry[0] + np.arange(dh)
+                own_y = (gy >= ry[2]) & (gy < ry[3])
+                tgt = levels[l]
+                for yi in np.nonzero(own_y)[0]:
+                    row = tgt[gy[yi]]
+                    cols = gx[own_x]
+                    old = row[cols]
+                    new = D[yi][own_x]
+                    assert np.all((old == -1) | (old == new)), "two workgroups disagree on a pixel"
+                    row[cols] = new
+                S, prev_x, prev_y = D, rx, ry
+    return levels
+
+
+def test_one_launch_pyramid_plan_reproduces_the_level_chain(afv, oracle):
+    """k_pyramid_fused computes every level from the level-0 window of its tile: the plan must make every pixel of every level
+    owned by some tile, computed from taps the tile holds, and equal to the level-by-level INTER_LINEAR_EXACT chain"""
+    cases = [(640, 480, 8, 1.2, 32, 16), (642, 481, 8, 1.2, 32, 16), (333, 251, 8, 1.2, 16, 16), (1280, 720, 8, 1.2, 32, 16),
+             (640, 480, 8, 1.1892, 32, 16), (640, 480, 4, 1.5, 32, 16), (640, 480, 3, 2.0, 32, 32), (640, 480, 2, 1.2, 64, 32),
+             (752, 480, 8, 1.2, 48, 24)]
+    for (w, h, nl, sf, tw, th) in cases:
+        P = _pyramid_plan(afv, w, h, nl, sf, tw, th)
+        img = afv.synth.corners_frame(5, w, h).astype(np.int64)
+        levels = _replay_fused_pyramid(P, img)
+        ref = img.astype(np.uint8)
+        for l in range(1, nl):
+            ref = oracle.resize_linear_exact(ref, int(P["w"][l]), int(P["h"][l]))
+            got = levels[l][:, :P["w"][l]]
+            assert got.min() >= 0, "level %d of %s: a pixel nobody owns" % (l, (w, h, nl, sf))
+            assert np.array_equal(got, ref), "level %d of %s differs" % (l, (w, h, nl, sf))
+        assert P["lds"] <= 160 * 1024
