@@ -590,12 +590,12 @@ static void enqueue_range(afv_ctx *c, const FrameSrc &src, int f0, int nf, afv_k
     {
         StageTimer t_(c, AFV_STAGE_HARRIS, s, nf);
         afv_launch_retain_harris(c->d_geo, g.nlevels, &src, c->d_pyr, c->d_cand_packed, c->d_cand_count, c->d_l1, c->d_l1_count,
-                                 c->d_l1_resp, c->d_hq + (size_t)f0 * c->hq_per_frame, c->d_hq_n + f0, f0, nf, s);
+                                 c->d_l1_resp, c->d_hq + (size_t)f0 * c->hq_per_frame, c->d_hq_n + f0, f0, nf, small ? 1 : 0, s);
     }
     {
         StageTimer t_(c, AFV_STAGE_SELECT, s, nf);
         afv_launch_select(c->d_geo, g.nlevels, c->d_l1, c->d_l1_resp, c->d_l1_count, c->d_kept_xy, c->d_kept_resp,
-                          c->d_kept_node, c->d_sel, c->d_sel_count, c->select_M, f0, nf, s);
+                          c->d_kept_node, c->d_sel, c->d_sel_count, c->select_M, f0, nf, small ? 1 : 0, s);
     }
     {
         StageTimer t_(c, AFV_STAGE_DESCRIBE, s, nf);
@@ -1109,7 +1109,8 @@ static int afv_match_bow_impl(afv_ctx *c, const afv_match_job *jobs, int njobs, 
                 }
             }
             const size_t match_off = b.reserve((size_t)njobs * cap * 4), nm_off = b.reserve((size_t)njobs * 4);
-            const size_t topk_off = b.reserve_scratch((size_t)njobs * cap * 32);
+            const int nslices = small_batch_path(c, njobs) ? afv_match_topk_slices(cap, c->match_engine, ((cap + 63) / 64 + 1) / 2) : 1;
+            const size_t topk_off = b.reserve_scratch((size_t)njobs * cap * 32 * nslices);
             int rc = ensure_match_buffer(c, b.h.size());
             if (rc) return rc;
             HIPCHK(c, hipMemcpyAsync(c->d_match, b.h.data(), match_off, hipMemcpyHostToDevice, c->stream));  // inputs only
@@ -1123,10 +1124,10 @@ static int afv_match_bow_impl(afv_ctx *c, const afv_match_job *jobs, int njobs, 
                 const float *angp = any_ori ? reinterpret_cast<const float *>(c->d_match + ang_off) : nullptr;
                 const int *np_ = reinterpret_cast<const int *>(c->d_match + n_off);
                 const int *pa_ = reinterpret_cast<const int *>(c->d_match + pa_off), *pb_ = reinterpret_cast<const int *>(c->d_match + pb_off);
-                afv_launch_match_topk(c->d_match + desc_off, np_, cap, pa_, pb_, i1 - i0, c->d_match + topk_off, i0, c->match_engine, c->stream);
+                afv_launch_match_topk(c->d_match + desc_off, np_, cap, pa_, pb_, i1 - i0, c->d_match + topk_off, i0, c->match_engine, nslices, c->stream);
                 afv_launch_match_resolve(c->d_match + desc_off, angp, 1, np_, cap, pa_, pb_, i1 - i0, jobs[i0].th_low, jobs[i0].nnratio,
                                          jobs[i0].check_orientation != 0, reinterpret_cast<int *>(c->d_match + match_off),
-                                         reinterpret_cast<int *>(c->d_match + nm_off), c->d_match + topk_off, i0, c->stream);
+                                         reinterpret_cast<int *>(c->d_match + nm_off), c->d_match + topk_off, i0, nslices, c->stream);
                 i0 = i1;
             }
             HIPCHK(c, hipGetLastError());
@@ -1278,7 +1279,10 @@ int afv_match_pairs_core(afv_ctx *c, const uint8_t *d_desc, const float *d_ang, 
                          const int32_t *d_pair_a, const int32_t *d_pair_b, int npairs, float th_low, float nnratio,
                          int check_orientation, int32_t *d_match, int32_t *d_nmatches, hipStream_t s) {
     c->prof = c->prof_every && (c->prof_tick_match++ % (unsigned)c->prof_every) == 0;
-    const size_t need = (size_t)npairs * cap * 32;  // one 2 x int4 key record per row
+    // the small-batch path deals the column tiles of phase 1 to several workgroups per row tile (two 64-column tiles each): a single
+    // pair then runs on 32 workgroups instead of 4, and the resolve kernel merges the slices' key records
+    const int nslices = small_batch_path(c, npairs) ? afv_match_topk_slices(cap, c->match_engine, ((cap + 63) / 64 + 1) / 2) : 1;
+    const size_t need = (size_t)npairs * cap * 32 * nslices;  // one 2 x int4 key record per row (and slice)
     if (need > c->topk_bytes) {  // grow-only scratch (first call / larger batch): implies a device sync
         HIPCHK(c, hipDeviceSynchronize());
         if (c->d_topk) (void)hipFree(c->d_topk);
@@ -1299,22 +1303,22 @@ int afv_match_pairs_core(afv_ctx *c, const uint8_t *d_desc, const float *d_ang, 
             hipStream_t ks = (k & 1) ? c->stream2 : s;
             {
                 StageTimer t_(c, AFV_STAGE_MATCH, ks, e0 - b0);
-                afv_launch_match_topk(d_desc, d_n, cap, d_pair_a, d_pair_b, e0 - b0, c->d_topk, b0, c->match_engine, ks);
+                afv_launch_match_topk(d_desc, d_n, cap, d_pair_a, d_pair_b, e0 - b0, c->d_topk, b0, c->match_engine, nslices, ks);
             }
             StageTimer t_(c, AFV_STAGE_MATCH_RESOLVE, ks, e0 - b0);
             afv_launch_match_resolve(d_desc, d_ang, ang_stride, d_n, cap, d_pair_a, d_pair_b, e0 - b0, th_low, nnratio, check_orientation,
-                                     d_match, d_nmatches, c->d_topk, b0, ks);
+                                     d_match, d_nmatches, c->d_topk, b0, nslices, ks);
         }
         HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0));
     } else {
         {
             StageTimer t_(c, AFV_STAGE_MATCH, s, npairs);
-            afv_launch_match_topk(d_desc, d_n, cap, d_pair_a, d_pair_b, npairs, c->d_topk, 0, c->match_engine, s);
+            afv_launch_match_topk(d_desc, d_n, cap, d_pair_a, d_pair_b, npairs, c->d_topk, 0, c->match_engine, nslices, s);
         }
         StageTimer t_(c, AFV_STAGE_MATCH_RESOLVE, s, npairs);
         afv_launch_match_resolve(d_desc, d_ang, ang_stride, d_n, cap, d_pair_a, d_pair_b, npairs, th_low, nnratio, check_orientation, d_match,
-                                 d_nmatches, c->d_topk, 0, s);
+                                 d_nmatches, c->d_topk, 0, nslices, s);
     }
     HIPCHK(c, hipGetLastError());
     return AFV_OK;

@@ -28,11 +28,11 @@ extern "C" void afv_launch_fast_nms(const Geo *geo, int total_tiles, const Frame
 extern "C" size_t afv_harris_queue_per_frame(const Geo *g);
 extern "C" void afv_launch_retain_harris(const Geo *geo_dev, int nlevels, const FrameSrc *src0, const uint8_t *pyr,
                                          const uint32_t *cand_packed, const int *cand_count, uint32_t *l1, int *l1_count,
-                                         float *l1_resp, uint2 *queue, int *queue_n, int frame_base, int nframes, hipStream_t stream);
+                                         float *l1_resp, uint2 *queue, int *queue_n, int frame_base, int nframes, int small, hipStream_t stream);
 extern "C" size_t afv_select_lds_bytes(int M);
 extern "C" void afv_launch_select(const Geo *geo_dev, int nlevels, const uint32_t *cand_packed, const float *cand_resp,
                                   const int *cand_count, uint32_t *kept_xy, float *kept_resp, uint16_t *kept_node, SelPoint *sel,
-                                  int *sel_count, int M, int frame_base, int nframes, hipStream_t stream);
+                                  int *sel_count, int M, int frame_base, int nframes, int wide, hipStream_t stream);
 extern "C" int afv_describe_blocks_per_frame(const Geo *g);
 extern "C" void afv_launch_describe(const Geo *geo_dev, int blocks_per_frame, const FrameSrc *src0, const uint8_t *pyr,
                                     const SelPoint *sel, const int *sel_count, afv_keypoint *kps, uint8_t *desc,
@@ -56,11 +56,12 @@ struct DevTriJob {
 extern "C" void afv_launch_match_bow(const DevMatchJob *jobs, int njobs, hipStream_t stream);
 extern "C" void afv_launch_match_bow_seg(const DevMatchJob *jobs, int njobs, const void *tasks, int ntasks, int *hist, uint8_t *bins,
                                          const int *bin_off, int any_ori, hipStream_t stream);
+extern "C" int afv_match_topk_slices(int cap, int engine, int want);
 extern "C" void afv_launch_match_topk(const uint8_t *desc, const int *nset, int cap, const int *pa, const int *pb, int npairs,
-                                      void *topk_scratch, int pair_base, int engine, hipStream_t stream);
+                                      void *topk_scratch, int pair_base, int engine, int nslices, hipStream_t stream);
 extern "C" void afv_launch_match_resolve(const uint8_t *desc, const float *ang, int ang_stride, const int *nset, int cap, const int *pa,
                                          const int *pb, int npairs, float th, float ratio, int check_ori, int *match, int *nmatches,
-                                         const void *topk_scratch, int pair_base, hipStream_t stream);
+                                         const void *topk_scratch, int pair_base, int nslices, hipStream_t stream);
 extern "C" void afv_launch_match_tri(const DevTriJob *jobs, int njobs, int max_n1, hipStream_t stream);
 extern "C" void afv_launch_match_l2(const float *d1, int n1, const float *d2, int n2, int dim, const uint8_t *v1,
                                     const uint8_t *v2, float th, float ratio, int *out, int *nmatches, hipStream_t stream);

@@ -262,6 +262,113 @@ __global__ __launch_bounds__(256) void k_harris(const Geo *__restrict__ geo_p, F
     }
 }
 
+// ---------------- retainBest + Harris in ONE launch (the small-batch path: one or a few frames) ----------------
+// k_retain_score + k_harris cost one frame 11 + 5 us plus a launch boundary: one workgroup per level walks a list of up to ~11 000
+// candidates in 36 dependent compaction steps, then a second kernel picks the survivors up from a queue.  Here a level is dealt to
+// RH_SLICES workgroups of 1024 threads.  Every one of them histograms the WHOLE level (44 KB out of L2, the loads of a thread in flight
+// together), derives the same threshold T1, counts the survivors in front of its slice (its output offset: deterministic, no
+// counter to clear), writes the survivors of its slice and computes their Harris responses - one lane per survivor, the same
+// harris_response as k_harris.  The last slice publishes the level's survivor count.
+#define RH_T 1024
+#define RH_SLICES 4
+
+__global__ __launch_bounds__(RH_T) void k_retain_harris_small(const Geo *__restrict__ geo_p, FrameSrc src0, const uint8_t *__restrict__ pyr,
+                                                              const uint32_t *__restrict__ cand_packed, const int *__restrict__ cand_count,
+                                                              uint32_t *__restrict__ l1, int *__restrict__ l1_count, float *__restrict__ l1_resp,
+                                                              int frame_base, int total_blocks) {
+    __shared__ int hist[4][256];  // four copies (lane & 3): FAST scores crowd a few bins just above the threshold
+    __shared__ int wsum[RH_T / 64];
+    __shared__ int s_T1, s_before, s_mine;
+    __shared__ uint32_t s_surv[RH_T];  // survivors of the current chunk of this workgroup's slice
+    const Geo &geo = *geo_p;
+    const int work = (int)blockIdx.x;
+    if (work >= total_blocks) return;
+    const int slice = work % RH_SLICES, fl = work / RH_SLICES;
+    const int l = fl % geo.nlevels, f = frame_base + fl / geo.nlevels;
+    const LevelGeo &L = geo.lv[l];
+    const size_t base = L.cand_off + (size_t)f * L.cand_frame_stride;
+    const uint32_t *cp = cand_packed + base;
+    const int n = min(cand_count[f * AFV_MAX_LEVELS + l], L.cand_cap);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int K = 2 * L.cv_quota;
+    const int start = (int)((long)n * slice / RH_SLICES), end = (int)((long)n * (slice + 1) / RH_SLICES);
+    int T1 = 0;
+    if (tid == 0) {
+        s_before = 0;
+        s_mine = 0;
+    }
+    if (n > K) {  // uniform
+        if (tid < 256) hist[0][tid] = hist[1][tid] = hist[2][tid] = hist[3][tid] = 0;
+        if (tid == 0) s_T1 = 0;
+        __syncthreads();
+#pragma unroll 4
+        for (int i = tid; i < n; i += RH_T) atomicAdd(&hist[lane & 3][cp[i] >> 24], 1);
+        __syncthreads();
+        // thread t < 256 owns bin 255 - t: the threshold is the bin at which the count from the top reaches K
+        int h = 0, incl = 0;
+        if (tid < 256) {
+            h = hist[0][255 - tid] + hist[1][255 - tid] + hist[2][255 - tid] + hist[3][255 - tid];
+            incl = afv_wave_incl_scan(h);
+            if (lane == 63) wsum[tid >> 6] = incl;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            int before = incl - h;
+            for (int w = 0; w < (tid >> 6); ++w) before += wsum[w];
+            if (before < K && K <= before + h) s_T1 = 255 - tid;
+        }
+        __syncthreads();
+        T1 = s_T1;
+    }
+    __syncthreads();  // s_before / s_mine cleared
+    // survivors in front of the slice: this workgroup's first output slot
+    {
+        int c = 0;
+#pragma unroll 4
+        for (int i = tid; i < start; i += RH_T) c += (int)(cp[i] >> 24) >= T1;
+        c = afv_wave_incl_scan(c);
+        if (lane == 63 && c) atomicAdd(&s_before, c);
+    }
+    __syncthreads();
+    int out_base = s_before;
+    // raw buffer over this frame's level image, as in harris_item
+    HarrisItem it;
+    if (l == 0) {
+        it.img = src0.base + (size_t)f * src0.frame_stride;
+        it.pitch = src0.stride;
+    } else {
+        it.img = pyr + L.pyr_off + (size_t)f * L.pyr_frame_stride;
+        it.pitch = L.pitch;
+    }
+    it.lw = L.w;
+    it.lh = L.h;
+    it.cnt = 0;
+    it.base = 0;
+    it.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(it.img), 0, (it.lh - 1) * it.pitch + it.lw, 0x00027000);
+    for (int c0 = start; c0 < end; c0 += RH_T) {  // uniform trip count
+        const int i = c0 + tid;
+        const uint32_t e = i < end ? cp[i] : 0u;
+        const bool keep = i < end && (int)(e >> 24) >= T1;
+        const unsigned long long m = __ballot(keep);
+        int wbase = 0;
+        if (lane == 0 && m) wbase = atomicAdd(&s_mine, __popcll(m));
+        wbase = __shfl(wbase, 0, 64);
+        if (keep) s_surv[wbase + __popcll(m & ((1ull << lane) - 1ull))] = e;
+        __syncthreads();
+        const int cnt = s_mine;
+        if (tid < cnt) {
+            const uint32_t es = s_surv[tid];
+            l1[base + out_base + tid] = es;
+            l1_resp[base + out_base + tid] = harris_response(it, es, geo.harris_scale4);
+        }
+        out_base += cnt;
+        __syncthreads();
+        if (tid == 0) s_mine = 0;
+        __syncthreads();
+    }
+    if (slice == RH_SLICES - 1 && tid == 0) l1_count[f * AFV_MAX_LEVELS + l] = out_base;
+}
+
 // queue capacity per frame: every level can hand over all its candidate slots
 extern "C" size_t afv_harris_queue_per_frame(const Geo *g) {
     size_t n = 0;
@@ -272,7 +379,13 @@ extern "C" size_t afv_harris_queue_per_frame(const Geo *g) {
 // `queue` / `queue_n` belong to this launch (the runtime hands every chunk of a split batch its own); *queue_n must be 0 on entry
 extern "C" void afv_launch_retain_harris(const Geo *geo_dev, int nlevels, const FrameSrc *src0, const uint8_t *pyr,
                                          const uint32_t *cand_packed, const int *cand_count, uint32_t *l1, int *l1_count,
-                                         float *l1_resp, uint2 *queue, int *queue_n, int frame_base, int nframes, hipStream_t stream) {
+                                         float *l1_resp, uint2 *queue, int *queue_n, int frame_base, int nframes, int small, hipStream_t stream) {
+    if (small) {
+        const int total = nlevels * nframes * RH_SLICES;
+        hipLaunchKernelGGL(k_retain_harris_small, dim3(total), dim3(RH_T), 0, stream, geo_dev, *src0, pyr, cand_packed, cand_count, l1, l1_count,
+                           l1_resp, frame_base, total);
+        return;
+    }
     const int total = nlevels * nframes;
     hipLaunchKernelGGL(k_retain_score, dim3((total + 7) / 8 * 8), dim3(256), 0, stream, geo_dev, cand_packed, cand_count, l1, l1_count,
                        queue, queue_n, frame_base, total);

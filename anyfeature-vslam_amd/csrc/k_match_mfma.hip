@@ -95,13 +95,17 @@ __device__ __forceinline__ void mq_compute(const uint8_t *buf, const v4i (&bq)[2
 
 __global__ __launch_bounds__(MQ_T, 2) void k_match_topk_mfma(const uint8_t *__restrict__ desc, const int *__restrict__ nset, int cap,
                                                              const int *__restrict__ pair_a, const int *__restrict__ pair_b,
-                                                             int4 *__restrict__ topk, int pair_base) {
+                                                             int4 *__restrict__ topk, int pair_base, int nslices) {
     __shared__ __attribute__((aligned(16))) uint2 s_lut[256];
     __shared__ __attribute__((aligned(16))) uint8_t s_a[2][T_TILE * A_PITCH];
     const int p = pair_base + blockIdx.y;
     const int sa = pair_a[p], sb = pair_b[p];
     const int n1 = min(nset[sa], cap), n2 = min(nset[sb], cap);
-    if (blockIdx.x * MQ_T >= n1) return;  // uniform
+    // nslices > 1 (one or a few pairs, the per-frame plugin call): the 64-column tiles of the train set are dealt to `nslices`
+    // workgroups per row tile; every slice writes its own record per row, k_match_resolve merges them (records of disjoint column
+    // sets merge exactly like the two lane halves below)
+    const int rt = (int)blockIdx.x / nslices, slice = (int)blockIdx.x - rt * nslices;
+    if (rt * MQ_T >= n1) return;  // uniform
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     {   // byte -> eight +-64 bytes: bit j of the byte -> byte j (0x40 if set, 0xC0 = -64 if clear)
         const uint32_t lo = ((uint32_t)(tid & 15) * 0x00204081u) & 0x01010101u, hi = ((uint32_t)(tid >> 4) * 0x00204081u) & 0x01010101u;
@@ -112,8 +116,10 @@ __global__ __launch_bounds__(MQ_T, 2) void k_match_topk_mfma(const uint8_t *__re
     for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
         for (int i = 0; i < 4; ++i) kk[qb][i] = NO_KEY;
-    const int row0 = blockIdx.x * MQ_T + wv * 64;  // first query of this wavefront
-    if (n2 > 0) {
+    const int row0 = rt * MQ_T + wv * 64;  // first query of this wavefront
+    const int ntiles_all = (n2 + T_TILE - 1) / T_TILE, per_slice = (ntiles_all + nslices - 1) / nslices;
+    const int tile0 = slice * per_slice, tile1 = min(tile0 + per_slice, ntiles_all);
+    if (tile0 < tile1) {
         __syncthreads();  // table ready
         // B fragments: lane (n = lane & 31, g = lane >> 5) holds, for instruction t, the k-slots 32 t + 16 g .. + 15 = descriptor bytes
         // 4 t + 2 g, 4 t + 2 g + 1 of query row0 + 32 qb + n, signs flipped
@@ -140,12 +146,11 @@ __global__ __launch_bounds__(MQ_T, 2) void k_match_topk_mfma(const uint8_t *__re
         v4i bidx = {0, 0, 0, 0};
         if (lane < 32) bidx[0] = 1 | (64 << 8);
         const uint32_t *train = reinterpret_cast<const uint32_t *>(desc + (size_t)sb * cap * 32);
-        const int ntiles = (n2 + T_TILE - 1) / T_TILE;
         const bool wave_has_rows = row0 < n1;
-        mq_stage(train, n2, 0, s_lut, s_a[0], tid);
+        mq_stage(train, n2, tile0 * T_TILE, s_lut, s_a[tile0 & 1], tid);
         __syncthreads();
-        for (int tile = 0; tile < ntiles; ++tile) {
-            if (tile + 1 < ntiles) mq_stage(train, n2, (tile + 1) * T_TILE, s_lut, s_a[(tile + 1) & 1], tid);
+        for (int tile = tile0; tile < tile1; ++tile) {
+            if (tile + 1 < tile1) mq_stage(train, n2, (tile + 1) * T_TILE, s_lut, s_a[(tile + 1) & 1], tid);
             if (wave_has_rows) {
                 if ((tile + 1) * T_TILE <= n2) mq_compute<false>(s_a[tile & 1], bq, bidx, kk, tile * T_TILE, n2, lane);
                 else mq_compute<true>(s_a[tile & 1], bq, bidx, kk, tile * T_TILE, n2, lane);
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(MQ_T, 2) void k_match_topk_mfma(const uint8_t *__re
                 const int D = m[i] + (1 << 20);
                 s[i] = m[i] == NO_KEY ? NO_KEY : (((D >> 13) << 16) | (D & 8191));
             }
-            int4 *rec = topk + ((size_t)p * cap + row) * 2;
+            int4 *rec = topk + (((size_t)p * cap + row) * nslices + slice) * 2;
             rec[0] = make_int4(s[0], s[1], s[2], s[3]);
             rec[1] = make_int4(s[4], s[5], s[6], max(nk, 1));
         }
@@ -190,8 +195,8 @@ __global__ __launch_bounds__(MQ_T, 2) void k_match_topk_mfma(const uint8_t *__re
 }
 
 extern "C" void afv_launch_match_topk_mfma(const uint8_t *desc, const int *nset, int cap, const int *pa, const int *pb, int npairs,
-                                           void *topk_scratch, int pair_base, hipStream_t stream) {
+                                           void *topk_scratch, int pair_base, int nslices, hipStream_t stream) {
     int4 *topk = reinterpret_cast<int4 *>(topk_scratch);
-    hipLaunchKernelGGL(k_match_topk_mfma, dim3((cap + MQ_T - 1) / MQ_T, npairs), dim3(MQ_T), 0, stream, desc, nset, cap, pa, pb, topk,
-                       pair_base);
+    hipLaunchKernelGGL(k_match_topk_mfma, dim3((cap + MQ_T - 1) / MQ_T * nslices, npairs), dim3(MQ_T), 0, stream, desc, nset, cap, pa, pb, topk,
+                       pair_base, nslices);
 }

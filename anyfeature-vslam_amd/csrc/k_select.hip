@@ -19,11 +19,22 @@
 //     Termination tests (:366-369, :427-430) are evaluated on the same quantities as the reference.
 //   * the survivor of each node is the max-response point, ties -> smallest raster index (== "first max wins" on
 //     raster-ordered input, :446-453), found with one 64-bit LDS atomic max per point.
+#include <algorithm>
+
 #include "afv_device.h"
 
-#define ST 256  // threads per workgroup
-#define CPT 20        // candidates a thread keeps in registers: the fast path covers n <= ST * CPT = 5120
-#define KEPT_LDS 2304 // retainBest survivors (position + node label) kept in LDS for the quadtree rounds (else global scratch)
+// Two instantiations: ST = 256 threads per workgroup for batches (what a batch costs is set by how many (frame, level) workgroups a CU
+// holds: 29 KB of LDS, <= 96 VGPRs), ST = 1024 for the small-batch path (one frame: the eight workgroups of a frame are alone on the
+// chip and the kernel's time is the critical path of level 0 - four times the lanes shorten every per-thread loop: 5 instead of 20
+// candidates, 3 instead of 9 survivors per thread).
+#define SEL_CAND 5120  // candidates kept in registers: the fast path covers n <= ST * CPT = 5120
+template <int ST> struct SelCfg {
+    static constexpr int CPT = SEL_CAND / ST;             // candidates a thread keeps in registers
+    static constexpr int PPT = ST == 256 ? 9 : 3;         // retainBest survivors a thread keeps in registers over the quadtree rounds
+    static constexpr int KEPT_LDS = ST * PPT;             // ... and how many of them (position + node label) LDS holds (else global scratch)
+    static constexpr int NW = ST / 64;
+};
+#define SEL_TMP 32    // ints of small shared state: [0..15] counters / results, [16..31] per-wavefront partial sums
 // The kernel is a chain of short dependent phases (latency-, not throughput-bound): what a batch costs is set by how many
 // (frame, level) workgroups a CU holds at once, so the LDS footprint (~29 KB at M = 256 -> 5 workgroups per CU) and the
 // register budget (<= 96 VGPRs, 5 waves per SIMD) are the tuning parameters here.
@@ -48,19 +59,25 @@ __device__ __forceinline__ float key_float(uint32_t k) {
 // ---- block-wide helpers (256 threads = 4 waves) ----
 __device__ __forceinline__ int wave_incl_scan(int v) { return afv_wave_incl_scan(v); }
 
-// exclusive prefix sum of arr[0..n) in place; returns the total.  n <= ST * 16.  `tmp` = 8 ints of LDS.
+// exclusive prefix sum of arr[0..n) in place; returns the total.  n <= ST * 16.  `tmp` = SEL_TMP ints of LDS.
+template <int ST>
 __device__ int block_excl_scan(int *arr, int n, int *tmp) {
+    int *ws = tmp + 16;
     const int per = (n + ST - 1) / ST;
     const int b = threadIdx.x * per, e = min(b + per, n);
     int local = 0;
     for (int i = b; i < e; ++i) local += arr[i];
     const int incl = wave_incl_scan(local);
     const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 63) tmp[w] = incl;
+    if ((threadIdx.x & 63) == 63) ws[w] = incl;
     __syncthreads();
-    int base = incl - local;
-    for (int k = 0; k < w; ++k) base += tmp[k];
-    const int total = tmp[0] + tmp[1] + tmp[2] + tmp[3];
+    int base = incl - local, total = 0;
+#pragma unroll
+    for (int k = 0; k < ST / 64; ++k) {
+        const int v = ws[k];
+        base += k < w ? v : 0;
+        total += v;
+    }
     for (int i = b; i < e; ++i) {
         const int v = arr[i];
         arr[i] = base;
@@ -72,7 +89,9 @@ __device__ int block_excl_scan(int *arr, int n, int *tmp) {
 
 // two exclusive prefix sums in ONE pass: a[0..na) and u[0..nu) (na <= nu), both with totals < 65536 so that the pair rides one packed
 // wave scan.  Returns (total of a) | (total of u) << 16.  `tmp` = 4 ints of LDS.  One barrier inside, one at the end.
+template <int ST>
 __device__ int block_excl_scan2(int *a, int na, int *u, int nu, int *tmp) {
+    int *ws = tmp + 16;
     const int per = (nu + ST - 1) / ST;
     const int b = threadIdx.x * per, e = min(b + per, nu), ea = min(e, na);
     int local = 0;
@@ -80,11 +99,15 @@ __device__ int block_excl_scan2(int *a, int na, int *u, int nu, int *tmp) {
     for (int i = b; i < e; ++i) local += u[i] << 16;
     const int incl = wave_incl_scan(local);
     const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 63) tmp[w] = incl;
+    if ((threadIdx.x & 63) == 63) ws[w] = incl;
     __syncthreads();
-    int base = incl - local;
-    for (int k = 0; k < w; ++k) base += tmp[k];
-    const int total = tmp[0] + tmp[1] + tmp[2] + tmp[3];
+    int base = incl - local, total = 0;
+#pragma unroll
+    for (int k = 0; k < ST / 64; ++k) {
+        const int v = ws[k];
+        base += k < w ? v : 0;
+        total += v;
+    }
     int ba = base & 0xffff, bu = (int)((unsigned)base >> 16);
     for (int i = b; i < ea; ++i) {
         const int v = a[i];
@@ -102,7 +125,9 @@ __device__ int block_excl_scan2(int *a, int na, int *u, int nu, int *tmp) {
 
 // k-th largest over a histogram hist[0..nbins): returns the bin b such that sum(hist[b+1..]) < k <= sum(hist[b..]),
 // and *above = sum(hist[b+1..]).  hist is destroyed.  Requires sum(hist) >= k >= 1.
+template <int ST>
 __device__ int block_kth_from_top(int *hist, int nbins, int k, int *above, int *tmp) {
+    int *ws = tmp + 16;
     // suffix sums via a prefix scan of the reversed index space
     const int per = (nbins + ST - 1) / ST;
     const int b = threadIdx.x * per, e = min(b + per, nbins);
@@ -110,11 +135,12 @@ __device__ int block_kth_from_top(int *hist, int nbins, int k, int *above, int *
     for (int i = b; i < e; ++i) local += hist[nbins - 1 - i];
     const int incl = wave_incl_scan(local);
     const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 63) tmp[w] = incl;
+    if ((threadIdx.x & 63) == 63) ws[w] = incl;
     if (threadIdx.x == 0) tmp[4] = -1;
     __syncthreads();
     int base = incl - local;
-    for (int q = 0; q < w; ++q) base += tmp[q];
+#pragma unroll
+    for (int q = 0; q < ST / 64; ++q) base += q < w ? ws[q] : 0;
     // this thread's chunk (in reversed order) covers cumulative counts (base, base+local]
     if (base < k && k <= base + local) {
         int cum = base;
@@ -157,14 +183,16 @@ __device__ __forceinline__ Rect16 child_rect(const Rect16 r, int q) {
 //   quadtree region (60 * M bytes): Rect16 rect[2][M]; int cnt[2][M]; int child[M*4] (the survivor keys best[M] reuse it after the
 //     last round); int aux[M], aux2[M], unt[M]; uint16 remap[M*4]
 //   the retainBest histograms hist[2048] live on top of that region (dead before the first node is created)
-//   int tmp[16]; kept_xy u32[KEPT_LDS]; kept_node u16[KEPT_LDS]        (the responses of the survivors stay in global scratch)
-__global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_select_quadtree(const Geo *__restrict__ geo_p, const uint32_t *__restrict__ cand_packed,
+//   int tmp[SEL_TMP]; kept_xy u32[KEPT_LDS]; kept_node u16[KEPT_LDS]        (the responses of the survivors stay in global scratch)
+template <int ST>
+__device__ __forceinline__ void select_quadtree_body(const Geo *__restrict__ geo_p, const uint32_t *__restrict__ cand_packed,
                                                        const float *__restrict__ cand_resp,
                                                        const int *__restrict__ cand_count, uint32_t *__restrict__ kept_xy,
                                                        float *__restrict__ kept_resp, uint16_t *__restrict__ kept_node,
                                                        SelPoint *__restrict__ sel, int *__restrict__ sel_count, int M, int frame_base,
                                                        int total_blocks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CPT = SelCfg<ST>::CPT, KEPT_LDS = SelCfg<ST>::KEPT_LDS;
     int *hist = reinterpret_cast<int *>(smem);
     Rect16 *rect0 = reinterpret_cast<Rect16 *>(smem);
     Rect16 *rect1 = rect0 + M;
@@ -196,7 +224,7 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     uint32_t *kxy = kept_xy + base;  // re-pointed to LDS below when the survivors fit
     float *kr = kept_resp + base;
     uint16_t *kn = kept_node + base;
-    uint32_t *lds_kxy = reinterpret_cast<uint32_t *>(tmp + 16);
+    uint32_t *lds_kxy = reinterpret_cast<uint32_t *>(tmp + SEL_TMP);
     uint16_t *lds_kn = reinterpret_cast<uint16_t *>(lds_kxy + KEPT_LDS);
     const int n = min(cand_count[f * AFV_MAX_LEVELS + l], L.cand_cap);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -255,7 +283,7 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             })
             __syncthreads();
             int above;
-            const int bin = block_kth_from_top(hist, nb, k, &above, tmp);
+            const int bin = block_kth_from_top<ST>(hist, nb, k, &above, tmp);
             k -= above;
             prefix |= (uint32_t)bin << sh;
             mask |= (uint32_t)(nb - 1) << sh;
@@ -372,7 +400,7 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     bool phase_b = false;
     // the usual case (survivors fit the LDS arrays): every thread keeps its <= PPT points (position, node label) in registers for
     // all rounds; kn[] is written back once after the last round
-    constexpr int PPT = KEPT_LDS / ST;
+    constexpr int PPT = SelCfg<ST>::PPT;
     const bool small = m2 > 0 && m2 <= KEPT_LDS;
     int nd_[PPT];
     uint32_t xy_[PPT];
@@ -471,7 +499,7 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             if (lane == 63) atomicAdd(&tmp[10], ecount);
             __syncthreads();
             const int E = tmp[10];
-            block_excl_scan(aux, E, tmp);  // aux[r] = sum of deltas of ranks < r  (deltas >= 0: monotone)
+            block_excl_scan<ST>(aux, E, tmp);  // aux[r] = sum of deltas of ranks < r  (deltas >= 0: monotone)
             // stop rank r*: smallest r whose split lifts the node count to >= N (ORBextractor.cc:424-425); the
             // count after rank r is prev_size + aux[r+1]; if no rank reaches N every node is processed
             for (int r = tid; r + 1 < E; r += ST)
@@ -493,7 +521,7 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         // 3. suffix sums over the processing order: children of later-processed nodes come first in the new list
         // child (node i, quadrant q) -> position (total - aux[key] - ne(i)) + #non-empty children with quadrant > q
         // untouched node i (unt[i] = 1, set with aux2 above) -> total_children + rank among untouched nodes
-        const int totals = block_excl_scan2(aux, nproc, unt, size, tmp);  // aux[key] = children of keys < key
+        const int totals = block_excl_scan2<ST>(aux, nproc, unt, size, tmp);  // aux[key] = children of keys < key
         const int total_children = totals & 0xffff, untouched = (int)((unsigned)totals >> 16);
         const int new_size = total_children + untouched;
         int n_expand_local = 0;
@@ -539,7 +567,9 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(5, 5))) void
 #pragma unroll
             for (int k_ = 0; k_ < PPT; ++k_) {
                 const int q = (key_[k_] >= 0) ? (int)((quads >> (2 * k_)) & 3u) : 0;  // aux2 >= 0 implies the node had > 1 point
-                nd_[k_] = remap[4 * nd_[k_] + q];
+                // the tail threads' clamped duplicates keep their (in-range, never counted) label: their quadrant bits were never
+                // set, and remap[4 * node] of a split node whose first quadrant is empty is not written this round
+                if (tid + k_ * ST < m2) nd_[k_] = remap[4 * nd_[k_] + q];
             }
         } else {
             for (int p = tid; p < m2; p += ST) {
@@ -603,15 +633,40 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(5, 5))) void
 #endif
 }
 
-extern "C" size_t afv_select_lds_bytes(int M) {
-    return afv_select_tree_bytes(M) + 64 /*tmp*/ + (size_t)KEPT_LDS * 6 /*kept xy, node*/;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_select_quadtree(const Geo *__restrict__ geo_p, const uint32_t *__restrict__ cand_packed,
+                                                       const float *__restrict__ cand_resp,
+                                                       const int *__restrict__ cand_count, uint32_t *__restrict__ kept_xy,
+                                                       float *__restrict__ kept_resp, uint16_t *__restrict__ kept_node,
+                                                       SelPoint *__restrict__ sel, int *__restrict__ sel_count, int M, int frame_base,
+                                                       int total_blocks) {
+    select_quadtree_body<256>(geo_p, cand_packed, cand_resp, cand_count, kept_xy, kept_resp, kept_node, sel, sel_count, M, frame_base, total_blocks);
 }
+// the small-batch instantiation (see the top of the file)
+__global__ __launch_bounds__(1024) void k_select_quadtree_wide(const Geo *__restrict__ geo_p, const uint32_t *__restrict__ cand_packed,
+                                                               const float *__restrict__ cand_resp, const int *__restrict__ cand_count,
+                                                               uint32_t *__restrict__ kept_xy, float *__restrict__ kept_resp,
+                                                               uint16_t *__restrict__ kept_node, SelPoint *__restrict__ sel,
+                                                               int *__restrict__ sel_count, int M, int frame_base, int total_blocks) {
+    select_quadtree_body<1024>(geo_p, cand_packed, cand_resp, cand_count, kept_xy, kept_resp, kept_node, sel, sel_count, M, frame_base, total_blocks);
+}
+
+static size_t select_lds_bytes(int M, int kept) { return afv_select_tree_bytes(M) + SEL_TMP * 4 + (size_t)kept * 6 /*kept xy, node*/; }
+extern "C" size_t afv_select_lds_bytes(int M) { return std::max(select_lds_bytes(M, SelCfg<256>::KEPT_LDS), select_lds_bytes(M, SelCfg<1024>::KEPT_LDS)); }
 
 extern "C" void afv_launch_select(const Geo *geo_dev, int nlevels, const uint32_t *cand_packed, const float *cand_resp,
                                   const int *cand_count, uint32_t *kept_xy, float *kept_resp, uint16_t *kept_node,
-                                  SelPoint *sel, int *sel_count, int M, int frame_base, int nframes, hipStream_t stream) {
+                                  SelPoint *sel, int *sel_count, int M, int frame_base, int nframes, int wide, hipStream_t stream) {
     const int total = nlevels * nframes;
     dim3 grid((total + 7) / 8 * 8);
-    hipLaunchKernelGGL(k_select_quadtree, grid, dim3(ST), afv_select_lds_bytes(M), stream, geo_dev, cand_packed, cand_resp,
+    if (wide) {
+        const size_t lds = select_lds_bytes(M, SelCfg<1024>::KEPT_LDS);
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_select_quadtree_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_select_quadtree_wide, grid, dim3(1024), lds, stream, geo_dev, cand_packed, cand_resp, cand_count, kept_xy, kept_resp,
+                           kept_node, sel, sel_count, M, frame_base, total);
+        return;
+    }
+    const size_t lds = select_lds_bytes(M, SelCfg<256>::KEPT_LDS);
+    hipLaunchKernelGGL(k_select_quadtree, grid, dim3(256), lds, stream, geo_dev, cand_packed, cand_resp,
                        cand_count, kept_xy, kept_resp, kept_node, sel, sel_count, M, frame_base, total);
 }

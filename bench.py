@@ -756,8 +756,10 @@ def extra_single_frame(afv, device, reps=200):
     dev = torch.device("cuda", device)
     frames_h = afv.synth.corners_batch(7001, 8, W, H)
     out = {}
-    for nctx in (1, 2, 4):
+    for nctx, mode in ((1, 1), (2, 1), (4, 1), (1, 0)):   # the last run: the same calls served by the batch kernels (the round-3 figure)
         ctxs = [afv.Context(max_batch=2, device=device) for _ in range(nctx)]
+        for c in ctxs:
+            c.set_small_batch_path(mode)
         ms = [afv.FeatureMatcher(0.6, True, ctx=c) for c in ctxs]
         cap = ctxs[0].cap
         st = []
@@ -784,7 +786,7 @@ def extra_single_frame(afv, device, reps=200):
             one(i)
         torch.cuda.synchronize(dev)
         dt = (time.perf_counter() - t0) / reps
-        out["contexts_%d" % nctx] = {"frames_per_s": 1.0 / dt, "ms_per_frame": dt * 1e3}
+        out["contexts_%d" % nctx if mode else "contexts_1_batch_kernels"] = {"frames_per_s": 1.0 / dt, "ms_per_frame": dt * 1e3}
         for c in ctxs:
             c.close()
     out["note"] = "one extract + match call per frame; contexts_1 = back-to-back latency, contexts_2 / _4 = calls of different contexts overlap"
@@ -823,6 +825,8 @@ def main():
     ap.add_argument("--lib", default=None, help="measurement tooling: bind this build of libafv_hip.so (tools/experiments.py variants)")
     ap.add_argument("--split-chunks", type=int, default=0, help="orb32: chunks a batch is split into over the two streams (0 = automatic)")
     ap.add_argument("--no-split", action="store_true", help="orb32: one stream, one chunk (per-kernel timelines)")
+    ap.add_argument("--small-path", type=int, default=None, choices=[0, 1, 2], help="orb32: small-batch kernels 0 = never, 1 = calls of <= 4 "
+                    "frames / pairs (library default), 2 = always (afv_set_small_batch_path)")
     ap.add_argument("--keyframes", type=int, default=1000, help="pairs10k: keyframes in the table")
     ap.add_argument("--jobs", type=int, default=10000, help="pairs10k: pair jobs per step (whole job, all GPUs)")
     ap.add_argument("--bcast-reps", type=int, default=3, help="pairs10k: repetitions of the table broadcast")
@@ -870,6 +874,8 @@ def main():
         ctx.set_split_chunks(args.split_chunks)
     if args.no_split:
         ctx.set_split_threshold(0x7fffffff)
+    if args.small_path is not None:
+        ctx.set_small_batch_path(args.small_path)
     afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
     matcher = afv.FeatureMatcher(0.6, True, ctx=ctx)
 

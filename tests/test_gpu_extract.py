@@ -25,6 +25,20 @@ def frames(afv):
     return _frames(afv)
 
 
+@pytest.fixture(scope="module", params=["auto", "batch-kernels", "small-batch-kernels"])
+def gpu_ctx(afv, request):
+    """every test of this module that takes the shared context runs three times: with the library's own choice (calls of <= 4 frames
+    take the small-batch kernels: one-launch pyramid, retainBest + Harris in one launch, 1024-thread quadtree), with the batch kernels
+    forced for every call, and with the small-batch kernels forced for every call (also the 5- and 6-frame batches)"""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ctx = afv.Context(max_width=1280, max_height=720, max_batch=8)
+    ctx.set_small_batch_path({"auto": 1, "batch-kernels": 0, "small-batch-kernels": 2}[request.param])
+    yield ctx
+    ctx.close()
+
+
 def _cand_sets(ctx, oracle_trace, level):
     x, y, s, r = ctx.debug_candidates(0, level)
     got = sorted(zip(y.tolist(), x.tolist(), s.tolist(), r.view(np.uint32).tolist()))

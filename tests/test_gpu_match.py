@@ -25,6 +25,16 @@ def _featvec(afv, seed, n, nnodes):
     return fv
 
 
+@pytest.fixture(params=["batch-kernels", "small-batch-kernels"])
+def pairs_path(gpu_ctx, request):
+    """the brute-force pair tests run twice: with the batch kernels, and with the small-batch kernels forced for every call (phase 1
+    dealt to column slices - one key record per row and slice, merged by the resolve kernel); the library's own choice (calls of <= 4
+    pairs take the small-batch kernels) is restored afterwards"""
+    gpu_ctx.set_small_batch_path(0 if request.param == "batch-kernels" else 2)
+    yield request.param
+    gpu_ctx.set_small_batch_path(1)
+
+
 @pytest.fixture(scope="module")
 def matcher(afv, gpu_ctx):
     afv.FeatureMatcher.setDescriptorDistanceThresholds({"FeatureMatcher.matchingTh": 75.0})
@@ -250,7 +260,7 @@ def test_akaze61_byte_hamming(afv, oracle, matcher):
     assert n == wn and np.array_equal(got, want) and wn > 50
 
 
-def test_device_pairs_match_extracted_frames(afv, oracle, matcher, gpu_ctx):
+def test_device_pairs_match_extracted_frames(afv, oracle, matcher, gpu_ctx, pairs_path):
     """bench shape: extract a batch on the device, match frame t against t-1 without leaving HBM"""
     import torch
     frames = np.stack([afv.synth.corners_frame(80 + i) for i in range(4)])
@@ -276,7 +286,7 @@ def test_device_pairs_match_extracted_frames(afv, oracle, matcher, gpu_ctx):
 
 
 @pytest.mark.parametrize("nproto,flips", [(40, 2), (8, 1), (200, 6)])
-def test_device_pairs_heavy_contention(afv, oracle, matcher, gpu_ctx, nproto, flips):
+def test_device_pairs_heavy_contention(afv, oracle, matcher, gpu_ctx, nproto, flips, pairs_path):
     """many rows compete for the same few columns: exercises the claim / replay logic of the ordered resolve and the
     exact-rescan path taken when a row's four best columns are all gone"""
     import torch
@@ -322,7 +332,7 @@ def test_device_pairs_heavy_contention(afv, oracle, matcher, gpu_ctx, nproto, fl
 
 
 @pytest.mark.parametrize("engine", [0, 1])
-def test_match_engines_on_ragged_sizes(afv, oracle, matcher, gpu_ctx, engine):
+def test_match_engines_on_ragged_sizes(afv, oracle, matcher, gpu_ctx, engine, pairs_path):
     """phase 1 on the vector ALU (popcount) and on the matrix cores (exact i8 contraction, 32 x 32 x 32 tiles, 64 train rows per LDS
     stage, 256 queries per workgroup): set sizes on every tile boundary, fewer than four columns, near-duplicate rows (distance
     ties are ordered by column).  Both engines must reproduce the oracle's match vector."""
@@ -366,7 +376,7 @@ def test_match_engines_on_ragged_sizes(afv, oracle, matcher, gpu_ctx, engine):
 
 
 @pytest.mark.parametrize("engine", [0, 1])
-def test_device_pairs_above_the_lds_limits(afv, oracle, matcher, gpu_ctx, engine):
+def test_device_pairs_above_the_lds_limits(afv, oracle, matcher, gpu_ctx, engine, pairs_path):
     """sets larger than 1024 rows: the resolve walk keeps only the first 1024 key records in LDS (the rest are read from global
     memory) and rescans through L2 instead of an LDS copy of the columns; clustered descriptors force rescans"""
     import torch

@@ -4,6 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 afv = importlib.import_module("anyfeature-vslam_amd")
 ctx = afv.Context()
+mode = int(sys.argv[1]) if len(sys.argv) > 1 else 1   # afv_set_small_batch_path: 0 = the batch kernels, 1 = library default
+ctx.set_small_batch_path(mode)
+print("small-batch path mode", mode)
 for name, img in (("corners", afv.synth.corners_frame(1)), ("toy", np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "toy_gray.npz"))["gray"])):
     t = torch.from_numpy(img[None]).cuda()
     for _ in range(5): ctx.extract_batch_device(t)
