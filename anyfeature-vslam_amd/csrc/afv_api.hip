@@ -218,29 +218,37 @@ static bool plan_pyr_fuse(const Geo &g, const short2 *tab, const size_t *tab_off
         off = align_up(off + bytes, 16);
         return (int)o;
     };
-    A.off_reg = take(2 * AFV_MAX_LEVELS * sizeof(short4));
-    size_t buf[2] = {0, 0}, hrow = 0;
+    size_t buf[2] = {0, 0};
     for (int l = 0; l < NL; ++l) {
         A.pitch[l] = (int)align_up((size_t)maxlen[0][l], 4);
-        A.lg_p[l] = l == 0 ? ceil_log2(A.pitch[l] / 4) + 1 : std::max(1, ceil_log2(A.pitch[l] / 2));
-        if (A.lg_p[l] > 10) return false;  // more column slots per row than the workgroup has threads
+        A.lg_q[l] = ceil_log2(A.pitch[l] / 4);
+        if (A.lg_q[l] > 10) return false;  // more dword slots per row than the workgroup has threads
         buf[l & 1] = std::max(buf[l & 1], (size_t)A.pitch[l] * maxlen[1][l]);
         if (l > 0) {
             A.tabx[l] = (int)tab_off_x[l];
             A.taby[l] = (int)tab_off_y[l];
             A.off_xt[l] = take((size_t)A.pitch[l] * sizeof(short2));
             A.off_yt[l] = take((size_t)maxlen[1][l] * sizeof(short2));
-            hrow = std::max(hrow, (size_t)maxlen[1][l - 1] * ((size_t)4 << A.lg_p[l]));
         }
     }
     A.off_buf[0] = take(buf[0]);
     A.off_buf[1] = take(buf[1]);
-    A.off_hrow = take(hrow);
     lds = off;
     return true;
 }
-static bool build_pyr_fuse(afv_ctx *c, const Geo &g, const short2 *tab, std::vector<short4> &reg, PyrFuseArgs &A, size_t &lds) {
-    return plan_pyr_fuse(g, tab, c->tab_off_x, c->tab_off_y, c->pf_tw, c->pf_th, reg, A, lds) && afv_pyramid_fused_prepare(lds) != 0;
+// the plan for the context's geometry; the top-level tile doubles until the region descriptors fit the kernel-argument block
+static bool build_pyr_fuse(afv_ctx *c, const Geo &g, const short2 *tab) {
+    std::vector<short4> reg;
+    for (int tw = c->pf_tw, th = c->pf_th; tw <= 256; tw *= 2, th *= 2) {
+        if (!plan_pyr_fuse(g, tab, c->tab_off_x, c->tab_off_y, tw, th, reg, c->pf, c->pf_lds)) return false;
+        if (reg.size() <= PF_MAX_REG) {
+            std::memset(&c->pf_reg, 0, sizeof(c->pf_reg));
+            std::memcpy(c->pf_reg.r, reg.data(), reg.size() * sizeof(short4));
+            c->pf.tab = c->d_tab;
+            return afv_pyramid_fused_prepare(c->pf_lds) != 0;
+        }
+    }
+    return false;
 }
 
 // host-only view of the plan and of the coefficient tables (no device needed): tests/test_host_logic.py replays the one-launch pyramid
@@ -278,7 +286,7 @@ extern "C" int afv_debug_pyramid_plan(const afv_orb_params *p, int width, int he
     for (int l = 0; l < AFV_MAX_LEVELS; ++l) info[k++] = g.lv[l].w;
     for (int l = 0; l < AFV_MAX_LEVELS; ++l) info[k++] = g.lv[l].h;
     for (int l = 0; l < AFV_MAX_LEVELS; ++l) info[k++] = A.pitch[l];
-    for (int l = 0; l < AFV_MAX_LEVELS; ++l) info[k++] = A.lg_p[l];
+    for (int l = 0; l < AFV_MAX_LEVELS; ++l) info[k++] = A.lg_q[l];
     for (int l = 0; l < AFV_MAX_LEVELS; ++l) info[k++] = A.tabx[l];
     for (int l = 0; l < AFV_MAX_LEVELS; ++l) info[k++] = A.taby[l];
     return AFV_OK;  // info: 4 + 6 * AFV_MAX_LEVELS ints
@@ -313,23 +321,7 @@ static int set_geometry(afv_ctx *c, int w, int h) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(c->d_tab, tab.data(), off * sizeof(short2), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_geo, &g, sizeof(Geo), hipMemcpyHostToDevice));
-    {   // the one-launch pyramid of the small-batch path
-        std::vector<short4> reg;
-        c->pf_ok = build_pyr_fuse(c, g, tab.data(), reg, c->pf, c->pf_lds);
-        if (c->pf_ok) {
-            if (reg.size() > c->pf_reg_cap) {
-                if (c->d_pf_reg) (void)hipFree(c->d_pf_reg);
-                c->d_pf_reg = nullptr;
-                c->pf_reg_cap = 0;
-                HIPCHK(c, hipMalloc(&c->d_pf_reg, reg.size() * sizeof(short4)));
-                c->pf_reg_cap = reg.size();
-            }
-            HIPCHK(c, hipMemcpy(c->d_pf_reg, reg.data(), reg.size() * sizeof(short4), hipMemcpyHostToDevice));
-            c->pf.tab = c->d_tab;
-            c->pf.rx = c->d_pf_reg;
-            c->pf.ry = c->d_pf_reg + (size_t)g.nlevels * c->pf.ntx;
-        }
-    }
+    c->pf_ok = build_pyr_fuse(c, g, tab.data());  // the one-launch pyramid of the small-batch path
     c->geo = g;
     c->geo_valid = true;
     return AFV_OK;
@@ -350,7 +342,7 @@ extern "C" void afv_destroy(afv_ctx *c) {
     afv_table_release_all(c);
     void *ptrs[] = {c->d_geo, c->d_tab, c->d_pyr, c->d_cand_packed, c->d_kept_xy, c->d_l1, c->d_l1_resp, c->d_l1_count, c->d_hq, c->d_hq_n, c->d_kept_resp,
                     c->d_kept_node, c->d_cand_count, c->d_sel_count, c->d_sel, c->d_frames, c->d_kps, c->d_desc,
-                    c->d_n, c->d_status, c->d_match, c->d_topk, c->d_pf_reg};
+                    c->d_n, c->d_status, c->d_match, c->d_topk, c->d_slice, c->d_tickets};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_stage) {
@@ -547,13 +539,15 @@ static bool small_batch_path(const afv_ctx *c, int nf) {
 }
 
 // kernels of one contiguous frame range [f0, f0 + nf) on stream s
+// clear_status: this range is the whole call, *d_status is cleared ahead of its kernels (by the one-launch pyramid when there is one)
 static void enqueue_range(afv_ctx *c, const FrameSrc &src, int f0, int nf, afv_keypoint *d_kps, uint8_t *d_desc, int cap, int *d_n,
-                          int *d_status, hipStream_t s) {
+                          int *d_status, hipStream_t s, bool clear_status = false) {
     const Geo &g = c->geo;
     {   // work lists are indexed with afv_udiv (exact below AFV_MAX_WORK items): longer ranges go out in pieces
         const int per = std::max(std::max(g.total_tiles, afv_describe_blocks_per_frame(&g)), 1);
         const int max_nf = std::max(1, (AFV_MAX_WORK - 8) / per);
         if (nf > max_nf) {
+            if (clear_status && d_status) (void)hipMemsetAsync(d_status, 0, sizeof(int), s);
             for (int b = 0; b < nf; b += max_nf) enqueue_range(c, src, f0 + b, std::min(max_nf, nf - b), d_kps, d_desc, cap, d_n, d_status, s);
             return;
         }
@@ -564,13 +558,15 @@ static void enqueue_range(afv_ctx *c, const FrameSrc &src, int f0, int nf, afv_k
         (void)hipMemsetAsync(c->d_hq_n + f0, 0, sizeof(int), s);
     }
     const bool small = small_batch_path(c, nf);
+    if (clear_status && d_status && !(small && c->pf_ok)) (void)hipMemsetAsync(d_status, 0, sizeof(int), s);
     if (small && c->pf_ok) {
         StageTimer t_(c, AFV_STAGE_PYRAMID, s, nf);
         PyrFuseArgs A = c->pf;
         A.zero_counts = cnt0;
         A.n_zero = nf * AFV_MAX_LEVELS;
         A.zero_one = c->d_hq_n + f0;
-        afv_launch_pyramid_fused(c->d_geo, &src, c->d_pyr, &A, c->pf_lds, f0, nf, s);
+        A.zero_two = clear_status ? d_status : nullptr;
+        afv_launch_pyramid_fused(c->d_geo, &src, c->d_pyr, &A, &c->pf_reg, c->pf_lds, f0, nf, s);
     } else {
         StageTimer t_(c, AFV_STAGE_PYRAMID, s, nf);
         for (int l = 1; l < g.nlevels; ++l) {
@@ -608,8 +604,8 @@ static void enqueue_range(afv_ctx *c, const FrameSrc &src, int f0, int nf, afv_k
 static int enqueue_extract(afv_ctx *c, const FrameSrc &src, int nframes, afv_keypoint *d_kps, uint8_t *d_desc, int cap,
                            int *d_n, int *d_status, hipStream_t s) {
     c->prof = c->prof_every && (c->prof_tick_extract++ % (unsigned)c->prof_every) == 0;
-    if (d_status) HIPCHK(c, hipMemsetAsync(d_status, 0, sizeof(int), s));
     if (nframes >= c->split_min_frames) {
+        if (d_status) HIPCHK(c, hipMemsetAsync(d_status, 0, sizeof(int), s));
         // two halves on two streams: the select / describe tail of one half overlaps the FAST kernel of the other
         HIPCHK(c, hipEventRecord(c->ev_fork, s));
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
@@ -624,7 +620,7 @@ static int enqueue_extract(afv_ctx *c, const FrameSrc &src, int nframes, afv_key
         HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0));
     } else {
-        enqueue_range(c, src, 0, nframes, d_kps, d_desc, cap, d_n, d_status, s);
+        enqueue_range(c, src, 0, nframes, d_kps, d_desc, cap, d_n, d_status, s, true);
     }
     HIPCHK(c, hipGetLastError());
     c->last_src = src;
@@ -724,8 +720,8 @@ extern "C" int afv_orb_extract_batch(afv_ctx *c, const uint8_t *const *frames, i
             if (!c->stream_copy) HIPCHK(c, hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
             s_copy = s_back = c->stream_copy;
         }
-        HIPCHK(c, hipMemsetAsync(c->d_status, 0, sizeof(int), c->stream));
         if (nchunks > 1) {
+            HIPCHK(c, hipMemsetAsync(c->d_status, 0, sizeof(int), c->stream));
             HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
             HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
             HIPCHK(c, hipStreamWaitEvent(s_copy, c->ev_fork, 0));  // earlier work of this context that still reads d_frames
@@ -770,7 +766,7 @@ extern "C" int afv_orb_extract_batch(afv_ctx *c, const uint8_t *const *frames, i
             // ---- compute ----
             hipStream_t cs = (k & 1) ? c->stream2 : c->stream;
             if (nchunks > 1) HIPCHK(c, hipStreamWaitEvent(cs, e_in, 0));
-            enqueue_range(c, src, f0, nf, c->d_kps, c->d_desc, c->stage_cap, c->d_n, c->d_status, cs);
+            enqueue_range(c, src, f0, nf, c->d_kps, c->d_desc, c->stage_cap, c->d_n, c->d_status, cs, nchunks == 1);
             // ---- D2H ----
             if (nchunks > 1) {
                 HIPCHK(c, hipEventRecord(e_done, cs));
@@ -1110,7 +1106,11 @@ static int afv_match_bow_impl(afv_ctx *c, const afv_match_job *jobs, int njobs, 
             }
             const size_t match_off = b.reserve((size_t)njobs * cap * 4), nm_off = b.reserve((size_t)njobs * 4);
             const int nslices = small_batch_path(c, njobs) ? afv_match_topk_slices(cap, c->match_engine, ((cap + 63) / 64 + 1) / 2) : 1;
-            const size_t topk_off = b.reserve_scratch((size_t)njobs * cap * 32 * nslices);
+            const size_t topk_off = b.reserve_scratch((size_t)njobs * cap * 32);
+            {
+                const int rc_ = ensure_slice_scratch(c, njobs, cap, nslices);
+                if (rc_) return rc_;
+            }
             int rc = ensure_match_buffer(c, b.h.size());
             if (rc) return rc;
             HIPCHK(c, hipMemcpyAsync(c->d_match, b.h.data(), match_off, hipMemcpyHostToDevice, c->stream));  // inputs only
@@ -1124,10 +1124,10 @@ static int afv_match_bow_impl(afv_ctx *c, const afv_match_job *jobs, int njobs, 
                 const float *angp = any_ori ? reinterpret_cast<const float *>(c->d_match + ang_off) : nullptr;
                 const int *np_ = reinterpret_cast<const int *>(c->d_match + n_off);
                 const int *pa_ = reinterpret_cast<const int *>(c->d_match + pa_off), *pb_ = reinterpret_cast<const int *>(c->d_match + pb_off);
-                afv_launch_match_topk(c->d_match + desc_off, np_, cap, pa_, pb_, i1 - i0, c->d_match + topk_off, i0, c->match_engine, nslices, c->stream);
+                afv_launch_match_topk(c->d_match + desc_off, np_, cap, pa_, pb_, i1 - i0, c->d_match + topk_off, i0, c->match_engine, nslices, c->d_slice, c->d_tickets, c->stream);
                 afv_launch_match_resolve(c->d_match + desc_off, angp, 1, np_, cap, pa_, pb_, i1 - i0, jobs[i0].th_low, jobs[i0].nnratio,
                                          jobs[i0].check_orientation != 0, reinterpret_cast<int *>(c->d_match + match_off),
-                                         reinterpret_cast<int *>(c->d_match + nm_off), c->d_match + topk_off, i0, nslices, c->stream);
+                                         reinterpret_cast<int *>(c->d_match + nm_off), c->d_match + topk_off, i0, c->stream);
                 i0 = i1;
             }
             HIPCHK(c, hipGetLastError());
@@ -1282,7 +1282,11 @@ int afv_match_pairs_core(afv_ctx *c, const uint8_t *d_desc, const float *d_ang, 
     // the small-batch path deals the column tiles of phase 1 to several workgroups per row tile (two 64-column tiles each): a single
     // pair then runs on 32 workgroups instead of 4, and the resolve kernel merges the slices' key records
     const int nslices = small_batch_path(c, npairs) ? afv_match_topk_slices(cap, c->match_engine, ((cap + 63) / 64 + 1) / 2) : 1;
-    const size_t need = (size_t)npairs * cap * 32 * nslices;  // one 2 x int4 key record per row (and slice)
+    {
+        const int rc = ensure_slice_scratch(c, npairs, cap, nslices);
+        if (rc) return rc;
+    }
+    const size_t need = (size_t)npairs * cap * 32;  // one 2 x int4 key record per row
     if (need > c->topk_bytes) {  // grow-only scratch (first call / larger batch): implies a device sync
         HIPCHK(c, hipDeviceSynchronize());
         if (c->d_topk) (void)hipFree(c->d_topk);
@@ -1303,22 +1307,22 @@ int afv_match_pairs_core(afv_ctx *c, const uint8_t *d_desc, const float *d_ang, 
             hipStream_t ks = (k & 1) ? c->stream2 : s;
             {
                 StageTimer t_(c, AFV_STAGE_MATCH, ks, e0 - b0);
-                afv_launch_match_topk(d_desc, d_n, cap, d_pair_a, d_pair_b, e0 - b0, c->d_topk, b0, c->match_engine, nslices, ks);
+                afv_launch_match_topk(d_desc, d_n, cap, d_pair_a, d_pair_b, e0 - b0, c->d_topk, b0, c->match_engine, nslices, c->d_slice, c->d_tickets, ks);
             }
             StageTimer t_(c, AFV_STAGE_MATCH_RESOLVE, ks, e0 - b0);
             afv_launch_match_resolve(d_desc, d_ang, ang_stride, d_n, cap, d_pair_a, d_pair_b, e0 - b0, th_low, nnratio, check_orientation,
-                                     d_match, d_nmatches, c->d_topk, b0, nslices, ks);
+                                     d_match, d_nmatches, c->d_topk, b0, ks);
         }
         HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0));
     } else {
         {
             StageTimer t_(c, AFV_STAGE_MATCH, s, npairs);
-            afv_launch_match_topk(d_desc, d_n, cap, d_pair_a, d_pair_b, npairs, c->d_topk, 0, c->match_engine, nslices, s);
+            afv_launch_match_topk(d_desc, d_n, cap, d_pair_a, d_pair_b, npairs, c->d_topk, 0, c->match_engine, nslices, c->d_slice, c->d_tickets, s);
         }
         StageTimer t_(c, AFV_STAGE_MATCH_RESOLVE, s, npairs);
         afv_launch_match_resolve(d_desc, d_ang, ang_stride, d_n, cap, d_pair_a, d_pair_b, npairs, th_low, nnratio, check_orientation, d_match,
-                                 d_nmatches, c->d_topk, 0, nslices, s);
+                                 d_nmatches, c->d_topk, 0, s);
     }
     HIPCHK(c, hipGetLastError());
     return AFV_OK;

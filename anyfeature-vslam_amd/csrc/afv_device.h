@@ -78,19 +78,22 @@ struct SelPoint {  // quadtree survivor, level coordinates
     float response;
 };
 
-// arguments of k_pyramid_fused (k_pyramid.hip: the whole pyramid of a frame in one launch); filled by afv_api.hip: build_pyr_fuse
+// arguments of k_pyramid_fused (k_pyramid.hip: the whole pyramid of a frame in one launch); filled by afv_api.hip: plan_pyr_fuse
+#define PF_MAX_REG 416  // region descriptors that ride in the kernel arguments: nlevels * (ntx + nty) <= PF_MAX_REG (3.3 KB of the 4 KB block)
+struct PyrFuseRegions {  // [nlevels][ntx] then [nlevels][nty]: (need.lo, need.hi inclusive, own.lo, own.hi exclusive) per tile index; level 0: the source window
+    short4 r[PF_MAX_REG];
+};
 struct PyrFuseArgs {
     const short2 *tab;          // resize tables of all levels (afv_ctx::d_tab)
-    const short4 *rx, *ry;      // [nlevels][ntx] / [nlevels][nty]: (need.lo, need.hi inclusive, own.lo, own.hi exclusive) per tile index; level 0: the source window
     int tabx[AFV_MAX_LEVELS], taby[AFV_MAX_LEVELS];  // element offset of level l's x / y table in `tab`
     int pitch[AFV_MAX_LEVELS];  // LDS row pitch of level l's region (bytes, multiple of 4; level 0 = the source window)
-    int lg_p[AFV_MAX_LEVELS];   // log2 of the column-PAIR slots per row of level l (power of two >= pitch / 2)
+    int lg_q[AFV_MAX_LEVELS];   // log2 of the DWORD slots per row of level l (power of two >= pitch / 4)
     int off_xt[AFV_MAX_LEVELS], off_yt[AFV_MAX_LEVELS];  // LDS byte offsets of the staged tables
-    int off_buf[2], off_hrow, off_reg;  // LDS byte offsets: region buffers (level parity), filtered rows, region descriptors
+    int off_buf[2];             // LDS byte offsets of the two region buffers (level parity)
     int nlevels, ntx, nty;
     int *zero_counts;           // as in ResizeTab: the candidate / queue counters of the frame range are cleared here
     int n_zero;
-    int *zero_one;
+    int *zero_one, *zero_two;
 };
 
 // XCD-aware block -> work-item mapping (cdna_hip_programming.md T1): hardware places linear block b on XCD b % 8, each

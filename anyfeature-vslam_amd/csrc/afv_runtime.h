@@ -20,8 +20,8 @@ extern "C" void afv_launch_resize(const uint8_t *src, int sw, int sh, int spitch
                                   int dpitch, size_t dframe, const short2 *xt, const short2 *yt, int frame_base, int nframes, int *zero_counts,
                                   int n_zero, int *zero_one, hipStream_t stream);
 extern "C" int afv_resize_window_ok(int sw, int sh, int dw, int dh);
-extern "C" void afv_launch_pyramid_fused(const Geo *geo_dev, const FrameSrc *src0, uint8_t *pyr, const PyrFuseArgs *args, size_t lds_bytes,
-                                         int frame_base, int nframes, hipStream_t stream);
+extern "C" void afv_launch_pyramid_fused(const Geo *geo_dev, const FrameSrc *src0, uint8_t *pyr, const PyrFuseArgs *args, const PyrFuseRegions *regions,
+                                         size_t lds_bytes, int frame_base, int nframes, hipStream_t stream);
 extern "C" int afv_pyramid_fused_prepare(size_t lds_bytes);
 extern "C" void afv_launch_fast_nms(const Geo *geo, int total_tiles, const FrameSrc *src0, const uint8_t *pyr, uint32_t *cand_packed,
                                     int *cand_count, int frame_base, int nframes, hipStream_t stream);
@@ -58,10 +58,11 @@ extern "C" void afv_launch_match_bow_seg(const DevMatchJob *jobs, int njobs, con
                                          const int *bin_off, int any_ori, hipStream_t stream);
 extern "C" int afv_match_topk_slices(int cap, int engine, int want);
 extern "C" void afv_launch_match_topk(const uint8_t *desc, const int *nset, int cap, const int *pa, const int *pb, int npairs,
-                                      void *topk_scratch, int pair_base, int engine, int nslices, hipStream_t stream);
+                                      void *topk_scratch, int pair_base, int engine, int nslices, void *slice_scratch, int *tickets,
+                                      hipStream_t stream);
 extern "C" void afv_launch_match_resolve(const uint8_t *desc, const float *ang, int ang_stride, const int *nset, int cap, const int *pa,
                                          const int *pb, int npairs, float th, float ratio, int check_ori, int *match, int *nmatches,
-                                         const void *topk_scratch, int pair_base, int nslices, hipStream_t stream);
+                                         const void *topk_scratch, int pair_base, hipStream_t stream);
 extern "C" void afv_launch_match_tri(const DevTriJob *jobs, int njobs, int max_n1, hipStream_t stream);
 extern "C" void afv_launch_match_l2(const float *d1, int n1, const float *d2, int n2, int dim, const uint8_t *v1,
                                     const uint8_t *v2, float th, float ratio, int *out, int *nmatches, hipStream_t stream);
@@ -120,8 +121,7 @@ struct afv_ctx {
     bool pf_ok = false;            // the current geometry has a one-launch pyramid (else: level-by-level launches)
     PyrFuseArgs pf{};
     size_t pf_lds = 0;
-    short4 *d_pf_reg = nullptr;    // region descriptors, [nlevels][ntx] then [nlevels][nty]
-    size_t pf_reg_cap = 0;
+    PyrFuseRegions pf_reg{};       // region descriptors, [nlevels][ntx] then [nlevels][nty] (ride in the kernel arguments)
     afv_orb_params p{};
     Geo geo{};          // current geometry (host copy)
     Geo cap_geo{};      // geometry of (max_width, max_height): sizes every allocation
@@ -158,6 +158,11 @@ struct afv_ctx {
     bool stage_pinned = false;
     void *d_topk = nullptr;  // [npairs][cap] 2 x int4: key record per row (seven (distance, column) keys + the exact-prefix length)
     size_t topk_bytes = 0;
+    // column-sliced phase 1 (small-batch path): per-slice records [npairs][cap][nslices] 2 x int4 and the row-tile tickets (zero at rest)
+    void *d_slice = nullptr;
+    size_t slice_bytes = 0;
+    int *d_tickets = nullptr;
+    size_t tickets_n = 0;
     // last extraction (debug getters)
     FrameSrc last_src{};
     int last_nframes = 0;
@@ -289,6 +294,29 @@ struct Blob {
         pending.clear();
     }
 };
+
+// scratch of a column-sliced phase 1 over `npairs` pairs (grow-only; growing implies a device sync, tickets are zeroed once)
+static inline int ensure_slice_scratch(afv_ctx *c, int npairs, int cap, int nslices) {
+    if (nslices <= 1) return AFV_OK;
+    const size_t need = (size_t)npairs * cap * 32 * nslices, nt = (size_t)npairs * ((cap + 255) / 256);
+    if (need > c->slice_bytes || nt > c->tickets_n) HIPCHK(c, hipDeviceSynchronize());
+    if (need > c->slice_bytes) {
+        if (c->d_slice) (void)hipFree(c->d_slice);
+        c->d_slice = nullptr;
+        c->slice_bytes = 0;
+        HIPCHK(c, hipMalloc(&c->d_slice, need));
+        c->slice_bytes = need;
+    }
+    if (nt > c->tickets_n) {
+        if (c->d_tickets) (void)hipFree(c->d_tickets);
+        c->d_tickets = nullptr;
+        c->tickets_n = 0;
+        HIPCHK(c, hipMalloc(&c->d_tickets, nt * sizeof(int)));
+        HIPCHK(c, hipMemset(c->d_tickets, 0, nt * sizeof(int)));
+        c->tickets_n = nt;
+    }
+    return AFV_OK;
+}
 
 static inline int ensure_match_buffer(afv_ctx *c, size_t bytes) {
     if (bytes <= c->match_bytes) return AFV_OK;

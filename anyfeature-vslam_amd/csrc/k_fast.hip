@@ -52,7 +52,13 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_BCAST31, 0xc, 0xf, false);
     return v;
 }
-#define RING_OFF(dx, dy) ((dy) * FT_LW + (dx))
+// LDS row pitch of the tile and of the score plane: the 72 staged bytes of a row, optionally padded (a build-time experiment for the bank
+// pattern of the scattered byte reads of stage 2b: tools/experiments.py, -DFT_PITCH=76 ...; must be a multiple of 4)
+#ifndef FT_PITCH
+#define FT_PITCH FT_LW
+#endif
+static_assert(FT_PITCH >= FT_LW && FT_PITCH % 4 == 0, "tile pitch");
+#define RING_OFF(dx, dy) ((dy) * FT_PITCH + (dx))
 #define PRE_ROWS (FT_H + 2)             // LDS rows 3 .. 36 (tile pixels -1 .. 32)
 #define PRE_PAIRS ((FT_W + 4) / 2)      // LDS columns 2 .. 69 as 34 pixel pairs at EVEN columns (aligned 16-bit LDS reads); columns
                                         // 2 and 69 are outside the ring-extended tile and masked out
@@ -110,8 +116,8 @@ __device__ __forceinline__ short2v fast_score2(const uint8_t *c0, const uint8_t 
 __global__ __launch_bounds__(256) void k_fast_nms(const Geo *__restrict__ geo_p, FrameSrc src0, const uint8_t *__restrict__ pyr,
                                                   uint32_t *__restrict__ cand_packed, int *__restrict__ cand_count, int total_blocks,
                                                   int frame_base) {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[(FT_LH + 1) * FT_LW + 16];  // + pad: masked pre-test positions (row 34, column 69) read up to one row + 2 bytes past row 39
-    __shared__ __attribute__((aligned(16))) uint8_t sc[FT_LH * FT_LW];  // same geometry as `tile`
+    __shared__ __attribute__((aligned(16))) uint8_t tile[(FT_LH + 1) * FT_PITCH + 16];  // + pad: masked pre-test positions (row 34, column 69) read up to one row + 2 bytes past row 39
+    __shared__ __attribute__((aligned(16))) uint8_t sc[FT_LH * FT_PITCH];  // same geometry as `tile`
     __shared__ __attribute__((aligned(4))) unsigned short pre[PRE_MAX];  // bright entries from the front, dark entries from the back
     __shared__ int list_n, out_base, pre_nb, pre_nd;
     uint32_t *list = reinterpret_cast<uint32_t *>(pre);  // NMS survivors (<= 512): reuses `pre`, which is dead after step 2b
@@ -184,8 +190,8 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Geo *__restrict__ geo_p,
             for (int k3 = 0; k3 < 3; ++k3) {
                 const int ry = rs + 14 * k3;
                 if (ry < FT_LH) {
-                    *reinterpret_cast<uint32_t *>(&tile[ry * FT_LW + rq * 4]) = v[k3];
-                    *reinterpret_cast<uint32_t *>(&sc[ry * FT_LW + rq * 4]) = 0u;
+                    *reinterpret_cast<uint32_t *>(&tile[ry * FT_PITCH + rq * 4]) = v[k3];
+                    *reinterpret_cast<uint32_t *>(&sc[ry * FT_PITCH + rq * 4]) = 0u;
                 }
             }
         }
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Geo *__restrict__ geo_p,
         if (rg < PRE_GROUPS) {
             short2v T0;
             T0.x = T0.y = (short)thr;
-            const uint8_t *c = &tile[(rg * PRE_ITERS + 3) * FT_LW + col];
+            const uint8_t *c = &tile[(rg * PRE_ITERS + 3) * FT_PITCH + col];
             // centre row: v and the ring pixels at dx = -3 / +3 sit at ODD distances, and an unaligned LDS read stalls the LDS pipe
             // (SQ_LDS_UNALIGNED_STALL).  So the row is read as the three ALIGNED dwords that hold bytes col-4 .. col+5 and the
             // three pairs are cut out with byte permutes whose selectors depend on col & 2 only (computed once per thread).
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Geo *__restrict__ geo_p,
             // reads one row past the tile into the padding) are computed like the others and masked out afterwards.
 #pragma unroll
             for (int it = 0; it < PRE_ITERS; ++it) {
-                const int o = it * FT_LW;
+                const int o = it * FT_PITCH;
                 const uint32_t w0 = cw[o / 4], w1 = cw[o / 4 + 1], w2 = cw[o / 4 + 2];
                 const short2v V = as_s2(__builtin_amdgcn_perm(w1, w0, sel_v));
                 const short2v a4 = as_s2(__builtin_amdgcn_perm(w2, w1, sel_a)), b4 = as_s2(__builtin_amdgcn_perm(w1, w0, sel_b));
@@ -263,13 +269,13 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Geo *__restrict__ geo_p,
         const int excl = incl - cnt;
         unsigned short *wb = pre + __shfl(base_b, 63, 64) + (excl & 0xffff);
         unsigned short *wd = pre + (PRE_MAX - 1) - (__shfl(base_d, 63, 64) + (excl >> 16));
-        const int p00 = (rg * PRE_ITERS + 3) * FT_LW + col;
+        const int p00 = (rg * PRE_ITERS + 3) * FT_PITCH + col;
 #pragma unroll
         for (int it = 0; it < PRE_ITERS; ++it) {
 #pragma unroll
             for (int px = 0; px < 2; ++px) {
                 const int pos = 16 * px + 16 - PRE_ITERS + it;
-                const unsigned short val = (unsigned short)(p00 + it * FT_LW + px);
+                const unsigned short val = (unsigned short)(p00 + it * FT_PITCH + px);
                 if ((bb >> pos) & 1u) *wb = val;
                 wb += (bb >> pos) & 1u;
                 if ((bd >> pos) & 1u) *wd = val;
@@ -316,16 +322,16 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Geo *__restrict__ geo_p,
     //    high halves; keep <=> own score > every neighbour (a zero score never is).  Keep flags -> one compaction per wavefront.
     {
         const int c = 4 + 2 * (tid & 31), rr = tid >> 5;
-        const uint8_t *q0 = &sc[(4 + rr) * FT_LW + c];
+        const uint8_t *q0 = &sc[(4 + rr) * FT_PITCH + c];
         uint32_t kb = 0;
 #pragma unroll
         for (int it = 0; it < FT_H / 8; ++it) {
-            const uint8_t *q = q0 + it * 8 * FT_LW;
+            const uint8_t *q = q0 + it * 8 * FT_PITCH;
             unsigned short top, mid, bot;
-            __builtin_memcpy(&top, q - FT_LW, 2);
+            __builtin_memcpy(&top, q - FT_PITCH, 2);
             __builtin_memcpy(&mid, q, 2);
-            __builtin_memcpy(&bot, q + FT_LW, 2);
-            const uint32_t tl = q[-FT_LW - 1], tr = q[-FT_LW + 2], ml = q[-1], mr = q[2], bl = q[FT_LW - 1], br = q[FT_LW + 2];
+            __builtin_memcpy(&bot, q + FT_PITCH, 2);
+            const uint32_t tl = q[-FT_PITCH - 1], tr = q[-FT_PITCH + 2], ml = q[-1], mr = q[2], bl = q[FT_PITCH - 1], br = q[FT_PITCH + 2];
 #define NMS_A(w, l) as_s2(__builtin_amdgcn_perm((uint32_t)(w), (l), 0x0c040c00u))  // (left, w.byte0)
 #define NMS_B(w) as_s2(__builtin_amdgcn_perm(0u, (uint32_t)(w), 0x0c010c00u))       // (w.byte0, w.byte1)
 #define NMS_C(w, r) as_s2(__builtin_amdgcn_perm((uint32_t)(w), (r), 0x0c000c05u))  // (w.byte1, right)
@@ -350,7 +356,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Geo *__restrict__ geo_p,
             const int qb = __builtin_ctz(kb);
             kb &= kb - 1;
             const int px = c - FT_HALO + (qb >> 4), py = rr + 8 * ((qb & 15) - (16 - FT_H / 8));
-            list[base++] = (uint32_t)px | ((uint32_t)py << 8) | ((uint32_t)sc[(py + FT_HALO) * FT_LW + px + FT_HALO] << 16);
+            list[base++] = (uint32_t)px | ((uint32_t)py << 8) | ((uint32_t)sc[(py + FT_HALO) * FT_PITCH + px + FT_HALO] << 16);
         }
     }
     __syncthreads();

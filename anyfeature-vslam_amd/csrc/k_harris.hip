@@ -265,33 +265,48 @@ __global__ __launch_bounds__(256) void k_harris(const Geo *__restrict__ geo_p, F
 // ---------------- retainBest + Harris in ONE launch (the small-batch path: one or a few frames) ----------------
 // k_retain_score + k_harris cost one frame 11 + 5 us plus a launch boundary: one workgroup per level walks a list of up to ~11 000
 // candidates in 36 dependent compaction steps, then a second kernel picks the survivors up from a queue.  Here a level is dealt to
-// RH_SLICES workgroups of 1024 threads.  Every one of them histograms the WHOLE level (44 KB out of L2, the loads of a thread in flight
-// together), derives the same threshold T1, counts the survivors in front of its slice (its output offset: deterministic, no
-// counter to clear), writes the survivors of its slice and computes their Harris responses - one lane per survivor, the same
-// harris_response as k_harris.  The last slice publishes the level's survivor count.
+// RH_SLICES workgroups of 1024 threads.  Every one of them reads the WHOLE level once (44 KB out of L2, a thread's <= 12 loads in
+// flight together, the values stay in registers), histograms it, derives the same threshold T1, counts the survivors in front of its
+// slice (its output offset: deterministic, no counter to clear), compacts the survivors of its slice in LDS and computes their Harris
+// responses - one lane per survivor, the same harris_response as k_harris.  The last slice publishes the level's survivor count.
+// Global round trips on the critical path: candidate count -> candidates -> Harris windows.
 #define RH_T 1024
 #define RH_SLICES 4
+#define RH_CPT 12     // candidates a thread keeps in registers (lists up to 12 288 entries; longer ones are re-read from memory)
+#define RH_SURV 3072  // survivors compacted per pass (= the slice of a 12 288-entry list)
 
-__global__ __launch_bounds__(RH_T) void k_retain_harris_small(const Geo *__restrict__ geo_p, FrameSrc src0, const uint8_t *__restrict__ pyr,
-                                                              const uint32_t *__restrict__ cand_packed, const int *__restrict__ cand_count,
-                                                              uint32_t *__restrict__ l1, int *__restrict__ l1_count, float *__restrict__ l1_resp,
-                                                              int frame_base, int total_blocks) {
+template <bool REG>
+__device__ __forceinline__ void retain_harris_small_body(const Geo &geo, const FrameSrc &src0, const uint8_t *__restrict__ pyr,
+                                                         const uint32_t *__restrict__ cp, int n, int l, int f, int slice, size_t base,
+                                                         uint32_t *__restrict__ l1, int *__restrict__ l1_count, float *__restrict__ l1_resp) {
     __shared__ int hist[4][256];  // four copies (lane & 3): FAST scores crowd a few bins just above the threshold
-    __shared__ int wsum[RH_T / 64];
+    __shared__ int wsum[4];
     __shared__ int s_T1, s_before, s_mine;
-    __shared__ uint32_t s_surv[RH_T];  // survivors of the current chunk of this workgroup's slice
-    const Geo &geo = *geo_p;
-    const int work = (int)blockIdx.x;
-    if (work >= total_blocks) return;
-    const int slice = work % RH_SLICES, fl = work / RH_SLICES;
-    const int l = fl % geo.nlevels, f = frame_base + fl / geo.nlevels;
+    __shared__ uint32_t s_surv[RH_SURV];
     const LevelGeo &L = geo.lv[l];
-    const size_t base = L.cand_off + (size_t)f * L.cand_frame_stride;
-    const uint32_t *cp = cand_packed + base;
-    const int n = min(cand_count[f * AFV_MAX_LEVELS + l], L.cand_cap);
     const int tid = threadIdx.x, lane = tid & 63;
     const int K = 2 * L.cv_quota;
     const int start = (int)((long)n * slice / RH_SLICES), end = (int)((long)n * (slice + 1) / RH_SLICES);
+    const int nk = (n + RH_T - 1) / RH_T;  // items per thread
+    uint32_t cpk[RH_CPT];
+    if (REG) {
+#pragma unroll
+        for (int k = 0; k < RH_CPT; ++k) cpk[k] = (k < nk && k * RH_T + tid < n) ? cp[k * RH_T + tid] : 0u;
+    }
+#define RH_FOR_ITEMS(BODY)                                            \
+    if (REG) {                                                        \
+        _Pragma("unroll") for (int k = 0; k < RH_CPT; ++k) {          \
+            const int i = k * RH_T + tid;                             \
+            const uint32_t e = cpk[k];                                \
+            if (k < nk) { BODY }                                      \
+        }                                                             \
+    } else {                                                          \
+        for (int k = 0; k < nk; ++k) {                                \
+            const int i = k * RH_T + tid;                             \
+            const uint32_t e = i < n ? cp[i] : 0u;                    \
+            { BODY }                                                  \
+        }                                                             \
+    }
     int T1 = 0;
     if (tid == 0) {
         s_before = 0;
@@ -301,8 +316,7 @@ __global__ __launch_bounds__(RH_T) void k_retain_harris_small(const Geo *__restr
         if (tid < 256) hist[0][tid] = hist[1][tid] = hist[2][tid] = hist[3][tid] = 0;
         if (tid == 0) s_T1 = 0;
         __syncthreads();
-#pragma unroll 4
-        for (int i = tid; i < n; i += RH_T) atomicAdd(&hist[lane & 3][cp[i] >> 24], 1);
+        RH_FOR_ITEMS(if (i < n) atomicAdd(&hist[lane & 3][e >> 24], 1);)
         __syncthreads();
         // thread t < 256 owns bin 255 - t: the threshold is the bin at which the count from the top reaches K
         int h = 0, incl = 0;
@@ -321,11 +335,9 @@ __global__ __launch_bounds__(RH_T) void k_retain_harris_small(const Geo *__restr
         T1 = s_T1;
     }
     __syncthreads();  // s_before / s_mine cleared
-    // survivors in front of the slice: this workgroup's first output slot
-    {
+    {   // survivors in front of the slice: this workgroup's first output slot
         int c = 0;
-#pragma unroll 4
-        for (int i = tid; i < start; i += RH_T) c += (int)(cp[i] >> 24) >= T1;
+        RH_FOR_ITEMS(c += (i < start && (int)(e >> 24) >= T1) ? 1 : 0;)
         c = afv_wave_incl_scan(c);
         if (lane == 63 && c) atomicAdd(&s_before, c);
     }
@@ -345,28 +357,47 @@ __global__ __launch_bounds__(RH_T) void k_retain_harris_small(const Geo *__restr
     it.cnt = 0;
     it.base = 0;
     it.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(it.img), 0, (it.lh - 1) * it.pitch + it.lw, 0x00027000);
-    for (int c0 = start; c0 < end; c0 += RH_T) {  // uniform trip count
-        const int i = c0 + tid;
-        const uint32_t e = i < end ? cp[i] : 0u;
-        const bool keep = i < end && (int)(e >> 24) >= T1;
-        const unsigned long long m = __ballot(keep);
-        int wbase = 0;
-        if (lane == 0 && m) wbase = atomicAdd(&s_mine, __popcll(m));
-        wbase = __shfl(wbase, 0, 64);
-        if (keep) s_surv[wbase + __popcll(m & ((1ull << lane) - 1ull))] = e;
+    for (int s0 = start; s0 < end; s0 += RH_SURV) {  // uniform trip count (one pass for lists that fit the registers)
+        const int s1 = min(s0 + RH_SURV, end);
+        RH_FOR_ITEMS(
+            if (k * RH_T < s1 && (k + 1) * RH_T > s0) {  // uniform
+                const bool keep = i >= s0 && i < s1 && (int)(e >> 24) >= T1;
+                const unsigned long long m = __ballot(keep);
+                int wbase = 0;
+                if (lane == 0 && m) wbase = atomicAdd(&s_mine, __popcll(m));
+                wbase = __shfl(wbase, 0, 64);
+                if (keep) s_surv[wbase + __popcll(m & ((1ull << lane) - 1ull))] = e;
+            })
         __syncthreads();
         const int cnt = s_mine;
-        if (tid < cnt) {
-            const uint32_t es = s_surv[tid];
-            l1[base + out_base + tid] = es;
-            l1_resp[base + out_base + tid] = harris_response(it, es, geo.harris_scale4);
+        for (int j = tid; j < cnt; j += RH_T) {
+            const uint32_t es = s_surv[j];
+            l1[base + out_base + j] = es;
+            l1_resp[base + out_base + j] = harris_response(it, es, geo.harris_scale4);
         }
         out_base += cnt;
         __syncthreads();
         if (tid == 0) s_mine = 0;
         __syncthreads();
     }
+#undef RH_FOR_ITEMS
     if (slice == RH_SLICES - 1 && tid == 0) l1_count[f * AFV_MAX_LEVELS + l] = out_base;
+}
+
+__global__ __launch_bounds__(RH_T) void k_retain_harris_small(const Geo *__restrict__ geo_p, FrameSrc src0, const uint8_t *__restrict__ pyr,
+                                                              const uint32_t *__restrict__ cand_packed, const int *__restrict__ cand_count,
+                                                              uint32_t *__restrict__ l1, int *__restrict__ l1_count, float *__restrict__ l1_resp,
+                                                              int frame_base, int total_blocks) {
+    const Geo &geo = *geo_p;
+    const int work = (int)blockIdx.x;
+    if (work >= total_blocks) return;
+    const int slice = work % RH_SLICES, fl = work / RH_SLICES;
+    const int l = fl % geo.nlevels, f = frame_base + fl / geo.nlevels;
+    const LevelGeo &L = geo.lv[l];
+    const size_t base = L.cand_off + (size_t)f * L.cand_frame_stride;
+    const int n = min(cand_count[f * AFV_MAX_LEVELS + l], L.cand_cap);
+    if (n <= RH_T * RH_CPT) retain_harris_small_body<true>(geo, src0, pyr, cand_packed + base, n, l, f, slice, base, l1, l1_count, l1_resp);
+    else retain_harris_small_body<false>(geo, src0, pyr, cand_packed + base, n, l, f, slice, base, l1, l1_count, l1_resp);
 }
 
 // queue capacity per frame: every level can hand over all its candidate slots

@@ -392,52 +392,6 @@ __global__ __launch_bounds__(MT) void k_match_topk(const uint8_t *__restrict__ d
 // CU: the ordered walk is one wavefront deep and latency-bound, what a batch costs is set by how many walks run at once)
 #define PAIR_COLS_LDS 1024  // sets up to this capacity also keep the column descriptors in LDS (exact rescans of the walk): 56 KB in all,
                             // below the 64 KB a launch may ask for without raising the function's dynamic-LDS limit
-// The key record of one row: seven keys (distance << 16 | column, ascending, NO_KEY padded) + nk, the number of leading keys that are
-// EXACTLY the row's nk nearest columns.  Phase 1 may have dealt the columns to `nslices` workgroups (k_match_topk_mfma, the
-// small-batch path): then the row has one record per slice, each over its own columns, and the row's record is their merge - the
-// seven smallest keys of the union, exact as far as the smallest of the slices' bounds (a slice's bound = its last exact key: every
-// column of the slice that is not among its exact keys lies beyond it; a slice whose list ends inside the exact prefix has no
-// other columns and no bound).  Same rule as the merge of the two lane halves inside k_match_topk_mfma.
-__device__ __forceinline__ void load_key_record(const int4 *__restrict__ tk, int row, int nslices, int4 &t4, int4 &t8) {
-    if (nslices == 1) {
-        t4 = tk[2 * row];
-        t8 = tk[2 * row + 1];
-        return;
-    }
-    int m[RKEYS];
-#pragma unroll
-    for (int q = 0; q < RKEYS; ++q) m[q] = NO_KEY;
-    int bound = NO_KEY;
-    for (int sl = 0; sl < nslices; ++sl) {
-        const int4 a = tk[((size_t)row * nslices + sl) * 2], b = tk[((size_t)row * nslices + sl) * 2 + 1];
-        const int k[RKEYS] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z};
-        const int nk = min(max(b.w, 1), RKEYS);
-        int last = k[0];
-        bool complete = false;
-#pragma unroll
-        for (int q = 0; q < RKEYS; ++q) {
-            last = q < nk ? k[q] : last;
-            complete = complete || (q < nk && k[q] == NO_KEY);
-        }
-        bound = min(bound, complete ? NO_KEY : last);
-#pragma unroll
-        for (int q = 0; q < RKEYS; ++q) {
-            const int key = k[q];
-            if (key < m[RKEYS - 1]) {  // sorted insert, the largest falls out
-#pragma unroll
-                for (int j = RKEYS - 1; j >= 1; --j) m[j] = max(min(m[j - 1], m[j]), min(max(m[j - 1], m[j]), key));  // med3(m[j-1], m[j], key)
-                m[0] = min(m[0], key);
-            }
-        }
-    }
-    int nk = 0;
-#pragma unroll
-    for (int q = 0; q < RKEYS; ++q) nk += (m[q] != NO_KEY && m[q] <= bound) ? 1 : 0;
-    if (bound == NO_KEY) nk = RKEYS;  // every slice complete: all columns are in the list, the NO_KEY slots end it
-    t4 = make_int4(m[0], m[1], m[2], m[3]);
-    t8 = make_int4(m[4], m[5], m[6], max(nk, 1));
-}
-
 static inline size_t resolve_lds_bytes(int cap, bool stage_cols) {
     const size_t c = ((size_t)cap + 63) & ~(size_t)63;
     return std::min<size_t>(c, PAIR_KEYS_LDS) * 32 /*key records*/ + c * 4 /*claim*/ + c * 4 /*matches*/ + c * 2 /*live*/ + c /*bin*/ + c / 8 /*matched*/ +
@@ -448,7 +402,7 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve(const uint8_t *__restri
                                                       const int *__restrict__ nset, int cap, const int *__restrict__ pair_a,
                                                       const int *__restrict__ pair_b, const int4 *__restrict__ topk, float th,
                                                       float ratio, int check_ori, int *__restrict__ match,
-                                                      int *__restrict__ nmatches, int pair_base, int stage_cols, int nslices) {
+                                                      int *__restrict__ nmatches, int pair_base, int stage_cols) {
     extern __shared__ __attribute__((aligned(16))) char s_dyn[];
     const int capr = (cap + 63) & ~63;
     int4 *s_keys = reinterpret_cast<int4 *>(s_dyn);  // key records (2 x int4) of the live rows (first PAIR_KEYS_LDS of them)
@@ -472,7 +426,7 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve(const uint8_t *__restri
 #endif
     const int a = pair_a[p], b = pair_b[p];
     const int n1 = min(nset[a], cap), n2 = min(nset[b], cap);
-    const int4 *tk = topk + (size_t)p * cap * 2 * nslices;
+    const int4 *tk = topk + (size_t)p * cap * 2;
     int *out = match + (size_t)p * cap;
     for (int i = tid; i < capr; i += MT) s_out[i] = -1;
     for (int i = tid; i < (n2 + 31) / 32; i += MT) s_matched[i] = 0;
@@ -484,7 +438,10 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve(const uint8_t *__restri
     for (int i0 = 0; i0 < n1; i0 += MT) {
         const int i = i0 + tid;
         int4 t4 = make_int4(NO_KEY, NO_KEY, NO_KEY, NO_KEY), t8 = make_int4(NO_KEY, NO_KEY, NO_KEY, TOPK);
-        if (i < n1) load_key_record(tk, i, nslices, t4, t8);
+        if (i < n1) {
+            t4 = tk[2 * i];
+            t8 = tk[2 * i + 1];
+        }
         const bool live = t4.x != NO_KEY && (float)(t4.x >> 16) < th;
         const unsigned long long m = __ballot(live);
         if (lane == 0) s_wave[wv] = __popcll(m);
@@ -552,12 +509,8 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve(const uint8_t *__restri
             const int row = act ? s_live[li] : 0;
             int4 t4 = make_int4(NO_KEY, NO_KEY, NO_KEY, NO_KEY), t8 = make_int4(NO_KEY, NO_KEY, NO_KEY, TOPK);
             if (act) {
-                if (li < PAIR_KEYS_LDS) {
-                    t4 = s_keys[2 * li];
-                    t8 = s_keys[2 * li + 1];
-                } else {
-                    load_key_record(tk, row, nslices, t4, t8);
-                }
+                t4 = li < PAIR_KEYS_LDS ? s_keys[2 * li] : tk[2 * row];
+                t8 = li < PAIR_KEYS_LDS ? s_keys[2 * li + 1] : tk[2 * row + 1];
             }
             // the first nk keys are the row's nk nearest columns EXACTLY (4 from the popcount engine; 4..7 from the matrix-core engine,
             // whose two lane halves each keep a top-4 over half of the columns: the merged list is exact up to the first half's 4th key)
@@ -919,17 +872,20 @@ extern "C" void afv_launch_match_bow_seg(const DevMatchJob *jobs, int njobs, con
 // phase 1 (VALU-bound: the 8 xor + 8 v_bcnt per descriptor pair) and phase 2 (latency-bound ordered resolve) are launched
 // separately so that the runtime can time them apart.
 extern "C" void afv_launch_match_topk_mfma(const uint8_t *desc, const int *nset, int cap, const int *pa, const int *pb, int npairs,
-                                           void *topk_scratch, int pair_base, int nslices, hipStream_t stream);
+                                           void *topk_scratch, int pair_base, int nslices, void *slice_scratch, void *tickets, hipStream_t stream);
 // engine: AFV_MATCH_ENGINE_MFMA (default: the exact i8 contraction of k_match_mfma.hip; its keys hold the column in 13 bits) or
 // AFV_MATCH_ENGINE_POPCOUNT (k_match_topk below).  Both write the same top-4 keys.
-// column slices of phase 1 (one key record per row AND slice): only the matrix-core engine deals its column tiles out
+// Column slices of phase 1 (the small-batch path; only the matrix-core engine deals its column tiles out).  A sliced launch needs, beside
+// the key records (2 x int4 per row), `slice_scratch` = 2 x int4 per row AND slice, and `tickets` = one int per pair and row tile of
+// 256 rows, ZERO before the first launch (the kernel re-arms them), both indexed by the global pair number like the records.
 extern "C" int afv_match_topk_slices(int cap, int engine, int want) {
     return (engine == AFV_MATCH_ENGINE_MFMA && cap < 8192) ? std::max(1, std::min(want, 16)) : 1;
 }
 extern "C" void afv_launch_match_topk(const uint8_t *desc, const int *nset, int cap, const int *pa, const int *pb, int npairs,
-                                      void *topk_scratch, int pair_base, int engine, int nslices, hipStream_t stream) {
+                                      void *topk_scratch, int pair_base, int engine, int nslices, void *slice_scratch, int *tickets,
+                                      hipStream_t stream) {
     if (engine == AFV_MATCH_ENGINE_MFMA && cap < 8192) {
-        afv_launch_match_topk_mfma(desc, nset, cap, pa, pb, npairs, topk_scratch, pair_base, nslices, stream);
+        afv_launch_match_topk_mfma(desc, nset, cap, pa, pb, npairs, topk_scratch, pair_base, nslices, slice_scratch, tickets, stream);
         return;
     }
     int4 *topk = reinterpret_cast<int4 *>(topk_scratch);
@@ -938,7 +894,7 @@ extern "C" void afv_launch_match_topk(const uint8_t *desc, const int *nset, int 
 // ang: keypoint angles in degrees, element (set, i) at ang[(set * cap + i) * ang_stride] (stride 7 = afv_keypoint::angle)
 extern "C" void afv_launch_match_resolve(const uint8_t *desc, const float *ang, int ang_stride, const int *nset, int cap, const int *pa,
                                          const int *pb, int npairs, float th, float ratio, int check_ori, int *match, int *nmatches,
-                                         const void *topk_scratch, int pair_base, int nslices, hipStream_t stream) {
+                                         const void *topk_scratch, int pair_base, hipStream_t stream) {
     const int4 *topk = reinterpret_cast<const int4 *>(topk_scratch);
     // the column descriptors ride in LDS (for the exact rescans) when they fit and the launch is a batch; a handful of pairs (the
     // single-frame plugin path) runs leaner: 39 KB instead of 71 KB, rescans through L2
@@ -954,7 +910,7 @@ extern "C" void afv_launch_match_resolve(const uint8_t *desc, const float *ang, 
         }
     }
     hipLaunchKernelGGL(k_match_resolve, dim3(npairs), dim3(MT), lds, stream, desc, ang, ang_stride, nset, cap, pa, pb, topk, th, ratio,
-                       check_ori, match, nmatches, pair_base, stage_cols ? 1 : 0, nslices);
+                       check_ori, match, nmatches, pair_base, stage_cols ? 1 : 0);
 }
 extern "C" void afv_launch_match_tri(const DevTriJob *jobs, int njobs, int max_n1, hipStream_t stream) {
     if (max_n1 > 0) hipLaunchKernelGGL(k_match_tri, dim3((max_n1 + MT - 1) / MT, njobs), dim3(MT), 0, stream, jobs);

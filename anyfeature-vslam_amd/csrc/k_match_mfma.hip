@@ -66,6 +66,31 @@ __device__ __forceinline__ void mq_stage(const uint32_t *__restrict__ train, int
     }
 }
 
+#define RKEYS 7  // key slots of a record (int4 x 2: seven keys + the exact-prefix length), as in k_match.hip
+// Column slices (nslices > 1): a row has one record per slice, each over its own columns; the row's record is their merge - the seven
+// smallest keys of the union, exact as far as the smallest of the slices' bounds (a slice's bound = its last exact key: every column
+// of the slice that is not among its exact keys lies beyond it; a slice whose list ends inside the exact prefix has no other columns
+// and no bound).  Same rule as the merge of the two lane halves at the end of the kernel.
+__device__ __forceinline__ void mq_merge_record(int (&m)[RKEYS], int &bound, const int4 a, const int4 b) {
+    const int k[RKEYS] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z};
+    const int nk = min(max(b.w, 1), RKEYS);
+    int last = k[0];
+    bool complete = false;
+#pragma unroll
+    for (int q = 0; q < RKEYS; ++q) {
+        last = q < nk ? k[q] : last;
+        complete = complete || (q < nk && k[q] == NO_KEY);
+    }
+    bound = min(bound, complete ? NO_KEY : last);
+#pragma unroll
+    for (int q = 0; q < RKEYS; ++q) {  // sorted insert, the largest falls out
+        const int key = k[q];
+#pragma unroll
+        for (int j = RKEYS - 1; j >= 1; --j) m[j] = mq_med3(m[j - 1], m[j], key);
+        m[0] = min(m[0], key);
+    }
+}
+
 template <bool PARTIAL>
 __device__ __forceinline__ void mq_compute(const uint8_t *buf, const v4i (&bq)[2][8], const v4i &bidx, int (&kk)[2][4], int tile_row0, int n2,
                                            int lane) {
@@ -95,15 +120,16 @@ __device__ __forceinline__ void mq_compute(const uint8_t *buf, const v4i (&bq)[2
 
 __global__ __launch_bounds__(MQ_T, 2) void k_match_topk_mfma(const uint8_t *__restrict__ desc, const int *__restrict__ nset, int cap,
                                                              const int *__restrict__ pair_a, const int *__restrict__ pair_b,
-                                                             int4 *__restrict__ topk, int pair_base, int nslices) {
+                                                             int4 *__restrict__ topk, int pair_base, int nslices, int4 *__restrict__ slice_rec,
+                                                             int *__restrict__ tickets) {
     __shared__ __attribute__((aligned(16))) uint2 s_lut[256];
     __shared__ __attribute__((aligned(16))) uint8_t s_a[2][T_TILE * A_PITCH];
     const int p = pair_base + blockIdx.y;
     const int sa = pair_a[p], sb = pair_b[p];
     const int n1 = min(nset[sa], cap), n2 = min(nset[sb], cap);
     // nslices > 1 (one or a few pairs, the per-frame plugin call): the 64-column tiles of the train set are dealt to `nslices`
-    // workgroups per row tile; every slice writes its own record per row, k_match_resolve merges them (records of disjoint column
-    // sets merge exactly like the two lane halves below)
+    // workgroups per row tile; every slice writes its own record per row, and the workgroup that finishes LAST for a row tile (a
+    // ticket per pair and row tile) merges them into the record k_match_resolve reads
     const int rt = (int)blockIdx.x / nslices, slice = (int)blockIdx.x - rt * nslices;
     if (rt * MQ_T >= n1) return;  // uniform
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -187,16 +213,61 @@ __global__ __launch_bounds__(MQ_T, 2) void k_match_topk_mfma(const uint8_t *__re
                 const int D = m[i] + (1 << 20);
                 s[i] = m[i] == NO_KEY ? NO_KEY : (((D >> 13) << 16) | (D & 8191));
             }
-            int4 *rec = topk + (((size_t)p * cap + row) * nslices + slice) * 2;
+            int4 *rec = nslices > 1 ? slice_rec + (((size_t)p * cap + row) * nslices + slice) * 2 : topk + ((size_t)p * cap + row) * 2;
             rec[0] = make_int4(s[0], s[1], s[2], s[3]);
             rec[1] = make_int4(s[4], s[5], s[6], max(nk, 1));
         }
     }
+    if (nslices == 1) return;
+    // ---- the last workgroup of the row tile merges the slices (cdna_hip_programming.md Guideline 16: every wave's stores drained by
+    // the barrier -> ONE lane: agent-scope release, ticket; the last arriver: ONE agent-scope acquire -> barrier -> plain loads) ----
+    __shared__ int s_last;
+    __syncthreads();
+    if (tid == 0) {
+        int *tk = tickets + (size_t)p * gridDim.x / nslices + rt;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // restated where the compiler cannot drop it (ROCm 7.2)
+        const int old = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == nslices - 1;
+        if (last) {
+            __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch over this scratch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const int row = rt * MQ_T + tid;
+    if (row >= n1) return;
+    int m[RKEYS];
+#pragma unroll
+    for (int q = 0; q < RKEYS; ++q) m[q] = NO_KEY;
+    int bound = NO_KEY;
+    const int4 *rp = slice_rec + ((size_t)p * cap + row) * nslices * 2;
+    for (int s0 = 0; s0 < nslices; s0 += 4) {  // four slices per step: their eight 16-byte loads are in flight together
+        int4 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int sl = min(s0 + u, nslices - 1);
+            a[u] = rp[2 * sl];
+            b[u] = rp[2 * sl + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (s0 + u < nslices) mq_merge_record(m, bound, a[u], b[u]);
+    }
+    int nk = 0;
+#pragma unroll
+    for (int q = 0; q < RKEYS; ++q) nk += (m[q] != NO_KEY && m[q] <= bound) ? 1 : 0;
+    if (bound == NO_KEY) nk = RKEYS;  // every slice complete: all columns are in the list, the NO_KEY slots end it
+    int4 *rec = topk + ((size_t)p * cap + row) * 2;
+    rec[0] = make_int4(m[0], m[1], m[2], m[3]);
+    rec[1] = make_int4(m[4], m[5], m[6], max(nk, 1));
 }
 
 extern "C" void afv_launch_match_topk_mfma(const uint8_t *desc, const int *nset, int cap, const int *pa, const int *pb, int npairs,
-                                           void *topk_scratch, int pair_base, int nslices, hipStream_t stream) {
+                                           void *topk_scratch, int pair_base, int nslices, void *slice_scratch, void *tickets, hipStream_t stream) {
     int4 *topk = reinterpret_cast<int4 *>(topk_scratch);
     hipLaunchKernelGGL(k_match_topk_mfma, dim3((cap + MQ_T - 1) / MQ_T * nslices, npairs), dim3(MQ_T), 0, stream, desc, nset, cap, pa, pb, topk,
-                       pair_base, nslices);
+                       pair_base, nslices, reinterpret_cast<int4 *>(slice_scratch), reinterpret_cast<int *>(tickets));
 }

@@ -197,18 +197,25 @@ extern "C" void afv_launch_resize(const uint8_t *src, int sw, int sh, int spitch
 // partitioned into OWNED rectangles (own_l(t) = [off_(l+1)[own_(l+1)(t).lo], off_(l+1)[own_(l+1)(t + 1).lo)): monotone tables make
 // them a disjoint cover) and a workgroup stores exactly its rectangle, widened to whole dwords - two workgroups may store the same
 // dword, with the same bytes.  Region bookkeeping (per level and tile index: needed range, owned range) is host work, done once per
-// geometry (afv_api.hip: build_pyr_fuse).
+// geometry (afv_api.hip: plan_pyr_fuse) and handed over IN THE KERNEL ARGUMENTS: the region descriptors arrive by scalar loads, so the
+// kernel's only global round trip is the one that fetches its level-0 window and its slices of the coefficient tables.
+// Latency shape: one barrier per level.  A thread owns four consecutive columns (their x coefficients stay in registers for the
+// level) and walks down the rows; an output dword is evaluated directly from its 2 x 8 source bytes (horizontal blend of the two source
+// rows on packed column pairs, vertical blend by v_dot2 - the separable form of k_resize_level would save a third of the LDS reads
+// and cost a second barrier and two more dependent LDS round trips per level).
 
 #define PF_T 1024
 
 __global__ __launch_bounds__(PF_T) void k_pyramid_fused(const Geo *__restrict__ geo_p, FrameSrc src0, uint8_t *__restrict__ pyr, PyrFuseArgs A,
-                                                        int frame_base, int total_blocks) {
+                                                        PyrFuseRegions R, int frame_base, int total_blocks) {
     extern __shared__ __attribute__((aligned(16))) uint8_t pf_smem[];
     const Geo &geo = *geo_p;
     const int tid = threadIdx.x;
-    if (A.zero_counts && blockIdx.x == 0) {
-        for (int i = tid; i < A.n_zero; i += PF_T) A.zero_counts[i] = 0;
+    if (blockIdx.x == 0) {
+        if (A.zero_counts)
+            for (int i = tid; i < A.n_zero; i += PF_T) A.zero_counts[i] = 0;
         if (tid == 0 && A.zero_one) *A.zero_one = 0;
+        if (tid == 1 && A.zero_two) *A.zero_two = 0;
     }
     const int work = afv_xcd_remap(blockIdx.x, total_blocks);  // a frame's tiles share level-0 cache lines: keep them on one XCD
     if (work >= total_blocks) return;
@@ -216,14 +223,10 @@ __global__ __launch_bounds__(PF_T) void k_pyramid_fused(const Geo *__restrict__ 
     const int fl = work / per_frame, t = work - fl * per_frame, ty = t / A.ntx, tx = t - ty * A.ntx;
     const int f = frame_base + fl;
     const int NL = A.nlevels;
-    short4 *s_rx = reinterpret_cast<short4 *>(pf_smem + A.off_reg), *s_ry = s_rx + AFV_MAX_LEVELS;
-    if (tid < NL) s_rx[tid] = A.rx[tid * A.ntx + tx];
-    else if (tid >= 64 && tid < 64 + NL) s_ry[tid - 64] = A.ry[(tid - 64) * A.nty + ty];
-    __syncthreads();
-    // stage every level's slice of the coefficient tables (offsets relative to the source region) and the level-0 window: all
-    // global loads of the kernel are issued here, behind one round trip for the region descriptors
+    const short4 *Rx = R.r + tx, *Ry = R.r + NL * A.ntx + ty;  // level l: Rx[l * ntx], Ry[l * nty] (uniform: scalar loads from the argument block)
+    // stage every level's slice of the coefficient tables (offsets relative to the source region) and the level-0 window
     for (int l = 1; l < NL; ++l) {
-        const short4 rx = s_rx[l], rxp = s_rx[l - 1], ry = s_ry[l], ryp = s_ry[l - 1];
+        const short4 rx = Rx[l * A.ntx], rxp = Rx[(l - 1) * A.ntx], ry = Ry[l * A.nty], ryp = Ry[(l - 1) * A.nty];
         const int lw = geo.lv[l].w;
         short2 *xt = reinterpret_cast<short2 *>(pf_smem + A.off_xt[l]), *yt = reinterpret_cast<short2 *>(pf_smem + A.off_yt[l]);
         const int nxe = rx.y - rx.x + 1, nye = ry.y - ry.x + 1;
@@ -245,10 +248,10 @@ __global__ __launch_bounds__(PF_T) void k_pyramid_fused(const Geo *__restrict__ 
         }
     }
     {
-        const short4 rx = s_rx[0], ry = s_ry[0];
+        const short4 rx = Rx[0], ry = Ry[0];
         const uint8_t *img = src0.base + (size_t)f * src0.frame_stride;
         uint8_t *S = pf_smem + A.off_buf[0];
-        const int sp = A.pitch[0], lg = A.lg_p[0] - 1;  // dword slots per row = pair slots / 2
+        const int sp = A.pitch[0], lg = A.lg_q[0];
         const int ndw = (rx.y - rx.x + 4) >> 2, nrows = ry.y - ry.x + 1, w0 = geo.width;
         const int q = tid & ((1 << lg) - 1);
         if (q < ndw) {
@@ -270,75 +273,64 @@ __global__ __launch_bounds__(PF_T) void k_pyramid_fused(const Geo *__restrict__ 
     }
     __syncthreads();
     for (int l = 1; l < NL; ++l) {
-        const short4 rx = s_rx[l], ry = s_ry[l], rxp = s_rx[l - 1], ryp = s_ry[l - 1];
+        const short4 rx = Rx[l * A.ntx], ry = Ry[l * A.nty], rxp = Rx[(l - 1) * A.ntx], ryp = Ry[(l - 1) * A.nty];
         const uint8_t *S = pf_smem + A.off_buf[(l - 1) & 1];
         uint8_t *D = pf_smem + A.off_buf[l & 1];
-        uint32_t *hrow = reinterpret_cast<uint32_t *>(pf_smem + A.off_hrow);
         const short2 *xt = reinterpret_cast<const short2 *>(pf_smem + A.off_xt[l]), *yt = reinterpret_cast<const short2 *>(pf_smem + A.off_yt[l]);
-        const int sp = A.pitch[l - 1], dp = A.pitch[l], lgp = A.lg_p[l];
+        const int sp = A.pitch[l - 1], dp = A.pitch[l], lgq = A.lg_q[l];
         const int sw = rxp.y - rxp.x + 1, sh = ryp.y - ryp.x + 1;  // source region
         const int dwp = rx.y - rx.x + 1, dh = ry.y - ry.x + 1;     // this level's region (width a multiple of 4)
-        // ---- horizontal pass over every source row: thread = column pair (fixed) x row group ----
-        {
-            const int cp = tid & ((1 << lgp) - 1);
-            if (2 * cp < dwp) {
-                const short2 xa = xt[2 * cp], xb = xt[2 * cp + 1];
-                const int a0 = xa.x, a1 = min(xa.x + 1, sw - 1), b0 = xb.x, b1 = min(xb.x + 1, sw - 1);
-                ushort2r WR, WL;
-                WR.x = (unsigned short)xa.y;
-                WR.y = (unsigned short)xb.y;
-                WL.x = (unsigned short)(256 - xa.y);
-                WL.y = (unsigned short)(256 - xb.y);
-#pragma unroll 2
-                for (int r = tid >> lgp; r < sh; r += PF_T >> lgp) {
-                    const uint8_t *row = S + r * sp;
-                    ushort2r Lv, Rv;
-                    Lv.x = row[a0];
-                    Lv.y = row[b0];
-                    Rv.x = row[a1];
-                    Rv.y = row[b1];
-                    const ushort2r hv = WL * Lv + WR * Rv;
-                    hrow[(r << lgp) + cp] = __builtin_bit_cast(uint32_t, hv);
-                }
-            }
-        }
-        __syncthreads();
-        // ---- vertical pass: thread = 4 consecutive columns (fixed) x row group; the owned rectangle also goes to memory ----
-        {
-            const int lgq = lgp - 1, cq = tid & ((1 << lgq) - 1);
-            if (4 * cq < dwp) {
-                const LevelGeo &Lg = geo.lv[l];
-                uint8_t *dst = pyr + Lg.pyr_off + (size_t)f * Lg.pyr_frame_stride;
-                const int gx = rx.x + 4 * cq;
-                const bool own_x = gx >= (rx.z & ~3) && gx < rx.w;  // owned columns [own.lo & ~3, align4(own.hi)): whole dwords
-                for (int y = tid >> lgq; y < dh; y += PF_T >> lgq) {
-                    const short2 e = yt[y];
-                    const uint32_t *h0 = hrow + (e.x << lgp) + 2 * cq, *h1 = hrow + (min(e.x + 1, sh - 1) << lgp) + 2 * cq;
-                    ushort2r WY;
-                    WY.x = (unsigned short)(256 - e.y);
-                    WY.y = (unsigned short)e.y;
-                    const uint2 u = *reinterpret_cast<const uint2 *>(h0), lo = *reinterpret_cast<const uint2 *>(h1);
-                    const ushort2r p0 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(lo.x, u.x, 0x05040100u));
-                    const ushort2r p1 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(lo.x, u.x, 0x07060302u));
-                    const ushort2r p2 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(lo.y, u.y, 0x05040100u));
-                    const ushort2r p3 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(lo.y, u.y, 0x07060302u));
-                    const uint32_t o0 = __builtin_amdgcn_udot2(p0, WY, 32768u, false) >> 16, o1 = __builtin_amdgcn_udot2(p1, WY, 32768u, false) >> 16;
-                    const uint32_t o2 = __builtin_amdgcn_udot2(p2, WY, 32768u, false) >> 16, o3 = __builtin_amdgcn_udot2(p3, WY, 32768u, false) >> 16;
-                    const uint32_t o = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
-                    *reinterpret_cast<uint32_t *>(D + y * dp + 4 * cq) = o;
-                    const int gy = ry.x + y;
-                    if (own_x && gy >= ry.z && gy < ry.w) *reinterpret_cast<uint32_t *>(dst + (size_t)gy * Lg.pitch + gx) = o;
-                }
+        const int cq = tid & ((1 << lgq) - 1);
+        if (4 * cq < dwp) {
+            const LevelGeo &Lg = geo.lv[l];
+            uint8_t *dst = pyr + Lg.pyr_off + (size_t)f * Lg.pyr_frame_stride;
+            const int gx = rx.x + 4 * cq;
+            const bool own_x = gx >= (rx.z & ~3) && gx < rx.w;  // owned columns [own.lo & ~3, align4(own.hi)): whole dwords
+            const uint2 xe = *reinterpret_cast<const uint2 *>(xt + 4 * cq), xf = *reinterpret_cast<const uint2 *>(xt + 4 * cq + 2);  // 4 x (offset, weight)
+            const int o0 = (short)(xe.x & 0xffffu), o1 = (short)(xe.y & 0xffffu), o2 = (short)(xf.x & 0xffffu), o3 = (short)(xf.y & 0xffffu);
+            const int r0 = min(o0 + 1, sw - 1), r1 = min(o1 + 1, sw - 1), r2 = min(o2 + 1, sw - 1), r3 = min(o3 + 1, sw - 1);
+            ushort2r WR01, WL01, WR23, WL23;
+            WR01.x = (unsigned short)(xe.x >> 16);
+            WR01.y = (unsigned short)(xe.y >> 16);
+            WR23.x = (unsigned short)(xf.x >> 16);
+            WR23.y = (unsigned short)(xf.y >> 16);
+            WL01.x = (unsigned short)(256 - WR01.x);
+            WL01.y = (unsigned short)(256 - WR01.y);
+            WL23.x = (unsigned short)(256 - WR23.x);
+            WL23.y = (unsigned short)(256 - WR23.y);
+            for (int y = tid >> lgq; y < dh; y += PF_T >> lgq) {
+                const short2 e = yt[y];
+                const uint8_t *ru = S + e.x * sp, *rl = S + min(e.x + 1, sh - 1) * sp;
+                ushort2r Lu01, Ru01, Lu23, Ru23, Ll01, Rl01, Ll23, Rl23;
+                Lu01.x = ru[o0]; Lu01.y = ru[o1]; Ru01.x = ru[r0]; Ru01.y = ru[r1];
+                Lu23.x = ru[o2]; Lu23.y = ru[o3]; Ru23.x = ru[r2]; Ru23.y = ru[r3];
+                Ll01.x = rl[o0]; Ll01.y = rl[o1]; Rl01.x = rl[r0]; Rl01.y = rl[r1];
+                Ll23.x = rl[o2]; Ll23.y = rl[o3]; Rl23.x = rl[r2]; Rl23.y = rl[r3];
+                const uint32_t u01 = __builtin_bit_cast(uint32_t, (ushort2r)(WL01 * Lu01 + WR01 * Ru01)), u23 = __builtin_bit_cast(uint32_t, (ushort2r)(WL23 * Lu23 + WR23 * Ru23));
+                const uint32_t l01 = __builtin_bit_cast(uint32_t, (ushort2r)(WL01 * Ll01 + WR01 * Rl01)), l23 = __builtin_bit_cast(uint32_t, (ushort2r)(WL23 * Ll23 + WR23 * Rl23));
+                ushort2r WY;
+                WY.x = (unsigned short)(256 - e.y);
+                WY.y = (unsigned short)e.y;
+                const ushort2r p0 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(l01, u01, 0x05040100u));
+                const ushort2r p1 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(l01, u01, 0x07060302u));
+                const ushort2r p2 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(l23, u23, 0x05040100u));
+                const ushort2r p3 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(l23, u23, 0x07060302u));
+                const uint32_t q0 = __builtin_amdgcn_udot2(p0, WY, 32768u, false) >> 16, q1 = __builtin_amdgcn_udot2(p1, WY, 32768u, false) >> 16;
+                const uint32_t q2 = __builtin_amdgcn_udot2(p2, WY, 32768u, false) >> 16, q3 = __builtin_amdgcn_udot2(p3, WY, 32768u, false) >> 16;
+                const uint32_t o = q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
+                *reinterpret_cast<uint32_t *>(D + y * dp + 4 * cq) = o;
+                const int gy = ry.x + y;
+                if (own_x && gy >= ry.z && gy < ry.w) *reinterpret_cast<uint32_t *>(dst + (size_t)gy * Lg.pitch + gx) = o;
             }
         }
         __syncthreads();
     }
 }
 
-extern "C" void afv_launch_pyramid_fused(const Geo *geo_dev, const FrameSrc *src0, uint8_t *pyr, const PyrFuseArgs *args, size_t lds_bytes,
-                                         int frame_base, int nframes, hipStream_t stream) {
+extern "C" void afv_launch_pyramid_fused(const Geo *geo_dev, const FrameSrc *src0, uint8_t *pyr, const PyrFuseArgs *args, const PyrFuseRegions *regions,
+                                         size_t lds_bytes, int frame_base, int nframes, hipStream_t stream) {
     const int total = args->ntx * args->nty * nframes;
-    hipLaunchKernelGGL(k_pyramid_fused, dim3((total + 7) / 8 * 8), dim3(PF_T), lds_bytes, stream, geo_dev, *src0, pyr, *args, frame_base, total);
+    hipLaunchKernelGGL(k_pyramid_fused, dim3((total + 7) / 8 * 8), dim3(PF_T), lds_bytes, stream, geo_dev, *src0, pyr, *args, *regions, frame_base, total);
 }
 
 extern "C" int afv_pyramid_fused_prepare(size_t lds_bytes) {

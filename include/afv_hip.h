@@ -374,7 +374,7 @@ int afv_debug_blur_level(afv_ctx *ctx, int frame, int level, uint8_t *out);
 /* host-only (no device, no context): the work plan of the one-launch pyramid for a geometry - per level and per tile index of the top
  * level the (need.lo, need.hi, own.lo, own.hi) ranges in x (first [nlevels][ntx] quadruples) and y ([nlevels][nty]), the resize
  * coefficient tables (pairs (source offset, weight of the right tap) per level: x then y, levels 1..) and, in info[4 + 6 * 8]:
- * nlevels, ntx, nty, LDS bytes, then per level w, h, LDS pitch, log2 pair slots, x-table offset, y-table offset (in pairs).
+ * nlevels, ntx, nty, LDS bytes, then per level w, h, LDS pitch, log2 dword slots per row, x-table offset, y-table offset (in pairs).
  * tests/test_host_logic.py replays the kernel's data flow on the CPU from exactly these numbers. */
 int afv_debug_pyramid_plan(const afv_orb_params *params, int width, int height, int tile_w, int tile_h, int16_t *regions,
                            int regions_cap, int32_t *info, int16_t *tables, int tables_cap);

@@ -155,7 +155,7 @@ def _pyramid_plan(afv, w, h, nlevels, sf, tw, th):
     rx = regions[:nl * ntx * 4].reshape(nl, ntx, 4).astype(int)
     ry = regions[nl * ntx * 4:nl * (ntx + nty) * 4].reshape(nl, nty, 4).astype(int)
     tab = tables.reshape(-1, 2).astype(int)
-    return dict(nl=nl, ntx=ntx, nty=nty, lds=lds, w=f[0], h=f[1], pitch=f[2], lg_p=f[3], tabx=f[4], taby=f[5], rx=rx, ry=ry, tab=tab)
+    return dict(nl=nl, ntx=ntx, nty=nty, lds=lds, w=f[0], h=f[1], pitch=f[2], lg_q=f[3], tabx=f[4], taby=f[5], rx=rx, ry=ry, tab=tab)
 
 
 def _replay_fused_pyramid(P, img):
@@ -173,7 +173,7 @@ def _replay_fused_pyramid(P, img):
             for l in range(1, nl):
                 rx, ry = P["rx"][l, tx], P["ry"][l, ty]
                 dwp, dh = rx[1] - rx[0] + 1, ry[1] - ry[0] + 1
-                assert dwp % 4 == 0 and rx[0] % 4 == 0 and dwp <= P["pitch"][l] and dwp // 2 <= (1 << P["lg_p"][l])
+                assert dwp % 4 == 0 and rx[0] % 4 == 0 and dwp <= P["pitch"][l] and dwp // 4 <= (1 << P["lg_q"][l])
                 sw, sh = prev_x[1] - prev_x[0] + 1, S.shape[0]
                 X = rx[0] + np.arange(dwp)
                 inside = X < P["w"][l]
