@@ -65,6 +65,11 @@ class TableTriJob(C.Structure):
                 ("th_low", C.c_float)]
 
 
+class FrameView(C.Structure):
+    _fields_ = [("desc32", C.c_void_p), ("n", C.c_int32), ("angle", C.c_void_p), ("node_id", C.c_void_p), ("seg_ptr", C.c_void_p),
+                ("seg_idx", C.c_void_p), ("nnodes", C.c_int32)]
+
+
 class ProjJob(C.Structure):
     _fields_ = [("desc", C.c_void_p), ("n", C.c_int32), ("desc_bytes", C.c_int32),
                 ("x", C.c_void_p), ("y", C.c_void_p), ("size", C.c_void_p), ("angle", C.c_void_p), ("occupied", C.c_void_p),
@@ -105,6 +110,7 @@ SYMBOLS = {
     "afv_table_match_pairs_device": (_i, [_vp, _vp, _vp, _i, _f, _f, _i, _vp, _vp, _vp]),
     "afv_table_match_bow": (_i, [_vp, _vp, _vp, _i, _f, _f, _i, _vp, _vp]),
     "afv_table_match_triangulation": (_i, [_vp, _vp, _vp, C.POINTER(TableTriJob), _i, _vp, _vp]),
+    "afv_table_match_bow_frame": (_i, [_vp, _vp, _i, C.POINTER(FrameView), _f, _f, _i, _vp, _vp]),
     "afv_table_broadcast": (_i, [_vp, _vp, _i, C.POINTER(_f)]),
     "afv_table_clone": (_i, [_vp, _vp]),
     "afv_comm_unique_id": (_i, [_vp]),

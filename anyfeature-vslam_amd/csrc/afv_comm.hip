@@ -483,6 +483,113 @@ extern "C" int afv_table_match_bow(afv_table *t, const int32_t *pair_a, const in
     return guarded(t->c, [&] { return table_match_bow_impl(t, pair_a, pair_b, npairs, th_low, nnratio, check_orientation, match12, nmatches); });
 }
 
+// Relocalisation batch: SearchByBoW(KF, Frame) (FeatureMatcher.cc:186-283) of ONE frame against `nslots` candidate keyframes of the
+// table (Tracking::Relocalization, Tracking.cc:1162,1182: a loop over the candidates of DetectRelocalizationCandidates).  The frame
+// travels once (descriptors, angles, FeatureVector feature indices); per candidate only the merge-join of the two FeatureVectors (host,
+// a few hundred ints).  M3 rules: validity on the keyframe side only (:216-222), a frame feature that already has a match is skipped
+// (:232), accept best <= TH_LOW (:250), rotation histogram keyed by the frame feature (:259).
+static int table_match_bow_frame_impl(afv_table *t, const int32_t *slots, int nslots, const afv_frame_view *F, float th_low, float nnratio,
+                                      int check_orientation, int32_t *match_f, int32_t *nmatches) {
+    afv_ctx *c = t->c;
+    if (!t->d_idx) return AFV_EINVAL;  // no FeatureVector was ever stored
+    const int nf = F->n, cap = t->cap;
+    for (int p = 0; p < nslots; ++p) {
+        const int s = slots[p];
+        if (s < 0 || s >= t->nsets) return AFV_EINVAL;
+        if (t->h_n[s] > 0 && !t->has_fv[s]) {
+            c->last_error = "afv_table_match_bow_frame: set " + std::to_string(s) + " holds features but no FeatureVector (afv_table_set_featvec)";
+            return AFV_EINVAL;
+        }
+    }
+    // the frame's FeatureVector: ascending node ids, indices inside the frame
+    HostFeatVec FV;
+    if (F->nnodes > 0) {
+        FV.node_id.assign(F->node_id, F->node_id + F->nnodes);
+        FV.seg_ptr.assign(F->seg_ptr, F->seg_ptr + F->nnodes + 1);
+        const int total = FV.seg_ptr[F->nnodes];
+        if (FV.seg_ptr[0] != 0 || total < 0 || total > nf) return AFV_EINVAL;
+        for (int k = 0; k < F->nnodes; ++k)
+            if (FV.seg_ptr[k + 1] < FV.seg_ptr[k] || (k > 0 && FV.node_id[k] <= FV.node_id[k - 1])) return AFV_EINVAL;
+        for (int i = 0; i < total; ++i)
+            if (F->seg_idx[i] < 0 || F->seg_idx[i] >= nf) return AFV_EINVAL;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    Blob b(c);
+    struct SegTaskH { int job, seg; };
+    std::vector<Seg> segs;
+    std::vector<SegTaskH> tasks;
+    std::vector<int> seg_first((size_t)nslots + 1, 0);
+    for (int p = 0; p < nslots; ++p) {
+        const size_t before = segs.size();
+        join_featvecs(t->fv[slots[p]], FV, segs);
+        for (size_t s = before; s < segs.size(); ++s) tasks.push_back(SegTaskH{p, (int)(s - before)});
+        seg_first[p + 1] = (int)segs.size();
+    }
+    const int nfe = std::max(nf, 1);
+    const size_t fdesc_off = b.put(F->desc32, (size_t)nf * 32);
+    const size_t fang_off = (check_orientation && nf) ? b.put(F->angle, (size_t)nf * sizeof(float)) : 0;
+    const size_t fidx_off = b.put(F->nnodes > 0 ? F->seg_idx : nullptr, (size_t)(F->nnodes > 0 ? FV.seg_ptr[F->nnodes] : 0) * sizeof(int32_t));
+    const size_t segs_off = b.put(segs.data(), segs.size() * sizeof(Seg));
+    const size_t tasks_off = b.put(tasks.data(), tasks.size() * sizeof(SegTaskH));
+    const size_t jobs_off = b.reserve((size_t)nslots * sizeof(DevMatchJob));
+    const size_t binoff_off = b.reserve((size_t)nslots * sizeof(int));
+    const size_t hist_off = b.reserve((size_t)nslots * 32 * sizeof(int));
+    const size_t nm_off = b.reserve((size_t)nslots * sizeof(int));
+    const size_t in_bytes = b.h.size();
+    const size_t out_off = b.reserve_scratch((size_t)nslots * nfe * sizeof(int));
+    const size_t bins_off = b.reserve_scratch((size_t)nslots * nfe);
+    int rc = ensure_match_buffer(c, b.h.size());
+    if (rc) return rc;
+    DevMatchJob *J = reinterpret_cast<DevMatchJob *>(b.h.data() + jobs_off);
+    int *bin_off = reinterpret_cast<int *>(b.h.data() + binoff_off);
+    for (int p = 0; p < nslots; ++p) {
+        const int a = slots[p];
+        DevMatchJob &d = J[p];
+        d.d1 = reinterpret_cast<const uint32_t *>(t->d_desc + (size_t)a * cap * 32);
+        d.d2 = reinterpret_cast<const uint32_t *>(c->d_match + fdesc_off);
+        d.n1 = t->h_n[a];
+        d.n2 = nf;
+        d.words = 8;
+        d.segs = reinterpret_cast<const Seg *>(c->d_match + segs_off) + seg_first[p];
+        d.nseg = seg_first[p + 1] - seg_first[p];
+        d.idx1 = t->d_idx + (size_t)a * cap;
+        d.idx2 = reinterpret_cast<const int *>(c->d_match + fidx_off);
+        d.valid1 = t->d_valid ? t->d_valid + (size_t)a * cap : nullptr;  // FeatureMatcher.cc:216-222
+        d.valid2 = nullptr;
+        d.ang1 = t->d_angle + (size_t)a * cap;
+        d.ang2 = reinterpret_cast<const float *>(c->d_match + fang_off);
+        d.ang_stride = 1;
+        d.th = th_low;
+        d.ratio = nnratio;
+        d.check_ori = check_orientation != 0;
+        d.mode = AFV_MATCH_KF_FRAME;
+        d.out = reinterpret_cast<int *>(c->d_match + out_off) + (size_t)p * nfe;
+        d.nmatches = reinterpret_cast<int *>(c->d_match + nm_off) + p;
+        bin_off[p] = p * nfe;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_match, b.h.data(), in_bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_match + out_off, 0xff, (size_t)nslots * nfe * sizeof(int), c->stream));  // -1
+    if (!tasks.empty())
+        afv_launch_match_bow_seg(reinterpret_cast<const DevMatchJob *>(c->d_match + jobs_off), nslots, c->d_match + tasks_off,
+                                 (int)tasks.size(), reinterpret_cast<int *>(c->d_match + hist_off), c->d_match + bins_off,
+                                 reinterpret_cast<const int *>(c->d_match + binoff_off), check_orientation ? 1 : 0, c->stream);
+    HIPCHK(c, hipGetLastError());
+    if (match_f && nf) HIPCHK(c, b.fetch(match_f, out_off, (size_t)nslots * nf * sizeof(int), c->stream));
+    HIPCHK(c, b.fetch(nmatches, nm_off, (size_t)nslots * sizeof(int), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    b.finish();
+    return AFV_OK;
+}
+
+extern "C" int afv_table_match_bow_frame(afv_table *t, const int32_t *slots, int nslots, const afv_frame_view *frame, float th_low,
+                                         float nnratio, int check_orientation, int32_t *match_f, int32_t *nmatches) {
+    if (!t || !slots || nslots < 1 || !frame || !nmatches) return AFV_EINVAL;
+    if (frame->n < 0 || frame->n > AFV_MAX_SIDE || (frame->n > 0 && !frame->desc32) || frame->nnodes < 0) return AFV_EINVAL;
+    if (frame->nnodes > 0 && (!frame->node_id || !frame->seg_ptr || !frame->seg_idx)) return AFV_EINVAL;
+    if (check_orientation && frame->n > 0 && !frame->angle) return AFV_EINVAL;
+    return guarded(t->c, [&] { return table_match_bow_frame_impl(t, slots, nslots, frame, th_low, nnratio, check_orientation, match_f, nmatches); });
+}
+
 static int table_match_tri_impl(afv_table *t, const int32_t *pair_a, const int32_t *pair_b, const afv_table_tri_job *geo, int npairs,
                                 int32_t *match12, int32_t *nmatches) {
     afv_ctx *c = t->c;

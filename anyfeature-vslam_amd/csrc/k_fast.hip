@@ -52,10 +52,11 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_BCAST31, 0xc, 0xf, false);
     return v;
 }
-// LDS row pitch of the tile and of the score plane: the 72 staged bytes of a row, optionally padded (a build-time experiment for the bank
-// pattern of the scattered byte reads of stage 2b: tools/experiments.py, -DFT_PITCH=76 ...; must be a multiple of 4)
+// LDS row pitch of the tile and of the score plane: the 72 staged bytes of a row + 4 bytes of padding.  19 dwords per row instead of 18
+// skews the bank pattern of the scattered byte reads of stage 2b (round 4, tools/experiments.py with -DFT_PITCH=n: 72 -> 76 bytes
+// = 5 % fewer bank-conflict cycles, kernel -2.2 %; 80 and 84 are worse than 72).  Must be a multiple of 4.
 #ifndef FT_PITCH
-#define FT_PITCH FT_LW
+#define FT_PITCH (FT_LW + 4)
 #endif
 static_assert(FT_PITCH >= FT_LW && FT_PITCH % 4 == 0, "tile pitch");
 #define RING_OFF(dx, dy) ((dy) * FT_PITCH + (dx))

@@ -435,10 +435,27 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve(const uint8_t *__restri
     if (tid == 0) s_cols_ready = 0;
     // rows whose best distance fails TH_LOW can never match: compact the others IN ROW ORDER, keys staged in LDS
     int nlive = 0;
+    // the records of a thread's first four rows (sets of up to 1024 rows: all of them) are fetched together: one L2 round trip instead of
+    // one per pass of the compaction loop
+    int4 pre4[4], pre8[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = u * MT + tid;
+        pre4[u] = make_int4(NO_KEY, NO_KEY, NO_KEY, NO_KEY);
+        pre8[u] = make_int4(NO_KEY, NO_KEY, NO_KEY, TOPK);
+        if (i < n1) {
+            pre4[u] = tk[2 * i];
+            pre8[u] = tk[2 * i + 1];
+        }
+    }
     for (int i0 = 0; i0 < n1; i0 += MT) {
         const int i = i0 + tid;
         int4 t4 = make_int4(NO_KEY, NO_KEY, NO_KEY, NO_KEY), t8 = make_int4(NO_KEY, NO_KEY, NO_KEY, TOPK);
-        if (i < n1) {
+        if (i0 < 4 * MT) {  // uniform
+            const int u = i0 / MT;
+            t4 = u == 0 ? pre4[0] : u == 1 ? pre4[1] : u == 2 ? pre4[2] : pre4[3];
+            t8 = u == 0 ? pre8[0] : u == 1 ? pre8[1] : u == 2 ? pre8[2] : pre8[3];
+        } else if (i < n1) {
             t4 = tk[2 * i];
             t8 = tk[2 * i + 1];
         }

@@ -224,50 +224,101 @@ __global__ __launch_bounds__(PF_T) void k_pyramid_fused(const Geo *__restrict__ 
     const int f = frame_base + fl;
     const int NL = A.nlevels;
     const short4 *Rx = R.r + tx, *Ry = R.r + NL * A.ntx + ty;  // level l: Rx[l * ntx], Ry[l * nty] (uniform: scalar loads from the argument block)
-    // stage every level's slice of the coefficient tables (offsets relative to the source region) and the level-0 window
-    for (int l = 1; l < NL; ++l) {
-        const short4 rx = Rx[l * A.ntx], rxp = Rx[(l - 1) * A.ntx], ry = Ry[l * A.nty], ryp = Ry[(l - 1) * A.nty];
-        const int lw = geo.lv[l].w;
-        short2 *xt = reinterpret_cast<short2 *>(pf_smem + A.off_xt[l]), *yt = reinterpret_cast<short2 *>(pf_smem + A.off_yt[l]);
-        const int nxe = rx.y - rx.x + 1, nye = ry.y - ry.x + 1;
-        for (int i = tid; i < nxe + nye; i += PF_T) {
-            short2 e;
-            e.x = 0;
-            e.y = 0;
-            if (i < nxe) {
-                if (rx.x + i < lw) {  // columns past the level's width (dword padding): offset 0, weight 0
-                    e = A.tab[A.tabx[l] + rx.x + i];
-                    e.x = (short)(e.x - rxp.x);
-                }
-                xt[i] = e;
+    // Stage every level's slice of the coefficient tables (offsets relative to the source region) and the level-0 window.  ALL global
+    // loads are issued before the first LDS store (a level-by-level "load, fix up, store" loop is seven dependent round trips: that
+    // was 10 of this kernel's 16 us): a thread owns at most one table entry per level (region width + height <= 1024) ...
+    short2 te[AFV_MAX_LEVELS];
+    bool fallback = false;  // a region wider + taller than the workgroup (not at any supported geometry): plain loop
+#pragma unroll
+    for (int l = 1; l < AFV_MAX_LEVELS; ++l) {
+        te[l].x = 0;
+        te[l].y = 0;
+        if (l < NL) {
+            const short4 rx = Rx[l * A.ntx], ry = Ry[l * A.nty];
+            const int nxe = rx.y - rx.x + 1, nye = ry.y - ry.x + 1;
+            fallback = fallback || nxe + nye > PF_T;
+            if (tid < nxe) {
+                if (rx.x + tid < geo.lv[l].w) te[l] = A.tab[A.tabx[l] + rx.x + tid];  // columns past the level's width (dword padding): offset 0, weight 0
+            } else if (tid < nxe + nye) {
+                te[l] = A.tab[A.taby[l] + ry.x + (tid - nxe)];
+            }
+        }
+    }
+    // ... and up to PF_W0 dwords of the level-0 window
+    constexpr int PF_W0 = 8;
+    uint32_t w0v[PF_W0];
+    const short4 rx0 = Rx[0], ry0 = Ry[0];
+    const uint8_t *img = src0.base + (size_t)f * src0.frame_stride;
+    const int lg0 = A.lg_q[0], ndw0 = (rx0.y - rx0.x + 4) >> 2, nrows0 = ry0.y - ry0.x + 1;
+    const int q0 = tid & ((1 << lg0) - 1), gx0 = rx0.x + 4 * q0, rstep0 = PF_T >> lg0;
+    const bool dw_ok0 = gx0 + 3 < src0.stride;
+#pragma unroll
+    for (int k = 0; k < PF_W0; ++k) {
+        const int r = (tid >> lg0) + k * rstep0;
+        w0v[k] = 0;
+        if (q0 < ndw0 && r < nrows0) {
+            const uint8_t *p = img + (size_t)(ry0.x + r) * src0.stride + gx0;
+            if (dw_ok0) {
+                w0v[k] = *reinterpret_cast<const uint32_t *>(p);
             } else {
-                e = A.tab[A.taby[l] + ry.x + (i - nxe)];
+                for (int b = 0; b < 4; ++b)
+                    if (gx0 + b < geo.width) w0v[k] |= (uint32_t)p[b] << (8 * b);
+            }
+        }
+    }
+#pragma unroll
+    for (int l = 1; l < AFV_MAX_LEVELS; ++l) {
+        if (l < NL) {
+            const short4 rx = Rx[l * A.ntx], rxp = Rx[(l - 1) * A.ntx], ry = Ry[l * A.nty], ryp = Ry[(l - 1) * A.nty];
+            short2 *xt = reinterpret_cast<short2 *>(pf_smem + A.off_xt[l]), *yt = reinterpret_cast<short2 *>(pf_smem + A.off_yt[l]);
+            const int nxe = rx.y - rx.x + 1, nye = ry.y - ry.x + 1;
+            short2 e = te[l];
+            if (tid < nxe) {
+                if (rx.x + tid < geo.lv[l].w) e.x = (short)(e.x - rxp.x);
+                xt[tid] = e;
+            } else if (tid < nxe + nye) {
                 e.x = (short)(e.x - ryp.x);
-                yt[i - nxe] = e;
+                yt[tid - nxe] = e;
+            }
+            if (fallback) {
+                for (int i = tid + PF_T; i < nxe + nye; i += PF_T) {
+                    short2 g;
+                    g.x = 0;
+                    g.y = 0;
+                    if (i < nxe) {
+                        if (rx.x + i < geo.lv[l].w) {
+                            g = A.tab[A.tabx[l] + rx.x + i];
+                            g.x = (short)(g.x - rxp.x);
+                        }
+                        xt[i] = g;
+                    } else {
+                        g = A.tab[A.taby[l] + ry.x + (i - nxe)];
+                        g.x = (short)(g.x - ryp.x);
+                        yt[i - nxe] = g;
+                    }
+                }
             }
         }
     }
     {
-        const short4 rx = Rx[0], ry = Ry[0];
-        const uint8_t *img = src0.base + (size_t)f * src0.frame_stride;
         uint8_t *S = pf_smem + A.off_buf[0];
-        const int sp = A.pitch[0], lg = A.lg_q[0];
-        const int ndw = (rx.y - rx.x + 4) >> 2, nrows = ry.y - ry.x + 1, w0 = geo.width;
-        const int q = tid & ((1 << lg) - 1);
-        if (q < ndw) {
-            const int gx = rx.x + 4 * q;
-            const bool dw_ok = gx + 3 < src0.stride;
-#pragma unroll 4
-            for (int r = tid >> lg; r < nrows; r += PF_T >> lg) {
-                const uint8_t *p = img + (size_t)(ry.x + r) * src0.stride + gx;
+        const int sp = A.pitch[0];
+#pragma unroll
+        for (int k = 0; k < PF_W0; ++k) {
+            const int r = (tid >> lg0) + k * rstep0;
+            if (q0 < ndw0 && r < nrows0) *reinterpret_cast<uint32_t *>(S + r * sp + 4 * q0) = w0v[k];
+        }
+        for (int r = (tid >> lg0) + PF_W0 * rstep0; r < nrows0; r += rstep0) {  // windows taller than PF_W0 row groups
+            if (q0 < ndw0) {
+                const uint8_t *p = img + (size_t)(ry0.x + r) * src0.stride + gx0;
                 uint32_t v = 0;
-                if (dw_ok) {
+                if (dw_ok0) {
                     v = *reinterpret_cast<const uint32_t *>(p);
                 } else {
                     for (int b = 0; b < 4; ++b)
-                        if (gx + b < w0) v |= (uint32_t)p[b] << (8 * b);
+                        if (gx0 + b < geo.width) v |= (uint32_t)p[b] << (8 * b);
                 }
-                *reinterpret_cast<uint32_t *>(S + r * sp + 4 * q) = v;
+                *reinterpret_cast<uint32_t *>(S + r * sp + 4 * q0) = v;
             }
         }
     }

@@ -473,27 +473,38 @@ __device__ __forceinline__ void select_quadtree_body(const Geo *__restrict__ geo
             // permutation of 0..E-1, so aux[0..E) is fully rewritten here: aux[rank] = nodes gained by that split.
             // tmp[10] (E) and tmp[11] (stop rank) were reset in the previous round's relabel phase.
             int ecount = 0;
-            for (int i = tid; i < size; i += ST) {
+            // RL lanes per node share the O(size) rank count (the 1024-thread instantiation: 4 lanes, each a quarter of the list; the
+            // partial ranks meet by two DPP quad shuffles)
+            constexpr int RL = ST / 256;
+            const int sub = tid & (RL - 1);
+            for (int i0 = 0; i0 < size; i0 += ST / RL) {  // uniform trip count: the quad shuffles need whole quads
+                const int i = i0 + tid / RL;
                 int key = -1;
-                const int ci = cc[i];
+                const int ci = i < size ? cc[i] : 0;
+                // (count, -index) as one key: node j goes first iff kj > ki.  Four nodes per LDS read (cnt arrays are
+                // 16-byte aligned, M is a multiple of 64); slots past `size` are masked.
+                const int ki = (ci << 12) | (4095 - i);
+                int r = 0;
                 if (ci > 1) {
-                    // (count, -index) as one key: node j goes first iff kj > ki.  Four nodes per LDS read (cnt arrays are
-                    // 16-byte aligned, M is a multiple of 64); slots past `size` are masked.
-                    const int ki = (ci << 12) | (4095 - i);
-                    int r = 0;
 #pragma unroll 4
-                    for (int j = 0; j < size; j += 4) {
+                    for (int j = 4 * sub; j < size; j += 4 * RL) {
                         const int4 c4 = *reinterpret_cast<const int4 *>(cc + j);
                         const int k0 = (c4.x << 12) | (4095 - j), k1 = (c4.y << 12) | (4094 - j);
                         const int k2 = (c4.z << 12) | (4093 - j), k3 = (c4.w << 12) | (4092 - j);
                         r += (c4.x > 1 && k0 > ki) + (j + 1 < size && c4.y > 1 && k1 > ki) + (j + 2 < size && c4.z > 1 && k2 > ki) +
                              (j + 3 < size && c4.w > 1 && k3 > ki);
                     }
+                }
+                if (RL == 4) {
+                    r += __builtin_amdgcn_update_dpp(0, r, 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, true);
+                    r += __builtin_amdgcn_update_dpp(0, r, 0x4E /*quad_perm:[2,3,0,1]*/, 0xf, 0xf, true);
+                }
+                if (ci > 1 && sub == 0) {
                     key = r;
                     ++ecount;
                     aux[key] = (child[4 * i] > 0) + (child[4 * i + 1] > 0) + (child[4 * i + 2] > 0) + (child[4 * i + 3] > 0) - 1;
                 }
-                aux2[i] = key;
+                if (i < size && sub == 0) aux2[i] = key;
             }
             ecount = wave_incl_scan(ecount);
             if (lane == 63) atomicAdd(&tmp[10], ecount);

@@ -192,6 +192,23 @@ class DescriptorTable:
                                                     ptr(m), ptr(nm)), "afv_table_match_bow")
         return m, nm
 
+    def match_bow_frame(self, slots, frame, th_low, nnratio, check_orientation=True, want_matches=True):
+        """relocalisation batch: SearchByBoW(KF, Frame) of ONE frame (a matcher.FeatureView: descriptors, FeatureVector, angles) against
+        the keyframes in `slots`.  Returns match_f[nslots, frame.N] (keyframe feature per frame feature, -1 = none) and nmatches[nslots]"""
+        from ._lib import FrameView
+        sl = _i32(slots)
+        desc = np.ascontiguousarray(frame.descriptors, np.uint8).reshape(-1, 32)
+        ids, sp, flat, nn = frame.csr()
+        ids, sp, flat = _i32(ids), _i32(sp), _i32(flat)
+        ang = None if frame.angles is None else np.ascontiguousarray(frame.angles, np.float32)
+        fv = FrameView(desc.ctypes.data if len(desc) else None, len(desc), None if ang is None else ang.ctypes.data,
+                       ids.ctypes.data if nn else None, sp.ctypes.data if nn else None, flat.ctypes.data if nn else None, int(nn))
+        m = np.empty((len(sl), len(desc)), np.int32) if want_matches else None
+        nm = np.zeros(len(sl), np.int32)
+        self.ctx.check(self.lib.afv_table_match_bow_frame(self.handle, ptr(sl), len(sl), C.byref(fv), float(th_low), float(nnratio),
+                                                          int(bool(check_orientation)), ptr(m), ptr(nm)), "afv_table_match_bow_frame")
+        return m, nm
+
     def match_triangulation(self, pair_a, pair_b, F12, epipoles, th_low, has_mp1=None, has_mp2=None):
         """SearchForTriangulation per pair.  F12: [npairs, 9] (row-major), epipoles: [npairs, 2]; has_mp1/2: per pair uint8
         arrays or None"""

@@ -185,6 +185,21 @@ int afv_table_match_pairs_device(afv_table *t, const int32_t *d_pair_a, const in
  * arrays in, host results out (match12 may be NULL); descriptors and feature indices stay in HBM. */
 int afv_table_match_bow(afv_table *t, const int32_t *pair_a, const int32_t *pair_b, int npairs, float th_low, float nnratio,
                         int check_orientation, int32_t *match12, int32_t *nmatches);
+/* Relocalisation batch: SearchByBoW(KF, Frame) (FeatureMatcher.cc:186-283) of ONE frame against `nslots` candidate keyframes of the
+ * table - what Tracking::Relocalization does in a loop over the candidates of DetectRelocalizationCandidates (src/Tracking.cc:1162,
+ * 1182).  The frame is uploaded once (descriptors, angles, the feature indices of its FeatureVector); every candidate is one job of the
+ * same launch pair.  Rules of the reference: validity (afv_table_set_valid) on the keyframe side only (:216-222), a frame feature that
+ * already holds a match is skipped (:232), accept best <= th_low (:250), rotation histogram keyed by the frame feature (:259).
+ * Host pointers.  match_f[nslots][frame->n] = index of the matched keyframe feature per FRAME feature or -1 (may be NULL: counts
+ * only); nmatches[nslots]. */
+typedef struct {
+    const uint8_t *desc32; int32_t n;   /* the frame's n x 32-byte descriptors (Frame::mDescriptors) */
+    const float *angle;                 /* mvKeysUn[i].angle in degrees; required iff check_orientation */
+    /* Frame::mFeatVec as CSR over ascending node ids (as in afv_match_job); nnodes == 0: the frame shares no node with anybody */
+    const int32_t *node_id; const int32_t *seg_ptr; const int32_t *seg_idx; int32_t nnodes;
+} afv_frame_view;
+int afv_table_match_bow_frame(afv_table *t, const int32_t *slots, int nslots, const afv_frame_view *frame, float th_low, float nnratio,
+                              int check_orientation, int32_t *match_f, int32_t *nmatches);
 /* SearchForTriangulation (FeatureMatcher.cc:662-790, mono) of npairs slot pairs over the stored FeatureVectors and the
  * per-keyframe geometry stored with afv_table_set_geometry (mvKeysUn[i].pt and KeyFrame::GetKeyPt1DSigma2(i)): what
  * LocalMapping::CreateNewMapPoints does against <= 20 neighbours (src/LocalMapping.cc:238-297).  Per pair only the

@@ -188,6 +188,30 @@ def test_other_budgets(afv, oracle):
         ctx.close()
 
 
+@pytest.mark.parametrize("path", [1, 0])
+@pytest.mark.parametrize("sf,nl", [(1.1892, 8), (1.5, 4), (2.0, 4), (2.0, 3), (1.2, 2), (1.2, 4), (1.3, 6)])
+def test_other_scale_factors_and_level_counts(afv, oracle, sf, nl, path):
+    """FeatureExtractor.scaleFactor / numOctaves are settings (settings/*.yaml:6-7: 1.2, 1.1892 = 2^(1/4), 1.5, 2.0 across the
+    reference's plugins): the resize coefficient tables at non-1.2 ratios (2.0 is the exact 2:1 case: weights 128 / 128), the wider
+    source window of k_resize_level above a ratio of 1.37, the one-launch pyramid's plan, quotas and capacities with few levels.
+    Both kernel paths (path 1 = small-batch kernels for the single frame, 0 = batch kernels), pyramid level by level and end to end."""
+    img = afv.synth.corners_frame(33)
+    ctx = afv.Context(nfeatures=1000, nlevels=nl, scale_factor=sf)
+    ctx.set_small_batch_path(path)
+    kps, desc = ctx.extract(img)
+    prm = oracle.default_params(1000, nl, sf, 20)
+    okps, odesc, tr = oracle.orb_extract_trace(img, prm)
+    for l in range(nl):
+        got = ctx.debug_level(0, l)
+        assert got.shape == tr["level"][l].shape and np.array_equal(got, tr["level"][l]), (sf, nl, l)
+    assert len(kps) == len(okps) and len(kps) > 300
+    assert kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc), (sf, nl)
+    size, s2, inf = ctx.size_sigma(kps)
+    osz, os2, oinf = oracle.size_sigma(kps, sf)
+    assert np.array_equal(size, osz) and np.array_equal(s2, os2) and np.array_equal(inf, oinf)
+    ctx.close()
+
+
 def test_tiny_budgets_keep_the_unconditional_first_split(afv, oracle):
     """DistributeOctTree's first split round is unconditional (ORBextractor.cc:283-366): a level whose quota is 0..3 still
     returns up to 4 * nIni keypoints, so a 5-feature extractor yields ~26 keypoints.  Capacities must follow."""

@@ -135,6 +135,56 @@ def test_table_bow_guided_pairs(afv, oracle, tbl, ori):
     ctx.close()
 
 
+@pytest.mark.parametrize("ori", [False, True])
+def test_table_bow_frame_relocalisation_batch(afv, oracle, tbl, ori):
+    """SearchByBoW(KF, Frame) (FeatureMatcher.cc:186-283) of ONE frame against 36 candidate keyframes of the table in one call
+    (Tracking::Relocalization, Tracking.cc:1162,1182): ragged counts, an empty keyframe, validity masks on the keyframe side, the
+    inclusive threshold, the rotation histogram keyed by the frame feature"""
+    t, ang, cnt = _small_table(afv, K=36, cap=384)
+    K = len(cnt)
+    ctx = afv.Context()
+    table = tbl.DescriptorTable(ctx, K, t.shape[1])
+    fvs, valid = [], [None] * K
+    for k in range(K):
+        table.set(k, t[k, :cnt[k]], ang[k, :cnt[k]])
+        # the same feature index sits in the same node in every keyframe (rows keep their identity along the table): real matches
+        fv = _featvec(afv, 77, int(cnt[k]), 40 if k % 4 else 9)
+        fvs.append(fv)
+        table.set_featvec(k, *_csr(fv))
+        if k % 3 == 0 and cnt[k]:
+            valid[k] = (afv.synth.lcg_bytes(900 + k, int(cnt[k])) > 50).astype(np.uint8)
+            table.set_valid(k, valid[k])
+    # the frame: keyframe 17 seen again (10 % bit flips, 30 % new rows), 350 features, its own FeatureVector and angles
+    nf = 350
+    fdesc = afv.synth.perturbed_descriptors(t[17, :nf].copy(), 4242)
+    fang = ((ang[17, :nf] + 3.0) % 360.0).astype(np.float32)
+    ffv = _featvec(afv, 77, nf, 40)
+    frame = afv.FeatureView(fdesc, ffv, None, fang)
+    slots = np.array([k for k in range(K)][::-1], np.int32)           # every keyframe, the empty one included, in a non-trivial order
+    m, nm = table.match_bow_frame(slots, frame, TH, RATIO, ori)
+    assert m.shape == (K, nf)
+    total = 0
+    for p, k in enumerate(slots):
+        want, wn = oracle.search_by_bow_kf_frame(t[k, :cnt[k]], fdesc, fvs[k], ffv, valid[k], ang[k, :cnt[k]], fang, TH, RATIO, ori)
+        assert nm[p] == wn, (p, k)
+        assert np.array_equal(m[p], want), (p, k)
+        total += wn
+    assert total > 300 and nm[list(slots).index(17)] > 100
+    _, nm2 = table.match_bow_frame(slots, frame, TH, RATIO, ori, want_matches=False)
+    assert np.array_equal(nm, nm2)
+    # a frame without a FeatureVector shares no node with anybody; an empty frame is legal
+    m0, nm0 = table.match_bow_frame(slots[:3], afv.FeatureView(fdesc, [], None, fang), TH, RATIO, ori)
+    assert np.all(nm0 == 0) and np.all(m0 == -1)
+    m1, nm1 = table.match_bow_frame(slots[:3], afv.FeatureView(np.zeros((0, 32), np.uint8), [], None, np.zeros(0, np.float32)), TH, RATIO, ori)
+    assert np.all(nm1 == 0) and m1.shape == (3, 0)
+    # a recycled slot without a FeatureVector must be refused, not answered with "no matches"
+    table.set(2, t[2, :cnt[2]], ang[2, :cnt[2]])
+    with pytest.raises(afv._lib.AfvError):
+        table.match_bow_frame(np.array([2], np.int32), frame, TH, RATIO, ori)
+    table.close()
+    ctx.close()
+
+
 def test_table_triangulation_pairs(afv, oracle, tbl):
     """device-resident SearchForTriangulation (FeatureMatcher.cc:662-790): per-keyframe geometry in the table, per pair only
     F12 / epipole / map-point masks"""

@@ -205,3 +205,44 @@ def test_pinning_script_is_self_contained():
     synth = importlib.import_module("anyfeature-vslam_amd.synth")
     assert np.array_equal(pin.corners_frame(5), synth.corners_frame(5)) and np.array_equal(pin.noise_frame(3), synth.noise_frame(3))
     assert pin.level_sizes(640, 480) == [(640, 480), (533, 400), (444, 333), (370, 278), (309, 231), (257, 193), (214, 161), (179, 134)]
+
+
+def test_pinning_script_drives_cv2_like_the_reference(oracle, tmp_path, monkeypatch):
+    """tools/pin_against_opencv.py has never met a real cv2 here.  Run it against tests/fake_cv2 (the OpenCV 4.x Python signatures, strict
+    about argument order and keywords; numbers from the oracle): the ORB object must be configured and called exactly as
+    Feature_orb32.cpp:20-53 does - create, setMaxFeatures(nfeatures * 10), setEdgeThreshold(0), setFastThreshold(int), setNLevels, ONE
+    detect, then ONE compute per level on that level's keypoints - and the file it writes must satisfy the consumer above."""
+    import importlib.util
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "fake_cv2"))
+    try:
+        sys.modules.pop("cv2", None)
+        import cv2 as fake
+        assert fake.__version__.endswith("fake")
+        fake.LOG.clear()
+        spec = importlib.util.spec_from_file_location("pin_tool", os.path.join(ROOT, "tools", "pin_against_opencv.py"))
+        pin = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(pin)
+        monkeypatch.setattr(pin, "OUT", str(tmp_path))
+        gray = pin.corners_frame(1)
+        pin.pin_orb(fake, "selftest", gray)
+        pin.pin_akaze(fake, "selftest", pin.corners_frame(1, 320, 240))
+    finally:
+        sys.path.remove(os.path.join(ROOT, "tests", "fake_cv2"))
+        sys.modules.pop("cv2", None)
+    log = [e for e in fake.LOG if e[0].startswith("ORB")]
+    assert [e[0] for e in log[:6]] == ["ORB_create", "ORB.setMaxFeatures", "ORB.setEdgeThreshold", "ORB.setFastThreshold", "ORB.setNLevels", "ORB.detect"]
+    assert log[0][1:] == (500, 1.2, 8, 31, 0, 2, 0, 31, 20)                      # cv::ORB::create() with its defaults (Feature_orb32.cpp:21)
+    assert log[1][1] == 10000 and log[2][1] == 0 and log[3][1] == 20 and isinstance(log[3][1], int) and log[4][1] == 8   # :22-24, :30
+    assert log[5][1] == (480, 640) and log[5][2] is None                        # detect(image, mask = none) (:34)
+    computes = log[6:]
+    assert all(e[0] == "ORB.compute" for e in computes) and [e[2] for e in computes] == [[l] for l in range(8)]       # one call per level (:42-53)
+    assert ("FastFeatureDetector_create", 20, True, fake.FastFeatureDetector_TYPE_9_16) in fake.LOG
+    assert sum(e[0] == "resize" for e in fake.LOG) == 7 and all(e[2] == fake.INTER_LINEAR_EXACT for e in fake.LOG if e[0] == "resize")
+    assert ("AKAZE_create", fake.AKAZE_DESCRIPTOR_MLDB, 0, 3, 0.0005, 2, 4, fake.KAZE_DIFF_PM_G2) in fake.LOG   # Feature_akaze61.cpp:24-61
+    path = os.path.join(str(tmp_path), "opencv_selftest.npz")
+    d = np.load(path)
+    need = {"gray", "detect"} | {"%s_%d" % (k, l) for l in range(8) for k in ("level", "blur", "fast", "compute_kps", "compute_desc")}
+    assert need <= set(d.files), sorted(need - set(d.files))
+    assert d["detect"].dtype == pin.KP_DTYPE and d["compute_desc_0"].dtype == np.uint8 and d["compute_desc_0"].shape[1] == 32
+    test_oracle_against_real_opencv(oracle, path)      # the consumer accepts the producer's file (every stage "ok": the fake IS the oracle)

@@ -24,7 +24,7 @@ import zlib
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("AFV_PIN_OUT") or os.path.join(ROOT, "tests", "golden")   # where the files go (the override is for the self-test)
 NFEATURES, NLEVELS, SCALE, FAST_TH = 1000, 8, 1.2, 20
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
@@ -96,7 +96,8 @@ def pin_orb(cv2, name, gray):
         d["level_%d" % l] = im
         d["level_crc_%d" % l] = np.array(zlib.crc32(im.tobytes()), np.uint32)
         # E9: what cv::ORB::compute applies to each level before sampling (the level ROI is blurred in place)
-        d["blur_%d" % l] = cv2.GaussianBlur(im, (7, 7), 2, 2, borderType=cv2.BORDER_REFLECT_101)
+        # (sigmaY by keyword: the fourth POSITIONAL parameter of the Python binding is `dst`)
+        d["blur_%d" % l] = cv2.GaussianBlur(im, (7, 7), sigmaX=2, sigmaY=2, borderType=cv2.BORDER_REFLECT_101)
         # E3: FAST-9/16 + NMS on the un-bordered level
         kf = fast.detect(im, None)
         d["fast_%d" % l] = np.array([(k.pt[0], k.pt[1], k.response) for k in kf], np.float32).reshape(-1, 3)
