@@ -233,6 +233,13 @@ static bool plan_pyr_fuse(const Geo &g, const short2 *tab, const size_t *tab_off
     }
     A.off_buf[0] = take(buf[0]);
     A.off_buf[1] = take(buf[1]);
+    A.off_lv = take((size_t)AFV_MAX_LEVELS * 48);
+    for (int l = 0; l < NL; ++l) {
+        A.lw[l] = g.lv[l].w;
+        A.gpitch[l] = g.lv[l].pitch;
+        A.pyr_off[l] = g.lv[l].pyr_off;
+        A.fstride[l] = g.lv[l].pyr_frame_stride;
+    }
     lds = off;
     return true;
 }
@@ -566,7 +573,7 @@ static void enqueue_range(afv_ctx *c, const FrameSrc &src, int f0, int nf, afv_k
         A.n_zero = nf * AFV_MAX_LEVELS;
         A.zero_one = c->d_hq_n + f0;
         A.zero_two = clear_status ? d_status : nullptr;
-        afv_launch_pyramid_fused(c->d_geo, &src, c->d_pyr, &A, &c->pf_reg, c->pf_lds, f0, nf, s);
+        afv_launch_pyramid_fused(&src, c->d_pyr, &A, &c->pf_reg, c->pf_lds, f0, nf, s);
     } else {
         StageTimer t_(c, AFV_STAGE_PYRAMID, s, nf);
         for (int l = 1; l < g.nlevels; ++l) {

@@ -90,7 +90,11 @@ struct PyrFuseArgs {
     int lg_q[AFV_MAX_LEVELS];   // log2 of the DWORD slots per row of level l (power of two >= pitch / 4)
     int off_xt[AFV_MAX_LEVELS], off_yt[AFV_MAX_LEVELS];  // LDS byte offsets of the staged tables
     int off_buf[2];             // LDS byte offsets of the two region buffers (level parity)
+    int off_lv;                 // LDS byte offset of the per-level descriptors the prologue parks for the level loop
     int nlevels, ntx, nty;
+    // level geometry (a copy of what Geo holds: the kernel reads nothing but its arguments through the scalar cache)
+    int lw[AFV_MAX_LEVELS], gpitch[AFV_MAX_LEVELS];
+    unsigned long long pyr_off[AFV_MAX_LEVELS], fstride[AFV_MAX_LEVELS];
     int *zero_counts;           // as in ResizeTab: the candidate / queue counters of the frame range are cleared here
     int n_zero;
     int *zero_one, *zero_two;

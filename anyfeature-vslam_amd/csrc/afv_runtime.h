@@ -20,7 +20,7 @@ extern "C" void afv_launch_resize(const uint8_t *src, int sw, int sh, int spitch
                                   int dpitch, size_t dframe, const short2 *xt, const short2 *yt, int frame_base, int nframes, int *zero_counts,
                                   int n_zero, int *zero_one, hipStream_t stream);
 extern "C" int afv_resize_window_ok(int sw, int sh, int dw, int dh);
-extern "C" void afv_launch_pyramid_fused(const Geo *geo_dev, const FrameSrc *src0, uint8_t *pyr, const PyrFuseArgs *args, const PyrFuseRegions *regions,
+extern "C" void afv_launch_pyramid_fused(const FrameSrc *src0, uint8_t *pyr, const PyrFuseArgs *args, const PyrFuseRegions *regions,
                                          size_t lds_bytes, int frame_base, int nframes, hipStream_t stream);
 extern "C" int afv_pyramid_fused_prepare(size_t lds_bytes);
 extern "C" void afv_launch_fast_nms(const Geo *geo, int total_tiles, const FrameSrc *src0, const uint8_t *pyr, uint32_t *cand_packed,

@@ -206,10 +206,22 @@ extern "C" void afv_launch_resize(const uint8_t *src, int sw, int sh, int spitch
 
 #define PF_T 1024
 
-__global__ __launch_bounds__(PF_T) void k_pyramid_fused(const Geo *__restrict__ geo_p, FrameSrc src0, uint8_t *__restrict__ pyr, PyrFuseArgs A,
-                                                        PyrFuseRegions R, int frame_base, int total_blocks) {
+// what the level loop needs about one level, parked in LDS by the prologue: inside the loop (run-time level index) nothing is fetched
+// through the scalar cache any more - with the region descriptors and the level geometry read there, every level paid two or three
+// exposed scalar-load misses (kernel arguments / geometry: a new cache line per level), 10 of the kernel's 16 us
+struct PfLevel {
+    short4 rx, ry;                // region of this workgroup at the level (need.lo, need.hi, own.lo, own.hi)
+    int lds_pitch, lg_q, off_xt, off_yt;
+    int gpitch, pad;              // row pitch of the level image in memory
+    unsigned long long dst_off;   // byte offset of this frame's level image in the pyramid buffer
+};
+
+static_assert(sizeof(PfLevel) == 48, "afv_api.hip reserves 48 bytes of LDS per level");
+static_assert(sizeof(PyrFuseArgs) + sizeof(PyrFuseRegions) + sizeof(FrameSrc) + 32 <= 4096, "kernel argument block");
+
+__global__ __launch_bounds__(PF_T) void k_pyramid_fused(FrameSrc src0, uint8_t *__restrict__ pyr, PyrFuseArgs A, PyrFuseRegions R, int frame_base,
+                                                        int total_blocks) {
     extern __shared__ __attribute__((aligned(16))) uint8_t pf_smem[];
-    const Geo &geo = *geo_p;
     const int tid = threadIdx.x;
     if (blockIdx.x == 0) {
         if (A.zero_counts)
@@ -224,30 +236,52 @@ __global__ __launch_bounds__(PF_T) void k_pyramid_fused(const Geo *__restrict__ 
     const int f = frame_base + fl;
     const int NL = A.nlevels;
     const short4 *Rx = R.r + tx, *Ry = R.r + NL * A.ntx + ty;  // level l: Rx[l * ntx], Ry[l * nty] (uniform: scalar loads from the argument block)
-    // Stage every level's slice of the coefficient tables (offsets relative to the source region) and the level-0 window.  ALL global
-    // loads are issued before the first LDS store (a level-by-level "load, fix up, store" loop is seven dependent round trips: that
-    // was 10 of this kernel's 16 us): a thread owns at most one table entry per level (region width + height <= 1024) ...
+    PfLevel *s_lv = reinterpret_cast<PfLevel *>(pf_smem + A.off_lv);
+    // Prologue, unrolled over the levels (compile-time level index: the scalar loads of all levels are independent and issued together).
+    // Per level: park its descriptor in LDS; fetch this thread's entry of the level's coefficient-table slices (a thread owns at most
+    // one entry per level: region width + height <= 1024).  ALL global loads of the kernel - the table entries and the level-0
+    // window - are issued before the first LDS store of loaded data: one round trip.
     short2 te[AFV_MAX_LEVELS];
+    short4 rxs[AFV_MAX_LEVELS], rys[AFV_MAX_LEVELS];
     bool fallback = false;  // a region wider + taller than the workgroup (not at any supported geometry): plain loop
 #pragma unroll
-    for (int l = 1; l < AFV_MAX_LEVELS; ++l) {
+    for (int l = 0; l < AFV_MAX_LEVELS; ++l) {
         te[l].x = 0;
         te[l].y = 0;
+        rxs[l] = short4{0, 0, 0, 0};
+        rys[l] = short4{0, 0, 0, 0};
         if (l < NL) {
             const short4 rx = Rx[l * A.ntx], ry = Ry[l * A.nty];
-            const int nxe = rx.y - rx.x + 1, nye = ry.y - ry.x + 1;
-            fallback = fallback || nxe + nye > PF_T;
-            if (tid < nxe) {
-                if (rx.x + tid < geo.lv[l].w) te[l] = A.tab[A.tabx[l] + rx.x + tid];  // columns past the level's width (dword padding): offset 0, weight 0
-            } else if (tid < nxe + nye) {
-                te[l] = A.tab[A.taby[l] + ry.x + (tid - nxe)];
+            rxs[l] = rx;
+            rys[l] = ry;
+            if (tid == l) {
+                PfLevel v;
+                v.rx = rx;
+                v.ry = ry;
+                v.lds_pitch = A.pitch[l];
+                v.lg_q = A.lg_q[l];
+                v.off_xt = A.off_xt[l];
+                v.off_yt = A.off_yt[l];
+                v.gpitch = A.gpitch[l];
+                v.pad = 0;
+                v.dst_off = (unsigned long long)A.pyr_off[l] + (unsigned long long)f * A.fstride[l];
+                s_lv[l] = v;
+            }
+            if (l > 0) {
+                const int nxe = rx.y - rx.x + 1, nye = ry.y - ry.x + 1;
+                fallback = fallback || nxe + nye > PF_T;
+                if (tid < nxe) {
+                    if (rx.x + tid < A.lw[l]) te[l] = A.tab[A.tabx[l] + rx.x + tid];  // columns past the level's width (dword padding): offset 0, weight 0
+                } else if (tid < nxe + nye) {
+                    te[l] = A.tab[A.taby[l] + ry.x + (tid - nxe)];
+                }
             }
         }
     }
     // ... and up to PF_W0 dwords of the level-0 window
     constexpr int PF_W0 = 8;
     uint32_t w0v[PF_W0];
-    const short4 rx0 = Rx[0], ry0 = Ry[0];
+    const short4 rx0 = rxs[0], ry0 = rys[0];
     const uint8_t *img = src0.base + (size_t)f * src0.frame_stride;
     const int lg0 = A.lg_q[0], ndw0 = (rx0.y - rx0.x + 4) >> 2, nrows0 = ry0.y - ry0.x + 1;
     const int q0 = tid & ((1 << lg0) - 1), gx0 = rx0.x + 4 * q0, rstep0 = PF_T >> lg0;
@@ -262,19 +296,19 @@ __global__ __launch_bounds__(PF_T) void k_pyramid_fused(const Geo *__restrict__ 
                 w0v[k] = *reinterpret_cast<const uint32_t *>(p);
             } else {
                 for (int b = 0; b < 4; ++b)
-                    if (gx0 + b < geo.width) w0v[k] |= (uint32_t)p[b] << (8 * b);
+                    if (gx0 + b < A.lw[0]) w0v[k] |= (uint32_t)p[b] << (8 * b);
             }
         }
     }
 #pragma unroll
     for (int l = 1; l < AFV_MAX_LEVELS; ++l) {
         if (l < NL) {
-            const short4 rx = Rx[l * A.ntx], rxp = Rx[(l - 1) * A.ntx], ry = Ry[l * A.nty], ryp = Ry[(l - 1) * A.nty];
+            const short4 rx = rxs[l], rxp = rxs[l - 1], ry = rys[l], ryp = rys[l - 1];
             short2 *xt = reinterpret_cast<short2 *>(pf_smem + A.off_xt[l]), *yt = reinterpret_cast<short2 *>(pf_smem + A.off_yt[l]);
             const int nxe = rx.y - rx.x + 1, nye = ry.y - ry.x + 1;
             short2 e = te[l];
             if (tid < nxe) {
-                if (rx.x + tid < geo.lv[l].w) e.x = (short)(e.x - rxp.x);
+                if (rx.x + tid < A.lw[l]) e.x = (short)(e.x - rxp.x);
                 xt[tid] = e;
             } else if (tid < nxe + nye) {
                 e.x = (short)(e.x - ryp.x);
@@ -286,7 +320,7 @@ __global__ __launch_bounds__(PF_T) void k_pyramid_fused(const Geo *__restrict__ 
                     g.x = 0;
                     g.y = 0;
                     if (i < nxe) {
-                        if (rx.x + i < geo.lv[l].w) {
+                        if (rx.x + i < A.lw[l]) {
                             g = A.tab[A.tabx[l] + rx.x + i];
                             g.x = (short)(g.x - rxp.x);
                         }
@@ -316,25 +350,28 @@ __global__ __launch_bounds__(PF_T) void k_pyramid_fused(const Geo *__restrict__ 
                     v = *reinterpret_cast<const uint32_t *>(p);
                 } else {
                     for (int b = 0; b < 4; ++b)
-                        if (gx0 + b < geo.width) v |= (uint32_t)p[b] << (8 * b);
+                        if (gx0 + b < A.lw[0]) v |= (uint32_t)p[b] << (8 * b);
                 }
                 *reinterpret_cast<uint32_t *>(S + r * sp + 4 * q0) = v;
             }
         }
     }
     __syncthreads();
+    const int buf0 = A.off_buf[0], buf1 = A.off_buf[1];
+    PfLevel vp = s_lv[0];
     for (int l = 1; l < NL; ++l) {
-        const short4 rx = Rx[l * A.ntx], ry = Ry[l * A.nty], rxp = Rx[(l - 1) * A.ntx], ryp = Ry[(l - 1) * A.nty];
-        const uint8_t *S = pf_smem + A.off_buf[(l - 1) & 1];
-        uint8_t *D = pf_smem + A.off_buf[l & 1];
-        const short2 *xt = reinterpret_cast<const short2 *>(pf_smem + A.off_xt[l]), *yt = reinterpret_cast<const short2 *>(pf_smem + A.off_yt[l]);
-        const int sp = A.pitch[l - 1], dp = A.pitch[l], lgq = A.lg_q[l];
+        const PfLevel v = s_lv[l];
+        const short4 rx = v.rx, ry = v.ry, rxp = vp.rx, ryp = vp.ry;
+        const uint8_t *S = pf_smem + ((l & 1) ? buf0 : buf1);
+        uint8_t *D = pf_smem + ((l & 1) ? buf1 : buf0);
+        const short2 *xt = reinterpret_cast<const short2 *>(pf_smem + v.off_xt), *yt = reinterpret_cast<const short2 *>(pf_smem + v.off_yt);
+        const int sp = vp.lds_pitch, dp = v.lds_pitch, lgq = v.lg_q;
         const int sw = rxp.y - rxp.x + 1, sh = ryp.y - ryp.x + 1;  // source region
         const int dwp = rx.y - rx.x + 1, dh = ry.y - ry.x + 1;     // this level's region (width a multiple of 4)
         const int cq = tid & ((1 << lgq) - 1);
         if (4 * cq < dwp) {
-            const LevelGeo &Lg = geo.lv[l];
-            uint8_t *dst = pyr + Lg.pyr_off + (size_t)f * Lg.pyr_frame_stride;
+            uint8_t *dst = pyr + v.dst_off;
+            const int gpitch = v.gpitch;
             const int gx = rx.x + 4 * cq;
             const bool own_x = gx >= (rx.z & ~3) && gx < rx.w;  // owned columns [own.lo & ~3, align4(own.hi)): whole dwords
             const uint2 xe = *reinterpret_cast<const uint2 *>(xt + 4 * cq), xf = *reinterpret_cast<const uint2 *>(xt + 4 * cq + 2);  // 4 x (offset, weight)
@@ -366,22 +403,23 @@ __global__ __launch_bounds__(PF_T) void k_pyramid_fused(const Geo *__restrict__ 
                 const ushort2r p1 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(l01, u01, 0x07060302u));
                 const ushort2r p2 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(l23, u23, 0x05040100u));
                 const ushort2r p3 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(l23, u23, 0x07060302u));
-                const uint32_t q0 = __builtin_amdgcn_udot2(p0, WY, 32768u, false) >> 16, q1 = __builtin_amdgcn_udot2(p1, WY, 32768u, false) >> 16;
-                const uint32_t q2 = __builtin_amdgcn_udot2(p2, WY, 32768u, false) >> 16, q3 = __builtin_amdgcn_udot2(p3, WY, 32768u, false) >> 16;
-                const uint32_t o = q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
+                const uint32_t q0_ = __builtin_amdgcn_udot2(p0, WY, 32768u, false) >> 16, q1_ = __builtin_amdgcn_udot2(p1, WY, 32768u, false) >> 16;
+                const uint32_t q2_ = __builtin_amdgcn_udot2(p2, WY, 32768u, false) >> 16, q3_ = __builtin_amdgcn_udot2(p3, WY, 32768u, false) >> 16;
+                const uint32_t o = q0_ | (q1_ << 8) | (q2_ << 16) | (q3_ << 24);
                 *reinterpret_cast<uint32_t *>(D + y * dp + 4 * cq) = o;
                 const int gy = ry.x + y;
-                if (own_x && gy >= ry.z && gy < ry.w) *reinterpret_cast<uint32_t *>(dst + (size_t)gy * Lg.pitch + gx) = o;
+                if (own_x && gy >= ry.z && gy < ry.w) *reinterpret_cast<uint32_t *>(dst + (size_t)gy * gpitch + gx) = o;
             }
         }
+        vp = v;
         __syncthreads();
     }
 }
 
-extern "C" void afv_launch_pyramid_fused(const Geo *geo_dev, const FrameSrc *src0, uint8_t *pyr, const PyrFuseArgs *args, const PyrFuseRegions *regions,
+extern "C" void afv_launch_pyramid_fused(const FrameSrc *src0, uint8_t *pyr, const PyrFuseArgs *args, const PyrFuseRegions *regions,
                                          size_t lds_bytes, int frame_base, int nframes, hipStream_t stream) {
     const int total = args->ntx * args->nty * nframes;
-    hipLaunchKernelGGL(k_pyramid_fused, dim3((total + 7) / 8 * 8), dim3(PF_T), lds_bytes, stream, geo_dev, *src0, pyr, *args, *regions, frame_base, total);
+    hipLaunchKernelGGL(k_pyramid_fused, dim3((total + 7) / 8 * 8), dim3(PF_T), lds_bytes, stream, *src0, pyr, *args, *regions, frame_base, total);
 }
 
 extern "C" int afv_pyramid_fused_prepare(size_t lds_bytes) {
