@@ -159,6 +159,7 @@ SYMBOLS = {
     "afv_set_split_chunks": (_i, [_vp, _i]),
     "afv_set_match_engine": (_i, [_vp, _i]),
     "afv_set_small_batch_path": (_i, [_vp, _i, _i]),
+    "afv_set_match_resolve": (_i, [_vp, _i]),
     "afv_debug_pyramid_plan": (_i, [C.POINTER(OrbParams), _i, _i, _i, _i, _vp, _i, _vp, _vp, _i]),
     "afv_set_pipeline_chunk": (_i, [_vp, _i, _i]),
     "afv_get_geometry": (_i, [_vp, C.POINTER(Geometry)]),

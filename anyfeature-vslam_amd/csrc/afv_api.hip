@@ -151,7 +151,7 @@ static int ceil_log2(int v) {
     return lg;
 }
 static bool plan_pyr_fuse(const Geo &g, const short2 *tab, const size_t *tab_off_x, const size_t *tab_off_y, int TW, int TH,
-                          std::vector<short4> &reg, PyrFuseArgs &A, size_t &lds) {
+                          std::vector<short4> &reg, PyrFusePlan &P) {
     const int NL = g.nlevels, L = NL - 1;
     if (NL < 2 || TW < 4 || (TW & 3) || TH < 1) return false;
     const int ntx = (g.lv[L].w + TW - 1) / TW, nty = (g.lv[L].h + TH - 1) / TH;
@@ -208,54 +208,124 @@ static bool plan_pyr_fuse(const Geo &g, const short2 *tab, const size_t *tab_off
             }
         }
     }
+    std::memset(&P, 0, sizeof(P));
+    P.nlevels = NL;
+    P.ntx = ntx;
+    P.nty = nty;
+    for (int l = 0; l < NL; ++l) {
+        P.pitch[l] = (int)align_up((size_t)maxlen[0][l], 4);
+        P.maxh[l] = maxlen[1][l];
+        P.lg_q[l] = ceil_log2(P.pitch[l] / 4);
+        if (P.lg_q[l] > 10) return false;  // more dword slots per row than the workgroup has threads
+        if (l > 0) {
+            P.tabx[l] = (int)tab_off_x[l];
+            P.taby[l] = (int)tab_off_y[l];
+            // the dword-read form of the level loop: left tap of column c + 3 at most 6 bytes past that of column c
+            const short2 *xt = tab + tab_off_x[l];
+            bool narrow = true;
+            for (int x = 0; x + 3 < g.lv[l].w && narrow; x += 4) narrow = xt[x + 3].x - xt[x].x <= 6;
+            P.narrow[l] = narrow ? 1 : 0;
+        }
+    }
+    return true;
+}
+
+// the device image of a plan (layout: afv_device.h) and the kernel's arguments / LDS size
+static void pack_pyr_fuse(const Geo &g, const short2 *tab, const std::vector<short4> &reg, const PyrFusePlan &P, std::vector<uint8_t> &blob,
+                          PyrFuseArgs &A, size_t &lds) {
+    const int NL = P.nlevels;
     std::memset(&A, 0, sizeof(A));
     A.nlevels = NL;
-    A.ntx = ntx;
-    A.nty = nty;
-    size_t off = 0;
+    A.ntx = P.ntx;
+    A.nty = P.nty;
+    A.w0 = g.width;
+    PfLevelC C[AFV_MAX_LEVELS];
+    std::memset(C, 0, sizeof(C));
+    size_t sx = 0, sy = 0;
+    for (int l = 0; l < NL; ++l) {
+        C[l].lds_pitch = P.pitch[l];
+        C[l].lg_q = P.lg_q[l];
+        C[l].narrow = P.narrow[l];
+        C[l].gpitch = g.lv[l].pitch;
+        C[l].pyr_off = g.lv[l].pyr_off;
+        C[l].fstride = g.lv[l].pyr_frame_stride;
+        C[l].x_rx = (int)sx;
+        sx += 16;
+        C[l].y_ry = (int)sy;
+        sy += 16;
+        if (l > 0) {
+            C[l].x_xt = (int)sx;
+            sx = align_up(sx + (size_t)P.pitch[l] * sizeof(short2), 16);
+            C[l].y_yt = (int)sy;
+            sy = align_up(sy + (size_t)P.maxh[l] * sizeof(short2), 16);
+        }
+    }
+    A.sx = (int)sx;
+    A.sy = (int)sy;
+    A.off_x = (int)sizeof(C);
+    A.off_y = A.off_x + (int)sx * P.ntx;
+    blob.assign((size_t)A.off_y + sy * P.nty, 0);
+    std::memcpy(blob.data(), C, sizeof(C));
+    for (int ax = 0; ax < 2; ++ax) {
+        const bool is_x = ax == 0;
+        const int nt = is_x ? P.ntx : P.nty;
+        const short4 *R = reg.data() + (is_x ? 0 : (size_t)NL * P.ntx);
+        for (int t = 0; t < nt; ++t) {
+            uint8_t *part = blob.data() + (is_x ? (size_t)A.off_x + sx * t : (size_t)A.off_y + sy * t);
+            for (int l = 0; l < NL; ++l) {
+                const short4 r = R[(size_t)l * nt + t];
+                std::memcpy(part + (is_x ? C[l].x_rx : C[l].y_ry), &r, sizeof(r));
+                if (l == 0) continue;
+                const short4 rp = R[(size_t)(l - 1) * nt + t];
+                const short2 *tb = tab + (is_x ? P.tabx[l] : P.taby[l]);
+                const int dim = is_x ? g.lv[l].w : g.lv[l].h;
+                short2 *out = reinterpret_cast<short2 *>(part + (is_x ? C[l].x_xt : C[l].y_yt));
+                for (int i = 0; i <= r.y - r.x; ++i) {
+                    short2 e{0, 0};  // columns past the level's width (dword padding): offset 0, weight 0
+                    if (r.x + i < dim) {
+                        e = tb[r.x + i];
+                        e.x = (short)(e.x - rp.x);  // relative to the source region
+                    }
+                    out[i] = e;
+                }
+            }
+        }
+    }
+    size_t off = sizeof(C);
     auto take = [&](size_t bytes) {
         const size_t o = off;
         off = align_up(off + bytes, 16);
         return (int)o;
     };
+    A.lds_x = take(sx);
+    A.lds_y = take(sy);
     size_t buf[2] = {0, 0};
-    for (int l = 0; l < NL; ++l) {
-        A.pitch[l] = (int)align_up((size_t)maxlen[0][l], 4);
-        A.lg_q[l] = ceil_log2(A.pitch[l] / 4);
-        if (A.lg_q[l] > 10) return false;  // more dword slots per row than the workgroup has threads
-        buf[l & 1] = std::max(buf[l & 1], (size_t)A.pitch[l] * maxlen[1][l]);
-        if (l > 0) {
-            A.tabx[l] = (int)tab_off_x[l];
-            A.taby[l] = (int)tab_off_y[l];
-            A.off_xt[l] = take((size_t)A.pitch[l] * sizeof(short2));
-            A.off_yt[l] = take((size_t)maxlen[1][l] * sizeof(short2));
-        }
-    }
-    A.off_buf[0] = take(buf[0]);
-    A.off_buf[1] = take(buf[1]);
-    A.off_lv = take((size_t)AFV_MAX_LEVELS * 48);
-    for (int l = 0; l < NL; ++l) {
-        A.lw[l] = g.lv[l].w;
-        A.gpitch[l] = g.lv[l].pitch;
-        A.pyr_off[l] = g.lv[l].pyr_off;
-        A.fstride[l] = g.lv[l].pyr_frame_stride;
-    }
+    for (int l = 0; l < NL; ++l) buf[l & 1] = std::max(buf[l & 1], (size_t)P.pitch[l] * P.maxh[l]);
+    A.off_buf[0] = take(buf[0] + 16);  // + slack: the dword-read form fetches up to 12 bytes past a row's last tap
+    A.off_buf[1] = take(buf[1] + 16);
     lds = off;
-    return true;
 }
-// the plan for the context's geometry; the top-level tile doubles until the region descriptors fit the kernel-argument block
-static bool build_pyr_fuse(afv_ctx *c, const Geo &g, const short2 *tab) {
+// the plan for the context's geometry
+static int build_pyr_fuse(afv_ctx *c, const Geo &g, const short2 *tab) {
     std::vector<short4> reg;
-    for (int tw = c->pf_tw, th = c->pf_th; tw <= 256; tw *= 2, th *= 2) {
-        if (!plan_pyr_fuse(g, tab, c->tab_off_x, c->tab_off_y, tw, th, reg, c->pf, c->pf_lds)) return false;
-        if (reg.size() <= PF_MAX_REG) {
-            std::memset(&c->pf_reg, 0, sizeof(c->pf_reg));
-            std::memcpy(c->pf_reg.r, reg.data(), reg.size() * sizeof(short4));
-            c->pf.tab = c->d_tab;
-            return afv_pyramid_fused_prepare(c->pf_lds) != 0;
-        }
+    PyrFusePlan P;
+    c->pf_ok = false;
+    if (!plan_pyr_fuse(g, tab, c->tab_off_x, c->tab_off_y, c->pf_tw, c->pf_th, reg, P)) return AFV_OK;
+    std::vector<uint8_t> blob;
+    pack_pyr_fuse(g, tab, reg, P, blob, c->pf, c->pf_lds);
+    if ((size_t)(sizeof(PfLevelC) * AFV_MAX_LEVELS + c->pf.sx + c->pf.sy) / 4 > 2 * 1024) return AFV_OK;  // the prologue copies <= 2 dwords per thread
+    if (!afv_pyramid_fused_prepare(c->pf_lds)) return AFV_OK;
+    if (blob.size() > c->pf_blob_cap) {
+        if (c->d_pf_blob) (void)hipFree(c->d_pf_blob);
+        c->d_pf_blob = nullptr;
+        c->pf_blob_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_pf_blob, blob.size()));
+        c->pf_blob_cap = blob.size();
     }
-    return false;
+    HIPCHK(c, hipMemcpy(c->d_pf_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    c->pf.blob = c->d_pf_blob;
+    c->pf_ok = true;
+    return AFV_OK;
 }
 
 // host-only view of the plan and of the coefficient tables (no device needed): tests/test_host_logic.py replays the one-launch pyramid
@@ -279,9 +349,12 @@ extern "C" int afv_debug_pyramid_plan(const afv_orb_params *p, int width, int he
         off += (size_t)g.lv[l].h;
     }
     std::vector<short4> reg;
-    PyrFuseArgs A;
+    PyrFusePlan A;
+    if (!plan_pyr_fuse(g, tab.data(), tox, toy, tile_w, tile_h, reg, A)) return AFV_EUNSUPPORTED;
+    std::vector<uint8_t> blob;
+    PyrFuseArgs args;
     size_t lds = 0;
-    if (!plan_pyr_fuse(g, tab.data(), tox, toy, tile_w, tile_h, reg, A, lds)) return AFV_EUNSUPPORTED;
+    pack_pyr_fuse(g, tab.data(), reg, A, blob, args, lds);
     if ((int)reg.size() * 4 > regions_cap || (tables && (int)n * 2 > tables_cap)) return AFV_ECAPACITY;
     std::memcpy(regions, reg.data(), reg.size() * sizeof(short4));
     if (tables) std::memcpy(tables, tab.data(), n * sizeof(short2));
@@ -328,7 +401,10 @@ static int set_geometry(afv_ctx *c, int w, int h) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(c->d_tab, tab.data(), off * sizeof(short2), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_geo, &g, sizeof(Geo), hipMemcpyHostToDevice));
-    c->pf_ok = build_pyr_fuse(c, g, tab.data());  // the one-launch pyramid of the small-batch path
+    {   // the one-launch pyramid of the small-batch path
+        const int rc_pf = build_pyr_fuse(c, g, tab.data());
+        if (rc_pf) return rc_pf;
+    }
     c->geo = g;
     c->geo_valid = true;
     return AFV_OK;
@@ -349,7 +425,7 @@ extern "C" void afv_destroy(afv_ctx *c) {
     afv_table_release_all(c);
     void *ptrs[] = {c->d_geo, c->d_tab, c->d_pyr, c->d_cand_packed, c->d_kept_xy, c->d_l1, c->d_l1_resp, c->d_l1_count, c->d_hq, c->d_hq_n, c->d_kept_resp,
                     c->d_kept_node, c->d_cand_count, c->d_sel_count, c->d_sel, c->d_frames, c->d_kps, c->d_desc,
-                    c->d_n, c->d_status, c->d_match, c->d_topk, c->d_slice, c->d_tickets};
+                    c->d_n, c->d_status, c->d_match, c->d_topk, c->d_slice, c->d_tickets, c->d_pf_blob};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_stage) {
@@ -476,6 +552,12 @@ extern "C" int afv_set_match_engine(afv_ctx *c, int engine) {
     return AFV_OK;
 }
 
+extern "C" int afv_set_match_resolve(afv_ctx *c, int engine) {
+    if (!c || (engine != 0 && engine != 1)) return AFV_EINVAL;
+    c->resolve_engine = engine;
+    return AFV_OK;
+}
+
 extern "C" int afv_set_small_batch_path(afv_ctx *c, int mode, int max_frames) {
     if (!c || mode < 0 || mode > 2 || max_frames < 0) return AFV_EINVAL;
     c->small_mode = mode;
@@ -573,7 +655,7 @@ static void enqueue_range(afv_ctx *c, const FrameSrc &src, int f0, int nf, afv_k
         A.n_zero = nf * AFV_MAX_LEVELS;
         A.zero_one = c->d_hq_n + f0;
         A.zero_two = clear_status ? d_status : nullptr;
-        afv_launch_pyramid_fused(&src, c->d_pyr, &A, &c->pf_reg, c->pf_lds, f0, nf, s);
+        afv_launch_pyramid_fused(&src, c->d_pyr, &A, c->pf_lds, f0, nf, s);
     } else {
         StageTimer t_(c, AFV_STAGE_PYRAMID, s, nf);
         for (int l = 1; l < g.nlevels; ++l) {
@@ -1134,7 +1216,7 @@ static int afv_match_bow_impl(afv_ctx *c, const afv_match_job *jobs, int njobs, 
                 afv_launch_match_topk(c->d_match + desc_off, np_, cap, pa_, pb_, i1 - i0, c->d_match + topk_off, i0, c->match_engine, nslices, c->d_slice, c->d_tickets, c->stream);
                 afv_launch_match_resolve(c->d_match + desc_off, angp, 1, np_, cap, pa_, pb_, i1 - i0, jobs[i0].th_low, jobs[i0].nnratio,
                                          jobs[i0].check_orientation != 0, reinterpret_cast<int *>(c->d_match + match_off),
-                                         reinterpret_cast<int *>(c->d_match + nm_off), c->d_match + topk_off, i0, c->stream);
+                                         reinterpret_cast<int *>(c->d_match + nm_off), c->d_match + topk_off, i0, c->resolve_engine, c->stream);
                 i0 = i1;
             }
             HIPCHK(c, hipGetLastError());
@@ -1318,7 +1400,7 @@ int afv_match_pairs_core(afv_ctx *c, const uint8_t *d_desc, const float *d_ang, 
             }
             StageTimer t_(c, AFV_STAGE_MATCH_RESOLVE, ks, e0 - b0);
             afv_launch_match_resolve(d_desc, d_ang, ang_stride, d_n, cap, d_pair_a, d_pair_b, e0 - b0, th_low, nnratio, check_orientation,
-                                     d_match, d_nmatches, c->d_topk, b0, ks);
+                                     d_match, d_nmatches, c->d_topk, b0, c->resolve_engine, ks);
         }
         HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0));
@@ -1329,7 +1411,7 @@ int afv_match_pairs_core(afv_ctx *c, const uint8_t *d_desc, const float *d_ang, 
         }
         StageTimer t_(c, AFV_STAGE_MATCH_RESOLVE, s, npairs);
         afv_launch_match_resolve(d_desc, d_ang, ang_stride, d_n, cap, d_pair_a, d_pair_b, npairs, th_low, nnratio, check_orientation, d_match,
-                                 d_nmatches, c->d_topk, 0, s);
+                                 d_nmatches, c->d_topk, 0, c->resolve_engine, s);
     }
     HIPCHK(c, hipGetLastError());
     return AFV_OK;

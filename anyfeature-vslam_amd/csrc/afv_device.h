@@ -78,26 +78,33 @@ struct SelPoint {  // quadtree survivor, level coordinates
     float response;
 };
 
-// arguments of k_pyramid_fused (k_pyramid.hip: the whole pyramid of a frame in one launch); filled by afv_api.hip: plan_pyr_fuse
-#define PF_MAX_REG 416  // region descriptors that ride in the kernel arguments: nlevels * (ntx + nty) <= PF_MAX_REG (3.3 KB of the 4 KB block)
-struct PyrFuseRegions {  // [nlevels][ntx] then [nlevels][nty]: (need.lo, need.hi inclusive, own.lo, own.hi exclusive) per tile index; level 0: the source window
-    short4 r[PF_MAX_REG];
+// ---- k_pyramid_fused (k_pyramid.hip: the whole pyramid of a frame in one launch); plan and device image: afv_api.hip ----
+// The work plan lives in ONE device buffer ("blob"), written once per geometry, laid out so that a workgroup's share is a flat copy into
+// LDS: [common: one PfLevelC per level][x part of tile column 0][x part of tile column 1] ... [y part of tile row 0] ...
+// x part of tile column tx = per level the region descriptor (need.lo, need.hi inclusive, own.lo, own.hi exclusive; level 0: the source
+// window) and the level's coefficient-table slice with offsets already relative to the source region; y part likewise.
+struct PfLevelC {
+    int lds_pitch, lg_q, narrow, gpitch;      // LDS row pitch of the region, log2 dword slots per row, dword-read form allowed, pitch in memory
+    unsigned long long pyr_off, fstride;      // level image of frame f = pyramid buffer + pyr_off + f * fstride
+    int x_rx, x_xt, y_ry, y_yt;               // byte offsets inside the x / y part: region descriptor, table slice
 };
 struct PyrFuseArgs {
-    const short2 *tab;          // resize tables of all levels (afv_ctx::d_tab)
-    int tabx[AFV_MAX_LEVELS], taby[AFV_MAX_LEVELS];  // element offset of level l's x / y table in `tab`
-    int pitch[AFV_MAX_LEVELS];  // LDS row pitch of level l's region (bytes, multiple of 4; level 0 = the source window)
-    int lg_q[AFV_MAX_LEVELS];   // log2 of the DWORD slots per row of level l (power of two >= pitch / 4)
-    int off_xt[AFV_MAX_LEVELS], off_yt[AFV_MAX_LEVELS];  // LDS byte offsets of the staged tables
-    int off_buf[2];             // LDS byte offsets of the two region buffers (level parity)
-    int off_lv;                 // LDS byte offset of the per-level descriptors the prologue parks for the level loop
+    const uint8_t *blob;
     int nlevels, ntx, nty;
-    // level geometry (a copy of what Geo holds: the kernel reads nothing but its arguments through the scalar cache)
-    int lw[AFV_MAX_LEVELS], gpitch[AFV_MAX_LEVELS];
-    unsigned long long pyr_off[AFV_MAX_LEVELS], fstride[AFV_MAX_LEVELS];
-    int *zero_counts;           // as in ResizeTab: the candidate / queue counters of the frame range are cleared here
+    int sx, sy;              // bytes of one x / y part (multiples of 16)
+    int off_x, off_y;        // byte offsets of the first x / y part inside the blob
+    int lds_x, lds_y;        // LDS byte offsets of the parked x / y part (the common part sits at 0)
+    int off_buf[2];          // LDS byte offsets of the two region buffers (level parity)
+    int w0;                  // level-0 width
+    int *zero_counts;        // as in ResizeTab: the candidate / queue counters of the frame range are cleared here
     int n_zero;
     int *zero_one, *zero_two;
+};
+// host view of the plan (tests replay it on the CPU: afv_debug_pyramid_plan)
+struct PyrFusePlan {
+    int nlevels, ntx, nty;
+    int pitch[AFV_MAX_LEVELS], lg_q[AFV_MAX_LEVELS], narrow[AFV_MAX_LEVELS], maxh[AFV_MAX_LEVELS];
+    int tabx[AFV_MAX_LEVELS], taby[AFV_MAX_LEVELS];
 };
 
 // XCD-aware block -> work-item mapping (cdna_hip_programming.md T1): hardware places linear block b on XCD b % 8, each

@@ -20,8 +20,8 @@ extern "C" void afv_launch_resize(const uint8_t *src, int sw, int sh, int spitch
                                   int dpitch, size_t dframe, const short2 *xt, const short2 *yt, int frame_base, int nframes, int *zero_counts,
                                   int n_zero, int *zero_one, hipStream_t stream);
 extern "C" int afv_resize_window_ok(int sw, int sh, int dw, int dh);
-extern "C" void afv_launch_pyramid_fused(const FrameSrc *src0, uint8_t *pyr, const PyrFuseArgs *args, const PyrFuseRegions *regions,
-                                         size_t lds_bytes, int frame_base, int nframes, hipStream_t stream);
+extern "C" void afv_launch_pyramid_fused(const FrameSrc *src0, uint8_t *pyr, const PyrFuseArgs *args, size_t lds_bytes, int frame_base, int nframes,
+                                         hipStream_t stream);
 extern "C" int afv_pyramid_fused_prepare(size_t lds_bytes);
 extern "C" void afv_launch_fast_nms(const Geo *geo, int total_tiles, const FrameSrc *src0, const uint8_t *pyr, uint32_t *cand_packed,
                                     int *cand_count, int frame_base, int nframes, hipStream_t stream);
@@ -62,7 +62,7 @@ extern "C" void afv_launch_match_topk(const uint8_t *desc, const int *nset, int 
                                       hipStream_t stream);
 extern "C" void afv_launch_match_resolve(const uint8_t *desc, const float *ang, int ang_stride, const int *nset, int cap, const int *pa,
                                          const int *pb, int npairs, float th, float ratio, int check_ori, int *match, int *nmatches,
-                                         const void *topk_scratch, int pair_base, hipStream_t stream);
+                                         const void *topk_scratch, int pair_base, int engine, hipStream_t stream);
 extern "C" void afv_launch_match_tri(const DevTriJob *jobs, int njobs, int max_n1, hipStream_t stream);
 extern "C" void afv_launch_match_l2(const float *d1, int n1, const float *d2, int n2, int dim, const uint8_t *v1,
                                     const uint8_t *v2, float th, float ratio, int *out, int *nmatches, hipStream_t stream);
@@ -113,15 +113,18 @@ struct afv_ctx {
     int pipe_ahead = 8;                                        // uploads run this many chunks ahead of the compute
     int split_min_frames = 64;     // batches of at least this many frames / pairs are split over the two streams
     int match_engine = AFV_MATCH_ENGINE_MFMA;  // phase 1 of the brute-force pair matcher; afv_set_match_engine
+    int resolve_engine = 1;        // phase 2: 0 = ordered walk on one wavefront (64-row rounds), 1 = workgroup-wide fixed point; afv_set_match_resolve
     int split_chunks = 0;          // ... into this many chunks (alternating streams); 0 = about 85 frames each; afv_set_split_chunks
     // small-batch ("latency") path: kernels shaped for one or a few frames; afv_set_small_batch_path
     int small_mode = 1;            // 0 = never, 1 = batches of at most small_max_frames, 2 = always
     int small_max_frames = 4;
-    int pf_tw = 32, pf_th = 16;    // top-level tile of the one-launch pyramid (k_pyramid_fused)
+    int pf_tw = 16, pf_th = 8;     // top-level tile of the one-launch pyramid (k_pyramid_fused): 204 workgroups for one 640 x 480 frame - the
+                                   // kernel's level loop is bound by the vector ALU of the CUs it runs on (32 x 16 tiles: 54 CUs, 7.7 us of levels)
     bool pf_ok = false;            // the current geometry has a one-launch pyramid (else: level-by-level launches)
     PyrFuseArgs pf{};
     size_t pf_lds = 0;
-    PyrFuseRegions pf_reg{};       // region descriptors, [nlevels][ntx] then [nlevels][nty] (ride in the kernel arguments)
+    uint8_t *d_pf_blob = nullptr;  // device image of the plan (afv_device.h)
+    size_t pf_blob_cap = 0;
     afv_orb_params p{};
     Geo geo{};          // current geometry (host copy)
     Geo cap_geo{};      // geometry of (max_width, max_height): sizes every allocation

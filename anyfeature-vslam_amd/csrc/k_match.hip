@@ -696,7 +696,7 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve(const uint8_t *__restri
         if (lane == 0) s_t[1] = wall_clock64();
 #endif
 #ifdef AFV_RESOLVE_STATS
-        if (AFV_RESOLVE_STATS == 1 && lane == 0 && (p == 1 || p == 2)) printf("resolve pair %d: n1 %d nlive %d rounds %d passes %d rescans %d matches %d walk %lld us (prologue %lld passes %lld commit %lld rescan %lld = wait %lld scan %lld reduce %lld)\n", p, n1, nlive, st_rounds, st_iters, st_rescans, nm, (wall_clock64() - st_t0) / 100, st_pre / 100, st_pass / 100, st_commit / 100, st_resc / 100, st_r1 / 100, st_r2 / 100, st_r3 / 100);
+        if (AFV_RESOLVE_STATS == 1 && lane == 0 && p <= 2) printf("resolve pair %d: n1 %d nlive %d rounds %d passes %d rescans %d matches %d walk %lld us (prologue %lld passes %lld commit %lld rescan %lld = wait %lld scan %lld reduce %lld)\n", p, n1, nlive, st_rounds, st_iters, st_rescans, nm, (wall_clock64() - st_t0) / 100, st_pre / 100, st_pass / 100, st_commit / 100, st_resc / 100, st_r1 / 100, st_r2 / 100, st_r3 / 100);
 #endif
     }
     __syncthreads();
@@ -739,10 +739,310 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve(const uint8_t *__restri
     for (int i = tid; i < cap; i += MT) out[i] = s_out[i];  // every thread re-reads its own entries (same i -> tid mapping throughout)
     if (tid == 0) nmatches[p] = s_nm;
 #ifdef AFV_RESOLVE_STATS
-    if (AFV_RESOLVE_STATS == 2 && tid == 0 && (p == 1 || p == 2))
+    if (AFV_RESOLVE_STATS == 2 && tid == 0 && p <= 2)
         printf("resolve pair %d: whole workgroup %lld us (set-up + compaction %lld, walk %lld, histogram %lld)\n", p, (wall_clock64() - st_k0) / 100,
                (s_t[0] - st_k0) / 100, (s_t[1] - s_t[0]) / 100, (wall_clock64() - s_t[1]) / 100);
 #endif
+}
+
+// ---------------- phase 2, workgroup form (round 4): ONE fixed point over all live rows, all four wavefronts ----------------
+// k_match_resolve above walks the live rows 64 at a time on one wavefront: a pair of consecutive video frames (~900 live rows) costs
+// 15-20 rounds of ~2 us of dependent LDS round trips, and a pair of unrelated frames still 11 rounds although hardly a row matches.
+// The fixed-point argument of that walk does not need the rounds: row i's decision is a function f of the columns WANTED by the rows
+// before it, want_i = f({want_j : j < i}), so any assignment that satisfies all these equations IS the sequential outcome (induction
+// on i), and iterating "every row re-evaluates f against the current claims" reaches it after as many passes as the longest chain of
+// rows competing for a column (2..4 in practice) + 1.  Here all live rows do that at once, a thread per row (x 4 for 1000 rows):
+//   * claims live in THREE rotating LDS arrays (claim[c] = smallest live index that wants column c, by atomic min): a pass reads the
+//     array written by the previous pass, writes the next one and clears its own entries of the third - ONE barrier per pass, which
+//     also carries the "did anything change" vote;
+//   * a row whose exact keys are used up needs the exact rescan of the free columns, which is only meaningful once every row before it
+//     is final: after convergence the FIRST such row is rescanned by the whole workgroup against the claims of the rows before it,
+//     its answer is pinned, and the iteration continues (rows after it that looked at the same columns re-evaluate);
+//   * there is no matched-set bitmap: "column c is taken for row i" is claim[c] < i.
+#define RW_INF 0x7fffffff
+static inline size_t resolve_wg_lds_bytes(int cap, bool stage_cols) {
+    const size_t c = ((size_t)cap + 63) & ~(size_t)63;
+    return std::min<size_t>(c, PAIR_KEYS_LDS) * 32 /*key records*/ + 3 * c * 4 /*claims*/ + c * 4 /*matches*/ + 2 * c * 2 /*wants of the last two passes*/ +
+           c * 2 /*live*/ + c /*bin*/ + c /*flags*/ + (stage_cols ? c * 32 + 16 : 0) /*columns, 16-byte aligned*/;
+}
+
+// one row against the claims in R: the column it accepts (-1: none) and whether it needs the exact rescan.  Same decisions as the walk of
+// k_match_resolve (FeatureMatcher.cc:587-641), "taken" = claimed by an earlier live row
+__device__ __forceinline__ void resolve_eval(const int4 t4, const int4 t8, const int *R, int li, int n2, float th, float ratio, int &want, bool &rescan) {
+    const int keys[RKEYS] = {t4.x, t4.y, t4.z, t4.w, t8.x, t8.y, t8.z};
+    const int nk = min(max(t8.w, 1), RKEYS);
+    int last_key = keys[0];
+#pragma unroll
+    for (int q = 1; q < RKEYS; ++q) last_key = q < nk ? keys[q] : last_key;
+    const float last_d = (float)(last_key >> 16);  // every column outside the list is at least this far
+    int v[RKEYS], cq[RKEYS];
+    bool complete = false;  // a NO_KEY inside the exact prefix: the row has fewer than nk columns, the list is all there is
+#pragma unroll
+    for (int q = 0; q < RKEYS; ++q) {
+        const bool has = q < nk && keys[q] != NO_KEY;
+        complete = complete || (q < nk && keys[q] == NO_KEY);
+        cq[q] = has ? (keys[q] & 0xffff) : 0;
+        v[q] = has ? keys[q] : NO_KEY;
+    }
+    int cl[RKEYS], a[RKEYS];
+#pragma unroll
+    for (int q = 0; q < RKEYS; ++q) cl[q] = R[cq[q]];  // seven LDS reads in flight together
+#pragma unroll
+    for (int q = 0; q < RKEYS; ++q) a[q] = (cl[q] < li) ? NO_KEY : v[q];
+    const int best = min(min(min(a[0], a[1]), min(a[2], a[3])), min(min(a[4], a[5]), a[6]));
+#pragma unroll
+    for (int q = 0; q < RKEYS; ++q) a[q] = a[q] > best ? a[q] : NO_KEY;
+    const int second_key = min(min(min(a[0], a[1]), min(a[2], a[3])), min(min(a[4], a[5]), a[6]));
+    const int second = second_key == NO_KEY ? -1 : (second_key >> 16);
+    const bool exhausted = second < 0 && !complete;
+    const int e0 = best == NO_KEY ? -1 : (best & 0xffff);
+    int type = 0;  // 0 = no match, 1 = accept column e0, 2 = exact rescan needed
+    if (best != NO_KEY && !((float)(best >> 16) < th)) {
+        // the best free column already fails TH_LOW: final whatever happens to the set
+    } else if (exhausted && n2 > nk) {
+        if (best != NO_KEY) type = ((float)(best >> 16) < ratio * last_d) ? 1 : 2;
+        else type = (last_d < th) ? 2 : 0;
+    } else if (best != NO_KEY) {
+        const float best1 = (float)(best >> 16);
+        const float best2 = second < 0 ? 3.402823466e+38f : (float)second;
+        type = (best1 < th && best1 < ratio * best2) ? 1 : 0;  // FeatureMatcher.cc:630,632
+    }
+    want = type == 1 ? e0 : -1;
+    rescan = type == 2;
+}
+
+__global__ __launch_bounds__(MT, 2) void k_match_resolve_wg(const uint8_t *__restrict__ desc, const float *__restrict__ ang, int ang_stride,
+                                                         const int *__restrict__ nset, int cap, const int *__restrict__ pair_a,
+                                                         const int *__restrict__ pair_b, const int4 *__restrict__ topk, float th,
+                                                         float ratio, int check_ori, int *__restrict__ match,
+                                                         int *__restrict__ nmatches, int pair_base, int stage_cols) {
+    extern __shared__ __attribute__((aligned(16))) char s_dyn[];
+    const int capr = (cap + 63) & ~63;
+    int4 *s_keys = reinterpret_cast<int4 *>(s_dyn);  // key records (2 x int4) of the live rows (first PAIR_KEYS_LDS of them)
+    int *s_claim = reinterpret_cast<int *>(s_keys + 2 * min(capr, PAIR_KEYS_LDS));  // three arrays of capr
+    int *s_out = s_claim + 3 * capr;
+    short *s_w1 = reinterpret_cast<short *>(s_out + capr), *s_w2 = s_w1 + capr;  // a live row's want after the last / the last but one pass
+    unsigned short *s_live = reinterpret_cast<unsigned short *>(s_w2 + capr);
+    uint8_t *s_bin = reinterpret_cast<uint8_t *>(s_live + capr);
+    uint8_t *s_flag = s_bin + capr;  // per live row: 1 = asked for a rescan in the last pass, 2 = pinned by a rescan
+    uint32_t *s_cols = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(s_flag + capr) + 15) & ~(uintptr_t)15);
+    __shared__ int s_hist[32];
+    __shared__ int s_wave[8];
+    __shared__ int s_nm, s_drop[3], s_first, s_part[2 * (MT / 64)];
+    const int p = pair_base + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int a = pair_a[p], b = pair_b[p];
+    const int n1 = min(nset[a], cap), n2 = min(nset[b], cap);
+    const int4 *tk = topk + (size_t)p * cap * 2;
+    int *out = match + (size_t)p * cap;
+    for (int i = tid; i < capr; i += MT) s_out[i] = -1;
+    for (int i = tid; i < 3 * capr; i += MT) s_claim[i] = RW_INF;
+    if (tid < 32) s_hist[tid] = 0;
+    // rows whose best distance fails TH_LOW can never match: compact the others IN ROW ORDER, keys staged in LDS
+    int nlive = 0;
+    int4 pre4[4], pre8[4];  // the records of a thread's first four rows: one L2 round trip
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = u * MT + tid;
+        pre4[u] = make_int4(NO_KEY, NO_KEY, NO_KEY, NO_KEY);
+        pre8[u] = make_int4(NO_KEY, NO_KEY, NO_KEY, TOPK);
+        if (i < n1) {
+            pre4[u] = tk[2 * i];
+            pre8[u] = tk[2 * i + 1];
+        }
+    }
+    for (int i0 = 0; i0 < n1; i0 += MT) {
+        const int i = i0 + tid;
+        int4 t4 = make_int4(NO_KEY, NO_KEY, NO_KEY, NO_KEY), t8 = make_int4(NO_KEY, NO_KEY, NO_KEY, TOPK);
+        if (i0 < 4 * MT) {  // uniform
+            const int u = i0 / MT;
+            t4 = u == 0 ? pre4[0] : u == 1 ? pre4[1] : u == 2 ? pre4[2] : pre4[3];
+            t8 = u == 0 ? pre8[0] : u == 1 ? pre8[1] : u == 2 ? pre8[2] : pre8[3];
+        } else if (i < n1) {
+            t4 = tk[2 * i];
+            t8 = tk[2 * i + 1];
+        }
+        const bool live = t4.x != NO_KEY && (float)(t4.x >> 16) < th;
+        const unsigned long long m = __ballot(live);
+        if (lane == 0) s_wave[wv] = __popcll(m);
+        __syncthreads();
+        int off = nlive;
+        for (int w = 0; w < wv; ++w) off += s_wave[w];
+        if (live) {
+            const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
+            s_live[slot] = (unsigned short)i;
+            s_w1[slot] = -1;
+            s_w2[slot] = -1;
+            s_flag[slot] = 0;
+            if (slot < PAIR_KEYS_LDS) {
+                s_keys[2 * slot] = t4;
+                s_keys[2 * slot + 1] = t8;
+            }
+        }
+        nlive += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    const uint32_t *d1 = reinterpret_cast<const uint32_t *>(desc + (size_t)a * cap * 32);
+    const uint32_t *d2 = reinterpret_cast<const uint32_t *>(desc + (size_t)b * cap * 32);
+    // ---- the fixed point ----
+    bool cols_ready = false;
+    int pass = 0;
+    const int pass_limit = 3 * nlive + 64;  // every pass finalises at least one more row or rescans one: a guard, never reached
+    while (nlive > 0 && pass < pass_limit) {
+        int *R = s_claim + (pass % 3) * capr, *W = s_claim + ((pass + 1) % 3) * capr, *Z = s_claim + ((pass + 2) % 3) * capr;
+        bool changed = false;
+        for (int li = tid; li < nlive; li += MT) {
+            const int w1 = s_w1[li], w2 = s_w2[li];
+            const int flag = s_flag[li];
+            int want = 0;
+            bool rescan = false;
+            if (flag & 2) {
+                want = s_out[s_live[li]];  // pinned by its rescan: the row asserts that answer in every pass
+            } else {
+                int4 t4, t8;
+                if (li < PAIR_KEYS_LDS) {
+                    t4 = s_keys[2 * li];
+                    t8 = s_keys[2 * li + 1];
+                } else {
+                    const int row = s_live[li];
+                    t4 = tk[2 * row];
+                    t8 = tk[2 * row + 1];
+                }
+                resolve_eval(t4, t8, R, li, n2, th, ratio, want, rescan);
+                s_flag[li] = rescan ? 1 : 0;
+            }
+            if (want >= 0) atomicMin(&W[want], li);
+            if (w2 >= 0) Z[w2] = RW_INF;  // what this row put into Z two passes ago (every row that did clears it: the array is empty before it is written again)
+            s_w2[li] = (short)w1;
+            s_w1[li] = (short)want;
+            changed = changed || want != w1 || (rescan != ((flag & 1) != 0));
+        }
+        ++pass;
+        if (__syncthreads_or(changed ? 1 : 0)) continue;
+        // converged: W holds the claims of the final wants (so far).  First row that asked for a rescan?
+        if (tid == 0) s_first = RW_INF;
+        __syncthreads();
+        {
+            int mine = RW_INF;
+            for (int li = tid; li < nlive; li += MT)
+                if ((s_flag[li] & 3) == 1) mine = min(mine, li);
+            if (mine != RW_INF) atomicMin(&s_first, mine);
+        }
+        __syncthreads();
+        const int r = s_first;
+        if (r == RW_INF) break;
+        // exact rescan of live row r over the columns no EARLIER row claims (every row before r is final: none of them waits for a rescan)
+        const int rrow = s_live[r];
+        if (stage_cols && !cols_ready) {  // first rescan of this pair: park the column descriptors in LDS
+            const uint4 *gc = reinterpret_cast<const uint4 *>(d2);
+            uint4 *sc = reinterpret_cast<uint4 *>(s_cols);
+            for (int i = tid; i < n2 * 2; i += MT) sc[i] = gc[i];
+            cols_ready = true;
+            __syncthreads();
+        }
+        const uint4 *cb = (stage_cols && cols_ready) ? reinterpret_cast<const uint4 *>(s_cols) : reinterpret_cast<const uint4 *>(d2);
+        const uint4 *qp = reinterpret_cast<const uint4 *>(d1 + (size_t)rrow * 8);
+        const uint4 qlo = qp[0], qhi = qp[1];
+        const uint32_t q[8] = {qlo.x, qlo.y, qlo.z, qlo.w, qhi.x, qhi.y, qhi.z, qhi.w};
+        int k = NO_KEY, s2nd = NO_KEY >> 16;
+        for (int c0 = tid; c0 < n2; c0 += 4 * MT) {
+            uint4 lo[4], hi[4];
+            int cl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = min(c0 + MT * u, n2 - 1);
+                lo[u] = cb[2 * c];
+                hi[u] = cb[2 * c + 1];
+                cl[u] = W[c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + MT * u;
+                const int d = __popc(q[0] ^ lo[u].x) + __popc(q[1] ^ lo[u].y) + __popc(q[2] ^ lo[u].z) + __popc(q[3] ^ lo[u].w) +
+                              __popc(q[4] ^ hi[u].x) + __popc(q[5] ^ hi[u].y) + __popc(q[6] ^ hi[u].z) + __popc(q[7] ^ hi[u].w);
+                const bool usable = c < n2 && !(cl[u] < r);
+                const int key = usable ? ((d << 16) | c) : NO_KEY;
+                s2nd = min(s2nd, max(k, key) >> 16);
+                k = min(k, key);
+            }
+        }
+        wave_merge_best(k, s2nd);
+        if (lane == 0) {
+            s_part[2 * wv] = k;
+            s_part[2 * wv + 1] = s2nd;
+        }
+        __syncthreads();
+        int K = s_part[0], S2 = s_part[1];
+#pragma unroll
+        for (int w = 1; w < MT / 64; ++w) merge_best(K, S2, s_part[2 * w], s_part[2 * w + 1]);
+        int wr = -1;
+        if (K != NO_KEY) {
+            const float best1 = (float)(K >> 16);
+            const float best2 = (S2 == (NO_KEY >> 16)) ? 3.402823466e+38f : (float)S2;
+            if (best1 < th && best1 < ratio * best2) wr = K & 0xffff;
+        }
+        if (tid == 0) {
+            // pinned: the answer is parked where it ends up anyway.  The row's want so far was -1 (a row that asks for a rescan accepts
+            // nothing): if it now takes a column, the next pass sees its want change, claims the column, and the rows behind it
+            // re-evaluate until nothing changes again; if it takes none, the next pass changes nothing and the search goes on to
+            // the next waiting row.
+            s_flag[r] = 2;
+            s_out[rrow] = wr;
+        }
+        __syncthreads();
+    }
+    // ---- matches, count ----
+    {
+        int cnt = 0;
+        for (int li = tid; li < nlive; li += MT) {
+            const int w = s_w1[li];
+            if (w >= 0) {
+                s_out[s_live[li]] = w;
+                ++cnt;
+            }
+        }
+        if (tid == 0) s_nm = 0;
+        __syncthreads();
+        cnt = afv_wave_incl_scan(cnt);
+        if (lane == 63 && cnt) atomicAdd(&s_nm, cnt);
+        __syncthreads();
+    }
+    if (check_ori) {
+        // rotation histogram of the accepted matches (FeatureMatcher.cc:1587-1599): it never influences the walk
+        for (int i = tid; i < n1; i += MT) {
+            const int c = s_out[i];
+            if (c >= 0) {
+                const int bin = rotation_bin(ang[((size_t)a * cap + i) * ang_stride], ang[((size_t)b * cap + c) * ang_stride]);
+                s_bin[i] = (uint8_t)bin;
+                atomicAdd(&s_hist[bin], 1);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {  // computeThreeMaxima (FeatureMatcher.cc:1631-1668)
+            int i1 = -1, i2 = -1, i3 = -1, max1 = 0, max2 = 0, max3 = 0;
+            for (int i = 0; i < 30; ++i) {
+                const int sz = s_hist[i];
+                if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; i3 = i2; i2 = i1; i1 = i; }
+                else if (sz > max2) { max3 = max2; max2 = sz; i3 = i2; i2 = i; }
+                else if (sz > max3) { max3 = sz; i3 = i; }
+            }
+            if ((float)max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+            else if ((float)max3 < 0.1f * (float)max1) { i3 = -1; }
+            s_drop[0] = i1; s_drop[1] = i2; s_drop[2] = i3;
+        }
+        __syncthreads();
+        const int i1 = s_drop[0], i2 = s_drop[1], i3 = s_drop[2];
+        int dropped = 0;
+        for (int i = tid; i < n1; i += MT) {
+            if (s_out[i] >= 0) {
+                const int bb = s_bin[i];
+                if (bb != i1 && bb != i2 && bb != i3) { s_out[i] = -1; ++dropped; }
+            }
+        }
+        if (dropped) atomicSub(&s_nm, dropped);
+        __syncthreads();
+    }
+    for (int i = tid; i < cap; i += MT) out[i] = s_out[i];
+    if (tid == 0) nmatches[p] = s_nm;
 }
 
 // ---------------- M4: SearchForTriangulation ----------------
@@ -911,8 +1211,22 @@ extern "C" void afv_launch_match_topk(const uint8_t *desc, const int *nset, int 
 // ang: keypoint angles in degrees, element (set, i) at ang[(set * cap + i) * ang_stride] (stride 7 = afv_keypoint::angle)
 extern "C" void afv_launch_match_resolve(const uint8_t *desc, const float *ang, int ang_stride, const int *nset, int cap, const int *pa,
                                          const int *pb, int npairs, float th, float ratio, int check_ori, int *match, int *nmatches,
-                                         const void *topk_scratch, int pair_base, hipStream_t stream) {
+                                         const void *topk_scratch, int pair_base, int engine, hipStream_t stream) {
     const int4 *topk = reinterpret_cast<const int4 *>(topk_scratch);
+    if (engine == 1) {  // workgroup-wide fixed point (round 4); columns are parked in LDS only for batches, and only once a pair needs a rescan
+        const bool stage = cap <= PAIR_COLS_LDS && npairs > 8;
+        const size_t lds_wg = resolve_wg_lds_bytes(cap, stage);
+        static bool done_wg[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (lds_wg > 48 * 1024 && dev >= 0 && dev < 64 && !done_wg[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_match_resolve_wg), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            done_wg[dev] = true;
+        }
+        hipLaunchKernelGGL(k_match_resolve_wg, dim3(npairs), dim3(MT), lds_wg, stream, desc, ang, ang_stride, nset, cap, pa, pb, topk, th, ratio,
+                           check_ori, match, nmatches, pair_base, stage ? 1 : 0);
+        return;
+    }
     // the column descriptors ride in LDS (for the exact rescans) when they fit and the launch is a batch; a handful of pairs (the
     // single-frame plugin path) runs leaner: 39 KB instead of 71 KB, rescans through L2
     const bool stage_cols = cap <= PAIR_COLS_LDS && npairs > 8;

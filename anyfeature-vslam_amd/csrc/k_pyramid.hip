@@ -191,38 +191,31 @@ extern "C" void afv_launch_resize(const uint8_t *src, int sw, int sh, int spitch
 // few hundred nanoseconds of the chip: what is paid is seven kernel ramps and seven cache write-back / invalidate boundaries.  Here
 // one workgroup owns one tile of the TOP level and computes, level by level, everything that tile depends on: its regions of levels
 // 1 .. L live in LDS (ping-pong), only level 0 is read from memory.  Neighbouring workgroups recompute the overlap of their regions
-// (a halo of ~2 px per level: 1.7x the pixels at a 32x16 top tile) instead of waiting for each other - no workgroup ever
-// reads what another one wrote, so there is no hand-off at all.  Every pixel is produced by the same two expressions as in
-// k_resize_level from the same source pixels, so the levels are bit-identical whichever workgroup writes them: level l is
-// partitioned into OWNED rectangles (own_l(t) = [off_(l+1)[own_(l+1)(t).lo], off_(l+1)[own_(l+1)(t + 1).lo)): monotone tables make
-// them a disjoint cover) and a workgroup stores exactly its rectangle, widened to whole dwords - two workgroups may store the same
-// dword, with the same bytes.  Region bookkeeping (per level and tile index: needed range, owned range) is host work, done once per
-// geometry (afv_api.hip: plan_pyr_fuse) and handed over IN THE KERNEL ARGUMENTS: the region descriptors arrive by scalar loads, so the
-// kernel's only global round trip is the one that fetches its level-0 window and its slices of the coefficient tables.
-// Latency shape: one barrier per level.  A thread owns four consecutive columns (their x coefficients stay in registers for the
-// level) and walks down the rows; an output dword is evaluated directly from its 2 x 8 source bytes (horizontal blend of the two source
-// rows on packed column pairs, vertical blend by v_dot2 - the separable form of k_resize_level would save a third of the LDS reads
-// and cost a second barrier and two more dependent LDS round trips per level).
+// (a halo of ~2 px per level) instead of waiting for each other - no workgroup ever reads what another one wrote, so there is no
+// hand-off at all.  Every pixel is produced by the same two expressions as in k_resize_level from the same source pixels, so the
+// levels are bit-identical whichever workgroup writes them: level l is partitioned into OWNED rectangles (own_l(t) =
+// [off_(l+1)[own_(l+1)(t).lo], off_(l+1)[own_(l+1)(t + 1).lo)): monotone tables make them a disjoint cover) and a workgroup stores
+// exactly its rectangle, widened to whole dwords - two workgroups may store the same dword, with the same bytes.
+// Latency shape (round 4, measured with -DAFV_PF_STATS; the first form took 16 us):
+//   * the plan is a device blob laid out for a flat copy (afv_device.h): a workgroup's prologue is TWO scalar loads (its level-0
+//     window) and ONE round of vector loads (its share of the blob + the window), nothing else is fetched through the scalar cache -
+//     per-level scalar loads (kernel arguments, geometry) each cost an exposed miss and serialise behind LDS traffic (one counter);
+//   * one barrier per level, and it waits for LDS only: __syncthreads() also drains the level's global stores (0.5 us per level);
+//   * a thread owns four consecutive columns (their x coefficients stay in registers for the level) and walks down the rows; an
+//     output dword is evaluated directly from its 2 x 8 source bytes, fetched as three aligned dwords per source row;
+//   * 16 x 8 top tiles: 204 workgroups for a 640 x 480 frame - the level loop is bound by the vector ALU of the CUs it runs on.
 
 #define PF_T 1024
+#define PF_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-// what the level loop needs about one level, parked in LDS by the prologue: inside the loop (run-time level index) nothing is fetched
-// through the scalar cache any more - with the region descriptors and the level geometry read there, every level paid two or three
-// exposed scalar-load misses (kernel arguments / geometry: a new cache line per level), 10 of the kernel's 16 us
-struct PfLevel {
-    short4 rx, ry;                // region of this workgroup at the level (need.lo, need.hi, own.lo, own.hi)
-    int lds_pitch, lg_q, off_xt, off_yt;
-    int gpitch, pad;              // row pitch of the level image in memory
-    unsigned long long dst_off;   // byte offset of this frame's level image in the pyramid buffer
-};
-
-static_assert(sizeof(PfLevel) == 48, "afv_api.hip reserves 48 bytes of LDS per level");
-static_assert(sizeof(PyrFuseArgs) + sizeof(PyrFuseRegions) + sizeof(FrameSrc) + 32 <= 4096, "kernel argument block");
-
-__global__ __launch_bounds__(PF_T) void k_pyramid_fused(FrameSrc src0, uint8_t *__restrict__ pyr, PyrFuseArgs A, PyrFuseRegions R, int frame_base,
-                                                        int total_blocks) {
+__global__ __launch_bounds__(PF_T) void k_pyramid_fused(FrameSrc src0, uint8_t *__restrict__ pyr, PyrFuseArgs A, int frame_base, int total_blocks) {
     extern __shared__ __attribute__((aligned(16))) uint8_t pf_smem[];
     const int tid = threadIdx.x;
+#ifdef AFV_PF_STATS
+    long long st[12];
+    int sti = 0;
+    st[sti++] = wall_clock64();
+#endif
     if (blockIdx.x == 0) {
         if (A.zero_counts)
             for (int i = tid; i < A.n_zero; i += PF_T) A.zero_counts[i] = 0;
@@ -235,55 +228,30 @@ __global__ __launch_bounds__(PF_T) void k_pyramid_fused(FrameSrc src0, uint8_t *
     const int fl = work / per_frame, t = work - fl * per_frame, ty = t / A.ntx, tx = t - ty * A.ntx;
     const int f = frame_base + fl;
     const int NL = A.nlevels;
-    const short4 *Rx = R.r + tx, *Ry = R.r + NL * A.ntx + ty;  // level l: Rx[l * ntx], Ry[l * nty] (uniform: scalar loads from the argument block)
-    PfLevel *s_lv = reinterpret_cast<PfLevel *>(pf_smem + A.off_lv);
-    // Prologue, unrolled over the levels (compile-time level index: the scalar loads of all levels are independent and issued together).
-    // Per level: park its descriptor in LDS; fetch this thread's entry of the level's coefficient-table slices (a thread owns at most
-    // one entry per level: region width + height <= 1024).  ALL global loads of the kernel - the table entries and the level-0
-    // window - are issued before the first LDS store of loaded data: one round trip.
-    short2 te[AFV_MAX_LEVELS];
-    short4 rxs[AFV_MAX_LEVELS], rys[AFV_MAX_LEVELS];
-    bool fallback = false;  // a region wider + taller than the workgroup (not at any supported geometry): plain loop
+    const uint8_t *bx = A.blob + A.off_x + (size_t)tx * A.sx, *by = A.blob + A.off_y + (size_t)ty * A.sy;
+    // the level-0 window of this tile (the first 8 bytes of its x / y part): uniform addresses -> two scalar loads
+    const short4 rx0 = *reinterpret_cast<const short4 *>(bx), ry0 = *reinterpret_cast<const short4 *>(by);
+    // flat copy of [common | x part | y part] into LDS, <= 2 dwords per thread, and up to PF_W0 dwords of the window: every global load of
+    // the kernel is issued here, before the first LDS store
+    constexpr int NC = (int)(sizeof(PfLevelC) * AFV_MAX_LEVELS / 4);
+    const int nX = A.sx >> 2, nY = A.sy >> 2;
+    uint32_t cpv[2];
 #pragma unroll
-    for (int l = 0; l < AFV_MAX_LEVELS; ++l) {
-        te[l].x = 0;
-        te[l].y = 0;
-        rxs[l] = short4{0, 0, 0, 0};
-        rys[l] = short4{0, 0, 0, 0};
-        if (l < NL) {
-            const short4 rx = Rx[l * A.ntx], ry = Ry[l * A.nty];
-            rxs[l] = rx;
-            rys[l] = ry;
-            if (tid == l) {
-                PfLevel v;
-                v.rx = rx;
-                v.ry = ry;
-                v.lds_pitch = A.pitch[l];
-                v.lg_q = A.lg_q[l];
-                v.off_xt = A.off_xt[l];
-                v.off_yt = A.off_yt[l];
-                v.gpitch = A.gpitch[l];
-                v.pad = 0;
-                v.dst_off = (unsigned long long)A.pyr_off[l] + (unsigned long long)f * A.fstride[l];
-                s_lv[l] = v;
-            }
-            if (l > 0) {
-                const int nxe = rx.y - rx.x + 1, nye = ry.y - ry.x + 1;
-                fallback = fallback || nxe + nye > PF_T;
-                if (tid < nxe) {
-                    if (rx.x + tid < A.lw[l]) te[l] = A.tab[A.tabx[l] + rx.x + tid];  // columns past the level's width (dword padding): offset 0, weight 0
-                } else if (tid < nxe + nye) {
-                    te[l] = A.tab[A.taby[l] + ry.x + (tid - nxe)];
-                }
-            }
-        }
+    for (int k = 0; k < 2; ++k) {
+        const int i = tid + k * PF_T;
+        cpv[k] = 0;
+        if (i < NC) cpv[k] = reinterpret_cast<const uint32_t *>(A.blob)[i];
+        else if (i < NC + nX) cpv[k] = reinterpret_cast<const uint32_t *>(bx)[i - NC];
+        else if (i < NC + nX + nY) cpv[k] = reinterpret_cast<const uint32_t *>(by)[i - NC - nX];
     }
-    // ... and up to PF_W0 dwords of the level-0 window
     constexpr int PF_W0 = 8;
     uint32_t w0v[PF_W0];
-    const short4 rx0 = rxs[0], ry0 = rys[0];
     const uint8_t *img = src0.base + (size_t)f * src0.frame_stride;
-    const int lg0 = A.lg_q[0], ndw0 = (rx0.y - rx0.x + 4) >> 2, nrows0 = ry0.y - ry0.x + 1;
+    const PfLevelC *s_C = reinterpret_cast<const PfLevelC *>(pf_smem);
+    const int pitch0 = (rx0.y - rx0.x + 4) & ~3;  // level 0 keeps the window's own dword-rounded width as its LDS pitch
+    int lg0 = 0;
+    while ((4 << lg0) < pitch0) ++lg0;           // uniform: a handful of scalar steps
+    const int ndw0 = pitch0 >> 2, nrows0 = ry0.y - ry0.x + 1;
     const int q0 = tid & ((1 << lg0) - 1), gx0 = rx0.x + 4 * q0, rstep0 = PF_T >> lg0;
     const bool dw_ok0 = gx0 + 3 < src0.stride;
 #pragma unroll
@@ -296,51 +264,26 @@ __global__ __launch_bounds__(PF_T) void k_pyramid_fused(FrameSrc src0, uint8_t *
                 w0v[k] = *reinterpret_cast<const uint32_t *>(p);
             } else {
                 for (int b = 0; b < 4; ++b)
-                    if (gx0 + b < A.lw[0]) w0v[k] |= (uint32_t)p[b] << (8 * b);
+                    if (gx0 + b < A.w0) w0v[k] |= (uint32_t)p[b] << (8 * b);
             }
         }
     }
+#ifdef AFV_PF_STATS
+    st[sti++] = wall_clock64();
+#endif
 #pragma unroll
-    for (int l = 1; l < AFV_MAX_LEVELS; ++l) {
-        if (l < NL) {
-            const short4 rx = rxs[l], rxp = rxs[l - 1], ry = rys[l], ryp = rys[l - 1];
-            short2 *xt = reinterpret_cast<short2 *>(pf_smem + A.off_xt[l]), *yt = reinterpret_cast<short2 *>(pf_smem + A.off_yt[l]);
-            const int nxe = rx.y - rx.x + 1, nye = ry.y - ry.x + 1;
-            short2 e = te[l];
-            if (tid < nxe) {
-                if (rx.x + tid < A.lw[l]) e.x = (short)(e.x - rxp.x);
-                xt[tid] = e;
-            } else if (tid < nxe + nye) {
-                e.x = (short)(e.x - ryp.x);
-                yt[tid - nxe] = e;
-            }
-            if (fallback) {
-                for (int i = tid + PF_T; i < nxe + nye; i += PF_T) {
-                    short2 g;
-                    g.x = 0;
-                    g.y = 0;
-                    if (i < nxe) {
-                        if (rx.x + i < A.lw[l]) {
-                            g = A.tab[A.tabx[l] + rx.x + i];
-                            g.x = (short)(g.x - rxp.x);
-                        }
-                        xt[i] = g;
-                    } else {
-                        g = A.tab[A.taby[l] + ry.x + (i - nxe)];
-                        g.x = (short)(g.x - ryp.x);
-                        yt[i - nxe] = g;
-                    }
-                }
-            }
-        }
+    for (int k = 0; k < 2; ++k) {
+        const int i = tid + k * PF_T;
+        if (i < NC) reinterpret_cast<uint32_t *>(pf_smem)[i] = cpv[k];
+        else if (i < NC + nX) reinterpret_cast<uint32_t *>(pf_smem + A.lds_x)[i - NC] = cpv[k];
+        else if (i < NC + nX + nY) reinterpret_cast<uint32_t *>(pf_smem + A.lds_y)[i - NC - nX] = cpv[k];
     }
     {
         uint8_t *S = pf_smem + A.off_buf[0];
-        const int sp = A.pitch[0];
 #pragma unroll
         for (int k = 0; k < PF_W0; ++k) {
             const int r = (tid >> lg0) + k * rstep0;
-            if (q0 < ndw0 && r < nrows0) *reinterpret_cast<uint32_t *>(S + r * sp + 4 * q0) = w0v[k];
+            if (q0 < ndw0 && r < nrows0) *reinterpret_cast<uint32_t *>(S + r * pitch0 + 4 * q0) = w0v[k];
         }
         for (int r = (tid >> lg0) + PF_W0 * rstep0; r < nrows0; r += rstep0) {  // windows taller than PF_W0 row groups
             if (q0 < ndw0) {
@@ -350,33 +293,37 @@ __global__ __launch_bounds__(PF_T) void k_pyramid_fused(FrameSrc src0, uint8_t *
                     v = *reinterpret_cast<const uint32_t *>(p);
                 } else {
                     for (int b = 0; b < 4; ++b)
-                        if (gx0 + b < A.lw[0]) v |= (uint32_t)p[b] << (8 * b);
+                        if (gx0 + b < A.w0) v |= (uint32_t)p[b] << (8 * b);
                 }
-                *reinterpret_cast<uint32_t *>(S + r * sp + 4 * q0) = v;
+                *reinterpret_cast<uint32_t *>(S + r * pitch0 + 4 * q0) = v;
             }
         }
     }
-    __syncthreads();
     const int buf0 = A.off_buf[0], buf1 = A.off_buf[1];
-    PfLevel vp = s_lv[0];
+    const uint8_t *s_X = pf_smem + A.lds_x, *s_Y = pf_smem + A.lds_y;
+    PF_LDS_BARRIER();
+#ifdef AFV_PF_STATS
+    st[sti++] = wall_clock64();
+#endif
+    short4 rxp = rx0, ryp = ry0;
+    int sp = pitch0;
     for (int l = 1; l < NL; ++l) {
-        const PfLevel v = s_lv[l];
-        const short4 rx = v.rx, ry = v.ry, rxp = vp.rx, ryp = vp.ry;
+        const PfLevelC v = s_C[l];
+        const short4 rx = *reinterpret_cast<const short4 *>(s_X + v.x_rx), ry = *reinterpret_cast<const short4 *>(s_Y + v.y_ry);
         const uint8_t *S = pf_smem + ((l & 1) ? buf0 : buf1);
         uint8_t *D = pf_smem + ((l & 1) ? buf1 : buf0);
-        const short2 *xt = reinterpret_cast<const short2 *>(pf_smem + v.off_xt), *yt = reinterpret_cast<const short2 *>(pf_smem + v.off_yt);
-        const int sp = vp.lds_pitch, dp = v.lds_pitch, lgq = v.lg_q;
+        const short2 *xt = reinterpret_cast<const short2 *>(s_X + v.x_xt), *yt = reinterpret_cast<const short2 *>(s_Y + v.y_yt);
+        const int dp = v.lds_pitch, lgq = v.lg_q;
         const int sw = rxp.y - rxp.x + 1, sh = ryp.y - ryp.x + 1;  // source region
         const int dwp = rx.y - rx.x + 1, dh = ry.y - ry.x + 1;     // this level's region (width a multiple of 4)
         const int cq = tid & ((1 << lgq) - 1);
-        if (4 * cq < dwp) {
-            uint8_t *dst = pyr + v.dst_off;
+        if (4 * cq < dwp && (tid >> lgq) < dh) {
+            uint8_t *dst = pyr + v.pyr_off + (unsigned long long)f * v.fstride;
             const int gpitch = v.gpitch;
             const int gx = rx.x + 4 * cq;
             const bool own_x = gx >= (rx.z & ~3) && gx < rx.w;  // owned columns [own.lo & ~3, align4(own.hi)): whole dwords
             const uint2 xe = *reinterpret_cast<const uint2 *>(xt + 4 * cq), xf = *reinterpret_cast<const uint2 *>(xt + 4 * cq + 2);  // 4 x (offset, weight)
             const int o0 = (short)(xe.x & 0xffffu), o1 = (short)(xe.y & 0xffffu), o2 = (short)(xf.x & 0xffffu), o3 = (short)(xf.y & 0xffffu);
-            const int r0 = min(o0 + 1, sw - 1), r1 = min(o1 + 1, sw - 1), r2 = min(o2 + 1, sw - 1), r3 = min(o3 + 1, sw - 1);
             ushort2r WR01, WL01, WR23, WL23;
             WR01.x = (unsigned short)(xe.x >> 16);
             WR01.y = (unsigned short)(xe.y >> 16);
@@ -386,14 +333,40 @@ __global__ __launch_bounds__(PF_T) void k_pyramid_fused(FrameSrc src0, uint8_t *
             WL01.y = (unsigned short)(256 - WR01.y);
             WL23.x = (unsigned short)(256 - WR23.x);
             WL23.y = (unsigned short)(256 - WR23.y);
+            // The eight source bytes of a row (left and right tap of four neighbouring columns) lie within the 8 bytes that start at the
+            // first column's left tap when the level ratio is below 2 (o3 + 1 - o0 <= 7): THREE aligned dwords per source row shifted
+            // into an 8-byte window by two v_alignbyte, then one byte permute per packed operand with selectors that are constant for
+            // the level.  A right tap past the region's last column has weight 0: whatever byte the window holds there is multiplied
+            // by 0.  Wider spans (ratio >= 2 ...) take the byte-read form.
+            const bool narrow = v.narrow != 0;  // host: every group of four columns of this level spans <= 8 bytes
+            const int base = o0 & ~3, bsh = o0 & 3;
+            const uint32_t k1 = (uint32_t)(o1 - o0), k2 = (uint32_t)(o2 - o0), k3 = (uint32_t)(o3 - o0);
+            const uint32_t selL01 = 0x0c000c00u | (k1 << 16), selR01 = 0x0c000c01u | ((k1 + 1) << 16);            // (byte 0, byte k1), (byte 1, byte k1 + 1)
+            const uint32_t selL23 = 0x0c000c00u | k2 | (k3 << 16), selR23 = 0x0c000c00u | (k2 + 1) | ((k3 + 1) << 16);
+            const int r0 = min(o0 + 1, sw - 1), r1 = min(o1 + 1, sw - 1), r2 = min(o2 + 1, sw - 1), r3 = min(o3 + 1, sw - 1);
             for (int y = tid >> lgq; y < dh; y += PF_T >> lgq) {
                 const short2 e = yt[y];
                 const uint8_t *ru = S + e.x * sp, *rl = S + min(e.x + 1, sh - 1) * sp;
                 ushort2r Lu01, Ru01, Lu23, Ru23, Ll01, Rl01, Ll23, Rl23;
-                Lu01.x = ru[o0]; Lu01.y = ru[o1]; Ru01.x = ru[r0]; Ru01.y = ru[r1];
-                Lu23.x = ru[o2]; Lu23.y = ru[o3]; Ru23.x = ru[r2]; Ru23.y = ru[r3];
-                Ll01.x = rl[o0]; Ll01.y = rl[o1]; Rl01.x = rl[r0]; Rl01.y = rl[r1];
-                Ll23.x = rl[o2]; Ll23.y = rl[o3]; Rl23.x = rl[r2]; Rl23.y = rl[r3];
+                if (narrow) {
+                    const uint32_t *du = reinterpret_cast<const uint32_t *>(ru + base), *dl = reinterpret_cast<const uint32_t *>(rl + base);
+                    const uint32_t u0 = du[0], u1 = du[1], u2 = du[2], l0 = dl[0], l1 = dl[1], l2 = dl[2];
+                    const uint32_t wu0 = __builtin_amdgcn_alignbyte(u1, u0, bsh), wu1 = __builtin_amdgcn_alignbyte(u2, u1, bsh);
+                    const uint32_t wl0 = __builtin_amdgcn_alignbyte(l1, l0, bsh), wl1 = __builtin_amdgcn_alignbyte(l2, l1, bsh);
+                    Lu01 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(wu1, wu0, selL01));
+                    Ru01 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(wu1, wu0, selR01));
+                    Lu23 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(wu1, wu0, selL23));
+                    Ru23 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(wu1, wu0, selR23));
+                    Ll01 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(wl1, wl0, selL01));
+                    Rl01 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(wl1, wl0, selR01));
+                    Ll23 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(wl1, wl0, selL23));
+                    Rl23 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(wl1, wl0, selR23));
+                } else {
+                    Lu01.x = ru[o0]; Lu01.y = ru[o1]; Ru01.x = ru[r0]; Ru01.y = ru[r1];
+                    Lu23.x = ru[o2]; Lu23.y = ru[o3]; Ru23.x = ru[r2]; Ru23.y = ru[r3];
+                    Ll01.x = rl[o0]; Ll01.y = rl[o1]; Rl01.x = rl[r0]; Rl01.y = rl[r1];
+                    Ll23.x = rl[o2]; Ll23.y = rl[o3]; Rl23.x = rl[r2]; Rl23.y = rl[r3];
+                }
                 const uint32_t u01 = __builtin_bit_cast(uint32_t, (ushort2r)(WL01 * Lu01 + WR01 * Ru01)), u23 = __builtin_bit_cast(uint32_t, (ushort2r)(WL23 * Lu23 + WR23 * Ru23));
                 const uint32_t l01 = __builtin_bit_cast(uint32_t, (ushort2r)(WL01 * Ll01 + WR01 * Rl01)), l23 = __builtin_bit_cast(uint32_t, (ushort2r)(WL23 * Ll23 + WR23 * Rl23));
                 ushort2r WY;
@@ -411,15 +384,29 @@ __global__ __launch_bounds__(PF_T) void k_pyramid_fused(FrameSrc src0, uint8_t *
                 if (own_x && gy >= ry.z && gy < ry.w) *reinterpret_cast<uint32_t *>(dst + (size_t)gy * gpitch + gx) = o;
             }
         }
-        vp = v;
-        __syncthreads();
+        rxp = rx;
+        ryp = ry;
+        sp = dp;
+        PF_LDS_BARRIER();
+#ifdef AFV_PF_STATS
+        if (sti < 11) st[sti++] = wall_clock64();
+#endif
     }
+#ifdef AFV_PF_STATS
+    __builtin_amdgcn_s_waitcnt(0);
+    st[sti++] = wall_clock64();
+    if (tid == 0 && (work == 0 || work == total_blocks - 1)) {
+        printf("pyramid_fused block %d (work %d): x10 ns since start:", (int)blockIdx.x, work);
+        for (int i = 1; i < sti; ++i) printf(" %lld", st[i] - st[0]);
+        printf("\n");
+    }
+#endif
 }
 
-extern "C" void afv_launch_pyramid_fused(const FrameSrc *src0, uint8_t *pyr, const PyrFuseArgs *args, const PyrFuseRegions *regions,
-                                         size_t lds_bytes, int frame_base, int nframes, hipStream_t stream) {
+extern "C" void afv_launch_pyramid_fused(const FrameSrc *src0, uint8_t *pyr, const PyrFuseArgs *args, size_t lds_bytes, int frame_base, int nframes,
+                                         hipStream_t stream) {
     const int total = args->ntx * args->nty * nframes;
-    hipLaunchKernelGGL(k_pyramid_fused, dim3((total + 7) / 8 * 8), dim3(PF_T), lds_bytes, stream, *src0, pyr, *args, *regions, frame_base, total);
+    hipLaunchKernelGGL(k_pyramid_fused, dim3((total + 7) / 8 * 8), dim3(PF_T), lds_bytes, stream, *src0, pyr, *args, frame_base, total);
 }
 
 extern "C" int afv_pyramid_fused_prepare(size_t lds_bytes) {

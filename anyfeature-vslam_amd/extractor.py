@@ -197,6 +197,10 @@ class Context:
         """0 = never, 1 = calls of at most max_frames frames / pairs (default), 2 = always; identical results either way"""
         self.check(self.lib.afv_set_small_batch_path(self.handle, int(mode), int(max_frames)))
 
+    def set_match_resolve(self, engine):
+        """phase 2 of the pair matchers: 1 = workgroup-wide fixed point (default), 0 = ordered walk on one wavefront; identical results"""
+        self.check(self.lib.afv_set_match_resolve(self.handle, int(engine)))
+
     def set_split_chunks(self, chunks):
         self.check(self.lib.afv_set_split_chunks(self.handle, int(chunks)))
 

@@ -25,14 +25,17 @@ def _featvec(afv, seed, n, nnodes):
     return fv
 
 
-@pytest.fixture(params=["batch-kernels", "small-batch-kernels"])
+@pytest.fixture(params=["batch-kernels", "small-batch-kernels", "batch-kernels, one-wavefront walk"])
 def pairs_path(gpu_ctx, request):
-    """the brute-force pair tests run twice: with the batch kernels, and with the small-batch kernels forced for every call (phase 1
-    dealt to column slices - one key record per row and slice, merged by the resolve kernel); the library's own choice (calls of <= 4
-    pairs take the small-batch kernels) is restored afterwards"""
-    gpu_ctx.set_small_batch_path(0 if request.param == "batch-kernels" else 2)
+    """the brute-force pair tests run three times: with the batch kernels, with the small-batch kernels forced for every call (phase 1
+    dealt to column slices - one key record per row and slice, merged by the last workgroup of a row tile), and with phase 2 as the
+    ordered walk on one wavefront (rounds 2-3) instead of the workgroup-wide fixed point; the library's own choices are restored
+    afterwards"""
+    gpu_ctx.set_small_batch_path(2 if request.param == "small-batch-kernels" else 0)
+    gpu_ctx.set_match_resolve(0 if "walk" in request.param else 1)
     yield request.param
     gpu_ctx.set_small_batch_path(1)
+    gpu_ctx.set_match_resolve(1)
 
 
 @pytest.fixture(scope="module")
