@@ -424,8 +424,8 @@ extern "C" void afv_destroy(afv_ctx *c) {
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     afv_table_release_all(c);
     void *ptrs[] = {c->d_geo, c->d_tab, c->d_pyr, c->d_cand_packed, c->d_kept_xy, c->d_l1, c->d_l1_resp, c->d_l1_count, c->d_hq, c->d_hq_n, c->d_kept_resp,
-                    c->d_kept_node, c->d_cand_count, c->d_sel_count, c->d_sel, c->d_frames, c->d_kps, c->d_desc,
-                    c->d_n, c->d_status, c->d_match, c->d_topk, c->d_slice, c->d_tickets, c->d_pf_blob};
+                    c->d_kept_node, c->d_cand_count, c->d_sel_count, c->d_sel, c->d_frames, c->d_out_block,
+                    c->d_status, c->d_match, c->d_topk, c->d_slice, c->d_tickets, c->d_pf_blob};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_stage) {
@@ -502,9 +502,16 @@ extern "C" int afv_create(int device, const afv_orb_params *params, afv_ctx **ou
     c->frames_stride = align_up(c->frames_pitch * (size_t)params->max_height, 256);
     CREATE_CHK(hipMalloc(&c->d_frames, c->frames_stride * (size_t)B + 256));  // frames back to back, one guard at the very end
     c->stage_cap = afv_max_keypoints_per_frame(c);
-    CREATE_CHK(hipMalloc(&c->d_kps, (size_t)B * c->stage_cap * sizeof(afv_keypoint)));
-    CREATE_CHK(hipMalloc(&c->d_desc, (size_t)B * c->stage_cap * AFV_DESC_BYTES));
-    CREATE_CHK(hipMalloc(&c->d_n, (size_t)B * sizeof(int)));
+    {   // counts, keypoints and descriptors of the host-pointer calls in ONE block: [n][kps][desc] - with max_batch 1 (the plugin
+        // context) the results of a frame are one contiguous range, i.e. one device-to-host copy
+        c->out_kps_off = align_up((size_t)B * sizeof(int), 256);
+        c->out_desc_off = c->out_kps_off + align_up((size_t)B * c->stage_cap * sizeof(afv_keypoint), 256);
+        c->out_bytes = c->out_desc_off + (size_t)B * c->stage_cap * AFV_DESC_BYTES;
+        CREATE_CHK(hipMalloc(&c->d_out_block, c->out_bytes));
+        c->d_n = reinterpret_cast<int *>(c->d_out_block);
+        c->d_kps = reinterpret_cast<afv_keypoint *>(c->d_out_block + c->out_kps_off);
+        c->d_desc = c->d_out_block + c->out_desc_off;
+    }
     CREATE_CHK(hipMalloc(&c->d_status, sizeof(int)));
     // quadtree node capacity: alive nodes <= max(quota + 3, 4 * n_ini)
     int M = 64;
@@ -553,7 +560,7 @@ extern "C" int afv_set_match_engine(afv_ctx *c, int engine) {
 }
 
 extern "C" int afv_set_match_resolve(afv_ctx *c, int engine) {
-    if (!c || (engine != 0 && engine != 1)) return AFV_EINVAL;
+    if (!c || engine < 0 || engine > 2) return AFV_EINVAL;
     c->resolve_engine = engine;
     return AFV_OK;
 }
@@ -617,6 +624,13 @@ extern "C" int afv_get_geometry(const afv_ctx *c, afv_geometry *g) {
         g->cand_cap[l] = s.lv[l].cand_cap;
     }
     return AFV_OK;
+}
+
+// phase 2 of a brute-force pair call: the workgroup-wide fixed point halves the latency of a pair (one pair of unrelated frames 23 -> 13 us,
+// a frame against itself 38 -> 20 us) but evaluates every live row in every pass; a batch that fills the chip is throughput-bound and
+// faster with the one-wavefront walk (10 000 jobs: 3.26 M jobs/s against 2.75 M; 256 overlapping pairs: 0.25 against 0.38 ms)
+static int resolve_engine_for(const afv_ctx *c, int npairs) {
+    return c->resolve_engine == 2 ? (npairs <= c->resolve_wg_max_pairs ? 1 : 0) : c->resolve_engine;
 }
 
 // ---- the pipeline ----
@@ -916,10 +930,91 @@ extern "C" int afv_orb_extract_batch(afv_ctx *c, const uint8_t *const *frames, i
     });
 }
 
+// The plugin call (FeatureExtractor::operator(), FeatureExtractor.cpp:111-129: ONE host image in, host vectors out) without the batch
+// pipeline's bookkeeping: no events, no output probes, everything on the context's stream.  A pageable image goes through the pinned
+// arena in four strips (the CPU copies strip k + 1 while strip k is on the link); the results come back in one copy when the context
+// was created for one frame (counts, keypoints and descriptors are then one contiguous range), else in three.
+static int extract_one(afv_ctx *c, const uint8_t *gray, int width, int height, int stride_bytes, afv_keypoint *kps, uint8_t *desc32, int cap,
+                       int *n_out) {
+    struct Quiesce {  // whatever path leaves this function, no DMA may still be in flight into the arena
+        afv_ctx *c;
+        bool armed = true;
+        ~Quiesce() {
+            if (armed) (void)hipStreamSynchronize(c->stream);
+        }
+    } quiesce{c};
+    const size_t pitch = align_up((size_t)width, 64);
+    const size_t fstride = align_up(pitch * (size_t)height, 256);
+    FrameSrc src{c->d_frames, (int)pitch, fstride};
+    hipStream_t s = c->stream;
+    const bool pinned_in = is_pinned_host(gray) && is_pinned_host(gray + (size_t)(height - 1) * stride_bytes + width - 1);
+    const size_t frame_bytes = (size_t)width * height;
+    const bool one_copy = c->p.max_batch == 1;
+    const size_t res_bytes = one_copy ? c->out_bytes : 256 + (size_t)c->stage_cap * (sizeof(afv_keypoint) + AFV_DESC_BYTES);
+    HostImage arena{c};
+    const size_t res_off = align_up(pinned_in ? 0 : frame_bytes, 256);
+    arena.resize(res_off + res_bytes, false);
+    uint8_t *hb = arena.data();
+    if (pinned_in) {
+        HIPCHK(c, hipMemcpy2DAsync(c->d_frames, pitch, gray, (size_t)stride_bytes, (size_t)width, (size_t)height, hipMemcpyHostToDevice, s));
+    } else {
+        const int NS = height >= 64 ? 4 : 1;
+        for (int k = 0; k < NS; ++k) {
+            const int r0 = (int)((long)height * k / NS), r1 = (int)((long)height * (k + 1) / NS);
+            if ((size_t)stride_bytes == (size_t)width) {
+                std::memcpy(hb + (size_t)r0 * width, gray + (size_t)r0 * width, (size_t)(r1 - r0) * width);
+            } else {
+                for (int y = r0; y < r1; ++y) std::memcpy(hb + (size_t)y * width, gray + (size_t)y * stride_bytes, (size_t)width);
+            }
+            if (pitch == (size_t)width) {
+                HIPCHK(c, hipMemcpyAsync(c->d_frames + (size_t)r0 * pitch, hb + (size_t)r0 * width, (size_t)(r1 - r0) * width, hipMemcpyHostToDevice, s));
+            } else {
+                HIPCHK(c, hipMemcpy2DAsync(c->d_frames + (size_t)r0 * pitch, pitch, hb + (size_t)r0 * width, (size_t)width, (size_t)width,
+                                           (size_t)(r1 - r0), hipMemcpyHostToDevice, s));
+            }
+        }
+    }
+    enqueue_range(c, src, 0, 1, c->d_kps, c->d_desc, c->stage_cap, c->d_n, c->d_status, s, true);
+    HIPCHK(c, hipGetLastError());
+    uint8_t *hres = hb + res_off;
+    const uint8_t *h_kps, *h_desc;
+    if (one_copy) {
+        HIPCHK(c, hipMemcpyAsync(hres, c->d_out_block, c->out_bytes, hipMemcpyDeviceToHost, s));
+        h_kps = hres + c->out_kps_off;
+        h_desc = hres + c->out_desc_off;
+    } else {
+        HIPCHK(c, hipMemcpyAsync(hres, c->d_n, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(hres + 256, c->d_kps, (size_t)c->stage_cap * sizeof(afv_keypoint), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(hres + 256 + (size_t)c->stage_cap * sizeof(afv_keypoint), c->d_desc, (size_t)c->stage_cap * AFV_DESC_BYTES,
+                                 hipMemcpyDeviceToHost, s));
+        h_kps = hres + 256;
+        h_desc = hres + 256 + (size_t)c->stage_cap * sizeof(afv_keypoint);
+    }
+    c->last_src = src;
+    c->last_nframes = 1;
+    HIPCHK(c, hipStreamSynchronize(s));
+    quiesce.armed = false;
+    int n = *reinterpret_cast<const int *>(hres), result = AFV_OK;
+    if (n > cap) {
+        n = cap;
+        result = AFV_ECAPACITY;
+    }
+    n = std::max(n, 0);
+    *n_out = n;
+    std::memcpy(kps, h_kps, (size_t)n * sizeof(afv_keypoint));
+    std::memcpy(desc32, h_desc, (size_t)n * AFV_DESC_BYTES);
+    return result;
+}
+
 extern "C" int afv_orb_extract(afv_ctx *c, const uint8_t *gray, int width, int height, int stride_bytes, afv_keypoint *kps,
                                uint8_t *desc32, int cap, int *n_out) {
-    const uint8_t *frames[1] = {gray};
-    return afv_orb_extract_batch(c, frames, 1, width, height, stride_bytes, kps, desc32, cap, n_out);
+    if (!c || !gray || !kps || !desc32 || !n_out) return AFV_EINVAL;
+    if (cap < 1 || stride_bytes < width) return AFV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = set_geometry(c, width, height);
+    if (rc) return rc;
+    c->prof = c->prof_every && (c->prof_tick_extract++ % (unsigned)c->prof_every) == 0;
+    return guarded(c, [&]() -> int { return extract_one(c, gray, width, height, stride_bytes, kps, desc32, cap, n_out); });
 }
 
 // E12 (FeatureExtractor.cpp:132-172, settings FeatureExtractor.cpp:52-55)
@@ -1216,7 +1311,7 @@ static int afv_match_bow_impl(afv_ctx *c, const afv_match_job *jobs, int njobs, 
                 afv_launch_match_topk(c->d_match + desc_off, np_, cap, pa_, pb_, i1 - i0, c->d_match + topk_off, i0, c->match_engine, nslices, c->d_slice, c->d_tickets, c->stream);
                 afv_launch_match_resolve(c->d_match + desc_off, angp, 1, np_, cap, pa_, pb_, i1 - i0, jobs[i0].th_low, jobs[i0].nnratio,
                                          jobs[i0].check_orientation != 0, reinterpret_cast<int *>(c->d_match + match_off),
-                                         reinterpret_cast<int *>(c->d_match + nm_off), c->d_match + topk_off, i0, c->resolve_engine, c->stream);
+                                         reinterpret_cast<int *>(c->d_match + nm_off), c->d_match + topk_off, i0, resolve_engine_for(c, njobs), c->stream);
                 i0 = i1;
             }
             HIPCHK(c, hipGetLastError());
@@ -1400,7 +1495,7 @@ int afv_match_pairs_core(afv_ctx *c, const uint8_t *d_desc, const float *d_ang, 
             }
             StageTimer t_(c, AFV_STAGE_MATCH_RESOLVE, ks, e0 - b0);
             afv_launch_match_resolve(d_desc, d_ang, ang_stride, d_n, cap, d_pair_a, d_pair_b, e0 - b0, th_low, nnratio, check_orientation,
-                                     d_match, d_nmatches, c->d_topk, b0, c->resolve_engine, ks);
+                                     d_match, d_nmatches, c->d_topk, b0, resolve_engine_for(c, npairs), ks);
         }
         HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0));
@@ -1411,7 +1506,7 @@ int afv_match_pairs_core(afv_ctx *c, const uint8_t *d_desc, const float *d_ang, 
         }
         StageTimer t_(c, AFV_STAGE_MATCH_RESOLVE, s, npairs);
         afv_launch_match_resolve(d_desc, d_ang, ang_stride, d_n, cap, d_pair_a, d_pair_b, npairs, th_low, nnratio, check_orientation, d_match,
-                                 d_nmatches, c->d_topk, 0, c->resolve_engine, s);
+                                 d_nmatches, c->d_topk, 0, resolve_engine_for(c, npairs), s);
     }
     HIPCHK(c, hipGetLastError());
     return AFV_OK;

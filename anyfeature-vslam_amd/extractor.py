@@ -198,7 +198,7 @@ class Context:
         self.check(self.lib.afv_set_small_batch_path(self.handle, int(mode), int(max_frames)))
 
     def set_match_resolve(self, engine):
-        """phase 2 of the pair matchers: 1 = workgroup-wide fixed point (default), 0 = ordered walk on one wavefront; identical results"""
+        """phase 2 of the pair matchers: 1 = workgroup-wide fixed point, 0 = ordered walk on one wavefront, 2 = by call size (default); identical results"""
         self.check(self.lib.afv_set_match_resolve(self.handle, int(engine)))
 
     def set_split_chunks(self, chunks):

@@ -352,8 +352,10 @@ int afv_set_split_threshold(afv_ctx *ctx, int min_frames);
 int afv_set_split_chunks(afv_ctx *ctx, int chunks); /* ... into this many chunks alternating over the two streams (2..64; 0 = automatic,
                                                       * chunks of about 85 frames: the default) */
 /* Phase 2 of the brute-force pair matchers (the ordered greedy assignment of SearchByBoW, FeatureMatcher.cc:587-641); identical results:
- *   1 (default): one fixed point over all live rows of a pair, a thread per row, claims in rotating LDS arrays (one barrier per pass)
- *   0:           the ordered walk of rounds 2-3: one wavefront, 64 rows per round */
+ *   1: one fixed point over all live rows of a pair, a thread per row, claims in rotating LDS arrays (one barrier per pass): half the
+ *      latency of a pair, more total work
+ *   0: the ordered walk of rounds 2-3: one wavefront, 64 rows per round: what a batch that fills the chip runs fastest with
+ *   2 (default): 1 for calls of at most 32 pairs, else 0 */
 int afv_set_match_resolve(afv_ctx *ctx, int engine);
 /* The small-batch ("latency") path.  Tracking extracts ONE frame per call (src/Frame.cc:186 -> src/FeatureExtractor.cpp:111-121) and
  * matches it against ONE other frame: at that size the batch kernels are a chain of dependent launches, each a few microseconds of

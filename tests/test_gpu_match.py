@@ -35,7 +35,7 @@ def pairs_path(gpu_ctx, request):
     gpu_ctx.set_match_resolve(0 if "walk" in request.param else 1)
     yield request.param
     gpu_ctx.set_small_batch_path(1)
-    gpu_ctx.set_match_resolve(1)
+    gpu_ctx.set_match_resolve(2)
 
 
 @pytest.fixture(scope="module")
