@@ -3,6 +3,8 @@
 // of one context; stages host-pointer calls; enqueues the kernel pipeline
 //   resize x (nlevels-1) -> FAST+NMS+Harris -> retainBest x2 + quadtree -> IC + blur + rBRIEF.
 // No CPU fallback exists: without a HIP device afv_create fails with AFV_ENODEV.
+#include <chrono>
+
 #include "afv_runtime.h"
 
 static const char *k_errors[] = {"ok", "invalid argument", "no usable HIP device", "out of memory", "HIP runtime error",
@@ -943,56 +945,66 @@ static int extract_one(afv_ctx *c, const uint8_t *gray, int width, int height, i
             if (armed) (void)hipStreamSynchronize(c->stream);
         }
     } quiesce{c};
+    // AFV_TRACE_HOST=1: where the host spends a call (averages over 100 calls on stderr) - a measurement aid, off by default
+    static const bool trace = std::getenv("AFV_TRACE_HOST") != nullptr;
+    static thread_local double acc[8] = {};
+    static thread_local int ncalls = 0;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double ts[8] = {};
+    if (trace) ts[0] = now();
     const size_t pitch = align_up((size_t)width, 64);
     const size_t fstride = align_up(pitch * (size_t)height, 256);
     FrameSrc src{c->d_frames, (int)pitch, fstride};
     hipStream_t s = c->stream;
     const bool pinned_in = is_pinned_host(gray) && is_pinned_host(gray + (size_t)(height - 1) * stride_bytes + width - 1);
     const size_t frame_bytes = (size_t)width * height;
-    const bool one_copy = c->p.max_batch == 1;
-    const size_t res_bytes = one_copy ? c->out_bytes : 256 + (size_t)c->stage_cap * (sizeof(afv_keypoint) + AFV_DESC_BYTES);
+    // results: the describe kernel writes counts, keypoints and descriptors STRAIGHT into the pinned arena (device-visible host memory:
+    // 60 KB of posted writes over the link) - no copy engine between the last kernel and the host (that hop cost ~7 us)
+    const size_t kps_off = 256, desc_off = kps_off + align_up((size_t)c->stage_cap * sizeof(afv_keypoint), 256);
+    const size_t res_bytes = desc_off + (size_t)c->stage_cap * AFV_DESC_BYTES;
     HostImage arena{c};
     const size_t res_off = align_up(pinned_in ? 0 : frame_bytes, 256);
     arena.resize(res_off + res_bytes, false);
     uint8_t *hb = arena.data();
+    const bool zero_copy_out = c->stage_pinned;  // (a pageable arena only exists when pinning failed: results then take the copy engine)
+    if (trace) ts[1] = now();
     if (pinned_in) {
         HIPCHK(c, hipMemcpy2DAsync(c->d_frames, pitch, gray, (size_t)stride_bytes, (size_t)width, (size_t)height, hipMemcpyHostToDevice, s));
     } else {
-        const int NS = height >= 64 ? 4 : 1;
-        for (int k = 0; k < NS; ++k) {
-            const int r0 = (int)((long)height * k / NS), r1 = (int)((long)height * (k + 1) / NS);
-            if ((size_t)stride_bytes == (size_t)width) {
-                std::memcpy(hb + (size_t)r0 * width, gray + (size_t)r0 * width, (size_t)(r1 - r0) * width);
-            } else {
-                for (int y = r0; y < r1; ++y) std::memcpy(hb + (size_t)y * width, gray + (size_t)y * stride_bytes, (size_t)width);
-            }
-            if (pitch == (size_t)width) {
-                HIPCHK(c, hipMemcpyAsync(c->d_frames + (size_t)r0 * pitch, hb + (size_t)r0 * width, (size_t)(r1 - r0) * width, hipMemcpyHostToDevice, s));
-            } else {
-                HIPCHK(c, hipMemcpy2DAsync(c->d_frames + (size_t)r0 * pitch, pitch, hb + (size_t)r0 * width, (size_t)width, (size_t)width,
-                                           (size_t)(r1 - r0), hipMemcpyHostToDevice, s));
-            }
+        // one copy into the arena, one DMA: strips (CPU copy of strip k + 1 beside the DMA of strip k) lose more to the per-transfer
+        // latency of the copy engine (~6 us each, serialised) than the overlap wins (measured: 4 strips +16 us)
+        if ((size_t)stride_bytes == (size_t)width) {
+            std::memcpy(hb, gray, frame_bytes);
+        } else {
+            for (int y = 0; y < height; ++y) std::memcpy(hb + (size_t)y * width, gray + (size_t)y * stride_bytes, (size_t)width);
+        }
+        if (pitch == (size_t)width) {
+            HIPCHK(c, hipMemcpyAsync(c->d_frames, hb, frame_bytes, hipMemcpyHostToDevice, s));
+        } else {
+            HIPCHK(c, hipMemcpy2DAsync(c->d_frames, pitch, hb, (size_t)width, (size_t)width, (size_t)height, hipMemcpyHostToDevice, s));
         }
     }
-    enqueue_range(c, src, 0, 1, c->d_kps, c->d_desc, c->stage_cap, c->d_n, c->d_status, s, true);
-    HIPCHK(c, hipGetLastError());
     uint8_t *hres = hb + res_off;
-    const uint8_t *h_kps, *h_desc;
-    if (one_copy) {
-        HIPCHK(c, hipMemcpyAsync(hres, c->d_out_block, c->out_bytes, hipMemcpyDeviceToHost, s));
-        h_kps = hres + c->out_kps_off;
-        h_desc = hres + c->out_desc_off;
+    if (trace) ts[2] = now();
+    if (zero_copy_out) {
+        enqueue_range(c, src, 0, 1, reinterpret_cast<afv_keypoint *>(hres + kps_off), hres + desc_off, c->stage_cap, reinterpret_cast<int *>(hres),
+                      c->d_status, s, true);
     } else {
-        HIPCHK(c, hipMemcpyAsync(hres, c->d_n, sizeof(int), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(hres + 256, c->d_kps, (size_t)c->stage_cap * sizeof(afv_keypoint), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(hres + 256 + (size_t)c->stage_cap * sizeof(afv_keypoint), c->d_desc, (size_t)c->stage_cap * AFV_DESC_BYTES,
-                                 hipMemcpyDeviceToHost, s));
-        h_kps = hres + 256;
-        h_desc = hres + 256 + (size_t)c->stage_cap * sizeof(afv_keypoint);
+        enqueue_range(c, src, 0, 1, c->d_kps, c->d_desc, c->stage_cap, c->d_n, c->d_status, s, true);
     }
+    HIPCHK(c, hipGetLastError());
+    if (trace) ts[3] = now();
+    if (!zero_copy_out) {
+        HIPCHK(c, hipMemcpyAsync(hres, c->d_n, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(hres + kps_off, c->d_kps, (size_t)c->stage_cap * sizeof(afv_keypoint), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(hres + desc_off, c->d_desc, (size_t)c->stage_cap * AFV_DESC_BYTES, hipMemcpyDeviceToHost, s));
+    }
+    const uint8_t *h_kps = hres + kps_off, *h_desc = hres + desc_off;
     c->last_src = src;
     c->last_nframes = 1;
+    if (trace) ts[4] = now();
     HIPCHK(c, hipStreamSynchronize(s));
+    if (trace) ts[5] = now();
     quiesce.armed = false;
     int n = *reinterpret_cast<const int *>(hres), result = AFV_OK;
     if (n > cap) {
@@ -1003,6 +1015,15 @@ static int extract_one(afv_ctx *c, const uint8_t *gray, int width, int height, i
     *n_out = n;
     std::memcpy(kps, h_kps, (size_t)n * sizeof(afv_keypoint));
     std::memcpy(desc32, h_desc, (size_t)n * AFV_DESC_BYTES);
+    if (trace) {
+        ts[6] = now();
+        for (int i = 0; i < 6; ++i) acc[i] += ts[i + 1] - ts[i];
+        if (++ncalls % 100 == 0) {
+            fprintf(stderr, "afv_orb_extract (us, mean of 100): probes + arena %.1f | upload enqueue %.1f | kernel launches %.1f | download enqueue %.1f | wait %.1f | hand-over %.1f\n",
+                    acc[0] / 100, acc[1] / 100, acc[2] / 100, acc[3] / 100, acc[4] / 100, acc[5] / 100);
+            for (double &v : acc) v = 0;
+        }
+    }
     return result;
 }
 

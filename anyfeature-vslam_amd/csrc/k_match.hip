@@ -394,7 +394,7 @@ __global__ __launch_bounds__(MT) void k_match_topk(const uint8_t *__restrict__ d
                             // below the 64 KB a launch may ask for without raising the function's dynamic-LDS limit
 static inline size_t resolve_lds_bytes(int cap, bool stage_cols) {
     const size_t c = ((size_t)cap + 63) & ~(size_t)63;
-    return std::min<size_t>(c, PAIR_KEYS_LDS) * 32 /*key records*/ + c * 4 /*claim*/ + c * 4 /*matches*/ + c * 2 /*live*/ + c /*bin*/ + c / 8 /*matched*/ +
+    return std::min<size_t>(c, PAIR_KEYS_LDS) * 32 /*key records*/ + c * 4 /*claim*/ + c * 2 /*live*/ + c /*bin*/ + c / 8 /*matched*/ +
            (stage_cols ? c * 32 + 16 : 0) /*columns, 16-byte aligned*/;
 }
 
@@ -407,8 +407,7 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve(const uint8_t *__restri
     const int capr = (cap + 63) & ~63;
     int4 *s_keys = reinterpret_cast<int4 *>(s_dyn);  // key records (2 x int4) of the live rows (first PAIR_KEYS_LDS of them)
     int *s_claim = reinterpret_cast<int *>(s_keys + 2 * min(capr, PAIR_KEYS_LDS));
-    int *s_out = s_claim + capr;  // the row -> column matches live here until the rotation histogram has filtered them: one store per row at the end
-    unsigned short *s_live = reinterpret_cast<unsigned short *>(s_out + capr);
+    unsigned short *s_live = reinterpret_cast<unsigned short *>(s_claim + capr);
     uint8_t *s_bin = reinterpret_cast<uint8_t *>(s_live + capr);
     uint32_t *s_matched = reinterpret_cast<uint32_t *>(s_bin + capr);
     const bool cols_in_lds = stage_cols != 0;
@@ -428,34 +427,17 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve(const uint8_t *__restri
     const int n1 = min(nset[a], cap), n2 = min(nset[b], cap);
     const int4 *tk = topk + (size_t)p * cap * 2;
     int *out = match + (size_t)p * cap;
-    for (int i = tid; i < capr; i += MT) s_out[i] = -1;
+    for (int i = tid; i < cap; i += MT) out[i] = -1;
     for (int i = tid; i < (n2 + 31) / 32; i += MT) s_matched[i] = 0;
     for (int i = tid; i < n2; i += MT) s_claim[i] = 0x7fffffff;
     if (tid < 32) s_hist[tid] = 0;
     if (tid == 0) s_cols_ready = 0;
     // rows whose best distance fails TH_LOW can never match: compact the others IN ROW ORDER, keys staged in LDS
     int nlive = 0;
-    // the records of a thread's first four rows (sets of up to 1024 rows: all of them) are fetched together: one L2 round trip instead of
-    // one per pass of the compaction loop
-    int4 pre4[4], pre8[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int i = u * MT + tid;
-        pre4[u] = make_int4(NO_KEY, NO_KEY, NO_KEY, NO_KEY);
-        pre8[u] = make_int4(NO_KEY, NO_KEY, NO_KEY, TOPK);
-        if (i < n1) {
-            pre4[u] = tk[2 * i];
-            pre8[u] = tk[2 * i + 1];
-        }
-    }
     for (int i0 = 0; i0 < n1; i0 += MT) {
         const int i = i0 + tid;
         int4 t4 = make_int4(NO_KEY, NO_KEY, NO_KEY, NO_KEY), t8 = make_int4(NO_KEY, NO_KEY, NO_KEY, TOPK);
-        if (i0 < 4 * MT) {  // uniform
-            const int u = i0 / MT;
-            t4 = u == 0 ? pre4[0] : u == 1 ? pre4[1] : u == 2 ? pre4[2] : pre4[3];
-            t8 = u == 0 ? pre8[0] : u == 1 ? pre8[1] : u == 2 ? pre8[2] : pre8[3];
-        } else if (i < n1) {
+        if (i < n1) {
             t4 = tk[2 * i];
             t8 = tk[2 * i + 1];
         }
@@ -609,7 +591,7 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve(const uint8_t *__restri
             const int stop = sm ? (int)__builtin_ctzll(sm) : 64;
             const bool commit = type == 1 && lane < stop;
             if (commit) {
-                s_out[row] = e0;
+                out[row] = e0;
                 atomicOr(&s_matched[e0 >> 5], 1u << (e0 & 31));
             }
             nm += __popcll(__ballot(commit));
@@ -678,7 +660,7 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve(const uint8_t *__restri
                     if (best1 < th && best1 < ratio * best2) {
                         const int bcol = k & 0xffff;
                         if (lane == 0) {
-                            s_out[i] = bcol;
+                            out[i] = bcol;
                             s_matched[bcol >> 5] |= 1u << (bcol & 31);
                         }
                         ++nm;
@@ -704,7 +686,7 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve(const uint8_t *__restri
         // rotation histogram of the accepted matches (FeatureMatcher.cc:1587-1599): it never influences the walk, so
         // it is built afterwards by the whole workgroup
         for (int i = tid; i < n1; i += MT) {
-            const int c = s_out[i];
+            const int c = out[i];
             if (c >= 0) {
                 const int bin = rotation_bin(ang[((size_t)a * cap + i) * ang_stride], ang[((size_t)b * cap + c) * ang_stride]);
                 s_bin[i] = (uint8_t)bin;
@@ -728,15 +710,14 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve(const uint8_t *__restri
         const int i1 = s_drop[0], i2 = s_drop[1], i3 = s_drop[2];
         int dropped = 0;
         for (int i = tid; i < n1; i += MT) {
-            if (s_out[i] >= 0) {
+            if (out[i] >= 0) {
                 const int bb = s_bin[i];
-                if (bb != i1 && bb != i2 && bb != i3) { s_out[i] = -1; ++dropped; }
+                if (bb != i1 && bb != i2 && bb != i3) { out[i] = -1; ++dropped; }
             }
         }
         if (dropped) atomicSub(&s_nm, dropped);
         __syncthreads();
     }
-    for (int i = tid; i < cap; i += MT) out[i] = s_out[i];  // every thread re-reads its own entries (same i -> tid mapping throughout)
     if (tid == 0) nmatches[p] = s_nm;
 #ifdef AFV_RESOLVE_STATS
     if (AFV_RESOLVE_STATS == 2 && tid == 0 && p <= 2)

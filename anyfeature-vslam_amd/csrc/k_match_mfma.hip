@@ -118,10 +118,14 @@ __device__ __forceinline__ void mq_compute(const uint8_t *buf, const v4i (&bq)[2
     }
 }
 
+// SLICED = false: the batch form (one workgroup per row tile walks all column tiles; nslices is 1 and the slice arguments are unused) -
+// kept as its own instantiation so that the column-slice logic costs the throughput-bound launches nothing
+template <bool SLICED>
 __global__ __launch_bounds__(MQ_T, 2) void k_match_topk_mfma(const uint8_t *__restrict__ desc, const int *__restrict__ nset, int cap,
                                                              const int *__restrict__ pair_a, const int *__restrict__ pair_b,
-                                                             int4 *__restrict__ topk, int pair_base, int nslices, int4 *__restrict__ slice_rec,
+                                                             int4 *__restrict__ topk, int pair_base, int nslices_arg, int4 *__restrict__ slice_rec,
                                                              int *__restrict__ tickets) {
+    const int nslices = SLICED ? nslices_arg : 1;
     __shared__ __attribute__((aligned(16))) uint2 s_lut[256];
     __shared__ __attribute__((aligned(16))) uint8_t s_a[2][T_TILE * A_PITCH];
     const int p = pair_base + blockIdx.y;
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(MQ_T, 2) void k_match_topk_mfma(const uint8_t *__re
     // nslices > 1 (one or a few pairs, the per-frame plugin call): the 64-column tiles of the train set are dealt to `nslices`
     // workgroups per row tile; every slice writes its own record per row, and the workgroup that finishes LAST for a row tile (a
     // ticket per pair and row tile) merges them into the record k_match_resolve reads
-    const int rt = (int)blockIdx.x / nslices, slice = (int)blockIdx.x - rt * nslices;
+    const int rt = SLICED ? (int)blockIdx.x / nslices : (int)blockIdx.x, slice = SLICED ? (int)blockIdx.x - rt * nslices : 0;
     if (rt * MQ_T >= n1) return;  // uniform
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     {   // byte -> eight +-64 bytes: bit j of the byte -> byte j (0x40 if set, 0xC0 = -64 if clear)
@@ -213,12 +217,12 @@ __global__ __launch_bounds__(MQ_T, 2) void k_match_topk_mfma(const uint8_t *__re
                 const int D = m[i] + (1 << 20);
                 s[i] = m[i] == NO_KEY ? NO_KEY : (((D >> 13) << 16) | (D & 8191));
             }
-            int4 *rec = nslices > 1 ? slice_rec + (((size_t)p * cap + row) * nslices + slice) * 2 : topk + ((size_t)p * cap + row) * 2;
+            int4 *rec = SLICED ? slice_rec + (((size_t)p * cap + row) * nslices + slice) * 2 : topk + ((size_t)p * cap + row) * 2;
             rec[0] = make_int4(s[0], s[1], s[2], s[3]);
             rec[1] = make_int4(s[4], s[5], s[6], max(nk, 1));
         }
     }
-    if (nslices == 1) return;
+    if (!SLICED) return;
     // ---- the last workgroup of the row tile merges the slices (cdna_hip_programming.md Guideline 16: every wave's stores drained by
     // the barrier -> ONE lane: agent-scope release, ticket; the last arriver: ONE agent-scope acquire -> barrier -> plain loads) ----
     __shared__ int s_last;
@@ -268,6 +272,10 @@ __global__ __launch_bounds__(MQ_T, 2) void k_match_topk_mfma(const uint8_t *__re
 extern "C" void afv_launch_match_topk_mfma(const uint8_t *desc, const int *nset, int cap, const int *pa, const int *pb, int npairs,
                                            void *topk_scratch, int pair_base, int nslices, void *slice_scratch, void *tickets, hipStream_t stream) {
     int4 *topk = reinterpret_cast<int4 *>(topk_scratch);
-    hipLaunchKernelGGL(k_match_topk_mfma, dim3((cap + MQ_T - 1) / MQ_T * nslices, npairs), dim3(MQ_T), 0, stream, desc, nset, cap, pa, pb, topk,
-                       pair_base, nslices, reinterpret_cast<int4 *>(slice_scratch), reinterpret_cast<int *>(tickets));
+    if (nslices > 1)
+        hipLaunchKernelGGL(k_match_topk_mfma<true>, dim3((cap + MQ_T - 1) / MQ_T * nslices, npairs), dim3(MQ_T), 0, stream, desc, nset, cap, pa, pb, topk,
+                           pair_base, nslices, reinterpret_cast<int4 *>(slice_scratch), reinterpret_cast<int *>(tickets));
+    else
+        hipLaunchKernelGGL(k_match_topk_mfma<false>, dim3((cap + MQ_T - 1) / MQ_T, npairs), dim3(MQ_T), 0, stream, desc, nset, cap, pa, pb, topk,
+                           pair_base, 1, static_cast<int4 *>(nullptr), static_cast<int *>(nullptr));
 }
