@@ -23,7 +23,7 @@ def use_library(path):
 
 MAX_LEVELS = 8
 DESC_BYTES = 32
-OK, EINVAL, ENODEV, ENOMEM, EHIP, ECAPACITY, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+OK, EINVAL, ENODEV, ENOMEM, EHIP, ECAPACITY, EUNSUPPORTED, ETIMEOUT = 0, -1, -2, -3, -4, -5, -6, -7
 MATCH_KF_KF, MATCH_KF_FRAME = 0, 1
 PROJ_LOCALMAP, PROJ_LASTFRAME = 0, 1
 STAGES = ("pyramid", "fast_nms", "select_quadtree", "describe", "match_topk", "match_resolve", "retain_harris")
@@ -160,6 +160,7 @@ SYMBOLS = {
     "afv_set_match_engine": (_i, [_vp, _i]),
     "afv_set_small_batch_path": (_i, [_vp, _i, _i]),
     "afv_set_match_resolve": (_i, [_vp, _i]),
+    "afv_set_l2_chunk_pairs": (_i, [_vp, _i]),
     "afv_debug_pyramid_plan": (_i, [C.POINTER(OrbParams), _i, _i, _i, _i, _vp, _i, _vp, _vp, _i]),
     "afv_set_pipeline_chunk": (_i, [_vp, _i, _i]),
     "afv_get_geometry": (_i, [_vp, C.POINTER(Geometry)]),
@@ -193,6 +194,10 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    # the profile getters write afv_num_stages() entries: a (variant) build with more stages than this mirror knows would overrun the
+    # arrays the wrapper hands it
+    if lib.afv_num_stages() > len(STAGES):
+        raise ImportError("%s reports %d profile stages, this mirror knows %d" % (LIB_PATH, lib.afv_num_stages(), len(STAGES)))
     _lib = lib
     return lib
 

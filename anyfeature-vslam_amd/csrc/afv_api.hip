@@ -8,7 +8,7 @@
 #include "afv_runtime.h"
 
 static const char *k_errors[] = {"ok", "invalid argument", "no usable HIP device", "out of memory", "HIP runtime error",
-                                 "output capacity too small", "unsupported"};
+                                 "output capacity too small", "unsupported", "device-side wait timed out"};
 
 
 extern "C" void afv_default_orb_params(afv_orb_params *p) {
@@ -24,7 +24,7 @@ extern "C" void afv_default_orb_params(afv_orb_params *p) {
 
 extern "C" const char *afv_strerror(int code) {
     const int i = -code;
-    if (i < 0 || i > 6) return "unknown error";
+    if (i < 0 || i > 7) return "unknown error";
     return k_errors[i];
 }
 extern "C" const char *afv_last_error(const afv_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
@@ -427,7 +427,7 @@ extern "C" void afv_destroy(afv_ctx *c) {
     afv_table_release_all(c);
     void *ptrs[] = {c->d_geo, c->d_tab, c->d_pyr, c->d_cand_packed, c->d_kept_xy, c->d_l1, c->d_l1_resp, c->d_l1_count, c->d_hq, c->d_hq_n, c->d_kept_resp,
                     c->d_kept_node, c->d_cand_count, c->d_sel_count, c->d_sel, c->d_frames, c->d_out_block,
-                    c->d_status, c->d_match, c->d_topk, c->d_slice, c->d_tickets, c->d_pf_blob};
+                    c->d_status, c->d_match, c->d_topk, c->d_slice, c->d_tickets, c->d_pf_blob, c->d_l2_scratch};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_stage) {
@@ -558,6 +558,12 @@ extern "C" int afv_set_pipeline_chunk(afv_ctx *c, int frames, int chunks_ahead) 
 extern "C" int afv_set_match_engine(afv_ctx *c, int engine) {
     if (!c || (engine != AFV_MATCH_ENGINE_POPCOUNT && engine != AFV_MATCH_ENGINE_MFMA)) return AFV_EINVAL;
     c->match_engine = engine;
+    return AFV_OK;
+}
+
+extern "C" int afv_set_l2_chunk_pairs(afv_ctx *c, int pairs) {
+    if (!c || pairs < 1 || pairs > 65535) return AFV_EINVAL;
+    c->l2_chunk_pairs = pairs;
     return AFV_OK;
 }
 
@@ -1591,19 +1597,22 @@ extern "C" int afv_match_l2_pairs_device(afv_ctx *c, const float *d_desc, const 
         if (npairs == 0) return AFV_OK;
         HIPCHK(c, hipSetDevice(c->device));
         hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-        const int chunk = std::min(npairs, 2048);  // pairs per launch: grid.y and the scratch stay bounded
+        const int chunk = std::min(npairs, c->l2_chunk_pairs);  // pairs per launch: grid.y and the scratch stay bounded
+        // the float matcher's own key scratch: the Hamming pair calls keep theirs (d_topk) busy on the context's streams, and a caller
+        // may run the two kinds on different streams of one context
         const size_t need = (size_t)chunk * cap * 32;
-        if (need > c->topk_bytes) {  // grow-only scratch (first call / larger batch): implies a device sync
+        if (need > c->l2_bytes) {  // grow-only (first call / larger batch): implies a device sync
             HIPCHK(c, hipDeviceSynchronize());
-            if (c->d_topk) (void)hipFree(c->d_topk);
-            c->d_topk = nullptr;
-            c->topk_bytes = 0;
-            HIPCHK(c, hipMalloc(&c->d_topk, need));
-            c->topk_bytes = need;
+            if (c->d_l2_scratch) (void)hipFree(c->d_l2_scratch);
+            c->d_l2_scratch = nullptr;
+            c->l2_bytes = 0;
+            HIPCHK(c, hipMalloc(&c->d_l2_scratch, need));
+            c->l2_bytes = need;
         }
+        // chunks reuse the scratch one after the other: same stream, so chunk k + 1 starts after chunk k has read its keys
         for (int b0 = 0; b0 < npairs; b0 += chunk)
             if (!afv_launch_match_l2_pairs(d_desc, d_n, cap, dim, d_pair_a, d_pair_b, std::min(chunk, npairs - b0), b0, th_low, nnratio, d_match,
-                                           d_nmatches, c->d_topk, s))
+                                           d_nmatches, c->d_l2_scratch, s))
                 return AFV_EUNSUPPORTED;
         HIPCHK(c, hipGetLastError());
         return AFV_OK;

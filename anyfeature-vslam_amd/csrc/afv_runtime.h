@@ -165,6 +165,9 @@ struct afv_ctx {
     void *d_topk = nullptr;  // [npairs][cap] 2 x int4: key record per row (seven (distance, column) keys + the exact-prefix length)
     size_t topk_bytes = 0;
     // column-sliced phase 1 (small-batch path): per-slice records [npairs][cap][nslices] 2 x int4 and the row-tile tickets (zero at rest)
+    void *d_l2_scratch = nullptr;  // key records of the float-descriptor pair matcher (afv_match_l2_pairs_device), its own buffer
+    size_t l2_bytes = 0;
+    int l2_chunk_pairs = 2048;     // pairs per launch of that matcher; afv_set_l2_chunk_pairs
     void *d_slice = nullptr;
     size_t slice_bytes = 0;
     int *d_tickets = nullptr;

@@ -573,7 +573,7 @@ static int akz_detect_enqueue(afv_akaze *a) {
     {
         const int rc = akz_grid_geometry(P, a->prm.derivative_factor, D.lv, &D.gcells, &D.gelems, &D.lds_bytes);
         if (rc) return rc;
-        if ((size_t)D.gcells > a->grid_cells_max || (size_t)D.gelems > a->grid_elems_max || D.lds_bytes > 60 * 1024) return AFV_EUNSUPPORTED;
+        if ((size_t)D.gcells > a->grid_cells_max || (size_t)D.gelems > a->grid_elems_max || D.lds_bytes > 58 * 1024) return AFV_EUNSUPPORTED;  // + ~5 KB of static LDS in k_akz_suppress: 64 KB in all
     }
     D.entry_cap = AKD_SLOT_CAP; D.kp_cap = AKD_ENTRY_CAP;
     hipStream_t st = a->stream;
@@ -602,9 +602,13 @@ static int akz_status(afv_akaze *a) {
     int st = 0;
     AKZ_HIPCHK(a, hipStreamSynchronize(a->stream));
     AKZ_HIPCHK(a, hipMemcpy(&st, a->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    if (st == 5) {  // not a capacity problem: an earlier ticket holder of the level pipeline did not move for ~1 s (k_akaze_detect.hip)
+        a->last_error = "level pipeline stalled (suppression): the device was preempted or is being profiled; repeat the call";
+        return AFV_ETIMEOUT;
+    }
     if (st) {
         a->last_error = st == 1 ? "candidate capacity exceeded" : st == 2 ? "grid cell capacity exceeded" : st == 3 ? "keypoint list capacity exceeded"
-                        : st == 5 ? "level pipeline stalled (suppression)" : "output capacity exceeded";
+                        : "output capacity exceeded";
         return AFV_ECAPACITY;
     }
     return AFV_OK;
@@ -692,17 +696,19 @@ extern "C" int afv_akaze_extract(afv_akaze *a, const uint8_t *gray, int nframes,
     if (!a || !n_out || !kps || !desc61 || cap_per_frame < 1) return AFV_EINVAL;
     int rc = afv_akaze_scale_space(a, gray, nframes, w, h, stride, frame_stride);
     if (rc) return rc;
-    rc = akz_detect_enqueue(a);
-    if (rc) return rc;
-    rc = akz_describe_enqueue(a);
-    if (rc) return rc;
-    for (int f = 0; f < nframes; ++f) {
-        int n = 0;
-        rc = afv_akaze_get_features(a, f, kps + (size_t)f * cap_per_frame, desc61 + (size_t)f * cap_per_frame * 61, cap_per_frame, &n);
-        n_out[f] = n;
+    for (int attempt = 0; attempt < 2; ++attempt) {  // a stalled level pipeline (AFV_ETIMEOUT) is repeated once: the scale space is still there
+        rc = akz_detect_enqueue(a);
         if (rc) return rc;
+        rc = akz_describe_enqueue(a);
+        if (rc) return rc;
+        for (int f = 0; f < nframes && !rc; ++f) {
+            int n = 0;
+            rc = afv_akaze_get_features(a, f, kps + (size_t)f * cap_per_frame, desc61 + (size_t)f * cap_per_frame * 61, cap_per_frame, &n);
+            n_out[f] = n;
+        }
+        if (rc != AFV_ETIMEOUT) break;
     }
-    return AFV_OK;
+    return rc;
 }
 
 extern "C" int afv_akaze_extract_device(afv_akaze *a, const uint8_t *d_gray, int nframes, int w, int h, int stride, size_t frame_stride) {

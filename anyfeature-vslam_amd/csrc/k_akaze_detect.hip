@@ -246,6 +246,7 @@ struct AkdState {
     unsigned int epoch;       // 1 .. AKD_EPOCH_MAX, changes with every launch
 };
 
+#define AKD_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define AKD_T 1024
 #define AKD_COMM (AKD_T - 64)    // the lane that talks to the neighbouring levels (first lane of the last wavefront)
 #define AKD_PAIRS 8   // 2 grids x the (at most) 2 x 2 cells a candidate's disc overlaps
@@ -524,7 +525,9 @@ __global__ __launch_bounds__(AKD_T, 8) void k_akz_suppress(AkdParams P, AkdState
             const unsigned long long apm = __ballot(type == 1);
             if (lane == 0) s_apps[tid >> 6] = __popcll(apm);
         }
-        __syncthreads();
+        // LDS-only barrier (round 4): what crosses it is s_moved / s_apps.  __syncthreads() also drains the vector-memory counter of
+        // every wavefront - here that is the communication lane's L2 write-back, which is meant to run BEHIND the decision phases
+        AKD_LDS_BARRIER();
 #ifdef AFV_AKZ_STATS
         const long long ph3 = wall_clock64();
 #endif
@@ -555,7 +558,7 @@ __global__ __launch_bounds__(AKD_T, 8) void k_akz_suppress(AkdParams P, AkdState
 #ifdef AFV_AKZ_STATS
         const long long ph3a = wall_clock64();
 #endif
-        __syncthreads();
+        AKD_LDS_BARRIER();  // s_stop (LDS atomics) is all that crosses; the write-back is waited for right below, by its own lane only
 #ifdef AFV_AKZ_STATS
         const long long ph3b = wall_clock64();
 #endif

@@ -177,8 +177,9 @@ class Context:
         self.check(self.lib.afv_profile_enable(self.handle, int(every) if enable else 0))
 
     def profile_read(self):
-        launches = np.zeros(len(_lib.STAGES), np.int32); ms = np.zeros(len(_lib.STAGES), np.float32)
-        units = np.zeros(len(_lib.STAGES), np.int64)
+        ns = max(int(self.lib.afv_num_stages()), len(_lib.STAGES))  # the library writes afv_num_stages() entries
+        launches = np.zeros(ns, np.int32); ms = np.zeros(ns, np.float32)
+        units = np.zeros(ns, np.int64)
         self.check(self.lib.afv_profile_read(self.handle, ptr(launches), ptr(ms), ptr(units)))
         return {name: {"launches": int(launches[i]), "total_ms": float(ms[i]), "units": int(units[i])}
                 for i, name in enumerate(_lib.STAGES)}
@@ -196,6 +197,9 @@ class Context:
     def set_small_batch_path(self, mode, max_frames=0):
         """0 = never, 1 = calls of at most max_frames frames / pairs (default), 2 = always; identical results either way"""
         self.check(self.lib.afv_set_small_batch_path(self.handle, int(mode), int(max_frames)))
+
+    def set_l2_chunk_pairs(self, pairs):
+        self.check(self.lib.afv_set_l2_chunk_pairs(self.handle, int(pairs)))
 
     def set_match_resolve(self, engine):
         """phase 2 of the pair matchers: 1 = workgroup-wide fixed point, 0 = ordered walk on one wavefront, 2 = by call size (default); identical results"""

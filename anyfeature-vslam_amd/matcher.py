@@ -307,6 +307,13 @@ class FeatureMatcher:
             match = torch.empty((npairs, cap), dtype=torch.int32, device=desc.device)
         if nmatches is None:
             nmatches = torch.empty((npairs,), dtype=torch.int32, device=desc.device)
+        # raw pointers cross the C boundary: a wrong dtype / a strided view / a tensor on another device would be read as garbage jobs
+        for name, t_, dt in (("desc", desc, torch.float32), ("n", n, torch.int32), ("pair_a", pair_a, torch.int32), ("pair_b", pair_b, torch.int32),
+                             ("match", match, torch.int32), ("nmatches", nmatches, torch.int32)):
+            if t_.dtype != dt or not t_.is_cuda or t_.device != desc.device or not t_.is_contiguous():
+                raise TypeError("match_l2_pairs_device: %s must be a contiguous %s tensor on %s" % (name, dt, desc.device))
+        if pair_b.numel() != npairs or match.numel() < npairs * cap or nmatches.numel() < npairs:
+            raise ValueError("match_l2_pairs_device: pair lists / outputs of different lengths")
         rc = _lib.launch_ordered(self.ctx, desc.device, stream, lambda s: self.lib.afv_match_l2_pairs_device(
             self.ctx.handle, desc.data_ptr(), n.data_ptr(), cap, dim, pair_a.data_ptr(), pair_b.data_ptr(), npairs, float(th_low),
             float(self.mfNNratio if nnratio is None else nnratio), match.data_ptr(), nmatches.data_ptr(), s),

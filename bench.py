@@ -22,6 +22,7 @@ import argparse
 import importlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -281,6 +282,11 @@ def pairs_cpu_baseline(table, angles, counts, pa, pb, budget_s=12.0):
                       "oracle/afvo.c, 1 pinned thread, %d logical cores on the host" % (per_rep, os.cpu_count() or 0)}
 
 
+def table_broadcast_bytes(K, cap):
+    """what one replication of the keyframe table moves: descriptors + angles + counts (36 004 000 B at K = 1000, cap = 1000)"""
+    return int(K * cap * 32 + K * cap * 4 + K * 4)
+
+
 def pairs_main(args):
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -326,7 +332,7 @@ def pairs_main(args):
         dist.broadcast(t, src=0)
         return bytes(t.cpu().numpy().tobytes())
 
-    bc = {"bytes": int(K * cap * 32 + K * cap * 4 + K * 4), "via": None}
+    bc = {"bytes": table_broadcast_bytes(K, cap), "via": None}
     comm = None
     if args.backend == "nccl":
         try:
@@ -421,6 +427,7 @@ def pairs_main(args):
                                       "nnratio 0.75, orientation check; table built on rank 0 and replicated with one broadcast; jobs block-partitioned"
                                       % (njobs, K, cap), "jobs_per_step": njobs, "jobs_per_gpu_per_step": tbl_mod.shard_range(njobs, 0, world)[1],
                           "parallelism": "jobs sharded x%d, table replicated" % world,
+                          "job_ranges": [list(tbl_mod.shard_range(njobs, r, world)) for r in range(world)], "backend": args.backend if world > 1 else None,
                           "matches_per_job": float(allnm.mean()), "jobs_with_matches": int((allnm > 0).sum())},
                "descriptor_pairs_per_s": jobs_s * cap * cap,
                "broadcast": bc, "gather_ms": gather_ms,
@@ -747,6 +754,19 @@ def extra_akaze61(afv, device, B=64, steps=3):
     return out
 
 
+def extra_host_api():
+    """the reference's call shape measured from C++ (tools/host_latency.cpp, built by __graft_entry__.build()): afv_orb_extract host to
+    host, with a pageable and with a page-locked image, and the brute-force afv_match_bow of two frames through host buffers"""
+    exe = os.path.join(ROOT, "tools", "host_latency")
+    if not os.path.exists(exe):
+        return {"error": "tools/host_latency is not built"}
+    r = subprocess.run([exe, "300"], capture_output=True, text=True, timeout=120)
+    for line in r.stdout.splitlines():
+        if line.startswith("{"):
+            return json.loads(line)
+    return {"error": (r.stderr or r.stdout)[-300:]}
+
+
 def extra_single_frame(afv, device, reps=200):
     """The plugin shape (Frame.cc:186: ONE frame per call; Tracking.cc:78,84 keeps two extractor instances): latency of one
     640 x 480 frame extracted + matched against its predecessor on one context, and the frame rate when 2 / 4 contexts (each with its own
@@ -934,6 +954,12 @@ def main():
         dist.all_reduce(k, op=dist.ReduceOp.SUM)
     dt = float(t.item())
     total_kp = int(k.item()) * args.steps
+    # who did what (the first multi-GPU run should be boring): every rank's frame seeds and keypoint count
+    per_rank = [{"rank": rank, "first_seed": seed0, "frames": B, "keypoints_per_step": kp_step}]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
 
     if rank == 0:
         out = {
@@ -943,7 +969,8 @@ def main():
             "config": {"workload": "ORB32 640x480 synthetic corners frames (LCG), 1000 kp/frame budget, 8 levels x1.2, FAST 20; "
                                    "extract+describe on device, brute-force Hamming match frame t vs t-1 (TH 75, ratio 0.6, "
                                    "orientation check)", "frames_per_gpu_per_step": B, "global_frames_per_step": B * world,
-                       "keypoints_per_frame": kp_step / B, "matches_per_frame": nm_step / B, "parallelism": "frames sharded x%d" % world},
+                       "keypoints_per_frame": kp_step / B, "matches_per_frame": nm_step / B, "parallelism": "frames sharded x%d" % world,
+                       "per_rank": per_rank, "backend": args.backend if world > 1 else None},
             "keypoints_per_ms": total_kp / dt / 1e3,
             "frames_per_s": B * world * args.steps / dt,
         }
@@ -1012,6 +1039,15 @@ def main():
                                              "op-class shares (profiles/r*/isa_valu_classes.json) and dynamic counts - uncalibrated classes at the plain rate, so "
                                              "frac_vs_isa_mix is a lower bound.  stale = the sources changed since the pass, "
                                              "the fractions are withheld"}
+            cp = _newest_profile("cache_pmc.json")
+            if cp:   # north_star: "L2/LDS hit rate on the BRIEF + Hamming pass"; same staleness rule as valu_issue / roofline.traffic
+                keep = ("k_describe", "k_match_topk_mfma", "k_match_resolve", "k_fast_nms", "k_harris", "k_resize_level<96, 48>", "k_select_quadtree")
+                out["cache"] = {"stale": cp["_stale"], "source": cp["_path"],
+                                "kernels": None if cp["_stale"] else {k: {f: (round(v, 4) if isinstance(v, float) else v) for f, v in e.items() if f in
+                                                                           ("l2_hit", "lds_conflict_cycles_per_inst", "lds_wait_cycles_per_inst")}
+                                                                       for k, e in cp["kernels"].items() if k in keep},
+                                "note": "l2_hit = TCC_HIT / (TCC_HIT + TCC_MISS), LDS bank-conflict and wait cycles per LDS instruction: committed PMC passes "
+                                        "(tools/collect_profiles.sh -> tools/pmc_cache.py), withheld when the sources changed since"}
             out["stage_ms_per_step"] = {kk: (v["total_ms"] / prof_steps) for kk, v in stages.items()}  # overlapping streams: sums exceed ms_per_step
             out["stage_events_on_steps"] = "%d of %d timed steps (every %d-th)" % (prof_steps, args.steps, PROF_EVERY)
         if world == 1 and not args.no_extras:
@@ -1026,6 +1062,10 @@ def main():
             out["host_fed"] = host_fed(afv, ctx, frames.cpu().numpy(), max(args.steps // 3, 5), dev_fps)
             out["batch_sweep"] = batch_sweep(afv, local)
             out["overlap_match"] = overlap_step(afv, local)
+            try:
+                out["host_api"] = extra_host_api()
+            except Exception as e:
+                out["host_api"] = {"error": str(e)[:200]}
             for key, fn in (("single_frame", extra_single_frame), ("pairs10k", extra_pairs10k), ("l2_sift128", extra_l2_sift128), ("akaze61", extra_akaze61)):
                 try:
                     out[key] = fn(afv, local)

@@ -40,7 +40,9 @@ enum {
     AFV_ENOMEM = -3,     /* device or host allocation failed */
     AFV_EHIP = -4,       /* a HIP runtime call or kernel failed; see afv_last_error() */
     AFV_ECAPACITY = -5,  /* caller-provided output capacity too small; outputs truncated */
-    AFV_EUNSUPPORTED = -6
+    AFV_EUNSUPPORTED = -6,
+    AFV_ETIMEOUT = -7    /* a device-side wait gave up (a level pipeline stalled for ~1 s: preemption, a debugger, a profiler); nothing
+                            about the inputs is wrong - the call can be repeated (afv_akaze_extract does so once by itself) */
 };
 
 typedef struct afv_ctx afv_ctx;
@@ -351,6 +353,9 @@ int afv_profile_read(afv_ctx *ctx, int32_t *launches /*[afv_num_stages()]*/, flo
 int afv_set_split_threshold(afv_ctx *ctx, int min_frames);
 int afv_set_split_chunks(afv_ctx *ctx, int chunks); /* ... into this many chunks alternating over the two streams (2..64; 0 = automatic,
                                                       * chunks of about 85 frames: the default) */
+/* afv_match_l2_pairs_device processes its jobs in launches of at most `pairs` jobs (default 2048; the key scratch of a launch is
+ * pairs x cap x 32 bytes and is reused by the next launch on the same stream) */
+int afv_set_l2_chunk_pairs(afv_ctx *ctx, int pairs);
 /* Phase 2 of the brute-force pair matchers (the ordered greedy assignment of SearchByBoW, FeatureMatcher.cc:587-641); identical results:
  *   1: one fixed point over all live rows of a pair, a thread per row, claims in rotating LDS arrays (one barrier per pass): half the
  *      latency of a pair, more total work

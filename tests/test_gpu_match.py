@@ -239,6 +239,39 @@ def test_l2_pairs_over_a_device_table(afv, oracle, matcher, dim, noise, ratio):
     assert total > 500
 
 
+def test_l2_pairs_in_several_launches_with_a_ragged_last_one(afv, oracle, matcher, gpu_ctx):
+    """afv_match_l2_pairs_device cuts its job list into launches that reuse one key scratch (2048 jobs per launch by default; 4 here):
+    11 jobs = 4 + 4 + 3, every job against the oracle, and a wrapper call with a wrong dtype is refused"""
+    import torch
+    s = afv.synth
+    dim, K, cap = 64, 5, 300
+    counts = [300, 257, 64, 299, 130]
+    table = np.zeros((K, cap, dim), np.float32)
+    base, other = _sift_like(s, 4711, cap, dim, 700.0)
+    for k in range(K):
+        table[k, :counts[k]] = np.roll(base if k % 2 == 0 else other, 11 * k, axis=0)[:counts[k]]
+    pa = np.array([0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 0], np.int32)
+    pb = np.array([1, 2, 3, 4, 0, 2, 3, 4, 0, 1, 4], np.int32)
+    dev = torch.device("cuda", 0)
+    t_table, t_n = torch.from_numpy(table).to(dev), torch.tensor(counts, dtype=torch.int32, device=dev)
+    gpu_ctx.set_l2_chunk_pairs(4)
+    try:
+        m, nm = matcher.match_l2_pairs_device(t_table, t_n, torch.from_numpy(pa).to(dev), torch.from_numpy(pb).to(dev), 0.5, 0.95)
+        torch.cuda.synchronize()
+    finally:
+        gpu_ctx.set_l2_chunk_pairs(2048)
+    m, nm = m.cpu().numpy(), nm.cpu().numpy()
+    total = 0
+    for j in range(len(pa)):
+        a, b = table[pa[j], :counts[pa[j]]], table[pb[j], :counts[pb[j]]]
+        want, wn = oracle.match_l2_bruteforce(a, b, 0.5, 0.95)
+        assert nm[j] == wn and np.array_equal(m[j, :len(a)], want) and (m[j, len(a):] == -1).all(), j
+        total += wn
+    assert total > 300
+    with pytest.raises(TypeError):
+        matcher.match_l2_pairs_device(t_table, t_n, torch.from_numpy(pa.astype(np.int64)).to(dev), torch.from_numpy(pb).to(dev), 0.5, 0.95)
+
+
 def test_l2_duplicate_columns_ties(afv, oracle, matcher):
     """identical train descriptors: equal distances must resolve to the lowest column, and the duplicates make the ratio test
     fail (best == second) until all but one copy are taken"""

@@ -466,3 +466,35 @@ def test_comm_two_ranks(afv, oracle):
     b = ((a.astype(np.int64) + 1 + (b.astype(np.int64) % 3)) % K).astype(np.int32)
     want = [_oracle_job(oracle, host, int(a[j]), int(b[j]))[1] for j in range(njobs)]
     assert res[0][1] == want and res[1][1] == want
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("workload", ["orb32", "pairs10k"])
+def test_bench_two_ranks_on_one_device_through_the_self_launch(workload):
+    """the N > 1 path of bench.py end to end, as far as one GPU allows: `python bench.py --gpus 2` without a launcher re-executes itself
+    under torch.distributed.run (one process per rank, 127.0.0.1), both ranks share cuda:0 (--single-device) and talk gloo.  Checked on
+    the JSON line: world size, per-rank ownership (frame seeds / job ranges), totals, and which replication path the table took."""
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device", "--steps", "2", "--warmup", "1",
+           "--cpu-frames", "0", "--no-extras", "--no-profile", "--workload", workload]
+    cmd += ["--batch", "16"] if workload == "orb32" else ["--keyframes", "64", "--jobs", "400", "--bcast-reps", "1"]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=540, env=env, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["steps"] == 2
+    if workload == "orb32":
+        pr = d["config"]["per_rank"]
+        assert [p["rank"] for p in pr] == [0, 1] and [p["first_seed"] for p in pr] == [1, 17] and all(p["frames"] == 16 for p in pr)
+        assert all(p["keypoints_per_step"] > 16 * 900 for p in pr) and pr[0]["keypoints_per_step"] != pr[1]["keypoints_per_step"]
+        assert d["config"]["global_frames_per_step"] == 32 and d["scaling"] == "weak" and d["config"]["backend"] == "gloo"
+        assert abs(d["value"] - sum(p["keypoints_per_step"] for p in pr) * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    else:
+        assert d["config"]["job_ranges"] == [[0, 200], [200, 400]] and d["config"]["jobs_per_step"] == 400 and d["scaling"] == "strong"
+        assert d["broadcast"]["bytes"] == 64 * 1000 * 32 + 64 * 1000 * 4 + 64 * 4
+        assert d["broadcast"]["via"] == "torch.distributed.broadcast (gloo)"      # nccl: "afv_table_broadcast (ncclBroadcast ...)"
+        assert d["config"]["jobs_with_matches"] > 0

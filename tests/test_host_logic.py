@@ -221,3 +221,16 @@ def test_one_launch_pyramid_plan_reproduces_the_level_chain(afv, oracle):
             assert got.min() >= 0, "level %d of %s: a pixel nobody owns" % (l, (w, h, nl, sf))
             assert np.array_equal(got, ref), "level %d of %s differs" % (l, (w, h, nl, sf))
         assert P["lds"] <= 160 * 1024
+
+
+def test_bench_table_broadcast_bytes_and_job_partition(afv):
+    """config #4 bookkeeping bench.py reports for N > 1: one replication of the K = 1000 x 1000 x 32 B table (+ angles, counts) is
+    36 004 000 bytes, and the 10 000 jobs are cut into contiguous per-rank ranges that cover them exactly"""
+    import importlib
+    import bench
+    tbl = importlib.import_module("anyfeature-vslam_amd.table")
+    assert bench.table_broadcast_bytes(1000, 1000) == 36004000
+    for world in (1, 2, 4, 8):
+        rs = [tbl.shard_range(10000, r, world) for r in range(world)]
+        assert rs[0][0] == 0 and rs[-1][1] == 10000 and all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+        assert max(b - a for a, b in rs) - min(b - a for a, b in rs) <= 1

@@ -7,7 +7,8 @@ set -u
 TAG=${1:-rXX}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/profiles_$TAG
-mkdir -p "$OUT"
+RAW=$ROOT/gpurun_out/profiles_${TAG}_raw     # raw counter CSVs stay in scratch: only the summaries derived from them are copied to profiles/
+mkdir -p "$OUT" "$RAW"
 cd /tmp && export TMPDIR=/tmp
 PY=python
 B=256; STEPS=3; WARM=1
@@ -61,15 +62,16 @@ cp "$OUT"/stats_default/*kernel_stats.csv "$OUT/kernel_stats_default.csv" 2>/dev
 echo "== PMC passes on: bench.py $BENCHARGS"
 for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
   timeout 400 rocprofv3 --kernel-trace --pmc $C -d "$OUT/pmc_$C" -o p --output-format csv -- $PY "$ROOT/bench.py" $BENCHARGS > /dev/null 2>&1
-  F=$(find "$OUT/pmc_$C" -name "*counter_collection.csv" | head -1); cp "$F" "$OUT/pmc_${C}_counter_collection.csv"
+  F=$(find "$OUT/pmc_$C" -name "*counter_collection.csv" | head -1); cp "$F" "$RAW/pmc_${C}_counter_collection.csv"
 done
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS -d "$OUT/pmc_LDS" -o p --output-format csv -- $PY "$ROOT/bench.py" $BENCHARGS > /dev/null 2>&1
-cp "$(find "$OUT/pmc_LDS" -name "*counter_collection.csv" | head -1)" "$OUT/pmc_lds_counter_collection.csv"
+cp "$(find "$OUT/pmc_LDS" -name "*counter_collection.csv" | head -1)" "$RAW/pmc_lds_counter_collection.csv"
 timeout 400 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d "$OUT/pmc_L2" -o p --output-format csv -- $PY "$ROOT/bench.py" $BENCHARGS > /dev/null 2>&1
-cp "$(find "$OUT/pmc_L2" -name "*counter_collection.csv" | head -1)" "$OUT/pmc_l2_counter_collection.csv" 2>/dev/null
-cd "$ROOT" && $PY tools/pmc_per_frame.py $B $((STEPS + WARM)) "$OUT" "$OUT/pmc_FETCH_SIZE_counter_collection.csv" "$OUT/pmc_WRITE_SIZE_counter_collection.csv" \
-    "$OUT/pmc_SQ_INSTS_VALU_counter_collection.csv" "$OUT/calib_fetch.json" "$OUT/calib_valu.json" > "$OUT/pmc_per_frame.txt"
-$PY tools/pmc_summary.py "$OUT/pmc_lds_counter_collection.csv" "$OUT/pmc_l2_counter_collection.csv" > "$OUT/pmc_lds_l2_summary.txt" 2>/dev/null
+cp "$(find "$OUT/pmc_L2" -name "*counter_collection.csv" | head -1)" "$RAW/pmc_l2_counter_collection.csv" 2>/dev/null
+cd "$ROOT" && $PY tools/pmc_per_frame.py $B $((STEPS + WARM)) "$OUT" "$RAW/pmc_FETCH_SIZE_counter_collection.csv" "$RAW/pmc_WRITE_SIZE_counter_collection.csv" \
+    "$RAW/pmc_SQ_INSTS_VALU_counter_collection.csv" "$OUT/calib_fetch.json" "$OUT/calib_valu.json" > "$OUT/pmc_per_frame.txt"
+$PY tools/pmc_summary.py "$RAW/pmc_lds_counter_collection.csv" "$RAW/pmc_l2_counter_collection.csv" > "$OUT/pmc_lds_l2_summary.txt" 2>/dev/null
+$PY tools/pmc_cache.py "$OUT" "$RAW/pmc_lds_counter_collection.csv" "$RAW/pmc_l2_counter_collection.csv" > "$OUT/pmc_cache.txt" 2>/dev/null
 cd /tmp
 
 echo "== static VALU op-class shares of the kernels (from the ISA; feeds valu_issue.peak_isa_mix)"
@@ -81,8 +83,8 @@ timeout 400 rocprofv3 --kernel-trace --stats -d "$OUT/stats_pairs" -o st --outpu
 cp "$(find "$OUT/stats_pairs" -name "*kernel_stats.csv" | head -1)" "$OUT/kernel_stats_pairs10k.csv"
 
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT -d "$OUT/pmc_pairs" -o p --output-format csv -- $PY "$ROOT/bench.py" --workload pairs10k --steps 3 --cpu-frames 0 --no-profile > /dev/null 2>&1
-cp "$(find "$OUT/pmc_pairs" -name "*counter_collection.csv" | head -1)" "$OUT/pmc_pairs10k_counter_collection.csv" 2>/dev/null
-$PY "$ROOT/tools/pmc_summary.py" "$OUT/pmc_pairs10k_counter_collection.csv" > "$OUT/pmc_pairs10k_summary.txt" 2>/dev/null
+cp "$(find "$OUT/pmc_pairs" -name "*counter_collection.csv" | head -1)" "$RAW/pmc_pairs10k_counter_collection.csv" 2>/dev/null
+$PY "$ROOT/tools/pmc_summary.py" "$RAW/pmc_pairs10k_counter_collection.csv" > "$OUT/pmc_pairs10k_summary.txt" 2>/dev/null
 
 echo "== config #5: AKAZE61 bench + kernel stats"
 cd "$ROOT" && $PY bench.py --workload akaze61 --batch 64 --steps 5 > "$OUT/bench_akaze61.json" 2> "$OUT/bench_akaze61.err"; cd /tmp
