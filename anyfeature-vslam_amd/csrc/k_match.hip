@@ -809,7 +809,7 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve_wg(const uint8_t *__res
     uint32_t *s_cols = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(s_flag + capr) + 15) & ~(uintptr_t)15);
     __shared__ int s_hist[32];
     __shared__ int s_wave[8];
-    __shared__ int s_nm, s_drop[3], s_first, s_part[2 * (MT / 64)];
+    __shared__ int s_nm, s_drop[3], s_first, s_part[2 * (MT / 64)], s_cntw[16];
     const int p = pair_base + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int a = pair_a[p], b = pair_b[p];
     const int n1 = min(nset[a], cap), n2 = min(nset[b], cap);
@@ -818,49 +818,82 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve_wg(const uint8_t *__res
     for (int i = tid; i < capr; i += MT) s_out[i] = -1;
     for (int i = tid; i < 3 * capr; i += MT) s_claim[i] = RW_INF;
     if (tid < 32) s_hist[tid] = 0;
-    // rows whose best distance fails TH_LOW can never match: compact the others IN ROW ORDER, keys staged in LDS
+    // rows whose best distance fails TH_LOW can never match: compact the others IN ROW ORDER, keys staged in LDS.  Sets of up to 1024 rows
+    // (the usual case) in ONE step: a thread fetches the records of its four rows together (one L2 round trip), the 16 (block of 256
+    // rows, wavefront) live counts meet in LDS behind one barrier, and every thread places its rows from them
     int nlive = 0;
-    int4 pre4[4], pre8[4];  // the records of a thread's first four rows: one L2 round trip
+    if (n1 <= 4 * MT) {
+        int4 pre4[4], pre8[4];
+        unsigned long long bal[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int i = u * MT + tid;
-        pre4[u] = make_int4(NO_KEY, NO_KEY, NO_KEY, NO_KEY);
-        pre8[u] = make_int4(NO_KEY, NO_KEY, NO_KEY, TOPK);
-        if (i < n1) {
-            pre4[u] = tk[2 * i];
-            pre8[u] = tk[2 * i + 1];
-        }
-    }
-    for (int i0 = 0; i0 < n1; i0 += MT) {
-        const int i = i0 + tid;
-        int4 t4 = make_int4(NO_KEY, NO_KEY, NO_KEY, NO_KEY), t8 = make_int4(NO_KEY, NO_KEY, NO_KEY, TOPK);
-        if (i0 < 4 * MT) {  // uniform
-            const int u = i0 / MT;
-            t4 = u == 0 ? pre4[0] : u == 1 ? pre4[1] : u == 2 ? pre4[2] : pre4[3];
-            t8 = u == 0 ? pre8[0] : u == 1 ? pre8[1] : u == 2 ? pre8[2] : pre8[3];
-        } else if (i < n1) {
-            t4 = tk[2 * i];
-            t8 = tk[2 * i + 1];
-        }
-        const bool live = t4.x != NO_KEY && (float)(t4.x >> 16) < th;
-        const unsigned long long m = __ballot(live);
-        if (lane == 0) s_wave[wv] = __popcll(m);
-        __syncthreads();
-        int off = nlive;
-        for (int w = 0; w < wv; ++w) off += s_wave[w];
-        if (live) {
-            const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
-            s_live[slot] = (unsigned short)i;
-            s_w1[slot] = -1;
-            s_w2[slot] = -1;
-            s_flag[slot] = 0;
-            if (slot < PAIR_KEYS_LDS) {
-                s_keys[2 * slot] = t4;
-                s_keys[2 * slot + 1] = t8;
+        for (int u = 0; u < 4; ++u) {
+            const int i = u * MT + tid;
+            pre4[u] = make_int4(NO_KEY, NO_KEY, NO_KEY, NO_KEY);
+            pre8[u] = make_int4(NO_KEY, NO_KEY, NO_KEY, TOPK);
+            if (i < n1) {
+                pre4[u] = tk[2 * i];
+                pre8[u] = tk[2 * i + 1];
             }
         }
-        nlive += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool live = pre4[u].x != NO_KEY && (float)(pre4[u].x >> 16) < th;
+            bal[u] = __ballot(live);
+            if (lane == 0) s_cntw[u * 4 + wv] = __popcll(bal[u]);
+        }
         __syncthreads();
+        int run = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int off = run;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int cw = s_cntw[u * 4 + w];
+                off += w < wv ? cw : 0;
+                run += cw;
+            }
+            if ((bal[u] >> lane) & 1ull) {
+                const int slot = off + __popcll(bal[u] & ((1ull << lane) - 1ull));
+                s_live[slot] = (unsigned short)(u * MT + tid);
+                s_w1[slot] = -1;
+                s_w2[slot] = -1;
+                s_flag[slot] = 0;
+                if (slot < PAIR_KEYS_LDS) {
+                    s_keys[2 * slot] = pre4[u];
+                    s_keys[2 * slot + 1] = pre8[u];
+                }
+            }
+        }
+        nlive = run;
+        __syncthreads();
+    } else {
+        for (int i0 = 0; i0 < n1; i0 += MT) {
+            const int i = i0 + tid;
+            int4 t4 = make_int4(NO_KEY, NO_KEY, NO_KEY, NO_KEY), t8 = make_int4(NO_KEY, NO_KEY, NO_KEY, TOPK);
+            if (i < n1) {
+                t4 = tk[2 * i];
+                t8 = tk[2 * i + 1];
+            }
+            const bool live = t4.x != NO_KEY && (float)(t4.x >> 16) < th;
+            const unsigned long long m = __ballot(live);
+            if (lane == 0) s_wave[wv] = __popcll(m);
+            __syncthreads();
+            int off = nlive;
+            for (int w = 0; w < wv; ++w) off += s_wave[w];
+            if (live) {
+                const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
+                s_live[slot] = (unsigned short)i;
+                s_w1[slot] = -1;
+                s_w2[slot] = -1;
+                s_flag[slot] = 0;
+                if (slot < PAIR_KEYS_LDS) {
+                    s_keys[2 * slot] = t4;
+                    s_keys[2 * slot + 1] = t8;
+                }
+            }
+            nlive += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+            __syncthreads();
+        }
     }
     const uint32_t *d1 = reinterpret_cast<const uint32_t *>(desc + (size_t)a * cap * 32);
     const uint32_t *d2 = reinterpret_cast<const uint32_t *>(desc + (size_t)b * cap * 32);

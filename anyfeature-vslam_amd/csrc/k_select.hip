@@ -383,8 +383,19 @@ __device__ __forceinline__ void select_quadtree_body(const Geo *__restrict__ geo
         for (int p = tid; p < m2; p += ST) kn[p] = (uint16_t)aux2[kn[p]];
     }
     int size = tmp[9];
-    // every round starts with child[0 .. 4*size) and its n_expand slot cleared (the previous round does it; this is round 0's)
-    for (int i = tid; i < size * 4; i += ST) child[i] = 0;
+    // the fast-forward below counts points per grid cell at depths 1..ff_dmax under each root (S_d = roots * 4^d cells, S_dmax <= M):
+    // counters by natural path index ((root * 4 + q1) * 4 + q2) * 4 + q3.  C2 sits in `aux` (the root counts in it were consumed
+    // before the barrier above), C3 and C1 borrow `remap` (only used inside a round: 2 M ints)
+    int ff_dmax = 0;
+    for (int d = 1, S = size * 4; d <= 3 && S <= M && m2 > 0 && m2 <= SelCfg<ST>::KEPT_LDS; ++d, S *= 4) ff_dmax = d;
+    const int ff_SM = size * (ff_dmax == 0 ? 1 : ff_dmax == 1 ? 4 : ff_dmax == 2 ? 16 : 64);
+    int *C1 = reinterpret_cast<int *>(remap) + M, *C2 = aux, *C3 = reinterpret_cast<int *>(remap);
+    if (ff_dmax >= 1) for (int i = tid; i < size * 4; i += ST) C1[i] = 0;
+    if (ff_dmax >= 2) for (int i = tid; i < size * 16; i += ST) C2[i] = 0;
+    if (ff_dmax >= 3) for (int i = tid; i < size * 64; i += ST) C3[i] = 0;
+    // every round starts with child[0 .. 4*size) and its n_expand slot cleared (the previous round does it; this is round 0's - wide
+    // enough for whatever list the fast-forward hands over)
+    for (int i = tid; i < ff_SM * 4; i += ST) child[i] = 0;
     if (tid == 0) {
         tmp[12] = tmp[13] = tmp[10] = 0;
         tmp[11] = 0x7fffffff;
@@ -413,6 +424,144 @@ __device__ __forceinline__ void select_quadtree_body(const Geo *__restrict__ geo
         }
     }
     int par = 0;  // n_expand slot of this round: tmp[12 + par]
+
+    // ---------------- fast-forward through the first rounds (round 4) ----------------
+    // While phase A lasts, EVERY node with more than one point splits, so as long as no node holds a single point the list after round
+    // d is the set of non-empty cells of the 4^d grid below each root (cells cut by DivideNode's own halving rule), in an order that
+    // follows from "children of later-processed nodes first, n4 before n1": list index j_d = (S_(d-1) - 1 - j_(d-1)) * 4 + (3 - q_d),
+    // j_0 = the root's index, S_d = roots * 4^d.  A point finds its cell at depths 1..3 by arithmetic on its root's box (no list, no
+    // barrier), three LDS atomics count the cells' points, and the loop's own bookkeeping - sizes, nodes that can still split, the
+    // termination and phase-B tests of every round (ORBextractor.cc:366-370) - is evaluated on those counts.  The deepest round D
+    // for which the loop would still have been in phase A with every node splitting is adopted as the loop's starting state (list,
+    // counts, boxes, labels): three rounds of ~3.5 us of dependent LDS phases become one pass.  Anything else (a single-point node, an
+    // early stop) falls back to the loop from wherever the fast-forward is still exact - round 0 at worst.
+    if (small && !finish && ff_dmax >= 1) {
+        __shared__ int s_ff[4];  // wave 0's verdict: D, size of the list after round D, finished, phase B
+        const int nroots = size, dmax = ff_dmax;
+        uint32_t paths[PPT];  // natural path index at depth dmax, and the digits q1..q3 in bits 24..29
+#pragma unroll
+        for (int k_ = 0; k_ < PPT; ++k_) {
+            paths[k_] = 0;
+            if (tid + k_ * ST < m2) {
+                Rect16 r = rc[nd_[k_]];
+                int pth = nd_[k_];
+                uint32_t dig = 0;
+                for (int d = 1; d <= dmax; ++d) {
+                    const int q = point_quadrant(xy_[k_], scale, r);
+                    r = child_rect(r, q);
+                    pth = pth * 4 + q;
+                    dig |= (uint32_t)q << (22 + 2 * d);
+                    atomicAdd(d == 1 ? &C1[pth] : d == 2 ? &C2[pth] : &C3[pth], 1);
+                }
+                paths[k_] = (uint32_t)pth | dig;
+            }
+        }
+        __syncthreads();
+        // list order -> natural path at depth D (and back: the digit flips are involutions)
+        auto nat_of = [&](int j, int D, int &root) {
+            int q[3] = {0, 0, 0};
+            int S = nroots * (D == 1 ? 1 : D == 2 ? 4 : 16);
+            for (int d = D; d >= 1; --d) {
+                q[d - 1] = 3 - (j & 3);
+                j = S - 1 - (j >> 2);
+                S >>= 2;
+            }
+            root = j;
+            int nat = j;
+            for (int d = 0; d < D; ++d) nat = nat * 4 + q[d];
+            return nat;
+        };
+        if (tid < 64) {
+            // ONE wavefront replays the loop's bookkeeping on the counts (a workgroup-wide phase costs ~0.8 us of barrier + dependent LDS
+            // round trips whatever it does; this is a few hundred counters): per depth the non-empty cells and the cells that can still
+            // split, the loop's decisions round by round, then the list positions of the adopted depth by a wave-wide prefix sum
+            int D = 0, sz_prev = nroots;
+            bool fin = false, pb = false;
+            int nx_prev = __ballot(tid < nroots && cc[min(tid, nroots - 1)] < 2) ? -1 : nroots;  // every root must split in round 1 (<= 16 roots)
+            for (int d = 1, S = nroots * 4; d <= dmax; ++d, S *= 4) {
+                if (fin || pb || nx_prev != sz_prev) break;  // the loop would not run round d as an all-splitting phase-A round
+                const int *C = d == 1 ? C1 : d == 2 ? C2 : C3;
+                int ne = 0, nx = 0;
+                for (int i = tid; i < S; i += 64) {
+                    const int c = C[i];
+                    ne += c > 0;
+                    nx += c > 1;
+                }
+                const int packed = __builtin_amdgcn_readlane(afv_wave_incl_scan(ne | (nx << 16)), 63);
+                const int sz = packed & 0xffff;
+                nx = packed >> 16;
+                D = d;
+                fin = sz >= N || sz == sz_prev;
+                pb = !fin && sz + nx * 3 > N;
+                sz_prev = sz;
+                nx_prev = nx;
+            }
+            int new_size = 0;
+            if (D >= 1) {
+                const int SD = nroots * (D == 1 ? 4 : D == 2 ? 16 : 64);
+                const int *C = D == 1 ? C1 : D == 2 ? C2 : C3;
+                const int per = (SD + 63) / 64, b = tid * per, e = min(b + per, SD);
+                int local = 0;
+                for (int j = b; j < e; ++j) {
+                    int root;
+                    local += C[nat_of(j, D, root)] > 0 ? 1 : 0;
+                }
+                const int incl = afv_wave_incl_scan(local);
+                new_size = __builtin_amdgcn_readlane(incl, 63);
+                int pos = incl - local;
+                for (int j = b; j < e; ++j) {
+                    int root;
+                    unt[j] = pos;  // list position of slot j (meaningful where the cell is non-empty)
+                    pos += C[nat_of(j, D, root)] > 0 ? 1 : 0;
+                }
+            }
+            if (tid == 0) {
+                s_ff[0] = D;
+                s_ff[1] = new_size;
+                s_ff[2] = fin ? 1 : 0;
+                s_ff[3] = pb ? 1 : 0;
+            }
+        }
+        __syncthreads();
+        const int D = s_ff[0];
+        if (D >= 1) {
+            const int SD = nroots * (D == 1 ? 4 : D == 2 ? 16 : 64);
+            const int *C = D == 1 ? C1 : D == 2 ? C2 : C3;
+            for (int j = tid; j < SD; j += ST) {
+                int root;
+                const int nat = nat_of(j, D, root);
+                const int c = C[nat];
+                if (c > 0) {
+                    Rect16 r = rc[root];
+                    for (int d = D - 1; d >= 0; --d) r = child_rect(r, (nat >> (2 * d)) & 3);
+                    rn[unt[j]] = r;
+                    cn[unt[j]] = c;
+                }
+            }
+            // labels: a point's list slot from its digits
+#pragma unroll
+            for (int k_ = 0; k_ < PPT; ++k_) {
+                if (tid + k_ * ST < m2) {
+                    int nat = (int)(paths[k_] & 0xffffffu);
+                    for (int d = dmax; d > D; --d) nat >>= 2;  // the path was taken down to dmax
+                    int j = nat >> (2 * D), S = nroots;        // the root
+                    for (int d = 1; d <= D; ++d) {
+                        j = (S - 1 - j) * 4 + (3 - (int)((paths[k_] >> (22 + 2 * d)) & 3u));
+                        S *= 4;
+                    }
+                    nd_[k_] = unt[j];
+                }
+            }
+            size = s_ff[1];
+            {
+                Rect16 *t = rc; rc = rn; rn = t;
+                int *u = cc; cc = cn; cn = u;
+            }
+            finish = s_ff[2] != 0;
+            phase_b = s_ff[3] != 0;
+        }
+        __syncthreads();
+    }
 
     // Barriers per round: occupancy | order | (scan: 2) | new list | relabel.  Everything a later phase reads is written at
     // least one barrier earlier; the clears for the NEXT round ride the relabel phase, which touches neither array.
