@@ -20,6 +20,11 @@ for W in orb32 pairs10k; do
 done
 python tools/timeline.py --batch 1 --no-split > "$OUT/timeline_single_frame.json" 2>/dev/null
 python tools/bench_single_frame.py > "$OUT/single_frame.txt" 2>/dev/null
+# the per-frame plugin call (round 4): kernel-level trace of bench.py's single_frame.contexts_1 workload with the small-batch kernels (1) and
+# with the batch kernels (0), and the host-to-host latencies measured from C++
+for M in 1 0; do python tools/single_frame_trace.py $M > /dev/null 2>&1; cp gpurun_out/single_frame_trace/summary_mode$M.json "$OUT/single_frame_trace_mode$M.json" 2>/dev/null; done
+./tools/host_latency 300 > "$OUT/host_latency.json" 2>&1
+AFV_TRACE_HOST=1 ./tools/host_latency 300 2>&1 | grep "afv_orb_extract (us" | tail -2 > "$OUT/host_latency_breakdown.txt"
 python tools/probes/probe_pcie.py > "$OUT/pcie_probe.txt" 2>&1
 for P in probe_cvt_pk_u8 probe_mfma_valu; do
   hipcc --offload-arch=gfx950 -O3 tools/probes/$P.hip -o /tmp/$P 2>/dev/null && /tmp/$P > "$OUT/$P.txt" 2>&1
