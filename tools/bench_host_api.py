@@ -65,3 +65,16 @@ actx = afv.AkazeContext(afv.akaze.default_params())
 big = s.corners_batch(1, 1, 1280, 720)[0]
 ms, r = med(lambda: actx.extract(big), n=10)
 print("afv_akaze_extract (1 frame 1280x720, host buffers): %.3f ms  (%d keypoints)" % (ms, len(r[0])))
+# relocalisation batch: ONE frame against 32 candidate keyframes of a device-resident table (Tracking::Relocalization, Tracking.cc:1162-1182)
+tblm = importlib.import_module("anyfeature-vslam_amd.table")
+tt, ta, tc = s.keyframe_table(32, 1000, seed=5)
+table = tblm.DescriptorTable(ctx, 32, 1000)
+for kf in range(32):
+    table.set(kf, tt[kf], ta[kf])
+    nodes = s.lcg_states(77, 1000) % 100
+    f_ = [(int(q), np.nonzero(nodes == q)[0].tolist()) for q in range(100) if (nodes == q).any()]
+    ids = np.array([q for q, _ in f_], np.int32); ptr_ = np.cumsum([0] + [len(v) for _, v in f_]).astype(np.int32)
+    table.set_featvec(kf, ids, ptr_, np.array([x for _, v in f_ for x in v], np.int32))
+fr = afv.FeatureView(s.perturbed_descriptors(tt[16].copy(), 99), f_, None, ta[16])
+ms, r = med(lambda: table.match_bow_frame(np.arange(32, dtype=np.int32), fr, 75.0, 0.75, True), n=30)
+print("afv_table_match_bow_frame, 1 frame x 32 keyframes (100 nodes): %.3f ms  (%d matches in all, %d against its own keyframe)" % (ms, int(r[1].sum()), int(r[1][16])))
