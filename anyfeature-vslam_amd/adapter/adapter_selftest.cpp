@@ -68,6 +68,14 @@ int main(int argc, char **argv) {
               dump(out + ".kps2", k2.data(), k2.size() * sizeof(afv::KeyPoint)) && dump(out + ".desc2", d2.ptr(), d2.data.size()) &&
               dump(out + ".match21", m21.data(), m21.size() * sizeof(int)) && dump(out + ".size1", size.data(), size.size() * 4);
     if (!ok) return 5;
+    {   // mvImagePyramid of the last frame (img2): levels dumped for the Python side to compare with the oracle's pyramid
+        std::vector<afv::Mat8> pyr;
+        extractor.ImagePyramid(pyr);
+        if ((int)pyr.size() != settings->nOctaves || pyr[0].rows != h || pyr[0].cols != w) return 6;
+        std::vector<uint8_t> flat;
+        for (const afv::Mat8 &m : pyr) flat.insert(flat.end(), m.data.begin(), m.data.end());
+        if (!dump(out + ".pyramid2", flat.data(), flat.size())) return 6;
+    }
 
     // ---- Vocabulary::transform + SearchByBoW over the feature vectors (KeyFrame::ComputeBoW -> SearchByBoW(KF, KF)) ----
     {

@@ -155,6 +155,28 @@ class FeatureExtractor_orb32_hip {
         fill_descriptors(descriptors, desc.data(), n);
     }
 
+    // FeatureExtractor::mvImagePyramid (FeatureExtractor.h:142; read by Frame::ComputeStereoMatches, Frame.cc:475,568): the levels of
+    // the LAST extracted frame, copied from the device on demand (the mono entry point never asks).  MatT: cv::Mat (CV_8UC1) or Mat8.
+    template <class MatT>
+    void ImagePyramid(std::vector<MatT> &pyramid) {
+        afv_geometry g;
+        int rc = afv_get_geometry(ctx, &g);
+        if (rc != AFV_OK) fatal("afv_get_geometry", rc, ctx);
+        pyramid.resize((size_t)g.nlevels);
+        std::vector<uint8_t> tight;
+        for (int l = 0; l < g.nlevels; ++l) {
+            tight.resize((size_t)g.lw[l] * g.lh[l]);
+            rc = afv_debug_get_level(ctx, 0, l, tight.data());
+            if (rc != AFV_OK) fatal("afv_debug_get_level", rc, ctx);
+#ifdef AFV_WITH_OPENCV
+            pyramid[(size_t)l].create(g.lh[l], g.lw[l], CV_8UC1);
+#else
+            pyramid[(size_t)l].create(g.lh[l], g.lw[l]);
+#endif
+            for (int y = 0; y < g.lh[l]; ++y) std::copy(tight.begin() + (size_t)y * g.lw[l], tight.begin() + (size_t)(y + 1) * g.lw[l], pyramid[(size_t)l].ptr(y));
+        }
+    }
+
     int GetLevels() { return settings->nOctaves; }
     float GetScaleFactor() { return settings->scaleFactor; }
     std::vector<float> GetScaleFactors() { return mvScaleFactor; }

@@ -579,6 +579,40 @@ def overlap_step(afv, device, B=256, steps=8):
     return out
 
 
+def standalone_fast_nms(afv, device, B, steps=6):
+    """k_fast_nms with the chip to itself: the default step runs as chunks alternating over two streams, so its launches share the CUs with
+    the other stream's kernels and `roofline.avg_launch_ms` overstates the kernel; here the same batch goes out as ONE chunk on one
+    stream and the library's stage events give the duration of the launch alone"""
+    import torch
+    ctx = afv.Context(max_batch=B, device=device)
+    ctx.set_split_threshold(0x7fffffff)
+    frames = torch.from_numpy(afv.synth.corners_batch(1, min(B, 64), W, H)).cuda(device)
+    if B > 64:
+        frames = frames.repeat((B + 63) // 64, 1, 1)[:B].contiguous()
+    cap = ctx.cap
+    kps = torch.empty((B, cap, 7), dtype=torch.float32, device=frames.device)
+    desc = torch.empty((B, cap, 32), dtype=torch.uint8, device=frames.device)
+    n = torch.empty((B,), dtype=torch.int32, device=frames.device)
+    st = torch.zeros((1,), dtype=torch.int32, device=frames.device)
+    side = torch.cuda.Stream(frames.device)
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            ctx.extract_batch_device(frames, kps, desc, n, st, cap)
+        torch.cuda.synchronize()
+        ctx.profile_enable(True)
+        for _ in range(steps):
+            ctx.extract_batch_device(frames, kps, desc, n, st, cap)
+        torch.cuda.synchronize()
+    fh = ctx.profile_read()["fast_nms"]
+    ctx.profile_enable(False)
+    ctx.close()
+    if not fh["launches"]:
+        return None
+    ms = fh["total_ms"] / fh["launches"]
+    ach = level_pixels(W, H) * (fh["units"] / fh["launches"]) / (ms * 1e-3) / 1e9
+    return {"avg_launch_ms": ms, "frames_per_launch": fh["units"] / fh["launches"], "achieved": ach, "frac": ach / HBM_PEAK_GBS}
+
+
 def batch_sweep(afv, device, sizes=(1, 64, 256, 1024)):
     """SURVEY.md 8d batch sizes: the full step (extract + describe + match t vs t-1), device-resident, a few steps each"""
     import torch
@@ -1041,11 +1075,11 @@ def main():
                                              "the fractions are withheld"}
             cp = _newest_profile("cache_pmc.json")
             if cp:   # north_star: "L2/LDS hit rate on the BRIEF + Hamming pass"; same staleness rule as valu_issue / roofline.traffic
-                keep = ("k_describe", "k_match_topk_mfma", "k_match_resolve", "k_fast_nms", "k_harris", "k_resize_level<96, 48>", "k_select_quadtree")
+                keep = ("k_describe", "k_match_topk_mfma", "k_match_resolve", "k_fast_nms", "k_harris", "k_resize_level", "k_select_quadtree")
                 out["cache"] = {"stale": cp["_stale"], "source": cp["_path"],
                                 "kernels": None if cp["_stale"] else {k: {f: (round(v, 4) if isinstance(v, float) else v) for f, v in e.items() if f in
                                                                            ("l2_hit", "lds_conflict_cycles_per_inst", "lds_wait_cycles_per_inst")}
-                                                                       for k, e in cp["kernels"].items() if k in keep},
+                                                                       for k, e in cp["kernels"].items() if k.split("<")[0] in keep},
                                 "note": "l2_hit = TCC_HIT / (TCC_HIT + TCC_MISS), LDS bank-conflict and wait cycles per LDS instruction: committed PMC passes "
                                         "(tools/collect_profiles.sh -> tools/pmc_cache.py), withheld when the sources changed since"}
             out["stage_ms_per_step"] = {kk: (v["total_ms"] / prof_steps) for kk, v in stages.items()}  # overlapping streams: sums exceed ms_per_step
@@ -1060,6 +1094,11 @@ def main():
             barrier()
             dev_fps = B * max(args.steps // 2, 2) / (time.perf_counter() - t1)
             out["host_fed"] = host_fed(afv, ctx, frames.cpu().numpy(), max(args.steps // 3, 5), dev_fps)
+            if "roofline" in out:
+                try:
+                    out["roofline"]["standalone"] = standalone_fast_nms(afv, local, B)
+                except Exception as e:
+                    out["roofline"]["standalone"] = {"error": str(e)[:200]}
             out["batch_sweep"] = batch_sweep(afv, local)
             out["overlap_match"] = overlap_step(afv, local)
             try:

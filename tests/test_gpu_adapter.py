@@ -34,6 +34,10 @@ def test_cpp_adapter_end_to_end(afv, oracle, tmp_path):
                                           check_orientation=True)
     assert nm == wn and np.array_equal(m21, want) and wn > 300
     assert np.array_equal(size1, oracle.size_sigma(ok1)[0])
+    # FeatureExtractor::mvImagePyramid of the last extracted frame (ImagePyramid accessor: what Frame::ComputeStereoMatches reads)
+    _, _, tr2 = oracle.orb_extract_trace(np.roll(img, 4, axis=1))
+    pyr = np.fromfile(out + ".pyramid2", dtype=np.uint8)
+    assert pyr.tobytes() == b"".join(np.ascontiguousarray(l).tobytes() for l in tr2["level"])
 
     # Vocabulary::transform + SearchByBoW over the feature vectors (the selftest's LCG tree, k = 6, L = 2, levelsup 1)
     from oracle import akaze_binding as akz
