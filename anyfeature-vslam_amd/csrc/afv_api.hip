@@ -634,9 +634,10 @@ extern "C" int afv_get_geometry(const afv_ctx *c, afv_geometry *g) {
     return AFV_OK;
 }
 
-// phase 2 of a brute-force pair call: the workgroup-wide fixed point halves the latency of a pair (one pair of unrelated frames 23 -> 13 us,
-// a frame against itself 38 -> 20 us) but evaluates every live row in every pass; a batch that fills the chip is throughput-bound and
-// faster with the one-wavefront walk (10 000 jobs: 3.26 M jobs/s against 2.75 M; 256 overlapping pairs: 0.25 against 0.38 ms)
+// phase 2 of a brute-force pair call.  The workgroup-wide fixed point is the faster form while every pair has a CU to itself (one pair of
+// unrelated frames 23 -> 10 us, of overlapping video frames 61 -> 28 us; 256 overlapping pairs per call: 0.16 against 0.19 ms of
+// resolve tail), but it evaluates every live row in every pass: a batch that fills the chip several times over is throughput-bound
+// and faster with the one-wavefront walk (10 000 jobs: 3.52 M jobs/s against 3.30 M)
 static int resolve_engine_for(const afv_ctx *c, int npairs) {
     return c->resolve_engine == 2 ? (npairs <= c->resolve_wg_max_pairs ? 1 : 0) : c->resolve_engine;
 }

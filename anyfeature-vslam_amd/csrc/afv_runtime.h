@@ -114,7 +114,7 @@ struct afv_ctx {
     int split_min_frames = 64;     // batches of at least this many frames / pairs are split over the two streams
     int match_engine = AFV_MATCH_ENGINE_MFMA;  // phase 1 of the brute-force pair matcher; afv_set_match_engine
     int resolve_engine = 2;        // phase 2: 0 = ordered walk on one wavefront (64-row rounds), 1 = workgroup-wide fixed point, 2 = by call size
-    int resolve_wg_max_pairs = 32; // ... 2: calls of at most this many pairs take the fixed point; afv_set_match_resolve
+    int resolve_wg_max_pairs = 256; // ... 2: calls of at most this many pairs take the fixed point; afv_set_match_resolve
     int split_chunks = 0;          // ... into this many chunks (alternating streams); 0 = about 85 frames each; afv_set_split_chunks
     // small-batch ("latency") path: kernels shaped for one or a few frames; afv_set_small_batch_path
     int small_mode = 1;            // 0 = never, 1 = batches of at most small_max_frames, 2 = always

@@ -494,7 +494,7 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve(const uint8_t *__restri
         int pos = 0;
         bool cols_ready = false;
 #ifdef AFV_RESOLVE_STATS
-        int st_rounds = 0, st_rescans = 0, st_iters = 0;
+        int st_rounds = 0, st_rescans = 0, st_iters = 0, st_racc = 0;
         long long st_pre = 0, st_pass = 0, st_commit = 0, st_resc = 0, st_mark = 0, st_r1 = 0, st_r2 = 0, st_r3 = 0;
         const long long st_t0 = wall_clock64();
 #endif
@@ -587,22 +587,25 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve(const uint8_t *__restri
 #ifdef AFV_RESOLVE_STATS
             { const long long t = wall_clock64(); st_pass += t - st_mark; st_mark = t; }
 #endif
-            const unsigned long long sm = __ballot(type == 2);
-            const int stop = sm ? (int)__builtin_ctzll(sm) : 64;
-            const bool commit = type == 1 && lane < stop;
-            if (commit) {
-                out[row] = e0;
-                atomicOr(&s_matched[e0 >> 5], 1u << (e0 & 31));
-            }
-            nm += __popcll(__ballot(commit));
-            if (my_claim >= 0) s_claim[my_claim] = 0x7fffffff;  // release every claim of this round
-            WAVE_LDS_ONLY_SYNC();
-            pos += stop;
-#ifdef AFV_RESOLVE_STATS
-            { const long long t = wall_clock64(); st_commit += t - st_mark; st_mark = t; }
-#endif
-            if (stop < 64 && pos < nlive) {
-                // row `pos` needs the exact rescan of the unmatched columns: whole wave, columns from LDS once the copy has landed
+            // The converged round holds for every lane UP TO the first one that needs the exact rescan - and, when that rescan ends in
+            // "no match" (it almost always does: on overlapping video frames 0-1 of a pair's 8-30 rescans take a column), beyond it:
+            // the fixed point already treated that lane as taking nothing.  So the lanes before a rescan lane are committed, the
+            // rescan runs against the then exact matched set, and only a rescan that TAKES a column cuts the round (round 4: before,
+            // every rescan cut it and paid a new round set-up + two passes: 25 of them cost a slow pair 50 us).
+            unsigned long long sm = __ballot(type == 2);
+            int done = 0;  // lanes [0, done) of the round are settled
+            while (true) {
+                const int stop = sm ? (int)__builtin_ctzll(sm) : 64;
+                const bool commit = type == 1 && lane >= done && lane < stop;
+                if (commit) {
+                    out[row] = e0;
+                    atomicOr(&s_matched[e0 >> 5], 1u << (e0 & 31));
+                }
+                nm += __popcll(__ballot(commit));
+                done = stop;
+                if (stop == 64 || pos + stop >= nlive) break;
+                WAVE_LDS_ONLY_SYNC();
+                // row `pos + stop` needs the exact rescan of the unmatched columns: whole wave, columns from LDS once the copy has landed
 #ifdef AFV_RESOLVE_STATS
                 ++st_rescans;
 #endif
@@ -610,9 +613,6 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve(const uint8_t *__restri
                     while (__hip_atomic_load(&s_cols_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < MT / 64 - 1) __builtin_amdgcn_s_sleep(1);
                     cols_ready = true;
                 }
-#ifdef AFV_RESOLVE_STATS
-                const long long tr0 = wall_clock64();
-#endif
                 const uint4 *cb = cols_in_lds ? reinterpret_cast<const uint4 *>(s_cols) : reinterpret_cast<const uint4 *>(d2);
                 const int i = __builtin_amdgcn_readlane(row, stop);
                 const uint32_t qv[8] = {qlo.x, qlo.y, qlo.z, qlo.w, qhi.x, qhi.y, qhi.z, qhi.w};
@@ -644,16 +644,8 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve(const uint8_t *__restri
                         k = min(k, key);
                     }
                 }
-#ifdef AFV_RESOLVE_STATS
-                if (k == 12345 && lane == 77) st_r1 = 1;
-                const long long tr1 = wall_clock64();
-#endif
                 wave_merge_best(k, s2nd);
-#ifdef AFV_RESOLVE_STATS
-                if (k == 12345 && lane == 77) st_r1 = 1;
-                const long long tr2 = wall_clock64();
-                st_r1 += tr0 - st_mark; st_r2 += tr1 - tr0; st_r3 += tr2 - tr1;
-#endif
+                bool took = false;
                 if (k != NO_KEY) {
                     const float best1 = (float)(k >> 16);
                     const float best2 = (s2nd == (NO_KEY >> 16)) ? 3.402823466e+38f : (float)s2nd;
@@ -664,20 +656,29 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve(const uint8_t *__restri
                             s_matched[bcol >> 5] |= 1u << (bcol & 31);
                         }
                         ++nm;
+                        took = true;
+#ifdef AFV_RESOLVE_STATS
+                        ++st_racc;
+#endif
                     }
                 }
-                WAVE_LDS_ONLY_SYNC();
-                pos += 1;
-#ifdef AFV_RESOLVE_STATS
-                { const long long t = wall_clock64(); st_resc += t - st_mark; st_mark = t; }
-#endif
+                done = stop + 1;
+                if (took) break;  // the lanes behind it were evaluated without this column taken: new round from there
+                sm &= ~(1ull << stop);
             }
+            if (my_claim >= 0) s_claim[my_claim] = 0x7fffffff;  // release every claim of this round
+            WAVE_LDS_ONLY_SYNC();
+            pos += done;
+#ifdef AFV_RESOLVE_STATS
+            { const long long t = wall_clock64(); st_commit += t - st_mark; st_mark = t; }
+#endif
         }
         if (lane == 0) s_nm = nm;
 #ifdef AFV_RESOLVE_STATS
         if (lane == 0) s_t[1] = wall_clock64();
 #endif
 #ifdef AFV_RESOLVE_STATS
+        if (AFV_RESOLVE_STATS == 3 && lane == 0) printf("pair %d nlive %d rounds %d passes %d rescans %d accepting %d matches %d walk_us %lld\n", p, nlive, st_rounds, st_iters, st_rescans, st_racc, nm, (wall_clock64() - st_t0) / 100);
         if (AFV_RESOLVE_STATS == 1 && lane == 0 && p <= 2) printf("resolve pair %d: n1 %d nlive %d rounds %d passes %d rescans %d matches %d walk %lld us (prologue %lld passes %lld commit %lld rescan %lld = wait %lld scan %lld reduce %lld)\n", p, n1, nlive, st_rounds, st_iters, st_rescans, nm, (wall_clock64() - st_t0) / 100, st_pre / 100, st_pass / 100, st_commit / 100, st_resc / 100, st_r1 / 100, st_r2 / 100, st_r3 / 100);
 #endif
     }
@@ -741,6 +742,7 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve(const uint8_t *__restri
 //     its answer is pinned, and the iteration continues (rows after it that looked at the same columns re-evaluate);
 //   * there is no matched-set bitmap: "column c is taken for row i" is claim[c] < i.
 #define RW_INF 0x7fffffff
+#define RW_WLIST 128  // waiting rows looked at per convergence
 static inline size_t resolve_wg_lds_bytes(int cap, bool stage_cols) {
     const size_t c = ((size_t)cap + 63) & ~(size_t)63;
     return std::min<size_t>(c, PAIR_KEYS_LDS) * 32 /*key records*/ + 3 * c * 4 /*claims*/ + c * 4 /*matches*/ + 2 * c * 2 /*wants of the last two passes*/ +
@@ -810,6 +812,7 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve_wg(const uint8_t *__res
     __shared__ int s_hist[32];
     __shared__ int s_wave[8];
     __shared__ int s_nm, s_drop[3], s_first, s_part[2 * (MT / 64)], s_cntw[16];
+    __shared__ unsigned short s_wlist[RW_WLIST];  // live indices of the rows waiting for a rescan, in row order
     const int p = pair_base + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int a = pair_a[p], b = pair_b[p];
     const int n1 = min(nset[a], cap), n2 = min(nset[b], cap);
@@ -932,20 +935,52 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve_wg(const uint8_t *__res
         }
         ++pass;
         if (__syncthreads_or(changed ? 1 : 0)) continue;
-        // converged: W holds the claims of the final wants (so far).  First row that asked for a rescan?
-        if (tid == 0) s_first = RW_INF;
-        __syncthreads();
+        // converged: W holds the claims of the final wants (so far).  The rows that asked for a rescan, in row order (s_wlist): the
+        // k-th block of 256 live rows is held by the threads in order, so a ballot per block + the blocks' wave counts place them
         {
+            unsigned long long bal[4];
+            const int nblk = (nlive + MT - 1) / MT;  // <= 4 blocks here; more live rows: only the first 1024 are looked at per cycle
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int li = u * MT + tid;
+                bal[u] = __ballot(u < nblk && li < nlive && (s_flag[li] & 3) == 1);
+                if (lane == 0) s_cntw[u * 4 + wv] = __popcll(bal[u]);
+            }
+            __syncthreads();
+            int run = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int off = run;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const int cw = s_cntw[u * 4 + w];
+                    off += w < wv ? cw : 0;
+                    run += cw;
+                }
+                if ((bal[u] >> lane) & 1ull) {
+                    const int slot = off + __popcll(bal[u] & ((1ull << lane) - 1ull));
+                    if (slot < RW_WLIST) s_wlist[slot] = (unsigned short)(u * MT + tid);
+                }
+            }
+            if (tid == 0) s_first = run;
+            __syncthreads();
+        }
+        int nw = min(s_first, RW_WLIST);
+        if (nw == 0 && nlive > 4 * MT) {  // sets above 1024 live rows: the rows behind the first 1024, one at a time (rare, slow, exact)
+            if (tid == 0) s_first = RW_INF;
+            __syncthreads();
             int mine = RW_INF;
-            for (int li = tid; li < nlive; li += MT)
+            for (int li = 4 * MT + tid; li < nlive; li += MT)
                 if ((s_flag[li] & 3) == 1) mine = min(mine, li);
             if (mine != RW_INF) atomicMin(&s_first, mine);
+            __syncthreads();
+            if (s_first != RW_INF) {
+                if (tid == 0) s_wlist[0] = (unsigned short)s_first;
+                nw = 1;
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        const int r = s_first;
-        if (r == RW_INF) break;
-        // exact rescan of live row r over the columns no EARLIER row claims (every row before r is final: none of them waits for a rescan)
-        const int rrow = s_live[r];
+        if (nw == 0) break;
         if (stage_cols && !cols_ready) {  // first rescan of this pair: park the column descriptors in LDS
             const uint4 *gc = reinterpret_cast<const uint4 *>(d2);
             uint4 *sc = reinterpret_cast<uint4 *>(s_cols);
@@ -954,55 +989,70 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve_wg(const uint8_t *__res
             __syncthreads();
         }
         const uint4 *cb = (stage_cols && cols_ready) ? reinterpret_cast<const uint4 *>(s_cols) : reinterpret_cast<const uint4 *>(d2);
-        const uint4 *qp = reinterpret_cast<const uint4 *>(d1 + (size_t)rrow * 8);
-        const uint4 qlo = qp[0], qhi = qp[1];
-        const uint32_t q[8] = {qlo.x, qlo.y, qlo.z, qlo.w, qhi.x, qhi.y, qhi.z, qhi.w};
-        int k = NO_KEY, s2nd = NO_KEY >> 16;
-        for (int c0 = tid; c0 < n2; c0 += 4 * MT) {
-            uint4 lo[4], hi[4];
-            int cl[4];
+        // Exact rescans, FOUR waiting rows at a time (one per wavefront), each over the columns no EARLIER row claims.  A row's answer is
+        // final when every row before it is final: the rows before the first waiting row are (converged, none of them waits), and a
+        // rescan that ends in "no match" - nearly all do - changes nothing for anybody behind it.  So the answers are adopted in row
+        // order up to and including the first one that TAKES a column; the rows behind that one are rescanned again after the
+        // iteration has settled with the new claim.
+        bool took = false;
+        for (int g0 = 0; g0 < nw && !took; g0 += MT / 64) {
+            const int g = g0 + wv;
+            int wr = -1;
+            if (g < nw) {
+                const int r = s_wlist[g], rrow = s_live[r];
+                const uint4 *qp = reinterpret_cast<const uint4 *>(d1 + (size_t)rrow * 8);
+                const uint4 qlo = qp[0], qhi = qp[1];
+                const uint32_t q[8] = {qlo.x, qlo.y, qlo.z, qlo.w, qhi.x, qhi.y, qhi.z, qhi.w};
+                int k = NO_KEY, s2nd = NO_KEY >> 16;
+                for (int c0 = lane; c0 < n2; c0 += 256) {
+                    uint4 lo[4], hi[4];
+                    int cl[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int c = min(c0 + MT * u, n2 - 1);
-                lo[u] = cb[2 * c];
-                hi[u] = cb[2 * c + 1];
-                cl[u] = W[c];
+                    for (int u = 0; u < 4; ++u) {
+                        const int c = min(c0 + 64 * u, n2 - 1);
+                        lo[u] = cb[2 * c];
+                        hi[u] = cb[2 * c + 1];
+                        cl[u] = W[c];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int c = c0 + 64 * u;
+                        const int d = __popc(q[0] ^ lo[u].x) + __popc(q[1] ^ lo[u].y) + __popc(q[2] ^ lo[u].z) + __popc(q[3] ^ lo[u].w) +
+                                      __popc(q[4] ^ hi[u].x) + __popc(q[5] ^ hi[u].y) + __popc(q[6] ^ hi[u].z) + __popc(q[7] ^ hi[u].w);
+                        const bool usable = c < n2 && !(cl[u] < r);
+                        const int key = usable ? ((d << 16) | c) : NO_KEY;
+                        s2nd = min(s2nd, max(k, key) >> 16);
+                        k = min(k, key);
+                    }
+                }
+                wave_merge_best(k, s2nd);
+                if (k != NO_KEY) {
+                    const float best1 = (float)(k >> 16);
+                    const float best2 = (s2nd == (NO_KEY >> 16)) ? 3.402823466e+38f : (float)s2nd;
+                    if (best1 < th && best1 < ratio * best2) wr = k & 0xffff;
+                }
             }
+            if (lane == 0) s_part[wv] = wr;
+            __syncthreads();
+            // adopt in row order (every thread computes the same verdict; thread 0 writes)
+            int nadopt = 0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int c = c0 + MT * u;
-                const int d = __popc(q[0] ^ lo[u].x) + __popc(q[1] ^ lo[u].y) + __popc(q[2] ^ lo[u].z) + __popc(q[3] ^ lo[u].w) +
-                              __popc(q[4] ^ hi[u].x) + __popc(q[5] ^ hi[u].y) + __popc(q[6] ^ hi[u].z) + __popc(q[7] ^ hi[u].w);
-                const bool usable = c < n2 && !(cl[u] < r);
-                const int key = usable ? ((d << 16) | c) : NO_KEY;
-                s2nd = min(s2nd, max(k, key) >> 16);
-                k = min(k, key);
+            for (int w = 0; w < MT / 64; ++w) {
+                if (g0 + w < nw && !took) {
+                    ++nadopt;
+                    took = s_part[w] >= 0;
+                }
             }
+            if (tid < nadopt) {
+                const int r = s_wlist[g0 + tid];
+                s_flag[r] = 2;  // pinned: from now on the row asserts this answer in every pass (its want so far was -1)
+                s_out[s_live[r]] = s_part[tid];
+            }
+            __syncthreads();
         }
-        wave_merge_best(k, s2nd);
-        if (lane == 0) {
-            s_part[2 * wv] = k;
-            s_part[2 * wv + 1] = s2nd;
-        }
-        __syncthreads();
-        int K = s_part[0], S2 = s_part[1];
-#pragma unroll
-        for (int w = 1; w < MT / 64; ++w) merge_best(K, S2, s_part[2 * w], s_part[2 * w + 1]);
-        int wr = -1;
-        if (K != NO_KEY) {
-            const float best1 = (float)(K >> 16);
-            const float best2 = (S2 == (NO_KEY >> 16)) ? 3.402823466e+38f : (float)S2;
-            if (best1 < th && best1 < ratio * best2) wr = K & 0xffff;
-        }
-        if (tid == 0) {
-            // pinned: the answer is parked where it ends up anyway.  The row's want so far was -1 (a row that asks for a rescan accepts
-            // nothing): if it now takes a column, the next pass sees its want change, claims the column, and the rows behind it
-            // re-evaluate until nothing changes again; if it takes none, the next pass changes nothing and the search goes on to
-            // the next waiting row.
-            s_flag[r] = 2;
-            s_out[rrow] = wr;
-        }
-        __syncthreads();
+        // a taken column enters the claims with the next pass (the pinned row's want changes from -1), the rows behind it re-evaluate;
+        // if nothing was taken and every waiting row was looked at, the converged state is the final one
+        if (!took && s_first <= RW_WLIST && nlive <= 4 * MT) break;
     }
     // ---- matches, count ----
     {

@@ -314,6 +314,8 @@ def pairs_main(args):
     ctx = afv.Context(max_batch=1, device=local)
     if args.match_engine is not None:
         ctx.set_match_engine(args.match_engine)
+    if args.match_resolve is not None:
+        ctx.set_match_resolve(args.match_resolve)
     table = tbl_mod.DescriptorTable(ctx, K, cap)
     host = None
     if rank == 0:                                           # the table exists on ONE rank before the exchange step
@@ -879,6 +881,8 @@ def main():
     ap.add_argument("--lib", default=None, help="measurement tooling: bind this build of libafv_hip.so (tools/experiments.py variants)")
     ap.add_argument("--split-chunks", type=int, default=0, help="orb32: chunks a batch is split into over the two streams (0 = automatic)")
     ap.add_argument("--no-split", action="store_true", help="orb32: one stream, one chunk (per-kernel timelines)")
+    ap.add_argument("--match-resolve", type=int, default=None, choices=[0, 1, 2], help="phase 2 of the pair matcher: 0 = one-wavefront walk, 1 = workgroup-wide "
+                    "fixed point, 2 = by call size (library default)")
     ap.add_argument("--small-path", type=int, default=None, choices=[0, 1, 2], help="orb32: small-batch kernels 0 = never, 1 = calls of <= 4 "
                     "frames / pairs (library default), 2 = always (afv_set_small_batch_path)")
     ap.add_argument("--keyframes", type=int, default=1000, help="pairs10k: keyframes in the table")
@@ -930,6 +934,8 @@ def main():
         ctx.set_split_threshold(0x7fffffff)
     if args.small_path is not None:
         ctx.set_small_batch_path(args.small_path)
+    if args.match_resolve is not None:
+        ctx.set_match_resolve(args.match_resolve)
     afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
     matcher = afv.FeatureMatcher(0.6, True, ctx=ctx)
 

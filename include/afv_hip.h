@@ -360,7 +360,7 @@ int afv_set_l2_chunk_pairs(afv_ctx *ctx, int pairs);
  *   1: one fixed point over all live rows of a pair, a thread per row, claims in rotating LDS arrays (one barrier per pass): half the
  *      latency of a pair, more total work
  *   0: the ordered walk of rounds 2-3: one wavefront, 64 rows per round: what a batch that fills the chip runs fastest with
- *   2 (default): 1 for calls of at most 32 pairs, else 0 */
+ *   2 (default): 1 for calls of at most 256 pairs (every pair then has a CU to itself), else 0 */
 int afv_set_match_resolve(afv_ctx *ctx, int engine);
 /* The small-batch ("latency") path.  Tracking extracts ONE frame per call (src/Frame.cc:186 -> src/FeatureExtractor.cpp:111-121) and
  * matches it against ONE other frame: at that size the batch kernels are a chain of dependent launches, each a few microseconds of
