@@ -169,7 +169,7 @@ class FeatureExtractor_orb32_hip {
             rc = afv_debug_get_level(ctx, 0, l, tight.data());
             if (rc != AFV_OK) fatal("afv_debug_get_level", rc, ctx);
 #ifdef AFV_WITH_OPENCV
-            pyramid[(size_t)l].create(g.lh[l], g.lw[l], CV_8UC1);
+            pyramid[(size_t)l].create(g.lh[l], g.lw[l], CV_8U);
 #else
             pyramid[(size_t)l].create(g.lh[l], g.lw[l]);
 #endif

@@ -15,6 +15,8 @@ void instantiate(afv::FeatureExtractor_orb32_hip &orb, afv::FeatureExtractor_aka
     orb(im, kps, desc);
     orb.detectAndCompute(im, kps, desc);
     akz.detectAndCompute(im, kps, desc);
+    std::vector<cv::Mat> pyramid;  // mvImagePyramid, read by the stereo matcher (Frame.cc:475)
+    orb.ImagePyramid(pyramid);
     (void)orb.GetKeypointSize(kps[0]);
     (void)akz.GetKeypointOctave(kps[0]);
 }
