@@ -390,6 +390,20 @@ __device__ __forceinline__ float akz_from_right(float v) {  // lane i <- lane i 
 // expressions on a tile with two more rings, rows then columns) and written out for the derivative kernels, instead of being read
 // back from a kernel that ran just before: Lt_in is read once for both, Lsmooth is never read by this kernel.
 #define AKZ_FSRC 70  // source tile edge: 66 + 2 x 2
+#ifdef AKZ_EXP_STOP  // measurement builds (tools/experiments.py): end the kernel after a phase, keeping that phase's results live
+#define AKZ_STOP(n, expr)                                                                                  \
+    if (AKZ_EXP_STOP == (n)) {                                                                             \
+        float *o_ = Lt_out + (size_t)f * w * h;                                                            \
+        if (tx >= N && tx < N + OW && gx >= 0 && gx < w)                                                   \
+            for (int j = 0; j < AKZ_FR; ++j) {                                                             \
+                const int r = r0 + j, gy = y0 - N + r;                                                     \
+                if (r >= N && r < N + AKZ_FH && gy < h) o_[(size_t)gy * w + gx] = (expr);                  \
+            }                                                                                              \
+        return;                                                                                            \
+    }
+#else
+#define AKZ_STOP(n, expr)
+#endif
 template <bool GAUSS>
 __global__ __launch_bounds__(AKZ_FT) void k_akz_fed_fused(const float *__restrict__ Lt_in, float *__restrict__ lsm, const float *__restrict__ taps, int w,
                                                           int h, int nframes, const float *__restrict__ kcontrast, int octave, int nsteps, AkzTau tau,
@@ -417,6 +431,7 @@ __global__ __launch_bounds__(AKZ_FT) void k_akz_fed_fused(const float *__restric
             for (int px = tx; px < AKZ_FSRC; px += 64) s_src[py * AKZ_FSRC + px] = rs[akz_clamp(x0 - N - 3 + px, w)];
         }
         __syncthreads();
+        AKZ_STOP(1, s_src[min(r0 + j + 3, SH + 3) * AKZ_FSRC + tx + 3])
         // the band's own pixels of Lt (tile row r0 + j, tile column tx) sit in the source tile
 #pragma unroll
         for (int j = 0; j < AKZ_FR; ++j) L[j] = s_src[min(r0 + j + 3, SH + 3) * AKZ_FSRC + tx + 3];
@@ -438,6 +453,7 @@ __global__ __launch_bounds__(AKZ_FT) void k_akz_fed_fused(const float *__restric
             }
         }
         __syncthreads();
+        AKZ_STOP(2, s_row[min(r0 + j + 3, SH + 3) * SW + tx + 1] + L[j])
         float *pl = lsm + (size_t)f * w * h;
         for (int i = threadIdx.x; i < SW * 8; i += AKZ_FT) {  // column pass: item = (column, run of rows)
             const int g = i / SW, lx = i - g * SW;
@@ -462,6 +478,7 @@ __global__ __launch_bounds__(AKZ_FT) void k_akz_fed_fused(const float *__restric
             }
         }
         __syncthreads();
+        AKZ_STOP(3, s_s[min(r0 + j + 1, SH - 1) * SW + tx + 1] + L[j])
         // entries outside the image (border tiles only): the conductivity stencil reads Lsmooth at BORDER_REFLECT_101 coordinates;
         // the mirror entry is inside the tile for everything a valid pixel can reach (N + 1 pixels beyond the border), further out
         // it is clamped
@@ -531,6 +548,7 @@ __global__ __launch_bounds__(AKZ_FT) void k_akz_fed_fused(const float *__restric
         cU[j] = upd && gy > 0 ? c[j] + cc : 0.0f;
         if (!GAUSS) L[j] = pin[(size_t)akz_clamp(gy, h) * w + akz_clamp(gx, w)];
     }
+    AKZ_STOP(4, ((cR[j] + cL[j]) + (cD[j] + cU[j])) + L[j])
     for (int st = 0; st < N; ++st) {
         // boundary rows of every band through LDS (double-buffered by step parity: one barrier per step)
         float *xb = s_x + (st & 1) * (2 * 8 * 64);
@@ -565,6 +583,219 @@ __global__ __launch_bounds__(AKZ_FT) void k_akz_fed_fused(const float *__restric
         for (int j = 0; j < AKZ_FR; ++j) {
             const int r = r0 + j, gy = y0 - N + r;
             if (r >= N && r < N + AKZ_FH && gy < h) o[(size_t)gy * w + gx] = L[j];
+        }
+    }
+}
+
+// ---- the same level update, shaped by what rocprofv3 said about the kernel above (round 4) ----
+// k_akz_fed_fused<true> is bound by the vector ALU, and most of what it issues is not arithmetic: 5.0 wavefront instructions per pixel
+// (322 lane operations) for about 100 of filter + conductivity + FED arithmetic - per-element clamps and 64-bit addresses in the
+// staging loop, run-time divisions in the item mappings, nine predicated stores per run, a six-term predicate per Lsmooth store.
+// This form has the step count as a template parameter and keeps everything per-row on the scalar unit:
+//   * tile = (62 - 2N) x (64 - 2N) outputs; lane = tile column (lanes 0 and 63 only carry the Lsmooth ring), wavefront = band of 8 rows,
+//     every wavefront busy in every phase;
+//   * staging: a wavefront fetches whole rows (row clamp on the scalar unit, one column clamp per lane), all loads in flight before the
+//     first LDS write;
+//   * row pass: item = (source row, run of 16 columns): five 128-bit LDS reads, packed fp32 arithmetic (two outputs per instruction,
+//     same expression order), written TRANSPOSED so that
+//   * the column pass is four 128-bit LDS reads per lane and leaves the 12 Lsmooth rows a band's conductivity needs in registers - no
+//     Lsmooth plane in LDS, no reflect fix-up pass (the two rows / columns just outside the image are patched in registers);
+//   * conductivity and FED steps on row pairs (packed fp32); barriers wait for LDS only, so the Lsmooth stores drain behind the FED cycle.
+// Bit-identical to the step-by-step path (same per-pixel expressions, -ffp-contract=off).
+typedef float akz_f2 __attribute__((ext_vector_type(2)));
+typedef float akz_f4 __attribute__((ext_vector_type(4)));
+#define AKZ_G_PS 76  // source tile pitch: 68 columns used; 76 mod 32 = 12 spreads the 128-bit reads of lanes that differ in the row
+#define AKZ_G_PT 76  // transposed row-pass plane: [column][source row + 1], 72 entries used
+#define AKZ_G_ROWS 70
+#define AKZ_G_LDS_FLOATS (AKZ_G_ROWS * AKZ_G_PS + 64 * AKZ_G_PT + 2 * 2 * 8 * 64)
+#define AKZ_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// NOUT outputs of the symmetric 5-tap filter from a window of NOUT + 4 values, two at a time: out[k] = k0 v[k+2] + k1 (v[k+3] + v[k+1]) + k2 (v[k+4] + v[k])
+template <int NOUT>
+__device__ __forceinline__ void akz_gauss5_window(const float *v, float k0, float k1, float k2, float *out) {
+#pragma unroll
+    for (int k = 0; k < NOUT; k += 2) {
+        const akz_f2 c = {v[k + 2], v[k + 3]}, p1 = {v[k + 3], v[k + 4]}, m1 = {v[k + 1], v[k + 2]}, p2 = {v[k + 4], v[k + 5]}, m2 = {v[k], v[k + 1]};
+        akz_f2 a = k0 * c;
+        a += k1 * (p1 + m1);
+        a += k2 * (p2 + m2);
+        out[k] = a.x;
+        out[k + 1] = a.y;
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(AKZ_FT) void k_akz_fed_gauss(const float *__restrict__ Lt_in, float *__restrict__ lsm, const float *__restrict__ taps, int w,
+                                                          int h, int nframes, const float *__restrict__ kcontrast, int octave, AkzTau tau,
+                                                          float *__restrict__ Lt_out) {
+    extern __shared__ float s_fed[];
+    constexpr int OW = 62 - 2 * N, FH = 64 - 2 * N, PS = AKZ_G_PS, PT = AKZ_G_PT, SR = AKZ_G_ROWS;
+    float *s_src = s_fed;            // [70][PS]: source rows y0 - N - 3 .., columns x0 - N - 3 .. (replicate coordinates)
+    float *s_t = s_fed + SR * PS;    // [64][PT]: row-pass result of tile column c, source row py at [c][py + 1]
+    float *s_x = s_t + 64 * PT;      // band boundary rows: [2 parities][top, bottom][8 waves][64]
+    AKZ_TILE(OW, FH)
+    const int tid = threadIdx.x, tx = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r0 = wv * 8;
+    const int gx = x0 - N - 1 + tx;  // image column of tile column tx
+    const int ty0 = y0 - N;          // image row of tile row 0
+    const float *pin = Lt_in + (size_t)f * w * h;
+    {   // ---- staging: 70 rows x 68 columns
+        const float *pc = pin + akz_clamp(x0 - N - 3 + tx, w);
+        float v[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int py = wv + 8 * k;
+            if (py < SR) v[k] = pc[(size_t)akz_clamp(ty0 - 3 + py, h) * w];
+        }
+        float e = 0.0f;
+        if (tid < SR * 4) e = pin[(size_t)akz_clamp(ty0 - 3 + (tid >> 2), h) * w + akz_clamp(x0 - N - 3 + 64 + (tid & 3), w)];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int py = wv + 8 * k;
+            if (py < SR) s_src[py * PS + tx] = v[k];
+        }
+        if (tid < SR * 4) s_src[(tid >> 2) * PS + 64 + (tid & 3)] = e;
+    }
+    const float k0 = taps[2], k1 = taps[3], k2 = taps[4];
+    float kc = kcontrast[f];
+    for (int i = 0; i < octave; ++i) kc = kc * 0.75f;
+    const float k2inv = 1.0f / (kc * kc);
+    AKZ_LDS_BARRIER();
+    float L[8];  // the band's own pixels of Lt: tile row r0 + j = source row r0 + j + 3, tile column tx = source column tx + 2
+#pragma unroll
+    for (int j = 0; j < 8; ++j) L[j] = s_src[(r0 + j + 3) * PS + tx + 2];
+    if (tid < SR * 4) {  // ---- row pass: item = (source row, run of 16 tile columns)
+        const int g = tid / SR, py = tid - g * SR;
+        const akz_f4 *q = reinterpret_cast<const akz_f4 *>(&s_src[py * PS + 16 * g]);
+        float v[22], o[16];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const akz_f4 t = q[k];
+            v[4 * k] = t.x, v[4 * k + 1] = t.y, v[4 * k + 2] = t.z, v[4 * k + 3] = t.w;
+        }
+        v[20] = v[21] = 0.0f;
+        akz_gauss5_window<16>(v, k0, k1, k2, o);
+        float *d = &s_t[(16 * g) * PT + py + 1];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) d[k * PT] = o[k];
+    }
+    AKZ_LDS_BARRIER();
+    // ---- column pass: Lsmooth of tile rows r0 - 2 .. r0 + 9, tile column tx
+    float vc[12], vl[12], vr[12];
+    {
+        const akz_f4 *q = reinterpret_cast<const akz_f4 *>(&s_t[tx * PT + r0]);
+        float v[18];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const akz_f4 t = q[k];
+            v[4 * k] = t.x, v[4 * k + 1] = t.y, v[4 * k + 2] = t.z, v[4 * k + 3] = t.w;
+        }
+        v[16] = v[17] = 0.0f;
+        akz_gauss5_window<12>(v, k0, k1, k2, vc);
+    }
+    const bool lane_out = tx > N && tx <= N + OW && gx < w;
+    {   // this tile's Lsmooth goes out for the derivative kernels
+        float *pl = lsm + (size_t)f * w * h + gx;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = r0 + j, gy = ty0 + r;
+            if (r >= N && r < N + FH && gy < h && lane_out) pl[(size_t)gy * w] = vc[j + 2];
+        }
+    }
+    // the conductivity stencil reads Lsmooth at BORDER_REFLECT_101 coordinates: a pixel inside the image reaches one row / column
+    // outside it, whose mirror image is two rows / columns further in (held by the same lane / the neighbour on the other side)
+    const int m_top = -1 - (ty0 + r0 - 2), m_bot = h - (ty0 + r0 - 2);  // window index of image rows -1 and h
+    if (m_top >= 0 || m_bot < 12) {
+#pragma unroll
+        for (int m = 0; m < 10; ++m)
+            if (m == m_top) vc[m] = vc[m + 2];
+#pragma unroll
+        for (int m = 2; m < 12; ++m)
+            if (m == m_bot) vc[m] = vc[m - 2];
+    }
+#pragma unroll
+    for (int m = 0; m < 12; ++m) {
+        vl[m] = akz_from_left(vc[m]);
+        vr[m] = akz_from_right(vc[m]);
+    }
+    if (x0 - N - 1 <= 0 || x0 - N - 1 + 64 >= w) {
+#pragma unroll
+        for (int m = 0; m < 12; ++m) {
+            const float a = vl[m], b = vr[m];
+            vl[m] = gx == 0 ? b : a;
+            vr[m] = gx == w - 1 ? a : b;
+        }
+    }
+    // ---- conductivity of tile rows r0 - 1 .. r0 + 8 (pm_g2), Scharr on the 12-row window
+    float c[10];
+    {
+        float t[12], u[12];
+#pragma unroll
+        for (int m = 0; m < 12; m += 2) {
+            const akz_f2 l2 = {vl[m], vl[m + 1]}, r2 = {vr[m], vr[m + 1]}, c2 = {vc[m], vc[m + 1]};
+            const akz_f2 t2 = r2 - l2, u2 = 10.0f * c2 + 3.0f * (l2 + r2);
+            t[m] = t2.x, t[m + 1] = t2.y, u[m] = u2.x, u[m + 1] = u2.y;
+        }
+#pragma unroll
+        for (int q = 0; q < 10; q += 2) {
+            const akz_f2 ta = {t[q], t[q + 1]}, tb = {t[q + 1], t[q + 2]}, tc = {t[q + 2], t[q + 3]};
+            const akz_f2 ua = {u[q], u[q + 1]}, uc = {u[q + 2], u[q + 3]};
+            const akz_f2 lxv = 10.0f * tb + 3.0f * (ta + tc);
+            const akz_f2 lyv = uc - ua;
+            const akz_f2 d = 1.0f + (lxv * lxv + lyv * lyv) * k2inv;
+            c[q] = 1.0f / d.x;
+            c[q + 1] = 1.0f / d.y;
+        }
+    }
+    // image border (no neighbour: that flux term is 0) and pixels this tile does not update folded into the conductivity sums (see above)
+    const bool col_in = tx >= 1 && tx <= 62 && gx >= 0 && gx < w, has_r = gx + 1 < w, has_l = gx > 0;
+    float cR[8], cL[8], cD[8], cU[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float cc = c[j + 1];
+        const int gy = ty0 + r0 + j;
+        const bool upd = col_in && gy >= 0 && gy < h;
+        const float cr = cc + akz_from_right(cc), cl = akz_from_left(cc) + cc;
+        cR[j] = upd && has_r ? cr : 0.0f;
+        cL[j] = upd && has_l ? cl : 0.0f;
+        cD[j] = upd && gy + 1 < h ? cc + c[j + 2] : 0.0f;
+        cU[j] = upd && gy > 0 ? c[j] + cc : 0.0f;
+    }
+#pragma unroll
+    for (int st = 0; st < N; ++st) {
+        float *xb = s_x + (st & 1) * (2 * 8 * 64);
+        xb[wv * 64 + tx] = L[0];
+        xb[8 * 64 + wv * 64 + tx] = L[7];
+        AKZ_LDS_BARRIER();
+        const float up_halo = xb[8 * 64 + max(wv - 1, 0) * 64 + tx];  // bands 0 / 7: their outer rows are never valid
+        const float dn_halo = xb[min(wv + 1, 7) * 64 + tx];
+        const float hs = 0.5f * tau.t[st];  // exact; see k_akz_fed_fused
+        float Lr[8], Ll[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Lr[j] = akz_from_right(L[j]), Ll[j] = akz_from_left(L[j]);
+        float nl[8];
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            const akz_f2 Lc = {L[j], L[j + 1]}, R2 = {Lr[j], Lr[j + 1]}, L2 = {Ll[j], Ll[j + 1]};
+            const akz_f2 U2 = {j > 0 ? L[j - 1] : up_halo, L[j]}, D2 = {L[j + 1], j < 6 ? L[j + 2] : dn_halo};
+            const akz_f2 cr = {cR[j], cR[j + 1]}, cl = {cL[j], cL[j + 1]}, cd = {cD[j], cD[j + 1]}, cu = {cU[j], cU[j + 1]};
+            const akz_f2 xpos = cr * (R2 - Lc);
+            const akz_f2 xneg = cl * (Lc - L2);
+            const akz_f2 ypos = cd * (D2 - Lc);
+            const akz_f2 yneg = cu * (Lc - U2);
+            const akz_f2 sum = ((xpos - xneg) + ypos) - yneg;
+            const akz_f2 n2 = Lc + hs * sum;
+            nl[j] = n2.x, nl[j + 1] = n2.y;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) L[j] = nl[j];
+    }
+    if (lane_out) {
+        float *o = Lt_out + (size_t)f * w * h + gx;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = r0 + j, gy = ty0 + r;
+            if (r >= N && r < N + FH && gy < h) o[(size_t)gy * w] = L[j];
         }
     }
 }
@@ -791,7 +1022,18 @@ extern "C" int afv_akz_launch_fed_fused(const float *Lt_in, float *lsm, const fl
     AkzTau t{};
     for (int i = 0; i < nsteps; ++i) t.t[i] = tau[i];
     const int OW = 64 - 2 * nsteps;
-    if (taps) {
+    if (taps && w >= 4 && h >= 4) {
+        const size_t lds = (size_t)AKZ_G_LDS_FLOATS * sizeof(float);
+        const dim3 g = akz_grid1(w, h, nframes, 62 - 2 * nsteps, 64 - 2 * nsteps);
+#define AKZ_FG_CASE(NN)                                                                                                                      \
+    case NN:                                                                                                                                 \
+        hipLaunchKernelGGL(k_akz_fed_gauss<NN>, g, dim3(AKZ_FT), lds, st, Lt_in, lsm, taps, w, h, nframes, kcontrast, octave, t, Lt_out);    \
+        break;
+        switch (nsteps) {
+            AKZ_FG_CASE(1) AKZ_FG_CASE(2) AKZ_FG_CASE(3) AKZ_FG_CASE(4) AKZ_FG_CASE(5) AKZ_FG_CASE(6) AKZ_FG_CASE(7) AKZ_FG_CASE(8)
+        }
+#undef AKZ_FG_CASE
+    } else if (taps) {
         const size_t lds = ((size_t)AKZ_FSRC * AKZ_FSRC + 2 * 2 * 8 * 64 + (size_t)AKZ_FSRC * 66) * sizeof(float);
         hipLaunchKernelGGL(k_akz_fed_fused<true>, akz_grid1(w, h, nframes, OW, AKZ_FH), dim3(AKZ_FT), lds, st, Lt_in, lsm, taps, w, h, nframes, kcontrast,
                            octave, nsteps, t, Lt_out);
