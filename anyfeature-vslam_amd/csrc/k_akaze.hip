@@ -10,6 +10,7 @@
 // replaces baked into the staging coordinates) in LDS with coalesced row reads, and writes each output once.
 // Batch layout: plane[frame][y][x], frame stride = w * h of the level.
 #include "afv_device.h"
+#include "akz_recip.h"
 
 #define AT_W 64
 #define AT_H 32
@@ -380,10 +381,10 @@ struct AkzTau {
 // neighbour-conductivity sums of its band in registers for the whole cycle.  Horizontal neighbours come from DPP wave shifts,
 // vertical ones from the registers of the same lane; only the two boundary rows of a band go through LDS per step.
 __device__ __forceinline__ float akz_from_left(float v) {   // lane i <- lane i - 1 (DPP wave_shr:1)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float akz_from_right(float v) {  // lane i <- lane i + 1 (DPP wave_shl:1)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
 // GAUSS: the level's Lsmooth = GaussianBlur(Lt_in, 5 x 5, sigma 1, BORDER_REPLICATE) is computed here as well (k_akz_gauss<2, false>'s
@@ -743,23 +744,35 @@ __global__ __launch_bounds__(AKZ_FT) void k_akz_fed_gauss(const float *__restric
             const akz_f2 lxv = 10.0f * tb + 3.0f * (ta + tc);
             const akz_f2 lyv = uc - ua;
             const akz_f2 d = 1.0f + (lxv * lxv + lyv * lyv) * k2inv;
-            c[q] = 1.0f / d.x;
-            c[q + 1] = 1.0f / d.y;
+            c[q] = akz_recip_ge1(d.x);
+            c[q + 1] = akz_recip_ge1(d.y);
         }
     }
-    // image border (no neighbour: that flux term is 0) and pixels this tile does not update folded into the conductivity sums (see above)
-    const bool col_in = tx >= 1 && tx <= 62 && gx >= 0 && gx < w, has_r = gx + 1 < w, has_l = gx > 0;
-    float cR[8], cL[8], cD[8], cU[8];
+    // Flux form of the step: xpos of a pixel is xneg of its right neighbour and ypos is yneg of the pixel below - the same product of
+    // the same operands ((c_a + c_b) * (L_b - L_a)), so every edge is evaluated once: eX[j] = the conductivity sum of the edge to the
+    // right of this lane in band row j, eY[k] = of the edge above band row k (k = 8: below row 7).  An edge that leaves the image has
+    // coefficient 0 (that flux term is 0, as upstream); pixels outside the image and the tile's outermost lanes / rows pick up fluxes
+    // they should not, which only makes values wrong that no output depends on (the halo argument of the step-by-step kernel).
+    const bool x_in = gx >= 0 && gx < w;
+    const bool x_edge = gx >= 0 && gx + 1 < w;
+    float eX[8];
+    akz_f2 eYa[4], eYb[4];  // {eY[2p], eY[2p + 1]}, {eY[2p + 1], eY[2p + 2]}
+    {
+        float eY[9];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float cc = c[j + 1];
-        const int gy = ty0 + r0 + j;
-        const bool upd = col_in && gy >= 0 && gy < h;
-        const float cr = cc + akz_from_right(cc), cl = akz_from_left(cc) + cc;
-        cR[j] = upd && has_r ? cr : 0.0f;
-        cL[j] = upd && has_l ? cl : 0.0f;
-        cD[j] = upd && gy + 1 < h ? cc + c[j + 2] : 0.0f;
-        cU[j] = upd && gy > 0 ? c[j] + cc : 0.0f;
+        for (int k = 0; k < 9; ++k) {
+            const int gyb = ty0 + r0 + k;  // image row below the edge
+            eY[k] = x_in && gyb >= 1 && gyb < h ? c[k] + c[k + 1] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int gy = ty0 + r0 + j;
+            const float cc = c[j + 1];
+            const float cr = cc + akz_from_right(cc);  // outside the select: a lane-crossing read must not sit under a divergent condition
+            eX[j] = x_edge && gy >= 0 && gy < h ? cr : 0.0f;
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) eYa[p] = akz_f2{eY[2 * p], eY[2 * p + 1]}, eYb[p] = akz_f2{eY[2 * p + 1], eY[2 * p + 2]};
     }
 #pragma unroll
     for (int st = 0; st < N; ++st) {
@@ -770,20 +783,21 @@ __global__ __launch_bounds__(AKZ_FT) void k_akz_fed_gauss(const float *__restric
         const float up_halo = xb[8 * 64 + max(wv - 1, 0) * 64 + tx];  // bands 0 / 7: their outer rows are never valid
         const float dn_halo = xb[min(wv + 1, 7) * 64 + tx];
         const float hs = 0.5f * tau.t[st];  // exact; see k_akz_fed_fused
-        float Lr[8], Ll[8];
+        float xd[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) Lr[j] = akz_from_right(L[j]), Ll[j] = akz_from_left(L[j]);
+        for (int j = 0; j < 8; ++j) {
+            const float fx = eX[j] * (akz_from_right(L[j]) - L[j]);  // xpos
+            xd[j] = fx - akz_from_left(fx);                           // xpos - xneg
+        }
         float nl[8];
 #pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-            const akz_f2 Lc = {L[j], L[j + 1]}, R2 = {Lr[j], Lr[j + 1]}, L2 = {Ll[j], Ll[j + 1]};
-            const akz_f2 U2 = {j > 0 ? L[j - 1] : up_halo, L[j]}, D2 = {L[j + 1], j < 6 ? L[j + 2] : dn_halo};
-            const akz_f2 cr = {cR[j], cR[j + 1]}, cl = {cL[j], cL[j + 1]}, cd = {cD[j], cD[j + 1]}, cu = {cU[j], cU[j + 1]};
-            const akz_f2 xpos = cr * (R2 - Lc);
-            const akz_f2 xneg = cl * (Lc - L2);
-            const akz_f2 ypos = cd * (D2 - Lc);
-            const akz_f2 yneg = cu * (Lc - U2);
-            const akz_f2 sum = ((xpos - xneg) + ypos) - yneg;
+        for (int p = 0; p < 4; ++p) {
+            const int j = 2 * p;
+            const akz_f2 Lc = {L[j], L[j + 1]}, U2 = {j > 0 ? L[j - 1] : up_halo, L[j]}, D2 = {L[j + 1], j < 6 ? L[j + 2] : dn_halo};
+            const akz_f2 ga = eYa[p] * (Lc - U2);  // yneg of rows j, j + 1
+            const akz_f2 gb = eYb[p] * (D2 - Lc);  // ypos
+            const akz_f2 x2 = {xd[j], xd[j + 1]};
+            const akz_f2 sum = (x2 + gb) - ga;
             const akz_f2 n2 = Lc + hs * sum;
             nl[j] = n2.x, nl[j + 1] = n2.y;
         }

@@ -2,6 +2,7 @@
 end to end; bit-exact float parity (same expressions, one rounding per operator on both sides).  The libAKAZE fork the
 reference links is absent: parity against it is unpinned (oracle/akaze.h)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -64,6 +65,17 @@ def test_scale_space_stages_bit_exact(afv, akz, w, h):
             assert np.array_equal(ctx.plane(f, i, afv.akaze.LY), ly), (f, i, "Ly")
             assert np.array_equal(ctx.plane(f, i, afv.akaze.LDET), ldet), (f, i, "Ldet")
     ctx.close()
+
+
+def test_conductivity_reciprocal_is_the_ieee_quotient():
+    """k_akz_fed_gauss forms 1 / (1 + |grad|^2 / k^2) as v_rcp_f32 + one fused Newton step (csrc/akz_recip.h) instead of the division
+    sequence; tools/akaze_recip_check (built by __graft_entry__.build()) compares it with 1.0f / d for every float in [1, 2^96)"""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "akaze_recip_check")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "recip_check ok" in r.stdout, r.stdout + r.stderr
+    assert r.stdout.count("akz_recip_ge1 in 0") == 3, r.stdout
 
 
 def test_fused_and_step_by_step_scale_space_agree(afv):
