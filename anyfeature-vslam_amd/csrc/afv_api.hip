@@ -1509,7 +1509,8 @@ int afv_match_pairs_core(afv_ctx *c, const uint8_t *d_desc, const float *d_ang, 
     }
     if (npairs >= c->split_min_frames) {
         // grid.y carries the pair index (<= 65535 per launch) and the two streams overlap the latency-bound ordered
-        // resolve of one chunk with the VALU-bound top-k of the other
+        // resolve of one chunk with the VALU-bound top-k of the other (more, smaller chunks were measured and are slower: 256 frames,
+        // 4 / 6 / 8 chunks: -4 / -9 / -13 %)
         HIPCHK(c, hipEventRecord(c->ev_fork, s));
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
         const int K = std::max(2, (npairs + 32767) / 32768 * 2);

@@ -727,22 +727,26 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve(const uint8_t *__restri
 #endif
 }
 
-// ---------------- phase 2, workgroup form (round 4): ONE fixed point over all live rows, all four wavefronts ----------------
+// ---------------- phase 2, workgroup form (round 4): ONE fixed point over all live rows, 1024 threads ----------------
 // k_match_resolve above walks the live rows 64 at a time on one wavefront: a pair of consecutive video frames (~900 live rows) costs
 // 15-20 rounds of ~2 us of dependent LDS round trips, and a pair of unrelated frames still 11 rounds although hardly a row matches.
 // The fixed-point argument of that walk does not need the rounds: row i's decision is a function f of the columns WANTED by the rows
 // before it, want_i = f({want_j : j < i}), so any assignment that satisfies all these equations IS the sequential outcome (induction
 // on i), and iterating "every row re-evaluates f against the current claims" reaches it after as many passes as the longest chain of
-// rows competing for a column (2..4 in practice) + 1.  Here all live rows do that at once, a thread per row (x 4 for 1000 rows):
+// rows competing for a column (2..4 in practice) + 1.  Here all live rows do that at once, a thread per row (a pass of four rows per
+// thread on 256 threads cost 4-5 us of dependent LDS round trips; one row per thread: about 1.5):
 //   * claims live in THREE rotating LDS arrays (claim[c] = smallest live index that wants column c, by atomic min): a pass reads the
 //     array written by the previous pass, writes the next one and clears its own entries of the third - ONE barrier per pass, which
 //     also carries the "did anything change" vote;
 //   * a row whose exact keys are used up needs the exact rescan of the free columns, which is only meaningful once every row before it
-//     is final: after convergence the FIRST such row is rescanned by the whole workgroup against the claims of the rows before it,
-//     its answer is pinned, and the iteration continues (rows after it that looked at the same columns re-evaluate);
+//     is final: after convergence the waiting rows are rescanned, up to 32 at a time (two per wavefront), against the claims of the
+//     rows before them, the answers up to the first that takes a column are pinned, and the iteration continues;
 //   * there is no matched-set bitmap: "column c is taken for row i" is claim[c] < i.
 #define RW_INF 0x7fffffff
 #define RW_WLIST 128  // waiting rows looked at per convergence
+#define RW_RPW 2      // waiting rows a wavefront rescans together (they share the column loads): 32 per step
+#define RWT 1024      // threads: one per live row
+#define RW_NW (RWT / 64)
 static inline size_t resolve_wg_lds_bytes(int cap, bool stage_cols) {
     const size_t c = ((size_t)cap + 63) & ~(size_t)63;
     return std::min<size_t>(c, PAIR_KEYS_LDS) * 32 /*key records*/ + 3 * c * 4 /*claims*/ + c * 4 /*matches*/ + 2 * c * 2 /*wants of the last two passes*/ +
@@ -794,7 +798,7 @@ __device__ __forceinline__ void resolve_eval(const int4 t4, const int4 t8, const
     rescan = type == 2;
 }
 
-__global__ __launch_bounds__(MT, 2) void k_match_resolve_wg(const uint8_t *__restrict__ desc, const float *__restrict__ ang, int ang_stride,
+__global__ __launch_bounds__(RWT) void k_match_resolve_wg(const uint8_t *__restrict__ desc, const float *__restrict__ ang, int ang_stride,
                                                          const int *__restrict__ nset, int cap, const int *__restrict__ pair_a,
                                                          const int *__restrict__ pair_b, const int4 *__restrict__ topk, float th,
                                                          float ratio, int check_ori, int *__restrict__ match,
@@ -810,96 +814,59 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve_wg(const uint8_t *__res
     uint8_t *s_flag = s_bin + capr;  // per live row: 1 = asked for a rescan in the last pass, 2 = pinned by a rescan
     uint32_t *s_cols = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(s_flag + capr) + 15) & ~(uintptr_t)15);
     __shared__ int s_hist[32];
-    __shared__ int s_wave[8];
-    __shared__ int s_nm, s_drop[3], s_first, s_part[2 * (MT / 64)], s_cntw[16];
+    __shared__ int s_nm, s_drop[3], s_first, s_part[RW_RPW * RW_NW], s_cntw[RW_NW];
     __shared__ unsigned short s_wlist[RW_WLIST];  // live indices of the rows waiting for a rescan, in row order
     const int p = pair_base + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int a = pair_a[p], b = pair_b[p];
     const int n1 = min(nset[a], cap), n2 = min(nset[b], cap);
     const int4 *tk = topk + (size_t)p * cap * 2;
     int *out = match + (size_t)p * cap;
-    for (int i = tid; i < capr; i += MT) s_out[i] = -1;
-    for (int i = tid; i < 3 * capr; i += MT) s_claim[i] = RW_INF;
+    for (int i = tid; i < capr; i += RWT) s_out[i] = -1;
+    for (int i = tid; i < 3 * capr; i += RWT) s_claim[i] = RW_INF;
     if (tid < 32) s_hist[tid] = 0;
-    // rows whose best distance fails TH_LOW can never match: compact the others IN ROW ORDER, keys staged in LDS.  Sets of up to 1024 rows
-    // (the usual case) in ONE step: a thread fetches the records of its four rows together (one L2 round trip), the 16 (block of 256
-    // rows, wavefront) live counts meet in LDS behind one barrier, and every thread places its rows from them
+    // rows whose best distance fails TH_LOW can never match: compact the others IN ROW ORDER, keys staged in LDS.  A thread per row (sets of
+    // up to 1024 rows - the usual case - in ONE step: one L2 round trip for the records, the 16 wavefronts' live counts meet in LDS behind
+    // one barrier, every thread places its row from them)
     int nlive = 0;
-    if (n1 <= 4 * MT) {
-        int4 pre4[4], pre8[4];
-        unsigned long long bal[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = u * MT + tid;
-            pre4[u] = make_int4(NO_KEY, NO_KEY, NO_KEY, NO_KEY);
-            pre8[u] = make_int4(NO_KEY, NO_KEY, NO_KEY, TOPK);
-            if (i < n1) {
-                pre4[u] = tk[2 * i];
-                pre8[u] = tk[2 * i + 1];
-            }
+    for (int i0 = 0; i0 < n1; i0 += RWT) {
+        const int i = i0 + tid;
+        int4 t4 = make_int4(NO_KEY, NO_KEY, NO_KEY, NO_KEY), t8 = make_int4(NO_KEY, NO_KEY, NO_KEY, TOPK);
+        if (i < n1) {
+            t4 = tk[2 * i];
+            t8 = tk[2 * i + 1];
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const bool live = pre4[u].x != NO_KEY && (float)(pre4[u].x >> 16) < th;
-            bal[u] = __ballot(live);
-            if (lane == 0) s_cntw[u * 4 + wv] = __popcll(bal[u]);
-        }
+        const bool live = t4.x != NO_KEY && (float)(t4.x >> 16) < th;
+        const unsigned long long m = __ballot(live);
+        if (lane == 0) s_cntw[wv] = __popcll(m);
         __syncthreads();
-        int run = 0;
+        int off = nlive, tot = 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            int off = run;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const int cw = s_cntw[u * 4 + w];
-                off += w < wv ? cw : 0;
-                run += cw;
-            }
-            if ((bal[u] >> lane) & 1ull) {
-                const int slot = off + __popcll(bal[u] & ((1ull << lane) - 1ull));
-                s_live[slot] = (unsigned short)(u * MT + tid);
-                s_w1[slot] = -1;
-                s_w2[slot] = -1;
-                s_flag[slot] = 0;
-                if (slot < PAIR_KEYS_LDS) {
-                    s_keys[2 * slot] = pre4[u];
-                    s_keys[2 * slot + 1] = pre8[u];
-                }
+        for (int w = 0; w < RW_NW; ++w) {
+            const int cw = s_cntw[w];
+            off += w < wv ? cw : 0;
+            tot += cw;
+        }
+        if (live) {
+            const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
+            s_live[slot] = (unsigned short)i;
+            s_w1[slot] = -1;
+            s_w2[slot] = -1;
+            s_flag[slot] = 0;
+            if (slot < PAIR_KEYS_LDS) {
+                s_keys[2 * slot] = t4;
+                s_keys[2 * slot + 1] = t8;
             }
         }
-        nlive = run;
+        nlive += tot;
         __syncthreads();
-    } else {
-        for (int i0 = 0; i0 < n1; i0 += MT) {
-            const int i = i0 + tid;
-            int4 t4 = make_int4(NO_KEY, NO_KEY, NO_KEY, NO_KEY), t8 = make_int4(NO_KEY, NO_KEY, NO_KEY, TOPK);
-            if (i < n1) {
-                t4 = tk[2 * i];
-                t8 = tk[2 * i + 1];
-            }
-            const bool live = t4.x != NO_KEY && (float)(t4.x >> 16) < th;
-            const unsigned long long m = __ballot(live);
-            if (lane == 0) s_wave[wv] = __popcll(m);
-            __syncthreads();
-            int off = nlive;
-            for (int w = 0; w < wv; ++w) off += s_wave[w];
-            if (live) {
-                const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
-                s_live[slot] = (unsigned short)i;
-                s_w1[slot] = -1;
-                s_w2[slot] = -1;
-                s_flag[slot] = 0;
-                if (slot < PAIR_KEYS_LDS) {
-                    s_keys[2 * slot] = t4;
-                    s_keys[2 * slot + 1] = t8;
-                }
-            }
-            nlive += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-            __syncthreads();
-        }
     }
     const uint32_t *d1 = reinterpret_cast<const uint32_t *>(desc + (size_t)a * cap * 32);
     const uint32_t *d2 = reinterpret_cast<const uint32_t *>(desc + (size_t)b * cap * 32);
+#if defined(AFV_RESOLVE_STATS) && AFV_RESOLVE_STATS == 4
+    const long long wg_t0 = wall_clock64();
+    long long wg_tresc = 0;
+    int wg_steps = 0, wg_resc = 0, wg_took = 0, wg_conv = 0;
+#endif
     // ---- the fixed point ----
     bool cols_ready = false;
     int pass = 0;
@@ -907,7 +874,7 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve_wg(const uint8_t *__res
     while (nlive > 0 && pass < pass_limit) {
         int *R = s_claim + (pass % 3) * capr, *W = s_claim + ((pass + 1) % 3) * capr, *Z = s_claim + ((pass + 2) % 3) * capr;
         bool changed = false;
-        for (int li = tid; li < nlive; li += MT) {
+        for (int li = tid; li < nlive; li += RWT) {
             const int w1 = s_w1[li], w2 = s_w2[li];
             const int flag = s_flag[li];
             int want = 0;
@@ -935,42 +902,37 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve_wg(const uint8_t *__res
         }
         ++pass;
         if (__syncthreads_or(changed ? 1 : 0)) continue;
-        // converged: W holds the claims of the final wants (so far).  The rows that asked for a rescan, in row order (s_wlist): the
-        // k-th block of 256 live rows is held by the threads in order, so a ballot per block + the blocks' wave counts place them
+        // converged: W holds the claims of the final wants (so far).  The rows that asked for a rescan, in row order (s_wlist): live row
+        // t is held by thread t, so a ballot + the wavefronts' counts place them
         {
-            unsigned long long bal[4];
-            const int nblk = (nlive + MT - 1) / MT;  // <= 4 blocks here; more live rows: only the first 1024 are looked at per cycle
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int li = u * MT + tid;
-                bal[u] = __ballot(u < nblk && li < nlive && (s_flag[li] & 3) == 1);
-                if (lane == 0) s_cntw[u * 4 + wv] = __popcll(bal[u]);
-            }
+            const bool waits = tid < nlive && (s_flag[tid] & 3) == 1;  // the first 1024 live rows are looked at per cycle
+            const unsigned long long bal = __ballot(waits);
+            if (lane == 0) s_cntw[wv] = __popcll(bal);
             __syncthreads();
-            int run = 0;
+            int off = 0, run = 0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int off = run;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const int cw = s_cntw[u * 4 + w];
-                    off += w < wv ? cw : 0;
-                    run += cw;
-                }
-                if ((bal[u] >> lane) & 1ull) {
-                    const int slot = off + __popcll(bal[u] & ((1ull << lane) - 1ull));
-                    if (slot < RW_WLIST) s_wlist[slot] = (unsigned short)(u * MT + tid);
-                }
+            for (int w = 0; w < RW_NW; ++w) {
+                const int cw = s_cntw[w];
+                off += w < wv ? cw : 0;
+                run += cw;
+            }
+            if (waits) {
+                const int slot = off + __popcll(bal & ((1ull << lane) - 1ull));
+                if (slot < RW_WLIST) s_wlist[slot] = (unsigned short)tid;
             }
             if (tid == 0) s_first = run;
             __syncthreads();
         }
         int nw = min(s_first, RW_WLIST);
-        if (nw == 0 && nlive > 4 * MT) {  // sets above 1024 live rows: the rows behind the first 1024, one at a time (rare, slow, exact)
+#if defined(AFV_RESOLVE_STATS) && AFV_RESOLVE_STATS == 4
+        ++wg_conv;
+        const long long wg_r0 = wall_clock64();
+#endif
+        if (nw == 0 && nlive > RWT) {  // sets above 1024 live rows: the rows behind the first 1024, one at a time (rare, slow, exact)
             if (tid == 0) s_first = RW_INF;
             __syncthreads();
             int mine = RW_INF;
-            for (int li = 4 * MT + tid; li < nlive; li += MT)
+            for (int li = RWT + tid; li < nlive; li += RWT)
                 if ((s_flag[li] & 3) == 1) mine = min(mine, li);
             if (mine != RW_INF) atomicMin(&s_first, mine);
             __syncthreads();
@@ -984,65 +946,87 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve_wg(const uint8_t *__res
         if (stage_cols && !cols_ready) {  // first rescan of this pair: park the column descriptors in LDS
             const uint4 *gc = reinterpret_cast<const uint4 *>(d2);
             uint4 *sc = reinterpret_cast<uint4 *>(s_cols);
-            for (int i = tid; i < n2 * 2; i += MT) sc[i] = gc[i];
+            for (int i = tid; i < n2 * 2; i += RWT) sc[i] = gc[i];
             cols_ready = true;
             __syncthreads();
         }
         const uint4 *cb = (stage_cols && cols_ready) ? reinterpret_cast<const uint4 *>(s_cols) : reinterpret_cast<const uint4 *>(d2);
-        // Exact rescans, FOUR waiting rows at a time (one per wavefront), each over the columns no EARLIER row claims.  A row's answer is
-        // final when every row before it is final: the rows before the first waiting row are (converged, none of them waits), and a
-        // rescan that ends in "no match" - nearly all do - changes nothing for anybody behind it.  So the answers are adopted in row
+        // Exact rescans, RW_RPW waiting rows per wavefront and step (16 at a time), each over the columns no EARLIER row claims; the
+        // rows of a wavefront share the column loads.  A row's answer is final when every row before it is final: the rows before the
+        // first waiting row are (converged, none of them waits), and a rescan that ends in "no match" - nearly all do: 0-2 of the 6-30
+        // of a pair of consecutive frames take a column - changes nothing for anybody behind it.  So the answers are adopted in row
         // order up to and including the first one that TAKES a column; the rows behind that one are rescanned again after the
-        // iteration has settled with the new claim.
+        // iteration has settled with the new claim.  (Four rows per step, one per wavefront, left the slowest of 128 concurrent pairs
+        // at 8 steps of two barriers each: that tail, not the median, is what a batch waits for.)
         bool took = false;
-        for (int g0 = 0; g0 < nw && !took; g0 += MT / 64) {
-            const int g = g0 + wv;
-            int wr = -1;
-            if (g < nw) {
-                const int r = s_wlist[g], rrow = s_live[r];
-                const uint4 *qp = reinterpret_cast<const uint4 *>(d1 + (size_t)rrow * 8);
-                const uint4 qlo = qp[0], qhi = qp[1];
-                const uint32_t q[8] = {qlo.x, qlo.y, qlo.z, qlo.w, qhi.x, qhi.y, qhi.z, qhi.w};
-                int k = NO_KEY, s2nd = NO_KEY >> 16;
-                for (int c0 = lane; c0 < n2; c0 += 256) {
-                    uint4 lo[4], hi[4];
-                    int cl[4];
+        for (int g0 = 0; g0 < nw && !took; g0 += RW_RPW * RW_NW) {
+            int rr[RW_RPW], kk[RW_RPW], s2[RW_RPW], wr[RW_RPW];
+            uint32_t q[RW_RPW][8];
+            const int gb = g0 + wv * RW_RPW;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+            for (int j = 0; j < RW_RPW; ++j) {
+                rr[j] = s_wlist[min(gb + j, nw - 1)];
+                const uint4 *qp = reinterpret_cast<const uint4 *>(d1 + (size_t)s_live[rr[j]] * 8);
+                const uint4 qlo = qp[0], qhi = qp[1];
+                q[j][0] = qlo.x, q[j][1] = qlo.y, q[j][2] = qlo.z, q[j][3] = qlo.w, q[j][4] = qhi.x, q[j][5] = qhi.y, q[j][6] = qhi.z, q[j][7] = qhi.w;
+                kk[j] = NO_KEY;
+                s2[j] = NO_KEY >> 16;
+                wr[j] = -1;
+            }
+            if (gb < nw) {
+                for (int c0 = lane; c0 < n2; c0 += 128) {
+                    uint4 lo[2], hi[2];
+                    int cl[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
                         const int c = min(c0 + 64 * u, n2 - 1);
                         lo[u] = cb[2 * c];
                         hi[u] = cb[2 * c + 1];
                         cl[u] = W[c];
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < 2; ++u) {
                         const int c = c0 + 64 * u;
-                        const int d = __popc(q[0] ^ lo[u].x) + __popc(q[1] ^ lo[u].y) + __popc(q[2] ^ lo[u].z) + __popc(q[3] ^ lo[u].w) +
-                                      __popc(q[4] ^ hi[u].x) + __popc(q[5] ^ hi[u].y) + __popc(q[6] ^ hi[u].z) + __popc(q[7] ^ hi[u].w);
-                        const bool usable = c < n2 && !(cl[u] < r);
-                        const int key = usable ? ((d << 16) | c) : NO_KEY;
-                        s2nd = min(s2nd, max(k, key) >> 16);
-                        k = min(k, key);
+#pragma unroll
+                        for (int j = 0; j < RW_RPW; ++j) {
+                            const int d = __popc(q[j][0] ^ lo[u].x) + __popc(q[j][1] ^ lo[u].y) + __popc(q[j][2] ^ lo[u].z) + __popc(q[j][3] ^ lo[u].w) +
+                                          __popc(q[j][4] ^ hi[u].x) + __popc(q[j][5] ^ hi[u].y) + __popc(q[j][6] ^ hi[u].z) + __popc(q[j][7] ^ hi[u].w);
+                            const bool usable = c < n2 && !(cl[u] < rr[j]);
+                            const int key = usable ? ((d << 16) | c) : NO_KEY;
+                            s2[j] = min(s2[j], max(kk[j], key) >> 16);
+                            kk[j] = min(kk[j], key);
+                        }
                     }
                 }
-                wave_merge_best(k, s2nd);
-                if (k != NO_KEY) {
-                    const float best1 = (float)(k >> 16);
-                    const float best2 = (s2nd == (NO_KEY >> 16)) ? 3.402823466e+38f : (float)s2nd;
-                    if (best1 < th && best1 < ratio * best2) wr = k & 0xffff;
+#pragma unroll
+                for (int j = 0; j < RW_RPW; ++j) {
+                    wave_merge_best(kk[j], s2[j]);
+                    if (kk[j] != NO_KEY) {
+                        const float best1 = (float)(kk[j] >> 16);
+                        const float best2 = (s2[j] == (NO_KEY >> 16)) ? 3.402823466e+38f : (float)s2[j];
+                        if (best1 < th && best1 < ratio * best2) wr[j] = kk[j] & 0xffff;
+                    }
                 }
             }
-            if (lane == 0) s_part[wv] = wr;
+            if (lane < RW_RPW) {
+                int v = wr[0];
+#pragma unroll
+                for (int j = 1; j < RW_RPW; ++j) v = lane == j ? wr[j] : v;
+                s_part[wv * RW_RPW + lane] = v;
+            }
             __syncthreads();
-            // adopt in row order (every thread computes the same verdict; thread 0 writes)
+            // adopt in row order (every thread computes the same verdict)
             int nadopt = 0;
 #pragma unroll
-            for (int w = 0; w < MT / 64; ++w) {
+            for (int w = 0; w < RW_RPW * RW_NW; ++w) {
                 if (g0 + w < nw && !took) {
                     ++nadopt;
                     took = s_part[w] >= 0;
                 }
             }
+#if defined(AFV_RESOLVE_STATS) && AFV_RESOLVE_STATS == 4
+            ++wg_steps; wg_resc += nadopt; wg_took += took ? 1 : 0;
+#endif
             if (tid < nadopt) {
                 const int r = s_wlist[g0 + tid];
                 s_flag[r] = 2;  // pinned: from now on the row asserts this answer in every pass (its want so far was -1)
@@ -1052,12 +1036,18 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve_wg(const uint8_t *__res
         }
         // a taken column enters the claims with the next pass (the pinned row's want changes from -1), the rows behind it re-evaluate;
         // if nothing was taken and every waiting row was looked at, the converged state is the final one
-        if (!took && s_first <= RW_WLIST && nlive <= 4 * MT) break;
+#if defined(AFV_RESOLVE_STATS) && AFV_RESOLVE_STATS == 4
+        wg_tresc += wall_clock64() - wg_r0;
+#endif
+        if (!took && s_first <= RW_WLIST && nlive <= RWT) break;
     }
+#if defined(AFV_RESOLVE_STATS) && AFV_RESOLVE_STATS == 4
+    if (tid == 0) printf("wgpair %d nlive %d passes %d convergences %d rescan_steps %d rescans %d took %d fixedpoint_x10ns %lld rescan_x10ns %lld\n", p, nlive, pass, wg_conv, wg_steps, wg_resc, wg_took, wall_clock64() - wg_t0, wg_tresc);
+#endif
     // ---- matches, count ----
     {
         int cnt = 0;
-        for (int li = tid; li < nlive; li += MT) {
+        for (int li = tid; li < nlive; li += RWT) {
             const int w = s_w1[li];
             if (w >= 0) {
                 s_out[s_live[li]] = w;
@@ -1072,7 +1062,7 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve_wg(const uint8_t *__res
     }
     if (check_ori) {
         // rotation histogram of the accepted matches (FeatureMatcher.cc:1587-1599): it never influences the walk
-        for (int i = tid; i < n1; i += MT) {
+        for (int i = tid; i < n1; i += RWT) {
             const int c = s_out[i];
             if (c >= 0) {
                 const int bin = rotation_bin(ang[((size_t)a * cap + i) * ang_stride], ang[((size_t)b * cap + c) * ang_stride]);
@@ -1096,7 +1086,7 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve_wg(const uint8_t *__res
         __syncthreads();
         const int i1 = s_drop[0], i2 = s_drop[1], i3 = s_drop[2];
         int dropped = 0;
-        for (int i = tid; i < n1; i += MT) {
+        for (int i = tid; i < n1; i += RWT) {
             if (s_out[i] >= 0) {
                 const int bb = s_bin[i];
                 if (bb != i1 && bb != i2 && bb != i3) { s_out[i] = -1; ++dropped; }
@@ -1105,7 +1095,7 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve_wg(const uint8_t *__res
         if (dropped) atomicSub(&s_nm, dropped);
         __syncthreads();
     }
-    for (int i = tid; i < cap; i += MT) out[i] = s_out[i];
+    for (int i = tid; i < cap; i += RWT) out[i] = s_out[i];
     if (tid == 0) nmatches[p] = s_nm;
 }
 
@@ -1287,7 +1277,7 @@ extern "C" void afv_launch_match_resolve(const uint8_t *desc, const float *ang, 
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_match_resolve_wg), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             done_wg[dev] = true;
         }
-        hipLaunchKernelGGL(k_match_resolve_wg, dim3(npairs), dim3(MT), lds_wg, stream, desc, ang, ang_stride, nset, cap, pa, pb, topk, th, ratio,
+        hipLaunchKernelGGL(k_match_resolve_wg, dim3(npairs), dim3(RWT), lds_wg, stream, desc, ang, ang_stride, nset, cap, pa, pb, topk, th, ratio,
                            check_ori, match, nmatches, pair_base, stage ? 1 : 0);
         return;
     }
