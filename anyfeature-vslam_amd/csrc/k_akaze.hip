@@ -608,7 +608,7 @@ typedef float akz_f4 __attribute__((ext_vector_type(4)));
 #define AKZ_G_PS 76  // source tile pitch: 68 columns used; 76 mod 32 = 12 spreads the 128-bit reads of lanes that differ in the row
 #define AKZ_G_PT 76  // transposed row-pass plane: [column][source row + 1], 72 entries used
 #define AKZ_G_ROWS 70
-#define AKZ_G_LDS_FLOATS (AKZ_G_ROWS * AKZ_G_PS + 64 * AKZ_G_PT + 2 * 2 * 8 * 64)
+#define AKZ_G_LDS_FLOATS (AKZ_G_ROWS * AKZ_G_PS + 64 * AKZ_G_PT)  // 40736 B: four workgroups per CU
 #define AKZ_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // NOUT outputs of the symmetric 5-tap filter from a window of NOUT + 4 values, two at a time: out[k] = k0 v[k+2] + k1 (v[k+3] + v[k+1]) + k2 (v[k+4] + v[k])
@@ -626,27 +626,28 @@ __device__ __forceinline__ void akz_gauss5_window(const float *v, float k0, floa
 }
 
 template <int N>
-__global__ __launch_bounds__(AKZ_FT) void k_akz_fed_gauss(const float *__restrict__ Lt_in, float *__restrict__ lsm, const float *__restrict__ taps, int w,
+__global__ __launch_bounds__(AKZ_FT, 8) void k_akz_fed_gauss(const float *__restrict__ Lt_in, float *__restrict__ lsm, const float *__restrict__ taps, int w,
                                                           int h, int nframes, const float *__restrict__ kcontrast, int octave, AkzTau tau,
                                                           float *__restrict__ Lt_out) {
     extern __shared__ float s_fed[];
     constexpr int OW = 62 - 2 * N, FH = 64 - 2 * N, PS = AKZ_G_PS, PT = AKZ_G_PT, SR = AKZ_G_ROWS;
     float *s_src = s_fed;            // [70][PS]: source rows y0 - N - 3 .., columns x0 - N - 3 .. (replicate coordinates)
     float *s_t = s_fed + SR * PS;    // [64][PT]: row-pass result of tile column c, source row py at [c][py + 1]
-    float *s_x = s_t + 64 * PT;      // band boundary rows: [2 parities][top, bottom][8 waves][64]
+    float *s_x = s_src;              // band boundary rows: [2 parities][top, bottom][8 waves][64], on top of the source tile (dead by then)
     AKZ_TILE(OW, FH)
-    const int tid = threadIdx.x, tx = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, tx = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6) & 7;  // & 7: a known range removes the row tests below
     const int r0 = wv * 8;
     const int gx = x0 - N - 1 + tx;  // image column of tile column tx
     const int ty0 = y0 - N;          // image row of tile row 0
     const float *pin = Lt_in + (size_t)f * w * h;
     {   // ---- staging: 70 rows x 68 columns
-        const float *pc = pin + akz_clamp(x0 - N - 3 + tx, w);
+        const unsigned cxb = (unsigned)akz_clamp(x0 - N - 3 + tx, w) * 4u;  // byte offset inside a row: 32 bits, zero-extended by the load
         float v[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             const int py = wv + 8 * k;
-            if (py < SR) v[k] = pc[(size_t)akz_clamp(ty0 - 3 + py, h) * w];
+            if (py < SR)  // row pointer on the scalar unit + lane offset
+                v[k] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(pin + (size_t)akz_clamp(ty0 - 3 + py, h) * w) + cxb);
         }
         float e = 0.0f;
         if (tid < SR * 4) e = pin[(size_t)akz_clamp(ty0 - 3 + (tid >> 2), h) * w + akz_clamp(x0 - N - 3 + 64 + (tid & 3), w)];
