@@ -78,13 +78,15 @@ def test_conductivity_reciprocal_is_the_ieee_quotient():
     assert r.stdout.count("akz_recip_ge1 in 0") == 3, r.stdout
 
 
-def test_fused_and_step_by_step_scale_space_agree(afv):
-    """the fused level kernel (conductivity + whole FED cycle in LDS) against one kernel per step, and the one-pass derivative /
-    Hessian strip kernel against its two-kernel form, at a size whose tiles are ragged on both axes"""
-    ctx = afv.AkazeContext(afv.akaze.default_params(max_width=700, max_height=404, max_batch=1))
-    frame = _frames(afv, 700, 404, (8,))
+@pytest.mark.parametrize("w,h", [(700, 404), (97, 61), (66, 203), (41, 37)])
+def test_fused_and_step_by_step_scale_space_agree(afv, w, h):
+    """the fused level kernel (Lsmooth + conductivity + whole FED cycle in one launch) against one kernel per step, and the one-pass
+    derivative / Hessian strip kernel against its two-kernel form, at sizes whose tiles are ragged on both axes - down to images smaller
+    than one tile, where a tile meets all four borders (the Lsmooth rows / columns just outside the image are patched in registers)"""
+    ctx = afv.AkazeContext(afv.akaze.default_params(max_width=w, max_height=h, max_batch=1))
+    frame = _frames(afv, w, h, (8,))
     plan = ctx.scale_space(frame)
-    planes = (afv.akaze.LT, afv.akaze.LX, afv.akaze.LY, afv.akaze.LDET)
+    planes = (afv.akaze.LT, afv.akaze.LSMOOTH, afv.akaze.LX, afv.akaze.LY, afv.akaze.LDET)
     fused = [[ctx.plane(0, i, which) for which in planes] for i in range(plan.nlevels)]
     ctx.set_step_by_step(True)  # also: first derivatives and Hessian as two LDS-tiled kernels instead of the one-pass strip kernel
     ctx.scale_space(frame)
