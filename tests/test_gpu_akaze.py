@@ -78,11 +78,12 @@ def test_conductivity_reciprocal_is_the_ieee_quotient():
     assert r.stdout.count("akz_recip_ge1 in 0") == 3, r.stdout
 
 
-@pytest.mark.parametrize("w,h", [(700, 404), (97, 61), (66, 203), (41, 37)])
+@pytest.mark.parametrize("w,h", [(700, 404), (97, 61), (80, 203), (83, 40)])
 def test_fused_and_step_by_step_scale_space_agree(afv, w, h):
     """the fused level kernel (Lsmooth + conductivity + whole FED cycle in one launch) against one kernel per step, and the one-pass
     derivative / Hessian strip kernel against its two-kernel form, at sizes whose tiles are ragged on both axes - down to images smaller
-    than one tile, where a tile meets all four borders (the Lsmooth rows / columns just outside the image are patched in registers)"""
+    than one tile at octave 1 (41 x 20: a tile meets all four borders; the Lsmooth rows / columns just outside the image are patched in
+    registers); 80 x 40 is the smallest frame the extractor accepts"""
     ctx = afv.AkazeContext(afv.akaze.default_params(max_width=w, max_height=h, max_batch=1))
     frame = _frames(afv, w, h, (8,))
     plan = ctx.scale_space(frame)
