@@ -907,7 +907,7 @@ __global__ __launch_bounds__(AKZ_T) void k_akz_hessian(const float *__restrict__
 // What bounds it (round 4, all measured): the SHAPE of its memory accesses.  A 1-read : 3-write stream in strips of 56 / 52 / 48
 // columns reaches 3.8 / 3.5 / 3.7 TB/s on this chip (248 / 271 / 255 us for one level of 64 frames) where full 256-byte rows reach
 // 5.1 (184 us; tools/probes/probe_stream13.hip) - and this kernel takes 230 / 265-285 / 260 us.  The vector ALU is ~30 % busy; more
-// wavefronts per SIMD (-DAKZ_DH_WPE builds: 89 -> 70 and 111 -> 92 VGPRs without spills) and DPP shift chains instead of the
+// wavefronts per SIMD (__launch_bounds__(256, 5) builds: 89 -> 70 and 111 -> 92 VGPRs without spills) and DPP shift chains instead of the
 // crossbar change nothing.  A variant with 64-ALIGNED strips in which every lane loads its five taps x - 2S .. x + 2S itself and
 // evaluates the first-derivative filters at x - S, x, x + S (no lane crossing, full-line stores, bit-identical) was built and is
 // SLOWER: 285 / 305-320 / 366 us - five loads per row instead of one put the time into cache round trips.  Dropped.
