@@ -57,7 +57,8 @@ class MatchJob(C.Structure):
 
 class TriJob(C.Structure):
     _fields_ = [("bow", MatchJob), ("x1", C.c_void_p), ("y1", C.c_void_p), ("x2", C.c_void_p), ("y2", C.c_void_p),
-                ("sigma2_2", C.c_void_p), ("F12", C.c_float * 9), ("ex", C.c_float), ("ey", C.c_float)]
+                ("sigma2_2", C.c_void_p), ("F12", C.c_float * 9), ("ex", C.c_float), ("ey", C.c_float),
+                ("u_right1", C.c_void_p), ("u_right2", C.c_void_p), ("only_stereo", C.c_int32)]
 
 
 class TableTriJob(C.Structure):
@@ -78,7 +79,8 @@ class ProjJob(C.Structure):
                 ("qdesc", C.c_void_p), ("qvalid", C.c_void_p), ("qu", C.c_void_p), ("qv", C.c_void_p), ("qr", C.c_void_p),
                 ("qmin_size", C.c_void_p), ("qmax_size", C.c_void_p), ("qangle", C.c_void_p), ("qoccupies", C.c_void_p),
                 ("th_high", C.c_float), ("nnratio", C.c_float), ("size_tol", C.c_float), ("inv_size_tol", C.c_float),
-                ("check_orientation", C.c_int32), ("mode", C.c_int32)]
+                ("check_orientation", C.c_int32), ("mode", C.c_int32),
+                ("u_right", C.c_void_p), ("q_ur", C.c_void_p), ("q_er_max", C.c_void_p)]
 
 
 # every symbol include/afv_hip.h declares: (name, restype, argtypes)

@@ -14,8 +14,9 @@
 //   FeatureMatcher::SearchByProjection x4 / Fuse x2 / SearchBySim3 / SearchForInitialization (matching cores)
 //                                   include/FeatureMatcher.h:47-82, src/FeatureMatcher.cc:73-154, 287-397, 399-557, 794-1064,
 //                                   1066-1287, 1291-1506 — the projection geometry stays with the caller, as in the reference
-// MONO ONLY: the reference binary is vslamlab_anyfeature_mono; the stereo branches (FeatureMatcher.cc:118-123, 706-733) and
-// mvImagePyramid (FeatureExtractor.h:142, read only by Frame::ComputeStereoMatches, Frame.cc:475,568) are not provided.
+// The reference binary is vslamlab_anyfeature_mono; the stereo branches of the matchers (FeatureMatcher.cc:114-119, 705-747, 880-894,
+// 1367-1372) are served through the optional mvuRight members below, mvImagePyramid through ImagePyramid().  What stays with the
+// reference is Frame::ComputeStereoMatches itself (Frame.cc:465-645), which is Frame code, not plugin code.
 // Error behaviour follows the reference: no exceptions cross the boundary; an empty image leaves the outputs
 // untouched (ORBextractor.cc:570-571); an unrecoverable device error terminates (cf. Feature_sift128.cpp:61).
 #pragma once
@@ -217,6 +218,7 @@ struct FeatureView {
     const float *angles = nullptr;           // mvKeysUn[i].angle
     const float *x = nullptr, *y = nullptr;  // mvKeysUn[i].pt       (triangulation)
     const float *sigma2 = nullptr;           // GetKeyPt1DSigma2(i)  (triangulation)
+    const float *mvuRight = nullptr;         // KeyFrame::mvuRight (stereo keyframes; nullptr: monocular)  (triangulation)
 };
 
 class FeatureMatcherHip {
@@ -234,15 +236,16 @@ class FeatureMatcherHip {
     int SearchByBoW_Frame(const FeatureView &kf, const FeatureView &frame, std::vector<int> &matchesF) {
         return run(kf, frame, AFV_MATCH_KF_FRAME, matchesF);
     }
-    // SearchForTriangulation (:662-790, mono): vMatchedPairs ascending idx1
+    // SearchForTriangulation (:662-790; stereo branches :705-709, :727-731, :741 through FeatureView::mvuRight): vMatchedPairs ascending idx1
     int SearchForTriangulation(const FeatureView &kf1, const FeatureView &kf2, const float F12[9], float ex, float ey,
-                               std::vector<std::pair<size_t, size_t>> &vMatchedPairs) {
+                               std::vector<std::pair<size_t, size_t>> &vMatchedPairs, bool bOnlyStereo = false) {
         Csr c1(kf1), c2(kf2);
         afv_tri_job t{};
         fill(t.bow, kf1, kf2, c1, c2, AFV_MATCH_KF_KF);
         t.x1 = kf1.x; t.y1 = kf1.y; t.x2 = kf2.x; t.y2 = kf2.y; t.sigma2_2 = kf2.sigma2;
         for (int i = 0; i < 9; ++i) t.F12[i] = F12[i];
         t.ex = ex; t.ey = ey;
+        t.u_right1 = kf1.mvuRight; t.u_right2 = kf2.mvuRight; t.only_stereo = bOnlyStereo ? 1 : 0;
         std::vector<int32_t> m((size_t)std::max(kf1.N, 1), -1);
         int32_t n = 0;
         const int rc = afv_match_triangulation(ctx, &t, 1, m.data(), &n);
@@ -262,6 +265,7 @@ class FeatureMatcherHip {
         const float *angle = nullptr;            // mvKeysUn[i].angle
         const uint8_t *occupied = nullptr;       // pts[i] (&& observations > 0 where the reference asks) ; nullptr = none
         const float *inf = nullptr;              // GetKeyPt1DInf(i) (Fuse only)
+        const float *mvuRight = nullptr;         // stereo frames / keyframes (nullptr: monocular): FeatureMatcher.cc:114, :880, :1367
         float mnMinX = 0.f, mnMinY = 0.f, mfGridElementWidthInv = 0.f, mfGridElementHeightInv = 0.f;
         int grid_cols = 64, grid_rows = 48;      // FRAME_GRID_COLS / ROWS
         float sizeTolerance = 1.2f, invSizeTolerance = 1.0f / 1.2f;  // Frame.cc:73-74
@@ -272,22 +276,25 @@ class FeatureMatcherHip {
         const uint8_t *valid = nullptr;      // nullptr = all
         const float *angle = nullptr;        // last-frame style searches with orientation check
         const uint8_t *occupies = nullptr;   // pMP->NumberOfObservations() > 0 (nullptr = yes)
+        // stereo: projected right-image coordinate (pMP->mTrackProjXR :116 / u - mbf * invzc :1369 / ur :885) and the gate on
+        // |ur - mvuRight| of the two SearchByProjection flavours that have one (r * pMP->trackSigma :117 / the window radius :1371)
+        const float *ur = nullptr, *er_max = nullptr;
     };
     // SearchByProjection(F, vpMapPoints, radiusTh) (FeatureMatcher.cc:73-154): assign[i] = query stored in F.pts[i] or -1
     int SearchByProjection(const FrameGridView &F, const ProjectionQueries &q, std::vector<int> &assign) {
         return projection(F, q, TH_HIGH, AFV_PROJ_LOCALMAP, false, assign);
     }
-    // SearchByProjection(CurrentFrame, LastFrame, radiusTh) (:1291-1402, mono)
+    // SearchByProjection(CurrentFrame, LastFrame, radiusTh) (:1291-1402)
     int SearchByProjection_LastFrame(const FrameGridView &F, const ProjectionQueries &q, std::vector<int> &assign) {
         return projection(F, q, TH_HIGH, AFV_PROJ_LASTFRAME, mbCheckOrientation, assign);
     }
     // SearchByProjection(CurrentFrame, pKF, sAlreadyFound, radiusTh, useHighMatchingThreshold) (:1404-1506, relocalisation)
     int SearchByProjection_Reloc(const FrameGridView &F, const ProjectionQueries &q, float th, std::vector<int> &assign) {
-        return projection(F, q, th, AFV_PROJ_LASTFRAME, mbCheckOrientation, assign);
+        return projection(F, q, th, AFV_PROJ_LASTFRAME, mbCheckOrientation, assign, false);
     }
     // SearchByProjection(pKF, Scw, vpPoints, vpMatched, radiusTh) (:287-397, loop closing)
     int SearchByProjection_Sim3(const FrameGridView &KF, const ProjectionQueries &q, std::vector<int> &assign) {
-        return projection(KF, q, TH_LOW, AFV_PROJ_LASTFRAME, false, assign);
+        return projection(KF, q, TH_LOW, AFV_PROJ_LASTFRAME, false, assign, false);
     }
     // Fuse(pKF, vpMapPoints, radiusTh) (:794-940): best[q] = keypoint index or -1; with KF.inf == nullptr it is
     // Fuse(pKF, Scw, vpPoints, radiusTh, vpReplacePoint) (:942-1064)
@@ -336,10 +343,13 @@ class FeatureMatcherHip {
         j.nq = q.n; j.qdesc = q.descriptors; j.qvalid = q.valid; j.qu = q.u; j.qv = q.v; j.qr = q.r;
         j.qmin_size = q.min_size; j.qmax_size = q.max_size; j.qangle = q.angle; j.qoccupies = q.occupies;
         j.nnratio = mfNNratio; j.size_tol = F.sizeTolerance; j.inv_size_tol = F.invSizeTolerance;
+        j.u_right = F.mvuRight; j.q_ur = q.ur; j.q_er_max = q.er_max;
         return j;
     }
-    int projection(const FrameGridView &F, const ProjectionQueries &q, float th, int mode, bool ori, std::vector<int> &assign) {
+    // stereo = false: the relocalisation / Sim3 flavours share the entry point but have no mvuRight branch (:287-397, :1404-1506)
+    int projection(const FrameGridView &F, const ProjectionQueries &q, float th, int mode, bool ori, std::vector<int> &assign, bool stereo = true) {
         afv_proj_job j = proj_job(F, q);
+        if (!stereo) j.u_right = nullptr;
         j.th_high = th; j.mode = mode; j.check_orientation = ori;
         assign.assign((size_t)std::max(F.N, 1), -1);
         int32_t n = 0;

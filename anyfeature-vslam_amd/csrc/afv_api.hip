@@ -1422,11 +1422,12 @@ static int afv_match_triangulation_impl(afv_ctx *c, const afv_tri_job *jobs, int
         if (rc) return rc;
         const afv_tri_job &t = jobs[i];
         if ((t.bow.n1 > 0 && (!t.x1 || !t.y1)) || (t.bow.n2 > 0 && (!t.x2 || !t.y2 || !t.sigma2_2))) return AFV_EINVAL;
+        if (t.only_stereo != 0 && t.only_stereo != 1) return AFV_EINVAL;
     }
     HIPCHK(c, hipSetDevice(c->device));
     Blob b(c);
     std::vector<JobOffsets> offs(njobs);
-    std::vector<size_t> geo_off(njobs * 5), rowseg_off(njobs);
+    std::vector<size_t> geo_off(njobs * 5), rowseg_off(njobs), ur_off(njobs * 2);
     for (int i = 0; i < njobs; ++i) {
         stage_job(b, jobs[i].bow, true, offs[i]);
         const afv_tri_job &t = jobs[i];
@@ -1435,6 +1436,8 @@ static int afv_match_triangulation_impl(afv_ctx *c, const afv_tri_job *jobs, int
         geo_off[5 * i + 2] = b.put(t.x2, (size_t)t.bow.n2 * 4);
         geo_off[5 * i + 3] = b.put(t.y2, (size_t)t.bow.n2 * 4);
         geo_off[5 * i + 4] = b.put(t.sigma2_2, (size_t)t.bow.n2 * 4);
+        ur_off[2 * i + 0] = t.u_right1 ? b.put(t.u_right1, (size_t)t.bow.n1 * 4) : 0;  // stereo keyframes (FeatureMatcher.cc:705, :727)
+        ur_off[2 * i + 1] = t.u_right2 ? b.put(t.u_right2, (size_t)t.bow.n2 * 4) : 0;
         // feature -> shared node (a feature sits in exactly one node of its FeatureVector)
         std::vector<Seg> segs;
         afv_shared_segments(t.bow, segs);
@@ -1470,6 +1473,9 @@ static int afv_match_triangulation_impl(afv_ctx *c, const afv_tri_job *jobs, int
         d.ex = jobs[i].ex;
         d.ey = jobs[i].ey;
         d.row_seg = reinterpret_cast<const int *>(c->d_match + rowseg_off[i]);
+        d.u_right1 = jobs[i].u_right1 ? reinterpret_cast<const float *>(c->d_match + ur_off[2 * i + 0]) : nullptr;
+        d.u_right2 = jobs[i].u_right2 ? reinterpret_cast<const float *>(c->d_match + ur_off[2 * i + 1]) : nullptr;
+        d.only_stereo = jobs[i].only_stereo;
     }
     HIPCHK(c, hipMemcpyAsync(c->d_match, b.h.data(), b.h.size(), hipMemcpyHostToDevice, c->stream));
     int max_n1 = 0;
@@ -1635,10 +1641,12 @@ static int match_projection_impl(afv_ctx *c, const afv_proj_job *jobs, int njobs
         if (kind == KIND_INIT && j.check_orientation && ((j.n > 0 && !j.angle) || (j.nq > 0 && !j.qangle))) return AFV_EINVAL;
         if (kind == KIND_PROJ && j.mode != AFV_PROJ_LOCALMAP && j.mode != AFV_PROJ_LASTFRAME) return AFV_EINVAL;
         if (kind == KIND_PROJ && j.mode == AFV_PROJ_LASTFRAME && j.check_orientation && ((j.n > 0 && !j.angle) || (j.nq > 0 && !j.qangle))) return AFV_EINVAL;
+        // stereo frames: the queries' right-image coordinate (and, for the projection searches, their gate) come with mvuRight
+        if (j.u_right && (kind == KIND_PROJ || kind == KIND_FUSE) && j.nq > 0 && (!j.q_ur || (kind == KIND_PROJ && !j.q_er_max))) return AFV_EINVAL;
     }
     HIPCHK(c, hipSetDevice(c->device));
     Blob b(c);
-    struct Off { size_t fd, x, y, size, angle, occ, inf, cptr, cidx, qd, qvalid, qu, qv, qr, qmin, qmax, qang, qocc, keys, ncand, ori, assign, nm; int words; };
+    struct Off { size_t fd, x, y, size, angle, occ, inf, cptr, cidx, qd, qvalid, qu, qv, qr, qmin, qmax, qang, qocc, keys, ncand, ori, assign, nm, ur, qur, qer; int words; bool stereo; };
     std::vector<Off> offs(njobs);
     size_t total_out = 0;
     for (int i = 0; i < njobs; ++i) {
@@ -1650,6 +1658,10 @@ static int match_projection_impl(afv_ctx *c, const afv_proj_job *jobs, int njobs
         o.angle = j.angle ? b.put(j.angle, (size_t)j.n * 4) : 0;
         o.occ = j.occupied ? b.put(j.occupied, (size_t)j.n) : 0;
         o.inf = (fuse && j.inf) ? b.put(j.inf, (size_t)j.n * 4) : 0;
+        o.stereo = j.u_right && (kind == KIND_PROJ || kind == KIND_FUSE);  // FeatureMatcher.cc:114-119, :1367-1372, :880-894
+        o.ur = o.stereo ? b.put(j.u_right, (size_t)j.n * 4) : 0;
+        o.qur = o.stereo ? b.put(j.q_ur, (size_t)j.nq * 4) : 0;
+        o.qer = (o.stereo && kind == KIND_PROJ) ? b.put(j.q_er_max, (size_t)j.nq * 4) : 0;
         // Frame::AssignFeaturesToGrid / PosInGrid (Frame.cc:225-240, 383-394): cell = ix * rows + iy, ascending index
         const int nc = j.grid_cols * j.grid_rows;
         std::vector<int> cptr((size_t)nc + 1, 0), cidx((size_t)std::max(j.n, 1)), cell((size_t)std::max(j.n, 1));
@@ -1708,6 +1720,10 @@ static int match_projection_impl(afv_ctx *c, const afv_proj_job *jobs, int njobs
         d.check_ori = j.check_orientation != 0; d.mode = j.mode;
         d.keys = reinterpret_cast<unsigned long long *>(B + o.keys); d.ncand = reinterpret_cast<int *>(B + o.ncand);
         d.orilist = reinterpret_cast<int *>(B + o.ori);
+        d.u_right = o.stereo ? reinterpret_cast<const float *>(B + o.ur) : nullptr;
+        d.q_ur = o.stereo ? reinterpret_cast<const float *>(B + o.qur) : nullptr;
+        d.q_er = (o.stereo && kind == KIND_PROJ) ? reinterpret_cast<const float *>(B + o.qer) : nullptr;
+        d.stereo_gate = (o.stereo && kind == KIND_PROJ) ? 1 : 0;
         d.assign = reinterpret_cast<int *>(B + out_off + acc * 4); d.nmatches = reinterpret_cast<int *>(B + nm_off + (size_t)i * 4);
         acc += (size_t)(per_query ? j.nq : j.n);
     }
@@ -1750,6 +1766,7 @@ static int afv_match_sim3_impl(afv_ctx *c, const afv_proj_job *j12, const afv_pr
     afv_proj_job jobs[2] = {*j12, *j21};
     jobs[0].inf = nullptr;  // no reprojection gate in SearchBySim3
     jobs[1].inf = nullptr;
+    jobs[0].u_right = jobs[1].u_right = nullptr;  // ... and no stereo branch (FeatureMatcher.cc:1066-1287)
     std::vector<int32_t> best((size_t)j12->nq + (size_t)j21->nq + 1);
     int32_t nf[2];
     const int rc = match_projection_impl(c, jobs, 2, best.data(), nf, KIND_FUSE);

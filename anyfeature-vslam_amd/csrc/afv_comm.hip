@@ -667,6 +667,8 @@ static int table_match_tri_impl(afv_table *t, const int32_t *pair_a, const int32
         T.ex = geo[p].ex;
         T.ey = geo[p].ey;
         T.row_seg = reinterpret_cast<const int *>(c->d_match + rowseg_off[p]);
+        T.u_right1 = T.u_right2 = nullptr;  // the table holds monocular keyframes (no mvuRight plane)
+        T.only_stereo = 0;
     }
     HIPCHK(c, hipMemcpyAsync(c->d_match, b.h.data(), in_bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_match + out_off, 0xff, (size_t)npairs * cap * sizeof(int), c->stream));

@@ -52,6 +52,8 @@ struct DevTriJob {
     float F[9];
     float ex, ey;
     const int *row_seg;
+    const float *u_right1, *u_right2;  // mvuRight of either keyframe (NULL: monocular)
+    int only_stereo;
 };
 extern "C" void afv_launch_match_bow(const DevMatchJob *jobs, int njobs, hipStream_t stream);
 extern "C" void afv_launch_match_bow_seg(const DevMatchJob *jobs, int njobs, const void *tasks, int ntasks, int *hist, uint8_t *bins,
@@ -76,6 +78,7 @@ struct DevProjJob {
     const float *qu, *qv, *qr, *qmin, *qmax, *qangle; const uint8_t *qocc;
     float th, ratio, tol, inv_tol; int check_ori, mode;
     unsigned long long *keys; int *ncand; int *orilist; int *assign; int *nmatches;
+    const float *u_right, *q_ur, *q_er; int stereo_gate;
 };
 extern "C" void afv_launch_match_projection(const DevProjJob *jobs, int njobs, int max_nq, hipStream_t stream);
 extern "C" void afv_launch_match_fuse(const DevProjJob *jobs, int njobs, int max_nq, hipStream_t stream);

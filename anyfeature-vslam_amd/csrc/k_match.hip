@@ -1106,6 +1106,8 @@ struct DevTriJob {
     float F[9];
     float ex, ey;
     const int *row_seg;  // [n1] index of the shared node holding the feature, -1 = none
+    const float *u_right1, *u_right2;  // mvuRight of either keyframe (NULL: monocular)
+    int only_stereo;                   // bOnlyStereo
 };
 
 // One thread per KF1 feature (row_seg = the shared node it belongs to, -1 if none): rows are independent here (vbMatched2 is
@@ -1117,6 +1119,8 @@ __device__ int tri_row(const DevTriJob &T, int idx1) {
     const int sg = T.row_seg[idx1];
     if (sg < 0) return -1;
     if (J.valid1 && J.valid1[idx1]) return -1;  // already has a MapPoint (:699-703)
+    const bool stereo1 = T.u_right1 && T.u_right1[idx1] >= 0.0f;  // :705
+    if (T.only_stereo && !stereo1) return -1;                      // :707-709
     const Seg S = J.segs[sg];
     uint32_t q[W];
 #pragma unroll
@@ -1132,11 +1136,15 @@ __device__ int tri_row(const DevTriJob &T, int idx1) {
     for (int b = 0; b < S.n2; ++b) {
         const int idx2 = J.idx2 ? J.idx2[S.s2 + b] : S.s2 + b;
         if (J.valid2 && J.valid2[idx2]) continue;
+        const bool stereo2 = T.u_right2 && T.u_right2[idx2] >= 0.0f;  // :727
+        if (T.only_stereo && !stereo2) continue;                      // :729-731
         const int d = hamming_words<W>(q, J.d2 + (size_t)idx2 * W);
         if ((float)d > J.th || d > best) continue;
         const float x2 = T.x2[idx2], y2 = T.y2[idx2], sg2 = T.sigma2_2[idx2];
-        const float dex = T.ex - x2, dey = T.ey - y2;
-        if (dex * dex + dey * dey < 100.0f * sqrtf(sg2)) continue;  // too close to the epipole (:741-748)
+        if (!stereo1 && !stereo2) {
+            const float dex = T.ex - x2, dey = T.ey - y2;
+            if (dex * dex + dey * dey < 100.0f * sqrtf(sg2)) continue;  // too close to the epipole (:741-748)
+        }
         const float num = la * x2 + lb * y2 + lc;
         const float dsqr = num * num / den;
         if (!(dsqr < 3.84f * sg2)) continue;  // CheckDistEpipolarLine (:172-181)

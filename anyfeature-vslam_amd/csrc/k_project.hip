@@ -55,6 +55,8 @@ struct DevProjJob {
     int *orilist;              // [nq][2] accepted (slot, rotation bin) pairs
     int *assign;               // [n] (projection) or [nq] (fuse, initialization)
     int *nmatches;
+    const float *u_right, *q_ur, *q_er;  // stereo: mvuRight of the features, projected right coordinate / gate of the queries (NULL: mono)
+    int stereo_gate;                     // the projection searches skip features with u_right > 0 and |q_ur - u_right| > q_er (:114-119, :1367-1372)
 };
 
 __device__ __forceinline__ int key_dist(unsigned long long k) { return (int)(k >> 48); }
@@ -112,6 +114,8 @@ __device__ __forceinline__ Window proj_window(const DevProjJob &J, float x, floa
 #define PROJ_WAVE_WINDOW(J, q, lane, VISIT)                                                           \
     {                                                                                                 \
         const float x_ = J.qu[q], y_ = J.qv[q], r_ = J.qr[q], mn_ = J.qmin[q], mx_ = J.qmax[q];       \
+        const bool sg_ = J.stereo_gate != 0;                                                          \
+        const float qur_ = sg_ ? J.q_ur[q] : 0.0f, qer_ = sg_ ? J.q_er[q] : 0.0f;                      \
         const Window w_ = proj_window(J, x_, y_, r_);                                                 \
         if (w_.ok) {                                                                                  \
             const int ny_ = w_.cy1 - w_.cy0 + 1, ncells_ = (w_.cx1 - w_.cx0 + 1) * ny_;               \
@@ -123,6 +127,10 @@ __device__ __forceinline__ Window proj_window(const DevProjJob &J, float x, floa
                     const float s_ = J.size[idx];                                                     \
                     if (s_ < mn_ || s_ > mx_) continue;                                               \
                     if (!(fabsf(J.x[idx] - x_) < r_ && fabsf(J.y[idx] - y_) < r_)) continue;          \
+                    if (sg_) {                                                                        \
+                        const float ur_ = J.u_right[idx];                                             \
+                        if (ur_ > 0.0f && fabsf(qur_ - ur_) > qer_) continue;                          \
+                    }                                                                                 \
                     const int kpos = k_ - kb_;                                                        \
                     VISIT                                                                             \
                 }                                                                                     \
@@ -438,12 +446,20 @@ __device__ void fuse_query(const DevProjJob &J, int q, int lane) {
 #pragma unroll
         for (int i = 0; i < W; ++i) qd[i] = J.qdesc[(size_t)q * W + i];
         const float u = J.qu[q], v = J.qv[q];
+        const float qur = J.u_right ? J.q_ur[q] : 0.0f;
         PROJ_WAVE_WINDOW(J, q, lane, {
-            if (J.inf) {  // reprojection gate of Fuse (:897-898); absent in Fuse(Sim3) / SearchBySim3
+            if (J.inf) {  // reprojection gate of Fuse (:876-900); absent in Fuse(Sim3) / SearchBySim3
                 const float ex = u - J.x[idx];
                 const float ey = v - J.y[idx];
-                const float e2 = ex * ex + ey * ey;
-                if ((double)(e2 * J.inf[idx]) > 5.99) continue;
+                const float kpr = J.u_right ? J.u_right[idx] : -1.0f;
+                if (kpr >= 0.0f) {  // stereo keypoint: three degrees of freedom (:880-894)
+                    const float er = qur - kpr;
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if ((double)(e2 * J.inf[idx]) > 7.8) continue;
+                } else {
+                    const float e2 = ex * ex + ey * ey;
+                    if ((double)(e2 * J.inf[idx]) > 5.99) continue;
+                }
             }
             const unsigned long long key = make_key(proj_hamming<W>(qd, J.fdesc + (size_t)idx * W), c, kpos, idx);
             k0 = key < k0 ? key : k0;

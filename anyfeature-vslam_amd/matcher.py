@@ -28,9 +28,10 @@ class FeatureView:
     valid        N uint8: map point exists and !isBad()  (for SearchForTriangulation: "has a map point")
     angles       N float32 degrees (mvKeysUn[i].angle)
     pts          N x 2 float32 (mvKeysUn[i].pt), sigma2 N float32 (GetKeyPt1DSigma2) — triangulation only
+    u_right      None (monocular keyframe) or N float32 (KeyFrame::mvuRight, < 0: no right-image match) — triangulation only
     """
 
-    def __init__(self, descriptors, featvec=None, valid=None, angles=None, pts=None, sigma2=None):
+    def __init__(self, descriptors, featvec=None, valid=None, angles=None, pts=None, sigma2=None, u_right=None):
         self.descriptors = np.ascontiguousarray(descriptors, np.uint8)
         if self.descriptors.ndim != 2:
             self.descriptors = self.descriptors.reshape(0, 32)
@@ -40,6 +41,7 @@ class FeatureView:
         self.angles = None if angles is None else np.ascontiguousarray(angles, np.float32)
         self.pts = None if pts is None else np.ascontiguousarray(pts, np.float32)
         self.sigma2 = None if sigma2 is None else np.ascontiguousarray(sigma2, np.float32)
+        self.u_right = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
         self._csr = None
 
     def csr(self):
@@ -63,7 +65,7 @@ class FrameGridView:
     (Frame.cc:100-101: mnMinX, mnMinY, mfGridElementWidthInv/HeightInv; Frame.h:40-41: 64 x 48 cells)."""
 
     def __init__(self, descriptors, pts, sizes, angles=None, occupied=None, min_x=0.0, min_y=0.0, max_x=640.0, max_y=480.0,
-                 grid_cols=64, grid_rows=48, size_tolerance=1.2, inf=None):
+                 grid_cols=64, grid_rows=48, size_tolerance=1.2, inf=None, u_right=None):
         self.descriptors = np.ascontiguousarray(descriptors, np.uint8)
         self.N = self.descriptors.shape[0]
         pts = np.asarray(pts, np.float32).reshape(-1, 2)
@@ -72,6 +74,7 @@ class FrameGridView:
         self.angles = None if angles is None else np.ascontiguousarray(angles, np.float32)
         self.occupied = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
         self.inf = None if inf is None else np.ascontiguousarray(inf, np.float32)  # GetKeyPt1DInf (Fuse)
+        self.u_right = None if u_right is None else np.ascontiguousarray(u_right, np.float32)  # mvuRight (stereo frames; None: mono)
         self.min_x, self.min_y = np.float32(min_x), np.float32(min_y)
         self.grid_inv_w = np.float32(grid_cols) / (np.float32(max_x) - np.float32(min_x))
         self.grid_inv_h = np.float32(grid_rows) / (np.float32(max_y) - np.float32(min_y))
@@ -84,7 +87,7 @@ class ProjectionQueries:
     """Projected map points / last-frame keypoints in the reference's iteration order: descriptor, projected (u, v),
     window radius r, admissible keyPtsSize band, validity, angle (last-frame mode), occupies (observations > 0)."""
 
-    def __init__(self, descriptors, u, v, r, min_size, max_size, valid=None, angles=None, occupies=None):
+    def __init__(self, descriptors, u, v, r, min_size, max_size, valid=None, angles=None, occupies=None, ur=None, er_max=None):
         self.descriptors = np.ascontiguousarray(descriptors, np.uint8)
         self.n = self.descriptors.shape[0]
         f = lambda a: np.ascontiguousarray(a, np.float32)
@@ -92,6 +95,10 @@ class ProjectionQueries:
         self.valid = None if valid is None else np.ascontiguousarray(valid, np.uint8)
         self.angles = None if angles is None else f(angles)
         self.occupies = None if occupies is None else np.ascontiguousarray(occupies, np.uint8)
+        # stereo frames: the projected right-image coordinate (mTrackProjXR / u - mbf * invzc / Fuse's ur) and, for the projection
+        # searches, the gate on |ur - mvuRight| (r * trackSigma, FeatureMatcher.cc:117; the window radius, :1371)
+        self.ur = None if ur is None else f(ur)
+        self.er_max = None if er_max is None else f(er_max)
 
 
 class FeatureMatcher:
@@ -167,9 +174,10 @@ class FeatureMatcher:
         mode = _lib.MATCH_KF_FRAME if frame else _lib.MATCH_KF_KF
         return self._run_bow(list(pairs), mode)
 
-    def SearchForTriangulation(self, pKF1, pKF2, F12, epipole):
-        """FeatureMatcher.cc:662-790 (mono) -> (vMatchedPairs [(idx1, idx2)...] ascending idx1, nMatches).
-        pKF*.valid = has-map-point masks; epipole = projection of camera 1's centre in image 2 (:669-675)."""
+    def SearchForTriangulation(self, pKF1, pKF2, F12, epipole, bOnlyStereo=False):
+        """FeatureMatcher.cc:662-790 -> (vMatchedPairs [(idx1, idx2)...] ascending idx1, nMatches).
+        pKF*.valid = has-map-point masks; epipole = projection of camera 1's centre in image 2 (:669-675); pKF*.u_right =
+        mvuRight of stereo keyframes (:705, :727)."""
         keep = []
         t = TriJob()
         t.bow = self._job(pKF1, pKF2, _lib.MATCH_KF_KF, keep)
@@ -180,6 +188,7 @@ class FeatureMatcher:
         for i in range(9):
             t.F12[i] = float(F[i])
         t.ex, t.ey = float(epipole[0]), float(epipole[1])
+        t.u_right1 = ptr(pKF1.u_right); t.u_right2 = ptr(pKF2.u_right); t.only_stereo = int(bool(bOnlyStereo))
         out = np.full(max(pKF1.N, 1), -1, np.int32)
         nm = np.zeros(1, np.int32)
         jobs = (TriJob * 1)(t)
@@ -201,10 +210,11 @@ class FeatureMatcher:
         j.qangle = ptr(queries.angles); j.qoccupies = ptr(queries.occupies)
         j.nnratio = self.mfNNratio
         j.size_tol = float(F.sizeTolerance); j.inv_size_tol = float(F.invSizeTolerance)
+        j.u_right = ptr(getattr(F, "u_right", None)); j.q_ur = ptr(queries.ur); j.q_er_max = ptr(queries.er_max)
         return j
 
     def Fuse(self, pKF, queries):
-        """matching core of Fuse(pKF, vpMapPoints, th) (FeatureMatcher.cc:794-940, mono): returns (bestIdx per map point
+        """matching core of Fuse(pKF, vpMapPoints, th) (FeatureMatcher.cc:794-940; stereo keyframes: pKF.u_right + queries.ur): returns (bestIdx per map point
         | -1, nFused candidates); the Replace / AddObservation surgery (:918-936) stays with the caller."""
         j = self._proj_job(pKF, queries)
         j.th_high = self.TH_LOW
@@ -214,8 +224,10 @@ class FeatureMatcher:
         self.ctx.check(self.lib.afv_match_fuse(self.ctx.handle, jobs, 1, ptr(out), ptr(nm)), "afv_match_fuse")
         return out[:queries.n].copy(), int(nm[0])
 
-    def _run_projection(self, F, queries, th, mode, check_orientation):
+    def _run_projection(self, F, queries, th, mode, check_orientation, stereo=True):
         j = self._proj_job(F, queries)
+        if not stereo:  # the relocalisation / Sim3 flavours have no mvuRight branch (FeatureMatcher.cc:287-397, :1404-1506)
+            j.u_right = None
         j.th_high = float(th)
         j.check_orientation = int(bool(check_orientation)); j.mode = mode
         out = np.full(max(F.N, 1), -1, np.int32)
@@ -226,7 +238,8 @@ class FeatureMatcher:
 
     def SearchByProjection(self, F, queries, last_frame=False):
         """matching core of SearchByProjection(F, vpMapPoints, radiusTh) (FeatureMatcher.cc:73-154) or, with
-        last_frame=True, of SearchByProjection(CurrentFrame, LastFrame, ...) (:1291-1402, mono).  Returns
+        last_frame=True, of SearchByProjection(CurrentFrame, LastFrame, ...) (:1291-1402).  Stereo frames: F.u_right + queries.ur /
+        queries.er_max (:114-119, :1367-1372).  Returns
         (assign[F.N] = query index now stored in F.pts[i] | -1, nmatches)."""
         return self._run_projection(F, queries, self.TH_HIGH, _lib.PROJ_LASTFRAME if last_frame else _lib.PROJ_LOCALMAP,
                                     self.mbCheckOrientation)
@@ -236,19 +249,20 @@ class FeatureMatcher:
         queries = pKF's map points in keyframe feature order (valid = good, not in sAlreadyFound, projects inside the image
         and the distance band; angles = pKF->mvKeysUn[i].angle); CurrentFrame.occupied = pts[i] != NULL."""
         th = self.descDistTh_high_reloc if useHighMatchingThreshold else self.descDistTh_low_reloc
-        return self._run_projection(CurrentFrame, queries, th, _lib.PROJ_LASTFRAME, self.mbCheckOrientation)
+        return self._run_projection(CurrentFrame, queries, th, _lib.PROJ_LASTFRAME, self.mbCheckOrientation, stereo=False)
 
     def SearchByProjection_sim3(self, pKF, queries):
         """matching core of SearchByProjection(pKF, Scw, vpPoints, vpMatched, radiusTh) (FeatureMatcher.cc:287-397):
         pKF.occupied = vpMatched[i] != NULL; size band = predictedSize / , * sizeTolerance (:365-367); no orientation check;
         accept bestDist <= TH_LOW (:380).  assign[i] = index into vpPoints now stored in vpMatched[i]."""
-        return self._run_projection(pKF, queries, self.TH_LOW, _lib.PROJ_LASTFRAME, False)
+        return self._run_projection(pKF, queries, self.TH_LOW, _lib.PROJ_LASTFRAME, False, stereo=False)
 
     def Fuse_sim3(self, pKF, queries):
         """matching core of Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (FeatureMatcher.cc:942-1064): as Fuse without the
         reprojection gate."""
         j = self._proj_job(pKF, queries)
         j.inf = None
+        j.u_right = None
         j.th_high = self.TH_LOW
         out = np.full(max(queries.n, 1), -1, np.int32)
         nm = np.zeros(1, np.int32)

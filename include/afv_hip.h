@@ -136,6 +136,11 @@ typedef struct {
     const float *sigma2_2;           /* KeyFrame::GetKeyPt1DSigma2 of side 2 */
     float F12[9];                    /* row-major fundamental matrix */
     float ex, ey;                    /* epipole of camera 1 in image 2 */
+    /* stereo keyframes (FeatureMatcher.cc:705-709, :727-731, :741): KeyFrame::mvuRight of either side (>= 0: the keypoint has a
+       right-image match); NULL = monocular.  only_stereo = bOnlyStereo: features without a right match are skipped on both sides;
+       the epipole-distance test (:741-748) only applies when NEITHER feature is stereo.  A zero-initialised tail = the mono call. */
+    const float *u_right1, *u_right2;
+    int32_t only_stereo;
 } afv_tri_job;
 int afv_match_triangulation(afv_ctx *ctx, const afv_tri_job *jobs, int njobs, int32_t *match12, int32_t *nmatches);
 
@@ -202,7 +207,7 @@ typedef struct {
 } afv_frame_view;
 int afv_table_match_bow_frame(afv_table *t, const int32_t *slots, int nslots, const afv_frame_view *frame, float th_low, float nnratio,
                               int check_orientation, int32_t *match_f, int32_t *nmatches);
-/* SearchForTriangulation (FeatureMatcher.cc:662-790, mono) of npairs slot pairs over the stored FeatureVectors and the
+/* SearchForTriangulation (FeatureMatcher.cc:662-790, monocular keyframes: the table has no mvuRight plane) of npairs slot pairs over the stored FeatureVectors and the
  * per-keyframe geometry stored with afv_table_set_geometry (mvKeysUn[i].pt and KeyFrame::GetKeyPt1DSigma2(i)): what
  * LocalMapping::CreateNewMapPoints does against <= 20 neighbours (src/LocalMapping.cc:238-297).  Per pair only the
  * fundamental matrix, the epipole and the "already has a map point" masks travel. */
@@ -283,10 +288,18 @@ typedef struct {
     const uint8_t *qoccupies;                           /* pMP->NumberOfObservations() > 0 (NULL = yes) */
     float th_high, nnratio, size_tol, inv_size_tol;     /* TH_HIGH, mfNNratio, F.sizeTolerance, F.invSizeTolerance */
     int32_t check_orientation, mode;
+    /* stereo frames / keyframes (NULL u_right = monocular; a zero-initialised tail = the mono call):
+       u_right[i] = mvuRight of feature i; q_ur[q] = the query's projected right-image coordinate (pMP->mTrackProjXR :116,
+       u - mbf * invzc :1369, ur of Fuse :885); q_er_max[q] = the gate of afv_match_projection (r * pMP->trackSigma :117 in
+       AFV_PROJ_LOCALMAP, the window radius :1371 in AFV_PROJ_LASTFRAME).
+       afv_match_projection skips a feature with u_right > 0 whose |q_ur - u_right| exceeds q_er_max (:114-119, :1367-1372);
+       afv_match_fuse replaces the 2-dof gate e2 * inf <= 5.99 by the 3-dof one (ex^2 + ey^2 + er^2) * inf <= 7.8 for features with
+       u_right >= 0 (:880-894).  afv_match_sim3 / afv_match_initialization have no stereo branch and ignore the three fields. */
+    const float *u_right; const float *q_ur; const float *q_er_max;
 } afv_proj_job;
 /* assign = concatenation over jobs of int32[n]: index of the query assigned to feature i (F.pts[i] = pMP) or -1 */
 int afv_match_projection(afv_ctx *ctx, const afv_proj_job *jobs, int njobs, int32_t *assign, int32_t *nmatches);
-/* matching core of FeatureMatcher::Fuse(pKF, vpMapPoints, th) (src/FeatureMatcher.cc:794-940, mono) over
+/* matching core of FeatureMatcher::Fuse(pKF, vpMapPoints, th) (src/FeatureMatcher.cc:794-940) over
  * KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:613-652): per map point the most similar keypoint of the window that lies in
  * the size band [qmin_size, qmax_size] (= predictedSize / sizeTolerance .. * sizeTolerance, :871-873) and passes the
  * reprojection gate e2 * inf <= 5.99 (:897); th_high carries TH_LOW (:915).  Map points are independent here; the map surgery

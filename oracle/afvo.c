@@ -1080,7 +1080,7 @@ static int check_dist_epipolar(float x1, float y1, float x2, float y2, const flo
     return dsqr < 3.84f * sigma2_kp2;
 }
 
-/* FeatureMatcher.cc:695-764, mono branch (bStereo1 == bStereo2 == false, bOnlyStereo == false) */
+/* FeatureMatcher.cc:695-764 */
 static void m4_node(void *vctx, const int32_t *s1, int n1, const int32_t *s2, int n2) {
     m4_ctx *c = (m4_ctx *)vctx;
     const afvo_tri_job *t = c->t;
@@ -1088,15 +1088,21 @@ static void m4_node(void *vctx, const int32_t *s1, int n1, const int32_t *s2, in
     for (int a = 0; a < n1; ++a) {
         const int idx1 = s1[a];
         if (j->valid1 && j->valid1[idx1]) continue; /* already has a MapPoint */
+        const int stereo1 = t->u_right1 && t->u_right1[idx1] >= 0.0f; /* :705 */
+        if (t->only_stereo && !stereo1) continue;                      /* :707-709 */
         float best_dist = j->th_low;
         int best_idx2 = -1;
         for (int b = 0; b < n2; ++b) {
             const int idx2 = s2[b];
             if (j->valid2 && j->valid2[idx2]) continue;
+            const int stereo2 = t->u_right2 && t->u_right2[idx2] >= 0.0f; /* :727 */
+            if (t->only_stereo && !stereo2) continue;                      /* :729-731 */
             const float d = bow_dist(j, idx1, idx2);
             if (d > j->th_low || d > best_dist) continue;
-            const float distex = t->ex - t->x2[idx2], distey = t->ey - t->y2[idx2];
-            if (distex * distex + distey * distey < 100.0f * sqrtf(t->sigma2_2[idx2])) continue;
+            if (!stereo1 && !stereo2) { /* :741-748 */
+                const float distex = t->ex - t->x2[idx2], distey = t->ey - t->y2[idx2];
+                if (distex * distex + distey * distey < 100.0f * sqrtf(t->sigma2_2[idx2])) continue;
+            }
             if (check_dist_epipolar(t->x1[idx1], t->y1[idx1], t->x2[idx2], t->y2[idx2], t->F12, t->sigma2_2[idx2])) {
                 best_idx2 = idx2;
                 best_dist = d;
@@ -1201,6 +1207,10 @@ int afvo_match_projection(const afvo_proj_job *j, int32_t *assign) {
                     if (!(fabsf(dx) < r && fabsf(dy) < r)) continue;
                     /* matching loop (FeatureMatcher.cc:108-139 / :1362-1386) */
                     if (occ[idx]) continue;
+                    if (j->u_right && j->u_right[idx] > 0.0f) { /* :114-119 / :1367-1372 */
+                        const float er = fabsf(j->q_ur[q] - j->u_right[idx]);
+                        if (er > j->q_er_max[q]) continue;
+                    }
                     const u8 *a = j->qdesc + (size_t)q * j->desc_bytes, *b = j->desc + (size_t)idx * j->desc_bytes;
                     const float d = (float)(j->desc_bytes == 32 ? afvo_hamming256(a, b) : afvo_hamming_bytes(a, b, j->desc_bytes));
                     if (d < best) {
@@ -1271,8 +1281,14 @@ int afvo_match_fuse(const afvo_proj_job *j, int32_t *best_out) {
                     const float sz = j->size[idx];
                     if ((sz < min_size) || (sz > max_size)) continue;             /* :871-873 */
                     const float ex = u - j->x[idx], ey = v - j->y[idx];
-                    const float e2 = ex * ex + ey * ey;
-                    if (j->inf && e2 * j->inf[idx] > 5.99) continue;              /* :897-898 (float product vs double); no gate in Fuse(Sim3) / SearchBySim3 */
+                    if (j->inf && j->u_right && j->u_right[idx] >= 0.0f) {        /* :880-894: reprojection error in stereo */
+                        const float er = j->q_ur[q] - j->u_right[idx];
+                        const float e2 = ex * ex + ey * ey + er * er;
+                        if (e2 * j->inf[idx] > 7.8) continue;
+                    } else {
+                        const float e2 = ex * ex + ey * ey;
+                        if (j->inf && e2 * j->inf[idx] > 5.99) continue;          /* :897-898 (float product vs double); no gate in Fuse(Sim3) / SearchBySim3 */
+                    }
                     const u8 *a = j->qdesc + (size_t)q * j->desc_bytes, *b = j->desc + (size_t)idx * j->desc_bytes;
                     const float d = (float)(j->desc_bytes == 32 ? afvo_hamming256(a, b) : afvo_hamming_bytes(a, b, j->desc_bytes));
                     if (d < best) { best = d; best_idx = idx; }

@@ -134,8 +134,12 @@ typedef struct {
     const float *sigma2_2;          /* GetKeyPt1DSigma2 of KF2 */
     float F12[9];                   /* row-major */
     float ex, ey;                   /* epipole in image 2 */
+    /* stereo (FeatureMatcher.cc:705-709, :727-731, :741): mvuRight of either keyframe (>= 0: the keypoint has a right match); NULL =
+       monocular keyframe.  only_stereo = bOnlyStereo. */
+    const float *u_right1, *u_right2;
+    int32_t only_stereo;
 } afvo_tri_job;
-/* M4: SearchForTriangulation FeatureMatcher.cc:662-790 (mono branch). match12[n1] */
+/* M4: SearchForTriangulation FeatureMatcher.cc:662-790. match12[n1] */
 int afvo_search_for_triangulation(const afvo_tri_job *j, int32_t *match12);
 
 /* float-descriptor brute force / BoW (M8 distance inside M2 control flow) */
@@ -148,7 +152,7 @@ int afvo_match_l2_bruteforce(const afvo_l2_job *j, int32_t *match12);
 
 /* ---- projection-guided matching core (grid window + Hamming) ----
  * Flat restatement of the matching loops of SearchByProjection(F, localMapPoints) (FeatureMatcher.cc:73-154, mode 0) and
- * SearchByProjection(CurrentFrame, LastFrame) (:1291-1402, mode 1, mono) over Frame::GetFeaturesInArea (Frame.cc:333-382)
+ * SearchByProjection(CurrentFrame, LastFrame) (:1291-1402, mode 1) over Frame::GetFeaturesInArea (Frame.cc:333-382)
  * and the 64x48 grid of Frame::AssignFeaturesToGrid / PosInGrid (Frame.cc:225-240, :383-394).  The projection itself
  * (pose * point, radius from viewing angle / keypoint size) is evaluated by the caller exactly as the reference does and
  * arrives as (u, v, r, min_size, max_size) per query. */
@@ -165,9 +169,14 @@ typedef struct {
     const uint8_t *qoccupies;                             /* assigned point has observations (> 0); NULL = yes */
     float th_high, nnratio, size_tol, inv_size_tol;
     int32_t check_orientation, mode;                      /* mode 0 = local map, 1 = last frame */
+    /* stereo (NULL u_right = monocular): u_right[i] = mvuRight of feature i; q_ur[q] = the query's projected right coordinate
+       (pMP->mTrackProjXR :116, u - mbf * invzc :1369, ur of Fuse :885); q_er_max[q] = the gate of modes 0 / 1 (r * pMP->trackSigma
+       :117, radius :1371).  Modes 0 / 1 skip a feature with u_right > 0 whose |q_ur - u_right| exceeds the gate; Fuse replaces the
+       2-dof gate (5.99) by the 3-dof one (7.8) for features with u_right >= 0 (:880-894). */
+    const float *u_right; const float *q_ur; const float *q_er_max;
 } afvo_proj_job;
 int afvo_match_projection(const afvo_proj_job *j, int32_t *assign /* [n]: query index or -1 */);
-/* matching core of FeatureMatcher::Fuse(pKF, vpMapPoints, th) (FeatureMatcher.cc:794-940, mono): per map point the most
+/* matching core of FeatureMatcher::Fuse(pKF, vpMapPoints, th) (FeatureMatcher.cc:794-940): per map point the most
  * similar keypoint in the window that lies in the predicted size band and passes the 5.99 reprojection gate; best[q] = feature
  * index or -1 (bestDist > TH_LOW).  Independent per point: the map surgery (:918-936) stays with the caller.  returns #found */
 int afvo_match_fuse(const afvo_proj_job *j, int32_t *best /* [nq] */);   /* inf == NULL: no gate = Fuse(Sim3) core (:942-1064) */

@@ -48,7 +48,8 @@ class BowJob(C.Structure):
 
 class TriJob(C.Structure):
     _fields_ = [("bow", BowJob), ("x1", C.c_void_p), ("y1", C.c_void_p), ("x2", C.c_void_p), ("y2", C.c_void_p),
-                ("sigma2_2", C.c_void_p), ("F12", C.c_float * 9), ("ex", C.c_float), ("ey", C.c_float)]
+                ("sigma2_2", C.c_void_p), ("F12", C.c_float * 9), ("ex", C.c_float), ("ey", C.c_float),
+                ("u_right1", C.c_void_p), ("u_right2", C.c_void_p), ("only_stereo", C.c_int32)]
 
 
 class ProjJob(C.Structure):
@@ -59,7 +60,8 @@ class ProjJob(C.Structure):
                 ("qdesc", C.c_void_p), ("qvalid", C.c_void_p), ("qu", C.c_void_p), ("qv", C.c_void_p), ("qr", C.c_void_p),
                 ("qmin_size", C.c_void_p), ("qmax_size", C.c_void_p), ("qangle", C.c_void_p), ("qoccupies", C.c_void_p),
                 ("th_high", C.c_float), ("nnratio", C.c_float), ("size_tol", C.c_float), ("inv_size_tol", C.c_float),
-                ("check_orientation", C.c_int32), ("mode", C.c_int32)]
+                ("check_orientation", C.c_int32), ("mode", C.c_int32),
+                ("u_right", C.c_void_p), ("q_ur", C.c_void_p), ("q_er_max", C.c_void_p)]
 
 
 class L2Job(C.Structure):
@@ -369,7 +371,7 @@ def search_by_bow_kf_frame(desc_kf, desc_f, nodes_kf=None, nodes_f=None, valid_k
 
 
 def search_for_triangulation(desc1, desc2, pts1, pts2, sigma2_2, F12, epipole, nodes1=None, nodes2=None,
-                             has_mp1=None, has_mp2=None, th_low=75.0):
+                             has_mp1=None, has_mp2=None, th_low=75.0, u_right1=None, u_right2=None, only_stereo=False):
     keep = []
     t = TriJob()
     t.bow = _bow_job(desc1, desc2, nodes1, nodes2, has_mp1, has_mp2, None, None, th_low, 0.6, False, keep)
@@ -382,6 +384,9 @@ def search_for_triangulation(desc1, desc2, pts1, pts2, sigma2_2, F12, epipole, n
     for i in range(9):
         t.F12[i] = float(F[i])
     t.ex, t.ey = float(epipole[0]), float(epipole[1])
+    ur1 = None if u_right1 is None else np.ascontiguousarray(u_right1, np.float32)
+    ur2 = None if u_right2 is None else np.ascontiguousarray(u_right2, np.float32)
+    t.u_right1 = _p(ur1); t.u_right2 = _p(ur2); t.only_stereo = int(bool(only_stereo))
     out = np.zeros(max(t.bow.n1, 1), np.int32)
     nm = lib().afvo_search_for_triangulation(C.byref(t), _p(out))
     return out[:t.bow.n1].copy(), nm
@@ -422,6 +427,7 @@ def _proj_job(F, Q, th_high, nnratio, check_orientation, last_frame):
     j.qangle = _p(Q.angles); j.qoccupies = _p(Q.occupies)
     j.th_high = th_high; j.nnratio = nnratio; j.size_tol = float(F.sizeTolerance); j.inv_size_tol = float(F.invSizeTolerance)
     j.check_orientation = int(bool(check_orientation)); j.mode = 1 if last_frame else 0
+    j.u_right = _p(getattr(F, 'u_right', None)); j.q_ur = _p(getattr(Q, 'ur', None)); j.q_er_max = _p(getattr(Q, 'er_max', None))
     return j
 
 

@@ -159,6 +159,27 @@ def test_triangulation(afv, oracle, matcher):
         for a, b in pairs:
             got[a] = b
         assert n == wn and np.array_equal(got, want)
+    # stereo keyframes (FeatureMatcher.cc:705-709, :727-731, :741): mvuRight on either side, bOnlyStereo; an epipole INSIDE image 2 so
+    # that the epipole-distance test (mono-mono candidates only) bites
+    afv.FeatureMatcher.TH_LOW = 120.0
+    ur1 = np.where(s.lcg_bytes(48, n1) > 100, p1[:, 0] - np.float32(12.5), np.float32(-1.0)).astype(np.float32)
+    ur2 = np.where(s.lcg_bytes(49, n2) > 140, p2[:, 0] - np.float32(9.0), np.float32(-1.0)).astype(np.float32)
+    ep2 = (320.0, 240.0)
+    sigma2b = (sigma2 * np.float32(25.0)).astype(np.float32)  # 100 * sqrt(sigma2) reaches a few hundred px^2 .. a good part of the image
+    outcomes = []
+    for (a1, a2, only) in ((ur1, ur2, False), (ur1, ur2, True), (ur1, None, False), (None, ur2, True), (None, None, False)):
+        k1 = afv.FeatureView(d1, fv1, has1, pts=p1, u_right=a1)
+        k2 = afv.FeatureView(d2, fv2, has2, pts=p2, sigma2=sigma2b, u_right=a2)
+        pairs, n = matcher.SearchForTriangulation(k1, k2, F, ep2, bOnlyStereo=only)
+        want, wn = oracle.search_for_triangulation(d1, d2, p1, p2, sigma2b, F, ep2, fv1, fv2, has1, has2, 120.0, u_right1=a1, u_right2=a2,
+                                                   only_stereo=only)
+        got = np.full(n1, -1, np.int32)
+        for a, b in pairs:
+            got[a] = b
+        assert n == wn and np.array_equal(got, want), (a1 is None, a2 is None, only)
+        outcomes.append(want)
+    assert not np.array_equal(outcomes[0], outcomes[4]) and not np.array_equal(outcomes[0], outcomes[1])  # the branches changed something
+    assert (outcomes[3] >= 0).sum() == 0  # bOnlyStereo with a monocular first keyframe: nothing can match
     afv.FeatureMatcher.TH_LOW = 75.0
     assert wn > 10
 

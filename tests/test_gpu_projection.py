@@ -109,6 +109,68 @@ def test_fuse_core(afv, oracle, gpu_ctx, seed, shift, rs):
     assert 50 < wn < Q.n  # the gate and the threshold both bite
 
 
+# ---- stereo frames (FeatureMatcher.cc:114-119, :1367-1372, :880-894): mvuRight on the feature side, the projected right coordinate on
+#      the query side ----
+def _stereo(afv, F, Q, seed, gate_scale):
+    """about half of the features get a right-image coordinate (mvuRight > 0, the others -1); a query's projected right coordinate is
+    u minus a disparity, jittered so that the gate removes some candidates and keeps others"""
+    s = afv.synth
+    disp_f = (s.lcg_states(seed + 21, F.N) % 4000).astype(np.float32) / np.float32(100.0)
+    has = s.lcg_bytes(seed + 22, F.N) > 110
+    F.u_right = np.where(has, F.x - disp_f, np.float32(-1.0)).astype(np.float32)
+    disp_q = (s.lcg_states(seed + 23, Q.n) % 4000).astype(np.float32) / np.float32(100.0)
+    Q.ur = (Q.u - disp_q).astype(np.float32)
+    Q.er_max = (np.float32(gate_scale) * Q.r).astype(np.float32)
+    return F, Q
+
+
+@pytest.mark.parametrize("last_frame", [False, True])
+@pytest.mark.parametrize("seed,shift,rs,gate", [(31, 4, 15.0, 0.5), (32, 2, 60.0, 0.2), (33, 5, 25.0, 1.0)])
+def test_projection_with_stereo_gate(afv, oracle, gpu_ctx, seed, shift, rs, gate, last_frame):
+    F, Q = _stereo(afv, *_scene(afv, gpu_ctx, seed, shift, rs), seed, gate)
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+    m = afv.FeatureMatcher(0.85, True, ctx=gpu_ctx)
+    got, n = m.SearchByProjection(F, Q, last_frame=last_frame)
+    want, wn = oracle.match_projection(F, Q, th_high=75.0, nnratio=0.85, check_orientation=last_frame, last_frame=last_frame)
+    assert n == wn and np.array_equal(got, want)
+    ur = F.u_right
+    F.u_right = None  # the gate must have changed the outcome, or the test shows nothing
+    mono, _ = oracle.match_projection(F, Q, th_high=75.0, nnratio=0.85, check_orientation=last_frame, last_frame=last_frame)
+    F.u_right = ur
+    assert wn > 50 and not np.array_equal(mono, want)
+    # the relocalisation / Sim3 flavours run through the same entry point but have no mvuRight branch: the wrapper drops it
+    got2, n2 = m.SearchByProjection_sim3(F, Q)
+    F.u_right = None
+    want2, wn2 = oracle.match_projection(F, Q, th_high=75.0, nnratio=0.85, check_orientation=False, last_frame=True)
+    assert n2 == wn2 and np.array_equal(got2, want2)
+
+
+@pytest.mark.parametrize("seed,shift,rs", [(41, 4, 15.0), (42, 1, 50.0)])
+def test_fuse_core_with_stereo_keypoints(afv, oracle, gpu_ctx, seed, shift, rs):
+    """Fuse(pKF, vpMapPoints) on a stereo keyframe: keypoints with mvuRight >= 0 pass the 3-dof gate (7.8), the others the 2-dof one"""
+    F, Q = _stereo(afv, *_scene(afv, gpu_ctx, seed, shift, rs), seed, 1.0)
+    F.inf = np.ascontiguousarray(np.float32(0.2) / (F.sizes * F.sizes))
+    # right coordinates consistent with the projection up to a few pixels, so that the 3-dof gate sometimes holds and sometimes not
+    Q.ur = (Q.u - np.float32(20.0) + (afv.synth.lcg_states(seed + 24, Q.n) % 9).astype(np.float32) - 4).astype(np.float32)
+    F.u_right = np.where(F.u_right >= 0, F.x - np.float32(20.0), np.float32(-1.0)).astype(np.float32)
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+    m = afv.FeatureMatcher(0.6, True, ctx=gpu_ctx)
+    got, n = m.Fuse(F, Q)
+    want, wn = oracle.match_projection(F, Q, th_high=75.0, fuse=True)
+    assert n == wn and np.array_equal(got, want)
+    ur = F.u_right
+    F.u_right = None
+    mono, _ = oracle.match_projection(F, Q, th_high=75.0, fuse=True)
+    F.u_right = ur
+    assert 50 < wn < Q.n and not np.array_equal(mono, want)
+    got3, n3 = m.Fuse_sim3(F, Q)  # no gate at all, stereo or not
+    inf = F.inf
+    F.inf = None
+    want3, wn3 = oracle.match_projection(F, Q, th_high=75.0, fuse=True)
+    F.inf = inf
+    assert n3 == wn3 and np.array_equal(got3, want3)
+
+
 # ---- the remaining rank-1 searches: relocalisation / Sim3 projection, Fuse(Sim3), SearchBySim3, SearchForInitialization ----
 @pytest.mark.parametrize("use_high", [False, True])
 def test_relocalisation_and_sim3_projection(afv, oracle, gpu_ctx, use_high):
