@@ -207,8 +207,8 @@ typedef struct {
 } afv_frame_view;
 int afv_table_match_bow_frame(afv_table *t, const int32_t *slots, int nslots, const afv_frame_view *frame, float th_low, float nnratio,
                               int check_orientation, int32_t *match_f, int32_t *nmatches);
-/* SearchForTriangulation (FeatureMatcher.cc:662-790, monocular keyframes: the table has no mvuRight plane) of npairs slot pairs over the stored FeatureVectors and the
- * per-keyframe geometry stored with afv_table_set_geometry (mvKeysUn[i].pt and KeyFrame::GetKeyPt1DSigma2(i)): what
+/* SearchForTriangulation (FeatureMatcher.cc:662-790; monocular keyframes: the table has no mvuRight plane) of npairs slot pairs
+ * over the stored FeatureVectors and the per-keyframe geometry stored with afv_table_set_geometry (mvKeysUn[i].pt and KeyFrame::GetKeyPt1DSigma2(i)): what
  * LocalMapping::CreateNewMapPoints does against <= 20 neighbours (src/LocalMapping.cc:238-297).  Per pair only the
  * fundamental matrix, the epipole and the "already has a map point" masks travel. */
 int afv_table_set_geometry(afv_table *t, int set, const float *x, const float *y, const float *sigma2);
