@@ -26,7 +26,10 @@ for M in 1 0; do python tools/single_frame_trace.py $M > /dev/null 2>&1; cp gpur
 ./tools/host_latency 300 > "$OUT/host_latency.json" 2>&1
 AFV_TRACE_HOST=1 ./tools/host_latency 300 2>&1 | grep "afv_orb_extract (us" | tail -2 > "$OUT/host_latency_breakdown.txt"
 python tools/probes/probe_pcie.py > "$OUT/pcie_probe.txt" 2>&1
-for P in probe_cvt_pk_u8 probe_mfma_valu; do
+for P in probe_cvt_pk_u8 probe_mfma_valu probe_stream13 probe_u8_tiles; do
   hipcc --offload-arch=gfx950 -O3 tools/probes/$P.hip -o /tmp/$P 2>/dev/null && /tmp/$P > "$OUT/$P.txt" 2>&1
 done
+./tools/akaze_recip_check > "$OUT/akaze_recip_check.txt" 2>&1
+python tools/overlap_trace.py 2 > "$OUT/overlap_trace.txt" 2>/dev/null
+python tools/probes/probe_resolve_pair.py 2>/dev/null | grep "^pairs" > "$OUT/resolve_pairs.txt"
 ls -la "$OUT"
