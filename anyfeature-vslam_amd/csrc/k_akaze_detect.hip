@@ -67,7 +67,12 @@ __device__ __forceinline__ bool akd_is_candidate(const AkdParams &P, const AkdLe
 // v > max(left, right) of its own row and v > the 3-wide row maxima above and below.  Bit x of word
 // mask[frame][row][x / 64] = pixel (x, row) is a candidate.
 #define AKD_MAXCHUNKS 32  // 64-column chunks per row: levels up to 2048 pixels wide
+#ifndef AKM_ROWS
 #define AKM_ROWS 32
+#endif
+#ifndef AKM_G
+#define AKM_G 8
+#endif
 struct AkmWork {
     int strip_off[17];  // first strip of every level (strips of a level: chunks x row blocks x frames)
 };
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(256) void k_akz_cand_mask(AkdParams P, AkmWork W, i
         c_m = c1;
     }
     const int rows = min(AKM_ROWS, L.h - ty0);
-    constexpr int G = 4;  // rows fetched together: a wavefront keeps G full lines in flight
+    constexpr int G = AKM_G;  // rows fetched together: a wavefront keeps G full lines in flight
     for (int g0 = 0; g0 < rows; g0 += G) {
         float cd[G], ed[G];
 #pragma unroll
