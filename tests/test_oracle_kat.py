@@ -387,6 +387,34 @@ def test_m4_last_minimum_wins_and_epipolar_gate(oracle):
     assert m.tolist() == [-1]
 
 
+def test_m4_stereo_branches(oracle):
+    """FeatureMatcher.cc:705-709, :727-731, :741: bOnlyStereo skips features without a right match on both sides; the epipole-distance
+    test only applies to mono-mono candidates"""
+    d1 = np.stack([_d(0), _d(0)])
+    d2 = np.stack([_d(10), _d(12)])
+    p1 = np.float32([[100, 100], [200, 100]])
+    p2 = np.float32([[50, 100], [60, 100]])                 # both on the line y2 = y1, both close to the epipole (55, 100)
+    F = np.float32([[0, 0, 0], [0, 0, -1], [0, 1, 0]])
+    s2 = np.float32([1, 1])
+    ep = (55.0, 100.0)                                      # 25 px^2 < 100 * sqrt(1): mono-mono candidates are skipped
+    m, n = oracle.search_for_triangulation(d1, d2, p1, p2, s2, F, ep, th_low=75.0)
+    assert m.tolist() == [-1, -1] and n == 0
+    # a right-image coordinate on EITHER side switches the epipole test off for that candidate
+    m, n = oracle.search_for_triangulation(d1, d2, p1, p2, s2, F, ep, th_low=75.0, u_right1=[90.0, -1.0])
+    assert m.tolist() == [0, -1] and n == 1                 # row 0 is stereo: takes the closer descriptor (column 0)
+    m, n = oracle.search_for_triangulation(d1, d2, p1, p2, s2, F, ep, th_low=75.0, u_right2=[-1.0, 40.0])
+    assert m.tolist() == [1, 1] and n == 2                  # only column 1 escapes the epipole test
+    # mvuRight == 0 counts as stereo here (>= 0, :705) ...
+    m, n = oracle.search_for_triangulation(d1, d2, p1, p2, s2, F, ep, th_low=75.0, u_right1=[0.0, -1.0])
+    assert m.tolist() == [0, -1]
+    # bOnlyStereo: mono features are skipped outright, on both sides
+    m, n = oracle.search_for_triangulation(d1, d2, p1, p2, s2, F, (1e6, 0.0), th_low=75.0, u_right1=[90.0, -1.0], u_right2=[-1.0, 40.0],
+                                           only_stereo=True)
+    assert m.tolist() == [1, -1] and n == 1
+    m, n = oracle.search_for_triangulation(d1, d2, p1, p2, s2, F, (1e6, 0.0), th_low=75.0, only_stereo=True)
+    assert m.tolist() == [-1, -1] and n == 0                # monocular keyframes: nothing qualifies
+
+
 def test_l2sqr(oracle):
     a = np.float32([1, 2, 3, 4, 5]); b = np.float32([0, 0, 0, 0, 0])
     assert oracle.l2sqr(a, b) == 55.0
@@ -462,6 +490,45 @@ def test_projection_hand_checked(oracle, afv):
     # last-frame flavour: best only, inclusive threshold
     a4, n4 = oracle.match_projection(F, Q, th_high=1.0, nnratio=0.8, last_frame=True)
     assert a4.tolist() == [0, -1, -1] and n4 == 1
+
+
+def test_projection_stereo_gates_hand_checked(oracle, afv):
+    """FeatureMatcher.cc:114-119 / :1367-1372 (a feature with mvuRight > 0 is skipped when the query's projected right coordinate lies
+    further away than the gate) and :880-894 (Fuse: 3-dof reprojection gate 7.8 for stereo keypoints, 2-dof 5.99 otherwise)"""
+    desc = np.stack([_d(0), _d(8), _d(60)])
+    pts = np.float32([[100, 100], [104, 100], [300, 300]])
+    q = np.stack([_d(1), _d(2)])
+    # feature 0 has a right match at 80, feature 1 is monocular (-1): only feature 0 can be gated out
+    F = afv.FrameGridView(desc, pts, np.float32([1.0, 1.0, 1.0]), u_right=[80.0, -1.0, -1.0])
+    Q = afv.ProjectionQueries(q, [101, 101], [100, 100], [10, 10], [0.8, 0.8], [1.3, 1.3], ur=[81.0, 95.0], er_max=[2.0, 2.0])
+    a, n = oracle.match_projection(F, Q, th_high=75.0, nnratio=0.8)
+    # q0: |81 - 80| = 1 <= 2: as in the mono case it takes feature 0; q1: feature 0 is occupied anyway -> feature 1
+    assert a.tolist() == [0, 1, -1] and n == 2
+    Q.ur = np.float32([90.0, 95.0])  # q0 now 10 px off on the right image: feature 0 is skipped, q0 falls back to feature 1 (7 bits)
+    a, n = oracle.match_projection(F, Q, th_high=75.0, nnratio=0.8)
+    assert a.tolist() == [-1, 0, -1] and n == 1  # ... and q1 (15 px off feature 0, feature 1 taken) finds nothing
+    F.u_right = np.float32([0.0, -1.0, -1.0])    # mvuRight == 0 is NOT stereo for these two searches (> 0, :114 / :1367)
+    a, n = oracle.match_projection(F, Q, th_high=75.0, nnratio=0.8)
+    assert a.tolist() == [0, 1, -1]
+    a, n = oracle.match_projection(F, Q, th_high=75.0, nnratio=0.8, last_frame=True)
+    assert a.tolist() == [0, 1, -1]
+    # Fuse: e2 * inf with inf = 1: mono gate 5.99, stereo gate 7.8 on ex^2 + ey^2 + er^2
+    F = afv.FrameGridView(desc[:1], pts[:1], np.float32([1.0]), inf=[1.0], u_right=[80.0])
+    Qf = afv.ProjectionQueries(q[:1], [102.0], [101.0], [10], [0.8], [1.3], ur=[81.5])
+    b, n = oracle.match_projection(F, Qf, th_high=75.0, fuse=True)
+    assert b.tolist() == [0]                     # 4 + 1 + 2.25 = 7.25 <= 7.8
+    Qf.ur = np.float32([82.0])
+    b, n = oracle.match_projection(F, Qf, th_high=75.0, fuse=True)
+    assert b.tolist() == [-1]                    # 4 + 1 + 4 = 9 > 7.8
+    F.u_right = np.float32([-1.0])
+    b, n = oracle.match_projection(F, Qf, th_high=75.0, fuse=True)
+    assert b.tolist() == [0]                     # mono keypoint: 4 + 1 = 5 <= 5.99
+    Qf.u = np.float32([102.5])
+    b, n = oracle.match_projection(F, Qf, th_high=75.0, fuse=True)
+    assert b.tolist() == [-1]                    # 6.25 + 1 > 5.99
+    F.u_right = np.float32([0.0])                # mvuRight == 0 IS stereo in Fuse (>= 0, :880): er = 82 - 0
+    b, n = oracle.match_projection(F, Qf, th_high=75.0, fuse=True)
+    assert b.tolist() == [-1]
 
 
 def test_bow_transform_hand_tree(afv, oracle):
