@@ -20,7 +20,7 @@ extern "C" void afv_akz_launch_halfsample(const float *src, int w, int h, float 
 extern "C" void afv_akz_launch_flow(const float *lsm, int w, int h, int nframes, const float *kcontrast, int octave, float *flow,
                                     hipStream_t st);
 extern "C" void afv_akz_launch_nld_step(const float *Lt, const float *flow, int w, int h, int nframes, float tau, float *out, hipStream_t st);
-extern "C" int afv_akz_launch_fed_fused(const float *Lt_in, float *lsm, const float *taps, int w, int h, int nframes, const float *kcontrast,
+extern "C" int afv_akz_launch_fed_gauss(const float *Lt_in, float *lsm, const float *taps, int w, int h, int nframes, const float *kcontrast,
                                         int octave, int nsteps, const float *tau, float *Lt_out, hipStream_t st);
 extern "C" int afv_akz_launch_hessian(const float *lsm, int w, int h, int nframes, int s, int two_kernels, float *dx, float *dy,
                                       float *Ldet, hipStream_t st);
@@ -421,13 +421,11 @@ static int akz_enqueue(afv_akaze *a, const uint8_t *d_gray, int nframes, int w, 
         }
         // Lsmooth + conductivity + the whole FED cycle of this level in one kernel (the usual case: 5-tap Gaussian, <= AKZ_FED_MAX steps)
         if (!a->step_by_step && P.ksize_one == 5 &&
-            afv_akz_launch_fed_fused(src, a->lsm[i], a->d_taps + 32, L.w, L.h, nframes, a->d_kcontrast, L.octave, L.nsteps, L.tau, a->lt[i], st))
+            afv_akz_launch_fed_gauss(src, a->lsm[i], a->d_taps + 32, L.w, L.h, nframes, a->d_kcontrast, L.octave, L.nsteps, L.tau, a->lt[i], st))
             continue;
+        // step by step (the test reference, longer FED cycles, degenerate sizes): Gaussian, conductivity, one kernel per FED step
         if (afv_akz_launch_gauss(src, 0, L.w, (size_t)L.w * L.h, L.w, L.h, nframes, a->d_taps + 32, P.ksize_one, a->lsm[i], st))
             return AFV_EUNSUPPORTED;
-        if (!a->step_by_step &&
-            afv_akz_launch_fed_fused(src, a->lsm[i], nullptr, L.w, L.h, nframes, a->d_kcontrast, L.octave, L.nsteps, L.tau, a->lt[i], st))
-            continue;  // conductivity + the whole FED cycle of this level in one kernel
         afv_akz_launch_flow(a->lsm[i], L.w, L.h, nframes, a->d_kcontrast, L.octave, a->flow, st);
         // FED cycle, ping-pong so that the last step lands in Lt of this level
         const float *cur = src;

@@ -374,234 +374,22 @@ __global__ __launch_bounds__(AKZ_T) void k_akz_nld_step(const float *__restrict_
     }
 }
 
-// ---- fused level update: pm_g2 conductivity from Lsmooth + the whole FED cycle (N <= 8 steps) in LDS ----
-// One tile = (64 - 2N) x 48 outputs with a halo of N pixels (one wavefront per LDS row): Lt (halo N) and Lsmooth (halo N + 1,
-// reflect-101 for the Scharr stencil)
-// are read once, the conductivity never leaves LDS, step j updates the region that still has valid neighbours (halo N - 1 - j),
-// and Lt of the new level is written once.  Every pixel sees exactly the per-step arithmetic of k_akz_flow / k_akz_nld_step
-// (zero flux across the image border; out-of-image halo cells are never read), so the result is bit-identical to the
-// step-by-step path — only the traffic changes: 12 B/px per level instead of 8 + 12 B/px per step.
+// ---- fused level update: Lsmooth (5-tap Gaussian) + pm_g2 conductivity + the whole FED cycle (N <= 8 steps) in one launch ----
 #define AKZ_FED_MAX 8
 struct AkzTau {
     float t[AKZ_FED_MAX];
 };
-
 #define AKZ_FT 512
-#define AKZ_FH 48   // output rows per fused tile; the tile is (64 - 2N) x 48 outputs so that output + halo is exactly one wave wide
-#define AKZ_FR 8    // rows per wavefront: 8 waves x 8 rows >= 48 + 2N
-// Register-resident formulation: lane = tile column, every wavefront owns a band of 8 tile rows and keeps Lt and the four
-// neighbour-conductivity sums of its band in registers for the whole cycle.  Horizontal neighbours come from DPP wave shifts,
-// vertical ones from the registers of the same lane; only the two boundary rows of a band go through LDS per step.
-__device__ __forceinline__ float akz_from_left(float v) {   // lane i <- lane i - 1 (DPP wave_shr:1)
+__device__ __forceinline__ float akz_from_left(float v) {   // lane i <- lane i - 1 (DPP wave_shr:1; lane 0 reads 0)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float akz_from_right(float v) {  // lane i <- lane i + 1 (DPP wave_shl:1)
+__device__ __forceinline__ float akz_from_right(float v) {  // lane i <- lane i + 1 (DPP wave_shl:1; lane 63 reads 0)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
-// GAUSS: the level's Lsmooth = GaussianBlur(Lt_in, 5 x 5, sigma 1, BORDER_REPLICATE) is computed here as well (k_akz_gauss<2, false>'s
-// expressions on a tile with two more rings, rows then columns) and written out for the derivative kernels, instead of being read
-// back from a kernel that ran just before: Lt_in is read once for both, Lsmooth is never read by this kernel.
-#define AKZ_FSRC 70  // source tile edge: 66 + 2 x 2
-#ifdef AKZ_EXP_STOP  // measurement builds (tools/experiments.py): end the kernel after a phase, keeping that phase's results live
-#define AKZ_STOP(n, expr)                                                                                  \
-    if (AKZ_EXP_STOP == (n)) {                                                                             \
-        float *o_ = Lt_out + (size_t)f * w * h;                                                            \
-        if (tx >= N && tx < N + OW && gx >= 0 && gx < w)                                                   \
-            for (int j = 0; j < AKZ_FR; ++j) {                                                             \
-                const int r = r0 + j, gy = y0 - N + r;                                                     \
-                if (r >= N && r < N + AKZ_FH && gy < h) o_[(size_t)gy * w + gx] = (expr);                  \
-            }                                                                                              \
-        return;                                                                                            \
-    }
-#else
-#define AKZ_STOP(n, expr)
-#endif
-template <bool GAUSS>
-__global__ __launch_bounds__(AKZ_FT) void k_akz_fed_fused(const float *__restrict__ Lt_in, float *__restrict__ lsm, const float *__restrict__ taps, int w,
-                                                          int h, int nframes, const float *__restrict__ kcontrast, int octave, int nsteps, AkzTau tau,
-                                                          float *__restrict__ Lt_out) {
-    extern __shared__ float s_fed[];
-    const int N = nsteps;
-    const int OW = 64 - 2 * N;                          // output columns of this tile
-    const int LH = AKZ_FH + 2 * N;                      // tile rows incl. halo (<= 64)
-    constexpr int SW = 66;                              // Lsmooth plane: tile + one more ring
-    const int SH = LH + 2;
-    float *s_s = s_fed;                                 // [SH][SW]  (GAUSS: on top of the source tile, which is dead by then)
-    float *s_x = s_fed + (GAUSS ? AKZ_FSRC * AKZ_FSRC : SW * 66);  // boundary-row exchange: [2 parities][2 (top, bottom)][8 waves][64]
-    AKZ_TILE(OW, AKZ_FH)
-    const float *pin = Lt_in + (size_t)f * w * h;
-    const int tx = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int gx = x0 - N + tx;
-    const int r0 = wv * AKZ_FR;
-    float L[AKZ_FR];
-    if (GAUSS) {
-        float *s_src = s_fed;                                        // [SH + 4][AKZ_FSRC], replicate coordinates
-        float *s_row = s_fed + AKZ_FSRC * AKZ_FSRC + 2 * 2 * 8 * 64;  // [SH + 4][SW] after the row pass
-        const float k0 = taps[2], k1 = taps[3], k2 = taps[4];
-        for (int py = wv; py < SH + 4; py += AKZ_FT / 64) {
-            const float *rs = pin + (size_t)akz_clamp(y0 - N - 3 + py, h) * w;
-            for (int px = tx; px < AKZ_FSRC; px += 64) s_src[py * AKZ_FSRC + px] = rs[akz_clamp(x0 - N - 3 + px, w)];
-        }
-        __syncthreads();
-        AKZ_STOP(1, s_src[min(r0 + j + 3, SH + 3) * AKZ_FSRC + tx + 3])
-        // the band's own pixels of Lt (tile row r0 + j, tile column tx) sit in the source tile
-#pragma unroll
-        for (int j = 0; j < AKZ_FR; ++j) L[j] = s_src[min(r0 + j + 3, SH + 3) * AKZ_FSRC + tx + 3];
-        // both passes as runs of 9 outputs from a 13-value register window (a tap is read from LDS once, not five times)
-        constexpr int RUN = 9;  // 8 runs cover 66 columns / up to 66 rows
-        for (int i = threadIdx.x; i < (SH + 4) * 8; i += AKZ_FT) {  // row pass: item = (source row, run of columns)
-            const int g = i / (SH + 4), py = i - g * (SH + 4);
-            const int c0 = g * RUN, n = min(RUN, SW - c0);
-            const float *c = &s_src[py * AKZ_FSRC + c0];
-            float v[RUN + 4];
-#pragma unroll
-            for (int k = 0; k < RUN + 4; ++k) v[k] = c[min(k, n + 3)];
-#pragma unroll
-            for (int k = 0; k < RUN; ++k) {
-                float a = k0 * v[k + 2];
-                a += k1 * (v[k + 3] + v[k + 1]);
-                a += k2 * (v[k + 4] + v[k]);
-                if (k < n) s_row[py * SW + c0 + k] = a;
-            }
-        }
-        __syncthreads();
-        AKZ_STOP(2, s_row[min(r0 + j + 3, SH + 3) * SW + tx + 1] + L[j])
-        float *pl = lsm + (size_t)f * w * h;
-        for (int i = threadIdx.x; i < SW * 8; i += AKZ_FT) {  // column pass: item = (column, run of rows)
-            const int g = i / SW, lx = i - g * SW;
-            const int l0 = g * RUN, n = min(RUN, SH - l0);
-            if (n <= 0) continue;
-            const float *c = &s_row[l0 * SW + lx];
-            float v[RUN + 4];
-#pragma unroll
-            for (int k = 0; k < RUN + 4; ++k) v[k] = c[min(k, n + 3) * SW];
-            const int ix = x0 - N - 1 + lx;
-#pragma unroll
-            for (int k = 0; k < RUN; ++k) {
-                float a = k0 * v[k + 2];
-                a += k1 * (v[k + 3] + v[k + 1]);
-                a += k2 * (v[k + 4] + v[k]);
-                if (k < n) {
-                    const int ly = l0 + k, iy = y0 - N - 1 + ly;
-                    s_s[ly * SW + lx] = a;
-                    // this tile owns the outputs (x0 .. x0 + OW) x (y0 .. y0 + AKZ_FH): their Lsmooth goes out for the derivative kernels
-                    if (ly > N && ly <= N + AKZ_FH && lx > N && lx <= N + OW && iy < h && ix < w) pl[(size_t)iy * w + ix] = a;
-                }
-            }
-        }
-        __syncthreads();
-        AKZ_STOP(3, s_s[min(r0 + j + 1, SH - 1) * SW + tx + 1] + L[j])
-        // entries outside the image (border tiles only): the conductivity stencil reads Lsmooth at BORDER_REFLECT_101 coordinates;
-        // the mirror entry is inside the tile for everything a valid pixel can reach (N + 1 pixels beyond the border), further out
-        // it is clamped
-        if (x0 - N - 1 < 0 || y0 - N - 1 < 0 || x0 - N - 1 + SW > w || y0 - N - 1 + SH > h) {
-            for (int ly = wv; ly < SH; ly += AKZ_FT / 64)
-                for (int lx = tx; lx < SW; lx += 64) {
-                    const int iy = y0 - N - 1 + ly, ix = x0 - N - 1 + lx;
-                    if (iy < 0 || iy >= h || ix < 0 || ix >= w) {
-                        const int my = min(max(akz_reflect(iy, h) - (y0 - N - 1), 0), SH - 1), mx = min(max(akz_reflect(ix, w) - (x0 - N - 1), 0), SW - 1);
-                        s_s[ly * SW + lx] = s_s[my * SW + mx];
-                    }
-                }
-            __syncthreads();
-        }
-    } else {
-        const float *ps = lsm + (size_t)f * w * h;
-        for (int ly = wv; ly < SH; ly += AKZ_FT / 64) {
-            const float *rs = ps + (size_t)akz_reflect(y0 - N - 1 + ly, h) * w;
-            for (int lx = tx; lx < SW; lx += 64) s_s[ly * SW + lx] = rs[akz_reflect(x0 - N - 1 + lx, w)];
-        }
-        __syncthreads();
-    }
-    float k = kcontrast[f];
-    for (int i = 0; i < octave; ++i) k = k * 0.75f;
-    const float k2inv = 1.0f / (k * k);
-    const bool col_in = gx >= 0 && gx < w, has_r = gx + 1 < w, has_l = gx > 0;
-    // conductivity of the band rows and of the rows just above / below it (rows outside the tile are never used by a valid pixel)
-    float c[AKZ_FR + 2];
-    {
-        // Scharr on a sliding 3-row window: one LDS read per source row (the centre column); the left / right columns are the
-        // neighbouring lanes' centres (DPP), except for the two edge lanes which read the extra ring column
-        float vc[AKZ_FR + 4], vl[AKZ_FR + 4], vr[AKZ_FR + 4];
-#pragma unroll
-        for (int j = 0; j < AKZ_FR + 4; ++j) {
-            const int sr = min(max(r0 - 1 + j, 0), SH - 1);  // s_s row of tile row r0 - 2 + j
-            const float *q = &s_s[sr * SW + tx + 1];
-            vc[j] = q[0];
-            const float dl = akz_from_left(vc[j]), dr = akz_from_right(vc[j]);
-            vl[j] = tx == 0 ? q[-1] : dl;
-            vr[j] = tx == 63 ? q[1] : dr;
-        }
-#pragma unroll
-        for (int j = 0; j < AKZ_FR + 2; ++j) {
-            // tile row r0 - 1 + j: source rows j (above), j + 1 (centre), j + 2 (below); rows clamped into the tile are never used by a valid pixel
-            const float t0 = vr[j] - vl[j], t1 = vr[j + 1] - vl[j + 1], t2 = vr[j + 2] - vl[j + 2];
-            const float lxv = 10.0f * t1 + 3.0f * (t0 + t2);
-            const float u0 = 10.0f * vc[j] + 3.0f * (vl[j] + vr[j]);
-            const float u2 = 10.0f * vc[j + 2] + 3.0f * (vl[j + 2] + vr[j + 2]);
-            const float lyv = u2 - u0;
-            c[j] = 1.0f / (1.0f + (lxv * lxv + lyv * lyv) * k2inv);
-        }
-    }
-    // The image border (no neighbour: that flux term is 0) and the pixels this tile does not update (outside the image or the
-    // tile: they keep their value) are folded into the conductivity sums once, instead of four selects + one per pixel and step:
-    // a zero conductivity makes the flux term +-0, and Lc + hs * (+-0) == Lc for every Lc except -0.0, which a smoothed
-    // non-negative image never holds.
-    float cR[AKZ_FR], cL[AKZ_FR], cD[AKZ_FR], cU[AKZ_FR];
-#pragma unroll
-    for (int j = 0; j < AKZ_FR; ++j) {
-        const float cc = c[j + 1];
-        const int r = r0 + j, gy = y0 - N + r;
-        const bool upd = col_in && r < LH && gy >= 0 && gy < h;
-        const float cr = cc + akz_from_right(cc), cl = akz_from_left(cc) + cc;
-        cR[j] = upd && has_r ? cr : 0.0f;
-        cL[j] = upd && has_l ? cl : 0.0f;
-        cD[j] = upd && gy + 1 < h ? cc + c[j + 2] : 0.0f;
-        cU[j] = upd && gy > 0 ? c[j] + cc : 0.0f;
-        if (!GAUSS) L[j] = pin[(size_t)akz_clamp(gy, h) * w + akz_clamp(gx, w)];
-    }
-    AKZ_STOP(4, ((cR[j] + cL[j]) + (cD[j] + cU[j])) + L[j])
-    for (int st = 0; st < N; ++st) {
-        // boundary rows of every band through LDS (double-buffered by step parity: one barrier per step)
-        float *xb = s_x + (st & 1) * (2 * 8 * 64);
-        xb[wv * 64 + tx] = L[0];
-        xb[8 * 64 + wv * 64 + tx] = L[AKZ_FR - 1];
-        __syncthreads();
-        const float up_halo = wv > 0 ? xb[8 * 64 + (wv - 1) * 64 + tx] : 0.0f;
-        const float dn_halo = wv < 7 ? xb[(wv + 1) * 64 + tx] : 0.0f;
-        // upstream forms 0.5 * stepsize * sum in double; 0.5 * tau is exact in float and a float x float product rounded once
-        // from double equals the IEEE float product, so the float multiply below is bit-identical (tests compare with the
-        // double formulation of the step-by-step kernel and of the oracle)
-        const float hs = 0.5f * tau.t[st];
-        float nl[AKZ_FR];
-#pragma unroll
-        for (int j = 0; j < AKZ_FR; ++j) {
-            const float Lc = L[j];
-            const float Lr = akz_from_right(Lc), Ll = akz_from_left(Lc);
-            const float Lu = j > 0 ? L[j - 1] : up_halo, Ld = j < AKZ_FR - 1 ? L[j + 1] : dn_halo;
-            const float xpos = cR[j] * (Lr - Lc);
-            const float xneg = cL[j] * (Lc - Ll);
-            const float ypos = cD[j] * (Ld - Lc);
-            const float yneg = cU[j] * (Lc - Lu);
-            const float sum = ((xpos - xneg) + ypos) - yneg;
-            nl[j] = Lc + hs * sum;
-        }
-#pragma unroll
-        for (int j = 0; j < AKZ_FR; ++j) L[j] = nl[j];
-    }
-    float *o = Lt_out + (size_t)f * w * h;
-    if (tx >= N && tx < N + OW && col_in) {
-#pragma unroll
-        for (int j = 0; j < AKZ_FR; ++j) {
-            const int r = r0 + j, gy = y0 - N + r;
-            if (r >= N && r < N + AKZ_FH && gy < h) o[(size_t)gy * w + gx] = L[j];
-        }
-    }
-}
-
-// ---- the same level update, shaped by what rocprofv3 said about the kernel above (round 4) ----
-// k_akz_fed_fused<true> is bound by the vector ALU, and most of what it issues is not arithmetic: 5.0 wavefront instructions per pixel
+// Shaped by what rocprofv3 said about its first form (round 3's k_akz_fed_fused: a (64 - 2N) x 48 tile, the Gaussian as LDS-tiled row /
+// column passes with run-time item mappings, the conductivity and the FED steps per band of 8 rows in registers): that one was bound by
+// the vector ALU, and most of what it issued was not arithmetic: 5.0 wavefront instructions per pixel
 // (322 lane operations) for about 100 of filter + conductivity + FED arithmetic - per-element clamps and 64-bit addresses in the
 // staging loop, run-time divisions in the item mappings, nine predicated stores per run, a six-term predicate per Lsmooth store.
 // This form has the step count as a template parameter and keeps everything per-row on the scalar unit:
@@ -614,7 +402,9 @@ __global__ __launch_bounds__(AKZ_FT) void k_akz_fed_fused(const float *__restric
 //   * the column pass is four 128-bit LDS reads per lane and leaves the 12 Lsmooth rows a band's conductivity needs in registers - no
 //     Lsmooth plane in LDS, no reflect fix-up pass (the two rows / columns just outside the image are patched in registers);
 //   * conductivity and FED steps on row pairs (packed fp32); barriers wait for LDS only, so the Lsmooth stores drain behind the FED cycle.
-// Bit-identical to the step-by-step path (same per-pixel expressions, -ffp-contract=off).
+// Every pixel sees exactly the per-step arithmetic of k_akz_gauss / k_akz_flow / k_akz_nld_step (zero flux across the image border;
+// out-of-image halo cells never reach an output), so the result is bit-identical to the step-by-step path (-ffp-contract=off); only the
+// traffic changes: 12 B/px per level instead of 8 + 8 + 12 B/px per step.
 typedef float akz_f2 __attribute__((ext_vector_type(2)));
 typedef float akz_f4 __attribute__((ext_vector_type(4)));
 #define AKZ_G_PS 76  // source tile pitch: 68 columns used; 76 mod 32 = 12 spreads the 128-bit reads of lanes that differ in the row
@@ -795,7 +585,10 @@ __global__ __launch_bounds__(AKZ_FT, 8) void k_akz_fed_gauss(const float *__rest
         AKZ_LDS_BARRIER();
         const float up_halo = xb[8 * 64 + max(wv - 1, 0) * 64 + tx];  // bands 0 / 7: their outer rows are never valid
         const float dn_halo = xb[min(wv + 1, 7) * 64 + tx];
-        const float hs = 0.5f * tau.t[st];  // exact; see k_akz_fed_fused
+        // upstream forms 0.5 * stepsize * sum in double; 0.5 * tau is exact in float and a float x float product rounded once from
+        // double equals the IEEE float product, so the float multiply below is bit-identical (the tests compare with the double
+        // formulation of the step-by-step kernel and of the oracle)
+        const float hs = 0.5f * tau.t[st];
         float xd[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -1048,34 +841,24 @@ extern "C" void afv_akz_launch_nld_step(const float *Lt, const float *flow, int 
     hipLaunchKernelGGL(k_akz_nld_step, akz_grid(w, h, nframes), dim3(AKZ_T), 0, st, Lt, flow, w, h, nframes, tau, out);
 }
 
-// returns 0 when the cycle does not fit the fused kernel (the caller then steps through k_akz_flow + k_akz_nld_step)
-// taps != nullptr: the 5 taps of the level's Gaussian; Lsmooth is then COMPUTED here (and written to lsm) instead of read
-extern "C" int afv_akz_launch_fed_fused(const float *Lt_in, float *lsm, const float *taps, int w, int h, int nframes, const float *kcontrast,
+// Lsmooth (the 5 taps of the level's Gaussian; written to lsm for the derivative kernels) + conductivity + FED cycle in one launch.
+// Returns 0 when the level does not fit the fused kernel - more than AKZ_FED_MAX steps, or an image too small for the register patch of
+// the rows / columns just outside it - and the caller then steps through k_akz_gauss + k_akz_flow + k_akz_nld_step.
+extern "C" int afv_akz_launch_fed_gauss(const float *Lt_in, float *lsm, const float *taps, int w, int h, int nframes, const float *kcontrast,
                                         int octave, int nsteps, const float *tau, float *Lt_out, hipStream_t st) {
-    if (nsteps < 1 || nsteps > AKZ_FED_MAX) return 0;
+    if (nsteps < 1 || nsteps > AKZ_FED_MAX || w < 4 || h < 4) return 0;
     AkzTau t{};
     for (int i = 0; i < nsteps; ++i) t.t[i] = tau[i];
-    const int OW = 64 - 2 * nsteps;
-    if (taps && w >= 4 && h >= 4) {
-        const size_t lds = (size_t)AKZ_G_LDS_FLOATS * sizeof(float);
-        const dim3 g = akz_grid1(w, h, nframes, 62 - 2 * nsteps, 64 - 2 * nsteps);
-#define AKZ_FG_CASE(NN)                                                                                                                      \
-    case NN:                                                                                                                                 \
-        hipLaunchKernelGGL(k_akz_fed_gauss<NN>, g, dim3(AKZ_FT), lds, st, Lt_in, lsm, taps, w, h, nframes, kcontrast, octave, t, Lt_out);    \
+    const size_t lds = (size_t)AKZ_G_LDS_FLOATS * sizeof(float);
+    const dim3 g = akz_grid1(w, h, nframes, 62 - 2 * nsteps, 64 - 2 * nsteps);
+#define AKZ_FG_CASE(NN)                                                                                                                  \
+    case NN:                                                                                                                             \
+        hipLaunchKernelGGL(k_akz_fed_gauss<NN>, g, dim3(AKZ_FT), lds, st, Lt_in, lsm, taps, w, h, nframes, kcontrast, octave, t, Lt_out); \
         break;
-        switch (nsteps) {
-            AKZ_FG_CASE(1) AKZ_FG_CASE(2) AKZ_FG_CASE(3) AKZ_FG_CASE(4) AKZ_FG_CASE(5) AKZ_FG_CASE(6) AKZ_FG_CASE(7) AKZ_FG_CASE(8)
-        }
-#undef AKZ_FG_CASE
-    } else if (taps) {
-        const size_t lds = ((size_t)AKZ_FSRC * AKZ_FSRC + 2 * 2 * 8 * 64 + (size_t)AKZ_FSRC * 66) * sizeof(float);
-        hipLaunchKernelGGL(k_akz_fed_fused<true>, akz_grid1(w, h, nframes, OW, AKZ_FH), dim3(AKZ_FT), lds, st, Lt_in, lsm, taps, w, h, nframes, kcontrast,
-                           octave, nsteps, t, Lt_out);
-    } else {
-        const size_t lds = ((size_t)66 * 66 + 2 * 2 * 8 * 64) * sizeof(float);
-        hipLaunchKernelGGL(k_akz_fed_fused<false>, akz_grid1(w, h, nframes, OW, AKZ_FH), dim3(AKZ_FT), lds, st, Lt_in, lsm, taps, w, h, nframes, kcontrast,
-                           octave, nsteps, t, Lt_out);
+    switch (nsteps) {
+        AKZ_FG_CASE(1) AKZ_FG_CASE(2) AKZ_FG_CASE(3) AKZ_FG_CASE(4) AKZ_FG_CASE(5) AKZ_FG_CASE(6) AKZ_FG_CASE(7) AKZ_FG_CASE(8)
     }
+#undef AKZ_FG_CASE
     return 1;
 }
 
