@@ -20,7 +20,7 @@ def main():
            "--steps", str(steps), "--warmup", "2", "--cpu-frames", "0", "--no-profile", "--no-extras"] + sys.argv[1:]
     subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
     rows = list(csv.DictReader(open(glob.glob(os.path.join(out, "**", "tl_kernel_trace.csv"), recursive=True)[0])))
-    ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0]) for r in rows)
+    ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "")) for r in rows)  # template kernels print as "void k_x<...>(...)"
     ev = [e for e in ev if e[2].startswith("k_")]
     per_step = len(ev) // (steps + 2)          # warm-up 2 + timed steps, every step launches the same kernels
     ev = ev[-per_step * steps:]
