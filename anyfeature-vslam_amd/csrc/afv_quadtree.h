@@ -1,5 +1,5 @@
 // afv_quadtree.h — FeatureExtractor::DistributeOctTree (reference src/ORBextractor.cc:239-458, DivideNode :181-237) as a
-// level-synchronous build for one 256-thread workgroup, over an abstract point set (float level-0 coordinates).
+// level-synchronous build for one 1024-thread workgroup, over an abstract point set (float level-0 coordinates).
 //
 // Same algorithm as the ORB path's k_select.hip (see its header for the derivation: std::list order is determined by creation
 // order, so the list is a dense array rebuilt with prefix sums; phase A splits every multi-point node, phase B splits
@@ -10,7 +10,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define QT_T 256
+#define QT_T 1024
+#define QT_NW (QT_T / 64)
+#define QT_PPT 8  // points a thread keeps in registers (coordinates + node label): sets of up to 8192 points never re-read memory
 
 struct QtRect {
     short x0, y0, x1, y1;
@@ -23,7 +25,7 @@ __device__ __forceinline__ uint32_t qt_float_key(float r) {  // order-preserving
 
 __device__ __forceinline__ int qt_wave_incl_scan(int v) { return afv_wave_incl_scan(v); }
 
-// exclusive prefix sum of arr[0..n) in place; returns the total.  `tmp` = 8 ints of LDS.
+// exclusive prefix sum of arr[0..n) in place; returns the total.  `tmp` = QT_NW ints of LDS (the scalar slots live behind them).
 __device__ inline int qt_block_excl_scan(int *arr, int n, int *tmp) {
     const int per = (n + QT_T - 1) / QT_T;
     const int b = threadIdx.x * per, e = min(b + per, n);
@@ -35,7 +37,9 @@ __device__ inline int qt_block_excl_scan(int *arr, int n, int *tmp) {
     __syncthreads();
     int base = incl - local;
     for (int k = 0; k < w; ++k) base += tmp[k];
-    const int total = tmp[0] + tmp[1] + tmp[2] + tmp[3];
+    int total = 0;
+#pragma unroll
+    for (int k = 0; k < QT_NW; ++k) total += tmp[k];
     for (int i = b; i < e; ++i) {
         const int v = arr[i];
         arr[i] = base;
@@ -70,7 +74,7 @@ struct QtScratch {
 };
 
 __host__ __device__ inline size_t qt_lds_bytes(int M) {
-    return (size_t)M * 8 * 2 /*rect*/ + (size_t)M * 4 * 2 /*cnt*/ + (size_t)M * 16 /*child*/ + (size_t)M * 4 * 3 /*aux, aux2, scan*/ + 64 /*tmp*/ +
+    return (size_t)M * 8 * 2 /*rect*/ + (size_t)M * 4 * 2 /*cnt*/ + (size_t)M * 16 /*child*/ + (size_t)M * 4 * 3 /*aux, aux2, scan*/ + 128 /*tmp: QT_NW wave sums + scalar slots*/ +
            (size_t)M * 8 /*remap*/;
 }
 
@@ -85,15 +89,36 @@ __device__ inline QtScratch qt_carve(char *smem, int M) {
     S.aux2 = S.aux + M;
     S.scan = S.aux2 + M;
     S.tmp = S.scan + M;
-    S.remap = reinterpret_cast<uint16_t *>(S.tmp + 16);
+    S.remap = reinterpret_cast<uint16_t *>(S.tmp + 32);
     return S;
 }
 
 // Builds the tree over points p = 0..m2-1 (P.x(p), P.y(p) in level-0 pixels).  kn[p] (any memory) receives the index, in
 // std::list order, of the node that holds point p; the return value is the number of nodes.  N = quota; n_ini / h_x /
-// height describe the root boxes (ORBextractor.cc:243-283).  All 256 threads must call it.
-template <class Pts>
-__device__ int qt_build(const Pts &P, int m2, int N, int n_ini, float h_x, int height, uint16_t *kn, const QtScratch &S) {
+// height describe the root boxes (ORBextractor.cc:243-283).  All QT_T threads must call it.
+// REG: a thread keeps the coordinates and the node label of its <= QT_PPT points in registers for the whole build (the two passes over
+// the points per round were two dependent memory round trips per point and pass: 240 us for the 7 000 points of one AKAZE level); sets
+// beyond QT_T x QT_PPT points walk memory as before.
+#define QT_FOR_POINTS(BODY)                                           \
+    if (REG) {                                                        \
+        _Pragma("unroll") for (int k_ = 0; k_ < QT_PPT; ++k_) {       \
+            if (k_ * QT_T + tid < m2) {                               \
+                const float px = rx[k_], py = ry[k_];                 \
+                int nd = rn_[k_];                                     \
+                BODY                                                  \
+                rn_[k_] = nd;                                         \
+            }                                                         \
+        }                                                             \
+    } else {                                                          \
+        for (int p_ = tid; p_ < m2; p_ += QT_T) {                     \
+            const float px = P.x(p_), py = P.y(p_);                   \
+            int nd = kn[p_];                                          \
+            BODY                                                      \
+            kn[p_] = (uint16_t)nd;                                    \
+        }                                                             \
+    }
+template <class Pts, bool REG>
+__device__ int qt_build_impl(const Pts &P, int m2, int N, int n_ini, float h_x, int height, uint16_t *kn, const QtScratch &S) {
     const int tid = threadIdx.x, lane = tid & 63;
     QtRect *rect0 = S.rect0, *rect1 = S.rect1;
     int *cnt0 = S.cnt0, *cnt1 = S.cnt1, *child = S.child, *aux = S.aux, *aux2 = S.aux2, *scan = S.scan, *tmp = S.tmp;
@@ -101,14 +126,26 @@ __device__ int qt_build(const Pts &P, int m2, int N, int n_ini, float h_x, int h
     // root assignment: vpIniNodes[kp.pt.x / hX]
     if (tid < 16) aux[tid] = 0;
     __syncthreads();
-    for (int p = tid; p < m2; p += QT_T) {
+    float rx[QT_PPT], ry[QT_PPT];
+    int rn_[QT_PPT];
+    if (REG) {
+#pragma unroll
+        for (int k_ = 0; k_ < QT_PPT; ++k_) {
+            const int p = min(k_ * QT_T + tid, max(m2 - 1, 0));
+            rx[k_] = m2 > 0 ? P.x(p) : 0.0f;
+            ry[k_] = m2 > 0 ? P.y(p) : 0.0f;
+            rn_[k_] = 0;
+        }
+    }
+    QT_FOR_POINTS({
+        (void)py;
         int root = 0;
         if (n_ini > 1) {
-            root = min((int)(P.x(p) / h_x), n_ini - 1);
+            root = min((int)(px / h_x), n_ini - 1);
             atomicAdd(&aux[root], 1);
         }
-        kn[p] = (uint16_t)root;
-    }
+        nd = root;
+    })
     __syncthreads();
     if (tid == 0) {
         int sz = 0;
@@ -128,12 +165,13 @@ __device__ int qt_build(const Pts &P, int m2, int N, int n_ini, float h_x, int h
                 aux2[i] = 0;
             }
         }
-        tmp[9] = sz;
+        tmp[QT_NW + 0] = sz;
     }
     __syncthreads();
-    if (n_ini > 1)
-        for (int p = tid; p < m2; p += QT_T) kn[p] = (uint16_t)aux2[kn[p]];
-    int size = tmp[9];
+    if (n_ini > 1) {
+        QT_FOR_POINTS({ (void)px; (void)py; nd = aux2[nd]; })
+    }
+    int size = tmp[QT_NW + 0];
     __syncthreads();
 
     QtRect *rc = rect0, *rn = rect1;
@@ -145,10 +183,9 @@ __device__ int qt_build(const Pts &P, int m2, int N, int n_ini, float h_x, int h
         // 1. child occupancy of every node that may split this round
         for (int i = tid; i < size * 4; i += QT_T) child[i] = 0;
         __syncthreads();
-        for (int p = tid; p < m2; p += QT_T) {
-            const int nd = kn[p];
-            if (cc[nd] > 1) atomicAdd(&child[nd * 4 + qt_quadrant(P.x(p), P.y(p), rc[nd])], 1);
-        }
+        QT_FOR_POINTS({
+            if (cc[nd] > 1) atomicAdd(&child[nd * 4 + qt_quadrant(px, py, rc[nd])], 1);
+        })
         __syncthreads();
         // 2. processing order: aux[key] = non-empty children of the node processed key-th; aux2[i] = key of node i or -1
         int nproc;
@@ -164,7 +201,7 @@ __device__ int qt_build(const Pts &P, int m2, int N, int n_ini, float h_x, int h
         } else {
             // rank among expandable nodes by (count desc, list index asc) == ascending sort of (size, pointer) walked from the
             // back (ORBextractor.cc:381-382), pointer ties resolved by creation order
-            if (tid == 0) tmp[10] = 0;
+            if (tid == 0) tmp[QT_NW + 1] = 0;
             for (int i = tid; i < size; i += QT_T) aux[i] = 0;
             __syncthreads();
             int ecount = 0;
@@ -183,22 +220,22 @@ __device__ int qt_build(const Pts &P, int m2, int N, int n_ini, float h_x, int h
                 aux2[i] = key;
             }
             ecount = qt_wave_incl_scan(ecount);
-            if (lane == 63) atomicAdd(&tmp[10], ecount);
+            if (lane == 63) atomicAdd(&tmp[QT_NW + 1], ecount);
             __syncthreads();
-            const int E = tmp[10];
+            const int E = tmp[QT_NW + 1];
             for (int i = tid; i < size; i += QT_T) {
                 const int key = aux2[i];
                 if (key >= 0) aux[key] = (child[4 * i] > 0) + (child[4 * i + 1] > 0) + (child[4 * i + 2] > 0) + (child[4 * i + 3] > 0) - 1;
             }
             __syncthreads();
             qt_block_excl_scan(aux, E, tmp);  // aux[r] = sum of deltas of ranks < r
-            if (tid == 0) tmp[11] = E - 1;
+            if (tid == 0) tmp[QT_NW + 2] = E - 1;
             __syncthreads();
             // stop rank: smallest r whose split lifts the node count to >= N (ORBextractor.cc:424-425)
             for (int r = tid; r + 1 < E; r += QT_T)
-                if (prev_size + aux[r + 1] >= N) atomicMin(&tmp[11], r);
+                if (prev_size + aux[r + 1] >= N) atomicMin(&tmp[QT_NW + 2], r);
             __syncthreads();
-            const int rstar = tmp[11];
+            const int rstar = tmp[QT_NW + 2];
             __syncthreads();
             for (int i = tid; i < E; i += QT_T) aux[i] = 0;
             __syncthreads();
@@ -244,17 +281,16 @@ __device__ int qt_build(const Pts &P, int m2, int N, int n_ini, float h_x, int h
             }
         }
         n_expand_local = qt_wave_incl_scan(n_expand_local);
-        if (tid == 0) tmp[12] = 0;
+        if (tid == 0) tmp[QT_NW + 3] = 0;
         __syncthreads();
-        if (lane == 63) atomicAdd(&tmp[12], n_expand_local);
+        if (lane == 63) atomicAdd(&tmp[QT_NW + 3], n_expand_local);
         // 4. relabel the points
-        for (int p = tid; p < m2; p += QT_T) {
-            const int nd = kn[p];
-            const int q = (aux2[nd] >= 0) ? qt_quadrant(P.x(p), P.y(p), rc[nd]) : 0;
-            kn[p] = remap[4 * nd + q];
-        }
+        QT_FOR_POINTS({
+            const int q = (aux2[nd] >= 0) ? qt_quadrant(px, py, rc[nd]) : 0;
+            nd = remap[4 * nd + q];
+        })
         __syncthreads();
-        const int n_expand = tmp[12];
+        const int n_expand = tmp[QT_NW + 3];
         size = new_size;
         {
             QtRect *t = rc; rc = rn; rn = t;
@@ -265,6 +301,19 @@ __device__ int qt_build(const Pts &P, int m2, int N, int n_ini, float h_x, int h
         else if (!phase_b && size + n_expand * 3 > N) phase_b = true;
         __syncthreads();
     }
+    if (REG) {  // the labels leave the registers once
+#pragma unroll
+        for (int k_ = 0; k_ < QT_PPT; ++k_)
+            if (k_ * QT_T + tid < m2) kn[k_ * QT_T + tid] = (uint16_t)rn_[k_];
+    }
+    __syncthreads();
     return size;
+}
+#undef QT_FOR_POINTS
+
+template <class Pts>
+__device__ int qt_build(const Pts &P, int m2, int N, int n_ini, float h_x, int height, uint16_t *kn, const QtScratch &S) {
+    if (m2 <= QT_T * QT_PPT) return qt_build_impl<Pts, true>(P, m2, N, n_ini, h_x, height, kn, S);  // uniform
+    return qt_build_impl<Pts, false>(P, m2, N, n_ini, h_x, height, kn, S);
 }
 #endif

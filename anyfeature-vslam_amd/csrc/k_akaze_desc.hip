@@ -47,8 +47,10 @@ __global__ __launch_bounds__(QT_T) void k_akz_select(AksParams P, const afv_keyp
     const int n = kp_count[f];
     // ordered gather of this level's keypoints (keypoints_level[class_id].push_back in detection order).  Every workgroup of a frame
     // walks all of the frame's keypoints (a replaced entry keeps its slot, so a level's points are not contiguous): GU x QT_T of them
-    // per step, ONE barrier per step (the wave counts alternate between two LDS rows, the running total lives in registers) - the
-    // first form took a keypoint per thread and four barriers per step, 73 steps of ~2 us for the 18.7 k keypoints of a 1280 x 720 frame
+    // per step, ONE barrier per step (the wave counts alternate between two LDS rows, the running total lives in registers)
+#ifdef AFV_AKS_STATS
+    const long long st0 = wall_clock64();
+#endif
     int m2 = 0;
     for (int i0 = 0, it = 0; i0 < n; i0 += GU * QT_T, ++it) {
         unsigned long long m[GU];
@@ -75,8 +77,14 @@ __global__ __launch_bounds__(QT_T) void k_akz_select(AksParams P, const afv_keyp
     }
     __threadfence_block();
     __syncthreads();
+#ifdef AFV_AKS_STATS
+    const long long st1 = wall_clock64();
+#endif
     AksPts pts{k, idx};
     const int size = qt_build(pts, m2, P.quota[level], P.n_ini, P.h_x, P.H, kn, S);
+#ifdef AFV_AKS_STATS
+    const long long st2 = wall_clock64();
+#endif
     // survivor of each node: max response, first in input order on ties (ORBextractor.cc:446-453)
     for (int i = tid; i < size; i += QT_T) best[i] = 0ull;
     __syncthreads();
@@ -89,6 +97,9 @@ __global__ __launch_bounds__(QT_T) void k_akz_select(AksParams P, const afv_keyp
     int *out = sel + ((size_t)f * P.nlevels + level) * P.sel_cap;
     for (int i = tid; i < nout; i += QT_T) out[i] = idx[0xffffffffu - (uint32_t)(best[i] & 0xffffffffu)];
     if (tid == 0) sel_count[f * AKS_MAX_LEVELS + level] = nout;
+#ifdef AFV_AKS_STATS
+    if (tid == 0 && f == 0) printf("akz_select level %d: n %d m2 %d size %d | x10 ns: gather %lld build %lld pick %lld\n", level, n, m2, size, st1 - st0, st2 - st1, wall_clock64() - st2);
+#endif
 }
 
 // ---------------- Compute_Descriptors ----------------
