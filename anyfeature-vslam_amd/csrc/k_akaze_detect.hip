@@ -165,7 +165,14 @@ __global__ __launch_bounds__(AKE_T) void k_akz_cand_emit(AkdParams P, const unsi
     int sum = 0;
     for (int r = b; r < e; ++r) {
         int c = 0;
-        for (int k = 0; k < nchunks; ++k) c += __popcll(mk[(size_t)r * AKD_MAXCHUNKS + k]);
+        const ulonglong2 *w2 = reinterpret_cast<const ulonglong2 *>(mk + (size_t)r * AKD_MAXCHUNKS);  // 16-byte loads, all in flight
+#pragma unroll
+        for (int k = 0; k < AKD_MAXCHUNKS / 2; ++k) {
+            if (2 * k < nchunks) {
+                const ulonglong2 v = w2[k];
+                c += __popcll(v.x) + (2 * k + 1 < nchunks ? __popcll(v.y) : 0);
+            }
+        }
         rs[r] = c;  // row count for now
         sum += c;
     }
@@ -193,25 +200,47 @@ __global__ __launch_bounds__(AKE_T) void k_akz_cand_emit(AkdParams P, const unsi
     const float *ld = L.ldet + (size_t)f * L.w * L.h;
     int *co = cand + (size_t)f * P.cand_stride + L.cand_off;
     float *cr = cand_resp + (size_t)f * P.cand_stride + L.cand_off;
-    for (int r = wv; r < L.h; r += AKE_T / 64) {
+    constexpr int ER = 4;  // rows a wavefront fetches together (mask words + row offsets: one memory round trip for four rows)
+    for (int r0 = wv * ER; r0 < L.h; r0 += ER * (AKE_T / 64)) {
         // lane k holds chunk k's word; exclusive scan of the popcounts gives every chunk its offset inside the row
-        unsigned long long m = lane < nchunks ? mk[(size_t)r * AKD_MAXCHUNKS + lane] : 0ull;
-        const int cnt = __popcll(m);
-        const int in = afv_wave_incl_scan(cnt);
-        if (__shfl(in, 63, 64) == 0) continue;
-        int o = rs[r] + in - cnt;
-        const int idx0 = r * L.w + (lane << 6);
-        while (m) {
-            const int bit = (int)__builtin_ctzll(m);
-            m &= m - 1;
-            if (o < L.cand_cap) co[o] = idx0 + bit;
-            ++o;
+        unsigned long long mw[ER];
+        int ro[ER];
+#pragma unroll
+        for (int u = 0; u < ER; ++u) {
+            const int r = min(r0 + u, L.h - 1);
+            mw[u] = (lane < nchunks && r0 + u < L.h) ? mk[(size_t)r * AKD_MAXCHUNKS + lane] : 0ull;
+            ro[u] = rs[r];
+        }
+#pragma unroll
+        for (int u = 0; u < ER; ++u) {
+            unsigned long long m = mw[u];
+            const int cnt = __popcll(m);
+            const int in = afv_wave_incl_scan(cnt);
+            int o = ro[u] + in - cnt;
+            const int idx0 = (r0 + u) * L.w + (lane << 6);
+            while (m) {
+                const int bit = (int)__builtin_ctzll(m);
+                m &= m - 1;
+                if (o < L.cand_cap) co[o] = idx0 + bit;
+                ++o;
+            }
         }
     }
     __threadfence_block();
     __syncthreads();
     const int ntot = min(total, L.cand_cap);
-    for (int k = tid; k < ntot; k += AKE_T) cr[k] = fabsf(ld[co[k]]);
+    // |response| of the emitted indices: independent gathers, four in flight per thread
+    for (int k0 = tid; k0 < ntot; k0 += 4 * AKE_T) {
+        int ci[4];
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ci[u] = k0 + u * AKE_T < ntot ? co[k0 + u * AKE_T] : 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ld[ci[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k0 + u * AKE_T < ntot) cr[k0 + u * AKE_T] = fabsf(v[u]);
+    }
 }
 
 // ---------------- ordered suppression + upper-level filter: one workgroup per (frame, level), levels pipelined ----------------
