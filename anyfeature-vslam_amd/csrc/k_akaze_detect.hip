@@ -722,6 +722,14 @@ __global__ __launch_bounds__(AKD_CHUNK) void k_akz_refine_a(AkdParams P, AkdStat
     __shared__ int s_wsum[AKD_CHUNK / 64];
     const int f = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int slot = chunk * AKD_CHUNK + tid;
+    {   // the slot space is 131 072 wide, a frame uses the first sum-of-candidates of it (~40 k): the chunks behind that have nothing to do
+        int slots = 0;
+        for (int k = 0; k < P.nlevels; ++k) slots += cand_count[f * 16 + k];
+        if (chunk * AKD_CHUNK >= slots) {  // uniform
+            if (tid == 0) S.chunk_cnt[(size_t)f * gridDim.x + chunk] = 0;  // k_akz_refine_b then never looks at `keep` of this chunk
+            return;
+        }
+    }
     float *ex = S.ex + (size_t)f * P.entry_cap, *ey = S.ey + (size_t)f * P.entry_cap;
     unsigned char *keep = S.keep + (size_t)f * P.entry_cap;
     bool ok = false;
@@ -792,7 +800,8 @@ __global__ __launch_bounds__(AKD_CHUNK) void k_akz_refine_b(AkdParams P, AkdStat
             s_total = all;
         }
     }
-    const bool ok = slot < P.entry_cap && S.keep[(size_t)f * P.entry_cap + slot] != 0;
+    // a chunk without survivors (k_akz_refine_a counted them; the chunks behind the used slot range never set `keep`) has nothing to write
+    const bool ok = cc[chunk] > 0 && slot < P.entry_cap && S.keep[(size_t)f * P.entry_cap + slot] != 0;
     const unsigned long long m = __ballot(ok);
     if (lane == 0) s_wsum[tid >> 6] = __popcll(m);
     __syncthreads();
