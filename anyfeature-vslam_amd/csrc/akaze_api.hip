@@ -41,8 +41,7 @@ struct AkdParams {
     int cand_stride, rows_stride, gcells, gelems, lds_bytes, entry_cap, kp_cap;
 };
 struct AkdState {
-    float *ex, *ey, *eresp;
-    int *elevel;
+    float4 *entry;
     uint4 *cells;
     int *gcnt, *ticket, *used, *chunk_cnt;
     unsigned char *keep;
@@ -328,10 +327,7 @@ extern "C" int afv_akaze_create(int device, const afv_akaze_params *prm, afv_aka
         if (rc == AFV_OK) rc = akz_alloc(a, &a->d_kp_count, B);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->d_status, 1);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->d_kps, (size_t)AKD_ENTRY_CAP * B);
-        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.ex, (size_t)AKD_SLOT_CAP * B);
-        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.ey, (size_t)AKD_SLOT_CAP * B);
-        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.eresp, (size_t)AKD_SLOT_CAP * B);
-        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.elevel, (size_t)AKD_SLOT_CAP * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.entry, (size_t)AKD_SLOT_CAP * B);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.keep, (size_t)AKD_SLOT_CAP * B);
         // one cell grid per level (the levels of a frame are suppressed as a pipeline), sized for the largest frame
         // one cell grid per level (the levels of a frame are suppressed as a pipeline), sized for the largest frame

@@ -269,8 +269,7 @@ __global__ __launch_bounds__(AKE_T) void k_akz_cand_emit(AkdParams P, const unsi
 // A replaced entry is not unlinked: its old list element is marked dead and a fresh element goes into the list of its new cell
 // (in the replacing candidate's level grid), so every list only grows and all commits of a round run in parallel.
 struct AkdState {
-    float *ex, *ey, *eresp;   // [frame][entry_cap]  (slot-indexed)
-    int *elevel;              // [frame][entry_cap]
+    float4 *entry;            // [frame][entry_cap], slot-indexed: {x, y, response, level (integer bits)} - one 16-byte store per commit
     uint4 *cells;             // [frame][gelems] {x, y, response, tag}; level c's lists start at lv[c].gelem_off
     int *gcnt;                // [frame][gcells] published list lengths (hints, see above)
     int *ticket;              // [8] per-XCD ticket counters, then [frame][16] committed candidates per level (all zeroed before the launch)
@@ -377,8 +376,7 @@ __global__ __launch_bounds__(AKD_T, 8) void k_akz_suppress(AkdParams P, AkdState
     __shared__ int s_apps[AKD_R / 64], s_napp[AKD_R / 64];  // per deciding wavefront: appends, committed appends
     __shared__ int s_stop[2];                                // first candidate of the round that must be redone (by round parity)
     __shared__ int s_reacq;                                  // the communication lane had to wait (and acquire) this round
-    float *ex = S.ex + (size_t)f * P.entry_cap, *ey = S.ey + (size_t)f * P.entry_cap, *er = S.eresp + (size_t)f * P.entry_cap;
-    int *el = S.elevel + (size_t)f * P.entry_cap;
+    float4 *entry = S.entry + (size_t)f * P.entry_cap;
     uint4 *cells = S.cells + (size_t)f * P.gelems;
     int *gcnt_own = S.gcnt + (size_t)f * P.gcells + L.gcell_off;
     const int *gcnt_prev = S.gcnt + (size_t)f * P.gcells + Lp.gcell_off;
@@ -619,10 +617,7 @@ __global__ __launch_bounds__(AKD_T, 8) void k_akz_suppress(AkdParams P, AkdState
                     cells[mloc].w = mtag | AKD_DEADBIT;
                 }
                 if (slot < P.entry_cap) {
-                    ex[slot] = sx;
-                    ey[slot] = sy;
-                    er[slot] = resp;
-                    el[slot] = c;
+                    entry[slot] = make_float4(sx, sy, resp, __int_as_float(c));
                     // list slot from an LDS atomic on the packed 8-bit counters (several commits may share a cell)
                     const unsigned int old = atomicAdd(&s_cnt32[ci >> 2], 1u << ((ci & 3) * 8));
                     const int cn = (int)((old >> ((ci & 3) * 8)) & 0xffu);
@@ -730,7 +725,7 @@ __global__ __launch_bounds__(AKD_CHUNK) void k_akz_refine_a(AkdParams P, AkdStat
             return;
         }
     }
-    float *ex = S.ex + (size_t)f * P.entry_cap, *ey = S.ey + (size_t)f * P.entry_cap;
+    float4 *entry = S.entry + (size_t)f * P.entry_cap;
     unsigned char *keep = S.keep + (size_t)f * P.entry_cap;
     bool ok = false;
     {
@@ -743,8 +738,9 @@ __global__ __launch_bounds__(AKD_CHUNK) void k_akz_refine_a(AkdParams P, AkdStat
     }
     ok = ok && slot < P.entry_cap && keep[slot] != 0;
     if (ok) {
-        const AkdLevel L = P.lv[S.elevel[(size_t)f * P.entry_cap + slot]];
-        const int x = akd_fround(ex[slot] / L.ratio), y = akd_fround(ey[slot] / L.ratio), w = L.w;
+        const float4 en = entry[slot];
+        const AkdLevel L = P.lv[__float_as_int(en.w)];
+        const int x = akd_fround(en.x / L.ratio), y = akd_fround(en.y / L.ratio), w = L.w;
         const float *D = L.ldet + (size_t)f * L.w * L.h;
 #define LD(yy, xx) D[(size_t)(yy) * w + (xx)]
         const float Dx = (float)(0.5 * (double)(LD(y, x + 1) - LD(y, x - 1)));
@@ -762,8 +758,7 @@ __global__ __launch_bounds__(AKD_CHUNK) void k_akz_refine_a(AkdParams P, AkdStat
             const float d1 = (float)((b1 * (double)Dxx - b0 * (double)Dxy) * inv);
             if (fabsf(d0) <= 1.0f && fabsf(d1) <= 1.0f) {
                 const float power = (float)(1 << L.octave);
-                ex[slot] = ((float)x + d0) * power;
-                ey[slot] = ((float)y + d1) * power;
+                entry[slot] = make_float4(((float)x + d0) * power, ((float)y + d1) * power, en.z, en.w);
             } else {
                 ok = false;
             }
@@ -814,10 +809,11 @@ __global__ __launch_bounds__(AKD_CHUNK) void k_akz_refine_b(AkdParams P, AkdStat
     for (int w = 0; w < (tid >> 6); ++w) o += s_wsum[w];
     if (o >= P.kp_cap) return;
     const size_t si = (size_t)f * P.entry_cap + slot;
-    const int klev = S.elevel[si];
+    const float4 en = S.entry[si];
+    const int klev = __float_as_int(en.w);
     const AkdLevel L = P.lv[klev];
     afv_keypoint k;
-    k.x = S.ex[si]; k.y = S.ey[si]; k.size = L.psize * 2.0f; k.angle = 0.0f; k.response = S.eresp[si]; k.octave = L.octave; k.class_id = klev;
+    k.x = en.x; k.y = en.y; k.size = L.psize * 2.0f; k.angle = 0.0f; k.response = en.z; k.octave = L.octave; k.class_id = klev;
     kps[(size_t)f * P.kp_cap + o] = k;
 }
 
