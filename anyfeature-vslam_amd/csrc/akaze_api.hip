@@ -567,7 +567,7 @@ static int akz_detect_enqueue(afv_akaze *a) {
     {
         const int rc = akz_grid_geometry(P, a->prm.derivative_factor, D.lv, &D.gcells, &D.gelems, &D.lds_bytes);
         if (rc) return rc;
-        if ((size_t)D.gcells > a->grid_cells_max || (size_t)D.gelems > a->grid_elems_max || D.lds_bytes > 58 * 1024) return AFV_EUNSUPPORTED;  // + ~5 KB of static LDS in k_akz_suppress: 64 KB in all
+        if ((size_t)D.gcells > a->grid_cells_max || (size_t)D.gelems > a->grid_elems_max || D.lds_bytes > 52 * 1024) return AFV_EUNSUPPORTED;  // + ~10 KB of static LDS in k_akz_suppress (256-candidate rounds): 64 KB in all
     }
     D.entry_cap = AKD_SLOT_CAP; D.kp_cap = AKD_ENTRY_CAP;
     hipStream_t st = a->stream;

@@ -9,7 +9,7 @@
 //     the result).
 //  2. k_akz_suppress: upstream inserts the candidates one by one into kpts_aux, comparing each against the FIRST earlier
 //     entry of the same / previous level within its radius (replace it or drop the newcomer).  One workgroup per (frame,
-//     level) replays that loop in speculative rounds of AKD_R (128) consecutive candidates: the (candidate, grid cell) pairs
+//     level) replays that loop in speculative rounds of AKD_R (256) consecutive candidates: the (candidate, grid cell) pairs
 //     of a round are scanned by all threads in two uniform grids (the level below, this level; entries inline in the cell
 //     lists); then every candidate checks exactly whether an earlier candidate of the round changes what its search saw (a
 //     new / moved entry inside its radius, or a replaced entry that lay inside it) and the round commits, in parallel, up to
@@ -284,7 +284,8 @@ struct AkdState {
 #define AKD_COMM (AKD_T - 64)    // the lane that talks to the neighbouring levels (first lane of the last wavefront)
 #define AKD_PAIRS 8   // 2 grids x the (at most) 2 x 2 cells a candidate's disc overlaps
 #ifndef AKD_R
-#define AKD_R 128      // candidates per speculative round (AKD_R / 64 wavefronts decide / commit); AKD_R * AKD_PAIRS / AKD_T pairs per thread
+#define AKD_R 256      // candidates per speculative round (AKD_R / 64 wavefronts decide / commit); AKD_R * AKD_PAIRS / AKD_T pairs per thread.
+                       // 128 -> 256 (round 4): 5.56 -> 5.49 ms per 64-frame step; the static LDS arrays below grow to ~10 KB (akaze_api's gate)
 #endif
 #define AKD_CPER (AKD_T / (AKD_R / 2))  // threads per row pair of the conflict test
 #define AKD_DEADBIT 0x80000000u
