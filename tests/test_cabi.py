@@ -122,3 +122,32 @@ def test_adapter_compiles_in_its_opencv_configuration():
            os.path.join(ROOT, "tests", "opencv_mock", "compile_check.cpp")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
+
+
+def test_python_struct_mirrors_match_the_headers(tmp_path):
+    """the ctypes structures of _lib.py / akaze.py against the layouts gcc gives include/afv_hip.h and include/afv_akaze.h: size of every
+    structure and offset of every field (a field added to a header and forgotten in a mirror shifts everything behind it)"""
+    import ctypes as C
+    import importlib
+    import subprocess
+    pkg = importlib.import_module("anyfeature-vslam_amd")
+    lib, akz = pkg._lib, importlib.import_module("anyfeature-vslam_amd.akaze")
+    pairs = [("afv_orb_params", lib.OrbParams), ("afv_geometry", lib.Geometry), ("afv_match_job", lib.MatchJob), ("afv_tri_job", lib.TriJob),
+             ("afv_table_tri_job", lib.TableTriJob), ("afv_frame_view", lib.FrameView), ("afv_proj_job", lib.ProjJob),
+             ("afv_akaze_params", akz.AkazeParams), ("afv_akaze_level", akz.AkazeLevel), ("afv_akaze_plan", akz.AkazePlan)]
+    lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "afv_hip.h"', '#include "afv_akaze.h"', 'int main(void) {']
+    for cname, st in pairs:
+        lines.append('  printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in st._fields_:
+            lines.append('  printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    r = subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr  # a field name the header does not have fails here
+    got = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True, timeout=60).stdout.splitlines())
+    for cname, st in pairs:
+        assert int(got[cname]) == C.sizeof(st), (cname, got[cname], C.sizeof(st))
+        for fname, _ in st._fields_:
+            assert int(got["%s.%s" % (cname, fname)]) == getattr(st, fname).offset, (cname, fname)

@@ -553,3 +553,27 @@ def test_bow_transform_hand_tree(afv, oracle):
     assert lf.tolist() == [3, 4, 5, 3] and nid.tolist() == [0, 0, 0, 0]
     lf, nid = oracle.bow_transform(voc, q, levelsup=0)
     assert nid.tolist() == lf.tolist()
+
+
+def test_oracle_binding_mirrors_match_afvo_h(tmp_path):
+    """the ctypes structures of oracle/binding.py against the layouts gcc gives oracle/afvo.h (sizes and field offsets): the checker's own
+    plumbing, checked the same way as the product's (tests/test_cabi.py)"""
+    import ctypes as C
+    import os
+    import subprocess
+    import oracle.binding as ob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pairs = [("afvo_keypoint", ob.Keypoint), ("afvo_params", ob.Params), ("afvo_trace", ob.Trace), ("afvo_bow_job", ob.BowJob),
+             ("afvo_tri_job", ob.TriJob), ("afvo_proj_job", ob.ProjJob), ("afvo_l2_job", ob.L2Job), ("afvo_vocab", ob.Vocab)]
+    lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "afvo.h"', 'int main(void) {']
+    for cname, st in pairs:
+        lines.append('  printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    r = subprocess.run(["gcc", "-std=gnu11", "-I", os.path.join(root, "oracle"), str(src), "-o", str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    got = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True, timeout=60).stdout.splitlines())
+    for cname, st in pairs:
+        assert int(got[cname]) == C.sizeof(st), (cname, got[cname], C.sizeof(st))
