@@ -1366,20 +1366,19 @@ static int afv_match_bow_impl(afv_ctx *c, const afv_match_job *jobs, int njobs, 
     const size_t out_off = b.reserve(std::max<size_t>(total_out, 1) * 4);
     const size_t nm_off = b.reserve((size_t)njobs * 4);
     const size_t jobs_off = b.reserve((size_t)njobs * sizeof(DevMatchJob));
-    struct SegTaskH { int job, seg; };
-    std::vector<SegTaskH> tasks;
+    std::vector<SegTask> tasks;
     std::vector<int> bin_off(njobs, 0);
     size_t tasks_off = 0, hist_off = 0, bins_off = 0, binoff_off = 0;
     bool any_ori = false;
     if (per_node) {
         size_t acc = 0;
         for (int i = 0; i < njobs; ++i) {
-            for (int sgi = 0; sgi < offs[i].nseg; ++sgi) tasks.push_back(SegTaskH{i, sgi});
+            for (int sgi = 0; sgi < offs[i].nseg; ++sgi) tasks.push_back(SegTask{i, sgi});
             bin_off[i] = (int)acc;
             acc += (size_t)offs[i].nout;
             any_ori = any_ori || jobs[i].check_orientation;
         }
-        tasks_off = b.put(tasks.data(), tasks.size() * sizeof(SegTaskH));
+        tasks_off = b.put(tasks.data(), tasks.size() * sizeof(SegTask));
         hist_off = b.reserve((size_t)njobs * 32 * 4);
         bins_off = b.reserve(std::max<size_t>(acc, 1));
         binoff_off = b.put(bin_off.data(), (size_t)njobs * 4);

@@ -414,18 +414,17 @@ static int table_match_bow_impl(afv_table *t, const int32_t *pair_a, const int32
     HIPCHK(c, hipSetDevice(c->device));
     const int cap = t->cap;
     Blob b(c);
-    struct SegTaskH { int job, seg; };
     std::vector<Seg> segs;
-    std::vector<SegTaskH> tasks;
+    std::vector<SegTask> tasks;
     std::vector<int> seg_first((size_t)npairs + 1, 0);
     for (int p = 0; p < npairs; ++p) {
         const size_t before = segs.size();
         join_featvecs(t->fv[pair_a[p]], t->fv[pair_b[p]], segs);
-        for (size_t s = before; s < segs.size(); ++s) tasks.push_back(SegTaskH{p, (int)(s - before)});
+        for (size_t s = before; s < segs.size(); ++s) tasks.push_back(SegTask{p, (int)(s - before)});
         seg_first[p + 1] = (int)segs.size();
     }
     const size_t segs_off = b.put(segs.data(), segs.size() * sizeof(Seg));
-    const size_t tasks_off = b.put(tasks.data(), tasks.size() * sizeof(SegTaskH));
+    const size_t tasks_off = b.put(tasks.data(), tasks.size() * sizeof(SegTask));
     const size_t jobs_off = b.reserve((size_t)npairs * sizeof(DevMatchJob));
     const size_t binoff_off = b.reserve((size_t)npairs * sizeof(int));
     const size_t hist_off = b.reserve((size_t)npairs * 32 * sizeof(int));
@@ -515,14 +514,13 @@ static int table_match_bow_frame_impl(afv_table *t, const int32_t *slots, int ns
     }
     HIPCHK(c, hipSetDevice(c->device));
     Blob b(c);
-    struct SegTaskH { int job, seg; };
     std::vector<Seg> segs;
-    std::vector<SegTaskH> tasks;
+    std::vector<SegTask> tasks;
     std::vector<int> seg_first((size_t)nslots + 1, 0);
     for (int p = 0; p < nslots; ++p) {
         const size_t before = segs.size();
         join_featvecs(t->fv[slots[p]], FV, segs);
-        for (size_t s = before; s < segs.size(); ++s) tasks.push_back(SegTaskH{p, (int)(s - before)});
+        for (size_t s = before; s < segs.size(); ++s) tasks.push_back(SegTask{p, (int)(s - before)});
         seg_first[p + 1] = (int)segs.size();
     }
     const int nfe = std::max(nf, 1);
@@ -530,7 +528,7 @@ static int table_match_bow_frame_impl(afv_table *t, const int32_t *slots, int ns
     const size_t fang_off = (check_orientation && nf) ? b.put(F->angle, (size_t)nf * sizeof(float)) : 0;
     const size_t fidx_off = b.put(F->nnodes > 0 ? F->seg_idx : nullptr, (size_t)(F->nnodes > 0 ? FV.seg_ptr[F->nnodes] : 0) * sizeof(int32_t));
     const size_t segs_off = b.put(segs.data(), segs.size() * sizeof(Seg));
-    const size_t tasks_off = b.put(tasks.data(), tasks.size() * sizeof(SegTaskH));
+    const size_t tasks_off = b.put(tasks.data(), tasks.size() * sizeof(SegTask));
     const size_t jobs_off = b.reserve((size_t)nslots * sizeof(DevMatchJob));
     const size_t binoff_off = b.reserve((size_t)nslots * sizeof(int));
     const size_t hist_off = b.reserve((size_t)nslots * 32 * sizeof(int));

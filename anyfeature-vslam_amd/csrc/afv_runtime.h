@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "afv_device.h"
+#include "afv_jobs.h"
 
 // ---- kernel launchers (k_*.hip) ----
 extern "C" void afv_launch_resize(const uint8_t *src, int sw, int sh, int spitch, size_t sframe, uint8_t *dst, int dw, int dh,
@@ -39,22 +40,6 @@ extern "C" void afv_launch_describe(const Geo *geo_dev, int blocks_per_frame, co
                                     int cap_per_frame, int *n_out, int *status, int frame_base, int nframes, hipStream_t stream);
 extern "C" void afv_launch_blur_level(const uint8_t *img, int w, int h, int pitch, uint8_t *out, hipStream_t stream);
 
-struct Seg { int s1, n1, s2, n2; };
-struct DevMatchJob {
-    const uint32_t *d1; const uint32_t *d2; int n1, n2, words;
-    const Seg *segs; int nseg; const int *idx1; const int *idx2;
-    const uint8_t *valid1; const uint8_t *valid2; const float *ang1; const float *ang2; int ang_stride;
-    float th, ratio; int check_ori, mode; int *out; int *nmatches;
-};
-struct DevTriJob {
-    DevMatchJob m;
-    const float *x1, *y1, *x2, *y2, *sigma2_2;
-    float F[9];
-    float ex, ey;
-    const int *row_seg;
-    const float *u_right1, *u_right2;  // mvuRight of either keyframe (NULL: monocular)
-    int only_stereo;
-};
 extern "C" void afv_launch_match_bow(const DevMatchJob *jobs, int njobs, hipStream_t stream);
 extern "C" void afv_launch_match_bow_seg(const DevMatchJob *jobs, int njobs, const void *tasks, int ntasks, int *hist, uint8_t *bins,
                                          const int *bin_off, int any_ori, hipStream_t stream);
@@ -69,17 +54,6 @@ extern "C" void afv_launch_match_tri(const DevTriJob *jobs, int njobs, int max_n
 extern "C" void afv_launch_match_l2(const float *d1, int n1, const float *d2, int n2, int dim, const uint8_t *v1,
                                     const uint8_t *v2, float th, float ratio, int *out, int *nmatches, hipStream_t stream);
 
-struct DevProjJob {
-    const uint32_t *fdesc; int n, words;
-    const float *x, *y, *size, *angle; const uint8_t *occupied; const float *inf;
-    float min_x, min_y, inv_w, inv_h; int cols, rows;
-    const int *cell_ptr, *cell_idx;
-    int nq; const uint32_t *qdesc; const uint8_t *qvalid;
-    const float *qu, *qv, *qr, *qmin, *qmax, *qangle; const uint8_t *qocc;
-    float th, ratio, tol, inv_tol; int check_ori, mode;
-    unsigned long long *keys; int *ncand; int *orilist; int *assign; int *nmatches;
-    const float *u_right, *q_ur, *q_er; int stereo_gate;
-};
 extern "C" void afv_launch_match_projection(const DevProjJob *jobs, int njobs, int max_nq, hipStream_t stream);
 extern "C" void afv_launch_match_fuse(const DevProjJob *jobs, int njobs, int max_nq, hipStream_t stream);
 extern "C" size_t afv_match_l2_scratch_bytes(int n1, int n2, int *ntiles_out, int *cols_per_tile_out);
@@ -90,11 +64,6 @@ extern "C" int afv_launch_match_l2_pairs(const float *desc, const int *nset, int
                                          int pair_base, float th, float ratio, int *out, int *nmatches, void *scratch, hipStream_t stream);
 extern "C" void afv_launch_match_init(const DevProjJob *jobs, int njobs, int max_nq, hipStream_t stream);
 
-struct DevVocab {
-    int k, L, nnodes, words;
-    const int *child_ptr, *child_idx;
-    const uint32_t *desc;
-};
 extern "C" void afv_launch_bow_transform(const DevVocab *v, const uint32_t *desc, int n, int levelsup, int *leaf_node,
                                          int *node_at_level, hipStream_t stream);
 struct afv_vocab {

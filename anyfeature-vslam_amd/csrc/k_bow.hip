@@ -5,12 +5,8 @@
 // descriptor: at each level the Hamming distance to every child of the current node (8 xor + 8 v_bcnt per child), first
 // minimum wins (strict <), until a node without children is reached.  Embarrassingly parallel, read-only tree.
 #include "afv_device.h"
+#include "afv_jobs.h"
 
-struct DevVocab {
-    int k, L, nnodes, words;  // words = dwords per node descriptor
-    const int *child_ptr, *child_idx;
-    const uint32_t *desc;
-};
 
 template <int W>
 __global__ __launch_bounds__(256) void k_bow_transform(DevVocab v, const uint32_t *__restrict__ desc, int n, int levelsup,

@@ -16,6 +16,7 @@
 #include <algorithm>
 
 #include "afv_device.h"
+#include "afv_jobs.h"
 
 
 #define MT 256
@@ -41,28 +42,7 @@
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
     } while (0)
 
-struct Seg {
-    int s1, n1, s2, n2;  // ranges into idx1/idx2 (or identity when the idx pointer is null)
-};
 
-struct DevMatchJob {
-    const uint32_t *d1;
-    const uint32_t *d2;
-    int n1, n2, words;  // words per descriptor (8 for ORB32)
-    const Seg *segs;
-    int nseg;
-    const int *idx1;
-    const int *idx2;
-    const uint8_t *valid1;
-    const uint8_t *valid2;
-    const float *ang1;
-    const float *ang2;
-    int ang_stride;  // in floats (1 for plain arrays, 7 for afv_keypoint::angle)
-    float th, ratio;
-    int check_ori, mode;
-    int *out;
-    int *nmatches;
-};
 
 __device__ __forceinline__ int rotation_bin(float a1, float a2) {
     // FeatureMatcher.cc:1587-1599, rotFactor = 1/30 (:1579-1585)
@@ -229,9 +209,6 @@ __global__ __launch_bounds__(MT) void k_match_bow(const DevMatchJob *__restrict_
 // so the nodes of a job are independent: each wavefront walks the rows of its node in the reference's order, the 64
 // lanes scan the node's columns, and the "taken" flags live in a per-wave LDS bitset indexed by the column's position
 // inside the node.  Orientation bins go to a per-job histogram (global atomics); k_match_bow_finish applies M6.
-struct SegTask {
-    int job, seg;
-};
 
 template <int W>
 __device__ void bow_segment(const DevMatchJob &J, const Seg S, uint32_t *s_taken, int *hist, uint8_t *bins) {
@@ -1100,15 +1077,6 @@ __global__ __launch_bounds__(RWT) void k_match_resolve_wg(const uint8_t *__restr
 }
 
 // ---------------- M4: SearchForTriangulation ----------------
-struct DevTriJob {
-    DevMatchJob m;  // valid1/valid2 = "has a map point" => skip
-    const float *x1, *y1, *x2, *y2, *sigma2_2;
-    float F[9];
-    float ex, ey;
-    const int *row_seg;  // [n1] index of the shared node holding the feature, -1 = none
-    const float *u_right1, *u_right2;  // mvuRight of either keyframe (NULL: monocular)
-    int only_stereo;                   // bOnlyStereo
-};
 
 // One thread per KF1 feature (row_seg = the shared node it belongs to, -1 if none): rows are independent here (vbMatched2 is
 // never set, FeatureMatcher.cc:681,724), so the whole job runs in one pass; the threads of a wave mostly sit in the same node

@@ -20,6 +20,7 @@
 //   2. k_proj_resolve — one wave per job replays the queries in order in speculative 64-query rounds (claim / replay on
 //      the feature-occupancy bitset); a query that runs out of keys is rescanned exactly, again with lanes over cells.
 #include "afv_device.h"
+#include "afv_jobs.h"
 
 #define PT 256
 #define PK 4
@@ -34,30 +35,6 @@
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
     } while (0)
 
-struct DevProjJob {
-    const uint32_t *fdesc;
-    int n, words;
-    const float *x, *y, *size, *angle;
-    const uint8_t *occupied;
-    const float *inf;
-    float min_x, min_y, inv_w, inv_h;
-    int cols, rows;
-    const int *cell_ptr, *cell_idx;  // grid CSR, cell = ix * rows + iy, ascending feature index inside a cell
-    int nq;
-    const uint32_t *qdesc;
-    const uint8_t *qvalid;
-    const float *qu, *qv, *qr, *qmin, *qmax, *qangle;
-    const uint8_t *qocc;
-    float th, ratio, tol, inv_tol;
-    int check_ori, mode;
-    unsigned long long *keys;  // projection: [nq] 64-byte records (see topk_query); initialization: [nq][IK] keys
-    int *ncand;                // [nq] candidates inside the window (geometry only)
-    int *orilist;              // [nq][2] accepted (slot, rotation bin) pairs
-    int *assign;               // [n] (projection) or [nq] (fuse, initialization)
-    int *nmatches;
-    const float *u_right, *q_ur, *q_er;  // stereo: mvuRight of the features, projected right coordinate / gate of the queries (NULL: mono)
-    int stereo_gate;                     // the projection searches skip features with u_right > 0 and |q_ur - u_right| > q_er (:114-119, :1367-1372)
-};
 
 __device__ __forceinline__ int key_dist(unsigned long long k) { return (int)(k >> 48); }
 __device__ __forceinline__ int key_idx(unsigned long long k) { return (int)(k & 0xffff); }
