@@ -10,6 +10,7 @@
 
 #include "../../include/afv_akaze.h"
 #include "../../include/afv_hip.h"
+#include "akz_jobs.h"
 
 extern "C" int afv_akz_launch_gauss(const void *src, int is_u8, int src_stride, size_t src_frame_stride, int w, int h, int nframes,
                                     const float *taps, int ksize, float *dst, hipStream_t st);
@@ -25,48 +26,11 @@ extern "C" int afv_akz_launch_fed_gauss(const float *Lt_in, float *lsm, const fl
 extern "C" int afv_akz_launch_hessian(const float *lsm, int w, int h, int nframes, int s, int two_kernels, float *dx, float *dy,
                                       float *Ldet, hipStream_t st);
 
-// mirrors of the kernel-side structs in k_akaze_detect.hip
-struct AkdLevel {
-    int w, h, octave, sigma_size;
-    float psize, ratio;
-    const float *ldet;
-    int cand_off, cand_cap, row_off;
-    float ginv;
-    int gw, gh, gcap, gcell_off, gelem_off;
-};
-struct AkdParams {
-    int nlevels, W, H;
-    float dthreshold, min_dthreshold;
-    AkdLevel lv[16];
-    int cand_stride, rows_stride, gcells, gelems, lds_bytes, entry_cap, kp_cap;
-};
-struct AkdState {
-    float4 *entry;
-    uint4 *cells;
-    int *gcnt, *ticket, *used, *chunk_cnt;
-    unsigned char *keep;
-    unsigned int epoch;
-};
 extern "C" void afv_akz_launch_candidates(const AkdParams *P, int nframes, unsigned long long *mask, int *row_start, int *cand, float *cand_resp,
                                           int *cand_count, int *status, hipStream_t st);
 extern "C" void afv_akz_launch_suppress(const AkdParams *P, const AkdState *S, int nframes, const int *cand, const float *cand_resp,
                                         const int *cand_count, const int *row_start,
                                         afv_keypoint *kps, int *kp_count, int *status, hipStream_t st);
-struct AksParams {
-    int nlevels, W, H, n_ini;
-    float h_x;
-    int quota[16];
-    int kp_cap, sel_cap, out_cap, M;
-};
-struct AkdLevelPlanes {
-    const float *lt, *lx, *ly;
-    int w, h, octave;
-    float fs;
-};
-struct AkdDescParams {
-    int nlevels, kp_cap, sel_cap, out_cap, desc_pitch;
-    AkdLevelPlanes lv[16];
-};
 extern "C" size_t afv_akz_select_lds_bytes(int M);
 extern "C" void afv_akz_launch_select(const AksParams *P, int nframes, const afv_keypoint *kps, const int *kp_count, int *lvl_idx,
                                       uint16_t *lvl_node, int *sel, int *sel_count, hipStream_t st);

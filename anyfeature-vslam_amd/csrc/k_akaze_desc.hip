@@ -9,21 +9,12 @@
 // Float sums are order sensitive, so every accumulation below runs in upstream's loop order inside one lane: the 42
 // orientation windows and the 29 MLDB grid cells are spread over lanes, their inner sums stay sequential.
 #include "afv_device.h"
+#include "akz_jobs.h"
 #include "../../include/afv_hip.h"
 #include "afv_quadtree.h"
 #include "akaze_tables.inc"
 
-#define AKS_MAX_LEVELS 16
 
-struct AksParams {
-    int nlevels, W, H, n_ini;
-    float h_x;
-    int quota[AKS_MAX_LEVELS];
-    int kp_cap;    // detected keypoints per frame (input stride)
-    int sel_cap;   // selected per (frame, level)
-    int out_cap;   // final keypoints per frame
-    int M;         // quadtree node capacity
-};
 
 struct AksPts {
     const afv_keypoint *k;
@@ -103,15 +94,6 @@ __global__ __launch_bounds__(QT_T) void k_akz_select(AksParams P, const afv_keyp
 }
 
 // ---------------- Compute_Descriptors ----------------
-struct AkdLevelPlanes {
-    const float *lt, *lx, *ly;  // [frame][h][w]; lx / ly hold the UNSCALED first derivatives
-    int w, h, octave;
-    float fs;                   // sigma_size: Lx = lx * fs, Ly = ly * fs (the in-place scaling of Compute_Multiscale_Derivatives)
-};
-struct AkdDescParams {
-    int nlevels, kp_cap, sel_cap, out_cap, desc_pitch;
-    AkdLevelPlanes lv[AKS_MAX_LEVELS];
-};
 
 #define AKZ_PI_D 3.14159265358979323846
 

@@ -17,33 +17,10 @@
 //     pair runs in the workgroup that finishes it.
 //  3. k_akz_refine_a / _b: the 2x2 sub-pixel solve and the ordered compaction over the slot space.
 #include "afv_device.h"
+#include "akz_jobs.h"
 #include "../../include/afv_hip.h"
 
-struct AkdLevel {
-    int w, h, octave, sigma_size;
-    float psize, ratio;      // esigma * derivative_factor, 2^octave
-    const float *ldet;       // [frame][h][w]
-    int cand_off;            // offset of this level's candidate slice inside a frame's candidate array
-    int cand_cap;
-    int row_off;             // offset of this level's rows inside a frame's row-count array
-    // uniform grid over the entries of this level (level-0 pixel coordinates).  The cell edge is at least twice the largest
-    // radius the grid is ever searched with (this level's and the next one's), so a search disc overlaps at most 2 x 2 cells;
-    // gcap = the number of strict 3 x 3 maxima that fit into a cell = the longest a cell list can get.
-    float ginv;              // 1 / cell edge
-    int gw, gh, gcap;
-    int gcell_off, gelem_off;  // offsets of this level's cells / list elements inside a frame's arrays
-};
 
-struct AkdParams {
-    int nlevels, W, H;
-    float dthreshold, min_dthreshold;
-    AkdLevel lv[16];
-    int cand_stride;   // candidates per frame (all levels)
-    int rows_stride;   // rows per frame (all levels)
-    int gcells, gelems;  // cells / list elements per frame (all levels)
-    int lds_bytes;       // list lengths (u8) of a level's own grid + length hints of the grid below, largest level pair
-    int entry_cap, kp_cap;
-};
 
 __device__ __forceinline__ int akd_fround(float x) { return (int)(x + 0.5f); }
 
@@ -268,16 +245,6 @@ __global__ __launch_bounds__(AKE_T) void k_akz_cand_emit(AkdParams P, const unsi
 //     the same list (the two levels below of the same frame), whose holders started earlier.
 // A replaced entry is not unlinked: its old list element is marked dead and a fresh element goes into the list of its new cell
 // (in the replacing candidate's level grid), so every list only grows and all commits of a round run in parallel.
-struct AkdState {
-    float4 *entry;            // [frame][entry_cap], slot-indexed: {x, y, response, level (integer bits)} - one 16-byte store per commit
-    uint4 *cells;             // [frame][gelems] {x, y, response, tag}; level c's lists start at lv[c].gelem_off
-    int *gcnt;                // [frame][gcells] published list lengths (hints, see above)
-    int *ticket;              // [8] per-XCD ticket counters, then [frame][16] committed candidates per level (all zeroed before the launch)
-    int *used;                // [frame][16] slots used per level
-    int *chunk_cnt;           // [frame][AKD_CHUNKS] refined keypoints per 1024-slot chunk
-    unsigned char *keep;      // [frame][entry_cap]  (set to 1 before the launch; the upper-level filter clears)
-    unsigned int epoch;       // 1 .. AKD_EPOCH_MAX, changes with every launch
-};
 
 #define AKD_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define AKD_T 1024
