@@ -1,8 +1,11 @@
-// akz_jobs.h - the parameter / state records of the AKAZE detection and description kernels: ONE definition for the kernels
-// (k_akaze_detect.hip, k_akaze_desc.hip) and the runtime that fills them (akaze_api.hip).
+// akz_jobs.h - the parameter / state records of the AKAZE kernels and their launchers: ONE definition / declaration for the kernels
+// (k_akaze.hip, k_akaze_detect.hip, k_akaze_desc.hip) and the runtime that drives them (akaze_api.hip): a record or a signature that drifts
+// is a compile error, not a silent mismatch.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include "../../include/afv_hip.h"  // afv_keypoint
 
 #define AKS_MAX_LEVELS 16
 
@@ -63,3 +66,30 @@ struct AkdDescParams {
     int nlevels, kp_cap, sel_cap, out_cap, desc_pitch;
     AkdLevelPlanes lv[AKS_MAX_LEVELS];
 };
+
+// ---- launchers (defined next to their kernels) ----
+extern "C" int afv_akz_launch_gauss(const void *src, int is_u8, int src_stride, size_t src_frame_stride, int w, int h, int nframes,
+                                    const float *taps, int ksize, float *dst, hipStream_t st);
+extern "C" void afv_akz_launch_kcontrast(const float *gsm, const uint8_t *gray, int src_stride, size_t src_frame_stride, const float *taps, int w,
+                                         int h, int nframes, float *modg, unsigned int *hmax_bits, int *hist, int nbins, float perc,
+                                         float *kcontrast, hipStream_t st);
+extern "C" void afv_akz_launch_halfsample(const float *src, int w, int h, float *dst, int dw, int dh, int nframes, hipStream_t st);
+extern "C" void afv_akz_launch_flow(const float *lsm, int w, int h, int nframes, const float *kcontrast, int octave, float *flow,
+                                    hipStream_t st);
+extern "C" void afv_akz_launch_nld_step(const float *Lt, const float *flow, int w, int h, int nframes, float tau, float *out, hipStream_t st);
+extern "C" int afv_akz_launch_fed_gauss(const float *Lt_in, float *lsm, const float *taps, int w, int h, int nframes, const float *kcontrast,
+                                        int octave, int nsteps, const float *tau, float *Lt_out, hipStream_t st);
+extern "C" int afv_akz_launch_hessian(const float *lsm, int w, int h, int nframes, int s, int two_kernels, float *dx, float *dy,
+                                      float *Ldet, hipStream_t st);
+
+extern "C" void afv_akz_launch_candidates(const AkdParams *P, int nframes, unsigned long long *mask, int *row_start, int *cand, float *cand_resp,
+                                          int *cand_count, int *status, hipStream_t st);
+extern "C" void afv_akz_launch_suppress(const AkdParams *P, const AkdState *S, int nframes, const int *cand, const float *cand_resp,
+                                        const int *cand_count, const int *row_start,
+                                        afv_keypoint *kps, int *kp_count, int *status, hipStream_t st);
+extern "C" size_t afv_akz_select_lds_bytes(int M);
+extern "C" void afv_akz_launch_select(const AksParams *P, int nframes, const afv_keypoint *kps, const int *kp_count, int *lvl_idx,
+                                      uint16_t *lvl_node, int *sel, int *sel_count, hipStream_t st);
+extern "C" void afv_akz_launch_describe(const AkdDescParams *P, int nframes, int max_out, const afv_keypoint *kps, const int *sel,
+                                        const int *sel_count, afv_keypoint *out_kps, uint8_t *out_desc, int *out_count, int *status,
+                                        hipStream_t st);

@@ -10,6 +10,7 @@
 // replaces baked into the staging coordinates) in LDS with coalesced row reads, and writes each output once.
 // Batch layout: plane[frame][y][x], frame stride = w * h of the level.
 #include "afv_device.h"
+#include "akz_jobs.h"
 #include "akz_recip.h"
 
 #define AT_W 64

@@ -5,6 +5,7 @@
 // descriptor: at each level the Hamming distance to every child of the current node (8 xor + 8 v_bcnt per child), first
 // minimum wins (strict <), until a node without children is reached.  Embarrassingly parallel, read-only tree.
 #include "afv_device.h"
+#include "afv_runtime.h"  // the launchers below are declared there: a signature that drifts is a compile error, not a silent ABI mismatch
 #include "afv_jobs.h"
 
 

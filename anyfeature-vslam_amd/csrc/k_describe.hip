@@ -14,6 +14,7 @@
 // pass + round-half-even(S/65536) only at the sampled locations.  A test that falls outside the level ROI reads the unblurred apron pixel, as in OpenCV
 // where only the ROI is blurred in place.  No blurred image ever touches HBM.
 #include "afv_device.h"
+#include "afv_runtime.h"  // the launchers below are declared there: a signature that drifts is a compile error, not a silent ABI mismatch
 
 // the 256 test pairs (x0, y0, x1, y1) as floats (FeatureExtractor.h:219-477): one 16-byte load per test, no conversions
 __device__ __constant__ __attribute__((aligned(16))) const float k_brief_pattern[1024] = {

@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "afv_device.h"
+#include "afv_runtime.h"  // the launchers below are declared there: a signature that drifts is a compile error, not a silent ABI mismatch
 
 typedef short short2v __attribute__((ext_vector_type(2)));
 

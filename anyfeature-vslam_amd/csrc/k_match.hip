@@ -16,6 +16,7 @@
 #include <algorithm>
 
 #include "afv_device.h"
+#include "afv_runtime.h"  // the launchers below are declared there: a signature that drifts is a compile error, not a silent ABI mismatch
 #include "afv_jobs.h"
 
 

@@ -14,6 +14,7 @@
 //     64-row rounds (claim table, stop at the first conflict); a row whose 4 keys are used up is rescanned exactly
 //     (64 lanes over the columns).
 #include "afv_device.h"
+#include "afv_runtime.h"  // the launchers below are declared there: a signature that drifts is a compile error, not a silent ABI mismatch
 
 #define L2T 256
 #define L2K 4

@@ -20,6 +20,7 @@
 // lives in LDS), double-buffered, one barrier per tile; every wavefront reads its A fragments with ds_read_b128 (row pitch 304 B =
 // 256 expanded bytes + the 32 index slots + 16: 16 consecutive rows start in 16 different bank quads).
 #include "afv_device.h"
+#include "afv_runtime.h"  // the launchers below are declared there: a signature that drifts is a compile error, not a silent ABI mismatch
 
 #define MQ_T 256
 #define NO_KEY 0x7fffffff

@@ -20,6 +20,7 @@
 //   2. k_proj_resolve — one wave per job replays the queries in order in speculative 64-query rounds (claim / replay on
 //      the feature-occupancy bitset); a query that runs out of keys is rescanned exactly, again with lanes over cells.
 #include "afv_device.h"
+#include "afv_runtime.h"  // the launchers below are declared there: a signature that drifts is a compile error, not a silent ABI mismatch
 #include "afv_jobs.h"
 
 #define PT 256

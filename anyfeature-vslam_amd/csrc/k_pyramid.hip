@@ -14,6 +14,7 @@
 // packed column pairs (v_pk_mul_lo_u16 + v_pk_mad_u16 per pair and row), the vertical pass is one v_dot2_u32_u16 per pixel on
 // the (upper, lower) pair with the 2^15 rounding term as its accumulator.
 #include "afv_device.h"
+#include "afv_runtime.h"  // the launchers below are declared there: a signature that drifts is a compile error, not a silent ABI mismatch
 
 #define RT_W 64
 #define RT_H 32

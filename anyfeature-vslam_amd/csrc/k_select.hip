@@ -22,6 +22,7 @@
 #include <algorithm>
 
 #include "afv_device.h"
+#include "afv_runtime.h"  // the launchers below are declared there: a signature that drifts is a compile error, not a silent ABI mismatch
 
 // Two instantiations: ST = 256 threads per workgroup for batches (what a batch costs is set by how many (frame, level) workgroups a CU
 // holds: 29 KB of LDS, <= 96 VGPRs), ST = 1024 for the small-batch path (one frame: the eight workgroups of a frame are alone on the
