@@ -63,7 +63,7 @@ class TriJob(C.Structure):
 
 class TableTriJob(C.Structure):
     _fields_ = [("F12", C.c_float * 9), ("ex", C.c_float), ("ey", C.c_float), ("has_mp1", C.c_void_p), ("has_mp2", C.c_void_p),
-                ("th_low", C.c_float)]
+                ("th_low", C.c_float), ("only_stereo", C.c_int32)]
 
 
 class FrameView(C.Structure):
@@ -105,6 +105,7 @@ SYMBOLS = {
     "afv_table_set": (_i, [_vp, _i, _vp, _vp, _i]),
     "afv_table_set_featvec": (_i, [_vp, _i, _vp, _vp, _vp, _i]),
     "afv_table_set_geometry": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "afv_table_set_u_right": (_i, [_vp, _i, _vp]),
     "afv_table_set_valid": (_i, [_vp, _i, _vp]),
     "afv_table_device_ptrs": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "afv_table_sync_counts": (_i, [_vp]),

@@ -43,7 +43,7 @@ struct afv_table {
     float *d_angle = nullptr;   // [nsets][cap]
     int32_t *d_n = nullptr;     // [nsets]
     int32_t *d_idx = nullptr;   // [nsets][cap] FeatureVector feature indices in node order (afv_table_set_featvec), lazily allocated
-    float *d_geo = nullptr;     // [3][nsets][cap]: x, y, sigma2 (afv_table_set_geometry), lazily allocated
+    float *d_geo = nullptr;     // [4][nsets][cap]: x, y, sigma2, mvuRight (afv_table_set_geometry / _u_right; -1 = monocular), lazily allocated
     uint8_t *d_valid = nullptr; // [nsets][cap] "map point exists && !isBad()" (afv_table_set_valid), lazily allocated, default 1
     std::vector<int32_t> h_n;
     std::vector<HostFeatVec> fv;
@@ -188,13 +188,25 @@ extern "C" int afv_table_set_geometry(afv_table *t, int set, const float *x, con
     afv_ctx *c = t->c;
     HIPCHK(c, hipSetDevice(c->device));
     const size_t plane = (size_t)t->nsets * t->cap;
-    if (!t->d_geo) HIPCHK(c, hipMalloc(&t->d_geo, 3 * plane * sizeof(float)));
+    if (!t->d_geo) HIPCHK(c, hipMalloc(&t->d_geo, 4 * plane * sizeof(float)));
     const int n = t->h_n[set];
     t->has_geo[set] = 1;
     if (n == 0) return AFV_OK;
-    const float *src[3] = {x, y, sigma2};
-    for (int k = 0; k < 3; ++k)
+    const std::vector<float> mono((size_t)n, -1.0f);  // a keyframe is monocular until afv_table_set_u_right says otherwise
+    const float *src[4] = {x, y, sigma2, mono.data()};
+    for (int k = 0; k < 4; ++k)
         HIPCHK(c, hipMemcpy(t->d_geo + k * plane + (size_t)set * t->cap, src[k], (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    return AFV_OK;
+}
+
+extern "C" int afv_table_set_u_right(afv_table *t, int set, const float *u_right) {
+    if (!t || set < 0 || set >= t->nsets || !u_right) return AFV_EINVAL;
+    if (!t->d_geo || !t->has_geo[set]) return AFV_EINVAL;  // after afv_table_set_geometry of the same slot
+    afv_ctx *c = t->c;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t plane = (size_t)t->nsets * t->cap;
+    const int n = t->h_n[set];
+    if (n > 0) HIPCHK(c, hipMemcpy(t->d_geo + 3 * plane + (size_t)set * t->cap, u_right, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
     return AFV_OK;
 }
 
@@ -304,13 +316,13 @@ extern "C" int afv_table_clone(const afv_table *src, afv_table *dst) {
         HIPCHK(c, hipSetDevice(c->device));
         const size_t plane = (size_t)dst->nsets * dst->cap;
         if (src->d_idx && !dst->d_idx) HIPCHK(c, hipMalloc(&dst->d_idx, plane * sizeof(int32_t)));
-        if (src->d_geo && !dst->d_geo) HIPCHK(c, hipMalloc(&dst->d_geo, 3 * plane * sizeof(float)));
+        if (src->d_geo && !dst->d_geo) HIPCHK(c, hipMalloc(&dst->d_geo, 4 * plane * sizeof(float)));
         if (src->d_valid && !dst->d_valid) HIPCHK(c, hipMalloc(&dst->d_valid, plane));
         HIPCHK(c, hipMemcpy(dst->d_desc, src->d_desc, plane * 32, hipMemcpyDefault));
         HIPCHK(c, hipMemcpy(dst->d_angle, src->d_angle, plane * sizeof(float), hipMemcpyDefault));
         HIPCHK(c, hipMemcpy(dst->d_n, src->d_n, (size_t)dst->nsets * sizeof(int32_t), hipMemcpyDefault));
         if (src->d_idx) HIPCHK(c, hipMemcpy(dst->d_idx, src->d_idx, plane * sizeof(int32_t), hipMemcpyDefault));
-        if (src->d_geo) HIPCHK(c, hipMemcpy(dst->d_geo, src->d_geo, 3 * plane * sizeof(float), hipMemcpyDefault));
+        if (src->d_geo) HIPCHK(c, hipMemcpy(dst->d_geo, src->d_geo, 4 * plane * sizeof(float), hipMemcpyDefault));
         if (src->d_valid) HIPCHK(c, hipMemcpy(dst->d_valid, src->d_valid, plane, hipMemcpyDefault));
         else if (dst->d_valid) HIPCHK(c, hipMemset(dst->d_valid, 1, plane));
         for (int s = 0; s < dst->nsets; ++s) {  // nothing of the destination's previous content survives
@@ -665,8 +677,9 @@ static int table_match_tri_impl(afv_table *t, const int32_t *pair_a, const int32
         T.ex = geo[p].ex;
         T.ey = geo[p].ey;
         T.row_seg = reinterpret_cast<const int *>(c->d_match + rowseg_off[p]);
-        T.u_right1 = T.u_right2 = nullptr;  // the table holds monocular keyframes (no mvuRight plane)
-        T.only_stereo = 0;
+        T.u_right1 = t->d_geo + 3 * plane + (size_t)a * cap;  // -1 everywhere for a monocular keyframe (afv_table_set_geometry)
+        T.u_right2 = t->d_geo + 3 * plane + (size_t)bb * cap;
+        T.only_stereo = geo[p].only_stereo != 0;
     }
     HIPCHK(c, hipMemcpyAsync(c->d_match, b.h.data(), in_bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_match + out_off, 0xff, (size_t)npairs * cap * sizeof(int), c->stream));
@@ -838,7 +851,7 @@ extern "C" int afv_table_broadcast(afv_comm *m, afv_table *t, int root, float *e
         if (flags[3] < 1) return AFV_EINVAL;
         const size_t plane = (size_t)t->nsets * t->cap;
         if (flags[0] && !t->d_idx) HIPCHK(c, hipMalloc(&t->d_idx, plane * sizeof(int32_t)));
-        if (flags[1] && !t->d_geo) HIPCHK(c, hipMalloc(&t->d_geo, 3 * plane * sizeof(float)));
+        if (flags[1] && !t->d_geo) HIPCHK(c, hipMalloc(&t->d_geo, 4 * plane * sizeof(float)));
         if (flags[2] && !t->d_valid) HIPCHK(c, hipMalloc(&t->d_valid, plane));
         int32_t *d_meta = nullptr;
         HIPCHK(c, hipMalloc(&d_meta, (size_t)flags[3] * sizeof(int32_t)));
@@ -849,7 +862,7 @@ extern "C" int afv_table_broadcast(afv_comm *m, afv_table *t, int root, float *e
         if (!rc) rc = afv_comm_broadcast(m, t->d_angle, plane * sizeof(float), root, c->stream);
         if (!rc) rc = afv_comm_broadcast(m, t->d_n, (size_t)t->nsets * sizeof(int32_t), root, c->stream);
         if (!rc && flags[0]) rc = afv_comm_broadcast(m, t->d_idx, plane * sizeof(int32_t), root, c->stream);
-        if (!rc && flags[1]) rc = afv_comm_broadcast(m, t->d_geo, 3 * plane * sizeof(float), root, c->stream);
+        if (!rc && flags[1]) rc = afv_comm_broadcast(m, t->d_geo, 4 * plane * sizeof(float), root, c->stream);
         if (!rc && flags[2]) rc = afv_comm_broadcast(m, t->d_valid, plane, root, c->stream);
         if (!rc) rc = afv_comm_broadcast(m, d_meta, (size_t)flags[3] * sizeof(int32_t), root, c->stream);
         if (rc) {

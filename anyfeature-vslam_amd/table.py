@@ -98,9 +98,13 @@ class DescriptorTable:
         self.ctx.check(self.lib.afv_table_set_featvec(self.handle, int(slot), ptr(node_id), ptr(seg_ptr), ptr(seg_idx), len(node_id)),
                        "afv_table_set_featvec")
 
-    def set_geometry(self, slot, x, y, sigma2):
+    def set_geometry(self, slot, x, y, sigma2, u_right=None):
+        """mvKeysUn positions and GetKeyPt1DSigma2 of a slot; u_right = KeyFrame::mvuRight of a stereo keyframe (None: monocular)"""
         x, y, s = (np.ascontiguousarray(v, np.float32) for v in (x, y, sigma2))
         self.ctx.check(self.lib.afv_table_set_geometry(self.handle, int(slot), ptr(x), ptr(y), ptr(s)), "afv_table_set_geometry")
+        if u_right is not None:
+            u = np.ascontiguousarray(u_right, np.float32)
+            self.ctx.check(self.lib.afv_table_set_u_right(self.handle, int(slot), ptr(u)), "afv_table_set_u_right")
 
     def set_valid(self, slot, valid):
         """valid[i] = feature i has a good map point (None = all valid); honoured by match_bow"""
@@ -209,7 +213,7 @@ class DescriptorTable:
                                                           int(bool(check_orientation)), ptr(m), ptr(nm)), "afv_table_match_bow_frame")
         return m, nm
 
-    def match_triangulation(self, pair_a, pair_b, F12, epipoles, th_low, has_mp1=None, has_mp2=None):
+    def match_triangulation(self, pair_a, pair_b, F12, epipoles, th_low, has_mp1=None, has_mp2=None, only_stereo=False):
         """SearchForTriangulation per pair.  F12: [npairs, 9] (row-major), epipoles: [npairs, 2]; has_mp1/2: per pair uint8
         arrays or None"""
         pa, pb = _i32(pair_a), _i32(pair_b)
@@ -223,6 +227,7 @@ class DescriptorTable:
             for k in range(9):
                 j.F12[k] = float(F12[p, k])
             j.ex, j.ey, j.th_low = float(ep[p, 0]), float(ep[p, 1]), float(th_low)
+            j.only_stereo = int(bool(only_stereo))
             for name, src in (("has_mp1", has_mp1), ("has_mp2", has_mp2)):
                 if src is not None and src[p] is not None:
                     a = np.ascontiguousarray(src[p], np.uint8)

@@ -207,11 +207,14 @@ typedef struct {
 } afv_frame_view;
 int afv_table_match_bow_frame(afv_table *t, const int32_t *slots, int nslots, const afv_frame_view *frame, float th_low, float nnratio,
                               int check_orientation, int32_t *match_f, int32_t *nmatches);
-/* SearchForTriangulation (FeatureMatcher.cc:662-790; monocular keyframes: the table has no mvuRight plane) of npairs slot pairs
+/* SearchForTriangulation (FeatureMatcher.cc:662-790, stereo branches included: afv_table_set_u_right) of npairs slot pairs
  * over the stored FeatureVectors and the per-keyframe geometry stored with afv_table_set_geometry (mvKeysUn[i].pt and KeyFrame::GetKeyPt1DSigma2(i)): what
  * LocalMapping::CreateNewMapPoints does against <= 20 neighbours (src/LocalMapping.cc:238-297).  Per pair only the
  * fundamental matrix, the epipole and the "already has a map point" masks travel. */
 int afv_table_set_geometry(afv_table *t, int set, const float *x, const float *y, const float *sigma2);
+/* KeyFrame::mvuRight of a stereo keyframe (>= 0: the keypoint has a right-image match; FeatureMatcher.cc:705, :727), after
+ * afv_table_set_geometry of the same slot, which marks every feature monocular (-1). */
+int afv_table_set_u_right(afv_table *t, int set, const float *u_right);
 /* afv_table_set (a recycled slot) forgets the slot's FeatureVector, geometry and validity mask: afv_table_match_bow /
  * afv_table_match_triangulation return AFV_EINVAL for a slot that holds features but lacks what the call needs, instead of
  * answering "no matches". */
@@ -221,6 +224,7 @@ typedef struct {
     const uint8_t *has_mp1;  /* [n_a] feature already has a map point => skipped (NULL = none has) */
     const uint8_t *has_mp2;  /* [n_b] */
     float th_low;            /* FeatureMatcher::TH_LOW */
+    int32_t only_stereo;     /* bOnlyStereo (FeatureMatcher.cc:707-709, :729-731); 0 for monocular maps */
 } afv_table_tri_job;
 int afv_table_match_triangulation(afv_table *t, const int32_t *pair_a, const int32_t *pair_b, const afv_table_tri_job *geo, int npairs,
                                   int32_t *match12 /*[npairs][cap]: idx_b | -1*/, int32_t *nmatches);

@@ -241,6 +241,30 @@ def test_table_triangulation_pairs(afv, oracle, tbl):
         assert np.array_equal(got, np.asarray(want)[:na]), p
         total += wn
     assert total > 300
+    # stereo keyframes (FeatureMatcher.cc:705-709, :727-731, :741): every second slot gets mvuRight for about half of its features; the
+    # epipole-on-a-feature pairs then only lose their mono-mono candidates, and bOnlyStereo leaves the stereo-stereo ones
+    urs = []
+    for k in range(K):
+        n = int(cnt[k])
+        ur = None
+        if k % 2 == 0 and n:
+            ur = np.where(s.lcg_bytes(1000 + k, n) > 120, geo[k][0] - np.float32(11.0), np.float32(-1.0)).astype(np.float32)
+        urs.append(ur)
+        table.set_geometry(k, *geo[k], u_right=ur)
+    changed = 0
+    for only in (False, True):
+        m2, nm2 = table.match_triangulation(pa, pb, F, ep, TH, mp1, mp2, only_stereo=only)
+        for p in range(K):
+            a, b = int(pa[p]), int(pb[p])
+            na, nb = int(cnt[a]), int(cnt[b])
+            pts1 = np.stack([geo[a][0], geo[a][1]], 1) if na else np.zeros((0, 2), np.float32)
+            pts2 = np.stack([geo[b][0], geo[b][1]], 1) if nb else np.zeros((0, 2), np.float32)
+            want, wn = oracle.search_for_triangulation(t[a, :na], t[b, :nb], pts1, pts2, geo[b][2], F[p].reshape(3, 3), ep[p], fvs[a], fvs[b],
+                                                       mp1[p], mp2[p], TH, u_right1=urs[a], u_right2=urs[b], only_stereo=only)
+            assert nm2[p] == wn, (only, p, nm2[p], wn)
+            assert np.array_equal(m2[p, :na], np.asarray(want)[:na]), (only, p)
+            changed += int(not np.array_equal(m2[p, :na], m[p, :na]))
+    assert changed > 0  # the stereo branches changed some pair's outcome
     table.close()
     ctx.close()
 
