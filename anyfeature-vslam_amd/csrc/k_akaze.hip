@@ -34,6 +34,30 @@ __device__ __forceinline__ int akz_reflect(int p, int n) {  // BORDER_REFLECT_10
     return p;
 }
 
+// ---- helpers of the lane = column kernels (k_akz_contrast_modg, k_akz_fed_gauss) ----
+typedef float akz_f2 __attribute__((ext_vector_type(2)));
+typedef float akz_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float akz_from_left(float v) {   // lane i <- lane i - 1 (DPP wave_shr:1; lane 0 reads 0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float akz_from_right(float v) {  // lane i <- lane i + 1 (DPP wave_shl:1; lane 63 reads 0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+
+// NOUT outputs of the symmetric 5-tap filter from a window of NOUT + 4 values, two at a time: out[k] = k0 v[k+2] + k1 (v[k+3] + v[k+1]) + k2 (v[k+4] + v[k])
+template <int NOUT>
+__device__ __forceinline__ void akz_gauss5_window(const float *v, float k0, float k1, float k2, float *out) {
+#pragma unroll
+    for (int k = 0; k < NOUT; k += 2) {
+        const akz_f2 c = {v[k + 2], v[k + 3]}, p1 = {v[k + 3], v[k + 4]}, m1 = {v[k + 1], v[k + 2]}, p2 = {v[k + 4], v[k + 5]}, m2 = {v[k], v[k + 1]};
+        akz_f2 a = k0 * c;
+        a += k1 * (p1 + m1);
+        a += k2 * (p2 + m2);
+        out[k] = a.x;
+        out[k + 1] = a.y;
+    }
+}
+
 // stage a (AT_W + 2R) x (AT_H + 2R) float tile around (x0, y0); REFLECT: reflect-101 coordinates, else clamped (replicate)
 template <int R, bool REFLECT>
 __device__ __forceinline__ void akz_stage(const float *__restrict__ src, int w, int h, int x0, int y0, float *lds) {
@@ -174,96 +198,153 @@ __global__ __launch_bounds__(AKZ_T) void k_akz_modg(const float *__restrict__ gs
 }
 
 // pass 1 without the detour through HBM: the sigma = 1 image (k_akz_gauss<2, true>'s expressions: convertTo(1/255) + 5 x 5 Gaussian,
-// BORDER_REPLICATE) of the tile and one ring around it stays in LDS, k_akz_modg's expressions run on it.  Only pixels whose whole
-// 3 x 3 neighbourhood is inside the image get a magnitude, so nothing of the ring that lies outside the image is ever used.
+// BORDER_REPLICATE) of the tile and one ring around it never leaves the workgroup, k_akz_modg's expressions run on it.  Only pixels whose
+// whole 3 x 3 neighbourhood is inside the image get a magnitude, so nothing of the ring that lies outside the image is ever used.
+// Shape (round 4, after k_akz_fed_gauss): 64 x 32 tile, lane = tile column, a wavefront owns a band of 8 rows; the row pass works on
+// (source row, run of 16 columns) items with 128-bit LDS reads and packed fp32 arithmetic and writes its result TRANSPOSED, so that the
+// column pass is four 128-bit reads per lane and leaves the 10 smoothed rows a band's Scharr stencils need in registers; the left /
+// right neighbours are DPP shifts, the two ring columns (tile columns -1 and 64) a small job of 20 lanes per wavefront.  (The first
+// form staged, filtered and differentiated through three LDS planes with run-time item mappings: 183 us per 64 frames of 1280 x 720.)
+#define AKZ_CM_PS 72   // source tile pitch in BYTES (columns x0 - 4 .. x0 + 67 as 18 dwords)
+#define AKZ_CM_PT 44   // transposed row-pass plane: [column 0 .. 65][source row 0 .. 37]; 44 mod 32 = 12 as above
+#define AKZ_CM_ROWS 38
 __global__ __launch_bounds__(AKZ_T) void k_akz_contrast_modg(const uint8_t *__restrict__ gray, int src_stride, size_t src_frame_stride, int w, int h,
                                                              int nframes, const float *__restrict__ taps, float *__restrict__ modg,
                                                              unsigned int *__restrict__ hmax_bits) {
-    constexpr int R = 3;                          // Gaussian radius 2 + the Scharr ring
-    constexpr int LW = AT_W + 2 * R + 2, LH = AT_H + 2 * R, LP = LW | 1;  // 70 x 38 source pixels, staged as 72 columns from x0 - 4 (dwords)
-    constexpr int PW = AT_W + 2, PH = AT_H + 2;   // smoothed tile + ring: 66 x 34
-    constexpr int RUNX = 11, RUNY = 9;            // 6 x 11 = 66 columns, 4 x 9 >= 34 rows
-    __shared__ float s_in[LP * LH];
-    __shared__ float s_row[PW * LH];
-    __shared__ float s_p[PW * PH];
+    constexpr int PS = AKZ_CM_PS, PT = AKZ_CM_PT, SR = AKZ_CM_ROWS;
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[SR * PS];  // source rows y0 - 3 .., byte column = image column - (x0 - 4) (replicate coordinates)
+    __shared__ __attribute__((aligned(16))) float s_t[66 * PT];      // row-pass result of tile column c - 1 at [c][source row]
+    __shared__ float s_ring[4][2][10];
     __shared__ unsigned int s_max;
     AKZ_TILE(AT_W, AT_H)
-    if (threadIdx.x == 0) s_max = 0;
+    const int tid = threadIdx.x, tx = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6) & 3;
+    const int r0 = wv * 8;
+    if (tid == 0) s_max = 0;
     const float k0 = taps[2], k1 = taps[3], k2 = taps[4];
     const uint8_t *src = gray + (size_t)f * src_frame_stride;
     const float a = (float)(1.0 / 255.0);
-    if (x0 - R - 1 >= 0 && x0 - R - 1 + LW <= w) {  // no column clamped: four pixels per load
-        for (int i = threadIdx.x; i < (LW / 4) * LH; i += AKZ_T) {
-            const int ly = i / (LW / 4), q = i - ly * (LW / 4);
-            const int gy = akz_clamp(y0 - R + ly, h);
-            uint32_t v;
-            __builtin_memcpy(&v, src + (size_t)gy * src_stride + (x0 - R - 1 + 4 * q), 4);
-            float *d = &s_in[ly * LP + 4 * q];
-            d[0] = (float)(v & 0xffu) * a;
-            d[1] = (float)((v >> 8) & 0xffu) * a;
-            d[2] = (float)((v >> 16) & 0xffu) * a;
-            d[3] = (float)(v >> 24) * a;
+    // ---- staging: the u8 pixels as they are (2.7 KB instead of 11.5 KB of floats: more workgroups per CU); converted where they are read
+    if (x0 - 4 >= 0 && x0 + 68 <= w) {  // no column clamped (all but the first and last tile column): 38 rows x 18 aligned dwords from x0 - 4
+        uint32_t v[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int i = tid + k * AKZ_T;
+            const int py = min(i / 18, SR - 1), q = i - (i / 18) * 18;
+            v[k] = *reinterpret_cast<const uint32_t *>(src + (size_t)akz_clamp(y0 - 3 + py, h) * src_stride + (x0 - 4 + 4 * q));
         }
-    } else {
-        for (int i = threadIdx.x; i < LW * LH; i += AKZ_T) {
-            const int ly = i / LW, lx = i - ly * LW;
-            const int gx = akz_clamp(x0 - R - 1 + lx, w), gy = akz_clamp(y0 - R + ly, h);
-            s_in[ly * LP + lx] = (float)src[(size_t)gy * src_stride + gx] * a;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int i = tid + k * AKZ_T;
+            const int py = i / 18, q = i - py * 18;
+            if (py < SR) *reinterpret_cast<uint32_t *>(&s_src[py * PS + 4 * q]) = v[k];
         }
+    } else {  // replicate coordinates: byte gathers, columns x0 - 3 .. x0 + 66 at byte columns 1 .. 70
+        const unsigned cxb = (unsigned)akz_clamp(x0 - 3 + tx, w);
+        uint8_t v[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            const int py = wv + 4 * k;
+            if (py < SR) v[k] = (src + (size_t)akz_clamp(y0 - 3 + py, h) * src_stride)[cxb];
+        }
+        uint8_t e = 0;
+        const int ey = tid / 6, ex = tid - ey * 6;  // the six columns 64 .. 69: one element per thread (228 of them)
+        if (tid < SR * 6) e = src[(size_t)akz_clamp(y0 - 3 + ey, h) * src_stride + akz_clamp(x0 - 3 + 64 + ex, w)];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            const int py = wv + 4 * k;
+            if (py < SR) s_src[py * PS + 1 + tx] = v[k];
+        }
+        if (tid < SR * 6) s_src[ey * PS + 1 + 64 + ex] = e;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < LH * (PW / RUNX); i += AKZ_T) {  // rows: item = (source row, run of 11 columns)
-        const int g = i / LH, ly = i - g * LH;
-        const float *c = &s_in[ly * LP + g * RUNX + 1];  // smoothed column j of the ring-extended tile sits on staged columns j + 1 .. j + 5
-        float v[RUNX + 4];
+    // ---- row pass: items 0 .. 151 = (source row, run of 16 output columns 16 g .. 16 g + 15), items 152 .. 189 = the columns 64, 65 of a row.
+    //      Window value j = source column 16 g + j = byte 16 g + j + 1 of the row: convertTo(CV_32F, 1 / 255) as (float)byte * a
+    if (tid < SR * 4) {
+        const int g = tid / SR, py = tid - g * SR;
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(&s_src[py * PS + 16 * g]);
+        uint32_t d[6];
 #pragma unroll
-        for (int t = 0; t < RUNX + 4; ++t) v[t] = c[t];
+        for (int k = 0; k < 6; ++k) d[k] = q[k];
+        float v[22], o[16];
 #pragma unroll
-        for (int t = 0; t < RUNX; ++t) {
-            float r = k0 * v[t + 2];
-            r += k1 * (v[t + 3] + v[t + 1]);
-            r += k2 * (v[t + 4] + v[t]);
-            s_row[ly * PW + g * RUNX + t] = r;
-        }
+        for (int j = 0; j < 20; ++j) v[j] = (float)((d[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 0xffu) * a;
+        v[20] = v[21] = 0.0f;
+        akz_gauss5_window<16>(v, k0, k1, k2, o);
+        float *dst = &s_t[(16 * g) * PT + py];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dst[k * PT] = o[k];
+    } else if (tid < SR * 5) {
+        const int py = tid - SR * 4;
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(&s_src[py * PS + 64]);
+        const uint32_t d0 = q[0], d1 = q[1];  // bytes 64 .. 71: source columns 63 .. 70
+        float v[8], o[2];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) v[j] = (float)(((j + 1 < 4 ? d0 : d1) >> (8 * ((j + 1) & 3))) & 0xffu) * a;
+        v[6] = v[7] = 0.0f;
+        akz_gauss5_window<2>(v, k0, k1, k2, o);
+        s_t[64 * PT + py] = o[0];
+        s_t[65 * PT + py] = o[1];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < PW * 4; i += AKZ_T) {  // columns: item = (column, run of 9 rows)
-        const int g = i / PW, lx = i - g * PW;
-        const int l0 = g * RUNY, n = min(RUNY, PH - l0);
-        const float *c = &s_row[l0 * PW + lx];
-        float v[RUNY + 4];
+    // ---- column pass: smoothed rows r0 - 1 .. r0 + 8 of tile column tx (row-pass column tx + 1; source rows r0 .. r0 + 13)
+    float vc[10], vl[10], vr[10];
+    {
+        const akz_f4 *q = reinterpret_cast<const akz_f4 *>(&s_t[(tx + 1) * PT + r0]);
+        float v[16];
 #pragma unroll
-        for (int t = 0; t < RUNY + 4; ++t) v[t] = c[min(t, n + 3) * PW];
-#pragma unroll
-        for (int t = 0; t < RUNY; ++t) {
-            float r = k0 * v[t + 2];
-            r += k1 * (v[t + 3] + v[t + 1]);
-            r += k2 * (v[t + 4] + v[t]);
-            if (t < n) s_p[(l0 + t) * PW + lx] = r;
+        for (int k = 0; k < 4; ++k) {
+            const akz_f4 t = q[k];
+            v[4 * k] = t.x, v[4 * k + 1] = t.y, v[4 * k + 2] = t.z, v[4 * k + 3] = t.w;
         }
+        akz_gauss5_window<10>(v, k0, k1, k2, vc);
     }
-    __syncthreads();
+    if (tx < 20) {  // the ring columns -1 (row-pass column 0) and 64 (column 65), ten rows each
+        const int side = tx >= 10, m = tx - 10 * side;
+        const float *c = &s_t[(side ? 65 : 0) * PT + r0 + m];
+        float rr = k0 * c[2];
+        rr += k1 * (c[3] + c[1]);
+        rr += k2 * (c[4] + c[0]);
+        s_ring[wv][side][m] = rr;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // same wavefront: LDS operations execute in order, the compiler must not reorder
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+    for (int m = 0; m < 10; ++m) {
+        const float dl = akz_from_left(vc[m]), dr = akz_from_right(vc[m]);
+        vl[m] = tx == 0 ? s_ring[wv][0][m] : dl;
+        vr[m] = tx == 63 ? s_ring[wv][1][m] : dr;
+    }
+    // ---- Scharr + magnitude of the band rows (k_akz_modg's expressions), frame maximum
     float *out = modg + (size_t)f * w * h;
+    const int gx = x0 + tx;
+    const bool col_ok = gx >= 1 && gx < w - 1;
     unsigned int mx = 0;
-    for (int i = threadIdx.x; i < AT_W * AT_H; i += AKZ_T) {
-        const int ly = i / AT_W, lx = i - ly * AT_W;
-        const int gx = x0 + lx, gy = y0 + ly;
+    float t[10], u[10];
+#pragma unroll
+    for (int m = 0; m < 10; ++m) {
+        t[m] = vr[m] - vl[m];
+        u[m] = 10.0f * vc[m] + 3.0f * (vl[m] + vr[m]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int gy = y0 + r0 + j;
         if (gx < w && gy < h) {
-            float m = 0.0f;
-            if (gx >= 1 && gx < w - 1 && gy >= 1 && gy < h - 1) {  // the histogram skips the 1 px border
-                const float *c = &s_p[(ly + 1) * PW + lx + 1];
-                const float lxv = akz_scharr_x(c, PW), lyv = akz_scharr_y(c, PW);
-                m = sqrtf(lxv * lxv + lyv * lyv);
+            float mg = 0.0f;
+            if (col_ok && gy >= 1 && gy < h - 1) {  // the histogram skips the 1 px border
+                const float lxv = 10.0f * t[j + 1] + 3.0f * (t[j] + t[j + 2]);
+                const float lyv = u[j + 2] - u[j];
+                mg = sqrtf(lxv * lxv + lyv * lyv);
             }
-            out[(size_t)gy * w + gx] = m;
-            mx = max(mx, __float_as_uint(m));  // m >= 0: the bit pattern orders like the value
+            out[(size_t)gy * w + gx] = mg;
+            mx = max(mx, __float_as_uint(mg));  // mg >= 0: the bit pattern orders like the value
         }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned int)__shfl_xor((int)mx, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(&s_max, mx);
+    if (tx == 0) atomicMax(&s_max, mx);
     __syncthreads();
-    if (threadIdx.x == 0 && s_max) atomicMax(&hmax_bits[f], s_max);
+    if (tid == 0 && s_max) atomicMax(&hmax_bits[f], s_max);
 }
 
 // pass 2: histogram of the non-zero magnitudes (bins depend on the frame maximum)
@@ -381,12 +462,6 @@ struct AkzTau {
     float t[AKZ_FED_MAX];
 };
 #define AKZ_FT 512
-__device__ __forceinline__ float akz_from_left(float v) {   // lane i <- lane i - 1 (DPP wave_shr:1; lane 0 reads 0)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float akz_from_right(float v) {  // lane i <- lane i + 1 (DPP wave_shl:1; lane 63 reads 0)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
-}
 
 // Shaped by what rocprofv3 said about its first form (round 3's k_akz_fed_fused: a (64 - 2N) x 48 tile, the Gaussian as LDS-tiled row /
 // column passes with run-time item mappings, the conductivity and the FED steps per band of 8 rows in registers): that one was bound by
@@ -406,27 +481,11 @@ __device__ __forceinline__ float akz_from_right(float v) {  // lane i <- lane i 
 // Every pixel sees exactly the per-step arithmetic of k_akz_gauss / k_akz_flow / k_akz_nld_step (zero flux across the image border;
 // out-of-image halo cells never reach an output), so the result is bit-identical to the step-by-step path (-ffp-contract=off); only the
 // traffic changes: 12 B/px per level instead of 8 + 8 + 12 B/px per step.
-typedef float akz_f2 __attribute__((ext_vector_type(2)));
-typedef float akz_f4 __attribute__((ext_vector_type(4)));
 #define AKZ_G_PS 76  // source tile pitch: 68 columns used; 76 mod 32 = 12 spreads the 128-bit reads of lanes that differ in the row
 #define AKZ_G_PT 76  // transposed row-pass plane: [column][source row + 1], 72 entries used
 #define AKZ_G_ROWS 70
 #define AKZ_G_LDS_FLOATS (AKZ_G_ROWS * AKZ_G_PS + 64 * AKZ_G_PT)  // 40736 B: four workgroups per CU
 #define AKZ_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-
-// NOUT outputs of the symmetric 5-tap filter from a window of NOUT + 4 values, two at a time: out[k] = k0 v[k+2] + k1 (v[k+3] + v[k+1]) + k2 (v[k+4] + v[k])
-template <int NOUT>
-__device__ __forceinline__ void akz_gauss5_window(const float *v, float k0, float k1, float k2, float *out) {
-#pragma unroll
-    for (int k = 0; k < NOUT; k += 2) {
-        const akz_f2 c = {v[k + 2], v[k + 3]}, p1 = {v[k + 3], v[k + 4]}, m1 = {v[k + 1], v[k + 2]}, p2 = {v[k + 4], v[k + 5]}, m2 = {v[k], v[k + 1]};
-        akz_f2 a = k0 * c;
-        a += k1 * (p1 + m1);
-        a += k2 * (p2 + m2);
-        out[k] = a.x;
-        out[k + 1] = a.y;
-    }
-}
 
 template <int N>
 __global__ __launch_bounds__(AKZ_FT, 8) void k_akz_fed_gauss(const float *__restrict__ Lt_in, float *__restrict__ lsm, const float *__restrict__ taps, int w,
