@@ -56,13 +56,14 @@ class MatchJob(C.Structure):
 
 
 class TriJob(C.Structure):
-    _fields_ = [("bow", MatchJob), ("x1", C.c_void_p), ("y1", C.c_void_p), ("x2", C.c_void_p), ("y2", C.c_void_p),
+    """struct_size first: the runtime strides the array by it and reads only what it covers (include/afv_hip.h)"""
+    _fields_ = [("struct_size", C.c_uint32), ("bow", MatchJob), ("x1", C.c_void_p), ("y1", C.c_void_p), ("x2", C.c_void_p), ("y2", C.c_void_p),
                 ("sigma2_2", C.c_void_p), ("F12", C.c_float * 9), ("ex", C.c_float), ("ey", C.c_float),
                 ("u_right1", C.c_void_p), ("u_right2", C.c_void_p), ("only_stereo", C.c_int32)]
 
 
 class TableTriJob(C.Structure):
-    _fields_ = [("F12", C.c_float * 9), ("ex", C.c_float), ("ey", C.c_float), ("has_mp1", C.c_void_p), ("has_mp2", C.c_void_p),
+    _fields_ = [("struct_size", C.c_uint32), ("F12", C.c_float * 9), ("ex", C.c_float), ("ey", C.c_float), ("has_mp1", C.c_void_p), ("has_mp2", C.c_void_p),
                 ("th_low", C.c_float), ("only_stereo", C.c_int32)]
 
 
@@ -72,7 +73,7 @@ class FrameView(C.Structure):
 
 
 class ProjJob(C.Structure):
-    _fields_ = [("desc", C.c_void_p), ("n", C.c_int32), ("desc_bytes", C.c_int32),
+    _fields_ = [("struct_size", C.c_uint32), ("desc", C.c_void_p), ("n", C.c_int32), ("desc_bytes", C.c_int32),
                 ("x", C.c_void_p), ("y", C.c_void_p), ("size", C.c_void_p), ("angle", C.c_void_p), ("occupied", C.c_void_p),
                 ("inf", C.c_void_p), ("min_x", C.c_float), ("min_y", C.c_float), ("grid_inv_w", C.c_float), ("grid_inv_h", C.c_float),
                 ("grid_cols", C.c_int32), ("grid_rows", C.c_int32), ("nq", C.c_int32),
@@ -81,6 +82,26 @@ class ProjJob(C.Structure):
                 ("th_high", C.c_float), ("nnratio", C.c_float), ("size_tol", C.c_float), ("inv_size_tol", C.c_float),
                 ("check_orientation", C.c_int32), ("mode", C.c_int32),
                 ("u_right", C.c_void_p), ("q_ur", C.c_void_p), ("q_er_max", C.c_void_p)]
+
+
+class FrameParams(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float),
+                ("grid_cols", C.c_int32), ("grid_rows", C.c_int32), ("distorted", C.c_int32), ("cap", C.c_int32)]
+
+
+class ProjQueries(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("nq", C.c_int32), ("qdesc", C.c_void_p), ("desc_bytes", C.c_int32),
+                ("qvalid", C.c_void_p), ("qu", C.c_void_p), ("qv", C.c_void_p), ("qr", C.c_void_p), ("qmin_size", C.c_void_p),
+                ("qmax_size", C.c_void_p), ("qangle", C.c_void_p), ("qoccupies", C.c_void_p), ("q_ur", C.c_void_p), ("q_er_max", C.c_void_p),
+                ("occupied", C.c_void_p), ("th_high", C.c_float), ("nnratio", C.c_float), ("check_orientation", C.c_int32), ("mode", C.c_int32),
+                ("qref_table", C.c_void_p), ("qref_slot", C.c_void_p), ("qref_idx", C.c_void_p)]
+
+
+def sized(struct):
+    """a job record with its struct_size filled in"""
+    obj = struct()
+    obj.struct_size = C.sizeof(struct)
+    return obj
 
 
 # every symbol include/afv_hip.h declares: (name, restype, argtypes)
@@ -133,6 +154,23 @@ SYMBOLS = {
     "afv_vocab_create": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, C.POINTER(_vp)]),
     "afv_vocab_destroy": (None, [_vp, _vp]),
     "afv_bow_transform": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "afv_vocab_set_stopped": (_i, [_vp, _vp, _vp]),
+    "afv_frame_create": (_i, [_vp, C.POINTER(FrameParams), C.POINTER(_vp)]),
+    "afv_frame_destroy": (None, [_vp]),
+    "afv_frame_extract": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, C.POINTER(_i)]),
+    "afv_frame_set_features": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "afv_frame_set_undistorted": (_i, [_vp, _vp, _vp]),
+    "afv_frame_count": (_i, [_vp]),
+    "afv_frame_device_ptrs": (_i, [_vp] + [C.POINTER(_vp)] * 7),
+    "afv_frame_get_grid": (_i, [_vp, _vp, _vp]),
+    "afv_frame_bow_transform": (_i, [_vp, _vp, _i, _vp, _vp, C.POINTER(C.c_int32)]),
+    "afv_frame_get_featvec": (_i, [_vp, _vp, _vp, _vp]),
+    "afv_frame_match_projection": (_i, [_vp, C.POINTER(ProjQueries), _vp, _vp]),
+    "afv_frame_match_fuse": (_i, [_vp, C.POINTER(ProjQueries), _i, _vp, _vp]),
+    "afv_frame_match_initialization": (_i, [_vp, _vp, _vp, _vp, _f, _f, _f, _i, _vp, _vp]),
+    "afv_table_set_from_frame": (_i, [_vp, _i, _vp]),
+    "afv_table_match_bow_frame_h": (_i, [_vp, _vp, _i, _vp, _f, _f, _i, _vp, _vp]),
+    "afv_set_projection_resolve": (_i, [_vp, _i]),
     "afv_hamming256": (_i, [_vp, _vp]),
     # include/afv_akaze.h
     "afv_akaze_default_params": (None, [_vp]),

@@ -241,6 +241,7 @@ class FeatureMatcherHip {
                                std::vector<std::pair<size_t, size_t>> &vMatchedPairs, bool bOnlyStereo = false) {
         Csr c1(kf1), c2(kf2);
         afv_tri_job t{};
+        t.struct_size = sizeof(t);
         fill(t.bow, kf1, kf2, c1, c2, AFV_MATCH_KF_KF);
         t.x1 = kf1.x; t.y1 = kf1.y; t.x2 = kf2.x; t.y2 = kf2.y; t.sigma2_2 = kf2.sigma2;
         for (int i = 0; i < 9; ++i) t.F12[i] = F12[i];
@@ -336,6 +337,7 @@ class FeatureMatcherHip {
   private:
     afv_proj_job proj_job(const FrameGridView &F, const ProjectionQueries &q) const {
         afv_proj_job j{};
+        j.struct_size = sizeof(j);
         j.desc = F.descriptors; j.n = F.N; j.desc_bytes = AFV_DESC_BYTES;
         j.x = F.x; j.y = F.y; j.size = F.size; j.angle = F.angle; j.occupied = F.occupied; j.inf = F.inf;
         j.min_x = F.mnMinX; j.min_y = F.mnMinY; j.grid_inv_w = F.mfGridElementWidthInv; j.grid_inv_h = F.mfGridElementHeightInv;

@@ -11,8 +11,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libafv_hip.so")
-SOURCES = ["k_pyramid.hip", "k_fast.hip", "k_harris.hip", "k_select.hip", "k_describe.hip", "k_match.hip", "k_match_mfma.hip", "k_project.hip", "k_bow.hip", "k_match_l2.hip",
-           "afv_api.hip", "afv_comm.hip", "k_akaze.hip", "k_akaze_detect.hip", "k_akaze_desc.hip", "akaze_api.hip"]
+SOURCES = ["k_pyramid.hip", "k_fast.hip", "k_harris.hip", "k_select.hip", "k_describe.hip", "k_match.hip", "k_match_mfma.hip", "k_project.hip", "k_bow.hip", "k_match_l2.hip", "k_frame.hip",
+           "afv_api.hip", "afv_comm.hip", "afv_frame.hip", "k_akaze.hip", "k_akaze_detect.hip", "k_akaze_desc.hip", "akaze_api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]
 

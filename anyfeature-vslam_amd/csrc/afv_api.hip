@@ -425,6 +425,7 @@ extern "C" void afv_destroy(afv_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     afv_table_release_all(c);
+    afv_frame_release_all(c);
     void *ptrs[] = {c->d_geo, c->d_tab, c->d_pyr, c->d_cand_packed, c->d_kept_xy, c->d_l1, c->d_l1_resp, c->d_l1_count, c->d_hq, c->d_hq_n, c->d_kept_resp,
                     c->d_kept_node, c->d_cand_count, c->d_sel_count, c->d_sel, c->d_frames, c->d_out_block,
                     c->d_status, c->d_match, c->d_topk, c->d_slice, c->d_tickets, c->d_pf_blob, c->d_l2_scratch};
@@ -526,6 +527,7 @@ extern "C" int afv_create(int device, const afv_orb_params *params, afv_ctx **ou
         return AFV_EUNSUPPORTED;
     }
 #undef CREATE_CHK
+    c->proj_wg_lds_max = afv_project_prepare();  // 0: the projection searches keep to the ordered walk
     *out = c;
     return AFV_OK;
 }
@@ -653,7 +655,7 @@ static bool small_batch_path(const afv_ctx *c, int nf) {
 // kernels of one contiguous frame range [f0, f0 + nf) on stream s
 // clear_status: this range is the whole call, *d_status is cleared ahead of its kernels (by the one-launch pyramid when there is one)
 static void enqueue_range(afv_ctx *c, const FrameSrc &src, int f0, int nf, afv_keypoint *d_kps, uint8_t *d_desc, int cap, int *d_n,
-                          int *d_status, hipStream_t s, bool clear_status = false) {
+                          int *d_status, hipStream_t s, bool clear_status = false, const DescribeMirror *mirror = nullptr) {
     const Geo &g = c->geo;
     {   // work lists are indexed with afv_udiv (exact below AFV_MAX_WORK items): longer ranges go out in pieces
         const int per = std::max(std::max(g.total_tiles, afv_describe_blocks_per_frame(&g)), 1);
@@ -708,7 +710,7 @@ static void enqueue_range(afv_ctx *c, const FrameSrc &src, int f0, int nf, afv_k
     {
         StageTimer t_(c, AFV_STAGE_DESCRIBE, s, nf);
         afv_launch_describe(c->d_geo, afv_describe_blocks_per_frame(&g), &src, c->d_pyr, c->d_sel, c->d_sel_count, d_kps, d_desc, cap, d_n,
-                            d_status, f0, nf, s);
+                            d_status, f0, nf, mirror, s);
     }
 }
 
@@ -943,8 +945,10 @@ extern "C" int afv_orb_extract_batch(afv_ctx *c, const uint8_t *const *frames, i
 // pipeline's bookkeeping: no events, no output probes, everything on the context's stream.  A pageable image goes through the pinned
 // arena in four strips (the CPU copies strip k + 1 while strip k is on the link); the results come back in one copy when the context
 // was created for one frame (counts, keypoints and descriptors are then one contiguous range), else in three.
+// `frame` (afv_frame_extract): the describe kernel also writes the frame's device arrays, and k_frame_grid (per-feature arrays + grid) follows
+// on the stream before the host waits.
 static int extract_one(afv_ctx *c, const uint8_t *gray, int width, int height, int stride_bytes, afv_keypoint *kps, uint8_t *desc32, int cap,
-                       int *n_out) {
+                       int *n_out, afv_frame *frame = nullptr) {
     struct Quiesce {  // whatever path leaves this function, no DMA may still be in flight into the arena
         afv_ctx *c;
         bool armed = true;
@@ -993,12 +997,17 @@ static int extract_one(afv_ctx *c, const uint8_t *gray, int width, int height, i
     }
     uint8_t *hres = hb + res_off;
     if (trace) ts[2] = now();
+    DescribeMirror mir{nullptr, nullptr, nullptr};
+    if (frame) mir = DescribeMirror{frame->d_kps, frame->d_desc, frame->d_n};
+    // (a frame smaller than the staging capacity: slots beyond frame->cap would be written past its arrays - afv_frame_create sizes frames
+    // for the context's capacity, afv_frame_extract checks)
     if (zero_copy_out) {
         enqueue_range(c, src, 0, 1, reinterpret_cast<afv_keypoint *>(hres + kps_off), hres + desc_off, c->stage_cap, reinterpret_cast<int *>(hres),
-                      c->d_status, s, true);
+                      c->d_status, s, true, frame ? &mir : nullptr);
     } else {
-        enqueue_range(c, src, 0, 1, c->d_kps, c->d_desc, c->stage_cap, c->d_n, c->d_status, s, true);
+        enqueue_range(c, src, 0, 1, c->d_kps, c->d_desc, c->stage_cap, c->d_n, c->d_status, s, true, frame ? &mir : nullptr);
     }
+    if (frame) afv_frame_after_extract(frame, s);
     HIPCHK(c, hipGetLastError());
     if (trace) ts[3] = now();
     if (!zero_copy_out) {
@@ -1019,9 +1028,10 @@ static int extract_one(afv_ctx *c, const uint8_t *gray, int width, int height, i
         result = AFV_ECAPACITY;
     }
     n = std::max(n, 0);
-    *n_out = n;
-    std::memcpy(kps, h_kps, (size_t)n * sizeof(afv_keypoint));
-    std::memcpy(desc32, h_desc, (size_t)n * AFV_DESC_BYTES);
+    if (frame) frame->n = std::min(std::max(*reinterpret_cast<const int *>(hres), 0), frame->cap);
+    if (n_out) *n_out = n;
+    if (kps) std::memcpy(kps, h_kps, (size_t)n * sizeof(afv_keypoint));
+    if (desc32) std::memcpy(desc32, h_desc, (size_t)n * AFV_DESC_BYTES);
     if (trace) {
         ts[6] = now();
         for (int i = 0; i < 6; ++i) acc[i] += ts[i + 1] - ts[i];
@@ -1045,16 +1055,31 @@ extern "C" int afv_orb_extract(afv_ctx *c, const uint8_t *gray, int width, int h
     return guarded(c, [&]() -> int { return extract_one(c, gray, width, height, stride_bytes, kps, desc32, cap, n_out); });
 }
 
+// afv_frame_extract (afv_frame.hip): the same call with a frame attached
+int afv_extract_into_frame(afv_ctx *c, afv_frame *f, const uint8_t *gray, int width, int height, int stride_bytes, afv_keypoint *kps,
+                           uint8_t *desc32, int cap, int *n_out) {
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = set_geometry(c, width, height);
+    if (rc) return rc;
+    if (f->cap < c->stage_cap) return AFV_ECAPACITY;  // the describe kernel writes up to stage_cap slots of the mirror
+    c->prof = c->prof_every && (c->prof_tick_extract++ % (unsigned)c->prof_every) == 0;
+    return guarded(c, [&]() -> int { return extract_one(c, gray, width, height, stride_bytes, kps, desc32, cap, n_out, f); });
+}
+
 // E12 (FeatureExtractor.cpp:132-172, settings FeatureExtractor.cpp:52-55)
-extern "C" int afv_orb_size_sigma(const afv_ctx *c, const afv_keypoint *kps, int n, float *size, float *sigma2, float *inf) {
-    if (!c || (n > 0 && (!kps || !size || !sigma2 || !inf)) || n < 0) return AFV_EINVAL;
+float afv_size_of_octave(const afv_ctx *c, int octave) {
     const float scale_factor_orb = 1.2f;
     const float max_size0 = powf(scale_factor_orb, float(8 - 1.0));
     const float max_size = max_size0, min_size = 1.0f;
+    const float s = powf(c->p.scale_factor, float(octave));  // GetKeypointSize Feature_orb32.cpp:59-61
+    float norm = max_size;
+    if (max_size > min_size) norm = 1.0f + (s - min_size) * (max_size0 - 1.0f) / (max_size - min_size);
+    return norm;
+}
+extern "C" int afv_orb_size_sigma(const afv_ctx *c, const afv_keypoint *kps, int n, float *size, float *sigma2, float *inf) {
+    if (!c || (n > 0 && (!kps || !size || !sigma2 || !inf)) || n < 0) return AFV_EINVAL;
     for (int i = 0; i < n; ++i) {
-        const float s = powf(c->p.scale_factor, float(kps[i].octave));  // GetKeypointSize Feature_orb32.cpp:59-61
-        float norm = max_size;
-        if (max_size > min_size) norm = 1.0f + (s - min_size) * (max_size0 - 1.0f) / (max_size - min_size);
+        const float norm = afv_size_of_octave(c, kps[i].octave);
         size[i] = norm;
         const float s2 = norm * norm;
         sigma2[i] = s2;
@@ -1414,8 +1439,11 @@ extern "C" int afv_match_bow(afv_ctx *c, const afv_match_job *jobs, int njobs, i
     return guarded(c, [&] { return afv_match_bow_impl(c, jobs, njobs, out, nmatches); });
 }
 
-static int afv_match_triangulation_impl(afv_ctx *c, const afv_tri_job *jobs, int njobs, int32_t *match12, int32_t *nmatches) {
-    if (!c || !jobs || njobs < 1 || !match12 || !nmatches) return AFV_EINVAL;
+static int afv_match_triangulation_impl(afv_ctx *c, const afv_tri_job *caller_jobs, int njobs, int32_t *match12, int32_t *nmatches) {
+    if (!c || !caller_jobs || njobs < 1 || !match12 || !nmatches) return AFV_EINVAL;
+    std::vector<afv_tri_job> loaded;
+    if (!afv_load_jobs(caller_jobs, njobs, offsetof(afv_tri_job, u_right1), loaded)) return AFV_EINVAL;
+    const afv_tri_job *jobs = loaded.data();
     for (int i = 0; i < njobs; ++i) {
         const int rc = validate_job(jobs[i].bow, false);
         if (rc) return rc;
@@ -1627,117 +1655,182 @@ extern "C" int afv_match_l2_pairs_device(afv_ctx *c, const float *d_desc, const 
 }
 
 // ---- projection-guided matching ----
-enum { KIND_PROJ = 0, KIND_FUSE = 1, KIND_INIT = 2 };
-static int match_projection_impl(afv_ctx *c, const afv_proj_job *jobs, int njobs, int32_t *assign, int32_t *nmatches, int kind) {
-    const bool fuse = kind == KIND_FUSE, per_query = kind != KIND_PROJ;
+// One implementation behind afv_match_projection / _fuse / _initialization / _sim3 (host arrays on both sides) and the afv_frame_* forms
+// (afv_frame.hip: the feature side, its grid and possibly the queries' descriptors are already on the device: `dev`).  The grid of
+// Frame::AssignFeaturesToGrid is built ON THE DEVICE in both cases (k_frame_grid): the host-array form uploads x / y / size and runs the
+// same kernel a resident frame ran when it was extracted.
+int afv_match_projection_core(afv_ctx *c, const afv_proj_job *jobs, int njobs, int32_t *assign, int32_t *nmatches, int kind,
+                              const ProjFeatureSide *dev) {
+    const bool fuse = kind == AFV_KIND_FUSE, per_query = kind != AFV_KIND_PROJ;
     if (!c || !jobs || njobs < 1 || !assign || !nmatches) return AFV_EINVAL;
+    if (dev && njobs != 1) return AFV_EINVAL;
     for (int i = 0; i < njobs; ++i) {
         const afv_proj_job &j = jobs[i];
         if (j.n < 0 || j.n > AFV_MAX_SIDE || j.nq < 0 || j.nq > 65535 || j.desc_bytes < 1 || j.desc_bytes > 64) return AFV_EINVAL;
-        if (j.grid_cols < 1 || j.grid_rows < 1 || (long)j.grid_cols * j.grid_rows > 65536) return AFV_EINVAL;
-        if (j.n > 0 && (!j.desc || !j.x || !j.y || !j.size)) return AFV_EINVAL;
-        if (j.nq > 0 && (!j.qdesc || !j.qu || !j.qv || !j.qr || !j.qmin_size || !j.qmax_size)) return AFV_EINVAL;
-        if (kind == KIND_INIT && j.check_orientation && ((j.n > 0 && !j.angle) || (j.nq > 0 && !j.qangle))) return AFV_EINVAL;
-        if (kind == KIND_PROJ && j.mode != AFV_PROJ_LOCALMAP && j.mode != AFV_PROJ_LASTFRAME) return AFV_EINVAL;
-        if (kind == KIND_PROJ && j.mode == AFV_PROJ_LASTFRAME && j.check_orientation && ((j.n > 0 && !j.angle) || (j.nq > 0 && !j.qangle))) return AFV_EINVAL;
+        if (j.grid_cols < 1 || j.grid_rows < 1 || (long)j.grid_cols * j.grid_rows > 8192) return AFV_EINVAL;
+        if (!dev && j.n > 0 && (!j.desc || !j.x || !j.y || !j.size)) return AFV_EINVAL;
+        if (j.nq > 0 && ((!j.qdesc && !(dev && (dev->qdesc_dev || dev->qref_table))) || !j.qu || !j.qv || !j.qr || !j.qmin_size || !j.qmax_size)) return AFV_EINVAL;
+        const bool has_angle = dev ? dev->angle != nullptr : j.angle != nullptr;
+        const bool has_qangle = j.qangle != nullptr || (dev && dev->qangle_dev);
+        if (kind == AFV_KIND_INIT && j.check_orientation && ((j.n > 0 && !has_angle) || (j.nq > 0 && !has_qangle))) return AFV_EINVAL;
+        if (kind == AFV_KIND_PROJ && j.mode != AFV_PROJ_LOCALMAP && j.mode != AFV_PROJ_LASTFRAME) return AFV_EINVAL;
+        if (kind == AFV_KIND_PROJ && j.mode == AFV_PROJ_LASTFRAME && j.check_orientation && ((j.n > 0 && !has_angle) || (j.nq > 0 && !has_qangle)))
+            return AFV_EINVAL;
         // stereo frames: the queries' right-image coordinate (and, for the projection searches, their gate) come with mvuRight
-        if (j.u_right && (kind == KIND_PROJ || kind == KIND_FUSE) && j.nq > 0 && (!j.q_ur || (kind == KIND_PROJ && !j.q_er_max))) return AFV_EINVAL;
+        if (j.u_right && (kind == AFV_KIND_PROJ || kind == AFV_KIND_FUSE) && j.nq > 0 && (!j.q_ur || (kind == AFV_KIND_PROJ && !j.q_er_max)))
+            return AFV_EINVAL;
     }
     HIPCHK(c, hipSetDevice(c->device));
     Blob b(c);
-    struct Off { size_t fd, x, y, size, angle, occ, inf, cptr, cidx, qd, qvalid, qu, qv, qr, qmin, qmax, qang, qocc, keys, ncand, ori, assign, nm, ur, qur, qer; int words; bool stereo; };
+    struct Off { size_t fd, x, y, size, angle, occ, inf, cptr, cent, qd, qrs, qri, qvalid, qu, qv, qr, qmin, qmax, qang, qocc, keys, ncand, ori, ur, qur, qer; int words; bool stereo; };
     std::vector<Off> offs(njobs);
     size_t total_out = 0;
+    int max_nq = 0, max_n = 0;
+    size_t grid_lds = 0;
     for (int i = 0; i < njobs; ++i) {
         const afv_proj_job &j = jobs[i];
         Off &o = offs[i];
+        o = Off{};
         o.words = j.desc_bytes <= 32 ? 8 : 16;
-        o.fd = put_desc(b, j.desc, j.n, j.desc_bytes, o.words);
-        o.x = b.put(j.x, (size_t)j.n * 4); o.y = b.put(j.y, (size_t)j.n * 4); o.size = b.put(j.size, (size_t)j.n * 4);
-        o.angle = j.angle ? b.put(j.angle, (size_t)j.n * 4) : 0;
-        o.occ = j.occupied ? b.put(j.occupied, (size_t)j.n) : 0;
-        o.inf = (fuse && j.inf) ? b.put(j.inf, (size_t)j.n * 4) : 0;
-        o.stereo = j.u_right && (kind == KIND_PROJ || kind == KIND_FUSE);  // FeatureMatcher.cc:114-119, :1367-1372, :880-894
-        o.ur = o.stereo ? b.put(j.u_right, (size_t)j.n * 4) : 0;
-        o.qur = o.stereo ? b.put(j.q_ur, (size_t)j.nq * 4) : 0;
-        o.qer = (o.stereo && kind == KIND_PROJ) ? b.put(j.q_er_max, (size_t)j.nq * 4) : 0;
-        // Frame::AssignFeaturesToGrid / PosInGrid (Frame.cc:225-240, 383-394): cell = ix * rows + iy, ascending index
-        const int nc = j.grid_cols * j.grid_rows;
-        std::vector<int> cptr((size_t)nc + 1, 0), cidx((size_t)std::max(j.n, 1)), cell((size_t)std::max(j.n, 1));
-        for (int f = 0; f < j.n; ++f) {
-            const int px = (int)roundf((j.x[f] - j.min_x) * j.grid_inv_w), py = (int)roundf((j.y[f] - j.min_y) * j.grid_inv_h);
-            cell[f] = (px < 0 || px >= j.grid_cols || py < 0 || py >= j.grid_rows) ? -1 : px * j.grid_rows + py;
-            if (cell[f] >= 0) cptr[cell[f] + 1]++;
+        if (dev && dev->words != o.words) return AFV_EINVAL;
+        // mvuRight branches: FeatureMatcher.cc:114-119, :1367-1372, :880-894.  A resident frame always carries the plane (-1 = monocular);
+        // it takes part when the caller sends the queries' side of the gate
+        const bool ur_here = dev ? (dev->u_right != nullptr && j.q_ur != nullptr) : j.u_right != nullptr;
+        o.stereo = ur_here && (kind == AFV_KIND_PROJ || kind == AFV_KIND_FUSE);
+        if (o.stereo && kind == AFV_KIND_PROJ && j.nq > 0 && !j.q_er_max) return AFV_EINVAL;
+        if (!dev) {
+            o.fd = put_desc(b, j.desc, j.n, j.desc_bytes, o.words);
+            o.x = b.put(j.x, (size_t)j.n * 4); o.y = b.put(j.y, (size_t)j.n * 4); o.size = b.put(j.size, (size_t)j.n * 4);
+            o.angle = j.angle ? b.put(j.angle, (size_t)j.n * 4) : 0;
+            o.inf = (fuse && j.inf) ? b.put(j.inf, (size_t)j.n * 4) : 0;
+            o.ur = o.stereo ? b.put(j.u_right, (size_t)j.n * 4) : 0;
+            grid_lds = std::max(grid_lds, afv_frame_grid_lds(j.grid_cols, j.grid_rows, std::max(j.n, 1)));
         }
-        for (int q = 0; q < nc; ++q) cptr[q + 1] += cptr[q];
-        std::vector<int> fill(cptr.begin(), cptr.end() - 1);
-        for (int f = 0; f < j.n; ++f)
-            if (cell[f] >= 0) cidx[fill[cell[f]]++] = f;
-        o.cptr = b.put(cptr.data(), cptr.size() * 4);
-        o.cidx = b.put(cidx.data(), cidx.size() * 4);
-        o.qd = put_desc(b, j.qdesc, j.nq, j.desc_bytes, o.words);
-        o.qvalid = j.qvalid ? b.put(j.qvalid, (size_t)j.nq) : 0;
+        o.occ = (j.occupied && kind != AFV_KIND_INIT) ? b.put(j.occupied, (size_t)j.n) : 0;
+        o.qur = o.stereo ? b.put(j.q_ur, (size_t)j.nq * 4) : 0;
+        o.qer = (o.stereo && kind == AFV_KIND_PROJ) ? b.put(j.q_er_max, (size_t)j.nq * 4) : 0;
+        const bool by_ref = dev && dev->qref_table && !dev->qdesc_dev;
+        if (by_ref) {
+            // MapPoint descriptors by reference (rows of a keyframe table): checked here, gathered on the device behind the upload
+            const afv_table *qt = dev->qref_table;
+            if (qt->c != c || !dev->qref_slot || !dev->qref_idx || o.words != 8) return AFV_EINVAL;
+            for (int q = 0; q < j.nq; ++q) {
+                const int sl = dev->qref_slot[q];
+                if (sl < 0 || sl >= qt->nsets || dev->qref_idx[q] < 0 || dev->qref_idx[q] >= qt->h_n[sl]) return AFV_EINVAL;
+            }
+            o.qrs = b.put(dev->qref_slot, (size_t)j.nq * 4);
+            o.qri = b.put(dev->qref_idx, (size_t)j.nq * 4);
+        } else if (!(dev && dev->qdesc_dev)) {
+            o.qd = put_desc(b, j.qdesc, j.nq, j.desc_bytes, o.words);
+        }
+        o.qvalid = (j.qvalid && !(dev && dev->qvalid_dev)) ? b.put(j.qvalid, (size_t)j.nq) : 0;
         o.qu = b.put(j.qu, (size_t)j.nq * 4); o.qv = b.put(j.qv, (size_t)j.nq * 4); o.qr = b.put(j.qr, (size_t)j.nq * 4);
         o.qmin = b.put(j.qmin_size, (size_t)j.nq * 4); o.qmax = b.put(j.qmax_size, (size_t)j.nq * 4);
-        o.qang = j.qangle ? b.put(j.qangle, (size_t)j.nq * 4) : 0;
+        o.qang = (j.qangle && !(dev && dev->qangle_dev)) ? b.put(j.qangle, (size_t)j.nq * 4) : 0;
         o.qocc = j.qoccupies ? b.put(j.qoccupies, (size_t)j.nq) : 0;
         total_out += (size_t)(per_query ? j.nq : j.n);
+        max_nq = std::max(max_nq, j.nq);
+        max_n = std::max(max_n, j.n);
     }
+    // records the kernels read: the search jobs and, for staged feature sides, the grid jobs (uploaded with the inputs)
+    const size_t jobs_off = b.reserve((size_t)njobs * sizeof(DevProjJob));
+    const size_t gjobs_off = dev ? 0 : b.reserve((size_t)njobs * sizeof(DevGridJob));
+    const size_t nm_off = b.reserve((size_t)njobs * 4);
     const size_t in_bytes = b.h.size();
     for (int i = 0; i < njobs; ++i) {  // device-only scratch
         const afv_proj_job &j = jobs[i];
         offs[i].keys = b.reserve_scratch((size_t)std::max(j.nq, 1) * 64);  // 64-byte record / 8 keys per query
         offs[i].ncand = b.reserve_scratch((size_t)std::max(j.nq, 1) * 4);
         offs[i].ori = b.reserve_scratch((size_t)std::max(j.nq, 1) * 8);
+        if (dev && dev->qref_table && !dev->qdesc_dev) offs[i].qd = b.reserve_scratch((size_t)std::max(j.nq, 1) * 32);
+        if (!dev) {
+            offs[i].cptr = b.reserve_scratch(((size_t)j.grid_cols * j.grid_rows + 1) * 4);
+            offs[i].cent = b.reserve_scratch((size_t)std::max(j.n, 1) * 16);
+        }
     }
-    const size_t out_off = b.reserve(std::max<size_t>(total_out, 1) * 4);
-    const size_t nm_off = b.reserve((size_t)njobs * 4);
-    const size_t jobs_off = b.reserve((size_t)njobs * sizeof(DevProjJob));
+    const size_t out_off = b.reserve_scratch(std::max<size_t>(total_out, 1) * 4);
     int rc = ensure_match_buffer(c, b.h.size());
     if (rc) return rc;
-    uint8_t *B = c->d_match;
+    // ordered phase: the workgroup fixed point when the largest job's tables fit the LDS it may use
+    size_t wg_lds = 0;
+    if (!fuse && c->proj_engine != 0 && c->proj_wg_lds_max > 0 && (kind != AFV_KIND_INIT || max_nq <= 32767)) {
+        for (int i = 0; i < njobs; ++i) wg_lds = std::max(wg_lds, afv_project_wg_lds(kind == AFV_KIND_INIT, jobs[i].n, jobs[i].nq));
+        if (wg_lds > (size_t)c->proj_wg_lds_max) wg_lds = 0;
+    }
+    // results straight into the pinned arena (device-visible host memory) when the kernels write them once and never read them back
+    const bool zero_copy = c->stage_pinned && (fuse || wg_lds != 0);
+    uint8_t *B = c->d_match, *H = b.h.data();
     size_t acc = 0;
     for (int i = 0; i < njobs; ++i) {
         const afv_proj_job &j = jobs[i];
         const Off &o = offs[i];
-        DevProjJob &d = reinterpret_cast<DevProjJob *>(b.h.data() + jobs_off)[i];
-        d.fdesc = reinterpret_cast<const uint32_t *>(B + o.fd); d.n = j.n; d.words = o.words;
-        d.x = reinterpret_cast<const float *>(B + o.x); d.y = reinterpret_cast<const float *>(B + o.y);
-        d.size = reinterpret_cast<const float *>(B + o.size);
-        d.angle = j.angle ? reinterpret_cast<const float *>(B + o.angle) : nullptr;
-        d.occupied = j.occupied ? B + o.occ : nullptr;
-        d.inf = (fuse && j.inf) ? reinterpret_cast<const float *>(B + o.inf) : nullptr;
+        DevProjJob &d = reinterpret_cast<DevProjJob *>(H + jobs_off)[i];
+        d = DevProjJob{};
+        d.n = j.n; d.words = o.words;
+        if (dev) {
+            d.fdesc = dev->fdesc; d.x = dev->x; d.y = dev->y; d.size = dev->size; d.angle = dev->angle;
+            d.inf = fuse ? dev->inf : nullptr;
+            d.u_right = o.stereo ? dev->u_right : nullptr;
+            d.cell_ptr = dev->cell_ptr; d.cell_ent = dev->cell_ent;
+        } else {
+            d.fdesc = reinterpret_cast<const uint32_t *>(B + o.fd);
+            d.x = reinterpret_cast<const float *>(B + o.x); d.y = reinterpret_cast<const float *>(B + o.y);
+            d.size = reinterpret_cast<const float *>(B + o.size);
+            d.angle = j.angle ? reinterpret_cast<const float *>(B + o.angle) : nullptr;
+            d.inf = (fuse && j.inf) ? reinterpret_cast<const float *>(B + o.inf) : nullptr;
+            d.u_right = o.stereo ? reinterpret_cast<const float *>(B + o.ur) : nullptr;
+            d.cell_ptr = reinterpret_cast<const int *>(B + o.cptr); d.cell_ent = reinterpret_cast<const int4 *>(B + o.cent);
+            DevGridJob &g = reinterpret_cast<DevGridJob *>(H + gjobs_off)[i];
+            g = DevGridJob{};
+            g.n = j.n; g.cap = std::max(j.n, 1);
+            g.x = const_cast<float *>(d.x); g.y = const_cast<float *>(d.y); g.size = const_cast<float *>(d.size);
+            g.min_x = j.min_x; g.min_y = j.min_y; g.inv_w = j.grid_inv_w; g.inv_h = j.grid_inv_h; g.cols = j.grid_cols; g.rows = j.grid_rows;
+            g.cell_ptr = reinterpret_cast<int *>(B + o.cptr); g.cell_ent = reinterpret_cast<int4 *>(B + o.cent);
+        }
+        d.occupied = (j.occupied && kind != AFV_KIND_INIT) ? B + o.occ : nullptr;
         d.min_x = j.min_x; d.min_y = j.min_y; d.inv_w = j.grid_inv_w; d.inv_h = j.grid_inv_h; d.cols = j.grid_cols; d.rows = j.grid_rows;
-        d.cell_ptr = reinterpret_cast<const int *>(B + o.cptr); d.cell_idx = reinterpret_cast<const int *>(B + o.cidx);
-        d.nq = j.nq; d.qdesc = reinterpret_cast<const uint32_t *>(B + o.qd); d.qvalid = j.qvalid ? B + o.qvalid : nullptr;
+        d.nq = j.nq;
+        d.qdesc = (dev && dev->qdesc_dev) ? dev->qdesc_dev : reinterpret_cast<const uint32_t *>(B + o.qd);
+        d.qvalid = (dev && dev->qvalid_dev) ? dev->qvalid_dev : (j.qvalid ? B + o.qvalid : nullptr);
         d.qu = reinterpret_cast<const float *>(B + o.qu); d.qv = reinterpret_cast<const float *>(B + o.qv);
         d.qr = reinterpret_cast<const float *>(B + o.qr); d.qmin = reinterpret_cast<const float *>(B + o.qmin);
         d.qmax = reinterpret_cast<const float *>(B + o.qmax);
-        d.qangle = j.qangle ? reinterpret_cast<const float *>(B + o.qang) : nullptr;
+        d.qangle = (dev && dev->qangle_dev) ? dev->qangle_dev : (j.qangle ? reinterpret_cast<const float *>(B + o.qang) : nullptr);
         d.qocc = j.qoccupies ? B + o.qocc : nullptr;
         d.th = j.th_high; d.ratio = j.nnratio; d.tol = j.size_tol; d.inv_tol = j.inv_size_tol;
         d.check_ori = j.check_orientation != 0; d.mode = j.mode;
         d.keys = reinterpret_cast<unsigned long long *>(B + o.keys); d.ncand = reinterpret_cast<int *>(B + o.ncand);
         d.orilist = reinterpret_cast<int *>(B + o.ori);
-        d.u_right = o.stereo ? reinterpret_cast<const float *>(B + o.ur) : nullptr;
         d.q_ur = o.stereo ? reinterpret_cast<const float *>(B + o.qur) : nullptr;
-        d.q_er = (o.stereo && kind == KIND_PROJ) ? reinterpret_cast<const float *>(B + o.qer) : nullptr;
-        d.stereo_gate = (o.stereo && kind == KIND_PROJ) ? 1 : 0;
-        d.assign = reinterpret_cast<int *>(B + out_off + acc * 4); d.nmatches = reinterpret_cast<int *>(B + nm_off + (size_t)i * 4);
+        d.q_er = (o.stereo && kind == AFV_KIND_PROJ) ? reinterpret_cast<const float *>(B + o.qer) : nullptr;
+        d.stereo_gate = (o.stereo && kind == AFV_KIND_PROJ) ? 1 : 0;
+        uint8_t *R = zero_copy ? H : B;
+        d.assign = reinterpret_cast<int *>(R + out_off + acc * 4); d.nmatches = reinterpret_cast<int *>(R + nm_off + (size_t)i * 4);
         acc += (size_t)(per_query ? j.nq : j.n);
     }
-    HIPCHK(c, hipMemcpyAsync(B, b.h.data(), in_bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(B + jobs_off, b.h.data() + jobs_off, (size_t)njobs * sizeof(DevProjJob), hipMemcpyHostToDevice, c->stream));
-    int max_nq = 0;
-    for (int i = 0; i < njobs; ++i) max_nq = std::max(max_nq, jobs[i].nq);
-    if (fuse) afv_launch_match_fuse(reinterpret_cast<const DevProjJob *>(B + jobs_off), njobs, max_nq, c->stream);
-    else if (kind == KIND_INIT) afv_launch_match_init(reinterpret_cast<const DevProjJob *>(B + jobs_off), njobs, max_nq, c->stream);
-    else afv_launch_match_projection(reinterpret_cast<const DevProjJob *>(B + jobs_off), njobs, max_nq, c->stream);
+    HIPCHK(c, hipMemcpyAsync(B, H, in_bytes, hipMemcpyHostToDevice, c->stream));
+    if (!dev) afv_launch_frame_grid(reinterpret_cast<const DevGridJob *>(B + gjobs_off), njobs, grid_lds, c->stream);
+    if (dev && dev->qref_table && !dev->qdesc_dev) {
+        const afv_table *qt = dev->qref_table;
+        afv_launch_frame_gather(qt->d_desc, qt->d_n, qt->nsets, qt->cap, reinterpret_cast<const int *>(B + offs[0].qrs),
+                                reinterpret_cast<const int *>(B + offs[0].qri), jobs[0].nq, B + offs[0].qd, nullptr, c->stream);
+    }
+    const DevProjJob *dj = reinterpret_cast<const DevProjJob *>(B + jobs_off);
+    if (fuse) afv_launch_match_fuse(dj, njobs, max_nq, c->stream);
+    else if (kind == AFV_KIND_INIT) afv_launch_match_init(dj, njobs, max_nq, wg_lds, c->stream);
+    else afv_launch_match_projection(dj, njobs, max_nq, wg_lds, c->stream);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, b.fetch(assign, out_off, total_out * 4, c->stream));
-    if (!fuse) HIPCHK(c, b.fetch(nmatches, nm_off, (size_t)njobs * 4, c->stream));
+    if (!zero_copy) {
+        HIPCHK(c, b.fetch(assign, out_off, total_out * 4, c->stream));
+        if (!fuse) HIPCHK(c, b.fetch(nmatches, nm_off, (size_t)njobs * 4, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    b.finish();
+    if (zero_copy) {
+        std::memcpy(assign, H + out_off, total_out * 4);
+        if (!fuse) std::memcpy(nmatches, H + nm_off, (size_t)njobs * 4);
+    } else {
+        b.finish();
+    }
     if (fuse) {  // independent queries: the count is just the number of hits
         size_t at = 0;
         for (int i = 0; i < njobs; ++i) {
@@ -1746,33 +1839,49 @@ static int match_projection_impl(afv_ctx *c, const afv_proj_job *jobs, int njobs
             nmatches[i] = found;
             at += (size_t)jobs[i].nq;
         }
+    } else {
+        for (int i = 0; i < njobs; ++i)
+            if (nmatches[i] == -0x7fffffff) {  // PW_GUARD: the fixed point did not settle within its pass guard (never observed)
+                c->last_error = "projection search: the fixed point hit its pass guard; afv_set_projection_resolve(ctx, 0) selects the ordered walk";
+                return AFV_EHIP;
+            }
     }
     return AFV_OK;
 }
 
+// job arrays arrive with the layout the caller was compiled against (struct_size): bring them to the current one
+static int proj_jobs_entry(afv_ctx *c, const afv_proj_job *jobs, int njobs, int32_t *out, int32_t *nm, int kind) {
+    return guarded(c, [&]() -> int {
+        std::vector<afv_proj_job> J;
+        if (!afv_load_jobs(jobs, njobs, offsetof(afv_proj_job, u_right), J)) return AFV_EINVAL;
+        return afv_match_projection_core(c, J.data(), njobs, out, nm, kind, nullptr);
+    });
+}
 extern "C" int afv_match_projection(afv_ctx *c, const afv_proj_job *jobs, int njobs, int32_t *assign, int32_t *nmatches) {
-    return guarded(c, [&] { return match_projection_impl(c, jobs, njobs, assign, nmatches, KIND_PROJ); });
+    return proj_jobs_entry(c, jobs, njobs, assign, nmatches, AFV_KIND_PROJ);
 }
 extern "C" int afv_match_fuse(afv_ctx *c, const afv_proj_job *jobs, int njobs, int32_t *best, int32_t *nfound) {
-    return guarded(c, [&] { return match_projection_impl(c, jobs, njobs, best, nfound, KIND_FUSE); });
+    return proj_jobs_entry(c, jobs, njobs, best, nfound, AFV_KIND_FUSE);
 }
 extern "C" int afv_match_initialization(afv_ctx *c, const afv_proj_job *jobs, int njobs, int32_t *match12, int32_t *nmatches) {
-    return guarded(c, [&] { return match_projection_impl(c, jobs, njobs, match12, nmatches, KIND_INIT); });
+    return proj_jobs_entry(c, jobs, njobs, match12, nmatches, AFV_KIND_INIT);
 }
 static int afv_match_sim3_impl(afv_ctx *c, const afv_proj_job *j12, const afv_proj_job *j21, int32_t *match12, int32_t *nfound) {
     if (!c || !j12 || !j21 || !match12 || !nfound) return AFV_EINVAL;
-    if (j12->nq != j21->n || j21->nq != j12->n) return AFV_EINVAL;
-    afv_proj_job jobs[2] = {*j12, *j21};
+    std::vector<afv_proj_job> A, Bv;
+    if (!afv_load_jobs(j12, 1, offsetof(afv_proj_job, u_right), A) || !afv_load_jobs(j21, 1, offsetof(afv_proj_job, u_right), Bv)) return AFV_EINVAL;
+    if (A[0].nq != Bv[0].n || Bv[0].nq != A[0].n) return AFV_EINVAL;
+    afv_proj_job jobs[2] = {A[0], Bv[0]};
     jobs[0].inf = nullptr;  // no reprojection gate in SearchBySim3
     jobs[1].inf = nullptr;
     jobs[0].u_right = jobs[1].u_right = nullptr;  // ... and no stereo branch (FeatureMatcher.cc:1066-1287)
-    std::vector<int32_t> best((size_t)j12->nq + (size_t)j21->nq + 1);
+    std::vector<int32_t> best((size_t)jobs[0].nq + (size_t)jobs[1].nq + 1);
     int32_t nf[2];
-    const int rc = match_projection_impl(c, jobs, 2, best.data(), nf, KIND_FUSE);
+    const int rc = afv_match_projection_core(c, jobs, 2, best.data(), nf, AFV_KIND_FUSE, nullptr);
     if (rc) return rc;
-    const int32_t *m1 = best.data(), *m2 = best.data() + j12->nq;
+    const int32_t *m1 = best.data(), *m2 = best.data() + jobs[0].nq;
     int found = 0;
-    for (int i1 = 0; i1 < j12->nq; ++i1) {  // FeatureMatcher.cc:1268-1284
+    for (int i1 = 0; i1 < jobs[0].nq; ++i1) {  // FeatureMatcher.cc:1268-1284
         const int idx2 = m1[i1];
         const bool agree = idx2 >= 0 && m2[idx2] == i1;
         match12[i1] = agree ? idx2 : -1;
@@ -1783,6 +1892,11 @@ static int afv_match_sim3_impl(afv_ctx *c, const afv_proj_job *j12, const afv_pr
 }
 extern "C" int afv_match_sim3(afv_ctx *c, const afv_proj_job *j12, const afv_proj_job *j21, int32_t *match12, int32_t *nfound) {
     return guarded(c, [&] { return afv_match_sim3_impl(c, j12, j21, match12, nfound); });
+}
+extern "C" int afv_set_projection_resolve(afv_ctx *c, int engine) {
+    if (!c || engine < 0 || engine > 2) return AFV_EINVAL;
+    c->proj_engine = engine;
+    return AFV_OK;
 }
 
 // ---- BoW quantisation ----
@@ -1812,26 +1926,71 @@ extern "C" int afv_vocab_create(afv_ctx *c, int k, int L, int nnodes, const int3
             frontier.swap(next);
         }
     }
+    for (int i = 0; i < nnodes; ++i)
+        if (child_ptr[i + 1] - child_ptr[i] > 65535) return AFV_EINVAL;  // the descent's key carries the child position in 16 bits
     HIPCHK(c, hipSetDevice(c->device));
     afv_vocab *v = new (std::nothrow) afv_vocab();
     if (!v) return AFV_ENOMEM;
     v->desc_bytes = desc_bytes;
-    const int words = desc_bytes <= 32 ? 8 : 16;
-    std::vector<uint8_t> padded((size_t)nnodes * words * 4, 0);
-    for (int i = 0; i < nnodes; ++i) std::memcpy(padded.data() + (size_t)i * words * 4, desc + (size_t)i * desc_bytes, (size_t)desc_bytes);
-    hipError_t e = hipMalloc(&v->d_child_ptr, (size_t)(nnodes + 1) * 4);
-    if (e == hipSuccess) e = hipMalloc(&v->d_child_idx, (size_t)std::max(nchild, 1) * 4);
-    if (e == hipSuccess) e = hipMalloc(&v->d_desc, padded.size());
-    if (e == hipSuccess) e = hipMemcpy(v->d_child_ptr, child_ptr, (size_t)(nnodes + 1) * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess && nchild) e = hipMemcpy(v->d_child_idx, child_idx, (size_t)nchild * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(v->d_desc, padded.data(), padded.size(), hipMemcpyHostToDevice);
+    const int words = desc_bytes <= 32 ? 8 : 16, RD = words + 4;
+    // device image (k_bow.hip): nodes renumbered breadth first, the children of a node consecutive and in DBoW2 order; record =
+    // descriptor | first child record | #children | DBoW2 id | 0.  Nodes the root does not reach keep no record.
+    std::vector<int> order;  // record -> DBoW2 id
+    order.reserve((size_t)nnodes);
+    order.push_back(0);
+    std::vector<uint32_t> rec((size_t)nnodes * RD, 0);
+    std::vector<int> depth((size_t)nnodes, -1);  // by DBoW2 id; -1: not reachable from the root
+    depth[0] = 0;
+    for (size_t r = 0; r < order.size(); ++r) {
+        const int id = order[r];
+        for (int q = child_ptr[id]; q < child_ptr[id + 1]; ++q) depth[child_idx[q]] = depth[id] + 1;
+        uint32_t *R = rec.data() + r * RD;
+        std::memcpy(R, desc + (size_t)id * desc_bytes, (size_t)desc_bytes);
+        const int nc = child_ptr[id + 1] - child_ptr[id];
+        R[words] = (uint32_t)order.size();
+        R[words + 1] = (uint32_t)nc;
+        R[words + 2] = (uint32_t)id;
+        for (int q = child_ptr[id]; q < child_ptr[id + 1]; ++q) order.push_back(child_idx[q]);
+    }
+    {   // rank of every node among the nodes of its depth, ascending DBoW2 id: the FeatureVector's sort key (k_featvec_build)
+        std::vector<int> rank_of((size_t)nnodes, 0);
+        v->depth_width.clear();
+        for (int id = 0; id < nnodes; ++id) {
+            if (depth[id] < 0) continue;
+            if ((size_t)depth[id] >= v->depth_width.size()) v->depth_width.resize((size_t)depth[id] + 1, 0);
+            rank_of[id] = v->depth_width[(size_t)depth[id]]++;
+        }
+        for (size_t r = 0; r < order.size(); ++r) rec[r * RD + words + 3] = (uint32_t)rank_of[order[r]];
+    }
+    hipError_t e = hipMalloc(&v->d_rec, rec.size() * 4);
+    if (e == hipSuccess) e = hipMemcpy(v->d_rec, rec.data(), rec.size() * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         c->last_error = std::string("afv_vocab_create: ") + hipGetErrorString(e);
         afv_vocab_destroy(c, v);
         return e == hipErrorOutOfMemory ? AFV_ENOMEM : AFV_EHIP;
     }
-    v->dev = DevVocab{k, L, nnodes, words, (const int *)v->d_child_ptr, (const int *)v->d_child_idx, (const uint32_t *)v->d_desc};
+    v->dev = DevVocab{k, L, nnodes, words, RD, (const uint32_t *)v->d_rec, nullptr};
     *out = v;
+    return AFV_OK;
+}
+
+extern "C" int afv_vocab_set_stopped(afv_ctx *c, afv_vocab *v, const uint8_t *stopped) {
+    if (!c || !v) return AFV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!stopped) {
+        v->dev.stopped = nullptr;
+        v->h_stopped.clear();
+        return AFV_OK;
+    }
+    try {
+        v->h_stopped.assign(stopped, stopped + v->dev.nnodes);
+    } catch (...) {
+        return AFV_ENOMEM;
+    }
+    if (!v->d_stopped) HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&v->d_stopped), (size_t)v->dev.nnodes));
+    HIPCHK(c, hipMemcpy(v->d_stopped, stopped, (size_t)v->dev.nnodes, hipMemcpyHostToDevice));
+    v->dev.stopped = v->d_stopped;
     return AFV_OK;
 }
 
@@ -1841,9 +2000,8 @@ extern "C" void afv_vocab_destroy(afv_ctx *c, afv_vocab *v) {
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
     }
-    if (v->d_child_ptr) (void)hipFree(v->d_child_ptr);
-    if (v->d_child_idx) (void)hipFree(v->d_child_idx);
-    if (v->d_desc) (void)hipFree(v->d_desc);
+    if (v->d_rec) (void)hipFree(v->d_rec);
+    if (v->d_stopped) (void)hipFree(v->d_stopped);
     delete v;
 }
 
@@ -1860,7 +2018,7 @@ static int afv_bow_transform_impl(afv_ctx *c, const afv_vocab *v, const uint8_t 
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->d_match, b.h.data(), in_bytes, hipMemcpyHostToDevice, c->stream));
     afv_launch_bow_transform(&v->dev, reinterpret_cast<const uint32_t *>(c->d_match + d_off), n, levelsup,
-                             reinterpret_cast<int *>(c->d_match + leaf_off), reinterpret_cast<int *>(c->d_match + nid_off), c->stream);
+                             reinterpret_cast<int *>(c->d_match + leaf_off), reinterpret_cast<int *>(c->d_match + nid_off), nullptr, c->stream);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, b.fetch(leaf_node, leaf_off, (size_t)n * 4, c->stream));
     HIPCHK(c, b.fetch(node_at_level, nid_off, (size_t)n * 4, c->stream));

@@ -32,31 +32,6 @@ typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1 } ncclDataType_t;
 // ------------------------------------------------------------------------------------------------------------------
 // table
 // ------------------------------------------------------------------------------------------------------------------
-struct HostFeatVec {  // host copy of one keyframe's FeatureVector (node ids, CSR pointers, feature indices)
-    std::vector<int32_t> node_id, seg_ptr, seg_idx;
-};
-
-struct afv_table {
-    afv_ctx *c = nullptr;
-    int nsets = 0, cap = 0;
-    uint8_t *d_desc = nullptr;  // [nsets][cap][32]
-    float *d_angle = nullptr;   // [nsets][cap]
-    int32_t *d_n = nullptr;     // [nsets]
-    int32_t *d_idx = nullptr;   // [nsets][cap] FeatureVector feature indices in node order (afv_table_set_featvec), lazily allocated
-    float *d_geo = nullptr;     // [4][nsets][cap]: x, y, sigma2, mvuRight (afv_table_set_geometry / _u_right; -1 = monocular), lazily allocated
-    uint8_t *d_valid = nullptr; // [nsets][cap] "map point exists && !isBad()" (afv_table_set_valid), lazily allocated, default 1
-    std::vector<int32_t> h_n;
-    std::vector<HostFeatVec> fv;
-    std::vector<uint8_t> has_fv, has_geo;  // per set: afv_table_set_featvec / afv_table_set_geometry called since the last afv_table_set
-    // grow-only device buffers of the pair entry points + their pinned host image
-    int32_t *d_pairs = nullptr;  // [2][pair_cap]
-    int32_t *d_out = nullptr;    // [pair_cap][cap]
-    int32_t *d_nm = nullptr;     // [pair_cap]
-    int32_t *h_pin = nullptr;    // pinned: [2][pair_cap] pairs, then [pair_cap] counts, then [pair_cap][cap] matches
-    int pair_cap = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-};
-
 struct afv_comm {
     afv_ctx *c = nullptr;
     ncclComm_t comm = nullptr;
@@ -105,6 +80,7 @@ extern "C" int afv_table_create(afv_ctx *c, int nsets, int cap, afv_table **out)
         t->fv.resize((size_t)nsets);
         t->has_fv.assign((size_t)nsets, 0);
         t->has_geo.assign((size_t)nsets, 0);
+        t->fv_body_on_device.assign((size_t)nsets, 0);
         std::lock_guard<std::mutex> g(g_reg_mutex);
         g_tables.push_back(t);
     } catch (...) {
@@ -145,6 +121,7 @@ extern "C" int afv_table_set(afv_table *t, int set, const uint8_t *desc32, const
     // exists" mask (unset = all valid), geometry (afv_table_match_triangulation refuses the slot until it is set again)
     t->fv[set] = HostFeatVec();
     t->has_fv[set] = 0;
+    t->fv_body_on_device[set] = 0;
     t->has_geo[set] = 0;
     if (t->d_valid) HIPCHK(c, hipMemsetAsync(t->d_valid + (size_t)set * t->cap, 1, (size_t)t->cap, c->stream));
     HIPCHK(c, hipMemcpyAsync(t->d_n + set, &t->h_n[set], sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
@@ -177,6 +154,7 @@ extern "C" int afv_table_set_featvec(afv_table *t, int set, const int32_t *node_
         f.node_id.assign(node_id, node_id + nnodes);
         f.seg_ptr.assign(seg_ptr, seg_ptr + (nnodes ? nnodes + 1 : 0));
         f.seg_idx.assign(seg_idx, seg_idx + total);
+        t->fv_body_on_device[set] = 0;
         if (total) HIPCHK(c, hipMemcpy(t->d_idx + (size_t)set * t->cap, seg_idx, (size_t)total * sizeof(int32_t), hipMemcpyHostToDevice));
         t->has_fv[set] = 1;
         return AFV_OK;
@@ -246,11 +224,12 @@ extern "C" int afv_table_sync_counts(afv_table *t) {  // after a broadcast / ext
         const int v = std::min(std::max(fresh[s], 0), t->cap);
         if (v < t->h_n[s] && t->has_fv[s]) {
             // the set shrank under a stored FeatureVector: indices >= v would address rows that no longer exist
-            bool stale = false;
+            bool stale = t->fv_body_on_device[s] != 0;  // (a promoted frame's body has no host copy to check: dropped with the shrink)
             for (int32_t i : t->fv[s].seg_idx) stale |= i >= v;
             if (stale) {
                 t->fv[s] = HostFeatVec();
                 t->has_fv[s] = 0;
+                t->fv_body_on_device[s] = 0;
             }
         }
         t->h_n[s] = v;
@@ -301,6 +280,7 @@ static int table_unpack_meta(afv_table *t, const int32_t *blob, size_t len) {
             }
         }
         t->fv[s] = std::move(f);
+        t->fv_body_on_device[s] = 0;
         t->has_fv[s] = has_fv != 0;
         t->has_geo[s] = has_geo != 0;
     }
@@ -328,6 +308,7 @@ extern "C" int afv_table_clone(const afv_table *src, afv_table *dst) {
         for (int s = 0; s < dst->nsets; ++s) {  // nothing of the destination's previous content survives
             dst->fv[s] = HostFeatVec();
             dst->has_fv[s] = dst->has_geo[s] = 0;
+            dst->fv_body_on_device[s] = 0;
         }
         int rc = afv_table_sync_counts(dst);
         if (rc) return rc;
@@ -499,8 +480,10 @@ extern "C" int afv_table_match_bow(afv_table *t, const int32_t *pair_a, const in
 // travels once (descriptors, angles, FeatureVector feature indices); per candidate only the merge-join of the two FeatureVectors (host,
 // a few hundred ints).  M3 rules: validity on the keyframe side only (:216-222), a frame feature that already has a match is skipped
 // (:232), accept best <= TH_LOW (:250), rotation histogram keyed by the frame feature (:259).
+// `fr` != null: the frame side is a resident afv_frame (descriptors, angles and the FeatureVector body are on the device already; its node
+// structure on the host side of the handle) and F only carries n
 static int table_match_bow_frame_impl(afv_table *t, const int32_t *slots, int nslots, const afv_frame_view *F, float th_low, float nnratio,
-                                      int check_orientation, int32_t *match_f, int32_t *nmatches) {
+                                      int check_orientation, int32_t *match_f, int32_t *nmatches, const afv_frame *fr = nullptr) {
     afv_ctx *c = t->c;
     if (!t->d_idx) return AFV_EINVAL;  // no FeatureVector was ever stored
     const int nf = F->n, cap = t->cap;
@@ -514,7 +497,10 @@ static int table_match_bow_frame_impl(afv_table *t, const int32_t *slots, int ns
     }
     // the frame's FeatureVector: ascending node ids, indices inside the frame
     HostFeatVec FV;
-    if (F->nnodes > 0) {
+    if (fr) {
+        FV.node_id = fr->fv_node_id;
+        FV.seg_ptr = fr->fv_seg_ptr;
+    } else if (F->nnodes > 0) {
         FV.node_id.assign(F->node_id, F->node_id + F->nnodes);
         FV.seg_ptr.assign(F->seg_ptr, F->seg_ptr + F->nnodes + 1);
         const int total = FV.seg_ptr[F->nnodes];
@@ -536,9 +522,9 @@ static int table_match_bow_frame_impl(afv_table *t, const int32_t *slots, int ns
         seg_first[p + 1] = (int)segs.size();
     }
     const int nfe = std::max(nf, 1);
-    const size_t fdesc_off = b.put(F->desc32, (size_t)nf * 32);
-    const size_t fang_off = (check_orientation && nf) ? b.put(F->angle, (size_t)nf * sizeof(float)) : 0;
-    const size_t fidx_off = b.put(F->nnodes > 0 ? F->seg_idx : nullptr, (size_t)(F->nnodes > 0 ? FV.seg_ptr[F->nnodes] : 0) * sizeof(int32_t));
+    const size_t fdesc_off = fr ? 0 : b.put(F->desc32, (size_t)nf * 32);
+    const size_t fang_off = (!fr && check_orientation && nf) ? b.put(F->angle, (size_t)nf * sizeof(float)) : 0;
+    const size_t fidx_off = fr ? 0 : b.put(F->nnodes > 0 ? F->seg_idx : nullptr, (size_t)(F->nnodes > 0 ? FV.seg_ptr[F->nnodes] : 0) * sizeof(int32_t));
     const size_t segs_off = b.put(segs.data(), segs.size() * sizeof(Seg));
     const size_t tasks_off = b.put(tasks.data(), tasks.size() * sizeof(SegTask));
     const size_t jobs_off = b.reserve((size_t)nslots * sizeof(DevMatchJob));
@@ -556,18 +542,18 @@ static int table_match_bow_frame_impl(afv_table *t, const int32_t *slots, int ns
         const int a = slots[p];
         DevMatchJob &d = J[p];
         d.d1 = reinterpret_cast<const uint32_t *>(t->d_desc + (size_t)a * cap * 32);
-        d.d2 = reinterpret_cast<const uint32_t *>(c->d_match + fdesc_off);
+        d.d2 = fr ? reinterpret_cast<const uint32_t *>(fr->d_desc) : reinterpret_cast<const uint32_t *>(c->d_match + fdesc_off);
         d.n1 = t->h_n[a];
         d.n2 = nf;
         d.words = 8;
         d.segs = reinterpret_cast<const Seg *>(c->d_match + segs_off) + seg_first[p];
         d.nseg = seg_first[p + 1] - seg_first[p];
         d.idx1 = t->d_idx + (size_t)a * cap;
-        d.idx2 = reinterpret_cast<const int *>(c->d_match + fidx_off);
+        d.idx2 = fr ? fr->d_seg_idx : reinterpret_cast<const int *>(c->d_match + fidx_off);
         d.valid1 = t->d_valid ? t->d_valid + (size_t)a * cap : nullptr;  // FeatureMatcher.cc:216-222
         d.valid2 = nullptr;
         d.ang1 = t->d_angle + (size_t)a * cap;
-        d.ang2 = reinterpret_cast<const float *>(c->d_match + fang_off);
+        d.ang2 = fr ? fr->d_angle : reinterpret_cast<const float *>(c->d_match + fang_off);
         d.ang_stride = 1;
         d.th = th_low;
         d.ratio = nnratio;
@@ -600,9 +586,86 @@ extern "C" int afv_table_match_bow_frame(afv_table *t, const int32_t *slots, int
     return guarded(t->c, [&] { return table_match_bow_frame_impl(t, slots, nslots, frame, th_low, nnratio, check_orientation, match_f, nmatches); });
 }
 
-static int table_match_tri_impl(afv_table *t, const int32_t *pair_a, const int32_t *pair_b, const afv_table_tri_job *geo, int npairs,
+extern "C" int afv_table_match_bow_frame_h(afv_table *t, const int32_t *slots, int nslots, afv_frame *f, float th_low, float nnratio,
+                                           int check_orientation, int32_t *match_f, int32_t *nmatches) {
+    if (!t || !slots || nslots < 1 || !f || !nmatches) return AFV_EINVAL;
+    if (f->c != t->c || !f->has_features || !f->has_fv) return AFV_EINVAL;  // afv_frame_bow_transform first
+    afv_frame_view view{};
+    view.n = f->n;
+    return guarded(t->c, [&] { return table_match_bow_frame_impl(t, slots, nslots, &view, th_low, nnratio, check_orientation, match_f, nmatches, f); });
+}
+
+// KeyFrame::KeyFrame(Frame &F, ...) (src/KeyFrame.cc:36-60) on the device: one kernel copies the frame's arrays into the slot's rows of the
+// table planes; the FeatureVector's node structure goes host to host
+extern "C" int afv_table_set_from_frame(afv_table *t, int slot, afv_frame *f) {
+    if (!t || !f || slot < 0 || slot >= t->nsets || f->c != t->c || !f->has_features) return AFV_EINVAL;
+    if (f->n > t->cap) return AFV_ECAPACITY;
+    afv_ctx *c = t->c;
+    return guarded(c, [&]() -> int {
+        HIPCHK(c, hipSetDevice(c->device));
+        const size_t plane = (size_t)t->nsets * t->cap;
+        if (!t->d_geo) {  // a promoted frame brings its geometry: the planes exist from the first promotion on
+            HIPCHK(c, hipMalloc(&t->d_geo, 4 * plane * sizeof(float)));
+        }
+        if (f->has_fv && !t->d_idx) HIPCHK(c, hipMalloc(&t->d_idx, plane * sizeof(int32_t)));
+        PromoteArgs A{};
+        A.f_desc = reinterpret_cast<const uint4 *>(f->d_desc);
+        A.f_angle = f->d_angle; A.f_x = f->d_x; A.f_y = f->d_y; A.f_sigma2 = f->d_sigma2; A.f_ur = f->d_ur;
+        A.f_seg_idx = f->has_fv ? f->d_seg_idx : nullptr;
+        A.t_desc = reinterpret_cast<uint4 *>(t->d_desc + (size_t)slot * t->cap * 32);
+        A.t_angle = t->d_angle + (size_t)slot * t->cap;
+        A.t_x = t->d_geo + (size_t)slot * t->cap;
+        A.t_y = t->d_geo + plane + (size_t)slot * t->cap;
+        A.t_sigma2 = t->d_geo + 2 * plane + (size_t)slot * t->cap;
+        A.t_ur = t->d_geo + 3 * plane + (size_t)slot * t->cap;
+        A.t_idx = (f->has_fv && t->d_idx) ? t->d_idx + (size_t)slot * t->cap : nullptr;
+        A.t_valid = t->d_valid ? t->d_valid + (size_t)slot * t->cap : nullptr;
+        A.t_n = t->d_n + slot;
+        A.n = f->n; A.cap = t->cap; A.nkept = f->has_fv ? f->fv_total : 0;
+        afv_launch_table_promote(&A, f->n, t->cap, c->stream);
+        HIPCHK(c, hipGetLastError());
+        t->h_n[slot] = f->n;
+        t->fv[slot] = HostFeatVec();
+        t->has_fv[slot] = 0;
+        if (f->has_fv) {
+            t->fv[slot].node_id = f->fv_node_id;
+            t->fv[slot].seg_ptr = f->fv_seg_ptr;
+            // the body lives on the device only; the host copy is fetched on demand by the few paths that read it (triangulation row map)
+            t->fv[slot].seg_idx.clear();
+            t->fv_body_on_device[slot] = 1;
+            t->has_fv[slot] = 1;
+        }
+        t->has_geo[slot] = 1;
+        return AFV_OK;
+    });
+}
+
+// host copy of a slot's FeatureVector body when it was promoted from a frame (device to device): fetched once, on first need
+static int table_fetch_fv_body(afv_table *t, int slot) {
+    if (!t->fv_body_on_device[slot]) return AFV_OK;
+    afv_ctx *c = t->c;
+    HostFeatVec &f = t->fv[slot];
+    const int total = f.seg_ptr.empty() ? 0 : f.seg_ptr.back();
+    f.seg_idx.assign((size_t)total, 0);
+    if (total) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy(f.seg_idx.data(), t->d_idx + (size_t)slot * t->cap, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    t->fv_body_on_device[slot] = 0;
+    return AFV_OK;
+}
+
+static int table_match_tri_impl(afv_table *t, const int32_t *pair_a, const int32_t *pair_b, const afv_table_tri_job *caller_geo, int npairs,
                                 int32_t *match12, int32_t *nmatches) {
     afv_ctx *c = t->c;
+    std::vector<afv_table_tri_job> loaded;
+    if (!afv_load_jobs(caller_geo, npairs, offsetof(afv_table_tri_job, only_stereo), loaded)) return AFV_EINVAL;
+    const afv_table_tri_job *geo = loaded.data();
+    for (int p = 0; p < npairs; ++p) {
+        if (geo[p].only_stereo != 0 && geo[p].only_stereo != 1) return AFV_EINVAL;
+        const int rcf = table_fetch_fv_body(t, pair_a[p]);
+        if (rcf) return rcf;
+    }
     if (!t->d_idx || !t->d_geo) return AFV_EINVAL;
     for (int p = 0; p < npairs; ++p)
         for (int s : {pair_a[p], pair_b[p]})

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -35,9 +36,16 @@ extern "C" void afv_launch_select(const Geo *geo_dev, int nlevels, const uint32_
                                   const int *cand_count, uint32_t *kept_xy, float *kept_resp, uint16_t *kept_node, SelPoint *sel,
                                   int *sel_count, int M, int frame_base, int nframes, int wide, hipStream_t stream);
 extern "C" int afv_describe_blocks_per_frame(const Geo *g);
+// second destination of the describe kernel's outputs (afv_frame_extract: the frame's device arrays next to the pinned host copy); all null = none
+struct DescribeMirror {
+    afv_keypoint *kps;
+    uint8_t *desc;
+    int *n;
+};
 extern "C" void afv_launch_describe(const Geo *geo_dev, int blocks_per_frame, const FrameSrc *src0, const uint8_t *pyr,
                                     const SelPoint *sel, const int *sel_count, afv_keypoint *kps, uint8_t *desc,
-                                    int cap_per_frame, int *n_out, int *status, int frame_base, int nframes, hipStream_t stream);
+                                    int cap_per_frame, int *n_out, int *status, int frame_base, int nframes, const DescribeMirror *mirror,
+                                    hipStream_t stream);
 extern "C" void afv_launch_blur_level(const uint8_t *img, int w, int h, int pitch, uint8_t *out, hipStream_t stream);
 
 extern "C" void afv_launch_match_bow(const DevMatchJob *jobs, int njobs, hipStream_t stream);
@@ -54,7 +62,17 @@ extern "C" void afv_launch_match_tri(const DevTriJob *jobs, int njobs, int max_n
 extern "C" void afv_launch_match_l2(const float *d1, int n1, const float *d2, int n2, int dim, const uint8_t *v1,
                                     const uint8_t *v2, float th, float ratio, int *out, int *nmatches, hipStream_t stream);
 
-extern "C" void afv_launch_match_projection(const DevProjJob *jobs, int njobs, int max_nq, hipStream_t stream);
+extern "C" void afv_launch_match_projection(const DevProjJob *jobs, int njobs, int max_nq, size_t wg_lds, hipStream_t stream);
+extern "C" int afv_project_prepare(void);
+extern "C" size_t afv_project_wg_lds(int kind_init, int n, int nq);
+extern "C" size_t afv_frame_grid_lds(int cols, int rows, int cap);
+extern "C" void afv_launch_frame_grid(const DevGridJob *jobs, int njobs, size_t lds_bytes, hipStream_t stream);
+extern "C" void afv_launch_frame_grid1(const DevGridJob *job, size_t lds_bytes, hipStream_t stream);
+extern "C" void afv_launch_frame_gather(const uint8_t *table, const int *nset, int nsets, int cap, const int *slot, const int *idx, int nq,
+                                        void *out, int *bad, hipStream_t stream);
+extern "C" void afv_launch_featvec_build(const int *leaf, const int *nid, const int *dense, int n, int cap, int width, const uint8_t *stopped,
+                                         int *seg_idx, int *n_kept, int *h_leaf, int *h_nid, int *h_dense, hipStream_t stream);
+extern "C" void afv_launch_table_promote(const void *args, int n, int cap, hipStream_t stream);
 extern "C" void afv_launch_match_fuse(const DevProjJob *jobs, int njobs, int max_nq, hipStream_t stream);
 extern "C" size_t afv_match_l2_scratch_bytes(int n1, int n2, int *ntiles_out, int *cols_per_tile_out);
 extern "C" int afv_launch_match_l2_tiled(const float *d1, int n1, const float *d2, int n2, int dim, const uint8_t *v1, const uint8_t *v2,
@@ -62,14 +80,37 @@ extern "C" int afv_launch_match_l2_tiled(const float *d1, int n1, const float *d
                                          hipStream_t stream);
 extern "C" int afv_launch_match_l2_pairs(const float *desc, const int *nset, int cap, int dim, const int *pa, const int *pb, int npairs,
                                          int pair_base, float th, float ratio, int *out, int *nmatches, void *scratch, hipStream_t stream);
-extern "C" void afv_launch_match_init(const DevProjJob *jobs, int njobs, int max_nq, hipStream_t stream);
+extern "C" void afv_launch_match_init(const DevProjJob *jobs, int njobs, int max_nq, size_t wg_lds, hipStream_t stream);
 
 extern "C" void afv_launch_bow_transform(const DevVocab *v, const uint32_t *desc, int n, int levelsup, int *leaf_node,
-                                         int *node_at_level, hipStream_t stream);
+                                         int *node_at_level, int *rank_at_level, hipStream_t stream);
 struct afv_vocab {
     DevVocab dev{};
     int desc_bytes = 32;
-    void *d_child_ptr = nullptr, *d_child_idx = nullptr, *d_desc = nullptr;
+    void *d_rec = nullptr;       // breadth-first records (k_bow.hip)
+    uint8_t *d_stopped = nullptr;
+    std::vector<uint8_t> h_stopped;  // host copy of the stop list (empty: none)
+    std::vector<int> depth_width;    // nodes per depth (index = depth, 0 = the root)
+};
+
+// the device-resident Frame (afv_frame.hip)
+struct afv_frame {
+    afv_ctx *c = nullptr;
+    afv_frame_params p{};
+    int cap = 0, n = 0;
+    float inv_w = 0, inv_h = 0;
+    bool has_features = false, has_grid = false, has_fv = false;
+    // device arrays, one allocation
+    uint8_t *d_block = nullptr;
+    afv_keypoint *d_kps = nullptr;
+    uint8_t *d_desc = nullptr;
+    float *d_x = nullptr, *d_y = nullptr, *d_size = nullptr, *d_angle = nullptr, *d_sigma2 = nullptr, *d_inf = nullptr, *d_ur = nullptr;
+    int *d_n = nullptr, *d_cell_ptr = nullptr, *d_leaf = nullptr, *d_nid = nullptr, *d_dense = nullptr, *d_seg_idx = nullptr, *d_nkept = nullptr;
+    int4 *d_cell_ent = nullptr;
+    uint8_t *d_oct0 = nullptr;         // octave == 0 per feature (the query filter of SearchForInitialization)
+    // host side of the FeatureVector: node structure for the merge-join
+    std::vector<int32_t> fv_node_id, fv_seg_ptr;
+    int fv_total = 0;
 };
 
 #define AFV_MAX_SIDE 8192
@@ -87,6 +128,9 @@ struct afv_ctx {
     int match_engine = AFV_MATCH_ENGINE_MFMA;  // phase 1 of the brute-force pair matcher; afv_set_match_engine
     int resolve_engine = 2;        // phase 2: 0 = ordered walk on one wavefront (64-row rounds), 1 = workgroup-wide fixed point, 2 = by call size
     int resolve_wg_max_pairs = 256; // ... 2: calls of at most this many pairs take the fixed point; afv_set_match_resolve
+    int proj_engine = 2;           // ordered phase of the projection searches: 0 = ordered walk, 1 = workgroup fixed point, 2 = 1 when it fits
+    int proj_wg_lds_max = 0;       // dynamic LDS bytes the workgroup engines may use (0: unavailable); afv_project_prepare at afv_create
+    std::vector<afv_frame *> frames;  // frames alive on this context (destroyed with it)
     int split_chunks = 0;          // ... into this many chunks (alternating streams); 0 = about 85 frames each; afv_set_split_chunks
     // small-batch ("latency") path: kernels shaped for one or a few frames; afv_set_small_batch_path
     int small_mode = 1;            // 0 = never, 1 = batches of at most small_max_frames, 2 = always
@@ -210,6 +254,29 @@ static inline int guarded(afv_ctx *c, F &&f) {
     }
 }
 
+// versioned job arrays (include/afv_hip.h, "JOB RECORDS THAT CARRY struct_size"): the caller's array, whatever layout it was compiled
+// against, copied into the current one; fields its layout does not have are zero.  false = AFV_EINVAL (missing / inconsistent / absurd
+// struct_size)
+template <class T>
+static inline bool afv_load_jobs(const T *jobs, int njobs, size_t first_layout_bytes, std::vector<T> &out) {
+    if (!jobs || njobs < 1) return false;
+    const uint8_t *base = reinterpret_cast<const uint8_t *>(jobs);
+    uint32_t ss;
+    std::memcpy(&ss, base, sizeof(ss));
+    if (ss < first_layout_bytes || ss > 4 * sizeof(T) || (ss & 3)) return false;
+    out.resize((size_t)njobs);
+    for (int i = 0; i < njobs; ++i) {
+        const uint8_t *p = base + (size_t)i * ss;
+        uint32_t si;
+        std::memcpy(&si, p, sizeof(si));
+        if (si != ss) return false;
+        std::memset(static_cast<void *>(&out[i]), 0, sizeof(T));
+        std::memcpy(static_cast<void *>(&out[i]), p, std::min<size_t>(ss, sizeof(T)));
+        out[i].struct_size = (uint32_t)sizeof(T);
+    }
+    return true;
+}
+
 // ---- matcher staging ----
 // Host image of the device staging buffer.  It lives in the context's pinned arena, so the one H2D copy of a call and the
 // D2H copies of its results are true async DMA transfers (no pageable bounce inside the runtime); results land at the same
@@ -321,9 +388,59 @@ static inline size_t put_desc(Blob &b, const uint8_t *d, int n, int desc_bytes, 
     return off;
 }
 
+// ---- the keyframe table (afv_comm.hip; afv_frame.hip gathers query descriptors from it) ----
+struct HostFeatVec {  // host copy of one keyframe's FeatureVector (node ids, CSR pointers, feature indices)
+    std::vector<int32_t> node_id, seg_ptr, seg_idx;
+};
+
+struct afv_table {
+    afv_ctx *c = nullptr;
+    int nsets = 0, cap = 0;
+    uint8_t *d_desc = nullptr;  // [nsets][cap][32]
+    float *d_angle = nullptr;   // [nsets][cap]
+    int32_t *d_n = nullptr;     // [nsets]
+    int32_t *d_idx = nullptr;   // [nsets][cap] FeatureVector feature indices in node order (afv_table_set_featvec), lazily allocated
+    float *d_geo = nullptr;     // [4][nsets][cap]: x, y, sigma2, mvuRight (afv_table_set_geometry / _u_right; -1 = monocular), lazily allocated
+    uint8_t *d_valid = nullptr; // [nsets][cap] "map point exists && !isBad()" (afv_table_set_valid), lazily allocated, default 1
+    std::vector<int32_t> h_n;
+    std::vector<HostFeatVec> fv;
+    std::vector<uint8_t> has_fv, has_geo;  // per set: afv_table_set_featvec / afv_table_set_geometry called since the last afv_table_set
+    std::vector<uint8_t> fv_body_on_device;  // per set: the FeatureVector body came from a frame (afv_table_set_from_frame): no host copy yet
+    // grow-only device buffers of the pair entry points + their pinned host image
+    int32_t *d_pairs = nullptr;  // [2][pair_cap]
+    int32_t *d_out = nullptr;    // [pair_cap][cap]
+    int32_t *d_nm = nullptr;     // [pair_cap]
+    int32_t *h_pin = nullptr;    // pinned: [2][pair_cap] pairs, then [pair_cap] counts, then [pair_cap][cap] matches
+    int pair_cap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
 // ---- shared between afv_api.hip and afv_comm.hip ----
 int afv_match_pairs_core(afv_ctx *c, const uint8_t *d_desc, const float *d_ang, int ang_stride, const int32_t *d_n, int cap,
                          const int32_t *d_pair_a, const int32_t *d_pair_b, int npairs, float th_low, float nnratio,
                          int check_orientation, int32_t *d_match, int32_t *d_nmatches, hipStream_t s);
 void afv_shared_segments(const afv_match_job &j, std::vector<Seg> &segs);
 void afv_table_release_all(afv_ctx *c);  // afv_destroy: tables / communicators still alive die with their context
+void afv_frame_release_all(afv_ctx *c);  // ... and so do its frames
+void afv_frame_after_extract(afv_frame *f, hipStream_t s);  // afv_frame.hip: k_frame_grid behind the describe kernel of afv_frame_extract
+int afv_extract_into_frame(afv_ctx *c, afv_frame *f, const uint8_t *gray, int width, int height, int stride_bytes, afv_keypoint *kps,
+                           uint8_t *desc32, int cap, int *n_out);  // afv_api.hip: afv_orb_extract with the frame as second destination
+// the host side of E12 (FeatureExtractor.cpp:132-172): keyPtsSize of octave `o` as afv_orb_size_sigma computes it
+float afv_size_of_octave(const afv_ctx *c, int octave);
+// projection searches over a feature side that is already on the device (afv_frame.hip) share the staging / launch code of the host-pointer
+// entry points (afv_api.hip)
+struct ProjFeatureSide {      // device pointers of the feature side; null fdesc = stage it from the job's host arrays
+    const uint32_t *fdesc = nullptr;
+    int n = 0, words = 8;
+    const float *x = nullptr, *y = nullptr, *size = nullptr, *angle = nullptr, *inf = nullptr, *u_right = nullptr;
+    const int *cell_ptr = nullptr;
+    const int4 *cell_ent = nullptr;
+    const uint32_t *qdesc_dev = nullptr;  // queries' descriptors already on the device (another frame's rows)
+    const afv_table *qref_table = nullptr;  // ... or rows (slot, idx) of a keyframe table, gathered on the device (host arrays of nq ints)
+    const int32_t *qref_slot = nullptr, *qref_idx = nullptr;
+    const float *qangle_dev = nullptr;
+    const uint8_t *qvalid_dev = nullptr;
+};
+enum { AFV_KIND_PROJ = 0, AFV_KIND_FUSE = 1, AFV_KIND_INIT = 2 };
+int afv_match_projection_core(afv_ctx *c, const afv_proj_job *jobs, int njobs, int32_t *assign, int32_t *nmatches, int kind,
+                              const ProjFeatureSide *dev_side);

@@ -153,7 +153,8 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
                                                                 const int *__restrict__ sel_count,
                                                                 afv_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
                                                                 int cap_per_frame, int *__restrict__ n_out,
-                                                                int *__restrict__ status, int frame_base, int per_frame, int total_blocks) {
+                                                                int *__restrict__ status, int frame_base, int per_frame, int total_blocks,
+                                                                DescribeMirror mir) {
     // patch rows are PP = 52 bytes apart (13 dwords: odd -> rows spread over all LDS banks); 2 guard rows/dwords so that
     // the 3-dword row reads of blur_at never leave the slice
     __shared__ __attribute__((aligned(16))) uint8_t s_patch[KP_PER_BLOCK][(PS + 1) * PP];
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
     }
     if (blk == 0 && threadIdx.x == 0) {
         n_out[f] = min(total, cap_per_frame);
+        if (mir.n) mir.n[f] = min(total, cap_per_frame);
         if (status && total > cap_per_frame) atomicMin(status, AFV_ECAPACITY);
     }
     if (idx >= mine) return;  // wave-uniform
@@ -325,6 +327,7 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
         for (int i = 1; i < 8; ++i)
             if (lane == i) w = words[i];
         reinterpret_cast<uint32_t *>(desc + o * 32)[lane] = w;
+        if (mir.desc) reinterpret_cast<uint32_t *>(mir.desc + o * 32)[lane] = w;  // afv_frame_extract: the frame's device copy
     }
     if (lane == 0) {
         afv_keypoint k;
@@ -336,6 +339,7 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
         k.octave = l;
         k.class_id = -1;
         kps[o] = k;
+        if (mir.kps) mir.kps[o] = k;
     }
 }
 
@@ -347,11 +351,13 @@ extern "C" int afv_describe_blocks_per_frame(const Geo *g) {
 
 extern "C" void afv_launch_describe(const Geo *geo_dev, int blocks_per_frame, const FrameSrc *src0, const uint8_t *pyr,
                                     const SelPoint *sel, const int *sel_count, afv_keypoint *kps, uint8_t *desc,
-                                    int cap_per_frame, int *n_out, int *status, int frame_base, int nframes, hipStream_t stream) {
+                                    int cap_per_frame, int *n_out, int *status, int frame_base, int nframes, const DescribeMirror *mirror,
+                                    hipStream_t stream) {
     const int total = blocks_per_frame * nframes;
     dim3 grid((total + 7) / 8 * 8);
+    const DescribeMirror mir = mirror ? *mirror : DescribeMirror{nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(k_describe, grid, dim3(64 * KP_PER_BLOCK), 0, stream, geo_dev, *src0, pyr, sel, sel_count, kps, desc,
-                       cap_per_frame, n_out, status, frame_base, blocks_per_frame, total);
+                       cap_per_frame, n_out, status, frame_base, blocks_per_frame, total, mir);
 }
 
 // ---------------- standalone E9: blur one level of one frame (debug / parity of the blur arithmetic) ----------------

@@ -17,8 +17,16 @@
 //      (cell-major = the reference's visiting order), each lane keeps its K best keys
 //      (distance << 48 | window cell rank << 32 | position in cell << 16 | feature), and K wave-minimum rounds extract
 //      the query's K best.  Keys order candidates exactly like the reference's sequential best/second scan.
-//   2. k_proj_resolve — one wave per job replays the queries in order in speculative 64-query rounds (claim / replay on
+//   2. the ordered phase, two engines with identical results (afv_set_projection_resolve):
+//      k_proj_resolve_wg (round 5, default) — ONE fixed point over all live queries of a job on a 1024-thread workgroup, the recipe of
+//      k_match_resolve_wg (k_match.hip): a query's decision is a function of the features wanted by the OCCUPYING queries before it, so any
+//      assignment that satisfies all these equations is the sequential outcome; every pass all live queries re-evaluate against the
+//      claims of the previous pass (three rotating LDS arrays, one barrier per pass); queries whose keys are used up are rescanned
+//      exactly after convergence, in order, up to the first that takes a feature.
+//      k_proj_resolve (rounds 1-4) — one wave per job replays the queries in order in speculative 64-query rounds (claim / replay on
 //      the feature-occupancy bitset); a query that runs out of keys is rescanned exactly, again with lanes over cells.
+// The grid arrives as cell_ptr + cell_ent (k_frame.hip builds it on the device): an entry carries the feature's index, position and
+// keyPtsSize, so a candidate costs ONE dependent load before its descriptor instead of two (index, then x / y / size).
 #include "afv_device.h"
 #include "afv_runtime.h"  // the launchers below are declared there: a signature that drifts is a compile error, not a silent ABI mismatch
 #include "afv_jobs.h"
@@ -57,14 +65,38 @@ __device__ __forceinline__ int proj_hamming(const uint32_t *a, const uint32_t *b
     return d;
 }
 
+// wave-wide minimum on DPP (row shifts inside the rows of 16 lanes, then row_bcast15 / row_bcast31 carry the row results: no LDS
+// crossbar - the __shfl_xor butterfly of rounds 1-4 was six dependent ds_bpermute pairs per call); every lane receives the result
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long t = __shfl_xor(v, o, 64);
-        v = t < v ? t : v;
+#define AFV_MIN64_STEP(ctrl, rmask)                                                                                       \
+    {                                                                                                                     \
+        const unsigned lo_ = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)(unsigned)v, ctrl, rmask, 0xf, false);        \
+        const unsigned hi_ = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)(unsigned)(v >> 32), ctrl, rmask, 0xf, false); \
+        const unsigned long long t_ = ((unsigned long long)hi_ << 32) | lo_;                                              \
+        v = t_ < v ? t_ : v;                                                                                              \
     }
-    return v;
+    AFV_MIN64_STEP(0x111, 0xf)  // row_shr:1
+    AFV_MIN64_STEP(0x112, 0xf)  // row_shr:2
+    AFV_MIN64_STEP(0x114, 0xf)  // row_shr:4
+    AFV_MIN64_STEP(0x118, 0xf)  // row_shr:8
+    AFV_MIN64_STEP(0x142, 0xa)  // row_bcast:15 into rows 1, 3
+    AFV_MIN64_STEP(0x143, 0xc)  // row_bcast:31 into rows 2, 3
+#undef AFV_MIN64_STEP
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
 }
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#define AFV_MIN32_STEP(ctrl, rmask) v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, ctrl, rmask, 0xf, false));
+    AFV_MIN32_STEP(0x111, 0xf)
+    AFV_MIN32_STEP(0x112, 0xf)
+    AFV_MIN32_STEP(0x114, 0xf)
+    AFV_MIN32_STEP(0x118, 0xf)
+    AFV_MIN32_STEP(0x142, 0xa)
+    AFV_MIN32_STEP(0x143, 0xc)
+#undef AFV_MIN32_STEP
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ int wave_sum_i32(int v) { return __builtin_amdgcn_readlane(afv_wave_incl_scan(v), 63); }
 
 struct Window {
     int cx0, cx1, cy0, cy1;
@@ -101,10 +133,12 @@ __device__ __forceinline__ Window proj_window(const DevProjJob &J, float x, floa
                 const int cell_ = (w_.cx0 + c / ny_) * J.rows + (w_.cy0 + c % ny_);                   \
                 const int kb_ = J.cell_ptr[cell_], ke_ = J.cell_ptr[cell_ + 1];                       \
                 for (int k_ = kb_; k_ < ke_; ++k_) {                                                  \
-                    const int idx = J.cell_idx[k_];                                                   \
-                    const float s_ = J.size[idx];                                                     \
+                    const int4 e_ = J.cell_ent[k_];                                                   \
+                    const int idx = e_.x;                                                             \
+                    const float fx_ = __int_as_float(e_.y), fy_ = __int_as_float(e_.z);               \
+                    const float s_ = __int_as_float(e_.w);                                            \
                     if (s_ < mn_ || s_ > mx_) continue;                                               \
-                    if (!(fabsf(J.x[idx] - x_) < r_ && fabsf(J.y[idx] - y_) < r_)) continue;          \
+                    if (!(fabsf(fx_ - x_) < r_ && fabsf(fy_ - y_) < r_)) continue;                    \
                     if (sg_) {                                                                        \
                         const float ur_ = J.u_right[idx];                                             \
                         if (ur_ > 0.0f && fabsf(qur_ - ur_) > qer_) continue;                          \
@@ -122,7 +156,15 @@ __device__ __forceinline__ unsigned long long make_key(int d, int c, int kpos, i
 }
 
 // ---------------- phase 1: K best keys per query, one wave per query ----------------
-template <int W, int K>
+// REC selects what the ordered phase reads:
+//   0  projection, ordered walk (k_proj_resolve): 64-byte record = 4 keys | 4 aux | #candidates | "occupies"
+//   1  projection, fixed point (k_proj_resolve_wg): 32-byte record = 4 x (distance << 16 | feature) | #candidates | "occupies" | 0 | 0
+//   2  initialization, ordered walk (k_init_resolve): IK 64-bit keys + ncand
+//   3  initialization, fixed point (k_init_resolve_wg): IK x (distance << 16 | feature) + ncand
+// Features that are occupied before the search starts (F.pts[i] with observations, :108-110, :1361-1363) never become free again: they
+// are dropped here, so the ordered phase only deals with what the queries of THIS call take from each other.
+#define PROJ_NO_KEY32 0xffffffffu
+template <int W, int K, int REC>
 __device__ void topk_query(const DevProjJob &J, int q, int lane) {
     unsigned long long k[K];
 #pragma unroll
@@ -130,9 +172,16 @@ __device__ void topk_query(const DevProjJob &J, int q, int lane) {
     int visited = 0;
     if (!J.qvalid || J.qvalid[q]) {
         uint32_t qd[W];
+        {
+            const uint4 *qp = reinterpret_cast<const uint4 *>(J.qdesc + (size_t)q * W);
 #pragma unroll
-        for (int i = 0; i < W; ++i) qd[i] = J.qdesc[(size_t)q * W + i];
+            for (int i = 0; i < W / 4; ++i) {
+                const uint4 t = qp[i];
+                qd[4 * i] = t.x, qd[4 * i + 1] = t.y, qd[4 * i + 2] = t.z, qd[4 * i + 3] = t.w;
+            }
+        }
         PROJ_WAVE_WINDOW(J, q, lane, {
+            if (REC < 2 && J.occupied && J.occupied[idx]) continue;
             unsigned long long key = make_key(proj_hamming<W>(qd, J.fdesc + (size_t)idx * W), c, kpos, idx);
             _Pragma("unroll") for (int s = 0; s < K; ++s) {
                 if (key < k[s]) {
@@ -144,22 +193,27 @@ __device__ void topk_query(const DevProjJob &J, int q, int lane) {
             ++visited;
         })
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) visited += __shfl_xor(visited, o, 64);
+    visited = wave_sum_i32(visited);
+    // K extraction rounds.  A lane's cells are c = lane, lane + 64, ...: the top half of a key (distance << 16 | window cell rank) is
+    // unique to its lane, so the wave minimum of the heads' top halves (32-bit DPP) names the winner lane (cell rank & 63), and the
+    // bottom half (position in cell << 16 | feature) is read from that lane.
     unsigned long long mine = P_NO_KEY;  // lane s ends up holding the query's s-th best key
 #pragma unroll
     for (int s = 0; s < K; ++s) {
-        const unsigned long long m = wave_min_u64(k[0]);
+        const unsigned top = wave_min_u32((unsigned)(k[0] >> 32));
+        const int wl = (int)(top & 63u);
+        const unsigned bot = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k[0], wl);
+        const unsigned long long m = top == PROJ_NO_KEY32 ? P_NO_KEY : (((unsigned long long)top << 32) | bot);
         if (lane == s) mine = m;
-        if (k[0] == m && m != P_NO_KEY) {  // keys are unique (the feature is part of the key): exactly one lane pops
+        if (lane == wl && top != PROJ_NO_KEY32) {
 #pragma unroll
             for (int t = 0; t + 1 < K; ++t) k[t] = k[t + 1];
             k[K - 1] = P_NO_KEY;
         }
     }
-    if (K == PK) {
-        // projection searches: a 64-byte record per query so that the ordered phase never touches global memory on its fast
-        // path: 4 keys | 4 x (candidate size [mode 0] or rotation bin [mode 1]) | #candidates | "occupies" flag
+    if (REC == 0) {
+        // a 64-byte record per query so that the ordered walk never touches global memory on its fast path:
+        // 4 keys | 4 x (candidate size [mode 0] or rotation bin [mode 1]) | #candidates | "occupies" flag
         uint32_t *rec = reinterpret_cast<uint32_t *>(J.keys) + (size_t)q * 16;
         if (lane < PK) {
             reinterpret_cast<unsigned long long *>(rec)[lane] = mine;
@@ -175,19 +229,28 @@ __device__ void topk_query(const DevProjJob &J, int q, int lane) {
             rec[12] = (uint32_t)visited;
             rec[13] = (!J.qocc || J.qocc[q]) ? 1u : 0u;
         }
-    } else {
+    } else if (REC == 1) {
+        uint32_t *rec = reinterpret_cast<uint32_t *>(J.keys) + (size_t)q * 8;
+        if (lane < PK) rec[lane] = mine == P_NO_KEY ? PROJ_NO_KEY32 : (((uint32_t)key_dist(mine) << 16) | (uint32_t)key_idx(mine));
+        if (lane == PK) rec[4] = (uint32_t)visited;
+        if (lane == PK + 1) rec[5] = (!J.qocc || J.qocc[q]) ? 1u : 0u;
+    } else if (REC == 2) {
         if (lane < K) J.keys[(size_t)q * K + lane] = mine;
+        if (lane == 0) J.ncand[q] = visited;
+    } else {
+        uint32_t *rec = reinterpret_cast<uint32_t *>(J.keys) + (size_t)q * K;
+        if (lane < K) rec[lane] = mine == P_NO_KEY ? PROJ_NO_KEY32 : (((uint32_t)key_dist(mine) << 16) | (uint32_t)key_idx(mine));
         if (lane == 0) J.ncand[q] = visited;
     }
 }
 
-template <int K>
+template <int K, int REC>
 __global__ __launch_bounds__(PT) void k_proj_topk(const DevProjJob *__restrict__ jobs) {
     const DevProjJob J = jobs[blockIdx.y];
     const int lane = threadIdx.x & 63, q = blockIdx.x * (PT / 64) + (threadIdx.x >> 6);
     if (q >= J.nq) return;
-    if (J.words == 8) topk_query<8, K>(J, q, lane);
-    else topk_query<16, K>(J, q, lane);
+    if (J.words == 8) topk_query<8, K, REC>(J, q, lane);
+    else topk_query<16, K, REC>(J, q, lane);
 }
 
 // ---------------- phase 2: ordered resolve, one wave per job ----------------
@@ -399,8 +462,7 @@ __device__ void proj_resolve(const DevProjJob &J, int stage_cap) {
                 ++dropped;
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) dropped += __shfl_xor(dropped, o, 64);
+        dropped = wave_sum_i32(dropped);
         nm -= dropped;
     }
 #ifdef AFV_PROJ_STATS
@@ -415,6 +477,328 @@ __global__ __launch_bounds__(PT) void k_proj_resolve(const DevProjJob *__restric
     else proj_resolve<16>(J, stage_cap);
 }
 
+// ---------------- phase 2, workgroup form (round 5): ONE fixed point over all live queries of a job, 1024 threads ----------------
+// The ordered walk above replays the queries 64 at a time on one wavefront: a job of 1000 queries costs 16+ rounds of dependent LDS
+// round trips behind workgroup-scope fences (37 us measured in round 2).  The argument of k_match_resolve_wg (k_match.hip) carries over:
+// query i's decision is a function f of the features WANTED by the occupying queries before it - want_i = f({want_j : j < i, j
+// occupies}) - so any assignment that satisfies all these equations IS the sequential outcome (induction on i), and iterating "every
+// query re-evaluates f against the current claims" reaches it after as many passes as the longest chain of queries competing for a
+// feature + 1.
+//   * "feature c is taken for query i" = claim[c] < i, claim[c] = smallest live index of an OCCUPYING query that wants c (atomic min);
+//     three rotating LDS arrays (read / write / clear): one barrier per pass, which also carries the "did anything change" vote;
+//   * features occupied before the call never appear (phase 1 drops them);
+//   * a query whose four keys are used up (and whose window holds more) needs the exact rescan of its window, meaningful once every
+//     query before it is final: after convergence the waiting queries are rescanned, one per wavefront (16 per step), against the claims
+//     of the queries before them; the answers are adopted in order up to and including the first that takes a feature, those queries
+//     are pinned, the iteration continues.  Two shortcuts keep rescans rare: the best free key already above TH_HIGH is final, and in
+//     the local-map mode a best key that passes the ratio test against the LAST key passes it against anything outside the list;
+//   * F.pts[c] ends up as the LAST query that took c (a query without observations does not block later ones, :108-110): atomic max over
+//     the final wants.
+#define PW_T 1024
+#define PW_NW (PW_T / 64)
+#define PW_INF 0x7fffffff
+#define PW_WLIST 128
+#define PW_GUARD (-0x7fffffff)  // *nmatches when the pass guard trips (never observed; the host turns it into AFV_EHIP)
+
+static inline size_t proj_wg_lds_bytes(int n, int nq) {
+    const size_t nr = ((size_t)n + 63) & ~(size_t)63, qr = ((size_t)nq + 63) & ~(size_t)63;
+    return 3 * nr * 4 + qr * 16 /*keys*/ + qr * 4 /*meta*/ + 3 * qr * 2 /*w1, w2, pin*/ + qr * 2 /*live*/ + qr /*flag*/ + 64;
+}
+
+// one live query against the claims in R: the feature it accepts (-1: none) and whether it needs the exact rescan
+__device__ __forceinline__ void proj_eval(const DevProjJob &J, const int4 kk, int meta, const int *R, int li, int &want, bool &rescan) {
+    const unsigned keys[PK] = {(unsigned)kk.x, (unsigned)kk.y, (unsigned)kk.z, (unsigned)kk.w};
+    const bool complete = (meta & 0x7fffffff) <= PK;  // the key list holds the whole window
+    int cl[PK];
+#pragma unroll
+    for (int s = 0; s < PK; ++s) cl[s] = keys[s] == PROJ_NO_KEY32 ? -1 : R[keys[s] & 0xffffu];  // four LDS reads in flight together
+    int e0 = -1, e1 = -1, d0 = 0, d1 = 0;
+#pragma unroll
+    for (int s = 0; s < PK; ++s) {
+        const bool fr = keys[s] != PROJ_NO_KEY32 && !(cl[s] < li);
+        const int idx = (int)(keys[s] & 0xffffu), d = (int)(keys[s] >> 16);
+        if (fr && e0 < 0) {
+            e0 = idx;
+            d0 = d;
+        } else if (fr && e1 < 0) {
+            e1 = idx;
+            d1 = d;
+        }
+    }
+    const float d_last = (float)(keys[PK - 1] >> 16);  // incomplete lists are full: every candidate outside is at least this far
+    want = -1;
+    rescan = false;
+    if (e0 < 0) {
+        rescan = !complete && d_last <= J.th;
+    } else if (!((float)d0 <= J.th)) {
+        // the best free candidate fails TH_HIGH: final
+    } else if (J.mode == 1) {
+        want = e0;  // best only (:1379-1393)
+    } else if (e1 >= 0) {
+        bool rej = false;
+        if ((float)d0 > J.ratio * (float)d1) {  // FeatureMatcher.cc:142-148
+            const float bs = J.size[e0], bs2 = J.size[e1];
+            rej = (bs / bs2 < J.tol) && (bs / bs2 > J.inv_tol) && (bs2 > 0.0f);
+        }
+        want = rej ? -1 : e0;
+    } else if (complete) {
+        want = e0;  // no second candidate at all: bestSize2 = -1, the ratio test is skipped
+    } else if (J.ratio >= 0.0f && !((float)d0 > J.ratio * d_last)) {
+        want = e0;  // ratio * d2 >= ratio * d_last >= d0 for every candidate outside the list: the test cannot reject
+    } else {
+        rescan = true;
+    }
+}
+
+template <int W>
+__device__ void proj_resolve_wg(const DevProjJob &J) {
+    extern __shared__ __attribute__((aligned(16))) char pw_smem[];
+    const int nr = (J.n + 63) & ~63, qr = (J.nq + 63) & ~63;
+    int *s_claim = reinterpret_cast<int *>(pw_smem);                         // three arrays of nr
+    int4 *s_keys = reinterpret_cast<int4 *>(s_claim + 3 * nr);               // per live query
+    int *s_meta = reinterpret_cast<int *>(s_keys + qr);                       // #candidates | occupies << 31
+    short *s_w1 = reinterpret_cast<short *>(s_meta + qr), *s_w2 = s_w1 + qr;  // a live query's want after the last / the last but one pass
+    short *s_pin = s_w2 + qr;                                                 // the answer of its rescan
+    unsigned short *s_live = reinterpret_cast<unsigned short *>(s_pin + qr);  // live index -> query
+    uint8_t *s_flag = reinterpret_cast<uint8_t *>(s_live + qr);               // 1 = asked for a rescan in the last pass, 2 = pinned by a rescan
+    __shared__ int s_hist[32];
+    __shared__ int s_nm, s_drop[3], s_first, s_part[PW_NW], s_cntw[PW_NW], s_guard;
+    __shared__ unsigned short s_wlist[PW_WLIST];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < 3 * nr; i += PW_T) s_claim[i] = PW_INF;
+    if (tid < 32) s_hist[tid] = 0;
+    if (tid == 0) s_guard = 0;
+    // live queries (valid, at least one candidate, best key within TH_HIGH) IN QUERY ORDER
+    const int4 *grec = reinterpret_cast<const int4 *>(J.keys);
+    int nlive = 0;
+    for (int q0 = 0; q0 < J.nq; q0 += PW_T) {
+        const int q = q0 + tid;
+        int4 ka = make_int4(-1, -1, -1, -1), kb = make_int4(0, 0, 0, 0);
+        if (q < J.nq) {
+            ka = grec[2 * q];
+            kb = grec[2 * q + 1];
+        }
+        const bool live = (unsigned)ka.x != PROJ_NO_KEY32 && (float)((unsigned)ka.x >> 16) <= J.th;
+        const unsigned long long m = __ballot(live);
+        if (lane == 0) s_cntw[wv] = __popcll(m);
+        __syncthreads();
+        int off = nlive, tot = 0;
+#pragma unroll
+        for (int w = 0; w < PW_NW; ++w) {
+            const int cw = s_cntw[w];
+            off += w < wv ? cw : 0;
+            tot += cw;
+        }
+        if (live) {
+            const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
+            s_live[slot] = (unsigned short)q;
+            s_keys[slot] = ka;
+            s_meta[slot] = (kb.x & 0x7fffffff) | (kb.y ? (int)0x80000000 : 0);
+            s_w1[slot] = -1;
+            s_w2[slot] = -1;
+            s_pin[slot] = -1;
+            s_flag[slot] = 0;
+        }
+        nlive += tot;
+        __syncthreads();
+    }
+    // ---- the fixed point ----
+    int pass = 0;
+    const int pass_limit = 3 * nlive + 64;  // every pass finalises at least one more query or a rescan does: a guard
+    bool done = nlive == 0;
+    while (!done) {
+        if (pass >= pass_limit) {
+            if (tid == 0) s_guard = 1;
+            break;
+        }
+        int *R = s_claim + (pass % 3) * nr, *Wc = s_claim + ((pass + 1) % 3) * nr, *Z = s_claim + ((pass + 2) % 3) * nr;
+        bool changed = false;
+        for (int li = tid; li < nlive; li += PW_T) {
+            const int w1 = s_w1[li], w2 = s_w2[li];
+            const int flag = s_flag[li];
+            const int meta = s_meta[li];
+            int want = -1;
+            bool rescan = false;
+            if (flag & 2) {
+                want = s_pin[li];  // pinned by its rescan: the query asserts that answer in every pass
+            } else {
+                proj_eval(J, s_keys[li], meta, R, li, want, rescan);
+                s_flag[li] = rescan ? 1 : 0;
+            }
+            if (want >= 0 && meta < 0) atomicMin(&Wc[want], li);  // only a map point with observations blocks later queries
+            if (w2 >= 0) Z[w2] = PW_INF;  // what this query (maybe) put into Z two passes ago: Z is empty before it is written again
+            s_w2[li] = (short)w1;
+            s_w1[li] = (short)want;
+            changed = changed || want != w1 || (rescan != ((flag & 1) != 0));
+        }
+        ++pass;
+        if (__syncthreads_or(changed ? 1 : 0)) continue;
+        // converged: Wc holds the claims of the final wants (so far).  The queries that asked for a rescan, in order
+        {
+            const bool waits = tid < nlive && (s_flag[tid] & 3) == 1;  // the first 1024 live queries are looked at per cycle
+            const unsigned long long bal = __ballot(waits);
+            if (lane == 0) s_cntw[wv] = __popcll(bal);
+            __syncthreads();
+            int off = 0, run = 0;
+#pragma unroll
+            for (int w = 0; w < PW_NW; ++w) {
+                const int cw = s_cntw[w];
+                off += w < wv ? cw : 0;
+                run += cw;
+            }
+            if (waits) {
+                const int slot = off + __popcll(bal & ((1ull << lane) - 1ull));
+                if (slot < PW_WLIST) s_wlist[slot] = (unsigned short)tid;
+            }
+            if (tid == 0) s_first = run;
+            __syncthreads();
+        }
+        const int nwait = s_first;
+        int nw = min(nwait, PW_WLIST);
+        if (nw == 0 && nlive > PW_T) {  // jobs above 1024 live queries: the waiting ones behind the first 1024, one at a time
+            __syncthreads();
+            if (tid == 0) s_first = PW_INF;
+            __syncthreads();
+            int mine = PW_INF;
+            for (int li = PW_T + tid; li < nlive; li += PW_T)
+                if ((s_flag[li] & 3) == 1) mine = min(mine, li);
+            if (mine != PW_INF) atomicMin(&s_first, mine);
+            __syncthreads();
+            if (s_first != PW_INF) {
+                if (tid == 0) s_wlist[0] = (unsigned short)s_first;
+                nw = 1;
+            }
+            __syncthreads();
+        }
+        if (nw == 0) break;
+        // exact rescans, one waiting query per wavefront (lanes over its window's cells), each against the claims of the queries BEFORE
+        // it; adopted in order up to and including the first that takes a feature
+        bool took = false;
+        for (int g0 = 0; g0 < nw && !took; g0 += PW_NW) {
+            const int g = g0 + wv;
+            int wr = -1;
+            if (g < nw) {
+                const int li = s_wlist[g], q0 = s_live[li];
+                uint32_t qd[W];
+                {
+                    const uint4 *qp = reinterpret_cast<const uint4 *>(J.qdesc + (size_t)q0 * W);
+#pragma unroll
+                    for (int i = 0; i < W / 4; ++i) {
+                        const uint4 t = qp[i];
+                        qd[4 * i] = t.x, qd[4 * i + 1] = t.y, qd[4 * i + 2] = t.z, qd[4 * i + 3] = t.w;
+                    }
+                }
+                unsigned long long k0 = P_NO_KEY, k1 = P_NO_KEY;
+                PROJ_WAVE_WINDOW(J, q0, lane, {
+                    if (J.occupied && J.occupied[idx]) continue;
+                    if (Wc[idx] < li) continue;
+                    const unsigned long long key = make_key(proj_hamming<W>(qd, J.fdesc + (size_t)idx * W), c, kpos, idx);
+                    if (key < k0) {
+                        k1 = k0;
+                        k0 = key;
+                    } else if (key < k1) {
+                        k1 = key;
+                    }
+                })
+                const unsigned long long b0 = wave_min_u64(k0);
+                const unsigned long long b1 = wave_min_u64(k0 == b0 ? k1 : k0);
+                if (b0 != P_NO_KEY) {
+                    const float best = (float)key_dist(b0);
+                    const int bidx = key_idx(b0);
+                    bool ok = best <= J.th;
+                    if (ok && J.mode == 0 && b1 != P_NO_KEY) {
+                        const float best2 = (float)key_dist(b1), bsz = J.size[bidx], bsz2 = J.size[key_idx(b1)];
+                        if ((bsz / bsz2 < J.tol) && (bsz / bsz2 > J.inv_tol) && (bsz2 > 0.0f) && (best > J.ratio * best2)) ok = false;
+                    }
+                    if (ok) wr = bidx;
+                }
+            }
+            if (lane == 0) s_part[wv] = wr;
+            __syncthreads();
+            int nadopt = 0;
+#pragma unroll
+            for (int w = 0; w < PW_NW; ++w) {
+                if (g0 + w < nw && !took) {
+                    ++nadopt;
+                    took = s_part[w] >= 0;
+                }
+            }
+            if (tid < nadopt) {
+                const int r = s_wlist[g0 + tid];
+                s_flag[r] = 2;
+                s_pin[r] = (short)s_part[tid];
+            }
+            __syncthreads();
+        }
+        // a taken feature enters the claims with the next pass (the pinned query's want changes from -1); if nothing was taken and every
+        // waiting query was looked at, the converged state is the final one
+        if (!took && nwait <= PW_WLIST && nlive <= PW_T) break;
+    }
+    __syncthreads();
+    // ---- F.pts, count ----
+    int *A = s_claim;  // assign[feature] = last query that took it
+    for (int i = tid; i < nr; i += PW_T) A[i] = -1;
+    if (tid == 0) s_nm = 0;
+    __syncthreads();
+    int cnt = 0;
+    const bool ori = J.mode == 1 && J.check_ori;
+    for (int li = tid; li < nlive; li += PW_T) {
+        const int w = (s_flag[li] & 2) ? (int)s_pin[li] : (int)s_w1[li];
+        s_w1[li] = (short)w;
+        if (w >= 0) {
+            const int q = s_live[li];
+            atomicMax(&A[w], q);
+            ++cnt;
+            if (ori) {  // updateRotationHistogram(rotHist, bestIdx2, LastFrame.mvKeysUn[i], CurrentFrame.mvKeysUn[bestIdx2]) (:1384-1385)
+                const int bin = proj_rotation_bin(J.qangle[q], J.angle[w]);
+                s_flag[li] = (uint8_t)bin;
+                atomicAdd(&s_hist[bin], 1);
+            }
+        }
+    }
+    cnt = afv_wave_incl_scan(cnt);
+    if (lane == 63 && cnt) atomicAdd(&s_nm, cnt);
+    __syncthreads();
+    if (ori) {
+        // filterMatchesWithOrientation (Pt flavour, FeatureMatcher.cc:1601-1613): every accepted entry of a losing bin clears F.pts
+        if (tid == 0) {
+            int i1 = -1, i2 = -1, i3 = -1, max1 = 0, max2 = 0, max3 = 0;
+            for (int i = 0; i < 30; ++i) {
+                const int sz = s_hist[i];
+                if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; i3 = i2; i2 = i1; i1 = i; }
+                else if (sz > max2) { max3 = max2; max2 = sz; i3 = i2; i2 = i; }
+                else if (sz > max3) { max3 = sz; i3 = i; }
+            }
+            if ((float)max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+            else if ((float)max3 < 0.1f * (float)max1) { i3 = -1; }
+            s_drop[0] = i1; s_drop[1] = i2; s_drop[2] = i3;
+        }
+        __syncthreads();
+        const int i1 = s_drop[0], i2 = s_drop[1], i3 = s_drop[2];
+        int dropped = 0;
+        for (int li = tid; li < nlive; li += PW_T) {
+            const int w = s_w1[li];
+            if (w >= 0) {
+                const int b = s_flag[li];
+                if (b != i1 && b != i2 && b != i3) {
+                    A[w] = -1;
+                    ++dropped;
+                }
+            }
+        }
+        if (dropped) atomicSub(&s_nm, dropped);
+        __syncthreads();
+    }
+    for (int i = tid; i < J.n; i += PW_T) J.assign[i] = A[i];
+    if (tid == 0) *J.nmatches = s_guard ? PW_GUARD : s_nm;
+}
+
+__global__ __launch_bounds__(PW_T) void k_proj_resolve_wg(const DevProjJob *__restrict__ jobs) {
+    const DevProjJob J = jobs[blockIdx.x];
+    if (J.words == 8) proj_resolve_wg<8>(J);
+    else proj_resolve_wg<16>(J);
+}
+
 // ---------------- Fuse / SearchBySim3: independent queries, one wave each; first minimum in visiting order (:905) ----------------
 template <int W>
 __device__ void fuse_query(const DevProjJob &J, int q, int lane) {
@@ -427,8 +811,8 @@ __device__ void fuse_query(const DevProjJob &J, int q, int lane) {
         const float qur = J.u_right ? J.q_ur[q] : 0.0f;
         PROJ_WAVE_WINDOW(J, q, lane, {
             if (J.inf) {  // reprojection gate of Fuse (:876-900); absent in Fuse(Sim3) / SearchBySim3
-                const float ex = u - J.x[idx];
-                const float ey = v - J.y[idx];
+                const float ex = u - fx_;
+                const float ey = v - fy_;
                 const float kpr = J.u_right ? J.u_right[idx] : -1.0f;
                 if (kpr >= 0.0f) {  // stereo keypoint: three degrees of freedom (:880-894)
                     const float er = qur - kpr;
@@ -574,8 +958,7 @@ __device__ void init_resolve(const DevProjJob &J) {
     // nMatches = entries still standing (accepts minus steals minus orientation drops)
     int cnt = 0;
     for (int q = lane; q < J.nq; q += 64) cnt += J.assign[q] >= 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    cnt = wave_sum_i32(cnt);
     if (lane == 0) *J.nmatches = cnt;
 }
 
@@ -585,17 +968,373 @@ __global__ __launch_bounds__(64) void k_init_resolve(const DevProjJob *__restric
     else init_resolve<16>(J);
 }
 
-extern "C" void afv_launch_match_init(const DevProjJob *jobs, int njobs, int max_nq, hipStream_t stream) {
-    if (max_nq > 0) hipLaunchKernelGGL(k_proj_topk<IK>, dim3((max_nq + PT / 64 - 1) / (PT / 64), njobs), dim3(PT), 0, stream, jobs);
-    hipLaunchKernelGGL(k_init_resolve, dim3(njobs), dim3(64), 0, stream, jobs);
+// ---------------- SearchForInitialization, workgroup form (round 5) ----------------
+// The same fixed point for the ordered loop of :480-556.  What query i may take depends on the queries before it through
+// vMatchedDistance: candidate f at distance d is skipped when an EARLIER query holds f at a distance <= d (:513); an accepted match
+// steals f from its previous holder (:531-535), so the holders of a feature, in query order, have strictly decreasing distances and
+// the last one keeps it.  want_i = f({(want_j, d_j) : j < i}) again, so any assignment satisfying all equations is the sequential
+// outcome.  Per feature three rotating LDS words describe the queries that currently want it:
+//   E = min(live index << 16 | distance)   the earliest wanter          M = min(distance << 16 | live index)   the closest wanter
+//   C = how many
+// gate(i, f, d) = "some wanter j < i of f has d_j <= d" follows exactly from them in all but one constellation (an earlier wanter
+// farther than d, the closest wanter not earlier than i, three or more wanters), which falls back to a scan of the wants of the
+// queries before i (double-buffered by pass parity, so the scan reads the previous pass consistently).
+#define IW_T 1024
+#define IW_NW (IW_T / 64)
+#define IW_INF 0x7fffffff
+#define IW_WLIST 128
+static inline size_t init_wg_lds_bytes(int n, int nq) {
+    const size_t nr = ((size_t)n + 63) & ~(size_t)63, qr = ((size_t)nq + 63) & ~(size_t)63;
+    return 9 * nr * 4 + qr * 32 /*keys*/ + qr * 4 /*ncand*/ + 4 * qr * 2 /*want, dist x 2 buffers*/ + 2 * qr * 2 /*pin*/ + qr * 2 /*live*/ + qr /*flag*/ + 64;
+}
+
+struct InitState {
+    const int *E, *M, *C;          // the arrays of the previous pass
+    const short *want, *dist;      // the wants / distances of the previous pass, by live index
+};
+__device__ __forceinline__ bool init_gate(const InitState &S, int li, int f, int d) {
+    const int e = S.E[f];
+    if (e == IW_INF) return false;
+    if ((e >> 16) >= li) return false;                 // nobody before li wants f
+    if ((e & 0xffff) <= d) return true;                // the earliest wanter already holds it at <= d
+    const int m = S.M[f];
+    if ((m & 0xffff) < li) return (m >> 16) <= d;      // the closest wanter of all is before li
+    if (S.C[f] == 2) return false;                     // two wanters: only the earliest is before li, and it is farther than d
+    int mind = IW_INF;                                 // exact: the closest wanter among the queries before li
+    for (int j = 0; j < li; ++j)
+        if (S.want[j] == f) mind = min(mind, (int)S.dist[j]);
+    return mind <= d;
+}
+
+template <int W>
+__device__ void init_resolve_wg(const DevProjJob &J) {
+    extern __shared__ __attribute__((aligned(16))) char iw_smem[];
+    const int nr = (J.n + 63) & ~63, qr = (J.nq + 63) & ~63;
+    int *s_E = reinterpret_cast<int *>(iw_smem), *s_M = s_E + 3 * nr, *s_C = s_M + 3 * nr;
+    int4 *s_keys = reinterpret_cast<int4 *>(s_C + 3 * nr);  // two int4 per live query
+    int *s_ncand = reinterpret_cast<int *>(s_keys + 2 * qr);
+    short *s_want = reinterpret_cast<short *>(s_ncand + qr);  // [2][qr] by pass parity
+    short *s_dist = s_want + 2 * qr;                            // [2][qr]
+    short *s_pin = s_dist + 2 * qr, *s_pind = s_pin + qr;
+    unsigned short *s_live = reinterpret_cast<unsigned short *>(s_pind + qr);
+    uint8_t *s_flag = reinterpret_cast<uint8_t *>(s_live + qr);
+    __shared__ int s_hist[32];
+    __shared__ int s_nm, s_drop[3], s_first, s_part[IW_NW], s_partd[IW_NW], s_cntw[IW_NW], s_guard;
+    __shared__ unsigned short s_wlist[IW_WLIST];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < 9 * nr; i += IW_T) s_E[i] = (i >= 6 * nr) ? 0 : IW_INF;
+    for (int q = tid; q < J.nq; q += IW_T) J.assign[q] = -1;
+    if (tid < 32) s_hist[tid] = 0;
+    if (tid == 0) s_guard = 0;
+    const int4 *grec = reinterpret_cast<const int4 *>(J.keys);
+    int nlive = 0;
+    for (int q0 = 0; q0 < J.nq; q0 += IW_T) {
+        const int q = q0 + tid;
+        int4 ka = make_int4(-1, -1, -1, -1), kb = ka;
+        int nc = 0;
+        if (q < J.nq && (!J.qvalid || J.qvalid[q])) {
+            ka = grec[2 * q];
+            kb = grec[2 * q + 1];
+            nc = J.ncand[q];
+        }
+        const bool live = (unsigned)ka.x != PROJ_NO_KEY32 && (float)((unsigned)ka.x >> 16) <= J.th;
+        const unsigned long long m = __ballot(live);
+        if (lane == 0) s_cntw[wv] = __popcll(m);
+        __syncthreads();
+        int off = nlive, tot = 0;
+#pragma unroll
+        for (int w = 0; w < IW_NW; ++w) {
+            const int cw = s_cntw[w];
+            off += w < wv ? cw : 0;
+            tot += cw;
+        }
+        if (live) {
+            const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
+            s_live[slot] = (unsigned short)q;
+            s_keys[2 * slot] = ka;
+            s_keys[2 * slot + 1] = kb;
+            s_ncand[slot] = nc;
+            s_want[slot] = -1;
+            s_want[qr + slot] = -1;
+            s_dist[slot] = 0;
+            s_dist[qr + slot] = 0;
+            s_pin[slot] = -1;
+            s_pind[slot] = 0;
+            s_flag[slot] = 0;
+        }
+        nlive += tot;
+        __syncthreads();
+    }
+    int pass = 0;
+    const int pass_limit = 3 * nlive + 64;
+    bool done = nlive == 0;
+    while (!done) {
+        if (pass >= pass_limit) {
+            if (tid == 0) s_guard = 1;
+            break;
+        }
+        const int ir = pass % 3, iw = (pass + 1) % 3, iz = (pass + 2) % 3;
+        const int cur = pass & 1, nxt = cur ^ 1;
+        InitState S{s_E + ir * nr, s_M + ir * nr, s_C + ir * nr, s_want + cur * qr, s_dist + cur * qr};
+        int *WE = s_E + iw * nr, *WM = s_M + iw * nr, *WC = s_C + iw * nr;
+        bool changed = false;
+        for (int li = tid; li < nlive; li += IW_T) {
+            const int w1 = S.want[li], w2 = s_want[nxt * qr + li];
+            const int flag = s_flag[li];
+            int want = -1, dw = 0;
+            bool rescan = false;
+            if (flag & 2) {
+                want = s_pin[li];
+                dw = s_pind[li];
+            } else {
+                const int4 ka = s_keys[2 * li], kb = s_keys[2 * li + 1];
+                const unsigned keys[IK] = {(unsigned)ka.x, (unsigned)ka.y, (unsigned)ka.z, (unsigned)ka.w,
+                                           (unsigned)kb.x, (unsigned)kb.y, (unsigned)kb.z, (unsigned)kb.w};
+                const bool complete = s_ncand[li] <= IK;
+                int b0 = -1, d0 = 0, d1 = -1;
+#pragma unroll
+                for (int s = 0; s < IK; ++s) {
+                    if (keys[s] != PROJ_NO_KEY32 && d1 < 0) {
+                        const int f = (int)(keys[s] & 0xffffu), d = (int)(keys[s] >> 16);
+                        if (!init_gate(S, li, f, d)) {
+                            if (b0 < 0) {
+                                b0 = f;
+                                d0 = d;
+                            } else {
+                                d1 = d;
+                            }
+                        }
+                    }
+                }
+                const float d_last = (float)(keys[IK - 1] >> 16);
+                if (b0 < 0) {
+                    rescan = !complete && d_last <= J.th;
+                } else if (!((float)d0 <= J.th)) {
+                    // final: everything else is farther
+                } else if (d1 >= 0) {
+                    if ((float)d0 < (float)d1 * J.ratio) want = b0;  // :527-529
+                } else if (complete) {
+                    if ((float)d0 < 3.402823466e+38f * J.ratio) want = b0;
+                } else if (J.ratio >= 0.0f && (float)d0 < d_last * J.ratio) {
+                    want = b0;  // the second candidate, wherever it is, is at least as far as the last key
+                } else {
+                    rescan = true;
+                }
+                dw = d0;
+                s_flag[li] = rescan ? 1 : 0;
+            }
+            if (want >= 0) {
+                atomicMin(&WE[want], (li << 16) | dw);
+                atomicMin(&WM[want], (dw << 16) | li);
+                atomicAdd(&WC[want], 1);
+            }
+            if (w2 >= 0) {
+                s_E[iz * nr + w2] = IW_INF;
+                s_M[iz * nr + w2] = IW_INF;
+                s_C[iz * nr + w2] = 0;
+            }
+            const int dprev = S.dist[li];
+            s_want[nxt * qr + li] = (short)want;
+            s_dist[nxt * qr + li] = (short)dw;
+            changed = changed || want != w1 || (want >= 0 && dw != dprev) || (rescan != ((flag & 1) != 0));
+        }
+        ++pass;
+        if (__syncthreads_or(changed ? 1 : 0)) continue;
+        {
+            const bool waits = tid < nlive && (s_flag[tid] & 3) == 1;
+            const unsigned long long bal = __ballot(waits);
+            if (lane == 0) s_cntw[wv] = __popcll(bal);
+            __syncthreads();
+            int off = 0, run = 0;
+#pragma unroll
+            for (int w = 0; w < IW_NW; ++w) {
+                const int cw = s_cntw[w];
+                off += w < wv ? cw : 0;
+                run += cw;
+            }
+            if (waits) {
+                const int slot = off + __popcll(bal & ((1ull << lane) - 1ull));
+                if (slot < IW_WLIST) s_wlist[slot] = (unsigned short)tid;
+            }
+            if (tid == 0) s_first = run;
+            __syncthreads();
+        }
+        const int nwait = s_first;
+        int nw = min(nwait, IW_WLIST);
+        if (nw == 0 && nlive > IW_T) {
+            __syncthreads();
+            if (tid == 0) s_first = IW_INF;
+            __syncthreads();
+            int mine = IW_INF;
+            for (int li = IW_T + tid; li < nlive; li += IW_T)
+                if ((s_flag[li] & 3) == 1) mine = min(mine, li);
+            if (mine != IW_INF) atomicMin(&s_first, mine);
+            __syncthreads();
+            if (s_first != IW_INF) {
+                if (tid == 0) s_wlist[0] = (unsigned short)s_first;
+                nw = 1;
+            }
+            __syncthreads();
+        }
+        if (nw == 0) break;
+        // the state the rescans read: the arrays written by the pass that just converged, the wants it produced
+        InitState F{s_E + iw * nr, s_M + iw * nr, s_C + iw * nr, s_want + nxt * qr, s_dist + nxt * qr};
+        bool took = false;
+        for (int g0 = 0; g0 < nw && !took; g0 += IW_NW) {
+            const int g = g0 + wv;
+            int wr = -1, wd = 0;
+            if (g < nw) {
+                const int li = s_wlist[g], q0 = s_live[li];
+                uint32_t qd[W];
+                {
+                    const uint4 *qp = reinterpret_cast<const uint4 *>(J.qdesc + (size_t)q0 * W);
+#pragma unroll
+                    for (int i = 0; i < W / 4; ++i) {
+                        const uint4 t = qp[i];
+                        qd[4 * i] = t.x, qd[4 * i + 1] = t.y, qd[4 * i + 2] = t.z, qd[4 * i + 3] = t.w;
+                    }
+                }
+                unsigned long long k0 = P_NO_KEY, k1 = P_NO_KEY;
+                PROJ_WAVE_WINDOW(J, q0, lane, {
+                    const int d = proj_hamming<W>(qd, J.fdesc + (size_t)idx * W);
+                    if (init_gate(F, li, idx, d)) continue;
+                    const unsigned long long kk = make_key(d, c, kpos, idx);
+                    if (kk < k0) {
+                        k1 = k0;
+                        k0 = kk;
+                    } else if (kk < k1) {
+                        k1 = kk;
+                    }
+                })
+                const unsigned long long b0 = wave_min_u64(k0);
+                const unsigned long long b1 = wave_min_u64(k0 == b0 ? k1 : k0);
+                if (b0 != P_NO_KEY) {
+                    const float best = (float)key_dist(b0);
+                    const float best2 = b1 == P_NO_KEY ? 3.402823466e+38f : (float)key_dist(b1);
+                    if (best <= J.th && best < best2 * J.ratio) {
+                        wr = key_idx(b0);
+                        wd = key_dist(b0);
+                    }
+                }
+            }
+            if (lane == 0) {
+                s_part[wv] = wr;
+                s_partd[wv] = wd;
+            }
+            __syncthreads();
+            int nadopt = 0;
+#pragma unroll
+            for (int w = 0; w < IW_NW; ++w) {
+                if (g0 + w < nw && !took) {
+                    ++nadopt;
+                    took = s_part[w] >= 0;
+                }
+            }
+            if (tid < nadopt) {
+                const int r = s_wlist[g0 + tid];
+                s_flag[r] = 2;
+                s_pin[r] = (short)s_part[tid];
+                s_pind[r] = (short)s_partd[tid];
+            }
+            __syncthreads();
+        }
+        if (!took && nwait <= IW_WLIST && nlive <= IW_T) break;
+    }
+    __syncthreads();
+    // ---- matches: a query keeps its feature iff it is the closest (= last) of the feature's holders ----
+    const int fin = pass % 3, fb = pass & 1;  // arrays / wants written by the last pass
+    const int *FM = s_M + fin * nr;
+    const short *fw = s_want + fb * qr;
+    if (tid == 0) s_nm = 0;
+    __syncthreads();
+    int cnt = 0;
+    for (int li = tid; li < nlive; li += IW_T) {
+        const int w = (s_flag[li] & 2) ? (int)s_pin[li] : (int)fw[li];
+        int keep = -1, bin = 31;
+        if (w >= 0) {
+            const int q = s_live[li];
+            // a pinned answer of the last adoption round that took nothing is -1; one that took something was followed by a pass
+            if ((FM[w] & 0xffff) == li) keep = w;
+            if (J.check_ori) {
+                bin = proj_rotation_bin(J.qangle[q], J.angle[w]);  // F1 keypoint first (:543); stolen matches stay in the histogram
+                atomicAdd(&s_hist[bin], 1);
+            }
+        }
+        s_pin[li] = (short)keep;
+        s_flag[li] = (uint8_t)bin;
+    }
+    __syncthreads();
+    if (J.check_ori && tid == 0) {
+        int i1 = -1, i2 = -1, i3 = -1, max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < 30; ++i) {
+            const int sz = s_hist[i];
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; i3 = i2; i2 = i1; i1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; i3 = i2; i2 = i; }
+            else if (sz > max3) { max3 = sz; i3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { i3 = -1; }
+        s_drop[0] = i1; s_drop[1] = i2; s_drop[2] = i3;
+    }
+    __syncthreads();
+    for (int li = tid; li < nlive; li += IW_T) {
+        int keep = s_pin[li];
+        if (keep >= 0 && J.check_ori) {
+            const int b = s_flag[li];
+            if (b != s_drop[0] && b != s_drop[1] && b != s_drop[2]) keep = -1;  // filterMatchesWithOrientation, int flavour (:1615-1629)
+        }
+        if (keep >= 0) {
+            J.assign[s_live[li]] = keep;
+            ++cnt;
+        }
+    }
+    cnt = afv_wave_incl_scan(cnt);
+    if (lane == 63 && cnt) atomicAdd(&s_nm, cnt);
+    __syncthreads();
+    if (tid == 0) *J.nmatches = s_guard ? PW_GUARD : s_nm;
+}
+
+__global__ __launch_bounds__(IW_T) void k_init_resolve_wg(const DevProjJob *__restrict__ jobs) {
+    const DevProjJob J = jobs[blockIdx.x];
+    if (J.words == 8) init_resolve_wg<8>(J);
+    else init_resolve_wg<16>(J);
+}
+
+// the workgroup engines need more LDS than the 64 KB a kernel gets by default: raised once per device (afv_create), checked
+extern "C" int afv_project_prepare(void) {
+    const int want = 150 * 1024;
+    bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_resolve_wg), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
+    ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_init_resolve_wg), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess && ok;
+    if (!ok) (void)hipGetLastError();
+    // dynamic bytes a job may ask for (the kernels' static arrays take about 1 KB more); without the raised limit: what every kernel gets
+    return ok ? want - 2048 : 62 * 1024;
+}
+extern "C" size_t afv_project_wg_lds(int kind_init, int n, int nq) { return kind_init ? init_wg_lds_bytes(n, nq) : proj_wg_lds_bytes(n, nq); }
+
+extern "C" void afv_launch_match_init(const DevProjJob *jobs, int njobs, int max_nq, size_t wg_lds, hipStream_t stream) {
+    const dim3 tg((max_nq + PT / 64 - 1) / (PT / 64), njobs);
+    if (wg_lds) {
+        if (max_nq > 0) hipLaunchKernelGGL((k_proj_topk<IK, 3>), tg, dim3(PT), 0, stream, jobs);
+        hipLaunchKernelGGL(k_init_resolve_wg, dim3(njobs), dim3(IW_T), wg_lds, stream, jobs);
+    } else {
+        if (max_nq > 0) hipLaunchKernelGGL((k_proj_topk<IK, 2>), tg, dim3(PT), 0, stream, jobs);
+        hipLaunchKernelGGL(k_init_resolve, dim3(njobs), dim3(64), 0, stream, jobs);
+    }
 }
 
 extern "C" void afv_launch_match_fuse(const DevProjJob *jobs, int njobs, int max_nq, hipStream_t stream) {
     if (max_nq > 0) hipLaunchKernelGGL(k_match_fuse, dim3((max_nq + PT / 64 - 1) / (PT / 64), njobs), dim3(PT), 0, stream, jobs);
 }
 
-extern "C" void afv_launch_match_projection(const DevProjJob *jobs, int njobs, int max_nq, hipStream_t stream) {
-    if (max_nq > 0) hipLaunchKernelGGL(k_proj_topk<PK>, dim3((max_nq + PT / 64 - 1) / (PT / 64), njobs), dim3(PT), 0, stream, jobs);
+// wg_lds != 0: the fixed-point engine with that much dynamic LDS (the largest job's tables); 0: the ordered walk
+extern "C" void afv_launch_match_projection(const DevProjJob *jobs, int njobs, int max_nq, size_t wg_lds, hipStream_t stream) {
+    const dim3 tg((max_nq + PT / 64 - 1) / (PT / 64), njobs);
+    if (wg_lds) {
+        if (max_nq > 0) hipLaunchKernelGGL((k_proj_topk<PK, 1>), tg, dim3(PT), 0, stream, jobs);
+        hipLaunchKernelGGL(k_proj_resolve_wg, dim3(njobs), dim3(PW_T), wg_lds, stream, jobs);
+        return;
+    }
+    if (max_nq > 0) hipLaunchKernelGGL((k_proj_topk<PK, 0>), tg, dim3(PT), 0, stream, jobs);
     // stage the query records in LDS when the largest job fits (64 B per query next to the 33.9 KB of tables; 160 KB per CU)
     int stage_cap = max_nq;
     if ((size_t)PR_LDS_FIXED + (size_t)stage_cap * PR_REC_BYTES > 128 * 1024) stage_cap = 0;

@@ -179,7 +179,7 @@ class FeatureMatcher:
         pKF*.valid = has-map-point masks; epipole = projection of camera 1's centre in image 2 (:669-675); pKF*.u_right =
         mvuRight of stereo keyframes (:705, :727)."""
         keep = []
-        t = TriJob()
+        t = _lib.sized(TriJob)
         t.bow = self._job(pKF1, pKF2, _lib.MATCH_KF_KF, keep)
         x1 = np.ascontiguousarray(pKF1.pts[:, 0]); y1 = np.ascontiguousarray(pKF1.pts[:, 1])
         x2 = np.ascontiguousarray(pKF2.pts[:, 0]); y2 = np.ascontiguousarray(pKF2.pts[:, 1])
@@ -198,7 +198,7 @@ class FeatureMatcher:
         return pairs, int(nm[0])
 
     def _proj_job(self, F, queries):
-        j = ProjJob()
+        j = _lib.sized(ProjJob)
         j.desc = ptr(F.descriptors); j.n = F.N; j.desc_bytes = F.descriptors.shape[1] if F.N else 32
         j.x = ptr(F.x); j.y = ptr(F.y); j.size = ptr(F.sizes); j.angle = ptr(F.angles); j.occupied = ptr(F.occupied)
         j.inf = ptr(F.inf)

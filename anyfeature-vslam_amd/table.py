@@ -213,6 +213,19 @@ class DescriptorTable:
                                                           int(bool(check_orientation)), ptr(m), ptr(nm)), "afv_table_match_bow_frame")
         return m, nm
 
+    def set_from_frame(self, slot, frame):
+        """KeyFrame::KeyFrame(Frame&) (KeyFrame.cc:36-60): a resident frame (frame.Frame) becomes keyframe `slot`, device to device"""
+        self.ctx.check(self.lib.afv_table_set_from_frame(self.handle, int(slot), frame.handle), "afv_table_set_from_frame")
+
+    def match_bow_frame_resident(self, slots, frame, th_low, nnratio, check_orientation=True, want_matches=True):
+        """match_bow_frame with the frame side taken from a resident frame (frame.Frame after ComputeBoW): nothing of the frame travels"""
+        sl = _i32(slots)
+        m = np.empty((len(sl), frame.N), np.int32) if want_matches else None
+        nm = np.zeros(len(sl), np.int32)
+        self.ctx.check(self.lib.afv_table_match_bow_frame_h(self.handle, ptr(sl), len(sl), frame.handle, float(th_low), float(nnratio),
+                                                            int(bool(check_orientation)), ptr(m), ptr(nm)), "afv_table_match_bow_frame_h")
+        return m, nm
+
     def match_triangulation(self, pair_a, pair_b, F12, epipoles, th_low, has_mp1=None, has_mp2=None, only_stereo=False):
         """SearchForTriangulation per pair.  F12: [npairs, 9] (row-major), epipoles: [npairs, 2]; has_mp1/2: per pair uint8
         arrays or None"""
@@ -224,6 +237,7 @@ class DescriptorTable:
         keep = []
         for p in range(n):
             j = jobs[p]
+            j.struct_size = C.sizeof(TableTriJob)
             for k in range(9):
                 j.F12[k] = float(F12[p, k])
             j.ex, j.ey, j.th_low = float(ep[p, 0]), float(ep[p, 1]), float(th_low)

@@ -66,6 +66,10 @@ class Vocabulary:
                                                ptr(self.node_desc), self.node_desc.shape[1], C.byref(h))
             self.ctx.check(rc, "afv_vocab_create")
             self._handle = h
+            stopped = np.ascontiguousarray(~(self.weight > 0), np.uint8)   # DBoW2 transform: a word enters the vectors only if(w > 0)
+            stopped[~self.is_leaf] = 0
+            if stopped.any():
+                self.ctx.check(self.ctx.lib.afv_vocab_set_stopped(self.ctx.handle, h, ptr(stopped)), "afv_vocab_set_stopped")
         return self._handle
 
     def close(self):
@@ -89,6 +93,10 @@ class Vocabulary:
         (BowVector {word_id: weight}, L1-normalised (TF-IDF weighting, L1 scoring: the ORB-SLAM vocabulary settings),
          FeatureVector [(node_id, [feature indices ascending])] ascending by node id)."""
         leaf, nid = self.transform_nodes(descriptors, levelsup)
+        return self.vectors_from_nodes(leaf, nid)
+
+    def vectors_from_nodes(self, leaf, nid):
+        """BowVector / FeatureVector from the per-descriptor (leaf node, node at level L - levelsup) the GPU descent returned"""
         w = self.weight[leaf]
         keep = w > 0                                   # stopped words are skipped (DBoW2 transform: if(w > 0))
         bow = {}

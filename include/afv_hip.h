@@ -129,7 +129,13 @@ typedef struct {
    int32[n1] (KF_KF) or int32[n2] (KF_FRAME); nmatches[njobs]. */
 int afv_match_bow(afv_ctx *ctx, const afv_match_job *jobs, int njobs, int32_t *out, int32_t *nmatches);
 
+/* JOB RECORDS THAT CARRY struct_size (afv_tri_job, afv_proj_job, afv_table_tri_job): set the FIRST field to sizeof(the struct you were
+ * compiled against) in every job of the array.  The runtime uses it as the array stride and reads only the fields it covers; fields
+ * beyond it are taken as zero (= the monocular call).  A value below the record's first published layout, above 4 x the current one,
+ * or different between the jobs of one call is AFV_EINVAL - so a caller that forgot to fill it (0, stack garbage) is rejected instead of
+ * having uninitialised tail pointers dereferenced.  Records grow only at the end. */
 typedef struct {
+    uint32_t struct_size;            /* sizeof(afv_tri_job) */
     afv_match_job bow;               /* valid1/valid2 mean "already HAS a map point" => skipped; mode/nnratio/
                                         check_orientation ignored */
     const float *x1, *y1, *x2, *y2; /* mvKeysUn */
@@ -219,6 +225,7 @@ int afv_table_set_u_right(afv_table *t, int set, const float *u_right);
  * afv_table_match_triangulation return AFV_EINVAL for a slot that holds features but lacks what the call needs, instead of
  * answering "no matches". */
 typedef struct {
+    uint32_t struct_size;    /* sizeof(afv_table_tri_job) (see afv_tri_job) */
     float F12[9];            /* row-major fundamental matrix (as afv_tri_job) */
     float ex, ey;            /* epipole of camera a in image b */
     const uint8_t *has_mp1;  /* [n_a] feature already has a map point => skipped (NULL = none has) */
@@ -277,6 +284,7 @@ int afv_match_l2_pairs_device(afv_ctx *ctx, const float *d_desc, const int32_t *
  * (u, v) = projected position, r = window radius (:91 / :1343), [min_size, max_size] = admissible keyPtsSize band. */
 enum { AFV_PROJ_LOCALMAP = 0, AFV_PROJ_LASTFRAME = 1 };
 typedef struct {
+    uint32_t struct_size;                               /* sizeof(afv_proj_job) (see afv_tri_job) */
     const uint8_t *desc; int32_t n; int32_t desc_bytes; /* frame features F.mDescriptors (n <= 8192) */
     const float *x; const float *y;                     /* F.mvKeysUn[i].pt */
     const float *size;                                  /* F.keyPtsSize[i] */
@@ -284,7 +292,7 @@ typedef struct {
     const uint8_t *occupied;                            /* F.pts[i] && F.pts[i]->NumberOfObservations() > 0; NULL = none */
     const float *inf;                                   /* KeyFrame::GetKeyPt1DInf(i): afv_match_fuse only */
     float min_x, min_y, grid_inv_w, grid_inv_h;         /* mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv */
-    int32_t grid_cols, grid_rows;                       /* FRAME_GRID_COLS 64, FRAME_GRID_ROWS 48 (Frame.h:40-41) */
+    int32_t grid_cols, grid_rows;                       /* FRAME_GRID_COLS 64, FRAME_GRID_ROWS 48 (Frame.h:40-41); cols * rows <= 8192 */
     int32_t nq;                                         /* queries: map points / last-frame keypoints */
     const uint8_t *qdesc; const uint8_t *qvalid;        /* pMP->GetDescriptor(); pMP && in view && !isBad (NULL = all) */
     const float *qu; const float *qv; const float *qr; const float *qmin_size; const float *qmax_size;
@@ -345,6 +353,103 @@ int afv_vocab_create(afv_ctx *ctx, int k, int L, int nnodes, const int32_t *chil
 void afv_vocab_destroy(afv_ctx *ctx, afv_vocab *v);
 int afv_bow_transform(afv_ctx *ctx, const afv_vocab *v, const uint8_t *desc, int n, int levelsup, int32_t *leaf_node,
                       int32_t *node_at_level);
+
+/* words the vocabulary stops (DBoW2 transform: a word whose weight is not > 0 enters neither the BowVector nor the FeatureVector):
+ * stopped[nnodes] != 0 marks them; NULL = none (the default).  Only the device-built FeatureVector of afv_frame_bow_transform reads it. */
+int afv_vocab_set_stopped(afv_ctx *ctx, afv_vocab *v, const uint8_t *stopped);
+
+/* ---- the device-resident Frame (round 5) ----
+ * In the reference a Frame is built once (src/Frame.cc:171-223: ExtractFeatures :242-259 -> UndistortKeyPoints :403-433 ->
+ * AssignFeaturesToGrid :225-240) and then consumed by every matcher of that tracking step: SearchByProjection(cur, last)
+ * (src/Tracking.cc:747,753), SearchByProjection(F, local map points) (:1026), Frame::ComputeBoW (Frame.cc:397-401) -> SearchByBoW(KF, F)
+ * (Tracking.cc:626-629), SearchForInitialization, and - if promoted - copied into a KeyFrame (src/KeyFrame.cc:36).  An afv_frame is that
+ * object on the device: afv_frame_extract runs the extraction of afv_orb_extract and KEEPS keypoints and descriptors in HBM, derives
+ * mvKeysUn / keyPtsSize / keyPtsSigma2 / keyPtsInf per feature and builds the 64 x 48 grid there (PosInGrid's expression, Frame.cc:384-394:
+ * cell = round((x - mnMinX) * mfGridElementWidthInv), ascending feature index inside a cell); the consumers below read it in place.
+ * After the image nothing of the frame is uploaded again: a projection search sends its queries, a BoW search nothing at all.
+ * A frame belongs to the context it was created on (one calling thread at a time, like the context) and dies with it. */
+typedef struct afv_frame afv_frame;
+typedef struct {
+    uint32_t struct_size;             /* sizeof(afv_frame_params) */
+    float min_x, min_y, max_x, max_y; /* mnMinX, mnMinY, mnMaxX, mnMaxY (Frame::ComputeImageBounds, Frame.cc:435-466) */
+    int32_t grid_cols, grid_rows;     /* FRAME_GRID_COLS 64, FRAME_GRID_ROWS 48 (Frame.h:40-41); cols * rows <= 8192 */
+    int32_t distorted;                /* 0: mDistCoef[0] == 0, mvKeysUn = mvKeys (Frame.cc:405-409) and the grid is built inside
+                                         afv_frame_extract; 1: the caller undistorts (cv::undistortPoints of N points is host work) and
+                                         hands mvKeysUn over with afv_frame_set_undistorted, which builds the grid */
+    int32_t cap;                      /* most features the frame can hold; 0 = afv_max_keypoints_per_frame(ctx); <= 8192 */
+} afv_frame_params;
+int afv_frame_create(afv_ctx *ctx, const afv_frame_params *params, afv_frame **out);
+void afv_frame_destroy(afv_frame *f);
+/* FeatureExtractor::operator() into the frame: host outputs exactly as afv_orb_extract (kps / desc32 / n_out; the three may all be NULL
+ * when the caller wants the device copy only) and the device-resident frame described above.  Synchronous. */
+int afv_frame_extract(afv_frame *f, const uint8_t *gray, int width, int height, int stride_bytes, afv_keypoint *kps, uint8_t *desc32,
+                      int cap, int *n_out);
+/* a frame whose features were produced elsewhere (a stereo rig, another extractor, a test): n keypoints (cv::KeyPoint layout; pt =
+ * mvKeysUn unless `distorted`), n x 32-byte descriptors, per-feature keyPtsSize (NULL = E12 from the octave as afv_orb_size_sigma) and
+ * mvuRight (NULL = monocular: -1).  Host pointers; asynchronous on the context's stream (the arrays are copied before the call returns). */
+int afv_frame_set_features(afv_frame *f, const afv_keypoint *kps, const uint8_t *desc32, int n, const float *size, const float *u_right);
+/* mvKeysUn of a `distorted` frame: x[n], y[n] (host); builds the grid.  Asynchronous on the context's stream. */
+int afv_frame_set_undistorted(afv_frame *f, const float *x, const float *y);
+int afv_frame_count(const afv_frame *f); /* N of the last afv_frame_extract / afv_frame_set_features */
+/* device views (valid until the frame is destroyed; contents change with the next extract): any may be NULL.
+ * d_kps[cap] afv_keypoint (mvKeys), d_desc[cap][32], d_xy = {x[cap], y[cap]} of mvKeysUn, d_size[cap] keyPtsSize, d_angle[cap],
+ * d_n = the count */
+int afv_frame_device_ptrs(afv_frame *f, afv_keypoint **d_kps, uint8_t **d_desc, float **d_x, float **d_y, float **d_size, float **d_angle,
+                          int32_t **d_n);
+/* parity / debugging: the grid as CSR over cells (cell = ix * grid_rows + iy): cell_ptr[cols * rows + 1], cell_idx[n] */
+int afv_frame_get_grid(afv_frame *f, int32_t *cell_ptr, int32_t *cell_idx);
+/* Frame::ComputeBoW (Frame.cc:397-401): the tree descent of afv_bow_transform over the frame's own descriptors.  leaf_node[n] /
+ * node_at_level[n] (host, may be NULL) feed the caller's BowVector; the FeatureVector (node -> ascending feature indices, stopped words
+ * left out) is built ON THE DEVICE and stays with the frame for afv_table_match_bow_frame_h / afv_table_set_from_frame; its node
+ * structure (what the merge-join of two FeatureVectors walks, FeatureMatcher.cc:205-276) is kept on the host side of the handle.
+ * nnodes_out (may be NULL) = number of distinct nodes.  Synchronous. */
+int afv_frame_bow_transform(afv_frame *f, const afv_vocab *v, int levelsup, int32_t *leaf_node, int32_t *node_at_level, int32_t *nnodes_out);
+/* the FeatureVector of the last afv_frame_bow_transform as CSR (host copies; any may be NULL): node_id[nnodes], seg_ptr[nnodes + 1],
+ * seg_idx[seg_ptr[nnodes]] */
+int afv_frame_get_featvec(afv_frame *f, int32_t *node_id, int32_t *seg_ptr, int32_t *seg_idx);
+/* the queries of a projection search (everything afv_proj_job carries on the query side), host pointers */
+typedef struct {
+    uint32_t struct_size;                               /* sizeof(afv_proj_queries) */
+    int32_t nq;
+    const uint8_t *qdesc; int32_t desc_bytes;           /* pMP->GetDescriptor(), nq x desc_bytes (32) */
+    const uint8_t *qvalid;                              /* NULL = all */
+    const float *qu; const float *qv; const float *qr; const float *qmin_size; const float *qmax_size;
+    const float *qangle;                                /* AFV_PROJ_LASTFRAME / initialization with check_orientation */
+    const uint8_t *qoccupies;                           /* NULL = yes */
+    const float *q_ur; const float *q_er_max;           /* stereo frames only (see afv_proj_job) */
+    const uint8_t *occupied;                            /* F.pts[i] && F.pts[i]->NumberOfObservations() > 0 per FRAME feature; NULL = none:
+                                                           the one piece of map state the searches read from the frame side */
+    float th_high, nnratio;                             /* TH_HIGH (or the threshold of the flavour), mfNNratio */
+    int32_t check_orientation, mode;                    /* mode: AFV_PROJ_LOCALMAP / AFV_PROJ_LASTFRAME */
+    /* the queries' descriptors by reference instead of by value: a map point's descriptor is a row of the keyframe that observed it
+     * (MapPoint::ComputeDistinctDescriptors copies pKF->mDescriptors.row(idx)), so when that keyframe sits in an afv_table the row is
+     * gathered on the device: qref_table + qref_slot[nq] + qref_idx[nq] (qdesc NULL).  8 bytes per query instead of 32. */
+    afv_table *qref_table; const int32_t *qref_slot; const int32_t *qref_idx;
+} afv_proj_queries;
+/* SearchByProjection(F, vpMapPoints, th) (FeatureMatcher.cc:73-154) / SearchByProjection(CurrentFrame, LastFrame, th, mono) (:1291-1402)
+ * and the flavours listed under afv_match_projection, against the frame's resident features and grid; size_tol = the frame's
+ * sizeTolerance (the context's scale_factor, Frame.cc:73-74).  assign[n] (query index now in F.pts[i] | -1), *nmatches.  Synchronous. */
+int afv_frame_match_projection(afv_frame *f, const afv_proj_queries *q, int32_t *assign, int32_t *nmatches);
+/* matching core of Fuse(pKF, vpMapPoints, th) with the frame in the role of the keyframe (KeyFrame::GetFeaturesInArea reads the grid the
+ * KeyFrame copied from its Frame, KeyFrame.cc:36,613-652): best[nq] (feature index | -1), *nfound.  use_inf_gate 0 = the Sim3 flavour. */
+int afv_frame_match_fuse(afv_frame *f, const afv_proj_queries *q, int use_inf_gate, int32_t *best, int32_t *nfound);
+/* SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (FeatureMatcher.cc:399-557) between two resident frames: the
+ * queries are F1's own features (descriptor, angle, octave-0 filter: all on the device), prev_x / prev_y = vbPrevMatched (host, n1
+ * floats each).  match12[n1], *nmatches.  Nothing but the 8 n1 bytes of vbPrevMatched is uploaded. */
+int afv_frame_match_initialization(afv_frame *f1, afv_frame *f2, const float *prev_x, const float *prev_y, float window_size, float th_low,
+                                   float nnratio, int check_orientation, int32_t *match12, int32_t *nmatches);
+/* KeyFrame::KeyFrame(Frame &F, ...) (src/KeyFrame.cc:36-60): the frame's descriptors, angles, mvKeysUn, sigma2, mvuRight and - when
+ * afv_frame_bow_transform ran - its FeatureVector become keyframe `slot` of the table, device to device (the node structure host to
+ * host).  The slot's validity mask is reset to "all valid" like afv_table_set does.  Asynchronous on the context's stream. */
+int afv_table_set_from_frame(afv_table *t, int slot, afv_frame *f);
+/* afv_table_match_bow_frame with the frame side taken from a resident frame (afv_frame_bow_transform must have run): SearchByBoW(KF, F)
+ * of TrackReferenceKeyFrame (Tracking.cc:626-629, one slot) and of Relocalization (:1162-1182, the candidates). */
+int afv_table_match_bow_frame_h(afv_table *t, const int32_t *slots, int nslots, afv_frame *f, float th_low, float nnratio,
+                                int check_orientation, int32_t *match_f, int32_t *nmatches);
+/* engine of the ordered phase of the projection searches / SearchForInitialization (identical results):
+ *   1: one fixed point over all live queries of a job on a 1024-thread workgroup (round 5)   0: the ordered walk of rounds 1-4 on one
+ *   wavefront   2 (default): 1 whenever the job's tables fit the workgroup's LDS, else 0 */
+int afv_set_projection_resolve(afv_ctx *ctx, int engine);
 
 /* DescriptorDistance_orb32 on the host (utility for adapters / tests) */
 int afv_hamming256(const uint8_t *a, const uint8_t *b);

@@ -134,6 +134,7 @@ def test_python_struct_mirrors_match_the_headers(tmp_path):
     lib, akz = pkg._lib, importlib.import_module("anyfeature-vslam_amd.akaze")
     pairs = [("afv_orb_params", lib.OrbParams), ("afv_geometry", lib.Geometry), ("afv_match_job", lib.MatchJob), ("afv_tri_job", lib.TriJob),
              ("afv_table_tri_job", lib.TableTriJob), ("afv_frame_view", lib.FrameView), ("afv_proj_job", lib.ProjJob),
+             ("afv_frame_params", lib.FrameParams), ("afv_proj_queries", lib.ProjQueries),
              ("afv_akaze_params", akz.AkazeParams), ("afv_akaze_level", akz.AkazeLevel), ("afv_akaze_plan", akz.AkazePlan)]
     lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "afv_hip.h"', '#include "afv_akaze.h"', 'int main(void) {']
     for cname, st in pairs:

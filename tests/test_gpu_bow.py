@@ -64,3 +64,44 @@ def test_extract_transform_match_chain(afv, oracle, gpu_ctx):
     want, wn = oracle.search_by_bow_kf_kf(d1, d2, fv1, fv2, None, None, k1["angle"], k2["angle"], 75.0, 0.75, True)
     assert n == wn and np.array_equal(got, want) and wn > 100
     voc.close()
+
+
+def test_transform_at_the_shipped_vocabulary_shape(afv, oracle, gpu_ctx):
+    """k = 10, L = 6 (createVocabulary.py:39-42 defaults; ORBvoc.txt): 1 111 111 nodes, a 53 MB device image - the lower levels of the
+    descent miss L2, which the toy trees above never do"""
+    voc = afv.Vocabulary.random(101, k=10, L=6, ctx=gpu_ctx)
+    assert len(voc.weight) == 1111111 and voc.size() == 10 ** 6
+    desc = afv.synth.random_descriptors(5, 2000)
+    leaf, nid = voc.transform_nodes(desc, 4)
+    oleaf, onid = oracle.bow_transform(voc, desc, 4)
+    assert np.array_equal(leaf, oleaf) and np.array_equal(nid, onid)
+    assert np.all(voc.is_leaf[leaf]) and len(np.unique(nid)) > 50     # level-2 nodes: at most 100
+    # descriptors that ARE node descriptors must find their own leaf
+    own = np.nonzero(voc.is_leaf)[0][afv.synth.lcg_states(3, 64) % 10 ** 6]
+    d2 = voc.node_desc[own]
+    leaf2, _ = voc.transform_nodes(d2, 4)
+    oleaf2, _ = oracle.bow_transform(voc, d2, 4)
+    assert np.array_equal(leaf2, oleaf2)
+    voc.close()
+
+
+def test_ragged_trees_and_wide_nodes(afv, oracle, gpu_ctx):
+    """nodes with 1 .. 37 children (more than a 16-lane row: several chunks), leaves at different depths, ids not in breadth-first order"""
+    s = afv.synth
+    n = 4000
+    st = s.lcg_states(17, n)
+    parent = np.zeros(n, np.int32)
+    for i in range(1, n):
+        parent[i] = int(st[i] % min(i, 120)) if i < 3000 else 120 + int(st[i] % 2500)   # early nodes collect many children, later ones 0 - 3
+    has_child = np.zeros(n, bool)
+    has_child[parent[1:]] = True
+    desc = s.lcg_bytes(18, n * 32).reshape(n, 32)
+    voc = afv.Vocabulary(37, 60, parent, desc, np.ones(n), ~has_child, ctx=gpu_ctx)
+    counts = np.diff(voc.child_ptr)
+    assert counts.max() > 16 and counts[counts > 0].min() == 1
+    q = s.random_descriptors(19, 1200)
+    for levelsup in (1, 3, 57, 58, 70):
+        leaf, nid = voc.transform_nodes(q, levelsup)
+        oleaf, onid = oracle.bow_transform(voc, q, levelsup)
+        assert np.array_equal(leaf, oleaf) and np.array_equal(nid, onid), levelsup
+    voc.close()

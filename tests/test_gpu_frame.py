@@ -1,0 +1,310 @@
+"""-m gpu: the device-resident Frame (afv_frame_*): extraction into the frame, the device-built grid, and every consumer of the
+tracking chain - SearchByProjection x2, Fuse, SearchForInitialization, ComputeBoW, SearchByBoW(KF, F), promotion into the keyframe
+table - bit-identical to the oracle run on the host copies of the same frame."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _round_half_away(v):
+    v = v.astype(np.float64)
+    return (np.sign(v) * np.floor(np.abs(v) + 0.5)).astype(np.int64)
+
+
+def _host_grid(x, y, min_x, min_y, inv_w, inv_h, cols=64, rows=48):
+    """Frame::AssignFeaturesToGrid with PosInGrid's expression (Frame.cc:225-240,384-394), float32 arithmetic, ascending index per cell"""
+    px = _round_half_away((x.astype(np.float32) - np.float32(min_x)) * np.float32(inv_w))
+    py = _round_half_away((y.astype(np.float32) - np.float32(min_y)) * np.float32(inv_h))
+    ok = (px >= 0) & (px < cols) & (py >= 0) & (py < rows)
+    cell = np.where(ok, px * rows + py, -1)
+    order = np.argsort(np.where(ok, cell, cols * rows), kind="stable")
+    order = order[:int(ok.sum())]
+    ptr = np.zeros(cols * rows + 1, np.int32)
+    np.add.at(ptr, cell[ok] + 1, 1)
+    return np.cumsum(ptr).astype(np.int32), order.astype(np.int32)
+
+
+@pytest.fixture(scope="module")
+def fctx(afv):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    c = afv.Context()
+    yield c
+    c.close()
+
+
+def _queries(afv, ctx, seed, img, shift, rs, n_extra=0):
+    """queries = keypoints of the shifted image projected back with that offset (what a motion model does)"""
+    s = afv.synth
+    k2, d2 = ctx.extract(np.roll(img, shift, axis=1))
+    size2, _, _ = ctx.size_sigma(k2)
+    order = np.argsort(s.lcg_states(seed + 5, len(k2)), kind="stable")
+    k2, d2, size2 = k2[order], d2[order], size2[order]
+    u = k2["x"] - np.float32(shift) + ((s.lcg_states(seed + 6, len(k2)) % 5).astype(np.float32) - 2)
+    v = k2["y"] + ((s.lcg_states(seed + 7, len(k2)) % 5).astype(np.float32) - 2)
+    valid = (s.lcg_bytes(seed + 8, len(k2)) > 20).astype(np.uint8)
+    occupies = (s.lcg_bytes(seed + 10, len(k2)) > 10).astype(np.uint8)
+    return afv.ProjectionQueries(d2, u, v, np.float32(rs) * size2, size2 / np.float32(1.2), size2 * np.float32(1.2), valid=valid,
+                                 angles=k2["angle"], occupies=occupies)
+
+
+def test_extract_into_frame_equals_plain_extract_and_builds_the_grid(afv, oracle, fctx):
+    fr = afv.Frame(fctx)
+    for seed in (1, 2):
+        img = afv.synth.corners_frame(seed)
+        k0, d0 = fctx.extract(img)
+        k1, d1 = fr.extract(img)
+        assert k0.tobytes() == k1.tobytes() and np.array_equal(d0, d1) and fr.N == len(k0) > 900
+        ok, od = oracle.orb_extract(img)
+        assert k1.tobytes() == ok.tobytes() and np.array_equal(d1, od)
+        cp, ci = fr.grid()
+        wp, wi = _host_grid(k1["x"], k1["y"], 0.0, 0.0, fr.grid_inv_w, fr.grid_inv_h)
+        assert np.array_equal(cp, wp) and np.array_equal(ci, wi)
+        assert cp[-1] == len(k1)  # 640 x 480 keypoints all land inside the 64 x 48 grid
+    assert fr.extract(afv.synth.corners_frame(3), host_outputs=False) > 900
+    # a frame without corners
+    k, d = fr.extract(afv.synth.constant_frame())
+    assert len(k) == 0 and fr.N == 0
+    cp, ci = fr.grid()
+    assert cp[-1] == 0 and len(ci) == 0
+    fr.close()
+
+
+@pytest.mark.parametrize("engine", [1, 0], ids=["fixed_point", "ordered_walk"])
+@pytest.mark.parametrize("seed,shift,rs,last", [(1, 4, 15.0, False), (2, 7, 40.0, False), (4, 3, 120.0, False), (5, 5, 15.0, True), (6, 2, 60.0, True)])
+def test_projection_searches_on_the_resident_frame(afv, oracle, fctx, seed, shift, rs, last, engine):
+    fctx.check(fctx.lib.afv_set_projection_resolve(fctx.handle, engine))
+    img = afv.synth.corners_frame(seed)
+    fr = afv.Frame(fctx)
+    k1, d1 = fr.extract(img)
+    size1, _, _ = fctx.size_sigma(k1)
+    occ = (afv.synth.lcg_bytes(seed + 9, len(k1)) < 30).astype(np.uint8)
+    Q = _queries(afv, fctx, seed, img, shift, rs)
+    F = afv.FrameGridView(d1, np.stack([k1["x"], k1["y"]], 1), size1, angles=k1["angle"], occupied=occ)
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+    m = afv.FeatureMatcher(0.9 if last else 0.8, True, ctx=fctx)
+    got, n = fr.SearchByProjection(m, Q, last_frame=last, occupied=occ)
+    want, wn = oracle.match_projection(F, Q, th_high=75.0, nnratio=m.mfNNratio, check_orientation=last, last_frame=last)
+    assert n == wn and np.array_equal(got, want) and wn > 100
+    # the host-array entry point (same kernels, grid built from uploaded x / y) must agree too
+    got2, n2 = m.SearchByProjection(F, Q, last_frame=last)
+    assert n2 == wn and np.array_equal(got2, want)
+    fctx.lib.afv_set_projection_resolve(fctx.handle, 2)
+    fr.close()
+
+
+def test_projection_dense_cluster_on_a_resident_frame(afv, oracle, fctx):
+    """all queries aim at the same window of a frame uploaded with afv_frame_set_features: claims, rescans, non-occupying queries"""
+    s = afv.synth
+    n, nq = 60, 400
+    proto = s.random_descriptors(77, 6)
+    d = proto[s.lcg_states(1, n) % 6].copy()
+    d[np.arange(n), s.lcg_states(2, n) % 32] ^= 1
+    kps = np.zeros(n, afv.KP_DTYPE)
+    kps["x"] = 300 + (s.lcg_states(3, n) % 40).astype(np.float32)
+    kps["y"] = 200 + (s.lcg_states(4, n) % 40).astype(np.float32)
+    fr = afv.Frame(fctx)
+    fr.set_features(kps, d, sizes=np.ones(n, np.float32))
+    F = afv.FrameGridView(d, np.stack([kps["x"], kps["y"]], 1), np.ones(n, np.float32))
+    qd = proto[s.lcg_states(5, nq) % 6].copy()
+    qd[np.arange(nq), s.lcg_states(6, nq) % 32] ^= 2
+    for occupies in (None, (s.lcg_bytes(9, nq) > 128).astype(np.uint8)):
+        Q = afv.ProjectionQueries(qd, np.full(nq, 320.0), np.full(nq, 220.0), np.full(nq, 30.0), np.full(nq, 0.5), np.full(nq, 2.0),
+                                  occupies=occupies)
+        afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+        for engine in (1, 0):
+            fctx.check(fctx.lib.afv_set_projection_resolve(fctx.handle, engine))
+            for mode, ratio in ((False, 0.8), (False, 2.0), (True, 0.9)):
+                m = afv.FeatureMatcher(ratio, False, ctx=fctx)
+                got, nn = fr.SearchByProjection(m, Q, last_frame=mode)
+                want, wn = oracle.match_projection(F, Q, th_high=75.0, nnratio=ratio, last_frame=mode)
+                assert nn == wn and np.array_equal(got, want), (mode, ratio, engine, occupies is None)
+    fctx.lib.afv_set_projection_resolve(fctx.handle, 2)
+    fr.close()
+
+
+def test_undistorted_keypoints_rebuild_the_grid(afv, oracle, fctx):
+    """a `distorted` frame: the caller hands mvKeysUn over (Frame.cc:403-433); some points leave the image bounds and drop out of the grid"""
+    img = afv.synth.corners_frame(7)
+    fr = afv.Frame(fctx, min_x=-8.0, min_y=-6.0, max_x=652.0, max_y=489.0, distorted=True)
+    k1, d1 = fr.extract(img)
+    s = afv.synth
+    xu = (k1["x"] * np.float32(1.1) - np.float32(40.0)).astype(np.float32)
+    yu = (k1["y"] * np.float32(1.02) - np.float32(7.5)).astype(np.float32)
+    fr.set_undistorted(xu, yu)
+    cp, ci = fr.grid()
+    wp, wi = _host_grid(xu, yu, -8.0, -6.0, fr.grid_inv_w, fr.grid_inv_h)
+    assert np.array_equal(cp, wp) and np.array_equal(ci, wi) and 0 < cp[-1] < len(k1)
+    size1, _, _ = fctx.size_sigma(k1)
+    F = afv.FrameGridView(d1, np.stack([xu, yu], 1), size1, angles=k1["angle"], min_x=-8.0, min_y=-6.0, max_x=652.0, max_y=489.0)
+    Q = _queries(afv, fctx, 7, img, 4, 20.0)
+    Q.u = (Q.u * np.float32(1.1) - np.float32(40.0)).astype(np.float32)
+    Q.v = (Q.v * np.float32(1.02) - np.float32(7.5)).astype(np.float32)
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+    m = afv.FeatureMatcher(0.8, True, ctx=fctx)
+    got, n = fr.SearchByProjection(m, Q)
+    want, wn = oracle.match_projection(F, Q, th_high=75.0, nnratio=0.8)
+    assert n == wn and np.array_equal(got, want) and wn > 100
+    fr.close()
+
+
+def test_fuse_on_a_resident_frame(afv, oracle, fctx):
+    img = afv.synth.corners_frame(11)
+    fr = afv.Frame(fctx)
+    k1, d1 = fr.extract(img)
+    size1, sigma2, inf = fctx.size_sigma(k1)
+    Q = _queries(afv, fctx, 11, img, 4, 15.0)
+    F = afv.FrameGridView(d1, np.stack([k1["x"], k1["y"]], 1), size1, angles=k1["angle"], inf=inf)
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+    m = afv.FeatureMatcher(0.6, True, ctx=fctx)
+    got, n = fr.Fuse(m, Q)
+    want, wn = oracle.match_projection(F, Q, th_high=75.0, fuse=True)
+    assert n == wn and np.array_equal(got, want) and 50 < wn
+    got, n = fr.Fuse(m, Q, use_inf_gate=False)
+    F.inf = None
+    want, wn = oracle.match_projection(F, Q, th_high=75.0, fuse=True)
+    assert n == wn and np.array_equal(got, want)
+    fr.close()
+
+
+@pytest.mark.parametrize("engine", [1, 0], ids=["fixed_point", "ordered_walk"])
+@pytest.mark.parametrize("ori", [False, True])
+@pytest.mark.parametrize("seed,shift,window", [(24, 6, 100.0), (25, 30, 40.0), (26, 0, 12.0)])
+def test_initialization_between_two_resident_frames(afv, oracle, seed, shift, window, ori, engine):
+    s = afv.synth
+    ctx2k = afv.Context(nfeatures=2000)
+    ctx2k.check(ctx2k.lib.afv_set_projection_resolve(ctx2k.handle, engine))
+    img = s.corners_frame(seed)
+    f1, f2 = afv.Frame(ctx2k), afv.Frame(ctx2k)
+    k1, d1 = f1.extract(img)
+    k2, d2 = f2.extract(np.roll(img, shift, axis=1))
+    z1, _, _ = ctx2k.size_sigma(k1); z2, _, _ = ctx2k.size_sigma(k2)
+    F2 = afv.FrameGridView(d2, np.stack([k2["x"], k2["y"]], 1), z2, angles=k2["angle"])
+    prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+    n1 = len(k1)
+    maxsz = np.float32(max(ctx2k.size_sigma(np.array([(0, 0, 0, 0, 0, o, -1)], afv.KP_DTYPE))[0][0] for o in range(8)))
+    Q1 = afv.ProjectionQueries(d1, prev[:, 0].copy(), prev[:, 1].copy(), np.full(n1, window, np.float32), np.zeros(n1, np.float32),
+                               np.full(n1, maxsz, np.float32), valid=(k1["octave"] == 0).astype(np.uint8), angles=k1["angle"])
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+    m = afv.FeatureMatcher(0.9, ori, ctx=ctx2k)
+    got, n = f1.SearchForInitialization(m, f2, prev, windowSize=window)
+    want, wn = oracle.match_initialization(F2, Q1, th_low=75.0, nnratio=0.9, check_orientation=ori)
+    assert n == wn and np.array_equal(got, want)
+    if shift <= window:
+        assert wn > 50
+    f1.close(); f2.close(); ctx2k.close()
+
+
+def test_compute_bow_on_the_frame_and_search_by_bow(afv, oracle, fctx):
+    """Frame::ComputeBoW on the device (FeatureVector left there) -> promotion of two frames into the keyframe table ->
+    SearchByBoW(KF, KF) over the table and SearchByBoW(KF, F) of a third resident frame: nothing but the images was uploaded"""
+    voc = afv.Vocabulary.random(3, k=8, L=3, ctx=fctx)
+    img = afv.synth.corners_frame(1)
+    frames, host = [], []
+    for sh in (0, 3, 5):
+        fr = afv.Frame(fctx)
+        k, d = fr.extract(np.roll(img, sh, axis=1))
+        bow, fv = fr.ComputeBoW(voc, levelsup=2)
+        wb, wf = voc.transform(d, levelsup=2)            # the host-array path (afv_bow_transform)
+        assert bow == wb and fv == wf
+        oleaf, onid = oracle.bow_transform(voc, d, 2)
+        kept = voc.weight[oleaf] > 0
+        assert sorted(i for _, idx in fv for i in idx) == np.nonzero(kept)[0].tolist() and not kept.all()
+        assert fr.featvec() == fv                          # the device-built CSR
+        frames.append(fr); host.append((k, d, fv))
+    table = afv.table.DescriptorTable(fctx, 4, fctx.cap)
+    table.set_from_frame(0, frames[0])
+    table.set_from_frame(2, frames[1])
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+    (k0, d0, fv0), (k1, d1, fv1), (k2, d2, fv2) = host
+    # SearchByBoW(KF, KF), BoW-guided and brute force, over the promoted slots
+    m, nm = table.match_bow([0], [2], 75.0, 0.75, True)
+    want, wn = oracle.search_by_bow_kf_kf(d0, d1, fv0, fv1, None, None, k0["angle"], k1["angle"], 75.0, 0.75, True)
+    assert nm[0] == wn and np.array_equal(m[0, :len(d0)], want) and wn > 100
+    m, nm = table.match_pairs([2], [0], 75.0, 0.6, True)
+    want, wn = oracle.search_by_bow_kf_kf(d1, d0, None, None, None, None, k1["angle"], k0["angle"], 75.0, 0.6, True)
+    assert nm[0] == wn and np.array_equal(m[0, :len(d1)], want)
+    # SearchByBoW(KF, F) with the frame side resident
+    mf, nf = table.match_bow_frame_resident([0, 2], frames[2], 75.0, 0.7, True)
+    for row, (dk, kk, fvk) in enumerate(((d0, k0, fv0), (d1, k1, fv1))):
+        want, wn = oracle.search_by_bow_kf_frame(dk, d2, fvk, fv2, None, kk["angle"], k2["angle"], 75.0, 0.7, True)
+        assert nf[row] == wn and np.array_equal(mf[row], want) and wn > 100
+    # SearchForTriangulation over promoted slots (geometry came with the frames; the FeatureVector body is fetched from the device)
+    F12 = np.array([0, 0, 0, 0, 0, -1, 0, 1, 0], np.float32)
+    sig0 = fctx.size_sigma(k0)[1]
+    mt, nt = table.match_triangulation([2], [0], F12[None], np.array([[-1000.0, -1000.0]], np.float32), 75.0)
+    want, wn = oracle.search_for_triangulation(d1, d0, np.stack([k1["x"], k1["y"]], 1), np.stack([k0["x"], k0["y"]], 1), sig0, F12,
+                                               (-1000.0, -1000.0), fv1, fv0, None, None, 75.0)
+    assert nt[0] == wn and np.array_equal(mt[0, :len(d1)], want) and wn > 20
+    for fr in frames:
+        fr.close()
+    table.close(); voc.close()
+
+
+def test_projection_queries_by_reference_into_the_keyframe_table(afv, oracle, fctx):
+    """a map point's descriptor is a row of the keyframe that observed it: the queries of SearchByProjection name (slot, row) of the
+    table instead of carrying 32 bytes each"""
+    img = afv.synth.corners_frame(9)
+    kf = afv.Frame(fctx)
+    kk, kd = kf.extract(np.roll(img, 5, axis=1))
+    table = afv.table.DescriptorTable(fctx, 3, fctx.cap)
+    table.set_from_frame(1, kf)
+    cur = afv.Frame(fctx)
+    k1, d1 = cur.extract(img)
+    size1, _, _ = fctx.size_sigma(k1)
+    sizek, _, _ = fctx.size_sigma(kk)
+    s = afv.synth
+    pick = np.argsort(s.lcg_states(3, len(kk)), kind="stable")[:700]
+    u = kk["x"][pick] - np.float32(5); v = kk["y"][pick]
+    Q = afv.ProjectionQueries(kd[pick], u, v, np.float32(15) * sizek[pick], sizek[pick] / np.float32(1.2), sizek[pick] * np.float32(1.2),
+                              angles=kk["angle"][pick])
+    F = afv.FrameGridView(d1, np.stack([k1["x"], k1["y"]], 1), size1, angles=k1["angle"])
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+    m = afv.FeatureMatcher(0.9, True, ctx=fctx)
+    got, n = cur.SearchByProjection(m, Q, last_frame=True, qref=(table, np.full(len(pick), 1, np.int32), pick))
+    want, wn = oracle.match_projection(F, Q, th_high=75.0, nnratio=0.9, check_orientation=True, last_frame=True)
+    assert n == wn and np.array_equal(got, want) and wn > 300
+    with pytest.raises(afv._lib.AfvError):  # a row the slot does not hold
+        cur.SearchByProjection(m, Q, last_frame=True, qref=(table, np.full(len(pick), 1, np.int32), pick + 5000))
+    kf.close(); cur.close(); table.close()
+
+
+def test_toy_sequence_as_one_chained_run(afv, oracle, fctx):
+    """the reference's docs/toy_sequence (five 640 x 480 frames, committed as gray arrays): frame t is extracted into a resident frame,
+    quantised, searched against frame t - 1 by projection (the identity motion model) and by BoW against the promoted keyframe, then
+    promoted itself - every stage compared with the oracle on the host copies"""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "toy_seq_gray.npz"))
+    seq = [np.ascontiguousarray(g) for g in z["gray"]]
+    assert len(seq) == 5
+    voc = afv.Vocabulary.random(5, k=10, L=3, ctx=fctx)
+    table = afv.table.DescriptorTable(fctx, 5, fctx.cap)
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+    m = afv.FeatureMatcher(0.9, True, ctx=fctx)
+    prev = None
+    for t, img in enumerate(seq):
+        assert img.shape == (480, 640)
+        fr = afv.Frame(fctx)
+        k, d = fr.extract(img)
+        ok, od = oracle.orb_extract(img)
+        assert k.tobytes() == ok.tobytes() and np.array_equal(d, od)
+        bow, fv = fr.ComputeBoW(voc, levelsup=2)
+        oleaf, onid = oracle.bow_transform(voc, d, 2)
+        assert fv == voc.vectors_from_nodes(oleaf, onid)[1]
+        size, _, _ = fctx.size_sigma(k)
+        if prev is not None:
+            pk, pd, pfv, psize = prev
+            Q = afv.ProjectionQueries(pd, pk["x"], pk["y"], np.float32(15) * psize, psize / np.float32(1.2), psize * np.float32(1.2), angles=pk["angle"])
+            F = afv.FrameGridView(d, np.stack([k["x"], k["y"]], 1), size, angles=k["angle"])
+            got, n = fr.SearchByProjection(m, Q, last_frame=True, qref=(table, np.full(len(pk), t - 1, np.int32), np.arange(len(pk))))
+            want, wn = oracle.match_projection(F, Q, th_high=75.0, nnratio=0.9, check_orientation=True, last_frame=True)
+            assert n == wn and np.array_equal(got, want)
+            mf, nf = table.match_bow_frame_resident([t - 1], fr, 75.0, 0.7, True)
+            want, wn = oracle.search_by_bow_kf_frame(pd, d, pfv, fv, None, pk["angle"], k["angle"], 75.0, 0.7, True)
+            assert nf[0] == wn and np.array_equal(mf[0], want)
+        table.set_from_frame(t, fr)
+        prev = (k, d, fv, size)
+        fr.close()
+    table.close(); voc.close()

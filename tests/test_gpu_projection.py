@@ -5,6 +5,15 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[1, 0], ids=["fixed_point", "ordered_walk"])
+def proj_engine(request, gpu_ctx):
+    """every case of this file through both engines of the ordered phase (afv_set_projection_resolve): the round-5 workgroup fixed
+    point and the one-wavefront ordered walk of rounds 1-4 must give the same answers as the oracle"""
+    gpu_ctx.check(gpu_ctx.lib.afv_set_projection_resolve(gpu_ctx.handle, request.param), "afv_set_projection_resolve")
+    yield request.param
+    gpu_ctx.lib.afv_set_projection_resolve(gpu_ctx.handle, 2)
+
+
 def _scene(afv, gpu_ctx, seed, shift, radius_scale, perm=True):
     """frame features = keypoints of a frame; queries = keypoints of the same frame shifted by `shift` px, 'projected'
     back with that offset (what a motion model does), window r = radius_scale * size"""
