@@ -1759,7 +1759,12 @@ int afv_match_projection_core(afv_ctx *c, const afv_proj_job *jobs, int njobs, i
     }
     // results straight into the pinned arena (device-visible host memory) when the kernels write them once and never read them back
     const bool zero_copy = c->stage_pinned && (fuse || wg_lds != 0);
+    // ... and, for ONE job against a resident frame, the inputs straight out of it: the job record is the kernel argument, the queries
+    // (a few KB per array, read once by the ranking kernel) come over the link without a copy-engine hop ahead of the launch
+    // (not with an occupancy mask: that one is gathered per candidate, which belongs in device memory)
+    const bool zero_copy_in = zero_copy && dev && njobs == 1 && !(jobs[0].occupied && kind != AFV_KIND_INIT);
     uint8_t *B = c->d_match, *H = b.h.data();
+    uint8_t *IN = zero_copy_in ? H : B;  // where the kernels find the staged inputs
     size_t acc = 0;
     for (int i = 0; i < njobs; ++i) {
         const afv_proj_job &j = jobs[i];
@@ -1787,38 +1792,40 @@ int afv_match_projection_core(afv_ctx *c, const afv_proj_job *jobs, int njobs, i
             g.min_x = j.min_x; g.min_y = j.min_y; g.inv_w = j.grid_inv_w; g.inv_h = j.grid_inv_h; g.cols = j.grid_cols; g.rows = j.grid_rows;
             g.cell_ptr = reinterpret_cast<int *>(B + o.cptr); g.cell_ent = reinterpret_cast<int4 *>(B + o.cent);
         }
-        d.occupied = (j.occupied && kind != AFV_KIND_INIT) ? B + o.occ : nullptr;
+        d.occupied = (j.occupied && kind != AFV_KIND_INIT) ? IN + o.occ : nullptr;
         d.min_x = j.min_x; d.min_y = j.min_y; d.inv_w = j.grid_inv_w; d.inv_h = j.grid_inv_h; d.cols = j.grid_cols; d.rows = j.grid_rows;
         d.nq = j.nq;
-        d.qdesc = (dev && dev->qdesc_dev) ? dev->qdesc_dev : reinterpret_cast<const uint32_t *>(B + o.qd);
-        d.qvalid = (dev && dev->qvalid_dev) ? dev->qvalid_dev : (j.qvalid ? B + o.qvalid : nullptr);
-        d.qu = reinterpret_cast<const float *>(B + o.qu); d.qv = reinterpret_cast<const float *>(B + o.qv);
-        d.qr = reinterpret_cast<const float *>(B + o.qr); d.qmin = reinterpret_cast<const float *>(B + o.qmin);
-        d.qmax = reinterpret_cast<const float *>(B + o.qmax);
-        d.qangle = (dev && dev->qangle_dev) ? dev->qangle_dev : (j.qangle ? reinterpret_cast<const float *>(B + o.qang) : nullptr);
-        d.qocc = j.qoccupies ? B + o.qocc : nullptr;
+        d.qdesc = (dev && dev->qdesc_dev) ? dev->qdesc_dev
+                                          : reinterpret_cast<const uint32_t *>(((dev && dev->qref_table) ? B : IN) + o.qd);
+        d.qvalid = (dev && dev->qvalid_dev) ? dev->qvalid_dev : (j.qvalid ? IN + o.qvalid : nullptr);
+        d.qu = reinterpret_cast<const float *>(IN + o.qu); d.qv = reinterpret_cast<const float *>(IN + o.qv);
+        d.qr = reinterpret_cast<const float *>(IN + o.qr); d.qmin = reinterpret_cast<const float *>(IN + o.qmin);
+        d.qmax = reinterpret_cast<const float *>(IN + o.qmax);
+        d.qangle = (dev && dev->qangle_dev) ? dev->qangle_dev : (j.qangle ? reinterpret_cast<const float *>(IN + o.qang) : nullptr);
+        d.qocc = j.qoccupies ? IN + o.qocc : nullptr;
         d.th = j.th_high; d.ratio = j.nnratio; d.tol = j.size_tol; d.inv_tol = j.inv_size_tol;
         d.check_ori = j.check_orientation != 0; d.mode = j.mode;
         d.keys = reinterpret_cast<unsigned long long *>(B + o.keys); d.ncand = reinterpret_cast<int *>(B + o.ncand);
         d.orilist = reinterpret_cast<int *>(B + o.ori);
-        d.q_ur = o.stereo ? reinterpret_cast<const float *>(B + o.qur) : nullptr;
-        d.q_er = (o.stereo && kind == AFV_KIND_PROJ) ? reinterpret_cast<const float *>(B + o.qer) : nullptr;
+        d.q_ur = o.stereo ? reinterpret_cast<const float *>(IN + o.qur) : nullptr;
+        d.q_er = (o.stereo && kind == AFV_KIND_PROJ) ? reinterpret_cast<const float *>(IN + o.qer) : nullptr;
         d.stereo_gate = (o.stereo && kind == AFV_KIND_PROJ) ? 1 : 0;
         uint8_t *R = zero_copy ? H : B;
         d.assign = reinterpret_cast<int *>(R + out_off + acc * 4); d.nmatches = reinterpret_cast<int *>(R + nm_off + (size_t)i * 4);
         acc += (size_t)(per_query ? j.nq : j.n);
     }
-    HIPCHK(c, hipMemcpyAsync(B, H, in_bytes, hipMemcpyHostToDevice, c->stream));
+    if (!zero_copy_in) HIPCHK(c, hipMemcpyAsync(B, H, in_bytes, hipMemcpyHostToDevice, c->stream));
     if (!dev) afv_launch_frame_grid(reinterpret_cast<const DevGridJob *>(B + gjobs_off), njobs, grid_lds, c->stream);
     if (dev && dev->qref_table && !dev->qdesc_dev) {
         const afv_table *qt = dev->qref_table;
-        afv_launch_frame_gather(qt->d_desc, qt->d_n, qt->nsets, qt->cap, reinterpret_cast<const int *>(B + offs[0].qrs),
-                                reinterpret_cast<const int *>(B + offs[0].qri), jobs[0].nq, B + offs[0].qd, nullptr, c->stream);
+        afv_launch_frame_gather(qt->d_desc, qt->d_n, qt->nsets, qt->cap, reinterpret_cast<const int *>(IN + offs[0].qrs),
+                                reinterpret_cast<const int *>(IN + offs[0].qri), jobs[0].nq, B + offs[0].qd, nullptr, c->stream);
     }
     const DevProjJob *dj = reinterpret_cast<const DevProjJob *>(B + jobs_off);
-    if (fuse) afv_launch_match_fuse(dj, njobs, max_nq, c->stream);
-    else if (kind == AFV_KIND_INIT) afv_launch_match_init(dj, njobs, max_nq, wg_lds, c->stream);
-    else afv_launch_match_projection(dj, njobs, max_nq, wg_lds, c->stream);
+    const DevProjJob *one = zero_copy_in ? reinterpret_cast<const DevProjJob *>(H + jobs_off) : nullptr;
+    if (fuse) afv_launch_match_fuse(dj, njobs, max_nq, one, c->stream);
+    else if (kind == AFV_KIND_INIT) afv_launch_match_init(dj, njobs, max_nq, wg_lds, one, c->stream);
+    else afv_launch_match_projection(dj, njobs, max_nq, wg_lds, one, c->stream);
     HIPCHK(c, hipGetLastError());
     if (!zero_copy) {
         HIPCHK(c, b.fetch(assign, out_off, total_out * 4, c->stream));

@@ -62,7 +62,7 @@ extern "C" void afv_launch_match_tri(const DevTriJob *jobs, int njobs, int max_n
 extern "C" void afv_launch_match_l2(const float *d1, int n1, const float *d2, int n2, int dim, const uint8_t *v1,
                                     const uint8_t *v2, float th, float ratio, int *out, int *nmatches, hipStream_t stream);
 
-extern "C" void afv_launch_match_projection(const DevProjJob *jobs, int njobs, int max_nq, size_t wg_lds, hipStream_t stream);
+extern "C" void afv_launch_match_projection(const DevProjJob *jobs, int njobs, int max_nq, size_t wg_lds, const DevProjJob *one, hipStream_t stream);
 extern "C" int afv_project_prepare(void);
 extern "C" size_t afv_project_wg_lds(int kind_init, int n, int nq);
 extern "C" size_t afv_frame_grid_lds(int cols, int rows, int cap);
@@ -73,14 +73,14 @@ extern "C" void afv_launch_frame_gather(const uint8_t *table, const int *nset, i
 extern "C" void afv_launch_featvec_build(const int *leaf, const int *nid, const int *dense, int n, int cap, int width, const uint8_t *stopped,
                                          int *seg_idx, int *n_kept, int *h_leaf, int *h_nid, int *h_dense, hipStream_t stream);
 extern "C" void afv_launch_table_promote(const void *args, int n, int cap, hipStream_t stream);
-extern "C" void afv_launch_match_fuse(const DevProjJob *jobs, int njobs, int max_nq, hipStream_t stream);
+extern "C" void afv_launch_match_fuse(const DevProjJob *jobs, int njobs, int max_nq, const DevProjJob *one, hipStream_t stream);
 extern "C" size_t afv_match_l2_scratch_bytes(int n1, int n2, int *ntiles_out, int *cols_per_tile_out);
 extern "C" int afv_launch_match_l2_tiled(const float *d1, int n1, const float *d2, int n2, int dim, const uint8_t *v1, const uint8_t *v2,
                                          float th, float ratio, int *out, int *nmatches, void *scratch, int ntiles, int cols_per_tile,
                                          hipStream_t stream);
 extern "C" int afv_launch_match_l2_pairs(const float *desc, const int *nset, int cap, int dim, const int *pa, const int *pb, int npairs,
                                          int pair_base, float th, float ratio, int *out, int *nmatches, void *scratch, hipStream_t stream);
-extern "C" void afv_launch_match_init(const DevProjJob *jobs, int njobs, int max_nq, size_t wg_lds, hipStream_t stream);
+extern "C" void afv_launch_match_init(const DevProjJob *jobs, int njobs, int max_nq, size_t wg_lds, const DevProjJob *one, hipStream_t stream);
 
 extern "C" void afv_launch_bow_transform(const DevVocab *v, const uint32_t *desc, int n, int levelsup, int *leaf_node,
                                          int *node_at_level, int *rank_at_level, hipStream_t stream);

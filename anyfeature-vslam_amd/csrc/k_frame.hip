@@ -46,31 +46,39 @@ __device__ __forceinline__ int fg_bytes_before(const uint4 row, int wv) {  // su
 
 // s_key[i] (u16, FG_NOCELL = not placed) for i < n; s_start[key]: exclusive prefix of the histogram (advanced as the chunks go by);
 // s_tab: nkeys x 16 bytes.  emit(i, pos) for every placed feature.  All 1024 threads call this.
+// The caller zeroes s_tab before its last barrier ahead of the call (the first chunk then starts without one).
+// A wave's count of a key is accumulated with ONE LDS atomic per feature (add 1 to the wave's byte of the key's row: at most 64 per byte,
+// no carry); the rank among equal keys of the same wave - by lane, i.e. by feature index - is 0 for every key the wave holds once
+// (read back from the row: LDS operations of a wave complete in order), and only lanes that share a key with another lane of their wave
+// enter the ballot loop (grid cells: almost never; FeatureVector nodes: a few dozen rounds).
 template <class Emit>
 __device__ __forceinline__ void fg_stable_place(const unsigned short *s_key, int n, int nkeys, int *s_start, uint4 *s_tab, Emit emit) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    unsigned *tab32 = reinterpret_cast<unsigned *>(s_tab);
+    const int sh = 8 * (wv & 3), wd = wv >> 2;
     for (int c0 = 0; c0 < n; c0 += FG_T) {
-        for (int k = tid; k < nkeys; k += FG_T) s_tab[k] = make_uint4(0, 0, 0, 0);
-        __syncthreads();
         const int i = c0 + tid;
         const unsigned key = i < n ? (unsigned)s_key[i] : FG_NOCELL;
-        int rank = 0, cnt = 0;
-        unsigned long long todo = __ballot(key != FG_NOCELL);
+        int rank = 0;
+        if (key != FG_NOCELL) atomicAdd(&tab32[key * 4 + wd], 1u << sh);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int cnt = key != FG_NOCELL ? (int)((tab32[key * 4 + wd] >> sh) & 0xffu) : 0;
+        unsigned long long todo = __ballot(cnt > 1);
         while (todo) {
             const int l = (int)__builtin_ctzll(todo);
             const unsigned kc = (unsigned)__builtin_amdgcn_readlane((int)key, l);
             const unsigned long long m = __ballot(key == kc);
-            if (key == kc) {
-                rank = __popcll(m & ((1ull << lane) - 1ull));
-                cnt = __popcll(m);
-            }
+            if (key == kc) rank = __popcll(m & ((1ull << lane) - 1ull));
             todo &= ~m;
         }
-        if (key != FG_NOCELL && rank == 0) reinterpret_cast<unsigned char *>(&s_tab[key])[wv] = (unsigned char)cnt;  // <= 64
         __syncthreads();
         if (key != FG_NOCELL) emit(i, s_start[key] + fg_bytes_before(s_tab[key], wv) + rank);
+        if (c0 + FG_T >= n) break;  // the usual frame: one chunk, one barrier
         __syncthreads();
         if (key != FG_NOCELL && rank == 0) atomicAdd(&s_start[key], cnt);
+        for (int k = tid; k < nkeys; k += FG_T) s_tab[k] = make_uint4(0, 0, 0, 0);
         __syncthreads();
     }
 }
@@ -108,44 +116,68 @@ __device__ __forceinline__ void frame_grid_body(const DevGridJob &J) {
     extern __shared__ __attribute__((aligned(16))) char fg_smem[];
     __shared__ int s_wsum[FG_NW];
     const int tid = threadIdx.x;
+    // the first 1024 features (all of them for the usual frame) stay in registers from the keypoint load to the grid entry: their
+    // position / size is never read back from memory.  The keypoint load does not wait for the count (slots below cap are readable).
+    afv_keypoint k0{};
+    if (J.kps && tid < J.cap) k0 = J.kps[tid];
     int n = J.n_ptr ? *J.n_ptr : J.n;
     n = min(max(n, 0), J.cap);
+    float xr = 0.0f, yr = 0.0f, sr = 0.0f;
     // ---- phase 1: per-feature arrays from the keypoints ----
     if (J.kps) {
         for (int i = tid; i < n; i += FG_T) {
-            const afv_keypoint k = J.kps[i];
+            const afv_keypoint k = i == tid ? k0 : J.kps[i];
+            float xx, yy, ss;
             if (J.copy_xy) {
-                J.x[i] = k.x;
-                J.y[i] = k.y;
+                xx = k.x;
+                yy = k.y;
+                J.x[i] = xx;
+                J.y[i] = yy;
+            } else {
+                xx = J.x[i];
+                yy = J.y[i];
             }
             J.angle[i] = k.angle;
             if (J.use_tab) {
                 const int o = min(max(k.octave, 0), AFV_MAX_LEVELS - 1);
-                J.size[i] = J.tab_size[o];
+                ss = J.tab_size[o];
+                J.size[i] = ss;
                 J.sigma2[i] = J.tab_sigma2[o];
                 J.inf[i] = J.tab_inf[o];
             } else {
-                const float s = J.size[i], s2 = s * s;  // keyPtsSigma2 = size^2, keyPtsInf = 1 / size^2 (FeatureExtractor.cpp:160-170)
+                ss = J.size[i];
+                const float s2 = ss * ss;  // keyPtsSigma2 = size^2, keyPtsInf = 1 / size^2 (FeatureExtractor.cpp:160-170)
                 J.sigma2[i] = s2;
                 J.inf[i] = 1.0f / s2;
             }
             if (J.fill_mono) J.u_right[i] = -1.0f;
             if (J.oct0) J.oct0[i] = k.octave == 0;  // SearchForInitialization only looks at level-0 keypoints of F1 (:485-489)
+            if (i == tid) {
+                xr = xx;
+                yr = yy;
+                sr = ss;
+            }
         }
+    } else if (J.cell_ptr && tid < n) {
+        xr = J.x[tid];
+        yr = J.y[tid];
+        sr = J.size[tid];
     }
     if (!J.cell_ptr) return;
-    __syncthreads();  // (a thread reads back only what it wrote itself; the barrier keeps the phases apart for the reader)
     const int ncell = J.cols * J.rows;
     const int n8 = (n + 7) & ~7;
     int *s_cnt = reinterpret_cast<int *>(fg_smem);
     unsigned short *s_cell = reinterpret_cast<unsigned short *>(fg_smem + (((size_t)ncell + 1) * 4 + 15) / 16 * 16);
     uint4 *s_tab = reinterpret_cast<uint4 *>(fg_smem + (((size_t)ncell + 1) * 4 + 15) / 16 * 16 + (((size_t)J.cap + 7) & ~(size_t)7) * 2);
     for (int c = tid; c <= ncell; c += FG_T) s_cnt[c] = 0;
-    __syncthreads();
+    if (ncell <= FG_TAB_MAX)
+        for (int c = tid; c < ncell; c += FG_T) s_tab[c] = make_uint4(0, 0, 0, 0);
+    __syncthreads();  // (features beyond the first 1024 are read back by the thread that wrote them)
     for (int i = tid; i < n8; i += FG_T) {
         unsigned cell = FG_NOCELL;
         if (i < n) {
-            const int px = (int)roundf((J.x[i] - J.min_x) * J.inv_w), py = (int)roundf((J.y[i] - J.min_y) * J.inv_h);  // PosInGrid
+            const float xx = i == tid ? xr : J.x[i], yy = i == tid ? yr : J.y[i];
+            const int px = (int)roundf((xx - J.min_x) * J.inv_w), py = (int)roundf((yy - J.min_y) * J.inv_h);  // PosInGrid
             if (!(px < 0 || px >= J.cols || py < 0 || py >= J.rows)) {
                 cell = (unsigned)(px * J.rows + py);
                 atomicAdd(&s_cnt[cell], 1);
@@ -155,7 +187,10 @@ __device__ __forceinline__ void frame_grid_body(const DevGridJob &J) {
     }
     __syncthreads();
     fg_exclusive_scan(s_cnt, ncell, J.cell_ptr, s_wsum);
-    auto emit = [&](int i, int pos) { J.cell_ent[pos] = make_int4(i, __float_as_int(J.x[i]), __float_as_int(J.y[i]), __float_as_int(J.size[i])); };
+    auto emit = [&](int i, int pos) {
+        const bool mine = i == tid;
+        J.cell_ent[pos] = make_int4(i, __float_as_int(mine ? xr : J.x[i]), __float_as_int(mine ? yr : J.y[i]), __float_as_int(mine ? sr : J.size[i]));
+    };
     if (ncell <= FG_TAB_MAX) {
         fg_stable_place(s_cell, n, ncell, s_cnt, s_tab, emit);
         return;
@@ -239,6 +274,7 @@ extern "C" __global__ __launch_bounds__(FG_T) void k_featvec_build(const int *__
         unsigned short *s_key = reinterpret_cast<unsigned short *>(fv_smem + (((size_t)width + 1) * 4 + 15) / 16 * 16);
         uint4 *s_tab = reinterpret_cast<uint4 *>(fv_smem + (((size_t)width + 1) * 4 + 15) / 16 * 16 + (((size_t)cap + 7) & ~(size_t)7) * 2);
         for (int c = tid; c <= width; c += FG_T) s_cnt[c] = 0;
+        for (int c = tid; c < width; c += FG_T) s_tab[c] = make_uint4(0, 0, 0, 0);
         __syncthreads();
         for (int i = tid; i < n8; i += FG_T) {
             unsigned key = FG_NOCELL;

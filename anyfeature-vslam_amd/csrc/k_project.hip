@@ -252,6 +252,15 @@ __global__ __launch_bounds__(PT) void k_proj_topk(const DevProjJob *__restrict__
     if (J.words == 8) topk_query<8, K, REC>(J, q, lane);
     else topk_query<16, K, REC>(J, q, lane);
 }
+// one job, its record a kernel argument: a search against a resident frame uploads nothing ahead of the launch - the queries are read
+// straight from the caller's pinned staging arena (a few KB over the link, once)
+template <int K, int REC>
+__global__ __launch_bounds__(PT) void k_proj_topk1(const DevProjJob J) {
+    const int lane = threadIdx.x & 63, q = blockIdx.x * (PT / 64) + (threadIdx.x >> 6);
+    if (q >= J.nq) return;
+    if (J.words == 8) topk_query<8, K, REC>(J, q, lane);
+    else topk_query<16, K, REC>(J, q, lane);
+}
 
 // ---------------- phase 2: ordered resolve, one wave per job ----------------
 // dynamic LDS: claim table [P_MAX_FEATS] | occupancy bitset | histogram | (when the job fits) the queries' records, so that
@@ -496,13 +505,22 @@ __global__ __launch_bounds__(PT) void k_proj_resolve(const DevProjJob *__restric
 //     the final wants.
 #define PW_T 1024
 #define PW_NW (PW_T / 64)
+// "did any thread change something in this pass": ONE barrier.  Three rotating flags (the pass that writes flag p % 3 clears the one the
+// pass after next will use): __syncthreads_or goes through the device library's workgroup reduction (an LDS round plus two barriers).
+__device__ __forceinline__ bool wg_any_changed(bool changed, int pass, int *s_vote) {
+    if (__ballot(changed) && (threadIdx.x & 63) == 0) s_vote[pass % 3] = 1;
+    __syncthreads();
+    const bool any = s_vote[pass % 3] != 0;
+    if (threadIdx.x == 0) s_vote[(pass + 2) % 3] = 0;
+    return any;
+}
 #define PW_INF 0x7fffffff
 #define PW_WLIST 128
 #define PW_GUARD (-0x7fffffff)  // *nmatches when the pass guard trips (never observed; the host turns it into AFV_EHIP)
 
 static inline size_t proj_wg_lds_bytes(int n, int nq) {
     const size_t nr = ((size_t)n + 63) & ~(size_t)63, qr = ((size_t)nq + 63) & ~(size_t)63;
-    return 3 * nr * 4 + qr * 16 /*keys*/ + qr * 4 /*meta*/ + 3 * qr * 2 /*w1, w2, pin*/ + qr * 2 /*live*/ + qr /*flag*/ + 64;
+    return 3 * nr * 4 + qr * 16 /*keys*/ + qr * 4 /*meta*/ + qr * 4 /*query angle*/ + 3 * qr * 2 /*w1, w2, pin*/ + qr * 2 /*live*/ + qr /*flag*/ + 64;
 }
 
 // one live query against the claims in R: the feature it accepts (-1: none) and whether it needs the exact rescan
@@ -557,14 +575,21 @@ __device__ void proj_resolve_wg(const DevProjJob &J) {
     int *s_claim = reinterpret_cast<int *>(pw_smem);                         // three arrays of nr
     int4 *s_keys = reinterpret_cast<int4 *>(s_claim + 3 * nr);               // per live query
     int *s_meta = reinterpret_cast<int *>(s_keys + qr);                       // #candidates | occupies << 31
-    short *s_w1 = reinterpret_cast<short *>(s_meta + qr), *s_w2 = s_w1 + qr;  // a live query's want after the last / the last but one pass
+    float *s_qang = reinterpret_cast<float *>(s_meta + qr);                   // the query's angle (orientation check), fetched with its keys
+    short *s_w1 = reinterpret_cast<short *>(s_qang + qr), *s_w2 = s_w1 + qr;  // a live query's want after the last / the last but one pass
     short *s_pin = s_w2 + qr;                                                 // the answer of its rescan
     unsigned short *s_live = reinterpret_cast<unsigned short *>(s_pin + qr);  // live index -> query
     uint8_t *s_flag = reinterpret_cast<uint8_t *>(s_live + qr);               // 1 = asked for a rescan in the last pass, 2 = pinned by a rescan
     __shared__ int s_hist[32];
-    __shared__ int s_nm, s_drop[3], s_first, s_part[PW_NW], s_cntw[PW_NW], s_guard;
+    __shared__ int s_nm, s_drop[3], s_first, s_part[PW_NW], s_cntw[PW_NW], s_guard, s_vote[3];
     __shared__ unsigned short s_wlist[PW_WLIST];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < 3) s_vote[tid] = 0;
+#ifdef AFV_PROJ_STATS
+    const long long st_t0 = wall_clock64();
+    long long st_t1 = 0, st_t2 = 0, st_tr = 0;
+    int st_conv = 0, st_steps = 0, st_adopt = 0, st_took = 0;
+#endif
     for (int i = tid; i < 3 * nr; i += PW_T) s_claim[i] = PW_INF;
     if (tid < 32) s_hist[tid] = 0;
     if (tid == 0) s_guard = 0;
@@ -574,9 +599,11 @@ __device__ void proj_resolve_wg(const DevProjJob &J) {
     for (int q0 = 0; q0 < J.nq; q0 += PW_T) {
         const int q = q0 + tid;
         int4 ka = make_int4(-1, -1, -1, -1), kb = make_int4(0, 0, 0, 0);
+        float qa = 0.0f;
         if (q < J.nq) {
             ka = grec[2 * q];
             kb = grec[2 * q + 1];
+            if (J.mode == 1 && J.check_ori) qa = J.qangle[q];
         }
         const bool live = (unsigned)ka.x != PROJ_NO_KEY32 && (float)((unsigned)ka.x >> 16) <= J.th;
         const unsigned long long m = __ballot(live);
@@ -593,6 +620,7 @@ __device__ void proj_resolve_wg(const DevProjJob &J) {
             const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
             s_live[slot] = (unsigned short)q;
             s_keys[slot] = ka;
+            s_qang[slot] = qa;
             s_meta[slot] = (kb.x & 0x7fffffff) | (kb.y ? (int)0x80000000 : 0);
             s_w1[slot] = -1;
             s_w2[slot] = -1;
@@ -602,6 +630,9 @@ __device__ void proj_resolve_wg(const DevProjJob &J) {
         nlive += tot;
         __syncthreads();
     }
+#ifdef AFV_PROJ_STATS
+    st_t1 = wall_clock64();
+#endif
     // ---- the fixed point ----
     int pass = 0;
     const int pass_limit = 3 * nlive + 64;  // every pass finalises at least one more query or a rescan does: a guard
@@ -631,8 +662,7 @@ __device__ void proj_resolve_wg(const DevProjJob &J) {
             s_w1[li] = (short)want;
             changed = changed || want != w1 || (rescan != ((flag & 1) != 0));
         }
-        ++pass;
-        if (__syncthreads_or(changed ? 1 : 0)) continue;
+        if (wg_any_changed(changed, pass++, s_vote)) continue;
         // converged: Wc holds the claims of the final wants (so far).  The queries that asked for a rescan, in order
         {
             const bool waits = tid < nlive && (s_flag[tid] & 3) == 1;  // the first 1024 live queries are looked at per cycle
@@ -671,6 +701,10 @@ __device__ void proj_resolve_wg(const DevProjJob &J) {
             __syncthreads();
         }
         if (nw == 0) break;
+#ifdef AFV_PROJ_STATS
+        ++st_conv;
+        const long long st_r0 = wall_clock64();
+#endif
         // exact rescans, one waiting query per wavefront (lanes over its window's cells), each against the claims of the queries BEFORE
         // it; adopted in order up to and including the first that takes a feature
         bool took = false;
@@ -728,13 +762,24 @@ __device__ void proj_resolve_wg(const DevProjJob &J) {
                 s_flag[r] = 2;
                 s_pin[r] = (short)s_part[tid];
             }
+#ifdef AFV_PROJ_STATS
+            ++st_steps;
+            st_adopt += nadopt;
+            st_took += took ? 1 : 0;
+#endif
             __syncthreads();
         }
+#ifdef AFV_PROJ_STATS
+        st_tr += wall_clock64() - st_r0;
+#endif
         // a taken feature enters the claims with the next pass (the pinned query's want changes from -1); if nothing was taken and every
         // waiting query was looked at, the converged state is the final one
         if (!took && nwait <= PW_WLIST && nlive <= PW_T) break;
     }
     __syncthreads();
+#ifdef AFV_PROJ_STATS
+    st_t2 = wall_clock64();
+#endif
     // ---- F.pts, count ----
     int *A = s_claim;  // assign[feature] = last query that took it
     for (int i = tid; i < nr; i += PW_T) A[i] = -1;
@@ -750,7 +795,7 @@ __device__ void proj_resolve_wg(const DevProjJob &J) {
             atomicMax(&A[w], q);
             ++cnt;
             if (ori) {  // updateRotationHistogram(rotHist, bestIdx2, LastFrame.mvKeysUn[i], CurrentFrame.mvKeysUn[bestIdx2]) (:1384-1385)
-                const int bin = proj_rotation_bin(J.qangle[q], J.angle[w]);
+                const int bin = proj_rotation_bin(s_qang[li], J.angle[w]);
                 s_flag[li] = (uint8_t)bin;
                 atomicAdd(&s_hist[bin], 1);
             }
@@ -791,10 +836,19 @@ __device__ void proj_resolve_wg(const DevProjJob &J) {
     }
     for (int i = tid; i < J.n; i += PW_T) J.assign[i] = A[i];
     if (tid == 0) *J.nmatches = s_guard ? PW_GUARD : s_nm;
+#ifdef AFV_PROJ_STATS
+    if (tid == 0)
+        printf("proj_resolve_wg: mode %d nq %d nlive %d passes %d convergences %d rescan_steps %d adopted %d took %d | x10ns: setup %lld fixedpoint %lld (rescans %lld) tail %lld\n",
+               J.mode, J.nq, nlive, pass, st_conv, st_steps, st_adopt, st_took, st_t1 - st_t0, st_t2 - st_t1, st_tr, wall_clock64() - st_t2);
+#endif
 }
 
 __global__ __launch_bounds__(PW_T) void k_proj_resolve_wg(const DevProjJob *__restrict__ jobs) {
     const DevProjJob J = jobs[blockIdx.x];
+    if (J.words == 8) proj_resolve_wg<8>(J);
+    else proj_resolve_wg<16>(J);
+}
+__global__ __launch_bounds__(PW_T) void k_proj_resolve_wg1(const DevProjJob J) {
     if (J.words == 8) proj_resolve_wg<8>(J);
     else proj_resolve_wg<16>(J);
 }
@@ -833,6 +887,12 @@ __device__ void fuse_query(const DevProjJob &J, int q, int lane) {
 
 __global__ __launch_bounds__(PT) void k_match_fuse(const DevProjJob *__restrict__ jobs) {
     const DevProjJob J = jobs[blockIdx.y];
+    const int lane = threadIdx.x & 63, q = blockIdx.x * (PT / 64) + (threadIdx.x >> 6);
+    if (q >= J.nq) return;
+    if (J.words == 8) fuse_query<8>(J, q, lane);
+    else fuse_query<16>(J, q, lane);
+}
+__global__ __launch_bounds__(PT) void k_match_fuse1(const DevProjJob J) {
     const int lane = threadIdx.x & 63, q = blockIdx.x * (PT / 64) + (threadIdx.x >> 6);
     if (q >= J.nq) return;
     if (J.words == 8) fuse_query<8>(J, q, lane);
@@ -1019,9 +1079,10 @@ __device__ void init_resolve_wg(const DevProjJob &J) {
     unsigned short *s_live = reinterpret_cast<unsigned short *>(s_pind + qr);
     uint8_t *s_flag = reinterpret_cast<uint8_t *>(s_live + qr);
     __shared__ int s_hist[32];
-    __shared__ int s_nm, s_drop[3], s_first, s_part[IW_NW], s_partd[IW_NW], s_cntw[IW_NW], s_guard;
+    __shared__ int s_nm, s_drop[3], s_first, s_part[IW_NW], s_partd[IW_NW], s_cntw[IW_NW], s_guard, s_vote[3];
     __shared__ unsigned short s_wlist[IW_WLIST];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < 3) s_vote[tid] = 0;
     for (int i = tid; i < 9 * nr; i += IW_T) s_E[i] = (i >= 6 * nr) ? 0 : IW_INF;
     for (int q = tid; q < J.nq; q += IW_T) J.assign[q] = -1;
     if (tid < 32) s_hist[tid] = 0;
@@ -1138,8 +1199,7 @@ __device__ void init_resolve_wg(const DevProjJob &J) {
             s_dist[nxt * qr + li] = (short)dw;
             changed = changed || want != w1 || (want >= 0 && dw != dprev) || (rescan != ((flag & 1) != 0));
         }
-        ++pass;
-        if (__syncthreads_or(changed ? 1 : 0)) continue;
+        if (wg_any_changed(changed, pass++, s_vote)) continue;
         {
             const bool waits = tid < nlive && (s_flag[tid] & 3) == 1;
             const unsigned long long bal = __ballot(waits);
@@ -1299,21 +1359,32 @@ __global__ __launch_bounds__(IW_T) void k_init_resolve_wg(const DevProjJob *__re
     if (J.words == 8) init_resolve_wg<8>(J);
     else init_resolve_wg<16>(J);
 }
+__global__ __launch_bounds__(IW_T) void k_init_resolve_wg1(const DevProjJob J) {
+    if (J.words == 8) init_resolve_wg<8>(J);
+    else init_resolve_wg<16>(J);
+}
 
 // the workgroup engines need more LDS than the 64 KB a kernel gets by default: raised once per device (afv_create), checked
 extern "C" int afv_project_prepare(void) {
     const int want = 150 * 1024;
     bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_resolve_wg), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
     ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_init_resolve_wg), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess && ok;
+    ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_resolve_wg1), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess && ok;
+    ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_init_resolve_wg1), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess && ok;
     if (!ok) (void)hipGetLastError();
     // dynamic bytes a job may ask for (the kernels' static arrays take about 1 KB more); without the raised limit: what every kernel gets
     return ok ? want - 2048 : 62 * 1024;
 }
 extern "C" size_t afv_project_wg_lds(int kind_init, int n, int nq) { return kind_init ? init_wg_lds_bytes(n, nq) : proj_wg_lds_bytes(n, nq); }
 
-extern "C" void afv_launch_match_init(const DevProjJob *jobs, int njobs, int max_nq, size_t wg_lds, hipStream_t stream) {
+// `one` != nullptr: a single job whose record travels as the kernel argument (the fixed-point engines and Fuse); else `jobs` is the
+// device array of njobs records
+extern "C" void afv_launch_match_init(const DevProjJob *jobs, int njobs, int max_nq, size_t wg_lds, const DevProjJob *one, hipStream_t stream) {
     const dim3 tg((max_nq + PT / 64 - 1) / (PT / 64), njobs);
-    if (wg_lds) {
+    if (wg_lds && one) {
+        if (max_nq > 0) hipLaunchKernelGGL((k_proj_topk1<IK, 3>), tg, dim3(PT), 0, stream, *one);
+        hipLaunchKernelGGL(k_init_resolve_wg1, dim3(1), dim3(IW_T), wg_lds, stream, *one);
+    } else if (wg_lds) {
         if (max_nq > 0) hipLaunchKernelGGL((k_proj_topk<IK, 3>), tg, dim3(PT), 0, stream, jobs);
         hipLaunchKernelGGL(k_init_resolve_wg, dim3(njobs), dim3(IW_T), wg_lds, stream, jobs);
     } else {
@@ -1322,13 +1393,21 @@ extern "C" void afv_launch_match_init(const DevProjJob *jobs, int njobs, int max
     }
 }
 
-extern "C" void afv_launch_match_fuse(const DevProjJob *jobs, int njobs, int max_nq, hipStream_t stream) {
-    if (max_nq > 0) hipLaunchKernelGGL(k_match_fuse, dim3((max_nq + PT / 64 - 1) / (PT / 64), njobs), dim3(PT), 0, stream, jobs);
+extern "C" void afv_launch_match_fuse(const DevProjJob *jobs, int njobs, int max_nq, const DevProjJob *one, hipStream_t stream) {
+    if (max_nq <= 0) return;
+    const dim3 tg((max_nq + PT / 64 - 1) / (PT / 64), njobs);
+    if (one) hipLaunchKernelGGL(k_match_fuse1, tg, dim3(PT), 0, stream, *one);
+    else hipLaunchKernelGGL(k_match_fuse, tg, dim3(PT), 0, stream, jobs);
 }
 
 // wg_lds != 0: the fixed-point engine with that much dynamic LDS (the largest job's tables); 0: the ordered walk
-extern "C" void afv_launch_match_projection(const DevProjJob *jobs, int njobs, int max_nq, size_t wg_lds, hipStream_t stream) {
+extern "C" void afv_launch_match_projection(const DevProjJob *jobs, int njobs, int max_nq, size_t wg_lds, const DevProjJob *one, hipStream_t stream) {
     const dim3 tg((max_nq + PT / 64 - 1) / (PT / 64), njobs);
+    if (wg_lds && one) {
+        if (max_nq > 0) hipLaunchKernelGGL((k_proj_topk1<PK, 1>), tg, dim3(PT), 0, stream, *one);
+        hipLaunchKernelGGL(k_proj_resolve_wg1, dim3(1), dim3(PW_T), wg_lds, stream, *one);
+        return;
+    }
     if (wg_lds) {
         if (max_nq > 0) hipLaunchKernelGGL((k_proj_topk<PK, 1>), tg, dim3(PT), 0, stream, jobs);
         hipLaunchKernelGGL(k_proj_resolve_wg, dim3(njobs), dim3(PW_T), wg_lds, stream, jobs);

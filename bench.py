@@ -806,6 +806,39 @@ def extra_host_api():
     return {"error": (r.stderr or r.stdout)[-300:]}
 
 
+def tracking_keys(host_api):
+    """The per-frame matcher path of Tracking as driver-visible keys, host to host through the C-ABI (tools/host_latency.cpp,
+    300 calls each): `projection` / `initialization` / `fuse` / `bow_transform` against a device-resident Frame (afv_frame_*), the same
+    calls through the host-array entry points beside them, and the whole tracking step of one frame.  Device time per kernel:
+    profiles/rNN/kernel_stats_tracking.json (rocprofv3 of the same program), attached when it matches the sources."""
+    t = (host_api or {}).get("tracking_frame")
+    if not t:
+        return None
+    out = {
+        "tracking_frame": {"chain_us": t["chain_us"], "chain_queries_by_reference_us": t["chain_queries_by_reference_us"],
+                           "host_array_chain_us": t["host_array_chain_us"], "stages": t["stages"],
+                           "frame_extract_us": t["frame_extract_us"], "promote_us": t["promote_us"]},
+        "projection": {"resident_frame_lastframe_1000q_us": t["frame_projection_lastframe_1000q_us"],
+                       "resident_frame_lastframe_1000q_by_reference_us": t["frame_projection_lastframe_1000q_by_reference_us"],
+                       "resident_frame_localmap_2000q_us": t["frame_projection_localmap_2000q_us"],
+                       "host_arrays_1000q_us": t["host_array_projection_1000q_us"], "host_arrays_2000q_us": t["host_array_projection_2000q_us"],
+                       "matches_lastframe": t["matches_lastframe"], "matches_localmap": t["matches_localmap"],
+                       "reference": "SearchByProjection, FeatureMatcher.cc:73-154, :1291-1402"},
+        "initialization": {"resident_frames_us": t["initialization_resident_frames_us"], "host_arrays_us": t["initialization_host_arrays_us"],
+                           "matches": t["matches_initialization"], "reference": "SearchForInitialization, FeatureMatcher.cc:399-557"},
+        "fuse": {"resident_frame_2000q_us": t.get("frame_fuse_2000q_us"), "found": t.get("matches_fuse"), "reference": "Fuse, FeatureMatcher.cc:794-940"},
+        "bow_transform": {"resident_frame_us": t["frame_bow_transform_us"], "host_arrays_us": t["host_array_bow_transform_us"],
+                          "vocabulary": "k = 10, L = 6, %d nodes (random tree of the shipped shape)" % t["vocabulary_nodes"], "descriptors": host_api.get("keypoints"),
+                          "search_by_bow_kf_f_us": t["frame_search_by_bow_kf_f_us"], "reference": "Vocabulary.cpp:156-206, Frame.cc:397-401"},
+    }
+    ks = _newest_profile("kernel_stats_tracking.json")
+    if ks:
+        out["device_kernels_us"] = None if ks["_stale"] else {k: round(v["avg_ns"] / 1e3, 2) for k, v in ks["kernels"].items()}
+        out["device_kernels_source"] = ks["_path"]
+        out["device_kernels_stale"] = bool(ks["_stale"])
+    return out
+
+
 def extra_single_frame(afv, device, reps=200):
     """The plugin shape (Frame.cc:186: ONE frame per call; Tracking.cc:78,84 keeps two extractor instances): latency of one
     640 x 480 frame extracted + matched against its predecessor on one context, and the frame rate when 2 / 4 contexts (each with its own
@@ -1016,25 +1049,50 @@ def main():
                        "per_rank": per_rank, "backend": args.backend if world > 1 else None},
             "keypoints_per_ms": total_kp / dt / 1e3,
             "frames_per_s": B * world * args.steps / dt,
+            "csrc_sha": _csrc_sha(),
         }
         if stages:
             px = level_pixels(W, H)
             fh = stages["fast_nms"]
             if fh["launches"]:
-                ms = fh["total_ms"] / fh["launches"]                 # mean launch duration (hipEvents on the launch stream)
-                frames_per_launch = fh["units"] / fh["launches"]     # the runtime splits a batch over two streams
-                achieved = px * frames_per_launch / (ms * 1e-3) / 1e9
+                # The dominant kernel, measured so that rocprof sees the same thing: ONE launch over the whole batch on
+                # ONE stream with the chip otherwise idle, HIP events on the launch stream (standalone_fast_nms) - the launch shape of
+                # profiles/rNN/kernel_stats_single_stream.csv (bench.py --no-split under rocprofv3 --kernel-trace --stats).  The figures of
+                # the timed region itself - chunks of about 85 frames alternating over two streams, so an event pair around a launch also
+                # spans the other stream's kernels - stay under `timed_region_two_streams`.
+                ms2 = fh["total_ms"] / fh["launches"]
+                fpl2 = fh["units"] / fh["launches"]
+                ach2 = px * fpl2 / (ms2 * 1e-3) / 1e9
+                two = {"avg_launch_ms_spanning_both_streams": ms2, "frames_per_launch": fpl2, "achieved": ach2, "frac": ach2 / HBM_PEAK_GBS,
+                       "note": "hipEvent pairs around the launches of the timed region; a launch shares the chip with the other stream's "
+                               "kernels, so this is an upper bound of the kernel's own duration, not a kernel duration"}
                 traffic, tpath, tstale = pmc_traffic("k_fast_nms", B)
-                out["roofline"] = {"bound": "hbm", "kernel": "k_fast_nms", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                   "traffic": None if (traffic is None or tstale) else traffic * frames_per_launch,
+                sa = None
+                if world == 1:
+                    try:
+                        sa = standalone_fast_nms(afv, local, B)
+                    except Exception as e:
+                        sa = None
+                        two["standalone_error"] = str(e)[:200]
+                ms, fpl, ach = (sa["avg_launch_ms"], sa["frames_per_launch"], sa["achieved"]) if sa else (ms2, fpl2, ach2)
+                out["roofline"] = {"bound": "hbm", "kernel": "k_fast_nms", "achieved": ach, "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                   "traffic": None if (traffic is None or tstale) else traffic * fpl,
                                    "traffic_source": tpath, "traffic_stale": bool(tstale),
-                                   "algorithmic_bytes_per_launch": px * frames_per_launch, "avg_launch_ms": ms,
-                                   "frames_per_launch": frames_per_launch,
+                                   "algorithmic_bytes_per_launch": px * fpl, "avg_launch_ms": ms,
+                                   "frames_per_launch": fpl,
+                                   "measured": ("one launch over the whole batch, one stream, chip otherwise idle; HIP events on the launch stream"
+                                                if sa else "timed region (two streams): see timed_region_two_streams"),
+                                   "timed_region_two_streams": two,
                                    "note": "integer-VALU-bound kernel (FAST ring tests, exact scores, NMS): the HBM fraction is low by "
-                                           "construction; the runtime runs a step as chunks of about 85 frames alternating over two "
-                                           "streams, so a launch shares the chip with the other stream's kernels (DESIGN.md section 4); "
-                                           "traffic = committed PMC pass, null when the sources changed since (traffic_stale)"}
+                                           "construction (DESIGN.md section 4); traffic = committed PMC pass x frames_per_launch, null when "
+                                           "the sources changed since (traffic_stale)"}
+                ks = _newest_profile("kernel_stats_single_stream.json")
+                if ks and "k_fast_nms" in ks.get("kernels", {}):   # the committed rocprofv3 summary of the same launch shape
+                    e = ks["kernels"]["k_fast_nms"]
+                    pf = px * ks.get("frames_per_launch", fpl) / (e["avg_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBS
+                    out["roofline"]["rocprof"] = {"avg_launch_ms": e["avg_ns"] / 1e6, "frames_per_launch": ks.get("frames_per_launch"), "frac": pf,
+                                                  "source": ks["_path"], "stale": bool(ks["_stale"])}
             # whole-pipeline algorithmic bytes (resize 1 569 878 + FAST read 950 532 + blur 1 901 064 + outputs
             # 60 000 = 4 481 534 B per 640x480 frame; the blur never touches HBM here, the figure is the reference's data flow)
             out["roofline_pipeline"] = {"bound": "hbm", "achieved": out["frames_per_s"] * 4481534 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -1091,7 +1149,9 @@ def main():
                                                                        for k, e in cp["kernels"].items() if k.split("<")[0] in keep},
                                 "note": "l2_hit = TCC_HIT / (TCC_HIT + TCC_MISS), LDS bank-conflict and wait cycles per LDS instruction: committed PMC passes "
                                         "(tools/collect_profiles.sh -> tools/pmc_cache.py), withheld when the sources changed since"}
-            out["stage_ms_per_step"] = {kk: (v["total_ms"] / prof_steps) for kk, v in stages.items()}  # overlapping streams: sums exceed ms_per_step
+            # event time of each stage summed over BOTH streams of a step: the two streams run concurrently, so an entry (and their sum)
+            # may exceed ms_per_step - these are not kernel durations (rocprof: profiles/rNN/kernel_stats_default.csv)
+            out["stage_event_ms_per_step_summed_over_concurrent_streams"] = {kk: (v["total_ms"] / prof_steps) for kk, v in stages.items()}
             out["stage_events_on_steps"] = "%d of %d timed steps (every %d-th)" % (prof_steps, args.steps, PROF_EVERY)
         if world == 1 and not args.no_extras:
             # extraction alone, device-resident (the yardstick of the host-fed pipeline)
@@ -1103,15 +1163,13 @@ def main():
             barrier()
             dev_fps = B * max(args.steps // 2, 2) / (time.perf_counter() - t1)
             out["host_fed"] = host_fed(afv, ctx, frames.cpu().numpy(), max(args.steps // 3, 5), dev_fps)
-            if "roofline" in out:
-                try:
-                    out["roofline"]["standalone"] = standalone_fast_nms(afv, local, B)
-                except Exception as e:
-                    out["roofline"]["standalone"] = {"error": str(e)[:200]}
             out["batch_sweep"] = batch_sweep(afv, local)
             out["overlap_match"] = overlap_step(afv, local)
             try:
                 out["host_api"] = extra_host_api()
+                tk = tracking_keys(out["host_api"])
+                if tk:   # the per-frame tracking calls as keys of the driver's line
+                    out.update(tk)
             except Exception as e:
                 out["host_api"] = {"error": str(e)[:200]}
             for key, fn in (("single_frame", extra_single_frame), ("pairs10k", extra_pairs10k), ("l2_sift128", extra_l2_sift128), ("akaze61", extra_akaze61)):

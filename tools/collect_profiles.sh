@@ -59,6 +59,24 @@ cd "$ROOT" && $PY bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.er
 timeout 400 rocprofv3 --kernel-trace --stats -d "$OUT/stats_default" -o st --output-format csv -- $PY "$ROOT/bench.py" --cpu-frames 0 --no-extras > /dev/null 2>&1
 cp "$OUT"/stats_default/*kernel_stats.csv "$OUT/kernel_stats_default.csv" 2>/dev/null || cp "$OUT"/stats_default/*/*kernel_stats.csv "$OUT/kernel_stats_default.csv"
 
+echo "== the dominant kernel in the launch shape bench.py's roofline quotes: one stream, one chunk (bench.py --no-split), rocprof beside the hipEvents"
+timeout 400 rocprofv3 --kernel-trace --stats -d "$OUT/stats_single" -o st --output-format csv -- $PY "$ROOT/bench.py" --no-split --cpu-frames 0 --no-extras --no-profile > /dev/null 2>&1
+cp "$(find "$OUT/stats_single" -name "*kernel_stats.csv" | head -1)" "$OUT/kernel_stats_single_stream.csv"
+cd "$ROOT" && $PY tools/kernel_stats_json.py "$OUT/kernel_stats_single_stream.csv" "$OUT/kernel_stats_single_stream.json" 512; cd /tmp
+rm -rf "$OUT/stats_single"
+
+echo "== the tracking step of one frame (tools/host_latency: resident Frame, projection searches, BoW, initialization): kernel stats + counters"
+"$ROOT/tools/host_latency" 300 > "$OUT/host_latency.json" 2> "$OUT/host_latency.err"
+timeout 400 rocprofv3 --kernel-trace --stats -d "$OUT/stats_tracking" -o st --output-format csv -- "$ROOT/tools/host_latency" 100 > /dev/null 2>&1
+cp "$(find "$OUT/stats_tracking" -name "*kernel_stats.csv" | head -1)" "$OUT/kernel_stats_tracking.csv"
+cd "$ROOT" && $PY tools/kernel_stats_json.py "$OUT/kernel_stats_tracking.csv" "$OUT/kernel_stats_tracking.json" - k_proj,k_init,k_match_fuse,k_bow,k_frame,k_featvec,k_table_promote,k_match_bow; cd /tmp
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVES SQ_BUSY_CU_CYCLES -d "$OUT/pmc_tracking" -o p --output-format csv -- "$ROOT/tools/host_latency" 20 > /dev/null 2>&1
+cp "$(find "$OUT/pmc_tracking" -name "*counter_collection.csv" | head -1)" "$RAW/pmc_tracking_counter_collection.csv" 2>/dev/null
+timeout 400 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d "$OUT/pmc_tracking_l2" -o p --output-format csv -- "$ROOT/tools/host_latency" 20 > /dev/null 2>&1
+cp "$(find "$OUT/pmc_tracking_l2" -name "*counter_collection.csv" | head -1)" "$RAW/pmc_tracking_l2_counter_collection.csv" 2>/dev/null
+$PY "$ROOT/tools/pmc_tracking.py" "$RAW/pmc_tracking_counter_collection.csv" "$RAW/pmc_tracking_l2_counter_collection.csv" "$OUT/pmc_tracking.json" > "$OUT/pmc_tracking.txt" 2>&1
+rm -rf "$OUT/stats_tracking" "$OUT/pmc_tracking" "$OUT/pmc_tracking_l2"
+
 echo "== PMC passes on: bench.py $BENCHARGS"
 for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
   timeout 400 rocprofv3 --kernel-trace --pmc $C -d "$OUT/pmc_$C" -o p --output-format csv -- $PY "$ROOT/bench.py" $BENCHARGS > /dev/null 2>&1

@@ -94,8 +94,8 @@ int main(int argc, char **argv) {
     // a keyframe (KeyFrame.cc:36), each stage a synchronous C call with host results, against the same chain through the host-array
     // entry points (what round 4 offered: every call re-uploads the frame and rebuilds its grid) ----
     double t_chain = -1, t_chain_ref = -1, t_fextract = -1, t_fbow = -1, t_fproj1 = -1, t_fproj1_ref = -1, t_fproj2 = -1, t_fpromote = -1, t_old_chain = -1,
-           t_old_bow = -1, t_old_proj1 = -1, t_old_proj2 = -1, t_init_old = -1, t_init_frame = -1, t_fbowmatch = -1;
-    int nm_p1 = 0, nm_p2 = 0, nm_init = 0, nm_bf = 0, vocab_nodes = 0;
+           t_old_bow = -1, t_old_proj1 = -1, t_old_proj2 = -1, t_init_old = -1, t_init_frame = -1, t_fbowmatch = -1, t_ffuse = -1;
+    int nm_p1 = 0, nm_p2 = 0, nm_init = 0, nm_bf = 0, vocab_nodes = 0, nm_fuse = 0;
     {
         // a vocabulary of the shipped shape (k = 10, L = 6: createVocabulary.py:39-42), LCG descriptors
         const int K = 10, L = 6;
@@ -196,6 +196,14 @@ int main(int argc, char **argv) {
             t_fproj1 = time_us(reps, [&] { afv_frame_match_projection(cur, &Q1, assign.data(), &nm1); });
             t_fproj1_ref = time_us(reps, [&] { afv_frame_match_projection(cur, &Q1r, assign.data(), &nm1); });
             t_fproj2 = time_us(reps, [&] { afv_frame_match_projection(cur, &Q2, assign.data(), &nm2); });
+            {   // matching core of Fuse(pKF, vpMapPoints) (FeatureMatcher.cc:794-940) with the frame in the keyframe's role: 2000 map points
+                std::vector<int32_t> best(nq2);
+                int32_t nf = 0;
+                afv_proj_queries QF = Q2;
+                QF.th_high = 75.f;
+                t_ffuse = time_us(reps, [&] { afv_frame_match_fuse(cur, &QF, 1, best.data(), &nf); });
+                nm_fuse = nf;
+            }
             t_fpromote = time_us(reps, [&] {
                 afv_table_set_from_frame(table, 2, cur);
                 (void)hipStreamSynchronize((hipStream_t)afv_stream(ctx));
@@ -272,12 +280,12 @@ int main(int argc, char **argv) {
     printf("{\"afv_orb_extract_us\": %.1f, \"afv_orb_extract_pinned_input_us\": %.1f, \"afv_match_bow_us\": %.1f, \"keypoints\": %d, \"matches\": %d, \"reps\": %d, "
            "\"tracking_frame\": {\"chain_us\": %.1f, \"chain_queries_by_reference_us\": %.1f, \"frame_extract_us\": %.1f, \"frame_bow_transform_us\": %.1f, "
            "\"frame_projection_lastframe_1000q_us\": %.1f, \"frame_projection_lastframe_1000q_by_reference_us\": %.1f, "
-           "\"frame_projection_localmap_2000q_us\": %.1f, \"promote_us\": %.1f, \"frame_search_by_bow_kf_f_us\": %.1f, "
+           "\"frame_projection_localmap_2000q_us\": %.1f, \"frame_fuse_2000q_us\": %.1f, \"matches_fuse\": %d, \"promote_us\": %.1f, \"frame_search_by_bow_kf_f_us\": %.1f, "
            "\"host_array_chain_us\": %.1f, \"host_array_bow_transform_us\": %.1f, \"host_array_projection_1000q_us\": %.1f, "
            "\"host_array_projection_2000q_us\": %.1f, \"initialization_host_arrays_us\": %.1f, \"initialization_resident_frames_us\": %.1f, "
            "\"matches_lastframe\": %d, \"matches_localmap\": %d, \"matches_initialization\": %d, \"matches_bow_kf_f\": %d, \"vocabulary_nodes\": %d, "
            "\"stages\": \"extract+grid -> ComputeBoW (k=10, L=6) -> SearchByProjection(cur,last) 1000 q -> SearchByProjection(F, local map) 2000 q -> promote; every stage a synchronous C call with host results\"}}\n",
-           t_pageable, t_pinned, t_match, n2, nm, reps, t_chain, t_chain_ref, t_fextract, t_fbow, t_fproj1, t_fproj1_ref, t_fproj2, t_fpromote, t_fbowmatch,
+           t_pageable, t_pinned, t_match, n2, nm, reps, t_chain, t_chain_ref, t_fextract, t_fbow, t_fproj1, t_fproj1_ref, t_fproj2, t_ffuse, nm_fuse, t_fpromote, t_fbowmatch,
            t_old_chain, t_old_bow, t_old_proj1, t_old_proj2, t_init_old, t_init_frame, nm_p1, nm_p2, nm_init, nm_bf, vocab_nodes);
     afv_destroy(ctx);
     return 0;
