@@ -160,6 +160,33 @@ int main(int argc, char **argv) {
              dumpv(".p_fuse", o_fuse) && dumpv(".p_fuse3", o_fuse3) && dumpv(".p_sim3", o_sim3) && dumpv(".p_init", o_init) &&
              dump(out + ".size2", size2.data(), size2.size() * 4) && dump(out + ".inf1", inf1.data(), inf1.size() * 4);
         if (!ok) return 5;
+        // ---- the same searches through DeviceFrame (resident frames: nothing of the frame is uploaded again): must reproduce the host-array
+        // results above element for element ----
+        {
+            afv::DeviceFrame D1(extractor.context(), 0.0f, 0.0f, (float)w, (float)h), D2(extractor.context(), 0.0f, 0.0f, (float)w, (float)h);
+            std::vector<afv::KeyPoint> kd1, kd2;
+            afv::Mat8 dd1, dd2;
+            D1.Extract(img, kd1, dd1);
+            D2.Extract(img2, kd2, dd2);
+            if (kd1.size() != n1 || kd2.size() != n2 || std::memcmp(kd1.data(), k1.data(), n1 * sizeof(afv::KeyPoint)) != 0 || dd1.data != d1.data ||
+                dd2.data != d2.data)
+                return 8;
+            std::vector<int> f_local, f_last, f_reloc, f_fuse, f_fuse3, f_init;
+            const int e0 = pm.SearchByProjection(D1, Q2, nullptr, f_local);
+            const int e1 = pm.SearchByProjection_LastFrame(D1, Q2, nullptr, f_last);
+            const int e2 = pm.SearchByProjection_Reloc(D1, Q2, nullptr, 60.0f, f_reloc);
+            const int e4 = pm.Fuse(D1, Q2, true, f_fuse);
+            const int e5 = pm.Fuse(D1, Q2, false, f_fuse3);
+            std::vector<float> px(x1), py(y1);
+            const int e7 = im.SearchForInitialization(D1, D2, px, py, 100, f_init);
+            if (e0 != c0 || e1 != c1 || e2 != c2 || e4 != c4 || e5 != c5 || e7 != c7 || f_local != o_local || f_last != o_last || f_reloc != o_reloc ||
+                f_fuse != o_fuse || f_fuse3 != o_fuse3 || f_init != o_init) {
+                std::fprintf(stderr, "resident-frame searches differ from the host-array ones: %d/%d %d/%d %d/%d %d/%d %d/%d %d/%d\n", e0, c0, e1, c1, e2,
+                             c2, e4, c4, e5, c5, e7, c7);
+                return 8;
+            }
+            std::printf("frame %d %d %d %d %d %d\n", e0, e1, e2, e4, e5, e7);
+        }
     }
     // ---- AKAZE61 plugin ----
     {

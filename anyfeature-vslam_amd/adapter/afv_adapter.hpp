@@ -11,6 +11,7 @@
 //   FeatureExtractor_orb32          include/Feature_orb32.h:12-33, src/Feature_orb32.cpp:11-65
 //   FeatureMatcher::SearchByBoW x2  include/FeatureMatcher.h:59-60, src/FeatureMatcher.cc:186-283, 561-660
 //   FeatureMatcher::SearchForTriangulation  include/FeatureMatcher.h:66-67, src/FeatureMatcher.cc:662-790
+//   Frame (the part the front end reads)  include/Frame.h, src/Frame.cc:171-240, 333-433 -> DeviceFrame (afv_frame_*)
 //   FeatureMatcher::SearchByProjection x4 / Fuse x2 / SearchBySim3 / SearchForInitialization (matching cores)
 //                                   include/FeatureMatcher.h:47-82, src/FeatureMatcher.cc:73-154, 287-397, 399-557, 794-1064,
 //                                   1066-1287, 1291-1506 — the projection geometry stays with the caller, as in the reference
@@ -207,6 +208,72 @@ class FeatureExtractor_orb32_hip {
     std::vector<float> mvScaleFactor;
 };
 
+// ---- the device-resident Frame (include/afv_hip.h afv_frame_*; reference object: Frame, src/Frame.cc:171-240) ----
+// One per Frame the tracker keeps alive (currentFrame, lastFrame, the initial frame): Frame::Frame calls Extract() instead of the plain
+// operator(), and from then on SearchByProjection / Fuse / SearchForInitialization / ComputeBoW / SearchByBoW(KF, F) and the promotion to
+// a KeyFrame read the frame where the extraction left it ("Tracking through a resident frame").
+class DeviceFrame {
+  public:
+    // mnMinX .. mnMaxY: Frame::ComputeImageBounds (Frame.cc:435-466); distorted: mDistCoef.at<float>(0) != 0 (Frame.cc:405)
+    DeviceFrame(afv_ctx *ctx_, float mnMinX, float mnMinY, float mnMaxX, float mnMaxY, bool distorted = false, int grid_cols = 64, int grid_rows = 48)
+        : ctx(ctx_) {
+        afv_frame_params p{};
+        p.struct_size = sizeof(p);
+        p.min_x = mnMinX; p.min_y = mnMinY; p.max_x = mnMaxX; p.max_y = mnMaxY;
+        p.grid_cols = grid_cols; p.grid_rows = grid_rows;
+        p.distorted = distorted ? 1 : 0;
+        const int rc = afv_frame_create(ctx, &p, &f);
+        if (rc != AFV_OK) fatal("afv_frame_create", rc, ctx);
+    }
+    ~DeviceFrame() { afv_frame_destroy(f); }
+    DeviceFrame(const DeviceFrame &) = delete;
+    DeviceFrame &operator=(const DeviceFrame &) = delete;
+
+    // Frame::ExtractFeatures (Frame.cc:242-259): FeatureExtractor::operator() 3-argument form into the resident frame; the host vectors
+    // are filled exactly as by FeatureExtractor_orb32_hip::detectAndCompute
+    template <class ImageT, class MatT>
+    void Extract(const ImageT &img, std::vector<KeyPoint> &keypoints, MatT &descriptors) {
+        const auto &g = img.grayImg;
+        if (g.empty()) return;
+        const int cap = afv_max_keypoints_per_frame(ctx);
+        std::vector<KeyPoint> kps((size_t)cap);
+        std::vector<uint8_t> desc((size_t)cap * AFV_DESC_BYTES);
+        int n = 0;
+#ifdef AFV_WITH_OPENCV
+        const size_t step = (size_t)g.step;
+#else
+        const size_t step = g.step();
+#endif
+        const int rc = afv_frame_extract(f, g.ptr(0), g.cols, g.rows, (int)step, reinterpret_cast<afv_keypoint *>(kps.data()), desc.data(), cap, &n);
+        if (rc != AFV_OK) fatal("afv_frame_extract", rc, ctx);
+        kps.resize((size_t)n);
+        keypoints.swap(kps);
+#ifdef AFV_WITH_OPENCV
+        descriptors.create(n, AFV_DESC_BYTES, CV_8U);
+#else
+        descriptors.create(n, AFV_DESC_BYTES);
+#endif
+        for (int i = 0; i < n; ++i) std::copy(desc.data() + (size_t)i * AFV_DESC_BYTES, desc.data() + (size_t)(i + 1) * AFV_DESC_BYTES, descriptors.ptr(i));
+    }
+    // Frame::UndistortKeyPoints for a distorted camera: mvKeysUn after cv::undistortPoints (Frame.cc:411-432); builds the grid
+    void SetUndistorted(const std::vector<KeyPoint> &mvKeysUn) {
+        std::vector<float> x(mvKeysUn.size()), y(mvKeysUn.size());
+        for (size_t i = 0; i < mvKeysUn.size(); ++i) {
+            x[i] = mvKeysUn[i].pt.x;
+            y[i] = mvKeysUn[i].pt.y;
+        }
+        const int rc = afv_frame_set_undistorted(f, x.data(), y.data());
+        if (rc != AFV_OK) fatal("afv_frame_set_undistorted", rc, ctx);
+    }
+    int N() const { return afv_frame_count(f); }
+    afv_frame *handle() { return f; }
+    afv_ctx *context() { return ctx; }
+
+  private:
+    afv_ctx *ctx;
+    afv_frame *f = nullptr;
+};
+
 // ---- matcher side: flat view of what FeatureMatcher reads from KeyFrame / Frame ----
 using FeatureVector = std::map<unsigned, std::vector<unsigned>>;  // DBoW2::FeatureVector (node id -> feature indices)
 
@@ -219,6 +286,12 @@ struct FeatureView {
     const float *x = nullptr, *y = nullptr;  // mvKeysUn[i].pt       (triangulation)
     const float *sigma2 = nullptr;           // GetKeyPt1DSigma2(i)  (triangulation)
     const float *mvuRight = nullptr;         // KeyFrame::mvuRight (stereo keyframes; nullptr: monocular)  (triangulation)
+};
+
+// the queries' descriptors named as rows (slot, idx) of a keyframe table instead of carried by value (afv_proj_queries::qref_*)
+struct TableRefs {
+    afv_table *table = nullptr;
+    const int32_t *slot = nullptr, *idx = nullptr;
 };
 
 class FeatureMatcherHip {
@@ -334,7 +407,73 @@ class FeatureMatcherHip {
         return n;
     }
 
+    // ---- the same searches against a resident frame: nothing of the frame is uploaded, only the queries travel (or, with q_table /
+    // q_slot / q_idx, only 8 bytes per query: a map point's descriptor named as the keyframe row MapPoint::ComputeDistinctDescriptors
+    // copied it from) ----
+    int SearchByProjection(DeviceFrame &F, const ProjectionQueries &q, const uint8_t *occupied, std::vector<int> &assign, TableRefs refs = TableRefs()) {
+        return frame_projection(F, q, occupied, TH_HIGH, AFV_PROJ_LOCALMAP, false, refs, assign);
+    }
+    int SearchByProjection_LastFrame(DeviceFrame &F, const ProjectionQueries &q, const uint8_t *occupied, std::vector<int> &assign,
+                                     TableRefs refs = TableRefs()) {
+        return frame_projection(F, q, occupied, TH_HIGH, AFV_PROJ_LASTFRAME, mbCheckOrientation, refs, assign);
+    }
+    int SearchByProjection_Reloc(DeviceFrame &F, const ProjectionQueries &q, const uint8_t *occupied, float th, std::vector<int> &assign) {
+        ProjectionQueries mono = q;
+        mono.ur = mono.er_max = nullptr;  // no mvuRight branch in :1404-1506
+        return frame_projection(F, mono, occupied, th, AFV_PROJ_LASTFRAME, mbCheckOrientation, TableRefs(), assign);
+    }
+    int Fuse(DeviceFrame &KF, const ProjectionQueries &q, bool reprojection_gate, std::vector<int> &best) {
+        afv_proj_queries Q = frame_queries(q, nullptr, TH_LOW, 0, false, TableRefs());
+        best.assign((size_t)std::max(q.n, 1), -1);
+        int32_t n = 0;
+        const int rc = afv_frame_match_fuse(KF.handle(), &Q, reprojection_gate ? 1 : 0, best.data(), &n);
+        if (rc != AFV_OK) fatal("afv_frame_match_fuse", rc, ctx);
+        best.resize((size_t)q.n);
+        return n;
+    }
+    // SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (:399-557) between two resident frames; vbPrevMatched is
+    // refreshed like :551-553 when F2's undistorted keypoints are given
+    int SearchForInitialization(DeviceFrame &F1, DeviceFrame &F2, std::vector<float> &prev_x, std::vector<float> &prev_y, int windowSize,
+                                std::vector<int> &vnMatches12, const std::vector<KeyPoint> *F2_mvKeysUn = nullptr) {
+        const int n1 = F1.N();
+        vnMatches12.assign((size_t)std::max(n1, 1), -1);
+        int32_t n = 0;
+        const int rc = afv_frame_match_initialization(F1.handle(), F2.handle(), prev_x.data(), prev_y.data(), (float)windowSize, TH_LOW, mfNNratio,
+                                                      mbCheckOrientation ? 1 : 0, vnMatches12.data(), &n);
+        if (rc != AFV_OK) fatal("afv_frame_match_initialization", rc, ctx);
+        vnMatches12.resize((size_t)n1);
+        if (F2_mvKeysUn)
+            for (int i = 0; i < n1; ++i)
+                if (vnMatches12[i] >= 0) {
+                    prev_x[i] = (*F2_mvKeysUn)[(size_t)vnMatches12[i]].pt.x;
+                    prev_y[i] = (*F2_mvKeysUn)[(size_t)vnMatches12[i]].pt.y;
+                }
+        return n;
+    }
+
   private:
+    afv_proj_queries frame_queries(const ProjectionQueries &q, const uint8_t *occupied, float th, int mode, bool ori, TableRefs refs) const {
+        afv_proj_queries Q{};
+        Q.struct_size = sizeof(Q);
+        Q.nq = q.n; Q.qdesc = refs.table ? nullptr : q.descriptors; Q.desc_bytes = AFV_DESC_BYTES;
+        Q.qvalid = q.valid; Q.qu = q.u; Q.qv = q.v; Q.qr = q.r; Q.qmin_size = q.min_size; Q.qmax_size = q.max_size;
+        Q.qangle = q.angle; Q.qoccupies = q.occupies; Q.q_ur = q.ur; Q.q_er_max = q.er_max;
+        Q.occupied = occupied;
+        Q.th_high = th; Q.nnratio = mfNNratio; Q.check_orientation = ori ? 1 : 0; Q.mode = mode;
+        Q.qref_table = refs.table; Q.qref_slot = refs.slot; Q.qref_idx = refs.idx;
+        return Q;
+    }
+    int frame_projection(DeviceFrame &F, const ProjectionQueries &q, const uint8_t *occupied, float th, int mode, bool ori, TableRefs refs,
+                         std::vector<int> &assign) {
+        afv_proj_queries Q = frame_queries(q, occupied, th, mode, ori, refs);
+        const int n = F.N();
+        assign.assign((size_t)std::max(n, 1), -1);
+        int32_t nm = 0;
+        const int rc = afv_frame_match_projection(F.handle(), &Q, assign.data(), &nm);
+        if (rc != AFV_OK) fatal("afv_frame_match_projection", rc, ctx);
+        assign.resize((size_t)n);
+        return nm;
+    }
     afv_proj_job proj_job(const FrameGridView &F, const ProjectionQueries &q) const {
         afv_proj_job j{};
         j.struct_size = sizeof(j);
@@ -485,8 +624,16 @@ class VocabularyHip {
         int words = 0;
         for (int i = 0; i < n; ++i)
             if (is_leaf[i]) word_id[i] = words++;
-        const int rc = afv_vocab_create(ctx, k, L, n, child_ptr.data(), child_idx.data(), node_desc.data(), 32, &voc);
+        int rc = afv_vocab_create(ctx, k, L, n, child_ptr.data(), child_idx.data(), node_desc.data(), 32, &voc);
         if (rc != AFV_OK) fatal("afv_vocab_create", rc, ctx);
+        std::vector<uint8_t> stopped((size_t)n, 0);  // DBoW2 transform: a word enters the vectors only if (w > 0)
+        bool any = false;
+        for (int i = 0; i < n; ++i)
+            if (is_leaf[i] && !(weight[(size_t)i] > 0)) stopped[(size_t)i] = 1, any = true;
+        if (any) {
+            rc = afv_vocab_set_stopped(ctx, voc, stopped.data());
+            if (rc != AFV_OK) fatal("afv_vocab_set_stopped", rc, ctx);
+        }
     }
     ~VocabularyHip() { afv_vocab_destroy(ctx, voc); }
     VocabularyHip(const VocabularyHip &) = delete;
@@ -511,6 +658,29 @@ class VocabularyHip {
         if (s > 0)
             for (auto &kv : bow) kv.second /= s;  // BowVector::normalize(L1)
     }
+
+    // Frame::ComputeBoW (Frame.cc:397-401) on a resident frame: mBowVec / mFeatVec for the host's own use (KeyFrameDatabase scoring);
+    // the FeatureVector also stays on the device with the frame (SearchByBoW(KF, F) through afv_table_match_bow_frame_h, promotion)
+    void transform(DeviceFrame &F, BowVector &bow, FeatureVector &fv, int levelsup = 4) {
+        bow.clear();
+        fv.clear();
+        const int n = F.N();
+        std::vector<int32_t> leaf((size_t)std::max(n, 1)), nid((size_t)std::max(n, 1));
+        const int rc = afv_frame_bow_transform(F.handle(), voc, levelsup, leaf.data(), nid.data(), nullptr);
+        if (rc != AFV_OK) fatal("afv_frame_bow_transform", rc, ctx);
+        for (int i = 0; i < n; ++i) {
+            const double w = weight[(size_t)leaf[i]];
+            if (w > 0) {
+                bow[(unsigned)word_id[(size_t)leaf[i]]] += w;
+                fv[(unsigned)nid[i]].push_back((unsigned)i);
+            }
+        }
+        double s = 0;
+        for (const auto &kv : bow) s += std::fabs(kv.second);
+        if (s > 0)
+            for (auto &kv : bow) kv.second /= s;
+    }
+    afv_vocab *handle() { return voc; }
 
   private:
     afv_ctx *ctx;
