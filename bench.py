@@ -232,6 +232,10 @@ def akaze_main(args):
                         "unit": "GB/s", "frac": strict * B / dt_ss / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "algorithmic_bytes_per_frame": strict, "kernel_structure_bytes_per_frame": kern,
                         "kernel_structure_GBps": kern * B / dt_ss / 1e9}}
+    try:
+        out["single_frame"] = akaze_single_frame()
+    except Exception as e:
+        out["single_frame"] = {"error": str(e)[:200]}
     if args.cpu_frames > 0:
         out["cpu_baseline"] = akaze_cpu_baseline(afv, frames_h[:min(args.cpu_frames, B, 4)], ctx.quotas())
     emit(out)
@@ -790,7 +794,26 @@ def extra_akaze61(afv, device, B=64, steps=3):
            "described_per_frame": nk / B, "scale_space_ms_per_step": dt_ss * 1e3, "scale_space_GBps": strict * B / dt_ss / 1e9,
            "scale_space_frac_of_hbm_peak": strict * B / dt_ss / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_frame": strict}
     del ctx
+    try:
+        out["single_frame"] = akaze_single_frame()
+    except Exception as e:
+        out["single_frame"] = {"error": str(e)[:200]}
     return out
+
+
+def akaze_single_frame():
+    """FeatureExtractor_akaze61::detectAndCompute for ONE 1280 x 720 frame per call, host to host through the C-ABI (tools/akaze_latency.cpp):
+    the reference's per-frame operator() (FeatureExtractor.cpp:111-121)"""
+    exe = os.path.join(ROOT, "tools", "akaze_latency")
+    if not os.path.exists(exe):
+        return {"error": "tools/akaze_latency is not built"}
+    r = subprocess.run([exe, "100"], capture_output=True, text=True, timeout=120)
+    for line in r.stdout.splitlines():
+        if line.startswith("{"):
+            d = json.loads(line)
+            return {"ms_per_call": d["afv_akaze_extract_1280x720_us"] / 1e3, "keypoints": d["keypoints"], "calls": d["reps"],
+                    "note": "one synchronous afv_akaze_extract call per frame: pageable host image in, host keypoints + 61-byte descriptors out"}
+    return {"error": (r.stderr or r.stdout)[-300:]}
 
 
 def extra_host_api():

@@ -308,3 +308,28 @@ def test_other_settings_and_full_size(afv, akz, oracle, num_octaves, th, w, h, n
     assert len(gk) == len(wk) and len(wk) > 0.4 * nfeatures
     assert gk.tobytes() == wk.tobytes() and np.array_equal(gd, wd)
     ctx.close()
+
+
+def test_one_frame_per_call_equals_the_batch_path(afv):
+    """the plugin shape (FeatureExtractor.cpp:111-121: ONE frame per operator() call) against the batch call on the same frames"""
+    w, h, seeds = 640, 480, (3, 9, 21)
+    frames = _frames(afv, w, h, seeds)
+    bctx = afv.AkazeContext(afv.akaze.default_params(max_width=w, max_height=h, max_batch=len(seeds)))
+    batch = bctx.extract(frames)
+    sctx = afv.AkazeContext(afv.akaze.default_params(max_width=w, max_height=h, max_batch=1))
+    for f in range(len(seeds)):
+        for rep in range(2):   # the second call of a frame reuses every buffer of the first
+            k, d = sctx.extract(frames[f])
+            assert k.tobytes() == batch[f][0].tobytes() and np.array_equal(d, batch[f][1]) and len(k) > 500
+    # a strided view (a ROI of a larger image) and a page-locked source take the other upload branches
+    import torch
+    big = np.zeros((h + 8, w + 16), np.uint8)
+    big[4:4 + h, 8:8 + w] = frames[0]
+    roi = big[4:4 + h, 8:8 + w]
+    kps = np.zeros(1064, afv.KP_DTYPE); desc = np.zeros((1064, 61), np.uint8); n = np.zeros(1, np.int32)
+    rc = sctx.lib.afv_akaze_extract(sctx.handle, roi.ctypes.data, 1, w, h, big.strides[0], 0, kps.ctypes.data, desc.ctypes.data, 1064, n.ctypes.data)
+    assert rc == 0 and kps[:n[0]].tobytes() == batch[0][0].tobytes() and np.array_equal(desc[:n[0]], batch[0][1])
+    pinned = torch.from_numpy(frames[1].copy()).pin_memory()
+    rc = sctx.lib.afv_akaze_extract(sctx.handle, pinned.data_ptr(), 1, w, h, w, 0, kps.ctypes.data, desc.ctypes.data, 1064, n.ctypes.data)
+    assert rc == 0 and kps[:n[0]].tobytes() == batch[1][0].tobytes() and np.array_equal(desc[:n[0]], batch[1][1])
+    bctx.close(); sctx.close()
