@@ -527,7 +527,10 @@ extern "C" int afv_create(int device, const afv_orb_params *params, afv_ctx **ou
         return AFV_EUNSUPPORTED;
     }
 #undef CREATE_CHK
-    c->proj_wg_lds_max = afv_project_prepare();  // 0: the projection searches keep to the ordered walk
+    // kernels that ask for more dynamic LDS than the default: raised once per context, on its device, checked
+    c->proj_wg_lds_max = afv_project_prepare();
+    (void)afv_match_prepare();
+    c->select_wide_ok = afv_select_prepare(c->select_M) != 0;
     *out = c;
     return AFV_OK;
 }
@@ -705,7 +708,7 @@ static void enqueue_range(afv_ctx *c, const FrameSrc &src, int f0, int nf, afv_k
     {
         StageTimer t_(c, AFV_STAGE_SELECT, s, nf);
         afv_launch_select(c->d_geo, g.nlevels, c->d_l1, c->d_l1_resp, c->d_l1_count, c->d_kept_xy, c->d_kept_resp,
-                          c->d_kept_node, c->d_sel, c->d_sel_count, c->select_M, f0, nf, small ? 1 : 0, s);
+                          c->d_kept_node, c->d_sel, c->d_sel_count, c->select_M, f0, nf, (small && c->select_wide_ok) ? 1 : 0, s);
     }
     {
         StageTimer t_(c, AFV_STAGE_DESCRIBE, s, nf);
@@ -1376,7 +1379,7 @@ static int afv_match_bow_impl(afv_ctx *c, const afv_match_job *jobs, int njobs, 
             HIPCHK(c, b.fetch(nmatches, nm_off, (size_t)njobs * 4, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             b.finish();
-            return AFV_OK;
+            return afv_check_resolve_guard(c, nmatches, njobs);
         }
     }
     Blob b(c);
@@ -1519,6 +1522,17 @@ extern "C" int afv_match_triangulation(afv_ctx *c, const afv_tri_job *jobs, int 
     return guarded(c, [&] { return afv_match_triangulation_impl(c, jobs, njobs, match12, nmatches); });
 }
 
+// a pair whose fixed point hit its pass guard carries nmatches = -0x7fffffff (k_match_resolve_wg): entry points that hand results to the
+// host report it (never observed outside the test hook afv_debug_pass_cap)
+int afv_check_resolve_guard(afv_ctx *c, const int32_t *nmatches, int n) {
+    for (int i = 0; i < n; ++i)
+        if (nmatches[i] == -0x7fffffff) {
+            c->last_error = "pair matcher: the fixed point of pair " + std::to_string(i) + " hit its pass guard; afv_set_match_resolve(ctx, 0) selects the ordered walk";
+            return AFV_EHIP;
+        }
+    return AFV_OK;
+}
+
 // core of the device-resident brute-force batch; angles as a strided float array (see afv_launch_match_resolve)
 int afv_match_pairs_core(afv_ctx *c, const uint8_t *d_desc, const float *d_ang, int ang_stride, const int32_t *d_n, int cap,
                          const int32_t *d_pair_a, const int32_t *d_pair_b, int npairs, float th_low, float nnratio,
@@ -1570,7 +1584,16 @@ int afv_match_pairs_core(afv_ctx *c, const uint8_t *d_desc, const float *d_ang, 
         afv_launch_match_resolve(d_desc, d_ang, ang_stride, d_n, cap, d_pair_a, d_pair_b, npairs, th_low, nnratio, check_orientation, d_match,
                                  d_nmatches, c->d_topk, 0, resolve_engine_for(c, npairs), s);
     }
-    HIPCHK(c, hipGetLastError());
+    {
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            // a sliced launch that did not go out (or went out half) may leave row-tile tickets behind: zero them, so that the next
+            // small-batch call on this context starts from rest instead of merging early or never
+            if (nslices > 1 && c->d_tickets) (void)hipMemsetAsync(c->d_tickets, 0, c->tickets_n * sizeof(int), s);
+            c->last_error = std::string("pair matcher launch: ") + hipGetErrorString(e);
+            return AFV_EHIP;
+        }
+    }
     return AFV_OK;
 }
 
@@ -1805,6 +1828,7 @@ int afv_match_projection_core(afv_ctx *c, const afv_proj_job *jobs, int njobs, i
         d.qocc = j.qoccupies ? IN + o.qocc : nullptr;
         d.th = j.th_high; d.ratio = j.nnratio; d.tol = j.size_tol; d.inv_tol = j.inv_size_tol;
         d.check_ori = j.check_orientation != 0; d.mode = j.mode;
+        d.pass_cap = afv_debug_pass_cap;
         d.keys = reinterpret_cast<unsigned long long *>(B + o.keys); d.ncand = reinterpret_cast<int *>(B + o.ncand);
         d.orilist = reinterpret_cast<int *>(B + o.ori);
         d.q_ur = o.stereo ? reinterpret_cast<const float *>(IN + o.qur) : nullptr;

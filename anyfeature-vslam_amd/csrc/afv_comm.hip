@@ -374,7 +374,7 @@ extern "C" int afv_table_match_pairs(afv_table *t, const int32_t *pair_a, const 
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::memcpy(nmatches, h_nm, (size_t)npairs * sizeof(int32_t));
     if (match12) std::memcpy(match12, h_out, (size_t)npairs * t->cap * sizeof(int32_t));
-    return AFV_OK;
+    return afv_check_resolve_guard(c, nmatches, npairs);
 }
 
 // ---- BoW-guided / triangulation batches over the table: the kernels of k_match.hip with job records that point into

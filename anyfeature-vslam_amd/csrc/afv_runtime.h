@@ -64,6 +64,9 @@ extern "C" void afv_launch_match_l2(const float *d1, int n1, const float *d2, in
 
 extern "C" void afv_launch_match_projection(const DevProjJob *jobs, int njobs, int max_nq, size_t wg_lds, const DevProjJob *one, hipStream_t stream);
 extern "C" int afv_project_prepare(void);
+extern "C" int afv_match_prepare(void);
+extern "C" int afv_select_prepare(int M);
+extern "C" int afv_debug_pass_cap;
 extern "C" size_t afv_project_wg_lds(int kind_init, int n, int nq);
 extern "C" size_t afv_frame_grid_lds(int cols, int rows, int cap);
 extern "C" void afv_launch_frame_grid(const DevGridJob *jobs, int njobs, size_t lds_bytes, hipStream_t stream);
@@ -163,6 +166,7 @@ struct afv_ctx {
     int *d_cand_count = nullptr, *d_sel_count = nullptr;
     SelPoint *d_sel = nullptr;
     int select_M = 64;
+    bool select_wide_ok = true;   // the 1024-thread quadtree kernel got its LDS (afv_select_prepare at afv_create)
     // staging of the host-pointer entry points
     uint8_t *d_frames = nullptr;
     size_t frames_pitch = 0, frames_stride = 0;
@@ -420,6 +424,7 @@ int afv_match_pairs_core(afv_ctx *c, const uint8_t *d_desc, const float *d_ang, 
                          const int32_t *d_pair_a, const int32_t *d_pair_b, int npairs, float th_low, float nnratio,
                          int check_orientation, int32_t *d_match, int32_t *d_nmatches, hipStream_t s);
 void afv_shared_segments(const afv_match_job &j, std::vector<Seg> &segs);
+int afv_check_resolve_guard(afv_ctx *c, const int32_t *nmatches, int n);
 void afv_table_release_all(afv_ctx *c);  // afv_destroy: tables / communicators still alive die with their context
 void afv_frame_release_all(afv_ctx *c);  // ... and so do its frames
 void afv_frame_after_extract(afv_frame *f, hipStream_t s);  // afv_frame.hip: k_frame_grid behind the describe kernel of afv_frame_extract

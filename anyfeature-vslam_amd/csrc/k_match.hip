@@ -721,6 +721,7 @@ __global__ __launch_bounds__(MT, 2) void k_match_resolve(const uint8_t *__restri
 //     rows before them, the answers up to the first that takes a column are pinned, and the iteration continues;
 //   * there is no matched-set bitmap: "column c is taken for row i" is claim[c] < i.
 #define RW_INF 0x7fffffff
+#define AFV_RESOLVE_GUARD (-0x7fffffff)  // nmatches of a pair whose fixed point hit its pass guard
 #define RW_WLIST 128  // waiting rows looked at per convergence
 #define RW_RPW 2      // waiting rows a wavefront rescans together (they share the column loads): 32 per step
 #define RWT 1024      // threads: one per live row
@@ -780,7 +781,7 @@ __global__ __launch_bounds__(RWT) void k_match_resolve_wg(const uint8_t *__restr
                                                          const int *__restrict__ nset, int cap, const int *__restrict__ pair_a,
                                                          const int *__restrict__ pair_b, const int4 *__restrict__ topk, float th,
                                                          float ratio, int check_ori, int *__restrict__ match,
-                                                         int *__restrict__ nmatches, int pair_base, int stage_cols) {
+                                                         int *__restrict__ nmatches, int pair_base, int stage_cols, int pass_cap) {
     extern __shared__ __attribute__((aligned(16))) char s_dyn[];
     const int capr = (cap + 63) & ~63;
     int4 *s_keys = reinterpret_cast<int4 *>(s_dyn);  // key records (2 x int4) of the live rows (first PAIR_KEYS_LDS of them)
@@ -848,8 +849,15 @@ __global__ __launch_bounds__(RWT) void k_match_resolve_wg(const uint8_t *__restr
     // ---- the fixed point ----
     bool cols_ready = false;
     int pass = 0;
-    const int pass_limit = 3 * nlive + 64;  // every pass finalises at least one more row or rescans one: a guard, never reached
-    while (nlive > 0 && pass < pass_limit) {
+    // every pass finalises at least one more row or rescans one: a guard, never reached - if it ever is, the pair is REPORTED
+    // (nmatches = AFV_RESOLVE_GUARD, which the host entry points turn into AFV_EHIP), not returned half settled
+    const int pass_limit = pass_cap > 0 ? pass_cap : 3 * nlive + 64;
+    bool guard_hit = false;
+    while (nlive > 0) {
+        if (pass >= pass_limit) {
+            guard_hit = true;
+            break;
+        }
         int *R = s_claim + (pass % 3) * capr, *W = s_claim + ((pass + 1) % 3) * capr, *Z = s_claim + ((pass + 2) % 3) * capr;
         bool changed = false;
         for (int li = tid; li < nlive; li += RWT) {
@@ -1074,7 +1082,7 @@ __global__ __launch_bounds__(RWT) void k_match_resolve_wg(const uint8_t *__restr
         __syncthreads();
     }
     for (int i = tid; i < cap; i += RWT) out[i] = s_out[i];
-    if (tid == 0) nmatches[p] = s_nm;
+    if (tid == 0) nmatches[p] = guard_hit ? AFV_RESOLVE_GUARD : s_nm;
 }
 
 // ---------------- M4: SearchForTriangulation ----------------
@@ -1240,37 +1248,33 @@ extern "C" void afv_launch_match_topk(const uint8_t *desc, const int *nset, int 
     hipLaunchKernelGGL(k_match_topk, dim3((cap + MT - 1) / MT, npairs), dim3(MT), 0, stream, desc, nset, cap, pa, pb, topk, pair_base);
 }
 // ang: keypoint angles in degrees, element (set, i) at ang[(set * cap + i) * ang_stride] (stride 7 = afv_keypoint::angle)
+// test hook (process-wide, 0 = off): caps the passes of the fixed-point engines (k_match_resolve_wg, k_proj_resolve_wg, k_init_resolve_wg) so
+// that a test can drive them into their guard and check that the call reports it instead of returning a half-settled assignment
+extern "C" int afv_debug_pass_cap = 0;
+
+// once per context (afv_create, on the context's device): both ordered-phase kernels may ask for more dynamic LDS than the default 64 KB
+extern "C" int afv_match_prepare(void) {
+    bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_match_resolve_wg), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
+    ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_match_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess && ok;
+    if (!ok) (void)hipGetLastError();
+    return ok ? 1 : 0;
+}
+
 extern "C" void afv_launch_match_resolve(const uint8_t *desc, const float *ang, int ang_stride, const int *nset, int cap, const int *pa,
                                          const int *pb, int npairs, float th, float ratio, int check_ori, int *match, int *nmatches,
                                          const void *topk_scratch, int pair_base, int engine, hipStream_t stream) {
     const int4 *topk = reinterpret_cast<const int4 *>(topk_scratch);
     if (engine == 1) {  // workgroup-wide fixed point (round 4); columns are parked in LDS only for batches, and only once a pair needs a rescan
         const bool stage = cap <= PAIR_COLS_LDS && npairs > 8;
-        const size_t lds_wg = resolve_wg_lds_bytes(cap, stage);
-        static bool done_wg[64] = {};
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (lds_wg > 48 * 1024 && dev >= 0 && dev < 64 && !done_wg[dev]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_match_resolve_wg), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            done_wg[dev] = true;
-        }
+        const size_t lds_wg = resolve_wg_lds_bytes(cap, stage);  // (the raised LDS limit: afv_match_prepare at afv_create)
         hipLaunchKernelGGL(k_match_resolve_wg, dim3(npairs), dim3(RWT), lds_wg, stream, desc, ang, ang_stride, nset, cap, pa, pb, topk, th, ratio,
-                           check_ori, match, nmatches, pair_base, stage ? 1 : 0);
+                           check_ori, match, nmatches, pair_base, stage ? 1 : 0, afv_debug_pass_cap);
         return;
     }
     // the column descriptors ride in LDS (for the exact rescans) when they fit and the launch is a batch; a handful of pairs (the
     // single-frame plugin path) runs leaner: 39 KB instead of 71 KB, rescans through L2
     const bool stage_cols = cap <= PAIR_COLS_LDS && npairs > 8;
-    const size_t lds = resolve_lds_bytes(cap, stage_cols);  // 71 KB with the columns: above the default 64 KB limit
-    if (lds > 64 * 1024) {  // once per device: the attribute belongs to the device's copy of the function
-        static bool done[64] = {};
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (dev >= 0 && dev < 64 && !done[dev]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_match_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            done[dev] = true;
-        }
-    }
+    const size_t lds = resolve_lds_bytes(cap, stage_cols);  // 71 KB with the columns: above the default 64 KB limit (afv_match_prepare)
     hipLaunchKernelGGL(k_match_resolve, dim3(npairs), dim3(MT), lds, stream, desc, ang, ang_stride, nset, cap, pa, pb, topk, th, ratio,
                        check_ori, match, nmatches, pair_base, stage_cols ? 1 : 0);
 }

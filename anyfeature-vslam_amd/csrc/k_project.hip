@@ -635,7 +635,7 @@ __device__ void proj_resolve_wg(const DevProjJob &J) {
 #endif
     // ---- the fixed point ----
     int pass = 0;
-    const int pass_limit = 3 * nlive + 64;  // every pass finalises at least one more query or a rescan does: a guard
+    const int pass_limit = J.pass_cap > 0 ? J.pass_cap : 3 * nlive + 64;  // every pass finalises at least one more query or a rescan does: a guard
     bool done = nlive == 0;
     while (!done) {
         if (pass >= pass_limit) {
@@ -1127,7 +1127,7 @@ __device__ void init_resolve_wg(const DevProjJob &J) {
         __syncthreads();
     }
     int pass = 0;
-    const int pass_limit = 3 * nlive + 64;
+    const int pass_limit = J.pass_cap > 0 ? J.pass_cap : 3 * nlive + 64;
     bool done = nlive == 0;
     while (!done) {
         if (pass >= pass_limit) {

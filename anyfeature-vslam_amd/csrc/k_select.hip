@@ -814,15 +814,25 @@ __global__ __launch_bounds__(1024) void k_select_quadtree_wide(const Geo *__rest
 static size_t select_lds_bytes(int M, int kept) { return afv_select_tree_bytes(M) + SEL_TMP * 4 + (size_t)kept * 6 /*kept xy, node*/; }
 extern "C" size_t afv_select_lds_bytes(int M) { return std::max(select_lds_bytes(M, SelCfg<256>::KEPT_LDS), select_lds_bytes(M, SelCfg<1024>::KEPT_LDS)); }
 
+// once per context (afv_create, on the context's device): the wide instantiation may need more dynamic LDS than the 64 KB a kernel gets
+// by default.  false: the attribute call failed and the tables do not fit without it - the caller keeps to the 256-thread kernel.
+extern "C" int afv_select_prepare(int M) {
+    const size_t lds = select_lds_bytes(M, SelCfg<1024>::KEPT_LDS);
+    if (lds <= 64 * 1024) return 1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_select_quadtree_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return 1;
+}
+
 extern "C" void afv_launch_select(const Geo *geo_dev, int nlevels, const uint32_t *cand_packed, const float *cand_resp,
                                   const int *cand_count, uint32_t *kept_xy, float *kept_resp, uint16_t *kept_node,
                                   SelPoint *sel, int *sel_count, int M, int frame_base, int nframes, int wide, hipStream_t stream) {
     const int total = nlevels * nframes;
     dim3 grid((total + 7) / 8 * 8);
     if (wide) {
-        const size_t lds = select_lds_bytes(M, SelCfg<1024>::KEPT_LDS);
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_select_quadtree_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const size_t lds = select_lds_bytes(M, SelCfg<1024>::KEPT_LDS);  // above 64 KB: afv_select_prepare raised the limit at afv_create
         hipLaunchKernelGGL(k_select_quadtree_wide, grid, dim3(1024), lds, stream, geo_dev, cand_packed, cand_resp, cand_count, kept_xy, kept_resp,
                            kept_node, sel, sel_count, M, frame_base, total);
         return;

@@ -153,6 +153,9 @@ int afv_match_triangulation(afv_ctx *ctx, const afv_tri_job *jobs, int njobs, in
 /* device-resident brute-force batch: pair p matches descriptor set a[p] (side 1) against set b[p] (side 2) of a
    table d_desc[nsets][cap][32] with per-set counts d_n[nsets] and angles d_kps (afv_keypoint, may be NULL when
    !check_orientation).  d_match[npairs][cap] (idx2 | -1), d_nmatches[npairs].  SearchByBoW(KF,KF) semantics. */
+/* (d_nmatches[p] == -0x7fffffff marks a pair whose ordered phase gave up at its pass guard - never observed; the host-result entry
+   points turn it into AFV_EHIP.  At most ONE call that uses the column-sliced phase 1 (calls of at most afv_set_small_batch_path's
+   max_frames pairs) may be in flight per context: its tickets and slice records are per context, not per stream.) */
 int afv_match_bruteforce_pairs_device(afv_ctx *ctx, const uint8_t *d_desc, const afv_keypoint *d_kps,
                                       const int32_t *d_n, int nsets, int cap, const int32_t *d_pair_a,
                                       const int32_t *d_pair_b, int npairs, float th_low, float nnratio,

@@ -550,3 +550,36 @@ def test_three_threads_three_contexts(afv, oracle):
         assert np.array_equal(got[i][0], want[i][0])
         assert got[i][1][1] == want[i][1][1] and np.array_equal(got[i][1][0], want[i][1][0])
     serial_ctx.close()
+
+
+def test_fixed_point_guard_is_reported_not_swallowed(afv, oracle, gpu_ctx):
+    """the workgroup fixed points leave their loop at a pass guard that is never reached in practice; if it ever were, the call
+    must say so instead of returning a half-settled assignment.  The test hook afv_debug_pass_cap drives all three engines into it."""
+    import ctypes as C
+    lib = gpu_ctx.lib
+    cap_var = C.c_int.in_dll(lib, "afv_debug_pass_cap")
+    img = afv.synth.corners_frame(1)
+    k1, d1 = gpu_ctx.extract(img)
+    k2, d2 = gpu_ctx.extract(np.roll(img, 3, axis=1))
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+    m = afv.FeatureMatcher(0.6, True, ctx=gpu_ctx)
+    v1, v2 = afv.FeatureView(d1, angles=k1["angle"]), afv.FeatureView(d2, angles=k2["angle"])
+    want, wn = m.SearchByBoW(v1, v2)
+    size1 = gpu_ctx.size_sigma(k1)[0]
+    size2 = gpu_ctx.size_sigma(k2)[0]
+    F = afv.FrameGridView(d1, np.stack([k1["x"], k1["y"]], 1), size1, angles=k1["angle"])
+    Q = afv.ProjectionQueries(d2, k2["x"] - np.float32(3), k2["y"], np.float32(15) * size2, size2 / np.float32(1.2), size2 * np.float32(1.2),
+                              angles=k2["angle"])
+    pw, pn = m.SearchByProjection(F, Q, last_frame=True)
+    cap_var.value = 1          # one pass can never confirm convergence
+    try:
+        with pytest.raises(afv._lib.AfvError):
+            m.SearchByBoW(v1, v2)
+        with pytest.raises(afv._lib.AfvError):
+            m.SearchByProjection(F, Q, last_frame=True)
+    finally:
+        cap_var.value = 0
+    got, n = m.SearchByBoW(v1, v2)
+    assert n == wn and np.array_equal(got, want)
+    got, n = m.SearchByProjection(F, Q, last_frame=True)
+    assert n == pn and np.array_equal(got, pw)
