@@ -291,6 +291,37 @@ def table_broadcast_bytes(K, cap):
     return int(K * cap * 32 + K * cap * 4 + K * 4)
 
 
+def multi_gpu_identity(rank, world, local, dev, dist, backend, comm_size=None, single_device=False):
+    """who ran where (the first run on real multi-GPU hardware must verify itself): per rank the device ordinal, its PCI
+    bus id, name, host and pid, gathered on rank 0, plus the communicator sizes both layers report and the RCCL version"""
+    import socket
+
+    import torch
+    pr = torch.cuda.get_device_properties(dev)
+    bus = None
+    try:
+        bus = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+    except Exception:
+        pass
+    me = {"rank": rank, "local_rank": local, "device_ordinal": dev.index, "pci_bus_id": bus, "device_name": pr.name,
+          "hbm_GiB": round(pr.total_memory / 2 ** 30, 1), "host": socket.gethostname(), "pid": os.getpid()}
+    ranks = [me]
+    if world > 1:
+        g = [None] * world
+        dist.all_gather_object(g, me)
+        ranks = g
+    ver = None
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        pass
+    devs = {(r["host"], r["pci_bus_id"] if r["pci_bus_id"] else r["device_ordinal"]) for r in ranks}
+    return {"world_size": world, "backend": backend if world > 1 else None,
+            "rccl_ranks_seen": {"torch_distributed": (dist.get_world_size() if world > 1 else 1), "afv_comm": comm_size},
+            "rccl_version": ver, "ranks": ranks, "distinct_devices": len(devs), "single_device_rehearsal": bool(single_device),
+            "one_rank_per_device": len(devs) == world}
+
+
 def pairs_main(args):
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -309,6 +340,18 @@ def pairs_main(args):
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+    out = pairs_run(args, rank, world, local, dev, dist, args.steps, args.warmup, not args.no_profile, args.cpu_frames > 0)
+    if rank == 0:
+        emit(out)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def pairs_run(args, rank, world, local, dev, dist, steps, warmup, profile, want_cpu):
+    """config #4 on the ranks of an initialised process group (world 1: none): table built on rank 0, ONE broadcast, 10 000 jobs in all
+    (strong scaling), block-partitioned.  Returns the result dict on rank 0, None elsewhere."""
+    import torch
     red_dev = dev if args.backend == "nccl" else torch.device("cpu")
     afv = importlib.import_module("anyfeature-vslam_amd")
     tbl_mod = importlib.import_module("anyfeature-vslam_amd.table")
@@ -420,13 +463,20 @@ def pairs_main(args):
         gather_ms = (time.perf_counter() - t1) * 1e3
         return float(t.item()), stages, allnm, gather_ms, (a, b), match
 
-    dt, stages, allnm, gather_ms, (ja, jb), match = run("uniform", args.steps, args.warmup, not args.no_profile)
-    dt_c, _, allnm_c, _, _, _ = run("covisible", max(args.steps // 2, 1), 1, False)
+    dt, stages, allnm, gather_ms, (ja, jb), match = run("uniform", steps, warmup, profile)
+    dt_c, _, allnm_c, _, _, _ = run("covisible", max(steps // 2, 1), 1, False)
 
+    comm_size = None
+    if comm is not None:
+        try:
+            comm_size = int(ctx.lib.afv_comm_size(comm.handle))
+        except Exception:
+            comm_size = None
+    out = None
     if rank == 0:
-        jobs_s = njobs * args.steps / dt
+        jobs_s = njobs * steps / dt
         out = {"metric": "keyframe-pair Hamming match jobs /sec (ORB32, 1000x1000 brute-force SearchByBoW(KF,KF))", "value": jobs_s, "unit": "jobs/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+               "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
                "config": {"workload": "BASELINE.json configs[3]: %d (a, b) keyframe-pair jobs drawn by LCG over a table of K = %d keyframes x %d x 32 B "
                                       "(keyframe k+1 = keyframe k with 10 %% bit flips and 30 %% rows replaced); brute-force SearchByBoW(KF,KF), TH_LOW 75, "
@@ -437,7 +487,7 @@ def pairs_main(args):
                           "matches_per_job": float(allnm.mean()), "jobs_with_matches": int((allnm > 0).sum())},
                "descriptor_pairs_per_s": jobs_s * cap * cap,
                "broadcast": bc, "gather_ms": gather_ms,
-               "covisible": {"jobs_per_s": njobs * max(args.steps // 2, 1) / dt_c, "matches_per_job": float(allnm_c.mean()),
+               "covisible": {"jobs_per_s": njobs * max(steps // 2, 1) / dt_c, "matches_per_job": float(allnm_c.mean()),
                              "note": "same table and job count, but b = a + 1..3 (loop candidates that really overlap): loads k_match_resolve"}}
         if stages and stages["match_topk"]["launches"]:
             tk, rs = stages["match_topk"], stages["match_resolve"]
@@ -470,17 +520,20 @@ def pairs_main(args):
                                      "descriptor_pairs_per_s_in_kernel": pairs_s,
                                      "note": "the remaining issue slots of the kernel go to the key and the branch-free top-4 insertion (1 + 4 VALU per pair: v_min + 3 v_med3)"}
             out["match_engine"] = "mfma_i8" if engine == 1 else "popcount"
-            out["stage_ms_per_step"] = {"match_topk": tk["total_ms"] / args.steps, "match_resolve": rs["total_ms"] / args.steps}
-        if args.cpu_frames > 0 and world == 1 and host is not None:
+            out["stage_event_ms_per_step_summed_over_concurrent_streams"] = {"match_topk": tk["total_ms"] / steps, "match_resolve": rs["total_ms"] / steps}
+        if want_cpu and world == 1 and host is not None:
             out["cpu_baseline"] = pairs_cpu_baseline(host[0], host[1], host[2], ja, jb)
-        elif args.cpu_frames > 0:
+        elif want_cpu:
             out["cpu_baseline"] = None
-        emit(out)
+    ident = multi_gpu_identity(rank, world, local, dev, dist, args.backend, comm_size, args.single_device)
     if comm is not None:
         comm.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    table.close()
+    ctx.close()
+    if rank == 0:
+        out["multi_gpu"] = ident
+        return out
+    return None
 
 
 def valu_calibration():
@@ -972,6 +1025,7 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -1060,6 +1114,15 @@ def main():
         dist.all_gather_object(gathered, per_rank[0])
         per_rank = gathered
 
+    # collective, every rank: who ran where, and config #4 as the STRONG-scaling companion of this weak-scaling line (10 000 jobs in all,
+    # table broadcast from rank 0 through the C-ABI communicator) - at N = 1 the same code path gives the single-GPU figure
+    ident = multi_gpu_identity(rank, world, local, dev, dist, args.backend, None, args.single_device)
+    strong = None
+    if not args.no_extras:
+        try:
+            strong = pairs_run(args, rank, world, local, dev, dist, 5, 2, False, False)
+        except Exception as e:
+            strong = {"error": repr(e)[:300]}
     if rank == 0:
         out = {
             "metric": METRIC, "value": total_kp / dt, "unit": "keypoints/s", "n_gpus": world, "steps": args.steps,
@@ -1073,7 +1136,15 @@ def main():
             "keypoints_per_ms": total_kp / dt / 1e3,
             "frames_per_s": B * world * args.steps / dt,
             "csrc_sha": _csrc_sha(),
+            "multi_gpu": ident,
         }
+        if strong:
+            out["pairs10k_strong"] = strong if "error" in strong else {
+                "metric": strong["metric"], "value": strong["value"], "unit": strong["unit"], "n_gpus": strong["n_gpus"], "scaling": "strong",
+                "ms_per_step": strong["ms_per_step"], "jobs_per_step": strong["config"]["jobs_per_step"], "job_ranges": strong["config"]["job_ranges"],
+                "matches_per_job": strong["config"]["matches_per_job"], "broadcast": strong["broadcast"], "covisible": strong["covisible"],
+                "rccl_ranks_seen": strong["multi_gpu"]["rccl_ranks_seen"],
+                "note": "BASELINE.json configs[3] on the same ranks: total work fixed, table replicated with one broadcast from rank 0"}
         if stages:
             px = level_pixels(W, H)
             fh = stages["fast_nms"]

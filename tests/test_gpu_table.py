@@ -511,6 +511,12 @@ def test_bench_two_ranks_on_one_device_through_the_self_launch(workload):
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["steps"] == 2
+    # the self-verification block of a multi-rank run: both layers saw two ranks, every rank names its device (here the same one)
+    mg = d["multi_gpu"]
+    assert mg["world_size"] == 2 and mg["backend"] == "gloo" and mg["rccl_ranks_seen"]["torch_distributed"] == 2
+    assert [r["rank"] for r in mg["ranks"]] == [0, 1] and all(r["device_ordinal"] == 0 and r["device_name"] for r in mg["ranks"])
+    assert mg["single_device_rehearsal"] is True and mg["distinct_devices"] == 1 and mg["one_rank_per_device"] is False
+    assert "rccl_version" in mg and len({r["pid"] for r in mg["ranks"]}) == 2
     if workload == "orb32":
         pr = d["config"]["per_rank"]
         assert [p["rank"] for p in pr] == [0, 1] and [p["first_seed"] for p in pr] == [1, 17] and all(p["frames"] == 16 for p in pr)

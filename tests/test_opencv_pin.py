@@ -9,7 +9,9 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FILES = sorted(f for f in glob.glob(os.path.join(ROOT, "tests", "golden", "opencv_*.npz")) if "akaze" not in os.path.basename(f))
+FILES = sorted(f for f in glob.glob(os.path.join(ROOT, "tests", "golden", "opencv_*.npz"))
+               if "akaze" not in os.path.basename(f) and "pyramids" not in os.path.basename(f))
+PYR_FILES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "opencv_pyramids_*.npz")))
 NEED = "no tests/golden/opencv_*.npz: run tools/pin_against_opencv.py where OpenCV is installed (parity unpinned until then)"
 
 
@@ -192,6 +194,53 @@ def test_hip_against_real_opencv(afv, oracle, path):
     _report(stages)
 
 
+def _pyramid_mismatches(d, build_level):
+    """levels of every dumped pyramid that differ from build_level(k, scale, nlevels, l, previous level)"""
+    bad = []
+    k = 0
+    while "pyr%d_scale" % k in d:
+        scale, nl = float(d["pyr%d_scale" % k]), int(d["pyr%d_nlevels" % k])
+        for l in range(1, nl):
+            if not np.array_equal(build_level(k, scale, nl, l), d["pyr%d_level_%d" % (k, l)]):
+                bad.append((scale, l))
+        k += 1
+    assert k > 0
+    return bad
+
+
+@pytest.mark.parametrize("path", PYR_FILES or [None])
+def test_oracle_pyramids_at_other_scale_factors_against_real_opencv(oracle, path):
+    """E2 at scaleFactor 1.1892 / 1.5 / 2.0 / 1.3 (round 4 made the parity tests depend on the restated INTER_LINEAR_EXACT coefficient rule
+    at these ratios): the oracle's resize, level by level from OpenCV's own previous level"""
+    if path is None:
+        pytest.skip(NEED)
+    d = np.load(path)
+    bad = _pyramid_mismatches(d, lambda k, scale, nl, l: oracle.resize_linear_exact(
+        np.ascontiguousarray(d["pyr%d_level_%d" % (k, l - 1)]), d["pyr%d_level_%d" % (k, l)].shape[1], d["pyr%d_level_%d" % (k, l)].shape[0]))
+    assert not bad, "oracle resize differs from OpenCV at (scale factor, level): %s" % bad
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", PYR_FILES or [None])
+def test_hip_pyramids_at_other_scale_factors_against_real_opencv(afv, path):
+    if path is None:
+        pytest.skip(NEED)
+    d = np.load(path)
+    gray = np.ascontiguousarray(d["gray"])
+    h, w = gray.shape
+    cache = {}
+
+    def level(k, scale, nl, l):
+        if k not in cache:
+            ctx = afv.Context(nlevels=nl, scale_factor=scale, max_width=w, max_height=h)
+            ctx.extract(gray)
+            cache[k] = [ctx.debug_level(0, q) for q in range(nl)]
+            ctx.close()
+        return cache[k][l]
+    bad = _pyramid_mismatches(d, level)
+    assert not bad, "HIP pyramid differs from OpenCV at (scale factor, level): %s" % bad
+
+
 def test_pinning_script_is_self_contained():
     """the generator must run on a machine that has only cv2 + numpy: it may import nothing from this repository"""
     text = open(os.path.join(ROOT, "tools", "pin_against_opencv.py")).read()
@@ -227,6 +276,7 @@ def test_pinning_script_drives_cv2_like_the_reference(oracle, tmp_path, monkeypa
         gray = pin.corners_frame(1)
         pin.pin_orb(fake, "selftest", gray)
         pin.pin_akaze(fake, "selftest", pin.corners_frame(1, 320, 240))
+        pin.pin_pyramids(fake, "selftest", pin.corners_frame(2, 320, 240))
     finally:
         sys.path.remove(os.path.join(ROOT, "tests", "fake_cv2"))
         sys.modules.pop("cv2", None)
@@ -238,7 +288,8 @@ def test_pinning_script_drives_cv2_like_the_reference(oracle, tmp_path, monkeypa
     computes = log[6:]
     assert all(e[0] == "ORB.compute" for e in computes) and [e[2] for e in computes] == [[l] for l in range(8)]       # one call per level (:42-53)
     assert ("FastFeatureDetector_create", 20, True, fake.FastFeatureDetector_TYPE_9_16) in fake.LOG
-    assert sum(e[0] == "resize" for e in fake.LOG) == 7 and all(e[2] == fake.INTER_LINEAR_EXACT for e in fake.LOG if e[0] == "resize")
+    npyr = sum(n - 1 for _, n in pin.PYRAMIDS)
+    assert sum(e[0] == "resize" for e in fake.LOG) == 7 + npyr and all(e[2] == fake.INTER_LINEAR_EXACT for e in fake.LOG if e[0] == "resize")
     assert ("AKAZE_create", fake.AKAZE_DESCRIPTOR_MLDB, 0, 3, 0.0005, 2, 4, fake.KAZE_DIFF_PM_G2) in fake.LOG   # Feature_akaze61.cpp:24-61
     path = os.path.join(str(tmp_path), "opencv_selftest.npz")
     d = np.load(path)
@@ -246,3 +297,7 @@ def test_pinning_script_drives_cv2_like_the_reference(oracle, tmp_path, monkeypa
     assert need <= set(d.files), sorted(need - set(d.files))
     assert d["detect"].dtype == pin.KP_DTYPE and d["compute_desc_0"].dtype == np.uint8 and d["compute_desc_0"].shape[1] == 32
     test_oracle_against_real_opencv(oracle, path)      # the consumer accepts the producer's file (every stage "ok": the fake IS the oracle)
+    ppath = os.path.join(str(tmp_path), "opencv_pyramids_selftest.npz")
+    pd = np.load(ppath)
+    assert float(pd["pyr0_scale"]) == np.float32(1.1892) and int(pd["pyr2_nlevels"]) == 4 and pd["pyr2_level_1"].shape == (120, 160)
+    test_oracle_pyramids_at_other_scale_factors_against_real_opencv(oracle, ppath)

@@ -5,7 +5,8 @@ algorithm (E2 pyramid, E3 FAST + NMS, E4/E5 retainBest + Harris, E6 IC angle, E9
 Needs only `cv2` (>= 4.5) and numpy — neither the GPU nor this package's library.  It can NOT run in the build image or on the
 GPU box (no OpenCV there); run it on any machine that has OpenCV, from the repository root:
 
-    python tools/pin_against_opencv.py            # writes tests/golden/opencv_<frame>.npz  (+ opencv_akaze_<frame>.npz)
+    python tools/pin_against_opencv.py            # writes tests/golden/opencv_<frame>.npz  (+ opencv_pyramids_<frame>.npz: the pyramid at
+                                                  #   scale factors 1.1892 / 1.5 / 2.0 / 1.3, + opencv_akaze_<frame>.npz)
 
 and commit the files.  tests/test_opencv_pin.py then activates: the CPU test compares oracle/ with them stage by stage and
 names the FIRST stage that diverges; the `-m gpu` test does the same for the HIP path.  Until somebody runs this, parity of
@@ -121,6 +122,36 @@ def pin_orb(cv2, name, gray):
     print("opencv_%s.npz: %d keypoints from detect, levels %s" % (name, len(kps), [im.shape for im in levels]))
 
 
+# scale factors / level counts the parity tests started to rely on in round 4 (settings/*.yaml:6-7: 1.2 x 8 for ORB32, 1.1892 x 8 for the
+# AKAZE61 quotas; 1.5 / 2.0 / 1.3 exercise the other branches of the INTER_LINEAR_EXACT coefficient rule: exact halves, long tap distances)
+PYRAMIDS = ((1.1892, 8), (1.5, 5), (2.0, 4), (1.3, 6))
+
+
+def level_sizes_for(w, h, scale, nlevels):
+    out = []
+    for l in range(nlevels):
+        s = np.float32(np.power(np.float64(np.float32(scale)), l))
+        inv = np.float32(1.0) / s
+        out.append((int(np.rint(np.float32(w) * inv)), int(np.rint(np.float32(h) * inv))))
+    return out
+
+
+def pin_pyramids(cv2, name, gray):
+    """E2 at other scale factors: the pyramid cv::ORB would build (level l = INTER_LINEAR_EXACT resize of level l - 1)"""
+    d = {"gray": gray, "cv_version": np.array(cv2.__version__)}
+    h, w = gray.shape
+    for k, (scale, nlevels) in enumerate(PYRAMIDS):
+        d["pyr%d_scale" % k] = np.float32(scale)
+        d["pyr%d_nlevels" % k] = np.int32(nlevels)
+        im = gray
+        for l, (lw, lh) in enumerate(level_sizes_for(w, h, scale, nlevels)):
+            if l:
+                im = cv2.resize(im, (lw, lh), interpolation=cv2.INTER_LINEAR_EXACT)
+            d["pyr%d_level_%d" % (k, l)] = im
+    np.savez_compressed(os.path.join(OUT, "opencv_pyramids_%s.npz" % name), **d)
+    print("opencv_pyramids_%s.npz: %s" % (name, [(s, n) for s, n in PYRAMIDS]))
+
+
 def pin_akaze(cv2, name, gray):
     """cv::AKAZE is OpenCV's port of libAKAZE, not the fork the reference links: a softer check (counts, overlap of positions)."""
     ak = cv2.AKAZE_create(descriptor_type=cv2.AKAZE_DESCRIPTOR_MLDB, descriptor_size=0, descriptor_channels=3, threshold=0.0005,
@@ -139,6 +170,8 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     for name, gray in frames().items():
         pin_orb(cv2, name, np.ascontiguousarray(gray))
+    pin_pyramids(cv2, "corners1", corners_frame(1))
+    pin_pyramids(cv2, "noise3", noise_frame(3))
     pin_akaze(cv2, "corners1_720p", corners_frame(1, 1280, 720))
 
 
