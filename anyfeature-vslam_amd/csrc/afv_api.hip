@@ -1010,6 +1010,13 @@ static int extract_one(afv_ctx *c, const uint8_t *gray, int width, int height, i
     } else {
         enqueue_range(c, src, 0, 1, c->d_kps, c->d_desc, c->stage_cap, c->d_n, c->d_status, s, true, frame ? &mir : nullptr);
     }
+    // a resident frame: the host vectors are complete when the describe kernel is (it writes them straight into the pinned arena);
+    // k_frame_grid, which only feeds later device-side consumers on the same stream, runs on while the call returns
+    bool wait_event = false;
+    if (frame && zero_copy_out) {
+        wait_event = hipEventRecord(c->ev_fork, s) == hipSuccess;
+        if (!wait_event) (void)hipGetLastError();
+    }
     if (frame) afv_frame_after_extract(frame, s);
     HIPCHK(c, hipGetLastError());
     if (trace) ts[3] = now();
@@ -1022,7 +1029,8 @@ static int extract_one(afv_ctx *c, const uint8_t *gray, int width, int height, i
     c->last_src = src;
     c->last_nframes = 1;
     if (trace) ts[4] = now();
-    HIPCHK(c, hipStreamSynchronize(s));
+    if (wait_event) HIPCHK(c, hipEventSynchronize(c->ev_fork));
+    else HIPCHK(c, hipStreamSynchronize(s));
     if (trace) ts[5] = now();
     quiesce.armed = false;
     int n = *reinterpret_cast<const int *>(hres), result = AFV_OK;
