@@ -8,7 +8,9 @@
 
 // FAST / Harris tile: 64 x 32 output pixels per 256-thread workgroup, 4 px halo
 #define FT_W 64
-#define FT_H 32
+#ifndef FT_H
+#define FT_H 32   // (round-5 experiment: -DFT_H=64, see DESIGN "measured and dropped")
+#endif
 #define FT_HALO 4
 #define FT_LW (FT_W + 2 * FT_HALO)  // 72
 #define FT_LH (FT_H + 2 * FT_HALO)  // 40

@@ -67,6 +67,10 @@ static_assert(FT_PITCH >= FT_LW && FT_PITCH % 4 == 0, "tile pitch");
 #define PRE_GROUPS (256 / PRE_PAIRS)      // 7 row groups of 34 threads
 #define PRE_ITERS ((PRE_ROWS + PRE_GROUPS - 1) / PRE_GROUPS)  // rows rg, rg + 7, ... : 5 iterations
 #define PRE_MAX (2 * PRE_ROWS * 2 * PRE_PAIRS)  // one entry per (pixel, polarity)
+#define PRE_PAD_ROWS (PRE_GROUPS * PRE_ITERS - PRE_ROWS)  // rows past the tile the masked iterations of the last row group touch (1 at FT_H = 32)
+#define ST_GROUPS 14                                       // staging: 18 dword columns x 14 row groups = 252 threads
+#define ST_ITERS ((FT_LH + ST_GROUPS - 1) / ST_GROUPS)     // rows rs, rs + 14, ... (3 at FT_H = 32)
+static_assert(PRE_ITERS <= 16, "pre-test flags live in 16-bit halves");
 
 // two horizontally adjacent tile bytes as a packed u16 pair: one 16-bit LDS read (any alignment) + one byte permute
 __device__ __forceinline__ short2v ld_pair(const uint8_t *c, int off) {
@@ -118,7 +122,8 @@ __device__ __forceinline__ short2v fast_score2(const uint8_t *c0, const uint8_t 
 __global__ __launch_bounds__(256) void k_fast_nms(const Geo *__restrict__ geo_p, FrameSrc src0, const uint8_t *__restrict__ pyr,
                                                   uint32_t *__restrict__ cand_packed, int *__restrict__ cand_count, int total_blocks,
                                                   int frame_base) {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[(FT_LH + 1) * FT_PITCH + 16];  // + pad: masked pre-test positions (row 34, column 69) read up to one row + 2 bytes past row 39
+    // + pad: masked pre-test positions (the rows the last row group computes beyond PRE_ROWS, column 69) read up to PRE_PAD_ROWS rows + 2 bytes past the last row
+    __shared__ __attribute__((aligned(16))) uint8_t tile[(FT_LH + PRE_PAD_ROWS) * FT_PITCH + 16];
     __shared__ __attribute__((aligned(16))) uint8_t sc[FT_LH * FT_PITCH];  // same geometry as `tile`
     __shared__ __attribute__((aligned(4))) unsigned short pre[PRE_MAX];  // bright entries from the front, dark entries from the back
     __shared__ int list_n, out_base, pre_nb, pre_nd;
@@ -165,32 +170,32 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Geo *__restrict__ geo_p,
         const int rq = tid - rs * (FT_LW / 4);
         const int gx = gx0 + rq * 4;
         const bool interior = gx >= 0 && gx + 3 < lw;
-        if (rs < 14) {
-            // the three row offsets first, then the three loads back to back (one global round trip), then the LDS writes;
-            // row 28 + rs only exists for rs < 12: its load is redirected to row 39 and its write dropped
-            uint32_t roff[3], v[3];
+        if (rs < ST_GROUPS) {
+            // the row offsets first, then the loads back to back (one global round trip), then the LDS writes;
+            // the last row of a thread may not exist (FT_H = 32: row 28 + rs only for rs < 12): its load is redirected to the last row and its write dropped
+            uint32_t roff[ST_ITERS], v[ST_ITERS];
 #pragma unroll
-            for (int k3 = 0; k3 < 3; ++k3) {
-                const int ry = min(rs + 14 * k3, FT_LH - 1);
+            for (int k3 = 0; k3 < ST_ITERS; ++k3) {
+                const int ry = min(rs + ST_GROUPS * k3, FT_LH - 1);
                 const int gy = min(max(afv_reflect101(gy0 + ry, lh), 0), lh - 1);
                 roff[k3] = (uint32_t)gy * (uint32_t)pitch;
             }
             if (interior) {
 #pragma unroll
-                for (int k3 = 0; k3 < 3; ++k3) v[k3] = *reinterpret_cast<const uint32_t *>(img + (roff[k3] + (uint32_t)gx));
+                for (int k3 = 0; k3 < ST_ITERS; ++k3) v[k3] = *reinterpret_cast<const uint32_t *>(img + (roff[k3] + (uint32_t)gx));
             } else {  // left / right image edge: four reflected byte gathers per row
                 uint32_t xs[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) xs[k] = (uint32_t)min(max(afv_reflect101(gx + k, lw), 0), lw - 1);
 #pragma unroll
-                for (int k3 = 0; k3 < 3; ++k3) {
+                for (int k3 = 0; k3 < ST_ITERS; ++k3) {
                     const uint8_t *row = img + roff[k3];
                     v[k3] = (uint32_t)row[xs[0]] | ((uint32_t)row[xs[1]] << 8) | ((uint32_t)row[xs[2]] << 16) | ((uint32_t)row[xs[3]] << 24);
                 }
             }
 #pragma unroll
-            for (int k3 = 0; k3 < 3; ++k3) {
-                const int ry = rs + 14 * k3;
+            for (int k3 = 0; k3 < ST_ITERS; ++k3) {
+                const int ry = rs + ST_GROUPS * k3;
                 if (ry < FT_LH) {
                     *reinterpret_cast<uint32_t *>(&tile[ry * FT_PITCH + rq * 4]) = v[k3];
                     *reinterpret_cast<uint32_t *>(&sc[ry * FT_PITCH + rq * 4]) = 0u;

@@ -64,6 +64,33 @@ def test_invalid_arguments_do_not_crash(afv):
     assert lib.afv_orb_extract(None, None, 0, 0, 0, None, None, 0, None) == afv._lib.EINVAL
     assert lib.afv_match_bow(None, None, 0, None, None) == afv._lib.EINVAL
     assert lib.afv_profile_enable(None, 1) == afv._lib.EINVAL
+    # the device-resident Frame and its consumers (round 5)
+    fh = C.c_void_p()
+    assert lib.afv_frame_create(None, None, C.byref(fh)) == afv._lib.EINVAL
+    lib.afv_frame_destroy(None)  # no-op
+    assert lib.afv_frame_extract(None, None, 0, 0, 0, None, None, 0, None) == afv._lib.EINVAL
+    assert lib.afv_frame_set_features(None, None, None, 0, None, None) == afv._lib.EINVAL
+    assert lib.afv_frame_set_undistorted(None, None, None) == afv._lib.EINVAL
+    assert lib.afv_frame_count(None) == afv._lib.EINVAL
+    assert lib.afv_frame_get_grid(None, None, None) == afv._lib.EINVAL
+    assert lib.afv_frame_bow_transform(None, None, 4, None, None, None) == afv._lib.EINVAL
+    assert lib.afv_frame_get_featvec(None, None, None, None) == afv._lib.EINVAL
+    assert lib.afv_frame_match_projection(None, None, None, None) == afv._lib.EINVAL
+    assert lib.afv_frame_match_fuse(None, None, 1, None, None) == afv._lib.EINVAL
+    assert lib.afv_frame_match_initialization(None, None, None, None, 100.0, 75.0, 0.9, 1, None, None) == afv._lib.EINVAL
+    assert lib.afv_table_set_from_frame(None, 0, None) == afv._lib.EINVAL
+    assert lib.afv_table_match_bow_frame_h(None, None, 0, None, 75.0, 0.7, 1, None, None) == afv._lib.EINVAL
+    assert lib.afv_set_projection_resolve(None, 1) == afv._lib.EINVAL
+    assert lib.afv_vocab_set_stopped(None, None, None) == afv._lib.EINVAL
+
+
+def test_versioned_job_records_carry_their_size(afv):
+    """afv_tri_job / afv_proj_job / afv_table_tri_job grew in place; now their first field is struct_size - the runtime
+    strides by it, reads only what it covers, and rejects records that do not carry a plausible one.  The mirrors fill it (sized())."""
+    L = afv._lib
+    for st in (L.TriJob, L.ProjJob, L.TableTriJob, L.FrameParams, L.ProjQueries):
+        assert st._fields_[0][0] == "struct_size" and L.sized(st).struct_size == C.sizeof(st)
+    assert C.sizeof(L.ProjJob) % 8 == 0 and L.ProjJob.u_right.offset > L.ProjJob.mode.offset   # the stereo tail stays at the end
 
 
 def test_akaze_abi_without_gpu(afv):

@@ -275,3 +275,26 @@ def test_initialization_stealing_hand_case(afv, oracle, gpu_ctx):
     want, wn = oracle.match_initialization(F2, Q1, th_low=75.0, nnratio=0.9, check_orientation=False)
     assert want.tolist() == [-1, -1, 0, 1] and wn == 2
     assert got.tolist() == want.tolist() and n == wn
+
+
+def test_job_records_of_an_older_layout_and_without_a_size(afv, oracle, gpu_ctx):
+    """a caller compiled against the layout BEFORE the stereo fields (struct_size = offsetof(u_right)) is served as the monocular call;
+    a record whose struct_size is 0 / garbage is AFV_EINVAL instead of having its tail dereferenced"""
+    import ctypes as C
+    F, Q = _scene(afv, gpu_ctx, 3, 4, 15.0)
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+    m = afv.FeatureMatcher(0.8, False, ctx=gpu_ctx)
+    j = m._proj_job(F, Q)
+    j.th_high = 75.0; j.mode = 0
+    # poison the tail, then declare the old size: the runtime must not look at it
+    j.u_right = 0xdeadbeef; j.q_ur = 0xdeadbeef; j.q_er_max = 0xdeadbeef
+    j.struct_size = afv._lib.ProjJob.u_right.offset
+    out = np.full(F.N, -1, np.int32); nm = np.zeros(1, np.int32)
+    jobs = (afv._lib.ProjJob * 1)(j)
+    assert gpu_ctx.lib.afv_match_projection(gpu_ctx.handle, jobs, 1, out.ctypes.data, nm.ctypes.data) == 0
+    want, wn = oracle.match_projection(F, Q, th_high=75.0, nnratio=0.8)
+    assert nm[0] == wn and np.array_equal(out, want)
+    for bad in (0, 12, 7, 1 << 20):
+        j.struct_size = bad
+        jobs = (afv._lib.ProjJob * 1)(j)
+        assert gpu_ctx.lib.afv_match_projection(gpu_ctx.handle, jobs, 1, out.ctypes.data, nm.ctypes.data) == afv._lib.EINVAL
