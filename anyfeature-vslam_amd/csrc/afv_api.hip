@@ -428,7 +428,7 @@ extern "C" void afv_destroy(afv_ctx *c) {
     afv_frame_release_all(c);
     void *ptrs[] = {c->d_geo, c->d_tab, c->d_pyr, c->d_cand_packed, c->d_kept_xy, c->d_l1, c->d_l1_resp, c->d_l1_count, c->d_hq, c->d_hq_n, c->d_kept_resp,
                     c->d_kept_node, c->d_cand_count, c->d_sel_count, c->d_sel, c->d_frames, c->d_out_block,
-                    c->d_status, c->d_match, c->d_topk, c->d_slice, c->d_tickets, c->d_pf_blob, c->d_l2_scratch};
+                    c->d_status, c->d_match, c->d_topk, c->d_slice, c->d_tickets, c->d_pf_blob, c->d_l2_scratch, c->d_proj_ticket};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_stage) {
@@ -528,6 +528,11 @@ extern "C" int afv_create(int device, const afv_orb_params *params, afv_ctx **ou
     }
 #undef CREATE_CHK
     // kernels that ask for more dynamic LDS than the default: raised once per context, on its device, checked
+    if (hipMalloc(reinterpret_cast<void **>(&c->d_proj_ticket), 256) != hipSuccess || hipMemset(c->d_proj_ticket, 0, 256) != hipSuccess) {
+        (void)hipGetLastError();
+        if (c->d_proj_ticket) (void)hipFree(c->d_proj_ticket);
+        c->d_proj_ticket = nullptr;  // the searches then take two launches
+    }
     c->proj_wg_lds_max = afv_project_prepare();
     (void)afv_match_prepare();
     c->select_wide_ok = afv_select_prepare(c->select_M) != 0;
@@ -1855,10 +1860,21 @@ int afv_match_projection_core(afv_ctx *c, const afv_proj_job *jobs, int njobs, i
     }
     const DevProjJob *dj = reinterpret_cast<const DevProjJob *>(B + jobs_off);
     const DevProjJob *one = zero_copy_in ? reinterpret_cast<const DevProjJob *>(H + jobs_off) : nullptr;
+    // one launch for ranking + ordered phase: the projection searches (a few candidates per query).  SearchForInitialization keeps two: its
+    // ranking walks 100-pixel windows (hundreds of cells per query) and is better off on 250 four-wave workgroups than on 63 sixteen-wave
+    // ones (measured: 59.6 us against 72.5 host to host)
+    int *ticket = (one && wg_lds && c->proj_fuse && kind == AFV_KIND_PROJ) ? c->d_proj_ticket : nullptr;
     if (fuse) afv_launch_match_fuse(dj, njobs, max_nq, one, c->stream);
-    else if (kind == AFV_KIND_INIT) afv_launch_match_init(dj, njobs, max_nq, wg_lds, one, c->stream);
-    else afv_launch_match_projection(dj, njobs, max_nq, wg_lds, one, c->stream);
-    HIPCHK(c, hipGetLastError());
+    else if (kind == AFV_KIND_INIT) afv_launch_match_init(dj, njobs, max_nq, wg_lds, one, ticket, c->stream);
+    else afv_launch_match_projection(dj, njobs, max_nq, wg_lds, one, ticket, c->stream);
+    {
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            if (ticket) (void)hipMemsetAsync(ticket, 0, sizeof(int), c->stream);  // a launch that did not go out must not leave the ticket armed
+            c->last_error = std::string("projection search launch: ") + hipGetErrorString(e);
+            return AFV_EHIP;
+        }
+    }
     if (!zero_copy) {
         HIPCHK(c, b.fetch(assign, out_off, total_out * 4, c->stream));
         if (!fuse) HIPCHK(c, b.fetch(nmatches, nm_off, (size_t)njobs * 4, c->stream));
@@ -1933,8 +1949,9 @@ extern "C" int afv_match_sim3(afv_ctx *c, const afv_proj_job *j12, const afv_pro
     return guarded(c, [&] { return afv_match_sim3_impl(c, j12, j21, match12, nfound); });
 }
 extern "C" int afv_set_projection_resolve(afv_ctx *c, int engine) {
-    if (!c || engine < 0 || engine > 2) return AFV_EINVAL;
-    c->proj_engine = engine;
+    if (!c || engine < 0 || engine > 3) return AFV_EINVAL;
+    c->proj_fuse = engine != 3;          // 3 = the fixed point as two launches (ranking, then ordered phase): the A / B of the one-launch form
+    c->proj_engine = engine == 3 ? 1 : engine;
     return AFV_OK;
 }
 

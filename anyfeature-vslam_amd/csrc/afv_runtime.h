@@ -62,7 +62,8 @@ extern "C" void afv_launch_match_tri(const DevTriJob *jobs, int njobs, int max_n
 extern "C" void afv_launch_match_l2(const float *d1, int n1, const float *d2, int n2, int dim, const uint8_t *v1,
                                     const uint8_t *v2, float th, float ratio, int *out, int *nmatches, hipStream_t stream);
 
-extern "C" void afv_launch_match_projection(const DevProjJob *jobs, int njobs, int max_nq, size_t wg_lds, const DevProjJob *one, hipStream_t stream);
+extern "C" void afv_launch_match_projection(const DevProjJob *jobs, int njobs, int max_nq, size_t wg_lds, const DevProjJob *one, int *ticket,
+                                            hipStream_t stream);
 extern "C" int afv_project_prepare(void);
 extern "C" int afv_match_prepare(void);
 extern "C" int afv_select_prepare(int M);
@@ -83,7 +84,8 @@ extern "C" int afv_launch_match_l2_tiled(const float *d1, int n1, const float *d
                                          hipStream_t stream);
 extern "C" int afv_launch_match_l2_pairs(const float *desc, const int *nset, int cap, int dim, const int *pa, const int *pb, int npairs,
                                          int pair_base, float th, float ratio, int *out, int *nmatches, void *scratch, hipStream_t stream);
-extern "C" void afv_launch_match_init(const DevProjJob *jobs, int njobs, int max_nq, size_t wg_lds, const DevProjJob *one, hipStream_t stream);
+extern "C" void afv_launch_match_init(const DevProjJob *jobs, int njobs, int max_nq, size_t wg_lds, const DevProjJob *one, int *ticket,
+                                      hipStream_t stream);
 
 extern "C" void afv_launch_bow_transform(const DevVocab *v, const uint32_t *desc, int n, int levelsup, int *leaf_node,
                                          int *node_at_level, int *rank_at_level, hipStream_t stream);
@@ -133,6 +135,8 @@ struct afv_ctx {
     int resolve_wg_max_pairs = 256; // ... 2: calls of at most this many pairs take the fixed point; afv_set_match_resolve
     int proj_engine = 2;           // ordered phase of the projection searches: 0 = ordered walk, 1 = workgroup fixed point, 2 = 1 when it fits
     int proj_wg_lds_max = 0;       // dynamic LDS bytes the workgroup engines may use (0: unavailable); afv_project_prepare at afv_create
+    int *d_proj_ticket = nullptr;  // hand-off ticket of the one-launch search (k_proj_search1), zero at rest
+    int proj_fuse = 1;             // 1: single-job searches rank and resolve in one launch (afv_set_projection_fuse)
     std::vector<afv_frame *> frames;  // frames alive on this context (destroyed with it)
     int split_chunks = 0;          // ... into this many chunks (alternating streams); 0 = about 85 frames each; afv_set_split_chunks
     // small-batch ("latency") path: kernels shaped for one or a few frames; afv_set_small_batch_path

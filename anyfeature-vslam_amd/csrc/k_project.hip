@@ -1364,6 +1364,49 @@ __global__ __launch_bounds__(IW_T) void k_init_resolve_wg1(const DevProjJob J) {
     else init_resolve_wg<16>(J);
 }
 
+// ---------------- ranking + ordered phase in ONE launch (a single job whose record is the kernel argument) ----------------
+// A search against a resident frame is two dependent launches of a few microseconds each; the second one's dispatch and prologue are as long
+// as its work.  Here the ranking runs on 1024-thread workgroups (16 queries each, a wavefront per query as in k_proj_topk), and the
+// workgroup that finishes LAST (one ticket per launch; cdna_hip_programming.md Guideline 16, the hand-off of k_match_topk_mfma: every
+// wave's stores drained by the barrier -> ONE lane: agent-scope release, ticket; the last arriver: ONE agent-scope acquire -> barrier
+// -> plain loads) goes on as the fixed-point workgroup.  The ticket is zero at rest: the last arriver re-arms it.
+template <int KIND>  // 0 = projection (PK keys, REC 1), 1 = initialization (IK keys, REC 3)
+__global__ __launch_bounds__(PW_T) void k_proj_search1(const DevProjJob J, int *__restrict__ ticket) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int q = (int)blockIdx.x * PW_NW + wv;
+    if (q < J.nq) {  // wave-uniform
+        if (KIND == 0) {
+            if (J.words == 8) topk_query<8, PK, 1>(J, q, lane);
+            else topk_query<16, PK, 1>(J, q, lane);
+        } else {
+            if (J.words == 8) topk_query<8, IK, 3>(J, q, lane);
+            else topk_query<16, IK, 3>(J, q, lane);
+        }
+    }
+    __shared__ int s_last;
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // restated where the compiler cannot drop it (ROCm 7.2)
+        const int old = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == (int)gridDim.x - 1;
+        if (last) {
+            __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (KIND == 0) {
+        if (J.words == 8) proj_resolve_wg<8>(J);
+        else proj_resolve_wg<16>(J);
+    } else {
+        if (J.words == 8) init_resolve_wg<8>(J);
+        else init_resolve_wg<16>(J);
+    }
+}
+
 // the workgroup engines need more LDS than the 64 KB a kernel gets by default: raised once per device (afv_create), checked
 extern "C" int afv_project_prepare(void) {
     const int want = 150 * 1024;
@@ -1371,6 +1414,8 @@ extern "C" int afv_project_prepare(void) {
     ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_init_resolve_wg), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess && ok;
     ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_resolve_wg1), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess && ok;
     ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_init_resolve_wg1), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess && ok;
+    ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_search1<0>), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess && ok;
+    ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_search1<1>), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess && ok;
     if (!ok) (void)hipGetLastError();
     // dynamic bytes a job may ask for (the kernels' static arrays take about 1 KB more); without the raised limit: what every kernel gets
     return ok ? want - 2048 : 62 * 1024;
@@ -1379,8 +1424,13 @@ extern "C" size_t afv_project_wg_lds(int kind_init, int n, int nq) { return kind
 
 // `one` != nullptr: a single job whose record travels as the kernel argument (the fixed-point engines and Fuse); else `jobs` is the
 // device array of njobs records
-extern "C" void afv_launch_match_init(const DevProjJob *jobs, int njobs, int max_nq, size_t wg_lds, const DevProjJob *one, hipStream_t stream) {
+extern "C" void afv_launch_match_init(const DevProjJob *jobs, int njobs, int max_nq, size_t wg_lds, const DevProjJob *one, int *ticket,
+                                      hipStream_t stream) {
     const dim3 tg((max_nq + PT / 64 - 1) / (PT / 64), njobs);
+    if (wg_lds && one && ticket) {  // ranking + ordered phase in one launch
+        hipLaunchKernelGGL(k_proj_search1<1>, dim3(std::max((max_nq + PW_NW - 1) / PW_NW, 1)), dim3(PW_T), wg_lds, stream, *one, ticket);
+        return;
+    }
     if (wg_lds && one) {
         if (max_nq > 0) hipLaunchKernelGGL((k_proj_topk1<IK, 3>), tg, dim3(PT), 0, stream, *one);
         hipLaunchKernelGGL(k_init_resolve_wg1, dim3(1), dim3(IW_T), wg_lds, stream, *one);
@@ -1401,8 +1451,13 @@ extern "C" void afv_launch_match_fuse(const DevProjJob *jobs, int njobs, int max
 }
 
 // wg_lds != 0: the fixed-point engine with that much dynamic LDS (the largest job's tables); 0: the ordered walk
-extern "C" void afv_launch_match_projection(const DevProjJob *jobs, int njobs, int max_nq, size_t wg_lds, const DevProjJob *one, hipStream_t stream) {
+extern "C" void afv_launch_match_projection(const DevProjJob *jobs, int njobs, int max_nq, size_t wg_lds, const DevProjJob *one, int *ticket,
+                                            hipStream_t stream) {
     const dim3 tg((max_nq + PT / 64 - 1) / (PT / 64), njobs);
+    if (wg_lds && one && ticket) {  // ranking + ordered phase in one launch
+        hipLaunchKernelGGL(k_proj_search1<0>, dim3(std::max((max_nq + PW_NW - 1) / PW_NW, 1)), dim3(PW_T), wg_lds, stream, *one, ticket);
+        return;
+    }
     if (wg_lds && one) {
         if (max_nq > 0) hipLaunchKernelGGL((k_proj_topk1<PK, 1>), tg, dim3(PT), 0, stream, *one);
         hipLaunchKernelGGL(k_proj_resolve_wg1, dim3(1), dim3(PW_T), wg_lds, stream, *one);

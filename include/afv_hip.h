@@ -451,7 +451,9 @@ int afv_table_match_bow_frame_h(afv_table *t, const int32_t *slots, int nslots, 
                                 int check_orientation, int32_t *match_f, int32_t *nmatches);
 /* engine of the ordered phase of the projection searches / SearchForInitialization (identical results):
  *   1: one fixed point over all live queries of a job on a 1024-thread workgroup (round 5)   0: the ordered walk of rounds 1-4 on one
- *   wavefront   2 (default): 1 whenever the job's tables fit the workgroup's LDS, else 0 */
+ *   wavefront   2 (default): 1 whenever the job's tables fit the workgroup's LDS, else 0   3: as 1, but ranking and ordered phase as two
+ *   launches even for a single job on a resident frame (by default those run in ONE launch: the last ranking workgroup goes on as the
+ *   fixed-point workgroup) */
 int afv_set_projection_resolve(afv_ctx *ctx, int engine);
 
 /* DescriptorDistance_orb32 on the host (utility for adapters / tests) */

@@ -72,7 +72,7 @@ def test_extract_into_frame_equals_plain_extract_and_builds_the_grid(afv, oracle
     fr.close()
 
 
-@pytest.mark.parametrize("engine", [1, 0], ids=["fixed_point", "ordered_walk"])
+@pytest.mark.parametrize("engine", [1, 3, 0], ids=["fixed_point_one_launch", "fixed_point_two_launches", "ordered_walk"])
 @pytest.mark.parametrize("seed,shift,rs,last", [(1, 4, 15.0, False), (2, 7, 40.0, False), (4, 3, 120.0, False), (5, 5, 15.0, True), (6, 2, 60.0, True)])
 def test_projection_searches_on_the_resident_frame(afv, oracle, fctx, seed, shift, rs, last, engine):
     fctx.check(fctx.lib.afv_set_projection_resolve(fctx.handle, engine))
@@ -114,7 +114,7 @@ def test_projection_dense_cluster_on_a_resident_frame(afv, oracle, fctx):
         Q = afv.ProjectionQueries(qd, np.full(nq, 320.0), np.full(nq, 220.0), np.full(nq, 30.0), np.full(nq, 0.5), np.full(nq, 2.0),
                                   occupies=occupies)
         afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
-        for engine in (1, 0):
+        for engine in (1, 3, 0):
             fctx.check(fctx.lib.afv_set_projection_resolve(fctx.handle, engine))
             for mode, ratio in ((False, 0.8), (False, 2.0), (True, 0.9)):
                 m = afv.FeatureMatcher(ratio, False, ctx=fctx)
@@ -169,7 +169,7 @@ def test_fuse_on_a_resident_frame(afv, oracle, fctx):
     fr.close()
 
 
-@pytest.mark.parametrize("engine", [1, 0], ids=["fixed_point", "ordered_walk"])
+@pytest.mark.parametrize("engine", [1, 3, 0], ids=["fixed_point_one_launch", "fixed_point_two_launches", "ordered_walk"])
 @pytest.mark.parametrize("ori", [False, True])
 @pytest.mark.parametrize("seed,shift,window", [(24, 6, 100.0), (25, 30, 40.0), (26, 0, 12.0)])
 def test_initialization_between_two_resident_frames(afv, oracle, seed, shift, window, ori, engine):
