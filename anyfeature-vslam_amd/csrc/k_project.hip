@@ -121,6 +121,9 @@ __device__ __forceinline__ Window proj_window(const DevProjJob &J, float x, floa
 // The 64 lanes of a wave walk the window of query q: lane l takes the window cells l, l + 64, ... (rank c in the
 // reference's ix-outer / iy-inner order).  VISIT(idx, c, kpos) runs for every feature that passes the geometric filters of
 // GetFeaturesInArea (size band, |dx| < r, |dy| < r); (c, kpos) orders the candidates like the reference's vIndices.
+// Cells are taken PW_CPL at a time per lane: their (begin, end) pairs are loaded first, all in flight together, then their entries are
+// walked - a 100-pixel window (SearchForInitialization: ~400 cells, 6-7 per lane) was a chain of 6-7 x 2 dependent loads per lane.
+#define PW_CPL 4
 #define PROJ_WAVE_WINDOW(J, q, lane, VISIT)                                                           \
     {                                                                                                 \
         const float x_ = J.qu[q], y_ = J.qv[q], r_ = J.qr[q], mn_ = J.qmin[q], mx_ = J.qmax[q];       \
@@ -129,22 +132,113 @@ __device__ __forceinline__ Window proj_window(const DevProjJob &J, float x, floa
         const Window w_ = proj_window(J, x_, y_, r_);                                                 \
         if (w_.ok) {                                                                                  \
             const int ny_ = w_.cy1 - w_.cy0 + 1, ncells_ = (w_.cx1 - w_.cx0 + 1) * ny_;               \
-            for (int c = lane; c < ncells_; c += 64) {                                                \
-                const int cell_ = (w_.cx0 + c / ny_) * J.rows + (w_.cy0 + c % ny_);                   \
-                const int kb_ = J.cell_ptr[cell_], ke_ = J.cell_ptr[cell_ + 1];                       \
-                for (int k_ = kb_; k_ < ke_; ++k_) {                                                  \
-                    const int4 e_ = J.cell_ent[k_];                                                   \
-                    const int idx = e_.x;                                                             \
-                    const float fx_ = __int_as_float(e_.y), fy_ = __int_as_float(e_.z);               \
-                    const float s_ = __int_as_float(e_.w);                                            \
-                    if (s_ < mn_ || s_ > mx_) continue;                                               \
-                    if (!(fabsf(fx_ - x_) < r_ && fabsf(fy_ - y_) < r_)) continue;                    \
-                    if (sg_) {                                                                        \
-                        const float ur_ = J.u_right[idx];                                             \
-                        if (ur_ > 0.0f && fabsf(qur_ - ur_) > qer_) continue;                          \
+            for (int cb_ = 0; cb_ < ncells_; cb_ += 64 * PW_CPL) {                                    \
+                int kb_[PW_CPL], ke_[PW_CPL];                                                         \
+                _Pragma("unroll") for (int u_ = 0; u_ < PW_CPL; ++u_) {                               \
+                    const int cc_ = cb_ + u_ * 64 + lane;                                             \
+                    kb_[u_] = 0;                                                                      \
+                    ke_[u_] = 0;                                                                      \
+                    if (cc_ < ncells_) {                                                              \
+                        const int cxo_ = cc_ / ny_;                                                   \
+                        const int cell_ = (w_.cx0 + cxo_) * J.rows + (w_.cy0 + cc_ - cxo_ * ny_);     \
+                        kb_[u_] = J.cell_ptr[cell_];                                                  \
+                        ke_[u_] = J.cell_ptr[cell_ + 1];                                              \
                     }                                                                                 \
-                    const int kpos = k_ - kb_;                                                        \
-                    VISIT                                                                             \
+                }                                                                                     \
+                _Pragma("unroll") for (int u_ = 0; u_ < PW_CPL; ++u_) {                               \
+                    const int c = cb_ + u_ * 64 + lane;                                               \
+                    for (int k_ = kb_[u_]; k_ < ke_[u_]; ++k_) {                                      \
+                        const int4 e_ = J.cell_ent[k_];                                               \
+                        const int idx = e_.x;                                                         \
+                        const float fx_ = __int_as_float(e_.y), fy_ = __int_as_float(e_.z);           \
+                        const float s_ = __int_as_float(e_.w);                                        \
+                        if (s_ < mn_ || s_ > mx_) continue;                                           \
+                        if (!(fabsf(fx_ - x_) < r_ && fabsf(fy_ - y_) < r_)) continue;                \
+                        if (sg_) {                                                                    \
+                            const float ur_ = J.u_right[idx];                                         \
+                            if (ur_ > 0.0f && fabsf(qur_ - ur_) > qer_) continue;                      \
+                        }                                                                             \
+                        const int kpos = k_ - kb_[u_];                                                \
+                        VISIT                                                                         \
+                    }                                                                                 \
+                }                                                                                     \
+            }                                                                                         \
+        }                                                                                             \
+    }
+
+// The ranking kernels walk the window DENSELY: the candidates of a chunk of cells (64 x PW_CPL cells) are first listed in LDS - every lane
+// appends the entry ranges of its cells at the offset a wave scan of the counts gives it - and then dealt to the lanes round robin.  In the
+// per-lane form above the wavefront runs as many iterations as its busiest lane has candidates, each a dependent entry -> descriptor load
+// pair with most lanes idle (SearchForInitialization, 100-pixel windows: ~20 iterations of ~1.5 us; PMC: 114 vector-memory instructions
+// per live wavefront); here it runs ceil(candidates / 64) of them with all lanes loading.  A chunk with more than PW_LIST candidates
+// (never at the reference's 64 x 48 grid and feature budgets) falls back to the per-lane walk for that chunk.
+#define PW_LIST 256
+#define PROJ_WAVE_WINDOW_DENSE(J, q, lane, S_LIST, VISIT)                                             \
+    {                                                                                                 \
+        const float x_ = J.qu[q], y_ = J.qv[q], r_ = J.qr[q], mn_ = J.qmin[q], mx_ = J.qmax[q];       \
+        const bool sg_ = J.stereo_gate != 0;                                                          \
+        const float qur_ = sg_ ? J.q_ur[q] : 0.0f, qer_ = sg_ ? J.q_er[q] : 0.0f;                      \
+        const Window w_ = proj_window(J, x_, y_, r_);                                                 \
+        if (w_.ok) {                                                                                  \
+            const int ny_ = w_.cy1 - w_.cy0 + 1, ncells_ = (w_.cx1 - w_.cx0 + 1) * ny_;               \
+            for (int cb_ = 0; cb_ < ncells_; cb_ += 64 * PW_CPL) {                                    \
+                int kb_[PW_CPL], ke_[PW_CPL];                                                         \
+                int cnt_ = 0;                                                                         \
+                _Pragma("unroll") for (int u_ = 0; u_ < PW_CPL; ++u_) {                               \
+                    const int cc_ = cb_ + u_ * 64 + lane;                                             \
+                    kb_[u_] = 0;                                                                      \
+                    ke_[u_] = 0;                                                                      \
+                    if (cc_ < ncells_) {                                                              \
+                        const int cxo_ = cc_ / ny_;                                                   \
+                        const int cell_ = (w_.cx0 + cxo_) * J.rows + (w_.cy0 + cc_ - cxo_ * ny_);     \
+                        kb_[u_] = J.cell_ptr[cell_];                                                  \
+                        ke_[u_] = J.cell_ptr[cell_ + 1];                                              \
+                    }                                                                                 \
+                    cnt_ += ke_[u_] - kb_[u_];                                                        \
+                }                                                                                     \
+                const int incl_ = afv_wave_incl_scan(cnt_);                                           \
+                const int total_ = __builtin_amdgcn_readlane(incl_, 63);                              \
+                if (total_ == 0) continue;                                                            \
+                if (total_ <= PW_LIST) {                                                              \
+                    int at_ = incl_ - cnt_;                                                           \
+                    _Pragma("unroll") for (int u_ = 0; u_ < PW_CPL; ++u_)                             \
+                        for (int k_ = kb_[u_]; k_ < ke_[u_]; ++k_)                                    \
+                            S_LIST[at_++] = make_int2(k_, ((cb_ + u_ * 64 + lane) << 16) | (k_ - kb_[u_])); \
+                    WAVE_LDS_SYNC();                                                                  \
+                    for (int i_ = lane; i_ < total_; i_ += 64) {                                      \
+                        const int2 ck_ = S_LIST[i_];                                                  \
+                        const int4 e_ = J.cell_ent[ck_.x];                                            \
+                        const int idx = e_.x;                                                         \
+                        const float fx_ = __int_as_float(e_.y), fy_ = __int_as_float(e_.z);           \
+                        const float s_ = __int_as_float(e_.w);                                        \
+                        if (s_ < mn_ || s_ > mx_) continue;                                           \
+                        if (!(fabsf(fx_ - x_) < r_ && fabsf(fy_ - y_) < r_)) continue;                \
+                        if (sg_) {                                                                    \
+                            const float ur_ = J.u_right[idx];                                         \
+                            if (ur_ > 0.0f && fabsf(qur_ - ur_) > qer_) continue;                      \
+                        }                                                                             \
+                        const int c = (int)((unsigned)ck_.y >> 16), kpos = ck_.y & 0xffff;            \
+                        VISIT                                                                         \
+                    }                                                                                 \
+                    WAVE_LDS_SYNC();                                                                  \
+                } else {                                                                              \
+                    _Pragma("unroll") for (int u_ = 0; u_ < PW_CPL; ++u_) {                           \
+                        const int c = cb_ + u_ * 64 + lane;                                           \
+                        for (int k_ = kb_[u_]; k_ < ke_[u_]; ++k_) {                                  \
+                            const int4 e_ = J.cell_ent[k_];                                           \
+                            const int idx = e_.x;                                                     \
+                            const float fx_ = __int_as_float(e_.y), fy_ = __int_as_float(e_.z);       \
+                            const float s_ = __int_as_float(e_.w);                                    \
+                            if (s_ < mn_ || s_ > mx_) continue;                                       \
+                            if (!(fabsf(fx_ - x_) < r_ && fabsf(fy_ - y_) < r_)) continue;            \
+                            if (sg_) {                                                                \
+                                const float ur_ = J.u_right[idx];                                     \
+                                if (ur_ > 0.0f && fabsf(qur_ - ur_) > qer_) continue;                  \
+                            }                                                                         \
+                            const int kpos = k_ - kb_[u_];                                            \
+                            VISIT                                                                     \
+                        }                                                                             \
+                    }                                                                                 \
                 }                                                                                     \
             }                                                                                         \
         }                                                                                             \
@@ -165,7 +259,7 @@ __device__ __forceinline__ unsigned long long make_key(int d, int c, int kpos, i
 // are dropped here, so the ordered phase only deals with what the queries of THIS call take from each other.
 #define PROJ_NO_KEY32 0xffffffffu
 template <int W, int K, int REC>
-__device__ void topk_query(const DevProjJob &J, int q, int lane) {
+__device__ void topk_query(const DevProjJob &J, int q, int lane, int2 *s_list /* this wavefront's PW_LIST candidate slots in LDS */) {
     unsigned long long k[K];
 #pragma unroll
     for (int s = 0; s < K; ++s) k[s] = P_NO_KEY;
@@ -180,7 +274,7 @@ __device__ void topk_query(const DevProjJob &J, int q, int lane) {
                 qd[4 * i] = t.x, qd[4 * i + 1] = t.y, qd[4 * i + 2] = t.z, qd[4 * i + 3] = t.w;
             }
         }
-        PROJ_WAVE_WINDOW(J, q, lane, {
+        PROJ_WAVE_WINDOW_DENSE(J, q, lane, s_list, {
             if (REC < 2 && J.occupied && J.occupied[idx]) continue;
             unsigned long long key = make_key(proj_hamming<W>(qd, J.fdesc + (size_t)idx * W), c, kpos, idx);
             _Pragma("unroll") for (int s = 0; s < K; ++s) {
@@ -194,18 +288,13 @@ __device__ void topk_query(const DevProjJob &J, int q, int lane) {
         })
     }
     visited = wave_sum_i32(visited);
-    // K extraction rounds.  A lane's cells are c = lane, lane + 64, ...: the top half of a key (distance << 16 | window cell rank) is
-    // unique to its lane, so the wave minimum of the heads' top halves (32-bit DPP) names the winner lane (cell rank & 63), and the
-    // bottom half (position in cell << 16 | feature) is read from that lane.
+    // K extraction rounds: the wave minimum of the lanes' heads (keys are unique: the feature is part of the key), the holder pops
     unsigned long long mine = P_NO_KEY;  // lane s ends up holding the query's s-th best key
 #pragma unroll
     for (int s = 0; s < K; ++s) {
-        const unsigned top = wave_min_u32((unsigned)(k[0] >> 32));
-        const int wl = (int)(top & 63u);
-        const unsigned bot = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k[0], wl);
-        const unsigned long long m = top == PROJ_NO_KEY32 ? P_NO_KEY : (((unsigned long long)top << 32) | bot);
+        const unsigned long long m = wave_min_u64(k[0]);
         if (lane == s) mine = m;
-        if (lane == wl && top != PROJ_NO_KEY32) {
+        if (k[0] == m && m != P_NO_KEY) {
 #pragma unroll
             for (int t = 0; t + 1 < K; ++t) k[t] = k[t + 1];
             k[K - 1] = P_NO_KEY;
@@ -246,20 +335,22 @@ __device__ void topk_query(const DevProjJob &J, int q, int lane) {
 
 template <int K, int REC>
 __global__ __launch_bounds__(PT) void k_proj_topk(const DevProjJob *__restrict__ jobs) {
+    __shared__ int2 s_list[PT / 64][PW_LIST];
     const DevProjJob J = jobs[blockIdx.y];
     const int lane = threadIdx.x & 63, q = blockIdx.x * (PT / 64) + (threadIdx.x >> 6);
     if (q >= J.nq) return;
-    if (J.words == 8) topk_query<8, K, REC>(J, q, lane);
-    else topk_query<16, K, REC>(J, q, lane);
+    if (J.words == 8) topk_query<8, K, REC>(J, q, lane, s_list[threadIdx.x >> 6]);
+    else topk_query<16, K, REC>(J, q, lane, s_list[threadIdx.x >> 6]);
 }
 // one job, its record a kernel argument: a search against a resident frame uploads nothing ahead of the launch - the queries are read
 // straight from the caller's pinned staging arena (a few KB over the link, once)
 template <int K, int REC>
 __global__ __launch_bounds__(PT) void k_proj_topk1(const DevProjJob J) {
+    __shared__ int2 s_list[PT / 64][PW_LIST];
     const int lane = threadIdx.x & 63, q = blockIdx.x * (PT / 64) + (threadIdx.x >> 6);
     if (q >= J.nq) return;
-    if (J.words == 8) topk_query<8, K, REC>(J, q, lane);
-    else topk_query<16, K, REC>(J, q, lane);
+    if (J.words == 8) topk_query<8, K, REC>(J, q, lane, s_list[threadIdx.x >> 6]);
+    else topk_query<16, K, REC>(J, q, lane, s_list[threadIdx.x >> 6]);
 }
 
 // ---------------- phase 2: ordered resolve, one wave per job ----------------
@@ -1372,15 +1463,16 @@ __global__ __launch_bounds__(IW_T) void k_init_resolve_wg1(const DevProjJob J) {
 // -> plain loads) goes on as the fixed-point workgroup.  The ticket is zero at rest: the last arriver re-arms it.
 template <int KIND>  // 0 = projection (PK keys, REC 1), 1 = initialization (IK keys, REC 3)
 __global__ __launch_bounds__(PW_T) void k_proj_search1(const DevProjJob J, int *__restrict__ ticket) {
+    __shared__ int2 s_list[PW_NW][PW_LIST];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int q = (int)blockIdx.x * PW_NW + wv;
     if (q < J.nq) {  // wave-uniform
         if (KIND == 0) {
-            if (J.words == 8) topk_query<8, PK, 1>(J, q, lane);
-            else topk_query<16, PK, 1>(J, q, lane);
+            if (J.words == 8) topk_query<8, PK, 1>(J, q, lane, s_list[wv]);
+            else topk_query<16, PK, 1>(J, q, lane, s_list[wv]);
         } else {
-            if (J.words == 8) topk_query<8, IK, 3>(J, q, lane);
-            else topk_query<16, IK, 3>(J, q, lane);
+            if (J.words == 8) topk_query<8, IK, 3>(J, q, lane, s_list[wv]);
+            else topk_query<16, IK, 3>(J, q, lane, s_list[wv]);
         }
     }
     __shared__ int s_last;
@@ -1409,7 +1501,9 @@ __global__ __launch_bounds__(PW_T) void k_proj_search1(const DevProjJob J, int *
 
 // the workgroup engines need more LDS than the 64 KB a kernel gets by default: raised once per device (afv_create), checked
 extern "C" int afv_project_prepare(void) {
-    const int want = 150 * 1024;
+    // the one-launch search keeps 32 KB of static LDS for the ranking phase's candidate lists (16 wavefronts x PW_LIST x 8 bytes): its
+    // dynamic share is what is left of the 160 KB of a CU, and that is the budget every engine is held to
+    const int want = 150 * 1024 - (int)sizeof(int2) * PW_NW * PW_LIST;
     bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_resolve_wg), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
     ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_init_resolve_wg), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess && ok;
     ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_resolve_wg1), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess && ok;
@@ -1418,7 +1512,7 @@ extern "C" int afv_project_prepare(void) {
     ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_search1<1>), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess && ok;
     if (!ok) (void)hipGetLastError();
     // dynamic bytes a job may ask for (the kernels' static arrays take about 1 KB more); without the raised limit: what every kernel gets
-    return ok ? want - 2048 : 62 * 1024;
+    return ok ? want - 2048 : 62 * 1024 - (int)sizeof(int2) * PW_NW * PW_LIST;
 }
 extern "C" size_t afv_project_wg_lds(int kind_init, int n, int nq) { return kind_init ? init_wg_lds_bytes(n, nq) : proj_wg_lds_bytes(n, nq); }
 
