@@ -211,8 +211,73 @@ __global__ __launch_bounds__(MT) void k_match_bow(const DevMatchJob *__restrict_
 // lanes scan the node's columns, and the "taken" flags live in a per-wave LDS bitset indexed by the column's position
 // inside the node.  Orientation bins go to a per-job histogram (global atomics); k_match_bow_finish applies M6.
 
+// A node of at most 64 x 64 features (all of them at the shipped vocabulary: ~10 features per node of depth 2) lives in REGISTERS for the
+// whole walk: lane a holds row a's descriptor, lane b column b's; a row's descriptor reaches the columns through eight v_readlane, the
+// (best, second) pair through the DPP reduction of the pair matcher, the "taken" flags are one 64-bit scalar.  The walk itself touches
+// no memory: the loop below cost four dependent memory round trips and a store drain PER ROW in the general form (50 us for one pair of
+// frames, measured in round 5: a node with 12 rows = 12 x 4 us); results leave once, after the walk.
+template <int W>
+__device__ __forceinline__ void bow_segment_small(const DevMatchJob &J, const Seg S, int *hist, uint8_t *bins) {
+    const int lane = threadIdx.x & 63;
+    const bool kf_frame = J.mode == AFV_MATCH_KF_FRAME;
+    const int idx1 = lane < S.n1 ? (J.idx1 ? J.idx1[S.s1 + lane] : S.s1 + lane) : -1;
+    const int idx2 = lane < S.n2 ? (J.idx2 ? J.idx2[S.s2 + lane] : S.s2 + lane) : -1;
+    const bool v1 = idx1 >= 0 && !(J.valid1 && !J.valid1[idx1]);
+    const bool v2 = idx2 >= 0 && !(!kf_frame && J.valid2 && !J.valid2[idx2]);
+    uint32_t rd[W], cd[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        rd[i] = idx1 >= 0 ? J.d1[(size_t)idx1 * W + i] : 0u;
+        cd[i] = idx2 >= 0 ? J.d2[(size_t)idx2 * W + i] : 0u;
+    }
+    float a1 = 0.0f, a2 = 0.0f;
+    if (J.check_ori) {
+        if (idx1 >= 0) a1 = J.ang1[(size_t)idx1 * J.ang_stride];
+        if (idx2 >= 0) a2 = J.ang2[(size_t)idx2 * J.ang_stride];
+    }
+    unsigned long long taken = ~__ballot(v2);  // columns that can never be taken count as taken
+    const unsigned long long rows = __ballot(v1);
+    int mine = -1, nm = 0;
+    for (int a = 0; a < S.n1; ++a) {
+        if (!((rows >> a) & 1ull)) continue;  // uniform
+        int d = 0;
+#pragma unroll
+        for (int i = 0; i < W; ++i) d += __popc((uint32_t)__builtin_amdgcn_readlane((int)rd[i], a) ^ cd[i]);
+        int k = ((taken >> lane) & 1ull) ? NO_KEY : ((d << 16) | lane), s2 = NO_KEY >> 16;
+        wave_merge_best(k, s2);
+        if (k == NO_KEY) continue;
+        const float best1 = (float)(k >> 16);
+        const float best2 = (s2 == (NO_KEY >> 16)) ? 3.402823466e+38f : (float)s2;
+        const bool under = kf_frame ? (best1 <= J.th) : (best1 < J.th);  // FeatureMatcher.cc:250 / :630
+        if (under && best1 < J.ratio * best2) {                            // :252 / :632
+            const int b = k & 0xffff;
+            taken |= 1ull << b;
+            if (lane == a) mine = b;
+            ++nm;
+        }
+    }
+    // results: row a's lane fetches its column's feature index (and angle) from the column's lane
+    const int src = (mine >= 0 ? mine : 0) * 4;
+    const int m_idx2 = __builtin_amdgcn_ds_bpermute(src, idx2);
+    const float m_a2 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, a2)));
+    if (mine >= 0) {
+        const int key = kf_frame ? m_idx2 : idx1;
+        J.out[key] = kf_frame ? idx1 : m_idx2;
+        if (J.check_ori) {
+            const int bin = rotation_bin(a1, m_a2);
+            bins[key] = (uint8_t)bin;
+            atomicAdd(&hist[bin], 1);
+        }
+    }
+    if (lane == 0 && nm) atomicAdd(J.nmatches, nm);
+}
+
 template <int W>
 __device__ void bow_segment(const DevMatchJob &J, const Seg S, uint32_t *s_taken, int *hist, uint8_t *bins) {
+    if (S.n1 <= 64 && S.n2 <= 64) {  // wave-uniform
+        bow_segment_small<W>(J, S, hist, bins);
+        return;
+    }
     const int lane = threadIdx.x & 63;
     const bool kf_frame = J.mode == AFV_MATCH_KF_FRAME;
     for (int i = lane; i < (S.n2 + 31) / 32; i += 64) s_taken[i] = 0;

@@ -946,7 +946,7 @@ __global__ __launch_bounds__(PW_T) void k_proj_resolve_wg1(const DevProjJob J) {
 
 // ---------------- Fuse / SearchBySim3: independent queries, one wave each; first minimum in visiting order (:905) ----------------
 template <int W>
-__device__ void fuse_query(const DevProjJob &J, int q, int lane) {
+__device__ void fuse_query(const DevProjJob &J, int q, int lane, int2 *s_list) {
     unsigned long long k0 = P_NO_KEY;
     if (!J.qvalid || J.qvalid[q]) {
         uint32_t qd[W];
@@ -954,7 +954,7 @@ __device__ void fuse_query(const DevProjJob &J, int q, int lane) {
         for (int i = 0; i < W; ++i) qd[i] = J.qdesc[(size_t)q * W + i];
         const float u = J.qu[q], v = J.qv[q];
         const float qur = J.u_right ? J.q_ur[q] : 0.0f;
-        PROJ_WAVE_WINDOW(J, q, lane, {
+        PROJ_WAVE_WINDOW_DENSE(J, q, lane, s_list, {
             if (J.inf) {  // reprojection gate of Fuse (:876-900); absent in Fuse(Sim3) / SearchBySim3
                 const float ex = u - fx_;
                 const float ey = v - fy_;
@@ -977,17 +977,19 @@ __device__ void fuse_query(const DevProjJob &J, int q, int lane) {
 }
 
 __global__ __launch_bounds__(PT) void k_match_fuse(const DevProjJob *__restrict__ jobs) {
+    __shared__ int2 s_list[PT / 64][PW_LIST];
     const DevProjJob J = jobs[blockIdx.y];
     const int lane = threadIdx.x & 63, q = blockIdx.x * (PT / 64) + (threadIdx.x >> 6);
     if (q >= J.nq) return;
-    if (J.words == 8) fuse_query<8>(J, q, lane);
-    else fuse_query<16>(J, q, lane);
+    if (J.words == 8) fuse_query<8>(J, q, lane, s_list[threadIdx.x >> 6]);
+    else fuse_query<16>(J, q, lane, s_list[threadIdx.x >> 6]);
 }
 __global__ __launch_bounds__(PT) void k_match_fuse1(const DevProjJob J) {
+    __shared__ int2 s_list[PT / 64][PW_LIST];
     const int lane = threadIdx.x & 63, q = blockIdx.x * (PT / 64) + (threadIdx.x >> 6);
     if (q >= J.nq) return;
-    if (J.words == 8) fuse_query<8>(J, q, lane);
-    else fuse_query<16>(J, q, lane);
+    if (J.words == 8) fuse_query<8>(J, q, lane, s_list[threadIdx.x >> 6]);
+    else fuse_query<16>(J, q, lane, s_list[threadIdx.x >> 6]);
 }
 
 // ---------------- SearchForInitialization (FeatureMatcher.cc:399-557, active part :480-556) ----------------

@@ -105,3 +105,29 @@ def test_ragged_trees_and_wide_nodes(afv, oracle, gpu_ctx):
         oleaf, onid = oracle.bow_transform(voc, q, levelsup)
         assert np.array_equal(leaf, oleaf) and np.array_equal(nid, onid), levelsup
     voc.close()
+
+
+@pytest.mark.parametrize("k,L,levelsup", [(8, 3, 1), (10, 4, 2), (6, 3, 2), (3, 5, 1)])
+@pytest.mark.parametrize("ori", [False, True])
+def test_bow_guided_matchers_over_small_and_large_nodes(afv, oracle, gpu_ctx, k, L, levelsup, ori):
+    """SearchByBoW(KF, KF) and SearchByBoW(KF, F) over FeatureVectors whose nodes hold a handful of features (the register-resident node
+    walk: both sides <= 64) as well as hundreds (the general walk), with validity masks"""
+    s = afv.synth
+    img = s.corners_frame(2)
+    k1, d1 = gpu_ctx.extract(img)
+    k2, d2 = gpu_ctx.extract(np.roll(img, 4, axis=1))
+    voc = afv.Vocabulary.random(13 + k, k=k, L=L, ctx=gpu_ctx)
+    _, fv1 = voc.transform(d1, levelsup=levelsup)
+    _, fv2 = voc.transform(d2, levelsup=levelsup)
+    sizes = [len(idx) for _, idx in fv1]
+    v1 = (s.lcg_bytes(5, len(d1)) > 40).astype(np.uint8); v2 = (s.lcg_bytes(6, len(d2)) > 40).astype(np.uint8)
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+    m = afv.FeatureMatcher(0.8, ori, ctx=gpu_ctx)
+    A = afv.FeatureView(d1, fv1, valid=v1, angles=k1["angle"]); B = afv.FeatureView(d2, fv2, valid=v2, angles=k2["angle"])
+    got, n = m.SearchByBoW(A, B)
+    want, wn = oracle.search_by_bow_kf_kf(d1, d2, fv1, fv2, v1, v2, k1["angle"], k2["angle"], 75.0, 0.8, ori)
+    assert n == wn and np.array_equal(got, want) and wn > 30, (sizes[:8], n, wn)
+    got, n = m.SearchByBoW(A, B, frame=True)
+    want, wn = oracle.search_by_bow_kf_frame(d1, d2, fv1, fv2, v1, k1["angle"], k2["angle"], 75.0, 0.8, ori)
+    assert n == wn and np.array_equal(got, want) and wn > 30
+    voc.close()
