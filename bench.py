@@ -1118,8 +1118,8 @@ def main():
     # table broadcast from rank 0 through the C-ABI communicator) - at N = 1 the same code path gives the single-GPU figure
     ident = multi_gpu_identity(rank, world, local, dev, dist, args.backend, None, args.single_device)
     strong = None
-    if not args.no_extras:
-        try:
+    if world > 1 and not args.no_extras:   # (N = 1: after the other sub-runs - initialising RCCL ahead of the host-fed pipeline figure
+        try:                               # costs that figure a third of its PCIe rate on this box: 4.0 -> 6.0 ms per 512 frames, measured)
             strong = pairs_run(args, rank, world, local, dev, dist, 5, 2, False, False)
         except Exception as e:
             strong = {"error": repr(e)[:300]}
@@ -1138,13 +1138,6 @@ def main():
             "csrc_sha": _csrc_sha(),
             "multi_gpu": ident,
         }
-        if strong:
-            out["pairs10k_strong"] = strong if "error" in strong else {
-                "metric": strong["metric"], "value": strong["value"], "unit": strong["unit"], "n_gpus": strong["n_gpus"], "scaling": "strong",
-                "ms_per_step": strong["ms_per_step"], "jobs_per_step": strong["config"]["jobs_per_step"], "job_ranges": strong["config"]["job_ranges"],
-                "matches_per_job": strong["config"]["matches_per_job"], "broadcast": strong["broadcast"], "covisible": strong["covisible"],
-                "rccl_ranks_seen": strong["multi_gpu"]["rccl_ranks_seen"],
-                "note": "BASELINE.json configs[3] on the same ranks: total work fixed, table replicated with one broadcast from rank 0"}
         if stages:
             px = level_pixels(W, H)
             fh = stages["fast_nms"]
@@ -1271,6 +1264,18 @@ def main():
                     out[key] = fn(afv, local)
                 except Exception as e:  # a secondary figure must never cost the headline line
                     out[key] = {"error": repr(e)[:300]}
+        if world == 1 and not args.no_extras:
+            try:
+                strong = pairs_run(args, rank, world, local, dev, dist, 5, 2, False, False)
+            except Exception as e:
+                strong = {"error": repr(e)[:300]}
+        if strong:
+            out["pairs10k_strong"] = strong if "error" in strong else {
+                "metric": strong["metric"], "value": strong["value"], "unit": strong["unit"], "n_gpus": strong["n_gpus"], "scaling": "strong",
+                "ms_per_step": strong["ms_per_step"], "jobs_per_step": strong["config"]["jobs_per_step"], "job_ranges": strong["config"]["job_ranges"],
+                "matches_per_job": strong["config"]["matches_per_job"], "broadcast": strong["broadcast"], "covisible": strong["covisible"],
+                "rccl_ranks_seen": strong["multi_gpu"]["rccl_ranks_seen"],
+                "note": "BASELINE.json configs[3] on the same ranks: total work fixed, table replicated with one broadcast from rank 0"}
         if args.cpu_frames > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(afv, args.cpu_frames, seed0)
         elif args.cpu_frames > 0:
