@@ -21,9 +21,9 @@ struct afv_akaze {
     afv_akaze_plan plan{};  // for the current frame size
     hipStream_t stream = nullptr;
     std::string last_error;
-    // HBM: per level 5 planes x max_batch frames (level 0: Lsmooth aliases Lt); scratch at level-0 size
-    float *lt[AFV_AKZ_MAX_LEVELS] = {}, *lsm[AFV_AKZ_MAX_LEVELS] = {}, *lx[AFV_AKZ_MAX_LEVELS] = {}, *ly[AFV_AKZ_MAX_LEVELS] = {},
-          *ldet[AFV_AKZ_MAX_LEVELS] = {};
+    // HBM: per level 3 planes x max_batch frames (level 0: Lsmooth aliases Lt); scratch at level-0 size.  The first derivatives have no
+    // planes (round 5): k_akz_dhess keeps them in registers, the descriptor stage evaluates them where it samples (k_akaze_desc.hip)
+    float *lt[AFV_AKZ_MAX_LEVELS] = {}, *lsm[AFV_AKZ_MAX_LEVELS] = {}, *ldet[AFV_AKZ_MAX_LEVELS] = {};
     float *flow = nullptr, *pong = nullptr, *half = nullptr;
     float *d_taps = nullptr;  // gauss_soffset[32] | gauss_one[8]
     unsigned int *d_hmax = nullptr;
@@ -242,8 +242,6 @@ extern "C" int afv_akaze_create(int device, const afv_akaze_params *prm, afv_aka
             if (i == 0) a->lsm[0] = a->lt[0];  // evolution_[0].Lt.copyTo(evolution_[0].Lsmooth)
             else rc = akz_alloc(a, &a->lsm[i], n);
         }
-        if (rc == AFV_OK) rc = akz_alloc(a, &a->lx[i], n);
-        if (rc == AFV_OK) rc = akz_alloc(a, &a->ly[i], n);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->ldet[i], n);
     }
     const size_t n0 = (size_t)prm->max_width * prm->max_height * B;
@@ -378,8 +376,11 @@ static int akz_enqueue(afv_akaze *a, const uint8_t *d_gray, int nframes, int w, 
     if (a->profiling) AKZ_HIPCHK(a, hipEventRecord(a->ev[1], st));
     for (int i = 0; i < P.nlevels; ++i) {
         const afv_akaze_level &L = P.lv[i];
-        // lx / ly keep the UNSCALED first derivatives; readers apply sigma_size (k_akz_describe, afv_akaze_get_plane)
-        if (afv_akz_launch_hessian(a->lsm[i], L.w, L.h, nframes, L.sigma_size, a->step_by_step ? 1 : 0, a->lx[i], a->ly[i], a->ldet[i], st))
+        // the first derivatives stay in the kernel's registers; the two-kernel form (test reference, other sigma sizes) hands them over
+        // through the scratch planes, which are free once the scale space is built
+        const bool fused = !a->step_by_step && L.sigma_size >= 2 && L.sigma_size <= 4;
+        if (afv_akz_launch_hessian(a->lsm[i], L.w, L.h, nframes, L.sigma_size, fused ? 0 : 1, fused ? nullptr : a->pong, fused ? nullptr : a->flow,
+                                   a->ldet[i], st))
             return AFV_EUNSUPPORTED;
     }
     if (a->profiling) {
@@ -446,14 +447,23 @@ extern "C" int afv_akaze_get_plane(afv_akaze *a, int frame, int level, int which
     switch (which) {
         case AFV_AKZ_LT: base = a->lt[level]; break;
         case AFV_AKZ_LSMOOTH: base = a->lsm[level]; break;
-        case AFV_AKZ_LX: base = a->lx[level]; break;
-        case AFV_AKZ_LY: base = a->ly[level]; break;
+        case AFV_AKZ_LX: base = a->pong; break;  // evaluated below
+        case AFV_AKZ_LY: base = a->flow; break;
         case AFV_AKZ_LDET: base = a->ldet[level]; break;
         default: return AFV_EINVAL;
     }
     AKZ_HIPCHK(a, hipSetDevice(a->device));
+    size_t off = (size_t)frame * L.w * L.h;
+    if (which == AFV_AKZ_LX || which == AFV_AKZ_LY) {
+        // no derivative planes exist: this frame's are produced now, by the kernel the pipeline ran (with its first-derivative stores
+        // switched on; the determinant it rewrites is the one that is there), into the scratch planes
+        if (afv_akz_launch_hessian(a->lsm[level] + off, L.w, L.h, 1, L.sigma_size, a->step_by_step ? 1 : 0, a->pong, a->flow, a->ldet[level] + off,
+                                   a->stream))
+            return AFV_EUNSUPPORTED;
+        off = 0;
+    }
     AKZ_HIPCHK(a, hipStreamSynchronize(a->stream));
-    AKZ_HIPCHK(a, hipMemcpy(out, base + (size_t)frame * L.w * L.h, (size_t)L.w * L.h * sizeof(float), hipMemcpyDeviceToHost));
+    AKZ_HIPCHK(a, hipMemcpy(out, base + off, (size_t)L.w * L.h * sizeof(float), hipMemcpyDeviceToHost));
     if (which == AFV_AKZ_LX || which == AFV_AKZ_LY) {  // the device planes are unscaled: Lx *= sigma_size as upstream does in place
         const float fs = (float)L.sigma_size;
         for (size_t i = 0, n = (size_t)L.w * L.h; i < n; ++i) out[i] = out[i] * fs;
@@ -594,7 +604,7 @@ static int akz_describe_enqueue(afv_akaze *a) {
     S.kp_cap = AKD_ENTRY_CAP; S.sel_cap = a->sel_cap; S.out_cap = a->out_cap; S.M = a->qt_M;
     AkdDescParams D{};
     D.nlevels = P.nlevels; D.kp_cap = AKD_ENTRY_CAP; D.sel_cap = a->sel_cap; D.out_cap = a->out_cap; D.desc_pitch = 64;
-    for (int l = 0; l < P.nlevels; ++l) D.lv[l] = AkdLevelPlanes{a->lt[l], a->lx[l], a->ly[l], P.lv[l].w, P.lv[l].h, P.lv[l].octave, (float)P.lv[l].sigma_size};
+    for (int l = 0; l < P.nlevels; ++l) D.lv[l] = AkdLevelPlanes{a->lt[l], a->lsm[l], P.lv[l].w, P.lv[l].h, P.lv[l].octave, P.lv[l].sigma_size, (float)P.lv[l].sigma_size};
     hipStream_t st = a->stream;
     afv_akz_launch_select(&S, a->cur_frames, a->d_kps, a->d_kp_count, a->d_lvl_idx, a->d_lvl_node, a->d_sel, a->d_sel_count, st);
     afv_akz_launch_describe(&D, a->cur_frames, a->out_cap, a->d_kps, a->d_sel, a->d_sel_count, a->d_out_kps, a->d_out_desc, a->d_out_count,

@@ -58,9 +58,11 @@ struct AksParams {
 };
 
 struct AkdLevelPlanes {
-    const float *lt, *lx, *ly;  // [frame][h][w]; lx / ly hold the UNSCALED first derivatives
+    const float *lt, *lsm;  // [frame][h][w]: Lt and Lsmooth of the level.  The first derivatives are NOT stored (round 5): the descriptor
+                            // stage evaluates them from Lsmooth at its ~550 sample positions per keypoint with k_akz_deriv1's expressions
     int w, h, octave;
-    float fs;                   // sigma_size: Lx = lx * fs, Ly = ly * fs (the in-place scaling of Compute_Multiscale_Derivatives)
+    int s;                  // sigma_size (tap distance of the derivative filters)
+    float fs;               // (float)sigma_size: Lx = lx * fs, Ly = ly * fs (the in-place scaling of Compute_Multiscale_Derivatives)
 };
 struct AkdDescParams {
     int nlevels, kp_cap, sel_cap, out_cap, desc_pitch;

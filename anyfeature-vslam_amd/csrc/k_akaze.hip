@@ -778,7 +778,10 @@ __global__ __launch_bounds__(AKZ_T) void k_akz_hessian(const float *__restrict__
 // SLOWER: 285 / 305-320 / 366 us - five loads per row instead of one put the time into cache round trips.  Dropped.
 #define AKZ_DH_ROWS 64  // rows per strip (+ 4S rows of run-in).  Round 4 sweep, 64 frames of 1280 x 720, all eight levels: 64 rows 1.36 ms,
                        // 96: 1.39, 128: 1.42, 180: 1.50, 240: 1.74, 360: 2.08 (fewer, longer wavefronts lose more than the run-in costs)
-template <int S>
+// SD: also store the (unscaled) first derivatives.  The pipeline does not (round 5): their only reader is the descriptor stage, which
+// evaluates them at its sample positions from Lsmooth (k_akaze_desc.hip) - 8 of this kernel's 16 B per pixel were written for a plane
+// of which under a tenth is ever read.  SD = true serves afv_akaze_get_plane (and keeps the fused Lx / Ly under the plane tests).
+template <int S, bool SD>
 __global__ __launch_bounds__(256) void k_akz_dhess(const float *__restrict__ lsm, int w, int h, int nframes, float *__restrict__ dx,
                                                    float *__restrict__ dy, float *__restrict__ Ldet) {
     constexpr int P = 2 * S + 1;     // ring depth
@@ -829,7 +832,7 @@ __global__ __launch_bounds__(256) void k_akz_dhess(const float *__restrict__ lsm
             const int q = v - S;
             const float lx = mid * D[km] + norm * (D[kmm] + D[k]);
             const float ly = U[k] - U[kmm];
-            if (q >= y0 && q < y0 + rows && out_lane) {
+            if (SD && q >= y0 && q < y0 + rows && out_lane) {
                 const size_t o = fo + (size_t)q * w + gx;
                 dx[o] = lx;
                 dy[o] = ly;
@@ -923,7 +926,7 @@ extern "C" int afv_akz_launch_fed_gauss(const float *Lt_in, float *lsm, const fl
     return 1;
 }
 
-// dx, dy: the level's first-derivative planes (unscaled; written here, kept for the descriptor stage)
+// dx, dy: where the level's (unscaled) first derivatives go; nullptr (fused form only): they are not stored
 extern "C" int afv_akz_launch_hessian(const float *lsm, int w, int h, int nframes, int s, int two_kernels, float *dx, float *dy, float *Ldet,
                                       hipStream_t st) {
     if (s < 1 || s > AKZ_MAX_S) return -1;
@@ -931,11 +934,18 @@ extern "C" int afv_akz_launch_hessian(const float *lsm, int w, int h, int nframe
         const int ow = 64 - 4 * s;
         const int strips = ((w + ow - 1) / ow) * ((h + AKZ_DH_ROWS - 1) / AKZ_DH_ROWS) * nframes;
         const dim3 g((strips + 3) / 4);
-        if (s == 2) hipLaunchKernelGGL(k_akz_dhess<2>, g, dim3(256), 0, st, lsm, w, h, nframes, dx, dy, Ldet);
-        else if (s == 3) hipLaunchKernelGGL(k_akz_dhess<3>, g, dim3(256), 0, st, lsm, w, h, nframes, dx, dy, Ldet);
-        else hipLaunchKernelGGL(k_akz_dhess<4>, g, dim3(256), 0, st, lsm, w, h, nframes, dx, dy, Ldet);
+        if (dx && dy) {
+            if (s == 2) hipLaunchKernelGGL((k_akz_dhess<2, true>), g, dim3(256), 0, st, lsm, w, h, nframes, dx, dy, Ldet);
+            else if (s == 3) hipLaunchKernelGGL((k_akz_dhess<3, true>), g, dim3(256), 0, st, lsm, w, h, nframes, dx, dy, Ldet);
+            else hipLaunchKernelGGL((k_akz_dhess<4, true>), g, dim3(256), 0, st, lsm, w, h, nframes, dx, dy, Ldet);
+        } else {
+            if (s == 2) hipLaunchKernelGGL((k_akz_dhess<2, false>), g, dim3(256), 0, st, lsm, w, h, nframes, dx, dy, Ldet);
+            else if (s == 3) hipLaunchKernelGGL((k_akz_dhess<3, false>), g, dim3(256), 0, st, lsm, w, h, nframes, dx, dy, Ldet);
+            else hipLaunchKernelGGL((k_akz_dhess<4, false>), g, dim3(256), 0, st, lsm, w, h, nframes, dx, dy, Ldet);
+        }
         return 0;
     }
+    if (!dx || !dy) return -1;  // the two-kernel form hands the first derivatives over in memory
     const size_t plane = (size_t)(AT_W + 2 * s) * (AT_H + 2 * s) * sizeof(float);
     hipLaunchKernelGGL(k_akz_deriv1, akz_grid(w, h, nframes), dim3(AKZ_T), plane, st, lsm, w, h, nframes, s, dx, dy);
     hipLaunchKernelGGL(k_akz_hessian, akz_grid(w, h, nframes), dim3(AKZ_T), 2 * plane, st, dx, dy, w, h, nframes, s, Ldet);

@@ -8,6 +8,7 @@
 //                   surviving keypoint, in the order mergeKeypointLevels produces (levels ascending, list order inside).
 // Float sums are order sensitive, so every accumulation below runs in upstream's loop order inside one lane: the 42
 // orientation windows and the 29 MLDB grid cells are spread over lanes, their inner sums stay sequential.
+#include <type_traits>
 #include "afv_device.h"
 #include "akz_jobs.h"
 #include "../../include/afv_hip.h"
@@ -161,6 +162,37 @@ __constant__ float k_gauss25[7][7] = {
     {0.00344629f, 0.00318132f, 0.00250252f, 0.00167749f, 0.00095820f, 0.00046640f, 0.00019346f},
     {0.00142946f, 0.00131956f, 0.00103800f, 0.00069579f, 0.00039744f, 0.00019346f, 0.00008024f}};
 
+// ---- first derivatives on demand ----
+// Upstream computes Lx / Ly for every pixel of every level (Compute_Multiscale_Derivatives) and the descriptor stage reads them at ~550
+// positions per keypoint: on a 1280 x 720 frame with 850 keypoints less than a tenth of the 37 MB of derivative planes is ever read.
+// Round 5 stopped storing them (k_akz_dhess keeps them in registers for the Hessian only): a sample position (x, y) gets its
+// derivatives from the eight Lsmooth taps around it with exactly the expressions of k_akz_deriv1 (k_akaze.hip; the Scharr pair at
+// tap distance s, inputs at BORDER_REFLECT_101 coordinates), i.e. the same float bits the planes held.
+__device__ __forceinline__ int akd_reflect(int p, int n) {
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
+    return p;
+}
+struct AkdTaps {
+    float a, b, c, d, e, f, g, h;  // rows y - s, y, y + s x columns x - s, x, x + s without the centre
+};
+__device__ __forceinline__ AkdTaps akd_load_taps(const float *__restrict__ S, int w, int h, int s, int x, int y) {
+    const int xm = akd_reflect(x - s, w), xp = akd_reflect(x + s, w);
+    const size_t rm = (size_t)akd_reflect(y - s, h) * w, r0 = (size_t)y * w, rp = (size_t)akd_reflect(y + s, h) * w;
+    AkdTaps t;
+    t.a = S[rm + xm]; t.b = S[rm + x]; t.c = S[rm + xp];
+    t.d = S[r0 + xm];                  t.e = S[r0 + xp];
+    t.f = S[rp + xm]; t.g = S[rp + x]; t.h = S[rp + xp];
+    return t;
+}
+__device__ __forceinline__ void akd_deriv(const AkdTaps &t, float mid, float norm, float *vx, float *vy) {
+    const float t0 = t.c - t.a, t1 = t.e - t.d, t2 = t.h - t.f;   // Lx: row derivative, column smoothing
+    *vx = mid * t1 + norm * (t0 + t2);
+    const float u0 = mid * t.b + norm * (t.a + t.c);              // Ly: row smoothing, column derivative
+    const float u2 = mid * t.g + norm * (t.f + t.h);
+    *vy = u2 - u0;
+}
+
 #define AKD_LDS_SYNC()                                         \
     do {                                                       \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
@@ -192,7 +224,8 @@ __global__ __launch_bounds__(256) void k_akz_describe(AkdDescParams P, const afv
     afv_keypoint kp = kps[(size_t)f * P.kp_cap + sel[((size_t)f * P.nlevels + level) * P.sel_cap + pos]];
     const AkdLevelPlanes L = P.lv[level];
     const size_t fo = (size_t)f * L.w * L.h;
-    const float *Lt = L.lt + fo, *Lx = L.lx + fo, *Ly = L.ly + fo;
+    const float *Lt = L.lt + fo, *Ls = L.lsm + fo;
+    const float d_wgt = 10.0f / 3.0f, d_norm = 1.0f / (2.0f * (float)L.s * (d_wgt + 2.0f)), d_mid = d_wgt * d_norm;  // as k_akz_deriv1
     const float ratio = (float)(1 << L.octave);
     const float xf = kp.x / ratio, yf = kp.y / ratio;
     float4 *ori = s_smp[wv];
@@ -200,15 +233,17 @@ __global__ __launch_bounds__(256) void k_akz_describe(AkdDescParams P, const afv
     // ---- Compute_Main_Orientation ----
     {
         const int s = akd_fround((float)(0.5 * (double)kp.size / (double)ratio));
-        float ox[2], oy[2];
+        AkdTaps ot[2];
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {  // both gathers of a lane in flight together
+        for (int it = 0; it < 2; ++it) {  // the gathers of both samples of a lane in flight together
             const int idx = min(lane + 64 * it, 108);
             const int i = k_ori_ij[idx][0], j = k_ori_ij[idx][1];
             const int iy = akd_iclamp(akd_fround(yf + (float)(j * s)), 0, L.h - 1), ix = akd_iclamp(akd_fround(xf + (float)(i * s)), 0, L.w - 1);
-            ox[it] = Lx[(size_t)iy * L.w + ix];
-            oy[it] = Ly[(size_t)iy * L.w + ix];
+            ot[it] = akd_load_taps(Ls, L.w, L.h, L.s, ix, iy);
         }
+        float ox[2], oy[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) akd_deriv(ot[it], d_mid, d_norm, &ox[it], &oy[it]);
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int idx = lane + 64 * it;
@@ -266,29 +301,33 @@ __global__ __launch_bounds__(256) void k_akz_describe(AkdDescParams P, const afv
         // if every cell fetches its own), and every cell then adds ITS samples in upstream's (k, l) loop order from LDS.
         AKD_LDS_SYNC();  // every lane is through with the orientation samples that share this wavefront's block
         float4 *smp = s_smp[wv];
-        {
-            float ri[7], gx[7], gy[7];  // all 21 gathers of a lane in flight together
+        auto mldb_samples = [&](auto first, auto count) {  // the 9 gathers of each of `count` samples of a lane in flight together
+            constexpr int IT0 = decltype(first)::value, N = decltype(count)::value;
+            float ri[N];
+            AkdTaps tp[N];
 #pragma unroll
-            for (int it = 0; it < 7; ++it) {
-                const int p = min(lane + 64 * it, 440);
+            for (int n = 0; n < N; ++n) {
+                const int p = min(lane + 64 * (IT0 + n), 440);
                 const int k = p / 21 - 10, l = p - (p / 21) * 21 - 10;
                 const float sample_y = yf + ((float)l * co * scale + (float)k * si * scale);
                 const float sample_x = xf + (-(float)l * si * scale + (float)k * co * scale);
                 const int y1 = akd_iclamp(akd_fround(sample_y), 0, L.h - 1), x1 = akd_iclamp(akd_fround(sample_x), 0, L.w - 1);
-                const size_t o = (size_t)y1 * L.w + x1;
-                ri[it] = Lt[o];
-                gx[it] = Lx[o];
-                gy[it] = Ly[o];
+                ri[n] = Lt[(size_t)y1 * L.w + x1];
+                tp[n] = akd_load_taps(Ls, L.w, L.h, L.s, x1, y1);
             }
 #pragma unroll
-            for (int it = 0; it < 7; ++it) {
-                const int p = lane + 64 * it;
+            for (int n = 0; n < N; ++n) {
+                const int p = lane + 64 * (IT0 + n);
                 if (p < 441) {
-                    const float vx = gx[it] * L.fs, vy = gy[it] * L.fs;
-                    smp[p] = make_float4(ri[it], -vx * si + vy * co /* rrx */, vx * co + vy * si /* rry */, 0.0f);
+                    float gx, gy;
+                    akd_deriv(tp[n], d_mid, d_norm, &gx, &gy);
+                    const float vx = gx * L.fs, vy = gy * L.fs;
+                    smp[p] = make_float4(ri[n], -vx * si + vy * co /* rrx */, vx * co + vy * si /* rry */, 0.0f);
                 }
             }
-        }
+        };
+        mldb_samples(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+        mldb_samples(std::integral_constant<int, 4>{}, std::integral_constant<int, 3>{});
         AKD_LDS_SYNC();
         if (lane < 29) {
             const int i0 = k_mldb_cell[lane][1], j0 = k_mldb_cell[lane][2], step = k_mldb_cell[lane][3];
