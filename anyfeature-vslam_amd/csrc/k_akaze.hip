@@ -776,8 +776,10 @@ __global__ __launch_bounds__(AKZ_T) void k_akz_hessian(const float *__restrict__
 // crossbar change nothing.  A variant with 64-ALIGNED strips in which every lane loads its five taps x - 2S .. x + 2S itself and
 // evaluates the first-derivative filters at x - S, x, x + S (no lane crossing, full-line stores, bit-identical) was built and is
 // SLOWER: 285 / 305-320 / 366 us - five loads per row instead of one put the time into cache round trips.  Dropped.
+#ifndef AKZ_DH_ROWS
 #define AKZ_DH_ROWS 64  // rows per strip (+ 4S rows of run-in).  Round 4 sweep, 64 frames of 1280 x 720, all eight levels: 64 rows 1.36 ms,
                        // 96: 1.39, 128: 1.42, 180: 1.50, 240: 1.74, 360: 2.08 (fewer, longer wavefronts lose more than the run-in costs)
+#endif
 // SD: also store the (unscaled) first derivatives.  The pipeline does not (round 5): their only reader is the descriptor stage, which
 // evaluates them at its sample positions from Lsmooth (k_akaze_desc.hip) - 8 of this kernel's 16 B per pixel were written for a plane
 // of which under a tenth is ever read.  SD = true serves afv_akaze_get_plane (and keeps the fused Lx / Ly under the plane tests).

@@ -88,7 +88,8 @@ int afv_akaze_extract(afv_akaze *a, const uint8_t *gray, int nframes, int w, int
 int afv_akaze_extract_device(afv_akaze *a, const uint8_t *d_gray, int nframes, int w, int h, int stride, size_t frame_stride);
 int afv_akaze_get_quotas(const afv_akaze *a, int32_t *quota16);
 
-/* test / inspection access (synchronises) */
+/* test / inspection access (synchronises).  LX / LY have no planes on the device (the pipeline keeps them in registers): they are
+ * produced for the requested frame by the pipeline's own kernel at the time of the call. */
 int afv_akaze_get_plane(afv_akaze *a, int frame, int level, int which, float *out);
 int afv_akaze_get_kcontrast(afv_akaze *a, int frame, float *out);
 /* 1 = conductivity and every FED step as separate kernels (upstream's structure), 0 = one fused kernel per level (default);

@@ -130,7 +130,7 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
 fr, wr = cal.get("fetch_ratio_4B") or 0.5, cal.get("write_ratio_4B") or 1.0
 def mb(d):
     return (d.get("FETCH_SIZE", 0.0) * 1024 / fr + d.get("WRITE_SIZE", 0.0) * 1024 / wr) / (B * steps) / 1e6
-res = {"frames": B, "scale_space_calls": steps, "hbm_MB_per_frame": mb(tot), "algorithmic_MB_per_frame": 126.2592,
+res = {"frames": B, "scale_space_calls": steps, "hbm_MB_per_frame": mb(tot), "algorithmic_MB_per_frame": 89.3952,
        "per_kernel_MB_per_frame": {k: round(mb(v), 2) for k, v in sorted(per_kernel.items())}}
 res["ratio_to_algorithmic"] = res["hbm_MB_per_frame"] / res["algorithmic_MB_per_frame"]
 json.dump(res, open(out + "/akaze_traffic_pmc.json", "w"), indent=1)
