@@ -160,6 +160,10 @@ class AkazeContext:
     def set_step_by_step(self, on=True):
         self.check(self.lib.afv_akaze_set_step_by_step(self.handle, int(on)), "afv_akaze_set_step_by_step")
 
+    def set_suppress_engine(self, mode=2, pass_cap=0):
+        """ordered duplicate suppression: 0 = speculative rounds, 1 = fixed point, 2 = fixed point with fallback (default)"""
+        self.check(self.lib.afv_akaze_set_suppress_engine(self.handle, int(mode), int(pass_cap)), "afv_akaze_set_suppress_engine")
+
     def profile_enable(self, on=True):
         self.check(self.lib.afv_akaze_profile_enable(self.handle, int(on)), "afv_akaze_profile_enable")
 

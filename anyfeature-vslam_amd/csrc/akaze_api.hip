@@ -49,6 +49,9 @@ struct afv_akaze {
     int sel_cap = 0, out_cap = 0, qt_M = 0;
     int quota[16] = {};
     bool step_by_step = false;  // test hook: one kernel per FED step instead of the fused level kernel
+    int suppress_mode = 2;      // ordered duplicate suppression: 0 = speculative rounds, 1 = fixed point, 2 = fixed point, falling back to 0
+                                // for a batch in which a candidate has more than AKF_K earlier in-range candidates (or the pass bound is hit)
+    bool detect_fallback = false;  // this scale space already needed the fallback
     bool profiling = false;
     hipEvent_t ev[3] = {};
     float ms_ss = 0, ms_hess = 0;
@@ -283,6 +286,13 @@ extern "C" int afv_akaze_create(int device, const afv_akaze_params *prm, afv_aka
         if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.ticket, (size_t)8 + 16 * B);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.used, (size_t)16 * B);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.chunk_cnt, (size_t)(AKD_SLOT_CAP / 1024) * B);
+        // fixed-point engine
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.fp_nbr, (size_t)AKD_SLOT_CAP * AKF_K * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.fp_state, (size_t)AKD_SLOT_CAP * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.fp_succ, (size_t)AKD_SLOT_CAP * 3 * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.fp_active, (size_t)AKD_SLOT_CAP * 2 * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.fp_ctl, (size_t)AKF_CTL * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.wpre, rows * 32 * B);
     }
     {   // quadtree quotas (FeatureExtractor.cpp:97-108) for nfeatures / scaleFactor / nlevels of the akaze61 settings
         const int nl = plan.nlevels;
@@ -335,6 +345,7 @@ static int akz_enqueue(afv_akaze *a, const uint8_t *d_gray, int nframes, int w, 
     a->cur_frames = nframes;
     a->have_scale_space = true;
     a->have_keypoints = false;
+    a->detect_fallback = false;
     const afv_akaze_plan &P = a->plan;
     hipStream_t st = a->stream;
     const int nb = a->prm.kcontrast_nbins;
@@ -531,8 +542,10 @@ static int akz_detect_enqueue(afv_akaze *a) {
         a->ds.epoch = 0;
     }
     ++a->ds.epoch;
-    afv_akz_launch_candidates(&D, a->cur_frames, a->d_mask, a->d_row_start, a->d_cand, a->d_cand_resp, a->d_cand_count, a->d_status, st);
-    afv_akz_launch_suppress(&D, &a->ds, a->cur_frames, a->d_cand, a->d_cand_resp, a->d_cand_count, a->d_row_start, a->d_kps, a->d_kp_count, a->d_status, st);
+    const int engine = (a->suppress_mode == 0 || a->detect_fallback) ? 0 : 1;
+    afv_akz_launch_candidates(&D, a->cur_frames, a->d_mask, a->d_row_start, a->ds.wpre, a->d_cand, a->d_cand_resp, a->d_cand_count, a->d_status, st);
+    afv_akz_launch_suppress(&D, &a->ds, a->cur_frames, engine, a->d_mask, a->d_cand, a->d_cand_resp, a->d_cand_count, a->d_row_start, a->d_kps,
+                            a->d_kp_count, a->d_status, st);
     AKZ_HIPCHK(a, hipGetLastError());
     a->have_keypoints = true;
     a->have_descriptors = false;
@@ -545,17 +558,32 @@ extern "C" int afv_akaze_detect(afv_akaze *a) {
     return akz_detect_enqueue(a);
 }
 
+static const char *akz_status_text(int st) {
+    return st == 1 ? "candidate capacity exceeded" : st == 2 ? "grid cell capacity exceeded" : st == 3 ? "keypoint list capacity exceeded"
+           : st == 6 ? "fixed-point suppression: more than AKF_K earlier in-range candidates" : st == 7 ? "fixed-point suppression: pass bound hit"
+           : "output capacity exceeded";
+}
+static int akz_describe_enqueue(afv_akaze *a);
 static int akz_status(afv_akaze *a) {
     int st = 0;
     AKZ_HIPCHK(a, hipStreamSynchronize(a->stream));
     AKZ_HIPCHK(a, hipMemcpy(&st, a->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    if ((st == 6 || st == 7) && a->suppress_mode == 2 && !a->detect_fallback) {
+        // the fixed-point engine gave up on this batch: the same scale space goes through the ordered-rounds engine
+        const bool desc = a->have_descriptors;
+        a->detect_fallback = true;
+        int rc = akz_detect_enqueue(a);
+        if (rc == AFV_OK && desc) rc = akz_describe_enqueue(a);
+        if (rc) return rc;
+        AKZ_HIPCHK(a, hipStreamSynchronize(a->stream));
+        AKZ_HIPCHK(a, hipMemcpy(&st, a->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    }
     if (st == 5) {  // not a capacity problem: an earlier ticket holder of the level pipeline did not move for ~1 s (k_akaze_detect.hip)
         a->last_error = "level pipeline stalled (suppression): the device was preempted or is being profiled; repeat the call";
         return AFV_ETIMEOUT;
     }
     if (st) {
-        a->last_error = st == 1 ? "candidate capacity exceeded" : st == 2 ? "grid cell capacity exceeded" : st == 3 ? "keypoint list capacity exceeded"
-                        : "output capacity exceeded";
+        a->last_error = akz_status_text(st);
         return AFV_ECAPACITY;
     }
     return AFV_OK;
@@ -697,7 +725,7 @@ extern "C" int afv_akaze_extract(afv_akaze *a, const uint8_t *gray, int nframes,
     }
     rc = akz_enqueue(a, a->d_gray, nframes, w, h, w, img);
     if (rc) return rc;
-    for (int attempt = 0; attempt < 2; ++attempt) {  // a stalled level pipeline (AFV_ETIMEOUT) is repeated once: the scale space is still there
+    for (int attempt = 0; attempt < 3; ++attempt) {  // a stalled level pipeline (AFV_ETIMEOUT) is repeated once: the scale space is still there
         rc = akz_detect_enqueue(a);
         if (rc) return rc;
         rc = akz_describe_enqueue(a);
@@ -713,9 +741,13 @@ extern "C" int afv_akaze_extract(afv_akaze *a, const uint8_t *gray, int nframes,
             rc = AFV_ETIMEOUT;
             continue;
         }
+        if ((status == 6 || status == 7) && a->suppress_mode == 2 && !a->detect_fallback) {
+            a->detect_fallback = true;  // the fixed-point engine gave up on this batch: once more through the ordered rounds
+            rc = AFV_ECAPACITY;
+            continue;
+        }
         if (status) {
-            a->last_error = status == 1 ? "candidate capacity exceeded" : status == 2 ? "grid cell capacity exceeded" : status == 3 ? "keypoint list capacity exceeded"
-                            : "output capacity exceeded";
+            a->last_error = akz_status_text(status);
             rc = AFV_ECAPACITY;
         } else {
             rc = AFV_OK;
@@ -750,6 +782,15 @@ extern "C" int afv_akaze_extract_device(afv_akaze *a, const uint8_t *d_gray, int
 extern "C" int afv_akaze_get_quotas(const afv_akaze *a, int32_t *quota16) {
     if (!a || !quota16) return AFV_EINVAL;
     for (int l = 0; l < 16; ++l) quota16[l] = a->quota[l];
+    return AFV_OK;
+}
+
+// 0 = ordered speculative rounds (k_akz_suppress), 1 = fixed point (k_akz_fp_*), 2 = fixed point with fallback (default); pass_cap > 0
+// bounds the fixed point's passes (test hook: 1 forces the fallback / the error)
+extern "C" int afv_akaze_set_suppress_engine(afv_akaze *a, int mode, int pass_cap) {
+    if (!a || mode < 0 || mode > 2) return AFV_EINVAL;
+    a->suppress_mode = mode;
+    a->ds.fp_pass_cap = pass_cap > 0 ? pass_cap : 0;
     return AFV_OK;
 }
 

@@ -45,7 +45,23 @@ struct AkdState {
     int *chunk_cnt;           // [frame][AKD_CHUNKS] refined keypoints per 1024-slot chunk
     unsigned char *keep;      // [frame][entry_cap]  (set to 1 before the launch; the upper-level filter clears)
     unsigned int epoch;       // 1 .. AKD_EPOCH_MAX, changes with every launch
+    // fixed-point engine (round 5, k_akz_fp_*): everything indexed by a candidate's position in upstream's loop order
+    // (gid = candidates of the levels below + index inside its level), [frame][entry_cap]
+    int *fp_nbr;              // x AKF_K: the EARLIER candidates (same level / level below) inside the candidate's radius
+    int4 *fp_state;           // {what the candidate does: AKF_APPEND, AKF_DROP or the gid of the holder it replaces; its entry's slot = root gid;
+                              //  response; -}
+    int *fp_succ;             // x 3 (rotating): smallest gid that replaces this candidate, AKF_NONE if none
+    int4 *fp_active;          // x 2: the candidates with at least one such neighbour (any order): {gid, count, response, act} {root, n0, n1, n2}
+    int *fp_ctl;              // [frame][AKF_CTL]: how many of those | the pass that found the frame converged | per pass: changed something
+    unsigned short *wpre;     // [frame][rows_stride][AKD_MAXCHUNKS] candidates of the row in front of the 64-column word (k_akz_cand_emit)
+    int fp_pass_cap;
 };
+#define AKF_K 16
+#define AKF_PASSES 12  // pass launches enqueued per call (the bench frames need 8)
+#define AKF_CTL (2 + AKF_PASSES + 2)
+#define AKF_APPEND (-1)
+#define AKF_DROP (-2)
+#define AKF_NONE 0x7fffffff
 
 struct AksParams {
     int nlevels, W, H, n_ini;
@@ -84,11 +100,12 @@ extern "C" int afv_akz_launch_fed_gauss(const float *Lt_in, float *lsm, const fl
 extern "C" int afv_akz_launch_hessian(const float *lsm, int w, int h, int nframes, int s, int two_kernels, float *dx, float *dy,
                                       float *Ldet, hipStream_t st);
 
-extern "C" void afv_akz_launch_candidates(const AkdParams *P, int nframes, unsigned long long *mask, int *row_start, int *cand, float *cand_resp,
-                                          int *cand_count, int *status, hipStream_t st);
-extern "C" void afv_akz_launch_suppress(const AkdParams *P, const AkdState *S, int nframes, const int *cand, const float *cand_resp,
-                                        const int *cand_count, const int *row_start,
-                                        afv_keypoint *kps, int *kp_count, int *status, hipStream_t st);
+extern "C" void afv_akz_launch_candidates(const AkdParams *P, int nframes, unsigned long long *mask, int *row_start, unsigned short *wpre, int *cand,
+                                          float *cand_resp, int *cand_count, int *status, hipStream_t st);
+// engine: 0 = ordered speculative rounds (k_akz_suppress), 1 = fixed point (k_akz_fp_build + k_akz_fp_resolve); identical results
+extern "C" void afv_akz_launch_suppress(const AkdParams *P, const AkdState *S, int nframes, int engine, const unsigned long long *mask, const int *cand,
+                                        const float *cand_resp, const int *cand_count, const int *row_start, afv_keypoint *kps, int *kp_count,
+                                        int *status, hipStream_t st);
 extern "C" size_t afv_akz_select_lds_bytes(int M);
 extern "C" void afv_akz_launch_select(const AksParams *P, int nframes, const afv_keypoint *kps, const int *kp_count, int *lvl_idx,
                                       uint16_t *lvl_node, int *sel, int *sel_count, hipStream_t st);

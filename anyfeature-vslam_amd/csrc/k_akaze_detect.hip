@@ -130,8 +130,8 @@ __global__ __launch_bounds__(256) void k_akz_cand_mask(AkdParams P, AkmWork W, i
 // fetches |response| for the emitted indices (independent loads; fetched inside the expansion they serialised it)
 #define AKE_T 1024
 __global__ __launch_bounds__(AKE_T) void k_akz_cand_emit(AkdParams P, const unsigned long long *__restrict__ mask, int *__restrict__ row_start,
-                                                       int *__restrict__ cand, float *__restrict__ cand_resp, int *__restrict__ cand_count,
-                                                       int *__restrict__ status) {
+                                                       unsigned short *__restrict__ wpre, int *__restrict__ cand, float *__restrict__ cand_resp,
+                                                       int *__restrict__ cand_count, int *__restrict__ status) {
     __shared__ int s_w[AKE_T / 64];
     const int level = blockIdx.x, f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const AkdLevel L = P.lv[level];
@@ -194,6 +194,9 @@ __global__ __launch_bounds__(AKE_T) void k_akz_cand_emit(AkdParams P, const unsi
             const int cnt = __popcll(m);
             const int in = afv_wave_incl_scan(cnt);
             int o = ro[u] + in - cnt;
+            // candidates of the row in front of this word: the fixed-point engine turns a bitmap position into a candidate index with it
+            if (wpre && lane < nchunks && r0 + u < L.h)
+                wpre[((size_t)f * P.rows_stride + L.row_off + r0 + u) * AKD_MAXCHUNKS + lane] = (unsigned short)(in - cnt);
             const int idx0 = (r0 + u) * L.w + (lane << 6);
             while (m) {
                 const int bit = (int)__builtin_ctzll(m);
@@ -676,6 +679,294 @@ __global__ __launch_bounds__(AKD_T, 8) void k_akz_suppress(AkdParams P, AkdState
 #endif
 }
 
+// ---------------- ordered suppression as a FIXED POINT (round 5): all candidates of all frames at once ----------------
+// What upstream's loop does to candidate c (in loop order: level-major, raster inside a level) depends on the list as the candidates
+// before it left it: c looks for the FIRST list entry (smallest slot) of its own level or the level below inside its radius; none ->
+// c is appended (a new slot); one with a smaller response -> c takes over that slot (the entry now IS c: position, level, response);
+// else c is dropped.  An entry is always "the candidate that holds the slot now", so the whole state is a function of what every
+// candidate did:   act(c) in {APPEND, DROP, REPLACE(j)},  j = the holder c pushed out.
+//   * j holds its slot at time c   <=>  act(j) != DROP and no candidate before c replaced j        (succ(j) = the smallest such, >= c)
+//   * slot order = order of the candidates that opened the slots: slot(j) = root(j), root(c) = c if APPEND, root(j) if REPLACE(j)
+//   * act(c) = f(the holders at time c among c's EARLIER IN-RANGE candidates): the one with the smallest root decides.
+// act(c) only depends on candidates before c, so (induction on c) ANY assignment that satisfies all equations is the loop's outcome -
+// and iterating "every candidate re-evaluates f against the current state" reaches it in (longest chain of decisions that depend on
+// each other) + 1 passes, in any evaluation order (a pass that changes nothing has evaluated every equation against the final state).
+// Strict 3 x 3 maxima lie at least two pixels apart and the radii are 2.4 - 4.8 pixels of the level scanned: a candidate has 0.6 - 0.8
+// earlier in-range candidates on average (at most a few) and the chains are short: 8 passes on the bench frames (40 k candidates) and
+// on band-limited noise (52 k), where the speculative rounds of k_akz_suppress need ~330 rounds of 5 barriers each on a pipeline of
+// eight workgroups per frame.  The in-range candidates are found in the candidate BITMAPS (k_akz_cand_mask), once: no grids, no lists
+// that grow, no hand-off between levels, nothing that depends on where or when a workgroup runs.
+//   k_akz_fp_build    per candidate: its earlier in-range candidates (bitmap windows of its level and the level below; exact float
+//                     test, upstream's expression) as gids; start state APPEND; the candidates that have any form the active list
+//   k_akz_fp_pass     one launch per pass over the active candidates of ALL frames (a kernel boundary is the only synchronisation a
+//                     pass needs); the succ arrays rotate read / write / clear; a frame whose previous pass changed nothing is done,
+//                     its workgroups leave at once.  AKF_PASSES launches are enqueued; a frame that needs more reports status 7.
+//   k_akz_fp_entries  the list: slot = root gid (same layout as k_akz_suppress's), keep = "this candidate opened a slot"
+//   k_akz_fp_upper    the upper-level filter, again from the bitmap of the level above.
+// Both engines leave entry / keep / used for k_akz_refine_a / _b; tests/test_gpu_akaze.py runs every case through both.
+#define AKF_T 256
+#define AKF_ROWS 12   // bitmap rows fetched together (a window is at most 2 * 4.8 + 2 rows high with the akaze61 radii; more rows: another group)
+#define AKF_ROWS_UP 6  // ... of the rows up to the candidate's own (same level: radius <= 4.04 rows)
+
+// the candidates of level G (bitmap rows mk, row starts rs, word prefixes wp) inside the disc (sx, sy, size2): rows up to y_last, on row
+// y_last only the columns up to x_last (same level: the candidates in front of c); visit(index inside the level).  A window is at most
+// 13 columns wide: one or two 64-bit words per row, all rows' words in flight together.
+template <int ROWS, typename F>
+__device__ __forceinline__ void akf_scan(const AkdLevel &G, const unsigned long long *__restrict__ mk, const int *__restrict__ rs,
+                                         const unsigned short *__restrict__ wp, float sx, float sy, float rq, float size2, int y_last, int x_last,
+                                         F visit) {
+    const int xa = max((int)floorf((sx - rq) / G.ratio), 0), xb = min((int)((sx + rq) / G.ratio) + 1, G.w - 1);
+    const int ya = max((int)floorf((sy - rq) / G.ratio), 0), yb = min(min((int)((sy + rq) / G.ratio) + 1, G.h - 1), y_last);
+    if (xa > xb) return;
+    const int w0 = xa >> 6, w1 = min(xb >> 6, w0 + 1);  // (a window wider than 64 columns would need more: not with these radii)
+    for (int yg = ya; yg <= yb; yg += ROWS) {
+        unsigned long long m0[ROWS], m1[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int y = min(yg + r, yb);
+            m0[r] = yg + r <= yb ? mk[(size_t)y * AKD_MAXCHUNKS + w0] : 0ull;
+            m1[r] = (w1 != w0 && yg + r <= yb) ? mk[(size_t)y * AKD_MAXCHUNKS + w1] : 0ull;  // one window in five straddles two words
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int y = yg + r;
+            if (y > yb) break;
+            const int xe = (y == y_last) ? min(xb, x_last) : xb;
+            if (xa > xe) continue;
+            const float ay = (float)y * G.ratio, dy = sy - ay;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int wd = h ? w1 : w0;
+                if (h && w1 == w0) break;
+                if ((wd << 6) > xe) break;
+                const unsigned long long full = h ? m1[r] : m0[r];
+                const int lo = max(xa - (wd << 6), 0), hi = min(xe - (wd << 6), 63);
+                unsigned long long m = full & (~0ull << lo) & (~0ull >> (63 - hi));
+                while (m) {
+                    const int b = (int)__builtin_ctzll(m);
+                    m &= m - 1;
+                    const float ax = (float)((wd << 6) + b) * G.ratio, dx = sx - ax;
+                    if (dx * dx + dy * dy <= size2)
+                        visit(rs[y] + (int)wp[(size_t)y * AKD_MAXCHUNKS + wd] + __popcll(full & ((1ull << b) - 1ull)));
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void akf_bases(const int *__restrict__ cand_count, int f, int NL, int *s_base) {
+    if (threadIdx.x == 0) {
+        int b = 0;
+        for (int k = 0; k < NL; ++k) {
+            s_base[k] = b;
+            b += cand_count[f * 16 + k];
+        }
+        for (int k = NL; k < 17; ++k) s_base[k] = b;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(AKF_T) void k_akz_fp_build(AkdParams P, AkdState S, const unsigned long long *__restrict__ mask,
+                                                        const int *__restrict__ row_start, const int *__restrict__ cand,
+                                                        const float *__restrict__ cand_resp, const int *__restrict__ cand_count,
+                                                        int *__restrict__ status) {
+    const int c = blockIdx.x, f = blockIdx.y, part = blockIdx.z, nparts = gridDim.z, tid = threadIdx.x, lane = tid & 63;
+    const AkdLevel L = P.lv[c];
+    const AkdLevel Lp = P.lv[c > 0 ? c - 1 : 0];
+    const int n = cand_count[f * 16 + c];
+    int base = 0, base_prev = 0;
+    for (int k = 0; k < c; ++k) {
+        base_prev = base;
+        base += cand_count[f * 16 + k];
+    }
+    if (base + n > P.entry_cap) {
+        if (tid == 0) atomicExch(status, 3);
+        return;
+    }
+    const unsigned long long *mk = mask + ((size_t)f * P.rows_stride + L.row_off) * AKD_MAXCHUNKS;
+    const unsigned long long *mkp = mask + ((size_t)f * P.rows_stride + Lp.row_off) * AKD_MAXCHUNKS;
+    const int *rs = row_start + (size_t)f * P.rows_stride + L.row_off, *rsp = row_start + (size_t)f * P.rows_stride + Lp.row_off;
+    const unsigned short *wp = S.wpre + ((size_t)f * P.rows_stride + L.row_off) * AKD_MAXCHUNKS;
+    const unsigned short *wpp = S.wpre + ((size_t)f * P.rows_stride + Lp.row_off) * AKD_MAXCHUNKS;
+    const int *cd = cand + (size_t)f * P.cand_stride + L.cand_off;
+    const float *cr = cand_resp + (size_t)f * P.cand_stride + L.cand_off;
+    const size_t fo = (size_t)f * P.entry_cap;
+    const float size2 = L.psize * L.psize, rq = L.psize * 1.0001f + 1e-3f;
+    for (int kb = part * AKF_T; kb < n; kb += nparts * AKF_T) {  // uniform trip count per workgroup
+        const int k = kb + tid;
+        bool active = false;
+        int my_cnt = 0;
+        float my_resp = 0.f;
+        if (k < n) {
+            const int idx = cd[k], iy = idx / L.w, jx = idx - iy * L.w;
+            const float sx = (float)jx * L.ratio, sy = (float)iy * L.ratio;
+            const int gid = base + k;
+            int *list = S.fp_nbr + (fo + gid) * AKF_K;
+            int cnt = 0;
+            // the FIRST entry in slot order decides, and slot order is the order of the roots: the order inside the list does not matter
+            if (c > 0)
+                akf_scan<AKF_ROWS>(Lp, mkp, rsp, wpp, sx, sy, rq, size2, Lp.h - 1, Lp.w - 1, [&](int g) {
+                    if (cnt < AKF_K) list[cnt] = base_prev + g;
+                    ++cnt;
+                });
+            akf_scan<AKF_ROWS_UP>(L, mk, rs, wp, sx, sy, rq, size2, iy, jx - 1, [&](int g) {
+                if (cnt < AKF_K) list[cnt] = base + g;
+                ++cnt;
+            });
+            if (cnt > AKF_K) atomicExch(status, 6);
+            my_cnt = min(cnt, AKF_K);
+            my_resp = cr[k];
+            S.fp_state[fo + gid] = make_int4(AKF_APPEND, gid, __float_as_int(my_resp), 0);
+            S.fp_succ[fo * 3 + gid] = AKF_NONE;
+            S.fp_succ[fo * 3 + P.entry_cap + gid] = AKF_NONE;
+            S.fp_succ[fo * 3 + 2 * (size_t)P.entry_cap + gid] = AKF_NONE;
+            active = cnt > 0;
+        }
+        const unsigned long long am = __ballot(active);
+        int o = 0;
+        if (lane == 0 && am) o = atomicAdd(S.fp_ctl + (size_t)f * AKF_CTL, __popcll(am));
+        o = __shfl(o, 0, 64);
+        if (active) {  // the candidate's record: what a pass needs of it in one 32-byte load (the first three neighbours inline)
+            const int *list = S.fp_nbr + (fo + base + k) * AKF_K;
+            int4 *rec = S.fp_active + (fo + o + __popcll(am & ((1ull << lane) - 1ull))) * 2;
+            rec[0] = make_int4(base + k, my_cnt, __float_as_int(my_resp), AKF_APPEND);
+            rec[1] = make_int4(base + k, list[0], my_cnt > 1 ? list[1] : 0, my_cnt > 2 ? list[2] : 0);
+        }
+    }
+}
+
+// fp_ctl[frame][AKF_CTL]: [0] active candidates, [1] the pass that found the frame converged (0: not yet), [2 + p] pass p changed something
+__global__ __launch_bounds__(AKF_T) void k_akz_fp_pass(AkdParams P, AkdState S, int pass) {
+    const int f = blockIdx.y, tid = threadIdx.x;
+    int *ctl = S.fp_ctl + (size_t)f * AKF_CTL;
+    if (pass > 0) {
+        if (ctl[1] != 0) return;      // converged in an earlier pass
+        if (ctl[2 + pass - 1] == 0) {  // the previous pass changed nothing: every equation holds
+            if (blockIdx.x == 0 && tid == 0) ctl[1] = pass;
+            return;
+        }
+    }
+    const size_t fo = (size_t)f * P.entry_cap;
+    int4 *state = S.fp_state + fo;
+    const int *nbr = S.fp_nbr + fo * AKF_K;
+    int4 *recs = S.fp_active + fo * 2;
+    const int nact = min(ctl[0], P.entry_cap);
+    int *succ0 = S.fp_succ + fo * 3;
+    // pass p: reads succ[p % 3] (written in pass p - 1), writes succ[(p + 1) % 3], clears succ[(p + 2) % 3] (every index a pass can write
+    // is an earlier neighbour of an active candidate: clearing those is clearing everything)
+    const int *sR = succ0 + (size_t)(pass % 3) * P.entry_cap;
+    int *sW = succ0 + (size_t)((pass + 1) % 3) * P.entry_cap, *sC = succ0 + (size_t)((pass + 2) % 3) * P.entry_cap;
+    bool changed = false;
+    for (int i = blockIdx.x * AKF_T + tid; i < nact; i += gridDim.x * AKF_T) {
+        const int4 r0 = recs[2 * i], r1 = recs[2 * i + 1];  // {gid, count, response, act} {root, n0, n1, n2}
+        const int c = r0.x, cn = r0.y;
+        const int *list = nbr + (size_t)c * AKF_K;
+        int best = -1, best_root = AKF_NONE, best_resp = 0;
+        for (int k = 0; k < cn; ++k) {
+            const int j = k == 0 ? r1.y : k == 1 ? r1.z : k == 2 ? r1.w : list[k];
+            const int4 sj = state[j];  // {act, root, response, -}
+            const int su = sR[j];
+            sC[j] = AKF_NONE;
+            if (sj.x != AKF_DROP && su >= c && sj.y < best_root) {
+                best_root = sj.y;
+                best = j;
+                best_resp = sj.z;
+            }
+        }
+        int2 nw;
+        if (best < 0) nw = make_int2(AKF_APPEND, c);
+        else if (__int_as_float(r0.z) > __int_as_float(best_resp)) nw = make_int2(best, best_root);
+        else nw = make_int2(AKF_DROP, c);
+        if (nw.x != r0.w || nw.y != r1.x) {
+            recs[2 * i].w = nw.x;
+            recs[2 * i + 1].x = nw.y;
+            *reinterpret_cast<int2 *>(state + c) = nw;
+            changed = true;
+        }
+        if (nw.x >= 0) __hip_atomic_fetch_min(sW + nw.x, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (changed) ctl[2 + pass] = 1;
+}
+
+// which succ array describes the final state: the one the last executed pass wrote.  -1: the frame did not converge in AKF_PASSES passes
+__device__ __forceinline__ int akf_final(const int *ctl, int npass) {
+    int q = ctl[1];
+    if (q == 0 && ctl[2 + npass - 1] == 0) q = npass;  // the last launch was the pass that changed nothing
+    return q == 0 ? -1 : q % 3;
+}
+
+__global__ __launch_bounds__(AKF_T) void k_akz_fp_entries(AkdParams P, AkdState S, const int *__restrict__ cand, const int *__restrict__ cand_count,
+                                                          int npass, int *__restrict__ status) {
+    __shared__ int s_base[17];
+    const int f = blockIdx.y, tid = threadIdx.x, NL = P.nlevels;
+    akf_bases(cand_count, f, NL, s_base);
+    const int total = s_base[NL];
+    if (total > P.entry_cap) return;  // k_akz_fp_build reported it
+    const int *ctl = S.fp_ctl + (size_t)f * AKF_CTL;
+    const int fin = akf_final(ctl, npass);
+    if (fin < 0) {
+        if (blockIdx.x == 0 && tid == 0) atomicExch(status, 7);
+        return;
+    }
+    const size_t fo = (size_t)f * P.entry_cap;
+    const int4 *state = S.fp_state + fo;
+    const int *sF = S.fp_succ + fo * 3 + (size_t)fin * P.entry_cap;
+    float4 *entry = S.entry + fo;
+    unsigned char *keep = S.keep + fo;
+    if (blockIdx.x == 0 && tid < NL) S.used[f * 16 + tid] = cand_count[f * 16 + tid];
+    // slot = root gid: a slot exists for every candidate that appended, its entry is the candidate that holds it at the end
+    for (int g = blockIdx.x * AKF_T + tid; g < total; g += gridDim.x * AKF_T) {
+        int lv = 0;
+        while (g >= s_base[lv + 1]) ++lv;
+        const int4 st = state[g];
+        keep[g] = st.x == AKF_APPEND ? 1 : 0;
+        if (st.x != AKF_DROP && sF[g] == AKF_NONE) {
+            const AkdLevel &L = P.lv[lv];
+            const int idx = cand[(size_t)f * P.cand_stride + L.cand_off + (g - s_base[lv])];
+            const int iy = idx / L.w, jx = idx - iy * L.w;
+            entry[st.y] = make_float4((float)jx * L.ratio, (float)iy * L.ratio, __int_as_float(st.z), __int_as_float(lv));
+        }
+    }
+}
+
+// "Now filter points with the upper scale level": entry i (holder a, level A) is repeated if a LATER entry (slot > i) of level A + 1
+// lies within size_A of it and has a larger response
+__global__ __launch_bounds__(AKF_T) void k_akz_fp_upper(AkdParams P, AkdState S, const unsigned long long *__restrict__ mask,
+                                                        const int *__restrict__ row_start, const int *__restrict__ cand,
+                                                        const int *__restrict__ cand_count, int npass) {
+    __shared__ int s_base[17];
+    const int f = blockIdx.y, tid = threadIdx.x, NL = P.nlevels;
+    akf_bases(cand_count, f, NL, s_base);
+    const int total = s_base[NL];
+    if (total > P.entry_cap) return;
+    const int fin = akf_final(S.fp_ctl + (size_t)f * AKF_CTL, npass);
+    if (fin < 0) return;
+    const size_t fo = (size_t)f * P.entry_cap;
+    const int4 *state = S.fp_state + fo;
+    const int *sF = S.fp_succ + fo * 3 + (size_t)fin * P.entry_cap;
+    unsigned char *keep = S.keep + fo;
+    for (int g = blockIdx.x * AKF_T + tid; g < s_base[NL - 1]; g += gridDim.x * AKF_T) {  // the last level has no level above
+        int lv = 0;
+        while (g >= s_base[lv + 1]) ++lv;
+        const int4 st = state[g];
+        if (st.x == AKF_DROP || sF[g] != AKF_NONE) continue;
+        const AkdLevel &A = P.lv[lv], &B = P.lv[lv + 1];
+        const int idx = cand[(size_t)f * P.cand_stride + A.cand_off + (g - s_base[lv])];
+        const int iy = idx / A.w, jx = idx - iy * A.w;
+        const float x = (float)jx * A.ratio, y = (float)iy * A.ratio, r = __int_as_float(st.z);
+        const unsigned long long *mkb = mask + ((size_t)f * P.rows_stride + B.row_off) * AKD_MAXCHUNKS;
+        const int *rsb = row_start + (size_t)f * P.rows_stride + B.row_off;
+        const unsigned short *wpb = S.wpre + ((size_t)f * P.rows_stride + B.row_off) * AKD_MAXCHUNKS;
+        const int bb = s_base[lv + 1];
+        bool rep = false;
+        akf_scan<AKF_ROWS>(B, mkb, rsb, wpb, x, y, A.psize * 1.0001f + 1e-3f, A.psize * A.psize, B.h - 1, B.w - 1, [&](int gb) {
+            const int4 sb = state[bb + gb];
+            if (sb.x != AKF_DROP && sF[bb + gb] == AKF_NONE && sb.y > st.y && r < __int_as_float(sb.z)) rep = true;
+        });
+        if (rep) keep[st.y] = 0;
+    }
+}
+
 // ---------------- Do_Subpixel_Refinement + ordered compaction over the slot space, two passes ----------------
 // pass A: one thread per slot: level range -> used? kept? -> the 2x2 solve; the refined position goes back into ex / ey, the
 //         verdict into keep, the number of survivors of every 1024-slot chunk into chunk_cnt
@@ -785,8 +1076,8 @@ __global__ __launch_bounds__(AKD_CHUNK) void k_akz_refine_b(AkdParams P, AkdStat
     kps[(size_t)f * P.kp_cap + o] = k;
 }
 
-extern "C" void afv_akz_launch_candidates(const AkdParams *P, int nframes, unsigned long long *mask, int *row_start, int *cand, float *cand_resp,
-                                          int *cand_count, int *status, hipStream_t st) {
+extern "C" void afv_akz_launch_candidates(const AkdParams *P, int nframes, unsigned long long *mask, int *row_start, unsigned short *wpre, int *cand,
+                                          float *cand_resp, int *cand_count, int *status, hipStream_t st) {
     AkmWork W;
     int strips = 0;
     for (int l = 0; l < P->nlevels; ++l) {
@@ -795,18 +1086,32 @@ extern "C" void afv_akz_launch_candidates(const AkdParams *P, int nframes, unsig
     }
     for (int l = P->nlevels; l < 17; ++l) W.strip_off[l] = strips;
     hipLaunchKernelGGL(k_akz_cand_mask, dim3((strips + 3) / 4), dim3(256), 0, st, *P, W, nframes, mask);
-    hipLaunchKernelGGL(k_akz_cand_emit, dim3(P->nlevels, nframes), dim3(AKE_T), 0, st, *P, mask, row_start, cand, cand_resp, cand_count, status);
+    hipLaunchKernelGGL(k_akz_cand_emit, dim3(P->nlevels, nframes), dim3(AKE_T), 0, st, *P, mask, row_start, wpre, cand, cand_resp, cand_count, status);
 }
 
-extern "C" void afv_akz_launch_suppress(const AkdParams *P, const AkdState *S, int nframes, const int *cand, const float *cand_resp,
-                                        const int *cand_count, const int *row_start,
-                                        afv_keypoint *kps, int *kp_count, int *status, hipStream_t st) {
-    const size_t lds = (size_t)P->lds_bytes;  // list lengths (u8): a level's own grid + hints of the one below
-    (void)hipMemsetAsync(S->ticket, 0, (size_t)(8 + nframes * 16) * sizeof(int), st);
-    (void)hipMemsetAsync(S->keep, 1, (size_t)nframes * P->entry_cap, st);
-    const int nfx = (nframes + 7) / 8, G = nfx < 8 ? nfx : 8;  // frames per XCD list, group size (see the ticket decoding in the kernel)
-    const int blocks = (nfx + G - 1) / G * G * P->nlevels * 8;
-    hipLaunchKernelGGL(k_akz_suppress, dim3(blocks), dim3(AKD_T), lds, st, *P, *S, nframes, cand, cand_resp, cand_count, row_start, status);
+extern "C" void afv_akz_launch_suppress(const AkdParams *P, const AkdState *S, int nframes, int engine, const unsigned long long *mask, const int *cand,
+                                        const float *cand_resp, const int *cand_count, const int *row_start, afv_keypoint *kps, int *kp_count,
+                                        int *status, hipStream_t st) {
+    if (engine == 1) {
+        const int npass = S->fp_pass_cap > 0 ? (S->fp_pass_cap < AKF_PASSES ? S->fp_pass_cap : AKF_PASSES) : AKF_PASSES;
+        (void)hipMemsetAsync(S->fp_ctl, 0, (size_t)nframes * AKF_CTL * sizeof(int), st);
+        int per = 4096 / (nframes > 0 ? nframes : 1);  // workgroups per frame
+        per = per < 16 ? 16 : (per > 128 ? 128 : per);
+        int parts = per / P->nlevels;
+        parts = parts < 1 ? 1 : parts;
+        hipLaunchKernelGGL(k_akz_fp_build, dim3(P->nlevels, nframes, parts), dim3(AKF_T), 0, st, *P, *S, mask, row_start, cand, cand_resp, cand_count,
+                           status);
+        for (int p = 0; p < npass; ++p) hipLaunchKernelGGL(k_akz_fp_pass, dim3(per, nframes), dim3(AKF_T), 0, st, *P, *S, p);
+        hipLaunchKernelGGL(k_akz_fp_entries, dim3(per, nframes), dim3(AKF_T), 0, st, *P, *S, cand, cand_count, npass, status);
+        hipLaunchKernelGGL(k_akz_fp_upper, dim3(per, nframes), dim3(AKF_T), 0, st, *P, *S, mask, row_start, cand, cand_count, npass);
+    } else {
+        const size_t lds = (size_t)P->lds_bytes;  // list lengths (u8): a level's own grid + hints of the one below
+        (void)hipMemsetAsync(S->ticket, 0, (size_t)(8 + nframes * 16) * sizeof(int), st);
+        (void)hipMemsetAsync(S->keep, 1, (size_t)nframes * P->entry_cap, st);
+        const int nfx = (nframes + 7) / 8, G = nfx < 8 ? nfx : 8;  // frames per XCD list, group size (see the ticket decoding in the kernel)
+        const int blocks = (nfx + G - 1) / G * G * P->nlevels * 8;
+        hipLaunchKernelGGL(k_akz_suppress, dim3(blocks), dim3(AKD_T), lds, st, *P, *S, nframes, cand, cand_resp, cand_count, row_start, status);
+    }
     const int nchunks = (P->entry_cap + AKD_CHUNK - 1) / AKD_CHUNK;
     hipLaunchKernelGGL(k_akz_refine_a, dim3(nchunks, nframes), dim3(AKD_CHUNK), 0, st, *P, *S, cand_count);
     hipLaunchKernelGGL(k_akz_refine_b, dim3(nchunks, nframes), dim3(AKD_CHUNK), 0, st, *P, *S, kps, kp_count, status);

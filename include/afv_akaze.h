@@ -95,6 +95,11 @@ int afv_akaze_get_kcontrast(afv_akaze *a, int frame, float *out);
 /* 1 = conductivity and every FED step as separate kernels (upstream's structure), 0 = one fused kernel per level (default);
  * both produce identical planes (tests/test_gpu_akaze.py) */
 int afv_akaze_set_step_by_step(afv_akaze *a, int on);
+/* The ordered duplicate suppression of Find_Scale_Space_Extrema has two engines with identical results: 0 = the loop replayed in
+ * speculative rounds, 1 = a fixed point over all candidates of a frame (faster; gives up with AFV_ECAPACITY when a candidate has more
+ * than 16 earlier candidates inside its radius), 2 = engine 1, and engine 0 for a batch it gives up on (default).  pass_cap > 0 bounds
+ * the fixed point's passes (test hook). */
+int afv_akaze_set_suppress_engine(afv_akaze *a, int mode, int pass_cap);
 /* per-stage timing like afv_profile_*: stage 0 scale space, 1 hessian */
 int afv_akaze_profile_enable(afv_akaze *a, int on);
 int afv_akaze_profile_read(afv_akaze *a, float *ms_scale_space, float *ms_hessian, int *launches);

@@ -16,6 +16,19 @@ def akz():
     return akaze_binding
 
 
+@pytest.fixture(autouse=True, params=[1, 0], ids=["fixed_point", "ordered_rounds"])
+def suppress_engine(request, afv, monkeypatch):
+    """every case runs through both engines of the ordered duplicate suppression (afv_akaze_set_suppress_engine): 1 = the fixed point
+    WITHOUT its fallback, 0 = the speculative rounds of k_akz_suppress"""
+    init = afv.akaze.AkazeContext.__init__
+
+    def patched(self, *a, **k):
+        init(self, *a, **k)
+        self.set_suppress_engine(request.param)
+    monkeypatch.setattr(afv.akaze.AkazeContext, "__init__", patched)
+    return request.param
+
+
 def _oracle_plan(akz, plan):
     """feed the oracle the product's own evolution plan (sizes, FED steps, Gaussian taps): the stage comparisons below then do
     not depend on host libm details; the plans themselves are compared in test_plan_matches_oracle"""
@@ -155,7 +168,7 @@ def test_detection_matches_oracle(afv, akz, w, h, seeds):
     ctx.close()
 
 
-def test_level_pipeline_under_load(afv, akz):
+def test_level_pipeline_under_load(afv, akz, suppress_engine):
     """the eight levels of a frame are suppressed by eight workgroups that hand list state to each other (k_akaze_detect.hip):
     more workgroups than the chip holds at once, a chip that is busy with something else, repeated launches (the launch epoch in
     the list elements moves on) -> the same keypoints every time, and they are the oracle's"""
@@ -189,9 +202,11 @@ def test_level_pipeline_under_load(afv, akz):
     ctx.close()
 
 
-def test_detection_survives_the_epoch_wrap(afv):
+def test_detection_survives_the_epoch_wrap(afv, suppress_engine):
     """list elements of the suppression grids carry a 14-bit launch epoch; when it wraps the grids are wiped (akaze_api.hip).  More
     launches than that on one context: the keypoints never change"""
+    if suppress_engine != 0:
+        pytest.skip("the launch epoch belongs to the ordered-rounds engine")
     w, h = 160, 96
     ctx = afv.AkazeContext(afv.akaze.default_params(max_width=w, max_height=h, max_batch=2))
     ctx.scale_space(_frames(afv, w, h, (21, 22)))
@@ -333,3 +348,60 @@ def test_one_frame_per_call_equals_the_batch_path(afv):
     rc = sctx.lib.afv_akaze_extract(sctx.handle, pinned.data_ptr(), 1, w, h, w, 0, kps.ctypes.data, desc.ctypes.data, 1064, n.ctypes.data)
     assert rc == 0 and kps[:n[0]].tobytes() == batch[1][0].tobytes() and np.array_equal(desc[:n[0]], batch[1][1])
     bctx.close(); sctx.close()
+
+
+def _noise_frame(seed, w, h, sigma):
+    """band-limited noise: candidates everywhere instead of at the corners of a pattern (more, and differently clustered, neighbours)"""
+    rng = np.random.default_rng(seed)
+    k = np.exp(-0.5 * (np.arange(-8, 9) / sigma) ** 2)
+    k /= k.sum()
+    a = rng.random((h + 16, w + 16))
+    a = np.apply_along_axis(lambda r: np.convolve(r, k, "valid"), 1, a)
+    a = np.apply_along_axis(lambda c: np.convolve(c, k, "valid"), 0, a)
+    a = (a - a.min()) / (a.max() - a.min())
+    return (a * 2000.0 % 255.0).astype(np.uint8)
+
+
+@pytest.mark.parametrize("sigma", [1.0, 2.0])
+def test_suppression_on_dense_noise(afv, akz, sigma):
+    """the ordered suppression on frames whose candidates crowd each other: both engines against the oracle's sequential loop"""
+    w, h = 480, 360
+    frames = np.stack([_noise_frame(5, w, h, sigma), _noise_frame(6, w, h, sigma)])
+    ctx = afv.AkazeContext(afv.akaze.default_params(max_width=w, max_height=h, max_batch=2))
+    plan = ctx.scale_space(frames)
+    ctx.detect()
+    op = _oracle_plan(akz, plan)
+    for f in range(2):
+        levels, _ = akz.full_evolution(frames[f], op)
+        want = akz.subpixel(op, levels, akz.find_extrema(op, levels))
+        got = ctx.keypoints(f)
+        assert len(got) == len(want) and len(want) > 1500, (len(got), len(want))
+        for name in ("x", "y", "response", "class_id"):
+            assert np.array_equal(got[name], want[name]), (f, name)
+    ctx.close()
+
+
+def test_fixed_point_gives_up_loudly_or_falls_back(afv, suppress_engine):
+    """a pass bound of 1 cannot be enough: engine 1 reports it (AFV_ECAPACITY, never a wrong list), engine 2 repeats the batch through
+    the ordered rounds and returns their keypoints"""
+    if suppress_engine != 1:
+        pytest.skip("one run is enough")
+    w, h = 320, 200
+    frames = _frames(afv, w, h, (4, 5))
+    ctx = afv.AkazeContext(afv.akaze.default_params(max_width=w, max_height=h, max_batch=2))
+    ctx.scale_space(frames)
+    ctx.detect()
+    want = [ctx.keypoints(f).tobytes() for f in range(2)]
+    ctx.set_suppress_engine(1, pass_cap=1)
+    ctx.detect()
+    with pytest.raises(RuntimeError):
+        ctx.keypoints(0)
+    ctx.set_suppress_engine(2, pass_cap=1)
+    ctx.scale_space(frames)
+    ctx.detect()
+    assert [ctx.keypoints(f).tobytes() for f in range(2)] == want
+    kps, desc = ctx.extract(frames)[0]
+    ctx.set_suppress_engine(0)
+    kps0, desc0 = ctx.extract(frames)[0]
+    assert kps.tobytes() == kps0.tobytes() and np.array_equal(desc, desc0)
+    ctx.close()
