@@ -52,13 +52,13 @@ struct AkdState {
                               //  response; -}
     int *fp_succ;             // x 3 (rotating): smallest gid that replaces this candidate, AKF_NONE if none
     int4 *fp_active;          // x 2: the candidates with at least one such neighbour (any order): {gid, count, response, act} {root, n0, n1, n2}
-    int *fp_ctl;              // [frame][AKF_CTL]: how many of those | the pass that found the frame converged | per pass: changed something
+    int *fp_ctl;              // [frame][AKF_CTL]: how many of those per level [16] | the pass that found the frame converged | per pass: changed something
     unsigned short *wpre;     // [frame][rows_stride][AKD_MAXCHUNKS] candidates of the row in front of the 64-column word (k_akz_cand_emit)
     int fp_pass_cap;
 };
 #define AKF_K 16
 #define AKF_PASSES 12  // pass launches enqueued per call (the bench frames need 8)
-#define AKF_CTL (2 + AKF_PASSES + 2)
+#define AKF_CTL (17 + AKF_PASSES + 3)
 #define AKF_APPEND (-1)
 #define AKF_DROP (-2)
 #define AKF_NONE 0x7fffffff

@@ -706,15 +706,17 @@ __global__ __launch_bounds__(AKD_T, 8) void k_akz_suppress(AkdParams P, AkdState
 // Both engines leave entry / keep / used for k_akz_refine_a / _b; tests/test_gpu_akaze.py runs every case through both.
 #define AKF_T 256
 #define AKF_ROWS 12   // bitmap rows fetched together (a window is at most 2 * 4.8 + 2 rows high with the akaze61 radii; more rows: another group)
+#define AKF_UP_K 32   // level-above candidates inside one disc of the upper-level filter: strict 3 x 3 maxima lie >= 2 pixels apart, radius <= 4.04
 #define AKF_ROWS_UP 6  // ... of the rows up to the candidate's own (same level: radius <= 4.04 rows)
 
-// the candidates of level G (bitmap rows mk, row starts rs, word prefixes wp) inside the disc (sx, sy, size2): rows up to y_last, on row
-// y_last only the columns up to x_last (same level: the candidates in front of c); visit(index inside the level).  A window is at most
-// 13 columns wide: one or two 64-bit words per row, all rows' words in flight together.
+// the candidates of level G (bitmap rows mk) inside the disc (sx, sy, size2): rows up to y_last, on row y_last only the columns up to
+// x_last (same level: the candidates in front of c); visit(x | y << 16).  A window is at most 13 columns wide: one or two 64-bit words
+// per row, all rows' words in flight together.  Turning a position into the candidate's index costs three more loads (akf_index): the
+// callers collect the hits first and resolve them together - inside the row loop every hit was a dependent memory round trip of its own
+// (64 lanes, 18 rows: nearly every row has a hit in some lane) and k_akz_fp_build took 0.17 ms per 64 frames.
 template <int ROWS, typename F>
-__device__ __forceinline__ void akf_scan(const AkdLevel &G, const unsigned long long *__restrict__ mk, const int *__restrict__ rs,
-                                         const unsigned short *__restrict__ wp, float sx, float sy, float rq, float size2, int y_last, int x_last,
-                                         F visit) {
+__device__ __forceinline__ void akf_scan(const AkdLevel &G, const unsigned long long *__restrict__ mk, float sx, float sy, float rq, float size2,
+                                         int y_last, int x_last, F visit) {
     const int xa = max((int)floorf((sx - rq) / G.ratio), 0), xb = min((int)((sx + rq) / G.ratio) + 1, G.w - 1);
     const int ya = max((int)floorf((sy - rq) / G.ratio), 0), yb = min(min((int)((sy + rq) / G.ratio) + 1, G.h - 1), y_last);
     if (xa > xb) return;
@@ -746,13 +748,31 @@ __device__ __forceinline__ void akf_scan(const AkdLevel &G, const unsigned long 
                     const int b = (int)__builtin_ctzll(m);
                     m &= m - 1;
                     const float ax = (float)((wd << 6) + b) * G.ratio, dx = sx - ax;
-                    if (dx * dx + dy * dy <= size2)
-                        visit(rs[y] + (int)wp[(size_t)y * AKD_MAXCHUNKS + wd] + __popcll(full & ((1ull << b) - 1ull)));
+                    if (dx * dx + dy * dy <= size2) visit((unsigned)((wd << 6) + b) | ((unsigned)y << 16));
                 }
             }
         }
     }
 }
+
+// index of the candidate at bitmap position (x, y) inside its level: candidates of the rows above + of the words in front + of the bits below
+struct AkfPos {
+    int rs;
+    unsigned short wp;
+    unsigned long long word;
+    int bit;
+};
+__device__ __forceinline__ AkfPos akf_index_load(const unsigned long long *__restrict__ mk, const int *__restrict__ rs,
+                                                 const unsigned short *__restrict__ wp, unsigned code) {
+    const int x = (int)(code & 0xffffu), y = (int)((code >> 16) & 0x7fffu);
+    AkfPos p;
+    p.rs = rs[y];
+    p.wp = wp[(size_t)y * AKD_MAXCHUNKS + (x >> 6)];
+    p.word = mk[(size_t)y * AKD_MAXCHUNKS + (x >> 6)];
+    p.bit = x & 63;
+    return p;
+}
+__device__ __forceinline__ int akf_index(const AkfPos &p) { return p.rs + (int)p.wp + __popcll(p.word & ((1ull << p.bit) - 1ull)); }
 
 __device__ __forceinline__ void akf_bases(const int *__restrict__ cand_count, int f, int NL, int *s_base) {
     if (threadIdx.x == 0) {
@@ -770,6 +790,7 @@ __global__ __launch_bounds__(AKF_T) void k_akz_fp_build(AkdParams P, AkdState S,
                                                         const int *__restrict__ row_start, const int *__restrict__ cand,
                                                         const float *__restrict__ cand_resp, const int *__restrict__ cand_count,
                                                         int *__restrict__ status) {
+    __shared__ unsigned s_hit[AKF_K][AKF_T];  // per thread: the positions its scans found (bit 31: in the level below)
     const int c = blockIdx.x, f = blockIdx.y, part = blockIdx.z, nparts = gridDim.z, tid = threadIdx.x, lane = tid & 63;
     const AkdLevel L = P.lv[c];
     const AkdLevel Lp = P.lv[c > 0 ? c - 1 : 0];
@@ -795,24 +816,42 @@ __global__ __launch_bounds__(AKF_T) void k_akz_fp_build(AkdParams P, AkdState S,
     for (int kb = part * AKF_T; kb < n; kb += nparts * AKF_T) {  // uniform trip count per workgroup
         const int k = kb + tid;
         bool active = false;
-        int my_cnt = 0;
+        int my_cnt = 0, n0 = 0, n1 = 0, n2 = 0;
         float my_resp = 0.f;
         if (k < n) {
             const int idx = cd[k], iy = idx / L.w, jx = idx - iy * L.w;
             const float sx = (float)jx * L.ratio, sy = (float)iy * L.ratio;
             const int gid = base + k;
-            int *list = S.fp_nbr + (fo + gid) * AKF_K;
+            int *list = S.fp_nbr + (fo + gid) * AKF_K;  // only a candidate with more than three neighbours ever touches its 64-byte list
             int cnt = 0;
             // the FIRST entry in slot order decides, and slot order is the order of the roots: the order inside the list does not matter
             if (c > 0)
-                akf_scan<AKF_ROWS>(Lp, mkp, rsp, wpp, sx, sy, rq, size2, Lp.h - 1, Lp.w - 1, [&](int g) {
-                    if (cnt < AKF_K) list[cnt] = base_prev + g;
+                akf_scan<AKF_ROWS>(Lp, mkp, sx, sy, rq, size2, Lp.h - 1, Lp.w - 1, [&](unsigned code) {
+                    if (cnt < AKF_K) s_hit[cnt][tid] = code | 0x80000000u;
                     ++cnt;
                 });
-            akf_scan<AKF_ROWS_UP>(L, mk, rs, wp, sx, sy, rq, size2, iy, jx - 1, [&](int g) {
-                if (cnt < AKF_K) list[cnt] = base + g;
+            akf_scan<AKF_ROWS_UP>(L, mk, sx, sy, rq, size2, iy, jx - 1, [&](unsigned code) {
+                if (cnt < AKF_K) s_hit[cnt][tid] = code;
                 ++cnt;
             });
+            for (int h0 = 0; h0 < min(cnt, AKF_K); h0 += 4) {  // four hits' loads in flight together
+                AkfPos ps[4];
+                unsigned cd4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    cd4[u] = s_hit[min(h0 + u, AKF_K - 1)][tid];
+                    const bool below = (cd4[u] >> 31) != 0;
+                    if (h0 + u < cnt) ps[u] = akf_index_load(below ? mkp : mk, below ? rsp : rs, below ? wpp : wp, cd4[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int h = h0 + u;
+                    if (h < cnt && h < AKF_K) {
+                        const int v = ((cd4[u] >> 31) ? base_prev : base) + akf_index(ps[u]);
+                        if (h == 0) n0 = v; else if (h == 1) n1 = v; else if (h == 2) n2 = v; else list[h] = v;
+                    }
+                }
+            }
             if (cnt > AKF_K) atomicExch(status, 6);
             my_cnt = min(cnt, AKF_K);
             my_resp = cr[k];
@@ -824,40 +863,47 @@ __global__ __launch_bounds__(AKF_T) void k_akz_fp_build(AkdParams P, AkdState S,
         }
         const unsigned long long am = __ballot(active);
         int o = 0;
-        if (lane == 0 && am) o = atomicAdd(S.fp_ctl + (size_t)f * AKF_CTL, __popcll(am));
+        if (lane == 0 && am) o = atomicAdd(S.fp_ctl + (size_t)f * AKF_CTL + c, __popcll(am));  // one counter per (frame, level): 8 x fewer collisions
         o = __shfl(o, 0, 64);
         if (active) {  // the candidate's record: what a pass needs of it in one 32-byte load (the first three neighbours inline)
-            const int *list = S.fp_nbr + (fo + base + k) * AKF_K;
-            int4 *rec = S.fp_active + (fo + o + __popcll(am & ((1ull << lane) - 1ull))) * 2;
+            // level c's records start at its gid base: a level has at most as many active candidates as candidates
+            int4 *rec = S.fp_active + (fo + base + o + __popcll(am & ((1ull << lane) - 1ull))) * 2;
             rec[0] = make_int4(base + k, my_cnt, __float_as_int(my_resp), AKF_APPEND);
-            rec[1] = make_int4(base + k, list[0], my_cnt > 1 ? list[1] : 0, my_cnt > 2 ? list[2] : 0);
+            rec[1] = make_int4(base + k, n0, n1, n2);
         }
     }
 }
 
-// fp_ctl[frame][AKF_CTL]: [0] active candidates, [1] the pass that found the frame converged (0: not yet), [2 + p] pass p changed something
-__global__ __launch_bounds__(AKF_T) void k_akz_fp_pass(AkdParams P, AkdState S, int pass) {
+// fp_ctl[frame][AKF_CTL]: [0 .. 15] active candidates per level, [16] the pass that found the frame converged (0: not yet), [17 + p] pass p
+// changed something
+__global__ __launch_bounds__(AKF_T) void k_akz_fp_pass(AkdParams P, AkdState S, const int *__restrict__ cand_count, int pass) {
+    __shared__ int s_base[17], s_nact[16];
     const int f = blockIdx.y, tid = threadIdx.x;
     int *ctl = S.fp_ctl + (size_t)f * AKF_CTL;
     if (pass > 0) {
-        if (ctl[1] != 0) return;      // converged in an earlier pass
-        if (ctl[2 + pass - 1] == 0) {  // the previous pass changed nothing: every equation holds
-            if (blockIdx.x == 0 && tid == 0) ctl[1] = pass;
+        if (ctl[16] != 0) return;       // converged in an earlier pass
+        if (ctl[17 + pass - 1] == 0) {  // the previous pass changed nothing: every equation holds
+            if (blockIdx.x == 0 && tid == 0) ctl[16] = pass;
             return;
         }
     }
+    if (tid < 16) s_nact[tid] = ctl[tid];
+    akf_bases(cand_count, f, P.nlevels, s_base);
+    const int total = min(s_base[P.nlevels], P.entry_cap);
     const size_t fo = (size_t)f * P.entry_cap;
     int4 *state = S.fp_state + fo;
     const int *nbr = S.fp_nbr + fo * AKF_K;
     int4 *recs = S.fp_active + fo * 2;
-    const int nact = min(ctl[0], P.entry_cap);
     int *succ0 = S.fp_succ + fo * 3;
     // pass p: reads succ[p % 3] (written in pass p - 1), writes succ[(p + 1) % 3], clears succ[(p + 2) % 3] (every index a pass can write
     // is an earlier neighbour of an active candidate: clearing those is clearing everything)
     const int *sR = succ0 + (size_t)(pass % 3) * P.entry_cap;
     int *sW = succ0 + (size_t)((pass + 1) % 3) * P.entry_cap, *sC = succ0 + (size_t)((pass + 2) % 3) * P.entry_cap;
     bool changed = false;
-    for (int i = blockIdx.x * AKF_T + tid; i < nact; i += gridDim.x * AKF_T) {
+    for (int i = blockIdx.x * AKF_T + tid; i < total; i += gridDim.x * AKF_T) {
+        int lv = 0;
+        while (i >= s_base[lv + 1]) ++lv;
+        if (i - s_base[lv] >= s_nact[lv]) continue;  // behind the level's records
         const int4 r0 = recs[2 * i], r1 = recs[2 * i + 1];  // {gid, count, response, act} {root, n0, n1, n2}
         const int c = r0.x, cn = r0.y;
         const int *list = nbr + (size_t)c * AKF_K;
@@ -885,13 +931,13 @@ __global__ __launch_bounds__(AKF_T) void k_akz_fp_pass(AkdParams P, AkdState S, 
         }
         if (nw.x >= 0) __hip_atomic_fetch_min(sW + nw.x, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (changed) ctl[2 + pass] = 1;
+    if (changed) ctl[17 + pass] = 1;
 }
 
 // which succ array describes the final state: the one the last executed pass wrote.  -1: the frame did not converge in AKF_PASSES passes
 __device__ __forceinline__ int akf_final(const int *ctl, int npass) {
-    int q = ctl[1];
-    if (q == 0 && ctl[2 + npass - 1] == 0) q = npass;  // the last launch was the pass that changed nothing
+    int q = ctl[16];
+    if (q == 0 && ctl[17 + npass - 1] == 0) q = npass;  // the last launch was the pass that changed nothing
     return q == 0 ? -1 : q % 3;
 }
 
@@ -933,8 +979,9 @@ __global__ __launch_bounds__(AKF_T) void k_akz_fp_entries(AkdParams P, AkdState 
 // lies within size_A of it and has a larger response
 __global__ __launch_bounds__(AKF_T) void k_akz_fp_upper(AkdParams P, AkdState S, const unsigned long long *__restrict__ mask,
                                                         const int *__restrict__ row_start, const int *__restrict__ cand,
-                                                        const int *__restrict__ cand_count, int npass) {
+                                                        const int *__restrict__ cand_count, int npass, int *__restrict__ status) {
     __shared__ int s_base[17];
+    __shared__ unsigned s_hit[AKF_UP_K][AKF_T];
     const int f = blockIdx.y, tid = threadIdx.x, NL = P.nlevels;
     akf_bases(cand_count, f, NL, s_base);
     const int total = s_base[NL];
@@ -958,11 +1005,32 @@ __global__ __launch_bounds__(AKF_T) void k_akz_fp_upper(AkdParams P, AkdState S,
         const int *rsb = row_start + (size_t)f * P.rows_stride + B.row_off;
         const unsigned short *wpb = S.wpre + ((size_t)f * P.rows_stride + B.row_off) * AKD_MAXCHUNKS;
         const int bb = s_base[lv + 1];
-        bool rep = false;
-        akf_scan<AKF_ROWS>(B, mkb, rsb, wpb, x, y, A.psize * 1.0001f + 1e-3f, A.psize * A.psize, B.h - 1, B.w - 1, [&](int gb) {
-            const int4 sb = state[bb + gb];
-            if (sb.x != AKF_DROP && sF[bb + gb] == AKF_NONE && sb.y > st.y && r < __int_as_float(sb.z)) rep = true;
+        int cnt = 0;
+        akf_scan<AKF_ROWS>(B, mkb, x, y, A.psize * 1.0001f + 1e-3f, A.psize * A.psize, B.h - 1, B.w - 1, [&](unsigned code) {
+            if (cnt < AKF_UP_K) s_hit[cnt][tid] = code;
+            ++cnt;
         });
+        bool rep = false;
+        for (int h0 = 0; h0 < cnt; h0 += 4) {
+            AkfPos ps[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (h0 + u < cnt) ps[u] = akf_index_load(mkb, rsb, wpb, s_hit[min(h0 + u, AKF_UP_K - 1)][tid]);
+            int gb[4];
+            int4 sb[4];
+            int su[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (h0 + u < cnt) {
+                    gb[u] = bb + akf_index(ps[u]);
+                    sb[u] = state[gb[u]];
+                    su[u] = sF[gb[u]];
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (h0 + u < cnt && sb[u].x != AKF_DROP && su[u] == AKF_NONE && sb[u].y > st.y && r < __int_as_float(sb[u].z)) rep = true;
+        }
+        if (cnt > AKF_UP_K) atomicExch(status, 6);  // more level-above candidates in one disc than 2-pixel-apart maxima can be
         if (rep) keep[st.y] = 0;
     }
 }
@@ -1101,9 +1169,9 @@ extern "C" void afv_akz_launch_suppress(const AkdParams *P, const AkdState *S, i
         parts = parts < 1 ? 1 : parts;
         hipLaunchKernelGGL(k_akz_fp_build, dim3(P->nlevels, nframes, parts), dim3(AKF_T), 0, st, *P, *S, mask, row_start, cand, cand_resp, cand_count,
                            status);
-        for (int p = 0; p < npass; ++p) hipLaunchKernelGGL(k_akz_fp_pass, dim3(per, nframes), dim3(AKF_T), 0, st, *P, *S, p);
+        for (int p = 0; p < npass; ++p) hipLaunchKernelGGL(k_akz_fp_pass, dim3(per, nframes), dim3(AKF_T), 0, st, *P, *S, cand_count, p);
         hipLaunchKernelGGL(k_akz_fp_entries, dim3(per, nframes), dim3(AKF_T), 0, st, *P, *S, cand, cand_count, npass, status);
-        hipLaunchKernelGGL(k_akz_fp_upper, dim3(per, nframes), dim3(AKF_T), 0, st, *P, *S, mask, row_start, cand, cand_count, npass);
+        hipLaunchKernelGGL(k_akz_fp_upper, dim3(per, nframes), dim3(AKF_T), 0, st, *P, *S, mask, row_start, cand, cand_count, npass, status);
     } else {
         const size_t lds = (size_t)P->lds_bytes;  // list lengths (u8): a level's own grid + hints of the one below
         (void)hipMemsetAsync(S->ticket, 0, (size_t)(8 + nframes * 16) * sizeof(int), st);
