@@ -288,8 +288,7 @@ extern "C" int afv_akaze_create(int device, const afv_akaze_params *prm, afv_aka
         if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.chunk_cnt, (size_t)(AKD_SLOT_CAP / 1024) * B);
         // fixed-point engine
         if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.fp_nbr, (size_t)AKD_SLOT_CAP * AKF_K * B);
-        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.fp_state, (size_t)AKD_SLOT_CAP * B);
-        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.fp_succ, (size_t)AKD_SLOT_CAP * 3 * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.fp_state, (size_t)AKD_SLOT_CAP * 2 * B);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.fp_active, (size_t)AKD_SLOT_CAP * 2 * B);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.fp_ctl, (size_t)AKF_CTL * B);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.wpre, rows * 32 * B);

@@ -48,9 +48,8 @@ struct AkdState {
     // fixed-point engine (round 5, k_akz_fp_*): everything indexed by a candidate's position in upstream's loop order
     // (gid = candidates of the levels below + index inside its level), [frame][entry_cap]
     int *fp_nbr;              // x AKF_K: the EARLIER candidates (same level / level below) inside the candidate's radius
-    int4 *fp_state;           // {what the candidate does: AKF_APPEND, AKF_DROP or the gid of the holder it replaces; its entry's slot = root gid;
-                              //  response; -}
-    int *fp_succ;             // x 3 (rotating): smallest gid that replaces this candidate, AKF_NONE if none
+    int4 *fp_state;           // x 2: {what the candidate does: AKF_APPEND, AKF_DROP or the gid of the holder it replaces; its entry's slot = root
+                              //  gid; response; -} {stamped minima of the candidates that replace it: even passes, odd passes; -; -}
     int4 *fp_active;          // x 2: the candidates with at least one such neighbour (any order): {gid, count, response, act} {root, n0, n1, n2}
     int *fp_ctl;              // [frame][AKF_CTL]: how many of those per level [16] | the pass that found the frame converged | per pass: changed something
     unsigned short *wpre;     // [frame][rows_stride][AKD_MAXCHUNKS] candidates of the row in front of the 64-column word (k_akz_cand_emit)

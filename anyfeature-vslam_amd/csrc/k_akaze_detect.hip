@@ -855,10 +855,8 @@ __global__ __launch_bounds__(AKF_T) void k_akz_fp_build(AkdParams P, AkdState S,
             if (cnt > AKF_K) atomicExch(status, 6);
             my_cnt = min(cnt, AKF_K);
             my_resp = cr[k];
-            S.fp_state[fo + gid] = make_int4(AKF_APPEND, gid, __float_as_int(my_resp), 0);
-            S.fp_succ[fo * 3 + gid] = AKF_NONE;
-            S.fp_succ[fo * 3 + P.entry_cap + gid] = AKF_NONE;
-            S.fp_succ[fo * 3 + 2 * (size_t)P.entry_cap + gid] = AKF_NONE;
+            S.fp_state[(fo + gid) * 2] = make_int4(AKF_APPEND, gid, __float_as_int(my_resp), 0);
+            S.fp_state[(fo + gid) * 2 + 1] = make_int4(-1, -1, 0, 0);  // 0xffffffff: above every stamped value, and no pass has stamp 255
             active = cnt > 0;
         }
         const unsigned long long am = __ballot(active);
@@ -891,14 +889,14 @@ __global__ __launch_bounds__(AKF_T) void k_akz_fp_pass(AkdParams P, AkdState S, 
     akf_bases(cand_count, f, P.nlevels, s_base);
     const int total = min(s_base[P.nlevels], P.entry_cap);
     const size_t fo = (size_t)f * P.entry_cap;
-    int4 *state = S.fp_state + fo;
+    int4 *state = S.fp_state + fo * 2;  // per candidate 32 bytes: {act, root, response, -} {succ of the even passes, of the odd passes, -, -}
     const int *nbr = S.fp_nbr + fo * AKF_K;
     int4 *recs = S.fp_active + fo * 2;
-    int *succ0 = S.fp_succ + fo * 3;
-    // pass p: reads succ[p % 3] (written in pass p - 1), writes succ[(p + 1) % 3], clears succ[(p + 2) % 3] (every index a pass can write
-    // is an earlier neighbour of an active candidate: clearing those is clearing everything)
-    const int *sR = succ0 + (size_t)(pass % 3) * P.entry_cap;
-    int *sW = succ0 + (size_t)((pass + 1) % 3) * P.entry_cap, *sC = succ0 + (size_t)((pass + 2) % 3) * P.entry_cap;
+    // succ(j) = the smallest candidate that replaces j, as the passes' atomic minima of  (254 - pass) << 24 | candidate : a later pass's
+    // value is smaller than anything an earlier pass left, so nothing is ever cleared; pass p writes word p & 1 and reads the other one,
+    // which holds pass p - 1's minima exactly where its stamp says so
+    const unsigned want = (unsigned)(254 - (pass - 1)) & 0xffu, stamp = (unsigned)(254 - pass) << 24;
+    const int rd = (pass + 1) & 1, wr = pass & 1;
     bool changed = false;
     for (int i = blockIdx.x * AKF_T + tid; i < total; i += gridDim.x * AKF_T) {
         int lv = 0;
@@ -910,9 +908,9 @@ __global__ __launch_bounds__(AKF_T) void k_akz_fp_pass(AkdParams P, AkdState S, 
         int best = -1, best_root = AKF_NONE, best_resp = 0;
         for (int k = 0; k < cn; ++k) {
             const int j = k == 0 ? r1.y : k == 1 ? r1.z : k == 2 ? r1.w : list[k];
-            const int4 sj = state[j];  // {act, root, response, -}
-            const int su = sR[j];
-            sC[j] = AKF_NONE;
+            const int4 sj = state[2 * j], tj = state[2 * j + 1];
+            const unsigned sv = (unsigned)(rd ? tj.y : tj.x);
+            const int su = pass > 0 && (sv >> 24) == want ? (int)(sv & 0xffffffu) : AKF_NONE;
             if (sj.x != AKF_DROP && su >= c && sj.y < best_root) {
                 best_root = sj.y;
                 best = j;
@@ -926,19 +924,25 @@ __global__ __launch_bounds__(AKF_T) void k_akz_fp_pass(AkdParams P, AkdState S, 
         if (nw.x != r0.w || nw.y != r1.x) {
             recs[2 * i].w = nw.x;
             recs[2 * i + 1].x = nw.y;
-            *reinterpret_cast<int2 *>(state + c) = nw;
+            *reinterpret_cast<int2 *>(state + 2 * c) = nw;
             changed = true;
         }
-        if (nw.x >= 0) __hip_atomic_fetch_min(sW + nw.x, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (nw.x >= 0)
+            __hip_atomic_fetch_min(reinterpret_cast<unsigned *>(state + 2 * nw.x + 1) + wr, stamp | (unsigned)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (changed) ctl[17 + pass] = 1;
 }
 
-// which succ array describes the final state: the one the last executed pass wrote.  -1: the frame did not converge in AKF_PASSES passes
+// the last executed pass (its succ minima describe the final state); -1: the frame did not converge in the passes that were enqueued
 __device__ __forceinline__ int akf_final(const int *ctl, int npass) {
     int q = ctl[16];
     if (q == 0 && ctl[17 + npass - 1] == 0) q = npass;  // the last launch was the pass that changed nothing
-    return q == 0 ? -1 : q % 3;
+    return q - 1;
+}
+// has the candidate with this state been replaced at the end (last pass: fin)?
+__device__ __forceinline__ bool akf_replaced(const int4 &t, int fin) {
+    const unsigned sv = (unsigned)((fin & 1) ? t.y : t.x);
+    return (sv >> 24) == ((unsigned)(254 - fin) & 0xffu);
 }
 
 __global__ __launch_bounds__(AKF_T) void k_akz_fp_entries(AkdParams P, AkdState S, const int *__restrict__ cand, const int *__restrict__ cand_count,
@@ -955,8 +959,7 @@ __global__ __launch_bounds__(AKF_T) void k_akz_fp_entries(AkdParams P, AkdState 
         return;
     }
     const size_t fo = (size_t)f * P.entry_cap;
-    const int4 *state = S.fp_state + fo;
-    const int *sF = S.fp_succ + fo * 3 + (size_t)fin * P.entry_cap;
+    const int4 *state = S.fp_state + fo * 2;
     float4 *entry = S.entry + fo;
     unsigned char *keep = S.keep + fo;
     if (blockIdx.x == 0 && tid < NL) S.used[f * 16 + tid] = cand_count[f * 16 + tid];
@@ -964,9 +967,9 @@ __global__ __launch_bounds__(AKF_T) void k_akz_fp_entries(AkdParams P, AkdState 
     for (int g = blockIdx.x * AKF_T + tid; g < total; g += gridDim.x * AKF_T) {
         int lv = 0;
         while (g >= s_base[lv + 1]) ++lv;
-        const int4 st = state[g];
+        const int4 st = state[2 * g];
         keep[g] = st.x == AKF_APPEND ? 1 : 0;
-        if (st.x != AKF_DROP && sF[g] == AKF_NONE) {
+        if (st.x != AKF_DROP && !akf_replaced(state[2 * g + 1], fin)) {
             const AkdLevel &L = P.lv[lv];
             const int idx = cand[(size_t)f * P.cand_stride + L.cand_off + (g - s_base[lv])];
             const int iy = idx / L.w, jx = idx - iy * L.w;
@@ -989,14 +992,13 @@ __global__ __launch_bounds__(AKF_T) void k_akz_fp_upper(AkdParams P, AkdState S,
     const int fin = akf_final(S.fp_ctl + (size_t)f * AKF_CTL, npass);
     if (fin < 0) return;
     const size_t fo = (size_t)f * P.entry_cap;
-    const int4 *state = S.fp_state + fo;
-    const int *sF = S.fp_succ + fo * 3 + (size_t)fin * P.entry_cap;
+    const int4 *state = S.fp_state + fo * 2;
     unsigned char *keep = S.keep + fo;
     for (int g = blockIdx.x * AKF_T + tid; g < s_base[NL - 1]; g += gridDim.x * AKF_T) {  // the last level has no level above
         int lv = 0;
         while (g >= s_base[lv + 1]) ++lv;
-        const int4 st = state[g];
-        if (st.x == AKF_DROP || sF[g] != AKF_NONE) continue;
+        const int4 st = state[2 * g];
+        if (st.x == AKF_DROP || akf_replaced(state[2 * g + 1], fin)) continue;
         const AkdLevel &A = P.lv[lv], &B = P.lv[lv + 1];
         const int idx = cand[(size_t)f * P.cand_stride + A.cand_off + (g - s_base[lv])];
         const int iy = idx / A.w, jx = idx - iy * A.w;
@@ -1017,18 +1019,17 @@ __global__ __launch_bounds__(AKF_T) void k_akz_fp_upper(AkdParams P, AkdState S,
             for (int u = 0; u < 4; ++u)
                 if (h0 + u < cnt) ps[u] = akf_index_load(mkb, rsb, wpb, s_hit[min(h0 + u, AKF_UP_K - 1)][tid]);
             int gb[4];
-            int4 sb[4];
-            int su[4];
+            int4 sb[4], tb[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (h0 + u < cnt) {
                     gb[u] = bb + akf_index(ps[u]);
-                    sb[u] = state[gb[u]];
-                    su[u] = sF[gb[u]];
+                    sb[u] = state[2 * gb[u]];
+                    tb[u] = state[2 * gb[u] + 1];
                 }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (h0 + u < cnt && sb[u].x != AKF_DROP && su[u] == AKF_NONE && sb[u].y > st.y && r < __int_as_float(sb[u].z)) rep = true;
+                if (h0 + u < cnt && sb[u].x != AKF_DROP && !akf_replaced(tb[u], fin) && sb[u].y > st.y && r < __int_as_float(sb[u].z)) rep = true;
         }
         if (cnt > AKF_UP_K) atomicExch(status, 6);  // more level-above candidates in one disc than 2-pixel-apart maxima can be
         if (rep) keep[st.y] = 0;
