@@ -252,8 +252,9 @@ extern "C" int afv_akaze_create(int device, const afv_akaze_params *prm, afv_aka
     if (rc == AFV_OK) rc = akz_alloc(a, &a->pong, n0);
     if (rc == AFV_OK) rc = akz_alloc(a, &a->half, n0 / 4 + B);
     if (rc == AFV_OK) rc = akz_alloc(a, &a->d_taps, 40);
-    if (rc == AFV_OK) rc = akz_alloc(a, &a->d_hmax, B);
-    if (rc == AFV_OK) rc = akz_alloc(a, &a->d_hist, B * (size_t)(prm->kcontrast_nbins + 1));
+    // maxima and histograms of the contrast percentile in one block: one memset per call clears both
+    if (rc == AFV_OK) rc = akz_alloc(a, &a->d_hmax, B + B * (size_t)(prm->kcontrast_nbins + 1));
+    if (rc == AFV_OK) a->d_hist = reinterpret_cast<int *>(a->d_hmax + B);
     if (rc == AFV_OK) rc = akz_alloc(a, &a->d_kcontrast, B);
     {   // detection buffers sized for the largest frame
         size_t cands = 0, rows = 0;
@@ -269,7 +270,7 @@ extern "C" int afv_akaze_create(int device, const afv_akaze_params *prm, afv_aka
         if (rc == AFV_OK) rc = akz_alloc(a, &a->d_cand_resp, cands * B);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->d_cand_count, 16 * B);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->d_kp_count, B);
-        if (rc == AFV_OK) rc = akz_alloc(a, &a->d_status, 1);
+
         if (rc == AFV_OK) rc = akz_alloc(a, &a->d_kps, (size_t)AKD_ENTRY_CAP * B);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.entry, (size_t)AKD_SLOT_CAP * B);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.keep, (size_t)AKD_SLOT_CAP * B);
@@ -290,7 +291,8 @@ extern "C" int afv_akaze_create(int device, const afv_akaze_params *prm, afv_aka
         if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.fp_nbr, (size_t)AKD_SLOT_CAP * AKF_K * B);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.fp_state, (size_t)AKD_SLOT_CAP * 2 * B);
         if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.fp_active, (size_t)AKD_SLOT_CAP * 2 * B);
-        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.fp_ctl, (size_t)AKF_CTL * B);
+        if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.fp_ctl, (size_t)AKF_CTL * B + 1);  // + the status word: one memset per detection
+        if (rc == AFV_OK) a->d_status = a->ds.fp_ctl + (size_t)AKF_CTL * B;
         if (rc == AFV_OK) rc = akz_alloc(a, &a->ds.wpre, rows * 32 * B);
     }
     {   // quadtree quotas (FeatureExtractor.cpp:97-108) for nfeatures / scaleFactor / nlevels of the akaze61 settings
@@ -355,8 +357,7 @@ static int akz_enqueue(afv_akaze *a, const uint8_t *d_gray, int nframes, int w, 
     const bool fused_contrast = !a->step_by_step && P.ksize_one == 5;
     if (!fused_contrast && afv_akz_launch_gauss(d_gray, 1, stride, frame_stride, w, h, nframes, a->d_taps + 32, P.ksize_one, a->pong, st))
         return AFV_EUNSUPPORTED;
-    AKZ_HIPCHK(a, hipMemsetAsync(a->d_hmax, 0, (size_t)nframes * sizeof(unsigned int), st));
-    AKZ_HIPCHK(a, hipMemsetAsync(a->d_hist, 0, (size_t)nframes * (nb + 1) * sizeof(int), st));
+    AKZ_HIPCHK(a, hipMemsetAsync(a->d_hmax, 0, ((size_t)a->prm.max_batch + (size_t)nframes * (nb + 1)) * sizeof(int), st));  // d_hist follows d_hmax
     afv_akz_launch_kcontrast(fused_contrast ? nullptr : a->pong, d_gray, stride, (size_t)frame_stride, a->d_taps + 32, w, h, nframes, a->flow, a->d_hmax,
                              a->d_hist, nb, a->prm.kcontrast_percentile, a->d_kcontrast, st);
     for (int i = 1; i < P.nlevels; ++i) {
@@ -534,7 +535,7 @@ static int akz_detect_enqueue(afv_akaze *a) {
     }
     D.entry_cap = AKD_SLOT_CAP; D.kp_cap = AKD_ENTRY_CAP;
     hipStream_t st = a->stream;
-    AKZ_HIPCHK(a, hipMemsetAsync(a->d_status, 0, sizeof(int), st));
+    AKZ_HIPCHK(a, hipMemsetAsync(a->ds.fp_ctl, 0, ((size_t)AKF_CTL * a->prm.max_batch + 1) * sizeof(int), st));  // fixed-point control block + d_status
     // list elements carry a 14-bit launch epoch (k_akaze_detect.hip); the grids are wiped whenever it starts over
     if (a->ds.epoch == 0 || a->ds.epoch >= 0x3fffu) {
         AKZ_HIPCHK(a, hipMemsetAsync(a->ds.cells, 0, a->cells_bytes, st));

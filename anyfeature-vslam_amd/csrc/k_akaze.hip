@@ -784,17 +784,17 @@ __global__ __launch_bounds__(AKZ_T) void k_akz_hessian(const float *__restrict__
 // evaluates them at its sample positions from Lsmooth (k_akaze_desc.hip) - 8 of this kernel's 16 B per pixel were written for a plane
 // of which under a tenth is ever read.  SD = true serves afv_akaze_get_plane (and keeps the fused Lx / Ly under the plane tests).
 template <int S, bool SD>
-__global__ __launch_bounds__(256) void k_akz_dhess(const float *__restrict__ lsm, int w, int h, int nframes, float *__restrict__ dx,
+__global__ __launch_bounds__(256) void k_akz_dhess(const float *__restrict__ lsm, int w, int h, int nframes, int band_rows, float *__restrict__ dx,
                                                    float *__restrict__ dy, float *__restrict__ Ldet) {
     constexpr int P = 2 * S + 1;     // ring depth
     constexpr int OW = 64 - 4 * S;   // output columns per strip
     const int lane = threadIdx.x & 63;
-    const int nstr = (w + OW - 1) / OW, nband = (h + AKZ_DH_ROWS - 1) / AKZ_DH_ROWS;
+    const int nstr = (w + OW - 1) / OW, nband = (h + band_rows - 1) / band_rows;
     int id = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
     if (id >= nstr * nband * nframes) return;
     const int f = id / (nstr * nband);
     id -= f * nstr * nband;
-    const int band = id / nstr, x0 = (id - band * nstr) * OW, y0 = band * AKZ_DH_ROWS;
+    const int band = id / nstr, x0 = (id - band * nstr) * OW, y0 = band * band_rows;
     const int gx = x0 - 2 * S + lane;
     const bool colv = gx < 0 || gx >= w;  // virtual column
     const int cx = akz_reflect(gx, w);
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(256) void k_akz_dhess(const float *__restrict__ lsm
     const size_t fo = (size_t)f * w * h;
     const float wgt = 10.0f / 3.0f, norm = 1.0f / (2.0f * (float)S * (wgt + 2.0f)), mid = wgt * norm;
     const float fs2 = (float)(S * S);
-    const int rows = min(AKZ_DH_ROWS, h - y0);
+    const int rows = min(band_rows, h - y0);
     const int T = rows + 4 * S;  // Lsmooth rows y0 - 2S .. y0 + rows - 1 + 2S
     float D[P], U[P], DX[P], UX[P], UY[P];
 #pragma unroll
@@ -934,16 +934,19 @@ extern "C" int afv_akz_launch_hessian(const float *lsm, int w, int h, int nframe
     if (s < 1 || s > AKZ_MAX_S) return -1;
     if (s >= 2 && s <= 4 && !two_kernels) {
         const int ow = 64 - 4 * s;
-        const int strips = ((w + ow - 1) / ow) * ((h + AKZ_DH_ROWS - 1) / AKZ_DH_ROWS) * nframes;
+        // a wavefront walks its strip row group by row group (a dependent load per group): a batch wants long strips (64 rows: fewest run-in
+        // rows), a single frame short ones - 300 strips of 64 rows leave the chip idle for 25 us per level, strips of 16 rows take 9
+        const int band_rows = nframes >= 8 ? AKZ_DH_ROWS : 16;
+        const int strips = ((w + ow - 1) / ow) * ((h + band_rows - 1) / band_rows) * nframes;
         const dim3 g((strips + 3) / 4);
         if (dx && dy) {
-            if (s == 2) hipLaunchKernelGGL((k_akz_dhess<2, true>), g, dim3(256), 0, st, lsm, w, h, nframes, dx, dy, Ldet);
-            else if (s == 3) hipLaunchKernelGGL((k_akz_dhess<3, true>), g, dim3(256), 0, st, lsm, w, h, nframes, dx, dy, Ldet);
-            else hipLaunchKernelGGL((k_akz_dhess<4, true>), g, dim3(256), 0, st, lsm, w, h, nframes, dx, dy, Ldet);
+            if (s == 2) hipLaunchKernelGGL((k_akz_dhess<2, true>), g, dim3(256), 0, st, lsm, w, h, nframes, band_rows, dx, dy, Ldet);
+            else if (s == 3) hipLaunchKernelGGL((k_akz_dhess<3, true>), g, dim3(256), 0, st, lsm, w, h, nframes, band_rows, dx, dy, Ldet);
+            else hipLaunchKernelGGL((k_akz_dhess<4, true>), g, dim3(256), 0, st, lsm, w, h, nframes, band_rows, dx, dy, Ldet);
         } else {
-            if (s == 2) hipLaunchKernelGGL((k_akz_dhess<2, false>), g, dim3(256), 0, st, lsm, w, h, nframes, dx, dy, Ldet);
-            else if (s == 3) hipLaunchKernelGGL((k_akz_dhess<3, false>), g, dim3(256), 0, st, lsm, w, h, nframes, dx, dy, Ldet);
-            else hipLaunchKernelGGL((k_akz_dhess<4, false>), g, dim3(256), 0, st, lsm, w, h, nframes, dx, dy, Ldet);
+            if (s == 2) hipLaunchKernelGGL((k_akz_dhess<2, false>), g, dim3(256), 0, st, lsm, w, h, nframes, band_rows, dx, dy, Ldet);
+            else if (s == 3) hipLaunchKernelGGL((k_akz_dhess<3, false>), g, dim3(256), 0, st, lsm, w, h, nframes, band_rows, dx, dy, Ldet);
+            else hipLaunchKernelGGL((k_akz_dhess<4, false>), g, dim3(256), 0, st, lsm, w, h, nframes, band_rows, dx, dy, Ldet);
         }
         return 0;
     }

@@ -1163,7 +1163,7 @@ extern "C" void afv_akz_launch_suppress(const AkdParams *P, const AkdState *S, i
                                         int *status, hipStream_t st) {
     if (engine == 1) {
         const int npass = S->fp_pass_cap > 0 ? (S->fp_pass_cap < AKF_PASSES ? S->fp_pass_cap : AKF_PASSES) : AKF_PASSES;
-        (void)hipMemsetAsync(S->fp_ctl, 0, (size_t)nframes * AKF_CTL * sizeof(int), st);
+        // S->fp_ctl was cleared together with the status word (akaze_api.hip)
         int per = 4096 / (nframes > 0 ? nframes : 1);  // workgroups per frame
         per = per < 16 ? 16 : (per > 128 ? 128 : per);
         int parts = per / P->nlevels;
