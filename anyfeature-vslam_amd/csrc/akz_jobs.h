@@ -56,7 +56,7 @@ struct AkdState {
     int fp_pass_cap;
 };
 #define AKF_K 16
-#define AKF_PASSES 12  // pass launches enqueued per call (the bench frames need 8)
+#define AKF_PASSES 16  // pass launches enqueued per call (the bench frames and band-limited noise need 8; a launch for a converged frame costs ~5 us)
 #define AKF_CTL (17 + AKF_PASSES + 3)
 #define AKF_APPEND (-1)
 #define AKF_DROP (-2)

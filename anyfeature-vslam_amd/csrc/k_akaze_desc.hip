@@ -168,10 +168,9 @@ __constant__ float k_gauss25[7][7] = {
 // Round 5 stopped storing them (k_akz_dhess keeps them in registers for the Hessian only): a sample position (x, y) gets its
 // derivatives from the eight Lsmooth taps around it with exactly the expressions of k_akz_deriv1 (k_akaze.hip; the Scharr pair at
 // tap distance s, inputs at BORDER_REFLECT_101 coordinates), i.e. the same float bits the planes held.
-__device__ __forceinline__ int akd_reflect(int p, int n) {
-    if (n == 1) return 0;
-    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
-    return p;
+__device__ __forceinline__ int akd_reflect(int p, int n) {  // BORDER_REFLECT_101 for -n < p < 2n - 1 (tap distance <= 8, levels >= 20 pixels): one fold
+    p = p < 0 ? -p : p;
+    return p >= n ? 2 * n - 2 - p : p;
 }
 struct AkdTaps {
     float a, b, c, d, e, f, g, h;  // rows y - s, y, y + s x columns x - s, x, x + s without the centre
@@ -192,6 +191,21 @@ __device__ __forceinline__ void akd_deriv(const AkdTaps &t, float mid, float nor
     const float u2 = mid * t.g + norm * (t.f + t.h);
     *vy = u2 - u0;
 }
+
+// window start angles of Compute_Main_Orientation: upstream's loop variable ang1 += 0.15f, i.e. lane t holds the float sum of t additions
+struct AkdAngles {
+    float a[64];
+};
+constexpr AkdAngles akd_make_angles() {
+    AkdAngles r{};
+    float v = 0.0f;
+    for (int i = 0; i < 64; ++i) {
+        r.a[i] = v;
+        v += 0.15f;
+    }
+    return r;
+}
+__constant__ AkdAngles k_ang1 = akd_make_angles();
 
 #define AKD_LDS_SYNC()                                         \
     do {                                                       \
@@ -257,22 +271,28 @@ __global__ __launch_bounds__(256) void k_akz_describe(AkdDescParams P, const afv
         }
         AKD_LDS_SYNC();
         // 42 sliding windows (ang1 = 0, 0.15, ... accumulated in float like upstream's loop variable), one per lane
-        float ang1 = 0.0f;
-        for (int t = 0; t < lane; ++t) ang1 += 0.15f;
+        const float ang1 = k_ang1.a[lane];
         const bool live = (double)ang1 < 2.0 * AKZ_PI_D;
         float sumX = 0.f, sumY = 0.f;
-        if (live) {
+        {
             const float ang2 =
                 (float)((double)ang1 + AKZ_PI_D / 3.0 > 2.0 * AKZ_PI_D ? (double)ang1 - 5.0 * AKZ_PI_D / 3.0 : (double)ang1 + AKZ_PI_D / 3.0);
             // upstream: if (ang1 < ang2 && ang1 < ang && ang < ang2) add; else if (ang2 < ang1 && ((ang > 0 && ang < ang2) ||
-            // (ang > ang1 && ang < 2 pi))) add - the window either wraps or it does not, which is a property of the lane
+            // (ang > ang1 && ang < 2 pi))) add - the window either wraps or it does not, which is a property of the lane.
+            // Eight samples' broadcast reads in flight, the test as mask arithmetic (as short-circuit code every sample was an LDS round
+            // trip followed by a ladder of exec-mask branches: most of this kernel's time); every window still adds ITS samples in order.
             const bool nowrap = ang1 < ang2, wrap = ang2 < ang1;
-            for (int k = 0; k < 109; ++k) {
-                const float4 o = ori[k];  // one broadcast read per sample
-                const bool a1 = ang1 < o.x, a2 = o.x < ang2;
-                const bool in = nowrap ? (a1 && a2) : (wrap && ((o.x > 0 && a2) || (a1 && o.w != 0.0f)));
-                sumX = in ? sumX + o.y : sumX;
-                sumY = in ? sumY + o.z : sumY;
+            for (int k0 = 0; k0 < 109; k0 += 8) {
+                float4 o[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) o[u] = ori[min(k0 + u, 108)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool a1 = ang1 < o[u].x, a2 = o[u].x < ang2;
+                    const bool in = (k0 + u < 109) & ((nowrap & a1 & a2) | (!nowrap & wrap & (((o[u].x > 0) & a2) | (a1 & (o[u].w != 0.0f)))));
+                    sumX = in ? sumX + o[u].y : sumX;
+                    sumY = in ? sumY + o[u].z : sumY;
+                }
             }
         }
         const float mag = live ? sumX * sumX + sumY * sumY : 0.0f;
@@ -332,14 +352,28 @@ __global__ __launch_bounds__(256) void k_akz_describe(AkdDescParams P, const afv
         if (lane < 29) {
             const int i0 = k_mldb_cell[lane][1], j0 = k_mldb_cell[lane][2], step = k_mldb_cell[lane][3];
             float di = 0.f, dx = 0.f, dy = 0.f;
-            for (int k = i0; k < i0 + step; ++k) {
-                const float4 *q = smp + (k + 10) * 21 + (j0 + 10);
-                for (int l = 0; l < step; ++l) {
-                    const float4 v = q[l];
-                    di += v.x;
-                    dx += v.y;
-                    dy += v.z;
+            // the cell's samples in upstream's (k, l) order as one flat walk, four reads in flight (a 10 x 10 cell is a chain of 100 additions
+            // per channel: as nested loops every addition waited for its own LDS round trip)
+            const float4 *q = smp + (i0 + 10) * 21 + (j0 + 10);
+            const int nn = step * step;
+            int kk = 0, ll = 0;
+            for (int t0 = 0; t0 < nn; t0 += 4) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    v[u] = q[min(kk, step - 1) * 21 + ll];
+                    if (++ll == step) {
+                        ll = 0;
+                        ++kk;
+                    }
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (t0 + u < nn) {
+                        di += v[u].x;
+                        dx += v[u].y;
+                        dy += v[u].z;
+                    }
             }
             const float ns = (float)(step * step);
             val[3 * lane] = di / ns;

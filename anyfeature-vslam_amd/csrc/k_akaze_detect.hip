@@ -16,6 +16,7 @@
 //     the first such candidate.  The levels of a frame run as a pipeline (see the kernel); the upper-level filter of a level
 //     pair runs in the workgroup that finishes it.
 //  3. k_akz_refine_a / _b: the 2x2 sub-pixel solve and the ordered compaction over the slot space.
+#include <cstdlib>
 #include "afv_device.h"
 #include "akz_jobs.h"
 #include "../../include/afv_hip.h"
@@ -721,6 +722,15 @@ __device__ __forceinline__ void akf_scan(const AkdLevel &G, const unsigned long 
     const int ya = max((int)floorf((sy - rq) / G.ratio), 0), yb = min(min((int)((sy + rq) / G.ratio) + 1, G.h - 1), y_last);
     if (xa > xb) return;
     const int w0 = xa >> 6, w1 = min(xb >> 6, w0 + 1);  // (a window wider than 64 columns would need more: not with these radii)
+    // the column masks of the window's one or two words are the same for every row but the last (64-bit shifts are slow: once per scan)
+    auto col_mask = [&](int wd, int xe) -> unsigned long long {
+        if ((wd << 6) > xe) return 0ull;
+        const int lo = max(xa - (wd << 6), 0), hi = min(xe - (wd << 6), 63);
+        return (~0ull << lo) & (~0ull >> (63 - hi));
+    };
+    const unsigned long long cm0 = col_mask(w0, xb), cm1 = w1 != w0 ? col_mask(w1, xb) : 0ull;
+    const int xl = min(xb, x_last);
+    const unsigned long long lm0 = xa <= xl ? col_mask(w0, xl) : 0ull, lm1 = (w1 != w0 && xa <= xl) ? col_mask(w1, xl) : 0ull;
     for (int yg = ya; yg <= yb; yg += ROWS) {
         unsigned long long m0[ROWS], m1[ROWS];
 #pragma unroll
@@ -732,24 +742,21 @@ __device__ __forceinline__ void akf_scan(const AkdLevel &G, const unsigned long 
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             const int y = yg + r;
-            if (y > yb) break;
-            const int xe = (y == y_last) ? min(xb, x_last) : xb;
-            if (xa > xe) continue;
+            const bool last = y == y_last;
+            unsigned long long a = m0[r] & (last ? lm0 : cm0), b = m1[r] & (last ? lm1 : cm1);
+            if ((a | b) == 0ull) continue;
             const float ay = (float)y * G.ratio, dy = sy - ay;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int wd = h ? w1 : w0;
-                if (h && w1 == w0) break;
-                if ((wd << 6) > xe) break;
-                const unsigned long long full = h ? m1[r] : m0[r];
-                const int lo = max(xa - (wd << 6), 0), hi = min(xe - (wd << 6), 63);
-                unsigned long long m = full & (~0ull << lo) & (~0ull >> (63 - hi));
-                while (m) {
-                    const int b = (int)__builtin_ctzll(m);
-                    m &= m - 1;
-                    const float ax = (float)((wd << 6) + b) * G.ratio, dx = sx - ax;
-                    if (dx * dx + dy * dy <= size2) visit((unsigned)((wd << 6) + b) | ((unsigned)y << 16));
-                }
+            while (a) {
+                const int bit = (int)__builtin_ctzll(a);
+                a &= a - 1;
+                const float ax = (float)((w0 << 6) + bit) * G.ratio, dx = sx - ax;
+                if (dx * dx + dy * dy <= size2) visit((unsigned)((w0 << 6) + bit) | ((unsigned)y << 16));
+            }
+            while (b) {
+                const int bit = (int)__builtin_ctzll(b);
+                b &= b - 1;
+                const float ax = (float)((w1 << 6) + bit) * G.ratio, dx = sx - ax;
+                if (dx * dx + dy * dy <= size2) visit((unsigned)((w1 << 6) + bit) | ((unsigned)y << 16));
             }
         }
     }
