@@ -34,6 +34,14 @@ __device__ __forceinline__ int akz_reflect(int p, int n) {  // BORDER_REFLECT_10
     return p;
 }
 
+// BORDER_REFLECT_101 for -n < p < 2n - 1 (every row k_akz_dhess USES: its strip +- 2S rows, levels of at least 20 rows): one fold, no
+// loop.  Rows it only prefetches past the end of a strip can lie further out: clamped, so that the address stays inside the plane.
+__device__ __forceinline__ int akz_reflect1(int p, int n) {
+    p = p < 0 ? -p : p;
+    p = p >= n ? 2 * n - 2 - p : p;
+    return min(max(p, 0), n - 1);
+}
+
 // ---- helpers of the lane = column kernels (k_akz_contrast_modg, k_akz_fed_gauss) ----
 typedef float akz_f2 __attribute__((ext_vector_type(2)));
 typedef float akz_f4 __attribute__((ext_vector_type(4)));
@@ -790,7 +798,8 @@ __global__ __launch_bounds__(256) void k_akz_dhess(const float *__restrict__ lsm
     constexpr int OW = 64 - 4 * S;   // output columns per strip
     const int lane = threadIdx.x & 63;
     const int nstr = (w + OW - 1) / OW, nband = (h + band_rows - 1) / band_rows;
-    int id = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    // the strip is a property of the wavefront: said so, its rows' addresses (reflection included) are computed on the scalar unit
+    int id = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     if (id >= nstr * nband * nframes) return;
     const int f = id / (nstr * nband);
     id -= f * nstr * nband;
@@ -814,10 +823,10 @@ __global__ __launch_bounds__(256) void k_akz_dhess(const float *__restrict__ lsm
     // the rows of the NEXT group of P are fetched while this group is worked on: P full lines in flight per wavefront
     float cur[P], nxt[P];
 #pragma unroll
-    for (int k = 0; k < P; ++k) cur[k] = src[(size_t)akz_reflect(y0 - 2 * S + k, h) * w + cx];
+    for (int k = 0; k < P; ++k) cur[k] = src[(size_t)akz_reflect1(y0 - 2 * S + k, h) * w + cx];
     for (int t0 = 0; t0 < T; t0 += P) {
 #pragma unroll
-        for (int k = 0; k < P; ++k) nxt[k] = src[(size_t)akz_reflect(y0 - 2 * S + t0 + P + k, h) * w + cx];
+        for (int k = 0; k < P; ++k) nxt[k] = src[(size_t)akz_reflect1(y0 - 2 * S + t0 + P + k, h) * w + cx];
 #pragma unroll
         for (int k = 0; k < P; ++k) {
             const int t = t0 + k;
