@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void k_akz_describe(AkdDescParams P, const afv
     __shared__ float s_val[4][96];
     __shared__ float4 s_smp[4][441];  // MLDB samples of the 21 x 21 pattern positions: {Lt, rotated Lx, rotated Ly, -}; before that, the
                                       // first 109 entries hold the orientation samples {angle, weighted Lx, weighted Ly, angle < 2 pi (as 1 / 0)}
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, f = blockIdx.y;
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63, f = blockIdx.y;  // the keypoint is the wavefront's
     const int slot = blockIdx.x * 4 + wv;
     // slot -> (level, position): levels ascending (mergeKeypointLevels, FeatureExtractor.cpp:296-308)
     int level = -1, pos = slot, total = 0;

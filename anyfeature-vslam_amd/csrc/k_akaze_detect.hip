@@ -62,7 +62,7 @@ __device__ __forceinline__ float akm_from_right(float v) {  // lane i <- lane i 
 }
 __global__ __launch_bounds__(256) void k_akz_cand_mask(AkdParams P, AkmWork W, int nframes, unsigned long long *__restrict__ mask) {
     const int lane = threadIdx.x & 63;
-    const int strip = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    const int strip = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);  // wave-uniform: level / strip / row arithmetic on the scalar unit
     if (strip >= W.strip_off[P.nlevels]) return;
     int level = 0;
     while (strip >= W.strip_off[level + 1]) ++level;

@@ -174,7 +174,8 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
     const LevelGeo &L = geo.lv[l];
     const int kblk = blk - L.desc_blk_base;
     const int f = frame_base + fl;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the keypoint is a property of the wavefront: said so, its record, its patch origin and every per-keypoint scalar live on the scalar unit
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int idx = kblk * KP_PER_BLOCK + wv;
 
     // frame-level bookkeeping: counts of the eight levels (scalar loads), this level's first output slot, total

@@ -337,7 +337,7 @@ template <int K, int REC>
 __global__ __launch_bounds__(PT) void k_proj_topk(const DevProjJob *__restrict__ jobs) {
     __shared__ int2 s_list[PT / 64][PW_LIST];
     const DevProjJob J = jobs[blockIdx.y];
-    const int lane = threadIdx.x & 63, q = blockIdx.x * (PT / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, q = blockIdx.x * (PT / 64) + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     if (q >= J.nq) return;
     if (J.words == 8) topk_query<8, K, REC>(J, q, lane, s_list[threadIdx.x >> 6]);
     else topk_query<16, K, REC>(J, q, lane, s_list[threadIdx.x >> 6]);
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(PT) void k_proj_topk(const DevProjJob *__restrict__
 template <int K, int REC>
 __global__ __launch_bounds__(PT) void k_proj_topk1(const DevProjJob J) {
     __shared__ int2 s_list[PT / 64][PW_LIST];
-    const int lane = threadIdx.x & 63, q = blockIdx.x * (PT / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, q = blockIdx.x * (PT / 64) + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     if (q >= J.nq) return;
     if (J.words == 8) topk_query<8, K, REC>(J, q, lane, s_list[threadIdx.x >> 6]);
     else topk_query<16, K, REC>(J, q, lane, s_list[threadIdx.x >> 6]);
@@ -979,14 +979,14 @@ __device__ void fuse_query(const DevProjJob &J, int q, int lane, int2 *s_list) {
 __global__ __launch_bounds__(PT) void k_match_fuse(const DevProjJob *__restrict__ jobs) {
     __shared__ int2 s_list[PT / 64][PW_LIST];
     const DevProjJob J = jobs[blockIdx.y];
-    const int lane = threadIdx.x & 63, q = blockIdx.x * (PT / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, q = blockIdx.x * (PT / 64) + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     if (q >= J.nq) return;
     if (J.words == 8) fuse_query<8>(J, q, lane, s_list[threadIdx.x >> 6]);
     else fuse_query<16>(J, q, lane, s_list[threadIdx.x >> 6]);
 }
 __global__ __launch_bounds__(PT) void k_match_fuse1(const DevProjJob J) {
     __shared__ int2 s_list[PT / 64][PW_LIST];
-    const int lane = threadIdx.x & 63, q = blockIdx.x * (PT / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, q = blockIdx.x * (PT / 64) + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     if (q >= J.nq) return;
     if (J.words == 8) fuse_query<8>(J, q, lane, s_list[threadIdx.x >> 6]);
     else fuse_query<16>(J, q, lane, s_list[threadIdx.x >> 6]);
