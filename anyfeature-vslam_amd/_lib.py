@@ -193,6 +193,7 @@ SYMBOLS = {
     "afv_akaze_get_quotas": (_i, [_vp, _vp]),
     "afv_akaze_set_step_by_step": (_i, [_vp, _i]),
     "afv_akaze_set_suppress_engine": (_i, [_vp, _i, _i]),
+    "afv_akaze_debug_neighbour_cap": (_i, [_vp, _i]),
     "afv_akaze_profile_enable": (_i, [_vp, _i]),
     "afv_akaze_profile_read": (_i, [_vp, _vp, _vp, _vp]),
     "afv_profile_enable": (_i, [_vp, _i]),

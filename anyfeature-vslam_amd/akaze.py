@@ -164,6 +164,9 @@ class AkazeContext:
         """ordered duplicate suppression: 0 = speculative rounds, 1 = fixed point, 2 = fixed point with fallback (default)"""
         self.check(self.lib.afv_akaze_set_suppress_engine(self.handle, int(mode), int(pass_cap)), "afv_akaze_set_suppress_engine")
 
+    def debug_neighbour_cap(self, cap=0):
+        self.check(self.lib.afv_akaze_debug_neighbour_cap(self.handle, int(cap)), "afv_akaze_debug_neighbour_cap")
+
     def profile_enable(self, on=True):
         self.check(self.lib.afv_akaze_profile_enable(self.handle, int(on)), "afv_akaze_profile_enable")
 

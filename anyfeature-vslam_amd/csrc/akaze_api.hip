@@ -794,6 +794,13 @@ extern "C" int afv_akaze_set_suppress_engine(afv_akaze *a, int mode, int pass_ca
     return AFV_OK;
 }
 
+// test hook: the fixed-point engine gives up (status 6) on a candidate with more than `cap` earlier in-range candidates (0: the built-in 16)
+extern "C" int afv_akaze_debug_neighbour_cap(afv_akaze *a, int cap) {
+    if (!a || cap < 0) return AFV_EINVAL;
+    a->ds.fp_nbr_cap = cap;
+    return AFV_OK;
+}
+
 // test hook: 1 = run pm_g2 and every FED step as its own kernel (the reference structure), 0 = fused level kernel (default)
 extern "C" int afv_akaze_set_step_by_step(afv_akaze *a, int on) {
     if (!a) return AFV_EINVAL;

@@ -54,6 +54,7 @@ struct AkdState {
     int *fp_ctl;              // [frame][AKF_CTL]: how many of those per level [16] | the pass that found the frame converged | per pass: changed something
     unsigned short *wpre;     // [frame][rows_stride][AKD_MAXCHUNKS] candidates of the row in front of the 64-column word (k_akz_cand_emit)
     int fp_pass_cap;
+    int fp_nbr_cap;           // 0 = AKF_K; smaller: test hook that makes the engine give up (status 6) on ordinary frames
 };
 #define AKF_K 16
 #define AKF_PASSES 16  // pass launches enqueued per call (the bench frames and band-limited noise need 8; a launch for a converged frame costs ~5 us)

@@ -859,7 +859,7 @@ __global__ __launch_bounds__(AKF_T) void k_akz_fp_build(AkdParams P, AkdState S,
                     }
                 }
             }
-            if (cnt > AKF_K) atomicExch(status, 6);
+            if (cnt > (S.fp_nbr_cap > 0 ? min(S.fp_nbr_cap, AKF_K) : AKF_K)) atomicExch(status, 6);
             my_cnt = min(cnt, AKF_K);
             my_resp = cr[k];
             S.fp_state[(fo + gid) * 2] = make_int4(AKF_APPEND, gid, __float_as_int(my_resp), 0);

@@ -100,6 +100,8 @@ int afv_akaze_set_step_by_step(afv_akaze *a, int on);
  * than 16 earlier candidates inside its radius), 2 = engine 1, and engine 0 for a batch it gives up on (default).  pass_cap > 0 bounds
  * the fixed point's passes (test hook). */
 int afv_akaze_set_suppress_engine(afv_akaze *a, int mode, int pass_cap);
+/* test hook: engine 1 gives up on a candidate with more than `cap` earlier in-range candidates (0 = the built-in 16) */
+int afv_akaze_debug_neighbour_cap(afv_akaze *a, int cap);
 /* per-stage timing like afv_profile_*: stage 0 scale space, 1 hessian */
 int afv_akaze_profile_enable(afv_akaze *a, int on);
 int afv_akaze_profile_read(afv_akaze *a, float *ms_scale_space, float *ms_hessian, int *launches);

@@ -400,6 +400,18 @@ def test_fixed_point_gives_up_loudly_or_falls_back(afv, suppress_engine):
     ctx.scale_space(frames)
     ctx.detect()
     assert [ctx.keypoints(f).tobytes() for f in range(2)] == want
+    # the other reason to give up: more earlier in-range candidates than a record holds (forced: at most one)
+    ctx.set_suppress_engine(1)
+    ctx.debug_neighbour_cap(1)
+    ctx.scale_space(frames)
+    ctx.detect()
+    with pytest.raises(RuntimeError):
+        ctx.keypoints(0)
+    ctx.set_suppress_engine(2)
+    ctx.scale_space(frames)
+    ctx.detect()
+    assert [ctx.keypoints(f).tobytes() for f in range(2)] == want
+    ctx.debug_neighbour_cap(0)
     kps, desc = ctx.extract(frames)[0]
     ctx.set_suppress_engine(0)
     kps0, desc0 = ctx.extract(frames)[0]
