@@ -7,14 +7,15 @@
 //   1. the tile plus a 4 px halo (ring radius 3 + the NMS neighbour) is staged in LDS with coalesced dword loads;
 //   2a. OpenCV's necessary pre-test (each of the 4 even antipodal ring pairs must hold a brighter / a darker pixel) on
 //      the 66x34 ring-extended tile, TWO horizontally adjacent pixels per lane as packed u16 pairs: per polarity
-//      min over the pairs of max(a, b) - v > t  /  v - max over the pairs of min(a, b) > t.  Survivors go to an LDS list,
-//      one entry per (pixel, polarity);
+//      min over the pairs of max(a, b) - v > t  /  v - max over the pairs of min(a, b) > t.  A thread's 5 rows share their
+//      operands (a row's centre pair is the vertical ring pair three rows up and down, ...): 16 LDS reads of aligned dwords
+//      per thread.  Survivors go to two LDS lists (bright / dark), one entry per (pixel, polarity);
 //   2b. the exact corner score = largest threshold for which the pixel is still a 9-arc corner, two list entries per
 //      lane (the packed halves now carry two different pixels of one polarity each): 16 ring differences,
 //      van-Herk prefix/suffix minima over the two ring halves (59 packed min/max), corner iff score > threshold; scores go
 //      to an LDS score plane (a pixel is a corner in at most one polarity: two 9-arcs of a 16-ring overlap);
-//   3. strict 3x3 maxima, dense over the score plane (again two pixels per lane, packed max), compacted into an LDS list
-//      (<= 512 per tile);
+//   3. strict 3x3 maxima, dense over the score plane (again two pixels per lane, packed max; a thread owns 4 consecutive rows
+//      and reduces each score row once), compacted into an LDS list (<= 512 per tile);
 //   4. one global atomic per tile reserves output slots in the (frame, level) candidate array.
 // Candidates leave the kernel unordered; everything downstream is order-independent (ties are broken by the
 // raster index), see DESIGN.md "canonical order".
@@ -53,6 +54,14 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_BCAST31, 0xc, 0xf, false);
     return v;
 }
+// one lane's LDS fetch-add as ONE instruction (the compiler's wave aggregation of atomics - mbcnt, compare, popcount, multiply - is dead
+// weight when a single lane is active by construction)
+__device__ __forceinline__ int lds_add_rtn_one_lane(int *p, int v) {
+    int r;
+    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int *)p;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(a), "v"(v) : "memory");
+    return r;
+}
 // LDS row pitch of the tile and of the score plane: the 72 staged bytes of a row + 4 bytes of padding.  19 dwords per row instead of 18
 // skews the bank pattern of the scattered byte reads of stage 2b (round 4, tools/experiments.py with -DFT_PITCH=n: 72 -> 76 bytes
 // = 5 % fewer bank-conflict cycles, kernel -2.2 %; 80 and 84 are worse than 72).  Must be a multiple of 4.
@@ -67,6 +76,7 @@ static_assert(FT_PITCH >= FT_LW && FT_PITCH % 4 == 0, "tile pitch");
 #define PRE_GROUPS (256 / PRE_PAIRS)      // 7 row groups of 34 threads
 #define PRE_ITERS ((PRE_ROWS + PRE_GROUPS - 1) / PRE_GROUPS)  // rows rg, rg + 7, ... : 5 iterations
 #define PRE_MAX (2 * PRE_ROWS * 2 * PRE_PAIRS)  // one entry per (pixel, polarity)
+#define PRE_DARK0 (PRE_MAX / 2)  // first entry of the dark list (ballot form: both lists grow upwards, each can hold every pixel)
 #define PRE_PAD_ROWS (PRE_GROUPS * PRE_ITERS - PRE_ROWS)  // rows past the tile the masked iterations of the last row group touch (1 at FT_H = 32)
 #define ST_GROUPS 14                                       // staging: 18 dword columns x 14 row groups = 252 threads
 #define ST_ITERS ((FT_LH + ST_GROUPS - 1) / ST_GROUPS)     // rows rs, rs + 14, ... (3 at FT_H = 32)
@@ -210,73 +220,90 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Geo *__restrict__ geo_p,
     return;
 #endif
     // 2a. pre-test on LDS rows 3..36 x columns 3..68 (= tile pixels -1..32 x -1..64).  Thread (pr, rg) = (tid % 34, tid / 34)
-    //     owns the pixel pair at columns 2 + 2 pr, 3 + 2 pr of the rows 5 rg .. 5 rg + 4 (238 of the 256 threads): the column
-    //     never changes, so every LDS read of the unrolled loop is base + immediate.  The pass flags are the sign bits of
-    //     (v + t) - (min over pairs of max(a, b)) [bright] and (max over pairs of min(a, b)) - (v - t) [dark].
+    //     owns the pixel pair at columns 2 + 2 pr, 3 + 2 pr of the rows 5 rg .. 5 rg + 4 (238 of the 256 threads; threads 238 .. 255
+    //     repeat row group 6 with every pixel declared invalid): the column never changes, so every LDS read is base + immediate.
+    //     The pass flags are the sign bits of (v + t) - (min over pairs of max(a, b)) [bright] and (max over pairs of min(a, b)) -
+    //     (v - t) [dark].  Validity costs nothing inside the loop (round 5): a pixel outside the FAST border of the level in x (or outside
+    //     the ring-extended tile) gets the threshold 0x3fff in ITS half of T0 and can never pass; rows are not tested here at all - rows
+    //     outside the FAST border in y exist in the top / bottom tiles of a level only and their scores are cleared by step 3 before
+    //     anything looks at them, and the one row the last row group computes past the ring-extended tile (LDS row 38) lies where
+    //     step 3 never reads.
     const int thr = geo.fast_threshold;
     {
-        const int rg = (int)(__umul24((unsigned)tid, 1928u) >> 16);  // tid / 34 (exact for tid < 256)
-        const int pr = tid - rg * PRE_PAIRS;
+        const int rg0 = (int)(__umul24((unsigned)tid, 1928u) >> 16);  // tid / 34 (exact for tid < 256)
+        const int rg = min(rg0, PRE_GROUPS - 1);
+        const int pr = tid - rg0 * PRE_PAIRS;  // threads >= 238: 0 .. 17 (in range, unused)
         const int col = 2 + 2 * pr, gx = gx0 + col;
-        uint32_t pb = 0, pd = 0;  // PASS flags: bit (16 - PRE_ITERS + it) = pixel 0, bit (32 - PRE_ITERS + it) = pixel 1 of iteration it
-        if (rg < PRE_GROUPS) {
-            short2v T0;
-            T0.x = T0.y = (short)thr;
-            const uint8_t *c = &tile[(rg * PRE_ITERS + 3) * FT_PITCH + col];
-            // centre row: v and the ring pixels at dx = -3 / +3 sit at ODD distances, and an unaligned LDS read stalls the LDS pipe
-            // (SQ_LDS_UNALIGNED_STALL).  So the row is read as the three ALIGNED dwords that hold bytes col-4 .. col+5 and the
-            // three pairs are cut out with byte permutes whose selectors depend on col & 2 only (computed once per thread).
-            const int sh = (col - 4) & 3;  // 0 or 2
-            const uint32_t *cw = reinterpret_cast<const uint32_t *>(c - 4 - sh);
-            const uint32_t sel_b = 0x0c020c01u + (uint32_t)sh * 0x00010001u;  // (col-3, col-2) out of (w1:w0)
-            const uint32_t sel_v = 0x0c050c04u + (uint32_t)sh * 0x00010001u;  // (col,   col+1) out of (w1:w0)
-            const uint32_t sel_a = 0x0c040c03u + (uint32_t)sh * 0x00010001u;  // (col+3, col+4) out of (w2:w1)
-            // No row test inside the loop: rows outside the FAST border of the level (and row 34 of the last row group, which
-            // reads one row past the tile into the padding) are computed like the others and masked out afterwards.
+        short2v T0;
+        T0.x = (short)((rg0 < PRE_GROUPS && pr > 0 && gx >= 3 && gx < lw - 3) ? thr : 0x3fff);
+        T0.y = (short)((rg0 < PRE_GROUPS && pr < PRE_PAIRS - 1 && gx + 1 >= 3 && gx + 1 < lw - 3) ? thr : 0x3fff);
+        const int p00 = (rg * PRE_ITERS + 3) * FT_PITCH + col;
+        const uint8_t *c = &tile[p00];
+        const int sh = (col - 4) & 3;  // 0 or 2
+        const uint32_t *cw = reinterpret_cast<const uint32_t *>(c - 4 - sh);
+        const uint32_t sel_b = 0x0c020c01u + (uint32_t)sh * 0x00010001u;  // (col-3, col-2) out of (w1:w0)
+        const uint32_t sel_v = 0x0c050c04u + (uint32_t)sh * 0x00010001u;  // (col,   col+1) out of (w1:w0)
+        const uint32_t sel_a = 0x0c040c03u + (uint32_t)sh * 0x00010001u;  // (col+3, col+4) out of (w2:w1)
+        // Operand fetch, LDS instructions counted (the LDS pipe is as busy as the vector ALU in this kernel): the thread's rows r = -3 ..
+        // PRE_ITERS + 2 around its PRE_ITERS centre rows.  The centre pair of row r is the vertical ring pair of rows r - 3 and r + 3, the
+        // pairs at columns -2 / +2 of row r serve rows r - 2 and r + 2, and all of them lie in the aligned dwords read for the row anyway:
+        // centre rows = 3 dwords (bytes col-4-sh .. col+7-sh, two instructions), the two rows above / below = 2 dwords (bytes col-2-sh2 ..
+        // col+5-sh2, one instruction), rows -3 and PRE_ITERS + 2 = the centre pair alone.  16 LDS instructions per thread (35 when every
+        // pair was read by itself); every pair is cut out with one byte permute whose selector depends on col & 2 only.
+        const int sh2 = sh ^ 2;
+        const uint32_t *cw2 = reinterpret_cast<const uint32_t *>(c - 2 - sh2);
+        const uint32_t sel_l = 0x0c030c02u + (uint32_t)sh * 0x00010001u;    // (col-2, col-1) out of (w1:w0); (col+2, col+3) out of (w2:w1)
+        const uint32_t sel2_l = 0x0c010c00u + (uint32_t)sh2 * 0x00010001u;  // two-dword rows: (col-2, col-1)
+        const uint32_t sel2_v = 0x0c030c02u + (uint32_t)sh2 * 0x00010001u;  //                 (col,   col+1)
+        const uint32_t sel2_r = 0x0c050c04u + (uint32_t)sh2 * 0x00010001u;  //                 (col+2, col+3)
+        short2v Vc[PRE_ITERS + 6], R2[PRE_ITERS + 4], L2[PRE_ITERS + 4], A4[PRE_ITERS], B4[PRE_ITERS];  // Vc[k]: row k - 3; R2 / L2[k]: row k - 2
+        Vc[0] = ld_pair(c, -3 * FT_PITCH);
+        Vc[PRE_ITERS + 5] = ld_pair(c, (PRE_ITERS + 2) * FT_PITCH);
 #pragma unroll
-            for (int it = 0; it < PRE_ITERS; ++it) {
-                const int o = it * FT_PITCH;
+        for (int r = -2; r < PRE_ITERS + 2; ++r) {
+            if (r >= 0 && r < PRE_ITERS) {
+                const int o = r * FT_PITCH;
                 const uint32_t w0 = cw[o / 4], w1 = cw[o / 4 + 1], w2 = cw[o / 4 + 2];
-                const short2v V = as_s2(__builtin_amdgcn_perm(w1, w0, sel_v));
-                const short2v a4 = as_s2(__builtin_amdgcn_perm(w2, w1, sel_a)), b4 = as_s2(__builtin_amdgcn_perm(w1, w0, sel_b));
-                const short2v a0 = ld_pair(c, o + RING_OFF(0, 3)), b0 = ld_pair(c, o + RING_OFF(0, -3));
-                const short2v a2 = ld_pair(c, o + RING_OFF(2, 2)), b2 = ld_pair(c, o + RING_OFF(-2, -2));
-                const short2v a6 = ld_pair(c, o + RING_OFF(2, -2)), b6 = ld_pair(c, o + RING_OFF(-2, 2));
-                const short2v hi = pkmin(pkmin(pkmax(a0, b0), pkmax(a2, b2)), pkmin(pkmax(a4, b4), pkmax(a6, b6)));
-                const short2v lo = pkmax(pkmax(pkmin(a0, b0), pkmin(a2, b2)), pkmax(pkmin(a4, b4), pkmin(a6, b6)));
-                // (V + t) - hi < 0  <=>  hi - V > t (bright);  lo - (V - t) < 0  <=>  V - lo > t (dark): the arithmetic shift spreads
-                // the sign over the half, the iteration's bit is kept
-                const uint32_t bit = 0x00010001u << (16 - PRE_ITERS + it);
-                pb |= as_u32(pk_sar15((V + T0) - hi)) & bit;
-                pd |= as_u32(pk_sar15(lo - (V - T0))) & bit;
+                Vc[r + 3] = as_s2(__builtin_amdgcn_perm(w1, w0, sel_v));
+                A4[r] = as_s2(__builtin_amdgcn_perm(w2, w1, sel_a));
+                B4[r] = as_s2(__builtin_amdgcn_perm(w1, w0, sel_b));
+                L2[r + 2] = as_s2(__builtin_amdgcn_perm(w1, w0, sel_l));
+                R2[r + 2] = as_s2(__builtin_amdgcn_perm(w2, w1, sel_l));
+            } else {
+                const int o = r * FT_PITCH;  // FT_PITCH is a multiple of 4
+                const uint32_t w0 = cw2[o / 4], w1 = cw2[o / 4 + 1];
+                L2[r + 2] = as_s2(__builtin_amdgcn_perm(w1, w0, sel2_l));
+                Vc[r + 3] = as_s2(__builtin_amdgcn_perm(w1, w0, sel2_v));
+                R2[r + 2] = as_s2(__builtin_amdgcn_perm(w1, w0, sel2_r));
             }
-            // rows: iteration `it` is row r = 5 rg + it, global row gy0 + 3 + r; valid <=> r < PRE_ROWS and 3 <= gy < lh - 3
-            const int gyr = gy0 + 3 + rg * PRE_ITERS;
-            const int it_lo = max(3 - gyr, 0), it_hi = min(min(lh - 3 - gyr, PRE_ROWS - rg * PRE_ITERS), PRE_ITERS);
-            const uint32_t rowm = it_hi > it_lo ? (((1u << it_hi) - (1u << it_lo)) << (16 - PRE_ITERS)) * 0x00010001u : 0u;
-            pb &= rowm;
-            pd &= rowm;
         }
-        // columns inside the FAST border of the level (and inside the ring-extended tile)
-        const uint32_t itm = (0xffffu << (16 - PRE_ITERS)) & 0xffffu;
-        const uint32_t colm = ((pr > 0 && gx >= 3 && gx < lw - 3) ? itm : 0u) |
-                              ((pr < PRE_PAIRS - 1 && gx + 1 >= 3 && gx + 1 < lw - 3) ? (itm << 16) : 0u);
-        const uint32_t bb = pb & colm, bd = pd & colm;
-        // Compaction: exclusive prefix of the per-lane survivor counts (both polarities packed in one register, one DPP scan), two
-        // LDS atomics per wavefront, then every lane writes its own <= 10 + 10 entries with predicated stores (no loops, no
-        // ballots).  A lane's entries are a 2 x 5 pixel block and neighbouring lanes hold neighbouring column pairs, so list
-        // neighbours stay image neighbours and the scattered ring reads of step 2b hit few LDS bank windows.
+        // flags as bits of two registers (bit 16 - PRE_ITERS + it = pixel 0, bit 32 - PRE_ITERS + it = pixel 1 of iteration it), compaction:
+        // exclusive prefix of the per-lane survivor counts (both polarities packed in one register, one DPP scan), two LDS atomics per
+        // wavefront, then every lane writes its own <= 10 + 10 entries with predicated stores.  A lane's entries are a 2 x 5 pixel block and
+        // neighbouring lanes hold neighbouring column pairs, so list neighbours stay image neighbours and the scattered ring reads of
+        // step 2b hit few LDS bank windows.
+        uint32_t bb = 0, bd = 0;
+#pragma unroll
+        for (int it = 0; it < PRE_ITERS; ++it) {
+            const short2v V = Vc[it + 3], a0 = Vc[it + 6], b0 = Vc[it];
+            const short2v a2 = R2[it + 4], b2 = L2[it], a6 = R2[it], b6 = L2[it + 4];
+            const short2v a4 = A4[it], b4 = B4[it];
+            const short2v hi = pkmin(pkmin(pkmax(a0, b0), pkmax(a2, b2)), pkmin(pkmax(a4, b4), pkmax(a6, b6)));
+            const short2v lo = pkmax(pkmax(pkmin(a0, b0), pkmin(a2, b2)), pkmax(pkmin(a4, b4), pkmin(a6, b6)));
+            const uint32_t bit = 0x00010001u << (16 - PRE_ITERS + it);
+            bb |= as_u32(pk_sar15((V + T0) - hi)) & bit;
+            bd |= as_u32(pk_sar15(lo - (V - T0))) & bit;
+        }
         const int cnt = __popc(bb) | (__popc(bd) << 16);
         const int incl = wave_incl_scan(cnt);
         int base_b = 0, base_d = 0;
         if (lane == 63) {
-            base_b = atomicAdd(&pre_nb, incl & 0xffff);
-            base_d = atomicAdd(&pre_nd, incl >> 16);
+            base_b = lds_add_rtn_one_lane(&pre_nb, incl & 0xffff);
+            base_d = lds_add_rtn_one_lane(&pre_nd, incl >> 16);
         }
         const int excl = incl - cnt;
-        unsigned short *wb = pre + __shfl(base_b, 63, 64) + (excl & 0xffff);
-        unsigned short *wd = pre + (PRE_MAX - 1) - (__shfl(base_d, 63, 64) + (excl >> 16));
-        const int p00 = (rg * PRE_ITERS + 3) * FT_PITCH + col;
+        unsigned short *wb = pre + __builtin_amdgcn_readlane(base_b, 63) + (excl & 0xffff);
+        unsigned short *wd = pre + PRE_DARK0 + __builtin_amdgcn_readlane(base_d, 63) + (excl >> 16);
 #pragma unroll
         for (int it = 0; it < PRE_ITERS; ++it) {
 #pragma unroll
@@ -286,7 +313,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Geo *__restrict__ geo_p,
                 if ((bb >> pos) & 1u) *wb = val;
                 wb += (bb >> pos) & 1u;
                 if ((bd >> pos) & 1u) *wd = val;
-                wd -= (bd >> pos) & 1u;
+                wd += (bd >> pos) & 1u;
             }
         }
     }
@@ -302,10 +329,10 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Geo *__restrict__ geo_p,
             const int i = i0 + tid;
             if (2 * i < nlist) {
                 const bool two = 2 * i + 1 < nlist;
-                // bright: entries 2i, 2i+1 from the front; dark: entries PRE_MAX-1-2i, PRE_MAX-2-2i (one aligned dword either way)
-                const uint32_t e2 = *reinterpret_cast<const uint32_t *>(&pre[DARK ? PRE_MAX - 2 - 2 * i : 2 * i]);
-                const int p0 = (int)(DARK ? (e2 >> 16) : (e2 & 0xffffu));
-                const int p1 = two ? (int)(DARK ? (e2 & 0xffffu) : (e2 >> 16)) : p0;
+                // entries 2i, 2i+1 of the bright list (from entry 0) or of the dark list (from entry PRE_DARK0): one aligned dword
+                const uint32_t e2 = *reinterpret_cast<const uint32_t *>(&pre[(DARK ? PRE_DARK0 : 0) + 2 * i]);
+                const int p0 = (int)(e2 & 0xffffu);
+                const int p1 = two ? (int)(e2 >> 16) : p0;
                 const uint8_t *c0 = &tile[p0], *c1 = &tile[p1];
                 const short2v best = fast_score2<DARK>(c0, c1, ld_two(c0, c1, 0));
                 const int s0 = best.x, s1 = best.y;
@@ -324,32 +351,47 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Geo *__restrict__ geo_p,
     return;
 #endif
     // 3. strict 3x3 maxima, dense over the score plane: thread (pair, rr) = (tid & 31, tid >> 5) owns the pixel pair at LDS columns
-    //    4 + 2 pair, 5 + 2 pair of rows 4 + rr, 12 + rr, 20 + rr, 28 + rr.  Per row of the 3x3 neighbourhood the three packed pairs
-    //    A = (s[c-1], s[c]), B = (s[c], s[c+1]), C = (s[c+1], s[c+2]) hold the neighbours of pixel 0 in the low and of pixel 1 in the
-    //    high halves; keep <=> own score > every neighbour (a zero score never is).  Keep flags -> one compaction per wavefront.
+    //    c = 4 + 2 pair, c + 1 of the NR = FT_H / 8 CONSECUTIVE tile rows NR rr .. NR rr + NR - 1.  Per score row the packed pairs
+    //    (s[c-1], s[c]), (s[c], s[c+1]), (s[c+1], s[c+2]) hold left neighbour / self / right neighbour of pixel 0 in the low and of
+    //    pixel 1 in the high halves; the horizontal maxima of a row serve the pixel above and the pixel below, so each of the NR + 2
+    //    rows is read (two aligned dwords, one LDS instruction) and reduced ONCE - 3 permutes + 2 packed max - and an output costs two
+    //    more packed max (round 5; rows 8 apart, every row of every 3x3 window fetched by itself: 114 -> 86 vector, 40 -> 10 LDS
+    //    instructions per thread).  keep <=> own score > every neighbour (a zero score never is).  Keep flags -> one compaction per wavefront.
     {
         const int c = 4 + 2 * (tid & 31), rr = tid >> 5;
-        const uint8_t *q0 = &sc[(4 + rr) * FT_PITCH + c];
         uint32_t kb = 0;
+        constexpr int NR = FT_H / 8;
+        const uint8_t *q0 = &sc[(FT_HALO + NR * rr) * FT_PITCH + c];
+        short2v Hm[NR + 2], Sd[NR + 2], Sf[NR + 2];  // max of (left, self, right); max of (left, right); self
+        // the four scores c-1 .. c+2 of a row lie in two aligned dwords (one LDS instruction); selectors depend on c & 2 only
+        const int nsh = (c - 1) & 3;  // 3 or 1
+        const uint32_t *qw = reinterpret_cast<const uint32_t *>(q0 - 1 - nsh);
+        const uint32_t nsel_a = 0x0c010c00u + (uint32_t)nsh * 0x00010001u;  // (c-1, c)
+        const uint32_t nsel_b = 0x0c020c01u + (uint32_t)nsh * 0x00010001u;  // (c,   c+1)
+        const uint32_t nsel_c = 0x0c030c02u + (uint32_t)nsh * 0x00010001u;  // (c+1, c+2)
 #pragma unroll
-        for (int it = 0; it < FT_H / 8; ++it) {
-            const uint8_t *q = q0 + it * 8 * FT_PITCH;
-            unsigned short top, mid, bot;
-            __builtin_memcpy(&top, q - FT_PITCH, 2);
-            __builtin_memcpy(&mid, q, 2);
-            __builtin_memcpy(&bot, q + FT_PITCH, 2);
-            const uint32_t tl = q[-FT_PITCH - 1], tr = q[-FT_PITCH + 2], ml = q[-1], mr = q[2], bl = q[FT_PITCH - 1], br = q[FT_PITCH + 2];
-#define NMS_A(w, l) as_s2(__builtin_amdgcn_perm((uint32_t)(w), (l), 0x0c040c00u))  // (left, w.byte0)
-#define NMS_B(w) as_s2(__builtin_amdgcn_perm(0u, (uint32_t)(w), 0x0c010c00u))       // (w.byte0, w.byte1)
-#define NMS_C(w, r) as_s2(__builtin_amdgcn_perm((uint32_t)(w), (r), 0x0c000c05u))  // (w.byte1, right)
-            const short2v nt = pkmax(pkmax(NMS_A(top, tl), NMS_B(top)), NMS_C(top, tr));
-            const short2v nb = pkmax(pkmax(NMS_A(bot, bl), NMS_B(bot)), NMS_C(bot, br));
-            const short2v nm = pkmax(NMS_A(mid, ml), NMS_C(mid, mr));
-            const short2v self = NMS_B(mid);
-#undef NMS_A
-#undef NMS_B
-#undef NMS_C
-            const uint32_t x = as_u32(pkmax(pkmax(nt, nb), nm) - self);  // sign bit set <=> self > every neighbour
+        for (int k = 0; k < NR + 2; ++k) {
+            const uint32_t w0 = qw[(k - 1) * (FT_PITCH / 4)], w1 = qw[(k - 1) * (FT_PITCH / 4) + 1];
+            Sf[k] = as_s2(__builtin_amdgcn_perm(w1, w0, nsel_b));
+            Sd[k] = pkmax(as_s2(__builtin_amdgcn_perm(w1, w0, nsel_a)), as_s2(__builtin_amdgcn_perm(w1, w0, nsel_c)));
+            Hm[k] = pkmax(Sd[k], Sf[k]);
+        }
+        // top / bottom tiles of a level: scores of rows outside the FAST border (rows < 3 or >= h - 3; step 2a does not test rows) are
+        // not scores - cleared here, in registers, before anything compares with them
+        if (gy0 < 0 || gy0 + FT_HALO + FT_H >= lh - 3) {
+#pragma unroll
+            for (int k = 0; k < NR + 2; ++k) {
+                const int gy = gy0 + FT_HALO + NR * rr + k - 1;
+                if (gy < 3 || gy >= lh - 3) {
+                    Hm[k] = as_s2(0u);
+                    Sd[k] = as_s2(0u);
+                    Sf[k] = as_s2(0u);
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NR; ++it) {
+            const uint32_t x = as_u32(pkmax(pkmax(Hm[it], Hm[it + 2]), Sd[it + 1]) - Sf[it + 1]);  // sign bit set <=> self > every neighbour
             kb = pk_shr1(kb) | (x & 0x80008000u);
         }
         kb &= ((0xffffu << (16 - FT_H / 8)) & 0xffffu) * 0x00010001u;
@@ -362,7 +404,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Geo *__restrict__ geo_p,
         while (kb) {
             const int qb = __builtin_ctz(kb);
             kb &= kb - 1;
-            const int px = c - FT_HALO + (qb >> 4), py = rr + 8 * ((qb & 15) - (16 - FT_H / 8));
+            const int px = c - FT_HALO + (qb >> 4), py = NR * rr + ((qb & 15) - (16 - NR));
             list[base++] = (uint32_t)px | ((uint32_t)py << 8) | ((uint32_t)sc[(py + FT_HALO) * FT_PITCH + px + FT_HALO] << 16);
         }
     }
