@@ -308,3 +308,66 @@ def test_toy_sequence_as_one_chained_run(afv, oracle, fctx):
         prev = (k, d, fv, size)
         fr.close()
     table.close(); voc.close()
+
+
+@pytest.mark.parametrize("engine", [1, 3, 0], ids=["fixed_point_one_launch", "fixed_point_two_launches", "ordered_walk"])
+def test_featureless_and_nearly_featureless_frames_through_the_whole_chain(afv, oracle, fctx, engine):
+    """a constant image yields a frame with N = 0 (the tracker sees these: lens cap, saturation); every consumer of the chain must
+    answer 'nothing' for it - as the searched frame and as the source of the queries - and a frame with a handful of features must
+    still agree with the oracle"""
+    fctx.check(fctx.lib.afv_set_projection_resolve(fctx.handle, engine))
+    voc = afv.Vocabulary.random(11, k=6, L=3, ctx=fctx)
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+    m = afv.FeatureMatcher(0.9, True, ctx=fctx)
+    blank = afv.Frame(fctx)
+    k0, d0 = blank.extract(np.full((480, 640), 128, np.uint8))
+    assert len(k0) == 0 and len(d0) == 0 and blank.N == 0
+    ptr, order = blank.grid()
+    assert not ptr.any() and len(order) == 0
+    bow, fv = blank.ComputeBoW(voc, levelsup=1)
+    assert len(bow) == 0 and len(fv) == 0 and blank.featvec() == []
+    img = afv.synth.corners_frame(21)
+    full = afv.Frame(fctx)
+    k1, d1 = full.extract(img)
+    full.ComputeBoW(voc, levelsup=1)
+    Q = _queries(afv, fctx, 21, img, 4, 15.0)
+    got, n = blank.SearchByProjection(m, Q)                       # queries against nothing
+    assert n == 0 and len(got) == 0
+    best, nf = blank.Fuse(m, Q)
+    assert nf == 0 and np.all(best < 0)
+    empty_q = afv.ProjectionQueries(np.zeros((0, 32), np.uint8), [], [], [], [], [])
+    got, n = full.SearchByProjection(m, empty_q)                  # nothing against a full frame
+    assert n == 0 and len(got) == len(k1) and np.all(got == -1)
+    m12, n12 = blank.SearchForInitialization(m, full, np.zeros((0, 2), np.float32), 100.0)
+    assert n12 == 0 and len(m12) == 0
+    prev = np.stack([k1["x"], k1["y"]], 1)
+    m12, n12 = full.SearchForInitialization(m, blank, prev, 100.0)
+    assert n12 == 0 and len(m12) == len(k1) and np.all(m12 == -1)
+    table = afv.table.DescriptorTable(fctx, 3, fctx.cap)
+    table.set_from_frame(0, blank)                                # KeyFrame(F) of a featureless frame
+    table.set_from_frame(1, full)
+    mm, nm = table.match_bow([0, 1], [1, 0], 75.0, 0.75, True)
+    assert nm[0] == 0 and nm[1] == 0
+    mf, nfr = table.match_bow_frame_resident([0, 1], blank, 75.0, 0.7, True)
+    assert nfr[0] == 0 and nfr[1] == 0
+    mf, nfr = table.match_bow_frame_resident([0], full, 75.0, 0.7, True)
+    assert nfr[0] == 0
+    # a handful of features: three squares on a flat background
+    few_img = np.full((480, 640), 90, np.uint8)
+    for (y, x) in ((100, 120), (240, 400), (380, 220)):
+        few_img[y:y + 24, x:x + 24] = 200
+    few = afv.Frame(fctx)
+    kf, df = few.extract(few_img)
+    okf, odf = oracle.orb_extract(few_img)
+    assert kf.tobytes() == okf.tobytes() and np.array_equal(df, odf) and 0 < len(kf) < 200
+    sizef, _, _ = fctx.size_sigma(kf)
+    Fv = afv.FrameGridView(df, np.stack([kf["x"], kf["y"]], 1), sizef, angles=kf["angle"])
+    Qf = afv.ProjectionQueries(df, kf["x"] + np.float32(1), kf["y"], np.float32(15) * sizef, sizef / np.float32(1.2), sizef * np.float32(1.2),
+                               angles=kf["angle"])
+    got, n = few.SearchByProjection(m, Qf)
+    want, wn = oracle.match_projection(Fv, Qf, th_high=75.0, nnratio=0.9, check_orientation=True, last_frame=False)
+    assert n == wn and np.array_equal(got, want) and wn > 0
+    for fr in (blank, full, few):
+        fr.close()
+    table.close(); voc.close()
+    fctx.lib.afv_set_projection_resolve(fctx.handle, 2)
