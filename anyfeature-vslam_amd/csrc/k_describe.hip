@@ -103,7 +103,9 @@ __device__ __forceinline__ uint32_t blur_round(uint32_t S) { return __builtin_am
 // Row pass of the separable 8U filter over the whole staged patch, once per keypoint: H[r][xh] = sum_k taps[k] * P[r][xh + k]
 // for xh = 0..39 (<= 257 * 255 = 65535: exact in 16 bits).  One lane per group of 4 adjacent outputs: 3 aligned dwords in, two
 // v_dot4_u32_u8 per output on funnel-shifted dwords, 4 x u16 out.
-#define HP 44  // u16 pitch of the row-filtered plane (88 bytes: 8-byte aligned rows)
+#ifndef HP
+#define HP 40  // u16 pitch of the row-filtered plane (80 bytes: 8-byte aligned rows, no padding: 44 cost a workgroup of occupancy per CU)
+#endif
 __device__ __forceinline__ void blur_rows(const uint8_t *P, uint16_t *H, int lane) {
     const uint32_t T_LO = 18u | (34u << 8) | (49u << 16) | (55u << 24);  // taps for bytes xh .. xh+3
     const uint32_t T_HI = 49u | (34u << 8) | (18u << 16);                // taps for bytes xh+4 .. xh+6
@@ -155,10 +157,17 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
                                                                 int cap_per_frame, int *__restrict__ n_out,
                                                                 int *__restrict__ status, int frame_base, int per_frame, int total_blocks,
                                                                 DescribeMirror mir) {
-    // patch rows are PP = 52 bytes apart (13 dwords: odd -> rows spread over all LDS banks); 2 guard rows/dwords so that
-    // the 3-dword row reads of blur_at never leave the slice
-    __shared__ __attribute__((aligned(16))) uint8_t s_patch[KP_PER_BLOCK][(PS + 1) * PP];
-    __shared__ __attribute__((aligned(16))) uint16_t s_rows[KP_PER_BLOCK][PS * HP];  // row-filtered patch
+    // One LDS slice per wavefront holds BOTH the staged patch (u8, rows PP = 52 bytes apart: 13 dwords, odd -> rows spread over all
+    // LDS banks) and the row-filtered plane H (u16, rows 2 HP = 80 bytes apart) that is computed from it: H starts at byte 0, the patch
+    // at byte SLICE - PS * PP, and H row r ends at or before patch row r + 1 begins (80 r + 80 <= P_OFF + 52 (r + 1) for r <= 42), so the
+    // ascending row pass only ever overwrites patch rows it has consumed (rows sharing a wave iteration are read before anything of
+    // that iteration is written: DS operations of a wave execute in order).  3440 instead of 6028 bytes per keypoint: 8 instead of 6
+    // workgroups per CU.  The patch is dead after the row pass: the IC moments are taken first, and the rare test of a border keypoint
+    // that falls outside the level reads its (unblurred, reflected) pixel from the level image itself.
+    constexpr int SLICE = PS * HP * 2, P_OFF = SLICE - PS * PP;
+    static_assert(P_OFF % 4 == 0 && P_OFF >= 0 && 2 * HP * PS <= SLICE, "slice layout");
+    static_assert(2 * HP * (PS - 1) + 2 * HP <= P_OFF + PP * PS, "H row r must end before patch row r + 1 begins");
+    __shared__ __attribute__((aligned(16))) uint8_t s_slice[KP_PER_BLOCK][SLICE];
 
     const Geo &geo = *geo_p;
     // XCD-aware placement: all keypoints of a frame are described on one XCD (their patches share L2 lines)
@@ -211,8 +220,8 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
         img = pyr + L.pyr_off + (size_t)f * L.pyr_frame_stride;
         pitch = L.pitch;
     }
-    uint8_t *P = s_patch[wv];
-    uint16_t *H = s_rows[wv];
+    uint8_t *P = s_slice[wv] + P_OFF;
+    uint16_t *H = reinterpret_cast<uint16_t *>(s_slice[wv]);
 
     // ---- 1. stage the 43x43 unblurred patch; P[r][a + c] = level(cx-21+c, cy-21+r) with reflect-101 ----
     const int px0 = cx - PR, py0 = cy - PR;
@@ -246,10 +255,8 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
         }
     }
     wave_sync();  // each wave owns its LDS slice: no workgroup barrier anywhere in this kernel
-    blur_rows(P, H, lane);  // consumed after the IC stage below (wave_sync before the BRIEF tests)
 
     // ---- 2. intensity centroid over the radius-15 disc: lane = (row, half) ----
-    const uint8_t *C = &P[PR * PP + PR + a];  // patch centre
     int m10 = 0, m01 = 0;
     {
         const int v = (lane >> 1) - 15;  // -15..16
@@ -285,6 +292,7 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
             m01 = v * (int)s1;
         }
     }
+    blur_rows(P, H, lane);  // overwrites the patch (see the slice layout above): everything that reads P comes before this line
     m10 = wave_sum(m10);
     m01 = wave_sum(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
@@ -313,8 +321,10 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
             t1 = blur_at(H, PR + a + ix1, PR + iy1);
         } else {
             const int gx0 = cx + ix0, gy0 = cy + iy0, gx1 = cx + ix1, gy1 = cy + iy1;
-            t0 = (gx0 >= 0 && gx0 < lw && gy0 >= 0 && gy0 < lh) ? blur_at(H, PR + a + ix0, PR + iy0) : C[iy0 * PP + ix0];
-            t1 = (gx1 >= 0 && gx1 < lw && gy1 >= 0 && gy1 < lh) ? blur_at(H, PR + a + ix1, PR + iy1) : C[iy1 * PP + ix1];
+            t0 = (gx0 >= 0 && gx0 < lw && gy0 >= 0 && gy0 < lh) ? blur_at(H, PR + a + ix0, PR + iy0)
+                                                                 : (int)img[(size_t)afv_reflect101(gy0, lh) * pitch + afv_reflect101(gx0, lw)];
+            t1 = (gx1 >= 0 && gx1 < lw && gy1 >= 0 && gy1 < lh) ? blur_at(H, PR + a + ix1, PR + iy1)
+                                                                 : (int)img[(size_t)afv_reflect101(gy1, lh) * pitch + afv_reflect101(gx1, lw)];
         }
         const unsigned long long m = __ballot(t0 < t1);
         words[2 * g] = (uint32_t)m;
