@@ -177,11 +177,16 @@ struct AkdTaps {
 };
 __device__ __forceinline__ AkdTaps akd_load_taps(const float *__restrict__ S, int w, int h, int s, int x, int y) {
     const int xm = akd_reflect(x - s, w), xp = akd_reflect(x + s, w);
-    const size_t rm = (size_t)akd_reflect(y - s, h) * w, r0 = (size_t)y * w, rp = (size_t)akd_reflect(y + s, h) * w;
+    // 32-bit BYTE offsets into the frame's plane (S is wave-uniform: scalar base + vector offset is what the load takes; rows and widths
+    // are far below 2^24, a plane far below 4 GB): 24-bit multiplies instead of three 64-bit multiply-adds (quarter rate) per sample
+    const uint32_t rm = __umul24((uint32_t)akd_reflect(y - s, h), (uint32_t)w), r0 = __umul24((uint32_t)y, (uint32_t)w),
+                   rp = __umul24((uint32_t)akd_reflect(y + s, h), (uint32_t)w);
+    const char *B = reinterpret_cast<const char *>(S);
+    auto at = [&](uint32_t row, int col) { return *reinterpret_cast<const float *>(B + ((row + (uint32_t)col) << 2)); };
     AkdTaps t;
-    t.a = S[rm + xm]; t.b = S[rm + x]; t.c = S[rm + xp];
-    t.d = S[r0 + xm];                  t.e = S[r0 + xp];
-    t.f = S[rp + xm]; t.g = S[rp + x]; t.h = S[rp + xp];
+    t.a = at(rm, xm); t.b = at(rm, x); t.c = at(rm, xp);
+    t.d = at(r0, xm);                  t.e = at(r0, xp);
+    t.f = at(rp, xm); t.g = at(rp, x); t.h = at(rp, xp);
     return t;
 }
 __device__ __forceinline__ void akd_deriv(const AkdTaps &t, float mid, float norm, float *vx, float *vy) {
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(256) void k_akz_describe(AkdDescParams P, const afv
                 const float sample_y = yf + ((float)l * co * scale + (float)k * si * scale);
                 const float sample_x = xf + (-(float)l * si * scale + (float)k * co * scale);
                 const int y1 = akd_iclamp(akd_fround(sample_y), 0, L.h - 1), x1 = akd_iclamp(akd_fround(sample_x), 0, L.w - 1);
-                ri[n] = Lt[(size_t)y1 * L.w + x1];
+                ri[n] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(Lt) + ((__umul24((uint32_t)y1, (uint32_t)L.w) + (uint32_t)x1) << 2));
                 tp[n] = akd_load_taps(Ls, L.w, L.h, L.s, x1, y1);
             }
 #pragma unroll

@@ -130,7 +130,7 @@ __device__ __forceinline__ void blur_rows(const uint8_t *P, uint16_t *H, int lan
 // then round-half-even(S / 65536)
 typedef unsigned short ushort2d __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int blur_at(const uint16_t *H, int x, int y) {
-    const uint16_t *c = H + (y - 3) * HP + (x - 3);
+    const uint16_t *c = H + (__umul24((uint32_t)(y - 3), (uint32_t)HP) + (uint32_t)(x - 3));  // 24-bit multiply (y - 3 is 0 .. 36): a plain int product is a quarter-rate v_mul_lo_u32
     // symmetric taps: rows k and 6 - k share a weight -> three v_dot2_u32_u16 on (row k, row 6 - k) pairs + the centre row
     ushort2d p0, p1, p2, t0, t1, t2;
     p0.x = c[0];
@@ -233,12 +233,19 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
         const int ax0 = px0 - a;
         const int rr = lane / 12, rq = lane - rr * 12;
         if (lane < 60) {
-            const uint8_t *gp = img + (size_t)(py0 + rr) * pitch + ax0 + rq * 4;
+            // 32-bit byte offsets into the level image (a level is far below 4 GB; scalar base + vector offset is what the load takes):
+            // the patch origin on the scalar unit, the lane's part by a 24-bit multiply, the row steps by scalar adds - no 64-bit
+            // vector multiply-adds (quarter rate) in the address chain
+            uint32_t o_patch = (uint32_t)py0 * (uint32_t)pitch + (uint32_t)ax0, o_step = 5u * (uint32_t)pitch;
+            asm("" : "+s"(o_patch), "+s"(o_step));  // opaque scalars: the compiler would re-form (py0 + rr + 5 k) * pitch per row
+            uint32_t o = o_patch + __umul24((uint32_t)rr, (uint32_t)pitch) + (uint32_t)(rq * 4);
             uint8_t *lp = &P[rr * PP + rq * 4];
             uint32_t v[9];  // rows rr, rr + 5, ..., rr + 40 (PS = 43: the last one exists for rr < 3): loads first, then the LDS writes
 #pragma unroll
-            for (int k = 0; k < 9; ++k)
-                if (k < 8 || rr < PS - 40) v[k] = *reinterpret_cast<const uint32_t *>(gp + (size_t)k * 5 * pitch);
+            for (int k = 0; k < 9; ++k) {
+                if (k < 8 || rr < PS - 40) v[k] = *reinterpret_cast<const uint32_t *>(img + o);
+                o += o_step;
+            }
 #pragma unroll
             for (int k = 0; k < 9; ++k)
                 if (k < 8 || rr < PS - 40) *reinterpret_cast<uint32_t *>(lp + k * 5 * PP) = v[k];
@@ -249,8 +256,8 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
         if (lane < PS) {
             const int x = afv_reflect101(px0 + lane, lw);
             for (int r = 0; r < PS; ++r) {
-                const int y = afv_reflect101(py0 + r, lh);
-                P[r * PP + lane] = img[(size_t)y * pitch + x];
+                const int y = afv_reflect101(py0 + r, lh);  // wave-uniform
+                P[r * PP + lane] = img[(uint32_t)y * (uint32_t)pitch + (uint32_t)x];
             }
         }
     }
@@ -322,9 +329,9 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
         } else {
             const int gx0 = cx + ix0, gy0 = cy + iy0, gx1 = cx + ix1, gy1 = cy + iy1;
             t0 = (gx0 >= 0 && gx0 < lw && gy0 >= 0 && gy0 < lh) ? blur_at(H, PR + a + ix0, PR + iy0)
-                                                                 : (int)img[(size_t)afv_reflect101(gy0, lh) * pitch + afv_reflect101(gx0, lw)];
+                                                                 : (int)img[__umul24((uint32_t)afv_reflect101(gy0, lh), (uint32_t)pitch) + (uint32_t)afv_reflect101(gx0, lw)];
             t1 = (gx1 >= 0 && gx1 < lw && gy1 >= 0 && gy1 < lh) ? blur_at(H, PR + a + ix1, PR + iy1)
-                                                                 : (int)img[(size_t)afv_reflect101(gy1, lh) * pitch + afv_reflect101(gx1, lw)];
+                                                                 : (int)img[__umul24((uint32_t)afv_reflect101(gy1, lh), (uint32_t)pitch) + (uint32_t)afv_reflect101(gx1, lw)];
         }
         const unsigned long long m = __ballot(t0 < t1);
         words[2 * g] = (uint32_t)m;

@@ -81,6 +81,7 @@ static_assert(FT_PITCH >= FT_LW && FT_PITCH % 4 == 0, "tile pitch");
 #define ST_GROUPS 14                                       // staging: 18 dword columns x 14 row groups = 252 threads
 #define ST_ITERS ((FT_LH + ST_GROUPS - 1) / ST_GROUPS)     // rows rs, rs + 14, ... (3 at FT_H = 32)
 static_assert(PRE_ITERS <= 16, "pre-test flags live in 16-bit halves");
+static_assert(ST_ITERS >= 2 && ST_GROUPS * (ST_ITERS - 1) <= FT_LH - 1, "staging rows");
 
 // two horizontally adjacent tile bytes as a packed u16 pair: one 16-bit LDS read (any alignment) + one byte permute
 __device__ __forceinline__ short2v ld_pair(const uint8_t *c, int off) {
@@ -184,11 +185,23 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Geo *__restrict__ geo_p,
             // the row offsets first, then the loads back to back (one global round trip), then the LDS writes;
             // the last row of a thread may not exist (FT_H = 32: row 28 + rs only for rs < 12): its load is redirected to the last row and its write dropped
             uint32_t roff[ST_ITERS], v[ST_ITERS];
+            // (24-bit multiplies: rows and pitches are far below 2^24 and v_mul_lo_u32 is a quarter-rate instruction)
+            if (gy0 >= 0 && gy0 + FT_LH <= lh) {  // tile-uniform: no row of the staged window leaves the level (all but the top / bottom tile rows)
+                uint32_t r0 = (uint32_t)gy0 * (uint32_t)pitch;  // scalar unit
+                asm("" : "+s"(r0));                             // opaque: keeps (gy0 + ry) * pitch from being re-formed as one 32-bit vector multiply
+                uint32_t pg = (uint32_t)(ST_GROUPS * pitch);  // scalar, opaque for the same reason
+                asm("" : "+s"(pg));
+                roff[0] = r0 + __umul24((uint32_t)rs, (uint32_t)pitch);
 #pragma unroll
-            for (int k3 = 0; k3 < ST_ITERS; ++k3) {
-                const int ry = min(rs + ST_GROUPS * k3, FT_LH - 1);
-                const int gy = min(max(afv_reflect101(gy0 + ry, lh), 0), lh - 1);
-                roff[k3] = (uint32_t)gy * (uint32_t)pitch;
+                for (int k3 = 1; k3 < ST_ITERS - 1; ++k3) roff[k3] = roff[k3 - 1] + pg;  // rs + ST_GROUPS * k3 <= FT_LH - 1 for these
+                roff[ST_ITERS - 1] = r0 + __umul24((uint32_t)min(rs + ST_GROUPS * (ST_ITERS - 1), FT_LH - 1), (uint32_t)pitch);
+            } else {
+#pragma unroll
+                for (int k3 = 0; k3 < ST_ITERS; ++k3) {
+                    const int ry = min(rs + ST_GROUPS * k3, FT_LH - 1);
+                    const int gy = min(max(afv_reflect101(gy0 + ry, lh), 0), lh - 1);
+                    roff[k3] = __umul24((uint32_t)gy, (uint32_t)pitch);
+                }
             }
             if (interior) {
 #pragma unroll
