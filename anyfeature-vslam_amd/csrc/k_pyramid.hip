@@ -18,8 +18,8 @@
 
 #define RT_W 64
 #define RT_H 32
-// LDS source window (bytes per row x rows) = source span of a 64 x 32 output tile plus alignment slack; two instantiations:
-// 96 x 48 for level ratios up to 1.37 (the ORB pyramid's 1.2, 2^(1/4)), 160 x 80 for ratios up to 2.37 (the reference's settings files
+// LDS source window (bytes per row x rows) = source span of a 64 x 32 output tile plus alignment slack; three instantiations:
+// 88 x 44 for level ratios up to 1.25 (the ORB pyramid's 1.2, 2^(1/4): 9.9 KB of LDS = 8 wavefronts per SIMD), 96 x 48 up to 1.37, 160 x 80 for ratios up to 2.37 (the reference's settings files
 // go up to FeatureExtractor.scaleFactor 2.0: settings/sift128_settings.yaml:7)
 #define RT_T 128  // threads per workgroup: the kernel waits on its global loads most of the time, so what counts is how many tiles a
                   // CU has in flight (LDS 10.9 KB, 2 waves per tile -> 14 tiles per CU instead of 8 with 256 threads)
@@ -179,7 +179,11 @@ extern "C" void afv_launch_resize(const uint8_t *src, int sw, int sh, int spitch
     const int total = per_frame * nframes;
     dim3 grid((total + 7) / 8 * 8);
     ResizeTab tab{xt, yt, zero_counts, n_zero, zero_one, afv_div_magic((uint32_t)per_frame), afv_div_magic((uint32_t)tx)};
-    if (afv_resize_window_ok(sw, sh, dw, dh) == 1)
+    const double fx = (double)sw / dw, fy = (double)sh / dh;
+    if ((RT_W * fx + 8 <= 88) && (RT_H * fy + 3 <= 44))  // ratios up to 1.25 (the ORB pyramid's 1.2): 9.9 KB of LDS, 16 tiles = 8 wavefronts per SIMD in flight
+        hipLaunchKernelGGL((k_resize_level<88, 44>), grid, dim3(RT_T), 0, stream, src, sw, sh, spitch, sframe, dst, dw, dh, dpitch, dframe, tab,
+                           total, frame_base);
+    else if (afv_resize_window_ok(sw, sh, dw, dh) == 1)
         hipLaunchKernelGGL((k_resize_level<96, 48>), grid, dim3(RT_T), 0, stream, src, sw, sh, spitch, sframe, dst, dw, dh, dpitch, dframe, tab,
                            total, frame_base);
     else
