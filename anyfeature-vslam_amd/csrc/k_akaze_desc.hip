@@ -223,8 +223,10 @@ __global__ __launch_bounds__(256) void k_akz_describe(AkdDescParams P, const afv
                                                       const int *__restrict__ sel_count, afv_keypoint *__restrict__ out_kps,
                                                       uint8_t *__restrict__ out_desc, int *__restrict__ out_count, int *__restrict__ status) {
     __shared__ float s_val[4][96];
-    __shared__ float4 s_smp[4][441];  // MLDB samples of the 21 x 21 pattern positions: {Lt, rotated Lx, rotated Ly, -}; before that, the
-                                      // first 109 entries hold the orientation samples {angle, weighted Lx, weighted Ly, angle < 2 pi (as 1 / 0)}
+    // MLDB samples of the 21 x 21 pattern positions as three planes {Lt, rotated Lx, rotated Ly} of 441 floats (a float4 per sample
+    // with an unused lane cost 7 KB per workgroup and, at 29.8 KB, two workgroups of occupancy per CU); before that, the first 436
+    // floats hold the 109 orientation samples {angle, weighted Lx, weighted Ly, angle < 2 pi (as 1 / 0)} as float4
+    __shared__ __attribute__((aligned(16))) float s_smp[4][3 * 441 + 1];
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63, f = blockIdx.y;  // the keypoint is the wavefront's
     const int slot = blockIdx.x * 4 + wv;
     // slot -> (level, position): levels ascending (mergeKeypointLevels, FeatureExtractor.cpp:296-308)
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(256) void k_akz_describe(AkdDescParams P, const afv
     const float d_wgt = 10.0f / 3.0f, d_norm = 1.0f / (2.0f * (float)L.s * (d_wgt + 2.0f)), d_mid = d_wgt * d_norm;  // as k_akz_deriv1
     const float ratio = (float)(1 << L.octave);
     const float xf = kp.x / ratio, yf = kp.y / ratio;
-    float4 *ori = s_smp[wv];
+    float4 *ori = reinterpret_cast<float4 *>(s_smp[wv]);
     float *val = s_val[wv];
     // ---- Compute_Main_Orientation ----
     {
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(256) void k_akz_describe(AkdDescParams P, const afv
         // depends on (k, l) only: the 441 positions are fetched once, all lanes in parallel (1241 dependent gathers per keypoint
         // if every cell fetches its own), and every cell then adds ITS samples in upstream's (k, l) loop order from LDS.
         AKD_LDS_SYNC();  // every lane is through with the orientation samples that share this wavefront's block
-        float4 *smp = s_smp[wv];
+        float *smp = s_smp[wv];
         auto mldb_samples = [&](auto first, auto count) {  // the 9 gathers of each of `count` samples of a lane in flight together
             constexpr int IT0 = decltype(first)::value, N = decltype(count)::value;
             float ri[N];
@@ -347,7 +349,9 @@ __global__ __launch_bounds__(256) void k_akz_describe(AkdDescParams P, const afv
                     float gx, gy;
                     akd_deriv(tp[n], d_mid, d_norm, &gx, &gy);
                     const float vx = gx * L.fs, vy = gy * L.fs;
-                    smp[p] = make_float4(ri[n], -vx * si + vy * co /* rrx */, vx * co + vy * si /* rry */, 0.0f);
+                    smp[p] = ri[n];
+                    smp[441 + p] = -vx * si + vy * co;  // rrx
+                    smp[882 + p] = vx * co + vy * si;   // rry
                 }
             }
         };
@@ -359,14 +363,15 @@ __global__ __launch_bounds__(256) void k_akz_describe(AkdDescParams P, const afv
             float di = 0.f, dx = 0.f, dy = 0.f;
             // the cell's samples in upstream's (k, l) order as one flat walk, four reads in flight (a 10 x 10 cell is a chain of 100 additions
             // per channel: as nested loops every addition waited for its own LDS round trip)
-            const float4 *q = smp + (i0 + 10) * 21 + (j0 + 10);
+            const float *q = smp + (i0 + 10) * 21 + (j0 + 10);
             const int nn = step * step;
             int kk = 0, ll = 0;
             for (int t0 = 0; t0 < nn; t0 += 4) {
-                float4 v[4];
+                float3 v[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    v[u] = q[min(kk, step - 1) * 21 + ll];
+                    const int o = min(kk, step - 1) * 21 + ll;
+                    v[u] = make_float3(q[o], q[441 + o], q[882 + o]);
                     if (++ll == step) {
                         ll = 0;
                         ++kk;

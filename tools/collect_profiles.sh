@@ -92,6 +92,55 @@ $PY tools/pmc_summary.py "$RAW/pmc_lds_counter_collection.csv" "$RAW/pmc_l2_coun
 $PY tools/pmc_cache.py "$OUT" "$RAW/pmc_lds_counter_collection.csv" "$RAW/pmc_l2_counter_collection.csv" > "$OUT/pmc_cache.txt" 2>/dev/null
 cd /tmp
 
+echo "== what the two big kernels wait for: SQ activity / wait counters (three passes per kernel; tools/experiments.py prints per-frame sums)"
+( cd "$ROOT" && for K in k_fast_nms k_describe; do
+    AFV_EXP_KERNEL=$K AFV_EXP_PMC="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" $PY tools/experiments.py run base
+    AFV_EXP_KERNEL=$K AFV_EXP_PMC="SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_LDS_IDX_ACTIVE SQ_IFETCH SQ_BUSY_CU_CYCLES SQ_WAVES" $PY tools/experiments.py run base
+    AFV_EXP_KERNEL=$K AFV_EXP_PMC="SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_CYCLES" $PY tools/experiments.py run base
+  done ) > "$OUT/sq_activity.jsonl" 2>/dev/null
+$PY - "$OUT" <<'PYEOF'
+import json, sys
+out = sys.argv[1]
+acc = {}
+for line in open(out + "/sq_activity.jsonl"):
+    if not line.startswith("{"):
+        continue
+    d = json.loads(line)
+    k = acc.setdefault(d["kernel"], {"us_per_launch": []})
+    k["us_per_launch"].append(d["us_per_launch"])
+    k["frames_per_launch_assumed"] = d["frames_per_launch"]
+    for key, v in d.items():
+        if key.endswith("_per_frame"):
+            k[key[:-10]] = v
+res = {}
+for name, k in acc.items():
+    us = sum(k["us_per_launch"]) / len(k["us_per_launch"])
+    cu_cycles = k.get("SQ_BUSY_CU_CYCLES", 0.0) * k["frames_per_launch_assumed"] / 256.0   # per CU and launch
+    res[name] = {
+        "us_per_launch": us,
+        "sclk_GHz_while_running": cu_cycles / us / 1e3 if us else None,
+        "valu_busy_frac": 4.0 * k.get("SQ_ACTIVE_INST_VALU", 0.0) / (4.0 * k["SQ_BUSY_CU_CYCLES"]) if k.get("SQ_BUSY_CU_CYCLES") else None,
+        "lds_array_busy_frac": k.get("SQ_LDS_IDX_ACTIVE", 0.0) / k["SQ_BUSY_CU_CYCLES"] if k.get("SQ_BUSY_CU_CYCLES") else None,
+        "scalar_busy_frac": k.get("SQ_INST_CYCLES_SALU", 0.0) / k["SQ_BUSY_CU_CYCLES"] if k.get("SQ_BUSY_CU_CYCLES") else None,
+        "wave_cycles_waiting_on_waitcnt_frac": k.get("SQ_WAIT_ANY", 0.0) / k["SQ_WAVE_CYCLES"] if k.get("SQ_WAVE_CYCLES") else None,
+        "wave_cycles_waiting_to_issue_frac": k.get("SQ_WAIT_INST_ANY", 0.0) / k["SQ_WAVE_CYCLES"] if k.get("SQ_WAVE_CYCLES") else None,
+        "wave_cycles_issuing_frac": k.get("SQ_ACTIVE_INST_ANY", 0.0) / k["SQ_WAVE_CYCLES"] if k.get("SQ_WAVE_CYCLES") else None,
+        "resident_waves_per_simd": k.get("SQ_WAVE_CYCLES", 0.0) / k["SQ_BUSY_CU_CYCLES"] if k.get("SQ_BUSY_CU_CYCLES") else None,
+        "counters_per_frame_as_normalised_by_tools_experiments": {c: v for c, v in k.items() if c.startswith("SQ_")},
+    }
+res["note"] = ("SQ_ACTIVE_INST_VALU counts 4-cycle issue slots per SIMD (one per vector instruction): valu_busy_frac = SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES "
+               "(4 SIMDs x 1 slot per 4 cycles = 1 per CU cycle) - 1.0 means the vector issue port is never idle; SQ_WAVE_CYCLES likewise in units of 4 cycles "
+               "(resident_waves_per_simd = 8 is full occupancy).  sclk from SQ_BUSY_CU_CYCLES over the kernel's duration in the trace of the same pass.")
+try:
+    sys.path.insert(0, out + "/../../tools")
+    import csrc_sha
+    res["csrc_sha"] = csrc_sha.csrc_sha()
+except Exception:
+    pass
+json.dump(res, open(out + "/sq_activity.json", "w"), indent=1)
+print(json.dumps({k: {a: b for a, b in v.items() if a != "counters_per_frame_as_normalised_by_tools_experiments"} for k, v in res.items() if isinstance(v, dict)}, indent=1))
+PYEOF
+
 echo "== static VALU op-class shares of the kernels (from the ISA; feeds valu_issue.peak_isa_mix)"
 cd "$ROOT" && $PY tools/isa_valu_classes.py "$OUT/isa_valu_classes.json" > "$OUT/isa_valu_classes.txt" 2>&1; cd /tmp
 
