@@ -791,8 +791,12 @@ __global__ __launch_bounds__(AKZ_T) void k_akz_hessian(const float *__restrict__
 // SD: also store the (unscaled) first derivatives.  The pipeline does not (round 5): their only reader is the descriptor stage, which
 // evaluates them at its sample positions from Lsmooth (k_akaze_desc.hip) - 8 of this kernel's 16 B per pixel were written for a plane
 // of which under a tenth is ever read.  SD = true serves afv_akaze_get_plane (and keeps the fused Lx / Ly under the plane tests).
+// At least 5 wavefronts per SIMD (round 5, late): left alone the register allocator takes 90 / 158 VGPRs for S = 3 / 4 (5 / 3 wavefronts), and
+// the SQ counters had the S = 4 instantiation at 0.58 vector-busy with 2.7 resident wavefronts.  With the bound it takes 68 / 96 (7 / 5
+// wavefronts; 20 bytes of scratch at S = 4): 97 -> 91 and 134 -> 108 us per level of 64 frames.  6 and 7 spill more than they hide
+// (130 and 630 us at S = 4).
 template <int S, bool SD>
-__global__ __launch_bounds__(256) void k_akz_dhess(const float *__restrict__ lsm, int w, int h, int nframes, int band_rows, float *__restrict__ dx,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_akz_dhess(const float *__restrict__ lsm, int w, int h, int nframes, int band_rows, float *__restrict__ dx,
                                                    float *__restrict__ dy, float *__restrict__ Ldet) {
     constexpr int P = 2 * S + 1;     // ring depth
     constexpr int OW = 64 - 4 * S;   // output columns per strip
