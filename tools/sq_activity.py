@@ -4,13 +4,13 @@ acc = {}
 for p in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(p)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if not k.startswith("k_akz"): continue
+        if not k.startswith(sys.argv[2] if len(sys.argv) > 2 else "k_akz"): continue
         acc.setdefault(k, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 dur = {}
 for p in glob.glob(out + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(p)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if k.startswith("k_akz"): dur.setdefault(k, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        if k.startswith(sys.argv[2] if len(sys.argv) > 2 else "k_akz"): dur.setdefault(k, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 rows = []
 for k, c in acc.items():
     s = {n: sum(v) for n, v in c.items()}
