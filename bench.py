@@ -1238,6 +1238,15 @@ def main():
                                                                        for k, e in cp["kernels"].items() if k.split("<")[0] in keep},
                                 "note": "l2_hit = TCC_HIT / (TCC_HIT + TCC_MISS), LDS bank-conflict and wait cycles per LDS instruction: committed PMC passes "
                                         "(tools/collect_profiles.sh -> tools/pmc_cache.py), withheld when the sources changed since"}
+            sq = _newest_profile("sq_activity.json")
+            if sq:   # why the HBM fraction of the dominant kernel is low: its vector issue slots are full (SQ activity counters, same staleness rule)
+                keys = ("valu_busy_frac", "lds_array_busy_frac", "scalar_busy_frac", "resident_waves_per_simd", "sclk_GHz_while_running",
+                        "wave_cycles_issuing_frac", "wave_cycles_waiting_on_waitcnt_frac", "wave_cycles_waiting_to_issue_frac")
+                out["issue_activity"] = {"stale": sq["_stale"], "source": sq["_path"],
+                                         "kernels": None if sq["_stale"] else {k: {f: round(v[f], 4) for f in keys if isinstance(v.get(f), (int, float))}
+                                                                               for k, v in sq.items() if isinstance(v, dict) and "valu_busy_frac" in v},
+                                         "note": "valu_busy_frac = SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES (one vector issue slot per SIMD and 4 cycles; 1.0 = never idle, "
+                                                 "above 1.0 = co-issued instructions): committed PMC passes of tools/collect_profiles.sh, withheld when the sources changed since"}
             # event time of each stage summed over BOTH streams of a step: the two streams run concurrently, so an entry (and their sum)
             # may exceed ms_per_step - these are not kernel durations (rocprof: profiles/rNN/kernel_stats_default.csv)
             out["stage_event_ms_per_step_summed_over_concurrent_streams"] = {kk: (v["total_ms"] / prof_steps) for kk, v in stages.items()}
