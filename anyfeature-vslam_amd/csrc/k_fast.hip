@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Geo *__restrict__ geo_p,
         }
         // flags as bits of two registers (bit 16 - PRE_ITERS + it = pixel 0, bit 32 - PRE_ITERS + it = pixel 1 of iteration it), compaction:
         // exclusive prefix of the per-lane survivor counts (both polarities packed in one register, one DPP scan), two LDS atomics per
-        // wavefront, then every lane writes its own <= 10 + 10 entries with predicated stores.  A lane's entries are a 2 x 5 pixel block and
+        // wavefront, then every lane writes its own <= 10 + 10 entries with predicated stores (below).  A lane's entries are a 2 x 5 pixel block and
         // neighbouring lanes hold neighbouring column pairs, so list neighbours stay image neighbours and the scattered ring reads of
         // step 2b hit few LDS bank windows.
         uint32_t bb = 0, bd = 0;
@@ -317,16 +317,28 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Geo *__restrict__ geo_p,
         const int excl = incl - cnt;
         unsigned short *wb = pre + __builtin_amdgcn_readlane(base_b, 63) + (excl & 0xffff);
         unsigned short *wd = pre + PRE_DARK0 + __builtin_amdgcn_readlane(base_d, 63) + (excl >> 16);
+        // the flags leave their registers through the carry: x + x shifts the next flag out of bit 31 (v_add_co_u32: shift AND test in one
+        // instruction), the store runs under that carry, the pointer advances by it - three vector instructions per slot instead of
+        // four (mask, compare, extract, add).  Slot order: pixel 1 of rows PRE_ITERS - 1 .. 0, then pixel 0 (its flags are brought to
+        // the top by one shift): a lane's entries are still its 2 x 5 pixel block.
+        {
+            uint32_t sb = bb, sd = bd;
 #pragma unroll
-        for (int it = 0; it < PRE_ITERS; ++it) {
+            for (int px = 1; px >= 0; --px) {
+                if (px == 0) {
+                    sb <<= 16 - PRE_ITERS;
+                    sd <<= 16 - PRE_ITERS;
+                }
 #pragma unroll
-            for (int px = 0; px < 2; ++px) {
-                const int pos = 16 * px + 16 - PRE_ITERS + it;
-                const unsigned short val = (unsigned short)(p00 + it * FT_PITCH + px);
-                if ((bb >> pos) & 1u) *wb = val;
-                wb += (bb >> pos) & 1u;
-                if ((bd >> pos) & 1u) *wd = val;
-                wd += (bd >> pos) & 1u;
+                for (int it = PRE_ITERS - 1; it >= 0; --it) {
+                    const unsigned short val = (unsigned short)(p00 + it * FT_PITCH + px);
+                    const bool cb = __builtin_uadd_overflow(sb, sb, &sb);
+                    if (cb) *wb = val;
+                    wb += cb;
+                    const bool cd = __builtin_uadd_overflow(sd, sd, &sd);
+                    if (cd) *wd = val;
+                    wd += cd;
+                }
             }
         }
     }
