@@ -107,8 +107,10 @@ __device__ __forceinline__ uint32_t blur_round(uint32_t S) { return __builtin_am
 #define HP 40  // u16 pitch of the row-filtered plane (80 bytes: 8-byte aligned rows, no padding: 44 cost a workgroup of occupancy per CU)
 #endif
 __device__ __forceinline__ void blur_rows(const uint8_t *P, uint16_t *H, int lane) {
-    const uint32_t T_LO = 18u | (34u << 8) | (49u << 16) | (55u << 24);  // taps for bytes xh .. xh+3
-    const uint32_t T_HI = 49u | (34u << 8) | (18u << 16);                // taps for bytes xh+4 .. xh+6
+    // output k of a group = taps over bytes k .. k + 6 of the 12-byte window (d0, d1, d2): instead of shifting the DATA to the taps
+    // (two funnel shifts per output) the TAPS are laid out at the byte positions of every k - eleven constants in scalar registers,
+    // 2 + 3 + 3 + 3 dot products and no shifts for the four outputs
+    constexpr unsigned long long TAPS = 18ull | (34ull << 8) | (49ull << 16) | (55ull << 24) | (49ull << 32) | (34ull << 40) | (18ull << 48);
     for (int i = lane; i < PS * 10; i += 64) {
         const int r = i / 10, g = i - r * 10;
         const uint32_t *row = reinterpret_cast<const uint32_t *>(P + r * PP + g * 4);
@@ -116,8 +118,12 @@ __device__ __forceinline__ void blur_rows(const uint8_t *P, uint16_t *H, int lan
         uint32_t o[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint32_t lo = k ? __builtin_amdgcn_alignbit(d1, d0, 8 * k) : d0, hi = k ? __builtin_amdgcn_alignbit(d2, d1, 8 * k) : d1;
-            o[k] = __builtin_amdgcn_udot4(hi, T_HI, __builtin_amdgcn_udot4(lo, T_LO, 0u, false), false);
+            // the 7 taps shifted up by k bytes inside a 96-bit field: its three dwords
+            const unsigned __int128 F = (unsigned __int128)TAPS << (8 * k);
+            const uint32_t t0 = (uint32_t)F, t1 = (uint32_t)(F >> 32), t2 = (uint32_t)(F >> 64);
+            uint32_t a = __builtin_amdgcn_udot4(d1, t1, __builtin_amdgcn_udot4(d0, t0, 0u, false), false);
+            if (t2) a = __builtin_amdgcn_udot4(d2, t2, a, false);
+            o[k] = a;
         }
         uint2 w;
         w.x = o[0] | (o[1] << 16);
@@ -129,6 +135,7 @@ __device__ __forceinline__ void blur_rows(const uint8_t *P, uint16_t *H, int lan
 // column pass + rounding at patch position (row y, column x), taps centred: exact integer arithmetic of the separable filter,
 // then round-half-even(S / 65536)
 typedef unsigned short ushort2d __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int blur_at(const uint16_t *H, int x, int y) {
     const uint16_t *c = H + (__umul24((uint32_t)(y - 3), (uint32_t)HP) + (uint32_t)(x - 3));  // 24-bit multiply (y - 3 is 0 .. 36): a plain int product is a quarter-rate v_mul_lo_u32
     // symmetric taps: rows k and 6 - k share a weight -> three v_dot2_u32_u16 on (row k, row 6 - k) pairs + the centre row
@@ -313,14 +320,18 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
     const float ptx = (float)cx * L.scale, pty = (float)cy * L.scale;
     const int bx = (int)rintf(ptx * L.inv_scale), by = (int)rintf(pty * L.inv_scale);
     const int ox = bx - cx, oy = by - cy;  // 0 in practice; kept literal
+    const f32x2 cs_a = {ca, sb}, cs_b = {-sb, ca};
     uint32_t words[8];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int t = g * 64 + lane;
         const float4 pt = reinterpret_cast<const float4 *>(k_brief_pattern)[t];
         const float x0 = pt.x, y0 = pt.y, x1 = pt.z, y1 = pt.w;
-        const int ix0 = (int)rintf(x0 * ca - y0 * sb) + ox, iy0 = (int)rintf(x0 * sb + y0 * ca) + oy;
-        const int ix1 = (int)rintf(x1 * ca - y1 * sb) + ox, iy1 = (int)rintf(x1 * sb + y1 * ca) + oy;
+        // (x ca - y sb, x sb + y ca) as three packed fp32 instructions per point: (x, x) * (ca, sb) + (y, y) * (-sb, ca) - the same
+        // products and sums bit for bit (a - b = a + (-b), (-s) y = -(s y), one rounding per operator: -ffp-contract=off)
+        const f32x2 rp0 = f32x2{x0, x0} * cs_a + f32x2{y0, y0} * cs_b, rp1 = f32x2{x1, x1} * cs_a + f32x2{y1, y1} * cs_b;
+        const int ix0 = (int)rintf(rp0.x) + ox, iy0 = (int)rintf(rp0.y) + oy;
+        const int ix1 = (int)rintf(rp1.x) + ox, iy1 = (int)rintf(rp1.y) + oy;
         // inside the ROI -> blurred, outside -> unblurred apron (a patch that lies inside the level has no outside samples)
         int t0, t1;
         if (interior) {
