@@ -321,6 +321,7 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
     const int bx = (int)rintf(ptx * L.inv_scale), by = (int)rintf(pty * L.inv_scale);
     const int ox = bx - cx, oy = by - cy;  // 0 in practice; kept literal
     const f32x2 cs_a = {ca, sb}, cs_b = {-sb, ca};
+    const int kox = ox - 0x4B400000, koy = oy - 0x4B400000;  // scalar: the mantissa offset of the rounding trick below and the (0) centre offset
     uint32_t words[8];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -330,8 +331,13 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
         // (x ca - y sb, x sb + y ca) as three packed fp32 instructions per point: (x, x) * (ca, sb) + (y, y) * (-sb, ca) - the same
         // products and sums bit for bit (a - b = a + (-b), (-s) y = -(s y), one rounding per operator: -ffp-contract=off)
         const f32x2 rp0 = f32x2{x0, x0} * cs_a + f32x2{y0, y0} * cs_b, rp1 = f32x2{x1, x1} * cs_a + f32x2{y1, y1} * cs_b;
-        const int ix0 = (int)rintf(rp0.x) + ox, iy0 = (int)rintf(rp0.y) + oy;
-        const int ix1 = (int)rintf(rp1.x) + ox, iy1 = (int)rintf(rp1.y) + oy;
+        // cvRound = round half to even: x + 1.5 * 2^23 leaves the rounded integer in the mantissa (|x| < 2^22; the addition rounds to
+        // nearest even exactly where rintf does), one packed add per point instead of two v_rndne + two v_cvt; the integer
+        // offset 0x4B400000 folds into the address constants below
+        const f32x2 rmag = {12582912.0f, 12582912.0f};
+        const f32x2 rq0 = rp0 + rmag, rq1 = rp1 + rmag;
+        const int ix0 = __float_as_int(rq0.x) + kox, iy0 = __float_as_int(rq0.y) + koy;
+        const int ix1 = __float_as_int(rq1.x) + kox, iy1 = __float_as_int(rq1.y) + koy;
         // inside the ROI -> blurred, outside -> unblurred apron (a patch that lies inside the level has no outside samples)
         int t0, t1;
         if (interior) {
