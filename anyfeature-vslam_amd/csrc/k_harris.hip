@@ -133,6 +133,20 @@ struct HarrisItem {
     size_t base;  // first l1 slot of the item
 };
 
+// raw buffer over one frame's level image: reads past its last byte return 0 instead of faulting.  Pointer, pitch and size go through
+// v_readfirstlane: after the l == 0 / l > 0 join the compiler keeps them in vector registers, and with a resource it takes for divergent
+// every window load sits in a waterfall loop (four v_readfirstlane, two 64-bit compares, a branch: 12 loads x 6 vector instructions per
+// wavefront of candidates; round 5)
+__device__ __forceinline__ void harris_item_rsrc(HarrisItem &it) {
+    const uint64_t ip = reinterpret_cast<uint64_t>(it.img);
+    const uint32_t ip_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ip), ip_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ip >> 32));
+    it.img = reinterpret_cast<const uint8_t *>(((uint64_t)ip_hi << 32) | ip_lo);
+    it.pitch = __builtin_amdgcn_readfirstlane(it.pitch);
+    it.lw = __builtin_amdgcn_readfirstlane(it.lw);
+    it.lh = __builtin_amdgcn_readfirstlane(it.lh);
+    it.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(it.img), 0, (it.lh - 1) * it.pitch + it.lw, 0x00027000);
+}
+
 __device__ __forceinline__ HarrisItem harris_item(const Geo &geo, const FrameSrc &src0, const uint8_t *pyr, uint2 item) {
     HarrisItem it;
     const int fl = (int)item.x, f = fl / AFV_MAX_LEVELS, l = fl - f * AFV_MAX_LEVELS;
@@ -148,8 +162,7 @@ __device__ __forceinline__ HarrisItem harris_item(const Geo &geo, const FrameSrc
     it.lh = L.h;
     it.cnt = (int)(item.y >> 24);
     it.base = L.cand_off + (size_t)f * L.cand_frame_stride + (size_t)(item.y & 0x00ffffffu);
-    // raw buffer over this frame's level image: reads past its last byte return 0 instead of faulting
-    it.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(it.img), 0, (it.lh - 1) * it.pitch + it.lw, 0x00027000);
+    harris_item_rsrc(it);
     return it;
 }
 
@@ -357,7 +370,7 @@ __device__ __forceinline__ void retain_harris_small_body(const Geo &geo, const F
     it.lh = L.h;
     it.cnt = 0;
     it.base = 0;
-    it.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(it.img), 0, (it.lh - 1) * it.pitch + it.lw, 0x00027000);
+    harris_item_rsrc(it);
     for (int s0 = start; s0 < end; s0 += RH_SURV) {  // uniform trip count (one pass for lists that fit the registers)
         const int s1 = min(s0 + RH_SURV, end);
         RH_FOR_ITEMS(
