@@ -80,19 +80,22 @@ __global__ __launch_bounds__(RT_T) void k_resize_level(const uint8_t *__restrict
     const bool s_dword = sx0 + sq * 4 + 3 < spitch;  // else: the last bytes of a row whose pitch is not a multiple of 4
     uint32_t stg[STG];
     {
-        const uint8_t *p = s + (size_t)(sy0 + srr) * spitch + sx0 + sq * 4;
+        // 32-bit byte offsets into the frame's level image (scalar frame base + vector offset; a level is far below 4 GB): one 24-bit
+        // multiply for the thread's first row, scalar steps after it - no 64-bit vector address arithmetic (quarter / half rate)
+        uint32_t po = __umul24((uint32_t)(sy0 + srr), (uint32_t)spitch) + (uint32_t)(sx0 + sq * 4);
+        const uint32_t pstep = (uint32_t)(SG * spitch);
 #pragma unroll
         for (int k = 0; k < STG; ++k) {
             stg[k] = 0;
             if (s_on && srr + k * SG < nrows) {
                 if (s_dword) {
-                    stg[k] = *reinterpret_cast<const uint32_t *>(p);
+                    stg[k] = *reinterpret_cast<const uint32_t *>(s + po);
                 } else {
                     for (int b = 0; b < 4; ++b)
-                        if (sx0 + sq * 4 + b < sw) stg[k] |= (uint32_t)p[b] << (8 * b);
+                        if (sx0 + sq * 4 + b < sw) stg[k] |= (uint32_t)s[po + b] << (8 * b);
                 }
             }
-            p += (size_t)SG * spitch;
+            po += pstep;
         }
     }
     if (s_on) {
@@ -141,8 +144,11 @@ __global__ __launch_bounds__(RT_T) void k_resize_level(const uint8_t *__restrict
     // ---- vertical pass: thread -> 4 consecutive columns, rows ry, ry + RT_T / 16, ... ----
     const int cx = (threadIdx.x & 15) * 4, ry = threadIdx.x >> 4;
     if (cx >= nx) return;
+    uint8_t *const dstf = dst + (size_t)f * dframe;  // scalar
+    uint32_t doff = __umul24((uint32_t)(y0 + ry), (uint32_t)dpitch) + (uint32_t)(x0 + cx);
+    const uint32_t dstep = (uint32_t)((RT_T / 16) * dpitch);
 #pragma unroll
-    for (int part = 0; part < RT_H / (RT_T / 16); ++part) {
+    for (int part = 0; part < RT_H / (RT_T / 16); ++part, doff += dstep) {
         const int y = ry + part * (RT_T / 16);
         if (y >= ny) break;
         const short2 yt = s_yt[y];
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(RT_T) void k_resize_level(const uint8_t *__restrict
         const uint32_t o0 = __builtin_amdgcn_udot2(p0, WY, 32768u, false) >> 16, o1 = __builtin_amdgcn_udot2(p1, WY, 32768u, false) >> 16;
         const uint32_t o2 = __builtin_amdgcn_udot2(p2, WY, 32768u, false) >> 16, o3 = __builtin_amdgcn_udot2(p3, WY, 32768u, false) >> 16;
         // pitch is a multiple of 64: the dword store never leaves the row (columns past nx hold filtered padding, never read)
-        *reinterpret_cast<uint32_t *>(dst + (size_t)f * dframe + (size_t)(y0 + y) * dpitch + x0 + cx) = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
+        *reinterpret_cast<uint32_t *>(dstf + doff) = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
     }
 }
 
