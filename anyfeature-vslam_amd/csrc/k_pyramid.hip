@@ -163,10 +163,12 @@ __global__ __launch_bounds__(RT_T) void k_resize_level(const uint8_t *__restrict
         const ushort2r p1 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(l.x, u.x, 0x07060302u));
         const ushort2r p2 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(l.y, u.y, 0x05040100u));
         const ushort2r p3 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm(l.y, u.y, 0x07060302u));
-        const uint32_t o0 = __builtin_amdgcn_udot2(p0, WY, 32768u, false) >> 16, o1 = __builtin_amdgcn_udot2(p1, WY, 32768u, false) >> 16;
-        const uint32_t o2 = __builtin_amdgcn_udot2(p2, WY, 32768u, false) >> 16, o3 = __builtin_amdgcn_udot2(p3, WY, 32768u, false) >> 16;
+        // the output byte is byte 2 of each sum (<= 255 << 16 + 65535): the four of them are gathered with two byte permutes + one OR
+        const uint32_t q0 = __builtin_amdgcn_udot2(p0, WY, 32768u, false), q1 = __builtin_amdgcn_udot2(p1, WY, 32768u, false);
+        const uint32_t q2 = __builtin_amdgcn_udot2(p2, WY, 32768u, false), q3 = __builtin_amdgcn_udot2(p3, WY, 32768u, false);
+        const uint32_t out4 = __builtin_amdgcn_perm(q1, q0, 0x0c0c0602u) | __builtin_amdgcn_perm(q3, q2, 0x06020c0cu);
         // pitch is a multiple of 64: the dword store never leaves the row (columns past nx hold filtered padding, never read)
-        *reinterpret_cast<uint32_t *>(dstf + doff) = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
+        *reinterpret_cast<uint32_t *>(dstf + doff) = out4;
     }
 }
 
