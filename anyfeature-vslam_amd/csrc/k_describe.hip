@@ -20,8 +20,38 @@
 __device__ __constant__ __attribute__((aligned(16))) const float k_brief_pattern[1024] = {
 #include "brief_pattern.inc"
 };
-// umax[v], v = 0..15: last column of row v of the radius-15 disc (orb.cpp / ORBextractor.cc:124-139)
-__device__ __constant__ const signed char k_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+// IC stage: lane = (row v = (lane >> 1) - 15, half): the four byte masks of the lane's 16-byte run (which bytes lie inside the disc) depend
+// on the lane only - a table instead of ~24 vector instructions of min / max / shift per keypoint
+struct IcMasks {
+    uint32_t m[64][4];
+};
+constexpr IcMasks ic_make_masks() {
+    IcMasks t{};
+    // umax[v], v = 0..15: last column of row v of the radius-15 disc (orb.cpp / ORBextractor.cc:124-139)
+    constexpr int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    for (int lane = 0; lane < 64; ++lane) {
+        const int v = (lane >> 1) - 15, half = lane & 1;
+        for (int q = 0; q < 4; ++q) {
+            uint32_t m = 0;
+            if (v <= 15) {
+                const int d = umax[v < 0 ? -v : v];
+                if (half) {
+                    int nb = d + 1 - 4 * q;  // valid leading bytes
+                    nb = nb < 0 ? 0 : (nb > 4 ? 4 : nb);
+                    m = nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
+                } else {
+                    int nz = 16 - d - 4 * q;  // invalid leading bytes
+                    nz = nz < 0 ? 0 : (nz > 4 ? 4 : nz);
+                    m = nz >= 4 ? 0u : (0xffffffffu << (8 * nz));
+                }
+            }
+            t.m[lane][q] = m;
+        }
+    }
+    return t;
+}
+__device__ __constant__ __attribute__((aligned(16))) const IcMasks k_ic_masks = ic_make_masks();
 
 #define PR 21        // patch radius: 18 (BRIEF reach) + 3 (blur)
 #define PS 43        // patch side
@@ -275,32 +305,22 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
     {
         const int v = (lane >> 1) - 15;  // -15..16
         if (v <= 15) {
-            const int av = v < 0 ? -v : v;
-            const int d = k_umax[av];
             // half 0: u in [-d, -1] = bytes j = 16-d .. 15 of the 16 bytes starting at u = -16; half 1: u in [0, d] = bytes
-            // j = 0 .. d of the 16 bytes starting at u = 0.  Five aligned dwords, funnel-shifted to the start byte, bytes outside
-            // the disc masked to zero, then sum(val) and sum(j * val) by v_dot4_u32_u8.
+            // j = 0 .. d of the 16 bytes starting at u = 0 (d = umax[|v|]).  Five aligned dwords, funnel-shifted to the start byte, bytes
+            // outside the disc masked to zero (k_ic_masks), then sum(val) and sum(j * val) by v_dot4_u32_u8.
             const int half = lane & 1;
             const int A = (PR + v) * PP + PR + a + (half ? 0 : -16);
             const uint32_t *wp = reinterpret_cast<const uint32_t *>(P + (A & ~3));
             const int sh = (A & 3) * 8;
+            const uint4 mk = *reinterpret_cast<const uint4 *>(k_ic_masks.m[lane]);
             const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3], w4 = wp[4];
-            uint32_t b[4] = {__builtin_amdgcn_alignbit(w1, w0, sh), __builtin_amdgcn_alignbit(w2, w1, sh), __builtin_amdgcn_alignbit(w3, w2, sh),
-                             __builtin_amdgcn_alignbit(w4, w3, sh)};
+            const uint32_t b[4] = {__builtin_amdgcn_alignbit(w1, w0, sh) & mk.x, __builtin_amdgcn_alignbit(w2, w1, sh) & mk.y,
+                                   __builtin_amdgcn_alignbit(w3, w2, sh) & mk.z, __builtin_amdgcn_alignbit(w4, w3, sh) & mk.w};
             uint32_t s1 = 0, sj = 0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                uint32_t m;
-                if (half) {
-                    const int nb = min(max(d + 1 - 4 * q, 0), 4);                  // valid leading bytes
-                    m = nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
-                } else {
-                    const int nz = min(max(16 - d - 4 * q, 0), 4);                 // invalid leading bytes
-                    m = nz >= 4 ? 0u : (0xffffffffu << (8 * nz));
-                }
-                const uint32_t x = b[q] & m;
-                s1 = __builtin_amdgcn_udot4(x, 0x01010101u, s1, false);
-                sj = __builtin_amdgcn_udot4(x, 0x03020100u + 0x04040404u * (uint32_t)q, sj, false);
+                s1 = __builtin_amdgcn_udot4(b[q], 0x01010101u, s1, false);
+                sj = __builtin_amdgcn_udot4(b[q], 0x03020100u + 0x04040404u * (uint32_t)q, sj, false);
             }
             m10 = half ? (int)sj : (int)sj - 16 * (int)s1;
             m01 = v * (int)s1;
