@@ -428,14 +428,14 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Geo *__restrict__ geo_p,
         const int cnt = __popc(kb);
         const int incl = wave_incl_scan(cnt);
         int base = 0;
-        if (lane == 63) base = atomicAdd(&list_n, incl);
-        base = __shfl(base, 63, 64) + incl - cnt;
+        if (lane == 63) base = lds_add_rtn_one_lane(&list_n, incl);
         // `list` aliases `pre`: every wavefront must be done with the score lists before anyone writes (barrier above)
+        uint32_t *wl = list + (__builtin_amdgcn_readlane(base, 63) + incl - cnt);
         while (kb) {
             const int qb = __builtin_ctz(kb);
             kb &= kb - 1;
             const int px = c - FT_HALO + (qb >> 4), py = NR * rr + ((qb & 15) - (16 - NR));
-            list[base++] = (uint32_t)px | ((uint32_t)py << 8) | ((uint32_t)sc[(py + FT_HALO) * FT_PITCH + px + FT_HALO] << 16);
+            *wl++ = (uint32_t)px | ((uint32_t)py << 8) | ((uint32_t)sc[(py + FT_HALO) * FT_PITCH + px + FT_HALO] << 16);
         }
     }
     __syncthreads();
