@@ -259,9 +259,13 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Geo *__restrict__ geo_p,
         const uint8_t *c = &tile[p00];
         const int sh = (col - 4) & 3;  // 0 or 2
         const uint32_t *cw = reinterpret_cast<const uint32_t *>(c - 4 - sh);
-        const uint32_t sel_b = 0x0c020c01u + (uint32_t)sh * 0x00010001u;  // (col-3, col-2) out of (w1:w0)
-        const uint32_t sel_v = 0x0c050c04u + (uint32_t)sh * 0x00010001u;  // (col,   col+1) out of (w1:w0)
-        const uint32_t sel_a = 0x0c040c03u + (uint32_t)sh * 0x00010001u;  // (col+3, col+4) out of (w2:w1)
+        // (one product, then additions of literals: a multiply-add per selector needs its constant in a register first)
+        uint32_t shm = (uint32_t)sh * 0x00010001u;
+        asm("" : "+v"(shm));  // opaque: the compiler would fold every `literal + sh * 0x10001` back into a multiply-add with the literal moved into a register first
+        const uint32_t shm2 = shm ^ 0x00020002u;  // sh2 = sh ^ 2 in both halves
+        const uint32_t sel_b = 0x0c020c01u + shm;  // (col-3, col-2) out of (w1:w0)
+        const uint32_t sel_v = 0x0c050c04u + shm;  // (col,   col+1) out of (w1:w0)
+        const uint32_t sel_a = 0x0c040c03u + shm;  // (col+3, col+4) out of (w2:w1)
         // Operand fetch, LDS instructions counted (the LDS pipe is as busy as the vector ALU in this kernel): the thread's rows r = -3 ..
         // PRE_ITERS + 2 around its PRE_ITERS centre rows.  The centre pair of row r is the vertical ring pair of rows r - 3 and r + 3, the
         // pairs at columns -2 / +2 of row r serve rows r - 2 and r + 2, and all of them lie in the aligned dwords read for the row anyway:
@@ -270,10 +274,10 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Geo *__restrict__ geo_p,
         // pair was read by itself); every pair is cut out with one byte permute whose selector depends on col & 2 only.
         const int sh2 = sh ^ 2;
         const uint32_t *cw2 = reinterpret_cast<const uint32_t *>(c - 2 - sh2);
-        const uint32_t sel_l = 0x0c030c02u + (uint32_t)sh * 0x00010001u;    // (col-2, col-1) out of (w1:w0); (col+2, col+3) out of (w2:w1)
-        const uint32_t sel2_l = 0x0c010c00u + (uint32_t)sh2 * 0x00010001u;  // two-dword rows: (col-2, col-1)
-        const uint32_t sel2_v = 0x0c030c02u + (uint32_t)sh2 * 0x00010001u;  //                 (col,   col+1)
-        const uint32_t sel2_r = 0x0c050c04u + (uint32_t)sh2 * 0x00010001u;  //                 (col+2, col+3)
+        const uint32_t sel_l = 0x0c030c02u + shm;    // (col-2, col-1) out of (w1:w0); (col+2, col+3) out of (w2:w1)
+        const uint32_t sel2_l = 0x0c010c00u + shm2;  // two-dword rows: (col-2, col-1)
+        const uint32_t sel2_v = 0x0c030c02u + shm2;  //                 (col,   col+1)
+        const uint32_t sel2_r = 0x0c050c04u + shm2;  //                 (col+2, col+3)
         short2v Vc[PRE_ITERS + 6], R2[PRE_ITERS + 4], L2[PRE_ITERS + 4], A4[PRE_ITERS], B4[PRE_ITERS];  // Vc[k]: row k - 3; R2 / L2[k]: row k - 2
         Vc[0] = ld_pair(c, -3 * FT_PITCH);
         Vc[PRE_ITERS + 5] = ld_pair(c, (PRE_ITERS + 2) * FT_PITCH);
@@ -396,9 +400,11 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Geo *__restrict__ geo_p,
         // the four scores c-1 .. c+2 of a row lie in two aligned dwords (one LDS instruction); selectors depend on c & 2 only
         const int nsh = (c - 1) & 3;  // 3 or 1
         const uint32_t *qw = reinterpret_cast<const uint32_t *>(q0 - 1 - nsh);
-        const uint32_t nsel_a = 0x0c010c00u + (uint32_t)nsh * 0x00010001u;  // (c-1, c)
-        const uint32_t nsel_b = 0x0c020c01u + (uint32_t)nsh * 0x00010001u;  // (c,   c+1)
-        const uint32_t nsel_c = 0x0c030c02u + (uint32_t)nsh * 0x00010001u;  // (c+1, c+2)
+        uint32_t nshm = (uint32_t)nsh * 0x00010001u;
+        asm("" : "+v"(nshm));  // as in step 2a
+        const uint32_t nsel_a = 0x0c010c00u + nshm;  // (c-1, c)
+        const uint32_t nsel_b = 0x0c020c01u + nshm;  // (c,   c+1)
+        const uint32_t nsel_c = 0x0c030c02u + nshm;  // (c+1, c+2)
 #pragma unroll
         for (int k = 0; k < NR + 2; ++k) {
             const uint32_t w0 = qw[(k - 1) * (FT_PITCH / 4)], w1 = qw[(k - 1) * (FT_PITCH / 4) + 1];
