@@ -75,8 +75,8 @@ static_assert(FT_PITCH >= FT_LW && FT_PITCH % 4 == 0, "tile pitch");
                                         // 2 and 69 are outside the ring-extended tile and masked out
 #define PRE_GROUPS (256 / PRE_PAIRS)      // 7 row groups of 34 threads
 #define PRE_ITERS ((PRE_ROWS + PRE_GROUPS - 1) / PRE_GROUPS)  // rows rg, rg + 7, ... : 5 iterations
-#define PRE_MAX (2 * PRE_ROWS * 2 * PRE_PAIRS)  // one entry per (pixel, polarity)
-#define PRE_DARK0 (PRE_MAX / 2)  // first entry of the dark list (ballot form: both lists grow upwards, each can hold every pixel)
+#define PRE_MAX (2 * (PRE_GROUPS * PRE_ITERS) * 2 * PRE_PAIRS)  // one entry per (pixel, polarity) of every row the row groups compute (PRE_ROWS + the padding row: its pixels can make entries since step 2a stopped testing rows)
+#define PRE_DARK0 (PRE_MAX / 2)  // first entry of the dark list (both lists grow upwards, each can hold every pixel)
 #define PRE_PAD_ROWS (PRE_GROUPS * PRE_ITERS - PRE_ROWS)  // rows past the tile the masked iterations of the last row group touch (1 at FT_H = 32)
 #define ST_GROUPS 14                                       // staging: 18 dword columns x 14 row groups = 252 threads
 #define ST_ITERS ((FT_LH + ST_GROUPS - 1) / ST_GROUPS)     // rows rs, rs + 14, ... (3 at FT_H = 32)
@@ -177,6 +177,9 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Geo *__restrict__ geo_p,
         pre_nb = 0;
         pre_nd = 0;
     }
+    // the padding row(s) behind the staged window: read by the last row group's padding iteration (its entries land where step 3 never
+    // looks) - cleared so that not even the COUNT of entries depends on what an earlier workgroup left in LDS
+    if (tid < PRE_PAD_ROWS * (FT_PITCH / 4)) reinterpret_cast<uint32_t *>(&tile[FT_LH * FT_PITCH])[tid] = 0u;
 
     // 1. stage 72x40 bytes and clear the score plane.  Thread (rq, rs) = (tid % 18, tid / 18) owns the dword column rq of the rows
     //    rs, rs + 14, rs + 28 (252 of the 256 threads): the column part of the address (and its reflect-101 handling at the left /
