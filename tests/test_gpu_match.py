@@ -547,7 +547,13 @@ def test_three_threads_three_contexts(afv, oracle):
     [t.join() for t in th]
     assert not errs, errs
     for i in range(3):
-        assert np.array_equal(got[i][0], want[i][0])
+        if not np.array_equal(got[i][0], want[i][0]):
+            # say WHICH side left the truth (the oracle on the same image) and where: a concurrency fault and a fault of the serial
+            # context look the same from here otherwise
+            _, od = oracle.orb_extract(imgs[i])
+            rows = np.nonzero((got[i][0] != want[i][0]).any(axis=1))[0] if got[i][0].shape == want[i][0].shape else None
+            raise AssertionError("thread %d: descriptors differ from the serial context in rows %s; threaded == oracle: %s, serial == oracle: %s"
+                                 % (i, None if rows is None else rows[:16].tolist(), np.array_equal(got[i][0], od), np.array_equal(want[i][0], od)))
         assert got[i][1][1] == want[i][1][1] and np.array_equal(got[i][1][0], want[i][1][0])
     serial_ctx.close()
 
