@@ -95,7 +95,7 @@ static int build_geometry(const afv_orb_params &p, int w, int h, int max_batch, 
         L.sel_base = sel_base;
         sel_base += L.sel_cap;
         L.desc_blk_base = desc_blk_base;
-        desc_blk_base += (L.sel_cap + 3) / 4;  // KP_PER_BLOCK keypoints per k_describe block
+        desc_blk_base += (L.sel_cap + AFV_KP_PER_BLOCK - 1) / AFV_KP_PER_BLOCK;  // keypoints per k_describe block
         L.pyr_frame_stride = align_up((size_t)L.h * L.pitch + 64, 256);
         L.pyr_off = pyr_off;
         if (l > 0) pyr_off += L.pyr_frame_stride * (size_t)max_batch;
@@ -499,7 +499,7 @@ extern "C" int afv_create(int device, const afv_orb_params *params, afv_ctx **ou
     CREATE_CHK(hipMalloc(&c->d_cand_count, (size_t)B * AFV_MAX_LEVELS * sizeof(int)));
     CREATE_CHK(hipMalloc(&c->d_sel_count, (size_t)B * AFV_MAX_LEVELS * sizeof(int)));
     CREATE_CHK(hipMalloc(&c->d_sel, (size_t)B * g.sel_per_frame * sizeof(SelPoint)));
-    CREATE_CHK(hipMemset(c->d_sel_count, 0, (size_t)B * AFV_MAX_LEVELS * sizeof(int)));
+    CREATE_CHK(afv_fill(c, c->d_sel_count, 0, (size_t)B * AFV_MAX_LEVELS * sizeof(int)));
     // staging for host-pointer calls
     c->frames_pitch = align_up((size_t)params->max_width, 64);
     c->frames_stride = align_up(c->frames_pitch * (size_t)params->max_height, 256);
@@ -528,7 +528,7 @@ extern "C" int afv_create(int device, const afv_orb_params *params, afv_ctx **ou
     }
 #undef CREATE_CHK
     // kernels that ask for more dynamic LDS than the default: raised once per context, on its device, checked
-    if (hipMalloc(reinterpret_cast<void **>(&c->d_proj_ticket), 256) != hipSuccess || hipMemset(c->d_proj_ticket, 0, 256) != hipSuccess) {
+    if (hipMalloc(reinterpret_cast<void **>(&c->d_proj_ticket), 256) != hipSuccess || afv_fill(c, c->d_proj_ticket, 0, 256) != hipSuccess) {
         (void)hipGetLastError();
         if (c->d_proj_ticket) (void)hipFree(c->d_proj_ticket);
         c->d_proj_ticket = nullptr;  // the searches then take two launches

@@ -66,8 +66,8 @@ extern "C" int afv_table_create(afv_ctx *c, int nsets, int cap, afv_table **out)
     hipError_t e = hipMalloc(&t->d_desc, (size_t)nsets * cap * 32);
     if (e == hipSuccess) e = hipMalloc(&t->d_angle, (size_t)nsets * cap * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&t->d_n, (size_t)nsets * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMemset(t->d_n, 0, (size_t)nsets * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMemset(t->d_angle, 0, (size_t)nsets * cap * sizeof(float));
+    if (e == hipSuccess) e = afv_fill(c, t->d_n, 0, (size_t)nsets * sizeof(int32_t));
+    if (e == hipSuccess) e = afv_fill(c, t->d_angle, 0, (size_t)nsets * cap * sizeof(float));
     if (e == hipSuccess) e = hipEventCreate(&t->ev0);
     if (e == hipSuccess) e = hipEventCreate(&t->ev1);
     if (e != hipSuccess) {
@@ -195,13 +195,13 @@ extern "C" int afv_table_set_valid(afv_table *t, int set, const uint8_t *valid) 
     if (!t->d_valid) {
         if (!valid) return AFV_OK;  // nothing was ever restricted
         HIPCHK(c, hipMalloc(&t->d_valid, (size_t)t->nsets * t->cap));
-        HIPCHK(c, hipMemset(t->d_valid, 1, (size_t)t->nsets * t->cap));
+        HIPCHK(c, afv_fill(c, t->d_valid, 1, (size_t)t->nsets * t->cap));
     }
     const int n = t->h_n[set];
     if (valid) {
         if (n) HIPCHK(c, hipMemcpy(t->d_valid + (size_t)set * t->cap, valid, (size_t)n, hipMemcpyHostToDevice));
     } else {
-        HIPCHK(c, hipMemset(t->d_valid + (size_t)set * t->cap, 1, (size_t)t->cap));
+        HIPCHK(c, afv_fill(c, t->d_valid + (size_t)set * t->cap, 1, (size_t)t->cap));
     }
     return AFV_OK;
 }
@@ -298,13 +298,13 @@ extern "C" int afv_table_clone(const afv_table *src, afv_table *dst) {
         if (src->d_idx && !dst->d_idx) HIPCHK(c, hipMalloc(&dst->d_idx, plane * sizeof(int32_t)));
         if (src->d_geo && !dst->d_geo) HIPCHK(c, hipMalloc(&dst->d_geo, 4 * plane * sizeof(float)));
         if (src->d_valid && !dst->d_valid) HIPCHK(c, hipMalloc(&dst->d_valid, plane));
-        HIPCHK(c, hipMemcpy(dst->d_desc, src->d_desc, plane * 32, hipMemcpyDefault));
-        HIPCHK(c, hipMemcpy(dst->d_angle, src->d_angle, plane * sizeof(float), hipMemcpyDefault));
-        HIPCHK(c, hipMemcpy(dst->d_n, src->d_n, (size_t)dst->nsets * sizeof(int32_t), hipMemcpyDefault));
-        if (src->d_idx) HIPCHK(c, hipMemcpy(dst->d_idx, src->d_idx, plane * sizeof(int32_t), hipMemcpyDefault));
-        if (src->d_geo) HIPCHK(c, hipMemcpy(dst->d_geo, src->d_geo, 4 * plane * sizeof(float), hipMemcpyDefault));
-        if (src->d_valid) HIPCHK(c, hipMemcpy(dst->d_valid, src->d_valid, plane, hipMemcpyDefault));
-        else if (dst->d_valid) HIPCHK(c, hipMemset(dst->d_valid, 1, plane));
+        HIPCHK(c, afv_copy_dd(c, dst->d_desc, src->d_desc, plane * 32));
+        HIPCHK(c, afv_copy_dd(c, dst->d_angle, src->d_angle, plane * sizeof(float)));
+        HIPCHK(c, afv_copy_dd(c, dst->d_n, src->d_n, (size_t)dst->nsets * sizeof(int32_t)));
+        if (src->d_idx) HIPCHK(c, afv_copy_dd(c, dst->d_idx, src->d_idx, plane * sizeof(int32_t)));
+        if (src->d_geo) HIPCHK(c, afv_copy_dd(c, dst->d_geo, src->d_geo, 4 * plane * sizeof(float)));
+        if (src->d_valid) HIPCHK(c, afv_copy_dd(c, dst->d_valid, src->d_valid, plane));
+        else if (dst->d_valid) HIPCHK(c, afv_fill(c, dst->d_valid, 1, plane));
         for (int s = 0; s < dst->nsets; ++s) {  // nothing of the destination's previous content survives
             dst->fv[s] = HostFeatVec();
             dst->has_fv[s] = dst->has_geo[s] = 0;
@@ -941,7 +941,7 @@ extern "C" int afv_table_broadcast(afv_comm *m, afv_table *t, int root, float *e
             t->fv[s] = HostFeatVec();
             t->has_fv[s] = t->has_geo[s] = 0;
         }
-        if (!flags[2] && t->d_valid) HIPCHK(c, hipMemset(t->d_valid, 1, plane));
+        if (!flags[2] && t->d_valid) HIPCHK(c, afv_fill(c, t->d_valid, 1, plane));
         rc = afv_table_sync_counts(t);
         if (rc) return rc;
         blob.resize((size_t)flags[3]);

@@ -16,6 +16,11 @@
 #define FT_LH (FT_H + 2 * FT_HALO)  // 40
 #define FT_MAXC 1024                 // candidates per tile after NMS: <= (64/2)*(32/2) = 512 (strict 3x3 maxima)
 
+// k_describe: keypoints (= wavefronts) per workgroup
+#ifndef AFV_KP_PER_BLOCK
+#define AFV_KP_PER_BLOCK 4
+#endif
+
 // quadtree limits
 #define QT_MAX_NODES 1536  // alive nodes <= N+3 ; supports per-level quotas up to ~1500 (nfeatures <= ~6900)
 

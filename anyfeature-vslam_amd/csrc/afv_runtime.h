@@ -246,6 +246,21 @@ struct StageTimer {  // RAII: record begin/end events around one stage on the la
         }                                                                                            \
     } while (0)
 
+// Fills and device-to-device copies that a later launch depends on.  hipMemset / hipMemcpy(device -> device) run on the NULL stream and
+// may return before they have run; the contexts' streams are created non-blocking, so nothing orders a launch on them behind such an
+// operation (round 6: a fresh context's first sliced match could meet ticket words the fill had not reached yet - or have its counts
+// wiped by a fill that ran late).  These run on the context's own stream and the host waits for them.
+static inline hipError_t afv_fill(afv_ctx *c, void *p, int v, size_t n) {
+    if (!n) return hipSuccess;
+    const hipError_t e = hipMemsetAsync(p, v, n, c->stream);
+    return e == hipSuccess ? hipStreamSynchronize(c->stream) : e;
+}
+static inline hipError_t afv_copy_dd(afv_ctx *c, void *dst, const void *src, size_t n) {
+    if (!n) return hipSuccess;
+    const hipError_t e = hipMemcpyAsync(dst, src, n, hipMemcpyDefault, c->stream);
+    return e == hipSuccess ? hipStreamSynchronize(c->stream) : e;
+}
+
 static inline int cv_round(float v) { return (int)lrintf(v); }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // the C-ABI never throws: host allocation failures inside the matcher entry points become AFV_ENOMEM
@@ -368,7 +383,7 @@ static inline int ensure_slice_scratch(afv_ctx *c, int npairs, int cap, int nsli
         c->d_tickets = nullptr;
         c->tickets_n = 0;
         HIPCHK(c, hipMalloc(&c->d_tickets, nt * sizeof(int)));
-        HIPCHK(c, hipMemset(c->d_tickets, 0, nt * sizeof(int)));
+        HIPCHK(c, afv_fill(c, c->d_tickets, 0, nt * sizeof(int)));
         c->tickets_n = nt;
     }
     return AFV_OK;

@@ -56,7 +56,7 @@ __device__ __constant__ __attribute__((aligned(16))) const IcMasks k_ic_masks = 
 #define PR 21        // patch radius: 18 (BRIEF reach) + 3 (blur)
 #define PS 43        // patch side
 #define PP 52        // LDS pitch of the patch rows: 13 dwords (odd => conflict-free row strides)
-#define KP_PER_BLOCK 4
+#define KP_PER_BLOCK AFV_KP_PER_BLOCK  // afv_device.h (the host plan of the block list divides by it too)
 
 // cv::fastAtan2 (OpenCV mathfuncs_core atan_f32), degrees
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
@@ -340,7 +340,6 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
     const float ptx = (float)cx * L.scale, pty = (float)cy * L.scale;
     const int bx = (int)rintf(ptx * L.inv_scale), by = (int)rintf(pty * L.inv_scale);
     const int ox = bx - cx, oy = by - cy;  // 0 in practice; kept literal
-    const f32x2 cs_a = {ca, sb}, cs_b = {-sb, ca};
     const int kox = ox - 0x4B400000, koy = oy - 0x4B400000;  // scalar: the mantissa offset of the rounding trick below and the (0) centre offset
     uint32_t words[8];
 #pragma unroll
@@ -348,16 +347,19 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
         const int t = g * 64 + lane;
         const float4 pt = reinterpret_cast<const float4 *>(k_brief_pattern)[t];
         const float x0 = pt.x, y0 = pt.y, x1 = pt.z, y1 = pt.w;
-        // (x ca - y sb, x sb + y ca) as three packed fp32 instructions per point: (x, x) * (ca, sb) + (y, y) * (-sb, ca) - the same
-        // products and sums bit for bit (a - b = a + (-b), (-s) y = -(s y), one rounding per operator: -ffp-contract=off)
-        const f32x2 rp0 = f32x2{x0, x0} * cs_a + f32x2{y0, y0} * cs_b, rp1 = f32x2{x1, x1} * cs_a + f32x2{y1, y1} * cs_b;
+        // (x ca - y sb, x sb + y ca) in PLAIN fp32, one rounding per operator (a - b = a + (-b), (-s) y = -(s y); -ffp-contract=off).
+        // Round 5 held this as three packed instructions per point ((x, x) * (ca, sb) + (y, y) * (-sb, ca)); round 6 found that
+        // v_pk_mul_f32 with a broadcast of its second operand's register (op_sel / op_sel_hi) returns the product of the OTHER register
+        // in lanes 48..63 now and then while a wavefront of an MFMA kernel of another queue shares the SIMD (one wrong descriptor in a
+        // few hundred frames beside k_match_topk_mfma; tools/probes/probe_pk_real.hip reproduces it in seconds, DESIGN_LOG round 6).
+        // The whole library is built without packed fp32 instructions (build.py); this kernel does not ask for them either.
+        const float rx0 = x0 * ca + y0 * -sb, ry0 = x0 * sb + y0 * ca, rx1 = x1 * ca + y1 * -sb, ry1 = x1 * sb + y1 * ca;
         // cvRound = round half to even: x + 1.5 * 2^23 leaves the rounded integer in the mantissa (|x| < 2^22; the addition rounds to
-        // nearest even exactly where rintf does), one packed add per point instead of two v_rndne + two v_cvt; the integer
-        // offset 0x4B400000 folds into the address constants below
-        const f32x2 rmag = {12582912.0f, 12582912.0f};
-        const f32x2 rq0 = rp0 + rmag, rq1 = rp1 + rmag;
-        const int ix0 = __float_as_int(rq0.x) + kox, iy0 = __float_as_int(rq0.y) + koy;
-        const int ix1 = __float_as_int(rq1.x) + kox, iy1 = __float_as_int(rq1.y) + koy;
+        // nearest even exactly where rintf does), one add per coordinate instead of v_rndne + v_cvt; the integer offset 0x4B400000
+        // folds into the address constants below
+        const float rmag = 12582912.0f;
+        const int ix0 = __float_as_int(rx0 + rmag) + kox, iy0 = __float_as_int(ry0 + rmag) + koy;
+        const int ix1 = __float_as_int(rx1 + rmag) + kox, iy1 = __float_as_int(ry1 + rmag) + koy;
         // inside the ROI -> blurred, outside -> unblurred apron (a patch that lies inside the level has no outside samples)
         int t0, t1;
         if (interior) {

@@ -11,12 +11,20 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    variant = os.environ.get("AFV_TEST_LIB") or None
+    if variant:  # before any test module can load the in-tree library
+        importlib.import_module("anyfeature-vslam_amd")._lib.use_library(variant)
 
 
 @pytest.fixture(scope="session")
 def afv():
-    """the product package (directory name has a hyphen)"""
-    return importlib.import_module("anyfeature-vslam_amd")
+    """the product package (directory name has a hyphen).  AFV_TEST_LIB=path binds a variant build of the library for this test run
+    (the poison build of tools/poison_build.py: csrc/afv_poison.h) - a switch of the TESTS; the package's loader ignores the environment."""
+    pkg = importlib.import_module("anyfeature-vslam_amd")
+    variant = os.environ.get("AFV_TEST_LIB") or None
+    if variant:
+        assert os.path.samefile(pkg._lib.LIB_PATH, variant), "AFV_TEST_LIB came too late: the library is already loaded"
+    return pkg
 
 
 @pytest.fixture(scope="session")

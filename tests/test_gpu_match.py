@@ -514,8 +514,12 @@ def test_config4_pair_jobs_from_descriptor_table(afv, oracle, matcher, gpu_ctx):
 def test_three_threads_three_contexts(afv, oracle):
     """the matchers are called from three threads of the reference (tracking, local mapping, loop closing); the
     C-ABI is used with one context per calling thread.  Three threads extract + match concurrently (ctypes releases the GIL
-    inside the calls); every thread must reproduce the serial results."""
+    inside the calls); every thread must reproduce the serial results AND the oracle's, in every iteration (not only the last).
+    AFV_STRESS_ROUNDS=n repeats the whole scene n times inside this process (tools/poison_suite.sh runs it with hundreds); a
+    mismatch names the first pipeline stage at which the thread's context differs from a serial re-run (tests/_stage_dump.py)."""
+    import os
     import threading
+    from _stage_dump import first_difference, stage_state
     s = afv.synth
     imgs = [s.corners_frame(40 + i) for i in range(3)]
     serial_ctx = afv.Context()
@@ -524,37 +528,65 @@ def test_three_threads_three_contexts(afv, oracle):
     for im in imgs:
         k1, d1 = serial_ctx.extract(im)
         k2, d2 = serial_ctx.extract(np.roll(im, 3, axis=1))
+        _, od = oracle.orb_extract(im)
+        assert np.array_equal(d1, od), "the serial context left the oracle"
         m = afv.FeatureMatcher(0.7, True, ctx=serial_ctx)
-        want.append((d1.copy(), m.SearchByBoW(afv.FeatureView(d1, angles=k1["angle"]), afv.FeatureView(d2, angles=k2["angle"]))))
-    got = [None] * 3
+        want.append((k1.copy(), d1.copy(), k2.copy(), d2.copy(),
+                     m.SearchByBoW(afv.FeatureView(d1, angles=k1["angle"]), afv.FeatureView(d2, angles=k2["angle"]))))
     errs = []
+    serial_lock = threading.Lock()
 
-    def work(i):
+    def explain(ctx, i, img, what, got=None, ref_kd=None, prev_kd=None):
+        # the thread's context still holds the state of the call that went wrong; the serial context re-runs the same image
+        mine = stage_state(ctx)
+        with serial_lock:
+            serial_ctx.extract(img)
+            ref = stage_state(serial_ctx)
+        msg = "thread %d: %s differ from the serial context; first stage that differs: %s" % (i, what, first_difference(ref, mine) or "none (describe)")
+        if got is not None:
+            gk, gd = got
+            rk, rd = ref_kd
+            msg += "; counts %d / %d" % (len(gk), len(rk))
+            m = min(len(gk), len(rk))
+            bad_k = np.nonzero(gk[:m].view(np.uint8).reshape(m, -1) != rk[:m].view(np.uint8).reshape(m, -1))[0]
+            bad_d = np.nonzero((gd[:m] != rd[:m]).any(axis=1))[0]
+            msg += "; keypoint rows that differ %s, descriptor rows that differ %s" % (np.unique(bad_k)[:12].tolist(), bad_d[:12].tolist())
+            if prev_kd is not None and len(bad_d):
+                pk, pd = prev_kd
+                same_prev = [bool(r < len(pd) and np.array_equal(gd[r], pd[r])) for r in bad_d[:12]]
+                zero = [bool(not gd[r].any()) for r in bad_d[:12]]
+                msg += "; those descriptor rows equal the PREVIOUS call's rows: %s, all zero: %s, first bad row %s against %s" % (
+                    same_prev, zero, gd[bad_d[0]].tolist(), rd[bad_d[0]].tolist())
+            again = [bool(np.array_equal(ctx.extract(img)[1], rd)) for _ in range(3)]
+            msg += "; the same call repeated on the thread's context matches: %s" % again
+        return msg
+
+    def work(i, iters):
         try:
             ctx = afv.Context()
             m = afv.FeatureMatcher(0.7, True, ctx=ctx)
-            for _ in range(5):
+            rolled = np.roll(imgs[i], 3, axis=1)
+            for _ in range(iters):
                 k1, d1 = ctx.extract(imgs[i])
-                k2, d2 = ctx.extract(np.roll(imgs[i], 3, axis=1))
+                if not (np.array_equal(d1, want[i][1]) and k1.tobytes() == want[i][0].tobytes()):
+                    raise AssertionError(explain(ctx, i, imgs[i], "keypoints / descriptors of the frame", (k1, d1), (want[i][0], want[i][1]), (want[i][2], want[i][3])))
+                k2, d2 = ctx.extract(rolled)
+                if not (np.array_equal(d2, want[i][3]) and k2.tobytes() == want[i][2].tobytes()):
+                    raise AssertionError(explain(ctx, i, rolled, "keypoints / descriptors of the shifted frame", (k2, d2), (want[i][2], want[i][3]), (want[i][0], want[i][1])))
                 r = m.SearchByBoW(afv.FeatureView(d1, angles=k1["angle"]), afv.FeatureView(d2, angles=k2["angle"]))
-            got[i] = (d1.copy(), r)
+                assert r[1] == want[i][4][1] and np.array_equal(r[0], want[i][4][0]), "thread %d: SearchByBoW differs from the serial context" % i
             ctx.close()
-        except Exception as e:  # noqa: BLE001
+        except BaseException as e:  # noqa: BLE001
+            import sys
+            print("three-threads:", e, file=sys.stderr, flush=True)  # the whole message (pytest abbreviates long assertion texts)
             errs.append(e)
 
-    th = [threading.Thread(target=work, args=(i,)) for i in range(3)]
-    [t.start() for t in th]
-    [t.join() for t in th]
-    assert not errs, errs
-    for i in range(3):
-        if not np.array_equal(got[i][0], want[i][0]):
-            # say WHICH side left the truth (the oracle on the same image) and where: a concurrency fault and a fault of the serial
-            # context look the same from here otherwise
-            _, od = oracle.orb_extract(imgs[i])
-            rows = np.nonzero((got[i][0] != want[i][0]).any(axis=1))[0] if got[i][0].shape == want[i][0].shape else None
-            raise AssertionError("thread %d: descriptors differ from the serial context in rows %s; threaded == oracle: %s, serial == oracle: %s"
-                                 % (i, None if rows is None else rows[:16].tolist(), np.array_equal(got[i][0], od), np.array_equal(want[i][0], od)))
-        assert got[i][1][1] == want[i][1][1] and np.array_equal(got[i][1][0], want[i][1][0])
+    rounds = int(os.environ.get("AFV_STRESS_ROUNDS", "1"))
+    for rnd in range(rounds):
+        th = [threading.Thread(target=work, args=(i, 5)) for i in range(3)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errs, (rnd, errs)
     serial_ctx.close()
 
 
