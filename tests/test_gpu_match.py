@@ -581,13 +581,89 @@ def test_three_threads_three_contexts(afv, oracle):
             print("three-threads:", e, file=sys.stderr, flush=True)  # the whole message (pytest abbreviates long assertion texts)
             errs.append(e)
 
-    rounds = int(os.environ.get("AFV_STRESS_ROUNDS", "1"))
+    rounds = int(os.environ.get("AFV_STRESS_ROUNDS", "25"))
     for rnd in range(rounds):
         th = [threading.Thread(target=work, args=(i, 5)) for i in range(3)]
         [t.start() for t in th]
         [t.join() for t in th]
         assert not errs, (rnd, errs)
     serial_ctx.close()
+
+
+def _concurrent_scene(afv, oracle, roles, rounds):
+    """tools/stress_threads.py as a test: one fresh context per thread and round; `roles` gives every thread its job (e = it extracts two
+    frames per iteration, m = it matches two descriptor sets, the per-frame plugin shape).  Returns the list of everything that differed
+    from the serial results (which are checked against the oracle first)."""
+    import threading
+    s = afv.synth
+    nt = len(roles)
+    imgs = [s.corners_frame(40 + i) for i in range(nt)]
+    serial = afv.Context()
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+    want = []
+    for im in imgs:
+        k1, d1 = serial.extract(im)
+        k2, d2 = serial.extract(np.roll(im, 3, axis=1))
+        _, od = oracle.orb_extract(im)
+        assert np.array_equal(d1, od)
+        m = afv.FeatureMatcher(0.7, True, ctx=serial)
+        r = m.SearchByBoW(afv.FeatureView(d1, angles=k1["angle"]), afv.FeatureView(d2, angles=k2["angle"]))
+        w, wn = oracle.search_by_bow_kf_kf(d1, d2, angle1=k1["angle"], angle2=k2["angle"], th_low=75.0, nnratio=0.7, check_orientation=True)
+        assert r[1] == wn and np.array_equal(r[0], w)
+        want.append((k1, d1, k2, d2, r))
+    serial.close()
+    bad, lock = [], threading.Lock()
+
+    def work(i, rnd):
+        try:
+            ctx = afv.Context()
+            m = afv.FeatureMatcher(0.7, True, ctx=ctx)
+            rolled = np.roll(imgs[i], 3, axis=1)
+            k1w, d1w, k2w, d2w, rw = want[i]
+            for it in range(5):
+                if roles[i] == "e":
+                    for which, im, kw, dw in (("frame", imgs[i], k1w, d1w), ("shifted frame", rolled, k2w, d2w)):
+                        k, d = ctx.extract(im)
+                        if k.tobytes() != kw.tobytes() or not np.array_equal(d, dw):
+                            rows = np.nonzero((d != dw).any(axis=1))[0].tolist() if d.shape == dw.shape else None
+                            with lock:
+                                bad.append("round %d thread %d: extraction of the %s differs (descriptor rows %s)" % (rnd, i, which, rows))
+                else:
+                    r = m.SearchByBoW(afv.FeatureView(d1w, angles=k1w["angle"]), afv.FeatureView(d2w, angles=k2w["angle"]))
+                    if r[1] != rw[1] or not np.array_equal(r[0], rw[0]):
+                        with lock:
+                            bad.append("round %d thread %d: SearchByBoW differs (%d against %d matches)" % (rnd, i, r[1], rw[1]))
+            ctx.close()
+        except BaseException as e:  # noqa: BLE001
+            with lock:
+                bad.append("round %d thread %d: %r" % (rnd, i, e))
+
+    for rnd in range(rounds):
+        th = [threading.Thread(target=work, args=(i, rnd)) for i in range(nt)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        if len(bad) > 8:
+            break
+    return bad
+
+
+def test_extraction_beside_the_sliced_mfma_matcher(afv, oracle):
+    """Round 6, regression.  One thread extracts while two others run the per-frame brute-force match of their own contexts (column-sliced
+    k_match_topk_mfma): on the round-5 sources about one frame in four hundred came back with one descriptor row wrong in the bits of the
+    lanes 48..63 of a BRIEF group - v_pk_mul_f32 with op_sel:[0,1] in k_describe's rotation beside the MFMA wavefronts (DESIGN_LOG round 6,
+    tools/probes/probe_pk_real.hip).  200 rounds = 2000 extractions: the old sources fail this with probability > 0.99."""
+    import os
+    bad = _concurrent_scene(afv, oracle, "emm", int(os.environ.get("AFV_STRESS_ROUNDS", "200")))
+    assert not bad, bad[:8]
+
+
+def test_fresh_contexts_match_at_once(afv, oracle):
+    """Round 6, regression.  Three threads, each round a NEW context per thread whose first call is a sliced match: its ticket words are
+    allocated and cleared in that call.  The clear was a hipMemset (null stream, which the non-blocking context stream does not wait
+    for): about one match in two thousand merged its slices early (173 instead of 584 matches).  200 rounds x 3 fresh contexts."""
+    import os
+    bad = _concurrent_scene(afv, oracle, "mmm", int(os.environ.get("AFV_STRESS_ROUNDS", "200")))
+    assert not bad, bad[:8]
 
 
 def test_fixed_point_guard_is_reported_not_swallowed(afv, oracle, gpu_ctx):
