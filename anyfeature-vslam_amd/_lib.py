@@ -21,6 +21,7 @@ def use_library(path):
     LIB_PATH = os.path.abspath(path)
 
 
+ABI_VERSION = 6  # include/afv_hip.h AFV_ABI_VERSION this mirror was written against
 MAX_LEVELS = 8
 DESC_BYTES = 32
 OK, EINVAL, ENODEV, ENOMEM, EHIP, ECAPACITY, EUNSUPPORTED, ETIMEOUT = 0, -1, -2, -3, -4, -5, -6, -7
@@ -107,6 +108,7 @@ def sized(struct):
 # every symbol include/afv_hip.h declares: (name, restype, argtypes)
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SYMBOLS = {
+    "afv_abi_version": (_i, []),
     "afv_default_orb_params": (None, [C.POINTER(OrbParams)]),
     "afv_create": (_i, [_i, C.POINTER(OrbParams), C.POINTER(_vp)]),
     "afv_destroy": (None, [_vp]),
@@ -115,6 +117,8 @@ SYMBOLS = {
     "afv_max_keypoints_per_frame": (_i, [_vp]),
     "afv_stream": (_vp, [_vp]),
     "afv_orb_extract": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, C.POINTER(_i)]),
+    "afv_orb_detect": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, C.POINTER(_i)]),
+    "afv_orb_compute": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "afv_orb_extract_batch": (_i, [_vp, C.POINTER(_vp), _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "afv_orb_extract_batch_device": (_i, [_vp, _vp, _i, _i, _i, _i, _sz, _vp, _vp, _i, _vp, _vp, _vp]),
     "afv_orb_size_sigma": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
@@ -239,6 +243,8 @@ def load():
         fn.argtypes = args
     # the profile getters write afv_num_stages() entries: a (variant) build with more stages than this mirror knows would overrun the
     # arrays the wrapper hands it
+    if lib.afv_abi_version() != ABI_VERSION:
+        raise ImportError("%s speaks ABI revision %d, this mirror %d" % (LIB_PATH, lib.afv_abi_version(), ABI_VERSION))
     if lib.afv_num_stages() > len(STAGES):
         raise ImportError("%s reports %d profile stages, this mirror knows %d" % (LIB_PATH, lib.afv_num_stages(), len(STAGES)))
     _lib = lib

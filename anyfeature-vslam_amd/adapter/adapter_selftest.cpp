@@ -53,6 +53,22 @@ int main(int argc, char **argv) {
     extractor(img2, k2, d2);                // 3-arg operator()
     if (settings->ON_automaticTuning || k1.empty() || (int)size.size() != (int)k1.size()) return 4;
 
+    {   // the virtuals one by one (FeatureExtractor.h:123-128): detectKeypoints -> filterKeypoints -> computeDescriptors -> merge == detectAndCompute
+        std::map<int, std::vector<afv::KeyPoint>> kl;
+        std::map<int, afv::Mat8> dl;
+        extractor.detectKeypoints(kl, img, settings->detectTh, settings->nOctaves);
+        extractor.filterKeypoints(kl, img.grayImg, img.grayImg);
+        extractor.computeDescriptors(dl, kl, img);
+        std::vector<afv::KeyPoint> km;
+        std::vector<uint8_t> dm;
+        for (auto &lk : kl) {
+            km.insert(km.end(), lk.second.begin(), lk.second.end());
+            dm.insert(dm.end(), dl[lk.first].data.begin(), dl[lk.first].data.end());
+        }
+        if (km.size() != k1.size() || std::memcmp(km.data(), k1.data(), km.size() * sizeof(afv::KeyPoint)) != 0) return 7;
+        if (dm.size() != d1.data.size() || std::memcmp(dm.data(), d1.ptr(), dm.size()) != 0) return 7;
+    }
+
     afv::FeatureMatcherHip::setDescriptorDistanceThresholds(75.0f);
     afv::FeatureMatcherHip matcher(extractor.context(), 0.6f, true);
     std::vector<float> a1(k1.size()), a2(k2.size());

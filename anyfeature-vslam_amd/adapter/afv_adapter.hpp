@@ -157,6 +157,41 @@ class FeatureExtractor_orb32_hip {
         fill_descriptors(descriptors, desc.data(), n);
     }
 
+    // The three virtuals detectAndCompute is composed of (FeatureExtractor.h:123-128), for a host that calls them one by one - a vocabulary
+    // builder that keeps keypoints and recomputes descriptors at them (cv::ORB::compute semantics).  detectKeypoints here already
+    // includes the quadtree of filterKeypoints (the device never ships cv::ORB::detect's 10x candidate set to the host), so the
+    // filterKeypoints override is the identity; detectKeypoints -> filterKeypoints -> computeDescriptors -> mergeKeypointLevels gives
+    // detectAndCompute's outputs bit for bit (tests/test_gpu_extract.py::test_plugin_virtuals_one_by_one, adapter_selftest).
+    template <class ImageT>
+    void detectKeypoints(std::map<int, std::vector<KeyPoint>> &keypoints_level, const ImageT &img, const float & /*detectTh*/, const int & /*nOctaves*/) const {
+        const auto &g = img.grayImg;
+        if (g.empty()) return;
+        std::vector<KeyPoint> kps((size_t)cap);
+        int n = 0;
+        const int rc = afv_orb_detect(ctx, g.ptr(0), g.cols, g.rows, (int)row_step(g), reinterpret_cast<afv_keypoint *>(kps.data()), cap, &n);
+        if (rc != AFV_OK) fatal("afv_orb_detect", rc, ctx);
+        for (int i = 0; i < n; ++i) keypoints_level[kps[(size_t)i].octave].push_back(kps[(size_t)i]);  // GetKeypointOctave (Feature_orb32.cpp:55-57)
+    }
+    template <class MatT>
+    void filterKeypoints(std::map<int, std::vector<KeyPoint>> & /*keypoints_level*/, const MatT & /*image*/, const MatT & /*mask*/) const {}
+    // descriptors_level[level]: n x 32 rows in the order of keypoints_level[level] (one cv::ORB::compute per level in the reference,
+    // Feature_orb32.cpp:49-50; ONE device call here)
+    template <class ImageT, class MatT>
+    void computeDescriptors(std::map<int, MatT> &descriptors_level, std::map<int, std::vector<KeyPoint>> &keypoints_level, const ImageT &img) const {
+        const auto &g = img.grayImg;
+        std::vector<KeyPoint> all;
+        for (auto &lk : keypoints_level) all.insert(all.end(), lk.second.begin(), lk.second.end());
+        std::vector<uint8_t> desc(all.size() * AFV_DESC_BYTES);
+        const int rc = afv_orb_compute(ctx, g.ptr(0), g.cols, g.rows, (int)row_step(g), reinterpret_cast<const afv_keypoint *>(all.data()), (int)all.size(),
+                                       desc.data());
+        if (rc != AFV_OK) fatal("afv_orb_compute", rc, ctx);
+        size_t o = 0;
+        for (auto &lk : keypoints_level) {
+            fill_descriptors(descriptors_level[lk.first], desc.data() + o * AFV_DESC_BYTES, (int)lk.second.size());
+            o += lk.second.size();
+        }
+    }
+
     // FeatureExtractor::mvImagePyramid (FeatureExtractor.h:142; read by Frame::ComputeStereoMatches, Frame.cc:475,568): the levels of
     // the LAST extracted frame, copied from the device on demand (the mono entry point never asks).  MatT: cv::Mat (CV_8UC1) or Mat8.
     template <class MatT>

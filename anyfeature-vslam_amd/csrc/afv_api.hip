@@ -22,6 +22,8 @@ extern "C" void afv_default_orb_params(afv_orb_params *p) {
     p->max_batch = 1;
 }
 
+extern "C" int afv_abi_version(void) { return AFV_ABI_VERSION; }
+
 extern "C" const char *afv_strerror(int code) {
     const int i = -code;
     if (i < 0 || i > 7) return "unknown error";
@@ -534,6 +536,7 @@ extern "C" int afv_create(int device, const afv_orb_params *params, afv_ctx **ou
         c->d_proj_ticket = nullptr;  // the searches then take two launches
     }
     c->proj_wg_lds_max = afv_project_prepare();
+    c->frame_lds_max = afv_frame_prepare();
     (void)afv_match_prepare();
     c->select_wide_ok = afv_select_prepare(c->select_M) != 0;
     *out = c;
@@ -662,15 +665,16 @@ static bool small_batch_path(const afv_ctx *c, int nf) {
 
 // kernels of one contiguous frame range [f0, f0 + nf) on stream s
 // clear_status: this range is the whole call, *d_status is cleared ahead of its kernels (by the one-launch pyramid when there is one)
+// d_desc == nullptr: keypoints only (afv_orb_detect); pyramid_only: nothing behind the pyramid (afv_orb_compute describes given keypoints on it)
 static void enqueue_range(afv_ctx *c, const FrameSrc &src, int f0, int nf, afv_keypoint *d_kps, uint8_t *d_desc, int cap, int *d_n,
-                          int *d_status, hipStream_t s, bool clear_status = false, const DescribeMirror *mirror = nullptr) {
+                          int *d_status, hipStream_t s, bool clear_status = false, const DescribeMirror *mirror = nullptr, bool pyramid_only = false) {
     const Geo &g = c->geo;
     {   // work lists are indexed with afv_udiv (exact below AFV_MAX_WORK items): longer ranges go out in pieces
         const int per = std::max(std::max(g.total_tiles, afv_describe_blocks_per_frame(&g)), 1);
         const int max_nf = std::max(1, (AFV_MAX_WORK - 8) / per);
         if (nf > max_nf) {
             if (clear_status && d_status) (void)hipMemsetAsync(d_status, 0, sizeof(int), s);
-            for (int b = 0; b < nf; b += max_nf) enqueue_range(c, src, f0 + b, std::min(max_nf, nf - b), d_kps, d_desc, cap, d_n, d_status, s);
+            for (int b = 0; b < nf; b += max_nf) enqueue_range(c, src, f0 + b, std::min(max_nf, nf - b), d_kps, d_desc, cap, d_n, d_status, s, false, mirror, pyramid_only);
             return;
         }
     }
@@ -701,6 +705,7 @@ static void enqueue_range(afv_ctx *c, const FrameSrc &src, int f0, int nf, afv_k
                               l == 1 ? c->d_hq_n + f0 : nullptr, s);
         }
     }
+    if (pyramid_only) return;
     {
         StageTimer t_(c, AFV_STAGE_FAST_NMS, s, nf);
         afv_launch_fast_nms(c->d_geo, g.total_tiles, &src, c->d_pyr, c->d_cand_packed, c->d_cand_count, f0, nf, s);
@@ -955,8 +960,9 @@ extern "C" int afv_orb_extract_batch(afv_ctx *c, const uint8_t *const *frames, i
 // was created for one frame (counts, keypoints and descriptors are then one contiguous range), else in three.
 // `frame` (afv_frame_extract): the describe kernel also writes the frame's device arrays, and k_frame_grid (per-feature arrays + grid) follows
 // on the stream before the host waits.
+// `keypoints_only` (afv_orb_detect): the last kernel writes keypoints (position, angle, response) and no descriptors.
 static int extract_one(afv_ctx *c, const uint8_t *gray, int width, int height, int stride_bytes, afv_keypoint *kps, uint8_t *desc32, int cap,
-                       int *n_out, afv_frame *frame = nullptr) {
+                       int *n_out, afv_frame *frame = nullptr, bool keypoints_only = false) {
     struct Quiesce {  // whatever path leaves this function, no DMA may still be in flight into the arena
         afv_ctx *c;
         bool armed = true;
@@ -1010,10 +1016,10 @@ static int extract_one(afv_ctx *c, const uint8_t *gray, int width, int height, i
     // (a frame smaller than the staging capacity: slots beyond frame->cap would be written past its arrays - afv_frame_create sizes frames
     // for the context's capacity, afv_frame_extract checks)
     if (zero_copy_out) {
-        enqueue_range(c, src, 0, 1, reinterpret_cast<afv_keypoint *>(hres + kps_off), hres + desc_off, c->stage_cap, reinterpret_cast<int *>(hres),
-                      c->d_status, s, true, frame ? &mir : nullptr);
+        enqueue_range(c, src, 0, 1, reinterpret_cast<afv_keypoint *>(hres + kps_off), keypoints_only ? nullptr : hres + desc_off, c->stage_cap,
+                      reinterpret_cast<int *>(hres), c->d_status, s, true, frame ? &mir : nullptr);
     } else {
-        enqueue_range(c, src, 0, 1, c->d_kps, c->d_desc, c->stage_cap, c->d_n, c->d_status, s, true, frame ? &mir : nullptr);
+        enqueue_range(c, src, 0, 1, c->d_kps, keypoints_only ? nullptr : c->d_desc, c->stage_cap, c->d_n, c->d_status, s, true, frame ? &mir : nullptr);
     }
     // a resident frame: the host vectors are complete when the describe kernel is (it writes them straight into the pinned arena);
     // k_frame_grid, which only feeds later device-side consumers on the same stream, runs on while the call returns
@@ -1022,13 +1028,16 @@ static int extract_one(afv_ctx *c, const uint8_t *gray, int width, int height, i
         wait_event = hipEventRecord(c->ev_fork, s) == hipSuccess;
         if (!wait_event) (void)hipGetLastError();
     }
-    if (frame) afv_frame_after_extract(frame, s);
+    if (frame) {
+        const int rc_grid = afv_frame_after_extract(frame, s);  // (a failed launch must not leave has_grid set over the zeroed memset: ADVICE r5)
+        if (rc_grid) return rc_grid;
+    }
     HIPCHK(c, hipGetLastError());
     if (trace) ts[3] = now();
     if (!zero_copy_out) {
         HIPCHK(c, hipMemcpyAsync(hres, c->d_n, sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipMemcpyAsync(hres + kps_off, c->d_kps, (size_t)c->stage_cap * sizeof(afv_keypoint), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(hres + desc_off, c->d_desc, (size_t)c->stage_cap * AFV_DESC_BYTES, hipMemcpyDeviceToHost, s));
+        if (!keypoints_only) HIPCHK(c, hipMemcpyAsync(hres + desc_off, c->d_desc, (size_t)c->stage_cap * AFV_DESC_BYTES, hipMemcpyDeviceToHost, s));
     }
     const uint8_t *h_kps = hres + kps_off, *h_desc = hres + desc_off;
     c->last_src = src;
@@ -1047,7 +1056,7 @@ static int extract_one(afv_ctx *c, const uint8_t *gray, int width, int height, i
     if (frame) frame->n = std::min(std::max(*reinterpret_cast<const int *>(hres), 0), frame->cap);
     if (n_out) *n_out = n;
     if (kps) std::memcpy(kps, h_kps, (size_t)n * sizeof(afv_keypoint));
-    if (desc32) std::memcpy(desc32, h_desc, (size_t)n * AFV_DESC_BYTES);
+    if (desc32 && !keypoints_only) std::memcpy(desc32, h_desc, (size_t)n * AFV_DESC_BYTES);
     if (trace) {
         ts[6] = now();
         for (int i = 0; i < 6; ++i) acc[i] += ts[i + 1] - ts[i];
@@ -1069,6 +1078,72 @@ extern "C" int afv_orb_extract(afv_ctx *c, const uint8_t *gray, int width, int h
     if (rc) return rc;
     c->prof = c->prof_every && (c->prof_tick_extract++ % (unsigned)c->prof_every) == 0;
     return guarded(c, [&]() -> int { return extract_one(c, gray, width, height, stride_bytes, kps, desc32, cap, n_out); });
+}
+
+// ---- the two halves of the plugin call as entry points of their own (FeatureExtractor.h:123-124, Feature_orb32.cpp:26-53) ----
+// detectKeypoints + filterKeypoints (E1-E7): what afv_orb_extract returns as keypoints, before any descriptor is computed
+extern "C" int afv_orb_detect(afv_ctx *c, const uint8_t *gray, int width, int height, int stride_bytes, afv_keypoint *kps, int cap, int *n_out) {
+    if (!c || !gray || !kps || !n_out) return AFV_EINVAL;
+    if (cap < 1 || stride_bytes < width) return AFV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = set_geometry(c, width, height);
+    if (rc) return rc;
+    c->prof = c->prof_every && (c->prof_tick_extract++ % (unsigned)c->prof_every) == 0;
+    return guarded(c, [&]() -> int { return extract_one(c, gray, width, height, stride_bytes, kps, nullptr, cap, n_out, nullptr, true); });
+}
+
+// computeDescriptors = cv::ORB::compute at caller-given keypoints (E8-E10): for every keypoint the rBRIEF descriptor at
+// cvRound(pt / scale(octave)) of its OWN octave and at its OWN angle, on the blurred level with the unblurred apron - the pyramid is
+// rebuilt from the image as cv::ORB::compute rebuilds levels 0 .. max octave (here: all levels, in one launch).  Keypoints are taken as
+// they are (orb.cpp runByImageBorder with edgeThreshold 0 removes nothing); a keypoint whose octave is not a level of this context or
+// whose centre does not lie on its level image is refused (AFV_EINVAL), nothing is described then.
+extern "C" int afv_orb_compute(afv_ctx *c, const uint8_t *gray, int width, int height, int stride_bytes, const afv_keypoint *kps, int n, uint8_t *desc32) {
+    if (!c || !gray || n < 0 || (n > 0 && (!kps || !desc32)) || stride_bytes < width) return AFV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = set_geometry(c, width, height);
+    if (rc) return rc;
+    const Geo &g = c->geo;
+    for (int i = 0; i < n; ++i) {
+        const afv_keypoint &k = kps[i];
+        if (k.octave < 0 || k.octave >= g.nlevels) return AFV_EINVAL;
+        const LevelGeo &L = g.lv[k.octave];
+        const float cx = rintf(k.x * L.inv_scale), cy = rintf(k.y * L.inv_scale);
+        if (!(cx >= 0.f && cx <= (float)L.w && cy >= 0.f && cy <= (float)L.h)) return AFV_EINVAL;  // (also refuses NaN)
+    }
+    if (n == 0) return AFV_OK;
+    return guarded(c, [&]() -> int {
+        struct Quiesce {
+            afv_ctx *c;
+            ~Quiesce() { (void)hipStreamSynchronize(c->stream); }
+        } quiesce{c};
+        hipStream_t s = c->stream;
+        const size_t pitch = align_up((size_t)width, 64), fstride = align_up(pitch * (size_t)height, 256), frame_bytes = (size_t)width * height;
+        FrameSrc src{c->d_frames, (int)pitch, fstride};
+        // arena: [image][keypoints][descriptors]; device side of the keypoints / descriptors: the matcher staging buffer
+        const size_t k_off = align_up(frame_bytes, 256), k_bytes = (size_t)n * sizeof(afv_keypoint);
+        const size_t d_off = align_up(k_off + k_bytes, 256), d_bytes = (size_t)n * AFV_DESC_BYTES;
+        HostImage arena{c};
+        arena.resize(d_off + d_bytes, false);
+        uint8_t *hb = arena.data();
+        int rc2 = ensure_match_buffer(c, d_off + d_bytes);
+        if (rc2) return rc2;
+        if ((size_t)stride_bytes == (size_t)width) std::memcpy(hb, gray, frame_bytes);
+        else
+            for (int y = 0; y < height; ++y) std::memcpy(hb + (size_t)y * width, gray + (size_t)y * stride_bytes, (size_t)width);
+        std::memcpy(hb + k_off, kps, k_bytes);
+        if (pitch == (size_t)width) HIPCHK(c, hipMemcpyAsync(c->d_frames, hb, frame_bytes, hipMemcpyHostToDevice, s));
+        else HIPCHK(c, hipMemcpy2DAsync(c->d_frames, pitch, hb, (size_t)width, (size_t)width, (size_t)height, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->d_match + k_off, hb + k_off, k_bytes, hipMemcpyHostToDevice, s));
+        enqueue_range(c, src, 0, 1, nullptr, nullptr, 0, nullptr, nullptr, s, false, nullptr, true);
+        afv_launch_describe_given(c->d_geo, &src, c->d_pyr, reinterpret_cast<const afv_keypoint *>(c->d_match + k_off), n, c->d_match + d_off, 0, s);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(hb + d_off, c->d_match + d_off, d_bytes, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        std::memcpy(desc32, hb + d_off, d_bytes);
+        c->last_src = src;
+        c->last_nframes = 1;
+        return AFV_OK;
+    });
 }
 
 // afv_frame_extract (afv_frame.hip): the same call with a frame attached
@@ -1852,7 +1927,13 @@ int afv_match_projection_core(afv_ctx *c, const afv_proj_job *jobs, int njobs, i
         acc += (size_t)(per_query ? j.nq : j.n);
     }
     if (!zero_copy_in) HIPCHK(c, hipMemcpyAsync(B, H, in_bytes, hipMemcpyHostToDevice, c->stream));
-    if (!dev) afv_launch_frame_grid(reinterpret_cast<const DevGridJob *>(B + gjobs_off), njobs, grid_lds, c->stream);
+    if (!dev) {
+        if (grid_lds > (size_t)c->frame_lds_max) {
+            c->last_error = "projection search: the grid of the feature side does not fit the LDS of one workgroup (cells x features too large)";
+            return AFV_EUNSUPPORTED;
+        }
+        afv_launch_frame_grid(reinterpret_cast<const DevGridJob *>(B + gjobs_off), njobs, grid_lds, c->stream);
+    }
     if (dev && dev->qref_table && !dev->qdesc_dev) {
         const afv_table *qt = dev->qref_table;
         afv_launch_frame_gather(qt->d_desc, qt->d_n, qt->nsets, qt->cap, reinterpret_cast<const int *>(IN + offs[0].qrs),

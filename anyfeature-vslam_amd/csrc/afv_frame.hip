@@ -4,10 +4,23 @@
 // per-feature scale data (keyPtsSize / Sigma2 / Inf, FeatureExtractor.cpp:132-172), the 64 x 48 grid (:225-240) - and what the tracking
 // thread then asks of it - GetFeaturesInArea inside the projection searches (Tracking.cc:747,753,1026), ComputeBoW (:397-401) ahead of
 // SearchByBoW (Tracking.cc:626-629), the copy into a KeyFrame (KeyFrame.cc:36-60) - happens here against arrays that never leave HBM.
+#include <mutex>
+#include <unordered_set>
+
 #include "afv_runtime.h"
+
+// Frames alive in the process.  A Frame of the host commonly outlives the extractor (the tracker's last / initial frames at shutdown,
+// adapter ~DeviceFrame): afv_frame_destroy after afv_destroy must be a no-op, and it can only know by looking the POINTER up - the
+// object, and the context it names, are gone by then (reading f->c there was a use-after-free).
+static std::mutex g_frames_mutex;
+static std::unordered_set<const afv_frame *> g_live_frames;
 
 static void frame_free(afv_frame *f) {
     if (!f) return;
+    {
+        std::lock_guard<std::mutex> lk(g_frames_mutex);
+        g_live_frames.erase(f);
+    }
     if (f->c) (void)hipSetDevice(f->c->device);
     if (f->d_block) (void)hipFree(f->d_block);
     delete f;
@@ -29,6 +42,11 @@ extern "C" int afv_frame_create(afv_ctx *c, const afv_frame_params *params, afv_
     if (!(p.max_x > p.min_x) || !(p.max_y > p.min_y)) return AFV_EINVAL;
     const int cap = p.cap > 0 ? p.cap : c->stage_cap;
     if (cap < 1 || cap > AFV_MAX_SIDE) return AFV_EINVAL;
+    // the grid and the FeatureVector body are each built by ONE workgroup in LDS: what does not fit is refused here, not at the first launch
+    if (afv_frame_grid_lds(p.grid_cols, p.grid_rows, cap) > (size_t)c->frame_lds_max || afv_featvec_build_lds(cap, 1) > (size_t)c->frame_lds_max) {
+        c->last_error = "afv_frame_create: grid_cols x grid_rows x cap does not fit the LDS of one workgroup";
+        return AFV_EUNSUPPORTED;
+    }
     return guarded(c, [&]() -> int {
         HIPCHK(c, hipSetDevice(c->device));
         afv_frame *f = new (std::nothrow) afv_frame();
@@ -75,7 +93,11 @@ extern "C" int afv_frame_create(afv_ctx *c, const afv_frame_params *params, afv_
         f->d_dense = reinterpret_cast<int *>(B + o_dense);
         try {
             c->frames.push_back(f);
+            std::lock_guard<std::mutex> lk(g_frames_mutex);
+            g_live_frames.insert(f);
         } catch (...) {
+            auto it = std::find(c->frames.begin(), c->frames.end(), f);
+            if (it != c->frames.end()) c->frames.erase(it);
             frame_free(f);
             return AFV_ENOMEM;
         }
@@ -86,6 +108,10 @@ extern "C" int afv_frame_create(afv_ctx *c, const afv_frame_params *params, afv_
 
 extern "C" void afv_frame_destroy(afv_frame *f) {
     if (!f) return;
+    {
+        std::lock_guard<std::mutex> lk(g_frames_mutex);
+        if (!g_live_frames.count(f)) return;  // released with its context (afv_destroy): the pointer is dead, nothing of it may be read
+    }
     afv_ctx *c = f->c;
     auto it = std::find(c->frames.begin(), c->frames.end(), f);
     if (it == c->frames.end()) return;  // already released with its context
@@ -123,11 +149,14 @@ static int frame_launch_grid(afv_frame *f, bool soa, bool copy_xy, bool use_tab,
 }
 
 // called by extract_one (afv_api.hip) right after the describe kernel was enqueued with the frame as second destination
-void afv_frame_after_extract(afv_frame *f, hipStream_t s) {
+int afv_frame_after_extract(afv_frame *f, hipStream_t s) {
     f->has_features = true;
     f->has_fv = false;
+    f->has_grid = false;
+    const int rc = frame_launch_grid(f, true, !f->p.distorted, true, true, !f->p.distorted, true, s);
+    if (rc) return rc;
     f->has_grid = !f->p.distorted;
-    (void)frame_launch_grid(f, true, !f->p.distorted, true, true, !f->p.distorted, true, s);
+    return AFV_OK;
 }
 
 extern "C" int afv_frame_extract(afv_frame *f, const uint8_t *gray, int width, int height, int stride_bytes, afv_keypoint *kps, uint8_t *desc32,
@@ -154,9 +183,10 @@ extern "C" int afv_frame_set_features(afv_frame *f, const afv_keypoint *kps, con
         f->n = n;
         f->has_features = true;
         f->has_fv = false;
-        f->has_grid = !f->p.distorted;
+        f->has_grid = false;
         const int rc = frame_launch_grid(f, true, !f->p.distorted, size == nullptr, u_right == nullptr, !f->p.distorted, false, s);
         if (rc) return rc;
+        f->has_grid = !f->p.distorted;
         HIPCHK(c, hipStreamSynchronize(s));  // the sources were pageable: nothing of the caller's may still be in flight
         return AFV_OK;
     });
@@ -243,6 +273,10 @@ extern "C" int afv_frame_bow_transform(afv_frame *f, const afv_vocab *v, int lev
         // sort key of a feature: 0 = the root, 1 + rank of its node among the nodes of depth L - levelsup (k_bow.hip)
         const int nid_level = v->dev.L - levelsup;
         const int width = (nid_level > 0 && (size_t)nid_level < v->depth_width.size()) ? v->depth_width[(size_t)nid_level] + 1 : 1;
+        if (afv_featvec_build_lds(f->cap, width) > (size_t)c->frame_lds_max) {
+            c->last_error = "afv_frame_bow_transform: the node level is too wide for the LDS of one workgroup";
+            return AFV_EUNSUPPORTED;
+        }
         afv_launch_bow_transform(&v->dev, reinterpret_cast<const uint32_t *>(f->d_desc), n, levelsup, f->d_leaf, f->d_nid, f->d_dense, s);
         afv_launch_featvec_build(f->d_leaf, f->d_nid, f->d_dense, n, f->cap, width, v->dev.stopped, f->d_seg_idx, zc ? h_kept : f->d_nkept,
                                  zc ? h_leaf : nullptr, zc ? h_nid : nullptr, zc ? h_dense : nullptr, s);
@@ -377,8 +411,10 @@ extern "C" int afv_frame_match_initialization(afv_frame *f1, afv_frame *f2, cons
     return guarded(c, [&]() -> int {
         HIPCHK(c, hipSetDevice(c->device));
         const int n1 = f1->n;
-        float max_size = afv_size_of_octave(c, 0);
-        for (int o = 1; o < std::max(c->p.nlevels, 1); ++o) max_size = std::max(max_size, afv_size_of_octave(c, o));  // F1.maxKeyPtSize
+        // F1.maxKeyPtSize = featureExtractor->GetMaxKeyPtSize() (Frame.cc:251) = the settings constant scaleFactorOrb^(nOctavesOrb - 1) =
+        // 1.2^7 (FeatureExtractor.cpp:52-54), whatever the detector's own pyramid (the largest size OF THE PYRAMID differs
+        // from it for non-default scale factors / level counts)
+        const float max_size = powf(1.2f, float(8 - 1.0));
         std::vector<float> r((size_t)std::max(n1, 1), window_size), mn((size_t)std::max(n1, 1), 0.0f), mx((size_t)std::max(n1, 1), max_size);
         ProjFeatureSide S;
         S.fdesc = reinterpret_cast<const uint32_t *>(f2->d_desc);

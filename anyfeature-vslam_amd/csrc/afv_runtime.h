@@ -46,6 +46,8 @@ extern "C" void afv_launch_describe(const Geo *geo_dev, int blocks_per_frame, co
                                     const SelPoint *sel, const int *sel_count, afv_keypoint *kps, uint8_t *desc,
                                     int cap_per_frame, int *n_out, int *status, int frame_base, int nframes, const DescribeMirror *mirror,
                                     hipStream_t stream);
+extern "C" void afv_launch_describe_given(const Geo *geo_dev, const FrameSrc *src0, const uint8_t *pyr, const afv_keypoint *given, int n, uint8_t *desc,
+                                          int frame, hipStream_t stream);
 extern "C" void afv_launch_blur_level(const uint8_t *img, int w, int h, int pitch, uint8_t *out, hipStream_t stream);
 
 extern "C" void afv_launch_match_bow(const DevMatchJob *jobs, int njobs, hipStream_t stream);
@@ -70,6 +72,8 @@ extern "C" int afv_select_prepare(int M);
 extern "C" int afv_debug_pass_cap;
 extern "C" size_t afv_project_wg_lds(int kind_init, int n, int nq);
 extern "C" size_t afv_frame_grid_lds(int cols, int rows, int cap);
+extern "C" int afv_frame_prepare(void);
+extern "C" size_t afv_featvec_build_lds(int cap, int width);
 extern "C" void afv_launch_frame_grid(const DevGridJob *jobs, int njobs, size_t lds_bytes, hipStream_t stream);
 extern "C" void afv_launch_frame_grid1(const DevGridJob *job, size_t lds_bytes, hipStream_t stream);
 extern "C" void afv_launch_frame_gather(const uint8_t *table, const int *nset, int nsets, int cap, const int *slot, const int *idx, int nq,
@@ -135,6 +139,7 @@ struct afv_ctx {
     int resolve_wg_max_pairs = 256; // ... 2: calls of at most this many pairs take the fixed point; afv_set_match_resolve
     int proj_engine = 2;           // ordered phase of the projection searches: 0 = ordered walk, 1 = workgroup fixed point, 2 = 1 when it fits
     int proj_wg_lds_max = 0;       // dynamic LDS bytes the workgroup engines may use (0: unavailable); afv_project_prepare at afv_create
+    int frame_lds_max = 0;         // dynamic LDS bytes k_frame_grid / k_featvec_build may use; afv_frame_prepare at afv_create
     int *d_proj_ticket = nullptr;  // hand-off ticket of the one-launch search (k_proj_search1), zero at rest
     int proj_fuse = 1;             // 1: single-job searches rank and resolve in one launch (afv_set_projection_fuse)
     std::vector<afv_frame *> frames;  // frames alive on this context (destroyed with it)
@@ -446,7 +451,7 @@ void afv_shared_segments(const afv_match_job &j, std::vector<Seg> &segs);
 int afv_check_resolve_guard(afv_ctx *c, const int32_t *nmatches, int n);
 void afv_table_release_all(afv_ctx *c);  // afv_destroy: tables / communicators still alive die with their context
 void afv_frame_release_all(afv_ctx *c);  // ... and so do its frames
-void afv_frame_after_extract(afv_frame *f, hipStream_t s);  // afv_frame.hip: k_frame_grid behind the describe kernel of afv_frame_extract
+int afv_frame_after_extract(afv_frame *f, hipStream_t s);  // afv_frame.hip: k_frame_grid behind the describe kernel of afv_frame_extract
 int afv_extract_into_frame(afv_ctx *c, afv_frame *f, const uint8_t *gray, int width, int height, int stride_bytes, afv_keypoint *kps,
                            uint8_t *desc32, int cap, int *n_out);  // afv_api.hip: afv_orb_extract with the frame as second destination
 // the host side of E12 (FeatureExtractor.cpp:132-172): keyPtsSize of octave `o` as afv_orb_size_sigma computes it

@@ -725,7 +725,11 @@ extern "C" int afv_akaze_extract(afv_akaze *a, const uint8_t *gray, int nframes,
     }
     rc = akz_enqueue(a, a->d_gray, nframes, w, h, w, img);
     if (rc) return rc;
-    for (int attempt = 0; attempt < 3; ++attempt) {  // a stalled level pipeline (AFV_ETIMEOUT) is repeated once: the scale space is still there
+    // a stalled level pipeline (AFV_ETIMEOUT) is repeated, twice at most: the scale space is still there.  The re-run through the ordered
+    // rounds after the fixed point gave up is NOT one of those repeats (they shared one budget of three, and a loop that ended on a
+    // `continue` copied the rejected run's results out).
+    bool settled = false;
+    for (int timeouts = 0, fallbacks = 0; timeouts < 3 && fallbacks < 2;) {
         rc = akz_detect_enqueue(a);
         if (rc) return rc;
         rc = akz_describe_enqueue(a);
@@ -739,11 +743,14 @@ extern "C" int afv_akaze_extract(afv_akaze *a, const uint8_t *gray, int nframes,
         if (status == 5) {
             a->last_error = "level pipeline stalled (suppression): the device was preempted or is being profiled; repeat the call";
             rc = AFV_ETIMEOUT;
+            ++timeouts;
             continue;
         }
         if ((status == 6 || status == 7) && a->suppress_mode == 2 && !a->detect_fallback) {
             a->detect_fallback = true;  // the fixed-point engine gave up on this batch: once more through the ordered rounds
+            a->last_error = akz_status_text(status);
             rc = AFV_ECAPACITY;
+            ++fallbacks;
             continue;
         }
         if (status) {
@@ -752,9 +759,13 @@ extern "C" int afv_akaze_extract(afv_akaze *a, const uint8_t *gray, int nframes,
         } else {
             rc = AFV_OK;
         }
+        settled = true;
         break;
     }
-    if (rc != AFV_OK && rc != AFV_ECAPACITY) return rc;
+    if (!settled || (rc != AFV_OK && rc != AFV_ECAPACITY)) {  // no run was accepted: nothing of the arena is a result
+        for (int f = 0; f < nframes; ++f) n_out[f] = 0;
+        return rc;
+    }
     const int *cnt = reinterpret_cast<const int *>(a->h_pin + off_n);
     for (int f = 0; f < nframes; ++f) {
         int n = std::min(std::max(cnt[f], 0), (int)oc);

@@ -186,14 +186,16 @@ __device__ __forceinline__ int blur_at(const uint16_t *H, int x, int y) {
     return (int)blur_round(S);
 }
 
-__global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__restrict__ geo_p, FrameSrc src0,
-                                                                const uint8_t *__restrict__ pyr,
-                                                                const SelPoint *__restrict__ sel,
-                                                                const int *__restrict__ sel_count,
-                                                                afv_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
-                                                                int cap_per_frame, int *__restrict__ n_out,
-                                                                int *__restrict__ status, int frame_base, int per_frame, int total_blocks,
-                                                                DescribeMirror mir) {
+// MODE 0: the extraction pipeline (keypoints of the quadtree survivors + their descriptors: detectAndCompute);
+// MODE 1: keypoints only - position, IC angle, response (afv_orb_detect: detectKeypoints + filterKeypoints, Feature_orb32.cpp:26-40, :63-65);
+// MODE 2: descriptors of CALLER-GIVEN keypoints at their own angle (afv_orb_compute: computeDescriptors = cv::ORB::compute, :42-53):
+//         `given` holds total_blocks * KP_PER_BLOCK >= n keypoints of frame `frame_base`, `cap_per_frame` = n, descriptor i to desc[i]
+template <int MODE>
+__device__ __forceinline__ void describe_body(const Geo *__restrict__ geo_p, const FrameSrc src0, const uint8_t *__restrict__ pyr,
+                                              const SelPoint *__restrict__ sel, const int *__restrict__ sel_count, afv_keypoint *__restrict__ kps,
+                                              uint8_t *__restrict__ desc, int cap_per_frame, int *__restrict__ n_out, int *__restrict__ status,
+                                              int frame_base, int per_frame, int total_blocks, const DescribeMirror mir,
+                                              const afv_keypoint *__restrict__ given) {
     // One LDS slice per wavefront holds BOTH the staged patch (u8, rows PP = 52 bytes apart: 13 dwords, odd -> rows spread over all
     // LDS banks) and the row-filtered plane H (u16, rows 2 HP = 80 bytes apart) that is computed from it: H starts at byte 0, the patch
     // at byte SLICE - PS * PP, and H row r ends at or before patch row r + 1 begins (80 r + 80 <= P_OFF + 52 (r + 1) for r <= 42), so the
@@ -207,46 +209,63 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
     __shared__ __attribute__((aligned(16))) uint8_t s_slice[KP_PER_BLOCK][SLICE];
 
     const Geo &geo = *geo_p;
-    // XCD-aware placement: all keypoints of a frame are described on one XCD (their patches share L2 lines)
-    const int work = afv_xcd_remap(blockIdx.x, total_blocks);
-    if (work >= total_blocks) return;
-    // a frame's blocks: level after level, ceil(sel_cap / KP_PER_BLOCK) blocks each (per_frame in total)
-    const int fl = (int)afv_udiv((uint32_t)work, geo.dv_desc_per_frame);
-    const int blk = work - fl * per_frame;
-    int l = 0;
-#pragma unroll
-    for (int i = 1; i < AFV_MAX_LEVELS; ++i)
-        if (i < geo.nlevels && blk >= geo.lv[i].desc_blk_base) l = i;
-    const LevelGeo &L = geo.lv[l];
-    const int kblk = blk - L.desc_blk_base;
-    const int f = frame_base + fl;
     // the keypoint is a property of the wavefront: said so, its record, its patch origin and every per-keypoint scalar live on the scalar unit
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int idx = kblk * KP_PER_BLOCK + wv;
-
-    // frame-level bookkeeping: counts of the eight levels (scalar loads), this level's first output slot, total
-    const int4 *scp = reinterpret_cast<const int4 *>(sel_count + f * AFV_MAX_LEVELS);
-    const int4 ca_ = scp[0], cb_ = scp[1];
-    const int cnt[AFV_MAX_LEVELS] = {ca_.x, ca_.y, ca_.z, ca_.w, cb_.x, cb_.y, cb_.z, cb_.w};
-    int level_base = 0, total = 0, mine = 0;
+    int l = 0, f, out_idx, cx, cy;
+    float given_angle = 0.f, resp = 0.f;
+    if constexpr (MODE == 2) {
+        // caller-given keypoints: wave i describes keypoint i.  BRIEF centre = cvRound(pt * (1 / scale)) in the keypoint's OWN octave
+        // (orb.cpp computeOrbDescriptors; the host checked 0 <= octave < nlevels)
+        f = frame_base;
+        out_idx = (int)blockIdx.x * KP_PER_BLOCK + wv;
+        if (out_idx >= cap_per_frame) return;  // wave-uniform
+        const afv_keypoint g = given[out_idx];
+        l = __builtin_amdgcn_readfirstlane(g.octave);
+        const float inv = geo.lv[l].inv_scale;
+        cx = __builtin_amdgcn_readfirstlane((int)rintf(g.x * inv));
+        cy = __builtin_amdgcn_readfirstlane((int)rintf(g.y * inv));
+        given_angle = g.angle;
+    } else {
+        // XCD-aware placement: all keypoints of a frame are described on one XCD (their patches share L2 lines)
+        const int work = afv_xcd_remap(blockIdx.x, total_blocks);
+        if (work >= total_blocks) return;
+        // a frame's blocks: level after level, ceil(sel_cap / KP_PER_BLOCK) blocks each (per_frame in total)
+        const int fl = (int)afv_udiv((uint32_t)work, geo.dv_desc_per_frame);
+        const int blk = work - fl * per_frame;
 #pragma unroll
-    for (int i = 0; i < AFV_MAX_LEVELS; ++i) {
-        const int c = i < geo.nlevels ? cnt[i] : 0;
-        level_base += i < l ? c : 0;
-        mine = i == l ? c : mine;
-        total += c;
-    }
-    if (blk == 0 && threadIdx.x == 0) {
-        n_out[f] = min(total, cap_per_frame);
-        if (mir.n) mir.n[f] = min(total, cap_per_frame);
-        if (status && total > cap_per_frame) atomicMin(status, AFV_ECAPACITY);
-    }
-    if (idx >= mine) return;  // wave-uniform
-    const int out_idx = level_base + idx;
-    if (out_idx >= cap_per_frame) return;
+        for (int i = 1; i < AFV_MAX_LEVELS; ++i)
+            if (i < geo.nlevels && blk >= geo.lv[i].desc_blk_base) l = i;
+        const int kblk = blk - geo.lv[l].desc_blk_base;
+        f = frame_base + fl;
+        const int idx = kblk * KP_PER_BLOCK + wv;
 
-    const SelPoint sp = sel[(size_t)f * geo.sel_per_frame + L.sel_base + idx];
-    const int cx = sp.x, cy = sp.y;
+        // frame-level bookkeeping: counts of the eight levels (scalar loads), this level's first output slot, total
+        const int4 *scp = reinterpret_cast<const int4 *>(sel_count + f * AFV_MAX_LEVELS);
+        const int4 ca_ = scp[0], cb_ = scp[1];
+        const int cnt[AFV_MAX_LEVELS] = {ca_.x, ca_.y, ca_.z, ca_.w, cb_.x, cb_.y, cb_.z, cb_.w};
+        int level_base = 0, total = 0, mine = 0;
+#pragma unroll
+        for (int i = 0; i < AFV_MAX_LEVELS; ++i) {
+            const int c = i < geo.nlevels ? cnt[i] : 0;
+            level_base += i < l ? c : 0;
+            mine = i == l ? c : mine;
+            total += c;
+        }
+        if (blk == 0 && threadIdx.x == 0) {
+            n_out[f] = min(total, cap_per_frame);
+            if (mir.n) mir.n[f] = min(total, cap_per_frame);
+            if (status && total > cap_per_frame) atomicMin(status, AFV_ECAPACITY);
+        }
+        if (idx >= mine) return;  // wave-uniform
+        out_idx = level_base + idx;
+        if (out_idx >= cap_per_frame) return;
+
+        const SelPoint sp = sel[(size_t)f * geo.sel_per_frame + geo.lv[l].sel_base + idx];
+        cx = sp.x;
+        cy = sp.y;
+        resp = sp.response;
+    }
+    const LevelGeo &L = geo.lv[l];
     const int lw = L.w, lh = L.h;
     const uint8_t *img;
     int pitch;
@@ -302,7 +321,7 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
 
     // ---- 2. intensity centroid over the radius-15 disc: lane = (row, half) ----
     int m10 = 0, m01 = 0;
-    {
+    if constexpr (MODE != 2) {
         const int v = (lane >> 1) - 15;  // -15..16
         if (v <= 15) {
             // half 0: u in [-d, -1] = bytes j = 16-d .. 15 of the 16 bytes starting at u = -16; half 1: u in [0, d] = bytes
@@ -326,19 +345,37 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
             m01 = v * (int)s1;
         }
     }
-    blur_rows(P, H, lane);  // overwrites the patch (see the slice layout above): everything that reads P comes before this line
-    m10 = wave_sum(m10);
-    m01 = wave_sum(m01);
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    if constexpr (MODE != 1) blur_rows(P, H, lane);  // overwrites the patch (see the slice layout above): everything that reads P comes before this line
+    float angle = given_angle;
+    if constexpr (MODE != 2) {
+        m10 = wave_sum(m10);
+        m01 = wave_sum(m01);
+        angle = fast_atan2_deg((float)m01, (float)m10);
+    }
+    const float ptx = (float)cx * L.scale, pty = (float)cy * L.scale;
+    if constexpr (MODE == 1) {  // keypoints only
+        if (lane == 0) {
+            afv_keypoint k;
+            k.x = ptx;
+            k.y = pty;
+            k.size = 31 * L.scale;
+            k.angle = angle;
+            k.response = resp;
+            k.octave = l;
+            k.class_id = -1;
+            kps[(size_t)f * cap_per_frame + out_idx] = k;
+        }
+        return;
+    }
 
     // ---- 3+4. rotated BRIEF on the blurred patch: lane handles tests lane, lane+64, lane+128, lane+192; the blur is
     // evaluated only where a test samples it (512 of the 1369 patch positions) ----
     float ca, sb;
     sincos_deg(angle, ca, sb);
     wave_sync();  // row-filtered plane complete
-    // BRIEF centre = cvRound(pt * (1/scale)) with pt = level coordinate * scale (orb.cpp computeOrbDescriptors)
-    const float ptx = (float)cx * L.scale, pty = (float)cy * L.scale;
-    const int bx = (int)rintf(ptx * L.inv_scale), by = (int)rintf(pty * L.inv_scale);
+    // BRIEF centre = cvRound(pt * (1/scale)) with pt = level coordinate * scale (orb.cpp computeOrbDescriptors); a given keypoint's
+    // centre IS that rounding already
+    const int bx = MODE == 2 ? cx : (int)rintf(ptx * L.inv_scale), by = MODE == 2 ? cy : (int)rintf(pty * L.inv_scale);
     const int ox = bx - cx, oy = by - cy;  // 0 in practice; kept literal
     const int kox = ox - 0x4B400000, koy = oy - 0x4B400000;  // scalar: the mantissa offset of the rounding trick below and the (0) centre offset
     uint32_t words[8];
@@ -377,7 +414,7 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
         words[2 * g + 1] = (uint32_t)(m >> 32);
     }
     // ---- 5. outputs (E11 merge: ascending level, list order inside a level) ----
-    const size_t o = (size_t)f * cap_per_frame + out_idx;
+    const size_t o = MODE == 2 ? (size_t)out_idx : (size_t)f * cap_per_frame + out_idx;
     if (lane < 8) {
         uint32_t w = words[0];
 #pragma unroll
@@ -386,18 +423,38 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__res
         reinterpret_cast<uint32_t *>(desc + o * 32)[lane] = w;
         if (mir.desc) reinterpret_cast<uint32_t *>(mir.desc + o * 32)[lane] = w;  // afv_frame_extract: the frame's device copy
     }
-    if (lane == 0) {
+    if (MODE == 0 && lane == 0) {
         afv_keypoint k;
         k.x = ptx;
         k.y = pty;
         k.size = 31 * L.scale;
         k.angle = angle;
-        k.response = sp.response;
+        k.response = resp;
         k.octave = l;
         k.class_id = -1;
         kps[o] = k;
         if (mir.kps) mir.kps[o] = k;
     }
+}
+
+__global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const Geo *__restrict__ geo_p, FrameSrc src0, const uint8_t *__restrict__ pyr,
+                                                                const SelPoint *__restrict__ sel, const int *__restrict__ sel_count,
+                                                                afv_keypoint *__restrict__ kps, uint8_t *__restrict__ desc, int cap_per_frame,
+                                                                int *__restrict__ n_out, int *__restrict__ status, int frame_base, int per_frame,
+                                                                int total_blocks, DescribeMirror mir) {
+    describe_body<0>(geo_p, src0, pyr, sel, sel_count, kps, desc, cap_per_frame, n_out, status, frame_base, per_frame, total_blocks, mir, nullptr);
+}
+__global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe_angles(const Geo *__restrict__ geo_p, FrameSrc src0, const uint8_t *__restrict__ pyr,
+                                                                       const SelPoint *__restrict__ sel, const int *__restrict__ sel_count,
+                                                                       afv_keypoint *__restrict__ kps, int cap_per_frame, int *__restrict__ n_out,
+                                                                       int *__restrict__ status, int frame_base, int per_frame, int total_blocks) {
+    describe_body<1>(geo_p, src0, pyr, sel, sel_count, kps, nullptr, cap_per_frame, n_out, status, frame_base, per_frame, total_blocks,
+                     DescribeMirror{nullptr, nullptr, nullptr}, nullptr);
+}
+__global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe_given(const Geo *__restrict__ geo_p, FrameSrc src0, const uint8_t *__restrict__ pyr,
+                                                                      const afv_keypoint *__restrict__ given, int n, uint8_t *__restrict__ desc,
+                                                                      int frame) {
+    describe_body<2>(geo_p, src0, pyr, nullptr, nullptr, nullptr, desc, n, nullptr, nullptr, frame, 0, 0, DescribeMirror{nullptr, nullptr, nullptr}, given);
 }
 
 extern "C" int afv_describe_blocks_per_frame(const Geo *g) {
@@ -406,15 +463,29 @@ extern "C" int afv_describe_blocks_per_frame(const Geo *g) {
     return n;
 }
 
+// `desc` == nullptr: keypoints only (afv_orb_detect)
 extern "C" void afv_launch_describe(const Geo *geo_dev, int blocks_per_frame, const FrameSrc *src0, const uint8_t *pyr,
                                     const SelPoint *sel, const int *sel_count, afv_keypoint *kps, uint8_t *desc,
                                     int cap_per_frame, int *n_out, int *status, int frame_base, int nframes, const DescribeMirror *mirror,
                                     hipStream_t stream) {
     const int total = blocks_per_frame * nframes;
     dim3 grid((total + 7) / 8 * 8);
+    if (!desc) {
+        hipLaunchKernelGGL(k_describe_angles, grid, dim3(64 * KP_PER_BLOCK), 0, stream, geo_dev, *src0, pyr, sel, sel_count, kps, cap_per_frame, n_out,
+                           status, frame_base, blocks_per_frame, total);
+        return;
+    }
     const DescribeMirror mir = mirror ? *mirror : DescribeMirror{nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(k_describe, grid, dim3(64 * KP_PER_BLOCK), 0, stream, geo_dev, *src0, pyr, sel, sel_count, kps, desc,
                        cap_per_frame, n_out, status, frame_base, blocks_per_frame, total, mir);
+}
+
+// descriptors of n caller-given keypoints (device array) on the pyramid of frame `frame`
+extern "C" void afv_launch_describe_given(const Geo *geo_dev, const FrameSrc *src0, const uint8_t *pyr, const afv_keypoint *given, int n, uint8_t *desc,
+                                          int frame, hipStream_t stream) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_describe_given, dim3((n + KP_PER_BLOCK - 1) / KP_PER_BLOCK), dim3(64 * KP_PER_BLOCK), 0, stream, geo_dev, *src0, pyr, given, n, desc,
+                       frame);
 }
 
 // ---------------- standalone E9: blur one level of one frame (debug / parity of the blur arithmetic) ----------------

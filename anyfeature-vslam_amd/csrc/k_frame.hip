@@ -340,10 +340,24 @@ extern "C" __global__ __launch_bounds__(FG_T) void k_featvec_build(const int *__
     if (tid == 0) *n_kept = s_kept;
 }
 
+// once per context (afv_create): a 64 x 48 grid with 2000 features already asks for more than the 64 KB of dynamic LDS a kernel gets by
+// default.  Returns the bytes a launch may ask for (without this the launch failed and the grid stayed the zeroed memset).
+extern "C" int afv_frame_prepare(void) {
+    const int want = 150 * 1024;
+    bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_frame_grid), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
+    ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_frame_grid1), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess && ok;
+    ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_featvec_build), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess && ok;
+    if (!ok) (void)hipGetLastError();
+    return ok ? want - 1024 : 63 * 1024;  // (the kernels' static arrays take a few hundred bytes)
+}
+extern "C" size_t afv_featvec_build_lds(int cap, int width) {
+    const size_t cap8 = ((size_t)cap + 7) & ~(size_t)7;
+    return width <= FG_TAB_MAX ? (((size_t)width + 1) * 4 + 15) / 16 * 16 + cap8 * 2 + (size_t)width * 16 + 16 : cap8 * 4 + 16;
+}
+
 extern "C" void afv_launch_featvec_build(const int *leaf, const int *nid, const int *dense, int n, int cap, int width, const uint8_t *stopped,
                                          int *seg_idx, int *n_kept, int *h_leaf, int *h_nid, int *h_dense, hipStream_t stream) {
-    const size_t cap8 = ((size_t)cap + 7) & ~(size_t)7;
-    const size_t lds = width <= FG_TAB_MAX ? (((size_t)width + 1) * 4 + 15) / 16 * 16 + cap8 * 2 + (size_t)width * 16 + 16 : cap8 * 4 + 16;
+    const size_t lds = afv_featvec_build_lds(cap, width);
     hipLaunchKernelGGL(k_featvec_build, dim3(1), dim3(FG_T), lds, stream, leaf, nid, dense, n, cap, width, stopped, seg_idx, n_kept, h_leaf, h_nid,
                        h_dense);
 }

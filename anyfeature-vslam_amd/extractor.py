@@ -112,6 +112,25 @@ class Context:
         self.check(rc, "afv_orb_extract")
         return kps[:n.value].copy(), desc[:n.value].copy()
 
+    def detect(self, gray, cap=None):
+        """afv_orb_detect: detectKeypoints + filterKeypoints (Feature_orb32.cpp:26-40, :63-65): the keypoints afv_orb_extract returns, no descriptors"""
+        gray = np.ascontiguousarray(gray, np.uint8)
+        h, w = gray.shape
+        cap = cap or self.cap
+        kps = np.zeros(cap, KP_DTYPE)
+        n = C.c_int(0)
+        self.check(self.lib.afv_orb_detect(self.handle, ptr(gray), w, h, gray.strides[0], ptr(kps), cap, C.byref(n)), "afv_orb_detect")
+        return kps[:n.value].copy()
+
+    def compute(self, gray, kps):
+        """afv_orb_compute: computeDescriptors = cv::ORB::compute at the given keypoints (Feature_orb32.cpp:42-53)"""
+        gray = np.ascontiguousarray(gray, np.uint8)
+        h, w = gray.shape
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        desc = np.zeros((len(kps), 32), np.uint8)
+        self.check(self.lib.afv_orb_compute(self.handle, ptr(gray), w, h, gray.strides[0], ptr(kps), len(kps), ptr(desc)), "afv_orb_compute")
+        return desc
+
     def extract_batch(self, frames, cap=None):
         frames = [np.ascontiguousarray(f, np.uint8) for f in frames]
         h, w = frames[0].shape
@@ -283,6 +302,28 @@ class FeatureExtractor_orb32:
     def automaticTuning(self, img):  # FeatureExtractor.cpp:195-274: detectTh = th0, then disables itself
         self.settings.detectTh = self.settings.GetDetectorNominalThreshold()
         self.settings.ON_automaticTuning = False
+
+    # the three virtuals detectAndCompute is made of (FeatureExtractor.h:123-128): a host may call them one by one
+    def detectKeypoints(self, gray):
+        """-> {level: keypoints}; the quadtree (filterKeypoints) already ran on the device, see filterKeypoints"""
+        kps = self.ctx.detect(gray)
+        return {int(l): kps[kps["octave"] == l] for l in np.unique(kps["octave"])}
+
+    def filterKeypoints(self, keypoints_level, gray=None, mask=None):
+        """DistributeOctTree per level (Feature_orb32.cpp:63-65): done inside afv_orb_detect - the device never hands the 10x candidate set
+        of cv::ORB::detect to the host - so this is the identity on detectKeypoints' output"""
+        return keypoints_level
+
+    def computeDescriptors(self, keypoints_level, gray):
+        """-> {level: descriptors} (one cv::ORB::compute per level in the reference, Feature_orb32.cpp:49-50; one call here)"""
+        levels = sorted(keypoints_level)
+        allk = np.concatenate([keypoints_level[l] for l in levels]) if levels else np.zeros(0, KP_DTYPE)
+        desc = self.ctx.compute(gray, allk)
+        out, o = {}, 0
+        for l in levels:
+            out[l] = desc[o:o + len(keypoints_level[l])]
+            o += len(keypoints_level[l])
+        return out
 
     def detectAndCompute(self, gray):
         if gray is None or gray.size == 0:  # ORBextractor.cc:570-571: empty image -> outputs untouched

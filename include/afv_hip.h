@@ -45,6 +45,14 @@ enum {
                             about the inputs is wrong - the call can be repeated (afv_akaze_extract does so once by itself) */
 };
 
+/* ABI revision of this header.  It goes up whenever a record, an argument list or a limit changes incompatibly; a host built against
+ * another revision must not call into the library (check once: afv_abi_version() == AFV_ABI_VERSION).
+ *   5  (round 5) afv_proj_job / afv_tri_job / afv_table_tri_job start with struct_size; frame grids hold at most 8192 cells (was 65536)
+ *   6  (round 6) afv_orb_detect / afv_orb_compute; afv_frame_params.desc_bytes; grids / frames whose one-workgroup build does not fit the
+ *      LDS are refused with AFV_EUNSUPPORTED at creation instead of failing at the first launch */
+#define AFV_ABI_VERSION 6
+int afv_abi_version(void);
+
 typedef struct afv_ctx afv_ctx;
 
 /* bit-compatible with cv::KeyPoint {Point2f pt; float size, angle, response; int octave, class_id;} */
@@ -75,6 +83,20 @@ void *afv_stream(afv_ctx *ctx); /* the context's hipStream_t (for callers that e
 /* ---- extraction: host-buffer plugin path (one frame; synchronous) ---- */
 int afv_orb_extract(afv_ctx *ctx, const uint8_t *gray, int width, int height, int stride_bytes,
                     afv_keypoint *kps, uint8_t *desc32, int cap, int *n_out);
+
+/* ---- the two halves of the plugin call on their own (FeatureExtractor::detectKeypoints / computeDescriptors, include/FeatureExtractor.h:123-124,
+ * src/Feature_orb32.cpp:26-53): a host that calls the virtuals separately - a vocabulary builder that keeps keypoints and recomputes
+ * descriptors at them - binds to these.  afv_orb_detect followed by afv_orb_compute on its keypoints gives afv_orb_extract's outputs bit for bit.
+ *   afv_orb_detect   detectKeypoints + filterKeypoints: cv::ORB::detect (FAST + NMS, retainBest x 2, Harris response, IC angle, pt scaled to
+ *                    level 0; Feature_orb32.cpp:26-40) and DistributeOctTree per level (:63-65, FeatureExtractor.cpp:276-284), merged in
+ *                    ascending level order: keypoints with angle and response, no descriptors.
+ *   afv_orb_compute  computeDescriptors: cv::ORB::compute (:42-53) for n caller-given keypoints - each described in its own octave at
+ *                    cvRound(pt / scale) with its own angle, on the pyramid rebuilt from `gray` (cv::ORB::compute rebuilds levels 0 .. max
+ *                    octave of its keypoints).  desc32[n][32] in the order of kps.  Keypoints whose octave is not a level of the context
+ *                    or whose centre falls off their level image: AFV_EINVAL, nothing is written. */
+int afv_orb_detect(afv_ctx *ctx, const uint8_t *gray, int width, int height, int stride_bytes, afv_keypoint *kps, int cap, int *n_out);
+int afv_orb_compute(afv_ctx *ctx, const uint8_t *gray, int width, int height, int stride_bytes, const afv_keypoint *kps, int n,
+                    uint8_t *desc32);
 
 /* ---- extraction: host-buffer batch (vocabulary builder shape, createVocabulary.cpp:161-174).  frames[f] = row-major gray image
  * with stride_bytes between rows; outputs kps[nframes][cap_per_frame], desc32[nframes][cap_per_frame][32], n_out[nframes].

@@ -851,6 +851,33 @@ int afvo_orb_extract(const afvo_params *p, const u8 *gray, int w, int h, int str
     return 0;
 }
 
+/* computeDescriptors on its own (Feature_orb32.cpp:42-53: orb32_extractor->compute(img.grayImg, keypoints, descriptors_level[level])):
+ * cv::ORB::compute = detectAndCompute(..., useProvidedKeypoints = true) - levels 0 .. (octave of the keypoints) are rebuilt from the image and
+ * blurred, every keypoint is described at cvRound(pt * (1 / scale)) of its own octave with the angle it carries (orb.cpp computeOrbDescriptors);
+ * KeyPointsFilter::runByImageBorder with edgeThreshold 0 (Feature_orb32.cpp:23) removes nothing.  desc32[n][32] in the order of kps.
+ * Returns -1 for a keypoint whose octave is not a level or whose centre lies off its level image (the sampling would leave the apron). */
+int afvo_orb_compute(const afvo_params *p, const u8 *gray, int w, int h, int stride, const afvo_keypoint *kps, int n, u8 *desc32) {
+    const int nl = p->nlevels;
+    if (nl < 1 || nl > AFVO_MAX_LEVELS) return -1;
+    int lw[AFVO_MAX_LEVELS], lh[AFVO_MAX_LEVELS];
+    float ls[AFVO_MAX_LEVELS];
+    afvo_level_geometry(w, h, nl, p->scale_factor, lw, lh, ls);
+    u8 *bb[AFVO_MAX_LEVELS];
+    memset(bb, 0, sizeof(bb));
+    int rc = 0;
+    for (int i = 0; i < n && rc == 0; ++i) {
+        const int L = kps[i].octave;
+        if (L < 0 || L >= nl) { rc = -1; break; }
+        const float inv = 1.f / ls[L];
+        const int cx = cv_round_f(kps[i].x * inv), cy = cv_round_f(kps[i].y * inv);
+        if (cx < 0 || cx > lw[L] || cy < 0 || cy > lh[L]) { rc = -1; break; }
+        if (!bb[L]) bb[L] = faithful_compute_level(gray, w, h, stride, lw, lh, L);
+        afvo_brief_descriptor(bb[L], lw[L] + 2 * AFVO_BORDER, cx, cy, kps[i].angle, desc32 + (size_t)i * 32);
+    }
+    for (int l = 0; l < nl; ++l) free(bb[l]);
+    return rc;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * Matching
  * ---------------------------------------------------------------------------------------------- */

@@ -89,6 +89,8 @@ int afvo_quadtree(const float *px, const float *py, const float *resp, const int
    (1 detect pyramid + 8 compute() calls that rebuild and blur levels 0..L).  Same outputs. */
 int afvo_orb_extract(const afvo_params *p, const uint8_t *gray, int w, int h, int stride, int variant,
                      afvo_keypoint *kps, uint8_t *desc32, int cap, int *n_out);
+/* computeDescriptors alone (Feature_orb32.cpp:42-53 = cv::ORB::compute at caller-given keypoints) */
+int afvo_orb_compute(const afvo_params *p, const uint8_t *gray, int w, int h, int stride, const afvo_keypoint *kps, int n, uint8_t *desc32);
 /* intermediate products for stage-level parity tests */
 typedef struct {
     int nlevels;

@@ -278,6 +278,19 @@ def orb_extract(gray, params=None, variant=0, cap=None):
     return kps[:n.value].copy(), desc[:n.value].copy()
 
 
+def orb_compute(gray, kps, params=None):
+    """computeDescriptors alone: cv::ORB::compute at the given keypoints (Feature_orb32.cpp:42-53)"""
+    gray = _u8(gray)
+    h, w = gray.shape
+    params = params or default_params()
+    kps = np.ascontiguousarray(kps, KP_DTYPE)
+    desc = np.zeros((len(kps), 32), np.uint8)
+    rc = lib().afvo_orb_compute(C.byref(params), _p(gray), w, h, w, _p(kps), len(kps), _p(desc))
+    if rc != 0:
+        raise RuntimeError("afvo_orb_compute rc=%d" % rc)
+    return desc
+
+
 def orb_extract_trace(gray, params=None, cap=None):
     """Returns (kps, desc, trace dict with levels / blurred / candidates / keep masks / per-level counts)."""
     gray = _u8(gray)

@@ -159,6 +159,75 @@ def test_extract_end_to_end_bit_exact(gpu_ctx, oracle, frames, name):
     assert np.array_equal(desc, odesc)
 
 
+def _perturbed_keypoints(afv, k, seed):
+    """keypoints a vocabulary builder might hand back: sub-pixel positions, arbitrary angles, octaves reassigned, order shuffled"""
+    s = afv.synth
+    n = len(k)
+    r = s.lcg_states(seed, 4 * n).reshape(4, n)
+    out = k.copy()
+    out["x"] = k["x"] + ((r[0] % 2001).astype(np.float32) - np.float32(1000)) * np.float32(0.0013)
+    out["y"] = k["y"] + ((r[1] % 2001).astype(np.float32) - np.float32(1000)) * np.float32(0.0013)
+    out["angle"] = (r[2] % 360000).astype(np.float32) * np.float32(0.001)
+    oct2 = (k["octave"] + (r[3] % 3).astype(np.int32) - 1).clip(0, 7)
+    out["octave"] = oct2
+    return out[np.argsort(r[3] % 9973, kind="stable")]
+
+
+@pytest.mark.parametrize("name", ["corners1", "corners7", "noise"])
+def test_detect_then_compute_is_extract(gpu_ctx, oracle, frames, name):
+    """the split entry points (FeatureExtractor.h:123-124, Feature_orb32.cpp:26-53): afv_orb_detect gives extract's keypoints byte for byte,
+    afv_orb_compute at them gives extract's descriptors"""
+    img = frames[name]
+    k, d = gpu_ctx.extract(img)
+    kd = gpu_ctx.detect(img)
+    assert kd.tobytes() == k.tobytes()
+    assert np.array_equal(gpu_ctx.compute(img, kd), d)
+    wk, wd = oracle.orb_extract(img)
+    assert kd.tobytes() == wk.tobytes() and np.array_equal(oracle.orb_compute(img, wk), wd)
+
+
+@pytest.mark.parametrize("name", ["corners1", "noise"])
+def test_compute_at_caller_given_keypoints(gpu_ctx, oracle, frames, afv, name):
+    """cv::ORB::compute semantics: every keypoint described in ITS octave at cvRound(pt / scale) with ITS angle, in the caller's order
+    (keypoints moved by up to 1.3 px, re-angled, pushed one octave up or down, shuffled) - against the oracle's restatement"""
+    img = frames[name]
+    k, _ = gpu_ctx.extract(img)
+    for seed in (5, 6):
+        q = _perturbed_keypoints(afv, k, seed)
+        assert np.array_equal(gpu_ctx.compute(img, q), oracle.orb_compute(img, q))
+    # keypoints at the very edge of their level (centre on the last row / column and one beyond: the patch is all apron on one side)
+    e = k[:6].copy()
+    e["octave"] = [0, 0, 3, 3, 7, 7]
+    e["x"] = [0.0, 639.6, 0.2, 639.0, 1.0, 636.0]
+    e["y"] = [0.0, 479.6, 479.0, 0.3, 478.0, 2.0]
+    assert np.array_equal(gpu_ctx.compute(img, e), oracle.orb_compute(img, e))
+    assert len(gpu_ctx.compute(img, k[:0])) == 0
+
+
+def test_compute_refuses_keypoints_it_cannot_describe(gpu_ctx, frames, afv):
+    img = frames["corners1"]
+    k, _ = gpu_ctx.extract(img)
+    for field, value in (("octave", 8), ("octave", -1), ("x", 700.0), ("y", -3.0), ("x", np.nan)):
+        bad = k[:4].copy()
+        bad[field][2] = value
+        with pytest.raises(afv._lib.AfvError):
+            gpu_ctx.compute(img, bad)
+
+
+def test_plugin_virtuals_one_by_one(afv, oracle):
+    """detectKeypoints -> filterKeypoints -> computeDescriptors -> merge, as detectAndCompute composes them (Feature_orb32.cpp:11-18)"""
+    ext = afv.FeatureExtractor_orb32(1000)
+    img = afv.synth.corners_frame(3)
+    kl = ext.filterKeypoints(ext.detectKeypoints(img))
+    dl = ext.computeDescriptors(kl, img)
+    k = np.concatenate([kl[l] for l in sorted(kl)])
+    d = np.concatenate([dl[l] for l in sorted(dl)])
+    wk, wd = oracle.orb_extract(img)
+    assert k.tobytes() == wk.tobytes() and np.array_equal(d, wd)
+    k2, d2 = ext.detectAndCompute(img)
+    assert k2.tobytes() == k.tobytes() and np.array_equal(d2, d)
+
+
 def test_extract_1280x720_two_roots(gpu_ctx, oracle, afv):
     """1280x720: DistributeOctTree starts from nIni = round(1280/720) = 2 root cells"""
     img = afv.synth.corners_frame(11, 1280, 720)

@@ -297,6 +297,25 @@ def test_extract_variants_agree(oracle, afv):
     assert k0.tobytes() == k1.tobytes() and np.array_equal(d0, d1) and len(k0) > 300
 
 
+def test_compute_alone_reproduces_extract(oracle, afv):
+    """afvo_orb_compute (cv::ORB::compute at given keypoints, Feature_orb32.cpp:42-53) on extract's own keypoints gives extract's
+    descriptors; a keypoint moved into another octave is described THERE; off-level keypoints are refused"""
+    img = afv.synth.corners_frame(2)
+    k, d = oracle.orb_extract(img)
+    assert np.array_equal(oracle.orb_compute(img, k), d)
+    assert np.array_equal(oracle.orb_compute(img, k[::-1]), d[::-1])
+    q = k[:1].copy()
+    q["octave"] = 2
+    tr = oracle.orb_extract_trace(img)[2]
+    cx, cy = int(np.rint(q["x"][0] / np.float32(1.44))), int(np.rint(q["y"][0] / np.float32(1.44)))
+    assert 0 <= cx < tr["lw"][2] and 0 <= cy < tr["lh"][2]
+    assert not np.array_equal(oracle.orb_compute(img, q), d[:1])
+    bad = k[:1].copy()
+    bad["x"] = 2000.0
+    with pytest.raises(RuntimeError):
+        oracle.orb_compute(img, bad)
+
+
 def test_extract_structure(oracle, afv):
     img = afv.synth.corners_frame(1)
     kps, desc, tr = oracle.orb_extract_trace(img)
