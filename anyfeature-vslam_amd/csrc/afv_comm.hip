@@ -590,6 +590,7 @@ extern "C" int afv_table_match_bow_frame_h(afv_table *t, const int32_t *slots, i
                                            int check_orientation, int32_t *match_f, int32_t *nmatches) {
     if (!t || !slots || nslots < 1 || !f || !nmatches) return AFV_EINVAL;
     if (f->c != t->c || !f->has_features || !f->has_fv) return AFV_EINVAL;  // afv_frame_bow_transform first
+    if (f->desc_bytes != AFV_DESC_BYTES) return AFV_EUNSUPPORTED;           // the table holds 32-byte rows
     afv_frame_view view{};
     view.n = f->n;
     return guarded(t->c, [&] { return table_match_bow_frame_impl(t, slots, nslots, &view, th_low, nnratio, check_orientation, match_f, nmatches, f); });
@@ -599,6 +600,7 @@ extern "C" int afv_table_match_bow_frame_h(afv_table *t, const int32_t *slots, i
 // table planes; the FeatureVector's node structure goes host to host
 extern "C" int afv_table_set_from_frame(afv_table *t, int slot, afv_frame *f) {
     if (!t || !f || slot < 0 || slot >= t->nsets || f->c != t->c || !f->has_features) return AFV_EINVAL;
+    if (f->desc_bytes != AFV_DESC_BYTES) return AFV_EUNSUPPORTED;  // the table holds 32-byte rows
     if (f->n > t->cap) return AFV_ECAPACITY;
     afv_ctx *c = t->c;
     return guarded(c, [&]() -> int {

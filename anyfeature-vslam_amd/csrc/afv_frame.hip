@@ -40,6 +40,9 @@ extern "C" int afv_frame_create(afv_ctx *c, const afv_frame_params *params, afv_
     std::memcpy(&p, params, std::min<size_t>(params->struct_size, sizeof(p)));
     if (p.grid_cols < 1 || p.grid_rows < 1 || (long)p.grid_cols * p.grid_rows > 8192) return AFV_EINVAL;
     if (!(p.max_x > p.min_x) || !(p.max_y > p.min_y)) return AFV_EINVAL;
+    const int desc_bytes = p.desc_bytes == 0 ? AFV_DESC_BYTES : p.desc_bytes;  // (callers of the round-5 layout: the field reads 0)
+    if (desc_bytes < 1 || desc_bytes > 64) return AFV_EINVAL;
+    const int words = desc_bytes <= 32 ? 8 : 16;
     const int cap = p.cap > 0 ? p.cap : c->stage_cap;
     if (cap < 1 || cap > AFV_MAX_SIDE) return AFV_EINVAL;
     // the grid and the FeatureVector body are each built by ONE workgroup in LDS: what does not fit is refused here, not at the first launch
@@ -54,6 +57,8 @@ extern "C" int afv_frame_create(afv_ctx *c, const afv_frame_params *params, afv_
         f->c = c;
         f->p = p;
         f->cap = cap;
+        f->desc_bytes = desc_bytes;
+        f->words = words;
         // Frame.cc:201-202: mfGridElementWidthInv = FRAME_GRID_COLS / (mnMaxX - mnMinX), same for the height (float arithmetic)
         f->inv_w = static_cast<float>(p.grid_cols) / static_cast<float>(p.max_x - p.min_x);
         f->inv_h = static_cast<float>(p.grid_rows) / static_cast<float>(p.max_y - p.min_y);
@@ -64,7 +69,7 @@ extern "C" int afv_frame_create(afv_ctx *c, const afv_frame_params *params, afv_
             off = align_up(off + bytes, 256);
             return o;
         };
-        const size_t o_kps = take((size_t)cap * sizeof(afv_keypoint)), o_desc = take((size_t)cap * 32);
+        const size_t o_kps = take((size_t)cap * sizeof(afv_keypoint)), o_desc = take((size_t)cap * words * 4);
         size_t o_f[7];
         for (size_t &o : o_f) o = take((size_t)cap * 4);
         const size_t o_n = take(16), o_cptr = take((ncell + 1) * 4), o_cent = take((size_t)cap * 16);
@@ -163,6 +168,7 @@ extern "C" int afv_frame_extract(afv_frame *f, const uint8_t *gray, int width, i
                                  int cap, int *n_out) {
     if (!f || !gray || stride_bytes < width) return AFV_EINVAL;
     if ((kps || desc32) && (!kps || !desc32 || !n_out || cap < 1)) return AFV_EINVAL;
+    if (f->desc_bytes != AFV_DESC_BYTES) return AFV_EUNSUPPORTED;  // this is the ORB32 extractor
     return afv_extract_into_frame(f->c, f, gray, width, height, stride_bytes, kps, desc32, kps ? cap : 0x7fffffff, n_out);
 }
 
@@ -175,7 +181,19 @@ extern "C" int afv_frame_set_features(afv_frame *f, const afv_keypoint *kps, con
         // pageable sources: hipMemcpyAsync stages them before it returns (the caller's arrays may die after the call)
         if (n) {
             HIPCHK(c, hipMemcpyAsync(f->d_kps, kps, (size_t)n * sizeof(afv_keypoint), hipMemcpyHostToDevice, s));
-            HIPCHK(c, hipMemcpyAsync(f->d_desc, desc32, (size_t)n * 32, hipMemcpyHostToDevice, s));
+            const size_t row = (size_t)f->words * 4;
+            if ((size_t)f->desc_bytes == row) {
+                HIPCHK(c, hipMemcpyAsync(f->d_desc, desc32, (size_t)n * row, hipMemcpyHostToDevice, s));
+            } else {  // rows of desc_bytes -> zero-padded device rows (the distance over the padded dwords is the distance over the bytes)
+                HostImage arena{c};
+                arena.resize((size_t)n * row, false);
+                uint8_t *hb = arena.data();
+                for (int i = 0; i < n; ++i) {
+                    std::memcpy(hb + (size_t)i * row, desc32 + (size_t)i * f->desc_bytes, (size_t)f->desc_bytes);
+                    std::memset(hb + (size_t)i * row + f->desc_bytes, 0, row - (size_t)f->desc_bytes);
+                }
+                HIPCHK(c, hipMemcpyAsync(f->d_desc, hb, (size_t)n * row, hipMemcpyHostToDevice, s));
+            }
             if (size) HIPCHK(c, hipMemcpyAsync(f->d_size, size, (size_t)n * 4, hipMemcpyHostToDevice, s));
             if (u_right) HIPCHK(c, hipMemcpyAsync(f->d_ur, u_right, (size_t)n * 4, hipMemcpyHostToDevice, s));
         }
@@ -248,7 +266,7 @@ extern "C" int afv_frame_get_grid(afv_frame *f, int32_t *cell_ptr, int32_t *cell
 // ---- Frame::ComputeBoW ----
 extern "C" int afv_frame_bow_transform(afv_frame *f, const afv_vocab *v, int levelsup, int32_t *leaf_node, int32_t *node_at_level, int32_t *nnodes_out) {
     if (!f || !v || !f->has_features) return AFV_EINVAL;
-    if (v->dev.words != 8) return AFV_EUNSUPPORTED;  // the frame holds 32-byte descriptors
+    if (v->dev.words != f->words || v->desc_bytes != f->desc_bytes) return AFV_EUNSUPPORTED;  // a vocabulary of another descriptor size
     afv_ctx *c = f->c;
     return guarded(c, [&]() -> int {
         HIPCHK(c, hipSetDevice(c->device));
@@ -341,7 +359,7 @@ extern "C" int afv_frame_get_featvec(afv_frame *f, int32_t *node_id, int32_t *se
 static void frame_side(const afv_frame *f, ProjFeatureSide &S) {
     S.fdesc = reinterpret_cast<const uint32_t *>(f->d_desc);
     S.n = f->n;
-    S.words = 8;
+    S.words = f->words;
     S.x = f->d_x; S.y = f->d_y; S.size = f->d_size; S.angle = f->d_angle; S.inf = f->d_inf; S.u_right = f->d_ur;
     S.cell_ptr = f->d_cell_ptr;
     S.cell_ent = f->d_cell_ent;
@@ -351,7 +369,7 @@ static int frame_proj_job(const afv_frame *f, const afv_proj_queries &q, afv_pro
     j = afv_proj_job{};
     j.struct_size = sizeof(afv_proj_job);
     j.n = f->n;
-    j.desc_bytes = 32;
+    j.desc_bytes = f->desc_bytes;
     j.min_x = f->p.min_x; j.min_y = f->p.min_y; j.grid_inv_w = f->inv_w; j.grid_inv_h = f->inv_h;
     j.grid_cols = f->p.grid_cols; j.grid_rows = f->p.grid_rows;
     j.occupied = q.occupied;
@@ -377,7 +395,8 @@ static int frame_match(afv_frame *f, const afv_proj_queries *caller_q, int kind,
         afv_proj_queries q{};
         std::memcpy(&q, caller_q, std::min<size_t>(ss, sizeof(q)));
         if (q.nq < 0 || q.nq > 65535) return AFV_EINVAL;
-        if (q.nq > 0 && q.desc_bytes != 32 && !q.qref_table) return AFV_EINVAL;
+        if (q.nq > 0 && q.desc_bytes != f->desc_bytes && !q.qref_table) return AFV_EINVAL;
+        if (q.qref_table && f->desc_bytes != AFV_DESC_BYTES) return AFV_EUNSUPPORTED;  // the keyframe table holds 32-byte rows
         ProjFeatureSide S;
         frame_side(f, S);
         if (kind == AFV_KIND_FUSE && !use_inf_gate) S.inf = nullptr;
@@ -404,7 +423,7 @@ extern "C" int afv_frame_match_fuse(afv_frame *f, const afv_proj_queries *q, int
 // F1's device arrays; vbPrevMatched and three constant per-query arrays (window radius, size band 0 .. F1.maxKeyPtSize) are all that travels.
 extern "C" int afv_frame_match_initialization(afv_frame *f1, afv_frame *f2, const float *prev_x, const float *prev_y, float window_size, float th_low,
                                               float nnratio, int check_orientation, int32_t *match12, int32_t *nmatches) {
-    if (!f1 || !f2 || !match12 || !nmatches || f1->c != f2->c) return AFV_EINVAL;
+    if (!f1 || !f2 || !match12 || !nmatches || f1->c != f2->c || f1->desc_bytes != f2->desc_bytes) return AFV_EINVAL;
     if (!f1->has_features || !f2->has_features || !f2->has_grid) return AFV_EINVAL;
     if (f1->n > 0 && (!prev_x || !prev_y)) return AFV_EINVAL;
     afv_ctx *c = f1->c;
@@ -419,7 +438,7 @@ extern "C" int afv_frame_match_initialization(afv_frame *f1, afv_frame *f2, cons
         ProjFeatureSide S;
         S.fdesc = reinterpret_cast<const uint32_t *>(f2->d_desc);
         S.n = f2->n;
-        S.words = 8;
+        S.words = f2->words;
         S.x = f2->d_x; S.y = f2->d_y; S.size = f2->d_size; S.angle = f2->d_angle;
         S.cell_ptr = f2->d_cell_ptr; S.cell_ent = f2->d_cell_ent;
         S.qdesc_dev = reinterpret_cast<const uint32_t *>(f1->d_desc);
@@ -428,7 +447,7 @@ extern "C" int afv_frame_match_initialization(afv_frame *f1, afv_frame *f2, cons
         afv_proj_job j{};
         j.struct_size = sizeof(afv_proj_job);
         j.n = f2->n;
-        j.desc_bytes = 32;
+        j.desc_bytes = f2->desc_bytes;
         j.min_x = f2->p.min_x; j.min_y = f2->p.min_y; j.grid_inv_w = f2->inv_w; j.grid_inv_h = f2->inv_h;
         j.grid_cols = f2->p.grid_cols; j.grid_rows = f2->p.grid_rows;
         j.nq = n1;

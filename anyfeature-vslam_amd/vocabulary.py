@@ -35,13 +35,19 @@ class Vocabulary:
     def loadFromTextFile(cls, path, ctx=None):
         with open(path) as fh:
             k, L, _scoring, _weighting = [int(v) for v in fh.readline().split()[:4]]
-            parent, leaf, desc, weight = [0], [False], [np.zeros(32, np.uint8)], [0.0]
+            parent, leaf, desc, weight = [0], [False], [None], [0.0]
+            nbytes = None
             for line in fh:
                 t = line.split()
-                if len(t) < 35:
+                if len(t) < 4:
+                    continue
+                if nbytes is None:
+                    nbytes = len(t) - 3   # parent, isLeaf, F::L descriptor bytes (32 ORB, 61 AKAZE, 48 BRISK ...), weight
+                if len(t) != nbytes + 3:
                     continue
                 parent.append(int(t[0])); leaf.append(int(t[1]) > 0)
-                desc.append(np.array(t[2:34], dtype=np.int64).astype(np.uint8)); weight.append(float(t[34]))
+                desc.append(np.array(t[2:2 + nbytes], dtype=np.int64).astype(np.uint8)); weight.append(float(t[2 + nbytes]))
+        desc[0] = np.zeros(nbytes or 32, np.uint8)
         return cls(k, L, parent, np.stack(desc), weight, leaf, ctx)
 
     def saveToTextFile(self, path):

@@ -817,6 +817,16 @@ def extra_l2_sift128(afv, device, reps=20):
             m.match_l2_pairs_device(tt, cnt, pa, pb, 0.5, 0.8, match=match, nmatches=nm)
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / 3
+    # roofline of config #3: f64 vector work.  Per descriptor pair 128 x (v_sub_f32, v_cvt_f64_f32, v_mul_f64, v_add_f64): no FMA - cv::norm's
+    # operation order is part of the result (-ffp-contract=off) - so 256 f64 flops ride on 512 vector instructions.  Peaks: 78.6 TFLOP/s f64
+    # (an FMA per lane and clock: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz x 2), 39.3 T vector instructions per second.  `achieved` covers
+    # BOTH launches of a job batch (ranking + ordered resolve) by the wall clock: the ranking kernel alone is faster (profiles/r06/kernel_stats_l2.csv).
+    pairs_per_s = njobs * n * n / dt
+    out["roofline"] = {"bound": "valu_f64", "kernel": "k_l2_topk_pairs", "achieved": pairs_per_s * 2 * dim / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                       "frac": pairs_per_s * 2 * dim / 1e12 / 78.6, "flops_per_descriptor_pair": 2 * dim,
+                       "vector_instructions_per_descriptor_pair": 4 * dim, "issue_rate_achieved_T_per_s": pairs_per_s * 4 * dim / 1e12,
+                       "issue_rate_peak_T_per_s": 39.3, "issue_frac": pairs_per_s * 4 * dim / 1e12 / 39.3,
+                       "note": "no FMA by contract (cv::norm order): the flop fraction cannot pass 0.5 x 2 / 4 = 0.25; the issue fraction is the one to read"}
     out["pairs_device"] = {"keyframes": K, "jobs": njobs, "jobs_per_s": njobs / dt, "us_per_job": dt / njobs * 1e6,
                            "descriptor_pairs_per_s": njobs * n * n / dt, "matches_per_job": float(nm.float().mean().item()),
                            "note": "afv_match_l2_pairs_device: table resident in HBM, one launch pair per 2048 jobs; every distance is 128 float "
@@ -980,6 +990,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeat", type=int, default=5, help="timed blocks of --steps steps each; the line reports the median block (value_min / value_max: the others)")
     ap.add_argument("--batch", type=int, default=512, help="frames per GPU per step")
     ap.add_argument("--cpu-frames", type=int, default=256, help="frames in the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage hipEvents")
@@ -987,7 +998,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
                                                       "multi-rank control flow on a 1-GPU box)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
-    ap.add_argument("--workload", default="orb32", choices=["orb32", "akaze61", "pairs10k"],
+    ap.add_argument("--workload", default="orb32", choices=["orb32", "akaze61", "pairs10k", "l2sift128"],
                     help="orb32 = the BASELINE.json metric (default); akaze61 = configs[4], 1280x720, single GPU (use --batch 64); "
                          "pairs10k = configs[3], 10 000 keyframe-pair match jobs over a K = 1000 table, RCCL broadcast timed separately")
     ap.add_argument("--match-engine", type=int, default=None, choices=[0, 1], help="phase 1 of the pair matcher: 1 = matrix cores (library "
@@ -1017,6 +1028,14 @@ def main():
         return akaze_main(args)
     if args.workload == "pairs10k":
         return pairs_main(args)
+    if args.workload == "l2sift128":   # configs[2] alone (profiling runs: profiles/rNN/kernel_stats_l2.csv)
+        afv = importlib.import_module("anyfeature-vslam_amd")
+        out = {"metric": "SIFT128 L2 descriptor pairs /sec", "config": {"workload": "configs[2]: float descriptors 1000 x 1000 x 128, device table of 64 sets, 2048 pair jobs"}}
+        out.update(extra_l2_sift128(afv, 0))
+        out["value"] = out["pairs_device"]["descriptor_pairs_per_s"]
+        out["unit"] = "descriptor pairs/s"
+        print(json.dumps(out), file=_REAL_STDOUT, flush=True)
+        return
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -1090,24 +1109,31 @@ def main():
     prof_steps = (args.steps + PROF_EVERY - 1) // PROF_EVERY
     if not args.no_profile:
         ctx.profile_enable(True, every=PROF_EVERY)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    stages = None if args.no_profile else ctx.profile_read()
-    if not args.no_profile:
-        ctx.profile_enable(False)
+    # The timed region, `repeat` times over: every block is EXACTLY `steps` steps between two barriers (the contract's bracket), the
+    # reported value is the MEDIAN block's (one 51 ms window moves by a few per cent with a clock-ramp hiccup), the slowest and
+    # fastest block are printed next to it.  The stage events of the first block only feed stage_ms / the two-stream roofline note.
+    block_dt = []
+    stages = None
+    for blk in range(max(args.repeat, 1)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        block_dt.append(time.perf_counter() - t0)
+        if blk == 0 and not args.no_profile:
+            stages = ctx.profile_read()
+            ctx.profile_enable(False)
 
     kp_step = int(n_out.sum().item())
     nm_step = int(nmatch.sum().item())
-    t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    t = torch.tensor(block_dt, dtype=torch.float64, device=red_dev)
     k = torch.tensor([kp_step], dtype=torch.int64, device=red_dev)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)   # per block: the slowest rank
         dist.all_reduce(k, op=dist.ReduceOp.SUM)
-    dt = float(t.item())
+    block_dt = sorted(float(v) for v in t.tolist())
+    dt = block_dt[(len(block_dt) - 1) // 2]        # median block (the lower one of an even count)
     total_kp = int(k.item()) * args.steps
     # who did what (the first multi-GPU run should be boring): every rank's frame seeds and keypoint count
     per_rank = [{"rank": rank, "first_seed": seed0, "frames": B, "keypoints_per_step": kp_step}]
@@ -1129,6 +1155,8 @@ def main():
         out = {
             "metric": METRIC, "value": total_kp / dt, "unit": "keypoints/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "timed_blocks": len(block_dt), "value_min": total_kp / block_dt[-1], "value_max": total_kp / block_dt[0],
+            "value_is": "median of %d timed blocks of %d steps each (every block bracketed by barrier + synchronize)" % (len(block_dt), args.steps),
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "ORB32 640x480 synthetic corners frames (LCG), 1000 kp/frame budget, 8 levels x1.2, FAST 20; "
                                    "extract+describe on device, brute-force Hamming match frame t vs t-1 (TH 75, ratio 0.6, "

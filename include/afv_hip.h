@@ -402,6 +402,12 @@ typedef struct {
                                          afv_frame_extract; 1: the caller undistorts (cv::undistortPoints of N points is host work) and
                                          hands mvKeysUn over with afv_frame_set_undistorted, which builds the grid */
     int32_t cap;                      /* most features the frame can hold; 0 = afv_max_keypoints_per_frame(ctx); <= 8192 */
+    int32_t desc_bytes;               /* (ABI 6) bytes of one binary descriptor, 1 .. 64: 32 ORB (0 = 32), 61 AKAZE, 48 BRISK ... - the reference's
+                                         matchers dispatch on DescriptorType (FeatureMatcher.cc:1508-1531).  Rows live zero-padded to 8 or 16
+                                         dwords in HBM.  A frame that is not 32-byte is filled with afv_frame_set_features (afv_frame_extract
+                                         is the ORB32 extractor; the keyframe TABLE holds 32-byte rows only: afv_table_set_from_frame /
+                                         afv_table_match_bow_frame_h answer AFV_EUNSUPPORTED for it) and serves afv_frame_bow_transform with a
+                                         vocabulary of the same descriptor size, afv_frame_match_projection / _fuse / _initialization */
 } afv_frame_params;
 int afv_frame_create(afv_ctx *ctx, const afv_frame_params *params, afv_frame **out);
 void afv_frame_destroy(afv_frame *f);

@@ -131,3 +131,52 @@ def test_bow_guided_matchers_over_small_and_large_nodes(afv, oracle, gpu_ctx, k,
     want, wn = oracle.search_by_bow_kf_frame(d1, d2, fv1, fv2, v1, k1["angle"], k2["angle"], 75.0, 0.8, ori)
     assert n == wn and np.array_equal(got, want) and wn > 30
     voc.close()
+
+
+# ---- descriptor-generic: Vocabulary::transform has a case per descriptor type (Vocabulary.cpp:156-206); binary ones of other sizes ----
+@pytest.mark.parametrize("nbytes", [61, 48, 20])
+@pytest.mark.parametrize("k,L,levelsup", [(10, 3, 2), (4, 5, 4)])
+def test_transform_of_other_descriptor_sizes(afv, oracle, gpu_ctx, nbytes, k, L, levelsup):
+    voc = afv.Vocabulary.random(17 + k, k=k, L=L, ctx=gpu_ctx, desc_bytes=nbytes)
+    desc = afv.synth.lcg_bytes(3, 1500 * nbytes).reshape(1500, nbytes)
+    leaf, nid = voc.transform_nodes(desc, levelsup)
+    oleaf, onid = oracle.bow_transform(voc, desc, levelsup)
+    assert np.array_equal(leaf, oleaf) and np.array_equal(nid, onid) and np.all(voc.is_leaf[leaf])
+    # descriptors that ARE node descriptors find their own leaf; descriptors of another width are refused
+    own = np.nonzero(voc.is_leaf)[0][:64]
+    assert np.array_equal(voc.transform_nodes(voc.node_desc[own], levelsup)[0], oracle.bow_transform(voc, voc.node_desc[own], levelsup)[0])
+    voc.close()
+
+
+@pytest.mark.parametrize("nbytes", [61, 48])
+@pytest.mark.parametrize("ori", [False, True])
+def test_bow_guided_matchers_on_other_descriptor_sizes(afv, oracle, gpu_ctx, nbytes, ori):
+    """SearchByBoW(KF, KF) / (KF, F) over 61- and 48-byte descriptors with FeatureVectors from a vocabulary of that size"""
+    s = afv.synth
+    img = s.corners_frame(2)
+    k1, d1 = gpu_ctx.extract(img)
+    k2, d2 = gpu_ctx.extract(np.roll(img, 4, axis=1))
+    wide = lambda d: np.ascontiguousarray(np.concatenate([d, np.roll(d, 5, axis=1) ^ np.uint8(0x5A)], 1)[:, :nbytes])
+    d1, d2 = wide(d1), wide(d2)
+    th = float(round(75.0 * nbytes / 32.0))
+    voc = afv.Vocabulary.random(23, k=8, L=3, ctx=gpu_ctx, desc_bytes=nbytes)
+    _, fv1 = voc.transform(d1, levelsup=2)
+    _, fv2 = voc.transform(d2, levelsup=2)
+    v1 = (s.lcg_bytes(5, len(d1)) > 40).astype(np.uint8); v2 = (s.lcg_bytes(6, len(d2)) > 40).astype(np.uint8)
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(th)
+    try:
+        m = afv.FeatureMatcher(0.8, ori, ctx=gpu_ctx)
+        A = afv.FeatureView(d1, fv1, valid=v1, angles=k1["angle"]); B = afv.FeatureView(d2, fv2, valid=v2, angles=k2["angle"])
+        got, n = m.SearchByBoW(A, B)
+        want, wn = oracle.search_by_bow_kf_kf(d1, d2, fv1, fv2, v1, v2, k1["angle"], k2["angle"], th, 0.8, ori)
+        assert n == wn and np.array_equal(got, want) and wn > 30
+        got, n = m.SearchByBoW(A, B, frame=True)
+        want, wn = oracle.search_by_bow_kf_frame(d1, d2, fv1, fv2, v1, k1["angle"], k2["angle"], th, 0.8, ori)
+        assert n == wn and np.array_equal(got, want) and wn > 30
+        # brute force (no FeatureVectors) of wide descriptors: the popcount walk (the MFMA / top-k pair path is for 32-byte sets)
+        got, n = m.SearchByBoW(afv.FeatureView(d1, angles=k1["angle"]), afv.FeatureView(d2, angles=k2["angle"]))
+        want, wn = oracle.search_by_bow_kf_kf(d1, d2, None, None, None, None, k1["angle"], k2["angle"], th, 0.8, ori)
+        assert n == wn and np.array_equal(got, want) and wn > 100
+    finally:
+        afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+    voc.close()

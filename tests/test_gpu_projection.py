@@ -298,3 +298,92 @@ def test_job_records_of_an_older_layout_and_without_a_size(afv, oracle, gpu_ctx)
         j.struct_size = bad
         jobs = (afv._lib.ProjJob * 1)(j)
         assert gpu_ctx.lib.afv_match_projection(gpu_ctx.handle, jobs, 1, out.ctypes.data, nm.ctypes.data) == afv._lib.EINVAL
+
+
+# ---- descriptor-generic: the reference dispatches every matcher on DescriptorType (FeatureMatcher.cc:1508-1531, called from
+#      :122,236,379,440,509,616,734,907,1036,1175,1253,1376,1481); 61 bytes = AKAZE61's MLDB, 48 = BRISK48, 20 = a short one ----
+def _widen(d32, nbytes):
+    """an nbytes-wide descriptor set with the neighbourhood structure of the 32-byte one: its bytes, then a rotated and inverted copy,
+    cut to nbytes - distances between widened rows are about nbytes / 32 times those between the originals"""
+    d32 = np.ascontiguousarray(d32, np.uint8)
+    if nbytes == 32:
+        return d32
+    wide = np.concatenate([d32, np.roll(d32, 5, axis=1) ^ np.uint8(0x5A)], 1)
+    return np.ascontiguousarray(wide[:, :nbytes])
+
+
+def _widen_scene(F, Q, nbytes):
+    F.descriptors = _widen(F.descriptors, nbytes)
+    Q.descriptors = _widen(Q.descriptors, nbytes)
+    return F, Q
+
+
+@pytest.mark.parametrize("nbytes", [61, 48, 20])
+def test_projection_searches_are_descriptor_generic(afv, oracle, gpu_ctx, nbytes):
+    th = float(round(75.0 * nbytes / 32.0))
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(th)
+    try:
+        # SearchByProjection(F, local map) / (cur, last) with and without the orientation histogram
+        F, Q = _widen_scene(*_scene(afv, gpu_ctx, 51, 4, 15.0), nbytes)
+        m = afv.FeatureMatcher(0.8, True, ctx=gpu_ctx)
+        got, n = m.SearchByProjection(F, Q)
+        want, wn = oracle.match_projection(F, Q, th_high=th, nnratio=0.8)
+        assert n == wn and np.array_equal(got, want) and wn > 100
+        for ori in (False, True):
+            m = afv.FeatureMatcher(0.9, ori, ctx=gpu_ctx)
+            got, n = m.SearchByProjection(F, Q, last_frame=True)
+            want, wn = oracle.match_projection(F, Q, th_high=th, nnratio=0.9, check_orientation=ori, last_frame=True)
+            assert n == wn and np.array_equal(got, want) and wn > 100
+        # stereo gate
+        Fs, Qs = _stereo(afv, *_widen_scene(*_scene(afv, gpu_ctx, 52, 3, 40.0), nbytes), 52, 0.5)
+        m = afv.FeatureMatcher(0.85, True, ctx=gpu_ctx)
+        got, n = m.SearchByProjection(Fs, Qs)
+        want, wn = oracle.match_projection(Fs, Qs, th_high=th, nnratio=0.85)
+        assert n == wn and np.array_equal(got, want) and wn > 50
+        # Fuse (with its reprojection gate) and Fuse(Sim3)
+        F, Q = _widen_scene(*_scene(afv, gpu_ctx, 53, 4, 15.0), nbytes)
+        F.inf = np.ascontiguousarray(np.float32(0.2) / (F.sizes * F.sizes))
+        m = afv.FeatureMatcher(0.6, True, ctx=gpu_ctx)
+        got, n = m.Fuse(F, Q)
+        want, wn = oracle.match_projection(F, Q, th_high=th, fuse=True)
+        assert n == wn and np.array_equal(got, want) and wn > 50
+        # a dense cluster: the ordered phase's claim / rescan logic on wide rows
+        s = afv.synth
+        nf, nq = 60, 400
+        proto = _widen(s.random_descriptors(77, 6), nbytes)
+        d = proto[s.lcg_states(1, nf) % 6].copy()
+        d[np.arange(nf), s.lcg_states(2, nf) % nbytes] ^= 1
+        pts = np.stack([300 + (s.lcg_states(3, nf) % 40).astype(np.float32), 200 + (s.lcg_states(4, nf) % 40).astype(np.float32)], 1)
+        Fc = afv.FrameGridView(d, pts, np.ones(nf, np.float32))
+        qd = proto[s.lcg_states(5, nq) % 6].copy()
+        qd[np.arange(nq), s.lcg_states(6, nq) % nbytes] ^= 2
+        Qc = afv.ProjectionQueries(qd, np.full(nq, 320.0), np.full(nq, 220.0), np.full(nq, 30.0), np.full(nq, 0.5), np.full(nq, 2.0))
+        for mode, ratio in ((False, 0.8), (True, 0.9)):
+            m = afv.FeatureMatcher(ratio, False, ctx=gpu_ctx)
+            got, nn = m.SearchByProjection(Fc, Qc, last_frame=mode)
+            want, wn = oracle.match_projection(Fc, Qc, th_high=th, nnratio=ratio, last_frame=mode)
+            assert nn == wn and np.array_equal(got, want), (mode, ratio)
+        # SearchBySim3 and SearchForInitialization
+        img = s.corners_frame(54)
+        k1, d1 = gpu_ctx.extract(img)
+        k2, d2 = gpu_ctx.extract(np.roll(img, 6, axis=1))
+        d1, d2 = _widen(d1, nbytes), _widen(d2, nbytes)
+        z1, _, _ = gpu_ctx.size_sigma(k1); z2, _, _ = gpu_ctx.size_sigma(k2)
+        F1 = afv.FrameGridView(d1, np.stack([k1["x"], k1["y"]], 1), z1, angles=k1["angle"])
+        F2 = afv.FrameGridView(d2, np.stack([k2["x"], k2["y"]], 1), z2, angles=k2["angle"])
+        Q1 = afv.ProjectionQueries(d1, k1["x"] + 6, k1["y"], 12.0 * z1, z1 / np.float32(1.2), z1 * np.float32(1.2))
+        Q2 = afv.ProjectionQueries(d2, k2["x"] - 6, k2["y"], 12.0 * z2, z2 / np.float32(1.2), z2 * np.float32(1.2))
+        m = afv.FeatureMatcher(0.8, True, ctx=gpu_ctx)
+        got, n = m.SearchBySim3(F1, Q1, F2, Q2)
+        want, wn = oracle.match_sim3(F2, Q1, F1, Q2, th_high=th)
+        assert n == wn and np.array_equal(got, want) and wn > 200
+        prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+        n1 = len(k1)
+        Qi = afv.ProjectionQueries(d1, prev[:, 0].copy(), prev[:, 1].copy(), np.full(n1, 50.0, np.float32), np.zeros(n1, np.float32),
+                                   np.full(n1, z1.max(), np.float32), valid=(k1["octave"] == 0).astype(np.uint8), angles=k1["angle"])
+        m = afv.FeatureMatcher(0.9, True, ctx=gpu_ctx)
+        got, n = m.SearchForInitialization(Qi, F2, vbPrevMatched=prev)
+        want, wn = oracle.match_initialization(F2, Qi, th_low=th, nnratio=0.9, check_orientation=True)
+        assert n == wn and np.array_equal(got, want) and wn > 50
+    finally:
+        afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)

@@ -108,7 +108,7 @@ for line in open(out + "/sq_activity.jsonl"):
     d = json.loads(line)
     k = acc.setdefault(d["kernel"], {"us_per_launch": []})
     k["us_per_launch"].append(d["us_per_launch"])
-    k["frames_per_launch_assumed"] = d["frames_per_launch"]
+    k["frames_per_launch_assumed"] = d["frames_per_launch"]   # frames of the run / launches of the kernel (tools/experiments.py)
     for key, v in d.items():
         if key.endswith("_per_frame"):
             k[key[:-10]] = v
@@ -126,7 +126,7 @@ for name, k in acc.items():
         "wave_cycles_waiting_to_issue_frac": k.get("SQ_WAIT_INST_ANY", 0.0) / k["SQ_WAVE_CYCLES"] if k.get("SQ_WAVE_CYCLES") else None,
         "wave_cycles_issuing_frac": k.get("SQ_ACTIVE_INST_ANY", 0.0) / k["SQ_WAVE_CYCLES"] if k.get("SQ_WAVE_CYCLES") else None,
         "resident_waves_per_simd": k.get("SQ_WAVE_CYCLES", 0.0) / k["SQ_BUSY_CU_CYCLES"] if k.get("SQ_BUSY_CU_CYCLES") else None,
-        "counters_per_frame_as_normalised_by_tools_experiments": {c: v for c, v in k.items() if c.startswith("SQ_")},
+        "counters_per_frame": {c: v for c, v in k.items() if c.startswith("SQ_")},
     }
 res["note"] = ("SQ_ACTIVE_INST_VALU counts 4-cycle issue slots per SIMD (one per vector instruction): valu_busy_frac = SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES "
                "(4 SIMDs x 1 slot per 4 cycles = 1 per CU cycle) - 1.0 means the vector issue port is never idle; SQ_WAVE_CYCLES likewise in units of 4 cycles "
@@ -138,7 +138,7 @@ try:
 except Exception:
     pass
 json.dump(res, open(out + "/sq_activity.json", "w"), indent=1)
-print(json.dumps({k: {a: b for a, b in v.items() if a != "counters_per_frame_as_normalised_by_tools_experiments"} for k, v in res.items() if isinstance(v, dict)}, indent=1))
+print(json.dumps({k: {a: b for a, b in v.items() if a != "counters_per_frame"} for k, v in res.items() if isinstance(v, dict)}, indent=1))
 PYEOF
 
 echo "== static VALU op-class shares of the kernels (from the ISA; feeds valu_issue.peak_isa_mix)"
@@ -152,6 +152,12 @@ cp "$(find "$OUT/stats_pairs" -name "*kernel_stats.csv" | head -1)" "$OUT/kernel
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT -d "$OUT/pmc_pairs" -o p --output-format csv -- $PY "$ROOT/bench.py" --workload pairs10k --steps 3 --cpu-frames 0 --no-profile > /dev/null 2>&1
 cp "$(find "$OUT/pmc_pairs" -name "*counter_collection.csv" | head -1)" "$RAW/pmc_pairs10k_counter_collection.csv" 2>/dev/null
 $PY "$ROOT/tools/pmc_summary.py" "$RAW/pmc_pairs10k_counter_collection.csv" > "$OUT/pmc_pairs10k_summary.txt" 2>/dev/null
+
+echo "== config #3: SIFT128 L2 pair matcher: bench line + kernel stats (the roofline of bench.py's l2_sift128 key quotes k_l2_topk_pairs)"
+cd "$ROOT" && $PY bench.py --workload l2sift128 > "$OUT/bench_l2sift128.json" 2> "$OUT/bench_l2sift128.err"; cd /tmp
+timeout 400 rocprofv3 --kernel-trace --stats -d "$OUT/stats_l2" -o st --output-format csv -- $PY "$ROOT/bench.py" --workload l2sift128 > /dev/null 2>&1
+cp "$(find "$OUT/stats_l2" -name "*kernel_stats.csv" | head -1)" "$OUT/kernel_stats_l2.csv"
+rm -rf "$OUT/stats_l2"
 
 echo "== config #5: AKAZE61 bench + kernel stats"
 cd "$ROOT" && $PY bench.py --workload akaze61 --batch 64 --steps 5 > "$OUT/bench_akaze61.json" 2> "$OUT/bench_akaze61.err"; cd /tmp

@@ -44,9 +44,15 @@ def run(name, batch=256):
         if kern in r["Kernel_Name"]:
             acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
             cnt[r["Counter_Name"]] = cnt.get(r["Counter_Name"], 0) + 1
-    frames_per_launch = batch / 4
+    # ONE definition of "per frame" for every PMC tool of this repository (tools/pmc_per_frame.py, tools/pmc_tracking.py, this file): the sum of
+    # a counter over ALL launches of the kernel in the run, divided by the frames the run processed (batch x (steps + warm-up) = batch x 3).
+    # (Round 5 divided a launch's average by batch / 4 here - the split was two chunks of 128 frames, not four of 64: its figures were 2 x
+    # those of pmc_per_frame.py for the same kernel and counter)
+    frames_total = batch * 3
+    launches = max(cnt.values()) if cnt else 1
+    frames_per_launch = frames_total / launches
     for k in acc:
-        res[k + "_per_frame"] = acc[k] / cnt[k] / frames_per_launch
+        res[k + "_per_frame"] = acc[k] / frames_total
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in
          csv.DictReader(open(glob.glob(os.path.join(out, "**", "pmc_kernel_trace.csv"), recursive=True)[0])) if kern in r["Kernel_Name"]]
     res["us_per_launch"] = sum(d) / len(d)
