@@ -41,8 +41,12 @@ template <int ST> struct SelCfg {
 // register budget (<= 96 VGPRs, 5 waves per SIMD) are the tuning parameters here.
 
 // quadtree region of the LDS layout (see the kernel); never smaller than the 2048-bin histogram that shares it
-__host__ __device__ constexpr size_t afv_select_tree_bytes(int M) {
-    return (size_t)M * 60 > 8192 ? (size_t)M * 60 : 8192;
+// (the 1024-thread instantiation finds the retainBest threshold with ONE 4096-bin pass + an exact ranking of the threshold bin's keys: its
+// histogram (16 KB) and key list (SEL_EXACT u32) share the region)
+#define SEL_EXACT 1024  // keys of the threshold bin the exact ranking takes (more: the three radix passes)
+__host__ __device__ constexpr size_t afv_select_tree_bytes(int M, bool wide = false) {
+    const size_t tree = (size_t)M * 60, need = wide ? (size_t)4096 * 4 + SEL_EXACT * 4 : (size_t)8192;
+    return tree > need ? tree : need;
 }
 
 struct Rect16 {
@@ -205,7 +209,7 @@ __device__ __forceinline__ void select_quadtree_body(const Geo *__restrict__ geo
     int *aux2 = aux + M;
     int *unt = aux2 + M;
     uint16_t *remap = reinterpret_cast<uint16_t *>(unt + M);
-    int *tmp = reinterpret_cast<int *>(smem + afv_select_tree_bytes(M));
+    int *tmp = reinterpret_cast<int *>(smem + afv_select_tree_bytes(M, ST == 1024));
 
 #ifdef AFV_SELECT_STATS
     const long long st0 = wall_clock64();
@@ -269,7 +273,51 @@ __device__ __forceinline__ void select_quadtree_body(const Geo *__restrict__ geo
     // ---------------- E4b: threshold on the Harris response (retainBest on the score already happened: k_harris.hip) ----------------
     const int n1 = n;
     uint32_t T2 = 0;
-    if (n1 > L.cv_quota) {  // uniform
+    int known_survivors = -1;  // how many candidates pass T2, when the selection below already knows (saves the counting pass)
+    bool have_T2 = false;
+    if (ST == 1024 && n1 > L.cv_quota) {  // uniform
+        // The one-frame instantiation (round 6): what this kernel costs is its chain of workgroup-wide phases (16 wavefronts: ~0.8 us per
+        // barrier and dependent LDS round trip), and the three radix passes were eighteen of them.  ONE pass over the top 12 key bits (sign,
+        // exponent, 3 mantissa bits: 4096 bins) finds the bin that holds the k-th largest key; that bin's keys (a few dozen of some thousand
+        // responses) are listed and ranked exactly - a key x is the k-th largest iff  #{y > x} < k <= #{y >= x}  among them - and the number
+        // of survivors (keys >= T2, ties kept: KeyPointsFilter::retainBest) falls out of the same counts.  A bin with more than SEL_EXACT
+        // keys (flat images: thousands of equal responses) takes the radix passes below.
+        const int k = L.cv_quota;
+        uint32_t *klist = reinterpret_cast<uint32_t *>(hist + 4096);
+        for (int i = tid; i < 4096; i += ST) hist[i] = 0;
+        if (tid == 0) tmp[6] = 0;
+        __syncthreads();
+        FOR_CAND({ atomicAdd(&hist[float_key(r) >> 20], 1); })
+        __syncthreads();
+        int above;
+        const int bin = block_kth_from_top<ST>(hist, 4096, k, &above, tmp);
+        const int in_bin = hist[bin], kk = k - above;  // the kk-th largest key of the bin is the threshold
+        if (in_bin <= SEL_EXACT) {  // uniform
+            FOR_CAND({
+                const uint32_t key = float_key(r);
+                if ((int)(key >> 20) == bin) klist[atomicAdd(&tmp[6], 1)] = key;
+            })
+            __syncthreads();
+            if (tid < in_bin) {
+                const uint32_t x = klist[tid];
+                int g = 0, ge = 0;
+                for (int j = 0; j < in_bin; ++j) {  // broadcast reads: every lane the same word
+                    const uint32_t y = klist[j];
+                    g += y > x;
+                    ge += y >= x;
+                }
+                if (g < kk && kk <= ge) {  // every key equal to the threshold says the same
+                    tmp[7] = (int)x;
+                    tmp[9] = above + ge;
+                }
+            }
+            __syncthreads();
+            T2 = (uint32_t)tmp[7];
+            known_survivors = tmp[9];  // (tmp[7] / tmp[9] are next written behind the compaction's barrier)
+            have_T2 = true;
+        }
+    }
+    if (n1 > L.cv_quota && !have_T2) {  // uniform
         int k = L.cv_quota;
         uint32_t prefix = 0, mask = 0;
         const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
@@ -295,20 +343,25 @@ __device__ __forceinline__ void select_quadtree_body(const Geo *__restrict__ geo
     st1 = wall_clock64();
 #endif
     // number of survivors decides where they live during the quadtree rounds
-    if (tid == 0) tmp[9] = 0;
-    __syncthreads();
-    {
-        int c = 0;
-        FOR_CAND(c += (float_key(r) >= T2);)
-        c = wave_incl_scan(c);
-        if (lane == 63) atomicAdd(&tmp[9], c);
+    int n_surv = known_survivors;
+    if (n1 <= L.cv_quota) n_surv = n1;  // nothing is cut
+    if (n_surv < 0) {  // uniform: the radix passes do not count
+        if (tid == 0) tmp[9] = 0;
+        __syncthreads();
+        {
+            int c = 0;
+            FOR_CAND(c += (float_key(r) >= T2);)
+            c = wave_incl_scan(c);
+            if (lane == 63) atomicAdd(&tmp[9], c);
+        }
+        __syncthreads();
+        n_surv = tmp[9];
+        __syncthreads();
     }
-    __syncthreads();
-    if (tmp[9] <= KEPT_LDS) {
+    if (n_surv <= KEPT_LDS) {
         kxy = lds_kxy;
         kn = lds_kn;
     }
-    __syncthreads();
 
     // ---------------- compaction of the survivors + root assignment ----------------
     const int n_ini = geo.n_ini;
@@ -811,13 +864,13 @@ __global__ __launch_bounds__(1024) void k_select_quadtree_wide(const Geo *__rest
     select_quadtree_body<1024>(geo_p, cand_packed, cand_resp, cand_count, kept_xy, kept_resp, kept_node, sel, sel_count, M, frame_base, total_blocks);
 }
 
-static size_t select_lds_bytes(int M, int kept) { return afv_select_tree_bytes(M) + SEL_TMP * 4 + (size_t)kept * 6 /*kept xy, node*/; }
-extern "C" size_t afv_select_lds_bytes(int M) { return std::max(select_lds_bytes(M, SelCfg<256>::KEPT_LDS), select_lds_bytes(M, SelCfg<1024>::KEPT_LDS)); }
+static size_t select_lds_bytes(int M, int kept, bool wide) { return afv_select_tree_bytes(M, wide) + SEL_TMP * 4 + (size_t)kept * 6 /*kept xy, node*/; }
+extern "C" size_t afv_select_lds_bytes(int M) { return std::max(select_lds_bytes(M, SelCfg<256>::KEPT_LDS, false), select_lds_bytes(M, SelCfg<1024>::KEPT_LDS, true)); }
 
 // once per context (afv_create, on the context's device): the wide instantiation may need more dynamic LDS than the 64 KB a kernel gets
 // by default.  false: the attribute call failed and the tables do not fit without it - the caller keeps to the 256-thread kernel.
 extern "C" int afv_select_prepare(int M) {
-    const size_t lds = select_lds_bytes(M, SelCfg<1024>::KEPT_LDS);
+    const size_t lds = select_lds_bytes(M, SelCfg<1024>::KEPT_LDS, true);
     if (lds <= 64 * 1024) return 1;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_select_quadtree_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         (void)hipGetLastError();
@@ -832,12 +885,12 @@ extern "C" void afv_launch_select(const Geo *geo_dev, int nlevels, const uint32_
     const int total = nlevels * nframes;
     dim3 grid((total + 7) / 8 * 8);
     if (wide) {
-        const size_t lds = select_lds_bytes(M, SelCfg<1024>::KEPT_LDS);  // above 64 KB: afv_select_prepare raised the limit at afv_create
+        const size_t lds = select_lds_bytes(M, SelCfg<1024>::KEPT_LDS, true);  // above 64 KB: afv_select_prepare raised the limit at afv_create
         hipLaunchKernelGGL(k_select_quadtree_wide, grid, dim3(1024), lds, stream, geo_dev, cand_packed, cand_resp, cand_count, kept_xy, kept_resp,
                            kept_node, sel, sel_count, M, frame_base, total);
         return;
     }
-    const size_t lds = select_lds_bytes(M, SelCfg<256>::KEPT_LDS);
+    const size_t lds = select_lds_bytes(M, SelCfg<256>::KEPT_LDS, false);
     hipLaunchKernelGGL(k_select_quadtree, grid, dim3(256), lds, stream, geo_dev, cand_packed, cand_resp,
                        cand_count, kept_xy, kept_resp, kept_node, sel, sel_count, M, frame_base, total);
 }
