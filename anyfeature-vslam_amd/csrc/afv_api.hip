@@ -2037,10 +2037,26 @@ extern "C" int afv_set_projection_resolve(afv_ctx *c, int engine) {
 }
 
 // ---- BoW quantisation ----
+// the tree image of k_bow.hip for node descriptors of `words` dwords each (binary: 8 or 16, zero-padded; float: the dimension)
+static int vocab_create_impl(afv_ctx *c, int k, int L, int nnodes, const int32_t *child_ptr, const int32_t *child_idx, const uint8_t *desc, int desc_bytes,
+                             int words, int float_dim, afv_vocab **out);
+
 extern "C" int afv_vocab_create(afv_ctx *c, int k, int L, int nnodes, const int32_t *child_ptr, const int32_t *child_idx,
                                 const uint8_t *desc, int desc_bytes, afv_vocab **out) {
     if (!c || !out || !child_ptr || !child_idx || !desc || k < 1 || L < 1 || nnodes < 1 || desc_bytes < 1 || desc_bytes > 64)
         return AFV_EINVAL;
+    return vocab_create_impl(c, k, L, nnodes, child_ptr, child_idx, desc, desc_bytes, desc_bytes <= 32 ? 8 : 16, 0, out);
+}
+
+// float node descriptors (the non-binary cases of Vocabulary::transform, Vocabulary.cpp:158-187): dim = 64 (SURF64 / KAZE64), 128 (SIFT128 / R2D2) or 256
+extern "C" int afv_vocab_create_f32(afv_ctx *c, int k, int L, int nnodes, const int32_t *child_ptr, const int32_t *child_idx, const float *desc, int dim,
+                                    afv_vocab **out) {
+    if (!c || !out || !child_ptr || !child_idx || !desc || k < 1 || L < 1 || nnodes < 1 || (dim != 64 && dim != 128 && dim != 256)) return AFV_EINVAL;
+    return vocab_create_impl(c, k, L, nnodes, child_ptr, child_idx, reinterpret_cast<const uint8_t *>(desc), dim * 4, dim, dim, out);
+}
+
+static int vocab_create_impl(afv_ctx *c, int k, int L, int nnodes, const int32_t *child_ptr, const int32_t *child_idx, const uint8_t *desc, int desc_bytes,
+                             int words, int float_dim, afv_vocab **out) {
     *out = nullptr;
     const int nchild = child_ptr[nnodes];
     if (child_ptr[0] != 0 || nchild < 0 || nchild > nnodes) return AFV_EINVAL;
@@ -2069,7 +2085,8 @@ extern "C" int afv_vocab_create(afv_ctx *c, int k, int L, int nnodes, const int3
     afv_vocab *v = new (std::nothrow) afv_vocab();
     if (!v) return AFV_ENOMEM;
     v->desc_bytes = desc_bytes;
-    const int words = desc_bytes <= 32 ? 8 : 16, RD = words + 4;
+    v->float_dim = float_dim;
+    const int RD = words + 4;
     // device image (k_bow.hip): nodes renumbered breadth first, the children of a node consecutive and in DBoW2 order; record =
     // descriptor | first child record | #children | DBoW2 id | 0.  Nodes the root does not reach keep no record.
     std::vector<int> order;  // record -> DBoW2 id
@@ -2145,6 +2162,7 @@ extern "C" void afv_vocab_destroy(afv_ctx *c, afv_vocab *v) {
 static int afv_bow_transform_impl(afv_ctx *c, const afv_vocab *v, const uint8_t *desc, int n, int levelsup, int32_t *leaf_node,
                                  int32_t *node_at_level) {
     if (!c || !v || n < 0 || (n > 0 && (!desc || !leaf_node || !node_at_level))) return AFV_EINVAL;
+    if (v->float_dim) return AFV_EINVAL;  // a float vocabulary: afv_bow_transform_f32
     if (n == 0) return AFV_OK;
     HIPCHK(c, hipSetDevice(c->device));
     Blob b(c);
@@ -2166,4 +2184,29 @@ static int afv_bow_transform_impl(afv_ctx *c, const afv_vocab *v, const uint8_t 
 extern "C" int afv_bow_transform(afv_ctx *c, const afv_vocab *v, const uint8_t *desc, int n, int levelsup, int32_t *leaf_node,
                                  int32_t *node_at_level) {
     return guarded(c, [&] { return afv_bow_transform_impl(c, v, desc, n, levelsup, leaf_node, node_at_level); });
+}
+
+extern "C" int afv_bow_transform_f32(afv_ctx *c, const afv_vocab *v, const float *desc, int n, int levelsup, int32_t *leaf_node, int32_t *node_at_level) {
+    if (!c || !v || n < 0 || (n > 0 && (!desc || !leaf_node || !node_at_level))) return AFV_EINVAL;
+    if (!v->float_dim) return AFV_EINVAL;  // a binary vocabulary: afv_bow_transform
+    if (n == 0) return AFV_OK;
+    return guarded(c, [&]() -> int {
+        HIPCHK(c, hipSetDevice(c->device));
+        Blob b(c);
+        const size_t d_off = b.put(desc, (size_t)n * v->float_dim * 4);
+        const size_t in_bytes = b.h.size();
+        const size_t leaf_off = b.reserve((size_t)n * 4), nid_off = b.reserve((size_t)n * 4);
+        const int rc = ensure_match_buffer(c, b.h.size());
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->d_match, b.h.data(), in_bytes, hipMemcpyHostToDevice, c->stream));
+        if (!afv_launch_bow_transform_f32(&v->dev, reinterpret_cast<const float *>(c->d_match + d_off), n, v->float_dim, levelsup,
+                                          reinterpret_cast<int *>(c->d_match + leaf_off), reinterpret_cast<int *>(c->d_match + nid_off), nullptr, c->stream))
+            return AFV_EUNSUPPORTED;
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, b.fetch(leaf_node, leaf_off, (size_t)n * 4, c->stream));
+        HIPCHK(c, b.fetch(node_at_level, nid_off, (size_t)n * 4, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        b.finish();
+        return AFV_OK;
+    });
 }

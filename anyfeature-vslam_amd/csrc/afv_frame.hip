@@ -266,7 +266,7 @@ extern "C" int afv_frame_get_grid(afv_frame *f, int32_t *cell_ptr, int32_t *cell
 // ---- Frame::ComputeBoW ----
 extern "C" int afv_frame_bow_transform(afv_frame *f, const afv_vocab *v, int levelsup, int32_t *leaf_node, int32_t *node_at_level, int32_t *nnodes_out) {
     if (!f || !v || !f->has_features) return AFV_EINVAL;
-    if (v->dev.words != f->words || v->desc_bytes != f->desc_bytes) return AFV_EUNSUPPORTED;  // a vocabulary of another descriptor size
+    if (v->float_dim || v->dev.words != f->words || v->desc_bytes != f->desc_bytes) return AFV_EUNSUPPORTED;  // a vocabulary of another descriptor kind / size
     afv_ctx *c = f->c;
     return guarded(c, [&]() -> int {
         HIPCHK(c, hipSetDevice(c->device));

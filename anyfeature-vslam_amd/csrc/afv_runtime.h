@@ -93,9 +93,12 @@ extern "C" void afv_launch_match_init(const DevProjJob *jobs, int njobs, int max
 
 extern "C" void afv_launch_bow_transform(const DevVocab *v, const uint32_t *desc, int n, int levelsup, int *leaf_node,
                                          int *node_at_level, int *rank_at_level, hipStream_t stream);
+extern "C" int afv_launch_bow_transform_f32(const DevVocab *v, const float *desc, int n, int dim, int levelsup, int *leaf_node, int *node_at_level,
+                                            int *rank_at_level, hipStream_t stream);
 struct afv_vocab {
     DevVocab dev{};
     int desc_bytes = 32;
+    int float_dim = 0;           // > 0: node descriptors are float_dim floats (afv_vocab_create_f32), `desc_bytes` = 4 * float_dim
     void *d_rec = nullptr;       // breadth-first records (k_bow.hip)
     uint8_t *d_stopped = nullptr;
     std::vector<uint8_t> h_stopped;  // host copy of the stop list (empty: none)

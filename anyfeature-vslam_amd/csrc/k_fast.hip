@@ -102,6 +102,41 @@ __device__ __forceinline__ short2v ld_two(const uint8_t *c0, const uint8_t *c1, 
 // ring pixels, so it leaves the network: bright  max_arcs min_arc (r - v) = (max_arcs min_arc r) - v,  dark  max_arcs min_arc (v - r) =
 // v - (min_arcs max_arc r) - the network runs on the RAW ring values (0 .. 255 in the u16 halves) with min / max swapped for the dark
 // list, and v is subtracted once at the end instead of once per ring pixel (round 5: 16 packed subtractions per lane and list pair less).
+#ifdef FT_MIN3
+// Round-6 experiment: the ring values 0 .. 255 in u16 halves are, read as f16 bit patterns, ordered subnormals, so
+// gfx950's three-input packed v_pk_minimum3_f16 / v_pk_maximum3_f16 compute the same packed min / max as the i16 forms (f16 denormals are
+// preserved in the kernel's MODE).  Triples t_k = m3(d_k, d_k+1, d_k+2), windows w_k = m3(t_k, t_k+3, t_k+6) = the 9 ring pixels from k,
+// outer reduction by threes: 16 + 16 + 8 = 40 packed instructions instead of van Herk's 59.
+__device__ __forceinline__ short2v pkmin3(short2v a, short2v b, short2v c) {
+    uint32_t r;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(as_u32(a)), "v"(as_u32(b)), "v"(as_u32(c)));
+    return as_s2(r);
+}
+__device__ __forceinline__ short2v pkmax3(short2v a, short2v b, short2v c) {
+    uint32_t r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(as_u32(a)), "v"(as_u32(b)), "v"(as_u32(c)));
+    return as_s2(r);
+}
+template <bool DARK>
+__device__ __forceinline__ short2v fast_score2(const uint8_t *c0, const uint8_t *c1, short2v V) {
+    auto inner3 = [](short2v a, short2v b, short2v c) { return DARK ? pkmax3(a, b, c) : pkmin3(a, b, c); };
+    auto outer3 = [](short2v a, short2v b, short2v c) { return DARK ? pkmin3(a, b, c) : pkmax3(a, b, c); };
+    short2v d[16], t[16], w[16];
+#define RD(k, dx, dy) d[k] = ld_two(c0, c1, RING_OFF(dx, dy))
+    RD(0, 0, 3); RD(1, 1, 3); RD(2, 2, 2); RD(3, 3, 1); RD(4, 3, 0); RD(5, 3, -1); RD(6, 2, -2); RD(7, 1, -3);
+    RD(8, 0, -3); RD(9, -1, -3); RD(10, -2, -2); RD(11, -3, -1); RD(12, -3, 0); RD(13, -3, 1); RD(14, -2, 2); RD(15, -1, 3);
+#undef RD
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k] = inner3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) w[k] = inner3(t[k], t[(k + 3) & 15], t[(k + 6) & 15]);
+    short2v o[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) o[i] = outer3(w[3 * i], w[3 * i + 1], w[3 * i + 2]);
+    const short2v best = outer3(outer3(o[0], o[1], o[2]), outer3(o[3], o[4], w[15]), w[15]);
+    return DARK ? (V - best) : (best - V);
+}
+#else
 template <bool DARK>
 __device__ __forceinline__ short2v fast_score2(const uint8_t *c0, const uint8_t *c1, short2v V) {
     auto inner = [](short2v a, short2v b) { return DARK ? pkmax(a, b) : pkmin(a, b); };  // over the pixels of an arc
@@ -134,6 +169,7 @@ __device__ __forceinline__ short2v fast_score2(const uint8_t *c0, const uint8_t 
     for (int k = 0; k < 8; ++k) best = outer(best, inner(suf1[k], pre0[k]));
     return DARK ? (V - best) : (best - V);
 }
+#endif
 
 __global__ __launch_bounds__(256) void k_fast_nms(const Geo *__restrict__ geo_p, FrameSrc src0, const uint8_t *__restrict__ pyr,
                                                   uint32_t *__restrict__ cand_packed, int *__restrict__ cand_count, int total_blocks,

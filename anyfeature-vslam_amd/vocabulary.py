@@ -21,7 +21,11 @@ class Vocabulary:
         self.child_ptr = np.zeros(n + 1, np.int32)
         self.child_ptr[1:] = np.cumsum(counts)
         self.child_idx = np.ascontiguousarray(order, np.int32)
-        self.node_desc = np.ascontiguousarray(node_desc, np.uint8)
+        node_desc = np.asarray(node_desc)
+        # binary descriptors (uint8 rows: ORB32, AKAZE61, BRISK48 ...) or float ones (float32 rows of 64 / 128 / 256: SIFT128, SURF64, KAZE64,
+        # R2D2 - the non-binary cases of Vocabulary::transform, Vocabulary.cpp:158-187)
+        self.is_float = node_desc.dtype.kind == "f"
+        self.node_desc = np.ascontiguousarray(node_desc, np.float32 if self.is_float else np.uint8)
         self.weight = np.asarray(weight, np.float64)
         self.is_leaf = np.asarray(is_leaf, bool)
         # word ids are assigned to leaves in node order (loadFromTextFile)
@@ -68,8 +72,9 @@ class Vocabulary:
             from .extractor import Context
             self.ctx = self.ctx or Context()
             h = C.c_void_p()
-            rc = self.ctx.lib.afv_vocab_create(self.ctx.handle, self.k, self.L, len(self.weight), ptr(self.child_ptr), ptr(self.child_idx),
-                                               ptr(self.node_desc), self.node_desc.shape[1], C.byref(h))
+            create = self.ctx.lib.afv_vocab_create_f32 if self.is_float else self.ctx.lib.afv_vocab_create
+            rc = create(self.ctx.handle, self.k, self.L, len(self.weight), ptr(self.child_ptr), ptr(self.child_idx),
+                        ptr(self.node_desc), self.node_desc.shape[1], C.byref(h))
             self.ctx.check(rc, "afv_vocab_create")
             self._handle = h
             stopped = np.ascontiguousarray(~(self.weight > 0), np.uint8)   # DBoW2 transform: a word enters the vectors only if(w > 0)
@@ -84,11 +89,11 @@ class Vocabulary:
             self._handle = None
 
     def transform_nodes(self, descriptors, levelsup=4):
-        descriptors = np.ascontiguousarray(descriptors, np.uint8)
+        descriptors = np.ascontiguousarray(descriptors, np.float32 if self.is_float else np.uint8)
         n = len(descriptors)
         leaf = np.zeros(max(n, 1), np.int32); nid = np.zeros(max(n, 1), np.int32)
-        rc = self.ctx.lib.afv_bow_transform(self.ctx.handle, self._device(), ptr(descriptors), n, int(levelsup), ptr(leaf), ptr(nid)) \
-            if n else 0
+        fn = self.ctx.lib.afv_bow_transform_f32 if self.is_float else self.ctx.lib.afv_bow_transform
+        rc = fn(self.ctx.handle, self._device(), ptr(descriptors), n, int(levelsup), ptr(leaf), ptr(nid)) if n else 0
         if n == 0:
             self._device()
         self.ctx.check(rc, "afv_bow_transform")
@@ -117,6 +122,19 @@ class Vocabulary:
         return dict(sorted(bow.items())), sorted(fv.items())
 
     # ---- synthetic vocabulary for tests (no ORBvoc.txt offline) ----
+    @classmethod
+    def random_float(cls, seed, k=6, L=3, ctx=None, dim=128):
+        """a synthetic float vocabulary: node descriptors = non-negative unit vectors (SIFT-like)"""
+        v = cls.random(seed, k, L, None, desc_bytes=dim)
+        d = v.node_desc.astype(np.float32) ** 2
+        d[0] = 1.0
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        d[0] = 0.0
+        parent = np.zeros(len(v.weight), np.int32)
+        for p in range(len(v.weight)):
+            parent[v.child_idx[v.child_ptr[p]:v.child_ptr[p + 1]]] = p
+        return cls(k, L, parent, d.astype(np.float32), v.weight, v.is_leaf, ctx)
+
     @classmethod
     def random(cls, seed, k=6, L=3, ctx=None, desc_bytes=32):
         from .synth import lcg_bytes, lcg_states

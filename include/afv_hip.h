@@ -48,7 +48,7 @@ enum {
 /* ABI revision of this header.  It goes up whenever a record, an argument list or a limit changes incompatibly; a host built against
  * another revision must not call into the library (check once: afv_abi_version() == AFV_ABI_VERSION).
  *   5  (round 5) afv_proj_job / afv_tri_job / afv_table_tri_job start with struct_size; frame grids hold at most 8192 cells (was 65536)
- *   6  (round 6) afv_orb_detect / afv_orb_compute; afv_frame_params.desc_bytes; grids / frames whose one-workgroup build does not fit the
+ *   6  (round 6) afv_orb_detect / afv_orb_compute; afv_frame_params.desc_bytes; afv_vocab_create_f32 / afv_bow_transform_f32; grids / frames whose one-workgroup build does not fit the
  *      LDS are refused with AFV_EUNSUPPORTED at creation instead of failing at the first launch */
 #define AFV_ABI_VERSION 6
 int afv_abi_version(void);
@@ -378,6 +378,15 @@ int afv_vocab_create(afv_ctx *ctx, int k, int L, int nnodes, const int32_t *chil
 void afv_vocab_destroy(afv_ctx *ctx, afv_vocab *v);
 int afv_bow_transform(afv_ctx *ctx, const afv_vocab *v, const uint8_t *desc, int n, int levelsup, int32_t *leaf_node,
                       int32_t *node_at_level);
+
+/* The float cases of Vocabulary::transform (src/Vocabulary.cpp:158-187: SIFT128, SURF64, KAZE64, R2D2, any non-binary feature): node
+ * descriptors and features are `dim` floats (64, 128 or 256), the distance at a node is DBoW2's float-descriptor distance - squared
+ * differences evaluated in float, accumulated in double in index order (upstream FSurf64::distance; the reference's fork with the classes
+ * it instantiates is an empty submodule: parity unpinned) - first minimum wins.  Same tree arguments as afv_vocab_create; destroyed with
+ * afv_vocab_destroy; afv_bow_transform / afv_frame_bow_transform refuse a float vocabulary and afv_bow_transform_f32 a binary one. */
+int afv_vocab_create_f32(afv_ctx *ctx, int k, int L, int nnodes, const int32_t *child_ptr, const int32_t *child_idx, const float *desc, int dim,
+                         afv_vocab **out);
+int afv_bow_transform_f32(afv_ctx *ctx, const afv_vocab *v, const float *desc, int n, int levelsup, int32_t *leaf_node, int32_t *node_at_level);
 
 /* words the vocabulary stops (DBoW2 transform: a word whose weight is not > 0 enters neither the BowVector nor the FeatureVector):
  * stopped[nnodes] != 0 marks them; NULL = none (the default).  Only the device-built FeatureVector of afv_frame_bow_transform reads it. */

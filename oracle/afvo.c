@@ -1420,6 +1420,38 @@ int afvo_match_initialization(const afvo_proj_job *j, int32_t *match12) {
 /* ------------------------------------------------------------------------------------------------
  * BoW quantisation (DBoW2 transform, upstream semantics; parity unpinned)
  * ---------------------------------------------------------------------------------------------- */
+/* float descriptors (Vocabulary.cpp:158-187): DBoW2's float classes take the distance as the squared differences evaluated in float,
+ * accumulated in double in index order (upstream FSurf64::distance); first minimum wins.  v->desc = float[nnodes][dim], v->desc_bytes = 4 * dim. */
+void afvo_bow_transform_f32(const afvo_vocab *v, const float *desc, int n, int levelsup, int32_t *leaf_node, int32_t *node_at_level) {
+    const int nid_level = v->L - levelsup, dim = v->desc_bytes / 4;
+    const float *nd = (const float *)v->desc;
+    for (int i = 0; i < n; ++i) {
+        const float *f = desc + (size_t)i * dim;
+        int final_id = 0, level = 0, nid = 0;
+        while (v->child_ptr[final_id + 1] > v->child_ptr[final_id]) {
+            ++level;
+            const int b = v->child_ptr[final_id], e = v->child_ptr[final_id + 1];
+            int best = -1;
+            double best_d = 0.0;
+            for (int c = b; c < e; ++c) {
+                const int id = v->child_idx[c];
+                const float *g = nd + (size_t)id * dim;
+                double sqd = 0.0;
+                for (int t = 0; t < dim; ++t) {
+                    const float df = f[t] - g[t];
+                    const float sq = df * df;
+                    sqd += (double)sq;
+                }
+                if (best < 0 || sqd < best_d) { best_d = sqd; best = id; }
+            }
+            final_id = best;
+            if (level == nid_level) nid = final_id;
+        }
+        leaf_node[i] = final_id;
+        node_at_level[i] = nid_level <= 0 ? 0 : nid;
+    }
+}
+
 void afvo_bow_transform(const afvo_vocab *v, const uint8_t *desc, int n, int levelsup, int32_t *leaf_node, int32_t *node_at_level) {
     const int nid_level = v->L - levelsup;
     for (int i = 0; i < n; ++i) {

@@ -464,13 +464,14 @@ class Vocab(C.Structure):
 def bow_transform(vocab, desc, levelsup=4):
     """vocab: object with k, L, child_ptr, child_idx, node_desc (anyfeature-vslam_amd Vocabulary); returns (leaf node ids,
     node ids at depth L - levelsup)"""
-    desc = np.ascontiguousarray(desc, np.uint8)
+    is_float = vocab.node_desc.dtype.kind == "f"
+    desc = np.ascontiguousarray(desc, np.float32 if is_float else np.uint8)
     v = Vocab()
     v.k, v.L, v.nnodes = vocab.k, vocab.L, len(vocab.child_ptr) - 1
     v.child_ptr = _p(vocab.child_ptr); v.child_idx = _p(vocab.child_idx); v.desc = _p(vocab.node_desc)
-    v.desc_bytes = vocab.node_desc.shape[1]
+    v.desc_bytes = vocab.node_desc.shape[1] * (4 if is_float else 1)
     leaf = np.zeros(max(len(desc), 1), np.int32); nid = np.zeros(max(len(desc), 1), np.int32)
-    lib().afvo_bow_transform(C.byref(v), _p(desc), len(desc), int(levelsup), _p(leaf), _p(nid))
+    (lib().afvo_bow_transform_f32 if is_float else lib().afvo_bow_transform)(C.byref(v), _p(desc), len(desc), int(levelsup), _p(leaf), _p(nid))
     return leaf[:len(desc)].copy(), nid[:len(desc)].copy()
 
 

@@ -180,3 +180,51 @@ def test_bow_guided_matchers_on_other_descriptor_sizes(afv, oracle, gpu_ctx, nby
     finally:
         afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
     voc.close()
+
+
+# ---- float descriptors: the non-binary cases of Vocabulary::transform (Vocabulary.cpp:158-187: SIFT128, SURF64, KAZE64, R2D2) ----
+def _float_descriptors(afv, seed, n, dim):
+    d = afv.synth.lcg_bytes(seed, n * dim).reshape(n, dim).astype(np.float32) ** 2
+    return (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+
+
+@pytest.mark.parametrize("dim", [128, 64, 256])
+@pytest.mark.parametrize("k,L,levelsup", [(10, 3, 2), (4, 5, 4), (20, 2, 1)])
+def test_float_vocabulary_descent(afv, oracle, gpu_ctx, dim, k, L, levelsup):
+    """L2^2 descent (float differences and squares, double accumulation in index order: DBoW2's float descriptor classes), first minimum
+    wins; 20 children = two chunks of the 16-lane row"""
+    voc = afv.Vocabulary.random_float(31 + k, k=k, L=L, ctx=gpu_ctx, dim=dim)
+    desc = _float_descriptors(afv, 7, 1200, dim)
+    leaf, nid = voc.transform_nodes(desc, levelsup)
+    oleaf, onid = oracle.bow_transform(voc, desc, levelsup)
+    assert np.array_equal(leaf, oleaf) and np.array_equal(nid, onid) and np.all(voc.is_leaf[leaf])
+    assert len(np.unique(leaf)) > 100
+    # node descriptors find their own leaf; the vectors come out as for binary vocabularies
+    own = np.nonzero(voc.is_leaf)[0][:96]
+    assert np.array_equal(voc.transform_nodes(voc.node_desc[own], levelsup)[0], own)
+    bow, fv = voc.transform(desc, levelsup=levelsup)
+    assert abs(sum(bow.values()) - 1.0) < 1e-9 and [n for n, _ in fv] == sorted(n for n, _ in fv)
+    voc.close()
+
+
+def test_float_vocabulary_ties_and_kind_checks(afv, oracle, gpu_ctx):
+    voc = afv.Vocabulary.random_float(5, k=5, L=2, ctx=gpu_ctx, dim=128)
+    voc.node_desc[1:6] = voc.node_desc[3]           # all level-1 children identical: the first one wins
+    desc = _float_descriptors(afv, 9, 64, 128)
+    leaf, nid = voc.transform_nodes(desc, 1)
+    oleaf, onid = oracle.bow_transform(voc, desc, 1)
+    assert np.array_equal(leaf, oleaf) and np.array_equal(nid, onid) and np.all(nid == 1)
+    # a binary vocabulary refuses floats and the other way round (no silent reinterpretation of the bytes)
+    import ctypes as C
+    b = afv.Vocabulary.random(5, k=5, L=2, ctx=gpu_ctx)
+    out = np.zeros(64, np.int32)
+    assert gpu_ctx.lib.afv_bow_transform_f32(gpu_ctx.handle, b._device(), desc.ctypes.data, 64, 1, out.ctypes.data, out.ctypes.data) == afv._lib.EINVAL
+    assert gpu_ctx.lib.afv_bow_transform(gpu_ctx.handle, voc._device(), desc.ctypes.data, 64, 1, out.ctypes.data, out.ctypes.data) == afv._lib.EINVAL
+    h = C.c_void_p()
+    assert gpu_ctx.lib.afv_vocab_create_f32(gpu_ctx.handle, 5, 2, len(voc.weight), voc.child_ptr.ctypes.data, voc.child_idx.ctypes.data,
+                                            voc.node_desc.ctypes.data, 100, C.byref(h)) == afv._lib.EINVAL
+    fr = afv.Frame(gpu_ctx)
+    fr.extract(afv.synth.corners_frame(1))
+    with pytest.raises(afv._lib.AfvError):
+        fr.ComputeBoW(voc)
+    fr.close(); voc.close(); b.close()

@@ -443,6 +443,35 @@ def test_l2sqr(oracle):
 
 
 # ---------------- committed golden fixtures ----------------
+
+def test_float_vocabulary_descent_by_hand(oracle, afv):
+    """afvo_bow_transform_f32: squared differences in float, summed in double, first minimum wins - against an independent numpy descent
+    (checked wherever the best child leads the runner-up by more than the summation order could matter), and on a tie"""
+    voc = afv.Vocabulary.random_float(3, k=4, L=2, dim=64)
+    d = afv.synth.lcg_bytes(5, 50 * 64).reshape(50, 64).astype(np.float32) ** 2
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    leaf, nid = oracle.bow_transform(voc, d, 1)
+    checked = 0
+    for i in range(50):
+        node, level, clear = 0, 0, True
+        while voc.child_ptr[node + 1] > voc.child_ptr[node]:
+            ch = voc.child_idx[voc.child_ptr[node]:voc.child_ptr[node + 1]]
+            dist = ((d[i][None, :].astype(np.float64) - voc.node_desc[ch].astype(np.float64)) ** 2).sum(axis=1)
+            srt = np.sort(dist)
+            clear = clear and (srt[1] - srt[0] > 1e-6)
+            node = int(ch[np.argmin(dist)])
+            level += 1
+            if level == voc.L - 1 and clear:
+                assert nid[i] == node
+        if clear:
+            assert leaf[i] == node
+            checked += 1
+    assert checked > 40
+    voc.node_desc[1:5] = voc.node_desc[2]   # all level-1 children identical: the first one wins
+    leaf, nid = oracle.bow_transform(voc, d, 1)
+    assert np.all(nid == 1)
+
+
 @pytest.mark.parametrize("name", ["toy", "corners1", "corners2", "noise3"])
 def test_oracle_reproduces_golden(oracle, afv, gold, name):
     if name == "toy":
