@@ -1315,6 +1315,73 @@ extern "C" void afv_launch_match_topk(const uint8_t *desc, const int *nset, int 
 // ang: keypoint angles in degrees, element (set, i) at ang[(set * cap + i) * ang_stride] (stride 7 = afv_keypoint::angle)
 // test hook (process-wide, 0 = off): caps the passes of the fixed-point engines (k_match_resolve_wg, k_proj_resolve_wg, k_init_resolve_wg) so
 // that a test can drive them into their guard and check that the call reports it instead of returning a half-settled assignment
+// ---------------- MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:279-349), batched over map points ----------------
+// Per map point: the N x N Hamming distances of its N observed descriptors, per row the median = the floor(0.5 (N - 1))-th smallest
+// entry (the row sorted, MapPoint.cc:329-331; the self-distance 0 is part of the row), the row with the least median wins, first one on
+// ties (strict <, :333).  One wavefront per map point, lane = row (rows in chunks of 64); nothing is sorted or stored: the m-th smallest of a
+// row of integers in [0, 8 * bytes] is found by bisection on the VALUE - count(d < mid) against m - recomputing the row's distances in each
+// of the <= 10 steps (N = 20 observations: 10 x 20 x 8 xor + popcount per lane; the other rows' descriptors are the same address in all lanes).
+template <int W>
+__global__ __launch_bounds__(256) void k_distinctive(const uint32_t *__restrict__ desc, const int *__restrict__ set_ptr, int nsets, int max_dist,
+                                                     int *__restrict__ best_idx, int *__restrict__ best_median) {
+    const int s = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (s >= nsets) return;  // wave-uniform
+    const int b = set_ptr[s], n = set_ptr[s + 1] - b;
+    if (n <= 0) {
+        if (lane == 0) {
+            best_idx[s] = -1;
+            best_median[s] = 0;
+        }
+        return;
+    }
+    const int m = (n - 1) >> 1;  // vDists[0.5 * (N - 1)]
+    unsigned best = 0xffffffffu;  // median << 16 | row
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        uint32_t q[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) q[w] = desc[(size_t)(b + min(i, n - 1)) * W + w];
+        // smallest v with count(d <= v) > m  <=>  the m-th smallest (0-based) value
+        int lo = 0, hi = max_dist;  // answer in [lo, hi]
+        while (__any(lo < hi)) {
+            const int mid = (lo + hi) >> 1;
+            int cnt = 0;  // #{j : d(i, j) <= mid}
+            for (int j = 0; j < n; ++j) {
+                const uint32_t *r = desc + (size_t)(b + j) * W;
+                int d = 0;
+#pragma unroll
+                for (int w = 0; w < W; ++w) d += __popc(q[w] ^ r[w]);
+                cnt += d <= mid;
+            }
+            if (lo < hi) {
+                if (cnt > m) hi = mid;
+                else lo = mid + 1;
+            }
+        }
+        if (i < n) best = min(best, ((unsigned)lo << 16) | (unsigned)i);
+    }
+    // wave minimum of (median, row): the least median, the first row on ties
+    best = min(best, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)best, 0x111, 0xf, 0xf, false));
+    best = min(best, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)best, 0x112, 0xf, 0xf, false));
+    best = min(best, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)best, 0x114, 0xf, 0xf, false));
+    best = min(best, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)best, 0x118, 0xf, 0xf, false));
+    best = min(best, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)best, 0x142, 0xa, 0xf, false));
+    best = min(best, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)best, 0x143, 0xc, 0xf, false));
+    const unsigned g = (unsigned)__builtin_amdgcn_readlane((int)best, 63);
+    if (lane == 0) {
+        best_idx[s] = (int)(g & 0xffffu);
+        best_median[s] = (int)(g >> 16);
+    }
+}
+
+extern "C" void afv_launch_distinctive(const uint32_t *desc, const int *set_ptr, int nsets, int words, int desc_bytes, int *best_idx, int *best_median,
+                                       hipStream_t stream) {
+    if (nsets <= 0) return;
+    const dim3 grid((nsets + 3) / 4);
+    if (words == 8) hipLaunchKernelGGL(k_distinctive<8>, grid, dim3(256), 0, stream, desc, set_ptr, nsets, 8 * desc_bytes, best_idx, best_median);
+    else hipLaunchKernelGGL(k_distinctive<16>, grid, dim3(256), 0, stream, desc, set_ptr, nsets, 8 * desc_bytes, best_idx, best_median);
+}
+
 extern "C" int afv_debug_pass_cap = 0;
 
 // once per context (afv_create, on the context's device): both ordered-phase kernels may ask for more dynamic LDS than the default 64 KB

@@ -19,6 +19,19 @@ def DescriptorDistance_orb32(a, b):
     return float(_lib.load().afv_hamming256(ptr(a), ptr(b)))
 
 
+def ComputeDistinctiveDescriptors(ctx, descriptor_sets):
+    """MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:279-349) for a batch of map points: descriptor_sets = one [N_s, bytes] uint8 array per
+    map point (the descriptors of its observations, in observation order); returns (best index per set | -1 for an empty one, its median)"""
+    sets = [np.ascontiguousarray(d, np.uint8).reshape(len(d), -1) for d in descriptor_sets]
+    nbytes = next((d.shape[1] for d in sets if len(d)), 32)
+    ptrs = np.zeros(len(sets) + 1, np.int32)
+    ptrs[1:] = np.cumsum([len(d) for d in sets])
+    flat = np.ascontiguousarray(np.concatenate([d.reshape(-1, nbytes) for d in sets]) if sets and ptrs[-1] else np.zeros((0, nbytes), np.uint8))
+    best = np.zeros(max(len(sets), 1), np.int32); med = np.zeros(max(len(sets), 1), np.int32)
+    ctx.check(ctx.lib.afv_distinctive_descriptors(ctx.handle, ptr(flat), nbytes, ptr(ptrs), len(sets), ptr(best), ptr(med)), "afv_distinctive_descriptors")
+    return best[:len(sets)].copy(), med[:len(sets)].copy()
+
+
 class FeatureView:
     """Flattened view of one KeyFrame / Frame for matching.
 

@@ -379,6 +379,15 @@ void afv_vocab_destroy(afv_ctx *ctx, afv_vocab *v);
 int afv_bow_transform(afv_ctx *ctx, const afv_vocab *v, const uint8_t *desc, int n, int levelsup, int32_t *leaf_node,
                       int32_t *node_at_level);
 
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:279-349) for a batch of map points - the one M1 (DescriptorDistance) call site
+ * of the reference that had no device form (LocalMapping calls it per created / fused point).  Map point s observes the
+ * descriptors desc[set_ptr[s] .. set_ptr[s + 1]) (rows of desc_bytes, host memory, <= 65535 per point); best_idx[s] = the row (index
+ * INSIDE the set) with the least median distance to the others - the median as the reference takes it: the floor(0.5 (N - 1))-th entry
+ * of the sorted row of the N x N matrix, the zero self-distance included; the first row wins ties - or -1 for an empty set;
+ * best_median[s] (may be NULL) = that median.  Binary descriptors. */
+int afv_distinctive_descriptors(afv_ctx *ctx, const uint8_t *desc, int desc_bytes, const int32_t *set_ptr, int nsets, int32_t *best_idx,
+                                int32_t *best_median);
+
 /* The float cases of Vocabulary::transform (src/Vocabulary.cpp:158-187: SIFT128, SURF64, KAZE64, R2D2, any non-binary feature): node
  * descriptors and features are `dim` floats (64, 128 or 256), the distance at a node is DBoW2's float-descriptor distance - squared
  * differences evaluated in float, accumulated in double in index order (upstream FSurf64::distance; the reference's fork with the classes

@@ -1420,6 +1420,32 @@ int afvo_match_initialization(const afvo_proj_job *j, int32_t *match12) {
 /* ------------------------------------------------------------------------------------------------
  * BoW quantisation (DBoW2 transform, upstream semantics; parity unpinned)
  * ---------------------------------------------------------------------------------------------- */
+/* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:279-349): N x N distances, per row the sorted row's entry 0.5 * (N - 1), least median
+ * wins (strict <: the first row on ties).  Returns the row, *median_out its median; -1 for n = 0. */
+static int cmp_int(const void *a, const void *b) { return *(const int *)a - *(const int *)b; }
+int afvo_distinctive_descriptor(const uint8_t *desc, int n, int desc_bytes, int *median_out) {
+    if (n <= 0) { if (median_out) *median_out = 0; return -1; }
+    int *D = (int *)malloc(sizeof(int) * (size_t)n * n), *row = (int *)malloc(sizeof(int) * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        D[(size_t)i * n + i] = 0;
+        for (int j = i + 1; j < n; ++j) {
+            const int d = desc_bytes == 32 ? afvo_hamming256(desc + (size_t)i * 32, desc + (size_t)j * 32)
+                                           : afvo_hamming_bytes(desc + (size_t)i * desc_bytes, desc + (size_t)j * desc_bytes, desc_bytes);
+            D[(size_t)i * n + j] = D[(size_t)j * n + i] = d;
+        }
+    }
+    int best = 0, best_median = 0x7fffffff;
+    for (int i = 0; i < n; ++i) {
+        memcpy(row, D + (size_t)i * n, sizeof(int) * (size_t)n);
+        qsort(row, (size_t)n, sizeof(int), cmp_int);
+        const int median = row[(size_t)(0.5 * (n - 1))];
+        if (median < best_median) { best_median = median; best = i; }
+    }
+    free(D); free(row);
+    if (median_out) *median_out = best_median;
+    return best;
+}
+
 /* float descriptors (Vocabulary.cpp:158-187): DBoW2's float classes take the distance as the squared differences evaluated in float,
  * accumulated in double in index order (upstream FSurf64::distance); first minimum wins.  v->desc = float[nnodes][dim], v->desc_bytes = 4 * dim. */
 void afvo_bow_transform_f32(const afvo_vocab *v, const float *desc, int n, int levelsup, int32_t *leaf_node, int32_t *node_at_level) {

@@ -475,6 +475,14 @@ def bow_transform(vocab, desc, levelsup=4):
     return leaf[:len(desc)].copy(), nid[:len(desc)].copy()
 
 
+def distinctive_descriptor(desc):
+    """MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:279-349) of one map point: (best row | -1, its median)"""
+    desc = np.ascontiguousarray(desc, np.uint8)
+    desc = desc.reshape(len(desc), -1) if len(desc) else desc.reshape(0, 32)
+    med = C.c_int(0)
+    return lib().afvo_distinctive_descriptor(_p(desc), len(desc), desc.shape[1], C.byref(med)), med.value
+
+
 def match_initialization(F2, Q1, th_low=75.0, nnratio=0.9, check_orientation=True):
     j = _proj_job(F2, Q1, th_low, nnratio, check_orientation, False)
     out = np.zeros(max(Q1.n, 1), np.int32)

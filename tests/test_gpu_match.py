@@ -697,3 +697,27 @@ def test_fixed_point_guard_is_reported_not_swallowed(afv, oracle, gpu_ctx):
     assert n == wn and np.array_equal(got, want)
     got, n = m.SearchByProjection(F, Q, last_frame=True)
     assert n == pn and np.array_equal(got, pw)
+
+
+@pytest.mark.parametrize("nbytes", [32, 61])
+def test_distinctive_descriptors_of_map_points(afv, oracle, gpu_ctx, nbytes):
+    """MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:279-349) for a batch of map points: set sizes 0 .. 200 (more than one 64-row
+    chunk), clusters (ties between medians: the first row wins), identical descriptors, one observation"""
+    s = afv.synth
+    sizes = [0, 1, 2, 3, 4, 5, 7, 8, 13, 20, 33, 63, 64, 65, 100, 129, 200] + [int(v % 12) + 2 for v in s.lcg_states(3, 120)]
+    sets = []
+    for k, n in enumerate(sizes):
+        proto = s.lcg_bytes(100 + k, 3 * nbytes).reshape(3, nbytes)
+        d = proto[s.lcg_states(200 + k, max(n, 1)) % 3][:n].copy()
+        if n:
+            flip = s.lcg_states(300 + k, n)
+            d[np.arange(n), flip % nbytes] ^= (1 << (flip // 7 % 8)).astype(np.uint8) * (flip % 3 != 0)   # a third stay exact copies: ties
+        sets.append(d)
+    sets.append(np.tile(s.lcg_bytes(9, nbytes), (10, 1)))   # ten identical observations: every median 0, row 0 wins
+    best, med = afv.ComputeDistinctiveDescriptors(gpu_ctx, sets)
+    for k, d in enumerate(sets):
+        wi, wm = oracle.distinctive_descriptor(d)
+        assert best[k] == wi and (wi < 0 or med[k] == wm), (k, len(d), best[k], wi, med[k], wm)
+    assert best[0] == -1 and best[1] == 0 and best[-1] == 0 and med[-1] == 0
+    b0, _ = afv.ComputeDistinctiveDescriptors(gpu_ctx, [])
+    assert len(b0) == 0

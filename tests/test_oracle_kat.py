@@ -625,3 +625,19 @@ def test_oracle_binding_mirrors_match_afvo_h(tmp_path):
     got = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True, timeout=60).stdout.splitlines())
     for cname, st in pairs:
         assert int(got[cname]) == C.sizeof(st), (cname, got[cname], C.sizeof(st))
+
+
+def test_distinctive_descriptor_by_hand(oracle):
+    """MapPoint.cc:279-349: three descriptors at distances d01 = 8, d02 = 24, d12 = 16: rows sorted (0, 8, 24), (0, 8, 16), (0, 16, 24),
+    medians (entry 0.5 * 2 = 1) 8, 8, 16 -> row 0 (the first of the tie); four: entry 0.5 * 3 = 1 (the LOWER middle)"""
+    d = np.zeros((3, 32), np.uint8)
+    d[1, 0] = 0xFF
+    d[2, 0] = 0xFF; d[2, 1] = 0xFF; d[2, 2] = 0xFF
+    assert oracle.distinctive_descriptor(d) == (0, 8)
+    assert oracle.distinctive_descriptor(d[::-1].copy()) == (1, 8)      # rows (0,16,24), (0,8,16), (0,8,24): medians 16, 8, 8
+    four = np.zeros((4, 32), np.uint8)
+    four[1, 0] = 0x01; four[2, 0] = 0x03; four[3, 0] = 0xFF             # distances from row 0: 1, 2, 8
+    idx, med = oracle.distinctive_descriptor(four)
+    assert med == 1 and idx == 0
+    assert oracle.distinctive_descriptor(np.zeros((0, 32), np.uint8))[0] == -1
+    assert oracle.distinctive_descriptor(np.zeros((1, 32), np.uint8)) == (0, 0)
