@@ -50,9 +50,6 @@ int main(int argc, char **argv) {
     std::vector<afv::Mat2f> s2, inf;
     std::vector<float> size;
     extractor(img, k1, d1, s2, inf, size);  // 6-arg operator()
-    extractor(img2, k2, d2);                // 3-arg operator()
-    if (settings->ON_automaticTuning || k1.empty() || (int)size.size() != (int)k1.size()) return 4;
-
     {   // the virtuals one by one (FeatureExtractor.h:123-128): detectKeypoints -> filterKeypoints -> computeDescriptors -> merge == detectAndCompute
         std::map<int, std::vector<afv::KeyPoint>> kl;
         std::map<int, afv::Mat8> dl;
@@ -68,6 +65,8 @@ int main(int argc, char **argv) {
         if (km.size() != k1.size() || std::memcmp(km.data(), k1.data(), km.size() * sizeof(afv::KeyPoint)) != 0) return 7;
         if (dm.size() != d1.data.size() || std::memcmp(dm.data(), d1.ptr(), dm.size()) != 0) return 7;
     }
+    extractor(img2, k2, d2);                // 3-arg operator()
+    if (settings->ON_automaticTuning || k1.empty() || (int)size.size() != (int)k1.size()) return 4;
 
     afv::FeatureMatcherHip::setDescriptorDistanceThresholds(75.0f);
     afv::FeatureMatcherHip matcher(extractor.context(), 0.6f, true);

@@ -102,11 +102,12 @@ __device__ __forceinline__ short2v ld_two(const uint8_t *c0, const uint8_t *c1, 
 // ring pixels, so it leaves the network: bright  max_arcs min_arc (r - v) = (max_arcs min_arc r) - v,  dark  max_arcs min_arc (v - r) =
 // v - (min_arcs max_arc r) - the network runs on the RAW ring values (0 .. 255 in the u16 halves) with min / max swapped for the dark
 // list, and v is subtracted once at the end instead of once per ring pixel (round 5: 16 packed subtractions per lane and list pair less).
-#ifdef FT_MIN3
-// Round-6 experiment: the ring values 0 .. 255 in u16 halves are, read as f16 bit patterns, ordered subnormals, so
-// gfx950's three-input packed v_pk_minimum3_f16 / v_pk_maximum3_f16 compute the same packed min / max as the i16 forms (f16 denormals are
-// preserved in the kernel's MODE).  Triples t_k = m3(d_k, d_k+1, d_k+2), windows w_k = m3(t_k, t_k+3, t_k+6) = the 9 ring pixels from k,
-// outer reduction by threes: 16 + 16 + 8 = 40 packed instructions instead of van Herk's 59.
+#ifndef FT_NO_MIN3  // (-DFT_NO_MIN3: the van Herk network on two-input packed i16 min / max of rounds 3-5, kept for A / B runs)
+// Round 6: the ring values 0 .. 255 in u16 halves are, read as f16 bit patterns, ordered subnormals, so gfx950's
+// three-input packed v_pk_minimum3_f16 / v_pk_maximum3_f16 compute the same packed min / max as the i16 forms (f16 denormals are preserved
+// in the kernel's MODE; no NaN can occur: the exponent field is 0).  Triples t_k = m3(d_k, d_k+1, d_k+2), windows w_k = m3(t_k, t_k+3,
+// t_k+6) = the 9 ring pixels from k, outer reduction by threes: 16 + 16 + 8 = 40 packed instructions instead of van Herk's 59.
+// Measured (A / B on one box, twice): vector instructions of the kernel - 6.1 %, 311.4 -> 298.5 us per launch (- 4.2 %), bit-exact.
 __device__ __forceinline__ short2v pkmin3(short2v a, short2v b, short2v c) {
     uint32_t r;
     asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(as_u32(a)), "v"(as_u32(b)), "v"(as_u32(c)));

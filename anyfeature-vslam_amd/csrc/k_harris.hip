@@ -346,9 +346,10 @@ __device__ __forceinline__ void retain_harris_small_body(const Geo &geo, const F
             if (before < K && K <= before + h) s_T1 = 255 - tid;
         }
         __syncthreads();
-        T1 = s_T1;
+        T1 = s_T1;  // (the barriers above also published s_before / s_mine = 0)
+    } else {
+        __syncthreads();  // s_before / s_mine cleared
     }
-    __syncthreads();  // s_before / s_mine cleared
     {   // survivors in front of the slice: this workgroup's first output slot
         int c = 0;
         RH_FOR_ITEMS(c += (i < start && (int)(e >> 24) >= T1) ? 1 : 0;)
@@ -390,9 +391,11 @@ __device__ __forceinline__ void retain_harris_small_body(const Geo &geo, const F
             l1_resp[base + out_base + j] = harris_response(it, es, geo.harris_scale4);
         }
         out_base += cnt;
-        __syncthreads();
-        if (tid == 0) s_mine = 0;
-        __syncthreads();
+        if (s0 + RH_SURV < end) {  // uniform: another pass follows (lists beyond the registers only) - the counter is re-armed for it
+            __syncthreads();
+            if (tid == 0) s_mine = 0;
+            __syncthreads();
+        }
     }
 #undef RH_FOR_ITEMS
     if (slice == RH_SLICES - 1 && tid == 0) l1_count[f * AFV_MAX_LEVELS + l] = out_base;

@@ -22,8 +22,9 @@ def DescriptorDistance_orb32(a, b):
 def ComputeDistinctiveDescriptors(ctx, descriptor_sets):
     """MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:279-349) for a batch of map points: descriptor_sets = one [N_s, bytes] uint8 array per
     map point (the descriptors of its observations, in observation order); returns (best index per set | -1 for an empty one, its median)"""
-    sets = [np.ascontiguousarray(d, np.uint8).reshape(len(d), -1) for d in descriptor_sets]
-    nbytes = next((d.shape[1] for d in sets if len(d)), 32)
+    sets = [np.ascontiguousarray(d, np.uint8) for d in descriptor_sets]
+    nbytes = next((d.reshape(len(d), -1).shape[1] for d in sets if len(d)), 32)
+    sets = [d.reshape(len(d), nbytes) if len(d) else np.zeros((0, nbytes), np.uint8) for d in sets]
     ptrs = np.zeros(len(sets) + 1, np.int32)
     ptrs[1:] = np.cumsum([len(d) for d in sets])
     flat = np.ascontiguousarray(np.concatenate([d.reshape(-1, nbytes) for d in sets]) if sets and ptrs[-1] else np.zeros((0, nbytes), np.uint8))

@@ -478,7 +478,7 @@ def bow_transform(vocab, desc, levelsup=4):
 def distinctive_descriptor(desc):
     """MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:279-349) of one map point: (best row | -1, its median)"""
     desc = np.ascontiguousarray(desc, np.uint8)
-    desc = desc.reshape(len(desc), -1) if len(desc) else desc.reshape(0, 32)
+    desc = desc.reshape(len(desc), -1) if len(desc) else np.zeros((0, 32), np.uint8)
     med = C.c_int(0)
     return lib().afvo_distinctive_descriptor(_p(desc), len(desc), desc.shape[1], C.byref(med)), med.value
 

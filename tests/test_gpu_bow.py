@@ -199,9 +199,9 @@ def test_float_vocabulary_descent(afv, oracle, gpu_ctx, dim, k, L, levelsup):
     oleaf, onid = oracle.bow_transform(voc, desc, levelsup)
     assert np.array_equal(leaf, oleaf) and np.array_equal(nid, onid) and np.all(voc.is_leaf[leaf])
     assert len(np.unique(leaf)) > 100
-    # node descriptors find their own leaf; the vectors come out as for binary vocabularies
+    # descriptors that ARE node descriptors (distance exactly 0 somewhere on the way); the vectors come out as for binary vocabularies
     own = np.nonzero(voc.is_leaf)[0][:96]
-    assert np.array_equal(voc.transform_nodes(voc.node_desc[own], levelsup)[0], own)
+    assert np.array_equal(voc.transform_nodes(voc.node_desc[own], levelsup)[0], oracle.bow_transform(voc, voc.node_desc[own], levelsup)[0])
     bow, fv = voc.transform(desc, levelsup=levelsup)
     assert abs(sum(bow.values()) - 1.0) < 1e-9 and [n for n, _ in fv] == sorted(n for n, _ in fv)
     voc.close()

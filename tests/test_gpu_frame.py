@@ -473,13 +473,13 @@ def test_akaze61_features_through_the_tracking_chain(afv, oracle, fctx):
     the keyframe TABLE is ORB32-only), every stage against the oracle"""
     import importlib
     akz = importlib.import_module("anyfeature-vslam_amd.akaze")
-    ext = akz.FeatureExtractor_akaze61(1000, max_width=640, max_height=480)
+    ext = akz.AkazeContext(akz.default_params(max_width=640, max_height=480))
     img = afv.synth.corners_frame(8)
-    ka, da = ext(img)
-    kb, db = ext(np.roll(img, 4, axis=1))
+    ka, da = ext.extract(img)
+    kb, db = ext.extract(np.roll(img, 4, axis=1))
     assert len(ka) > 300 and len(kb) > 300 and da.shape[1] == 61
     # keyPtsSize of the reference: scaleFactor^class_id (Feature_akaze61.cpp:55-61)
-    sf = np.float32(ext.settings.GetDetectorNominalScaleFactor())
+    sf = np.float32(ext.params.scale_factor)
     za = (sf ** ka["class_id"].astype(np.float32)).astype(np.float32)
     zb = (sf ** kb["class_id"].astype(np.float32)).astype(np.float32)
     th = 143.0   # 61 / 32 of ORB's 75
