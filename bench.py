@@ -866,6 +866,54 @@ def extra_akaze61(afv, device, B=64, steps=3):
     return out
 
 
+def extra_tracking_frame_akaze61(afv, device, reps=50):
+    """the tracking chain of DESIGN.md section 7 on AKAZE61 features: afv_akaze_extract (640 x 480) -> resident 61-byte frame
+    (afv_frame_set_features) -> Frame::ComputeBoW on a 61-byte vocabulary (k = 10, L = 4) -> SearchByProjection(cur, last); every stage a
+    synchronous call with host results, timed from Python (the ORB32 chain's figures come from the C++ probe: these carry ~10 us of ctypes / numpy
+    per call on top)"""
+    import numpy as np
+    akz = afv.akaze
+    ext = akz.AkazeContext(akz.default_params(max_width=640, max_height=480), device)
+    ctx = afv.Context(device=device)
+    img = afv.synth.corners_frame(8)
+    prev_img = np.roll(img, 4, axis=1)
+    ka, da = ext.extract(prev_img)
+    sf = np.float32(ext.params.scale_factor)
+    za = (sf ** ka["class_id"].astype(np.float32)).astype(np.float32)
+    voc = afv.Vocabulary.random(9, k=10, L=4, ctx=ctx, desc_bytes=61)
+    cur = afv.Frame(ctx, desc_bytes=61)
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(143.0)
+    m = afv.FeatureMatcher(0.9, True, ctx=ctx)
+    Q = afv.ProjectionQueries(da, ka["x"] - np.float32(4), ka["y"], np.float32(15) * za, za / sf, za * sf, angles=ka["angle"])
+    t = {"akaze_extract_us": 0.0, "frame_set_features_us": 0.0, "frame_bow_transform_us": 0.0, "frame_projection_lastframe_us": 0.0}
+    nm = 0
+    for it in range(reps + 5):
+        t0 = time.perf_counter()
+        kb, db = ext.extract(img)
+        t1 = time.perf_counter()
+        zb = (sf ** kb["class_id"].astype(np.float32)).astype(np.float32)
+        t1b = time.perf_counter()
+        cur.set_features(kb, db, sizes=zb)
+        t2 = time.perf_counter()
+        cur.ComputeBoW(voc, levelsup=2)
+        t3 = time.perf_counter()
+        _, nm = cur.SearchByProjection(m, Q, last_frame=True)
+        t4 = time.perf_counter()
+        if it >= 5:
+            t["akaze_extract_us"] += (t1 - t0) * 1e6 / reps
+            t["frame_set_features_us"] += (t2 - t1b) * 1e6 / reps
+            t["frame_bow_transform_us"] += (t3 - t2) * 1e6 / reps
+            t["frame_projection_lastframe_us"] += (t4 - t3) * 1e6 / reps
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+    out = dict(t)
+    out["chain_us"] = sum(t.values())
+    out["keypoints"] = int(len(ka))
+    out["matches"] = int(nm)
+    out["stages"] = "afv_akaze_extract 640x480 -> afv_frame_set_features (61-byte rows) -> ComputeBoW (k = 10, L = 4, 61-byte words) -> SearchByProjection(cur, last)"
+    cur.close(); voc.close(); ctx.close(); ext.close()
+    return out
+
+
 def akaze_single_frame():
     """FeatureExtractor_akaze61::detectAndCompute for ONE 1280 x 720 frame per call, host to host through the C-ABI (tools/akaze_latency.cpp):
     the reference's per-frame operator() (FeatureExtractor.cpp:111-121)"""
@@ -1298,7 +1346,8 @@ def main():
                     out.update(tk)
             except Exception as e:
                 out["host_api"] = {"error": str(e)[:200]}
-            for key, fn in (("single_frame", extra_single_frame), ("pairs10k", extra_pairs10k), ("l2_sift128", extra_l2_sift128), ("akaze61", extra_akaze61)):
+            for key, fn in (("single_frame", extra_single_frame), ("pairs10k", extra_pairs10k), ("l2_sift128", extra_l2_sift128), ("akaze61", extra_akaze61),
+                            ("tracking_frame_akaze61", extra_tracking_frame_akaze61)):
                 try:
                     out[key] = fn(afv, local)
                 except Exception as e:  # a secondary figure must never cost the headline line

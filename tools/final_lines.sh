@@ -32,4 +32,12 @@ done
 ./tools/akaze_recip_check > "$OUT/akaze_recip_check.txt" 2>&1
 python tools/overlap_trace.py 2 > "$OUT/overlap_trace.txt" 2>/dev/null
 python tools/probes/probe_resolve_pair.py 2>/dev/null | grep "^pairs" > "$OUT/resolve_pairs.txt"
+# round 6: the instruction fault's reproducer, the stress scenes and the poison differential on the final sources
+hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize tools/probes/probe_pk_real.hip -Iinclude -Lanyfeature-vslam_amd -lafv_hip -Wl,-rpath,$ROOT/anyfeature-vslam_amd \
+    -lpthread -o /tmp/probe_pk_real 2>/dev/null && /tmp/probe_pk_real 4 single > "$OUT/probe_pk_real_single_instructions.txt" 2>&1
+/tmp/probe_pk_real 4 2>&1 | head -4 > "$OUT/probe_pk_real_forms.txt"
+python tools/stress_threads.py --rounds 400 --roles emm 2>&1 | tail -1 > "$OUT/stress_threads.txt"
+python tools/stress_threads.py --rounds 400 --roles mmm 2>&1 | tail -1 >> "$OUT/stress_threads.txt"
+python tools/stress_threads.py --rounds 400 2>&1 | tail -1 >> "$OUT/stress_threads.txt"
+python tools/poison_build.py > /dev/null 2>&1; bash tools/poison_suite.sh 60 > "$OUT/poison_suite.txt" 2>&1
 ls -la "$OUT"
