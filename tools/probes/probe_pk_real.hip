@@ -49,6 +49,22 @@ __global__ __launch_bounds__(256) void k_victim(const float4 *__restrict__ table
                 const f32x2 xs = {x0, x1}, ys = {y0, y1};
                 const f32x2 X = xs * f32x2{ca, ca} + ys * f32x2{-sb, -sb} + rmag, Y = xs * f32x2{sb, sb} + ys * f32x2{ca, ca} + rmag;
                 ix0 = __float_as_int(X.x) + kox; ix1 = __float_as_int(X.y) + kox; iy0 = __float_as_int(Y.x) + kox; iy1 = __float_as_int(Y.y) + kox;
+            } else if (MODE >= 16) {
+                // packed 16-bit forms the kernels rely on (k_fast_nms: v_pk_minimum3_f16 / v_pk_maximum3_f16 on u16 values 0 .. 255, v_pk_min_i16,
+                // v_pk_sub_i16; k_harris: v_pk_mul_lo_u16 / v_pk_add_u16): result against the scalar evaluation of the same selection
+                const unsigned a = (unsigned)(int)x0 & 0xffu, bb = (unsigned)(int)y0 & 0xffu, c = (unsigned)(int)x1 & 0xffu, d = (unsigned)(int)y1 & 0xffu;
+                const unsigned pa = a | (bb << 16), pb = c | (d << 16), pc = d | (a << 16);
+                unsigned o, e;
+                auto mn = [](unsigned u, unsigned v) { return u < v ? u : v; };
+                auto mx = [](unsigned u, unsigned v) { return u > v ? u : v; };
+                if (MODE == 16) { asm volatile("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(o) : "v"(pa), "v"(pb), "v"(pc)); e = mn(mn(a, c), d) | (mn(mn(bb, d), a) << 16); }
+                else if (MODE == 17) { asm volatile("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(o) : "v"(pa), "v"(pb), "v"(pc)); e = mx(mx(a, c), d) | (mx(mx(bb, d), a) << 16); }
+                else if (MODE == 18) { asm volatile("v_pk_min_i16 %0, %1, %2" : "=v"(o) : "v"(pa), "v"(pb)); e = mn(a, c) | (mn(bb, d) << 16); }
+                else if (MODE == 19) { asm volatile("v_pk_sub_i16 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(o) : "v"(pa), "v"(pb)); e = ((bb - c) & 0xffffu) | (((a - d) & 0xffffu) << 16); }
+                else { asm volatile("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(o) : "v"(pa), "v"(pb), "v"(pc)); e = ((a * c + d) & 0xffffu) | (((bb * d + a) & 0xffffu) << 16); }
+                asm volatile("" : "+v"(e));
+                b[g] += o != e ? 1u : 0u;
+                continue;
             } else if (MODE >= 9) {
                 // single instructions: which forms are hit?  result (o0, o1) against what the same selection gives with v_mov / plain ops
                 float o0, o1, e0, e1;
@@ -190,6 +206,13 @@ int main(int argc, char **argv) {
         run<13>("v_pk_mul_f32 op_sel_hi:[0,1]", d_table, d_bad, s, seconds, true);
         run<14>("v_pk_mul_f32 (no selection)", d_table, d_bad, s, seconds, true);
         run<15>("v_pk_add_f32 op_sel_hi:[1,0]", d_table, d_bad, s, seconds, true);
+        run<16>("v_pk_minimum3_f16 (u16 values 0..255)", d_table, d_bad, s, seconds, true);
+        run<17>("v_pk_maximum3_f16", d_table, d_bad, s, seconds, true);
+        run<18>("v_pk_min_i16", d_table, d_bad, s, seconds, true);
+        run<19>("v_pk_sub_i16 op_sel:[1,0] op_sel_hi:[0,1]", d_table, d_bad, s, seconds, true);
+        run<20>("v_pk_mad_u16", d_table, d_bad, s, seconds, true);
+        run<16>("v_pk_minimum3_f16 (u16 values 0..255)", d_table, d_bad, s, 2.0, false);
+        run<19>("v_pk_sub_i16 op_sel:[1,0] op_sel_hi:[0,1]", d_table, d_bad, s, 2.0, false);
         run<9>("v_pk_mov_b32 op_sel:[0,1] (64-bit copy)", d_table, d_bad, s, 2.0, false);
         run<12>("v_pk_mul_f32 op_sel:[0,1]", d_table, d_bad, s, 2.0, false);
         return 0;
