@@ -43,7 +43,13 @@ def main():
         m = afv.FeatureMatcher(0.7, True, ctx=serial)
         want.append((k1, d1, k2, d2, m.SearchByBoW(afv.FeatureView(d1, angles=k1["angle"]), afv.FeatureView(d2, angles=k2["angle"]))))
     lock = threading.Lock()
-    stats = {"calls": 0, "bad_rows": 0, "bad_kps": 0, "bad_match": 0, "bad_count": 0}
+    stats = {"calls": 0, "bad_rows": 0, "bad_kps": 0, "bad_match": 0, "bad_count": 0, "bad_akaze": 0}
+    akz_want = None
+    if args.roles and "a" in args.roles:  # role a: AKAZE61 extraction (its kernels carried ~1200 packed-fp32 instructions with op_sel before round 6)
+        akz = importlib.import_module("anyfeature-vslam_amd.akaze")
+        a0 = akz.AkazeContext(akz.default_params(max_width=640, max_height=480))
+        akz_want = [a0.extract(im) for im in imgs]
+        a0.close()
     ctxs = [afv.Context() for _ in range(nt)] if args.keep_contexts else None
 
     def check(i, which, k, d, wk, wd, rnd):
@@ -83,6 +89,22 @@ def main():
             ctx.set_small_batch_path(args.small)
         role = (args.roles or "b" * nt)[i]
         m = afv.FeatureMatcher(0.7, True, ctx=ctx)
+        if role == "a":
+            actx = akz.AkazeContext(akz.default_params(max_width=640, max_height=480))
+            for _ in range(args.iters):
+                k, d = actx.extract(imgs[i])
+                wk, wd = akz_want[i]
+                if k.tobytes() != wk.tobytes() or not np.array_equal(d, wd):
+                    with lock:
+                        stats["bad_akaze"] += 1
+                        rows = np.nonzero((d != wd).any(axis=1))[0][:8].tolist() if d.shape == wd.shape else None
+                        print("thread %d round %d: AKAZE61 extraction differs (counts %d / %d, descriptor rows %s)" % (i, rnd, len(k), len(wk), rows), flush=True)
+                with lock:
+                    stats["calls"] += 1
+            actx.close()
+            if not ctxs:
+                ctx.close()
+            return
         rolled = np.roll(imgs[i], 3, axis=1)
         for _ in range(args.iters):
             if role in "eb":
