@@ -12,7 +12,7 @@ mkdir -p "$OUT" "$RAW"
 cd /tmp && export TMPDIR=/tmp
 PY=python
 B=256; STEPS=3; WARM=1
-BENCHARGS="--batch $B --steps $STEPS --warmup $WARM --cpu-frames 0 --no-profile --no-extras"
+BENCHARGS="--batch $B --steps $STEPS --warmup $WARM --repeat 1 --cpu-frames 0 --no-profile --no-extras"   # ONE timed block: the per-frame figures divide by B x (STEPS + WARM)
 
 echo "== calibration: integer VALU issue peak (tools/calib_valu.hip)"
 hipcc --offload-arch=gfx950 -O3 "$ROOT/tools/calib_valu.hip" -o /tmp/calib_valu && /tmp/calib_valu | tee "$OUT/calib_valu.txt"

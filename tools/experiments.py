@@ -34,7 +34,7 @@ def run(name, batch=256):
     env = dict(os.environ, TMPDIR="/tmp")
     counters = os.environ.get("AFV_EXP_PMC", "SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU").split()
     cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + counters + ["-d", out, "-o", "pmc",
-           "--output-format", "csv", "--", sys.executable, os.path.join(ROOT, "bench.py"), "--batch", str(batch), "--steps", "2", "--warmup", "1",
+           "--output-format", "csv", "--", sys.executable, os.path.join(ROOT, "bench.py"), "--batch", str(batch), "--steps", "2", "--warmup", "1", "--repeat", "1",
            "--cpu-frames", "0", "--no-profile", "--no-extras", "--lib", lib]
     subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
     kern = os.environ.get("AFV_EXP_KERNEL", "k_fast_nms")
