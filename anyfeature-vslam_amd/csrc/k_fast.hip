@@ -350,8 +350,13 @@ __global__ __launch_bounds__(256) void k_fast_nms(const Geo *__restrict__ geo_p,
             const short2v V = Vc[it + 3], a0 = Vc[it + 6], b0 = Vc[it];
             const short2v a2 = R2[it + 4], b2 = L2[it], a6 = R2[it], b6 = L2[it + 4];
             const short2v a4 = A4[it], b4 = B4[it];
+#if !defined(FT_NO_MIN3) && !defined(FT_PRE_MIN2)  // the outer reduction over the four pairs with one three-input instruction: 12 instead of 14 per pixel pair
+            const short2v hi = pkmin3(pkmax(a0, b0), pkmax(a2, b2), pkmin(pkmax(a4, b4), pkmax(a6, b6)));
+            const short2v lo = pkmax3(pkmin(a0, b0), pkmin(a2, b2), pkmax(pkmin(a4, b4), pkmin(a6, b6)));
+#else
             const short2v hi = pkmin(pkmin(pkmax(a0, b0), pkmax(a2, b2)), pkmin(pkmax(a4, b4), pkmax(a6, b6)));
             const short2v lo = pkmax(pkmax(pkmin(a0, b0), pkmin(a2, b2)), pkmax(pkmin(a4, b4), pkmin(a6, b6)));
+#endif
             const uint32_t bit = 0x00010001u << (16 - PRE_ITERS + it);
             bb |= as_u32(pk_sar15((V + T0) - hi)) & bit;
             bd |= as_u32(pk_sar15(lo - (V - T0))) & bit;
