@@ -82,7 +82,7 @@ class ProjJob(C.Structure):
                 ("qmin_size", C.c_void_p), ("qmax_size", C.c_void_p), ("qangle", C.c_void_p), ("qoccupies", C.c_void_p),
                 ("th_high", C.c_float), ("nnratio", C.c_float), ("size_tol", C.c_float), ("inv_size_tol", C.c_float),
                 ("check_orientation", C.c_int32), ("mode", C.c_int32),
-                ("u_right", C.c_void_p), ("q_ur", C.c_void_p), ("q_er_max", C.c_void_p)]
+                ("u_right", C.c_void_p), ("q_ur", C.c_void_p), ("q_er_max", C.c_void_p), ("float_dim", C.c_int32)]
 
 
 class FrameParams(C.Structure):

@@ -1777,7 +1777,13 @@ int afv_match_projection_core(afv_ctx *c, const afv_proj_job *jobs, int njobs, i
     if (dev && njobs != 1) return AFV_EINVAL;
     for (int i = 0; i < njobs; ++i) {
         const afv_proj_job &j = jobs[i];
-        if (j.n < 0 || j.n > AFV_MAX_SIDE || j.nq < 0 || j.nq > 65535 || j.desc_bytes < 1 || j.desc_bytes > 64) return AFV_EINVAL;
+        if (j.n < 0 || j.n > AFV_MAX_SIDE || j.nq < 0 || j.nq > 65535) return AFV_EINVAL;
+        if (j.float_dim != 0) {  // float descriptors (L2^2): host arrays on both sides, rows of float_dim floats
+            if (j.float_dim < 4 || j.float_dim > 1024 || (j.float_dim & 3)) return AFV_EINVAL;
+            if (dev) return AFV_EUNSUPPORTED;  // the resident frame holds binary rows
+        } else if (j.desc_bytes < 1 || j.desc_bytes > 64) {
+            return AFV_EINVAL;
+        }
         if (j.grid_cols < 1 || j.grid_rows < 1 || (long)j.grid_cols * j.grid_rows > 8192) return AFV_EINVAL;
         if (!dev && j.n > 0 && (!j.desc || !j.x || !j.y || !j.size)) return AFV_EINVAL;
         if (j.nq > 0 && ((!j.qdesc && !(dev && (dev->qdesc_dev || dev->qref_table))) || !j.qu || !j.qv || !j.qr || !j.qmin_size || !j.qmax_size)) return AFV_EINVAL;
@@ -1798,11 +1804,13 @@ int afv_match_projection_core(afv_ctx *c, const afv_proj_job *jobs, int njobs, i
     size_t total_out = 0;
     int max_nq = 0, max_n = 0;
     size_t grid_lds = 0;
+    bool any_float = false;
     for (int i = 0; i < njobs; ++i) {
         const afv_proj_job &j = jobs[i];
         Off &o = offs[i];
         o = Off{};
-        o.words = j.desc_bytes <= 32 ? 8 : 16;
+        o.words = j.float_dim ? j.float_dim : (j.desc_bytes <= 32 ? 8 : 16);  // dwords of one row
+        any_float = any_float || j.float_dim != 0;
         if (dev && dev->words != o.words) return AFV_EINVAL;
         // mvuRight branches: FeatureMatcher.cc:114-119, :1367-1372, :880-894.  A resident frame always carries the plane (-1 = monocular);
         // it takes part when the caller sends the queries' side of the gate
@@ -1810,7 +1818,7 @@ int afv_match_projection_core(afv_ctx *c, const afv_proj_job *jobs, int njobs, i
         o.stereo = ur_here && (kind == AFV_KIND_PROJ || kind == AFV_KIND_FUSE);
         if (o.stereo && kind == AFV_KIND_PROJ && j.nq > 0 && !j.q_er_max) return AFV_EINVAL;
         if (!dev) {
-            o.fd = put_desc(b, j.desc, j.n, j.desc_bytes, o.words);
+            o.fd = j.float_dim ? b.put(j.desc, (size_t)j.n * j.float_dim * 4) : put_desc(b, j.desc, j.n, j.desc_bytes, o.words);
             o.x = b.put(j.x, (size_t)j.n * 4); o.y = b.put(j.y, (size_t)j.n * 4); o.size = b.put(j.size, (size_t)j.n * 4);
             o.angle = j.angle ? b.put(j.angle, (size_t)j.n * 4) : 0;
             o.inf = (fuse && j.inf) ? b.put(j.inf, (size_t)j.n * 4) : 0;
@@ -1832,7 +1840,7 @@ int afv_match_projection_core(afv_ctx *c, const afv_proj_job *jobs, int njobs, i
             o.qrs = b.put(dev->qref_slot, (size_t)j.nq * 4);
             o.qri = b.put(dev->qref_idx, (size_t)j.nq * 4);
         } else if (!(dev && dev->qdesc_dev)) {
-            o.qd = put_desc(b, j.qdesc, j.nq, j.desc_bytes, o.words);
+            o.qd = j.float_dim ? b.put(j.qdesc, (size_t)j.nq * j.float_dim * 4) : put_desc(b, j.qdesc, j.nq, j.desc_bytes, o.words);
         }
         o.qvalid = (j.qvalid && !(dev && dev->qvalid_dev)) ? b.put(j.qvalid, (size_t)j.nq) : 0;
         o.qu = b.put(j.qu, (size_t)j.nq * 4); o.qv = b.put(j.qv, (size_t)j.nq * 4); o.qr = b.put(j.qr, (size_t)j.nq * 4);
@@ -1864,7 +1872,8 @@ int afv_match_projection_core(afv_ctx *c, const afv_proj_job *jobs, int njobs, i
     if (rc) return rc;
     // ordered phase: the workgroup fixed point when the largest job's tables fit the LDS it may use
     size_t wg_lds = 0;
-    if (!fuse && c->proj_engine != 0 && c->proj_wg_lds_max > 0 && (kind != AFV_KIND_INIT || max_nq <= 32767)) {
+    // (float descriptors: the ordered walk - the fixed-point engines' records hold 16-bit distances)
+    if (!fuse && !any_float && c->proj_engine != 0 && c->proj_wg_lds_max > 0 && (kind != AFV_KIND_INIT || max_nq <= 32767)) {
         for (int i = 0; i < njobs; ++i) wg_lds = std::max(wg_lds, afv_project_wg_lds(kind == AFV_KIND_INIT, jobs[i].n, jobs[i].nq));
         if (wg_lds > (size_t)c->proj_wg_lds_max) wg_lds = 0;
     }
@@ -1882,7 +1891,7 @@ int afv_match_projection_core(afv_ctx *c, const afv_proj_job *jobs, int njobs, i
         const Off &o = offs[i];
         DevProjJob &d = reinterpret_cast<DevProjJob *>(H + jobs_off)[i];
         d = DevProjJob{};
-        d.n = j.n; d.words = o.words;
+        d.n = j.n; d.words = j.float_dim ? 0 : o.words; d.fdim = j.float_dim;
         if (dev) {
             d.fdesc = dev->fdesc; d.x = dev->x; d.y = dev->y; d.size = dev->size; d.angle = dev->angle;
             d.inf = fuse ? dev->inf : nullptr;

@@ -69,6 +69,7 @@ struct DevProjJob {
     const float *u_right, *q_ur, *q_er;  // stereo: mvuRight of the features, projected right coordinate / gate of the queries (NULL: mono)
     int pass_cap;                        // test hook: cap on the passes of the fixed-point engines (0 = their own guard)
     int stereo_gate;                     // the projection searches skip features with u_right > 0 and |q_ur - u_right| > q_er (:114-119, :1367-1372)
+    int fdim;                            // > 0: float descriptors - fdesc / qdesc are rows of fdim floats, the distance is L2^2 (k_project.hip); 0: binary, `words` dwords
 };
 
 // ---------------- the device-resident Frame (k_frame.hip) ----------------

@@ -31,6 +31,8 @@
 #include "afv_runtime.h"  // the launchers below are declared there: a signature that drifts is a compile error, not a silent ABI mismatch
 #include "afv_jobs.h"
 
+#include <type_traits>
+
 #define PT 256
 #define PK 4
 #define IK 8  // keys per query for SearchForInitialization
@@ -158,7 +160,8 @@ __device__ __forceinline__ Window proj_window(const DevProjJob &J, float x, floa
                             const float ur_ = J.u_right[idx];                                         \
                             if (ur_ > 0.0f && fabsf(qur_ - ur_) > qer_) continue;                      \
                         }                                                                             \
-                        const int kpos = k_ - kb_[u_];                                                \
+                        const int kpos = k_ - kb_[u_], epos = k_;                                     \
+                        (void)epos, (void)kpos, (void)c;                                              \
                         VISIT                                                                         \
                     }                                                                                 \
                 }                                                                                     \
@@ -217,7 +220,8 @@ __device__ __forceinline__ Window proj_window(const DevProjJob &J, float x, floa
                             const float ur_ = J.u_right[idx];                                         \
                             if (ur_ > 0.0f && fabsf(qur_ - ur_) > qer_) continue;                      \
                         }                                                                             \
-                        const int c = (int)((unsigned)ck_.y >> 16), kpos = ck_.y & 0xffff;            \
+                        const int c = (int)((unsigned)ck_.y >> 16), kpos = ck_.y & 0xffff, epos = ck_.x; \
+                        (void)epos, (void)kpos, (void)c;                                              \
                         VISIT                                                                         \
                     }                                                                                 \
                     WAVE_LDS_SYNC();                                                                  \
@@ -235,7 +239,8 @@ __device__ __forceinline__ Window proj_window(const DevProjJob &J, float x, floa
                                 const float ur_ = J.u_right[idx];                                     \
                                 if (ur_ > 0.0f && fabsf(qur_ - ur_) > qer_) continue;                  \
                             }                                                                         \
-                            const int kpos = k_ - kb_[u_];                                            \
+                            const int kpos = k_ - kb_[u_], epos = k_;                                 \
+                            (void)epos, (void)kpos, (void)c;                                          \
                             VISIT                                                                     \
                         }                                                                             \
                     }                                                                                 \
@@ -247,6 +252,35 @@ __device__ __forceinline__ Window proj_window(const DevProjJob &J, float x, floa
 __device__ __forceinline__ unsigned long long make_key(int d, int c, int kpos, int idx) {
     return ((unsigned long long)d << 48) | ((unsigned long long)(c & 0xffff) << 32) | ((unsigned long long)(kpos & 0xffff) << 16) |
            (unsigned)idx;
+}
+
+// Float descriptors (round 6; W == 0 in the templates below).  FeatureMatcher::DescriptorDistance dispatches on DescriptorType
+// (FeatureMatcher.cc:1508-1531): SIFT128 / SURF64 / KAZE64 / R2D2 ... return cv::norm(a, b, NORM_L2SQR) narrowed to Descriptor_Distance_Type =
+// float (Feature_sift128.cpp:132-134, Types.h:127).  The distance is evaluated as k_match_l2.hip does (float differences, squares and 4-way
+// partial sums in double, one rounding to float at the end: the summation order is part of the result), and a non-negative float's bit
+// pattern orders like the number, so the candidate key is  distance bits << 32 | entry position << 16 | feature:  the position of the
+// candidate in cell_ent is monotonic in the reference's visiting order (cells in ix-outer / iy-inner order ARE ascending cell indices, and
+// the entries are stored cell by cell), < 8192, and breaks distance ties exactly as (window cell rank, position in cell) does for the
+// binary keys.  Rows are J.fdim floats (a multiple of 4, 16-byte aligned); only the ordered-walk engines (REC 0 / 2) read these keys.
+__device__ __forceinline__ float proj_l2sqr(const float *__restrict__ a, const float *__restrict__ b, int dim) {
+    double s = 0;
+    for (int i = 0; i < dim; i += 4) {
+        const float4 x = *reinterpret_cast<const float4 *>(a + i), y = *reinterpret_cast<const float4 *>(b + i);
+        const double v0 = (double)(x.x - y.x), v1 = (double)(x.y - y.y), v2 = (double)(x.z - y.z), v3 = (double)(x.w - y.w);
+        s += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
+    }
+    return (float)s;
+}
+__device__ __forceinline__ const float *proj_frow(const DevProjJob &J, int idx) { return reinterpret_cast<const float *>(J.fdesc) + (size_t)idx * J.fdim; }
+__device__ __forceinline__ const float *proj_qrow(const DevProjJob &J, int q) { return reinterpret_cast<const float *>(J.qdesc) + (size_t)q * J.fdim; }
+__device__ __forceinline__ unsigned long long make_key_f32(float d, int epos, int idx) {
+    return ((unsigned long long)__float_as_uint(d) << 32) | ((unsigned long long)(epos & 0xffff) << 16) | (unsigned)idx;
+}
+// the distance a key carries, as the type the reference computes with for that descriptor kind (int widened to float at the comparisons)
+template <int W>
+__device__ __forceinline__ auto key_dist_of(unsigned long long k) {
+    if constexpr (W == 0) return __uint_as_float((unsigned)(k >> 32));
+    else return key_dist(k);
 }
 
 // ---------------- phase 1: K best keys per query, one wave per query ----------------
@@ -264,7 +298,24 @@ __device__ void topk_query(const DevProjJob &J, int q, int lane, int2 *s_list /*
 #pragma unroll
     for (int s = 0; s < K; ++s) k[s] = P_NO_KEY;
     int visited = 0;
-    if (!J.qvalid || J.qvalid[q]) {
+    if constexpr (W == 0) {
+        if constexpr ((REC & 1) != 0) return;  // the fixed-point engines' 32-bit records cannot carry a float distance: never launched for float jobs
+        if (!J.qvalid || J.qvalid[q]) {
+            const float *qrow = proj_qrow(J, q);
+            PROJ_WAVE_WINDOW_DENSE(J, q, lane, s_list, {
+                if (REC < 2 && J.occupied && J.occupied[idx]) continue;
+                unsigned long long key = make_key_f32(proj_l2sqr(qrow, proj_frow(J, idx), J.fdim), epos, idx);
+                _Pragma("unroll") for (int s = 0; s < K; ++s) {
+                    if (key < k[s]) {
+                        const unsigned long long t = k[s];
+                        k[s] = key;
+                        key = t;
+                    }
+                }
+                ++visited;
+            })
+        }
+    } else if (!J.qvalid || J.qvalid[q]) {
         uint32_t qd[W];
         {
             const uint4 *qp = reinterpret_cast<const uint4 *>(J.qdesc + (size_t)q * W);
@@ -339,7 +390,8 @@ __global__ __launch_bounds__(PT) void k_proj_topk(const DevProjJob *__restrict__
     const DevProjJob J = jobs[blockIdx.y];
     const int lane = threadIdx.x & 63, q = blockIdx.x * (PT / 64) + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     if (q >= J.nq) return;
-    if (J.words == 8) topk_query<8, K, REC>(J, q, lane, s_list[threadIdx.x >> 6]);
+    if (J.fdim) topk_query<0, K, REC>(J, q, lane, s_list[threadIdx.x >> 6]);
+    else if (J.words == 8) topk_query<8, K, REC>(J, q, lane, s_list[threadIdx.x >> 6]);
     else topk_query<16, K, REC>(J, q, lane, s_list[threadIdx.x >> 6]);
 }
 // one job, its record a kernel argument: a search against a resident frame uploads nothing ahead of the launch - the queries are read
@@ -349,7 +401,8 @@ __global__ __launch_bounds__(PT) void k_proj_topk1(const DevProjJob J) {
     __shared__ int2 s_list[PT / 64][PW_LIST];
     const int lane = threadIdx.x & 63, q = blockIdx.x * (PT / 64) + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     if (q >= J.nq) return;
-    if (J.words == 8) topk_query<8, K, REC>(J, q, lane, s_list[threadIdx.x >> 6]);
+    if (J.fdim) topk_query<0, K, REC>(J, q, lane, s_list[threadIdx.x >> 6]);
+    else if (J.words == 8) topk_query<8, K, REC>(J, q, lane, s_list[threadIdx.x >> 6]);
     else topk_query<16, K, REC>(J, q, lane, s_list[threadIdx.x >> 6]);
 }
 
@@ -412,7 +465,8 @@ __device__ void proj_resolve(const DevProjJob &J, int stage_cap) {
             visited = (int)r3.x;
             occupies = (r3.y & 1u) != 0;
         }
-        int e0 = -1, e1 = -1, d0 = 0, d1 = 0;
+        int e0 = -1, e1 = -1;
+        decltype(key_dist_of<W>(0ull)) d0 = 0, d1 = 0;  // int (Hamming) or float (L2^2)
         uint32_t a0 = 0, a1 = 0;
         bool open = act, exhausted = act;
 #pragma unroll
@@ -426,7 +480,7 @@ __device__ void proj_resolve(const DevProjJob &J, int stage_cap) {
                     if (!((s_occ[idx >> 5] >> (idx & 31)) & 1u)) {
                         if (e0 < 0) {
                             e0 = idx;
-                            d0 = key_dist(k[s]);
+                            d0 = key_dist_of<W>(k[s]);
                             a0 = aux[s];
                             if (J.mode == 1) {  // best only
                                 open = false;
@@ -434,7 +488,7 @@ __device__ void proj_resolve(const DevProjJob &J, int stage_cap) {
                             }
                         } else {
                             e1 = idx;
-                            d1 = key_dist(k[s]);
+                            d1 = key_dist_of<W>(k[s]);
                             a1 = aux[s];
                             open = false;
                             exhausted = false;
@@ -496,28 +550,42 @@ __device__ void proj_resolve(const DevProjJob &J, int stage_cap) {
 #endif
             // exact rescan of the first query's window against the current occupancy, lanes over the window's cells
             const int q0 = pos;
-            uint32_t qd[W];
-#pragma unroll
-            for (int i = 0; i < W; ++i) qd[i] = J.qdesc[(size_t)q0 * W + i];
             unsigned long long k0 = P_NO_KEY, k1 = P_NO_KEY;
-            PROJ_WAVE_WINDOW(J, q0, lane, {
-                if ((s_occ[idx >> 5] >> (idx & 31)) & 1u) continue;
-                const unsigned long long key = make_key(proj_hamming<W>(qd, J.fdesc + (size_t)idx * W), c, kpos, idx);
-                if (key < k0) {
-                    k1 = k0;
-                    k0 = key;
-                } else if (key < k1) {
-                    k1 = key;
-                }
-            })
+            if constexpr (W == 0) {
+                const float *qrow = proj_qrow(J, q0);
+                PROJ_WAVE_WINDOW(J, q0, lane, {
+                    if ((s_occ[idx >> 5] >> (idx & 31)) & 1u) continue;
+                    const unsigned long long key = make_key_f32(proj_l2sqr(qrow, proj_frow(J, idx), J.fdim), epos, idx);
+                    if (key < k0) {
+                        k1 = k0;
+                        k0 = key;
+                    } else if (key < k1) {
+                        k1 = key;
+                    }
+                })
+            } else {
+                uint32_t qd[W];
+#pragma unroll
+                for (int i = 0; i < W; ++i) qd[i] = J.qdesc[(size_t)q0 * W + i];
+                PROJ_WAVE_WINDOW(J, q0, lane, {
+                    if ((s_occ[idx >> 5] >> (idx & 31)) & 1u) continue;
+                    const unsigned long long key = make_key(proj_hamming<W>(qd, J.fdesc + (size_t)idx * W), c, kpos, idx);
+                    if (key < k0) {
+                        k1 = k0;
+                        k0 = key;
+                    } else if (key < k1) {
+                        k1 = key;
+                    }
+                })
+            }
             const unsigned long long g0 = wave_min_u64(k0);
             const unsigned long long g1 = wave_min_u64(k0 == g0 ? k1 : k0);
             if (g0 != P_NO_KEY) {
-                const float best = (float)key_dist(g0);
+                const float best = (float)key_dist_of<W>(g0);
                 const int bidx = key_idx(g0);
                 bool ok = best <= J.th;
                 if (ok && J.mode == 0 && g1 != P_NO_KEY) {
-                    const float best2 = (float)key_dist(g1), bsz = J.size[bidx], bsz2 = J.size[key_idx(g1)];
+                    const float best2 = (float)key_dist_of<W>(g1), bsz = J.size[bidx], bsz2 = J.size[key_idx(g1)];
                     if ((bsz / bsz2 < J.tol) && (bsz / bsz2 > J.inv_tol) && (bsz2 > 0.0f) && (best > J.ratio * best2)) ok = false;
                 }
                 if (ok) {
@@ -573,7 +641,8 @@ __device__ void proj_resolve(const DevProjJob &J, int stage_cap) {
 
 __global__ __launch_bounds__(PT) void k_proj_resolve(const DevProjJob *__restrict__ jobs, int stage_cap) {
     const DevProjJob J = jobs[blockIdx.x];
-    if (J.words == 8) proj_resolve<8>(J, stage_cap);
+    if (J.fdim) proj_resolve<0>(J, stage_cap);
+    else if (J.words == 8) proj_resolve<8>(J, stage_cap);
     else proj_resolve<16>(J, stage_cap);
 }
 
@@ -949,9 +1018,16 @@ template <int W>
 __device__ void fuse_query(const DevProjJob &J, int q, int lane, int2 *s_list) {
     unsigned long long k0 = P_NO_KEY;
     if (!J.qvalid || J.qvalid[q]) {
-        uint32_t qd[W];
+        uint32_t qd[W == 0 ? 1 : W];
+        const float *qrow = nullptr;
+        if constexpr (W == 0) {
+            qrow = proj_qrow(J, q);
+            (void)qd;
+        } else {
+            (void)qrow;
 #pragma unroll
-        for (int i = 0; i < W; ++i) qd[i] = J.qdesc[(size_t)q * W + i];
+            for (int i = 0; i < W; ++i) qd[i] = J.qdesc[(size_t)q * W + i];
+        }
         const float u = J.qu[q], v = J.qv[q];
         const float qur = J.u_right ? J.q_ur[q] : 0.0f;
         PROJ_WAVE_WINDOW_DENSE(J, q, lane, s_list, {
@@ -968,12 +1044,14 @@ __device__ void fuse_query(const DevProjJob &J, int q, int lane, int2 *s_list) {
                     if ((double)(e2 * J.inf[idx]) > 5.99) continue;
                 }
             }
-            const unsigned long long key = make_key(proj_hamming<W>(qd, J.fdesc + (size_t)idx * W), c, kpos, idx);
+            unsigned long long key;
+            if constexpr (W == 0) key = make_key_f32(proj_l2sqr(qrow, proj_frow(J, idx), J.fdim), epos, idx);
+            else key = make_key(proj_hamming<W>(qd, J.fdesc + (size_t)idx * W), c, kpos, idx);
             k0 = key < k0 ? key : k0;
         })
     }
     const unsigned long long g0 = wave_min_u64(k0);
-    if (lane == 0) J.assign[q] = (g0 != P_NO_KEY && (float)key_dist(g0) <= J.th) ? key_idx(g0) : -1;
+    if (lane == 0) J.assign[q] = (g0 != P_NO_KEY && (float)key_dist_of<W>(g0) <= J.th) ? key_idx(g0) : -1;
 }
 
 __global__ __launch_bounds__(PT) void k_match_fuse(const DevProjJob *__restrict__ jobs) {
@@ -981,14 +1059,16 @@ __global__ __launch_bounds__(PT) void k_match_fuse(const DevProjJob *__restrict_
     const DevProjJob J = jobs[blockIdx.y];
     const int lane = threadIdx.x & 63, q = blockIdx.x * (PT / 64) + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     if (q >= J.nq) return;
-    if (J.words == 8) fuse_query<8>(J, q, lane, s_list[threadIdx.x >> 6]);
+    if (J.fdim) fuse_query<0>(J, q, lane, s_list[threadIdx.x >> 6]);
+    else if (J.words == 8) fuse_query<8>(J, q, lane, s_list[threadIdx.x >> 6]);
     else fuse_query<16>(J, q, lane, s_list[threadIdx.x >> 6]);
 }
 __global__ __launch_bounds__(PT) void k_match_fuse1(const DevProjJob J) {
     __shared__ int2 s_list[PT / 64][PW_LIST];
     const int lane = threadIdx.x & 63, q = blockIdx.x * (PT / 64) + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     if (q >= J.nq) return;
-    if (J.words == 8) fuse_query<8>(J, q, lane, s_list[threadIdx.x >> 6]);
+    if (J.fdim) fuse_query<0>(J, q, lane, s_list[threadIdx.x >> 6]);
+    else if (J.words == 8) fuse_query<8>(J, q, lane, s_list[threadIdx.x >> 6]);
     else fuse_query<16>(J, q, lane, s_list[threadIdx.x >> 6]);
 }
 
@@ -1000,13 +1080,18 @@ __global__ __launch_bounds__(PT) void k_match_fuse1(const DevProjJob J) {
 // IK keys run out before two are found (and the window holds more) the window is rescanned exactly.
 template <int W>
 __device__ void init_resolve(const DevProjJob &J) {
-    __shared__ int s_m21[P_MAX_FEATS];
-    __shared__ unsigned short s_mdist[P_MAX_FEATS];
+    // binary: holder as int, its distance as u16 (48 KB); float distances need 32 bits, so the holder shrinks to u16 (nq <= 65535: 0xffff = none)
+    using m21_t = std::conditional_t<W == 0, unsigned short, int>;
+    using md_t = std::conditional_t<W == 0, float, unsigned short>;
+    constexpr m21_t M21_NONE = (m21_t)-1;
+    __shared__ m21_t s_m21[P_MAX_FEATS];
+    __shared__ md_t s_mdist[P_MAX_FEATS];
     __shared__ int s_hist[32];
     const int lane = threadIdx.x;
     for (int i = lane; i < J.n; i += 64) {
-        s_m21[i] = -1;
-        s_mdist[i] = 0xffff;
+        s_m21[i] = M21_NONE;
+        if constexpr (W == 0) s_mdist[i] = 3.402823466e+38f;  // vMatchedDistance starts at highestPossibleDistance = numeric_limits<float>::max() (:485)
+        else s_mdist[i] = 0xffff;
     }
     for (int q = lane; q < J.nq; q += 64) J.assign[q] = -1;
     if (lane < 32) s_hist[lane] = 0;
@@ -1035,7 +1120,9 @@ __device__ void init_resolve(const DevProjJob &J) {
             const unsigned long long key = __shfl(kreg, j * IK + sub, 64);  // every lane group of 8 sees the 8 keys
             const int ncand = __shfl(ncand_l, j * IK, 64);
             const int ki = key == P_NO_KEY ? 0 : key_idx(key);
-            const bool okk = key != P_NO_KEY && !((int)s_mdist[ki] <= key_dist(key));  // gate (:513)
+            bool okk;  // gate (:513)
+            if constexpr (W == 0) okk = key != P_NO_KEY && !(s_mdist[ki] <= key_dist_of<0>(key));
+            else okk = key != P_NO_KEY && !((int)s_mdist[ki] <= key_dist(key));
             const unsigned m8 = (unsigned)(__ballot(okk) & 0xffull);  // lanes 0..7 hold slots 0..7
             unsigned long long g0 = P_NO_KEY, g1 = P_NO_KEY;
             if (__popc(m8) >= 2 || ncand <= IK) {
@@ -1047,35 +1134,50 @@ __device__ void init_resolve(const DevProjJob &J) {
                 }
             } else {
                 // exact rescan of the window with the gate applied, lanes over cells
-                uint32_t qd[W];
-#pragma unroll
-                for (int i = 0; i < W; ++i) qd[i] = J.qdesc[(size_t)q * W + i];
                 unsigned long long k0 = P_NO_KEY, k1 = P_NO_KEY;
-                PROJ_WAVE_WINDOW(J, q, lane, {
-                    const int d = proj_hamming<W>(qd, J.fdesc + (size_t)idx * W);
-                    if ((int)s_mdist[idx] <= d) continue;
-                    const unsigned long long kk = make_key(d, c, kpos, idx);
-                    if (kk < k0) {
-                        k1 = k0;
-                        k0 = kk;
-                    } else if (kk < k1) {
-                        k1 = kk;
-                    }
-                })
+                if constexpr (W == 0) {
+                    const float *qrow = proj_qrow(J, q);
+                    PROJ_WAVE_WINDOW(J, q, lane, {
+                        const float d = proj_l2sqr(qrow, proj_frow(J, idx), J.fdim);
+                        if (s_mdist[idx] <= d) continue;
+                        const unsigned long long kk = make_key_f32(d, epos, idx);
+                        if (kk < k0) {
+                            k1 = k0;
+                            k0 = kk;
+                        } else if (kk < k1) {
+                            k1 = kk;
+                        }
+                    })
+                } else {
+                    uint32_t qd[W];
+#pragma unroll
+                    for (int i = 0; i < W; ++i) qd[i] = J.qdesc[(size_t)q * W + i];
+                    PROJ_WAVE_WINDOW(J, q, lane, {
+                        const int d = proj_hamming<W>(qd, J.fdesc + (size_t)idx * W);
+                        if ((int)s_mdist[idx] <= d) continue;
+                        const unsigned long long kk = make_key(d, c, kpos, idx);
+                        if (kk < k0) {
+                            k1 = k0;
+                            k0 = kk;
+                        } else if (kk < k1) {
+                            k1 = kk;
+                        }
+                    })
+                }
                 g0 = wave_min_u64(k0);
                 g1 = wave_min_u64(k0 == g0 ? k1 : k0);
             }
             if (g0 == P_NO_KEY) continue;
-            const float best = (float)key_dist(g0);
-            const float best2 = g1 == P_NO_KEY ? 3.402823466e+38f : (float)key_dist(g1);
+            const float best = (float)key_dist_of<W>(g0);
+            const float best2 = g1 == P_NO_KEY ? 3.402823466e+38f : (float)key_dist_of<W>(g1);
             const int bidx = key_idx(g0);
             if (best <= J.th && best < best2 * J.ratio) {  // :527-529
                 if (lane == 0) {
-                    const int prev = s_m21[bidx];
-                    if (prev >= 0) J.assign[prev] = -1;  // stolen (:531-535)
+                    const m21_t prev = s_m21[bidx];
+                    if (prev != M21_NONE) J.assign[prev] = -1;  // stolen (:531-535)
                     J.assign[q] = bidx;
-                    s_m21[bidx] = q;
-                    s_mdist[bidx] = (unsigned short)key_dist(g0);
+                    s_m21[bidx] = (m21_t)q;
+                    s_mdist[bidx] = (md_t)key_dist_of<W>(g0);
                     if (J.check_ori) {
                         const int bin = proj_rotation_bin(J.qangle[q], J.angle[bidx]);  // F1 keypoint first (:543)
                         J.orilist[2 * nori] = q;
@@ -1117,7 +1219,8 @@ __device__ void init_resolve(const DevProjJob &J) {
 
 __global__ __launch_bounds__(64) void k_init_resolve(const DevProjJob *__restrict__ jobs) {
     const DevProjJob J = jobs[blockIdx.x];
-    if (J.words == 8) init_resolve<8>(J);
+    if (J.fdim) init_resolve<0>(J);
+    else if (J.words == 8) init_resolve<8>(J);
     else init_resolve<16>(J);
 }
 

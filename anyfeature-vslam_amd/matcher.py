@@ -73,6 +73,14 @@ class FeatureView:
         return self._csr
 
 
+def _descriptor_rows(descriptors):
+    """mDescriptors as the matchers take it: uint8 rows (binary descriptors, Hamming) or float32 rows (SIFT128 / SURF64 / KAZE64 / R2D2 ...:
+    cv::norm(a, b, NORM_L2SQR), Feature_sift128.cpp:132-134) - FeatureMatcher::DescriptorDistance dispatches on the type
+    (FeatureMatcher.cc:1508-1531)"""
+    d = np.asarray(descriptors)
+    return np.ascontiguousarray(d, np.float32 if d.dtype.kind == "f" else np.uint8)
+
+
 class FrameGridView:
     """What the projection-guided matchers read from a Frame: mvKeysUn (pts, angles), keyPtsSize, mDescriptors, the
     occupancy of F.pts (point present with NumberOfObservations() > 0) and the feature grid parameters
@@ -80,7 +88,7 @@ class FrameGridView:
 
     def __init__(self, descriptors, pts, sizes, angles=None, occupied=None, min_x=0.0, min_y=0.0, max_x=640.0, max_y=480.0,
                  grid_cols=64, grid_rows=48, size_tolerance=1.2, inf=None, u_right=None):
-        self.descriptors = np.ascontiguousarray(descriptors, np.uint8)
+        self.descriptors = _descriptor_rows(descriptors)
         self.N = self.descriptors.shape[0]
         pts = np.asarray(pts, np.float32).reshape(-1, 2)
         self.x = np.ascontiguousarray(pts[:, 0]); self.y = np.ascontiguousarray(pts[:, 1])
@@ -102,7 +110,7 @@ class ProjectionQueries:
     window radius r, admissible keyPtsSize band, validity, angle (last-frame mode), occupies (observations > 0)."""
 
     def __init__(self, descriptors, u, v, r, min_size, max_size, valid=None, angles=None, occupies=None, ur=None, er_max=None):
-        self.descriptors = np.ascontiguousarray(descriptors, np.uint8)
+        self.descriptors = _descriptor_rows(descriptors)
         self.n = self.descriptors.shape[0]
         f = lambda a: np.ascontiguousarray(a, np.float32)
         self.u, self.v, self.r, self.min_size, self.max_size = f(u), f(v), f(r), f(min_size), f(max_size)
@@ -214,6 +222,11 @@ class FeatureMatcher:
     def _proj_job(self, F, queries):
         j = _lib.sized(ProjJob)
         j.desc = ptr(F.descriptors); j.n = F.N; j.desc_bytes = F.descriptors.shape[1] if F.N else 32
+        if F.descriptors.dtype.kind == "f" or queries.descriptors.dtype.kind == "f":  # float descriptors: L2^2 distances
+            if F.descriptors.dtype != queries.descriptors.dtype or (F.N and queries.n and F.descriptors.shape[1] != queries.descriptors.shape[1]):
+                raise ValueError("frame and queries must carry the same kind of descriptor")
+            j.float_dim = F.descriptors.shape[1] if F.N else queries.descriptors.shape[1]
+            j.desc_bytes = 4 * j.float_dim
         j.x = ptr(F.x); j.y = ptr(F.y); j.size = ptr(F.sizes); j.angle = ptr(F.angles); j.occupied = ptr(F.occupied)
         j.inf = ptr(F.inf)
         j.min_x = float(F.min_x); j.min_y = float(F.min_y); j.grid_inv_w = float(F.grid_inv_w); j.grid_inv_h = float(F.grid_inv_h)

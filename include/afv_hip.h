@@ -48,7 +48,7 @@ enum {
 /* ABI revision of this header.  It goes up whenever a record, an argument list or a limit changes incompatibly; a host built against
  * another revision must not call into the library (check once: afv_abi_version() == AFV_ABI_VERSION).
  *   5  (round 5) afv_proj_job / afv_tri_job / afv_table_tri_job start with struct_size; frame grids hold at most 8192 cells (was 65536)
- *   6  (round 6) afv_orb_detect / afv_orb_compute; afv_frame_params.desc_bytes; afv_vocab_create_f32 / afv_bow_transform_f32; grids / frames whose one-workgroup build does not fit the
+ *   6  (round 6) afv_orb_detect / afv_orb_compute; afv_frame_params.desc_bytes; afv_vocab_create_f32 / afv_bow_transform_f32; afv_proj_job.float_dim; grids / frames whose one-workgroup build does not fit the
  *      LDS are refused with AFV_EUNSUPPORTED at creation instead of failing at the first launch */
 #define AFV_ABI_VERSION 6
 int afv_abi_version(void);
@@ -333,6 +333,14 @@ typedef struct {
        afv_match_fuse replaces the 2-dof gate e2 * inf <= 5.99 by the 3-dof one (ex^2 + ey^2 + er^2) * inf <= 7.8 for features with
        u_right >= 0 (:880-894).  afv_match_sim3 / afv_match_initialization have no stereo branch and ignore the three fields. */
     const float *u_right; const float *q_ur; const float *q_er_max;
+    /* (ABI 6, appended: struct_size tells) float descriptors.  FeatureMatcher::DescriptorDistance dispatches on DescriptorType (FeatureMatcher.cc:1508-1531) and returns
+       Descriptor_Distance_Type = float (Types.h:127): for SIFT128 / SURF64 / KAZE64 / R2D2 / any non-binary feature it is
+       cv::norm(a, b, NORM_L2SQR) (Feature_sift128.cpp:132-134).  float_dim > 0: desc and qdesc point to rows of float_dim floats
+       (a multiple of 4, <= 1024; desc_bytes is ignored), distances are evaluated like afv_match_l2 (float differences, squares and 4-way
+       partial sums in double, narrowed once), th_high / nnratio apply to them as they stand; 0 (what a caller compiled against an older
+       header gets) = binary rows of desc_bytes.  All four searches below accept it; the ordered phase runs on the ordered-walk engine
+       (afv_set_projection_resolve 0) whatever the context's setting - the fixed-point engines' records carry 16-bit distances. */
+    int32_t float_dim;
 } afv_proj_job;
 /* assign = concatenation over jobs of int32[n]: index of the query assigned to feature i (F.pts[i] = pMP) or -1 */
 int afv_match_projection(afv_ctx *ctx, const afv_proj_job *jobs, int njobs, int32_t *assign, int32_t *nmatches);

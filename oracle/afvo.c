@@ -1201,6 +1201,15 @@ static void build_grid(const afvo_proj_job *j, proj_grid *g) {
     free(cell);
 }
 
+/* FeatureMatcher::DescriptorDistance (FeatureMatcher.cc:1508-1531) between query q and feature idx: Descriptor_Distance_Type = float */
+static float proj_dist(const afvo_proj_job *j, int q, int idx) {
+    if (j->float_dim > 0)
+        return afvo_l2sqr((const float *)(const void *)j->qdesc + (size_t)q * j->float_dim, (const float *)(const void *)j->desc + (size_t)idx * j->float_dim,
+                          j->float_dim);
+    const u8 *a = j->qdesc + (size_t)q * j->desc_bytes, *b = j->desc + (size_t)idx * j->desc_bytes;
+    return (float)(j->desc_bytes == 32 ? afvo_hamming256(a, b) : afvo_hamming_bytes(a, b, j->desc_bytes));
+}
+
 int afvo_match_projection(const afvo_proj_job *j, int32_t *assign) {
     proj_grid g;
     build_grid(j, &g);
@@ -1238,8 +1247,7 @@ int afvo_match_projection(const afvo_proj_job *j, int32_t *assign) {
                         const float er = fabsf(j->q_ur[q] - j->u_right[idx]);
                         if (er > j->q_er_max[q]) continue;
                     }
-                    const u8 *a = j->qdesc + (size_t)q * j->desc_bytes, *b = j->desc + (size_t)idx * j->desc_bytes;
-                    const float d = (float)(j->desc_bytes == 32 ? afvo_hamming256(a, b) : afvo_hamming_bytes(a, b, j->desc_bytes));
+                    const float d = proj_dist(j, q, idx);
                     if (d < best) {
                         best2 = best; best = d; best_idx = idx;
                         best_size2 = best_size; best_size = j->size[idx];
@@ -1316,8 +1324,7 @@ int afvo_match_fuse(const afvo_proj_job *j, int32_t *best_out) {
                         const float e2 = ex * ex + ey * ey;
                         if (j->inf && e2 * j->inf[idx] > 5.99) continue;          /* :897-898 (float product vs double); no gate in Fuse(Sim3) / SearchBySim3 */
                     }
-                    const u8 *a = j->qdesc + (size_t)q * j->desc_bytes, *b = j->desc + (size_t)idx * j->desc_bytes;
-                    const float d = (float)(j->desc_bytes == 32 ? afvo_hamming256(a, b) : afvo_hamming_bytes(a, b, j->desc_bytes));
+                    const float d = proj_dist(j, q, idx);
                     if (d < best) { best = d; best_idx = idx; }
                 }
             }
@@ -1384,8 +1391,7 @@ int afvo_match_initialization(const afvo_proj_job *j, int32_t *match12) {
                     if (j->size[idx] > max_size) continue;
                     const float dx = j->x[idx] - x, dy = j->y[idx] - y;
                     if (!(fabsf(dx) < r && fabsf(dy) < r)) continue;
-                    const u8 *a = j->qdesc + (size_t)q * j->desc_bytes, *b = j->desc + (size_t)idx * j->desc_bytes;
-                    const float d = (float)(j->desc_bytes == 32 ? afvo_hamming256(a, b) : afvo_hamming_bytes(a, b, j->desc_bytes));
+                    const float d = proj_dist(j, q, idx);
                     if (mdist[idx] <= d) continue;                                 /* :513-514 */
                     if (d < best) { best2 = best; best = d; best_idx = idx; }
                     else if (d < best2) best2 = d;

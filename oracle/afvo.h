@@ -176,6 +176,10 @@ typedef struct {
        :117, radius :1371).  Modes 0 / 1 skip a feature with u_right > 0 whose |q_ur - u_right| exceeds the gate; Fuse replaces the
        2-dof gate (5.99) by the 3-dof one (7.8) for features with u_right >= 0 (:880-894). */
     const float *u_right; const float *q_ur; const float *q_er_max;
+    /* float descriptors (FeatureMatcher::DescriptorDistance dispatches on DescriptorType, FeatureMatcher.cc:1508-1531: SIFT128, SURF64,
+       KAZE64, R2D2 ... = cv::norm(a, b, NORM_L2SQR), Feature_sift128.cpp:132-134): float_dim > 0 = desc / qdesc point to rows of float_dim
+       floats (desc_bytes is ignored), the distance is afvo_l2sqr; 0 = binary rows of desc_bytes */
+    int32_t float_dim;
 } afvo_proj_job;
 int afvo_match_projection(const afvo_proj_job *j, int32_t *assign /* [n]: query index or -1 */);
 /* matching core of FeatureMatcher::Fuse(pKF, vpMapPoints, th) (FeatureMatcher.cc:794-940): per map point the most

@@ -61,7 +61,7 @@ class ProjJob(C.Structure):
                 ("qmin_size", C.c_void_p), ("qmax_size", C.c_void_p), ("qangle", C.c_void_p), ("qoccupies", C.c_void_p),
                 ("th_high", C.c_float), ("nnratio", C.c_float), ("size_tol", C.c_float), ("inv_size_tol", C.c_float),
                 ("check_orientation", C.c_int32), ("mode", C.c_int32),
-                ("u_right", C.c_void_p), ("q_ur", C.c_void_p), ("q_er_max", C.c_void_p)]
+                ("u_right", C.c_void_p), ("q_ur", C.c_void_p), ("q_er_max", C.c_void_p), ("float_dim", C.c_int32)]
 
 
 class L2Job(C.Structure):
@@ -431,6 +431,9 @@ def three_maxima(sizes):
 def _proj_job(F, Q, th_high, nnratio, check_orientation, last_frame):
     j = ProjJob()
     j.desc = _p(F.descriptors); j.n = F.N; j.desc_bytes = F.descriptors.shape[1] if F.N else 32
+    if F.descriptors.dtype.kind == "f" or Q.descriptors.dtype.kind == "f":  # float descriptors: L2^2 (Feature_sift128.cpp:132-134)
+        assert F.descriptors.dtype == np.float32 and Q.descriptors.dtype == np.float32
+        j.float_dim = F.descriptors.shape[1]; j.desc_bytes = 4 * j.float_dim
     j.x = _p(F.x); j.y = _p(F.y); j.size = _p(F.sizes); j.angle = _p(F.angles); j.occupied = _p(F.occupied)
     j.inf = _p(getattr(F, 'inf', None))
     j.min_x = float(F.min_x); j.min_y = float(F.min_y); j.grid_inv_w = float(F.grid_inv_w); j.grid_inv_h = float(F.grid_inv_h)

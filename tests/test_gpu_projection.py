@@ -318,13 +318,18 @@ def _widen_scene(F, Q, nbytes):
     return F, Q
 
 
-@pytest.mark.parametrize("nbytes", [61, 48, 20])
-def test_projection_searches_are_descriptor_generic(afv, oracle, gpu_ctx, nbytes):
-    th = float(round(75.0 * nbytes / 32.0))
+def _all_searches(afv, oracle, gpu_ctx, conv, th):
+    """every projection-guided search of the reference on descriptors converted by `conv` (from the extractor's 32-byte rows), against the
+    oracle with the distance threshold `th`"""
+    def conv_scene(F, Q):
+        F.descriptors = conv(F.descriptors)
+        Q.descriptors = conv(Q.descriptors)
+        return F, Q
+
     afv.FeatureMatcher.setDescriptorDistanceThresholds(th)
     try:
         # SearchByProjection(F, local map) / (cur, last) with and without the orientation histogram
-        F, Q = _widen_scene(*_scene(afv, gpu_ctx, 51, 4, 15.0), nbytes)
+        F, Q = conv_scene(*_scene(afv, gpu_ctx, 51, 4, 15.0))
         m = afv.FeatureMatcher(0.8, True, ctx=gpu_ctx)
         got, n = m.SearchByProjection(F, Q)
         want, wn = oracle.match_projection(F, Q, th_high=th, nnratio=0.8)
@@ -335,39 +340,44 @@ def test_projection_searches_are_descriptor_generic(afv, oracle, gpu_ctx, nbytes
             want, wn = oracle.match_projection(F, Q, th_high=th, nnratio=0.9, check_orientation=ori, last_frame=True)
             assert n == wn and np.array_equal(got, want) and wn > 100
         # stereo gate
-        Fs, Qs = _stereo(afv, *_widen_scene(*_scene(afv, gpu_ctx, 52, 3, 40.0), nbytes), 52, 0.5)
+        Fs, Qs = _stereo(afv, *conv_scene(*_scene(afv, gpu_ctx, 52, 3, 40.0)), 52, 0.5)
         m = afv.FeatureMatcher(0.85, True, ctx=gpu_ctx)
         got, n = m.SearchByProjection(Fs, Qs)
         want, wn = oracle.match_projection(Fs, Qs, th_high=th, nnratio=0.85)
         assert n == wn and np.array_equal(got, want) and wn > 50
         # Fuse (with its reprojection gate) and Fuse(Sim3)
-        F, Q = _widen_scene(*_scene(afv, gpu_ctx, 53, 4, 15.0), nbytes)
+        F, Q = conv_scene(*_scene(afv, gpu_ctx, 53, 4, 15.0))
         F.inf = np.ascontiguousarray(np.float32(0.2) / (F.sizes * F.sizes))
         m = afv.FeatureMatcher(0.6, True, ctx=gpu_ctx)
         got, n = m.Fuse(F, Q)
         want, wn = oracle.match_projection(F, Q, th_high=th, fuse=True)
         assert n == wn and np.array_equal(got, want) and wn > 50
-        # a dense cluster: the ordered phase's claim / rescan logic on wide rows
+        got, n = m.Fuse_sim3(F, Q)
+        F.inf = None
+        want, wn = oracle.match_projection(F, Q, th_high=th, fuse=True)
+        assert n == wn and np.array_equal(got, want) and wn > 50
+        # a dense cluster: the ordered phase's claim / rescan logic (the key lists run out, equal distances abound)
         s = afv.synth
         nf, nq = 60, 400
-        proto = _widen(s.random_descriptors(77, 6), nbytes)
+        proto = s.random_descriptors(77, 6)
         d = proto[s.lcg_states(1, nf) % 6].copy()
-        d[np.arange(nf), s.lcg_states(2, nf) % nbytes] ^= 1
+        d[np.arange(nf), s.lcg_states(2, nf) % 32] ^= 1
         pts = np.stack([300 + (s.lcg_states(3, nf) % 40).astype(np.float32), 200 + (s.lcg_states(4, nf) % 40).astype(np.float32)], 1)
-        Fc = afv.FrameGridView(d, pts, np.ones(nf, np.float32))
+        Fc = afv.FrameGridView(conv(d), pts, np.ones(nf, np.float32))
         qd = proto[s.lcg_states(5, nq) % 6].copy()
-        qd[np.arange(nq), s.lcg_states(6, nq) % nbytes] ^= 2
-        Qc = afv.ProjectionQueries(qd, np.full(nq, 320.0), np.full(nq, 220.0), np.full(nq, 30.0), np.full(nq, 0.5), np.full(nq, 2.0))
+        qd[np.arange(nq), s.lcg_states(6, nq) % 32] ^= 2
+        Qc = afv.ProjectionQueries(conv(qd), np.full(nq, 320.0), np.full(nq, 220.0), np.full(nq, 30.0), np.full(nq, 0.5), np.full(nq, 2.0))
         for mode, ratio in ((False, 0.8), (True, 0.9)):
             m = afv.FeatureMatcher(ratio, False, ctx=gpu_ctx)
             got, nn = m.SearchByProjection(Fc, Qc, last_frame=mode)
             want, wn = oracle.match_projection(Fc, Qc, th_high=th, nnratio=ratio, last_frame=mode)
             assert nn == wn and np.array_equal(got, want), (mode, ratio)
+            assert wn > 10 or not mode  # (the local-map mode's ratio test rejects nearly everything inside a cluster)
         # SearchBySim3 and SearchForInitialization
         img = s.corners_frame(54)
         k1, d1 = gpu_ctx.extract(img)
         k2, d2 = gpu_ctx.extract(np.roll(img, 6, axis=1))
-        d1, d2 = _widen(d1, nbytes), _widen(d2, nbytes)
+        d1, d2 = conv(d1), conv(d2)
         z1, _, _ = gpu_ctx.size_sigma(k1); z2, _, _ = gpu_ctx.size_sigma(k2)
         F1 = afv.FrameGridView(d1, np.stack([k1["x"], k1["y"]], 1), z1, angles=k1["angle"])
         F2 = afv.FrameGridView(d2, np.stack([k2["x"], k2["y"]], 1), z2, angles=k2["angle"])
@@ -379,11 +389,52 @@ def test_projection_searches_are_descriptor_generic(afv, oracle, gpu_ctx, nbytes
         assert n == wn and np.array_equal(got, want) and wn > 200
         prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
         n1 = len(k1)
-        Qi = afv.ProjectionQueries(d1, prev[:, 0].copy(), prev[:, 1].copy(), np.full(n1, 50.0, np.float32), np.zeros(n1, np.float32),
-                                   np.full(n1, z1.max(), np.float32), valid=(k1["octave"] == 0).astype(np.uint8), angles=k1["angle"])
-        m = afv.FeatureMatcher(0.9, True, ctx=gpu_ctx)
-        got, n = m.SearchForInitialization(Qi, F2, vbPrevMatched=prev)
-        want, wn = oracle.match_initialization(F2, Qi, th_low=th, nnratio=0.9, check_orientation=True)
-        assert n == wn and np.array_equal(got, want) and wn > 50
+        for window in (50.0, 100.0):  # the wider window: more than IK candidates per query, gated keys, exact rescans
+            Qi = afv.ProjectionQueries(d1, prev[:, 0].copy(), prev[:, 1].copy(), np.full(n1, window, np.float32), np.zeros(n1, np.float32),
+                                       np.full(n1, z1.max(), np.float32), valid=(k1["octave"] == 0).astype(np.uint8), angles=k1["angle"])
+            m = afv.FeatureMatcher(0.9, True, ctx=gpu_ctx)
+            got, n = m.SearchForInitialization(Qi, F2, vbPrevMatched=prev.copy())
+            want, wn = oracle.match_initialization(F2, Qi, th_low=th, nnratio=0.9, check_orientation=True)
+            assert n == wn and np.array_equal(got, want) and wn > 50
     finally:
         afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+
+
+@pytest.mark.parametrize("nbytes", [61, 48, 20])
+def test_projection_searches_are_descriptor_generic(afv, oracle, gpu_ctx, nbytes):
+    _all_searches(afv, oracle, gpu_ctx, lambda d: _widen(d, nbytes), float(round(75.0 * nbytes / 32.0)))
+
+
+# ---- float descriptors: DescriptorDistance_sift128 / _surf64 / _kaze64 / _r2d2_128 = cv::norm(a, b, NORM_L2SQR) as a float
+#      (Feature_sift128.cpp:132-134; Descriptor_Distance_Type = float, Types.h:127) behind the same dispatch ----
+def _floaten(d32, dim, real):
+    """float rows with the neighbourhood structure of the 32-byte ones: the first `dim` bits as 0.0 / 1.0 (real = False: L2^2 = the Hamming
+    distance over those bits - equal distances everywhere, which is what exercises the visiting-order tie-break of the keys) or the bits
+    scaled, plus a deterministic fraction per element (real = True: distances with full float mantissas, where the summation order shows)"""
+    bits = np.unpackbits(np.ascontiguousarray(d32, np.uint8), axis=1)[:, :dim].astype(np.float32)
+    if not real:
+        return np.ascontiguousarray(bits)
+    n = len(bits)
+    frac = ((np.arange(n * dim, dtype=np.uint64).reshape(n, dim) * np.uint64(2654435761) + np.uint64(12345)) % np.uint64(1 << 20)).astype(np.float32)
+    rows = np.ascontiguousarray(d32, np.uint8).astype(np.uint64).sum(1, keepdims=True)  # a per-row phase so that equal rows of different sets differ
+    frac = (frac + (rows * np.uint64(977) % np.uint64(1 << 20)).astype(np.float32)) % np.float32(1 << 20)
+    return np.ascontiguousarray(bits * np.float32(0.75) + frac * np.float32(0.2 / (1 << 20)), np.float32)
+
+
+@pytest.mark.parametrize("dim,real", [(128, False), (128, True), (64, True), (256, False)])
+def test_projection_searches_with_float_descriptors(afv, oracle, gpu_ctx, dim, real):
+    th = 75.0 * dim / 256.0 * (0.6 if real else 1.0)
+    _all_searches(afv, oracle, gpu_ctx, lambda d: _floaten(d, dim, real), float(th))
+
+
+def test_float_jobs_that_are_refused(afv, gpu_ctx):
+    F, Q = _scene(afv, gpu_ctx, 61, 4, 15.0)
+    Ff = _floaten(F.descriptors, 128, True)
+    m = afv.FeatureMatcher(0.8, True, ctx=gpu_ctx)
+    Q.descriptors = _floaten(Q.descriptors, 128, True)
+    with pytest.raises(ValueError):  # binary frame, float queries
+        m.SearchByProjection(F, Q)
+    F.descriptors = np.ascontiguousarray(Ff[:, :126])  # not a multiple of 4
+    Q.descriptors = np.ascontiguousarray(Q.descriptors[:, :126])
+    with pytest.raises(afv._lib.AfvError):
+        m.SearchByProjection(F, Q)
