@@ -26,6 +26,7 @@ MAX_LEVELS = 8
 DESC_BYTES = 32
 OK, EINVAL, ENODEV, ENOMEM, EHIP, ECAPACITY, EUNSUPPORTED, ETIMEOUT = 0, -1, -2, -3, -4, -5, -6, -7
 MATCH_KF_KF, MATCH_KF_FRAME = 0, 1
+MATCH_FLOAT32 = 0x100  # OR-ed into MatchJob.mode: float rows, L2^2 distances (include/afv_hip.h AFV_MATCH_FLOAT32)
 PROJ_LOCALMAP, PROJ_LASTFRAME = 0, 1
 STAGES = ("pyramid", "fast_nms", "select_quadtree", "describe", "match_topk", "match_resolve", "retain_harris")
 

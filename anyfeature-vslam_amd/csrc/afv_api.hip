@@ -1311,14 +1311,18 @@ void afv_shared_segments(const afv_match_job &j, std::vector<Seg> &segs) {
 
 struct JobOffsets {
     size_t d1, d2, segs, idx1, idx2, v1, v2, a1, a2, out, nm;
-    int nseg, words, nout;
+    int nseg, words, nout, fdim;
     bool has_idx, has_v1, has_v2, has_ang;
 };
 
 static int validate_job(const afv_match_job &j, bool need_angles) {
     if (j.n1 < 0 || j.n2 < 0 || j.n1 > AFV_MAX_SIDE || j.n2 > AFV_MAX_SIDE) return AFV_EINVAL;
     if ((j.n1 > 0 && !j.desc1) || (j.n2 > 0 && !j.desc2)) return AFV_EINVAL;
-    if (j.desc_bytes < 1 || j.desc_bytes > 64) return AFV_EINVAL;
+    if (j.mode & AFV_MATCH_FLOAT32) {  // float rows: desc_bytes = 4 * dim, rows 16-byte aligned in the staging blob
+        if (j.desc_bytes < 16 || j.desc_bytes > 4096 || (j.desc_bytes & 15)) return AFV_EINVAL;
+    } else if (j.desc_bytes < 1 || j.desc_bytes > 64) {
+        return AFV_EINVAL;
+    }
     if (j.nnodes1 < 0 || j.nnodes2 < 0) return AFV_EINVAL;
     if (j.nnodes1 > 0 && (!j.node_id1 || !j.seg_ptr1 || !j.seg_idx1)) return AFV_EINVAL;
     if (j.nnodes2 > 0 && (!j.node_id2 || !j.seg_ptr2 || !j.seg_idx2)) return AFV_EINVAL;
@@ -1342,9 +1346,11 @@ static int validate_job(const afv_match_job &j, bool need_angles) {
 }
 
 static void stage_job(Blob &b, const afv_match_job &j, bool tri, JobOffsets &o) {
-    o.words = j.desc_bytes <= 32 ? 8 : 16;
-    o.d1 = put_desc(b, j.desc1, j.n1, j.desc_bytes, o.words);
-    o.d2 = put_desc(b, j.desc2, j.n2, j.desc_bytes, o.words);
+    o.fdim = (j.mode & AFV_MATCH_FLOAT32) ? j.desc_bytes / 4 : 0;
+    const int kind = j.mode & ~AFV_MATCH_FLOAT32;
+    o.words = o.fdim ? o.fdim : (j.desc_bytes <= 32 ? 8 : 16);
+    o.d1 = o.fdim ? b.put(j.desc1, (size_t)j.n1 * j.desc_bytes) : put_desc(b, j.desc1, j.n1, j.desc_bytes, o.words);
+    o.d2 = o.fdim ? b.put(j.desc2, (size_t)j.n2 * j.desc_bytes) : put_desc(b, j.desc2, j.n2, j.desc_bytes, o.words);
     std::vector<Seg> segs;
     afv_shared_segments(j, segs);
     o.nseg = (int)segs.size();
@@ -1355,7 +1361,7 @@ static void stage_job(Blob &b, const afv_match_job &j, bool tri, JobOffsets &o) 
         o.idx2 = b.put(j.seg_idx2, (size_t)j.seg_ptr2[j.nnodes2] * 4);
     }
     o.has_v1 = j.valid1 != nullptr;
-    o.has_v2 = j.valid2 != nullptr && (tri || j.mode != AFV_MATCH_KF_FRAME);
+    o.has_v2 = j.valid2 != nullptr && (tri || kind != AFV_MATCH_KF_FRAME);
     if (o.has_v1) o.v1 = b.put(j.valid1, (size_t)j.n1);
     if (o.has_v2) o.v2 = b.put(j.valid2, (size_t)j.n2);
     o.has_ang = !tri && j.check_orientation;
@@ -1363,7 +1369,7 @@ static void stage_job(Blob &b, const afv_match_job &j, bool tri, JobOffsets &o) 
         o.a1 = b.put(j.angle1, (size_t)j.n1 * 4);
         o.a2 = b.put(j.angle2, (size_t)j.n2 * 4);
     }
-    o.nout = (!tri && j.mode == AFV_MATCH_KF_FRAME) ? j.n2 : j.n1;
+    o.nout = (!tri && kind == AFV_MATCH_KF_FRAME) ? j.n2 : j.n1;
 }
 
 static void fill_dev_job(DevMatchJob &d, const afv_match_job &j, const JobOffsets &o, uint8_t *base, bool tri) {
@@ -1371,7 +1377,8 @@ static void fill_dev_job(DevMatchJob &d, const afv_match_job &j, const JobOffset
     d.d2 = reinterpret_cast<const uint32_t *>(base + o.d2);
     d.n1 = j.n1;
     d.n2 = j.n2;
-    d.words = o.words;
+    d.words = o.fdim ? 0 : o.words;
+    d.fdim = o.fdim;
     d.segs = reinterpret_cast<const Seg *>(base + o.segs);
     d.nseg = o.nseg;
     d.idx1 = o.has_idx ? reinterpret_cast<const int *>(base + o.idx1) : nullptr;
@@ -1384,7 +1391,7 @@ static void fill_dev_job(DevMatchJob &d, const afv_match_job &j, const JobOffset
     d.th = j.th_low;
     d.ratio = j.nnratio;
     d.check_ori = tri ? 0 : (j.check_orientation != 0);
-    d.mode = tri ? AFV_MATCH_KF_KF : j.mode;
+    d.mode = tri ? AFV_MATCH_KF_KF : (j.mode & ~AFV_MATCH_FLOAT32);
     d.out = reinterpret_cast<int *>(base + o.out);
     d.nmatches = reinterpret_cast<int *>(base + o.nm);
 }
@@ -1394,7 +1401,8 @@ static int afv_match_bow_impl(afv_ctx *c, const afv_match_job *jobs, int njobs, 
     for (int i = 0; i < njobs; ++i) {
         const int rc = validate_job(jobs[i], true);
         if (rc) return rc;
-        if (jobs[i].mode != AFV_MATCH_KF_KF && jobs[i].mode != AFV_MATCH_KF_FRAME) return AFV_EINVAL;
+        const int kind = jobs[i].mode & ~AFV_MATCH_FLOAT32;
+        if (kind != AFV_MATCH_KF_KF && kind != AFV_MATCH_KF_FRAME) return AFV_EINVAL;
     }
     HIPCHK(c, hipSetDevice(c->device));
     {

@@ -25,6 +25,7 @@ struct DevMatchJob {
     int check_ori, mode;
     int *out;
     int *nmatches;
+    int fdim;  // > 0: float descriptors - d1 / d2 are rows of fdim floats, the distance is L2^2 as cv::norm evaluates it; 0: binary, `words` dwords
 };
 
 struct SegTask {

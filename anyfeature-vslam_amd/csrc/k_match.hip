@@ -20,6 +20,8 @@
 #include "afv_jobs.h"
 
 
+#include <type_traits>
+
 #define MT 256
 #define NO_KEY 0x7fffffff
 #define MAX_SIDE 8192  // features per side a job may hold (LDS bitset + bin table)
@@ -100,6 +102,56 @@ __device__ __forceinline__ int hamming_words(const uint32_t *a_regs, const uint3
     return d;
 }
 
+// ---------------- float descriptors inside the BoW-guided matchers (round 6; W == 0 in the templates below) ----------------
+// FeatureMatcher::DescriptorDistance dispatches on DescriptorType (FeatureMatcher.cc:1508-1531, called from SearchByBoW :236 / :616 and
+// SearchForTriangulation :734); for SIFT128 / SURF64 / KAZE64 / R2D2 it is cv::norm(a, b, NORM_L2SQR) narrowed to float
+// (Feature_sift128.cpp:132-134, Types.h:127).  A non-negative float's bits order like the number, so (best key, second distance) =
+// (distance bits << 32 | position, distance bits) merge exactly like the integer pair of the binary path.
+__device__ __forceinline__ float l2sqr(const float *a, const float *b, int n) {
+    // normL2Sqr<float,double>: float differences, double squares, 4-way partial sums
+    double s = 0;
+    int i = 0;
+    for (; i <= n - 4; i += 4) {
+        const double v0 = (double)(a[i] - b[i]), v1 = (double)(a[i + 1] - b[i + 1]), v2 = (double)(a[i + 2] - b[i + 2]),
+                     v3 = (double)(a[i + 3] - b[i + 3]);
+        s += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
+    }
+    for (; i < n; ++i) {
+        const double v = (double)(a[i] - b[i]);
+        s += v * v;
+    }
+    return (float)s;
+}
+__device__ __forceinline__ void merge_best(unsigned long long &k, unsigned &s, unsigned long long k2, unsigned s2) {
+    if (k2 < k) {
+        s = min(s2, (unsigned)(k >> 32));
+        k = k2;
+    } else {
+        s = min(s, (unsigned)(k2 >> 32));
+    }
+}
+template <int W>
+struct BowKey {  // binary: distance << 16 | position in an int, second-best distance in an int
+    using key_t = int;
+    using sec_t = int;
+    static constexpr key_t none = NO_KEY;
+    static constexpr sec_t none2 = NO_KEY >> 16;
+    static __device__ __forceinline__ key_t make(int d, int b) { return (d << 16) | b; }
+    static __device__ __forceinline__ float dist(key_t k) { return (float)(k >> 16); }
+    static __device__ __forceinline__ float second(sec_t s) { return s == none2 ? 3.402823466e+38f : (float)s; }
+};
+template <>
+struct BowKey<0> {  // float: distance bits << 32 | position, second-best distance bits
+    using key_t = unsigned long long;
+    using sec_t = unsigned;
+    static constexpr key_t none = ~0ull;
+    static constexpr sec_t none2 = ~0u;
+    static __device__ __forceinline__ key_t make(float d, int b) { return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)b; }
+    static __device__ __forceinline__ float dist(key_t k) { return __uint_as_float((unsigned)(k >> 32)); }
+    static __device__ __forceinline__ float second(sec_t s) { return s == none2 ? 3.402823466e+38f : __uint_as_float(s); }
+};
+__device__ __forceinline__ const float *frow(const uint32_t *base, int idx, int dim) { return reinterpret_cast<const float *>(base) + (size_t)idx * dim; }
+
 // core of M2 / M3 for one job, executed by a whole workgroup.  s_* are LDS scratch.
 template <int W>
 __device__ void match_bow_job(const DevMatchJob &J, uint32_t *s_matched, uint8_t *s_bin, int *s_red, int *s_hist) {
@@ -117,36 +169,62 @@ __device__ void match_bow_job(const DevMatchJob &J, uint32_t *s_matched, uint8_t
         for (int a = 0; a < S.n1; ++a) {
             const int idx1 = J.idx1 ? J.idx1[S.s1 + a] : S.s1 + a;
             if (J.valid1 && !J.valid1[idx1]) continue;  // uniform
-            uint32_t q[W];
+            using BK = BowKey<W>;
+            uint32_t q[W == 0 ? 1 : W];
+            if constexpr (W != 0) {
 #pragma unroll
-            for (int i = 0; i < W; ++i) q[i] = J.d1[(size_t)idx1 * W + i];
-            int k = NO_KEY, s = NO_KEY >> 16;
+                for (int i = 0; i < W; ++i) q[i] = J.d1[(size_t)idx1 * W + i];
+            }
+            typename BK::key_t k = BK::none;
+            typename BK::sec_t s = BK::none2;
             for (int b = tid; b < S.n2; b += MT) {
                 const int idx2 = J.idx2 ? J.idx2[S.s2 + b] : S.s2 + b;
                 if ((s_matched[idx2 >> 5] >> (idx2 & 31)) & 1u) continue;
                 if (!kf_frame && J.valid2 && !J.valid2[idx2]) continue;
-                const int d = hamming_words<W>(q, J.d2 + (size_t)idx2 * W);
-                merge_best(k, s, (d << 16) | b, NO_KEY >> 16);
+                if constexpr (W == 0) {
+                    (void)q;
+                    merge_best(k, s, BK::make(l2sqr(frow(J.d1, idx1, J.fdim), frow(J.d2, idx2, J.fdim), J.fdim), b), BK::none2);
+                } else {
+                    const int d = hamming_words<W>(q, J.d2 + (size_t)idx2 * W);
+                    merge_best(k, s, (d << 16) | b, NO_KEY >> 16);
+                }
             }
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) {
-                const int k2 = __shfl_xor(k, m, 64), s2 = __shfl_xor(s, m, 64);
+                const typename BK::key_t k2 = __shfl_xor(k, m, 64);
+                const typename BK::sec_t s2 = __shfl_xor(s, m, 64);
                 merge_best(k, s, k2, s2);
             }
+            // (binary: slots 2 wv, 2 wv + 1; float: the key's two halves and the second distance in slots 20 + 3 wv ..)
             if (lane == 0) {
-                s_red[wv * 2] = k;
-                s_red[wv * 2 + 1] = s;
+                if constexpr (W == 0) {
+                    s_red[20 + wv * 3] = (int)(unsigned)k;
+                    s_red[21 + wv * 3] = (int)(unsigned)(k >> 32);
+                    s_red[22 + wv * 3] = (int)s;
+                } else {
+                    s_red[wv * 2] = k;
+                    s_red[wv * 2 + 1] = s;
+                }
             }
             __syncthreads();
             if (tid == 0) {
-                int K = s_red[0], Sx = s_red[1];
-                for (int w = 1; w < MT / 64; ++w) merge_best(K, Sx, s_red[2 * w], s_red[2 * w + 1]);
-                if (K != NO_KEY) {
-                    const float best1 = (float)(K >> 16);
-                    const float best2 = (Sx == (NO_KEY >> 16)) ? 3.402823466e+38f : (float)Sx;
+                typename BK::key_t K;
+                typename BK::sec_t Sx;
+                if constexpr (W == 0) {
+                    K = ((unsigned long long)(unsigned)s_red[21] << 32) | (unsigned)s_red[20];
+                    Sx = (unsigned)s_red[22];
+                    for (int w = 1; w < MT / 64; ++w)
+                        merge_best(K, Sx, ((unsigned long long)(unsigned)s_red[21 + 3 * w] << 32) | (unsigned)s_red[20 + 3 * w], (unsigned)s_red[22 + 3 * w]);
+                } else {
+                    K = s_red[0], Sx = s_red[1];
+                    for (int w = 1; w < MT / 64; ++w) merge_best(K, Sx, s_red[2 * w], s_red[2 * w + 1]);
+                }
+                if (K != BK::none) {
+                    const float best1 = BK::dist(K);
+                    const float best2 = BK::second(Sx);
                     const bool under = kf_frame ? (best1 <= J.th) : (best1 < J.th);  // FeatureMatcher.cc:250 / :630
                     if (under && best1 < J.ratio * best2) {                            // :252 / :632
-                        const int b = K & 0xffff;
+                        const int b = (int)(K & 0xffff);
                         const int idx2 = J.idx2 ? J.idx2[S.s2 + b] : S.s2 + b;
                         const int key = kf_frame ? idx2 : idx1;
                         J.out[key] = kf_frame ? idx1 : idx2;
@@ -201,7 +279,8 @@ __global__ __launch_bounds__(MT) void k_match_bow(const DevMatchJob *__restrict_
     __shared__ int s_red[32];
     __shared__ int s_hist[32];
     const DevMatchJob J = jobs[blockIdx.x];
-    if (J.words == 8) match_bow_job<8>(J, s_matched, s_bin, s_red, s_hist);
+    if (J.fdim) match_bow_job<0>(J, s_matched, s_bin, s_red, s_hist);
+    else if (J.words == 8) match_bow_job<8>(J, s_matched, s_bin, s_red, s_hist);
     else match_bow_job<16>(J, s_matched, s_bin, s_red, s_hist);
 }
 
@@ -274,10 +353,13 @@ __device__ __forceinline__ void bow_segment_small(const DevMatchJob &J, const Se
 
 template <int W>
 __device__ void bow_segment(const DevMatchJob &J, const Seg S, uint32_t *s_taken, int *hist, uint8_t *bins) {
-    if (S.n1 <= 64 && S.n2 <= 64) {  // wave-uniform
-        bow_segment_small<W>(J, S, hist, bins);
-        return;
+    if constexpr (W != 0) {
+        if (S.n1 <= 64 && S.n2 <= 64) {  // wave-uniform
+            bow_segment_small<W>(J, S, hist, bins);
+            return;
+        }
     }
+    using BK = BowKey<W>;
     const int lane = threadIdx.x & 63;
     const bool kf_frame = J.mode == AFV_MATCH_KF_FRAME;
     for (int i = lane; i < (S.n2 + 31) / 32; i += 64) s_taken[i] = 0;
@@ -286,28 +368,37 @@ __device__ void bow_segment(const DevMatchJob &J, const Seg S, uint32_t *s_taken
     for (int a = 0; a < S.n1; ++a) {
         const int idx1 = J.idx1 ? J.idx1[S.s1 + a] : S.s1 + a;
         if (J.valid1 && !J.valid1[idx1]) continue;  // uniform
-        uint32_t q[W];
+        uint32_t q[W == 0 ? 1 : W];
+        if constexpr (W != 0) {
 #pragma unroll
-        for (int i = 0; i < W; ++i) q[i] = J.d1[(size_t)idx1 * W + i];
-        int k = NO_KEY, s = NO_KEY >> 16;
+            for (int i = 0; i < W; ++i) q[i] = J.d1[(size_t)idx1 * W + i];
+        }
+        typename BK::key_t k = BK::none;
+        typename BK::sec_t s = BK::none2;
         for (int b = lane; b < S.n2; b += 64) {
             if ((s_taken[b >> 5] >> (b & 31)) & 1u) continue;
             const int idx2 = J.idx2 ? J.idx2[S.s2 + b] : S.s2 + b;
             if (!kf_frame && J.valid2 && !J.valid2[idx2]) continue;
-            const int d = hamming_words<W>(q, J.d2 + (size_t)idx2 * W);
-            merge_best(k, s, (d << 16) | b, NO_KEY >> 16);
+            if constexpr (W == 0) {
+                (void)q;
+                merge_best(k, s, BK::make(l2sqr(frow(J.d1, idx1, J.fdim), frow(J.d2, idx2, J.fdim), J.fdim), b), BK::none2);
+            } else {
+                const int d = hamming_words<W>(q, J.d2 + (size_t)idx2 * W);
+                merge_best(k, s, (d << 16) | b, NO_KEY >> 16);
+            }
         }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
-            const int k2 = __shfl_xor(k, m, 64), s2 = __shfl_xor(s, m, 64);
+            const typename BK::key_t k2 = __shfl_xor(k, m, 64);
+            const typename BK::sec_t s2 = __shfl_xor(s, m, 64);
             merge_best(k, s, k2, s2);
         }
-        if (k == NO_KEY) continue;
-        const float best1 = (float)(k >> 16);
-        const float best2 = (s == (NO_KEY >> 16)) ? 3.402823466e+38f : (float)s;
+        if (k == BK::none) continue;
+        const float best1 = BK::dist(k);
+        const float best2 = BK::second(s);
         const bool under = kf_frame ? (best1 <= J.th) : (best1 < J.th);  // FeatureMatcher.cc:250 / :630
         if (under && best1 < J.ratio * best2) {                            // :252 / :632
-            const int b = k & 0xffff;
+            const int b = (int)(k & 0xffff);
             if (lane == 0) {
                 const int idx2 = J.idx2 ? J.idx2[S.s2 + b] : S.s2 + b;
                 const int key = kf_frame ? idx2 : idx1;
@@ -337,7 +428,8 @@ __global__ __launch_bounds__(MT) void k_match_bow_seg(const DevMatchJob *__restr
     const SegTask T = tasks[t];
     const DevMatchJob J = jobs[T.job];
     const Seg S = J.segs[T.seg];
-    if (J.words == 8) bow_segment<8>(J, S, s_taken[wv], hist + T.job * 32, bins + bin_off[T.job]);
+    if (J.fdim) bow_segment<0>(J, S, s_taken[wv], hist + T.job * 32, bins + bin_off[T.job]);
+    else if (J.words == 8) bow_segment<8>(J, S, s_taken[wv], hist + T.job * 32, bins + bin_off[T.job]);
     else bow_segment<16>(J, S, s_taken[wv], hist + T.job * 32, bins + bin_off[T.job]);
 }
 
@@ -1164,9 +1256,11 @@ __device__ int tri_row(const DevTriJob &T, int idx1) {
     const bool stereo1 = T.u_right1 && T.u_right1[idx1] >= 0.0f;  // :705
     if (T.only_stereo && !stereo1) return -1;                      // :707-709
     const Seg S = J.segs[sg];
-    uint32_t q[W];
+    uint32_t q[W == 0 ? 1 : W];
+    if constexpr (W != 0) {
 #pragma unroll
-    for (int i = 0; i < W; ++i) q[i] = J.d1[(size_t)idx1 * W + i];
+        for (int i = 0; i < W; ++i) q[i] = J.d1[(size_t)idx1 * W + i];
+    }
     const float kx = T.x1[idx1], ky = T.y1[idx1];
     // epipolar line in image 2: l = x1' F12 (:168-170)
     const float la = kx * T.F[0] + ky * T.F[3] + T.F[6];
@@ -1174,13 +1268,22 @@ __device__ int tri_row(const DevTriJob &T, int idx1) {
     const float lc = kx * T.F[2] + ky * T.F[5] + T.F[8];
     const float den = la * la + lb * lb;
     if (den == 0) return -1;
-    int best = 0x7fffffff, best_idx = -1;
+    std::conditional_t<W == 0, float, int> best;  // bestDist starts at TH_LOW (:714): the test below against J.th says the same
+    if constexpr (W == 0) best = 3.402823466e+38f;
+    else best = 0x7fffffff;
+    int best_idx = -1;
     for (int b = 0; b < S.n2; ++b) {
         const int idx2 = J.idx2 ? J.idx2[S.s2 + b] : S.s2 + b;
         if (J.valid2 && J.valid2[idx2]) continue;
         const bool stereo2 = T.u_right2 && T.u_right2[idx2] >= 0.0f;  // :727
         if (T.only_stereo && !stereo2) continue;                      // :729-731
-        const int d = hamming_words<W>(q, J.d2 + (size_t)idx2 * W);
+        decltype(best) d;
+        if constexpr (W == 0) {
+            (void)q;
+            d = l2sqr(frow(J.d1, idx1, J.fdim), frow(J.d2, idx2, J.fdim), J.fdim);
+        } else {
+            d = hamming_words<W>(q, J.d2 + (size_t)idx2 * W);
+        }
         if ((float)d > J.th || d > best) continue;
         const float x2 = T.x2[idx2], y2 = T.y2[idx2], sg2 = T.sigma2_2[idx2];
         if (!stereo1 && !stereo2) {
@@ -1201,30 +1304,14 @@ __global__ __launch_bounds__(MT) void k_match_tri(const DevTriJob *__restrict__ 
     const int i = blockIdx.x * MT + threadIdx.x;
     int r = -1;
     if (i < T.m.n1) {
-        r = T.m.words == 8 ? tri_row<8>(T, i) : tri_row<16>(T, i);
+        r = T.m.fdim ? tri_row<0>(T, i) : (T.m.words == 8 ? tri_row<8>(T, i) : tri_row<16>(T, i));
         T.m.out[i] = r;
     }
     const int cnt = __popcll(__ballot(r >= 0));
     if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(T.m.nmatches, cnt);  // the counter arrives zeroed with the staging blob
 }
 
-// ---------------- M8: float descriptors, L2^2 (cv::norm NORM_L2SQR semantics) ----------------
-__device__ __forceinline__ float l2sqr(const float *a, const float *b, int n) {
-    // normL2Sqr<float,double>: float differences, double squares, 4-way partial sums
-    double s = 0;
-    int i = 0;
-    for (; i <= n - 4; i += 4) {
-        const double v0 = (double)(a[i] - b[i]), v1 = (double)(a[i + 1] - b[i + 1]), v2 = (double)(a[i + 2] - b[i + 2]),
-                     v3 = (double)(a[i + 3] - b[i + 3]);
-        s += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
-    }
-    for (; i < n; ++i) {
-        const double v = (double)(a[i] - b[i]);
-        s += v * v;
-    }
-    return (float)s;
-}
-
+// ---------------- M8: float descriptors, L2^2 (cv::norm NORM_L2SQR semantics): l2sqr() above ----------------
 __device__ __forceinline__ void merge_best_f(float &d, int &p, float &s, float d2, int p2, float s2) {
     if (d2 < d || (d2 == d && p2 < p)) {
         s = fminf(s2, d);

@@ -33,6 +33,14 @@ def ComputeDistinctiveDescriptors(ctx, descriptor_sets):
     return best[:len(sets)].copy(), med[:len(sets)].copy()
 
 
+def _descriptor_rows(descriptors):
+    """mDescriptors as the matchers take it: uint8 rows (binary descriptors, Hamming) or float32 rows (SIFT128 / SURF64 / KAZE64 / R2D2 ...:
+    cv::norm(a, b, NORM_L2SQR), Feature_sift128.cpp:132-134) - FeatureMatcher::DescriptorDistance dispatches on the type
+    (FeatureMatcher.cc:1508-1531)"""
+    d = np.asarray(descriptors)
+    return np.ascontiguousarray(d, np.float32 if d.dtype.kind == "f" else np.uint8)
+
+
 class FeatureView:
     """Flattened view of one KeyFrame / Frame for matching.
 
@@ -46,7 +54,7 @@ class FeatureView:
     """
 
     def __init__(self, descriptors, featvec=None, valid=None, angles=None, pts=None, sigma2=None, u_right=None):
-        self.descriptors = np.ascontiguousarray(descriptors, np.uint8)
+        self.descriptors = _descriptor_rows(descriptors)   # uint8 rows (Hamming) or float32 rows (L2^2)
         if self.descriptors.ndim != 2:
             self.descriptors = self.descriptors.reshape(0, 32)
         self.N = self.descriptors.shape[0]
@@ -71,14 +79,6 @@ class FeatureView:
                         if self.featvec else np.zeros(0, np.int32))
                 self._csr = (ids, ptrs, np.ascontiguousarray(flat, np.int32), len(self.featvec))
         return self._csr
-
-
-def _descriptor_rows(descriptors):
-    """mDescriptors as the matchers take it: uint8 rows (binary descriptors, Hamming) or float32 rows (SIFT128 / SURF64 / KAZE64 / R2D2 ...:
-    cv::norm(a, b, NORM_L2SQR), Feature_sift128.cpp:132-134) - FeatureMatcher::DescriptorDistance dispatches on the type
-    (FeatureMatcher.cc:1508-1531)"""
-    d = np.asarray(descriptors)
-    return np.ascontiguousarray(d, np.float32 if d.dtype.kind == "f" else np.uint8)
 
 
 class FrameGridView:
@@ -163,6 +163,12 @@ class FeatureMatcher:
         j.desc1 = ptr(v1.descriptors); j.n1 = v1.N
         j.desc2 = ptr(v2.descriptors); j.n2 = v2.N
         j.desc_bytes = v1.descriptors.shape[1] if v1.N else (v2.descriptors.shape[1] if v2.N else 32)
+        is_float = (v1.N and v1.descriptors.dtype.kind == "f") or (v2.N and v2.descriptors.dtype.kind == "f")
+        if is_float:  # float descriptors: rows of desc_bytes / 4 floats, L2^2 distances (AFV_MATCH_FLOAT32)
+            if v1.N and v2.N and (v1.descriptors.dtype != v2.descriptors.dtype or v1.descriptors.shape[1] != v2.descriptors.shape[1]):
+                raise ValueError("both sides must carry the same kind of descriptor")
+            j.desc_bytes *= 4
+            mode |= _lib.MATCH_FLOAT32
         i1, p1, f1, n1 = v1.csr(); i2, p2, f2, n2 = v2.csr()
         j.node_id1 = ptr(i1); j.seg_ptr1 = ptr(p1); j.seg_idx1 = ptr(f1); j.nnodes1 = n1
         j.node_id2 = ptr(i2); j.seg_ptr2 = ptr(p2); j.seg_idx2 = ptr(f2); j.nnodes2 = n2

@@ -127,7 +127,13 @@ int afv_orb_extract_batch_device(afv_ctx *ctx, const uint8_t *d_frames, int nfra
 int afv_orb_size_sigma(const afv_ctx *ctx, const afv_keypoint *kps, int n, float *size, float *sigma2, float *inf);
 
 /* ---- matching ---- */
-enum { AFV_MATCH_KF_KF = 0, AFV_MATCH_KF_FRAME = 1 };
+enum { AFV_MATCH_KF_KF = 0, AFV_MATCH_KF_FRAME = 1,
+       /* OR-ed into afv_match_job.mode (round 6): the descriptors are FLOAT rows - desc1 / desc2 point to n x (desc_bytes / 4) floats,
+          desc_bytes = 4 * dim (a multiple of 16, <= 4096) - and the distance is cv::norm(a, b, NORM_L2SQR) narrowed to float, what
+          FeatureMatcher::DescriptorDistance returns for SIFT128 / SURF64 / KAZE64 / R2D2 (FeatureMatcher.cc:1508-1531,
+          Feature_sift128.cpp:132-134), evaluated like afv_match_l2.  afv_match_bow and afv_match_triangulation (bow.mode) take it;
+          th_low / nnratio apply to the float distances as they stand. */
+       AFV_MATCH_FLOAT32 = 0x100 };
 
 typedef struct {
     const uint8_t *desc1; int32_t n1;   /* side 1 (KF1 / KF), n1 x desc_bytes, row-major */
@@ -158,8 +164,8 @@ int afv_match_bow(afv_ctx *ctx, const afv_match_job *jobs, int njobs, int32_t *o
  * having uninitialised tail pointers dereferenced.  Records grow only at the end. */
 typedef struct {
     uint32_t struct_size;            /* sizeof(afv_tri_job) */
-    afv_match_job bow;               /* valid1/valid2 mean "already HAS a map point" => skipped; mode/nnratio/
-                                        check_orientation ignored */
+    afv_match_job bow;               /* valid1/valid2 mean "already HAS a map point" => skipped; nnratio / check_orientation and
+                                        mode (but for its AFV_MATCH_FLOAT32 bit) ignored */
     const float *x1, *y1, *x2, *y2; /* mvKeysUn */
     const float *sigma2_2;           /* KeyFrame::GetKeyPt1DSigma2 of side 2 */
     float F12[9];                    /* row-major fundamental matrix */

@@ -923,6 +923,9 @@ float afvo_l2sqr(const float *a, const float *b, int n) {
 }
 
 static float bow_dist(const afvo_bow_job *j, int i1, int i2) {
+    if (j->float_dim > 0)
+        return afvo_l2sqr((const float *)(const void *)j->desc1 + (size_t)i1 * j->float_dim, (const float *)(const void *)j->desc2 + (size_t)i2 * j->float_dim,
+                          j->float_dim);
     const u8 *a = j->desc1 + (size_t)i1 * j->desc_bytes, *b = j->desc2 + (size_t)i2 * j->desc_bytes;
     if (j->desc_bytes == 32) return (float)afvo_hamming256(a, b);
     return (float)afvo_hamming_bytes(a, b, j->desc_bytes);

@@ -123,6 +123,8 @@ typedef struct {
     const uint8_t *valid1; const uint8_t *valid2; /* NULL => all valid */
     const float *angle1; const float *angle2;     /* degrees, needed iff check_orientation */
     float th_low; float nnratio; int32_t check_orientation;
+    int32_t float_dim;             /* > 0: desc1 / desc2 are rows of float_dim floats, the distance is afvo_l2sqr (DescriptorDistance
+                                      dispatches on DescriptorType, FeatureMatcher.cc:1508-1531); 0: binary rows of desc_bytes */
 } afvo_bow_job;
 
 /* M2: SearchByBoW(KF,KF) FeatureMatcher.cc:561-660. match12[n1] = idx2 or -1. returns nmatches */

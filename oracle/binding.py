@@ -43,7 +43,7 @@ class BowJob(C.Structure):
                 ("node_id1", C.c_void_p), ("seg_ptr1", C.c_void_p), ("seg_idx1", C.c_void_p), ("nnodes1", C.c_int32),
                 ("node_id2", C.c_void_p), ("seg_ptr2", C.c_void_p), ("seg_idx2", C.c_void_p), ("nnodes2", C.c_int32),
                 ("valid1", C.c_void_p), ("valid2", C.c_void_p), ("angle1", C.c_void_p), ("angle2", C.c_void_p),
-                ("th_low", C.c_float), ("nnratio", C.c_float), ("check_orientation", C.c_int32)]
+                ("th_low", C.c_float), ("nnratio", C.c_float), ("check_orientation", C.c_int32), ("float_dim", C.c_int32)]
 
 
 class TriJob(C.Structure):
@@ -348,10 +348,14 @@ def _csr(nodes):
 
 
 def _bow_job(desc1, desc2, nodes1, nodes2, valid1, valid2, angle1, angle2, th_low, nnratio, check_ori, keep):
-    desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    is_float = np.asarray(desc1).dtype.kind == "f" or np.asarray(desc2).dtype.kind == "f"  # float descriptors: L2^2 (Feature_sift128.cpp:132-134)
+    dt = np.float32 if is_float else np.uint8
+    desc1 = np.ascontiguousarray(desc1, dt); desc2 = np.ascontiguousarray(desc2, dt)
     j = BowJob()
     j.desc1 = _p(desc1); j.n1 = desc1.shape[0]; j.desc2 = _p(desc2); j.n2 = desc2.shape[0]
     j.desc_bytes = desc1.shape[1] if desc1.ndim == 2 and desc1.shape[0] else (desc2.shape[1] if desc2.ndim == 2 else 32)
+    if is_float:
+        j.float_dim = j.desc_bytes; j.desc_bytes *= 4
     i1, p1, f1, n1 = _csr(nodes1); i2, p2, f2, n2 = _csr(nodes2)
     j.node_id1 = _p(i1); j.seg_ptr1 = _p(p1); j.seg_idx1 = _p(f1); j.nnodes1 = n1
     j.node_id2 = _p(i2); j.seg_ptr2 = _p(p2); j.seg_idx2 = _p(f2); j.nnodes2 = n2

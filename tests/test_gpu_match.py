@@ -199,6 +199,72 @@ def test_l2_float_descriptors(afv, oracle, matcher):
     assert gn == wn and np.array_equal(got, want) and wn > 100
 
 
+@pytest.mark.parametrize("dim,real", [(128, True), (64, False)])
+@pytest.mark.parametrize("frame", [False, True])
+def test_bow_guided_matchers_on_float_descriptors(afv, oracle, matcher, frame, dim, real):
+    """SearchByBoW(KF, KF) / (KF, F) with DescriptorDistance = cv::norm(a, b, NORM_L2SQR) (FeatureMatcher.cc:1508-1531 dispatches on the
+    descriptor type; Feature_sift128.cpp:132-134): per-node walks and the one-node brute-force form"""
+    from _float_desc import floaten
+    d1, d2, a1, a2 = _sets(afv, 71, 900, 1000)
+    f1, f2 = floaten(d1, dim, real), floaten(d2, dim, real)
+    th = 75.0 * dim / 256.0 * (0.6 if real else 1.0)
+    v1 = (afv.synth.lcg_bytes(72, 900) > 40).astype(np.uint8)
+    v2 = (afv.synth.lcg_bytes(73, 1000) > 40).astype(np.uint8)
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(th)
+    try:
+        matcher.mbCheckOrientation = True
+        matcher.mfNNratio = 0.8
+        def fvec(node_of, nnodes):
+            return [(int(k * 3 + 1), np.nonzero(node_of == k)[0].tolist()) for k in range(nnodes) if (node_of == k).any()]
+
+        for nnodes in (60, 3, 0):  # many small nodes; nodes above 64 features; one node (brute force)
+            fv1 = fv2 = None
+            if nnodes:  # a feature of side 2 mostly sits in the node of the side-1 feature it was derived from (row i % 900)
+                node1 = afv.synth.lcg_states(74, 900) % nnodes
+                node2 = np.where(afv.synth.lcg_bytes(75, 1000) < 230, node1[np.arange(1000) % 900], afv.synth.lcg_states(76, 1000) % nnodes)
+                fv1, fv2 = fvec(node1, nnodes), fvec(node2, nnodes)
+            got, n = matcher.SearchByBoW(afv.FeatureView(f1, fv1, v1, a1), afv.FeatureView(f2, fv2, v2, a2), frame=frame)
+            if frame:
+                want, wn = oracle.search_by_bow_kf_frame(f1, f2, fv1, fv2, v1, a1, a2, th, 0.8, True)
+            else:
+                want, wn = oracle.search_by_bow_kf_kf(f1, f2, fv1, fv2, v1, v2, a1, a2, th, 0.8, True)
+            assert n == wn and np.array_equal(got, want), nnodes
+            assert wn > 20, nnodes
+    finally:
+        matcher.mfNNratio = 0.6
+        afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+
+
+def test_triangulation_on_float_descriptors(afv, oracle, matcher):
+    from _float_desc import floaten
+    s = afv.synth
+    n1, n2 = 800, 900
+    d1, d2, _, _ = _sets(afv, 81, n1, n2)
+    fv1, fv2 = _featvec(afv, 82, n1, 40), _featvec(afv, 83, n2, 40)
+    p1 = np.stack([(s.lcg_states(84, n1) % 64000) / 100.0, (s.lcg_states(85, n1) % 48000) / 100.0], 1).astype(np.float32)
+    p2 = np.stack([(s.lcg_states(86, n2) % 64000) / 100.0, (s.lcg_states(87, n2) % 48000) / 100.0], 1).astype(np.float32)
+    sigma2 = ((np.float32(1.2) ** (s.lcg_states(88, n2) % 8).astype(np.float32)) ** 2).astype(np.float32) * 400.0
+    has1 = (s.lcg_bytes(89, n1) > 128).astype(np.uint8)
+    has2 = (s.lcg_bytes(90, n2) > 128).astype(np.uint8)
+    F = np.array([[0, 0, 0], [0, 0, -1e-3], [0, 1e-3, 0]], np.float32)
+    ep = (1e6, 240.0)
+    try:
+        for dim, real, th in ((128, True, 40.0), (64, False, 30.0)):  # the tie-rich rows: "the LAST candidate at the best distance wins" (:736)
+            f1, f2 = floaten(d1, dim, real), floaten(d2, dim, real)
+            afv.FeatureMatcher.TH_LOW = th
+            k1 = afv.FeatureView(f1, fv1, has1, pts=p1)
+            k2 = afv.FeatureView(f2, fv2, has2, pts=p2, sigma2=sigma2)
+            pairs, n = matcher.SearchForTriangulation(k1, k2, F, ep)
+            want, wn = oracle.search_for_triangulation(f1, f2, p1, p2, sigma2, F, ep, fv1, fv2, has1, has2, th)
+            got = np.full(n1, -1, np.int32)
+            for a, b in pairs:
+                got[a] = b
+            assert n == wn and np.array_equal(got, want), (dim, real)
+            assert wn > 10
+    finally:
+        afv.FeatureMatcher.TH_LOW = 75.0
+
+
 def _sift_like(s, seed, n, dim, noise_div):
     a = (s.lcg_bytes(seed, n * dim).reshape(n, dim).astype(np.float32)) ** 2
     a /= np.linalg.norm(a, axis=1, keepdims=True)
