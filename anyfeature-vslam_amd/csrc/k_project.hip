@@ -1079,14 +1079,14 @@ __global__ __launch_bounds__(PT) void k_match_fuse1(const DevProjJob J) {
 // queries in order.  The gate only ever removes candidates, so best / second are the first two ungated keys; when the
 // IK keys run out before two are found (and the window holds more) the window is rescanned exactly.
 template <int W>
-__device__ void init_resolve(const DevProjJob &J) {
-    // binary: holder as int, its distance as u16 (48 KB); float distances need 32 bits, so the holder shrinks to u16 (nq <= 65535: 0xffff = none)
+__device__ void init_resolve(const DevProjJob &J, unsigned char *s_tables /* 6 x P_MAX_FEATS bytes, 16-byte aligned */, int *s_hist) {
+    // binary: holder as int, its distance as u16 (48 KB); float distances need 32 bits, so the holder shrinks to u16 (nq <= 65535: 0xffff = none).
+    // (One buffer in the kernel, typed here: static arrays inside this template would be laid out once PER INSTANTIATION - 3 x 48 KB.)
     using m21_t = std::conditional_t<W == 0, unsigned short, int>;
     using md_t = std::conditional_t<W == 0, float, unsigned short>;
     constexpr m21_t M21_NONE = (m21_t)-1;
-    __shared__ m21_t s_m21[P_MAX_FEATS];
-    __shared__ md_t s_mdist[P_MAX_FEATS];
-    __shared__ int s_hist[32];
+    md_t *s_mdist = reinterpret_cast<md_t *>(s_tables + (W == 0 ? 0 : P_MAX_FEATS * 4));
+    m21_t *s_m21 = reinterpret_cast<m21_t *>(s_tables + (W == 0 ? P_MAX_FEATS * 4 : 0));
     const int lane = threadIdx.x;
     for (int i = lane; i < J.n; i += 64) {
         s_m21[i] = M21_NONE;
@@ -1218,10 +1218,12 @@ __device__ void init_resolve(const DevProjJob &J) {
 }
 
 __global__ __launch_bounds__(64) void k_init_resolve(const DevProjJob *__restrict__ jobs) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_tables[P_MAX_FEATS * 6];
+    __shared__ int s_hist[32];
     const DevProjJob J = jobs[blockIdx.x];
-    if (J.fdim) init_resolve<0>(J);
-    else if (J.words == 8) init_resolve<8>(J);
-    else init_resolve<16>(J);
+    if (J.fdim) init_resolve<0>(J, s_tables, s_hist);
+    else if (J.words == 8) init_resolve<8>(J, s_tables, s_hist);
+    else init_resolve<16>(J, s_tables, s_hist);
 }
 
 // ---------------- SearchForInitialization, workgroup form (round 5) ----------------
