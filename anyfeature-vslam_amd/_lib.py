@@ -88,7 +88,8 @@ class ProjJob(C.Structure):
 
 class FrameParams(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float),
-                ("grid_cols", C.c_int32), ("grid_rows", C.c_int32), ("distorted", C.c_int32), ("cap", C.c_int32), ("desc_bytes", C.c_int32)]
+                ("grid_cols", C.c_int32), ("grid_rows", C.c_int32), ("distorted", C.c_int32), ("cap", C.c_int32), ("desc_bytes", C.c_int32),
+                ("float_dim", C.c_int32)]
 
 
 class ProjQueries(C.Structure):

@@ -1786,9 +1786,8 @@ int afv_match_projection_core(afv_ctx *c, const afv_proj_job *jobs, int njobs, i
     for (int i = 0; i < njobs; ++i) {
         const afv_proj_job &j = jobs[i];
         if (j.n < 0 || j.n > AFV_MAX_SIDE || j.nq < 0 || j.nq > 65535) return AFV_EINVAL;
-        if (j.float_dim != 0) {  // float descriptors (L2^2): host arrays on both sides, rows of float_dim floats
+        if (j.float_dim != 0) {  // float descriptors (L2^2): rows of float_dim floats
             if (j.float_dim < 4 || j.float_dim > 1024 || (j.float_dim & 3)) return AFV_EINVAL;
-            if (dev) return AFV_EUNSUPPORTED;  // the resident frame holds binary rows
         } else if (j.desc_bytes < 1 || j.desc_bytes > 64) {
             return AFV_EINVAL;
         }

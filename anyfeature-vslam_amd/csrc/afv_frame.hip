@@ -40,9 +40,10 @@ extern "C" int afv_frame_create(afv_ctx *c, const afv_frame_params *params, afv_
     std::memcpy(&p, params, std::min<size_t>(params->struct_size, sizeof(p)));
     if (p.grid_cols < 1 || p.grid_rows < 1 || (long)p.grid_cols * p.grid_rows > 8192) return AFV_EINVAL;
     if (!(p.max_x > p.min_x) || !(p.max_y > p.min_y)) return AFV_EINVAL;
-    const int desc_bytes = p.desc_bytes == 0 ? AFV_DESC_BYTES : p.desc_bytes;  // (callers of the round-5 layout: the field reads 0)
-    if (desc_bytes < 1 || desc_bytes > 64) return AFV_EINVAL;
-    const int words = desc_bytes <= 32 ? 8 : 16;
+    if (p.float_dim != 0 && (p.float_dim < 4 || p.float_dim > 1024 || (p.float_dim & 3))) return AFV_EINVAL;
+    const int desc_bytes = p.float_dim ? 4 * p.float_dim : (p.desc_bytes == 0 ? AFV_DESC_BYTES : p.desc_bytes);  // (callers of the round-5 layout: the fields read 0)
+    if (!p.float_dim && (desc_bytes < 1 || desc_bytes > 64)) return AFV_EINVAL;
+    const int words = p.float_dim ? p.float_dim : (desc_bytes <= 32 ? 8 : 16);
     const int cap = p.cap > 0 ? p.cap : c->stage_cap;
     if (cap < 1 || cap > AFV_MAX_SIDE) return AFV_EINVAL;
     // the grid and the FeatureVector body are each built by ONE workgroup in LDS: what does not fit is refused here, not at the first launch
@@ -59,6 +60,7 @@ extern "C" int afv_frame_create(afv_ctx *c, const afv_frame_params *params, afv_
         f->cap = cap;
         f->desc_bytes = desc_bytes;
         f->words = words;
+        f->float_dim = p.float_dim;
         // Frame.cc:201-202: mfGridElementWidthInv = FRAME_GRID_COLS / (mnMaxX - mnMinX), same for the height (float arithmetic)
         f->inv_w = static_cast<float>(p.grid_cols) / static_cast<float>(p.max_x - p.min_x);
         f->inv_h = static_cast<float>(p.grid_rows) / static_cast<float>(p.max_y - p.min_y);
@@ -266,7 +268,7 @@ extern "C" int afv_frame_get_grid(afv_frame *f, int32_t *cell_ptr, int32_t *cell
 // ---- Frame::ComputeBoW ----
 extern "C" int afv_frame_bow_transform(afv_frame *f, const afv_vocab *v, int levelsup, int32_t *leaf_node, int32_t *node_at_level, int32_t *nnodes_out) {
     if (!f || !v || !f->has_features) return AFV_EINVAL;
-    if (v->float_dim || v->dev.words != f->words || v->desc_bytes != f->desc_bytes) return AFV_EUNSUPPORTED;  // a vocabulary of another descriptor kind / size
+    if (v->float_dim != f->float_dim || v->dev.words != f->words || v->desc_bytes != f->desc_bytes) return AFV_EUNSUPPORTED;  // a vocabulary of another descriptor kind / size
     afv_ctx *c = f->c;
     return guarded(c, [&]() -> int {
         HIPCHK(c, hipSetDevice(c->device));
@@ -295,7 +297,14 @@ extern "C" int afv_frame_bow_transform(afv_frame *f, const afv_vocab *v, int lev
             c->last_error = "afv_frame_bow_transform: the node level is too wide for the LDS of one workgroup";
             return AFV_EUNSUPPORTED;
         }
-        afv_launch_bow_transform(&v->dev, reinterpret_cast<const uint32_t *>(f->d_desc), n, levelsup, f->d_leaf, f->d_nid, f->d_dense, s);
+        if (f->float_dim) {
+            if (!afv_launch_bow_transform_f32(&v->dev, reinterpret_cast<const float *>(f->d_desc), n, f->float_dim, levelsup, f->d_leaf, f->d_nid, f->d_dense, s)) {
+                c->last_error = "afv_frame_bow_transform: float descriptors of this dimension have no descent kernel (64, 128, 256)";
+                return AFV_EUNSUPPORTED;
+            }
+        } else {
+            afv_launch_bow_transform(&v->dev, reinterpret_cast<const uint32_t *>(f->d_desc), n, levelsup, f->d_leaf, f->d_nid, f->d_dense, s);
+        }
         afv_launch_featvec_build(f->d_leaf, f->d_nid, f->d_dense, n, f->cap, width, v->dev.stopped, f->d_seg_idx, zc ? h_kept : f->d_nkept,
                                  zc ? h_leaf : nullptr, zc ? h_nid : nullptr, zc ? h_dense : nullptr, s);
         HIPCHK(c, hipGetLastError());
@@ -370,6 +379,7 @@ static int frame_proj_job(const afv_frame *f, const afv_proj_queries &q, afv_pro
     j.struct_size = sizeof(afv_proj_job);
     j.n = f->n;
     j.desc_bytes = f->desc_bytes;
+    j.float_dim = f->float_dim;
     j.min_x = f->p.min_x; j.min_y = f->p.min_y; j.grid_inv_w = f->inv_w; j.grid_inv_h = f->inv_h;
     j.grid_cols = f->p.grid_cols; j.grid_rows = f->p.grid_rows;
     j.occupied = q.occupied;
@@ -448,6 +458,7 @@ extern "C" int afv_frame_match_initialization(afv_frame *f1, afv_frame *f2, cons
         j.struct_size = sizeof(afv_proj_job);
         j.n = f2->n;
         j.desc_bytes = f2->desc_bytes;
+        j.float_dim = f2->float_dim;
         j.min_x = f2->p.min_x; j.min_y = f2->p.min_y; j.grid_inv_w = f2->inv_w; j.grid_inv_h = f2->inv_h;
         j.grid_cols = f2->p.grid_cols; j.grid_rows = f2->p.grid_rows;
         j.nq = n1;

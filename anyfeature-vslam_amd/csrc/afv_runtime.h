@@ -113,6 +113,7 @@ struct afv_frame {
     afv_frame_params p{};
     int cap = 0, n = 0;
     int desc_bytes = 32, words = 8;  // descriptor size and dwords per (zero-padded) device row: 8 up to 32 bytes, 16 up to 64
+    int float_dim = 0;               // > 0: the rows are float_dim floats (desc_bytes = 4 * float_dim, words = float_dim): L2^2 distances
     float inv_w = 0, inv_h = 0;
     bool has_features = false, has_grid = false, has_fv = false;
     // device arrays, one allocation

@@ -20,15 +20,18 @@ FRAME_GRID_COLS, FRAME_GRID_ROWS = 64, 48  # Frame.h:40-41
 
 class Frame:
     def __init__(self, ctx, min_x=0.0, min_y=0.0, max_x=640.0, max_y=480.0, grid_cols=FRAME_GRID_COLS, grid_rows=FRAME_GRID_ROWS,
-                 distorted=False, cap=0, desc_bytes=32):
-        """desc_bytes: size of one binary descriptor (32 ORB, 61 AKAZE, 48 BRISK ...; <= 64) - the reference's matchers dispatch on the
-        descriptor type (FeatureMatcher.cc:1508-1531); frames that are not 32-byte are filled with set_features"""
+                 distorted=False, cap=0, desc_bytes=32, float_dim=0):
+        """desc_bytes: size of one binary descriptor (32 ORB, 61 AKAZE, 48 BRISK ...; <= 64); float_dim > 0: float descriptors of that many
+        floats instead (SIFT128, SURF64, KAZE64 ...: L2^2 distances) - the reference's matchers dispatch on the descriptor type
+        (FeatureMatcher.cc:1508-1531); frames that are not 32-byte binary are filled with set_features"""
         self.ctx, self.lib = ctx, ctx.lib
-        self.desc_bytes = int(desc_bytes)
+        self.float_dim = int(float_dim)
+        self.desc_bytes = 4 * self.float_dim if self.float_dim else int(desc_bytes)
         p = _lib.sized(FrameParams)
         p.min_x, p.min_y, p.max_x, p.max_y = float(min_x), float(min_y), float(max_x), float(max_y)
         p.grid_cols, p.grid_rows, p.distorted, p.cap = int(grid_cols), int(grid_rows), int(bool(distorted)), int(cap)
         p.desc_bytes = int(desc_bytes)
+        p.float_dim = self.float_dim
         self.params = p
         h = C.c_void_p()
         ctx.check(self.lib.afv_frame_create(ctx.handle, C.byref(p), C.byref(h)), "afv_frame_create")
@@ -73,7 +76,10 @@ class Frame:
     def set_features(self, kps, desc, sizes=None, u_right=None):
         """a frame whose features come from elsewhere (stereo rigs, another extractor, tests): kps (KP_DTYPE), desc [n, desc_bytes]"""
         kps = np.ascontiguousarray(kps, KP_DTYPE)
-        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, self.desc_bytes)
+        if self.float_dim:
+            desc = np.ascontiguousarray(desc, np.float32).reshape(-1, self.float_dim)
+        else:
+            desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, self.desc_bytes)
         sz = None if sizes is None else np.ascontiguousarray(sizes, np.float32)
         ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
         self.ctx.check(self.lib.afv_frame_set_features(self.handle, ptr(kps), ptr(desc), len(kps), ptr(sz), ptr(ur)), "afv_frame_set_features")
@@ -123,7 +129,9 @@ class Frame:
         keep = []
         s.nq = q.n
         if qref is None:
-            s.qdesc = ptr(q.descriptors); s.desc_bytes = q.descriptors.shape[1] if q.n else self.desc_bytes
+            if q.n and (q.descriptors.dtype.kind == "f") != bool(self.float_dim):
+                raise ValueError("the queries must carry the frame's kind of descriptor")
+            s.qdesc = ptr(q.descriptors); s.desc_bytes = q.descriptors.shape[1] * q.descriptors.itemsize if q.n else self.desc_bytes
         else:
             table, slots, idx = qref
             sl = np.ascontiguousarray(slots, np.int32); ix = np.ascontiguousarray(idx, np.int32)

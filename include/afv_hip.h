@@ -440,6 +440,14 @@ typedef struct {
                                          is the ORB32 extractor; the keyframe TABLE holds 32-byte rows only: afv_table_set_from_frame /
                                          afv_table_match_bow_frame_h answer AFV_EUNSUPPORTED for it) and serves afv_frame_bow_transform with a
                                          vocabulary of the same descriptor size, afv_frame_match_projection / _fuse / _initialization */
+    int32_t float_dim;                /* (ABI 6, appended) > 0: the frame holds FLOAT descriptors of float_dim floats (a multiple of 4, <= 1024:
+                                         SIFT128, SURF64, KAZE64, R2D2 ...; desc_bytes is ignored): afv_frame_set_features takes the rows as
+                                         n x float_dim floats behind its uint8_t pointer, afv_frame_bow_transform wants a float vocabulary of
+                                         that dimension (afv_vocab_create_f32), the projection searches and SearchForInitialization use
+                                         L2^2 distances (afv_proj_job.float_dim; afv_proj_queries.qdesc = nq x float_dim floats,
+                                         desc_bytes = 4 * float_dim).  Like every frame that is not 32-byte it stays out of the keyframe
+                                         table: SearchByBoW(KF, F) on float rows is afv_match_bow with AFV_MATCH_FLOAT32 and the frame's
+                                         FeatureVector (afv_frame_get_featvec) */
 } afv_frame_params;
 int afv_frame_create(afv_ctx *ctx, const afv_frame_params *params, afv_frame **out);
 void afv_frame_destroy(afv_frame *f);

@@ -467,6 +467,95 @@ def test_resident_frames_of_other_descriptor_sizes(afv, oracle, fctx, nbytes, en
         fctx.lib.afv_set_projection_resolve(fctx.handle, 2)
 
 
+@pytest.mark.parametrize("dim", [128, 64])
+def test_float_descriptor_frames_through_the_tracking_chain(afv, oracle, fctx, dim):
+    """BASELINE config #3's kind of feature (float descriptors, L2^2: SIFT128 / SURF64 / KAZE64) through the chain of round 5: a resident
+    float frame (afv_frame_params.float_dim) -> grid -> Frame::ComputeBoW on a float vocabulary -> SearchByProjection (both flavours) -> Fuse
+    -> SearchForInitialization -> SearchByBoW(KF, F) with the frame's FeatureVector, every stage against the oracle"""
+    from _float_desc import floaten
+    th = 75.0 * dim / 256.0 * 0.6
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(th)
+    try:
+        img = afv.synth.corners_frame(63)
+        k1, d1 = fctx.extract(img)
+        f1 = floaten(d1, dim, True)
+        size1, _, inf = fctx.size_sigma(k1)
+        fr = afv.Frame(fctx, float_dim=dim)
+        fr.set_features(k1, f1)
+        assert fr.N == len(k1) > 900
+        cp, ci = fr.grid()
+        wp, wi = _host_grid(k1["x"], k1["y"], 0.0, 0.0, fr.grid_inv_w, fr.grid_inv_h)
+        assert np.array_equal(cp, wp) and np.array_equal(ci, wi)
+        # Frame::ComputeBoW on a float vocabulary (Vocabulary.cpp:158-187)
+        voc = afv.Vocabulary.random_float(5, k=8, L=3, ctx=fctx, dim=dim)
+        bow, fv = fr.ComputeBoW(voc, levelsup=2)
+        wb, wf = voc.transform(f1, levelsup=2)
+        assert bow == wb and fv == wf and fr.featvec() == fv and len(fv) > 4
+        oleaf, onid = oracle.bow_transform(voc, f1, 2)
+        for nd, idx in fv:
+            assert np.all(onid[idx] == nd)
+        for other in (afv.Vocabulary.random(5, k=8, L=3, ctx=fctx, desc_bytes=32), afv.Vocabulary.random_float(5, k=8, L=3, ctx=fctx, dim=192 - dim)):
+            with pytest.raises(afv._lib.AfvError):
+                fr.ComputeBoW(other, levelsup=2)       # a vocabulary of another descriptor kind / dimension
+            other.close()
+        # SearchByProjection, both flavours
+        occ = (afv.synth.lcg_bytes(70, len(k1)) < 30).astype(np.uint8)
+        Q = _queries(afv, fctx, 63, img, 4, 15.0)
+        Qbin = _queries(afv, fctx, 63, img, 4, 15.0)
+        Q.descriptors = floaten(Q.descriptors, dim, True)
+        F = afv.FrameGridView(f1, np.stack([k1["x"], k1["y"]], 1), size1, angles=k1["angle"], occupied=occ, inf=inf)
+        for last in (False, True):
+            m = afv.FeatureMatcher(0.9 if last else 0.8, True, ctx=fctx)
+            got, n = fr.SearchByProjection(m, Q, last_frame=last, occupied=occ)
+            want, wn = oracle.match_projection(F, Q, th_high=th, nnratio=m.mfNNratio, check_orientation=last, last_frame=last)
+            assert n == wn and np.array_equal(got, want) and wn > 100
+        with pytest.raises(ValueError):
+            fr.SearchByProjection(m, Qbin)             # binary queries against a float frame
+        # Fuse
+        m = afv.FeatureMatcher(0.6, True, ctx=fctx)
+        got, n = fr.Fuse(m, Q)
+        F.occupied = None
+        want, wn = oracle.match_projection(F, Q, th_high=th, fuse=True)
+        assert n == wn and np.array_equal(got, want) and wn > 50
+        # SearchForInitialization against a second float frame
+        k2, d2 = fctx.extract(np.roll(img, 6, axis=1))
+        f2 = floaten(d2, dim, True)
+        size2, _, _ = fctx.size_sigma(k2)
+        fr2 = afv.Frame(fctx, float_dim=dim)
+        fr2.set_features(k2, f2)
+        F2 = afv.FrameGridView(f2, np.stack([k2["x"], k2["y"]], 1), size2, angles=k2["angle"])
+        prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+        n1 = len(k1)
+        Q1 = afv.ProjectionQueries(f1, prev[:, 0].copy(), prev[:, 1].copy(), np.full(n1, 50.0, np.float32), np.zeros(n1, np.float32),
+                                   np.full(n1, np.float32(1.2) ** np.float32(7), np.float32), valid=(k1["octave"] == 0).astype(np.uint8),
+                                   angles=k1["angle"])
+        m = afv.FeatureMatcher(0.9, True, ctx=fctx)
+        got, n = fr.SearchForInitialization(m, fr2, prev, windowSize=50.0)
+        want, wn = oracle.match_initialization(F2, Q1, th_low=th, nnratio=0.9, check_orientation=True)
+        assert n == wn and np.array_equal(got, want) and wn > 50
+        # SearchByBoW(KF, F): the keyframe (frame 1's features with map points on most of them) against frame 2 and ITS FeatureVector
+        _, fvk = voc.transform(f1, levelsup=2)
+        fr2.ComputeBoW(voc, levelsup=2)
+        fvf = fr2.featvec()
+        has_mp = (afv.synth.lcg_bytes(71, n1) > 40).astype(np.uint8)
+        m = afv.FeatureMatcher(0.8, True, ctx=fctx)
+        got, n = m.SearchByBoW(afv.FeatureView(f1, fvk, has_mp, k1["angle"]), afv.FeatureView(f2, fvf, None, k2["angle"]), frame=True)
+        want, wn = oracle.search_by_bow_kf_frame(f1, f2, fvk, fvf, has_mp, k1["angle"], k2["angle"], th, 0.8, True)
+        assert n == wn and np.array_equal(got, want) and wn > 50
+        # what only exists for 32-byte rows says so
+        table = afv.table.DescriptorTable(fctx, 2, fctx.cap)
+        with pytest.raises(afv._lib.AfvError):
+            table.set_from_frame(0, fr)
+        with pytest.raises(afv._lib.AfvError):
+            fr.extract(img)
+        frb = afv.Frame(fctx, desc_bytes=61)
+        with pytest.raises(afv._lib.AfvError):
+            fr.SearchForInitialization(m, frb, prev)
+        table.close(); fr.close(); fr2.close(); frb.close(); voc.close()
+    finally:
+        afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+
+
 def test_akaze61_features_through_the_tracking_chain(afv, oracle, fctx):
     """BASELINE config #5's output flows through the chain of round 5: afv_akaze_extract -> resident 61-byte frame -> Frame::ComputeBoW on a
     61-byte vocabulary -> SearchByProjection(cur, last) -> SearchByBoW(KF, F) (FeatureMatcher.cc:186-283; the keyframe side as host arrays:
