@@ -914,6 +914,55 @@ def extra_tracking_frame_akaze61(afv, device, reps=50):
     return out
 
 
+def extra_tracking_frame_float128(afv, device, reps=50):
+    """the same chain on float descriptors (BASELINE config #3's kind of feature: 128 floats, L2^2 - SIFT128; the SIFT extractor itself is
+    SiftGPU / OpenGL, out of scope): resident float frame (afv_frame_set_features, 512-byte rows) -> Frame::ComputeBoW on a float vocabulary
+    (k = 10, L = 4) -> SearchByProjection(cur, last) with L2^2 distances (ordered-walk engine); keypoints of an ORB frame, SIFT-like unit rows;
+    synchronous calls timed from Python like tracking_frame_akaze61"""
+    import numpy as np
+    ctx = afv.Context(device=device)
+    s = afv.synth
+    img = s.corners_frame(8)
+    kb, _ = ctx.extract(img)
+    zb, _, _ = ctx.size_sigma(kb)
+
+    def unit(a):
+        return np.ascontiguousarray(a / np.linalg.norm(a, axis=1, keepdims=True), np.float32)
+
+    n = len(kb)
+    db = unit(s.lcg_bytes(31, n * 128).reshape(n, 128).astype(np.float32) ** 2)
+    # the last frame's view of the same points: the rows perturbed, the positions two pixels off (what the motion model predicts)
+    da = unit(np.abs(db + (s.lcg_bytes(33, n * 128).reshape(n, 128).astype(np.float32) - 128) / 3000.0))
+    voc = afv.Vocabulary.random_float(9, k=10, L=4, ctx=ctx, dim=128)
+    cur = afv.Frame(ctx, float_dim=128)
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(0.5)
+    m = afv.FeatureMatcher(0.9, True, ctx=ctx)
+    sf = np.float32(1.2)
+    Q = afv.ProjectionQueries(da, kb["x"] + np.float32(2), kb["y"] - np.float32(1), np.float32(15) * zb, zb / sf, zb * sf, angles=kb["angle"])
+    t = {"frame_set_features_us": 0.0, "frame_bow_transform_us": 0.0, "frame_projection_lastframe_us": 0.0}
+    nm = 0
+    for it in range(reps + 5):
+        t1 = time.perf_counter()
+        cur.set_features(kb, db)
+        t2 = time.perf_counter()
+        cur.ComputeBoW(voc, levelsup=2)
+        t3 = time.perf_counter()
+        _, nm = cur.SearchByProjection(m, Q, last_frame=True)
+        t4 = time.perf_counter()
+        if it >= 5:
+            t["frame_set_features_us"] += (t2 - t1) * 1e6 / reps
+            t["frame_bow_transform_us"] += (t3 - t2) * 1e6 / reps
+            t["frame_projection_lastframe_us"] += (t4 - t3) * 1e6 / reps
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+    out = dict(t)
+    out["chain_us"] = sum(t.values())
+    out["keypoints"] = int(len(kb))
+    out["matches"] = int(nm)
+    out["stages"] = "afv_frame_set_features (128-float rows) -> ComputeBoW (float vocabulary k = 10, L = 4) -> SearchByProjection(cur, last), L2^2"
+    cur.close(); voc.close(); ctx.close()
+    return out
+
+
 def akaze_single_frame():
     """FeatureExtractor_akaze61::detectAndCompute for ONE 1280 x 720 frame per call, host to host through the C-ABI (tools/akaze_latency.cpp):
     the reference's per-frame operator() (FeatureExtractor.cpp:111-121)"""
@@ -1347,7 +1396,7 @@ def main():
             except Exception as e:
                 out["host_api"] = {"error": str(e)[:200]}
             for key, fn in (("single_frame", extra_single_frame), ("pairs10k", extra_pairs10k), ("l2_sift128", extra_l2_sift128), ("akaze61", extra_akaze61),
-                            ("tracking_frame_akaze61", extra_tracking_frame_akaze61)):
+                            ("tracking_frame_akaze61", extra_tracking_frame_akaze61), ("tracking_frame_float128", extra_tracking_frame_float128)):
                 try:
                     out[key] = fn(afv, local)
                 except Exception as e:  # a secondary figure must never cost the headline line
