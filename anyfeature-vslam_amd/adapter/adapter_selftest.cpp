@@ -203,6 +203,34 @@ int main(int argc, char **argv) {
             std::printf("frame %d %d %d %d %d %d\n", e0, e1, e2, e4, e5, e7);
         }
     }
+    // ---- float descriptors through the matcher's dispatch (FeatureMatcher.cc:1508-1531): SearchByBoW on 128-float rows (one node = brute
+    //      force) must equal afv_match_l2, the float matcher of config #3, called directly ----
+    {
+        const int n1 = (int)k1.size(), n2 = (int)k2.size(), dim = 128;
+        auto floaten = [&](const afv::Mat8 &d, int n) {
+            std::vector<float> f((size_t)n * dim);
+            for (int i = 0; i < n; ++i)
+                for (int b = 0; b < dim; ++b)
+                    f[(size_t)i * dim + b] = ((d.ptr(i)[b >> 3] >> (7 - (b & 7))) & 1) * 0.75f + (float)((i * 131 + b * 29) % 97) * (0.2f / 97.0f);
+            return f;
+        };
+        const std::vector<float> f1 = floaten(d1, n1), f2 = floaten(d2, n2);
+        afv::FeatureMatcherHip::setDescriptorDistanceThresholds(20.0f);
+        afv::FeatureMatcherHip fm(extractor.context(), 0.8f, true);
+        afv::FeatureView fa, fb;
+        fa.descriptors = reinterpret_cast<const uint8_t *>(f1.data()); fa.N = n1; fa.float_dim = dim;
+        fb.descriptors = reinterpret_cast<const uint8_t *>(f2.data()); fb.N = n2; fb.float_dim = dim;
+        std::vector<int> m12;
+        const int nf = fm.SearchByBoW(fa, fb, m12);
+        std::vector<int32_t> want((size_t)std::max(n1, 1), -1);
+        int32_t nw = 0;
+        if (afv_match_l2(extractor.context(), f1.data(), n1, f2.data(), n2, dim, nullptr, nullptr, 20.0f, 0.8f, want.data(), &nw) != AFV_OK) return 9;
+        std::printf("float128 %d %d\n", nf, (int)nw);
+        if (nf != nw || nf < 50) return 9;
+        for (int i = 0; i < n1; ++i)
+            if (m12[(size_t)i] != want[(size_t)i]) return 9;
+        afv::FeatureMatcherHip::setDescriptorDistanceThresholds(75.0f);
+    }
     // ---- AKAZE61 plugin ----
     {
         auto s2 = std::make_shared<afv::FeatureExtractorSettings>();

@@ -312,9 +312,14 @@ class DeviceFrame {
 // ---- matcher side: flat view of what FeatureMatcher reads from KeyFrame / Frame ----
 using FeatureVector = std::map<unsigned, std::vector<unsigned>>;  // DBoW2::FeatureVector (node id -> feature indices)
 
+// The reference's matchers dispatch on the descriptor type (FeatureMatcher::DescriptorDistance, FeatureMatcher.cc:1508-1531): the views
+// below carry it as `desc_bytes` (binary rows: 32 ORB, 61 AKAZE, 48 BRISK ..., Hamming) or `float_dim` > 0 (float rows - SIFT128, SURF64,
+// KAZE64, R2D2 ...: `descriptors` then points to N x float_dim floats, mDescriptors.ptr<float>(), and the distance is
+// cv::norm(a, b, NORM_L2SQR) as a float, Feature_sift128.cpp:132-134).  Both sides of a call must agree.
 struct FeatureView {
-    const uint8_t *descriptors = nullptr;  // N x 32, continuous (KeyFrame::mDescriptors)
+    const uint8_t *descriptors = nullptr;  // N x desc_bytes (or N x float_dim floats), continuous (KeyFrame::mDescriptors)
     int N = 0;
+    int desc_bytes = AFV_DESC_BYTES, float_dim = 0;
     const FeatureVector *featVec = nullptr;  // nullptr => brute force
     const uint8_t *valid = nullptr;          // map point exists && !isBad() (triangulation: has a map point)
     const float *angles = nullptr;           // mvKeysUn[i].angle
@@ -369,6 +374,7 @@ class FeatureMatcherHip {
     // and hands over, per query in the reference's iteration order, (u, v, r, size band); see include/afv_hip.h ----
     struct FrameGridView {  // what the matchers read from a Frame / KeyFrame (Frame.cc:100-101, Frame.h:40-41)
         const uint8_t *descriptors = nullptr; int N = 0;
+        int desc_bytes = AFV_DESC_BYTES, float_dim = 0;  // descriptor kind (see FeatureView); the queries carry the same kind
         const float *x = nullptr, *y = nullptr;  // mvKeysUn[i].pt
         const float *size = nullptr;             // keyPtsSize[i]
         const float *angle = nullptr;            // mvKeysUn[i].angle
@@ -512,7 +518,7 @@ class FeatureMatcherHip {
     afv_proj_job proj_job(const FrameGridView &F, const ProjectionQueries &q) const {
         afv_proj_job j{};
         j.struct_size = sizeof(j);
-        j.desc = F.descriptors; j.n = F.N; j.desc_bytes = AFV_DESC_BYTES;
+        j.desc = F.descriptors; j.n = F.N; j.desc_bytes = F.float_dim ? 4 * F.float_dim : F.desc_bytes; j.float_dim = F.float_dim;
         j.x = F.x; j.y = F.y; j.size = F.size; j.angle = F.angle; j.occupied = F.occupied; j.inf = F.inf;
         j.min_x = F.mnMinX; j.min_y = F.mnMinY; j.grid_inv_w = F.mfGridElementWidthInv; j.grid_inv_h = F.mfGridElementHeightInv;
         j.grid_cols = F.grid_cols; j.grid_rows = F.grid_rows;
@@ -547,7 +553,10 @@ class FeatureMatcherHip {
         }
     };
     void fill(afv_match_job &j, const FeatureView &a, const FeatureView &b, const Csr &ca, const Csr &cb, int mode) const {
-        j.desc1 = a.descriptors; j.n1 = a.N; j.desc2 = b.descriptors; j.n2 = b.N; j.desc_bytes = AFV_DESC_BYTES;
+        j.desc1 = a.descriptors; j.n1 = a.N; j.desc2 = b.descriptors; j.n2 = b.N;
+        if (a.float_dim != b.float_dim || a.desc_bytes != b.desc_bytes) fatal("FeatureMatcherHip: the two sides carry different descriptor kinds", AFV_EINVAL, ctx);
+        j.desc_bytes = a.float_dim ? 4 * a.float_dim : a.desc_bytes;
+        if (a.float_dim) mode |= AFV_MATCH_FLOAT32;
         j.node_id1 = ca.id.data(); j.seg_ptr1 = ca.ptr.data(); j.seg_idx1 = ca.idx.data(); j.nnodes1 = (int32_t)ca.id.size();
         j.node_id2 = cb.id.data(); j.seg_ptr2 = cb.ptr.data(); j.seg_idx2 = cb.idx.data(); j.nnodes2 = (int32_t)cb.id.size();
         j.valid1 = a.valid; j.valid2 = b.valid; j.angle1 = a.angles; j.angle2 = b.angles;
