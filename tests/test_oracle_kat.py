@@ -641,3 +641,29 @@ def test_distinctive_descriptor_by_hand(oracle):
     assert med == 1 and idx == 0
     assert oracle.distinctive_descriptor(np.zeros((0, 32), np.uint8))[0] == -1
     assert oracle.distinctive_descriptor(np.zeros((1, 32), np.uint8)) == (0, 0)
+
+
+def test_float_descriptors_by_hand(oracle, afv):
+    """DescriptorDistance for float descriptors = cv::norm(a, b, NORM_L2SQR) as a float (Feature_sift128.cpp:132-134) inside the control flow
+    of the searches: numbers small enough to do in the head"""
+    # SearchByBoW(KF, KF), one node: row 0 sees (3.81, 0.01, 4) -> column 1; row 1 sees column 0 at 0.01 and column 2 at 0 -> column 2
+    d1 = np.float32([[0, 0, 0, 0], [1, 1, 1, 1]])
+    d2 = np.float32([[1, 1, 1, 0.9], [0, 0, 0, 0.1], [1, 1, 1, 1]])
+    m, n = oracle.search_by_bow_kf_kf(d1, d2, th_low=0.5, nnratio=0.8)
+    assert m.tolist() == [1, 2] and n == 2
+    m, n = oracle.search_by_bow_kf_kf(d1, d2, th_low=0.005, nnratio=0.8)   # best < th_low, strictly
+    assert m.tolist() == [-1, 2] and n == 1
+    # the first of two equal distances wins, the ratio test then fails (0 < 0.8 * 0 is false)
+    m, n = oracle.search_by_bow_kf_kf(np.float32([[1, 1, 1, 1]]), np.float32([[1, 1, 1, 1], [1, 1, 1, 1]]), th_low=0.5, nnratio=0.8)
+    assert m.tolist() == [-1] and n == 0
+    # projection search, last-frame flavour (best only): q0 sees (0.81, 0.0100000.) -> feature 1; q1 finds feature 1 taken -> feature 0
+    F = afv.FrameGridView(np.float32([[0, 0, 0, 0], [1, 0, 0, 0], [5, 5, 5, 5]]), np.float32([[100, 100], [102, 100], [300, 300]]),
+                          np.float32([1, 1, 1]))
+    Q = afv.ProjectionQueries(np.float32([[0.9, 0, 0, 0], [0, 0, 0, 0]]), [101, 101], [100, 100], [10, 10], [0.8, 0.8], [1.3, 1.3])
+    a, n = oracle.match_projection(F, Q, th_high=0.5, nnratio=0.8, last_frame=True)
+    assert a.tolist() == [1, 0, -1] and n == 2
+    a, n = oracle.match_projection(F, Q, th_high=0.5, nnratio=0.8)          # local-map flavour: 0.01 <= 0.8 * 0.81, then no second candidate
+    assert a.tolist() == [1, 0, -1] and n == 2
+    a, n = oracle.match_projection(F, Q, th_high=0.5, nnratio=0.01)         # 0.01 > 0.01 * 0.81 in the same scale band: q0 rejected, q1 sees (0, 1): 0 <= 0.01
+    assert a.tolist() == [1, -1, -1] and n == 1
+    assert oracle.l2sqr(np.float32([0.9, 0, 0, 0]), np.float32([1, 0, 0, 0])) == np.float32(np.float64(np.float32(0.9) - np.float32(1)) ** 2)
