@@ -19,4 +19,4 @@ from .frame import Frame  # noqa: F401
 from . import akaze, table  # noqa: F401
 from .akaze import AkazeContext  # noqa: F401
 from .matcher import (FeatureMatcher, FeatureView, FrameGridView, ProjectionQueries, ComputeDistinctiveDescriptors,  # noqa: F401
-                      DescriptorDistance_orb32)
+                      DescriptorDistance_orb32, DescriptorDistance_sift128)

@@ -19,6 +19,21 @@ def DescriptorDistance_orb32(a, b):
     return float(_lib.load().afv_hamming256(ptr(a), ptr(b)))
 
 
+def DescriptorDistance_sift128(a, b):
+    """Feature_sift128.cpp:132-134 (and the surf64 / kaze64 / r2d2 twins): cv::norm(a, b, NORM_L2SQR) narrowed to Descriptor_Distance_Type =
+    float, in cv::norm's order - float differences, squares in double, 4-way partial sums added to one accumulator (host utility; the
+    kernels evaluate the same expression per candidate)"""
+    a = np.ascontiguousarray(a, np.float32).ravel(); b = np.ascontiguousarray(b, np.float32).ravel()
+    v = (a - b).astype(np.float64)
+    n4 = len(v) // 4 * 4
+    q = v[:n4].reshape(-1, 4) ** 2
+    groups = ((q[:, 0] + q[:, 1]) + q[:, 2]) + q[:, 3]
+    s = np.float64(0.0)
+    for g in groups.tolist() + (v[n4:] ** 2).tolist():   # sequential: the summation order is part of the result
+        s = s + np.float64(g)
+    return float(np.float32(s))
+
+
 def ComputeDistinctiveDescriptors(ctx, descriptor_sets):
     """MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:279-349) for a batch of map points: descriptor_sets = one [N_s, bytes] uint8 array per
     map point (the descriptors of its observations, in observation order); returns (best index per set | -1 for an empty one, its median)"""
@@ -156,7 +171,14 @@ class FeatureMatcher:
 
     @staticmethod
     def DescriptorDistance(a, b):
-        return DescriptorDistance_orb32(a, b)
+        """FeatureMatcher::DescriptorDistance (FeatureMatcher.cc:1508-1531): dispatched on the descriptor type - float rows: L2^2; 32-byte rows:
+        the ORB popcount; other binary rows: Hamming over their bytes"""
+        a = np.asarray(a)
+        if a.dtype.kind == "f":
+            return DescriptorDistance_sift128(a, b)
+        if a.size == 32:
+            return DescriptorDistance_orb32(a, b)
+        return float(np.unpackbits(np.bitwise_xor(np.ascontiguousarray(a, np.uint8).ravel(), np.ascontiguousarray(b, np.uint8).ravel())).sum())
 
     def _job(self, v1, v2, mode, keep):
         j = MatchJob()

@@ -129,6 +129,18 @@ def test_host_hamming_utility(afv, oracle):
         assert afv.DescriptorDistance_orb32(d[i], d[i + 1]) == float(oracle.hamming256(d[i], d[i + 1]))
 
 
+def test_host_descriptor_distance_dispatch(afv, oracle):
+    """FeatureMatcher::DescriptorDistance (FeatureMatcher.cc:1508-1531) as the host utility: float rows -> L2^2 in cv::norm's order, 61-byte
+    rows -> Hamming over the bytes"""
+    s = afv.synth
+    for dim in (128, 64, 6):
+        a = (s.lcg_bytes(5, dim).astype(np.float32) / np.float32(255.0)) ** 2
+        b = (s.lcg_bytes(6, dim).astype(np.float32) / np.float32(251.0))
+        assert afv.FeatureMatcher.DescriptorDistance(a, b) == float(oracle.l2sqr(a, b))
+    d = s.lcg_bytes(7, 2 * 61).reshape(2, 61)
+    assert afv.FeatureMatcher.DescriptorDistance(d[0], d[1]) == float(oracle.hamming_bytes(d[0], d[1]))
+
+
 def test_product_does_not_import_the_oracle():
     """only tests/, smoke() and bench.py's cpu_baseline may touch oracle/"""
     pkg = os.path.join(ROOT, "anyfeature-vslam_amd")
