@@ -18,7 +18,14 @@ def build(force=False):
     d = os.path.join(EXP, "poison")
     os.makedirs(d, exist_ok=True)
     flags = ["-DAFV_POISON", "-include", os.path.join(PKG, "csrc", "afv_poison.h")]
-    return mod.build(force=force, extra_flags=flags, out=os.path.join(EXP, "libafv_poison.so"), objdir=d)
+    out = mod.build(force=force, extra_flags=flags, out=os.path.join(EXP, "libafv_poison.so"), objdir=d)
+    # stamp of the sources this library was built from: tools/poison_suite.sh rebuilds when it is not the current one (a stale poison
+    # library lacks the entry points added since and fails every test at load time)
+    import subprocess
+    sha = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "csrc_sha.py")], capture_output=True, text=True).stdout.strip()
+    with open(os.path.join(EXP, "libafv_poison.sha"), "w") as fh:
+        fh.write(sha + "\n")
+    return out
 
 
 if __name__ == "__main__":
