@@ -159,6 +159,7 @@ SYMBOLS = {
     "afv_match_initialization": (_i, [_vp, _vp, _i, _vp, _vp]),
     "afv_vocab_create": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, C.POINTER(_vp)]),
     "afv_distinctive_descriptors": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "afv_distinctive_descriptors_f32": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
     "afv_vocab_create_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, C.POINTER(_vp)]),
     "afv_bow_transform_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "afv_vocab_destroy": (None, [_vp, _vp]),

@@ -2084,6 +2084,36 @@ extern "C" int afv_distinctive_descriptors(afv_ctx *c, const uint8_t *desc, int 
     });
 }
 
+extern "C" int afv_distinctive_descriptors_f32(afv_ctx *c, const float *desc, int dim, const int32_t *set_ptr, int nsets, int32_t *best_idx,
+                                               float *best_median) {
+    if (!c || !set_ptr || nsets < 0 || dim < 1 || dim > 1024 || (nsets > 0 && !best_idx)) return AFV_EINVAL;
+    if (nsets == 0) return AFV_OK;
+    if (set_ptr[0] != 0) return AFV_EINVAL;
+    for (int s = 0; s < nsets; ++s)
+        if (set_ptr[s + 1] < set_ptr[s] || set_ptr[s + 1] - set_ptr[s] > 65535) return AFV_EINVAL;
+    const int total = set_ptr[nsets];
+    if (total > 0 && !desc) return AFV_EINVAL;
+    return guarded(c, [&]() -> int {
+        HIPCHK(c, hipSetDevice(c->device));
+        Blob b(c);
+        const size_t d_off = b.put(desc, (size_t)total * dim * 4);
+        const size_t p_off = b.put(set_ptr, (size_t)(nsets + 1) * 4);
+        const size_t in_bytes = b.h.size();
+        const size_t bi_off = b.reserve((size_t)nsets * 4), bm_off = b.reserve((size_t)nsets * 4);
+        const int rc = ensure_match_buffer(c, b.h.size());
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->d_match, b.h.data(), in_bytes, hipMemcpyHostToDevice, c->stream));
+        afv_launch_distinctive_f32(reinterpret_cast<const float *>(c->d_match + d_off), dim, reinterpret_cast<const int *>(c->d_match + p_off), nsets,
+                                   reinterpret_cast<int *>(c->d_match + bi_off), reinterpret_cast<float *>(c->d_match + bm_off), c->stream);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, b.fetch(best_idx, bi_off, (size_t)nsets * 4, c->stream));
+        if (best_median) HIPCHK(c, b.fetch(best_median, bm_off, (size_t)nsets * 4, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        b.finish();
+        return AFV_OK;
+    });
+}
+
 // ---- BoW quantisation ----
 // the tree image of k_bow.hip for node descriptors of `words` dwords each (binary: 8 or 16, zero-padded; float: the dimension)
 static int vocab_create_impl(afv_ctx *c, int k, int L, int nnodes, const int32_t *child_ptr, const int32_t *child_idx, const uint8_t *desc, int desc_bytes,

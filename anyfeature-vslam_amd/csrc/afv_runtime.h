@@ -64,6 +64,7 @@ extern "C" void afv_launch_match_tri(const DevTriJob *jobs, int njobs, int max_n
 extern "C" void afv_launch_match_l2(const float *d1, int n1, const float *d2, int n2, int dim, const uint8_t *v1,
                                     const uint8_t *v2, float th, float ratio, int *out, int *nmatches, hipStream_t stream);
 
+extern "C" void afv_launch_distinctive_f32(const float *desc, int dim, const int *set_ptr, int nsets, int *best_idx, float *best_median, hipStream_t stream);
 extern "C" void afv_launch_distinctive(const uint32_t *desc, const int *set_ptr, int nsets, int words, int desc_bytes, int *best_idx, int *best_median,
                                        hipStream_t stream);
 extern "C" void afv_launch_match_projection(const DevProjJob *jobs, int njobs, int max_nq, size_t wg_lds, const DevProjJob *one, int *ticket,

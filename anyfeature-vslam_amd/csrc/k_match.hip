@@ -1461,6 +1461,73 @@ __global__ __launch_bounds__(256) void k_distinctive(const uint32_t *__restrict_
     }
 }
 
+// The same for FLOAT descriptors (DescriptorDistance = L2^2 as a float, FeatureMatcher.cc:1508-1531): the m-th smallest of a row is found by
+// bisection on the BIT PATTERN of the distances (non-negative floats order like their bits: <= 31 steps).  A map point with at most 64
+// observations keeps its rows' distances in LDS (row i = lane, column-major: conflict-free) and pays the 4 x dim double operations per pair
+// once; a larger one recomputes them in every step.
+#define DF_CACHE 64
+__global__ __launch_bounds__(256) void k_distinctive_f32(const float *__restrict__ desc, int dim, const int *__restrict__ set_ptr, int nsets,
+                                                         int *__restrict__ best_idx, float *__restrict__ best_median) {
+    __shared__ unsigned s_d[4][DF_CACHE][64];  // [wavefront][j][lane = row i]
+    const int wv = (int)threadIdx.x >> 6;
+    const int s = (int)blockIdx.x * 4 + wv, lane = threadIdx.x & 63;
+    if (s >= nsets) return;  // wave-uniform
+    const int b = set_ptr[s], n = set_ptr[s + 1] - b;
+    if (n <= 0) {
+        if (lane == 0) {
+            best_idx[s] = -1;
+            best_median[s] = 0.0f;
+        }
+        return;
+    }
+    const int m = (n - 1) >> 1;  // vDists[0.5 * (N - 1)]
+    const bool cached = n <= DF_CACHE;  // wave-uniform
+    unsigned best_med = 0xffffffffu, best_row = 0xffffffffu;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const float *q = desc + (size_t)(b + min(i, n - 1)) * dim;
+        if (cached)
+            for (int j = 0; j < n; ++j) s_d[wv][j][lane] = __float_as_uint(l2sqr(q, desc + (size_t)(b + j) * dim, dim));  // (the diagonal: 0)
+        unsigned lo = 0u, hi = 0x7f800000u;  // smallest key v with #{j : key(d(i, j)) <= v} > m  <=>  the m-th smallest (0-based) distance
+        while (__any(lo < hi)) {
+            const unsigned mid = lo + ((hi - lo) >> 1);
+            int cnt = 0;
+            if (cached)
+                for (int j = 0; j < n; ++j) cnt += s_d[wv][j][lane] <= mid;
+            else
+                for (int j = 0; j < n; ++j) cnt += __float_as_uint(l2sqr(q, desc + (size_t)(b + j) * dim, dim)) <= mid;
+            if (lo < hi) {
+                if (cnt > m) hi = mid;
+                else lo = mid + 1u;
+            }
+        }
+        if (i < n && lo < best_med) {  // strict: the first row keeps a tie (rows ascend with i0 inside a lane)
+            best_med = lo;
+            best_row = (unsigned)i;
+        }
+    }
+    // the least median over the lanes, then the first row that has it
+    auto wave_min = [](unsigned v) {
+        v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111, 0xf, 0xf, false));
+        v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x112, 0xf, 0xf, false));
+        v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x114, 0xf, 0xf, false));
+        v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x118, 0xf, 0xf, false));
+        v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x142, 0xa, 0xf, false));
+        v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x143, 0xc, 0xf, false));
+        return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+    };
+    const unsigned gm = wave_min(best_med);
+    const unsigned gr = wave_min(best_med == gm ? best_row : 0xffffffffu);
+    if (lane == 0) {
+        best_idx[s] = (int)gr;
+        best_median[s] = __uint_as_float(gm);
+    }
+}
+extern "C" void afv_launch_distinctive_f32(const float *desc, int dim, const int *set_ptr, int nsets, int *best_idx, float *best_median, hipStream_t stream) {
+    if (nsets <= 0) return;
+    hipLaunchKernelGGL(k_distinctive_f32, dim3((nsets + 3) / 4), dim3(256), 0, stream, desc, dim, set_ptr, nsets, best_idx, best_median);
+}
+
 extern "C" void afv_launch_distinctive(const uint32_t *desc, const int *set_ptr, int nsets, int words, int desc_bytes, int *best_idx, int *best_median,
                                        hipStream_t stream) {
     if (nsets <= 0) return;

@@ -37,6 +37,17 @@ def DescriptorDistance_sift128(a, b):
 def ComputeDistinctiveDescriptors(ctx, descriptor_sets):
     """MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:279-349) for a batch of map points: descriptor_sets = one [N_s, bytes] uint8 array per
     map point (the descriptors of its observations, in observation order); returns (best index per set | -1 for an empty one, its median)"""
+    if any(np.asarray(d).dtype.kind == "f" for d in descriptor_sets):  # float descriptors: L2^2 distances, the median comes back as a float
+        sets = [np.ascontiguousarray(d, np.float32) for d in descriptor_sets]
+        dim = next((d.reshape(len(d), -1).shape[1] for d in sets if len(d)), 128)
+        sets = [d.reshape(len(d), dim) if len(d) else np.zeros((0, dim), np.float32) for d in sets]
+        ptrs = np.zeros(len(sets) + 1, np.int32)
+        ptrs[1:] = np.cumsum([len(d) for d in sets])
+        flat = np.ascontiguousarray(np.concatenate(sets) if sets and ptrs[-1] else np.zeros((0, dim), np.float32))
+        best = np.zeros(max(len(sets), 1), np.int32); med = np.zeros(max(len(sets), 1), np.float32)
+        ctx.check(ctx.lib.afv_distinctive_descriptors_f32(ctx.handle, ptr(flat), dim, ptr(ptrs), len(sets), ptr(best), ptr(med)),
+                  "afv_distinctive_descriptors_f32")
+        return best[:len(sets)].copy(), med[:len(sets)].copy()
     sets = [np.ascontiguousarray(d, np.uint8) for d in descriptor_sets]
     nbytes = next((d.reshape(len(d), -1).shape[1] for d in sets if len(d)), 32)
     sets = [d.reshape(len(d), nbytes) if len(d) else np.zeros((0, nbytes), np.uint8) for d in sets]

@@ -402,6 +402,11 @@ int afv_bow_transform(afv_ctx *ctx, const afv_vocab *v, const uint8_t *desc, int
 int afv_distinctive_descriptors(afv_ctx *ctx, const uint8_t *desc, int desc_bytes, const int32_t *set_ptr, int nsets, int32_t *best_idx,
                                 int32_t *best_median);
 
+/* ... and for float descriptors (DescriptorDistance = cv::norm(a, b, NORM_L2SQR) as a float, like afv_match_l2): desc = rows of `dim` floats,
+ * best_median (may be NULL) = the winning row's median distance. */
+int afv_distinctive_descriptors_f32(afv_ctx *ctx, const float *desc, int dim, const int32_t *set_ptr, int nsets, int32_t *best_idx,
+                                    float *best_median);
+
 /* The float cases of Vocabulary::transform (src/Vocabulary.cpp:158-187: SIFT128, SURF64, KAZE64, R2D2, any non-binary feature): node
  * descriptors and features are `dim` floats (64, 128 or 256), the distance at a node is DBoW2's float-descriptor distance - squared
  * differences evaluated in float, accumulated in double in index order (upstream FSurf64::distance; the reference's fork with the classes

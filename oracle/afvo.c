@@ -1455,6 +1455,34 @@ int afvo_distinctive_descriptor(const uint8_t *desc, int n, int desc_bytes, int 
     return best;
 }
 
+static int cmp_float(const void *a, const void *b) {
+    const float x = *(const float *)a, y = *(const float *)b;
+    return (x > y) - (x < y);
+}
+/* the same with Descriptor_Distance_Type = float distances of float descriptors (DescriptorDistance -> afvo_l2sqr) */
+int afvo_distinctive_descriptor_f32(const float *desc, int n, int dim, float *median_out) {
+    if (n <= 0) { if (median_out) *median_out = 0.0f; return -1; }
+    float *D = (float *)malloc(sizeof(float) * (size_t)n * n), *row = (float *)malloc(sizeof(float) * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        D[(size_t)i * n + i] = 0.0f;
+        for (int j = i + 1; j < n; ++j) {
+            const float d = afvo_l2sqr(desc + (size_t)i * dim, desc + (size_t)j * dim, dim);
+            D[(size_t)i * n + j] = D[(size_t)j * n + i] = d;
+        }
+    }
+    int best = 0;
+    float best_median = FLT_MAX;
+    for (int i = 0; i < n; ++i) {
+        memcpy(row, D + (size_t)i * n, sizeof(float) * (size_t)n);
+        qsort(row, (size_t)n, sizeof(float), cmp_float);
+        const float median = row[(size_t)(0.5 * (n - 1))];
+        if (median < best_median) { best_median = median; best = i; }
+    }
+    free(D); free(row);
+    if (median_out) *median_out = best_median;
+    return best;
+}
+
 /* float descriptors (Vocabulary.cpp:158-187): DBoW2's float classes take the distance as the squared differences evaluated in float,
  * accumulated in double in index order (upstream FSurf64::distance); first minimum wins.  v->desc = float[nnodes][dim], v->desc_bytes = 4 * dim. */
 void afvo_bow_transform_f32(const afvo_vocab *v, const float *desc, int n, int levelsup, int32_t *leaf_node, int32_t *node_at_level) {

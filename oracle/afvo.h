@@ -206,6 +206,7 @@ typedef struct {
 } afvo_vocab;
 void afvo_bow_transform(const afvo_vocab *v, const uint8_t *desc, int n, int levelsup, int32_t *leaf_node, int32_t *node_at_level);
 int afvo_distinctive_descriptor(const uint8_t *desc, int n, int desc_bytes, int *median_out);  /* MapPoint.cc:279-349 */
+int afvo_distinctive_descriptor_f32(const float *desc, int n, int dim, float *median_out);        /* ... on float descriptors (L2^2) */
 void afvo_bow_transform_f32(const afvo_vocab *v, const float *desc, int n, int levelsup, int32_t *leaf_node, int32_t *node_at_level);
 
 /* M6 pieces, exposed for KATs */

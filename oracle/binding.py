@@ -484,6 +484,13 @@ def bow_transform(vocab, desc, levelsup=4):
 
 def distinctive_descriptor(desc):
     """MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:279-349) of one map point: (best row | -1, its median)"""
+    if np.asarray(desc).dtype.kind == "f":
+        desc = np.ascontiguousarray(desc, np.float32)
+        desc = desc.reshape(len(desc), -1) if len(desc) else np.zeros((0, 4), np.float32)
+        fmed = C.c_float(0)
+        fn = lib().afvo_distinctive_descriptor_f32
+        fn.restype = C.c_int
+        return fn(_p(desc), len(desc), desc.shape[1], C.byref(fmed)), np.float32(fmed.value)
     desc = np.ascontiguousarray(desc, np.uint8)
     desc = desc.reshape(len(desc), -1) if len(desc) else np.zeros((0, 32), np.uint8)
     med = C.c_int(0)

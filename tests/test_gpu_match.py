@@ -787,3 +787,30 @@ def test_distinctive_descriptors_of_map_points(afv, oracle, gpu_ctx, nbytes):
     assert best[0] == -1 and best[1] == 0 and best[-1] == 0 and med[-1] == 0
     b0, _ = afv.ComputeDistinctiveDescriptors(gpu_ctx, [])
     assert len(b0) == 0
+
+
+@pytest.mark.parametrize("dim,real", [(128, True), (64, False)])
+def test_distinctive_descriptors_of_float_map_points(afv, oracle, gpu_ctx, dim, real):
+    """the same on float descriptors (DescriptorDistance = L2^2 as a float): sets below and above the 64 observations whose distances stay
+    in LDS, exact copies (ties between medians: the first row wins; equal distances inside a row)"""
+    from _float_desc import floaten
+    s = afv.synth
+    sizes = [0, 1, 2, 3, 4, 5, 7, 8, 13, 20, 33, 63, 64, 65, 100, 129] + [int(v % 12) + 2 for v in s.lcg_states(3, 60)]
+    sets = []
+    for k, n in enumerate(sizes):
+        proto = s.lcg_bytes(100 + k, 3 * 32).reshape(3, 32)
+        d = proto[s.lcg_states(200 + k, max(n, 1)) % 3][:n].copy()
+        if n:
+            flip = s.lcg_states(300 + k, n)
+            d[np.arange(n), flip % 32] ^= (1 << (flip // 7 % 8)).astype(np.uint8) * (flip % 3 != 0)
+        f = floaten(d, dim, real) if n else np.zeros((0, dim), np.float32)
+        if real and n > 3:
+            f[n // 2] = f[0]   # an exact copy among rows that otherwise all differ
+        sets.append(f)
+    sets.append(np.tile(floaten(s.lcg_bytes(9, 32).reshape(1, 32), dim, real), (10, 1)))
+    best, med = afv.ComputeDistinctiveDescriptors(gpu_ctx, sets)
+    assert med.dtype == np.float32
+    for k, d in enumerate(sets):
+        wi, wm = oracle.distinctive_descriptor(d)
+        assert best[k] == wi and (wi < 0 or med[k] == wm), (k, len(d), best[k], wi, med[k], wm)
+    assert best[0] == -1 and best[1] == 0 and best[-1] == 0 and med[-1] == 0

@@ -667,3 +667,16 @@ def test_float_descriptors_by_hand(oracle, afv):
     a, n = oracle.match_projection(F, Q, th_high=0.5, nnratio=0.01)         # 0.01 > 0.01 * 0.81 in the same scale band: q0 rejected, q1 sees (0, 1): 0 <= 0.01
     assert a.tolist() == [1, -1, -1] and n == 1
     assert oracle.l2sqr(np.float32([0.9, 0, 0, 0]), np.float32([1, 0, 0, 0])) == np.float32(np.float64(np.float32(0.9) - np.float32(1)) ** 2)
+
+
+def test_distinctive_float_descriptor_by_hand(oracle):
+    """MapPoint::ComputeDistinctiveDescriptors with float distances: rows 0, 1, 2 on a line at 0, 1, 3 (one coordinate): the rows of squared
+    distances are (0 1 9), (0 1 4), (0 4 9) with medians 1, 1, 4 - the FIRST least median wins (strict <, MapPoint.cc:333)"""
+    d = np.zeros((3, 4), np.float32)
+    d[:, 0] = [0, 1, 3]
+    i, m = oracle.distinctive_descriptor(d)
+    assert i == 0 and m == np.float32(1)
+    d[:, 0] = [0, 2, 3]            # rows (0 4 9), (0 1 4), (0 1 9): medians 4, 1, 1 -> row 1
+    i, m = oracle.distinctive_descriptor(d)
+    assert i == 1 and m == np.float32(1)
+    assert oracle.distinctive_descriptor(np.zeros((0, 4), np.float32))[0] == -1
