@@ -427,3 +427,50 @@ def test_float_jobs_that_are_refused(afv, gpu_ctx):
     Q.descriptors = np.ascontiguousarray(Q.descriptors[:, :126])
     with pytest.raises(afv._lib.AfvError):
         m.SearchByProjection(F, Q)
+
+
+def test_float_descriptor_edge_cases(afv, oracle, gpu_ctx):
+    """empty feature side, no queries, the smallest (4) and the largest (1024) row the float path takes, one feature shared by many queries"""
+    s = afv.synth
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(1e9)
+    try:
+        m = afv.FeatureMatcher(0.9, False, ctx=gpu_ctx)
+        for dim in (4, 1024):
+            n, nq = 40, 90
+            d = (s.lcg_bytes(1, n * dim).reshape(n, dim).astype(np.float32) - 128) / np.float32(64)
+            q = (s.lcg_bytes(2, nq * dim).reshape(nq, dim).astype(np.float32) - 128) / np.float32(64)
+            pts = np.stack([100 + (s.lcg_states(3, n) % 200).astype(np.float32), 100 + (s.lcg_states(4, n) % 200).astype(np.float32)], 1)
+            F = afv.FrameGridView(d, pts, np.ones(n, np.float32), angles=np.zeros(n, np.float32))
+            Q = afv.ProjectionQueries(q, 100 + (s.lcg_states(5, nq) % 200).astype(np.float32), 100 + (s.lcg_states(6, nq) % 200).astype(np.float32),
+                                      np.full(nq, 60.0), np.full(nq, 0.5), np.full(nq, 2.0), angles=np.zeros(nq, np.float32))
+            for last in (False, True):
+                got, nn = m.SearchByProjection(F, Q, last_frame=last)
+                want, wn = oracle.match_projection(F, Q, th_high=1e9, nnratio=0.9, last_frame=last)
+                assert nn == wn and np.array_equal(got, want) and (wn > 5 or (dim == 1024 and not last)), (dim, last)  # (random 1024-float rows: the ratio test rejects all)
+            got, nn = m.Fuse_sim3(F, Q)
+            want, wn = oracle.match_projection(F, Q, th_high=1e9, fuse=True)
+            assert nn == wn and np.array_equal(got, want)
+            # no queries / no features
+            Q0 = afv.ProjectionQueries(np.zeros((0, dim), np.float32), [], [], [], [], [])
+            got, nn = m.SearchByProjection(F, Q0)
+            assert nn == 0 and np.all(got == -1) and len(got) == n
+            F0 = afv.FrameGridView(np.zeros((0, dim), np.float32), np.zeros((0, 2), np.float32), np.zeros(0, np.float32))
+            got, nn = m.SearchByProjection(F0, Q)
+            assert nn == 0 and len(got) == 0
+            got, nn = m.SearchForInitialization(Q, F0)
+            assert nn == 0 and np.all(got == -1) and len(got) == nq
+        # one feature, many queries that all want it: the local-map flavour hands it to the first (later ones find it occupied), the
+        # initialization search lets a closer later query steal it
+        dim = 8
+        F1 = afv.FrameGridView(np.zeros((1, dim), np.float32), np.float32([[200, 200]]), np.ones(1, np.float32), angles=np.zeros(1, np.float32))
+        qd = np.zeros((5, dim), np.float32)
+        qd[:, 0] = [3, 2, 2, 1, 4]
+        Q5 = afv.ProjectionQueries(qd, np.full(5, 200.0), np.full(5, 200.0), np.full(5, 20.0), np.full(5, 0.5), np.full(5, 2.0), angles=np.zeros(5, np.float32))
+        got, nn = m.SearchByProjection(F1, Q5)
+        want, wn = oracle.match_projection(F1, Q5, th_high=1e9, nnratio=0.9)
+        assert nn == wn == 1 and got.tolist() == want.tolist() == [0]
+        got, nn = m.SearchForInitialization(Q5, F1)
+        want, wn = oracle.match_initialization(F1, Q5, th_low=1e9, nnratio=0.9, check_orientation=False)
+        assert nn == wn == 1 and got.tolist() == want.tolist() == [-1, -1, -1, 0, -1]   # 9, then 4 (steals), 4 (not < 4: gated), then 1 (steals), 16
+    finally:
+        afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
