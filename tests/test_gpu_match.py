@@ -122,6 +122,40 @@ def test_empty_and_ragged(afv, oracle, matcher):
     assert n == 0 and np.all(got == -1)
 
 
+def test_empty_and_ragged_float(afv, oracle, matcher):
+    """the float rows of the same entry point: empty sides, one row, a batch mixing binary and float jobs"""
+    from _float_desc import floaten
+    matcher.mbCheckOrientation = False
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(40.0)
+    try:
+        d8 = afv.synth.random_descriptors(3, 10)
+        d = floaten(d8, 128, True)
+        empty = np.zeros((0, 128), np.float32)
+        for a, b in [(empty, d), (d, empty), (empty, empty), (d[:1], d[:1])]:
+            for frame in (False, True):
+                got, n = matcher.SearchByBoW(afv.FeatureView(a), afv.FeatureView(b), frame=frame)
+                if frame:
+                    want, wn = oracle.search_by_bow_kf_frame(a, b, None, None, None, None, None, 40.0, 0.6, False)
+                else:
+                    want, wn = oracle.search_by_bow_kf_kf(a, b, th_low=40.0, nnratio=0.6)
+                assert n == wn and np.array_equal(got, want), (len(a), len(b), frame)
+        # one call, three jobs: float, binary, float of another dimension
+        d1, d2, _, _ = _sets(afv, 5, 300, 320)
+        jobs = [(afv.FeatureView(floaten(d1, 128, True)), afv.FeatureView(floaten(d2, 128, True))),
+                (afv.FeatureView(d1), afv.FeatureView(d2)),
+                (afv.FeatureView(floaten(d1, 64, False)), afv.FeatureView(floaten(d2, 64, False)))]
+        res = matcher.SearchByBoW_batch(jobs)
+        for (a, b), (got, n) in zip(jobs, res):
+            want, wn = oracle.search_by_bow_kf_kf(a.descriptors, b.descriptors, th_low=40.0, nnratio=0.6)
+            assert n == wn and np.array_equal(got, want)
+        assert res[0][1] > 20 and res[2][1] > 20
+        # rows that are neither binary nor whole 16-byte groups of floats are refused
+        with pytest.raises(afv._lib.AfvError):
+            matcher.SearchByBoW(afv.FeatureView(d[:, :126].copy()), afv.FeatureView(d[:, :126].copy()))
+    finally:
+        afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)
+
+
 def test_batch_of_jobs(afv, oracle, matcher):
     matcher.mbCheckOrientation = True
     pairs, want = [], []
