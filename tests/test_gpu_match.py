@@ -848,3 +848,32 @@ def test_distinctive_descriptors_of_float_map_points(afv, oracle, gpu_ctx, dim, 
         wi, wm = oracle.distinctive_descriptor(d)
         assert best[k] == wi and (wi < 0 or med[k] == wm), (k, len(d), best[k], wi, med[k], wm)
     assert best[0] == -1 and best[1] == 0 and best[-1] == 0 and med[-1] == 0
+
+
+def test_float_matchers_against_the_committed_fixture(afv, gpu_ctx):
+    """the HIP float paths against tests/golden/float_matchers_expected.npz - no oracle binary involved (the inputs are rebuilt from the ORB32
+    fixture by the committed generator's own helpers)"""
+    import importlib.util
+    import os
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_golden_float", os.path.join(gdir, "make_golden_float.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    gold = np.load(os.path.join(gdir, "orb32_expected.npz"))
+    fg = np.load(os.path.join(gdir, "float_matchers_expected.npz"))
+    k1, ks, f1, fs, z1, zs = mk.scene(gold)
+    F, Q, Qi, sets = mk.views(k1, ks, f1, fs, z1, zs)
+    afv.FeatureMatcher.setDescriptorDistanceThresholds(mk.TH)
+    try:
+        m = afv.FeatureMatcher(0.8, True, ctx=gpu_ctx)
+        got, n = m.SearchByBoW(afv.FeatureView(fs, angles=ks["angle"]), afv.FeatureView(f1, angles=k1["angle"]))
+        assert n == int(fg["bow_n"][0]) and np.array_equal(got, fg["bow_match12"])
+        m = afv.FeatureMatcher(0.9, True, ctx=gpu_ctx)
+        got, n = m.SearchByProjection(F, Q, last_frame=True)
+        assert n == int(fg["proj_n"][0]) and np.array_equal(got, fg["proj_assign"])
+        got, n = m.SearchForInitialization(Qi, F)
+        assert n == int(fg["init_n"][0]) and np.array_equal(got, fg["init_match12"])
+        best, med = afv.ComputeDistinctiveDescriptors(gpu_ctx, sets)
+        assert best.tolist() == fg["dist_best"].tolist() and np.array_equal(med, fg["dist_median"])
+    finally:
+        afv.FeatureMatcher.setDescriptorDistanceThresholds(75.0)

@@ -680,3 +680,24 @@ def test_distinctive_float_descriptor_by_hand(oracle):
     i, m = oracle.distinctive_descriptor(d)
     assert i == 1 and m == np.float32(1)
     assert oracle.distinctive_descriptor(np.zeros((0, 4), np.float32))[0] == -1
+
+
+def test_golden_float_matcher_vectors(oracle, afv, gold):
+    """tests/golden/float_matchers_expected.npz (made by tests/golden/make_golden_float.py): the float-descriptor paths of the matchers on the
+    frames of the ORB32 fixture - the oracle must still answer what it answered when the fixture was committed"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_float", os.path.join(GOLD, "make_golden_float.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    fg = np.load(os.path.join(GOLD, "float_matchers_expected.npz"))
+    k1, ks, f1, fs, z1, zs = mk.scene(gold)
+    assert [int(np.frombuffer(f.tobytes(), np.uint8).astype(np.uint64).sum()) for f in (f1, fs)] == fg["row_crc"].tolist()  # the inputs are the same
+    F, Q, Qi, sets = mk.views(k1, ks, f1, fs, z1, zs)
+    m, n = oracle.search_by_bow_kf_kf(fs, f1, angle1=ks["angle"], angle2=k1["angle"], th_low=mk.TH, nnratio=0.8, check_orientation=True)
+    assert n == int(fg["bow_n"][0]) and np.array_equal(m, fg["bow_match12"]) and n > 300
+    a, n = oracle.match_projection(F, Q, th_high=mk.TH, nnratio=0.9, check_orientation=True, last_frame=True)
+    assert n == int(fg["proj_n"][0]) and np.array_equal(a, fg["proj_assign"]) and n > 300
+    i12, n = oracle.match_initialization(F, Qi, th_low=mk.TH, nnratio=0.9, check_orientation=True)
+    assert n == int(fg["init_n"][0]) and np.array_equal(i12, fg["init_match12"]) and n > 100
+    best = [oracle.distinctive_descriptor(s) for s in sets]
+    assert [b[0] for b in best] == fg["dist_best"].tolist() and np.array_equal(np.float32([b[1] for b in best]), fg["dist_median"])
