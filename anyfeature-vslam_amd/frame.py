@@ -104,16 +104,21 @@ class Frame:
         return dict(zip(("kps", "desc", "x", "y", "size", "angle", "n"), (o.value for o in out)))
 
     # ---- Frame::ComputeBoW ----
-    def ComputeBoW(self, vocabulary, levelsup=4):
-        """Frame::ComputeBoW (Frame.cc:397-401): returns (BowVector, FeatureVector) like Vocabulary.transform; the FeatureVector also
-        stays on the device with the frame"""
+    def bow_transform_nodes(self, vocabulary, levelsup=4):
+        """afv_frame_bow_transform alone: (leaf node, node at depth L - levelsup) per feature; the FeatureVector is built on the device and
+        stays with the frame.  ComputeBoW = this + the host-side BowVector / FeatureVector containers"""
         n = self.N
         leaf = np.zeros(max(n, 1), np.int32); nid = np.zeros(max(n, 1), np.int32)
         nn = C.c_int32(0)
         self.ctx.check(self.lib.afv_frame_bow_transform(self.handle, vocabulary._device(), int(levelsup), ptr(leaf), ptr(nid), C.byref(nn)),
                        "afv_frame_bow_transform")
         self._nnodes = int(nn.value)
-        return vocabulary.vectors_from_nodes(leaf[:n], nid[:n])
+        return leaf[:n], nid[:n]
+
+    def ComputeBoW(self, vocabulary, levelsup=4):
+        """Frame::ComputeBoW (Frame.cc:397-401): returns (BowVector, FeatureVector) like Vocabulary.transform; the FeatureVector also
+        stays on the device with the frame"""
+        return vocabulary.vectors_from_nodes(*self.bow_transform_nodes(vocabulary, levelsup))
 
     def featvec(self):
         """the resident FeatureVector as [(node_id, [feature indices])]"""

@@ -895,7 +895,7 @@ def extra_tracking_frame_akaze61(afv, device, reps=50):
         t1b = time.perf_counter()
         cur.set_features(kb, db, sizes=zb)
         t2 = time.perf_counter()
-        cur.ComputeBoW(voc, levelsup=2)
+        cur.bow_transform_nodes(voc, levelsup=2)   # the C call (afv_frame_bow_transform); the BowVector / FeatureVector dictionaries of ComputeBoW are host Python
         t3 = time.perf_counter()
         _, nm = cur.SearchByProjection(m, Q, last_frame=True)
         t4 = time.perf_counter()
@@ -918,7 +918,7 @@ def extra_tracking_frame_float128(afv, device, reps=50):
     """the same chain on float descriptors (BASELINE config #3's kind of feature: 128 floats, L2^2 - SIFT128; the SIFT extractor itself is
     SiftGPU / OpenGL, out of scope): resident float frame (afv_frame_set_features, 512-byte rows) -> Frame::ComputeBoW on a float vocabulary
     (k = 10, L = 4) -> SearchByProjection(cur, last) with L2^2 distances (ordered-walk engine); keypoints of an ORB frame, SIFT-like unit rows;
-    synchronous calls timed from Python like tracking_frame_akaze61"""
+    synchronous calls timed from Python like tracking_frame_akaze61 (ComputeBoW = the C call afv_frame_bow_transform; the Python containers are not timed)"""
     import numpy as np
     ctx = afv.Context(device=device)
     s = afv.synth
@@ -945,7 +945,7 @@ def extra_tracking_frame_float128(afv, device, reps=50):
         t1 = time.perf_counter()
         cur.set_features(kb, db)
         t2 = time.perf_counter()
-        cur.ComputeBoW(voc, levelsup=2)
+        cur.bow_transform_nodes(voc, levelsup=2)   # the C call (afv_frame_bow_transform); the BowVector / FeatureVector dictionaries of ComputeBoW are host Python
         t3 = time.perf_counter()
         _, nm = cur.SearchByProjection(m, Q, last_frame=True)
         t4 = time.perf_counter()
