@@ -411,7 +411,8 @@ int afv_distinctive_descriptors_f32(afv_ctx *ctx, const float *desc, int dim, co
  * descriptors and features are `dim` floats (64, 128 or 256), the distance at a node is DBoW2's float-descriptor distance - squared
  * differences evaluated in float, accumulated in double in index order (upstream FSurf64::distance; the reference's fork with the classes
  * it instantiates is an empty submodule: parity unpinned) - first minimum wins.  Same tree arguments as afv_vocab_create; destroyed with
- * afv_vocab_destroy; afv_bow_transform / afv_frame_bow_transform refuse a float vocabulary and afv_bow_transform_f32 a binary one. */
+ * afv_vocab_destroy; afv_bow_transform refuses a float vocabulary and afv_bow_transform_f32 a binary one; afv_frame_bow_transform wants the
+ * vocabulary of the frame's own descriptor kind and size (a float frame - afv_frame_params.float_dim - a float vocabulary of that dimension). */
 int afv_vocab_create_f32(afv_ctx *ctx, int k, int L, int nnodes, const int32_t *child_ptr, const int32_t *child_idx, const float *desc, int dim,
                          afv_vocab **out);
 int afv_bow_transform_f32(afv_ctx *ctx, const afv_vocab *v, const float *desc, int n, int levelsup, int32_t *leaf_node, int32_t *node_at_level);
@@ -461,14 +462,14 @@ void afv_frame_destroy(afv_frame *f);
 int afv_frame_extract(afv_frame *f, const uint8_t *gray, int width, int height, int stride_bytes, afv_keypoint *kps, uint8_t *desc32,
                       int cap, int *n_out);
 /* a frame whose features were produced elsewhere (a stereo rig, another extractor, a test): n keypoints (cv::KeyPoint layout; pt =
- * mvKeysUn unless `distorted`), n x 32-byte descriptors, per-feature keyPtsSize (NULL = E12 from the octave as afv_orb_size_sigma) and
+ * mvKeysUn unless `distorted`), n descriptor rows of the frame's kind (desc_bytes bytes each; float_dim floats each for a float frame), per-feature keyPtsSize (NULL = E12 from the octave as afv_orb_size_sigma) and
  * mvuRight (NULL = monocular: -1).  Host pointers; asynchronous on the context's stream (the arrays are copied before the call returns). */
 int afv_frame_set_features(afv_frame *f, const afv_keypoint *kps, const uint8_t *desc32, int n, const float *size, const float *u_right);
 /* mvKeysUn of a `distorted` frame: x[n], y[n] (host); builds the grid.  Asynchronous on the context's stream. */
 int afv_frame_set_undistorted(afv_frame *f, const float *x, const float *y);
 int afv_frame_count(const afv_frame *f); /* N of the last afv_frame_extract / afv_frame_set_features */
 /* device views (valid until the frame is destroyed; contents change with the next extract): any may be NULL.
- * d_kps[cap] afv_keypoint (mvKeys), d_desc[cap][32], d_xy = {x[cap], y[cap]} of mvKeysUn, d_size[cap] keyPtsSize, d_angle[cap],
+ * d_kps[cap] afv_keypoint (mvKeys), d_desc[cap][row] (row = 32 bytes; 64 for binary rows above 32 bytes, zero-padded; 4 * float_dim for a float frame), d_xy = {x[cap], y[cap]} of mvKeysUn, d_size[cap] keyPtsSize, d_angle[cap],
  * d_n = the count */
 int afv_frame_device_ptrs(afv_frame *f, afv_keypoint **d_kps, uint8_t **d_desc, float **d_x, float **d_y, float **d_size, float **d_angle,
                           int32_t **d_n);
