@@ -1879,9 +1879,10 @@ int afv_match_projection_core(afv_ctx *c, const afv_proj_job *jobs, int njobs, i
     if (rc) return rc;
     // ordered phase: the workgroup fixed point when the largest job's tables fit the LDS it may use
     size_t wg_lds = 0;
-    // (float descriptors: the ordered walk - the fixed-point engines' records hold 16-bit distances)
-    if (!fuse && !any_float && c->proj_engine != 0 && c->proj_wg_lds_max > 0 && (kind != AFV_KIND_INIT || max_nq <= 32767)) {
-        for (int i = 0; i < njobs; ++i) wg_lds = std::max(wg_lds, afv_project_wg_lds(kind == AFV_KIND_INIT, jobs[i].n, jobs[i].nq));
+    // (float descriptors: the projection searches' fixed point carries float distances; SearchForInitialization's packs them in 16 bits and
+    // float jobs take its ordered walk)
+    if (!fuse && !(any_float && kind == AFV_KIND_INIT) && c->proj_engine != 0 && c->proj_wg_lds_max > 0 && (kind != AFV_KIND_INIT || max_nq <= 32767)) {
+        for (int i = 0; i < njobs; ++i) wg_lds = std::max(wg_lds, afv_project_wg_lds(kind == AFV_KIND_INIT, jobs[i].n, jobs[i].nq, any_float ? 1 : 0));
         if (wg_lds > (size_t)c->proj_wg_lds_max) wg_lds = 0;
     }
     // results straight into the pinned arena (device-visible host memory) when the kernels write them once and never read them back
@@ -1889,7 +1890,8 @@ int afv_match_projection_core(afv_ctx *c, const afv_proj_job *jobs, int njobs, i
     // ... and, for ONE job against a resident frame, the inputs straight out of it: the job record is the kernel argument, the queries
     // (a few KB per array, read once by the ranking kernel) come over the link without a copy-engine hop ahead of the launch
     // (not with an occupancy mask: that one is gathered per candidate, which belongs in device memory)
-    const bool zero_copy_in = zero_copy && dev && njobs == 1 && !(jobs[0].occupied && kind != AFV_KIND_INIT);
+    // (nor with float rows: a query row is 4 * dim bytes and is read once per CANDIDATE - that belongs in device memory too)
+    const bool zero_copy_in = zero_copy && dev && njobs == 1 && !any_float && !(jobs[0].occupied && kind != AFV_KIND_INIT);
     uint8_t *B = c->d_match, *H = b.h.data();
     uint8_t *IN = zero_copy_in ? H : B;  // where the kernels find the staged inputs
     size_t acc = 0;
@@ -1960,7 +1962,7 @@ int afv_match_projection_core(afv_ctx *c, const afv_proj_job *jobs, int njobs, i
     // one launch for ranking + ordered phase: the projection searches (a few candidates per query).  SearchForInitialization keeps two: its
     // ranking walks 100-pixel windows (hundreds of cells per query) and is better off on 250 four-wave workgroups than on 63 sixteen-wave
     // ones (measured: 59.6 us against 72.5 host to host)
-    int *ticket = (one && wg_lds && c->proj_fuse && kind == AFV_KIND_PROJ) ? c->d_proj_ticket : nullptr;
+    int *ticket = (one && wg_lds && c->proj_fuse && kind == AFV_KIND_PROJ && !any_float) ? c->d_proj_ticket : nullptr;  // (the one-launch kernel is binary-only)
     if (fuse) afv_launch_match_fuse(dj, njobs, max_nq, one, c->stream);
     else if (kind == AFV_KIND_INIT) afv_launch_match_init(dj, njobs, max_nq, wg_lds, one, ticket, c->stream);
     else afv_launch_match_projection(dj, njobs, max_nq, wg_lds, one, ticket, c->stream);

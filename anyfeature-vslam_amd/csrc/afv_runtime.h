@@ -73,7 +73,7 @@ extern "C" int afv_project_prepare(void);
 extern "C" int afv_match_prepare(void);
 extern "C" int afv_select_prepare(int M);
 extern "C" int afv_debug_pass_cap;
-extern "C" size_t afv_project_wg_lds(int kind_init, int n, int nq);
+extern "C" size_t afv_project_wg_lds(int kind_init, int n, int nq, int float_rows);
 extern "C" size_t afv_frame_grid_lds(int cols, int rows, int cap);
 extern "C" int afv_frame_prepare(void);
 extern "C" size_t afv_featvec_build_lds(int cap, int width);

@@ -299,7 +299,7 @@ __device__ void topk_query(const DevProjJob &J, int q, int lane, int2 *s_list /*
     for (int s = 0; s < K; ++s) k[s] = P_NO_KEY;
     int visited = 0;
     if constexpr (W == 0) {
-        if constexpr ((REC & 1) != 0) return;  // the fixed-point engines' 32-bit records cannot carry a float distance: never launched for float jobs
+        if constexpr (REC == 3) return;  // SearchForInitialization's fixed point packs distances in 16 bits: float jobs take its ordered walk (REC 2)
         if (!J.qvalid || J.qvalid[q]) {
             const float *qrow = proj_qrow(J, q);
             PROJ_WAVE_WINDOW_DENSE(J, q, lane, s_list, {
@@ -371,7 +371,16 @@ __device__ void topk_query(const DevProjJob &J, int q, int lane, int2 *s_list /*
         }
     } else if (REC == 1) {
         uint32_t *rec = reinterpret_cast<uint32_t *>(J.keys) + (size_t)q * 8;
-        if (lane < PK) rec[lane] = mine == P_NO_KEY ? PROJ_NO_KEY32 : (((uint32_t)key_dist(mine) << 16) | (uint32_t)key_idx(mine));
+        if constexpr (W == 0) {
+            // float distances: the same 32 bytes hold 4 x distance bits | #candidates | "occupies" | the four features as 16-bit halves
+            // (0xffff = no key; a feature index is < 8192)
+            if (lane < PK) rec[lane] = (uint32_t)(mine >> 32);
+            const uint32_t f = mine == P_NO_KEY ? 0xffffu : (uint32_t)key_idx(mine);
+            const uint32_t f_next = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + 1) & 63) * 4, (int)f);
+            if (lane == 0 || lane == 2) rec[6 + (lane >> 1)] = f | (f_next << 16);
+        } else {
+            if (lane < PK) rec[lane] = mine == P_NO_KEY ? PROJ_NO_KEY32 : (((uint32_t)key_dist(mine) << 16) | (uint32_t)key_idx(mine));
+        }
         if (lane == PK) rec[4] = (uint32_t)visited;
         if (lane == PK + 1) rec[5] = (!J.qocc || J.qocc[q]) ? 1u : 0u;
     } else if (REC == 2) {
@@ -678,23 +687,46 @@ __device__ __forceinline__ bool wg_any_changed(bool changed, int pass, int *s_vo
 #define PW_WLIST 128
 #define PW_GUARD (-0x7fffffff)  // *nmatches when the pass guard trips (never observed; the host turns it into AFV_EHIP)
 
-static inline size_t proj_wg_lds_bytes(int n, int nq) {
+static inline size_t proj_wg_lds_bytes(int n, int nq, bool float_rows = false) {
     const size_t nr = ((size_t)n + 63) & ~(size_t)63, qr = ((size_t)nq + 63) & ~(size_t)63;
-    return 3 * nr * 4 + qr * 16 /*keys*/ + qr * 4 /*meta*/ + qr * 4 /*query angle*/ + 3 * qr * 2 /*w1, w2, pin*/ + qr * 2 /*live*/ + qr /*flag*/ + 64;
+    return 3 * nr * 4 + qr * 16 /*keys*/ + qr * 4 /*meta*/ + qr * 4 /*query angle*/ + 3 * qr * 2 /*w1, w2, pin*/ + qr * 2 /*live*/ + qr /*flag*/ + 64 +
+           (float_rows ? qr * 8 /*the keys' features*/ : 0);
 }
 
 // one live query against the claims in R: the feature it accepts (-1: none) and whether it needs the exact rescan
-__device__ __forceinline__ void proj_eval(const DevProjJob &J, const int4 kk, int meta, const int *R, int li, int &want, bool &rescan) {
+// (W == 0, float descriptors: kk = the four distances' bits, feats = the four features as 16-bit halves, 0xffff = no key)
+template <int W>
+__device__ __forceinline__ void proj_eval(const DevProjJob &J, const int4 kk, const int2 feats, int meta, const int *R, int li, int &want, bool &rescan) {
     const unsigned keys[PK] = {(unsigned)kk.x, (unsigned)kk.y, (unsigned)kk.z, (unsigned)kk.w};
     const bool complete = (meta & 0x7fffffff) <= PK;  // the key list holds the whole window
+    int fi[PK];
+    bool has[PK];
+    if constexpr (W == 0) {
+        fi[0] = feats.x & 0xffff, fi[1] = (int)((unsigned)feats.x >> 16), fi[2] = feats.y & 0xffff, fi[3] = (int)((unsigned)feats.y >> 16);
+#pragma unroll
+        for (int s = 0; s < PK; ++s) has[s] = fi[s] != 0xffff;
+    } else {
+#pragma unroll
+        for (int s = 0; s < PK; ++s) {
+            has[s] = keys[s] != PROJ_NO_KEY32;
+            fi[s] = (int)(keys[s] & 0xffffu);
+        }
+    }
     int cl[PK];
 #pragma unroll
-    for (int s = 0; s < PK; ++s) cl[s] = keys[s] == PROJ_NO_KEY32 ? -1 : R[keys[s] & 0xffffu];  // four LDS reads in flight together
-    int e0 = -1, e1 = -1, d0 = 0, d1 = 0;
+    for (int s = 0; s < PK; ++s) cl[s] = has[s] ? R[fi[s]] : -1;  // four LDS reads in flight together
+    using dist_t = std::conditional_t<W == 0, float, int>;
+    auto dist_of = [&](int s) -> dist_t {
+        if constexpr (W == 0) return __uint_as_float(keys[s]);
+        else return (int)(keys[s] >> 16);
+    };
+    int e0 = -1, e1 = -1;
+    dist_t d0 = 0, d1 = 0;
 #pragma unroll
     for (int s = 0; s < PK; ++s) {
-        const bool fr = keys[s] != PROJ_NO_KEY32 && !(cl[s] < li);
-        const int idx = (int)(keys[s] & 0xffffu), d = (int)(keys[s] >> 16);
+        const bool fr = has[s] && !(cl[s] < li);
+        const int idx = fi[s];
+        const dist_t d = dist_of(s);
         if (fr && e0 < 0) {
             e0 = idx;
             d0 = d;
@@ -703,7 +735,7 @@ __device__ __forceinline__ void proj_eval(const DevProjJob &J, const int4 kk, in
             d1 = d;
         }
     }
-    const float d_last = (float)(keys[PK - 1] >> 16);  // incomplete lists are full: every candidate outside is at least this far
+    const float d_last = (float)dist_of(PK - 1);  // incomplete lists are full: every candidate outside is at least this far
     want = -1;
     rescan = false;
     if (e0 < 0) {
@@ -740,6 +772,7 @@ __device__ void proj_resolve_wg(const DevProjJob &J) {
     short *s_pin = s_w2 + qr;                                                 // the answer of its rescan
     unsigned short *s_live = reinterpret_cast<unsigned short *>(s_pin + qr);  // live index -> query
     uint8_t *s_flag = reinterpret_cast<uint8_t *>(s_live + qr);               // 1 = asked for a rescan in the last pass, 2 = pinned by a rescan
+    int2 *s_feat = reinterpret_cast<int2 *>(s_flag + qr + 64 - 8);            // float jobs only: the keys' features (qr and the 64 spare bytes keep it 8-byte aligned)
     __shared__ int s_hist[32];
     __shared__ int s_nm, s_drop[3], s_first, s_part[PW_NW], s_cntw[PW_NW], s_guard, s_vote[3];
     __shared__ unsigned short s_wlist[PW_WLIST];
@@ -765,7 +798,9 @@ __device__ void proj_resolve_wg(const DevProjJob &J) {
             kb = grec[2 * q + 1];
             if (J.mode == 1 && J.check_ori) qa = J.qangle[q];
         }
-        const bool live = (unsigned)ka.x != PROJ_NO_KEY32 && (float)((unsigned)ka.x >> 16) <= J.th;
+        bool live;
+        if constexpr (W == 0) live = q < J.nq && (kb.z & 0xffff) != 0xffff && __int_as_float(ka.x) <= J.th;
+        else live = (unsigned)ka.x != PROJ_NO_KEY32 && (float)((unsigned)ka.x >> 16) <= J.th;
         const unsigned long long m = __ballot(live);
         if (lane == 0) s_cntw[wv] = __popcll(m);
         __syncthreads();
@@ -780,6 +815,7 @@ __device__ void proj_resolve_wg(const DevProjJob &J) {
             const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
             s_live[slot] = (unsigned short)q;
             s_keys[slot] = ka;
+            if constexpr (W == 0) s_feat[slot] = make_int2(kb.z, kb.w);
             s_qang[slot] = qa;
             s_meta[slot] = (kb.x & 0x7fffffff) | (kb.y ? (int)0x80000000 : 0);
             s_w1[slot] = -1;
@@ -813,7 +849,9 @@ __device__ void proj_resolve_wg(const DevProjJob &J) {
             if (flag & 2) {
                 want = s_pin[li];  // pinned by its rescan: the query asserts that answer in every pass
             } else {
-                proj_eval(J, s_keys[li], meta, R, li, want, rescan);
+                int2 ft = make_int2(0, 0);
+                if constexpr (W == 0) ft = s_feat[li];
+                proj_eval<W>(J, s_keys[li], ft, meta, R, li, want, rescan);
                 s_flag[li] = rescan ? 1 : 0;
             }
             if (want >= 0 && meta < 0) atomicMin(&Wc[want], li);  // only a map point with observations blocks later queries
@@ -873,35 +911,50 @@ __device__ void proj_resolve_wg(const DevProjJob &J) {
             int wr = -1;
             if (g < nw) {
                 const int li = s_wlist[g], q0 = s_live[li];
-                uint32_t qd[W];
-                {
-                    const uint4 *qp = reinterpret_cast<const uint4 *>(J.qdesc + (size_t)q0 * W);
-#pragma unroll
-                    for (int i = 0; i < W / 4; ++i) {
-                        const uint4 t = qp[i];
-                        qd[4 * i] = t.x, qd[4 * i + 1] = t.y, qd[4 * i + 2] = t.z, qd[4 * i + 3] = t.w;
-                    }
-                }
                 unsigned long long k0 = P_NO_KEY, k1 = P_NO_KEY;
-                PROJ_WAVE_WINDOW(J, q0, lane, {
-                    if (J.occupied && J.occupied[idx]) continue;
-                    if (Wc[idx] < li) continue;
-                    const unsigned long long key = make_key(proj_hamming<W>(qd, J.fdesc + (size_t)idx * W), c, kpos, idx);
-                    if (key < k0) {
-                        k1 = k0;
-                        k0 = key;
-                    } else if (key < k1) {
-                        k1 = key;
+                if constexpr (W == 0) {
+                    const float *qrow = proj_qrow(J, q0);
+                    PROJ_WAVE_WINDOW(J, q0, lane, {
+                        if (J.occupied && J.occupied[idx]) continue;
+                        if (Wc[idx] < li) continue;
+                        const unsigned long long key = make_key_f32(proj_l2sqr(qrow, proj_frow(J, idx), J.fdim), epos, idx);
+                        if (key < k0) {
+                            k1 = k0;
+                            k0 = key;
+                        } else if (key < k1) {
+                            k1 = key;
+                        }
+                    })
+                } else {
+                    uint32_t qd[W];
+                    {
+                        const uint4 *qp = reinterpret_cast<const uint4 *>(J.qdesc + (size_t)q0 * W);
+#pragma unroll
+                        for (int i = 0; i < W / 4; ++i) {
+                            const uint4 t = qp[i];
+                            qd[4 * i] = t.x, qd[4 * i + 1] = t.y, qd[4 * i + 2] = t.z, qd[4 * i + 3] = t.w;
+                        }
                     }
-                })
+                    PROJ_WAVE_WINDOW(J, q0, lane, {
+                        if (J.occupied && J.occupied[idx]) continue;
+                        if (Wc[idx] < li) continue;
+                        const unsigned long long key = make_key(proj_hamming<W>(qd, J.fdesc + (size_t)idx * W), c, kpos, idx);
+                        if (key < k0) {
+                            k1 = k0;
+                            k0 = key;
+                        } else if (key < k1) {
+                            k1 = key;
+                        }
+                    })
+                }
                 const unsigned long long b0 = wave_min_u64(k0);
                 const unsigned long long b1 = wave_min_u64(k0 == b0 ? k1 : k0);
                 if (b0 != P_NO_KEY) {
-                    const float best = (float)key_dist(b0);
+                    const float best = (float)key_dist_of<W>(b0);
                     const int bidx = key_idx(b0);
                     bool ok = best <= J.th;
                     if (ok && J.mode == 0 && b1 != P_NO_KEY) {
-                        const float best2 = (float)key_dist(b1), bsz = J.size[bidx], bsz2 = J.size[key_idx(b1)];
+                        const float best2 = (float)key_dist_of<W>(b1), bsz = J.size[bidx], bsz2 = J.size[key_idx(b1)];
                         if ((bsz / bsz2 < J.tol) && (bsz / bsz2 > J.inv_tol) && (bsz2 > 0.0f) && (best > J.ratio * best2)) ok = false;
                     }
                     if (ok) wr = bidx;
@@ -1005,11 +1058,13 @@ __device__ void proj_resolve_wg(const DevProjJob &J) {
 
 __global__ __launch_bounds__(PW_T) void k_proj_resolve_wg(const DevProjJob *__restrict__ jobs) {
     const DevProjJob J = jobs[blockIdx.x];
-    if (J.words == 8) proj_resolve_wg<8>(J);
+    if (J.fdim) proj_resolve_wg<0>(J);
+    else if (J.words == 8) proj_resolve_wg<8>(J);
     else proj_resolve_wg<16>(J);
 }
 __global__ __launch_bounds__(PW_T) void k_proj_resolve_wg1(const DevProjJob J) {
-    if (J.words == 8) proj_resolve_wg<8>(J);
+    if (J.fdim) proj_resolve_wg<0>(J);
+    else if (J.words == 8) proj_resolve_wg<8>(J);
     else proj_resolve_wg<16>(J);
 }
 
@@ -1574,7 +1629,7 @@ __global__ __launch_bounds__(PW_T) void k_proj_search1(const DevProjJob J, int *
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int q = (int)blockIdx.x * PW_NW + wv;
     if (q < J.nq) {  // wave-uniform
-        if (KIND == 0) {
+        if (KIND == 0) {  // (binary rows only: float jobs take the two-launch form - their instantiations would push this kernel into spilling)
             if (J.words == 8) topk_query<8, PK, 1>(J, q, lane, s_list[wv]);
             else topk_query<16, PK, 1>(J, q, lane, s_list[wv]);
         } else {
@@ -1621,7 +1676,9 @@ extern "C" int afv_project_prepare(void) {
     // dynamic bytes a job may ask for (the kernels' static arrays take about 1 KB more); without the raised limit: what every kernel gets
     return ok ? want - 2048 : 62 * 1024 - (int)sizeof(int2) * PW_NW * PW_LIST;
 }
-extern "C" size_t afv_project_wg_lds(int kind_init, int n, int nq) { return kind_init ? init_wg_lds_bytes(n, nq) : proj_wg_lds_bytes(n, nq); }
+extern "C" size_t afv_project_wg_lds(int kind_init, int n, int nq, int float_rows) {
+    return kind_init ? init_wg_lds_bytes(n, nq) : proj_wg_lds_bytes(n, nq, float_rows != 0);
+}
 
 // `one` != nullptr: a single job whose record travels as the kernel argument (the fixed-point engines and Fuse); else `jobs` is the
 // device array of njobs records

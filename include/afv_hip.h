@@ -344,8 +344,9 @@ typedef struct {
        cv::norm(a, b, NORM_L2SQR) (Feature_sift128.cpp:132-134).  float_dim > 0: desc and qdesc point to rows of float_dim floats
        (a multiple of 4, <= 1024; desc_bytes is ignored), distances are evaluated like afv_match_l2 (float differences, squares and 4-way
        partial sums in double, narrowed once), th_high / nnratio apply to them as they stand; 0 (what a caller compiled against an older
-       header gets) = binary rows of desc_bytes.  All four searches below accept it; the ordered phase runs on the ordered-walk engine
-       (afv_set_projection_resolve 0) whatever the context's setting - the fixed-point engines' records carry 16-bit distances. */
+       header gets) = binary rows of desc_bytes.  All four searches below accept it; afv_match_projection runs float jobs on either engine of
+       its ordered phase (afv_set_projection_resolve), afv_match_initialization always on the ordered walk (its fixed point packs
+       distances in 16 bits). */
     int32_t float_dim;
 } afv_proj_job;
 /* assign = concatenation over jobs of int32[n]: index of the query assigned to feature i (F.pts[i] = pMP) or -1 */
